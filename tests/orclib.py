@@ -1,0 +1,169 @@
+"""ctypes bindings to oracle/liboracle.so — the CPU oracle (test infrastructure only)."""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = 0xFFFFFFFF00000001
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+u64p = C.POINTER(C.c_uint64)
+
+
+class OrcParams(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("k", C.c_uint64), ("s_bound", C.c_uint64), ("e_bound", C.c_uint64),
+                ("k1_bound", C.c_uint64), ("r1_bounds", u64p), ("r2_bounds", u64p), ("qis", u64p), ("k0is", u64p)]
+
+
+class OrcInputs(C.Structure):
+    _fields_ = [(f, u64p) for f in ("s", "e", "k1", "ais", "r1is", "r2is", "ct0is")]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        so = os.path.join(ROOT, "oracle", "liboracle.so")
+        if not os.path.exists(so):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+        _lib = C.CDLL(so)
+        _lib.orc_root_of_unity.restype = C.c_uint64
+        _lib.orc_subtable_cutoff.restype = C.c_uint64
+    return _lib
+
+
+def ptr(a):
+    return a.ctypes.data_as(u64p)
+
+
+def constants(n, k):
+    return json.load(open(os.path.join(GOLDEN, "constants.json")))[f"{n}_{k}"]
+
+
+class Params:
+    """Keeps the numpy arrays alive next to the ctypes struct."""
+
+    def __init__(self, c):
+        self.c = c
+        self.n, self.k = c["n"], c["k"]
+        self.L = self.n.bit_length()  # log2(n) + 1
+        self.arrs = {f: np.array(c[f], dtype=np.uint64) for f in ("r1_bounds", "r2_bounds", "qis", "k0is")}
+        self.struct = OrcParams(c["n"], c["k"], c["s_bound"], c["e_bound"], c["k1_bound"],
+                                *(ptr(self.arrs[f]) for f in ("r1_bounds", "r2_bounds", "qis", "k0is")))
+
+
+def params(n, k):
+    return Params(constants(n, k))
+
+
+def layout_inputs(n, k, w):
+    """Python restatement of get_inputs / Poly::{new,new_padded,new_shifted}
+    [REF sk_encryption_circuit.rs:365-415, poly.rs:12-44] for cross-checking the product's loader."""
+    L = n.bit_length()
+    SZ = 1 << L
+
+    def arr(x):
+        return np.array([int(v) for v in x], dtype=np.uint64)
+
+    def padded(x):
+        a = np.zeros(SZ, dtype=np.uint64)
+        a[:len(x)] = arr(x)
+        return a
+
+    def shifted(x, size):
+        pad = max(size - len(x), 0)
+        v = np.concatenate([np.zeros(pad, dtype=np.uint64), arr(x)])
+        npow = 1 << (size - 1).bit_length()
+        out = np.zeros(npow, dtype=np.uint64)
+        out[:len(v)] = v
+        return out
+
+    d = {}
+    d["s"] = padded(w["s"])
+    d["e"] = shifted(w["e"], SZ - 1)
+    d["k1"] = shifted(w["k1"], SZ - 1)
+    d["ais"] = np.concatenate([padded(w["ais"][z]) for z in range(k)])
+    d["r1is"] = np.concatenate([padded(w["r1is"][z]) for z in range(k)])
+    d["r2is"] = np.concatenate([np.concatenate([arr(w["r2is"][z]), np.zeros(1, dtype=np.uint64)]) for z in range(k)])
+    ct = []
+    for z in range(k):
+        c = shifted(w["ct0is"][z], SZ)
+        ct.append(np.concatenate([c[1:], np.zeros(1, dtype=np.uint64)]))
+    d["ct0is"] = np.concatenate(ct)
+    return d
+
+
+class Inputs:
+    def __init__(self, d):
+        self.d = {k: np.ascontiguousarray(v, dtype=np.uint64) for k, v in d.items()}
+        self.struct = OrcInputs(*(ptr(self.d[f]) for f in ("s", "e", "k1", "ais", "r1is", "r2is", "ct0is")))
+
+
+def fixture_inputs(n, k, bits):
+    w = json.load(open(os.path.join(GOLDEN, f"sk_enc_{n}_{k}x{bits}_65537.json")))
+    return Inputs(layout_inputs(n, k, w))
+
+
+def _err():
+    return C.create_string_buffer(512)
+
+
+def prove(p, inp, threads=1, cap=1 << 24):
+    buf = (C.c_uint8 * cap)()
+    ln = C.c_size_t(0)
+    tm = (C.c_double * 2)()
+    err = _err()
+    rc = lib().orc_prove(C.byref(p.struct), C.byref(inp.struct), threads, buf, C.c_size_t(cap), C.byref(ln), tm, err, C.c_size_t(512))
+    if rc != 0:
+        raise RuntimeError(err.value.decode())
+    return bytes(buf[:ln.value]), (tm[0], tm[1])
+
+
+def verify(p, inp, proof, threads=1):
+    err = _err()
+    rc = lib().orc_verify(C.byref(p.struct), C.byref(inp.struct), threads, proof, C.c_size_t(len(proof)), err, C.c_size_t(512))
+    return rc == 0, err.value.decode()
+
+
+def circuit_eval(p, inp):
+    info = (C.c_uint64 * 3)()
+    err = _err()
+    lib().orc_circuit_eval(C.byref(p.struct), C.byref(inp.struct), None, C.c_size_t(0), None, info, err, C.c_size_t(512))
+    nu = info[0]
+    lasso_in = np.zeros(1 << nu, dtype=np.uint64)
+    sum_out = np.zeros(p.k << p.L, dtype=np.uint64)
+    rc = lib().orc_circuit_eval(C.byref(p.struct), C.byref(inp.struct), ptr(lasso_in), C.c_size_t(lasso_in.size), ptr(sum_out), info, err, C.c_size_t(512))
+    if rc != 0:
+        raise RuntimeError(err.value.decode())
+    return lasso_in, sum_out, dict(nu=int(info[0]), num_nodes=int(info[1]), rows=int(info[2]))
+
+
+def lasso_prove(p, lasso_in, threads=1, cap=1 << 24):
+    buf = (C.c_uint8 * cap)()
+    ln = C.c_size_t(0)
+    nu = int(np.log2(lasso_in.size))
+    claim = np.zeros(2 * nu + 2, dtype=np.uint64)
+    err = _err()
+    rc = lib().orc_lasso_prove(C.byref(p.struct), ptr(lasso_in), threads, buf, C.c_size_t(cap), C.byref(ln), ptr(claim), err, C.c_size_t(512))
+    if rc != 0:
+        raise RuntimeError(err.value.decode())
+    return bytes(buf[:ln.value]), claim
+
+
+def lasso_verify(p, proof):
+    err = _err()
+    rc = lib().orc_lasso_verify(C.byref(p.struct), proof, C.c_size_t(len(proof)), err, C.c_size_t(512))
+    return rc == 0, err.value.decode()
+
+
+def lasso_layout(p):
+    buf = C.create_string_buffer(1 << 16)
+    n = lib().orc_lasso_layout(C.byref(p.struct), buf, C.c_size_t(1 << 16))
+    assert n > 0
+    mems, lk = buf.value.decode().split("|")
+    return mems.split(","), lk.split(";")
