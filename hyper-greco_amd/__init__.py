@@ -1,0 +1,287 @@
+"""hyper-greco-amd: MI355X-native GKR prover for the BFV secret-key-encryption circuit.
+
+Python host mirror of the reference's `bfv-gkr` API for this path (same names and argument meaning):
+`BfvEncrypt.new(k) / setup / get_inputs / prove` [REF bfv-gkr/src/sk_encryption_circuit.rs:300-460] and
+`LassoNode.prove_claim_reduction` [REF lasso/src/lasso.rs:57-114], over the C ABI of `include/hg.h`
+(libhypergreco.so: hand-written HIP kernels for gfx950). There is no CPU fallback: without a HIP
+device `Context()` raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libhypergreco.so")
+HG_MAX_K = 16
+P = 0xFFFFFFFF00000001
+
+u64p = C.POINTER(C.c_uint64)
+
+
+class HgParams(C.Structure):
+    _fields_ = [("n", C.c_uint32), ("k", C.c_uint32), ("s_bound", C.c_uint64), ("e_bound", C.c_uint64),
+                ("k1_bound", C.c_uint64), ("r1_bounds", C.c_uint64 * HG_MAX_K), ("r2_bounds", C.c_uint64 * HG_MAX_K),
+                ("qis", C.c_uint64 * HG_MAX_K), ("k0is", C.c_uint64 * HG_MAX_K)]
+
+
+class HgTimings(C.Structure):
+    _fields_ = [("witness_ms", C.c_double), ("upload_ms", C.c_double), ("prove_ms", C.c_double), ("gpu_ms", C.c_double),
+                ("total_ms", C.c_double)]
+
+
+class HgKernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double), ("algo_bytes", C.c_double)]
+
+
+EXPORTS = [
+    "hg_last_error", "hg_device_count", "hg_create", "hg_destroy", "hg_params_builtin", "hg_setup", "hg_pk_free",
+    "hg_pk_lasso_layout", "hg_pk_info", "hg_witness_from_json", "hg_witness_synthetic", "hg_witness_from_arrays",
+    "hg_witness_get", "hg_witness_free", "hg_prove", "hg_circuit_eval", "hg_lasso_prove", "hg_sumcheck", "hg_mle_eval",
+    "hg_ntt", "hg_challenges", "hg_profile", "hg_profile_reset", "hg_profile_get",
+]
+
+
+def build(force=False):
+    """Compiles csrc/ for gfx950 into libhypergreco.so (hipcc cross-compiles without a GPU)."""
+    src = os.path.join(_HERE, "csrc")
+    if force:
+        subprocess.check_call(["make", "-C", src, "clean"])
+    subprocess.check_call(["make", "-C", src, "-j4"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(f"{_LIB_PATH} is missing: run __graft_entry__.build() (the HIP extension is required)")
+        L = C.CDLL(_LIB_PATH)
+        L.hg_last_error.restype = C.c_char_p
+        L.hg_create.restype = C.c_void_p
+        L.hg_create.argtypes = [C.c_int]
+        L.hg_destroy.argtypes = [C.c_void_p]
+        L.hg_setup.argtypes = [C.c_void_p, C.POINTER(HgParams), C.POINTER(C.c_void_p)]
+        L.hg_pk_free.argtypes = [C.c_void_p]
+        L.hg_pk_lasso_layout.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        L.hg_pk_info.argtypes = [C.c_void_p, u64p]
+        L.hg_witness_from_json.argtypes = [C.POINTER(HgParams), C.c_char_p, C.POINTER(C.c_void_p)]
+        L.hg_witness_synthetic.argtypes = [C.POINTER(HgParams), C.c_uint64, C.POINTER(C.c_void_p)]
+        L.hg_witness_from_arrays.argtypes = [C.POINTER(HgParams)] + [u64p] * 7 + [C.POINTER(C.c_void_p)]
+        L.hg_witness_get.restype = C.c_int64
+        L.hg_witness_get.argtypes = [C.c_void_p, C.c_int, u64p, C.c_size_t]
+        L.hg_witness_free.argtypes = [C.c_void_p]
+        L.hg_prove.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(HgTimings)]
+        L.hg_circuit_eval.argtypes = [C.c_void_p, C.c_void_p, u64p, C.c_size_t, u64p, C.c_size_t]
+        L.hg_lasso_prove.argtypes = [C.c_void_p, C.c_void_p, u64p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), u64p]
+        L.hg_sumcheck.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(u64p), C.POINTER(C.c_int), u64p, C.c_size_t,
+                                  u64p, C.c_size_t, u64p, u64p, u64p, u64p]
+        L.hg_mle_eval.argtypes = [C.c_void_p, u64p, C.c_size_t, u64p, u64p]
+        L.hg_ntt.argtypes = [C.c_void_p, u64p, C.c_size_t, C.c_int, C.c_size_t, u64p]
+        L.hg_challenges.argtypes = [C.c_size_t, u64p]
+        L.hg_profile.argtypes = [C.c_void_p, C.c_int]
+        L.hg_profile_reset.argtypes = [C.c_void_p]
+        L.hg_profile_get.argtypes = [C.c_void_p, C.POINTER(HgKernelStat), C.c_int]
+        _lib = L
+    return _lib
+
+
+class HgError(RuntimeError):
+    pass
+
+
+def _check(rc):
+    if rc is None or (isinstance(rc, int) and rc < 0):
+        raise HgError(lib().hg_last_error().decode())
+    return rc
+
+
+def _ptr(a):
+    return a.ctypes.data_as(u64p)
+
+
+def params_builtin(n, k):
+    p = HgParams()
+    _check(lib().hg_params_builtin(n, k, C.byref(p)))
+    return p
+
+
+def challenges(n):
+    out = np.zeros(n, dtype=np.uint64)
+    _check(lib().hg_challenges(n, _ptr(out)))
+    return out
+
+
+class Context:
+    """One per GPU (hg_ctx): HIP stream, workspace arena, challenge chain in HBM."""
+
+    def __init__(self, device=0):
+        h = lib().hg_create(device)
+        if not h:
+            raise HgError(lib().hg_last_error().decode())
+        self.h = C.c_void_p(h)
+
+    def close(self):
+        if self.h:
+            lib().hg_destroy(self.h)
+            self.h = None
+
+    def profile(self, level):
+        lib().hg_profile(self.h, level)
+
+    def profile_reset(self):
+        lib().hg_profile_reset(self.h)
+
+    def profile_get(self):
+        arr = (HgKernelStat * 32)()
+        n = lib().hg_profile_get(self.h, arr, 32)
+        return [dict(name=arr[i].name.decode(), launches=int(arr[i].launches), total_ms=arr[i].total_ms, algo_bytes=arr[i].algo_bytes)
+                for i in range(n)]
+
+    # kernel-level entry points (parity tests)
+    def sumcheck(self, kind, tables, is_base, pw, claim, chain_skip=0):
+        ntab = len(tables)
+        nv = int(np.log2(tables[0].size if is_base[0] else tables[0].size // 2))
+        d = 3 if kind == 1 else 2
+        tabs = [np.ascontiguousarray(t, dtype=np.uint64) for t in tables]
+        ptrs = (u64p * ntab)(*[_ptr(t) for t in tabs])
+        flags = (C.c_int * ntab)(*[int(b) for b in is_base])
+        pw = np.ascontiguousarray(pw, dtype=np.uint64).reshape(-1)
+        claim = np.ascontiguousarray(claim, dtype=np.uint64)
+        msgs = np.zeros(nv * (d + 1) * 2, dtype=np.uint64)
+        point = np.zeros(nv * 2, dtype=np.uint64)
+        evals = np.zeros(ntab * 2, dtype=np.uint64)
+        sums = np.zeros(nv * d * 2, dtype=np.uint64)
+        _check(lib().hg_sumcheck(self.h, kind, nv, ntab, ptrs, flags, _ptr(pw), pw.size // 2, _ptr(claim), chain_skip,
+                                 _ptr(msgs), _ptr(point), _ptr(evals), _ptr(sums)))
+        return msgs, point, evals, sums
+
+    def mle_eval(self, table, point):
+        table = np.ascontiguousarray(table, dtype=np.uint64)
+        point = np.ascontiguousarray(point, dtype=np.uint64)
+        out = np.zeros(2, dtype=np.uint64)
+        _check(lib().hg_mle_eval(self.h, _ptr(table), point.size // 2, _ptr(point), _ptr(out)))
+        return out
+
+    def ntt(self, data, log2n, inverse=False, batch=1):
+        data = np.ascontiguousarray(data, dtype=np.uint64)
+        out = np.zeros_like(data)
+        _check(lib().hg_ntt(self.h, _ptr(data), log2n, int(inverse), batch, _ptr(out)))
+        return out
+
+
+class Witness:
+    """BfvSkEncryptArgs after get_inputs [REF sk_encryption_circuit.rs:64-73, 365-415]."""
+    FIELDS = ["s", "e", "k1", "ais", "r1is", "r2is", "ct0is"]
+
+    def __init__(self, handle, params):
+        self.h = handle
+        self.params = params
+
+    @classmethod
+    def from_json(cls, params, path):
+        h = C.c_void_p()
+        _check(lib().hg_witness_from_json(C.byref(params), path.encode(), C.byref(h)))
+        return cls(h, params)
+
+    @classmethod
+    def synthetic(cls, params, seed):
+        h = C.c_void_p()
+        _check(lib().hg_witness_synthetic(C.byref(params), seed, C.byref(h)))
+        return cls(h, params)
+
+    @classmethod
+    def from_arrays(cls, params, d):
+        h = C.c_void_p()
+        arrs = [np.ascontiguousarray(d[f], dtype=np.uint64) for f in cls.FIELDS]
+        _check(lib().hg_witness_from_arrays(C.byref(params), *[_ptr(a) for a in arrs], C.byref(h)))
+        return cls(h, params)
+
+    def arrays(self):
+        out = {}
+        for i, f in enumerate(self.FIELDS):
+            n = lib().hg_witness_get(self.h, i, None, 0)
+            a = np.zeros(n, dtype=np.uint64)
+            lib().hg_witness_get(self.h, i, _ptr(a), n)
+            out[f] = a
+        return out
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().hg_witness_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+class ProverKey:
+    def __init__(self, handle, params):
+        self.h = handle
+        self.params = params
+        info = (C.c_uint64 * 4)()
+        lib().hg_pk_info(self.h, info)
+        self.nu, self.num_nodes, self.rows, self.alpha = (int(x) for x in info)
+
+    def lasso_layout(self):
+        buf = C.create_string_buffer(1 << 16)
+        _check(lib().hg_pk_lasso_layout(self.h, buf, 1 << 16))
+        mems, lk = buf.value.decode().split("|")
+        return mems.split(","), lk.split(";")
+
+    def circuit_eval(self, w):
+        lasso_in = np.zeros(1 << self.nu, dtype=np.uint64)
+        sum_out = np.zeros(self.params.k * 2 * self.params.n, dtype=np.uint64)
+        _check(lib().hg_circuit_eval(self.h, w.h, _ptr(lasso_in), lasso_in.size, _ptr(sum_out), sum_out.size))
+        return lasso_in, sum_out
+
+    def free(self):
+        if self.h:
+            lib().hg_pk_free(self.h)
+            self.h = None
+
+
+class BfvEncrypt:
+    """Mirror of `BfvEncrypt::<Params, K>` [REF sk_encryption_circuit.rs:300-523]."""
+
+    def __init__(self, n, k):  # = BfvEncrypt::<SkEnc{n}_{k}x.._65537, k>::new(k)
+        self.params = params_builtin(n, k)
+
+    @classmethod
+    def new(cls, n, k):
+        return cls(n, k)
+
+    def setup(self, ctx):  # -> (pk); the verifier key of the reference is the same preprocessing
+        h = C.c_void_p()
+        _check(lib().hg_setup(ctx.h if ctx is not None else None, C.byref(self.params), C.byref(h)))
+        return ProverKey(h, self.params)
+
+    def get_inputs(self, path):
+        return Witness.from_json(self.params, path)
+
+    def prove(self, ctx, pk, witness, cap=1 << 24):
+        buf = (C.c_uint8 * cap)()
+        ln = C.c_size_t(0)
+        tm = HgTimings()
+        _check(lib().hg_prove(ctx.h, pk.h, witness.h, buf, cap, C.byref(ln), C.byref(tm)))
+        return bytes(buf[:ln.value]), {f: getattr(tm, f) for f, _ in HgTimings._fields_}
+
+
+class LassoNode:
+    """Mirror of `LassoNode<F, E, 4, 65536>` as a gkr Node [REF lasso/src/lasso.rs:32-140]."""
+
+    def __init__(self, pk):
+        self.pk = pk
+
+    def prove_claim_reduction(self, ctx, inputs, cap=1 << 24):
+        inputs = np.ascontiguousarray(inputs, dtype=np.uint64)
+        assert inputs.size == 1 << self.pk.nu
+        buf = (C.c_uint8 * cap)()
+        ln = C.c_size_t(0)
+        claim = np.zeros(2 * self.pk.nu + 2, dtype=np.uint64)
+        _check(lib().hg_lasso_prove(ctx.h, self.pk.h, _ptr(inputs), buf, cap, C.byref(ln), _ptr(claim)))
+        return bytes(buf[:ln.value]), claim

@@ -1,0 +1,344 @@
+// C ABI (include/hg.h). No exception crosses the boundary: every entry point catches, stores the
+// message for hg_last_error() and returns a negative status.
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <memory>
+#include <string>
+#include "prover.hpp"
+
+using namespace hg;
+
+static thread_local std::string g_last_error;
+
+#define HG_TRY try {
+#define HG_CATCH(ret)                                                           \
+    }                                                                           \
+    catch (const std::exception& ex) { g_last_error = ex.what(); return ret; } \
+    catch (...) { g_last_error = "unknown error"; return ret; }
+
+template <typename T>
+static const T* upload_vec(hg_pk* pk, const std::vector<T>& v) {
+    if (!pk->ctx) return nullptr;  // host-only key (hg_setup(NULL, ..)): wiring without a device copy
+    T* d = nullptr;
+    size_t bytes = std::max<size_t>(v.size() * sizeof(T), 16);
+    hip_check(hipMalloc((void**)&d, bytes), "hipMalloc(prover key)");
+    if (!v.empty()) hip_check(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice), "upload prover key");
+    pk->owned.push_back(d);
+    return d;
+}
+
+// counting-sort a term list into a CSR keyed by position `key(t)` in [0, S)
+template <typename Term, typename KeyFn, typename EmitFn>
+static void build_csr(const std::vector<const Term*>& terms, size_t S, KeyFn key, std::vector<u32>& ptr, EmitFn emit) {
+    ptr.assign(S + 1, 0);
+    for (const Term* t : terms) ptr[key(*t) + 1]++;
+    for (size_t i = 0; i < S; i++) ptr[i + 1] += ptr[i];
+    std::vector<u32> fill(ptr.begin(), ptr.end() - 1);
+    for (const Term* t : terms) emit(*t, fill[key(*t)]++);
+}
+
+extern "C" {
+
+const char* hg_last_error(void) { return g_last_error.c_str(); }
+
+int hg_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+hg_ctx* hg_create(int device_id) {
+    HG_TRY
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
+        throw Error("no HIP device available: the prover has no CPU fallback (the CPU restatement lives in oracle/ and is test-only)");
+    if (device_id < 0 || device_id >= n) throw Error("device id out of range");
+    hip_check(hipSetDevice(device_id), "hipSetDevice");
+    hg_ctx* c = new hg_ctx();
+    c->device = device_id;
+    hip_check(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate");
+    c->res_cap = (size_t)1 << 17;
+    hip_check(hipMalloc((void**)&c->d_res, c->res_cap * sizeof(E2)), "hipMalloc(results)");
+    hip_check(hipHostMalloc((void**)&c->h_res, c->res_cap * sizeof(E2), hipHostMallocDefault), "hipHostMalloc(results)");
+    hip_check(hipMalloc((void**)&c->d_partials, (size_t)dev::SC_MAX_BLOCKS * 8 * sizeof(E2)), "hipMalloc(partials)");
+    c->ensure_chain(16384);
+    return c;
+    HG_CATCH(nullptr)
+}
+
+void hg_destroy(hg_ctx* ctx) { delete ctx; }
+
+int hg_params_builtin(uint32_t n, uint32_t k, hg_params* out) {
+    HG_TRY
+    if (!params_builtin(n, k, out)) throw Error("no built-in parameter set for this (n, k)");
+    return 0;
+    HG_CATCH(-1)
+}
+
+int hg_setup(hg_ctx* ctx, const hg_params* params, hg_pk** out) {
+    HG_TRY
+    if (ctx) hip_check(hipSetDevice(ctx->device), "hipSetDevice");
+    std::unique_ptr<hg_pk> pk(new hg_pk(*params));
+    pk->ctx = ctx;
+    pk->lasso = lasso_preprocess(pk->params);
+    pk->circuit = build_circuit(pk->params, pk->lasso);
+    const LassoPlan& lp = pk->lasso;
+    if (lp.alpha > 32 || lp.lookups.size() > 32) throw Error("lasso: more than 32 memories / lookup types");
+    dev::LassoDev& L = pk->lasso_dev;
+    memset(&L, 0, sizeof(L));
+    L.nu = lp.nu; L.alpha = lp.alpha; L.num_lookups = (int)lp.lookups.size(); L.seg_shift = lp.seg_shift; L.rows = lp.rows;
+    L.seg_lookup = upload_vec(pk.get(), lp.seg_lookup);
+    for (size_t l = 0; l < lp.lookups.size(); l++) {
+        int tb = lp.lookups[l].total_bits;
+        L.lookup_mask[l] = tb >= 64 ? ~0ULL : ((1ULL << tb) - 1);
+        L.lookup_nmems[l] = (int)lp.lookups[l].mems.size();
+        if (lp.lookups[l].mems.size() > 4) throw Error("lasso: lookup touches more than C memories");
+        for (size_t i = 0; i < lp.lookups[l].mems.size(); i++) {
+            L.lookup_uses[l] |= 1ULL << lp.lookups[l].mems[i];
+            L.lookup_mems[l][i] = lp.lookups[l].mems[i];
+        }
+    }
+    for (int m = 0; m < lp.alpha; m++) { L.mem_dim[m] = lp.mems[m].dim; L.mem_cutoff[m] = (u32)lp.mems[m].cutoff; }
+    L.mpow[0] = 1;
+    for (int i = 1; i < 5; i++) L.mpow[i] = gl_mul(L.mpow[i - 1], 65536);
+    // circuit wiring as CSR per (node, input)
+    const HCircuit& c = pk->circuit;
+    pk->node_dev.resize(c.nodes.size());
+    for (size_t id = 0; id < c.nodes.size(); id++) {
+        const HNode& n = c.nodes[id];
+        if (n.kind == NK_FFT) {
+            for (int inv = 0; inv < 2; inv++) {
+                auto& tab = inv ? pk->w_inv : pk->w_fwd;
+                if (tab.count(n.log2_size)) continue;
+                size_t N = (size_t)1 << n.log2_size;
+                std::vector<u64> W(N);
+                u64 w = root_of_unity(n.log2_size);
+                if (inv) w = gl_inv(w);
+                W[0] = 1;
+                for (size_t i = 1; i < N; i++) W[i] = gl_mul(W[i - 1], w);
+                tab[n.log2_size] = upload_vec(pk.get(), W);
+            }
+        }
+        if (n.kind != NK_VANILLA) continue;
+        hg_pk::NodeDev& nd = pk->node_dev[id];
+        const size_t S = (size_t)1 << n.log2_sub_in;
+        nd.lin.assign(n.arity, dev::CsrLin{nullptr, nullptr, nullptr});
+        nd.mulL.assign(n.arity, dev::CsrMul{nullptr, nullptr, nullptr, nullptr, nullptr});
+        nd.mulR.assign(n.arity, dev::CsrMul{nullptr, nullptr, nullptr, nullptr, nullptr});
+        std::vector<std::vector<const LinTerm*>> lin_by(n.arity);
+        std::vector<std::vector<const MulTerm*>> ml_by(n.arity), mr_by(n.arity);
+        for (auto& t : n.lin) lin_by[t.in].push_back(&t);
+        for (auto& t : n.mul) { ml_by[t.i0].push_back(&t); mr_by[t.i1].push_back(&t); }
+        for (int i = 0; i < n.arity; i++) {
+            if (!lin_by[i].empty()) {
+                std::vector<u32> ptr, gate(lin_by[i].size());
+                std::vector<u64> coef(lin_by[i].size());
+                build_csr<LinTerm>(lin_by[i], S, [](const LinTerm& t) { return (size_t)t.j; }, ptr,
+                                   [&](const LinTerm& t, u32 at) { gate[at] = t.gate; coef[at] = t.c; });
+                nd.lin[i] = dev::CsrLin{upload_vec(pk.get(), ptr), upload_vec(pk.get(), gate), upload_vec(pk.get(), coef)};
+            }
+            auto mk = [&](const std::vector<const MulTerm*>& ts, bool left) {
+                std::vector<u32> ptr, gate(ts.size()), oin(ts.size()), oj(ts.size());
+                std::vector<u64> coef(ts.size());
+                build_csr<MulTerm>(ts, S, [left](const MulTerm& t) { return (size_t)(left ? t.j0 : t.j1); }, ptr,
+                                   [&](const MulTerm& t, u32 at) {
+                                       gate[at] = t.gate; coef[at] = t.c;
+                                       oin[at] = left ? t.i1 : t.i0;
+                                       oj[at] = left ? t.j1 : t.j0;
+                                   });
+                return dev::CsrMul{upload_vec(pk.get(), ptr), upload_vec(pk.get(), gate), upload_vec(pk.get(), coef),
+                                   upload_vec(pk.get(), oin), upload_vec(pk.get(), oj)};
+            };
+            if (!ml_by[i].empty()) nd.mulL[i] = mk(ml_by[i], true);
+            if (!mr_by[i].empty()) nd.mulR[i] = mk(mr_by[i], false);
+        }
+        if (!n.w0.empty()) {
+            std::vector<u32> g;
+            std::vector<u64> cf;
+            for (auto& t : n.w0) { g.push_back(t.gate); cf.push_back(t.c); }
+            nd.const_gate = upload_vec(pk.get(), g);
+            nd.const_coef = upload_vec(pk.get(), cf);
+            nd.nconst = g.size();
+        }
+    }
+    *out = pk.release();
+    return 0;
+    HG_CATCH(-1)
+}
+
+void hg_pk_free(hg_pk* pk) {
+    if (!pk) return;
+    for (void* p : pk->owned) (void)hipFree(p);
+    delete pk;
+}
+
+int hg_pk_lasso_layout(const hg_pk* pk, char* out, size_t cap) {
+    HG_TRY
+    std::string s = pk->lasso.layout_text();
+    if (s.size() + 1 > cap) throw Error("buffer too small");
+    memcpy(out, s.c_str(), s.size() + 1);
+    return (int)s.size();
+    HG_CATCH(-1)
+}
+
+int hg_pk_info(const hg_pk* pk, uint64_t out[4]) {
+    out[0] = (uint64_t)pk->lasso.nu;
+    out[1] = pk->circuit.nodes.size();
+    out[2] = pk->lasso.rows;
+    out[3] = (uint64_t)pk->lasso.alpha;
+    return 0;
+}
+
+int hg_witness_from_json(const hg_params* params, const char* path, hg_witness** w) {
+    HG_TRY
+    Params p(*params);
+    std::unique_ptr<hg_witness> hw(new hg_witness{witness_from_json(p, path), *params});
+    *w = hw.release();
+    return 0;
+    HG_CATCH(-1)
+}
+
+int hg_witness_synthetic(const hg_params* params, uint64_t seed, hg_witness** w) {
+    HG_TRY
+    Params p(*params);
+    std::unique_ptr<hg_witness> hw(new hg_witness{witness_synthetic(p, seed), *params});
+    *w = hw.release();
+    return 0;
+    HG_CATCH(-1)
+}
+
+int hg_witness_from_arrays(const hg_params* params, const uint64_t* s, const uint64_t* e, const uint64_t* k1, const uint64_t* ais,
+                           const uint64_t* r1is, const uint64_t* r2is, const uint64_t* ct0is, hg_witness** w) {
+    HG_TRY
+    Params p(*params);
+    const size_t SZ = p.SZ(), PZ = p.PZ(), k = (size_t)p.k;
+    std::unique_ptr<hg_witness> hw(new hg_witness());
+    hw->params = *params;
+    auto cp = [](std::vector<u64>& dst, const u64* src, size_t n) {
+        dst.assign(src, src + n);
+        for (u64 v : dst) if (v >= GL_P) throw Error("witness: non-canonical field element");
+    };
+    cp(hw->w.s, s, SZ); cp(hw->w.e, e, SZ); cp(hw->w.k1, k1, SZ);
+    cp(hw->w.ais, ais, k * SZ); cp(hw->w.r1is, r1is, k * SZ); cp(hw->w.r2is, r2is, k * PZ); cp(hw->w.ct0is, ct0is, k * SZ);
+    *w = hw.release();
+    return 0;
+    HG_CATCH(-1)
+}
+
+int64_t hg_witness_get(const hg_witness* w, int which, uint64_t* out, size_t cap) {
+    const std::vector<u64>* v = nullptr;
+    switch (which) {
+        case 0: v = &w->w.s; break;
+        case 1: v = &w->w.e; break;
+        case 2: v = &w->w.k1; break;
+        case 3: v = &w->w.ais; break;
+        case 4: v = &w->w.r1is; break;
+        case 5: v = &w->w.r2is; break;
+        case 6: v = &w->w.ct0is; break;
+        default: g_last_error = "hg_witness_get: bad selector"; return -1;
+    }
+    if (out) memcpy(out, v->data(), std::min(cap, v->size()) * 8);
+    return (int64_t)v->size();
+}
+
+void hg_witness_free(hg_witness* w) { delete w; }
+
+int hg_prove(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, uint8_t* proof, size_t cap, size_t* len, hg_timings* timings) {
+    HG_TRY
+    if (!ctx || !pk || !w) throw Error("hg_prove: null argument");
+    if (!pk->ctx) throw Error("hg_prove: host-only prover key (created without a context)");
+    double t0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    ProveResult r = prove_full(ctx, pk, w->w);
+    double t1 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    if (timings) { timings->witness_ms = r.witness_ms; timings->upload_ms = r.upload_ms; timings->prove_ms = r.prove_ms; timings->gpu_ms = r.gpu_ms; timings->total_ms = t1 - t0; }
+    *len = r.proof.size();
+    if (r.proof.size() > cap) throw Error("proof buffer too small");
+    memcpy(proof, r.proof.data(), r.proof.size());
+    return 0;
+    HG_CATCH(-1)
+}
+
+int hg_circuit_eval(const hg_pk* pk, const hg_witness* w, uint64_t* lasso_in, size_t lasso_cap, uint64_t* sum_out, size_t sum_cap) {
+    HG_TRY
+    auto vals = circuit_evaluate(pk->circuit, pk->params, w->w);
+    const auto& li = vals[pk->circuit.lasso_in_id];
+    const auto& so = vals[pk->circuit.sum_id];
+    if (lasso_in) { if (li.size() > lasso_cap) throw Error("lasso_in buffer too small"); memcpy(lasso_in, li.data(), li.size() * 8); }
+    if (sum_out) { if (so.size() > sum_cap) throw Error("sum_out buffer too small"); memcpy(sum_out, so.data(), so.size() * 8); }
+    return 0;
+    HG_CATCH(-1)
+}
+
+int hg_lasso_prove(hg_ctx* ctx, const hg_pk* pk, const uint64_t* lasso_in, uint8_t* proof, size_t cap, size_t* len, uint64_t* claim_out) {
+    HG_TRY
+    if (!ctx || !pk || !pk->ctx) throw Error("hg_lasso_prove: needs a device context and a device prover key");
+    std::vector<E2> claim;
+    std::vector<uint8_t> pr = prove_lasso_node(ctx, pk, lasso_in, &claim);
+    *len = pr.size();
+    if (pr.size() > cap) throw Error("proof buffer too small");
+    memcpy(proof, pr.data(), pr.size());
+    if (claim_out) for (size_t i = 0; i < claim.size(); i++) { claim_out[2 * i] = claim[i].c0; claim_out[2 * i + 1] = claim[i].c1; }
+    return 0;
+    HG_CATCH(-1)
+}
+
+int hg_sumcheck(hg_ctx* ctx, int kind, size_t nv, size_t ntab, const uint64_t* const* tables, const int* is_base, const uint64_t* pw,
+                size_t npw, const uint64_t* claim2, size_t chain_skip, uint64_t* msgs, uint64_t* point, uint64_t* evals, uint64_t* sums) {
+    HG_TRY
+    SumcheckIO io;
+    io.kind = kind; io.nv = nv; io.chain_skip = chain_skip;
+    io.tables.assign(tables, tables + ntab);
+    io.is_base.assign(is_base, is_base + ntab);
+    for (size_t i = 0; i < npw; i++) io.pw.push_back(e2(pw[2 * i], pw[2 * i + 1]));
+    io.claim = e2(claim2[0], claim2[1]);
+    sumcheck_on_tables(ctx, io);
+    auto put = [](uint64_t* dst, const std::vector<E2>& v) { if (dst) for (size_t i = 0; i < v.size(); i++) { dst[2 * i] = v[i].c0; dst[2 * i + 1] = v[i].c1; } };
+    put(msgs, io.msgs); put(point, io.point); put(evals, io.evals); put(sums, io.sums);
+    return 0;
+    HG_CATCH(-1)
+}
+
+int hg_mle_eval(hg_ctx* ctx, const uint64_t* table, size_t nv, const uint64_t* point, uint64_t out2[2]) {
+    HG_TRY
+    std::vector<E2> pt(nv);
+    for (size_t i = 0; i < nv; i++) pt[i] = e2(point[2 * i], point[2 * i + 1]);
+    E2 v = mle_eval_device(ctx, table, nv, pt.data());
+    out2[0] = v.c0; out2[1] = v.c1;
+    return 0;
+    HG_CATCH(-1)
+}
+
+int hg_ntt(hg_ctx* ctx, const uint64_t* in, size_t log2n, int inverse, size_t batch, uint64_t* out) {
+    HG_TRY
+    ntt_device(ctx, in, (int)log2n, inverse != 0, batch, out);
+    return 0;
+    HG_CATCH(-1)
+}
+
+int hg_challenges(size_t n, uint64_t* out) {
+    HG_TRY
+    const u64* c = challenge_chain(n);
+    memcpy(out, c, n * 8);
+    return 0;
+    HG_CATCH(-1)
+}
+
+int hg_profile(hg_ctx* ctx, int level) { ctx->prof_level = level; return 0; }
+int hg_profile_reset(hg_ctx* ctx) {
+    for (auto& s : ctx->prof_stats) { s.launches = 0; s.ms = 0; s.bytes = 0; }
+    return 0;
+}
+int hg_profile_get(hg_ctx* ctx, hg_kernel_stat* out, int cap) {
+    int n = 0;
+    for (auto& s : ctx->prof_stats) {
+        if (n >= cap) break;
+        memset(&out[n], 0, sizeof(out[n]));
+        strncpy(out[n].name, s.name.c_str(), sizeof(out[n].name) - 1);
+        out[n].launches = s.launches; out[n].total_ms = s.ms; out[n].algo_bytes = s.bytes;
+        n++;
+    }
+    return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,698 @@
+#include "host.hpp"
+#include <algorithm>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <mutex>
+#include <queue>
+#include <sstream>
+#include <functional>
+#include <omp.h>
+
+namespace hg {
+
+// ------------------------------------------------------------------------------------------------
+// Keccak-256 (rate 136, pad 0x01..0x80) — sha3::Keccak256 as used by transcript.rs:117,141
+static const u64 KECCAK_RC[24] = {
+    0x1ULL, 0x8082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x808bULL, 0x80000001ULL,
+    0x8000000080008081ULL, 0x8000000000008009ULL, 0x8aULL, 0x88ULL, 0x80008009ULL, 0x8000000aULL,
+    0x8000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
+    0x8000000000008002ULL, 0x8000000000000080ULL, 0x800aULL, 0x800000008000000aULL,
+    0x8000000080008081ULL, 0x8000000000008080ULL, 0x80000001ULL, 0x8000000080008008ULL};
+// rho rotation and pi destination of lane i = x + 5y, walked along the pi cycle starting at lane 1
+static const int KECCAK_PILN[24] = {10, 7, 11, 17, 18, 3, 5, 16, 8, 21, 24, 4, 15, 23, 19, 13, 12, 2, 20, 14, 22, 9, 6, 1};
+static const int KECCAK_ROTC[24] = {1, 3, 6, 10, 15, 21, 28, 36, 45, 55, 2, 14, 27, 41, 56, 8, 25, 43, 62, 18, 39, 61, 20, 44};
+
+static inline u64 rol(u64 x, int s) { return (x << s) | (x >> (64 - s)); }
+
+static void keccak_permute(u64 a[25]) {
+    for (int rnd = 0; rnd < 24; rnd++) {
+        u64 bc[5];
+        for (int i = 0; i < 5; i++) bc[i] = a[i] ^ a[i + 5] ^ a[i + 10] ^ a[i + 15] ^ a[i + 20];
+        for (int i = 0; i < 5; i++) {
+            u64 t = bc[(i + 4) % 5] ^ rol(bc[(i + 1) % 5], 1);
+            for (int j = 0; j < 25; j += 5) a[j + i] ^= t;
+        }
+        u64 t = a[1];
+        for (int i = 0; i < 24; i++) {
+            int j = KECCAK_PILN[i];
+            u64 b = a[j];
+            a[j] = rol(t, KECCAK_ROTC[i]);
+            t = b;
+        }
+        for (int j = 0; j < 25; j += 5) {
+            for (int i = 0; i < 5; i++) bc[i] = a[j + i];
+            for (int i = 0; i < 5; i++) a[j + i] ^= (~bc[(i + 1) % 5]) & bc[(i + 2) % 5];
+        }
+        a[0] ^= KECCAK_RC[rnd];
+    }
+}
+
+void keccak256(const uint8_t* data, size_t len, uint8_t out[32]) {
+    u64 st[25] = {0};
+    uint8_t* sb = reinterpret_cast<uint8_t*>(st);  // little-endian host
+    const size_t rate = 136;
+    size_t fill = 0;
+    for (size_t i = 0; i < len; i++) {
+        sb[fill++] ^= data[i];
+        if (fill == rate) { keccak_permute(st); fill = 0; }
+    }
+    sb[fill] ^= 0x01;
+    sb[rate - 1] ^= 0x80;
+    keccak_permute(st);
+    memcpy(out, sb, 32);
+}
+
+// fe_mod_from_le_bytes (transcript.rs:202): 256-bit little-endian integer mod p
+static u64 felt_from_hash(const uint8_t h[32]) {
+    u64 limb[4];
+    memcpy(limb, h, 32);
+    u64 acc = 0;
+    for (int i = 3; i >= 0; i--) acc = gl_add(gl_mul(acc, GL_EPS), gl_from_u64(limb[i]));  // * 2^64 = * (2^32-1)
+    return acc;
+}
+
+const u64* challenge_chain(size_t n_base) {
+    static std::mutex mu;
+    static std::vector<u64>* cache = nullptr;  // leaked on purpose: pointers stay valid for the process lifetime
+    static uint8_t last[32];
+    static std::vector<std::vector<u64>*> old;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!cache) cache = new std::vector<u64>();
+    if (cache->size() < n_base) {
+        size_t want = std::max<size_t>(n_base, cache->size() * 2 + 4096);
+        auto* grown = new std::vector<u64>(*cache);
+        grown->reserve(want);
+        while (grown->size() < want) {
+            uint8_t nh[32];
+            if (grown->empty()) keccak256(nullptr, 0, nh);
+            else keccak256(last, 32, nh);
+            memcpy(last, nh, 32);
+            grown->push_back(felt_from_hash(nh));
+        }
+        old.push_back(cache);  // keep earlier buffers alive for readers holding a pointer
+        cache = grown;
+    }
+    return cache->data();
+}
+
+// ------------------------------------------------------------------------------------------------
+static int ilog2u(u64 x) { return 63 - __builtin_clzll(x); }
+
+Params::Params(const hg_params& p) : raw(p) {
+    if (p.n < 4 || (p.n & (p.n - 1))) throw Error("n must be a power of two");
+    if (p.k < 1 || p.k > HG_MAX_K || (p.k & (p.k - 1))) throw Error("k must be a power of two <= 16");
+    n_log2 = ilog2u(p.n);
+    L = n_log2 + 1;
+    k = (int)p.k;
+    log2k = ilog2u(p.k);
+}
+
+static const hg_params BUILTIN[] = {
+#include "params_table.inc"
+};
+
+bool params_builtin(uint32_t n, uint32_t k, hg_params* out) {
+    for (const hg_params& b : BUILTIN)
+        if (b.n == n && b.k == k) { *out = b; return true; }
+    return false;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// JSON witness: {"s":[".."],"e":[..],"k1":[..],"r2is":[[..]],"r1is":[[..]],"ais":[[..]],"ct0is":[[..]]}
+namespace {
+struct JsonCursor {
+    const std::string& s;
+    size_t i = 0;
+    explicit JsonCursor(const std::string& str) : s(str) {}
+    void ws() { while (i < s.size() && (s[i] == ' ' || s[i] == '\n' || s[i] == '\t' || s[i] == '\r')) i++; }
+    bool eat(char c) { ws(); if (i < s.size() && s[i] == c) { i++; return true; } return false; }
+    void need(char c) { if (!eat(c)) throw Error(std::string("witness json: expected '") + c + "' at offset " + std::to_string(i)); }
+    std::string str() {
+        need('"');
+        size_t b = i;
+        while (i < s.size() && s[i] != '"') i++;
+        if (i >= s.size()) throw Error("witness json: unterminated string");
+        return s.substr(b, i++ - b);
+    }
+    u64 felt() {  // F::from_str_vartime on a decimal string (poly.rs:13-16)
+        std::string d = str();
+        if (d.empty()) throw Error("witness json: empty coefficient");
+        unsigned __int128 v = 0;
+        for (char c : d) {
+            if (c < '0' || c > '9') throw Error("witness json: non-decimal coefficient");
+            v = v * 10 + (unsigned)(c - '0');
+            if (v >= ((unsigned __int128)1 << 64)) throw Error("witness json: coefficient out of field range");
+        }
+        if ((u64)v >= GL_P) throw Error("witness json: coefficient out of field range");
+        return (u64)v;
+    }
+    std::vector<u64> felts() {
+        std::vector<u64> v;
+        need('[');
+        if (eat(']')) return v;
+        do v.push_back(felt()); while (eat(','));
+        need(']');
+        return v;
+    }
+    std::vector<std::vector<u64>> felts2() {
+        std::vector<std::vector<u64>> v;
+        need('[');
+        if (eat(']')) return v;
+        do v.push_back(felts()); while (eat(','));
+        need(']');
+        return v;
+    }
+};
+
+// Poly::new_padded (poly.rs:20-28)
+void put_padded(const std::vector<u64>& c, size_t size, u64* dst) {
+    if (c.size() > size) throw Error("witness: polynomial longer than its table");
+    std::fill(dst, dst + size, 0);
+    std::copy(c.begin(), c.end(), dst);
+}
+// Poly::new_shifted (poly.rs:30-44): left-pad to `size`, then resize to next_power_of_two(size)
+std::vector<u64> shifted(const std::vector<u64>& c, size_t size) {
+    size_t pad = size > c.size() ? size - c.size() : 0;
+    std::vector<u64> v(pad, 0);
+    v.insert(v.end(), c.begin(), c.end());
+    size_t np = 1;
+    while (np < size) np <<= 1;
+    v.resize(np, 0);
+    return v;
+}
+
+struct RawArgs {  // BfvSkEncryptArgs (sk_encryption_circuit.rs:64-73), coefficients highest degree first
+    std::vector<u64> s, e, k1;
+    std::vector<std::vector<u64>> r2is, r1is, ais, ct0is;
+};
+
+Witness layout_inputs(const Params& p, const RawArgs& a) {  // get_inputs (sk_encryption_circuit.rs:365-415)
+    const size_t SZ = p.SZ(), PZ = p.PZ();
+    const size_t k = (size_t)p.k;
+    if (a.ct0is.size() < k || a.ais.size() < k || a.r1is.size() < k || a.r2is.size() < k) throw Error("witness: fewer CRT components than k");
+    Witness w;
+    w.s.resize(SZ);
+    put_padded(a.s, SZ, w.s.data());
+    w.e = shifted(a.e, SZ - 1);
+    w.k1 = shifted(a.k1, SZ - 1);
+    if (w.e.size() != SZ || w.k1.size() != SZ) throw Error("witness: e/k1 length");
+    w.ais.resize(k * SZ);
+    w.r1is.resize(k * SZ);
+    w.r2is.assign(k * PZ, 0);
+    w.ct0is.resize(k * SZ);
+    for (size_t z = 0; z < k; z++) {
+        put_padded(a.ais[z], SZ, &w.ais[z * SZ]);
+        put_padded(a.r1is[z], SZ, &w.r1is[z * SZ]);
+        if (a.r2is[z].size() + 1 != PZ) throw Error("witness: r2i must have n-1 coefficients");
+        std::copy(a.r2is[z].begin(), a.r2is[z].end(), &w.r2is[z * PZ]);  // + one trailing zero (:402-405)
+        std::vector<u64> ct = shifted(a.ct0is[z], SZ);                    // :393
+        if (ct.size() != SZ) throw Error("witness: ct0i length");
+        std::copy(ct.begin() + 1, ct.end(), &w.ct0is[z * SZ]);            // [1..] then push 0 (:394-395)
+        w.ct0is[z * SZ + SZ - 1] = 0;
+    }
+    return w;
+}
+}  // namespace
+
+Witness witness_from_json(const Params& p, const std::string& path) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw Error("witness json: cannot open " + path);
+    std::stringstream ss;
+    ss << f.rdbuf();
+    std::string text = ss.str();
+    JsonCursor c(text);
+    RawArgs a;
+    c.need('{');
+    int seen = 0;
+    do {
+        std::string key = c.str();
+        c.need(':');
+        if (key == "s") a.s = c.felts();
+        else if (key == "e") a.e = c.felts();
+        else if (key == "k1") a.k1 = c.felts();
+        else if (key == "r2is") a.r2is = c.felts2();
+        else if (key == "r1is") a.r1is = c.felts2();
+        else if (key == "ais") a.ais = c.felts2();
+        else if (key == "ct0is") a.ct0is = c.felts2();
+        else throw Error("witness json: unknown key " + key);
+        seen++;
+    } while (c.eat(','));
+    c.need('}');
+    if (seen != 7) throw Error("witness json: expected 7 fields");
+    return layout_inputs(p, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Synthetic witness: the math of scripts/circuit_sk.py:18-140 on seeded integer-only samplers.
+//   s uniform in {-1,0,1}; e centred binomial (eta = 20, variance 10 ~ sigma 3.2) truncated to +-19;
+//   a_i uniform in [-(q_i-1)/2, (q_i-1)/2]; k1 uniform in [-(t-1)/2, (t-1)/2] ([q m]_t is a bijection of m);
+//   ct0i_hat = a_i s + e + k0_i k1 over Z;  ct0i = ct0i_hat mod (X^n+1, q_i) centred;
+//   r2i = ((ct0i - ct0i_hat) mod q_i) / (X^n+1);  r1i = (ct0i - ct0i_hat - r2i (X^n+1)) / q_i;
+//   negatives are assigned as p - |z| (utils.py:4-18).
+namespace {
+struct SplitMix64 {
+    u64 x;
+    u64 next() {
+        u64 z = (x += 0x9E3779B97F4A7C15ULL);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+        return z ^ (z >> 31);
+    }
+    u64 below(u64 m) {  // uniform in [0, m) by rejection
+        u64 lim = ~0ULL - (~0ULL % m);
+        u64 v;
+        do v = next(); while (v >= lim);
+        return v % m;
+    }
+};
+typedef __int128 i128;
+inline u64 assign(i128 z) { return z >= 0 ? (u64)z : GL_P - (u64)(-z); }
+inline i128 centre_mod(i128 z, i128 q) {
+    i128 r = z % q;
+    if (r < 0) r += q;
+    if (r > (q - 1) / 2) r -= q;
+    return r;
+}
+}  // namespace
+
+Witness witness_synthetic(const Params& p, u64 seed) {
+    const size_t n = p.raw.n, k = (size_t)p.k;
+    const int64_t t = 65537;
+    for (int attempt = 0; attempt < 8; attempt++) {
+        SplitMix64 rng{seed + 0x1000003ULL * (u64)attempt};
+        std::vector<int64_t> s(n), e(n), k1(n);  // ascending degree
+        for (auto& x : s) x = (int64_t)rng.below(3) - 1;
+        for (auto& x : e) {
+            int64_t v;
+            do {
+                u64 bits = rng.next();
+                v = (int64_t)__builtin_popcountll(bits & 0xFFFFFULL) - (int64_t)__builtin_popcountll((bits >> 20) & 0xFFFFFULL);
+            } while (v > 19 || v < -19);
+            x = v;
+        }
+        for (auto& x : k1) x = (int64_t)rng.below((u64)t) - (t - 1) / 2;
+        std::vector<std::vector<int64_t>> a(k, std::vector<int64_t>(n));
+        for (size_t i = 0; i < k; i++) {
+            u64 q = p.raw.qis[i];
+            for (auto& x : a[i]) x = (int64_t)rng.below(q) - (int64_t)((q - 1) / 2);
+        }
+        RawArgs out;
+        out.r2is.resize(k); out.r1is.resize(k); out.ais.resize(k); out.ct0is.resize(k);
+        bool ok = true;
+#pragma omp parallel for schedule(dynamic, 1)
+        for (long long ii = 0; ii < (long long)k; ii++) {
+            size_t i = (size_t)ii;
+            const i128 q = (i128)p.raw.qis[i];
+            const i128 k0 = (i128)p.raw.k0is[i];
+            // a_i * s over Z with a split into 32-bit halves so the inner loops stay in int64
+            std::vector<int64_t> alo(n), ahi(n), acc_lo(2 * n, 0), acc_hi(2 * n, 0);
+            for (size_t m = 0; m < n; m++) { alo[m] = (int64_t)((u64)a[i][m] & 0xFFFFFFFFULL); ahi[m] = a[i][m] >> 32; }
+            for (size_t j = 0; j < n; j++) {
+                if (s[j] == 0) continue;
+                int64_t* dl = &acc_lo[j];
+                int64_t* dh = &acc_hi[j];
+                if (s[j] > 0) for (size_t m = 0; m < n; m++) { dl[m] += alo[m]; dh[m] += ahi[m]; }
+                else for (size_t m = 0; m < n; m++) { dl[m] -= alo[m]; dh[m] -= ahi[m]; }
+            }
+            std::vector<i128> h(2 * n, 0);  // ct0i_hat, ascending, degree <= 2n-2
+            for (size_t j = 0; j < 2 * n - 1; j++) h[j] = ((i128)acc_hi[j] << 32) + (i128)acc_lo[j];
+            for (size_t j = 0; j < n; j++) h[j] += (i128)e[j] + k0 * (i128)k1[j];
+            std::vector<i128> ct0(n), r2(n - 1), r1(2 * n - 1);
+            for (size_t j = 0; j < n; j++) ct0[j] = centre_mod(h[j] - h[j + n], q);
+            for (size_t j = 0; j + 1 < n; j++) r2[j] = centre_mod(-h[j + n], q);
+            bool good = true;
+            for (size_t j = 0; j < 2 * n - 1; j++) {
+                i128 d = (j < n ? ct0[j] : 0) - h[j];
+                size_t jj = j < n ? j : j - n;
+                if (jj + 1 < n) d -= r2[jj];
+                if (d % q != 0) good = false;
+                r1[j] = d / q;
+            }
+            const i128 b1 = (i128)p.raw.r1_bounds[i], b2 = (i128)p.raw.r2_bounds[i], b2c = (i128)p.raw.r2_bounds[0];
+            for (auto v : r1) if (v > b1 || v < -b1) good = false;
+            for (auto v : r2) if (v > b2 || v < -b2 || v > b2c || v < -b2c) good = false;
+            auto rev = [&](const std::vector<i128>& v) {
+                std::vector<u64> o(v.size());
+                for (size_t j = 0; j < v.size(); j++) o[v.size() - 1 - j] = assign(v[j]);
+                return o;
+            };
+            out.ct0is[i] = rev(ct0);
+            out.r2is[i] = rev(r2);
+            out.r1is[i] = rev(r1);
+            std::vector<i128> ai(n);
+            for (size_t j = 0; j < n; j++) ai[j] = a[i][j];
+            out.ais[i] = rev(ai);
+            if (!good) {
+#pragma omp critical
+                ok = false;
+            }
+        }
+        if (!ok) continue;  // a coefficient left its range-check bound (probability ~2^-40): resample
+        auto rev64 = [&](const std::vector<int64_t>& v) {
+            std::vector<u64> o(v.size());
+            for (size_t j = 0; j < v.size(); j++) o[v.size() - 1 - j] = assign((i128)v[j]);
+            return o;
+        };
+        out.s = rev64(s); out.e = rev64(e); out.k1 = rev64(k1);
+        return layout_inputs(p, out);
+    }
+    throw Error("synthetic witness: could not satisfy the range bounds");
+}
+
+// ------------------------------------------------------------------------------------------------
+// Lasso preprocessing
+int LassoPlan::lookup_index(u64 bound) const {
+    for (size_t i = 0; i < lookups.size(); i++) if (lookups[i].bound == bound) return (int)i;
+    throw Error("lasso: unknown lookup bound");
+}
+
+std::string LassoPlan::layout_text() const {
+    std::string s;
+    for (int m = 0; m < alpha; m++) { if (m) s += ","; s += mems[m].subtable_id + "@" + std::to_string(mems[m].dim); }
+    s += "|";
+    for (size_t l = 0; l < lookups.size(); l++) {
+        if (l) s += ";";
+        s += lookups[l].id + ":" + std::to_string(lookups[l].total_bits) + ":";
+        for (size_t i = 0; i < lookups[l].mems.size(); i++) { if (i) s += "/"; s += std::to_string(lookups[l].mems[i]); }
+    }
+    return s;
+}
+
+namespace {
+// RangeLookup decomposition of one bound (range.rs:207-250): which subtable serves which dimension
+struct RangeShape {
+    int full_dims;      // dimensions 0..full_dims-1 use the full 16-bit limb table
+    bool has_rem;       // one BoundSubtable at dimension `rem_dim`
+    int rem_dim;
+    u64 cutoff;         // BoundSubtable cutoff (range.rs:59-61)
+    int total_bits;     // sum(chunk_bits) (range.rs:234-250)
+};
+RangeShape range_shape(u64 bound) {
+    const u64 M = 1u << LassoPlan::LOGM;
+    RangeShape r{};
+    int bits = ilog2u(bound);
+    int limbs = bits / LassoPlan::LOGM;
+    u64 cutoff = (1ULL << (bits % LassoPlan::LOGM)) + bound % M;
+    if (bound % M == 0) { r.full_dims = limbs; r.has_rem = false; }
+    else if (bound < M) { r.full_dims = 0; r.has_rem = true; r.rem_dim = 0; }
+    else { r.full_dims = limbs; r.has_rem = true; r.rem_dim = limbs; }
+    r.cutoff = cutoff;
+    r.total_bits = limbs * LassoPlan::LOGM + (bound % M != 0 ? ilog2u(cutoff) : 0);
+    return r;
+}
+}  // namespace
+
+LassoPlan lasso_preprocess(const Params& p) {
+    LassoPlan lp;
+    // setup(): S, E, K1, R1[..k], R2[..k] as RangeLookup(2b+1) (sk_encryption_circuit.rs:327-341), keyed by id string
+    std::map<std::string, u64> by_id;
+    auto add = [&](u64 b) { by_id["range_" + std::to_string(2 * b + 1)] = 2 * b + 1; };
+    add(p.raw.s_bound); add(p.raw.e_bound); add(p.raw.k1_bound);
+    for (int i = 0; i < p.k; i++) add(p.raw.r1_bounds[i]);
+    for (int i = 0; i < p.k; i++) add(p.raw.r2_bounds[i]);
+    // subtables in first-seen order over lookups in key order; per subtable the union of its dimensions
+    std::vector<u64> st_dims_mask;
+    auto subtable_slot = [&](const std::string& id, u64 bound) {
+        for (size_t i = 0; i < lp.subtable_ids.size(); i++) if (lp.subtable_ids[i] == id) return (int)i;
+        lp.subtable_ids.push_back(id);
+        lp.subtable_bound.push_back(bound);
+        st_dims_mask.push_back(0);
+        return (int)lp.subtable_ids.size() - 1;
+    };
+    struct Use { int subtable; u64 dims_mask; };
+    std::vector<std::vector<Use>> uses;
+    for (auto& kv : by_id) {
+        RangeShape sh = range_shape(kv.second);
+        std::vector<Use> u;
+        if (sh.full_dims > 0 || !sh.has_rem) {
+            int si = subtable_slot("full", 0);
+            u64 mask = (1ULL << sh.full_dims) - 1;
+            st_dims_mask[si] |= mask;
+            u.push_back({si, mask});
+        }
+        if (sh.has_rem) {
+            int si = subtable_slot("bound_" + std::to_string(kv.second), kv.second);
+            st_dims_mask[si] |= 1ULL << sh.rem_dim;
+            u.push_back({si, 1ULL << sh.rem_dim});
+        }
+        uses.push_back(u);
+        lp.lookups.push_back({kv.second, kv.first, sh.total_bits, {}});
+    }
+    // memories: contiguous per subtable, ascending dimension (lasso.rs:574-586)
+    std::vector<std::vector<int>> st_mems(lp.subtable_ids.size());
+    for (size_t si = 0; si < lp.subtable_ids.size(); si++)
+        for (int d = 0; d < 64; d++)
+            if (st_dims_mask[si] >> d & 1) {
+                u64 cutoff = lp.subtable_bound[si] ? range_shape(lp.subtable_bound[si]).cutoff : (1u << LassoPlan::LOGM);
+                if (cutoff > (1u << LassoPlan::LOGM)) cutoff = 1u << LassoPlan::LOGM;
+                st_mems[si].push_back((int)lp.mems.size());
+                lp.mems.push_back({(int)si, d, cutoff, lp.subtable_ids[si]});
+            }
+    lp.alpha = (int)lp.mems.size();
+    for (size_t l = 0; l < lp.lookups.size(); l++)
+        for (auto& u : uses[l])
+            for (int m : st_mems[u.subtable])
+                if (u.dims_mask >> lp.mems[m].dim & 1) lp.lookups[l].mems.push_back(m);
+    for (auto& m : lp.mems) if (m.dim >= LassoPlan::C) throw Error("lasso: dimension index exceeds C");
+    // node rows (sk_encryption_circuit.rs:182-204)
+    const int P = p.n_log2, L = p.L;
+    const int r2i_l = p.k == 1 ? L : P;
+    lp.seg_shift = P;
+    auto push_rows = [&](u64 bound, int log2rows) {
+        uint8_t id = (uint8_t)lp.lookup_index(2 * bound + 1);
+        lp.seg_lookup.insert(lp.seg_lookup.end(), (size_t)1 << (log2rows - P), id);
+    };
+    for (int i = 0; i < p.k; i++) push_rows(p.raw.r1_bounds[i], L);
+    for (int i = 0; i < p.k; i++) push_rows(p.raw.r2_bounds[i], r2i_l);
+    push_rows(p.raw.s_bound, L); push_rows(p.raw.e_bound, L); push_rows(p.raw.k1_bound, L);
+    lp.rows = lp.seg_lookup.size() << P;
+    lp.nu = 0;
+    while (((size_t)1 << lp.nu) < lp.rows) lp.nu++;
+    // memory-checking chunks
+    std::map<int, std::vector<int>> cm;
+    for (int m = 0; m < lp.alpha; m++) cm[lp.mems[m].dim].push_back(m);
+    for (auto& kv : cm) {
+        lp.chunks.push_back(kv);
+        for (int m : kv.second) { lp.gkr_order.push_back(m); lp.gkr_chunk.push_back(kv.first); }
+        if (kv.first >= lp.alpha) throw Error("lasso: chunk index has no counter memory");
+    }
+    return lp;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Circuit wiring (BfvEncryptBlock::configure)
+namespace {
+struct Gates {  // VanillaNode::new(input_arity, log2_sub_input_size, gates, num_reps)
+    HNode n;
+    u32 g = 0;
+    Gates(int arity, int log2_sub_in, int reps) {
+        n.kind = NK_VANILLA; n.arity = arity; n.log2_sub_in = log2_sub_in; n.log2_reps = ilog2u((u64)reps);
+    }
+    void relay(u32 i, u32 j, u64 scale = 1, u64 add = 0) {  // relay / relay_mul_const / relay_add_const (:525-531)
+        if (add) n.w0.push_back({g, add});
+        n.lin.push_back({g, i, j, scale});
+        g++;
+    }
+    void zero() { g++; }  // VanillaGate::constant(F::ZERO)
+    void mul(u32 i0, u32 j0, u32 i1, u32 j1) { n.mul.push_back({g, i0, j0, i1, j1, 1}); g++; }
+    void begin_sum() {}
+    void sum_term(u32 i, u32 j) { n.lin.push_back({g, i, j, 1}); }
+    void end_sum() { g++; }
+    HNode done() {
+        n.num_gates = g;
+        n.log2_sub_out = 0;
+        while ((1u << n.log2_sub_out) < g) n.log2_sub_out++;
+        n.left_use.assign(n.arity, 0);
+        n.right_use.assign(n.arity, 0);
+        for (auto& t : n.lin) n.left_use[t.in] = 1;
+        for (auto& t : n.mul) { n.left_use[t.i0] = 1; n.right_use[t.i1] = 1; }
+        return n;
+    }
+};
+}  // namespace
+
+HCircuit build_circuit(const Params& p, const LassoPlan& lp) {
+    HCircuit c;
+    auto insert = [&](HNode n) { c.nodes.push_back(std::move(n)); return (int)c.nodes.size() - 1; };
+    auto connect = [&](int from, int to) { c.nodes[to].preds.push_back(from); c.nodes[from].succs.push_back(to); };
+    auto input = [&](int log2, int reps) { HNode n; n.kind = NK_INPUT; n.log2_size = log2 + ilog2u((u64)reps); return insert(n); };
+    auto fft = [&](int log2, bool inv) { HNode n; n.kind = NK_FFT; n.log2_size = log2; n.inverse = inv; return insert(n); };
+    const int P = p.n_log2, L = p.L, k = p.k;
+    const u32 SZ = (u32)1 << L;
+    int s = input(L, 1), e = input(L, 1), k1 = input(L, 1);  // :358-360
+    int es, k1kis;
+    { Gates g(1, L, 1); for (int i = 0; i < k; i++) for (u32 j = 0; j < SZ; j++) g.relay(0, j); es = insert(g.done()); }                          // :97-103
+    { Gates g(1, L, 1); for (int i = 0; i < k; i++) for (u32 j = 0; j < SZ; j++) g.relay(0, j, gl_from_u64(p.raw.k0is[i])); k1kis = insert(g.done()); }  // :105-115
+    connect(e, es); connect(k1, k1kis);
+    std::vector<int> ais, r1is;
+    for (int i = 0; i < k; i++) ais.push_back(input(L, 1));   // :122-124
+    for (int i = 0; i < k; i++) r1is.push_back(input(L, 1));  // :126-128
+    int r1iqis;
+    { Gates g(k, L, 1); for (int i = 0; i < k; i++) for (u32 j = 0; j < SZ; j++) g.relay((u32)i, j, gl_from_u64(p.raw.qis[i])); r1iqis = insert(g.done()); }  // :130-141
+    for (int i = 0; i < k; i++) connect(r1is[i], r1iqis);
+    int r2is = input(P, k);  // :147
+    const int r2l = P + p.log2k;
+    std::vector<int> chunks;
+    for (u64 st = 0; st < (1ULL << r2l); st += SZ) {  // :149-161
+        Gates g(1, r2l, 1);
+        u64 en = std::min<u64>(st + SZ, 1ULL << r2l);
+        for (u64 j = st; j < en; j++) g.relay(0, (u32)j);
+        for (u64 j = en - st; j < SZ; j++) g.zero();
+        int node = insert(g.done());
+        connect(r2is, node);
+        chunks.push_back(node);
+    }
+    {   // lasso_inputs_batched :163-181
+        std::vector<u64> bounds;
+        for (int i = 0; i < k; i++) bounds.push_back(p.raw.r1_bounds[i]);
+        for (size_t i = 0; i < chunks.size(); i++) bounds.push_back(p.raw.r2_bounds[0]);
+        bounds.push_back(p.raw.s_bound); bounds.push_back(p.raw.e_bound); bounds.push_back(p.raw.k1_bound);
+        Gates g((int)bounds.size(), L, 1);
+        for (size_t i = 0; i < bounds.size(); i++) for (u32 j = 0; j < SZ; j++) g.relay((u32)i, j, 1, gl_from_u64(bounds[i]));
+        c.lasso_in_id = insert(g.done());
+    }
+    { HNode n; n.kind = NK_LASSO; c.lasso_id = insert(n); }  // :182-210 (rows/lookups live in the LassoPlan)
+    if ((int)c.nodes[c.lasso_in_id].log2_out() != lp.nu) throw Error("circuit: lasso input size != 2^nu");
+    for (int i = 0; i < k; i++) connect(r1is[i], c.lasso_in_id);
+    for (int ch : chunks) connect(ch, c.lasso_in_id);
+    connect(s, c.lasso_in_id); connect(e, c.lasso_in_id); connect(k1, c.lasso_in_id);
+    connect(c.lasso_in_id, c.lasso_id);
+    int s_eval = fft(L, false);  // :224-225
+    connect(s, s_eval);
+    int s_eval_copy;
+    { Gates g(1, L, 1); for (u32 j = 0; j < SZ; j++) g.relay(0, j); s_eval_copy = insert(g.done()); }  // :227-235
+    connect(s_eval, s_eval_copy);
+    int sai_par;
+    { Gates g(k, L, 1); for (int i = 0; i < k; i++) for (u32 j = 0; j < SZ; j++) g.relay((u32)i, j); sai_par = insert(g.done()); }  // :237-243
+    for (int i = 0; i < k; i++) {  // :245-260
+        int ai_eval = fft(L, false);
+        int sai_eval;
+        { Gates g(2, L, 1); for (u32 j = 0; j < SZ; j++) g.mul(0, j, 1, j); sai_eval = insert(g.done()); }
+        int sai = fft(L, true);
+        connect(ais[i], ai_eval);
+        connect(s_eval_copy, sai_eval); connect(ai_eval, sai_eval);
+        connect(sai_eval, sai);
+        connect(sai, sai_par);
+    }
+    int cyclo;
+    {   // r2i_cyclo :262-278
+        u32 r2sz = ((u32)1 << P) - 1;
+        Gates g(1, P, k);
+        for (u32 j = 0; j < r2sz; j++) g.relay(0, j);
+        g.zero();
+        for (u32 j = 0; j < r2sz; j++) g.relay(0, j);
+        g.zero();
+        cyclo = insert(g.done());
+    }
+    {   // sum :280-285
+        Gates g(5, L, k);
+        for (u32 j = 0; j < SZ; j++) { for (u32 i = 0; i < 5; i++) g.sum_term(i, j); g.end_sum(); }
+        c.sum_id = insert(g.done());
+    }
+    connect(r2is, cyclo);
+    connect(sai_par, c.sum_id); connect(es, c.sum_id); connect(k1kis, c.sum_id); connect(r1iqis, c.sum_id); connect(cyclo, c.sum_id);
+    // node order: Kahn, smallest id first
+    std::vector<int> indeg(c.nodes.size());
+    for (size_t i = 0; i < c.nodes.size(); i++) indeg[i] = (int)c.nodes[i].preds.size();
+    std::priority_queue<int, std::vector<int>, std::greater<int>> ready;
+    for (size_t i = 0; i < c.nodes.size(); i++) if (!indeg[i]) ready.push((int)i);
+    while (!ready.empty()) {
+        int u = ready.top(); ready.pop();
+        c.topo.push_back(u);
+        for (int v : c.nodes[u].succs) if (--indeg[v] == 0) ready.push(v);
+    }
+    if (c.topo.size() != c.nodes.size()) throw Error("circuit: cycle");
+    for (size_t i = 0; i < c.nodes.size(); i++) if (c.nodes[i].kind == NK_INPUT) c.input_ids.push_back((int)i);
+    return c;
+}
+
+// ------------------------------------------------------------------------------------------------
+u64 root_of_unity(int log2n) {
+    u64 w = gl_pow(7, (GL_P - 1) >> 32);
+    for (int i = log2n; i < 32; i++) w = gl_mul(w, w);
+    return w;
+}
+
+void ntt_host(u64* a, int log2n, bool inverse) {
+    // decimation in frequency (natural in, bit-reversed out) followed by the bit-reversal permutation
+    const size_t N = (size_t)1 << log2n;
+    u64 w = root_of_unity(log2n);
+    if (inverse) w = gl_inv(w);
+    std::vector<u64> tw(N / 2);
+    tw[0] = 1;
+    for (size_t i = 1; i < N / 2; i++) tw[i] = gl_mul(tw[i - 1], w);
+    for (int s = log2n - 1; s >= 0; s--) {
+        size_t h = (size_t)1 << s, step = N >> (s + 1);
+        for (size_t base = 0; base < N; base += 2 * h)
+            for (size_t j = 0; j < h; j++) {
+                u64 x = a[base + j], y = a[base + j + h];
+                a[base + j] = gl_add(x, y);
+                a[base + j + h] = gl_mul(gl_sub(x, y), tw[j * step]);
+            }
+    }
+    for (size_t i = 0; i < N; i++) {
+        size_t r = 0;
+        for (int b = 0; b < log2n; b++) r |= ((i >> b) & 1) << (log2n - 1 - b);
+        if (r > i) std::swap(a[i], a[r]);
+    }
+    if (inverse) {
+        u64 ninv = gl_inv(gl_from_u64(N));
+        for (size_t i = 0; i < N; i++) a[i] = gl_mul(a[i], ninv);
+    }
+}
+
+std::vector<std::vector<u64>> circuit_evaluate(const HCircuit& c, const Params& p, const Witness& w) {
+    std::vector<std::vector<u64>> v(c.nodes.size());
+    const size_t SZ = p.SZ();
+    {   // inputs in NodeId order: s, e, k1, ais.., r1is.., r2is (chain_par! :408)
+        size_t idx = 0;
+        auto put = [&](const u64* src, size_t len) {
+            int id = c.input_ids.at(idx++);
+            if (len != ((size_t)1 << c.nodes[id].log2_size)) throw Error("circuit: input size mismatch");
+            v[id].assign(src, src + len);
+        };
+        put(w.s.data(), SZ); put(w.e.data(), SZ); put(w.k1.data(), SZ);
+        for (int i = 0; i < p.k; i++) put(&w.ais[i * SZ], SZ);
+        for (int i = 0; i < p.k; i++) put(&w.r1is[i * SZ], SZ);
+        put(w.r2is.data(), w.r2is.size());
+        if (idx != c.input_ids.size()) throw Error("circuit: input count mismatch");
+    }
+    // level-synchronous evaluation so independent nodes (the 2k FFT chains) run in parallel
+    std::vector<int> level(c.nodes.size(), 0);
+    int maxl = 0;
+    for (int id : c.topo) { for (int pr : c.nodes[id].preds) level[id] = std::max(level[id], level[pr] + 1); maxl = std::max(maxl, level[id]); }
+    for (int l = 1; l <= maxl; l++) {
+        std::vector<int> ids;
+        for (int id : c.topo) if (level[id] == l) ids.push_back(id);
+#pragma omp parallel for schedule(dynamic, 1)
+        for (long long q = 0; q < (long long)ids.size(); q++) {
+            int id = ids[q];
+            const HNode& n = c.nodes[id];
+            if (n.kind == NK_FFT) {
+                v[id] = v[n.preds[0]];
+                ntt_host(v[id].data(), n.log2_size, n.inverse);
+            } else if (n.kind == NK_LASSO) {
+                v[id].assign(1, 0);  // LassoNode::evaluate returns [0] (lasso.rs:53-55)
+            } else if (n.kind == NK_VANILLA) {
+                const size_t G = (size_t)1 << n.log2_sub_out, S = (size_t)1 << n.log2_sub_in, R = (size_t)1 << n.log2_reps;
+                std::vector<u64>& o = v[id];
+                o.assign(G * R, 0);
+                for (size_t rep = 0; rep < R; rep++) {
+                    u64* dst = o.data() + rep * G;
+                    for (auto& t : n.w0) dst[t.gate] = gl_add(dst[t.gate], t.c);
+                    for (auto& t : n.lin) {
+                        u64 x = v[n.preds[t.in]][rep * S + t.j];
+                        dst[t.gate] = gl_add(dst[t.gate], t.c == 1 ? x : gl_mul(t.c, x));
+                    }
+                    for (auto& t : n.mul)
+                        dst[t.gate] = gl_add(dst[t.gate], gl_mul(t.c, gl_mul(v[n.preds[t.i0]][rep * S + t.j0], v[n.preds[t.i1]][rep * S + t.j1])));
+                }
+            }
+        }
+    }
+    return v;
+}
+
+}  // namespace hg

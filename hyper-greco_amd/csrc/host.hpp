@@ -1,0 +1,136 @@
+// Host side of the prover: Fiat-Shamir chain + proof stream, parameter tables, witness loading /
+// synthesis, Lasso preprocessing and the circuit wiring of the BFV sk-encryption circuit.
+// Mirrors the reference's host-level API for this path (names and argument meaning):
+//   Keccak256Transcript         [REF bfv-gkr/src/transcript.rs:117-203]
+//   BfvSkEncryptConstans        [REF bfv-gkr/src/constants/mod.rs:16-35]
+//   Poly::{new,new_padded,new_shifted}, BfvEncrypt::get_inputs  [REF poly.rs:12-44, sk_encryption_circuit.rs:365-415]
+//   LassoPreprocessing::preprocess, RangeLookup, {FullLimb,Bound}Subtable  [REF lasso.rs:527-627, table/range.rs]
+//   BfvEncrypt::configure       [REF sk_encryption_circuit.rs:86-293, 351-363]
+#pragma once
+#include <cstdint>
+#include <cstddef>
+#include <string>
+#include <vector>
+#include <stdexcept>
+#include "gl.cuh"
+#include "../../include/hg.h"
+
+namespace hg {
+
+struct Error : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Fiat-Shamir. The reference transcript never absorbs prover messages (write_felt only appends to
+// the stream, common_felt is a no-op, transcript.rs:156,183-189), so the challenges are the fixed
+// chain c_j = LE(H_j) mod p, H_1 = Keccak256(""), H_{j+1} = Keccak256(H_j). The chain is cached
+// process-wide; `ChallengeSource` is the seam where an absorbing transcript would plug in.
+void keccak256(const uint8_t* data, size_t len, uint8_t out[32]);
+const u64* challenge_chain(size_t n_base);  // pointer to >= n_base cached base-field challenges
+
+struct ChallengeSource {
+    size_t pos = 0;  // base-field challenges consumed so far
+    E2 squeeze() {   // E challenge = from_bases of DEGREE = 2 consecutive base challenges (transcript.rs:149-154)
+        const u64* c = challenge_chain(pos + 2);
+        E2 r = e2(c[pos], c[pos + 1]);
+        pos += 2;
+        return r;
+    }
+    std::vector<E2> squeeze_n(size_t n) { std::vector<E2> v(n); for (auto& x : v) x = squeeze(); return v; }
+};
+
+struct ProofStream {
+    std::vector<uint8_t> bytes;
+    void write_f(u64 a) { for (int s = 56; s >= 0; s -= 8) bytes.push_back((uint8_t)(a >> s)); }  // BE (transcript.rs:183-189)
+    void write_e(E2 a) { write_f(a.c0); write_f(a.c1); }                                           // bases in order (:191-195)
+};
+
+// ---------------------------------------------------------------------------------------------
+struct Params {
+    hg_params raw;
+    int n_log2, L;  // L = log2_size = N_LOG2 + 1 (sk_encryption_circuit.rs:81-83)
+    int k, log2k;
+    explicit Params(const hg_params& p);
+    size_t SZ() const { return (size_t)1 << L; }
+    size_t PZ() const { return (size_t)1 << n_log2; }
+    int ct0is_log2() const { return L + log2k; }  // sk_encryption_circuit.rs:519-522
+    int num_chunks() const { return k / 2 > 1 ? k / 2 : 1; }
+};
+bool params_builtin(uint32_t n, uint32_t k, hg_params* out);
+
+struct Witness {  // tables exactly as get_inputs lays them out
+    std::vector<u64> s, e, k1;  // 2^L
+    std::vector<u64> ais, r1is; // k * 2^L
+    std::vector<u64> r2is;      // k * 2^P
+    std::vector<u64> ct0is;     // k * 2^L
+};
+Witness witness_from_json(const Params& p, const std::string& path);
+Witness witness_synthetic(const Params& p, u64 seed);
+
+// ---------------------------------------------------------------------------------------------
+// Lasso preprocessing (host description; the device copy lives in the prover key)
+struct LassoLookup {
+    u64 bound;                // RangeLookup bound (2b+1)
+    std::string id;           // "range_{bound}"
+    int total_bits;           // sum(chunk_bits)
+    std::vector<int> mems;    // lookup_to_memory_indices
+};
+struct LassoMemory {
+    int subtable, dim;
+    u64 cutoff;               // T[a] = a < cutoff ? a : 0   (65536 for the full-limb table)
+    std::string subtable_id;
+};
+struct LassoPlan {
+    static constexpr int C = 4, LOGM = 16;
+    std::vector<LassoLookup> lookups;  // BTreeMap<String,_> order
+    std::vector<LassoMemory> mems;
+    std::vector<std::string> subtable_ids;
+    std::vector<u64> subtable_bound;   // 0 = full
+    int alpha = 0;
+    // node
+    int nu = 0;
+    size_t rows = 0;
+    int seg_shift = 0;                 // rows come in segments of 2^seg_shift with one lookup type each
+    std::vector<uint8_t> seg_lookup;
+    // memory checking order: chunks by dimension, memories ascending (lasso.rs:303-336)
+    std::vector<std::pair<int, std::vector<int>>> chunks;
+    std::vector<int> gkr_order, gkr_chunk;
+    int lookup_index(u64 bound) const;
+    std::string layout_text() const;
+};
+LassoPlan lasso_preprocess(const Params& p);
+
+// ---------------------------------------------------------------------------------------------
+// Circuit wiring
+enum NodeKind { NK_INPUT = 0, NK_VANILLA = 1, NK_FFT = 2, NK_LASSO = 3 };
+struct LinTerm { u32 gate, in, j; u64 c; };
+struct MulTerm { u32 gate, i0, j0, i1, j1; u64 c; };
+struct ConstTerm { u32 gate; u64 c; };
+struct HNode {
+    NodeKind kind = NK_INPUT;
+    int log2_size = 0;  // input / fft: log2 of the whole table
+    int arity = 0, log2_sub_in = 0, log2_sub_out = 0, log2_reps = 0;
+    u32 num_gates = 0;
+    bool inverse = false;
+    std::vector<ConstTerm> w0;
+    std::vector<LinTerm> lin;
+    std::vector<MulTerm> mul;
+    std::vector<int> preds, succs;
+    std::vector<char> left_use, right_use;  // per input: appears as linear/left operand, as right operand
+    int log2_out() const { return kind == NK_VANILLA ? log2_sub_out + log2_reps : (kind == NK_LASSO ? 0 : log2_size); }
+};
+struct HCircuit {
+    std::vector<HNode> nodes;
+    std::vector<int> topo;  // Kahn order, smallest id first
+    std::vector<int> input_ids;
+    int lasso_id = -1, lasso_in_id = -1, sum_id = -1;
+};
+HCircuit build_circuit(const Params& p, const LassoPlan& lp);
+
+// host witness generation = Circuit::evaluate (sk_encryption_circuit.rs:442); returns one table per node
+std::vector<std::vector<u64>> circuit_evaluate(const HCircuit& c, const Params& p, const Witness& w);
+void ntt_host(u64* a, int log2n, bool inverse);  // in place, natural order
+u64 root_of_unity(int log2n);                    // 2^log2n-th root from ROOT_OF_UNITY = 7^((p-1)/2^32)
+
+}  // namespace hg

@@ -1,0 +1,566 @@
+// gfx950 (MI355X / CDNA4) kernels of the GKR prover. Integer modular work in 64-bit lanes: no MFMA.
+// Conventions: 256-thread workgroups (4 wave64), grid-stride loops over a fixed fan-in of at most
+// SC_MAX_BLOCKS workgroups, 16-byte coalesced loads of adjacent table entries (a sum-check pair
+// (T[2j], T[2j+1]) is one 16-B or 32-B contiguous access per lane), wave-level __shfl reductions then
+// one LDS hop per workgroup, per-block partial sums reduced by a second tiny launch.
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <algorithm>
+#include <rocprim/rocprim.hpp>
+#include <type_traits>
+#include "kernels.hpp"
+
+namespace hg {
+namespace dev {
+
+constexpr int TPB = 256;
+
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 shfl_down_u64(u64 v, int off) {
+    return (u64)__shfl_down((unsigned long long)v, off, 64);
+}
+__device__ __forceinline__ E2 wave_sum(E2 v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        v.c0 = gl_add(v.c0, shfl_down_u64(v.c0, off));
+        v.c1 = gl_add(v.c1, shfl_down_u64(v.c1, off));
+    }
+    return v;
+}
+// sums `v` over the workgroup; result valid in thread 0. `sm` holds TPB/64 E2 slots.
+__device__ __forceinline__ E2 block_sum(E2 v, E2* sm) {
+    v = wave_sum(v);
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sm[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < TPB / 64; w++) v = e2_add(v, sm[w]);
+    }
+    return v;
+}
+
+static inline int grid_for(size_t work_items) {
+    size_t b = (work_items + TPB - 1) / TPB;
+    if (b < 1) b = 1;
+    return (int)(b > (size_t)SC_MAX_BLOCKS ? SC_MAX_BLOCKS : b);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sum-check round, stride layout. KIND 0: g = p0 * sum_i M^i p_i (deg 2). KIND 1: g = p0 * sum_i gam^i p_2i p_2i+1 (deg 3).
+template <typename T> struct Val;
+template <> struct Val<u64> {
+    static __device__ __forceinline__ u64 add(u64 a, u64 b) { return gl_add(a, b); }
+    static __device__ __forceinline__ u64 sub(u64 a, u64 b) { return gl_sub(a, b); }
+    static __device__ __forceinline__ u64 mul(u64 a, u64 b) { return gl_mul(a, b); }
+    static __device__ __forceinline__ E2 scale(E2 c, u64 a) { return e2_mul_f(c, a); }        // c (E) * a
+    static __device__ __forceinline__ E2 fold(u64 x, u64 d, E2 r) { return e2_add_f(e2_mul_f(r, d), x); }
+    static __device__ __forceinline__ E2 lift(u64 a) { return e2(a, 0); }
+    static __device__ __forceinline__ u64 zero() { return 0; }
+};
+template <> struct Val<E2> {
+    static __device__ __forceinline__ E2 add(E2 a, E2 b) { return e2_add(a, b); }
+    static __device__ __forceinline__ E2 sub(E2 a, E2 b) { return e2_sub(a, b); }
+    static __device__ __forceinline__ E2 mul(E2 a, E2 b) { return e2_mul(a, b); }
+    static __device__ __forceinline__ E2 scale(E2 c, E2 a) { return e2_mul(c, a); }
+    static __device__ __forceinline__ E2 fold(E2 x, E2 d, E2 r) { return e2_add(x, e2_mul(r, d)); }
+    static __device__ __forceinline__ E2 lift(E2 a) { return a; }
+    static __device__ __forceinline__ E2 zero() { return e2_zero(); }
+};
+
+template <typename T>
+__device__ __forceinline__ void load_pair(const T* p, T& x, T& y);
+template <>
+__device__ __forceinline__ void load_pair<u64>(const u64* p, u64& x, u64& y) {
+    ulonglong2 v = *reinterpret_cast<const ulonglong2*>(p);
+    x = v.x; y = v.y;
+}
+template <>
+__device__ __forceinline__ void load_pair<E2>(const E2* p, E2& x, E2& y) {
+    ulonglong2 a = *reinterpret_cast<const ulonglong2*>(p);
+    ulonglong2 b = *reinterpret_cast<const ulonglong2*>(p + 1);
+    x = e2(a.x, a.y); y = e2(b.x, b.y);
+}
+__device__ __forceinline__ void store_e2(E2* p, E2 v) {
+    *reinterpret_cast<ulonglong2*>(p) = make_ulonglong2(v.c0, v.c1);
+}
+
+template <int KIND, typename T>
+__global__ __launch_bounds__(TPB) void k_sc_round(const T* __restrict__ in, size_t in_stride, E2* __restrict__ out,
+                                                  size_t out_stride, int ntab, size_t half, E2 r, Powers pw,
+                                                  E2* __restrict__ partials) {
+    using V = Val<T>;
+    constexpr int NV = KIND == SC_GRANDPROD ? 3 : 2;
+    __shared__ E2 sm[TPB / 64];
+    E2 acc[NV];
+#pragma unroll
+    for (int t = 0; t < NV; t++) acc[t] = e2_zero();
+    for (size_t j = (size_t)blockIdx.x * TPB + threadIdx.x; j < half; j += (size_t)gridDim.x * TPB) {
+        if constexpr (KIND == SC_GRANDPROD) {
+            E2 s0 = e2_zero(), s2 = e2_zero(), s3 = e2_zero();
+            T p0 = V::zero(), p2 = V::zero(), p3 = V::zero();
+            const int nb = ntab >> 1;
+            for (int i = 0; i < nb; i++) {
+                T xl, yl, xr, yr;
+                load_pair<T>(in + (size_t)(2 * i) * in_stride + 2 * j, xl, yl);
+                load_pair<T>(in + (size_t)(2 * i + 1) * in_stride + 2 * j, xr, yr);
+                T dl = V::sub(yl, xl), dr = V::sub(yr, xr);
+                T l2 = V::add(yl, dl), r2 = V::add(yr, dr);
+                T l3 = V::add(l2, dl), r3 = V::add(r2, dr);
+                if (i == 0) { p0 = xl; p2 = l2; p3 = l3; }
+                E2 g = pw.v[i];
+                s0 = e2_add(s0, V::scale(g, V::mul(xl, xr)));
+                s2 = e2_add(s2, V::scale(g, V::mul(l2, r2)));
+                s3 = e2_add(s3, V::scale(g, V::mul(l3, r3)));
+                store_e2(out + (size_t)(2 * i) * out_stride + j, V::fold(xl, dl, r));
+                store_e2(out + (size_t)(2 * i + 1) * out_stride + j, V::fold(xr, dr, r));
+            }
+            acc[0] = e2_add(acc[0], V::scale(s0, p0));
+            acc[1] = e2_add(acc[1], V::scale(s2, p2));
+            acc[2] = e2_add(acc[2], V::scale(s3, p3));
+        } else {
+            T s0 = V::zero(), s2 = V::zero(), p0 = V::zero(), p2 = V::zero();
+            for (int i = 0; i < ntab; i++) {
+                T x, y;
+                load_pair<T>(in + (size_t)i * in_stride + 2 * j, x, y);
+                T d = V::sub(y, x);
+                T v2 = V::add(y, d);
+                if (i == 0) { p0 = x; p2 = v2; }
+                u64 m = pw.v[i].c0;  // M^i is a base-field constant
+                if constexpr (std::is_same<T, u64>::value) {
+                    s0 = gl_add(s0, gl_mul(m, x));
+                    s2 = gl_add(s2, gl_mul(m, v2));
+                } else {
+                    s0 = e2_add(s0, e2_mul_f(x, m));
+                    s2 = e2_add(s2, e2_mul_f(v2, m));
+                }
+                store_e2(out + (size_t)i * out_stride + j, V::fold(x, d, r));
+            }
+            acc[0] = e2_add(acc[0], V::lift(V::mul(p0, s0)));
+            acc[1] = e2_add(acc[1], V::lift(V::mul(p2, s2)));
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NV; t++) {
+        E2 s = block_sum(acc[t], sm);
+        if (threadIdx.x == 0) partials[(size_t)blockIdx.x * NV + t] = s;
+    }
+}
+
+int sc_round(hipStream_t st, int kind, bool base, const void* in, size_t in_stride, E2* out, size_t out_stride, int ntab,
+             size_t half, E2 r, const Powers& pw, E2* partials) {
+    int grid = grid_for(half);
+    if (kind == SC_GRANDPROD) {
+        if (base) k_sc_round<SC_GRANDPROD, u64><<<grid, TPB, 0, st>>>((const u64*)in, in_stride, out, out_stride, ntab, half, r, pw, partials);
+        else k_sc_round<SC_GRANDPROD, E2><<<grid, TPB, 0, st>>>((const E2*)in, in_stride, out, out_stride, ntab, half, r, pw, partials);
+    } else {
+        if (base) k_sc_round<SC_COLLATION, u64><<<grid, TPB, 0, st>>>((const u64*)in, in_stride, out, out_stride, ntab, half, r, pw, partials);
+        else k_sc_round<SC_COLLATION, E2><<<grid, TPB, 0, st>>>((const E2*)in, in_stride, out, out_stride, ntab, half, r, pw, partials);
+    }
+    return grid;
+}
+
+// Sum-check round for g = sum_i a_i * b_i (Libra / zkCNN reductions), pointer-list layout.
+template <typename TA>
+__global__ __launch_bounds__(TPB) void k_sc_round_ps(PsTables t, size_t half, E2 r, E2* __restrict__ partials) {
+    using V = Val<TA>;
+    __shared__ E2 sm[TPB / 64];
+    E2 a0 = e2_zero(), a2 = e2_zero();
+    for (size_t j = (size_t)blockIdx.x * TPB + threadIdx.x; j < half; j += (size_t)gridDim.x * TPB) {
+        for (int i = 0; i < t.npairs; i++) {
+            TA xa, ya;
+            E2 xb, yb;
+            load_pair<TA>(reinterpret_cast<const TA*>(t.a[i]) + 2 * j, xa, ya);
+            load_pair<E2>(t.b[i] + 2 * j, xb, yb);
+            TA da = V::sub(ya, xa);
+            E2 db = e2_sub(yb, xb);
+            a0 = e2_add(a0, V::scale(xb, xa));
+            a2 = e2_add(a2, V::scale(e2_add(yb, db), V::add(ya, da)));
+            store_e2(t.oa[i] + j, V::fold(xa, da, r));
+            store_e2(t.ob[i] + j, e2_add(xb, e2_mul(r, db)));
+        }
+    }
+    E2 s = block_sum(a0, sm);
+    if (threadIdx.x == 0) partials[(size_t)blockIdx.x * 2] = s;
+    s = block_sum(a2, sm);
+    if (threadIdx.x == 0) partials[(size_t)blockIdx.x * 2 + 1] = s;
+}
+
+int sc_round_prodsum(hipStream_t st, bool a_base, const PsTables& t, size_t half, E2 r, E2* partials) {
+    int grid = grid_for(half);
+    if (a_base) k_sc_round_ps<u64><<<grid, TPB, 0, st>>>(t, half, r, partials);
+    else k_sc_round_ps<E2><<<grid, TPB, 0, st>>>(t, half, r, partials);
+    return grid;
+}
+
+__global__ __launch_bounds__(TPB) void k_reduce_partials(const E2* __restrict__ partials, int nblocks, int nv, E2* __restrict__ out) {
+    __shared__ E2 sm[TPB / 64];
+    for (int v = 0; v < nv; v++) {
+        E2 a = e2_zero();
+        for (int b = threadIdx.x; b < nblocks; b += TPB) a = e2_add(a, partials[(size_t)b * nv + v]);
+        a = block_sum(a, sm);
+        if (threadIdx.x == 0) out[v] = a;
+    }
+}
+void reduce_partials(hipStream_t st, const E2* partials, int nblocks, int nv, E2* out) {
+    k_reduce_partials<<<1, TPB, 0, st>>>(partials, nblocks, nv, out);
+}
+
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ E2 eq_at(const E2* __restrict__ pt, int n, size_t idx) {
+    E2 p = e2_one();
+    for (int i = 0; i < n; i++) {
+        E2 ri = pt[i];
+        E2 f = (idx >> i) & 1 ? ri : e2_sub(e2_one(), ri);
+        p = e2_mul(p, f);
+    }
+    return p;
+}
+__global__ __launch_bounds__(TPB) void k_eq_table(E2* __restrict__ out, int n, const E2* __restrict__ pt) {
+    size_t N = (size_t)1 << n;
+    for (size_t idx = (size_t)blockIdx.x * TPB + threadIdx.x; idx < N; idx += (size_t)gridDim.x * TPB)
+        store_e2(out + idx, eq_at(pt, n, idx));
+}
+void eq_table(hipStream_t st, E2* out, int n, const E2* chal, size_t point_off) {
+    size_t N = (size_t)1 << n;
+    int grid = (int)std::min<size_t>((N + TPB - 1) / TPB, 65535 * 16);
+    k_eq_table<<<grid, TPB, 0, st>>>(out, n, chal + point_off);
+}
+__global__ __launch_bounds__(TPB) void k_eq_combined(E2* __restrict__ out, int n, const E2* __restrict__ chal, ClaimSet cs) {
+    size_t N = (size_t)1 << n;
+    for (size_t idx = (size_t)blockIdx.x * TPB + threadIdx.x; idx < N; idx += (size_t)gridDim.x * TPB) {
+        E2 acc = e2_zero();
+        for (int a = 0; a < cs.n; a++) {
+            E2 q = eq_at(chal + cs.point_off[a], n, idx);
+            acc = e2_add(acc, cs.unit_alpha ? q : e2_mul(chal[cs.alpha_off + a], q));
+        }
+        store_e2(out + idx, acc);
+    }
+}
+void eq_combined(hipStream_t st, E2* out, int n, const E2* chal, const ClaimSet& cs) {
+    size_t N = (size_t)1 << n;
+    int grid = (int)std::min<size_t>((N + TPB - 1) / TPB, 65535 * 16);
+    k_eq_combined<<<grid, TPB, 0, st>>>(out, n, chal, cs);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Lasso
+__global__ __launch_bounds__(TPB) void k_lasso_split(LassoDev L, const u64* __restrict__ input, u64* __restrict__ dims,
+                                                     u64* __restrict__ e_polys) {
+    const size_t N = (size_t)1 << L.nu;
+    for (size_t j = (size_t)blockIdx.x * TPB + threadIdx.x; j < N; j += (size_t)gridDim.x * TPB) {
+        u32 idx[4] = {0, 0, 0, 0};
+        u64 uses = 0;
+        if (j < L.rows) {
+            int l = L.seg_lookup[j >> L.seg_shift];
+            u64 v = input[j] & L.lookup_mask[l];  // truncate to sum(chunk_bits) (lasso.rs:388-389)
+            idx[0] = (u32)(v & 0xFFFF); idx[1] = (u32)((v >> 16) & 0xFFFF);
+            idx[2] = (u32)((v >> 32) & 0xFFFF); idx[3] = (u32)((v >> 48) & 0xFFFF);
+            uses = L.lookup_uses[l];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) dims[(size_t)c * N + j] = idx[c];
+        for (int m = 0; m < L.alpha; m++) {
+            u32 a = idx[L.mem_dim[m]];
+            u64 ev = ((uses >> m) & 1) && a < L.mem_cutoff[m] ? (u64)a : 0;  // T_s[a] (range.rs:15-17, 58-72)
+            e_polys[(size_t)m * N + j] = ev;
+        }
+    }
+}
+void lasso_split(hipStream_t st, const LassoDev& L, const u64* input, u64* dims, u64* e_polys) {
+    size_t N = (size_t)1 << L.nu;
+    k_lasso_split<<<(unsigned)std::min<size_t>((N + TPB - 1) / TPB, 4096), TPB, 0, st>>>(L, input, dims, e_polys);
+}
+
+__global__ __launch_bounds__(TPB) void k_counter_keys(LassoDev L, int m, const u64* __restrict__ dim, u32* __restrict__ keys,
+                                                      u32* __restrict__ rows) {
+    const size_t N = (size_t)1 << L.nu;
+    for (size_t j = (size_t)blockIdx.x * TPB + threadIdx.x; j < N; j += (size_t)gridDim.x * TPB) {
+        u32 key = 65536;  // rows that do not touch memory m sort last
+        if (j < L.rows) {
+            int l = L.seg_lookup[j >> L.seg_shift];
+            if ((L.lookup_uses[l] >> m) & 1) key = (u32)dim[j];
+        }
+        keys[j] = key;
+        rows[j] = (u32)j;
+    }
+}
+__global__ __launch_bounds__(TPB) void k_counter_starts(const u32* __restrict__ ks, size_t n, u32* __restrict__ starts) {
+    for (size_t p = (size_t)blockIdx.x * TPB + threadIdx.x; p < n; p += (size_t)gridDim.x * TPB) {
+        u32 key = ks[p];
+        if (p == 0 || ks[p - 1] != key) starts[key] = (u32)p;
+    }
+}
+__global__ __launch_bounds__(TPB) void k_counter_ranks(const u32* __restrict__ ks, const u32* __restrict__ rs, size_t n,
+                                                       const u32* __restrict__ starts, u64* __restrict__ read_ts,
+                                                       u64* __restrict__ final_cts) {
+    for (size_t p = (size_t)blockIdx.x * TPB + threadIdx.x; p < n; p += (size_t)gridDim.x * TPB) {
+        u32 key = ks[p];
+        if (key >= 65536) continue;
+        u32 rank = (u32)p - starts[key];
+        read_ts[rs[p]] = rank;                                   // = number of earlier rows on the same address
+        if (p + 1 == n || ks[p + 1] != key) final_cts[key] = (u64)rank + 1;
+    }
+}
+size_t lasso_counter_temp_bytes(size_t n) {
+    size_t bytes = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, (u32*)nullptr, (u32*)nullptr, (u32*)nullptr, (u32*)nullptr, n, 0, 17);
+    return bytes;
+}
+void lasso_counters(hipStream_t st, const LassoDev& L, int m, const u64* dims, u64* read_ts, u64* final_cts, void* temp,
+                    size_t temp_bytes, u32* keys, u32* keys_sorted, u32* rows_in, u32* rows_sorted, u32* starts) {
+    const size_t N = (size_t)1 << L.nu;
+    int grid = grid_for(N) * 2;
+    k_counter_keys<<<grid, TPB, 0, st>>>(L, m, dims + (size_t)L.mem_dim[m] * N, keys, rows_in);
+    // stable LSD radix sort on the 17-bit key keeps rows of one address in row order
+    (void)rocprim::radix_sort_pairs(temp, temp_bytes, keys, keys_sorted, rows_in, rows_sorted, N, 0, 17, st);
+    (void)hipMemsetAsync(read_ts, 0, N * sizeof(u64), st);
+    (void)hipMemsetAsync(final_cts, 0, 65536 * sizeof(u64), st);
+    k_counter_starts<<<grid, TPB, 0, st>>>(keys_sorted, N, starts);
+    k_counter_ranks<<<grid, TPB, 0, st>>>(keys_sorted, rows_sorted, N, starts, read_ts, final_cts);
+}
+
+__global__ __launch_bounds__(TPB) void k_lasso_claim(LassoDev L, const E2* __restrict__ eq, const u64* __restrict__ e_polys,
+                                                     E2* __restrict__ partials) {
+    __shared__ E2 sm[TPB / 64];
+    const size_t N = (size_t)1 << L.nu;
+    E2 acc = e2_zero();
+    for (size_t k = (size_t)blockIdx.x * TPB + threadIdx.x; k < L.rows; k += (size_t)gridDim.x * TPB) {
+        int l = L.seg_lookup[k >> L.seg_shift];
+        u64 comb = 0;  // combine_lookups (range.rs:184-195): sum_i M^i * operand_i
+        for (int i = 0; i < L.lookup_nmems[l]; i++) comb = gl_add(comb, gl_mul(L.mpow[i], e_polys[(size_t)L.lookup_mems[l][i] * N + k]));
+        E2 e = eq[k];
+        acc = e2_add(acc, e2_mul_f(e, comb));
+    }
+    E2 s = block_sum(acc, sm);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+int lasso_claim(hipStream_t st, const LassoDev& L, const E2* eq, const u64* e_polys, E2* partials) {
+    int grid = grid_for(L.rows);
+    k_lasso_claim<<<grid, TPB, 0, st>>>(L, eq, e_polys, partials);
+    return grid;
+}
+
+__global__ __launch_bounds__(TPB) void k_hash_rw(size_t n, const u64* __restrict__ dim, const u64* __restrict__ ep,
+                                                 const u64* __restrict__ ts, u64 gamma, u64 gamma2, u64 tau,
+                                                 u64* __restrict__ rd, u64* __restrict__ wr) {
+    for (size_t j = (size_t)blockIdx.x * TPB + threadIdx.x; j < n; j += (size_t)gridDim.x * TPB) {
+        // h(a,v,t) = a + v*gamma + t*gamma^2 - tau   (prover.rs:44)
+        u64 h = gl_sub(gl_add(gl_add(dim[j], gl_mul(ep[j], gamma)), gl_mul(ts[j], gamma2)), tau);
+        rd[j] = h;
+        wr[j] = gl_add(h, gamma2);  // t + 1
+    }
+}
+void lasso_hash_rw(hipStream_t st, size_t n, const u64* dim, const u64* e_poly, const u64* read_ts, u64 gamma, u64 tau, u64* rd, u64* wr) {
+    k_hash_rw<<<grid_for(n) * 4, TPB, 0, st>>>(n, dim, e_poly, read_ts, gamma, gl_mul(gamma, gamma), tau, rd, wr);
+}
+__global__ __launch_bounds__(TPB) void k_hash_if(u32 cutoff, const u64* __restrict__ fc, u64 gamma, u64 gamma2, u64 tau,
+                                                 u64* __restrict__ init, u64* __restrict__ fin) {
+    u32 a = blockIdx.x * TPB + threadIdx.x;
+    if (a >= 65536) return;
+    u64 tv = a < cutoff ? (u64)a : 0;
+    u64 h0 = gl_sub(gl_add((u64)a, gl_mul(tv, gamma)), tau);
+    init[a] = h0;
+    fin[a] = gl_add(h0, gl_mul(gl_from_u64(fc[a]), gamma2));
+}
+void lasso_hash_if(hipStream_t st, u32 cutoff, const u64* final_cts, u64 gamma, u64 tau, u64* init, u64* fin) {
+    k_hash_if<<<65536 / TPB, TPB, 0, st>>>(cutoff, final_cts, gamma, gl_mul(gamma, gamma), tau, init, fin);
+}
+
+__global__ __launch_bounds__(TPB) void k_prod_level(const u64* __restrict__ in, size_t in_len, u64* __restrict__ out) {
+    const size_t h = in_len >> 1;
+    const u64* src = in + (size_t)blockIdx.y * in_len;
+    u64* dst = out + (size_t)blockIdx.y * h;
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < h; i += (size_t)gridDim.x * TPB) dst[i] = gl_mul(src[i], src[i + h]);
+}
+void prod_level(hipStream_t st, const u64* in, size_t in_len, u64* out, int nb) {
+    size_t h = in_len >> 1;
+    dim3 grid((unsigned)std::min<size_t>((h + TPB - 1) / TPB, 256), (unsigned)nb);
+    k_prod_level<<<grid, TPB, 0, st>>>(in, in_len, out);
+}
+__global__ void k_gp_top(const u64* __restrict__ top, int nb, E2* __restrict__ roots, E2* __restrict__ evals) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    u64 l = top[2 * b], r = top[2 * b + 1];
+    roots[b] = e2(gl_mul(l, r), 0);
+    evals[2 * b] = e2(l, 0);
+    evals[2 * b + 1] = e2(r, 0);
+}
+void gp_top(hipStream_t st, const u64* top, int nb, E2* roots, E2* evals) {
+    k_gp_top<<<(nb + 63) / 64, 64, 0, st>>>(top, nb, roots, evals);
+}
+
+struct DotTabs { const u64* t[8]; };
+__global__ __launch_bounds__(TPB) void k_dot_eq(const E2* __restrict__ eq, DotTabs tabs, int ntab, size_t n, E2* __restrict__ partials) {
+    __shared__ E2 sm[TPB / 64];
+    E2 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) acc[t] = e2_zero();
+    for (size_t j = (size_t)blockIdx.x * TPB + threadIdx.x; j < n; j += (size_t)gridDim.x * TPB) {
+        E2 e = eq[j];
+#pragma unroll
+        for (int t = 0; t < 8; t++)
+            if (t < ntab) {
+                u64 v = tabs.t[t][j];
+                acc[t] = e2_add(acc[t], e2_mul_f(e, v));
+            }
+    }
+#pragma unroll
+    for (int t = 0; t < 8; t++)
+        if (t < ntab) {
+            E2 s = block_sum(acc[t], sm);
+            if (threadIdx.x == 0) partials[(size_t)blockIdx.x * ntab + t] = s;
+        }
+}
+int dot_eq(hipStream_t st, const E2* eq, const u64* const tabs[8], int ntab, size_t n, E2* partials) {
+    DotTabs d;
+    for (int t = 0; t < 8; t++) d.t[t] = t < ntab ? tabs[t] : nullptr;
+    int grid = grid_for(n);
+    k_dot_eq<<<grid, TPB, 0, st>>>(eq, d, ntab, n, partials);
+    return grid;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Vanilla / FFT node bookkeeping
+__global__ __launch_bounds__(TPB) void k_gather_T(GatherT g, const E2* __restrict__ eqc, int log2_S, int log2_G, int log2_R,
+                                                  E2* __restrict__ T) {
+    const size_t total = (size_t)1 << (log2_S + log2_R);
+    const size_t smask = ((size_t)1 << log2_S) - 1;
+    for (size_t idx = (size_t)blockIdx.x * TPB + threadIdx.x; idx < total; idx += (size_t)gridDim.x * TPB) {
+        size_t x = idx & smask, rep = idx >> log2_S;
+        const E2* eq_rep = eqc + (rep << log2_G);
+        E2 acc = e2_zero();
+        if (g.lin.ptr) {
+            for (u32 e = g.lin.ptr[x]; e < g.lin.ptr[x + 1]; e++) {
+                E2 q = eq_rep[g.lin.gate[e]];
+                u64 c = g.lin.coef[e];
+                acc = e2_add(acc, c == 1 ? q : e2_mul_f(q, c));
+            }
+        }
+        if (g.mul.ptr) {
+            for (u32 e = g.mul.ptr[x]; e < g.mul.ptr[x + 1]; e++) {
+                E2 q = eq_rep[g.mul.gate[e]];
+                u64 other = g.in_vals[g.mul.other_in[e]][(rep << log2_S) + g.mul.other_j[e]];
+                u64 c = g.mul.coef[e];
+                acc = e2_add(acc, e2_mul_f(q, c == 1 ? other : gl_mul(c, other)));
+            }
+        }
+        store_e2(T + idx, acc);
+    }
+}
+void vanilla_gather_T(hipStream_t st, const GatherT& g, const E2* eqc, int log2_S, int log2_G, int log2_R, E2* T) {
+    size_t total = (size_t)1 << (log2_S + log2_R);
+    k_gather_T<<<grid_for(total) * 4, TPB, 0, st>>>(g, eqc, log2_S, log2_G, log2_R, T);
+}
+__global__ __launch_bounds__(TPB) void k_gather_B(CsrMul m, const E2* __restrict__ eqc, const E2* __restrict__ eqx,
+                                                  const E2* __restrict__ u, int log2_S, int log2_G, int log2_R, E2* __restrict__ B) {
+    const size_t total = (size_t)1 << (log2_S + log2_R);
+    const size_t smask = ((size_t)1 << log2_S) - 1;
+    for (size_t idx = (size_t)blockIdx.x * TPB + threadIdx.x; idx < total; idx += (size_t)gridDim.x * TPB) {
+        size_t y = idx & smask, rep = idx >> log2_S;
+        E2 acc = e2_zero();
+        for (u32 e = m.ptr[y]; e < m.ptr[y + 1]; e++) {
+            E2 q = eqc[(rep << log2_G) + m.gate[e]];
+            u64 c = m.coef[e];
+            if (c != 1) q = e2_mul_f(q, c);
+            q = e2_mul(q, eqx[(rep << log2_S) + m.other_j[e]]);
+            acc = e2_add(acc, e2_mul(q, u[m.other_in[e]]));
+        }
+        store_e2(B + idx, acc);
+    }
+}
+void vanilla_gather_B(hipStream_t st, const CsrMul& mulR, const E2* eqc, const E2* eqx, const E2* u, int log2_S, int log2_G, int log2_R, E2* B) {
+    size_t total = (size_t)1 << (log2_S + log2_R);
+    k_gather_B<<<grid_for(total) * 4, TPB, 0, st>>>(mulR, eqc, eqx, u, log2_S, log2_G, log2_R, B);
+}
+__global__ __launch_bounds__(TPB) void k_const_sum(const u32* __restrict__ gate, const u64* __restrict__ coef, size_t nterms,
+                                                   const E2* __restrict__ eqc, int log2_G, int log2_R, E2* __restrict__ partials) {
+    __shared__ E2 sm[TPB / 64];
+    const size_t total = nterms << log2_R;
+    E2 acc = e2_zero();
+    for (size_t idx = (size_t)blockIdx.x * TPB + threadIdx.x; idx < total; idx += (size_t)gridDim.x * TPB) {
+        size_t t = idx % nterms, rep = idx / nterms;
+        acc = e2_add(acc, e2_mul_f(eqc[(rep << log2_G) + gate[t]], coef[t]));
+    }
+    E2 s = block_sum(acc, sm);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+int vanilla_const_sum(hipStream_t st, const u32* gate, const u64* coef, size_t nterms, const E2* eqc, int log2_G, int log2_R, E2* partials) {
+    int grid = grid_for(nterms << log2_R);
+    k_const_sum<<<grid, TPB, 0, st>>>(gate, coef, nterms, eqc, log2_G, log2_R, partials);
+    return grid;
+}
+
+__global__ __launch_bounds__(TPB) void k_fft_table(E2* __restrict__ out, int L, const u64* __restrict__ W, u64 scale,
+                                                   const E2* __restrict__ chal, ClaimSet cs) {
+    const size_t N = (size_t)1 << L;
+    for (size_t x = (size_t)blockIdx.x * TPB + threadIdx.x; x < N; x += (size_t)gridDim.x * TPB) {
+        E2 acc = e2_zero();
+        for (int a = 0; a < cs.n; a++) {
+            const E2* r = chal + cs.point_off[a];
+            E2 p = e2(scale, 0);
+            for (int b = 0; b < L; b++) {
+                u64 wx = W[(x << b) & (N - 1)];
+                E2 f = e2_add_f(e2_mul_f(r[b], gl_sub(wx, 1)), 1);  // 1 - r_b + r_b w^(2^b x)
+                p = e2_mul(p, f);
+            }
+            acc = e2_add(acc, cs.unit_alpha ? p : e2_mul(chal[cs.alpha_off + a], p));
+        }
+        store_e2(out + x, acc);
+    }
+}
+void fft_table(hipStream_t st, E2* out, int L, const u64* W, u64 scale, const E2* chal, const ClaimSet& cs) {
+    size_t N = (size_t)1 << L;
+    k_fft_table<<<(unsigned)((N + TPB - 1) / TPB), TPB, 0, st>>>(out, L, W, scale, chal, cs);
+}
+__global__ void k_powers_table(u64* __restrict__ W, u64 w, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 r = 1, b = w;
+    for (size_t e = i; e; e >>= 1) { if (e & 1) r = gl_mul(r, b); b = gl_mul(b, b); }
+    W[i] = r;
+}
+void powers_table(hipStream_t st, u64* W, u64 w, size_t n) {
+    k_powers_table<<<(unsigned)((n + TPB - 1) / TPB), TPB, 0, st>>>(W, w, n);
+}
+
+// ------------------------------------------------------------------------------------------------
+// NTT: decimation-in-frequency stages in HBM, then bit reversal (+ scaling for the inverse)
+__global__ __launch_bounds__(TPB) void k_ntt_stage(u64* __restrict__ data, int log2n, int s, size_t batch, const u64* __restrict__ W) {
+    const size_t halfN = (size_t)1 << (log2n - 1);
+    const size_t total = batch * halfN;
+    const size_t h = (size_t)1 << s;
+    for (size_t idx = (size_t)blockIdx.x * TPB + threadIdx.x; idx < total; idx += (size_t)gridDim.x * TPB) {
+        size_t bi = idx >> (log2n - 1), k = idx & (halfN - 1);
+        size_t j = k & (h - 1), base = (k >> s) << (s + 1);
+        u64* a = data + (bi << log2n) + base + j;
+        u64 x = a[0], y = a[h];
+        a[0] = gl_add(x, y);
+        a[h] = gl_mul(gl_sub(x, y), W[j << (log2n - 1 - s)]);
+    }
+}
+__global__ __launch_bounds__(TPB) void k_ntt_bitrev(u64* __restrict__ data, int log2n, size_t batch, u64 scale) {
+    const size_t N = (size_t)1 << log2n;
+    const size_t total = batch * N;
+    for (size_t idx = (size_t)blockIdx.x * TPB + threadIdx.x; idx < total; idx += (size_t)gridDim.x * TPB) {
+        size_t bi = idx >> log2n, i = idx & (N - 1);
+        size_t r = (size_t)(__brevll((unsigned long long)i) >> (64 - log2n));
+        u64* a = data + (bi << log2n);
+        if (r > i) {
+            u64 x = a[i], y = a[r];
+            if (scale != 1) { x = gl_mul(x, scale); y = gl_mul(y, scale); }
+            a[i] = y; a[r] = x;
+        } else if (r == i && scale != 1) {
+            a[i] = gl_mul(a[i], scale);
+        }
+    }
+}
+void ntt_batch(hipStream_t st, u64* data, int log2n, size_t batch, const u64* W, u64 scale) {
+    size_t total = batch << (log2n - 1);
+    int grid = (int)std::min<size_t>((total + TPB - 1) / TPB, 4096);
+    for (int s = log2n - 1; s >= 0; s--) k_ntt_stage<<<grid, TPB, 0, st>>>(data, log2n, s, batch, W);
+    k_ntt_bitrev<<<grid * 2, TPB, 0, st>>>(data, log2n, batch, scale);
+}
+
+}  // namespace dev
+}  // namespace hg

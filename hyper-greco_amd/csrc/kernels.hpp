@@ -1,0 +1,101 @@
+// Launch wrappers of the gfx950 kernels (definitions in kernels.hip). All pointers are device
+// pointers; every launch goes to the given stream; nothing here synchronises.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "gl.cuh"
+
+namespace hg {
+namespace dev {
+
+constexpr int SC_MAX_BLOCKS = 1024;  // fixed partial-sum fan-in of the round kernels
+constexpr int PS_MAX_PAIRS = 32;     // max (input, bookkeeping) table pairs of one PRODSUM sum-check
+constexpr int PW_MAX = 64;           // max batched products / memories carried in kernarg powers
+
+struct Powers { E2 v[PW_MAX]; };     // by-value kernarg: gamma^i (grand product) or M^i (collation)
+// by-value kernarg: the output claims of one node. Points and alphas are runs of the (device-resident)
+// challenge chain, so a claim set is just offsets into it.
+constexpr int MAX_CLAIMS = 32;
+struct ClaimSet {
+    int n;                       // number of claims
+    int unit_alpha;              // n == 1: alpha = 1 (nothing squeezed)
+    size_t alpha_off;            // chain index (E units) of alpha_0
+    size_t point_off[MAX_CLAIMS];  // chain index of each point's coordinate 0
+};
+
+enum ScKind { SC_COLLATION = 0, SC_GRANDPROD = 1 };
+
+// One round of a stride-layout sum-check: table t lives at in + t*in_stride (u64 if base else E2).
+// Accumulates the true hypercube sums of g at t = 0,2[,3] into partials[block][nv] AND writes the
+// table folded at `r` to out + t*out_stride (E2). Returns the number of blocks used.
+int sc_round(hipStream_t st, int kind, bool base, const void* in, size_t in_stride, E2* out, size_t out_stride,
+             int ntab, size_t half, E2 r, const Powers& pw, E2* partials);
+
+struct PsTables {
+    const void* a[PS_MAX_PAIRS];  // u64* (round 0) or E2*
+    const E2* b[PS_MAX_PAIRS];
+    E2* oa[PS_MAX_PAIRS];
+    E2* ob[PS_MAX_PAIRS];
+    int npairs;
+};
+int sc_round_prodsum(hipStream_t st, bool a_base, const PsTables& t, size_t half, E2 r, E2* partials);
+
+// out[v] = sum_b partials[b*nv + v], v < nv
+void reduce_partials(hipStream_t st, const E2* partials, int nblocks, int nv, E2* out);
+
+// eq(r, .) over n variables (little-endian); multi-point form: out = sum_a alpha[a] * eq(points[a], .)
+void eq_table(hipStream_t st, E2* out, int n, const E2* chal, size_t point_off);
+void eq_combined(hipStream_t st, E2* out, int n, const E2* chal, const ClaimSet& cs);
+
+// ---- Lasso ------------------------------------------------------------------------------------
+struct LassoDev {
+    int nu, alpha, num_lookups, seg_shift;
+    size_t rows;
+    const uint8_t* seg_lookup;   // device
+    u64 lookup_mask[32];         // per lookup: (1 << total_bits) - 1
+    u64 lookup_uses[32];         // per lookup: bitmask of memories
+    int mem_dim[32];
+    u32 mem_cutoff[32];
+    u64 mpow[5];                 // M^i
+    int lookup_nmems[32];
+    int lookup_mems[32][4];
+};
+// dims[c][j] (4 x 2^nu) and E[m][j] (alpha x 2^nu), zero beyond `rows`
+void lasso_split(hipStream_t st, const LassoDev& L, const u64* input, u64* dims, u64* e_polys);
+// read/final counters of memory m (sequential-scan semantics of lasso.rs:181-196) via a stable sort
+size_t lasso_counter_temp_bytes(size_t n);
+void lasso_counters(hipStream_t st, const LassoDev& L, int m, const u64* dims, u64* read_ts, u64* final_cts,
+                    void* temp, size_t temp_bytes, u32* keys, u32* keys_sorted, u32* rows_in, u32* rows_sorted, u32* starts);
+// sum_k eq[k] * sum_i M^i E_{mems(lookup(k))[i]}[k]  -> partials (nv = 1)
+int lasso_claim(hipStream_t st, const LassoDev& L, const E2* eq, const u64* e_polys, E2* partials);
+// multiset hashes h = a + v*gamma + t*gamma^2 - tau
+void lasso_hash_rw(hipStream_t st, size_t n, const u64* dim, const u64* e_poly, const u64* read_ts, u64 gamma, u64 tau, u64* rd, u64* wr);
+void lasso_hash_if(hipStream_t st, u32 cutoff, const u64* final_cts, u64 gamma, u64 tau, u64* init, u64* fin);
+// product tree level: out[b][i] = in[b][i] * in[b][i + h], b < nb, i < h
+void prod_level(hipStream_t st, const u64* in, size_t in_len, u64* out, int nb);
+// gathers: roots[b] = top[b][0]*top[b][1] (as E2) ; evals[2b+s] = top[b][s]
+void gp_top(hipStream_t st, const u64* top, int nb, E2* roots, E2* evals);
+// dot products with an eq table: out_partials for ntab base tables (stride layout); nv = ntab (<= 8 per call)
+int dot_eq(hipStream_t st, const E2* eq, const u64* const tabs[8], int ntab, size_t n, E2* partials);
+
+// ---- Vanilla / FFT nodes ----------------------------------------------------------------------
+struct CsrLin { const u32* ptr; const u32* gate; const u64* coef; };           // per input position -> (gate, c)
+struct CsrMul { const u32* ptr; const u32* gate; const u64* coef; const u32* other_in; const u32* other_j; };
+// T[rep*S + x] = sum_lin eqc[rep*G+gate]*c + sum_mul eqc[rep*G+gate]*c*in_other[rep*S + j1]
+struct GatherT {
+    CsrLin lin; CsrMul mul;     // ptr == nullptr when absent
+    const u64* in_vals[PS_MAX_PAIRS];  // node input tables (for the mul part)
+};
+void vanilla_gather_T(hipStream_t st, const GatherT& g, const E2* eqc, int log2_S, int log2_G, int log2_R, E2* T);
+// B[rep*S + y] = sum_mulR eqc[rep*G+gate]*c*eqx[rep*S + j0]*u[i0]
+void vanilla_gather_B(hipStream_t st, const CsrMul& mulR, const E2* eqc, const E2* eqx, const E2* u, int log2_S, int log2_G, int log2_R, E2* B);
+// sum over reps and constant gates of eqc[rep*G+gate]*c -> partials (nv = 1)
+int vanilla_const_sum(hipStream_t st, const u32* gate, const u64* coef, size_t nterms, const E2* eqc, int log2_G, int log2_R, E2* partials);
+// F_c(x) = sum_a alpha_a * scale * prod_b (1 + r_{a,b} (W[(x<<b) & (N-1)] - 1))
+void fft_table(hipStream_t st, E2* out, int L, const u64* W, u64 scale, const E2* chal, const ClaimSet& cs);
+void powers_table(hipStream_t st, u64* W, u64 w, size_t n);  // W[i] = w^i
+
+// ---- NTT (witness generation / hg_ntt) ----------------------------------------------------------
+void ntt_batch(hipStream_t st, u64* data, int log2n, size_t batch, const u64* W /* w^i, i < N/2 */, u64 scale);
+
+}  // namespace dev
+}  // namespace hg

@@ -1,0 +1,755 @@
+#include "prover.hpp"
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+
+namespace hg {
+
+void hip_check(hipError_t e, const char* what) {
+    if (e != hipSuccess) throw Error(std::string(what) + ": " + hipGetErrorString(e));
+}
+static double wall_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace hg
+
+using namespace hg;
+
+// ------------------------------------------------------------------------------------------------
+// context
+void* hg_ctx::alloc(size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (bytes == 0) bytes = 256;
+    for (auto& c : chunks)
+        if (c.cap - c.used >= bytes) { void* p = c.p + c.used; c.used += bytes; return p; }
+    size_t cap = std::max<size_t>(bytes, (size_t)512 << 20);
+    char* p = nullptr;
+    hip_check(hipMalloc((void**)&p, cap), "hipMalloc(arena chunk)");
+    chunks.push_back({p, cap, bytes});
+    arena_total += cap;
+    return p;
+}
+void hg_ctx::arena_reset() {
+    // coalesce into one chunk once the high-water mark is known, so later proves never call hipMalloc
+    size_t used = 0;
+    for (auto& c : chunks) used += c.used;
+    if (chunks.size() > 1) {
+        hip_check(hipStreamSynchronize(stream), "sync before arena coalesce");
+        for (auto& c : chunks) (void)hipFree(c.p);
+        chunks.clear();
+        size_t cap = used + used / 8 + ((size_t)64 << 20);
+        char* p = nullptr;
+        hip_check(hipMalloc((void**)&p, cap), "hipMalloc(arena)");
+        chunks.push_back({p, cap, 0});
+        arena_total = cap;
+    }
+    for (auto& c : chunks) c.used = 0;
+}
+void hg_ctx::ensure_chain(size_t n_e) {
+    if (n_e <= chal_e) return;
+    size_t want = std::max<size_t>(n_e, chal_e ? chal_e * 2 : 16384);
+    const u64* host = challenge_chain(2 * want);
+    hip_check(hipStreamSynchronize(stream), "sync before chain growth");
+    if (d_chal) (void)hipFree(d_chal);
+    hip_check(hipMalloc((void**)&d_chal, want * sizeof(E2)), "hipMalloc(chain)");
+    hip_check(hipMemcpy(d_chal, host, want * sizeof(E2), hipMemcpyHostToDevice), "upload chain");
+    chal_e = want;
+}
+int hg_ctx::prof_class(const char* name, bool dominant) {
+    for (size_t i = 0; i < prof_stats.size(); i++) if (prof_stats[i].name == name) return (int)i;
+    ProfStat s; s.name = name; s.dominant = dominant;
+    prof_stats.push_back(s);
+    return (int)prof_stats.size() - 1;
+}
+void hg_ctx::prof_begin(int cls, double bytes) {
+    cur_cls = -1;
+    if (prof_level == 0) return;
+    if (prof_level == 1 && !prof_stats[cls].dominant) return;
+    hipEvent_t a, b;
+    auto get = [&]() { if (!event_pool.empty()) { hipEvent_t e = event_pool.back(); event_pool.pop_back(); return e; } hipEvent_t e; (void)hipEventCreate(&e); return e; };
+    a = get(); b = get();
+    (void)hipEventRecord(a, stream);
+    cur_cls = cls; cur_a = a;
+    prof_events.push_back({cls, a, b});
+    prof_stats[cls].launches++;
+    prof_stats[cls].bytes += bytes;
+}
+void hg_ctx::prof_end() {
+    if (cur_cls < 0) return;
+    (void)hipEventRecord(prof_events.back().b, stream);
+    cur_cls = -1;
+}
+void hg_ctx::prof_collect() {
+    for (auto& e : prof_events) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) prof_stats[e.cls].ms += ms;
+        event_pool.push_back(e.a); event_pool.push_back(e.b);
+    }
+    prof_events.clear();
+}
+hg_ctx::~hg_ctx() {
+    if (stream) (void)hipStreamSynchronize(stream);
+    for (auto& c : chunks) (void)hipFree(c.p);
+    if (d_chal) (void)hipFree(d_chal);
+    if (d_res) (void)hipFree(d_res);
+    if (h_res) (void)hipHostFree(h_res);
+    if (d_partials) (void)hipFree(d_partials);
+    for (auto e : event_pool) (void)hipEventDestroy(e);
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+namespace hg {
+
+// ------------------------------------------------------------------------------------------------
+// host-side scalar glue (round-polynomial interpolation, Horner)
+static const u64 INV2 = gl_inv(2), INV3 = gl_inv(3), INV6 = gl_inv(6);
+
+// coefficients (low -> high) of the degree-d polynomial through (0,e0) (1,e1) .. (d,ed), d in {2,3}
+static void interpolate(const E2* ev, int d, E2* c) {
+    E2 d1 = e2_sub(ev[1], ev[0]);
+    E2 d2 = e2_add(e2_sub(ev[2], e2_dbl(ev[1])), ev[0]);  // second finite difference
+    if (d == 2) {
+        c[0] = ev[0];
+        c[2] = e2_mul_f(d2, INV2);
+        c[1] = e2_sub(d1, c[2]);
+        return;
+    }
+    // third finite difference e3 - 3 e2 + 3 e1 - e0
+    E2 d3 = e2_sub(e2_sub(ev[3], ev[0]), e2_mul_f(e2_sub(ev[2], ev[1]), 3));
+    c[0] = ev[0];
+    c[3] = e2_mul_f(d3, INV6);
+    c[2] = e2_mul_f(e2_sub(d2, d3), INV2);
+    c[1] = e2_add(e2_sub(d1, e2_mul_f(d2, INV2)), e2_mul_f(d3, INV3));
+}
+static E2 horner(const E2* c, int d, E2 x) {
+    E2 r = c[d];
+    for (int i = d - 1; i >= 0; i--) r = e2_add(e2_mul(r, x), c[i]);
+    return r;
+}
+
+typedef std::shared_ptr<E2> Cell;
+static Cell cell(E2 v = e2_zero()) { return std::make_shared<E2>(v); }
+
+struct ClaimRef {  // an evaluation claim whose point is a run of the challenge chain
+    size_t point_off;
+    int len;
+    Cell value;
+};
+
+struct ScHandle {
+    size_t sums_slot = 0;
+    int nv = 2;  // sums per round: t = 0,2[,3]
+    int nvars = 0;
+    size_t point_off = 0;
+    std::vector<E2> rs;
+};
+
+struct Prover {
+    hg_ctx* ctx;
+    const hg_pk* pk;
+    hipStream_t st;
+    ChallengeSource ch;
+    ProofStream proof;
+    std::vector<std::function<void()>> ops;  // transcript steps, replayed after the single synchronisation
+    size_t res_used = 0;
+    int cls_gp_base, cls_gp_ext, cls_col_base, cls_col_ext, cls_ps, cls_reduce, cls_aux, cls_tree, cls_hash, cls_gather;
+
+    Prover(hg_ctx* c, const hg_pk* k) : ctx(c), pk(k), st(c->stream) {
+        cls_gp_ext = ctx->prof_class("sc_round<grand_product,ext>", true);
+        cls_gp_base = ctx->prof_class("sc_round<grand_product,base>", false);
+        cls_col_base = ctx->prof_class("sc_round<collation,base>", false);
+        cls_col_ext = ctx->prof_class("sc_round<collation,ext>", false);
+        cls_ps = ctx->prof_class("sc_round<prodsum>", false);
+        cls_reduce = ctx->prof_class("reduce_partials", false);
+        cls_tree = ctx->prof_class("prod_level", false);
+        cls_hash = ctx->prof_class("lasso_hash", false);
+        cls_gather = ctx->prof_class("vanilla_gather", false);
+        cls_aux = ctx->prof_class("aux", false);
+        ctx->ensure_chain(16384);
+    }
+    E2* d_res() { return ctx->d_res; }
+    const E2* h_res() { return ctx->h_res; }
+    size_t slot(size_t n) {
+        if (res_used + n > ctx->res_cap) throw Error("result buffer exhausted");
+        size_t s = res_used;
+        res_used += n;
+        return s;
+    }
+    size_t epos() const { return ch.pos / 2; }
+    E2 squeeze() {
+        E2 r = ch.squeeze();
+        if (ch.pos / 2 > ctx->chal_e) throw Error("challenge chain in HBM too short");
+        return r;
+    }
+    void reduce(int grid, int nv, size_t out_slot) {
+        ctx->prof_begin(cls_reduce, 0);
+        dev::reduce_partials(st, ctx->d_partials, grid, nv, d_res() + out_slot);
+        ctx->prof_end();
+    }
+
+    // ---- sum-check drivers ---------------------------------------------------------------------
+    ScHandle sc_stride(int kind, const void* in, bool base, size_t in_stride, int ntab, int nvars, const dev::Powers& pw, E2* final_out) {
+        ScHandle h;
+        h.nv = kind == dev::SC_GRANDPROD ? 3 : 2;
+        h.nvars = nvars;
+        h.point_off = epos();
+        h.sums_slot = slot((size_t)nvars * h.nv);
+        const size_t N = (size_t)1 << nvars;
+        E2* buf[2] = {ctx->alloc_n<E2>((size_t)ntab * std::max<size_t>(N / 2, 1)), ctx->alloc_n<E2>((size_t)ntab * std::max<size_t>(N / 4, 1))};
+        if (!final_out) final_out = ctx->alloc_n<E2>(ntab);
+        for (int i = 0; i < nvars; i++) {
+            size_t half = N >> (i + 1);
+            E2 r = squeeze();
+            E2* out = i == nvars - 1 ? final_out : buf[i & 1];
+            int cls = kind == dev::SC_GRANDPROD ? (base ? cls_gp_base : cls_gp_ext) : (base ? cls_col_base : cls_col_ext);
+            ctx->prof_begin(cls, (double)ntab * (2.0 * half * (base ? 8 : 16) + half * 16.0));
+            int grid = dev::sc_round(st, kind, base, in, in_stride, out, half, ntab, half, r, pw, ctx->d_partials);
+            ctx->prof_end();
+            reduce(grid, h.nv, h.sums_slot + (size_t)i * h.nv);
+            in = out; in_stride = half; base = false;
+            h.rs.push_back(r);
+        }
+        return h;
+    }
+    ScHandle sc_prodsum(const std::vector<const u64*>& a, const std::vector<const E2*>& b, int nvars,
+                        const std::vector<E2*>& fin_a, const std::vector<E2*>& fin_b) {
+        ScHandle h;
+        h.nv = 2;
+        h.nvars = nvars;
+        h.point_off = epos();
+        h.sums_slot = slot((size_t)nvars * 2);
+        const int np = (int)a.size();
+        if (np > dev::PS_MAX_PAIRS) throw Error("prodsum: too many table pairs");
+        const size_t N = (size_t)1 << nvars;
+        E2* bufa[2] = {ctx->alloc_n<E2>((size_t)np * std::max<size_t>(N / 2, 1)), ctx->alloc_n<E2>((size_t)np * std::max<size_t>(N / 4, 1))};
+        E2* bufb[2] = {ctx->alloc_n<E2>((size_t)np * std::max<size_t>(N / 2, 1)), ctx->alloc_n<E2>((size_t)np * std::max<size_t>(N / 4, 1))};
+        dev::PsTables t;
+        memset(&t, 0, sizeof(t));
+        t.npairs = np;
+        for (int i = 0; i < np; i++) { t.a[i] = a[i]; t.b[i] = b[i]; }
+        bool a_base = true;
+        for (int r_i = 0; r_i < nvars; r_i++) {
+            size_t half = N >> (r_i + 1);
+            E2 r = squeeze();
+            for (int i = 0; i < np; i++) {
+                if (r_i == nvars - 1) { t.oa[i] = fin_a[i]; t.ob[i] = fin_b[i]; }
+                else { t.oa[i] = bufa[r_i & 1] + (size_t)i * half; t.ob[i] = bufb[r_i & 1] + (size_t)i * half; }
+            }
+            ctx->prof_begin(cls_ps, (double)np * (2.0 * half * ((a_base ? 8 : 16) + 16) + half * 32.0));
+            int grid = dev::sc_round_prodsum(st, a_base, t, half, r, ctx->d_partials);
+            ctx->prof_end();
+            reduce(grid, 2, h.sums_slot + (size_t)r_i * 2);
+            for (int i = 0; i < np; i++) { t.a[i] = t.oa[i]; t.b[i] = t.ob[i]; }
+            a_base = false;
+            h.rs.push_back(r);
+        }
+        return h;
+    }
+    // transcript side of prove_sum_check: d+1 coefficients per round, eval(1) derived from the running claim
+    void defer_sumcheck(const ScHandle& h, int deg, Cell claim_in, Cell claim_out) {
+        ops.push_back([this, h, deg, claim_in, claim_out] {
+            E2 claim = *claim_in;
+            for (int i = 0; i < h.nvars; i++) {
+                const E2* s = h_res() + h.sums_slot + (size_t)i * h.nv;
+                E2 ev[4], c[4];
+                ev[0] = s[0];
+                ev[1] = e2_sub(claim, s[0]);
+                ev[2] = s[1];
+                if (deg == 3) ev[3] = s[2];
+                interpolate(ev, deg, c);
+                for (int k = 0; k <= deg; k++) proof.write_e(c[k]);
+                claim = horner(c, deg, h.rs[i]);
+            }
+            if (claim_out) *claim_out = claim;
+        });
+    }
+    void defer_write_slots(size_t s, size_t n) {
+        ops.push_back([this, s, n] { for (size_t i = 0; i < n; i++) proof.write_e(h_res()[s + i]); });
+    }
+
+    // ---- Lasso node (lasso.rs:57-114) ------------------------------------------------------------
+    struct GpOut { size_t point_off; };
+    // prove_grand_product (prover.rs:183-266) over nb contiguous tables of `len` base-field values
+    GpOut grand_product(const u64* H, size_t len, int nb) {
+        int nv = 0;
+        while (((size_t)1 << nv) < len) nv++;
+        std::vector<const u64*> lev(nv);
+        lev[0] = H;
+        for (int k = 1; k < nv; k++) {  // Layer::bottom / Layer::up: w = v_l * v_r on the MSB split
+            u64* out = ctx->alloc_n<u64>((size_t)nb * (len >> k));
+            ctx->prof_begin(cls_tree, (double)nb * (len >> (k - 1)) * 8.0 * 1.5);
+            dev::prod_level(st, lev[k - 1], len >> (k - 1), out, nb);
+            ctx->prof_end();
+            lev[k] = out;
+        }
+        size_t roots = slot(nb), ev0 = slot(2 * (size_t)nb);
+        dev::gp_top(st, lev[nv - 1], nb, d_res() + roots, d_res() + ev0);
+        auto claims = std::make_shared<std::vector<E2>>(nb);
+        ops.push_back([this, roots, nb, claims] {  // root products (prover.rs:197-221)
+            for (int b = 0; b < nb; b++) { (*claims)[b] = h_res()[roots + b]; proof.write_e((*claims)[b]); }
+        });
+        auto layer_down = [this, claims, nb](size_t evals_slot, E2 mu) {  // prover.rs:288-294
+            ops.push_back([this, claims, nb, evals_slot, mu] {
+                const E2* ev = h_res() + evals_slot;
+                for (int b = 0; b < nb; b++) (*claims)[b] = e2_add(ev[2 * b], e2_mul(mu, e2_sub(ev[2 * b + 1], ev[2 * b])));
+            });
+        };
+        GpOut out{0};
+        // layer with num_vars 0
+        defer_write_slots(ev0, 2 * (size_t)nb);
+        out.point_off = epos();
+        layer_down(ev0, squeeze());
+        for (int n = 1; n < nv; n++) {
+            int k = nv - 1 - n;
+            size_t h = (size_t)1 << n;
+            E2 gamma = squeeze();  // prover.rs:238
+            dev::Powers pw;
+            memset(&pw, 0, sizeof(pw));
+            if (nb > dev::PW_MAX) throw Error("grand product: too many batched tables");
+            E2 g = e2_one();
+            for (int b = 0; b < nb; b++) { pw.v[b] = g; g = e2_mul(g, gamma); }
+            Cell claim = cell();
+            ops.push_back([claims, nb, pw, claim] {  // sum_check_claim (prover.rs:281-286)
+                E2 c = e2_zero();
+                for (int b = 0; b < nb; b++) c = e2_add(c, e2_mul((*claims)[b], pw.v[b]));
+                *claim = c;
+            });
+            size_t evals = slot(2 * (size_t)nb);
+            ScHandle sc = sc_stride(dev::SC_GRANDPROD, lev[k], true, h, 2 * nb, n, pw, d_res() + evals);
+            defer_sumcheck(sc, 3, claim, nullptr);
+            defer_write_slots(evals, 2 * (size_t)nb);  // prover.rs:257
+            out.point_off = sc.point_off;
+            layer_down(evals, squeeze());              // mu (prover.rs:259)
+        }
+        return out;
+    }
+
+    ClaimRef lasso_node(const u64* d_input) {
+        const LassoPlan& lp = pk->lasso;
+        const dev::LassoDev& L = pk->lasso_dev;
+        const int nu = lp.nu, A = lp.alpha;
+        const size_t N = (size_t)1 << nu, M = 65536;
+        // polynomialize (lasso.rs:157-250)
+        u64* dims = ctx->alloc_n<u64>(4 * N);
+        u64* ep = ctx->alloc_n<u64>((size_t)A * N);
+        ctx->prof_begin(cls_aux, (double)N * 8 * (1 + 4 + A));
+        dev::lasso_split(st, L, d_input, dims, ep);
+        ctx->prof_end();
+        // r, claimed sum (lasso.rs:85, 264-269)
+        size_t r_off = epos();
+        for (int i = 0; i < nu; i++) squeeze();
+        E2* eq = ctx->alloc_n<E2>(N);
+        dev::eq_table(st, eq, nu, ctx->d_chal, r_off);
+        size_t claim_slot = slot(1);
+        int grid = dev::lasso_claim(st, L, eq, ep, ctx->d_partials);
+        reduce(grid, 1, claim_slot);
+        Cell claimed = cell();
+        ops.push_back([this, claim_slot, claimed] { *claimed = h_res()[claim_slot]; proof.write_e(*claimed); });
+        {   // collation sum-check (lasso.rs:271-279): g = poly(0) * sum_i M^i poly(i)
+            dev::Powers pw;
+            memset(&pw, 0, sizeof(pw));
+            if (A > dev::PW_MAX) throw Error("lasso: too many memories");
+            u64 c = 1;
+            for (int i = 0; i < A; i++) { pw.v[i] = e2(c, 0); c = gl_mul(c, M); }
+            ScHandle sc = sc_stride(dev::SC_COLLATION, ep, true, N, A, nu, pw, nullptr);
+            defer_sumcheck(sc, 2, claimed, nullptr);
+        }
+        E2 gamma_e = squeeze(), tau_e = squeeze();  // lasso.rs:99
+        u64 gamma = gamma_e.c0, tau = tau_e.c0;     // prover.rs:38-39: base limb 0 only
+        // counters: only the memories whose index equals a chunk (dimension) index reach the transcript
+        // (lasso.rs:317-319 indexes read_ts/final_cts by chunk index)
+        std::map<int, u64*> read_ts, final_cts;
+        {
+            size_t tb = dev::lasso_counter_temp_bytes(N);
+            void* temp = ctx->alloc(tb);
+            u32* keys = ctx->alloc_n<u32>(N); u32* keys2 = ctx->alloc_n<u32>(N);
+            u32* rows = ctx->alloc_n<u32>(N); u32* rows2 = ctx->alloc_n<u32>(N);
+            u32* starts = ctx->alloc_n<u32>(65537);
+            for (auto& chk : lp.chunks) {
+                int c = chk.first;
+                read_ts[c] = ctx->alloc_n<u64>(N);
+                final_cts[c] = ctx->alloc_n<u64>(M);
+                ctx->prof_begin(cls_aux, (double)N * 40);
+                dev::lasso_counters(st, L, c, dims, read_ts[c], final_cts[c], temp, tb, keys, keys2, rows, rows2, starts);
+                ctx->prof_end();
+            }
+        }
+        // MemoryCheckingProver::new (prover.rs:35-89)
+        const int G = (int)lp.gkr_order.size();
+        u64* H1 = ctx->alloc_n<u64>((size_t)2 * G * N);
+        u64* H2 = ctx->alloc_n<u64>((size_t)2 * G * M);
+        for (int i = 0; i < G; i++) {
+            int m = lp.gkr_order[i], c = lp.gkr_chunk[i];
+            ctx->prof_begin(cls_hash, (double)N * 8 * 5);
+            dev::lasso_hash_rw(st, N, dims + (size_t)c * N, ep + (size_t)m * N, read_ts[c], gamma, tau, H1 + (size_t)i * N, H1 + (size_t)(G + i) * N);
+            ctx->prof_end();
+            dev::lasso_hash_if(st, (u32)lp.mems[m].cutoff, final_cts[c], gamma, tau, H2 + (size_t)i * M, H2 + (size_t)(G + i) * M);
+        }
+        GpOut g1 = grand_product(H1, N, 2 * G);  // reads then writes (prover.rs:161-165)
+        GpOut g2 = grand_product(H2, M, 2 * G);  // inits then finals (prover.rs:167-171)
+        // openings (prover.rs:173-178, mod.rs:80-93)
+        E2* eqx = eq;  // the eq(r,.) table is dead by now
+        dev::eq_table(st, eqx, nu, ctx->d_chal, g1.point_off);
+        E2* eqy = ctx->alloc_n<E2>(M);
+        dev::eq_table(st, eqy, 16, ctx->d_chal, g2.point_off);
+        for (auto& chk : lp.chunks) {
+            int c = chk.first;
+            std::vector<const u64*> xs = {dims + (size_t)c * N, read_ts[c]};
+            for (int m : chk.second) xs.push_back(ep + (size_t)m * N);
+            size_t base_slot = slot(3 + chk.second.size());
+            // order on the wire: dim(x), read_ts(x), final_cts(y), then E_m(x)
+            std::vector<size_t> dst = {base_slot, base_slot + 1};
+            for (size_t i = 0; i < chk.second.size(); i++) dst.push_back(base_slot + 3 + i);
+            for (size_t o = 0; o < xs.size(); o += 8) {
+                int cnt = (int)std::min<size_t>(8, xs.size() - o);
+                const u64* tabs[8] = {nullptr};
+                for (int t = 0; t < cnt; t++) tabs[t] = xs[o + t];
+                size_t tmp = slot(cnt);
+                ctx->prof_begin(cls_aux, (double)N * (16 + 8.0 * cnt));
+                int grid2 = dev::dot_eq(st, eqx, tabs, cnt, N, ctx->d_partials);
+                ctx->prof_end();
+                reduce(grid2, cnt, tmp);
+                for (int t = 0; t < cnt; t++) {
+                    size_t from = tmp + t, to = dst[o + t];
+                    ops.push_back([this, from, to] { ctx->h_res[to] = ctx->h_res[from]; });
+                }
+            }
+            {
+                const u64* tabs[8] = {final_cts[c]};
+                int grid2 = dev::dot_eq(st, eqy, tabs, 1, M, ctx->d_partials);
+                reduce(grid2, 1, base_slot + 2);
+            }
+            defer_write_slots(base_slot, 3 + chk.second.size());
+        }
+        return ClaimRef{r_off, nu, claimed};  // (r, claimed_sum) for the single predecessor (lasso.rs:97,113)
+    }
+
+    // ---- GKR driver ----------------------------------------------------------------------------
+    std::vector<const u64*> d_vals;               // node values in HBM
+    std::vector<std::vector<ClaimRef>> claims;    // per node
+
+    dev::ClaimSet claim_set(const std::vector<ClaimRef>& cl, std::vector<E2>* alphas_host) {
+        dev::ClaimSet cs;
+        memset(&cs, 0, sizeof(cs));
+        if (cl.empty()) throw Error("gkr: node without claim");
+        if (cl.size() > (size_t)dev::MAX_CLAIMS) throw Error("gkr: too many claims on one node");
+        cs.n = (int)cl.size();
+        cs.unit_alpha = cl.size() == 1;
+        cs.alpha_off = epos();
+        alphas_host->clear();
+        if (cl.size() > 1) for (size_t a = 0; a < cl.size(); a++) alphas_host->push_back(squeeze());
+        else alphas_host->push_back(e2_one());
+        for (size_t a = 0; a < cl.size(); a++) cs.point_off[a] = cl[a].point_off;
+        return cs;
+    }
+    Cell combined_value(const std::vector<ClaimRef>& cl, const std::vector<E2>& alphas) {
+        Cell v = cell();
+        std::vector<Cell> vals;
+        for (auto& c : cl) vals.push_back(c.value);
+        ops.push_back([v, vals, alphas] {
+            E2 s = e2_zero();
+            for (size_t a = 0; a < vals.size(); a++) s = e2_add(s, e2_mul(*vals[a], alphas[a]));
+            *v = s;
+        });
+        return v;
+    }
+
+    void vanilla_node(int id) {
+        const HNode& n = pk->circuit.nodes[id];
+        const hg_pk::NodeDev& nd = pk->node_dev[id];
+        const int nin = n.log2_sub_in + n.log2_reps;
+        const size_t SR = (size_t)1 << nin;
+        std::vector<E2> alphas;
+        dev::ClaimSet cs = claim_set(claims[id], &alphas);
+        for (auto& c : claims[id]) if (c.len != n.log2_out()) throw Error("gkr: claim arity mismatch");
+        Cell claim = combined_value(claims[id], alphas);
+        E2* eqc = ctx->alloc_n<E2>((size_t)1 << n.log2_out());
+        ctx->prof_begin(cls_aux, 16.0 * ((size_t)1 << n.log2_out()));
+        dev::eq_combined(st, eqc, n.log2_out(), ctx->d_chal, cs);
+        ctx->prof_end();
+        if (nd.nconst) {  // claim -= sum_g eqc[g] * w0_g
+            size_t s = slot(1);
+            int grid = dev::vanilla_const_sum(st, nd.const_gate, nd.const_coef, nd.nconst, eqc, n.log2_sub_out, n.log2_reps, ctx->d_partials);
+            reduce(grid, 1, s);
+            ops.push_back([this, s, claim] { *claim = e2_sub(*claim, h_res()[s]); });
+        }
+        // phase 1: sum_x sum_i in_i(x) T_i(x)
+        std::vector<int> li, ri;
+        for (int i = 0; i < n.arity; i++) { if (n.left_use[i]) li.push_back(i); if (n.right_use[i]) ri.push_back(i); }
+        dev::GatherT gt;
+        memset(&gt, 0, sizeof(gt));
+        if (n.arity > dev::PS_MAX_PAIRS) throw Error("vanilla: arity too large");
+        for (int i = 0; i < n.arity; i++) gt.in_vals[i] = d_vals[n.preds[i]];
+        std::vector<const u64*> a;
+        std::vector<const E2*> b;
+        std::vector<E2*> fa, fb;
+        size_t u_base = slot(n.arity);
+        E2* scratch = ctx->alloc_n<E2>(n.arity);
+        for (int i : li) {
+            E2* T = ctx->alloc_n<E2>(SR);
+            gt.lin = nd.lin[i];
+            gt.mul = nd.mulL[i];
+            ctx->prof_begin(cls_gather, 24.0 * SR);
+            dev::vanilla_gather_T(st, gt, eqc, n.log2_sub_in, n.log2_sub_out, n.log2_reps, T);
+            ctx->prof_end();
+            a.push_back(d_vals[n.preds[i]]);
+            b.push_back(T);
+            fa.push_back(d_res() + u_base + i);
+            fb.push_back(scratch + i);
+        }
+        ScHandle s1 = sc_prodsum(a, b, nin, fa, fb);
+        Cell after1 = cell();
+        defer_sumcheck(s1, 2, claim, after1);
+        for (int i : li) {
+            defer_write_slots(u_base + i, 1);
+            Cell v = cell();
+            size_t sl = u_base + i;
+            ops.push_back([this, v, sl] { *v = h_res()[sl]; });
+            claims[n.preds[i]].push_back(ClaimRef{s1.point_off, nin, v});
+        }
+        if (!n.mul.empty()) {
+            if (!n.lin.empty()) throw Error("vanilla: nodes mixing linear and mul gates are not on this path");
+            // phase 2: sum_y sum_i in_i(y) B_i(y), claim carried over from phase 1 (no linear part)
+            E2* eqx = ctx->alloc_n<E2>(SR);
+            dev::eq_table(st, eqx, nin, ctx->d_chal, s1.point_off);
+            std::vector<const u64*> a2;
+            std::vector<const E2*> b2;
+            std::vector<E2*> fa2, fb2;
+            size_t w_base = slot(n.arity);
+            for (int i : ri) {
+                E2* B = ctx->alloc_n<E2>(SR);
+                ctx->prof_begin(cls_gather, 40.0 * SR);
+                dev::vanilla_gather_B(st, nd.mulR[i], eqc, eqx, d_res() + u_base, n.log2_sub_in, n.log2_sub_out, n.log2_reps, B);
+                ctx->prof_end();
+                a2.push_back(d_vals[n.preds[i]]);
+                b2.push_back(B);
+                fa2.push_back(d_res() + w_base + i);
+                fb2.push_back(scratch + i);
+            }
+            ScHandle s2 = sc_prodsum(a2, b2, nin, fa2, fb2);
+            defer_sumcheck(s2, 2, after1, nullptr);
+            for (int i : ri) {
+                defer_write_slots(w_base + i, 1);
+                Cell v = cell();
+                size_t sl = w_base + i;
+                ops.push_back([this, v, sl] { *v = h_res()[sl]; });
+                claims[n.preds[i]].push_back(ClaimRef{s2.point_off, nin, v});
+            }
+        }
+    }
+
+    void fft_node(int id) {
+        const HNode& n = pk->circuit.nodes[id];
+        const int L = n.log2_size;
+        const size_t N = (size_t)1 << L;
+        std::vector<E2> alphas;
+        dev::ClaimSet cs = claim_set(claims[id], &alphas);
+        Cell claim = combined_value(claims[id], alphas);
+        E2* F = ctx->alloc_n<E2>(N);
+        const u64* W = (n.inverse ? pk->w_inv : pk->w_fwd).at(L);
+        u64 scale = n.inverse ? gl_inv(gl_from_u64(N)) : 1;
+        ctx->prof_begin(cls_aux, 24.0 * N);
+        dev::fft_table(st, F, L, W, scale, ctx->d_chal, cs);
+        ctx->prof_end();
+        size_t u = slot(1);
+        E2* scratch = ctx->alloc_n<E2>(1);
+        ScHandle s = sc_prodsum({d_vals[n.preds[0]]}, {F}, L, {d_res() + u}, {scratch});
+        defer_sumcheck(s, 2, claim, nullptr);
+        defer_write_slots(u, 1);
+        Cell v = cell();
+        ops.push_back([this, v, u] { *v = h_res()[u]; });
+        claims[n.preds[0]].push_back(ClaimRef{s.point_off, L, v});
+    }
+
+    void gkr(const ClaimRef& sum_claim) {  // prove_gkr (sk_encryption_circuit.rs:455-457)
+        const HCircuit& c = pk->circuit;
+        claims.assign(c.nodes.size(), {});
+        claims[c.lasso_id].push_back(ClaimRef{epos(), 0, cell()});  // EvalClaim::new(vec![], E::ZERO) (:450)
+        claims[c.sum_id].push_back(sum_claim);
+        for (size_t q = c.topo.size(); q-- > 0;) {
+            int id = c.topo[q];
+            const HNode& n = c.nodes[id];
+            switch (n.kind) {
+                case NK_INPUT: break;
+                case NK_VANILLA: vanilla_node(id); break;
+                case NK_FFT: fft_node(id); break;
+                case NK_LASSO: {
+                    ClaimRef cr = lasso_node(d_vals[n.preds[0]]);
+                    claims[n.preds[0]].push_back(cr);
+                    break;
+                }
+            }
+        }
+    }
+
+    // copies the result buffer back (the only synchronisation) and replays the transcript
+    void finish() {
+        if (res_used) hip_check(hipMemcpyAsync(ctx->h_res, ctx->d_res, res_used * sizeof(E2), hipMemcpyDeviceToHost, st), "copy results");
+        hip_check(hipStreamSynchronize(st), "prove: stream sync");
+        hip_check(hipGetLastError(), "prove: kernel launch");
+        for (auto& op : ops) op();
+        ctx->prof_collect();
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+ProveResult prove_full(hg_ctx* ctx, const hg_pk* pk, const Witness& w) {
+    ProveResult res;
+    hip_check(hipSetDevice(ctx->device), "hipSetDevice");
+    ctx->arena_reset();
+    const Params& p = pk->params;
+    const HCircuit& c = pk->circuit;
+    double t0 = wall_ms();
+    std::vector<std::vector<u64>> vals = circuit_evaluate(c, p, w);  // witness generation (host, OpenMP)
+    double t1 = wall_ms();
+    res.witness_ms = t1 - t0;
+    Prover P(ctx, pk);
+    // node values -> HBM
+    P.d_vals.assign(c.nodes.size(), nullptr);
+    for (size_t id = 0; id < c.nodes.size(); id++) {
+        if (c.nodes[id].succs.empty()) continue;  // outputs are never read by a reduction
+        u64* d = ctx->alloc_n<u64>(vals[id].size());
+        hip_check(hipMemcpyAsync(d, vals[id].data(), vals[id].size() * 8, hipMemcpyHostToDevice, ctx->stream), "upload node values");
+        P.d_vals[id] = d;
+    }
+    u64* d_ct0 = ctx->alloc_n<u64>(w.ct0is.size());
+    hip_check(hipMemcpyAsync(d_ct0, w.ct0is.data(), w.ct0is.size() * 8, hipMemcpyHostToDevice, ctx->stream), "upload ct0is");
+    hip_check(hipStreamSynchronize(ctx->stream), "upload sync");
+    double t2 = wall_ms();
+    res.upload_ms = t2 - t1;
+    hipEvent_t ev_a, ev_b;
+    hip_check(hipEventCreate(&ev_a), "event"); hip_check(hipEventCreate(&ev_b), "event");
+    // "eval output" (sk_encryption_circuit.rs:444-448): point, ct0is MLE value
+    const int ov = p.ct0is_log2();
+    size_t point_off = P.epos();
+    for (int i = 0; i < ov; i++) P.squeeze();
+    size_t vslot = P.slot(1);
+    {
+        E2* eq = ctx->alloc_n<E2>((size_t)1 << ov);
+        dev::eq_table(ctx->stream, eq, ov, ctx->d_chal, point_off);
+        const u64* tabs[8] = {d_ct0};
+        int grid = dev::dot_eq(ctx->stream, eq, tabs, 1, (size_t)1 << ov, ctx->d_partials);
+        P.reduce(grid, 1, vslot);
+    }
+    Cell out_value = cell();
+    P.ops.push_back([&P, out_value, vslot] { *out_value = P.h_res()[vslot]; });
+    hip_check(hipEventRecord(ev_a, ctx->stream), "event record");
+    double t3 = wall_ms();
+    P.gkr(ClaimRef{point_off, ov, out_value});
+    hip_check(hipEventRecord(ev_b, ctx->stream), "event record");
+    P.finish();
+    double t4 = wall_ms();
+    float gms = 0;
+    (void)hipEventElapsedTime(&gms, ev_a, ev_b);
+    (void)hipEventDestroy(ev_a); (void)hipEventDestroy(ev_b);
+    res.prove_ms = t4 - t3;
+    res.gpu_ms = gms;
+    res.proof = std::move(P.proof.bytes);
+    return res;
+}
+
+std::vector<uint8_t> prove_lasso_node(hg_ctx* ctx, const hg_pk* pk, const u64* lasso_in_host, std::vector<E2>* claim_out) {
+    hip_check(hipSetDevice(ctx->device), "hipSetDevice");
+    ctx->arena_reset();
+    Prover P(ctx, pk);
+    const size_t N = (size_t)1 << pk->lasso.nu;
+    u64* d_in = ctx->alloc_n<u64>(N);
+    hip_check(hipMemcpyAsync(d_in, lasso_in_host, N * 8, hipMemcpyHostToDevice, ctx->stream), "upload lasso input");
+    ClaimRef cr = P.lasso_node(d_in);
+    P.finish();
+    if (claim_out) {
+        const u64* chain = challenge_chain(2 * (cr.point_off + cr.len));
+        claim_out->clear();
+        for (int i = 0; i < cr.len; i++) claim_out->push_back(e2(chain[2 * (cr.point_off + i)], chain[2 * (cr.point_off + i) + 1]));
+        claim_out->push_back(*cr.value);
+    }
+    return std::move(P.proof.bytes);
+}
+
+void sumcheck_on_tables(hg_ctx* ctx, SumcheckIO& io) {
+    hip_check(hipSetDevice(ctx->device), "hipSetDevice");
+    ctx->arena_reset();
+    Prover P(ctx, nullptr);
+    const size_t N = (size_t)1 << io.nv;
+    const int ntab = (int)io.tables.size();
+    P.ch.pos = 2 * io.chain_skip;
+    Cell claim = cell(io.claim), out = cell();
+    ScHandle h;
+    size_t evals = P.slot(ntab);
+    if (io.kind == 2) {
+        std::vector<const u64*> a;
+        std::vector<const E2*> b;
+        std::vector<E2*> fa, fb;
+        for (int i = 0; i < ntab; i += 2) {
+            if (!io.is_base[i] || io.is_base[i + 1]) throw Error("hg_sumcheck: prodsum expects (base, ext) table pairs");
+            u64* da = ctx->alloc_n<u64>(N);
+            E2* db = ctx->alloc_n<E2>(N);
+            hip_check(hipMemcpyAsync(da, io.tables[i], N * 8, hipMemcpyHostToDevice, ctx->stream), "upload");
+            hip_check(hipMemcpyAsync(db, io.tables[i + 1], N * 16, hipMemcpyHostToDevice, ctx->stream), "upload");
+            a.push_back(da); b.push_back(db);
+            fa.push_back(ctx->d_res + evals + i); fb.push_back(ctx->d_res + evals + i + 1);
+        }
+        h = P.sc_prodsum(a, b, (int)io.nv, fa, fb);
+    } else {
+        bool base = io.is_base[0] != 0;
+        for (int i = 0; i < ntab; i++) if ((io.is_base[i] != 0) != base) throw Error("hg_sumcheck: mixed table fields");
+        size_t el = base ? 8 : 16;
+        char* d = (char*)ctx->alloc((size_t)ntab * N * el);
+        for (int i = 0; i < ntab; i++) hip_check(hipMemcpyAsync(d + (size_t)i * N * el, io.tables[i], N * el, hipMemcpyHostToDevice, ctx->stream), "upload");
+        dev::Powers pw;
+        memset(&pw, 0, sizeof(pw));
+        for (size_t i = 0; i < io.pw.size() && i < (size_t)dev::PW_MAX; i++) pw.v[i] = io.pw[i];
+        h = P.sc_stride(io.kind == 1 ? dev::SC_GRANDPROD : dev::SC_COLLATION, d, base, N, ntab, (int)io.nv, pw, ctx->d_res + evals);
+    }
+    int deg = io.kind == 1 ? 3 : 2;
+    P.defer_sumcheck(h, deg, claim, out);
+    P.finish();
+    io.point = h.rs;
+    io.evals.assign(ctx->h_res + evals, ctx->h_res + evals + ntab);
+    io.sums.assign(ctx->h_res + h.sums_slot, ctx->h_res + h.sums_slot + (size_t)h.nvars * h.nv);
+    // decode the coefficient messages back from the stream
+    io.msgs.clear();
+    const std::vector<uint8_t>& b = P.proof.bytes;
+    for (size_t o = 0; o + 16 <= b.size(); o += 16) {
+        u64 c0 = 0, c1 = 0;
+        for (int i = 0; i < 8; i++) { c0 = (c0 << 8) | b[o + i]; c1 = (c1 << 8) | b[o + 8 + i]; }
+        io.msgs.push_back(e2(c0, c1));
+    }
+}
+
+E2 mle_eval_device(hg_ctx* ctx, const u64* table_host, size_t nv, const E2* point_host) {
+    hip_check(hipSetDevice(ctx->device), "hipSetDevice");
+    ctx->arena_reset();
+    Prover P(ctx, nullptr);
+    const size_t N = (size_t)1 << nv;
+    u64* d = ctx->alloc_n<u64>(N);
+    E2* pt = ctx->alloc_n<E2>(nv ? nv : 1);
+    E2* eq = ctx->alloc_n<E2>(N);
+    hip_check(hipMemcpyAsync(d, table_host, N * 8, hipMemcpyHostToDevice, ctx->stream), "upload");
+    if (nv) hip_check(hipMemcpyAsync(pt, point_host, nv * 16, hipMemcpyHostToDevice, ctx->stream), "upload");
+    dev::eq_table(ctx->stream, eq, (int)nv, pt, 0);
+    const u64* tabs[8] = {d};
+    int grid = dev::dot_eq(ctx->stream, eq, tabs, 1, N, ctx->d_partials);
+    size_t s = P.slot(1);
+    P.reduce(grid, 1, s);
+    P.finish();
+    return ctx->h_res[s];
+}
+
+void ntt_device(hg_ctx* ctx, const u64* in_host, int log2n, bool inverse, size_t batch, u64* out_host) {
+    hip_check(hipSetDevice(ctx->device), "hipSetDevice");
+    ctx->arena_reset();
+    const size_t N = (size_t)1 << log2n;
+    u64* d = ctx->alloc_n<u64>(N * batch);
+    u64* W = ctx->alloc_n<u64>(N);
+    u64 w = root_of_unity(log2n);
+    if (inverse) w = gl_inv(w);
+    hip_check(hipMemcpyAsync(d, in_host, N * batch * 8, hipMemcpyHostToDevice, ctx->stream), "upload");
+    dev::powers_table(ctx->stream, W, w, N / 2 ? N / 2 : 1);
+    dev::ntt_batch(ctx->stream, d, log2n, batch, W, inverse ? gl_inv(gl_from_u64(N)) : 1);
+    hip_check(hipMemcpyAsync(out_host, d, N * batch * 8, hipMemcpyDeviceToHost, ctx->stream), "download");
+    hip_check(hipStreamSynchronize(ctx->stream), "ntt sync");
+}
+
+}  // namespace hg

@@ -1,0 +1,101 @@
+// Device-side proving engine: context (stream, arena, result buffer, challenge chain in HBM),
+// prover key (circuit wiring as CSR in HBM) and the enqueue-everything / assemble-later prover.
+//
+// Because the reference transcript never absorbs prover messages (host.hpp), every challenge is
+// known before the first launch. The prover therefore (1) walks the protocol once on the host,
+// squeezing challenges in protocol order and enqueueing kernels whose scalar outputs (round sums,
+// final evaluations) land in one result buffer in HBM, (2) copies that buffer back with a single
+// synchronisation, (3) replays the recorded transcript steps on the host to interpolate round
+// polynomials, chain the claims and emit the proof bytes. No device->host round trip per round.
+#pragma once
+#include <functional>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+#include "host.hpp"
+#include "kernels.hpp"
+
+struct hg_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // bump arena: chunks are kept across proves, offsets reset per prove
+    struct Chunk { char* p; size_t cap, used; };
+    std::vector<Chunk> chunks;
+    size_t arena_total = 0;
+    void* alloc(size_t bytes);
+    template <typename T> T* alloc_n(size_t n) { return static_cast<T*>(alloc(n * sizeof(T))); }
+    void arena_reset();
+    // challenge chain in HBM (as E2 pairs)
+    hg::E2* d_chal = nullptr;
+    size_t chal_e = 0;
+    void ensure_chain(size_t n_e);
+    // scalar results
+    hg::E2* d_res = nullptr;
+    hg::E2* h_res = nullptr;  // pinned
+    size_t res_cap = 0;
+    hg::E2* d_partials = nullptr;
+    // profiling
+    int prof_level = 0;
+    struct ProfEvent { int cls; hipEvent_t a, b; };
+    std::vector<ProfEvent> prof_events;
+    std::vector<hipEvent_t> event_pool;
+    struct ProfStat { std::string name; uint64_t launches = 0; double ms = 0, bytes = 0; bool dominant = false; };
+    std::vector<ProfStat> prof_stats;
+    int prof_class(const char* name, bool dominant);
+    void prof_begin(int cls, double bytes);
+    void prof_end();
+    void prof_collect();
+    int cur_cls = -1;
+    hipEvent_t cur_a = nullptr;
+    ~hg_ctx();
+};
+
+struct hg_witness {
+    hg::Witness w;
+    hg_params params;
+};
+
+struct hg_pk {
+    hg_ctx* ctx = nullptr;
+    hg::Params params;
+    hg::LassoPlan lasso;
+    hg::HCircuit circuit;
+    hg::dev::LassoDev lasso_dev;
+    // per vanilla node, per input: device CSRs
+    struct NodeDev {
+        std::vector<hg::dev::CsrLin> lin;    // [arity]
+        std::vector<hg::dev::CsrMul> mulL;   // [arity] keyed by left operand
+        std::vector<hg::dev::CsrMul> mulR;   // [arity] keyed by right operand
+        const hg::u32* const_gate = nullptr;
+        const hg::u64* const_coef = nullptr;
+        size_t nconst = 0;
+    };
+    std::vector<NodeDev> node_dev;
+    std::map<int, const hg::u64*> w_fwd, w_inv;  // log2n -> w^i table (N entries)
+    std::vector<void*> owned;                    // device allocations released in hg_pk_free
+    explicit hg_pk(const hg_params& p) : params(p) {}
+};
+
+namespace hg {
+
+struct ProveResult {
+    std::vector<uint8_t> proof;
+    double witness_ms = 0, upload_ms = 0, prove_ms = 0, gpu_ms = 0;
+};
+
+ProveResult prove_full(hg_ctx* ctx, const hg_pk* pk, const Witness& w);
+// Lasso node alone on a fresh transcript; claim_out = nu point coordinates then the value
+std::vector<uint8_t> prove_lasso_node(hg_ctx* ctx, const hg_pk* pk, const u64* lasso_in_host, std::vector<E2>* claim_out);
+// one sum-check on caller tables (kernel-level parity entry point)
+struct SumcheckIO {
+    int kind; size_t nv; std::vector<const u64*> tables; std::vector<int> is_base; std::vector<E2> pw; E2 claim; size_t chain_skip;
+    std::vector<E2> msgs, point, evals, sums;
+};
+void sumcheck_on_tables(hg_ctx* ctx, SumcheckIO& io);
+E2 mle_eval_device(hg_ctx* ctx, const u64* table_host, size_t nv, const E2* point_host);
+void ntt_device(hg_ctx* ctx, const u64* in_host, int log2n, bool inverse, size_t batch, u64* out_host);
+
+void hip_check(hipError_t e, const char* what);
+
+}  // namespace hg

@@ -1,0 +1,128 @@
+/* hyper-greco-amd: C ABI of the MI355X-native GKR prover for the BFV secret-key-encryption circuit.
+ *
+ * This is the drop-in boundary: plain C, caller-owned buffers, `int` status
+ * (0 = OK, negative = error, text via hg_last_error()). Field elements cross the boundary as
+ * canonical little-endian u64 limbs (Goldilocks: 1 limb; GoldilocksExt2: 2 limbs [c0, c1]); proof
+ * bytes use the reference wire format (canonical repr, big-endian, ext = bases in order)
+ * [REF bfv-gkr/src/transcript.rs:183-195].
+ *
+ * Each entry point names the reference interface it replaces. The Rust-side binding a maintainer
+ * would add is shown in INTEGRATION.md.
+ */
+#ifndef HG_H
+#define HG_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HG_MAX_K 16
+
+typedef struct hg_ctx hg_ctx;         /* one per GPU: stream, workspace arena, cached challenge chain */
+typedef struct hg_pk hg_pk;           /* prover key = LassoPreprocessing + circuit wiring, device resident */
+typedef struct hg_witness hg_witness; /* BfvSkEncryptArgs after get_inputs(): laid-out field tables (host) */
+
+/* Per-parameter-set constants [REF bfv-gkr/src/constants/mod.rs:16-35, constants/sk_enc_constants_*.rs] */
+typedef struct hg_params {
+    uint32_t n;        /* ring degree N */
+    uint32_t k;        /* number of CRT moduli (const generic K) */
+    uint64_t s_bound, e_bound, k1_bound;
+    uint64_t r1_bounds[HG_MAX_K], r2_bounds[HG_MAX_K];
+    uint64_t qis[HG_MAX_K], k0is[HG_MAX_K];
+} hg_params;
+
+typedef struct hg_timings {
+    double witness_ms; /* "wintess gen" span: circuit.evaluate + output claim [REF sk_encryption_circuit.rs:439-453] */
+    double upload_ms;  /* host -> HBM copy of node values (not part of any reference span) */
+    double prove_ms;   /* "GKR prove" span [REF sk_encryption_circuit.rs:455-457]: HIP events on the prover stream,
+                          node values resident in HBM at start; wall clock from the
+                          first launch to the assembled proof bytes (includes host launch + transcript replay) */
+    double gpu_ms;     /* the same span measured with HIP events on the prover stream (device time only) */
+    double total_ms;   /* wall clock of the whole hg_prove call */
+} hg_timings;
+
+/* Per-kernel-class profile (HIP events recorded on the prover stream around every launch of the class). */
+typedef struct hg_kernel_stat {
+    char name[48];
+    uint64_t launches;
+    double total_ms;
+    double algo_bytes; /* algorithmic bytes over all launches: tables read once + folded tables written once */
+} hg_kernel_stat;
+
+const char* hg_last_error(void);
+int hg_device_count(void);
+
+/* = nothing in the reference (single-process rayon); one ctx per device, calls on a ctx are serialised by the caller */
+hg_ctx* hg_create(int device_id);
+void hg_destroy(hg_ctx* ctx);
+
+/* = `type Params = constants::SkEnc{N}_{K}x{bits}_65537` [REF bfv-gkr/src/test.rs:8] */
+int hg_params_builtin(uint32_t n, uint32_t k, hg_params* out);
+
+/* = BfvEncrypt::setup -> LassoPreprocessing::preprocess::<4, 65536> [REF sk_encryption_circuit.rs:319-349, lasso.rs:527-627]
+ *   plus BfvEncrypt::configure (circuit wiring) [REF sk_encryption_circuit.rs:351-363, 86-293], done once. */
+int hg_setup(hg_ctx* ctx, const hg_params* params, hg_pk** pk); /* ctx == NULL: host-only key (layout / circuit_eval) */
+void hg_pk_free(hg_pk* pk);
+/* Lasso memory map as text "subtable@dim,...|lookup:bits:m/m;..." (for tests) */
+int hg_pk_lasso_layout(const hg_pk* pk, char* out, size_t cap);
+/* [nu, num_nodes, rows, alpha] */
+int hg_pk_info(const hg_pk* pk, uint64_t out[4]);
+
+/* = serde_json::from_str::<BfvSkEncryptArgs> + BfvEncrypt::get_inputs / Poly::{new,new_padded,new_shifted}
+ *   [REF bfv-gkr/src/test.rs:21-33, sk_encryption_circuit.rs:365-415, poly.rs:12-44] */
+int hg_witness_from_json(const hg_params* params, const char* path, hg_witness** w);
+/* Replaces scripts/circuit_sk.py (offline witness generator) with a seeded synthetic BFV sk-encryption
+ * [REF scripts/circuit_sk.py:18-140, scripts/utils.py:4-18]; needed because the n=32768 fixture is a missing blob. */
+int hg_witness_synthetic(const hg_params* params, uint64_t seed, hg_witness** w);
+/* Already laid-out tables: s,e,k1: 2^L; ais,r1is: k*2^L; r2is: k*2^P; ct0is: k*2^L (L = log2 n + 1, P = log2 n) */
+int hg_witness_from_arrays(const hg_params* params, const uint64_t* s, const uint64_t* e, const uint64_t* k1,
+                           const uint64_t* ais, const uint64_t* r1is, const uint64_t* r2is, const uint64_t* ct0is,
+                           hg_witness** w);
+/* which: 0 s, 1 e, 2 k1, 3 ais, 4 r1is, 5 r2is, 6 ct0is. Returns the element count (copies min(count, cap)). */
+int64_t hg_witness_get(const hg_witness* w, int which, uint64_t* out, size_t cap);
+void hg_witness_free(hg_witness* w);
+
+/* = BfvEncrypt::prove [REF sk_encryption_circuit.rs:417-460]. Fails (never falls back to a CPU path)
+ *   when no HIP device is available. */
+int hg_prove(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, uint8_t* proof, size_t cap, size_t* len,
+             hg_timings* timings);
+
+/* = circuit.evaluate (host part of witness generation) [REF sk_encryption_circuit.rs:442]:
+ *   copies out the Lasso node's input table (2^nu) and the `sum` node output (k*2^L). Host only. */
+int hg_circuit_eval(const hg_pk* pk, const hg_witness* w, uint64_t* lasso_in, size_t lasso_cap, uint64_t* sum_out,
+                    size_t sum_cap);
+
+/* = <LassoNode as gkr::circuit::node::Node>::prove_claim_reduction [REF lasso/src/lasso.rs:57-114] on a fresh
+ *   transcript. lasso_in: host table of 2^nu field elements. claim_out: nu E coordinates then the value. */
+int hg_lasso_prove(hg_ctx* ctx, const hg_pk* pk, const uint64_t* lasso_in, uint8_t* proof, size_t cap, size_t* len,
+                   uint64_t* claim_out);
+
+/* = gkr::sum_check::prove_sum_check [REF call sites lasso.rs:278-279, prover.rs:242-252] on caller tables.
+ *   kind: 0 collation g = p0*sum M^i p_i, 1 grand product g = p0*sum gam^i p_2i p_2i+1, 2 sum of pair products.
+ *   tables[i]: host pointer, 2^nv u64 (is_base) or 2^nv (c0,c1) pairs. The challenge chain starts after
+ *   `chain_skip` E challenges. Outputs: msgs nv*(d+1) E, point nv E, evals ntab E, sums nv*d E (raw per-round sums). */
+int hg_sumcheck(hg_ctx* ctx, int kind, size_t nv, size_t ntab, const uint64_t* const* tables, const int* is_base,
+                const uint64_t* pw, size_t npw, const uint64_t* claim2, size_t chain_skip, uint64_t* msgs,
+                uint64_t* point, uint64_t* evals, uint64_t* sums);
+
+/* = BoxMultilinearPoly::evaluate [REF call sites memory_checking/mod.rs:80-93, sk_encryption_circuit.rs:446]
+ *   on a host table of 2^nv base-field values at an E point. */
+int hg_mle_eval(hg_ctx* ctx, const uint64_t* table, size_t nv, const uint64_t* point, uint64_t out2[2]);
+
+/* = FftNode evaluate (size-2^log2n NTT, natural order in/out) [REF sk_encryption_circuit.rs:224,249,251]. Device. */
+int hg_ntt(hg_ctx* ctx, const uint64_t* in, size_t log2n, int inverse, size_t batch, uint64_t* out);
+
+/* Fiat-Shamir challenge chain [REF bfv-gkr/src/transcript.rs:146-157,198-203]: first n base-field challenges. */
+int hg_challenges(size_t n, uint64_t* out);
+
+/* profiling: level 0 off, 1 = events around the dominant kernel class only, 2 = every class */
+int hg_profile(hg_ctx* ctx, int level);
+int hg_profile_reset(hg_ctx* ctx);
+int hg_profile_get(hg_ctx* ctx, hg_kernel_stat* out, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -347,7 +347,7 @@ static inline std::vector<std::vector<EvalClaim>> fft_prove(const Node& n, const
     E claim = combined_value(cl, alpha);
     std::vector<ScTable> tabs;
     tabs.push_back(ScTable::from_f(in.data(), in.size()));
-    tabs.push_back(ScTable::from_e(std::move(Fc)));
+    tabs.push_back(ScTable::from_e(Fc));
     ScFunc g{SC_PRODSUM, n.log2_size, {}};
     ScResult r = prove_sum_check(g, claim, std::move(tabs), tr);
     tr.write_e(r.evals[0]);

@@ -210,7 +210,7 @@ int orc_sumcheck(int kind, size_t nv, size_t ntab, const uint64_t* const* tables
     size_t N = (size_t)1 << nv;
     for (size_t i = 0; i < ntab; i++) {
         if (is_base[i]) T.push_back(ScTable::from_f(tables[i], N));
-        else { std::vector<E> v(N); memcpy(v.data(), tables[i], N * 16); T.push_back(ScTable::from_e(std::move(v))); }
+        else { std::vector<E> v(N); memcpy(v.data(), tables[i], N * 16); T.push_back(ScTable::from_e(v)); }
     }
     TranscriptW tr;
     for (size_t i = 0; i < chain_skip; i++) tr.squeeze();

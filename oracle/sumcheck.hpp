@@ -26,6 +26,8 @@
 #pragma once
 #include <vector>
 #include <stdexcept>
+#include <memory>
+#include <algorithm>
 #include "gl.hpp"
 #include "poly.hpp"
 #include "transcript.hpp"
@@ -36,12 +38,20 @@ enum ScKind { SC_COLLATION = 0, SC_GRANDPROD = 1, SC_PRODSUM = 2 };
 
 struct ScTable {
     const uint64_t* fp = nullptr;  // base-field view (round 0), not owned
-    std::vector<E> e;              // extension values (after first fold, or from the start)
+    const E* ep = nullptr;         // extension view (after the first fold, or from the start)
+    std::unique_ptr<E[]> own[2];   // ping-pong storage for folded tables (uninitialised on allocation)
+    int cur = 0;
     bool base = false;
     size_t n = 0;                  // current length
     static ScTable from_f(const uint64_t* p, size_t n) { ScTable t; t.fp = p; t.base = true; t.n = n; return t; }
-    static ScTable from_e(std::vector<E> v) { ScTable t; t.n = v.size(); t.e = std::move(v); return t; }
-    inline E at(size_t i) const { return base ? E{fp[i], 0} : e[i]; }
+    static ScTable from_e(const std::vector<E>& v) {
+        ScTable t; t.n = v.size();
+        t.own[0].reset(new E[v.size() ? v.size() : 1]);
+        for (size_t i = 0; i < v.size(); i++) t.own[0][i] = v[i];
+        t.ep = t.own[0].get();
+        return t;
+    }
+    inline E at(size_t i) const { return base ? E{fp[i], 0} : ep[i]; }
 };
 
 struct ScFunc {
@@ -80,91 +90,103 @@ static inline std::vector<E> interpolate(const std::vector<E>& ev) {
     throw std::runtime_error("interpolate: unsupported degree");
 }
 
-// true hypercube sums of g at t = 0, 2, .., d (index 1 left zero) for the current tables
+// true hypercube sums of g at t = 0, 2, .., d (index 1 left zero) for the current tables.
+// Blocked over j so that each table is streamed in contiguous runs (the tables sit at power-of-two
+// strides; touching all of them per j would thrash the cache sets).
 static inline void sc_round_evals(const ScFunc& g, const std::vector<ScTable>& T, E out[4]) {
     const size_t P = T.size();
     const size_t half = T[0].n >> 1;
     const int d = g.degree();
     const bool all_base = [&] { for (auto& t : T) if (!t.base) return false; return true; }();
+    const size_t BLK = 256;
+    const size_t nblk = (half + BLK - 1) / BLK;
     E acc[4] = {e_zero(), e_zero(), e_zero(), e_zero()};
 #pragma omp parallel
     {
         E a[4] = {e_zero(), e_zero(), e_zero(), e_zero()};
+        std::vector<E> s0(BLK), s2(BLK), s3(BLK), q0(BLK), q2(BLK), q3(BLK);
 #pragma omp for nowait schedule(static)
-        for (long long jj = 0; jj < (long long)half; jj++) {
-            size_t j = (size_t)jj;
+        for (long long bb = 0; bb < (long long)nblk; bb++) {
+            const size_t j0 = (size_t)bb * BLK, cnt = std::min(BLK, half - j0);
+            for (size_t u = 0; u < cnt; u++) s0[u] = s2[u] = s3[u] = e_zero();
             if (g.kind == SC_COLLATION) {
-                if (all_base) {
-                    uint64_t in0 = 0, in2 = 0, p00 = 0, p02 = 0;
-                    for (size_t i = 0; i < P; i++) {
-                        uint64_t x = T[i].fp[2 * j], y = T[i].fp[2 * j + 1];
-                        uint64_t v2 = f_sub(f_add(y, y), x);
-                        if (i == 0) { p00 = x; p02 = v2; }
-                        in0 = f_add(in0, f_mul(g.pw[i].c0, x));
-                        in2 = f_add(in2, f_mul(g.pw[i].c0, v2));
+                for (size_t i = 0; i < P; i++) {
+                    const uint64_t m = g.pw[i].c0;
+                    if (all_base) {
+                        const uint64_t* p = T[i].fp + 2 * j0;
+                        for (size_t u = 0; u < cnt; u++) {
+                            uint64_t x = p[2 * u], y = p[2 * u + 1];
+                            uint64_t v2 = f_sub(f_add(y, y), x);
+                            if (i == 0) { q0[u] = E{x, 0}; q2[u] = E{v2, 0}; }
+                            s0[u].c0 = f_add(s0[u].c0, f_mul(m, x));
+                            s2[u].c0 = f_add(s2[u].c0, f_mul(m, v2));
+                        }
+                    } else {
+                        for (size_t u = 0; u < cnt; u++) {
+                            E x = T[i].at(2 * (j0 + u)), y = T[i].at(2 * (j0 + u) + 1);
+                            E v2 = e_sub(e_dbl(y), x);
+                            if (i == 0) { q0[u] = x; q2[u] = v2; }
+                            s0[u] = e_add(s0[u], e_mul_f(x, m));
+                            s2[u] = e_add(s2[u], e_mul_f(v2, m));
+                        }
                     }
-                    a[0] = e_add_f(a[0], f_mul(p00, in0));
-                    a[2] = e_add_f(a[2], f_mul(p02, in2));
-                } else {
-                    E in0 = e_zero(), in2 = e_zero(), p00 = e_zero(), p02 = e_zero();
-                    for (size_t i = 0; i < P; i++) {
-                        E x = T[i].at(2 * j), y = T[i].at(2 * j + 1);
-                        E v2 = e_sub(e_dbl(y), x);
-                        if (i == 0) { p00 = x; p02 = v2; }
-                        in0 = e_add(in0, e_mul_f(x, g.pw[i].c0));
-                        in2 = e_add(in2, e_mul_f(v2, g.pw[i].c0));
-                    }
-                    a[0] = e_add(a[0], e_mul(p00, in0));
-                    a[2] = e_add(a[2], e_mul(p02, in2));
                 }
+                for (size_t u = 0; u < cnt; u++) { a[0] = e_add(a[0], e_mul(q0[u], s0[u])); a[2] = e_add(a[2], e_mul(q2[u], s2[u])); }
             } else if (g.kind == SC_GRANDPROD) {
-                if (all_base) {
-                    E in[4] = {e_zero(), e_zero(), e_zero(), e_zero()};
-                    uint64_t p0[4] = {0, 0, 0, 0};
-                    for (size_t i = 0; i < P / 2; i++) {
-                        uint64_t xl = T[2 * i].fp[2 * j], yl = T[2 * i].fp[2 * j + 1];
-                        uint64_t xr = T[2 * i + 1].fp[2 * j], yr = T[2 * i + 1].fp[2 * j + 1];
-                        uint64_t dl = f_sub(yl, xl), dr = f_sub(yr, xr);
-                        uint64_t l2 = f_add(yl, dl), r2 = f_add(yr, dr);
-                        uint64_t l3 = f_add(l2, dl), r3 = f_add(r2, dr);
-                        if (i == 0) { p0[0] = xl; p0[2] = l2; p0[3] = l3; }
-                        in[0] = e_add(in[0], e_mul_f(g.pw[i], f_mul(xl, xr)));
-                        in[2] = e_add(in[2], e_mul_f(g.pw[i], f_mul(l2, r2)));
-                        in[3] = e_add(in[3], e_mul_f(g.pw[i], f_mul(l3, r3)));
+                for (size_t i = 0; i < P / 2; i++) {
+                    const E gm = g.pw[i];
+                    if (all_base) {
+                        const uint64_t* pl = T[2 * i].fp + 2 * j0;
+                        const uint64_t* pr = T[2 * i + 1].fp + 2 * j0;
+                        for (size_t u = 0; u < cnt; u++) {
+                            uint64_t xl = pl[2 * u], yl = pl[2 * u + 1], xr = pr[2 * u], yr = pr[2 * u + 1];
+                            uint64_t dl = f_sub(yl, xl), dr = f_sub(yr, xr);
+                            uint64_t l2 = f_add(yl, dl), r2 = f_add(yr, dr);
+                            uint64_t l3 = f_add(l2, dl), r3 = f_add(r2, dr);
+                            if (i == 0) { q0[u] = E{xl, 0}; q2[u] = E{l2, 0}; q3[u] = E{l3, 0}; }
+                            s0[u] = e_add(s0[u], e_mul_f(gm, f_mul(xl, xr)));
+                            s2[u] = e_add(s2[u], e_mul_f(gm, f_mul(l2, r2)));
+                            s3[u] = e_add(s3[u], e_mul_f(gm, f_mul(l3, r3)));
+                        }
+                    } else {
+                        for (size_t u = 0; u < cnt; u++) {
+                            size_t j = j0 + u;
+                            E xl = T[2 * i].at(2 * j), yl = T[2 * i].at(2 * j + 1);
+                            E xr = T[2 * i + 1].at(2 * j), yr = T[2 * i + 1].at(2 * j + 1);
+                            E dl = e_sub(yl, xl), dr = e_sub(yr, xr);
+                            E l2 = e_add(yl, dl), r2 = e_add(yr, dr);
+                            E l3 = e_add(l2, dl), r3 = e_add(r2, dr);
+                            if (i == 0) { q0[u] = xl; q2[u] = l2; q3[u] = l3; }
+                            s0[u] = e_add(s0[u], e_mul(gm, e_mul(xl, xr)));
+                            s2[u] = e_add(s2[u], e_mul(gm, e_mul(l2, r2)));
+                            s3[u] = e_add(s3[u], e_mul(gm, e_mul(l3, r3)));
+                        }
                     }
-                    for (int t : {0, 2, 3}) a[t] = e_add(a[t], e_mul_f(in[t], p0[t]));
-                } else {
-                    E in[4] = {e_zero(), e_zero(), e_zero(), e_zero()};
-                    E p0[4] = {e_zero(), e_zero(), e_zero(), e_zero()};
-                    for (size_t i = 0; i < P / 2; i++) {
-                        E xl = T[2 * i].at(2 * j), yl = T[2 * i].at(2 * j + 1);
-                        E xr = T[2 * i + 1].at(2 * j), yr = T[2 * i + 1].at(2 * j + 1);
-                        E dl = e_sub(yl, xl), dr = e_sub(yr, xr);
-                        E l2 = e_add(yl, dl), r2 = e_add(yr, dr);
-                        E l3 = e_add(l2, dl), r3 = e_add(r2, dr);
-                        if (i == 0) { p0[0] = xl; p0[2] = l2; p0[3] = l3; }
-                        in[0] = e_add(in[0], e_mul(g.pw[i], e_mul(xl, xr)));
-                        in[2] = e_add(in[2], e_mul(g.pw[i], e_mul(l2, r2)));
-                        in[3] = e_add(in[3], e_mul(g.pw[i], e_mul(l3, r3)));
-                    }
-                    for (int t : {0, 2, 3}) a[t] = e_add(a[t], e_mul(in[t], p0[t]));
+                }
+                for (size_t u = 0; u < cnt; u++) {
+                    a[0] = e_add(a[0], e_mul(s0[u], q0[u]));
+                    a[2] = e_add(a[2], e_mul(s2[u], q2[u]));
+                    a[3] = e_add(a[3], e_mul(s3[u], q3[u]));
                 }
             } else {  // SC_PRODSUM
                 for (size_t i = 0; i < P / 2; i++) {
                     const ScTable& A = T[2 * i];
                     const ScTable& B = T[2 * i + 1];
-                    E xb = B.at(2 * j), yb = B.at(2 * j + 1);
-                    E b2 = e_sub(e_dbl(yb), xb);
-                    if (A.base) {
-                        uint64_t xa = A.fp[2 * j], ya = A.fp[2 * j + 1];
-                        uint64_t a2 = f_sub(f_add(ya, ya), xa);
-                        a[0] = e_add(a[0], e_mul_f(xb, xa));
-                        a[2] = e_add(a[2], e_mul_f(b2, a2));
-                    } else {
-                        E xa = A.e[2 * j], ya = A.e[2 * j + 1];
-                        E a2 = e_sub(e_dbl(ya), xa);
-                        a[0] = e_add(a[0], e_mul(xb, xa));
-                        a[2] = e_add(a[2], e_mul(b2, a2));
+                    for (size_t u = 0; u < cnt; u++) {
+                        size_t j = j0 + u;
+                        E xb = B.at(2 * j), yb = B.at(2 * j + 1);
+                        E b2 = e_sub(e_dbl(yb), xb);
+                        if (A.base) {
+                            uint64_t xa = A.fp[2 * j], ya = A.fp[2 * j + 1];
+                            uint64_t a2 = f_sub(f_add(ya, ya), xa);
+                            a[0] = e_add(a[0], e_mul_f(xb, xa));
+                            a[2] = e_add(a[2], e_mul_f(b2, a2));
+                        } else {
+                            E xa = A.ep[2 * j], ya = A.ep[2 * j + 1];
+                            E a2 = e_sub(e_dbl(ya), xa);
+                            a[0] = e_add(a[0], e_mul(xb, xa));
+                            a[2] = e_add(a[2], e_mul(b2, a2));
+                        }
                     }
                 }
             }
@@ -176,24 +198,31 @@ static inline void sc_round_evals(const ScFunc& g, const std::vector<ScTable>& T
 }
 
 static inline void sc_fold(std::vector<ScTable>& T, E r) {
+    const size_t half = T[0].n >> 1;
     for (auto& t : T) {
-        size_t half = t.n >> 1;
-        std::vector<E> nv(half);
-        if (t.base) {
-            const uint64_t* p = t.fp;
-#pragma omp parallel for schedule(static)
-            for (long long j = 0; j < (long long)half; j++) {
-                uint64_t x = p[2 * j], y = p[2 * j + 1];
-                nv[j] = e_add_f(e_mul_f(r, f_sub(y, x)), x);
-            }
-        } else {
-#pragma omp parallel for schedule(static)
-            for (long long j = 0; j < (long long)half; j++) {
-                E x = t.e[2 * j], y = t.e[2 * j + 1];
-                nv[j] = e_add(x, e_mul(r, e_sub(y, x)));
+        int dst = t.base || t.ep != t.own[t.cur].get() ? 0 : 1 - t.cur;
+        if (!t.own[dst]) t.own[dst].reset(new E[half ? half : 1]);
+    }
+    const size_t BLK = 1024, nblk = (half + BLK - 1) / BLK;
+#pragma omp parallel for schedule(static) collapse(2)
+    for (long long ti = 0; ti < (long long)T.size(); ti++)
+        for (long long bb = 0; bb < (long long)nblk; bb++) {
+            ScTable& t = T[ti];
+            int dst = t.base || t.ep != t.own[t.cur].get() ? 0 : 1 - t.cur;
+            E* o = t.own[dst].get();
+            size_t j0 = (size_t)bb * BLK, j1 = std::min(half, j0 + BLK);
+            if (t.base) {
+                const uint64_t* p = t.fp;
+                for (size_t j = j0; j < j1; j++) { uint64_t x = p[2 * j], y = p[2 * j + 1]; o[j] = e_add_f(e_mul_f(r, f_sub(y, x)), x); }
+            } else {
+                const E* p = t.ep;
+                for (size_t j = j0; j < j1; j++) { E x = p[2 * j], y = p[2 * j + 1]; o[j] = e_add(x, e_mul(r, e_sub(y, x))); }
             }
         }
-        t.e.swap(nv);
+    for (auto& t : T) {
+        int dst = t.base || t.ep != t.own[t.cur].get() ? 0 : 1 - t.cur;
+        t.cur = dst;
+        t.ep = t.own[dst].get();
         t.base = false;
         t.fp = nullptr;
         t.n = half;

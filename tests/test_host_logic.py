@@ -1,0 +1,131 @@
+"""CPU-only tests of the product's host logic and of the C-ABI surface (no GPU compute):
+library loads and exports every symbol include/hg.h declares, Fiat-Shamir chain KATs, JSON loader vs a
+Python restatement of get_inputs, Lasso preprocessing map, circuit wiring (sum == ct0is), synthetic witness."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import orclib
+from hglib import hg, ROOT
+
+
+def test_c_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "hg.h")).read()
+    declared = set(re.findall(r"\b(hg_[a-z_0-9]+)\s*\(", hdr))
+    lib = C.CDLL(os.path.join(ROOT, "hyper-greco_amd", "libhypergreco.so"))
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/hg.h but not exported"
+    assert declared == set(hg.EXPORTS)
+
+
+def test_no_device_fails_loudly():
+    if hg.lib().hg_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(hg.HgError, match="no HIP device"):
+        hg.Context(0)
+
+
+def test_product_never_links_the_oracle():
+    # the product sources may not include / link / call anything under oracle/
+    src = os.path.join(ROOT, "hyper-greco_amd")
+    for dp, _, files in os.walk(src):
+        for f in files:
+            if f.endswith((".hip", ".cpp", ".hpp", ".cuh", ".py", "Makefile")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "oracle/" not in txt.replace("lives in oracle/", "") and "liboracle" not in txt and "orclib" not in txt, f
+
+
+def test_challenge_chain_kats():
+    c = hg.challenges(4)
+    assert [int(x) for x in c] == [15017384644633299356, 6854594310142832579, 9149254073876997563, 1396060396769822097]
+    # grows consistently
+    big = hg.challenges(20000)
+    assert (big[:4] == c).all()
+    ref = np.zeros(64, dtype=np.uint64)
+    orclib.lib().orc_challenge_chain(C.c_size_t(64), orclib.ptr(ref))
+    assert (big[:64] == ref).all()
+
+
+def test_builtin_params_match_reference_constants():
+    for key, c in [((1024, 1), orclib.constants(1024, 1)), ((4096, 2), orclib.constants(4096, 2)), ((32768, 16), orclib.constants(32768, 16)),
+                   ((2048, 1), orclib.constants(2048, 1)), ((8192, 4), orclib.constants(8192, 4)), ((16384, 8), orclib.constants(16384, 8))]:
+        p = hg.params_builtin(*key)
+        assert (p.n, p.k, p.s_bound, p.e_bound, p.k1_bound) == (c["n"], c["k"], c["s_bound"], c["e_bound"], c["k1_bound"])
+        for f in ("r1_bounds", "r2_bounds", "qis", "k0is"):
+            assert list(getattr(p, f))[:p.k] == c[f]
+    with pytest.raises(hg.HgError):
+        hg.params_builtin(1000, 3)
+
+
+@pytest.mark.parametrize("n,k,bits", [(1024, 1, 27), (4096, 2, 55)])
+def test_json_loader_matches_get_inputs(n, k, bits):
+    p = hg.params_builtin(n, k)
+    w = hg.Witness.from_json(p, os.path.join(orclib.GOLDEN, f"sk_enc_{n}_{k}x{bits}_65537.json"))
+    a = w.arrays()
+    ref = orclib.fixture_inputs(n, k, bits)
+    for f in a:
+        assert (a[f] == ref.d[f]).all(), f
+
+
+def test_json_loader_rejects_malformed(tmp_path):
+    p = hg.params_builtin(1024, 1)
+    bad = tmp_path / "bad.json"
+    bad.write_text('{"s": ["1", "x"]}')
+    with pytest.raises(hg.HgError):
+        hg.Witness.from_json(p, str(bad))
+    bad.write_text('{"s": ["18446744069414584321"]}')  # = p, not canonical
+    with pytest.raises(hg.HgError):
+        hg.Witness.from_json(p, str(bad))
+    with pytest.raises(hg.HgError):
+        hg.Witness.from_json(p, str(tmp_path / "missing.json"))
+
+
+@pytest.mark.parametrize("n,k", [(1024, 1), (4096, 2), (32768, 16)])
+def test_lasso_preprocessing_matches_oracle_and_survey(n, k):
+    pk = hg.BfvEncrypt.new(n, k).setup(None)  # host-only key
+    assert pk.lasso_layout() == orclib.lasso_layout(orclib.params(n, k))
+    chunks = max(1, k // 2)
+    assert pk.num_nodes == 5 * k + 14 + chunks
+    assert pk.rows == (k + chunks + 3) * 2 * n
+    pk.free()
+
+
+@pytest.mark.parametrize("n,k,bits", [(1024, 1, 27), (4096, 2, 55)])
+def test_circuit_wiring_on_fixtures(n, k, bits):
+    bfv = hg.BfvEncrypt.new(n, k)
+    pk = bfv.setup(None)
+    w = bfv.get_inputs(os.path.join(orclib.GOLDEN, f"sk_enc_{n}_{k}x{bits}_65537.json"))
+    lasso_in, sum_out = pk.circuit_eval(w)
+    assert (sum_out == w.arrays()["ct0is"]).all()
+    o_lasso, o_sum, _ = orclib.circuit_eval(orclib.params(n, k), orclib.Inputs(w.arrays()))
+    assert (lasso_in == o_lasso).all() and (sum_out == o_sum).all()
+    pk.free()
+
+
+@pytest.mark.parametrize("n,k", [(1024, 1), (4096, 2), (8192, 4)])
+def test_synthetic_witness_satisfies_circuit_and_bounds(n, k):
+    bfv = hg.BfvEncrypt.new(n, k)
+    pk = bfv.setup(None)
+    w = hg.Witness.synthetic(bfv.params, 0x4752454330 + n)
+    w2 = hg.Witness.synthetic(bfv.params, 0x4752454330 + n)
+    a = w.arrays()
+    assert all((a[f] == w2.arrays()[f]).all() for f in a)  # seeded, deterministic
+    lasso_in, sum_out = pk.circuit_eval(w)
+    assert (sum_out == a["ct0is"]).all()  # the encryption relation holds in the field
+    c = orclib.constants(n, k)
+    SZ = 2 * n
+    chunks = max(1, k // 2)
+    bounds = c["r1_bounds"][:k] + [c["r2_bounds"][0]] * chunks + [c["s_bound"], c["e_bound"], c["k1_bound"]]
+    for i, b in enumerate(bounds):
+        assert int(lasso_in[i * SZ:(i + 1) * SZ].max()) <= 2 * b
+    # and the oracle accepts its own proof on it
+    p = orclib.params(n, k)
+    inp = orclib.Inputs(a)
+    if n <= 4096:
+        proof, _ = orclib.prove(p, inp, threads=4)
+        ok, err = orclib.verify(p, inp, proof)
+        assert ok, err
+    pk.free()
