@@ -38,7 +38,7 @@ class HgKernelStat(C.Structure):
 EXPORTS = [
     "hg_last_error", "hg_device_count", "hg_create", "hg_destroy", "hg_params_builtin", "hg_setup", "hg_pk_free",
     "hg_pk_lasso_layout", "hg_pk_info", "hg_witness_from_json", "hg_witness_synthetic", "hg_witness_from_arrays",
-    "hg_witness_get", "hg_witness_free", "hg_prove", "hg_circuit_eval", "hg_lasso_prove", "hg_sumcheck", "hg_mle_eval",
+    "hg_witness_get", "hg_witness_free", "hg_prove", "hg_witness_gen", "hg_values_free", "hg_prove_resident", "hg_circuit_eval", "hg_lasso_prove", "hg_sumcheck", "hg_mle_eval",
     "hg_ntt", "hg_challenges", "hg_profile", "hg_profile_reset", "hg_profile_get",
 ]
 
@@ -76,6 +76,9 @@ def lib():
         L.hg_witness_get.argtypes = [C.c_void_p, C.c_int, u64p, C.c_size_t]
         L.hg_witness_free.argtypes = [C.c_void_p]
         L.hg_prove.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(HgTimings)]
+        L.hg_witness_gen.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(HgTimings)]
+        L.hg_values_free.argtypes = [C.c_void_p]
+        L.hg_prove_resident.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(HgTimings)]
         L.hg_circuit_eval.argtypes = [C.c_void_p, C.c_void_p, u64p, C.c_size_t, u64p, C.c_size_t]
         L.hg_lasso_prove.argtypes = [C.c_void_p, C.c_void_p, u64p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), u64p]
         L.hg_sumcheck.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(u64p), C.POINTER(C.c_int), u64p, C.c_size_t,
@@ -269,6 +272,47 @@ class BfvEncrypt:
         tm = HgTimings()
         _check(lib().hg_prove(ctx.h, pk.h, witness.h, buf, cap, C.byref(ln), C.byref(tm)))
         return bytes(buf[:ln.value]), {f: getattr(tm, f) for f, _ in HgTimings._fields_}
+
+
+class ResidentValues:
+    """circuit.evaluate() output kept in HBM (hg_values)."""
+
+    def __init__(self, handle, timings):
+        self.h = handle
+        self.timings = timings
+
+    def free(self):
+        if self.h:
+            lib().hg_values_free(self.h)
+            self.h = None
+
+
+def witness_gen(ctx, pk, witness):
+    h = C.c_void_p()
+    tm = HgTimings()
+    _check(lib().hg_witness_gen(ctx.h, pk.h, witness.h, C.byref(h), C.byref(tm)))
+    return ResidentValues(h, {f: getattr(tm, f) for f, _ in HgTimings._fields_})
+
+
+class ProofBuffer:
+    """Reusable output buffer so the timed loop does no Python-side allocation."""
+
+    def __init__(self, cap=1 << 22):
+        self.cap = cap
+        self.buf = (C.c_uint8 * cap)()
+        self.len = C.c_size_t(0)
+        self.tm = HgTimings()
+
+    def bytes(self):
+        return bytes(self.buf[:self.len.value])
+
+    def timings(self):
+        return {f: getattr(self.tm, f) for f, _ in HgTimings._fields_}
+
+
+def prove_resident(ctx, pk, values, out):
+    _check(lib().hg_prove_resident(ctx.h, pk.h, values.h, out.buf, out.cap, C.byref(out.len), C.byref(out.tm)))
+    return out
 
 
 class LassoNode:

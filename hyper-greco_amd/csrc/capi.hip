@@ -244,14 +244,44 @@ int64_t hg_witness_get(const hg_witness* w, int which, uint64_t* out, size_t cap
 
 void hg_witness_free(hg_witness* w) { delete w; }
 
+int hg_witness_gen(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, hg_values** out, hg_timings* timings) {
+    HG_TRY
+    if (!ctx || !pk || !w || !pk->ctx) throw Error("hg_witness_gen: needs a device context and a device prover key");
+    double wm = 0, um = 0;
+    *out = witness_gen(ctx, pk, w->w, &wm, &um);
+    if (timings) { memset(timings, 0, sizeof(*timings)); timings->witness_ms = wm; timings->upload_ms = um; }
+    return 0;
+    HG_CATCH(-1)
+}
+
+void hg_values_free(hg_values* v) { values_free(v); }
+
+static double now_ms_capi() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+int hg_prove_resident(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, uint8_t* proof, size_t cap, size_t* len, hg_timings* timings) {
+    HG_TRY
+    if (!ctx || !pk || !v || !pk->ctx) throw Error("hg_prove_resident: needs a device context, a device prover key and resident values");
+    double t0 = now_ms_capi();
+    ProveResult r = prove_resident(ctx, pk, v);
+    if (timings) { memset(timings, 0, sizeof(*timings)); timings->prove_ms = r.prove_ms; timings->gpu_ms = r.gpu_ms; timings->total_ms = now_ms_capi() - t0; }
+    *len = r.proof.size();
+    if (r.proof.size() > cap) throw Error("proof buffer too small");
+    memcpy(proof, r.proof.data(), r.proof.size());
+    return 0;
+    HG_CATCH(-1)
+}
+
 int hg_prove(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, uint8_t* proof, size_t cap, size_t* len, hg_timings* timings) {
     HG_TRY
     if (!ctx || !pk || !w) throw Error("hg_prove: null argument");
     if (!pk->ctx) throw Error("hg_prove: host-only prover key (created without a context)");
-    double t0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
-    ProveResult r = prove_full(ctx, pk, w->w);
-    double t1 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
-    if (timings) { timings->witness_ms = r.witness_ms; timings->upload_ms = r.upload_ms; timings->prove_ms = r.prove_ms; timings->gpu_ms = r.gpu_ms; timings->total_ms = t1 - t0; }
+    double t0 = now_ms_capi();
+    double wm = 0, um = 0;
+    hg_values* v = witness_gen(ctx, pk, w->w, &wm, &um);
+    ProveResult r;
+    try { r = prove_resident(ctx, pk, v); } catch (...) { values_free(v); throw; }
+    values_free(v);
+    if (timings) { timings->witness_ms = wm; timings->upload_ms = um; timings->prove_ms = r.prove_ms; timings->gpu_ms = r.gpu_ms; timings->total_ms = now_ms_capi() - t0; }
     *len = r.proof.size();
     if (r.proof.size() > cap) throw Error("proof buffer too small");
     memcpy(proof, r.proof.data(), r.proof.size());

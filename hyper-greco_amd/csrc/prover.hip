@@ -2,6 +2,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstring>
+#include <memory>
 
 namespace hg {
 
@@ -594,32 +595,52 @@ struct Prover {
 };
 
 // ------------------------------------------------------------------------------------------------
-ProveResult prove_full(hg_ctx* ctx, const hg_pk* pk, const Witness& w) {
+hg_values* witness_gen(hg_ctx* ctx, const hg_pk* pk, const Witness& w, double* witness_ms, double* upload_ms) {
+    hip_check(hipSetDevice(ctx->device), "hipSetDevice");
+    const HCircuit& c = pk->circuit;
+    double t0 = wall_ms();
+    std::vector<std::vector<u64>> vals = circuit_evaluate(c, pk->params, w);  // witness generation (host, OpenMP)
+    double t1 = wall_ms();
+    std::unique_ptr<hg_values> v(new hg_values());
+    v->d_vals.assign(c.nodes.size(), nullptr);
+    size_t total = w.ct0is.size();
+    for (size_t id = 0; id < c.nodes.size(); id++) if (!c.nodes[id].succs.empty()) total += vals[id].size();
+    u64* base = nullptr;
+    hip_check(hipMalloc((void**)&base, total * 8), "hipMalloc(node values)");
+    v->owned.push_back(base);
+    size_t off = 0;
+    for (size_t id = 0; id < c.nodes.size(); id++) {
+        if (c.nodes[id].succs.empty()) continue;  // outputs are never read by a reduction
+        hip_check(hipMemcpyAsync(base + off, vals[id].data(), vals[id].size() * 8, hipMemcpyHostToDevice, ctx->stream), "upload node values");
+        v->d_vals[id] = base + off;
+        off += vals[id].size();
+    }
+    hip_check(hipMemcpyAsync(base + off, w.ct0is.data(), w.ct0is.size() * 8, hipMemcpyHostToDevice, ctx->stream), "upload ct0is");
+    v->d_ct0is = base + off;
+    hip_check(hipStreamSynchronize(ctx->stream), "upload sync");
+    double t2 = wall_ms();
+    if (witness_ms) *witness_ms = t1 - t0;
+    if (upload_ms) *upload_ms = t2 - t1;
+    return v.release();
+}
+
+void values_free(hg_values* v) {
+    if (!v) return;
+    for (void* p : v->owned) (void)hipFree(p);
+    delete v;
+}
+
+ProveResult prove_resident(hg_ctx* ctx, const hg_pk* pk, const hg_values* v) {
     ProveResult res;
     hip_check(hipSetDevice(ctx->device), "hipSetDevice");
     ctx->arena_reset();
     const Params& p = pk->params;
-    const HCircuit& c = pk->circuit;
-    double t0 = wall_ms();
-    std::vector<std::vector<u64>> vals = circuit_evaluate(c, p, w);  // witness generation (host, OpenMP)
-    double t1 = wall_ms();
-    res.witness_ms = t1 - t0;
+    double t3 = wall_ms();
     Prover P(ctx, pk);
-    // node values -> HBM
-    P.d_vals.assign(c.nodes.size(), nullptr);
-    for (size_t id = 0; id < c.nodes.size(); id++) {
-        if (c.nodes[id].succs.empty()) continue;  // outputs are never read by a reduction
-        u64* d = ctx->alloc_n<u64>(vals[id].size());
-        hip_check(hipMemcpyAsync(d, vals[id].data(), vals[id].size() * 8, hipMemcpyHostToDevice, ctx->stream), "upload node values");
-        P.d_vals[id] = d;
-    }
-    u64* d_ct0 = ctx->alloc_n<u64>(w.ct0is.size());
-    hip_check(hipMemcpyAsync(d_ct0, w.ct0is.data(), w.ct0is.size() * 8, hipMemcpyHostToDevice, ctx->stream), "upload ct0is");
-    hip_check(hipStreamSynchronize(ctx->stream), "upload sync");
-    double t2 = wall_ms();
-    res.upload_ms = t2 - t1;
+    P.d_vals = v->d_vals;
     hipEvent_t ev_a, ev_b;
     hip_check(hipEventCreate(&ev_a), "event"); hip_check(hipEventCreate(&ev_b), "event");
+    hip_check(hipEventRecord(ev_a, ctx->stream), "event record");
     // "eval output" (sk_encryption_circuit.rs:444-448): point, ct0is MLE value
     const int ov = p.ct0is_log2();
     size_t point_off = P.epos();
@@ -628,14 +649,12 @@ ProveResult prove_full(hg_ctx* ctx, const hg_pk* pk, const Witness& w) {
     {
         E2* eq = ctx->alloc_n<E2>((size_t)1 << ov);
         dev::eq_table(ctx->stream, eq, ov, ctx->d_chal, point_off);
-        const u64* tabs[8] = {d_ct0};
+        const u64* tabs[8] = {v->d_ct0is};
         int grid = dev::dot_eq(ctx->stream, eq, tabs, 1, (size_t)1 << ov, ctx->d_partials);
         P.reduce(grid, 1, vslot);
     }
     Cell out_value = cell();
     P.ops.push_back([&P, out_value, vslot] { *out_value = P.h_res()[vslot]; });
-    hip_check(hipEventRecord(ev_a, ctx->stream), "event record");
-    double t3 = wall_ms();
     P.gkr(ClaimRef{point_off, ov, out_value});
     hip_check(hipEventRecord(ev_b, ctx->stream), "event record");
     P.finish();

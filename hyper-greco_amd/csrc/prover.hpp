@@ -77,6 +77,12 @@ struct hg_pk {
     explicit hg_pk(const hg_params& p) : params(p) {}
 };
 
+struct hg_values {
+    std::vector<const hg::u64*> d_vals;  // per node (nullptr for pure outputs)
+    const hg::u64* d_ct0is = nullptr;
+    std::vector<void*> owned;
+};
+
 namespace hg {
 
 struct ProveResult {
@@ -84,7 +90,9 @@ struct ProveResult {
     double witness_ms = 0, upload_ms = 0, prove_ms = 0, gpu_ms = 0;
 };
 
-ProveResult prove_full(hg_ctx* ctx, const hg_pk* pk, const Witness& w);
+hg_values* witness_gen(hg_ctx* ctx, const hg_pk* pk, const Witness& w, double* witness_ms, double* upload_ms);
+void values_free(hg_values* v);
+ProveResult prove_resident(hg_ctx* ctx, const hg_pk* pk, const hg_values* v);
 // Lasso node alone on a fresh transcript; claim_out = nu point coordinates then the value
 std::vector<uint8_t> prove_lasso_node(hg_ctx* ctx, const hg_pk* pk, const u64* lasso_in_host, std::vector<E2>* claim_out);
 // one sum-check on caller tables (kernel-level parity entry point)
