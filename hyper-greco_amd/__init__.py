@@ -28,7 +28,7 @@ class HgParams(C.Structure):
 
 class HgTimings(C.Structure):
     _fields_ = [("witness_ms", C.c_double), ("upload_ms", C.c_double), ("prove_ms", C.c_double), ("gpu_ms", C.c_double),
-                ("total_ms", C.c_double)]
+                ("total_ms", C.c_double), ("enqueue_ms", C.c_double), ("sync_ms", C.c_double), ("replay_ms", C.c_double)]
 
 
 class HgKernelStat(C.Structure):

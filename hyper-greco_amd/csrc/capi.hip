@@ -61,7 +61,9 @@ hg_ctx* hg_create(int device_id) {
     c->res_cap = (size_t)1 << 17;
     hip_check(hipMalloc((void**)&c->d_res, c->res_cap * sizeof(E2)), "hipMalloc(results)");
     hip_check(hipHostMalloc((void**)&c->h_res, c->res_cap * sizeof(E2), hipHostMallocDefault), "hipHostMalloc(results)");
-    hip_check(hipMalloc((void**)&c->d_partials, (size_t)dev::SC_MAX_BLOCKS * 8 * sizeof(E2)), "hipMalloc(partials)");
+    hip_check(hipMalloc((void**)&c->d_partials, (size_t)dev::SC_MAX_BLOCKS * 3 * 64 * sizeof(E2)), "hipMalloc(partials)");
+    c->stage_cap = (size_t)4 << 20;
+    hip_check(hipHostMalloc((void**)&c->h_stage, c->stage_cap, hipHostMallocDefault), "hipHostMalloc(staging)");
     c->ensure_chain(16384);
     return c;
     HG_CATCH(nullptr)
@@ -263,7 +265,7 @@ int hg_prove_resident(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, uint8_t*
     if (!ctx || !pk || !v || !pk->ctx) throw Error("hg_prove_resident: needs a device context, a device prover key and resident values");
     double t0 = now_ms_capi();
     ProveResult r = prove_resident(ctx, pk, v);
-    if (timings) { memset(timings, 0, sizeof(*timings)); timings->prove_ms = r.prove_ms; timings->gpu_ms = r.gpu_ms; timings->total_ms = now_ms_capi() - t0; }
+    if (timings) { memset(timings, 0, sizeof(*timings)); timings->prove_ms = r.prove_ms; timings->gpu_ms = r.gpu_ms; timings->total_ms = now_ms_capi() - t0; timings->enqueue_ms = r.enqueue_ms; timings->sync_ms = r.sync_ms; timings->replay_ms = r.replay_ms; }
     *len = r.proof.size();
     if (r.proof.size() > cap) throw Error("proof buffer too small");
     memcpy(proof, r.proof.data(), r.proof.size());
@@ -281,7 +283,7 @@ int hg_prove(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, uint8_t* proof, 
     ProveResult r;
     try { r = prove_resident(ctx, pk, v); } catch (...) { values_free(v); throw; }
     values_free(v);
-    if (timings) { timings->witness_ms = wm; timings->upload_ms = um; timings->prove_ms = r.prove_ms; timings->gpu_ms = r.gpu_ms; timings->total_ms = now_ms_capi() - t0; }
+    if (timings) { timings->witness_ms = wm; timings->upload_ms = um; timings->prove_ms = r.prove_ms; timings->gpu_ms = r.gpu_ms; timings->total_ms = now_ms_capi() - t0; timings->enqueue_ms = r.enqueue_ms; timings->sync_ms = r.sync_ms; timings->replay_ms = r.replay_ms; }
     *len = r.proof.size();
     if (r.proof.size() > cap) throw Error("proof buffer too small");
     memcpy(proof, r.proof.data(), r.proof.size());

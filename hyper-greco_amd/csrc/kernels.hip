@@ -85,22 +85,29 @@ __device__ __forceinline__ void store_e2(E2* p, E2 v) {
     *reinterpret_cast<ulonglong2*>(p) = make_ulonglong2(v.c0, v.c1);
 }
 
+// ---- one sum-check round as a device function ---------------------------------------------------
+// Thread mapping inside a workgroup of BD threads: JB = 2^jb_log2 threads along the pair index j
+// (coalesced) times G = BD/JB groups along the table index i. Large rounds use JB = BD (one thread per
+// pair, serial loop over tables); small rounds trade j-parallelism for i-parallelism so that the
+// serial per-thread loop over the tables (a dependent chain of HBM/L2 latencies) shrinks to
+// ceil(nb / G) iterations. Partial sums over the groups are combined through LDS (`red`: NV*BD E2)
+// BEFORE the multiplication by p_0, which is what the quirky g = p_0 * (sum_i ..) needs.
 template <int KIND, typename T>
-__global__ __launch_bounds__(TPB) void k_sc_round(const T* __restrict__ in, size_t in_stride, E2* __restrict__ out,
-                                                  size_t out_stride, int ntab, size_t half, E2 r, Powers pw,
-                                                  E2* __restrict__ partials) {
+__device__ __forceinline__ void sc_round_body(const T* __restrict__ in, size_t in_stride, E2* __restrict__ out,
+                                              size_t out_stride, int ntab, size_t half, E2 r, const E2* __restrict__ pw, int jb_log2,
+                                              E2* __restrict__ red, E2* acc, size_t first_tile, size_t tile_step) {
     using V = Val<T>;
-    constexpr int NV = KIND == SC_GRANDPROD ? 3 : 2;
-    __shared__ E2 sm[TPB / 64];
-    E2 acc[NV];
-#pragma unroll
-    for (int t = 0; t < NV; t++) acc[t] = e2_zero();
-    for (size_t j = (size_t)blockIdx.x * TPB + threadIdx.x; j < half; j += (size_t)gridDim.x * TPB) {
+    const int BD = blockDim.x, tid = threadIdx.x;
+    const int G = BD >> jb_log2;
+    const int jj = tid & ((1 << jb_log2) - 1), g = tid >> jb_log2;
+    const size_t ntiles = half >> jb_log2;  // host guarantees 2^jb_log2 <= half
+    for (size_t tile = first_tile; tile < ntiles; tile += tile_step) {
+        const size_t j = (tile << jb_log2) + jj;
         if constexpr (KIND == SC_GRANDPROD) {
             E2 s0 = e2_zero(), s2 = e2_zero(), s3 = e2_zero();
             T p0 = V::zero(), p2 = V::zero(), p3 = V::zero();
             const int nb = ntab >> 1;
-            for (int i = 0; i < nb; i++) {
+            for (int i = g; i < nb; i += G) {
                 T xl, yl, xr, yr;
                 load_pair<T>(in + (size_t)(2 * i) * in_stride + 2 * j, xl, yl);
                 load_pair<T>(in + (size_t)(2 * i + 1) * in_stride + 2 * j, xr, yr);
@@ -108,25 +115,39 @@ __global__ __launch_bounds__(TPB) void k_sc_round(const T* __restrict__ in, size
                 T l2 = V::add(yl, dl), r2 = V::add(yr, dr);
                 T l3 = V::add(l2, dl), r3 = V::add(r2, dr);
                 if (i == 0) { p0 = xl; p2 = l2; p3 = l3; }
-                E2 g = pw.v[i];
-                s0 = e2_add(s0, V::scale(g, V::mul(xl, xr)));
-                s2 = e2_add(s2, V::scale(g, V::mul(l2, r2)));
-                s3 = e2_add(s3, V::scale(g, V::mul(l3, r3)));
+                E2 gm = pw[i];
+                s0 = e2_add(s0, V::scale(gm, V::mul(xl, xr)));
+                s2 = e2_add(s2, V::scale(gm, V::mul(l2, r2)));
+                s3 = e2_add(s3, V::scale(gm, V::mul(l3, r3)));
                 store_e2(out + (size_t)(2 * i) * out_stride + j, V::fold(xl, dl, r));
                 store_e2(out + (size_t)(2 * i + 1) * out_stride + j, V::fold(xr, dr, r));
             }
-            acc[0] = e2_add(acc[0], V::scale(s0, p0));
-            acc[1] = e2_add(acc[1], V::scale(s2, p2));
-            acc[2] = e2_add(acc[2], V::scale(s3, p3));
+            if (G > 1) {
+                red[tid] = s0; red[BD + tid] = s2; red[2 * BD + tid] = s3;
+                __syncthreads();
+                if (g == 0) {
+                    const int gmax = G < nb ? G : nb;
+                    for (int gg = 1; gg < gmax; gg++) {
+                        int o = (gg << jb_log2) + jj;
+                        s0 = e2_add(s0, red[o]); s2 = e2_add(s2, red[BD + o]); s3 = e2_add(s3, red[2 * BD + o]);
+                    }
+                }
+                __syncthreads();
+            }
+            if (g == 0) {
+                acc[0] = e2_add(acc[0], V::scale(s0, p0));
+                acc[1] = e2_add(acc[1], V::scale(s2, p2));
+                acc[2] = e2_add(acc[2], V::scale(s3, p3));
+            }
         } else {
             T s0 = V::zero(), s2 = V::zero(), p0 = V::zero(), p2 = V::zero();
-            for (int i = 0; i < ntab; i++) {
+            for (int i = g; i < ntab; i += G) {
                 T x, y;
                 load_pair<T>(in + (size_t)i * in_stride + 2 * j, x, y);
                 T d = V::sub(y, x);
                 T v2 = V::add(y, d);
                 if (i == 0) { p0 = x; p2 = v2; }
-                u64 m = pw.v[i].c0;  // M^i is a base-field constant
+                u64 m = pw[i].c0;  // M^i is a base-field constant
                 if constexpr (std::is_same<T, u64>::value) {
                     s0 = gl_add(s0, gl_mul(m, x));
                     s2 = gl_add(s2, gl_mul(m, v2));
@@ -136,61 +157,259 @@ __global__ __launch_bounds__(TPB) void k_sc_round(const T* __restrict__ in, size
                 }
                 store_e2(out + (size_t)i * out_stride + j, V::fold(x, d, r));
             }
-            acc[0] = e2_add(acc[0], V::lift(V::mul(p0, s0)));
-            acc[1] = e2_add(acc[1], V::lift(V::mul(p2, s2)));
+            E2 t0 = V::lift(s0), t2 = V::lift(s2);
+            if (G > 1) {
+                red[tid] = t0; red[BD + tid] = t2;
+                __syncthreads();
+                if (g == 0) {
+                    const int gmax = G < ntab ? G : ntab;
+                    for (int gg = 1; gg < gmax; gg++) {
+                        int o = (gg << jb_log2) + jj;
+                        t0 = e2_add(t0, red[o]); t2 = e2_add(t2, red[BD + o]);
+                    }
+                }
+                __syncthreads();
+            }
+            if (g == 0) {
+                acc[0] = e2_add(acc[0], e2_mul(V::lift(p0), t0));
+                acc[1] = e2_add(acc[1], e2_mul(V::lift(p2), t2));
+            }
         }
     }
+}
+
+// sums `v` over a workgroup of any size (multiple of 64, <= 1024); result valid in thread 0
+__device__ __forceinline__ E2 block_sum_n(E2 v, E2* sm /* >= 16 */) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) sm[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) for (int w = 1; w < nw; w++) v = e2_add(v, sm[w]);
+    return v;
+}
+
+extern __shared__ E2 dyn_lds[];  // [16 block-sum slots][NV * BD reduction slots]
+
+// ---- stride-layout sum-check jobs, batched over grid.y ---------------------------------------------------
+// Round rd of job J reads tables of length 2h (h = 2^(nvars-1-rd)) at stride 2h (round 0: J.in / J.in_stride)
+// and writes the folded tables at stride h into the ping-pong buffers (last round: J.final_out, stride 1).
+__device__ __forceinline__ void st_io(const StJob& J, int rd, const void*& in, size_t& in_stride, E2*& out) {
+    const size_t h = (size_t)1 << (J.nvars - 1 - rd);
+    if (rd == 0) { in = J.in; in_stride = J.in_stride; }
+    else { in = J.buf[(rd - 1) & 1]; in_stride = 2 * h; }
+    out = rd == J.nvars - 1 ? J.final_out : J.buf[rd & 1];
+}
+
+// one step of the size-synchronised schedule: every listed job runs its round with half = 2^h_log2
+template <int KIND, typename T>
+__global__ __launch_bounds__(256) void k_st_step(const StJob* __restrict__ jobs, const int* __restrict__ list, int h_log2,
+                                                 const E2* __restrict__ chal, int jb_log2, E2* __restrict__ partials,
+                                                 E2* __restrict__ res) {
+    constexpr int NV = KIND == SC_GRANDPROD ? 3 : 2;
+    const StJob& J = jobs[list[blockIdx.y]];
+    const int rd = J.nvars - 1 - h_log2;
+    const size_t half = (size_t)1 << h_log2;
+    const void* in; size_t in_stride; E2* out;
+    st_io(J, rd, in, in_stride, out);
+    E2* sm = dyn_lds;
+    E2* red = dyn_lds + 16;
+    E2 acc[NV];
+#pragma unroll
+    for (int t = 0; t < NV; t++) acc[t] = e2_zero();
+    sc_round_body<KIND, T>(reinterpret_cast<const T*>(in), in_stride, out, half, J.ntab, half, chal[J.r_off + rd], J.pw, jb_log2, red,
+                           acc, blockIdx.x, gridDim.x);
 #pragma unroll
     for (int t = 0; t < NV; t++) {
-        E2 s = block_sum(acc[t], sm);
-        if (threadIdx.x == 0) partials[(size_t)blockIdx.x * NV + t] = s;
+        E2 s = block_sum_n(acc[t], sm);
+        if (threadIdx.x == 0) {
+            if (gridDim.x == 1) res[J.sums_slot + (size_t)rd * NV + t] = s;
+            else partials[((size_t)blockIdx.y * SC_MAX_BLOCKS + blockIdx.x) * NV + t] = s;
+        }
     }
 }
-
-int sc_round(hipStream_t st, int kind, bool base, const void* in, size_t in_stride, E2* out, size_t out_stride, int ntab,
-             size_t half, E2 r, const Powers& pw, E2* partials) {
-    int grid = grid_for(half);
-    if (kind == SC_GRANDPROD) {
-        if (base) k_sc_round<SC_GRANDPROD, u64><<<grid, TPB, 0, st>>>((const u64*)in, in_stride, out, out_stride, ntab, half, r, pw, partials);
-        else k_sc_round<SC_GRANDPROD, E2><<<grid, TPB, 0, st>>>((const E2*)in, in_stride, out, out_stride, ntab, half, r, pw, partials);
-    } else {
-        if (base) k_sc_round<SC_COLLATION, u64><<<grid, TPB, 0, st>>>((const u64*)in, in_stride, out, out_stride, ntab, half, r, pw, partials);
-        else k_sc_round<SC_COLLATION, E2><<<grid, TPB, 0, st>>>((const E2*)in, in_stride, out, out_stride, ntab, half, r, pw, partials);
-    }
-    return grid;
-}
-
-// Sum-check round for g = sum_i a_i * b_i (Libra / zkCNN reductions), pointer-list layout.
-template <typename TA>
-__global__ __launch_bounds__(TPB) void k_sc_round_ps(PsTables t, size_t half, E2 r, E2* __restrict__ partials) {
-    using V = Val<TA>;
+__global__ __launch_bounds__(TPB) void k_st_reduce(const StJob* __restrict__ jobs, const int* __restrict__ list, int h_log2, int nv,
+                                                   const E2* __restrict__ partials, int nblocks, E2* __restrict__ res) {
     __shared__ E2 sm[TPB / 64];
-    E2 a0 = e2_zero(), a2 = e2_zero();
-    for (size_t j = (size_t)blockIdx.x * TPB + threadIdx.x; j < half; j += (size_t)gridDim.x * TPB) {
-        for (int i = 0; i < t.npairs; i++) {
+    const StJob& J = jobs[list[blockIdx.x]];
+    const int rd = J.nvars - 1 - h_log2;
+    const E2* p = partials + (size_t)blockIdx.x * SC_MAX_BLOCKS * nv;
+    for (int v = 0; v < nv; v++) {
+        E2 a = e2_zero();
+        for (int b = threadIdx.x; b < nblocks; b += TPB) a = e2_add(a, p[(size_t)b * nv + v]);
+        a = block_sum(a, sm);
+        if (threadIdx.x == 0) res[J.sums_slot + (size_t)rd * nv + v] = a;
+    }
+}
+// all rounds with half <= 2^h_log2 of every listed job, one workgroup per job
+template <int KIND>
+__global__ __launch_bounds__(1024) void k_st_tail(const StJob* __restrict__ jobs, const int* __restrict__ list, int h_log2,
+                                                  const E2* __restrict__ chal, E2* __restrict__ res) {
+    constexpr int NV = KIND == SC_GRANDPROD ? 3 : 2;
+    const StJob& J = jobs[list[blockIdx.y]];
+    E2* sm = dyn_lds;
+    E2* red = dyn_lds + 16;
+    const int bd_log2 = 31 - __clz((int)blockDim.x);
+    int rd = J.nvars - 1 - h_log2;
+    if (rd < 0) rd = 0;
+    for (; rd < J.nvars; rd++) {
+        const int hl = J.nvars - 1 - rd;
+        const size_t half = (size_t)1 << hl;
+        const int jb_log2 = hl < bd_log2 ? hl : bd_log2;
+        const void* in; size_t in_stride; E2* out;
+        st_io(J, rd, in, in_stride, out);
+        E2 r = chal[J.r_off + rd];
+        E2 acc[NV];
+#pragma unroll
+        for (int t = 0; t < NV; t++) acc[t] = e2_zero();
+        if (rd == 0 && J.base) sc_round_body<KIND, u64>(reinterpret_cast<const u64*>(in), in_stride, out, half, J.ntab, half, r, J.pw, jb_log2, red, acc, 0, 1);
+        else sc_round_body<KIND, E2>(reinterpret_cast<const E2*>(in), in_stride, out, half, J.ntab, half, r, J.pw, jb_log2, red, acc, 0, 1);
+#pragma unroll
+        for (int t = 0; t < NV; t++) {
+            E2 s = block_sum_n(acc[t], sm);
+            if (threadIdx.x == 0) res[J.sums_slot + (size_t)rd * NV + t] = s;
+        }
+        __syncthreads();  // folded table (global, same workgroup) visible before the next round reads it
+    }
+}
+
+static inline size_t sc_lds_bytes(int nv, int bd) { return (16 + (size_t)nv * bd) * sizeof(E2); }
+
+int st_step(hipStream_t st, int kind, bool base, const StJob* jobs, const int* list, int njobs, int h_log2, const E2* chal,
+            E2* partials, E2* res) {
+    const size_t half = (size_t)1 << h_log2;
+    int jb_log2 = 8;
+    while (jb_log2 > 2 && ((size_t)half * njobs << (8 - jb_log2)) < 65536) jb_log2--;
+    if (jb_log2 > h_log2) jb_log2 = h_log2;
+    size_t ntiles = half >> jb_log2;
+    int gx = (int)(ntiles > (size_t)SC_MAX_BLOCKS ? SC_MAX_BLOCKS : ntiles);
+    const int nv = kind == SC_GRANDPROD ? 3 : 2;
+    size_t lds = sc_lds_bytes(jb_log2 == 8 ? 0 : nv, 256);
+    dim3 grid(gx, njobs);
+    if (kind == SC_GRANDPROD) {
+        if (base) k_st_step<SC_GRANDPROD, u64><<<grid, 256, lds, st>>>(jobs, list, h_log2, chal, jb_log2, partials, res);
+        else k_st_step<SC_GRANDPROD, E2><<<grid, 256, lds, st>>>(jobs, list, h_log2, chal, jb_log2, partials, res);
+    } else {
+        if (base) k_st_step<SC_COLLATION, u64><<<grid, 256, lds, st>>>(jobs, list, h_log2, chal, jb_log2, partials, res);
+        else k_st_step<SC_COLLATION, E2><<<grid, 256, lds, st>>>(jobs, list, h_log2, chal, jb_log2, partials, res);
+    }
+    if (gx > 1) k_st_reduce<<<njobs, TPB, 0, st>>>(jobs, list, h_log2, nv, partials, gx, res);
+    return gx;
+}
+void st_tail(hipStream_t st, int kind, const StJob* jobs, const int* list, int njobs, int h_log2, const E2* chal, E2* res) {
+    const int nv = kind == SC_GRANDPROD ? 3 : 2;
+    const int bd = 1024;
+    size_t lds = sc_lds_bytes(nv, bd);
+    dim3 grid(1, njobs);
+    if (kind == SC_GRANDPROD) k_st_tail<SC_GRANDPROD><<<grid, bd, lds, st>>>(jobs, list, h_log2, chal, res);
+    else k_st_tail<SC_COLLATION><<<grid, bd, lds, st>>>(jobs, list, h_log2, chal, res);
+}
+
+// ---- PRODSUM: g = sum_i a_i * b_i (Libra / zkCNN reductions), batched over independent instances -----
+// Round rd of job J: inputs are a[i]/b[i] (rd = 0; a in the base field) or the ping-pong buffers; table i of
+// a buffer sits at buf + i * (current length).
+__device__ __forceinline__ void ps_io(const PsJob& J, int rd, int i, const void*& a, const E2*& b, E2*& oa, E2*& ob) {
+    const size_t N = (size_t)1 << J.nvars;
+    if (rd == 0) { a = J.a[i]; b = J.b[i]; }
+    else { size_t len = N >> rd; a = J.bufa[(rd - 1) & 1] + (size_t)i * len; b = J.bufb[(rd - 1) & 1] + (size_t)i * len; }
+    if (rd == J.nvars - 1) { oa = J.fin_a[i]; ob = J.fin_b[i]; }
+    else { size_t len = N >> (rd + 1); oa = J.bufa[rd & 1] + (size_t)i * len; ob = J.bufb[rd & 1] + (size_t)i * len; }
+}
+
+template <typename TA>
+__device__ __forceinline__ void ps_round_body(const PsJob& J, int rd, size_t half, E2 r, int jb_log2, E2& a0, E2& a2,
+                                              size_t first_tile, size_t tile_step) {
+    using V = Val<TA>;
+    const int BD = blockDim.x, tid = threadIdx.x;
+    const int G = BD >> jb_log2;
+    const int jj = tid & ((1 << jb_log2) - 1), g = tid >> jb_log2;
+    const size_t ntiles = half >> jb_log2;
+    for (size_t tile = first_tile; tile < ntiles; tile += tile_step) {
+        const size_t j = (tile << jb_log2) + jj;
+        for (int i = g; i < J.npairs; i += G) {
+            const void* pa; const E2* pb; E2* oa; E2* ob;
+            ps_io(J, rd, i, pa, pb, oa, ob);
             TA xa, ya;
             E2 xb, yb;
-            load_pair<TA>(reinterpret_cast<const TA*>(t.a[i]) + 2 * j, xa, ya);
-            load_pair<E2>(t.b[i] + 2 * j, xb, yb);
+            load_pair<TA>(reinterpret_cast<const TA*>(pa) + 2 * j, xa, ya);
+            load_pair<E2>(pb + 2 * j, xb, yb);
             TA da = V::sub(ya, xa);
             E2 db = e2_sub(yb, xb);
             a0 = e2_add(a0, V::scale(xb, xa));
             a2 = e2_add(a2, V::scale(e2_add(yb, db), V::add(ya, da)));
-            store_e2(t.oa[i] + j, V::fold(xa, da, r));
-            store_e2(t.ob[i] + j, e2_add(xb, e2_mul(r, db)));
+            store_e2(oa + j, V::fold(xa, da, r));
+            store_e2(ob + j, e2_add(xb, e2_mul(r, db)));
         }
     }
-    E2 s = block_sum(a0, sm);
-    if (threadIdx.x == 0) partials[(size_t)blockIdx.x * 2] = s;
-    s = block_sum(a2, sm);
-    if (threadIdx.x == 0) partials[(size_t)blockIdx.x * 2 + 1] = s;
 }
 
-int sc_round_prodsum(hipStream_t st, bool a_base, const PsTables& t, size_t half, E2 r, E2* partials) {
-    int grid = grid_for(half);
-    if (a_base) k_sc_round_ps<u64><<<grid, TPB, 0, st>>>(t, half, r, partials);
-    else k_sc_round_ps<E2><<<grid, TPB, 0, st>>>(t, half, r, partials);
-    return grid;
+// one round of every job of a batch (grid.y = job); all jobs of a batch have the same nvars
+__global__ __launch_bounds__(256) void k_ps_one(const PsJob* __restrict__ jobs, int rd, const E2* __restrict__ chal, int jb_log2,
+                                                E2* __restrict__ partials, E2* __restrict__ res) {
+    const PsJob& J = jobs[blockIdx.y];
+    E2* sm = dyn_lds;
+    const size_t half = (size_t)1 << (J.nvars - 1 - rd);
+    E2 r = chal[J.r_off + rd];
+    E2 a0 = e2_zero(), a2 = e2_zero();
+    if (rd == 0) ps_round_body<u64>(J, rd, half, r, jb_log2, a0, a2, blockIdx.x, gridDim.x);
+    else ps_round_body<E2>(J, rd, half, r, jb_log2, a0, a2, blockIdx.x, gridDim.x);
+    E2 s0 = block_sum_n(a0, sm);
+    E2 s2 = block_sum_n(a2, sm);
+    if (threadIdx.x == 0) {
+        if (gridDim.x == 1) { res[J.sums_slot + 2 * rd] = s0; res[J.sums_slot + 2 * rd + 1] = s2; }
+        else {
+            E2* p = partials + ((size_t)blockIdx.y * SC_MAX_BLOCKS + blockIdx.x) * 2;
+            p[0] = s0; p[1] = s2;
+        }
+    }
+}
+// rounds [rd0, nvars) of every job of a batch, one workgroup per job
+__global__ __launch_bounds__(1024) void k_ps_tail(const PsJob* __restrict__ jobs, int rd0, const E2* __restrict__ chal,
+                                                  E2* __restrict__ res) {
+    const PsJob& J = jobs[blockIdx.y];
+    E2* sm = dyn_lds;
+    int bd_log2 = 31 - __clz((int)blockDim.x);
+    for (int rd = rd0; rd < J.nvars; rd++) {
+        const int hl = J.nvars - 1 - rd;
+        const size_t half = (size_t)1 << hl;
+        const int jb_log2 = hl < bd_log2 ? hl : bd_log2;
+        E2 r = chal[J.r_off + rd];
+        E2 a0 = e2_zero(), a2 = e2_zero();
+        if (rd == 0) ps_round_body<u64>(J, rd, half, r, jb_log2, a0, a2, 0, 1);
+        else ps_round_body<E2>(J, rd, half, r, jb_log2, a0, a2, 0, 1);
+        E2 s0 = block_sum_n(a0, sm);
+        E2 s2 = block_sum_n(a2, sm);
+        if (threadIdx.x == 0) { res[J.sums_slot + 2 * rd] = s0; res[J.sums_slot + 2 * rd + 1] = s2; }
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(TPB) void k_ps_reduce(const PsJob* __restrict__ jobs, int rd, const E2* __restrict__ partials, int nblocks,
+                                                   E2* __restrict__ res) {
+    __shared__ E2 sm[TPB / 64];
+    const PsJob& J = jobs[blockIdx.x];
+    const E2* p = partials + (size_t)blockIdx.x * SC_MAX_BLOCKS * 2;
+    for (int v = 0; v < 2; v++) {
+        E2 a = e2_zero();
+        for (int b = threadIdx.x; b < nblocks; b += TPB) a = e2_add(a, p[(size_t)b * 2 + v]);
+        a = block_sum(a, sm);
+        if (threadIdx.x == 0) res[J.sums_slot + 2 * rd + v] = a;
+    }
+}
+
+int ps_round(hipStream_t st, const PsJob* jobs, int njobs, int nvars, int rd, const E2* chal, E2* partials, E2* res) {
+    const int hl = nvars - 1 - rd;
+    const size_t half = (size_t)1 << hl;
+    int jb_log2 = 8;
+    while (jb_log2 > 2 && ((size_t)half * njobs << (8 - jb_log2)) < 65536) jb_log2--;
+    if (jb_log2 > hl) jb_log2 = hl;
+    size_t ntiles = half >> jb_log2;
+    int gx = (int)(ntiles > (size_t)SC_MAX_BLOCKS ? SC_MAX_BLOCKS : ntiles);
+    k_ps_one<<<dim3(gx, njobs), 256, 16 * sizeof(E2), st>>>(jobs, rd, chal, jb_log2, partials, res);
+    if (gx > 1) k_ps_reduce<<<njobs, TPB, 0, st>>>(jobs, rd, partials, gx, res);
+    return gx;
+}
+void ps_tail(hipStream_t st, const PsJob* jobs, int njobs, int rd0, const E2* chal, E2* res) {
+    k_ps_tail<<<dim3(1, njobs), 1024, 16 * sizeof(E2), st>>>(jobs, rd0, chal, res);
 }
 
 __global__ __launch_bounds__(TPB) void k_reduce_partials(const E2* __restrict__ partials, int nblocks, int nv, E2* __restrict__ out) {

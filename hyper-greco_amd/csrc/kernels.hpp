@@ -24,20 +24,43 @@ struct ClaimSet {
 
 enum ScKind { SC_COLLATION = 0, SC_GRANDPROD = 1 };
 
-// One round of a stride-layout sum-check: table t lives at in + t*in_stride (u64 if base else E2).
-// Accumulates the true hypercube sums of g at t = 0,2[,3] into partials[block][nv] AND writes the
-// table folded at `r` to out + t*out_stride (E2). Returns the number of blocks used.
-int sc_round(hipStream_t st, int kind, bool base, const void* in, size_t in_stride, E2* out, size_t out_stride,
-             int ntab, size_t half, E2 r, const Powers& pw, E2* partials);
-
-struct PsTables {
-    const void* a[PS_MAX_PAIRS];  // u64* (round 0) or E2*
-    const E2* b[PS_MAX_PAIRS];
-    E2* oa[PS_MAX_PAIRS];
-    E2* ob[PS_MAX_PAIRS];
-    int npairs;
+// Stride-layout sum-check instance (collation / grand-product shapes), device-visible descriptor.
+// Table t of round 0 lives at in + t*in_stride (u64 if base else E2). All instances of a prover run are
+// scheduled size-synchronously: step h launches, for every instance, its round whose half-length is h
+// (instances are independent on the device; only the transcript orders them).
+struct StJob {
+    const void* in;
+    size_t in_stride;
+    E2* buf[2];        // ping-pong storage for folded tables (ntab * len/2, ntab * len/4)
+    E2* final_out;     // ntab folded scalars
+    int kind, ntab, nvars, base;
+    size_t r_off;      // chain index of round 0's challenge
+    size_t sums_slot;  // result slots: nv per round
+    E2 pw[PW_MAX];     // gamma^i (grand product) or M^i (collation)
 };
-int sc_round_prodsum(hipStream_t st, bool a_base, const PsTables& t, size_t half, E2 r, E2* partials);
+// step: every job in `list` (device array of njobs indices into jobs) runs its round with half = 2^h_log2
+int st_step(hipStream_t st, int kind, bool base, const StJob* jobs, const int* list, int njobs, int h_log2, const E2* chal,
+            E2* partials, E2* res);
+// tail: every listed job runs all its rounds with half <= 2^h_log2 in one workgroup
+void st_tail(hipStream_t st, int kind, const StJob* jobs, const int* list, int njobs, int h_log2, const E2* chal, E2* res);
+
+// PRODSUM sum-check instance (g = sum_i a_i b_i), device-visible descriptor; instances of equal nvars are
+// batched over grid.y so that the 2k+1 independent FFT-node reductions etc. advance in lock step.
+struct PsJob {
+    const void* a[PS_MAX_PAIRS];  // u64* inputs (round 0)
+    const E2* b[PS_MAX_PAIRS];    // bookkeeping tables (round 0)
+    E2* fin_a[PS_MAX_PAIRS];      // where the fully folded scalars go
+    E2* fin_b[PS_MAX_PAIRS];
+    E2* bufa[2];                  // ping-pong storage, table i at buf + i * (current length)
+    E2* bufb[2];
+    int npairs, nvars;
+    size_t r_off;                 // chain index of round 0's challenge
+    size_t sums_slot;             // result slots: 2 per round
+};
+// round `rd` of every job (multi-workgroup; includes the partial reduction). Returns grid.x.
+int ps_round(hipStream_t st, const PsJob* jobs, int njobs, int nvars, int rd, const E2* chal, E2* partials, E2* res);
+// rounds [rd0, nvars) of every job, one workgroup per job
+void ps_tail(hipStream_t st, const PsJob* jobs, int njobs, int rd0, const E2* chal, E2* res);
 
 // out[v] = sum_b partials[b*nv + v], v < nv
 void reduce_partials(hipStream_t st, const E2* partials, int nblocks, int nv, E2* out);

@@ -46,6 +46,7 @@ void hg_ctx::arena_reset() {
         arena_total = cap;
     }
     for (auto& c : chunks) c.used = 0;
+    stage_used = 0;
 }
 void hg_ctx::ensure_chain(size_t n_e) {
     if (n_e <= chal_e) return;
@@ -95,6 +96,7 @@ hg_ctx::~hg_ctx() {
     if (d_chal) (void)hipFree(d_chal);
     if (d_res) (void)hipFree(d_res);
     if (h_res) (void)hipHostFree(h_res);
+    if (h_stage) (void)hipHostFree(h_stage);
     if (d_partials) (void)hipFree(d_partials);
     for (auto e : event_pool) (void)hipEventDestroy(e);
     if (stream) (void)hipStreamDestroy(stream);
@@ -154,7 +156,7 @@ struct Prover {
     ProofStream proof;
     std::vector<std::function<void()>> ops;  // transcript steps, replayed after the single synchronisation
     size_t res_used = 0;
-    int cls_gp_base, cls_gp_ext, cls_col_base, cls_col_ext, cls_ps, cls_reduce, cls_aux, cls_tree, cls_hash, cls_gather;
+    int cls_gp_base, cls_gp_ext, cls_col_base, cls_col_ext, cls_ps, cls_reduce, cls_aux, cls_tree, cls_hash, cls_gather, cls_tail, cls_ps_tail;
 
     Prover(hg_ctx* c, const hg_pk* k) : ctx(c), pk(k), st(c->stream) {
         cls_gp_ext = ctx->prof_class("sc_round<grand_product,ext>", true);
@@ -162,6 +164,8 @@ struct Prover {
         cls_col_base = ctx->prof_class("sc_round<collation,base>", false);
         cls_col_ext = ctx->prof_class("sc_round<collation,ext>", false);
         cls_ps = ctx->prof_class("sc_round<prodsum>", false);
+        cls_tail = ctx->prof_class("sc_tail<single-workgroup>", false);
+        cls_ps_tail = ctx->prof_class("ps_tail<single-workgroup>", false);
         cls_reduce = ctx->prof_class("reduce_partials", false);
         cls_tree = ctx->prof_class("prod_level", false);
         cls_hash = ctx->prof_class("lasso_hash", false);
@@ -190,6 +194,14 @@ struct Prover {
     }
 
     // ---- sum-check drivers ---------------------------------------------------------------------
+    // A sum-check whose remaining work is this small ((table pairs) x (pairs per table) items) finishes all
+    // remaining rounds in one single-workgroup launch; anything larger is ALU-bound on a single CU.
+    static constexpr size_t TAIL_ITEMS = 2048;
+
+    // Stride-layout sum-checks (collation, every grand-product layer) are queued as jobs and executed by
+    // flush_stride() in a size-synchronised schedule: they are independent on the device.
+    std::vector<dev::StJob> st_jobs;
+
     ScHandle sc_stride(int kind, const void* in, bool base, size_t in_stride, int ntab, int nvars, const dev::Powers& pw, E2* final_out) {
         ScHandle h;
         h.nv = kind == dev::SC_GRANDPROD ? 3 : 2;
@@ -197,22 +209,91 @@ struct Prover {
         h.point_off = epos();
         h.sums_slot = slot((size_t)nvars * h.nv);
         const size_t N = (size_t)1 << nvars;
-        E2* buf[2] = {ctx->alloc_n<E2>((size_t)ntab * std::max<size_t>(N / 2, 1)), ctx->alloc_n<E2>((size_t)ntab * std::max<size_t>(N / 4, 1))};
-        if (!final_out) final_out = ctx->alloc_n<E2>(ntab);
-        for (int i = 0; i < nvars; i++) {
-            size_t half = N >> (i + 1);
-            E2 r = squeeze();
-            E2* out = i == nvars - 1 ? final_out : buf[i & 1];
-            int cls = kind == dev::SC_GRANDPROD ? (base ? cls_gp_base : cls_gp_ext) : (base ? cls_col_base : cls_col_ext);
-            ctx->prof_begin(cls, (double)ntab * (2.0 * half * (base ? 8 : 16) + half * 16.0));
-            int grid = dev::sc_round(st, kind, base, in, in_stride, out, half, ntab, half, r, pw, ctx->d_partials);
-            ctx->prof_end();
-            reduce(grid, h.nv, h.sums_slot + (size_t)i * h.nv);
-            in = out; in_stride = half; base = false;
-            h.rs.push_back(r);
-        }
+        dev::StJob J;
+        memset(&J, 0, sizeof(J));
+        J.in = in; J.in_stride = in_stride;
+        J.buf[0] = ctx->alloc_n<E2>((size_t)ntab * std::max<size_t>(N / 2, 1));
+        J.buf[1] = ctx->alloc_n<E2>((size_t)ntab * std::max<size_t>(N / 4, 1));
+        J.final_out = final_out ? final_out : ctx->alloc_n<E2>(ntab);
+        J.kind = kind; J.ntab = ntab; J.nvars = nvars; J.base = base ? 1 : 0;
+        J.r_off = h.point_off; J.sums_slot = h.sums_slot;
+        memcpy(J.pw, pw.v, sizeof(J.pw));
+        for (int i = 0; i < nvars; i++) h.rs.push_back(squeeze());
+        if (nvars > 0) st_jobs.push_back(J);
         return h;
     }
+
+    void flush_stride() {
+        if (st_jobs.empty()) return;
+        const int nj = (int)st_jobs.size();
+        dev::StJob* d_jobs = ctx->alloc_n<dev::StJob>(nj);
+        hip_check(hipMemcpyAsync(d_jobs, stage(st_jobs.data(), (size_t)nj * sizeof(dev::StJob)), (size_t)nj * sizeof(dev::StJob),
+                                 hipMemcpyHostToDevice, st), "upload jobs");
+        // launch plan: (kind, base?, h_log2 | tail) -> list of job indices
+        struct Launch { int kind; bool base; int h_log2; bool tail; std::vector<int> jobs; };
+        std::vector<Launch> plan;
+        for (int kind : {dev::SC_COLLATION, dev::SC_GRANDPROD}) {
+            int max_h = -1;
+            size_t per_j = 1;
+            for (auto& J : st_jobs) if (J.kind == kind) {
+                max_h = std::max(max_h, J.nvars - 1);
+                per_j = std::max(per_j, kind == dev::SC_GRANDPROD ? (size_t)J.ntab / 2 : (size_t)J.ntab);
+            }
+            if (max_h < 0) continue;
+            int h_tail = 0;
+            while (h_tail + 1 <= max_h && ((size_t)2 << h_tail) * per_j <= TAIL_ITEMS) h_tail++;
+            for (int h = max_h; h > h_tail; h--) {
+                Launch lb{kind, true, h, false, {}}, le{kind, false, h, false, {}};
+                for (int q = 0; q < nj; q++) {
+                    const dev::StJob& J = st_jobs[q];
+                    if (J.kind != kind || J.nvars - 1 < h) continue;
+                    bool first = J.nvars - 1 == h;
+                    if (first && J.base) lb.jobs.push_back(q); else le.jobs.push_back(q);
+                }
+                if (!lb.jobs.empty()) plan.push_back(lb);
+                if (!le.jobs.empty()) plan.push_back(le);
+            }
+            Launch lt{kind, false, h_tail, true, {}};
+            for (int q = 0; q < nj; q++) if (st_jobs[q].kind == kind) lt.jobs.push_back(q);
+            plan.push_back(lt);
+        }
+        std::vector<int> flat;
+        std::vector<size_t> offs;
+        for (auto& L : plan) { offs.push_back(flat.size()); flat.insert(flat.end(), L.jobs.begin(), L.jobs.end()); }
+        int* d_list = ctx->alloc_n<int>(flat.size());
+        hip_check(hipMemcpyAsync(d_list, stage(flat.data(), flat.size() * sizeof(int)), flat.size() * sizeof(int), hipMemcpyHostToDevice, st), "upload job lists");
+        auto round_bytes = [&](const dev::StJob& J, int rd) {
+            size_t half = (size_t)1 << (J.nvars - 1 - rd);
+            return (double)J.ntab * (2.0 * half * ((J.base && rd == 0) ? 8 : 16) + half * 16.0);
+        };
+        for (size_t li = 0; li < plan.size(); li++) {
+            const Launch& L = plan[li];
+            for (size_t o = 0; o < L.jobs.size(); o += MAX_BATCH) {
+                const int cnt = (int)std::min<size_t>(MAX_BATCH, L.jobs.size() - o);
+                const int* list = d_list + offs[li] + o;
+                double bytes = 0;
+                if (L.tail) {
+                    for (int q = 0; q < cnt; q++) { const dev::StJob& J = st_jobs[L.jobs[o + q]]; for (int rd = std::max(0, J.nvars - 1 - L.h_log2); rd < J.nvars; rd++) bytes += round_bytes(J, rd); }
+                    ctx->prof_begin(cls_tail, bytes);
+                    dev::st_tail(st, L.kind, d_jobs, list, cnt, L.h_log2, ctx->d_chal, d_res());
+                    ctx->prof_end();
+                } else {
+                    for (int q = 0; q < cnt; q++) { const dev::StJob& J = st_jobs[L.jobs[o + q]]; bytes += round_bytes(J, J.nvars - 1 - L.h_log2); }
+                    int cls = L.kind == dev::SC_GRANDPROD ? (L.base ? cls_gp_base : cls_gp_ext) : (L.base ? cls_col_base : cls_col_ext);
+                    ctx->prof_begin(cls, bytes);
+                    dev::st_step(st, L.kind, L.base, d_jobs, list, cnt, L.h_log2, ctx->d_chal, ctx->d_partials, d_res());
+                    ctx->prof_end();
+                }
+            }
+        }
+        st_jobs.clear();
+    }
+
+    // PRODSUM instances are queued and executed in batches of equal nvars (grid.y = instance): the node
+    // reductions have no device-side dependencies on each other, only the transcript order matters.
+    std::map<int, std::vector<dev::PsJob>> ps_queue;
+    std::vector<std::function<void()>> second_wave;  // device work that needs first-wave results (Libra phase 2)
+
     ScHandle sc_prodsum(const std::vector<const u64*>& a, const std::vector<const E2*>& b, int nvars,
                         const std::vector<E2*>& fin_a, const std::vector<E2*>& fin_b) {
         ScHandle h;
@@ -223,30 +304,61 @@ struct Prover {
         const int np = (int)a.size();
         if (np > dev::PS_MAX_PAIRS) throw Error("prodsum: too many table pairs");
         const size_t N = (size_t)1 << nvars;
-        E2* bufa[2] = {ctx->alloc_n<E2>((size_t)np * std::max<size_t>(N / 2, 1)), ctx->alloc_n<E2>((size_t)np * std::max<size_t>(N / 4, 1))};
-        E2* bufb[2] = {ctx->alloc_n<E2>((size_t)np * std::max<size_t>(N / 2, 1)), ctx->alloc_n<E2>((size_t)np * std::max<size_t>(N / 4, 1))};
-        dev::PsTables t;
-        memset(&t, 0, sizeof(t));
-        t.npairs = np;
-        for (int i = 0; i < np; i++) { t.a[i] = a[i]; t.b[i] = b[i]; }
-        bool a_base = true;
-        for (int r_i = 0; r_i < nvars; r_i++) {
-            size_t half = N >> (r_i + 1);
-            E2 r = squeeze();
-            for (int i = 0; i < np; i++) {
-                if (r_i == nvars - 1) { t.oa[i] = fin_a[i]; t.ob[i] = fin_b[i]; }
-                else { t.oa[i] = bufa[r_i & 1] + (size_t)i * half; t.ob[i] = bufb[r_i & 1] + (size_t)i * half; }
-            }
-            ctx->prof_begin(cls_ps, (double)np * (2.0 * half * ((a_base ? 8 : 16) + 16) + half * 32.0));
-            int grid = dev::sc_round_prodsum(st, a_base, t, half, r, ctx->d_partials);
-            ctx->prof_end();
-            reduce(grid, 2, h.sums_slot + (size_t)r_i * 2);
-            for (int i = 0; i < np; i++) { t.a[i] = t.oa[i]; t.b[i] = t.ob[i]; }
-            a_base = false;
-            h.rs.push_back(r);
+        dev::PsJob J;
+        memset(&J, 0, sizeof(J));
+        J.npairs = np; J.nvars = nvars; J.r_off = h.point_off; J.sums_slot = h.sums_slot;
+        for (int q = 0; q < 2; q++) {
+            J.bufa[q] = ctx->alloc_n<E2>((size_t)np * std::max<size_t>(N >> (q + 1), 1));
+            J.bufb[q] = ctx->alloc_n<E2>((size_t)np * std::max<size_t>(N >> (q + 1), 1));
         }
+        for (int i = 0; i < np; i++) { J.a[i] = a[i]; J.b[i] = b[i]; J.fin_a[i] = fin_a[i]; J.fin_b[i] = fin_b[i]; }
+        for (int i = 0; i < nvars; i++) h.rs.push_back(squeeze());
+        ps_queue[nvars].push_back(J);
         return h;
     }
+    void flush_prodsum() {
+        for (auto& kv : ps_queue) {
+            const int nvars = kv.first;
+            std::vector<dev::PsJob>& jobs = kv.second;
+            if (jobs.empty()) continue;
+            const size_t N = (size_t)1 << nvars;
+            for (size_t o = 0; o < jobs.size(); o += MAX_BATCH) {
+                const int nj = (int)std::min<size_t>(MAX_BATCH, jobs.size() - o);
+                dev::PsJob* d_jobs = ctx->alloc_n<dev::PsJob>(nj);
+                dev::PsJob* staged = (dev::PsJob*)stage(jobs.data() + o, (size_t)nj * sizeof(dev::PsJob));
+                hip_check(hipMemcpyAsync(d_jobs, staged, (size_t)nj * sizeof(dev::PsJob), hipMemcpyHostToDevice, st), "upload jobs");
+                int maxp = 1;
+                double pairs = 0;
+                for (int q = 0; q < nj; q++) { maxp = std::max(maxp, jobs[o + q].npairs); pairs += jobs[o + q].npairs; }
+                int rd = 0;
+                for (; rd < nvars && ((N >> rd) / 2) * (size_t)maxp > TAIL_ITEMS; rd++) {
+                    size_t half = N >> (rd + 1);
+                    ctx->prof_begin(cls_ps, pairs * (2.0 * half * ((rd == 0 ? 8 : 16) + 16) + half * 32.0));
+                    dev::ps_round(st, d_jobs, nj, nvars, rd, ctx->d_chal, ctx->d_partials, d_res());
+                    ctx->prof_end();
+                }
+                if (rd < nvars) {
+                    double bytes = 0;
+                    for (int q = rd; q < nvars; q++) { size_t half = N >> (q + 1); bytes += pairs * (2.0 * half * ((q == 0 ? 8 : 16) + 16) + half * 32.0); }
+                    ctx->prof_begin(cls_ps_tail, bytes);
+                    dev::ps_tail(st, d_jobs, nj, rd, ctx->d_chal, d_res());
+                    ctx->prof_end();
+                }
+            }
+            jobs.clear();
+        }
+    }
+    static constexpr size_t MAX_BATCH = 64;
+    // pinned staging for small host->device descriptor copies (kept alive until the final synchronisation)
+    void* stage(const void* src, size_t bytes) {
+        size_t need = (bytes + 63) & ~(size_t)63;
+        if (ctx->stage_used + need > ctx->stage_cap) throw Error("staging buffer exhausted");
+        void* p = ctx->h_stage + ctx->stage_used;
+        ctx->stage_used += need;
+        memcpy(p, src, bytes);
+        return p;
+    }
+
     // transcript side of prove_sum_check: d+1 coefficients per round, eval(1) derived from the running claim
     void defer_sumcheck(const ScHandle& h, int deg, Cell claim_in, Cell claim_out) {
         ops.push_back([this, h, deg, claim_in, claim_out] {
@@ -423,6 +535,7 @@ struct Prover {
             }
             defer_write_slots(base_slot, 3 + chk.second.size());
         }
+        flush_stride();  // collation + every grand-product layer, size-synchronised
         return ClaimRef{r_off, nu, claimed};  // (r, claimed_sum) for the single predecessor (lasso.rs:97,113)
     }
 
@@ -511,24 +624,46 @@ struct Prover {
         }
         if (!n.mul.empty()) {
             if (!n.lin.empty()) throw Error("vanilla: nodes mixing linear and mul gates are not on this path");
-            // phase 2: sum_y sum_i in_i(y) B_i(y), claim carried over from phase 1 (no linear part)
-            E2* eqx = ctx->alloc_n<E2>(SR);
-            dev::eq_table(st, eqx, nin, ctx->d_chal, s1.point_off);
+            // phase 2: sum_y sum_i in_i(y) B_i(y), claim carried over from phase 1 (no linear part).
+            // Transcript bookkeeping (challenges, slots) happens now, in protocol order; the device work
+            // needs u = in(r_x) from phase 1 and is therefore queued for the second wave.
             std::vector<const u64*> a2;
-            std::vector<const E2*> b2;
-            std::vector<E2*> fa2, fb2;
+            std::vector<E2*> Bs, fa2, fb2;
             size_t w_base = slot(n.arity);
             for (int i : ri) {
                 E2* B = ctx->alloc_n<E2>(SR);
-                ctx->prof_begin(cls_gather, 40.0 * SR);
-                dev::vanilla_gather_B(st, nd.mulR[i], eqc, eqx, d_res() + u_base, n.log2_sub_in, n.log2_sub_out, n.log2_reps, B);
-                ctx->prof_end();
                 a2.push_back(d_vals[n.preds[i]]);
-                b2.push_back(B);
+                Bs.push_back(B);
                 fa2.push_back(d_res() + w_base + i);
                 fb2.push_back(scratch + i);
             }
-            ScHandle s2 = sc_prodsum(a2, b2, nin, fa2, fb2);
+            size_t rx_off = s1.point_off;
+            const hg_pk::NodeDev* ndp = &nd;
+            const HNode* np = &n;
+            // reserve the phase-2 sum-check (challenges + slots) now; attach its tables in the second wave
+            ScHandle s2;
+            s2.nv = 2; s2.nvars = nin; s2.point_off = epos(); s2.sums_slot = slot((size_t)nin * 2);
+            for (int i = 0; i < nin; i++) s2.rs.push_back(squeeze());
+            second_wave.push_back([this, ri, Bs, a2, fa2, fb2, rx_off, ndp, np, eqc, u_base, SR, nin, s2] {
+                E2* eqx = ctx->alloc_n<E2>(SR);
+                dev::eq_table(st, eqx, nin, ctx->d_chal, rx_off);
+                for (size_t q = 0; q < ri.size(); q++) {
+                    ctx->prof_begin(cls_gather, 40.0 * SR);
+                    dev::vanilla_gather_B(st, ndp->mulR[ri[q]], eqc, eqx, d_res() + u_base, np->log2_sub_in, np->log2_sub_out, np->log2_reps, Bs[q]);
+                    ctx->prof_end();
+                }
+                const int npairs = (int)ri.size();
+                const size_t N = (size_t)1 << nin;
+                dev::PsJob J;
+                memset(&J, 0, sizeof(J));
+                J.npairs = npairs; J.nvars = nin; J.r_off = s2.point_off; J.sums_slot = s2.sums_slot;
+                for (int q = 0; q < 2; q++) {
+                    J.bufa[q] = ctx->alloc_n<E2>((size_t)npairs * std::max<size_t>(N >> (q + 1), 1));
+                    J.bufb[q] = ctx->alloc_n<E2>((size_t)npairs * std::max<size_t>(N >> (q + 1), 1));
+                }
+                for (int q = 0; q < npairs; q++) { J.a[q] = a2[q]; J.b[q] = Bs[q]; J.fin_a[q] = fa2[q]; J.fin_b[q] = fb2[q]; }
+                ps_queue[nin].push_back(J);
+            });
             defer_sumcheck(s2, 2, after1, nullptr);
             for (int i : ri) {
                 defer_write_slots(w_base + i, 1);
@@ -582,14 +717,22 @@ struct Prover {
                 }
             }
         }
+        flush_prodsum();                       // first wave: every FFT / Libra phase-1 reduction, batched
+        for (auto& f : second_wave) f();       // Libra phase-2 bookkeeping (needs the phase-1 scalars in HBM)
+        second_wave.clear();
+        flush_prodsum();
     }
 
     // copies the result buffer back (the only synchronisation) and replays the transcript
+    double t_enqueued = 0, t_synced = 0, t_replayed = 0;
     void finish() {
         if (res_used) hip_check(hipMemcpyAsync(ctx->h_res, ctx->d_res, res_used * sizeof(E2), hipMemcpyDeviceToHost, st), "copy results");
+        t_enqueued = wall_ms();
         hip_check(hipStreamSynchronize(st), "prove: stream sync");
         hip_check(hipGetLastError(), "prove: kernel launch");
+        t_synced = wall_ms();
         for (auto& op : ops) op();
+        t_replayed = wall_ms();
         ctx->prof_collect();
     }
 };
@@ -664,6 +807,9 @@ ProveResult prove_resident(hg_ctx* ctx, const hg_pk* pk, const hg_values* v) {
     (void)hipEventDestroy(ev_a); (void)hipEventDestroy(ev_b);
     res.prove_ms = t4 - t3;
     res.gpu_ms = gms;
+    res.enqueue_ms = P.t_enqueued - t3;
+    res.sync_ms = P.t_synced - P.t_enqueued;
+    res.replay_ms = P.t_replayed - P.t_synced;
     res.proof = std::move(P.proof.bytes);
     return res;
 }
@@ -710,6 +856,7 @@ void sumcheck_on_tables(hg_ctx* ctx, SumcheckIO& io) {
             fa.push_back(ctx->d_res + evals + i); fb.push_back(ctx->d_res + evals + i + 1);
         }
         h = P.sc_prodsum(a, b, (int)io.nv, fa, fb);
+        P.flush_prodsum();
     } else {
         bool base = io.is_base[0] != 0;
         for (int i = 0; i < ntab; i++) if ((io.is_base[i] != 0) != base) throw Error("hg_sumcheck: mixed table fields");
@@ -720,6 +867,7 @@ void sumcheck_on_tables(hg_ctx* ctx, SumcheckIO& io) {
         memset(&pw, 0, sizeof(pw));
         for (size_t i = 0; i < io.pw.size() && i < (size_t)dev::PW_MAX; i++) pw.v[i] = io.pw[i];
         h = P.sc_stride(io.kind == 1 ? dev::SC_GRANDPROD : dev::SC_COLLATION, d, base, N, ntab, (int)io.nv, pw, ctx->d_res + evals);
+        P.flush_stride();
     }
     int deg = io.kind == 1 ? 3 : 2;
     P.defer_sumcheck(h, deg, claim, out);

@@ -35,6 +35,9 @@ struct hg_ctx {
     hg::E2* h_res = nullptr;  // pinned
     size_t res_cap = 0;
     hg::E2* d_partials = nullptr;
+    // pinned staging for small host->device descriptor copies; bump-allocated, reset per prove
+    char* h_stage = nullptr;
+    size_t stage_cap = 0, stage_used = 0;
     // profiling
     int prof_level = 0;
     struct ProfEvent { int cls; hipEvent_t a, b; };
@@ -87,7 +90,7 @@ namespace hg {
 
 struct ProveResult {
     std::vector<uint8_t> proof;
-    double witness_ms = 0, upload_ms = 0, prove_ms = 0, gpu_ms = 0;
+    double witness_ms = 0, upload_ms = 0, prove_ms = 0, gpu_ms = 0, enqueue_ms = 0, sync_ms = 0, replay_ms = 0;
 };
 
 hg_values* witness_gen(hg_ctx* ctx, const hg_pk* pk, const Witness& w, double* witness_ms, double* upload_ms);

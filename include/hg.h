@@ -42,6 +42,9 @@ typedef struct hg_timings {
                           first launch to the assembled proof bytes (includes host launch + transcript replay) */
     double gpu_ms;     /* the same span measured with HIP events on the prover stream (device time only) */
     double total_ms;   /* wall clock of the whole hg_prove call */
+    double enqueue_ms; /* host time spent walking the protocol and launching (part of prove_ms) */
+    double sync_ms;    /* host wait for the stream after the last launch (part of prove_ms) */
+    double replay_ms;  /* host transcript replay: interpolation, claim chaining, proof bytes (part of prove_ms) */
 } hg_timings;
 
 /* Per-kernel-class profile (HIP events recorded on the prover stream around every launch of the class). */
