@@ -92,7 +92,11 @@ __device__ __forceinline__ void store_e2(E2* p, E2 v) {
 // serial per-thread loop over the tables (a dependent chain of HBM/L2 latencies) shrinks to
 // ceil(nb / G) iterations. Partial sums over the groups are combined through LDS (`red`: NV*BD E2)
 // BEFORE the multiplication by p_0, which is what the quirky g = p_0 * (sum_i ..) needs.
-template <int KIND, typename T>
+// Grand-product shape: in the FIRST round of a job the folded LEFT table of pair i is stored multiplied by
+// gamma^i (pw[i]); later rounds then need no per-pair scaling at all (the weight rides along in the table),
+// which removes 3 of the 8 extension multiplications per (pair, j). The host divides the final left
+// evaluations by gamma^i again before they reach the transcript.
+template <int KIND, typename T, bool FIRST>
 __device__ __forceinline__ void sc_round_body(const T* __restrict__ in, size_t in_stride, E2* __restrict__ out,
                                               size_t out_stride, int ntab, size_t half, E2 r, const E2* __restrict__ pw, int jb_log2,
                                               E2* __restrict__ red, E2* acc, size_t first_tile, size_t tile_step) {
@@ -115,11 +119,19 @@ __device__ __forceinline__ void sc_round_body(const T* __restrict__ in, size_t i
                 T l2 = V::add(yl, dl), r2 = V::add(yr, dr);
                 T l3 = V::add(l2, dl), r3 = V::add(r2, dr);
                 if (i == 0) { p0 = xl; p2 = l2; p3 = l3; }
-                E2 gm = pw[i];
-                s0 = e2_add(s0, V::scale(gm, V::mul(xl, xr)));
-                s2 = e2_add(s2, V::scale(gm, V::mul(l2, r2)));
-                s3 = e2_add(s3, V::scale(gm, V::mul(l3, r3)));
-                store_e2(out + (size_t)(2 * i) * out_stride + j, V::fold(xl, dl, r));
+                if constexpr (FIRST) {
+                    E2 gm = pw[i];
+                    s0 = e2_add(s0, V::scale(gm, V::mul(xl, xr)));
+                    s2 = e2_add(s2, V::scale(gm, V::mul(l2, r2)));
+                    s3 = e2_add(s3, V::scale(gm, V::mul(l3, r3)));
+                    // gamma^i * (xl + r dl) = gamma^i xl + (gamma^i r) dl
+                    store_e2(out + (size_t)(2 * i) * out_stride + j, e2_add(V::scale(gm, xl), V::scale(e2_mul(gm, r), dl)));
+                } else {
+                    s0 = e2_add(s0, V::lift(V::mul(xl, xr)));
+                    s2 = e2_add(s2, V::lift(V::mul(l2, r2)));
+                    s3 = e2_add(s3, V::lift(V::mul(l3, r3)));
+                    store_e2(out + (size_t)(2 * i) * out_stride + j, V::fold(xl, dl, r));
+                }
                 store_e2(out + (size_t)(2 * i + 1) * out_stride + j, V::fold(xr, dr, r));
             }
             if (G > 1) {
@@ -217,8 +229,8 @@ __global__ __launch_bounds__(256) void k_st_step(const StJob* __restrict__ jobs,
     E2 acc[NV];
 #pragma unroll
     for (int t = 0; t < NV; t++) acc[t] = e2_zero();
-    sc_round_body<KIND, T>(reinterpret_cast<const T*>(in), in_stride, out, half, J.ntab, half, chal[J.r_off + rd], J.pw, jb_log2, red,
-                           acc, blockIdx.x, gridDim.x);
+    if (rd == 0) sc_round_body<KIND, T, true>(reinterpret_cast<const T*>(in), in_stride, out, half, J.ntab, half, chal[J.r_off + rd], J.pw, jb_log2, red, acc, blockIdx.x, gridDim.x);
+    else sc_round_body<KIND, T, false>(reinterpret_cast<const T*>(in), in_stride, out, half, J.ntab, half, chal[J.r_off + rd], J.pw, jb_log2, red, acc, blockIdx.x, gridDim.x);
 #pragma unroll
     for (int t = 0; t < NV; t++) {
         E2 s = block_sum_n(acc[t], sm);
@@ -262,8 +274,9 @@ __global__ __launch_bounds__(1024) void k_st_tail(const StJob* __restrict__ jobs
         E2 acc[NV];
 #pragma unroll
         for (int t = 0; t < NV; t++) acc[t] = e2_zero();
-        if (rd == 0 && J.base) sc_round_body<KIND, u64>(reinterpret_cast<const u64*>(in), in_stride, out, half, J.ntab, half, r, J.pw, jb_log2, red, acc, 0, 1);
-        else sc_round_body<KIND, E2>(reinterpret_cast<const E2*>(in), in_stride, out, half, J.ntab, half, r, J.pw, jb_log2, red, acc, 0, 1);
+        if (rd == 0 && J.base) sc_round_body<KIND, u64, true>(reinterpret_cast<const u64*>(in), in_stride, out, half, J.ntab, half, r, J.pw, jb_log2, red, acc, 0, 1);
+        else if (rd == 0) sc_round_body<KIND, E2, true>(reinterpret_cast<const E2*>(in), in_stride, out, half, J.ntab, half, r, J.pw, jb_log2, red, acc, 0, 1);
+        else sc_round_body<KIND, E2, false>(reinterpret_cast<const E2*>(in), in_stride, out, half, J.ntab, half, r, J.pw, jb_log2, red, acc, 0, 1);
 #pragma unroll
         for (int t = 0; t < NV; t++) {
             E2 s = block_sum_n(acc[t], sm);

@@ -377,6 +377,19 @@ struct Prover {
             if (claim_out) *claim_out = claim;
         });
     }
+    // the grand-product kernels leave the final LEFT evaluation of pair b multiplied by pw[b] (see kernels.hip)
+    void defer_gp_unscale(size_t evals_slot, int nb, const dev::Powers& pw) {
+        ops.push_back([this, evals_slot, nb, pw] {
+            if (nb < 2) return;
+            if (pw.v[1].c0 == 0 && pw.v[1].c1 == 0) throw Error("grand product: zero batching weight");
+            const E2 ginv = e2_inv(pw.v[1]);  // pw[b] = gamma^b
+            E2 w = ginv;
+            for (int b = 1; b < nb; b++) {
+                ctx->h_res[evals_slot + 2 * b] = e2_mul(ctx->h_res[evals_slot + 2 * b], w);
+                w = e2_mul(w, ginv);
+            }
+        });
+    }
     void defer_write_slots(size_t s, size_t n) {
         ops.push_back([this, s, n] { for (size_t i = 0; i < n; i++) proof.write_e(h_res()[s + i]); });
     }
@@ -431,6 +444,7 @@ struct Prover {
             size_t evals = slot(2 * (size_t)nb);
             ScHandle sc = sc_stride(dev::SC_GRANDPROD, lev[k], true, h, 2 * nb, n, pw, d_res() + evals);
             defer_sumcheck(sc, 3, claim, nullptr);
+            defer_gp_unscale(evals, nb, pw);
             defer_write_slots(evals, 2 * (size_t)nb);  // prover.rs:257
             out.point_off = sc.point_off;
             layer_down(evals, squeeze());              // mu (prover.rs:259)
@@ -871,6 +885,12 @@ void sumcheck_on_tables(hg_ctx* ctx, SumcheckIO& io) {
     }
     int deg = io.kind == 1 ? 3 : 2;
     P.defer_sumcheck(h, deg, claim, out);
+    if (io.kind == 1) {
+        dev::Powers pw;
+        memset(&pw, 0, sizeof(pw));
+        for (size_t i = 0; i < io.pw.size() && i < (size_t)dev::PW_MAX; i++) pw.v[i] = io.pw[i];
+        P.defer_gp_unscale(evals, ntab / 2, pw);
+    }
     P.finish();
     io.point = h.rs;
     io.evals.assign(ctx->h_res + evals, ctx->h_res + evals + ntab);

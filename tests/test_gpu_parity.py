@@ -66,8 +66,15 @@ def test_sumcheck_kernels_bit_exact(ctx, kind, ntab, nv, base):
     if kind == 0:
         pw = np.array([[pow(65536, i, P), 0] for i in range(npw)], dtype=np.uint64)
     else:
-        g = (rng.randrange(P), rng.randrange(P))
-        pw = np.array([[rng.randrange(P), rng.randrange(P)] for _ in range(npw)], dtype=np.uint64)
+        if kind == 1:  # grand product: pw[i] = gamma^i in GoldilocksExt2 (X^2 = 7), pw[0] = 1
+            g = (rng.randrange(P), rng.randrange(P))
+            cur, pws = (1, 0), []
+            for _ in range(npw):
+                pws.append(cur)
+                cur = ((cur[0] * g[0] + 7 * cur[1] * g[1]) % P, (cur[0] * g[1] + cur[1] * g[0]) % P)
+            pw = np.array(pws, dtype=np.uint64)
+        else:
+            pw = np.zeros((0, 2), dtype=np.uint64)
     claim = np.array([rng.randrange(P), rng.randrange(P)], dtype=np.uint64)
     skip = rng.randrange(50)
     got = ctx.sumcheck(kind, tables, is_base, pw, claim, skip)
