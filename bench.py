@@ -60,6 +60,39 @@ def cpu_baseline(n, k, seed, budget_s=45.0):
     return None
 
 
+def max_over_ranks(elapsed, world, dist, torch, device):
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def witness_seed(base_seed, n, rank):
+    return base_seed + n + 7919 * rank  # one independent witness per rank
+
+
+def selftest_dist(args, rank, world, dist, torch):
+    """gloo on CPU: the same rendezvous / barrier / max-over-ranks / rank-0 reporting as the GPU path, with a
+    dummy timed body (each rank sleeps (rank+1) * 10 ms per step)."""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.01 * (rank + 1))
+    if world > 1:
+        dist.barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0, world, dist, torch, "cpu")
+    seeds = [witness_seed(args.seed, args.n, r) for r in range(world)]
+    if rank == 0:
+        print(json.dumps({"selftest": "dist", "n_gpus": world, "steps": args.steps, "ms_per_step": elapsed / args.steps * 1e3,
+                          "value": elapsed / args.steps * 1e3 / world, "distinct_witness_seeds": len(set(seeds)) == world}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -69,6 +102,8 @@ def main():
     ap.add_argument("--k", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=0x4752454330)
+    ap.add_argument("--selftest-dist", action="store_true",
+                    help="CPU/gloo self-test of the N>1 plumbing (rendezvous, barrier, max-over-ranks, rank-0 JSON); proves nothing")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -79,6 +114,8 @@ def main():
 
     import torch
     import torch.distributed as dist
+    if args.selftest_dist:
+        return selftest_dist(args, rank, world, dist, torch)
     import __graft_entry__ as entry
     hg = entry.load_package()
 
@@ -95,7 +132,7 @@ def main():
     ctx = hg.Context(local_rank)
     bfv = hg.BfvEncrypt.new(args.n, args.k)
     pk = bfv.setup(ctx)
-    witness = hg.Witness.synthetic(bfv.params, args.seed + args.n + 7919 * rank)  # one independent witness per rank
+    witness = hg.Witness.synthetic(bfv.params, witness_seed(args.seed, args.n, rank))
     vals = hg.witness_gen(ctx, pk, witness)  # node tables -> HBM (outside the timed region)
     out = hg.ProofBuffer()
 
@@ -115,10 +152,7 @@ def main():
     assert out.bytes() == first, "proof changed between runs"
     elapsed = t1 - t0
     gpu_ms = out.timings()["gpu_ms"]
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed, world, dist, torch, "cuda")
     ms_per_step = elapsed / args.steps * 1e3
     dom = [s for s in ctx.profile_get() if s["name"] == DOMINANT][0]
 
