@@ -439,40 +439,64 @@ void reduce_partials(hipStream_t st, const E2* partials, int nblocks, int nv, E2
 }
 
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ E2 eq_at(const E2* __restrict__ pt, int n, size_t idx) {
+__device__ __forceinline__ E2 eq_bits(const E2* __restrict__ pt, int nbits, size_t idx) {
     E2 p = e2_one();
-    for (int i = 0; i < n; i++) {
+    for (int i = 0; i < nbits; i++) {
         E2 ri = pt[i];
-        E2 f = (idx >> i) & 1 ? ri : e2_sub(e2_one(), ri);
-        p = e2_mul(p, f);
+        p = e2_mul(p, (idx >> i) & 1 ? ri : e2_sub(e2_one(), ri));
     }
     return p;
 }
-__global__ __launch_bounds__(TPB) void k_eq_table(E2* __restrict__ out, int n, const E2* __restrict__ pt) {
-    size_t N = (size_t)1 << n;
-    for (size_t idx = (size_t)blockIdx.x * TPB + threadIdx.x; idx < N; idx += (size_t)gridDim.x * TPB)
-        store_e2(out + idx, eq_at(pt, n, idx));
+// high-index slice per workgroup: enough workgroups to fill the chip (>= 256 where the table allows), at least 4
+// outputs per thread so the per-workgroup A/B setup amortises
+__host__ __device__ inline size_t eq_k_for(int hi) {
+    size_t all = (size_t)1 << hi;
+    size_t k = all >> 8;
+    if (k < 4) k = 4;
+    if (k > 256) k = 256;
+    if (k > all) k = all;
+    return k;
 }
-void eq_table(hipStream_t st, E2* out, int n, const E2* chal, size_t point_off) {
-    size_t N = (size_t)1 << n;
-    int grid = (int)std::min<size_t>((N + TPB - 1) / TPB, 65535 * 16);
-    k_eq_table<<<grid, TPB, 0, st>>>(out, n, chal + point_off);
-}
-__global__ __launch_bounds__(TPB) void k_eq_combined(E2* __restrict__ out, int n, const E2* __restrict__ chal, ClaimSet cs) {
-    size_t N = (size_t)1 << n;
-    for (size_t idx = (size_t)blockIdx.x * TPB + threadIdx.x; idx < N; idx += (size_t)gridDim.x * TPB) {
-        E2 acc = e2_zero();
-        for (int a = 0; a < cs.n; a++) {
-            E2 q = eq_at(chal + cs.point_off[a], n, idx);
-            acc = e2_add(acc, cs.unit_alpha ? q : e2_mul(chal[cs.alpha_off + a], q));
+// eq tables as an outer product: eq(r, idx) = A[idx & (2^lo - 1)] * B[idx >> lo]. A workgroup builds the 256-entry
+// low table and a 256-entry slice of the high table in LDS (n multiplications per thread in total), then
+// emits 65,536 entries with ONE extension multiplication each (instead of n each). Multi-claim form:
+// out = sum_a alpha_a eq(r_a, .), alpha folded into B, accumulated claim by claim by the owning thread.
+__global__ __launch_bounds__(256) void k_eq_jobs(const EqJob* __restrict__ jobs, const E2* __restrict__ chal) {
+    const EqJob& J = jobs[blockIdx.y];
+    const int n = J.n;
+    const int lo = n < 8 ? n : 8;
+    const int hi = n - lo;
+    const size_t K = eq_k_for(hi);                         // high indices per workgroup
+    const size_t nblk = ((size_t)1 << hi) / K;
+    if (blockIdx.x >= nblk) return;
+    __shared__ E2 A[256], B[256];
+    const int t = threadIdx.x;
+    const size_t hi_base = (size_t)blockIdx.x * K;
+    const E2* base = J.point_dev ? J.point_dev : chal;
+    for (int a = 0; a < J.cs.n; a++) {
+        const E2* pt = base + J.cs.point_off[a];
+        __syncthreads();
+        if (t < (1 << lo)) A[t] = eq_bits(pt, lo, (size_t)t);
+        if ((size_t)t < K) {
+            E2 bv = eq_bits(pt + lo, hi, hi_base + t);
+            B[t] = J.cs.unit_alpha ? bv : e2_mul(bv, chal[J.cs.alpha_off + a]);
         }
-        store_e2(out + idx, acc);
+        __syncthreads();
+        if (t < (1 << lo)) {
+            E2 av = A[t];
+            for (size_t kk = 0; kk < K; kk++) {
+                size_t idx = ((hi_base + kk) << lo) | (size_t)t;
+                E2 v = e2_mul(av, B[kk]);
+                if (a > 0) v = e2_add(v, J.out[idx]);
+                store_e2(J.out + idx, v);
+            }
+        }
     }
 }
-void eq_combined(hipStream_t st, E2* out, int n, const E2* chal, const ClaimSet& cs) {
-    size_t N = (size_t)1 << n;
-    int grid = (int)std::min<size_t>((N + TPB - 1) / TPB, 65535 * 16);
-    k_eq_combined<<<grid, TPB, 0, st>>>(out, n, chal, cs);
+void eq_jobs(hipStream_t st, const EqJob* jobs, int njobs, int max_n, const E2* chal) {
+    int hi = max_n > 8 ? max_n - 8 : 0;
+    size_t nblk = ((size_t)1 << hi) / eq_k_for(hi);
+    k_eq_jobs<<<dim3((unsigned)nblk, njobs), 256, 0, st>>>(jobs, chal);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -654,36 +678,6 @@ int dot_eq(hipStream_t st, const E2* eq, const u64* const tabs[8], int ntab, siz
 
 // ------------------------------------------------------------------------------------------------
 // Vanilla / FFT node bookkeeping
-__global__ __launch_bounds__(TPB) void k_gather_T(GatherT g, const E2* __restrict__ eqc, int log2_S, int log2_G, int log2_R,
-                                                  E2* __restrict__ T) {
-    const size_t total = (size_t)1 << (log2_S + log2_R);
-    const size_t smask = ((size_t)1 << log2_S) - 1;
-    for (size_t idx = (size_t)blockIdx.x * TPB + threadIdx.x; idx < total; idx += (size_t)gridDim.x * TPB) {
-        size_t x = idx & smask, rep = idx >> log2_S;
-        const E2* eq_rep = eqc + (rep << log2_G);
-        E2 acc = e2_zero();
-        if (g.lin.ptr) {
-            for (u32 e = g.lin.ptr[x]; e < g.lin.ptr[x + 1]; e++) {
-                E2 q = eq_rep[g.lin.gate[e]];
-                u64 c = g.lin.coef[e];
-                acc = e2_add(acc, c == 1 ? q : e2_mul_f(q, c));
-            }
-        }
-        if (g.mul.ptr) {
-            for (u32 e = g.mul.ptr[x]; e < g.mul.ptr[x + 1]; e++) {
-                E2 q = eq_rep[g.mul.gate[e]];
-                u64 other = g.in_vals[g.mul.other_in[e]][(rep << log2_S) + g.mul.other_j[e]];
-                u64 c = g.mul.coef[e];
-                acc = e2_add(acc, e2_mul_f(q, c == 1 ? other : gl_mul(c, other)));
-            }
-        }
-        store_e2(T + idx, acc);
-    }
-}
-void vanilla_gather_T(hipStream_t st, const GatherT& g, const E2* eqc, int log2_S, int log2_G, int log2_R, E2* T) {
-    size_t total = (size_t)1 << (log2_S + log2_R);
-    k_gather_T<<<grid_for(total) * 4, TPB, 0, st>>>(g, eqc, log2_S, log2_G, log2_R, T);
-}
 __global__ __launch_bounds__(TPB) void k_gather_B(CsrMul m, const E2* __restrict__ eqc, const E2* __restrict__ eqx,
                                                   const E2* __restrict__ u, int log2_S, int log2_G, int log2_R, E2* __restrict__ B) {
     const size_t total = (size_t)1 << (log2_S + log2_R);
@@ -723,27 +717,63 @@ int vanilla_const_sum(hipStream_t st, const u32* gate, const u64* coef, size_t n
     return grid;
 }
 
-__global__ __launch_bounds__(TPB) void k_fft_table(E2* __restrict__ out, int L, const u64* __restrict__ W, u64 scale,
-                                                   const E2* __restrict__ chal, ClaimSet cs) {
+// zkCNN DFT-row tables of every FFT node in one launch (grid.y = node)
+__global__ __launch_bounds__(TPB) void k_fft_jobs(const FftJob* __restrict__ jobs, const E2* __restrict__ chal) {
+    const FftJob& J = jobs[blockIdx.y];
+    const int L = J.L;
     const size_t N = (size_t)1 << L;
+    const u64* __restrict__ W = J.W;
     for (size_t x = (size_t)blockIdx.x * TPB + threadIdx.x; x < N; x += (size_t)gridDim.x * TPB) {
         E2 acc = e2_zero();
-        for (int a = 0; a < cs.n; a++) {
-            const E2* r = chal + cs.point_off[a];
-            E2 p = e2(scale, 0);
+        for (int a = 0; a < J.cs.n; a++) {
+            const E2* r = chal + J.cs.point_off[a];
+            E2 p = e2(J.scale, 0);
             for (int b = 0; b < L; b++) {
                 u64 wx = W[(x << b) & (N - 1)];
                 E2 f = e2_add_f(e2_mul_f(r[b], gl_sub(wx, 1)), 1);  // 1 - r_b + r_b w^(2^b x)
                 p = e2_mul(p, f);
             }
-            acc = e2_add(acc, cs.unit_alpha ? p : e2_mul(chal[cs.alpha_off + a], p));
+            acc = e2_add(acc, J.cs.unit_alpha ? p : e2_mul(chal[J.cs.alpha_off + a], p));
         }
-        store_e2(out + x, acc);
+        store_e2(J.out + x, acc);
     }
 }
-void fft_table(hipStream_t st, E2* out, int L, const u64* W, u64 scale, const E2* chal, const ClaimSet& cs) {
-    size_t N = (size_t)1 << L;
-    k_fft_table<<<(unsigned)((N + TPB - 1) / TPB), TPB, 0, st>>>(out, L, W, scale, chal, cs);
+void fft_jobs(hipStream_t st, const FftJob* jobs, int njobs, int max_L, const E2* chal) {
+    size_t N = (size_t)1 << max_L;
+    k_fft_jobs<<<dim3((unsigned)std::min<size_t>((N + TPB - 1) / TPB, 1024), njobs), TPB, 0, st>>>(jobs, chal);
+}
+// Libra bookkeeping tables of many (node, input) pairs in one launch (grid.y = job)
+__global__ __launch_bounds__(TPB) void k_gather_jobs(const GatherJob* __restrict__ jobs) {
+    const GatherJob& J = jobs[blockIdx.y];
+    const GatherT& g = J.g;
+    const int log2_S = J.log2_S, log2_G = J.log2_G;
+    const size_t total = (size_t)1 << (log2_S + J.log2_R);
+    const size_t smask = ((size_t)1 << log2_S) - 1;
+    const E2* __restrict__ eqc = J.eqc;
+    for (size_t idx = (size_t)blockIdx.x * TPB + threadIdx.x; idx < total; idx += (size_t)gridDim.x * TPB) {
+        size_t x = idx & smask, rep = idx >> log2_S;
+        const E2* eq_rep = eqc + (rep << log2_G);
+        E2 acc = e2_zero();
+        if (g.lin.ptr) {
+            for (u32 e = g.lin.ptr[x]; e < g.lin.ptr[x + 1]; e++) {
+                E2 q = eq_rep[g.lin.gate[e]];
+                u64 c = g.lin.coef[e];
+                acc = e2_add(acc, c == 1 ? q : e2_mul_f(q, c));
+            }
+        }
+        if (g.mul.ptr) {
+            for (u32 e = g.mul.ptr[x]; e < g.mul.ptr[x + 1]; e++) {
+                E2 q = eq_rep[g.mul.gate[e]];
+                u64 other = g.in_vals[g.mul.other_in[e]][(rep << log2_S) + g.mul.other_j[e]];
+                u64 c = g.mul.coef[e];
+                acc = e2_add(acc, e2_mul_f(q, c == 1 ? other : gl_mul(c, other)));
+            }
+        }
+        store_e2(J.T + idx, acc);
+    }
+}
+void gather_jobs(hipStream_t st, const GatherJob* jobs, int njobs, size_t max_total) {
+    k_gather_jobs<<<dim3((unsigned)std::min<size_t>((max_total + TPB - 1) / TPB, 1024), njobs), TPB, 0, st>>>(jobs);
 }
 __global__ void k_powers_table(u64* __restrict__ W, u64 w, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -65,9 +65,15 @@ void ps_tail(hipStream_t st, const PsJob* jobs, int njobs, int rd0, const E2* ch
 // out[v] = sum_b partials[b*nv + v], v < nv
 void reduce_partials(hipStream_t st, const E2* partials, int nblocks, int nv, E2* out);
 
-// eq(r, .) over n variables (little-endian); multi-point form: out = sum_a alpha[a] * eq(points[a], .)
-void eq_table(hipStream_t st, E2* out, int n, const E2* chal, size_t point_off);
-void eq_combined(hipStream_t st, E2* out, int n, const E2* chal, const ClaimSet& cs);
+// eq tables: out = sum_a alpha_a * eq(point_a, .) over n variables (little-endian), batched over grid.y.
+// Points are runs of the challenge chain (cs.point_off) or, for the kernel-level entry points, of point_dev.
+struct EqJob {
+    E2* out;
+    int n;
+    const E2* point_dev;  // nullptr: points index the chain
+    ClaimSet cs;
+};
+void eq_jobs(hipStream_t st, const EqJob* jobs, int njobs, int max_n, const E2* chal);
 
 // ---- Lasso ------------------------------------------------------------------------------------
 struct LassoDev {
@@ -108,13 +114,15 @@ struct GatherT {
     CsrLin lin; CsrMul mul;     // ptr == nullptr when absent
     const u64* in_vals[PS_MAX_PAIRS];  // node input tables (for the mul part)
 };
-void vanilla_gather_T(hipStream_t st, const GatherT& g, const E2* eqc, int log2_S, int log2_G, int log2_R, E2* T);
+struct GatherJob { GatherT g; const E2* eqc; int log2_S, log2_G, log2_R; E2* T; };
+void gather_jobs(hipStream_t st, const GatherJob* jobs, int njobs, size_t max_total);
 // B[rep*S + y] = sum_mulR eqc[rep*G+gate]*c*eqx[rep*S + j0]*u[i0]
 void vanilla_gather_B(hipStream_t st, const CsrMul& mulR, const E2* eqc, const E2* eqx, const E2* u, int log2_S, int log2_G, int log2_R, E2* B);
 // sum over reps and constant gates of eqc[rep*G+gate]*c -> partials (nv = 1)
 int vanilla_const_sum(hipStream_t st, const u32* gate, const u64* coef, size_t nterms, const E2* eqc, int log2_G, int log2_R, E2* partials);
 // F_c(x) = sum_a alpha_a * scale * prod_b (1 + r_{a,b} (W[(x<<b) & (N-1)] - 1))
-void fft_table(hipStream_t st, E2* out, int L, const u64* W, u64 scale, const E2* chal, const ClaimSet& cs);
+struct FftJob { E2* out; const u64* W; u64 scale; int L; ClaimSet cs; };
+void fft_jobs(hipStream_t st, const FftJob* jobs, int njobs, int max_L, const E2* chal);
 void powers_table(hipStream_t st, u64* W, u64 w, size_t n);  // W[i] = w^i
 
 // ---- NTT (witness generation / hg_ntt) ----------------------------------------------------------

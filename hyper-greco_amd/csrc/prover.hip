@@ -394,6 +394,53 @@ struct Prover {
         ops.push_back([this, s, n] { for (size_t i = 0; i < n; i++) proof.write_e(h_res()[s + i]); });
     }
 
+    // ---- batched bookkeeping kernels (eq tables, zkCNN DFT rows, Libra gathers) ------------------------
+    std::vector<dev::EqJob> eq_queue;
+    std::vector<std::function<void()>> after_eq;  // device work that reads the queued eq tables
+    std::vector<dev::GatherJob> gather_queue;
+    std::vector<dev::FftJob> fft_queue;
+
+    void eq_now(E2* out, int n, size_t point_off, const E2* point_dev = nullptr) {  // single table, launched in place
+        dev::EqJob J;
+        memset(&J, 0, sizeof(J));
+        J.out = out; J.n = n; J.point_dev = point_dev;
+        J.cs.n = 1; J.cs.unit_alpha = 1; J.cs.point_off[0] = point_off;
+        dev::EqJob* d = ctx->alloc_n<dev::EqJob>(1);
+        hip_check(hipMemcpyAsync(d, stage(&J, sizeof(J)), sizeof(J), hipMemcpyHostToDevice, st), "upload eq job");
+        ctx->prof_begin(cls_aux, 16.0 * ((size_t)1 << n));
+        dev::eq_jobs(st, d, 1, n, ctx->d_chal);
+        ctx->prof_end();
+    }
+    void queue_eq(E2* out, int n, const dev::ClaimSet& cs) {
+        dev::EqJob J;
+        memset(&J, 0, sizeof(J));
+        J.out = out; J.n = n; J.cs = cs;
+        eq_queue.push_back(J);
+    }
+    template <typename JobT, typename LaunchFn>
+    void flush_jobs(std::vector<JobT>& q, int cls, double bytes, LaunchFn launch) {
+        if (q.empty()) return;
+        JobT* d = ctx->alloc_n<JobT>(q.size());
+        hip_check(hipMemcpyAsync(d, stage(q.data(), q.size() * sizeof(JobT)), q.size() * sizeof(JobT), hipMemcpyHostToDevice, st), "upload jobs");
+        ctx->prof_begin(cls, bytes);
+        launch(d, (int)q.size());
+        ctx->prof_end();
+        q.clear();
+    }
+    void flush_bookkeeping() {
+        int max_n = 0; double eb = 0;
+        for (auto& J : eq_queue) { max_n = std::max(max_n, J.n); eb += 16.0 * ((size_t)1 << J.n); }
+        flush_jobs(eq_queue, cls_aux, eb, [&](dev::EqJob* d, int nj) { dev::eq_jobs(st, d, nj, max_n, ctx->d_chal); });
+        for (auto& f : after_eq) f();
+        after_eq.clear();
+        size_t max_total = 0; double gb = 0;
+        for (auto& J : gather_queue) { size_t t = (size_t)1 << (J.log2_S + J.log2_R); max_total = std::max(max_total, t); gb += 24.0 * t; }
+        flush_jobs(gather_queue, cls_gather, gb, [&](dev::GatherJob* d, int nj) { dev::gather_jobs(st, d, nj, max_total); });
+        int max_L = 0; double fb = 0;
+        for (auto& J : fft_queue) { max_L = std::max(max_L, J.L); fb += 24.0 * ((size_t)1 << J.L); }
+        flush_jobs(fft_queue, cls_aux, fb, [&](dev::FftJob* d, int nj) { dev::fft_jobs(st, d, nj, max_L, ctx->d_chal); });
+    }
+
     // ---- Lasso node (lasso.rs:57-114) ------------------------------------------------------------
     struct GpOut { size_t point_off; };
     // prove_grand_product (prover.rs:183-266) over nb contiguous tables of `len` base-field values
@@ -467,7 +514,7 @@ struct Prover {
         size_t r_off = epos();
         for (int i = 0; i < nu; i++) squeeze();
         E2* eq = ctx->alloc_n<E2>(N);
-        dev::eq_table(st, eq, nu, ctx->d_chal, r_off);
+        eq_now(eq, nu, r_off);
         size_t claim_slot = slot(1);
         int grid = dev::lasso_claim(st, L, eq, ep, ctx->d_partials);
         reduce(grid, 1, claim_slot);
@@ -517,9 +564,9 @@ struct Prover {
         GpOut g2 = grand_product(H2, M, 2 * G);  // inits then finals (prover.rs:167-171)
         // openings (prover.rs:173-178, mod.rs:80-93)
         E2* eqx = eq;  // the eq(r,.) table is dead by now
-        dev::eq_table(st, eqx, nu, ctx->d_chal, g1.point_off);
+        eq_now(eqx, nu, g1.point_off);
         E2* eqy = ctx->alloc_n<E2>(M);
-        dev::eq_table(st, eqy, 16, ctx->d_chal, g2.point_off);
+        eq_now(eqy, 16, g2.point_off);
         for (auto& chk : lp.chunks) {
             int c = chk.first;
             std::vector<const u64*> xs = {dims + (size_t)c * N, read_ts[c]};
@@ -593,13 +640,15 @@ struct Prover {
         for (auto& c : claims[id]) if (c.len != n.log2_out()) throw Error("gkr: claim arity mismatch");
         Cell claim = combined_value(claims[id], alphas);
         E2* eqc = ctx->alloc_n<E2>((size_t)1 << n.log2_out());
-        ctx->prof_begin(cls_aux, 16.0 * ((size_t)1 << n.log2_out()));
-        dev::eq_combined(st, eqc, n.log2_out(), ctx->d_chal, cs);
-        ctx->prof_end();
+        queue_eq(eqc, n.log2_out(), cs);
+        const hg_pk::NodeDev* ndp0 = &nd;
+        const HNode* np0 = &n;
         if (nd.nconst) {  // claim -= sum_g eqc[g] * w0_g
             size_t s = slot(1);
-            int grid = dev::vanilla_const_sum(st, nd.const_gate, nd.const_coef, nd.nconst, eqc, n.log2_sub_out, n.log2_reps, ctx->d_partials);
-            reduce(grid, 1, s);
+            after_eq.push_back([this, ndp0, np0, eqc, s] {
+                int grid = dev::vanilla_const_sum(st, ndp0->const_gate, ndp0->const_coef, ndp0->nconst, eqc, np0->log2_sub_out, np0->log2_reps, ctx->d_partials);
+                reduce(grid, 1, s);
+            });
             ops.push_back([this, s, claim] { *claim = e2_sub(*claim, h_res()[s]); });
         }
         // phase 1: sum_x sum_i in_i(x) T_i(x)
@@ -618,9 +667,7 @@ struct Prover {
             E2* T = ctx->alloc_n<E2>(SR);
             gt.lin = nd.lin[i];
             gt.mul = nd.mulL[i];
-            ctx->prof_begin(cls_gather, 24.0 * SR);
-            dev::vanilla_gather_T(st, gt, eqc, n.log2_sub_in, n.log2_sub_out, n.log2_reps, T);
-            ctx->prof_end();
+            gather_queue.push_back(dev::GatherJob{gt, eqc, n.log2_sub_in, n.log2_sub_out, n.log2_reps, T});
             a.push_back(d_vals[n.preds[i]]);
             b.push_back(T);
             fa.push_back(d_res() + u_base + i);
@@ -660,12 +707,17 @@ struct Prover {
             for (int i = 0; i < nin; i++) s2.rs.push_back(squeeze());
             second_wave.push_back([this, ri, Bs, a2, fa2, fb2, rx_off, ndp, np, eqc, u_base, SR, nin, s2] {
                 E2* eqx = ctx->alloc_n<E2>(SR);
-                dev::eq_table(st, eqx, nin, ctx->d_chal, rx_off);
-                for (size_t q = 0; q < ri.size(); q++) {
-                    ctx->prof_begin(cls_gather, 40.0 * SR);
-                    dev::vanilla_gather_B(st, ndp->mulR[ri[q]], eqc, eqx, d_res() + u_base, np->log2_sub_in, np->log2_sub_out, np->log2_reps, Bs[q]);
-                    ctx->prof_end();
-                }
+                dev::ClaimSet one;
+                memset(&one, 0, sizeof(one));
+                one.n = 1; one.unit_alpha = 1; one.point_off[0] = rx_off;
+                queue_eq(eqx, nin, one);
+                after_eq.push_back([this, ri, Bs, ndp, np, eqc, eqx, u_base, SR] {
+                    for (size_t q = 0; q < ri.size(); q++) {
+                        ctx->prof_begin(cls_gather, 40.0 * SR);
+                        dev::vanilla_gather_B(st, ndp->mulR[ri[q]], eqc, eqx, d_res() + u_base, np->log2_sub_in, np->log2_sub_out, np->log2_reps, Bs[q]);
+                        ctx->prof_end();
+                    }
+                });
                 const int npairs = (int)ri.size();
                 const size_t N = (size_t)1 << nin;
                 dev::PsJob J;
@@ -699,9 +751,7 @@ struct Prover {
         E2* F = ctx->alloc_n<E2>(N);
         const u64* W = (n.inverse ? pk->w_inv : pk->w_fwd).at(L);
         u64 scale = n.inverse ? gl_inv(gl_from_u64(N)) : 1;
-        ctx->prof_begin(cls_aux, 24.0 * N);
-        dev::fft_table(st, F, L, W, scale, ctx->d_chal, cs);
-        ctx->prof_end();
+        fft_queue.push_back(dev::FftJob{F, W, scale, L, cs});
         size_t u = slot(1);
         E2* scratch = ctx->alloc_n<E2>(1);
         ScHandle s = sc_prodsum({d_vals[n.preds[0]]}, {F}, L, {d_res() + u}, {scratch});
@@ -731,9 +781,11 @@ struct Prover {
                 }
             }
         }
+        flush_bookkeeping();                   // eq tables, constant sums, Libra gathers, DFT-row tables: batched
         flush_prodsum();                       // first wave: every FFT / Libra phase-1 reduction, batched
         for (auto& f : second_wave) f();       // Libra phase-2 bookkeeping (needs the phase-1 scalars in HBM)
         second_wave.clear();
+        flush_bookkeeping();
         flush_prodsum();
     }
 
@@ -805,7 +857,7 @@ ProveResult prove_resident(hg_ctx* ctx, const hg_pk* pk, const hg_values* v) {
     size_t vslot = P.slot(1);
     {
         E2* eq = ctx->alloc_n<E2>((size_t)1 << ov);
-        dev::eq_table(ctx->stream, eq, ov, ctx->d_chal, point_off);
+        P.eq_now(eq, ov, point_off);
         const u64* tabs[8] = {v->d_ct0is};
         int grid = dev::dot_eq(ctx->stream, eq, tabs, 1, (size_t)1 << ov, ctx->d_partials);
         P.reduce(grid, 1, vslot);
@@ -915,7 +967,7 @@ E2 mle_eval_device(hg_ctx* ctx, const u64* table_host, size_t nv, const E2* poin
     E2* eq = ctx->alloc_n<E2>(N);
     hip_check(hipMemcpyAsync(d, table_host, N * 8, hipMemcpyHostToDevice, ctx->stream), "upload");
     if (nv) hip_check(hipMemcpyAsync(pt, point_host, nv * 16, hipMemcpyHostToDevice, ctx->stream), "upload");
-    dev::eq_table(ctx->stream, eq, (int)nv, pt, 0);
+    P.eq_now(eq, (int)nv, 0, pt);
     const u64* tabs[8] = {d};
     int grid = dev::dot_eq(ctx->stream, eq, tabs, 1, N, ctx->d_partials);
     size_t s = P.slot(1);
