@@ -19,7 +19,24 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
-DOMINANT = "sc_round<grand_product,ext>"
+DOMINANT = "sc_round<grand_product,ext>"          # profile class name in the library
+DOMINANT_SYMBOL = "k_st_step<1, hg::E2>"          # its kernel symbol in rocprofv3 output
+PMC_FILE = os.path.join(ROOT, "profiles", "r01_c_pmc_hbm_traffic.json")
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE collected in separate runs, FETCH_SIZE doubled as the MI355X guide prescribes for gfx950;
+    scripts/pmc_summary.py). PMC counters cannot be read from inside this process, so this is the value
+    measured by `rocprofv3 --pmc ... -- python3 scripts/prove_once.py 32768 16 2` on the same workload."""
+    try:
+        d = json.load(open(PMC_FILE))
+        for k, v in d.items():
+            if DOMINANT_SYMBOL in k:
+                return round(v["hbm_bytes_per_launch"])
+    except Exception:
+        pass
+    return None
 
 
 def cpu_baseline(n, k, seed, budget_s=45.0):
@@ -188,7 +205,7 @@ def main():
                        "proof_bytes": len(first), "gpu_ms_events": round(gpu_ms, 4),
                        "witness_gen_ms_host": round(vals.timings["witness_ms"], 2), "upload_ms": round(vals.timings["upload_ms"], 2)},
             "roofline": {"bound": "hbm", "kernel": DOMINANT, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(),
                          "launches_per_step": dom["launches"] // max(args.steps, 1),
                          "avg_launch_us": round(avg_ms * 1e3, 3), "algo_bytes_per_launch": round(per_launch_bytes)},
             "kernel_classes": classes,
