@@ -38,7 +38,7 @@ class HgKernelStat(C.Structure):
 EXPORTS = [
     "hg_last_error", "hg_device_count", "hg_create", "hg_destroy", "hg_params_builtin", "hg_setup", "hg_pk_free",
     "hg_pk_lasso_layout", "hg_pk_info", "hg_witness_from_json", "hg_witness_synthetic", "hg_witness_from_arrays",
-    "hg_witness_get", "hg_witness_free", "hg_prove", "hg_witness_gen", "hg_values_free", "hg_prove_resident", "hg_circuit_eval", "hg_lasso_prove", "hg_sumcheck", "hg_mle_eval",
+    "hg_witness_get", "hg_witness_free", "hg_prove", "hg_witness_gen", "hg_values_free", "hg_values_get", "hg_prove_resident", "hg_circuit_eval", "hg_lasso_prove", "hg_sumcheck", "hg_mle_eval",
     "hg_ntt", "hg_challenges", "hg_profile", "hg_profile_reset", "hg_profile_get",
 ]
 
@@ -78,6 +78,8 @@ def lib():
         L.hg_prove.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(HgTimings)]
         L.hg_witness_gen.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(HgTimings)]
         L.hg_values_free.argtypes = [C.c_void_p]
+        L.hg_values_get.restype = C.c_int64
+        L.hg_values_get.argtypes = [C.c_void_p, C.c_void_p, C.c_int, u64p, C.c_size_t]
         L.hg_prove_resident.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(HgTimings)]
         L.hg_circuit_eval.argtypes = [C.c_void_p, C.c_void_p, u64p, C.c_size_t, u64p, C.c_size_t]
         L.hg_lasso_prove.argtypes = [C.c_void_p, C.c_void_p, u64p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), u64p]
@@ -226,9 +228,9 @@ class ProverKey:
     def __init__(self, handle, params):
         self.h = handle
         self.params = params
-        info = (C.c_uint64 * 4)()
+        info = (C.c_uint64 * 6)()
         lib().hg_pk_info(self.h, info)
-        self.nu, self.num_nodes, self.rows, self.alpha = (int(x) for x in info)
+        self.nu, self.num_nodes, self.rows, self.alpha, self.lasso_in_id, self.sum_id = (int(x) for x in info)
 
     def lasso_layout(self):
         buf = C.create_string_buffer(1 << 16)
@@ -280,6 +282,14 @@ class ResidentValues:
     def __init__(self, handle, timings):
         self.h = handle
         self.timings = timings
+
+    def node(self, ctx, node_id):
+        n = lib().hg_values_get(ctx.h, self.h, node_id, None, 0)
+        if n < 0:
+            raise HgError(lib().hg_last_error().decode())
+        a = np.zeros(n, dtype=np.uint64)
+        lib().hg_values_get(ctx.h, self.h, node_id, _ptr(a), n)
+        return a
 
     def free(self):
         if self.h:

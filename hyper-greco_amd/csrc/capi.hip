@@ -155,6 +155,36 @@ int hg_setup(hg_ctx* ctx, const hg_params* params, hg_pk** out) {
             if (!ml_by[i].empty()) nd.mulL[i] = mk(ml_by[i], true);
             if (!mr_by[i].empty()) nd.mulR[i] = mk(mr_by[i], false);
         }
+        {   // gate-major (forward) wiring for witness generation on the device
+            dev::EvalNode& f = nd.fwd;
+            memset(&f, 0, sizeof(f));
+            f.log2_G = n.log2_sub_out; f.log2_S = n.log2_sub_in; f.log2_R = n.log2_reps; f.num_gates = n.num_gates;
+            const size_t G = n.num_gates;
+            if (!n.lin.empty()) {
+                std::vector<u32> ptr(G + 1, 0), in(n.lin.size()), jj(n.lin.size());
+                std::vector<u64> cf(n.lin.size());
+                for (auto& t : n.lin) ptr[t.gate + 1]++;
+                for (size_t i = 0; i < G; i++) ptr[i + 1] += ptr[i];
+                std::vector<u32> fill(ptr.begin(), ptr.end() - 1);
+                for (auto& t : n.lin) { u32 at = fill[t.gate]++; in[at] = t.in; jj[at] = t.j; cf[at] = t.c; }
+                f.lptr = upload_vec(pk.get(), ptr); f.lin_in = upload_vec(pk.get(), in); f.lin_j = upload_vec(pk.get(), jj); f.lcoef = upload_vec(pk.get(), cf);
+            }
+            if (!n.mul.empty()) {
+                std::vector<u32> ptr(G + 1, 0), i0(n.mul.size()), j0(n.mul.size()), i1(n.mul.size()), j1(n.mul.size());
+                std::vector<u64> cf(n.mul.size());
+                for (auto& t : n.mul) ptr[t.gate + 1]++;
+                for (size_t i = 0; i < G; i++) ptr[i + 1] += ptr[i];
+                std::vector<u32> fill(ptr.begin(), ptr.end() - 1);
+                for (auto& t : n.mul) { u32 at = fill[t.gate]++; i0[at] = t.i0; j0[at] = t.j0; i1[at] = t.i1; j1[at] = t.j1; cf[at] = t.c; }
+                f.mptr = upload_vec(pk.get(), ptr); f.mi0 = upload_vec(pk.get(), i0); f.mj0 = upload_vec(pk.get(), j0);
+                f.mi1 = upload_vec(pk.get(), i1); f.mj1 = upload_vec(pk.get(), j1); f.mcoef = upload_vec(pk.get(), cf);
+            }
+            if (!n.w0.empty()) {
+                std::vector<u64> dense(G, 0);
+                for (auto& t : n.w0) dense[t.gate] = gl_add(dense[t.gate], t.c);
+                f.w0 = upload_vec(pk.get(), dense);
+            }
+        }
         if (!n.w0.empty()) {
             std::vector<u32> g;
             std::vector<u64> cf;
@@ -184,7 +214,9 @@ int hg_pk_lasso_layout(const hg_pk* pk, char* out, size_t cap) {
     HG_CATCH(-1)
 }
 
-int hg_pk_info(const hg_pk* pk, uint64_t out[4]) {
+int hg_pk_info(const hg_pk* pk, uint64_t out[6]) {
+    out[4] = (uint64_t)pk->circuit.lasso_in_id;
+    out[5] = (uint64_t)pk->circuit.sum_id;
     out[0] = (uint64_t)pk->lasso.nu;
     out[1] = pk->circuit.nodes.size();
     out[2] = pk->lasso.rows;
@@ -257,6 +289,18 @@ int hg_witness_gen(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, hg_values*
 }
 
 void hg_values_free(hg_values* v) { values_free(v); }
+
+int64_t hg_values_get(hg_ctx* ctx, const hg_values* v, int node, uint64_t* out, size_t cap) {
+    HG_TRY
+    if (!v || node < 0 || (size_t)node >= v->d_vals.size()) throw Error("hg_values_get: bad node id");
+    size_t n = v->sizes[node];
+    if (out && v->d_vals[node]) {
+        hip_check(hipSetDevice(ctx->device), "hipSetDevice");
+        hip_check(hipMemcpy(out, v->d_vals[node], std::min(cap, n) * 8, hipMemcpyDeviceToHost), "download node values");
+    }
+    return (int64_t)n;
+    HG_CATCH(-1)
+}
 
 static double now_ms_capi() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 

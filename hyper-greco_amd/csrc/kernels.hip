@@ -787,6 +787,41 @@ void powers_table(hipStream_t st, u64* W, u64 w, size_t n) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Vanilla node evaluation: out[rep][g] = w0_g + sum c * in_i[rep][j] + sum c * in_i0[rep][j0] * in_i1[rep][j1]
+__global__ __launch_bounds__(TPB) void k_gate_eval(EvalNode N) {
+    const size_t total = (size_t)1 << (N.log2_G + N.log2_R);
+    const size_t gmask = ((size_t)1 << N.log2_G) - 1;
+    for (size_t idx = (size_t)blockIdx.x * TPB + threadIdx.x; idx < total; idx += (size_t)gridDim.x * TPB) {
+        const size_t g = idx & gmask, rep = idx >> N.log2_G;
+        u64 acc = 0;
+        if (g < N.num_gates) {
+            if (N.w0) acc = N.w0[g];
+            if (N.lptr) {
+                for (u32 e = N.lptr[g]; e < N.lptr[g + 1]; e++) {
+                    u64 x = N.in[N.lin_in[e]][(rep << N.log2_S) + N.lin_j[e]];
+                    u64 c = N.lcoef[e];
+                    acc = gl_add(acc, c == 1 ? x : gl_mul(c, x));
+                }
+            }
+            if (N.mptr) {
+                for (u32 e = N.mptr[g]; e < N.mptr[g + 1]; e++) {
+                    u64 x = N.in[N.mi0[e]][(rep << N.log2_S) + N.mj0[e]];
+                    u64 y = N.in[N.mi1[e]][(rep << N.log2_S) + N.mj1[e]];
+                    u64 c = N.mcoef[e];
+                    u64 pr = gl_mul(x, y);
+                    acc = gl_add(acc, c == 1 ? pr : gl_mul(c, pr));
+                }
+            }
+        }
+        N.out[idx] = acc;
+    }
+}
+void gate_eval(hipStream_t st, const EvalNode& n) {
+    size_t total = (size_t)1 << (n.log2_G + n.log2_R);
+    k_gate_eval<<<(unsigned)std::min<size_t>((total + TPB - 1) / TPB, 4096), TPB, 0, st>>>(n);
+}
+
+// ------------------------------------------------------------------------------------------------
 // NTT: decimation-in-frequency stages in HBM, then bit reversal (+ scaling for the inverse)
 __global__ __launch_bounds__(TPB) void k_ntt_stage(u64* __restrict__ data, int log2n, int s, size_t batch, const u64* __restrict__ W) {
     const size_t halfN = (size_t)1 << (log2n - 1);

@@ -125,6 +125,18 @@ struct FftJob { E2* out; const u64* W; u64 scale; int L; ClaimSet cs; };
 void fft_jobs(hipStream_t st, const FftJob* jobs, int njobs, int max_L, const E2* chal);
 void powers_table(hipStream_t st, u64* W, u64 w, size_t n);  // W[i] = w^i
 
+// ---- circuit evaluation (witness generation): one Vanilla node, gate-major wiring -------------------------
+struct EvalNode {
+    const u32* lptr; const u32* lin_in; const u32* lin_j; const u64* lcoef;   // linear terms per gate
+    const u32* mptr; const u32* mi0; const u32* mj0; const u32* mi1; const u32* mj1; const u64* mcoef;  // mul terms per gate
+    const u64* w0;                 // dense constants per gate, or nullptr
+    const u64* in[PS_MAX_PAIRS];   // input tables
+    u64* out;
+    int log2_G, log2_S, log2_R;
+    u32 num_gates;
+};
+void gate_eval(hipStream_t st, const EvalNode& n);
+
 // ---- NTT (witness generation / hg_ntt) ----------------------------------------------------------
 void ntt_batch(hipStream_t st, u64* data, int log2n, size_t batch, const u64* W /* w^i, i < N/2 */, u64 scale);
 

@@ -3,6 +3,7 @@
 #include <chrono>
 #include <cstring>
 #include <memory>
+#include <tuple>
 
 namespace hg {
 
@@ -805,31 +806,82 @@ struct Prover {
 
 // ------------------------------------------------------------------------------------------------
 hg_values* witness_gen(hg_ctx* ctx, const hg_pk* pk, const Witness& w, double* witness_ms, double* upload_ms) {
+    // Circuit::evaluate on the device: inputs are uploaded, then the circuit is evaluated level by level
+    // (Vanilla nodes: gate-major kernel; FFT nodes: batched NTTs, same level + direction in one batch).
     hip_check(hipSetDevice(ctx->device), "hipSetDevice");
     const HCircuit& c = pk->circuit;
+    const Params& p = pk->params;
+    const size_t nn = c.nodes.size();
     double t0 = wall_ms();
-    std::vector<std::vector<u64>> vals = circuit_evaluate(c, pk->params, w);  // witness generation (host, OpenMP)
-    double t1 = wall_ms();
+    std::vector<int> level(nn, 0);
+    int maxl = 0;
+    for (int id : c.topo) { for (int pr : c.nodes[id].preds) level[id] = std::max(level[id], level[pr] + 1); maxl = std::max(maxl, level[id]); }
     std::unique_ptr<hg_values> v(new hg_values());
-    v->d_vals.assign(c.nodes.size(), nullptr);
+    v->d_vals.assign(nn, nullptr);
+    v->sizes.assign(nn, 0);
+    // layout: FFT nodes of one (level, direction) group are contiguous so that one batched NTT covers the group
+    std::vector<int> order(nn);
+    for (size_t i = 0; i < nn; i++) order[i] = (int)i;
+    auto key = [&](int id) { const HNode& n = c.nodes[id]; return std::make_tuple(n.kind == NK_FFT ? 1 : 0, level[id], n.inverse ? 1 : 0, id); };
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return key(a) < key(b); });
     size_t total = w.ct0is.size();
-    for (size_t id = 0; id < c.nodes.size(); id++) if (!c.nodes[id].succs.empty()) total += vals[id].size();
+    for (size_t id = 0; id < nn; id++) { v->sizes[id] = (size_t)1 << c.nodes[id].log2_out(); total += v->sizes[id]; }
     u64* base = nullptr;
     hip_check(hipMalloc((void**)&base, total * 8), "hipMalloc(node values)");
     v->owned.push_back(base);
     size_t off = 0;
-    for (size_t id = 0; id < c.nodes.size(); id++) {
-        if (c.nodes[id].succs.empty()) continue;  // outputs are never read by a reduction
-        hip_check(hipMemcpyAsync(base + off, vals[id].data(), vals[id].size() * 8, hipMemcpyHostToDevice, ctx->stream), "upload node values");
-        v->d_vals[id] = base + off;
-        off += vals[id].size();
-    }
-    hip_check(hipMemcpyAsync(base + off, w.ct0is.data(), w.ct0is.size() * 8, hipMemcpyHostToDevice, ctx->stream), "upload ct0is");
+    std::vector<u64*> dv(nn);
+    for (int id : order) { dv[id] = base + off; v->d_vals[id] = dv[id]; off += v->sizes[id]; }
     v->d_ct0is = base + off;
-    hip_check(hipStreamSynchronize(ctx->stream), "upload sync");
+    hipStream_t st = ctx->stream;
+    {   // inputs in NodeId order: s, e, k1, ais.., r1is.., r2is (chain_par! sk_encryption_circuit.rs:408)
+        const size_t SZ = p.SZ();
+        size_t idx = 0;
+        auto put = [&](const u64* src, size_t len) {
+            int id = c.input_ids.at(idx++);
+            if (len != v->sizes[id]) throw Error("circuit: input size mismatch");
+            hip_check(hipMemcpyAsync(dv[id], src, len * 8, hipMemcpyHostToDevice, st), "upload input");
+        };
+        put(w.s.data(), SZ); put(w.e.data(), SZ); put(w.k1.data(), SZ);
+        for (int i = 0; i < p.k; i++) put(&w.ais[i * SZ], SZ);
+        for (int i = 0; i < p.k; i++) put(&w.r1is[i * SZ], SZ);
+        put(w.r2is.data(), w.r2is.size());
+        hip_check(hipMemcpyAsync(base + off, w.ct0is.data(), w.ct0is.size() * 8, hipMemcpyHostToDevice, st), "upload ct0is");
+    }
+    hip_check(hipStreamSynchronize(st), "upload sync");
+    double t1 = wall_ms();
+    for (int l = 1; l <= maxl; l++) {
+        for (int inv = 0; inv < 2; inv++) {  // FFT groups
+            std::vector<int> grp;
+            for (int id : order) if (c.nodes[id].kind == NK_FFT && level[id] == l && (int)c.nodes[id].inverse == inv) grp.push_back(id);
+            if (grp.empty()) continue;
+            const int L = c.nodes[grp[0]].log2_size;
+            const size_t N = (size_t)1 << L;
+            for (int id : grp) {
+                if (c.nodes[id].log2_size != L) throw Error("circuit: mixed FFT sizes in one level");
+                hip_check(hipMemcpyAsync(dv[id], dv[c.nodes[id].preds[0]], N * 8, hipMemcpyDeviceToDevice, st), "copy fft input");
+            }
+            const u64* W = (inv ? pk->w_inv : pk->w_fwd).at(L);
+            dev::ntt_batch(st, dv[grp[0]], L, grp.size(), W, inv ? gl_inv(gl_from_u64(N)) : 1);
+        }
+        for (int id : c.topo) {
+            const HNode& n = c.nodes[id];
+            if (level[id] != l) continue;
+            if (n.kind == NK_VANILLA) {
+                dev::EvalNode e = pk->node_dev[id].fwd;
+                for (int i = 0; i < n.arity; i++) e.in[i] = dv[n.preds[i]];
+                e.out = dv[id];
+                dev::gate_eval(st, e);
+            } else if (n.kind == NK_LASSO) {
+                hip_check(hipMemsetAsync(dv[id], 0, 8, st), "lasso output");  // LassoNode::evaluate returns [0] (lasso.rs:53-55)
+            }
+        }
+    }
+    hip_check(hipStreamSynchronize(st), "witness generation sync");
+    hip_check(hipGetLastError(), "witness generation");
     double t2 = wall_ms();
-    if (witness_ms) *witness_ms = t1 - t0;
-    if (upload_ms) *upload_ms = t2 - t1;
+    if (upload_ms) *upload_ms = t1 - t0;
+    if (witness_ms) *witness_ms = t2 - t1;
     return v.release();
 }
 

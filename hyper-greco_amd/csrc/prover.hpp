@@ -73,6 +73,7 @@ struct hg_pk {
         const hg::u32* const_gate = nullptr;
         const hg::u64* const_coef = nullptr;
         size_t nconst = 0;
+        hg::dev::EvalNode fwd{};  // gate-major wiring for circuit evaluation (in/out pointers filled per run)
     };
     std::vector<NodeDev> node_dev;
     std::map<int, const hg::u64*> w_fwd, w_inv;  // log2n -> w^i table (N entries)
@@ -81,7 +82,8 @@ struct hg_pk {
 };
 
 struct hg_values {
-    std::vector<const hg::u64*> d_vals;  // per node (nullptr for pure outputs)
+    std::vector<const hg::u64*> d_vals;  // per node
+    std::vector<size_t> sizes;
     const hg::u64* d_ct0is = nullptr;
     std::vector<void*> owned;
 };

@@ -71,8 +71,8 @@ int hg_setup(hg_ctx* ctx, const hg_params* params, hg_pk** pk); /* ctx == NULL: 
 void hg_pk_free(hg_pk* pk);
 /* Lasso memory map as text "subtable@dim,...|lookup:bits:m/m;..." (for tests) */
 int hg_pk_lasso_layout(const hg_pk* pk, char* out, size_t cap);
-/* [nu, num_nodes, rows, alpha] */
-int hg_pk_info(const hg_pk* pk, uint64_t out[4]);
+/* [nu, num_nodes, rows, alpha, NodeId of lasso_inputs_batched, NodeId of sum] */
+int hg_pk_info(const hg_pk* pk, uint64_t out[6]);
 
 /* = serde_json::from_str::<BfvSkEncryptArgs> + BfvEncrypt::get_inputs / Poly::{new,new_padded,new_shifted}
  *   [REF bfv-gkr/src/test.rs:21-33, sk_encryption_circuit.rs:365-415, poly.rs:12-44] */
@@ -94,12 +94,15 @@ int hg_prove(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, uint8_t* proof, 
              hg_timings* timings);
 
 /* The two halves of hg_prove, split where the reference splits its spans:
- *   hg_witness_gen   = "wintess gen": circuit.evaluate(inputs) [REF sk_encryption_circuit.rs:439-442], then the node
- *                      tables are copied to HBM and stay resident (owned by the returned handle);
+ *   hg_witness_gen   = "wintess gen": circuit.evaluate(inputs) [REF sk_encryption_circuit.rs:439-442] ON THE DEVICE: the
+ *                      3+2k+1 input tables are uploaded, the 2k+1 size-2^L NTTs (FFT -> pointwise mul -> IFFT) and
+ *                      the Vanilla gate maps run as HIP kernels; every node table stays resident in HBM;
  *   hg_prove_resident = "eval output" + "GKR prove" [REF sk_encryption_circuit.rs:444-457] on resident tables.
  * bench.py times hg_prove_resident (inputs already in HBM when the timed region starts). */
 int hg_witness_gen(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, hg_values** out, hg_timings* timings);
 void hg_values_free(hg_values* v);
+/* copies node `node`'s table (NodeId order of configure) back to the host; returns its element count */
+int64_t hg_values_get(hg_ctx* ctx, const hg_values* v, int node, uint64_t* out, size_t cap);
 int hg_prove_resident(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, uint8_t* proof, size_t cap, size_t* len,
                       hg_timings* timings);
 

@@ -106,6 +106,24 @@ def test_mle_eval_and_ntt(ctx):
 FIX = [(1024, 1, 27), (4096, 2, 55)]
 
 
+@pytest.mark.parametrize("n,k", [(1024, 1), (4096, 2), (32768, 16)])
+def test_device_witness_generation_matches_host(ctx, n, k):
+    """Circuit::evaluate on the device (batched NTTs + gate kernels) vs the host evaluation and the oracle."""
+    bfv = hg.BfvEncrypt.new(n, k)
+    pk = bfv.setup(ctx)
+    w = hg.Witness.synthetic(bfv.params, 0x4752454330 + n)
+    vals = hg.witness_gen(ctx, pk, w)
+    lasso_in, sum_out = pk.circuit_eval(w)  # host
+    assert (vals.node(ctx, pk.lasso_in_id) == lasso_in).all()
+    assert (vals.node(ctx, pk.sum_id) == sum_out).all()
+    assert (sum_out == w.arrays()["ct0is"]).all()
+    if n <= 4096:
+        o_lasso, o_sum, _ = orclib.circuit_eval(orclib.params(n, k), orclib.Inputs(w.arrays()))
+        assert (o_lasso == lasso_in).all() and (o_sum == sum_out).all()
+    vals.free()
+    pk.free()
+
+
 @pytest.mark.parametrize("n,k,bits", FIX)
 def test_lasso_node_transcript_bit_exact(ctx, n, k, bits):
     bfv = hg.BfvEncrypt.new(n, k)
