@@ -81,6 +81,21 @@ __device__ __forceinline__ void load_pair<E2>(const E2* p, E2& x, E2& y) {
     ulonglong2 b = *reinterpret_cast<const ulonglong2*>(p + 1);
     x = e2(a.x, a.y); y = e2(b.x, b.y);
 }
+// Folded (E2) tables are stored DE-INTERLEAVED: logical entry i of a table of length 2h lives at (i & 1) * h + (i >> 1),
+// so the pair (T[2j], T[2j+1]) the next round needs is (buf[j], buf[h + j]): both loads are 16 B per lane and
+// contiguous across the wave (a 32-B lane stride would halve the useful bytes per load instruction).
+// Round-0 inputs (level rows, node tables, bookkeeping tables) are in natural order.
+template <typename T, bool NATURAL>
+__device__ __forceinline__ void load_xy(const T* tab, size_t j, size_t half, T& x, T& y) {
+    if constexpr (NATURAL || std::is_same<T, u64>::value) load_pair<T>(tab + 2 * j, x, y);
+    else {
+        ulonglong2 a = *reinterpret_cast<const ulonglong2*>(tab + j);
+        ulonglong2 b = *reinterpret_cast<const ulonglong2*>(tab + half + j);
+        x = e2(a.x, a.y); y = e2(b.x, b.y);
+    }
+}
+// position of logical entry j in a de-interleaved table of length `len`
+__device__ __forceinline__ size_t dpos(size_t j, size_t len) { return (j & 1) * (len >> 1) + (j >> 1); }
 __device__ __forceinline__ void store_e2(E2* p, E2 v) {
     *reinterpret_cast<ulonglong2*>(p) = make_ulonglong2(v.c0, v.c1);
 }
@@ -98,8 +113,8 @@ __device__ __forceinline__ void store_e2(E2* p, E2 v) {
 // evaluations by gamma^i again before they reach the transcript.
 template <int KIND, typename T, bool FIRST>
 __device__ __forceinline__ void sc_round_body(const T* __restrict__ in, size_t in_stride, E2* __restrict__ out,
-                                              size_t out_stride, int ntab, size_t half, E2 r, const E2* __restrict__ pw, int jb_log2,
-                                              E2* __restrict__ red, E2* acc, size_t first_tile, size_t tile_step) {
+                                              size_t out_stride, int ntab, size_t half, E2 r, const E2* __restrict__ pw, const E2* __restrict__ pwr,
+                                              int jb_log2, E2* __restrict__ red, E2* acc, size_t first_tile, size_t tile_step) {
     using V = Val<T>;
     const int BD = blockDim.x, tid = threadIdx.x;
     const int G = BD >> jb_log2;
@@ -107,32 +122,33 @@ __device__ __forceinline__ void sc_round_body(const T* __restrict__ in, size_t i
     const size_t ntiles = half >> jb_log2;  // host guarantees 2^jb_log2 <= half
     for (size_t tile = first_tile; tile < ntiles; tile += tile_step) {
         const size_t j = (tile << jb_log2) + jj;
+        const size_t jo = dpos(j, half);  // this round's output (length `half`) is written de-interleaved
         if constexpr (KIND == SC_GRANDPROD) {
             E2 s0 = e2_zero(), s2 = e2_zero(), s3 = e2_zero();
             T p0 = V::zero(), p2 = V::zero(), p3 = V::zero();
             const int nb = ntab >> 1;
             for (int i = g; i < nb; i += G) {
                 T xl, yl, xr, yr;
-                load_pair<T>(in + (size_t)(2 * i) * in_stride + 2 * j, xl, yl);
-                load_pair<T>(in + (size_t)(2 * i + 1) * in_stride + 2 * j, xr, yr);
+                load_xy<T, FIRST>(in + (size_t)(2 * i) * in_stride, j, half, xl, yl);
+                load_xy<T, FIRST>(in + (size_t)(2 * i + 1) * in_stride, j, half, xr, yr);
                 T dl = V::sub(yl, xl), dr = V::sub(yr, xr);
-                T l2 = V::add(yl, dl), r2 = V::add(yr, dr);
-                T l3 = V::add(l2, dl), r3 = V::add(r2, dr);
-                if (i == 0) { p0 = xl; p2 = l2; p3 = l3; }
+                if (i == 0) { p0 = xl; p2 = V::add(yl, dl); p3 = V::add(p2, dl); }
+                // a(t) b(t) = P0 + t (P1 - P0 - Pinf) + t^2 Pinf with P0 = a(0)b(0), P1 = a(1)b(1), Pinf = (a1-a0)(b1-b0):
+                // accumulate the three products, combine to t = 2, 3 once per j (after the loop)
                 if constexpr (FIRST) {
                     E2 gm = pw[i];
                     s0 = e2_add(s0, V::scale(gm, V::mul(xl, xr)));
-                    s2 = e2_add(s2, V::scale(gm, V::mul(l2, r2)));
-                    s3 = e2_add(s3, V::scale(gm, V::mul(l3, r3)));
+                    s2 = e2_add(s2, V::scale(gm, V::mul(yl, yr)));
+                    s3 = e2_add(s3, V::scale(gm, V::mul(dl, dr)));
                     // gamma^i * (xl + r dl) = gamma^i xl + (gamma^i r) dl
-                    store_e2(out + (size_t)(2 * i) * out_stride + j, e2_add(V::scale(gm, xl), V::scale(e2_mul(gm, r), dl)));
+                    store_e2(out + (size_t)(2 * i) * out_stride + jo, e2_add(V::scale(gm, xl), V::scale(pwr[i], dl)));
                 } else {
                     s0 = e2_add(s0, V::lift(V::mul(xl, xr)));
-                    s2 = e2_add(s2, V::lift(V::mul(l2, r2)));
-                    s3 = e2_add(s3, V::lift(V::mul(l3, r3)));
-                    store_e2(out + (size_t)(2 * i) * out_stride + j, V::fold(xl, dl, r));
+                    s2 = e2_add(s2, V::lift(V::mul(yl, yr)));
+                    s3 = e2_add(s3, V::lift(V::mul(dl, dr)));
+                    store_e2(out + (size_t)(2 * i) * out_stride + jo, V::fold(xl, dl, r));
                 }
-                store_e2(out + (size_t)(2 * i + 1) * out_stride + j, V::fold(xr, dr, r));
+                store_e2(out + (size_t)(2 * i + 1) * out_stride + jo, V::fold(xr, dr, r));
             }
             if (G > 1) {
                 red[tid] = s0; red[BD + tid] = s2; red[2 * BD + tid] = s3;
@@ -147,15 +163,20 @@ __device__ __forceinline__ void sc_round_body(const T* __restrict__ in, size_t i
                 __syncthreads();
             }
             if (g == 0) {
-                acc[0] = e2_add(acc[0], V::scale(s0, p0));
-                acc[1] = e2_add(acc[1], V::scale(s2, p2));
-                acc[2] = e2_add(acc[2], V::scale(s3, p3));
+                // (s0, s2, s3) hold (sum P0, sum P1, sum Pinf): q(2) = 2 P1 - P0 + 2 Pinf, q(3) = 3 P1 - 2 P0 + 6 Pinf
+                E2 P0 = s0, P1 = s2, Pi = s3;
+                E2 P1x2 = e2_dbl(P1), Pix2 = e2_dbl(Pi);
+                E2 q2 = e2_add(e2_sub(P1x2, P0), Pix2);
+                E2 q3 = e2_add(e2_sub(e2_add(P1x2, P1), e2_dbl(P0)), e2_add(e2_dbl(Pix2), Pix2));
+                acc[0] = e2_add(acc[0], V::scale(P0, p0));
+                acc[1] = e2_add(acc[1], V::scale(q2, p2));
+                acc[2] = e2_add(acc[2], V::scale(q3, p3));
             }
         } else {
             T s0 = V::zero(), s2 = V::zero(), p0 = V::zero(), p2 = V::zero();
             for (int i = g; i < ntab; i += G) {
                 T x, y;
-                load_pair<T>(in + (size_t)i * in_stride + 2 * j, x, y);
+                load_xy<T, FIRST>(in + (size_t)i * in_stride, j, half, x, y);
                 T d = V::sub(y, x);
                 T v2 = V::add(y, d);
                 if (i == 0) { p0 = x; p2 = v2; }
@@ -167,7 +188,7 @@ __device__ __forceinline__ void sc_round_body(const T* __restrict__ in, size_t i
                     s0 = e2_add(s0, e2_mul_f(x, m));
                     s2 = e2_add(s2, e2_mul_f(v2, m));
                 }
-                store_e2(out + (size_t)i * out_stride + j, V::fold(x, d, r));
+                store_e2(out + (size_t)i * out_stride + jo, V::fold(x, d, r));
             }
             E2 t0 = V::lift(s0), t2 = V::lift(s2);
             if (G > 1) {
@@ -229,8 +250,8 @@ __global__ __launch_bounds__(256) void k_st_step(const StJob* __restrict__ jobs,
     E2 acc[NV];
 #pragma unroll
     for (int t = 0; t < NV; t++) acc[t] = e2_zero();
-    if (rd == 0) sc_round_body<KIND, T, true>(reinterpret_cast<const T*>(in), in_stride, out, half, J.ntab, half, chal[J.r_off + rd], J.pw, jb_log2, red, acc, blockIdx.x, gridDim.x);
-    else sc_round_body<KIND, T, false>(reinterpret_cast<const T*>(in), in_stride, out, half, J.ntab, half, chal[J.r_off + rd], J.pw, jb_log2, red, acc, blockIdx.x, gridDim.x);
+    if (rd == 0) sc_round_body<KIND, T, true>(reinterpret_cast<const T*>(in), in_stride, out, half, J.ntab, half, chal[J.r_off + rd], J.pw, J.pwr, jb_log2, red, acc, blockIdx.x, gridDim.x);
+    else sc_round_body<KIND, T, false>(reinterpret_cast<const T*>(in), in_stride, out, half, J.ntab, half, chal[J.r_off + rd], J.pw, J.pwr, jb_log2, red, acc, blockIdx.x, gridDim.x);
 #pragma unroll
     for (int t = 0; t < NV; t++) {
         E2 s = block_sum_n(acc[t], sm);
@@ -274,9 +295,9 @@ __global__ __launch_bounds__(1024) void k_st_tail(const StJob* __restrict__ jobs
         E2 acc[NV];
 #pragma unroll
         for (int t = 0; t < NV; t++) acc[t] = e2_zero();
-        if (rd == 0 && J.base) sc_round_body<KIND, u64, true>(reinterpret_cast<const u64*>(in), in_stride, out, half, J.ntab, half, r, J.pw, jb_log2, red, acc, 0, 1);
-        else if (rd == 0) sc_round_body<KIND, E2, true>(reinterpret_cast<const E2*>(in), in_stride, out, half, J.ntab, half, r, J.pw, jb_log2, red, acc, 0, 1);
-        else sc_round_body<KIND, E2, false>(reinterpret_cast<const E2*>(in), in_stride, out, half, J.ntab, half, r, J.pw, jb_log2, red, acc, 0, 1);
+        if (rd == 0 && J.base) sc_round_body<KIND, u64, true>(reinterpret_cast<const u64*>(in), in_stride, out, half, J.ntab, half, r, J.pw, J.pwr, jb_log2, red, acc, 0, 1);
+        else if (rd == 0) sc_round_body<KIND, E2, true>(reinterpret_cast<const E2*>(in), in_stride, out, half, J.ntab, half, r, J.pw, J.pwr, jb_log2, red, acc, 0, 1);
+        else sc_round_body<KIND, E2, false>(reinterpret_cast<const E2*>(in), in_stride, out, half, J.ntab, half, r, J.pw, J.pwr, jb_log2, red, acc, 0, 1);
 #pragma unroll
         for (int t = 0; t < NV; t++) {
             E2 s = block_sum_n(acc[t], sm);
@@ -339,19 +360,25 @@ __device__ __forceinline__ void ps_round_body(const PsJob& J, int rd, size_t hal
     const size_t ntiles = half >> jb_log2;
     for (size_t tile = first_tile; tile < ntiles; tile += tile_step) {
         const size_t j = (tile << jb_log2) + jj;
+        const size_t jo = dpos(j, half);
         for (int i = g; i < J.npairs; i += G) {
             const void* pa; const E2* pb; E2* oa; E2* ob;
             ps_io(J, rd, i, pa, pb, oa, ob);
             TA xa, ya;
             E2 xb, yb;
-            load_pair<TA>(reinterpret_cast<const TA*>(pa) + 2 * j, xa, ya);
-            load_pair<E2>(pb + 2 * j, xb, yb);
+            if (rd == 0) {
+                load_pair<TA>(reinterpret_cast<const TA*>(pa) + 2 * j, xa, ya);
+                load_pair<E2>(pb + 2 * j, xb, yb);
+            } else {
+                load_xy<TA, false>(reinterpret_cast<const TA*>(pa), j, half, xa, ya);
+                load_xy<E2, false>(pb, j, half, xb, yb);
+            }
             TA da = V::sub(ya, xa);
             E2 db = e2_sub(yb, xb);
             a0 = e2_add(a0, V::scale(xb, xa));
             a2 = e2_add(a2, V::scale(e2_add(yb, db), V::add(ya, da)));
-            store_e2(oa + j, V::fold(xa, da, r));
-            store_e2(ob + j, e2_add(xb, e2_mul(r, db)));
+            store_e2(oa + jo, V::fold(xa, da, r));
+            store_e2(ob + jo, e2_add(xb, e2_mul(r, db)));
         }
     }
 }

@@ -37,6 +37,7 @@ struct StJob {
     size_t r_off;      // chain index of round 0's challenge
     size_t sums_slot;  // result slots: nv per round
     E2 pw[PW_MAX];     // gamma^i (grand product) or M^i (collation)
+    E2 pwr[PW_MAX];    // gamma^i * r_0 (grand product: first-round fold of the left tables)
 };
 // step: every job in `list` (device array of njobs indices into jobs) runs its round with half = 2^h_log2
 int st_step(hipStream_t st, int kind, bool base, const StJob* jobs, const int* list, int njobs, int h_log2, const E2* chal,

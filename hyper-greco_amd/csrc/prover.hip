@@ -220,6 +220,8 @@ struct Prover {
         J.r_off = h.point_off; J.sums_slot = h.sums_slot;
         memcpy(J.pw, pw.v, sizeof(J.pw));
         for (int i = 0; i < nvars; i++) h.rs.push_back(squeeze());
+        if (kind == dev::SC_GRANDPROD && nvars > 0)
+            for (int i = 0; i < dev::PW_MAX; i++) J.pwr[i] = e2_mul(pw.v[i], h.rs[0]);
         if (nvars > 0) st_jobs.push_back(J);
         return h;
     }
