@@ -335,6 +335,16 @@ int hg_prove(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, uint8_t* proof, 
     HG_CATCH(-1)
 }
 
+int hg_verify(const hg_pk* pk, const hg_witness* w, const uint8_t* proof, size_t len) {
+    HG_TRY
+    if (!pk || !w || !proof) throw Error("hg_verify: null argument");
+    std::string why = verify_proof(pk->params, pk->lasso, pk->circuit, w->w, proof, len);
+    if (why.empty()) return 0;
+    g_last_error = why;
+    return 1;
+    HG_CATCH(-1)
+}
+
 int hg_circuit_eval(const hg_pk* pk, const hg_witness* w, uint64_t* lasso_in, size_t lasso_cap, uint64_t* sum_out, size_t sum_cap) {
     HG_TRY
     auto vals = circuit_evaluate(pk->circuit, pk->params, w->w);

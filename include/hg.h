@@ -93,6 +93,11 @@ void hg_witness_free(hg_witness* w);
 int hg_prove(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, uint8_t* proof, size_t cap, size_t* len,
              hg_timings* timings);
 
+/* = BfvEncrypt::verify [REF sk_encryption_circuit.rs:462-517] (host-side, like the reference's): the witness handle
+ *   supplies the public inputs and ct0is. Returns 0 = accepted, 1 = rejected (reason via hg_last_error), < 0 = error.
+ *   Works with a host-only key (hg_setup(NULL, ..)). */
+int hg_verify(const hg_pk* pk, const hg_witness* w, const uint8_t* proof, size_t len);
+
 /* The two halves of hg_prove, split where the reference splits its spans:
  *   hg_witness_gen   = "wintess gen": circuit.evaluate(inputs) [REF sk_encryption_circuit.rs:439-442] ON THE DEVICE: the
  *                      3+2k+1 input tables are uploaded, the 2k+1 size-2^L NTTs (FFT -> pointwise mul -> IFFT) and

@@ -166,12 +166,14 @@ def test_full_prove_bit_exact_on_reference_fixtures(ctx, n, k, bits):
     assert hashlib.sha256(proof).hexdigest() == gold["sha256"]
     ok, err = orclib.verify(p, inp, proof)
     assert ok, err
+    ok, err = hg.verify(pk, w, proof)  # product-side verifier (BfvEncrypt::verify)
+    assert ok, err
     proof2, _ = bfv.prove(ctx, pk, w)  # determinism + arena reuse
     assert proof2 == proof
     pk.free()
 
 
-@pytest.mark.parametrize("n,k", [(2048, 1), (8192, 4)])
+@pytest.mark.parametrize("n,k", [(2048, 1), (8192, 4), (16384, 8)])
 def test_full_prove_bit_exact_synthetic(ctx, n, k):
     bfv = hg.BfvEncrypt.new(n, k)
     pk = bfv.setup(ctx)

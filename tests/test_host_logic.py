@@ -129,3 +129,33 @@ def test_synthetic_witness_satisfies_circuit_and_bounds(n, k):
         ok, err = orclib.verify(p, inp, proof)
         assert ok, err
     pk.free()
+
+
+@pytest.mark.parametrize("n,k,bits", [(1024, 1, 27), (4096, 2, 55)])
+def test_product_verifier_accepts_oracle_proofs_and_rejects_tampering(n, k, bits):
+    """hg_verify (product, host) vs the oracle prover: two independent implementations of the same protocol."""
+    import random
+    bfv = hg.BfvEncrypt.new(n, k)
+    pk = bfv.setup(None)
+    w = bfv.get_inputs(os.path.join(orclib.GOLDEN, f"sk_enc_{n}_{k}x{bits}_65537.json"))
+    proof, _ = orclib.prove(orclib.params(n, k), orclib.Inputs(w.arrays()), threads=4)
+    ok, why = hg.verify(pk, w, proof)
+    assert ok, why
+    rng = random.Random(n)
+    verdicts = []
+    for _ in range(8):
+        bad = bytearray(proof)
+        bad[rng.randrange(len(bad))] ^= 1 << rng.randrange(8)
+        ok_p, _ = hg.verify(pk, w, bytes(bad))
+        ok_o, _ = orclib.verify(orclib.params(n, k), orclib.Inputs(w.arrays()), bytes(bad))
+        assert ok_p == ok_o  # both verifiers bind exactly the same sections
+        verdicts.append(ok_p)
+    assert verdicts.count(False) >= 5
+    ok, _ = hg.verify(pk, w, proof[:-8])
+    assert not ok
+    d = dict(w.arrays())
+    d["ct0is"] = d["ct0is"].copy()
+    d["ct0is"][3] ^= np.uint64(1)
+    ok, _ = hg.verify(pk, hg.Witness.from_arrays(bfv.params, d), proof)
+    assert not ok
+    pk.free()
