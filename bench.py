@@ -4,8 +4,10 @@ configs[2]), on N MI355X GPUs of one node.
 
 A "step" = one GKR prove (the reference's "GKR prove" span [REF bfv-gkr/src/sk_encryption_circuit.rs:455-457],
 plus the output-claim evaluation :444-448) of one synthetic witness whose node tables are already resident in
-HBM. N > 1: every rank proves its own independent witness (weak scaling, no data-path collective);
-`value` = max-over-ranks step time / N = ms per proof of the whole job.
+HBM. N > 1, default `--mode shard`: ONE proof is sharded over the N GPUs (strong scaling): every rank holds the
+same witness, runs the device jobs it owns (the jobs are independent) and one RCCL sum-all-reduce
+of the scalar result buffer per proof is the only exchange; `value` = max-over-ranks step time = ms per proof.
+`--mode dp`: every rank proves its own independent witness (weak scaling, no collective), `value` = step time / N.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel, HIP events on
 the prover stream inside the timed region) and `cpu_baseline` (the CPU oracle = a port, timed on this host)."""
@@ -115,10 +117,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=32768)
-    ap.add_argument("--k", type=int, default=16)
+    ap.add_argument("--ring-degree", "--n", dest="n", type=int, default=32768)
+    ap.add_argument("--crt-moduli", "--k", dest="k", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=0x4752454330)
+    ap.add_argument("--mode", choices=["shard", "dp"], default="shard",
+                    help="N>1: shard ONE proof over the GPUs (strong scaling, default) or one independent proof per GPU (weak)")
     ap.add_argument("--selftest-dist", action="store_true",
                     help="CPU/gloo self-test of the N>1 plumbing (rendezvous, barrier, max-over-ranks, rank-0 JSON); proves nothing")
     args = ap.parse_args()
@@ -136,10 +140,20 @@ def main():
     import __graft_entry__ as entry
     hg = entry.load_package()
 
+    # test hooks (single-GPU box): HG_BENCH_BACKEND=gloo reduces through host tensors, HG_BENCH_SAME_DEVICE=1 puts
+    # every rank on device 0. The driver's multi-GPU runs use neither: RCCL ("nccl"), one rank per GPU.
+    backend = os.environ.get("HG_BENCH_BACKEND", "nccl")
+    if os.environ.get("HG_BENCH_SAME_DEVICE") == "1":
+        local_rank = 0
+    shard = world > 1 and args.mode == "shard"
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
+    red_dev = "cuda" if backend == "nccl" else "cpu"
 
     def barrier():
         if world > 1:
@@ -149,34 +163,48 @@ def main():
     ctx = hg.Context(local_rank)
     bfv = hg.BfvEncrypt.new(args.n, args.k)
     pk = bfv.setup(ctx)
-    witness = hg.Witness.synthetic(bfv.params, witness_seed(args.seed, args.n, rank))
+    witness = hg.Witness.synthetic(bfv.params, witness_seed(args.seed, args.n, 0 if shard else rank))
     vals = hg.witness_gen(ctx, pk, witness)  # node tables -> HBM (outside the timed region)
     out = hg.ProofBuffer()
 
+    def step():
+        if not shard:
+            return hg.prove_resident(ctx, pk, vals, out)
+        import numpy as np
+        part = hg.prove_shard_begin(ctx, pk, vals, rank, world)      # this rank's jobs, one stream sync
+        t = torch.from_numpy(part.view(np.int64)).to(red_dev)        # u64 lanes: one non-zero contributor per lane
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)                     # the only exchange of the proof
+        part[:] = t.cpu().numpy().view(np.uint64)
+        return hg.prove_shard_finish(ctx, out)                       # transcript replay -> identical bytes on every rank
+
+    if shard:  # the sharded proof must equal the single-GPU proof bit for bit
+        unsharded = hg.prove_resident(ctx, pk, vals, out).bytes()
     for _ in range(max(args.warmup, 1)):
-        hg.prove_resident(ctx, pk, vals, out)
+        step()
     first = out.bytes()
+    if shard:
+        assert first == unsharded, "sharded proof differs from the single-GPU proof"
 
     ctx.profile(1)  # HIP events around the dominant kernel class only
     ctx.profile_reset()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        hg.prove_resident(ctx, pk, vals, out)
+        step()
     barrier()
     t1 = time.perf_counter()
     ctx.profile(0)
     assert out.bytes() == first, "proof changed between runs"
     elapsed = t1 - t0
     gpu_ms = out.timings()["gpu_ms"]
-    elapsed = max_over_ranks(elapsed, world, dist, torch, "cuda")
+    elapsed = max_over_ranks(elapsed, world, dist, torch, red_dev)
     ms_per_step = elapsed / args.steps * 1e3
     dom = [s for s in ctx.profile_get() if s["name"] == DOMINANT][0]
 
     # one extra, untimed pass with events on every kernel class: the per-class breakdown
     ctx.profile(2)
     ctx.profile_reset()
-    hg.prove_resident(ctx, pk, vals, out)
+    step()
     ctx.profile(0)
     classes = {s["name"]: {"launches": s["launches"], "ms": round(s["total_ms"], 4), "algo_GB": round(s["algo_bytes"] / 1e9, 4)}
                for s in ctx.profile_get() if s["launches"]}
@@ -187,23 +215,24 @@ def main():
         achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         line = {
             "metric": "GKR prove ms, n=32768 k=16 Goldilocks; achieved HBM GB/s vs roofline",
-            "value": round(ms_per_step / world, 4),
+            "value": round(ms_per_step if (shard or world == 1) else ms_per_step / world, 4),
             "unit": "ms",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": False,
-            "scaling": "weak",
+            "scaling": "strong" if shard else "weak",
             "vs_baseline": None,
             "dtype": "u64",
             "data": "synthetic",
             "config": {"workload": f"GKR prove (sk_encryption_circuit.rs:444-457) of the BFV sk-enc circuit, n={args.n} k={args.k} "
                                    "Goldilocks/GoldilocksExt2, seeded synthetic witness, node tables resident in HBM",
-                       "n": args.n, "k": args.k, "field": "goldilocks", "proofs_per_step": world,
-                       "parallelism": f"dp{world}: one independent proof per GPU, no data-path collective",
+                       "n": args.n, "k": args.k, "field": "goldilocks", "proofs_per_step": 1 if (shard or world == 1) else world,
+                       "parallelism": (f"shard{world}: one proof, device jobs partitioned over {world} GPUs, one RCCL sum-all-reduce of the result buffer per proof"
+                                       if shard else f"dp{world}: one independent proof per GPU, no data-path collective"),
                        "proof_bytes": len(first), "gpu_ms_events": round(gpu_ms, 4),
-                       "witness_gen_ms_host": round(vals.timings["witness_ms"], 2), "upload_ms": round(vals.timings["upload_ms"], 2)},
+                       "witness_gen_ms_device": round(vals.timings["witness_ms"], 2), "upload_ms": round(vals.timings["upload_ms"], 2)},
             "roofline": {"bound": "hbm", "kernel": DOMINANT, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(),
                          "launches_per_step": dom["launches"] // max(args.steps, 1),

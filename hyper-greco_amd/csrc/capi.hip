@@ -317,6 +317,28 @@ int hg_prove_resident(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, uint8_t*
     HG_CATCH(-1)
 }
 
+int hg_prove_shard_begin(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int rank, int world, uint64_t** partial, size_t* n_u64) {
+    HG_TRY
+    if (!ctx || !pk || !v || !pk->ctx) throw Error("hg_prove_shard_begin: needs a device context, a device prover key and resident values");
+    size_t n = prove_shard_begin(ctx, pk, v, rank, world);
+    *partial = reinterpret_cast<uint64_t*>(ctx->h_res);
+    *n_u64 = 2 * n;
+    return 0;
+    HG_CATCH(-1)
+}
+
+int hg_prove_shard_finish(hg_ctx* ctx, uint8_t* proof, size_t cap, size_t* len, hg_timings* timings) {
+    HG_TRY
+    if (!ctx) throw Error("hg_prove_shard_finish: null context");
+    ProveResult r = prove_shard_finish(ctx);
+    if (timings) { memset(timings, 0, sizeof(*timings)); timings->prove_ms = r.prove_ms; timings->gpu_ms = r.gpu_ms; timings->total_ms = r.prove_ms; timings->enqueue_ms = r.enqueue_ms; timings->sync_ms = r.sync_ms; timings->replay_ms = r.replay_ms; }
+    *len = r.proof.size();
+    if (r.proof.size() > cap) throw Error("proof buffer too small");
+    memcpy(proof, r.proof.data(), r.proof.size());
+    return 0;
+    HG_CATCH(-1)
+}
+
 int hg_prove(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, uint8_t* proof, size_t cap, size_t* len, hg_timings* timings) {
     HG_TRY
     if (!ctx || !pk || !w) throw Error("hg_prove: null argument");

@@ -1,6 +1,8 @@
 #include "prover.hpp"
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <tuple>
@@ -159,7 +161,58 @@ struct Prover {
     size_t res_used = 0;
     int cls_gp_base, cls_gp_ext, cls_col_base, cls_col_ext, cls_ps, cls_reduce, cls_aux, cls_tree, cls_hash, cls_gather, cls_tail, cls_ps_tail;
 
-    Prover(hg_ctx* c, const hg_pk* k) : ctx(c), pk(k), st(c->stream) {
+    // ---- single-proof sharding over `world` GPUs ---------------------------------------------------
+    // Device jobs are independent, so a proof shards by JOB with no data-path collective inside
+    // the proof: every rank walks the whole protocol (same challenges, same result slots) but only enqueues
+    // the jobs it owns; unowned slots stay zero and ONE sum-all-reduce of the result buffer at the end gives
+    // every rank the complete buffer.
+    int rank = 0, world = 1;
+    std::vector<int> node_owner;       // Vanilla / FFT node reductions
+    std::vector<int> gp1_owner;        // grand product #1 (reads|writes): per layer n (n = 0: roots + top evals)
+    int own_gp2 = 0, own_collation = 0, own_openings = 0, own_out_claim = 0;
+    bool mine(int owner) const { return owner == rank; }
+    void plan_shards() {
+        if (!pk) return;
+        const HCircuit& c = pk->circuit;
+        const int nu = pk->lasso.nu;
+        node_owner.assign(c.nodes.size(), 0);
+        gp1_owner.assign(nu, 0);
+        if (world <= 1) return;
+        struct Item { double cost; int kind, idx; };
+        std::vector<Item> items;
+        const double A = pk->lasso.alpha;
+        for (int n = 1; n < nu; n++) items.push_back({4.0 * A * (double)((size_t)1 << n) * 3.0, 0, n});
+        items.push_back({4.0 * A * 65536.0 * 3.0, 1, 0});                      // all of GP#2
+        items.push_back({A * (double)((size_t)1 << nu) * 3.0, 2, 0});         // collation (+ claim)
+        items.push_back({(A + 8) * (double)((size_t)1 << nu) * 1.0, 3, 0});   // openings
+        for (size_t id = 0; id < c.nodes.size(); id++) {
+            const HNode& n = c.nodes[id];
+            if (n.kind == NK_FFT) items.push_back({(double)((size_t)1 << n.log2_size) * 6.0, 4, (int)id});
+            if (n.kind == NK_VANILLA) {
+                int np = 0;
+                for (int i = 0; i < n.arity; i++) np += n.left_use[i] + n.right_use[i];
+                items.push_back({(double)np * (double)((size_t)1 << (n.log2_sub_in + n.log2_reps)) * 4.0 + (double)((size_t)1 << n.log2_out()), 4, (int)id});
+            }
+        }
+        std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.cost > b.cost; });
+        std::vector<double> load(world, 0.0);
+        for (auto& it : items) {  // longest-processing-time-first
+            int r = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+            load[r] += it.cost;
+            switch (it.kind) {
+                case 0: gp1_owner[it.idx] = r; break;
+                case 1: own_gp2 = r; break;
+                case 2: own_collation = r; break;
+                case 3: own_openings = r; break;
+                default: node_owner[it.idx] = r; break;
+            }
+        }
+        gp1_owner[0] = gp1_owner[1];  // the top of the tree rides with the smallest layer
+        own_out_claim = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+    }
+
+    Prover(hg_ctx* c, const hg_pk* k, int rank_ = 0, int world_ = 1) : ctx(c), pk(k), st(c->stream), rank(rank_), world(world_) {
+        plan_shards();
         cls_gp_ext = ctx->prof_class("sc_round<grand_product,ext>", true);
         cls_gp_base = ctx->prof_class("sc_round<grand_product,base>", false);
         cls_col_base = ctx->prof_class("sc_round<collation,base>", false);
@@ -203,13 +256,18 @@ struct Prover {
     // flush_stride() in a size-synchronised schedule: they are independent on the device.
     std::vector<dev::StJob> st_jobs;
 
-    ScHandle sc_stride(int kind, const void* in, bool base, size_t in_stride, int ntab, int nvars, const dev::Powers& pw, E2* final_out) {
+    ScHandle sc_stride(int kind, const void* in, bool base, size_t in_stride, int ntab, int nvars, const dev::Powers& pw, E2* final_out,
+                       bool enqueue = true) {
         ScHandle h;
         h.nv = kind == dev::SC_GRANDPROD ? 3 : 2;
         h.nvars = nvars;
         h.point_off = epos();
         h.sums_slot = slot((size_t)nvars * h.nv);
         const size_t N = (size_t)1 << nvars;
+        if (!enqueue) {  // another rank runs this job: transcript bookkeeping only
+            for (int i = 0; i < nvars; i++) h.rs.push_back(squeeze());
+            return h;
+        }
         dev::StJob J;
         memset(&J, 0, sizeof(J));
         J.in = in; J.in_stride = in_stride;
@@ -298,12 +356,16 @@ struct Prover {
     std::vector<std::function<void()>> second_wave;  // device work that needs first-wave results (Libra phase 2)
 
     ScHandle sc_prodsum(const std::vector<const u64*>& a, const std::vector<const E2*>& b, int nvars,
-                        const std::vector<E2*>& fin_a, const std::vector<E2*>& fin_b) {
+                        const std::vector<E2*>& fin_a, const std::vector<E2*>& fin_b, bool enqueue = true) {
         ScHandle h;
         h.nv = 2;
         h.nvars = nvars;
         h.point_off = epos();
         h.sums_slot = slot((size_t)nvars * 2);
+        if (!enqueue) {
+            for (int i = 0; i < nvars; i++) h.rs.push_back(squeeze());
+            return h;
+        }
         const int np = (int)a.size();
         if (np > dev::PS_MAX_PAIRS) throw Error("prodsum: too many table pairs");
         const size_t N = (size_t)1 << nvars;
@@ -447,12 +509,15 @@ struct Prover {
     // ---- Lasso node (lasso.rs:57-114) ------------------------------------------------------------
     struct GpOut { size_t point_off; };
     // prove_grand_product (prover.rs:183-266) over nb contiguous tables of `len` base-field values
-    GpOut grand_product(const u64* H, size_t len, int nb) {
+    // `owner[n]` = rank that runs layer n (n = 0: roots + top evaluations); H may be null when no layer is owned
+    GpOut grand_product(const u64* H, size_t len, int nb, const std::vector<int>& owner) {
         int nv = 0;
         while (((size_t)1 << nv) < len) nv++;
-        std::vector<const u64*> lev(nv);
+        std::vector<const u64*> lev(nv, nullptr);
         lev[0] = H;
-        for (int k = 1; k < nv; k++) {  // Layer::bottom / Layer::up: w = v_l * v_r on the MSB split
+        int deepest = 0;  // highest tree level this rank needs (layer n reads level nv-1-n)
+        for (int n = 0; n < nv; n++) if (mine(owner[n])) deepest = std::max(deepest, nv - 1 - n);
+        for (int k = 1; k <= deepest; k++) {  // Layer::bottom / Layer::up: w = v_l * v_r on the MSB split
             u64* out = ctx->alloc_n<u64>((size_t)nb * (len >> k));
             ctx->prof_begin(cls_tree, (double)nb * (len >> (k - 1)) * 8.0 * 1.5);
             dev::prod_level(st, lev[k - 1], len >> (k - 1), out, nb);
@@ -460,7 +525,7 @@ struct Prover {
             lev[k] = out;
         }
         size_t roots = slot(nb), ev0 = slot(2 * (size_t)nb);
-        dev::gp_top(st, lev[nv - 1], nb, d_res() + roots, d_res() + ev0);
+        if (mine(owner[0])) dev::gp_top(st, lev[nv - 1], nb, d_res() + roots, d_res() + ev0);
         auto claims = std::make_shared<std::vector<E2>>(nb);
         ops.push_back([this, roots, nb, claims] {  // root products (prover.rs:197-221)
             for (int b = 0; b < nb; b++) { (*claims)[b] = h_res()[roots + b]; proof.write_e((*claims)[b]); }
@@ -492,7 +557,7 @@ struct Prover {
                 *claim = c;
             });
             size_t evals = slot(2 * (size_t)nb);
-            ScHandle sc = sc_stride(dev::SC_GRANDPROD, lev[k], true, h, 2 * nb, n, pw, d_res() + evals);
+            ScHandle sc = sc_stride(dev::SC_GRANDPROD, lev[k], true, h, 2 * nb, n, pw, d_res() + evals, mine(owner[n]));
             defer_sumcheck(sc, 3, claim, nullptr);
             defer_gp_unscale(evals, nb, pw);
             defer_write_slots(evals, 2 * (size_t)nb);  // prover.rs:257
@@ -507,20 +572,32 @@ struct Prover {
         const dev::LassoDev& L = pk->lasso_dev;
         const int nu = lp.nu, A = lp.alpha;
         const size_t N = (size_t)1 << nu, M = 65536;
+        // what this rank needs of the node (single GPU: everything)
+        bool any_gp1 = false;
+        for (int n = 0; n < nu; n++) any_gp1 |= mine(gp1_owner[n]);
+        const bool do_col = mine(own_collation), do_open = mine(own_openings), do_gp2 = mine(own_gp2);
+        const bool need_counters = any_gp1 || do_gp2 || do_open;
+        const bool need_split = do_col || need_counters;
         // polynomialize (lasso.rs:157-250)
-        u64* dims = ctx->alloc_n<u64>(4 * N);
-        u64* ep = ctx->alloc_n<u64>((size_t)A * N);
-        ctx->prof_begin(cls_aux, (double)N * 8 * (1 + 4 + A));
-        dev::lasso_split(st, L, d_input, dims, ep);
-        ctx->prof_end();
+        u64* dims = nullptr;
+        u64* ep = nullptr;
+        if (need_split) {
+            dims = ctx->alloc_n<u64>(4 * N);
+            ep = ctx->alloc_n<u64>((size_t)A * N);
+            ctx->prof_begin(cls_aux, (double)N * 8 * (1 + 4 + A));
+            dev::lasso_split(st, L, d_input, dims, ep);
+            ctx->prof_end();
+        }
         // r, claimed sum (lasso.rs:85, 264-269)
         size_t r_off = epos();
         for (int i = 0; i < nu; i++) squeeze();
-        E2* eq = ctx->alloc_n<E2>(N);
-        eq_now(eq, nu, r_off);
+        E2* eq = (do_col || do_open) ? ctx->alloc_n<E2>(N) : nullptr;
         size_t claim_slot = slot(1);
-        int grid = dev::lasso_claim(st, L, eq, ep, ctx->d_partials);
-        reduce(grid, 1, claim_slot);
+        if (do_col) {
+            eq_now(eq, nu, r_off);
+            int grid = dev::lasso_claim(st, L, eq, ep, ctx->d_partials);
+            reduce(grid, 1, claim_slot);
+        }
         Cell claimed = cell();
         ops.push_back([this, claim_slot, claimed] { *claimed = h_res()[claim_slot]; proof.write_e(*claimed); });
         {   // collation sum-check (lasso.rs:271-279): g = poly(0) * sum_i M^i poly(i)
@@ -529,7 +606,7 @@ struct Prover {
             if (A > dev::PW_MAX) throw Error("lasso: too many memories");
             u64 c = 1;
             for (int i = 0; i < A; i++) { pw.v[i] = e2(c, 0); c = gl_mul(c, M); }
-            ScHandle sc = sc_stride(dev::SC_COLLATION, ep, true, N, A, nu, pw, nullptr);
+            ScHandle sc = sc_stride(dev::SC_COLLATION, ep, true, N, A, nu, pw, nullptr, do_col);
             defer_sumcheck(sc, 2, claimed, nullptr);
         }
         E2 gamma_e = squeeze(), tau_e = squeeze();  // lasso.rs:99
@@ -537,7 +614,7 @@ struct Prover {
         // counters: only the memories whose index equals a chunk (dimension) index reach the transcript
         // (lasso.rs:317-319 indexes read_ts/final_cts by chunk index)
         std::map<int, u64*> read_ts, final_cts;
-        {
+        if (need_counters) {
             size_t tb = dev::lasso_counter_temp_bytes(N);
             void* temp = ctx->alloc(tb);
             u32* keys = ctx->alloc_n<u32>(N); u32* keys2 = ctx->alloc_n<u32>(N);
@@ -554,26 +631,33 @@ struct Prover {
         }
         // MemoryCheckingProver::new (prover.rs:35-89)
         const int G = (int)lp.gkr_order.size();
-        u64* H1 = ctx->alloc_n<u64>((size_t)2 * G * N);
-        u64* H2 = ctx->alloc_n<u64>((size_t)2 * G * M);
+        u64* H1 = any_gp1 ? ctx->alloc_n<u64>((size_t)2 * G * N) : nullptr;
+        u64* H2 = do_gp2 ? ctx->alloc_n<u64>((size_t)2 * G * M) : nullptr;
         for (int i = 0; i < G; i++) {
             int m = lp.gkr_order[i], c = lp.gkr_chunk[i];
-            ctx->prof_begin(cls_hash, (double)N * 8 * 5);
-            dev::lasso_hash_rw(st, N, dims + (size_t)c * N, ep + (size_t)m * N, read_ts[c], gamma, tau, H1 + (size_t)i * N, H1 + (size_t)(G + i) * N);
-            ctx->prof_end();
-            dev::lasso_hash_if(st, (u32)lp.mems[m].cutoff, final_cts[c], gamma, tau, H2 + (size_t)i * M, H2 + (size_t)(G + i) * M);
+            if (any_gp1) {
+                ctx->prof_begin(cls_hash, (double)N * 8 * 5);
+                dev::lasso_hash_rw(st, N, dims + (size_t)c * N, ep + (size_t)m * N, read_ts[c], gamma, tau, H1 + (size_t)i * N, H1 + (size_t)(G + i) * N);
+                ctx->prof_end();
+            }
+            if (do_gp2) dev::lasso_hash_if(st, (u32)lp.mems[m].cutoff, final_cts[c], gamma, tau, H2 + (size_t)i * M, H2 + (size_t)(G + i) * M);
         }
-        GpOut g1 = grand_product(H1, N, 2 * G);  // reads then writes (prover.rs:161-165)
-        GpOut g2 = grand_product(H2, M, 2 * G);  // inits then finals (prover.rs:167-171)
+        GpOut g1 = grand_product(H1, N, 2 * G, gp1_owner);                          // reads then writes (prover.rs:161-165)
+        GpOut g2 = grand_product(H2, M, 2 * G, std::vector<int>(16, own_gp2));      // inits then finals (prover.rs:167-171)
         // openings (prover.rs:173-178, mod.rs:80-93)
         E2* eqx = eq;  // the eq(r,.) table is dead by now
-        eq_now(eqx, nu, g1.point_off);
-        E2* eqy = ctx->alloc_n<E2>(M);
-        eq_now(eqy, 16, g2.point_off);
+        E2* eqy = do_open ? ctx->alloc_n<E2>(M) : nullptr;
+        if (do_open) {
+            eq_now(eqx, nu, g1.point_off);
+            eq_now(eqy, 16, g2.point_off);
+        }
         for (auto& chk : lp.chunks) {
             int c = chk.first;
-            std::vector<const u64*> xs = {dims + (size_t)c * N, read_ts[c]};
-            for (int m : chk.second) xs.push_back(ep + (size_t)m * N);
+            std::vector<const u64*> xs;
+            if (do_open) {
+                xs = {dims + (size_t)c * N, read_ts[c]};
+                for (int m : chk.second) xs.push_back(ep + (size_t)m * N);
+            } else xs.assign(2 + chk.second.size(), nullptr);
             size_t base_slot = slot(3 + chk.second.size());
             // order on the wire: dim(x), read_ts(x), final_cts(y), then E_m(x)
             std::vector<size_t> dst = {base_slot, base_slot + 1};
@@ -583,16 +667,18 @@ struct Prover {
                 const u64* tabs[8] = {nullptr};
                 for (int t = 0; t < cnt; t++) tabs[t] = xs[o + t];
                 size_t tmp = slot(cnt);
-                ctx->prof_begin(cls_aux, (double)N * (16 + 8.0 * cnt));
-                int grid2 = dev::dot_eq(st, eqx, tabs, cnt, N, ctx->d_partials);
-                ctx->prof_end();
-                reduce(grid2, cnt, tmp);
+                if (do_open) {
+                    ctx->prof_begin(cls_aux, (double)N * (16 + 8.0 * cnt));
+                    int grid2 = dev::dot_eq(st, eqx, tabs, cnt, N, ctx->d_partials);
+                    ctx->prof_end();
+                    reduce(grid2, cnt, tmp);
+                }
                 for (int t = 0; t < cnt; t++) {
                     size_t from = tmp + t, to = dst[o + t];
                     ops.push_back([this, from, to] { ctx->h_res[to] = ctx->h_res[from]; });
                 }
             }
-            {
+            if (do_open) {
                 const u64* tabs[8] = {final_cts[c]};
                 int grid2 = dev::dot_eq(st, eqy, tabs, 1, M, ctx->d_partials);
                 reduce(grid2, 1, base_slot + 2);
@@ -642,13 +728,14 @@ struct Prover {
         dev::ClaimSet cs = claim_set(claims[id], &alphas);
         for (auto& c : claims[id]) if (c.len != n.log2_out()) throw Error("gkr: claim arity mismatch");
         Cell claim = combined_value(claims[id], alphas);
-        E2* eqc = ctx->alloc_n<E2>((size_t)1 << n.log2_out());
-        queue_eq(eqc, n.log2_out(), cs);
+        const bool own = mine(node_owner[id]);
+        E2* eqc = own ? ctx->alloc_n<E2>((size_t)1 << n.log2_out()) : nullptr;
+        if (own) queue_eq(eqc, n.log2_out(), cs);
         const hg_pk::NodeDev* ndp0 = &nd;
         const HNode* np0 = &n;
         if (nd.nconst) {  // claim -= sum_g eqc[g] * w0_g
             size_t s = slot(1);
-            after_eq.push_back([this, ndp0, np0, eqc, s] {
+            if (own) after_eq.push_back([this, ndp0, np0, eqc, s] {
                 int grid = dev::vanilla_const_sum(st, ndp0->const_gate, ndp0->const_coef, ndp0->nconst, eqc, np0->log2_sub_out, np0->log2_reps, ctx->d_partials);
                 reduce(grid, 1, s);
             });
@@ -665,18 +752,18 @@ struct Prover {
         std::vector<const E2*> b;
         std::vector<E2*> fa, fb;
         size_t u_base = slot(n.arity);
-        E2* scratch = ctx->alloc_n<E2>(n.arity);
+        E2* scratch = own ? ctx->alloc_n<E2>(n.arity) : nullptr;
         for (int i : li) {
-            E2* T = ctx->alloc_n<E2>(SR);
+            E2* T = own ? ctx->alloc_n<E2>(SR) : nullptr;
             gt.lin = nd.lin[i];
             gt.mul = nd.mulL[i];
-            gather_queue.push_back(dev::GatherJob{gt, eqc, n.log2_sub_in, n.log2_sub_out, n.log2_reps, T});
+            if (own) gather_queue.push_back(dev::GatherJob{gt, eqc, n.log2_sub_in, n.log2_sub_out, n.log2_reps, T});
             a.push_back(d_vals[n.preds[i]]);
             b.push_back(T);
             fa.push_back(d_res() + u_base + i);
             fb.push_back(scratch + i);
         }
-        ScHandle s1 = sc_prodsum(a, b, nin, fa, fb);
+        ScHandle s1 = sc_prodsum(a, b, nin, fa, fb, own);
         Cell after1 = cell();
         defer_sumcheck(s1, 2, claim, after1);
         for (int i : li) {
@@ -695,7 +782,7 @@ struct Prover {
             std::vector<E2*> Bs, fa2, fb2;
             size_t w_base = slot(n.arity);
             for (int i : ri) {
-                E2* B = ctx->alloc_n<E2>(SR);
+                E2* B = own ? ctx->alloc_n<E2>(SR) : nullptr;
                 a2.push_back(d_vals[n.preds[i]]);
                 Bs.push_back(B);
                 fa2.push_back(d_res() + w_base + i);
@@ -708,7 +795,7 @@ struct Prover {
             ScHandle s2;
             s2.nv = 2; s2.nvars = nin; s2.point_off = epos(); s2.sums_slot = slot((size_t)nin * 2);
             for (int i = 0; i < nin; i++) s2.rs.push_back(squeeze());
-            second_wave.push_back([this, ri, Bs, a2, fa2, fb2, rx_off, ndp, np, eqc, u_base, SR, nin, s2] {
+            if (own) second_wave.push_back([this, ri, Bs, a2, fa2, fb2, rx_off, ndp, np, eqc, u_base, SR, nin, s2] {
                 E2* eqx = ctx->alloc_n<E2>(SR);
                 dev::ClaimSet one;
                 memset(&one, 0, sizeof(one));
@@ -751,13 +838,14 @@ struct Prover {
         std::vector<E2> alphas;
         dev::ClaimSet cs = claim_set(claims[id], &alphas);
         Cell claim = combined_value(claims[id], alphas);
-        E2* F = ctx->alloc_n<E2>(N);
+        const bool own = mine(node_owner[id]);
+        E2* F = own ? ctx->alloc_n<E2>(N) : nullptr;
         const u64* W = (n.inverse ? pk->w_inv : pk->w_fwd).at(L);
         u64 scale = n.inverse ? gl_inv(gl_from_u64(N)) : 1;
-        fft_queue.push_back(dev::FftJob{F, W, scale, L, cs});
+        if (own) fft_queue.push_back(dev::FftJob{F, W, scale, L, cs});
         size_t u = slot(1);
-        E2* scratch = ctx->alloc_n<E2>(1);
-        ScHandle s = sc_prodsum({d_vals[n.preds[0]]}, {F}, L, {d_res() + u}, {scratch});
+        E2* scratch = own ? ctx->alloc_n<E2>(1) : nullptr;
+        ScHandle s = sc_prodsum({d_vals[n.preds[0]]}, {F}, L, {d_res() + u}, {scratch}, own);
         defer_sumcheck(s, 2, claim, nullptr);
         defer_write_slots(u, 1);
         Cell v = cell();
@@ -794,16 +882,20 @@ struct Prover {
 
     // copies the result buffer back (the only synchronisation) and replays the transcript
     double t_enqueued = 0, t_synced = 0, t_replayed = 0;
-    void finish() {
+    void sync_results() {
         if (res_used) hip_check(hipMemcpyAsync(ctx->h_res, ctx->d_res, res_used * sizeof(E2), hipMemcpyDeviceToHost, st), "copy results");
         t_enqueued = wall_ms();
         hip_check(hipStreamSynchronize(st), "prove: stream sync");
         hip_check(hipGetLastError(), "prove: kernel launch");
         t_synced = wall_ms();
+    }
+    void replay() {
+        double t = wall_ms();
         for (auto& op : ops) op();
-        t_replayed = wall_ms();
+        t_replayed = t_synced + (wall_ms() - t);
         ctx->prof_collect();
     }
+    void finish() { sync_results(); replay(); }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -893,44 +985,84 @@ void values_free(hg_values* v) {
     delete v;
 }
 
-ProveResult prove_resident(hg_ctx* ctx, const hg_pk* pk, const hg_values* v) {
-    ProveResult res;
+// enqueue + synchronise this rank's share of one proof; leaves the (partial) result buffer in ctx->h_res
+static std::unique_ptr<Prover> prove_begin(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int rank, int world, double* t_start, float* gpu_ms) {
     hip_check(hipSetDevice(ctx->device), "hipSetDevice");
     ctx->arena_reset();
     const Params& p = pk->params;
-    double t3 = wall_ms();
-    Prover P(ctx, pk);
-    P.d_vals = v->d_vals;
+    *t_start = wall_ms();
+    std::unique_ptr<Prover> P(new Prover(ctx, pk, rank, world));
+    P->d_vals = v->d_vals;
     hipEvent_t ev_a, ev_b;
     hip_check(hipEventCreate(&ev_a), "event"); hip_check(hipEventCreate(&ev_b), "event");
     hip_check(hipEventRecord(ev_a, ctx->stream), "event record");
+    if (world > 1) hip_check(hipMemsetAsync(ctx->d_res, 0, ctx->res_cap * sizeof(E2), ctx->stream), "clear result buffer");
     // "eval output" (sk_encryption_circuit.rs:444-448): point, ct0is MLE value
     const int ov = p.ct0is_log2();
-    size_t point_off = P.epos();
-    for (int i = 0; i < ov; i++) P.squeeze();
-    size_t vslot = P.slot(1);
-    {
+    size_t point_off = P->epos();
+    for (int i = 0; i < ov; i++) P->squeeze();
+    size_t vslot = P->slot(1);
+    if (P->mine(P->own_out_claim)) {
         E2* eq = ctx->alloc_n<E2>((size_t)1 << ov);
-        P.eq_now(eq, ov, point_off);
+        P->eq_now(eq, ov, point_off);
         const u64* tabs[8] = {v->d_ct0is};
         int grid = dev::dot_eq(ctx->stream, eq, tabs, 1, (size_t)1 << ov, ctx->d_partials);
-        P.reduce(grid, 1, vslot);
+        P->reduce(grid, 1, vslot);
     }
     Cell out_value = cell();
-    P.ops.push_back([&P, out_value, vslot] { *out_value = P.h_res()[vslot]; });
-    P.gkr(ClaimRef{point_off, ov, out_value});
+    Prover* pp = P.get();
+    P->ops.push_back([pp, out_value, vslot] { *out_value = pp->h_res()[vslot]; });
+    P->gkr(ClaimRef{point_off, ov, out_value});
     hip_check(hipEventRecord(ev_b, ctx->stream), "event record");
-    P.finish();
-    double t4 = wall_ms();
-    float gms = 0;
-    (void)hipEventElapsedTime(&gms, ev_a, ev_b);
+    P->sync_results();
+    *gpu_ms = 0;
+    (void)hipEventElapsedTime(gpu_ms, ev_a, ev_b);
     (void)hipEventDestroy(ev_a); (void)hipEventDestroy(ev_b);
+    return P;
+}
+
+ProveResult prove_resident(hg_ctx* ctx, const hg_pk* pk, const hg_values* v) {
+    ProveResult res;
+    double t3 = 0;
+    float gms = 0;
+    std::unique_ptr<Prover> P = prove_begin(ctx, pk, v, 0, 1, &t3, &gms);
+    P->replay();
+    double t4 = wall_ms();
     res.prove_ms = t4 - t3;
     res.gpu_ms = gms;
-    res.enqueue_ms = P.t_enqueued - t3;
-    res.sync_ms = P.t_synced - P.t_enqueued;
-    res.replay_ms = P.t_replayed - P.t_synced;
-    res.proof = std::move(P.proof.bytes);
+    res.enqueue_ms = P->t_enqueued - t3;
+    res.sync_ms = P->t_synced - P->t_enqueued;
+    res.replay_ms = P->t_replayed - P->t_synced;
+    res.proof = std::move(P->proof.bytes);
+    return res;
+}
+
+// sharded single proof: begin (this rank's jobs) -> caller sum-all-reduces ctx->h_res[0 .. n) -> finish
+struct PendingShard { std::unique_ptr<Prover> P; double t_start; float gpu_ms; };
+static std::map<hg_ctx*, PendingShard> g_pending;
+
+size_t prove_shard_begin(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int rank, int world) {
+    if (world < 1 || rank < 0 || rank >= world) throw Error("prove_shard_begin: bad rank/world");
+    PendingShard ps;
+    ps.P = prove_begin(ctx, pk, v, rank, world, &ps.t_start, &ps.gpu_ms);
+    size_t n = ps.P->res_used;
+    if (getenv("HG_SHARD_DEBUG")) fprintf(stderr, "[hg] shard rank %d/%d: gpu %.3f ms, enqueue %.3f ms\n", rank, world, ps.gpu_ms, ps.P->t_enqueued - ps.t_start);
+    g_pending[ctx] = std::move(ps);
+    return n;
+}
+ProveResult prove_shard_finish(hg_ctx* ctx) {
+    auto it = g_pending.find(ctx);
+    if (it == g_pending.end()) throw Error("prove_shard_finish: no sharded prove in flight on this context");
+    PendingShard ps = std::move(it->second);
+    g_pending.erase(it);
+    ProveResult res;
+    ps.P->replay();
+    res.prove_ms = wall_ms() - ps.t_start;
+    res.gpu_ms = ps.gpu_ms;
+    res.enqueue_ms = ps.P->t_enqueued - ps.t_start;
+    res.sync_ms = ps.P->t_synced - ps.P->t_enqueued;
+    res.replay_ms = ps.P->t_replayed - ps.P->t_synced;
+    res.proof = std::move(ps.P->proof.bytes);
     return res;
 }
 

@@ -111,6 +111,16 @@ int64_t hg_values_get(hg_ctx* ctx, const hg_values* v, int node, uint64_t* out, 
 int hg_prove_resident(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, uint8_t* proof, size_t cap, size_t* len,
                       hg_timings* timings);
 
+/* ONE proof sharded over `world` GPUs (one process per GPU, same witness resident on each). Every rank walks the whole
+ * protocol but runs only the device jobs it owns; `*partial` (pinned host memory owned by the context) then holds this
+ * rank's share of the scalar results with zeros elsewhere. The caller sum-all-reduces that buffer IN PLACE across ranks
+ * (u64 lanes, e.g. RCCL ncclSum on int64: every slot has exactly one non-zero contributor) and calls
+ * hg_prove_shard_finish, which replays the transcript — every rank obtains the identical proof bytes.
+ * *n_u64 = number of u64 lanes to reduce. world == 1 degenerates to hg_prove_resident. */
+int hg_prove_shard_begin(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int rank, int world, uint64_t** partial,
+                         size_t* n_u64);
+int hg_prove_shard_finish(hg_ctx* ctx, uint8_t* proof, size_t cap, size_t* len, hg_timings* timings);
+
 /* = circuit.evaluate (host part of witness generation) [REF sk_encryption_circuit.rs:442]:
  *   copies out the Lasso node's input table (2^nu) and the `sum` node output (k*2^L). Host only. */
 int hg_circuit_eval(const hg_pk* pk, const hg_witness* w, uint64_t* lasso_in, size_t lasso_cap, uint64_t* sum_out,

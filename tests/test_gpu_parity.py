@@ -207,3 +207,48 @@ def test_headline_config_properties(ctx):
     assert not ok
     print("c3 timings", tm2)
     pk.free()
+
+
+@pytest.mark.parametrize("n,k,world", [(1024, 1, 2), (4096, 2, 3), (8192, 4, 8), (32768, 16, 8), (32768, 16, 2)])
+def test_sharded_single_proof_reassembles_bit_exact(ctx, n, k, world):
+    """Single-proof sharding (hg_prove_shard_*): run every virtual rank of a `world`-GPU job on this one GPU, sum the
+    partial result buffers the way the all-reduce would, replay -> must give exactly the unsharded proof; every
+    result lane must have at most one non-zero contributor."""
+    bfv = hg.BfvEncrypt.new(n, k)
+    pk = bfv.setup(ctx)
+    w = hg.Witness.synthetic(bfv.params, 0x4752454330 + n)
+    vals = hg.witness_gen(ctx, pk, w)
+    out = hg.ProofBuffer()
+    ref = hg.prove_resident(ctx, pk, vals, out).bytes()
+    total = None
+    owners = None
+    for r in range(world):
+        part = hg.prove_shard_begin(ctx, pk, vals, r, world)
+        p = part.copy()
+        total = p if total is None else total + p
+        nz = (p != 0).astype(np.int32)
+        owners = nz if owners is None else owners + nz
+    assert owners.max() <= 1, "a result lane was produced by more than one rank"
+    part[:] = total  # what the in-place sum-all-reduce leaves on every rank
+    got = hg.prove_shard_finish(ctx, out).bytes()
+    assert got == ref
+    vals.free()
+    pk.free()
+
+
+def test_bench_sharded_two_processes_on_one_gpu():
+    """The N>1 bench path end to end with two real processes (gloo all-reduce through host tensors, both ranks on
+    device 0): rendezvous, per-rank job ownership, the all-reduce, replay; bench.py itself asserts that the sharded
+    proof equals the single-GPU proof."""
+    import json, subprocess, sys
+    from hglib import ROOT
+    env = dict(os.environ, HG_BENCH_BACKEND="gloo", HG_BENCH_SAME_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--ring-degree", "4096", "--crt-moduli", "2",
+           "--no-cpu-baseline"]
+    outp = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert outp.returncode == 0, outp.stderr[-3000:]
+    lines = [l for l in outp.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] == d["ms_per_step"]
