@@ -195,10 +195,37 @@ struct Prover {
             }
         }
         std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.cost > b.cost; });
+        // Longest-processing-time-first with set-up costs: the first Lasso item on a rank drags the node's
+        // prerequisites along (limb split, counters, hash tables, product-tree levels), replicated per rank.
+        // Costs are in "table entries touched"; the set-up constants are calibrated on MI355X at n=32768 k=16.
+        const double unit = A * (double)((size_t)1 << nu);          // one pass over the alpha E-tables
+        const double c_split = 1.2 * unit, c_counters = 3.5 * unit, c_hash1 = 2.5 * unit, c_tree1 = 1.4 * unit;
         std::vector<double> load(world, 0.0);
-        for (auto& it : items) {  // longest-processing-time-first
-            int r = (int)(std::min_element(load.begin(), load.end()) - load.begin());
-            load[r] += it.cost;
+        std::vector<char> has_split(world, 0), has_counters(world, 0), has_hash1(world, 0);
+        std::vector<int> tree_depth(world, 0);
+        auto setup_cost = [&](const Item& it, int r, bool commit) {
+            double extra = 0;
+            bool need_split = it.kind <= 3, need_counters = it.kind == 0 || it.kind == 1 || it.kind == 3, need_hash1 = it.kind == 0;
+            int depth = it.kind == 0 ? nu - 1 - it.idx : 0;
+            if (need_split && !has_split[r]) extra += c_split;
+            if (need_counters && !has_counters[r]) extra += c_counters;
+            if (need_hash1 && !has_hash1[r]) extra += c_hash1;
+            for (int k = tree_depth[r] + 1; k <= depth; k++) extra += c_tree1 / (double)(1 << (k - 1));
+            if (commit) {
+                has_split[r] |= need_split; has_counters[r] |= need_counters; has_hash1[r] |= need_hash1;
+                tree_depth[r] = std::max(tree_depth[r], depth);
+            }
+            return extra;
+        };
+        for (auto& it : items) {
+            int best = 0;
+            double best_load = 1e300;
+            for (int r = 0; r < world; r++) {
+                double l = load[r] + it.cost + setup_cost(it, r, false);
+                if (l < best_load) { best_load = l; best = r; }
+            }
+            int r = best;
+            load[r] += it.cost + setup_cost(it, r, true);
             switch (it.kind) {
                 case 0: gp1_owner[it.idx] = r; break;
                 case 1: own_gp2 = r; break;
