@@ -58,10 +58,15 @@ hg_ctx* hg_create(int device_id) {
     hg_ctx* c = new hg_ctx();
     c->device = device_id;
     hip_check(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate");
+    hip_check(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking), "hipStreamCreate");
+    hip_check(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming), "hipEventCreate");
+    hip_check(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming), "hipEventCreate");
+    c->prof_stream = c->stream;
     c->res_cap = (size_t)1 << 17;
     hip_check(hipMalloc((void**)&c->d_res, c->res_cap * sizeof(E2)), "hipMalloc(results)");
     hip_check(hipHostMalloc((void**)&c->h_res, c->res_cap * sizeof(E2), hipHostMallocDefault), "hipHostMalloc(results)");
     hip_check(hipMalloc((void**)&c->d_partials, (size_t)dev::SC_MAX_BLOCKS * 3 * 64 * sizeof(E2)), "hipMalloc(partials)");
+    hip_check(hipMalloc((void**)&c->d_partials2, (size_t)dev::SC_MAX_BLOCKS * 3 * 64 * sizeof(E2)), "hipMalloc(partials2)");
     c->stage_cap = (size_t)4 << 20;
     hip_check(hipHostMalloc((void**)&c->h_stage, c->stage_cap, hipHostMallocDefault), "hipHostMalloc(staging)");
     c->ensure_chain(16384);

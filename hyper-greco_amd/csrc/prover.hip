@@ -74,7 +74,7 @@ void hg_ctx::prof_begin(int cls, double bytes) {
     hipEvent_t a, b;
     auto get = [&]() { if (!event_pool.empty()) { hipEvent_t e = event_pool.back(); event_pool.pop_back(); return e; } hipEvent_t e; (void)hipEventCreate(&e); return e; };
     a = get(); b = get();
-    (void)hipEventRecord(a, stream);
+    (void)hipEventRecord(a, prof_stream);
     cur_cls = cls; cur_a = a;
     prof_events.push_back({cls, a, b});
     prof_stats[cls].launches++;
@@ -82,7 +82,7 @@ void hg_ctx::prof_begin(int cls, double bytes) {
 }
 void hg_ctx::prof_end() {
     if (cur_cls < 0) return;
-    (void)hipEventRecord(prof_events.back().b, stream);
+    (void)hipEventRecord(prof_events.back().b, prof_stream);
     cur_cls = -1;
 }
 void hg_ctx::prof_collect() {
@@ -101,6 +101,10 @@ hg_ctx::~hg_ctx() {
     if (h_res) (void)hipHostFree(h_res);
     if (h_stage) (void)hipHostFree(h_stage);
     if (d_partials) (void)hipFree(d_partials);
+    if (d_partials2) (void)hipFree(d_partials2);
+    if (stream2) { (void)hipStreamSynchronize(stream2); (void)hipStreamDestroy(stream2); }
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
     for (auto e : event_pool) (void)hipEventDestroy(e);
     if (stream) (void)hipStreamDestroy(stream);
 }
@@ -154,7 +158,9 @@ struct ScHandle {
 struct Prover {
     hg_ctx* ctx;
     const hg_pk* pk;
-    hipStream_t st;
+    hipStream_t st;   // stream currently being enqueued to
+    E2* partials;     // its per-workgroup partial-sum scratch
+    bool forked = false;
     ChallengeSource ch;
     ProofStream proof;
     std::vector<std::function<void()>> ops;  // transcript steps, replayed after the single synchronisation
@@ -238,7 +244,8 @@ struct Prover {
         own_out_claim = (int)(std::min_element(load.begin(), load.end()) - load.begin());
     }
 
-    Prover(hg_ctx* c, const hg_pk* k, int rank_ = 0, int world_ = 1) : ctx(c), pk(k), st(c->stream), rank(rank_), world(world_) {
+    Prover(hg_ctx* c, const hg_pk* k, int rank_ = 0, int world_ = 1) : ctx(c), pk(k), st(c->stream), partials(c->d_partials), rank(rank_), world(world_) {
+        ctx->prof_stream = st;
         plan_shards();
         cls_gp_ext = ctx->prof_class("sc_round<grand_product,ext>", true);
         cls_gp_base = ctx->prof_class("sc_round<grand_product,base>", false);
@@ -270,7 +277,7 @@ struct Prover {
     }
     void reduce(int grid, int nv, size_t out_slot) {
         ctx->prof_begin(cls_reduce, 0);
-        dev::reduce_partials(st, ctx->d_partials, grid, nv, d_res() + out_slot);
+        dev::reduce_partials(st, partials, grid, nv, d_res() + out_slot);
         ctx->prof_end();
     }
 
@@ -369,7 +376,7 @@ struct Prover {
                     for (int q = 0; q < cnt; q++) { const dev::StJob& J = st_jobs[L.jobs[o + q]]; bytes += round_bytes(J, J.nvars - 1 - L.h_log2); }
                     int cls = L.kind == dev::SC_GRANDPROD ? (L.base ? cls_gp_base : cls_gp_ext) : (L.base ? cls_col_base : cls_col_ext);
                     ctx->prof_begin(cls, bytes);
-                    dev::st_step(st, L.kind, L.base, d_jobs, list, cnt, L.h_log2, ctx->d_chal, ctx->d_partials, d_res());
+                    dev::st_step(st, L.kind, L.base, d_jobs, list, cnt, L.h_log2, ctx->d_chal, partials, d_res());
                     ctx->prof_end();
                 }
             }
@@ -426,7 +433,7 @@ struct Prover {
                 for (; rd < nvars && ((N >> rd) / 2) * (size_t)maxp > TAIL_ITEMS; rd++) {
                     size_t half = N >> (rd + 1);
                     ctx->prof_begin(cls_ps, pairs * (2.0 * half * ((rd == 0 ? 8 : 16) + 16) + half * 32.0));
-                    dev::ps_round(st, d_jobs, nj, nvars, rd, ctx->d_chal, ctx->d_partials, d_res());
+                    dev::ps_round(st, d_jobs, nj, nvars, rd, ctx->d_chal, partials, d_res());
                     ctx->prof_end();
                 }
                 if (rd < nvars) {
@@ -622,7 +629,7 @@ struct Prover {
         size_t claim_slot = slot(1);
         if (do_col) {
             eq_now(eq, nu, r_off);
-            int grid = dev::lasso_claim(st, L, eq, ep, ctx->d_partials);
+            int grid = dev::lasso_claim(st, L, eq, ep, partials);
             reduce(grid, 1, claim_slot);
         }
         Cell claimed = cell();
@@ -696,7 +703,7 @@ struct Prover {
                 size_t tmp = slot(cnt);
                 if (do_open) {
                     ctx->prof_begin(cls_aux, (double)N * (16 + 8.0 * cnt));
-                    int grid2 = dev::dot_eq(st, eqx, tabs, cnt, N, ctx->d_partials);
+                    int grid2 = dev::dot_eq(st, eqx, tabs, cnt, N, partials);
                     ctx->prof_end();
                     reduce(grid2, cnt, tmp);
                 }
@@ -707,7 +714,7 @@ struct Prover {
             }
             if (do_open) {
                 const u64* tabs[8] = {final_cts[c]};
-                int grid2 = dev::dot_eq(st, eqy, tabs, 1, M, ctx->d_partials);
+                int grid2 = dev::dot_eq(st, eqy, tabs, 1, M, partials);
                 reduce(grid2, 1, base_slot + 2);
             }
             defer_write_slots(base_slot, 3 + chk.second.size());
@@ -763,7 +770,7 @@ struct Prover {
         if (nd.nconst) {  // claim -= sum_g eqc[g] * w0_g
             size_t s = slot(1);
             if (own) after_eq.push_back([this, ndp0, np0, eqc, s] {
-                int grid = dev::vanilla_const_sum(st, ndp0->const_gate, ndp0->const_coef, ndp0->nconst, eqc, np0->log2_sub_out, np0->log2_reps, ctx->d_partials);
+                int grid = dev::vanilla_const_sum(st, ndp0->const_gate, ndp0->const_coef, ndp0->nconst, eqc, np0->log2_sub_out, np0->log2_reps, partials);
                 reduce(grid, 1, s);
             });
             ops.push_back([this, s, claim] { *claim = e2_sub(*claim, h_res()[s]); });
@@ -880,6 +887,19 @@ struct Prover {
         claims[n.preds[0]].push_back(ClaimRef{s.point_off, L, v});
     }
 
+    void fork_nodes_stream() {
+        static const bool two_streams = [] { const char* e = getenv("HG_TWO_STREAMS"); return e && e[0] == '1'; }();
+        if (!two_streams) return;
+        hip_check(hipEventRecord(ctx->ev_fork, ctx->stream), "fork event");   // after the result-buffer clear / uploads
+        hip_check(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0), "fork wait");
+        st = ctx->stream2; partials = ctx->d_partials2; ctx->prof_stream = st; forked = true;
+    }
+    void join_nodes_stream() {
+        if (!forked) return;
+        hip_check(hipEventRecord(ctx->ev_join, ctx->stream2), "join event");
+        st = ctx->stream; partials = ctx->d_partials; ctx->prof_stream = st;
+        hip_check(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0), "join wait");
+    }
     void gkr(const ClaimRef& sum_claim) {  // prove_gkr (sk_encryption_circuit.rs:455-457)
         const HCircuit& c = pk->circuit;
         claims.assign(c.nodes.size(), {});
@@ -899,12 +919,16 @@ struct Prover {
                 }
             }
         }
+        // The Vanilla / FFT node reductions go to the second stream: they are independent of the Lasso node on the
+        // device and consist mostly of small launches that leave CUs idle, so the two streams overlap.
+        fork_nodes_stream();
         flush_bookkeeping();                   // eq tables, constant sums, Libra gathers, DFT-row tables: batched
         flush_prodsum();                       // first wave: every FFT / Libra phase-1 reduction, batched
         for (auto& f : second_wave) f();       // Libra phase-2 bookkeeping (needs the phase-1 scalars in HBM)
         second_wave.clear();
         flush_bookkeeping();
         flush_prodsum();
+        join_nodes_stream();
     }
 
     // copies the result buffer back (the only synchronisation) and replays the transcript

@@ -18,7 +18,10 @@
 
 struct hg_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;   // Lasso node + everything sequential
+    hipStream_t stream2 = nullptr;  // Vanilla / FFT node reductions (independent of the Lasso node on the device)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t prof_stream = nullptr;  // stream the profiling events are recorded on (the one being enqueued to)
     // bump arena: chunks are kept across proves, offsets reset per prove
     struct Chunk { char* p; size_t cap, used; };
     std::vector<Chunk> chunks;
@@ -35,6 +38,7 @@ struct hg_ctx {
     hg::E2* h_res = nullptr;  // pinned
     size_t res_cap = 0;
     hg::E2* d_partials = nullptr;
+    hg::E2* d_partials2 = nullptr;  // scratch of stream2
     // pinned staging for small host->device descriptor copies; bump-allocated, reset per prove
     char* h_stage = nullptr;
     size_t stage_cap = 0, stage_used = 0;
