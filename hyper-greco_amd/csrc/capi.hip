@@ -107,6 +107,13 @@ int hg_setup(hg_ctx* ctx, const hg_params* params, hg_pk** out) {
         }
     }
     for (int m = 0; m < lp.alpha; m++) { L.mem_dim[m] = lp.mems[m].dim; L.mem_cutoff[m] = (u32)lp.mems[m].cutoff; }
+    if (lp.seg_lookup.size() > 128) throw Error("lasso: more than 128 row segments");
+    for (auto& chk : lp.chunks) {
+        int c = chk.first;  // counter memory = memory index c (lasso.rs:317-319)
+        if (c >= 4) throw Error("lasso: chunk index exceeds C");
+        for (size_t sg = 0; sg < lp.seg_lookup.size(); sg++)
+            if ((L.lookup_uses[lp.seg_lookup[sg]] >> c) & 1) L.cnt_segs[c][L.cnt_nsegs[c]++] = (uint8_t)sg;
+    }
     L.mpow[0] = 1;
     for (int i = 1; i < 5; i++) L.mpow[i] = gl_mul(L.mpow[i - 1], 65536);
     // circuit wiring as CSR per (node, input)

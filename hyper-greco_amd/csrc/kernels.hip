@@ -555,17 +555,15 @@ void lasso_split(hipStream_t st, const LassoDev& L, const u64* input, u64* dims,
     k_lasso_split<<<(unsigned)std::min<size_t>((N + TPB - 1) / TPB, 4096), TPB, 0, st>>>(L, input, dims, e_polys);
 }
 
+// keys/rows of the rows that touch counter memory m, compacted: position q -> row (segment list in LassoDev)
 __global__ __launch_bounds__(TPB) void k_counter_keys(LassoDev L, int m, const u64* __restrict__ dim, u32* __restrict__ keys,
                                                       u32* __restrict__ rows) {
-    const size_t N = (size_t)1 << L.nu;
-    for (size_t j = (size_t)blockIdx.x * TPB + threadIdx.x; j < N; j += (size_t)gridDim.x * TPB) {
-        u32 key = 65536;  // rows that do not touch memory m sort last
-        if (j < L.rows) {
-            int l = L.seg_lookup[j >> L.seg_shift];
-            if ((L.lookup_uses[l] >> m) & 1) key = (u32)dim[j];
-        }
-        keys[j] = key;
-        rows[j] = (u32)j;
+    const size_t cnt = (size_t)L.cnt_nsegs[m] << L.seg_shift;
+    const size_t smask = ((size_t)1 << L.seg_shift) - 1;
+    for (size_t q = (size_t)blockIdx.x * TPB + threadIdx.x; q < cnt; q += (size_t)gridDim.x * TPB) {
+        size_t row = ((size_t)L.cnt_segs[m][q >> L.seg_shift] << L.seg_shift) | (q & smask);
+        keys[q] = (u32)dim[row];
+        rows[q] = (u32)row;
     }
 }
 __global__ __launch_bounds__(TPB) void k_counter_starts(const u32* __restrict__ ks, size_t n, u32* __restrict__ starts) {
@@ -593,14 +591,16 @@ size_t lasso_counter_temp_bytes(size_t n) {
 void lasso_counters(hipStream_t st, const LassoDev& L, int m, const u64* dims, u64* read_ts, u64* final_cts, void* temp,
                     size_t temp_bytes, u32* keys, u32* keys_sorted, u32* rows_in, u32* rows_sorted, u32* starts) {
     const size_t N = (size_t)1 << L.nu;
-    int grid = grid_for(N) * 2;
-    k_counter_keys<<<grid, TPB, 0, st>>>(L, m, dims + (size_t)L.mem_dim[m] * N, keys, rows_in);
-    // stable LSD radix sort on the 17-bit key keeps rows of one address in row order
-    (void)rocprim::radix_sort_pairs(temp, temp_bytes, keys, keys_sorted, rows_in, rows_sorted, N, 0, 17, st);
     (void)hipMemsetAsync(read_ts, 0, N * sizeof(u64), st);
     (void)hipMemsetAsync(final_cts, 0, 65536 * sizeof(u64), st);
-    k_counter_starts<<<grid, TPB, 0, st>>>(keys_sorted, N, starts);
-    k_counter_ranks<<<grid, TPB, 0, st>>>(keys_sorted, rows_sorted, N, starts, read_ts, final_cts);
+    const size_t cnt = (size_t)L.cnt_nsegs[m] << L.seg_shift;  // rows whose lookup type uses memory m (lasso.rs:181-183)
+    if (cnt == 0) return;
+    int grid = grid_for(cnt);
+    k_counter_keys<<<grid, TPB, 0, st>>>(L, m, dims + (size_t)L.mem_dim[m] * N, keys, rows_in);
+    // stable LSD radix sort on the 16-bit address keeps the rows of one address in row order
+    (void)rocprim::radix_sort_pairs(temp, temp_bytes, keys, keys_sorted, rows_in, rows_sorted, cnt, 0, 16, st);
+    k_counter_starts<<<grid, TPB, 0, st>>>(keys_sorted, cnt, starts);
+    k_counter_ranks<<<grid, TPB, 0, st>>>(keys_sorted, rows_sorted, cnt, starts, read_ts, final_cts);
 }
 
 __global__ __launch_bounds__(TPB) void k_lasso_claim(LassoDev L, const E2* __restrict__ eq, const u64* __restrict__ e_polys,

@@ -88,6 +88,9 @@ struct LassoDev {
     u64 mpow[5];                 // M^i
     int lookup_nmems[32];
     int lookup_mems[32][4];
+    // row segments that touch counter memory c (c = chunk index < 4): only those rows are ranked
+    int cnt_nsegs[4];
+    uint8_t cnt_segs[4][128];
 };
 // dims[c][j] (4 x 2^nu) and E[m][j] (alpha x 2^nu), zero beyond `rows`
 void lasso_split(hipStream_t st, const LassoDev& L, const u64* input, u64* dims, u64* e_polys);
