@@ -38,7 +38,7 @@ class HgKernelStat(C.Structure):
 EXPORTS = [
     "hg_last_error", "hg_device_count", "hg_create", "hg_destroy", "hg_params_builtin", "hg_setup", "hg_pk_free",
     "hg_pk_lasso_layout", "hg_pk_info", "hg_witness_from_json", "hg_witness_synthetic", "hg_witness_from_arrays",
-    "hg_witness_get", "hg_witness_free", "hg_prove", "hg_verify", "hg_witness_gen", "hg_values_free", "hg_values_get", "hg_prove_shard_begin", "hg_prove_shard_finish", "hg_prove_resident", "hg_circuit_eval", "hg_lasso_prove", "hg_sumcheck", "hg_mle_eval",
+    "hg_witness_get", "hg_witness_free", "hg_prove", "hg_verify", "hg_witness_gen", "hg_values_free", "hg_values_get", "hg_prove_shard_begin", "hg_prove_shard_finish", "hg_prove_resident", "hg_circuit_eval", "hg_lasso_prove", "hg_lasso_prove_at", "hg_sumcheck", "hg_mle_eval",
     "hg_ntt", "hg_challenges", "hg_profile", "hg_profile_reset", "hg_profile_get",
 ]
 
@@ -86,6 +86,7 @@ def lib():
         L.hg_verify.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
         L.hg_circuit_eval.argtypes = [C.c_void_p, C.c_void_p, u64p, C.c_size_t, u64p, C.c_size_t]
         L.hg_lasso_prove.argtypes = [C.c_void_p, C.c_void_p, u64p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), u64p]
+        L.hg_lasso_prove_at.argtypes = [C.c_void_p, C.c_void_p, u64p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), u64p]
         L.hg_sumcheck.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(u64p), C.POINTER(C.c_int), u64p, C.c_size_t,
                                   u64p, C.c_size_t, u64p, u64p, u64p, u64p]
         L.hg_mle_eval.argtypes = [C.c_void_p, u64p, C.c_size_t, u64p, u64p]
@@ -356,11 +357,11 @@ class LassoNode:
     def __init__(self, pk):
         self.pk = pk
 
-    def prove_claim_reduction(self, ctx, inputs, cap=1 << 24):
+    def prove_claim_reduction(self, ctx, inputs, cap=1 << 24, chain_skip=0):
         inputs = np.ascontiguousarray(inputs, dtype=np.uint64)
         assert inputs.size == 1 << self.pk.nu
         buf = (C.c_uint8 * cap)()
         ln = C.c_size_t(0)
         claim = np.zeros(2 * self.pk.nu + 2, dtype=np.uint64)
-        _check(lib().hg_lasso_prove(ctx.h, self.pk.h, _ptr(inputs), buf, cap, C.byref(ln), _ptr(claim)))
+        _check(lib().hg_lasso_prove_at(ctx.h, self.pk.h, _ptr(inputs), chain_skip, buf, cap, C.byref(ln), _ptr(claim)))
         return bytes(buf[:ln.value]), claim

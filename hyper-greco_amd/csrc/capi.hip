@@ -391,10 +391,15 @@ int hg_circuit_eval(const hg_pk* pk, const hg_witness* w, uint64_t* lasso_in, si
 }
 
 int hg_lasso_prove(hg_ctx* ctx, const hg_pk* pk, const uint64_t* lasso_in, uint8_t* proof, size_t cap, size_t* len, uint64_t* claim_out) {
+    return hg_lasso_prove_at(ctx, pk, lasso_in, 0, proof, cap, len, claim_out);
+}
+
+int hg_lasso_prove_at(hg_ctx* ctx, const hg_pk* pk, const uint64_t* lasso_in, size_t chain_skip, uint8_t* proof, size_t cap, size_t* len,
+                      uint64_t* claim_out) {
     HG_TRY
     if (!ctx || !pk || !pk->ctx) throw Error("hg_lasso_prove: needs a device context and a device prover key");
     std::vector<E2> claim;
-    std::vector<uint8_t> pr = prove_lasso_node(ctx, pk, lasso_in, &claim);
+    std::vector<uint8_t> pr = prove_lasso_node(ctx, pk, lasso_in, chain_skip, &claim);
     *len = pr.size();
     if (pr.size() > cap) throw Error("proof buffer too small");
     memcpy(proof, pr.data(), pr.size());

@@ -879,7 +879,92 @@ __global__ __launch_bounds__(TPB) void k_ntt_bitrev(u64* __restrict__ data, int 
         }
     }
 }
-void ntt_batch(hipStream_t st, u64* data, int log2n, size_t batch, const u64* W, u64 scale) {
+// ---- four-step NTT, both steps LDS-resident -------------------------------------------------------------
+// N = N1*N2 (N1 = 2^n1, N2 = 2^n2 <= 256). Input index i = i1*N2 + i2, output index k = k1 + N1*k2:
+//   X[k1 + N1 k2] = sum_i2 w_N2^(i2 k2) * [ w^(i2 k1) * sum_i1 x[i1 N2 + i2] w_N1^(i1 k1) ]
+// Step A: a workgroup takes 16 adjacent columns i2 (128-B coalesced row segments), runs the N1-point transforms
+// down the columns in LDS (radix-2 decimation in frequency, bit reversal absorbed in the store index), applies
+// the twiddle w^(i2 k1) and stores Y[k1*N2 + i2]. Step B: a workgroup takes 16 adjacent rows k1, transposes them
+// into LDS (row stride 17: conflict-free), runs the N2-point transforms and stores 16 adjacent outputs per k2.
+constexpr int NTT_TILE = 16;
+__device__ __forceinline__ u32 brev_bits(u32 x, int bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
+
+template <int STRIDE>
+__device__ __forceinline__ void lds_ntt_dif(u64* tile, int m, const u64* __restrict__ W, size_t wstep_log2) {
+    // 2^m-point DIF along the slow index of tile[pos*STRIDE + lane16]; twiddle w_M^j = W[j << wstep_log2]
+    const int M = 1 << m;
+    for (int s = m - 1; s >= 0; s--) {
+        const int h = 1 << s;
+        for (int q = threadIdx.x; q < (M / 2) * NTT_TILE; q += blockDim.x) {
+            const int c = q & (NTT_TILE - 1), p = q >> 4;
+            const int j = p & (h - 1), a = ((p >> s) << (s + 1)) + j;
+            u64 x = tile[a * STRIDE + c], y = tile[(a + h) * STRIDE + c];
+            tile[a * STRIDE + c] = gl_add(x, y);
+            u64 d = gl_sub(x, y);
+            tile[(a + h) * STRIDE + c] = j ? gl_mul(d, W[((size_t)j << (m - 1 - s)) << wstep_log2]) : d;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ntt4_cols(const u64* __restrict__ in, u64* __restrict__ out, int n, int n1,
+                                                   const u64* __restrict__ W) {
+    extern __shared__ u64 ntile[];
+    const int n2 = n - n1;
+    const size_t N = (size_t)1 << n, N2 = (size_t)1 << n2;
+    const int N1 = 1 << n1;
+    const size_t i2_0 = (size_t)blockIdx.x * NTT_TILE;
+    const u64* x = in + (size_t)blockIdx.y * N;
+    u64* y = out + (size_t)blockIdx.y * N;
+    for (int idx = threadIdx.x; idx < N1 * NTT_TILE; idx += blockDim.x) {
+        int i1 = idx >> 4, c = idx & (NTT_TILE - 1);
+        ntile[idx] = x[(size_t)i1 * N2 + i2_0 + c];
+    }
+    __syncthreads();
+    lds_ntt_dif<NTT_TILE>(ntile, n1, W, n2);  // w_N1 = w^(N2)
+    for (int idx = threadIdx.x; idx < N1 * NTT_TILE; idx += blockDim.x) {
+        int pos = idx >> 4, c = idx & (NTT_TILE - 1);
+        u32 k1 = brev_bits((u32)pos, n1);
+        size_t i2 = i2_0 + c;
+        u64 v = ntile[idx];
+        size_t e = (size_t)k1 * i2;  // < N
+        y[(size_t)k1 * N2 + i2] = e ? gl_mul(v, W[e]) : v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ntt4_rows(const u64* __restrict__ in, u64* __restrict__ out, int n, int n1,
+                                                   const u64* __restrict__ W, u64 scale) {
+    extern __shared__ u64 ntile[];
+    constexpr int ST = NTT_TILE + 1;
+    const int n2 = n - n1;
+    const size_t N = (size_t)1 << n, N1 = (size_t)1 << n1;
+    const int N2 = 1 << n2;
+    const size_t k1_0 = (size_t)blockIdx.x * NTT_TILE;
+    const u64* y = in + (size_t)blockIdx.y * N;
+    u64* X = out + (size_t)blockIdx.y * N;
+    for (int idx = threadIdx.x; idx < N2 * NTT_TILE; idx += blockDim.x) {
+        int r = idx >> n2, i2 = idx & (N2 - 1);
+        ntile[i2 * ST + r] = y[(k1_0 + r) * (size_t)N2 + i2];
+    }
+    __syncthreads();
+    lds_ntt_dif<ST>(ntile, n2, W, n1);  // w_N2 = w^(N1)
+    for (int idx = threadIdx.x; idx < N2 * NTT_TILE; idx += blockDim.x) {
+        int pos = idx >> 4, r = idx & (NTT_TILE - 1);
+        u32 k2 = brev_bits((u32)pos, n2);
+        u64 v = ntile[pos * ST + r];
+        X[k1_0 + r + N1 * (size_t)k2] = scale == 1 ? v : gl_mul(v, scale);
+    }
+}
+
+// W must hold w^i for i < N (four-step) — the radix-2 fallback only reads i < N/2.
+void ntt_batch(hipStream_t st, u64* data, int log2n, size_t batch, const u64* W, u64 scale, u64* scratch) {
+    if (log2n >= 8 && log2n <= 16 && scratch) {
+        const int n1 = log2n / 2, n2 = log2n - n1;
+        const size_t lds = (size_t)(1 << (n1 > n2 ? n1 : n2)) * (NTT_TILE + 1) * sizeof(u64);
+        k_ntt4_cols<<<dim3(1u << (n2 - 4), (unsigned)batch), 256, lds, st>>>(data, scratch, log2n, n1, W);
+        k_ntt4_rows<<<dim3(1u << (n1 - 4), (unsigned)batch), 256, lds, st>>>(scratch, data, log2n, n1, W, scale);
+        return;
+    }
     size_t total = batch << (log2n - 1);
     int grid = (int)std::min<size_t>((total + TPB - 1) / TPB, 4096);
     for (int s = log2n - 1; s >= 0; s--) k_ntt_stage<<<grid, TPB, 0, st>>>(data, log2n, s, batch, W);

@@ -142,7 +142,9 @@ struct EvalNode {
 void gate_eval(hipStream_t st, const EvalNode& n);
 
 // ---- NTT (witness generation / hg_ntt) ----------------------------------------------------------
-void ntt_batch(hipStream_t st, u64* data, int log2n, size_t batch, const u64* W /* w^i, i < N/2 */, u64 scale);
+// In place, natural order in and out. 8 <= log2n <= 16 with a scratch buffer of batch*N u64: LDS-resident four-step
+// (two launches); otherwise radix-2 stages in HBM. W = w^i for i < N.
+void ntt_batch(hipStream_t st, u64* data, int log2n, size_t batch, const u64* W, u64 scale, u64* scratch);
 
 }  // namespace dev
 }  // namespace hg

@@ -995,6 +995,14 @@ hg_values* witness_gen(hg_ctx* ctx, const hg_pk* pk, const Witness& w, double* w
     }
     hip_check(hipStreamSynchronize(st), "upload sync");
     double t1 = wall_ms();
+    size_t max_fft = 0;
+    {
+        std::map<std::pair<int, int>, size_t> grp_sz;
+        for (size_t id = 0; id < nn; id++) if (c.nodes[id].kind == NK_FFT) grp_sz[{level[id], (int)c.nodes[id].inverse}] += v->sizes[id];
+        for (auto& kv : grp_sz) max_fft = std::max(max_fft, kv.second);
+    }
+    u64* ntt_scratch = nullptr;
+    if (max_fft) { hip_check(hipMalloc((void**)&ntt_scratch, max_fft * 8), "hipMalloc(ntt scratch)"); }
     for (int l = 1; l <= maxl; l++) {
         for (int inv = 0; inv < 2; inv++) {  // FFT groups
             std::vector<int> grp;
@@ -1007,7 +1015,7 @@ hg_values* witness_gen(hg_ctx* ctx, const hg_pk* pk, const Witness& w, double* w
                 hip_check(hipMemcpyAsync(dv[id], dv[c.nodes[id].preds[0]], N * 8, hipMemcpyDeviceToDevice, st), "copy fft input");
             }
             const u64* W = (inv ? pk->w_inv : pk->w_fwd).at(L);
-            dev::ntt_batch(st, dv[grp[0]], L, grp.size(), W, inv ? gl_inv(gl_from_u64(N)) : 1);
+            dev::ntt_batch(st, dv[grp[0]], L, grp.size(), W, inv ? gl_inv(gl_from_u64(N)) : 1, ntt_scratch);
         }
         for (int id : c.topo) {
             const HNode& n = c.nodes[id];
@@ -1023,6 +1031,7 @@ hg_values* witness_gen(hg_ctx* ctx, const hg_pk* pk, const Witness& w, double* w
         }
     }
     hip_check(hipStreamSynchronize(st), "witness generation sync");
+    if (ntt_scratch) (void)hipFree(ntt_scratch);
     hip_check(hipGetLastError(), "witness generation");
     double t2 = wall_ms();
     if (upload_ms) *upload_ms = t1 - t0;
@@ -1117,10 +1126,12 @@ ProveResult prove_shard_finish(hg_ctx* ctx) {
     return res;
 }
 
-std::vector<uint8_t> prove_lasso_node(hg_ctx* ctx, const hg_pk* pk, const u64* lasso_in_host, std::vector<E2>* claim_out) {
+std::vector<uint8_t> prove_lasso_node(hg_ctx* ctx, const hg_pk* pk, const u64* lasso_in_host, size_t chain_skip, std::vector<E2>* claim_out) {
     hip_check(hipSetDevice(ctx->device), "hipSetDevice");
     ctx->arena_reset();
     Prover P(ctx, pk);
+    ctx->ensure_chain(chain_skip + 4096);
+    P.ch.pos = 2 * chain_skip;  // the node is entered with `chain_skip` E challenges already squeezed by the caller
     const size_t N = (size_t)1 << pk->lasso.nu;
     u64* d_in = ctx->alloc_n<u64>(N);
     hip_check(hipMemcpyAsync(d_in, lasso_in_host, N * 8, hipMemcpyHostToDevice, ctx->stream), "upload lasso input");
@@ -1218,12 +1229,13 @@ void ntt_device(hg_ctx* ctx, const u64* in_host, int log2n, bool inverse, size_t
     ctx->arena_reset();
     const size_t N = (size_t)1 << log2n;
     u64* d = ctx->alloc_n<u64>(N * batch);
+    u64* scratch = ctx->alloc_n<u64>(N * batch);
     u64* W = ctx->alloc_n<u64>(N);
     u64 w = root_of_unity(log2n);
     if (inverse) w = gl_inv(w);
     hip_check(hipMemcpyAsync(d, in_host, N * batch * 8, hipMemcpyHostToDevice, ctx->stream), "upload");
-    dev::powers_table(ctx->stream, W, w, N / 2 ? N / 2 : 1);
-    dev::ntt_batch(ctx->stream, d, log2n, batch, W, inverse ? gl_inv(gl_from_u64(N)) : 1);
+    dev::powers_table(ctx->stream, W, w, N);
+    dev::ntt_batch(ctx->stream, d, log2n, batch, W, inverse ? gl_inv(gl_from_u64(N)) : 1, scratch);
     hip_check(hipMemcpyAsync(out_host, d, N * batch * 8, hipMemcpyDeviceToHost, ctx->stream), "download");
     hip_check(hipStreamSynchronize(ctx->stream), "ntt sync");
 }

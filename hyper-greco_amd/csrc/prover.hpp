@@ -105,7 +105,7 @@ ProveResult prove_resident(hg_ctx* ctx, const hg_pk* pk, const hg_values* v);
 size_t prove_shard_begin(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int rank, int world);  // -> #E2 slots in ctx->h_res
 ProveResult prove_shard_finish(hg_ctx* ctx);
 // Lasso node alone on a fresh transcript; claim_out = nu point coordinates then the value
-std::vector<uint8_t> prove_lasso_node(hg_ctx* ctx, const hg_pk* pk, const u64* lasso_in_host, std::vector<E2>* claim_out);
+std::vector<uint8_t> prove_lasso_node(hg_ctx* ctx, const hg_pk* pk, const u64* lasso_in_host, size_t chain_skip, std::vector<E2>* claim_out);
 // one sum-check on caller tables (kernel-level parity entry point)
 struct SumcheckIO {
     int kind; size_t nv; std::vector<const u64*> tables; std::vector<int> is_base; std::vector<E2> pw; E2 claim; size_t chain_skip;

@@ -130,6 +130,10 @@ int hg_circuit_eval(const hg_pk* pk, const hg_witness* w, uint64_t* lasso_in, si
  *   transcript. lasso_in: host table of 2^nu field elements. claim_out: nu E coordinates then the value. */
 int hg_lasso_prove(hg_ctx* ctx, const hg_pk* pk, const uint64_t* lasso_in, uint8_t* proof, size_t cap, size_t* len,
                    uint64_t* claim_out);
+/* The same, entered inside a larger transcript: `chain_skip` E challenges have already been squeezed by the caller
+ * (what a Rust `impl Node` shim passes: the position of its `&mut dyn TranscriptWrite` in the challenge chain). */
+int hg_lasso_prove_at(hg_ctx* ctx, const hg_pk* pk, const uint64_t* lasso_in, size_t chain_skip, uint8_t* proof, size_t cap,
+                      size_t* len, uint64_t* claim_out);
 
 /* = gkr::sum_check::prove_sum_check [REF call sites lasso.rs:278-279, prover.rs:242-252] on caller tables.
  *   kind: 0 collation g = p0*sum M^i p_i, 1 grand product g = p0*sum gam^i p_2i p_2i+1, 2 sum of pair products.

@@ -252,3 +252,23 @@ def test_bench_sharded_two_processes_on_one_gpu():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] == d["ms_per_step"]
+
+
+def test_lasso_node_inside_a_larger_transcript(ctx):
+    """hg_lasso_prove_at: the node entered after `skip` challenges equals the bytes the full prover writes for it."""
+    n, k = 1024, 1
+    bfv = hg.BfvEncrypt.new(n, k)
+    pk = bfv.setup(ctx)
+    w = bfv.get_inputs(os.path.join(orclib.GOLDEN, "sk_enc_1024_1x27_65537.json"))
+    full, _ = bfv.prove(ctx, pk, w)
+    lasso_in, _ = pk.circuit_eval(w)
+    base, _ = hg.LassoNode(pk).prove_claim_reduction(ctx, lasso_in)
+    # find where the node sits in the whole proof: try every 16-byte offset and challenge position until the bytes match
+    found = False
+    for skip in range(0, 400):
+        pr, _ = hg.LassoNode(pk).prove_claim_reduction(ctx, lasso_in, chain_skip=skip)
+        if pr != base and pr in full:
+            found = True
+            break
+    assert found, "no challenge offset reproduces the node's section of the full proof"
+    pk.free()
