@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <tuple>
 
 namespace hg {
@@ -961,7 +962,8 @@ hg_values* witness_gen(hg_ctx* ctx, const hg_pk* pk, const Witness& w, double* w
     std::vector<int> level(nn, 0);
     int maxl = 0;
     for (int id : c.topo) { for (int pr : c.nodes[id].preds) level[id] = std::max(level[id], level[pr] + 1); maxl = std::max(maxl, level[id]); }
-    std::unique_ptr<hg_values> v(new hg_values());
+    struct ValuesDeleter { void operator()(hg_values* p) const { values_free(p); } };
+    std::unique_ptr<hg_values, ValuesDeleter> v(new hg_values());
     v->d_vals.assign(nn, nullptr);
     v->sizes.assign(nn, 0);
     // layout: FFT nodes of one (level, direction) group are contiguous so that one batched NTT covers the group
@@ -1002,7 +1004,7 @@ hg_values* witness_gen(hg_ctx* ctx, const hg_pk* pk, const Witness& w, double* w
         for (auto& kv : grp_sz) max_fft = std::max(max_fft, kv.second);
     }
     u64* ntt_scratch = nullptr;
-    if (max_fft) { hip_check(hipMalloc((void**)&ntt_scratch, max_fft * 8), "hipMalloc(ntt scratch)"); }
+    if (max_fft) { hip_check(hipMalloc((void**)&ntt_scratch, max_fft * 8), "hipMalloc(ntt scratch)"); v->owned.push_back(ntt_scratch); }
     for (int l = 1; l <= maxl; l++) {
         for (int inv = 0; inv < 2; inv++) {  // FFT groups
             std::vector<int> grp;
@@ -1031,7 +1033,7 @@ hg_values* witness_gen(hg_ctx* ctx, const hg_pk* pk, const Witness& w, double* w
         }
     }
     hip_check(hipStreamSynchronize(st), "witness generation sync");
-    if (ntt_scratch) (void)hipFree(ntt_scratch);
+    if (ntt_scratch) { (void)hipFree(ntt_scratch); v->owned.pop_back(); }
     hip_check(hipGetLastError(), "witness generation");
     double t2 = wall_ms();
     if (upload_ms) *upload_ms = t1 - t0;
@@ -1099,7 +1101,8 @@ ProveResult prove_resident(hg_ctx* ctx, const hg_pk* pk, const hg_values* v) {
 
 // sharded single proof: begin (this rank's jobs) -> caller sum-all-reduces ctx->h_res[0 .. n) -> finish
 struct PendingShard { std::unique_ptr<Prover> P; double t_start; float gpu_ms; };
-static std::map<hg_ctx*, PendingShard> g_pending;
+static std::map<hg_ctx*, PendingShard> g_pending;  // one sharded prove in flight per context
+static std::mutex g_pending_mu;
 
 size_t prove_shard_begin(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int rank, int world) {
     if (world < 1 || rank < 0 || rank >= world) throw Error("prove_shard_begin: bad rank/world");
@@ -1107,14 +1110,18 @@ size_t prove_shard_begin(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int r
     ps.P = prove_begin(ctx, pk, v, rank, world, &ps.t_start, &ps.gpu_ms);
     size_t n = ps.P->res_used;
     if (getenv("HG_SHARD_DEBUG")) fprintf(stderr, "[hg] shard rank %d/%d: gpu %.3f ms, enqueue %.3f ms\n", rank, world, ps.gpu_ms, ps.P->t_enqueued - ps.t_start);
-    g_pending[ctx] = std::move(ps);
+    { std::lock_guard<std::mutex> lk(g_pending_mu); g_pending[ctx] = std::move(ps); }
     return n;
 }
 ProveResult prove_shard_finish(hg_ctx* ctx) {
-    auto it = g_pending.find(ctx);
-    if (it == g_pending.end()) throw Error("prove_shard_finish: no sharded prove in flight on this context");
-    PendingShard ps = std::move(it->second);
-    g_pending.erase(it);
+    PendingShard ps;
+    {
+        std::lock_guard<std::mutex> lk(g_pending_mu);
+        auto it = g_pending.find(ctx);
+        if (it == g_pending.end()) throw Error("prove_shard_finish: no sharded prove in flight on this context");
+        ps = std::move(it->second);
+        g_pending.erase(it);
+    }
     ProveResult res;
     ps.P->replay();
     res.prove_ms = wall_ms() - ps.t_start;
