@@ -624,18 +624,26 @@ int lasso_claim(hipStream_t st, const LassoDev& L, const E2* eq, const u64* e_po
     return grid;
 }
 
+// read / write multiset hashes of one memory and, in the same pass, the first product-tree level of both tables
+// (row j and row j + n/2 are hashed by the same thread), so the tree never re-reads the 2^nu-row hash tables
 __global__ __launch_bounds__(TPB) void k_hash_rw(size_t n, const u64* __restrict__ dim, const u64* __restrict__ ep,
                                                  const u64* __restrict__ ts, u64 gamma, u64 gamma2, u64 tau,
-                                                 u64* __restrict__ rd, u64* __restrict__ wr) {
-    for (size_t j = (size_t)blockIdx.x * TPB + threadIdx.x; j < n; j += (size_t)gridDim.x * TPB) {
+                                                 u64* __restrict__ rd, u64* __restrict__ wr, u64* __restrict__ rd1,
+                                                 u64* __restrict__ wr1) {
+    const size_t h = n >> 1;
+    for (size_t j = (size_t)blockIdx.x * TPB + threadIdx.x; j < h; j += (size_t)gridDim.x * TPB) {
         // h(a,v,t) = a + v*gamma + t*gamma^2 - tau   (prover.rs:44)
-        u64 h = gl_sub(gl_add(gl_add(dim[j], gl_mul(ep[j], gamma)), gl_mul(ts[j], gamma2)), tau);
-        rd[j] = h;
-        wr[j] = gl_add(h, gamma2);  // t + 1
+        u64 a0 = gl_sub(gl_add(gl_add(dim[j], gl_mul(ep[j], gamma)), gl_mul(ts[j], gamma2)), tau);
+        u64 a1 = gl_sub(gl_add(gl_add(dim[j + h], gl_mul(ep[j + h], gamma)), gl_mul(ts[j + h], gamma2)), tau);
+        u64 b0 = gl_add(a0, gamma2), b1 = gl_add(a1, gamma2);  // write hash: t + 1
+        rd[j] = a0; rd[j + h] = a1;
+        wr[j] = b0; wr[j + h] = b1;
+        if (rd1) { rd1[j] = gl_mul(a0, a1); wr1[j] = gl_mul(b0, b1); }  // Layer::bottom + Layer::up (prover.rs:310-354)
     }
 }
-void lasso_hash_rw(hipStream_t st, size_t n, const u64* dim, const u64* e_poly, const u64* read_ts, u64 gamma, u64 tau, u64* rd, u64* wr) {
-    k_hash_rw<<<grid_for(n) * 4, TPB, 0, st>>>(n, dim, e_poly, read_ts, gamma, gl_mul(gamma, gamma), tau, rd, wr);
+void lasso_hash_rw(hipStream_t st, size_t n, const u64* dim, const u64* e_poly, const u64* read_ts, u64 gamma, u64 tau, u64* rd, u64* wr,
+                   u64* rd1, u64* wr1) {
+    k_hash_rw<<<grid_for(n >> 1) * 4, TPB, 0, st>>>(n, dim, e_poly, read_ts, gamma, gl_mul(gamma, gamma), tau, rd, wr, rd1, wr1);
 }
 __global__ __launch_bounds__(TPB) void k_hash_if(u32 cutoff, const u64* __restrict__ fc, u64 gamma, u64 gamma2, u64 tau,
                                                  u64* __restrict__ init, u64* __restrict__ fin) {

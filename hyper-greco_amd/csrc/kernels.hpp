@@ -101,7 +101,9 @@ void lasso_counters(hipStream_t st, const LassoDev& L, int m, const u64* dims, u
 // sum_k eq[k] * sum_i M^i E_{mems(lookup(k))[i]}[k]  -> partials (nv = 1)
 int lasso_claim(hipStream_t st, const LassoDev& L, const E2* eq, const u64* e_polys, E2* partials);
 // multiset hashes h = a + v*gamma + t*gamma^2 - tau
-void lasso_hash_rw(hipStream_t st, size_t n, const u64* dim, const u64* e_poly, const u64* read_ts, u64 gamma, u64 tau, u64* rd, u64* wr);
+// rd1/wr1 (may be null): first product-tree level rd[j]*rd[j+n/2], wr[j]*wr[j+n/2], n/2 entries each
+void lasso_hash_rw(hipStream_t st, size_t n, const u64* dim, const u64* e_poly, const u64* read_ts, u64 gamma, u64 tau, u64* rd, u64* wr,
+                   u64* rd1, u64* wr1);
 void lasso_hash_if(hipStream_t st, u32 cutoff, const u64* final_cts, u64 gamma, u64 tau, u64* init, u64* fin);
 // product tree level: out[b][i] = in[b][i] * in[b][i + h], b < nb, i < h
 void prod_level(hipStream_t st, const u64* in, size_t in_len, u64* out, int nb);

@@ -545,14 +545,20 @@ struct Prover {
     struct GpOut { size_t point_off; };
     // prove_grand_product (prover.rs:183-266) over nb contiguous tables of `len` base-field values
     // `owner[n]` = rank that runs layer n (n = 0: roots + top evaluations); H may be null when no layer is owned
-    GpOut grand_product(const u64* H, size_t len, int nb, const std::vector<int>& owner) {
+    int gp_deepest(int nv, const std::vector<int>& owner) const {  // highest tree level this rank needs (layer n reads level nv-1-n)
+        int deepest = 0;
+        for (int n = 0; n < nv; n++) if (mine(owner[n])) deepest = std::max(deepest, nv - 1 - n);
+        return deepest;
+    }
+    // lev1 (optional): the first tree level, already produced by the hash kernel
+    GpOut grand_product(const u64* H, size_t len, int nb, const std::vector<int>& owner, const u64* lev1 = nullptr) {
         int nv = 0;
         while (((size_t)1 << nv) < len) nv++;
         std::vector<const u64*> lev(nv, nullptr);
         lev[0] = H;
-        int deepest = 0;  // highest tree level this rank needs (layer n reads level nv-1-n)
-        for (int n = 0; n < nv; n++) if (mine(owner[n])) deepest = std::max(deepest, nv - 1 - n);
-        for (int k = 1; k <= deepest; k++) {  // Layer::bottom / Layer::up: w = v_l * v_r on the MSB split
+        const int deepest = gp_deepest(nv, owner);
+        if (lev1 && nv > 1) lev[1] = lev1;
+        for (int k = (lev1 && nv > 1) ? 2 : 1; k <= deepest; k++) {  // Layer::bottom / Layer::up: w = v_l * v_r on the MSB split
             u64* out = ctx->alloc_n<u64>((size_t)nb * (len >> k));
             ctx->prof_begin(cls_tree, (double)nb * (len >> (k - 1)) * 8.0 * 1.5);
             dev::prod_level(st, lev[k - 1], len >> (k - 1), out, nb);
@@ -667,17 +673,19 @@ struct Prover {
         // MemoryCheckingProver::new (prover.rs:35-89)
         const int G = (int)lp.gkr_order.size();
         u64* H1 = any_gp1 ? ctx->alloc_n<u64>((size_t)2 * G * N) : nullptr;
+        u64* L1 = (any_gp1 && gp_deepest(nu, gp1_owner) >= 1) ? ctx->alloc_n<u64>((size_t)2 * G * (N / 2)) : nullptr;
         u64* H2 = do_gp2 ? ctx->alloc_n<u64>((size_t)2 * G * M) : nullptr;
         for (int i = 0; i < G; i++) {
             int m = lp.gkr_order[i], c = lp.gkr_chunk[i];
             if (any_gp1) {
-                ctx->prof_begin(cls_hash, (double)N * 8 * 5);
-                dev::lasso_hash_rw(st, N, dims + (size_t)c * N, ep + (size_t)m * N, read_ts[c], gamma, tau, H1 + (size_t)i * N, H1 + (size_t)(G + i) * N);
+                ctx->prof_begin(cls_hash, (double)N * 8 * (L1 ? 6 : 5));
+                dev::lasso_hash_rw(st, N, dims + (size_t)c * N, ep + (size_t)m * N, read_ts[c], gamma, tau, H1 + (size_t)i * N, H1 + (size_t)(G + i) * N,
+                                   L1 ? L1 + (size_t)i * (N / 2) : nullptr, L1 ? L1 + (size_t)(G + i) * (N / 2) : nullptr);
                 ctx->prof_end();
             }
             if (do_gp2) dev::lasso_hash_if(st, (u32)lp.mems[m].cutoff, final_cts[c], gamma, tau, H2 + (size_t)i * M, H2 + (size_t)(G + i) * M);
         }
-        GpOut g1 = grand_product(H1, N, 2 * G, gp1_owner);                          // reads then writes (prover.rs:161-165)
+        GpOut g1 = grand_product(H1, N, 2 * G, gp1_owner, L1);                      // reads then writes (prover.rs:161-165)
         GpOut g2 = grand_product(H2, M, 2 * G, std::vector<int>(16, own_gp2));      // inits then finals (prover.rs:167-171)
         // openings (prover.rs:173-178, mod.rs:80-93)
         E2* eqx = eq;  // the eq(r,.) table is dead by now
