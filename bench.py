@@ -5,8 +5,8 @@ configs[2]), on N MI355X GPUs of one node.
 A "step" = one GKR prove (the reference's "GKR prove" span [REF bfv-gkr/src/sk_encryption_circuit.rs:455-457],
 plus the output-claim evaluation :444-448) of one synthetic witness whose node tables are already resident in
 HBM. N > 1, default `--mode shard`: ONE proof is sharded over the N GPUs (strong scaling): every rank holds the
-same witness, runs the device jobs it owns (the jobs are independent) and one RCCL sum-all-reduce
-of the scalar result buffer per proof is the only exchange; `value` = max-over-ranks step time = ms per proof.
+same witness, runs the device jobs it owns (the jobs are independent; grand product #1 is split by memory, DESIGN.md
+§3/§7) and one RCCL all-gather of the scalar result buffers per proof is the only exchange; `value` = max-over-ranks step time = ms per proof.
 `--mode dp`: every rank proves its own independent witness (weak scaling, no collective), `value` = step time / N.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel, HIP events on
@@ -172,9 +172,11 @@ def main():
             return hg.prove_resident(ctx, pk, vals, out)
         import numpy as np
         part = hg.prove_shard_begin(ctx, pk, vals, rank, world)      # this rank's jobs, one stream sync
-        t = torch.from_numpy(part.view(np.int64)).to(red_dev)        # u64 lanes: one non-zero contributor per lane
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)                     # the only exchange of the proof
-        part[:] = t.cpu().numpy().view(np.uint64)
+        t = torch.from_numpy(part.view(np.int64).copy()).to(red_dev)
+        bufs = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(bufs, t)                                     # the only exchange of the proof (RCCL over xGMI)
+        gathered = torch.stack(bufs).cpu().numpy().view(np.uint64)
+        hg.prove_shard_combine(ctx, gathered, world)                 # lane-wise sum mod p (GP#1 round sums are partial sums)
         return hg.prove_shard_finish(ctx, out)                       # transcript replay -> identical bytes on every rank
 
     if shard:  # the sharded proof must equal the single-GPU proof bit for bit
@@ -229,7 +231,7 @@ def main():
             "config": {"workload": f"GKR prove (sk_encryption_circuit.rs:444-457) of the BFV sk-enc circuit, n={args.n} k={args.k} "
                                    "Goldilocks/GoldilocksExt2, seeded synthetic witness, node tables resident in HBM",
                        "n": args.n, "k": args.k, "field": "goldilocks", "proofs_per_step": 1 if (shard or world == 1) else world,
-                       "parallelism": (f"shard{world}: one proof, device jobs partitioned over {world} GPUs, one RCCL sum-all-reduce of the result buffer per proof"
+                       "parallelism": (f"shard{world}: one proof, device jobs partitioned over {world} GPUs, one RCCL all-gather of the result buffers per proof"
                                        if shard else f"dp{world}: one independent proof per GPU, no data-path collective"),
                        "proof_bytes": len(first), "gpu_ms_events": round(gpu_ms, 4),
                        "witness_gen_ms_device": round(vals.timings["witness_ms"], 2), "upload_ms": round(vals.timings["upload_ms"], 2)},

@@ -38,7 +38,7 @@ class HgKernelStat(C.Structure):
 EXPORTS = [
     "hg_last_error", "hg_device_count", "hg_create", "hg_destroy", "hg_params_builtin", "hg_setup", "hg_pk_free",
     "hg_pk_lasso_layout", "hg_pk_info", "hg_witness_from_json", "hg_witness_synthetic", "hg_witness_from_arrays",
-    "hg_witness_get", "hg_witness_free", "hg_prove", "hg_verify", "hg_witness_gen", "hg_values_free", "hg_values_get", "hg_prove_shard_begin", "hg_prove_shard_finish", "hg_prove_resident", "hg_circuit_eval", "hg_lasso_prove", "hg_lasso_prove_at", "hg_sumcheck", "hg_mle_eval",
+    "hg_witness_get", "hg_witness_free", "hg_prove", "hg_verify", "hg_witness_gen", "hg_values_free", "hg_values_get", "hg_prove_shard_begin", "hg_prove_shard_combine", "hg_prove_shard_finish", "hg_prove_resident", "hg_circuit_eval", "hg_lasso_prove", "hg_lasso_prove_at", "hg_sumcheck", "hg_mle_eval",
     "hg_ntt", "hg_challenges", "hg_profile", "hg_profile_reset", "hg_profile_get",
 ]
 
@@ -82,6 +82,7 @@ def lib():
         L.hg_values_get.argtypes = [C.c_void_p, C.c_void_p, C.c_int, u64p, C.c_size_t]
         L.hg_prove_resident.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(HgTimings)]
         L.hg_prove_shard_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(u64p), C.POINTER(C.c_size_t)]
+        L.hg_prove_shard_combine.argtypes = [C.c_void_p, u64p, C.c_int, C.c_size_t]
         L.hg_prove_shard_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(HgTimings)]
         L.hg_verify.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
         L.hg_circuit_eval.argtypes = [C.c_void_p, C.c_void_p, u64p, C.c_size_t, u64p, C.c_size_t]
@@ -330,12 +331,18 @@ def prove_resident(ctx, pk, values, out):
 
 
 def prove_shard_begin(ctx, pk, values, rank, world):
-    """This rank's share of ONE proof; returns a numpy view (u64) of the partial result buffer to be
-    sum-all-reduced in place across ranks before prove_shard_finish."""
+    """This rank's share of ONE proof; returns a numpy view (u64) of the partial result buffer, to be all-gathered
+    across ranks and handed to prove_shard_combine before prove_shard_finish."""
     ptr = u64p()
     n = C.c_size_t(0)
     _check(lib().hg_prove_shard_begin(ctx.h, pk.h, values.h, rank, world, C.byref(ptr), C.byref(n)))
     return np.ctypeslib.as_array(ptr, shape=(n.value,))
+
+
+def prove_shard_combine(ctx, gathered, world):
+    """gathered: the ranks' partial buffers (world x n u64, rank-major); installs their lane-wise sum mod p."""
+    gathered = np.ascontiguousarray(gathered, dtype=np.uint64).reshape(-1)
+    _check(lib().hg_prove_shard_combine(ctx.h, _ptr(gathered), world, gathered.size // world))
 
 
 def prove_shard_finish(ctx, out):

@@ -339,6 +339,14 @@ int hg_prove_shard_begin(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int r
     HG_CATCH(-1)
 }
 
+int hg_prove_shard_combine(hg_ctx* ctx, const uint64_t* gathered, int world, size_t n_u64) {
+    HG_TRY
+    if (!ctx || !gathered || world < 1) throw Error("hg_prove_shard_combine: bad argument");
+    prove_shard_combine(ctx, gathered, world, n_u64);
+    return 0;
+    HG_CATCH(-1)
+}
+
 int hg_prove_shard_finish(hg_ctx* ctx, uint8_t* proof, size_t cap, size_t* len, hg_timings* timings) {
     HG_TRY
     if (!ctx) throw Error("hg_prove_shard_finish: null context");

@@ -114,7 +114,8 @@ __device__ __forceinline__ void store_e2(E2* p, E2 v) {
 template <int KIND, typename T, bool FIRST>
 __device__ __forceinline__ void sc_round_body(const T* __restrict__ in, size_t in_stride, E2* __restrict__ out,
                                               size_t out_stride, int ntab, size_t half, E2 r, const E2* __restrict__ pw, const E2* __restrict__ pwr,
-                                              int jb_log2, E2* __restrict__ red, E2* acc, size_t first_tile, size_t tile_step) {
+                                              int jb_log2, E2* __restrict__ red, E2* acc, size_t first_tile, size_t tile_step,
+                                              bool p0_only = false) {
     using V = Val<T>;
     const int BD = blockDim.x, tid = threadIdx.x;
     const int G = BD >> jb_log2;
@@ -135,17 +136,22 @@ __device__ __forceinline__ void sc_round_body(const T* __restrict__ in, size_t i
                 if (i == 0) { p0 = xl; p2 = V::add(yl, dl); p3 = V::add(p2, dl); }
                 // a(t) b(t) = P0 + t (P1 - P0 - Pinf) + t^2 Pinf with P0 = a(0)b(0), P1 = a(1)b(1), Pinf = (a1-a0)(b1-b0):
                 // accumulate the three products, combine to t = 2, 3 once per j (after the loop)
+                const bool summed = !(p0_only && i == 0);  // a p0-only pair 0 belongs to another rank's share of the batch
                 if constexpr (FIRST) {
                     E2 gm = pw[i];
-                    s0 = e2_add(s0, V::scale(gm, V::mul(xl, xr)));
-                    s2 = e2_add(s2, V::scale(gm, V::mul(yl, yr)));
-                    s3 = e2_add(s3, V::scale(gm, V::mul(dl, dr)));
+                    if (summed) {
+                        s0 = e2_add(s0, V::scale(gm, V::mul(xl, xr)));
+                        s2 = e2_add(s2, V::scale(gm, V::mul(yl, yr)));
+                        s3 = e2_add(s3, V::scale(gm, V::mul(dl, dr)));
+                    }
                     // gamma^i * (xl + r dl) = gamma^i xl + (gamma^i r) dl
                     store_e2(out + (size_t)(2 * i) * out_stride + jo, e2_add(V::scale(gm, xl), V::scale(pwr[i], dl)));
                 } else {
-                    s0 = e2_add(s0, V::lift(V::mul(xl, xr)));
-                    s2 = e2_add(s2, V::lift(V::mul(yl, yr)));
-                    s3 = e2_add(s3, V::lift(V::mul(dl, dr)));
+                    if (summed) {
+                        s0 = e2_add(s0, V::lift(V::mul(xl, xr)));
+                        s2 = e2_add(s2, V::lift(V::mul(yl, yr)));
+                        s3 = e2_add(s3, V::lift(V::mul(dl, dr)));
+                    }
                     store_e2(out + (size_t)(2 * i) * out_stride + jo, V::fold(xl, dl, r));
                 }
                 store_e2(out + (size_t)(2 * i + 1) * out_stride + jo, V::fold(xr, dr, r));
@@ -250,8 +256,8 @@ __global__ __launch_bounds__(256) void k_st_step(const StJob* __restrict__ jobs,
     E2 acc[NV];
 #pragma unroll
     for (int t = 0; t < NV; t++) acc[t] = e2_zero();
-    if (rd == 0) sc_round_body<KIND, T, true>(reinterpret_cast<const T*>(in), in_stride, out, half, J.ntab, half, chal[J.r_off + rd], J.pw, J.pwr, jb_log2, red, acc, blockIdx.x, gridDim.x);
-    else sc_round_body<KIND, T, false>(reinterpret_cast<const T*>(in), in_stride, out, half, J.ntab, half, chal[J.r_off + rd], J.pw, J.pwr, jb_log2, red, acc, blockIdx.x, gridDim.x);
+    if (rd == 0) sc_round_body<KIND, T, true>(reinterpret_cast<const T*>(in), in_stride, out, half, J.ntab, half, chal[J.r_off + rd], J.pw, J.pwr, jb_log2, red, acc, blockIdx.x, gridDim.x, J.p0_only != 0);
+    else sc_round_body<KIND, T, false>(reinterpret_cast<const T*>(in), in_stride, out, half, J.ntab, half, chal[J.r_off + rd], J.pw, J.pwr, jb_log2, red, acc, blockIdx.x, gridDim.x, J.p0_only != 0);
 #pragma unroll
     for (int t = 0; t < NV; t++) {
         E2 s = block_sum_n(acc[t], sm);
@@ -295,9 +301,9 @@ __global__ __launch_bounds__(1024) void k_st_tail(const StJob* __restrict__ jobs
         E2 acc[NV];
 #pragma unroll
         for (int t = 0; t < NV; t++) acc[t] = e2_zero();
-        if (rd == 0 && J.base) sc_round_body<KIND, u64, true>(reinterpret_cast<const u64*>(in), in_stride, out, half, J.ntab, half, r, J.pw, J.pwr, jb_log2, red, acc, 0, 1);
-        else if (rd == 0) sc_round_body<KIND, E2, true>(reinterpret_cast<const E2*>(in), in_stride, out, half, J.ntab, half, r, J.pw, J.pwr, jb_log2, red, acc, 0, 1);
-        else sc_round_body<KIND, E2, false>(reinterpret_cast<const E2*>(in), in_stride, out, half, J.ntab, half, r, J.pw, J.pwr, jb_log2, red, acc, 0, 1);
+        if (rd == 0 && J.base) sc_round_body<KIND, u64, true>(reinterpret_cast<const u64*>(in), in_stride, out, half, J.ntab, half, r, J.pw, J.pwr, jb_log2, red, acc, 0, 1, J.p0_only != 0);
+        else if (rd == 0) sc_round_body<KIND, E2, true>(reinterpret_cast<const E2*>(in), in_stride, out, half, J.ntab, half, r, J.pw, J.pwr, jb_log2, red, acc, 0, 1, J.p0_only != 0);
+        else sc_round_body<KIND, E2, false>(reinterpret_cast<const E2*>(in), in_stride, out, half, J.ntab, half, r, J.pw, J.pwr, jb_log2, red, acc, 0, 1, J.p0_only != 0);
 #pragma unroll
         for (int t = 0; t < NV; t++) {
             E2 s = block_sum_n(acc[t], sm);
@@ -450,6 +456,14 @@ int ps_round(hipStream_t st, const PsJob* jobs, int njobs, int nvars, int rd, co
 }
 void ps_tail(hipStream_t st, const PsJob* jobs, int njobs, int rd0, const E2* chal, E2* res) {
     k_ps_tail<<<dim3(1, njobs), 1024, 16 * sizeof(E2), st>>>(jobs, rd0, chal, res);
+}
+
+__global__ void k_scatter_e2(const ScatterEnt* __restrict__ ents, size_t n, E2* __restrict__ dst_base) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst_base[ents[i].dst] = ents[i].src[0];
+}
+void scatter_e2(hipStream_t st, const ScatterEnt* ents, size_t n, E2* dst_base) {
+    if (n) k_scatter_e2<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(ents, n, dst_base);
 }
 
 __global__ __launch_bounds__(TPB) void k_reduce_partials(const E2* __restrict__ partials, int nblocks, int nv, E2* __restrict__ out) {

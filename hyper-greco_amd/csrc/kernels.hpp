@@ -34,6 +34,7 @@ struct StJob {
     E2* buf[2];        // ping-pong storage for folded tables (ntab * len/2, ntab * len/4)
     E2* final_out;     // ntab folded scalars
     int kind, ntab, nvars, base;
+    int p0_only;       // grand product on a subset of the batch (multi-GPU): pair 0 only supplies p_0, its product is not summed
     size_t r_off;      // chain index of round 0's challenge
     size_t sums_slot;  // result slots: nv per round
     E2 pw[PW_MAX];     // gamma^i (grand product) or M^i (collation)
@@ -62,6 +63,10 @@ struct PsJob {
 int ps_round(hipStream_t st, const PsJob* jobs, int njobs, int nvars, int rd, const E2* chal, E2* partials, E2* res);
 // rounds [rd0, nvars) of every job, one workgroup per job
 void ps_tail(hipStream_t st, const PsJob* jobs, int njobs, int rd0, const E2* chal, E2* res);
+
+// dst_base[ent[i].dst] = ent[i].src[0]: moves locally produced scalars to their global result slots
+struct ScatterEnt { const E2* src; size_t dst; };
+void scatter_e2(hipStream_t st, const ScatterEnt* ents, size_t n, E2* dst_base);
 
 // out[v] = sum_b partials[b*nv + v], v < nv
 void reduce_partials(hipStream_t st, const E2* partials, int nblocks, int nv, E2* out);

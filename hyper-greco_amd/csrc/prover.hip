@@ -175,7 +175,8 @@ struct Prover {
     // every rank the complete buffer.
     int rank = 0, world = 1;
     std::vector<int> node_owner;       // Vanilla / FFT node reductions
-    std::vector<int> gp1_owner;        // grand product #1 (reads|writes): per layer n (n = 0: roots + top evals)
+    std::vector<int> gp1_owner;        // grand product #1 (reads|writes): per layer n (all `rank` when it is split by memory)
+    std::vector<int> gp1_mem_owner;    // world > 1: grand product #1 is split by memory (batch item) over ALL ranks
     int own_gp2 = 0, own_collation = 0, own_openings = 0, own_out_claim = 0;
     bool mine(int owner) const { return owner == rank; }
     void plan_shards() {
@@ -188,17 +189,23 @@ struct Prover {
         struct Item { double cost; int kind, idx; };
         std::vector<Item> items;
         const double A = pk->lasso.alpha;
-        for (int n = 1; n < nu; n++) items.push_back({4.0 * A * (double)((size_t)1 << n) * 3.0, 0, n});
-        items.push_back({4.0 * A * 65536.0 * 3.0, 1, 0});                      // all of GP#2
+        // Grand product #1 (the bulk of the node) is split by memory: rank r hashes, multiplies up and runs every layer
+        // on its own memories' read/write tables (+ table 0, which supplies p_0). Its round sums are PARTIAL sums:
+        // the ranks' result buffers are combined by modular addition (hg_prove_shard_combine).
+        const int G = (int)pk->lasso.gkr_order.size();
+        gp1_mem_owner.assign(G, 0);
+        for (int i = 0; i < G; i++) gp1_mem_owner[i] = (int)(((long long)i * world) / G);
+        gp1_owner.assign(nu, rank);
+        items.push_back({4.0 * A * 65536.0 * 15.0, 1, 0});                     // all of GP#2 (small tables: latency-bound, hence the weight)
         items.push_back({A * (double)((size_t)1 << nu) * 3.0, 2, 0});         // collation (+ claim)
         items.push_back({(A + 8) * (double)((size_t)1 << nu) * 1.0, 3, 0});   // openings
         for (size_t id = 0; id < c.nodes.size(); id++) {
             const HNode& n = c.nodes[id];
-            if (n.kind == NK_FFT) items.push_back({(double)((size_t)1 << n.log2_size) * 6.0, 4, (int)id});
+            if (n.kind == NK_FFT) items.push_back({(double)((size_t)1 << n.log2_size) * 18.0, 4, (int)id});
             if (n.kind == NK_VANILLA) {
                 int np = 0;
                 for (int i = 0; i < n.arity; i++) np += n.left_use[i] + n.right_use[i];
-                items.push_back({(double)np * (double)((size_t)1 << (n.log2_sub_in + n.log2_reps)) * 4.0 + (double)((size_t)1 << n.log2_out()), 4, (int)id});
+                items.push_back({(double)np * (double)((size_t)1 << (n.log2_sub_in + n.log2_reps)) * 12.0 + 3.0 * (double)((size_t)1 << n.log2_out()), 4, (int)id});
             }
         }
         std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.cost > b.cost; });
@@ -208,7 +215,8 @@ struct Prover {
         const double unit = A * (double)((size_t)1 << nu);          // one pass over the alpha E-tables
         const double c_split = 1.2 * unit, c_counters = 3.5 * unit, c_hash1 = 2.5 * unit, c_tree1 = 1.4 * unit;
         std::vector<double> load(world, 0.0);
-        std::vector<char> has_split(world, 0), has_counters(world, 0), has_hash1(world, 0);
+        for (int i = 0; i < G; i++) load[gp1_mem_owner[i]] += 2.0 * (double)((size_t)1 << nu) * 9.0;  // its share of GP#1
+        std::vector<char> has_split(world, 1), has_counters(world, 1), has_hash1(world, 1);  // every rank runs GP#1
         std::vector<int> tree_depth(world, 0);
         auto setup_cost = [&](const Item& it, int r, bool commit) {
             double extra = 0;
@@ -241,7 +249,6 @@ struct Prover {
                 default: node_owner[it.idx] = r; break;
             }
         }
-        gp1_owner[0] = gp1_owner[1];  // the top of the tree rides with the smallest layer
         own_out_claim = (int)(std::min_element(load.begin(), load.end()) - load.begin());
     }
 
@@ -290,9 +297,10 @@ struct Prover {
     // Stride-layout sum-checks (collation, every grand-product layer) are queued as jobs and executed by
     // flush_stride() in a size-synchronised schedule: they are independent on the device.
     std::vector<dev::StJob> st_jobs;
+    std::vector<dev::ScatterEnt> scatter;  // locally produced scalars -> global result slots (batch-subset grand products)
 
     ScHandle sc_stride(int kind, const void* in, bool base, size_t in_stride, int ntab, int nvars, const dev::Powers& pw, E2* final_out,
-                       bool enqueue = true) {
+                       bool enqueue = true, bool p0_only = false) {
         ScHandle h;
         h.nv = kind == dev::SC_GRANDPROD ? 3 : 2;
         h.nvars = nvars;
@@ -309,7 +317,7 @@ struct Prover {
         J.buf[0] = ctx->alloc_n<E2>((size_t)ntab * std::max<size_t>(N / 2, 1));
         J.buf[1] = ctx->alloc_n<E2>((size_t)ntab * std::max<size_t>(N / 4, 1));
         J.final_out = final_out ? final_out : ctx->alloc_n<E2>(ntab);
-        J.kind = kind; J.ntab = ntab; J.nvars = nvars; J.base = base ? 1 : 0;
+        J.kind = kind; J.ntab = ntab; J.nvars = nvars; J.base = base ? 1 : 0; J.p0_only = p0_only ? 1 : 0;
         J.r_off = h.point_off; J.sums_slot = h.sums_slot;
         memcpy(J.pw, pw.v, sizeof(J.pw));
         for (int i = 0; i < nvars; i++) h.rs.push_back(squeeze());
@@ -383,6 +391,13 @@ struct Prover {
             }
         }
         st_jobs.clear();
+        if (!scatter.empty()) {
+            dev::ScatterEnt* d = ctx->alloc_n<dev::ScatterEnt>(scatter.size());
+            hip_check(hipMemcpyAsync(d, stage(scatter.data(), scatter.size() * sizeof(dev::ScatterEnt)), scatter.size() * sizeof(dev::ScatterEnt),
+                                     hipMemcpyHostToDevice, st), "upload scatter list");
+            dev::scatter_e2(st, d, scatter.size(), d_res());
+            scatter.clear();
+        }
     }
 
     // PRODSUM instances are queued and executed in batches of equal nvars (grid.y = instance): the node
@@ -550,23 +565,40 @@ struct Prover {
         for (int n = 0; n < nv; n++) if (mine(owner[n])) deepest = std::max(deepest, nv - 1 - n);
         return deepest;
     }
-    // lev1 (optional): the first tree level, already produced by the hash kernel
-    GpOut grand_product(const u64* H, size_t len, int nb, const std::vector<int>& owner, const u64* lev1 = nullptr) {
+    // lev1 (optional): the first tree level, already produced by the hash kernel.
+    // `local` (multi-GPU split by batch item): H holds only the rows of the global pairs listed in `local` (ascending);
+    // with p0_only the first of them is pair 0, held only to supply p_0.
+    GpOut grand_product(const u64* H, size_t len, int nb, const std::vector<int>& owner, const u64* lev1 = nullptr,
+                        const std::vector<int>* local = nullptr, bool p0_only = false) {
         int nv = 0;
         while (((size_t)1 << nv) < len) nv++;
+        const int nl = local ? (int)local->size() : nb;  // rows actually held
         std::vector<const u64*> lev(nv, nullptr);
         lev[0] = H;
         const int deepest = gp_deepest(nv, owner);
         if (lev1 && nv > 1) lev[1] = lev1;
         for (int k = (lev1 && nv > 1) ? 2 : 1; k <= deepest; k++) {  // Layer::bottom / Layer::up: w = v_l * v_r on the MSB split
-            u64* out = ctx->alloc_n<u64>((size_t)nb * (len >> k));
-            ctx->prof_begin(cls_tree, (double)nb * (len >> (k - 1)) * 8.0 * 1.5);
-            dev::prod_level(st, lev[k - 1], len >> (k - 1), out, nb);
+            u64* out = ctx->alloc_n<u64>((size_t)nl * (len >> k));
+            ctx->prof_begin(cls_tree, (double)nl * (len >> (k - 1)) * 8.0 * 1.5);
+            dev::prod_level(st, lev[k - 1], len >> (k - 1), out, nl);
             ctx->prof_end();
             lev[k] = out;
         }
         size_t roots = slot(nb), ev0 = slot(2 * (size_t)nb);
-        if (mine(owner[0])) dev::gp_top(st, lev[nv - 1], nb, d_res() + roots, d_res() + ev0);
+        if (mine(owner[0]) && nl > 0) {
+            if (!local) dev::gp_top(st, lev[nv - 1], nb, d_res() + roots, d_res() + ev0);
+            else {
+                E2* lr = ctx->alloc_n<E2>(nl);
+                E2* le = ctx->alloc_n<E2>(2 * (size_t)nl);
+                dev::gp_top(st, lev[nv - 1], nl, lr, le);
+                for (int li = p0_only ? 1 : 0; li < nl; li++) {
+                    int b = (*local)[li];
+                    scatter.push_back({lr + li, roots + (size_t)b});
+                    scatter.push_back({le + 2 * li, ev0 + 2 * (size_t)b});
+                    scatter.push_back({le + 2 * li + 1, ev0 + 2 * (size_t)b + 1});
+                }
+            }
+        }
         auto claims = std::make_shared<std::vector<E2>>(nb);
         ops.push_back([this, roots, nb, claims] {  // root products (prover.rs:197-221)
             for (int b = 0; b < nb; b++) { (*claims)[b] = h_res()[roots + b]; proof.write_e((*claims)[b]); }
@@ -598,7 +630,22 @@ struct Prover {
                 *claim = c;
             });
             size_t evals = slot(2 * (size_t)nb);
-            ScHandle sc = sc_stride(dev::SC_GRANDPROD, lev[k], true, h, 2 * nb, n, pw, d_res() + evals, mine(owner[n]));
+            ScHandle sc;
+            if (!local) sc = sc_stride(dev::SC_GRANDPROD, lev[k], true, h, 2 * nb, n, pw, d_res() + evals, mine(owner[n]));
+            else {
+                // this rank's share of the batch: local pair li is global pair b = local[li], weight gamma^b
+                dev::Powers pwl;
+                memset(&pwl, 0, sizeof(pwl));
+                for (int li = 0; li < nl; li++) pwl.v[li] = pw.v[(*local)[li]];
+                E2* fin = nl ? ctx->alloc_n<E2>(2 * (size_t)nl) : nullptr;
+                sc = sc_stride(dev::SC_GRANDPROD, lev[k], true, h, 2 * nl, n, pwl, fin, mine(owner[n]) && nl > (p0_only ? 1 : 0), p0_only);
+                if (mine(owner[n]))
+                    for (int li = p0_only ? 1 : 0; li < nl; li++) {
+                        int b = (*local)[li];
+                        scatter.push_back({fin + 2 * li, evals + 2 * (size_t)b});
+                        scatter.push_back({fin + 2 * li + 1, evals + 2 * (size_t)b + 1});
+                    }
+            }
             defer_sumcheck(sc, 3, claim, nullptr);
             defer_gp_unscale(evals, nb, pw);
             defer_write_slots(evals, 2 * (size_t)nb);  // prover.rs:257
@@ -672,20 +719,47 @@ struct Prover {
         }
         // MemoryCheckingProver::new (prover.rs:35-89)
         const int G = (int)lp.gkr_order.size();
-        u64* H1 = any_gp1 ? ctx->alloc_n<u64>((size_t)2 * G * N) : nullptr;
-        u64* L1 = (any_gp1 && gp_deepest(nu, gp1_owner) >= 1) ? ctx->alloc_n<u64>((size_t)2 * G * (N / 2)) : nullptr;
-        u64* H2 = do_gp2 ? ctx->alloc_n<u64>((size_t)2 * G * M) : nullptr;
-        for (int i = 0; i < G; i++) {
-            int m = lp.gkr_order[i], c = lp.gkr_chunk[i];
-            if (any_gp1) {
-                ctx->prof_begin(cls_hash, (double)N * 8 * (L1 ? 6 : 5));
-                dev::lasso_hash_rw(st, N, dims + (size_t)c * N, ep + (size_t)m * N, read_ts[c], gamma, tau, H1 + (size_t)i * N, H1 + (size_t)(G + i) * N,
-                                   L1 ? L1 + (size_t)i * (N / 2) : nullptr, L1 ? L1 + (size_t)(G + i) * (N / 2) : nullptr);
-                ctx->prof_end();
-            }
-            if (do_gp2) dev::lasso_hash_if(st, (u32)lp.mems[m].cutoff, final_cts[c], gamma, tau, H2 + (size_t)i * M, H2 + (size_t)(G + i) * M);
+        const bool split = world > 1;  // grand product #1 split by memory over the ranks
+        std::vector<int> local_pairs;  // global pair ids (reads: i, writes: G + i) whose hash rows this rank holds, ascending
+        std::vector<int> local_mems;
+        bool p0_only = false;
+        if (split) {
+            for (int i = 0; i < G; i++) if (mine(gp1_mem_owner[i])) local_mems.push_back(i);
+            p0_only = !mine(gp1_mem_owner[0]);
+            if (p0_only) local_pairs.push_back(0);
+            for (int i : local_mems) local_pairs.push_back(i);
+            for (int i : local_mems) local_pairs.push_back(G + i);
         }
-        GpOut g1 = grand_product(H1, N, 2 * G, gp1_owner, L1);                      // reads then writes (prover.rs:161-165)
+        const int nrows = split ? (int)local_pairs.size() : 2 * G;
+        u64* H1 = any_gp1 ? ctx->alloc_n<u64>((size_t)nrows * N) : nullptr;
+        u64* L1 = (any_gp1 && gp_deepest(nu, gp1_owner) >= 1) ? ctx->alloc_n<u64>((size_t)nrows * (N / 2)) : nullptr;
+        u64* H2 = do_gp2 ? ctx->alloc_n<u64>((size_t)2 * G * M) : nullptr;
+        auto hash_rw = [&](int i, u64* rd, u64* wr, u64* rd1, u64* wr1) {
+            int m = lp.gkr_order[i], c = lp.gkr_chunk[i];
+            ctx->prof_begin(cls_hash, (double)N * 8 * (L1 ? 6 : 5));
+            dev::lasso_hash_rw(st, N, dims + (size_t)c * N, ep + (size_t)m * N, read_ts[c], gamma, tau, rd, wr, rd1, wr1);
+            ctx->prof_end();
+        };
+        if (any_gp1 && !split) {
+            for (int i = 0; i < G; i++)
+                hash_rw(i, H1 + (size_t)i * N, H1 + (size_t)(G + i) * N, L1 ? L1 + (size_t)i * (N / 2) : nullptr, L1 ? L1 + (size_t)(G + i) * (N / 2) : nullptr);
+        } else if (any_gp1) {
+            const int base = p0_only ? 1 : 0, nlm = (int)local_mems.size();
+            if (p0_only) {  // table 0 (reads of the first memory) supplies p_0; its write table is not needed here
+                u64* junk = ctx->alloc_n<u64>(N + N / 2);
+                hash_rw(0, H1, junk, L1 ? L1 : nullptr, L1 ? junk + N : nullptr);
+            }
+            for (int q = 0; q < nlm; q++)
+                hash_rw(local_mems[q], H1 + (size_t)(base + q) * N, H1 + (size_t)(base + nlm + q) * N,
+                        L1 ? L1 + (size_t)(base + q) * (N / 2) : nullptr, L1 ? L1 + (size_t)(base + nlm + q) * (N / 2) : nullptr);
+        }
+        if (do_gp2)
+            for (int i = 0; i < G; i++) {
+                int m = lp.gkr_order[i], c = lp.gkr_chunk[i];
+                dev::lasso_hash_if(st, (u32)lp.mems[m].cutoff, final_cts[c], gamma, tau, H2 + (size_t)i * M, H2 + (size_t)(G + i) * M);
+            }
+        GpOut g1 = split ? grand_product(H1, N, 2 * G, gp1_owner, L1, &local_pairs, p0_only)
+                         : grand_product(H1, N, 2 * G, gp1_owner, L1);  // reads then writes (prover.rs:161-165)
         GpOut g2 = grand_product(H2, M, 2 * G, std::vector<int>(16, own_gp2));      // inits then finals (prover.rs:167-171)
         // openings (prover.rs:173-178, mod.rs:80-93)
         E2* eqx = eq;  // the eq(r,.) table is dead by now
@@ -1121,6 +1195,21 @@ size_t prove_shard_begin(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int r
     { std::lock_guard<std::mutex> lk(g_pending_mu); g_pending[ctx] = std::move(ps); }
     return n;
 }
+// installs the modular sum of the ranks' partial result buffers (`world` buffers of n_u64 lanes each, rank-major)
+void prove_shard_combine(hg_ctx* ctx, const u64* gathered, int world, size_t n_u64) {
+    if (2 * ctx->res_cap < n_u64) throw Error("prove_shard_combine: buffer larger than the result buffer");
+    u64* dst = reinterpret_cast<u64*>(ctx->h_res);
+    for (size_t i = 0; i < n_u64; i++) {
+        u64 acc = 0;
+        for (int r = 0; r < world; r++) {
+            u64 v = gathered[(size_t)r * n_u64 + i];
+            if (v >= GL_P) throw Error("prove_shard_combine: non-canonical lane");
+            acc = gl_add(acc, v);
+        }
+        dst[i] = acc;
+    }
+}
+
 ProveResult prove_shard_finish(hg_ctx* ctx) {
     PendingShard ps;
     {

@@ -103,6 +103,7 @@ hg_values* witness_gen(hg_ctx* ctx, const hg_pk* pk, const Witness& w, double* w
 void values_free(hg_values* v);
 ProveResult prove_resident(hg_ctx* ctx, const hg_pk* pk, const hg_values* v);
 size_t prove_shard_begin(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int rank, int world);  // -> #E2 slots in ctx->h_res
+void prove_shard_combine(hg_ctx* ctx, const u64* gathered, int world, size_t n_u64);
 ProveResult prove_shard_finish(hg_ctx* ctx);
 // Lasso node alone on a fresh transcript; claim_out = nu point coordinates then the value
 std::vector<uint8_t> prove_lasso_node(hg_ctx* ctx, const hg_pk* pk, const u64* lasso_in_host, size_t chain_skip, std::vector<E2>* claim_out);

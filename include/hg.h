@@ -112,13 +112,15 @@ int hg_prove_resident(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, uint8_t*
                       hg_timings* timings);
 
 /* ONE proof sharded over `world` GPUs (one process per GPU, same witness resident on each). Every rank walks the whole
- * protocol but runs only the device jobs it owns; `*partial` (pinned host memory owned by the context) then holds this
- * rank's share of the scalar results with zeros elsewhere. The caller sum-all-reduces that buffer IN PLACE across ranks
- * (u64 lanes, e.g. RCCL ncclSum on int64: every slot has exactly one non-zero contributor) and calls
- * hg_prove_shard_finish, which replays the transcript — every rank obtains the identical proof bytes.
- * *n_u64 = number of u64 lanes to reduce. world == 1 degenerates to hg_prove_resident. */
+ * protocol but runs only the device jobs it owns; the largest part, grand product #1 of the Lasso node, is split by
+ * memory (batch item), so its round sums are PARTIAL sums on every rank. `*partial` (pinned host memory owned by the
+ * context, *n_u64 lanes of canonical field elements) holds this rank's share of the scalar results, zeros elsewhere.
+ * The caller all-gathers the ranks' buffers (RCCL) and hands them to hg_prove_shard_combine, which installs their
+ * lane-wise sum mod p; hg_prove_shard_finish then replays the transcript — every rank obtains the identical bytes.
+ * One all-gather per proof is the only exchange. world == 1 degenerates to hg_prove_resident. */
 int hg_prove_shard_begin(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int rank, int world, uint64_t** partial,
                          size_t* n_u64);
+int hg_prove_shard_combine(hg_ctx* ctx, const uint64_t* gathered /* world x n_u64, rank-major */, int world, size_t n_u64);
 int hg_prove_shard_finish(hg_ctx* ctx, uint8_t* proof, size_t cap, size_t* len, hg_timings* timings);
 
 /* = circuit.evaluate (host part of witness generation) [REF sk_encryption_circuit.rs:442]:

@@ -217,24 +217,19 @@ def test_headline_config_properties(ctx):
 @pytest.mark.parametrize("n,k,world", [(1024, 1, 2), (4096, 2, 3), (8192, 4, 8), (32768, 16, 8), (32768, 16, 2)])
 def test_sharded_single_proof_reassembles_bit_exact(ctx, n, k, world):
     """Single-proof sharding (hg_prove_shard_*): run every virtual rank of a `world`-GPU job on this one GPU, sum the
-    partial result buffers the way the all-reduce would, replay -> must give exactly the unsharded proof; every
-    result lane must have at most one non-zero contributor."""
+    partial result buffers the way the all-gather + hg_prove_shard_combine does (lane-wise sum mod p: grand product
+    #1 is split by memory, its round sums are partial sums), replay -> must give exactly the unsharded proof."""
     bfv = hg.BfvEncrypt.new(n, k)
     pk = bfv.setup(ctx)
     w = hg.Witness.synthetic(bfv.params, 0x4752454330 + n)
     vals = hg.witness_gen(ctx, pk, w)
     out = hg.ProofBuffer()
     ref = hg.prove_resident(ctx, pk, vals, out).bytes()
-    total = None
-    owners = None
+    parts = []
     for r in range(world):
-        part = hg.prove_shard_begin(ctx, pk, vals, r, world)
-        p = part.copy()
-        total = p if total is None else total + p
-        nz = (p != 0).astype(np.int32)
-        owners = nz if owners is None else owners + nz
-    assert owners.max() <= 1, "a result lane was produced by more than one rank"
-    part[:] = total  # what the in-place sum-all-reduce leaves on every rank
+        parts.append(hg.prove_shard_begin(ctx, pk, vals, r, world).copy())
+    # every lane outside the shared round-sum slots has at most one contributor; the combine is a lane-wise sum mod p
+    hg.prove_shard_combine(ctx, np.stack(parts), world)
     got = hg.prove_shard_finish(ctx, out).bytes()
     assert got == ref
     vals.free()
