@@ -9,6 +9,7 @@
 #pragma once
 #include <cstdint>
 #include <cstddef>
+#include <cstring>
 #include <string>
 #include <vector>
 #include <stdexcept>
@@ -42,7 +43,12 @@ struct ChallengeSource {
 
 struct ProofStream {
     std::vector<uint8_t> bytes;
-    void write_f(u64 a) { for (int s = 56; s >= 0; s -= 8) bytes.push_back((uint8_t)(a >> s)); }  // BE (transcript.rs:183-189)
+    void write_f(u64 a) {  // canonical repr, byte-reversed to big-endian (transcript.rs:183-189)
+        u64 be = __builtin_bswap64(a);
+        size_t at = bytes.size();
+        bytes.resize(at + 8);
+        memcpy(bytes.data() + at, &be, 8);
+    }
     void write_e(E2 a) { write_f(a.c0); write_f(a.c1); }                                           // bases in order (:191-195)
 };
 

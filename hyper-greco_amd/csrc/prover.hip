@@ -1025,6 +1025,7 @@ struct Prover {
     }
     void replay() {
         double t = wall_ms();
+        proof.bytes.reserve((size_t)1 << 18);
         for (auto& op : ops) op();
         t_replayed = t_synced + (wall_ms() - t);
         ctx->prof_collect();
