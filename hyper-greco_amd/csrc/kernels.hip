@@ -534,6 +534,17 @@ __global__ __launch_bounds__(256) void k_eq_jobs(const EqJob* __restrict__ jobs,
         }
     }
 }
+// out[i] = sum_t tabs[t * n + i]  (multi-claim eq tables are built one claim per job, then summed)
+__global__ __launch_bounds__(TPB) void k_sum_tables(E2* __restrict__ out, const E2* __restrict__ tabs, int ntabs, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (size_t)gridDim.x * TPB) {
+        E2 acc = tabs[i];
+        for (int t = 1; t < ntabs; t++) acc = e2_add(acc, tabs[(size_t)t * n + i]);
+        store_e2(out + i, acc);
+    }
+}
+void sum_tables(hipStream_t st, E2* out, const E2* tabs, int ntabs, size_t n) {
+    k_sum_tables<<<(unsigned)std::min<size_t>((n + TPB - 1) / TPB, 2048), TPB, 0, st>>>(out, tabs, ntabs, n);
+}
 void eq_jobs(hipStream_t st, const EqJob* jobs, int njobs, int max_n, const E2* chal) {
     int hi = max_n > 8 ? max_n - 8 : 0;
     size_t nblk = ((size_t)1 << hi) / eq_k_for(hi);

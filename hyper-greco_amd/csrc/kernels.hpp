@@ -80,6 +80,7 @@ struct EqJob {
     ClaimSet cs;
 };
 void eq_jobs(hipStream_t st, const EqJob* jobs, int njobs, int max_n, const E2* chal);
+void sum_tables(hipStream_t st, E2* out, const E2* tabs, int ntabs, size_t n);  // out[i] = sum_t tabs[t*n + i]
 
 // ---- Lasso ------------------------------------------------------------------------------------
 struct LassoDev {

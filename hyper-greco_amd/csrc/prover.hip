@@ -526,11 +526,23 @@ struct Prover {
         dev::eq_jobs(st, d, 1, n, ctx->d_chal);
         ctx->prof_end();
     }
+    std::vector<std::function<void()>> eq_post;  // sums of per-claim eq tables, run right after the eq batch
     void queue_eq(E2* out, int n, const dev::ClaimSet& cs) {
         dev::EqJob J;
         memset(&J, 0, sizeof(J));
-        J.out = out; J.n = n; J.cs = cs;
-        eq_queue.push_back(J);
+        J.n = n;
+        if (cs.n == 1) { J.out = out; J.cs = cs; eq_queue.push_back(J); return; }
+        // several claims: one job per claim (all of them run in parallel in the batch), then one summing pass
+        const size_t N = (size_t)1 << n;
+        E2* tmp = ctx->alloc_n<E2>((size_t)cs.n * N);
+        for (int a = 0; a < cs.n; a++) {
+            J.out = tmp + (size_t)a * N;
+            memset(&J.cs, 0, sizeof(J.cs));
+            J.cs.n = 1; J.cs.unit_alpha = cs.unit_alpha; J.cs.alpha_off = cs.alpha_off + a; J.cs.point_off[0] = cs.point_off[a];
+            eq_queue.push_back(J);
+        }
+        const int nc = cs.n;
+        eq_post.push_back([this, out, tmp, nc, N] { dev::sum_tables(st, out, tmp, nc, N); });
     }
     template <typename JobT, typename LaunchFn>
     void flush_jobs(std::vector<JobT>& q, int cls, double bytes, LaunchFn launch) {
@@ -546,6 +558,8 @@ struct Prover {
         int max_n = 0; double eb = 0;
         for (auto& J : eq_queue) { max_n = std::max(max_n, J.n); eb += 16.0 * ((size_t)1 << J.n); }
         flush_jobs(eq_queue, cls_aux, eb, [&](dev::EqJob* d, int nj) { dev::eq_jobs(st, d, nj, max_n, ctx->d_chal); });
+        for (auto& f : eq_post) f();
+        eq_post.clear();
         for (auto& f : after_eq) f();
         after_eq.clear();
         size_t max_total = 0; double gb = 0;
