@@ -186,15 +186,24 @@ __device__ __forceinline__ void sc_round_body(const T* __restrict__ in, size_t i
                 T d = V::sub(y, x);
                 T v2 = V::add(y, d);
                 if (i == 0) { p0 = x; p2 = v2; }
-                u64 m = pw[i].c0;  // M^i is a base-field constant
-                if constexpr (std::is_same<T, u64>::value) {
-                    s0 = gl_add(s0, gl_mul(m, x));
-                    s2 = gl_add(s2, gl_mul(m, v2));
+                // Collation shape: like the grand product, the FIRST round stores table i multiplied by its weight M^i
+                // (pw[i], a base-field constant; pwr[i] = M^i r), so later rounds only add: s(t) = sum_i table_i(t).
+                if constexpr (FIRST) {
+                    u64 m = pw[i].c0;
+                    if constexpr (std::is_same<T, u64>::value) {
+                        s0 = gl_add(s0, gl_mul(m, x));
+                        s2 = gl_add(s2, gl_mul(m, v2));
+                        store_e2(out + (size_t)i * out_stride + jo, e2_add_f(e2_mul_f(pwr[i], d), gl_mul(m, x)));
+                    } else {
+                        s0 = e2_add(s0, e2_mul_f(x, m));
+                        s2 = e2_add(s2, e2_mul_f(v2, m));
+                        store_e2(out + (size_t)i * out_stride + jo, e2_mul_f(V::fold(x, d, r), m));
+                    }
                 } else {
-                    s0 = e2_add(s0, e2_mul_f(x, m));
-                    s2 = e2_add(s2, e2_mul_f(v2, m));
+                    s0 = V::add(s0, x);
+                    s2 = V::add(s2, v2);
+                    store_e2(out + (size_t)i * out_stride + jo, V::fold(x, d, r));
                 }
-                store_e2(out + (size_t)i * out_stride + jo, V::fold(x, d, r));
             }
             E2 t0 = V::lift(s0), t2 = V::lift(s2);
             if (G > 1) {

@@ -321,7 +321,7 @@ struct Prover {
         J.r_off = h.point_off; J.sums_slot = h.sums_slot;
         memcpy(J.pw, pw.v, sizeof(J.pw));
         for (int i = 0; i < nvars; i++) h.rs.push_back(squeeze());
-        if (kind == dev::SC_GRANDPROD && nvars > 0)
+        if (nvars > 0)  // weight * r_0: the first round stores the weighted fold (kernels.hip)
             for (int i = 0; i < dev::PW_MAX; i++) J.pwr[i] = e2_mul(pw.v[i], h.rs[0]);
         if (nvars > 0) st_jobs.push_back(J);
         return h;
@@ -1304,6 +1304,12 @@ void sumcheck_on_tables(hg_ctx* ctx, SumcheckIO& io) {
     }
     int deg = io.kind == 1 ? 3 : 2;
     P.defer_sumcheck(h, deg, claim, out);
+    if (io.kind == 0) {  // collation kernels leave the final evaluation of table i multiplied by M^i (pw[i])
+        std::vector<E2> w = io.pw;
+        P.ops.push_back([ctx, evals, ntab, w] {
+            for (int i = 0; i < ntab && i < (int)w.size(); i++) ctx->h_res[evals + i] = e2_mul(ctx->h_res[evals + i], e2_inv(w[i]));
+        });
+    }
     if (io.kind == 1) {
         dev::Powers pw;
         memset(&pw, 0, sizeof(pw));
