@@ -23,7 +23,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 DOMINANT = "sc_round<grand_product,ext>"          # profile class name in the library
 DOMINANT_SYMBOL = "k_st_step<1, hg::E2>"          # its kernel symbol in rocprofv3 output
-PMC_FILE = os.path.join(ROOT, "profiles", "r01_d_pmc_hbm_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r01_e_pmc_hbm_traffic.json")
 
 
 def pmc_traffic():
