@@ -9,6 +9,7 @@
 #include <rocprim/rocprim.hpp>
 #include <type_traits>
 #include "kernels.hpp"
+#include "gl_wide.cuh"
 
 namespace hg {
 namespace dev {
@@ -39,6 +40,14 @@ __device__ __forceinline__ E2 block_sum(E2 v, E2* sm) {
     }
     return v;
 }
+
+// launch-shape knobs (tuning hooks; the defaults are the measured best on MI355X)
+static size_t env_size(const char* name, size_t dflt) {
+    const char* v = getenv(name);
+    return v && *v ? (size_t)strtoull(v, nullptr, 0) : dflt;
+}
+static size_t st_min_threads() { static size_t v = env_size("HG_ST_MIN_THREADS", 65536); return v; }
+static int st_max_blocks() { static int v = (int)std::min<size_t>(env_size("HG_ST_MAX_BLOCKS", SC_MAX_BLOCKS), SC_MAX_BLOCKS); return v; }
 
 static inline int grid_for(size_t work_items) {
     size_t b = (work_items + TPB - 1) / TPB;
@@ -128,33 +137,81 @@ __device__ __forceinline__ void sc_round_body(const T* __restrict__ in, size_t i
             E2 s0 = e2_zero(), s2 = e2_zero(), s3 = e2_zero();
             T p0 = V::zero(), p2 = V::zero(), p3 = V::zero();
             const int nb = ntab >> 1;
+            // a(t) b(t) = P0 + t (P1 - P0 - Pinf) + t^2 Pinf with P0 = a(0)b(0), P1 = a(1)b(1), Pinf = (a1-a0)(b1-b0):
+            // the three dot products over the table pairs stay unreduced in column accumulators (gl_wide.cuh)
+            // and are reduced once per j after the loop.
+            if constexpr (!FIRST && std::is_same<T, E2>::value) {
+                WE2 w0 = we2_zero(), w1 = we2_zero(), wi = we2_zero();
+                const FoldR fr = fold_r(r);
+                // software pipeline: the four loads of the next pair are in flight while this pair is processed
+                E2 xl, yl, xr, yr;
+                if (g < nb) {
+                    load_xy<E2, false>(in + (size_t)(2 * g) * in_stride, j, half, xl, yl);
+                    load_xy<E2, false>(in + (size_t)(2 * g + 1) * in_stride, j, half, xr, yr);
+                }
+                for (int i = g; i < nb; i += G) {
+                    E2 nxl = xl, nyl = yl, nxr = xr, nyr = yr;
+                    if (i + G < nb) {
+                        load_xy<E2, false>(in + (size_t)(2 * (i + G)) * in_stride, j, half, nxl, nyl);
+                        load_xy<E2, false>(in + (size_t)(2 * (i + G) + 1) * in_stride, j, half, nxr, nyr);
+                    }
+                    E2 dl = e2_sub(yl, xl), dr = e2_sub(yr, xr);
+                    if (i == 0) { p0 = xl; p2 = e2_add(yl, dl); p3 = e2_add(p2, dl); }
+                    if (!(p0_only && i == 0)) {  // a p0-only pair 0 belongs to another rank's share of the batch
+                        we2_mac(w0, xl, xr);
+                        we2_mac(w1, yl, yr);
+                        we2_mac(wi, dl, dr);
+                    }
+                    store_e2(out + (size_t)(2 * i) * out_stride + jo, e2_fold_wide(xl, dl, fr));
+                    store_e2(out + (size_t)(2 * i + 1) * out_stride + jo, e2_fold_wide(xr, dr, fr));
+                    xl = nxl; yl = nyl; xr = nxr; yr = nyr;
+                }
+                s0 = we2_reduce(w0); s2 = we2_reduce(w1); s3 = we2_reduce(wi);
+            } else if constexpr (FIRST && std::is_same<T, u64>::value) {
+                // first round on base-field rows: sum_i gamma^i (xl xr) etc. with the Ext2 weight gamma^i = pw[i];
+                // each base product is reduced once, its two weighted copies accumulate unreduced.
+                WAcc a0 = wacc_zero(), b0 = wacc_zero(), a1 = wacc_zero(), b1 = wacc_zero(), ai = wacc_zero(), bi = wacc_zero();
+                for (int i = g; i < nb; i += G) {
+                    u64 xl, yl, xr, yr;
+                    load_xy<u64, true>(in + (size_t)(2 * i) * in_stride, j, half, xl, yl);
+                    load_xy<u64, true>(in + (size_t)(2 * i + 1) * in_stride, j, half, xr, yr);
+                    u64 dl = gl_sub(yl, xl), dr = gl_sub(yr, xr);
+                    if (i == 0) { p0 = xl; p2 = gl_add(yl, dl); p3 = gl_add(p2, dl); }
+                    const E2 gm = pw[i], gr = pwr[i];
+                    if (!(p0_only && i == 0)) {
+                        u64 q0 = gl_mul(xl, xr), q1 = gl_mul(yl, yr), qi = gl_mul(dl, dr);
+                        wmac2(a0, gm.c0, q0, b0, gm.c1, q0);
+                        wmac2(a1, gm.c0, q1, b1, gm.c1, q1);
+                        wmac2(ai, gm.c0, qi, bi, gm.c1, qi);
+                    }
+                    // gamma^i * (xl + r dl) = gamma^i xl + (gamma^i r) dl
+                    WAcc f0 = wacc_zero(), f1 = wacc_zero(), h0 = wacc_zero(), h1 = wacc_zero();
+                    wmac_pair(f0, gm.c0, xl, gr.c0, dl);
+                    wmac_pair(f1, gm.c1, xl, gr.c1, dl);
+                    store_e2(out + (size_t)(2 * i) * out_stride + jo, e2(wreduce(f0), wreduce(f1)));
+                    h0.L = xr;
+                    wmac2(h0, r.c0, dr, h1, r.c1, dr);
+                    store_e2(out + (size_t)(2 * i + 1) * out_stride + jo, e2(wreduce(h0), wreduce(h1)));
+                }
+                s0 = e2(wreduce(a0), wreduce(b0)); s2 = e2(wreduce(a1), wreduce(b1)); s3 = e2(wreduce(ai), wreduce(bi));
+            } else {
             for (int i = g; i < nb; i += G) {
                 T xl, yl, xr, yr;
                 load_xy<T, FIRST>(in + (size_t)(2 * i) * in_stride, j, half, xl, yl);
                 load_xy<T, FIRST>(in + (size_t)(2 * i + 1) * in_stride, j, half, xr, yr);
                 T dl = V::sub(yl, xl), dr = V::sub(yr, xr);
                 if (i == 0) { p0 = xl; p2 = V::add(yl, dl); p3 = V::add(p2, dl); }
-                // a(t) b(t) = P0 + t (P1 - P0 - Pinf) + t^2 Pinf with P0 = a(0)b(0), P1 = a(1)b(1), Pinf = (a1-a0)(b1-b0):
-                // accumulate the three products, combine to t = 2, 3 once per j (after the loop)
-                const bool summed = !(p0_only && i == 0);  // a p0-only pair 0 belongs to another rank's share of the batch
-                if constexpr (FIRST) {
-                    E2 gm = pw[i];
-                    if (summed) {
-                        s0 = e2_add(s0, V::scale(gm, V::mul(xl, xr)));
-                        s2 = e2_add(s2, V::scale(gm, V::mul(yl, yr)));
-                        s3 = e2_add(s3, V::scale(gm, V::mul(dl, dr)));
-                    }
-                    // gamma^i * (xl + r dl) = gamma^i xl + (gamma^i r) dl
-                    store_e2(out + (size_t)(2 * i) * out_stride + jo, e2_add(V::scale(gm, xl), V::scale(pwr[i], dl)));
-                } else {
-                    if (summed) {
-                        s0 = e2_add(s0, V::lift(V::mul(xl, xr)));
-                        s2 = e2_add(s2, V::lift(V::mul(yl, yr)));
-                        s3 = e2_add(s3, V::lift(V::mul(dl, dr)));
-                    }
-                    store_e2(out + (size_t)(2 * i) * out_stride + jo, V::fold(xl, dl, r));
+                const bool summed = !(p0_only && i == 0);
+                E2 gm = pw[i];
+                if (summed) {
+                    s0 = e2_add(s0, V::scale(gm, V::mul(xl, xr)));
+                    s2 = e2_add(s2, V::scale(gm, V::mul(yl, yr)));
+                    s3 = e2_add(s3, V::scale(gm, V::mul(dl, dr)));
                 }
+                // gamma^i * (xl + r dl) = gamma^i xl + (gamma^i r) dl
+                store_e2(out + (size_t)(2 * i) * out_stride + jo, e2_add(V::scale(gm, xl), V::scale(pwr[i], dl)));
                 store_e2(out + (size_t)(2 * i + 1) * out_stride + jo, V::fold(xr, dr, r));
+            }
             }
             if (G > 1) {
                 red[tid] = s0; red[BD + tid] = s2; red[2 * BD + tid] = s3;
@@ -180,14 +237,44 @@ __device__ __forceinline__ void sc_round_body(const T* __restrict__ in, size_t i
             }
         } else {
             T s0 = V::zero(), s2 = V::zero(), p0 = V::zero(), p2 = V::zero();
+            // Collation shape: like the grand product, the FIRST round stores table i multiplied by its weight M^i
+            // (pw[i], a base-field constant; pwr[i] = M^i r), so later rounds only add: s(t) = sum_i table_i(t).
+            if constexpr (FIRST && std::is_same<T, u64>::value) {
+                WAcc w0 = wacc_zero(), w2 = wacc_zero();
+                for (int i = g; i < ntab; i += G) {
+                    u64 x, y;
+                    load_xy<u64, true>(in + (size_t)i * in_stride, j, half, x, y);
+                    u64 d = gl_sub(y, x);
+                    u64 v2 = gl_add(y, d);
+                    if (i == 0) { p0 = x; p2 = v2; }
+                    const u64 m = pw[i].c0;
+                    const E2 mr = pwr[i];
+                    wmac2(w0, m, x, w2, m, v2);
+                    WAcc f0 = wacc_zero(), f1 = wacc_zero();
+                    wmac_pair(f0, m, x, mr.c0, d);
+                    wmac(f1, mr.c1, d);
+                    store_e2(out + (size_t)i * out_stride + jo, e2(wreduce(f0), wreduce(f1)));
+                }
+                s0 = wreduce(w0); s2 = wreduce(w2);
+            } else if constexpr (!FIRST && std::is_same<T, E2>::value) {
+                const FoldR fr = fold_r(r);
+                for (int i = g; i < ntab; i += G) {
+                    E2 x, y;
+                    load_xy<E2, false>(in + (size_t)i * in_stride, j, half, x, y);
+                    E2 d = e2_sub(y, x);
+                    E2 v2 = e2_add(y, d);
+                    if (i == 0) { p0 = x; p2 = v2; }
+                    s0 = e2_add(s0, x);
+                    s2 = e2_add(s2, v2);
+                    store_e2(out + (size_t)i * out_stride + jo, e2_fold_wide(x, d, fr));
+                }
+            } else {
             for (int i = g; i < ntab; i += G) {
                 T x, y;
                 load_xy<T, FIRST>(in + (size_t)i * in_stride, j, half, x, y);
                 T d = V::sub(y, x);
                 T v2 = V::add(y, d);
                 if (i == 0) { p0 = x; p2 = v2; }
-                // Collation shape: like the grand product, the FIRST round stores table i multiplied by its weight M^i
-                // (pw[i], a base-field constant; pwr[i] = M^i r), so later rounds only add: s(t) = sum_i table_i(t).
                 if constexpr (FIRST) {
                     u64 m = pw[i].c0;
                     if constexpr (std::is_same<T, u64>::value) {
@@ -204,6 +291,7 @@ __device__ __forceinline__ void sc_round_body(const T* __restrict__ in, size_t i
                     s2 = V::add(s2, v2);
                     store_e2(out + (size_t)i * out_stride + jo, V::fold(x, d, r));
                 }
+            }
             }
             E2 t0 = V::lift(s0), t2 = V::lift(s2);
             if (G > 1) {
@@ -328,10 +416,10 @@ int st_step(hipStream_t st, int kind, bool base, const StJob* jobs, const int* l
             E2* partials, E2* res) {
     const size_t half = (size_t)1 << h_log2;
     int jb_log2 = 8;
-    while (jb_log2 > 2 && ((size_t)half * njobs << (8 - jb_log2)) < 65536) jb_log2--;
+    while (jb_log2 > 2 && ((size_t)half * njobs << (8 - jb_log2)) < st_min_threads()) jb_log2--;
     if (jb_log2 > h_log2) jb_log2 = h_log2;
     size_t ntiles = half >> jb_log2;
-    int gx = (int)(ntiles > (size_t)SC_MAX_BLOCKS ? SC_MAX_BLOCKS : ntiles);
+    int gx = (int)(ntiles > (size_t)st_max_blocks() ? st_max_blocks() : ntiles);
     const int nv = kind == SC_GRANDPROD ? 3 : 2;
     size_t lds = sc_lds_bytes(jb_log2 == 8 ? 0 : nv, 256);
     dim3 grid(gx, njobs);
@@ -373,6 +461,10 @@ __device__ __forceinline__ void ps_round_body(const PsJob& J, int rd, size_t hal
     const int G = BD >> jb_log2;
     const int jj = tid & ((1 << jb_log2) - 1), g = tid >> jb_log2;
     const size_t ntiles = half >> jb_log2;
+    // g = sum_i a_i b_i has no per-j factor, so the two evaluation sums stay unreduced (gl_wide.cuh) over the
+    // whole grid-stride loop of this thread and are reduced once at the end.
+    WE2 w0 = we2_zero(), w2 = we2_zero();
+    const FoldR fr = fold_r(r);
     for (size_t tile = first_tile; tile < ntiles; tile += tile_step) {
         const size_t j = (tile << jb_log2) + jj;
         const size_t jo = dpos(j, half);
@@ -390,12 +482,25 @@ __device__ __forceinline__ void ps_round_body(const PsJob& J, int rd, size_t hal
             }
             TA da = V::sub(ya, xa);
             E2 db = e2_sub(yb, xb);
-            a0 = e2_add(a0, V::scale(xb, xa));
-            a2 = e2_add(a2, V::scale(e2_add(yb, db), V::add(ya, da)));
-            store_e2(oa + jo, V::fold(xa, da, r));
-            store_e2(ob + jo, e2_add(xb, e2_mul(r, db)));
+            E2 vb = e2_add(yb, db);
+            TA va = V::add(ya, da);
+            if constexpr (std::is_same<TA, u64>::value) {
+                wmac2(w0.A, xb.c0, xa, w0.C, xb.c1, xa);
+                wmac2(w2.A, vb.c0, va, w2.C, vb.c1, va);
+                WAcc f0 = wacc_zero(), f1 = wacc_zero();
+                f0.L = xa;
+                wmac2(f0, fr.r0, da, f1, fr.r1, da);
+                store_e2(oa + jo, e2(wreduce(f0), wreduce(f1)));
+            } else {
+                we2_mac(w0, xb, xa);
+                we2_mac(w2, vb, va);
+                store_e2(oa + jo, e2_fold_wide(xa, da, fr));
+            }
+            store_e2(ob + jo, e2_fold_wide(xb, db, fr));
         }
     }
+    a0 = e2_add(a0, we2_reduce(w0));
+    a2 = e2_add(a2, we2_reduce(w2));
 }
 
 // one round of every job of a batch (grid.y = job); all jobs of a batch have the same nvars
@@ -455,10 +560,10 @@ int ps_round(hipStream_t st, const PsJob* jobs, int njobs, int nvars, int rd, co
     const int hl = nvars - 1 - rd;
     const size_t half = (size_t)1 << hl;
     int jb_log2 = 8;
-    while (jb_log2 > 2 && ((size_t)half * njobs << (8 - jb_log2)) < 65536) jb_log2--;
+    while (jb_log2 > 2 && ((size_t)half * njobs << (8 - jb_log2)) < st_min_threads()) jb_log2--;
     if (jb_log2 > hl) jb_log2 = hl;
     size_t ntiles = half >> jb_log2;
-    int gx = (int)(ntiles > (size_t)SC_MAX_BLOCKS ? SC_MAX_BLOCKS : ntiles);
+    int gx = (int)(ntiles > (size_t)st_max_blocks() ? st_max_blocks() : ntiles);
     k_ps_one<<<dim3(gx, njobs), 256, 16 * sizeof(E2), st>>>(jobs, rd, chal, jb_log2, partials, res);
     if (gx > 1) k_ps_reduce<<<njobs, TPB, 0, st>>>(jobs, rd, partials, gx, res);
     return gx;
