@@ -65,8 +65,10 @@ hg_ctx* hg_create(int device_id) {
     c->res_cap = (size_t)1 << 17;
     hip_check(hipMalloc((void**)&c->d_res, c->res_cap * sizeof(E2)), "hipMalloc(results)");
     hip_check(hipHostMalloc((void**)&c->h_res, c->res_cap * sizeof(E2), hipHostMallocDefault), "hipHostMalloc(results)");
-    hip_check(hipMalloc((void**)&c->d_partials, (size_t)dev::SC_MAX_BLOCKS * 3 * 64 * sizeof(E2)), "hipMalloc(partials)");
-    hip_check(hipMalloc((void**)&c->d_partials2, (size_t)dev::SC_MAX_BLOCKS * 3 * 64 * sizeof(E2)), "hipMalloc(partials2)");
+    hip_check(hipMalloc((void**)&c->d_partials, dev::PARTIALS_BYTES), "hipMalloc(partials)");
+    hip_check(hipMalloc((void**)&c->d_partials2, dev::PARTIALS_BYTES), "hipMalloc(partials2)");
+    hip_check(hipMemset(c->d_partials, 0, dev::PARTIALS_BYTES), "hipMemset(partials)");
+    hip_check(hipMemset(c->d_partials2, 0, dev::PARTIALS_BYTES), "hipMemset(partials2)");
     c->stage_cap = (size_t)4 << 20;
     hip_check(hipHostMalloc((void**)&c->h_stage, c->stage_cap, hipHostMallocDefault), "hipHostMalloc(staging)");
     c->ensure_chain(16384);

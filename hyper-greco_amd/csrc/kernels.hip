@@ -327,6 +327,49 @@ __device__ __forceinline__ E2 block_sum_n(E2 v, E2* sm /* >= 16 */) {
 
 extern __shared__ E2 dyn_lds[];  // [16 block-sum slots][NV * BD reduction slots]
 
+// ---- per-workgroup partial sums, finished by the workgroup that arrives last --------------------------------------
+// Partials cross workgroups (and XCDs, whose L2s are not coherent with each other) as relaxed agent-scope atomics:
+// write-through stores, L2-bypassing loads, no cache-wide write-back or invalidate.
+__device__ __forceinline__ void part_store(E2* p, E2 v) {
+    __hip_atomic_store(&p->c0, v.c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&p->c1, v.c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ E2 part_load(const E2* p) {
+    return e2(__hip_atomic_load(&p->c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(&p->c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ unsigned* tickets_of(E2* partials) { return reinterpret_cast<unsigned*>(partials + PARTIALS_E2); }
+// Called by the whole workgroup after thread 0 part_store()d its `per` values at p[blockIdx.x * per ..]. In the
+// workgroup that arrives last (block-uniform), sums the nblocks partials of each value and stores them to out[0..per).
+__device__ __forceinline__ void finish_partials(E2* p, int per, unsigned* ticket, E2* __restrict__ out, E2* sm /* >= 16 */) {
+    __shared__ unsigned s_last;
+    if (threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the partial stores have reached the coherence point
+        unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == gridDim.x - 1) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    constexpr int PER_MAX = 6;
+    E2 a[PER_MAX];
+#pragma unroll
+    for (int v = 0; v < PER_MAX; v++) a[v] = e2_zero();
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += blockDim.x) {
+        E2 t[PER_MAX];
+#pragma unroll
+        for (int v = 0; v < PER_MAX; v++) if (v < per) t[v] = part_load(p + (size_t)b * per + v);  // all loads in flight together
+#pragma unroll
+        for (int v = 0; v < PER_MAX; v++) if (v < per) a[v] = e2_add(a[v], t[v]);
+    }
+#pragma unroll
+    for (int v = 0; v < PER_MAX; v++) {
+        if (v < per) {
+            E2 r = block_sum_n(a[v], sm);
+            if (threadIdx.x == 0) out[v] = r;
+        }
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+}
+
 // ---- stride-layout sum-check jobs, batched over grid.y ---------------------------------------------------
 // Round rd of job J reads tables of length 2h (h = 2^(nvars-1-rd)) at stride 2h (round 0: J.in / J.in_stride)
 // and writes the folded tables at stride h into the ping-pong buffers (last round: J.final_out, stride 1).
@@ -337,17 +380,17 @@ __device__ __forceinline__ void st_io(const StJob& J, int rd, const void*& in, s
     out = rd == J.nvars - 1 ? J.final_out : J.buf[rd & 1];
 }
 
-// one step of the size-synchronised schedule: every listed job runs its round with half = 2^h_log2
+// one step of the size-synchronised schedule: every item runs its job's round with half = 2^h_log2
 template <int KIND, typename T>
-__global__ __launch_bounds__(256) void k_st_step(const StJob* __restrict__ jobs, const int* __restrict__ list, int h_log2,
+__global__ __launch_bounds__(256) void k_st_step(const StJob* __restrict__ jobs, const StItem* __restrict__ items, int h_log2,
                                                  const E2* __restrict__ chal, int jb_log2, E2* __restrict__ partials,
                                                  E2* __restrict__ res) {
     constexpr int NV = KIND == SC_GRANDPROD ? 3 : 2;
-    const StJob& J = jobs[list[blockIdx.y]];
+    const StItem& I = items[blockIdx.y];
+    const StJob& J = jobs[I.job];
     const int rd = J.nvars - 1 - h_log2;
     const size_t half = (size_t)1 << h_log2;
-    const void* in; size_t in_stride; E2* out;
-    st_io(J, rd, in, in_stride, out);
+    const void* in = I.in; const size_t in_stride = I.in_stride; E2* out = I.out;
     E2* sm = dyn_lds;
     E2* red = dyn_lds + 16;
     E2 acc[NV];
@@ -355,27 +398,120 @@ __global__ __launch_bounds__(256) void k_st_step(const StJob* __restrict__ jobs,
     for (int t = 0; t < NV; t++) acc[t] = e2_zero();
     if (rd == 0) sc_round_body<KIND, T, true>(reinterpret_cast<const T*>(in), in_stride, out, half, J.ntab, half, chal[J.r_off + rd], J.pw, J.pwr, jb_log2, red, acc, blockIdx.x, gridDim.x, J.p0_only != 0);
     else sc_round_body<KIND, T, false>(reinterpret_cast<const T*>(in), in_stride, out, half, J.ntab, half, chal[J.r_off + rd], J.pw, J.pwr, jb_log2, red, acc, blockIdx.x, gridDim.x, J.p0_only != 0);
+    E2* part = partials + (size_t)blockIdx.y * SC_MAX_BLOCKS * NV;
 #pragma unroll
     for (int t = 0; t < NV; t++) {
         E2 s = block_sum_n(acc[t], sm);
         if (threadIdx.x == 0) {
             if (gridDim.x == 1) res[J.sums_slot + (size_t)rd * NV + t] = s;
-            else partials[((size_t)blockIdx.y * SC_MAX_BLOCKS + blockIdx.x) * NV + t] = s;
+            else part_store(part + (size_t)blockIdx.x * NV + t, s);
         }
     }
+    if (gridDim.x > 1) finish_partials(part, NV, tickets_of(partials) + blockIdx.y * 32, res + J.sums_slot + (size_t)rd * NV, sm);
 }
-__global__ __launch_bounds__(TPB) void k_st_reduce(const StJob* __restrict__ jobs, const int* __restrict__ list, int h_log2, int nv,
-                                                   const E2* __restrict__ partials, int nblocks, E2* __restrict__ res) {
-    __shared__ E2 sm[TPB / 64];
-    const StJob& J = jobs[list[blockIdx.x]];
+// ---- two grand-product rounds in one pass ------------------------------------------------------------------
+// Thread j (one per pair index of round t, jb = 8) does round t as in sc_round_body; the folded values T'[j] stay in
+// registers. Round t+1 pairs (T'[2j'], T'[2j'+1]) live in the two lanes 2j', 2j'+1 of a wave: they swap their
+// folded values (DPP quad_perm) and split the work: the even lane accumulates P0 = x'l x'r (its own values) and
+// folds the left table, the odd lane accumulates P1 = y'l y'r (its own values) and folds the right table; Pinf =
+// d'l d'r is split by Ext2 coordinate (the sign of d' cancels in the product). Round-t sums use two column
+// accumulators per Ext2 sum (7 a1 pre-multiplied), so the register count stays that of the single-round kernel.
+// HBM traffic per (pair, j): 64 B read + 16 B written instead of (64 + 32) + (32 + 16).
+struct W2 { WAcc c0, c1; };
+__device__ __forceinline__ W2 w2_zero() { W2 w; w.c0 = wacc_zero(); w.c1 = wacc_zero(); return w; }
+__device__ __forceinline__ void w2_mac(W2& w, E2 a, E2 b) {
+    const u64 a7 = gl_mul_small(a.c1, 7);
+    wmac_pair(w.c0, a.c0, b.c0, a7, b.c1);
+    wmac_pair(w.c1, a.c0, b.c1, a.c1, b.c0);
+}
+__device__ __forceinline__ E2 w2_reduce(const W2& w) { return e2(wreduce(w.c0), wreduce(w.c1)); }
+__device__ __forceinline__ u64 swap_lane_u64(u64 v) {
+    u32 lo = (u32)v, hi = (u32)(v >> 32);
+    lo = (u32)__builtin_amdgcn_mov_dpp((int)lo, 0xB1, 0xF, 0xF, true);  // quad_perm:[1,0,3,2]
+    hi = (u32)__builtin_amdgcn_mov_dpp((int)hi, 0xB1, 0xF, 0xF, true);
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ E2 swap_lane(E2 v) { return e2(swap_lane_u64(v.c0), swap_lane_u64(v.c1)); }
+__device__ __forceinline__ E2 gp_combine(E2 P0, E2 P1, E2 Pi, E2 p0, E2 p2, E2 p3, E2& a0, E2& a1, E2& a2) {
+    // q(2) = 2 P1 - P0 + 2 Pinf, q(3) = 3 P1 - 2 P0 + 6 Pinf
+    E2 P1x2 = e2_dbl(P1), Pix2 = e2_dbl(Pi);
+    E2 q2 = e2_add(e2_sub(P1x2, P0), Pix2);
+    E2 q3 = e2_add(e2_sub(e2_add(P1x2, P1), e2_dbl(P0)), e2_add(e2_dbl(Pix2), Pix2));
+    a0 = e2_add(a0, e2_mul(P0, p0));
+    a1 = e2_add(a1, e2_mul(q2, p2));
+    a2 = e2_add(a2, e2_mul(q3, p3));
+    return q2;
+}
+__global__ __launch_bounds__(256) void k_st_step2(const StJob* __restrict__ jobs, const StItem* __restrict__ items, int h_log2,
+                                                  const E2* __restrict__ chal, E2* __restrict__ partials, E2* __restrict__ res) {
+    const StItem& I = items[blockIdx.y];
+    const StJob& J = jobs[I.job];
     const int rd = J.nvars - 1 - h_log2;
-    const E2* p = partials + (size_t)blockIdx.x * SC_MAX_BLOCKS * nv;
-    for (int v = 0; v < nv; v++) {
-        E2 a = e2_zero();
-        for (int b = threadIdx.x; b < nblocks; b += TPB) a = e2_add(a, p[(size_t)b * nv + v]);
-        a = block_sum(a, sm);
-        if (threadIdx.x == 0) res[J.sums_slot + (size_t)rd * nv + v] = a;
+    const size_t half = (size_t)1 << h_log2, half2 = half >> 1;
+    const E2* __restrict__ in = reinterpret_cast<const E2*>(I.in);
+    const size_t in_stride = I.in_stride;
+    E2* __restrict__ out = I.out;
+    const int nb = J.ntab >> 1;
+    const bool p0_only = J.p0_only != 0;
+    const int tid = threadIdx.x;
+    const bool odd = tid & 1;
+    const FoldR fa = fold_r(chal[J.r_off + rd]);
+    const E2 rb = chal[J.r_off + rd + 1];
+    // the odd lane folds y' + (1 - r)(x' - y') = x' + r (y' - x') from its own value y'
+    const FoldR fb = fold_r(odd ? e2_sub(e2_one(), rb) : rb);
+    E2 acc[6];
+#pragma unroll
+    for (int t = 0; t < 6; t++) acc[t] = e2_zero();
+    const size_t ntiles = half >> 8;
+    for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const size_t j = (tile << 8) + tid;
+        const size_t j2 = j >> 1;
+        const size_t jo2 = dpos(j2, half2);
+        W2 w0 = w2_zero(), w1 = w2_zero(), wi = w2_zero(), vm = w2_zero();
+        WAcc vi = wacc_zero();
+        E2 p0 = e2_zero(), p2 = e2_zero(), p3 = e2_zero(), q0 = e2_zero(), q2 = e2_zero(), q3 = e2_zero();
+        for (int i = 0; i < nb; i++) {
+            E2 xl, yl, xr, yr;
+            load_xy<E2, false>(in + (size_t)(2 * i) * in_stride, j, half, xl, yl);
+            load_xy<E2, false>(in + (size_t)(2 * i + 1) * in_stride, j, half, xr, yr);
+            const E2 dl = e2_sub(yl, xl), dr = e2_sub(yr, xr);
+            const bool summed = !(p0_only && i == 0);
+            if (i == 0) { p0 = xl; p2 = e2_add(yl, dl); p3 = e2_add(p2, dl); }
+            if (summed) { w2_mac(w0, xl, xr); w2_mac(w1, yl, yr); w2_mac(wi, dl, dr); }
+            const E2 ml = e2_fold_wide(xl, dl, fa), mr = e2_fold_wide(xr, dr, fa);  // T'[j] of the left / right table
+            const E2 ol = swap_lane(ml), orr = swap_lane(mr);                        // the neighbour's
+            const E2 el = e2_sub(ol, ml), er = e2_sub(orr, mr);                      // +-(y' - x')
+            if (i == 0) {  // p' of round t+1 at 0, 2, 3 from x' = even lane's, y' = odd lane's left value
+                const E2 x = odd ? ol : ml, y = odd ? ml : ol;
+                const E2 d = e2_sub(y, x);
+                q0 = x; q2 = e2_add(y, d); q3 = e2_add(q2, d);
+            }
+            if (summed) {
+                w2_mac(vm, ml, mr);  // even lane: P0 term, odd lane: P1 term
+                // Pinf = el * er: the even lane takes coordinate 0 (el0 er0 + 7 el1 er1), the odd lane coordinate 1
+                const u64 b = odd ? er.c1 : er.c0, d = odd ? er.c0 : er.c1;
+                const u64 c = odd ? el.c1 : gl_mul_small(el.c1, 7);
+                wmac_pair(vi, el.c0, b, c, d);
+            }
+            const E2 fx = odd ? mr : ml, fd = odd ? er : el;
+            store_e2(out + (size_t)(2 * i + (odd ? 1 : 0)) * half2 + jo2, e2_fold_wide(fx, fd, fb));
+        }
+        gp_combine(w2_reduce(w0), w2_reduce(w1), w2_reduce(wi), p0, p2, p3, acc[0], acc[1], acc[2]);
+        const E2 mine = w2_reduce(vm), other = swap_lane(mine);
+        const u64 ip = wreduce(vi), iq = swap_lane_u64(ip);
+        if (!odd) gp_combine(mine, other, e2(ip, iq), q0, q2, q3, acc[3], acc[4], acc[5]);
     }
+    E2* sm = dyn_lds;
+    E2* part = partials + (size_t)blockIdx.y * SC_MAX_BLOCKS * 6;
+#pragma unroll
+    for (int t = 0; t < 6; t++) {
+        E2 s = block_sum_n(acc[t], sm);
+        if (threadIdx.x == 0) {
+            if (gridDim.x == 1) res[J.sums_slot + (size_t)rd * 3 + t] = s;
+            else part_store(part + (size_t)blockIdx.x * 6 + t, s);
+        }
+    }
+    if (gridDim.x > 1) finish_partials(part, 6, tickets_of(partials) + blockIdx.y * 32, res + J.sums_slot + (size_t)rd * 3, sm);
 }
 // all rounds with half <= 2^h_log2 of every listed job, one workgroup per job
 template <int KIND>
@@ -388,12 +524,12 @@ __global__ __launch_bounds__(1024) void k_st_tail(const StJob* __restrict__ jobs
     const int bd_log2 = 31 - __clz((int)blockDim.x);
     int rd = J.nvars - 1 - h_log2;
     if (rd < 0) rd = 0;
+    const void* in = J.tail_in; size_t in_stride = J.tail_in_stride;
     for (; rd < J.nvars; rd++) {
         const int hl = J.nvars - 1 - rd;
         const size_t half = (size_t)1 << hl;
         const int jb_log2 = hl < bd_log2 ? hl : bd_log2;
-        const void* in; size_t in_stride; E2* out;
-        st_io(J, rd, in, in_stride, out);
+        E2* out = rd == J.nvars - 1 ? J.final_out : (in == (const void*)J.buf[0] ? J.buf[1] : J.buf[0]);
         E2 r = chal[J.r_off + rd];
         E2 acc[NV];
 #pragma unroll
@@ -407,12 +543,13 @@ __global__ __launch_bounds__(1024) void k_st_tail(const StJob* __restrict__ jobs
             if (threadIdx.x == 0) res[J.sums_slot + (size_t)rd * NV + t] = s;
         }
         __syncthreads();  // folded table (global, same workgroup) visible before the next round reads it
+        in = out; in_stride = half;
     }
 }
 
 static inline size_t sc_lds_bytes(int nv, int bd) { return (16 + (size_t)nv * bd) * sizeof(E2); }
 
-int st_step(hipStream_t st, int kind, bool base, const StJob* jobs, const int* list, int njobs, int h_log2, const E2* chal,
+int st_step(hipStream_t st, int kind, bool base, const StJob* jobs, const StItem* items, int njobs, int h_log2, const E2* chal,
             E2* partials, E2* res) {
     const size_t half = (size_t)1 << h_log2;
     int jb_log2 = 8;
@@ -424,13 +561,18 @@ int st_step(hipStream_t st, int kind, bool base, const StJob* jobs, const int* l
     size_t lds = sc_lds_bytes(jb_log2 == 8 ? 0 : nv, 256);
     dim3 grid(gx, njobs);
     if (kind == SC_GRANDPROD) {
-        if (base) k_st_step<SC_GRANDPROD, u64><<<grid, 256, lds, st>>>(jobs, list, h_log2, chal, jb_log2, partials, res);
-        else k_st_step<SC_GRANDPROD, E2><<<grid, 256, lds, st>>>(jobs, list, h_log2, chal, jb_log2, partials, res);
+        if (base) k_st_step<SC_GRANDPROD, u64><<<grid, 256, lds, st>>>(jobs, items, h_log2, chal, jb_log2, partials, res);
+        else k_st_step<SC_GRANDPROD, E2><<<grid, 256, lds, st>>>(jobs, items, h_log2, chal, jb_log2, partials, res);
     } else {
-        if (base) k_st_step<SC_COLLATION, u64><<<grid, 256, lds, st>>>(jobs, list, h_log2, chal, jb_log2, partials, res);
-        else k_st_step<SC_COLLATION, E2><<<grid, 256, lds, st>>>(jobs, list, h_log2, chal, jb_log2, partials, res);
+        if (base) k_st_step<SC_COLLATION, u64><<<grid, 256, lds, st>>>(jobs, items, h_log2, chal, jb_log2, partials, res);
+        else k_st_step<SC_COLLATION, E2><<<grid, 256, lds, st>>>(jobs, items, h_log2, chal, jb_log2, partials, res);
     }
-    if (gx > 1) k_st_reduce<<<njobs, TPB, 0, st>>>(jobs, list, h_log2, nv, partials, gx, res);
+    return gx;
+}
+int st_step2(hipStream_t st, const StJob* jobs, const StItem* items, int njobs, int h_log2, const E2* chal, E2* partials, E2* res) {
+    const size_t ntiles = ((size_t)1 << h_log2) >> 8;
+    int gx = (int)(ntiles > (size_t)st_max_blocks() ? st_max_blocks() : ntiles);
+    k_st_step2<<<dim3(gx, njobs), 256, sc_lds_bytes(0, 256), st>>>(jobs, items, h_log2, chal, partials, res);
     return gx;
 }
 void st_tail(hipStream_t st, int kind, const StJob* jobs, const int* list, int njobs, int h_log2, const E2* chal, E2* res) {
@@ -515,13 +657,12 @@ __global__ __launch_bounds__(256) void k_ps_one(const PsJob* __restrict__ jobs, 
     else ps_round_body<E2>(J, rd, half, r, jb_log2, a0, a2, blockIdx.x, gridDim.x);
     E2 s0 = block_sum_n(a0, sm);
     E2 s2 = block_sum_n(a2, sm);
+    E2* part = partials + (size_t)blockIdx.y * SC_MAX_BLOCKS * 2;
     if (threadIdx.x == 0) {
         if (gridDim.x == 1) { res[J.sums_slot + 2 * rd] = s0; res[J.sums_slot + 2 * rd + 1] = s2; }
-        else {
-            E2* p = partials + ((size_t)blockIdx.y * SC_MAX_BLOCKS + blockIdx.x) * 2;
-            p[0] = s0; p[1] = s2;
-        }
+        else { part_store(part + (size_t)blockIdx.x * 2, s0); part_store(part + (size_t)blockIdx.x * 2 + 1, s2); }
     }
+    if (gridDim.x > 1) finish_partials(part, 2, tickets_of(partials) + blockIdx.y * 32, res + J.sums_slot + 2 * rd, sm);
 }
 // rounds [rd0, nvars) of every job of a batch, one workgroup per job
 __global__ __launch_bounds__(1024) void k_ps_tail(const PsJob* __restrict__ jobs, int rd0, const E2* __restrict__ chal,
@@ -543,19 +684,6 @@ __global__ __launch_bounds__(1024) void k_ps_tail(const PsJob* __restrict__ jobs
         __syncthreads();
     }
 }
-__global__ __launch_bounds__(TPB) void k_ps_reduce(const PsJob* __restrict__ jobs, int rd, const E2* __restrict__ partials, int nblocks,
-                                                   E2* __restrict__ res) {
-    __shared__ E2 sm[TPB / 64];
-    const PsJob& J = jobs[blockIdx.x];
-    const E2* p = partials + (size_t)blockIdx.x * SC_MAX_BLOCKS * 2;
-    for (int v = 0; v < 2; v++) {
-        E2 a = e2_zero();
-        for (int b = threadIdx.x; b < nblocks; b += TPB) a = e2_add(a, p[(size_t)b * 2 + v]);
-        a = block_sum(a, sm);
-        if (threadIdx.x == 0) res[J.sums_slot + 2 * rd + v] = a;
-    }
-}
-
 int ps_round(hipStream_t st, const PsJob* jobs, int njobs, int nvars, int rd, const E2* chal, E2* partials, E2* res) {
     const int hl = nvars - 1 - rd;
     const size_t half = (size_t)1 << hl;
@@ -565,7 +693,6 @@ int ps_round(hipStream_t st, const PsJob* jobs, int njobs, int nvars, int rd, co
     size_t ntiles = half >> jb_log2;
     int gx = (int)(ntiles > (size_t)st_max_blocks() ? st_max_blocks() : ntiles);
     k_ps_one<<<dim3(gx, njobs), 256, 16 * sizeof(E2), st>>>(jobs, rd, chal, jb_log2, partials, res);
-    if (gx > 1) k_ps_reduce<<<njobs, TPB, 0, st>>>(jobs, rd, partials, gx, res);
     return gx;
 }
 void ps_tail(hipStream_t st, const PsJob* jobs, int njobs, int rd0, const E2* chal, E2* res) {

@@ -8,6 +8,12 @@ namespace hg {
 namespace dev {
 
 constexpr int SC_MAX_BLOCKS = 1024;  // fixed partial-sum fan-in of the round kernels
+// A `partials` buffer holds PARTIALS_E2 per-workgroup partial sums followed by PARTIALS_TICKETS arrival counters
+// (zero between launches): the workgroup that arrives last sums the partials of its job, so a round needs no
+// second launch. One buffer per stream.
+constexpr size_t PARTIALS_E2 = (size_t)SC_MAX_BLOCKS * 6 * 64;
+constexpr int PARTIALS_TICKETS = 64 * 32;  // one 128-byte line per job of a launch
+constexpr size_t PARTIALS_BYTES = PARTIALS_E2 * sizeof(E2) + PARTIALS_TICKETS * sizeof(unsigned);
 constexpr int PS_MAX_PAIRS = 32;     // max (input, bookkeeping) table pairs of one PRODSUM sum-check
 constexpr int PW_MAX = 64;           // max batched products / memories carried in kernarg powers
 
@@ -27,12 +33,16 @@ enum ScKind { SC_COLLATION = 0, SC_GRANDPROD = 1 };
 // Stride-layout sum-check instance (collation / grand-product shapes), device-visible descriptor.
 // Table t of round 0 lives at in + t*in_stride (u64 if base else E2). All instances of a prover run are
 // scheduled size-synchronously: step h launches, for every instance, its round whose half-length is h
-// (instances are independent on the device; only the transcript orders them).
+// (instances are independent on the device; only the transcript orders them). Because the challenges do not
+// depend on the prover's messages (transcript.rs:146-157), two consecutive rounds of an instance can also run
+// in ONE launch (st_step2): the intermediate folded tables then never touch HBM.
 struct StJob {
     const void* in;
     size_t in_stride;
     E2* buf[2];        // ping-pong storage for folded tables (ntab * len/2, ntab * len/4)
     E2* final_out;     // ntab folded scalars
+    const void* tail_in;     // input of the first round the tail launch runs (host-planned), stride tail_in_stride
+    size_t tail_in_stride;
     int kind, ntab, nvars, base;
     int p0_only;       // grand product on a subset of the batch (multi-GPU): pair 0 only supplies p_0, its product is not summed
     size_t r_off;      // chain index of round 0's challenge
@@ -40,9 +50,19 @@ struct StJob {
     E2 pw[PW_MAX];     // gamma^i (grand product) or M^i (collation)
     E2 pwr[PW_MAX];    // gamma^i * r_0 (grand product: first-round fold of the left tables)
 };
-// step: every job in `list` (device array of njobs indices into jobs) runs its round with half = 2^h_log2
-int st_step(hipStream_t st, int kind, bool base, const StJob* jobs, const int* list, int njobs, int h_log2, const E2* chal,
+// one (job, round) of a step launch: where the round reads and writes (host-planned ping-pong)
+struct StItem {
+    int job, pad;
+    const void* in;
+    size_t in_stride;
+    E2* out;           // folded tables of the (last) round, stride = its half length
+};
+// step: every item runs its job's round with half = 2^h_log2
+int st_step(hipStream_t st, int kind, bool base, const StJob* jobs, const StItem* items, int nitems, int h_log2, const E2* chal,
             E2* partials, E2* res);
+// fused step (grand-product shape, folded Ext2 inputs): every item runs its job's rounds with half = 2^h_log2 and 2^(h_log2-1)
+int st_step2(hipStream_t st, const StJob* jobs, const StItem* items, int nitems, int h_log2, const E2* chal, E2* partials, E2* res);
+constexpr int ST_STEP2_MIN_H = 9;  // fused steps need 2^h_log2 >= 2 * 256 (one pair index per thread, lane pairs share the second round)
 // tail: every listed job runs all its rounds with half <= 2^h_log2 in one workgroup
 void st_tail(hipStream_t st, int kind, const StJob* jobs, const int* list, int njobs, int h_log2, const E2* chal, E2* res);
 

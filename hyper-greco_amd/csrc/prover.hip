@@ -330,12 +330,16 @@ struct Prover {
     void flush_stride() {
         if (st_jobs.empty()) return;
         const int nj = (int)st_jobs.size();
-        dev::StJob* d_jobs = ctx->alloc_n<dev::StJob>(nj);
-        hip_check(hipMemcpyAsync(d_jobs, stage(st_jobs.data(), (size_t)nj * sizeof(dev::StJob)), (size_t)nj * sizeof(dev::StJob),
-                                 hipMemcpyHostToDevice, st), "upload jobs");
-        // launch plan: (kind, base?, h_log2 | tail) -> list of job indices
-        struct Launch { int kind; bool base; int h_log2; bool tail; std::vector<int> jobs; };
+        // launch plan: (kind, base? | fused pair?, h_log2 | tail) -> items (job, where the round reads and writes).
+        // Folded tables ping-pong between the job's two buffers; the host tracks where each job's live tables are.
+        static const bool fuse2 = [] { const char* e = getenv("HG_NO_FUSE2"); return !(e && e[0] == '1'); }();
+        struct Launch { int kind; bool base; int h_log2; bool tail; int nrounds; std::vector<dev::StItem> items; };
         std::vector<Launch> plan;
+        std::vector<const void*> cur_in(nj);
+        std::vector<size_t> cur_stride(nj);
+        std::vector<int> done_h(nj, 1 << 30);  // smallest half-length (log2) already scheduled
+        for (int q = 0; q < nj; q++) { cur_in[q] = st_jobs[q].in; cur_stride[q] = st_jobs[q].in_stride; }
+        auto next_out = [&](int q) { return cur_in[q] == (const void*)st_jobs[q].buf[0] ? st_jobs[q].buf[1] : st_jobs[q].buf[0]; };
         for (int kind : {dev::SC_COLLATION, dev::SC_GRANDPROD}) {
             int max_h = -1;
             size_t per_j = 1;
@@ -346,46 +350,79 @@ struct Prover {
             if (max_h < 0) continue;
             int h_tail = 0;
             while (h_tail + 1 <= max_h && ((size_t)2 << h_tail) * per_j <= TAIL_ITEMS) h_tail++;
+            // fused pairs (h, h-1) start at the half-length of the largest job's first Ext2 round
+            const int pair_parity = (max_h - 1) & 1;
             for (int h = max_h; h > h_tail; h--) {
-                Launch lb{kind, true, h, false, {}}, le{kind, false, h, false, {}};
+                Launch lb{kind, true, h, false, 1, {}}, le{kind, false, h, false, 1, {}}, l2{kind, false, h, false, 2, {}};
+                const bool pair_start = fuse2 && kind == dev::SC_GRANDPROD && (h & 1) == pair_parity && h - 1 > h_tail &&
+                                        h >= std::max(dev::ST_STEP2_MIN_H, 13);
                 for (int q = 0; q < nj; q++) {
                     const dev::StJob& J = st_jobs[q];
-                    if (J.kind != kind || J.nvars - 1 < h) continue;
-                    bool first = J.nvars - 1 == h;
-                    if (first && J.base) lb.jobs.push_back(q); else le.jobs.push_back(q);
+                    if (J.kind != kind || J.nvars - 1 < h || done_h[q] <= h) continue;
+                    const bool first = J.nvars - 1 == h;
+                    dev::StItem it;
+                    it.job = q; it.pad = 0; it.in = cur_in[q]; it.in_stride = cur_stride[q];
+                    it.out = first ? J.buf[0] : next_out(q);
+                    if (!first && pair_start) {
+                        l2.items.push_back(it);
+                        done_h[q] = h - 1;
+                        cur_in[q] = it.out; cur_stride[q] = (size_t)1 << (h - 1);
+                    } else {
+                        (first && J.base ? lb : le).items.push_back(it);
+                        done_h[q] = h;
+                        cur_in[q] = it.out; cur_stride[q] = (size_t)1 << h;
+                    }
                 }
-                if (!lb.jobs.empty()) plan.push_back(lb);
-                if (!le.jobs.empty()) plan.push_back(le);
+                if (!lb.items.empty()) plan.push_back(lb);
+                if (!le.items.empty()) plan.push_back(le);
+                if (!l2.items.empty()) plan.push_back(l2);
             }
-            Launch lt{kind, false, h_tail, true, {}};
-            for (int q = 0; q < nj; q++) if (st_jobs[q].kind == kind) lt.jobs.push_back(q);
+            Launch lt{kind, false, h_tail, true, 1, {}};
+            for (int q = 0; q < nj; q++) if (st_jobs[q].kind == kind) {
+                dev::StItem it; it.job = q; it.pad = 0; it.in = cur_in[q]; it.in_stride = cur_stride[q]; it.out = nullptr;
+                lt.items.push_back(it);
+                st_jobs[q].tail_in = cur_in[q]; st_jobs[q].tail_in_stride = cur_stride[q];
+            }
             plan.push_back(lt);
         }
-        std::vector<int> flat;
+        dev::StJob* d_jobs = ctx->alloc_n<dev::StJob>(nj);
+        hip_check(hipMemcpyAsync(d_jobs, stage(st_jobs.data(), (size_t)nj * sizeof(dev::StJob)), (size_t)nj * sizeof(dev::StJob),
+                                 hipMemcpyHostToDevice, st), "upload jobs");
+        std::vector<dev::StItem> flat;
+        std::vector<int> flat_jobs;
         std::vector<size_t> offs;
-        for (auto& L : plan) { offs.push_back(flat.size()); flat.insert(flat.end(), L.jobs.begin(), L.jobs.end()); }
-        int* d_list = ctx->alloc_n<int>(flat.size());
-        hip_check(hipMemcpyAsync(d_list, stage(flat.data(), flat.size() * sizeof(int)), flat.size() * sizeof(int), hipMemcpyHostToDevice, st), "upload job lists");
+        for (auto& L : plan) {
+            offs.push_back(flat.size());
+            flat.insert(flat.end(), L.items.begin(), L.items.end());
+            for (auto& it : L.items) flat_jobs.push_back(it.job);
+        }
+        dev::StItem* d_items = ctx->alloc_n<dev::StItem>(flat.size());
+        hip_check(hipMemcpyAsync(d_items, stage(flat.data(), flat.size() * sizeof(dev::StItem)), flat.size() * sizeof(dev::StItem), hipMemcpyHostToDevice, st), "upload step items");
+        int* d_list = ctx->alloc_n<int>(flat_jobs.size());
+        hip_check(hipMemcpyAsync(d_list, stage(flat_jobs.data(), flat_jobs.size() * sizeof(int)), flat_jobs.size() * sizeof(int), hipMemcpyHostToDevice, st), "upload job lists");
         auto round_bytes = [&](const dev::StJob& J, int rd) {
             size_t half = (size_t)1 << (J.nvars - 1 - rd);
             return (double)J.ntab * (2.0 * half * ((J.base && rd == 0) ? 8 : 16) + half * 16.0);
         };
         for (size_t li = 0; li < plan.size(); li++) {
             const Launch& L = plan[li];
-            for (size_t o = 0; o < L.jobs.size(); o += MAX_BATCH) {
-                const int cnt = (int)std::min<size_t>(MAX_BATCH, L.jobs.size() - o);
-                const int* list = d_list + offs[li] + o;
+            for (size_t o = 0; o < L.items.size(); o += MAX_BATCH) {
+                const int cnt = (int)std::min<size_t>(MAX_BATCH, L.items.size() - o);
                 double bytes = 0;
                 if (L.tail) {
-                    for (int q = 0; q < cnt; q++) { const dev::StJob& J = st_jobs[L.jobs[o + q]]; for (int rd = std::max(0, J.nvars - 1 - L.h_log2); rd < J.nvars; rd++) bytes += round_bytes(J, rd); }
+                    for (int q = 0; q < cnt; q++) { const dev::StJob& J = st_jobs[L.items[o + q].job]; for (int rd = std::max(0, J.nvars - 1 - L.h_log2); rd < J.nvars; rd++) bytes += round_bytes(J, rd); }
                     ctx->prof_begin(cls_tail, bytes);
-                    dev::st_tail(st, L.kind, d_jobs, list, cnt, L.h_log2, ctx->d_chal, d_res());
+                    dev::st_tail(st, L.kind, d_jobs, d_list + offs[li] + o, cnt, L.h_log2, ctx->d_chal, d_res());
                     ctx->prof_end();
                 } else {
-                    for (int q = 0; q < cnt; q++) { const dev::StJob& J = st_jobs[L.jobs[o + q]]; bytes += round_bytes(J, J.nvars - 1 - L.h_log2); }
+                    for (int q = 0; q < cnt; q++) {
+                        const dev::StJob& J = st_jobs[L.items[o + q].job];
+                        for (int k = 0; k < L.nrounds; k++) bytes += round_bytes(J, J.nvars - 1 - L.h_log2 + k);
+                    }
                     int cls = L.kind == dev::SC_GRANDPROD ? (L.base ? cls_gp_base : cls_gp_ext) : (L.base ? cls_col_base : cls_col_ext);
                     ctx->prof_begin(cls, bytes);
-                    dev::st_step(st, L.kind, L.base, d_jobs, list, cnt, L.h_log2, ctx->d_chal, partials, d_res());
+                    if (L.nrounds == 2) dev::st_step2(st, d_jobs, d_items + offs[li] + o, cnt, L.h_log2, ctx->d_chal, partials, d_res());
+                    else dev::st_step(st, L.kind, L.base, d_jobs, d_items + offs[li] + o, cnt, L.h_log2, ctx->d_chal, partials, d_res());
                     ctx->prof_end();
                 }
             }
