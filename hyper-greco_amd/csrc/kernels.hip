@@ -17,17 +17,26 @@ namespace dev {
 constexpr int TPB = 256;
 
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ u64 shfl_down_u64(u64 v, int off) {
-    return (u64)__shfl_down((unsigned long long)v, off, 64);
+// Wave-level modular sum with DPP moves (VALU rate) instead of ds_bpermute: row_shr 1/2/4/8 inside the rows of 16,
+// then row_bcast15 / row_bcast31 across rows; lane 63 ends up with the total, which v_readlane broadcasts.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ u64 dpp_u64(u64 v) {
+    u32 lo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)v, CTRL, ROW_MASK, 0xF, false);
+    u32 hi = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(v >> 32), CTRL, ROW_MASK, 0xF, false);
+    return ((u64)hi << 32) | lo;   // lanes without a source (or outside ROW_MASK) read 0: the identity of gl_add
 }
-__device__ __forceinline__ E2 wave_sum(E2 v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        v.c0 = gl_add(v.c0, shfl_down_u64(v.c0, off));
-        v.c1 = gl_add(v.c1, shfl_down_u64(v.c1, off));
-    }
-    return v;
+__device__ __forceinline__ u64 wave_sum_u64(u64 v) {
+    v = gl_add(v, dpp_u64<0x111, 0xF>(v));  // row_shr:1
+    v = gl_add(v, dpp_u64<0x112, 0xF>(v));  // row_shr:2
+    v = gl_add(v, dpp_u64<0x114, 0xF>(v));  // row_shr:4
+    v = gl_add(v, dpp_u64<0x118, 0xF>(v));  // row_shr:8
+    v = gl_add(v, dpp_u64<0x142, 0xA>(v));  // row_bcast:15 into rows 1, 3
+    v = gl_add(v, dpp_u64<0x143, 0xC>(v));  // row_bcast:31 into rows 2, 3
+    u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)v, 63), hi = (u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), 63);
+    return ((u64)hi << 32) | lo;
 }
+// total over the wave, in every lane
+__device__ __forceinline__ E2 wave_sum(E2 v) { return e2(wave_sum_u64(v.c0), wave_sum_u64(v.c1)); }
 // sums `v` over the workgroup; result valid in thread 0. `sm` holds TPB/64 E2 slots.
 __device__ __forceinline__ E2 block_sum(E2 v, E2* sm) {
     v = wave_sum(v);
@@ -179,6 +188,8 @@ __device__ __forceinline__ void sc_round_body(const T* __restrict__ in, size_t i
                     if (i == 0) { p0 = xl; p2 = gl_add(yl, dl); p3 = gl_add(p2, dl); }
                     const E2 gm = pw[i], gr = pwr[i];
                     if (!(p0_only && i == 0)) {
+                        // (reading v_l v_r from the tree level above instead of multiplying was measured slower: the
+                        // first round is bound by its 8-byte-element traffic, not by these products)
                         u64 q0 = gl_mul(xl, xr), q1 = gl_mul(yl, yr), qi = gl_mul(dl, dr);
                         wmac2(a0, gm.c0, q0, b0, gm.c1, q0);
                         wmac2(a1, gm.c0, q1, b1, gm.c1, q1);
@@ -340,31 +351,35 @@ __device__ __forceinline__ E2 part_load(const E2* p) {
 __device__ __forceinline__ unsigned* tickets_of(E2* partials) { return reinterpret_cast<unsigned*>(partials + PARTIALS_E2); }
 // Called by the whole workgroup after thread 0 part_store()d its `per` values at p[blockIdx.x * per ..]. In the
 // workgroup that arrives last (block-uniform), sums the nblocks partials of each value and stores them to out[0..per).
-__device__ __forceinline__ void finish_partials(E2* p, int per, unsigned* ticket, E2* __restrict__ out, E2* sm /* >= 16 */) {
+__device__ __forceinline__ void finish_partials(E2* p, int per, unsigned* ticket, E2* __restrict__ out, E2* sm /* >= 16 */,
+                                                int nblocks = -1) {
     __shared__ unsigned s_last;
+    if (nblocks < 0) nblocks = (int)gridDim.x;
     if (threadIdx.x == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the partial stores have reached the coherence point
         unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (t == gridDim.x - 1) ? 1u : 0u;
+        s_last = (t == (unsigned)nblocks - 1) ? 1u : 0u;
     }
     __syncthreads();
     if (!s_last) return;
     constexpr int PER_MAX = 6;
-    E2 a[PER_MAX];
+    for (int v0 = 0; v0 < per; v0 += PER_MAX) {
+        E2 a[PER_MAX];
 #pragma unroll
-    for (int v = 0; v < PER_MAX; v++) a[v] = e2_zero();
-    for (int b = threadIdx.x; b < (int)gridDim.x; b += blockDim.x) {
-        E2 t[PER_MAX];
+        for (int v = 0; v < PER_MAX; v++) a[v] = e2_zero();
+        for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
+            E2 t[PER_MAX];
 #pragma unroll
-        for (int v = 0; v < PER_MAX; v++) if (v < per) t[v] = part_load(p + (size_t)b * per + v);  // all loads in flight together
+            for (int v = 0; v < PER_MAX; v++) if (v0 + v < per) t[v] = part_load(p + (size_t)b * per + v0 + v);  // all loads in flight together
 #pragma unroll
-        for (int v = 0; v < PER_MAX; v++) if (v < per) a[v] = e2_add(a[v], t[v]);
-    }
+            for (int v = 0; v < PER_MAX; v++) if (v0 + v < per) a[v] = e2_add(a[v], t[v]);
+        }
 #pragma unroll
-    for (int v = 0; v < PER_MAX; v++) {
-        if (v < per) {
-            E2 r = block_sum_n(a[v], sm);
-            if (threadIdx.x == 0) out[v] = r;
+        for (int v = 0; v < PER_MAX; v++) {
+            if (v0 + v < per) {
+                E2 r = block_sum_n(a[v], sm);
+                if (threadIdx.x == 0) out[v0 + v] = r;
+            }
         }
     }
     if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
@@ -513,37 +528,141 @@ __global__ __launch_bounds__(256) void k_st_step2(const StJob* __restrict__ jobs
     }
     if (gridDim.x > 1) finish_partials(part, 6, tickets_of(partials) + blockIdx.y * 32, res + J.sums_slot + (size_t)rd * 3, sm);
 }
-// all rounds with half <= 2^h_log2 of every listed job, one workgroup per job
+// ---- small rounds: one wave per pair index j, lanes along the tables ---------------------------------------------
+// For the rounds where the table index is the long axis (a few j, 25..50 table pairs) the per-j sums over the
+// tables are wave reductions (__shfl, no LDS, no barrier). `in` / `out` may be global or LDS (generic pointers).
+// Pair index jl of this call reads entry (in_j0 + jl) of a table laid out for in_half pairs and writes entry
+// (out_j0 + jl) of a table laid out for out_half = (number of pairs of this round) entries.
+template <int KIND, typename T, bool FIRST>
+__device__ __forceinline__ void sc_round_small(const T* in, size_t in_stride, size_t in_j0, size_t in_half, E2* out, size_t out_stride,
+                                               size_t out_j0, size_t out_half, size_t j_count, int ntab, E2 r,
+                                               const E2* __restrict__ pw, const E2* __restrict__ pwr, E2* acc, bool p0_only) {
+    using V = Val<T>;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, W = blockDim.x >> 6;
+    for (size_t jl = wave; jl < j_count; jl += W) {
+        const size_t j = in_j0 + jl;
+        const size_t jo = dpos(out_j0 + jl, out_half);
+        if constexpr (KIND == SC_GRANDPROD) {
+            E2 s0 = e2_zero(), s2 = e2_zero(), s3 = e2_zero();
+            T p0 = V::zero(), p2 = V::zero(), p3 = V::zero();
+            const int nb = ntab >> 1;
+            for (int i = lane; i < nb; i += 64) {
+                T xl, yl, xr, yr;
+                load_xy<T, FIRST>(in + (size_t)(2 * i) * in_stride, j, in_half, xl, yl);
+                load_xy<T, FIRST>(in + (size_t)(2 * i + 1) * in_stride, j, in_half, xr, yr);
+                T dl = V::sub(yl, xl), dr = V::sub(yr, xr);
+                if (i == 0) { p0 = xl; p2 = V::add(yl, dl); p3 = V::add(p2, dl); }
+                const bool summed = !(p0_only && i == 0);
+                if constexpr (FIRST) {
+                    E2 gm = pw[i];
+                    if (summed) {
+                        s0 = e2_add(s0, V::scale(gm, V::mul(xl, xr)));
+                        s2 = e2_add(s2, V::scale(gm, V::mul(yl, yr)));
+                        s3 = e2_add(s3, V::scale(gm, V::mul(dl, dr)));
+                    }
+                    store_e2(out + (size_t)(2 * i) * out_stride + jo, e2_add(V::scale(gm, xl), V::scale(pwr[i], dl)));
+                } else {
+                    if (summed) {
+                        s0 = e2_add(s0, V::lift(V::mul(xl, xr)));
+                        s2 = e2_add(s2, V::lift(V::mul(yl, yr)));
+                        s3 = e2_add(s3, V::lift(V::mul(dl, dr)));
+                    }
+                    store_e2(out + (size_t)(2 * i) * out_stride + jo, V::fold(xl, dl, r));
+                }
+                store_e2(out + (size_t)(2 * i + 1) * out_stride + jo, V::fold(xr, dr, r));
+            }
+            s0 = wave_sum(s0); s2 = wave_sum(s2); s3 = wave_sum(s3);
+            if (lane == 0) gp_combine(s0, s2, s3, V::lift(p0), V::lift(p2), V::lift(p3), acc[0], acc[1], acc[2]);
+        } else {
+            T s0 = V::zero(), s2 = V::zero(), p0 = V::zero(), p2 = V::zero();
+            for (int i = lane; i < ntab; i += 64) {
+                T x, y;
+                load_xy<T, FIRST>(in + (size_t)i * in_stride, j, in_half, x, y);
+                T d = V::sub(y, x);
+                T v2 = V::add(y, d);
+                if (i == 0) { p0 = x; p2 = v2; }
+                if constexpr (FIRST) {
+                    u64 m = pw[i].c0;
+                    if constexpr (std::is_same<T, u64>::value) {
+                        s0 = gl_add(s0, gl_mul(m, x));
+                        s2 = gl_add(s2, gl_mul(m, v2));
+                        store_e2(out + (size_t)i * out_stride + jo, e2_add_f(e2_mul_f(pwr[i], d), gl_mul(m, x)));
+                    } else {
+                        s0 = e2_add(s0, e2_mul_f(x, m));
+                        s2 = e2_add(s2, e2_mul_f(v2, m));
+                        store_e2(out + (size_t)i * out_stride + jo, e2_mul_f(V::fold(x, d, r), m));
+                    }
+                } else {
+                    s0 = V::add(s0, x);
+                    s2 = V::add(s2, v2);
+                    store_e2(out + (size_t)i * out_stride + jo, V::fold(x, d, r));
+                }
+            }
+            E2 t0 = wave_sum(V::lift(s0)), t2 = wave_sum(V::lift(s2));
+            if (lane == 0) {
+                acc[0] = e2_add(acc[0], e2_mul(V::lift(p0), t0));
+                acc[1] = e2_add(acc[1], e2_mul(V::lift(p2), t2));
+            }
+        }
+    }
+}
+
+// `nrounds` consecutive rounds of every item; workgroup (chunk k, item): see StItem / st_chunk in kernels.hpp.
+// Dynamic LDS: [16 block-sum slots][ntab * 2^c E2][ntab * 2^(c-1) E2] (intermediate folded tables, ping-pong).
 template <int KIND>
-__global__ __launch_bounds__(1024) void k_st_tail(const StJob* __restrict__ jobs, const int* __restrict__ list, int h_log2,
-                                                  const E2* __restrict__ chal, E2* __restrict__ res) {
+__global__ __launch_bounds__(512) void k_st_chunk(const StJob* __restrict__ jobs, const StItem* __restrict__ items, int lds_ntab,
+                                                   const E2* __restrict__ chal, E2* __restrict__ partials, E2* __restrict__ res) {
     constexpr int NV = KIND == SC_GRANDPROD ? 3 : 2;
-    const StJob& J = jobs[list[blockIdx.y]];
+    const StItem& I = items[blockIdx.y];
+    if ((int)blockIdx.x >= I.nchunks) return;
+    const StJob& J = jobs[I.job];
     E2* sm = dyn_lds;
-    E2* red = dyn_lds + 16;
-    const int bd_log2 = 31 - __clz((int)blockDim.x);
-    int rd = J.nvars - 1 - h_log2;
-    if (rd < 0) rd = 0;
-    const void* in = J.tail_in; size_t in_stride = J.tail_in_stride;
-    for (; rd < J.nvars; rd++) {
-        const int hl = J.nvars - 1 - rd;
-        const size_t half = (size_t)1 << hl;
-        const int jb_log2 = hl < bd_log2 ? hl : bd_log2;
-        E2* out = rd == J.nvars - 1 ? J.final_out : (in == (const void*)J.buf[0] ? J.buf[1] : J.buf[0]);
-        E2 r = chal[J.r_off + rd];
-        E2 acc[NV];
+    E2* scratch[2];
+    scratch[0] = dyn_lds + 16;
+    scratch[1] = scratch[0] + ((size_t)lds_ntab << ST_CHUNK_ROUNDS >> 1);
+    const int R = I.nrounds, c = I.c_log2;
+    const bool p0_only = J.p0_only != 0;
+    const int per = R * NV;
+    E2* part = partials + (size_t)blockIdx.y * ((size_t)(1 << ST_CHUNK_ROUNDS) * ST_CHUNK_ROUNDS * NV);  // nchunks <= 2^ST_CHUNK_ROUNDS
+    const void* in = I.in;
+    size_t in_stride = I.in_stride;
+    size_t in_j0 = (size_t)blockIdx.x << c, in_half = (size_t)1 << (J.nvars - 1 - I.rd);
+#pragma unroll 1
+    for (int u = 0; u < R; u++) {
+        const int rd = I.rd + u;
+        const size_t jc = (size_t)1 << (c - u);          // pairs of this chunk in this round
+        const bool last = u == R - 1;
+        E2* out; size_t out_stride, out_j0, out_half;
+        if (last) { out = I.out; out_half = (size_t)1 << (J.nvars - 1 - rd); out_stride = out_half; out_j0 = (size_t)blockIdx.x << (c - u); }
+        else { out = scratch[u & 1]; out_half = jc; out_stride = jc; out_j0 = 0; }
+        const E2 r = chal[J.r_off + rd];
+        E2 a[NV];
 #pragma unroll
-        for (int t = 0; t < NV; t++) acc[t] = e2_zero();
-        if (rd == 0 && J.base) sc_round_body<KIND, u64, true>(reinterpret_cast<const u64*>(in), in_stride, out, half, J.ntab, half, r, J.pw, J.pwr, jb_log2, red, acc, 0, 1, J.p0_only != 0);
-        else if (rd == 0) sc_round_body<KIND, E2, true>(reinterpret_cast<const E2*>(in), in_stride, out, half, J.ntab, half, r, J.pw, J.pwr, jb_log2, red, acc, 0, 1, J.p0_only != 0);
-        else sc_round_body<KIND, E2, false>(reinterpret_cast<const E2*>(in), in_stride, out, half, J.ntab, half, r, J.pw, J.pwr, jb_log2, red, acc, 0, 1, J.p0_only != 0);
+        for (int t = 0; t < NV; t++) a[t] = e2_zero();
+        if (rd == 0 && J.base) sc_round_small<KIND, u64, true>(reinterpret_cast<const u64*>(in), in_stride, in_j0, in_half, out, out_stride, out_j0, out_half, jc, J.ntab, r, J.pw, J.pwr, a, p0_only);
+        else if (rd == 0) sc_round_small<KIND, E2, true>(reinterpret_cast<const E2*>(in), in_stride, in_j0, in_half, out, out_stride, out_j0, out_half, jc, J.ntab, r, J.pw, J.pwr, a, p0_only);
+        else sc_round_small<KIND, E2, false>(reinterpret_cast<const E2*>(in), in_stride, in_j0, in_half, out, out_stride, out_j0, out_half, jc, J.ntab, r, J.pw, J.pwr, a, p0_only);
 #pragma unroll
         for (int t = 0; t < NV; t++) {
-            E2 s = block_sum_n(acc[t], sm);
-            if (threadIdx.x == 0) res[J.sums_slot + (size_t)rd * NV + t] = s;
+            E2 s = block_sum_n((threadIdx.x & 63) == 0 ? a[t] : e2_zero(), sm);   // also the barrier that completes the folded chunk in LDS
+            if (threadIdx.x == 0) {
+                if (I.nchunks == 1) res[J.sums_slot + (size_t)rd * NV + t] = s;
+                else part_store(part + (size_t)blockIdx.x * per + u * NV + t, s);
+            }
         }
-        __syncthreads();  // folded table (global, same workgroup) visible before the next round reads it
-        in = out; in_stride = half;
+        __syncthreads();
+        in = out; in_stride = out_stride; in_j0 = 0; in_half = jc >> 1;
+    }
+    if (I.nchunks > 1) finish_partials(part, per, tickets_of(partials) + blockIdx.y * 32, res + J.sums_slot + (size_t)I.rd * NV, sm, I.nchunks);
+}
+void st_chunk(hipStream_t st, int kind, const StJob* jobs, const StItem* items, int nitems, int max_chunks, int max_ntab,
+              const E2* chal, E2* partials, E2* res) {
+    const size_t lds = (16 + ((size_t)max_ntab << ST_CHUNK_ROUNDS >> 1) + ((size_t)max_ntab << ST_CHUNK_ROUNDS >> 2)) * sizeof(E2);
+    dim3 grid(max_chunks, nitems);
+    if (kind == SC_GRANDPROD) {
+        k_st_chunk<SC_GRANDPROD><<<grid, 512, lds, st>>>(jobs, items, max_ntab, chal, partials, res);
+    } else {
+        k_st_chunk<SC_COLLATION><<<grid, 512, lds, st>>>(jobs, items, max_ntab, chal, partials, res);
     }
 }
 
@@ -575,15 +694,6 @@ int st_step2(hipStream_t st, const StJob* jobs, const StItem* items, int njobs, 
     k_st_step2<<<dim3(gx, njobs), 256, sc_lds_bytes(0, 256), st>>>(jobs, items, h_log2, chal, partials, res);
     return gx;
 }
-void st_tail(hipStream_t st, int kind, const StJob* jobs, const int* list, int njobs, int h_log2, const E2* chal, E2* res) {
-    const int nv = kind == SC_GRANDPROD ? 3 : 2;
-    const int bd = 1024;
-    size_t lds = sc_lds_bytes(nv, bd);
-    dim3 grid(1, njobs);
-    if (kind == SC_GRANDPROD) k_st_tail<SC_GRANDPROD><<<grid, bd, lds, st>>>(jobs, list, h_log2, chal, res);
-    else k_st_tail<SC_COLLATION><<<grid, bd, lds, st>>>(jobs, list, h_log2, chal, res);
-}
-
 // ---- PRODSUM: g = sum_i a_i * b_i (Libra / zkCNN reductions), batched over independent instances -----
 // Round rd of job J: inputs are a[i]/b[i] (rd = 0; a in the base field) or the ping-pong buffers; table i of
 // a buffer sits at buf + i * (current length).

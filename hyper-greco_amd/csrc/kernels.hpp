@@ -41,8 +41,6 @@ struct StJob {
     size_t in_stride;
     E2* buf[2];        // ping-pong storage for folded tables (ntab * len/2, ntab * len/4)
     E2* final_out;     // ntab folded scalars
-    const void* tail_in;     // input of the first round the tail launch runs (host-planned), stride tail_in_stride
-    size_t tail_in_stride;
     int kind, ntab, nvars, base;
     int p0_only;       // grand product on a subset of the batch (multi-GPU): pair 0 only supplies p_0, its product is not summed
     size_t r_off;      // chain index of round 0's challenge
@@ -56,15 +54,21 @@ struct StItem {
     const void* in;
     size_t in_stride;
     E2* out;           // folded tables of the (last) round, stride = its half length
+    // chunk launches only (st_chunk): rounds [rd, rd + nrounds) run inside one workgroup per chunk of 2^c_log2 pair indices
+    int rd, nrounds, c_log2, nchunks;
 };
 // step: every item runs its job's round with half = 2^h_log2
 int st_step(hipStream_t st, int kind, bool base, const StJob* jobs, const StItem* items, int nitems, int h_log2, const E2* chal,
             E2* partials, E2* res);
 // fused step (grand-product shape, folded Ext2 inputs): every item runs its job's rounds with half = 2^h_log2 and 2^(h_log2-1)
 int st_step2(hipStream_t st, const StJob* jobs, const StItem* items, int nitems, int h_log2, const E2* chal, E2* partials, E2* res);
+// chunk step: every item runs `nrounds` consecutive rounds; workgroup k owns pair indices [k 2^c, (k+1) 2^c) of the
+// first round (nrounds <= c + 1) and keeps the intermediate folded tables in LDS, so the small rounds of all jobs
+// take one launch per ST_CHUNK_ROUNDS rounds instead of one launch per round. With nchunks = 1 this is the tail.
+constexpr int ST_CHUNK_ROUNDS = 5;
+void st_chunk(hipStream_t st, int kind, const StJob* jobs, const StItem* items, int nitems, int max_chunks, int max_ntab,
+              const E2* chal, E2* partials, E2* res);
 constexpr int ST_STEP2_MIN_H = 9;  // fused steps need 2^h_log2 >= 2 * 256 (one pair index per thread, lane pairs share the second round)
-// tail: every listed job runs all its rounds with half <= 2^h_log2 in one workgroup
-void st_tail(hipStream_t st, int kind, const StJob* jobs, const int* list, int njobs, int h_log2, const E2* chal, E2* res);
 
 // PRODSUM sum-check instance (g = sum_i a_i b_i), device-visible descriptor; instances of equal nvars are
 // batched over grid.y so that the 2k+1 independent FFT-node reductions etc. advance in lock step.

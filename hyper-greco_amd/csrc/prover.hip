@@ -337,39 +337,40 @@ struct Prover {
         std::vector<Launch> plan;
         std::vector<const void*> cur_in(nj);
         std::vector<size_t> cur_stride(nj);
-        std::vector<int> done_h(nj, 1 << 30);  // smallest half-length (log2) already scheduled
-        for (int q = 0; q < nj; q++) { cur_in[q] = st_jobs[q].in; cur_stride[q] = st_jobs[q].in_stride; }
+        std::vector<int> next_h(nj);  // half-length (log2) of the job's next unscheduled round
+        for (int q = 0; q < nj; q++) { cur_in[q] = st_jobs[q].in; cur_stride[q] = st_jobs[q].in_stride; next_h[q] = st_jobs[q].nvars - 1; }
         auto next_out = [&](int q) { return cur_in[q] == (const void*)st_jobs[q].buf[0] ? st_jobs[q].buf[1] : st_jobs[q].buf[0]; };
+        constexpr int CR = dev::ST_CHUNK_ROUNDS;
+        // rounds with half <= 2^H_SMALL run in chunk launches of CR rounds each: the last CR rounds always (one
+        // workgroup per job), the CR before them too when HG_CHUNK_A=1 (32 workgroups per job; measured slower than
+        // per-round launches on MI355X)
+        static const bool chunk_a = [] { const char* e = getenv("HG_CHUNK_A"); return e && e[0] == '1'; }();
+        const int H_SMALL = chunk_a ? 2 * CR - 1 : CR - 1;
         for (int kind : {dev::SC_COLLATION, dev::SC_GRANDPROD}) {
             int max_h = -1;
-            size_t per_j = 1;
-            for (auto& J : st_jobs) if (J.kind == kind) {
-                max_h = std::max(max_h, J.nvars - 1);
-                per_j = std::max(per_j, kind == dev::SC_GRANDPROD ? (size_t)J.ntab / 2 : (size_t)J.ntab);
-            }
+            for (auto& J : st_jobs) if (J.kind == kind) max_h = std::max(max_h, J.nvars - 1);
             if (max_h < 0) continue;
-            int h_tail = 0;
-            while (h_tail + 1 <= max_h && ((size_t)2 << h_tail) * per_j <= TAIL_ITEMS) h_tail++;
             // fused pairs (h, h-1) start at the half-length of the largest job's first Ext2 round
             const int pair_parity = (max_h - 1) & 1;
-            for (int h = max_h; h > h_tail; h--) {
+            for (int h = max_h; h > H_SMALL; h--) {
                 Launch lb{kind, true, h, false, 1, {}}, le{kind, false, h, false, 1, {}}, l2{kind, false, h, false, 2, {}};
-                const bool pair_start = fuse2 && kind == dev::SC_GRANDPROD && (h & 1) == pair_parity && h - 1 > h_tail &&
+                const bool pair_start = fuse2 && kind == dev::SC_GRANDPROD && (h & 1) == pair_parity && h - 1 > H_SMALL &&
                                         h >= std::max(dev::ST_STEP2_MIN_H, 13);
                 for (int q = 0; q < nj; q++) {
                     const dev::StJob& J = st_jobs[q];
-                    if (J.kind != kind || J.nvars - 1 < h || done_h[q] <= h) continue;
+                    if (J.kind != kind || next_h[q] != h) continue;
                     const bool first = J.nvars - 1 == h;
                     dev::StItem it;
-                    it.job = q; it.pad = 0; it.in = cur_in[q]; it.in_stride = cur_stride[q];
+                    memset(&it, 0, sizeof(it));
+                    it.job = q; it.in = cur_in[q]; it.in_stride = cur_stride[q];
                     it.out = first ? J.buf[0] : next_out(q);
                     if (!first && pair_start) {
                         l2.items.push_back(it);
-                        done_h[q] = h - 1;
+                        next_h[q] = h - 2;
                         cur_in[q] = it.out; cur_stride[q] = (size_t)1 << (h - 1);
                     } else {
                         (first && J.base ? lb : le).items.push_back(it);
-                        done_h[q] = h;
+                        next_h[q] = h - 1;
                         cur_in[q] = it.out; cur_stride[q] = (size_t)1 << h;
                     }
                 }
@@ -377,29 +378,37 @@ struct Prover {
                 if (!le.items.empty()) plan.push_back(le);
                 if (!l2.items.empty()) plan.push_back(l2);
             }
-            Launch lt{kind, false, h_tail, true, 1, {}};
-            for (int q = 0; q < nj; q++) if (st_jobs[q].kind == kind) {
-                dev::StItem it; it.job = q; it.pad = 0; it.in = cur_in[q]; it.in_stride = cur_stride[q]; it.out = nullptr;
-                lt.items.push_back(it);
-                st_jobs[q].tail_in = cur_in[q]; st_jobs[q].tail_in_stride = cur_stride[q];
+            // chunk launches: rounds with half 2^(H_SMALL) .. 2^CR (32 workgroups per job), then 2^(CR-1) .. 1 (one workgroup per job)
+            for (int lo : {CR, 0}) {
+                if (lo > H_SMALL) continue;
+                Launch lc{kind, false, lo, true, CR, {}};
+                for (int q = 0; q < nj; q++) {
+                    const dev::StJob& J = st_jobs[q];
+                    if (J.kind != kind || next_h[q] < lo) continue;
+                    const int hs = next_h[q];
+                    dev::StItem it;
+                    memset(&it, 0, sizeof(it));
+                    it.job = q; it.in = cur_in[q]; it.in_stride = cur_stride[q];
+                    it.rd = J.nvars - 1 - hs; it.nrounds = hs - lo + 1; it.c_log2 = it.nrounds - 1; it.nchunks = 1 << (hs - it.c_log2);
+                    it.out = lo == 0 ? J.final_out : (it.rd == 0 ? J.buf[0] : next_out(q));
+                    lc.items.push_back(it);
+                    next_h[q] = lo - 1;
+                    cur_in[q] = it.out; cur_stride[q] = (size_t)1 << lo;
+                }
+                if (!lc.items.empty()) plan.push_back(lc);
             }
-            plan.push_back(lt);
         }
         dev::StJob* d_jobs = ctx->alloc_n<dev::StJob>(nj);
         hip_check(hipMemcpyAsync(d_jobs, stage(st_jobs.data(), (size_t)nj * sizeof(dev::StJob)), (size_t)nj * sizeof(dev::StJob),
                                  hipMemcpyHostToDevice, st), "upload jobs");
         std::vector<dev::StItem> flat;
-        std::vector<int> flat_jobs;
         std::vector<size_t> offs;
         for (auto& L : plan) {
             offs.push_back(flat.size());
             flat.insert(flat.end(), L.items.begin(), L.items.end());
-            for (auto& it : L.items) flat_jobs.push_back(it.job);
         }
         dev::StItem* d_items = ctx->alloc_n<dev::StItem>(flat.size());
         hip_check(hipMemcpyAsync(d_items, stage(flat.data(), flat.size() * sizeof(dev::StItem)), flat.size() * sizeof(dev::StItem), hipMemcpyHostToDevice, st), "upload step items");
-        int* d_list = ctx->alloc_n<int>(flat_jobs.size());
-        hip_check(hipMemcpyAsync(d_list, stage(flat_jobs.data(), flat_jobs.size() * sizeof(int)), flat_jobs.size() * sizeof(int), hipMemcpyHostToDevice, st), "upload job lists");
         auto round_bytes = [&](const dev::StJob& J, int rd) {
             size_t half = (size_t)1 << (J.nvars - 1 - rd);
             return (double)J.ntab * (2.0 * half * ((J.base && rd == 0) ? 8 : 16) + half * 16.0);
@@ -410,9 +419,15 @@ struct Prover {
                 const int cnt = (int)std::min<size_t>(MAX_BATCH, L.items.size() - o);
                 double bytes = 0;
                 if (L.tail) {
-                    for (int q = 0; q < cnt; q++) { const dev::StJob& J = st_jobs[L.items[o + q].job]; for (int rd = std::max(0, J.nvars - 1 - L.h_log2); rd < J.nvars; rd++) bytes += round_bytes(J, rd); }
+                    int max_chunks = 1, max_ntab = 1;
+                    for (int q = 0; q < cnt; q++) {
+                        const dev::StItem& it = L.items[o + q];
+                        const dev::StJob& J = st_jobs[it.job];
+                        for (int k = 0; k < it.nrounds; k++) bytes += round_bytes(J, it.rd + k);
+                        max_chunks = std::max(max_chunks, it.nchunks); max_ntab = std::max(max_ntab, J.ntab);
+                    }
                     ctx->prof_begin(cls_tail, bytes);
-                    dev::st_tail(st, L.kind, d_jobs, d_list + offs[li] + o, cnt, L.h_log2, ctx->d_chal, d_res());
+                    dev::st_chunk(st, L.kind, d_jobs, d_items + offs[li] + o, cnt, max_chunks, max_ntab, ctx->d_chal, partials, d_res());
                     ctx->prof_end();
                 } else {
                     for (int q = 0; q < cnt; q++) {
