@@ -395,34 +395,45 @@ __device__ __forceinline__ void st_io(const StJob& J, int rd, const void*& in, s
     out = rd == J.nvars - 1 ? J.final_out : J.buf[rd & 1];
 }
 
-// one step of the size-synchronised schedule: every item runs its job's round with half = 2^h_log2
+// The items of a launch share a 1-D grid: item y owns workgroups [blk0, blk0 + nblk). Binary search (uniform).
+__device__ __forceinline__ int find_item(const StItem* __restrict__ items, int nitems, int blk) {
+    int lo = 0, hi = nitems - 1;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (items[mid].blk0 <= blk) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+// one step: every item runs its job's round with half = 2^item.h_log2
 template <int KIND, typename T>
-__global__ __launch_bounds__(256) void k_st_step(const StJob* __restrict__ jobs, const StItem* __restrict__ items, int h_log2,
-                                                 const E2* __restrict__ chal, int jb_log2, E2* __restrict__ partials,
-                                                 E2* __restrict__ res) {
+__global__ __launch_bounds__(256) void k_st_step(const StJob* __restrict__ jobs, const StItem* __restrict__ items, int nitems,
+                                                 const E2* __restrict__ chal, E2* __restrict__ partials, E2* __restrict__ res) {
     constexpr int NV = KIND == SC_GRANDPROD ? 3 : 2;
-    const StItem& I = items[blockIdx.y];
+    const int y = find_item(items, nitems, blockIdx.x);
+    const StItem& I = items[y];
     const StJob& J = jobs[I.job];
+    const int h_log2 = I.h_log2, jb_log2 = I.jb_log2;
     const int rd = J.nvars - 1 - h_log2;
     const size_t half = (size_t)1 << h_log2;
+    const int nblocks = I.nblk, bx = (int)blockIdx.x - I.blk0;
     const void* in = I.in; const size_t in_stride = I.in_stride; E2* out = I.out;
     E2* sm = dyn_lds;
     E2* red = dyn_lds + 16;
     E2 acc[NV];
 #pragma unroll
     for (int t = 0; t < NV; t++) acc[t] = e2_zero();
-    if (rd == 0) sc_round_body<KIND, T, true>(reinterpret_cast<const T*>(in), in_stride, out, half, J.ntab, half, chal[J.r_off + rd], J.pw, J.pwr, jb_log2, red, acc, blockIdx.x, gridDim.x, J.p0_only != 0);
-    else sc_round_body<KIND, T, false>(reinterpret_cast<const T*>(in), in_stride, out, half, J.ntab, half, chal[J.r_off + rd], J.pw, J.pwr, jb_log2, red, acc, blockIdx.x, gridDim.x, J.p0_only != 0);
-    E2* part = partials + (size_t)blockIdx.y * SC_MAX_BLOCKS * NV;
+    if (rd == 0) sc_round_body<KIND, T, true>(reinterpret_cast<const T*>(in), in_stride, out, half, J.ntab, half, chal[J.r_off + rd], J.pw, J.pwr, jb_log2, red, acc, bx, nblocks, J.p0_only != 0);
+    else sc_round_body<KIND, T, false>(reinterpret_cast<const T*>(in), in_stride, out, half, J.ntab, half, chal[J.r_off + rd], J.pw, J.pwr, jb_log2, red, acc, bx, nblocks, J.p0_only != 0);
+    E2* part = partials + (size_t)y * SC_MAX_BLOCKS * NV;
 #pragma unroll
     for (int t = 0; t < NV; t++) {
         E2 s = block_sum_n(acc[t], sm);
         if (threadIdx.x == 0) {
-            if (gridDim.x == 1) res[J.sums_slot + (size_t)rd * NV + t] = s;
-            else part_store(part + (size_t)blockIdx.x * NV + t, s);
+            if (nblocks == 1) res[J.sums_slot + (size_t)rd * NV + t] = s;
+            else part_store(part + (size_t)bx * NV + t, s);
         }
     }
-    if (gridDim.x > 1) finish_partials(part, NV, tickets_of(partials) + blockIdx.y * 32, res + J.sums_slot + (size_t)rd * NV, sm);
+    if (nblocks > 1) finish_partials(part, NV, tickets_of(partials) + y * 32, res + J.sums_slot + (size_t)rd * NV, sm, nblocks);
 }
 // ---- two grand-product rounds in one pass ------------------------------------------------------------------
 // Thread j (one per pair index of round t, jb = 8) does round t as in sc_round_body; the folded values T'[j] stay in
@@ -457,12 +468,16 @@ __device__ __forceinline__ E2 gp_combine(E2 P0, E2 P1, E2 Pi, E2 p0, E2 p2, E2 p
     a2 = e2_add(a2, e2_mul(q3, p3));
     return q2;
 }
-__global__ __launch_bounds__(256) void k_st_step2(const StJob* __restrict__ jobs, const StItem* __restrict__ items, int h_log2,
+__global__ __launch_bounds__(256) void k_st_step2(const StJob* __restrict__ jobs, const StItem* __restrict__ items, int nitems,
                                                   const E2* __restrict__ chal, E2* __restrict__ partials, E2* __restrict__ res) {
-    const StItem& I = items[blockIdx.y];
+    const int y = find_item(items, nitems, blockIdx.x);
+    const StItem& I = items[y];
     const StJob& J = jobs[I.job];
+    const int h_log2 = I.h_log2;
     const int rd = J.nvars - 1 - h_log2;
     const size_t half = (size_t)1 << h_log2, half2 = half >> 1;
+    const size_t ntiles = half >> 8;
+    const int nblocks = I.nblk, bx = (int)blockIdx.x - I.blk0;
     const E2* __restrict__ in = reinterpret_cast<const E2*>(I.in);
     const size_t in_stride = I.in_stride;
     E2* __restrict__ out = I.out;
@@ -477,8 +492,7 @@ __global__ __launch_bounds__(256) void k_st_step2(const StJob* __restrict__ jobs
     E2 acc[6];
 #pragma unroll
     for (int t = 0; t < 6; t++) acc[t] = e2_zero();
-    const size_t ntiles = half >> 8;
-    for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (size_t tile = bx; tile < ntiles; tile += nblocks) {
         const size_t j = (tile << 8) + tid;
         const size_t j2 = j >> 1;
         const size_t jo2 = dpos(j2, half2);
@@ -517,16 +531,16 @@ __global__ __launch_bounds__(256) void k_st_step2(const StJob* __restrict__ jobs
         if (!odd) gp_combine(mine, other, e2(ip, iq), q0, q2, q3, acc[3], acc[4], acc[5]);
     }
     E2* sm = dyn_lds;
-    E2* part = partials + (size_t)blockIdx.y * SC_MAX_BLOCKS * 6;
+    E2* part = partials + (size_t)y * SC_MAX_BLOCKS * 6;
 #pragma unroll
     for (int t = 0; t < 6; t++) {
         E2 s = block_sum_n(acc[t], sm);
         if (threadIdx.x == 0) {
-            if (gridDim.x == 1) res[J.sums_slot + (size_t)rd * 3 + t] = s;
-            else part_store(part + (size_t)blockIdx.x * 6 + t, s);
+            if (nblocks == 1) res[J.sums_slot + (size_t)rd * 3 + t] = s;
+            else part_store(part + (size_t)bx * 6 + t, s);
         }
     }
-    if (gridDim.x > 1) finish_partials(part, 6, tickets_of(partials) + blockIdx.y * 32, res + J.sums_slot + (size_t)rd * 3, sm);
+    if (nblocks > 1) finish_partials(part, 6, tickets_of(partials) + y * 32, res + J.sums_slot + (size_t)rd * 3, sm, nblocks);
 }
 // ---- small rounds: one wave per pair index j, lanes along the tables ---------------------------------------------
 // For the rounds where the table index is the long axis (a few j, 25..50 table pairs) the per-j sums over the
@@ -668,31 +682,38 @@ void st_chunk(hipStream_t st, int kind, const StJob* jobs, const StItem* items, 
 
 static inline size_t sc_lds_bytes(int nv, int bd) { return (16 + (size_t)nv * bd) * sizeof(E2); }
 
-int st_step(hipStream_t st, int kind, bool base, const StJob* jobs, const StItem* items, int njobs, int h_log2, const E2* chal,
-            E2* partials, E2* res) {
-    const size_t half = (size_t)1 << h_log2;
-    int jb_log2 = 8;
-    while (jb_log2 > 2 && ((size_t)half * njobs << (8 - jb_log2)) < st_min_threads()) jb_log2--;
-    if (jb_log2 > h_log2) jb_log2 = h_log2;
-    size_t ntiles = half >> jb_log2;
-    int gx = (int)(ntiles > (size_t)st_max_blocks() ? st_max_blocks() : ntiles);
-    const int nv = kind == SC_GRANDPROD ? 3 : 2;
-    size_t lds = sc_lds_bytes(jb_log2 == 8 ? 0 : nv, 256);
-    dim3 grid(gx, njobs);
-    if (kind == SC_GRANDPROD) {
-        if (base) k_st_step<SC_GRANDPROD, u64><<<grid, 256, lds, st>>>(jobs, items, h_log2, chal, jb_log2, partials, res);
-        else k_st_step<SC_GRANDPROD, E2><<<grid, 256, lds, st>>>(jobs, items, h_log2, chal, jb_log2, partials, res);
-    } else {
-        if (base) k_st_step<SC_COLLATION, u64><<<grid, 256, lds, st>>>(jobs, items, h_log2, chal, jb_log2, partials, res);
-        else k_st_step<SC_COLLATION, E2><<<grid, 256, lds, st>>>(jobs, items, h_log2, chal, jb_log2, partials, res);
+int st_plan_blocks(StItem* items, int nitems, bool rounds2) {
+    // total work of the launch decides how finely the small items are split along the tables (jb < 8)
+    size_t total = 0;
+    for (int q = 0; q < nitems; q++) total += (size_t)1 << items[q].h_log2;
+    int blk = 0;
+    for (int q = 0; q < nitems; q++) {
+        StItem& I = items[q];
+        int jb = 8;
+        if (!rounds2) while (jb > 2 && (total << (8 - jb)) < st_min_threads()) jb--;
+        if (jb > I.h_log2) jb = I.h_log2;
+        const size_t ntiles = ((size_t)1 << I.h_log2) >> jb;
+        I.jb_log2 = jb;
+        I.blk0 = blk;
+        I.nblk = (int)std::min<size_t>(ntiles, (size_t)st_max_blocks());
+        blk += I.nblk;
     }
-    return gx;
+    return blk;
 }
-int st_step2(hipStream_t st, const StJob* jobs, const StItem* items, int njobs, int h_log2, const E2* chal, E2* partials, E2* res) {
-    const size_t ntiles = ((size_t)1 << h_log2) >> 8;
-    int gx = (int)(ntiles > (size_t)st_max_blocks() ? st_max_blocks() : ntiles);
-    k_st_step2<<<dim3(gx, njobs), 256, sc_lds_bytes(0, 256), st>>>(jobs, items, h_log2, chal, partials, res);
-    return gx;
+void st_step(hipStream_t st, int kind, bool base, const StJob* jobs, const StItem* items, int nitems, int grid, const E2* chal,
+             E2* partials, E2* res) {
+    const int nv = kind == SC_GRANDPROD ? 3 : 2;
+    const size_t lds = sc_lds_bytes(nv, 256);
+    if (kind == SC_GRANDPROD) {
+        if (base) k_st_step<SC_GRANDPROD, u64><<<grid, 256, lds, st>>>(jobs, items, nitems, chal, partials, res);
+        else k_st_step<SC_GRANDPROD, E2><<<grid, 256, lds, st>>>(jobs, items, nitems, chal, partials, res);
+    } else {
+        if (base) k_st_step<SC_COLLATION, u64><<<grid, 256, lds, st>>>(jobs, items, nitems, chal, partials, res);
+        else k_st_step<SC_COLLATION, E2><<<grid, 256, lds, st>>>(jobs, items, nitems, chal, partials, res);
+    }
+}
+void st_step2(hipStream_t st, const StJob* jobs, const StItem* items, int nitems, int grid, const E2* chal, E2* partials, E2* res) {
+    k_st_step2<<<grid, 256, sc_lds_bytes(0, 256), st>>>(jobs, items, nitems, chal, partials, res);
 }
 // ---- PRODSUM: g = sum_i a_i * b_i (Libra / zkCNN reductions), batched over independent instances -----
 // Round rd of job J: inputs are a[i]/b[i] (rd = 0; a in the base field) or the ping-pong buffers; table i of

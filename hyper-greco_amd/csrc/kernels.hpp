@@ -50,18 +50,24 @@ struct StJob {
 };
 // one (job, round) of a step launch: where the round reads and writes (host-planned ping-pong)
 struct StItem {
-    int job, pad;
+    int job;
+    int h_log2;        // this item's half length (log2): a launch may mix sizes
+    int jb_log2;       // threads along the pair index (2^jb_log2 of the 256; the rest split the tables)
+    int blk0, nblk;    // this item's workgroups are [blk0, blk0 + nblk) of the 1-D grid (planned by st_plan_blocks)
     const void* in;
     size_t in_stride;
     E2* out;           // folded tables of the (last) round, stride = its half length
     // chunk launches only (st_chunk): rounds [rd, rd + nrounds) run inside one workgroup per chunk of 2^c_log2 pair indices
     int rd, nrounds, c_log2, nchunks;
 };
-// step: every item runs its job's round with half = 2^h_log2
-int st_step(hipStream_t st, int kind, bool base, const StJob* jobs, const StItem* items, int nitems, int h_log2, const E2* chal,
-            E2* partials, E2* res);
+// Fills jb_log2 / blk0 / nblk of the items of one launch (host side, before upload); returns the grid size.
+// `rounds2`: fused two-round launch (one pair index per thread).
+int st_plan_blocks(StItem* items, int nitems, bool rounds2);
+// step: every item runs its job's round with half = 2^item.h_log2; `grid` from st_plan_blocks
+void st_step(hipStream_t st, int kind, bool base, const StJob* jobs, const StItem* items, int nitems, int grid, const E2* chal,
+             E2* partials, E2* res);
 // fused step (grand-product shape, folded Ext2 inputs): every item runs its job's rounds with half = 2^h_log2 and 2^(h_log2-1)
-int st_step2(hipStream_t st, const StJob* jobs, const StItem* items, int nitems, int h_log2, const E2* chal, E2* partials, E2* res);
+void st_step2(hipStream_t st, const StJob* jobs, const StItem* items, int nitems, int grid, const E2* chal, E2* partials, E2* res);
 // chunk step: every item runs `nrounds` consecutive rounds; workgroup k owns pair indices [k 2^c, (k+1) 2^c) of the
 // first round (nrounds <= c + 1) and keeps the intermediate folded tables in LDS, so the small rounds of all jobs
 // take one launch per ST_CHUNK_ROUNDS rounds instead of one launch per round. With nchunks = 1 this is the tail.

@@ -333,6 +333,7 @@ struct Prover {
         // launch plan: (kind, base? | fused pair?, h_log2 | tail) -> items (job, where the round reads and writes).
         // Folded tables ping-pong between the job's two buffers; the host tracks where each job's live tables are.
         static const bool fuse2 = [] { const char* e = getenv("HG_NO_FUSE2"); return !(e && e[0] == '1'); }();
+        static const int fuse_min_h = [] { const char* e = getenv("HG_FUSE_MIN_H"); return e && *e ? atoi(e) : 13; }();
         struct Launch { int kind; bool base; int h_log2; bool tail; int nrounds; std::vector<dev::StItem> items; };
         std::vector<Launch> plan;
         std::vector<const void*> cur_in(nj);
@@ -350,33 +351,42 @@ struct Prover {
             int max_h = -1;
             for (auto& J : st_jobs) if (J.kind == kind) max_h = std::max(max_h, J.nvars - 1);
             if (max_h < 0) continue;
-            // fused pairs (h, h-1) start at the half-length of the largest job's first Ext2 round
-            const int pair_parity = (max_h - 1) & 1;
-            for (int h = max_h; h > H_SMALL; h--) {
-                Launch lb{kind, true, h, false, 1, {}}, le{kind, false, h, false, 1, {}}, l2{kind, false, h, false, 2, {}};
-                const bool pair_start = fuse2 && kind == dev::SC_GRANDPROD && (h & 1) == pair_parity && h - 1 > H_SMALL &&
-                                        h >= std::max(dev::ST_STEP2_MIN_H, 13);
+            // the first rounds on base-field rows only read finished tree levels / node tables: one launch for all of them
+            {
+                Launch lall{kind, true, -1, false, 1, {}};
                 for (int q = 0; q < nj; q++) {
                     const dev::StJob& J = st_jobs[q];
-                    if (J.kind != kind || next_h[q] != h) continue;
+                    if (J.kind != kind || !J.base || next_h[q] <= H_SMALL) continue;
+                    dev::StItem it;
+                    memset(&it, 0, sizeof(it));
+                    it.job = q; it.h_log2 = next_h[q]; it.in = cur_in[q]; it.in_stride = cur_stride[q]; it.out = J.buf[0];
+                    lall.items.push_back(it);
+                    cur_in[q] = it.out; cur_stride[q] = (size_t)1 << next_h[q];
+                    next_h[q]--;
+                }
+                if (!lall.items.empty()) plan.push_back(lall);
+            }
+            // then round-synchronised: launch k runs every job's next round (or, grand product with a long enough table,
+            // its next TWO rounds) whatever the sizes; the jobs only depend on their own previous launch
+            for (;;) {
+                Launch le{kind, false, -1, false, 1, {}}, l2{kind, false, -1, false, 2, {}};
+                for (int q = 0; q < nj; q++) {
+                    const dev::StJob& J = st_jobs[q];
+                    const int h = next_h[q];
+                    if (J.kind != kind || h <= H_SMALL) continue;
                     const bool first = J.nvars - 1 == h;
                     dev::StItem it;
                     memset(&it, 0, sizeof(it));
-                    it.job = q; it.in = cur_in[q]; it.in_stride = cur_stride[q];
+                    it.job = q; it.h_log2 = h; it.in = cur_in[q]; it.in_stride = cur_stride[q];
                     it.out = first ? J.buf[0] : next_out(q);
-                    if (!first && pair_start) {
-                        l2.items.push_back(it);
-                        next_h[q] = h - 2;
-                        cur_in[q] = it.out; cur_stride[q] = (size_t)1 << (h - 1);
-                    } else {
-                        (first && J.base ? lb : le).items.push_back(it);
-                        next_h[q] = h - 1;
-                        cur_in[q] = it.out; cur_stride[q] = (size_t)1 << h;
-                    }
+                    const bool pair = fuse2 && kind == dev::SC_GRANDPROD && !first && h - 1 > H_SMALL && h >= std::max(dev::ST_STEP2_MIN_H, fuse_min_h);
+                    (pair ? l2 : le).items.push_back(it);
+                    next_h[q] = h - (pair ? 2 : 1);
+                    cur_in[q] = it.out; cur_stride[q] = (size_t)1 << (pair ? h - 1 : h);
                 }
-                if (!lb.items.empty()) plan.push_back(lb);
-                if (!le.items.empty()) plan.push_back(le);
+                if (le.items.empty() && l2.items.empty()) break;
                 if (!l2.items.empty()) plan.push_back(l2);
+                if (!le.items.empty()) plan.push_back(le);
             }
             // chunk launches: rounds with half 2^(H_SMALL) .. 2^CR (32 workgroups per job), then 2^(CR-1) .. 1 (one workgroup per job)
             for (int lo : {CR, 0}) {
@@ -403,7 +413,12 @@ struct Prover {
                                  hipMemcpyHostToDevice, st), "upload jobs");
         std::vector<dev::StItem> flat;
         std::vector<size_t> offs;
-        for (auto& L : plan) {
+        std::vector<std::vector<int>> grids(plan.size());
+        for (size_t li = 0; li < plan.size(); li++) {
+            Launch& L = plan[li];
+            if (!L.tail)
+                for (size_t o = 0; o < L.items.size(); o += MAX_BATCH)
+                    grids[li].push_back(dev::st_plan_blocks(L.items.data() + o, (int)std::min<size_t>(MAX_BATCH, L.items.size() - o), L.nrounds == 2));
             offs.push_back(flat.size());
             flat.insert(flat.end(), L.items.begin(), L.items.end());
         }
@@ -431,13 +446,15 @@ struct Prover {
                     ctx->prof_end();
                 } else {
                     for (int q = 0; q < cnt; q++) {
-                        const dev::StJob& J = st_jobs[L.items[o + q].job];
-                        for (int k = 0; k < L.nrounds; k++) bytes += round_bytes(J, J.nvars - 1 - L.h_log2 + k);
+                        const dev::StItem& it = L.items[o + q];
+                        const dev::StJob& J = st_jobs[it.job];
+                        for (int k = 0; k < L.nrounds; k++) bytes += round_bytes(J, J.nvars - 1 - it.h_log2 + k);
                     }
+                    const int grid = grids[li][o / MAX_BATCH];
                     int cls = L.kind == dev::SC_GRANDPROD ? (L.base ? cls_gp_base : cls_gp_ext) : (L.base ? cls_col_base : cls_col_ext);
                     ctx->prof_begin(cls, bytes);
-                    if (L.nrounds == 2) dev::st_step2(st, d_jobs, d_items + offs[li] + o, cnt, L.h_log2, ctx->d_chal, partials, d_res());
-                    else dev::st_step(st, L.kind, L.base, d_jobs, d_items + offs[li] + o, cnt, L.h_log2, ctx->d_chal, partials, d_res());
+                    if (L.nrounds == 2) dev::st_step2(st, d_jobs, d_items + offs[li] + o, cnt, grid, ctx->d_chal, partials, d_res());
+                    else dev::st_step(st, L.kind, L.base, d_jobs, d_items + offs[li] + o, cnt, grid, ctx->d_chal, partials, d_res());
                     ctx->prof_end();
                 }
             }
