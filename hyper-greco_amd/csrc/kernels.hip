@@ -776,32 +776,39 @@ __device__ __forceinline__ void ps_round_body(const PsJob& J, int rd, size_t hal
     a2 = e2_add(a2, we2_reduce(w2));
 }
 
-// one round of every job of a batch (grid.y = job); all jobs of a batch have the same nvars
-__global__ __launch_bounds__(256) void k_ps_one(const PsJob* __restrict__ jobs, int rd, const E2* __restrict__ chal, int jb_log2,
-                                                E2* __restrict__ partials, E2* __restrict__ res) {
-    const PsJob& J = jobs[blockIdx.y];
+// round rd of every item's job; items share a 1-D grid (item y owns workgroups [blk0, blk0 + nblk))
+__global__ __launch_bounds__(256) void k_ps_one(const PsJob* __restrict__ jobs, const PsItem* __restrict__ items, int nitems, int rd,
+                                                const E2* __restrict__ chal, E2* __restrict__ partials, E2* __restrict__ res) {
+    int lo = 0, hi = nitems - 1;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (items[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const int y = lo;
+    const PsItem& I = items[y];
+    const PsJob& J = jobs[I.job];
+    const int nblocks = I.nblk, bx = (int)blockIdx.x - I.blk0;
     E2* sm = dyn_lds;
     const size_t half = (size_t)1 << (J.nvars - 1 - rd);
     E2 r = chal[J.r_off + rd];
     E2 a0 = e2_zero(), a2 = e2_zero();
-    if (rd == 0) ps_round_body<u64>(J, rd, half, r, jb_log2, a0, a2, blockIdx.x, gridDim.x);
-    else ps_round_body<E2>(J, rd, half, r, jb_log2, a0, a2, blockIdx.x, gridDim.x);
+    if (rd == 0) ps_round_body<u64>(J, rd, half, r, I.jb_log2, a0, a2, bx, nblocks);
+    else ps_round_body<E2>(J, rd, half, r, I.jb_log2, a0, a2, bx, nblocks);
     E2 s0 = block_sum_n(a0, sm);
     E2 s2 = block_sum_n(a2, sm);
-    E2* part = partials + (size_t)blockIdx.y * SC_MAX_BLOCKS * 2;
+    E2* part = partials + (size_t)y * SC_MAX_BLOCKS * 2;
     if (threadIdx.x == 0) {
-        if (gridDim.x == 1) { res[J.sums_slot + 2 * rd] = s0; res[J.sums_slot + 2 * rd + 1] = s2; }
-        else { part_store(part + (size_t)blockIdx.x * 2, s0); part_store(part + (size_t)blockIdx.x * 2 + 1, s2); }
+        if (nblocks == 1) { res[J.sums_slot + 2 * rd] = s0; res[J.sums_slot + 2 * rd + 1] = s2; }
+        else { part_store(part + (size_t)bx * 2, s0); part_store(part + (size_t)bx * 2 + 1, s2); }
     }
-    if (gridDim.x > 1) finish_partials(part, 2, tickets_of(partials) + blockIdx.y * 32, res + J.sums_slot + 2 * rd, sm);
+    if (nblocks > 1) finish_partials(part, 2, tickets_of(partials) + y * 32, res + J.sums_slot + 2 * rd, sm, nblocks);
 }
-// rounds [rd0, nvars) of every job of a batch, one workgroup per job
-__global__ __launch_bounds__(1024) void k_ps_tail(const PsJob* __restrict__ jobs, int rd0, const E2* __restrict__ chal,
-                                                  E2* __restrict__ res) {
-    const PsJob& J = jobs[blockIdx.y];
+// rounds [tail_rd, nvars) of every job, one workgroup per job
+__global__ __launch_bounds__(1024) void k_ps_tail(const PsJob* __restrict__ jobs, const E2* __restrict__ chal, E2* __restrict__ res) {
+    const PsJob& J = jobs[blockIdx.x];
     E2* sm = dyn_lds;
     int bd_log2 = 31 - __clz((int)blockDim.x);
-    for (int rd = rd0; rd < J.nvars; rd++) {
+    for (int rd = J.tail_rd; rd < J.nvars; rd++) {
         const int hl = J.nvars - 1 - rd;
         const size_t half = (size_t)1 << hl;
         const int jb_log2 = hl < bd_log2 ? hl : bd_log2;
@@ -815,19 +822,29 @@ __global__ __launch_bounds__(1024) void k_ps_tail(const PsJob* __restrict__ jobs
         __syncthreads();
     }
 }
-int ps_round(hipStream_t st, const PsJob* jobs, int njobs, int nvars, int rd, const E2* chal, E2* partials, E2* res) {
-    const int hl = nvars - 1 - rd;
-    const size_t half = (size_t)1 << hl;
-    int jb_log2 = 8;
-    while (jb_log2 > 2 && ((size_t)half * njobs << (8 - jb_log2)) < st_min_threads()) jb_log2--;
-    if (jb_log2 > hl) jb_log2 = hl;
-    size_t ntiles = half >> jb_log2;
-    int gx = (int)(ntiles > (size_t)st_max_blocks() ? st_max_blocks() : ntiles);
-    k_ps_one<<<dim3(gx, njobs), 256, 16 * sizeof(E2), st>>>(jobs, rd, chal, jb_log2, partials, res);
-    return gx;
+
+int ps_plan_blocks(PsItem* items, int nitems, const PsJob* host_jobs, int rd) {
+    size_t total = 0;
+    for (int q = 0; q < nitems; q++) total += ((size_t)1 << (host_jobs[items[q].job].nvars - 1 - rd)) * host_jobs[items[q].job].npairs;
+    int blk = 0;
+    for (int q = 0; q < nitems; q++) {
+        PsItem& I = items[q];
+        const int hl = host_jobs[I.job].nvars - 1 - rd;
+        int jb = 8;
+        while (jb > 2 && (total << (8 - jb)) < st_min_threads()) jb--;
+        if (jb > hl) jb = hl;
+        const size_t ntiles = ((size_t)1 << hl) >> jb;
+        I.jb_log2 = jb; I.blk0 = blk;
+        I.nblk = (int)std::min<size_t>(ntiles, (size_t)st_max_blocks());
+        blk += I.nblk;
+    }
+    return blk;
 }
-void ps_tail(hipStream_t st, const PsJob* jobs, int njobs, int rd0, const E2* chal, E2* res) {
-    k_ps_tail<<<dim3(1, njobs), 1024, 16 * sizeof(E2), st>>>(jobs, rd0, chal, res);
+void ps_round(hipStream_t st, const PsJob* jobs, const PsItem* items, int nitems, int grid, int rd, const E2* chal, E2* partials, E2* res) {
+    k_ps_one<<<grid, 256, 16 * sizeof(E2), st>>>(jobs, items, nitems, rd, chal, partials, res);
+}
+void ps_tail(hipStream_t st, const PsJob* jobs, int njobs, const E2* chal, E2* res) {
+    k_ps_tail<<<njobs, 1024, 16 * sizeof(E2), st>>>(jobs, chal, res);
 }
 
 __global__ void k_scatter_e2(const ScatterEnt* __restrict__ ents, size_t n, E2* __restrict__ dst_base) {

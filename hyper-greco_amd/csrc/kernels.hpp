@@ -86,13 +86,20 @@ struct PsJob {
     E2* bufa[2];                  // ping-pong storage, table i at buf + i * (current length)
     E2* bufb[2];
     int npairs, nvars;
+    int tail_rd;                  // first round of the single-workgroup tail (host-planned)
     size_t r_off;                 // chain index of round 0's challenge
     size_t sums_slot;             // result slots: 2 per round
 };
-// round `rd` of every job (multi-workgroup; includes the partial reduction). Returns grid.x.
-int ps_round(hipStream_t st, const PsJob* jobs, int njobs, int nvars, int rd, const E2* chal, E2* partials, E2* res);
-// rounds [rd0, nvars) of every job, one workgroup per job
-void ps_tail(hipStream_t st, const PsJob* jobs, int njobs, int rd0, const E2* chal, E2* res);
+// one (job, round) of a PRODSUM launch; the items of a launch share a 1-D grid like StItem
+struct PsItem {
+    int job, jb_log2, blk0, nblk;
+};
+// fills jb_log2 / blk0 / nblk for round rd of the listed jobs (host side); returns the grid size
+int ps_plan_blocks(PsItem* items, int nitems, const PsJob* host_jobs, int rd);
+// round `rd` of every item's job (jobs of different sizes share the launch)
+void ps_round(hipStream_t st, const PsJob* jobs, const PsItem* items, int nitems, int grid, int rd, const E2* chal, E2* partials, E2* res);
+// rounds [tail_rd, nvars) of every job, one workgroup per job
+void ps_tail(hipStream_t st, const PsJob* jobs, int njobs, const E2* chal, E2* res);
 
 // dst_base[ent[i].dst] = ent[i].src[0]: moves locally produced scalars to their global result slots
 struct ScatterEnt { const E2* src; size_t dst; };

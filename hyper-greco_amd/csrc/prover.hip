@@ -501,36 +501,47 @@ struct Prover {
         return h;
     }
     void flush_prodsum() {
-        for (auto& kv : ps_queue) {
-            const int nvars = kv.first;
-            std::vector<dev::PsJob>& jobs = kv.second;
-            if (jobs.empty()) continue;
-            const size_t N = (size_t)1 << nvars;
-            for (size_t o = 0; o < jobs.size(); o += MAX_BATCH) {
-                const int nj = (int)std::min<size_t>(MAX_BATCH, jobs.size() - o);
-                dev::PsJob* d_jobs = ctx->alloc_n<dev::PsJob>(nj);
-                dev::PsJob* staged = (dev::PsJob*)stage(jobs.data() + o, (size_t)nj * sizeof(dev::PsJob));
-                hip_check(hipMemcpyAsync(d_jobs, staged, (size_t)nj * sizeof(dev::PsJob), hipMemcpyHostToDevice, st), "upload jobs");
-                int maxp = 1;
-                double pairs = 0;
-                for (int q = 0; q < nj; q++) { maxp = std::max(maxp, jobs[o + q].npairs); pairs += jobs[o + q].npairs; }
-                int rd = 0;
-                for (; rd < nvars && ((N >> rd) / 2) * (size_t)maxp > TAIL_ITEMS; rd++) {
-                    size_t half = N >> (rd + 1);
-                    ctx->prof_begin(cls_ps, pairs * (2.0 * half * ((rd == 0 ? 8 : 16) + 16) + half * 32.0));
-                    dev::ps_round(st, d_jobs, nj, nvars, rd, ctx->d_chal, partials, d_res());
-                    ctx->prof_end();
-                }
-                if (rd < nvars) {
-                    double bytes = 0;
-                    for (int q = rd; q < nvars; q++) { size_t half = N >> (q + 1); bytes += pairs * (2.0 * half * ((q == 0 ? 8 : 16) + 16) + half * 32.0); }
-                    ctx->prof_begin(cls_ps_tail, bytes);
-                    dev::ps_tail(st, d_jobs, nj, rd, ctx->d_chal, d_res());
-                    ctx->prof_end();
-                }
-            }
-            jobs.clear();
+        // round-synchronised: launch rd runs round rd of every queued job whatever its size; the last rounds of each
+        // job (TAIL_ITEMS work items or fewer) run in one single-workgroup-per-job launch
+        std::vector<dev::PsJob> jobs;
+        for (auto& kv : ps_queue) { jobs.insert(jobs.end(), kv.second.begin(), kv.second.end()); kv.second.clear(); }
+        if (jobs.empty()) return;
+        const int nj = (int)jobs.size();
+        int max_rd = 0;
+        for (auto& J : jobs) {
+            const size_t N = (size_t)1 << J.nvars;
+            int rd = 0;
+            static const size_t ps_tail_items = [] { const char* e = getenv("HG_PS_TAIL_ITEMS"); return e && *e ? (size_t)atol(e) : TAIL_ITEMS; }();
+            while (rd < J.nvars && ((N >> rd) / 2) * (size_t)J.npairs > ps_tail_items) rd++;
+            J.tail_rd = rd;
+            max_rd = std::max(max_rd, rd);
         }
+        dev::PsJob* d_jobs = ctx->alloc_n<dev::PsJob>(nj);
+        hip_check(hipMemcpyAsync(d_jobs, stage(jobs.data(), (size_t)nj * sizeof(dev::PsJob)), (size_t)nj * sizeof(dev::PsJob), hipMemcpyHostToDevice, st), "upload jobs");
+        auto round_bytes = [&](const dev::PsJob& J, int rd) {
+            size_t half = ((size_t)1 << J.nvars) >> (rd + 1);
+            return (double)J.npairs * (2.0 * half * ((rd == 0 ? 8 : 16) + 16) + half * 32.0);
+        };
+        for (int rd = 0; rd < max_rd; rd++) {
+            std::vector<dev::PsItem> items;
+            for (int q = 0; q < nj; q++) if (rd < jobs[q].tail_rd) { dev::PsItem it; memset(&it, 0, sizeof(it)); it.job = q; items.push_back(it); }
+            for (size_t o = 0; o < items.size(); o += MAX_BATCH) {
+                const int cnt = (int)std::min<size_t>(MAX_BATCH, items.size() - o);
+                const int grid = dev::ps_plan_blocks(items.data() + o, cnt, jobs.data(), rd);
+                dev::PsItem* d_items = ctx->alloc_n<dev::PsItem>(cnt);
+                hip_check(hipMemcpyAsync(d_items, stage(items.data() + o, (size_t)cnt * sizeof(dev::PsItem)), (size_t)cnt * sizeof(dev::PsItem), hipMemcpyHostToDevice, st), "upload items");
+                double bytes = 0;
+                for (int q = 0; q < cnt; q++) bytes += round_bytes(jobs[items[o + q].job], rd);
+                ctx->prof_begin(cls_ps, bytes);
+                dev::ps_round(st, d_jobs, d_items, cnt, grid, rd, ctx->d_chal, partials, d_res());
+                ctx->prof_end();
+            }
+        }
+        double tb = 0;
+        for (auto& J : jobs) for (int rd = J.tail_rd; rd < J.nvars; rd++) tb += round_bytes(J, rd);
+        ctx->prof_begin(cls_ps_tail, tb);
+        dev::ps_tail(st, d_jobs, nj, ctx->d_chal, d_res());
+        ctx->prof_end();
     }
     static constexpr size_t MAX_BATCH = 64;
     // pinned staging for small host->device descriptor copies (kept alive until the final synchronisation)

@@ -53,6 +53,8 @@ def oracle_sumcheck(kind, tables, is_base, pw, claim, chain_skip=0, threads=4):
     (0, 6, 10, True), (0, 25, 12, True), (0, 3, 1, True), (0, 9, 7, False),
     (1, 12, 9, True), (1, 100, 11, True), (1, 4, 1, True), (1, 2, 14, True), (1, 8, 6, False),
     (2, 2, 11, None), (2, 10, 9, None), (2, 54, 8, None), (2, 2, 1, None),
+    # long tables: fused two-round grand-product launches (half >= 2^13), mixed-size launches, chunked last rounds
+    (1, 6, 15, True), (1, 4, 16, True), (1, 4, 15, False), (0, 5, 15, True), (2, 4, 14, None),
 ])
 def test_sumcheck_kernels_bit_exact(ctx, kind, ntab, nv, base):
     rng = random.Random(kind * 1000 + ntab * 10 + nv)
