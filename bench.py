@@ -21,12 +21,21 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
-DOMINANT = "sc_round<grand_product,ext>"          # profile class name in the library
-DOMINANT_SYMBOL = "k_st_step<1, hg::E2>"          # its kernel symbol in rocprofv3 output
-PMC_FILE = os.path.join(ROOT, "profiles", "r01_e_pmc_hbm_traffic.json")
+# profile class of the library -> kernel symbol in rocprofv3 output. The class with the largest share of the GPU time
+# in a warm-up prove is the "dominant kernel" of the roofline object; its launches are then timed with HIP events
+# inside the timed region.
+CLASS_SYMBOL = {
+    "sc_round2<grand_product,ext>": "k_st_step2(",
+    "sc_round<grand_product,ext>": "k_st_step<1, hg::E2>",
+    "sc_round<grand_product,base>": "k_st_step<1, unsigned long>",
+    "sc_round<collation,ext>": "k_st_step<0, hg::E2>",
+    "sc_round<collation,base>": "k_st_step<0, unsigned long>",
+    "sc_round<prodsum>": "k_ps_one(",
+}
+PMC_FILE = os.path.join(ROOT, "profiles", "r01_f_pmc_hbm_traffic.json")
 
 
-def pmc_traffic():
+def pmc_traffic(cls):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
     WRITE_SIZE collected in separate runs, FETCH_SIZE doubled as the MI355X guide prescribes for gfx950;
     scripts/pmc_summary.py). PMC counters cannot be read from inside this process, so this is the value
@@ -34,7 +43,7 @@ def pmc_traffic():
     try:
         d = json.load(open(PMC_FILE))
         for k, v in d.items():
-            if DOMINANT_SYMBOL in k:
+            if CLASS_SYMBOL.get(cls, "\0") in k:
                 return round(v["hbm_bytes_per_launch"])
     except Exception:
         pass
@@ -187,6 +196,13 @@ def main():
     if shard:
         assert first == unsharded, "sharded proof differs from the single-GPU proof"
 
+    # which kernel class dominates? one untimed prove with events on every class
+    ctx.profile(2)
+    ctx.profile_reset()
+    step()
+    ctx.profile(0)
+    DOMINANT = max((s for s in ctx.profile_get() if s["name"] in CLASS_SYMBOL and s["launches"]), key=lambda s: s["total_ms"])["name"]
+    ctx.profile_select(DOMINANT)
     ctx.profile(1)  # HIP events around the dominant kernel class only
     ctx.profile_reset()
     barrier()
@@ -202,6 +218,7 @@ def main():
     elapsed = max_over_ranks(elapsed, world, dist, torch, red_dev)
     ms_per_step = elapsed / args.steps * 1e3
     dom = [s for s in ctx.profile_get() if s["name"] == DOMINANT][0]
+    timed_launches = dom["launches"]
 
     # one extra, untimed pass with events on every kernel class: the per-class breakdown
     ctx.profile(2)
@@ -235,8 +252,8 @@ def main():
                                        if shard else f"dp{world}: one independent proof per GPU, no data-path collective"),
                        "proof_bytes": len(first), "gpu_ms_events": round(gpu_ms, 4),
                        "witness_gen_ms_device": round(vals.timings["witness_ms"], 2), "upload_ms": round(vals.timings["upload_ms"], 2)},
-            "roofline": {"bound": "hbm", "kernel": DOMINANT, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(),
+            "roofline": {"bound": "hbm", "kernel": DOMINANT, "symbol": CLASS_SYMBOL.get(DOMINANT, ""), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(DOMINANT),
                          "launches_per_step": dom["launches"] // max(args.steps, 1),
                          "avg_launch_us": round(avg_ms * 1e3, 3), "algo_bytes_per_launch": round(per_launch_bytes)},
             "kernel_classes": classes,

@@ -39,7 +39,7 @@ EXPORTS = [
     "hg_last_error", "hg_device_count", "hg_create", "hg_destroy", "hg_params_builtin", "hg_setup", "hg_pk_free",
     "hg_pk_lasso_layout", "hg_pk_info", "hg_witness_from_json", "hg_witness_synthetic", "hg_witness_from_arrays",
     "hg_witness_get", "hg_witness_free", "hg_prove", "hg_verify", "hg_witness_gen", "hg_values_free", "hg_values_get", "hg_prove_shard_begin", "hg_prove_shard_combine", "hg_prove_shard_finish", "hg_prove_resident", "hg_circuit_eval", "hg_lasso_prove", "hg_lasso_prove_at", "hg_sumcheck", "hg_mle_eval",
-    "hg_ntt", "hg_challenges", "hg_profile", "hg_profile_reset", "hg_profile_get",
+    "hg_ntt", "hg_challenges", "hg_profile", "hg_profile_select", "hg_profile_reset", "hg_profile_get",
 ]
 
 
@@ -94,6 +94,7 @@ def lib():
         L.hg_ntt.argtypes = [C.c_void_p, u64p, C.c_size_t, C.c_int, C.c_size_t, u64p]
         L.hg_challenges.argtypes = [C.c_size_t, u64p]
         L.hg_profile.argtypes = [C.c_void_p, C.c_int]
+        L.hg_profile_select.argtypes = [C.c_void_p, C.c_char_p]
         L.hg_profile_reset.argtypes = [C.c_void_p]
         L.hg_profile_get.argtypes = [C.c_void_p, C.POINTER(HgKernelStat), C.c_int]
         _lib = L
@@ -142,6 +143,9 @@ class Context:
 
     def profile(self, level):
         lib().hg_profile(self.h, level)
+
+    def profile_select(self, name):
+        _check(lib().hg_profile_select(self.h, name.encode()))
 
     def profile_reset(self):
         lib().hg_profile_reset(self.h)

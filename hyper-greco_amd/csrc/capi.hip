@@ -460,6 +460,13 @@ int hg_challenges(size_t n, uint64_t* out) {
 }
 
 int hg_profile(hg_ctx* ctx, int level) { ctx->prof_level = level; return 0; }
+int hg_profile_select(hg_ctx* ctx, const char* name) {
+    bool found = false;
+    for (auto& s : ctx->prof_stats) found = found || s.name == name;
+    if (!found) { g_last_error = std::string("hg_profile_select: no kernel class named ") + name; return -1; }
+    for (auto& s : ctx->prof_stats) s.dominant = s.name == name;
+    return 0;
+}
 int hg_profile_reset(hg_ctx* ctx) {
     for (auto& s : ctx->prof_stats) { s.launches = 0; s.ms = 0; s.bytes = 0; }
     return 0;

@@ -166,7 +166,7 @@ struct Prover {
     ProofStream proof;
     std::vector<std::function<void()>> ops;  // transcript steps, replayed after the single synchronisation
     size_t res_used = 0;
-    int cls_gp_base, cls_gp_ext, cls_col_base, cls_col_ext, cls_ps, cls_reduce, cls_aux, cls_tree, cls_hash, cls_gather, cls_tail, cls_ps_tail;
+    int cls_gp_base, cls_gp_ext, cls_gp_ext2, cls_col_base, cls_col_ext, cls_ps, cls_reduce, cls_aux, cls_tree, cls_hash, cls_gather, cls_tail, cls_ps_tail;
 
     // ---- single-proof sharding over `world` GPUs ---------------------------------------------------
     // Device jobs are independent, so a proof shards by JOB with no data-path collective inside
@@ -255,7 +255,8 @@ struct Prover {
     Prover(hg_ctx* c, const hg_pk* k, int rank_ = 0, int world_ = 1) : ctx(c), pk(k), st(c->stream), partials(c->d_partials), rank(rank_), world(world_) {
         ctx->prof_stream = st;
         plan_shards();
-        cls_gp_ext = ctx->prof_class("sc_round<grand_product,ext>", true);
+        cls_gp_ext2 = ctx->prof_class("sc_round2<grand_product,ext>", true);
+        cls_gp_ext = ctx->prof_class("sc_round<grand_product,ext>", false);
         cls_gp_base = ctx->prof_class("sc_round<grand_product,base>", false);
         cls_col_base = ctx->prof_class("sc_round<collation,base>", false);
         cls_col_ext = ctx->prof_class("sc_round<collation,ext>", false);
@@ -448,10 +449,12 @@ struct Prover {
                     for (int q = 0; q < cnt; q++) {
                         const dev::StItem& it = L.items[o + q];
                         const dev::StJob& J = st_jobs[it.job];
+                        // algorithmic bytes in the per-round accounting of SURVEY.md 8(d): a fused launch is credited with both of
+                        // its rounds although the intermediate folded tables never reach HBM
                         for (int k = 0; k < L.nrounds; k++) bytes += round_bytes(J, J.nvars - 1 - it.h_log2 + k);
                     }
                     const int grid = grids[li][o / MAX_BATCH];
-                    int cls = L.kind == dev::SC_GRANDPROD ? (L.base ? cls_gp_base : cls_gp_ext) : (L.base ? cls_col_base : cls_col_ext);
+                    int cls = L.kind == dev::SC_GRANDPROD ? (L.base ? cls_gp_base : (L.nrounds == 2 ? cls_gp_ext2 : cls_gp_ext)) : (L.base ? cls_col_base : cls_col_ext);
                     ctx->prof_begin(cls, bytes);
                     if (L.nrounds == 2) dev::st_step2(st, d_jobs, d_items + offs[li] + o, cnt, grid, ctx->d_chal, partials, d_res());
                     else dev::st_step(st, L.kind, L.base, d_jobs, d_items + offs[li] + o, cnt, grid, ctx->d_chal, partials, d_res());

@@ -155,8 +155,10 @@ int hg_ntt(hg_ctx* ctx, const uint64_t* in, size_t log2n, int inverse, size_t ba
 /* Fiat-Shamir challenge chain [REF bfv-gkr/src/transcript.rs:146-157,198-203]: first n base-field challenges. */
 int hg_challenges(size_t n, uint64_t* out);
 
-/* profiling: level 0 off, 1 = events around the dominant kernel class only, 2 = every class */
+/* profiling: level 0 off, 1 = events around the selected kernel class only, 2 = every class */
 int hg_profile(hg_ctx* ctx, int level);
+/* selects the class that level 1 times (a name hg_profile_get reported); returns 0, or -1 if there is no such class */
+int hg_profile_select(hg_ctx* ctx, const char* name);
 int hg_profile_reset(hg_ctx* ctx);
 int hg_profile_get(hg_ctx* ctx, hg_kernel_stat* out, int cap);
 
