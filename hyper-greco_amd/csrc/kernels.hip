@@ -542,6 +542,78 @@ __global__ __launch_bounds__(256) void k_st_step2(const StJob* __restrict__ jobs
     }
     if (nblocks > 1) finish_partials(part, 6, tickets_of(partials) + y * 32, res + J.sums_slot + (size_t)rd * 3, sm, nblocks);
 }
+// Collation shape, two rounds per pass (folded Ext2 tables, weights already in the tables): the round sums are plain
+// sums over the tables; the lane pair (2j', 2j'+1) shares round t+1 as in k_st_step2 - each lane adds up its own folded
+// values (even lane: x' = T'[2j'], odd lane: y' = T'[2j'+1]) and the folds of round t+1 are split by table parity
+// (tables are taken two at a time: the even lane folds table i, the odd lane table i+1).
+__global__ __launch_bounds__(256) void k_col_step2(const StJob* __restrict__ jobs, const StItem* __restrict__ items, int nitems,
+                                                   const E2* __restrict__ chal, E2* __restrict__ partials, E2* __restrict__ res) {
+    const int y = find_item(items, nitems, blockIdx.x);
+    const StItem& I = items[y];
+    const StJob& J = jobs[I.job];
+    const int h_log2 = I.h_log2;
+    const int rd = J.nvars - 1 - h_log2;
+    const size_t half = (size_t)1 << h_log2, half2 = half >> 1;
+    const size_t ntiles = half >> 8;
+    const int nblocks = I.nblk, bx = (int)blockIdx.x - I.blk0;
+    const E2* __restrict__ in = reinterpret_cast<const E2*>(I.in);
+    const size_t in_stride = I.in_stride;
+    E2* __restrict__ out = I.out;
+    const int ntab = J.ntab;
+    const int tid = threadIdx.x;
+    const bool odd = tid & 1;
+    const FoldR fa = fold_r(chal[J.r_off + rd]);
+    const E2 rb = chal[J.r_off + rd + 1];
+    const FoldR fb = fold_r(odd ? e2_sub(e2_one(), rb) : rb);  // odd lane: y' + (1 - r)(x' - y')
+    E2 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) acc[t] = e2_zero();
+    for (size_t tile = bx; tile < ntiles; tile += nblocks) {
+        const size_t j = (tile << 8) + tid;
+        const size_t jo2 = dpos(j >> 1, half2);
+        E2 s0 = e2_zero(), s2 = e2_zero(), own = e2_zero();
+        E2 p0 = e2_zero(), p2 = e2_zero(), q0 = e2_zero(), q2 = e2_zero();
+        for (int i = 0; i < ntab; i += 2) {
+            const bool two = i + 1 < ntab;
+            E2 xa, ya, xb = e2_zero(), yb = e2_zero();
+            load_xy<E2, false>(in + (size_t)i * in_stride, j, half, xa, ya);
+            if (two) load_xy<E2, false>(in + (size_t)(i + 1) * in_stride, j, half, xb, yb);
+            const E2 da = e2_sub(ya, xa), db = e2_sub(yb, xb);
+            const E2 va = e2_add(ya, da), vb = e2_add(yb, db);
+            if (i == 0) { p0 = xa; p2 = va; }
+            s0 = e2_add(s0, e2_add(xa, xb));
+            s2 = e2_add(s2, e2_add(va, vb));
+            const E2 ma = e2_fold_wide(xa, da, fa), mb = two ? e2_fold_wide(xb, db, fa) : e2_zero();  // T'[j] of tables i, i+1
+            const E2 oa = swap_lane(ma), ob = swap_lane(mb);
+            if (i == 0) {
+                const E2 x = odd ? oa : ma, yv = odd ? ma : oa;
+                q0 = x; q2 = e2_add(yv, e2_sub(yv, x));
+            }
+            own = e2_add(own, e2_add(ma, mb));
+            const E2 fx = odd ? mb : ma, fd = odd ? e2_sub(ob, mb) : e2_sub(oa, ma);
+            if (!odd || two) store_e2(out + (size_t)(i + (odd ? 1 : 0)) * half2 + jo2, e2_fold_wide(fx, fd, fb));
+        }
+        acc[0] = e2_add(acc[0], e2_mul(p0, s0));
+        acc[1] = e2_add(acc[1], e2_mul(p2, s2));
+        const E2 other = swap_lane(own);
+        if (!odd) {  // s0' = sum x', s2' = sum (2 y' - x')
+            acc[2] = e2_add(acc[2], e2_mul(q0, own));
+            acc[3] = e2_add(acc[3], e2_mul(q2, e2_sub(e2_dbl(other), own)));
+        }
+    }
+    E2* sm = dyn_lds;
+    E2* part = partials + (size_t)y * SC_MAX_BLOCKS * 4;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        E2 s = block_sum_n(acc[t], sm);
+        if (threadIdx.x == 0) {
+            if (nblocks == 1) res[J.sums_slot + (size_t)rd * 2 + t] = s;
+            else part_store(part + (size_t)bx * 4 + t, s);
+        }
+    }
+    if (nblocks > 1) finish_partials(part, 4, tickets_of(partials) + y * 32, res + J.sums_slot + (size_t)rd * 2, sm, nblocks);
+}
+
 // ---- small rounds: one wave per pair index j, lanes along the tables ---------------------------------------------
 // For the rounds where the table index is the long axis (a few j, 25..50 table pairs) the per-j sums over the
 // tables are wave reductions (__shfl, no LDS, no barrier). `in` / `out` may be global or LDS (generic pointers).
@@ -712,8 +784,9 @@ void st_step(hipStream_t st, int kind, bool base, const StJob* jobs, const StIte
         else k_st_step<SC_COLLATION, E2><<<grid, 256, lds, st>>>(jobs, items, nitems, chal, partials, res);
     }
 }
-void st_step2(hipStream_t st, const StJob* jobs, const StItem* items, int nitems, int grid, const E2* chal, E2* partials, E2* res) {
-    k_st_step2<<<grid, 256, sc_lds_bytes(0, 256), st>>>(jobs, items, nitems, chal, partials, res);
+void st_step2(hipStream_t st, int kind, const StJob* jobs, const StItem* items, int nitems, int grid, const E2* chal, E2* partials, E2* res) {
+    if (kind == SC_GRANDPROD) k_st_step2<<<grid, 256, sc_lds_bytes(0, 256), st>>>(jobs, items, nitems, chal, partials, res);
+    else k_col_step2<<<grid, 256, sc_lds_bytes(0, 256), st>>>(jobs, items, nitems, chal, partials, res);
 }
 // ---- PRODSUM: g = sum_i a_i * b_i (Libra / zkCNN reductions), batched over independent instances -----
 // Round rd of job J: inputs are a[i]/b[i] (rd = 0; a in the base field) or the ping-pong buffers; table i of

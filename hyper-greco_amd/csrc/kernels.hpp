@@ -66,8 +66,8 @@ int st_plan_blocks(StItem* items, int nitems, bool rounds2);
 // step: every item runs its job's round with half = 2^item.h_log2; `grid` from st_plan_blocks
 void st_step(hipStream_t st, int kind, bool base, const StJob* jobs, const StItem* items, int nitems, int grid, const E2* chal,
              E2* partials, E2* res);
-// fused step (grand-product shape, folded Ext2 inputs): every item runs its job's rounds with half = 2^h_log2 and 2^(h_log2-1)
-void st_step2(hipStream_t st, const StJob* jobs, const StItem* items, int nitems, int grid, const E2* chal, E2* partials, E2* res);
+// fused step (folded Ext2 inputs; grand-product or collation shape): every item runs its job's rounds with half = 2^h_log2 and 2^(h_log2-1)
+void st_step2(hipStream_t st, int kind, const StJob* jobs, const StItem* items, int nitems, int grid, const E2* chal, E2* partials, E2* res);
 // chunk step: every item runs `nrounds` consecutive rounds; workgroup k owns pair indices [k 2^c, (k+1) 2^c) of the
 // first round (nrounds <= c + 1) and keeps the intermediate folded tables in LDS, so the small rounds of all jobs
 // take one launch per ST_CHUNK_ROUNDS rounds instead of one launch per round. With nchunks = 1 this is the tail.

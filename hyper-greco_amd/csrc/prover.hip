@@ -166,7 +166,7 @@ struct Prover {
     ProofStream proof;
     std::vector<std::function<void()>> ops;  // transcript steps, replayed after the single synchronisation
     size_t res_used = 0;
-    int cls_gp_base, cls_gp_ext, cls_gp_ext2, cls_col_base, cls_col_ext, cls_ps, cls_reduce, cls_aux, cls_tree, cls_hash, cls_gather, cls_tail, cls_ps_tail;
+    int cls_gp_base, cls_gp_ext, cls_gp_ext2, cls_col_ext2, cls_col_base, cls_col_ext, cls_ps, cls_reduce, cls_aux, cls_tree, cls_hash, cls_gather, cls_tail, cls_ps_tail;
 
     // ---- single-proof sharding over `world` GPUs ---------------------------------------------------
     // Device jobs are independent, so a proof shards by JOB with no data-path collective inside
@@ -260,6 +260,7 @@ struct Prover {
         cls_gp_base = ctx->prof_class("sc_round<grand_product,base>", false);
         cls_col_base = ctx->prof_class("sc_round<collation,base>", false);
         cls_col_ext = ctx->prof_class("sc_round<collation,ext>", false);
+        cls_col_ext2 = ctx->prof_class("sc_round2<collation,ext>", false);
         cls_ps = ctx->prof_class("sc_round<prodsum>", false);
         cls_tail = ctx->prof_class("sc_tail<single-workgroup>", false);
         cls_ps_tail = ctx->prof_class("ps_tail<single-workgroup>", false);
@@ -380,7 +381,7 @@ struct Prover {
                     memset(&it, 0, sizeof(it));
                     it.job = q; it.h_log2 = h; it.in = cur_in[q]; it.in_stride = cur_stride[q];
                     it.out = first ? J.buf[0] : next_out(q);
-                    const bool pair = fuse2 && kind == dev::SC_GRANDPROD && !first && h - 1 > H_SMALL && h >= std::max(dev::ST_STEP2_MIN_H, fuse_min_h);
+                    const bool pair = fuse2 && !first && h - 1 > H_SMALL && h >= std::max(dev::ST_STEP2_MIN_H, fuse_min_h);
                     (pair ? l2 : le).items.push_back(it);
                     next_h[q] = h - (pair ? 2 : 1);
                     cur_in[q] = it.out; cur_stride[q] = (size_t)1 << (pair ? h - 1 : h);
@@ -454,9 +455,9 @@ struct Prover {
                         for (int k = 0; k < L.nrounds; k++) bytes += round_bytes(J, J.nvars - 1 - it.h_log2 + k);
                     }
                     const int grid = grids[li][o / MAX_BATCH];
-                    int cls = L.kind == dev::SC_GRANDPROD ? (L.base ? cls_gp_base : (L.nrounds == 2 ? cls_gp_ext2 : cls_gp_ext)) : (L.base ? cls_col_base : cls_col_ext);
+                    int cls = L.kind == dev::SC_GRANDPROD ? (L.base ? cls_gp_base : (L.nrounds == 2 ? cls_gp_ext2 : cls_gp_ext)) : (L.base ? cls_col_base : (L.nrounds == 2 ? cls_col_ext2 : cls_col_ext));
                     ctx->prof_begin(cls, bytes);
-                    if (L.nrounds == 2) dev::st_step2(st, d_jobs, d_items + offs[li] + o, cnt, grid, ctx->d_chal, partials, d_res());
+                    if (L.nrounds == 2) dev::st_step2(st, L.kind, d_jobs, d_items + offs[li] + o, cnt, grid, ctx->d_chal, partials, d_res());
                     else dev::st_step(st, L.kind, L.base, d_jobs, d_items + offs[li] + o, cnt, grid, ctx->d_chal, partials, d_res());
                     ctx->prof_end();
                 }
