@@ -526,18 +526,28 @@ struct Prover {
             size_t half = ((size_t)1 << J.nvars) >> (rd + 1);
             return (double)J.npairs * (2.0 * half * ((rd == 0 ? 8 : 16) + 16) + half * 32.0);
         };
+        // plan every round first, upload all items in one copy, then launch
+        struct PsLaunch { int rd, cnt, grid; size_t off; double bytes; };
+        std::vector<PsLaunch> launches;
+        std::vector<dev::PsItem> all_items;
         for (int rd = 0; rd < max_rd; rd++) {
             std::vector<dev::PsItem> items;
             for (int q = 0; q < nj; q++) if (rd < jobs[q].tail_rd) { dev::PsItem it; memset(&it, 0, sizeof(it)); it.job = q; items.push_back(it); }
             for (size_t o = 0; o < items.size(); o += MAX_BATCH) {
                 const int cnt = (int)std::min<size_t>(MAX_BATCH, items.size() - o);
                 const int grid = dev::ps_plan_blocks(items.data() + o, cnt, jobs.data(), rd);
-                dev::PsItem* d_items = ctx->alloc_n<dev::PsItem>(cnt);
-                hip_check(hipMemcpyAsync(d_items, stage(items.data() + o, (size_t)cnt * sizeof(dev::PsItem)), (size_t)cnt * sizeof(dev::PsItem), hipMemcpyHostToDevice, st), "upload items");
                 double bytes = 0;
                 for (int q = 0; q < cnt; q++) bytes += round_bytes(jobs[items[o + q].job], rd);
-                ctx->prof_begin(cls_ps, bytes);
-                dev::ps_round(st, d_jobs, d_items, cnt, grid, rd, ctx->d_chal, partials, d_res());
+                launches.push_back({rd, cnt, grid, all_items.size(), bytes});
+                all_items.insert(all_items.end(), items.begin() + o, items.begin() + o + cnt);
+            }
+        }
+        if (!all_items.empty()) {
+            dev::PsItem* d_items = ctx->alloc_n<dev::PsItem>(all_items.size());
+            hip_check(hipMemcpyAsync(d_items, stage(all_items.data(), all_items.size() * sizeof(dev::PsItem)), all_items.size() * sizeof(dev::PsItem), hipMemcpyHostToDevice, st), "upload items");
+            for (auto& L : launches) {
+                ctx->prof_begin(cls_ps, L.bytes);
+                dev::ps_round(st, d_jobs, d_items + L.off, L.cnt, L.grid, L.rd, ctx->d_chal, partials, d_res());
                 ctx->prof_end();
             }
         }
