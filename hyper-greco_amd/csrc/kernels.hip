@@ -1149,12 +1149,43 @@ __global__ __launch_bounds__(TPB) void k_prod_level(const u64* __restrict__ in, 
     const size_t h = in_len >> 1;
     const u64* src = in + (size_t)blockIdx.y * in_len;
     u64* dst = out + (size_t)blockIdx.y * h;
-    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < h; i += (size_t)gridDim.x * TPB) dst[i] = gl_mul(src[i], src[i + h]);
+    if (h & 1) {
+        for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < h; i += (size_t)gridDim.x * TPB) dst[i] = gl_mul(src[i], src[i + h]);
+        return;
+    }
+    // two outputs per thread: 16-byte loads and stores
+    for (size_t i = ((size_t)blockIdx.x * TPB + threadIdx.x) * 2; i < h; i += (size_t)gridDim.x * TPB * 2) {
+        const ulonglong2 a = *reinterpret_cast<const ulonglong2*>(src + i), b = *reinterpret_cast<const ulonglong2*>(src + i + h);
+        *reinterpret_cast<ulonglong2*>(dst + i) = make_ulonglong2(gl_mul(a.x, b.x), gl_mul(a.y, b.y));
+    }
 }
 void prod_level(hipStream_t st, const u64* in, size_t in_len, u64* out, int nb) {
     size_t h = in_len >> 1;
-    dim3 grid((unsigned)std::min<size_t>((h + TPB - 1) / TPB, 256), (unsigned)nb);
+    dim3 grid((unsigned)std::min<size_t>((h / 2 + TPB - 1) / TPB + 1, 256), (unsigned)nb);
     k_prod_level<<<grid, TPB, 0, st>>>(in, in_len, out);
+}
+// the small levels of the tree in one launch: workgroup b holds row b of a level of at most PROD_TAIL_LEN entries in LDS and
+// writes every level above it (levels[k] = row-major nb x (in_len >> (k+1)))
+__global__ __launch_bounds__(TPB) void k_prod_tail(const u64* __restrict__ in, int in_len, ProdTailOut outs, int nlevels) {
+    __shared__ u64 row[PROD_TAIL_LEN];
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < in_len; i += TPB) row[i] = in[(size_t)b * in_len + i];
+    __syncthreads();
+    int len = in_len;
+    for (int k = 0; k < nlevels; k++) {
+        const int h = len >> 1;
+        u64 v[PROD_TAIL_LEN / 2 / TPB + 1];
+        int c = 0;
+        for (int i = threadIdx.x; i < h; i += TPB) v[c++] = gl_mul(row[i], row[i + h]);
+        __syncthreads();
+        c = 0;
+        for (int i = threadIdx.x; i < h; i += TPB) { row[i] = v[c]; outs.p[k][(size_t)b * h + i] = v[c]; c++; }
+        __syncthreads();
+        len = h;
+    }
+}
+void prod_tail(hipStream_t st, const u64* in, int in_len, const ProdTailOut& outs, int nlevels, int nb) {
+    k_prod_tail<<<nb, TPB, 0, st>>>(in, in_len, outs, nlevels);
 }
 __global__ void k_gp_top(const u64* __restrict__ top, int nb, E2* __restrict__ roots, E2* __restrict__ evals) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;

@@ -150,6 +150,10 @@ void lasso_hash_rw(hipStream_t st, size_t n, const u64* dim, const u64* e_poly, 
 void lasso_hash_if(hipStream_t st, u32 cutoff, const u64* final_cts, u64 gamma, u64 tau, u64* init, u64* fin);
 // product tree level: out[b][i] = in[b][i] * in[b][i + h], b < nb, i < h
 void prod_level(hipStream_t st, const u64* in, size_t in_len, u64* out, int nb);
+// all levels above a level of in_len <= PROD_TAIL_LEN entries in one launch (one workgroup per row)
+constexpr int PROD_TAIL_LEN = 2048;
+struct ProdTailOut { u64* p[12]; };
+void prod_tail(hipStream_t st, const u64* in, int in_len, const ProdTailOut& outs, int nlevels, int nb);
 // gathers: roots[b] = top[b][0]*top[b][1] (as E2) ; evals[2b+s] = top[b][s]
 void gp_top(hipStream_t st, const u64* top, int nb, E2* roots, E2* evals);
 // dot products with an eq table: out_partials for ntab base tables (stride layout); nv = ntab (<= 8 per call)

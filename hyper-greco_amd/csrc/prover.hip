@@ -686,9 +686,25 @@ struct Prover {
         const int deepest = gp_deepest(nv, owner);
         if (lev1 && nv > 1) lev[1] = lev1;
         for (int k = (lev1 && nv > 1) ? 2 : 1; k <= deepest; k++) {  // Layer::bottom / Layer::up: w = v_l * v_r on the MSB split
+            const size_t in_len = len >> (k - 1);
+            if (in_len <= (size_t)dev::PROD_TAIL_LEN && in_len >= 2) {  // the remaining (small) levels in one launch
+                dev::ProdTailOut outs;
+                memset(&outs, 0, sizeof(outs));
+                int nlev = 0;
+                double bytes = 0;
+                for (int kk = k; kk <= deepest; kk++) {
+                    u64* o = ctx->alloc_n<u64>((size_t)nl * (len >> kk));
+                    outs.p[nlev++] = o; lev[kk] = o;
+                    bytes += (double)nl * (len >> (kk - 1)) * 8.0 * 1.5;
+                }
+                ctx->prof_begin(cls_tree, bytes);
+                if (nl > 0) dev::prod_tail(st, lev[k - 1], (int)in_len, outs, nlev, nl);
+                ctx->prof_end();
+                break;
+            }
             u64* out = ctx->alloc_n<u64>((size_t)nl * (len >> k));
-            ctx->prof_begin(cls_tree, (double)nl * (len >> (k - 1)) * 8.0 * 1.5);
-            dev::prod_level(st, lev[k - 1], len >> (k - 1), out, nl);
+            ctx->prof_begin(cls_tree, (double)nl * in_len * 8.0 * 1.5);
+            dev::prod_level(st, lev[k - 1], in_len, out, nl);
             ctx->prof_end();
             lev[k] = out;
         }
