@@ -1132,17 +1132,17 @@ void lasso_hash_rw(hipStream_t st, size_t n, const u64* dim, const u64* e_poly, 
                    u64* rd1, u64* wr1) {
     k_hash_rw<<<grid_for(n >> 1) * 4, TPB, 0, st>>>(n, dim, e_poly, read_ts, gamma, gl_mul(gamma, gamma), tau, rd, wr, rd1, wr1);
 }
-__global__ __launch_bounds__(TPB) void k_hash_if(u32 cutoff, const u64* __restrict__ fc, u64 gamma, u64 gamma2, u64 tau,
-                                                 u64* __restrict__ init, u64* __restrict__ fin) {
+__global__ __launch_bounds__(TPB) void k_hash_if(HashIfArgs args, u64 gamma, u64 gamma2, u64 tau, u64* __restrict__ H2, int G) {
+    const int i = blockIdx.y;  // memory
     u32 a = blockIdx.x * TPB + threadIdx.x;
     if (a >= 65536) return;
-    u64 tv = a < cutoff ? (u64)a : 0;
+    u64 tv = a < args.cutoff[i] ? (u64)a : 0;
     u64 h0 = gl_sub(gl_add((u64)a, gl_mul(tv, gamma)), tau);
-    init[a] = h0;
-    fin[a] = gl_add(h0, gl_mul(gl_from_u64(fc[a]), gamma2));
+    H2[(size_t)i * 65536 + a] = h0;
+    H2[(size_t)(G + i) * 65536 + a] = gl_add(h0, gl_mul(gl_from_u64(args.fc[i][a]), gamma2));
 }
-void lasso_hash_if(hipStream_t st, u32 cutoff, const u64* final_cts, u64 gamma, u64 tau, u64* init, u64* fin) {
-    k_hash_if<<<65536 / TPB, TPB, 0, st>>>(cutoff, final_cts, gamma, gl_mul(gamma, gamma), tau, init, fin);
+void lasso_hash_if(hipStream_t st, const HashIfArgs& args, int G, u64 gamma, u64 tau, u64* H2) {
+    k_hash_if<<<dim3(65536 / TPB, G), TPB, 0, st>>>(args, gamma, gl_mul(gamma, gamma), tau, H2, G);
 }
 
 __global__ __launch_bounds__(TPB) void k_prod_level(const u64* __restrict__ in, size_t in_len, u64* __restrict__ out) {
@@ -1200,8 +1200,9 @@ void gp_top(hipStream_t st, const u64* top, int nb, E2* roots, E2* evals) {
 }
 
 struct DotTabs { const u64* t[8]; };
-__global__ __launch_bounds__(TPB) void k_dot_eq(const E2* __restrict__ eq, DotTabs tabs, int ntab, size_t n, E2* __restrict__ partials) {
-    __shared__ E2 sm[TPB / 64];
+__global__ __launch_bounds__(TPB) void k_dot_eq(const E2* __restrict__ eq, DotTabs tabs, int ntab, size_t n, E2* __restrict__ partials,
+                                                E2* __restrict__ out) {
+    __shared__ E2 sm[16];
     E2 acc[8];
 #pragma unroll
     for (int t = 0; t < 8; t++) acc[t] = e2_zero();
@@ -1217,17 +1218,20 @@ __global__ __launch_bounds__(TPB) void k_dot_eq(const E2* __restrict__ eq, DotTa
 #pragma unroll
     for (int t = 0; t < 8; t++)
         if (t < ntab) {
-            E2 s = block_sum(acc[t], sm);
-            if (threadIdx.x == 0) partials[(size_t)blockIdx.x * ntab + t] = s;
+            E2 s = block_sum_n(acc[t], sm);
+            if (threadIdx.x == 0) {
+                if (gridDim.x == 1) out[t] = s;
+                else part_store(partials + (size_t)blockIdx.x * ntab + t, s);
+            }
         }
+    if (gridDim.x > 1) finish_partials(partials, ntab, tickets_of(partials), out, sm);
 }
-int dot_eq(hipStream_t st, const E2* eq, const u64* const tabs[8], int ntab, size_t n, E2* partials) {
+// out[t] = sum_j eq[j] * tabs[t][j]; `partials` is a partials buffer (the last-arriving workgroup sums into `out`)
+void dot_eq(hipStream_t st, const E2* eq, const u64* const tabs[8], int ntab, size_t n, E2* partials, E2* out) {
     DotTabs d;
     for (int t = 0; t < 8; t++) d.t[t] = t < ntab ? tabs[t] : nullptr;
     // (column accumulators were measured slower here: 8 independent 8-byte streams per thread need the occupancy more)
-    int grid = grid_for(n);
-    k_dot_eq<<<grid, TPB, 0, st>>>(eq, d, ntab, n, partials);
-    return grid;
+    k_dot_eq<<<grid_for(n), TPB, 0, st>>>(eq, d, ntab, n, partials, out);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1252,6 +1256,28 @@ __global__ __launch_bounds__(TPB) void k_gather_B(CsrMul m, const E2* __restrict
 void vanilla_gather_B(hipStream_t st, const CsrMul& mulR, const E2* eqc, const E2* eqx, const E2* u, int log2_S, int log2_G, int log2_R, E2* B) {
     size_t total = (size_t)1 << (log2_S + log2_R);
     k_gather_B<<<grid_for(total) * 4, TPB, 0, st>>>(mulR, eqc, eqx, u, log2_S, log2_G, log2_R, B);
+}
+// the same for a batch of (node, right input) jobs, grid.y = job
+__global__ __launch_bounds__(TPB) void k_gather_B_jobs(const GatherBJob* __restrict__ jobs) {
+    const GatherBJob& J = jobs[blockIdx.y];
+    const CsrMul& m = J.m;
+    const size_t total = (size_t)1 << (J.log2_S + J.log2_R);
+    const size_t smask = ((size_t)1 << J.log2_S) - 1;
+    for (size_t idx = (size_t)blockIdx.x * TPB + threadIdx.x; idx < total; idx += (size_t)gridDim.x * TPB) {
+        size_t y = idx & smask, rep = idx >> J.log2_S;
+        E2 acc = e2_zero();
+        for (u32 e = m.ptr[y]; e < m.ptr[y + 1]; e++) {
+            E2 q = J.eqc[(rep << J.log2_G) + m.gate[e]];
+            u64 c = m.coef[e];
+            if (c != 1) q = e2_mul_f(q, c);
+            q = e2_mul(q, J.eqx[(rep << J.log2_S) + m.other_j[e]]);
+            acc = e2_add(acc, e2_mul(q, J.u[m.other_in[e]]));
+        }
+        store_e2(J.B + idx, acc);
+    }
+}
+void gather_B_jobs(hipStream_t st, const GatherBJob* jobs, int njobs, size_t max_total) {
+    k_gather_B_jobs<<<dim3(grid_for(max_total) * 4, njobs), TPB, 0, st>>>(jobs);
 }
 __global__ __launch_bounds__(TPB) void k_const_sum(const u32* __restrict__ gate, const u64* __restrict__ coef, size_t nterms,
                                                    const E2* __restrict__ eqc, int log2_G, int log2_R, E2* __restrict__ partials) {

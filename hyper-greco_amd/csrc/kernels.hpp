@@ -147,7 +147,9 @@ int lasso_claim(hipStream_t st, const LassoDev& L, const E2* eq, const u64* e_po
 // rd1/wr1 (may be null): first product-tree level rd[j]*rd[j+n/2], wr[j]*wr[j+n/2], n/2 entries each
 void lasso_hash_rw(hipStream_t st, size_t n, const u64* dim, const u64* e_poly, const u64* read_ts, u64 gamma, u64 tau, u64* rd, u64* wr,
                    u64* rd1, u64* wr1);
-void lasso_hash_if(hipStream_t st, u32 cutoff, const u64* final_cts, u64 gamma, u64 tau, u64* init, u64* fin);
+// init / final hashes of all G memories in one launch: H2[i] = init_i, H2[G + i] = final_i (2^16 entries each)
+struct HashIfArgs { u32 cutoff[32]; const u64* fc[32]; };
+void lasso_hash_if(hipStream_t st, const HashIfArgs& args, int G, u64 gamma, u64 tau, u64* H2);
 // product tree level: out[b][i] = in[b][i] * in[b][i + h], b < nb, i < h
 void prod_level(hipStream_t st, const u64* in, size_t in_len, u64* out, int nb);
 // all levels above a level of in_len <= PROD_TAIL_LEN entries in one launch (one workgroup per row)
@@ -156,8 +158,8 @@ struct ProdTailOut { u64* p[12]; };
 void prod_tail(hipStream_t st, const u64* in, int in_len, const ProdTailOut& outs, int nlevels, int nb);
 // gathers: roots[b] = top[b][0]*top[b][1] (as E2) ; evals[2b+s] = top[b][s]
 void gp_top(hipStream_t st, const u64* top, int nb, E2* roots, E2* evals);
-// dot products with an eq table: out_partials for ntab base tables (stride layout); nv = ntab (<= 8 per call)
-int dot_eq(hipStream_t st, const E2* eq, const u64* const tabs[8], int ntab, size_t n, E2* partials);
+// dot products with an eq table: out[t] = sum_j eq[j] * tabs[t][j] for ntab <= 8 base tables; `partials` is a partials buffer
+void dot_eq(hipStream_t st, const E2* eq, const u64* const tabs[8], int ntab, size_t n, E2* partials, E2* out);
 
 // ---- Vanilla / FFT nodes ----------------------------------------------------------------------
 struct CsrLin { const u32* ptr; const u32* gate; const u64* coef; };           // per input position -> (gate, c)
@@ -171,6 +173,8 @@ struct GatherJob { GatherT g; const E2* eqc; int log2_S, log2_G, log2_R; E2* T; 
 void gather_jobs(hipStream_t st, const GatherJob* jobs, int njobs, size_t max_total);
 // B[rep*S + y] = sum_mulR eqc[rep*G+gate]*c*eqx[rep*S + j0]*u[i0]
 void vanilla_gather_B(hipStream_t st, const CsrMul& mulR, const E2* eqc, const E2* eqx, const E2* u, int log2_S, int log2_G, int log2_R, E2* B);
+struct GatherBJob { CsrMul m; const E2* eqc; const E2* eqx; const E2* u; int log2_S, log2_G, log2_R; E2* B; };
+void gather_B_jobs(hipStream_t st, const GatherBJob* jobs, int njobs, size_t max_total);
 // sum over reps and constant gates of eqc[rep*G+gate]*c -> partials (nv = 1)
 int vanilla_const_sum(hipStream_t st, const u32* gate, const u64* coef, size_t nterms, const E2* eqc, int log2_G, int log2_R, E2* partials);
 // F_c(x) = sum_a alpha_a * scale * prod_b (1 + r_{a,b} (W[(x<<b) & (N-1)] - 1))

@@ -607,6 +607,7 @@ struct Prover {
     std::vector<dev::EqJob> eq_queue;
     std::vector<std::function<void()>> after_eq;  // device work that reads the queued eq tables
     std::vector<dev::GatherJob> gather_queue;
+    std::vector<dev::GatherBJob> gatherB_queue;
     std::vector<dev::FftJob> fft_queue;
 
     void eq_now(E2* out, int n, size_t point_off, const E2* point_dev = nullptr) {  // single table, launched in place
@@ -659,6 +660,9 @@ struct Prover {
         size_t max_total = 0; double gb = 0;
         for (auto& J : gather_queue) { size_t t = (size_t)1 << (J.log2_S + J.log2_R); max_total = std::max(max_total, t); gb += 24.0 * t; }
         flush_jobs(gather_queue, cls_gather, gb, [&](dev::GatherJob* d, int nj) { dev::gather_jobs(st, d, nj, max_total); });
+        size_t maxB = 0; double bb = 0;
+        for (auto& J : gatherB_queue) { size_t t = (size_t)1 << (J.log2_S + J.log2_R); maxB = std::max(maxB, t); bb += 40.0 * t; }
+        flush_jobs(gatherB_queue, cls_gather, bb, [&](dev::GatherBJob* d, int nj) { dev::gather_B_jobs(st, d, nj, maxB); });
         int max_L = 0; double fb = 0;
         for (auto& J : fft_queue) { max_L = std::max(max_L, J.L); fb += 24.0 * ((size_t)1 << J.L); }
         flush_jobs(fft_queue, cls_aux, fb, [&](dev::FftJob* d, int nj) { dev::fft_jobs(st, d, nj, max_L, ctx->d_chal); });
@@ -877,11 +881,15 @@ struct Prover {
                 hash_rw(local_mems[q], H1 + (size_t)(base + q) * N, H1 + (size_t)(base + nlm + q) * N,
                         L1 ? L1 + (size_t)(base + q) * (N / 2) : nullptr, L1 ? L1 + (size_t)(base + nlm + q) * (N / 2) : nullptr);
         }
-        if (do_gp2)
-            for (int i = 0; i < G; i++) {
-                int m = lp.gkr_order[i], c = lp.gkr_chunk[i];
-                dev::lasso_hash_if(st, (u32)lp.mems[m].cutoff, final_cts[c], gamma, tau, H2 + (size_t)i * M, H2 + (size_t)(G + i) * M);
-            }
+        if (do_gp2) {
+            if (G > 32) throw Error("lasso: more than 32 memories");
+            dev::HashIfArgs ha;
+            memset(&ha, 0, sizeof(ha));
+            for (int i = 0; i < G; i++) { ha.cutoff[i] = (u32)lp.mems[lp.gkr_order[i]].cutoff; ha.fc[i] = final_cts[lp.gkr_chunk[i]]; }
+            ctx->prof_begin(cls_hash, (double)G * M * 8 * 3);
+            dev::lasso_hash_if(st, ha, G, gamma, tau, H2);
+            ctx->prof_end();
+        }
         GpOut g1 = split ? grand_product(H1, N, 2 * G, gp1_owner, L1, &local_pairs, p0_only)
                          : grand_product(H1, N, 2 * G, gp1_owner, L1);  // reads then writes (prover.rs:161-165)
         GpOut g2 = grand_product(H2, M, 2 * G, std::vector<int>(16, own_gp2));      // inits then finals (prover.rs:167-171)
@@ -910,9 +918,8 @@ struct Prover {
                 size_t tmp = slot(cnt);
                 if (do_open) {
                     ctx->prof_begin(cls_aux, (double)N * (16 + 8.0 * cnt));
-                    int grid2 = dev::dot_eq(st, eqx, tabs, cnt, N, partials);
+                    dev::dot_eq(st, eqx, tabs, cnt, N, partials, d_res() + tmp);
                     ctx->prof_end();
-                    reduce(grid2, cnt, tmp);
                 }
                 for (int t = 0; t < cnt; t++) {
                     size_t from = tmp + t, to = dst[o + t];
@@ -921,8 +928,7 @@ struct Prover {
             }
             if (do_open) {
                 const u64* tabs[8] = {final_cts[c]};
-                int grid2 = dev::dot_eq(st, eqy, tabs, 1, M, partials);
-                reduce(grid2, 1, base_slot + 2);
+                dev::dot_eq(st, eqy, tabs, 1, M, partials, d_res() + base_slot + 2);
             }
             defer_write_slots(base_slot, 3 + chk.second.size());
         }
@@ -1042,13 +1048,8 @@ struct Prover {
                 memset(&one, 0, sizeof(one));
                 one.n = 1; one.unit_alpha = 1; one.point_off[0] = rx_off;
                 queue_eq(eqx, nin, one);
-                after_eq.push_back([this, ri, Bs, ndp, np, eqc, eqx, u_base, SR] {
-                    for (size_t q = 0; q < ri.size(); q++) {
-                        ctx->prof_begin(cls_gather, 40.0 * SR);
-                        dev::vanilla_gather_B(st, ndp->mulR[ri[q]], eqc, eqx, d_res() + u_base, np->log2_sub_in, np->log2_sub_out, np->log2_reps, Bs[q]);
-                        ctx->prof_end();
-                    }
-                });
+                for (size_t q = 0; q < ri.size(); q++)  // batched by flush_bookkeeping, after the eq tables
+                    gatherB_queue.push_back(dev::GatherBJob{ndp->mulR[ri[q]], eqc, eqx, d_res() + u_base, np->log2_sub_in, np->log2_sub_out, np->log2_reps, Bs[q]});
                 const int npairs = (int)ri.size();
                 const size_t N = (size_t)1 << nin;
                 dev::PsJob J;
@@ -1275,8 +1276,7 @@ static std::unique_ptr<Prover> prove_begin(hg_ctx* ctx, const hg_pk* pk, const h
         E2* eq = ctx->alloc_n<E2>((size_t)1 << ov);
         P->eq_now(eq, ov, point_off);
         const u64* tabs[8] = {v->d_ct0is};
-        int grid = dev::dot_eq(ctx->stream, eq, tabs, 1, (size_t)1 << ov, ctx->d_partials);
-        P->reduce(grid, 1, vslot);
+        dev::dot_eq(ctx->stream, eq, tabs, 1, (size_t)1 << ov, ctx->d_partials, P->d_res() + vslot);
     }
     Cell out_value = cell();
     Prover* pp = P.get();
@@ -1452,9 +1452,8 @@ E2 mle_eval_device(hg_ctx* ctx, const u64* table_host, size_t nv, const E2* poin
     if (nv) hip_check(hipMemcpyAsync(pt, point_host, nv * 16, hipMemcpyHostToDevice, ctx->stream), "upload");
     P.eq_now(eq, (int)nv, 0, pt);
     const u64* tabs[8] = {d};
-    int grid = dev::dot_eq(ctx->stream, eq, tabs, 1, N, ctx->d_partials);
     size_t s = P.slot(1);
-    P.reduce(grid, 1, s);
+    dev::dot_eq(ctx->stream, eq, tabs, 1, N, ctx->d_partials, P.d_res() + s);
     P.finish();
     return ctx->h_res[s];
 }
