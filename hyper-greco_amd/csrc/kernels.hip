@@ -791,16 +791,16 @@ void st_step2(hipStream_t st, int kind, const StJob* jobs, const StItem* items, 
 // ---- PRODSUM: g = sum_i a_i * b_i (Libra / zkCNN reductions), batched over independent instances -----
 // Round rd of job J: inputs are a[i]/b[i] (rd = 0; a in the base field) or the ping-pong buffers; table i of
 // a buffer sits at buf + i * (current length).
-__device__ __forceinline__ void ps_io(const PsJob& J, int rd, int i, const void*& a, const E2*& b, E2*& oa, E2*& ob) {
+__device__ __forceinline__ void ps_io(const PsJob& J, int rd, int rounds, int in_buf, int out_buf, int i, const void*& a, const E2*& b, E2*& oa, E2*& ob) {
     const size_t N = (size_t)1 << J.nvars;
-    if (rd == 0) { a = J.a[i]; b = J.b[i]; }
-    else { size_t len = N >> rd; a = J.bufa[(rd - 1) & 1] + (size_t)i * len; b = J.bufb[(rd - 1) & 1] + (size_t)i * len; }
-    if (rd == J.nvars - 1) { oa = J.fin_a[i]; ob = J.fin_b[i]; }
-    else { size_t len = N >> (rd + 1); oa = J.bufa[rd & 1] + (size_t)i * len; ob = J.bufb[rd & 1] + (size_t)i * len; }
+    if (in_buf < 0) { a = J.a[i]; b = J.b[i]; }
+    else { size_t len = N >> rd; a = J.bufa[in_buf] + (size_t)i * len; b = J.bufb[in_buf] + (size_t)i * len; }
+    if (out_buf < 0) { oa = J.fin_a[i]; ob = J.fin_b[i]; }
+    else { size_t len = N >> (rd + rounds); oa = J.bufa[out_buf] + (size_t)i * len; ob = J.bufb[out_buf] + (size_t)i * len; }
 }
 
 template <typename TA>
-__device__ __forceinline__ void ps_round_body(const PsJob& J, int rd, size_t half, E2 r, int jb_log2, E2& a0, E2& a2,
+__device__ __forceinline__ void ps_round_body(const PsJob& J, int rd, int in_buf, int out_buf, size_t half, E2 r, int jb_log2, E2& a0, E2& a2,
                                               size_t first_tile, size_t tile_step) {
     using V = Val<TA>;
     const int BD = blockDim.x, tid = threadIdx.x;
@@ -816,10 +816,10 @@ __device__ __forceinline__ void ps_round_body(const PsJob& J, int rd, size_t hal
         const size_t jo = dpos(j, half);
         for (int i = g; i < J.npairs; i += G) {
             const void* pa; const E2* pb; E2* oa; E2* ob;
-            ps_io(J, rd, i, pa, pb, oa, ob);
+            ps_io(J, rd, 1, in_buf, out_buf, i, pa, pb, oa, ob);
             TA xa, ya;
             E2 xb, yb;
-            if (rd == 0) {
+            if (in_buf < 0) {
                 load_pair<TA>(reinterpret_cast<const TA*>(pa) + 2 * j, xa, ya);
                 load_pair<E2>(pb + 2 * j, xb, yb);
             } else {
@@ -849,72 +849,178 @@ __device__ __forceinline__ void ps_round_body(const PsJob& J, int rd, size_t hal
     a2 = e2_add(a2, we2_reduce(w2));
 }
 
-// round rd of every item's job; items share a 1-D grid (item y owns workgroups [blk0, blk0 + nblk))
-__global__ __launch_bounds__(256) void k_ps_one(const PsJob* __restrict__ jobs, const PsItem* __restrict__ items, int nitems, int rd,
-                                                const E2* __restrict__ chal, E2* __restrict__ partials, E2* __restrict__ res) {
+// one round of every item's job; items share a 1-D grid (item y owns workgroups [blk0, blk0 + nblk))
+__device__ __forceinline__ int find_ps_item(const PsItem* __restrict__ items, int nitems, int blk) {
     int lo = 0, hi = nitems - 1;
     while (lo < hi) {
         int mid = (lo + hi + 1) >> 1;
-        if (items[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+        if (items[mid].blk0 <= blk) lo = mid; else hi = mid - 1;
     }
-    const int y = lo;
+    return lo;
+}
+__global__ __launch_bounds__(256) void k_ps_one(const PsJob* __restrict__ jobs, const PsItem* __restrict__ items, int nitems,
+                                                const E2* __restrict__ chal, E2* __restrict__ partials, E2* __restrict__ res) {
+    const int y = find_ps_item(items, nitems, blockIdx.x);
     const PsItem& I = items[y];
     const PsJob& J = jobs[I.job];
+    const int rd = I.rd;
     const int nblocks = I.nblk, bx = (int)blockIdx.x - I.blk0;
     E2* sm = dyn_lds;
     const size_t half = (size_t)1 << (J.nvars - 1 - rd);
     E2 r = chal[J.r_off + rd];
     E2 a0 = e2_zero(), a2 = e2_zero();
-    if (rd == 0) ps_round_body<u64>(J, rd, half, r, I.jb_log2, a0, a2, bx, nblocks);
-    else ps_round_body<E2>(J, rd, half, r, I.jb_log2, a0, a2, bx, nblocks);
+    if (I.in_buf < 0) ps_round_body<u64>(J, rd, I.in_buf, I.out_buf, half, r, I.jb_log2, a0, a2, bx, nblocks);
+    else ps_round_body<E2>(J, rd, I.in_buf, I.out_buf, half, r, I.jb_log2, a0, a2, bx, nblocks);
     E2 s0 = block_sum_n(a0, sm);
     E2 s2 = block_sum_n(a2, sm);
-    E2* part = partials + (size_t)y * SC_MAX_BLOCKS * 2;
+    E2* part = partials + (size_t)y * SC_MAX_BLOCKS * 4;
     if (threadIdx.x == 0) {
         if (nblocks == 1) { res[J.sums_slot + 2 * rd] = s0; res[J.sums_slot + 2 * rd + 1] = s2; }
         else { part_store(part + (size_t)bx * 2, s0); part_store(part + (size_t)bx * 2 + 1, s2); }
     }
     if (nblocks > 1) finish_partials(part, 2, tickets_of(partials) + y * 32, res + J.sums_slot + 2 * rd, sm, nblocks);
 }
+// two consecutive rounds per pass: thread j runs round t; the lane pair (2j', 2j'+1) then shares round t+1 on the folded
+// values it holds in registers (even lane: a'b' at x' -> P0 and the fold of a; odd lane: at y' -> P1 and the fold of b;
+// Pinf = (a'_y - a'_x)(b'_y - b'_x) split by Ext2 coordinate). s0' = P0, s2' = 2 P1 - P0 + 2 Pinf.
+template <typename TA>
+__device__ __forceinline__ void ps_step2_body(const PsJob& J, const PsItem& I, size_t half, E2 ra, E2 rb, E2* acc /*[4]*/, E2* sm) {
+    using V = Val<TA>;
+    const int tid = threadIdx.x;
+    const bool odd = tid & 1;
+    const size_t half2 = half >> 1, ntiles = half >> 8;
+    const int nblocks = I.nblk, bx = (int)blockIdx.x - I.blk0;
+    const FoldR fa = fold_r(ra);
+    const FoldR fb = fold_r(odd ? e2_sub(e2_one(), rb) : rb);
+    WE2 w0 = we2_zero(), w2 = we2_zero();
+    W2 vm = w2_zero();
+    WAcc vi = wacc_zero();
+    for (size_t tile = bx; tile < ntiles; tile += nblocks) {
+        const size_t j = (tile << 8) + tid;
+        const size_t jo2 = dpos(j >> 1, half2);
+        for (int i = 0; i < J.npairs; i++) {
+            const void* pa; const E2* pb; E2* oa; E2* ob;
+            ps_io(J, I.rd, 2, I.in_buf, I.out_buf, i, pa, pb, oa, ob);
+            TA xa, ya;
+            E2 xb, yb;
+            if (I.in_buf < 0) {
+                load_pair<TA>(reinterpret_cast<const TA*>(pa) + 2 * j, xa, ya);
+                load_pair<E2>(pb + 2 * j, xb, yb);
+            } else {
+                load_xy<TA, false>(reinterpret_cast<const TA*>(pa), j, half, xa, ya);
+                load_xy<E2, false>(pb, j, half, xb, yb);
+            }
+            TA da = V::sub(ya, xa);
+            E2 db = e2_sub(yb, xb);
+            E2 vb = e2_add(yb, db);
+            TA va = V::add(ya, da);
+            E2 ma;  // folded a
+            if constexpr (std::is_same<TA, u64>::value) {
+                wmac2(w0.A, xb.c0, xa, w0.C, xb.c1, xa);
+                wmac2(w2.A, vb.c0, va, w2.C, vb.c1, va);
+                WAcc f0 = wacc_zero(), f1 = wacc_zero();
+                f0.L = xa;
+                wmac2(f0, fa.r0, da, f1, fa.r1, da);
+                ma = e2(wreduce(f0), wreduce(f1));
+            } else {
+                we2_mac(w0, xb, xa);
+                we2_mac(w2, vb, va);
+                ma = e2_fold_wide(xa, da, fa);
+            }
+            const E2 mb = e2_fold_wide(xb, db, fa);
+            const E2 oa_ = swap_lane(ma), ob_ = swap_lane(mb);
+            const E2 ea = e2_sub(oa_, ma), eb = e2_sub(ob_, mb);  // +-(y' - x'); the sign cancels in the product
+            w2_mac(vm, ma, mb);
+            const u64 b = odd ? eb.c1 : eb.c0, d = odd ? eb.c0 : eb.c1;
+            const u64 c = odd ? ea.c1 : gl_mul_small(ea.c1, 7);
+            wmac_pair(vi, ea.c0, b, c, d);
+            const E2 fx = odd ? mb : ma, fd = odd ? eb : ea;
+            store_e2((odd ? ob : oa) + jo2, e2_fold_wide(fx, fd, fb));
+        }
+    }
+    acc[0] = we2_reduce(w0);
+    acc[1] = we2_reduce(w2);
+    const E2 mine = w2_reduce(vm);
+    const u64 ip = wreduce(vi);
+    const E2 P0 = block_sum_n(odd ? e2_zero() : mine, sm);
+    const E2 P1 = block_sum_n(odd ? mine : e2_zero(), sm);
+    const E2 Pi = block_sum_n(odd ? e2(0, ip) : e2(ip, 0), sm);
+    acc[2] = P0;                                                        // valid in thread 0
+    acc[3] = e2_add(e2_sub(e2_dbl(P1), P0), e2_dbl(Pi));
+}
+__global__ __launch_bounds__(256) void k_ps_step2(const PsJob* __restrict__ jobs, const PsItem* __restrict__ items, int nitems,
+                                                  const E2* __restrict__ chal, E2* __restrict__ partials, E2* __restrict__ res) {
+    const int y = find_ps_item(items, nitems, blockIdx.x);
+    const PsItem& I = items[y];
+    const PsJob& J = jobs[I.job];
+    const int rd = I.rd;
+    const int nblocks = I.nblk, bx = (int)blockIdx.x - I.blk0;
+    E2* sm = dyn_lds;
+    const size_t half = (size_t)1 << (J.nvars - 1 - rd);
+    E2 acc[4];
+    if (I.in_buf < 0) ps_step2_body<u64>(J, I, half, chal[J.r_off + rd], chal[J.r_off + rd + 1], acc, sm);
+    else ps_step2_body<E2>(J, I, half, chal[J.r_off + rd], chal[J.r_off + rd + 1], acc, sm);
+    const E2 s0 = block_sum_n(acc[0], sm), s2 = block_sum_n(acc[1], sm);
+    E2* part = partials + (size_t)y * SC_MAX_BLOCKS * 4;
+    if (threadIdx.x == 0) {
+        E2* out = nblocks == 1 ? res + J.sums_slot + 2 * rd : nullptr;
+        const E2 v[4] = {s0, s2, acc[2], acc[3]};
+        for (int t = 0; t < 4; t++) { if (out) out[t] = v[t]; else part_store(part + (size_t)bx * 4 + t, v[t]); }
+    }
+    if (nblocks > 1) finish_partials(part, 4, tickets_of(partials) + y * 32, res + J.sums_slot + 2 * rd, sm, nblocks);
+}
 // rounds [tail_rd, nvars) of every job, one workgroup per job
 __global__ __launch_bounds__(1024) void k_ps_tail(const PsJob* __restrict__ jobs, const E2* __restrict__ chal, E2* __restrict__ res) {
     const PsJob& J = jobs[blockIdx.x];
     E2* sm = dyn_lds;
     int bd_log2 = 31 - __clz((int)blockDim.x);
+    int in_buf = J.tail_buf;
     for (int rd = J.tail_rd; rd < J.nvars; rd++) {
         const int hl = J.nvars - 1 - rd;
         const size_t half = (size_t)1 << hl;
         const int jb_log2 = hl < bd_log2 ? hl : bd_log2;
+        const int out_buf = rd == J.nvars - 1 ? -1 : (in_buf == 0 ? 1 : 0);
         E2 r = chal[J.r_off + rd];
         E2 a0 = e2_zero(), a2 = e2_zero();
-        if (rd == 0) ps_round_body<u64>(J, rd, half, r, jb_log2, a0, a2, 0, 1);
-        else ps_round_body<E2>(J, rd, half, r, jb_log2, a0, a2, 0, 1);
+        if (in_buf < 0) ps_round_body<u64>(J, rd, in_buf, out_buf, half, r, jb_log2, a0, a2, 0, 1);
+        else ps_round_body<E2>(J, rd, in_buf, out_buf, half, r, jb_log2, a0, a2, 0, 1);
         E2 s0 = block_sum_n(a0, sm);
         E2 s2 = block_sum_n(a2, sm);
         if (threadIdx.x == 0) { res[J.sums_slot + 2 * rd] = s0; res[J.sums_slot + 2 * rd + 1] = s2; }
         __syncthreads();
+        in_buf = out_buf;
     }
 }
 
-int ps_plan_blocks(PsItem* items, int nitems, const PsJob* host_jobs, int rd) {
+int ps_plan_blocks(PsItem* items, int nitems, const PsJob* host_jobs, bool rounds2) {
     size_t total = 0;
-    for (int q = 0; q < nitems; q++) total += ((size_t)1 << (host_jobs[items[q].job].nvars - 1 - rd)) * host_jobs[items[q].job].npairs;
+    for (int q = 0; q < nitems; q++) total += ((size_t)1 << (host_jobs[items[q].job].nvars - 1 - items[q].rd)) * host_jobs[items[q].job].npairs;
+    int jb0 = 8;
+    if (!rounds2) while (jb0 > 2 && (total << (8 - jb0)) < st_min_threads()) jb0--;
+    // a workgroup pays ~10 reductions and 4-5 block sums once, whatever it processed: give it several tiles when the
+    // launch has enough of them (the items have only 1-3 table pairs each, unlike the grand-product jobs)
+    size_t all_tiles = 0;
+    for (int q = 0; q < nitems; q++) all_tiles += ((size_t)1 << (host_jobs[items[q].job].nvars - 1 - items[q].rd)) >> jb0;
+    static const size_t target_blocks = env_size("HG_PS_TARGET_BLOCKS", 4096);
+    size_t per = all_tiles / target_blocks;
+    if (per < 1) per = 1;
+    if (per > 32) per = 32;
     int blk = 0;
     for (int q = 0; q < nitems; q++) {
         PsItem& I = items[q];
-        const int hl = host_jobs[I.job].nvars - 1 - rd;
-        int jb = 8;
-        while (jb > 2 && (total << (8 - jb)) < st_min_threads()) jb--;
+        const int hl = host_jobs[I.job].nvars - 1 - I.rd;
+        int jb = jb0;
         if (jb > hl) jb = hl;
         const size_t ntiles = ((size_t)1 << hl) >> jb;
         I.jb_log2 = jb; I.blk0 = blk;
-        I.nblk = (int)std::min<size_t>(ntiles, (size_t)st_max_blocks());
+        I.nblk = (int)std::min<size_t>((ntiles + per - 1) / per, (size_t)st_max_blocks());
         blk += I.nblk;
     }
     return blk;
 }
-void ps_round(hipStream_t st, const PsJob* jobs, const PsItem* items, int nitems, int grid, int rd, const E2* chal, E2* partials, E2* res) {
-    k_ps_one<<<grid, 256, 16 * sizeof(E2), st>>>(jobs, items, nitems, rd, chal, partials, res);
+void ps_round(hipStream_t st, bool rounds2, const PsJob* jobs, const PsItem* items, int nitems, int grid, const E2* chal, E2* partials, E2* res) {
+    if (rounds2) k_ps_step2<<<grid, 256, 16 * sizeof(E2), st>>>(jobs, items, nitems, chal, partials, res);
+    else k_ps_one<<<grid, 256, 16 * sizeof(E2), st>>>(jobs, items, nitems, chal, partials, res);
 }
 void ps_tail(hipStream_t st, const PsJob* jobs, int njobs, const E2* chal, E2* res) {
     k_ps_tail<<<njobs, 1024, 16 * sizeof(E2), st>>>(jobs, chal, res);

@@ -87,17 +87,21 @@ struct PsJob {
     E2* bufb[2];
     int npairs, nvars;
     int tail_rd;                  // first round of the single-workgroup tail (host-planned)
+    int tail_buf;                 // where that round reads: -1 = a[] / b[], else bufa/bufb[tail_buf]
     size_t r_off;                 // chain index of round 0's challenge
     size_t sums_slot;             // result slots: 2 per round
 };
 // one (job, round) of a PRODSUM launch; the items of a launch share a 1-D grid like StItem
 struct PsItem {
     int job, jb_log2, blk0, nblk;
+    int rd;                       // (first) round this item runs
+    int in_buf, out_buf;          // -1 = the job's a[] / b[] (in) or fin_a / fin_b (out), else bufa/bufb[.]; host-planned ping-pong
+    int pad;
 };
-// fills jb_log2 / blk0 / nblk for round rd of the listed jobs (host side); returns the grid size
-int ps_plan_blocks(PsItem* items, int nitems, const PsJob* host_jobs, int rd);
-// round `rd` of every item's job (jobs of different sizes share the launch)
-void ps_round(hipStream_t st, const PsJob* jobs, const PsItem* items, int nitems, int grid, int rd, const E2* chal, E2* partials, E2* res);
+// fills jb_log2 / blk0 / nblk of the items of one launch (host side); returns the grid size. rounds2: fused launch.
+int ps_plan_blocks(PsItem* items, int nitems, const PsJob* host_jobs, bool rounds2);
+// one round (rounds2: two consecutive rounds, lane pairs share the second) of every item's job; jobs of different sizes share the launch
+void ps_round(hipStream_t st, bool rounds2, const PsJob* jobs, const PsItem* items, int nitems, int grid, const E2* chal, E2* partials, E2* res);
 // rounds [tail_rd, nvars) of every job, one workgroup per job
 void ps_tail(hipStream_t st, const PsJob* jobs, int njobs, const E2* chal, E2* res);
 

@@ -520,34 +520,56 @@ struct Prover {
             J.tail_rd = rd;
             max_rd = std::max(max_rd, rd);
         }
-        dev::PsJob* d_jobs = ctx->alloc_n<dev::PsJob>(nj);
-        hip_check(hipMemcpyAsync(d_jobs, stage(jobs.data(), (size_t)nj * sizeof(dev::PsJob)), (size_t)nj * sizeof(dev::PsJob), hipMemcpyHostToDevice, st), "upload jobs");
         auto round_bytes = [&](const dev::PsJob& J, int rd) {
             size_t half = ((size_t)1 << J.nvars) >> (rd + 1);
             return (double)J.npairs * (2.0 * half * ((rd == 0 ? 8 : 16) + 16) + half * 32.0);
         };
-        // plan every round first, upload all items in one copy, then launch
-        struct PsLaunch { int rd, cnt, grid; size_t off; double bytes; };
+        // plan every step first (step s = every job's next round, or its next two rounds when its table is long
+        // enough), upload all items in one copy, then launch; the host tracks each job's ping-pong buffer
+        static const bool ps_fuse2 = [] { const char* e = getenv("HG_NO_PS_FUSE2"); return !(e && e[0] == '1'); }();
+        static const int ps_fuse_min_h = [] { const char* e = getenv("HG_PS_FUSE_MIN_H"); return e && *e ? atoi(e) : 11; }();
+        struct PsLaunch { bool two; int cnt, grid; size_t off; double bytes; };
         std::vector<PsLaunch> launches;
         std::vector<dev::PsItem> all_items;
-        for (int rd = 0; rd < max_rd; rd++) {
-            std::vector<dev::PsItem> items;
-            for (int q = 0; q < nj; q++) if (rd < jobs[q].tail_rd) { dev::PsItem it; memset(&it, 0, sizeof(it)); it.job = q; items.push_back(it); }
-            for (size_t o = 0; o < items.size(); o += MAX_BATCH) {
-                const int cnt = (int)std::min<size_t>(MAX_BATCH, items.size() - o);
-                const int grid = dev::ps_plan_blocks(items.data() + o, cnt, jobs.data(), rd);
-                double bytes = 0;
-                for (int q = 0; q < cnt; q++) bytes += round_bytes(jobs[items[o + q].job], rd);
-                launches.push_back({rd, cnt, grid, all_items.size(), bytes});
-                all_items.insert(all_items.end(), items.begin() + o, items.begin() + o + cnt);
+        std::vector<int> next_rd(nj, 0), cur_buf(nj, -1);
+        for (;;) {
+            std::vector<dev::PsItem> one, two;
+            for (int q = 0; q < nj; q++) {
+                const dev::PsJob& J = jobs[q];
+                const int rd = next_rd[q];
+                if (rd >= J.tail_rd) continue;
+                const int h = J.nvars - 1 - rd;
+                const bool pair = ps_fuse2 && rd + 1 < J.tail_rd && h >= std::max(9, ps_fuse_min_h);
+                dev::PsItem it;
+                memset(&it, 0, sizeof(it));
+                it.job = q; it.rd = rd; it.in_buf = cur_buf[q]; it.out_buf = cur_buf[q] == 1 ? 0 : 1;
+                if (cur_buf[q] < 0) it.out_buf = pair ? 1 : 0;  // sizes: bufa[0] holds N/2 entries per table, bufa[1] N/4
+                (pair ? two : one).push_back(it);
+                next_rd[q] = rd + (pair ? 2 : 1);
+                cur_buf[q] = it.out_buf;
+            }
+            if (one.empty() && two.empty()) break;
+            for (int kind = 0; kind < 2; kind++) {
+                std::vector<dev::PsItem>& items = kind ? two : one;
+                for (size_t o = 0; o < items.size(); o += MAX_BATCH) {
+                    const int cnt = (int)std::min<size_t>(MAX_BATCH, items.size() - o);
+                    const int grid = dev::ps_plan_blocks(items.data() + o, cnt, jobs.data(), kind == 1);
+                    double bytes = 0;
+                    for (int q = 0; q < cnt; q++) for (int k = 0; k <= kind; k++) bytes += round_bytes(jobs[items[o + q].job], items[o + q].rd + k);
+                    launches.push_back({kind == 1, cnt, grid, all_items.size(), bytes});
+                    all_items.insert(all_items.end(), items.begin() + o, items.begin() + o + cnt);
+                }
             }
         }
+        for (int q = 0; q < nj; q++) jobs[q].tail_buf = cur_buf[q];
+        dev::PsJob* d_jobs = ctx->alloc_n<dev::PsJob>(nj);
+        hip_check(hipMemcpyAsync(d_jobs, stage(jobs.data(), (size_t)nj * sizeof(dev::PsJob)), (size_t)nj * sizeof(dev::PsJob), hipMemcpyHostToDevice, st), "upload jobs");
         if (!all_items.empty()) {
             dev::PsItem* d_items = ctx->alloc_n<dev::PsItem>(all_items.size());
             hip_check(hipMemcpyAsync(d_items, stage(all_items.data(), all_items.size() * sizeof(dev::PsItem)), all_items.size() * sizeof(dev::PsItem), hipMemcpyHostToDevice, st), "upload items");
             for (auto& L : launches) {
                 ctx->prof_begin(cls_ps, L.bytes);
-                dev::ps_round(st, d_jobs, d_items + L.off, L.cnt, L.grid, L.rd, ctx->d_chal, partials, d_res());
+                dev::ps_round(st, L.two, d_jobs, d_items + L.off, L.cnt, L.grid, ctx->d_chal, partials, d_res());
                 ctx->prof_end();
             }
         }
