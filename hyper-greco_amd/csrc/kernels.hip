@@ -1306,9 +1306,8 @@ void gp_top(hipStream_t st, const u64* top, int nb, E2* roots, E2* evals) {
 }
 
 struct DotTabs { const u64* t[8]; };
-__global__ __launch_bounds__(TPB) void k_dot_eq(const E2* __restrict__ eq, DotTabs tabs, int ntab, size_t n, E2* __restrict__ partials,
-                                                E2* __restrict__ out) {
-    __shared__ E2 sm[16];
+__global__ __launch_bounds__(TPB) void k_dot_eq(const E2* __restrict__ eq, DotTabs tabs, int ntab, size_t n, E2* __restrict__ partials) {
+    __shared__ E2 sm[TPB / 64];
     E2 acc[8];
 #pragma unroll
     for (int t = 0; t < 8; t++) acc[t] = e2_zero();
@@ -1324,20 +1323,20 @@ __global__ __launch_bounds__(TPB) void k_dot_eq(const E2* __restrict__ eq, DotTa
 #pragma unroll
     for (int t = 0; t < 8; t++)
         if (t < ntab) {
-            E2 s = block_sum_n(acc[t], sm);
-            if (threadIdx.x == 0) {
-                if (gridDim.x == 1) out[t] = s;
-                else part_store(partials + (size_t)blockIdx.x * ntab + t, s);
-            }
+            E2 s = block_sum(acc[t], sm);
+            if (threadIdx.x == 0) partials[(size_t)blockIdx.x * ntab + t] = s;
         }
-    if (gridDim.x > 1) finish_partials(partials, ntab, tickets_of(partials), out, sm);
 }
-// out[t] = sum_j eq[j] * tabs[t][j]; `partials` is a partials buffer (the last-arriving workgroup sums into `out`)
+__global__ __launch_bounds__(TPB) void k_reduce_partials(const E2* __restrict__ partials, int nblocks, int nv, E2* __restrict__ out);
+// out[t] = sum_j eq[j] * tabs[t][j]
 void dot_eq(hipStream_t st, const E2* eq, const u64* const tabs[8], int ntab, size_t n, E2* partials, E2* out) {
     DotTabs d;
     for (int t = 0; t < 8; t++) d.t[t] = t < ntab ? tabs[t] : nullptr;
-    // (column accumulators were measured slower here: 8 independent 8-byte streams per thread need the occupancy more)
-    k_dot_eq<<<grid_for(n), TPB, 0, st>>>(eq, d, ntab, n, partials, out);
+    // (measured slower here: column accumulators - 8 independent 8-byte streams per thread need the occupancy more -
+    // and the last-arriving-workgroup reduction - 8 values x 1024 partials)
+    const int grid = grid_for(n);
+    k_dot_eq<<<grid, TPB, 0, st>>>(eq, d, ntab, n, partials);
+    k_reduce_partials<<<1, TPB, 0, st>>>(partials, grid, ntab, out);
 }
 
 // ------------------------------------------------------------------------------------------------

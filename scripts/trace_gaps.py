@@ -5,9 +5,8 @@ import csv, glob, sys
 f = sorted(glob.glob(sys.argv[1] + "/**/*_kernel_trace.csv", recursive=True))[-1]
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(f))), key=lambda r: r[0])
-# split into proves by the largest gaps
-gaps = sorted(((rows[i + 1][0] - rows[i][1], i) for i in range(len(rows) - 1)), reverse=True)[: n]
-cut = sorted(i for _, i in gaps)[-1] if n > 1 else -1
+# the last prove = everything after the last inter-kernel gap longer than 150 us (host replay between proves)
+cut = max([i for i in range(len(rows) - 1) if rows[i + 1][0] - rows[i][1] > 150000] or [-1])
 last = rows[cut + 1:]
 span = last[-1][1] - last[0][0]
 busy = sum(e - s for s, e, _ in last)
@@ -19,3 +18,5 @@ for i in range(len(last) - 1):
 print("last prove: %d dispatches, span %.3f ms, busy %.3f ms, gaps %.3f ms (avg %.2f us)" % (len(last), span / 1e6, busy / 1e6, tot_gap / 1e6, tot_gap / 1e3 / max(1, len(last) - 1)))
 small = [(e - s) / 1e3 for s, e, _ in last if e - s < 10000]
 print("dispatches shorter than 10 us: %d, total %.3f ms" % (len(small), sum(small) / 1e3))
+big_gaps = sorted(((last[i + 1][0] - last[i][1]) / 1e3, last[i][2][:50], last[i + 1][2][:50]) for i in range(len(last) - 1))[-8:]
+for g, a, b in big_gaps: print("gap %.1f us between %s -> %s" % (g, a, b))
