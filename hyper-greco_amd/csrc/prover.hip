@@ -621,6 +621,12 @@ struct Prover {
             }
         });
     }
+    // proof map (HG_PROOF_MAP=<file>): byte offset of every protocol element, for diffing against a proof dumped by the
+    // Rust reference (scripts/proof_diff.py) - each label names the convention that decides those bytes
+    std::vector<std::pair<size_t, std::string>> proof_map;
+    void mark(const std::string& label) {
+        if (getenv("HG_PROOF_MAP")) ops.push_back([this, label] { proof_map.push_back({proof.bytes.size(), label}); });
+    }
     void defer_write_slots(size_t s, size_t n) {
         ops.push_back([this, s, n] { for (size_t i = 0; i < n; i++) proof.write_e(h_res()[s + i]); });
     }
@@ -750,6 +756,7 @@ struct Prover {
             }
         }
         auto claims = std::make_shared<std::vector<E2>>(nb);
+        mark("grand product: " + std::to_string(nb) + " root products (prover.rs:197-221)");
         ops.push_back([this, roots, nb, claims] {  // root products (prover.rs:197-221)
             for (int b = 0; b < nb; b++) { (*claims)[b] = h_res()[roots + b]; proof.write_e((*claims)[b]); }
         });
@@ -761,6 +768,7 @@ struct Prover {
         };
         GpOut out{0};
         // layer with num_vars 0
+        mark("grand product layer 0: v_l, v_r evaluations per tree (prover.rs:257; no sum-check)");
         defer_write_slots(ev0, 2 * (size_t)nb);
         out.point_off = epos();
         layer_down(ev0, squeeze());
@@ -796,8 +804,10 @@ struct Prover {
                         scatter.push_back({fin + 2 * li + 1, evals + 2 * (size_t)b + 1});
                     }
             }
+            mark("grand product layer " + std::to_string(n) + ": sum-check, " + std::to_string(n) + " rounds x 4 coefficients [C1 message format, C2 power order, C3 variable order]");
             defer_sumcheck(sc, 3, claim, nullptr);
             defer_gp_unscale(evals, nb, pw);
+            mark("grand product layer " + std::to_string(n) + ": v_l, v_r evaluations per tree (prover.rs:257)");
             defer_write_slots(evals, 2 * (size_t)nb);  // prover.rs:257
             out.point_off = sc.point_off;
             layer_down(evals, squeeze());              // mu (prover.rs:259)
@@ -837,6 +847,7 @@ struct Prover {
             reduce(grid, 1, claim_slot);
         }
         Cell claimed = cell();
+        mark("lasso: claimed sum (lasso.rs:100-107)");
         ops.push_back([this, claim_slot, claimed] { *claimed = h_res()[claim_slot]; proof.write_e(*claimed); });
         {   // collation sum-check (lasso.rs:271-279): g = poly(0) * sum_i M^i poly(i)
             dev::Powers pw;
@@ -845,6 +856,7 @@ struct Prover {
             u64 c = 1;
             for (int i = 0; i < A; i++) { pw.v[i] = e2(c, 0); c = gl_mul(c, M); }
             ScHandle sc = sc_stride(dev::SC_COLLATION, ep, true, N, A, nu, pw, nullptr, do_col);
+            mark("lasso: collation sum-check, " + std::to_string(nu) + " rounds x 3 coefficients (lasso.rs:271-279) [C1, C3; poly(0) quirk]");
             defer_sumcheck(sc, 2, claimed, nullptr);
         }
         E2 gamma_e = squeeze(), tau_e = squeeze();  // lasso.rs:99
@@ -912,8 +924,10 @@ struct Prover {
             dev::lasso_hash_if(st, ha, G, gamma, tau, H2);
             ctx->prof_end();
         }
+        mark("lasso: memory checking, grand product #1 over reads then writes (prover.rs:161-165)");
         GpOut g1 = split ? grand_product(H1, N, 2 * G, gp1_owner, L1, &local_pairs, p0_only)
                          : grand_product(H1, N, 2 * G, gp1_owner, L1);  // reads then writes (prover.rs:161-165)
+        mark("lasso: memory checking, grand product #2 over inits then finals (prover.rs:167-171)");
         GpOut g2 = grand_product(H2, M, 2 * G, std::vector<int>(16, own_gp2));      // inits then finals (prover.rs:167-171)
         // openings (prover.rs:173-178, mod.rs:80-93)
         E2* eqx = eq;  // the eq(r,.) table is dead by now
@@ -952,6 +966,7 @@ struct Prover {
                 const u64* tabs[8] = {final_cts[c]};
                 dev::dot_eq(st, eqy, tabs, 1, M, partials, d_res() + base_slot + 2);
             }
+            mark("lasso: openings of chunk " + std::to_string(c) + ": dim(x), read_ts(x), final_cts(y), E_m(x) (prover.rs:173-178)");
             defer_write_slots(base_slot, 3 + chk.second.size());
         }
         flush_stride();  // collation + every grand-product layer, size-synchronised
@@ -1034,8 +1049,10 @@ struct Prover {
         }
         ScHandle s1 = sc_prodsum(a, b, nin, fa, fb, own);
         Cell after1 = cell();
+        mark("vanilla node " + std::to_string(id) + ": Libra phase 1 sum-check, " + std::to_string(nin) + " rounds x 3 coefficients [G1 node order, G2 alpha per claim, G3 Libra form]");
         defer_sumcheck(s1, 2, claim, after1);
         for (int i : li) {
+            mark("vanilla node " + std::to_string(id) + ": input " + std::to_string(i) + " evaluation at r_x");
             defer_write_slots(u_base + i, 1);
             Cell v = cell();
             size_t sl = u_base + i;
@@ -1084,8 +1101,10 @@ struct Prover {
                 for (int q = 0; q < npairs; q++) { J.a[q] = a2[q]; J.b[q] = Bs[q]; J.fin_a[q] = fa2[q]; J.fin_b[q] = fb2[q]; }
                 ps_queue[nin].push_back(J);
             });
+            mark("vanilla node " + std::to_string(id) + ": Libra phase 2 sum-check [G3]");
             defer_sumcheck(s2, 2, after1, nullptr);
             for (int i : ri) {
+                mark("vanilla node " + std::to_string(id) + ": input " + std::to_string(i) + " evaluation at r_y");
                 defer_write_slots(w_base + i, 1);
                 Cell v = cell();
                 size_t sl = w_base + i;
@@ -1110,7 +1129,9 @@ struct Prover {
         size_t u = slot(1);
         E2* scratch = own ? ctx->alloc_n<E2>(1) : nullptr;
         ScHandle s = sc_prodsum({d_vals[n.preds[0]]}, {F}, L, {d_res() + u}, {scratch}, own);
+        mark("fft node " + std::to_string(id) + ": zkCNN sum-check, " + std::to_string(L) + " rounds x 3 coefficients [G3 zkCNN form, G4 root of unity]");
         defer_sumcheck(s, 2, claim, nullptr);
+        mark("fft node " + std::to_string(id) + ": input evaluation");
         defer_write_slots(u, 1);
         Cell v = cell();
         ops.push_back([this, v, u] { *v = h_res()[u]; });
@@ -1174,6 +1195,13 @@ struct Prover {
         double t = wall_ms();
         proof.bytes.reserve((size_t)1 << 18);
         for (auto& op : ops) op();
+        if (const char* path = getenv("HG_PROOF_MAP")) {
+            if (FILE* f = fopen(path, "w")) {
+                for (auto& m : proof_map) fprintf(f, "%zu\t%s\n", m.first, m.second.c_str());
+                fprintf(f, "%zu\tend of proof\n", proof.bytes.size());
+                fclose(f);
+            }
+        }
         t_replayed = t_synced + (wall_ms() - t);
         ctx->prof_collect();
     }

@@ -17,3 +17,5 @@ out = hg.ProofBuffer()
 for _ in range(steps):
     hg.prove_resident(ctx, pk, vals, out)
     print(out.timings())
+if os.environ.get("HG_PROOF_OUT"):
+    open(os.environ["HG_PROOF_OUT"], "wb").write(out.bytes())

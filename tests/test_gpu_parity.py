@@ -274,3 +274,30 @@ def test_lasso_node_inside_a_larger_transcript(ctx):
             break
     assert found, "no challenge offset reproduces the node's section of the full proof"
     pk.free()
+
+
+def test_proof_map_covers_the_stream_and_diff_tool_localises_a_flip(ctx, tmp_path, monkeypatch):
+    """HG_PROOF_MAP labels every byte range of the proof (scripts/proof_diff.py uses it to name the first diverging
+    protocol element against a proof dumped by the Rust reference)."""
+    import subprocess, sys
+    mp = tmp_path / "map.tsv"
+    monkeypatch.setenv("HG_PROOF_MAP", str(mp))
+    bfv = hg.BfvEncrypt.new(1024, 1)
+    pk = bfv.setup(ctx)
+    w = bfv.get_inputs(os.path.join(orclib.GOLDEN, "sk_enc_1024_1x27_65537.json"))
+    proof, _ = bfv.prove(ctx, pk, w)
+    monkeypatch.delenv("HG_PROOF_MAP")
+    rows = [l.rstrip("\n").split("\t", 1) for l in open(mp)]
+    offs = [int(r[0]) for r in rows]
+    assert offs == sorted(offs) and offs[0] == 0 and offs[-1] == len(proof) and rows[-1][1] == "end of proof"
+    assert any("collation" in r[1] for r in rows) and any("fft node" in r[1] for r in rows) and any("vanilla node" in r[1] for r in rows)
+    # flip one byte inside the collation rounds and let the tool find it
+    start = next(int(r[0]) for r in rows if "collation" in r[1])
+    bad = bytearray(proof); bad[start + 24] ^= 1
+    a, b = tmp_path / "a.bin", tmp_path / "b.bin"
+    a.write_bytes(proof); b.write_bytes(bytes(bad))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "proof_diff.py"), str(a), str(b), str(mp)], capture_output=True, text=True)
+    assert r.returncode == 1 and "collation" in r.stdout and "byte %d" % (start + 24) in r.stdout
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "proof_diff.py"), str(a), str(a), str(mp)], capture_output=True, text=True)
+    assert r.returncode == 0 and "identical" in r.stdout
