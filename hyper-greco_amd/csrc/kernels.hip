@@ -1402,30 +1402,60 @@ int vanilla_const_sum(hipStream_t st, const u32* gate, const u64* coef, size_t n
     return grid;
 }
 
-// zkCNN DFT-row tables of every FFT node in one launch (grid.y = node)
-__global__ __launch_bounds__(TPB) void k_fft_jobs(const FftJob* __restrict__ jobs, const E2* __restrict__ chal) {
+// zkCNN DFT-row tables of every FFT node (grid.y = node): F(x) = scale * sum_a alpha_a prod_b f_{a,b}(x),
+// f_{a,b}(x) = 1 + r_{a,b} (w^(2^b x) - 1). The factor b only depends on x mod 2^(L-b), so the factors b >= FFT_SPLIT
+// are a table over x mod 2^(L - FFT_SPLIT) (k_fft_tab, 2^(L-4) entries per claim) and every output needs just the 4
+// low-b factors and one table lookup: 5 instead of 16 Ext2 multiplications per output at L = 16.
+constexpr int FFT_SPLIT = 4;
+__global__ __launch_bounds__(TPB) void k_fft_tab(const FftJob* __restrict__ jobs, const E2* __restrict__ chal, E2* __restrict__ tab, size_t tab_stride,
+                                                 int max_claims) {
+    const FftJob& J = jobs[blockIdx.y / max_claims];
+    const int a = blockIdx.y % max_claims;
+    const int L = J.L;
+    if (a >= J.cs.n || L <= FFT_SPLIT) return;
+    const size_t N = (size_t)1 << L, n = N >> FFT_SPLIT;
+    const u64* __restrict__ W = J.W;
+    const E2* r = chal + J.cs.point_off[a];
+    E2* out = tab + (size_t)blockIdx.y * tab_stride;
+    for (size_t y = (size_t)blockIdx.x * TPB + threadIdx.x; y < n; y += (size_t)gridDim.x * TPB) {
+        E2 p = J.cs.unit_alpha ? e2(J.scale, 0) : e2_mul_f(chal[J.cs.alpha_off + a], J.scale);
+        for (int b = FFT_SPLIT; b < L; b++) {
+            u64 wx = W[(y << b) & (N - 1)];
+            p = e2_mul(p, e2_add_f(e2_mul_f(r[b], gl_sub(wx, 1)), 1));
+        }
+        store_e2(out + y, p);
+    }
+}
+__global__ __launch_bounds__(TPB) void k_fft_jobs(const FftJob* __restrict__ jobs, const E2* __restrict__ chal, const E2* __restrict__ tab,
+                                                  size_t tab_stride, int max_claims) {
     const FftJob& J = jobs[blockIdx.y];
     const int L = J.L;
     const size_t N = (size_t)1 << L;
     const u64* __restrict__ W = J.W;
+    const bool split = L > FFT_SPLIT;
+    const int nb = split ? FFT_SPLIT : L;
     for (size_t x = (size_t)blockIdx.x * TPB + threadIdx.x; x < N; x += (size_t)gridDim.x * TPB) {
         E2 acc = e2_zero();
         for (int a = 0; a < J.cs.n; a++) {
             const E2* r = chal + J.cs.point_off[a];
-            E2 p = e2(J.scale, 0);
-            for (int b = 0; b < L; b++) {
+            E2 p = split ? tab[((size_t)blockIdx.y * max_claims + a) * tab_stride + (x & ((N >> FFT_SPLIT) - 1))]
+                         : (J.cs.unit_alpha ? e2(J.scale, 0) : e2_mul_f(chal[J.cs.alpha_off + a], J.scale));
+            for (int b = 0; b < nb; b++) {
                 u64 wx = W[(x << b) & (N - 1)];
                 E2 f = e2_add_f(e2_mul_f(r[b], gl_sub(wx, 1)), 1);  // 1 - r_b + r_b w^(2^b x)
                 p = e2_mul(p, f);
             }
-            acc = e2_add(acc, J.cs.unit_alpha ? p : e2_mul(chal[J.cs.alpha_off + a], p));
+            acc = e2_add(acc, p);
         }
         store_e2(J.out + x, acc);
     }
 }
-void fft_jobs(hipStream_t st, const FftJob* jobs, int njobs, int max_L, const E2* chal) {
+void fft_jobs(hipStream_t st, const FftJob* jobs, int njobs, int max_L, int max_claims, const E2* chal, E2* tab) {
     size_t N = (size_t)1 << max_L;
-    k_fft_jobs<<<dim3((unsigned)std::min<size_t>((N + TPB - 1) / TPB, 1024), njobs), TPB, 0, st>>>(jobs, chal);
+    const size_t tab_stride = max_L > FFT_SPLIT ? N >> FFT_SPLIT : 1;
+    if (max_L > FFT_SPLIT)
+        k_fft_tab<<<dim3((unsigned)std::min<size_t>((tab_stride + TPB - 1) / TPB, 64), njobs * max_claims), TPB, 0, st>>>(jobs, chal, tab, tab_stride, max_claims);
+    k_fft_jobs<<<dim3((unsigned)std::min<size_t>((N + TPB - 1) / TPB, 1024), njobs), TPB, 0, st>>>(jobs, chal, tab, tab_stride, max_claims);
 }
 // Libra bookkeeping tables of many (node, input) pairs in one launch (grid.y = job)
 __global__ __launch_bounds__(TPB) void k_gather_jobs(const GatherJob* __restrict__ jobs) {

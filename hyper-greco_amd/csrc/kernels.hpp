@@ -183,7 +183,8 @@ void gather_B_jobs(hipStream_t st, const GatherBJob* jobs, int njobs, size_t max
 int vanilla_const_sum(hipStream_t st, const u32* gate, const u64* coef, size_t nterms, const E2* eqc, int log2_G, int log2_R, E2* partials);
 // F_c(x) = sum_a alpha_a * scale * prod_b (1 + r_{a,b} (W[(x<<b) & (N-1)] - 1))
 struct FftJob { E2* out; const u64* W; u64 scale; int L; ClaimSet cs; };
-void fft_jobs(hipStream_t st, const FftJob* jobs, int njobs, int max_L, const E2* chal);
+// `tab`: scratch of njobs * max_claims * 2^(max_L - 4) E2 (the high-bit factor tables)
+void fft_jobs(hipStream_t st, const FftJob* jobs, int njobs, int max_L, int max_claims, const E2* chal, E2* tab);
 void powers_table(hipStream_t st, u64* W, u64 w, size_t n);  // W[i] = w^i
 
 // ---- circuit evaluation (witness generation): one Vanilla node, gate-major wiring -------------------------

@@ -691,9 +691,10 @@ struct Prover {
         size_t maxB = 0; double bb = 0;
         for (auto& J : gatherB_queue) { size_t t = (size_t)1 << (J.log2_S + J.log2_R); maxB = std::max(maxB, t); bb += 40.0 * t; }
         flush_jobs(gatherB_queue, cls_gather, bb, [&](dev::GatherBJob* d, int nj) { dev::gather_B_jobs(st, d, nj, maxB); });
-        int max_L = 0; double fb = 0;
-        for (auto& J : fft_queue) { max_L = std::max(max_L, J.L); fb += 24.0 * ((size_t)1 << J.L); }
-        flush_jobs(fft_queue, cls_aux, fb, [&](dev::FftJob* d, int nj) { dev::fft_jobs(st, d, nj, max_L, ctx->d_chal); });
+        int max_L = 0, max_claims = 1; double fb = 0;
+        for (auto& J : fft_queue) { max_L = std::max(max_L, J.L); max_claims = std::max(max_claims, J.cs.n); fb += 24.0 * ((size_t)1 << J.L); }
+        E2* fft_tab = fft_queue.empty() ? nullptr : ctx->alloc_n<E2>(fft_queue.size() * (size_t)max_claims * (((size_t)1 << max_L) >> 4) + 1);
+        flush_jobs(fft_queue, cls_aux, fb, [&](dev::FftJob* d, int nj) { dev::fft_jobs(st, d, nj, max_L, max_claims, ctx->d_chal, fft_tab); });
     }
 
     // ---- Lasso node (lasso.rs:57-114) ------------------------------------------------------------
