@@ -39,7 +39,7 @@ EXPORTS = [
     "hg_last_error", "hg_device_count", "hg_create", "hg_destroy", "hg_params_builtin", "hg_setup", "hg_pk_free",
     "hg_pk_lasso_layout", "hg_pk_info", "hg_witness_from_json", "hg_witness_synthetic", "hg_witness_from_arrays",
     "hg_witness_get", "hg_witness_free", "hg_prove", "hg_verify", "hg_witness_gen", "hg_values_free", "hg_values_get", "hg_prove_shard_begin", "hg_prove_shard_combine", "hg_prove_shard_finish", "hg_prove_resident", "hg_circuit_eval", "hg_lasso_prove", "hg_lasso_prove_at", "hg_sumcheck", "hg_mle_eval",
-    "hg_ntt", "hg_challenges", "hg_profile", "hg_profile_select", "hg_profile_reset", "hg_profile_get",
+    "hg_ntt", "hg_challenges", "hg_challenges_bn254", "hg_bn254_field_op", "hg_sumcheck_bn254", "hg_profile", "hg_profile_select", "hg_profile_reset", "hg_profile_get",
 ]
 
 
@@ -93,6 +93,10 @@ def lib():
         L.hg_mle_eval.argtypes = [C.c_void_p, u64p, C.c_size_t, u64p, u64p]
         L.hg_ntt.argtypes = [C.c_void_p, u64p, C.c_size_t, C.c_int, C.c_size_t, u64p]
         L.hg_challenges.argtypes = [C.c_size_t, u64p]
+        L.hg_challenges_bn254.argtypes = [C.c_size_t, u64p]
+        L.hg_bn254_field_op.argtypes = [C.c_void_p, C.c_int, C.c_size_t, u64p, u64p, u64p]
+        L.hg_sumcheck_bn254.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(u64p), u64p, C.c_size_t, u64p, C.c_size_t,
+                                        u64p, u64p, u64p, u64p]
         L.hg_profile.argtypes = [C.c_void_p, C.c_int]
         L.hg_profile_select.argtypes = [C.c_void_p, C.c_char_p]
         L.hg_profile_reset.argtypes = [C.c_void_p]
@@ -155,6 +159,45 @@ class Context:
         n = lib().hg_profile_get(self.h, arr, 32)
         return [dict(name=arr[i].name.decode(), launches=int(arr[i].launches), total_ms=arr[i].total_ms, algo_bytes=arr[i].algo_bytes)
                 for i in range(n)]
+
+    # ---- BN254 slice: elements are Python ints at this level, 4 little-endian u64 limbs at the C ABI
+    @staticmethod
+    def _fr_pack(vals):
+        a = np.zeros((len(vals), 4), dtype=np.uint64)
+        for i, v in enumerate(vals):
+            for k in range(4):
+                a[i, k] = (int(v) >> (64 * k)) & 0xFFFFFFFFFFFFFFFF
+        return a.reshape(-1)
+
+    @staticmethod
+    def _fr_unpack(a):
+        a = np.asarray(a, dtype=np.uint64).reshape(-1, 4)
+        return [sum(int(a[i, k]) << (64 * k) for k in range(4)) for i in range(a.shape[0])]
+
+    def bn254_field_op(self, op, a, b):
+        pa, pb = self._fr_pack(a), self._fr_pack(b)
+        out = np.zeros_like(pa)
+        _check(lib().hg_bn254_field_op(self.h, op, len(a), _ptr(pa), _ptr(pb), _ptr(out)))
+        return self._fr_unpack(out)
+
+    def sumcheck_bn254(self, kind, tables, pw, claim, chain_skip=0):
+        """gkr::sum_check::prove_sum_check over bn256::Fr: (msgs, point, evals, sums) as lists of ints."""
+        ntab = len(tables)
+        nv = (len(tables[0]) - 1).bit_length()
+        d = 3 if kind == 1 else 2
+        packed = [self._fr_pack(t) for t in tables]
+        ptrs = (u64p * ntab)(*[_ptr(t) for t in packed])
+        ppw = self._fr_pack(pw) if len(pw) else np.zeros(4, dtype=np.uint64)
+        pcl = self._fr_pack([claim])
+        msgs = np.zeros(max(nv * (d + 1), 1) * 4, dtype=np.uint64)
+        point = np.zeros(max(nv, 1) * 4, dtype=np.uint64)
+        evals = np.zeros(ntab * 4, dtype=np.uint64)
+        sums = np.zeros(max(nv * d, 1) * 4, dtype=np.uint64)
+        _check(lib().hg_sumcheck_bn254(self.h, kind, nv, ntab, ptrs, _ptr(ppw), len(pw), _ptr(pcl), chain_skip, _ptr(msgs), _ptr(point),
+                                       _ptr(evals), _ptr(sums)))
+        m = self._fr_unpack(msgs)[: nv * (d + 1)]
+        return ([m[i * (d + 1):(i + 1) * (d + 1)] for i in range(nv)], self._fr_unpack(point)[:nv], self._fr_unpack(evals),
+                [self._fr_unpack(sums)[i * d:(i + 1) * d] for i in range(nv)])
 
     # kernel-level entry points (parity tests)
     def sumcheck(self, kind, tables, is_base, pw, claim, chain_skip=0):
@@ -352,6 +395,13 @@ def prove_shard_combine(ctx, gathered, world):
 def prove_shard_finish(ctx, out):
     _check(lib().hg_prove_shard_finish(ctx.h, out.buf, out.cap, C.byref(out.len), C.byref(out.tm)))
     return out
+
+
+def challenges_bn254(n):
+    """First n Fiat-Shamir challenges over bn256::Fr (host)."""
+    out = np.zeros(n * 4, dtype=np.uint64)
+    _check(lib().hg_challenges_bn254(n, _ptr(out)))
+    return Context._fr_unpack(out)
 
 
 def verify(pk, witness, proof):

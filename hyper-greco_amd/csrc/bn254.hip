@@ -1,0 +1,282 @@
+// BN254 slice (BASELINE config 5, first step): Fr arithmetic on gfx950, the Keccak challenge chain over Fr, and
+// gkr::sum_check::prove_sum_check for the three shapes of the path on caller tables (hg_sumcheck_bn254), with the same
+// single-synchronisation structure as the Goldilocks prover: all rounds are enqueued with the (message-independent)
+// challenges, one copy back, then the transcript is replayed on the host.
+// [REF bfv-gkr/src/transcript.rs:146-157,183-189,198-203 (challenges, 32-byte big-endian felts);
+//  lasso/src/lasso.rs:457-475 (collation g), lasso/src/memory_checking/prover.rs:268-279 (grand-product g);
+//  sk_encryption_circuit.rs:614-626 (Fr, Fr)]
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <stdexcept>
+#include "bn254.cuh"
+#include "host.hpp"
+#include "prover.hpp"
+
+namespace hg {
+namespace bn {
+
+// ---- challenges: c_j = LE(Keccak^j("")) mod r; E = F, so one base challenge per squeeze -----------------------
+static Fr fr_from_le32_mod(const uint8_t h[32]) {
+    // 256-bit little-endian integer mod r: at most 5 subtractions of r (2^256 / r < 6)
+    Fr v;
+    memcpy(v.l, h, 32);
+    for (;;) {
+        bool ge = fr_geq_p(v);
+        if (!ge) break;
+        v = fr_sub_p(v);
+    }
+    return v;
+}
+std::vector<Fr> challenge_chain_bn254(size_t n) {
+    std::vector<Fr> out(n);
+    uint8_t h[32];
+    keccak256(nullptr, 0, h);
+    for (size_t i = 0; i < n; i++) {
+        out[i] = fr_from_le32_mod(h);
+        uint8_t nx[32];
+        keccak256(h, 32, nx);
+        memcpy(h, nx, 32);
+    }
+    return out;
+}
+
+void challenges_bn254_raw(size_t n, uint64_t* out4) {
+    std::vector<Fr> c = challenge_chain_bn254(n);
+    for (size_t i = 0; i < n; i++) memcpy(out4 + 4 * i, c[i].l, 32);
+}
+
+// ---- kernels ---------------------------------------------------------------------------------------------------
+constexpr int BN_TPB = 256;
+enum { BN_COLLATION = 0, BN_GRANDPROD = 1, BN_PRODSUM = 2 };
+
+__global__ void k_bn_to_mont(Fr* __restrict__ t, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) t[i] = fr_to_mont(t[i]);
+}
+__global__ void k_bn_from_mont(Fr* __restrict__ t, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) t[i] = fr_from_mont(t[i]);
+}
+// op 0 add, 1 sub, 2 mul (canonical in / out): the field KAT entry point
+__global__ void k_bn_binop(int op, size_t n, const Fr* __restrict__ a, const Fr* __restrict__ b, Fr* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr x = fr_to_mont(a[i]), y = fr_to_mont(b[i]);
+    Fr r = op == 0 ? fr_add(x, y) : (op == 1 ? fr_sub(x, y) : fr_mul(x, y));
+    out[i] = fr_from_mont(r);
+}
+
+__device__ __forceinline__ Fr block_sum_fr(Fr v, Fr* sm) {
+    const int t = threadIdx.x;
+    sm[t] = v;
+    __syncthreads();
+    for (int s = BN_TPB / 2; s > 0; s >>= 1) {
+        if (t < s) sm[t] = fr_add(sm[t], sm[t + s]);
+        __syncthreads();
+    }
+    Fr r = sm[0];
+    __syncthreads();
+    return r;
+}
+
+// One round. Tables in Montgomery form, natural order: table t at in + t * 2 * half, pair (T[2j], T[2j+1]) adjacent
+// (one 64-byte access per lane). Writes the folded tables (out + t * half) and the per-workgroup sums of
+// g(0), g(2)[, g(3)] to partials[blockIdx.x * nv + v].
+//   kind 0: g = p_0 * sum_i pw_i p_i;  kind 1: g = p_0 * sum_i pw_i p_2i p_2i+1;  kind 2: g = sum_i p_2i p_2i+1
+template <int KIND>
+__global__ __launch_bounds__(BN_TPB) void k_bn_round(const Fr* __restrict__ in, Fr* __restrict__ out, int ntab, size_t half, Fr r,
+                                                     const Fr* __restrict__ pw, Fr* __restrict__ partials) {
+    constexpr int NV = KIND == BN_GRANDPROD ? 3 : 2;
+    __shared__ Fr sm[BN_TPB];
+    Fr acc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; v++) acc[v] = fr_zero();
+    for (size_t j = (size_t)blockIdx.x * BN_TPB + threadIdx.x; j < half; j += (size_t)gridDim.x * BN_TPB) {
+        Fr s0 = fr_zero(), s2 = fr_zero(), s3 = fr_zero();
+        Fr p0 = fr_zero(), p2 = fr_zero(), p3 = fr_zero();
+        if (KIND == BN_COLLATION) {
+            for (int i = 0; i < ntab; i++) {
+                const Fr x = in[(size_t)i * 2 * half + 2 * j], y = in[(size_t)i * 2 * half + 2 * j + 1];
+                const Fr d = fr_sub(y, x);
+                const Fr v2 = fr_add(y, d);
+                if (i == 0) { p0 = x; p2 = v2; }
+                const Fr w = pw[i];
+                s0 = fr_add(s0, fr_mul(w, x));
+                s2 = fr_add(s2, fr_mul(w, v2));
+                out[(size_t)i * half + j] = fr_add(x, fr_mul(r, d));
+            }
+            acc[0] = fr_add(acc[0], fr_mul(p0, s0));
+            acc[1] = fr_add(acc[1], fr_mul(p2, s2));
+        } else {
+            const int nb = ntab >> 1;
+            for (int i = 0; i < nb; i++) {
+                const Fr xl = in[(size_t)(2 * i) * 2 * half + 2 * j], yl = in[(size_t)(2 * i) * 2 * half + 2 * j + 1];
+                const Fr xr = in[(size_t)(2 * i + 1) * 2 * half + 2 * j], yr = in[(size_t)(2 * i + 1) * 2 * half + 2 * j + 1];
+                const Fr dl = fr_sub(yl, xl), dr = fr_sub(yr, xr);
+                const Fr l2 = fr_add(yl, dl), r2 = fr_add(yr, dr);
+                if (KIND == BN_GRANDPROD) {
+                    const Fr l3 = fr_add(l2, dl), r3 = fr_add(r2, dr);
+                    if (i == 0) { p0 = xl; p2 = l2; p3 = l3; }
+                    const Fr w = pw[i];
+                    s0 = fr_add(s0, fr_mul(w, fr_mul(xl, xr)));
+                    s2 = fr_add(s2, fr_mul(w, fr_mul(l2, r2)));
+                    s3 = fr_add(s3, fr_mul(w, fr_mul(l3, r3)));
+                } else {
+                    s0 = fr_add(s0, fr_mul(xl, xr));
+                    s2 = fr_add(s2, fr_mul(l2, r2));
+                }
+                out[(size_t)(2 * i) * half + j] = fr_add(xl, fr_mul(r, dl));
+                out[(size_t)(2 * i + 1) * half + j] = fr_add(xr, fr_mul(r, dr));
+            }
+            if (KIND == BN_GRANDPROD) {
+                acc[0] = fr_add(acc[0], fr_mul(p0, s0));
+                acc[1] = fr_add(acc[1], fr_mul(p2, s2));
+                acc[2] = fr_add(acc[2], fr_mul(p3, s3));
+            } else {
+                acc[0] = fr_add(acc[0], s0);
+                acc[1] = fr_add(acc[1], s2);
+            }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+        Fr s = block_sum_fr(acc[v], sm);
+        if (threadIdx.x == 0) partials[(size_t)blockIdx.x * NV + v] = s;
+    }
+}
+__global__ __launch_bounds__(BN_TPB) void k_bn_reduce(const Fr* __restrict__ partials, int nblocks, int nv, Fr* __restrict__ out) {
+    __shared__ Fr sm[BN_TPB];
+    for (int v = 0; v < nv; v++) {
+        Fr a = fr_zero();
+        for (int b = threadIdx.x; b < nblocks; b += BN_TPB) a = fr_add(a, partials[(size_t)b * nv + v]);
+        a = block_sum_fr(a, sm);
+        if (threadIdx.x == 0) out[v] = fr_from_mont(a);  // canonical for the host
+    }
+}
+
+// ---- host arithmetic for the transcript replay (Montgomery form) ---------------------------------------------
+static Fr fr_pow(Fr b, const u64 e[4]) {
+    Fr r = fr_one_mont();
+    for (int w = 3; w >= 0; w--)
+        for (int bit = 63; bit >= 0; bit--) {
+            r = fr_mul(r, r);
+            if ((e[w] >> bit) & 1) r = fr_mul(r, b);
+        }
+    return r;
+}
+static Fr fr_inv(Fr a) {
+    const u64 e[4] = {FR_P0 - 2, FR_P1, FR_P2, FR_P3};
+    return fr_pow(a, e);
+}
+static Fr fr_small(u64 v) { return fr_to_mont(fr_make(v, 0, 0, 0)); }
+
+static void hipc(hipError_t e, const char* what) {
+    if (e != hipSuccess) throw Error(std::string(what) + ": " + hipGetErrorString(e));
+}
+
+// prove_sum_check on caller tables (all in the base field; E = F). Conventions as for Goldilocks:
+// a round message is the d+1 coefficients of the round polynomial, eval(1) = claim - eval(0), lowest variable first.
+void sumcheck_bn254(hg_ctx* ctx, int kind, size_t nv, size_t ntab, const u64* const* tables, const u64* pw4, size_t npw, const u64* claim4,
+                    size_t chain_skip, u64* msgs, u64* point, u64* evals, u64* sums) {
+    if (kind < 0 || kind > 2) throw Error("hg_sumcheck_bn254: kind must be 0, 1 or 2");
+    if (ntab == 0 || (kind != BN_COLLATION && (ntab & 1))) throw Error("hg_sumcheck_bn254: bad table count");
+    const size_t need_pw = kind == BN_COLLATION ? ntab : (kind == BN_GRANDPROD ? ntab / 2 : 0);
+    if (npw < need_pw) throw Error("hg_sumcheck_bn254: too few weights");
+    hipc(hipSetDevice(ctx->device), "hipSetDevice");
+    hipStream_t st = ctx->stream;
+    const size_t N = (size_t)1 << nv;
+    const int d = kind == BN_GRANDPROD ? 3 : 2, NV = d;
+    Fr *buf0 = nullptr, *buf1 = nullptr, *d_pw = nullptr, *d_part = nullptr, *d_sums = nullptr;
+    const int max_blocks = 1024;
+    hipc(hipMalloc((void**)&buf0, ntab * N * sizeof(Fr)), "hipMalloc");
+    hipc(hipMalloc((void**)&buf1, ntab * std::max<size_t>(N / 2, 1) * sizeof(Fr)), "hipMalloc");
+    hipc(hipMalloc((void**)&d_pw, std::max<size_t>(need_pw, 1) * sizeof(Fr)), "hipMalloc");
+    hipc(hipMalloc((void**)&d_part, (size_t)max_blocks * 3 * sizeof(Fr)), "hipMalloc");
+    hipc(hipMalloc((void**)&d_sums, std::max<size_t>(nv, 1) * 3 * sizeof(Fr)), "hipMalloc");
+    std::vector<Fr> h_sums(nv * NV), h_final(ntab);
+    try {
+        for (size_t t = 0; t < ntab; t++)
+            hipc(hipMemcpyAsync(buf0 + t * N, tables[t], N * sizeof(Fr), hipMemcpyHostToDevice, st), "upload table");
+        k_bn_to_mont<<<(unsigned)((ntab * N + 255) / 256), 256, 0, st>>>(buf0, ntab * N);
+        if (need_pw) {
+            hipc(hipMemcpyAsync(d_pw, pw4, need_pw * sizeof(Fr), hipMemcpyHostToDevice, st), "upload weights");
+            k_bn_to_mont<<<(unsigned)((need_pw + 255) / 256), 256, 0, st>>>(d_pw, need_pw);
+        }
+        const std::vector<Fr> chain = challenge_chain_bn254(chain_skip + nv);
+        Fr* cur = buf0;
+        Fr* nxt = buf1;
+        for (size_t rd = 0; rd < nv; rd++) {
+            const size_t half = N >> (rd + 1);
+            const Fr r = fr_to_mont(chain[chain_skip + rd]);
+            const int grid = (int)std::min<size_t>((half + BN_TPB - 1) / BN_TPB, (size_t)max_blocks);
+            if (kind == BN_COLLATION) k_bn_round<BN_COLLATION><<<grid, BN_TPB, 0, st>>>(cur, nxt, (int)ntab, half, r, d_pw, d_part);
+            else if (kind == BN_GRANDPROD) k_bn_round<BN_GRANDPROD><<<grid, BN_TPB, 0, st>>>(cur, nxt, (int)ntab, half, r, d_pw, d_part);
+            else k_bn_round<BN_PRODSUM><<<grid, BN_TPB, 0, st>>>(cur, nxt, (int)ntab, half, r, d_pw, d_part);
+            k_bn_reduce<<<1, BN_TPB, 0, st>>>(d_part, grid, NV, d_sums + rd * NV);
+            std::swap(cur, nxt);
+        }
+        k_bn_from_mont<<<(unsigned)((ntab + 255) / 256), 256, 0, st>>>(cur, ntab);  // the folded scalars (table t at cur + t)
+        if (nv) hipc(hipMemcpyAsync(h_sums.data(), d_sums, nv * NV * sizeof(Fr), hipMemcpyDeviceToHost, st), "copy sums");
+        hipc(hipMemcpyAsync(h_final.data(), cur, ntab * sizeof(Fr), hipMemcpyDeviceToHost, st), "copy evals");
+        hipc(hipStreamSynchronize(st), "sumcheck_bn254: sync");
+        hipc(hipGetLastError(), "sumcheck_bn254: launch");
+        // transcript replay
+        const Fr inv2 = fr_inv(fr_small(2)), inv3 = fr_inv(fr_small(3)), inv6 = fr_inv(fr_small(6)), three = fr_small(3);
+        Fr claim = fr_to_mont(fr_make(claim4[0], claim4[1], claim4[2], claim4[3]));
+        for (size_t rd = 0; rd < nv; rd++) {
+            Fr ev[4], c[4];
+            ev[0] = fr_to_mont(h_sums[rd * NV]);
+            ev[1] = fr_sub(claim, ev[0]);
+            ev[2] = fr_to_mont(h_sums[rd * NV + 1]);
+            if (d == 3) ev[3] = fr_to_mont(h_sums[rd * NV + 2]);
+            const Fr d1 = fr_sub(ev[1], ev[0]);
+            const Fr d2 = fr_add(fr_sub(ev[2], fr_dbl(ev[1])), ev[0]);
+            if (d == 2) {
+                c[0] = ev[0];
+                c[2] = fr_mul(d2, inv2);
+                c[1] = fr_sub(d1, c[2]);
+            } else {
+                const Fr d3 = fr_sub(fr_sub(ev[3], ev[0]), fr_mul(fr_sub(ev[2], ev[1]), three));
+                c[0] = ev[0];
+                c[3] = fr_mul(d3, inv6);
+                c[2] = fr_mul(fr_sub(d2, d3), inv2);
+                c[1] = fr_add(fr_sub(d1, fr_mul(d2, inv2)), fr_mul(d3, inv3));
+            }
+            const Fr rr = fr_to_mont(chain[chain_skip + rd]);
+            Fr h = c[d];
+            for (int i = d - 1; i >= 0; i--) h = fr_add(fr_mul(h, rr), c[i]);
+            claim = h;
+            for (int k = 0; k <= d; k++) { Fr o = fr_from_mont(c[k]); memcpy(msgs + (rd * (d + 1) + k) * 4, o.l, 32); }
+            memcpy(point + rd * 4, chain[chain_skip + rd].l, 32);
+            for (int v = 0; v < NV; v++) memcpy(sums + (rd * NV + v) * 4, h_sums[rd * NV + v].l, 32);
+        }
+        for (size_t t = 0; t < ntab; t++) memcpy(evals + t * 4, h_final[t].l, 32);
+    } catch (...) {
+        (void)hipFree(buf0); (void)hipFree(buf1); (void)hipFree(d_pw); (void)hipFree(d_part); (void)hipFree(d_sums);
+        throw;
+    }
+    (void)hipFree(buf0); (void)hipFree(buf1); (void)hipFree(d_pw); (void)hipFree(d_part); (void)hipFree(d_sums);
+}
+
+void field_op_bn254(hg_ctx* ctx, int op, size_t n, const u64* a, const u64* b, u64* out) {
+    if (op < 0 || op > 2) throw Error("hg_bn254_field_op: op must be 0 (add), 1 (sub) or 2 (mul)");
+    hipc(hipSetDevice(ctx->device), "hipSetDevice");
+    Fr *da = nullptr, *db = nullptr, *dc = nullptr;
+    hipc(hipMalloc((void**)&da, n * sizeof(Fr)), "hipMalloc");
+    hipc(hipMalloc((void**)&db, n * sizeof(Fr)), "hipMalloc");
+    hipc(hipMalloc((void**)&dc, n * sizeof(Fr)), "hipMalloc");
+    hipError_t e1 = hipMemcpy(da, a, n * sizeof(Fr), hipMemcpyHostToDevice), e2 = hipMemcpy(db, b, n * sizeof(Fr), hipMemcpyHostToDevice);
+    if (e1 == hipSuccess && e2 == hipSuccess) {
+        k_bn_binop<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(op, n, da, db, dc);
+        e1 = hipStreamSynchronize(ctx->stream);
+        if (e1 == hipSuccess) e1 = hipMemcpy(out, dc, n * sizeof(Fr), hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dc);
+    hipc(e1, "hg_bn254_field_op");
+    hipc(e2, "hg_bn254_field_op");
+}
+
+}  // namespace bn
+}  // namespace hg

@@ -7,6 +7,13 @@
 #include <string>
 #include "prover.hpp"
 
+// BN254 slice (bn254.hip)
+namespace hg { namespace bn {
+void sumcheck_bn254(hg_ctx* ctx, int kind, size_t nv, size_t ntab, const u64* const* tables, const u64* pw4, size_t npw, const u64* claim4,
+                    size_t chain_skip, u64* msgs, u64* point, u64* evals, u64* sums);
+void field_op_bn254(hg_ctx* ctx, int op, size_t n, const u64* a, const u64* b, u64* out);
+void challenges_bn254_raw(size_t n, uint64_t* out4);
+} }
 using namespace hg;
 
 static thread_local std::string g_last_error;
@@ -455,6 +462,28 @@ int hg_challenges(size_t n, uint64_t* out) {
     HG_TRY
     const u64* c = challenge_chain(n);
     memcpy(out, c, n * 8);
+    return 0;
+    HG_CATCH(-1)
+}
+
+int hg_challenges_bn254(size_t n, uint64_t* out4) {
+    HG_TRY
+    hg::bn::challenges_bn254_raw(n, out4);
+    return 0;
+    HG_CATCH(-1)
+}
+int hg_bn254_field_op(hg_ctx* ctx, int op, size_t n, const uint64_t* a4, const uint64_t* b4, uint64_t* out4) {
+    HG_TRY
+    if (!ctx) throw hg::Error("hg_bn254_field_op: no context (a HIP device is required)");
+    hg::bn::field_op_bn254(ctx, op, n, a4, b4, out4);
+    return 0;
+    HG_CATCH(-1)
+}
+int hg_sumcheck_bn254(hg_ctx* ctx, int kind, size_t nv, size_t ntab, const uint64_t* const* tables, const uint64_t* pw4, size_t npw,
+                      const uint64_t* claim4, size_t chain_skip, uint64_t* msgs, uint64_t* point, uint64_t* evals, uint64_t* sums) {
+    HG_TRY
+    if (!ctx) throw hg::Error("hg_sumcheck_bn254: no context (a HIP device is required)");
+    hg::bn::sumcheck_bn254(ctx, kind, nv, ntab, tables, pw4, npw, claim4, chain_skip, msgs, point, evals, sums);
     return 0;
     HG_CATCH(-1)
 }

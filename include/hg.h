@@ -155,6 +155,20 @@ int hg_ntt(hg_ctx* ctx, const uint64_t* in, size_t log2n, int inverse, size_t ba
 /* Fiat-Shamir challenge chain [REF bfv-gkr/src/transcript.rs:146-157,198-203]: first n base-field challenges. */
 int hg_challenges(size_t n, uint64_t* out);
 
+/* ---- BN254 (BASELINE config 5, first slice): field, challenges and sum-check kernels over halo2curves bn256::Fr --------
+ * Elements cross the boundary as 4 canonical little-endian u64 limbs (non-Montgomery). The extension field of the
+ * reference's bn254 tests is the field itself [REF sk_encryption_circuit.rs:614-626: (Fr, Fr)], so a challenge is one
+ * element. The full BfvEncrypt::prove over Fr is not built yet. */
+/* = Keccak256Transcript::squeeze_challenge over Fr: c_j = LE(Keccak^j("")) mod r [REF transcript.rs:146-157,198-203]; n x 4 limbs */
+int hg_challenges_bn254(size_t n, uint64_t* out4);
+/* device field arithmetic on n element pairs: op 0 add, 1 sub, 2 mul (known-answer tests of the Montgomery kernels) */
+int hg_bn254_field_op(hg_ctx* ctx, int op, size_t n, const uint64_t* a4, const uint64_t* b4, uint64_t* out4);
+/* = gkr::sum_check::prove_sum_check over Fr on caller tables, same shapes and conventions as hg_sumcheck
+ *   [REF call sites lasso.rs:278-279, prover.rs:242-252]. tables[i]: host pointer, 2^nv elements (4 limbs each).
+ *   Outputs: msgs nv*(d+1), point nv, evals ntab, sums nv*d elements. */
+int hg_sumcheck_bn254(hg_ctx* ctx, int kind, size_t nv, size_t ntab, const uint64_t* const* tables, const uint64_t* pw4, size_t npw,
+                      const uint64_t* claim4, size_t chain_skip, uint64_t* msgs, uint64_t* point, uint64_t* evals, uint64_t* sums);
+
 /* profiling: level 0 off, 1 = events around the selected kernel class only, 2 = every class */
 int hg_profile(hg_ctx* ctx, int level);
 /* selects the class that level 1 times (a name hg_profile_get reported); returns 0, or -1 if there is no such class */

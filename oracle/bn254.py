@@ -1,0 +1,85 @@
+"""CPU oracle (TEST INFRASTRUCTURE ONLY) for the BN254 slice: halo2curves bn256::Fr arithmetic as Python integers, the
+Fiat-Shamir challenge chain over Fr, and gkr::sum_check::prove_sum_check for the three shapes of the hot path.
+
+Only tests/ may import this module; the product (hyper-greco_amd/csrc/bn254.hip) never does.
+
+Follows [REF bfv-gkr/src/transcript.rs:146-157,198-203] (challenge = fe_mod_from_le_bytes(Keccak state), state re-hashed,
+prover messages never absorbed), [REF lasso/src/lasso.rs:457-475] (collation g = poly(0) * sum_i M^i poly(i)),
+[REF lasso/src/memory_checking/prover.rs:268-279] (grand-product g = poly(0) * sum_i gamma^i poly(2i) poly(2i+1)) and the
+Libra / zkCNN pair-product sums of the external `gkr` crate.
+
+PARITY UNPINNED for the conventions that live in the un-vendored `gkr` crate (same C1-C4 as the Goldilocks oracle,
+DESIGN.md 2): a round message is the d+1 coefficients of the round polynomial, eval(1) = claim - eval(0), the lowest
+variable is bound first. Pinned: the field modulus, and the first challenge over Fr (SURVEY.md 8(c)(5):
+7173236656320612194178997223602979818891828541827642103715116037219761443523)."""
+
+R = 21888242871839275222246405745257275088548364400416034343698204186575808495617  # bn256::Fr modulus
+
+
+def challenges(n, keccak256):
+    """c_j = int.from_bytes(Keccak^j(""), "little") mod r, j = 1..n. `keccak256`: bytes -> 32 bytes."""
+    out, h = [], keccak256(b"")
+    for _ in range(n):
+        out.append(int.from_bytes(h, "little") % R)
+        h = keccak256(h)
+    return out
+
+
+def sumcheck(kind, tables, pw, claim, chal):
+    """kind 0: g = p0 * sum_i pw_i p_i (deg 2); 1: g = p0 * sum_i pw_i p_2i p_2i+1 (deg 3); 2: g = sum_i p_2i p_2i+1 (deg 2).
+    tables: lists of 2^nv ints; chal: the nv round challenges. Returns (msgs, evals, sums): per round the d+1
+    coefficients, the fully folded table values, and the raw per-round sums g(0), g(2)[, g(3)]."""
+    tabs = [list(t) for t in tables]
+    nv = (len(tabs[0]) - 1).bit_length()
+    d = 3 if kind == 1 else 2
+    inv2, inv3, inv6 = pow(2, -1, R), pow(3, -1, R), pow(6, -1, R)
+    msgs, sums = [], []
+    for rd in range(nv):
+        half = len(tabs[0]) // 2
+        pts = [0, 2, 3][:d]
+        ev = {}
+        for t in pts:
+            acc = 0
+            for j in range(half):
+                at = [(T[2 * j] + t * (T[2 * j + 1] - T[2 * j])) % R for T in tabs]
+                if kind == 0:
+                    s = sum(pw[i] * at[i] for i in range(len(tabs))) % R
+                    acc += at[0] * s
+                elif kind == 1:
+                    s = sum(pw[i] * at[2 * i] * at[2 * i + 1] for i in range(len(tabs) // 2)) % R
+                    acc += at[0] * s
+                else:
+                    acc += sum(at[2 * i] * at[2 * i + 1] for i in range(len(tabs) // 2))
+            ev[t] = acc % R
+        sums.append([ev[t] for t in pts])
+        e0, e1, e2 = ev[0], (claim - ev[0]) % R, ev[2]
+        d1 = (e1 - e0) % R
+        d2 = (e2 - 2 * e1 + e0) % R
+        if d == 2:
+            c2 = d2 * inv2 % R
+            c = [e0, (d1 - c2) % R, c2]
+        else:
+            d3 = (ev[3] - e0 - 3 * (e2 - e1)) % R
+            c = [e0, (d1 - d2 * inv2 + d3 * inv3) % R, (d2 - d3) * inv2 % R, d3 * inv6 % R]
+        msgs.append(c)
+        r = chal[rd]
+        claim = sum(c[k] * pow(r, k, R) for k in range(d + 1)) % R
+        tabs = [[(T[2 * j] + r * (T[2 * j + 1] - T[2 * j])) % R for j in range(half)] for T in tabs]
+    return msgs, [T[0] for T in tabs], sums
+
+
+def verify_sumcheck(kind, msgs, evals, pw, claim, chal):
+    """The verifier's side: every round polynomial must sum to the running claim; the last claim must equal g at the
+    folded values. Returns True / False."""
+    d = 3 if kind == 1 else 2
+    for rd, c in enumerate(msgs):
+        if (2 * c[0] + sum(c[1:])) % R != claim % R:  # h(0) + h(1)
+            return False
+        claim = sum(c[k] * pow(chal[rd], k, R) for k in range(d + 1)) % R
+    if kind == 0:
+        g = evals[0] * sum(pw[i] * evals[i] for i in range(len(evals)))
+    elif kind == 1:
+        g = evals[0] * sum(pw[i] * evals[2 * i] * evals[2 * i + 1] for i in range(len(evals) // 2))
+    else:
+        g = sum(evals[2 * i] * evals[2 * i + 1] for i in range(len(evals) // 2))
+    return g % R == claim % R

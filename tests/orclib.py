@@ -167,3 +167,21 @@ def lasso_layout(p):
     assert n > 0
     mems, lk = buf.value.decode().split("|")
     return mems.split(","), lk.split(";")
+
+
+def keccak256(data: bytes) -> bytes:
+    """Keccak-256 of the C oracle (pinned by the reference's chain KATs in test_oracle_kats.py)."""
+    import ctypes
+    buf = (ctypes.c_uint8 * max(len(data), 1)).from_buffer_copy(data or b"\0")
+    out = (ctypes.c_uint8 * 32)()
+    lib().orc_keccak256(buf, ctypes.c_size_t(len(data)), out)
+    return bytes(out)
+
+
+def bn254():
+    """The BN254 Python oracle (oracle/bn254.py)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("oracle_bn254", os.path.join(ROOT, "oracle", "bn254.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m

@@ -301,3 +301,36 @@ def test_proof_map_covers_the_stream_and_diff_tool_localises_a_flip(ctx, tmp_pat
     assert r.returncode == 1 and "collation" in r.stdout and "byte %d" % (start + 24) in r.stdout
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "proof_diff.py"), str(a), str(a), str(mp)], capture_output=True, text=True)
     assert r.returncode == 0 and "identical" in r.stdout
+
+
+# ---- BN254 slice (hg_bn254_field_op, hg_challenges_bn254, hg_sumcheck_bn254) ----------------------------------------
+def test_bn254_field_kernels_against_python_integers(ctx):
+    bn = orclib.bn254()
+    rng = random.Random(254)
+    edge = [0, 1, 2, bn.R - 1, bn.R - 2, (1 << 64) - 1, 1 << 64, (1 << 128) + 5, (1 << 253), bn.R >> 1]
+    a = edge + [rng.randrange(bn.R) for _ in range(3000)]
+    b = list(reversed(edge)) + [rng.randrange(bn.R) for _ in range(3000)]
+    assert ctx.bn254_field_op(0, a, b) == [(x + y) % bn.R for x, y in zip(a, b)]
+    assert ctx.bn254_field_op(1, a, b) == [(x - y) % bn.R for x, y in zip(a, b)]
+    assert ctx.bn254_field_op(2, a, b) == [(x * y) % bn.R for x, y in zip(a, b)]
+
+
+def test_bn254_challenges_match_the_oracle():
+    bn = orclib.bn254()
+    assert hg.challenges_bn254(40) == bn.challenges(40, orclib.keccak256)
+
+
+@pytest.mark.parametrize("kind,ntab,nv", [(0, 6, 8), (0, 25, 5), (1, 4, 9), (1, 50, 4), (2, 2, 10), (2, 6, 7), (1, 2, 1), (2, 2, 0)])
+def test_bn254_sumcheck_kernels_bit_exact(ctx, kind, ntab, nv):
+    """HIP sum-check rounds over bn256::Fr (256-bit Montgomery limbs) against the Python-integer oracle, all three shapes."""
+    bn = orclib.bn254()
+    rng = random.Random(1000 * kind + 10 * ntab + nv)
+    tabs = [[rng.randrange(bn.R) for _ in range(1 << nv)] for _ in range(ntab)]
+    npw = ntab if kind == 0 else (ntab // 2 if kind == 1 else 0)
+    pw = [rng.randrange(bn.R) for _ in range(npw)]
+    claim = rng.randrange(bn.R)
+    skip = rng.randrange(30)
+    chal = bn.challenges(skip + nv, orclib.keccak256)[skip:]
+    msgs, point, evals, sums = ctx.sumcheck_bn254(kind, tabs, pw, claim, skip)
+    emsgs, eevals, esums = bn.sumcheck(kind, tabs, pw, claim, chal)
+    assert point == chal and msgs == emsgs and evals == eevals and sums == esums

@@ -226,3 +226,40 @@ def test_lasso_node_claim_is_mle_of_inputs():
         return 2 * alpha + nv * 4 * alpha + m3 * sum(range(1, nv))
     n_e = 1 + nu * m2 + gp(nu) + gp(16) + (3 * 2 + alpha)
     assert len(proof) == 16 * n_e
+
+
+# ---- BN254 slice (oracle/bn254.py) -----------------------------------------------------------------------------------
+def test_bn254_first_challenge_and_chain():
+    """SURVEY.md 8(c)(5): fe_mod_from_le_bytes(Keccak256("")) over bn256::Fr [REF transcript.rs:198-203]."""
+    bn = orclib.bn254()
+    c = bn.challenges(3, orclib.keccak256)
+    assert c[0] == 7173236656320612194178997223602979818891828541827642103715116037219761443523
+    h1 = bytes.fromhex("c5d2460186f7233c927e7db2dcc703c0e500b653ca82273b7bfad8045d85a470")
+    assert c[0] == int.from_bytes(h1, "little") % bn.R
+    h2 = bytes.fromhex("10ca3eff73ebec87d2394fc58560afeab86dac7a21f5e402ea0a55e5c8a6758f")
+    assert c[1] == int.from_bytes(h2, "little") % bn.R
+    assert bn.R == 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
+
+
+@pytest.mark.parametrize("kind,ntab,nv", [(0, 3, 4), (1, 4, 3), (2, 6, 4), (1, 2, 1)])
+def test_bn254_sumcheck_oracle_round_trip(kind, ntab, nv):
+    """prove -> verify with the true claim; a wrong claim or a tampered message is rejected."""
+    import random
+    bn = orclib.bn254()
+    rng = random.Random(17 * kind + ntab + nv)
+    tabs = [[rng.randrange(bn.R) for _ in range(1 << nv)] for _ in range(ntab)]
+    npw = ntab if kind == 0 else (ntab // 2 if kind == 1 else 0)
+    pw = [rng.randrange(bn.R) for _ in range(npw)]
+    # true sum over the hypercube of g
+    def g(vals):
+        if kind == 0: return vals[0] * sum(pw[i] * vals[i] for i in range(ntab))
+        if kind == 1: return vals[0] * sum(pw[i] * vals[2 * i] * vals[2 * i + 1] for i in range(ntab // 2))
+        return sum(vals[2 * i] * vals[2 * i + 1] for i in range(ntab // 2))
+    claim = sum(g([T[x] for T in tabs]) for x in range(1 << nv)) % bn.R
+    chal = bn.challenges(nv + 5, orclib.keccak256)[5:]
+    msgs, evals, sums = bn.sumcheck(kind, tabs, pw, claim, chal)
+    assert bn.verify_sumcheck(kind, msgs, evals, pw, claim, chal)
+    assert not bn.verify_sumcheck(kind, msgs, evals, pw, (claim + 1) % bn.R, chal)
+    bad = [list(m) for m in msgs]
+    bad[-1][1] = (bad[-1][1] + 1) % bn.R
+    assert not bn.verify_sumcheck(kind, bad, evals, pw, claim, chal)
