@@ -325,7 +325,7 @@ class BfvEncrypt:
         ln = C.c_size_t(0)
         tm = HgTimings()
         _check(lib().hg_prove(ctx.h, pk.h, witness.h, buf, cap, C.byref(ln), C.byref(tm)))
-        return bytes(buf[:ln.value]), {f: getattr(tm, f) for f, _ in HgTimings._fields_}
+        return C.string_at(buf, ln.value), {f: getattr(tm, f) for f, _ in HgTimings._fields_}
 
 
 class ResidentValues:
@@ -366,7 +366,7 @@ class ProofBuffer:
         self.tm = HgTimings()
 
     def bytes(self):
-        return bytes(self.buf[:self.len.value])
+        return C.string_at(self.buf, self.len.value)
 
     def timings(self):
         return {f: getattr(self.tm, f) for f, _ in HgTimings._fields_}

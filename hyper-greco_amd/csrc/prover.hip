@@ -1396,7 +1396,9 @@ ProveResult prove_shard_finish(hg_ctx* ctx) {
         g_pending.erase(it);
     }
     ProveResult res;
+    const double tf0 = wall_ms();
     ps.P->replay();
+    if (getenv("HG_SHARD_DEBUG")) fprintf(stderr, "[hg] shard finish: replay call %.3f ms\n", wall_ms() - tf0);
     res.prove_ms = wall_ms() - ps.t_start;
     res.gpu_ms = ps.gpu_ms;
     res.enqueue_ms = ps.P->t_enqueued - ps.t_start;

@@ -34,4 +34,5 @@ for world in worlds:
     t0 = time.perf_counter()
     got = hg.prove_shard_finish(ctx, out).bytes()
     fin = (time.perf_counter() - t0) * 1e3
-    print("world %d: per-rank begin ms %s  max %.2f  finish(replay) %.2f  ok=%s" % (world, " ".join("%.2f" % t for t in times), max(times), fin, got == ref))
+    tc = time.perf_counter(); hg.prove_shard_combine(ctx, np.stack(parts), world); tc = (time.perf_counter() - tc) * 1e3
+    print("world %d: per-rank begin ms %s  max %.2f  finish %.2f (replay %.2f)  combine %.2f  ok=%s" % (world, " ".join("%.2f" % t for t in times), max(times), fin, out.timings()["replay_ms"], tc, got == ref))
