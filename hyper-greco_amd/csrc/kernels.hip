@@ -1219,24 +1219,38 @@ int lasso_claim(hipStream_t st, const LassoDev& L, const E2* eq, const u64* e_po
 
 // read / write multiset hashes of one memory and, in the same pass, the first product-tree level of both tables
 // (row j and row j + n/2 are hashed by the same thread), so the tree never re-reads the 2^nu-row hash tables
-__global__ __launch_bounds__(TPB) void k_hash_rw(size_t n, const u64* __restrict__ dim, const u64* __restrict__ ep,
-                                                 const u64* __restrict__ ts, u64 gamma, u64 gamma2, u64 tau,
-                                                 u64* __restrict__ rd, u64* __restrict__ wr, u64* __restrict__ rd1,
-                                                 u64* __restrict__ wr1) {
+// Read / write multiset hashes of up to HASH_RW_MAX memories that share one chunk (same dim and read_ts columns):
+// h(a,v,t) = a + v*gamma + t*gamma^2 - tau (prover.rs:44); the address/counter part is computed once per row and
+// reused for every memory. Thread j handles rows 2j, 2j+1 and their partners in the upper half (16-byte accesses), and
+// also emits the first product-tree level rd1[j] = rd[j] rd[j + n/2] (Layer::bottom + Layer::up, prover.rs:310-354).
+__global__ __launch_bounds__(TPB) void k_hash_rw(size_t n, const u64* __restrict__ dim, const u64* __restrict__ ts, HashRwArgs args, int nmem,
+                                                 u64 gamma, u64 gamma2, u64 tau) {
     const size_t h = n >> 1;
-    for (size_t j = (size_t)blockIdx.x * TPB + threadIdx.x; j < h; j += (size_t)gridDim.x * TPB) {
-        // h(a,v,t) = a + v*gamma + t*gamma^2 - tau   (prover.rs:44)
-        u64 a0 = gl_sub(gl_add(gl_add(dim[j], gl_mul(ep[j], gamma)), gl_mul(ts[j], gamma2)), tau);
-        u64 a1 = gl_sub(gl_add(gl_add(dim[j + h], gl_mul(ep[j + h], gamma)), gl_mul(ts[j + h], gamma2)), tau);
-        u64 b0 = gl_add(a0, gamma2), b1 = gl_add(a1, gamma2);  // write hash: t + 1
-        rd[j] = a0; rd[j + h] = a1;
-        wr[j] = b0; wr[j + h] = b1;
-        if (rd1) { rd1[j] = gl_mul(a0, a1); wr1[j] = gl_mul(b0, b1); }  // Layer::bottom + Layer::up (prover.rs:310-354)
+    typedef ulonglong2 V2;
+    for (size_t j = ((size_t)blockIdx.x * TPB + threadIdx.x) * 2; j < h; j += (size_t)gridDim.x * TPB * 2) {
+        const V2 dl = *reinterpret_cast<const V2*>(dim + j), dh = *reinterpret_cast<const V2*>(dim + j + h);
+        const V2 tl = *reinterpret_cast<const V2*>(ts + j), th = *reinterpret_cast<const V2*>(ts + j + h);
+        const u64 c0 = gl_sub(gl_add(dl.x, gl_mul(tl.x, gamma2)), tau), c1 = gl_sub(gl_add(dl.y, gl_mul(tl.y, gamma2)), tau);
+        const u64 c2 = gl_sub(gl_add(dh.x, gl_mul(th.x, gamma2)), tau), c3 = gl_sub(gl_add(dh.y, gl_mul(th.y, gamma2)), tau);
+        for (int m = 0; m < nmem; m++) {
+            const u64* __restrict__ ep = args.ep[m];
+            const V2 el = *reinterpret_cast<const V2*>(ep + j), eh = *reinterpret_cast<const V2*>(ep + j + h);
+            const u64 a0 = gl_add(c0, gl_mul(el.x, gamma)), a1 = gl_add(c1, gl_mul(el.y, gamma));
+            const u64 a2 = gl_add(c2, gl_mul(eh.x, gamma)), a3 = gl_add(c3, gl_mul(eh.y, gamma));
+            const u64 b0 = gl_add(a0, gamma2), b1 = gl_add(a1, gamma2), b2 = gl_add(a2, gamma2), b3 = gl_add(a3, gamma2);  // write hash: t + 1
+            *reinterpret_cast<V2*>(args.rd[m] + j) = make_ulonglong2(a0, a1);
+            *reinterpret_cast<V2*>(args.rd[m] + j + h) = make_ulonglong2(a2, a3);
+            *reinterpret_cast<V2*>(args.wr[m] + j) = make_ulonglong2(b0, b1);
+            *reinterpret_cast<V2*>(args.wr[m] + j + h) = make_ulonglong2(b2, b3);
+            if (args.rd1[m]) {
+                *reinterpret_cast<V2*>(args.rd1[m] + j) = make_ulonglong2(gl_mul(a0, a2), gl_mul(a1, a3));
+                *reinterpret_cast<V2*>(args.wr1[m] + j) = make_ulonglong2(gl_mul(b0, b2), gl_mul(b1, b3));
+            }
+        }
     }
 }
-void lasso_hash_rw(hipStream_t st, size_t n, const u64* dim, const u64* e_poly, const u64* read_ts, u64 gamma, u64 tau, u64* rd, u64* wr,
-                   u64* rd1, u64* wr1) {
-    k_hash_rw<<<grid_for(n >> 1) * 4, TPB, 0, st>>>(n, dim, e_poly, read_ts, gamma, gl_mul(gamma, gamma), tau, rd, wr, rd1, wr1);
+void lasso_hash_rw(hipStream_t st, size_t n, const u64* dim, const u64* read_ts, const HashRwArgs& args, int nmem, u64 gamma, u64 tau) {
+    k_hash_rw<<<grid_for(n >> 2) * 4, TPB, 0, st>>>(n, dim, read_ts, args, nmem, gamma, gl_mul(gamma, gamma), tau);
 }
 __global__ __launch_bounds__(TPB) void k_hash_if(HashIfArgs args, u64 gamma, u64 gamma2, u64 tau, u64* __restrict__ H2, int G) {
     const int i = blockIdx.y;  // memory

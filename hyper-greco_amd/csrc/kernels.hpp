@@ -148,9 +148,11 @@ void lasso_counters(hipStream_t st, const LassoDev& L, int m, const u64* dims, u
 // sum_k eq[k] * sum_i M^i E_{mems(lookup(k))[i]}[k]  -> partials (nv = 1)
 int lasso_claim(hipStream_t st, const LassoDev& L, const E2* eq, const u64* e_polys, E2* partials);
 // multiset hashes h = a + v*gamma + t*gamma^2 - tau
+// for up to HASH_RW_MAX memories of one chunk (shared dim / read_ts columns); n >= 4, a multiple of 4
 // rd1/wr1 (may be null): first product-tree level rd[j]*rd[j+n/2], wr[j]*wr[j+n/2], n/2 entries each
-void lasso_hash_rw(hipStream_t st, size_t n, const u64* dim, const u64* e_poly, const u64* read_ts, u64 gamma, u64 tau, u64* rd, u64* wr,
-                   u64* rd1, u64* wr1);
+constexpr int HASH_RW_MAX = 8;
+struct HashRwArgs { const u64* ep[HASH_RW_MAX]; u64* rd[HASH_RW_MAX]; u64* wr[HASH_RW_MAX]; u64* rd1[HASH_RW_MAX]; u64* wr1[HASH_RW_MAX]; };
+void lasso_hash_rw(hipStream_t st, size_t n, const u64* dim, const u64* read_ts, const HashRwArgs& args, int nmem, u64 gamma, u64 tau);
 // init / final hashes of all G memories in one launch: H2[i] = init_i, H2[G + i] = final_i (2^16 entries each)
 struct HashIfArgs { u32 cutoff[32]; const u64* fc[32]; };
 void lasso_hash_if(hipStream_t st, const HashIfArgs& args, int G, u64 gamma, u64 tau, u64* H2);

@@ -897,12 +897,10 @@ struct Prover {
         u64* H1 = any_gp1 ? ctx->alloc_n<u64>((size_t)nrows * N) : nullptr;
         u64* L1 = (any_gp1 && gp_deepest(nu, gp1_owner) >= 1) ? ctx->alloc_n<u64>((size_t)nrows * (N / 2)) : nullptr;
         u64* H2 = do_gp2 ? ctx->alloc_n<u64>((size_t)2 * G * M) : nullptr;
-        auto hash_rw = [&](int i, u64* rd, u64* wr, u64* rd1, u64* wr1) {
-            int m = lp.gkr_order[i], c = lp.gkr_chunk[i];
-            ctx->prof_begin(cls_hash, (double)N * 8 * (L1 ? 6 : 5));
-            dev::lasso_hash_rw(st, N, dims + (size_t)c * N, ep + (size_t)m * N, read_ts[c], gamma, tau, rd, wr, rd1, wr1);
-            ctx->prof_end();
-        };
+        // hash launches are grouped by chunk: the memories of a chunk share the dim / read_ts columns
+        struct HashReq { int i; u64 *rd, *wr, *rd1, *wr1; };
+        std::vector<HashReq> reqs;
+        auto hash_rw = [&](int i, u64* rd, u64* wr, u64* rd1, u64* wr1) { reqs.push_back({i, rd, wr, rd1, wr1}); };
         if (any_gp1 && !split) {
             for (int i = 0; i < G; i++)
                 hash_rw(i, H1 + (size_t)i * N, H1 + (size_t)(G + i) * N, L1 ? L1 + (size_t)i * (N / 2) : nullptr, L1 ? L1 + (size_t)(G + i) * (N / 2) : nullptr);
@@ -915,6 +913,22 @@ struct Prover {
             for (int q = 0; q < nlm; q++)
                 hash_rw(local_mems[q], H1 + (size_t)(base + q) * N, H1 + (size_t)(base + nlm + q) * N,
                         L1 ? L1 + (size_t)(base + q) * (N / 2) : nullptr, L1 ? L1 + (size_t)(base + nlm + q) * (N / 2) : nullptr);
+        }
+        for (int c = 0; c < 4; c++) {
+            std::vector<HashReq> of_c;
+            for (auto& r : reqs) if (lp.gkr_chunk[r.i] == c) of_c.push_back(r);
+            for (size_t o = 0; o < of_c.size(); o += dev::HASH_RW_MAX) {
+                const int cnt = (int)std::min<size_t>(dev::HASH_RW_MAX, of_c.size() - o);
+                dev::HashRwArgs ha;
+                memset(&ha, 0, sizeof(ha));
+                for (int q = 0; q < cnt; q++) {
+                    const HashReq& r = of_c[o + q];
+                    ha.ep[q] = ep + (size_t)lp.gkr_order[r.i] * N; ha.rd[q] = r.rd; ha.wr[q] = r.wr; ha.rd1[q] = r.rd1; ha.wr1[q] = r.wr1;
+                }
+                ctx->prof_begin(cls_hash, (double)N * 8 * (2 + cnt * (L1 ? 4 : 3)));
+                dev::lasso_hash_rw(st, N, dims + (size_t)c * N, read_ts[c], ha, cnt, gamma, tau);
+                ctx->prof_end();
+            }
         }
         if (do_gp2) {
             if (G > 32) throw Error("lasso: more than 32 memories");
