@@ -1,8 +1,8 @@
 // gfx950 (MI355X / CDNA4) kernels of the GKR prover. Integer modular work in 64-bit lanes: no MFMA.
-// Conventions: 256-thread workgroups (4 wave64), grid-stride loops over a fixed fan-in of at most
-// SC_MAX_BLOCKS workgroups, 16-byte coalesced loads of adjacent table entries (a sum-check pair
-// (T[2j], T[2j+1]) is one 16-B or 32-B contiguous access per lane), wave-level __shfl reductions then
-// one LDS hop per workgroup, per-block partial sums reduced by a second tiny launch.
+// Conventions: 256-thread workgroups (4 wave64), grid-stride loops over at most SC_MAX_BLOCKS workgroups per job,
+// 16-byte coalesced loads of adjacent table entries (a sum-check pair (T[2j], T[2j+1]) is one 16-B or two
+// contiguous 16-B accesses per lane), deferred-reduction arithmetic for the dot products (gl_wide.cuh), wave-level
+// DPP reductions then one LDS hop per workgroup; the workgroup that arrives last sums the per-workgroup partials.
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <algorithm>

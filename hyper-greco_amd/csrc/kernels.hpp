@@ -32,8 +32,9 @@ enum ScKind { SC_COLLATION = 0, SC_GRANDPROD = 1 };
 
 // Stride-layout sum-check instance (collation / grand-product shapes), device-visible descriptor.
 // Table t of round 0 lives at in + t*in_stride (u64 if base else E2). All instances of a prover run are
-// scheduled size-synchronously: step h launches, for every instance, its round whose half-length is h
-// (instances are independent on the device; only the transcript orders them). Because the challenges do not
+// scheduled round-synchronously: launch k runs, for every instance, its next round(s), whatever the sizes - the
+// items of a launch share a 1-D grid (StItem::blk0 / nblk); instances are independent on the device, only the
+// transcript orders them. Because the challenges do not
 // depend on the prover's messages (transcript.rs:146-157), two consecutive rounds of an instance can also run
 // in ONE launch (st_step2): the intermediate folded tables then never touch HBM.
 struct StJob {

@@ -297,7 +297,7 @@ struct Prover {
     static constexpr size_t TAIL_ITEMS = 2048;
 
     // Stride-layout sum-checks (collation, every grand-product layer) are queued as jobs and executed by
-    // flush_stride() in a size-synchronised schedule: they are independent on the device.
+    // flush_stride() in a round-synchronised schedule (launch k = every job's next round(s)): they are independent on the device.
     std::vector<dev::StJob> st_jobs;
     std::vector<dev::ScatterEnt> scatter;  // locally produced scalars -> global result slots (batch-subset grand products)
 
@@ -984,7 +984,7 @@ struct Prover {
             mark("lasso: openings of chunk " + std::to_string(c) + ": dim(x), read_ts(x), final_cts(y), E_m(x) (prover.rs:173-178)");
             defer_write_slots(base_slot, 3 + chk.second.size());
         }
-        flush_stride();  // collation + every grand-product layer, size-synchronised
+        flush_stride();  // collation + every grand-product layer, round-synchronised
         return ClaimRef{r_off, nu, claimed};  // (r, claimed_sum) for the single predecessor (lasso.rs:97,113)
     }
 
