@@ -39,7 +39,7 @@ EXPORTS = [
     "hg_last_error", "hg_device_count", "hg_create", "hg_destroy", "hg_params_builtin", "hg_setup", "hg_pk_free",
     "hg_pk_lasso_layout", "hg_pk_info", "hg_witness_from_json", "hg_witness_synthetic", "hg_witness_from_arrays",
     "hg_witness_get", "hg_witness_free", "hg_prove", "hg_verify", "hg_witness_gen", "hg_values_free", "hg_values_get", "hg_prove_shard_begin", "hg_prove_shard_combine", "hg_prove_shard_finish", "hg_prove_resident", "hg_circuit_eval", "hg_lasso_prove", "hg_lasso_prove_at", "hg_sumcheck", "hg_mle_eval",
-    "hg_ntt", "hg_challenges", "hg_challenges_bn254", "hg_bn254_field_op", "hg_sumcheck_bn254", "hg_profile", "hg_profile_select", "hg_profile_reset", "hg_profile_get",
+    "hg_ntt", "hg_challenges", "hg_challenges_bn254", "hg_bn254_field_op", "hg_sumcheck_bn254", "hg_mle_eval_bn254", "hg_ntt_bn254", "hg_profile", "hg_profile_select", "hg_profile_reset", "hg_profile_get",
 ]
 
 
@@ -97,6 +97,8 @@ def lib():
         L.hg_bn254_field_op.argtypes = [C.c_void_p, C.c_int, C.c_size_t, u64p, u64p, u64p]
         L.hg_sumcheck_bn254.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(u64p), u64p, C.c_size_t, u64p, C.c_size_t,
                                         u64p, u64p, u64p, u64p]
+        L.hg_mle_eval_bn254.argtypes = [C.c_void_p, u64p, C.c_size_t, u64p, u64p]
+        L.hg_ntt_bn254.argtypes = [C.c_void_p, u64p, C.c_size_t, C.c_int, C.c_size_t, u64p]
         L.hg_profile.argtypes = [C.c_void_p, C.c_int]
         L.hg_profile_select.argtypes = [C.c_void_p, C.c_char_p]
         L.hg_profile_reset.argtypes = [C.c_void_p]
@@ -179,6 +181,22 @@ class Context:
         out = np.zeros_like(pa)
         _check(lib().hg_bn254_field_op(self.h, op, len(a), _ptr(pa), _ptr(pb), _ptr(out)))
         return self._fr_unpack(out)
+
+    def mle_eval_bn254(self, table, point):
+        nv = (len(table) - 1).bit_length()
+        pt, pp = self._fr_pack(table), self._fr_pack(point) if len(point) else np.zeros(4, dtype=np.uint64)
+        out = np.zeros(4, dtype=np.uint64)
+        _check(lib().hg_mle_eval_bn254(self.h, _ptr(pt), nv, _ptr(pp), _ptr(out)))
+        return self._fr_unpack(out)[0]
+
+    def ntt_bn254(self, rows, inverse=False):
+        """rows: list of equal-length lists (a batch of transforms)."""
+        n = len(rows[0])
+        flat = self._fr_pack([v for r in rows for v in r])
+        out = np.zeros_like(flat)
+        _check(lib().hg_ntt_bn254(self.h, _ptr(flat), n.bit_length() - 1, 1 if inverse else 0, len(rows), _ptr(out)))
+        vals = self._fr_unpack(out)
+        return [vals[i * n:(i + 1) * n] for i in range(len(rows))]
 
     def sumcheck_bn254(self, kind, tables, pw, claim, chain_skip=0):
         """gkr::sum_check::prove_sum_check over bn256::Fr: (msgs, point, evals, sums) as lists of ints."""

@@ -278,5 +278,112 @@ void field_op_bn254(hg_ctx* ctx, int op, size_t n, const u64* a, const u64* b, u
     hipc(e2, "hg_bn254_field_op");
 }
 
+// ---- MLE evaluation and NTT over Fr (the other primitives of the path, A13/A14) -------------------------------------
+// t'[j] = t[2j] + r (t[2j+1] - t[2j]): binds the lowest variable (fix_var order of the path)
+__global__ void k_bn_fold(const Fr* __restrict__ in, Fr* __restrict__ out, size_t half, Fr r) {
+    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= half) return;
+    const Fr x = in[2 * j], y = in[2 * j + 1];
+    out[j] = fr_add(x, fr_mul(r, fr_sub(y, x)));
+}
+// W[i] = w^i (Montgomery), i < n
+__global__ void k_bn_powers(Fr* __restrict__ W, Fr w, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr r = fr_one_mont(), b = w;
+    for (size_t e = i; e; e >>= 1) { if (e & 1) r = fr_mul(r, b); b = fr_mul(b, b); }
+    W[i] = r;
+}
+__global__ void k_bn_bitrev(const Fr* __restrict__ in, Fr* __restrict__ out, int log2n, size_t total) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const size_t n = (size_t)1 << log2n, b = i >> log2n, k = i & (n - 1);
+    size_t rv = 0;
+    for (int q = 0; q < log2n; q++) rv |= ((k >> q) & 1) << (log2n - 1 - q);
+    out[(b << log2n) + rv] = in[i];
+}
+// one radix-2 decimation-in-time stage (input bit-reversed): butterflies of span 2^s
+__global__ void k_bn_ntt_stage(Fr* __restrict__ a, const Fr* __restrict__ W, int log2n, int s, size_t total_half) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total_half) return;
+    const size_t half_n = (size_t)1 << (log2n - 1);
+    const size_t b = i / half_n, t = i % half_n;
+    const size_t span = (size_t)1 << s, grp = t >> s, pos = t & (span - 1);
+    const size_t i0 = (b << log2n) + (grp << (s + 1)) + pos, i1 = i0 + span;
+    const Fr w = W[pos << (log2n - 1 - s)];
+    const Fr u = a[i0], v = fr_mul(a[i1], w);
+    a[i0] = fr_add(u, v);
+    a[i1] = fr_sub(u, v);
+}
+__global__ void k_bn_scale(Fr* __restrict__ a, Fr c, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = fr_mul(a[i], c);
+}
+
+// 2^28-th root of unity of bn256::Fr = 7^((r-1)/2^28) (halo2curves ROOT_OF_UNITY, S = 28; checked: order exactly 2^28)
+static Fr fr_root_of_unity(int log2n) {
+    if (log2n > 28) throw Error("bn254: two-adicity is 28");
+    Fr w = fr_to_mont(fr_make(0xd34f1ed960c37c9cULL, 0x3215cf6dd39329c8ULL, 0x98865ea93dd31f74ULL, 0x03ddb9f5166d18b7ULL));
+    for (int i = log2n; i < 28; i++) w = fr_mul(w, w);
+    return w;
+}
+
+// = BoxMultilinearPoly::evaluate over Fr [REF memory_checking/mod.rs:80-93, sk_encryption_circuit.rs:446]
+void mle_eval_bn254(hg_ctx* ctx, const u64* table4, size_t nv, const u64* point4, u64* out4) {
+    hipc(hipSetDevice(ctx->device), "hipSetDevice");
+    hipStream_t st = ctx->stream;
+    const size_t N = (size_t)1 << nv;
+    Fr *a = nullptr, *b = nullptr;
+    hipc(hipMalloc((void**)&a, N * sizeof(Fr)), "hipMalloc");
+    hipc(hipMalloc((void**)&b, std::max<size_t>(N / 2, 1) * sizeof(Fr)), "hipMalloc");
+    hipError_t e = hipMemcpyAsync(a, table4, N * sizeof(Fr), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        k_bn_to_mont<<<(unsigned)((N + 255) / 256), 256, 0, st>>>(a, N);
+        Fr *cur = a, *nxt = b;
+        for (size_t v = 0; v < nv; v++) {
+            const size_t half = N >> (v + 1);
+            const Fr r = fr_to_mont(fr_make(point4[4 * v], point4[4 * v + 1], point4[4 * v + 2], point4[4 * v + 3]));
+            k_bn_fold<<<(unsigned)((half + 255) / 256), 256, 0, st>>>(cur, nxt, half, r);
+            std::swap(cur, nxt);
+        }
+        k_bn_from_mont<<<1, 64, 0, st>>>(cur, 1);
+        e = hipMemcpyAsync(out4, cur, sizeof(Fr), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    (void)hipFree(a); (void)hipFree(b);
+    hipc(e, "hg_mle_eval_bn254");
+}
+
+// = FftNode evaluate over Fr: out[k] = sum_j in[j] w^(jk), w the 2^log2n-th root of unity (inverse: w^-1 and 1/n);
+// natural order in and out [REF sk_encryption_circuit.rs:224,249,251]
+void ntt_bn254(hg_ctx* ctx, const u64* in4, int log2n, bool inverse, size_t batch, u64* out4) {
+    hipc(hipSetDevice(ctx->device), "hipSetDevice");
+    hipStream_t st = ctx->stream;
+    const size_t n = (size_t)1 << log2n, total = n * batch;
+    Fr w = fr_root_of_unity(log2n);
+    if (inverse) w = fr_inv(w);
+    Fr *a = nullptr, *b = nullptr, *W = nullptr;
+    hipc(hipMalloc((void**)&a, total * sizeof(Fr)), "hipMalloc");
+    hipc(hipMalloc((void**)&b, total * sizeof(Fr)), "hipMalloc");
+    hipc(hipMalloc((void**)&W, std::max<size_t>(n / 2, 1) * sizeof(Fr)), "hipMalloc");
+    hipError_t e = hipMemcpyAsync(a, in4, total * sizeof(Fr), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        k_bn_to_mont<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(a, total);
+        k_bn_powers<<<(unsigned)((std::max<size_t>(n / 2, 1) + 255) / 256), 256, 0, st>>>(W, w, std::max<size_t>(n / 2, 1));
+        k_bn_bitrev<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(a, b, log2n, total);
+        const size_t th = total / 2;
+        for (int s = 0; s < log2n; s++) k_bn_ntt_stage<<<(unsigned)((th + 255) / 256), 256, 0, st>>>(b, W, log2n, s, th);
+        if (inverse) {
+            const Fr ninv = fr_inv(fr_to_mont(fr_make((u64)n, 0, 0, 0)));
+            k_bn_scale<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(b, ninv, total);
+        }
+        k_bn_from_mont<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(b, total);
+        e = hipMemcpyAsync(out4, b, total * sizeof(Fr), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    (void)hipFree(a); (void)hipFree(b); (void)hipFree(W);
+    hipc(e, "hg_ntt_bn254");
+}
+
 }  // namespace bn
 }  // namespace hg

@@ -13,6 +13,8 @@ void sumcheck_bn254(hg_ctx* ctx, int kind, size_t nv, size_t ntab, const u64* co
                     size_t chain_skip, u64* msgs, u64* point, u64* evals, u64* sums);
 void field_op_bn254(hg_ctx* ctx, int op, size_t n, const u64* a, const u64* b, u64* out);
 void challenges_bn254_raw(size_t n, uint64_t* out4);
+void mle_eval_bn254(hg_ctx* ctx, const u64* table4, size_t nv, const u64* point4, u64* out4);
+void ntt_bn254(hg_ctx* ctx, const u64* in4, int log2n, bool inverse, size_t batch, u64* out4);
 } }
 using namespace hg;
 
@@ -484,6 +486,21 @@ int hg_sumcheck_bn254(hg_ctx* ctx, int kind, size_t nv, size_t ntab, const uint6
     HG_TRY
     if (!ctx) throw hg::Error("hg_sumcheck_bn254: no context (a HIP device is required)");
     hg::bn::sumcheck_bn254(ctx, kind, nv, ntab, tables, pw4, npw, claim4, chain_skip, msgs, point, evals, sums);
+    return 0;
+    HG_CATCH(-1)
+}
+
+int hg_mle_eval_bn254(hg_ctx* ctx, const uint64_t* table4, size_t nv, const uint64_t* point4, uint64_t out4[4]) {
+    HG_TRY
+    if (!ctx) throw hg::Error("hg_mle_eval_bn254: no context (a HIP device is required)");
+    hg::bn::mle_eval_bn254(ctx, table4, nv, point4, out4);
+    return 0;
+    HG_CATCH(-1)
+}
+int hg_ntt_bn254(hg_ctx* ctx, const uint64_t* in4, size_t log2n, int inverse, size_t batch, uint64_t* out4) {
+    HG_TRY
+    if (!ctx) throw hg::Error("hg_ntt_bn254: no context (a HIP device is required)");
+    hg::bn::ntt_bn254(ctx, in4, (int)log2n, inverse != 0, batch, out4);
     return 0;
     HG_CATCH(-1)
 }

@@ -169,6 +169,12 @@ int hg_bn254_field_op(hg_ctx* ctx, int op, size_t n, const uint64_t* a4, const u
 int hg_sumcheck_bn254(hg_ctx* ctx, int kind, size_t nv, size_t ntab, const uint64_t* const* tables, const uint64_t* pw4, size_t npw,
                       const uint64_t* claim4, size_t chain_skip, uint64_t* msgs, uint64_t* point, uint64_t* evals, uint64_t* sums);
 
+/* = BoxMultilinearPoly::evaluate over Fr [REF memory_checking/mod.rs:80-93]: table of 2^nv elements at a point of nv elements */
+int hg_mle_eval_bn254(hg_ctx* ctx, const uint64_t* table4, size_t nv, const uint64_t* point4, uint64_t out4[4]);
+/* = FftNode evaluate over Fr [REF sk_encryption_circuit.rs:224,249,251]: size-2^log2n NTT with the root of unity
+ *   7^((r-1)/2^log2n) (halo2curves ROOT_OF_UNITY, two-adicity 28), natural order in / out; inverse scales by 1/n */
+int hg_ntt_bn254(hg_ctx* ctx, const uint64_t* in4, size_t log2n, int inverse, size_t batch, uint64_t* out4);
+
 /* profiling: level 0 off, 1 = events around the selected kernel class only, 2 = every class */
 int hg_profile(hg_ctx* ctx, int level);
 /* selects the class that level 1 times (a name hg_profile_get reported); returns 0, or -1 if there is no such class */

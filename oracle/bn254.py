@@ -83,3 +83,31 @@ def verify_sumcheck(kind, msgs, evals, pw, claim, chal):
     else:
         g = sum(evals[2 * i] * evals[2 * i + 1] for i in range(len(evals) // 2))
     return g % R == claim % R
+
+
+ROOT_OF_UNITY_2_28 = pow(7, (R - 1) >> 28, R)  # halo2curves bn256::Fr::ROOT_OF_UNITY (S = 28, generator 7)
+
+
+def root_of_unity(log2n):
+    return pow(ROOT_OF_UNITY_2_28, 1 << (28 - log2n), R)
+
+
+def ntt(a, inverse=False):
+    """out[k] = sum_j a[j] w^(jk) (definition, O(n^2)); inverse: w^-1 and 1/n. Natural order in and out."""
+    n = len(a)
+    w = root_of_unity(n.bit_length() - 1)
+    if inverse:
+        w = pow(w, -1, R)
+    out = [sum(a[j] * pow(w, j * k, R) for j in range(n)) % R for k in range(n)]
+    if inverse:
+        ninv = pow(n, -1, R)
+        out = [x * ninv % R for x in out]
+    return out
+
+
+def mle_eval(table, point):
+    """Multilinear extension of `table` (little-endian variable order) at `point`."""
+    t = list(table)
+    for r in point:
+        t = [(t[2 * j] + r * (t[2 * j + 1] - t[2 * j])) % R for j in range(len(t) // 2)]
+    return t[0]

@@ -334,3 +334,24 @@ def test_bn254_sumcheck_kernels_bit_exact(ctx, kind, ntab, nv):
     msgs, point, evals, sums = ctx.sumcheck_bn254(kind, tabs, pw, claim, skip)
     emsgs, eevals, esums = bn.sumcheck(kind, tabs, pw, claim, chal)
     assert point == chal and msgs == emsgs and evals == eevals and sums == esums
+
+
+@pytest.mark.parametrize("nv", [0, 1, 5, 11])
+def test_bn254_mle_eval(ctx, nv):
+    bn = orclib.bn254()
+    rng = random.Random(nv)
+    table = [rng.randrange(bn.R) for _ in range(1 << nv)]
+    point = [rng.randrange(bn.R) for _ in range(nv)]
+    assert ctx.mle_eval_bn254(table, point) == bn.mle_eval(table, point)
+
+
+@pytest.mark.parametrize("log2n", [1, 4, 8])
+def test_bn254_ntt_matches_the_definition_and_inverts(ctx, log2n):
+    bn = orclib.bn254()
+    rng = random.Random(log2n)
+    rows = [[rng.randrange(bn.R) for _ in range(1 << log2n)] for _ in range(3)]
+    fwd = ctx.ntt_bn254(rows)
+    assert fwd == [bn.ntt(r) for r in rows]
+    assert ctx.ntt_bn254(fwd, inverse=True) == rows
+    big = [[rng.randrange(bn.R) for _ in range(1 << 14)]]   # size-independent property at a larger size: round trip
+    assert ctx.ntt_bn254(ctx.ntt_bn254(big), inverse=True) == big

@@ -263,3 +263,16 @@ def test_bn254_sumcheck_oracle_round_trip(kind, ntab, nv):
     bad = [list(m) for m in msgs]
     bad[-1][1] = (bad[-1][1] + 1) % bn.R
     assert not bn.verify_sumcheck(kind, bad, evals, pw, claim, chal)
+
+
+def test_bn254_root_of_unity_and_ntt_oracle():
+    """halo2curves bn256::Fr::ROOT_OF_UNITY = 7^((r-1)/2^28): the recalled constant, its order, and the O(n^2) NTT oracle."""
+    bn = orclib.bn254()
+    assert bn.ROOT_OF_UNITY_2_28 == 0x03ddb9f5166d18b798865ea93dd31f743215cf6dd39329c8d34f1ed960c37c9c
+    assert pow(bn.ROOT_OF_UNITY_2_28, 1 << 28, bn.R) == 1 and pow(bn.ROOT_OF_UNITY_2_28, 1 << 27, bn.R) == bn.R - 1
+    a = [3, 1, 4, 1, 5, 9, 2, 6]
+    assert bn.ntt(bn.ntt(a), inverse=True) == a
+    # convolution theorem on a cyclic product: (1 + x) * (1 + x) = 1 + 2x + x^2 mod x^8 - 1
+    f = bn.ntt([1, 1, 0, 0, 0, 0, 0, 0])
+    assert bn.ntt([x * x % bn.R for x in f], inverse=True) == [1, 2, 1, 0, 0, 0, 0, 0]
+    assert bn.mle_eval([5, 7], [3]) == (5 + 3 * 2) % bn.R
