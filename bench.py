@@ -259,6 +259,11 @@ def main():
                          "launches_per_step": dom["launches"] // max(args.steps, 1),
                          "avg_launch_us": round(avg_ms * 1e3, 3), "algo_bytes_per_launch": round(per_launch_bytes)},
             "kernel_classes": classes,
+            # whole prove against the same roofline: algorithmic bytes of every kernel class (SURVEY 8(d) accounting) over the
+            # GPU time of one prove (HIP events around the whole enqueue)
+            "whole_prove": {"algo_GB": round(sum(c["algo_GB"] for c in classes.values()), 3), "gpu_ms": round(gpu_ms, 4),
+                            "achieved": round(sum(c["algo_GB"] for c in classes.values()) / (gpu_ms * 1e-3), 1) if gpu_ms > 0 else None,
+                            "unit": "GB/s", "frac": round(sum(c["algo_GB"] for c in classes.values()) / (gpu_ms * 1e-3) / HBM_PEAK_GBS, 4) if gpu_ms > 0 else None},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -341,7 +341,26 @@ __device__ __forceinline__ E2 block_sum_n(E2 v, E2* sm /* >= 16 */) {
     return v;
 }
 
-extern __shared__ E2 dyn_lds[];  // [16 block-sum slots][NV * BD reduction slots]
+constexpr int SM_SLOTS = 96;      // block-sum scratch at the start of dynamic LDS: 16 waves x up to 6 values
+extern __shared__ E2 dyn_lds[];  // [SM_SLOTS block-sum slots][kernel-specific: NV * BD reduction slots, chunk tables, ...]
+// sums N values over the workgroup with one pair of barriers; results valid in thread 0
+template <int N>
+__device__ __forceinline__ void block_sum_multi(E2 (&v)[N], E2* sm /* >= 16 * N */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int k = 0; k < N; k++) v[k] = wave_sum(v[k]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < N; k++) sm[wave * N + k] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int w = 1; w < nw; w++) {
+#pragma unroll
+            for (int k = 0; k < N; k++) v[k] = e2_add(v[k], sm[w * N + k]);
+        }
+}
 
 // ---- per-workgroup partial sums, finished by the workgroup that arrives last --------------------------------------
 // Partials cross workgroups (and XCDs, whose L2s are not coherent with each other) as relaxed agent-scope atomics:
@@ -423,19 +442,19 @@ __global__ __launch_bounds__(256) void k_st_step(const StJob* __restrict__ jobs,
     const int nblocks = I.nblk, bx = (int)blockIdx.x - I.blk0;
     const void* in = I.in; const size_t in_stride = I.in_stride; E2* out = I.out;
     E2* sm = dyn_lds;
-    E2* red = dyn_lds + 16;
+    E2* red = dyn_lds + SM_SLOTS;
     E2 acc[NV];
 #pragma unroll
     for (int t = 0; t < NV; t++) acc[t] = e2_zero();
     if (rd == 0) sc_round_body<KIND, T, true>(reinterpret_cast<const T*>(in), in_stride, out, half, J.ntab, half, chal[J.r_off + rd], J.pw, J.pwr, jb_log2, red, acc, bx, nblocks, J.p0_only != 0);
     else sc_round_body<KIND, T, false>(reinterpret_cast<const T*>(in), in_stride, out, half, J.ntab, half, chal[J.r_off + rd], J.pw, J.pwr, jb_log2, red, acc, bx, nblocks, J.p0_only != 0);
     E2* part = partials + (size_t)y * SC_MAX_BLOCKS * NV;
+    block_sum_multi<NV>(acc, sm);
+    if (threadIdx.x == 0) {
 #pragma unroll
-    for (int t = 0; t < NV; t++) {
-        E2 s = block_sum_n(acc[t], sm);
-        if (threadIdx.x == 0) {
-            if (nblocks == 1) res[J.sums_slot + (size_t)rd * NV + t] = s;
-            else part_store(part + (size_t)bx * NV + t, s);
+        for (int t = 0; t < NV; t++) {
+            if (nblocks == 1) res[J.sums_slot + (size_t)rd * NV + t] = acc[t];
+            else part_store(part + (size_t)bx * NV + t, acc[t]);
         }
     }
     if (nblocks > 1) finish_partials(part, NV, tickets_of(partials) + y * 32, res + J.sums_slot + (size_t)rd * NV, sm, nblocks);
@@ -537,12 +556,12 @@ __global__ __launch_bounds__(256) void k_st_step2(const StJob* __restrict__ jobs
     }
     E2* sm = dyn_lds;
     E2* part = partials + (size_t)y * SC_MAX_BLOCKS * 6;
+    block_sum_multi<6>(acc, sm);
+    if (threadIdx.x == 0) {
 #pragma unroll
-    for (int t = 0; t < 6; t++) {
-        E2 s = block_sum_n(acc[t], sm);
-        if (threadIdx.x == 0) {
-            if (nblocks == 1) res[J.sums_slot + (size_t)rd * 3 + t] = s;
-            else part_store(part + (size_t)bx * 6 + t, s);
+        for (int t = 0; t < 6; t++) {
+            if (nblocks == 1) res[J.sums_slot + (size_t)rd * 3 + t] = acc[t];
+            else part_store(part + (size_t)bx * 6 + t, acc[t]);
         }
     }
     if (nblocks > 1) finish_partials(part, 6, tickets_of(partials) + y * 32, res + J.sums_slot + (size_t)rd * 3, sm, nblocks);
@@ -608,12 +627,12 @@ __global__ __launch_bounds__(256) void k_col_step2(const StJob* __restrict__ job
     }
     E2* sm = dyn_lds;
     E2* part = partials + (size_t)y * SC_MAX_BLOCKS * 4;
+    block_sum_multi<4>(acc, sm);
+    if (threadIdx.x == 0) {
 #pragma unroll
-    for (int t = 0; t < 4; t++) {
-        E2 s = block_sum_n(acc[t], sm);
-        if (threadIdx.x == 0) {
-            if (nblocks == 1) res[J.sums_slot + (size_t)rd * 2 + t] = s;
-            else part_store(part + (size_t)bx * 4 + t, s);
+        for (int t = 0; t < 4; t++) {
+            if (nblocks == 1) res[J.sums_slot + (size_t)rd * 2 + t] = acc[t];
+            else part_store(part + (size_t)bx * 4 + t, acc[t]);
         }
     }
     if (nblocks > 1) finish_partials(part, 4, tickets_of(partials) + y * 32, res + J.sums_slot + (size_t)rd * 2, sm, nblocks);
@@ -709,7 +728,7 @@ __global__ __launch_bounds__(512) void k_st_chunk(const StJob* __restrict__ jobs
     const StJob& J = jobs[I.job];
     E2* sm = dyn_lds;
     E2* scratch[2];
-    scratch[0] = dyn_lds + 16;
+    scratch[0] = dyn_lds + SM_SLOTS;
     scratch[1] = scratch[0] + ((size_t)lds_ntab << ST_CHUNK_ROUNDS >> 1);
     const int R = I.nrounds, c = I.c_log2;
     const bool p0_only = J.p0_only != 0;
@@ -734,11 +753,13 @@ __global__ __launch_bounds__(512) void k_st_chunk(const StJob* __restrict__ jobs
         else if (rd == 0) sc_round_small<KIND, E2, true>(reinterpret_cast<const E2*>(in), in_stride, in_j0, in_half, out, out_stride, out_j0, out_half, jc, J.ntab, r, J.pw, J.pwr, a, p0_only);
         else sc_round_small<KIND, E2, false>(reinterpret_cast<const E2*>(in), in_stride, in_j0, in_half, out, out_stride, out_j0, out_half, jc, J.ntab, r, J.pw, J.pwr, a, p0_only);
 #pragma unroll
-        for (int t = 0; t < NV; t++) {
-            E2 s = block_sum_n((threadIdx.x & 63) == 0 ? a[t] : e2_zero(), sm);   // also the barrier that completes the folded chunk in LDS
-            if (threadIdx.x == 0) {
-                if (I.nchunks == 1) res[J.sums_slot + (size_t)rd * NV + t] = s;
-                else part_store(part + (size_t)blockIdx.x * per + u * NV + t, s);
+        for (int t = 0; t < NV; t++) if ((threadIdx.x & 63) != 0) a[t] = e2_zero();
+        block_sum_multi<NV>(a, sm);   // also the barrier that completes the folded chunk in LDS
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int t = 0; t < NV; t++) {
+                if (I.nchunks == 1) res[J.sums_slot + (size_t)rd * NV + t] = a[t];
+                else part_store(part + (size_t)blockIdx.x * per + u * NV + t, a[t]);
             }
         }
         __syncthreads();
@@ -748,7 +769,7 @@ __global__ __launch_bounds__(512) void k_st_chunk(const StJob* __restrict__ jobs
 }
 void st_chunk(hipStream_t st, int kind, const StJob* jobs, const StItem* items, int nitems, int max_chunks, int max_ntab,
               const E2* chal, E2* partials, E2* res) {
-    const size_t lds = (16 + ((size_t)max_ntab << ST_CHUNK_ROUNDS >> 1) + ((size_t)max_ntab << ST_CHUNK_ROUNDS >> 2)) * sizeof(E2);
+    const size_t lds = (SM_SLOTS + ((size_t)max_ntab << ST_CHUNK_ROUNDS >> 1) + ((size_t)max_ntab << ST_CHUNK_ROUNDS >> 2)) * sizeof(E2);
     dim3 grid(max_chunks, nitems);
     if (kind == SC_GRANDPROD) {
         k_st_chunk<SC_GRANDPROD><<<grid, 512, lds, st>>>(jobs, items, max_ntab, chal, partials, res);
@@ -757,7 +778,7 @@ void st_chunk(hipStream_t st, int kind, const StJob* jobs, const StItem* items, 
     }
 }
 
-static inline size_t sc_lds_bytes(int nv, int bd) { return (16 + (size_t)nv * bd) * sizeof(E2); }
+static inline size_t sc_lds_bytes(int nv, int bd) { return (SM_SLOTS + (size_t)nv * bd) * sizeof(E2); }
 
 int st_plan_blocks(StItem* items, int nitems, bool rounds2) {
     // total work of the launch decides how finely the small items are split along the tables (jb < 8)
@@ -804,9 +825,12 @@ __device__ __forceinline__ void ps_io(const PsJob& J, int rd, int rounds, int in
     else { size_t len = N >> (rd + rounds); oa = J.bufa[out_buf] + (size_t)i * len; ob = J.bufb[out_buf] + (size_t)i * len; }
 }
 
+// optional LDS-resident tables (the single-workgroup tail keeps its intermediate folds on chip): table i of a region at
+// base + i * (its length); null = the global buffers of ps_io
+struct PsLds { const E2* ia; const E2* ib; E2* oa; E2* ob; };
 template <typename TA>
 __device__ __forceinline__ void ps_round_body(const PsJob& J, int rd, int in_buf, int out_buf, size_t half, E2 r, int jb_log2, E2& a0, E2& a2,
-                                              size_t first_tile, size_t tile_step) {
+                                              size_t first_tile, size_t tile_step, PsLds lds = PsLds{nullptr, nullptr, nullptr, nullptr}) {
     using V = Val<TA>;
     const int BD = blockDim.x, tid = threadIdx.x;
     const int G = BD >> jb_log2;
@@ -816,12 +840,16 @@ __device__ __forceinline__ void ps_round_body(const PsJob& J, int rd, int in_buf
     // whole grid-stride loop of this thread and are reduced once at the end.
     WE2 w0 = we2_zero(), w2 = we2_zero();
     const FoldR fr = fold_r(r);
+    bool touched = false;
     for (size_t tile = first_tile; tile < ntiles; tile += tile_step) {
         const size_t j = (tile << jb_log2) + jj;
         const size_t jo = dpos(j, half);
         for (int i = g; i < J.npairs; i += G) {
+            touched = true;
             const void* pa; const E2* pb; E2* oa; E2* ob;
             ps_io(J, rd, 1, in_buf, out_buf, i, pa, pb, oa, ob);
+            if (lds.ia) { pa = lds.ia + (size_t)i * 2 * half; pb = lds.ib + (size_t)i * 2 * half; }
+            if (lds.oa) { oa = lds.oa + (size_t)i * half; ob = lds.ob + (size_t)i * half; }
             TA xa, ya;
             E2 xb, yb;
             if (in_buf < 0) {
@@ -850,8 +878,10 @@ __device__ __forceinline__ void ps_round_body(const PsJob& J, int rd, int in_buf
             store_e2(ob + jo, e2_fold_wide(xb, db, fr));
         }
     }
-    a0 = e2_add(a0, we2_reduce(w0));
-    a2 = e2_add(a2, we2_reduce(w2));
+    if (touched) {  // (threads without work skip the six reductions: most of a small round's workgroup)
+        a0 = e2_add(a0, we2_reduce(w0));
+        a2 = e2_add(a2, we2_reduce(w2));
+    }
 }
 
 // one round of every item's job; items share a 1-D grid (item y owns workgroups [blk0, blk0 + nblk))
@@ -876,8 +906,9 @@ __global__ __launch_bounds__(256) void k_ps_one(const PsJob* __restrict__ jobs, 
     E2 a0 = e2_zero(), a2 = e2_zero();
     if (I.in_buf < 0) ps_round_body<u64>(J, rd, I.in_buf, I.out_buf, half, r, I.jb_log2, a0, a2, bx, nblocks);
     else ps_round_body<E2>(J, rd, I.in_buf, I.out_buf, half, r, I.jb_log2, a0, a2, bx, nblocks);
-    E2 s0 = block_sum_n(a0, sm);
-    E2 s2 = block_sum_n(a2, sm);
+    E2 sv[2] = {a0, a2};
+    block_sum_multi<2>(sv, sm);
+    const E2 s0 = sv[0], s2 = sv[1];
     E2* part = partials + (size_t)y * SC_MAX_BLOCKS * 4;
     if (threadIdx.x == 0) {
         if (nblocks == 1) { res[J.sums_slot + 2 * rd] = s0; res[J.sums_slot + 2 * rd + 1] = s2; }
@@ -947,11 +978,11 @@ __device__ __forceinline__ void ps_step2_body(const PsJob& J, const PsItem& I, s
     acc[1] = we2_reduce(w2);
     const E2 mine = w2_reduce(vm);
     const u64 ip = wreduce(vi);
-    const E2 P0 = block_sum_n(odd ? e2_zero() : mine, sm);
-    const E2 P1 = block_sum_n(odd ? mine : e2_zero(), sm);
-    const E2 Pi = block_sum_n(odd ? e2(0, ip) : e2(ip, 0), sm);
-    acc[2] = P0;                                                        // valid in thread 0
-    acc[3] = e2_add(e2_sub(e2_dbl(P1), P0), e2_dbl(Pi));
+    E2 v[5] = {acc[0], acc[1], odd ? e2_zero() : mine, odd ? mine : e2_zero(), odd ? e2(0, ip) : e2(ip, 0)};
+    block_sum_multi<5>(v, sm);                                          // results valid in thread 0
+    acc[0] = v[0]; acc[1] = v[1];
+    acc[2] = v[2];
+    acc[3] = e2_add(e2_sub(e2_dbl(v[3]), v[2]), e2_dbl(v[4]));
 }
 __global__ __launch_bounds__(256) void k_ps_step2(const PsJob* __restrict__ jobs, const PsItem* __restrict__ items, int nitems,
                                                   const E2* __restrict__ chal, E2* __restrict__ partials, E2* __restrict__ res) {
@@ -965,7 +996,7 @@ __global__ __launch_bounds__(256) void k_ps_step2(const PsJob* __restrict__ jobs
     E2 acc[4];
     if (I.in_buf < 0) ps_step2_body<u64>(J, I, half, chal[J.r_off + rd], chal[J.r_off + rd + 1], acc, sm);
     else ps_step2_body<E2>(J, I, half, chal[J.r_off + rd], chal[J.r_off + rd + 1], acc, sm);
-    const E2 s0 = block_sum_n(acc[0], sm), s2 = block_sum_n(acc[1], sm);
+    const E2 s0 = acc[0], s2 = acc[1];  // summed over the workgroup by ps_step2_body (thread 0)
     E2* part = partials + (size_t)y * SC_MAX_BLOCKS * 4;
     if (threadIdx.x == 0) {
         E2* out = nblocks == 1 ? res + J.sums_slot + 2 * rd : nullptr;
@@ -974,26 +1005,35 @@ __global__ __launch_bounds__(256) void k_ps_step2(const PsJob* __restrict__ jobs
     }
     if (nblocks > 1) finish_partials(part, 4, tickets_of(partials) + y * 32, res + J.sums_slot + 2 * rd, sm, nblocks);
 }
-// rounds [tail_rd, nvars) of every job, one workgroup per job
+// rounds [tail_rd, nvars) of every job, one workgroup per job; the folds between the rounds live in LDS
+// (dynamic LDS: 16 block-sum slots, then PS_TAIL_LDS_E2 Ext2 entries: two ping-pong regions of 2/3 and 1/3)
+constexpr size_t PS_TAIL_LDS_E2 = 6144;  // first tail round: <= 2048 pair items -> 2 * 2048 folded entries, then half of that
 __global__ __launch_bounds__(1024) void k_ps_tail(const PsJob* __restrict__ jobs, const E2* __restrict__ chal, E2* __restrict__ res) {
     const PsJob& J = jobs[blockIdx.x];
     E2* sm = dyn_lds;
     int bd_log2 = 31 - __clz((int)blockDim.x);
     int in_buf = J.tail_buf;
+    const E2* lin_a = nullptr; const E2* lin_b = nullptr;
     for (int rd = J.tail_rd; rd < J.nvars; rd++) {
         const int hl = J.nvars - 1 - rd;
         const size_t half = (size_t)1 << hl;
         const int jb_log2 = hl < bd_log2 ? hl : bd_log2;
-        const int out_buf = rd == J.nvars - 1 ? -1 : (in_buf == 0 ? 1 : 0);
+        const bool last = rd == J.nvars - 1;
+        const int out_buf = last ? -1 : (in_buf == 0 ? 1 : 0);
+        // this round's folds: npairs tables of `half` entries for a and for b
+        const bool fits = !last && 2 * (size_t)J.npairs * half <= ((rd - J.tail_rd) & 1 ? (size_t)2048 : (size_t)4096);
+        E2* reg = dyn_lds + SM_SLOTS + (((rd - J.tail_rd) & 1) ? 4096 : 0);
+        PsLds lds{lin_a, lin_b, fits ? reg : nullptr, fits ? reg + (size_t)J.npairs * half : nullptr};
         E2 r = chal[J.r_off + rd];
         E2 a0 = e2_zero(), a2 = e2_zero();
-        if (in_buf < 0) ps_round_body<u64>(J, rd, in_buf, out_buf, half, r, jb_log2, a0, a2, 0, 1);
-        else ps_round_body<E2>(J, rd, in_buf, out_buf, half, r, jb_log2, a0, a2, 0, 1);
-        E2 s0 = block_sum_n(a0, sm);
-        E2 s2 = block_sum_n(a2, sm);
-        if (threadIdx.x == 0) { res[J.sums_slot + 2 * rd] = s0; res[J.sums_slot + 2 * rd + 1] = s2; }
+        if (in_buf < 0 && !lin_a) ps_round_body<u64>(J, rd, in_buf, out_buf, half, r, jb_log2, a0, a2, 0, 1, lds);
+        else ps_round_body<E2>(J, rd, lin_a ? 0 : in_buf, out_buf, half, r, jb_log2, a0, a2, 0, 1, lds);
+        E2 sv[2] = {a0, a2};
+        block_sum_multi<2>(sv, sm);
+        if (threadIdx.x == 0) { res[J.sums_slot + 2 * rd] = sv[0]; res[J.sums_slot + 2 * rd + 1] = sv[1]; }
         __syncthreads();
-        in_buf = out_buf;
+        if (fits) { lin_a = lds.oa; lin_b = lds.ob; }
+        else { lin_a = lin_b = nullptr; in_buf = out_buf; }
     }
 }
 
@@ -1024,11 +1064,14 @@ int ps_plan_blocks(PsItem* items, int nitems, const PsJob* host_jobs, bool round
     return blk;
 }
 void ps_round(hipStream_t st, bool rounds2, const PsJob* jobs, const PsItem* items, int nitems, int grid, const E2* chal, E2* partials, E2* res) {
-    if (rounds2) k_ps_step2<<<grid, 256, 16 * sizeof(E2), st>>>(jobs, items, nitems, chal, partials, res);
-    else k_ps_one<<<grid, 256, 16 * sizeof(E2), st>>>(jobs, items, nitems, chal, partials, res);
+    if (rounds2) k_ps_step2<<<grid, 256, SM_SLOTS * sizeof(E2), st>>>(jobs, items, nitems, chal, partials, res);
+    else k_ps_one<<<grid, 256, SM_SLOTS * sizeof(E2), st>>>(jobs, items, nitems, chal, partials, res);
 }
 void ps_tail(hipStream_t st, const PsJob* jobs, int njobs, const E2* chal, E2* res) {
-    k_ps_tail<<<njobs, 1024, 16 * sizeof(E2), st>>>(jobs, chal, res);
+    const size_t lds = (SM_SLOTS + PS_TAIL_LDS_E2) * sizeof(E2);
+    static const hipError_t attr = hipFuncSetAttribute((const void*)k_ps_tail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)attr;
+    k_ps_tail<<<njobs, 1024, lds, st>>>(jobs, chal, res);
 }
 
 __global__ void k_scatter_e2(const ScatterEnt* __restrict__ ents, size_t n, E2* __restrict__ dst_base) {
