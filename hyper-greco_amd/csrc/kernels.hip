@@ -1373,14 +1373,23 @@ __global__ __launch_bounds__(TPB) void k_dot_eq(const E2* __restrict__ eq, DotTa
     E2 acc[8];
 #pragma unroll
     for (int t = 0; t < 8; t++) acc[t] = e2_zero();
-    for (size_t j = (size_t)blockIdx.x * TPB + threadIdx.x; j < n; j += (size_t)gridDim.x * TPB) {
-        E2 e = eq[j];
+    if ((n & 1) == 0) {  // two entries per thread: 16-byte table loads
+        for (size_t j = ((size_t)blockIdx.x * TPB + threadIdx.x) * 2; j < n; j += (size_t)gridDim.x * TPB * 2) {
+            const E2 e0 = eq[j], e1 = eq[j + 1];
 #pragma unroll
-        for (int t = 0; t < 8; t++)
-            if (t < ntab) {
-                u64 v = tabs.t[t][j];
-                acc[t] = e2_add(acc[t], e2_mul_f(e, v));
-            }
+            for (int t = 0; t < 8; t++)
+                if (t < ntab) {
+                    const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(tabs.t[t] + j);
+                    acc[t] = e2_add(acc[t], e2_add(e2_mul_f(e0, v.x), e2_mul_f(e1, v.y)));
+                }
+        }
+    } else {
+        for (size_t j = (size_t)blockIdx.x * TPB + threadIdx.x; j < n; j += (size_t)gridDim.x * TPB) {
+            E2 e = eq[j];
+#pragma unroll
+            for (int t = 0; t < 8; t++)
+                if (t < ntab) acc[t] = e2_add(acc[t], e2_mul_f(e, tabs.t[t][j]));
+        }
     }
 #pragma unroll
     for (int t = 0; t < 8; t++)
@@ -1396,7 +1405,7 @@ void dot_eq(hipStream_t st, const E2* eq, const u64* const tabs[8], int ntab, si
     for (int t = 0; t < 8; t++) d.t[t] = t < ntab ? tabs[t] : nullptr;
     // (measured slower here: column accumulators - 8 independent 8-byte streams per thread need the occupancy more -
     // and the last-arriving-workgroup reduction - 8 values x 1024 partials)
-    const int grid = grid_for(n);
+    const int grid = grid_for((n + 1) / 2);
     k_dot_eq<<<grid, TPB, 0, st>>>(eq, d, ntab, n, partials);
     k_reduce_partials<<<1, TPB, 0, st>>>(partials, grid, ntab, out);
 }
