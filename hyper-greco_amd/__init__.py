@@ -39,7 +39,7 @@ EXPORTS = [
     "hg_last_error", "hg_device_count", "hg_create", "hg_destroy", "hg_params_builtin", "hg_setup", "hg_pk_free",
     "hg_pk_lasso_layout", "hg_pk_info", "hg_witness_from_json", "hg_witness_synthetic", "hg_witness_from_arrays",
     "hg_witness_get", "hg_witness_free", "hg_prove", "hg_verify", "hg_witness_gen", "hg_values_free", "hg_values_get", "hg_prove_shard_begin", "hg_prove_shard_combine", "hg_prove_shard_finish", "hg_prove_resident", "hg_circuit_eval", "hg_lasso_prove", "hg_lasso_prove_at", "hg_sumcheck", "hg_mle_eval",
-    "hg_ntt", "hg_challenges", "hg_challenges_bn254", "hg_bn254_field_op", "hg_sumcheck_bn254", "hg_mle_eval_bn254", "hg_ntt_bn254", "hg_profile", "hg_profile_select", "hg_profile_reset", "hg_profile_get",
+    "hg_ntt", "hg_challenges", "hg_challenges_bn254", "hg_bn254_field_op", "hg_sumcheck_bn254", "hg_grand_product_bn254", "hg_mle_eval_bn254", "hg_ntt_bn254", "hg_profile", "hg_profile_select", "hg_profile_reset", "hg_profile_get",
 ]
 
 
@@ -97,6 +97,8 @@ def lib():
         L.hg_bn254_field_op.argtypes = [C.c_void_p, C.c_int, C.c_size_t, u64p, u64p, u64p]
         L.hg_sumcheck_bn254.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(u64p), u64p, C.c_size_t, u64p, C.c_size_t,
                                         u64p, u64p, u64p, u64p]
+        L.hg_grand_product_bn254.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(u64p), C.c_size_t, C.POINTER(C.c_uint8), C.c_size_t,
+                                             C.POINTER(C.c_size_t), u64p, u64p]
         L.hg_mle_eval_bn254.argtypes = [C.c_void_p, u64p, C.c_size_t, u64p, u64p]
         L.hg_ntt_bn254.argtypes = [C.c_void_p, u64p, C.c_size_t, C.c_int, C.c_size_t, u64p]
         L.hg_profile.argtypes = [C.c_void_p, C.c_int]
@@ -181,6 +183,20 @@ class Context:
         out = np.zeros_like(pa)
         _check(lib().hg_bn254_field_op(self.h, op, len(a), _ptr(pa), _ptr(pb), _ptr(out)))
         return self._fr_unpack(out)
+
+    def grand_product_bn254(self, tables, chain_skip=0):
+        """prove_grand_product over bn256::Fr: (proof bytes, final claims, point)."""
+        nb, ln = len(tables), len(tables[0])
+        nv = ln.bit_length() - 1
+        packed = [self._fr_pack(t) for t in tables]
+        ptrs = (u64p * nb)(*[_ptr(t) for t in packed])
+        cap = 32 * (nb + sum(4 * n + 2 * nb for n in range(nv)) + 2 * nb + 64)
+        buf = (C.c_uint8 * cap)()
+        ln_out = C.c_size_t(0)
+        claims = np.zeros(nb * 4, dtype=np.uint64)
+        point = np.zeros(max(nv, 1) * 4, dtype=np.uint64)
+        _check(lib().hg_grand_product_bn254(self.h, nb, ln, ptrs, chain_skip, buf, cap, C.byref(ln_out), _ptr(claims), _ptr(point)))
+        return C.string_at(buf, ln_out.value), self._fr_unpack(claims), self._fr_unpack(point)[:nv]
 
     def mle_eval_bn254(self, table, point):
         nv = (len(table) - 1).bit_length()

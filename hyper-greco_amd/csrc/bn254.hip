@@ -278,6 +278,159 @@ void field_op_bn254(hg_ctx* ctx, int op, size_t n, const u64* a, const u64* b, u
     hipc(e2, "hg_bn254_field_op");
 }
 
+// ---- prove_grand_product over Fr [REF lasso/src/memory_checking/prover.rs:183-266, 268-294, 297-355] ----------------------
+__global__ void k_bn_prod_level(const Fr* __restrict__ in, size_t in_len, Fr* __restrict__ out, int nb) {
+    const size_t h = in_len >> 1, total = h * nb;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const size_t b = i / h, j = i % h;
+    out[b * h + j] = fr_mul(in[b * in_len + j], in[b * in_len + j + h]);  // Layer::bottom / Layer::up: v_l * v_r on the MSB split
+}
+static void write_be32(std::vector<uint8_t>& out, const Fr& canonical) {  // transcript.rs:183-189: repr, byte-reversed
+    for (int w = 3; w >= 0; w--)
+        for (int b = 7; b >= 0; b--) out.push_back((uint8_t)(canonical.l[w] >> (8 * b)));
+}
+// interpolation of one round from g(0), g(2)[, g(3)] and the running claim (conventions C1: d+1 coefficients,
+// eval(1) = claim - eval(0)); returns the next claim; all values in Montgomery form
+static Fr replay_round(const Fr* sums_canonical, int d, Fr claim, Fr r, Fr* c /* d+1 */) {
+    static const Fr inv2 = fr_inv(fr_small(2)), inv3 = fr_inv(fr_small(3)), inv6 = fr_inv(fr_small(6)), three = fr_small(3);
+    Fr ev[4];
+    ev[0] = fr_to_mont(sums_canonical[0]);
+    ev[1] = fr_sub(claim, ev[0]);
+    ev[2] = fr_to_mont(sums_canonical[1]);
+    if (d == 3) ev[3] = fr_to_mont(sums_canonical[2]);
+    const Fr d1 = fr_sub(ev[1], ev[0]);
+    const Fr d2 = fr_add(fr_sub(ev[2], fr_dbl(ev[1])), ev[0]);
+    if (d == 2) {
+        c[0] = ev[0];
+        c[2] = fr_mul(d2, inv2);
+        c[1] = fr_sub(d1, c[2]);
+    } else {
+        const Fr d3 = fr_sub(fr_sub(ev[3], ev[0]), fr_mul(fr_sub(ev[2], ev[1]), three));
+        c[0] = ev[0];
+        c[3] = fr_mul(d3, inv6);
+        c[2] = fr_mul(fr_sub(d2, d3), inv2);
+        c[1] = fr_add(fr_sub(d1, fr_mul(d2, inv2)), fr_mul(d3, inv3));
+    }
+    Fr h = c[d];
+    for (int i = d - 1; i >= 0; i--) h = fr_add(fr_mul(h, r), c[i]);
+    return h;
+}
+
+// nb tables of `len` = 2^nv elements each (host, canonical). The transcript is entered after `chain_skip` challenges.
+// proof: root products, then per layer the sum-check rounds (4 coefficients each) and the 2 nb evaluations, as 32-byte
+// big-endian elements. claims_out: nb final claims, point_out: nv coordinates.
+void grand_product_bn254(hg_ctx* ctx, size_t nb, size_t len, const u64* const* tables, size_t chain_skip, std::vector<uint8_t>& proof,
+                         u64* claims_out, u64* point_out) {
+    if (nb == 0 || len < 2 || (len & (len - 1))) throw Error("hg_grand_product_bn254: need nb >= 1 tables of a power-of-two length >= 2");
+    hipc(hipSetDevice(ctx->device), "hipSetDevice");
+    hipStream_t st = ctx->stream;
+    int nv = 0;
+    while (((size_t)1 << nv) < len) nv++;
+    const size_t ntab = 2 * nb;
+    // challenges in protocol order: mu_0, then per layer n >= 1: gamma, n round challenges, mu
+    size_t need = 1;
+    for (int n = 1; n < nv; n++) need += 2 + n;
+    const std::vector<Fr> chain = challenge_chain_bn254(chain_skip + need);
+    std::vector<void*> to_free;
+    auto dalloc = [&](size_t n_fr) { Fr* p = nullptr; hipc(hipMalloc((void**)&p, std::max<size_t>(n_fr, 1) * sizeof(Fr)), "hipMalloc"); to_free.push_back(p); return p; };
+    struct LayerRec { size_t gamma_at, r_at, mu_at; Fr* d_sums; Fr* d_final; std::vector<Fr> sums, fin; };
+    std::vector<LayerRec> layers(nv);
+    std::vector<Fr> h_top(2 * nb), h_roots(nb);
+    try {
+        std::vector<Fr*> lev(nv, nullptr);
+        lev[0] = dalloc(nb * len);
+        for (size_t b = 0; b < nb; b++) hipc(hipMemcpyAsync(lev[0] + b * len, tables[b], len * sizeof(Fr), hipMemcpyHostToDevice, st), "upload table");
+        k_bn_to_mont<<<(unsigned)((nb * len + 255) / 256), 256, 0, st>>>(lev[0], nb * len);
+        for (int k = 1; k < nv; k++) {
+            lev[k] = dalloc(nb * (len >> k));
+            const size_t total = nb * (len >> k);
+            k_bn_prod_level<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(lev[k - 1], len >> (k - 1), lev[k], (int)nb);
+        }
+        // roots and top evaluations: level nv-1 has rows of length 2
+        Fr* d_roots = dalloc(nb);
+        k_bn_prod_level<<<(unsigned)((nb + 255) / 256), 256, 0, st>>>(lev[nv - 1], 2, d_roots, (int)nb);
+        Fr* d_top = dalloc(2 * nb);
+        hipc(hipMemcpyAsync(d_top, lev[nv - 1], 2 * nb * sizeof(Fr), hipMemcpyDeviceToDevice, st), "copy top");
+        k_bn_from_mont<<<(unsigned)((2 * nb + 255) / 256), 256, 0, st>>>(d_top, 2 * nb);
+        k_bn_from_mont<<<(unsigned)((nb + 255) / 256), 256, 0, st>>>(d_roots, nb);
+        hipc(hipMemcpyAsync(h_top.data(), d_top, 2 * nb * sizeof(Fr), hipMemcpyDeviceToHost, st), "copy");
+        hipc(hipMemcpyAsync(h_roots.data(), d_roots, nb * sizeof(Fr), hipMemcpyDeviceToHost, st), "copy");
+        Fr* d_part = dalloc((size_t)1024 * 3);
+        size_t pos = chain_skip;
+        layers[0].mu_at = pos++;
+        for (int n = 1; n < nv; n++) {
+            LayerRec& L = layers[n];
+            L.gamma_at = pos++; L.r_at = pos; pos += n; L.mu_at = pos++;
+            const size_t h = (size_t)1 << n;  // table length of this layer's sum-check (n variables)
+            // gamma powers
+            std::vector<Fr> pw(nb);
+            const Fr g = fr_to_mont(chain[L.gamma_at]);
+            Fr cur_pw = fr_one_mont();
+            for (size_t b = 0; b < nb; b++) { pw[b] = cur_pw; cur_pw = fr_mul(cur_pw, g); }
+            Fr* d_pw = dalloc(nb);
+            hipc(hipMemcpy(d_pw, pw.data(), nb * sizeof(Fr), hipMemcpyHostToDevice), "upload gamma powers");  // (already Montgomery)
+            Fr* buf0 = dalloc(ntab * (h / 2));
+            Fr* buf1 = dalloc(ntab * std::max<size_t>(h / 4, 1));
+            L.d_sums = dalloc((size_t)n * 3);
+            const Fr* cur = lev[nv - 1 - n];  // rows [v_l | v_r] of length 2h... table t at cur + t * h
+            Fr* nxt = buf0;
+            for (int rd = 0; rd < n; rd++) {
+                const size_t half = h >> (rd + 1);
+                const Fr r = fr_to_mont(chain[L.r_at + rd]);
+                const int grid = (int)std::min<size_t>((half + BN_TPB - 1) / BN_TPB, (size_t)1024);
+                k_bn_round<BN_GRANDPROD><<<grid, BN_TPB, 0, st>>>(cur, nxt, (int)ntab, half, r, d_pw, d_part);
+                k_bn_reduce<<<1, BN_TPB, 0, st>>>(d_part, grid, 3, L.d_sums + rd * 3);
+                cur = nxt;
+                nxt = nxt == buf0 ? buf1 : buf0;
+            }
+            L.d_final = dalloc(ntab);
+            hipc(hipMemcpyAsync(L.d_final, cur, ntab * sizeof(Fr), hipMemcpyDeviceToDevice, st), "copy final");
+            k_bn_from_mont<<<(unsigned)((ntab + 255) / 256), 256, 0, st>>>(L.d_final, ntab);
+            L.sums.resize((size_t)n * 3); L.fin.resize(ntab);
+            hipc(hipMemcpyAsync(L.sums.data(), L.d_sums, (size_t)n * 3 * sizeof(Fr), hipMemcpyDeviceToHost, st), "copy sums");
+            hipc(hipMemcpyAsync(L.fin.data(), L.d_final, ntab * sizeof(Fr), hipMemcpyDeviceToHost, st), "copy evals");
+        }
+        hipc(hipStreamSynchronize(st), "grand_product_bn254: sync");
+        hipc(hipGetLastError(), "grand_product_bn254: launch");
+    } catch (...) {
+        for (void* p : to_free) (void)hipFree(p);
+        throw;
+    }
+    for (void* p : to_free) (void)hipFree(p);
+    // transcript replay
+    proof.clear();
+    std::vector<Fr> claims(nb), x;
+    for (size_t b = 0; b < nb; b++) { write_be32(proof, h_roots[b]); claims[b] = fr_to_mont(h_roots[b]); }
+    for (int n = 0; n < nv; n++) {
+        const LayerRec& L = layers[n];
+        std::vector<Fr> evals(2 * nb);  // Montgomery
+        if (n == 0) {
+            x.clear();
+            for (size_t i = 0; i < 2 * nb; i++) evals[i] = fr_to_mont(h_top[i]);
+        } else {
+            const Fr g = fr_to_mont(chain[L.gamma_at]);
+            Fr claim = fr_zero(), w = fr_one_mont();
+            for (size_t b = 0; b < nb; b++) { claim = fr_add(claim, fr_mul(claims[b], w)); w = fr_mul(w, g); }  // prover.rs:281-286
+            x.clear();
+            for (int rd = 0; rd < n; rd++) {
+                Fr c[4];
+                const Fr r = fr_to_mont(chain[L.r_at + rd]);
+                claim = replay_round(&L.sums[(size_t)rd * 3], 3, claim, r, c);
+                for (int k = 0; k < 4; k++) write_be32(proof, fr_from_mont(c[k]));
+                x.push_back(chain[L.r_at + rd]);
+            }
+            for (size_t i = 0; i < 2 * nb; i++) evals[i] = fr_to_mont(L.fin[i]);
+        }
+        for (size_t i = 0; i < 2 * nb; i++) write_be32(proof, fr_from_mont(evals[i]));  // prover.rs:257
+        const Fr mu = fr_to_mont(chain[L.mu_at]);                                          // prover.rs:259
+        for (size_t b = 0; b < nb; b++) claims[b] = fr_add(evals[2 * b], fr_mul(mu, fr_sub(evals[2 * b + 1], evals[2 * b])));  // :288-294
+        x.push_back(chain[L.mu_at]);
+    }
+    for (size_t b = 0; b < nb; b++) { Fr c = fr_from_mont(claims[b]); memcpy(claims_out + 4 * b, c.l, 32); }
+    for (size_t i = 0; i < x.size(); i++) memcpy(point_out + 4 * i, x[i].l, 32);
+}
+
 // ---- MLE evaluation and NTT over Fr (the other primitives of the path, A13/A14) -------------------------------------
 // t'[j] = t[2j] + r (t[2j+1] - t[2j]): binds the lowest variable (fix_var order of the path)
 __global__ void k_bn_fold(const Fr* __restrict__ in, Fr* __restrict__ out, size_t half, Fr r) {

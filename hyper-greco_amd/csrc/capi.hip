@@ -15,6 +15,8 @@ void field_op_bn254(hg_ctx* ctx, int op, size_t n, const u64* a, const u64* b, u
 void challenges_bn254_raw(size_t n, uint64_t* out4);
 void mle_eval_bn254(hg_ctx* ctx, const u64* table4, size_t nv, const u64* point4, u64* out4);
 void ntt_bn254(hg_ctx* ctx, const u64* in4, int log2n, bool inverse, size_t batch, u64* out4);
+void grand_product_bn254(hg_ctx* ctx, size_t nb, size_t len, const u64* const* tables, size_t chain_skip, std::vector<uint8_t>& proof,
+                         u64* claims_out, u64* point_out);
 } }
 using namespace hg;
 
@@ -490,6 +492,18 @@ int hg_sumcheck_bn254(hg_ctx* ctx, int kind, size_t nv, size_t ntab, const uint6
     HG_CATCH(-1)
 }
 
+int hg_grand_product_bn254(hg_ctx* ctx, size_t nb, size_t len, const uint64_t* const* tables, size_t chain_skip, uint8_t* proof, size_t cap,
+                           size_t* proof_len, uint64_t* claims4, uint64_t* point4) {
+    HG_TRY
+    if (!ctx) throw hg::Error("hg_grand_product_bn254: no context (a HIP device is required)");
+    std::vector<uint8_t> bytes;
+    hg::bn::grand_product_bn254(ctx, nb, len, tables, chain_skip, bytes, claims4, point4);
+    *proof_len = bytes.size();
+    if (bytes.size() > cap) throw hg::Error("proof buffer too small");
+    memcpy(proof, bytes.data(), bytes.size());
+    return 0;
+    HG_CATCH(-1)
+}
 int hg_mle_eval_bn254(hg_ctx* ctx, const uint64_t* table4, size_t nv, const uint64_t* point4, uint64_t out4[4]) {
     HG_TRY
     if (!ctx) throw hg::Error("hg_mle_eval_bn254: no context (a HIP device is required)");

@@ -169,6 +169,11 @@ int hg_bn254_field_op(hg_ctx* ctx, int op, size_t n, const uint64_t* a4, const u
 int hg_sumcheck_bn254(hg_ctx* ctx, int kind, size_t nv, size_t ntab, const uint64_t* const* tables, const uint64_t* pw4, size_t npw,
                       const uint64_t* claim4, size_t chain_skip, uint64_t* msgs, uint64_t* point, uint64_t* evals, uint64_t* sums);
 
+/* = prove_grand_product over Fr [REF lasso/src/memory_checking/prover.rs:183-266]: nb tables of len = 2^nv elements; product tree on
+ *   the MSB split, root products, per layer a degree-3 sum-check with g = poly(0) * sum_b gamma^b v_l,b v_r,b, 2 nb evaluations and the
+ *   mu fold. proof: 32-byte big-endian canonical elements [REF transcript.rs:183-189]. claims4: nb final claims, point4: nv coordinates. */
+int hg_grand_product_bn254(hg_ctx* ctx, size_t nb, size_t len, const uint64_t* const* tables, size_t chain_skip, uint8_t* proof, size_t cap,
+                           size_t* proof_len, uint64_t* claims4, uint64_t* point4);
 /* = BoxMultilinearPoly::evaluate over Fr [REF memory_checking/mod.rs:80-93]: table of 2^nv elements at a point of nv elements */
 int hg_mle_eval_bn254(hg_ctx* ctx, const uint64_t* table4, size_t nv, const uint64_t* point4, uint64_t out4[4]);
 /* = FftNode evaluate over Fr [REF sk_encryption_circuit.rs:224,249,251]: size-2^log2n NTT with the root of unity

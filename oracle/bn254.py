@@ -111,3 +111,42 @@ def mle_eval(table, point):
     for r in point:
         t = [(t[2 * j] + r * (t[2 * j + 1] - t[2 * j])) % R for j in range(len(t) // 2)]
     return t[0]
+
+
+def grand_product(tables, chal):
+    """prove_grand_product [REF lasso/src/memory_checking/prover.rs:183-266]: tables = nb lists of 2^nv values; chal = the challenge
+    stream from the point where the protocol is entered (list). Returns (proof elements in wire order, final claims, point)."""
+    nb, ln = len(tables), len(tables[0])
+    nv = ln.bit_length() - 1
+    lev = [[list(t) for t in tables]]
+    for k in range(1, nv):
+        prev = lev[-1]
+        h = len(prev[0]) // 2
+        lev.append([[p[i] * p[i + h] % R for i in range(h)] for p in prev])   # Layer::bottom / Layer::up (MSB split)
+    top = lev[nv - 1]
+    proof = []
+    claims = [t[0] * t[1] % R for t in top]
+    proof += claims                                                                # root products (:197-221)
+    it = iter(chal)
+    x = []
+    for n in range(nv):
+        rows = lev[nv - 1 - n]
+        h = 1 << n
+        if n == 0:
+            x = []
+            evals = [v for t in rows for v in (t[0], t[1])]
+        else:
+            gamma = next(it)                                                       # :238
+            pw = [pow(gamma, b, R) for b in range(nb)]
+            claim = sum(c * w for c, w in zip(claims, pw)) % R                     # :281-286
+            tabs = [half for t in rows for half in (t[:h], t[h:])]
+            rs = [next(it) for _ in range(n)]
+            msgs, evals, _ = sumcheck(1, tabs, pw, claim, rs)                      # g = poly(0) * sum gamma^b v_l v_r (:268-279)
+            for m in msgs:
+                proof += m
+            x = list(rs)
+        proof += evals                                                             # :257
+        mu = next(it)                                                              # :259
+        claims = [(evals[2 * b] + mu * (evals[2 * b + 1] - evals[2 * b])) % R for b in range(nb)]   # :288-294
+        x.append(mu)
+    return proof, claims, x

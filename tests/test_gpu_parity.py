@@ -355,3 +355,21 @@ def test_bn254_ntt_matches_the_definition_and_inverts(ctx, log2n):
     assert ctx.ntt_bn254(fwd, inverse=True) == rows
     big = [[rng.randrange(bn.R) for _ in range(1 << 14)]]   # size-independent property at a larger size: round trip
     assert ctx.ntt_bn254(ctx.ntt_bn254(big), inverse=True) == big
+
+
+@pytest.mark.parametrize("nb,nv", [(1, 1), (2, 3), (6, 6), (50, 4), (4, 9)])
+def test_bn254_grand_product_bit_exact(ctx, nb, nv):
+    """prove_grand_product over Fr (product tree, root products, layered degree-3 sum-checks with the poly(0) quirk, mu folds)
+    against the Python oracle: proof bytes (32-byte big-endian elements), final claims and point."""
+    bn = orclib.bn254()
+    rng = random.Random(100 * nb + nv)
+    tabs = [[rng.randrange(bn.R) for _ in range(1 << nv)] for _ in range(nb)]
+    skip = rng.randrange(20)
+    need = 1 + sum(2 + n for n in range(1, nv))
+    chal = bn.challenges(skip + need, orclib.keccak256)[skip:]
+    proof, claims, point = ctx.grand_product_bn254(tabs, skip)
+    eproof, eclaims, epoint = bn.grand_product(tabs, chal)
+    assert proof == b"".join(int(v).to_bytes(32, "big") for v in eproof)
+    assert claims == eclaims and point == epoint
+    # the final claims are the tables' multilinear extensions at the final point (the relation the verifier relies on)
+    assert claims == [bn.mle_eval(t, point) for t in tabs]

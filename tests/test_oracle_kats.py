@@ -276,3 +276,17 @@ def test_bn254_root_of_unity_and_ntt_oracle():
     f = bn.ntt([1, 1, 0, 0, 0, 0, 0, 0])
     assert bn.ntt([x * x % bn.R for x in f], inverse=True) == [1, 2, 1, 0, 0, 0, 0, 0]
     assert bn.mle_eval([5, 7], [3]) == (5 + 3 * 2) % bn.R
+
+
+def test_bn254_grand_product_oracle_claims_are_mle_evaluations():
+    """Each layer reduces the product claim one level down; the final claims must equal the MLEs of the input tables at
+    the final point, and the first proof elements are the plain products of the tables."""
+    import random
+    from functools import reduce
+    bn = orclib.bn254()
+    rng = random.Random(5)
+    tabs = [[rng.randrange(bn.R) for _ in range(16)] for _ in range(3)]
+    chal = bn.challenges(40, orclib.keccak256)
+    proof, claims, point = bn.grand_product(tabs, chal)
+    assert proof[:3] == [reduce(lambda a, b: a * b % bn.R, t, 1) for t in tabs]
+    assert len(point) == 4 and claims == [bn.mle_eval(t, point) for t in tabs]
