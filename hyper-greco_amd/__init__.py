@@ -39,7 +39,7 @@ EXPORTS = [
     "hg_last_error", "hg_device_count", "hg_create", "hg_destroy", "hg_params_builtin", "hg_setup", "hg_pk_free",
     "hg_pk_lasso_layout", "hg_pk_info", "hg_witness_from_json", "hg_witness_synthetic", "hg_witness_from_arrays",
     "hg_witness_get", "hg_witness_free", "hg_prove", "hg_verify", "hg_witness_gen", "hg_values_free", "hg_values_get", "hg_prove_shard_begin", "hg_prove_shard_combine", "hg_prove_shard_finish", "hg_prove_resident", "hg_circuit_eval", "hg_lasso_prove", "hg_lasso_prove_at", "hg_sumcheck", "hg_mle_eval",
-    "hg_ntt", "hg_challenges", "hg_challenges_bn254", "hg_bn254_field_op", "hg_sumcheck_bn254", "hg_grand_product_bn254", "hg_mle_eval_bn254", "hg_ntt_bn254", "hg_profile", "hg_profile_select", "hg_profile_reset", "hg_profile_get",
+    "hg_ntt", "hg_challenges", "hg_challenges_bn254", "hg_bn254_field_op", "hg_sumcheck_bn254", "hg_grand_product_bn254", "hg_lasso_prove_bn254", "hg_mle_eval_bn254", "hg_ntt_bn254", "hg_profile", "hg_profile_select", "hg_profile_reset", "hg_profile_get",
 ]
 
 
@@ -99,6 +99,7 @@ def lib():
                                         u64p, u64p, u64p, u64p]
         L.hg_grand_product_bn254.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(u64p), C.c_size_t, C.POINTER(C.c_uint8), C.c_size_t,
                                              C.POINTER(C.c_size_t), u64p, u64p]
+        L.hg_lasso_prove_bn254.argtypes = [C.c_void_p, C.c_void_p, u64p, C.c_size_t, C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_size_t), u64p]
         L.hg_mle_eval_bn254.argtypes = [C.c_void_p, u64p, C.c_size_t, u64p, u64p]
         L.hg_ntt_bn254.argtypes = [C.c_void_p, u64p, C.c_size_t, C.c_int, C.c_size_t, u64p]
         L.hg_profile.argtypes = [C.c_void_p, C.c_int]
@@ -197,6 +198,18 @@ class Context:
         point = np.zeros(max(nv, 1) * 4, dtype=np.uint64)
         _check(lib().hg_grand_product_bn254(self.h, nb, ln, ptrs, chain_skip, buf, cap, C.byref(ln_out), _ptr(claims), _ptr(point)))
         return C.string_at(buf, ln_out.value), self._fr_unpack(claims), self._fr_unpack(point)[:nv]
+
+    def lasso_prove_bn254(self, pk, lasso_in, chain_skip=0, cap=1 << 22):
+        """LassoNode::prove_claim_reduction over bn256::Fr on a table of small integers: (proof bytes, r, claimed sum)."""
+        n = len(lasso_in)
+        nu = n.bit_length() - 1
+        packed = self._fr_pack(lasso_in)
+        buf = (C.c_uint8 * cap)()
+        ln = C.c_size_t(0)
+        claim = np.zeros((nu + 1) * 4, dtype=np.uint64)
+        _check(lib().hg_lasso_prove_bn254(self.h, pk.h, _ptr(packed), chain_skip, buf, cap, C.byref(ln), _ptr(claim)))
+        vals = self._fr_unpack(claim)
+        return C.string_at(buf, ln.value), vals[:nu], vals[nu]
 
     def mle_eval_bn254(self, table, point):
         nv = (len(table) - 1).bit_length()

@@ -13,6 +13,7 @@
 #include "bn254.cuh"
 #include "host.hpp"
 #include "prover.hpp"
+#include "kernels.hpp"
 
 namespace hg {
 namespace bn {
@@ -320,8 +321,10 @@ static Fr replay_round(const Fr* sums_canonical, int d, Fr claim, Fr r, Fr* c /*
 // nb tables of `len` = 2^nv elements each (host, canonical). The transcript is entered after `chain_skip` challenges.
 // proof: root products, then per layer the sum-check rounds (4 coefficients each) and the 2 nb evaluations, as 32-byte
 // big-endian elements. claims_out: nb final claims, point_out: nv coordinates.
-void grand_product_bn254(hg_ctx* ctx, size_t nb, size_t len, const u64* const* tables, size_t chain_skip, std::vector<uint8_t>& proof,
-                         u64* claims_out, u64* point_out) {
+static size_t gp_challenges(int nv) { size_t need = 1; for (int n = 1; n < nv; n++) need += 2 + n; return need; }
+// core: level 0 already on the device in Montgomery form (nb rows of len), or uploaded from `tables` when d_lev0 is null
+static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* const* tables, const Fr* d_lev0, size_t chain_skip,
+                               std::vector<uint8_t>& proof, std::vector<Fr>& claims_canon, std::vector<Fr>& point_canon) {
     if (nb == 0 || len < 2 || (len & (len - 1))) throw Error("hg_grand_product_bn254: need nb >= 1 tables of a power-of-two length >= 2");
     hipc(hipSetDevice(ctx->device), "hipSetDevice");
     hipStream_t st = ctx->stream;
@@ -338,14 +341,19 @@ void grand_product_bn254(hg_ctx* ctx, size_t nb, size_t len, const u64* const* t
     std::vector<LayerRec> layers(nv);
     std::vector<Fr> h_top(2 * nb), h_roots(nb);
     try {
-        std::vector<Fr*> lev(nv, nullptr);
-        lev[0] = dalloc(nb * len);
-        for (size_t b = 0; b < nb; b++) hipc(hipMemcpyAsync(lev[0] + b * len, tables[b], len * sizeof(Fr), hipMemcpyHostToDevice, st), "upload table");
-        k_bn_to_mont<<<(unsigned)((nb * len + 255) / 256), 256, 0, st>>>(lev[0], nb * len);
+        std::vector<const Fr*> lev(nv, nullptr);
+        if (d_lev0) lev[0] = d_lev0;
+        else {
+            Fr* l0 = dalloc(nb * len);
+            for (size_t b = 0; b < nb; b++) hipc(hipMemcpyAsync(l0 + b * len, tables[b], len * sizeof(Fr), hipMemcpyHostToDevice, st), "upload table");
+            k_bn_to_mont<<<(unsigned)((nb * len + 255) / 256), 256, 0, st>>>(l0, nb * len);
+            lev[0] = l0;
+        }
         for (int k = 1; k < nv; k++) {
-            lev[k] = dalloc(nb * (len >> k));
+            Fr* lk = dalloc(nb * (len >> k));
             const size_t total = nb * (len >> k);
-            k_bn_prod_level<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(lev[k - 1], len >> (k - 1), lev[k], (int)nb);
+            k_bn_prod_level<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(lev[k - 1], len >> (k - 1), lk, (int)nb);
+            lev[k] = lk;
         }
         // roots and top evaluations: level nv-1 has rows of length 2
         Fr* d_roots = dalloc(nb);
@@ -427,8 +435,227 @@ void grand_product_bn254(hg_ctx* ctx, size_t nb, size_t len, const u64* const* t
         for (size_t b = 0; b < nb; b++) claims[b] = fr_add(evals[2 * b], fr_mul(mu, fr_sub(evals[2 * b + 1], evals[2 * b])));  // :288-294
         x.push_back(chain[L.mu_at]);
     }
-    for (size_t b = 0; b < nb; b++) { Fr c = fr_from_mont(claims[b]); memcpy(claims_out + 4 * b, c.l, 32); }
+    claims_canon.resize(nb);
+    for (size_t b = 0; b < nb; b++) claims_canon[b] = fr_from_mont(claims[b]);
+    point_canon = x;
+}
+void grand_product_bn254(hg_ctx* ctx, size_t nb, size_t len, const u64* const* tables, size_t chain_skip, std::vector<uint8_t>& proof,
+                         u64* claims_out, u64* point_out) {
+    std::vector<Fr> claims, x;
+    grand_product_core(ctx, nb, len, tables, nullptr, chain_skip, proof, claims, x);
+    for (size_t b = 0; b < nb; b++) memcpy(claims_out + 4 * b, claims[b].l, 32);
     for (size_t i = 0; i < x.size(); i++) memcpy(point_out + 4 * i, x[i].l, 32);
+}
+
+// ---- LassoNode::prove_claim_reduction over Fr [REF lasso/src/lasso.rs:57-114] -------------------------------------------
+// The limb split and the counters are integer work on the low limb (fe_to_bits_le truncates to at most 63 bits,
+// lasso.rs:381-414, 654-669): the Goldilocks kernels (lasso_split, lasso_counters) are reused as they are; everything
+// that involves challenges runs over Fr.
+__global__ void k_bn_from_u64(const u64* __restrict__ in, Fr* __restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = fr_to_mont(fr_make(in[i], 0, 0, 0));
+}
+// eq table by doubling: after step i the first 2^(i+1) entries hold eq(r_0..r_i, .)
+__global__ void k_bn_eq_step(Fr* __restrict__ eq, size_t cur, Fr r) {
+    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= cur) return;
+    const Fr hi = fr_mul(eq[j], r);
+    eq[j + cur] = hi;
+    eq[j] = fr_sub(eq[j], hi);
+}
+struct MPow { Fr v[5]; };
+// sum_k eq[k] * sum_i M^i E_{mems(lookup(k))[i]}[k] (lasso.rs:422-454, range.rs:184-195) -> per-workgroup partials
+__global__ __launch_bounds__(BN_TPB) void k_bn_lasso_claim(dev::LassoDev L, const Fr* __restrict__ eq, const u64* __restrict__ e_polys, MPow mp,
+                                                           Fr* __restrict__ partials) {
+    __shared__ Fr sm[BN_TPB];
+    const size_t N = (size_t)1 << L.nu;
+    Fr acc = fr_zero();
+    for (size_t k = (size_t)blockIdx.x * BN_TPB + threadIdx.x; k < L.rows; k += (size_t)gridDim.x * BN_TPB) {
+        const int l = L.seg_lookup[k >> L.seg_shift];
+        Fr comb = fr_zero();
+        for (int i = 0; i < L.lookup_nmems[l]; i++)
+            comb = fr_add(comb, fr_mul(mp.v[i], fr_to_mont(fr_make(e_polys[(size_t)L.lookup_mems[l][i] * N + k], 0, 0, 0))));
+        acc = fr_add(acc, fr_mul(eq[k], comb));
+    }
+    Fr s = block_sum_fr(acc, sm);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+// sum_k eq[k] * t[k] for a table of small integers
+__global__ __launch_bounds__(BN_TPB) void k_bn_dot_u64(const Fr* __restrict__ eq, const u64* __restrict__ t, size_t n, Fr* __restrict__ partials) {
+    __shared__ Fr sm[BN_TPB];
+    Fr acc = fr_zero();
+    for (size_t k = (size_t)blockIdx.x * BN_TPB + threadIdx.x; k < n; k += (size_t)gridDim.x * BN_TPB)
+        acc = fr_add(acc, fr_mul(eq[k], fr_to_mont(fr_make(t[k], 0, 0, 0))));
+    Fr s = block_sum_fr(acc, sm);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+// h(a,v,t) = a + v gamma + t gamma^2 - tau (prover.rs:44) for the reads (t) and writes (t + 1) of one memory
+__global__ void k_bn_hash_rw(size_t n, const u64* __restrict__ dim, const u64* __restrict__ ep, const u64* __restrict__ ts, Fr gamma, Fr gamma2,
+                             Fr tau, Fr* __restrict__ rd, Fr* __restrict__ wr) {
+    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const Fr a = fr_to_mont(fr_make(dim[j], 0, 0, 0)), v = fr_to_mont(fr_make(ep[j], 0, 0, 0)), t = fr_to_mont(fr_make(ts[j], 0, 0, 0));
+    const Fr h = fr_sub(fr_add(fr_add(a, fr_mul(v, gamma)), fr_mul(t, gamma2)), tau);
+    rd[j] = h;
+    wr[j] = fr_add(h, gamma2);
+}
+__global__ void k_bn_hash_if(u32 cutoff, const u64* __restrict__ fc, Fr gamma, Fr gamma2, Fr tau, Fr* __restrict__ init, Fr* __restrict__ fin) {
+    u32 a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= 65536) return;
+    const Fr av = fr_to_mont(fr_make(a, 0, 0, 0));
+    const Fr tv = a < cutoff ? av : fr_zero();
+    const Fr h0 = fr_sub(fr_add(av, fr_mul(tv, gamma)), tau);
+    init[a] = h0;
+    fin[a] = fr_add(h0, fr_mul(fr_to_mont(fr_make(fc[a], 0, 0, 0)), gamma2));
+}
+
+void lasso_prove_bn254(hg_ctx* ctx, const hg_pk* pk, const u64* in4, size_t chain_skip, std::vector<uint8_t>& proof, u64* claim_out) {
+    if (!pk->ctx) throw Error("hg_lasso_prove_bn254: host-only prover key");
+    const LassoPlan& lp = pk->lasso;
+    const dev::LassoDev& L = pk->lasso_dev;
+    const int nu = lp.nu, A = lp.alpha;
+    const size_t N = (size_t)1 << nu, M = 65536;
+    hipc(hipSetDevice(ctx->device), "hipSetDevice");
+    hipStream_t st = ctx->stream;
+    // the node input must be small non-negative integers (range-shifted values): only the low limb takes part in the split
+    std::vector<u64> low(N);
+    for (size_t j = 0; j < N; j++) {
+        if (in4[4 * j + 1] | in4[4 * j + 2] | in4[4 * j + 3]) throw Error("hg_lasso_prove_bn254: input " + std::to_string(j) + " is not below 2^64 (not a range-shifted value)");
+        low[j] = in4[4 * j];
+    }
+    const size_t r_at = chain_skip, col_at = r_at + nu, gamma_at = col_at + nu, tau_at = gamma_at + 1, gp1_at = tau_at + 1,
+                 gp2_at = gp1_at + gp_challenges(nu), total = gp2_at + gp_challenges(16);
+    const std::vector<Fr> chain = challenge_chain_bn254(total);
+    std::vector<void*> to_free;
+    auto dalloc_b = [&](size_t bytes) { void* p = nullptr; hipc(hipMalloc(&p, std::max<size_t>(bytes, 16)), "hipMalloc"); to_free.push_back(p); return p; };
+    auto dalloc = [&](size_t n_fr) { return (Fr*)dalloc_b(n_fr * sizeof(Fr)); };
+    auto grid1 = [](size_t n) { return (unsigned)((n + 255) / 256); };
+    std::vector<uint8_t> gp1_bytes, gp2_bytes;
+    std::vector<Fr> x, y, tmp_claims, h_col((size_t)nu * 2), opens;
+    Fr h_claimed;
+    try {
+        // polynomialize (lasso.rs:157-250): integer kernels of the Goldilocks path
+        u64* d_in = (u64*)dalloc_b(N * 8);
+        hipc(hipMemcpyAsync(d_in, low.data(), N * 8, hipMemcpyHostToDevice, st), "upload input");
+        u64* dims = (u64*)dalloc_b(4 * N * 8);
+        u64* ep = (u64*)dalloc_b((size_t)A * N * 8);
+        dev::lasso_split(st, L, d_in, dims, ep);
+        std::map<int, u64*> read_ts, final_cts;
+        {
+            const size_t tb = dev::lasso_counter_temp_bytes(N);
+            void* temp = dalloc_b(tb);
+            u32* keys = (u32*)dalloc_b(N * 4); u32* keys2 = (u32*)dalloc_b(N * 4);
+            u32* rows = (u32*)dalloc_b(N * 4); u32* rows2 = (u32*)dalloc_b(N * 4);
+            u32* starts = (u32*)dalloc_b(65537 * 4);
+            for (auto& chk : lp.chunks) {
+                const int c = chk.first;
+                read_ts[c] = (u64*)dalloc_b(N * 8);
+                final_cts[c] = (u64*)dalloc_b(M * 8);
+                dev::lasso_counters(st, L, c, dims, read_ts[c], final_cts[c], temp, tb, keys, keys2, rows, rows2, starts);
+            }
+        }
+        Fr* d_part = dalloc(1024 * 3);
+        Fr* d_out = dalloc(64);
+        auto build_eq = [&](Fr* eq, const Fr* pt_canon, int n) {
+            const Fr one = fr_one_mont();
+            hipc(hipMemcpyAsync(eq, &one, sizeof(Fr), hipMemcpyHostToDevice, st), "eq seed");
+            hipc(hipStreamSynchronize(st), "sync");  // `one` is a stack temporary
+            for (int i = 0; i < n; i++) k_bn_eq_step<<<grid1((size_t)1 << i), 256, 0, st>>>(eq, (size_t)1 << i, fr_to_mont(pt_canon[i]));
+        };
+        // r, claimed sum (lasso.rs:85, 264-269)
+        Fr* eq = dalloc(N);
+        build_eq(eq, &chain[r_at], nu);
+        MPow mp;
+        {
+            const Fr m = fr_small(M);
+            mp.v[0] = fr_one_mont();
+            for (int i = 1; i < 5; i++) mp.v[i] = fr_mul(mp.v[i - 1], m);
+        }
+        {
+            const int grid = (int)std::min<size_t>((L.rows + BN_TPB - 1) / BN_TPB, 1024);
+            k_bn_lasso_claim<<<grid, BN_TPB, 0, st>>>(L, eq, ep, mp, d_part);
+            k_bn_reduce<<<1, BN_TPB, 0, st>>>(d_part, grid, 1, d_out);
+            hipc(hipMemcpyAsync(&h_claimed, d_out, sizeof(Fr), hipMemcpyDeviceToHost, st), "copy claimed sum");
+        }
+        // collation sum-check (lasso.rs:271-279): g = poly(0) * sum_i M^i poly(i) over the E tables
+        {
+            Fr* tabs = dalloc((size_t)A * N);
+            k_bn_from_u64<<<grid1((size_t)A * N), 256, 0, st>>>(ep, tabs, (size_t)A * N);
+            std::vector<Fr> pw(A);
+            const Fr m = fr_small(M);
+            Fr c = fr_one_mont();
+            for (int i = 0; i < A; i++) { pw[i] = c; c = fr_mul(c, m); }
+            Fr* d_pw = dalloc(A);
+            hipc(hipMemcpy(d_pw, pw.data(), A * sizeof(Fr), hipMemcpyHostToDevice), "upload M powers");
+            Fr* buf0 = dalloc((size_t)A * N / 2);
+            Fr* buf1 = dalloc((size_t)A * std::max<size_t>(N / 4, 1));
+            Fr* d_sums = dalloc((size_t)nu * 2);
+            const Fr* cur = tabs;
+            Fr* nxt = buf0;
+            for (int rd = 0; rd < nu; rd++) {
+                const size_t half = N >> (rd + 1);
+                const int grid = (int)std::min<size_t>((half + BN_TPB - 1) / BN_TPB, (size_t)1024);
+                k_bn_round<BN_COLLATION><<<grid, BN_TPB, 0, st>>>(cur, nxt, A, half, fr_to_mont(chain[col_at + rd]), d_pw, d_part);
+                k_bn_reduce<<<1, BN_TPB, 0, st>>>(d_part, grid, 2, d_sums + rd * 2);
+                cur = nxt;
+                nxt = nxt == buf0 ? buf1 : buf0;
+            }
+            hipc(hipMemcpyAsync(h_col.data(), d_sums, (size_t)nu * 2 * sizeof(Fr), hipMemcpyDeviceToHost, st), "copy collation sums");
+        }
+        // MemoryCheckingProver::new (prover.rs:35-89): gamma, tau are the challenges themselves (E = F)
+        const Fr gamma = fr_to_mont(chain[gamma_at]), tau = fr_to_mont(chain[tau_at]), gamma2 = fr_mul(gamma, gamma);
+        const int G = (int)lp.gkr_order.size();
+        Fr* H1 = dalloc((size_t)2 * G * N);
+        Fr* H2 = dalloc((size_t)2 * G * M);
+        for (int i = 0; i < G; i++) {
+            const int m = lp.gkr_order[i], c = lp.gkr_chunk[i];
+            k_bn_hash_rw<<<grid1(N), 256, 0, st>>>(N, dims + (size_t)c * N, ep + (size_t)m * N, read_ts[c], gamma, gamma2, tau, H1 + (size_t)i * N,
+                                                  H1 + (size_t)(G + i) * N);
+            k_bn_hash_if<<<65536 / 256, 256, 0, st>>>((u32)lp.mems[m].cutoff, final_cts[c], gamma, gamma2, tau, H2 + (size_t)i * M, H2 + (size_t)(G + i) * M);
+        }
+        hipc(hipStreamSynchronize(st), "lasso_prove_bn254: sync");
+        grand_product_core(ctx, 2 * G, N, nullptr, H1, gp1_at, gp1_bytes, tmp_claims, x);  // reads then writes (prover.rs:161-165)
+        grand_product_core(ctx, 2 * G, M, nullptr, H2, gp2_at, gp2_bytes, tmp_claims, y);  // inits then finals (prover.rs:167-171)
+        // openings (prover.rs:173-178, mod.rs:80-93)
+        Fr* eqy = dalloc(M);
+        build_eq(eq, x.data(), nu);
+        build_eq(eqy, y.data(), 16);
+        auto dot = [&](const Fr* e, const u64* t, size_t n) {
+            const int grid = (int)std::min<size_t>((n + BN_TPB - 1) / BN_TPB, 1024);
+            k_bn_dot_u64<<<grid, BN_TPB, 0, st>>>(e, t, n, d_part);
+            k_bn_reduce<<<1, BN_TPB, 0, st>>>(d_part, grid, 1, d_out);
+            Fr v;
+            hipc(hipMemcpyAsync(&v, d_out, sizeof(Fr), hipMemcpyDeviceToHost, st), "copy opening");
+            hipc(hipStreamSynchronize(st), "sync");
+            opens.push_back(v);
+        };
+        for (auto& chk : lp.chunks) {
+            const int c = chk.first;
+            dot(eq, dims + (size_t)c * N, N);
+            dot(eq, read_ts[c], N);
+            dot(eqy, final_cts[c], M);
+            for (int m : chk.second) dot(eq, ep + (size_t)m * N, N);
+        }
+        hipc(hipGetLastError(), "lasso_prove_bn254: launch");
+    } catch (...) {
+        for (void* p : to_free) (void)hipFree(p);
+        throw;
+    }
+    for (void* p : to_free) (void)hipFree(p);
+    // transcript (lasso.rs:57-114)
+    proof.clear();
+    write_be32(proof, h_claimed);                                        // :269
+    Fr claim = fr_to_mont(h_claimed);
+    for (int rd = 0; rd < nu; rd++) {                                   // collation rounds; the result is dropped (:97)
+        Fr c[4];
+        claim = replay_round(&h_col[(size_t)rd * 2], 2, claim, fr_to_mont(chain[col_at + rd]), c);
+        for (int k = 0; k < 3; k++) write_be32(proof, fr_from_mont(c[k]));
+    }
+    proof.insert(proof.end(), gp1_bytes.begin(), gp1_bytes.end());
+    proof.insert(proof.end(), gp2_bytes.begin(), gp2_bytes.end());
+    for (const Fr& v : opens) write_be32(proof, v);
+    for (int i = 0; i < nu; i++) memcpy(claim_out + 4 * i, chain[r_at + i].l, 32);
+    memcpy(claim_out + 4 * nu, h_claimed.l, 32);
 }
 
 // ---- MLE evaluation and NTT over Fr (the other primitives of the path, A13/A14) -------------------------------------

@@ -17,6 +17,7 @@ void mle_eval_bn254(hg_ctx* ctx, const u64* table4, size_t nv, const u64* point4
 void ntt_bn254(hg_ctx* ctx, const u64* in4, int log2n, bool inverse, size_t batch, u64* out4);
 void grand_product_bn254(hg_ctx* ctx, size_t nb, size_t len, const u64* const* tables, size_t chain_skip, std::vector<uint8_t>& proof,
                          u64* claims_out, u64* point_out);
+void lasso_prove_bn254(hg_ctx* ctx, const hg_pk* pk, const u64* in4, size_t chain_skip, std::vector<uint8_t>& proof, u64* claim_out);
 } }
 using namespace hg;
 
@@ -499,6 +500,18 @@ int hg_grand_product_bn254(hg_ctx* ctx, size_t nb, size_t len, const uint64_t* c
     std::vector<uint8_t> bytes;
     hg::bn::grand_product_bn254(ctx, nb, len, tables, chain_skip, bytes, claims4, point4);
     *proof_len = bytes.size();
+    if (bytes.size() > cap) throw hg::Error("proof buffer too small");
+    memcpy(proof, bytes.data(), bytes.size());
+    return 0;
+    HG_CATCH(-1)
+}
+int hg_lasso_prove_bn254(hg_ctx* ctx, const hg_pk* pk, const uint64_t* lasso_in4, size_t chain_skip, uint8_t* proof, size_t cap, size_t* len,
+                         uint64_t* claim_out4) {
+    HG_TRY
+    if (!ctx || !pk) throw hg::Error("hg_lasso_prove_bn254: null argument (a HIP device is required)");
+    std::vector<uint8_t> bytes;
+    hg::bn::lasso_prove_bn254(ctx, pk, lasso_in4, chain_skip, bytes, claim_out4);
+    *len = bytes.size();
     if (bytes.size() > cap) throw hg::Error("proof buffer too small");
     memcpy(proof, bytes.data(), bytes.size());
     return 0;

@@ -174,6 +174,12 @@ int hg_sumcheck_bn254(hg_ctx* ctx, int kind, size_t nv, size_t ntab, const uint6
  *   mu fold. proof: 32-byte big-endian canonical elements [REF transcript.rs:183-189]. claims4: nb final claims, point4: nv coordinates. */
 int hg_grand_product_bn254(hg_ctx* ctx, size_t nb, size_t len, const uint64_t* const* tables, size_t chain_skip, uint8_t* proof, size_t cap,
                            size_t* proof_len, uint64_t* claims4, uint64_t* point4);
+/* = <LassoNode as Node>::prove_claim_reduction over Fr [REF lasso/src/lasso.rs:57-114]: the same node as hg_lasso_prove_at, for the
+ *   bn254 test family. lasso_in4: 2^nu elements (4 limbs each; range-shifted values, i.e. below 2^64). The limb split and the
+ *   counters are integer kernels shared with the Goldilocks path; claimed sum, collation sum-check, multiset hashes, both grand
+ *   products and the openings run over Fr. proof: 32-byte big-endian elements. claim_out4: nu coordinates of r, then the claimed sum. */
+int hg_lasso_prove_bn254(hg_ctx* ctx, const hg_pk* pk, const uint64_t* lasso_in4, size_t chain_skip, uint8_t* proof, size_t cap, size_t* len,
+                         uint64_t* claim_out4);
 /* = BoxMultilinearPoly::evaluate over Fr [REF memory_checking/mod.rs:80-93]: table of 2^nv elements at a point of nv elements */
 int hg_mle_eval_bn254(hg_ctx* ctx, const uint64_t* table4, size_t nv, const uint64_t* point4, uint64_t out4[4]);
 /* = FftNode evaluate over Fr [REF sk_encryption_circuit.rs:224,249,251]: size-2^log2n NTT with the root of unity

@@ -150,3 +150,64 @@ def grand_product(tables, chal):
         claims = [(evals[2 * b] + mu * (evals[2 * b + 1] - evals[2 * b])) % R for b in range(nb)]   # :288-294
         x.append(mu)
     return proof, claims, x
+
+
+def eq_table(r):
+    """eq(r, k) for k < 2^len(r), little-endian variable order."""
+    t = [1]
+    for ri in r:
+        hi = [v * ri % R for v in t]
+        t = [(v - h) % R for v, h in zip(t, hi)] + hi
+    return t
+
+
+def lasso_prove(P, chal, sections=None):
+    """LassoNode::prove_claim_reduction over Fr [REF lasso/src/lasso.rs:57-114, 254-288, 303-336; memory_checking/prover.rs:35-89,
+    158-181; memory_checking/mod.rs:80-93] from the node's integer tables P (tests/orclib.py: lasso_polys - limb indices,
+    counters and subtable values are field-independent integers): dict with nu, A, rows, dims[4][N], read_cts[A][N],
+    final_cts[A][65536], e_polys[A][N], row_lookup[N], mem_dim[A], mem_cutoff[A], lookup_mems[l].
+    chal: challenge stream from the point where the node is entered. Returns (proof elements in wire order, r, claimed_sum)."""
+    nu, A, rows, N, M = P["nu"], P["A"], P["rows"], 1 << P["nu"], 65536
+    it = iter(chal)
+    r = [next(it) for _ in range(nu)]                                              # lasso.rs:85
+    eq = eq_table(r)
+    mp = [pow(M, i, R) for i in range(5)]
+    claimed = 0
+    for k in range(rows):                                                          # lasso.rs:422-454, range.rs:184-195
+        mems = P["lookup_mems"][P["row_lookup"][k]]
+        comb = sum(P["e_polys"][m][k] * mp[i] for i, m in enumerate(mems))
+        claimed += eq[k] * comb
+    claimed %= R
+    proof = [claimed]                                                              # lasso.rs:269
+    pw = [pow(M, i, R) for i in range(A)]                                          # distribute_powers(.., M) range.rs:197-204
+    msgs, _, _ = sumcheck(0, P["e_polys"], pw, claimed, [next(it) for _ in range(nu)])   # lasso.rs:278-279 (result dropped :97)
+    for m in msgs:
+        proof += m
+    gamma, tau = next(it), next(it)                                                # lasso.rs:99; as_bases()[0] is the element itself
+    g2 = gamma * gamma % R
+    h = lambda a, v, t: (a + v * gamma + t * g2 - tau) % R                         # prover.rs:44
+    order = [(m, c) for c in sorted(set(P["mem_dim"])) for m in range(A) if P["mem_dim"][m] == c]   # lasso.rs:303-336
+    tab = lambda m, a: a if a < P["mem_cutoff"][m] else 0
+    rd, wr, init, fin = [], [], [], []
+    for m, c in order:                                                             # prover.rs:35-89; counters indexed by chunk (quirk)
+        dim, rts, fct, ep = P["dims"][c], P["read_cts"][c], P["final_cts"][c], P["e_polys"][m]
+        init.append([h(a, tab(m, a), 0) for a in range(M)])
+        fin.append([h(a, tab(m, a), fct[a]) for a in range(M)])
+        rd.append([h(dim[j], ep[j], rts[j]) for j in range(N)])
+        wr.append([h(dim[j], ep[j], rts[j] + 1) for j in range(N)])
+    rest = list(it)
+    need1 = 1 + sum(2 + n for n in range(1, nu))
+    p1, c1, x = grand_product(rd + wr, rest[:need1])                               # prover.rs:161-165
+    p2, c2, y = grand_product(init + fin, rest[need1:])                            # prover.rs:167-171
+    if sections is not None:
+        sections.update(gp1=len(proof), gp2=len(proof) + len(p1), openings=len(proof) + len(p1) + len(p2), x=x, y=y,
+                        gp1_claims=c1, gp2_claims=c2, gamma=gamma, tau=tau, order=order)
+    proof += p1 + p2
+    for c in sorted(set(P["mem_dim"])):                                            # prover.rs:173-178, mod.rs:80-93
+        proof += [mle_eval(P["dims"][c], x), mle_eval(P["read_cts"][c], x), mle_eval(P["final_cts"][c], y)]
+        proof += [mle_eval(P["e_polys"][m], x) for m in range(A) if P["mem_dim"][m] == c]
+    return proof, r, claimed
+
+
+def lasso_challenge_count(nu):
+    return nu + nu + 2 + (1 + sum(2 + n for n in range(1, nu))) + (1 + sum(2 + n for n in range(1, 16)))

@@ -184,6 +184,37 @@ int orc_lasso_prove(const orc_params* p, const uint64_t* lasso_in, int threads, 
     } catch (const std::exception& ex) { set_err(err, errcap, ex.what()); return -1; }
 }
 
+// The integer tables of the Lasso node (lasso.rs:157-250 polynomialize): limb indices, counters and subtable values are
+// small non-negative integers, the same in every field - the BN254 oracle (oracle/bn254.py) starts from them.
+// Call with dims == nullptr to query sizes. row_lookup[j] for j >= rows is 255. mem_cutoff: 65536 = full subtable.
+int orc_lasso_polys(const orc_params* p, const uint64_t* lasso_in, size_t* nu_out, size_t* a_out, size_t* rows_out, uint64_t* dims,
+                    uint64_t* read_cts, uint64_t* final_cts, uint64_t* e_polys, uint8_t* row_lookup, int* mem_dim, uint64_t* mem_cutoff,
+                    char* err, size_t errcap) {
+    try {
+        BfvParams q = to_params(p);
+        BfvCircuit bc;
+        bc.pre.reset(new LassoPre(bfv_setup(q)));
+        bfv_configure(q, bc);
+        const LassoNodeDef& d = bc.c.nodes[bc.lasso_id].lasso;
+        const LassoPre& pre = *bc.pre;
+        const size_t N = (size_t)1 << d.nu, A = pre.num_memories;
+        *nu_out = d.nu; *a_out = A; *rows_out = d.row_lookup.size();
+        if (!dims) return 0;
+        LassoPolys P = polynomialize(pre, d.nu, d.row_lookup, lasso_in);
+        for (size_t c = 0; c < LASSO_C; c++) memcpy(dims + c * N, P.dims[c].data(), N * 8);
+        for (size_t m = 0; m < A; m++) {
+            memcpy(read_cts + m * N, P.read_cts[m].data(), N * 8);
+            memcpy(final_cts + m * LASSO_M, P.final_cts[m].data(), LASSO_M * 8);
+            memcpy(e_polys + m * N, P.e_polys[m].data(), N * 8);
+            mem_dim[m] = (int)pre.mem_dim[m];
+            const Subtable& st = pre.subtables[pre.mem_subtable[m]];
+            mem_cutoff[m] = st.full ? LASSO_M : st.cutoff();
+        }
+        for (size_t j = 0; j < N; j++) row_lookup[j] = j < d.row_lookup.size() ? d.row_lookup[j] : 255;
+        return 0;
+    } catch (const std::exception& ex) { set_err(err, errcap, ex.what()); return -1; }
+}
+
 int orc_lasso_verify(const orc_params* p, const uint8_t* proof, size_t len, char* err, size_t errcap) {
     try {
         BfvParams q = to_params(p);

@@ -185,3 +185,33 @@ def bn254():
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
     return m
+
+
+def lasso_polys(p, lasso_in):
+    """Integer tables of the Lasso node from the C oracle (orc_lasso_polys) as Python lists, plus lookup_mems."""
+    import ctypes as C
+    import numpy as np
+    L = lib()
+    nu, A, rows = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+    err = C.create_string_buffer(256)
+    lin = np.ascontiguousarray(lasso_in, dtype=np.uint64)
+    u64p, u8p, i32p = C.POINTER(C.c_uint64), C.POINTER(C.c_uint8), C.POINTER(C.c_int)
+    L.orc_lasso_polys.argtypes = [C.c_void_p, u64p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), u64p, u64p, u64p,
+                                  u64p, u8p, i32p, u64p, C.c_char_p, C.c_size_t]
+    pp = C.cast(C.byref(p.struct), C.c_void_p)
+    assert L.orc_lasso_polys(pp, ptr(lin), C.byref(nu), C.byref(A), C.byref(rows), None, None, None, None, None, None, None, err, 256) == 0, err.value
+    N = 1 << nu.value
+    dims = np.zeros(4 * N, dtype=np.uint64); rd = np.zeros(A.value * N, dtype=np.uint64)
+    fin = np.zeros(A.value * 65536, dtype=np.uint64); ep = np.zeros(A.value * N, dtype=np.uint64)
+    rl = np.zeros(N, dtype=np.uint8); md = np.zeros(A.value, dtype=np.int32); mc = np.zeros(A.value, dtype=np.uint64)
+    assert L.orc_lasso_polys(pp, ptr(lin), C.byref(nu), C.byref(A), C.byref(rows), ptr(dims), ptr(rd), ptr(fin), ptr(ep),
+                             rl.ctypes.data_as(u8p), md.ctypes.data_as(i32p), ptr(mc), err, 256) == 0, err.value
+    _, lookups = lasso_layout(p)
+    lookup_mems = [[int(x) for x in l.split(":")[2].split("/")] for l in lookups]
+    a = A.value
+    return dict(nu=nu.value, A=a, rows=rows.value,
+                dims=[dims[c * N:(c + 1) * N].tolist() for c in range(4)],
+                read_cts=[rd[m * N:(m + 1) * N].tolist() for m in range(a)],
+                final_cts=[fin[m * 65536:(m + 1) * 65536].tolist() for m in range(a)],
+                e_polys=[ep[m * N:(m + 1) * N].tolist() for m in range(a)],
+                row_lookup=rl.tolist(), mem_dim=md.tolist(), mem_cutoff=mc.tolist(), lookup_mems=lookup_mems)

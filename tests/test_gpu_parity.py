@@ -373,3 +373,23 @@ def test_bn254_grand_product_bit_exact(ctx, nb, nv):
     assert claims == eclaims and point == epoint
     # the final claims are the tables' multilinear extensions at the final point (the relation the verifier relies on)
     assert claims == [bn.mle_eval(t, point) for t in tabs]
+
+
+def test_bn254_lasso_node_bit_exact(ctx):
+    """The Lasso node of the n=1024 circuit over bn256::Fr: HIP (integer split / counters shared with the Goldilocks path, the rest
+    over Fr) against the Python oracle fed with the C oracle's integer tables; the node input is the reference fixture's
+    range-shifted lookup table (small integers, the same in both fields)."""
+    bn = orclib.bn254()
+    p = orclib.params(1024, 1)
+    lasso_in, _, info = orclib.circuit_eval(p, orclib.fixture_inputs(1024, 1, 27))
+    P = orclib.lasso_polys(p, lasso_in)
+    skip = 3
+    chal = bn.challenges(skip + bn.lasso_challenge_count(P["nu"]), orclib.keccak256)[skip:]
+    eproof, er, eclaimed = bn.lasso_prove(P, chal)
+    bfv = hg.BfvEncrypt.new(1024, 1)
+    pk = bfv.setup(ctx)
+    proof, r, claimed = ctx.lasso_prove_bn254(pk, [int(v) for v in lasso_in], skip)
+    assert r == er and claimed == eclaimed
+    assert proof == b"".join(int(v).to_bytes(32, "big") for v in eproof)
+    with pytest.raises(hg.HgError):   # a value that is not range-shifted (>= 2^64) is refused, not silently truncated
+        ctx.lasso_prove_bn254(pk, [int(v) for v in lasso_in[:-1]] + [bn.R - 1], skip)

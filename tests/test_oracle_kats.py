@@ -290,3 +290,37 @@ def test_bn254_grand_product_oracle_claims_are_mle_evaluations():
     proof, claims, point = bn.grand_product(tabs, chal)
     assert proof[:3] == [reduce(lambda a, b: a * b % bn.R, t, 1) for t in tabs]
     assert len(point) == 4 and claims == [bn.mle_eval(t, point) for t in tabs]
+
+
+def test_bn254_lasso_oracle_passes_the_verifier_checks():
+    """The checks of MemoryCheckingVerifier::verify_memories [REF lasso/src/memory_checking/verifier.rs:61-95] on the oracle's
+    output over Fr, for the reference fixture's lookup table: the grand-product claims equal the multiset hash of the
+    openings (reads / writes at x, init / final at y with the subtable MLE and the identity polynomial)."""
+    bn = orclib.bn254()
+    p = orclib.params(1024, 1)
+    lasso_in, _, _ = orclib.circuit_eval(p, orclib.fixture_inputs(1024, 1, 27))
+    P = orclib.lasso_polys(p, lasso_in)
+    assert P["nu"] == 14 and P["A"] == 6 and P["rows"] == 10240
+    chal = bn.challenges(bn.lasso_challenge_count(P["nu"]), orclib.keccak256)
+    sec = {}
+    proof, r, claimed = bn.lasso_prove(P, chal, sec)
+    A, R = P["A"], bn.R
+    gamma, tau, x, y = sec["gamma"], sec["tau"], sec["x"], sec["y"]
+    h = lambda a, v, t: (a + v * gamma + t * gamma * gamma - tau) % R
+    id_y = sum((1 << i) * yi for i, yi in enumerate(y)) % R
+    pos = sec["openings"]
+    i = 0
+    for c in sorted(set(P["mem_dim"])):
+        mems = [m for m in range(A) if P["mem_dim"][m] == c]
+        dim_x, rts_x, fct_y = proof[pos], proof[pos + 1], proof[pos + 2]
+        e_xs = proof[pos + 3:pos + 3 + len(mems)]
+        pos += 3 + len(mems)
+        for q, m in enumerate(mems):
+            assert sec["order"][i] == (m, c)
+            assert sec["gp1_claims"][i] == h(dim_x, e_xs[q], rts_x)
+            assert sec["gp1_claims"][A + i] == h(dim_x, e_xs[q], (rts_x + 1) % R)
+            t_y = bn.mle_eval([a if a < P["mem_cutoff"][m] else 0 for a in range(65536)], y)
+            assert sec["gp2_claims"][i] == h(id_y, t_y, 0)
+            assert sec["gp2_claims"][A + i] == h(id_y, t_y, fct_y)
+            i += 1
+    assert pos == len(proof) and proof[0] == claimed and len(r) == 14
