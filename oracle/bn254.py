@@ -211,3 +211,73 @@ def lasso_prove(P, chal, sections=None):
 
 def lasso_challenge_count(nu):
     return nu + nu + 2 + (1 + sum(2 + n for n in range(1, nu))) + (1 + sum(2 + n for n in range(1, 16)))
+
+
+def _verify_rounds(d, nv, claim, elems, pos, it):
+    """verify_sum_check (gkr crate; conventions C1): each round polynomial must satisfy h(0) + h(1) = claim; claim <- h(r)."""
+    point = []
+    for _ in range(nv):
+        c = elems[pos:pos + d + 1]
+        pos += d + 1
+        if (2 * c[0] + sum(c[1:])) % R != claim % R:
+            raise ValueError("InvalidSumCheck: round polynomial does not match claim")
+        r = next(it)
+        claim = sum(ck * pow(r, k, R) for k, ck in enumerate(c)) % R
+        point.append(r)
+    return claim, point, pos
+
+
+def verify_grand_product(num_vars, nb, elems, pos, it):
+    """[REF lasso/src/memory_checking/verifier.rs:178-235] (the final sum-check claim of a layer is not checked there either)."""
+    claims = elems[pos:pos + nb]
+    pos += nb
+    x = []
+    for n in range(num_vars):
+        if n == 0:
+            evals = elems[pos:pos + 2 * nb]
+            pos += 2 * nb
+            for b in range(nb):
+                if claims[b] != evals[2 * b] * evals[2 * b + 1] % R:
+                    raise ValueError("InvalidSumCheck: unmatched sum check output")
+            x = []
+        else:
+            gamma = next(it)
+            claim = sum(c * pow(gamma, b, R) for b, c in enumerate(claims)) % R
+            _, x, pos = _verify_rounds(3, n, claim, elems, pos, it)
+            evals = elems[pos:pos + 2 * nb]
+            pos += 2 * nb
+        mu = next(it)
+        claims = [(evals[2 * b] + mu * (evals[2 * b + 1] - evals[2 * b])) % R for b in range(nb)]
+        x.append(mu)
+    return claims, x, pos
+
+
+def lasso_verify(elems, nu, mem_dim, mem_cutoff, chal):
+    """LassoNode::verify_claim_reduction over Fr [REF lasso/src/lasso.rs:116-139, memory_checking/verifier.rs:61-95, 130-176]:
+    raises ValueError on the first failed check, returns (r, claimed_sum) otherwise. elems: the proof as integers."""
+    A = len(mem_dim)
+    it = iter(chal)
+    r = [next(it) for _ in range(nu)]
+    claimed = elems[0]
+    _, _, pos = _verify_rounds(2, nu, claimed, elems, 1, it)        # result ignored (lasso.rs:129-130)
+    gamma, tau = next(it), next(it)
+    h = lambda a, v, t: (a + v * gamma + t * gamma * gamma - tau) % R
+    rw, x, pos = verify_grand_product(nu, 2 * A, elems, pos, it)
+    ifr, y, pos = verify_grand_product(16, 2 * A, elems, pos, it)
+    id_y = sum((1 << i) * yi for i, yi in enumerate(y)) % R
+    off = 0
+    for c in sorted(set(mem_dim)):
+        mems = [m for m in range(A) if mem_dim[m] == c]
+        dim_x, rts_x, fct_y = elems[pos:pos + 3]
+        e_xs = elems[pos + 3:pos + 3 + len(mems)]
+        pos += 3 + len(mems)
+        for q, m in enumerate(mems):
+            t_y = mle_eval([a if a < mem_cutoff[m] else 0 for a in range(65536)], y)
+            if rw[off + q] != h(dim_x, e_xs[q], rts_x): raise ValueError("memory check: read hash mismatch")
+            if rw[A + off + q] != h(dim_x, e_xs[q], (rts_x + 1) % R): raise ValueError("memory check: write hash mismatch")
+            if ifr[off + q] != h(id_y, t_y, 0): raise ValueError("memory check: init hash mismatch")
+            if ifr[A + off + q] != h(id_y, t_y, fct_y): raise ValueError("memory check: final hash mismatch")
+        off += len(mems)
+    if pos != len(elems):
+        raise ValueError("trailing proof elements")
+    return r, claimed

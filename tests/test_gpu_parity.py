@@ -393,3 +393,31 @@ def test_bn254_lasso_node_bit_exact(ctx):
     assert proof == b"".join(int(v).to_bytes(32, "big") for v in eproof)
     with pytest.raises(hg.HgError):   # a value that is not range-shifted (>= 2^64) is refused, not silently truncated
         ctx.lasso_prove_bn254(pk, [int(v) for v in lasso_in[:-1]] + [bn.R - 1], skip)
+
+
+def test_bn254_lasso_node_full_size_accepted_by_the_verifier(ctx):
+    """BASELINE config 5 shape: the Lasso node of n=32768 k=16 (nu = 21, 25 memories) over bn256::Fr. Too large for the
+    Python prover oracle; the proof is checked by the oracle's verifier (round consistency of every sum-check, layer
+    chaining, the memory-checking hash relations at both grand-product points) and a tampered proof is rejected."""
+    import time
+    bn = orclib.bn254()
+    bfv = hg.BfvEncrypt.new(32768, 16)
+    pk = bfv.setup(ctx)
+    w = hg.Witness.synthetic(bfv.params, 0x4752454330 + 5)
+    lasso_in = pk.circuit_eval(w)[0]
+    t0 = time.time()
+    proof, r, claimed = ctx.lasso_prove_bn254(pk, [int(v) for v in lasso_in], 0, cap=1 << 24)
+    print("hg_lasso_prove_bn254 n=32768 k=16: %.1f ms, %d proof bytes" % ((time.time() - t0) * 1e3, len(proof)))
+    elems = [int.from_bytes(proof[i:i + 32], "big") for i in range(0, len(proof), 32)]
+    mems, _ = orclib.lasso_layout(orclib.params(32768, 16))
+    mem_dim = [int(m.split("@")[1]) for m in mems]
+    def cutoff(name):
+        if name == "full": return 65536
+        b = int(name.split("_")[1])
+        return (1 << ((b.bit_length() - 1) % 16)) + b % 65536
+    mem_cutoff = [cutoff(m.split("@")[0]) for m in mems]
+    chal = bn.challenges(bn.lasso_challenge_count(21), orclib.keccak256)
+    assert bn.lasso_verify(elems, 21, mem_dim, mem_cutoff, chal) == (r, claimed)
+    bad = list(elems); bad[len(bad) // 3] = (bad[len(bad) // 3] + 1) % bn.R
+    with pytest.raises(ValueError):
+        bn.lasso_verify(bad, 21, mem_dim, mem_cutoff, chal)

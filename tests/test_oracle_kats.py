@@ -324,3 +324,18 @@ def test_bn254_lasso_oracle_passes_the_verifier_checks():
             assert sec["gp2_claims"][A + i] == h(id_y, t_y, fct_y)
             i += 1
     assert pos == len(proof) and proof[0] == claimed and len(r) == 14
+
+
+def test_bn254_lasso_oracle_verifier_accepts_and_rejects():
+    bn = orclib.bn254()
+    p = orclib.params(1024, 1)
+    lasso_in, _, _ = orclib.circuit_eval(p, orclib.fixture_inputs(1024, 1, 27))
+    P = orclib.lasso_polys(p, lasso_in)
+    chal = bn.challenges(bn.lasso_challenge_count(P["nu"]), orclib.keccak256)
+    proof, r, claimed = bn.lasso_prove(P, chal)
+    assert bn.lasso_verify(proof, P["nu"], P["mem_dim"], P["mem_cutoff"], chal) == (r, claimed)
+    for at in (1, len(proof) // 2, len(proof) - 1):   # a collation coefficient, a grand-product element, the last opening
+        bad = list(proof)
+        bad[at] = (bad[at] + 1) % bn.R
+        with pytest.raises(ValueError):
+            bn.lasso_verify(bad, P["nu"], P["mem_dim"], P["mem_cutoff"], chal)
