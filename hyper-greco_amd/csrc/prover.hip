@@ -98,7 +98,7 @@ hg_ctx::~hg_ctx() {
     if (stream) (void)hipStreamSynchronize(stream);
     for (auto& c : chunks) (void)hipFree(c.p);
     if (d_chal) (void)hipFree(d_chal);
-    if (d_res) (void)hipFree(d_res);
+    if (d_res && d_res != h_res) (void)hipFree(d_res);
     if (h_res) (void)hipHostFree(h_res);
     if (h_stage) (void)hipHostFree(h_stage);
     if (d_partials) (void)hipFree(d_partials);
@@ -1200,9 +1200,19 @@ struct Prover {
     // copies the result buffer back (the only synchronisation) and replays the transcript
     double t_enqueued = 0, t_synced = 0, t_replayed = 0;
     void sync_results() {
-        if (res_used) hip_check(hipMemcpyAsync(ctx->h_res, ctx->d_res, res_used * sizeof(E2), hipMemcpyDeviceToHost, st), "copy results");
+        if (res_used && ctx->d_res != ctx->h_res) hip_check(hipMemcpyAsync(ctx->h_res, ctx->d_res, res_used * sizeof(E2), hipMemcpyDeviceToHost, st), "copy results");
         t_enqueued = wall_ms();
-        hip_check(hipStreamSynchronize(st), "prove: stream sync");
+        // The only synchronisation of a prove. Spin on an event instead of hipStreamSynchronize: a blocking wait can cost
+        // up to milliseconds of wake-up latency when another runtime in the process (PyTorch in bench.py) has switched the
+        // device to blocking-sync scheduling; the wait is a few milliseconds at most, so a busy core is the cheaper price.
+        hip_check(hipEventRecord(ctx->ev_join, st), "prove: done event");
+        const double t_spin = wall_ms();
+        for (;;) {
+            hipError_t q = hipEventQuery(ctx->ev_join);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) hip_check(q, "prove: event query");
+            if (wall_ms() - t_spin > 2000.0) { hip_check(hipStreamSynchronize(st), "prove: stream sync"); break; }
+        }
         hip_check(hipGetLastError(), "prove: kernel launch");
         t_synced = wall_ms();
     }
