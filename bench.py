@@ -33,7 +33,7 @@ CLASS_SYMBOL = {
     "sc_round<collation,base>": "k_st_step<0, unsigned long>",
     "sc_round<prodsum>": "k_ps_one(",
 }
-PMC_FILE = os.path.join(ROOT, "profiles", "r01_i_pmc_hbm_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r01_j_pmc_hbm_traffic.json")
 
 
 def pmc_traffic(cls):
