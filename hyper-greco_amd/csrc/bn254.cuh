@@ -108,6 +108,65 @@ BN_HD Fr fr_mul(const Fr& a, const Fr& b) {
     Fr r = fr_make(t0, t1, t2, t3);
     return (t4 || fr_geq_p(r)) ? fr_sub_p(r) : r;
 }
+// ---- deferred Montgomery reduction: sums of products stay as 512(+64)-bit integers and are reduced once --------------------
+struct W512 {
+    u64 l[9];  // little-endian limbs; l[8] collects the overflow of up to 2^64 accumulated products
+};
+BN_HD W512 w512_zero() { W512 w; for (int i = 0; i < 9; i++) w.l[i] = 0; return w; }
+// acc += a * b (plain integer product of two residues < r)
+BN_HD void w512_mac(W512& acc, const Fr& a, const Fr& b) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const u64 bi = b.l[i];
+        u128 c = (u128)a.l[0] * bi + acc.l[i];
+        acc.l[i] = (u64)c;
+        c = (u128)a.l[1] * bi + acc.l[i + 1] + (u64)(c >> 64);
+        acc.l[i + 1] = (u64)c;
+        c = (u128)a.l[2] * bi + acc.l[i + 2] + (u64)(c >> 64);
+        acc.l[i + 2] = (u64)c;
+        c = (u128)a.l[3] * bi + acc.l[i + 3] + (u64)(c >> 64);
+        acc.l[i + 3] = (u64)c;
+        // propagate the carry to the top
+        u64 carry = (u64)(c >> 64);
+#pragma unroll
+        for (int k = i + 4; k < 9; k++) {
+            const u128 d = (u128)acc.l[k] + carry;
+            acc.l[k] = (u64)d;
+            carry = (u64)(d >> 64);
+        }
+    }
+}
+// acc R^-1 mod r for acc < 2^10 r^2 (Montgomery reduction of the whole sum, then a few conditional subtractions)
+BN_HD Fr w512_reduce(W512 t) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const u64 m = t.l[i] * FR_INV;
+        u128 c = (u128)m * FR_P0 + t.l[i];
+        c = (u128)m * FR_P1 + t.l[i + 1] + (u64)(c >> 64);
+        t.l[i + 1] = (u64)c;
+        c = (u128)m * FR_P2 + t.l[i + 2] + (u64)(c >> 64);
+        t.l[i + 2] = (u64)c;
+        c = (u128)m * FR_P3 + t.l[i + 3] + (u64)(c >> 64);
+        t.l[i + 3] = (u64)c;
+        u64 carry = (u64)(c >> 64);
+#pragma unroll
+        for (int k = i + 4; k < 9; k++) {
+            const u128 d = (u128)t.l[k] + carry;
+            t.l[k] = (u64)d;
+            carry = (u64)(d >> 64);
+        }
+    }
+    // value = t.l[4..8] < 2^10 r: subtract r while it does not fit (top limb) or is >= r
+    Fr r = fr_make(t.l[4], t.l[5], t.l[6], t.l[7]);
+    u64 top = t.l[8];
+    for (int it = 0; it < 1100 && (top || fr_geq_p(r)); it++) {
+        const bool borrow = !fr_geq_p(r);  // r < p: the subtraction wraps and takes one from `top`
+        r = fr_sub_p(r);
+        if (borrow) top--;
+    }
+    return r;
+}
+
 BN_HD Fr fr_to_mont(const Fr& canonical) { return fr_mul(canonical, fr_r2()); }
 BN_HD Fr fr_from_mont(const Fr& m) { return fr_mul(m, fr_make(1, 0, 0, 0)); }
 BN_HD bool fr_eq(const Fr& a, const Fr& b) { return a.l[0] == b.l[0] && a.l[1] == b.l[1] && a.l[2] == b.l[2] && a.l[3] == b.l[3]; }

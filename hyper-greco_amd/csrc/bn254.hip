@@ -147,6 +147,44 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_round(const Fr* __restrict__ in, 
         if (threadIdx.x == 0) partials[(size_t)blockIdx.x * NV + v] = s;
     }
 }
+// Grand-product round of prove_grand_product, tuned: (a) in the FIRST round of a layer the folded LEFT table of pair i is stored
+// multiplied by its weight gamma^i, so later rounds need no weights (the host divides the final left evaluations by
+// gamma^i again); (b) the three dot products over the pairs are accumulated as unreduced 512-bit integers and Montgomery-
+// reduced once per pair index j (w512_*): per pair 3 half-cost products + 2 fold products instead of 8 full ones.
+template <bool FIRST>
+__global__ __launch_bounds__(BN_TPB) void k_bn_gp_round(const Fr* __restrict__ in, Fr* __restrict__ out, int ntab, size_t half, Fr r,
+                                                        const Fr* __restrict__ pw, Fr* __restrict__ partials) {
+    __shared__ Fr sm[BN_TPB];
+    Fr acc[3] = {fr_zero(), fr_zero(), fr_zero()};
+    const int nb = ntab >> 1;
+    for (size_t j = (size_t)blockIdx.x * BN_TPB + threadIdx.x; j < half; j += (size_t)gridDim.x * BN_TPB) {
+        W512 a0 = w512_zero(), a2 = w512_zero(), a3 = w512_zero();
+        Fr p0 = fr_zero(), p2 = fr_zero(), p3 = fr_zero();
+        for (int i = 0; i < nb; i++) {
+            Fr xl = in[(size_t)(2 * i) * 2 * half + 2 * j], yl = in[(size_t)(2 * i) * 2 * half + 2 * j + 1];
+            const Fr xr = in[(size_t)(2 * i + 1) * 2 * half + 2 * j], yr = in[(size_t)(2 * i + 1) * 2 * half + 2 * j + 1];
+            Fr dl = fr_sub(yl, xl);
+            if (FIRST) { const Fr w = pw[i]; xl = fr_mul(w, xl); dl = fr_mul(w, dl); }   // weight rides in the left table from here on
+            const Fr dr = fr_sub(yr, xr);
+            const Fr l2 = fr_add(fr_add(xl, dl), dl), l3 = fr_add(l2, dl);
+            const Fr r2 = fr_add(yr, dr), r3 = fr_add(r2, dr);
+            if (i == 0) { p0 = xl; p2 = l2; p3 = l3; }                                      // pw[0] = 1: table 0 itself
+            w512_mac(a0, xl, xr);
+            w512_mac(a2, l2, r2);
+            w512_mac(a3, l3, r3);
+            out[(size_t)(2 * i) * half + j] = fr_add(xl, fr_mul(r, dl));
+            out[(size_t)(2 * i + 1) * half + j] = fr_add(xr, fr_mul(r, dr));
+        }
+        acc[0] = fr_add(acc[0], fr_mul(p0, w512_reduce(a0)));
+        acc[1] = fr_add(acc[1], fr_mul(p2, w512_reduce(a2)));
+        acc[2] = fr_add(acc[2], fr_mul(p3, w512_reduce(a3)));
+    }
+#pragma unroll
+    for (int v = 0; v < 3; v++) {
+        Fr s = block_sum_fr(acc[v], sm);
+        if (threadIdx.x == 0) partials[(size_t)blockIdx.x * 3 + v] = s;
+    }
+}
 __global__ __launch_bounds__(BN_TPB) void k_bn_reduce(const Fr* __restrict__ partials, int nblocks, int nv, Fr* __restrict__ out) {
     __shared__ Fr sm[BN_TPB];
     for (int v = 0; v < nv; v++) {
@@ -387,7 +425,8 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
                 const size_t half = h >> (rd + 1);
                 const Fr r = fr_to_mont(chain[L.r_at + rd]);
                 const int grid = (int)std::min<size_t>((half + BN_TPB - 1) / BN_TPB, (size_t)1024);
-                k_bn_round<BN_GRANDPROD><<<grid, BN_TPB, 0, st>>>(cur, nxt, (int)ntab, half, r, d_pw, d_part);
+                if (rd == 0) k_bn_gp_round<true><<<grid, BN_TPB, 0, st>>>(cur, nxt, (int)ntab, half, r, d_pw, d_part);
+                else k_bn_gp_round<false><<<grid, BN_TPB, 0, st>>>(cur, nxt, (int)ntab, half, r, d_pw, d_part);
                 k_bn_reduce<<<1, BN_TPB, 0, st>>>(d_part, grid, 3, L.d_sums + rd * 3);
                 cur = nxt;
                 nxt = nxt == buf0 ? buf1 : buf0;
@@ -429,6 +468,10 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
                 x.push_back(chain[L.r_at + rd]);
             }
             for (size_t i = 0; i < 2 * nb; i++) evals[i] = fr_to_mont(L.fin[i]);
+            // the kernels leave the left evaluation of pair b multiplied by gamma^b (k_bn_gp_round)
+            const Fr ginv = fr_inv(g);
+            Fr u = ginv;
+            for (size_t b = 1; b < nb; b++) { evals[2 * b] = fr_mul(evals[2 * b], u); u = fr_mul(u, ginv); }
         }
         for (size_t i = 0; i < 2 * nb; i++) write_be32(proof, fr_from_mont(evals[i]));  // prover.rs:257
         const Fr mu = fr_to_mont(chain[L.mu_at]);                                          // prover.rs:259
