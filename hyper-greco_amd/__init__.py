@@ -39,7 +39,7 @@ EXPORTS = [
     "hg_last_error", "hg_device_count", "hg_create", "hg_destroy", "hg_params_builtin", "hg_setup", "hg_pk_free",
     "hg_pk_lasso_layout", "hg_pk_info", "hg_witness_from_json", "hg_witness_synthetic", "hg_witness_from_arrays",
     "hg_witness_get", "hg_witness_free", "hg_prove", "hg_verify", "hg_witness_gen", "hg_values_free", "hg_values_get", "hg_prove_shard_begin", "hg_prove_shard_combine", "hg_prove_shard_finish", "hg_prove_resident", "hg_circuit_eval", "hg_lasso_prove", "hg_lasso_prove_at", "hg_sumcheck", "hg_mle_eval",
-    "hg_ntt", "hg_challenges", "hg_challenges_bn254", "hg_bn254_field_op", "hg_sumcheck_bn254", "hg_grand_product_bn254", "hg_lasso_prove_bn254", "hg_mle_eval_bn254", "hg_ntt_bn254", "hg_profile", "hg_profile_select", "hg_profile_reset", "hg_profile_get",
+    "hg_ntt", "hg_challenges", "hg_challenges_bn254", "hg_bn254_field_op", "hg_sumcheck_bn254", "hg_grand_product_bn254", "hg_lasso_prove_bn254", "hg_witness_from_json_bn254", "hg_circuit_eval_bn254", "hg_prove_bn254", "hg_mle_eval_bn254", "hg_ntt_bn254", "hg_profile", "hg_profile_select", "hg_profile_reset", "hg_profile_get",
 ]
 
 
@@ -101,6 +101,9 @@ def lib():
                                              C.POINTER(C.c_size_t), u64p, u64p]
         L.hg_lasso_prove_bn254.argtypes = [C.c_void_p, C.c_void_p, u64p, C.c_size_t, C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_size_t), u64p]
         L.hg_mle_eval_bn254.argtypes = [C.c_void_p, u64p, C.c_size_t, u64p, u64p]
+        L.hg_witness_from_json_bn254.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p)]
+        L.hg_circuit_eval_bn254.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, u64p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.hg_prove_bn254.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_double)]
         L.hg_ntt_bn254.argtypes = [C.c_void_p, u64p, C.c_size_t, C.c_int, C.c_size_t, u64p]
         L.hg_profile.argtypes = [C.c_void_p, C.c_int]
         L.hg_profile_select.argtypes = [C.c_void_p, C.c_char_p]
@@ -211,6 +214,22 @@ class Context:
         vals = self._fr_unpack(claim)
         return C.string_at(buf, ln.value), vals[:nu], vals[nu]
 
+    def circuit_eval_bn254(self, pk, witness, which):
+        """Circuit::evaluate over bn256::Fr: which = 0 the sum node, 1 the Lasso input node, 2 the ct0is table (Python ints)."""
+        n = C.c_size_t(0)
+        cap = 1 << (pk.params.n.bit_length() + 6)
+        out = np.zeros(cap * 4, dtype=np.uint64)
+        _check(lib().hg_circuit_eval_bn254(self.h, pk.h, witness.h, which, _ptr(out), cap, C.byref(n)))
+        return self._fr_unpack(out[:n.value * 4])
+
+    def prove_bn254(self, pk, witness, cap=1 << 24):
+        """BfvEncrypt::prove over bn256::Fr: (proof bytes, witness-generation ms, prove ms)."""
+        buf = (C.c_uint8 * cap)()
+        ln = C.c_size_t(0)
+        ms = (C.c_double * 2)()
+        _check(lib().hg_prove_bn254(self.h, pk.h, witness.h, buf, cap, C.byref(ln), ms))
+        return C.string_at(buf, ln.value), ms[0], ms[1]
+
     def mle_eval_bn254(self, table, point):
         nv = (len(table) - 1).bit_length()
         pt, pp = self._fr_pack(table), self._fr_pack(point) if len(point) else np.zeros(4, dtype=np.uint64)
@@ -290,6 +309,13 @@ class Witness:
     def from_json(cls, params, path):
         h = C.c_void_p()
         _check(lib().hg_witness_from_json(C.byref(params), path.encode(), C.byref(h)))
+        return cls(h, params)
+
+    @classmethod
+    def from_json_bn254(cls, params, path):
+        """One of the reference's bn254 fixtures (elements of bn256::Fr holding small signed integers)."""
+        h = C.c_void_p()
+        _check(lib().hg_witness_from_json_bn254(C.byref(params), path.encode(), C.byref(h)))
         return cls(h, params)
 
     @classmethod

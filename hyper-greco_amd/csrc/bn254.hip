@@ -10,6 +10,8 @@
 #include <string>
 #include <vector>
 #include <stdexcept>
+#include <chrono>
+#include <map>
 #include "bn254.cuh"
 #include "host.hpp"
 #include "prover.hpp"
@@ -211,6 +213,7 @@ static Fr fr_inv(Fr a) {
 }
 static Fr fr_small(u64 v) { return fr_to_mont(fr_make(v, 0, 0, 0)); }
 
+static double wall_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static void hipc(hipError_t e, const char* what) {
     if (e != hipSuccess) throw Error(std::string(what) + ": " + hipGetErrorString(e));
 }
@@ -807,6 +810,8 @@ void ntt_bn254(hg_ctx* ctx, const u64* in4, int log2n, bool inverse, size_t batc
     (void)hipFree(a); (void)hipFree(b); (void)hipFree(W);
     hipc(e, "hg_ntt_bn254");
 }
+
+#include "bn254_gkr.inc"
 
 }  // namespace bn
 }  // namespace hg

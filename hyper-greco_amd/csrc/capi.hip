@@ -18,6 +18,8 @@ void ntt_bn254(hg_ctx* ctx, const u64* in4, int log2n, bool inverse, size_t batc
 void grand_product_bn254(hg_ctx* ctx, size_t nb, size_t len, const u64* const* tables, size_t chain_skip, std::vector<uint8_t>& proof,
                          u64* claims_out, u64* point_out);
 void lasso_prove_bn254(hg_ctx* ctx, const hg_pk* pk, const u64* in4, size_t chain_skip, std::vector<uint8_t>& proof, u64* claim_out);
+void circuit_eval_bn254(hg_ctx* ctx, const hg_pk* pk, const Witness& w, int which, std::vector<u64>& out4);
+void prove_bn254(hg_ctx* ctx, const hg_pk* pk, const Witness& w, std::vector<uint8_t>& proof, double* ms);
 } }
 using namespace hg;
 
@@ -514,6 +516,38 @@ int hg_lasso_prove_bn254(hg_ctx* ctx, const hg_pk* pk, const uint64_t* lasso_in4
     if (!ctx || !pk) throw hg::Error("hg_lasso_prove_bn254: null argument (a HIP device is required)");
     std::vector<uint8_t> bytes;
     hg::bn::lasso_prove_bn254(ctx, pk, lasso_in4, chain_skip, bytes, claim_out4);
+    *len = bytes.size();
+    if (bytes.size() > cap) throw hg::Error("proof buffer too small");
+    memcpy(proof, bytes.data(), bytes.size());
+    return 0;
+    HG_CATCH(-1)
+}
+int hg_witness_from_json_bn254(const hg_params* params, const char* path, hg_witness** out) {
+    HG_TRY
+    if (!params || !path || !out) throw hg::Error("hg_witness_from_json_bn254: null argument");
+    std::unique_ptr<hg_witness> w(new hg_witness());
+    w->params = *params;
+    w->w = hg::witness_from_json_bn254(hg::Params(*params), path);
+    *out = w.release();
+    return 0;
+    HG_CATCH(-1)
+}
+int hg_circuit_eval_bn254(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, int which, uint64_t* out4, size_t cap_elems, size_t* n_elems) {
+    HG_TRY
+    if (!ctx || !pk || !w || !n_elems) throw hg::Error("hg_circuit_eval_bn254: null argument (a HIP device is required)");
+    std::vector<uint64_t> v;
+    hg::bn::circuit_eval_bn254(ctx, pk, w->w, which, v);
+    *n_elems = v.size() / 4;
+    if (v.size() / 4 > cap_elems) throw hg::Error("hg_circuit_eval_bn254: output buffer too small");
+    memcpy(out4, v.data(), v.size() * 8);
+    return 0;
+    HG_CATCH(-1)
+}
+int hg_prove_bn254(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, uint8_t* proof, size_t cap, size_t* len, double* ms2) {
+    HG_TRY
+    if (!ctx || !pk || !w || !len) throw hg::Error("hg_prove_bn254: null argument (a HIP device is required)");
+    std::vector<uint8_t> bytes;
+    hg::bn::prove_bn254(ctx, pk, w->w, bytes, ms2);
     *len = bytes.size();
     if (bytes.size() > cap) throw hg::Error("proof buffer too small");
     memcpy(proof, bytes.data(), bytes.size());

@@ -72,6 +72,7 @@ struct Witness {  // tables exactly as get_inputs lays them out
     std::vector<u64> ct0is;     // k * 2^L
 };
 Witness witness_from_json(const Params& p, const std::string& path);
+Witness witness_from_json_bn254(const Params& p, const std::string& path);  // bn256::Fr fixture -> signed integers in Goldilocks form
 Witness witness_synthetic(const Params& p, u64 seed);
 
 // ---------------------------------------------------------------------------------------------

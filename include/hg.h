@@ -158,7 +158,7 @@ int hg_challenges(size_t n, uint64_t* out);
 /* ---- BN254 (BASELINE config 5, first slice): field, challenges and sum-check kernels over halo2curves bn256::Fr --------
  * Elements cross the boundary as 4 canonical little-endian u64 limbs (non-Montgomery). The extension field of the
  * reference's bn254 tests is the field itself [REF sk_encryption_circuit.rs:614-626: (Fr, Fr)], so a challenge is one
- * element. The full BfvEncrypt::prove over Fr is not built yet. */
+ * element. hg_prove_bn254 is the whole BfvEncrypt::prove over Fr; the entry points before it expose its parts for parity tests. */
 /* = Keccak256Transcript::squeeze_challenge over Fr: c_j = LE(Keccak^j("")) mod r [REF transcript.rs:146-157,198-203]; n x 4 limbs */
 int hg_challenges_bn254(size_t n, uint64_t* out4);
 /* device field arithmetic on n element pairs: op 0 add, 1 sub, 2 mul (known-answer tests of the Montgomery kernels) */
@@ -185,6 +185,19 @@ int hg_mle_eval_bn254(hg_ctx* ctx, const uint64_t* table4, size_t nv, const uint
 /* = FftNode evaluate over Fr [REF sk_encryption_circuit.rs:224,249,251]: size-2^log2n NTT with the root of unity
  *   7^((r-1)/2^log2n) (halo2curves ROOT_OF_UNITY, two-adicity 28), natural order in / out; inverse scales by 1/n */
 int hg_ntt_bn254(hg_ctx* ctx, const uint64_t* in4, size_t log2n, int inverse, size_t batch, uint64_t* out4);
+
+/* = BfvSkEncryptArgs from one of the reference's bn254 fixtures [REF bfv-gkr/src/data/bn254/ *.json, sk_encryption_circuit.rs:365-415]:
+ *   coefficients are bn256::Fr elements (negatives as r - |z|). Every coefficient of a valid witness is a small signed integer, which
+ *   is what the handle stores (an element that is not an integer below 2^62 in magnitude is rejected); the same handle type as
+ *   hg_witness_from_json / hg_witness_synthetic, so those witnesses can be proven over Fr as well. */
+int hg_witness_from_json_bn254(const hg_params* params, const char* path, hg_witness** out);
+/* = Circuit::evaluate over Fr on the device [REF sk_encryption_circuit.rs:434-442]; returns one table as canonical limbs:
+ *   which = 0 the `sum` node (must equal ct0is), 1 the Lasso input node, 2 the ct0is table as laid out by get_inputs */
+int hg_circuit_eval_bn254(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, int which, uint64_t* out4, size_t cap_elems, size_t* n_elems);
+/* = BfvEncrypt::<_, 1>::prove::<Fr, Fr> [REF sk_encryption_circuit.rs:417-460, 614-626]: witness generation, output claim, the
+ *   prove_gkr walk (Libra / zkCNN / Lasso node reductions) over bn256::Fr. proof: 32-byte big-endian elements
+ *   [REF transcript.rs:183-189]. ms2 (may be null): witness generation and proving wall time in ms. */
+int hg_prove_bn254(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, uint8_t* proof, size_t cap, size_t* len, double* ms2);
 
 /* profiling: level 0 off, 1 = events around the selected kernel class only, 2 = every class */
 int hg_profile(hg_ctx* ctx, int level);

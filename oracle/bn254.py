@@ -252,7 +252,7 @@ def verify_grand_product(num_vars, nb, elems, pos, it):
     return claims, x, pos
 
 
-def lasso_verify(elems, nu, mem_dim, mem_cutoff, chal):
+def lasso_verify(elems, nu, mem_dim, mem_cutoff, chal, partial=False):
     """LassoNode::verify_claim_reduction over Fr [REF lasso/src/lasso.rs:116-139, memory_checking/verifier.rs:61-95, 130-176]:
     raises ValueError on the first failed check, returns (r, claimed_sum) otherwise. elems: the proof as integers."""
     A = len(mem_dim)
@@ -278,6 +278,8 @@ def lasso_verify(elems, nu, mem_dim, mem_cutoff, chal):
             if ifr[off + q] != h(id_y, t_y, 0): raise ValueError("memory check: init hash mismatch")
             if ifr[A + off + q] != h(id_y, t_y, fct_y): raise ValueError("memory check: final hash mismatch")
         off += len(mems)
+    if partial:                      # the node inside a larger proof: also report what was consumed
+        return r, claimed, pos
     if pos != len(elems):
         raise ValueError("trailing proof elements")
     return r, claimed

@@ -187,6 +187,35 @@ def bn254():
     return m
 
 
+def bn254_gkr():
+    """The BN254 whole-proof Python oracle (oracle/bn254_gkr.py)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("oracle_bn254_gkr", os.path.join(ROOT, "oracle", "bn254_gkr.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def bn254_lasso_fns(p):
+    """(prove, verify) callbacks for bn254_gkr.prove / .verify: the Lasso node of oracle/bn254.py on the C oracle's integer tables."""
+    import numpy as np
+    bn = bn254()
+    state = {}
+
+    def prove_fn(vin, ch):
+        P = lasso_polys(p, np.array(vin, dtype=np.uint64))
+        state["P"] = P
+        els, r, v = bn.lasso_prove(P, ch)
+        return els, r, v, bn.lasso_challenge_count(P["nu"])
+
+    def verify_fn(els, ch, layout=None):
+        P = layout or state["P"]
+        r, v, pos = bn.lasso_verify(els, P["nu"], P["mem_dim"], P["mem_cutoff"], ch, partial=True)
+        return r, v, pos, bn.lasso_challenge_count(P["nu"])
+
+    return prove_fn, verify_fn
+
+
 def lasso_polys(p, lasso_in):
     """Integer tables of the Lasso node from the C oracle (orc_lasso_polys) as Python lists, plus lookup_mems."""
     import ctypes as C

@@ -421,3 +421,84 @@ def test_bn254_lasso_node_full_size_accepted_by_the_verifier(ctx):
     bad = list(elems); bad[len(bad) // 3] = (bad[len(bad) // 3] + 1) % bn.R
     with pytest.raises(ValueError):
         bn.lasso_verify(bad, 21, mem_dim, mem_cutoff, chal)
+
+
+# ---- BfvEncrypt::prove over bn256::Fr (hg_witness_from_json_bn254, hg_circuit_eval_bn254, hg_prove_bn254) -------------------
+BN_FIXTURE = os.path.join(orclib.GOLDEN, "bn254_sk_enc_1024_1x27_65537.json")
+
+
+def _elems(proof):
+    return [int.from_bytes(proof[i:i + 32], "big") for i in range(0, len(proof), 32)]
+
+
+def test_bn254_witness_generation_on_the_reference_fixture(ctx):
+    """The reference's own bn254 witness (bfv-gkr/src/data/bn254): loader + Circuit::evaluate over Fr on the device against the
+    Python oracle, and the circuit relation sum == ct0is on the device output."""
+    import json
+    G = orclib.bn254_gkr()
+    bfv = hg.BfvEncrypt.new(1024, 1)
+    pk = bfv.setup(ctx)
+    w = hg.Witness.from_json_bn254(bfv.params, BN_FIXTURE)
+    inputs, ct0is = G.layout_inputs(1024, 1, json.load(open(BN_FIXTURE)))
+    Cc, lasso_in, _, sum_id = G.build_circuit(orclib.constants(1024, 1))
+    vals = G.circuit_evaluate(Cc, inputs)
+    got_sum = ctx.circuit_eval_bn254(pk, w, 0)
+    assert got_sum == vals[sum_id] == ct0is
+    assert ctx.circuit_eval_bn254(pk, w, 1) == vals[lasso_in]
+    assert ctx.circuit_eval_bn254(pk, w, 2) == ct0is
+    # the Goldilocks fixture of the same parameter set is the same integer witness: it proves over Fr as well
+    w_gl = hg.Witness.from_json(bfv.params, os.path.join(orclib.GOLDEN, "sk_enc_1024_1x27_65537.json"))
+    s_gl = ctx.circuit_eval_bn254(pk, w_gl, 0)
+    assert s_gl == ctx.circuit_eval_bn254(pk, w_gl, 2)
+
+
+def test_bn254_prove_bit_exact_on_the_reference_fixture(ctx):
+    """hg_prove_bn254 on the reference's bn254 fixture (n=1024): every proof element equals the Python oracle's; the oracle's
+    verifier accepts it and rejects a tampered copy."""
+    import json
+    G, bn = orclib.bn254_gkr(), orclib.bn254()
+    c = orclib.constants(1024, 1)
+    inputs, ct0is = G.layout_inputs(1024, 1, json.load(open(BN_FIXTURE)))
+    chal = bn.challenges(3000, orclib.keccak256)
+    prove_fn, verify_fn = orclib.bn254_lasso_fns(orclib.params(1024, 1))
+    trace = []
+    expect, _ = G.prove(c, inputs, ct0is, chal, prove_fn, trace)
+    bfv = hg.BfvEncrypt.new(1024, 1)
+    pk = bfv.setup(ctx)
+    w = hg.Witness.from_json_bn254(bfv.params, BN_FIXTURE)
+    proof, wms, pms = ctx.prove_bn254(pk, w)
+    got = _elems(proof)
+    if got != expect:
+        first = next(i for i, (a, b) in enumerate(zip(got, expect)) if a != b) if len(got) == len(expect) else min(len(got), len(expect))
+        where = [t for t in trace if t[0] <= first][-1]
+        pytest.fail("proof differs at element %d (%s, starts at %d); lengths %d / %d" % (first, where[1], where[0], len(got), len(expect)))
+    assert G.verify(c, inputs, ct0is, got, chal, verify_fn)
+    bad = list(got)
+    bad[len(bad) // 2] = (bad[len(bad) // 2] + 1) % G.R
+    with pytest.raises(ValueError):
+        G.verify(c, inputs, ct0is, bad, chal, verify_fn)
+
+
+def test_bn254_prove_synthetic_k2_accepted_by_the_oracle_verifier(ctx):
+    """n=4096 k=2 synthetic witness (alpha claims on the shared inputs, two CRT components): the GPU proof over Fr passes the Python
+    oracle's verifier, including the final input-claim checks against the witness."""
+    G, bn = orclib.bn254_gkr(), orclib.bn254()
+    n, k = 4096, 2
+    bfv = hg.BfvEncrypt.new(n, k)
+    pk = bfv.setup(ctx)
+    w = hg.Witness.synthetic(bfv.params, 77)
+    d = w.arrays()
+    SZ = 2 * n
+    lift = G.lift_signed
+    inputs = [[lift(v) for v in d[f]] for f in ("s", "e", "k1")]
+    inputs += [[lift(v) for v in d["ais"][z * SZ:(z + 1) * SZ]] for z in range(k)]
+    inputs += [[lift(v) for v in d["r1is"][z * SZ:(z + 1) * SZ]] for z in range(k)]
+    inputs.append([lift(v) for v in d["r2is"]])
+    ct0is = [lift(v) for v in d["ct0is"]]
+    proof, wms, pms = ctx.prove_bn254(pk, w)
+    p = orclib.params(n, k)
+    lasso_in = [int(v) for v in ctx.circuit_eval_bn254(pk, w, 1)]
+    layout = orclib.lasso_polys(p, np.array(lasso_in, dtype=np.uint64))
+    _, verify_fn = orclib.bn254_lasso_fns(p)
+    chal = bn.challenges(4000, orclib.keccak256)
+    assert G.verify(orclib.constants(n, k), inputs, ct0is, _elems(proof), chal, lambda e, c: verify_fn(e, c, layout))

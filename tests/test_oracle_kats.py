@@ -339,3 +339,55 @@ def test_bn254_lasso_oracle_verifier_accepts_and_rejects():
         bad[at] = (bad[at] + 1) % bn.R
         with pytest.raises(ValueError):
             bn.lasso_verify(bad, P["nu"], P["mem_dim"], P["mem_cutoff"], chal)
+
+
+# ---- BN254 whole-proof oracle (oracle/bn254_gkr.py) on the reference's own bn254 fixture ---------------------------------------
+def test_bn254_gkr_oracle_on_the_reference_fixture():
+    """bfv-gkr/src/data/bn254/sk_enc_1024_1x27_65537.json: layout + circuit relation (sum == ct0is), prove -> verify round trip,
+    tamper rejection, and the proof has exactly as many elements as the Goldilocks oracle's proof of the same parameter set
+    (same protocol with E = F)."""
+    import json
+    G, bn = orclib.bn254_gkr(), orclib.bn254()
+    n, k = 1024, 1
+    c = orclib.constants(n, k)
+    w = json.load(open(os.path.join(orclib.GOLDEN, "bn254_sk_enc_1024_1x27_65537.json")))
+    inputs, ct0is = G.layout_inputs(n, k, w)
+    Cc, lasso_in, lasso_id, sum_id = G.build_circuit(c)
+    vals = G.circuit_evaluate(Cc, inputs)
+    assert vals[sum_id] == ct0is
+    assert max(vals[lasso_in]) < 1 << 28          # range-shifted lookups are small non-negative integers
+    # the Goldilocks fixture of this parameter set (another sample) is an integer witness too: lifted into Fr it satisfies the relation
+    gl = orclib.fixture_inputs(n, k, 27).d
+    lifted = [[G.lift_signed(v) for v in gl[f]] for f in ("s", "e", "k1", "ais", "r1is", "r2is")]
+    assert G.circuit_evaluate(Cc, lifted)[sum_id] == [G.lift_signed(v) for v in gl["ct0is"]]
+    p = orclib.params(n, k)
+    prove_fn, verify_fn = orclib.bn254_lasso_fns(p)
+    chal = bn.challenges(3000, orclib.keccak256)
+    proof, _ = G.prove(c, inputs, ct0is, chal, prove_fn)
+    gl_proof, _ = orclib.prove(p, orclib.fixture_inputs(n, k, 27))
+    assert len(proof) == len(gl_proof) // 16
+    assert G.verify(c, inputs, ct0is, proof, chal, verify_fn)
+    for at in (0, len(proof) // 2, len(proof) - 1):
+        bad = list(proof)
+        bad[at] = (bad[at] + 1) % G.R
+        with pytest.raises(ValueError):
+            G.verify(c, inputs, ct0is, bad, chal, verify_fn)
+    wrong = list(ct0is)
+    wrong[3] = (wrong[3] + 1) % G.R
+    with pytest.raises(ValueError):
+        G.verify(c, inputs, wrong, proof, chal, verify_fn)
+
+
+def test_bn254_gkr_oracle_fft_and_circuit_pieces():
+    G = orclib.bn254_gkr()
+    bn = orclib.bn254()
+    rng = random.Random(5)
+    a = [rng.randrange(G.R) for _ in range(16)]
+    assert G.ntt(a) == bn.ntt(a) and G.ntt(G.ntt(a), True) == a      # radix-2 vs the O(n^2) definition
+    r = [rng.randrange(G.R) for _ in range(4)]
+    # F(r, x) is the multilinear extension in the output index of the DFT matrix: sum_x F(r,x) a[x] = MLE(ntt(a))(r)
+    F = G.fft_table(r, 4, False)
+    assert sum(f * x for f, x in zip(F, a)) % G.R == G.mle_eval(G.ntt(a), r)
+    Fi = G.fft_table(r, 4, True)
+    assert sum(f * x for f, x in zip(Fi, a)) % G.R == G.mle_eval(G.ntt(a, True), r)
+    assert G.lift_signed(5) == 5 and G.lift_signed(G.GL_P - 7) == G.R - 7
