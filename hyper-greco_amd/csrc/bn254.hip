@@ -376,8 +376,9 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
     size_t need = 1;
     for (int n = 1; n < nv; n++) need += 2 + n;
     const std::vector<Fr> chain = challenge_chain_bn254(chain_skip + need);
-    std::vector<void*> to_free;
-    auto dalloc = [&](size_t n_fr) { Fr* p = nullptr; hipc(hipMalloc((void**)&p, std::max<size_t>(n_fr, 1) * sizeof(Fr)), "hipMalloc"); to_free.push_back(p); return p; };
+    // buffers come from the context's bump arena and are handed back (rewind) when the copy-back has completed
+    const std::vector<size_t> arena_mark = ctx->arena_mark();
+    auto dalloc = [&](size_t n_fr) { return static_cast<Fr*>(ctx->alloc(std::max<size_t>(n_fr, 1) * sizeof(Fr))); };
     struct LayerRec { size_t gamma_at, r_at, mu_at; Fr* d_sums; Fr* d_final; std::vector<Fr> sums, fin; };
     std::vector<LayerRec> layers(nv);
     std::vector<Fr> h_top(2 * nb), h_roots(nb);
@@ -444,10 +445,10 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
         hipc(hipStreamSynchronize(st), "grand_product_bn254: sync");
         hipc(hipGetLastError(), "grand_product_bn254: launch");
     } catch (...) {
-        for (void* p : to_free) (void)hipFree(p);
+        ctx->arena_rewind(arena_mark);
         throw;
     }
-    for (void* p : to_free) (void)hipFree(p);
+    ctx->arena_rewind(arena_mark);
     // transcript replay
     proof.clear();
     std::vector<Fr> claims(nb), x;
@@ -572,8 +573,8 @@ void lasso_prove_bn254(hg_ctx* ctx, const hg_pk* pk, const u64* in4, size_t chai
     const size_t r_at = chain_skip, col_at = r_at + nu, gamma_at = col_at + nu, tau_at = gamma_at + 1, gp1_at = tau_at + 1,
                  gp2_at = gp1_at + gp_challenges(nu), total = gp2_at + gp_challenges(16);
     const std::vector<Fr> chain = challenge_chain_bn254(total);
-    std::vector<void*> to_free;
-    auto dalloc_b = [&](size_t bytes) { void* p = nullptr; hipc(hipMalloc(&p, std::max<size_t>(bytes, 16)), "hipMalloc"); to_free.push_back(p); return p; };
+    const std::vector<size_t> arena_mark = ctx->arena_mark();
+    auto dalloc_b = [&](size_t bytes) { return ctx->alloc(std::max<size_t>(bytes, 16)); };
     auto dalloc = [&](size_t n_fr) { return (Fr*)dalloc_b(n_fr * sizeof(Fr)); };
     auto grid1 = [](size_t n) { return (unsigned)((n + 255) / 256); };
     std::vector<uint8_t> gp1_bytes, gp2_bytes;
@@ -684,10 +685,10 @@ void lasso_prove_bn254(hg_ctx* ctx, const hg_pk* pk, const u64* in4, size_t chai
         }
         hipc(hipGetLastError(), "lasso_prove_bn254: launch");
     } catch (...) {
-        for (void* p : to_free) (void)hipFree(p);
+        ctx->arena_rewind(arena_mark);
         throw;
     }
-    for (void* p : to_free) (void)hipFree(p);
+    ctx->arena_rewind(arena_mark);
     // transcript (lasso.rs:57-114)
     proof.clear();
     write_be32(proof, h_claimed);                                        // :269

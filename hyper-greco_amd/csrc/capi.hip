@@ -503,6 +503,7 @@ int hg_grand_product_bn254(hg_ctx* ctx, size_t nb, size_t len, const uint64_t* c
     HG_TRY
     if (!ctx) throw hg::Error("hg_grand_product_bn254: no context (a HIP device is required)");
     std::vector<uint8_t> bytes;
+    ctx->arena_reset();
     hg::bn::grand_product_bn254(ctx, nb, len, tables, chain_skip, bytes, claims4, point4);
     *proof_len = bytes.size();
     if (bytes.size() > cap) throw hg::Error("proof buffer too small");
@@ -515,6 +516,7 @@ int hg_lasso_prove_bn254(hg_ctx* ctx, const hg_pk* pk, const uint64_t* lasso_in4
     HG_TRY
     if (!ctx || !pk) throw hg::Error("hg_lasso_prove_bn254: null argument (a HIP device is required)");
     std::vector<uint8_t> bytes;
+    ctx->arena_reset();
     hg::bn::lasso_prove_bn254(ctx, pk, lasso_in4, chain_skip, bytes, claim_out4);
     *len = bytes.size();
     if (bytes.size() > cap) throw hg::Error("proof buffer too small");

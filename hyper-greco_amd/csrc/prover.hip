@@ -26,19 +26,30 @@ using namespace hg;
 void* hg_ctx::alloc(size_t bytes) {
     bytes = (bytes + 255) & ~(size_t)255;
     if (bytes == 0) bytes = 256;
+    auto note = [this] { size_t u = 0; for (auto& c : chunks) u += c.used; arena_high = std::max(arena_high, u); };
     for (auto& c : chunks)
-        if (c.cap - c.used >= bytes) { void* p = c.p + c.used; c.used += bytes; return p; }
+        if (c.cap - c.used >= bytes) { void* p = c.p + c.used; c.used += bytes; note(); return p; }
     size_t cap = std::max<size_t>(bytes, (size_t)512 << 20);
     char* p = nullptr;
     hip_check(hipMalloc((void**)&p, cap), "hipMalloc(arena chunk)");
     chunks.push_back({p, cap, bytes});
     arena_total += cap;
+    note();
     return p;
+}
+std::vector<size_t> hg_ctx::arena_mark() const {
+    std::vector<size_t> m;
+    for (auto& c : chunks) m.push_back(c.used);
+    return m;
+}
+void hg_ctx::arena_rewind(const std::vector<size_t>& mark) {
+    for (size_t i = 0; i < chunks.size(); i++) chunks[i].used = i < mark.size() ? mark[i] : 0;
 }
 void hg_ctx::arena_reset() {
     // coalesce into one chunk once the high-water mark is known, so later proves never call hipMalloc
     size_t used = 0;
     for (auto& c : chunks) used += c.used;
+    used = std::max(used, arena_high);
     if (chunks.size() > 1) {
         hip_check(hipStreamSynchronize(stream), "sync before arena coalesce");
         for (auto& c : chunks) (void)hipFree(c.p);
@@ -48,6 +59,7 @@ void hg_ctx::arena_reset() {
         hip_check(hipMalloc((void**)&p, cap), "hipMalloc(arena)");
         chunks.push_back({p, cap, 0});
         arena_total = cap;
+        arena_high = 0;
     }
     for (auto& c : chunks) c.used = 0;
     stage_used = 0;

@@ -29,6 +29,11 @@ struct hg_ctx {
     void* alloc(size_t bytes);
     template <typename T> T* alloc_n(size_t n) { return static_cast<T*>(alloc(n * sizeof(T))); }
     void arena_reset();
+    // nested scopes inside one prove (BN254 path): snapshot of the per-chunk offsets, restored when the scope's buffers are dead
+    // (single stream: later users of the recycled bytes are ordered after the earlier ones)
+    std::vector<size_t> arena_mark() const;
+    void arena_rewind(const std::vector<size_t>& mark);
+    size_t arena_high = 0;  // high-water mark since the last coalesce
     // challenge chain in HBM (as E2 pairs)
     hg::E2* d_chal = nullptr;
     size_t chal_e = 0;
