@@ -39,7 +39,7 @@ EXPORTS = [
     "hg_last_error", "hg_device_count", "hg_create", "hg_destroy", "hg_params_builtin", "hg_setup", "hg_pk_free",
     "hg_pk_lasso_layout", "hg_pk_info", "hg_witness_from_json", "hg_witness_synthetic", "hg_witness_from_arrays",
     "hg_witness_get", "hg_witness_free", "hg_prove", "hg_verify", "hg_witness_gen", "hg_values_free", "hg_values_get", "hg_prove_shard_begin", "hg_prove_shard_combine", "hg_prove_shard_finish", "hg_prove_resident", "hg_circuit_eval", "hg_lasso_prove", "hg_lasso_prove_at", "hg_sumcheck", "hg_mle_eval",
-    "hg_ntt", "hg_challenges", "hg_challenges_bn254", "hg_bn254_field_op", "hg_sumcheck_bn254", "hg_grand_product_bn254", "hg_lasso_prove_bn254", "hg_witness_from_json_bn254", "hg_circuit_eval_bn254", "hg_prove_bn254", "hg_mle_eval_bn254", "hg_ntt_bn254", "hg_profile", "hg_profile_select", "hg_profile_reset", "hg_profile_get",
+    "hg_ntt", "hg_challenges", "hg_challenges_bn254", "hg_bn254_field_op", "hg_sumcheck_bn254", "hg_grand_product_bn254", "hg_lasso_prove_bn254", "hg_witness_from_json_bn254", "hg_circuit_eval_bn254", "hg_prove_bn254", "hg_verify_bn254", "hg_mle_eval_bn254", "hg_ntt_bn254", "hg_profile", "hg_profile_select", "hg_profile_reset", "hg_profile_get",
 ]
 
 
@@ -85,6 +85,7 @@ def lib():
         L.hg_prove_shard_combine.argtypes = [C.c_void_p, u64p, C.c_int, C.c_size_t]
         L.hg_prove_shard_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(HgTimings)]
         L.hg_verify.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
+        L.hg_verify_bn254.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
         L.hg_circuit_eval.argtypes = [C.c_void_p, C.c_void_p, u64p, C.c_size_t, u64p, C.c_size_t]
         L.hg_lasso_prove.argtypes = [C.c_void_p, C.c_void_p, u64p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), u64p]
         L.hg_lasso_prove_at.argtypes = [C.c_void_p, C.c_void_p, u64p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), u64p]
@@ -480,6 +481,14 @@ def challenges_bn254(n):
 def verify(pk, witness, proof):
     """BfvEncrypt::verify [REF sk_encryption_circuit.rs:462-517]: (accepted, reason)."""
     rc = lib().hg_verify(pk.h, witness.h, proof, len(proof))
+    if rc < 0:
+        raise HgError(lib().hg_last_error().decode())
+    return rc == 0, ("" if rc == 0 else lib().hg_last_error().decode())
+
+
+def verify_bn254(pk, witness, proof):
+    """BfvEncrypt::verify over bn256::Fr [REF sk_encryption_circuit.rs:462-517, 614-626]: (accepted, reason)."""
+    rc = lib().hg_verify_bn254(pk.h, witness.h, proof, len(proof))
     if rc < 0:
         raise HgError(lib().hg_last_error().decode())
     return rc == 0, ("" if rc == 0 else lib().hg_last_error().decode())

@@ -406,6 +406,16 @@ int hg_verify(const hg_pk* pk, const hg_witness* w, const uint8_t* proof, size_t
     HG_CATCH(-1)
 }
 
+int hg_verify_bn254(const hg_pk* pk, const hg_witness* w, const uint8_t* proof, size_t len) {
+    HG_TRY
+    if (!pk || !w || !proof) throw Error("hg_verify_bn254: null argument");
+    std::string why = verify_proof_bn254(pk->params, pk->lasso, pk->circuit, w->w, proof, len);
+    if (why.empty()) return 0;
+    g_last_error = why;
+    return 1;
+    HG_CATCH(-1)
+}
+
 int hg_circuit_eval(const hg_pk* pk, const hg_witness* w, uint64_t* lasso_in, size_t lasso_cap, uint64_t* sum_out, size_t sum_cap) {
     HG_TRY
     auto vals = circuit_evaluate(pk->circuit, pk->params, w->w);

@@ -139,6 +139,8 @@ HCircuit build_circuit(const Params& p, const LassoPlan& lp);
 std::vector<std::vector<u64>> circuit_evaluate(const HCircuit& c, const Params& p, const Witness& w);
 // BfvEncrypt::verify on the host; "" = accept, otherwise the rejection reason (verifier.cpp)
 std::string verify_proof(const Params& p, const LassoPlan& lp, const HCircuit& c, const Witness& w, const uint8_t* proof, size_t len);
+// the same over bn256::Fr (F = E = Fr, 32-byte proof elements): the bn254 test family
+std::string verify_proof_bn254(const Params& p, const LassoPlan& lp, const HCircuit& c, const Witness& w, const uint8_t* proof, size_t len);
 void ntt_host(u64* a, int log2n, bool inverse);  // in place, natural order
 u64 root_of_unity(int log2n);                    // 2^log2n-th root from ROOT_OF_UNITY = 7^((p-1)/2^32)
 

@@ -5,9 +5,12 @@
 // this file is the product's own implementation (independent of the test-only CPU restatement).
 // The Vanilla / FFT node checks mirror the prover's conventions (the external `gkr`
 // crate is unpinned).
+// One template, two fields: GlField (F = Goldilocks, E = GoldilocksExt2: the `goldilocks` test family) and BnField
+// (F = E = bn256::Fr: the `bn254` test family, sk_encryption_circuit.rs:614-626).
 #include <cstring>
 #include <functional>
 #include "host.hpp"
+#include "bn254.cuh"
 
 namespace hg {
 
@@ -15,98 +18,182 @@ namespace {
 
 struct Reject : std::runtime_error { using std::runtime_error::runtime_error; };
 
-struct ProofReader {
+struct ProofBytes {
     const uint8_t* p; size_t len; size_t pos = 0;
-    u64 read_f() {  // read_felt (transcript.rs:162-170): 8 bytes big-endian, canonical
-        if (pos + 8 > len) throw Reject("proof: unexpected end of stream");
-        u64 a = 0;
-        for (int i = 0; i < 8; i++) a = (a << 8) | p[pos + i];
-        pos += 8;
-        if (a >= GL_P) throw Reject("proof: invalid field element");
-        return a;
+    const uint8_t* take(size_t n) {
+        if (pos + n > len) throw Reject("proof: unexpected end of stream");
+        const uint8_t* q = p + pos;
+        pos += n;
+        return q;
     }
-    E2 read_e() { u64 a = read_f(); u64 b = read_f(); return e2(a, b); }
-    std::vector<E2> read_es(size_t n) { std::vector<E2> v(n); for (auto& x : v) x = read_e(); return v; }
 };
 
-struct Claim { std::vector<E2> point; E2 value; };
+// ---- the two fields ---------------------------------------------------------------------------------------------
+struct GlField {
+    typedef E2 E;
+    static E zero() { return e2_zero(); }
+    static E one() { return e2_one(); }
+    static E add(E a, E b) { return e2_add(a, b); }
+    static E sub(E a, E b) { return e2_sub(a, b); }
+    static E mul(E a, E b) { return e2_mul(a, b); }
+    static bool eq(E a, E b) { return e2_eq(a, b); }
+    static E from_u(u64 c) { return e2(gl_from_u64(c), 0); }       // a non-negative integer constant
+    static E mul_u(E a, u64 c) { return e2_mul_f(a, gl_from_u64(c)); }
+    static E mul_table(E a, u64 v) { return e2_mul_f(a, v); }       // a * (witness table entry, a canonical base element)
+    static E base0(E c) { return e2(c.c0, 0); }                     // as_bases()[0] (verifier.rs:139-140)
+    static E inv_u(u64 c) { return e2(gl_inv(gl_from_u64(c)), 0); }
+    static E root(int L, bool inverse) { u64 w = root_of_unity(L); return e2(inverse ? gl_inv(w) : w, 0); }
+    static E read(ProofBytes& b) {  // read_felt (transcript.rs:162-170): 8 bytes big-endian, canonical; two bases per element
+        u64 c[2];
+        for (int h = 0; h < 2; h++) {
+            const uint8_t* q = b.take(8);
+            u64 a = 0;
+            for (int i = 0; i < 8; i++) a = (a << 8) | q[i];
+            if (a >= GL_P) throw Reject("proof: invalid field element");
+            c[h] = a;
+        }
+        return e2(c[0], c[1]);
+    }
+    struct Chal {
+        ChallengeSource src;
+        E squeeze() { return src.squeeze(); }
+    };
+};
 
-std::vector<E2> eq_table(const std::vector<E2>& r) {
-    std::vector<E2> t((size_t)1 << r.size());
-    t[0] = e2_one();
+struct BnField {  // elements in Montgomery form
+    typedef bn::Fr E;
+    static E zero() { return bn::fr_zero(); }
+    static E one() { return bn::fr_one_mont(); }
+    static E add(E a, E b) { return bn::fr_add(a, b); }
+    static E sub(E a, E b) { return bn::fr_sub(a, b); }
+    static E mul(E a, E b) { return bn::fr_mul(a, b); }
+    static bool eq(E a, E b) { return bn::fr_eq(a, b); }
+    static E from_u(u64 c) { return bn::fr_to_mont(bn::fr_make(c, 0, 0, 0)); }
+    static E mul_u(E a, u64 c) { return bn::fr_mul(a, from_u(c)); }
+    // witness entries are small signed integers kept in the Goldilocks form (host.cpp: witness_from_json_bn254)
+    static E mul_table(E a, u64 v) { return v < (1ULL << 63) ? bn::fr_mul(a, from_u(v)) : bn::fr_sub(zero(), bn::fr_mul(a, from_u(GL_P - v))); }
+    static E base0(E c) { return c; }
+    static E pow(E b, const u64 e[4]) {
+        E r = one();
+        for (int w = 3; w >= 0; w--)
+            for (int bit = 63; bit >= 0; bit--) { r = mul(r, r); if ((e[w] >> bit) & 1) r = mul(r, b); }
+        return r;
+    }
+    static E inv(E a) { const u64 e[4] = {bn::FR_P0 - 2, bn::FR_P1, bn::FR_P2, bn::FR_P3}; return pow(a, e); }
+    static E inv_u(u64 c) { return inv(from_u(c)); }
+    static E root(int L, bool inverse) {  // halo2curves ROOT_OF_UNITY = 7^((r-1)/2^28), squared down to order 2^L
+        if (L > 28) throw Reject("bn254: two-adicity is 28");
+        E w = bn::fr_to_mont(bn::fr_make(0xd34f1ed960c37c9cULL, 0x3215cf6dd39329c8ULL, 0x98865ea93dd31f74ULL, 0x03ddb9f5166d18b7ULL));
+        for (int i = L; i < 28; i++) w = mul(w, w);
+        return inverse ? inv(w) : w;
+    }
+    static E read(ProofBytes& b) {  // 32 bytes big-endian, canonical (transcript.rs:162-170, 183-189)
+        const uint8_t* q = b.take(32);
+        bn::Fr v;
+        for (int w = 0; w < 4; w++) {
+            u64 a = 0;
+            for (int i = 0; i < 8; i++) a = (a << 8) | q[8 * (3 - w) + i];
+            v.l[w] = a;
+        }
+        if (bn::fr_geq_p(v)) throw Reject("proof: invalid field element");
+        return bn::fr_to_mont(v);
+    }
+    struct Chal {  // c_j = LE(Keccak^j("")) mod r (transcript.rs:146-157, 198-203); one element per squeeze (E = F)
+        uint8_t h[32];
+        Chal() { keccak256(nullptr, 0, h); }
+        E squeeze() {
+            bn::Fr v;
+            memcpy(v.l, h, 32);
+            while (bn::fr_geq_p(v)) v = bn::fr_sub_p(v);
+            uint8_t nx[32];
+            keccak256(h, 32, nx);
+            memcpy(h, nx, 32);
+            return bn::fr_to_mont(v);
+        }
+    };
+};
+
+template <class F> std::vector<typename F::E> eq_table(const std::vector<typename F::E>& r) {
+    typedef typename F::E E;
+    std::vector<E> t((size_t)1 << r.size());
+    t[0] = F::one();
     size_t s = 1;
     for (size_t i = 0; i < r.size(); i++) {
-        for (size_t j = 0; j < s; j++) { E2 hi = e2_mul(t[j], r[i]); t[j + s] = hi; t[j] = e2_sub(t[j], hi); }
+        for (size_t j = 0; j < s; j++) { E hi = F::mul(t[j], r[i]); t[j + s] = hi; t[j] = F::sub(t[j], hi); }
         s <<= 1;
     }
     return t;
 }
-E2 mle_eval(const u64* tab, const std::vector<E2>& pt) {
-    std::vector<E2> eq = eq_table(pt);
-    u64 c0 = 0, c1 = 0;
-    for (size_t j = 0; j < eq.size(); j++) {
-        u64 v = tab[j];
-        if (v) { c0 = gl_add(c0, gl_mul(eq[j].c0, v)); c1 = gl_add(c1, gl_mul(eq[j].c1, v)); }
-    }
-    return e2(c0, c1);
+template <class F> typename F::E mle_eval(const u64* tab, const std::vector<typename F::E>& pt) {
+    typedef typename F::E E;
+    std::vector<E> eq = eq_table<F>(pt);
+    E acc = F::zero();
+    for (size_t j = 0; j < eq.size(); j++)
+        if (tab[j]) acc = F::add(acc, F::mul_table(eq[j], tab[j]));
+    return acc;
 }
-E2 horner(const std::vector<E2>& c, E2 x) {
-    E2 r = e2_zero();
-    for (size_t i = c.size(); i-- > 0;) r = e2_add(e2_mul(r, x), c[i]);
+template <class F> typename F::E horner(const std::vector<typename F::E>& c, typename F::E x) {
+    typename F::E r = F::zero();
+    for (size_t i = c.size(); i-- > 0;) r = F::add(F::mul(r, x), c[i]);
     return r;
 }
 
-struct Verifier {
-    ProofReader rd;
-    ChallengeSource ch;
+template <class F> struct Verifier {
+    typedef typename F::E E;
+    struct Claim { std::vector<E> point; E value; };
+    ProofBytes bytes;
+    typename F::Chal ch;
+    E read_e() { return F::read(bytes); }
+    std::vector<E> read_es(size_t n) { std::vector<E> v(n); for (auto& x : v) x = read_e(); return v; }
+    std::vector<E> squeeze_n(size_t n) { std::vector<E> v(n); for (auto& x : v) x = ch.squeeze(); return v; }
 
     // verify_sum_check: d+1 coefficients per round, 2 c0 + c1 + .. + cd == claim, claim <- p(r)
-    std::pair<E2, std::vector<E2>> sumcheck(int deg, int nvars, E2 claim) {
-        std::vector<E2> point;
+    std::pair<E, std::vector<E>> sumcheck(int deg, int nvars, E claim) {
+        std::vector<E> point;
         for (int i = 0; i < nvars; i++) {
-            std::vector<E2> c = rd.read_es(deg + 1);
-            E2 s = e2_dbl(c[0]);
-            for (int k = 1; k <= deg; k++) s = e2_add(s, c[k]);
-            if (!e2_eq(s, claim)) throw Reject("InvalidSumCheck: round polynomial does not match the running claim");
-            E2 r = ch.squeeze();
-            claim = horner(c, r);
+            std::vector<E> c = read_es(deg + 1);
+            E s = F::add(c[0], c[0]);
+            for (int k = 1; k <= deg; k++) s = F::add(s, c[k]);
+            if (!F::eq(s, claim)) throw Reject("InvalidSumCheck: round polynomial does not match the running claim");
+            E r = ch.squeeze();
+            claim = horner<F>(c, r);
             point.push_back(r);
         }
         return {claim, point};
     }
 
     // verify_grand_product (verifier.rs:178-235)
-    std::pair<std::vector<E2>, std::vector<E2>> grand_product(int num_vars, int nb) {
-        std::vector<E2> claims = rd.read_es(nb);
-        std::vector<E2> x;
+    std::pair<std::vector<E>, std::vector<E>> grand_product(int num_vars, int nb) {
+        std::vector<E> claims = read_es(nb);
+        std::vector<E> x;
         for (int n = 0; n < num_vars; n++) {
-            std::vector<E2> evals;
+            std::vector<E> evals;
             if (n == 0) {
-                evals = rd.read_es(2 * (size_t)nb);
+                evals = read_es(2 * (size_t)nb);
                 for (int b = 0; b < nb; b++)
-                    if (!e2_eq(claims[b], e2_mul(evals[2 * b], evals[2 * b + 1]))) throw Reject("InvalidSumCheck: unmatched sum check output");
+                    if (!F::eq(claims[b], F::mul(evals[2 * b], evals[2 * b + 1]))) throw Reject("InvalidSumCheck: unmatched sum check output");
                 x.clear();
             } else {
-                E2 gamma = ch.squeeze();
-                E2 claim = e2_zero(), g = e2_one();
-                for (int b = 0; b < nb; b++) { claim = e2_add(claim, e2_mul(claims[b], g)); g = e2_mul(g, gamma); }
+                E gamma = ch.squeeze();
+                E claim = F::zero(), g = F::one();
+                for (int b = 0; b < nb; b++) { claim = F::add(claim, F::mul(claims[b], g)); g = F::mul(g, gamma); }
                 auto r = sumcheck(3, n, claim);
                 x = r.second;
-                evals = rd.read_es(2 * (size_t)nb);
+                evals = read_es(2 * (size_t)nb);
             }
-            E2 mu = ch.squeeze();
-            for (int b = 0; b < nb; b++) claims[b] = e2_add(evals[2 * b], e2_mul(mu, e2_sub(evals[2 * b + 1], evals[2 * b])));
+            E mu = ch.squeeze();
+            for (int b = 0; b < nb; b++) claims[b] = F::add(evals[2 * b], F::mul(mu, F::sub(evals[2 * b + 1], evals[2 * b])));
             x.push_back(mu);
         }
         return {claims, x};
     }
 
     // sub-table MLE closed forms (range.rs:19-26, 74-112)
-    static E2 subtable_mle(u64 bound, const std::vector<E2>& y) {
-        E2 result = e2_zero();
+    static E subtable_mle(u64 bound, const std::vector<E>& y) {
+        E result = F::zero();
         const size_t b = y.size();
         if (bound == 0) {
-            for (size_t i = 0; i < b; i++) result = e2_add(result, e2_mul_f(y[i], 1ULL << i));
+            for (size_t i = 0; i < b; i++) result = F::add(result, F::mul_u(y[i], 1ULL << i));
             return result;
         }
         int bits = 63 - __builtin_clzll(bound);
@@ -114,141 +201,140 @@ struct Verifier {
         int cl2 = 63 - __builtin_clzll(cutoff);
         u64 g_base = 1ULL << cl2, extra = cutoff - g_base;
         for (size_t i = 0; i < b; i++) {
-            if ((int)i < cl2) { result = e2_add(result, e2_mul_f(y[i], 1ULL << i)); continue; }
-            E2 g_value = e2_zero();
+            if ((int)i < cl2) { result = F::add(result, F::mul_u(y[i], 1ULL << i)); continue; }
+            E g_value = F::zero();
             if ((int)i == cl2)
                 for (u64 k = 0; k < extra; k++) {
-                    E2 term = e2(gl_from_u64(g_base + k), 0);
-                    for (int j = 0; j < cl2; j++) term = e2_mul(term, (k >> j) & 1 ? y[j] : e2_sub(e2_one(), y[j]));
-                    g_value = e2_add(g_value, term);
+                    E term = F::from_u(g_base + k);
+                    for (int j = 0; j < cl2; j++) term = F::mul(term, (k >> j) & 1 ? y[j] : F::sub(F::one(), y[j]));
+                    g_value = F::add(g_value, term);
                 }
-            result = e2_add(e2_mul(e2_sub(e2_one(), y[i]), result), e2_mul(y[i], g_value));
+            result = F::add(F::mul(F::sub(F::one(), y[i]), result), F::mul(y[i], g_value));
         }
         return result;
     }
 
     Claim lasso(const LassoPlan& lp) {  // lasso.rs:116-139
-        std::vector<E2> r = ch.squeeze_n(lp.nu);
-        E2 claimed = rd.read_e();
+        std::vector<E> r = squeeze_n(lp.nu);
+        E claimed = read_e();
         sumcheck(2, lp.nu, claimed);  // collation: final evaluation not checked by the reference either (lasso.rs:129-130)
-        E2 ge = ch.squeeze(), te = ch.squeeze();
-        const u64 gamma = ge.c0, tau = te.c0, gamma2 = gl_mul(gamma, gamma);  // verifier.rs:139-140
-        auto hash = [&](E2 a, E2 v, E2 t) { return e2_sub_f(e2_add(e2_add(a, e2_mul_f(v, gamma)), e2_mul_f(t, gamma2)), tau); };
+        const E gamma = F::base0(ch.squeeze()), tau = F::base0(ch.squeeze()), gamma2 = F::mul(gamma, gamma);  // verifier.rs:139-140
+        auto hash = [&](E a, E v, E t) { return F::sub(F::add(F::add(a, F::mul(v, gamma)), F::mul(t, gamma2)), tau); };
         const int A = lp.alpha;
         auto rw = grand_product(lp.nu, 2 * A);
         auto ifr = grand_product(LassoPlan::LOGM, 2 * A);
-        const std::vector<E2>& y = ifr.second;
-        E2 id_y = e2_zero();
-        for (size_t i = 0; i < y.size(); i++) id_y = e2_add(id_y, e2_mul_f(y[i], 1ULL << i));
+        const std::vector<E>& y = ifr.second;
+        E id_y = F::zero();
+        for (size_t i = 0; i < y.size(); i++) id_y = F::add(id_y, F::mul_u(y[i], 1ULL << i));
         int off = 0;
         for (auto& chk : lp.chunks) {  // verify_memories (verifier.rs:61-95)
             const int nm = (int)chk.second.size();
-            E2 dim_x = rd.read_e(), rts_x = rd.read_e(), fct_y = rd.read_e();
-            std::vector<E2> e_xs = rd.read_es(nm);
+            E dim_x = read_e(), rts_x = read_e(), fct_y = read_e();
+            std::vector<E> e_xs = read_es(nm);
             for (int i = 0; i < nm; i++) {
                 int m = chk.second[i];
-                if (!e2_eq(rw.first[off + i], hash(dim_x, e_xs[i], rts_x))) throw Reject("memory check: read hash mismatch");
-                if (!e2_eq(rw.first[A + off + i], hash(dim_x, e_xs[i], e2_add_f(rts_x, 1)))) throw Reject("memory check: write hash mismatch");
-                E2 st = subtable_mle(lp.subtable_bound[lp.mems[m].subtable], y);
-                if (!e2_eq(ifr.first[off + i], hash(id_y, st, e2_zero()))) throw Reject("memory check: init hash mismatch");
-                if (!e2_eq(ifr.first[A + off + i], hash(id_y, st, fct_y))) throw Reject("memory check: final hash mismatch");
+                if (!F::eq(rw.first[off + i], hash(dim_x, e_xs[i], rts_x))) throw Reject("memory check: read hash mismatch");
+                if (!F::eq(rw.first[A + off + i], hash(dim_x, e_xs[i], F::add(rts_x, F::one())))) throw Reject("memory check: write hash mismatch");
+                E st = subtable_mle(lp.subtable_bound[lp.mems[m].subtable], y);
+                if (!F::eq(ifr.first[off + i], hash(id_y, st, F::zero()))) throw Reject("memory check: init hash mismatch");
+                if (!F::eq(ifr.first[A + off + i], hash(id_y, st, fct_y))) throw Reject("memory check: final hash mismatch");
             }
             off += nm;
         }
         return Claim{r, claimed};
     }
 
-    static std::vector<E2> combined_eq(const std::vector<Claim>& cl, const std::vector<E2>& alpha) {
-        std::vector<E2> eqc = eq_table(cl[0].point);
+    static std::vector<E> combined_eq(const std::vector<Claim>& cl, const std::vector<E>& alpha) {
+        std::vector<E> eqc = eq_table<F>(cl[0].point);
         if (cl.size() == 1) return eqc;
-        for (auto& x : eqc) x = e2_mul(x, alpha[0]);
+        for (auto& x : eqc) x = F::mul(x, alpha[0]);
         for (size_t a = 1; a < cl.size(); a++) {
-            std::vector<E2> t = eq_table(cl[a].point);
-            for (size_t i = 0; i < t.size(); i++) eqc[i] = e2_add(eqc[i], e2_mul(t[i], alpha[a]));
+            std::vector<E> t = eq_table<F>(cl[a].point);
+            for (size_t i = 0; i < t.size(); i++) eqc[i] = F::add(eqc[i], F::mul(t[i], alpha[a]));
         }
         return eqc;
     }
 
-    std::vector<std::vector<Claim>> vanilla(const HNode& n, const std::vector<Claim>& cl, const std::vector<E2>& alpha) {
+    std::vector<std::vector<Claim>> vanilla(const HNode& n, const std::vector<Claim>& cl, const std::vector<E>& alpha) {
         const size_t G = (size_t)1 << n.log2_sub_out, S = (size_t)1 << n.log2_sub_in, R = (size_t)1 << n.log2_reps;
         const int nin = n.log2_sub_in + n.log2_reps;
-        std::vector<E2> eqc = combined_eq(cl, alpha);
-        E2 claim = e2_zero();
-        for (size_t a = 0; a < cl.size(); a++) claim = e2_add(claim, e2_mul(cl[a].value, alpha[a]));
-        for (size_t rep = 0; rep < R; rep++) for (auto& t : n.w0) claim = e2_sub(claim, e2_mul_f(eqc[rep * G + t.gate], t.c));
+        std::vector<E> eqc = combined_eq(cl, alpha);
+        E claim = F::zero();
+        for (size_t a = 0; a < cl.size(); a++) claim = F::add(claim, F::mul(cl[a].value, alpha[a]));
+        for (size_t rep = 0; rep < R; rep++) for (auto& t : n.w0) claim = F::sub(claim, F::mul_u(eqc[rep * G + t.gate], t.c));
         auto r1 = sumcheck(2, nin, claim);
-        std::vector<E2> u(n.arity, e2_zero());
+        std::vector<E> u(n.arity, F::zero());
         std::vector<std::vector<Claim>> sub(n.arity);
-        for (int i = 0; i < n.arity; i++) if (n.left_use[i]) { u[i] = rd.read_e(); sub[i].push_back(Claim{r1.second, u[i]}); }
-        std::vector<E2> eqx = eq_table(r1.second);
-        E2 lin = e2_zero();
+        for (int i = 0; i < n.arity; i++) if (n.left_use[i]) { u[i] = read_e(); sub[i].push_back(Claim{r1.second, u[i]}); }
+        std::vector<E> eqx = eq_table<F>(r1.second);
+        E lin = F::zero();
         for (size_t rep = 0; rep < R; rep++)
-            for (auto& t : n.lin) lin = e2_add(lin, e2_mul(u[t.in], e2_mul(e2_mul_f(eqc[rep * G + t.gate], t.c), eqx[rep * S + t.j])));
+            for (auto& t : n.lin) lin = F::add(lin, F::mul(u[t.in], F::mul(F::mul_u(eqc[rep * G + t.gate], t.c), eqx[rep * S + t.j])));
         if (n.mul.empty()) {
-            if (!e2_eq(r1.first, lin)) throw Reject("vanilla node: final evaluation mismatch");
+            if (!F::eq(r1.first, lin)) throw Reject("vanilla node: final evaluation mismatch");
             return sub;
         }
-        auto r2 = sumcheck(2, nin, e2_sub(r1.first, lin));
-        std::vector<E2> w(n.arity, e2_zero());
-        for (int i = 0; i < n.arity; i++) if (n.right_use[i]) { w[i] = rd.read_e(); sub[i].push_back(Claim{r2.second, w[i]}); }
-        std::vector<E2> eqy = eq_table(r2.second);
-        E2 fin = e2_zero();
+        auto r2 = sumcheck(2, nin, F::sub(r1.first, lin));
+        std::vector<E> w(n.arity, F::zero());
+        for (int i = 0; i < n.arity; i++) if (n.right_use[i]) { w[i] = read_e(); sub[i].push_back(Claim{r2.second, w[i]}); }
+        std::vector<E> eqy = eq_table<F>(r2.second);
+        E fin = F::zero();
         for (size_t rep = 0; rep < R; rep++)
             for (auto& t : n.mul)
-                fin = e2_add(fin, e2_mul(e2_mul(w[t.i1], u[t.i0]), e2_mul(e2_mul(e2_mul_f(eqc[rep * G + t.gate], t.c), eqx[rep * S + t.j0]), eqy[rep * S + t.j1])));
-        if (!e2_eq(r2.first, fin)) throw Reject("vanilla node: phase-2 final evaluation mismatch");
+                fin = F::add(fin, F::mul(F::mul(w[t.i1], u[t.i0]), F::mul(F::mul(F::mul_u(eqc[rep * G + t.gate], t.c), eqx[rep * S + t.j0]), eqy[rep * S + t.j1])));
+        if (!F::eq(r2.first, fin)) throw Reject("vanilla node: phase-2 final evaluation mismatch");
         return sub;
     }
 
     // F(r, x) = scale * prod_b (1 + r_b (w^(2^b x) - 1)), built in O(N): factor b depends on x mod 2^(L-b)
-    static std::vector<E2> fft_row(const std::vector<E2>& r, int L, bool inverse) {
+    static std::vector<E> fft_row(const std::vector<E>& r, int L, bool inverse) {
         const size_t N = (size_t)1 << L;
-        u64 w = root_of_unity(L);
-        if (inverse) w = gl_inv(w);
-        std::vector<u64> W(N);
-        W[0] = 1;
-        for (size_t i = 1; i < N; i++) W[i] = gl_mul(W[i - 1], w);
-        std::vector<E2> cur(1, inverse ? e2(gl_inv(gl_from_u64(N)), 0) : e2_one());
+        const E w = F::root(L, inverse);
+        std::vector<E> W(N);
+        W[0] = F::one();
+        for (size_t i = 1; i < N; i++) W[i] = F::mul(W[i - 1], w);
+        std::vector<E> cur(1, inverse ? F::inv_u((u64)N) : F::one());
         for (int b = L - 1; b >= 0; b--) {
             const size_t sz = (size_t)1 << (L - b);
-            std::vector<E2> nxt(sz);
+            std::vector<E> nxt(sz);
             for (size_t x = 0; x < sz; x++) {
-                E2 f = e2_add_f(e2_mul_f(r[b], gl_sub(W[(x << b) & (N - 1)], 1)), 1);
-                nxt[x] = e2_mul(cur[x & (sz / 2 - 1)], f);
+                E f = F::add(F::mul(r[b], F::sub(W[(x << b) & (N - 1)], F::one())), F::one());
+                nxt[x] = F::mul(cur[x & (sz / 2 - 1)], f);
             }
             cur.swap(nxt);
         }
         return cur;
     }
 
-    std::vector<std::vector<Claim>> fft(const HNode& n, const std::vector<Claim>& cl, const std::vector<E2>& alpha) {
-        E2 claim = e2_zero();
-        for (size_t a = 0; a < cl.size(); a++) claim = e2_add(claim, e2_mul(cl[a].value, alpha[a]));
+    std::vector<std::vector<Claim>> fft(const HNode& n, const std::vector<Claim>& cl, const std::vector<E>& alpha) {
+        E claim = F::zero();
+        for (size_t a = 0; a < cl.size(); a++) claim = F::add(claim, F::mul(cl[a].value, alpha[a]));
         auto r = sumcheck(2, n.log2_size, claim);
-        E2 u = rd.read_e();
-        std::vector<E2> eqx = eq_table(r.second);
-        E2 fr = e2_zero();
+        E u = read_e();
+        std::vector<E> eqx = eq_table<F>(r.second);
+        E fr = F::zero();
         for (size_t a = 0; a < cl.size(); a++) {
-            std::vector<E2> F = fft_row(cl[a].point, n.log2_size, n.inverse);
-            E2 s = e2_zero();
-            for (size_t x = 0; x < F.size(); x++) s = e2_add(s, e2_mul(F[x], eqx[x]));
-            fr = e2_add(fr, e2_mul(s, alpha[a]));
+            std::vector<E> row = fft_row(cl[a].point, n.log2_size, n.inverse);
+            E s = F::zero();
+            for (size_t x = 0; x < row.size(); x++) s = F::add(s, F::mul(row[x], eqx[x]));
+            fr = F::add(fr, F::mul(s, alpha[a]));
         }
-        if (!e2_eq(r.first, e2_mul(u, fr))) throw Reject("fft node: final evaluation mismatch");
+        if (!F::eq(r.first, F::mul(u, fr))) throw Reject("fft node: final evaluation mismatch");
         return {{Claim{r.second, u}}};
     }
 };
 
-}  // namespace
 
-// returns "" on accept, the rejection reason otherwise
-std::string verify_proof(const Params& p, const LassoPlan& lp, const HCircuit& c, const Witness& w, const uint8_t* proof, size_t len) {
+template <class F>
+static std::string verify_impl(const Params& p, const LassoPlan& lp, const HCircuit& c, const Witness& w, const uint8_t* proof, size_t len) {
+    typedef typename F::E E;
+    typedef typename Verifier<F>::Claim Claim;
     try {
-        Verifier V{ProofReader{proof, len}, ChallengeSource{}};
-        std::vector<E2> point = V.ch.squeeze_n(p.ct0is_log2());     // sk_encryption_circuit.rs:482
-        E2 value = mle_eval(w.ct0is.data(), point);                 // :495
+        Verifier<F> V{ProofBytes{proof, len}, typename F::Chal{}};
+        std::vector<E> point = V.squeeze_n(p.ct0is_log2());         // sk_encryption_circuit.rs:482
+        E value = mle_eval<F>(w.ct0is.data(), point);               // :495
         std::vector<std::vector<Claim>> claims(c.nodes.size());
-        claims[c.lasso_id].push_back(Claim{{}, e2_zero()});         // :500
+        claims[c.lasso_id].push_back(Claim{{}, F::zero()});         // :500
         claims[c.sum_id].push_back(Claim{point, value});
         for (size_t q = c.topo.size(); q-- > 0;) {                  // verify_gkr :509-510
             int id = c.topo[q];
@@ -256,13 +342,14 @@ std::string verify_proof(const Params& p, const LassoPlan& lp, const HCircuit& c
             if (n.kind == NK_INPUT) continue;
             const std::vector<Claim>& cl = claims[id];
             if (cl.empty()) throw Reject("node without claim");
-            std::vector<E2> alpha = cl.size() > 1 ? V.ch.squeeze_n(cl.size()) : std::vector<E2>{e2_one()};
+            std::vector<E> alpha = cl.size() > 1 ? V.squeeze_n(cl.size()) : std::vector<E>{F::one()};
             std::vector<std::vector<Claim>> sub;
             if (n.kind == NK_VANILLA) sub = V.vanilla(n, cl, alpha);
             else if (n.kind == NK_FFT) sub = V.fft(n, cl, alpha);
             else sub = {{V.lasso(lp)}};
             for (size_t i = 0; i < n.preds.size(); i++) for (auto& s : sub[i]) claims[n.preds[i]].push_back(s);
         }
+        // (the reference does not check that the proof stream is fully consumed either)
         // izip_eq!(inputs, input_claims): input.evaluate(point) == value (:512-516)
         const size_t SZ = p.SZ();
         std::vector<const u64*> tabs = {w.s.data(), w.e.data(), w.k1.data()};
@@ -271,11 +358,21 @@ std::string verify_proof(const Params& p, const LassoPlan& lp, const HCircuit& c
         tabs.push_back(w.r2is.data());
         for (size_t k = 0; k < c.input_ids.size(); k++)
             for (auto& cl : claims[c.input_ids[k]])
-                if (!e2_eq(mle_eval(tabs[k], cl.point), cl.value)) throw Reject("input claim mismatch at input " + std::to_string(k));
+                if (!F::eq(mle_eval<F>(tabs[k], cl.point), cl.value)) throw Reject("input claim mismatch at input " + std::to_string(k));
         return "";
     } catch (const Reject& r) {
         return r.what();
     }
+}
+
+}  // namespace
+
+// return "" on accept, the rejection reason otherwise
+std::string verify_proof(const Params& p, const LassoPlan& lp, const HCircuit& c, const Witness& w, const uint8_t* proof, size_t len) {
+    return verify_impl<GlField>(p, lp, c, w, proof, len);
+}
+std::string verify_proof_bn254(const Params& p, const LassoPlan& lp, const HCircuit& c, const Witness& w, const uint8_t* proof, size_t len) {
+    return verify_impl<BnField>(p, lp, c, w, proof, len);
 }
 
 }  // namespace hg

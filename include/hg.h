@@ -198,6 +198,9 @@ int hg_circuit_eval_bn254(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, int
  *   prove_gkr walk (Libra / zkCNN / Lasso node reductions) over bn256::Fr. proof: 32-byte big-endian elements
  *   [REF transcript.rs:183-189]. ms2 (may be null): witness generation and proving wall time in ms. */
 int hg_prove_bn254(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, uint8_t* proof, size_t cap, size_t* len, double* ms2);
+/* = BfvEncrypt::verify::<Fr, Fr> [REF sk_encryption_circuit.rs:462-517]: host side (no device needed; pk may come from
+ *   hg_setup(NULL, ..)). Returns 0 accept, 1 reject (reason in hg_last_error), -1 error. */
+int hg_verify_bn254(const hg_pk* pk, const hg_witness* w, const uint8_t* proof, size_t len);
 
 /* profiling: level 0 off, 1 = events around the selected kernel class only, 2 = every class */
 int hg_profile(hg_ctx* ctx, int level);

@@ -473,10 +473,12 @@ def test_bn254_prove_bit_exact_on_the_reference_fixture(ctx):
         where = [t for t in trace if t[0] <= first][-1]
         pytest.fail("proof differs at element %d (%s, starts at %d); lengths %d / %d" % (first, where[1], where[0], len(got), len(expect)))
     assert G.verify(c, inputs, ct0is, got, chal, verify_fn)
+    assert hg.verify_bn254(pk, w, proof) == (True, "")              # the product's own host verifier over Fr
     bad = list(got)
     bad[len(bad) // 2] = (bad[len(bad) // 2] + 1) % G.R
     with pytest.raises(ValueError):
         G.verify(c, inputs, ct0is, bad, chal, verify_fn)
+    assert not hg.verify_bn254(pk, w, b"".join(v.to_bytes(32, "big") for v in bad))[0]
 
 
 def test_bn254_prove_synthetic_k2_accepted_by_the_oracle_verifier(ctx):
@@ -502,3 +504,22 @@ def test_bn254_prove_synthetic_k2_accepted_by_the_oracle_verifier(ctx):
     _, verify_fn = orclib.bn254_lasso_fns(p)
     chal = bn.challenges(4000, orclib.keccak256)
     assert G.verify(orclib.constants(n, k), inputs, ct0is, _elems(proof), chal, lambda e, c: verify_fn(e, c, layout))
+    assert hg.verify_bn254(pk, w, proof) == (True, "")
+    assert not hg.verify_bn254(pk, hg.Witness.synthetic(bfv.params, 78), proof)[0]   # another witness: input claims fail
+
+
+def test_bn254_prove_config5_shape_accepted_by_the_host_verifier(ctx):
+    """BASELINE config 5 (n=32768 k=16) over bn256::Fr: too large for the Python oracle; the proof must be accepted by
+    hg_verify_bn254 (itself cross-checked against the oracle at n=1024: test_bn254_host_verifier_agrees_with_the_oracle),
+    a tampered copy rejected, and it has as many elements as the Goldilocks proof of the same parameter set."""
+    bfv = hg.BfvEncrypt.new(32768, 16)
+    pk = bfv.setup(ctx)
+    w = hg.Witness.synthetic(bfv.params, 0x4752454330 + 5)
+    proof, wms, pms = ctx.prove_bn254(pk, w, cap=1 << 25)
+    print("hg_prove_bn254 n=32768 k=16: witness %.1f ms, prove %.1f ms, %d bytes" % (wms, pms, len(proof)))
+    gl, _ = bfv.prove(ctx, pk, w)
+    assert len(proof) // 32 == len(gl) // 16
+    assert hg.verify_bn254(pk, w, proof) == (True, "")
+    bad = bytearray(proof)
+    bad[len(bad) // 2 + 31] ^= 1
+    assert not hg.verify_bn254(pk, w, bytes(bad))[0]

@@ -159,3 +159,68 @@ def test_product_verifier_accepts_oracle_proofs_and_rejects_tampering(n, k, bits
     ok, _ = hg.verify(pk, hg.Witness.from_arrays(bfv.params, d), proof)
     assert not ok
     pk.free()
+
+
+# ---- bn254 family: fixture loader and host verifier (hg_witness_from_json_bn254, hg_verify_bn254) -------------------------------
+BN_FIXTURE = os.path.join(orclib.GOLDEN, "bn254_sk_enc_1024_1x27_65537.json")
+
+
+def test_bn254_fixture_loader_recovers_the_signed_integers(tmp_path):
+    """The reference's bn254 witness holds small signed integers as Fr elements; the loader keeps them in the Goldilocks form.
+    Lifted back into Fr they must equal the Python oracle's layout of the same file, and the integer witness satisfies the
+    circuit relation over Goldilocks too."""
+    import json
+    G = orclib.bn254_gkr()
+    bfv = hg.BfvEncrypt.new(1024, 1)
+    w = hg.Witness.from_json_bn254(bfv.params, BN_FIXTURE)
+    a = w.arrays()
+    inputs, ct0is = G.layout_inputs(1024, 1, json.load(open(BN_FIXTURE)))
+    got = [[G.lift_signed(v) for v in a[f]] for f in ("s", "e", "k1", "ais", "r1is", "r2is")]
+    assert got == inputs and [G.lift_signed(v) for v in a["ct0is"]] == ct0is
+    pk = bfv.setup(None)
+    _, sum_out = pk.circuit_eval(w)
+    assert (sum_out == a["ct0is"]).all()
+    # an element that is not a small signed integer is refused, not wrapped
+    raw = json.load(open(BN_FIXTURE))
+    raw["s"][0] = str(1 << 200)
+    bad = tmp_path / "bad.json"
+    bad.write_text(json.dumps(raw))
+    with pytest.raises(hg.HgError):
+        hg.Witness.from_json_bn254(bfv.params, str(bad))
+    raw["s"][0] = str(G.R)  # not a canonical field element
+    bad.write_text(json.dumps(raw))
+    with pytest.raises(hg.HgError):
+        hg.Witness.from_json_bn254(bfv.params, str(bad))
+    pk.free()
+
+
+def test_bn254_host_verifier_agrees_with_the_oracle():
+    """hg_verify_bn254 (host, no device) accepts the Python oracle's proof of the reference's bn254 fixture and rejects what
+    the oracle's verifier rejects: a tampered element at several places, a truncated / extended proof, another witness."""
+    import json
+    G, bn = orclib.bn254_gkr(), orclib.bn254()
+    n, k = 1024, 1
+    c = orclib.constants(n, k)
+    inputs, ct0is = G.layout_inputs(n, k, json.load(open(BN_FIXTURE)))
+    prove_fn, verify_fn = orclib.bn254_lasso_fns(orclib.params(n, k))
+    chal = bn.challenges(3000, orclib.keccak256)
+    proof, _ = G.prove(c, inputs, ct0is, chal, prove_fn)
+    enc = lambda els: b"".join(int(v).to_bytes(32, "big") for v in els)
+    bfv = hg.BfvEncrypt.new(n, k)
+    pk = bfv.setup(None)
+    w = hg.Witness.from_json_bn254(bfv.params, BN_FIXTURE)
+    ok, why = hg.verify_bn254(pk, w, enc(proof))
+    assert ok, why
+    for at in (0, 7, len(proof) // 3, len(proof) // 2, len(proof) - 1):
+        bad = list(proof)
+        bad[at] = (bad[at] + 1) % G.R
+        with pytest.raises(ValueError):
+            G.verify(c, inputs, ct0is, bad, chal, verify_fn)
+        ok, why = hg.verify_bn254(pk, w, enc(bad))
+        assert not ok and why
+    assert not hg.verify_bn254(pk, w, enc(proof[:-1]))[0]
+    assert hg.verify_bn254(pk, w, enc(proof) + b"\0" * 32)[0]   # like the reference, the verifier does not look past the last element it needs
+    assert not hg.verify_bn254(pk, w, enc(proof[:5]) + b"\xff" * 32 + enc(proof[6:]))[0]   # non-canonical element
+    other = hg.Witness.from_json(bfv.params, os.path.join(orclib.GOLDEN, "sk_enc_1024_1x27_65537.json"))  # a different sample
+    assert not hg.verify_bn254(pk, other, enc(proof))[0]
+    pk.free()
