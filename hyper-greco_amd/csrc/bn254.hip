@@ -91,20 +91,26 @@ __device__ __forceinline__ Fr block_sum_fr(Fr v, Fr* sm) {
 template <int KIND>
 __global__ __launch_bounds__(BN_TPB) void k_bn_round(const Fr* __restrict__ in, Fr* __restrict__ out, int ntab, size_t half, Fr r,
                                                      const Fr* __restrict__ pw, Fr* __restrict__ partials) {
+    // gridDim.y = P groups share the tables / pairs round-robin (see k_bn_gp_round); P = 1 is the plain one-thread-per-j form
     constexpr int NV = KIND == BN_GRANDPROD ? 3 : 2;
     __shared__ Fr sm[BN_TPB];
     Fr acc[NV];
 #pragma unroll
     for (int v = 0; v < NV; v++) acc[v] = fr_zero();
+    const int P = gridDim.y, pi = blockIdx.y;
     for (size_t j = (size_t)blockIdx.x * BN_TPB + threadIdx.x; j < half; j += (size_t)gridDim.x * BN_TPB) {
         Fr s0 = fr_zero(), s2 = fr_zero(), s3 = fr_zero();
-        Fr p0 = fr_zero(), p2 = fr_zero(), p3 = fr_zero();
+        Fr p0, p2, p3;  // table 0 at 0, 2, 3
+        {
+            const Fr x = in[2 * j], y = in[2 * j + 1];
+            const Fr d = fr_sub(y, x);
+            p0 = x; p2 = fr_add(y, d); p3 = fr_add(p2, d);
+        }
         if (KIND == BN_COLLATION) {
-            for (int i = 0; i < ntab; i++) {
+            for (int i = pi; i < ntab; i += P) {
                 const Fr x = in[(size_t)i * 2 * half + 2 * j], y = in[(size_t)i * 2 * half + 2 * j + 1];
                 const Fr d = fr_sub(y, x);
                 const Fr v2 = fr_add(y, d);
-                if (i == 0) { p0 = x; p2 = v2; }
                 const Fr w = pw[i];
                 s0 = fr_add(s0, fr_mul(w, x));
                 s2 = fr_add(s2, fr_mul(w, v2));
@@ -114,14 +120,13 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_round(const Fr* __restrict__ in, 
             acc[1] = fr_add(acc[1], fr_mul(p2, s2));
         } else {
             const int nb = ntab >> 1;
-            for (int i = 0; i < nb; i++) {
+            for (int i = pi; i < nb; i += P) {
                 const Fr xl = in[(size_t)(2 * i) * 2 * half + 2 * j], yl = in[(size_t)(2 * i) * 2 * half + 2 * j + 1];
                 const Fr xr = in[(size_t)(2 * i + 1) * 2 * half + 2 * j], yr = in[(size_t)(2 * i + 1) * 2 * half + 2 * j + 1];
                 const Fr dl = fr_sub(yl, xl), dr = fr_sub(yr, xr);
                 const Fr l2 = fr_add(yl, dl), r2 = fr_add(yr, dr);
                 if (KIND == BN_GRANDPROD) {
                     const Fr l3 = fr_add(l2, dl), r3 = fr_add(r2, dr);
-                    if (i == 0) { p0 = xl; p2 = l2; p3 = l3; }
                     const Fr w = pw[i];
                     s0 = fr_add(s0, fr_mul(w, fr_mul(xl, xr)));
                     s2 = fr_add(s2, fr_mul(w, fr_mul(l2, r2)));
@@ -136,17 +141,18 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_round(const Fr* __restrict__ in, 
             if (KIND == BN_GRANDPROD) {
                 acc[0] = fr_add(acc[0], fr_mul(p0, s0));
                 acc[1] = fr_add(acc[1], fr_mul(p2, s2));
-                acc[2] = fr_add(acc[2], fr_mul(p3, s3));
+                acc[NV - 1] = fr_add(acc[NV - 1], fr_mul(p3, s3));
             } else {
                 acc[0] = fr_add(acc[0], s0);
                 acc[1] = fr_add(acc[1], s2);
             }
         }
     }
+    const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
 #pragma unroll
     for (int v = 0; v < NV; v++) {
         Fr s = block_sum_fr(acc[v], sm);
-        if (threadIdx.x == 0) partials[(size_t)blockIdx.x * NV + v] = s;
+        if (threadIdx.x == 0) partials[blk * NV + v] = s;
     }
 }
 // Grand-product round of prove_grand_product, tuned: (a) in the FIRST round of a layer the folded LEFT table of pair i is stored
@@ -156,13 +162,20 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_round(const Fr* __restrict__ in, 
 template <bool FIRST>
 __global__ __launch_bounds__(BN_TPB) void k_bn_gp_round(const Fr* __restrict__ in, Fr* __restrict__ out, int ntab, size_t half, Fr r,
                                                         const Fr* __restrict__ pw, Fr* __restrict__ partials) {
+    // gridDim.y = P: the pairs are dealt round-robin to P thread groups so that small rounds are not one long serial chain per
+    // thread (Montgomery reduction is linear: every group reduces its own partial dot products and multiplies by p_v itself)
     __shared__ Fr sm[BN_TPB];
     Fr acc[3] = {fr_zero(), fr_zero(), fr_zero()};
-    const int nb = ntab >> 1;
+    const int nb = ntab >> 1, P = gridDim.y, pi = blockIdx.y;
     for (size_t j = (size_t)blockIdx.x * BN_TPB + threadIdx.x; j < half; j += (size_t)gridDim.x * BN_TPB) {
         W512 a0 = w512_zero(), a2 = w512_zero(), a3 = w512_zero();
-        Fr p0 = fr_zero(), p2 = fr_zero(), p3 = fr_zero();
-        for (int i = 0; i < nb; i++) {
+        Fr p0, p2, p3;  // table 0 (= left table of pair 0, weight gamma^0 = 1) at 0, 2, 3
+        {
+            const Fr x = in[2 * j], y = in[2 * j + 1];
+            const Fr d = fr_sub(y, x);
+            p0 = x; p2 = fr_add(y, d); p3 = fr_add(p2, d);
+        }
+        for (int i = pi; i < nb; i += P) {
             Fr xl = in[(size_t)(2 * i) * 2 * half + 2 * j], yl = in[(size_t)(2 * i) * 2 * half + 2 * j + 1];
             const Fr xr = in[(size_t)(2 * i + 1) * 2 * half + 2 * j], yr = in[(size_t)(2 * i + 1) * 2 * half + 2 * j + 1];
             Fr dl = fr_sub(yl, xl);
@@ -170,7 +183,6 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_gp_round(const Fr* __restrict__ i
             const Fr dr = fr_sub(yr, xr);
             const Fr l2 = fr_add(fr_add(xl, dl), dl), l3 = fr_add(l2, dl);
             const Fr r2 = fr_add(yr, dr), r3 = fr_add(r2, dr);
-            if (i == 0) { p0 = xl; p2 = l2; p3 = l3; }                                      // pw[0] = 1: table 0 itself
             w512_mac(a0, xl, xr);
             w512_mac(a2, l2, r2);
             w512_mac(a3, l3, r3);
@@ -181,12 +193,24 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_gp_round(const Fr* __restrict__ i
         acc[1] = fr_add(acc[1], fr_mul(p2, w512_reduce(a2)));
         acc[2] = fr_add(acc[2], fr_mul(p3, w512_reduce(a3)));
     }
+    const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
 #pragma unroll
     for (int v = 0; v < 3; v++) {
         Fr s = block_sum_fr(acc[v], sm);
-        if (threadIdx.x == 0) partials[(size_t)blockIdx.x * 3 + v] = s;
+        if (threadIdx.x == 0) partials[blk * 3 + v] = s;
     }
 }
+// launch shape of a round over `half` pair indices and `nitems` independent items (pairs / tables): grid.x workgroups along j,
+// grid.y groups of items; large rounds keep one thread per j, small ones spread the items
+struct RoundGrid { int gx, gy; int blocks() const { return gx * gy; } };
+static RoundGrid round_grid(size_t half, int nitems) {
+    RoundGrid g;
+    g.gx = (int)std::min<size_t>((half + BN_TPB - 1) / BN_TPB, (size_t)1024);
+    const size_t threads = (size_t)g.gx * BN_TPB;
+    g.gy = (int)std::max<size_t>(1, std::min<size_t>((size_t)nitems, (size_t)131072 / threads));
+    return g;
+}
+constexpr int BN_PART_STRIDE = 2048;  // per-round slots (workgroups) in a partials buffer; round_grid never exceeds 1024 + 512
 __global__ __launch_bounds__(BN_TPB) void k_bn_reduce(const Fr* __restrict__ partials, int nblocks, int nv, Fr* __restrict__ out) {
     __shared__ Fr sm[BN_TPB];
     for (int v = 0; v < nv; v++) {
@@ -194,6 +218,20 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_reduce(const Fr* __restrict__ par
         for (int b = threadIdx.x; b < nblocks; b += BN_TPB) a = fr_add(a, partials[(size_t)b * nv + v]);
         a = block_sum_fr(a, sm);
         if (threadIdx.x == 0) out[v] = fr_from_mont(a);  // canonical for the host
+    }
+}
+
+// all rounds of one sum-check in one launch: workgroup rd sums counts.n[rd] per-workgroup partials of round rd
+struct RoundCounts { int n[32]; };
+__global__ __launch_bounds__(BN_TPB) void k_bn_reduce_rounds(const Fr* __restrict__ partials, RoundCounts counts, int nv, Fr* __restrict__ out) {
+    __shared__ Fr sm[BN_TPB];
+    const int rd = blockIdx.x;
+    const Fr* src = partials + (size_t)rd * BN_PART_STRIDE * nv;
+    for (int v = 0; v < nv; v++) {
+        Fr a = fr_zero();
+        for (int b = threadIdx.x; b < counts.n[rd]; b += BN_TPB) a = fr_add(a, src[(size_t)b * nv + v]);
+        a = block_sum_fr(a, sm);
+        if (threadIdx.x == 0) out[rd * nv + v] = fr_from_mont(a);  // canonical for the host
     }
 }
 
@@ -406,7 +444,6 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
         k_bn_from_mont<<<(unsigned)((nb + 255) / 256), 256, 0, st>>>(d_roots, nb);
         hipc(hipMemcpyAsync(h_top.data(), d_top, 2 * nb * sizeof(Fr), hipMemcpyDeviceToHost, st), "copy");
         hipc(hipMemcpyAsync(h_roots.data(), d_roots, nb * sizeof(Fr), hipMemcpyDeviceToHost, st), "copy");
-        Fr* d_part = dalloc((size_t)1024 * 3);
         size_t pos = chain_skip;
         layers[0].mu_at = pos++;
         for (int n = 1; n < nv; n++) {
@@ -425,16 +462,21 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
             L.d_sums = dalloc((size_t)n * 3);
             const Fr* cur = lev[nv - 1 - n];  // rows [v_l | v_r] of length 2h... table t at cur + t * h
             Fr* nxt = buf0;
+            if (n > 32) throw Error("hg_grand_product_bn254: more than 32 rounds");
+            Fr* part = dalloc((size_t)n * BN_PART_STRIDE * 3);
+            RoundCounts rc;
             for (int rd = 0; rd < n; rd++) {
                 const size_t half = h >> (rd + 1);
                 const Fr r = fr_to_mont(chain[L.r_at + rd]);
-                const int grid = (int)std::min<size_t>((half + BN_TPB - 1) / BN_TPB, (size_t)1024);
-                if (rd == 0) k_bn_gp_round<true><<<grid, BN_TPB, 0, st>>>(cur, nxt, (int)ntab, half, r, d_pw, d_part);
-                else k_bn_gp_round<false><<<grid, BN_TPB, 0, st>>>(cur, nxt, (int)ntab, half, r, d_pw, d_part);
-                k_bn_reduce<<<1, BN_TPB, 0, st>>>(d_part, grid, 3, L.d_sums + rd * 3);
+                const RoundGrid g = round_grid(half, (int)nb);
+                Fr* pr = part + (size_t)rd * BN_PART_STRIDE * 3;
+                if (rd == 0) k_bn_gp_round<true><<<dim3(g.gx, g.gy), BN_TPB, 0, st>>>(cur, nxt, (int)ntab, half, r, d_pw, pr);
+                else k_bn_gp_round<false><<<dim3(g.gx, g.gy), BN_TPB, 0, st>>>(cur, nxt, (int)ntab, half, r, d_pw, pr);
+                rc.n[rd] = g.blocks();
                 cur = nxt;
                 nxt = nxt == buf0 ? buf1 : buf0;
             }
+            k_bn_reduce_rounds<<<n, BN_TPB, 0, st>>>(part, rc, 3, L.d_sums);
             L.d_final = dalloc(ntab);
             hipc(hipMemcpyAsync(L.d_final, cur, ntab * sizeof(Fr), hipMemcpyDeviceToDevice, st), "copy final");
             k_bn_from_mont<<<(unsigned)((ntab + 255) / 256), 256, 0, st>>>(L.d_final, ntab);
@@ -639,14 +681,19 @@ void lasso_prove_bn254(hg_ctx* ctx, const hg_pk* pk, const u64* in4, size_t chai
             Fr* d_sums = dalloc((size_t)nu * 2);
             const Fr* cur = tabs;
             Fr* nxt = buf0;
+            if (nu > 32) throw Error("hg_lasso_prove_bn254: more than 32 rounds");
+            Fr* part = dalloc((size_t)nu * BN_PART_STRIDE * 2);
+            RoundCounts rc;
             for (int rd = 0; rd < nu; rd++) {
                 const size_t half = N >> (rd + 1);
-                const int grid = (int)std::min<size_t>((half + BN_TPB - 1) / BN_TPB, (size_t)1024);
-                k_bn_round<BN_COLLATION><<<grid, BN_TPB, 0, st>>>(cur, nxt, A, half, fr_to_mont(chain[col_at + rd]), d_pw, d_part);
-                k_bn_reduce<<<1, BN_TPB, 0, st>>>(d_part, grid, 2, d_sums + rd * 2);
+                const RoundGrid g = round_grid(half, A);
+                k_bn_round<BN_COLLATION><<<dim3(g.gx, g.gy), BN_TPB, 0, st>>>(cur, nxt, A, half, fr_to_mont(chain[col_at + rd]), d_pw,
+                                                                               part + (size_t)rd * BN_PART_STRIDE * 2);
+                rc.n[rd] = g.blocks();
                 cur = nxt;
                 nxt = nxt == buf0 ? buf1 : buf0;
             }
+            k_bn_reduce_rounds<<<nu, BN_TPB, 0, st>>>(part, rc, 2, d_sums);
             hipc(hipMemcpyAsync(h_col.data(), d_sums, (size_t)nu * 2 * sizeof(Fr), hipMemcpyDeviceToHost, st), "copy collation sums");
         }
         // MemoryCheckingProver::new (prover.rs:35-89): gamma, tau are the challenges themselves (E = F)
