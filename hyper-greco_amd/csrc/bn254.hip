@@ -235,6 +235,58 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_reduce_rounds(const Fr* __restric
     }
 }
 
+// The last rounds of a sum-check (table length <= 2 * BN_TAIL_HALF) in ONE single-workgroup launch instead of one small launch per
+// round: tables in HBM (L2-resident at this size), work items (pair index, pair) dealt to the threads, round sums written in
+// canonical form. KIND 2: g = sum_i a_i b_i; KIND 1: g = p_0 * sum_i l_i r_i with the weights already in the left tables
+// (rounds after the first of a grand-product layer, see k_bn_gp_round).
+constexpr int BN_TAIL_HALF = 64, BN_TAIL_ROUNDS = 8;
+struct TailR { Fr r[BN_TAIL_ROUNDS]; };
+template <int KIND>
+__global__ __launch_bounds__(BN_TPB) void k_bn_tail(const Fr* __restrict__ in, Fr* __restrict__ buf, int npairs, int half0, int nrounds, TailR rs,
+                                                    Fr* __restrict__ sums_out, Fr* __restrict__ fin_out) {
+    constexpr int NV = KIND == BN_GRANDPROD ? 3 : 2;
+    __shared__ Fr sm[BN_TPB];
+    const int ntab = 2 * npairs;
+    const Fr* cur = in;                         // table t at cur + t * 2 * half
+    Fr* nxt = buf;                              // table t at nxt + t * half
+    for (int rd = 0; rd < nrounds; rd++) {
+        const int half = half0 >> rd;
+        const Fr r = rs.r[rd];
+        Fr acc[NV];
+#pragma unroll
+        for (int v = 0; v < NV; v++) acc[v] = fr_zero();
+        for (int idx = threadIdx.x; idx < half * npairs; idx += BN_TPB) {
+            const int j = idx % half, i = idx / half;
+            const Fr xa = cur[(size_t)(2 * i) * 2 * half + 2 * j], ya = cur[(size_t)(2 * i) * 2 * half + 2 * j + 1];
+            const Fr xb = cur[(size_t)(2 * i + 1) * 2 * half + 2 * j], yb = cur[(size_t)(2 * i + 1) * 2 * half + 2 * j + 1];
+            const Fr da = fr_sub(ya, xa), db = fr_sub(yb, xb);
+            const Fr a2 = fr_add(ya, da), b2 = fr_add(yb, db);
+            if (KIND == BN_GRANDPROD) {
+                const Fr x0 = cur[2 * j], y0 = cur[2 * j + 1];
+                const Fr d0 = fr_sub(y0, x0);
+                const Fr p2 = fr_add(y0, d0), p3 = fr_add(p2, d0);
+                acc[0] = fr_add(acc[0], fr_mul(x0, fr_mul(xa, xb)));
+                acc[1] = fr_add(acc[1], fr_mul(p2, fr_mul(a2, b2)));
+                acc[NV - 1] = fr_add(acc[NV - 1], fr_mul(p3, fr_mul(fr_add(a2, da), fr_add(b2, db))));
+            } else {
+                acc[0] = fr_add(acc[0], fr_mul(xa, xb));
+                acc[1] = fr_add(acc[1], fr_mul(a2, b2));
+            }
+            nxt[(size_t)(2 * i) * half + j] = fr_add(xa, fr_mul(r, da));
+            nxt[(size_t)(2 * i + 1) * half + j] = fr_add(xb, fr_mul(r, db));
+        }
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+            const Fr s = block_sum_fr(acc[v], sm);
+            if (threadIdx.x == 0) sums_out[rd * NV + v] = fr_from_mont(s);
+        }
+        __syncthreads();                        // the folded tables are complete (and visible to the workgroup)
+        cur = nxt;
+        nxt = nxt == buf ? buf + (size_t)ntab * half0 : buf;
+    }
+    for (int t = threadIdx.x; t < ntab; t += BN_TPB) fin_out[t] = fr_from_mont(cur[t]);
+}
+
 // ---- host arithmetic for the transcript replay (Montgomery form) ---------------------------------------------
 static Fr fr_pow(Fr b, const u64 e[4]) {
     Fr r = fr_one_mont();
@@ -465,8 +517,11 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
             if (n > 32) throw Error("hg_grand_product_bn254: more than 32 rounds");
             Fr* part = dalloc((size_t)n * BN_PART_STRIDE * 3);
             RoundCounts rc;
+            L.d_final = dalloc(ntab);
+            int nmain = n;   // rounds done by one launch each; the rest (short tables) by the single-workgroup tail
             for (int rd = 0; rd < n; rd++) {
                 const size_t half = h >> (rd + 1);
+                if (rd >= 1 && half <= (size_t)BN_TAIL_HALF && n - rd <= BN_TAIL_ROUNDS) { nmain = rd; break; }
                 const Fr r = fr_to_mont(chain[L.r_at + rd]);
                 const RoundGrid g = round_grid(half, (int)nb);
                 Fr* pr = part + (size_t)rd * BN_PART_STRIDE * 3;
@@ -476,10 +531,17 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
                 cur = nxt;
                 nxt = nxt == buf0 ? buf1 : buf0;
             }
-            k_bn_reduce_rounds<<<n, BN_TPB, 0, st>>>(part, rc, 3, L.d_sums);
-            L.d_final = dalloc(ntab);
-            hipc(hipMemcpyAsync(L.d_final, cur, ntab * sizeof(Fr), hipMemcpyDeviceToDevice, st), "copy final");
-            k_bn_from_mont<<<(unsigned)((ntab + 255) / 256), 256, 0, st>>>(L.d_final, ntab);
+            if (nmain) k_bn_reduce_rounds<<<nmain, BN_TPB, 0, st>>>(part, rc, 3, L.d_sums);
+            if (nmain < n) {
+                const int half0 = (int)(h >> (nmain + 1));
+                TailR tr;
+                for (int q = 0; q < BN_TAIL_ROUNDS; q++) tr.r[q] = q < n - nmain ? fr_to_mont(chain[L.r_at + nmain + q]) : fr_zero();
+                Fr* tbuf = dalloc(2 * ntab * (size_t)half0);
+                k_bn_tail<BN_GRANDPROD><<<1, BN_TPB, 0, st>>>(cur, tbuf, (int)nb, half0, n - nmain, tr, L.d_sums + (size_t)nmain * 3, L.d_final);
+            } else {
+                hipc(hipMemcpyAsync(L.d_final, cur, ntab * sizeof(Fr), hipMemcpyDeviceToDevice, st), "copy final");
+                k_bn_from_mont<<<(unsigned)((ntab + 255) / 256), 256, 0, st>>>(L.d_final, ntab);
+            }
             L.sums.resize((size_t)n * 3); L.fin.resize(ntab);
             hipc(hipMemcpyAsync(L.sums.data(), L.d_sums, (size_t)n * 3 * sizeof(Fr), hipMemcpyDeviceToHost, st), "copy sums");
             hipc(hipMemcpyAsync(L.fin.data(), L.d_final, ntab * sizeof(Fr), hipMemcpyDeviceToHost, st), "copy evals");
@@ -598,7 +660,17 @@ __global__ void k_bn_hash_if(u32 cutoff, const u64* __restrict__ fc, Fr gamma, F
     fin[a] = fr_add(h0, fr_mul(fr_to_mont(fr_make(fc[a], 0, 0, 0)), gamma2));
 }
 
-void lasso_prove_bn254(hg_ctx* ctx, const hg_pk* pk, const u64* in4, size_t chain_skip, std::vector<uint8_t>& proof, u64* claim_out) {
+// low limbs of a Montgomery-form table; *bad is set when an element does not fit one limb
+__global__ void k_bn_low_limb(const Fr* __restrict__ in, u64* __restrict__ out, size_t n, int* __restrict__ bad) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Fr v = fr_from_mont(in[i]);
+    out[i] = v.l[0];
+    if (v.l[1] | v.l[2] | v.l[3]) atomicOr(bad, 1);
+}
+// in4: host table (4 canonical limbs per element), or null with d_in_mont: the node input as it lies in HBM (Montgomery form)
+static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4, const Fr* d_in_mont, size_t chain_skip, std::vector<uint8_t>& proof,
+                                   u64* claim_out) {
     if (!pk->ctx) throw Error("hg_lasso_prove_bn254: host-only prover key");
     const LassoPlan& lp = pk->lasso;
     const dev::LassoDev& L = pk->lasso_dev;
@@ -607,11 +679,15 @@ void lasso_prove_bn254(hg_ctx* ctx, const hg_pk* pk, const u64* in4, size_t chai
     hipc(hipSetDevice(ctx->device), "hipSetDevice");
     hipStream_t st = ctx->stream;
     // the node input must be small non-negative integers (range-shifted values): only the low limb takes part in the split
-    std::vector<u64> low(N);
-    for (size_t j = 0; j < N; j++) {
-        if (in4[4 * j + 1] | in4[4 * j + 2] | in4[4 * j + 3]) throw Error("hg_lasso_prove_bn254: input " + std::to_string(j) + " is not below 2^64 (not a range-shifted value)");
-        low[j] = in4[4 * j];
+    std::vector<u64> low;
+    if (in4) {
+        low.resize(N);
+        for (size_t j = 0; j < N; j++) {
+            if (in4[4 * j + 1] | in4[4 * j + 2] | in4[4 * j + 3]) throw Error("hg_lasso_prove_bn254: input " + std::to_string(j) + " is not below 2^64 (not a range-shifted value)");
+            low[j] = in4[4 * j];
+        }
     }
+    int h_bad = 0;
     const size_t r_at = chain_skip, col_at = r_at + nu, gamma_at = col_at + nu, tau_at = gamma_at + 1, gp1_at = tau_at + 1,
                  gp2_at = gp1_at + gp_challenges(nu), total = gp2_at + gp_challenges(16);
     const std::vector<Fr> chain = challenge_chain_bn254(total);
@@ -625,7 +701,13 @@ void lasso_prove_bn254(hg_ctx* ctx, const hg_pk* pk, const u64* in4, size_t chai
     try {
         // polynomialize (lasso.rs:157-250): integer kernels of the Goldilocks path
         u64* d_in = (u64*)dalloc_b(N * 8);
-        hipc(hipMemcpyAsync(d_in, low.data(), N * 8, hipMemcpyHostToDevice, st), "upload input");
+        int* d_bad = (int*)dalloc_b(sizeof(int));
+        if (in4) hipc(hipMemcpyAsync(d_in, low.data(), N * 8, hipMemcpyHostToDevice, st), "upload input");
+        else {
+            hipc(hipMemsetAsync(d_bad, 0, sizeof(int), st), "clear flag");
+            k_bn_low_limb<<<grid1(N), 256, 0, st>>>(d_in_mont, d_in, N, d_bad);
+            hipc(hipMemcpyAsync(&h_bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, st), "copy flag");  // read after the next synchronisation
+        }
         u64* dims = (u64*)dalloc_b(4 * N * 8);
         u64* ep = (u64*)dalloc_b((size_t)A * N * 8);
         dev::lasso_split(st, L, d_in, dims, ep);
@@ -708,6 +790,7 @@ void lasso_prove_bn254(hg_ctx* ctx, const hg_pk* pk, const u64* in4, size_t chai
             k_bn_hash_if<<<65536 / 256, 256, 0, st>>>((u32)lp.mems[m].cutoff, final_cts[c], gamma, gamma2, tau, H2 + (size_t)i * M, H2 + (size_t)(G + i) * M);
         }
         hipc(hipStreamSynchronize(st), "lasso_prove_bn254: sync");
+        if (h_bad) throw Error("hg_lasso_prove_bn254: the node input holds a value that is not below 2^64 (not a range-shifted value)");
         grand_product_core(ctx, 2 * G, N, nullptr, H1, gp1_at, gp1_bytes, tmp_claims, x);  // reads then writes (prover.rs:161-165)
         grand_product_core(ctx, 2 * G, M, nullptr, H2, gp2_at, gp2_bytes, tmp_claims, y);  // inits then finals (prover.rs:167-171)
         // openings (prover.rs:173-178, mod.rs:80-93)
@@ -750,6 +833,11 @@ void lasso_prove_bn254(hg_ctx* ctx, const hg_pk* pk, const u64* in4, size_t chai
     for (const Fr& v : opens) write_be32(proof, v);
     for (int i = 0; i < nu; i++) memcpy(claim_out + 4 * i, chain[r_at + i].l, 32);
     memcpy(claim_out + 4 * nu, h_claimed.l, 32);
+}
+
+void lasso_prove_bn254(hg_ctx* ctx, const hg_pk* pk, const u64* in4, size_t chain_skip, std::vector<uint8_t>& proof, u64* claim_out) {
+    if (!in4) throw Error("hg_lasso_prove_bn254: null input");
+    lasso_prove_bn254_impl(ctx, pk, in4, nullptr, chain_skip, proof, claim_out);
 }
 
 // ---- MLE evaluation and NTT over Fr (the other primitives of the path, A13/A14) -------------------------------------
