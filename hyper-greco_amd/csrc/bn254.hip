@@ -239,7 +239,7 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_reduce_rounds(const Fr* __restric
 // round: tables in HBM (L2-resident at this size), work items (pair index, pair) dealt to the threads, round sums written in
 // canonical form. KIND 2: g = sum_i a_i b_i; KIND 1: g = p_0 * sum_i l_i r_i with the weights already in the left tables
 // (rounds after the first of a grand-product layer, see k_bn_gp_round).
-constexpr int BN_TAIL_HALF = 64, BN_TAIL_ROUNDS = 8;
+constexpr int BN_TAIL_HALF = 16, BN_TAIL_ROUNDS = 8;  // 16: at most two work items per thread in the first tail round
 struct TailR { Fr r[BN_TAIL_ROUNDS]; };
 template <int KIND>
 __global__ __launch_bounds__(BN_TPB) void k_bn_tail(const Fr* __restrict__ in, Fr* __restrict__ buf, int npairs, int half0, int nrounds, TailR rs,
