@@ -523,3 +523,56 @@ def test_bn254_prove_config5_shape_accepted_by_the_host_verifier(ctx):
     bad = bytearray(proof)
     bad[len(bad) // 2 + 31] ^= 1
     assert not hg.verify_bn254(pk, w, bytes(bad))[0]
+
+
+# ---- invalid witnesses: the prover must behave exactly like the CPU restatement, and every verifier must reject -------------
+def _tampered_witness(bfv, kind, field_p):
+    """A synthetic n=1024 witness made invalid. kind: "range" = an error coefficient outside its range-check bound (the Lasso
+    lookup then returns the wrong sub-table value); "relation" = one ct0 coefficient changed (the circuit relation fails);
+    "huge" = a secret coefficient that is not a small integer at all."""
+    d = {f: a.copy() for f, a in hg.Witness.synthetic(bfv.params, 4242).arrays().items()}
+    if kind == "range":
+        d["e"][5] = 1000          # e_bound = 19
+    elif kind == "relation":
+        d["ct0is"][7] = (int(d["ct0is"][7]) + 1) % field_p
+    else:
+        d["s"][3] = 1 << 40       # s_bound = 1
+    return hg.Witness.from_arrays(bfv.params, d)
+
+
+@pytest.mark.parametrize("kind", ["range", "relation", "huge"])
+def test_invalid_witness_same_transcript_as_the_oracle_and_rejected(ctx, kind):
+    bfv = hg.BfvEncrypt.new(1024, 1)
+    pk = bfv.setup(ctx)
+    w = _tampered_witness(bfv, kind, P)
+    proof, _ = bfv.prove(ctx, pk, w)             # no crash, no special casing: the reference prover does not validate either
+    p = orclib.params(1024, 1)
+    inp = orclib.Inputs(w.arrays())
+    ref, _ = orclib.prove(p, inp, threads=4)
+    assert proof == ref
+    ok_o, _ = orclib.verify(p, inp, proof)
+    ok_p, why = hg.verify(pk, w, proof)
+    assert not ok_o and not ok_p and why
+    pk.free()
+
+
+@pytest.mark.parametrize("kind", ["range", "relation"])
+def test_bn254_invalid_witness_rejected_by_both_verifiers(ctx, kind):
+    G, bn = orclib.bn254_gkr(), orclib.bn254()
+    n, k = 1024, 1
+    bfv = hg.BfvEncrypt.new(n, k)
+    pk = bfv.setup(ctx)
+    w = _tampered_witness(bfv, kind, P)
+    proof, _, _ = ctx.prove_bn254(pk, w)
+    assert not hg.verify_bn254(pk, w, proof)[0]
+    d = w.arrays()
+    lift = G.lift_signed
+    inputs = [[lift(v) for v in d[f]] for f in ("s", "e", "k1", "ais", "r1is", "r2is")]
+    ct0is = [lift(v) for v in d["ct0is"]]
+    p = orclib.params(n, k)
+    prove_fn, verify_fn = orclib.bn254_lasso_fns(p)
+    chal = bn.challenges(3000, orclib.keccak256)
+    expect, _ = G.prove(orclib.constants(n, k), inputs, ct0is, chal, prove_fn)
+    assert _elems(proof) == expect               # bit-exact on an invalid witness too
+    with pytest.raises(ValueError):
+        G.verify(orclib.constants(n, k), inputs, ct0is, expect, chal, verify_fn)
