@@ -2,8 +2,8 @@
 // limbs, Montgomery form (R = 2^256) inside the kernels, canonical little-endian limbs at the C ABI - the field of the
 // reference's `bn254` test family, where the extension is the field itself
 // [REF bfv-gkr/src/sk_encryption_circuit.rs:540,614-626: generate_sk_enc_test!("bn254", Fr, Fr, ..); halo2curves 0.7.0
-// bn256::Fr, Cargo.toml:29]. First slice of BASELINE config 5: field, transcript challenges and the
-// sum-check round kernels; the Goldilocks path does not use this header.
+// bn256::Fr, Cargo.toml:29]. Field layer of the BN254 path (BASELINE config 5), shared by the kernels (bn254.hip) and
+// the host verifier (verifier.cpp); the Goldilocks prover does not use this header.
 #pragma once
 #include <stdint.h>
 #include <hip/hip_runtime.h>

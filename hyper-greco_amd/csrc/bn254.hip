@@ -1,10 +1,11 @@
-// BN254 slice (BASELINE config 5, first step): Fr arithmetic on gfx950, the Keccak challenge chain over Fr, and
-// gkr::sum_check::prove_sum_check for the three shapes of the path on caller tables (hg_sumcheck_bn254), with the same
-// single-synchronisation structure as the Goldilocks prover: all rounds are enqueued with the (message-independent)
-// challenges, one copy back, then the transcript is replayed on the host.
+// BfvEncrypt::prove over bn256::Fr (BASELINE config 5: the reference's `bn254` test family, F = E = Fr): Fr arithmetic on gfx950, the
+// Keccak challenge chain over Fr, gkr::sum_check::prove_sum_check for the three shapes of the path, prove_grand_product, the whole
+// Lasso node, MLE evaluation and NTT; bn254_gkr.inc (included at the end) adds witness generation, the Libra / zkCNN node
+// reductions and the prove_gkr walk. Structure per sum-check as in the Goldilocks prover: all rounds are enqueued with the
+// (message-independent) challenges, one copy back, then the transcript is replayed on the host.
 // [REF bfv-gkr/src/transcript.rs:146-157,183-189,198-203 (challenges, 32-byte big-endian felts);
 //  lasso/src/lasso.rs:457-475 (collation g), lasso/src/memory_checking/prover.rs:268-279 (grand-product g);
-//  sk_encryption_circuit.rs:614-626 (Fr, Fr)]
+//  sk_encryption_circuit.rs:417-460, 614-626 (prove; Fr, Fr)]
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <string>

@@ -155,7 +155,7 @@ int hg_ntt(hg_ctx* ctx, const uint64_t* in, size_t log2n, int inverse, size_t ba
 /* Fiat-Shamir challenge chain [REF bfv-gkr/src/transcript.rs:146-157,198-203]: first n base-field challenges. */
 int hg_challenges(size_t n, uint64_t* out);
 
-/* ---- BN254 (BASELINE config 5, first slice): field, challenges and sum-check kernels over halo2curves bn256::Fr --------
+/* ---- BN254 (BASELINE config 5): the same path over halo2curves bn256::Fr (F = E = Fr) ---------------------------------
  * Elements cross the boundary as 4 canonical little-endian u64 limbs (non-Montgomery). The extension field of the
  * reference's bn254 tests is the field itself [REF sk_encryption_circuit.rs:614-626: (Fr, Fr)], so a challenge is one
  * element. hg_prove_bn254 is the whole BfvEncrypt::prove over Fr; the entry points before it expose its parts for parity tests. */
