@@ -309,6 +309,31 @@ static void hipc(hipError_t e, const char* what) {
     if (e != hipSuccess) throw Error(std::string(what) + ": " + hipGetErrorString(e));
 }
 
+// Scalar results (round sums, folded values, openings) are written by the kernels straight into the context's result buffer,
+// which is host-mapped pinned memory unless HG_RES_DEVICE is set: no copy-back calls, the host reads them after a synchronisation.
+struct ResRef { Fr* dev; const Fr* host; };
+static ResRef res_slots(hg_ctx* ctx, size_t n) {
+    const size_t bytes = std::max<size_t>(n, 1) * sizeof(Fr);
+    if (ctx->bn_res_used + bytes > ctx->res_cap * sizeof(E2)) throw Error("bn254: result buffer exhausted");
+    ResRef r;
+    r.dev = reinterpret_cast<Fr*>(reinterpret_cast<char*>(ctx->d_res) + ctx->bn_res_used);
+    r.host = reinterpret_cast<const Fr*>(reinterpret_cast<const char*>(ctx->h_res) + ctx->bn_res_used);
+    ctx->bn_res_used += bytes;
+    return r;
+}
+static void res_sync(hg_ctx* ctx, hipStream_t st, const char* what) {
+    if (ctx->d_res != ctx->h_res && ctx->bn_res_used)
+        hipc(hipMemcpyAsync(ctx->h_res, ctx->d_res, ctx->bn_res_used, hipMemcpyDeviceToHost, st), "copy results");
+    hipc(hipStreamSynchronize(st), what);
+    hipc(hipGetLastError(), what);
+}
+__global__ void k_bn_copy_from_mont(const Fr* __restrict__ src, Fr* __restrict__ dst, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = fr_from_mont(src[i]);
+}
+static void build_eq_dev(hipStream_t st, Fr* eq, const Fr* pt_canon, int n);  // bn254_gkr.inc
+__global__ void k_bn_powers(Fr* __restrict__ W, Fr w, size_t n);                  // W[i] = w^i (below)
+
 // prove_sum_check on caller tables (all in the base field; E = F). Conventions as for Goldilocks:
 // a round message is the d+1 coefficients of the round polynomial, eval(1) = claim - eval(0), lowest variable first.
 void sumcheck_bn254(hg_ctx* ctx, int kind, size_t nv, size_t ntab, const u64* const* tables, const u64* pw4, size_t npw, const u64* claim4,
@@ -470,9 +495,9 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
     // buffers come from the context's bump arena and are handed back (rewind) when the copy-back has completed
     const std::vector<size_t> arena_mark = ctx->arena_mark();
     auto dalloc = [&](size_t n_fr) { return static_cast<Fr*>(ctx->alloc(std::max<size_t>(n_fr, 1) * sizeof(Fr))); };
-    struct LayerRec { size_t gamma_at, r_at, mu_at; Fr* d_sums; Fr* d_final; std::vector<Fr> sums, fin; };
+    struct LayerRec { size_t gamma_at, r_at, mu_at; Fr* d_sums; Fr* d_final; const Fr* sums; const Fr* fin; };
     std::vector<LayerRec> layers(nv);
-    std::vector<Fr> h_top(2 * nb), h_roots(nb);
+    const Fr *h_top = nullptr, *h_roots = nullptr;
     try {
         std::vector<const Fr*> lev(nv, nullptr);
         if (d_lev0) lev[0] = d_lev0;
@@ -491,12 +516,10 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
         // roots and top evaluations: level nv-1 has rows of length 2
         Fr* d_roots = dalloc(nb);
         k_bn_prod_level<<<(unsigned)((nb + 255) / 256), 256, 0, st>>>(lev[nv - 1], 2, d_roots, (int)nb);
-        Fr* d_top = dalloc(2 * nb);
-        hipc(hipMemcpyAsync(d_top, lev[nv - 1], 2 * nb * sizeof(Fr), hipMemcpyDeviceToDevice, st), "copy top");
-        k_bn_from_mont<<<(unsigned)((2 * nb + 255) / 256), 256, 0, st>>>(d_top, 2 * nb);
-        k_bn_from_mont<<<(unsigned)((nb + 255) / 256), 256, 0, st>>>(d_roots, nb);
-        hipc(hipMemcpyAsync(h_top.data(), d_top, 2 * nb * sizeof(Fr), hipMemcpyDeviceToHost, st), "copy");
-        hipc(hipMemcpyAsync(h_roots.data(), d_roots, nb * sizeof(Fr), hipMemcpyDeviceToHost, st), "copy");
+        const ResRef top = res_slots(ctx, 2 * nb), roots = res_slots(ctx, nb);
+        k_bn_copy_from_mont<<<(unsigned)((2 * nb + 255) / 256), 256, 0, st>>>(lev[nv - 1], top.dev, 2 * nb);
+        k_bn_copy_from_mont<<<(unsigned)((nb + 255) / 256), 256, 0, st>>>(d_roots, roots.dev, nb);
+        h_top = top.host; h_roots = roots.host;
         size_t pos = chain_skip;
         layers[0].mu_at = pos++;
         for (int n = 1; n < nv; n++) {
@@ -504,21 +527,19 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
             L.gamma_at = pos++; L.r_at = pos; pos += n; L.mu_at = pos++;
             const size_t h = (size_t)1 << n;  // table length of this layer's sum-check (n variables)
             // gamma powers
-            std::vector<Fr> pw(nb);
             const Fr g = fr_to_mont(chain[L.gamma_at]);
-            Fr cur_pw = fr_one_mont();
-            for (size_t b = 0; b < nb; b++) { pw[b] = cur_pw; cur_pw = fr_mul(cur_pw, g); }
             Fr* d_pw = dalloc(nb);
-            hipc(hipMemcpy(d_pw, pw.data(), nb * sizeof(Fr), hipMemcpyHostToDevice), "upload gamma powers");  // (already Montgomery)
+            k_bn_powers<<<(unsigned)((nb + 255) / 256), 256, 0, st>>>(d_pw, g, nb);   // gamma^b, b < nb
             Fr* buf0 = dalloc(ntab * (h / 2));
             Fr* buf1 = dalloc(ntab * std::max<size_t>(h / 4, 1));
-            L.d_sums = dalloc((size_t)n * 3);
+            const ResRef rs_sums = res_slots(ctx, (size_t)n * 3), rs_fin = res_slots(ctx, ntab);
+            L.d_sums = rs_sums.dev; L.sums = rs_sums.host;
             const Fr* cur = lev[nv - 1 - n];  // rows [v_l | v_r] of length 2h... table t at cur + t * h
             Fr* nxt = buf0;
             if (n > 32) throw Error("hg_grand_product_bn254: more than 32 rounds");
             Fr* part = dalloc((size_t)n * BN_PART_STRIDE * 3);
             RoundCounts rc;
-            L.d_final = dalloc(ntab);
+            L.d_final = rs_fin.dev; L.fin = rs_fin.host;
             int nmain = n;   // rounds done by one launch each; the rest (short tables) by the single-workgroup tail
             for (int rd = 0; rd < n; rd++) {
                 const size_t half = h >> (rd + 1);
@@ -540,15 +561,10 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
                 Fr* tbuf = dalloc(2 * ntab * (size_t)half0);
                 k_bn_tail<BN_GRANDPROD><<<1, BN_TPB, 0, st>>>(cur, tbuf, (int)nb, half0, n - nmain, tr, L.d_sums + (size_t)nmain * 3, L.d_final);
             } else {
-                hipc(hipMemcpyAsync(L.d_final, cur, ntab * sizeof(Fr), hipMemcpyDeviceToDevice, st), "copy final");
-                k_bn_from_mont<<<(unsigned)((ntab + 255) / 256), 256, 0, st>>>(L.d_final, ntab);
+                k_bn_copy_from_mont<<<(unsigned)((ntab + 255) / 256), 256, 0, st>>>(cur, L.d_final, ntab);
             }
-            L.sums.resize((size_t)n * 3); L.fin.resize(ntab);
-            hipc(hipMemcpyAsync(L.sums.data(), L.d_sums, (size_t)n * 3 * sizeof(Fr), hipMemcpyDeviceToHost, st), "copy sums");
-            hipc(hipMemcpyAsync(L.fin.data(), L.d_final, ntab * sizeof(Fr), hipMemcpyDeviceToHost, st), "copy evals");
         }
-        hipc(hipStreamSynchronize(st), "grand_product_bn254: sync");
-        hipc(hipGetLastError(), "grand_product_bn254: launch");
+        res_sync(ctx, st, "grand_product_bn254: sync");
     } catch (...) {
         ctx->arena_rewind(arena_mark);
         throw;
@@ -707,7 +723,7 @@ static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4,
         else {
             hipc(hipMemsetAsync(d_bad, 0, sizeof(int), st), "clear flag");
             k_bn_low_limb<<<grid1(N), 256, 0, st>>>(d_in_mont, d_in, N, d_bad);
-            hipc(hipMemcpyAsync(&h_bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, st), "copy flag");  // read after the next synchronisation
+            hipc(hipMemcpyAsync(&h_bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, st), "copy flag");  // (a blocking copy: pageable destination)
         }
         u64* dims = (u64*)dalloc_b(4 * N * 8);
         u64* ep = (u64*)dalloc_b((size_t)A * N * 8);
@@ -727,13 +743,8 @@ static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4,
             }
         }
         Fr* d_part = dalloc(1024 * 3);
-        Fr* d_out = dalloc(64);
-        auto build_eq = [&](Fr* eq, const Fr* pt_canon, int n) {
-            const Fr one = fr_one_mont();
-            hipc(hipMemcpyAsync(eq, &one, sizeof(Fr), hipMemcpyHostToDevice, st), "eq seed");
-            hipc(hipStreamSynchronize(st), "sync");  // `one` is a stack temporary
-            for (int i = 0; i < n; i++) k_bn_eq_step<<<grid1((size_t)1 << i), 256, 0, st>>>(eq, (size_t)1 << i, fr_to_mont(pt_canon[i]));
-        };
+        const ResRef r_claimed = res_slots(ctx, 1), r_col = res_slots(ctx, (size_t)nu * 2);
+        auto build_eq = [&](Fr* eq, const Fr* pt_canon, int n) { build_eq_dev(st, eq, pt_canon, n); };
         // r, claimed sum (lasso.rs:85, 264-269)
         Fr* eq = dalloc(N);
         build_eq(eq, &chain[r_at], nu);
@@ -746,22 +757,17 @@ static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4,
         {
             const int grid = (int)std::min<size_t>((L.rows + BN_TPB - 1) / BN_TPB, 1024);
             k_bn_lasso_claim<<<grid, BN_TPB, 0, st>>>(L, eq, ep, mp, d_part);
-            k_bn_reduce<<<1, BN_TPB, 0, st>>>(d_part, grid, 1, d_out);
-            hipc(hipMemcpyAsync(&h_claimed, d_out, sizeof(Fr), hipMemcpyDeviceToHost, st), "copy claimed sum");
+            k_bn_reduce<<<1, BN_TPB, 0, st>>>(d_part, grid, 1, r_claimed.dev);
         }
         // collation sum-check (lasso.rs:271-279): g = poly(0) * sum_i M^i poly(i) over the E tables
         {
             Fr* tabs = dalloc((size_t)A * N);
             k_bn_from_u64<<<grid1((size_t)A * N), 256, 0, st>>>(ep, tabs, (size_t)A * N);
-            std::vector<Fr> pw(A);
-            const Fr m = fr_small(M);
-            Fr c = fr_one_mont();
-            for (int i = 0; i < A; i++) { pw[i] = c; c = fr_mul(c, m); }
             Fr* d_pw = dalloc(A);
-            hipc(hipMemcpy(d_pw, pw.data(), A * sizeof(Fr), hipMemcpyHostToDevice), "upload M powers");
+            k_bn_powers<<<1, 256, 0, st>>>(d_pw, fr_small(M), (size_t)A);   // M^i, i < alpha
             Fr* buf0 = dalloc((size_t)A * N / 2);
             Fr* buf1 = dalloc((size_t)A * std::max<size_t>(N / 4, 1));
-            Fr* d_sums = dalloc((size_t)nu * 2);
+            Fr* d_sums = r_col.dev;
             const Fr* cur = tabs;
             Fr* nxt = buf0;
             if (nu > 32) throw Error("hg_lasso_prove_bn254: more than 32 rounds");
@@ -777,7 +783,6 @@ static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4,
                 nxt = nxt == buf0 ? buf1 : buf0;
             }
             k_bn_reduce_rounds<<<nu, BN_TPB, 0, st>>>(part, rc, 2, d_sums);
-            hipc(hipMemcpyAsync(h_col.data(), d_sums, (size_t)nu * 2 * sizeof(Fr), hipMemcpyDeviceToHost, st), "copy collation sums");
         }
         // MemoryCheckingProver::new (prover.rs:35-89): gamma, tau are the challenges themselves (E = F)
         const Fr gamma = fr_to_mont(chain[gamma_at]), tau = fr_to_mont(chain[tau_at]), gamma2 = fr_mul(gamma, gamma);
@@ -790,22 +795,19 @@ static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4,
                                                   H1 + (size_t)(G + i) * N);
             k_bn_hash_if<<<65536 / 256, 256, 0, st>>>((u32)lp.mems[m].cutoff, final_cts[c], gamma, gamma2, tau, H2 + (size_t)i * M, H2 + (size_t)(G + i) * M);
         }
-        hipc(hipStreamSynchronize(st), "lasso_prove_bn254: sync");
-        if (h_bad) throw Error("hg_lasso_prove_bn254: the node input holds a value that is not below 2^64 (not a range-shifted value)");
         grand_product_core(ctx, 2 * G, N, nullptr, H1, gp1_at, gp1_bytes, tmp_claims, x);  // reads then writes (prover.rs:161-165)
         grand_product_core(ctx, 2 * G, M, nullptr, H2, gp2_at, gp2_bytes, tmp_claims, y);  // inits then finals (prover.rs:167-171)
         // openings (prover.rs:173-178, mod.rs:80-93)
         Fr* eqy = dalloc(M);
         build_eq(eq, x.data(), nu);
         build_eq(eqy, y.data(), 16);
-        auto dot = [&](const Fr* e, const u64* t, size_t n) {
+        std::vector<const Fr*> open_at;
+        auto dot = [&](const Fr* e, const u64* t, size_t n) {   // results land in the mapped buffer; read after the final synchronisation
             const int grid = (int)std::min<size_t>((n + BN_TPB - 1) / BN_TPB, 1024);
+            const ResRef o = res_slots(ctx, 1);
             k_bn_dot_u64<<<grid, BN_TPB, 0, st>>>(e, t, n, d_part);
-            k_bn_reduce<<<1, BN_TPB, 0, st>>>(d_part, grid, 1, d_out);
-            Fr v;
-            hipc(hipMemcpyAsync(&v, d_out, sizeof(Fr), hipMemcpyDeviceToHost, st), "copy opening");
-            hipc(hipStreamSynchronize(st), "sync");
-            opens.push_back(v);
+            k_bn_reduce<<<1, BN_TPB, 0, st>>>(d_part, grid, 1, o.dev);
+            open_at.push_back(o.host);
         };
         for (auto& chk : lp.chunks) {
             const int c = chk.first;
@@ -814,7 +816,11 @@ static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4,
             dot(eqy, final_cts[c], M);
             for (int m : chk.second) dot(eq, ep + (size_t)m * N, N);
         }
-        hipc(hipGetLastError(), "lasso_prove_bn254: launch");
+        res_sync(ctx, st, "lasso_prove_bn254: sync");
+        if (h_bad) throw Error("hg_lasso_prove_bn254: the node input holds a value that is not below 2^64 (not a range-shifted value)");
+        h_claimed = *r_claimed.host;
+        for (size_t i = 0; i < h_col.size(); i++) h_col[i] = r_col.host[i];
+        for (const Fr* q : open_at) opens.push_back(*q);
     } catch (...) {
         ctx->arena_rewind(arena_mark);
         throw;

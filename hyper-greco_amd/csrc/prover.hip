@@ -63,6 +63,7 @@ void hg_ctx::arena_reset() {
     }
     for (auto& c : chunks) c.used = 0;
     stage_used = 0;
+    bn_res_used = 0;
 }
 void hg_ctx::ensure_chain(size_t n_e) {
     if (n_e <= chal_e) return;
