@@ -14,6 +14,7 @@
 #include <chrono>
 #include <map>
 #include "bn254.cuh"
+#include "bn254_wide.cuh"
 #include "host.hpp"
 #include "prover.hpp"
 #include "kernels.hpp"
@@ -63,12 +64,18 @@ __global__ void k_bn_from_mont(Fr* __restrict__ t, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) t[i] = fr_from_mont(t[i]);
 }
-// op 0 add, 1 sub, 2 mul (canonical in / out): the field KAT entry point
+// op 0 add, 1 sub, 2 mul, 3 / 4 the column-accumulator forms (canonical in / out): the field KAT entry point
 __global__ void k_bn_binop(int op, size_t n, const Fr* __restrict__ a, const Fr* __restrict__ b, Fr* __restrict__ out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Fr x = fr_to_mont(a[i]), y = fr_to_mont(b[i]);
-    Fr r = op == 0 ? fr_add(x, y) : (op == 1 ? fr_sub(x, y) : fr_mul(x, y));
+    Fr r;
+    if (op == 3) r = fr_mul_wide(x, y);                       // column-accumulator product (bn254_wide.cuh)
+    else if (op == 4) {                                       // a b + a a + b b through one deferred reduction
+        WCol w = wcol_zero();
+        wcol_mac(w, x, y); wcol_mac(w, x, x); wcol_mac(w, y, y);
+        r = wcol_reduce(w);
+    } else r = op == 0 ? fr_add(x, y) : (op == 1 ? fr_sub(x, y) : fr_mul(x, y));
     out[i] = fr_from_mont(r);
 }
 
@@ -266,15 +273,15 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_tail(const Fr* __restrict__ in, F
                 const Fr x0 = cur[2 * j], y0 = cur[2 * j + 1];
                 const Fr d0 = fr_sub(y0, x0);
                 const Fr p2 = fr_add(y0, d0), p3 = fr_add(p2, d0);
-                acc[0] = fr_add(acc[0], fr_mul(x0, fr_mul(xa, xb)));
-                acc[1] = fr_add(acc[1], fr_mul(p2, fr_mul(a2, b2)));
-                acc[NV - 1] = fr_add(acc[NV - 1], fr_mul(p3, fr_mul(fr_add(a2, da), fr_add(b2, db))));
+                acc[0] = fr_add(acc[0], fr_mul_wide(x0, fr_mul_wide(xa, xb)));
+                acc[1] = fr_add(acc[1], fr_mul_wide(p2, fr_mul_wide(a2, b2)));
+                acc[NV - 1] = fr_add(acc[NV - 1], fr_mul_wide(p3, fr_mul_wide(fr_add(a2, da), fr_add(b2, db))));
             } else {
-                acc[0] = fr_add(acc[0], fr_mul(xa, xb));
-                acc[1] = fr_add(acc[1], fr_mul(a2, b2));
+                acc[0] = fr_add(acc[0], fr_mul_wide(xa, xb));
+                acc[1] = fr_add(acc[1], fr_mul_wide(a2, b2));
             }
-            nxt[(size_t)(2 * i) * half + j] = fr_add(xa, fr_mul(r, da));
-            nxt[(size_t)(2 * i + 1) * half + j] = fr_add(xb, fr_mul(r, db));
+            nxt[(size_t)(2 * i) * half + j] = fr_add(xa, fr_mul_wide(r, da));
+            nxt[(size_t)(2 * i + 1) * half + j] = fr_add(xb, fr_mul_wide(r, db));
         }
 #pragma unroll
         for (int v = 0; v < NV; v++) {
@@ -419,7 +426,7 @@ void sumcheck_bn254(hg_ctx* ctx, int kind, size_t nv, size_t ntab, const u64* co
 }
 
 void field_op_bn254(hg_ctx* ctx, int op, size_t n, const u64* a, const u64* b, u64* out) {
-    if (op < 0 || op > 2) throw Error("hg_bn254_field_op: op must be 0 (add), 1 (sub) or 2 (mul)");
+    if (op < 0 || op > 4) throw Error("hg_bn254_field_op: op must be 0 (add), 1 (sub), 2 (mul), 3 (wide mul) or 4 (wide a b + a a + b b)");
     hipc(hipSetDevice(ctx->device), "hipSetDevice");
     Fr *da = nullptr, *db = nullptr, *dc = nullptr;
     hipc(hipMalloc((void**)&da, n * sizeof(Fr)), "hipMalloc");

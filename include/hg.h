@@ -161,7 +161,8 @@ int hg_challenges(size_t n, uint64_t* out);
  * element. hg_prove_bn254 is the whole BfvEncrypt::prove over Fr; the entry points before it expose its parts for parity tests. */
 /* = Keccak256Transcript::squeeze_challenge over Fr: c_j = LE(Keccak^j("")) mod r [REF transcript.rs:146-157,198-203]; n x 4 limbs */
 int hg_challenges_bn254(size_t n, uint64_t* out4);
-/* device field arithmetic on n element pairs: op 0 add, 1 sub, 2 mul (known-answer tests of the Montgomery kernels) */
+/* device field arithmetic on n element pairs: op 0 add, 1 sub, 2 mul, 3 mul through the column accumulators, 4 a b + a a + b b
+ * through one deferred reduction (known-answer tests of the Montgomery kernels) */
 int hg_bn254_field_op(hg_ctx* ctx, int op, size_t n, const uint64_t* a4, const uint64_t* b4, uint64_t* out4);
 /* = gkr::sum_check::prove_sum_check over Fr on caller tables, same shapes and conventions as hg_sumcheck
  *   [REF call sites lasso.rs:278-279, prover.rs:242-252]. tables[i]: host pointer, 2^nv elements (4 limbs each).

@@ -313,6 +313,8 @@ def test_bn254_field_kernels_against_python_integers(ctx):
     assert ctx.bn254_field_op(0, a, b) == [(x + y) % bn.R for x, y in zip(a, b)]
     assert ctx.bn254_field_op(1, a, b) == [(x - y) % bn.R for x, y in zip(a, b)]
     assert ctx.bn254_field_op(2, a, b) == [(x * y) % bn.R for x, y in zip(a, b)]
+    assert ctx.bn254_field_op(3, a, b) == [(x * y) % bn.R for x, y in zip(a, b)]                    # column-accumulator product
+    assert ctx.bn254_field_op(4, a, b) == [(x * y + x * x + y * y) % bn.R for x, y in zip(a, b)]    # three products, one reduction
 
 
 def test_bn254_challenges_match_the_oracle():
