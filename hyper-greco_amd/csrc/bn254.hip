@@ -165,48 +165,48 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_round(const Fr* __restrict__ in, 
 }
 // Grand-product round of prove_grand_product, tuned: (a) in the FIRST round of a layer the folded LEFT table of pair i is stored
 // multiplied by its weight gamma^i, so later rounds need no weights (the host divides the final left evaluations by
-// gamma^i again); (b) the three dot products over the pairs are accumulated as unreduced 512-bit integers and Montgomery-
-// reduced once per pair index j (w512_*): per pair 3 half-cost products + 2 fold products instead of 8 full ones.
+// gamma^i again); (b) the dot product over the pairs is accumulated unreduced in column accumulators (bn254_wide.cuh) and
+// Montgomery-reduced once per pair index j; (c) the three evaluation points are three workgroup sets (blockIdx.z = 0: g(0) and
+// the left fold, 1: g(2) and the right fold, 2: g(3)): one accumulator per thread (three would not fit two waves per SIMD) and
+// a three times shorter dependent chain; the inputs are read three times, which an ALU-bound kernel does not notice;
+// (d) gridDim.y = P: the pairs are dealt round-robin to P thread groups so that small rounds are not one long serial chain per
+// thread (Montgomery reduction is linear: every group reduces its own partial dot product and multiplies by p_v itself).
 template <bool FIRST>
 __global__ __launch_bounds__(BN_TPB) void k_bn_gp_round(const Fr* __restrict__ in, Fr* __restrict__ out, int ntab, size_t half, Fr r,
                                                         const Fr* __restrict__ pw, Fr* __restrict__ partials) {
-    // gridDim.y = P: the pairs are dealt round-robin to P thread groups so that small rounds are not one long serial chain per
-    // thread (Montgomery reduction is linear: every group reduces its own partial dot products and multiplies by p_v itself)
     __shared__ Fr sm[BN_TPB];
-    Fr acc[3] = {fr_zero(), fr_zero(), fr_zero()};
-    const int nb = ntab >> 1, P = gridDim.y, pi = blockIdx.y;
+    Fr acc = fr_zero();
+    const int nb = ntab >> 1, P = gridDim.y, pi = blockIdx.y, v = blockIdx.z;
     for (size_t j = (size_t)blockIdx.x * BN_TPB + threadIdx.x; j < half; j += (size_t)gridDim.x * BN_TPB) {
-        W512 a0 = w512_zero(), a2 = w512_zero(), a3 = w512_zero();
-        Fr p0, p2, p3;  // table 0 (= left table of pair 0, weight gamma^0 = 1) at 0, 2, 3
+        WCol a = wcol_zero();
+        Fr pv;  // table 0 (= left table of pair 0, weight gamma^0 = 1) at the evaluation point 0 / 2 / 3
         {
             const Fr x = in[2 * j], y = in[2 * j + 1];
             const Fr d = fr_sub(y, x);
-            p0 = x; p2 = fr_add(y, d); p3 = fr_add(p2, d);
+            pv = v == 0 ? x : (v == 1 ? fr_add(y, d) : fr_add(fr_add(y, d), d));
         }
         for (int i = pi; i < nb; i += P) {
-            Fr xl = in[(size_t)(2 * i) * 2 * half + 2 * j], yl = in[(size_t)(2 * i) * 2 * half + 2 * j + 1];
+            const Fr xl = in[(size_t)(2 * i) * 2 * half + 2 * j], yl = in[(size_t)(2 * i) * 2 * half + 2 * j + 1];
             const Fr xr = in[(size_t)(2 * i + 1) * 2 * half + 2 * j], yr = in[(size_t)(2 * i + 1) * 2 * half + 2 * j + 1];
-            Fr dl = fr_sub(yl, xl);
-            if (FIRST) { const Fr w = pw[i]; xl = fr_mul(w, xl); dl = fr_mul(w, dl); }   // weight rides in the left table from here on
-            const Fr dr = fr_sub(yr, xr);
-            const Fr l2 = fr_add(fr_add(xl, dl), dl), l3 = fr_add(l2, dl);
-            const Fr r2 = fr_add(yr, dr), r3 = fr_add(r2, dr);
-            w512_mac(a0, xl, xr);
-            w512_mac(a2, l2, r2);
-            w512_mac(a3, l3, r3);
-            out[(size_t)(2 * i) * half + j] = fr_add(xl, fr_mul(r, dl));
-            out[(size_t)(2 * i + 1) * half + j] = fr_add(xr, fr_mul(r, dr));
+            const Fr dl = fr_sub(yl, xl), dr = fr_sub(yr, xr);
+            Fr lv, rv;  // the pair at the evaluation point
+            if (v == 0) { lv = xl; rv = xr; }
+            else if (v == 1) { lv = fr_add(yl, dl); rv = fr_add(yr, dr); }
+            else { lv = fr_add(fr_add(yl, dl), dl); rv = fr_add(fr_add(yr, dr), dr); }
+            if (FIRST) lv = fr_mul_wide(pw[i], lv);   // the weight is linear in the left operand; it rides in the left table from here on
+            wcol_mac(a, lv, rv);
+            if (v == 0) {
+                const Fr wdl = FIRST ? fr_mul_wide(pw[i], dl) : dl;
+                out[(size_t)(2 * i) * half + j] = fr_add(lv, fr_mul_wide(r, wdl));
+            } else if (v == 1) {
+                out[(size_t)(2 * i + 1) * half + j] = fr_add(xr, fr_mul_wide(r, dr));
+            }
         }
-        acc[0] = fr_add(acc[0], fr_mul(p0, w512_reduce(a0)));
-        acc[1] = fr_add(acc[1], fr_mul(p2, w512_reduce(a2)));
-        acc[2] = fr_add(acc[2], fr_mul(p3, w512_reduce(a3)));
+        acc = fr_add(acc, fr_mul_wide(pv, wcol_reduce(a)));
     }
     const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-#pragma unroll
-    for (int v = 0; v < 3; v++) {
-        Fr s = block_sum_fr(acc[v], sm);
-        if (threadIdx.x == 0) partials[blk * 3 + v] = s;
-    }
+    const Fr s = block_sum_fr(acc, sm);
+    if (threadIdx.x == 0) partials[blk * 3 + v] = s;
 }
 // launch shape of a round over `half` pair indices and `nitems` independent items (pairs / tables): grid.x workgroups along j,
 // grid.y groups of items; large rounds keep one thread per j, small ones spread the items
@@ -554,8 +554,8 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
                 const Fr r = fr_to_mont(chain[L.r_at + rd]);
                 const RoundGrid g = round_grid(half, (int)nb);
                 Fr* pr = part + (size_t)rd * BN_PART_STRIDE * 3;
-                if (rd == 0) k_bn_gp_round<true><<<dim3(g.gx, g.gy), BN_TPB, 0, st>>>(cur, nxt, (int)ntab, half, r, d_pw, pr);
-                else k_bn_gp_round<false><<<dim3(g.gx, g.gy), BN_TPB, 0, st>>>(cur, nxt, (int)ntab, half, r, d_pw, pr);
+                if (rd == 0) k_bn_gp_round<true><<<dim3(g.gx, g.gy, 3), BN_TPB, 0, st>>>(cur, nxt, (int)ntab, half, r, d_pw, pr);
+                else k_bn_gp_round<false><<<dim3(g.gx, g.gy, 3), BN_TPB, 0, st>>>(cur, nxt, (int)ntab, half, r, d_pw, pr);
                 rc.n[rd] = g.blocks();
                 cur = nxt;
                 nxt = nxt == buf0 ? buf1 : buf0;
