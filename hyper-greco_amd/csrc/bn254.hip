@@ -115,17 +115,18 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_round(const Fr* __restrict__ in, 
             p0 = x; p2 = fr_add(y, d); p3 = fr_add(p2, d);
         }
         if (KIND == BN_COLLATION) {
+            WCol c0 = wcol_zero(), c2 = wcol_zero();   // the two weighted sums stay unreduced over the tables
             for (int i = pi; i < ntab; i += P) {
                 const Fr x = in[(size_t)i * 2 * half + 2 * j], y = in[(size_t)i * 2 * half + 2 * j + 1];
                 const Fr d = fr_sub(y, x);
                 const Fr v2 = fr_add(y, d);
                 const Fr w = pw[i];
-                s0 = fr_add(s0, fr_mul(w, x));
-                s2 = fr_add(s2, fr_mul(w, v2));
-                out[(size_t)i * half + j] = fr_add(x, fr_mul(r, d));
+                wcol_mac(c0, w, x);
+                wcol_mac(c2, w, v2);
+                out[(size_t)i * half + j] = fr_add(x, fr_mul_wide(r, d));
             }
-            acc[0] = fr_add(acc[0], fr_mul(p0, s0));
-            acc[1] = fr_add(acc[1], fr_mul(p2, s2));
+            acc[0] = fr_add(acc[0], fr_mul_wide(p0, wcol_reduce(c0)));
+            acc[1] = fr_add(acc[1], fr_mul_wide(p2, wcol_reduce(c2)));
         } else {
             const int nb = ntab >> 1;
             for (int i = pi; i < nb; i += P) {
