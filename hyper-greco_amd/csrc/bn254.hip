@@ -251,49 +251,53 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_reduce_rounds(const Fr* __restric
 constexpr int BN_TAIL_HALF = 16, BN_TAIL_ROUNDS = 8;  // 16: at most two work items per thread in the first tail round
 struct TailR { Fr r[BN_TAIL_ROUNDS]; };
 template <int KIND>
-__global__ __launch_bounds__(BN_TPB) void k_bn_tail(const Fr* __restrict__ in, Fr* __restrict__ buf, int npairs, int half0, int nrounds, TailR rs,
-                                                    Fr* __restrict__ sums_out, Fr* __restrict__ fin_out) {
+__global__ __launch_bounds__(BN_TPB * (KIND == BN_GRANDPROD ? 3 : 2)) void k_bn_tail(const Fr* __restrict__ in, Fr* __restrict__ buf, int npairs, int half0,
+                                                                                       int nrounds, TailR rs, Fr* __restrict__ sums_out,
+                                                                                       Fr* __restrict__ fin_out) {
+    // blockDim.x = NV * BN_TPB: thread group v evaluates the round polynomial at its own point (0, 2[, 3]) and groups 0 / 1 write the
+    // left / right folds, so the per-item dependent chain is one or two products instead of eight
     constexpr int NV = KIND == BN_GRANDPROD ? 3 : 2;
-    __shared__ Fr sm[BN_TPB];
+    __shared__ Fr sm[NV][BN_TPB];
+    const int v = threadIdx.x / BN_TPB, t = threadIdx.x % BN_TPB;
     const int ntab = 2 * npairs;
-    const Fr* cur = in;                         // table t at cur + t * 2 * half
-    Fr* nxt = buf;                              // table t at nxt + t * half
+    const Fr* cur = in;                         // table q at cur + q * 2 * half
+    Fr* nxt = buf;                              // table q at nxt + q * half
     for (int rd = 0; rd < nrounds; rd++) {
         const int half = half0 >> rd;
         const Fr r = rs.r[rd];
-        Fr acc[NV];
-#pragma unroll
-        for (int v = 0; v < NV; v++) acc[v] = fr_zero();
-        for (int idx = threadIdx.x; idx < half * npairs; idx += BN_TPB) {
+        Fr acc = fr_zero();
+        for (int idx = t; idx < half * npairs; idx += BN_TPB) {
             const int j = idx % half, i = idx / half;
             const Fr xa = cur[(size_t)(2 * i) * 2 * half + 2 * j], ya = cur[(size_t)(2 * i) * 2 * half + 2 * j + 1];
             const Fr xb = cur[(size_t)(2 * i + 1) * 2 * half + 2 * j], yb = cur[(size_t)(2 * i + 1) * 2 * half + 2 * j + 1];
             const Fr da = fr_sub(ya, xa), db = fr_sub(yb, xb);
-            const Fr a2 = fr_add(ya, da), b2 = fr_add(yb, db);
+            Fr av, bv;  // the pair at this group's evaluation point
+            if (v == 0) { av = xa; bv = xb; }
+            else if (v == 1) { av = fr_add(ya, da); bv = fr_add(yb, db); }
+            else { av = fr_add(fr_add(ya, da), da); bv = fr_add(fr_add(yb, db), db); }
+            Fr term = fr_mul_wide(av, bv);
             if (KIND == BN_GRANDPROD) {
                 const Fr x0 = cur[2 * j], y0 = cur[2 * j + 1];
                 const Fr d0 = fr_sub(y0, x0);
-                const Fr p2 = fr_add(y0, d0), p3 = fr_add(p2, d0);
-                acc[0] = fr_add(acc[0], fr_mul_wide(x0, fr_mul_wide(xa, xb)));
-                acc[1] = fr_add(acc[1], fr_mul_wide(p2, fr_mul_wide(a2, b2)));
-                acc[NV - 1] = fr_add(acc[NV - 1], fr_mul_wide(p3, fr_mul_wide(fr_add(a2, da), fr_add(b2, db))));
-            } else {
-                acc[0] = fr_add(acc[0], fr_mul_wide(xa, xb));
-                acc[1] = fr_add(acc[1], fr_mul_wide(a2, b2));
+                const Fr pv = v == 0 ? x0 : (v == 1 ? fr_add(y0, d0) : fr_add(fr_add(y0, d0), d0));
+                term = fr_mul_wide(pv, term);
             }
-            nxt[(size_t)(2 * i) * half + j] = fr_add(xa, fr_mul_wide(r, da));
-            nxt[(size_t)(2 * i + 1) * half + j] = fr_add(xb, fr_mul_wide(r, db));
+            acc = fr_add(acc, term);
+            if (v == 0) nxt[(size_t)(2 * i) * half + j] = fr_add(xa, fr_mul_wide(r, da));
+            else if (v == 1) nxt[(size_t)(2 * i + 1) * half + j] = fr_add(xb, fr_mul_wide(r, db));
         }
-#pragma unroll
-        for (int v = 0; v < NV; v++) {
-            const Fr s = block_sum_fr(acc[v], sm);
-            if (threadIdx.x == 0) sums_out[rd * NV + v] = fr_from_mont(s);
+        sm[v][t] = acc;
+        __syncthreads();
+        for (int s = BN_TPB / 2; s > 0; s >>= 1) {
+            if (t < s) sm[v][t] = fr_add(sm[v][t], sm[v][t + s]);
+            __syncthreads();
         }
-        __syncthreads();                        // the folded tables are complete (and visible to the workgroup)
+        if (t == 0) sums_out[rd * NV + v] = fr_from_mont(sm[v][0]);
+        __syncthreads();                        // sums consumed; the folded tables are complete (and visible to the workgroup)
         cur = nxt;
         nxt = nxt == buf ? buf + (size_t)ntab * half0 : buf;
     }
-    for (int t = threadIdx.x; t < ntab; t += BN_TPB) fin_out[t] = fr_from_mont(cur[t]);
+    for (int q = threadIdx.x; q < ntab; q += blockDim.x) fin_out[q] = fr_from_mont(cur[q]);
 }
 
 // ---- host arithmetic for the transcript replay (Montgomery form) ---------------------------------------------
@@ -567,7 +571,7 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
                 TailR tr;
                 for (int q = 0; q < BN_TAIL_ROUNDS; q++) tr.r[q] = q < n - nmain ? fr_to_mont(chain[L.r_at + nmain + q]) : fr_zero();
                 Fr* tbuf = dalloc(2 * ntab * (size_t)half0);
-                k_bn_tail<BN_GRANDPROD><<<1, BN_TPB, 0, st>>>(cur, tbuf, (int)nb, half0, n - nmain, tr, L.d_sums + (size_t)nmain * 3, L.d_final);
+                k_bn_tail<BN_GRANDPROD><<<1, 3 * BN_TPB, 0, st>>>(cur, tbuf, (int)nb, half0, n - nmain, tr, L.d_sums + (size_t)nmain * 3, L.d_final);
             } else {
                 k_bn_copy_from_mont<<<(unsigned)((ntab + 255) / 256), 256, 0, st>>>(cur, L.d_final, ntab);
             }
