@@ -343,7 +343,8 @@ __global__ void k_bn_copy_from_mont(const Fr* __restrict__ src, Fr* __restrict__
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = fr_from_mont(src[i]);
 }
-static void build_eq_dev(hipStream_t st, Fr* eq, const Fr* pt_canon, int n);  // bn254_gkr.inc
+static void build_eq_dev(hipStream_t st, Fr* eq, const Fr* pt_canon, int n, Fr* scratch);  // bn254_gkr.inc
+static size_t eq_scratch_len(int n);
 __global__ void k_bn_powers(Fr* __restrict__ W, Fr w, size_t n);                  // W[i] = w^i (below)
 
 // prove_sum_check on caller tables (all in the base field; E = F). Conventions as for Goldilocks:
@@ -643,50 +644,58 @@ __global__ void k_bn_eq_step(Fr* __restrict__ eq, size_t cur, Fr r) {
     eq[j + cur] = hi;
     eq[j] = fr_sub(eq[j], hi);
 }
-struct MPow { Fr v[5]; };
+// Integer tables meet field constants through "double Montgomery" constants: for a plain integer x and K2 = K R^2 mod r (the raw
+// limbs of fr_to_mont(K~)), the Montgomery reduction of x * K2 is (x K) R, i.e. x K in Montgomery form - one short multiply-
+// accumulate (wcol_mac_u64) per table entry and one reduction per hash / row instead of a conversion and a full product each.
+struct MPow { Fr v[5]; };  // (M^i) R^2
 // sum_k eq[k] * sum_i M^i E_{mems(lookup(k))[i]}[k] (lasso.rs:422-454, range.rs:184-195) -> per-workgroup partials
-__global__ __launch_bounds__(BN_TPB) void k_bn_lasso_claim(dev::LassoDev L, const Fr* __restrict__ eq, const u64* __restrict__ e_polys, MPow mp,
+__global__ __launch_bounds__(BN_TPB) void k_bn_lasso_claim(dev::LassoDev L, const Fr* __restrict__ eq, const u64* __restrict__ e_polys, MPow mp2,
                                                            Fr* __restrict__ partials) {
     __shared__ Fr sm[BN_TPB];
     const size_t N = (size_t)1 << L.nu;
-    Fr acc = fr_zero();
+    WCol acc = wcol_zero();   // sum of eq~ * comb~ over this thread's rows (a handful)
     for (size_t k = (size_t)blockIdx.x * BN_TPB + threadIdx.x; k < L.rows; k += (size_t)gridDim.x * BN_TPB) {
         const int l = L.seg_lookup[k >> L.seg_shift];
-        Fr comb = fr_zero();
-        for (int i = 0; i < L.lookup_nmems[l]; i++)
-            comb = fr_add(comb, fr_mul(mp.v[i], fr_to_mont(fr_make(e_polys[(size_t)L.lookup_mems[l][i] * N + k], 0, 0, 0))));
-        acc = fr_add(acc, fr_mul(eq[k], comb));
+        WCol c = wcol_zero();
+        for (int i = 0; i < L.lookup_nmems[l]; i++) wcol_mac_u64(c, e_polys[(size_t)L.lookup_mems[l][i] * N + k], mp2.v[i]);
+        wcol_mac(acc, eq[k], wcol_reduce(c));
     }
-    Fr s = block_sum_fr(acc, sm);
+    Fr s = block_sum_fr(wcol_reduce(acc), sm);
     if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
 // sum_k eq[k] * t[k] for a table of small integers
 __global__ __launch_bounds__(BN_TPB) void k_bn_dot_u64(const Fr* __restrict__ eq, const u64* __restrict__ t, size_t n, Fr* __restrict__ partials) {
     __shared__ Fr sm[BN_TPB];
-    Fr acc = fr_zero();
-    for (size_t k = (size_t)blockIdx.x * BN_TPB + threadIdx.x; k < n; k += (size_t)gridDim.x * BN_TPB)
-        acc = fr_add(acc, fr_mul(eq[k], fr_to_mont(fr_make(t[k], 0, 0, 0))));
-    Fr s = block_sum_fr(acc, sm);
+    WCol acc = wcol_zero();
+    for (size_t k = (size_t)blockIdx.x * BN_TPB + threadIdx.x; k < n; k += (size_t)gridDim.x * BN_TPB) wcol_mac_u64(acc, t[k], eq[k]);
+    // reduce(sum t eq~) = sum t eq as a plain residue: back to Montgomery form once per thread
+    Fr s = block_sum_fr(fr_to_mont(wcol_reduce(acc)), sm);
     if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
 // h(a,v,t) = a + v gamma + t gamma^2 - tau (prover.rs:44) for the reads (t) and writes (t + 1) of one memory
-__global__ void k_bn_hash_rw(size_t n, const u64* __restrict__ dim, const u64* __restrict__ ep, const u64* __restrict__ ts, Fr gamma, Fr gamma2,
-                             Fr tau, Fr* __restrict__ rd, Fr* __restrict__ wr) {
+struct HashK { Fr one2, gamma2x, gammasq2x, gammasq, tau; };  // R^2, gamma R^2, gamma^2 R^2 (raw), gamma^2 and tau (Montgomery)
+__global__ void k_bn_hash_rw(size_t n, const u64* __restrict__ dim, const u64* __restrict__ ep, const u64* __restrict__ ts, HashK K,
+                             Fr* __restrict__ rd, Fr* __restrict__ wr) {
     size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
-    const Fr a = fr_to_mont(fr_make(dim[j], 0, 0, 0)), v = fr_to_mont(fr_make(ep[j], 0, 0, 0)), t = fr_to_mont(fr_make(ts[j], 0, 0, 0));
-    const Fr h = fr_sub(fr_add(fr_add(a, fr_mul(v, gamma)), fr_mul(t, gamma2)), tau);
+    WCol w = wcol_zero();
+    wcol_mac_u64(w, dim[j], K.one2);
+    wcol_mac_u64(w, ep[j], K.gamma2x);
+    wcol_mac_u64(w, ts[j], K.gammasq2x);
+    const Fr h = fr_sub(wcol_reduce(w), K.tau);
     rd[j] = h;
-    wr[j] = fr_add(h, gamma2);
+    wr[j] = fr_add(h, K.gammasq);
 }
-__global__ void k_bn_hash_if(u32 cutoff, const u64* __restrict__ fc, Fr gamma, Fr gamma2, Fr tau, Fr* __restrict__ init, Fr* __restrict__ fin) {
+__global__ void k_bn_hash_if(u32 cutoff, const u64* __restrict__ fc, HashK K, Fr* __restrict__ init, Fr* __restrict__ fin) {
     u32 a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= 65536) return;
-    const Fr av = fr_to_mont(fr_make(a, 0, 0, 0));
-    const Fr tv = a < cutoff ? av : fr_zero();
-    const Fr h0 = fr_sub(fr_add(av, fr_mul(tv, gamma)), tau);
-    init[a] = h0;
-    fin[a] = fr_add(h0, fr_mul(fr_to_mont(fr_make(fc[a], 0, 0, 0)), gamma2));
+    WCol w = wcol_zero();
+    wcol_mac_u64(w, a, K.one2);
+    if (a < cutoff) wcol_mac_u64(w, a, K.gamma2x);
+    WCol w2 = w;
+    wcol_mac_u64(w2, fc[a], K.gammasq2x);
+    init[a] = fr_sub(wcol_reduce(w), K.tau);
+    fin[a] = fr_sub(wcol_reduce(w2), K.tau);
 }
 
 // low limbs of a Montgomery-form table; *bad is set when an element does not fit one limb
@@ -756,15 +765,16 @@ static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4,
         }
         Fr* d_part = dalloc(1024 * 3);
         const ResRef r_claimed = res_slots(ctx, 1), r_col = res_slots(ctx, (size_t)nu * 2);
-        auto build_eq = [&](Fr* eq, const Fr* pt_canon, int n) { build_eq_dev(st, eq, pt_canon, n); };
+        Fr* eq_scratch = dalloc(eq_scratch_len(std::max(nu, 16)));
+        auto build_eq = [&](Fr* eq, const Fr* pt_canon, int n) { build_eq_dev(st, eq, pt_canon, n, eq_scratch); };
         // r, claimed sum (lasso.rs:85, 264-269)
         Fr* eq = dalloc(N);
         build_eq(eq, &chain[r_at], nu);
         MPow mp;
         {
             const Fr m = fr_small(M);
-            mp.v[0] = fr_one_mont();
-            for (int i = 1; i < 5; i++) mp.v[i] = fr_mul(mp.v[i - 1], m);
+            Fr pwr = fr_one_mont();
+            for (int i = 0; i < 5; i++) { mp.v[i] = fr_to_mont(pwr); pwr = fr_mul(pwr, m); }   // (M^i) R^2: see k_bn_lasso_claim
         }
         {
             const int grid = (int)std::min<size_t>((L.rows + BN_TPB - 1) / BN_TPB, 1024);
@@ -798,14 +808,16 @@ static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4,
         }
         // MemoryCheckingProver::new (prover.rs:35-89): gamma, tau are the challenges themselves (E = F)
         const Fr gamma = fr_to_mont(chain[gamma_at]), tau = fr_to_mont(chain[tau_at]), gamma2 = fr_mul(gamma, gamma);
+        HashK HK;
+        HK.one2 = fr_r2(); HK.gamma2x = fr_to_mont(gamma); HK.gammasq2x = fr_to_mont(gamma2); HK.gammasq = gamma2; HK.tau = tau;
         const int G = (int)lp.gkr_order.size();
         Fr* H1 = dalloc((size_t)2 * G * N);
         Fr* H2 = dalloc((size_t)2 * G * M);
         for (int i = 0; i < G; i++) {
             const int m = lp.gkr_order[i], c = lp.gkr_chunk[i];
-            k_bn_hash_rw<<<grid1(N), 256, 0, st>>>(N, dims + (size_t)c * N, ep + (size_t)m * N, read_ts[c], gamma, gamma2, tau, H1 + (size_t)i * N,
+            k_bn_hash_rw<<<grid1(N), 256, 0, st>>>(N, dims + (size_t)c * N, ep + (size_t)m * N, read_ts[c], HK, H1 + (size_t)i * N,
                                                   H1 + (size_t)(G + i) * N);
-            k_bn_hash_if<<<65536 / 256, 256, 0, st>>>((u32)lp.mems[m].cutoff, final_cts[c], gamma, gamma2, tau, H2 + (size_t)i * M, H2 + (size_t)(G + i) * M);
+            k_bn_hash_if<<<65536 / 256, 256, 0, st>>>((u32)lp.mems[m].cutoff, final_cts[c], HK, H2 + (size_t)i * M, H2 + (size_t)(G + i) * M);
         }
         grand_product_core(ctx, 2 * G, N, nullptr, H1, gp1_at, gp1_bytes, tmp_claims, x);  // reads then writes (prover.rs:161-165)
         grand_product_core(ctx, 2 * G, M, nullptr, H2, gp2_at, gp2_bytes, tmp_claims, y);  // inits then finals (prover.rs:167-171)

@@ -63,6 +63,20 @@ __device__ __forceinline__ void wcol_mac(WCol& w, const Fr& a, const Fr& b) {
     }
 }
 
+// w += x * b for a plain 64-bit integer x (table entries of the integer kernels: addresses, counters, limb values): two limb rows
+__device__ __forceinline__ void wcol_mac_u64(WCol& w, u64 x, const Fr& b) {
+    u32 bl[8];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { bl[2 * i] = (u32)b.l[i]; bl[2 * i + 1] = (u32)(b.l[i] >> 32); }
+    const u32 xl[2] = {(u32)x, (u32)(x >> 32)};
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        BN_WIDE_ROW4(w.C[i], w.C[i + 1], w.C[i + 2], w.C[i + 3], w.T[i], w.T[i + 1], w.T[i + 2], w.T[i + 3], xl[i], bl[0], bl[1], bl[2], bl[3]);
+        BN_WIDE_ROW4(w.C[i + 4], w.C[i + 5], w.C[i + 6], w.C[i + 7], w.T[i + 4], w.T[i + 5], w.T[i + 6], w.T[i + 7], xl[i], bl[4], bl[5], bl[6],
+                     bl[7]);
+    }
+}
+
 // running normalisation: 96-bit accumulator (lo, hi) at the weight of the current column
 struct WRun { u64 lo; u32 hi; };
 __device__ __forceinline__ void wrun_add(WRun& r, u64 v) {
