@@ -877,23 +877,7 @@ struct Prover {
         u64 gamma = gamma_e.c0, tau = tau_e.c0;     // prover.rs:38-39: base limb 0 only
         // counters: only the memories whose index equals a chunk (dimension) index reach the transcript
         // (lasso.rs:317-319 indexes read_ts/final_cts by chunk index)
-        std::map<int, u64*> read_ts, final_cts;
-        if (need_counters) {
-            size_t tb = dev::lasso_counter_temp_bytes(N);
-            void* temp = ctx->alloc(tb);
-            u32* keys = ctx->alloc_n<u32>(N); u32* keys2 = ctx->alloc_n<u32>(N);
-            u32* rows = ctx->alloc_n<u32>(N); u32* rows2 = ctx->alloc_n<u32>(N);
-            u32* starts = ctx->alloc_n<u32>(65537);
-            for (auto& chk : lp.chunks) {
-                int c = chk.first;
-                read_ts[c] = ctx->alloc_n<u64>(N);
-                final_cts[c] = ctx->alloc_n<u64>(M);
-                ctx->prof_begin(cls_aux, (double)N * 40);
-                dev::lasso_counters(st, L, c, dims, read_ts[c], final_cts[c], temp, tb, keys, keys2, rows, rows2, starts);
-                ctx->prof_end();
-            }
-        }
-        // MemoryCheckingProver::new (prover.rs:35-89)
+        // MemoryCheckingProver::new (prover.rs:35-89): which memories of grand product #1 this rank holds
         const int G = (int)lp.gkr_order.size();
         const bool split = world > 1;  // grand product #1 split by memory over the ranks
         std::vector<int> local_pairs;  // global pair ids (reads: i, writes: G + i) whose hash rows this rank holds, ascending
@@ -905,6 +889,29 @@ struct Prover {
             if (p0_only) local_pairs.push_back(0);
             for (int i : local_mems) local_pairs.push_back(i);
             for (int i : local_mems) local_pairs.push_back(G + i);
+        }
+        // a rank that only holds a few memories of grand product #1 needs the counters of their chunks only
+        std::vector<char> need_chunk(4, (!split || do_gp2 || do_open) ? 1 : 0);
+        if (any_gp1 && split) {
+            if (p0_only) need_chunk[lp.gkr_chunk[0]] = 1;
+            for (int i : local_mems) need_chunk[lp.gkr_chunk[i]] = 1;
+        }
+        std::map<int, u64*> read_ts, final_cts;
+        if (need_counters) {
+            size_t tb = dev::lasso_counter_temp_bytes(N);
+            void* temp = ctx->alloc(tb);
+            u32* keys = ctx->alloc_n<u32>(N); u32* keys2 = ctx->alloc_n<u32>(N);
+            u32* rows = ctx->alloc_n<u32>(N); u32* rows2 = ctx->alloc_n<u32>(N);
+            u32* starts = ctx->alloc_n<u32>(65537);
+            for (auto& chk : lp.chunks) {
+                int c = chk.first;
+                if (c < 0 || c >= 4 || !need_chunk[c]) continue;
+                read_ts[c] = ctx->alloc_n<u64>(N);
+                final_cts[c] = ctx->alloc_n<u64>(M);
+                ctx->prof_begin(cls_aux, (double)N * 40);
+                dev::lasso_counters(st, L, c, dims, read_ts[c], final_cts[c], temp, tb, keys, keys2, rows, rows2, starts);
+                ctx->prof_end();
+            }
         }
         const int nrows = split ? (int)local_pairs.size() : 2 * G;
         u64* H1 = any_gp1 ? ctx->alloc_n<u64>((size_t)nrows * N) : nullptr;
