@@ -12,6 +12,8 @@
 #include <vector>
 #include <stdexcept>
 #include <chrono>
+#include <functional>
+#include <memory>
 #include <map>
 #include "bn254.cuh"
 #include "bn254_wide.cuh"
