@@ -246,6 +246,22 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_reduce_rounds(const Fr* __restric
     }
 }
 
+// the same for many sum-checks: grid (32, jobs)
+struct RedJobDev { const Fr* part; Fr* out; int n[32]; int nrounds, pad; };
+__global__ __launch_bounds__(BN_TPB) void k_bn_reduce_jobs(const RedJobDev* __restrict__ jobs, int nv) {
+    __shared__ Fr sm[BN_TPB];
+    const RedJobDev& J = jobs[blockIdx.y];
+    const int rd = blockIdx.x;
+    if (rd >= J.nrounds) return;
+    const Fr* src = J.part + (size_t)rd * BN_PART_STRIDE * nv;
+    for (int v = 0; v < nv; v++) {
+        Fr a = fr_zero();
+        for (int b = threadIdx.x; b < J.n[rd]; b += BN_TPB) a = fr_add(a, src[(size_t)b * nv + v]);
+        a = block_sum_fr(a, sm);
+        if (threadIdx.x == 0) J.out[rd * nv + v] = fr_from_mont(a);
+    }
+}
+
 // The last rounds of a sum-check (table length <= 2 * BN_TAIL_HALF) in ONE single-workgroup launch instead of one small launch per
 // round: tables in HBM (L2-resident at this size), work items (pair index, pair) dealt to the threads, round sums written in
 // canonical form. KIND 2: g = sum_i a_i b_i; KIND 1: g = p_0 * sum_i l_i r_i with the weights already in the left tables
@@ -253,9 +269,8 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_reduce_rounds(const Fr* __restric
 constexpr int BN_TAIL_HALF = 16, BN_TAIL_ROUNDS = 8;  // 16: at most two work items per thread in the first tail round
 struct TailR { Fr r[BN_TAIL_ROUNDS]; };
 template <int KIND>
-__global__ __launch_bounds__(BN_TPB * (KIND == BN_GRANDPROD ? 3 : 2)) void k_bn_tail(const Fr* __restrict__ in, Fr* __restrict__ buf, int npairs, int half0,
-                                                                                       int nrounds, TailR rs, Fr* __restrict__ sums_out,
-                                                                                       Fr* __restrict__ fin_out) {
+__device__ __forceinline__ void bn_tail_body(const Fr* __restrict__ in, Fr* __restrict__ buf, int npairs, int half0, int nrounds, const TailR& rs,
+                                             Fr* __restrict__ sums_out, Fr* __restrict__ fin_out) {
     // blockDim.x = NV * BN_TPB: thread group v evaluates the round polynomial at its own point (0, 2[, 3]) and groups 0 / 1 write the
     // left / right folds, so the per-item dependent chain is one or two products instead of eight
     constexpr int NV = KIND == BN_GRANDPROD ? 3 : 2;
@@ -300,6 +315,20 @@ __global__ __launch_bounds__(BN_TPB * (KIND == BN_GRANDPROD ? 3 : 2)) void k_bn_
         nxt = nxt == buf ? buf + (size_t)ntab * half0 : buf;
     }
     for (int q = threadIdx.x; q < ntab; q += blockDim.x) fin_out[q] = fr_from_mont(cur[q]);
+}
+
+template <int KIND>
+__global__ __launch_bounds__(BN_TPB * (KIND == BN_GRANDPROD ? 3 : 2)) void k_bn_tail(const Fr* __restrict__ in, Fr* __restrict__ buf, int npairs, int half0,
+                                                                                       int nrounds, TailR rs, Fr* __restrict__ sums_out,
+                                                                                       Fr* __restrict__ fin_out) {
+    bn_tail_body<KIND>(in, buf, npairs, half0, nrounds, rs, sums_out, fin_out);
+}
+// the tails of many sum-checks at once: one workgroup per job
+struct TailJobDev { const Fr* in; Fr* buf; Fr* sums_out; Fr* fin_out; TailR rs; int npairs, half0, nrounds, pad; };
+template <int KIND>
+__global__ __launch_bounds__(BN_TPB * (KIND == BN_GRANDPROD ? 3 : 2)) void k_bn_tail_jobs(const TailJobDev* __restrict__ jobs) {
+    const TailJobDev& J = jobs[blockIdx.x];
+    bn_tail_body<KIND>(J.in, J.buf, J.npairs, J.half0, J.nrounds, J.rs, J.sums_out, J.fin_out);
 }
 
 // ---- host arithmetic for the transcript replay (Montgomery form) ---------------------------------------------
