@@ -211,6 +211,52 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_gp_round(const Fr* __restrict__ i
     const Fr s = block_sum_fr(acc, sm);
     if (threadIdx.x == 0) partials[blk * 3 + v] = s;
 }
+// the same round for many layers at once (blockIdx.y = layer; a layer uses gx * gy of the gridDim.x workgroups): the layers of a
+// grand product only share the product tree, so round k of every layer that still has one runs in launch k
+struct GpJobDev { const Fr* in; Fr* out; Fr* part; const Fr* pw; Fr r; unsigned long long half; int ntab, gx, gy, pad; };
+template <bool FIRST>
+__global__ __launch_bounds__(BN_TPB) void k_bn_gp_round_jobs(const GpJobDev* __restrict__ jobs) {
+    const GpJobDev& J = jobs[blockIdx.y];
+    if ((int)blockIdx.x >= J.gx * J.gy) return;
+    __shared__ Fr sm[BN_TPB];
+    Fr acc = fr_zero();
+    const Fr* __restrict__ in = J.in;
+    Fr* __restrict__ out = J.out;
+    const Fr* __restrict__ pw = J.pw;
+    const size_t half = J.half;
+    const Fr r = J.r;
+    const int nb = J.ntab >> 1, P = J.gy, bx = blockIdx.x % J.gx, pi = blockIdx.x / J.gx, v = blockIdx.z;
+    for (size_t j = (size_t)bx * BN_TPB + threadIdx.x; j < half; j += (size_t)J.gx * BN_TPB) {
+        WCol a = wcol_zero();
+        Fr pv;
+        {
+            const Fr x = in[2 * j], y = in[2 * j + 1];
+            const Fr d = fr_sub(y, x);
+            pv = v == 0 ? x : (v == 1 ? fr_add(y, d) : fr_add(fr_add(y, d), d));
+        }
+        for (int i = pi; i < nb; i += P) {
+            const Fr xl = in[(size_t)(2 * i) * 2 * half + 2 * j], yl = in[(size_t)(2 * i) * 2 * half + 2 * j + 1];
+            const Fr xr = in[(size_t)(2 * i + 1) * 2 * half + 2 * j], yr = in[(size_t)(2 * i + 1) * 2 * half + 2 * j + 1];
+            const Fr dl = fr_sub(yl, xl), dr = fr_sub(yr, xr);
+            Fr lv, rv;
+            if (v == 0) { lv = xl; rv = xr; }
+            else if (v == 1) { lv = fr_add(yl, dl); rv = fr_add(yr, dr); }
+            else { lv = fr_add(fr_add(yl, dl), dl); rv = fr_add(fr_add(yr, dr), dr); }
+            if (FIRST) lv = fr_mul_wide(pw[i], lv);
+            wcol_mac(a, lv, rv);
+            if (v == 0) {
+                const Fr wdl = FIRST ? fr_mul_wide(pw[i], dl) : dl;
+                out[(size_t)(2 * i) * half + j] = fr_add(lv, fr_mul_wide(r, wdl));
+            } else if (v == 1) {
+                out[(size_t)(2 * i + 1) * half + j] = fr_add(xr, fr_mul_wide(r, dr));
+            }
+        }
+        acc = fr_add(acc, fr_mul_wide(pv, wcol_reduce(a)));
+    }
+    const size_t blk = (size_t)pi * J.gx + bx;
+    const Fr s = block_sum_fr(acc, sm);
+    if (threadIdx.x == 0) J.part[blk * 3 + v] = s;
+}
 // launch shape of a round over `half` pair indices and `nitems` independent items (pairs / tables): grid.x workgroups along j,
 // grid.y groups of items; large rounds keep one thread per j, small ones spread the items
 struct RoundGrid { int gx, gy; int blocks() const { return gx * gy; } };
@@ -566,47 +612,93 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
         h_top = top.host; h_roots = roots.host;
         size_t pos = chain_skip;
         layers[0].mu_at = pos++;
+        // plan every layer (buffers, result slots, launch shapes), then run the rounds of all layers round-synchronised
+        struct LayerPlan { Fr *buf0, *buf1, *part, *tbuf, *d_pw; int nmain; };
+        std::vector<LayerPlan> plan(nv);
+        int max_main = 0;
         for (int n = 1; n < nv; n++) {
             LayerRec& L = layers[n];
             L.gamma_at = pos++; L.r_at = pos; pos += n; L.mu_at = pos++;
+            if (n > 32) throw Error("hg_grand_product_bn254: more than 32 rounds");
             const size_t h = (size_t)1 << n;  // table length of this layer's sum-check (n variables)
-            // gamma powers
-            const Fr g = fr_to_mont(chain[L.gamma_at]);
-            Fr* d_pw = dalloc(nb);
-            k_bn_powers<<<(unsigned)((nb + 255) / 256), 256, 0, st>>>(d_pw, g, nb);   // gamma^b, b < nb
-            Fr* buf0 = dalloc(ntab * (h / 2));
-            Fr* buf1 = dalloc(ntab * std::max<size_t>(h / 4, 1));
+            LayerPlan& P = plan[n];
+            P.d_pw = dalloc(nb);
+            k_bn_powers<<<(unsigned)((nb + 255) / 256), 256, 0, st>>>(P.d_pw, fr_to_mont(chain[L.gamma_at]), nb);   // gamma^b, b < nb
+            P.buf0 = dalloc(ntab * (h / 2));
+            P.buf1 = dalloc(ntab * std::max<size_t>(h / 4, 1));
+            P.part = dalloc((size_t)n * BN_PART_STRIDE * 3);
+            P.tbuf = dalloc(2 * ntab * (size_t)BN_TAIL_HALF);
             const ResRef rs_sums = res_slots(ctx, (size_t)n * 3), rs_fin = res_slots(ctx, ntab);
             L.d_sums = rs_sums.dev; L.sums = rs_sums.host;
-            const Fr* cur = lev[nv - 1 - n];  // rows [v_l | v_r] of length 2h... table t at cur + t * h
-            Fr* nxt = buf0;
-            if (n > 32) throw Error("hg_grand_product_bn254: more than 32 rounds");
-            Fr* part = dalloc((size_t)n * BN_PART_STRIDE * 3);
-            RoundCounts rc;
             L.d_final = rs_fin.dev; L.fin = rs_fin.host;
-            int nmain = n;   // rounds done by one launch each; the rest (short tables) by the single-workgroup tail
-            for (int rd = 0; rd < n; rd++) {
-                const size_t half = h >> (rd + 1);
-                if (rd >= 1 && half <= (size_t)BN_TAIL_HALF && n - rd <= BN_TAIL_ROUNDS) { nmain = rd; break; }
-                const Fr r = fr_to_mont(chain[L.r_at + rd]);
+            P.nmain = n;   // rounds done by the shared launches; the rest (short tables) by the tail workgroup of the layer
+            for (int rd = 1; rd < n; rd++)
+                if ((h >> (rd + 1)) <= (size_t)BN_TAIL_HALF && n - rd <= BN_TAIL_ROUNDS) { P.nmain = rd; break; }
+            max_main = std::max(max_main, P.nmain);
+        }
+        std::vector<GpJobDev> descs;
+        std::vector<RedJobDev> reds;
+        std::vector<TailJobDev> tails;
+        std::vector<size_t> off(max_main + 1, 0);
+        std::vector<int> max_blocks(max_main, 0), nactive(max_main, 0);
+        std::vector<int> red_index(nv, -1);
+        for (int n = 1; n < nv; n++) { red_index[n] = (int)reds.size(); RedJobDev r; memset(&r, 0, sizeof(r)); reds.push_back(r); }
+        for (int rd = 0; rd < max_main; rd++) {
+            off[rd] = descs.size();
+            for (int n = 1; n < nv; n++) {
+                const LayerPlan& P = plan[n];
+                if (rd >= P.nmain) continue;
+                const size_t h = (size_t)1 << n, half = h >> (rd + 1);
+                GpJobDev d;
+                memset(&d, 0, sizeof(d));
+                d.in = rd == 0 ? lev[nv - 1 - n] : ((rd & 1) ? P.buf0 : P.buf1);   // rows [v_l | v_r]: table t at in + t * 2 * half
+                d.out = (rd & 1) ? P.buf1 : P.buf0;
+                d.part = P.part + (size_t)rd * BN_PART_STRIDE * 3;
+                d.pw = P.d_pw;
+                d.r = fr_to_mont(chain[layers[n].r_at + rd]);
+                d.half = half;
+                d.ntab = (int)ntab;
                 const RoundGrid g = round_grid(half, (int)nb);
-                Fr* pr = part + (size_t)rd * BN_PART_STRIDE * 3;
-                if (rd == 0) k_bn_gp_round<true><<<dim3(g.gx, g.gy, 3), BN_TPB, 0, st>>>(cur, nxt, (int)ntab, half, r, d_pw, pr);
-                else k_bn_gp_round<false><<<dim3(g.gx, g.gy, 3), BN_TPB, 0, st>>>(cur, nxt, (int)ntab, half, r, d_pw, pr);
-                rc.n[rd] = g.blocks();
-                cur = nxt;
-                nxt = nxt == buf0 ? buf1 : buf0;
+                d.gx = g.gx; d.gy = g.gy;
+                reds[red_index[n]].n[rd] = g.blocks();
+                max_blocks[rd] = std::max(max_blocks[rd], g.blocks());
+                nactive[rd]++;
+                descs.push_back(d);
             }
-            if (nmain) k_bn_reduce_rounds<<<nmain, BN_TPB, 0, st>>>(part, rc, 3, L.d_sums);
-            if (nmain < n) {
-                const int half0 = (int)(h >> (nmain + 1));
-                TailR tr;
-                for (int q = 0; q < BN_TAIL_ROUNDS; q++) tr.r[q] = q < n - nmain ? fr_to_mont(chain[L.r_at + nmain + q]) : fr_zero();
-                Fr* tbuf = dalloc(2 * ntab * (size_t)half0);
-                k_bn_tail<BN_GRANDPROD><<<1, 3 * BN_TPB, 0, st>>>(cur, tbuf, (int)nb, half0, n - nmain, tr, L.d_sums + (size_t)nmain * 3, L.d_final);
-            } else {
-                k_bn_copy_from_mont<<<(unsigned)((ntab + 255) / 256), 256, 0, st>>>(cur, L.d_final, ntab);
+        }
+        for (int n = 1; n < nv; n++) {
+            const LayerPlan& P = plan[n];
+            const LayerRec& L = layers[n];
+            RedJobDev& r = reds[red_index[n]];
+            r.part = P.part; r.out = L.d_sums; r.nrounds = P.nmain;
+            const Fr* last = ((P.nmain - 1) & 1) ? P.buf1 : P.buf0;   // output of the last shared round
+            if (P.nmain < n) {
+                TailJobDev t;
+                memset(&t, 0, sizeof(t));
+                t.in = last; t.buf = P.tbuf; t.sums_out = L.d_sums + (size_t)P.nmain * 3; t.fin_out = L.d_final;
+                for (int q = 0; q < BN_TAIL_ROUNDS; q++) t.rs.r[q] = q < n - P.nmain ? fr_to_mont(chain[L.r_at + P.nmain + q]) : fr_zero();
+                t.npairs = (int)nb; t.half0 = (int)(((size_t)1 << n) >> (P.nmain + 1)); t.nrounds = n - P.nmain;
+                tails.push_back(t);
             }
+        }
+        if (!descs.empty()) {
+            GpJobDev* d_descs = static_cast<GpJobDev*>(ctx->alloc(descs.size() * sizeof(GpJobDev)));
+            RedJobDev* d_reds = static_cast<RedJobDev*>(ctx->alloc(reds.size() * sizeof(RedJobDev)));
+            TailJobDev* d_tails = static_cast<TailJobDev*>(ctx->alloc(std::max<size_t>(tails.size(), 1) * sizeof(TailJobDev)));
+            // (blocking copies: the staging vectors are locals)
+            hipc(hipMemcpy(d_descs, descs.data(), descs.size() * sizeof(GpJobDev), hipMemcpyHostToDevice), "upload round jobs");
+            hipc(hipMemcpy(d_reds, reds.data(), reds.size() * sizeof(RedJobDev), hipMemcpyHostToDevice), "upload reduce jobs");
+            if (!tails.empty()) hipc(hipMemcpy(d_tails, tails.data(), tails.size() * sizeof(TailJobDev), hipMemcpyHostToDevice), "upload tail jobs");
+            for (int rd = 0; rd < max_main; rd++) {
+                const dim3 grid(max_blocks[rd], nactive[rd], 3);
+                if (rd == 0) k_bn_gp_round_jobs<true><<<grid, BN_TPB, 0, st>>>(d_descs + off[rd]);
+                else k_bn_gp_round_jobs<false><<<grid, BN_TPB, 0, st>>>(d_descs + off[rd]);
+            }
+            k_bn_reduce_jobs<<<dim3(32, (unsigned)reds.size()), BN_TPB, 0, st>>>(d_reds, 3);
+            if (!tails.empty()) k_bn_tail_jobs<BN_GRANDPROD><<<(unsigned)tails.size(), 3 * BN_TPB, 0, st>>>(d_tails);
+            for (int n = 1; n < nv; n++)   // layers without a tail (n = 1): the folded values are the last shared round's output
+                if (plan[n].nmain == n)
+                    k_bn_copy_from_mont<<<(unsigned)((ntab + 255) / 256), 256, 0, st>>>(((plan[n].nmain - 1) & 1) ? plan[n].buf1 : plan[n].buf0, layers[n].d_final, ntab);
         }
         res_sync(ctx, st, "grand_product_bn254: sync");
     } catch (...) {
