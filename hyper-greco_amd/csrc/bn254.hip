@@ -101,7 +101,7 @@ __device__ __forceinline__ Fr block_sum_fr(Fr v, Fr* sm) {
 template <int KIND>
 __global__ __launch_bounds__(BN_TPB) void k_bn_round(const Fr* __restrict__ in, Fr* __restrict__ out, int ntab, size_t half, Fr r,
                                                      const Fr* __restrict__ pw, Fr* __restrict__ partials) {
-    // gridDim.y = P groups share the tables / pairs round-robin (see k_bn_gp_round); P = 1 is the plain one-thread-per-j form
+    // gridDim.y = P groups share the tables / pairs round-robin (see k_bn_gp_round_jobs); P = 1 is the plain one-thread-per-j form
     constexpr int NV = KIND == BN_GRANDPROD ? 3 : 2;
     __shared__ Fr sm[BN_TPB];
     Fr acc[NV];
@@ -172,47 +172,10 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_round(const Fr* __restrict__ in, 
 // Montgomery-reduced once per pair index j; (c) the three evaluation points are three workgroup sets (blockIdx.z = 0: g(0) and
 // the left fold, 1: g(2) and the right fold, 2: g(3)): one accumulator per thread (three would not fit two waves per SIMD) and
 // a three times shorter dependent chain; the inputs are read three times, which an ALU-bound kernel does not notice;
-// (d) gridDim.y = P: the pairs are dealt round-robin to P thread groups so that small rounds are not one long serial chain per
+// (d) the pairs are dealt round-robin to gy thread groups so that small rounds are not one long serial chain per
 // thread (Montgomery reduction is linear: every group reduces its own partial dot product and multiplies by p_v itself).
-template <bool FIRST>
-__global__ __launch_bounds__(BN_TPB) void k_bn_gp_round(const Fr* __restrict__ in, Fr* __restrict__ out, int ntab, size_t half, Fr r,
-                                                        const Fr* __restrict__ pw, Fr* __restrict__ partials) {
-    __shared__ Fr sm[BN_TPB];
-    Fr acc = fr_zero();
-    const int nb = ntab >> 1, P = gridDim.y, pi = blockIdx.y, v = blockIdx.z;
-    for (size_t j = (size_t)blockIdx.x * BN_TPB + threadIdx.x; j < half; j += (size_t)gridDim.x * BN_TPB) {
-        WCol a = wcol_zero();
-        Fr pv;  // table 0 (= left table of pair 0, weight gamma^0 = 1) at the evaluation point 0 / 2 / 3
-        {
-            const Fr x = in[2 * j], y = in[2 * j + 1];
-            const Fr d = fr_sub(y, x);
-            pv = v == 0 ? x : (v == 1 ? fr_add(y, d) : fr_add(fr_add(y, d), d));
-        }
-        for (int i = pi; i < nb; i += P) {
-            const Fr xl = in[(size_t)(2 * i) * 2 * half + 2 * j], yl = in[(size_t)(2 * i) * 2 * half + 2 * j + 1];
-            const Fr xr = in[(size_t)(2 * i + 1) * 2 * half + 2 * j], yr = in[(size_t)(2 * i + 1) * 2 * half + 2 * j + 1];
-            const Fr dl = fr_sub(yl, xl), dr = fr_sub(yr, xr);
-            Fr lv, rv;  // the pair at the evaluation point
-            if (v == 0) { lv = xl; rv = xr; }
-            else if (v == 1) { lv = fr_add(yl, dl); rv = fr_add(yr, dr); }
-            else { lv = fr_add(fr_add(yl, dl), dl); rv = fr_add(fr_add(yr, dr), dr); }
-            if (FIRST) lv = fr_mul_wide(pw[i], lv);   // the weight is linear in the left operand; it rides in the left table from here on
-            wcol_mac(a, lv, rv);
-            if (v == 0) {
-                const Fr wdl = FIRST ? fr_mul_wide(pw[i], dl) : dl;
-                out[(size_t)(2 * i) * half + j] = fr_add(lv, fr_mul_wide(r, wdl));
-            } else if (v == 1) {
-                out[(size_t)(2 * i + 1) * half + j] = fr_add(xr, fr_mul_wide(r, dr));
-            }
-        }
-        acc = fr_add(acc, fr_mul_wide(pv, wcol_reduce(a)));
-    }
-    const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-    const Fr s = block_sum_fr(acc, sm);
-    if (threadIdx.x == 0) partials[blk * 3 + v] = s;
-}
-// the same round for many layers at once (blockIdx.y = layer; a layer uses gx * gy of the gridDim.x workgroups): the layers of a
-// grand product only share the product tree, so round k of every layer that still has one runs in launch k
+// One launch is round k of every layer that still has one (blockIdx.y = layer; a layer uses gx * gy of the gridDim.x workgroups):
+// the layers of a grand product only share the product tree
 struct GpJobDev { const Fr* in; Fr* out; Fr* part; const Fr* pw; Fr r; unsigned long long half; int ntab, gx, gy, pad; };
 template <bool FIRST>
 __global__ __launch_bounds__(BN_TPB) void k_bn_gp_round_jobs(const GpJobDev* __restrict__ jobs) {
@@ -311,7 +274,7 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_reduce_jobs(const RedJobDev* __re
 // The last rounds of a sum-check (table length <= 2 * BN_TAIL_HALF) in ONE single-workgroup launch instead of one small launch per
 // round: tables in HBM (L2-resident at this size), work items (pair index, pair) dealt to the threads, round sums written in
 // canonical form. KIND 2: g = sum_i a_i b_i; KIND 1: g = p_0 * sum_i l_i r_i with the weights already in the left tables
-// (rounds after the first of a grand-product layer, see k_bn_gp_round).
+// (rounds after the first of a grand-product layer, see k_bn_gp_round_jobs).
 constexpr int BN_TAIL_HALF = 16, BN_TAIL_ROUNDS = 8;  // 16: at most two work items per thread in the first tail round
 struct TailR { Fr r[BN_TAIL_ROUNDS]; };
 template <int KIND>
@@ -363,12 +326,6 @@ __device__ __forceinline__ void bn_tail_body(const Fr* __restrict__ in, Fr* __re
     for (int q = threadIdx.x; q < ntab; q += blockDim.x) fin_out[q] = fr_from_mont(cur[q]);
 }
 
-template <int KIND>
-__global__ __launch_bounds__(BN_TPB * (KIND == BN_GRANDPROD ? 3 : 2)) void k_bn_tail(const Fr* __restrict__ in, Fr* __restrict__ buf, int npairs, int half0,
-                                                                                       int nrounds, TailR rs, Fr* __restrict__ sums_out,
-                                                                                       Fr* __restrict__ fin_out) {
-    bn_tail_body<KIND>(in, buf, npairs, half0, nrounds, rs, sums_out, fin_out);
-}
 // the tails of many sum-checks at once: one workgroup per job
 struct TailJobDev { const Fr* in; Fr* buf; Fr* sums_out; Fr* fin_out; TailR rs; int npairs, half0, nrounds, pad; };
 template <int KIND>
@@ -729,7 +686,7 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
                 x.push_back(chain[L.r_at + rd]);
             }
             for (size_t i = 0; i < 2 * nb; i++) evals[i] = fr_to_mont(L.fin[i]);
-            // the kernels leave the left evaluation of pair b multiplied by gamma^b (k_bn_gp_round)
+            // the kernels leave the left evaluation of pair b multiplied by gamma^b (k_bn_gp_round_jobs)
             const Fr ginv = fr_inv(g);
             Fr u = ginv;
             for (size_t b = 1; b < nb; b++) { evals[2 * b] = fr_mul(evals[2 * b], u); u = fr_mul(u, ginv); }
