@@ -11,7 +11,9 @@
 #include <string>
 #include <vector>
 #include <stdexcept>
+#include <algorithm>
 #include <chrono>
+#include <tuple>
 #include <functional>
 #include <memory>
 #include <map>
