@@ -474,6 +474,9 @@ def test_bn254_prove_bit_exact_on_the_reference_fixture(ctx):
         first = next(i for i, (a, b) in enumerate(zip(got, expect)) if a != b) if len(got) == len(expect) else min(len(got), len(expect))
         where = [t for t in trace if t[0] <= first][-1]
         pytest.fail("proof differs at element %d (%s, starts at %d); lengths %d / %d" % (first, where[1], where[0], len(got), len(expect)))
+    import hashlib
+    gold = json.load(open(os.path.join(orclib.GOLDEN, "oracle_proof_digests.json")))["bn254_1024_1"]
+    assert len(proof) == gold["bytes"] and hashlib.sha256(proof).hexdigest() == gold["sha256"]
     assert G.verify(c, inputs, ct0is, got, chal, verify_fn)
     assert hg.verify_bn254(pk, w, proof) == (True, "")              # the product's own host verifier over Fr
     bad = list(got)

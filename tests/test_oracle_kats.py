@@ -366,6 +366,9 @@ def test_bn254_gkr_oracle_on_the_reference_fixture():
     proof, _ = G.prove(c, inputs, ct0is, chal, prove_fn)
     gl_proof, _ = orclib.prove(p, orclib.fixture_inputs(n, k, 27))
     assert len(proof) == len(gl_proof) // 16
+    gold = json.load(open(os.path.join(orclib.GOLDEN, "oracle_proof_digests.json")))["bn254_1024_1"]   # regression pin of the oracle itself
+    wire = b"".join(int(v).to_bytes(32, "big") for v in proof)
+    assert len(wire) == gold["bytes"] and hashlib.sha256(wire).hexdigest() == gold["sha256"]
     assert G.verify(c, inputs, ct0is, proof, chal, verify_fn)
     for at in (0, len(proof) // 2, len(proof) - 1):
         bad = list(proof)
