@@ -168,9 +168,9 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_round(const Fr* __restrict__ in, 
         if (threadIdx.x == 0) partials[blk * NV + v] = s;
     }
 }
-// Grand-product round of prove_grand_product, tuned: (a) in the FIRST round of a layer the folded LEFT table of pair i is stored
-// multiplied by its weight gamma^i, so later rounds need no weights (the host divides the final left evaluations by
-// gamma^i again); (b) the dot product over the pairs is accumulated unreduced in column accumulators (bn254_wide.cuh) and
+// Grand-product round of prove_grand_product, tuned: (a) the LEFT table of pair i enters the first round already multiplied by
+// its weight gamma^i (k_bn_weight_rows: two products per (pair, j), once), so no round needs weights and the folded left
+// tables stay weighted (the host divides the final left evaluations by gamma^i again); (b) the dot product over the pairs is accumulated unreduced in column accumulators (bn254_wide.cuh) and
 // Montgomery-reduced once per pair index j; (c) the three evaluation points are three workgroup sets (blockIdx.z = 0: g(0) and
 // the left fold, 1: g(2) and the right fold, 2: g(3)): one accumulator per thread (three would not fit two waves per SIMD) and
 // a three times shorter dependent chain; the inputs are read three times, which an ALU-bound kernel does not notice;
@@ -178,49 +178,53 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_round(const Fr* __restrict__ in, 
 // thread (Montgomery reduction is linear: every group reduces its own partial dot product and multiplies by p_v itself).
 // One launch is round k of every layer that still has one (blockIdx.y = layer; a layer uses gx * gy of the gridDim.x workgroups):
 // the layers of a grand product only share the product tree
-struct GpJobDev { const Fr* in; Fr* out; Fr* part; const Fr* pw; Fr r; unsigned long long half; int ntab, gx, gy, pad; };
-template <bool FIRST>
+// left table of pair i at l_base + i * l_stride, right table at r_base + i * r_stride (first round: the pre-weighted left halves and
+// the right halves of the level rows; later rounds: the interleaved folded tables)
+struct GpJobDev { const Fr* l_base; const Fr* r_base; Fr* out; Fr* part; Fr r; unsigned long long half, l_stride, r_stride; int nb, gx, gy, pad; };
 __global__ __launch_bounds__(BN_TPB) void k_bn_gp_round_jobs(const GpJobDev* __restrict__ jobs) {
     const GpJobDev& J = jobs[blockIdx.y];
     if ((int)blockIdx.x >= J.gx * J.gy) return;
     __shared__ Fr sm[BN_TPB];
     Fr acc = fr_zero();
-    const Fr* __restrict__ in = J.in;
+    const Fr* __restrict__ lb = J.l_base;
+    const Fr* __restrict__ rb = J.r_base;
     Fr* __restrict__ out = J.out;
-    const Fr* __restrict__ pw = J.pw;
-    const size_t half = J.half;
+    const size_t half = J.half, ls = J.l_stride, rs = J.r_stride;
     const Fr r = J.r;
-    const int nb = J.ntab >> 1, P = J.gy, bx = blockIdx.x % J.gx, pi = blockIdx.x / J.gx, v = blockIdx.z;
+    const int nb = J.nb, P = J.gy, bx = blockIdx.x % J.gx, pi = blockIdx.x / J.gx, v = blockIdx.z;
     for (size_t j = (size_t)bx * BN_TPB + threadIdx.x; j < half; j += (size_t)J.gx * BN_TPB) {
         WCol a = wcol_zero();
-        Fr pv;
+        Fr pv;  // table 0 (= left table of pair 0, weight gamma^0 = 1) at the evaluation point 0 / 2 / 3
         {
-            const Fr x = in[2 * j], y = in[2 * j + 1];
+            const Fr x = lb[2 * j], y = lb[2 * j + 1];
             const Fr d = fr_sub(y, x);
             pv = v == 0 ? x : (v == 1 ? fr_add(y, d) : fr_add(fr_add(y, d), d));
         }
         for (int i = pi; i < nb; i += P) {
-            const Fr xl = in[(size_t)(2 * i) * 2 * half + 2 * j], yl = in[(size_t)(2 * i) * 2 * half + 2 * j + 1];
-            const Fr xr = in[(size_t)(2 * i + 1) * 2 * half + 2 * j], yr = in[(size_t)(2 * i + 1) * 2 * half + 2 * j + 1];
+            const Fr xl = lb[(size_t)i * ls + 2 * j], yl = lb[(size_t)i * ls + 2 * j + 1];
+            const Fr xr = rb[(size_t)i * rs + 2 * j], yr = rb[(size_t)i * rs + 2 * j + 1];
             const Fr dl = fr_sub(yl, xl), dr = fr_sub(yr, xr);
-            Fr lv, rv;
+            Fr lv, rv;  // the pair at the evaluation point
             if (v == 0) { lv = xl; rv = xr; }
             else if (v == 1) { lv = fr_add(yl, dl); rv = fr_add(yr, dr); }
             else { lv = fr_add(fr_add(yl, dl), dl); rv = fr_add(fr_add(yr, dr), dr); }
-            if (FIRST) lv = fr_mul_wide(pw[i], lv);
             wcol_mac(a, lv, rv);
-            if (v == 0) {
-                const Fr wdl = FIRST ? fr_mul_wide(pw[i], dl) : dl;
-                out[(size_t)(2 * i) * half + j] = fr_add(lv, fr_mul_wide(r, wdl));
-            } else if (v == 1) {
-                out[(size_t)(2 * i + 1) * half + j] = fr_add(xr, fr_mul_wide(r, dr));
-            }
+            if (v == 0) out[(size_t)(2 * i) * half + j] = fr_add(xl, fr_mul_wide(r, dl));
+            else if (v == 1) out[(size_t)(2 * i + 1) * half + j] = fr_add(xr, fr_mul_wide(r, dr));
         }
         acc = fr_add(acc, fr_mul_wide(pv, wcol_reduce(a)));
     }
     const size_t blk = (size_t)pi * J.gx + bx;
     const Fr s = block_sum_fr(acc, sm);
     if (threadIdx.x == 0) J.part[blk * 3 + v] = s;
+}
+// out[b][i] = pw[b] * rows[b][i], i < h: the left halves of a level's rows with the layer's weights gamma^b folded in
+__global__ void k_bn_weight_rows(const Fr* __restrict__ rows, size_t row_len, const Fr* __restrict__ pw, Fr* __restrict__ out, size_t h, int nb) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= h * (size_t)nb) return;
+    const size_t b = idx / h, i = idx % h;
+    const Fr x = rows[b * row_len + i];
+    out[idx] = b == 0 ? x : fr_mul_wide(pw[b], x);
 }
 // launch shape of a round over `half` pair indices and `nitems` independent items (pairs / tables): grid.x workgroups along j,
 // grid.y groups of items; large rounds keep one thread per j, small ones spread the items
@@ -572,7 +576,7 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
         size_t pos = chain_skip;
         layers[0].mu_at = pos++;
         // plan every layer (buffers, result slots, launch shapes), then run the rounds of all layers round-synchronised
-        struct LayerPlan { Fr *buf0, *buf1, *part, *tbuf, *d_pw; int nmain; };
+        struct LayerPlan { Fr *buf0, *buf1, *part, *tbuf, *d_pw, *lw; int nmain; };
         std::vector<LayerPlan> plan(nv);
         int max_main = 0;
         for (int n = 1; n < nv; n++) {
@@ -583,6 +587,8 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
             LayerPlan& P = plan[n];
             P.d_pw = dalloc(nb);
             k_bn_powers<<<(unsigned)((nb + 255) / 256), 256, 0, st>>>(P.d_pw, fr_to_mont(chain[L.gamma_at]), nb);   // gamma^b, b < nb
+            P.lw = dalloc(nb * h);                                                                                  // weighted left halves
+            k_bn_weight_rows<<<(unsigned)((nb * h + 255) / 256), 256, 0, st>>>(lev[nv - 1 - n], 2 * h, P.d_pw, P.lw, h, (int)nb);
             P.buf0 = dalloc(ntab * (h / 2));
             P.buf1 = dalloc(ntab * std::max<size_t>(h / 4, 1));
             P.part = dalloc((size_t)n * BN_PART_STRIDE * 3);
@@ -610,13 +616,18 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
                 const size_t h = (size_t)1 << n, half = h >> (rd + 1);
                 GpJobDev d;
                 memset(&d, 0, sizeof(d));
-                d.in = rd == 0 ? lev[nv - 1 - n] : ((rd & 1) ? P.buf0 : P.buf1);   // rows [v_l | v_r]: table t at in + t * 2 * half
+                if (rd == 0) {   // rows [v_l | v_r] of length 2h: weighted left halves (compact), right halves in place
+                    d.l_base = P.lw; d.l_stride = h;
+                    d.r_base = lev[nv - 1 - n] + h; d.r_stride = 2 * h;
+                } else {         // folded tables: table t at inb + t * 2 * half
+                    const Fr* inb = (rd & 1) ? P.buf0 : P.buf1;
+                    d.l_base = inb; d.r_base = inb + 2 * half; d.l_stride = d.r_stride = 4 * half;
+                }
                 d.out = (rd & 1) ? P.buf1 : P.buf0;
                 d.part = P.part + (size_t)rd * BN_PART_STRIDE * 3;
-                d.pw = P.d_pw;
                 d.r = fr_to_mont(chain[layers[n].r_at + rd]);
                 d.half = half;
-                d.ntab = (int)ntab;
+                d.nb = (int)nb;
                 const RoundGrid g = round_grid(half, (int)nb);
                 d.gx = g.gx; d.gy = g.gy;
                 reds[red_index[n]].n[rd] = g.blocks();
@@ -650,8 +661,7 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
             if (!tails.empty()) hipc(hipMemcpy(d_tails, tails.data(), tails.size() * sizeof(TailJobDev), hipMemcpyHostToDevice), "upload tail jobs");
             for (int rd = 0; rd < max_main; rd++) {
                 const dim3 grid(max_blocks[rd], nactive[rd], 3);
-                if (rd == 0) k_bn_gp_round_jobs<true><<<grid, BN_TPB, 0, st>>>(d_descs + off[rd]);
-                else k_bn_gp_round_jobs<false><<<grid, BN_TPB, 0, st>>>(d_descs + off[rd]);
+                k_bn_gp_round_jobs<<<grid, BN_TPB, 0, st>>>(d_descs + off[rd]);
             }
             k_bn_reduce_jobs<<<dim3(32, (unsigned)reds.size()), BN_TPB, 0, st>>>(d_reds, 3);
             if (!tails.empty()) k_bn_tail_jobs<BN_GRANDPROD><<<(unsigned)tails.size(), 3 * BN_TPB, 0, st>>>(d_tails);
