@@ -581,3 +581,23 @@ def test_bn254_invalid_witness_rejected_by_both_verifiers(ctx, kind):
     assert _elems(proof) == expect               # bit-exact on an invalid witness too
     with pytest.raises(ValueError):
         G.verify(orclib.constants(n, k), inputs, ct0is, expect, chal, verify_fn)
+
+
+@pytest.mark.parametrize("n,k", [(2048, 1), (8192, 4), (16384, 8)])
+def test_bn254_prove_other_parameter_sets_accepted_by_the_host_verifier(ctx, n, k):
+    """The remaining built-in parameter sets over bn256::Fr (different table lengths, chunk counts and claim multiplicities): the
+    proof has the Goldilocks proof's element count, the host verifier accepts it, rejects a flipped byte and another witness."""
+    bfv = hg.BfvEncrypt.new(n, k)
+    pk = bfv.setup(ctx)
+    w = hg.Witness.synthetic(bfv.params, 0x4752454330 + n)
+    proof, _, _ = ctx.prove_bn254(pk, w, cap=1 << 25)
+    gl, _ = bfv.prove(ctx, pk, w)
+    assert len(proof) // 32 == len(gl) // 16
+    assert hg.verify_bn254(pk, w, proof) == (True, "")
+    bad = bytearray(proof)
+    bad[(len(bad) // 3) | 31] ^= 4
+    assert not hg.verify_bn254(pk, w, bytes(bad))[0]
+    assert not hg.verify_bn254(pk, hg.Witness.synthetic(bfv.params, 1), proof)[0]
+    proof2, _, _ = ctx.prove_bn254(pk, w, cap=1 << 25)   # determinism + arena reuse
+    assert proof2 == proof
+    pk.free()
