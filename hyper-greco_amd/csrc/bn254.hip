@@ -171,9 +171,9 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_round(const Fr* __restrict__ in, 
 // Grand-product round of prove_grand_product, tuned: (a) the LEFT table of pair i enters the first round already multiplied by
 // its weight gamma^i (k_bn_weight_rows: two products per (pair, j), once), so no round needs weights and the folded left
 // tables stay weighted (the host divides the final left evaluations by gamma^i again); (b) the dot product over the pairs is accumulated unreduced in column accumulators (bn254_wide.cuh) and
-// Montgomery-reduced once per pair index j; (c) the three evaluation points are three workgroup sets (blockIdx.z = 0: g(0) and
+// Montgomery-reduced once per pair index j; (c) the three evaluation points are three workgroups per tile (v = 0: g(0) and
 // the left fold, 1: g(2) and the right fold, 2: g(3)): one accumulator per thread (three would not fit two waves per SIMD) and
-// a three times shorter dependent chain; the inputs are read three times, which an ALU-bound kernel does not notice;
+// a three times shorter dependent chain; the three are placed on one XCD so that the inputs come from HBM once;
 // (d) the pairs are dealt round-robin to gy thread groups so that small rounds are not one long serial chain per
 // thread (Montgomery reduction is linear: every group reduces its own partial dot product and multiplies by p_v itself).
 // One launch is round k of every layer that still has one (blockIdx.y = layer; a layer uses gx * gy of the gridDim.x workgroups):
@@ -183,7 +183,11 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_round(const Fr* __restrict__ in, 
 struct GpJobDev { const Fr* l_base; const Fr* r_base; Fr* out; Fr* part; Fr r; unsigned long long half, l_stride, r_stride; int nb, gx, gy, pad; };
 __global__ __launch_bounds__(BN_TPB) void k_bn_gp_round_jobs(const GpJobDev* __restrict__ jobs) {
     const GpJobDev& J = jobs[blockIdx.y];
-    if ((int)blockIdx.x >= J.gx * J.gy) return;
+    // XCD-aware mapping: consecutive workgroup ids go round-robin to the 8 XCDs (each with its own L2), so the three evaluation-
+    // point workgroups of one tile get ids 8 (3 q + v) + xcd: same XCD, adjacent dispatch slots - the second and third read of
+    // the tile's inputs hit that XCD's L2 instead of HBM (gridDim.x is a multiple of 8)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, v = slot % 3, tile = (slot / 3) * 8 + xcd;
+    if (tile >= J.gx * J.gy) return;
     __shared__ Fr sm[BN_TPB];
     Fr acc = fr_zero();
     const Fr* __restrict__ lb = J.l_base;
@@ -191,7 +195,7 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_gp_round_jobs(const GpJobDev* __r
     Fr* __restrict__ out = J.out;
     const size_t half = J.half, ls = J.l_stride, rs = J.r_stride;
     const Fr r = J.r;
-    const int nb = J.nb, P = J.gy, bx = blockIdx.x % J.gx, pi = blockIdx.x / J.gx, v = blockIdx.z;
+    const int nb = J.nb, P = J.gy, bx = tile % J.gx, pi = tile / J.gx;
     for (size_t j = (size_t)bx * BN_TPB + threadIdx.x; j < half; j += (size_t)J.gx * BN_TPB) {
         WCol a = wcol_zero();
         Fr pv;  // table 0 (= left table of pair 0, weight gamma^0 = 1) at the evaluation point 0 / 2 / 3
@@ -660,7 +664,7 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
             hipc(hipMemcpy(d_reds, reds.data(), reds.size() * sizeof(RedJobDev), hipMemcpyHostToDevice), "upload reduce jobs");
             if (!tails.empty()) hipc(hipMemcpy(d_tails, tails.data(), tails.size() * sizeof(TailJobDev), hipMemcpyHostToDevice), "upload tail jobs");
             for (int rd = 0; rd < max_main; rd++) {
-                const dim3 grid(max_blocks[rd], nactive[rd], 3);
+                const dim3 grid(3 * ((max_blocks[rd] + 7) / 8 * 8), nactive[rd], 1);   // (tile, evaluation point) folded into x: see the kernel
                 k_bn_gp_round_jobs<<<grid, BN_TPB, 0, st>>>(d_descs + off[rd]);
             }
             k_bn_reduce_jobs<<<dim3(32, (unsigned)reds.size()), BN_TPB, 0, st>>>(d_reds, 3);
