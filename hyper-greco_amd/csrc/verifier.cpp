@@ -113,29 +113,13 @@ struct BnField {  // elements in Montgomery form
     };
 };
 
-// sum_{i < n} term(i) on the host cores (field addition is exact: the order of the partial sums does not matter)
-template <class F, class Fn> typename F::E par_sum(size_t n, Fn term) {
-    typedef typename F::E E;
-    E total = F::zero();
-#pragma omp parallel if (n >= 8192)
-    {
-        E loc = F::zero();
-#pragma omp for schedule(static) nowait
-        for (long long i = 0; i < (long long)n; i++) loc = F::add(loc, term((size_t)i));
-#pragma omp critical
-        total = F::add(total, loc);
-    }
-    return total;
-}
-
 template <class F> std::vector<typename F::E> eq_table(const std::vector<typename F::E>& r) {
     typedef typename F::E E;
     std::vector<E> t((size_t)1 << r.size());
     t[0] = F::one();
     size_t s = 1;
     for (size_t i = 0; i < r.size(); i++) {
-#pragma omp parallel for schedule(static) if (s >= 8192)
-        for (long long j = 0; j < (long long)s; j++) { E hi = F::mul(t[j], r[i]); t[j + s] = hi; t[j] = F::sub(t[j], hi); }
+        for (size_t j = 0; j < s; j++) { E hi = F::mul(t[j], r[i]); t[j + s] = hi; t[j] = F::sub(t[j], hi); }
         s <<= 1;
     }
     return t;
@@ -143,7 +127,10 @@ template <class F> std::vector<typename F::E> eq_table(const std::vector<typenam
 template <class F> typename F::E mle_eval(const u64* tab, const std::vector<typename F::E>& pt) {
     typedef typename F::E E;
     std::vector<E> eq = eq_table<F>(pt);
-    return par_sum<F>(eq.size(), [&](size_t j) { return tab[j] ? F::mul_table(eq[j], tab[j]) : F::zero(); });
+    E acc = F::zero();
+    for (size_t j = 0; j < eq.size(); j++)
+        if (tab[j]) acc = F::add(acc, F::mul_table(eq[j], tab[j]));
+    return acc;
 }
 template <class F> typename F::E horner(const std::vector<typename F::E>& c, typename F::E x) {
     typename F::E r = F::zero();
@@ -260,12 +247,10 @@ template <class F> struct Verifier {
     static std::vector<E> combined_eq(const std::vector<Claim>& cl, const std::vector<E>& alpha) {
         std::vector<E> eqc = eq_table<F>(cl[0].point);
         if (cl.size() == 1) return eqc;
-#pragma omp parallel for schedule(static) if (eqc.size() >= 8192)
-        for (long long i = 0; i < (long long)eqc.size(); i++) eqc[i] = F::mul(eqc[i], alpha[0]);
+        for (auto& x : eqc) x = F::mul(x, alpha[0]);
         for (size_t a = 1; a < cl.size(); a++) {
             std::vector<E> t = eq_table<F>(cl[a].point);
-#pragma omp parallel for schedule(static) if (t.size() >= 8192)
-            for (long long i = 0; i < (long long)t.size(); i++) eqc[i] = F::add(eqc[i], F::mul(t[i], alpha[a]));
+            for (size_t i = 0; i < t.size(); i++) eqc[i] = F::add(eqc[i], F::mul(t[i], alpha[a]));
         }
         return eqc;
     }
@@ -276,21 +261,15 @@ template <class F> struct Verifier {
         std::vector<E> eqc = combined_eq(cl, alpha);
         E claim = F::zero();
         for (size_t a = 0; a < cl.size(); a++) claim = F::add(claim, F::mul(cl[a].value, alpha[a]));
-        if (!n.w0.empty()) {
-            const size_t nw = n.w0.size();
-            claim = F::sub(claim, par_sum<F>(R * nw, [&](size_t q) { const auto& t = n.w0[q % nw]; return F::mul_u(eqc[(q / nw) * G + t.gate], t.c); }));
-        }
+        for (size_t rep = 0; rep < R; rep++) for (auto& t : n.w0) claim = F::sub(claim, F::mul_u(eqc[rep * G + t.gate], t.c));
         auto r1 = sumcheck(2, nin, claim);
         std::vector<E> u(n.arity, F::zero());
         std::vector<std::vector<Claim>> sub(n.arity);
         for (int i = 0; i < n.arity; i++) if (n.left_use[i]) { u[i] = read_e(); sub[i].push_back(Claim{r1.second, u[i]}); }
         std::vector<E> eqx = eq_table<F>(r1.second);
-        const size_t nl = n.lin.size();
-        const E lin = par_sum<F>(R * nl, [&](size_t q) {
-            const auto& t = n.lin[q % nl];
-            const size_t rep = q / nl;
-            return F::mul(u[t.in], F::mul(F::mul_u(eqc[rep * G + t.gate], t.c), eqx[rep * S + t.j]));
-        });
+        E lin = F::zero();
+        for (size_t rep = 0; rep < R; rep++)
+            for (auto& t : n.lin) lin = F::add(lin, F::mul(u[t.in], F::mul(F::mul_u(eqc[rep * G + t.gate], t.c), eqx[rep * S + t.j])));
         if (n.mul.empty()) {
             if (!F::eq(r1.first, lin)) throw Reject("vanilla node: final evaluation mismatch");
             return sub;
@@ -299,12 +278,10 @@ template <class F> struct Verifier {
         std::vector<E> w(n.arity, F::zero());
         for (int i = 0; i < n.arity; i++) if (n.right_use[i]) { w[i] = read_e(); sub[i].push_back(Claim{r2.second, w[i]}); }
         std::vector<E> eqy = eq_table<F>(r2.second);
-        const size_t nm = n.mul.size();
-        const E fin = par_sum<F>(R * nm, [&](size_t q) {
-            const auto& t = n.mul[q % nm];
-            const size_t rep = q / nm;
-            return F::mul(F::mul(w[t.i1], u[t.i0]), F::mul(F::mul(F::mul_u(eqc[rep * G + t.gate], t.c), eqx[rep * S + t.j0]), eqy[rep * S + t.j1]));
-        });
+        E fin = F::zero();
+        for (size_t rep = 0; rep < R; rep++)
+            for (auto& t : n.mul)
+                fin = F::add(fin, F::mul(F::mul(w[t.i1], u[t.i0]), F::mul(F::mul(F::mul_u(eqc[rep * G + t.gate], t.c), eqx[rep * S + t.j0]), eqy[rep * S + t.j1])));
         if (!F::eq(r2.first, fin)) throw Reject("vanilla node: phase-2 final evaluation mismatch");
         return sub;
     }
@@ -320,8 +297,7 @@ template <class F> struct Verifier {
         for (int b = L - 1; b >= 0; b--) {
             const size_t sz = (size_t)1 << (L - b);
             std::vector<E> nxt(sz);
-#pragma omp parallel for schedule(static) if (sz >= 8192)
-            for (long long x = 0; x < (long long)sz; x++) {
+            for (size_t x = 0; x < sz; x++) {
                 E f = F::add(F::mul(r[b], F::sub(W[(x << b) & (N - 1)], F::one())), F::one());
                 nxt[x] = F::mul(cur[x & (sz / 2 - 1)], f);
             }
@@ -339,7 +315,8 @@ template <class F> struct Verifier {
         E fr = F::zero();
         for (size_t a = 0; a < cl.size(); a++) {
             std::vector<E> row = fft_row(cl[a].point, n.log2_size, n.inverse);
-            const E s = par_sum<F>(row.size(), [&](size_t x) { return F::mul(row[x], eqx[x]); });
+            E s = F::zero();
+            for (size_t x = 0; x < row.size(); x++) s = F::add(s, F::mul(row[x], eqx[x]));
             fr = F::add(fr, F::mul(s, alpha[a]));
         }
         if (!F::eq(r.first, F::mul(u, fr))) throw Reject("fft node: final evaluation mismatch");
