@@ -222,6 +222,15 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_gp_round_jobs(const GpJobDev* __r
     const Fr s = block_sum_fr(acc, sm);
     if (threadIdx.x == 0) J.part[blk * 3 + v] = s;
 }
+// pw[n][b] = g_n^b for every layer n of a grand product in one launch (blockIdx.y = layer)
+struct GammaSet { Fr g[32]; };
+__global__ void k_bn_gamma_powers(Fr* __restrict__ pw, GammaSet gs, int nb) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    Fr r = fr_one_mont(), base = gs.g[blockIdx.y];
+    for (int e = b; e; e >>= 1) { if (e & 1) r = fr_mul_wide(r, base); base = fr_mul_wide(base, base); }
+    pw[(size_t)blockIdx.y * nb + b] = r;
+}
 // out[b][i] = pw[b] * rows[b][i], i < h: the left halves of a level's rows with the layer's weights gamma^b folded in
 __global__ void k_bn_weight_rows(const Fr* __restrict__ rows, size_t row_len, const Fr* __restrict__ pw, Fr* __restrict__ out, size_t h, int nb) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -583,16 +592,19 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
         struct LayerPlan { Fr *buf0, *buf1, *part, *tbuf, *d_pw, *lw; int nmain; };
         std::vector<LayerPlan> plan(nv);
         int max_main = 0;
+        if (nv > 32) throw Error("hg_grand_product_bn254: more than 32 layers");
+        Fr* pw_all = dalloc((size_t)nv * nb);
+        GammaSet gammas;
+        for (auto& g : gammas.g) g = fr_zero();
         for (int n = 1; n < nv; n++) {
             LayerRec& L = layers[n];
             L.gamma_at = pos++; L.r_at = pos; pos += n; L.mu_at = pos++;
             if (n > 32) throw Error("hg_grand_product_bn254: more than 32 rounds");
             const size_t h = (size_t)1 << n;  // table length of this layer's sum-check (n variables)
             LayerPlan& P = plan[n];
-            P.d_pw = dalloc(nb);
-            k_bn_powers<<<(unsigned)((nb + 255) / 256), 256, 0, st>>>(P.d_pw, fr_to_mont(chain[L.gamma_at]), nb);   // gamma^b, b < nb
+            P.d_pw = pw_all + (size_t)n * nb;                                                                       // gamma_n^b, b < nb
+            gammas.g[n] = fr_to_mont(chain[L.gamma_at]);
             P.lw = dalloc(nb * h);                                                                                  // weighted left halves
-            k_bn_weight_rows<<<(unsigned)((nb * h + 255) / 256), 256, 0, st>>>(lev[nv - 1 - n], 2 * h, P.d_pw, P.lw, h, (int)nb);
             P.buf0 = dalloc(ntab * (h / 2));
             P.buf1 = dalloc(ntab * std::max<size_t>(h / 4, 1));
             P.part = dalloc((size_t)n * BN_PART_STRIDE * 3);
@@ -604,6 +616,13 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
             for (int rd = 1; rd < n; rd++)
                 if ((h >> (rd + 1)) <= (size_t)BN_TAIL_HALF && n - rd <= BN_TAIL_ROUNDS) { P.nmain = rd; break; }
             max_main = std::max(max_main, P.nmain);
+        }
+        if (nv > 1) {
+            k_bn_gamma_powers<<<dim3((unsigned)((nb + 255) / 256), nv), 256, 0, st>>>(pw_all, gammas, (int)nb);
+            for (int n = 1; n < nv; n++) {
+                const size_t h = (size_t)1 << n;
+                k_bn_weight_rows<<<(unsigned)((nb * h + 255) / 256), 256, 0, st>>>(lev[nv - 1 - n], 2 * h, plan[n].d_pw, plan[n].lw, h, (int)nb);
+            }
         }
         std::vector<GpJobDev> descs;
         std::vector<RedJobDev> reds;
