@@ -170,57 +170,96 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_round(const Fr* __restrict__ in, 
 }
 // Grand-product round of prove_grand_product, tuned: (a) the LEFT table of pair i enters the first round already multiplied by
 // its weight gamma^i (k_bn_weight_rows: two products per (pair, j), once), so no round needs weights and the folded left
-// tables stay weighted (the host divides the final left evaluations by gamma^i again); (b) the dot product over the pairs is accumulated unreduced in column accumulators (bn254_wide.cuh) and
-// Montgomery-reduced once per pair index j; (c) the three evaluation points are three workgroups per tile (v = 0: g(0) and
-// the left fold, 1: g(2) and the right fold, 2: g(3)): one accumulator per thread (three would not fit two waves per SIMD) and
-// a three times shorter dependent chain; the three are placed on one XCD so that the inputs come from HBM once;
-// (d) the pairs are dealt round-robin to gy thread groups so that small rounds are not one long serial chain per
-// thread (Montgomery reduction is linear: every group reduces its own partial dot product and multiplies by p_v itself).
+// tables stay weighted (the host divides the final left evaluations by gamma^i again); (b) the dot products over the pairs are
+// accumulated unreduced in column accumulators (bn254_wide.cuh) and Montgomery-reduced once per pair index j; (c) two lanes share
+// a pair index, one per table side (see the kernel): every table entry is loaded once, two accumulators per lane, two waves per
+// SIMD; (d) in small rounds the pairs are dealt round-robin to gy thread groups so that a round is not one long serial chain per
+// thread (Montgomery reduction is linear: every group reduces its own partial sums and multiplies by p_v itself).
 // One launch is round k of every layer that still has one (blockIdx.y = layer; a layer uses gx * gy of the gridDim.x workgroups):
 // the layers of a grand product only share the product tree
 // left table of pair i at l_base + i * l_stride, right table at r_base + i * r_stride (first round: the pre-weighted left halves and
 // the right halves of the level rows; later rounds: the interleaved folded tables)
 struct GpJobDev { const Fr* l_base; const Fr* r_base; Fr* out; Fr* part; Fr r; unsigned long long half, l_stride, r_stride; int nb, gx, gy, pad; };
-__global__ __launch_bounds__(BN_TPB) void k_bn_gp_round_jobs(const GpJobDev* __restrict__ jobs) {
+// Two lanes share one pair index j (quad_perm [1,0,3,2] swaps their registers): the even lane owns the LEFT tables, the odd lane the
+// RIGHT tables; each loads, folds and stores only its own tables, so every table entry is read from HBM once. With x, y = T[2j],
+// T[2j+1] and d = y - x the round polynomial needs P0 = sum xl xr, P1 = sum yl yr, Pinf = sum dl dr:
+//   g(0) = P0, g(2) = 2 P1 - P0 + 2 Pinf, g(3) = 3 P1 - 2 P0 + 6 Pinf.
+// Pairs are taken two at a time (a, b): the even lane accumulates P0 of both and Pinf of a, the odd lane P1 of both and Pinf of b -
+// the same instruction stream for both lanes (operands picked by v_cndmask), three multiply-accumulates and two folds per lane
+// per two pairs, i.e. exactly the 3 + 2 products a (pair, j) needs, two column accumulators per lane.
+__device__ __forceinline__ Fr fr_swap_lane(const Fr& v) {
+    Fr o;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        u32 lo = (u32)v.l[i], hi = (u32)(v.l[i] >> 32);
+        lo = (u32)__builtin_amdgcn_mov_dpp((int)lo, 0xB1, 0xF, 0xF, true);  // quad_perm:[1,0,3,2]
+        hi = (u32)__builtin_amdgcn_mov_dpp((int)hi, 0xB1, 0xF, 0xF, true);
+        o.l[i] = ((u64)hi << 32) | lo;
+    }
+    return o;
+}
+__device__ __forceinline__ Fr fr_sel(bool c, const Fr& a, const Fr& b) { return fr_make(c ? a.l[0] : b.l[0], c ? a.l[1] : b.l[1], c ? a.l[2] : b.l[2], c ? a.l[3] : b.l[3]); }
+constexpr int BN_GP_J = BN_TPB / 2;   // pair indices per workgroup
+__global__ __launch_bounds__(BN_TPB) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_bn_gp_round_jobs(const GpJobDev* __restrict__ jobs) {
     const GpJobDev& J = jobs[blockIdx.y];
-    // XCD-aware mapping: consecutive workgroup ids go round-robin to the 8 XCDs (each with its own L2), so the three evaluation-
-    // point workgroups of one tile get ids 8 (3 q + v) + xcd: same XCD, adjacent dispatch slots - the second and third read of
-    // the tile's inputs hit that XCD's L2 instead of HBM (gridDim.x is a multiple of 8)
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, v = slot % 3, tile = (slot / 3) * 8 + xcd;
+    const int tile = blockIdx.x;
     if (tile >= J.gx * J.gy) return;
     __shared__ Fr sm[BN_TPB];
-    Fr acc = fr_zero();
+    const bool isA = (threadIdx.x & 1) == 0;
+    const int jj = threadIdx.x >> 1, lane2 = threadIdx.x & 1;
+    const Fr* __restrict__ mb = isA ? J.l_base : J.r_base;   // my tables
+    const size_t ms = isA ? J.l_stride : J.r_stride;
     const Fr* __restrict__ lb = J.l_base;
-    const Fr* __restrict__ rb = J.r_base;
     Fr* __restrict__ out = J.out;
-    const size_t half = J.half, ls = J.l_stride, rs = J.r_stride;
+    const size_t half = J.half;
     const Fr r = J.r;
     const int nb = J.nb, P = J.gy, bx = tile % J.gx, pi = tile / J.gx;
-    for (size_t j = (size_t)bx * BN_TPB + threadIdx.x; j < half; j += (size_t)J.gx * BN_TPB) {
-        WCol a = wcol_zero();
-        Fr pv;  // table 0 (= left table of pair 0, weight gamma^0 = 1) at the evaluation point 0 / 2 / 3
+    Fr acc1 = fr_zero(), acc3 = fr_zero();   // even lane: g(0) and g(3); odd lane: g(2) (and an unused product)
+    for (size_t j = (size_t)bx * BN_GP_J + jj; j < half; j += (size_t)J.gx * BN_GP_J) {   // both lanes of a pair share j
+        WCol c1 = wcol_zero(), c2 = wcol_zero();
+        for (int ia = pi; ia < nb; ia += 2 * P) {
+            const int ib = ia + P;
+            const bool hb = ib < nb;   // uniform over the workgroup
+            Fr d_a;   // pair a first, then pair b: only d_a stays live in between
+            {
+                const Fr x_a = mb[(size_t)ia * ms + 2 * j], y_a = mb[(size_t)ia * ms + 2 * j + 1];
+                d_a = fr_sub(y_a, x_a);
+                out[(size_t)(2 * ia + lane2) * half + j] = fr_add(x_a, fr_mul_wide(r, d_a));
+                // even lane: x (own) * x (other side) -> P0; odd lane: y (own) * y (other side) -> P1
+                wcol_mac(c1, fr_sel(isA, x_a, y_a), fr_swap_lane(fr_sel(isA, y_a, x_a)));
+            }
+            Fr d_b = fr_zero();
+            if (hb) {
+                const Fr x_b = mb[(size_t)ib * ms + 2 * j], y_b = mb[(size_t)ib * ms + 2 * j + 1];
+                d_b = fr_sub(y_b, x_b);
+                out[(size_t)(2 * ib + lane2) * half + j] = fr_add(x_b, fr_mul_wide(r, d_b));
+                wcol_mac(c1, fr_sel(isA, x_b, y_b), fr_swap_lane(fr_sel(isA, y_b, x_b)));
+            }
+            // Pinf: pair a on the even lane, pair b on the odd lane
+            wcol_mac(c2, fr_sel(isA, d_a, d_b), fr_swap_lane(fr_sel(isA, d_b, d_a)));
+        }
+        Fr p0, p2, p3;  // table 0 (= left table of pair 0, weight gamma^0 = 1) at 0, 2, 3 (loaded here: not live across the pair loop)
         {
             const Fr x = lb[2 * j], y = lb[2 * j + 1];
             const Fr d = fr_sub(y, x);
-            pv = v == 0 ? x : (v == 1 ? fr_add(y, d) : fr_add(fr_add(y, d), d));
+            p0 = x; p2 = fr_add(y, d); p3 = fr_add(p2, d);
         }
-        for (int i = pi; i < nb; i += P) {
-            const Fr xl = lb[(size_t)i * ls + 2 * j], yl = lb[(size_t)i * ls + 2 * j + 1];
-            const Fr xr = rb[(size_t)i * rs + 2 * j], yr = rb[(size_t)i * rs + 2 * j + 1];
-            const Fr dl = fr_sub(yl, xl), dr = fr_sub(yr, xr);
-            Fr lv, rv;  // the pair at the evaluation point
-            if (v == 0) { lv = xl; rv = xr; }
-            else if (v == 1) { lv = fr_add(yl, dl); rv = fr_add(yr, dr); }
-            else { lv = fr_add(fr_add(yl, dl), dl); rv = fr_add(fr_add(yr, dr), dr); }
-            wcol_mac(a, lv, rv);
-            if (v == 0) out[(size_t)(2 * i) * half + j] = fr_add(xl, fr_mul_wide(r, dl));
-            else if (v == 1) out[(size_t)(2 * i + 1) * half + j] = fr_add(xr, fr_mul_wide(r, dr));
-        }
-        acc = fr_add(acc, fr_mul_wide(pv, wcol_reduce(a)));
+        const Fr R1 = wcol_reduce(c1), Ri = wcol_reduce(c2);
+        const Fr Ro = fr_swap_lane(R1), Pi = fr_add(Ri, fr_swap_lane(Ri));
+        const Fr P0 = fr_sel(isA, R1, Ro), P1 = fr_sel(isA, Ro, R1);
+        const Fr P1x2 = fr_add(P1, P1), Pix2 = fr_add(Pi, Pi);
+        const Fr q2 = fr_add(fr_sub(P1x2, P0), Pix2);
+        const Fr q3 = fr_add(fr_sub(fr_add(P1x2, P1), fr_add(P0, P0)), fr_add(fr_add(Pix2, Pix2), Pix2));
+        acc1 = fr_add(acc1, fr_mul_wide(fr_sel(isA, p0, p2), fr_sel(isA, P0, q2)));
+        acc3 = fr_add(acc3, fr_mul_wide(p3, q3));
     }
     const size_t blk = (size_t)pi * J.gx + bx;
-    const Fr s = block_sum_fr(acc, sm);
-    if (threadIdx.x == 0) J.part[blk * 3 + v] = s;
+    Fr s = block_sum_fr(isA ? acc1 : fr_zero(), sm);
+    if (threadIdx.x == 0) J.part[blk * 3 + 0] = s;
+    s = block_sum_fr(isA ? fr_zero() : acc1, sm);
+    if (threadIdx.x == 0) J.part[blk * 3 + 1] = s;
+    s = block_sum_fr(isA ? acc3 : fr_zero(), sm);
+    if (threadIdx.x == 0) J.part[blk * 3 + 2] = s;
 }
 // pw[n][b] = g_n^b for every layer n of a grand product in one launch (blockIdx.y = layer)
 struct GammaSet { Fr g[32]; };
@@ -247,6 +286,14 @@ static RoundGrid round_grid(size_t half, int nitems) {
     g.gx = (int)std::min<size_t>((half + BN_TPB - 1) / BN_TPB, (size_t)1024);
     const size_t threads = (size_t)g.gx * BN_TPB;
     g.gy = (int)std::max<size_t>(1, std::min<size_t>((size_t)nitems, (size_t)131072 / threads));
+    return g;
+}
+// grand-product rounds: two lanes per pair index (k_bn_gp_round_jobs), pairs taken two at a time per group
+static RoundGrid round_grid_gp(size_t half, int nb) {
+    RoundGrid g;
+    g.gx = (int)std::min<size_t>((half + BN_TPB / 2 - 1) / (BN_TPB / 2), (size_t)1024);
+    const size_t threads = (size_t)g.gx * BN_TPB;
+    g.gy = (int)std::max<size_t>(1, std::min<size_t>((size_t)(nb + 1) / 2, (size_t)131072 / threads));
     return g;
 }
 constexpr int BN_PART_STRIDE = 2048;  // per-round slots (workgroups) in a partials buffer; round_grid never exceeds 1024 + 512
@@ -651,7 +698,7 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
                 d.r = fr_to_mont(chain[layers[n].r_at + rd]);
                 d.half = half;
                 d.nb = (int)nb;
-                const RoundGrid g = round_grid(half, (int)nb);
+                const RoundGrid g = round_grid_gp(half, (int)nb);
                 d.gx = g.gx; d.gy = g.gy;
                 reds[red_index[n]].n[rd] = g.blocks();
                 max_blocks[rd] = std::max(max_blocks[rd], g.blocks());
@@ -683,8 +730,7 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
             hipc(hipMemcpy(d_reds, reds.data(), reds.size() * sizeof(RedJobDev), hipMemcpyHostToDevice), "upload reduce jobs");
             if (!tails.empty()) hipc(hipMemcpy(d_tails, tails.data(), tails.size() * sizeof(TailJobDev), hipMemcpyHostToDevice), "upload tail jobs");
             for (int rd = 0; rd < max_main; rd++) {
-                const dim3 grid(3 * ((max_blocks[rd] + 7) / 8 * 8), nactive[rd], 1);   // (tile, evaluation point) folded into x: see the kernel
-                k_bn_gp_round_jobs<<<grid, BN_TPB, 0, st>>>(d_descs + off[rd]);
+                k_bn_gp_round_jobs<<<dim3(max_blocks[rd], nactive[rd], 1), BN_TPB, 0, st>>>(d_descs + off[rd]);
             }
             k_bn_reduce_jobs<<<dim3(32, (unsigned)reds.size()), BN_TPB, 0, st>>>(d_reds, 3);
             if (!tails.empty()) k_bn_tail_jobs<BN_GRANDPROD><<<(unsigned)tails.size(), 3 * BN_TPB, 0, st>>>(d_tails);
