@@ -13,7 +13,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libhypergreco.so")
+_LIB_PATH = os.environ.get("HG_LIB") or os.path.join(_HERE, "libhypergreco.so")  # HG_LIB: an experimental build (scripts/build_variant.sh)
 HG_MAX_K = 16
 P = 0xFFFFFFFF00000001
 

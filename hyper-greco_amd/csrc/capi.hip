@@ -52,6 +52,19 @@ static void build_csr(const std::vector<const Term*>& terms, size_t S, KeyFn key
     for (const Term* t : terms) emit(*t, fill[key(*t)]++);
 }
 
+// A witness handle must have been built for the prover key's parameter set: the provers and verifiers index its
+// tables with sizes taken from the key (k * 2^L, k * 2^P ...), so a mismatch would read out of bounds.
+static void check_witness(const hg_pk* pk, const hg_witness* w, const char* who) {
+    const hg_params& a = pk->params.raw;
+    const hg_params& b = w->params;
+    if (a.n != b.n || a.k != b.k) throw Error(std::string(who) + ": witness was built for n=" + std::to_string(b.n) + " k=" + std::to_string(b.k) + ", the prover key for n=" + std::to_string(a.n) + " k=" + std::to_string(a.k));
+    const size_t SZ = pk->params.SZ(), PZ = pk->params.PZ(), k = (size_t)pk->params.k;
+    const Witness& v = w->w;
+    if (v.s.size() != SZ || v.e.size() != SZ || v.k1.size() != SZ || v.ais.size() != k * SZ || v.r1is.size() != k * SZ || v.r2is.size() != k * PZ ||
+        v.ct0is.size() != k * SZ)
+        throw Error(std::string(who) + ": witness table sizes do not match the parameter set");
+}
+
 extern "C" {
 
 const char* hg_last_error(void) { return g_last_error.c_str(); }
@@ -104,6 +117,7 @@ int hg_params_builtin(uint32_t n, uint32_t k, hg_params* out) {
 
 int hg_setup(hg_ctx* ctx, const hg_params* params, hg_pk** out) {
     HG_TRY
+    if (!params || !out) throw Error("hg_setup: null argument");
     if (ctx) hip_check(hipSetDevice(ctx->device), "hipSetDevice");
     std::unique_ptr<hg_pk> pk(new hg_pk(*params));
     pk->ctx = ctx;
@@ -238,6 +252,7 @@ void hg_pk_free(hg_pk* pk) {
 
 int hg_pk_lasso_layout(const hg_pk* pk, char* out, size_t cap) {
     HG_TRY
+    if (!pk || !out) throw Error("hg_pk_lasso_layout: null argument");
     std::string s = pk->lasso.layout_text();
     if (s.size() + 1 > cap) throw Error("buffer too small");
     memcpy(out, s.c_str(), s.size() + 1);
@@ -246,6 +261,7 @@ int hg_pk_lasso_layout(const hg_pk* pk, char* out, size_t cap) {
 }
 
 int hg_pk_info(const hg_pk* pk, uint64_t out[6]) {
+    if (!pk || !out) { g_last_error = "hg_pk_info: null argument"; return -1; }
     out[4] = (uint64_t)pk->circuit.lasso_in_id;
     out[5] = (uint64_t)pk->circuit.sum_id;
     out[0] = (uint64_t)pk->lasso.nu;
@@ -257,6 +273,7 @@ int hg_pk_info(const hg_pk* pk, uint64_t out[6]) {
 
 int hg_witness_from_json(const hg_params* params, const char* path, hg_witness** w) {
     HG_TRY
+    if (!params || !path || !w) throw Error("hg_witness_from_json: null argument");
     Params p(*params);
     std::unique_ptr<hg_witness> hw(new hg_witness{witness_from_json(p, path), *params});
     *w = hw.release();
@@ -266,6 +283,7 @@ int hg_witness_from_json(const hg_params* params, const char* path, hg_witness**
 
 int hg_witness_synthetic(const hg_params* params, uint64_t seed, hg_witness** w) {
     HG_TRY
+    if (!params || !w) throw Error("hg_witness_synthetic: null argument");
     Params p(*params);
     std::unique_ptr<hg_witness> hw(new hg_witness{witness_synthetic(p, seed), *params});
     *w = hw.release();
@@ -276,6 +294,7 @@ int hg_witness_synthetic(const hg_params* params, uint64_t seed, hg_witness** w)
 int hg_witness_from_arrays(const hg_params* params, const uint64_t* s, const uint64_t* e, const uint64_t* k1, const uint64_t* ais,
                            const uint64_t* r1is, const uint64_t* r2is, const uint64_t* ct0is, hg_witness** w) {
     HG_TRY
+    if (!params || !s || !e || !k1 || !ais || !r1is || !r2is || !ct0is || !w) throw Error("hg_witness_from_arrays: null argument");
     Params p(*params);
     const size_t SZ = p.SZ(), PZ = p.PZ(), k = (size_t)p.k;
     std::unique_ptr<hg_witness> hw(new hg_witness());
@@ -292,6 +311,7 @@ int hg_witness_from_arrays(const hg_params* params, const uint64_t* s, const uin
 }
 
 int64_t hg_witness_get(const hg_witness* w, int which, uint64_t* out, size_t cap) {
+    if (!w) { g_last_error = "hg_witness_get: null witness"; return -1; }
     const std::vector<u64>* v = nullptr;
     switch (which) {
         case 0: v = &w->w.s; break;
@@ -311,7 +331,8 @@ void hg_witness_free(hg_witness* w) { delete w; }
 
 int hg_witness_gen(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, hg_values** out, hg_timings* timings) {
     HG_TRY
-    if (!ctx || !pk || !w || !pk->ctx) throw Error("hg_witness_gen: needs a device context and a device prover key");
+    if (!ctx || !pk || !w || !out || !pk->ctx) throw Error("hg_witness_gen: needs a device context and a device prover key");
+    check_witness(pk, w, "hg_witness_gen");
     double wm = 0, um = 0;
     *out = witness_gen(ctx, pk, w->w, &wm, &um);
     if (timings) { memset(timings, 0, sizeof(*timings)); timings->witness_ms = wm; timings->upload_ms = um; }
@@ -323,6 +344,7 @@ void hg_values_free(hg_values* v) { values_free(v); }
 
 int64_t hg_values_get(hg_ctx* ctx, const hg_values* v, int node, uint64_t* out, size_t cap) {
     HG_TRY
+    if (out && !ctx) throw Error("hg_values_get: null context");
     if (!v || node < 0 || (size_t)node >= v->d_vals.size()) throw Error("hg_values_get: bad node id");
     size_t n = v->sizes[node];
     if (out && v->d_vals[node]) {
@@ -382,6 +404,8 @@ int hg_prove(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, uint8_t* proof, 
     HG_TRY
     if (!ctx || !pk || !w) throw Error("hg_prove: null argument");
     if (!pk->ctx) throw Error("hg_prove: host-only prover key (created without a context)");
+    if (!proof || !len) throw Error("hg_prove: null output argument");
+    check_witness(pk, w, "hg_prove");
     double t0 = now_ms_capi();
     double wm = 0, um = 0;
     hg_values* v = witness_gen(ctx, pk, w->w, &wm, &um);
@@ -399,6 +423,7 @@ int hg_prove(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, uint8_t* proof, 
 int hg_verify(const hg_pk* pk, const hg_witness* w, const uint8_t* proof, size_t len) {
     HG_TRY
     if (!pk || !w || !proof) throw Error("hg_verify: null argument");
+    check_witness(pk, w, "hg_verify");
     std::string why = verify_proof(pk->params, pk->lasso, pk->circuit, w->w, proof, len);
     if (why.empty()) return 0;
     g_last_error = why;
@@ -409,6 +434,7 @@ int hg_verify(const hg_pk* pk, const hg_witness* w, const uint8_t* proof, size_t
 int hg_verify_bn254(const hg_pk* pk, const hg_witness* w, const uint8_t* proof, size_t len) {
     HG_TRY
     if (!pk || !w || !proof) throw Error("hg_verify_bn254: null argument");
+    check_witness(pk, w, "hg_verify_bn254");
     std::string why = verify_proof_bn254(pk->params, pk->lasso, pk->circuit, w->w, proof, len);
     if (why.empty()) return 0;
     g_last_error = why;
@@ -418,6 +444,8 @@ int hg_verify_bn254(const hg_pk* pk, const hg_witness* w, const uint8_t* proof, 
 
 int hg_circuit_eval(const hg_pk* pk, const hg_witness* w, uint64_t* lasso_in, size_t lasso_cap, uint64_t* sum_out, size_t sum_cap) {
     HG_TRY
+    if (!pk || !w) throw Error("hg_circuit_eval: null argument");
+    check_witness(pk, w, "hg_circuit_eval");
     auto vals = circuit_evaluate(pk->circuit, pk->params, w->w);
     const auto& li = vals[pk->circuit.lasso_in_id];
     const auto& so = vals[pk->circuit.sum_id];
@@ -435,6 +463,7 @@ int hg_lasso_prove_at(hg_ctx* ctx, const hg_pk* pk, const uint64_t* lasso_in, si
                       uint64_t* claim_out) {
     HG_TRY
     if (!ctx || !pk || !pk->ctx) throw Error("hg_lasso_prove: needs a device context and a device prover key");
+    if (!lasso_in || !proof || !len) throw Error("hg_lasso_prove: null argument");
     std::vector<E2> claim;
     std::vector<uint8_t> pr = prove_lasso_node(ctx, pk, lasso_in, chain_skip, &claim);
     *len = pr.size();
@@ -448,6 +477,8 @@ int hg_lasso_prove_at(hg_ctx* ctx, const hg_pk* pk, const uint64_t* lasso_in, si
 int hg_sumcheck(hg_ctx* ctx, int kind, size_t nv, size_t ntab, const uint64_t* const* tables, const int* is_base, const uint64_t* pw,
                 size_t npw, const uint64_t* claim2, size_t chain_skip, uint64_t* msgs, uint64_t* point, uint64_t* evals, uint64_t* sums) {
     HG_TRY
+    if (!ctx || !tables || !is_base || !claim2 || (npw && !pw)) throw Error("hg_sumcheck: null argument (a HIP device is required)");
+    if (ntab == 0 || nv == 0 || nv > 30) throw Error("hg_sumcheck: bad shape");
     SumcheckIO io;
     io.kind = kind; io.nv = nv; io.chain_skip = chain_skip;
     io.tables.assign(tables, tables + ntab);
@@ -463,6 +494,7 @@ int hg_sumcheck(hg_ctx* ctx, int kind, size_t nv, size_t ntab, const uint64_t* c
 
 int hg_mle_eval(hg_ctx* ctx, const uint64_t* table, size_t nv, const uint64_t* point, uint64_t out2[2]) {
     HG_TRY
+    if (!ctx || !table || (nv && !point) || !out2) throw Error("hg_mle_eval: null argument (a HIP device is required)");
     std::vector<E2> pt(nv);
     for (size_t i = 0; i < nv; i++) pt[i] = e2(point[2 * i], point[2 * i + 1]);
     E2 v = mle_eval_device(ctx, table, nv, pt.data());
@@ -473,6 +505,8 @@ int hg_mle_eval(hg_ctx* ctx, const uint64_t* table, size_t nv, const uint64_t* p
 
 int hg_ntt(hg_ctx* ctx, const uint64_t* in, size_t log2n, int inverse, size_t batch, uint64_t* out) {
     HG_TRY
+    if (!ctx || !in || !out) throw Error("hg_ntt: null argument (a HIP device is required)");
+    if (log2n < 1 || log2n > 32) throw Error("hg_ntt: size out of range");
     ntt_device(ctx, in, (int)log2n, inverse != 0, batch, out);
     return 0;
     HG_CATCH(-1)
@@ -480,6 +514,7 @@ int hg_ntt(hg_ctx* ctx, const uint64_t* in, size_t log2n, int inverse, size_t ba
 
 int hg_challenges(size_t n, uint64_t* out) {
     HG_TRY
+    if (!out) throw Error("hg_challenges: null argument");
     const u64* c = challenge_chain(n);
     memcpy(out, c, n * 8);
     return 0;
@@ -547,6 +582,7 @@ int hg_witness_from_json_bn254(const hg_params* params, const char* path, hg_wit
 int hg_circuit_eval_bn254(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, int which, uint64_t* out4, size_t cap_elems, size_t* n_elems) {
     HG_TRY
     if (!ctx || !pk || !w || !n_elems) throw hg::Error("hg_circuit_eval_bn254: null argument (a HIP device is required)");
+    check_witness(pk, w, "hg_circuit_eval_bn254");
     std::vector<uint64_t> v;
     hg::bn::circuit_eval_bn254(ctx, pk, w->w, which, v);
     *n_elems = v.size() / 4;
@@ -558,6 +594,7 @@ int hg_circuit_eval_bn254(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, int
 int hg_prove_bn254(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, uint8_t* proof, size_t cap, size_t* len, double* ms2) {
     HG_TRY
     if (!ctx || !pk || !w || !len) throw hg::Error("hg_prove_bn254: null argument (a HIP device is required)");
+    check_witness(pk, w, "hg_prove_bn254");
     std::vector<uint8_t> bytes;
     hg::bn::prove_bn254(ctx, pk, w->w, bytes, ms2);
     *len = bytes.size();
@@ -581,8 +618,13 @@ int hg_ntt_bn254(hg_ctx* ctx, const uint64_t* in4, size_t log2n, int inverse, si
     HG_CATCH(-1)
 }
 
-int hg_profile(hg_ctx* ctx, int level) { ctx->prof_level = level; return 0; }
+int hg_profile(hg_ctx* ctx, int level) {
+    if (!ctx) { g_last_error = "hg_profile: null context"; return -1; }
+    ctx->prof_level = level;
+    return 0;
+}
 int hg_profile_select(hg_ctx* ctx, const char* name) {
+    if (!ctx || !name) { g_last_error = "hg_profile_select: null argument"; return -1; }
     bool found = false;
     for (auto& s : ctx->prof_stats) found = found || s.name == name;
     if (!found) { g_last_error = std::string("hg_profile_select: no kernel class named ") + name; return -1; }
@@ -590,10 +632,12 @@ int hg_profile_select(hg_ctx* ctx, const char* name) {
     return 0;
 }
 int hg_profile_reset(hg_ctx* ctx) {
+    if (!ctx) { g_last_error = "hg_profile_reset: null context"; return -1; }
     for (auto& s : ctx->prof_stats) { s.launches = 0; s.ms = 0; s.bytes = 0; }
     return 0;
 }
 int hg_profile_get(hg_ctx* ctx, hg_kernel_stat* out, int cap) {
+    if (!ctx || (!out && cap > 0)) { g_last_error = "hg_profile_get: null argument"; return -1; }
     int n = 0;
     for (auto& s : ctx->prof_stats) {
         if (n >= cap) break;

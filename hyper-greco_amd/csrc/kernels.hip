@@ -7,6 +7,8 @@
 #include <cstring>
 #include <algorithm>
 #include <rocprim/rocprim.hpp>
+#include <stdexcept>
+#include <string>
 #include <type_traits>
 #include "kernels.hpp"
 #include "gl_wide.cuh"
@@ -380,12 +382,27 @@ __device__ __forceinline__ void finish_partials(E2* p, int per, unsigned* ticket
     __shared__ unsigned s_last;
     if (nblocks < 0) nblocks = (int)gridDim.x;
     if (threadIdx.x == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the partial stores have reached the coherence point
+#ifdef HG_STRICT_TICKETS
+        // C++-memory-model form: release on the ticket (pairs with the last arriver's acquire). On gfx950 an agent-scope
+        // release is `buffer_wbl2 sc1` - a write-back of every dirty line of this XCD's L2, i.e. of the folded tables this very
+        // kernel is streaming out - once per workgroup: measured +0.8 ms on a 5.2 ms prove (profiles/r02_a_tickets_ab.txt).
+        unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+#else
+        // Default form. The partials are written by THIS thread with agent-scope atomic stores (part_store: `global_store ...
+        // sc1`, written through to the agent coherence point, never left dirty in the L2), so the only thing the ticket must
+        // be ordered after is the completion of those stores: `s_waitcnt vmcnt(0)` - the same vmcnt-tracked completion the
+        // compiler's own release sequence waits on after its write-back. The cache-wide write-back a formal release adds is
+        // only needed for plain (non-atomic) stores, and no plain store of this kernel is read through the ticket.
+        // The compiler barrier keeps the stores, the wait and the ticket RMW in program order.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
         s_last = (t == (unsigned)nblocks - 1) ? 1u : 0u;
     }
     __syncthreads();
     if (!s_last) return;
+    // acquire side (once per launch, cheap: `buffer_inv sc1`): the last workgroup must not see stale lines of the partials
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     constexpr int PER_MAX = 6;
     for (int v0 = 0; v0 < per; v0 += PER_MAX) {
         E2 a[PER_MAX];
@@ -1218,28 +1235,33 @@ __global__ __launch_bounds__(TPB) void k_counter_ranks(const u32* __restrict__ k
                                                        u64* __restrict__ final_cts) {
     for (size_t p = (size_t)blockIdx.x * TPB + threadIdx.x; p < n; p += (size_t)gridDim.x * TPB) {
         u32 key = ks[p];
-        if (key >= 65536) continue;
         u32 rank = (u32)p - starts[key];
         read_ts[rs[p]] = rank;                                   // = number of earlier rows on the same address
         if (p + 1 == n || ks[p + 1] != key) final_cts[key] = (u64)rank + 1;
     }
 }
+constexpr unsigned COUNTER_KEY_BITS = 16;  // subtable addresses are 16-bit limbs: the one bit range of the size query and of the sort
+static void check_hip(hipError_t e, const char* what) {
+    if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+}
 size_t lasso_counter_temp_bytes(size_t n) {
     size_t bytes = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, (u32*)nullptr, (u32*)nullptr, (u32*)nullptr, (u32*)nullptr, n, 0, 17);
+    check_hip(rocprim::radix_sort_pairs(nullptr, bytes, (u32*)nullptr, (u32*)nullptr, (u32*)nullptr, (u32*)nullptr, n, 0, COUNTER_KEY_BITS),
+              "radix_sort_pairs(size query)");
     return bytes;
 }
 void lasso_counters(hipStream_t st, const LassoDev& L, int m, const u64* dims, u64* read_ts, u64* final_cts, void* temp,
                     size_t temp_bytes, u32* keys, u32* keys_sorted, u32* rows_in, u32* rows_sorted, u32* starts) {
     const size_t N = (size_t)1 << L.nu;
-    (void)hipMemsetAsync(read_ts, 0, N * sizeof(u64), st);
-    (void)hipMemsetAsync(final_cts, 0, 65536 * sizeof(u64), st);
+    check_hip(hipMemsetAsync(read_ts, 0, N * sizeof(u64), st), "clear read_ts");
+    check_hip(hipMemsetAsync(final_cts, 0, 65536 * sizeof(u64), st), "clear final_cts");
     const size_t cnt = (size_t)L.cnt_nsegs[m] << L.seg_shift;  // rows whose lookup type uses memory m (lasso.rs:181-183)
     if (cnt == 0) return;
     int grid = grid_for(cnt);
     k_counter_keys<<<grid, TPB, 0, st>>>(L, m, dims + (size_t)L.mem_dim[m] * N, keys, rows_in);
     // stable LSD radix sort on the 16-bit address keeps the rows of one address in row order
-    (void)rocprim::radix_sort_pairs(temp, temp_bytes, keys, keys_sorted, rows_in, rows_sorted, cnt, 0, 16, st);
+    check_hip(rocprim::radix_sort_pairs(temp, temp_bytes, keys, keys_sorted, rows_in, rows_sorted, cnt, 0, COUNTER_KEY_BITS, st),
+              "radix_sort_pairs(counter keys)");
     k_counter_starts<<<grid, TPB, 0, st>>>(keys_sorted, cnt, starts);
     k_counter_ranks<<<grid, TPB, 0, st>>>(keys_sorted, rows_sorted, cnt, starts, read_ts, final_cts);
 }

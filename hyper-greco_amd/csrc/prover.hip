@@ -283,6 +283,10 @@ struct Prover {
         cls_gather = ctx->prof_class("vanilla_gather", false);
         cls_aux = ctx->prof_class("aux", false);
         ctx->ensure_chain(16384);
+        // arrival tickets of the last-workgroup reductions: a launch that died mid-way (fault, abort) would leave them non-zero
+        // and every later prove on this context would silently lose round sums, so each prove starts from cleared tickets
+        for (E2* pbuf : {ctx->d_partials, ctx->d_partials2})
+            hip_check(hipMemsetAsync(reinterpret_cast<char*>(pbuf) + dev::PARTIALS_E2 * sizeof(E2), 0, dev::PARTIALS_TICKETS * sizeof(unsigned), ctx->stream), "clear reduction tickets");
     }
     E2* d_res() { return ctx->d_res; }
     const E2* h_res() { return ctx->h_res; }

@@ -8,7 +8,7 @@
 #include <memory>
 #include "gkr.hpp"
 
-namespace orc {
+namespace ORC_NS {
 
 struct BfvParams {
     size_t n = 0, k = 0;
@@ -19,7 +19,7 @@ struct BfvParams {
     size_t ct0is_log2_size() const { return log2_size() + exact_log2(k); }  // :519-522
 };
 
-struct BfvInputs {  // get_inputs :365-415 (field elements, canonical u64)
+struct BfvInputs {  // get_inputs :365-415 (field elements)
     Values s, e, k1;              // 2^L each
     std::vector<Values> ais, r1is;  // k x 2^L
     Values r2is;                  // k * 2^P
@@ -74,7 +74,7 @@ static inline void bfv_configure(const BfvParams& p, BfvCircuit& bc) {
         for (size_t i = 0; i < chunks.size(); i++) bounds.push_back(p.r2_bounds[0]);
         bounds.push_back(p.s_bound); bounds.push_back(p.e_bound); bounds.push_back(p.k1_bound);
         GateBuilder g(chunks.size() + k + 3, L, 1);
-        for (size_t i = 0; i < bounds.size(); i++) for (size_t j = 0; j < SZ; j++) g.relay_add_const(i, j, f_from_u64(bounds[i]));
+        for (size_t i = 0; i < bounds.size(); i++) for (size_t j = 0; j < SZ; j++) g.relay_add_const(i, j, bounds[i]);
         lasso_in = c.insert(g.finish());
     }
     {   // :182-210
@@ -144,21 +144,21 @@ struct BfvProveTimings { double witness_ms = 0, prove_ms = 0; };
 static inline double now_ms();
 
 // prove :417-460
-static inline std::vector<uint8_t> bfv_prove(const BfvParams& p, const BfvInputs& in, BfvProveTimings* tm = nullptr);
-static inline bool bfv_verify(const BfvParams& p, const BfvInputs& in, const uint8_t* proof, size_t len, std::string* err);
+static inline std::vector<uint8_t> bfv_prove(const BfvParams& p, const BfvInputs& in, BfvProveTimings* tm = nullptr, ProtocolMode mode = ProtocolMode());
+static inline bool bfv_verify(const BfvParams& p, const BfvInputs& in, const uint8_t* proof, size_t len, std::string* err, ProtocolMode mode = ProtocolMode());
 
-}  // namespace orc
+}  // namespace ORC_NS
 
 #include <chrono>
-namespace orc {
+namespace ORC_NS {
 static inline double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-static inline std::vector<uint8_t> bfv_prove(const BfvParams& p, const BfvInputs& in, BfvProveTimings* tm) {
+static inline std::vector<uint8_t> bfv_prove(const BfvParams& p, const BfvInputs& in, BfvProveTimings* tm, ProtocolMode mode) {
     BfvCircuit bc;
     bc.pre.reset(new LassoPre(bfv_setup(p)));
-    TranscriptW tr;  // :431
+    TranscriptW tr(mode);  // :431
     bfv_configure(p, bc);  // :433-437
     double t0 = now_ms();
     std::vector<Values> vals = circuit_evaluate(bc.c, bfv_input_list(p, in));  // :442
@@ -172,11 +172,11 @@ static inline std::vector<uint8_t> bfv_prove(const BfvParams& p, const BfvInputs
     return tr.stream;  // :459
 }
 
-static inline bool bfv_verify(const BfvParams& p, const BfvInputs& in, const uint8_t* proof, size_t len, std::string* err) {
+static inline bool bfv_verify(const BfvParams& p, const BfvInputs& in, const uint8_t* proof, size_t len, std::string* err, ProtocolMode mode) {
     try {
         BfvCircuit bc;
         bc.pre.reset(new LassoPre(bfv_setup(p)));
-        TranscriptR tr(proof, len);  // :478
+        TranscriptR tr(proof, len, mode);  // :478
         std::vector<E> point = tr.squeeze_n(p.ct0is_log2_size());  // :482
         E value = mle_eval_f(in.ct0is.data(), point.size(), point.data());  // :495
         bfv_configure(p, bc);  // :503-507
@@ -199,4 +199,4 @@ static inline bool bfv_verify(const BfvParams& p, const BfvInputs& in, const uin
     }
 }
 
-}  // namespace orc
+}  // namespace ORC_NS

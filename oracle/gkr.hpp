@@ -23,46 +23,39 @@
 #include <queue>
 #include <functional>
 #include <stdexcept>
-#include "gl.hpp"
+#include "field.hpp"
 #include "poly.hpp"
 #include "sumcheck.hpp"
 #include "lasso.hpp"
 
-namespace orc {
-
-static inline uint64_t gl_root_of_unity(size_t log2n) {
-    // ff::PrimeField::ROOT_OF_UNITY for Goldilocks (S = 32, multiplicative generator 7)
-    uint64_t w = f_pow(7, (GL_P - 1) >> 32);
-    for (size_t i = log2n; i < 32; i++) w = f_mul(w, w);
-    return w;
-}
+namespace ORC_NS {
 
 // natural-order in/out NTT: out[z] = sum_x in[x] w^(xz); inverse: w^-1 and 1/N scaling
-static inline std::vector<uint64_t> ntt(const uint64_t* in, size_t log2n, bool inverse) {
+static inline std::vector<F> ntt(const F* in, size_t log2n, bool inverse) {
     size_t N = (size_t)1 << log2n;
-    std::vector<uint64_t> a(N);
+    std::vector<F> a(N);
     for (size_t i = 0; i < N; i++) {
         size_t r = 0;
         for (size_t b = 0; b < log2n; b++) if (i >> b & 1) r |= (size_t)1 << (log2n - 1 - b);
         a[r] = in[i];
     }
-    uint64_t w = gl_root_of_unity(log2n);
+    F w = f_root_of_unity(log2n);  // G4: the 2^log2n-th root derived from PrimeField::ROOT_OF_UNITY
     if (inverse) w = f_inv(w);
     for (size_t s = 1; s <= log2n; s++) {
         size_t m = (size_t)1 << s, h = m >> 1;
-        uint64_t wm = f_pow(w, N >> s);
-        std::vector<uint64_t> tw(h);
-        tw[0] = 1;
+        F wm = f_pow(w, N >> s);
+        std::vector<F> tw(h);
+        tw[0] = f_one();
         for (size_t j = 1; j < h; j++) tw[j] = f_mul(tw[j - 1], wm);
         for (size_t k = 0; k < N; k += m)
             for (size_t j = 0; j < h; j++) {
-                uint64_t t = f_mul(tw[j], a[k + j + h]), u = a[k + j];
+                F t = f_mul(tw[j], a[k + j + h]), u = a[k + j];
                 a[k + j] = f_add(u, t);
                 a[k + j + h] = f_sub(u, t);
             }
     }
     if (inverse) {
-        uint64_t ninv = f_inv(f_from_u64(N));
+        F ninv = f_inv(f_from_u64(N));
         for (auto& x : a) x = f_mul(x, ninv);
     }
     return a;
@@ -71,18 +64,18 @@ static inline std::vector<uint64_t> ntt(const uint64_t* in, size_t log2n, bool i
 // F(r, x) for all x in [0, 2^L), O(N): prod_b (1 + r_b (w^(2^b x) - 1)), factor b depends on x mod 2^(L-b)
 static inline std::vector<E> fft_table(const std::vector<E>& r, size_t L, bool inverse) {
     size_t N = (size_t)1 << L;
-    uint64_t w = gl_root_of_unity(L);
+    F w = f_root_of_unity(L);
     if (inverse) w = f_inv(w);
-    std::vector<uint64_t> W(N);
-    W[0] = 1;
+    std::vector<F> W(N);
+    W[0] = f_one();
     for (size_t i = 1; i < N; i++) W[i] = f_mul(W[i - 1], w);
     std::vector<E> cur(1, inverse ? e_from_f(f_inv(f_from_u64(N))) : e_one());
     for (size_t bb = L; bb-- > 0;) {
         size_t sz = (size_t)1 << (L - bb);
         std::vector<E> nxt(sz);
         for (size_t x = 0; x < sz; x++) {
-            uint64_t wx = W[(x << bb) & (N - 1)];
-            E f = e_add_f(e_mul_f(r[bb], f_sub(wx, 1)), 1);
+            F wx = W[(x << bb) & (N - 1)];
+            E f = e_add_f(e_mul_f(r[bb], f_sub(wx, f_one())), f_one());
             nxt[x] = e_mul(cur[x & (sz / 2 - 1)], f);
         }
         cur.swap(nxt);
@@ -92,6 +85,7 @@ static inline std::vector<E> fft_table(const std::vector<E>& r, size_t L, bool i
 
 enum NodeKind { NK_INPUT, NK_VANILLA, NK_FFT, NK_LASSO };
 
+// gate constants are non-negative integers (1, q_i, k0_i, range bounds): the same in every field, lifted with f_from_u64
 struct LinTerm { uint32_t gate, in, j; uint64_t c; };
 struct MulTerm { uint32_t gate, i0, j0, i1, j1; uint64_t c; };
 struct ConstTerm { uint32_t gate; uint64_t c; };
@@ -168,18 +162,18 @@ struct GateBuilder {  // VanillaNode::new(input_arity, log2_sub_input_size, gate
     Node finish() { n.num_gates = g; n.log2_sub_out = ceil_log2(g); return n; }
 };
 
-typedef std::vector<uint64_t> Values;
+typedef std::vector<F> Values;
 
 static inline Values vanilla_evaluate(const Node& n, const std::vector<const Values*>& in) {
     size_t G = (size_t)1 << n.log2_sub_out, S = (size_t)1 << n.log2_sub_in, R = (size_t)1 << n.log2_reps;
-    Values out(G * R, 0);
+    Values out(G * R, f_zero());
 #pragma omp parallel for schedule(static)
     for (long long rr = 0; rr < (long long)R; rr++) {
         size_t rep = (size_t)rr;
-        uint64_t* o = out.data() + rep * G;
-        for (auto& t : n.w0) o[t.gate] = f_add(o[t.gate], t.c);
-        for (auto& t : n.lin) o[t.gate] = f_add(o[t.gate], f_mul(t.c, (*in[t.in])[rep * S + t.j]));
-        for (auto& t : n.mul) o[t.gate] = f_add(o[t.gate], f_mul(t.c, f_mul((*in[t.i0])[rep * S + t.j0], (*in[t.i1])[rep * S + t.j1])));
+        F* o = out.data() + rep * G;
+        for (auto& t : n.w0) o[t.gate] = f_add(o[t.gate], f_from_u64(t.c));
+        for (auto& t : n.lin) o[t.gate] = f_add(o[t.gate], f_mul(f_from_u64(t.c), (*in[t.in])[rep * S + t.j]));
+        for (auto& t : n.mul) o[t.gate] = f_add(o[t.gate], f_mul(f_from_u64(t.c), f_mul((*in[t.i0])[rep * S + t.j0], (*in[t.i1])[rep * S + t.j1])));
     }
     return out;
 }
@@ -202,7 +196,7 @@ static inline std::vector<Values> circuit_evaluate(const Circuit& c, const std::
             case NK_INPUT: break;
             case NK_VANILLA: vals[id] = vanilla_evaluate(n, in); break;
             case NK_FFT: vals[id] = ntt(in[0]->data(), n.log2_size, n.inverse); break;
-            case NK_LASSO: vals[id] = Values(1, 0); break;  // lasso.rs:53-55
+            case NK_LASSO: vals[id] = Values(1, f_zero()); break;  // lasso.rs:53-55
         }
     }
     return vals;
@@ -241,16 +235,16 @@ static inline std::vector<std::vector<EvalClaim>> vanilla_prove(const Node& n, c
     std::vector<E> eqc = combined_eq(cl, alpha);
     E claim = combined_value(cl, alpha);
     for (size_t rep = 0; rep < R; rep++)
-        for (auto& t : n.w0) claim = e_sub(claim, e_mul_f(eqc[rep * G + t.gate], t.c));
+        for (auto& t : n.w0) claim = e_sub(claim, e_mul_f(eqc[rep * G + t.gate], f_from_u64(t.c)));
     VanillaUse use = vanilla_use(n);
     // phase 1 bookkeeping tables
     std::vector<std::vector<E>> T(n.arity);
     for (size_t i = 0; i < n.arity; i++) if (use.left[i]) T[i].assign(S * R, e_zero());
     for (size_t rep = 0; rep < R; rep++) {
-        for (auto& t : n.lin) { E& d = T[t.in][rep * S + t.j]; d = e_add(d, e_mul_f(eqc[rep * G + t.gate], t.c)); }
+        for (auto& t : n.lin) { E& d = T[t.in][rep * S + t.j]; d = e_add(d, e_mul_f(eqc[rep * G + t.gate], f_from_u64(t.c))); }
         for (auto& t : n.mul) {
             E& d = T[t.i0][rep * S + t.j0];
-            d = e_add(d, e_mul_f(eqc[rep * G + t.gate], f_mul(t.c, (*in[t.i1])[rep * S + t.j1])));
+            d = e_add(d, e_mul_f(eqc[rep * G + t.gate], f_mul(f_from_u64(t.c), (*in[t.i1])[rep * S + t.j1])));
         }
     }
     std::vector<ScTable> tabs;
@@ -270,13 +264,13 @@ static inline std::vector<std::vector<EvalClaim>> vanilla_prove(const Node& n, c
         std::vector<E> eqx = eq_table(r1.point);
         E claim2 = r1.claim;
         for (size_t rep = 0; rep < R; rep++)
-            for (auto& t : n.lin) claim2 = e_sub(claim2, e_mul(u[t.in], e_mul(e_mul_f(eqc[rep * G + t.gate], t.c), eqx[rep * S + t.j])));
+            for (auto& t : n.lin) claim2 = e_sub(claim2, e_mul(u[t.in], e_mul(e_mul_f(eqc[rep * G + t.gate], f_from_u64(t.c)), eqx[rep * S + t.j])));
         std::vector<std::vector<E>> B(n.arity);
         for (size_t i = 0; i < n.arity; i++) if (use.right[i]) B[i].assign(S * R, e_zero());
         for (size_t rep = 0; rep < R; rep++)
             for (auto& t : n.mul) {
                 E& d = B[t.i1][rep * S + t.j1];
-                d = e_add(d, e_mul(e_mul(e_mul_f(eqc[rep * G + t.gate], t.c), eqx[rep * S + t.j0]), u[t.i0]));
+                d = e_add(d, e_mul(e_mul(e_mul_f(eqc[rep * G + t.gate], f_from_u64(t.c)), eqx[rep * S + t.j0]), u[t.i0]));
             }
         std::vector<ScTable> tabs2;
         std::vector<size_t> ri;
@@ -302,7 +296,7 @@ static inline std::vector<std::vector<EvalClaim>> vanilla_verify(const Node& n, 
     std::vector<E> eqc = combined_eq(cl, alpha);
     E claim = combined_value(cl, alpha);
     for (size_t rep = 0; rep < R; rep++)
-        for (auto& t : n.w0) claim = e_sub(claim, e_mul_f(eqc[rep * G + t.gate], t.c));
+        for (auto& t : n.w0) claim = e_sub(claim, e_mul_f(eqc[rep * G + t.gate], f_from_u64(t.c)));
     VanillaUse use = vanilla_use(n);
     auto r1 = verify_sum_check(2, nin, claim, tr);
     std::vector<E> u(n.arity, e_zero());
@@ -311,7 +305,7 @@ static inline std::vector<std::vector<EvalClaim>> vanilla_verify(const Node& n, 
     std::vector<E> eqx = eq_table(r1.second);
     E lin_part = e_zero();
     for (size_t rep = 0; rep < R; rep++)
-        for (auto& t : n.lin) lin_part = e_add(lin_part, e_mul(u[t.in], e_mul(e_mul_f(eqc[rep * G + t.gate], t.c), eqx[rep * S + t.j])));
+        for (auto& t : n.lin) lin_part = e_add(lin_part, e_mul(u[t.in], e_mul(e_mul_f(eqc[rep * G + t.gate], f_from_u64(t.c)), eqx[rep * S + t.j])));
     if (!use.has_mul) {
         if (!e_eq(r1.first, lin_part)) throw std::runtime_error("vanilla node: final evaluation mismatch");
         return sub;
@@ -325,7 +319,7 @@ static inline std::vector<std::vector<EvalClaim>> vanilla_verify(const Node& n, 
     for (size_t rep = 0; rep < R; rep++)
         for (auto& t : n.mul)
             fin = e_add(fin, e_mul(e_mul(w[t.i1], u[t.i0]),
-                                   e_mul(e_mul(e_mul_f(eqc[rep * G + t.gate], t.c), eqx[rep * S + t.j0]), eqy[rep * S + t.j1])));
+                                   e_mul(e_mul(e_mul_f(eqc[rep * G + t.gate], f_from_u64(t.c)), eqx[rep * S + t.j0]), eqy[rep * S + t.j1])));
     if (!e_eq(r2.first, fin)) throw std::runtime_error("vanilla node: phase-2 final evaluation mismatch");
     return sub;
 }
@@ -429,4 +423,4 @@ static inline std::vector<std::vector<EvalClaim>> verify_gkr(const Circuit& c,
     return claims;
 }
 
-}  // namespace orc
+}  // namespace ORC_NS

@@ -10,13 +10,27 @@
 //   * Ext2 non-residue 7, bases order [c0, c1]    (as_bases / from_bases, transcript.rs:149-154,191-195)
 // The published definition (p, X^2-7) is restated here; every op is checked against
 // Python big-int arithmetic in tests/test_oracle_field.py.
+//
+// This header is one of the two field back ends of the oracle (the other is fr.hpp: bn256::Fr with E = F); the protocol
+// headers are written against the names both define: types F / E, f_* / e_* arithmetic, wire format, challenge derivation,
+// limb load / store for the C surface. field.hpp picks one per translation unit.
 #pragma once
 #include <cstdint>
 #include <cstddef>
+#include <cstring>
+
+#define ORC_NS orc
+#define ORC_SYM(name) orc_##name
+#define ORC_F_IS_U64 1
 
 namespace orc {
 
 typedef unsigned __int128 u128;
+typedef uint64_t F;                  // base-field element, canonical value in [0, p)
+static const size_t F_LIMBS = 1;     // u64 limbs per F / E at the C surface
+static const size_t E_LIMBS = 2;
+static const size_t F_BYTES = 8;     // <F as PrimeField>::Repr length
+static const size_t E_DEGREE = 2;    // ExtensionField::DEGREE
 static const uint64_t GL_P = 0xFFFFFFFF00000001ULL;
 static const uint64_t GL_EPS = 0xFFFFFFFFULL;  // 2^64 mod p = 2^32 - 1
 
@@ -49,6 +63,15 @@ static inline uint64_t f_pow(uint64_t b, uint64_t e) {
 }
 static inline uint64_t f_inv(uint64_t a) { return f_pow(a, GL_P - 2); }
 
+static inline F f_zero() { return 0; }
+static inline F f_one() { return 1; }
+static inline bool f_eq(F a, F b) { return a == b; }
+static inline bool f_is_zero(F a) { return a == 0; }
+static inline F f_dbl(F a) { return f_add(a, a); }
+// witness coefficients arrive as Goldilocks residues (negatives as p - |z|, utils.py:4-18): already field elements here
+static inline F f_from_signed_gl(uint64_t v) { return v; }
+static inline uint64_t f_low_u64(F a) { return a; }  // inverse of f_from_u64 for values below 2^63 (range-shifted lookups)
+
 struct E {
     uint64_t c0, c1;
 };
@@ -76,5 +99,41 @@ static inline E e_inv(E a) {
     uint64_t ni = f_inv(n);
     return E{f_mul(a.c0, ni), f_mul(f_neg(a.c1), ni)};
 }
+
+// ExtensionField::{from_bases, as_bases} (transcript.rs:149-154, 191-195): [c0, c1]
+static inline E e_from_bases(const F* b) { return E{b[0], b[1]}; }
+static inline void e_as_bases(E a, F* b) { b[0] = a.c0; b[1] = a.c1; }
+static inline F e_limb0(E a) { return a.c0; }  // `as_bases()[0]` (prover.rs:38-39)
+static inline bool e_is_zero(E a) { return a.c0 == 0 && a.c1 == 0; }
+
+// wire format (transcript.rs:183-189, 162-170): canonical repr byte-reversed to big-endian; non-canonical input rejected
+static inline void f_write_be(F a, uint8_t* out) { for (int i = 0; i < 8; i++) out[i] = (uint8_t)(a >> (8 * (7 - i))); }
+static inline bool f_read_be(const uint8_t* in, F& out) {
+    uint64_t a = 0;
+    for (int i = 0; i < 8; i++) a = (a << 8) | in[i];
+    out = a;
+    return a < GL_P;
+}
+// PrimeField::to_repr: canonical little-endian bytes (what an absorbing transcript hashes, transcript.rs:205-208, 224-226)
+static inline void f_repr_le(F a, uint8_t* out) { memcpy(out, &a, 8); }
+// plonkish fe_mod_from_le_bytes (call site transcript.rs:202): 256-bit little-endian integer reduced mod p
+static inline F f_from_hash_le(const uint8_t h[32]) {
+    uint64_t l[4];
+    memcpy(l, h, 32);
+    uint64_t r = f_from_u64(l[3]);
+    for (int i = 2; i >= 0; i--) r = f_add(f_mul(r, GL_EPS), f_from_u64(l[i]));
+    return r;
+}
+// ff::PrimeField::ROOT_OF_UNITY for Goldilocks (S = 32, multiplicative generator 7), squared down to order 2^log2n
+static inline F f_root_of_unity(size_t log2n) {
+    uint64_t w = f_pow(7, (GL_P - 1) >> 32);
+    for (size_t i = log2n; i < 32; i++) w = f_mul(w, w);
+    return w;
+}
+// canonical u64 limbs at the C surface
+static inline F f_load(const uint64_t* p) { return p[0]; }
+static inline void f_store(F a, uint64_t* p) { p[0] = a; }
+static inline E e_load(const uint64_t* p) { return E{p[0], p[1]}; }
+static inline void e_store(E a, uint64_t* p) { p[0] = a.c0; p[1] = a.c1; }
 
 }  // namespace orc

@@ -7,7 +7,7 @@
 #include <cstring>
 #include <cstddef>
 
-namespace orc {
+namespace orc_keccak {  // field-independent: shared by both field back ends
 
 static inline uint64_t rotl64(uint64_t x, int n) { return n ? (x << n) | (x >> (64 - n)) : x; }
 
@@ -65,4 +65,4 @@ static inline void keccak256(const uint8_t* in, size_t len, uint8_t out[32]) {
     memcpy(out, st, 32);
 }
 
-}  // namespace orc
+}  // namespace orc_keccak

@@ -8,12 +8,12 @@
 #include <map>
 #include <algorithm>
 #include <stdexcept>
-#include "gl.hpp"
+#include "field.hpp"
 #include "poly.hpp"
 #include "sumcheck.hpp"
 #include "transcript.hpp"
 
-namespace orc {
+namespace ORC_NS {
 
 static const size_t LASSO_C = 4;          // sk_encryption_circuit.rs:30
 static const size_t LASSO_LOGM = 16;      // sk_encryption_circuit.rs:29
@@ -43,7 +43,7 @@ struct Subtable {
         size_t b = point.size();
         E result = e_zero();
         if (full) {
-            for (size_t i = 0; i < b; i++) result = e_add(result, e_mul_f(point[i], 1ull << i));
+            for (size_t i = 0; i < b; i++) result = e_add(result, e_mul_f(point[i], f_from_u64(1ull << i)));
             return result;
         }
         uint64_t co = cutoff();
@@ -51,7 +51,7 @@ struct Subtable {
         uint64_t g_base = 1ull << cl2, num_extra = co - g_base;
         for (size_t i = 0; i < b; i++) {
             if (i < cl2) {
-                result = e_add(result, e_mul_f(point[i], 1ull << i));
+                result = e_add(result, e_mul_f(point[i], f_from_u64(1ull << i)));
             } else {
                 E g_value = e_zero();
                 if (i == cl2) {
@@ -161,12 +161,14 @@ struct LassoPre {
 };
 
 // lasso.rs:381-414 + :654-669 + range.rs:252-254: LE bits of the canonical repr, truncated to
-// sum(chunk_bits), cut in 16-bit chunks, at most C of them.
+// sum(chunk_bits), cut in 16-bit chunks, at most C of them (C * 16 = 64: only the low 64 bits of the repr matter).
 static inline void subtable_lookup_indices_row(uint64_t value, size_t total_bits, uint32_t idx[LASSO_C]) {
     uint64_t v = total_bits >= 64 ? value : (value & ((1ull << total_bits) - 1));
     for (size_t c = 0; c < LASSO_C; c++) idx[c] = (uint32_t)((v >> (16 * c)) & 0xFFFF);
 }
 
+// The node's witness polynomials are tables of small non-negative integers (limb indices, counters, subtable values):
+// the same in every field. They meet the field through f_from_u64.
 struct LassoPolys {
     size_t nu;
     std::vector<std::vector<uint64_t>> dims;       // C x 2^nu
@@ -175,9 +177,33 @@ struct LassoPolys {
     std::vector<std::vector<uint64_t>> e_polys;    // alpha x 2^nu
 };
 
+// base-field view of an integer table: Goldilocks shares the storage (every entry is below p), Fr converts
+struct FTab {
+    std::vector<F> own;
+    const uint64_t* shared = nullptr;
+    const F* p() const {
+#if ORC_F_IS_U64
+        return shared;
+#else
+        return own.data();
+#endif
+    }
+};
+static inline FTab ftab_from_u64(const std::vector<uint64_t>& v) {
+    FTab t;
+#if ORC_F_IS_U64
+    t.shared = v.data();
+#else
+    t.own.resize(v.size());
+#pragma omp parallel for schedule(static)
+    for (long long i = 0; i < (long long)v.size(); i++) t.own[i] = f_from_u64(v[i]);
+#endif
+    return t;
+}
+
 // lasso.rs:157-250. `row_lookup[j]` = index of row j's lookup in pre.lookups (rows = row_lookup.size()).
 static inline LassoPolys polynomialize(const LassoPre& pre, size_t nu, const std::vector<uint8_t>& row_lookup,
-                                       const uint64_t* inputs) {
+                                       const F* inputs) {
     LassoPolys P;
     P.nu = nu;
     const size_t N = (size_t)1 << nu, rows = row_lookup.size();
@@ -187,7 +213,7 @@ static inline LassoPolys polynomialize(const LassoPre& pre, size_t nu, const std
 #pragma omp parallel for schedule(static)
     for (long long j = 0; j < (long long)rows; j++) {
         uint32_t idx[LASSO_C];
-        subtable_lookup_indices_row(inputs[j], tb[row_lookup[j]], idx);
+        subtable_lookup_indices_row(f_low_u64(inputs[j]), tb[row_lookup[j]], idx);
         for (size_t c = 0; c < LASSO_C; c++) P.dims[c][j] = idx[c];
     }
     const size_t A = pre.num_memories;
@@ -223,54 +249,72 @@ static inline E lasso_sum_check_claim(const LassoPre& pre, const LassoPolys& P, 
                                       const std::vector<E>& r) {
     std::vector<E> eq = eq_table(r);
     const size_t rows = row_lookup.size();
-    std::vector<uint64_t> mp(LASSO_C + 1);
-    mp[0] = 1;
-    for (size_t i = 1; i < mp.size(); i++) mp[i] = f_mul(mp[i - 1], LASSO_M);
-    uint64_t s0 = 0, s1 = 0;
+    std::vector<F> mp(LASSO_C + 1);
+    mp[0] = f_one();
+    for (size_t i = 1; i < mp.size(); i++) mp[i] = f_mul(mp[i - 1], f_from_u64(LASSO_M));
+    E total = e_zero();
 #pragma omp parallel
     {
-        uint64_t a0 = 0, a1 = 0;
+        E a = e_zero();
 #pragma omp for nowait schedule(static)
         for (long long k = 0; k < (long long)rows; k++) {
             const std::vector<size_t>& mems = pre.lookup_mems[row_lookup[k]];
-            uint64_t comb = 0;
-            for (size_t i = 0; i < mems.size(); i++) comb = f_add(comb, f_mul(P.e_polys[mems[i]][k], mp[i]));
-            a0 = f_add(a0, f_mul(eq[k].c0, comb));
-            a1 = f_add(a1, f_mul(eq[k].c1, comb));
+            F comb = f_zero();
+            for (size_t i = 0; i < mems.size(); i++) comb = f_add(comb, f_mul(f_from_u64(P.e_polys[mems[i]][k]), mp[i]));
+            a = e_add(a, e_mul_f(eq[k], comb));
         }
 #pragma omp critical
-        { s0 = f_add(s0, a0); s1 = f_add(s1, a1); }
+        total = e_add(total, a);
     }
-    return E{s0, s1};
+    return total;
 }
 
-// prover.rs:183-266. vs: nb tables of `len` base-field values. Returns (final claims, point).
+// element type of the grand-product tables: base field (the reference: gamma, tau truncated to limb 0) or extension
+// field (ProtocolMode::ext_memcheck). A tag instead of overloading on the type, because F and E coincide over Fr.
+template <bool EXT> struct GpElem;
+template <> struct GpElem<false> {
+    typedef F T;
+    static inline T mul(T a, T b) { return f_mul(a, b); }
+    static inline E lift(T a) { return e_from_f(a); }
+    static inline ScTable table(const T* p, size_t n) { return ScTable::from_f(p, n); }
+};
+template <> struct GpElem<true> {
+    typedef E T;
+    static inline T mul(T a, T b) { return e_mul(a, b); }
+    static inline E lift(T a) { return a; }
+    static inline ScTable table(const T* p, size_t n) { return ScTable::view_e(p, n); }
+};
+
+// prover.rs:183-266. vs: nb tables of `len` values. Returns (final claims, point).
+template <bool EXT>
 static inline std::pair<std::vector<E>, std::vector<E>> prove_grand_product(
-    const std::vector<const uint64_t*>& vs, size_t len, TranscriptW& tr, std::vector<E>* record = nullptr) {
+    const std::vector<const typename GpElem<EXT>::T*>& vs, size_t len, TranscriptW& tr, std::vector<E>* record = nullptr) {
+    typedef GpElem<EXT> G;
+    typedef typename G::T T;
     const size_t nb = vs.size();
     size_t nv = ilog2_u64(len);  // table has nv variables; bottom layer has nv-1
     // level arrays: A_0 = v (view), A_k = A_{k-1}[lo] * A_{k-1}[hi]   (Layer::bottom :310-315, Layer::up :332-354)
-    std::vector<std::vector<std::vector<uint64_t>>> lev(nb);
+    std::vector<std::vector<std::vector<T>>> lev(nb);
     for (size_t b = 0; b < nb; b++) {
         lev[b].resize(nv);  // lev[b][0] unused (view of vs[b])
-        const uint64_t* prev = vs[b];
+        const T* prev = vs[b];
         size_t plen = len;
         for (size_t k = 1; k < nv; k++) {
             size_t h = plen >> 1;
             lev[b][k].resize(h);
-            uint64_t* out = lev[b][k].data();
+            T* out = lev[b][k].data();
 #pragma omp parallel for schedule(static) if (h > 4096)
-            for (long long i = 0; i < (long long)h; i++) out[i] = f_mul(prev[i], prev[i + h]);
+            for (long long i = 0; i < (long long)h; i++) out[i] = G::mul(prev[i], prev[i + h]);
             prev = out;
             plen = h;
         }
     }
-    auto level_ptr = [&](size_t b, size_t k) -> const uint64_t* { return k == 0 ? vs[b] : lev[b][k].data(); };
+    auto level_ptr = [&](size_t b, size_t k) -> const T* { return k == 0 ? vs[b] : lev[b][k].data(); };
     // root products (prover.rs:197-221): written, since claimed_v_0s are all None
     std::vector<E> claims(nb);
     for (size_t b = 0; b < nb; b++) {
-        const uint64_t* top = level_ptr(b, nv - 1);
-        claims[b] = e_from_f(f_mul(top[0], top[1]));
+        const T* top = level_ptr(b, nv - 1);
+        claims[b] = G::lift(G::mul(top[0], top[1]));
         tr.write_e(claims[b]);
     }
     std::vector<E> x;
@@ -281,22 +325,22 @@ static inline std::pair<std::vector<E>, std::vector<E>> prove_grand_product(
         if (n == 0) {
             x.clear();
             for (size_t b = 0; b < nb; b++) {
-                const uint64_t* a = level_ptr(b, k);
-                evals.push_back(e_from_f(a[0]));
-                evals.push_back(e_from_f(a[1]));
+                const T* a = level_ptr(b, k);
+                evals.push_back(G::lift(a[0]));
+                evals.push_back(G::lift(a[1]));
             }
         } else {
             E gamma = tr.squeeze();  // prover.rs:238
             ScFunc g{SC_GRANDPROD, n, powers_e(gamma, nb)};  // prover.rs:268-279
             E claim = e_zero();      // prover.rs:281-286
             for (size_t b = 0; b < nb; b++) claim = e_add(claim, e_mul(claims[b], g.pw[b]));
-            std::vector<ScTable> T;
+            std::vector<ScTable> Tb;
             for (size_t b = 0; b < nb; b++) {
-                const uint64_t* a = level_ptr(b, k);
-                T.push_back(ScTable::from_f(a, h));
-                T.push_back(ScTable::from_f(a + h, h));
+                const T* a = level_ptr(b, k);
+                Tb.push_back(G::table(a, h));
+                Tb.push_back(G::table(a + h, h));
             }
-            ScResult r = prove_sum_check(g, claim, std::move(T), tr, record);
+            ScResult r = prove_sum_check(g, claim, std::move(Tb), tr, record);
             x = r.point;
             evals = r.evals;
         }
@@ -358,38 +402,32 @@ struct LassoTrace {
     LassoPolys* polys_out = nullptr;
 };
 
-// lasso.rs:57-114
-static inline LassoClaim lasso_prove(const LassoPre& pre, const LassoNodeDef& node, const uint64_t* inputs,
-                                     TranscriptW& tr, LassoTrace* trace = nullptr) {
-    const size_t nu = node.nu, N = (size_t)1 << nu;
-    LassoPolys P = polynomialize(pre, nu, node.row_lookup, inputs);  // :64
-    // :77 assert inputs == lookup_outputs: RangeLookup::output is the identity (range.rs:230-232) -> holds
-    std::vector<E> r = tr.squeeze_n(nu);  // :85
-    // prove_collation_sum_check :254-288
-    E claimed_sum = lasso_sum_check_claim(pre, P, node.row_lookup, r);
-    tr.write_e(claimed_sum);  // :269
-    {
-        std::vector<E> pw(pre.num_memories);  // distribute_powers(poly(0..alpha), M)  range.rs:197-204
-        uint64_t c = 1;
-        for (size_t i = 0; i < pre.num_memories; i++) { pw[i] = e_from_f(c); c = f_mul(c, LASSO_M); }
-        ScFunc g{SC_COLLATION, nu, pw};
-        std::vector<ScTable> T;
-        for (size_t m = 0; m < pre.num_memories; m++) T.push_back(ScTable::from_f(P.e_polys[m].data(), N));
-        prove_sum_check(g, claimed_sum, std::move(T), tr, trace ? &trace->collation_sums : nullptr);  // :278-279, result dropped :97
-    }
-    E gamma_e = tr.squeeze(), tau_e = tr.squeeze();  // :99
-    uint64_t gamma = gamma_e.c0, tau = tau_e.c0;     // prover.rs:38-39 (base limb 0 only)
-    uint64_t gamma2 = f_mul(gamma, gamma);
-    auto hash = [&](uint64_t a, uint64_t v, uint64_t t) {  // prover.rs:44
-        return f_sub(f_add(f_add(a, f_mul(v, gamma)), f_mul(t, gamma2)), tau);
+// MemoryCheckingProver::new (prover.rs:35-89) + prove (prover.rs:158-181): multiset hashes of every memory in memory-GKR
+// order, then the two grand products. EXT = false is the reference (gamma, tau truncated to base limb 0, prover.rs:38-39:
+// base-field hash tables); EXT = true keeps them in E (ProtocolMode::ext_memcheck).
+// QUIRK reproduced (lasso.rs:317-319): read_ts / final_cts are indexed by the CHUNK index, not the memory index.
+template <bool EXT>
+static inline std::pair<std::vector<E>, std::vector<E>> lasso_memory_checking(const LassoPre& pre, const LassoPolys& P, E gamma_e, E tau_e,
+                                                                              TranscriptW& tr, LassoTrace* trace) {
+    typedef GpElem<EXT> G;
+    typedef typename G::T T;
+    const size_t N = (size_t)1 << P.nu;
+    T gamma, tau;
+    if constexpr (EXT) { gamma = gamma_e; tau = tau_e; }
+    else { gamma = e_limb0(gamma_e); tau = e_limb0(tau_e); }
+    const T gamma2 = G::mul(gamma, gamma);
+    // hash(a, v, t) = a + v*gamma + t*gamma^2 - tau (prover.rs:44) on small non-negative integers a, v, t
+    auto lift_u = [](uint64_t x) -> T { if constexpr (EXT) return e_from_f(f_from_u64(x)); else return f_from_u64(x); };
+    auto add = [](T a, T b) -> T { if constexpr (EXT) return e_add(a, b); else return f_add(a, b); };
+    auto sub = [](T a, T b) -> T { if constexpr (EXT) return e_sub(a, b); else return f_sub(a, b); };
+    auto hash = [&](uint64_t a, uint64_t v, uint64_t t) -> T {
+        return sub(add(add(lift_u(a), G::mul(lift_u(v), gamma)), G::mul(lift_u(t), gamma2)), tau);
     };
     auto chunks = lasso_chunks(pre);
-    std::vector<size_t> order;  // memory-GKR order
-    std::vector<size_t> chunk_of;
+    std::vector<size_t> order, chunk_of;  // memory-GKR order
     for (auto& ch : chunks) for (size_t m : ch.second) { order.push_back(m); chunk_of.push_back(ch.first); }
     const size_t A = order.size();
-    // MemoryCheckingProver::new prover.rs:35-89 (QUIRK lasso.rs:317-319: counters indexed by chunk index)
-    std::vector<std::vector<uint64_t>> init(A), rd(A), wr(A), fin(A);
+    std::vector<std::vector<T>> init(A), rd(A), wr(A), fin(A);
 #pragma omp parallel for schedule(dynamic, 1)
     for (long long ii = 0; ii < (long long)A; ii++) {
         size_t i = (size_t)ii, m = order[i], c = chunk_of[i];
@@ -401,32 +439,56 @@ static inline LassoClaim lasso_prove(const LassoPre& pre, const LassoNodeDef& no
         init[i].resize(LASSO_M); fin[i].resize(LASSO_M); rd[i].resize(N); wr[i].resize(N);
         for (size_t a = 0; a < LASSO_M; a++) {
             init[i][a] = hash(a, tab[a], 0);
-            fin[i][a] = hash(a, tab[a], f_from_u64(fct[a]));
+            fin[i][a] = hash(a, tab[a], fct[a]);
         }
         for (size_t j = 0; j < N; j++) {
-            uint64_t t = f_from_u64(rts[j]);
-            rd[i][j] = hash(dim[j], ep[j], t);
-            wr[i][j] = hash(dim[j], ep[j], f_add(t, 1));
+            rd[i][j] = hash(dim[j], ep[j], rts[j]);
+            wr[i][j] = hash(dim[j], ep[j], rts[j] + 1);
         }
     }
-    // prove() prover.rs:158-181
-    std::vector<const uint64_t*> v1, v2;
+    std::vector<const T*> v1, v2;
     for (size_t i = 0; i < A; i++) v1.push_back(rd[i].data());
     for (size_t i = 0; i < A; i++) v1.push_back(wr[i].data());
     for (size_t i = 0; i < A; i++) v2.push_back(init[i].data());
     for (size_t i = 0; i < A; i++) v2.push_back(fin[i].data());
-    auto g1 = prove_grand_product(v1, N, tr, trace ? &trace->gp1_sums : nullptr);
-    auto g2 = prove_grand_product(v2, LASSO_M, tr, trace ? &trace->gp2_sums : nullptr);
-    const std::vector<E>& x = g1.second;
-    const std::vector<E>& y = g2.second;
+    auto g1 = prove_grand_product<EXT>(v1, N, tr, trace ? &trace->gp1_sums : nullptr);
+    auto g2 = prove_grand_product<EXT>(v2, LASSO_M, tr, trace ? &trace->gp2_sums : nullptr);
+    return {g1.second, g2.second};
+}
+
+// lasso.rs:57-114
+static inline LassoClaim lasso_prove(const LassoPre& pre, const LassoNodeDef& node, const F* inputs,
+                                     TranscriptW& tr, LassoTrace* trace = nullptr) {
+    const size_t nu = node.nu, N = (size_t)1 << nu;
+    LassoPolys P = polynomialize(pre, nu, node.row_lookup, inputs);  // :64
+    // :77 assert inputs == lookup_outputs: RangeLookup::output is the identity (range.rs:230-232) -> holds
+    std::vector<E> r = tr.squeeze_n(nu);  // :85
+    // prove_collation_sum_check :254-288
+    E claimed_sum = lasso_sum_check_claim(pre, P, node.row_lookup, r);
+    tr.write_e(claimed_sum);  // :269
+    {
+        std::vector<E> pw(pre.num_memories);  // distribute_powers(poly(0..alpha), M)  range.rs:197-204
+        F c = f_one();
+        for (size_t i = 0; i < pre.num_memories; i++) { pw[i] = e_from_f(c); c = f_mul(c, f_from_u64(LASSO_M)); }
+        ScFunc g{SC_COLLATION, nu, pw};
+        std::vector<FTab> ft(pre.num_memories);
+        std::vector<ScTable> T;
+        for (size_t m = 0; m < pre.num_memories; m++) { ft[m] = ftab_from_u64(P.e_polys[m]); T.push_back(ScTable::from_f(ft[m].p(), N)); }
+        prove_sum_check(g, claimed_sum, std::move(T), tr, trace ? &trace->collation_sums : nullptr);  // :278-279, result dropped :97
+    }
+    E gamma_e = tr.squeeze(), tau_e = tr.squeeze();  // :99
+    auto xy = tr.mode.ext_memcheck ? lasso_memory_checking<true>(pre, P, gamma_e, tau_e, tr, trace)
+                                   : lasso_memory_checking<false>(pre, P, gamma_e, tau_e, tr, trace);
+    const std::vector<E>& x = xy.first;
+    const std::vector<E>& y = xy.second;
     {
         std::vector<E> eqx = eq_table(x), eqy = eq_table(y);
-        for (auto& ch : chunks) {  // prover.rs:173-178, mod.rs:80-93
+        for (auto& ch : lasso_chunks(pre)) {  // prover.rs:173-178, mod.rs:80-93
             size_t c = ch.first;
-            tr.write_e(dot_eq_f(eqx, P.dims[c].data(), N));
-            tr.write_e(dot_eq_f(eqx, P.read_cts[c].data(), N));
-            tr.write_e(dot_eq_f(eqy, P.final_cts[c].data(), LASSO_M));
-            for (size_t m : ch.second) tr.write_e(dot_eq_f(eqx, P.e_polys[m].data(), N));
+            tr.write_e(dot_eq_u64(eqx, P.dims[c].data(), N));
+            tr.write_e(dot_eq_u64(eqx, P.read_cts[c].data(), N));
+            tr.write_e(dot_eq_u64(eqy, P.final_cts[c].data(), LASSO_M));
+            for (size_t m : ch.second) tr.write_e(dot_eq_u64(eqx, P.e_polys[m].data(), N));
         }
     }
     if (trace && trace->polys_out) *trace->polys_out = std::move(P);
@@ -439,9 +501,11 @@ static inline LassoClaim lasso_verify(const LassoPre& pre, size_t nu, Transcript
     E claimed_sum = tr.read_e();
     verify_sum_check(2, nu, claimed_sum, tr);  // result ignored (lasso.rs:129-130)
     E gamma_e = tr.squeeze(), tau_e = tr.squeeze();
-    uint64_t gamma = gamma_e.c0, tau = tau_e.c0;
-    uint64_t gamma2 = f_mul(gamma, gamma);
-    auto hash = [&](E a, E v, E t) { return e_sub_f(e_add(e_add(a, e_mul_f(v, gamma)), e_mul_f(t, gamma2)), tau); };
+    // verifier.rs hashes with the same truncated gamma, tau as the prover unless ProtocolMode::ext_memcheck keeps them in E
+    const E gamma = tr.mode.ext_memcheck ? gamma_e : e_from_f(e_limb0(gamma_e));
+    const E tau = tr.mode.ext_memcheck ? tau_e : e_from_f(e_limb0(tau_e));
+    const E gamma2 = e_mul(gamma, gamma);
+    auto hash = [&](E a, E v, E t) { return e_sub(e_add(e_add(a, e_mul(v, gamma)), e_mul(t, gamma2)), tau); };
     auto chunks = lasso_chunks(pre);
     size_t A = pre.num_memories;
     auto rw = verify_grand_product(nu, 2 * A, tr);
@@ -453,11 +517,11 @@ static inline LassoClaim lasso_verify(const LassoPre& pre, size_t nu, Transcript
         E dim_x = tr.read_e(), rts_x = tr.read_e(), fct_y = tr.read_e();
         std::vector<E> e_xs = tr.read_es(nm);
         E id_y = e_zero();
-        for (size_t i = 0; i < y.size(); i++) id_y = e_add(id_y, e_mul_f(y[i], 1ull << i));
+        for (size_t i = 0; i < y.size(); i++) id_y = e_add(id_y, e_mul_f(y[i], f_from_u64(1ull << i)));
         for (size_t i = 0; i < nm; i++) {
             size_t m = ch.second[i];
             if (!e_eq(rw.first[off + i], hash(dim_x, e_xs[i], rts_x))) throw std::runtime_error("memory check: read hash mismatch");
-            if (!e_eq(rw.first[A + off + i], hash(dim_x, e_xs[i], e_add_f(rts_x, 1)))) throw std::runtime_error("memory check: write hash mismatch");
+            if (!e_eq(rw.first[A + off + i], hash(dim_x, e_xs[i], e_add(rts_x, e_one())))) throw std::runtime_error("memory check: write hash mismatch");
             E st_y = pre.subtables[pre.mem_subtable[m]].evaluate_mle(y);
             if (!e_eq(ifr.first[off + i], hash(id_y, st_y, e_zero()))) throw std::runtime_error("memory check: init hash mismatch");
             if (!e_eq(ifr.first[A + off + i], hash(id_y, st_y, fct_y))) throw std::runtime_error("memory check: final hash mismatch");
@@ -467,4 +531,4 @@ static inline LassoClaim lasso_verify(const LassoPre& pre, size_t nu, Transcript
     return LassoClaim{r, claimed_sum};
 }
 
-}  // namespace orc
+}  // namespace ORC_NS

@@ -1,12 +1,19 @@
 // ORACLE (test infrastructure): C entry points so that tests/, __graft_entry__.smoke() and
 // bench.py's cpu_baseline leg can drive the CPU restatement through ctypes. Nothing in the product
 // library (hyper-greco_amd/) includes, links or calls this file.
+//
+// Compiled twice into liboracle.so (oracle/Makefile): once over Goldilocks / GoldilocksExt2 (symbols orc_*) and once
+// with -DORC_FIELD_BN254 over bn256::Fr with E = F (symbols orcbn_*), see field.hpp. Field elements cross this surface
+// as canonical little-endian u64 limbs: F_LIMBS per base element (1 / 4), E_LIMBS per extension element (2 / 4).
+// Witness tables are always passed as Goldilocks residues of the small signed coefficients (the product's hg_witness
+// format); the Fr build lifts them to r - |z|.
+// `mode` arguments: bit 0 = absorbing transcript, bit 1 = extension-field memory checking (transcript.hpp ProtocolMode).
 #include <cstring>
 #include <string>
 #include <omp.h>
 #include "bfv.hpp"
 
-using namespace orc;
+using namespace ORC_NS;
 
 extern "C" {
 
@@ -27,73 +34,116 @@ static BfvParams to_params(const orc_params* p) {
     q.k0is.assign(p->k0is, p->k0is + p->k);
     return q;
 }
+static Values lift_table(const uint64_t* src, size_t n) {
+    Values v(n);
+#pragma omp parallel for schedule(static) if (n > 65536)
+    for (long long i = 0; i < (long long)n; i++) v[i] = f_from_signed_gl(src[i]);
+    return v;
+}
 static BfvInputs to_inputs(const BfvParams& q, const orc_inputs* in) {
     BfvInputs r;
     size_t SZ = (size_t)1 << q.log2_size(), PZ = (size_t)1 << q.n_log2();
-    r.s.assign(in->s, in->s + SZ); r.e.assign(in->e, in->e + SZ); r.k1.assign(in->k1, in->k1 + SZ);
+    r.s = lift_table(in->s, SZ); r.e = lift_table(in->e, SZ); r.k1 = lift_table(in->k1, SZ);
     for (size_t i = 0; i < q.k; i++) {
-        r.ais.push_back(Values(in->ais + i * SZ, in->ais + (i + 1) * SZ));
-        r.r1is.push_back(Values(in->r1is + i * SZ, in->r1is + (i + 1) * SZ));
+        r.ais.push_back(lift_table(in->ais + i * SZ, SZ));
+        r.r1is.push_back(lift_table(in->r1is + i * SZ, SZ));
     }
-    r.r2is.assign(in->r2is, in->r2is + q.k * PZ);
-    r.ct0is.assign(in->ct0is, in->ct0is + q.k * SZ);
+    r.r2is = lift_table(in->r2is, q.k * PZ);
+    r.ct0is = lift_table(in->ct0is, q.k * SZ);
     return r;
 }
 static void set_err(char* err, size_t cap, const std::string& s) {
     if (err && cap) { strncpy(err, s.c_str(), cap - 1); err[cap - 1] = 0; }
 }
+static ProtocolMode to_mode(int flags) {
+    ProtocolMode m;
+    m.absorb = (flags & 1) != 0;
+    m.ext_memcheck = (flags & 2) != 0;
+    return m;
+}
+static std::vector<E> load_es(const uint64_t* p, size_t n) {
+    std::vector<E> v(n);
+    for (size_t i = 0; i < n; i++) v[i] = e_load(p + i * E_LIMBS);
+    return v;
+}
+static void store_es(const std::vector<E>& v, uint64_t* p) {
+    for (size_t i = 0; i < v.size(); i++) e_store(v[i], p + i * E_LIMBS);
+}
+static std::vector<F> load_fs(const uint64_t* p, size_t n) {
+    std::vector<F> v(n);
+#pragma omp parallel for schedule(static) if (n > 65536)
+    for (long long i = 0; i < (long long)n; i++) v[i] = f_load(p + (size_t)i * F_LIMBS);
+    return v;
+}
 
 // ---- KAT helpers -------------------------------------------------------------------------------
-void orc_keccak256(const uint8_t* in, size_t len, uint8_t* out32) { keccak256(in, len, out32); }
-void orc_challenge_chain(size_t n, uint64_t* out) { ChallengeChain c; for (size_t i = 0; i < n; i++) out[i] = c.next_f(); }
-void orc_f_binop(int op, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out) {
-    for (size_t i = 0; i < n; i++) out[i] = op == 0 ? f_add(a[i], b[i]) : op == 1 ? f_sub(a[i], b[i]) : op == 2 ? f_mul(a[i], b[i]) : f_inv(a[i]);
-}
-void orc_e_binop(int op, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out) {
+#if ORC_F_IS_U64  // field-independent helpers: exported once
+void orc_keccak256(const uint8_t* in, size_t len, uint8_t* out32) { orc_keccak::keccak256(in, len, out32); }
+uint64_t orc_subtable_cutoff(uint64_t bound) { return Subtable{false, bound, ""}.cutoff(); }
+uint64_t orc_root_of_unity(size_t log2n) { return f_root_of_unity(log2n); }
+#endif
+size_t ORC_SYM(f_limbs)(void) { return F_LIMBS; }
+size_t ORC_SYM(e_limbs)(void) { return E_LIMBS; }
+// first n base-field challenges of a fresh (non-absorbing) transcript
+void ORC_SYM(challenge_chain)(size_t n, uint64_t* out) { FsState c; for (size_t i = 0; i < n; i++) f_store(c.squeeze_f(), out + i * F_LIMBS); }
+void ORC_SYM(f_binop)(int op, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out) {
     for (size_t i = 0; i < n; i++) {
-        E x{a[2 * i], a[2 * i + 1]}, y{b[2 * i], b[2 * i + 1]};
-        E r = op == 0 ? e_add(x, y) : op == 1 ? e_sub(x, y) : op == 2 ? e_mul(x, y) : e_inv(x);
-        out[2 * i] = r.c0; out[2 * i + 1] = r.c1;
+        F x = f_load(a + i * F_LIMBS), y = f_load(b + i * F_LIMBS);
+        F r = op == 0 ? f_add(x, y) : op == 1 ? f_sub(x, y) : op == 2 ? f_mul(x, y) : f_inv(x);
+        f_store(r, out + i * F_LIMBS);
     }
 }
-uint64_t orc_root_of_unity(size_t log2n) { return gl_root_of_unity(log2n); }
-void orc_ntt(const uint64_t* in, size_t log2n, int inverse, uint64_t* out) {
-    auto v = ntt(in, log2n, inverse != 0);
-    memcpy(out, v.data(), v.size() * 8);
+void ORC_SYM(e_binop)(int op, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out) {
+    for (size_t i = 0; i < n; i++) {
+        E x = e_load(a + i * E_LIMBS), y = e_load(b + i * E_LIMBS);
+        E r = op == 0 ? e_add(x, y) : op == 1 ? e_sub(x, y) : op == 2 ? e_mul(x, y) : e_inv(x);
+        e_store(r, out + i * E_LIMBS);
+    }
 }
-void orc_eq_table(const uint64_t* r, size_t n, uint64_t* out) {
-    std::vector<E> rr(n);
-    for (size_t i = 0; i < n; i++) rr[i] = E{r[2 * i], r[2 * i + 1]};
-    auto t = eq_table(rr);
-    memcpy(out, t.data(), t.size() * 16);
+// wire format round trip: writes n elements big-endian (transcript.rs:183-189), reads them back (:162-170); returns bytes written
+size_t ORC_SYM(wire_roundtrip)(size_t n, const uint64_t* in, uint8_t* bytes, uint64_t* back) {
+    TranscriptW w;
+    for (size_t i = 0; i < n; i++) w.write_f(f_load(in + i * F_LIMBS));
+    memcpy(bytes, w.stream.data(), w.stream.size());
+    TranscriptR r(w.stream.data(), w.stream.size());
+    for (size_t i = 0; i < n; i++) f_store(r.read_f(), back + i * F_LIMBS);
+    return w.stream.size();
 }
-void orc_mle_eval_f(const uint64_t* tab, size_t nvars, const uint64_t* pt, uint64_t* out2) {
-    std::vector<E> p(nvars);
-    for (size_t i = 0; i < nvars; i++) p[i] = E{pt[2 * i], pt[2 * i + 1]};
-    E v = mle_eval_f(tab, nvars, p.data());
-    out2[0] = v.c0; out2[1] = v.c1;
+void ORC_SYM(root_of_unity_limbs)(size_t log2n, uint64_t* out) { f_store(f_root_of_unity(log2n), out); }
+void ORC_SYM(ntt)(const uint64_t* in, size_t log2n, int inverse, uint64_t* out) {
+    std::vector<F> a = load_fs(in, (size_t)1 << log2n);
+    auto v = ntt(a.data(), log2n, inverse != 0);
+    for (size_t i = 0; i < v.size(); i++) f_store(v[i], out + i * F_LIMBS);
 }
-void orc_fft_table(const uint64_t* r, size_t L, int inverse, uint64_t* out) {
-    std::vector<E> rr(L);
-    for (size_t i = 0; i < L; i++) rr[i] = E{r[2 * i], r[2 * i + 1]};
-    auto t = fft_table(rr, L, inverse != 0);
-    memcpy(out, t.data(), t.size() * 16);
+void ORC_SYM(eq_table)(const uint64_t* r, size_t n, uint64_t* out) {
+    auto t = eq_table(load_es(r, n));
+    store_es(t, out);
+}
+void ORC_SYM(mle_eval_f)(const uint64_t* tab, size_t nvars, const uint64_t* pt, uint64_t* out) {
+    std::vector<F> t = load_fs(tab, (size_t)1 << nvars);
+    std::vector<E> p = load_es(pt, nvars);
+    e_store(mle_eval_f(t.data(), nvars, p.data()), out);
+}
+void ORC_SYM(fft_table)(const uint64_t* r, size_t L, int inverse, uint64_t* out) {
+    auto t = fft_table(load_es(r, L), L, inverse != 0);
+    store_es(t, out);
 }
 
 // range.rs:293-331 identities: dense MLE of the materialized subtable vs evaluate_mle closed form.
 // bound == 0 selects FullLimbSubtable. point: 16 E coordinates. Returns 1 if equal.
-int orc_subtable_mle_identity(uint64_t bound, const uint64_t* point, uint64_t* dense_out2, uint64_t* closed_out2) {
+int ORC_SYM(subtable_mle_identity)(uint64_t bound, const uint64_t* point, uint64_t* dense_out, uint64_t* closed_out) {
     Subtable s = bound ? Subtable{false, bound, "bound_" + std::to_string(bound)} : Subtable{true, 0, "full"};
-    std::vector<E> p(LASSO_LOGM);
-    for (size_t i = 0; i < LASSO_LOGM; i++) p[i] = E{point[2 * i], point[2 * i + 1]};
+    std::vector<E> p = load_es(point, LASSO_LOGM);
     auto tab = s.materialize();
-    E d = mle_eval_f(tab.data(), LASSO_LOGM, p.data());
+    std::vector<F> ft(tab.size());
+    for (size_t i = 0; i < tab.size(); i++) ft[i] = f_from_u64(tab[i]);
+    E d = mle_eval_f(ft.data(), LASSO_LOGM, p.data());
     E c = s.evaluate_mle(p);
-    dense_out2[0] = d.c0; dense_out2[1] = d.c1; closed_out2[0] = c.c0; closed_out2[1] = c.c1;
+    e_store(d, dense_out); e_store(c, closed_out);
     return e_eq(d, c) ? 1 : 0;
 }
-uint64_t orc_subtable_cutoff(uint64_t bound) { return Subtable{false, bound, ""}.cutoff(); }
 
+#if ORC_F_IS_U64
 // Lasso memory map as text: "subtable_id@dim,..." ; lookups as "range_x:bits:m0/m1/..;..."
 int orc_lasso_layout(const orc_params* p, char* out, size_t cap) {
     BfvParams q = to_params(p);
@@ -113,11 +163,12 @@ int orc_lasso_layout(const orc_params* p, char* out, size_t cap) {
     strcpy(out, s.c_str());
     return (int)s.size();
 }
+#endif
 
 // ---- circuit -----------------------------------------------------------------------------------
 // Evaluates the circuit; copies out the lasso node's input table (2^nu) and the `sum` node output (k*2^L).
-int orc_circuit_eval(const orc_params* p, const orc_inputs* in, uint64_t* lasso_in, size_t lasso_cap, uint64_t* sum_out,
-                     uint64_t* info /* [nu, num_nodes, rows] */, char* err, size_t errcap) {
+int ORC_SYM(circuit_eval)(const orc_params* p, const orc_inputs* in, uint64_t* lasso_in, size_t lasso_cap, uint64_t* sum_out,
+                          uint64_t* info /* [nu, num_nodes, rows] */, char* err, size_t errcap) {
     try {
         BfvParams q = to_params(p);
         BfvInputs bi = to_inputs(q, in);
@@ -127,20 +178,23 @@ int orc_circuit_eval(const orc_params* p, const orc_inputs* in, uint64_t* lasso_
         auto vals = circuit_evaluate(bc.c, bfv_input_list(q, bi));
         size_t lin = bc.c.preds[bc.lasso_id][0];
         if (info) { info[0] = bc.c.nodes[bc.lasso_id].lasso.nu; info[1] = bc.c.nodes.size(); info[2] = bc.c.nodes[bc.lasso_id].lasso.row_lookup.size(); }
-        if (lasso_in) { if (vals[lin].size() > lasso_cap) throw std::runtime_error("lasso_in buffer too small"); memcpy(lasso_in, vals[lin].data(), vals[lin].size() * 8); }
-        if (sum_out) memcpy(sum_out, vals[bc.sum_id].data(), vals[bc.sum_id].size() * 8);
+        if (lasso_in) {
+            if (vals[lin].size() > lasso_cap) throw std::runtime_error("lasso_in buffer too small");
+            for (size_t i = 0; i < vals[lin].size(); i++) f_store(vals[lin][i], lasso_in + i * F_LIMBS);
+        }
+        if (sum_out) for (size_t i = 0; i < vals[bc.sum_id].size(); i++) f_store(vals[bc.sum_id][i], sum_out + i * F_LIMBS);
         return 0;
     } catch (const std::exception& ex) { set_err(err, errcap, ex.what()); return -1; }
 }
 
-int orc_prove(const orc_params* p, const orc_inputs* in, int threads, uint8_t* proof, size_t cap, size_t* len,
-              double* timings_ms /* [witness, prove] */, char* err, size_t errcap) {
+int ORC_SYM(prove_mode)(const orc_params* p, const orc_inputs* in, int threads, int mode, uint8_t* proof, size_t cap, size_t* len,
+                        double* timings_ms /* [witness, prove] */, char* err, size_t errcap) {
     try {
         omp_set_num_threads(threads > 0 ? threads : 1);
         BfvParams q = to_params(p);
         BfvInputs bi = to_inputs(q, in);
         BfvProveTimings tm;
-        std::vector<uint8_t> pr = bfv_prove(q, bi, &tm);
+        std::vector<uint8_t> pr = bfv_prove(q, bi, &tm, to_mode(mode));
         if (timings_ms) { timings_ms[0] = tm.witness_ms; timings_ms[1] = tm.prove_ms; }
         *len = pr.size();
         if (pr.size() > cap) throw std::runtime_error("proof buffer too small");
@@ -148,22 +202,31 @@ int orc_prove(const orc_params* p, const orc_inputs* in, int threads, uint8_t* p
         return 0;
     } catch (const std::exception& ex) { set_err(err, errcap, ex.what()); return -1; }
 }
+int ORC_SYM(prove)(const orc_params* p, const orc_inputs* in, int threads, uint8_t* proof, size_t cap, size_t* len,
+                   double* timings_ms, char* err, size_t errcap) {
+    return ORC_SYM(prove_mode)(p, in, threads, 0, proof, cap, len, timings_ms, err, errcap);
+}
 
-int orc_verify(const orc_params* p, const orc_inputs* in, int threads, const uint8_t* proof, size_t len, char* err, size_t errcap) {
-    omp_set_num_threads(threads > 0 ? threads : 1);
-    BfvParams q = to_params(p);
-    BfvInputs bi = to_inputs(q, in);
-    std::string e;
-    bool ok = bfv_verify(q, bi, proof, len, &e);
-    if (!ok) set_err(err, errcap, e);
-    return ok ? 0 : -1;
+int ORC_SYM(verify_mode)(const orc_params* p, const orc_inputs* in, int threads, int mode, const uint8_t* proof, size_t len, char* err, size_t errcap) {
+    try {
+        omp_set_num_threads(threads > 0 ? threads : 1);
+        BfvParams q = to_params(p);
+        BfvInputs bi = to_inputs(q, in);
+        std::string e;
+        bool ok = bfv_verify(q, bi, proof, len, &e, to_mode(mode));
+        if (!ok) set_err(err, errcap, e);
+        return ok ? 0 : -1;
+    } catch (const std::exception& ex) { set_err(err, errcap, ex.what()); return -1; }
+}
+int ORC_SYM(verify)(const orc_params* p, const orc_inputs* in, int threads, const uint8_t* proof, size_t len, char* err, size_t errcap) {
+    return ORC_SYM(verify_mode)(p, in, threads, 0, proof, len, err, errcap);
 }
 
 // ---- node level: Lasso -------------------------------------------------------------------------
-// Proves the Lasso node alone on `lasso_in` (2^nu values) with a FRESH transcript (challenge chain
-// starts at H1). trace_* receive the raw per-round hypercube sums (t = 0,2[,3]) for kernel parity.
-int orc_lasso_prove(const orc_params* p, const uint64_t* lasso_in, int threads, uint8_t* proof, size_t cap, size_t* len,
-                    uint64_t* claim_out /* [nu*2 point | 2 value] */, char* err, size_t errcap) {
+// Proves the Lasso node alone on `lasso_in` (2^nu elements, F_LIMBS each); the transcript starts after `chain_skip` squeezed E
+// challenges (0 = fresh: the chain starts at H1).
+int ORC_SYM(lasso_prove_mode)(const orc_params* p, const uint64_t* lasso_in, int threads, int mode, size_t chain_skip, uint8_t* proof, size_t cap,
+                              size_t* len, uint64_t* claim_out /* [nu E point | E value] */, char* err, size_t errcap) {
     try {
         omp_set_num_threads(threads > 0 ? threads : 1);
         BfvParams q = to_params(p);
@@ -171,21 +234,25 @@ int orc_lasso_prove(const orc_params* p, const uint64_t* lasso_in, int threads, 
         bc.pre.reset(new LassoPre(bfv_setup(q)));
         bfv_configure(q, bc);
         const LassoNodeDef& d = bc.c.nodes[bc.lasso_id].lasso;
-        TranscriptW tr;
-        LassoClaim lc = lasso_prove(*bc.pre, d, lasso_in, tr);
+        std::vector<F> vin = load_fs(lasso_in, (size_t)1 << d.nu);
+        TranscriptW tr(to_mode(mode));
+        for (size_t i = 0; i < chain_skip; i++) tr.squeeze();
+        LassoClaim lc = lasso_prove(*bc.pre, d, vin.data(), tr);
         *len = tr.stream.size();
         if (tr.stream.size() > cap) throw std::runtime_error("proof buffer too small");
         memcpy(proof, tr.stream.data(), tr.stream.size());
-        if (claim_out) {
-            for (size_t i = 0; i < lc.r.size(); i++) { claim_out[2 * i] = lc.r[i].c0; claim_out[2 * i + 1] = lc.r[i].c1; }
-            claim_out[2 * lc.r.size()] = lc.value.c0; claim_out[2 * lc.r.size() + 1] = lc.value.c1;
-        }
+        if (claim_out) { store_es(lc.r, claim_out); e_store(lc.value, claim_out + lc.r.size() * E_LIMBS); }
         return 0;
     } catch (const std::exception& ex) { set_err(err, errcap, ex.what()); return -1; }
 }
+int ORC_SYM(lasso_prove)(const orc_params* p, const uint64_t* lasso_in, int threads, uint8_t* proof, size_t cap, size_t* len,
+                         uint64_t* claim_out, char* err, size_t errcap) {
+    return ORC_SYM(lasso_prove_mode)(p, lasso_in, threads, 0, 0, proof, cap, len, claim_out, err, errcap);
+}
 
+#if ORC_F_IS_U64
 // The integer tables of the Lasso node (lasso.rs:157-250 polynomialize): limb indices, counters and subtable values are
-// small non-negative integers, the same in every field - the BN254 oracle (oracle/bn254.py) starts from them.
+// small non-negative integers, the same in every field - the Python BN254 oracle (oracle/bn254.py) starts from them.
 // Call with dims == nullptr to query sizes. row_lookup[j] for j >= rows is 255. mem_cutoff: 65536 = full subtable.
 int orc_lasso_polys(const orc_params* p, const uint64_t* lasso_in, size_t* nu_out, size_t* a_out, size_t* rows_out, uint64_t* dims,
                     uint64_t* read_cts, uint64_t* final_cts, uint64_t* e_polys, uint8_t* row_lookup, int* mem_dim, uint64_t* mem_cutoff,
@@ -214,47 +281,73 @@ int orc_lasso_polys(const orc_params* p, const uint64_t* lasso_in, size_t* nu_ou
         return 0;
     } catch (const std::exception& ex) { set_err(err, errcap, ex.what()); return -1; }
 }
+#endif
 
-int orc_lasso_verify(const orc_params* p, const uint8_t* proof, size_t len, char* err, size_t errcap) {
+int ORC_SYM(lasso_verify_mode)(const orc_params* p, int mode, const uint8_t* proof, size_t len, char* err, size_t errcap) {
     try {
         BfvParams q = to_params(p);
         BfvCircuit bc;
         bc.pre.reset(new LassoPre(bfv_setup(q)));
         bfv_configure(q, bc);
-        TranscriptR tr(proof, len);
+        TranscriptR tr(proof, len, to_mode(mode));
         lasso_verify(*bc.pre, bc.c.nodes[bc.lasso_id].lasso.nu, tr);
         return 0;
     } catch (const std::exception& ex) { set_err(err, errcap, ex.what()); return -1; }
 }
+int ORC_SYM(lasso_verify)(const orc_params* p, const uint8_t* proof, size_t len, char* err, size_t errcap) {
+    return ORC_SYM(lasso_verify_mode)(p, 0, proof, len, err, errcap);
+}
 
 // ---- kernel level: one sum-check over caller-supplied tables -------------------------------------
 // kind: 0 collation, 1 grand product, 2 prodsum. tables: ntab pointers; is_base[i] says whether table i
-// holds 2^nv u64 base values or 2^nv (c0,c1) pairs. pw: powers (E) for kinds 0/1. The challenge chain
-// starts at position `chain_skip` (number of E challenges already consumed).
-int orc_sumcheck(int kind, size_t nv, size_t ntab, const uint64_t* const* tables, const int* is_base, const uint64_t* pw, size_t npw,
-                 const uint64_t* claim2, size_t chain_skip, int threads,
-                 uint64_t* msgs /* nv*(d+1)*2 */, uint64_t* point /* nv*2 */, uint64_t* evals /* ntab*2 */, uint64_t* sums /* nv*d*2 raw */) {
+// holds 2^nv base elements (F_LIMBS each) or 2^nv extension elements (E_LIMBS each). pw: powers (E) for kinds 0/1.
+// The challenge chain starts at position `chain_skip` (number of E challenges already consumed).
+int ORC_SYM(sumcheck)(int kind, size_t nv, size_t ntab, const uint64_t* const* tables, const int* is_base, const uint64_t* pw, size_t npw,
+                      const uint64_t* claim, size_t chain_skip, int threads,
+                      uint64_t* msgs /* nv*(d+1) E */, uint64_t* point /* nv E */, uint64_t* evals /* ntab E */, uint64_t* sums /* nv*d E raw */) {
     omp_set_num_threads(threads > 0 ? threads : 1);
-    ScFunc g{(ScKind)kind, nv, {}};
-    for (size_t i = 0; i < npw; i++) g.pw.push_back(E{pw[2 * i], pw[2 * i + 1]});
+    ScFunc g{(ScKind)kind, nv, load_es(pw, npw)};
     std::vector<ScTable> T;
+    std::vector<std::vector<F>> keep;
     size_t N = (size_t)1 << nv;
+    keep.reserve(ntab);
     for (size_t i = 0; i < ntab; i++) {
-        if (is_base[i]) T.push_back(ScTable::from_f(tables[i], N));
-        else { std::vector<E> v(N); memcpy(v.data(), tables[i], N * 16); T.push_back(ScTable::from_e(v)); }
+        if (is_base[i]) { keep.push_back(load_fs(tables[i], N)); T.push_back(ScTable::from_f(keep.back().data(), N)); }
+        else T.push_back(ScTable::from_e(load_es(tables[i], N)));
     }
     TranscriptW tr;
     for (size_t i = 0; i < chain_skip; i++) tr.squeeze();
     std::vector<E> rec;
-    ScResult r = prove_sum_check(g, E{claim2[0], claim2[1]}, std::move(T), tr, &rec);
+    ScResult r = prove_sum_check(g, e_load(claim), std::move(T), tr, &rec);
     int d = g.degree();
     // stream holds nv*(d+1) E elements big-endian; return them decoded
     TranscriptR rd(tr.stream.data(), tr.stream.size());
-    for (size_t i = 0; i < nv * (d + 1); i++) { E x = rd.read_e(); msgs[2 * i] = x.c0; msgs[2 * i + 1] = x.c1; }
-    for (size_t i = 0; i < nv; i++) { point[2 * i] = r.point[i].c0; point[2 * i + 1] = r.point[i].c1; }
-    for (size_t i = 0; i < ntab; i++) { evals[2 * i] = r.evals[i].c0; evals[2 * i + 1] = r.evals[i].c1; }
-    if (sums) for (size_t i = 0; i < rec.size(); i++) { sums[2 * i] = rec[i].c0; sums[2 * i + 1] = rec[i].c1; }
+    store_es(rd.read_es(nv * (d + 1)), msgs);
+    store_es(r.point, point);
+    store_es(r.evals, evals);
+    if (sums) store_es(rec, sums);
     return 0;
+}
+
+// = prove_grand_product (prover.rs:183-266) on nb caller-supplied base-field tables of len = 2^nv elements
+int ORC_SYM(grand_product)(size_t nb, size_t len, const uint64_t* const* tables, size_t chain_skip, int threads, uint8_t* proof, size_t cap,
+                           size_t* proof_len, uint64_t* claims /* nb E */, uint64_t* point /* nv E */, char* err, size_t errcap) {
+    try {
+        omp_set_num_threads(threads > 0 ? threads : 1);
+        std::vector<std::vector<F>> keep;
+        std::vector<const F*> vs;
+        keep.reserve(nb);
+        for (size_t b = 0; b < nb; b++) { keep.push_back(load_fs(tables[b], len)); vs.push_back(keep.back().data()); }
+        TranscriptW tr;
+        for (size_t i = 0; i < chain_skip; i++) tr.squeeze();
+        auto r = prove_grand_product<false>(vs, len, tr);
+        *proof_len = tr.stream.size();
+        if (tr.stream.size() > cap) throw std::runtime_error("proof buffer too small");
+        memcpy(proof, tr.stream.data(), tr.stream.size());
+        if (claims) store_es(r.first, claims);
+        if (point) store_es(r.second, point);
+        return 0;
+    } catch (const std::exception& ex) { set_err(err, errcap, ex.what()); return -1; }
 }
 
 }  // extern "C"

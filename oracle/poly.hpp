@@ -10,9 +10,9 @@
 #include <vector>
 #include <cstdint>
 #include <cstddef>
-#include "gl.hpp"
+#include "field.hpp"
 
-namespace orc {
+namespace ORC_NS {
 
 static inline std::vector<E> eq_table(const E* r, size_t n) {
     std::vector<E> t((size_t)1 << n);
@@ -30,24 +30,40 @@ static inline std::vector<E> eq_table(const E* r, size_t n) {
 }
 static inline std::vector<E> eq_table(const std::vector<E>& r) { return eq_table(r.data(), r.size()); }
 
-// sum_j eq[j] * tab[j]  (tab in base field), parallel over j
-static inline E dot_eq_f(const std::vector<E>& eq, const uint64_t* tab, size_t n) {
-    uint64_t s0 = 0, s1 = 0;
+// sum_j eq[j] * tab[j]  (tab in the base field), parallel over j
+static inline E dot_eq_f(const std::vector<E>& eq, const F* tab, size_t n) {
+    E total = e_zero();
 #pragma omp parallel
     {
-        uint64_t a0 = 0, a1 = 0;
+        E a = e_zero();
+#pragma omp for nowait
+        for (long long j = 0; j < (long long)n; j++) {
+            F v = tab[j];
+            if (!f_is_zero(v)) a = e_add(a, e_mul_f(eq[j], v));
+        }
+#pragma omp critical
+        total = e_add(total, a);
+    }
+    return total;
+}
+// the same for a table of small non-negative integers (limb indices, counters, subtable values)
+static inline E dot_eq_u64(const std::vector<E>& eq, const uint64_t* tab, size_t n) {
+    E total = e_zero();
+#pragma omp parallel
+    {
+        E a = e_zero();
 #pragma omp for nowait
         for (long long j = 0; j < (long long)n; j++) {
             uint64_t v = tab[j];
-            if (v) { a0 = f_add(a0, f_mul(eq[j].c0, v)); a1 = f_add(a1, f_mul(eq[j].c1, v)); }
+            if (v) a = e_add(a, e_mul_f(eq[j], f_from_u64(v)));
         }
 #pragma omp critical
-        { s0 = f_add(s0, a0); s1 = f_add(s1, a1); }
+        total = e_add(total, a);
     }
-    return E{s0, s1};
+    return total;
 }
 
-static inline E mle_eval_f(const uint64_t* tab, size_t nvars, const E* pt) {
+static inline E mle_eval_f(const F* tab, size_t nvars, const E* pt) {
     std::vector<E> eq = eq_table(pt, nvars);
     return dot_eq_f(eq, tab, (size_t)1 << nvars);
 }
@@ -64,4 +80,4 @@ static inline E horner(const std::vector<E>& c, E x) {
     return r;
 }
 
-}  // namespace orc
+}  // namespace ORC_NS

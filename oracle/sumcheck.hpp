@@ -28,22 +28,23 @@
 #include <stdexcept>
 #include <memory>
 #include <algorithm>
-#include "gl.hpp"
+#include "field.hpp"
 #include "poly.hpp"
 #include "transcript.hpp"
 
-namespace orc {
+namespace ORC_NS {
 
 enum ScKind { SC_COLLATION = 0, SC_GRANDPROD = 1, SC_PRODSUM = 2 };
 
 struct ScTable {
-    const uint64_t* fp = nullptr;  // base-field view (round 0), not owned
+    const F* fp = nullptr;         // base-field view (round 0), not owned
     const E* ep = nullptr;         // extension view (after the first fold, or from the start)
     std::unique_ptr<E[]> own[2];   // ping-pong storage for folded tables (uninitialised on allocation)
     int cur = 0;
     bool base = false;
     size_t n = 0;                  // current length
-    static ScTable from_f(const uint64_t* p, size_t n) { ScTable t; t.fp = p; t.base = true; t.n = n; return t; }
+    static ScTable from_f(const F* p, size_t n) { ScTable t; t.fp = p; t.base = true; t.n = n; return t; }
+    static ScTable view_e(const E* p, size_t n) { ScTable t; t.ep = p; t.n = n; return t; }  // not owned (first fold allocates)
     static ScTable from_e(const std::vector<E>& v) {
         ScTable t; t.n = v.size();
         t.own[0].reset(new E[v.size() ? v.size() : 1]);
@@ -51,7 +52,7 @@ struct ScTable {
         t.ep = t.own[0].get();
         return t;
     }
-    inline E at(size_t i) const { return base ? E{fp[i], 0} : ep[i]; }
+    inline E at(size_t i) const { return base ? e_from_f(fp[i]) : ep[i]; }
 };
 
 struct ScFunc {
@@ -70,7 +71,7 @@ static inline std::vector<E> powers_e(E b, size_t n) {
 
 // interpolate evaluations at t = 0..d (d = 2 or 3) to coefficients, low -> high
 static inline std::vector<E> interpolate(const std::vector<E>& ev) {
-    const uint64_t inv2 = f_inv(2), inv3 = f_inv(3), inv6 = f_inv(6);
+    static const F inv2 = f_inv(f_from_u64(2)), inv3 = f_inv(f_from_u64(3)), inv6 = f_inv(f_from_u64(6));
     size_t d = ev.size() - 1;
     if (d == 2) {
         E d2 = e_add(e_sub(ev[2], e_dbl(ev[1])), ev[0]);
@@ -105,21 +106,23 @@ static inline void sc_round_evals(const ScFunc& g, const std::vector<ScTable>& T
     {
         E a[4] = {e_zero(), e_zero(), e_zero(), e_zero()};
         std::vector<E> s0(BLK), s2(BLK), s3(BLK), q0(BLK), q2(BLK), q3(BLK);
+        std::vector<F> b0(BLK), b2(BLK);
 #pragma omp for nowait schedule(static)
         for (long long bb = 0; bb < (long long)nblk; bb++) {
             const size_t j0 = (size_t)bb * BLK, cnt = std::min(BLK, half - j0);
             for (size_t u = 0; u < cnt; u++) s0[u] = s2[u] = s3[u] = e_zero();
             if (g.kind == SC_COLLATION) {
+                if (all_base) for (size_t u = 0; u < cnt; u++) b0[u] = b2[u] = f_zero();
                 for (size_t i = 0; i < P; i++) {
-                    const uint64_t m = g.pw[i].c0;
+                    const F m = e_limb0(g.pw[i]);  // M^i is a base-field constant (range.rs:197-204)
                     if (all_base) {
-                        const uint64_t* p = T[i].fp + 2 * j0;
+                        const F* p = T[i].fp + 2 * j0;
                         for (size_t u = 0; u < cnt; u++) {
-                            uint64_t x = p[2 * u], y = p[2 * u + 1];
-                            uint64_t v2 = f_sub(f_add(y, y), x);
-                            if (i == 0) { q0[u] = E{x, 0}; q2[u] = E{v2, 0}; }
-                            s0[u].c0 = f_add(s0[u].c0, f_mul(m, x));
-                            s2[u].c0 = f_add(s2[u].c0, f_mul(m, v2));
+                            F x = p[2 * u], y = p[2 * u + 1];
+                            F v2 = f_sub(f_add(y, y), x);
+                            if (i == 0) { q0[u] = e_from_f(x); q2[u] = e_from_f(v2); }
+                            b0[u] = f_add(b0[u], f_mul(m, x));
+                            b2[u] = f_add(b2[u], f_mul(m, v2));
                         }
                     } else {
                         for (size_t u = 0; u < cnt; u++) {
@@ -131,19 +134,20 @@ static inline void sc_round_evals(const ScFunc& g, const std::vector<ScTable>& T
                         }
                     }
                 }
+                if (all_base) for (size_t u = 0; u < cnt; u++) { s0[u] = e_from_f(b0[u]); s2[u] = e_from_f(b2[u]); }
                 for (size_t u = 0; u < cnt; u++) { a[0] = e_add(a[0], e_mul(q0[u], s0[u])); a[2] = e_add(a[2], e_mul(q2[u], s2[u])); }
             } else if (g.kind == SC_GRANDPROD) {
                 for (size_t i = 0; i < P / 2; i++) {
                     const E gm = g.pw[i];
                     if (all_base) {
-                        const uint64_t* pl = T[2 * i].fp + 2 * j0;
-                        const uint64_t* pr = T[2 * i + 1].fp + 2 * j0;
+                        const F* pl = T[2 * i].fp + 2 * j0;
+                        const F* pr = T[2 * i + 1].fp + 2 * j0;
                         for (size_t u = 0; u < cnt; u++) {
-                            uint64_t xl = pl[2 * u], yl = pl[2 * u + 1], xr = pr[2 * u], yr = pr[2 * u + 1];
-                            uint64_t dl = f_sub(yl, xl), dr = f_sub(yr, xr);
-                            uint64_t l2 = f_add(yl, dl), r2 = f_add(yr, dr);
-                            uint64_t l3 = f_add(l2, dl), r3 = f_add(r2, dr);
-                            if (i == 0) { q0[u] = E{xl, 0}; q2[u] = E{l2, 0}; q3[u] = E{l3, 0}; }
+                            F xl = pl[2 * u], yl = pl[2 * u + 1], xr = pr[2 * u], yr = pr[2 * u + 1];
+                            F dl = f_sub(yl, xl), dr = f_sub(yr, xr);
+                            F l2 = f_add(yl, dl), r2 = f_add(yr, dr);
+                            F l3 = f_add(l2, dl), r3 = f_add(r2, dr);
+                            if (i == 0) { q0[u] = e_from_f(xl); q2[u] = e_from_f(l2); q3[u] = e_from_f(l3); }
                             s0[u] = e_add(s0[u], e_mul_f(gm, f_mul(xl, xr)));
                             s2[u] = e_add(s2[u], e_mul_f(gm, f_mul(l2, r2)));
                             s3[u] = e_add(s3[u], e_mul_f(gm, f_mul(l3, r3)));
@@ -177,8 +181,8 @@ static inline void sc_round_evals(const ScFunc& g, const std::vector<ScTable>& T
                         E xb = B.at(2 * j), yb = B.at(2 * j + 1);
                         E b2 = e_sub(e_dbl(yb), xb);
                         if (A.base) {
-                            uint64_t xa = A.fp[2 * j], ya = A.fp[2 * j + 1];
-                            uint64_t a2 = f_sub(f_add(ya, ya), xa);
+                            F xa = A.fp[2 * j], ya = A.fp[2 * j + 1];
+                            F a2 = f_sub(f_add(ya, ya), xa);
                             a[0] = e_add(a[0], e_mul_f(xb, xa));
                             a[2] = e_add(a[2], e_mul_f(b2, a2));
                         } else {
@@ -212,8 +216,8 @@ static inline void sc_fold(std::vector<ScTable>& T, E r) {
             E* o = t.own[dst].get();
             size_t j0 = (size_t)bb * BLK, j1 = std::min(half, j0 + BLK);
             if (t.base) {
-                const uint64_t* p = t.fp;
-                for (size_t j = j0; j < j1; j++) { uint64_t x = p[2 * j], y = p[2 * j + 1]; o[j] = e_add_f(e_mul_f(r, f_sub(y, x)), x); }
+                const F* p = t.fp;
+                for (size_t j = j0; j < j1; j++) { F x = p[2 * j], y = p[2 * j + 1]; o[j] = e_add_f(e_mul_f(r, f_sub(y, x)), x); }
             } else {
                 const E* p = t.ep;
                 for (size_t j = j0; j < j1; j++) { E x = p[2 * j], y = p[2 * j + 1]; o[j] = e_add(x, e_mul(r, e_sub(y, x))); }
@@ -274,4 +278,4 @@ static inline std::pair<E, std::vector<E>> verify_sum_check(int degree, size_t n
     return {claim, point};
 }
 
-}  // namespace orc
+}  // namespace ORC_NS

@@ -244,3 +244,141 @@ def lasso_polys(p, lasso_in):
                 final_cts=[fin[m * 65536:(m + 1) * 65536].tolist() for m in range(a)],
                 e_polys=[ep[m * N:(m + 1) * N].tolist() for m in range(a)],
                 row_lookup=rl.tolist(), mem_dim=md.tolist(), mem_cutoff=mc.tolist(), lookup_mems=lookup_mems)
+
+
+# ---- the C++ oracle over bn256::Fr (oracle/fr.hpp: symbols orcbn_*) and the protocol modes of both field builds -------------
+R_BN = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+MODE_ABSORB, MODE_EXT_MEMCHECK = 1, 2
+
+
+def _sym(field, name):
+    return getattr(lib(), ("orcbn_" if field == "bn254" else "orc_") + name)
+
+
+def limbs_of(field):
+    return (4, 4) if field == "bn254" else (1, 2)
+
+
+def to_limbs(vals, nl):
+    """Python integers -> canonical little-endian u64 limbs (nl per element)."""
+    a = np.zeros(len(vals) * nl, dtype=np.uint64)
+    for i, v in enumerate(vals):
+        for j in range(nl):
+            a[i * nl + j] = (int(v) >> (64 * j)) & 0xFFFFFFFFFFFFFFFF
+    return a
+
+
+def from_limbs(a, nl):
+    a = [int(x) for x in a]
+    return [sum(a[i * nl + j] << (64 * j) for j in range(nl)) for i in range(len(a) // nl)]
+
+
+def f_binop(field, op, a, b):
+    nl = limbs_of(field)[0]
+    out = np.zeros(len(a) * nl, dtype=np.uint64)
+    _sym(field, "f_binop")(op, C.c_size_t(len(a)), ptr(to_limbs(a, nl)), ptr(to_limbs(b, nl)), ptr(out))
+    return from_limbs(out, nl)
+
+
+def challenge_chain(field, n):
+    nl = limbs_of(field)[0]
+    out = np.zeros(n * nl, dtype=np.uint64)
+    _sym(field, "challenge_chain")(C.c_size_t(n), ptr(out))
+    return from_limbs(out, nl)
+
+
+def wire_roundtrip(field, vals):
+    nl = limbs_of(field)[0]
+    buf = (C.c_uint8 * (len(vals) * 8 * nl))()
+    back = np.zeros(len(vals) * nl, dtype=np.uint64)
+    f = _sym(field, "wire_roundtrip")
+    f.restype = C.c_size_t
+    n = f(C.c_size_t(len(vals)), ptr(to_limbs(vals, nl)), buf, ptr(back))
+    return bytes(buf[:n]), from_limbs(back, nl)
+
+
+def root_of_unity_f(field, log2n):
+    nl = limbs_of(field)[0]
+    out = np.zeros(nl, dtype=np.uint64)
+    _sym(field, "root_of_unity_limbs")(C.c_size_t(log2n), ptr(out))
+    return from_limbs(out, nl)[0]
+
+
+def prove_f(field, p, inp, threads=1, mode=0, cap=1 << 25):
+    """BfvEncrypt::prove of the C++ oracle over `field` ("goldilocks" | "bn254"); inp holds Goldilocks-form tables."""
+    buf = (C.c_uint8 * cap)()
+    ln = C.c_size_t(0)
+    tm = (C.c_double * 2)()
+    err = _err()
+    rc = _sym(field, "prove_mode")(C.byref(p.struct), C.byref(inp.struct), threads, mode, buf, C.c_size_t(cap), C.byref(ln), tm, err, C.c_size_t(512))
+    if rc != 0:
+        raise RuntimeError(err.value.decode())
+    return bytes(buf[:ln.value]), (tm[0], tm[1])
+
+
+def verify_f(field, p, inp, proof, threads=1, mode=0):
+    err = _err()
+    rc = _sym(field, "verify_mode")(C.byref(p.struct), C.byref(inp.struct), threads, mode, proof, C.c_size_t(len(proof)), err, C.c_size_t(512))
+    return rc == 0, err.value.decode()
+
+
+def lasso_prove_f(field, p, lasso_in_ints, threads=1, mode=0, chain_skip=0, cap=1 << 25):
+    """Lasso node of the C++ oracle over `field` on a table of Python integers / numpy u64 (2^nu entries)."""
+    fl, el = limbs_of(field)
+    nu = int(len(lasso_in_ints)).bit_length() - 1
+    lin = to_limbs(lasso_in_ints, fl) if fl > 1 else np.ascontiguousarray(lasso_in_ints, dtype=np.uint64)
+    buf = (C.c_uint8 * cap)()
+    ln = C.c_size_t(0)
+    claim = np.zeros((nu + 1) * el, dtype=np.uint64)
+    err = _err()
+    rc = _sym(field, "lasso_prove_mode")(C.byref(p.struct), ptr(lin), threads, mode, C.c_size_t(chain_skip), buf, C.c_size_t(cap), C.byref(ln), ptr(claim),
+                                        err, C.c_size_t(512))
+    if rc != 0:
+        raise RuntimeError(err.value.decode())
+    return bytes(buf[:ln.value]), from_limbs(claim, el) if field == "bn254" else claim
+
+
+def lasso_verify_f(field, p, proof, mode=0):
+    err = _err()
+    rc = _sym(field, "lasso_verify_mode")(C.byref(p.struct), mode, proof, C.c_size_t(len(proof)), err, C.c_size_t(512))
+    return rc == 0, err.value.decode()
+
+
+def grand_product_f(field, tabs, chain_skip=0, threads=1, cap=1 << 24):
+    """prove_grand_product of the C++ oracle on nb base-field tables (lists of Python ints); -> (proof bytes, claims, point)."""
+    fl, el = limbs_of(field)
+    nb, ln_ = len(tabs), len(tabs[0])
+    nv = ln_.bit_length() - 1
+    arrs = [to_limbs(t, fl) for t in tabs]
+    ptrs = (u64p * nb)(*[ptr(a) for a in arrs])
+    buf = (C.c_uint8 * cap)()
+    ln = C.c_size_t(0)
+    claims = np.zeros(nb * el, dtype=np.uint64)
+    point = np.zeros(nv * el, dtype=np.uint64)
+    err = _err()
+    rc = _sym(field, "grand_product")(C.c_size_t(nb), C.c_size_t(ln_), ptrs, C.c_size_t(chain_skip), threads, buf, C.c_size_t(cap), C.byref(ln),
+                                     ptr(claims), ptr(point), err, C.c_size_t(512))
+    if rc != 0:
+        raise RuntimeError(err.value.decode())
+    return bytes(buf[:ln.value]), from_limbs(claims, el), from_limbs(point, el)
+
+
+def gl_form(v):
+    """A small signed integer given as an Fr element (negatives as r - |z|) -> its Goldilocks residue (p - |z|)."""
+    v = int(v)
+    return v if v <= R_BN // 2 else P - (R_BN - v)
+
+
+def bn254_fixture_inputs(n=1024, k=1, bits=27):
+    """The reference's bn254 fixture laid out by get_inputs, as Goldilocks-form tables (what the C surface takes)."""
+    w = json.load(open(os.path.join(GOLDEN, f"bn254_sk_enc_{n}_{k}x{bits}_65537.json")))
+    conv = {}
+    for f in ("s", "e", "k1"):
+        conv[f] = [gl_form(x) for x in w[f]]
+    for f in ("ais", "r1is", "r2is", "ct0is"):
+        conv[f] = [[gl_form(x) for x in row] for row in w[f]]
+    return Inputs(layout_inputs(n, k, conv))
+
+
+def elems_be(proof, nbytes):
+    return [int.from_bytes(proof[i:i + nbytes], "big") for i in range(0, len(proof), nbytes)]

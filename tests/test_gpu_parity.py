@@ -119,9 +119,8 @@ def test_device_witness_generation_matches_host(ctx, n, k):
     assert (vals.node(ctx, pk.lasso_in_id) == lasso_in).all()
     assert (vals.node(ctx, pk.sum_id) == sum_out).all()
     assert (sum_out == w.arrays()["ct0is"]).all()
-    if n <= 4096:
-        o_lasso, o_sum, _ = orclib.circuit_eval(orclib.params(n, k), orclib.Inputs(w.arrays()))
-        assert (o_lasso == lasso_in).all() and (o_sum == sum_out).all()
+    o_lasso, o_sum, _ = orclib.circuit_eval(orclib.params(n, k), orclib.Inputs(w.arrays()))  # the oracle, at every size
+    assert (o_lasso == lasso_in).all() and (o_sum == sum_out).all()
     vals.free()
     pk.free()
 
@@ -511,6 +510,40 @@ def test_bn254_prove_synthetic_k2_accepted_by_the_oracle_verifier(ctx):
     assert G.verify(orclib.constants(n, k), inputs, ct0is, _elems(proof), chal, lambda e, c: verify_fn(e, c, layout))
     assert hg.verify_bn254(pk, w, proof) == (True, "")
     assert not hg.verify_bn254(pk, hg.Witness.synthetic(bfv.params, 78), proof)[0]   # another witness: input claims fail
+
+
+def _first_diff(a, b, nbytes=32):
+    if len(a) != len(b):
+        return "lengths %d / %d bytes" % (len(a), len(b))
+    for i in range(0, len(a), nbytes):
+        if a[i:i + nbytes] != b[i:i + nbytes]:
+            return "first differing element %d of %d" % (i // nbytes, len(a) // nbytes)
+    return "identical"
+
+
+@pytest.mark.parametrize("n,k", [(1024, 1), (2048, 1), (4096, 2), (8192, 4), (16384, 8), (32768, 16)])
+def test_bn254_prove_every_element_equals_the_cpp_oracle(ctx, n, k):
+    """hg_prove_bn254 against the C++ oracle compiled over bn256::Fr (oracle/fr.hpp, orcbn_prove): EVERY proof element, at every
+    built-in parameter set up to BASELINE config 5 (n=32768 k=16) - several claims per node, alpha combinations, k CRT
+    components. The oracle's verifier then accepts the bytes and rejects a flipped one.
+    [REF bfv-gkr/src/sk_encryption_circuit.rs:614-626: the bn254 test family]"""
+    bfv = hg.BfvEncrypt.new(n, k)
+    pk = bfv.setup(ctx)
+    w = hg.Witness.synthetic(bfv.params, 0x4752454330 + 5 + n)
+    proof, wms, pms = ctx.prove_bn254(pk, w, cap=1 << 25)
+    p = orclib.params(n, k)
+    inp = orclib.Inputs(w.arrays())
+    threads = min(64, os.cpu_count() or 8)
+    ref, tm = orclib.prove_f("bn254", p, inp, threads=threads)
+    print("bn254 n=%d k=%d: hg_prove_bn254 %.1f ms, oracle %.0f ms on %d threads, %d elements" % (n, k, pms, tm[1], threads, len(ref) // 32))
+    assert proof == ref, _first_diff(proof, ref)
+    ok, err = orclib.verify_f("bn254", p, inp, proof, threads=threads)
+    assert ok, err
+    bad = bytearray(proof)
+    bad[len(bad) // 2 + 31] ^= 1
+    assert not orclib.verify_f("bn254", p, inp, bytes(bad), threads=threads)[0]
+    assert hg.verify_bn254(pk, w, proof) == (True, "")
+    pk.free()
 
 
 def test_bn254_prove_config5_shape_accepted_by_the_host_verifier(ctx):

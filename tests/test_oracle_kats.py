@@ -394,3 +394,93 @@ def test_bn254_gkr_oracle_fft_and_circuit_pieces():
     Fi = G.fft_table(r, 4, True)
     assert sum(f * x for f, x in zip(Fi, a)) % G.R == G.mle_eval(G.ntt(a, True), r)
     assert G.lift_signed(5) == 5 and G.lift_signed(G.GL_P - 7) == G.R - 7
+
+
+# ---- the C++ oracle over bn256::Fr (oracle/fr.hpp) and the protocol modes (transcript.hpp ProtocolMode) -----------------------
+def test_fr_field_against_python_integers():
+    R = orclib.R_BN
+    rng = random.Random(11)
+    a = [rng.randrange(R) for _ in range(200)] + [0, 1, R - 1, R - 1, (1 << 253), (1 << 64) - 1]
+    b = [rng.randrange(R) for _ in range(200)] + [R - 1, R - 1, R - 1, 1, (1 << 253) + 5, (1 << 64) - 1]
+    assert orclib.f_binop("bn254", 0, a, b) == [(x + y) % R for x, y in zip(a, b)]
+    assert orclib.f_binop("bn254", 1, a, b) == [(x - y) % R for x, y in zip(a, b)]
+    assert orclib.f_binop("bn254", 2, a, b) == [(x * y) % R for x, y in zip(a, b)]
+    nz = [x for x in a if x][:20]
+    assert orclib.f_binop("bn254", 3, nz, nz) == [pow(x, -1, R) for x in nz]
+    # halo2curves bn256::Fr ROOT_OF_UNITY (S = 28): 7^((r-1)/2^28), of exact order 2^28
+    w = orclib.root_of_unity_f("bn254", 28)
+    assert w == pow(7, (R - 1) >> 28, R) == 0x03ddb9f5166d18b798865ea93dd31f743215cf6dd39329c8d34f1ed960c37c9c
+    assert pow(w, 1 << 27, R) == R - 1
+    assert orclib.root_of_unity_f("bn254", 11) == pow(w, 1 << 17, R)
+
+
+def test_fr_wire_format_and_challenge_chain():
+    R = orclib.R_BN
+    vals = [0, 1, R - 1, 0x0102030405060708090a0b0c0d0e0f101112131415161718191a1b1c1d1e1f20 % R]
+    by, back = orclib.wire_roundtrip("bn254", vals)
+    assert back == vals and by == b"".join(v.to_bytes(32, "big") for v in vals)   # transcript.rs:183-189: repr reversed to BE
+    by, back = orclib.wire_roundtrip("goldilocks", [5, P - 1])
+    assert by == (5).to_bytes(8, "big") + (P - 1).to_bytes(8, "big") and back == [5, P - 1]
+    # squeeze_challenge over Fr (transcript.rs:198-203): c_j = LE(Keccak^j("")) mod r; first value pinned in SURVEY 8(c)(5)
+    ch = orclib.challenge_chain("bn254", 8)
+    h, exp = b"", []
+    for _ in range(8):
+        h = orclib.keccak256(h)
+        exp.append(int.from_bytes(h, "little") % R)
+    assert ch == exp
+    assert ch[0] == 7173236656320612194178997223602979818891828541827642103715116037219761443523
+    assert orclib.challenge_chain("bn254", 8) == orclib.bn254().challenges(8, orclib.keccak256)
+
+
+def test_fr_oracle_reproduces_the_python_oracle_on_the_reference_bn254_fixture():
+    """orcbn_prove (C++ over Fr) on the reference's own bn254 witness: byte-identical to the Python-integer oracle's proof
+    (oracle/bn254_gkr.py, pinned by digest) - two independent restatements of the same protocol agree on all 2121 elements."""
+    import hashlib
+    p = orclib.params(1024, 1)
+    inp = orclib.bn254_fixture_inputs()
+    proof, _ = orclib.prove_f("bn254", p, inp, threads=4)
+    gold = json.load(open(os.path.join(orclib.GOLDEN, "oracle_proof_digests.json")))["bn254_1024_1"]
+    assert len(proof) == gold["bytes"] and hashlib.sha256(proof).hexdigest() == gold["sha256"]
+    ok, err = orclib.verify_f("bn254", p, inp, proof, threads=4)
+    assert ok, err
+    bad = bytearray(proof)
+    bad[len(bad) // 2] ^= 1
+    assert not orclib.verify_f("bn254", p, inp, bytes(bad), threads=4)[0]
+    # the same integer witness in its Goldilocks fixture proves to the same Fr transcript (the witness is field-independent)
+    proof_gl_fixture, _ = orclib.prove_f("bn254", p, orclib.fixture_inputs(1024, 1, 27), threads=4)
+    assert len(proof_gl_fixture) == len(proof)
+
+
+@pytest.mark.parametrize("field", ["goldilocks", "bn254"])
+def test_protocol_modes_round_trip_and_are_distinguished(field):
+    """f-4 modes of the oracle: absorbing transcript (bit 0) and extension-field memory checking (bit 1). Each mode's proof
+    verifies under that mode only; a flipped byte is rejected; mode 0 is the reference as it is."""
+    p = orclib.params(1024, 1)
+    inp = orclib.fixture_inputs(1024, 1, 27) if field == "goldilocks" else orclib.bn254_fixture_inputs()
+    base, _ = orclib.prove_f(field, p, inp, threads=4)
+    assert base == (orclib.prove(p, inp, threads=4)[0] if field == "goldilocks" else base)
+    for mode in (orclib.MODE_ABSORB, orclib.MODE_EXT_MEMCHECK, orclib.MODE_ABSORB | orclib.MODE_EXT_MEMCHECK):
+        proof, _ = orclib.prove_f(field, p, inp, threads=4, mode=mode)
+        assert len(proof) == len(base)
+        same_as_base = field == "bn254" and mode == orclib.MODE_EXT_MEMCHECK   # E = F over Fr: gamma, tau are never truncated
+        assert (proof == base) == same_as_base
+        ok, err = orclib.verify_f(field, p, inp, proof, threads=4, mode=mode)
+        assert ok, err
+        assert orclib.verify_f(field, p, inp, proof, threads=4, mode=0)[0] == same_as_base
+        bad = bytearray(proof)
+        bad[len(bad) // 3] ^= 2
+        assert not orclib.verify_f(field, p, inp, bytes(bad), threads=4, mode=mode)[0]
+
+
+def test_absorbing_transcript_depends_on_every_message():
+    """With ProtocolMode::absorb the challenge after a write is Keccak(previous hash || to_repr(message)) - the in-tree
+    plonkish-trait writer's rule (transcript.rs:205-208, 224-233) - so the Lasso node's proof changes with the point it enters at
+    and with its input; without it the challenges are the fixed chain."""
+    p = orclib.params(1024, 1)
+    lasso_in, _, _ = orclib.circuit_eval(p, orclib.fixture_inputs(1024, 1, 27))
+    a, _ = orclib.lasso_prove_f("goldilocks", p, lasso_in, threads=4, mode=orclib.MODE_ABSORB)
+    ok, err = orclib.lasso_verify_f("goldilocks", p, a, mode=orclib.MODE_ABSORB)
+    assert ok, err
+    assert not orclib.lasso_verify_f("goldilocks", p, a, mode=0)[0]
+    b, _ = orclib.lasso_prove_f("goldilocks", p, lasso_in, threads=4, mode=0)
+    assert a != b and b == orclib.lasso_prove(p, lasso_in, threads=4)[0]
