@@ -474,6 +474,18 @@ int hg_lasso_prove_at(hg_ctx* ctx, const hg_pk* pk, const uint64_t* lasso_in, si
     HG_CATCH(-1)
 }
 
+int hg_lasso_num_challenges(const hg_pk* pk, size_t* n_e) {
+    HG_TRY
+    if (!pk || !n_e) throw Error("hg_lasso_num_challenges: null argument");
+    // r: nu; collation rounds: nu; gamma, tau: 2; a grand product over 2^v entries: mu of layer 0, then per layer j = 1..v-1
+    // one batching challenge, j round challenges and mu (lasso.rs:85-111, prover.rs:183-266)
+    auto gp = [](size_t v) { size_t c = 1; for (size_t j = 1; j < v; j++) c += 2 + j; return c; };
+    const size_t nu = (size_t)pk->lasso.nu;
+    *n_e = nu + nu + 2 + gp(nu) + gp(16);
+    return 0;
+    HG_CATCH(-1)
+}
+
 int hg_sumcheck(hg_ctx* ctx, int kind, size_t nv, size_t ntab, const uint64_t* const* tables, const int* is_base, const uint64_t* pw,
                 size_t npw, const uint64_t* claim2, size_t chain_skip, uint64_t* msgs, uint64_t* point, uint64_t* evals, uint64_t* sums) {
     HG_TRY

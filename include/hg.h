@@ -137,6 +137,11 @@ int hg_lasso_prove(hg_ctx* ctx, const hg_pk* pk, const uint64_t* lasso_in, uint8
 int hg_lasso_prove_at(hg_ctx* ctx, const hg_pk* pk, const uint64_t* lasso_in, size_t chain_skip, uint8_t* proof, size_t cap,
                       size_t* len, uint64_t* claim_out);
 
+/* Number of E challenges the Lasso node squeezes (nu for r, nu collation rounds, gamma / tau, both grand products:
+ * SURVEY.md appendix C). A caller that replays the node's bytes into its own transcript (the Rust `impl Node` shim)
+ * advances its challenge position by this much. */
+int hg_lasso_num_challenges(const hg_pk* pk, size_t* n_e);
+
 /* = gkr::sum_check::prove_sum_check [REF call sites lasso.rs:278-279, prover.rs:242-252] on caller tables.
  *   kind: 0 collation g = p0*sum M^i p_i, 1 grand product g = p0*sum gam^i p_2i p_2i+1, 2 sum of pair products.
  *   tables[i]: host pointer, 2^nv u64 (is_base) or 2^nv (c0,c1) pairs. The challenge chain starts after
