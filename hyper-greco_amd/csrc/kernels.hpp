@@ -37,6 +37,21 @@ enum ScKind { SC_COLLATION = 0, SC_GRANDPROD = 1 };
 // transcript orders them. Because the challenges do not
 // depend on the prover's messages (transcript.rs:146-157), two consecutive rounds of an instance can also run
 // in ONE launch (st_step2): the intermediate folded tables then never touch HBM.
+// Grand product #1 without materialised hash tables: the first round of the top layer recomputes the multiset hashes
+// h = dim + E*gamma + ts*gamma^2 - tau (prover.rs:44; write hash = read hash + gamma^2) from the integer tables. The read pair
+// and the write pair of one memory share every input, and the memories of a chunk share dim / ts.
+struct GpHashMem {
+    const u64* ep;       // E_m (2^nu integers)
+    int chunk;           // dimension index: which dim / read_ts columns (the counters are indexed by chunk, lasso.rs:317-319)
+    int rd_row, wr_row;  // this job's pair indices of the memory's read / write tables (weight pw[row], tables 2 row, 2 row + 1); -1: not held
+};
+struct GpHashSrc {
+    const u64* dim[4];
+    const u64* ts[4];
+    const GpHashMem* mems;  // chunk-major (memory-GKR order)
+    int nmem;
+    u64 gamma, gamma2, tau;
+};
 struct StJob {
     const void* in;
     size_t in_stride;
@@ -46,6 +61,9 @@ struct StJob {
     int p0_only;       // grand product on a subset of the batch (multi-GPU): pair 0 only supplies p_0, its product is not summed
     size_t r_off;      // chain index of round 0's challenge
     size_t sums_slot;  // result slots: nv per round
+    const GpHashSrc* hash_src;  // first round reads these instead of `in` (st_first_hash); null otherwise
+    u64* next_level;   // grand product, first round on base-field rows: also emits the next product-tree level
+                       // (v_l[2j] v_r[2j], v_l[2j+1] v_r[2j+1] ARE the first-round products), row stride = in_stride; null: not emitted
     E2 pw[PW_MAX];     // gamma^i (grand product) or M^i (collation)
     E2 pwr[PW_MAX];    // gamma^i * r_0 (grand product: first-round fold of the left tables)
 };
@@ -67,6 +85,8 @@ int st_plan_blocks(StItem* items, int nitems, bool rounds2);
 // step: every item runs its job's round with half = 2^item.h_log2; `grid` from st_plan_blocks
 void st_step(hipStream_t st, int kind, bool base, const StJob* jobs, const StItem* items, int nitems, int grid, const E2* chal,
              E2* partials, E2* res);
+// first round of ONE grand-product job whose level-0 rows are recomputed from the Lasso integer tables (StJob::hash_src)
+void st_first_hash(hipStream_t st, const StJob* job, const StItem* item, int grid, const E2* chal, E2* partials, E2* res);
 // fused step (folded Ext2 inputs; grand-product or collation shape): every item runs its job's rounds with half = 2^h_log2 and 2^(h_log2-1)
 void st_step2(hipStream_t st, int kind, const StJob* jobs, const StItem* items, int nitems, int grid, const E2* chal, E2* partials, E2* res);
 // chunk step: every item runs `nrounds` consecutive rounds; workgroup k owns pair indices [k 2^c, (k+1) 2^c) of the

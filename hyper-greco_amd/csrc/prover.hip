@@ -1177,10 +1177,19 @@ struct Prover {
         claims[n.preds[0]].push_back(ClaimRef{s.point_off, L, v});
     }
 
+    // The Vanilla / FFT node reductions run on a second stream, concurrently with the Lasso node: they are independent on the
+    // device (claim points are challenges) and mostly small launches that leave CUs idle, while the Lasso node's critical
+    // path has its own latency-bound stretches (counter sorts, openings, last rounds). The fork point is recorded BEFORE the
+    // Lasso node is enqueued (record_fork, at the start of the walk); HG_ONE_STREAM=1 keeps everything on one stream.
+    bool fork_recorded = false;
+    void record_fork() {
+        static const bool one_stream = [] { const char* e = getenv("HG_ONE_STREAM"); return e && e[0] == '1'; }();
+        if (one_stream || world > 1) return;
+        hip_check(hipEventRecord(ctx->ev_fork, ctx->stream), "fork event");   // after the result-buffer clear / ticket reset
+        fork_recorded = true;
+    }
     void fork_nodes_stream() {
-        static const bool two_streams = [] { const char* e = getenv("HG_TWO_STREAMS"); return e && e[0] == '1'; }();
-        if (!two_streams) return;
-        hip_check(hipEventRecord(ctx->ev_fork, ctx->stream), "fork event");   // after the result-buffer clear / uploads
+        if (!fork_recorded) return;
         hip_check(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0), "fork wait");
         st = ctx->stream2; partials = ctx->d_partials2; ctx->prof_stream = st; forked = true;
     }
@@ -1195,6 +1204,7 @@ struct Prover {
         claims.assign(c.nodes.size(), {});
         claims[c.lasso_id].push_back(ClaimRef{epos(), 0, cell()});  // EvalClaim::new(vec![], E::ZERO) (:450)
         claims[c.sum_id].push_back(sum_claim);
+        record_fork();
         for (size_t q = c.topo.size(); q-- > 0;) {
             int id = c.topo[q];
             const HNode& n = c.nodes[id];
