@@ -125,6 +125,44 @@ __device__ __forceinline__ void store_e2_nt(E2* p, E2 v) {
     __builtin_nontemporal_store(v.c1, &p->c1);
 }
 
+// ---- first grand-product round of one table pair on base-field values ---------------------------------------------
+// Accumulates gamma^i * (P0, P1, Pinf) with P0 = xl xr, P1 = yl yr, Pinf = (yl - xl)(yr - xr) (each base product reduced once,
+// its two weighted copies unreduced), stores the folded left table multiplied by gamma^i and the folded right table, and -
+// when `nxt` is given - the next product-tree level: P0 and P1 ARE its entries 2j, 2j+1 (Layer::up, prover.rs:332-354).
+struct GpFirstAcc { WAcc a0, b0, a1, b1, ai, bi; };
+__device__ __forceinline__ GpFirstAcc gp_first_acc_zero() {
+    GpFirstAcc A;
+    A.a0 = wacc_zero(); A.b0 = wacc_zero(); A.a1 = wacc_zero(); A.b1 = wacc_zero(); A.ai = wacc_zero(); A.bi = wacc_zero();
+    return A;
+}
+__device__ __forceinline__ void gp_first_pair(GpFirstAcc& A, u64 xl, u64 yl, u64 xr, u64 yr, E2 gm, E2 gr, E2 r, bool summed,
+                                              E2* __restrict__ out_l, E2* __restrict__ out_r, u64* __restrict__ nxt) {
+    const u64 dl = gl_sub(yl, xl), dr = gl_sub(yr, xr);
+    if (summed || nxt) {
+        // (reading v_l v_r from the tree level above instead of multiplying was measured slower: the
+        // first round is bound by its 8-byte-element traffic, not by these products)
+        const u64 q0 = gl_mul(xl, xr), q1 = gl_mul(yl, yr);
+        if (nxt) *reinterpret_cast<ulonglong2*>(nxt) = make_ulonglong2(q0, q1);
+        if (summed) {
+            const u64 qi = gl_mul(dl, dr);
+            wmac2(A.a0, gm.c0, q0, A.b0, gm.c1, q0);
+            wmac2(A.a1, gm.c0, q1, A.b1, gm.c1, q1);
+            wmac2(A.ai, gm.c0, qi, A.bi, gm.c1, qi);
+        }
+    }
+    // gamma^i * (xl + r dl) = gamma^i xl + (gamma^i r) dl
+    WAcc f0 = wacc_zero(), f1 = wacc_zero(), h0 = wacc_zero(), h1 = wacc_zero();
+    wmac_pair(f0, gm.c0, xl, gr.c0, dl);
+    wmac_pair(f1, gm.c1, xl, gr.c1, dl);
+    store_e2_nt(out_l, e2(wreduce(f0), wreduce(f1)));
+    h0.L = xr;
+    wmac2(h0, r.c0, dr, h1, r.c1, dr);
+    store_e2_nt(out_r, e2(wreduce(h0), wreduce(h1)));
+}
+__device__ __forceinline__ void gp_first_acc_reduce(const GpFirstAcc& A, E2& s0, E2& s2, E2& s3) {
+    s0 = e2(wreduce(A.a0), wreduce(A.b0)); s2 = e2(wreduce(A.a1), wreduce(A.b1)); s3 = e2(wreduce(A.ai), wreduce(A.bi));
+}
+
 // ---- one sum-check round as a device function ---------------------------------------------------
 // Thread mapping inside a workgroup of BD threads: JB = 2^jb_log2 threads along the pair index j
 // (coalesced) times G = BD/JB groups along the table index i. Large rounds use JB = BD (one thread per
@@ -140,7 +178,7 @@ template <int KIND, typename T, bool FIRST>
 __device__ __forceinline__ void sc_round_body(const T* __restrict__ in, size_t in_stride, E2* __restrict__ out,
                                               size_t out_stride, int ntab, size_t half, E2 r, const E2* __restrict__ pw, const E2* __restrict__ pwr,
                                               int jb_log2, E2* __restrict__ red, E2* acc, size_t first_tile, size_t tile_step,
-                                              bool p0_only = false) {
+                                              bool p0_only = false, u64* __restrict__ next_level = nullptr) {
     using V = Val<T>;
     const int BD = blockDim.x, tid = threadIdx.x;
     const int G = BD >> jb_log2;
@@ -186,32 +224,16 @@ __device__ __forceinline__ void sc_round_body(const T* __restrict__ in, size_t i
             } else if constexpr (FIRST && std::is_same<T, u64>::value) {
                 // first round on base-field rows: sum_i gamma^i (xl xr) etc. with the Ext2 weight gamma^i = pw[i];
                 // each base product is reduced once, its two weighted copies accumulate unreduced.
-                WAcc a0 = wacc_zero(), b0 = wacc_zero(), a1 = wacc_zero(), b1 = wacc_zero(), ai = wacc_zero(), bi = wacc_zero();
+                GpFirstAcc A = gp_first_acc_zero();
                 for (int i = g; i < nb; i += G) {
                     u64 xl, yl, xr, yr;
                     load_xy<u64, true>(in + (size_t)(2 * i) * in_stride, j, half, xl, yl);
                     load_xy<u64, true>(in + (size_t)(2 * i + 1) * in_stride, j, half, xr, yr);
-                    u64 dl = gl_sub(yl, xl), dr = gl_sub(yr, xr);
-                    if (i == 0) { p0 = xl; p2 = gl_add(yl, dl); p3 = gl_add(p2, dl); }
-                    const E2 gm = pw[i], gr = pwr[i];
-                    if (!(p0_only && i == 0)) {
-                        // (reading v_l v_r from the tree level above instead of multiplying was measured slower: the
-                        // first round is bound by its 8-byte-element traffic, not by these products)
-                        u64 q0 = gl_mul(xl, xr), q1 = gl_mul(yl, yr), qi = gl_mul(dl, dr);
-                        wmac2(a0, gm.c0, q0, b0, gm.c1, q0);
-                        wmac2(a1, gm.c0, q1, b1, gm.c1, q1);
-                        wmac2(ai, gm.c0, qi, bi, gm.c1, qi);
-                    }
-                    // gamma^i * (xl + r dl) = gamma^i xl + (gamma^i r) dl
-                    WAcc f0 = wacc_zero(), f1 = wacc_zero(), h0 = wacc_zero(), h1 = wacc_zero();
-                    wmac_pair(f0, gm.c0, xl, gr.c0, dl);
-                    wmac_pair(f1, gm.c1, xl, gr.c1, dl);
-                    store_e2_nt(out + (size_t)(2 * i) * out_stride + jo, e2(wreduce(f0), wreduce(f1)));
-                    h0.L = xr;
-                    wmac2(h0, r.c0, dr, h1, r.c1, dr);
-                    store_e2_nt(out + (size_t)(2 * i + 1) * out_stride + jo, e2(wreduce(h0), wreduce(h1)));
+                    if (i == 0) { const u64 dl = gl_sub(yl, xl); p0 = xl; p2 = gl_add(yl, dl); p3 = gl_add(p2, dl); }
+                    gp_first_pair(A, xl, yl, xr, yr, pw[i], pwr[i], r, !(p0_only && i == 0), out + (size_t)(2 * i) * out_stride + jo,
+                                  out + (size_t)(2 * i + 1) * out_stride + jo, next_level ? next_level + (size_t)i * in_stride + 2 * j : nullptr);
                 }
-                s0 = e2(wreduce(a0), wreduce(b0)); s2 = e2(wreduce(a1), wreduce(b1)); s3 = e2(wreduce(ai), wreduce(bi));
+                gp_first_acc_reduce(A, s0, s2, s3);
             } else {
             for (int i = g; i < nb; i += G) {
                 T xl, yl, xr, yr;
@@ -463,7 +485,7 @@ __global__ __launch_bounds__(256) void k_st_step(const StJob* __restrict__ jobs,
     E2 acc[NV];
 #pragma unroll
     for (int t = 0; t < NV; t++) acc[t] = e2_zero();
-    if (rd == 0) sc_round_body<KIND, T, true>(reinterpret_cast<const T*>(in), in_stride, out, half, J.ntab, half, chal[J.r_off + rd], J.pw, J.pwr, jb_log2, red, acc, bx, nblocks, J.p0_only != 0);
+    if (rd == 0) sc_round_body<KIND, T, true>(reinterpret_cast<const T*>(in), in_stride, out, half, J.ntab, half, chal[J.r_off + rd], J.pw, J.pwr, jb_log2, red, acc, bx, nblocks, J.p0_only != 0, J.next_level);
     else sc_round_body<KIND, T, false>(reinterpret_cast<const T*>(in), in_stride, out, half, J.ntab, half, chal[J.r_off + rd], J.pw, J.pwr, jb_log2, red, acc, bx, nblocks, J.p0_only != 0);
     E2* part = partials + (size_t)y * SC_MAX_BLOCKS * NV;
     block_sum_multi<NV>(acc, sm);
@@ -476,6 +498,87 @@ __global__ __launch_bounds__(256) void k_st_step(const StJob* __restrict__ jobs,
     }
     if (nblocks > 1) finish_partials(part, NV, tickets_of(partials) + y * 32, res + J.sums_slot + (size_t)rd * NV, sm, nblocks);
 }
+// ---- first round of grand product #1's top layer straight from the Lasso integer tables ----------------------------------
+// The level-0 rows (the 2 alpha multiset-hash tables of 2^nu entries, 838 MB at n=32768 k=16) are never materialised: thread j
+// recomputes h = dim + E gamma + ts gamma^2 - tau at the four indices 2j, 2j+1, N/2 + 2j, N/2 + 2j+1 it needs (v_l, v_r are the
+// two halves of a row), once per MEMORY for its read pair and its write pair (write hash = read hash + gamma^2), with the
+// dim / ts part shared by the memories of a chunk. E, dim, ts are small integers (< 2^16, < 2^16, < 2^32): gl_mul_small.
+// It also emits product-tree level 1 (J.next_level), so no separate hash or level-1 pass exists.
+__global__ __launch_bounds__(256) void k_gp_first_hash(const StJob* __restrict__ job, const StItem* __restrict__ item,
+                                                       const E2* __restrict__ chal, E2* __restrict__ partials, E2* __restrict__ res) {
+    const StJob& J = *job;
+    const StItem& I = *item;
+    const GpHashSrc& H = *J.hash_src;
+    const int h_log2 = I.h_log2;
+    const size_t half = (size_t)1 << h_log2;      // pair indices j of this round; rows have 4 * half entries (v_l | v_r)
+    const size_t hN = half << 1;                  // N / 2: offset of v_r inside a row
+    const size_t ntiles = half >> 8;
+    const int nblocks = I.nblk, bx = (int)blockIdx.x;
+    E2* __restrict__ out = I.out;
+    const E2 r = chal[J.r_off];
+    const bool p0_only = J.p0_only != 0;
+    const u64 gamma = H.gamma, gamma2 = H.gamma2, tau = H.tau;
+    E2 acc[3] = {e2_zero(), e2_zero(), e2_zero()};
+    for (size_t tile = bx; tile < ntiles; tile += nblocks) {
+        const size_t j = (tile << 8) + threadIdx.x;
+        const size_t jo = dpos(j, half);
+        GpFirstAcc A = gp_first_acc_zero();
+        u64 p0 = 0, p2 = 0, p3 = 0;
+        int cur_chunk = -1;
+        u64 c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+        for (int m = 0; m < H.nmem; m++) {
+            const GpHashMem M = H.mems[m];
+            if (M.chunk != cur_chunk) {  // uniform: memories are listed chunk by chunk
+                cur_chunk = M.chunk;
+                const u64* __restrict__ dim = H.dim[cur_chunk];
+                const u64* __restrict__ ts = H.ts[cur_chunk];
+                const ulonglong2 dl = *reinterpret_cast<const ulonglong2*>(dim + 2 * j), dh = *reinterpret_cast<const ulonglong2*>(dim + hN + 2 * j);
+                const ulonglong2 tl = *reinterpret_cast<const ulonglong2*>(ts + 2 * j), th = *reinterpret_cast<const ulonglong2*>(ts + hN + 2 * j);
+                c0 = gl_sub(gl_add(dl.x, gl_mul_small(gamma2, (u32)tl.x)), tau); c1 = gl_sub(gl_add(dl.y, gl_mul_small(gamma2, (u32)tl.y)), tau);
+                c2 = gl_sub(gl_add(dh.x, gl_mul_small(gamma2, (u32)th.x)), tau); c3 = gl_sub(gl_add(dh.y, gl_mul_small(gamma2, (u32)th.y)), tau);
+            }
+            const ulonglong2 el = *reinterpret_cast<const ulonglong2*>(M.ep + 2 * j), eh = *reinterpret_cast<const ulonglong2*>(M.ep + hN + 2 * j);
+            u64 xl = gl_add(c0, gl_mul_small(gamma, (u32)el.x)), yl = gl_add(c1, gl_mul_small(gamma, (u32)el.y));
+            u64 xr = gl_add(c2, gl_mul_small(gamma, (u32)eh.x)), yr = gl_add(c3, gl_mul_small(gamma, (u32)eh.y));
+            if (M.rd_row >= 0) {
+                const int i = M.rd_row;
+                if (i == 0) { const u64 d = gl_sub(yl, xl); p0 = xl; p2 = gl_add(yl, d); p3 = gl_add(p2, d); }
+                gp_first_pair(A, xl, yl, xr, yr, J.pw[i], J.pwr[i], r, !(p0_only && i == 0), out + (size_t)(2 * i) * half + jo,
+                              out + (size_t)(2 * i + 1) * half + jo, J.next_level ? J.next_level + (size_t)i * hN + 2 * j : nullptr);
+            }
+            if (M.wr_row >= 0) {
+                const int i = M.wr_row;
+                xl = gl_add(xl, gamma2); yl = gl_add(yl, gamma2); xr = gl_add(xr, gamma2); yr = gl_add(yr, gamma2);  // t + 1
+                gp_first_pair(A, xl, yl, xr, yr, J.pw[i], J.pwr[i], r, true, out + (size_t)(2 * i) * half + jo,
+                              out + (size_t)(2 * i + 1) * half + jo, J.next_level ? J.next_level + (size_t)i * hN + 2 * j : nullptr);
+            }
+        }
+        E2 s0, s2, s3;
+        gp_first_acc_reduce(A, s0, s2, s3);
+        // (s0, s2, s3) = (sum P0, sum P1, sum Pinf): q(2) = 2 P1 - P0 + 2 Pinf, q(3) = 3 P1 - 2 P0 + 6 Pinf, times p(0), p(2), p(3)
+        const E2 P1x2 = e2_dbl(s2), Pix2 = e2_dbl(s3);
+        const E2 q2 = e2_add(e2_sub(P1x2, s0), Pix2);
+        const E2 q3 = e2_add(e2_sub(e2_add(P1x2, s2), e2_dbl(s0)), e2_add(e2_dbl(Pix2), Pix2));
+        acc[0] = e2_add(acc[0], e2_mul_f(s0, p0));
+        acc[1] = e2_add(acc[1], e2_mul_f(q2, p2));
+        acc[2] = e2_add(acc[2], e2_mul_f(q3, p3));
+    }
+    E2* sm = dyn_lds;
+    block_sum_multi<3>(acc, sm);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            if (nblocks == 1) res[J.sums_slot + t] = acc[t];
+            else part_store(partials + (size_t)bx * 3 + t, acc[t]);
+        }
+    }
+    if (nblocks > 1) finish_partials(partials, 3, tickets_of(partials), res + J.sums_slot, sm, nblocks);
+}
+static inline size_t sc_lds_bytes(int nv, int bd);
+void st_first_hash(hipStream_t st, const StJob* job, const StItem* item, int grid, const E2* chal, E2* partials, E2* res) {
+    k_gp_first_hash<<<grid, 256, sc_lds_bytes(0, 256), st>>>(job, item, chal, partials, res);
+}
+
 // ---- two grand-product rounds in one pass ------------------------------------------------------------------
 // Thread j (one per pair index of round t, jb = 8) does round t as in sc_round_body; the folded values T'[j] stay in
 // registers. Round t+1 pairs (T'[2j'], T'[2j'+1]) live in the two lanes 2j', 2j'+1 of a wave: they swap their

@@ -316,10 +316,15 @@ struct Prover {
     // Stride-layout sum-checks (collation, every grand-product layer) are queued as jobs and executed by
     // flush_stride() in a round-synchronised schedule (launch k = every job's next round(s)): they are independent on the device.
     std::vector<dev::StJob> st_jobs;
+    // Grand-product jobs whose FIRST round also produces a product-tree level (or reads recomputed hashes) must run one after
+    // the other, deepest layer first: job q with st_seq[q] = s > 0 gets its own first-round launch, in ascending s, before
+    // the shared first-round launch of everything else; `st_after_seq` then builds the remaining (small) tree levels.
+    std::vector<int> st_seq;
+    std::vector<std::function<void()>> st_after_seq;
     std::vector<dev::ScatterEnt> scatter;  // locally produced scalars -> global result slots (batch-subset grand products)
 
     ScHandle sc_stride(int kind, const void* in, bool base, size_t in_stride, int ntab, int nvars, const dev::Powers& pw, E2* final_out,
-                       bool enqueue = true, bool p0_only = false) {
+                       bool enqueue = true, bool p0_only = false, int seq = 0, u64* next_level = nullptr, const dev::GpHashSrc* hash_src = nullptr) {
         ScHandle h;
         h.nv = kind == dev::SC_GRANDPROD ? 3 : 2;
         h.nvars = nvars;
@@ -338,11 +343,12 @@ struct Prover {
         J.final_out = final_out ? final_out : ctx->alloc_n<E2>(ntab);
         J.kind = kind; J.ntab = ntab; J.nvars = nvars; J.base = base ? 1 : 0; J.p0_only = p0_only ? 1 : 0;
         J.r_off = h.point_off; J.sums_slot = h.sums_slot;
+        J.next_level = next_level; J.hash_src = hash_src;
         memcpy(J.pw, pw.v, sizeof(J.pw));
         for (int i = 0; i < nvars; i++) h.rs.push_back(squeeze());
         if (nvars > 0)  // weight * r_0: the first round stores the weighted fold (kernels.hip)
             for (int i = 0; i < dev::PW_MAX; i++) J.pwr[i] = e2_mul(pw.v[i], h.rs[0]);
-        if (nvars > 0) st_jobs.push_back(J);
+        if (nvars > 0) { st_jobs.push_back(J); st_seq.push_back(seq); }
         return h;
     }
 
@@ -353,7 +359,7 @@ struct Prover {
         // Folded tables ping-pong between the job's two buffers; the host tracks where each job's live tables are.
         static const bool fuse2 = [] { const char* e = getenv("HG_NO_FUSE2"); return !(e && e[0] == '1'); }();
         static const int fuse_min_h = [] { const char* e = getenv("HG_FUSE_MIN_H"); return e && *e ? atoi(e) : 13; }();
-        struct Launch { int kind; bool base; int h_log2; bool tail; int nrounds; std::vector<dev::StItem> items; };
+        struct Launch { int kind; bool base; int h_log2; bool tail; int nrounds; std::vector<dev::StItem> items; bool hash = false; bool after_seq = false; };
         std::vector<Launch> plan;
         std::vector<const void*> cur_in(nj);
         std::vector<size_t> cur_stride(nj);
@@ -370,12 +376,33 @@ struct Prover {
             int max_h = -1;
             for (auto& J : st_jobs) if (J.kind == kind) max_h = std::max(max_h, J.nvars - 1);
             if (max_h < 0) continue;
+            // sequenced first rounds (each produces the tree level the next one reads), then the remaining tree levels
+            if (kind == dev::SC_GRANDPROD) {
+                int max_seq = 0;
+                for (int q = 0; q < nj; q++) max_seq = std::max(max_seq, st_seq[q]);
+                for (int sq = 1; sq <= max_seq; sq++)
+                    for (int q = 0; q < nj; q++) {
+                        const dev::StJob& J = st_jobs[q];
+                        if (st_seq[q] != sq || J.kind != kind) continue;
+                        if (!J.base || next_h[q] <= H_SMALL) throw Error("sequenced first round on a job that has none");
+                        Launch ls{kind, true, -1, false, 1, {}};
+                        ls.hash = J.hash_src != nullptr;
+                        dev::StItem it;
+                        memset(&it, 0, sizeof(it));
+                        it.job = q; it.h_log2 = next_h[q]; it.in = cur_in[q]; it.in_stride = cur_stride[q]; it.out = J.buf[0];
+                        ls.items.push_back(it);
+                        cur_in[q] = it.out; cur_stride[q] = (size_t)1 << next_h[q];
+                        next_h[q]--;
+                        plan.push_back(ls);
+                    }
+                if (max_seq > 0 || !st_after_seq.empty()) { Launch la{kind, true, -1, false, 0, {}}; la.after_seq = true; plan.push_back(la); }
+            }
             // the first rounds on base-field rows only read finished tree levels / node tables: one launch for all of them
             {
                 Launch lall{kind, true, -1, false, 1, {}};
                 for (int q = 0; q < nj; q++) {
                     const dev::StJob& J = st_jobs[q];
-                    if (J.kind != kind || !J.base || next_h[q] <= H_SMALL) continue;
+                    if (J.kind != kind || !J.base || next_h[q] <= H_SMALL || next_h[q] != J.nvars - 1) continue;  // (sequenced jobs are past their first round)
                     dev::StItem it;
                     memset(&it, 0, sizeof(it));
                     it.job = q; it.h_log2 = next_h[q]; it.in = cur_in[q]; it.in_stride = cur_stride[q]; it.out = J.buf[0];
@@ -394,6 +421,7 @@ struct Prover {
                     const int h = next_h[q];
                     if (J.kind != kind || h <= H_SMALL) continue;
                     const bool first = J.nvars - 1 == h;
+                    if (first && J.hash_src) throw Error("hash-source job without a sequenced first round");
                     dev::StItem it;
                     memset(&it, 0, sizeof(it));
                     it.job = q; it.h_log2 = h; it.in = cur_in[q]; it.in_stride = cur_stride[q];
@@ -435,7 +463,7 @@ struct Prover {
         std::vector<std::vector<int>> grids(plan.size());
         for (size_t li = 0; li < plan.size(); li++) {
             Launch& L = plan[li];
-            if (!L.tail)
+            if (!L.tail && !L.after_seq)
                 for (size_t o = 0; o < L.items.size(); o += MAX_BATCH)
                     grids[li].push_back(dev::st_plan_blocks(L.items.data() + o, (int)std::min<size_t>(MAX_BATCH, L.items.size() - o), L.nrounds == 2));
             offs.push_back(flat.size());
@@ -449,9 +477,22 @@ struct Prover {
         };
         for (size_t li = 0; li < plan.size(); li++) {
             const Launch& L = plan[li];
+            if (L.after_seq) {
+                for (auto& f : st_after_seq) f();
+                st_after_seq.clear();
+                continue;
+            }
             for (size_t o = 0; o < L.items.size(); o += MAX_BATCH) {
                 const int cnt = (int)std::min<size_t>(MAX_BATCH, L.items.size() - o);
                 double bytes = 0;
+                if (L.hash) {
+                    const dev::StItem& it = L.items[o];
+                    bytes = round_bytes(st_jobs[it.job], 0);
+                    ctx->prof_begin(cls_gp_base, bytes);
+                    dev::st_first_hash(st, d_jobs + it.job, d_items + offs[li] + o, grids[li][0], ctx->d_chal, partials, d_res());
+                    ctx->prof_end();
+                    continue;
+                }
                 if (L.tail) {
                     int max_chunks = 1, max_ntab = 1;
                     for (int q = 0; q < cnt; q++) {
@@ -481,6 +522,9 @@ struct Prover {
             }
         }
         st_jobs.clear();
+        st_seq.clear();
+        for (auto& f : st_after_seq) f();  // (no grand-product job was queued: nothing can depend on these, but keep the order)
+        st_after_seq.clear();
         if (!scatter.empty()) {
             dev::ScatterEnt* d = ctx->alloc_n<dev::ScatterEnt>(scatter.size());
             hip_check(hipMemcpyAsync(d, stage(scatter.data(), scatter.size() * sizeof(dev::ScatterEnt)), scatter.size() * sizeof(dev::ScatterEnt),
@@ -726,53 +770,63 @@ struct Prover {
     // lev1 (optional): the first tree level, already produced by the hash kernel.
     // `local` (multi-GPU split by batch item): H holds only the rows of the global pairs listed in `local` (ascending);
     // with p0_only the first of them is pair 0, held only to supply p_0.
+    // `hash_src` (device pointer): level 0 is not materialised, the top layer's first round recomputes it (k_gp_first_hash).
+    // `emit` > 0: tree levels 1 .. emit are written by the first rounds of the top `emit` layers (their products ARE the next
+    // level), which therefore run one after the other before everything else; the remaining small levels follow them.
     GpOut grand_product(const u64* H, size_t len, int nb, const std::vector<int>& owner, const u64* lev1 = nullptr,
-                        const std::vector<int>* local = nullptr, bool p0_only = false) {
+                        const std::vector<int>* local = nullptr, bool p0_only = false, const dev::GpHashSrc* hash_src = nullptr, int emit = 0) {
         int nv = 0;
         while (((size_t)1 << nv) < len) nv++;
         const int nl = local ? (int)local->size() : nb;  // rows actually held
         std::vector<const u64*> lev(nv, nullptr);
         lev[0] = H;
         const int deepest = gp_deepest(nv, owner);
+        if (emit > 0) {
+            for (int n = 0; n < nv; n++) if (!mine(owner[n])) throw Error("grand product: level-emitting first rounds need every layer on this rank");
+            if (emit > nv - 1 || lev1) throw Error("grand product: bad emit depth");
+        } else if (hash_src) throw Error("grand product: recomputed level 0 needs emit >= 1");
         if (lev1 && nv > 1) lev[1] = lev1;
-        for (int k = (lev1 && nv > 1) ? 2 : 1; k <= deepest; k++) {  // Layer::bottom / Layer::up: w = v_l * v_r on the MSB split
-            const size_t in_len = len >> (k - 1);
-            if (in_len <= (size_t)dev::PROD_TAIL_LEN && in_len >= 2) {  // the remaining (small) levels in one launch
-                dev::ProdTailOut outs;
-                memset(&outs, 0, sizeof(outs));
-                int nlev = 0;
-                double bytes = 0;
-                for (int kk = k; kk <= deepest; kk++) {
-                    u64* o = ctx->alloc_n<u64>((size_t)nl * (len >> kk));
-                    outs.p[nlev++] = o; lev[kk] = o;
-                    bytes += (double)nl * (len >> (kk - 1)) * 8.0 * 1.5;
-                }
-                ctx->prof_begin(cls_tree, bytes);
-                if (nl > 0) dev::prod_tail(st, lev[k - 1], (int)in_len, outs, nlev, nl);
-                ctx->prof_end();
-                break;
-            }
-            u64* out = ctx->alloc_n<u64>((size_t)nl * (len >> k));
-            ctx->prof_begin(cls_tree, (double)nl * in_len * 8.0 * 1.5);
-            dev::prod_level(st, lev[k - 1], in_len, out, nl);
-            ctx->prof_end();
-            lev[k] = out;
-        }
+        // buffers of every level this rank needs (host-side bump allocation), then the launches that fill levels > emit
+        std::vector<u64*> lev_w(nv, nullptr);
+        for (int k = (lev1 && nv > 1) ? 2 : 1; k <= deepest; k++) { lev_w[k] = nl > 0 ? ctx->alloc_n<u64>((size_t)nl * (len >> k)) : nullptr; lev[k] = lev_w[k]; }
         size_t roots = slot(nb), ev0 = slot(2 * (size_t)nb);
-        if (mine(owner[0]) && nl > 0) {
-            if (!local) dev::gp_top(st, lev[nv - 1], nb, d_res() + roots, d_res() + ev0);
-            else {
-                E2* lr = ctx->alloc_n<E2>(nl);
-                E2* le = ctx->alloc_n<E2>(2 * (size_t)nl);
-                dev::gp_top(st, lev[nv - 1], nl, lr, le);
-                for (int li = p0_only ? 1 : 0; li < nl; li++) {
-                    int b = (*local)[li];
-                    scatter.push_back({lr + li, roots + (size_t)b});
-                    scatter.push_back({le + 2 * li, ev0 + 2 * (size_t)b});
-                    scatter.push_back({le + 2 * li + 1, ev0 + 2 * (size_t)b + 1});
+        E2* lr = nullptr;
+        E2* le = nullptr;
+        const bool top_mine = mine(owner[0]) && nl > 0;
+        if (top_mine && local) { lr = ctx->alloc_n<E2>(nl); le = ctx->alloc_n<E2>(2 * (size_t)nl); }
+        const int first_k = std::max((lev1 && nv > 1) ? 2 : 1, emit + 1);
+        auto build = [this, lev, lev_w, len, nl, nb, nv, deepest, first_k, roots, ev0, lr, le, top_mine, local]() {
+            for (int k = first_k; k <= deepest; k++) {  // Layer::bottom / Layer::up: w = v_l * v_r on the MSB split
+                const size_t in_len = len >> (k - 1);
+                if (in_len <= (size_t)dev::PROD_TAIL_LEN && in_len >= 2) {  // the remaining (small) levels in one launch
+                    dev::ProdTailOut outs;
+                    memset(&outs, 0, sizeof(outs));
+                    int nlev = 0;
+                    double bytes = 0;
+                    for (int kk = k; kk <= deepest; kk++) { outs.p[nlev++] = lev_w[kk]; bytes += (double)nl * (len >> (kk - 1)) * 8.0 * 1.5; }
+                    ctx->prof_begin(cls_tree, bytes);
+                    if (nl > 0) dev::prod_tail(st, lev[k - 1], (int)in_len, outs, nlev, nl);
+                    ctx->prof_end();
+                    break;
                 }
+                ctx->prof_begin(cls_tree, (double)nl * in_len * 8.0 * 1.5);
+                if (nl > 0) dev::prod_level(st, lev[k - 1], in_len, lev_w[k], nl);
+                ctx->prof_end();
             }
-        }
+            if (top_mine) {
+                if (!local) dev::gp_top(st, lev[nv - 1], nb, d_res() + roots, d_res() + ev0);
+                else dev::gp_top(st, lev[nv - 1], nl, lr, le);
+            }
+        };
+        if (emit > 0) st_after_seq.push_back(build);
+        else build();
+        if (top_mine && local)
+            for (int li = p0_only ? 1 : 0; li < nl; li++) {
+                int b = (*local)[li];
+                scatter.push_back({lr + li, roots + (size_t)b});
+                scatter.push_back({le + 2 * li, ev0 + 2 * (size_t)b});
+                scatter.push_back({le + 2 * li + 1, ev0 + 2 * (size_t)b + 1});
+            }
         auto claims = std::make_shared<std::vector<E2>>(nb);
         mark("grand product: " + std::to_string(nb) + " root products (prover.rs:197-221)");
         ops.push_back([this, roots, nb, claims] {  // root products (prover.rs:197-221)
@@ -807,14 +861,17 @@ struct Prover {
             });
             size_t evals = slot(2 * (size_t)nb);
             ScHandle sc;
-            if (!local) sc = sc_stride(dev::SC_GRANDPROD, lev[k], true, h, 2 * nb, n, pw, d_res() + evals, mine(owner[n]));
+            const int seq = n >= nv - emit ? nv - n : 0;                    // first round launched alone, deepest layer first
+            u64* nxt = seq ? lev_w[k + 1] : nullptr;                          // ... and writes tree level k + 1
+            const dev::GpHashSrc* hs = (hash_src && k == 0) ? hash_src : nullptr;
+            if (!local) sc = sc_stride(dev::SC_GRANDPROD, lev[k], true, h, 2 * nb, n, pw, d_res() + evals, mine(owner[n]), false, seq, nxt, hs);
             else {
                 // this rank's share of the batch: local pair li is global pair b = local[li], weight gamma^b
                 dev::Powers pwl;
                 memset(&pwl, 0, sizeof(pwl));
                 for (int li = 0; li < nl; li++) pwl.v[li] = pw.v[(*local)[li]];
                 E2* fin = nl ? ctx->alloc_n<E2>(2 * (size_t)nl) : nullptr;
-                sc = sc_stride(dev::SC_GRANDPROD, lev[k], true, h, 2 * nl, n, pwl, fin, mine(owner[n]) && nl > (p0_only ? 1 : 0), p0_only);
+                sc = sc_stride(dev::SC_GRANDPROD, lev[k], true, h, 2 * nl, n, pwl, fin, mine(owner[n]) && nl > (p0_only ? 1 : 0), p0_only, seq, nxt, hs);
                 if (mine(owner[n]))
                     for (int li = p0_only ? 1 : 0; li < nl; li++) {
                         int b = (*local)[li];
@@ -918,14 +975,49 @@ struct Prover {
             }
         }
         const int nrows = split ? (int)local_pairs.size() : 2 * G;
-        u64* H1 = any_gp1 ? ctx->alloc_n<u64>((size_t)nrows * N) : nullptr;
-        u64* L1 = (any_gp1 && gp_deepest(nu, gp1_owner) >= 1) ? ctx->alloc_n<u64>((size_t)nrows * (N / 2)) : nullptr;
+        // Grand product #1 without hash tables: the top layer's first round recomputes the hashes from dims / read_ts / E and
+        // writes tree level 1, the next layers' first rounds write levels 2 .. emit (HG_NO_HASH_FUSE=1: materialise them).
+        static const bool hash_fuse = [] { const char* e = getenv("HG_NO_HASH_FUSE"); return !(e && e[0] == '1'); }();
+        static const int emit_max = [] { const char* e = getenv("HG_GP_EMIT"); return e && *e ? atoi(e) : 4; }();
+        bool all_gp1 = any_gp1;
+        for (int n = 0; n < nu; n++) all_gp1 = all_gp1 && mine(gp1_owner[n]);
+        int emit = 0;
+        if (hash_fuse && all_gp1 && nu >= 12 && nrows > (p0_only ? 1 : 0))
+            for (int n = nu - 1; n >= 12 && emit < emit_max; n--) emit++;   // layers with 2^n >= 4096 entries per table
+        const dev::GpHashSrc* d_hash_src = nullptr;
+        if (emit > 0) {
+            std::vector<dev::GpHashMem> hm;
+            auto row_of = [&](int pair) -> int {
+                if (!split) return pair;
+                for (size_t q = 0; q < local_pairs.size(); q++) if (local_pairs[q] == pair) return (int)q;
+                return -1;
+            };
+            for (int i = 0; i < G; i++) {  // memory-GKR order is chunk-major
+                dev::GpHashMem m;
+                m.ep = ep + (size_t)lp.gkr_order[i] * N; m.chunk = lp.gkr_chunk[i]; m.rd_row = row_of(i); m.wr_row = row_of(G + i);
+                if (m.rd_row >= 0 || m.wr_row >= 0) hm.push_back(m);
+            }
+            dev::GpHashSrc hs;
+            memset(&hs, 0, sizeof(hs));
+            for (int c = 0; c < 4; c++) { hs.dim[c] = dims + (size_t)c * N; hs.ts[c] = read_ts.count(c) ? read_ts[c] : nullptr; }
+            for (auto& m : hm) if (!hs.ts[m.chunk]) throw Error("lasso: counters of a needed chunk were not computed");
+            dev::GpHashMem* d_hm = ctx->alloc_n<dev::GpHashMem>(hm.size());
+            hip_check(hipMemcpyAsync(d_hm, stage(hm.data(), hm.size() * sizeof(dev::GpHashMem)), hm.size() * sizeof(dev::GpHashMem), hipMemcpyHostToDevice, st), "upload hash sources");
+            hs.mems = d_hm; hs.nmem = (int)hm.size(); hs.gamma = gamma; hs.gamma2 = gl_mul(gamma, gamma); hs.tau = tau;
+            dev::GpHashSrc* d_hs = ctx->alloc_n<dev::GpHashSrc>(1);
+            hip_check(hipMemcpyAsync(d_hs, stage(&hs, sizeof(hs)), sizeof(hs), hipMemcpyHostToDevice, st), "upload hash sources");
+            d_hash_src = d_hs;
+        }
+        u64* H1 = (any_gp1 && !emit) ? ctx->alloc_n<u64>((size_t)nrows * N) : nullptr;
+        u64* L1 = (any_gp1 && !emit && gp_deepest(nu, gp1_owner) >= 1) ? ctx->alloc_n<u64>((size_t)nrows * (N / 2)) : nullptr;
         u64* H2 = do_gp2 ? ctx->alloc_n<u64>((size_t)2 * G * M) : nullptr;
         // hash launches are grouped by chunk: the memories of a chunk share the dim / read_ts columns
         struct HashReq { int i; u64 *rd, *wr, *rd1, *wr1; };
         std::vector<HashReq> reqs;
         auto hash_rw = [&](int i, u64* rd, u64* wr, u64* rd1, u64* wr1) { reqs.push_back({i, rd, wr, rd1, wr1}); };
-        if (any_gp1 && !split) {
+        if (emit > 0) {
+            // nothing to hash here
+        } else if (any_gp1 && !split) {
             for (int i = 0; i < G; i++)
                 hash_rw(i, H1 + (size_t)i * N, H1 + (size_t)(G + i) * N, L1 ? L1 + (size_t)i * (N / 2) : nullptr, L1 ? L1 + (size_t)(G + i) * (N / 2) : nullptr);
         } else if (any_gp1) {
@@ -964,8 +1056,8 @@ struct Prover {
             ctx->prof_end();
         }
         mark("lasso: memory checking, grand product #1 over reads then writes (prover.rs:161-165)");
-        GpOut g1 = split ? grand_product(H1, N, 2 * G, gp1_owner, L1, &local_pairs, p0_only)
-                         : grand_product(H1, N, 2 * G, gp1_owner, L1);  // reads then writes (prover.rs:161-165)
+        GpOut g1 = split ? grand_product(H1, N, 2 * G, gp1_owner, L1, &local_pairs, p0_only, d_hash_src, emit)
+                         : grand_product(H1, N, 2 * G, gp1_owner, L1, nullptr, false, d_hash_src, emit);  // reads then writes (prover.rs:161-165)
         mark("lasso: memory checking, grand product #2 over inits then finals (prover.rs:167-171)");
         GpOut g2 = grand_product(H2, M, 2 * G, std::vector<int>(16, own_gp2));      // inits then finals (prover.rs:167-171)
         // openings (prover.rs:173-178, mod.rs:80-93)
