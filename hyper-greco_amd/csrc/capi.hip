@@ -88,6 +88,7 @@ hg_ctx* hg_create(int device_id) {
     hip_check(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking), "hipStreamCreate");
     hip_check(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming), "hipEventCreate");
     hip_check(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming), "hipEventCreate");
+    for (auto& e : c->ev_aux) hip_check(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
     c->prof_stream = c->stream;
     c->res_cap = (size_t)1 << 17;
     hip_check(hipHostMalloc((void**)&c->h_res, c->res_cap * sizeof(E2), hipHostMallocDefault), "hipHostMalloc(results)");

@@ -119,6 +119,7 @@ hg_ctx::~hg_ctx() {
     if (stream2) { (void)hipStreamSynchronize(stream2); (void)hipStreamDestroy(stream2); }
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
+    for (auto e : ev_aux) if (e) (void)hipEventDestroy(e);
     for (auto e : event_pool) (void)hipEventDestroy(e);
     if (stream) (void)hipStreamDestroy(stream);
 }
@@ -477,6 +478,7 @@ struct Prover {
         };
         for (size_t li = 0; li < plan.size(); li++) {
             const Launch& L = plan[li];
+            if (L.kind == dev::SC_GRANDPROD && st_before_gp) { st_before_gp(); st_before_gp = nullptr; }
             if (L.after_seq) {
                 for (auto& f : st_after_seq) f();
                 st_after_seq.clear();
@@ -521,6 +523,7 @@ struct Prover {
                 }
             }
         }
+        if (st_before_gp) { st_before_gp(); st_before_gp = nullptr; }
         st_jobs.clear();
         st_seq.clear();
         for (auto& f : st_after_seq) f();  // (no grand-product job was queued: nothing can depend on these, but keep the order)
@@ -910,6 +913,7 @@ struct Prover {
             ctx->prof_begin(cls_aux, (double)N * 8 * (1 + 4 + A));
             dev::lasso_split(st, L, d_input, dims, ep);
             ctx->prof_end();
+            if (fork_recorded) hip_check(hipEventRecord(ctx->ev_aux[0], st), "lasso: split event");
         }
         // r, claimed sum (lasso.rs:85, 264-269)
         size_t r_off = epos();
@@ -951,6 +955,21 @@ struct Prover {
             for (int i : local_mems) local_pairs.push_back(i);
             for (int i : local_mems) local_pairs.push_back(G + i);
         }
+        const int nrows = split ? (int)local_pairs.size() : 2 * G;
+        // Grand product #1 without hash tables: the top layer's first round recomputes the hashes from dims / read_ts / E and
+        // writes tree level 1, the next layers' first rounds write levels 2 .. emit (HG_NO_HASH_FUSE=1: materialise them).
+        static const bool hash_fuse = [] { const char* e = getenv("HG_NO_HASH_FUSE"); return !(e && e[0] == '1'); }();
+        static const int emit_max = [] { const char* e = getenv("HG_GP_EMIT"); return e && *e ? atoi(e) : 4; }();
+        bool all_gp1 = any_gp1;
+        for (int n = 0; n < nu; n++) all_gp1 = all_gp1 && mine(gp1_owner[n]);
+        int emit = 0;
+        if (hash_fuse && all_gp1 && nu >= 12 && nrows > (p0_only ? 1 : 0))
+            for (int n = nu - 1; n >= 12 && emit < emit_max; n--) emit++;   // layers with 2^n >= 4096 entries per table
+        // Off the critical path, on the second stream: counter sorts (hidden under the collation sum-check), grand product #2's
+        // hashes and tree, the openings (hidden under grand product #1's rounds). Needs the hash-free grand product #1 (the
+        // classic path reads read_ts on the main stream right away).
+        const bool use_aux = fork_recorded && emit > 0;
+        auto aux = [&](const std::function<void()>& fn) { if (use_aux) on_aux(fn); else fn(); };
         // a rank that only holds a few memories of grand product #1 needs the counters of their chunks only
         std::vector<char> need_chunk(4, (!split || do_gp2 || do_open) ? 1 : 0);
         if (any_gp1 && split) {
@@ -958,7 +977,8 @@ struct Prover {
             for (int i : local_mems) need_chunk[lp.gkr_chunk[i]] = 1;
         }
         std::map<int, u64*> read_ts, final_cts;
-        if (need_counters) {
+        if (need_counters) aux([&] {
+            if (use_aux) hip_check(hipStreamWaitEvent(st, ctx->ev_aux[0], 0), "lasso: wait for the limb split");
             size_t tb = dev::lasso_counter_temp_bytes(N);
             void* temp = ctx->alloc(tb);
             u32* keys = ctx->alloc_n<u32>(N); u32* keys2 = ctx->alloc_n<u32>(N);
@@ -973,17 +993,7 @@ struct Prover {
                 dev::lasso_counters(st, L, c, dims, read_ts[c], final_cts[c], temp, tb, keys, keys2, rows, rows2, starts);
                 ctx->prof_end();
             }
-        }
-        const int nrows = split ? (int)local_pairs.size() : 2 * G;
-        // Grand product #1 without hash tables: the top layer's first round recomputes the hashes from dims / read_ts / E and
-        // writes tree level 1, the next layers' first rounds write levels 2 .. emit (HG_NO_HASH_FUSE=1: materialise them).
-        static const bool hash_fuse = [] { const char* e = getenv("HG_NO_HASH_FUSE"); return !(e && e[0] == '1'); }();
-        static const int emit_max = [] { const char* e = getenv("HG_GP_EMIT"); return e && *e ? atoi(e) : 4; }();
-        bool all_gp1 = any_gp1;
-        for (int n = 0; n < nu; n++) all_gp1 = all_gp1 && mine(gp1_owner[n]);
-        int emit = 0;
-        if (hash_fuse && all_gp1 && nu >= 12 && nrows > (p0_only ? 1 : 0))
-            for (int n = nu - 1; n >= 12 && emit < emit_max; n--) emit++;   // layers with 2^n >= 4096 entries per table
+        });
         const dev::GpHashSrc* d_hash_src = nullptr;
         if (emit > 0) {
             std::vector<dev::GpHashMem> hm;
@@ -1046,7 +1056,7 @@ struct Prover {
                 ctx->prof_end();
             }
         }
-        if (do_gp2) {
+        if (do_gp2) aux([&] {
             if (G > 32) throw Error("lasso: more than 32 memories");
             dev::HashIfArgs ha;
             memset(&ha, 0, sizeof(ha));
@@ -1054,14 +1064,24 @@ struct Prover {
             ctx->prof_begin(cls_hash, (double)G * M * 8 * 3);
             dev::lasso_hash_if(st, ha, G, gamma, tau, H2);
             ctx->prof_end();
-        }
+        });
         mark("lasso: memory checking, grand product #1 over reads then writes (prover.rs:161-165)");
         GpOut g1 = split ? grand_product(H1, N, 2 * G, gp1_owner, L1, &local_pairs, p0_only, d_hash_src, emit)
                          : grand_product(H1, N, 2 * G, gp1_owner, L1, nullptr, false, d_hash_src, emit);  // reads then writes (prover.rs:161-165)
         mark("lasso: memory checking, grand product #2 over inits then finals (prover.rs:167-171)");
-        GpOut g2 = grand_product(H2, M, 2 * G, std::vector<int>(16, own_gp2));      // inits then finals (prover.rs:167-171)
-        // openings (prover.rs:173-178, mod.rs:80-93)
-        E2* eqx = eq;  // the eq(r,.) table is dead by now
+        GpOut g2{0};
+        aux([&] { g2 = grand_product(H2, M, 2 * G, std::vector<int>(16, own_gp2)); });  // inits then finals (prover.rs:167-171); its tree on the second stream
+        if (use_aux) {
+            // grand product #1's first launch reads the counters, grand product #2's first rounds its tree: the main stream waits
+            // for the second one only there, after the collation sum-check has been enqueued
+            hip_check(hipEventRecord(ctx->ev_aux[1], ctx->stream2), "lasso: aux event");
+            hg_ctx* c = ctx;
+            st_before_gp = [c] { hip_check(hipStreamWaitEvent(c->stream, c->ev_aux[1], 0), "lasso: wait for counters / grand product #2 tree"); };
+        }
+        // openings (prover.rs:173-178, mod.rs:80-93). With two streams eq(r, .) may still be in use by the claimed-sum kernel on
+        // the main stream, so the openings get their own table.
+        aux([&] {
+        E2* eqx = (use_aux && do_open) ? ctx->alloc_n<E2>(N) : eq;  // (one stream: the eq(r,.) table is dead by now)
         E2* eqy = do_open ? ctx->alloc_n<E2>(M) : nullptr;
         if (do_open) {
             eq_now(eqx, nu, g1.point_off);
@@ -1100,6 +1120,7 @@ struct Prover {
             mark("lasso: openings of chunk " + std::to_string(c) + ": dim(x), read_ts(x), final_cts(y), E_m(x) (prover.rs:173-178)");
             defer_write_slots(base_slot, 3 + chk.second.size());
         }
+        });
         flush_stride();  // collation + every grand-product layer, round-synchronised
         return ClaimRef{r_off, nu, claimed};  // (r, claimed_sum) for the single predecessor (lasso.rs:97,113)
     }
@@ -1280,6 +1301,19 @@ struct Prover {
         hip_check(hipEventRecord(ctx->ev_fork, ctx->stream), "fork event");   // after the result-buffer clear / ticket reset
         fork_recorded = true;
     }
+    // Runs `fn` with the second stream as the enqueue target (work of the Lasso node that is off its critical path: counter
+    // sorts, grand product #2's hashes and tree, the openings). One stream only: runs it in place.
+    bool aux_started = false;
+    template <typename Fn> void on_aux(Fn fn) {
+        if (!fork_recorded) { fn(); return; }
+        hipStream_t s0 = st;
+        E2* p0 = partials;
+        if (!aux_started) { hip_check(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0), "aux: fork wait"); aux_started = true; }
+        st = ctx->stream2; partials = ctx->d_partials2; ctx->prof_stream = st;
+        fn();
+        st = s0; partials = p0; ctx->prof_stream = s0;
+    }
+    std::function<void()> st_before_gp;  // flush_stride runs it once before the first grand-product launch (cross-stream wait)
     void fork_nodes_stream() {
         if (!fork_recorded) return;
         hip_check(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0), "fork wait");
