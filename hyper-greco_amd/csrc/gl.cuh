@@ -70,6 +70,19 @@ HG_HD u64 gl_mul_small(u64 a, u32 c) {
     r -= (r >= GL_P) ? GL_P : 0;
     return r;
 }
+// 7 * a as SOME 64-bit residue (not canonical): for operands of the deferred-reduction multiply-accumulates, which accept any
+// 64-bit residue. 7a = lo + hi 2^64 with hi < 7, 2^64 = eps: lo + hi eps, plus eps once more if that sum wraps.
+HG_HD u64 gl_mul7_lazy(u64 a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u64 lo = a * 7ULL, hi = __umul64hi(a, 7ULL);
+#else
+    unsigned __int128 x = (unsigned __int128)a * 7;
+    u64 lo = (u64)x, hi = (u64)(x >> 64);
+#endif
+    u64 r = lo + ((hi << 32) - hi);
+    r += (r < lo) ? GL_EPS : 0;
+    return r;
+}
 HG_HD u64 gl_from_u64(u64 x) { return x >= GL_P ? x - GL_P : x; }
 
 inline u64 gl_pow(u64 b, u64 e) {

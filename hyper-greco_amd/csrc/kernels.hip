@@ -537,6 +537,7 @@ __global__ __launch_bounds__(256) void k_gp_first_hash(const StJob* __restrict__
                 c0 = gl_sub(gl_add(dl.x, gl_mul_small(gamma2, (u32)tl.x)), tau); c1 = gl_sub(gl_add(dl.y, gl_mul_small(gamma2, (u32)tl.y)), tau);
                 c2 = gl_sub(gl_add(dh.x, gl_mul_small(gamma2, (u32)th.x)), tau); c3 = gl_sub(gl_add(dh.y, gl_mul_small(gamma2, (u32)th.y)), tau);
             }
+            // (prefetching the next memory's E loads was measured slower here: 594 vs 560 us)
             const ulonglong2 el = *reinterpret_cast<const ulonglong2*>(M.ep + 2 * j), eh = *reinterpret_cast<const ulonglong2*>(M.ep + hN + 2 * j);
             u64 xl = gl_add(c0, gl_mul_small(gamma, (u32)el.x)), yl = gl_add(c1, gl_mul_small(gamma, (u32)el.y));
             u64 xr = gl_add(c2, gl_mul_small(gamma, (u32)eh.x)), yr = gl_add(c3, gl_mul_small(gamma, (u32)eh.y));
@@ -590,7 +591,7 @@ void st_first_hash(hipStream_t st, const StJob* job, const StItem* item, int gri
 struct W2 { WAcc c0, c1; };
 __device__ __forceinline__ W2 w2_zero() { W2 w; w.c0 = wacc_zero(); w.c1 = wacc_zero(); return w; }
 __device__ __forceinline__ void w2_mac(W2& w, E2 a, E2 b) {
-    const u64 a7 = gl_mul_small(a.c1, 7);
+    const u64 a7 = gl_mul7_lazy(a.c1);  // any 64-bit residue will do as a multiplicand
     wmac_pair(w.c0, a.c0, b.c0, a7, b.c1);
     wmac_pair(w.c1, a.c0, b.c1, a.c1, b.c0);
 }
@@ -640,17 +641,27 @@ __global__ __launch_bounds__(256) void k_st_step2(const StJob* __restrict__ jobs
         const size_t j = (tile << 8) + tid;
         const size_t j2 = j >> 1;
         const size_t jo2 = dpos(j2, half2);
-        W2 w0 = w2_zero(), w1 = w2_zero(), wi = w2_zero(), vm = w2_zero();
+        // round t: three accumulators per Ext2 sum (a0 b0 | a1 b1 | cross terms), the factor 7 of X^2 = 7 applied once per j at
+        // the reduction instead of once per operand; round t+1 (vm, vi): two accumulators with 7 a1 pre-multiplied (registers)
+        WE2 w0 = we2_zero(), w1 = we2_zero(), wi = we2_zero();
+        W2 vm = w2_zero();
         WAcc vi = wacc_zero();
         E2 p0 = e2_zero(), p2 = e2_zero(), p3 = e2_zero(), q0 = e2_zero(), q2 = e2_zero(), q3 = e2_zero();
+        // software pipeline: the four loads of the next pair are in flight while this pair is processed (two waves per SIMD
+        // cannot hide an HBM round trip behind ~800 instructions otherwise)
+        E2 xl, yl, xr, yr;
+        load_xy<E2, false>(in, j, half, xl, yl);
+        load_xy<E2, false>(in + in_stride, j, half, xr, yr);
         for (int i = 0; i < nb; i++) {
-            E2 xl, yl, xr, yr;
-            load_xy<E2, false>(in + (size_t)(2 * i) * in_stride, j, half, xl, yl);
-            load_xy<E2, false>(in + (size_t)(2 * i + 1) * in_stride, j, half, xr, yr);
+            E2 nxl = xl, nyl = yl, nxr = xr, nyr = yr;
+            if (i + 1 < nb) {
+                load_xy<E2, false>(in + (size_t)(2 * i + 2) * in_stride, j, half, nxl, nyl);
+                load_xy<E2, false>(in + (size_t)(2 * i + 3) * in_stride, j, half, nxr, nyr);
+            }
             const E2 dl = e2_sub(yl, xl), dr = e2_sub(yr, xr);
             const bool summed = !(p0_only && i == 0);
             if (i == 0) { p0 = xl; p2 = e2_add(yl, dl); p3 = e2_add(p2, dl); }
-            if (summed) { w2_mac(w0, xl, xr); w2_mac(w1, yl, yr); w2_mac(wi, dl, dr); }
+            if (summed) { we2_mac(w0, xl, xr); we2_mac(w1, yl, yr); we2_mac(wi, dl, dr); }
             const E2 ml = e2_fold_wide(xl, dl, fa), mr = e2_fold_wide(xr, dr, fa);  // T'[j] of the left / right table
             const E2 ol = swap_lane(ml), orr = swap_lane(mr);                        // the neighbour's
             const E2 el = e2_sub(ol, ml), er = e2_sub(orr, mr);                      // +-(y' - x')
@@ -663,13 +674,14 @@ __global__ __launch_bounds__(256) void k_st_step2(const StJob* __restrict__ jobs
                 w2_mac(vm, ml, mr);  // even lane: P0 term, odd lane: P1 term
                 // Pinf = el * er: the even lane takes coordinate 0 (el0 er0 + 7 el1 er1), the odd lane coordinate 1
                 const u64 b = odd ? er.c1 : er.c0, d = odd ? er.c0 : er.c1;
-                const u64 c = odd ? el.c1 : gl_mul_small(el.c1, 7);
+                const u64 c = odd ? el.c1 : gl_mul7_lazy(el.c1);
                 wmac_pair(vi, el.c0, b, c, d);
             }
             const E2 fx = odd ? mr : ml, fd = odd ? er : el;
             store_e2(out + (size_t)(2 * i + (odd ? 1 : 0)) * half2 + jo2, e2_fold_wide(fx, fd, fb));
+            xl = nxl; yl = nyl; xr = nxr; yr = nyr;
         }
-        gp_combine(w2_reduce(w0), w2_reduce(w1), w2_reduce(wi), p0, p2, p3, acc[0], acc[1], acc[2]);
+        gp_combine(we2_reduce(w0), we2_reduce(w1), we2_reduce(wi), p0, p2, p3, acc[0], acc[1], acc[2]);
         const E2 mine = w2_reduce(vm), other = swap_lane(mine);
         const u64 ip = wreduce(vi), iq = swap_lane_u64(ip);
         if (!odd) gp_combine(mine, other, e2(ip, iq), q0, q2, q3, acc[3], acc[4], acc[5]);
@@ -1088,7 +1100,7 @@ __device__ __forceinline__ void ps_step2_body(const PsJob& J, const PsItem& I, s
             const E2 ea = e2_sub(oa_, ma), eb = e2_sub(ob_, mb);  // +-(y' - x'); the sign cancels in the product
             w2_mac(vm, ma, mb);
             const u64 b = odd ? eb.c1 : eb.c0, d = odd ? eb.c0 : eb.c1;
-            const u64 c = odd ? ea.c1 : gl_mul_small(ea.c1, 7);
+            const u64 c = odd ? ea.c1 : gl_mul7_lazy(ea.c1);
             wmac_pair(vi, ea.c0, b, c, d);
             const E2 fx = odd ? mb : ma, fd = odd ? eb : ea;
             store_e2((odd ? ob : oa) + jo2, e2_fold_wide(fx, fd, fb));

@@ -937,6 +937,9 @@ struct Prover {
             ScHandle sc = sc_stride(dev::SC_COLLATION, ep, true, N, A, nu, pw, nullptr, do_col);
             mark("lasso: collation sum-check, " + std::to_string(nu) + " rounds x 3 coefficients (lasso.rs:271-279) [C1, C3; poly(0) quirk]");
             defer_sumcheck(sc, 2, claimed, nullptr);
+            // launched right away: the host still has the whole memory-checking bookkeeping to walk (about 0.5 ms), and the main
+            // stream would sit idle until the shared flush at the end of the node
+            flush_stride();
         }
         E2 gamma_e = squeeze(), tau_e = squeeze();  // lasso.rs:99
         u64 gamma = gamma_e.c0, tau = tau_e.c0;     // prover.rs:38-39: base limb 0 only
