@@ -28,42 +28,57 @@ CLASS_SYMBOL = {
     "sc_round2<grand_product,ext>": "k_st_step2(",
     "sc_round<grand_product,ext>": "k_st_step<1, hg::E2>",
     "sc_round<grand_product,base>": "k_st_step<1, unsigned long>",
+    "sc_round<grand_product,hash>": "k_gp_first_hash(",
     "sc_round2<collation,ext>": "k_col_step2(",
     "sc_round<collation,ext>": "k_st_step<0, hg::E2>",
     "sc_round<collation,base>": "k_st_step<0, unsigned long>",
     "sc_round<prodsum>": "k_ps_one(",
 }
-PMC_FILE = os.path.join(ROOT, "profiles", "r01_j_pmc_hbm_traffic.json")
+PMC_TAG = "r02"  # profiles/<tag>_pmc_hbm_traffic.json, profiles/<tag>_bn254_pmc_sq.json: this round's committed counter passes
+PMC_CMD = ("rocprofv3 --pmc FETCH_SIZE -- python3 scripts/prove_once.py 32768 16 2 ; rocprofv3 --pmc WRITE_SIZE -- (same): separate passes, "
+           "HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 per launch (gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md), "
+           "scripts/pmc_summary.py")
 
 
-def pmc_traffic(cls):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
-    WRITE_SIZE collected in separate runs, FETCH_SIZE doubled as the MI355X guide prescribes for gfx950;
-    scripts/pmc_summary.py). PMC counters cannot be read from inside this process, so this is the value
-    measured by `rocprofv3 --pmc ... -- python3 scripts/prove_once.py 32768 16 2` on the same workload."""
+def pmc_traffic(cls, n, k):
+    """HBM bytes per launch of the dominant kernel from this round's committed rocprofv3 PMC passes (PMC counters cannot be
+    read from inside this process). Only valid for the configuration the passes were taken on: n=32768 k=16."""
+    if (n, k) != (32768, 16):
+        return None, None
+    path = os.path.join(ROOT, "profiles", f"{PMC_TAG}_pmc_hbm_traffic.json")
     try:
-        d = json.load(open(PMC_FILE))
-        for k, v in d.items():
-            if CLASS_SYMBOL.get(cls, "\0") in k:
-                return round(v["hbm_bytes_per_launch"])
+        d = json.load(open(path))
+        for key, v in d.items():
+            if CLASS_SYMBOL.get(cls, "\0") in key:
+                return round(v["hbm_bytes_per_launch"]), os.path.relpath(path, ROOT)
     except Exception:
         pass
-    return None
+    return None, None
 
 
-def cpu_baseline(n, k, seed, budget_s=45.0):
-    """Times the CPU oracle (kind = "port": this repo's restatement of the reference algorithm, OpenMP at the
-    places the reference uses rayon) on the host cores. Bounded: a small config is timed first and the headline
-    config is only run when its predicted time fits the budget; otherwise the largest config that fits is
-    reported, scaled by the ratio of Lasso rows (stated in `sample`)."""
+def cpu_baseline(n, k, seed, budget_s=40.0):
+    """CPU baseline on this host's cores, same witness as the GPU run, GKR-prove span only.
+    kind "reference": the reference's own rayon prover (needs cargo + network + $HYPER_GRECO: scripts/reference_baseline.py);
+    otherwise kind "port": the CPU oracle (this repo's restatement, OpenMP where the reference uses rayon). Method: one run per
+    thread count in {64, 128, 256} (the first also warms the page cache), then two more at the best count; value = median of the
+    three runs at the best count. Bounded: a small config is timed first and the largest config whose predicted time fits the
+    budget is run (scaled by the ratio of Lasso rows, stated in `sample`)."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    try:
+        import reference_baseline
+        ref = reference_baseline.measure(n, k, seed + n)
+        if ref:
+            return ref
+    except Exception:
+        pass
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orclib  # CPU oracle: used here only as the thing being timed for the baseline line
+    import statistics
     import __graft_entry__ as entry
     hg = entry.load_package()
     cores = os.cpu_count() or 1
-    threads = min(cores, 64)
 
-    def run(nn, kk):
+    def run(nn, kk, threads):
         p = hg.params_builtin(nn, kk)
         w = hg.Witness.synthetic(p, seed + nn)
         inp = orclib.Inputs(w.arrays())
@@ -74,18 +89,25 @@ def cpu_baseline(n, k, seed, budget_s=45.0):
     def rows(nn, kk):
         return (kk + max(1, kk // 2) + 3) * 2 * nn
 
-    t_small = run(4096, 2)
+    t_small = run(4096, 2, min(cores, 64))
     ladder = [(32768, 16), (16384, 8), (8192, 4), (4096, 2)]
     for nn, kk in ladder:
-        predicted = t_small * rows(nn, kk) / rows(4096, 2) / 1000.0
+        predicted = 5 * t_small * rows(nn, kk) / rows(4096, 2) / 1000.0   # five runs
         if predicted <= budget_s or (nn, kk) == (4096, 2):
-            ms = run(nn, kk) if (nn, kk) != (4096, 2) else t_small
+            sweep = {}
+            for th in sorted({min(cores, t) for t in (64, 128, 256)}):
+                sweep[th] = run(nn, kk, th)
+            best = min(sweep, key=sweep.get)
+            runs = [sweep[best]] + [run(nn, kk, best) for _ in range(2)]
+            ms = statistics.median(runs)
             scale = rows(n, k) / rows(nn, kk)
-            sample = f"oracle GKR prove at n={nn} k={kk}, {threads} OpenMP threads"
+            sample = (f"oracle GKR prove at n={nn} k={kk}: one run per thread count {sorted(sweep)} (first = warm-up of the page cache), "
+                      f"best = {best} threads, median of 3 runs there")
             if scale != 1:
                 sample += f"; scaled x{scale:.2f} (Lasso rows ratio) to n={n} k={k}"
-            return {"value": round(ms * scale, 3), "unit": "ms", "cores": threads, "kind": "port", "sample": sample,
-                    "measured_ms": round(ms, 3), "host_cores": cores}
+            return {"value": round(ms * scale, 3), "unit": "ms", "cores": best, "kind": "port", "sample": sample,
+                    "measured_ms": round(ms, 3), "runs_ms": [round(r, 1) for r in runs],
+                    "thread_sweep_ms": {str(t): round(v, 1) for t, v in sweep.items()}, "host_cores": cores}
     return None
 
 
@@ -177,9 +199,17 @@ def main():
     vals = hg.witness_gen(ctx, pk, witness)  # node tables -> HBM (outside the timed region)
     out = hg.ProofBuffer()
 
+    lib_comm = shard and backend == "nccl"   # the library's own RCCL all-reduce (device buffers, no torch hop, no host staging)
+    if lib_comm:
+        uid = [hg.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)     # 128 bytes, once: the only use of torch.distributed on this path besides barriers
+        hg.comm_init(ctx, uid[0], rank, world)
+
     def step():
         if not shard:
             return hg.prove_resident(ctx, pk, vals, out)
+        if lib_comm:
+            return hg.prove_sharded(ctx, pk, vals, out)   # this rank's jobs -> one ncclAllReduce on the prover stream -> replay
         import numpy as np
         part = hg.prove_shard_begin(ctx, pk, vals, rank, world)      # this rank's jobs, one stream sync
         t = torch.from_numpy(part.view(np.int64).copy()).to(red_dev)
@@ -234,12 +264,27 @@ def main():
     classes = {s["name"]: {"launches": s["launches"], "ms": round(s["total_ms"], 4), "algo_GB": round(s["algo_bytes"] / 1e9, 4)}
                for s in ctx.profile_get() if s["launches"]}
 
+    # the dominant class once more with every launch on one stream (isolated kernel duration), untimed
+    ctx.set_option("one_stream", 1)
+    step()
+    ctx.profile(1)
+    ctx.profile_reset()
+    for _ in range(3):
+        step()
+    ctx.profile(0)
+    iso = [s for s in ctx.profile_get() if s["name"] == DOMINANT][0]
+    iso_ms = iso["total_ms"] / max(iso["launches"], 1)
+    iso_achieved = iso["algo_bytes"] / max(iso["launches"], 1) / (iso_ms * 1e-3) / 1e9 if iso_ms > 0 else 0.0
+    iso_gpu_ms = out.timings()["gpu_ms"]
+    ctx.set_option("one_stream", 0)
+
     if rank == 0:
         per_launch_bytes = dom["algo_bytes"] / max(dom["launches"], 1)
         avg_ms = dom["total_ms"] / max(dom["launches"], 1)
         achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic, traffic_file = pmc_traffic(DOMINANT, args.n, args.k)
         line = {
-            "metric": "GKR prove ms, n=32768 k=16 Goldilocks; achieved HBM GB/s vs roofline",
+            "metric": f"GKR prove ms, n={args.n} k={args.k} Goldilocks; achieved HBM GB/s vs roofline",
             "value": round(ms_per_step if (shard or world == 1) else ms_per_step / world, 4),
             "unit": "ms",
             "n_gpus": world,
@@ -254,14 +299,22 @@ def main():
             "config": {"workload": f"GKR prove (sk_encryption_circuit.rs:444-457) of the BFV sk-enc circuit, n={args.n} k={args.k} "
                                    "Goldilocks/GoldilocksExt2, seeded synthetic witness, node tables resident in HBM",
                        "n": args.n, "k": args.k, "field": "goldilocks", "proofs_per_step": 1 if (shard or world == 1) else world,
-                       "parallelism": (f"shard{world}: one proof, device jobs partitioned over {world} GPUs, one RCCL all-gather of the result buffers per proof"
+                       "parallelism": (f"shard{world}: one proof, device jobs partitioned over {world} GPUs, one RCCL all-reduce of the result buffer per proof (inside the library)"
                                        if shard else f"dp{world}: one independent proof per GPU, no data-path collective"),
                        "proof_bytes": len(first), "gpu_ms_events": round(gpu_ms, 4),
                        "witness_gen_ms_device": round(vals.timings["witness_ms"], 2), "upload_ms": round(vals.timings["upload_ms"], 2)},
+            # `achieved` / `avg_launch_us`: HIP events around the dominant kernel class INSIDE the timed region, where its launches
+            # share the GPU with the second stream (Vanilla / FFT reductions, counter sorts, openings); `isolated`: the same
+            # launches timed in an extra untimed prove with every launch on one stream.
             "roofline": {"bound": "hbm", "kernel": DOMINANT, "symbol": CLASS_SYMBOL.get(DOMINANT, ""), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(DOMINANT),
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_source": {"file": traffic_file, "command": PMC_CMD} if traffic else None,
+                         "traffic_frac": round(traffic / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and iso_ms > 0 else None,
                          "launches_per_step": dom["launches"] // max(args.steps, 1),
-                         "avg_launch_us": round(avg_ms * 1e3, 3), "algo_bytes_per_launch": round(per_launch_bytes)},
+                         "avg_launch_us": round(avg_ms * 1e3, 3), "algo_bytes_per_launch": round(per_launch_bytes),
+                         "isolated": {"avg_launch_us": round(iso_ms * 1e3, 3), "achieved": round(iso_achieved, 2),
+                                      "frac": round(iso_achieved / HBM_PEAK_GBS, 4), "gpu_ms_one_stream": round(iso_gpu_ms, 4),
+                                      "note": "hg_set_option(one_stream): no cross-stream overlap; traffic_frac uses this duration"}},
             "kernel_classes": classes,
             # whole prove against the same roofline: algorithmic bytes of every kernel class (SURVEY 8(d) accounting) over the
             # GPU time of one prove (HIP events around the whole enqueue)
@@ -287,6 +340,8 @@ def main():
                 line["cpu_baseline"] = {"error": str(ex)}
         print(json.dumps(line), flush=True)
 
+    if lib_comm:
+        hg.comm_destroy(ctx)
     vals.free()
     pk.free()
     ctx.close()

@@ -36,9 +36,9 @@ class HgKernelStat(C.Structure):
 
 
 EXPORTS = [
-    "hg_last_error", "hg_device_count", "hg_create", "hg_destroy", "hg_params_builtin", "hg_setup", "hg_pk_free",
+    "hg_last_error", "hg_device_count", "hg_create", "hg_destroy", "hg_set_option", "hg_params_builtin", "hg_setup", "hg_pk_free",
     "hg_pk_lasso_layout", "hg_pk_info", "hg_witness_from_json", "hg_witness_synthetic", "hg_witness_from_arrays",
-    "hg_witness_get", "hg_witness_free", "hg_prove", "hg_verify", "hg_witness_gen", "hg_values_free", "hg_values_get", "hg_prove_shard_begin", "hg_prove_shard_combine", "hg_prove_shard_finish", "hg_prove_resident", "hg_circuit_eval", "hg_lasso_prove", "hg_lasso_prove_at", "hg_lasso_num_challenges", "hg_sumcheck", "hg_mle_eval",
+    "hg_witness_get", "hg_witness_free", "hg_prove", "hg_verify", "hg_witness_gen", "hg_values_free", "hg_values_get", "hg_comm_unique_id", "hg_comm_init", "hg_comm_destroy", "hg_prove_sharded", "hg_prove_shard_begin", "hg_prove_shard_combine", "hg_prove_shard_finish", "hg_prove_resident", "hg_circuit_eval", "hg_lasso_prove", "hg_lasso_prove_at", "hg_lasso_num_challenges", "hg_sumcheck", "hg_mle_eval",
     "hg_ntt", "hg_challenges", "hg_challenges_bn254", "hg_bn254_field_op", "hg_sumcheck_bn254", "hg_grand_product_bn254", "hg_lasso_prove_bn254", "hg_witness_from_json_bn254", "hg_circuit_eval_bn254", "hg_prove_bn254", "hg_verify_bn254", "hg_mle_eval_bn254", "hg_ntt_bn254", "hg_profile", "hg_profile_select", "hg_profile_reset", "hg_profile_get",
 ]
 
@@ -153,6 +153,13 @@ class Context:
         if self.h:
             lib().hg_destroy(self.h)
             self.h = None
+
+    def set_option(self, name, value):
+        """hg_set_option: "one_stream" (1 = no cross-stream overlap, for per-kernel timings)."""
+        L = lib()
+        L.hg_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+        if L.hg_set_option(self.h, name.encode(), int(value)) != 0:
+            raise HgError(L.hg_last_error().decode())
 
     def profile(self, level):
         lib().hg_profile(self.h, level)
@@ -468,6 +475,35 @@ def prove_shard_combine(ctx, gathered, world):
 
 def prove_shard_finish(ctx, out):
     _check(lib().hg_prove_shard_finish(ctx.h, out.buf, out.cap, C.byref(out.len), C.byref(out.tm)))
+    return out
+
+
+def comm_unique_id():
+    """hg_comm_unique_id: the 128-byte RCCL id rank 0 shares with the other ranks."""
+    buf = (C.c_uint8 * 128)()
+    _check(lib().hg_comm_unique_id(buf))
+    return bytes(buf)
+
+
+def comm_init(ctx, uid, rank, world):
+    """hg_comm_init (collective): RCCL communicator of this rank's context."""
+    buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+    L = lib()
+    L.hg_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    _check(L.hg_comm_init(ctx.h, buf, rank, world))
+
+
+def comm_destroy(ctx):
+    L = lib()
+    L.hg_comm_destroy.argtypes = [C.c_void_p]
+    _check(L.hg_comm_destroy(ctx.h))
+
+
+def prove_sharded(ctx, pk, values, out):
+    """hg_prove_sharded (collective): this rank's share of ONE proof + the RCCL all-reduce inside the library + replay."""
+    L = lib()
+    L.hg_prove_sharded.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(HgTimings)]
+    _check(L.hg_prove_sharded(ctx.h, pk.h, values.h, out.buf, out.cap, C.byref(out.len), C.byref(out.tm)))
     return out
 
 

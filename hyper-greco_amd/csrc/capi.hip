@@ -109,6 +109,16 @@ hg_ctx* hg_create(int device_id) {
 
 void hg_destroy(hg_ctx* ctx) { delete ctx; }
 
+int hg_set_option(hg_ctx* ctx, const char* name, int64_t value) {
+    HG_TRY
+    if (!ctx || !name) throw Error("hg_set_option: null argument");
+    const std::string n(name);
+    if (n == "one_stream") ctx->one_stream = value != 0;
+    else throw Error("hg_set_option: unknown option " + n);
+    return 0;
+    HG_CATCH(-1)
+}
+
 int hg_params_builtin(uint32_t n, uint32_t k, hg_params* out) {
     HG_TRY
     if (!params_builtin(n, k, out)) throw Error("no built-in parameter set for this (n, k)");
@@ -393,6 +403,39 @@ int hg_prove_shard_finish(hg_ctx* ctx, uint8_t* proof, size_t cap, size_t* len, 
     HG_TRY
     if (!ctx) throw Error("hg_prove_shard_finish: null context");
     ProveResult r = prove_shard_finish(ctx);
+    if (timings) { memset(timings, 0, sizeof(*timings)); timings->prove_ms = r.prove_ms; timings->gpu_ms = r.gpu_ms; timings->total_ms = r.prove_ms; timings->enqueue_ms = r.enqueue_ms; timings->sync_ms = r.sync_ms; timings->replay_ms = r.replay_ms; }
+    *len = r.proof.size();
+    if (r.proof.size() > cap) throw Error("proof buffer too small");
+    memcpy(proof, r.proof.data(), r.proof.size());
+    return 0;
+    HG_CATCH(-1)
+}
+
+int hg_comm_unique_id(uint8_t out[128]) {
+    HG_TRY
+    if (!out) throw Error("hg_comm_unique_id: null argument");
+    comm_unique_id(out);
+    return 0;
+    HG_CATCH(-1)
+}
+int hg_comm_init(hg_ctx* ctx, const uint8_t id[128], int rank, int world) {
+    HG_TRY
+    if (!ctx || !id) throw Error("hg_comm_init: null argument");
+    comm_init(ctx, id, rank, world);
+    return 0;
+    HG_CATCH(-1)
+}
+int hg_comm_destroy(hg_ctx* ctx) {
+    HG_TRY
+    if (!ctx) throw Error("hg_comm_destroy: null context");
+    comm_destroy(ctx);
+    return 0;
+    HG_CATCH(-1)
+}
+int hg_prove_sharded(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, uint8_t* proof, size_t cap, size_t* len, hg_timings* timings) {
+    HG_TRY
+    if (!ctx || !pk || !v || !pk->ctx || !proof || !len) throw Error("hg_prove_sharded: needs a device context, a device prover key and resident values");
+    ProveResult r = prove_sharded(ctx, pk, v);
     if (timings) { memset(timings, 0, sizeof(*timings)); timings->prove_ms = r.prove_ms; timings->gpu_ms = r.gpu_ms; timings->total_ms = r.prove_ms; timings->enqueue_ms = r.enqueue_ms; timings->sync_ms = r.sync_ms; timings->replay_ms = r.replay_ms; }
     *len = r.proof.size();
     if (r.proof.size() > cap) throw Error("proof buffer too small");

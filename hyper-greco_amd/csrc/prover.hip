@@ -116,6 +116,8 @@ hg_ctx::~hg_ctx() {
     if (h_stage) (void)hipHostFree(h_stage);
     if (d_partials) (void)hipFree(d_partials);
     if (d_partials2) (void)hipFree(d_partials2);
+    if (comm) { try { hg::comm_destroy(this); } catch (...) {} }
+    if (d_xchg) (void)hipFree(d_xchg);
     if (stream2) { (void)hipStreamSynchronize(stream2); (void)hipStreamDestroy(stream2); }
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
@@ -180,7 +182,7 @@ struct Prover {
     ProofStream proof;
     std::vector<std::function<void()>> ops;  // transcript steps, replayed after the single synchronisation
     size_t res_used = 0;
-    int cls_gp_base, cls_gp_ext, cls_gp_ext2, cls_col_ext2, cls_col_base, cls_col_ext, cls_ps, cls_reduce, cls_aux, cls_tree, cls_hash, cls_gather, cls_tail, cls_ps_tail;
+    int cls_gp_hash, cls_gp_base, cls_gp_ext, cls_gp_ext2, cls_col_ext2, cls_col_base, cls_col_ext, cls_ps, cls_reduce, cls_aux, cls_tree, cls_hash, cls_gather, cls_tail, cls_ps_tail;
 
     // ---- single-proof sharding over `world` GPUs ---------------------------------------------------
     // Device jobs are independent, so a proof shards by JOB with no data-path collective inside
@@ -272,6 +274,7 @@ struct Prover {
         cls_gp_ext2 = ctx->prof_class("sc_round2<grand_product,ext>", true);
         cls_gp_ext = ctx->prof_class("sc_round<grand_product,ext>", false);
         cls_gp_base = ctx->prof_class("sc_round<grand_product,base>", false);
+        cls_gp_hash = ctx->prof_class("sc_round<grand_product,hash>", false);
         cls_col_base = ctx->prof_class("sc_round<collation,base>", false);
         cls_col_ext = ctx->prof_class("sc_round<collation,ext>", false);
         cls_col_ext2 = ctx->prof_class("sc_round2<collation,ext>", false);
@@ -490,7 +493,7 @@ struct Prover {
                 if (L.hash) {
                     const dev::StItem& it = L.items[o];
                     bytes = round_bytes(st_jobs[it.job], 0);
-                    ctx->prof_begin(cls_gp_base, bytes);
+                    ctx->prof_begin(cls_gp_hash, bytes);
                     dev::st_first_hash(st, d_jobs + it.job, d_items + offs[li] + o, grids[li][0], ctx->d_chal, partials, d_res());
                     ctx->prof_end();
                     continue;
@@ -1300,7 +1303,7 @@ struct Prover {
     bool fork_recorded = false;
     void record_fork() {
         static const bool one_stream = [] { const char* e = getenv("HG_ONE_STREAM"); return e && e[0] == '1'; }();
-        if (one_stream || world > 1) return;
+        if (one_stream || ctx->one_stream) return;
         hip_check(hipEventRecord(ctx->ev_fork, ctx->stream), "fork event");   // after the result-buffer clear / ticket reset
         fork_recorded = true;
     }
@@ -1494,7 +1497,8 @@ void values_free(hg_values* v) {
 }
 
 // enqueue + synchronise this rank's share of one proof; leaves the (partial) result buffer in ctx->h_res
-static std::unique_ptr<Prover> prove_begin(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int rank, int world, double* t_start, float* gpu_ms) {
+static std::unique_ptr<Prover> prove_begin(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int rank, int world, double* t_start, float* gpu_ms,
+                                           bool exchange = false) {
     hip_check(hipSetDevice(ctx->device), "hipSetDevice");
     ctx->arena_reset();
     const Params& p = pk->params;
@@ -1520,6 +1524,7 @@ static std::unique_ptr<Prover> prove_begin(hg_ctx* ctx, const hg_pk* pk, const h
     Prover* pp = P.get();
     P->ops.push_back([pp, out_value, vslot] { *out_value = pp->h_res()[vslot]; });
     P->gkr(ClaimRef{point_off, ov, out_value});
+    if (exchange) comm_allreduce_results(ctx, P->res_used);  // the one collective of a sharded proof, on the stream
     hip_check(hipEventRecord(ev_b, ctx->stream), "event record");
     P->sync_results();
     *gpu_ms = 0;
@@ -1536,6 +1541,23 @@ ProveResult prove_resident(hg_ctx* ctx, const hg_pk* pk, const hg_values* v) {
     P->replay();
     double t4 = wall_ms();
     res.prove_ms = t4 - t3;
+    res.gpu_ms = gms;
+    res.enqueue_ms = P->t_enqueued - t3;
+    res.sync_ms = P->t_synced - P->t_enqueued;
+    res.replay_ms = P->t_replayed - P->t_synced;
+    res.proof = std::move(P->proof.bytes);
+    return res;
+}
+
+ProveResult prove_sharded(hg_ctx* ctx, const hg_pk* pk, const hg_values* v) {
+    if (!ctx->comm) throw Error("hg_prove_sharded: no communicator on this context (hg_comm_init)");
+    if (ctx->d_res != ctx->h_res) throw Error("hg_prove_sharded: needs the host-mapped result buffer (unset HG_RES_DEVICE)");
+    ProveResult res;
+    double t3 = 0;
+    float gms = 0;
+    std::unique_ptr<Prover> P = prove_begin(ctx, pk, v, ctx->comm_rank, ctx->comm_world, &t3, &gms, true);
+    P->replay();
+    res.prove_ms = wall_ms() - t3;
     res.gpu_ms = gms;
     res.enqueue_ms = P->t_enqueued - t3;
     res.sync_ms = P->t_synced - P->t_enqueued;

@@ -17,12 +17,21 @@
 #include "kernels.hpp"
 
 struct hg_ctx {
+    typedef hg::u64 u64;
     int device = 0;
     hipStream_t stream = nullptr;   // Lasso node + everything sequential
     hipStream_t stream2 = nullptr;  // Vanilla / FFT node reductions (independent of the Lasso node on the device)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_aux[2] = {nullptr, nullptr};  // Lasso node: limb split done (stream -> stream2), counters + grand product #2 levels done (stream2 -> stream)
     hipStream_t prof_stream = nullptr;  // stream the profiling events are recorded on (the one being enqueued to)
+    // multi-GPU (comm.hip): RCCL communicator of this rank (ncclComm_t, type-erased: RCCL is loaded at run time), exchange buffer
+    void* comm = nullptr;
+    int comm_rank = 0, comm_world = 1;
+    u64* d_xchg = nullptr;
+    size_t xchg_cap = 0;
+    // options (hg_set_option)
+    bool one_stream = false;  // keep every launch on `stream` (per-kernel timings without cross-stream interference)
+    int mode = 0;             // protocol mode of the next proves: bit 0 absorbing transcript, bit 1 extension-field memory checking
     // bump arena: chunks are kept across proves, offsets reset per prove
     struct Chunk { char* p; size_t cap, used; };
     std::vector<Chunk> chunks;
@@ -110,6 +119,12 @@ hg_values* witness_gen(hg_ctx* ctx, const hg_pk* pk, const Witness& w, double* w
 void values_free(hg_values* v);
 ProveResult prove_resident(hg_ctx* ctx, const hg_pk* pk, const hg_values* v);
 size_t prove_shard_begin(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int rank, int world);  // -> #E2 slots in ctx->h_res
+// the whole sharded proof with the exchange inside the library (comm.hip): begin -> RCCL all-reduce on the stream -> replay
+ProveResult prove_sharded(hg_ctx* ctx, const hg_pk* pk, const hg_values* v);
+void comm_unique_id(uint8_t out[128]);
+void comm_init(hg_ctx* ctx, const uint8_t id[128], int rank, int world);
+void comm_destroy(hg_ctx* ctx);
+void comm_allreduce_results(hg_ctx* ctx, size_t n_e2);
 void prove_shard_combine(hg_ctx* ctx, const u64* gathered, int world, size_t n_u64);
 ProveResult prove_shard_finish(hg_ctx* ctx);
 // Lasso node alone on a fresh transcript; claim_out = nu point coordinates then the value

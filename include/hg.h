@@ -62,6 +62,12 @@ int hg_device_count(void);
 hg_ctx* hg_create(int device_id);
 void hg_destroy(hg_ctx* ctx);
 
+/* Context options (nothing in the reference: its only knob is the rayon pool). name:
+ *   "one_stream"  value != 0: every launch on one stream (the default overlaps the Vanilla / FFT node reductions, the counter
+ *                 sorts and the openings with the Lasso node's critical path on a second stream); used to time kernels in isolation
+ * Returns 0, or -1 for an unknown name. */
+int hg_set_option(hg_ctx* ctx, const char* name, int64_t value);
+
 /* = `type Params = constants::SkEnc{N}_{K}x{bits}_65537` [REF bfv-gkr/src/test.rs:8] */
 int hg_params_builtin(uint32_t n, uint32_t k, hg_params* out);
 
@@ -122,6 +128,18 @@ int hg_prove_shard_begin(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int r
                          size_t* n_u64);
 int hg_prove_shard_combine(hg_ctx* ctx, const uint64_t* gathered /* world x n_u64, rank-major */, int world, size_t n_u64);
 int hg_prove_shard_finish(hg_ctx* ctx, uint8_t* proof, size_t cap, size_t* len, hg_timings* timings);
+
+/* The same with the exchange INSIDE the library: one process per GPU, each with its own context and a copy of the resident
+ * witness; one RCCL all-reduce per proof (each 64-bit lane as two 32-bit halves in 64-bit lanes, ncclSum, folded back mod p on
+ * the device; no host staging), enqueued on the prover stream behind the rank's last kernel. Nothing in the reference
+ * corresponds (single-process rayon); BASELINE config 4.
+ *   hg_comm_unique_id: rank 0 obtains the 128-byte RCCL id and hands it to the other ranks out of band (any byte channel);
+ *   hg_comm_init:      collective over all `world` ranks (ncclCommInitRank); world == 1 is allowed (single-rank communicator);
+ *   hg_prove_sharded:  collective; every rank returns the identical proof bytes. */
+int hg_comm_unique_id(uint8_t out[128]);
+int hg_comm_init(hg_ctx* ctx, const uint8_t id[128], int rank, int world);
+int hg_comm_destroy(hg_ctx* ctx);
+int hg_prove_sharded(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, uint8_t* proof, size_t cap, size_t* len, hg_timings* timings);
 
 /* = circuit.evaluate (host part of witness generation) [REF sk_encryption_circuit.rs:442]:
  *   copies out the Lasso node's input table (2^nu) and the `sum` node output (k*2^L). Host only. */

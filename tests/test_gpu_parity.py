@@ -237,6 +237,29 @@ def test_sharded_single_proof_reassembles_bit_exact(ctx, n, k, world):
     pk.free()
 
 
+def test_library_collective_single_rank_communicator(ctx):
+    """hg_comm_init / hg_prove_sharded with a one-rank RCCL communicator (the only size a one-GPU box offers): the limb-split
+    kernel, ncclAllReduce on the prover stream and the fold-back kernel run for real and must leave the proof unchanged."""
+    n, k = 4096, 2
+    bfv = hg.BfvEncrypt.new(n, k)
+    pk = bfv.setup(ctx)
+    w = hg.Witness.synthetic(bfv.params, 0x4752454330 + n)
+    vals = hg.witness_gen(ctx, pk, w)
+    out = hg.ProofBuffer()
+    ref = hg.prove_resident(ctx, pk, vals, out).bytes()
+    with pytest.raises(hg.HgError, match="no communicator"):
+        hg.prove_sharded(ctx, pk, vals, out)
+    hg.comm_init(ctx, hg.comm_unique_id(), 0, 1)
+    with pytest.raises(hg.HgError, match="already has a communicator"):
+        hg.comm_init(ctx, hg.comm_unique_id(), 0, 1)
+    for _ in range(2):
+        assert hg.prove_sharded(ctx, pk, vals, out).bytes() == ref
+    hg.comm_destroy(ctx)
+    assert hg.prove_resident(ctx, pk, vals, out).bytes() == ref
+    vals.free()
+    pk.free()
+
+
 def test_bench_sharded_two_processes_on_one_gpu():
     """The N>1 bench path end to end with two real processes (gloo all-reduce through host tensors, both ranks on
     device 0): rendezvous, per-rank job ownership, the all-reduce, replay; bench.py itself asserts that the sharded
