@@ -38,7 +38,7 @@ class HgKernelStat(C.Structure):
 EXPORTS = [
     "hg_last_error", "hg_device_count", "hg_create", "hg_destroy", "hg_set_option", "hg_params_builtin", "hg_setup", "hg_pk_free",
     "hg_pk_lasso_layout", "hg_pk_info", "hg_witness_from_json", "hg_witness_synthetic", "hg_witness_from_arrays",
-    "hg_witness_get", "hg_witness_free", "hg_prove", "hg_verify", "hg_witness_gen", "hg_values_free", "hg_values_get", "hg_comm_unique_id", "hg_comm_init", "hg_comm_destroy", "hg_prove_sharded", "hg_prove_shard_begin", "hg_prove_shard_combine", "hg_prove_shard_finish", "hg_prove_resident", "hg_circuit_eval", "hg_lasso_prove", "hg_lasso_prove_at", "hg_lasso_num_challenges", "hg_sumcheck", "hg_mle_eval",
+    "hg_witness_get", "hg_witness_free", "hg_prove", "hg_verify", "hg_prove_mode", "hg_prove_resident_mode", "hg_verify_mode", "hg_witness_gen", "hg_values_free", "hg_values_get", "hg_comm_unique_id", "hg_comm_init", "hg_comm_destroy", "hg_prove_sharded", "hg_prove_shard_begin", "hg_prove_shard_combine", "hg_prove_shard_finish", "hg_prove_resident", "hg_circuit_eval", "hg_lasso_prove", "hg_lasso_prove_at", "hg_lasso_num_challenges", "hg_sumcheck", "hg_mle_eval",
     "hg_ntt", "hg_challenges", "hg_challenges_bn254", "hg_bn254_field_op", "hg_sumcheck_bn254", "hg_grand_product_bn254", "hg_lasso_prove_bn254", "hg_witness_from_json_bn254", "hg_circuit_eval_bn254", "hg_prove_bn254", "hg_verify_bn254", "hg_mle_eval_bn254", "hg_ntt_bn254", "hg_profile", "hg_profile_select", "hg_profile_reset", "hg_profile_get",
 ]
 
@@ -401,11 +401,17 @@ class BfvEncrypt:
     def get_inputs(self, path):
         return Witness.from_json(self.params, path)
 
-    def prove(self, ctx, pk, witness, cap=1 << 24):
+    def prove(self, ctx, pk, witness, cap=1 << 24, mode=0):
+        """BfvEncrypt::prove; mode != 0: hg_prove_mode (bit 0 absorbing transcript, bit 1 extension-field memory checking)."""
         buf = (C.c_uint8 * cap)()
         ln = C.c_size_t(0)
         tm = HgTimings()
-        _check(lib().hg_prove(ctx.h, pk.h, witness.h, buf, cap, C.byref(ln), C.byref(tm)))
+        L = lib()
+        if mode:
+            L.hg_prove_mode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(HgTimings)]
+            _check(L.hg_prove_mode(ctx.h, pk.h, witness.h, mode, buf, cap, C.byref(ln), C.byref(tm)))
+        else:
+            _check(L.hg_prove(ctx.h, pk.h, witness.h, buf, cap, C.byref(ln), C.byref(tm)))
         return C.string_at(buf, ln.value), {f: getattr(tm, f) for f, _ in HgTimings._fields_}
 
 
@@ -455,6 +461,14 @@ class ProofBuffer:
 
 def prove_resident(ctx, pk, values, out):
     _check(lib().hg_prove_resident(ctx.h, pk.h, values.h, out.buf, out.cap, C.byref(out.len), C.byref(out.tm)))
+    return out
+
+
+def prove_resident_mode(ctx, pk, values, out, mode):
+    """hg_prove_resident_mode: the round-by-round prover of the f-4 protocol modes on resident node tables."""
+    L = lib()
+    L.hg_prove_resident_mode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(HgTimings)]
+    _check(L.hg_prove_resident_mode(ctx.h, pk.h, values.h, mode, out.buf, out.cap, C.byref(out.len), C.byref(out.tm)))
     return out
 
 
@@ -514,9 +528,11 @@ def challenges_bn254(n):
     return Context._fr_unpack(out)
 
 
-def verify(pk, witness, proof):
-    """BfvEncrypt::verify [REF sk_encryption_circuit.rs:462-517]: (accepted, reason)."""
-    rc = lib().hg_verify(pk.h, witness.h, proof, len(proof))
+def verify(pk, witness, proof, mode=0):
+    """BfvEncrypt::verify [REF sk_encryption_circuit.rs:462-517]: (accepted, reason). mode: see hg_verify_mode."""
+    L = lib()
+    L.hg_verify_mode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_char_p, C.c_size_t]
+    rc = L.hg_verify_mode(pk.h, witness.h, mode, proof, len(proof)) if mode else L.hg_verify(pk.h, witness.h, proof, len(proof))
     if rc < 0:
         raise HgError(lib().hg_last_error().decode())
     return rc == 0, ("" if rc == 0 else lib().hg_last_error().decode())

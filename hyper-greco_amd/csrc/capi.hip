@@ -464,6 +464,48 @@ int hg_prove(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, uint8_t* proof, 
     HG_CATCH(-1)
 }
 
+int hg_prove_resident_mode(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int mode, uint8_t* proof, size_t cap, size_t* len, hg_timings* timings) {
+    HG_TRY
+    if (!ctx || !pk || !v || !pk->ctx || !proof || !len) throw Error("hg_prove_resident_mode: needs a device context, a device prover key and resident values");
+    double t0 = now_ms_capi();
+    ProveResult r = prove_resident_mode(ctx, pk, v, mode);
+    if (timings) { memset(timings, 0, sizeof(*timings)); timings->prove_ms = r.prove_ms; timings->gpu_ms = r.gpu_ms; timings->total_ms = now_ms_capi() - t0; timings->enqueue_ms = r.enqueue_ms; timings->sync_ms = r.sync_ms; timings->replay_ms = r.replay_ms; }
+    *len = r.proof.size();
+    if (r.proof.size() > cap) throw Error("proof buffer too small");
+    memcpy(proof, r.proof.data(), r.proof.size());
+    return 0;
+    HG_CATCH(-1)
+}
+int hg_prove_mode(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, int mode, uint8_t* proof, size_t cap, size_t* len, hg_timings* timings) {
+    HG_TRY
+    if (!ctx || !pk || !w || !proof || !len) throw Error("hg_prove_mode: null argument");
+    if (!pk->ctx) throw Error("hg_prove_mode: host-only prover key (created without a context)");
+    check_witness(pk, w, "hg_prove_mode");
+    double t0 = now_ms_capi();
+    double wm = 0, um = 0;
+    hg_values* v = witness_gen(ctx, pk, w->w, &wm, &um);
+    ProveResult r;
+    try { r = prove_resident_mode(ctx, pk, v, mode); } catch (...) { values_free(v); throw; }
+    values_free(v);
+    if (timings) { memset(timings, 0, sizeof(*timings)); timings->witness_ms = wm; timings->upload_ms = um; timings->prove_ms = r.prove_ms; timings->gpu_ms = r.gpu_ms; timings->total_ms = now_ms_capi() - t0; timings->enqueue_ms = r.enqueue_ms; timings->sync_ms = r.sync_ms; timings->replay_ms = r.replay_ms; }
+    *len = r.proof.size();
+    if (r.proof.size() > cap) throw Error("proof buffer too small");
+    memcpy(proof, r.proof.data(), r.proof.size());
+    return 0;
+    HG_CATCH(-1)
+}
+int hg_verify_mode(const hg_pk* pk, const hg_witness* w, int mode, const uint8_t* proof, size_t len) {
+    HG_TRY
+    if (!pk || !w || !proof) throw Error("hg_verify_mode: null argument");
+    if (mode < 0 || mode > 3) throw Error("hg_verify_mode: unknown mode bits");
+    check_witness(pk, w, "hg_verify_mode");
+    std::string why = verify_proof(pk->params, pk->lasso, pk->circuit, w->w, proof, len, mode);
+    if (why.empty()) return 0;
+    g_last_error = why;
+    return 1;
+    HG_CATCH(-1)
+}
+
 int hg_verify(const hg_pk* pk, const hg_witness* w, const uint8_t* proof, size_t len) {
     HG_TRY
     if (!pk || !w || !proof) throw Error("hg_verify: null argument");

@@ -64,7 +64,7 @@ void keccak256(const uint8_t* data, size_t len, uint8_t out[32]) {
 }
 
 // fe_mod_from_le_bytes (transcript.rs:202): 256-bit little-endian integer mod p
-static u64 felt_from_hash(const uint8_t h[32]) {
+u64 felt_from_hash(const uint8_t h[32]) {
     u64 limb[4];
     memcpy(limb, h, 32);
     u64 acc = 0;

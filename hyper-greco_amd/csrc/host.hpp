@@ -29,6 +29,35 @@ struct Error : std::runtime_error {
 // process-wide; `ChallengeSource` is the seam where an absorbing transcript would plug in.
 void keccak256(const uint8_t* data, size_t len, uint8_t out[32]);
 const u64* challenge_chain(size_t n_base);  // pointer to >= n_base cached base-field challenges
+u64 felt_from_hash(const uint8_t h[32]);    // fe_mod_from_le_bytes (transcript.rs:202): 256-bit little-endian integer mod p
+
+// The transcript with its hash state kept explicitly: the bytes absorbed since the last squeeze (H::update appends;
+// squeeze_challenge = finalize_fixed_reset, then update(hash), transcript.rs:198-203). With `absorb` off nothing but the
+// previous hash is ever in the state and the challenges are the fixed chain above. With it on, write_felt also hashes the
+// element the way the in-tree plonkish-trait writer of the same struct does (common_field_element -> update(to_repr),
+// transcript.rs:205-208, 224-233): SURVEY.md 8(f) f-4.
+struct FsTranscript {
+    bool absorb = false;
+    std::vector<uint8_t> pending;
+    std::vector<uint8_t> bytes;  // the proof stream
+    u64 squeeze_f() {
+        uint8_t h[32];
+        keccak256(pending.data(), pending.size(), h);
+        pending.assign(h, h + 32);
+        return felt_from_hash(h);
+    }
+    E2 squeeze() { u64 a = squeeze_f(); u64 b = squeeze_f(); return e2(a, b); }
+    void write_f(u64 a) {
+        if (absorb) { uint8_t le[8]; memcpy(le, &a, 8); pending.insert(pending.end(), le, le + 8); }
+        u64 be = __builtin_bswap64(a);
+        size_t at = bytes.size();
+        bytes.resize(at + 8);
+        memcpy(bytes.data() + at, &be, 8);
+    }
+    void write_e(E2 a) { write_f(a.c0); write_f(a.c1); }
+    // verifier side: read_felt absorbs what it read (transcript.rs:210-222)
+    void absorb_read(u64 a) { if (absorb) { uint8_t le[8]; memcpy(le, &a, 8); pending.insert(pending.end(), le, le + 8); } }
+};
 
 struct ChallengeSource {
     size_t pos = 0;  // base-field challenges consumed so far
@@ -138,7 +167,7 @@ HCircuit build_circuit(const Params& p, const LassoPlan& lp);
 // host witness generation = Circuit::evaluate (sk_encryption_circuit.rs:442); returns one table per node
 std::vector<std::vector<u64>> circuit_evaluate(const HCircuit& c, const Params& p, const Witness& w);
 // BfvEncrypt::verify on the host; "" = accept, otherwise the rejection reason (verifier.cpp)
-std::string verify_proof(const Params& p, const LassoPlan& lp, const HCircuit& c, const Witness& w, const uint8_t* proof, size_t len);
+std::string verify_proof(const Params& p, const LassoPlan& lp, const HCircuit& c, const Witness& w, const uint8_t* proof, size_t len, int mode = 0);
 // the same over bn256::Fr (F = E = Fr, 32-byte proof elements): the bn254 test family
 std::string verify_proof_bn254(const Params& p, const LassoPlan& lp, const HCircuit& c, const Witness& w, const uint8_t* proof, size_t len);
 void ntt_host(u64* a, int log2n, bool inverse);  // in place, natural order

@@ -118,6 +118,9 @@ struct ProveResult {
 hg_values* witness_gen(hg_ctx* ctx, const hg_pk* pk, const Witness& w, double* witness_ms, double* upload_ms);
 void values_free(hg_values* v);
 ProveResult prove_resident(hg_ctx* ctx, const hg_pk* pk, const hg_values* v);
+// the same in a protocol mode of SURVEY.md 8(f) f-4 (bit 0 absorbing transcript, bit 1 extension-field memory checking):
+// round-by-round prover (prover_seq.hip); mode 0 = prove_resident
+ProveResult prove_resident_mode(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int mode);
 size_t prove_shard_begin(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int rank, int world);  // -> #E2 slots in ctx->h_res
 // the whole sharded proof with the exchange inside the library (comm.hip): begin -> RCCL all-reduce on the stream -> replay
 ProveResult prove_sharded(hg_ctx* ctx, const hg_pk* pk, const hg_values* v);

@@ -54,9 +54,11 @@ struct GlField {
         }
         return e2(c[0], c[1]);
     }
-    struct Chal {
-        ChallengeSource src;
-        E squeeze() { return src.squeeze(); }
+    struct Chal {  // hash state kept explicitly (host.hpp FsTranscript): the fixed chain, or - mode bit 0 - absorbing what is read
+        FsTranscript t;
+        E squeeze() { return t.squeeze(); }
+        void absorb(E v) { t.absorb_read(v.c0); t.absorb_read(v.c1); }  // read_felt of an absorbing transcript (transcript.rs:210-222)
+        void set_mode(int mode) { t.absorb = (mode & 1) != 0; }
     };
 };
 
@@ -101,6 +103,8 @@ struct BnField {  // elements in Montgomery form
     struct Chal {  // c_j = LE(Keccak^j("")) mod r (transcript.rs:146-157, 198-203); one element per squeeze (E = F)
         uint8_t h[32];
         Chal() { keccak256(nullptr, 0, h); }
+        void absorb(E) {}
+        void set_mode(int mode) { if (mode != 0) throw Reject("bn254: protocol modes are implemented for the Goldilocks family only"); }
         E squeeze() {
             bn::Fr v;
             memcpy(v.l, h, 32);
@@ -143,7 +147,8 @@ template <class F> struct Verifier {
     struct Claim { std::vector<E> point; E value; };
     ProofBytes bytes;
     typename F::Chal ch;
-    E read_e() { return F::read(bytes); }
+    bool ext_memcheck = false;  // mode bit 1: gamma, tau stay in E (prover.rs:36-39 truncates them; README.md:108)
+    E read_e() { E v = F::read(bytes); ch.absorb(v); return v; }
     std::vector<E> read_es(size_t n) { std::vector<E> v(n); for (auto& x : v) x = read_e(); return v; }
     std::vector<E> squeeze_n(size_t n) { std::vector<E> v(n); for (auto& x : v) x = ch.squeeze(); return v; }
 
@@ -218,7 +223,8 @@ template <class F> struct Verifier {
         std::vector<E> r = squeeze_n(lp.nu);
         E claimed = read_e();
         sumcheck(2, lp.nu, claimed);  // collation: final evaluation not checked by the reference either (lasso.rs:129-130)
-        const E gamma = F::base0(ch.squeeze()), tau = F::base0(ch.squeeze()), gamma2 = F::mul(gamma, gamma);  // verifier.rs:139-140
+        const E gamma_e = ch.squeeze(), tau_e = ch.squeeze();
+        const E gamma = ext_memcheck ? gamma_e : F::base0(gamma_e), tau = ext_memcheck ? tau_e : F::base0(tau_e), gamma2 = F::mul(gamma, gamma);  // verifier.rs:139-140
         auto hash = [&](E a, E v, E t) { return F::sub(F::add(F::add(a, F::mul(v, gamma)), F::mul(t, gamma2)), tau); };
         const int A = lp.alpha;
         auto rw = grand_product(lp.nu, 2 * A);
@@ -326,11 +332,13 @@ template <class F> struct Verifier {
 
 
 template <class F>
-static std::string verify_impl(const Params& p, const LassoPlan& lp, const HCircuit& c, const Witness& w, const uint8_t* proof, size_t len) {
+static std::string verify_impl(const Params& p, const LassoPlan& lp, const HCircuit& c, const Witness& w, const uint8_t* proof, size_t len, int mode) {
     typedef typename F::E E;
     typedef typename Verifier<F>::Claim Claim;
     try {
         Verifier<F> V{ProofBytes{proof, len}, typename F::Chal{}};
+        V.ch.set_mode(mode);
+        V.ext_memcheck = (mode & 2) != 0;
         std::vector<E> point = V.squeeze_n(p.ct0is_log2());         // sk_encryption_circuit.rs:482
         E value = mle_eval<F>(w.ct0is.data(), point);               // :495
         std::vector<std::vector<Claim>> claims(c.nodes.size());
@@ -368,11 +376,11 @@ static std::string verify_impl(const Params& p, const LassoPlan& lp, const HCirc
 }  // namespace
 
 // return "" on accept, the rejection reason otherwise
-std::string verify_proof(const Params& p, const LassoPlan& lp, const HCircuit& c, const Witness& w, const uint8_t* proof, size_t len) {
-    return verify_impl<GlField>(p, lp, c, w, proof, len);
+std::string verify_proof(const Params& p, const LassoPlan& lp, const HCircuit& c, const Witness& w, const uint8_t* proof, size_t len, int mode) {
+    return verify_impl<GlField>(p, lp, c, w, proof, len, mode);
 }
 std::string verify_proof_bn254(const Params& p, const LassoPlan& lp, const HCircuit& c, const Witness& w, const uint8_t* proof, size_t len) {
-    return verify_impl<BnField>(p, lp, c, w, proof, len);
+    return verify_impl<BnField>(p, lp, c, w, proof, len, 0);
 }
 
 }  // namespace hg

@@ -104,6 +104,18 @@ int hg_prove(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, uint8_t* proof, 
  *   Works with a host-only key (hg_setup(NULL, ..)). */
 int hg_verify(const hg_pk* pk, const hg_witness* w, const uint8_t* proof, size_t len);
 
+/* The same pair in a protocol mode that FIXES the reference's two known soundness gaps. mode bits:
+ *   1  absorbing transcript: write_felt / read_felt also hash the element - the rule of the in-tree plonkish-trait writer of
+ *      the same struct [REF bfv-gkr/src/transcript.rs:205-208, 224-233]; the gkr-trait writer the prover uses does not
+ *      [REF :146-157, 180-196], which leaves every challenge independent of the proof;
+ *   2  extension-field memory checking: gamma, tau are used as E elements, not truncated to base limb 0
+ *      [REF lasso/src/memory_checking/prover.rs:36-39; README.md:108 "Known issues"].
+ * mode 0 = hg_prove / hg_verify (the reference as it is, bit-exact). Other modes are Goldilocks only and run the round-by-round
+ * prover (one device synchronisation per sum-check round; timings->sync_ms then holds the NUMBER of synchronisations). */
+int hg_prove_mode(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, int mode, uint8_t* proof, size_t cap, size_t* len, hg_timings* timings);
+int hg_prove_resident_mode(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int mode, uint8_t* proof, size_t cap, size_t* len, hg_timings* timings);
+int hg_verify_mode(const hg_pk* pk, const hg_witness* w, int mode, const uint8_t* proof, size_t len);
+
 /* The two halves of hg_prove, split where the reference splits its spans:
  *   hg_witness_gen   = "wintess gen": circuit.evaluate(inputs) [REF sk_encryption_circuit.rs:439-442] ON THE DEVICE: the
  *                      3+2k+1 input tables are uploaded, the 2k+1 size-2^L NTTs (FFT -> pointwise mul -> IFFT) and

@@ -23,6 +23,15 @@ def ctx():
     c.close()
 
 
+def _first_diff(a, b, nbytes=32):
+    if len(a) != len(b):
+        return "lengths %d / %d bytes" % (len(a), len(b))
+    for i in range(0, len(a), nbytes):
+        if a[i:i + nbytes] != b[i:i + nbytes]:
+            return "first differing element %d of %d" % (i // nbytes, len(a) // nbytes)
+    return "identical"
+
+
 def rand_f(rng, n):
     edge = [0, 1, P - 1, P - 2, 0xFFFFFFFF, 0x100000000, 0xFFFFFFFF00000000]
     v = [rng.randrange(P) for _ in range(n)]
@@ -234,6 +243,49 @@ def test_sharded_single_proof_reassembles_bit_exact(ctx, n, k, world):
     got = hg.prove_shard_finish(ctx, out).bytes()
     assert got == ref
     vals.free()
+    pk.free()
+
+
+@pytest.mark.parametrize("n,k,bits", FIX)
+@pytest.mark.parametrize("mode", [1, 2, 3])
+def test_protocol_modes_bit_exact_against_the_oracle(ctx, n, k, bits, mode):
+    """absorbing transcript (bit 0) and extension-field memory checking (bit 1). The round-by-round HIP prover
+    (hg_prove_mode) must produce the oracle's transcript in the same mode byte for byte - every challenge now depends on every
+    earlier message, so one wrong round sum anywhere changes everything after it - and both verifiers accept it in that mode only."""
+    bfv = hg.BfvEncrypt.new(n, k)
+    pk = bfv.setup(ctx)
+    w = bfv.get_inputs(os.path.join(orclib.GOLDEN, f"sk_enc_{n}_{k}x{bits}_65537.json"))
+    proof, tm = bfv.prove(ctx, pk, w, mode=mode)
+    p = orclib.params(n, k)
+    inp = orclib.Inputs(w.arrays())
+    ref, _ = orclib.prove_f("goldilocks", p, inp, threads=8, mode=mode)
+    assert proof == ref, _first_diff(proof, ref, 16)
+    base, _ = bfv.prove(ctx, pk, w)
+    assert proof != base and len(proof) == len(base)
+    assert orclib.verify_f("goldilocks", p, inp, proof, threads=8, mode=mode)[0]
+    assert hg.verify(pk, w, proof, mode=mode) == (True, "")
+    assert not hg.verify(pk, w, proof, mode=0)[0]
+    bad = bytearray(proof)
+    bad[len(bad) // 2] ^= 1
+    assert not hg.verify(pk, w, bytes(bad), mode=mode)[0]
+    print("mode %d n=%d: %.1f ms, %d synchronisations" % (mode, n, tm["prove_ms"], int(tm["sync_ms"])))
+    pk.free()
+
+
+def test_protocol_modes_at_the_headline_size(ctx):
+    """The same at n=32768 k=16 (mode 3 = both fixes): bit-exact against the oracle, accepted by both verifiers."""
+    n, k = 32768, 16
+    bfv = hg.BfvEncrypt.new(n, k)
+    pk = bfv.setup(ctx)
+    w = hg.Witness.synthetic(bfv.params, 0x4752454330 + n)
+    proof, tm = bfv.prove(ctx, pk, w, mode=3)
+    p = orclib.params(n, k)
+    inp = orclib.Inputs(w.arrays())
+    threads = min(64, os.cpu_count() or 8)
+    ref, _ = orclib.prove_f("goldilocks", p, inp, threads=threads, mode=3)
+    assert proof == ref, _first_diff(proof, ref, 16)
+    assert hg.verify(pk, w, proof, mode=3) == (True, "")
+    print("mode 3 n=32768 k=16: prove %.1f ms, %d synchronisations" % (tm["prove_ms"], int(tm["sync_ms"])))
     pk.free()
 
 
@@ -533,15 +585,6 @@ def test_bn254_prove_synthetic_k2_accepted_by_the_oracle_verifier(ctx):
     assert G.verify(orclib.constants(n, k), inputs, ct0is, _elems(proof), chal, lambda e, c: verify_fn(e, c, layout))
     assert hg.verify_bn254(pk, w, proof) == (True, "")
     assert not hg.verify_bn254(pk, hg.Witness.synthetic(bfv.params, 78), proof)[0]   # another witness: input claims fail
-
-
-def _first_diff(a, b, nbytes=32):
-    if len(a) != len(b):
-        return "lengths %d / %d bytes" % (len(a), len(b))
-    for i in range(0, len(a), nbytes):
-        if a[i:i + nbytes] != b[i:i + nbytes]:
-            return "first differing element %d of %d" % (i // nbytes, len(a) // nbytes)
-    return "identical"
 
 
 @pytest.mark.parametrize("n,k", [(1024, 1), (2048, 1), (4096, 2), (8192, 4), (16384, 8), (32768, 16)])
