@@ -28,11 +28,11 @@ void* hg_ctx::alloc(size_t bytes) {
     if (bytes == 0) bytes = 256;
     auto note = [this] { size_t u = 0; for (auto& c : chunks) u += c.used; arena_high = std::max(arena_high, u); };
     for (auto& c : chunks)
-        if (c.cap - c.used >= bytes) { void* p = c.p + c.used; c.used += bytes; note(); return p; }
+        if (c.cap - c.used >= bytes) { void* p = c.p + c.used; c.used += bytes; c.high = std::max(c.high, c.used); note(); return p; }
     size_t cap = std::max<size_t>(bytes, (size_t)512 << 20);
     char* p = nullptr;
     hip_check(hipMalloc((void**)&p, cap), "hipMalloc(arena chunk)");
-    chunks.push_back({p, cap, bytes});
+    chunks.push_back({p, cap, bytes, bytes});
     arena_total += cap;
     note();
     return p;
@@ -44,6 +44,9 @@ std::vector<size_t> hg_ctx::arena_mark() const {
 }
 void hg_ctx::arena_rewind(const std::vector<size_t>& mark) {
     for (size_t i = 0; i < chunks.size(); i++) chunks[i].used = i < mark.size() ? mark[i] : 0;
+}
+void hg_ctx::arena_skip_to_high() {
+    for (auto& c : chunks) c.used = std::max(c.used, c.high);
 }
 void hg_ctx::arena_reset() {
     // coalesce into one chunk once the high-water mark is known, so later proves never call hipMalloc
@@ -57,11 +60,11 @@ void hg_ctx::arena_reset() {
         size_t cap = used + used / 8 + ((size_t)64 << 20);
         char* p = nullptr;
         hip_check(hipMalloc((void**)&p, cap), "hipMalloc(arena)");
-        chunks.push_back({p, cap, 0});
+        chunks.push_back({p, cap, 0, 0});
         arena_total = cap;
         arena_high = 0;
     }
-    for (auto& c : chunks) c.used = 0;
+    for (auto& c : chunks) { c.used = 0; c.high = 0; }
     stage_used = 0;
     bn_res_used = 0;
 }

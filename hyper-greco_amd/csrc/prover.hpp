@@ -33,7 +33,7 @@ struct hg_ctx {
     bool one_stream = false;  // keep every launch on `stream` (per-kernel timings without cross-stream interference)
     int mode = 0;             // protocol mode of the next proves: bit 0 absorbing transcript, bit 1 extension-field memory checking
     // bump arena: chunks are kept across proves, offsets reset per prove
-    struct Chunk { char* p; size_t cap, used; };
+    struct Chunk { char* p; size_t cap, used; size_t high = 0; };  // high: largest `used` since the last reset
     std::vector<Chunk> chunks;
     size_t arena_total = 0;
     void* alloc(size_t bytes);
@@ -43,6 +43,9 @@ struct hg_ctx {
     // (single stream: later users of the recycled bytes are ordered after the earlier ones)
     std::vector<size_t> arena_mark() const;
     void arena_rewind(const std::vector<size_t>& mark);
+    // moves every chunk's offset to its high-water mark: what is allocated next aliases nothing handed out since the last reset,
+    // released or not (needed when a second stream may still be working on released scopes)
+    void arena_skip_to_high();
     size_t arena_high = 0;  // high-water mark since the last coalesce
     // challenge chain in HBM (as E2 pairs)
     hg::E2* d_chal = nullptr;
