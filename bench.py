@@ -33,6 +33,7 @@ CLASS_SYMBOL = {
     "sc_round<collation,ext>": "k_st_step<0, hg::E2>",
     "sc_round<collation,base>": "k_st_step<0, unsigned long>",
     "sc_round<prodsum>": "k_ps_one(",
+    "sc_round2<prodsum>": "k_ps_step2(",
 }
 PMC_TAG = "r02"  # profiles/<tag>_pmc_hbm_traffic.json, profiles/<tag>_bn254_pmc_sq.json: this round's committed counter passes
 PMC_CMD = ("rocprofv3 --pmc FETCH_SIZE -- python3 scripts/prove_once.py 32768 16 2 ; rocprofv3 --pmc WRITE_SIZE -- (same): separate passes, "
@@ -59,9 +60,8 @@ def pmc_traffic(cls, n, k):
 def cpu_baseline(n, k, seed, budget_s=40.0):
     """CPU baseline on this host's cores, same witness as the GPU run, GKR-prove span only.
     kind "reference": the reference's own rayon prover (needs cargo + network + $HYPER_GRECO: scripts/reference_baseline.py);
-    otherwise kind "port": the CPU oracle (this repo's restatement, OpenMP where the reference uses rayon). Method: one run per
-    thread count in {64, 128, 256} (the first also warms the page cache), then two more at the best count; value = median of the
-    three runs at the best count. Bounded: a small config is timed first and the largest config whose predicted time fits the
+    otherwise kind "port": the CPU oracle (this repo's restatement, OpenMP where the reference uses rayon). Method: the thread
+    count is chosen among {16, 32, 64, 128} on the small configuration, then 1 warm + 3 timed runs, median. Bounded: a small config is timed first and the largest config whose predicted time fits the
     budget is run (scaled by the ratio of Lasso rows, stated in `sample`)."""
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     try:
@@ -89,25 +89,26 @@ def cpu_baseline(n, k, seed, budget_s=40.0):
     def rows(nn, kk):
         return (kk + max(1, kk // 2) + 3) * 2 * nn
 
-    t_small = run(4096, 2, min(cores, 64))
+    # thread count: chosen on the small configuration (more threads than 128 thrash on this kind of host: a 256-thread run of
+    # n=16384 was measured at 294 s against 2.2 s with 64)
+    cands = sorted({min(cores, t) for t in (16, 32, 64, 128)})
+    run(4096, 2, cands[-1])  # warm the page cache / thread pool
+    sweep = {th: run(4096, 2, th) for th in cands}
+    best = min(sweep, key=sweep.get)
+    t_small = sweep[best]
     ladder = [(32768, 16), (16384, 8), (8192, 4), (4096, 2)]
     for nn, kk in ladder:
-        predicted = 5 * t_small * rows(nn, kk) / rows(4096, 2) / 1000.0   # five runs
+        predicted = 4 * 1.6 * t_small * rows(nn, kk) / rows(4096, 2) / 1000.0   # four runs; large tables scale a little worse than rows
         if predicted <= budget_s or (nn, kk) == (4096, 2):
-            sweep = {}
-            for th in sorted({min(cores, t) for t in (64, 128, 256)}):
-                sweep[th] = run(nn, kk, th)
-            best = min(sweep, key=sweep.get)
-            runs = [sweep[best]] + [run(nn, kk, best) for _ in range(2)]
+            runs = [run(nn, kk, best) for _ in range(4)][1:]   # 1 warm + 3 timed
             ms = statistics.median(runs)
             scale = rows(n, k) / rows(nn, kk)
-            sample = (f"oracle GKR prove at n={nn} k={kk}: one run per thread count {sorted(sweep)} (first = warm-up of the page cache), "
-                      f"best = {best} threads, median of 3 runs there")
+            sample = (f"oracle GKR prove at n={nn} k={kk}, {best} OpenMP threads (best of {cands} on n=4096 k=2), 1 warm + 3 timed runs, median")
             if scale != 1:
                 sample += f"; scaled x{scale:.2f} (Lasso rows ratio) to n={n} k={k}"
             return {"value": round(ms * scale, 3), "unit": "ms", "cores": best, "kind": "port", "sample": sample,
                     "measured_ms": round(ms, 3), "runs_ms": [round(r, 1) for r in runs],
-                    "thread_sweep_ms": {str(t): round(v, 1) for t, v in sweep.items()}, "host_cores": cores}
+                    "thread_sweep_ms_n4096": {str(t): round(v, 1) for t, v in sweep.items()}, "host_cores": cores}
     return None
 
 
@@ -227,12 +228,16 @@ def main():
     if shard:
         assert first == unsharded, "sharded proof differs from the single-GPU proof"
 
-    # which kernel class dominates? three untimed proves with events on every class
+    # which kernel class dominates? three untimed proves with events on every class, every launch on ONE stream (with the
+    # second stream active a class's event time also contains whatever shared the GPU with it)
+    ctx.set_option("one_stream", 1)
     ctx.profile(2)
     ctx.profile_reset()
     for _ in range(3):
         step()
     ctx.profile(0)
+    ctx.set_option("one_stream", 0)
+    step()
     DOMINANT = max((s for s in ctx.profile_get() if s["name"] in CLASS_SYMBOL and s["launches"]), key=lambda s: s["total_ms"])["name"]
     ctx.profile_select(DOMINANT)
     ctx.profile(1)  # HIP events around the dominant kernel class only
@@ -256,11 +261,14 @@ def main():
     dom = [s for s in ctx.profile_get() if s["name"] == DOMINANT][0]
     timed_launches = dom["launches"]
 
-    # one extra, untimed pass with events on every kernel class: the per-class breakdown
+    # one extra, untimed pass with events on every kernel class (one stream: isolated class times): the per-class breakdown
+    ctx.set_option("one_stream", 1)
+    step()
     ctx.profile(2)
     ctx.profile_reset()
     step()
     ctx.profile(0)
+    ctx.set_option("one_stream", 0)
     classes = {s["name"]: {"launches": s["launches"], "ms": round(s["total_ms"], 4), "algo_GB": round(s["algo_bytes"] / 1e9, 4)}
                for s in ctx.profile_get() if s["launches"]}
 

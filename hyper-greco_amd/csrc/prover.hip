@@ -185,7 +185,7 @@ struct Prover {
     ProofStream proof;
     std::vector<std::function<void()>> ops;  // transcript steps, replayed after the single synchronisation
     size_t res_used = 0;
-    int cls_gp_hash, cls_gp_base, cls_gp_ext, cls_gp_ext2, cls_col_ext2, cls_col_base, cls_col_ext, cls_ps, cls_reduce, cls_aux, cls_tree, cls_hash, cls_gather, cls_tail, cls_ps_tail;
+    int cls_gp_hash, cls_gp_base, cls_gp_ext, cls_gp_ext2, cls_col_ext2, cls_col_base, cls_col_ext, cls_ps, cls_ps2, cls_reduce, cls_aux, cls_tree, cls_hash, cls_gather, cls_tail, cls_ps_tail;
 
     // ---- single-proof sharding over `world` GPUs ---------------------------------------------------
     // Device jobs are independent, so a proof shards by JOB with no data-path collective inside
@@ -282,6 +282,7 @@ struct Prover {
         cls_col_ext = ctx->prof_class("sc_round<collation,ext>", false);
         cls_col_ext2 = ctx->prof_class("sc_round2<collation,ext>", false);
         cls_ps = ctx->prof_class("sc_round<prodsum>", false);
+        cls_ps2 = ctx->prof_class("sc_round2<prodsum>", false);
         cls_tail = ctx->prof_class("sc_tail<single-workgroup>", false);
         cls_ps_tail = ctx->prof_class("ps_tail<single-workgroup>", false);
         cls_reduce = ctx->prof_class("reduce_partials", false);
@@ -327,7 +328,9 @@ struct Prover {
     // the other, deepest layer first: job q with st_seq[q] = s > 0 gets its own first-round launch, in ascending s, before
     // the shared first-round launch of everything else; `st_after_seq` then builds the remaining (small) tree levels.
     std::vector<int> st_seq;
+    std::vector<double> st_fused_bytes;  // algorithmic bytes of the passes a job's first round absorbs (hash build, tree level)
     std::vector<std::function<void()>> st_after_seq;
+    double pending_fused_bytes = 0;      // set by the caller right before sc_stride (the hash build a hash-source job absorbs)
     std::vector<dev::ScatterEnt> scatter;  // locally produced scalars -> global result slots (batch-subset grand products)
 
     ScHandle sc_stride(int kind, const void* in, bool base, size_t in_stride, int ntab, int nvars, const dev::Powers& pw, E2* final_out,
@@ -339,6 +342,7 @@ struct Prover {
         h.sums_slot = slot((size_t)nvars * h.nv);
         const size_t N = (size_t)1 << nvars;
         if (!enqueue) {  // another rank runs this job: transcript bookkeeping only
+            pending_fused_bytes = 0;
             for (int i = 0; i < nvars; i++) h.rs.push_back(squeeze());
             return h;
         }
@@ -355,7 +359,15 @@ struct Prover {
         for (int i = 0; i < nvars; i++) h.rs.push_back(squeeze());
         if (nvars > 0)  // weight * r_0: the first round stores the weighted fold (kernels.hip)
             for (int i = 0; i < dev::PW_MAX; i++) J.pwr[i] = e2_mul(pw.v[i], h.rs[0]);
-        if (nvars > 0) { st_jobs.push_back(J); st_seq.push_back(seq); }
+        if (nvars > 0) {
+            st_jobs.push_back(J); st_seq.push_back(seq);
+            // a level-writing first round replaces prod_level on its input level: (nb rows of 2N entries) x 8 B x 1.5 (read +
+            // write), as prod_level is credited; the hash-source job's level 1 is credited with its write only, as the hash kernel
+            // it replaces was (round-1 accounting: the totals stay comparable)
+            double fused = next_level ? (double)(ntab / 2) * (double)(2 * N) * 8.0 * (hash_src ? 0.5 : 1.5) : 0.0;
+            st_fused_bytes.push_back(fused + pending_fused_bytes);
+            pending_fused_bytes = 0;
+        }
         return h;
     }
 
@@ -495,7 +507,9 @@ struct Prover {
                 double bytes = 0;
                 if (L.hash) {
                     const dev::StItem& it = L.items[o];
-                    bytes = round_bytes(st_jobs[it.job], 0);
+                    // algorithmic bytes: the sum-check round plus the passes this launch absorbs - the hash build
+                    // (dims, read_ts per chunk; E read, read / write hashes written per memory) and product-tree level 1
+                    bytes = round_bytes(st_jobs[it.job], 0) + st_fused_bytes[it.job];
                     ctx->prof_begin(cls_gp_hash, bytes);
                     dev::st_first_hash(st, d_jobs + it.job, d_items + offs[li] + o, grids[li][0], ctx->d_chal, partials, d_res());
                     ctx->prof_end();
@@ -519,6 +533,7 @@ struct Prover {
                         // algorithmic bytes in the per-round accounting of SURVEY.md 8(d): a fused launch is credited with both of
                         // its rounds although the intermediate folded tables never reach HBM
                         for (int k = 0; k < L.nrounds; k++) bytes += round_bytes(J, J.nvars - 1 - it.h_log2 + k);
+                        if (L.base && it.h_log2 == J.nvars - 1) bytes += st_fused_bytes[it.job];  // the tree level a first round also writes
                     }
                     const int grid = grids[li][o / MAX_BATCH];
                     int cls = L.kind == dev::SC_GRANDPROD ? (L.base ? cls_gp_base : (L.nrounds == 2 ? cls_gp_ext2 : cls_gp_ext)) : (L.base ? cls_col_base : (L.nrounds == 2 ? cls_col_ext2 : cls_col_ext));
@@ -532,6 +547,7 @@ struct Prover {
         if (st_before_gp) { st_before_gp(); st_before_gp = nullptr; }
         st_jobs.clear();
         st_seq.clear();
+        st_fused_bytes.clear();
         for (auto& f : st_after_seq) f();  // (no grand-product job was queued: nothing can depend on these, but keep the order)
         st_after_seq.clear();
         if (!scatter.empty()) {
@@ -638,7 +654,7 @@ struct Prover {
             dev::PsItem* d_items = ctx->alloc_n<dev::PsItem>(all_items.size());
             hip_check(hipMemcpyAsync(d_items, stage(all_items.data(), all_items.size() * sizeof(dev::PsItem)), all_items.size() * sizeof(dev::PsItem), hipMemcpyHostToDevice, st), "upload items");
             for (auto& L : launches) {
-                ctx->prof_begin(cls_ps, L.bytes);
+                ctx->prof_begin(L.two ? cls_ps2 : cls_ps, L.bytes);
                 dev::ps_round(st, L.two, d_jobs, d_items + L.off, L.cnt, L.grid, ctx->d_chal, partials, d_res());
                 ctx->prof_end();
             }
@@ -783,7 +799,8 @@ struct Prover {
     // `emit` > 0: tree levels 1 .. emit are written by the first rounds of the top `emit` layers (their products ARE the next
     // level), which therefore run one after the other before everything else; the remaining small levels follow them.
     GpOut grand_product(const u64* H, size_t len, int nb, const std::vector<int>& owner, const u64* lev1 = nullptr,
-                        const std::vector<int>* local = nullptr, bool p0_only = false, const dev::GpHashSrc* hash_src = nullptr, int emit = 0) {
+                        const std::vector<int>* local = nullptr, bool p0_only = false, const dev::GpHashSrc* hash_src = nullptr, int emit = 0,
+                        double hash_fused_bytes = 0) {
         int nv = 0;
         while (((size_t)1 << nv) < len) nv++;
         const int nl = local ? (int)local->size() : nb;  // rows actually held
@@ -873,6 +890,7 @@ struct Prover {
             const int seq = n >= nv - emit ? nv - n : 0;                    // first round launched alone, deepest layer first
             u64* nxt = seq ? lev_w[k + 1] : nullptr;                          // ... and writes tree level k + 1
             const dev::GpHashSrc* hs = (hash_src && k == 0) ? hash_src : nullptr;
+            if (hs) pending_fused_bytes = hash_fused_bytes;
             if (!local) sc = sc_stride(dev::SC_GRANDPROD, lev[k], true, h, 2 * nb, n, pw, d_res() + evals, mine(owner[n]), false, seq, nxt, hs);
             else {
                 // this rank's share of the batch: local pair li is global pair b = local[li], weight gamma^b
@@ -1004,6 +1022,7 @@ struct Prover {
             }
         });
         const dev::GpHashSrc* d_hash_src = nullptr;
+        double hash_build_bytes = 0;
         if (emit > 0) {
             std::vector<dev::GpHashMem> hm;
             auto row_of = [&](int pair) -> int {
@@ -1026,6 +1045,13 @@ struct Prover {
             dev::GpHashSrc* d_hs = ctx->alloc_n<dev::GpHashSrc>(1);
             hip_check(hipMemcpyAsync(d_hs, stage(&hs, sizeof(hs)), sizeof(hs), hipMemcpyHostToDevice, st), "upload hash sources");
             d_hash_src = d_hs;
+            // algorithmic bytes of the hash build this replaces (the accounting of lasso_hash_rw below): dim + read_ts per chunk in
+            // use, E read and read / write hash rows written per memory; level 1 is credited by sc_stride (next_level)
+            std::vector<char> chunk_used(4, 0);
+            for (auto& m : hm) chunk_used[m.chunk] = 1;
+            hash_build_bytes = 0;
+            for (int c = 0; c < 4; c++) if (chunk_used[c]) hash_build_bytes += (double)N * 8 * 2;
+            for (auto& m : hm) hash_build_bytes += (double)N * 8 * ((m.rd_row >= 0) + (m.wr_row >= 0) + 1);
         }
         u64* H1 = (any_gp1 && !emit) ? ctx->alloc_n<u64>((size_t)nrows * N) : nullptr;
         u64* L1 = (any_gp1 && !emit && gp_deepest(nu, gp1_owner) >= 1) ? ctx->alloc_n<u64>((size_t)nrows * (N / 2)) : nullptr;
@@ -1075,8 +1101,8 @@ struct Prover {
             ctx->prof_end();
         });
         mark("lasso: memory checking, grand product #1 over reads then writes (prover.rs:161-165)");
-        GpOut g1 = split ? grand_product(H1, N, 2 * G, gp1_owner, L1, &local_pairs, p0_only, d_hash_src, emit)
-                         : grand_product(H1, N, 2 * G, gp1_owner, L1, nullptr, false, d_hash_src, emit);  // reads then writes (prover.rs:161-165)
+        GpOut g1 = split ? grand_product(H1, N, 2 * G, gp1_owner, L1, &local_pairs, p0_only, d_hash_src, emit, hash_build_bytes)
+                         : grand_product(H1, N, 2 * G, gp1_owner, L1, nullptr, false, d_hash_src, emit, hash_build_bytes);  // reads then writes (prover.rs:161-165)
         mark("lasso: memory checking, grand product #2 over inits then finals (prover.rs:167-171)");
         GpOut g2{0};
         aux([&] { g2 = grand_product(H2, M, 2 * G, std::vector<int>(16, own_gp2)); });  // inits then finals (prover.rs:167-171); its tree on the second stream
