@@ -101,7 +101,11 @@ int hg_prove(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, uint8_t* proof, 
 
 /* = BfvEncrypt::verify [REF sk_encryption_circuit.rs:462-517] (host-side, like the reference's): the witness handle
  *   supplies the public inputs and ct0is. Returns 0 = accepted, 1 = rejected (reason via hg_last_error), < 0 = error.
- *   Works with a host-only key (hg_setup(NULL, ..)). */
+ *   Works with a host-only key (hg_setup(NULL, ..)).
+ *   NOTE: "accepted" means what the reference's verifier means, which is NOT soundness: the challenges are a fixed Keccak chain
+ *   independent of the proof bytes, gamma / tau are truncated to one base limb, the collation sum-check's final evaluation and
+ *   the multiset relation init * write == read * final between the two grand products are never checked, trailing bytes are
+ *   ignored. hg_verify_mode(.., 3, ..) closes the first two. */
 int hg_verify(const hg_pk* pk, const hg_witness* w, const uint8_t* proof, size_t len);
 
 /* The same pair in a protocol mode that FIXES the reference's two known soundness gaps. mode bits:
