@@ -36,7 +36,7 @@ class HgKernelStat(C.Structure):
 
 
 EXPORTS = [
-    "hg_last_error", "hg_device_count", "hg_create", "hg_destroy", "hg_set_option", "hg_params_builtin", "hg_setup", "hg_pk_free",
+    "hg_last_error", "hg_device_count", "hg_create", "hg_destroy", "hg_set_option", "hg_params_builtin", "hg_params_derive", "hg_grand_product", "hg_fold", "hg_setup", "hg_pk_free",
     "hg_pk_lasso_layout", "hg_pk_info", "hg_witness_from_json", "hg_witness_synthetic", "hg_witness_from_arrays",
     "hg_witness_get", "hg_witness_free", "hg_prove", "hg_verify", "hg_prove_mode", "hg_prove_resident_mode", "hg_verify_mode", "hg_witness_gen", "hg_values_free", "hg_values_get", "hg_comm_unique_id", "hg_comm_init", "hg_comm_destroy", "hg_prove_sharded", "hg_prove_shard_begin", "hg_prove_shard_combine", "hg_prove_shard_finish", "hg_prove_resident", "hg_circuit_eval", "hg_lasso_prove", "hg_lasso_prove_at", "hg_lasso_num_challenges", "hg_sumcheck", "hg_mle_eval",
     "hg_ntt", "hg_challenges", "hg_challenges_bn254", "hg_bn254_field_op", "hg_sumcheck_bn254", "hg_grand_product_bn254", "hg_lasso_prove_bn254", "hg_witness_from_json_bn254", "hg_circuit_eval_bn254", "hg_prove_bn254", "hg_verify_bn254", "hg_mle_eval_bn254", "hg_ntt_bn254", "hg_profile", "hg_profile_select", "hg_profile_reset", "hg_profile_get",
@@ -386,8 +386,8 @@ class ProverKey:
 class BfvEncrypt:
     """Mirror of `BfvEncrypt::<Params, K>` [REF sk_encryption_circuit.rs:300-523]."""
 
-    def __init__(self, n, k):  # = BfvEncrypt::<SkEnc{n}_{k}x.._65537, k>::new(k)
-        self.params = params_builtin(n, k)
+    def __init__(self, n, k=None):  # = BfvEncrypt::<SkEnc{n}_{k}x.._65537, k>::new(k); or BfvEncrypt(params) with a derived HgParams
+        self.params = n if isinstance(n, HgParams) else params_builtin(n, k)
 
     @classmethod
     def new(cls, n, k):
@@ -490,6 +490,45 @@ def prove_shard_combine(ctx, gathered, world):
 def prove_shard_finish(ctx, out):
     _check(lib().hg_prove_shard_finish(ctx.h, out.buf, out.cap, C.byref(out.len), C.byref(out.tm)))
     return out
+
+
+def params_derive(n, k, qis, t=65537):
+    """hg_params_derive: the constants emitter of scripts/circuit_sk.py:422-439 for ring degree n and moduli qis."""
+    p = HgParams()
+    arr = (C.c_uint64 * len(qis))(*qis)
+    L = lib()
+    L.hg_params_derive.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(HgParams)]
+    _check(L.hg_params_derive(n, k, arr, t, C.byref(p)))
+    return p
+
+
+def grand_product(ctx, tables, chain_skip=0, cap=1 << 22):
+    """hg_grand_product: prove_grand_product on base-field tables (numpy u64); -> (proof bytes, claims (nb x 2), point (nv x 2))."""
+    nb, ln = len(tables), tables[0].size
+    nv = ln.bit_length() - 1
+    tabs = [np.ascontiguousarray(t, dtype=np.uint64) for t in tables]
+    ptrs = (u64p * nb)(*[_ptr(t) for t in tabs])
+    buf = (C.c_uint8 * cap)()
+    n = C.c_size_t(0)
+    claims = np.zeros(2 * nb, dtype=np.uint64)
+    point = np.zeros(2 * nv, dtype=np.uint64)
+    L = lib()
+    L.hg_grand_product.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), u64p, u64p]
+    _check(L.hg_grand_product(ctx.h, nb, ln, ptrs, chain_skip, buf, cap, C.byref(n), _ptr(claims), _ptr(point)))
+    return C.string_at(buf, n.value), claims.reshape(nb, 2), point.reshape(nv, 2)
+
+
+def fold(ctx, table, is_base, r):
+    """hg_fold: fix_var on the lowest variable; table: numpy u64 (2^nv base values or 2^nv (c0, c1) pairs flattened)."""
+    t = np.ascontiguousarray(table, dtype=np.uint64)
+    n_el = t.size if is_base else t.size // 2
+    nv = n_el.bit_length() - 1
+    out = np.zeros(n_el, dtype=np.uint64)  # 2^(nv-1) pairs
+    rr = (C.c_uint64 * 2)(int(r[0]), int(r[1]))
+    L = lib()
+    L.hg_fold.argtypes = [C.c_void_p, u64p, C.c_size_t, C.c_int, C.POINTER(C.c_uint64), u64p]
+    _check(L.hg_fold(ctx.h, _ptr(t), nv, 1 if is_base else 0, rr, _ptr(out)))
+    return out.reshape(-1, 2)
 
 
 def comm_unique_id():

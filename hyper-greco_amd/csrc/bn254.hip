@@ -17,8 +17,8 @@
 #include <functional>
 #include <memory>
 #include <map>
-#include "bn254.cuh"
-#include "bn254_wide.cuh"
+#include "bn254_field.hpp"
+#include "bn254_wide.hpp"
 #include "host.hpp"
 #include "prover.hpp"
 #include "kernels.hpp"
@@ -74,7 +74,7 @@ __global__ void k_bn_binop(int op, size_t n, const Fr* __restrict__ a, const Fr*
     if (i >= n) return;
     Fr x = fr_to_mont(a[i]), y = fr_to_mont(b[i]);
     Fr r;
-    if (op == 3) r = fr_mul_wide(x, y);                       // column-accumulator product (bn254_wide.cuh)
+    if (op == 3) r = fr_mul_wide(x, y);                       // column-accumulator product (bn254_wide.hpp)
     else if (op == 4) {                                       // a b + a a + b b through one deferred reduction
         WCol w = wcol_zero();
         wcol_mac(w, x, y); wcol_mac(w, x, x); wcol_mac(w, y, y);
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_round(const Fr* __restrict__ in, 
 // Grand-product round of prove_grand_product, tuned: (a) the LEFT table of pair i enters the first round already multiplied by
 // its weight gamma^i (k_bn_weight_rows: two products per (pair, j), once), so no round needs weights and the folded left
 // tables stay weighted (the host divides the final left evaluations by gamma^i again); (b) the dot products over the pairs are
-// accumulated unreduced in column accumulators (bn254_wide.cuh) and Montgomery-reduced once per pair index j; (c) two lanes share
+// accumulated unreduced in column accumulators (bn254_wide.hpp) and Montgomery-reduced once per pair index j; (c) two lanes share
 // a pair index, one per table side (see the kernel): every table entry is loaded once, two accumulators per lane, two waves per
 // SIMD; (d) in small rounds the pairs are dealt round-robin to gy thread groups so that a round is not one long serial chain per
 // thread (Montgomery reduction is linear: every group reduces its own partial sums and multiplies by p_v itself).

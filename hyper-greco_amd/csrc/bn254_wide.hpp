@@ -1,6 +1,6 @@
-// Column-accumulator arithmetic for bn256::Fr on gfx950 (device only) - the 256-bit counterpart of gl_wide.cuh.
+// Column-accumulator arithmetic for bn256::Fr on gfx950 (device only) - the 256-bit counterpart of gl_wide.hpp.
 //
-// hipcc compiles the 4x64 CIOS product (bn254.cuh: fr_mul) to ~730 instructions: 132 v_mad_u64_u32, and around them carry
+// hipcc compiles the 4x64 CIOS product (bn254_field.hpp: fr_mul) to ~730 instructions: 132 v_mad_u64_u32, and around them carry
 // chains (v_addc_co), register moves and the s_nop slots of the VALU -> SGPR -> VALU carry hazard. Here a product is kept in
 // "columns" instead: with 32-bit limbs a_i, b_j the partial product a_i b_j is added by ONE v_mad_u64_u32 into the 64-bit
 // accumulator C[i+j] (weight 2^(32(i+j))), and the carry-out of that addition is banked by ONE v_addc_co_u32 in the counter
@@ -12,7 +12,7 @@
 // reduction, which works on the columns directly: limb i is made exact, m = limb * (-r^-1) mod 2^32, and m r is added with the
 // same mad/addc pairs. The asm blocks keep the gfx950 hazard distance themselves (four mads, then their four addc).
 #pragma once
-#include "bn254.cuh"
+#include "bn254_field.hpp"
 
 namespace hg {
 namespace bn {

@@ -590,6 +590,35 @@ int hg_sumcheck(hg_ctx* ctx, int kind, size_t nv, size_t ntab, const uint64_t* c
     HG_CATCH(-1)
 }
 
+int hg_grand_product(hg_ctx* ctx, size_t nb, size_t len, const uint64_t* const* tables, size_t chain_skip, uint8_t* proof, size_t cap,
+                     size_t* proof_len, uint64_t* claims2, uint64_t* point2) {
+    HG_TRY
+    if (!ctx || !tables || !proof || !proof_len) throw Error("hg_grand_product: null argument (a HIP device is required)");
+    std::vector<E2> claims, point;
+    std::vector<uint8_t> bytes = grand_product_on_tables(ctx, nb, len, tables, chain_skip, &claims, &point);
+    *proof_len = bytes.size();
+    if (bytes.size() > cap) throw Error("proof buffer too small");
+    memcpy(proof, bytes.data(), bytes.size());
+    if (claims2) for (size_t i = 0; i < claims.size(); i++) { claims2[2 * i] = claims[i].c0; claims2[2 * i + 1] = claims[i].c1; }
+    if (point2) for (size_t i = 0; i < point.size(); i++) { point2[2 * i] = point[i].c0; point2[2 * i + 1] = point[i].c1; }
+    return 0;
+    HG_CATCH(-1)
+}
+int hg_fold(hg_ctx* ctx, const uint64_t* table, size_t nv, int is_base, const uint64_t r2[2], uint64_t* out) {
+    HG_TRY
+    if (!ctx || !table || !r2 || !out) throw Error("hg_fold: null argument (a HIP device is required)");
+    fold_device(ctx, table, nv, is_base != 0, e2(r2[0], r2[1]), reinterpret_cast<E2*>(out));
+    return 0;
+    HG_CATCH(-1)
+}
+int hg_params_derive(uint32_t n, uint32_t k, const uint64_t* qis, uint64_t t, hg_params* out) {
+    HG_TRY
+    if (!qis || !out) throw Error("hg_params_derive: null argument");
+    params_derive(n, k, qis, t, out);
+    return 0;
+    HG_CATCH(-1)
+}
+
 int hg_mle_eval(hg_ctx* ctx, const uint64_t* table, size_t nv, const uint64_t* point, uint64_t out2[2]) {
     HG_TRY
     if (!ctx || !table || (nv && !point) || !out2) throw Error("hg_mle_eval: null argument (a HIP device is required)");

@@ -18,7 +18,7 @@
 // instructions (or wait states) in between; the compiler cannot see inside an asm block, so every block below
 // keeps that distance itself.
 #pragma once
-#include "gl.cuh"
+#include "gl_field.hpp"
 
 namespace hg {
 

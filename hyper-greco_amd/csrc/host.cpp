@@ -119,6 +119,61 @@ bool params_builtin(uint32_t n, uint32_t k, hg_params* out) {
 }
 
 
+// The constants emitter of scripts/circuit_sk.py (:80 k0i, :249 k1_bound, :296-297 r2i_bound, :334-337 r1i_bound, :422-439 the
+// emitted Rust constants). Python's `/` is true division to a double: int((q - 1) / 2) is the 53-bit rounding of (q-1)/2, which
+// is why the shipped R2 bounds are not exactly (q-1)/2; the R1 bound divides an exact big integer by q the same way.
+static u64 py_int_of_quotient(unsigned __int128 num, u64 den) {  // int(num / den) with num / den rounded to the nearest double
+    const unsigned __int128 q = num / den, rem = num % den;
+    if (q >= ((unsigned __int128)1 << 53)) {  // the quotient itself does not fit a double's mantissa: round it to 53 bits (ties to even)
+        int bits = 0;
+        for (unsigned __int128 t = q; t; t >>= 1) bits++;
+        const int drop = bits - 53;
+        unsigned __int128 m = q >> drop;
+        const unsigned __int128 lost = q & (((unsigned __int128)1 << drop) - 1), half = (unsigned __int128)1 << (drop - 1);
+        if (lost > half || (lost == half && (rem || (m & 1)))) m++;
+        return (u64)(m << drop);
+    }
+    // small quotient: the fraction rem / den only matters if it rounds the double up to the next integer
+    int bits = 0;
+    for (unsigned __int128 t = q; t; t >>= 1) bits++;
+    const int frac_bits = 53 - bits;  // bits of the fraction a double keeps
+    // rounds up to q + 1 iff 1 - rem/den <= 2^-(frac_bits + 1)
+    const unsigned __int128 gap = den - rem;
+    if (frac_bits < 126 && (gap << (frac_bits + 1)) <= (unsigned __int128)den && rem != 0) return (u64)q + 1;
+    return (u64)q;
+}
+static u64 inv_mod(u64 a, u64 m) {  // a^-1 mod m (extended Euclid), gcd(a, m) = 1
+    __int128 t = 0, nt = 1, r = m, nr = a % m;
+    while (nr != 0) {
+        __int128 qq = r / nr;
+        __int128 tmp = t - qq * nt; t = nt; nt = tmp;
+        tmp = r - qq * nr; r = nr; nr = tmp;
+    }
+    if (r != 1) throw Error("hg_params_derive: t is not invertible modulo a q_i");
+    if (t < 0) t += m;
+    return (u64)t;
+}
+void params_derive(uint32_t n, uint32_t k, const u64* qis, u64 t, hg_params* out) {
+    if (n < 2 || (n & (n - 1))) throw Error("hg_params_derive: n must be a power of two");
+    if (k < 1 || k > HG_MAX_K || (k & (k - 1))) throw Error("hg_params_derive: k must be 1, 2, 4, 8 or 16");
+    if (t < 3 || !(t & 1)) throw Error("hg_params_derive: t must be odd");
+    memset(out, 0, sizeof(*out));
+    out->n = n; out->k = k;
+    out->s_bound = 1;                                    // :225
+    out->e_bound = 19;                                   // :236 int(discrete_gaussian.z_upper), sigma = 3.2
+    out->k1_bound = py_int_of_quotient(t - 1, 2);        // :249
+    for (uint32_t i = 0; i < k; i++) {
+        const u64 q = qis[i];
+        if (q < 3 || !(q & 1) || q >= (1ULL << 62)) throw Error("hg_params_derive: q_i must be odd and below 2^62");
+        const u64 k0 = inv_mod(q - (t % q), q);          // :80 pow(-t, -1, q)
+        const u64 half = py_int_of_quotient(q - 1, 2);   // :296 int((qis[i] - 1) / 2)
+        const unsigned __int128 num = (unsigned __int128)half * (n + 2) + 19 + (unsigned __int128)out->k1_bound * k0;  // :334
+        out->qis[i] = q; out->k0is[i] = k0;
+        out->r2_bounds[i] = half;
+        out->r1_bounds[i] = py_int_of_quotient(num, q);  // :336 int(.. / qis[i])
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // JSON witness: {"s":[".."],"e":[..],"k1":[..],"r2is":[[..]],"r1is":[[..]],"ais":[[..]],"ct0is":[[..]]}
 namespace {

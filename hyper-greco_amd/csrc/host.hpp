@@ -13,7 +13,7 @@
 #include <string>
 #include <vector>
 #include <stdexcept>
-#include "gl.cuh"
+#include "gl_field.hpp"
 #include "../../include/hg.h"
 
 namespace hg {
@@ -93,6 +93,7 @@ struct Params {
     int num_chunks() const { return k / 2 > 1 ? k / 2 : 1; }
 };
 bool params_builtin(uint32_t n, uint32_t k, hg_params* out);
+void params_derive(uint32_t n, uint32_t k, const u64* qis, u64 t, hg_params* out);  // scripts/circuit_sk.py:422-439
 
 struct Witness {  // tables exactly as get_inputs lays them out
     std::vector<u64> s, e, k1;  // 2^L

@@ -1,7 +1,7 @@
 // gfx950 (MI355X / CDNA4) kernels of the GKR prover. Integer modular work in 64-bit lanes: no MFMA.
 // Conventions: 256-thread workgroups (4 wave64), grid-stride loops over at most SC_MAX_BLOCKS workgroups per job,
 // 16-byte coalesced loads of adjacent table entries (a sum-check pair (T[2j], T[2j+1]) is one 16-B or two
-// contiguous 16-B accesses per lane), deferred-reduction arithmetic for the dot products (gl_wide.cuh), wave-level
+// contiguous 16-B accesses per lane), deferred-reduction arithmetic for the dot products (gl_wide.hpp), wave-level
 // DPP reductions then one LDS hop per workgroup; the workgroup that arrives last sums the per-workgroup partials.
 #include <hip/hip_runtime.h>
 #include <cstring>
@@ -11,7 +11,7 @@
 #include <string>
 #include <type_traits>
 #include "kernels.hpp"
-#include "gl_wide.cuh"
+#include "gl_wide.hpp"
 
 namespace hg {
 namespace dev {
@@ -192,7 +192,7 @@ __device__ __forceinline__ void sc_round_body(const T* __restrict__ in, size_t i
             T p0 = V::zero(), p2 = V::zero(), p3 = V::zero();
             const int nb = ntab >> 1;
             // a(t) b(t) = P0 + t (P1 - P0 - Pinf) + t^2 Pinf with P0 = a(0)b(0), P1 = a(1)b(1), Pinf = (a1-a0)(b1-b0):
-            // the three dot products over the table pairs stay unreduced in column accumulators (gl_wide.cuh)
+            // the three dot products over the table pairs stay unreduced in column accumulators (gl_wide.hpp)
             // and are reduced once per j after the loop.
             if constexpr (!FIRST && std::is_same<T, E2>::value) {
                 WE2 w0 = we2_zero(), w1 = we2_zero(), wi = we2_zero();
@@ -968,7 +968,7 @@ __device__ __forceinline__ void ps_round_body(const PsJob& J, int rd, int in_buf
     const int G = BD >> jb_log2;
     const int jj = tid & ((1 << jb_log2) - 1), g = tid >> jb_log2;
     const size_t ntiles = half >> jb_log2;
-    // g = sum_i a_i b_i has no per-j factor, so the two evaluation sums stay unreduced (gl_wide.cuh) over the
+    // g = sum_i a_i b_i has no per-j factor, so the two evaluation sums stay unreduced (gl_wide.hpp) over the
     // whole grid-stride loop of this thread and are reduced once at the end.
     WE2 w0 = we2_zero(), w2 = we2_zero();
     const FoldR fr = fold_r(r);

@@ -2,7 +2,7 @@
 // pointers; every launch goes to the given stream; nothing here synchronises.
 #pragma once
 #include <hip/hip_runtime.h>
-#include "gl.cuh"
+#include "gl_field.hpp"
 
 namespace hg {
 namespace dev {

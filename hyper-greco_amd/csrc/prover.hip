@@ -784,7 +784,7 @@ struct Prover {
     }
 
     // ---- Lasso node (lasso.rs:57-114) ------------------------------------------------------------
-    struct GpOut { size_t point_off; };
+    struct GpOut { size_t point_off; std::shared_ptr<std::vector<E2>> claims; };  // claims: final per-table claims, valid after replay
     // prove_grand_product (prover.rs:183-266) over nb contiguous tables of `len` base-field values
     // `owner[n]` = rank that runs layer n (n = 0: roots + top evaluations); H may be null when no layer is owned
     int gp_deepest(int nv, const std::vector<int>& owner) const {  // highest tree level this rank needs (layer n reads level nv-1-n)
@@ -864,7 +864,7 @@ struct Prover {
                 for (int b = 0; b < nb; b++) (*claims)[b] = e2_add(ev[2 * b], e2_mul(mu, e2_sub(ev[2 * b + 1], ev[2 * b])));
             });
         };
-        GpOut out{0};
+        GpOut out{0, claims};
         // layer with num_vars 0
         mark("grand product layer 0: v_l, v_r evaluations per tree (prover.rs:257; no sum-check)");
         defer_write_slots(ev0, 2 * (size_t)nb);
@@ -1104,7 +1104,7 @@ struct Prover {
         GpOut g1 = split ? grand_product(H1, N, 2 * G, gp1_owner, L1, &local_pairs, p0_only, d_hash_src, emit, hash_build_bytes)
                          : grand_product(H1, N, 2 * G, gp1_owner, L1, nullptr, false, d_hash_src, emit, hash_build_bytes);  // reads then writes (prover.rs:161-165)
         mark("lasso: memory checking, grand product #2 over inits then finals (prover.rs:167-171)");
-        GpOut g2{0};
+        GpOut g2{0, nullptr};
         aux([&] { g2 = grand_product(H2, M, 2 * G, std::vector<int>(16, own_gp2)); });  // inits then finals (prover.rs:167-171); its tree on the second stream
         if (use_aux) {
             // grand product #1's first launch reads the counters, grand product #2's first rounds its tree: the main stream waits
@@ -1729,6 +1729,61 @@ void sumcheck_on_tables(hg_ctx* ctx, SumcheckIO& io) {
         for (int i = 0; i < 8; i++) { c0 = (c0 << 8) | b[o + i]; c1 = (c1 << 8) | b[o + 8 + i]; }
         io.msgs.push_back(e2(c0, c1));
     }
+}
+
+// prove_grand_product on caller tables (kernel-level parity entry point, hg_grand_product)
+std::vector<uint8_t> grand_product_on_tables(hg_ctx* ctx, size_t nb, size_t len, const u64* const* tables, size_t chain_skip, std::vector<E2>* claims_out,
+                                             std::vector<E2>* point_out) {
+    if (nb == 0 || nb > (size_t)dev::PW_MAX || len < 2 || (len & (len - 1))) throw Error("hg_grand_product: need 1..64 tables of a power-of-two length >= 2");
+    hip_check(hipSetDevice(ctx->device), "hipSetDevice");
+    ctx->arena_reset();
+    Prover P(ctx, nullptr);
+    int nv = 0;
+    while (((size_t)1 << nv) < len) nv++;
+    ctx->ensure_chain(chain_skip + 4096);
+    P.ch.pos = 2 * chain_skip;
+    u64* H = ctx->alloc_n<u64>(nb * len);
+    for (size_t b = 0; b < nb; b++) {
+        for (size_t i = 0; i < len; i++) if (tables[b][i] >= GL_P) throw Error("hg_grand_product: non-canonical table entry");
+        hip_check(hipMemcpyAsync(H + b * len, tables[b], len * 8, hipMemcpyHostToDevice, ctx->stream), "upload table");
+    }
+    Prover::GpOut g = P.grand_product(H, len, (int)nb, std::vector<int>(nv, 0));
+    P.flush_stride();
+    P.finish();
+    if (claims_out) *claims_out = *g.claims;
+    if (point_out) {
+        const u64* chain = challenge_chain(2 * (g.point_off + nv));
+        point_out->clear();
+        for (int i = 0; i < nv; i++) point_out->push_back(e2(chain[2 * (g.point_off + i)], chain[2 * (g.point_off + i) + 1]));
+    }
+    return std::move(P.proof.bytes);
+}
+
+// fix_var on the lowest variable of one table (hg_fold)
+__global__ void k_fold_table(const void* __restrict__ in, int is_base, size_t half, E2 r, E2* __restrict__ out) {
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < half; j += (size_t)gridDim.x * blockDim.x) {
+        if (is_base) {
+            const u64* t = static_cast<const u64*>(in);
+            const u64 x = t[2 * j], y = t[2 * j + 1];
+            out[j] = e2_add_f(e2_mul_f(r, gl_sub(y, x)), x);
+        } else {
+            const E2* t = static_cast<const E2*>(in);
+            const E2 x = t[2 * j], y = t[2 * j + 1];
+            out[j] = e2_add(x, e2_mul(r, e2_sub(y, x)));
+        }
+    }
+}
+void fold_device(hg_ctx* ctx, const u64* table_host, size_t nv, bool is_base, E2 r, E2* out_host) {
+    if (nv < 1 || nv > 30) throw Error("hg_fold: table size out of range");
+    hip_check(hipSetDevice(ctx->device), "hipSetDevice");
+    ctx->arena_reset();
+    const size_t N = (size_t)1 << nv, half = N >> 1, el = is_base ? 8 : 16;
+    void* d = ctx->alloc(N * el);
+    E2* o = ctx->alloc_n<E2>(half);
+    hip_check(hipMemcpyAsync(d, table_host, N * el, hipMemcpyHostToDevice, ctx->stream), "upload");
+    k_fold_table<<<(unsigned)std::min<size_t>((half + 255) / 256, 4096), 256, 0, ctx->stream>>>(d, is_base ? 1 : 0, half, r, o);
+    hip_check(hipMemcpyAsync(out_host, o, half * sizeof(E2), hipMemcpyDeviceToHost, ctx->stream), "download");
+    hip_check(hipStreamSynchronize(ctx->stream), "fold sync");
 }
 
 E2 mle_eval_device(hg_ctx* ctx, const u64* table_host, size_t nv, const E2* point_host) {

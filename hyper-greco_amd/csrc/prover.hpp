@@ -142,6 +142,9 @@ struct SumcheckIO {
 };
 void sumcheck_on_tables(hg_ctx* ctx, SumcheckIO& io);
 E2 mle_eval_device(hg_ctx* ctx, const u64* table_host, size_t nv, const E2* point_host);
+std::vector<uint8_t> grand_product_on_tables(hg_ctx* ctx, size_t nb, size_t len, const u64* const* tables, size_t chain_skip, std::vector<E2>* claims_out,
+                                             std::vector<E2>* point_out);
+void fold_device(hg_ctx* ctx, const u64* table_host, size_t nv, bool is_base, E2 r, E2* out_host);
 void ntt_device(hg_ctx* ctx, const u64* in_host, int log2n, bool inverse, size_t batch, u64* out_host);
 
 void hip_check(hipError_t e, const char* what);

@@ -10,7 +10,7 @@
 #include <cstring>
 #include <functional>
 #include "host.hpp"
-#include "bn254.cuh"
+#include "bn254_field.hpp"
 
 namespace hg {
 

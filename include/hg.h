@@ -71,6 +71,13 @@ int hg_set_option(hg_ctx* ctx, const char* name, int64_t value);
 /* = `type Params = constants::SkEnc{N}_{K}x{bits}_65537` [REF bfv-gkr/src/test.rs:8] */
 int hg_params_builtin(uint32_t n, uint32_t k, hg_params* out);
 
+/* = the constants emitter of scripts/circuit_sk.py [REF scripts/circuit_sk.py:80, 249, 296-297, 334-337, 422-439]: a parameter set
+ *   for ring degree n, k CRT moduli qis[] and plaintext modulus t, so that (n, k) can be swept beyond the six shipped sets.
+ *   S_BOUND = 1, E_BOUND = 19, K1_BOUND = (t-1)/2, K0_i = (-t)^-1 mod q_i, R2_BOUND_i = int((q_i - 1) / 2) and
+ *   R1_BOUND_i = int((int((q_i-1)/2) (n+2) + 19 + int((t-1)/2) K0_i) / q_i), with the script's float semantics of "/" reproduced
+ *   (that is why shipped R2 bounds are doubles rounded to 53 bits). n must be a power of two, k one of 1, 2, 4, 8, 16. */
+int hg_params_derive(uint32_t n, uint32_t k, const uint64_t* qis, uint64_t t, hg_params* out);
+
 /* = BfvEncrypt::setup -> LassoPreprocessing::preprocess::<4, 65536> [REF sk_encryption_circuit.rs:319-349, lasso.rs:527-627]
  *   plus BfvEncrypt::configure (circuit wiring) [REF sk_encryption_circuit.rs:351-363, 86-293], done once. */
 int hg_setup(hg_ctx* ctx, const hg_params* params, hg_pk** pk); /* ctx == NULL: host-only key (layout / circuit_eval) */
@@ -183,6 +190,16 @@ int hg_lasso_num_challenges(const hg_pk* pk, size_t* n_e);
 int hg_sumcheck(hg_ctx* ctx, int kind, size_t nv, size_t ntab, const uint64_t* const* tables, const int* is_base,
                 const uint64_t* pw, size_t npw, const uint64_t* claim2, size_t chain_skip, uint64_t* msgs,
                 uint64_t* point, uint64_t* evals, uint64_t* sums);
+
+/* = prove_grand_product [REF lasso/src/memory_checking/prover.rs:183-266] on nb host tables of len = 2^nv base-field values: product
+ *   tree on the MSB split, root products, per layer the batched degree-3 sum-check, 2 nb evaluations and the mu fold. The transcript
+ *   starts after `chain_skip` E challenges. claims2: nb final claims (E), point2: nv coordinates (E). (Goldilocks counterpart of
+ *   hg_grand_product_bn254) */
+int hg_grand_product(hg_ctx* ctx, size_t nb, size_t len, const uint64_t* const* tables, size_t chain_skip, uint8_t* proof, size_t cap,
+                     size_t* proof_len, uint64_t* claims2, uint64_t* point2);
+/* = BoxMultilinearPoly::fix_var on the lowest variable (inside gkr::sum_check::prove_sum_check; SURVEY.md 8(c) convention C3):
+ *   out[j] = T[2j] + r (T[2j+1] - T[2j]), j < 2^(nv-1). table: 2^nv base values (is_base) or (c0, c1) pairs; out: 2^(nv-1) pairs. */
+int hg_fold(hg_ctx* ctx, const uint64_t* table, size_t nv, int is_base, const uint64_t r2[2], uint64_t* out);
 
 /* = BoxMultilinearPoly::evaluate [REF call sites memory_checking/mod.rs:80-93, sk_encryption_circuit.rs:446]
  *   on a host table of 2^nv base-field values at an E point. */

@@ -2,7 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
-#include "../../hyper-greco_amd/csrc/gl.cuh"
+#include "../../hyper-greco_amd/csrc/gl_field.hpp"
 using namespace hg;
 
 // r = a + b mod p (a, b canonical): s = a + b (carry c1); t = s + EPS (carry c2: s >= p); r = (c1|c2) ? t : s

@@ -2,7 +2,7 @@
 // deferred-reduction dot products (w512_* vs wcol_*) over 25 terms. build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../hyper-greco_amd/csrc
 #include <hip/hip_runtime.h>
 #include <cstdio>
-#include "bn254_wide.cuh"
+#include "bn254_wide.hpp"
 using namespace hg::bn;
 template <int KIND>
 __global__ __launch_bounds__(256) void k(Fr* out, int iters) {

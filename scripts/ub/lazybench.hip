@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
-#include "../../hyper-greco_amd/csrc/gl.cuh"
+#include "../../hyper-greco_amd/csrc/gl_field.hpp"
 using namespace hg;
 
 struct Acc { u64 lo, hi; u32 top; };

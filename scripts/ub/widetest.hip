@@ -1,8 +1,8 @@
-// Correctness + throughput of the deferred-reduction Ext2 dot product (gl_wide.cuh) against e2_mul/e2_add.
+// Correctness + throughput of the deferred-reduction Ext2 dot product (gl_wide.hpp) against e2_mul/e2_add.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
-#include "../../hyper-greco_amd/csrc/gl_wide.cuh"
+#include "../../hyper-greco_amd/csrc/gl_wide.hpp"
 using namespace hg;
 
 template <int V> __global__ __launch_bounds__(256) void k(const E2* a, const E2* b, E2* out, int n, int reps) {

@@ -289,6 +289,59 @@ def test_protocol_modes_at_the_headline_size(ctx):
     pk.free()
 
 
+@pytest.mark.parametrize("nb,nv", [(2, 5), (6, 10), (50, 12), (3, 15)])
+def test_grand_product_entry_bit_exact(ctx, nb, nv):
+    """hg_grand_product (the Goldilocks counterpart of hg_grand_product_bn254) against the oracle's
+    prove_grand_product on random tables: proof bytes, final claims and the point."""
+    rng = random.Random(100 * nb + nv)
+    tabs = [rand_f(rng, 1 << nv) for _ in range(nb)]
+    skip = rng.randrange(40)
+    proof, claims, point = hg.grand_product(ctx, tabs, skip)
+    ref, rclaims, rpoint = orclib.grand_product_f("goldilocks", [[int(v) for v in t] for t in tabs], skip, threads=4)
+    assert proof == ref
+    assert [int(a) | (int(b) << 64) for a, b in claims] == rclaims
+    assert [int(a) | (int(b) << 64) for a, b in point] == rpoint
+
+
+def test_fold_entry_matches_the_definition(ctx):
+    """hg_fold = fix_var on the LOWEST variable (convention C3): out[j] = T[2j] + r (T[2j+1] - T[2j]) over GoldilocksExt2."""
+    rng = random.Random(5)
+
+    def emul(a, b):
+        return ((a[0] * b[0] + 7 * a[1] * b[1]) % P, (a[0] * b[1] + a[1] * b[0]) % P)
+
+    r = (rng.randrange(P), rng.randrange(P))
+    for nv, base in ((1, True), (9, True), (12, False), (3, False)):
+        t = rand_f(rng, (1 << nv) * (1 if base else 2))
+        got = hg.fold(ctx, t, base, r)
+        ent = [(int(v), 0) for v in t] if base else [(int(t[2 * i]), int(t[2 * i + 1])) for i in range(1 << nv)]
+        for j in range(1 << (nv - 1)):
+            x, y = ent[2 * j], ent[2 * j + 1]
+            d = ((y[0] - x[0]) % P, (y[1] - x[1]) % P)
+            rd = emul(r, d)
+            assert (int(got[j][0]), int(got[j][1])) == ((x[0] + rd[0]) % P, (x[1] + rd[1]) % P), (nv, base, j)
+
+
+def test_derived_parameter_set_proves_and_verifies(ctx):
+    """A parameter set that is NOT one of the six shipped ones (hg_params_derive: n = 2048 with two 55-bit moduli): setup, synthetic
+    witness, prove, bit-exact against the oracle on the same derived constants, accepted by both verifiers."""
+    c = orclib.constants(4096, 2)
+    params = hg.params_derive(2048, 2, c["qis"], 65537)
+    bfv = hg.BfvEncrypt(params)
+    pk = bfv.setup(ctx)
+    w = hg.Witness.synthetic(params, 99)
+    proof, _ = bfv.prove(ctx, pk, w)
+    assert (pk.circuit_eval(w)[1] == w.arrays()["ct0is"]).all()   # the synthetic witness satisfies the circuit relation for the derived constants
+    oc = dict(n=2048, k=2, s_bound=params.s_bound, e_bound=params.e_bound, k1_bound=params.k1_bound,
+              r1_bounds=list(params.r1_bounds)[:2], r2_bounds=list(params.r2_bounds)[:2], qis=list(params.qis)[:2], k0is=list(params.k0is)[:2])
+    p = orclib.Params(oc)
+    inp = orclib.Inputs(w.arrays())
+    ref, _ = orclib.prove(p, inp, threads=4)
+    assert proof == ref
+    assert orclib.verify(p, inp, proof)[0] and hg.verify(pk, w, proof) == (True, "")
+    pk.free()
+
+
 def test_library_collective_single_rank_communicator(ctx):
     """hg_comm_init / hg_prove_sharded with a one-rank RCCL communicator (the only size a one-GPU box offers): the limb-split
     kernel, ncclAllReduce on the prover stream and the fold-back kernel run for real and must leave the proof unchanged."""

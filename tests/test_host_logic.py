@@ -33,7 +33,7 @@ def test_product_never_links_the_oracle():
     src = os.path.join(ROOT, "hyper-greco_amd")
     for dp, _, files in os.walk(src):
         for f in files:
-            if f.endswith((".hip", ".cpp", ".hpp", ".cuh", ".py", "Makefile")):
+            if f.endswith((".hip", ".cpp", ".hpp", ".inc", ".py", "Makefile")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "oracle/" not in txt.replace("lives in oracle/", "") and "liboracle" not in txt and "orclib" not in txt, f
 
@@ -323,3 +323,38 @@ def test_witness_json_writer_inverts_get_inputs():
     from reference_baseline import parse_span_ms
     assert parse_span_ms("INFO     GKR prove [ 1.88s | 37.12% / 99.31% ]") == 1880.0
     assert parse_span_ms("  GKR prove [ 103ms | 3% ]") == 103.0 and parse_span_ms("nothing") is None
+
+
+def test_params_derive_reproduces_every_shipped_constant_set():
+    """hg_params_derive = the constants emitter of scripts/circuit_sk.py (:80, :249, :296-297, :334-337, :422-439), including the
+    script's float rounding of (q - 1) / 2: from (n, qis, t) alone it must reproduce all six constants/*.rs files."""
+    for key in ("1024_1", "2048_1", "4096_2", "8192_4", "16384_8", "32768_16"):
+        c = orclib.constants(*[int(x) for x in key.split("_")])
+        p = hg.params_derive(c["n"], c["k"], c["qis"], 65537)
+        b = hg.params_builtin(c["n"], c["k"])
+        assert (p.n, p.k, p.s_bound, p.e_bound, p.k1_bound) == (b.n, b.k, b.s_bound, b.e_bound, b.k1_bound), key
+        for f in ("r1_bounds", "r2_bounds", "qis", "k0is"):
+            assert list(getattr(p, f)) == list(getattr(b, f)), (key, f)
+    # a set the reference does not ship: n = 512 with one 27-bit modulus still gives a provable parameter set
+    p = hg.params_derive(512, 1, [orclib.constants(1024, 1)["qis"][0]], 65537)
+    assert p.n == 512 and p.r1_bounds[0] > 0 and p.r2_bounds[0] == (orclib.constants(1024, 1)["qis"][0] - 1) // 2
+    with pytest.raises(hg.HgError):
+        hg.params_derive(1000, 1, [12289], 65537)
+    with pytest.raises(hg.HgError):
+        hg.params_derive(1024, 3, [12289, 12289, 12289], 65537)
+
+
+def test_witness_for_other_parameters_is_refused():
+    """A witness handle built for one parameter set used with the prover key of another: every entry point that
+    indexes the witness with the key's sizes refuses instead of reading out of bounds."""
+    small, big = hg.BfvEncrypt.new(1024, 1), hg.BfvEncrypt.new(4096, 2)
+    pk_big = big.setup(None)           # host-only key: enough for the host-side entry points
+    w_small = hg.Witness.synthetic(small.params, 3)
+    L = hg.lib()
+    rc = L.hg_verify(pk_big.h, w_small.h, b"\0" * 64, 64)
+    assert rc == -1 and b"witness was built for n=1024 k=1" in L.hg_last_error()
+    rc = L.hg_verify_bn254(pk_big.h, w_small.h, b"\0" * 64, 64)
+    assert rc == -1 and b"witness was built for" in L.hg_last_error()
+    with pytest.raises(hg.HgError, match="witness was built for"):
+        pk_big.circuit_eval(w_small)
+    pk_big.free()
