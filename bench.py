@@ -339,6 +339,20 @@ def main():
                 best = min(runs, key=lambda t: t[1])
                 line["bn254"] = {"workload": f"BfvEncrypt::prove over bn256::Fr (hg_prove_bn254), n={args.n} k={args.k}, same witness",
                                  "witness_gen_ms": round(best[0], 2), "prove_ms": round(best[1], 2), "dtype": "u256 (4x64 Montgomery)"}
+                # this path is integer-ALU bound, not HBM bound: VALU wave-instructions of one prove (committed SQ_INSTS_VALU pass of
+                # this round, only valid for n=32768 k=16) over the measured time, against the VALU issue peak of the chip
+                try:
+                    sq = json.load(open(os.path.join(ROOT, "profiles", f"{PMC_TAG}_bn254_pmc_sq.json")))
+                    if (args.n, args.k) == (32768, 16):
+                        insts = sq["prove_valu_wave_insts_per_prove"]
+                        peak = 256 * 4 * 2.4e9 / 4 / 1e9   # CUs x SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction = 614 G wave-instr/s
+                        ach = insts / (best[1] * 1e-3) / 1e9
+                        line["bn254"]["roofline"] = {"bound": "valu", "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G wave-instr/s",
+                                                     "frac": round(ach / peak, 4), "valu_wave_insts_per_prove": round(insts),
+                                                     "source": {"file": f"profiles/{PMC_TAG}_bn254_pmc_sq.json", "command": sq["command"]},
+                                                     "note": "measured issue rate of v_mad_u64_u32 / VOP3 on this chip: 0.5 G wave-instr/s per SIMD = 512 (scripts/ub/ratebench.hip)"}
+                except Exception:
+                    pass
             except Exception as ex:
                 line["bn254"] = {"error": str(ex)}
         if world == 1 and not args.no_cpu_baseline:
