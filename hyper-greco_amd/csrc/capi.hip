@@ -114,6 +114,7 @@ int hg_set_option(hg_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) throw Error("hg_set_option: null argument");
     const std::string n(name);
     if (n == "one_stream") ctx->one_stream = value != 0;
+    else if (n == "graph") { ctx->use_graph = value != 0; if (!ctx->use_graph) prove_cache_drop(ctx); }
     else throw Error("hg_set_option: unknown option " + n);
     return 0;
     HG_CATCH(-1)

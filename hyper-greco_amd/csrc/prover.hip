@@ -49,6 +49,7 @@ void hg_ctx::arena_skip_to_high() {
     for (auto& c : chunks) c.used = std::max(c.used, c.high);
 }
 void hg_ctx::arena_reset() {
+    arena_epoch++;
     // coalesce into one chunk once the high-water mark is known, so later proves never call hipMalloc
     size_t used = 0;
     for (auto& c : chunks) used += c.used;
@@ -112,6 +113,7 @@ void hg_ctx::prof_collect() {
 }
 hg_ctx::~hg_ctx() {
     if (stream) (void)hipStreamSynchronize(stream);
+    hg::prove_cache_drop(this);
     for (auto& c : chunks) (void)hipFree(c.p);
     if (d_chal) (void)hipFree(d_chal);
     if (d_res && d_res != h_res) (void)hipFree(d_res);
@@ -1525,18 +1527,9 @@ void values_free(hg_values* v) {
     delete v;
 }
 
-// enqueue + synchronise this rank's share of one proof; leaves the (partial) result buffer in ctx->h_res
-static std::unique_ptr<Prover> prove_begin(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int rank, int world, double* t_start, float* gpu_ms,
-                                           bool exchange = false) {
-    hip_check(hipSetDevice(ctx->device), "hipSetDevice");
-    ctx->arena_reset();
+// everything a prove puts on the streams, in protocol order (also what a graph capture records)
+static void enqueue_prove(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, Prover* P, int world, bool exchange) {
     const Params& p = pk->params;
-    *t_start = wall_ms();
-    std::unique_ptr<Prover> P(new Prover(ctx, pk, rank, world));
-    P->d_vals = v->d_vals;
-    hipEvent_t ev_a, ev_b;
-    hip_check(hipEventCreate(&ev_a), "event"); hip_check(hipEventCreate(&ev_b), "event");
-    hip_check(hipEventRecord(ev_a, ctx->stream), "event record");
     if (world > 1) hip_check(hipMemsetAsync(ctx->d_res, 0, ctx->res_cap * sizeof(E2), ctx->stream), "clear result buffer");
     // "eval output" (sk_encryption_circuit.rs:444-448): point, ct0is MLE value
     const int ov = p.ct0is_log2();
@@ -1550,10 +1543,23 @@ static std::unique_ptr<Prover> prove_begin(hg_ctx* ctx, const hg_pk* pk, const h
         dev::dot_eq(ctx->stream, eq, tabs, 1, (size_t)1 << ov, ctx->d_partials, P->d_res() + vslot);
     }
     Cell out_value = cell();
-    Prover* pp = P.get();
-    P->ops.push_back([pp, out_value, vslot] { *out_value = pp->h_res()[vslot]; });
+    P->ops.push_back([P, out_value, vslot] { *out_value = P->h_res()[vslot]; });
     P->gkr(ClaimRef{point_off, ov, out_value});
     if (exchange) comm_allreduce_results(ctx, P->res_used);  // the one collective of a sharded proof, on the stream
+}
+
+// enqueue + synchronise this rank's share of one proof; leaves the (partial) result buffer in ctx->h_res
+static std::unique_ptr<Prover> prove_begin(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int rank, int world, double* t_start, float* gpu_ms,
+                                           bool exchange = false) {
+    hip_check(hipSetDevice(ctx->device), "hipSetDevice");
+    ctx->arena_reset();
+    *t_start = wall_ms();
+    std::unique_ptr<Prover> P(new Prover(ctx, pk, rank, world));
+    P->d_vals = v->d_vals;
+    hipEvent_t ev_a, ev_b;
+    hip_check(hipEventCreate(&ev_a), "event"); hip_check(hipEventCreate(&ev_b), "event");
+    hip_check(hipEventRecord(ev_a, ctx->stream), "event record");
+    enqueue_prove(ctx, pk, v, P.get(), world, exchange);
     hip_check(hipEventRecord(ev_b, ctx->stream), "event record");
     P->sync_results();
     *gpu_ms = 0;
@@ -1562,7 +1568,95 @@ static std::unique_ptr<Prover> prove_begin(hg_ctx* ctx, const hg_pk* pk, const h
     return P;
 }
 
+// ---- cached launch graph (hg_ctx::prove_cache) ---------------------------------------------------------------------------
+struct ProveCache {
+    std::unique_ptr<Prover> P;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    const hg_pk* pk = nullptr;
+    std::vector<const u64*> d_vals;
+    const u64* d_ct0is = nullptr;
+    bool one_stream = false;
+    uint64_t epoch = 0;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    ~ProveCache() {
+        if (exec) (void)hipGraphExecDestroy(exec);
+        if (graph) (void)hipGraphDestroy(graph);
+        if (ev_a) (void)hipEventDestroy(ev_a);
+        if (ev_b) (void)hipEventDestroy(ev_b);
+    }
+};
+void prove_cache_drop(hg_ctx* ctx) {
+    delete static_cast<ProveCache*>(ctx->prove_cache);
+    ctx->prove_cache = nullptr;
+}
+static bool graph_allowed(const hg_ctx* ctx) {
+    static const bool off = [] { const char* e = getenv("HG_NO_GRAPH"); return e && e[0] == '1'; }();
+    return !off && getenv("HG_PROOF_MAP") == nullptr && ctx->use_graph && ctx->prof_level == 0 && ctx->d_res == ctx->h_res;
+}
+// launches the cached graph, waits, replays the transcript
+static ProveResult prove_from_cache(hg_ctx* ctx, ProveCache* C) {
+    ProveResult res;
+    const double t0 = wall_ms();
+    hip_check(hipEventRecord(C->ev_a, ctx->stream), "event record");
+    hip_check(hipGraphLaunch(C->exec, ctx->stream), "hipGraphLaunch");
+    hip_check(hipEventRecord(C->ev_b, ctx->stream), "event record");
+    Prover* P = C->P.get();
+    P->st = ctx->stream;
+    P->sync_results();
+    float gms = 0;
+    (void)hipEventElapsedTime(&gms, C->ev_a, C->ev_b);
+    P->proof.bytes.clear();
+    P->proof_map.clear();
+    P->replay();
+    res.prove_ms = wall_ms() - t0;
+    res.gpu_ms = gms;
+    res.enqueue_ms = P->t_enqueued - t0;
+    res.sync_ms = P->t_synced - P->t_enqueued;
+    res.replay_ms = P->t_replayed - P->t_synced;
+    res.proof = P->proof.bytes;
+    return res;
+}
+// records the whole enqueue into a graph (no kernel runs during the capture), instantiates it, then proves through it
+static ProveResult prove_capture(hg_ctx* ctx, const hg_pk* pk, const hg_values* v) {
+    hip_check(hipSetDevice(ctx->device), "hipSetDevice");
+    prove_cache_drop(ctx);
+    ctx->arena_reset();
+    ctx->ensure_chain(16384);  // (may allocate and copy synchronously: not allowed once the capture has begun)
+    std::unique_ptr<ProveCache> C(new ProveCache());
+    hip_check(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
+    try {
+        C->P.reset(new Prover(ctx, pk, 0, 1));
+        C->P->d_vals = v->d_vals;
+        enqueue_prove(ctx, pk, v, C->P.get(), 1, false);
+    } catch (...) {
+        hipGraph_t g = nullptr;
+        (void)hipStreamEndCapture(ctx->stream, &g);
+        if (g) (void)hipGraphDestroy(g);
+        throw;
+    }
+    hip_check(hipStreamEndCapture(ctx->stream, &C->graph), "hipStreamEndCapture");
+    hip_check(hipGraphInstantiate(&C->exec, C->graph, nullptr, nullptr, 0), "hipGraphInstantiate");
+    hip_check(hipEventCreate(&C->ev_a), "event"); hip_check(hipEventCreate(&C->ev_b), "event");
+    C->pk = pk; C->d_vals = v->d_vals; C->d_ct0is = v->d_ct0is; C->one_stream = ctx->one_stream; C->epoch = ctx->arena_epoch;
+    ProveCache* raw = C.release();
+    ctx->prove_cache = raw;
+    return prove_from_cache(ctx, raw);
+}
+
 ProveResult prove_resident(hg_ctx* ctx, const hg_pk* pk, const hg_values* v) {
+    if (graph_allowed(ctx)) {
+        ProveCache* C = static_cast<ProveCache*>(ctx->prove_cache);
+        if (C && C->pk == pk && C->d_vals == v->d_vals && C->d_ct0is == v->d_ct0is && C->one_stream == ctx->one_stream && C->epoch == ctx->arena_epoch)
+            return prove_from_cache(ctx, C);
+        const void* vkey = v->d_vals.empty() ? nullptr : (const void*)v->d_vals[0];
+        const bool same = ctx->last_prove_key[0] == pk && ctx->last_prove_key[1] == vkey;
+        ctx->same_key_proves = same ? ctx->same_key_proves + 1 : 0;
+        ctx->last_prove_key[0] = pk; ctx->last_prove_key[1] = vkey;
+        // third prove of the same (key, values): the arena has grown (1st) and been coalesced (2nd) - its addresses are now stable
+        if (ctx->same_key_proves >= 2 && ctx->chunks.size() <= 1) return prove_capture(ctx, pk, v);
+    } else ctx->same_key_proves = 0;
+    if (ctx->prove_cache) prove_cache_drop(ctx);
     ProveResult res;
     double t3 = 0;
     float gms = 0;

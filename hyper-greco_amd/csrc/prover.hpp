@@ -29,6 +29,15 @@ struct hg_ctx {
     int comm_rank = 0, comm_world = 1;
     u64* d_xchg = nullptr;
     size_t xchg_cap = 0;
+    // cached launch graph of the resident prove (prover.hip: ProveCache). The launch sequence of a proof depends on the prover key
+    // and on ADDRESSES only - every challenge is known up front, no kernel argument depends on the witness - so after two ordinary
+    // proves of the same (key, values) pair the third is captured into a hipGraph and later ones replay it: the host's ~0.7 ms
+    // protocol walk and ~200 launch calls collapse into one hipGraphLaunch. Any other use of the arena invalidates it.
+    void* prove_cache = nullptr;
+    uint64_t arena_epoch = 0;       // bumped by arena_reset()
+    const void* last_prove_key[2] = {nullptr, nullptr};
+    int same_key_proves = 0;
+    bool use_graph = true;          // hg_set_option("graph", 0) / HG_NO_GRAPH=1 turn it off
     // options (hg_set_option)
     bool one_stream = false;  // keep every launch on `stream` (per-kernel timings without cross-stream interference)
     int mode = 0;             // protocol mode of the next proves: bit 0 absorbing transcript, bit 1 extension-field memory checking
@@ -148,5 +157,6 @@ void fold_device(hg_ctx* ctx, const u64* table_host, size_t nv, bool is_base, E2
 void ntt_device(hg_ctx* ctx, const u64* in_host, int log2n, bool inverse, size_t batch, u64* out_host);
 
 void hip_check(hipError_t e, const char* what);
+void prove_cache_drop(hg_ctx* ctx);
 
 }  // namespace hg

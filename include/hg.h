@@ -65,6 +65,9 @@ void hg_destroy(hg_ctx* ctx);
 /* Context options (nothing in the reference: its only knob is the rayon pool). name:
  *   "one_stream"  value != 0: every launch on one stream (the default overlaps the Vanilla / FFT node reductions, the counter
  *                 sorts and the openings with the Lasso node's critical path on a second stream); used to time kernels in isolation
+ *   "graph"       value == 0: never replay a cached launch graph (default: after two ordinary resident proves of the same key and
+ *                 values the third is captured into a hipGraph and later ones replay it - the launch sequence depends on
+ *                 addresses only, because every challenge is known up front)
  * Returns 0, or -1 for an unknown name. */
 int hg_set_option(hg_ctx* ctx, const char* name, int64_t value);
 

@@ -14,8 +14,11 @@ pk = bfv.setup(ctx)
 w = hg.Witness.synthetic(bfv.params, 0x4752454330 + n)
 vals = hg.witness_gen(ctx, pk, w)
 out = hg.ProofBuffer()
+first = None
 for _ in range(steps):
     hg.prove_resident(ctx, pk, vals, out)
+    first = first or out.bytes()
+    assert out.bytes() == first, "proof changed between runs"
     print(out.timings())
 if os.environ.get("HG_PROOF_OUT"):
     open(os.environ["HG_PROOF_OUT"], "wb").write(out.bytes())

@@ -342,6 +342,36 @@ def test_derived_parameter_set_proves_and_verifies(ctx):
     pk.free()
 
 
+def test_cached_launch_graph_replays_and_invalidates(ctx):
+    """Resident proves of one (key, values) pair: the third is captured into a hipGraph, later ones replay it. The bytes must not
+    change, other arena users in between must invalidate the graph, another witness must not reuse it, and the oracle agrees."""
+    n, k = 4096, 2
+    bfv = hg.BfvEncrypt.new(n, k)
+    pk = bfv.setup(ctx)
+    w1, w2 = hg.Witness.synthetic(bfv.params, 11), hg.Witness.synthetic(bfv.params, 12)
+    v1, v2 = hg.witness_gen(ctx, pk, w1), hg.witness_gen(ctx, pk, w2)
+    out = hg.ProofBuffer()
+    p = orclib.params(n, k)
+    ref1, _ = orclib.prove(p, orclib.Inputs(w1.arrays()), threads=4)
+    ref2, _ = orclib.prove(p, orclib.Inputs(w2.arrays()), threads=4)
+    for i in range(6):                                                     # walk, walk (arena coalesced), capture, replay x3
+        assert hg.prove_resident(ctx, pk, v1, out).bytes() == ref1, i
+    rng = random.Random(3)
+    tab = rand_f(rng, 1 << 10)
+    ctx.mle_eval(tab, rand_f(rng, 20))                                     # another user of the context's arena
+    for i in range(4):
+        assert hg.prove_resident(ctx, pk, v1, out).bytes() == ref1, i      # re-walked, re-captured, replayed
+    assert hg.prove_resident(ctx, pk, v2, out).bytes() == ref2             # other values: never the cached graph
+    for i in range(4):
+        assert hg.prove_resident(ctx, pk, v2, out).bytes() == ref2, i
+        assert hg.prove_resident(ctx, pk, v1, out).bytes() == ref1, i      # alternating keys: plain walks
+    ctx.set_option("graph", 0)
+    for i in range(4):
+        assert hg.prove_resident(ctx, pk, v1, out).bytes() == ref1, i
+    ctx.set_option("graph", 1)
+    v1.free(); v2.free(); pk.free()
+
+
 def test_library_collective_single_rank_communicator(ctx):
     """hg_comm_init / hg_prove_sharded with a one-rank RCCL communicator (the only size a one-GPU box offers): the limb-split
     kernel, ncclAllReduce on the prover stream and the fold-back kernel run for real and must leave the proof unchanged."""
