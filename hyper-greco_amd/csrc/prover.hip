@@ -963,9 +963,6 @@ struct Prover {
             ScHandle sc = sc_stride(dev::SC_COLLATION, ep, true, N, A, nu, pw, nullptr, do_col);
             mark("lasso: collation sum-check, " + std::to_string(nu) + " rounds x 3 coefficients (lasso.rs:271-279) [C1, C3; poly(0) quirk]");
             defer_sumcheck(sc, 2, claimed, nullptr);
-            // launched right away: the host still has the whole memory-checking bookkeeping to walk (about 0.5 ms), and the main
-            // stream would sit idle until the shared flush at the end of the node
-            flush_stride();
         }
         E2 gamma_e = squeeze(), tau_e = squeeze();  // lasso.rs:99
         u64 gamma = gamma_e.c0, tau = tau_e.c0;     // prover.rs:38-39: base limb 0 only
@@ -1006,8 +1003,14 @@ struct Prover {
             for (int i : local_mems) need_chunk[lp.gkr_chunk[i]] = 1;
         }
         std::map<int, u64*> read_ts, final_cts;
-        if (need_counters) aux([&] {
-            if (use_aux) hip_check(hipStreamWaitEvent(st, ctx->ev_aux[0], 0), "lasso: wait for the limb split");
+        // The counters feed grand product #1's first launch. On the second stream they hide under the collation rounds (measured
+        // 3.63 ms per prove); on the main stream, ahead of the collation rounds, they cost their ~250 us of small launches in full
+        // (3.87 ms): HG_COUNTERS_MAIN=1 selects that.
+        static const bool counters_aux = [] { const char* e = getenv("HG_COUNTERS_MAIN"); return !(e && e[0] == '1'); }();
+        if (use_aux && counters_aux) flush_stride();  // collation rounds first: see below
+        auto cnt_where = [&](const std::function<void()>& fn) { if (use_aux && counters_aux) on_aux(fn); else fn(); };
+        if (need_counters) cnt_where([&] {
+            if (use_aux && counters_aux) hip_check(hipStreamWaitEvent(st, ctx->ev_aux[0], 0), "lasso: wait for the limb split");
             size_t tb = dev::lasso_counter_temp_bytes(N);
             void* temp = ctx->alloc(tb);
             u32* keys = ctx->alloc_n<u32>(N); u32* keys2 = ctx->alloc_n<u32>(N);
@@ -1023,6 +1026,15 @@ struct Prover {
                 ctx->prof_end();
             }
         });
+        if (use_aux && !counters_aux && need_counters) {
+            // grand product #2's hashes and the openings (second stream) read the counters (main stream)
+            hip_check(hipEventRecord(ctx->ev_aux[0], ctx->stream), "lasso: counters event");
+            on_aux([&] { hip_check(hipStreamWaitEvent(st, ctx->ev_aux[0], 0), "lasso: wait for the counters"); });
+        }
+        // the collation rounds are launched now, not with the grand products at the end of the node: the host still has the whole
+        // memory-checking bookkeeping to walk (about 0.5 ms) and the main stream would sit idle meanwhile; behind the counters, so
+        // that the second stream (grand product #2's tree, openings) can start while they run
+        flush_stride();
         const dev::GpHashSrc* d_hash_src = nullptr;
         double hash_build_bytes = 0;
         if (emit > 0) {
