@@ -84,8 +84,17 @@ hg_ctx* hg_create(int device_id) {
     hip_check(hipSetDevice(device_id), "hipSetDevice");
     hg_ctx* c = new hg_ctx();
     c->device = device_id;
-    hip_check(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate");
-    hip_check(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking), "hipStreamCreate");
+    // the main stream carries the critical path (split -> collation -> grand product #1), the second stream work that hides under
+    // it: where the runtime offers stream priorities the main stream gets the highest, the second the lowest (HG_NO_PRIO=1: none)
+    int prio_lo = 0, prio_hi = 0;
+    if (getenv("HG_NO_PRIO") || hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) prio_lo = prio_hi = 0;
+    if (prio_lo != prio_hi) {
+        hip_check(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi), "hipStreamCreate");
+        hip_check(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_lo), "hipStreamCreate");
+    } else {
+        hip_check(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate");
+        hip_check(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking), "hipStreamCreate");
+    }
     hip_check(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming), "hipEventCreate");
     hip_check(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming), "hipEventCreate");
     for (auto& e : c->ev_aux) hip_check(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
