@@ -8,6 +8,13 @@ O=$GRAFT_REPO_ROOT/gpurun_out
 python bench.py > $O/bench_$tag.json 2> $O/bench_$tag.err
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $O/prof_$tag -o runc --output-format csv -- python3 $GRAFT_REPO_ROOT/scripts/prove_once.py 32768 16 6 > $O/prove_once_$tag.txt 2>/dev/null
+# the same for the bench command itself (its proves mix the overlapped timed region with one-stream profiling passes) and for
+# one-stream proves only (isolated kernel durations)
+rocprofv3 --kernel-trace --stats -d $O/profb_$tag -o runc --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_${tag}_under_rocprof.json 2>/dev/null
+HG_ONE_STREAM=1 rocprofv3 --kernel-trace --stats -d $O/profi_$tag -o runc --output-format csv -- python3 $GRAFT_REPO_ROOT/scripts/prove_once.py 32768 16 6 > /dev/null 2>&1
+python3 $GRAFT_REPO_ROOT/scripts/summarize_trace.py $(ls $O/profb_$tag/*kernel_trace.csv | head -1) 60 > $O/${tag}_bench_kernel_trace_summary.txt
+python3 $GRAFT_REPO_ROOT/scripts/summarize_trace.py $(ls $O/profi_$tag/*kernel_trace.csv | head -1) 60 > $O/${tag}_one_stream_kernel_trace_summary.txt
+rm -rf $O/profb_$tag $O/profi_$tag
 if [ "$2" = "pmc" ]; then
 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_${tag}_FETCH -o run --output-format csv -- python3 $GRAFT_REPO_ROOT/scripts/prove_once.py 32768 16 2 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_${tag}_WRITE -o run --output-format csv -- python3 $GRAFT_REPO_ROOT/scripts/prove_once.py 32768 16 2 > /dev/null 2>&1
