@@ -1381,6 +1381,68 @@ void lasso_counters(hipStream_t st, const LassoDev& L, int m, const u64* dims, u
     k_counter_ranks<<<grid, TPB, 0, st>>>(keys_sorted, rows_sorted, cnt, starts, read_ts, final_cts);
 }
 
+// ---- all counter memories in one sort -------------------------------------------------------------------------------------
+struct CounterPlan { int nchunks; int chunk[4]; size_t off[5]; };  // rows of chunk[q] occupy positions [off[q], off[q+1]) before the sort
+static CounterPlan counter_plan(const LassoDev& L, unsigned chunk_mask) {
+    CounterPlan P;
+    memset(&P, 0, sizeof(P));
+    for (int c = 0; c < 4; c++)
+        if ((chunk_mask >> c) & 1) {
+            P.chunk[P.nchunks] = c;
+            P.off[P.nchunks + 1] = P.off[P.nchunks] + ((size_t)L.cnt_nsegs[c] << L.seg_shift);
+            P.nchunks++;
+        }
+    return P;
+}
+size_t lasso_counters_all_elems(const LassoDev& L, unsigned chunk_mask) { CounterPlan P = counter_plan(L, chunk_mask); return P.off[P.nchunks]; }
+constexpr unsigned COUNTER_ALL_KEY_BITS = 18;  // chunk (2 bits) | 16-bit address
+size_t lasso_counters_all_temp_bytes(size_t n_elems) {
+    size_t bytes = 0;
+    check_hip(rocprim::radix_sort_pairs(nullptr, bytes, (u32*)nullptr, (u32*)nullptr, (u32*)nullptr, (u32*)nullptr, std::max<size_t>(n_elems, 1), 0,
+                                        COUNTER_ALL_KEY_BITS), "radix_sort_pairs(size query)");
+    return bytes;
+}
+__global__ __launch_bounds__(TPB) void k_counter_keys_all(LassoDev L, CounterPlan P, const u64* __restrict__ dims, u32* __restrict__ keys, u32* __restrict__ vals) {
+    const size_t N = (size_t)1 << L.nu, total = P.off[P.nchunks];
+    const size_t smask = ((size_t)1 << L.seg_shift) - 1;
+    for (size_t q = (size_t)blockIdx.x * TPB + threadIdx.x; q < total; q += (size_t)gridDim.x * TPB) {
+        int s = 0;
+        while (s + 1 < P.nchunks && q >= P.off[s + 1]) s++;
+        const int c = P.chunk[s];
+        const size_t local = q - P.off[s];
+        const size_t row = ((size_t)L.cnt_segs[c][local >> L.seg_shift] << L.seg_shift) | (local & smask);
+        keys[q] = ((u32)c << 16) | (u32)dims[(size_t)L.mem_dim[c] * N + row];
+        vals[q] = (u32)row;   // rows are listed in ascending order inside a chunk and the sort is stable: rank = position in the key's run
+    }
+}
+__global__ __launch_bounds__(TPB) void k_counter_ranks_all(const u32* __restrict__ ks, const u32* __restrict__ vs, size_t n, const u32* __restrict__ starts,
+                                                           CounterOut out) {
+    for (size_t p = (size_t)blockIdx.x * TPB + threadIdx.x; p < n; p += (size_t)gridDim.x * TPB) {
+        const u32 key = ks[p];
+        const u32 rank = (u32)p - starts[key];
+        const int c = (int)(key >> 16);
+        out.read_ts[c][vs[p]] = rank;                                                     // = number of earlier rows on the same address
+        if (p + 1 == n || ks[p + 1] != key) out.final_cts[c][key & 0xFFFF] = (u64)rank + 1;
+    }
+}
+void lasso_counters_all(hipStream_t st, const LassoDev& L, unsigned chunk_mask, const u64* dims, const CounterOut& out, void* temp, size_t temp_bytes,
+                        u32* keys, u32* keys_sorted, u32* vals, u32* vals_sorted, u32* starts) {
+    const size_t N = (size_t)1 << L.nu;
+    const CounterPlan P = counter_plan(L, chunk_mask);
+    for (int q = 0; q < P.nchunks; q++) {
+        check_hip(hipMemsetAsync(out.read_ts[P.chunk[q]], 0, N * sizeof(u64), st), "clear read_ts");
+        check_hip(hipMemsetAsync(out.final_cts[P.chunk[q]], 0, 65536 * sizeof(u64), st), "clear final_cts");
+    }
+    const size_t total = P.off[P.nchunks];
+    if (total == 0) return;
+    const int grid = grid_for(total);
+    k_counter_keys_all<<<grid, TPB, 0, st>>>(L, P, dims, keys, vals);
+    // stable LSD radix sort on (chunk, address) keeps the rows of one address of one chunk in row order
+    check_hip(rocprim::radix_sort_pairs(temp, temp_bytes, keys, keys_sorted, vals, vals_sorted, total, 0, COUNTER_ALL_KEY_BITS, st), "radix_sort_pairs(counter keys)");
+    k_counter_starts<<<grid, TPB, 0, st>>>(keys_sorted, total, starts);
+    k_counter_ranks_all<<<grid, TPB, 0, st>>>(keys_sorted, vals_sorted, total, starts, out);
+}
+
 __global__ __launch_bounds__(TPB) void k_lasso_claim(LassoDev L, const E2* __restrict__ eq, const u64* __restrict__ e_polys,
                                                      E2* __restrict__ partials) {
     __shared__ E2 sm[TPB / 64];

@@ -166,6 +166,13 @@ void lasso_split(hipStream_t st, const LassoDev& L, const u64* input, u64* dims,
 size_t lasso_counter_temp_bytes(size_t n);
 void lasso_counters(hipStream_t st, const LassoDev& L, int m, const u64* dims, u64* read_ts, u64* final_cts,
                     void* temp, size_t temp_bytes, u32* keys, u32* keys_sorted, u32* rows_in, u32* rows_sorted, u32* starts);
+// The same for SEVERAL counter memories (chunks) in one pass: one stable sort of (chunk << 16 | address) keys over the rows of all
+// requested chunks (13 launches instead of 12 per chunk). chunk_mask: bit c = compute chunk c; read_ts[c] / final_cts[c] as above.
+struct CounterOut { u64* read_ts[4]; u64* final_cts[4]; };
+size_t lasso_counters_all_elems(const LassoDev& L, unsigned chunk_mask);             // number of (row, chunk) pairs to sort
+size_t lasso_counters_all_temp_bytes(size_t n_elems);
+void lasso_counters_all(hipStream_t st, const LassoDev& L, unsigned chunk_mask, const u64* dims, const CounterOut& out, void* temp, size_t temp_bytes,
+                        u32* keys, u32* keys_sorted, u32* vals, u32* vals_sorted, u32* starts /* 4 * 65536 + 1 */);
 // sum_k eq[k] * sum_i M^i E_{mems(lookup(k))[i]}[k]  -> partials (nv = 1)
 int lasso_claim(hipStream_t st, const LassoDev& L, const E2* eq, const u64* e_polys, E2* partials);
 // multiset hashes h = a + v*gamma + t*gamma^2 - tau

@@ -946,11 +946,20 @@ struct Prover {
         for (int i = 0; i < nu; i++) squeeze();
         E2* eq = (do_col || do_open) ? ctx->alloc_n<E2>(N) : nullptr;
         size_t claim_slot = slot(1);
-        if (do_col) {
+        // Stream assignment inside the node (two streams). Schedule 0 (default): collation on the main stream ahead of the grand
+        // products, counters / grand product #2's tree / openings on the second stream. Schedule 1 (HG_LASSO_SCHED=1): the main
+        // stream carries split -> counters -> grand product #1 (the longest dependent chain starts as early as possible), the claimed
+        // sum and the collation sum-check run on the second stream - measured SLOWER (3.8-3.9 ms vs 3.55 ms: the second stream
+        // becomes the long pole and its bandwidth-bound collation rounds slow the grand-product kernels down).
+        static const int lasso_sched = [] { const char* e = getenv("HG_LASSO_SCHED"); return e && *e ? atoi(e) : 0; }();
+        const bool col_aux = fork_recorded && lasso_sched == 1;
+        auto col_where = [&](const std::function<void()>& fn) { if (col_aux) on_aux(fn); else fn(); };
+        if (do_col) col_where([&] {
+            if (col_aux) hip_check(hipStreamWaitEvent(st, ctx->ev_aux[0], 0), "lasso: wait for the limb split");
             eq_now(eq, nu, r_off);
             int grid = dev::lasso_claim(st, L, eq, ep, partials);
             reduce(grid, 1, claim_slot);
-        }
+        });
         Cell claimed = cell();
         mark("lasso: claimed sum (lasso.rs:100-107)");
         ops.push_back([this, claim_slot, claimed] { *claimed = h_res()[claim_slot]; proof.write_e(*claimed); });
@@ -963,6 +972,7 @@ struct Prover {
             ScHandle sc = sc_stride(dev::SC_COLLATION, ep, true, N, A, nu, pw, nullptr, do_col);
             mark("lasso: collation sum-check, " + std::to_string(nu) + " rounds x 3 coefficients (lasso.rs:271-279) [C1, C3; poly(0) quirk]");
             defer_sumcheck(sc, 2, claimed, nullptr);
+            if (col_aux) on_aux([&] { flush_stride(); });  // all collation rounds, now, on the second stream
         }
         E2 gamma_e = squeeze(), tau_e = squeeze();  // lasso.rs:99
         u64 gamma = gamma_e.c0, tau = tau_e.c0;     // prover.rs:38-39: base limb 0 only
@@ -1006,25 +1016,38 @@ struct Prover {
         // The counters feed grand product #1's first launch. On the second stream they hide under the collation rounds (measured
         // 3.63 ms per prove); on the main stream, ahead of the collation rounds, they cost their ~250 us of small launches in full
         // (3.87 ms): HG_COUNTERS_MAIN=1 selects that.
-        static const bool counters_aux = [] { const char* e = getenv("HG_COUNTERS_MAIN"); return !(e && e[0] == '1'); }();
+        static const bool counters_aux_env = [] { const char* e = getenv("HG_COUNTERS_MAIN"); return !(e && e[0] == '1'); }();
+        const bool counters_aux = counters_aux_env && !col_aux;   // schedule 1: the counters lead the main stream
         if (use_aux && counters_aux) flush_stride();  // collation rounds first: see below
         auto cnt_where = [&](const std::function<void()>& fn) { if (use_aux && counters_aux) on_aux(fn); else fn(); };
         if (need_counters) cnt_where([&] {
             if (use_aux && counters_aux) hip_check(hipStreamWaitEvent(st, ctx->ev_aux[0], 0), "lasso: wait for the limb split");
-            size_t tb = dev::lasso_counter_temp_bytes(N);
-            void* temp = ctx->alloc(tb);
-            u32* keys = ctx->alloc_n<u32>(N); u32* keys2 = ctx->alloc_n<u32>(N);
-            u32* rows = ctx->alloc_n<u32>(N); u32* rows2 = ctx->alloc_n<u32>(N);
-            u32* starts = ctx->alloc_n<u32>(65537);
+            // all requested chunks in ONE stable sort of (chunk, address) keys (HG_COUNTERS_PER_CHUNK=1: one sort per chunk)
+            static const bool per_chunk = [] { const char* e = getenv("HG_COUNTERS_PER_CHUNK"); return e && e[0] == '1'; }();
+            unsigned mask = 0;
             for (auto& chk : lp.chunks) {
                 int c = chk.first;
                 if (c < 0 || c >= 4 || !need_chunk[c]) continue;
+                mask |= 1u << c;
                 read_ts[c] = ctx->alloc_n<u64>(N);
                 final_cts[c] = ctx->alloc_n<u64>(M);
-                ctx->prof_begin(cls_aux, (double)N * 40);
-                dev::lasso_counters(st, L, c, dims, read_ts[c], final_cts[c], temp, tb, keys, keys2, rows, rows2, starts);
-                ctx->prof_end();
             }
+            const size_t elems = per_chunk ? N : std::max<size_t>(dev::lasso_counters_all_elems(L, mask), 1);
+            size_t tb = per_chunk ? dev::lasso_counter_temp_bytes(N) : dev::lasso_counters_all_temp_bytes(elems);
+            void* temp = ctx->alloc(tb);
+            u32* keys = ctx->alloc_n<u32>(elems); u32* keys2 = ctx->alloc_n<u32>(elems);
+            u32* rows = ctx->alloc_n<u32>(elems); u32* rows2 = ctx->alloc_n<u32>(elems);
+            u32* starts = ctx->alloc_n<u32>(4 * 65536 + 1);
+            ctx->prof_begin(cls_aux, (double)elems * 40);
+            if (per_chunk) {
+                for (int c = 0; c < 4; c++) if ((mask >> c) & 1) dev::lasso_counters(st, L, c, dims, read_ts[c], final_cts[c], temp, tb, keys, keys2, rows, rows2, starts);
+            } else {
+                dev::CounterOut co;
+                memset(&co, 0, sizeof(co));
+                for (int c = 0; c < 4; c++) if ((mask >> c) & 1) { co.read_ts[c] = read_ts[c]; co.final_cts[c] = final_cts[c]; }
+                dev::lasso_counters_all(st, L, mask, dims, co, temp, tb, keys, keys2, rows, rows2, starts);
+            }
+            ctx->prof_end();
         });
         if (use_aux && !counters_aux && need_counters) {
             // grand product #2's hashes and the openings (second stream) read the counters (main stream)
