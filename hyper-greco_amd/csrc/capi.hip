@@ -1,6 +1,7 @@
 // C ABI (include/hg.h). No exception crosses the boundary: every entry point catches, stores the
 // message for hg_last_error() and returns a negative status.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstring>
 #include <memory>
@@ -141,6 +142,8 @@ int hg_setup(hg_ctx* ctx, const hg_params* params, hg_pk** out) {
     if (!params || !out) throw Error("hg_setup: null argument");
     if (ctx) hip_check(hipSetDevice(ctx->device), "hipSetDevice");
     std::unique_ptr<hg_pk> pk(new hg_pk(*params));
+    static std::atomic<uint64_t> next_serial{1};
+    pk->serial = next_serial++;
     pk->ctx = ctx;
     pk->lasso = lasso_preprocess(pk->params);
     pk->circuit = build_circuit(pk->params, pk->lasso);

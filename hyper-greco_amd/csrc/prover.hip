@@ -271,6 +271,11 @@ struct Prover {
             }
         }
         own_out_claim = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+        if (getenv("HG_SHARD_DEBUG") && rank == 0) {
+            fprintf(stderr, "[hg] shard plan world %d: gp2 -> %d, collation -> %d, openings -> %d, out-claim -> %d; loads", world, own_gp2, own_collation, own_openings, own_out_claim);
+            for (int r = 0; r < world; r++) fprintf(stderr, " %.0fM", load[r] / 1e6);
+            fprintf(stderr, "\n");
+        }
     }
 
     Prover(hg_ctx* c, const hg_pk* k, int rank_ = 0, int world_ = 1) : ctx(c), pk(k), st(c->stream), partials(c->d_partials), rank(rank_), world(world_) {
@@ -1609,6 +1614,7 @@ struct ProveCache {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     const hg_pk* pk = nullptr;
+    uint64_t pk_serial = 0;
     std::vector<const u64*> d_vals;
     const u64* d_ct0is = nullptr;
     bool one_stream = false;
@@ -1673,7 +1679,7 @@ static ProveResult prove_capture(hg_ctx* ctx, const hg_pk* pk, const hg_values* 
     hip_check(hipStreamEndCapture(ctx->stream, &C->graph), "hipStreamEndCapture");
     hip_check(hipGraphInstantiate(&C->exec, C->graph, nullptr, nullptr, 0), "hipGraphInstantiate");
     hip_check(hipEventCreate(&C->ev_a), "event"); hip_check(hipEventCreate(&C->ev_b), "event");
-    C->pk = pk; C->d_vals = v->d_vals; C->d_ct0is = v->d_ct0is; C->one_stream = ctx->one_stream; C->epoch = ctx->arena_epoch;
+    C->pk = pk; C->pk_serial = pk->serial; C->d_vals = v->d_vals; C->d_ct0is = v->d_ct0is; C->one_stream = ctx->one_stream; C->epoch = ctx->arena_epoch;
     ProveCache* raw = C.release();
     ctx->prove_cache = raw;
     return prove_from_cache(ctx, raw);
@@ -1682,10 +1688,11 @@ static ProveResult prove_capture(hg_ctx* ctx, const hg_pk* pk, const hg_values* 
 ProveResult prove_resident(hg_ctx* ctx, const hg_pk* pk, const hg_values* v) {
     if (graph_allowed(ctx)) {
         ProveCache* C = static_cast<ProveCache*>(ctx->prove_cache);
-        if (C && C->pk == pk && C->d_vals == v->d_vals && C->d_ct0is == v->d_ct0is && C->one_stream == ctx->one_stream && C->epoch == ctx->arena_epoch)
+        if (C && C->pk == pk && C->pk_serial == pk->serial && C->d_vals == v->d_vals && C->d_ct0is == v->d_ct0is && C->one_stream == ctx->one_stream && C->epoch == ctx->arena_epoch)
             return prove_from_cache(ctx, C);
         const void* vkey = v->d_vals.empty() ? nullptr : (const void*)v->d_vals[0];
-        const bool same = ctx->last_prove_key[0] == pk && ctx->last_prove_key[1] == vkey;
+        const bool same = ctx->last_prove_key[0] == pk && ctx->last_prove_key[1] == vkey && ctx->last_prove_serial == pk->serial;
+        ctx->last_prove_serial = pk->serial;
         ctx->same_key_proves = same ? ctx->same_key_proves + 1 : 0;
         ctx->last_prove_key[0] = pk; ctx->last_prove_key[1] = vkey;
         // third prove of the same (key, values): the arena has grown (1st) and been coalesced (2nd) - its addresses are now stable

@@ -36,6 +36,7 @@ struct hg_ctx {
     void* prove_cache = nullptr;
     uint64_t arena_epoch = 0;       // bumped by arena_reset()
     const void* last_prove_key[2] = {nullptr, nullptr};
+    uint64_t last_prove_serial = 0;
     int same_key_proves = 0;
     bool use_graph = true;          // hg_set_option("graph", 0) / HG_NO_GRAPH=1 turn it off
     // options (hg_set_option)
@@ -92,6 +93,7 @@ struct hg_witness {
 };
 
 struct hg_pk {
+    uint64_t serial = 0;  // unique per hg_setup: identifies the key even if its address is reused after hg_pk_free
     hg_ctx* ctx = nullptr;
     hg::Params params;
     hg::LassoPlan lasso;
