@@ -909,7 +909,7 @@ static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4,
         }
         u64* dims = (u64*)dalloc_b(4 * N * 8);
         u64* ep = (u64*)dalloc_b((size_t)A * N * 8);
-        dev::lasso_split(st, L, d_in, dims, ep);
+        dev::lasso_split(st, L, d_in, dims, ep, dev::ep_rows_all(L.alpha));
         std::map<int, u64*> read_ts, final_cts;
         {
             const size_t tb = dev::lasso_counter_temp_bytes(N);

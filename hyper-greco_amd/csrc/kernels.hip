@@ -289,7 +289,7 @@ __device__ __forceinline__ void sc_round_body(const T* __restrict__ in, size_t i
                     if (i == 0) { p0 = x; p2 = v2; }
                     const u64 m = pw[i].c0;
                     const E2 mr = pwr[i];
-                    wmac2(w0, m, x, w2, m, v2);
+                    if (!(p0_only && i == 0)) wmac2(w0, m, x, w2, m, v2);  // (a p0-only table 0 belongs to another rank's share)
                     WAcc f0 = wacc_zero(), f1 = wacc_zero();
                     wmac_pair(f0, m, x, mr.c0, d);
                     wmac(f1, mr.c1, d);
@@ -304,8 +304,7 @@ __device__ __forceinline__ void sc_round_body(const T* __restrict__ in, size_t i
                     E2 d = e2_sub(y, x);
                     E2 v2 = e2_add(y, d);
                     if (i == 0) { p0 = x; p2 = v2; }
-                    s0 = e2_add(s0, x);
-                    s2 = e2_add(s2, v2);
+                    if (!(p0_only && i == 0)) { s0 = e2_add(s0, x); s2 = e2_add(s2, v2); }
                     store_e2(out + (size_t)i * out_stride + jo, e2_fold_wide(x, d, fr));
                 }
             } else {
@@ -315,20 +314,18 @@ __device__ __forceinline__ void sc_round_body(const T* __restrict__ in, size_t i
                 T d = V::sub(y, x);
                 T v2 = V::add(y, d);
                 if (i == 0) { p0 = x; p2 = v2; }
+                const bool summed = !(p0_only && i == 0);
                 if constexpr (FIRST) {
                     u64 m = pw[i].c0;
                     if constexpr (std::is_same<T, u64>::value) {
-                        s0 = gl_add(s0, gl_mul(m, x));
-                        s2 = gl_add(s2, gl_mul(m, v2));
+                        if (summed) { s0 = gl_add(s0, gl_mul(m, x)); s2 = gl_add(s2, gl_mul(m, v2)); }
                         store_e2(out + (size_t)i * out_stride + jo, e2_add_f(e2_mul_f(pwr[i], d), gl_mul(m, x)));
                     } else {
-                        s0 = e2_add(s0, e2_mul_f(x, m));
-                        s2 = e2_add(s2, e2_mul_f(v2, m));
+                        if (summed) { s0 = e2_add(s0, e2_mul_f(x, m)); s2 = e2_add(s2, e2_mul_f(v2, m)); }
                         store_e2(out + (size_t)i * out_stride + jo, e2_mul_f(V::fold(x, d, r), m));
                     }
                 } else {
-                    s0 = V::add(s0, x);
-                    s2 = V::add(s2, v2);
+                    if (summed) { s0 = V::add(s0, x); s2 = V::add(s2, v2); }
                     store_e2(out + (size_t)i * out_stride + jo, V::fold(x, d, r));
                 }
             }
@@ -716,6 +713,7 @@ __global__ __launch_bounds__(256) void k_col_step2(const StJob* __restrict__ job
     const size_t in_stride = I.in_stride;
     E2* __restrict__ out = I.out;
     const int ntab = J.ntab;
+    const bool p0_only = J.p0_only != 0;
     const int tid = threadIdx.x;
     const bool odd = tid & 1;
     const FoldR fa = fold_r(chal[J.r_off + rd]);
@@ -737,15 +735,15 @@ __global__ __launch_bounds__(256) void k_col_step2(const StJob* __restrict__ job
             const E2 da = e2_sub(ya, xa), db = e2_sub(yb, xb);
             const E2 va = e2_add(ya, da), vb = e2_add(yb, db);
             if (i == 0) { p0 = xa; p2 = va; }
-            s0 = e2_add(s0, e2_add(xa, xb));
-            s2 = e2_add(s2, e2_add(va, vb));
+            if (p0_only && i == 0) { s0 = e2_add(s0, xb); s2 = e2_add(s2, vb); }  // table 0 only supplies p_0 (another rank sums it)
+            else { s0 = e2_add(s0, e2_add(xa, xb)); s2 = e2_add(s2, e2_add(va, vb)); }
             const E2 ma = e2_fold_wide(xa, da, fa), mb = two ? e2_fold_wide(xb, db, fa) : e2_zero();  // T'[j] of tables i, i+1
             const E2 oa = swap_lane(ma), ob = swap_lane(mb);
             if (i == 0) {
                 const E2 x = odd ? oa : ma, yv = odd ? ma : oa;
                 q0 = x; q2 = e2_add(yv, e2_sub(yv, x));
             }
-            own = e2_add(own, e2_add(ma, mb));
+            own = e2_add(own, (p0_only && i == 0) ? mb : e2_add(ma, mb));
             const E2 fx = odd ? mb : ma, fd = odd ? e2_sub(ob, mb) : e2_sub(oa, ma);
             if (!odd || two) store_e2(out + (size_t)(i + (odd ? 1 : 0)) * half2 + jo2, e2_fold_wide(fx, fd, fb));
         }
@@ -823,20 +821,18 @@ __device__ __forceinline__ void sc_round_small(const T* in, size_t in_stride, si
                 T d = V::sub(y, x);
                 T v2 = V::add(y, d);
                 if (i == 0) { p0 = x; p2 = v2; }
+                const bool summed = !(p0_only && i == 0);
                 if constexpr (FIRST) {
                     u64 m = pw[i].c0;
                     if constexpr (std::is_same<T, u64>::value) {
-                        s0 = gl_add(s0, gl_mul(m, x));
-                        s2 = gl_add(s2, gl_mul(m, v2));
+                        if (summed) { s0 = gl_add(s0, gl_mul(m, x)); s2 = gl_add(s2, gl_mul(m, v2)); }
                         store_e2(out + (size_t)i * out_stride + jo, e2_add_f(e2_mul_f(pwr[i], d), gl_mul(m, x)));
                     } else {
-                        s0 = e2_add(s0, e2_mul_f(x, m));
-                        s2 = e2_add(s2, e2_mul_f(v2, m));
+                        if (summed) { s0 = e2_add(s0, e2_mul_f(x, m)); s2 = e2_add(s2, e2_mul_f(v2, m)); }
                         store_e2(out + (size_t)i * out_stride + jo, e2_mul_f(V::fold(x, d, r), m));
                     }
                 } else {
-                    s0 = V::add(s0, x);
-                    s2 = V::add(s2, v2);
+                    if (summed) { s0 = V::add(s0, x); s2 = V::add(s2, v2); }
                     store_e2(out + (size_t)i * out_stride + jo, V::fold(x, d, r));
                 }
             }
@@ -1301,8 +1297,13 @@ void eq_jobs(hipStream_t st, const EqJob* jobs, int njobs, int max_n, const E2* 
 
 // ------------------------------------------------------------------------------------------------
 // Lasso
+EpRows ep_rows_all(int alpha) {
+    EpRows r;
+    for (int m = 0; m < 32; m++) r.row[m] = m < alpha ? (signed char)m : (signed char)-1;
+    return r;
+}
 __global__ __launch_bounds__(TPB) void k_lasso_split(LassoDev L, const u64* __restrict__ input, u64* __restrict__ dims,
-                                                     u64* __restrict__ e_polys) {
+                                                     u64* __restrict__ e_polys, EpRows R) {
     const size_t N = (size_t)1 << L.nu;
     for (size_t j = (size_t)blockIdx.x * TPB + threadIdx.x; j < N; j += (size_t)gridDim.x * TPB) {
         u32 idx[4] = {0, 0, 0, 0};
@@ -1317,15 +1318,16 @@ __global__ __launch_bounds__(TPB) void k_lasso_split(LassoDev L, const u64* __re
 #pragma unroll
         for (int c = 0; c < 4; c++) dims[(size_t)c * N + j] = idx[c];
         for (int m = 0; m < L.alpha; m++) {
+            if (R.row[m] < 0) continue;
             u32 a = idx[L.mem_dim[m]];
             u64 ev = ((uses >> m) & 1) && a < L.mem_cutoff[m] ? (u64)a : 0;  // T_s[a] (range.rs:15-17, 58-72)
-            e_polys[(size_t)m * N + j] = ev;
+            e_polys[(size_t)R.row[m] * N + j] = ev;
         }
     }
 }
-void lasso_split(hipStream_t st, const LassoDev& L, const u64* input, u64* dims, u64* e_polys) {
+void lasso_split(hipStream_t st, const LassoDev& L, const u64* input, u64* dims, u64* e_polys, const EpRows& rows) {
     size_t N = (size_t)1 << L.nu;
-    k_lasso_split<<<(unsigned)std::min<size_t>((N + TPB - 1) / TPB, 4096), TPB, 0, st>>>(L, input, dims, e_polys);
+    k_lasso_split<<<(unsigned)std::min<size_t>((N + TPB - 1) / TPB, 4096), TPB, 0, st>>>(L, input, dims, e_polys, rows);
 }
 
 // keys/rows of the rows that touch counter memory m, compacted: position q -> row (segment list in LassoDev)
@@ -1443,7 +1445,7 @@ void lasso_counters_all(hipStream_t st, const LassoDev& L, unsigned chunk_mask, 
     k_counter_ranks_all<<<grid, TPB, 0, st>>>(keys_sorted, vals_sorted, total, starts, out);
 }
 
-__global__ __launch_bounds__(TPB) void k_lasso_claim(LassoDev L, const E2* __restrict__ eq, const u64* __restrict__ e_polys,
+__global__ __launch_bounds__(TPB) void k_lasso_claim(LassoDev L, const E2* __restrict__ eq, const u64* __restrict__ e_polys, EpRows R,
                                                      E2* __restrict__ partials) {
     __shared__ E2 sm[TPB / 64];
     const size_t N = (size_t)1 << L.nu;
@@ -1451,16 +1453,19 @@ __global__ __launch_bounds__(TPB) void k_lasso_claim(LassoDev L, const E2* __res
     for (size_t k = (size_t)blockIdx.x * TPB + threadIdx.x; k < L.rows; k += (size_t)gridDim.x * TPB) {
         int l = L.seg_lookup[k >> L.seg_shift];
         u64 comb = 0;  // combine_lookups (range.rs:184-195): sum_i M^i * operand_i
-        for (int i = 0; i < L.lookup_nmems[l]; i++) comb = gl_add(comb, gl_mul(L.mpow[i], e_polys[(size_t)L.lookup_mems[l][i] * N + k]));
+        for (int i = 0; i < L.lookup_nmems[l]; i++) {
+            const int row = R.row[L.lookup_mems[l][i]];
+            if (row >= 0) comb = gl_add(comb, gl_mul(L.mpow[i], e_polys[(size_t)row * N + k]));
+        }
         E2 e = eq[k];
         acc = e2_add(acc, e2_mul_f(e, comb));
     }
     E2 s = block_sum(acc, sm);
     if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
-int lasso_claim(hipStream_t st, const LassoDev& L, const E2* eq, const u64* e_polys, E2* partials) {
+int lasso_claim(hipStream_t st, const LassoDev& L, const E2* eq, const u64* e_polys, const EpRows& rows, E2* partials) {
     int grid = grid_for(L.rows);
-    k_lasso_claim<<<grid, TPB, 0, st>>>(L, eq, e_polys, partials);
+    k_lasso_claim<<<grid, TPB, 0, st>>>(L, eq, e_polys, rows, partials);
     return grid;
 }
 
@@ -1505,8 +1510,8 @@ __global__ __launch_bounds__(TPB) void k_hash_if(HashIfArgs args, u64 gamma, u64
     if (a >= 65536) return;
     u64 tv = a < args.cutoff[i] ? (u64)a : 0;
     u64 h0 = gl_sub(gl_add((u64)a, gl_mul(tv, gamma)), tau);
-    H2[(size_t)i * 65536 + a] = h0;
-    H2[(size_t)(G + i) * 65536 + a] = gl_add(h0, gl_mul(gl_from_u64(args.fc[i][a]), gamma2));
+    if (args.row_init[i] >= 0) H2[(size_t)args.row_init[i] * 65536 + a] = h0;
+    if (args.row_fin[i] >= 0) H2[(size_t)args.row_fin[i] * 65536 + a] = gl_add(h0, gl_mul(gl_from_u64(args.fc[i][a]), gamma2));
 }
 void lasso_hash_if(hipStream_t st, const HashIfArgs& args, int G, u64 gamma, u64 tau, u64* H2) {
     k_hash_if<<<dim3(65536 / TPB, G), TPB, 0, st>>>(args, gamma, gl_mul(gamma, gamma), tau, H2, G);

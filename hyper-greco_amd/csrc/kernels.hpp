@@ -160,8 +160,11 @@ struct LassoDev {
     int cnt_nsegs[4];
     uint8_t cnt_segs[4][128];
 };
-// dims[c][j] (4 x 2^nu) and E[m][j] (alpha x 2^nu), zero beyond `rows`
-void lasso_split(hipStream_t st, const LassoDev& L, const u64* input, u64* dims, u64* e_polys);
+// dims[c][j] (4 x 2^nu) and E[m][j] (alpha x 2^nu), zero beyond `rows`.
+// EpRows (multi-GPU: a rank only materialises the E tables of its own memories): row[m] = row of memory m in e_polys, -1 = not held.
+struct EpRows { signed char row[32]; };
+EpRows ep_rows_all(int alpha);
+void lasso_split(hipStream_t st, const LassoDev& L, const u64* input, u64* dims, u64* e_polys, const EpRows& rows);
 // read/final counters of memory m (sequential-scan semantics of lasso.rs:181-196) via a stable sort
 size_t lasso_counter_temp_bytes(size_t n);
 void lasso_counters(hipStream_t st, const LassoDev& L, int m, const u64* dims, u64* read_ts, u64* final_cts,
@@ -174,7 +177,8 @@ size_t lasso_counters_all_temp_bytes(size_t n_elems);
 void lasso_counters_all(hipStream_t st, const LassoDev& L, unsigned chunk_mask, const u64* dims, const CounterOut& out, void* temp, size_t temp_bytes,
                         u32* keys, u32* keys_sorted, u32* vals, u32* vals_sorted, u32* starts /* 4 * 65536 + 1 */);
 // sum_k eq[k] * sum_i M^i E_{mems(lookup(k))[i]}[k]  -> partials (nv = 1)
-int lasso_claim(hipStream_t st, const LassoDev& L, const E2* eq, const u64* e_polys, E2* partials);
+// (memories not held - EpRows::row < 0 - contribute nothing: the ranks' partial claimed sums add up)
+int lasso_claim(hipStream_t st, const LassoDev& L, const E2* eq, const u64* e_polys, const EpRows& rows, E2* partials);
 // multiset hashes h = a + v*gamma + t*gamma^2 - tau
 // for up to HASH_RW_MAX memories of one chunk (shared dim / read_ts columns); n >= 4, a multiple of 4
 // rd1/wr1 (may be null): first product-tree level rd[j]*rd[j+n/2], wr[j]*wr[j+n/2], n/2 entries each
@@ -182,7 +186,7 @@ constexpr int HASH_RW_MAX = 8;
 struct HashRwArgs { const u64* ep[HASH_RW_MAX]; u64* rd[HASH_RW_MAX]; u64* wr[HASH_RW_MAX]; u64* rd1[HASH_RW_MAX]; u64* wr1[HASH_RW_MAX]; };
 void lasso_hash_rw(hipStream_t st, size_t n, const u64* dim, const u64* read_ts, const HashRwArgs& args, int nmem, u64 gamma, u64 tau);
 // init / final hashes of all G memories in one launch: H2[i] = init_i, H2[G + i] = final_i (2^16 entries each)
-struct HashIfArgs { u32 cutoff[32]; const u64* fc[32]; };
+struct HashIfArgs { u32 cutoff[32]; const u64* fc[32]; int row_init[32], row_fin[32]; };  // rows of H2 (2^16 entries each); -1 = skip
 void lasso_hash_if(hipStream_t st, const HashIfArgs& args, int G, u64 gamma, u64 tau, u64* H2);
 // product tree level: out[b][i] = in[b][i] * in[b][i + h], b < nb, i < h
 void prod_level(hipStream_t st, const u64* in, size_t in_len, u64* out, int nb);

@@ -190,90 +190,57 @@ struct Prover {
     int cls_gp_hash, cls_gp_base, cls_gp_ext, cls_gp_ext2, cls_col_ext2, cls_col_base, cls_col_ext, cls_ps, cls_ps2, cls_reduce, cls_aux, cls_tree, cls_hash, cls_gather, cls_tail, cls_ps_tail;
 
     // ---- single-proof sharding over `world` GPUs ---------------------------------------------------
-    // Device jobs are independent, so a proof shards by JOB with no data-path collective inside
-    // the proof: every rank walks the whole protocol (same challenges, same result slots) but only enqueues
-    // the jobs it owns; unowned slots stay zero and ONE sum-all-reduce of the result buffer at the end gives
-    // every rank the complete buffer.
+    // Every rank walks the whole protocol (same challenges, same result slots) but only enqueues the work it owns; unowned
+    // slots stay zero and ONE sum-all-reduce of the result buffer at the end gives every rank the complete buffer.
+    //  * The Lasso node (most of the proof) is split BY MEMORY over all ranks: a rank runs the limb tables, the share of the
+    //    claimed sum, of the collation sum-check and of both grand products, and the openings, of its own memories only. Those
+    //    batched sum-checks are linear in their batch items, so the ranks' round sums are partial sums (lasso_node).
+    //  * The Vanilla / FFT node reductions are independent jobs, dealt to the ranks longest-first on top of that load.
     int rank = 0, world = 1;
     std::vector<int> node_owner;       // Vanilla / FFT node reductions
-    std::vector<int> gp1_owner;        // grand product #1 (reads|writes): per layer n (all `rank` when it is split by memory)
-    std::vector<int> gp1_mem_owner;    // world > 1: grand product #1 is split by memory (batch item) over ALL ranks
-    int own_gp2 = 0, own_collation = 0, own_openings = 0, own_out_claim = 0;
+    std::vector<int> gp1_owner;        // grand product #1 layers (all `rank`: every rank runs every layer on its memories)
+    std::vector<int> gp1_mem_owner;    // world > 1: memory-GKR index i -> owning rank
+    int own_out_claim = 0;
     bool mine(int owner) const { return owner == rank; }
     void plan_shards() {
         if (!pk) return;
         const HCircuit& c = pk->circuit;
         const int nu = pk->lasso.nu;
         node_owner.assign(c.nodes.size(), 0);
-        gp1_owner.assign(nu, 0);
+        gp1_owner.assign(nu, rank);
         if (world <= 1) return;
-        struct Item { double cost; int kind, idx; };
-        std::vector<Item> items;
-        const double A = pk->lasso.alpha;
-        // Grand product #1 (the bulk of the node) is split by memory: rank r hashes, multiplies up and runs every layer
-        // on its own memories' read/write tables (+ table 0, which supplies p_0). Its round sums are PARTIAL sums:
-        // the ranks' result buffers are combined by modular addition (hg_prove_shard_combine).
         const int G = (int)pk->lasso.gkr_order.size();
+        const double N = (double)((size_t)1 << nu);
         gp1_mem_owner.assign(G, 0);
         for (int i = 0; i < G; i++) gp1_mem_owner[i] = (int)(((long long)i * world) / G);
-        gp1_owner.assign(nu, rank);
-        items.push_back({4.0 * A * 65536.0 * 15.0, 1, 0});                     // all of GP#2 (small tables: latency-bound, hence the weight)
-        items.push_back({A * (double)((size_t)1 << nu) * 3.0, 2, 0});         // collation (+ claim)
-        items.push_back({(A + 8) * (double)((size_t)1 << nu) * 1.0, 3, 0});   // openings
+        // Load model in "table entries touched", calibrated on MI355X at n=32768 k=16. Per owned memory: two grand-product tables
+        // through every layer (~9 passes each), its E table in the split, the claim, the collation sum-check and the opening (~6).
+        // Per rank that owns any: the limb split of the input, the counters of the chunks it needs, and the p_0 tables.
+        std::vector<double> load(world, 0.0);
+        std::vector<int> nmem(world, 0);
+        for (int i = 0; i < G; i++) { load[gp1_mem_owner[i]] += N * (2.0 * 9.0 + 6.0); nmem[gp1_mem_owner[i]]++; }
+        for (int r = 0; r < world; r++) if (nmem[r]) load[r] += N * (5.0 + 3.5 * std::min(4, nmem[r]) + (r == gp1_mem_owner[0] ? 0.0 : 11.0));
+        struct Item { double cost; int idx; };
+        std::vector<Item> items;
         for (size_t id = 0; id < c.nodes.size(); id++) {
             const HNode& n = c.nodes[id];
-            if (n.kind == NK_FFT) items.push_back({(double)((size_t)1 << n.log2_size) * 18.0, 4, (int)id});
+            if (n.kind == NK_FFT) items.push_back({(double)((size_t)1 << n.log2_size) * 18.0, (int)id});
             if (n.kind == NK_VANILLA) {
                 int np = 0;
                 for (int i = 0; i < n.arity; i++) np += n.left_use[i] + n.right_use[i];
-                items.push_back({(double)np * (double)((size_t)1 << (n.log2_sub_in + n.log2_reps)) * 12.0 + 3.0 * (double)((size_t)1 << n.log2_out()), 4, (int)id});
+                items.push_back({(double)np * (double)((size_t)1 << (n.log2_sub_in + n.log2_reps)) * 12.0 + 3.0 * (double)((size_t)1 << n.log2_out()), (int)id});
             }
         }
         std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.cost > b.cost; });
-        // Longest-processing-time-first with set-up costs: the first Lasso item on a rank drags the node's
-        // prerequisites along (limb split, counters, hash tables, product-tree levels), replicated per rank.
-        // Costs are in "table entries touched"; the set-up constants are calibrated on MI355X at n=32768 k=16.
-        const double unit = A * (double)((size_t)1 << nu);          // one pass over the alpha E-tables
-        const double c_split = 1.2 * unit, c_counters = 3.5 * unit, c_hash1 = 2.5 * unit, c_tree1 = 1.4 * unit;
-        std::vector<double> load(world, 0.0);
-        for (int i = 0; i < G; i++) load[gp1_mem_owner[i]] += 2.0 * (double)((size_t)1 << nu) * 9.0;  // its share of GP#1
-        std::vector<char> has_split(world, 1), has_counters(world, 1), has_hash1(world, 1);  // every rank runs GP#1
-        std::vector<int> tree_depth(world, 0);
-        auto setup_cost = [&](const Item& it, int r, bool commit) {
-            double extra = 0;
-            bool need_split = it.kind <= 3, need_counters = it.kind == 0 || it.kind == 1 || it.kind == 3, need_hash1 = it.kind == 0;
-            int depth = it.kind == 0 ? nu - 1 - it.idx : 0;
-            if (need_split && !has_split[r]) extra += c_split;
-            if (need_counters && !has_counters[r]) extra += c_counters;
-            if (need_hash1 && !has_hash1[r]) extra += c_hash1;
-            for (int k = tree_depth[r] + 1; k <= depth; k++) extra += c_tree1 / (double)(1 << (k - 1));
-            if (commit) {
-                has_split[r] |= need_split; has_counters[r] |= need_counters; has_hash1[r] |= need_hash1;
-                tree_depth[r] = std::max(tree_depth[r], depth);
-            }
-            return extra;
-        };
-        for (auto& it : items) {
-            int best = 0;
-            double best_load = 1e300;
-            for (int r = 0; r < world; r++) {
-                double l = load[r] + it.cost + setup_cost(it, r, false);
-                if (l < best_load) { best_load = l; best = r; }
-            }
-            int r = best;
-            load[r] += it.cost + setup_cost(it, r, true);
-            switch (it.kind) {
-                case 0: gp1_owner[it.idx] = r; break;
-                case 1: own_gp2 = r; break;
-                case 2: own_collation = r; break;
-                case 3: own_openings = r; break;
-                default: node_owner[it.idx] = r; break;
-            }
+        for (auto& it : items) {   // longest-processing-time-first
+            int r = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+            load[r] += it.cost;
+            node_owner[it.idx] = r;
         }
         own_out_claim = (int)(std::min_element(load.begin(), load.end()) - load.begin());
         if (getenv("HG_SHARD_DEBUG") && rank == 0) {
-            fprintf(stderr, "[hg] shard plan world %d: gp2 -> %d, collation -> %d, openings -> %d, out-claim -> %d; loads", world, own_gp2, own_collation, own_openings, own_out_claim);
-            for (int r = 0; r < world; r++) fprintf(stderr, " %.0fM", load[r] / 1e6);
+            fprintf(stderr, "[hg] shard plan world %d: %d memories; out-claim -> %d; loads", world, G, own_out_claim);
+            for (int r = 0; r < world; r++) fprintf(stderr, " %.1fM", load[r] / 1e6);
             fprintf(stderr, "\n");
         }
     }
@@ -929,20 +896,58 @@ struct Prover {
         const dev::LassoDev& L = pk->lasso_dev;
         const int nu = lp.nu, A = lp.alpha;
         const size_t N = (size_t)1 << nu, M = 65536;
-        // what this rank needs of the node (single GPU: everything)
+        // What this rank does of the node (single GPU: everything). Sharded over `world` GPUs the whole node is split BY MEMORY:
+        // rank r owns the memories gkr_order[i] with gp1_mem_owner[i] == r and runs, for those, their E tables, their share of the
+        // claimed sum, of the collation sum-check, of both grand products and of the openings. Every batched sum-check here is
+        // linear in its batch items once p_0 is fixed, so every rank also keeps the one table that supplies p_0 (folded, never
+        // summed: StJob::p0_only) and the ranks' round sums are partial sums that the exchange adds up.
+        const int G = (int)lp.gkr_order.size();
+        const bool split = world > 1;
+        std::vector<int> local_pairs;  // global pair ids (reads / inits: i, writes / finals: G + i) this rank holds, ascending
+        std::vector<int> local_mems;   // memory-GKR indices i it owns
+        bool p0_only = false;          // pair 0 of the grand products is held only for p_0
+        std::vector<char> own_mem(A, split ? 0 : 1);   // by memory index m
+        if (split) {
+            for (int i = 0; i < G; i++) if (mine(gp1_mem_owner[i])) { local_mems.push_back(i); own_mem[lp.gkr_order[i]] = 1; }
+            p0_only = !mine(gp1_mem_owner[0]);
+            if (p0_only) local_pairs.push_back(0);
+            for (int i : local_mems) local_pairs.push_back(i);
+            for (int i : local_mems) local_pairs.push_back(G + i);
+        }
         bool any_gp1 = false;
         for (int n = 0; n < nu; n++) any_gp1 |= mine(gp1_owner[n]);
-        const bool do_col = mine(own_collation), do_open = mine(own_openings), do_gp2 = mine(own_gp2);
+        const bool any_local = !split || !local_mems.empty();
+        const bool do_col = any_local, do_open = any_local, do_gp2 = any_local;
         const bool need_counters = any_gp1 || do_gp2 || do_open;
         const bool need_split = do_col || need_counters;
+        // E tables this rank materialises: its own memories, memory 0 (p_0 of the collation sum-check) and memory gkr_order[0] (pair
+        // 0 of grand product #1). Row 0 is always memory 0 and the owned memories follow in ascending order, so the collation
+        // sum-check's tables are rows [0, ncol) of `ep`.
+        dev::EpRows ep_rows = dev::ep_rows_all(A), ep_rows_own = dev::ep_rows_all(A);
+        std::vector<int> col_mems;     // memory indices of the collation tables held, table 0 first
+        int ep_count = A;
+        if (split) {
+            for (int m = 0; m < 32; m++) ep_rows.row[m] = ep_rows_own.row[m] = -1;
+            col_mems.push_back(0);
+            for (int m = 1; m < A; m++) if (own_mem[m]) col_mems.push_back(m);
+            ep_count = 0;
+            for (int m : col_mems) ep_rows.row[m] = (signed char)ep_count++;
+            if (ep_rows.row[lp.gkr_order[0]] < 0) ep_rows.row[lp.gkr_order[0]] = (signed char)ep_count++;
+            for (int m = 0; m < A; m++) if (own_mem[m]) ep_rows_own.row[m] = ep_rows.row[m];
+        } else for (int m = 0; m < A; m++) col_mems.push_back(m);
+        const bool col_p0_only = split && !own_mem[0];
         // polynomialize (lasso.rs:157-250)
         u64* dims = nullptr;
         u64* ep = nullptr;
+        auto epm = [&](int m) -> const u64* {
+            if (ep_rows.row[m] < 0) throw Error("lasso: E table of a memory this rank does not hold");
+            return ep + (size_t)ep_rows.row[m] * N;
+        };
         if (need_split) {
             dims = ctx->alloc_n<u64>(4 * N);
-            ep = ctx->alloc_n<u64>((size_t)A * N);
-            ctx->prof_begin(cls_aux, (double)N * 8 * (1 + 4 + A));
-            dev::lasso_split(st, L, d_input, dims, ep);
+            ep = ctx->alloc_n<u64>((size_t)ep_count * N);
+            ctx->prof_begin(cls_aux, (double)N * 8 * (1 + 4 + ep_count));
+            dev::lasso_split(st, L, d_input, dims, ep, ep_rows);
             ctx->prof_end();
             if (fork_recorded) hip_check(hipEventRecord(ctx->ev_aux[0], st), "lasso: split event");
         }
@@ -962,7 +967,7 @@ struct Prover {
         if (do_col) col_where([&] {
             if (col_aux) hip_check(hipStreamWaitEvent(st, ctx->ev_aux[0], 0), "lasso: wait for the limb split");
             eq_now(eq, nu, r_off);
-            int grid = dev::lasso_claim(st, L, eq, ep, partials);
+            int grid = dev::lasso_claim(st, L, eq, ep, ep_rows_own, partials);  // sharded: this rank's memories only (partial sum)
             reduce(grid, 1, claim_slot);
         });
         Cell claimed = cell();
@@ -972,9 +977,11 @@ struct Prover {
             dev::Powers pw;
             memset(&pw, 0, sizeof(pw));
             if (A > dev::PW_MAX) throw Error("lasso: too many memories");
-            u64 c = 1;
-            for (int i = 0; i < A; i++) { pw.v[i] = e2(c, 0); c = gl_mul(c, M); }
-            ScHandle sc = sc_stride(dev::SC_COLLATION, ep, true, N, A, nu, pw, nullptr, do_col);
+            std::vector<u64> mpow(A, 1);
+            for (int i = 1; i < A; i++) mpow[i] = gl_mul(mpow[i - 1], M);
+            for (size_t q = 0; q < col_mems.size(); q++) pw.v[q] = e2(mpow[col_mems[q]], 0);   // table q is memory col_mems[q]: weight M^m
+            const bool col_run = do_col && (int)col_mems.size() > (col_p0_only ? 1 : 0);
+            ScHandle sc = sc_stride(dev::SC_COLLATION, ep, true, N, (int)col_mems.size(), nu, pw, nullptr, col_run, col_p0_only);
             mark("lasso: collation sum-check, " + std::to_string(nu) + " rounds x 3 coefficients (lasso.rs:271-279) [C1, C3; poly(0) quirk]");
             defer_sumcheck(sc, 2, claimed, nullptr);
             if (col_aux) on_aux([&] { flush_stride(); });  // all collation rounds, now, on the second stream
@@ -983,19 +990,7 @@ struct Prover {
         u64 gamma = gamma_e.c0, tau = tau_e.c0;     // prover.rs:38-39: base limb 0 only
         // counters: only the memories whose index equals a chunk (dimension) index reach the transcript
         // (lasso.rs:317-319 indexes read_ts/final_cts by chunk index)
-        // MemoryCheckingProver::new (prover.rs:35-89): which memories of grand product #1 this rank holds
-        const int G = (int)lp.gkr_order.size();
-        const bool split = world > 1;  // grand product #1 split by memory over the ranks
-        std::vector<int> local_pairs;  // global pair ids (reads: i, writes: G + i) whose hash rows this rank holds, ascending
-        std::vector<int> local_mems;
-        bool p0_only = false;
-        if (split) {
-            for (int i = 0; i < G; i++) if (mine(gp1_mem_owner[i])) local_mems.push_back(i);
-            p0_only = !mine(gp1_mem_owner[0]);
-            if (p0_only) local_pairs.push_back(0);
-            for (int i : local_mems) local_pairs.push_back(i);
-            for (int i : local_mems) local_pairs.push_back(G + i);
-        }
+        // MemoryCheckingProver::new (prover.rs:35-89)
         const int nrows = split ? (int)local_pairs.size() : 2 * G;
         // Grand product #1 without hash tables: the top layer's first round recomputes the hashes from dims / read_ts / E and
         // writes tree level 1, the next layers' first rounds write levels 2 .. emit (HG_NO_HASH_FUSE=1: materialise them).
@@ -1012,8 +1007,9 @@ struct Prover {
         const bool use_aux = fork_recorded && emit > 0;
         auto aux = [&](const std::function<void()>& fn) { if (use_aux) on_aux(fn); else fn(); };
         // a rank that only holds a few memories of grand product #1 needs the counters of their chunks only
-        std::vector<char> need_chunk(4, (!split || do_gp2 || do_open) ? 1 : 0);
-        if (any_gp1 && split) {
+        // (the chunk of pair 0, and the chunks whose dim / read_ts / final_cts openings it owns: those of its own memories)
+        std::vector<char> need_chunk(4, split ? 0 : 1);
+        if (split) {
             if (p0_only) need_chunk[lp.gkr_chunk[0]] = 1;
             for (int i : local_mems) need_chunk[lp.gkr_chunk[i]] = 1;
         }
@@ -1074,8 +1070,8 @@ struct Prover {
             };
             for (int i = 0; i < G; i++) {  // memory-GKR order is chunk-major
                 dev::GpHashMem m;
-                m.ep = ep + (size_t)lp.gkr_order[i] * N; m.chunk = lp.gkr_chunk[i]; m.rd_row = row_of(i); m.wr_row = row_of(G + i);
-                if (m.rd_row >= 0 || m.wr_row >= 0) hm.push_back(m);
+                m.chunk = lp.gkr_chunk[i]; m.rd_row = row_of(i); m.wr_row = row_of(G + i);
+                if (m.rd_row >= 0 || m.wr_row >= 0) { m.ep = epm(lp.gkr_order[i]); hm.push_back(m); }
             }
             dev::GpHashSrc hs;
             memset(&hs, 0, sizeof(hs));
@@ -1097,7 +1093,7 @@ struct Prover {
         }
         u64* H1 = (any_gp1 && !emit) ? ctx->alloc_n<u64>((size_t)nrows * N) : nullptr;
         u64* L1 = (any_gp1 && !emit && gp_deepest(nu, gp1_owner) >= 1) ? ctx->alloc_n<u64>((size_t)nrows * (N / 2)) : nullptr;
-        u64* H2 = do_gp2 ? ctx->alloc_n<u64>((size_t)2 * G * M) : nullptr;
+        u64* H2 = do_gp2 ? ctx->alloc_n<u64>((size_t)nrows * M) : nullptr;   // sharded: the rows of local_pairs only
         // hash launches are grouped by chunk: the memories of a chunk share the dim / read_ts columns
         struct HashReq { int i; u64 *rd, *wr, *rd1, *wr1; };
         std::vector<HashReq> reqs;
@@ -1126,7 +1122,7 @@ struct Prover {
                 memset(&ha, 0, sizeof(ha));
                 for (int q = 0; q < cnt; q++) {
                     const HashReq& r = of_c[o + q];
-                    ha.ep[q] = ep + (size_t)lp.gkr_order[r.i] * N; ha.rd[q] = r.rd; ha.wr[q] = r.wr; ha.rd1[q] = r.rd1; ha.wr1[q] = r.wr1;
+                    ha.ep[q] = epm(lp.gkr_order[r.i]); ha.rd[q] = r.rd; ha.wr[q] = r.wr; ha.rd1[q] = r.rd1; ha.wr1[q] = r.wr1;
                 }
                 ctx->prof_begin(cls_hash, (double)N * 8 * (2 + cnt * (L1 ? 4 : 3)));
                 dev::lasso_hash_rw(st, N, dims + (size_t)c * N, read_ts[c], ha, cnt, gamma, tau);
@@ -1137,8 +1133,18 @@ struct Prover {
             if (G > 32) throw Error("lasso: more than 32 memories");
             dev::HashIfArgs ha;
             memset(&ha, 0, sizeof(ha));
-            for (int i = 0; i < G; i++) { ha.cutoff[i] = (u32)lp.mems[lp.gkr_order[i]].cutoff; ha.fc[i] = final_cts[lp.gkr_chunk[i]]; }
-            ctx->prof_begin(cls_hash, (double)G * M * 8 * 3);
+            for (int i = 0; i < G; i++) {
+                ha.cutoff[i] = (u32)lp.mems[lp.gkr_order[i]].cutoff;
+                ha.row_init[i] = split ? -1 : i; ha.row_fin[i] = split ? -1 : G + i;
+                if (split)
+                    for (size_t q = 0; q < local_pairs.size(); q++) {
+                        if (local_pairs[q] == i) ha.row_init[i] = (int)q;
+                        if (local_pairs[q] == G + i) ha.row_fin[i] = (int)q;
+                    }
+                ha.fc[i] = ha.row_fin[i] >= 0 ? final_cts[lp.gkr_chunk[i]] : nullptr;   // (init hashes do not read the counters)
+                if (ha.row_fin[i] >= 0 && !ha.fc[i]) throw Error("lasso: counters of a needed chunk were not computed");
+            }
+            ctx->prof_begin(cls_hash, (double)nrows * M * 8 * 1.5);
             dev::lasso_hash_if(st, ha, G, gamma, tau, H2);
             ctx->prof_end();
         });
@@ -1147,7 +1153,10 @@ struct Prover {
                          : grand_product(H1, N, 2 * G, gp1_owner, L1, nullptr, false, d_hash_src, emit, hash_build_bytes);  // reads then writes (prover.rs:161-165)
         mark("lasso: memory checking, grand product #2 over inits then finals (prover.rs:167-171)");
         GpOut g2{0, nullptr};
-        aux([&] { g2 = grand_product(H2, M, 2 * G, std::vector<int>(16, own_gp2)); });  // inits then finals (prover.rs:167-171); its tree on the second stream
+        aux([&] {   // inits then finals (prover.rs:167-171); its tree on the second stream
+            g2 = split ? grand_product(H2, M, 2 * G, std::vector<int>(16, rank), nullptr, &local_pairs, p0_only)
+                       : grand_product(H2, M, 2 * G, std::vector<int>(16, rank));
+        });
         if (use_aux) {
             // grand product #1's first launch reads the counters, grand product #2's first rounds its tree: the main stream waits
             // for the second one only there, after the collation sum-check has been enqueued
@@ -1165,12 +1174,13 @@ struct Prover {
             eq_now(eqy, 16, g2.point_off);
         }
         for (auto& chk : lp.chunks) {
-            int c = chk.first;
+            const int c = chk.first;
+            // sharded: dim(x), read_ts(x), final_cts(y) of a chunk belong to the owner of its first memory, E_m(x) to the owner of m
+            const bool own_chunk = do_open && own_mem[chk.second[0]];
             std::vector<const u64*> xs;
-            if (do_open) {
-                xs = {dims + (size_t)c * N, read_ts[c]};
-                for (int m : chk.second) xs.push_back(ep + (size_t)m * N);
-            } else xs.assign(2 + chk.second.size(), nullptr);
+            xs.push_back(own_chunk ? dims + (size_t)c * N : nullptr);
+            xs.push_back(own_chunk ? read_ts[c] : nullptr);
+            for (int m : chk.second) xs.push_back(do_open && own_mem[m] ? epm(m) : nullptr);
             size_t base_slot = slot(3 + chk.second.size());
             // order on the wire: dim(x), read_ts(x), final_cts(y), then E_m(x)
             std::vector<size_t> dst = {base_slot, base_slot + 1};
@@ -1178,19 +1188,28 @@ struct Prover {
             for (size_t o = 0; o < xs.size(); o += 8) {
                 int cnt = (int)std::min<size_t>(8, xs.size() - o);
                 const u64* tabs[8] = {nullptr};
-                for (int t = 0; t < cnt; t++) tabs[t] = xs[o + t];
-                size_t tmp = slot(cnt);
-                if (do_open) {
+                bool all = true;
+                for (int t = 0; t < cnt; t++) { tabs[t] = xs[o + t]; all = all && tabs[t]; }
+                size_t tmp = slot(cnt);   // (the same slots on every rank, whatever it owns)
+                if (all) {
                     ctx->prof_begin(cls_aux, (double)N * (16 + 8.0 * cnt));
                     dev::dot_eq(st, eqx, tabs, cnt, N, partials, d_res() + tmp);
                     ctx->prof_end();
+                } else {
+                    for (int t = 0; t < cnt; t++) {   // a rank that holds only some tables of the group: one launch per table it owns
+                        if (!tabs[t]) continue;
+                        const u64* one[8] = {tabs[t]};
+                        ctx->prof_begin(cls_aux, (double)N * 24);
+                        dev::dot_eq(st, eqx, one, 1, N, partials, d_res() + tmp + t);
+                        ctx->prof_end();
+                    }
                 }
                 for (int t = 0; t < cnt; t++) {
                     size_t from = tmp + t, to = dst[o + t];
                     ops.push_back([this, from, to] { ctx->h_res[to] = ctx->h_res[from]; });
                 }
             }
-            if (do_open) {
+            if (own_chunk) {
                 const u64* tabs[8] = {final_cts[c]};
                 dev::dot_eq(st, eqy, tabs, 1, M, partials, d_res() + base_slot + 2);
             }

@@ -330,14 +330,14 @@ struct SeqProver {
         const size_t N = (size_t)1 << nu, M = 65536;
         u64* dims = ctx->alloc_n<u64>(4 * N);
         u64* ep = ctx->alloc_n<u64>((size_t)A * N);
-        dev::lasso_split(st, L, d_input, dims, ep);  // polynomialize (lasso.rs:157-250)
+        dev::lasso_split(st, L, d_input, dims, ep, dev::ep_rows_all(A));  // polynomialize (lasso.rs:157-250)
         const size_t r_off = epos();
         for (int i = 0; i < nu; i++) squeeze();       // lasso.rs:85
         E2* eq = ctx->alloc_n<E2>(N);
         eq_single(eq, nu, r_off);
         const size_t claim_slot = slot(1);
         {
-            int grid = dev::lasso_claim(st, L, eq, ep, ctx->d_partials);
+            int grid = dev::lasso_claim(st, L, eq, ep, dev::ep_rows_all(A), ctx->d_partials);
             dev::reduce_partials(st, ctx->d_partials, grid, 1, d_res() + claim_slot);
         }
         sync();
@@ -386,7 +386,7 @@ struct SeqProver {
             }
             dev::HashIfArgs hi;
             memset(&hi, 0, sizeof(hi));
-            for (int i = 0; i < G; i++) { hi.cutoff[i] = (u32)lp.mems[lp.gkr_order[i]].cutoff; hi.fc[i] = final_cts[lp.gkr_chunk[i]]; }
+            for (int i = 0; i < G; i++) { hi.cutoff[i] = (u32)lp.mems[lp.gkr_order[i]].cutoff; hi.fc[i] = final_cts[lp.gkr_chunk[i]]; hi.row_init[i] = i; hi.row_fin[i] = G + i; }
             dev::lasso_hash_if(st, hi, G, gamma, tau, H2);
             xoff = grand_product(H1, false, N, 2 * G);   // prover.rs:161-165
             yoff = grand_product(H2, false, M, 2 * G);   // prover.rs:167-171
