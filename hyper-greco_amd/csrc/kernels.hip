@@ -1427,14 +1427,22 @@ __global__ __launch_bounds__(TPB) void k_counter_ranks_all(const u32* __restrict
         if (p + 1 == n || ks[p + 1] != key) out.final_cts[c][key & 0xFFFF] = (u64)rank + 1;
     }
 }
+__global__ __launch_bounds__(TPB) void k_counter_clear(CounterOut out, CounterPlan P, size_t N) {
+    const size_t per = (N + 65536) / 2, total = per * P.nchunks;   // 16-byte units per chunk: read_ts (N entries) then final_cts (2^16)
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < total; i += (size_t)gridDim.x * TPB) {
+        const int c = P.chunk[i / per];
+        const size_t j = (i % per) * 2;
+        u64* dst = j < N ? out.read_ts[c] + j : out.final_cts[c] + (j - N);
+        *reinterpret_cast<ulonglong2*>(dst) = make_ulonglong2(0, 0);
+    }
+}
 void lasso_counters_all(hipStream_t st, const LassoDev& L, unsigned chunk_mask, const u64* dims, const CounterOut& out, void* temp, size_t temp_bytes,
                         u32* keys, u32* keys_sorted, u32* vals, u32* vals_sorted, u32* starts) {
     const size_t N = (size_t)1 << L.nu;
     const CounterPlan P = counter_plan(L, chunk_mask);
-    for (int q = 0; q < P.nchunks; q++) {
-        check_hip(hipMemsetAsync(out.read_ts[P.chunk[q]], 0, N * sizeof(u64), st), "clear read_ts");
-        check_hip(hipMemsetAsync(out.final_cts[P.chunk[q]], 0, 65536 * sizeof(u64), st), "clear final_cts");
-    }
+    // rows outside a chunk's counted segments and addresses never touched keep counter 0: one clearing launch for all chunks
+    // (eight hipMemsetAsync calls cost 5-14 us each on the stream and, as nodes of a captured graph, ~60 us each)
+    if (P.nchunks > 0) k_counter_clear<<<grid_for((size_t)P.nchunks * (N + 65536) / 2), TPB, 0, st>>>(out, P, N);
     const size_t total = P.off[P.nchunks];
     if (total == 0) return;
     const int grid = grid_for(total);
@@ -1571,9 +1579,13 @@ void gp_top(hipStream_t st, const u64* top, int nb, E2* roots, E2* evals) {
     k_gp_top<<<(nb + 63) / 64, 64, 0, st>>>(top, nb, roots, evals);
 }
 
-struct DotTabs { const u64* t[8]; };
-__global__ __launch_bounds__(TPB) void k_dot_eq(const E2* __restrict__ eq, DotTabs tabs, int ntab, size_t n, E2* __restrict__ partials) {
+// out[t] = sum_j eq[j] * tabs[t][j] for up to DOT_MAX base-field tables sharing one eq table, in ONE launch: grid.y = group of 8
+// tables (a thread keeps 8 accumulators; eq is re-read per group, from L2 / MALL after the first). The reduction launch has one
+// workgroup per table and writes result t to out[slot[t]].
+__global__ __launch_bounds__(TPB) void k_dot_eq(const E2* __restrict__ eq, DotTabs tabs, int ntab_all, size_t n, E2* __restrict__ partials) {
     __shared__ E2 sm[TPB / 64];
+    const int t0 = blockIdx.y * 8;
+    const int ntab = min(8, ntab_all - t0);
     E2 acc[8];
 #pragma unroll
     for (int t = 0; t < 8; t++) acc[t] = e2_zero();
@@ -1583,7 +1595,7 @@ __global__ __launch_bounds__(TPB) void k_dot_eq(const E2* __restrict__ eq, DotTa
 #pragma unroll
             for (int t = 0; t < 8; t++)
                 if (t < ntab) {
-                    const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(tabs.t[t] + j);
+                    const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(tabs.t[t0 + t] + j);
                     acc[t] = e2_add(acc[t], e2_add(e2_mul_f(e0, v.x), e2_mul_f(e1, v.y)));
                 }
         }
@@ -1592,26 +1604,38 @@ __global__ __launch_bounds__(TPB) void k_dot_eq(const E2* __restrict__ eq, DotTa
             E2 e = eq[j];
 #pragma unroll
             for (int t = 0; t < 8; t++)
-                if (t < ntab) acc[t] = e2_add(acc[t], e2_mul_f(e, tabs.t[t][j]));
+                if (t < ntab) acc[t] = e2_add(acc[t], e2_mul_f(e, tabs.t[t0 + t][j]));
         }
     }
 #pragma unroll
     for (int t = 0; t < 8; t++)
         if (t < ntab) {
             E2 s = block_sum(acc[t], sm);
-            if (threadIdx.x == 0) partials[(size_t)blockIdx.x * ntab + t] = s;
+            if (threadIdx.x == 0) partials[(size_t)blockIdx.x * ntab_all + t0 + t] = s;
         }
 }
-__global__ __launch_bounds__(TPB) void k_reduce_partials(const E2* __restrict__ partials, int nblocks, int nv, E2* __restrict__ out);
-// out[t] = sum_j eq[j] * tabs[t][j]
-void dot_eq(hipStream_t st, const E2* eq, const u64* const tabs[8], int ntab, size_t n, E2* partials, E2* out) {
-    DotTabs d;
-    for (int t = 0; t < 8; t++) d.t[t] = t < ntab ? tabs[t] : nullptr;
+__global__ __launch_bounds__(TPB) void k_dot_reduce(const E2* __restrict__ partials, int nblocks, int nv, DotTabs tabs, E2* __restrict__ out) {
+    __shared__ E2 sm[TPB / 64];
+    const int v = blockIdx.x;
+    E2 a = e2_zero();
+    for (int b = threadIdx.x; b < nblocks; b += TPB) a = e2_add(a, partials[(size_t)b * nv + v]);
+    a = block_sum(a, sm);
+    if (threadIdx.x == 0) out[tabs.slot[v]] = a;
+}
+void dot_eq_many(hipStream_t st, const E2* eq, const DotTabs& tabs, int ntab, size_t n, E2* partials, E2* out) {
+    if (ntab <= 0) return;
+    if (ntab > DOT_MAX) throw std::runtime_error("dot_eq_many: too many tables");
     // (measured slower here: column accumulators - 8 independent 8-byte streams per thread need the occupancy more -
     // and the last-arriving-workgroup reduction - 8 values x 1024 partials)
-    const int grid = grid_for((n + 1) / 2);
-    k_dot_eq<<<grid, TPB, 0, st>>>(eq, d, ntab, n, partials);
-    k_reduce_partials<<<1, TPB, 0, st>>>(partials, grid, ntab, out);
+    const int gx = grid_for((n + 1) / 2);
+    k_dot_eq<<<dim3(gx, (ntab + 7) / 8), TPB, 0, st>>>(eq, tabs, ntab, n, partials);
+    k_dot_reduce<<<ntab, TPB, 0, st>>>(partials, gx, ntab, tabs, out);
+}
+void dot_eq(hipStream_t st, const E2* eq, const u64* const tabs[8], int ntab, size_t n, E2* partials, E2* out) {
+    DotTabs d;
+    memset(&d, 0, sizeof(d));
+    for (int t = 0; t < ntab; t++) { d.t[t] = tabs[t]; d.slot[t] = t; }
+    dot_eq_many(st, eq, d, ntab, n, partials, out);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -198,6 +198,10 @@ void prod_tail(hipStream_t st, const u64* in, int in_len, const ProdTailOut& out
 void gp_top(hipStream_t st, const u64* top, int nb, E2* roots, E2* evals);
 // dot products with an eq table: out[t] = sum_j eq[j] * tabs[t][j] for ntab <= 8 base tables; `partials` is a partials buffer
 void dot_eq(hipStream_t st, const E2* eq, const u64* const tabs[8], int ntab, size_t n, E2* partials, E2* out);
+// the same for up to DOT_MAX tables in one launch (+ one reduction launch): result t goes to out[tabs.slot[t]]
+constexpr int DOT_MAX = 64;
+struct DotTabs { const u64* t[DOT_MAX]; int slot[DOT_MAX]; };
+void dot_eq_many(hipStream_t st, const E2* eq, const DotTabs& tabs, int ntab, size_t n, E2* partials, E2* out);
 
 // ---- Vanilla / FFT nodes ----------------------------------------------------------------------
 struct CsrLin { const u32* ptr; const u32* gate; const u64* coef; };           // per input position -> (gate, c)

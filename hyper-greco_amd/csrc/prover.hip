@@ -449,8 +449,7 @@ struct Prover {
             }
         }
         dev::StJob* d_jobs = ctx->alloc_n<dev::StJob>(nj);
-        hip_check(hipMemcpyAsync(d_jobs, stage(st_jobs.data(), (size_t)nj * sizeof(dev::StJob)), (size_t)nj * sizeof(dev::StJob),
-                                 hipMemcpyHostToDevice, st), "upload jobs");
+        upload(d_jobs, st_jobs.data(), (size_t)nj * sizeof(dev::StJob), "upload jobs");
         std::vector<dev::StItem> flat;
         std::vector<size_t> offs;
         std::vector<std::vector<int>> grids(plan.size());
@@ -463,7 +462,7 @@ struct Prover {
             flat.insert(flat.end(), L.items.begin(), L.items.end());
         }
         dev::StItem* d_items = ctx->alloc_n<dev::StItem>(flat.size());
-        hip_check(hipMemcpyAsync(d_items, stage(flat.data(), flat.size() * sizeof(dev::StItem)), flat.size() * sizeof(dev::StItem), hipMemcpyHostToDevice, st), "upload step items");
+        upload(d_items, flat.data(), flat.size() * sizeof(dev::StItem), "upload step items");
         auto round_bytes = [&](const dev::StJob& J, int rd) {
             size_t half = (size_t)1 << (J.nvars - 1 - rd);
             return (double)J.ntab * (2.0 * half * ((J.base && rd == 0) ? 8 : 16) + half * 16.0);
@@ -526,8 +525,7 @@ struct Prover {
         st_after_seq.clear();
         if (!scatter.empty()) {
             dev::ScatterEnt* d = ctx->alloc_n<dev::ScatterEnt>(scatter.size());
-            hip_check(hipMemcpyAsync(d, stage(scatter.data(), scatter.size() * sizeof(dev::ScatterEnt)), scatter.size() * sizeof(dev::ScatterEnt),
-                                     hipMemcpyHostToDevice, st), "upload scatter list");
+            upload(d, scatter.data(), scatter.size() * sizeof(dev::ScatterEnt), "upload scatter list");
             dev::scatter_e2(st, d, scatter.size(), d_res());
             scatter.clear();
         }
@@ -623,10 +621,10 @@ struct Prover {
         }
         for (int q = 0; q < nj; q++) jobs[q].tail_buf = cur_buf[q];
         dev::PsJob* d_jobs = ctx->alloc_n<dev::PsJob>(nj);
-        hip_check(hipMemcpyAsync(d_jobs, stage(jobs.data(), (size_t)nj * sizeof(dev::PsJob)), (size_t)nj * sizeof(dev::PsJob), hipMemcpyHostToDevice, st), "upload jobs");
+        upload(d_jobs, jobs.data(), (size_t)nj * sizeof(dev::PsJob), "upload jobs");
         if (!all_items.empty()) {
             dev::PsItem* d_items = ctx->alloc_n<dev::PsItem>(all_items.size());
-            hip_check(hipMemcpyAsync(d_items, stage(all_items.data(), all_items.size() * sizeof(dev::PsItem)), all_items.size() * sizeof(dev::PsItem), hipMemcpyHostToDevice, st), "upload items");
+            upload(d_items, all_items.data(), all_items.size() * sizeof(dev::PsItem), "upload items");
             for (auto& L : launches) {
                 ctx->prof_begin(L.two ? cls_ps2 : cls_ps, L.bytes);
                 dev::ps_round(st, L.two, d_jobs, d_items + L.off, L.cnt, L.grid, ctx->d_chal, partials, d_res());
@@ -641,6 +639,10 @@ struct Prover {
     }
     static constexpr size_t MAX_BATCH = 64;
     // pinned staging for small host->device descriptor copies (kept alive until the final synchronisation)
+    // small host->device descriptor copy through the staging buffer, on the current stream
+    void upload(void* dst, const void* src, size_t bytes, const char* what) {
+        hip_check(hipMemcpyAsync(dst, stage(src, bytes), bytes, hipMemcpyHostToDevice, st), what);
+    }
     void* stage(const void* src, size_t bytes) {
         size_t need = (bytes + 63) & ~(size_t)63;
         if (ctx->stage_used + need > ctx->stage_cap) throw Error("staging buffer exhausted");
@@ -704,7 +706,7 @@ struct Prover {
         J.out = out; J.n = n; J.point_dev = point_dev;
         J.cs.n = 1; J.cs.unit_alpha = 1; J.cs.point_off[0] = point_off;
         dev::EqJob* d = ctx->alloc_n<dev::EqJob>(1);
-        hip_check(hipMemcpyAsync(d, stage(&J, sizeof(J)), sizeof(J), hipMemcpyHostToDevice, st), "upload eq job");
+        upload(d, &J, sizeof(J), "upload eq job");
         ctx->prof_begin(cls_aux, 16.0 * ((size_t)1 << n));
         dev::eq_jobs(st, d, 1, n, ctx->d_chal);
         ctx->prof_end();
@@ -731,7 +733,7 @@ struct Prover {
     void flush_jobs(std::vector<JobT>& q, int cls, double bytes, LaunchFn launch) {
         if (q.empty()) return;
         JobT* d = ctx->alloc_n<JobT>(q.size());
-        hip_check(hipMemcpyAsync(d, stage(q.data(), q.size() * sizeof(JobT)), q.size() * sizeof(JobT), hipMemcpyHostToDevice, st), "upload jobs");
+        upload(d, q.data(), q.size() * sizeof(JobT), "upload jobs");
         ctx->prof_begin(cls, bytes);
         launch(d, (int)q.size());
         ctx->prof_end();
@@ -1078,10 +1080,10 @@ struct Prover {
             for (int c = 0; c < 4; c++) { hs.dim[c] = dims + (size_t)c * N; hs.ts[c] = read_ts.count(c) ? read_ts[c] : nullptr; }
             for (auto& m : hm) if (!hs.ts[m.chunk]) throw Error("lasso: counters of a needed chunk were not computed");
             dev::GpHashMem* d_hm = ctx->alloc_n<dev::GpHashMem>(hm.size());
-            hip_check(hipMemcpyAsync(d_hm, stage(hm.data(), hm.size() * sizeof(dev::GpHashMem)), hm.size() * sizeof(dev::GpHashMem), hipMemcpyHostToDevice, st), "upload hash sources");
+            upload(d_hm, hm.data(), hm.size() * sizeof(dev::GpHashMem), "upload hash sources");
             hs.mems = d_hm; hs.nmem = (int)hm.size(); hs.gamma = gamma; hs.gamma2 = gl_mul(gamma, gamma); hs.tau = tau;
             dev::GpHashSrc* d_hs = ctx->alloc_n<dev::GpHashSrc>(1);
-            hip_check(hipMemcpyAsync(d_hs, stage(&hs, sizeof(hs)), sizeof(hs), hipMemcpyHostToDevice, st), "upload hash sources");
+            upload(d_hs, &hs, sizeof(hs), "upload hash sources");
             d_hash_src = d_hs;
             // algorithmic bytes of the hash build this replaces (the accounting of lasso_hash_rw below): dim + read_ts per chunk in
             // use, E read and read / write hash rows written per memory; level 1 is credited by sc_stride (next_level)
@@ -1173,48 +1175,40 @@ struct Prover {
             eq_now(eqx, nu, g1.point_off);
             eq_now(eqy, 16, g2.point_off);
         }
+        // every opening at x in one launch, every opening at y in another (dev::dot_eq_many): results land in their wire slots
+        dev::DotTabs tx, ty;
+        memset(&tx, 0, sizeof(tx)); memset(&ty, 0, sizeof(ty));
+        int nx = 0, ny = 0;
+        auto add_x = [&](const u64* tab, size_t out_slot) {
+            if (nx >= dev::DOT_MAX) throw Error("lasso: too many openings");
+            tx.t[nx] = tab; tx.slot[nx] = (int)out_slot; nx++;
+        };
+        struct ChunkSlots { int c; size_t base, count; };
+        std::vector<ChunkSlots> chunk_slots;
         for (auto& chk : lp.chunks) {
             const int c = chk.first;
+            // order on the wire: dim(x), read_ts(x), final_cts(y), then E_m(x)
             // sharded: dim(x), read_ts(x), final_cts(y) of a chunk belong to the owner of its first memory, E_m(x) to the owner of m
             const bool own_chunk = do_open && own_mem[chk.second[0]];
-            std::vector<const u64*> xs;
-            xs.push_back(own_chunk ? dims + (size_t)c * N : nullptr);
-            xs.push_back(own_chunk ? read_ts[c] : nullptr);
-            for (int m : chk.second) xs.push_back(do_open && own_mem[m] ? epm(m) : nullptr);
-            size_t base_slot = slot(3 + chk.second.size());
-            // order on the wire: dim(x), read_ts(x), final_cts(y), then E_m(x)
-            std::vector<size_t> dst = {base_slot, base_slot + 1};
-            for (size_t i = 0; i < chk.second.size(); i++) dst.push_back(base_slot + 3 + i);
-            for (size_t o = 0; o < xs.size(); o += 8) {
-                int cnt = (int)std::min<size_t>(8, xs.size() - o);
-                const u64* tabs[8] = {nullptr};
-                bool all = true;
-                for (int t = 0; t < cnt; t++) { tabs[t] = xs[o + t]; all = all && tabs[t]; }
-                size_t tmp = slot(cnt);   // (the same slots on every rank, whatever it owns)
-                if (all) {
-                    ctx->prof_begin(cls_aux, (double)N * (16 + 8.0 * cnt));
-                    dev::dot_eq(st, eqx, tabs, cnt, N, partials, d_res() + tmp);
-                    ctx->prof_end();
-                } else {
-                    for (int t = 0; t < cnt; t++) {   // a rank that holds only some tables of the group: one launch per table it owns
-                        if (!tabs[t]) continue;
-                        const u64* one[8] = {tabs[t]};
-                        ctx->prof_begin(cls_aux, (double)N * 24);
-                        dev::dot_eq(st, eqx, one, 1, N, partials, d_res() + tmp + t);
-                        ctx->prof_end();
-                    }
-                }
-                for (int t = 0; t < cnt; t++) {
-                    size_t from = tmp + t, to = dst[o + t];
-                    ops.push_back([this, from, to] { ctx->h_res[to] = ctx->h_res[from]; });
-                }
-            }
+            const size_t base_slot = slot(3 + chk.second.size());
             if (own_chunk) {
-                const u64* tabs[8] = {final_cts[c]};
-                dev::dot_eq(st, eqy, tabs, 1, M, partials, d_res() + base_slot + 2);
+                add_x(dims + (size_t)c * N, base_slot);
+                add_x(read_ts[c], base_slot + 1);
+                ty.t[ny] = final_cts[c]; ty.slot[ny] = (int)(base_slot + 2); ny++;
             }
-            mark("lasso: openings of chunk " + std::to_string(c) + ": dim(x), read_ts(x), final_cts(y), E_m(x) (prover.rs:173-178)");
-            defer_write_slots(base_slot, 3 + chk.second.size());
+            for (size_t i = 0; i < chk.second.size(); i++)
+                if (do_open && own_mem[chk.second[i]]) add_x(epm(chk.second[i]), base_slot + 3 + i);
+            chunk_slots.push_back({c, base_slot, 3 + chk.second.size()});
+        }
+        if (nx) {
+            ctx->prof_begin(cls_aux, (double)N * (16.0 * ((nx + 7) / 8) + 8.0 * nx));
+            dev::dot_eq_many(st, eqx, tx, nx, N, partials, d_res());
+            ctx->prof_end();
+        }
+        if (ny) dev::dot_eq_many(st, eqy, ty, ny, M, partials, d_res());
+        for (auto& cs : chunk_slots) {
+            mark("lasso: openings of chunk " + std::to_string(cs.c) + ": dim(x), read_ts(x), final_cts(y), E_m(x) (prover.rs:173-178)");
+            defer_write_slots(cs.base, cs.count);
         }
         });
         flush_stride();  // collation + every grand-product layer, round-synchronised
@@ -1696,6 +1690,9 @@ static ProveResult prove_capture(hg_ctx* ctx, const hg_pk* pk, const hg_values* 
         throw;
     }
     hip_check(hipStreamEndCapture(ctx->stream, &C->graph), "hipStreamEndCapture");
+    // (Re-issuing the captured nodes from the library on two real streams - kernel parameters and dependencies read back from the
+    // graph - was measured against hipGraphLaunch: 3.50-3.59 ms vs 3.52-3.64 ms of GPU time and 0.53 vs 0.40 ms of host time per
+    // prove. No gain, not kept: the serialised look of a replay in a rocprofv3 trace is a profiling artefact.)
     hip_check(hipGraphInstantiate(&C->exec, C->graph, nullptr, nullptr, 0), "hipGraphInstantiate");
     hip_check(hipEventCreate(&C->ev_a), "event"); hip_check(hipEventCreate(&C->ev_b), "event");
     C->pk = pk; C->pk_serial = pk->serial; C->d_vals = v->d_vals; C->d_ct0is = v->d_ct0is; C->one_stream = ctx->one_stream; C->epoch = ctx->arena_epoch;
