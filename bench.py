@@ -5,8 +5,9 @@ configs[2]), on N MI355X GPUs of one node.
 A "step" = one GKR prove (the reference's "GKR prove" span [REF bfv-gkr/src/sk_encryption_circuit.rs:455-457],
 plus the output-claim evaluation :444-448) of one synthetic witness whose node tables are already resident in
 HBM. N > 1, default `--mode shard`: ONE proof is sharded over the N GPUs (strong scaling): every rank holds the
-same witness, runs the device jobs it owns (the jobs are independent; grand product #1 is split by memory, DESIGN.md
-§3/§7) and one RCCL all-gather of the scalar result buffers per proof is the only exchange; `value` = max-over-ranks step time = ms per proof.
+same witness, runs its share (the Lasso node split by memory, the node reductions dealt out whole) and
+ONE RCCL all-reduce of the scalar result buffer per proof, issued by the library on the prover stream, is the only exchange;
+`value` = max-over-ranks step time = ms per proof.
 `--mode dp`: every rank proves its own independent witness (weak scaling, no collective), `value` = step time / N.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel, HIP events on
@@ -201,10 +202,31 @@ def main():
     out = hg.ProofBuffer()
 
     lib_comm = shard and backend == "nccl"   # the library's own RCCL all-reduce (device buffers, no torch hop, no host staging)
+    exchange_note = None
     if lib_comm:
-        uid = [hg.comm_unique_id() if rank == 0 else None]
+        # every rank must take the same path: a failure anywhere (no librccl, init error) sends ALL ranks to the torch exchange
+        err = None
+        uid = [None]
+        if rank == 0:
+            try:
+                uid = [hg.comm_unique_id()]
+            except Exception as e:  # noqa: BLE001
+                err = str(e)
         dist.broadcast_object_list(uid, src=0)     # 128 bytes, once: the only use of torch.distributed on this path besides barriers
-        hg.comm_init(ctx, uid[0], rank, world)
+        if uid[0] is None:
+            err = err or "rank 0 could not create an RCCL id"
+        else:
+            try:
+                hg.comm_init(ctx, uid[0], rank, world)
+            except Exception as e:  # noqa: BLE001
+                err = str(e)
+        flag = torch.tensor([1 if err else 0], dtype=torch.int32, device=red_dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()):
+            if not err:
+                hg.comm_destroy(ctx)
+            lib_comm = False
+            exchange_note = "library RCCL communicator unavailable (%s): exchange through torch.distributed all_gather" % (err or "another rank failed")
 
     def step():
         if not shard:
@@ -307,8 +329,11 @@ def main():
             "config": {"workload": f"GKR prove (sk_encryption_circuit.rs:444-457) of the BFV sk-enc circuit, n={args.n} k={args.k} "
                                    "Goldilocks/GoldilocksExt2, seeded synthetic witness, node tables resident in HBM",
                        "n": args.n, "k": args.k, "field": "goldilocks", "proofs_per_step": 1 if (shard or world == 1) else world,
-                       "parallelism": (f"shard{world}: one proof, device jobs partitioned over {world} GPUs, one RCCL all-reduce of the result buffer per proof (inside the library)"
+                       "parallelism": ((f"shard{world}: one proof, Lasso node split by memory and node reductions dealt over {world} GPUs, "
+                                        + ("one RCCL all-reduce of the result buffer per proof (inside the library)" if lib_comm
+                                           else "one all-gather of the result buffers per proof through torch.distributed"))
                                        if shard else f"dp{world}: one independent proof per GPU, no data-path collective"),
+                       **({"exchange_note": exchange_note} if exchange_note else {}),
                        "proof_bytes": len(first), "gpu_ms_events": round(gpu_ms, 4),
                        "witness_gen_ms_device": round(vals.timings["witness_ms"], 2), "upload_ms": round(vals.timings["upload_ms"], 2)},
             # `achieved` / `avg_launch_us`: HIP events around the dominant kernel class INSIDE the timed region, where its launches

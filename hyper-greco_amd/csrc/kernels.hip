@@ -178,7 +178,7 @@ template <int KIND, typename T, bool FIRST>
 __device__ __forceinline__ void sc_round_body(const T* __restrict__ in, size_t in_stride, E2* __restrict__ out,
                                               size_t out_stride, int ntab, size_t half, E2 r, const E2* __restrict__ pw, const E2* __restrict__ pwr,
                                               int jb_log2, E2* __restrict__ red, E2* acc, size_t first_tile, size_t tile_step,
-                                              bool p0_only = false, u64* __restrict__ next_level = nullptr) {
+                                              bool p0_only = false, u64* __restrict__ next_level = nullptr, const StJob* __restrict__ mirror = nullptr) {
     using V = Val<T>;
     const int BD = blockDim.x, tid = threadIdx.x;
     const int G = BD >> jb_log2;
@@ -221,6 +221,13 @@ __device__ __forceinline__ void sc_round_body(const T* __restrict__ in, size_t i
                     xl = nxl; yl = nyl; xr = nxr; yr = nyr;
                 }
                 s0 = we2_reduce(w0); s2 = we2_reduce(w1); s3 = we2_reduce(wi);
+                if (mirror && g == 0) {  // the linear table S of a mirrored job (StJob::mirror): K1 S(t) + K2 joins P0 and P1
+                    E2 x, y;
+                    load_xy<E2, false>(in + (size_t)(2 * nb) * in_stride, j, half, x, y);
+                    s0 = e2_add(s0, e2_add(e2_mul(mirror->mk1, x), mirror->mk2));
+                    s2 = e2_add(s2, e2_add(e2_mul(mirror->mk1, y), mirror->mk2));
+                    store_e2(out + (size_t)(2 * nb) * out_stride + jo, e2_fold_wide(x, e2_sub(y, x), fr));
+                }
             } else if constexpr (FIRST && std::is_same<T, u64>::value) {
                 // first round on base-field rows: sum_i gamma^i (xl xr) etc. with the Ext2 weight gamma^i = pw[i];
                 // each base product is reduced once, its two weighted copies accumulate unreduced.
@@ -483,7 +490,8 @@ __global__ __launch_bounds__(256) void k_st_step(const StJob* __restrict__ jobs,
 #pragma unroll
     for (int t = 0; t < NV; t++) acc[t] = e2_zero();
     if (rd == 0) sc_round_body<KIND, T, true>(reinterpret_cast<const T*>(in), in_stride, out, half, J.ntab, half, chal[J.r_off + rd], J.pw, J.pwr, jb_log2, red, acc, bx, nblocks, J.p0_only != 0, J.next_level);
-    else sc_round_body<KIND, T, false>(reinterpret_cast<const T*>(in), in_stride, out, half, J.ntab, half, chal[J.r_off + rd], J.pw, J.pwr, jb_log2, red, acc, bx, nblocks, J.p0_only != 0);
+    else sc_round_body<KIND, T, false>(reinterpret_cast<const T*>(in), in_stride, out, half, J.ntab, half, chal[J.r_off + rd], J.pw, J.pwr, jb_log2, red, acc, bx, nblocks, J.p0_only != 0, nullptr,
+                                       J.mirror ? &J : nullptr);
     E2* part = partials + (size_t)y * SC_MAX_BLOCKS * NV;
     block_sum_multi<NV>(acc, sm);
     if (threadIdx.x == 0) {
@@ -501,7 +509,8 @@ __global__ __launch_bounds__(256) void k_st_step(const StJob* __restrict__ jobs,
 // two halves of a row), once per MEMORY for its read pair and its write pair (write hash = read hash + gamma^2), with the
 // dim / ts part shared by the memories of a chunk. E, dim, ts are small integers (< 2^16, < 2^16, < 2^32): gl_mul_small.
 // It also emits product-tree level 1 (J.next_level), so no separate hash or level-1 pass exists.
-__global__ __launch_bounds__(256) void k_gp_first_hash(const StJob* __restrict__ job, const StItem* __restrict__ item,
+template <bool MIRROR>   // write rows = read rows + gamma^2: not stored, not multiplied (StJob::mirror)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_gp_first_hash(const StJob* __restrict__ job, const StItem* __restrict__ item,
                                                        const E2* __restrict__ chal, E2* __restrict__ partials, E2* __restrict__ res) {
     const StJob& J = *job;
     const StItem& I = *item;
@@ -514,12 +523,14 @@ __global__ __launch_bounds__(256) void k_gp_first_hash(const StJob* __restrict__
     E2* __restrict__ out = I.out;
     const E2 r = chal[J.r_off];
     const bool p0_only = J.p0_only != 0;
+    constexpr bool mirror = MIRROR;
     const u64 gamma = H.gamma, gamma2 = H.gamma2, tau = H.tau;
     E2 acc[3] = {e2_zero(), e2_zero(), e2_zero()};
     for (size_t tile = bx; tile < ntiles; tile += nblocks) {
         const size_t j = (tile << 8) + threadIdx.x;
         const size_t jo = dpos(j, half);
         GpFirstAcc A = gp_first_acc_zero();
+        E2 Sx = e2_zero(), Sy = e2_zero();  // mirror: S at 0 and 1, S = sum_i w_i (l_i + r_i) (reduced sums: four column accumulators would cost a wave of occupancy)
         u64 p0 = 0, p2 = 0, p3 = 0;
         int cur_chunk = -1;
         u64 c0 = 0, c1 = 0, c2 = 0, c3 = 0;
@@ -543,16 +554,30 @@ __global__ __launch_bounds__(256) void k_gp_first_hash(const StJob* __restrict__
                 if (i == 0) { const u64 d = gl_sub(yl, xl); p0 = xl; p2 = gl_add(yl, d); p3 = gl_add(p2, d); }
                 gp_first_pair(A, xl, yl, xr, yr, J.pw[i], J.pwr[i], r, !(p0_only && i == 0), out + (size_t)(2 * i) * half + jo,
                               out + (size_t)(2 * i + 1) * half + jo, J.next_level ? J.next_level + (size_t)i * hN + 2 * j : nullptr);
+                if constexpr (MIRROR) if (!(p0_only && i == 0)) {
+                    const E2 gm = J.pw[i];
+                    const u64 hx = gl_add(xl, xr), hy = gl_add(yl, yr);
+                    Sx = e2_add(Sx, e2_mul_f(gm, hx));
+                    Sy = e2_add(Sy, e2_mul_f(gm, hy));
+                }
             }
             if (M.wr_row >= 0) {
                 const int i = M.wr_row;
                 xl = gl_add(xl, gamma2); yl = gl_add(yl, gamma2); xr = gl_add(xr, gamma2); yr = gl_add(yr, gamma2);  // t + 1
-                gp_first_pair(A, xl, yl, xr, yr, J.pw[i], J.pwr[i], r, true, out + (size_t)(2 * i) * half + jo,
-                              out + (size_t)(2 * i + 1) * half + jo, J.next_level ? J.next_level + (size_t)i * hN + 2 * j : nullptr);
+                if constexpr (!MIRROR)
+                    gp_first_pair(A, xl, yl, xr, yr, J.pw[i], J.pwr[i], r, true, out + (size_t)(2 * i) * half + jo,
+                                  out + (size_t)(2 * i + 1) * half + jo, J.next_level ? J.next_level + (size_t)i * hN + 2 * j : nullptr);
+                else if (J.next_level)   // only the tree needs the write row: its level-1 entries
+                    *reinterpret_cast<ulonglong2*>(J.next_level + (size_t)i * hN + 2 * j) = make_ulonglong2(gl_mul(xl, xr), gl_mul(yl, yr));
             }
         }
         E2 s0, s2, s3;
         gp_first_acc_reduce(A, s0, s2, s3);
+        if constexpr (MIRROR) {
+            s0 = e2_add(s0, e2_add(e2_mul(J.mk1, Sx), J.mk2));
+            s2 = e2_add(s2, e2_add(e2_mul(J.mk1, Sy), J.mk2));
+            store_e2_nt(out + (size_t)(J.ntab - 1) * half + jo, e2_add(Sx, e2_mul(r, e2_sub(Sy, Sx))));
+        }
         // (s0, s2, s3) = (sum P0, sum P1, sum Pinf): q(2) = 2 P1 - P0 + 2 Pinf, q(3) = 3 P1 - 2 P0 + 6 Pinf, times p(0), p(2), p(3)
         const E2 P1x2 = e2_dbl(s2), Pix2 = e2_dbl(s3);
         const E2 q2 = e2_add(e2_sub(P1x2, s0), Pix2);
@@ -573,8 +598,9 @@ __global__ __launch_bounds__(256) void k_gp_first_hash(const StJob* __restrict__
     if (nblocks > 1) finish_partials(partials, 3, tickets_of(partials), res + J.sums_slot, sm, nblocks);
 }
 static inline size_t sc_lds_bytes(int nv, int bd);
-void st_first_hash(hipStream_t st, const StJob* job, const StItem* item, int grid, const E2* chal, E2* partials, E2* res) {
-    k_gp_first_hash<<<grid, 256, sc_lds_bytes(0, 256), st>>>(job, item, chal, partials, res);
+void st_first_hash(hipStream_t st, const StJob* job, const StItem* item, int grid, bool mirror, const E2* chal, E2* partials, E2* res) {
+    if (mirror) k_gp_first_hash<true><<<grid, 256, sc_lds_bytes(0, 256), st>>>(job, item, chal, partials, res);
+    else k_gp_first_hash<false><<<grid, 256, sc_lds_bytes(0, 256), st>>>(job, item, chal, partials, res);
 }
 
 // ---- two grand-product rounds in one pass ------------------------------------------------------------------
@@ -644,6 +670,21 @@ __global__ __launch_bounds__(256) void k_st_step2(const StJob* __restrict__ jobs
         W2 vm = w2_zero();
         WAcc vi = wacc_zero();
         E2 p0 = e2_zero(), p2 = e2_zero(), p3 = e2_zero(), q0 = e2_zero(), q2 = e2_zero(), q3 = e2_zero();
+        if (J.mirror) {
+            // The linear table S of a mirrored job (StJob::mirror), both rounds, BEFORE the pair loop: K1 S + K2 joins P0 and P1 of
+            // round t and, on the folded S, of round t+1 (even lane: P0', odd lane: P1') - as the starting values of the column
+            // accumulators (their low word is a plain residue), so nothing stays live across the loop.
+            E2 x, y;
+            load_xy<E2, false>(in + (size_t)(2 * nb) * in_stride, j, half, x, y);
+            const E2 ms = e2_fold_wide(x, e2_sub(y, x), fa);
+            const E2 es = e2_sub(swap_lane(ms), ms);
+            const E2 c0 = e2_add(e2_mul(J.mk1, x), J.mk2), c1 = e2_add(e2_mul(J.mk1, y), J.mk2), cm = e2_add(e2_mul(J.mk1, ms), J.mk2);
+            w0.A.L = c0.c0; w0.C.L = c0.c1;
+            w1.A.L = c1.c0; w1.C.L = c1.c1;
+            vm.c0.L = cm.c0; vm.c1.L = cm.c1;
+            const E2 fs = e2_fold_wide(ms, es, fb);
+            if (!odd) store_e2(out + (size_t)(2 * nb) * half2 + jo2, fs);
+        }
         // software pipeline: the four loads of the next pair are in flight while this pair is processed (two waves per SIMD
         // cannot hide an HBM round trip behind ~800 instructions otherwise)
         E2 xl, yl, xr, yr;
@@ -776,7 +817,8 @@ __global__ __launch_bounds__(256) void k_col_step2(const StJob* __restrict__ job
 template <int KIND, typename T, bool FIRST>
 __device__ __forceinline__ void sc_round_small(const T* in, size_t in_stride, size_t in_j0, size_t in_half, E2* out, size_t out_stride,
                                                size_t out_j0, size_t out_half, size_t j_count, int ntab, E2 r,
-                                               const E2* __restrict__ pw, const E2* __restrict__ pwr, E2* acc, bool p0_only) {
+                                               const E2* __restrict__ pw, const E2* __restrict__ pwr, E2* acc, bool p0_only,
+                                               const StJob* __restrict__ mirror = nullptr) {
     using V = Val<T>;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, W = blockDim.x >> 6;
     for (size_t jl = wave; jl < j_count; jl += W) {
@@ -810,6 +852,15 @@ __device__ __forceinline__ void sc_round_small(const T* in, size_t in_stride, si
                     store_e2(out + (size_t)(2 * i) * out_stride + jo, V::fold(xl, dl, r));
                 }
                 store_e2(out + (size_t)(2 * i + 1) * out_stride + jo, V::fold(xr, dr, r));
+            }
+            if constexpr (!FIRST && std::is_same<T, E2>::value) {
+                if (mirror && lane == 63) {  // the linear table S of a mirrored job (StJob::mirror; nb <= 63): K1 S(t) + K2 joins P0 and P1
+                    E2 x, y;
+                    load_xy<E2, false>(in + (size_t)(2 * nb) * in_stride, j, in_half, x, y);
+                    s0 = e2_add(s0, e2_add(e2_mul(mirror->mk1, x), mirror->mk2));
+                    s2 = e2_add(s2, e2_add(e2_mul(mirror->mk1, y), mirror->mk2));
+                    store_e2(out + (size_t)(2 * nb) * out_stride + jo, V::fold(x, e2_sub(y, x), r));
+                }
             }
             s0 = wave_sum(s0); s2 = wave_sum(s2); s3 = wave_sum(s3);
             if (lane == 0) gp_combine(s0, s2, s3, V::lift(p0), V::lift(p2), V::lift(p3), acc[0], acc[1], acc[2]);
@@ -879,7 +930,8 @@ __global__ __launch_bounds__(512) void k_st_chunk(const StJob* __restrict__ jobs
         for (int t = 0; t < NV; t++) a[t] = e2_zero();
         if (rd == 0 && J.base) sc_round_small<KIND, u64, true>(reinterpret_cast<const u64*>(in), in_stride, in_j0, in_half, out, out_stride, out_j0, out_half, jc, J.ntab, r, J.pw, J.pwr, a, p0_only);
         else if (rd == 0) sc_round_small<KIND, E2, true>(reinterpret_cast<const E2*>(in), in_stride, in_j0, in_half, out, out_stride, out_j0, out_half, jc, J.ntab, r, J.pw, J.pwr, a, p0_only);
-        else sc_round_small<KIND, E2, false>(reinterpret_cast<const E2*>(in), in_stride, in_j0, in_half, out, out_stride, out_j0, out_half, jc, J.ntab, r, J.pw, J.pwr, a, p0_only);
+        else sc_round_small<KIND, E2, false>(reinterpret_cast<const E2*>(in), in_stride, in_j0, in_half, out, out_stride, out_j0, out_half, jc, J.ntab, r, J.pw, J.pwr, a, p0_only,
+                                             (KIND == SC_GRANDPROD && J.mirror) ? &J : nullptr);
 #pragma unroll
         for (int t = 0; t < NV; t++) if ((threadIdx.x & 63) != 0) a[t] = e2_zero();
         block_sum_multi<NV>(a, sm);   // also the barrier that completes the folded chunk in LDS

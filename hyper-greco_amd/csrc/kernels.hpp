@@ -59,6 +59,15 @@ struct StJob {
     E2* final_out;     // ntab folded scalars
     int kind, ntab, nvars, base;
     int p0_only;       // grand product on a subset of the batch (multi-GPU): pair 0 only supplies p_0, its product is not summed
+    // Mirrored grand product (top layer of the Lasso read / write product): every WRITE row is its READ row plus the constant
+    // c = gamma^2 and carries kappa times its weight, so the write pairs are never stored or multiplied. With l, r the halves of a
+    // read row and S = sum_i w_i (l_i + r_i):  sum_i w_i [l_i r_i + kappa (l_i + c)(r_i + c)] = (1 + kappa) [ sum_i w_i l_i r_i +
+    // K1 S + K2 ],  K1 = kappa c / (1 + kappa), K2 = kappa c^2 sum_i w_i / (1 + kappa). The job holds the R read pairs (tables
+    // 0 .. 2R-1) and ONE more table, S (index 2R = ntab - 1; S folds like any table because folding is linear and c is constant);
+    // every round adds K1 S(t) + K2 to P0 and P1 (Pinf is unchanged: constants cancel in differences) and the host multiplies the
+    // round sums by 1 + kappa and derives the write rows' final evaluations (read + c).
+    int mirror;        // 1: ntab = 2R + 1 as above
+    E2 mk1, mk2;       // K1, K2
     size_t r_off;      // chain index of round 0's challenge
     size_t sums_slot;  // result slots: nv per round
     const GpHashSrc* hash_src;  // first round reads these instead of `in` (st_first_hash); null otherwise
@@ -86,7 +95,8 @@ int st_plan_blocks(StItem* items, int nitems, bool rounds2);
 void st_step(hipStream_t st, int kind, bool base, const StJob* jobs, const StItem* items, int nitems, int grid, const E2* chal,
              E2* partials, E2* res);
 // first round of ONE grand-product job whose level-0 rows are recomputed from the Lasso integer tables (StJob::hash_src)
-void st_first_hash(hipStream_t st, const StJob* job, const StItem* item, int grid, const E2* chal, E2* partials, E2* res);
+// (`mirror` = the host copy of job->mirror: selects the kernel variant)
+void st_first_hash(hipStream_t st, const StJob* job, const StItem* item, int grid, bool mirror, const E2* chal, E2* partials, E2* res);
 // fused step (folded Ext2 inputs; grand-product or collation shape): every item runs its job's rounds with half = 2^h_log2 and 2^(h_log2-1)
 void st_step2(hipStream_t st, int kind, const StJob* jobs, const StItem* items, int nitems, int grid, const E2* chal, E2* partials, E2* res);
 // chunk step: every item runs `nrounds` consecutive rounds; workgroup k owns pair indices [k 2^c, (k+1) 2^c) of the

@@ -175,7 +175,10 @@ struct ScHandle {
     int nvars = 0;
     size_t point_off = 0;
     std::vector<E2> rs;
+    bool scaled = false;   // the device sums are the round sums divided by `scale` (mirrored grand product, StJob::mirror)
+    E2 scale = {0, 0};
 };
+struct MirrorSpec { E2 k1, k2; int credit_ntab; };  // StJob::mk1 / mk2; the table count the launch is credited with (the unmirrored batch)
 
 struct Prover {
     hg_ctx* ctx;
@@ -302,13 +305,15 @@ struct Prover {
     // the other, deepest layer first: job q with st_seq[q] = s > 0 gets its own first-round launch, in ascending s, before
     // the shared first-round launch of everything else; `st_after_seq` then builds the remaining (small) tree levels.
     std::vector<int> st_seq;
+    std::vector<int> st_credit_ntab;   // per queued job: table count its launches are credited with (MirrorSpec::credit_ntab)
     std::vector<double> st_fused_bytes;  // algorithmic bytes of the passes a job's first round absorbs (hash build, tree level)
     std::vector<std::function<void()>> st_after_seq;
     double pending_fused_bytes = 0;      // set by the caller right before sc_stride (the hash build a hash-source job absorbs)
     std::vector<dev::ScatterEnt> scatter;  // locally produced scalars -> global result slots (batch-subset grand products)
 
     ScHandle sc_stride(int kind, const void* in, bool base, size_t in_stride, int ntab, int nvars, const dev::Powers& pw, E2* final_out,
-                       bool enqueue = true, bool p0_only = false, int seq = 0, u64* next_level = nullptr, const dev::GpHashSrc* hash_src = nullptr) {
+                       bool enqueue = true, bool p0_only = false, int seq = 0, u64* next_level = nullptr, const dev::GpHashSrc* hash_src = nullptr,
+                       const MirrorSpec* mirror = nullptr) {
         ScHandle h;
         h.nv = kind == dev::SC_GRANDPROD ? 3 : 2;
         h.nvars = nvars;
@@ -329,16 +334,17 @@ struct Prover {
         J.kind = kind; J.ntab = ntab; J.nvars = nvars; J.base = base ? 1 : 0; J.p0_only = p0_only ? 1 : 0;
         J.r_off = h.point_off; J.sums_slot = h.sums_slot;
         J.next_level = next_level; J.hash_src = hash_src;
+        if (mirror) { J.mirror = 1; J.mk1 = mirror->k1; J.mk2 = mirror->k2; }
         memcpy(J.pw, pw.v, sizeof(J.pw));
         for (int i = 0; i < nvars; i++) h.rs.push_back(squeeze());
         if (nvars > 0)  // weight * r_0: the first round stores the weighted fold (kernels.hip)
             for (int i = 0; i < dev::PW_MAX; i++) J.pwr[i] = e2_mul(pw.v[i], h.rs[0]);
         if (nvars > 0) {
-            st_jobs.push_back(J); st_seq.push_back(seq);
+            st_jobs.push_back(J); st_seq.push_back(seq); st_credit_ntab.push_back(mirror ? mirror->credit_ntab : ntab);
             // a level-writing first round replaces prod_level on its input level: (nb rows of 2N entries) x 8 B x 1.5 (read +
             // write), as prod_level is credited; the hash-source job's level 1 is credited with its write only, as the hash kernel
             // it replaces was (round-1 accounting: the totals stay comparable)
-            double fused = next_level ? (double)(ntab / 2) * (double)(2 * N) * 8.0 * (hash_src ? 0.5 : 1.5) : 0.0;
+            double fused = next_level ? (double)((mirror ? mirror->credit_ntab : ntab) / 2) * (double)(2 * N) * 8.0 * (hash_src ? 0.5 : 1.5) : 0.0;
             st_fused_bytes.push_back(fused + pending_fused_bytes);
             pending_fused_bytes = 0;
         }
@@ -463,9 +469,12 @@ struct Prover {
         }
         dev::StItem* d_items = ctx->alloc_n<dev::StItem>(flat.size());
         upload(d_items, flat.data(), flat.size() * sizeof(dev::StItem), "upload step items");
-        auto round_bytes = [&](const dev::StJob& J, int rd) {
+        // algorithmic bytes of one round of job q: the tables of the protocol's batch (a mirrored grand product is
+        // credited with its read AND write tables: that is the work the round does for the proof, whatever is stored)
+        auto round_bytes = [&](int q, int rd) {
+            const dev::StJob& J = st_jobs[q];
             size_t half = (size_t)1 << (J.nvars - 1 - rd);
-            return (double)J.ntab * (2.0 * half * ((J.base && rd == 0) ? 8 : 16) + half * 16.0);
+            return (double)st_credit_ntab[q] * (2.0 * half * ((J.base && rd == 0) ? 8 : 16) + half * 16.0);
         };
         for (size_t li = 0; li < plan.size(); li++) {
             const Launch& L = plan[li];
@@ -482,9 +491,9 @@ struct Prover {
                     const dev::StItem& it = L.items[o];
                     // algorithmic bytes: the sum-check round plus the passes this launch absorbs - the hash build
                     // (dims, read_ts per chunk; E read, read / write hashes written per memory) and product-tree level 1
-                    bytes = round_bytes(st_jobs[it.job], 0) + st_fused_bytes[it.job];
+                    bytes = round_bytes(it.job, 0) + st_fused_bytes[it.job];
                     ctx->prof_begin(cls_gp_hash, bytes);
-                    dev::st_first_hash(st, d_jobs + it.job, d_items + offs[li] + o, grids[li][0], ctx->d_chal, partials, d_res());
+                    dev::st_first_hash(st, d_jobs + it.job, d_items + offs[li] + o, grids[li][0], st_jobs[it.job].mirror != 0, ctx->d_chal, partials, d_res());
                     ctx->prof_end();
                     continue;
                 }
@@ -493,7 +502,7 @@ struct Prover {
                     for (int q = 0; q < cnt; q++) {
                         const dev::StItem& it = L.items[o + q];
                         const dev::StJob& J = st_jobs[it.job];
-                        for (int k = 0; k < it.nrounds; k++) bytes += round_bytes(J, it.rd + k);
+                        for (int k = 0; k < it.nrounds; k++) bytes += round_bytes(it.job, it.rd + k);
                         max_chunks = std::max(max_chunks, it.nchunks); max_ntab = std::max(max_ntab, J.ntab);
                     }
                     ctx->prof_begin(cls_tail, bytes);
@@ -505,7 +514,7 @@ struct Prover {
                         const dev::StJob& J = st_jobs[it.job];
                         // algorithmic bytes in the per-round accounting of SURVEY.md 8(d): a fused launch is credited with both of
                         // its rounds although the intermediate folded tables never reach HBM
-                        for (int k = 0; k < L.nrounds; k++) bytes += round_bytes(J, J.nvars - 1 - it.h_log2 + k);
+                        for (int k = 0; k < L.nrounds; k++) bytes += round_bytes(it.job, J.nvars - 1 - it.h_log2 + k);
                         if (L.base && it.h_log2 == J.nvars - 1) bytes += st_fused_bytes[it.job];  // the tree level a first round also writes
                     }
                     const int grid = grids[li][o / MAX_BATCH];
@@ -520,6 +529,7 @@ struct Prover {
         if (st_before_gp) { st_before_gp(); st_before_gp = nullptr; }
         st_jobs.clear();
         st_seq.clear();
+        st_credit_ntab.clear();
         st_fused_bytes.clear();
         for (auto& f : st_after_seq) f();  // (no grand-product job was queued: nothing can depend on these, but keep the order)
         st_after_seq.clear();
@@ -656,6 +666,8 @@ struct Prover {
     void defer_sumcheck(const ScHandle& h, int deg, Cell claim_in, Cell claim_out) {
         ops.push_back([this, h, deg, claim_in, claim_out] {
             E2 claim = *claim_in;
+            if (h.scaled)   // mirrored grand product: the kernels summed everything but the common factor 1 + kappa
+                for (size_t q = 0; q < (size_t)h.nvars * h.nv; q++) ctx->h_res[h.sums_slot + q] = e2_mul(ctx->h_res[h.sums_slot + q], h.scale);
             for (int i = 0; i < h.nvars; i++) {
                 const E2* s = h_res() + h.sums_slot + (size_t)i * h.nv;
                 E2 ev[4], c[4];
@@ -776,7 +788,7 @@ struct Prover {
     // level), which therefore run one after the other before everything else; the remaining small levels follow them.
     GpOut grand_product(const u64* H, size_t len, int nb, const std::vector<int>& owner, const u64* lev1 = nullptr,
                         const std::vector<int>* local = nullptr, bool p0_only = false, const dev::GpHashSrc* hash_src = nullptr, int emit = 0,
-                        double hash_fused_bytes = 0) {
+                        double hash_fused_bytes = 0, const u64* mirror_c = nullptr) {
         int nv = 0;
         while (((size_t)1 << nv) < len) nv++;
         const int nl = local ? (int)local->size() : nb;  // rows actually held
@@ -867,7 +879,45 @@ struct Prover {
             u64* nxt = seq ? lev_w[k + 1] : nullptr;                          // ... and writes tree level k + 1
             const dev::GpHashSrc* hs = (hash_src && k == 0) ? hash_src : nullptr;
             if (hs) pending_fused_bytes = hash_fused_bytes;
-            if (!local) sc = sc_stride(dev::SC_GRANDPROD, lev[k], true, h, 2 * nb, n, pw, d_res() + evals, mine(owner[n]), false, seq, nxt, hs);
+            const bool mirrored = hs && mirror_c;
+            if (mirrored) {
+                // Top layer with row b + nb/2 = row b + c for every b < nb/2 (the Lasso write hashes, c = gamma^2): only the read rows
+                // are stored and multiplied (StJob::mirror in kernels.hpp). The kernels sum everything but the factor 1 + kappa.
+                const int G2 = nb / 2;
+                std::vector<int> rows;   // global ids of the read rows held, ascending (row 0 first)
+                for (int li = 0; li < nl; li++) { const int b = local ? (*local)[li] : li; if (b < G2) rows.push_back(b); }
+                const int R = (int)rows.size();
+                for (int li = 0; li < R; li++) if ((local ? (*local)[li] : li) != rows[li]) throw Error("grand product: read rows must come first");
+                int nwr = 0;
+                for (int li = R; li < nl; li++) {
+                    const int b = (local ? (*local)[li] : li) - G2;
+                    if (std::find(rows.begin(), rows.end(), b) == rows.end() || (p0_only && b == 0)) throw Error("grand product: write row without its read row");
+                    nwr++;
+                }
+                if (nwr != R - (p0_only ? 1 : 0)) throw Error("grand product: mirrored rows do not pair up");
+                if (R > 63 || 2 * R + 1 > dev::PW_MAX) throw Error("grand product: too many mirrored rows");
+                const E2 kappa = pw.v[G2], onek = e2_add(e2_one(), kappa);
+                if (onek.c0 == 0 && onek.c1 == 0) throw Error("grand product: degenerate batching challenge");
+                const E2 kp = e2_mul(kappa, e2_inv(onek));
+                dev::Powers pwl;
+                memset(&pwl, 0, sizeof(pwl));
+                E2 lam = e2_zero();
+                for (int li = 0; li < R; li++) { pwl.v[li] = pw.v[rows[li]]; if (!(p0_only && li == 0)) lam = e2_add(lam, pwl.v[li]); }
+                const u64 c = *mirror_c;
+                MirrorSpec ms;
+                ms.k1 = e2_mul_f(kp, c);
+                ms.k2 = e2_mul(e2_mul_f(kp, gl_mul(c, c)), lam);
+                ms.credit_ntab = 2 * nl;
+                E2* fin = ctx->alloc_n<E2>(2 * (size_t)R + 1);
+                const bool run = mine(owner[n]) && R > (p0_only ? 1 : 0);
+                sc = sc_stride(dev::SC_GRANDPROD, lev[k], true, h, 2 * R + 1, n, pwl, fin, run, p0_only, seq, nxt, hs, &ms);
+                sc.scaled = true; sc.scale = onek;
+                if (run)
+                    for (int li = p0_only ? 1 : 0; li < R; li++) {
+                        scatter.push_back({fin + 2 * li, evals + 2 * (size_t)rows[li]});
+                        scatter.push_back({fin + 2 * li + 1, evals + 2 * (size_t)rows[li] + 1});
+                    }
+            } else if (!local) sc = sc_stride(dev::SC_GRANDPROD, lev[k], true, h, 2 * nb, n, pw, d_res() + evals, mine(owner[n]), false, seq, nxt, hs);
             else {
                 // this rank's share of the batch: local pair li is global pair b = local[li], weight gamma^b
                 dev::Powers pwl;
@@ -885,6 +935,14 @@ struct Prover {
             mark("grand product layer " + std::to_string(n) + ": sum-check, " + std::to_string(n) + " rounds x 4 coefficients [C1 message format, C2 power order, C3 variable order]");
             defer_sumcheck(sc, 3, claim, nullptr);
             defer_gp_unscale(evals, nb, pw);
+            if (mirrored) {   // the write rows' evaluations: folding is affine with coefficients summing to one, so row + c stays row + c
+                const u64 c = *mirror_c;
+                const int G2 = nb / 2;
+                ops.push_back([this, evals, G2, c] {
+                    for (int b = 0; b < G2; b++)
+                        for (int t = 0; t < 2; t++) ctx->h_res[evals + 2 * (size_t)(G2 + b) + t] = e2_add_f(ctx->h_res[evals + 2 * (size_t)b + t], c);
+                });
+            }
             mark("grand product layer " + std::to_string(n) + ": v_l, v_r evaluations per tree (prover.rs:257)");
             defer_write_slots(evals, 2 * (size_t)nb);  // prover.rs:257
             out.point_off = sc.point_off;
@@ -1151,8 +1209,12 @@ struct Prover {
             ctx->prof_end();
         });
         mark("lasso: memory checking, grand product #1 over reads then writes (prover.rs:161-165)");
-        GpOut g1 = split ? grand_product(H1, N, 2 * G, gp1_owner, L1, &local_pairs, p0_only, d_hash_src, emit, hash_build_bytes)
-                         : grand_product(H1, N, 2 * G, gp1_owner, L1, nullptr, false, d_hash_src, emit, hash_build_bytes);  // reads then writes (prover.rs:161-165)
+        // the write hash of a row is its read hash + gamma^2 (prover.rs:44: t + 1): the top layer runs on the read rows only
+        static const bool use_mirror = [] { const char* e = getenv("HG_NO_MIRROR"); return !(e && e[0] == '1'); }();
+        const u64 gamma_sq = gl_mul(gamma, gamma);
+        const u64* mirror_c = (emit > 0 && use_mirror) ? &gamma_sq : nullptr;
+        GpOut g1 = split ? grand_product(H1, N, 2 * G, gp1_owner, L1, &local_pairs, p0_only, d_hash_src, emit, hash_build_bytes, mirror_c)
+                         : grand_product(H1, N, 2 * G, gp1_owner, L1, nullptr, false, d_hash_src, emit, hash_build_bytes, mirror_c);  // reads then writes (prover.rs:161-165)
         mark("lasso: memory checking, grand product #2 over inits then finals (prover.rs:167-171)");
         GpOut g2{0, nullptr};
         aux([&] {   // inits then finals (prover.rs:167-171); its tree on the second stream
