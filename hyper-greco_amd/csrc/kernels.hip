@@ -1355,7 +1355,7 @@ EpRows ep_rows_all(int alpha) {
     return r;
 }
 __global__ __launch_bounds__(TPB) void k_lasso_split(LassoDev L, const u64* __restrict__ input, u64* __restrict__ dims,
-                                                     u64* __restrict__ e_polys, EpRows R) {
+                                                     u64* __restrict__ e_polys, EpRows R, ColPow P, u64* __restrict__ col) {
     const size_t N = (size_t)1 << L.nu;
     for (size_t j = (size_t)blockIdx.x * TPB + threadIdx.x; j < N; j += (size_t)gridDim.x * TPB) {
         u32 idx[4] = {0, 0, 0, 0};
@@ -1369,17 +1369,23 @@ __global__ __launch_bounds__(TPB) void k_lasso_split(LassoDev L, const u64* __re
         }
 #pragma unroll
         for (int c = 0; c < 4; c++) dims[(size_t)c * N + j] = idx[c];
+        u64 cv = 0;   // sum_m colpow[m] E_m[j]: at most four non-zero terms (the memories of the row's lookup)
         for (int m = 0; m < L.alpha; m++) {
             if (R.row[m] < 0) continue;
             u32 a = idx[L.mem_dim[m]];
             u64 ev = ((uses >> m) & 1) && a < L.mem_cutoff[m] ? (u64)a : 0;  // T_s[a] (range.rs:15-17, 58-72)
             e_polys[(size_t)R.row[m] * N + j] = ev;
+            if (col && ev && P.v[m]) cv = gl_add(cv, gl_mul_small(P.v[m], (u32)ev));
         }
+        if (col) col[j] = cv;
     }
 }
-void lasso_split(hipStream_t st, const LassoDev& L, const u64* input, u64* dims, u64* e_polys, const EpRows& rows) {
+void lasso_split(hipStream_t st, const LassoDev& L, const u64* input, u64* dims, u64* e_polys, const EpRows& rows, const ColPow* colpow, u64* col) {
     size_t N = (size_t)1 << L.nu;
-    k_lasso_split<<<(unsigned)std::min<size_t>((N + TPB - 1) / TPB, 4096), TPB, 0, st>>>(L, input, dims, e_polys, rows);
+    ColPow P;
+    memset(&P, 0, sizeof(P));
+    if (colpow) P = *colpow;
+    k_lasso_split<<<(unsigned)std::min<size_t>((N + TPB - 1) / TPB, 4096), TPB, 0, st>>>(L, input, dims, e_polys, rows, P, colpow ? col : nullptr);
 }
 
 // keys/rows of the rows that touch counter memory m, compacted: position q -> row (segment list in LassoDev)

@@ -174,7 +174,11 @@ struct LassoDev {
 // EpRows (multi-GPU: a rank only materialises the E tables of its own memories): row[m] = row of memory m in e_polys, -1 = not held.
 struct EpRows { signed char row[32]; };
 EpRows ep_rows_all(int alpha);
-void lasso_split(hipStream_t st, const LassoDev& L, const u64* input, u64* dims, u64* e_polys, const EpRows& rows);
+// col (optional, with colpow): col[j] = sum_m colpow.v[m] E_m[j] over the memories held - the ONE table the collation sum-check
+// needs besides E_0: its round polynomial is E_0(t) * sum_m M^m E_m(t), and the sum folds as a single table (folding is linear).
+struct ColPow { u64 v[32]; };   // M^m for the memories to add up, 0 for the others
+void lasso_split(hipStream_t st, const LassoDev& L, const u64* input, u64* dims, u64* e_polys, const EpRows& rows, const ColPow* colpow = nullptr,
+                 u64* col = nullptr);
 // read/final counters of memory m (sequential-scan semantics of lasso.rs:181-196) via a stable sort
 size_t lasso_counter_temp_bytes(size_t n);
 void lasso_counters(hipStream_t st, const LassoDev& L, int m, const u64* dims, u64* read_ts, u64* final_cts,

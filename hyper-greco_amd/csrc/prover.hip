@@ -85,7 +85,7 @@ int hg_ctx::prof_class(const char* name, bool dominant) {
     prof_stats.push_back(s);
     return (int)prof_stats.size() - 1;
 }
-void hg_ctx::prof_begin(int cls, double bytes) {
+void hg_ctx::prof_begin(int cls, double bytes, double model_bytes) {
     cur_cls = -1;
     if (prof_level == 0) return;
     if (prof_level == 1 && !prof_stats[cls].dominant) return;
@@ -97,6 +97,7 @@ void hg_ctx::prof_begin(int cls, double bytes) {
     prof_events.push_back({cls, a, b});
     prof_stats[cls].launches++;
     prof_stats[cls].bytes += bytes;
+    prof_stats[cls].model += model_bytes < 0 ? bytes : model_bytes;
 }
 void hg_ctx::prof_end() {
     if (cur_cls < 0) return;
@@ -305,7 +306,7 @@ struct Prover {
     // the other, deepest layer first: job q with st_seq[q] = s > 0 gets its own first-round launch, in ascending s, before
     // the shared first-round launch of everything else; `st_after_seq` then builds the remaining (small) tree levels.
     std::vector<int> st_seq;
-    std::vector<int> st_credit_ntab;   // per queued job: table count its launches are credited with (MirrorSpec::credit_ntab)
+    std::vector<int> st_credit_ntab;   // per queued job: table count of the reference's batch (traffic model of SURVEY.md 8(d)); = ntab without a shortcut
     std::vector<double> st_fused_bytes;  // algorithmic bytes of the passes a job's first round absorbs (hash build, tree level)
     std::vector<std::function<void()>> st_after_seq;
     double pending_fused_bytes = 0;      // set by the caller right before sc_stride (the hash build a hash-source job absorbs)
@@ -313,7 +314,7 @@ struct Prover {
 
     ScHandle sc_stride(int kind, const void* in, bool base, size_t in_stride, int ntab, int nvars, const dev::Powers& pw, E2* final_out,
                        bool enqueue = true, bool p0_only = false, int seq = 0, u64* next_level = nullptr, const dev::GpHashSrc* hash_src = nullptr,
-                       const MirrorSpec* mirror = nullptr) {
+                       const MirrorSpec* mirror = nullptr, int model_ntab = 0) {
         ScHandle h;
         h.nv = kind == dev::SC_GRANDPROD ? 3 : 2;
         h.nvars = nvars;
@@ -340,7 +341,7 @@ struct Prover {
         if (nvars > 0)  // weight * r_0: the first round stores the weighted fold (kernels.hip)
             for (int i = 0; i < dev::PW_MAX; i++) J.pwr[i] = e2_mul(pw.v[i], h.rs[0]);
         if (nvars > 0) {
-            st_jobs.push_back(J); st_seq.push_back(seq); st_credit_ntab.push_back(mirror ? mirror->credit_ntab : ntab);
+            st_jobs.push_back(J); st_seq.push_back(seq); st_credit_ntab.push_back(mirror ? mirror->credit_ntab : (model_ntab ? model_ntab : ntab));
             // a level-writing first round replaces prod_level on its input level: (nb rows of 2N entries) x 8 B x 1.5 (read +
             // write), as prod_level is credited; the hash-source job's level 1 is credited with its write only, as the hash kernel
             // it replaces was (round-1 accounting: the totals stay comparable)
@@ -469,12 +470,13 @@ struct Prover {
         }
         dev::StItem* d_items = ctx->alloc_n<dev::StItem>(flat.size());
         upload(d_items, flat.data(), flat.size() * sizeof(dev::StItem), "upload step items");
-        // algorithmic bytes of one round of job q: the tables of the protocol's batch (a mirrored grand product is
-        // credited with its read AND write tables: that is the work the round does for the proof, whatever is stored)
-        auto round_bytes = [&](int q, int rd) {
+        // algorithmic bytes of one round of job q: every live table read once, every folded table written once.
+        // model = true: the tables of the reference's batch (a mirrored grand product is modelled with its read AND write tables, the
+        // collation sum-check with its alpha tables), false: the tables this implementation streams
+        auto round_bytes = [&](int q, int rd, bool model) {
             const dev::StJob& J = st_jobs[q];
             size_t half = (size_t)1 << (J.nvars - 1 - rd);
-            return (double)st_credit_ntab[q] * (2.0 * half * ((J.base && rd == 0) ? 8 : 16) + half * 16.0);
+            return (double)(model ? st_credit_ntab[q] : J.ntab) * (2.0 * half * ((J.base && rd == 0) ? 8 : 16) + half * 16.0);
         };
         for (size_t li = 0; li < plan.size(); li++) {
             const Launch& L = plan[li];
@@ -486,13 +488,14 @@ struct Prover {
             }
             for (size_t o = 0; o < L.items.size(); o += MAX_BATCH) {
                 const int cnt = (int)std::min<size_t>(MAX_BATCH, L.items.size() - o);
-                double bytes = 0;
+                double bytes = 0, model = 0;
                 if (L.hash) {
                     const dev::StItem& it = L.items[o];
                     // algorithmic bytes: the sum-check round plus the passes this launch absorbs - the hash build
                     // (dims, read_ts per chunk; E read, read / write hashes written per memory) and product-tree level 1
-                    bytes = round_bytes(it.job, 0) + st_fused_bytes[it.job];
-                    ctx->prof_begin(cls_gp_hash, bytes);
+                    bytes = round_bytes(it.job, 0, false) + st_fused_bytes[it.job];
+                    model = round_bytes(it.job, 0, true) + st_fused_bytes[it.job];
+                    ctx->prof_begin(cls_gp_hash, bytes, model);
                     dev::st_first_hash(st, d_jobs + it.job, d_items + offs[li] + o, grids[li][0], st_jobs[it.job].mirror != 0, ctx->d_chal, partials, d_res());
                     ctx->prof_end();
                     continue;
@@ -502,10 +505,10 @@ struct Prover {
                     for (int q = 0; q < cnt; q++) {
                         const dev::StItem& it = L.items[o + q];
                         const dev::StJob& J = st_jobs[it.job];
-                        for (int k = 0; k < it.nrounds; k++) bytes += round_bytes(it.job, it.rd + k);
+                        for (int k = 0; k < it.nrounds; k++) { bytes += round_bytes(it.job, it.rd + k, false); model += round_bytes(it.job, it.rd + k, true); }
                         max_chunks = std::max(max_chunks, it.nchunks); max_ntab = std::max(max_ntab, J.ntab);
                     }
-                    ctx->prof_begin(cls_tail, bytes);
+                    ctx->prof_begin(cls_tail, bytes, model);
                     dev::st_chunk(st, L.kind, d_jobs, d_items + offs[li] + o, cnt, max_chunks, max_ntab, ctx->d_chal, partials, d_res());
                     ctx->prof_end();
                 } else {
@@ -514,12 +517,12 @@ struct Prover {
                         const dev::StJob& J = st_jobs[it.job];
                         // algorithmic bytes in the per-round accounting of SURVEY.md 8(d): a fused launch is credited with both of
                         // its rounds although the intermediate folded tables never reach HBM
-                        for (int k = 0; k < L.nrounds; k++) bytes += round_bytes(it.job, J.nvars - 1 - it.h_log2 + k);
-                        if (L.base && it.h_log2 == J.nvars - 1) bytes += st_fused_bytes[it.job];  // the tree level a first round also writes
+                        for (int k = 0; k < L.nrounds; k++) { bytes += round_bytes(it.job, J.nvars - 1 - it.h_log2 + k, false); model += round_bytes(it.job, J.nvars - 1 - it.h_log2 + k, true); }
+                        if (L.base && it.h_log2 == J.nvars - 1) { bytes += st_fused_bytes[it.job]; model += st_fused_bytes[it.job]; }  // the tree level a first round also writes
                     }
                     const int grid = grids[li][o / MAX_BATCH];
                     int cls = L.kind == dev::SC_GRANDPROD ? (L.base ? cls_gp_base : (L.nrounds == 2 ? cls_gp_ext2 : cls_gp_ext)) : (L.base ? cls_col_base : (L.nrounds == 2 ? cls_col_ext2 : cls_col_ext));
-                    ctx->prof_begin(cls, bytes);
+                    ctx->prof_begin(cls, bytes, model);
                     if (L.nrounds == 2) dev::st_step2(st, L.kind, d_jobs, d_items + offs[li] + o, cnt, grid, ctx->d_chal, partials, d_res());
                     else dev::st_step(st, L.kind, L.base, d_jobs, d_items + offs[li] + o, cnt, grid, ctx->d_chal, partials, d_res());
                     ctx->prof_end();
@@ -1005,9 +1008,16 @@ struct Prover {
         };
         if (need_split) {
             dims = ctx->alloc_n<u64>(4 * N);
-            ep = ctx->alloc_n<u64>((size_t)ep_count * N);
-            ctx->prof_begin(cls_aux, (double)N * 8 * (1 + 4 + ep_count));
-            dev::lasso_split(st, L, d_input, dims, ep, ep_rows);
+            // one more row behind the E tables: C = sum_m M^m E_m over this rank's memories - with E_0 all the collation sum-check needs
+            ep = ctx->alloc_n<u64>((size_t)(ep_count + 1) * N);
+            dev::ColPow cp;
+            memset(&cp, 0, sizeof(cp));
+            {
+                u64 mp = 1;
+                for (int m = 0; m < A; m++) { if (own_mem[m]) cp.v[m] = mp; mp = gl_mul(mp, M); }
+            }
+            ctx->prof_begin(cls_aux, (double)N * 8 * (1 + 4 + ep_count + 1));
+            dev::lasso_split(st, L, d_input, dims, ep, ep_rows, &cp, ep + (size_t)ep_count * N);
             ctx->prof_end();
             if (fork_recorded) hip_check(hipEventRecord(ctx->ev_aux[0], st), "lasso: split event");
         }
@@ -1033,15 +1043,17 @@ struct Prover {
         Cell claimed = cell();
         mark("lasso: claimed sum (lasso.rs:100-107)");
         ops.push_back([this, claim_slot, claimed] { *claimed = h_res()[claim_slot]; proof.write_e(*claimed); });
-        {   // collation sum-check (lasso.rs:271-279): g = poly(0) * sum_i M^i poly(i)
+        {   // collation sum-check (lasso.rs:271-279): g = poly(0) * sum_i M^i poly(i). Only the SUM enters the round polynomials and the
+            // final evaluations are dropped (lasso.rs:97), so the sum-check runs on two tables: E_0 (supplies p_0, not summed) and
+            // C = sum_i M^i E_i, written by the limb split (folding is linear: fold(C) = sum_i M^i fold(E_i)). Sharded: every rank's C
+            // holds its own memories' terms, the round sums are partial sums.
             dev::Powers pw;
             memset(&pw, 0, sizeof(pw));
             if (A > dev::PW_MAX) throw Error("lasso: too many memories");
-            std::vector<u64> mpow(A, 1);
-            for (int i = 1; i < A; i++) mpow[i] = gl_mul(mpow[i - 1], M);
-            for (size_t q = 0; q < col_mems.size(); q++) pw.v[q] = e2(mpow[col_mems[q]], 0);   // table q is memory col_mems[q]: weight M^m
+            pw.v[0] = e2_one(); pw.v[1] = e2_one();
             const bool col_run = do_col && (int)col_mems.size() > (col_p0_only ? 1 : 0);
-            ScHandle sc = sc_stride(dev::SC_COLLATION, ep, true, N, (int)col_mems.size(), nu, pw, nullptr, col_run, col_p0_only);
+            ScHandle sc = sc_stride(dev::SC_COLLATION, ep, true, (size_t)ep_count * N, 2, nu, pw, nullptr, col_run, true, 0, nullptr, nullptr, nullptr,
+                                    (int)col_mems.size());
             mark("lasso: collation sum-check, " + std::to_string(nu) + " rounds x 3 coefficients (lasso.rs:271-279) [C1, C3; poly(0) quirk]");
             defer_sumcheck(sc, 2, claimed, nullptr);
             if (col_aux) on_aux([&] { flush_stride(); });  // all collation rounds, now, on the second stream

@@ -53,6 +53,8 @@ typedef struct hg_kernel_stat {
     uint64_t launches;
     double total_ms;
     double algo_bytes; /* algorithmic bytes over all launches: tables read once + folded tables written once */
+    double model_bytes; /* the same launches in the traffic model of the REFERENCE's algorithm: larger than algo_bytes
+                           where an algebraic shortcut avoids tables (mirrored grand product, two-table collation sum-check) */
 } hg_kernel_stat;
 
 const char* hg_last_error(void);
