@@ -824,6 +824,24 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_lasso_claim(dev::LassoDev L, cons
     Fr s = block_sum_fr(wcol_reduce(acc), sm);
     if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
+// The two tables of the collation sum-check (lasso.rs:271-279): g = E_0 * sum_m M^m E_m only needs E_0 and the weighted SUM of
+// the E tables (folding is linear, the final evaluations are dropped, lasso.rs:97). out[0][k] = E_0[k], out[1][k] = sum_{m >= 1}
+// M^m E_m[k] (so that the two rows add up to the full sum), both in Montgomery form; at most four memories are non-zero in a row.
+struct BnColPow { Fr v[32]; };  // (M^m) R^2 (raw limbs of fr_to_mont(M^m)), see k_bn_lasso_claim
+__global__ __launch_bounds__(BN_TPB) void k_bn_collation_tabs(dev::LassoDev L, const u64* __restrict__ e_polys, BnColPow P, Fr* __restrict__ out) {
+    const size_t N = (size_t)1 << L.nu;
+    for (size_t k = (size_t)blockIdx.x * BN_TPB + threadIdx.x; k < N; k += (size_t)gridDim.x * BN_TPB) {
+        WCol c0 = wcol_zero(), c1 = wcol_zero();
+        if (k < L.rows) {
+            const u64 uses = L.lookup_uses[L.seg_lookup[k >> L.seg_shift]];
+            if (uses & 1) wcol_mac_u64(c0, e_polys[k], P.v[0]);
+            for (int m = 1; m < L.alpha; m++)
+                if ((uses >> m) & 1) wcol_mac_u64(c1, e_polys[(size_t)m * N + k], P.v[m]);
+        }
+        out[k] = wcol_reduce(c0);
+        out[N + k] = wcol_reduce(c1);
+    }
+}
 // sum_k eq[k] * t[k] for a table of small integers
 __global__ __launch_bounds__(BN_TPB) void k_bn_dot_u64(const Fr* __restrict__ eq, const u64* __restrict__ t, size_t n, Fr* __restrict__ partials) {
     __shared__ Fr sm[BN_TPB];
@@ -942,14 +960,20 @@ static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4,
             k_bn_lasso_claim<<<grid, BN_TPB, 0, st>>>(L, eq, ep, mp, d_part);
             k_bn_reduce<<<1, BN_TPB, 0, st>>>(d_part, grid, 1, r_claimed.dev);
         }
-        // collation sum-check (lasso.rs:271-279): g = poly(0) * sum_i M^i poly(i) over the E tables
+        // collation sum-check (lasso.rs:271-279): g = poly(0) * sum_i M^i poly(i) - on two tables, E_0 and the weighted sum of the others
         {
-            Fr* tabs = dalloc((size_t)A * N);
-            k_bn_from_u64<<<grid1((size_t)A * N), 256, 0, st>>>(ep, tabs, (size_t)A * N);
-            Fr* d_pw = dalloc(A);
-            k_bn_powers<<<1, 256, 0, st>>>(d_pw, fr_small(M), (size_t)A);   // M^i, i < alpha
-            Fr* buf0 = dalloc((size_t)A * N / 2);
-            Fr* buf1 = dalloc((size_t)A * std::max<size_t>(N / 4, 1));
+            Fr* tabs = dalloc(2 * N);
+            BnColPow cp;
+            {
+                const Fr m = fr_small(M);
+                Fr pwr = fr_one_mont();
+                for (int i = 0; i < 32; i++) { cp.v[i] = i < A ? fr_to_mont(pwr) : fr_zero(); pwr = fr_mul(pwr, m); }
+            }
+            k_bn_collation_tabs<<<(unsigned)std::min<size_t>((N + BN_TPB - 1) / BN_TPB, 4096), BN_TPB, 0, st>>>(L, ep, cp, tabs);
+            Fr* d_pw = dalloc(2);
+            k_bn_powers<<<1, 256, 0, st>>>(d_pw, fr_one_mont(), (size_t)2);   // weights 1, 1: the powers of M are inside the second table
+            Fr* buf0 = dalloc(N);
+            Fr* buf1 = dalloc(std::max<size_t>(N / 2, 1));
             Fr* d_sums = r_col.dev;
             const Fr* cur = tabs;
             Fr* nxt = buf0;
@@ -958,8 +982,8 @@ static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4,
             RoundCounts rc;
             for (int rd = 0; rd < nu; rd++) {
                 const size_t half = N >> (rd + 1);
-                const RoundGrid g = round_grid(half, A);
-                k_bn_round<BN_COLLATION><<<dim3(g.gx, g.gy), BN_TPB, 0, st>>>(cur, nxt, A, half, fr_to_mont(chain[col_at + rd]), d_pw,
+                const RoundGrid g = round_grid(half, 2);
+                k_bn_round<BN_COLLATION><<<dim3(g.gx, g.gy), BN_TPB, 0, st>>>(cur, nxt, 2, half, fr_to_mont(chain[col_at + rd]), d_pw,
                                                                                part + (size_t)rd * BN_PART_STRIDE * 2);
                 rc.n[rd] = g.blocks();
                 cur = nxt;
