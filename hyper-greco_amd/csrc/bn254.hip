@@ -179,7 +179,10 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_round(const Fr* __restrict__ in, 
 // the layers of a grand product only share the product tree
 // left table of pair i at l_base + i * l_stride, right table at r_base + i * r_stride (first round: the pre-weighted left halves and
 // the right halves of the level rows; later rounds: the interleaved folded tables)
-struct GpJobDev { const Fr* l_base; const Fr* r_base; Fr* out; Fr* part; Fr r; unsigned long long half, l_stride, r_stride; int nb, gx, gy, pad; };
+// mirror (top layer of the Lasso read / write product, see StJob::mirror in kernels.hpp): the job holds the read pairs only; s_in is
+// the linear table S = sum_i w_i (l_i + r_i) in natural order ([2j], [2j+1]), folded into s_out; K1 S(t) + K2 joins P0 and P1.
+struct GpJobDev { const Fr* l_base; const Fr* r_base; Fr* out; Fr* part; Fr r; unsigned long long half, l_stride, r_stride; int nb, gx, gy, mirror;
+                  const Fr* s_in; Fr* s_out; Fr k1, k2; };
 // Two lanes share one pair index j (quad_perm [1,0,3,2] swaps their registers): the even lane owns the LEFT tables, the odd lane the
 // RIGHT tables; each loads, folds and stores only its own tables, so every table entry is read from HBM once. With x, y = T[2j],
 // T[2j+1] and d = y - x the round polynomial needs P0 = sum xl xr, P1 = sum yl yr, Pinf = sum dl dr:
@@ -244,7 +247,13 @@ __global__ __launch_bounds__(BN_TPB) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             const Fr d = fr_sub(y, x);
             p0 = x; p2 = fr_add(y, d); p3 = fr_add(p2, d);
         }
-        const Fr R1 = wcol_reduce(c1), Ri = wcol_reduce(c2);
+        Fr R1 = wcol_reduce(c1);
+        const Fr Ri = wcol_reduce(c2);
+        if (J.mirror && pi == 0) {   // (uniform over the workgroup) even lane: P0 += K1 S(0) + K2, odd lane: P1 += K1 S(1) + K2
+            const Fr sx = J.s_in[2 * j], sy = J.s_in[2 * j + 1];
+            R1 = fr_add(R1, fr_add(fr_mul_wide(J.k1, fr_sel(isA, sx, sy)), J.k2));
+            if (isA) J.s_out[j] = fr_add(sx, fr_mul_wide(r, fr_sub(sy, sx)));
+        }
         const Fr Ro = fr_swap_lane(R1), Pi = fr_add(Ri, fr_swap_lane(Ri));
         const Fr P0 = fr_sel(isA, R1, Ro), P1 = fr_sel(isA, Ro, R1);
         const Fr P1x2 = fr_add(P1, P1), Pix2 = fr_add(Pi, Pi);
@@ -277,6 +286,23 @@ __global__ void k_bn_weight_rows(const Fr* __restrict__ rows, size_t row_len, co
     const size_t b = idx / h, i = idx % h;
     const Fr x = rows[b * row_len + i];
     out[idx] = b == 0 ? x : fr_mul_wide(pw[b], x);
+}
+// mirrored top layer: the weighted left halves of the READ rows (as k_bn_weight_rows) and, in the same pass, the linear table
+// S[i] = sum_b pw[b] (l_b[i] + r_b[i]) over the read rows b < nb (r_b = the right half of row b, in place at rows + h)
+__global__ __launch_bounds__(256) void k_bn_weight_rows_sum(const Fr* __restrict__ rows, size_t row_len, const Fr* __restrict__ pw, Fr* __restrict__ out,
+                                                          Fr* __restrict__ S, size_t h, int nb) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= h) return;
+    Fr acc = fr_zero();
+    WCol c = wcol_zero();
+    for (int b = 0; b < nb; b++) {
+        const Fr x = rows[(size_t)b * row_len + i];
+        const Fr lw = b == 0 ? x : fr_mul_wide(pw[b], x);
+        out[(size_t)b * h + i] = lw;
+        acc = fr_add(acc, lw);
+        wcol_mac(c, pw[b], rows[(size_t)b * row_len + h + i]);
+    }
+    S[i] = fr_add(acc, wcol_reduce(c));
 }
 // launch shape of a round over `half` pair indices and `nitems` independent items (pairs / tables): grid.x workgroups along j,
 // grid.y groups of items; large rounds keep one thread per j, small ones spread the items
@@ -593,8 +619,10 @@ static Fr replay_round(const Fr* sums_canonical, int d, Fr claim, Fr r, Fr* c /*
 // big-endian elements. claims_out: nb final claims, point_out: nv coordinates.
 static size_t gp_challenges(int nv) { size_t need = 1; for (int n = 1; n < nv; n++) need += 2 + n; return need; }
 // core: level 0 already on the device in Montgomery form (nb rows of len), or uploaded from `tables` when d_lev0 is null
+// mirror_c (Montgomery, optional): rows nb/2 .. nb-1 of level 0 are rows 0 .. nb/2-1 plus this constant (the Lasso write hashes are
+// the read hashes + gamma^2): the top layer then runs on the read rows only (GpJobDev::mirror).
 static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* const* tables, const Fr* d_lev0, size_t chain_skip,
-                               std::vector<uint8_t>& proof, std::vector<Fr>& claims_canon, std::vector<Fr>& point_canon) {
+                               std::vector<uint8_t>& proof, std::vector<Fr>& claims_canon, std::vector<Fr>& point_canon, const Fr* mirror_c = nullptr) {
     if (nb == 0 || len < 2 || (len & (len - 1))) throw Error("hg_grand_product_bn254: need nb >= 1 tables of a power-of-two length >= 2");
     hipc(hipSetDevice(ctx->device), "hipSetDevice");
     hipStream_t st = ctx->stream;
@@ -636,7 +664,9 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
         size_t pos = chain_skip;
         layers[0].mu_at = pos++;
         // plan every layer (buffers, result slots, launch shapes), then run the rounds of all layers round-synchronised
-        struct LayerPlan { Fr *buf0, *buf1, *part, *tbuf, *d_pw, *lw; int nmain; };
+        struct LayerPlan { Fr *buf0, *buf1, *part, *tbuf, *d_pw, *lw, *S, *sbuf0, *sbuf1; int nmain; bool mirror; };
+        const size_t G2 = nb / 2;
+        if (mirror_c && (nv < 2 || (nb & 1))) throw Error("hg_grand_product_bn254: mirrored rows need an even batch and two layers");
         std::vector<LayerPlan> plan(nv);
         int max_main = 0;
         if (nv > 32) throw Error("hg_grand_product_bn254: more than 32 layers");
@@ -660,7 +690,10 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
             L.d_sums = rs_sums.dev; L.sums = rs_sums.host;
             L.d_final = rs_fin.dev; L.fin = rs_fin.host;
             P.nmain = n;   // rounds done by the shared launches; the rest (short tables) by the tail workgroup of the layer
-            for (int rd = 1; rd < n; rd++)
+            P.mirror = mirror_c && n == nv - 1;   // (every round of a mirrored layer runs in the shared launches: the tail kernel knows no S table)
+            P.S = P.sbuf0 = P.sbuf1 = nullptr;
+            if (P.mirror) { P.S = dalloc(h); P.sbuf0 = dalloc(h / 2); P.sbuf1 = dalloc(std::max<size_t>(h / 4, 1)); }
+            for (int rd = 1; rd < n && !P.mirror; rd++)
                 if ((h >> (rd + 1)) <= (size_t)BN_TAIL_HALF && n - rd <= BN_TAIL_ROUNDS) { P.nmain = rd; break; }
             max_main = std::max(max_main, P.nmain);
         }
@@ -668,7 +701,8 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
             k_bn_gamma_powers<<<dim3((unsigned)((nb + 255) / 256), nv), 256, 0, st>>>(pw_all, gammas, (int)nb);
             for (int n = 1; n < nv; n++) {
                 const size_t h = (size_t)1 << n;
-                k_bn_weight_rows<<<(unsigned)((nb * h + 255) / 256), 256, 0, st>>>(lev[nv - 1 - n], 2 * h, plan[n].d_pw, plan[n].lw, h, (int)nb);
+                if (plan[n].mirror) k_bn_weight_rows_sum<<<(unsigned)((h + 255) / 256), 256, 0, st>>>(lev[nv - 1 - n], 2 * h, plan[n].d_pw, plan[n].lw, plan[n].S, h, (int)G2);
+                else k_bn_weight_rows<<<(unsigned)((nb * h + 255) / 256), 256, 0, st>>>(lev[nv - 1 - n], 2 * h, plan[n].d_pw, plan[n].lw, h, (int)nb);
             }
         }
         std::vector<GpJobDev> descs;
@@ -698,7 +732,23 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
                 d.r = fr_to_mont(chain[layers[n].r_at + rd]);
                 d.half = half;
                 d.nb = (int)nb;
-                const RoundGrid g = round_grid_gp(half, (int)nb);
+                if (P.mirror) {
+                    // sum_b w_b l_b r_b over reads and writes = (1 + kappa) [sum_reads w l r + K1 S + K2], kappa = gamma^(nb/2), c = *mirror_c:
+                    // K1 = kappa c / (1 + kappa), K2 = kappa c^2 sum_{b < nb/2} gamma^b / (1 + kappa); the host applies 1 + kappa
+                    const Fr g = fr_to_mont(chain[layers[n].gamma_at]);
+                    Fr kappa = fr_one_mont(), lam = fr_zero();
+                    for (size_t b = 0; b < G2; b++) { lam = fr_add(lam, kappa); kappa = fr_mul(kappa, g); }
+                    const Fr onek = fr_add(fr_one_mont(), kappa);
+                    if (!(onek.l[0] | onek.l[1] | onek.l[2] | onek.l[3])) throw Error("hg_grand_product_bn254: degenerate batching challenge");
+                    const Fr kp = fr_mul(kappa, fr_inv(onek));
+                    d.nb = (int)G2;
+                    d.mirror = 1;
+                    d.k1 = fr_mul(kp, *mirror_c);
+                    d.k2 = fr_mul(fr_mul(kp, fr_mul(*mirror_c, *mirror_c)), lam);
+                    d.s_in = rd == 0 ? P.S : ((rd & 1) ? P.sbuf0 : P.sbuf1);
+                    d.s_out = (rd & 1) ? P.sbuf1 : P.sbuf0;
+                }
+                const RoundGrid g = round_grid_gp(half, d.nb);
                 d.gx = g.gx; d.gy = g.gy;
                 reds[red_index[n]].n[rd] = g.blocks();
                 max_blocks[rd] = std::max(max_blocks[rd], g.blocks());
@@ -735,8 +785,10 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
             k_bn_reduce_jobs<<<dim3(32, (unsigned)reds.size()), BN_TPB, 0, st>>>(d_reds, 3);
             if (!tails.empty()) k_bn_tail_jobs<BN_GRANDPROD><<<(unsigned)tails.size(), 3 * BN_TPB, 0, st>>>(d_tails);
             for (int n = 1; n < nv; n++)   // layers without a tail (n = 1): the folded values are the last shared round's output
-                if (plan[n].nmain == n)
-                    k_bn_copy_from_mont<<<(unsigned)((ntab + 255) / 256), 256, 0, st>>>(((plan[n].nmain - 1) & 1) ? plan[n].buf1 : plan[n].buf0, layers[n].d_final, ntab);
+                if (plan[n].nmain == n) {   // (a mirrored layer leaves the read rows' values only)
+                    const size_t cnt = plan[n].mirror ? 2 * G2 : ntab;
+                    k_bn_copy_from_mont<<<(unsigned)((cnt + 255) / 256), 256, 0, st>>>(((plan[n].nmain - 1) & 1) ? plan[n].buf1 : plan[n].buf0, layers[n].d_final, cnt);
+                }
         }
         res_sync(ctx, st, "grand_product_bn254: sync");
     } catch (...) {
@@ -759,18 +811,26 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
             Fr claim = fr_zero(), w = fr_one_mont();
             for (size_t b = 0; b < nb; b++) { claim = fr_add(claim, fr_mul(claims[b], w)); w = fr_mul(w, g); }  // prover.rs:281-286
             x.clear();
+            const bool mirrored = mirror_c && n == nv - 1;
+            Fr onek = fr_one_mont();
+            if (mirrored) { Fr kappa = fr_one_mont(); for (size_t b = 0; b < nb / 2; b++) kappa = fr_mul(kappa, g); onek = fr_add(onek, kappa); }
             for (int rd = 0; rd < n; rd++) {
                 Fr c[4];
                 const Fr r = fr_to_mont(chain[L.r_at + rd]);
-                claim = replay_round(&L.sums[(size_t)rd * 3], 3, claim, r, c);
+                Fr sums[3];
+                for (int t = 0; t < 3; t++) sums[t] = mirrored ? fr_from_mont(fr_mul(fr_to_mont(L.sums[(size_t)rd * 3 + t]), onek)) : L.sums[(size_t)rd * 3 + t];
+                claim = replay_round(sums, 3, claim, r, c);
                 for (int k = 0; k < 4; k++) write_be32(proof, fr_from_mont(c[k]));
                 x.push_back(chain[L.r_at + rd]);
             }
-            for (size_t i = 0; i < 2 * nb; i++) evals[i] = fr_to_mont(L.fin[i]);
+            const size_t held = mirrored ? nb / 2 : nb;   // rows whose evaluations the kernels produced
+            for (size_t i = 0; i < 2 * held; i++) evals[i] = fr_to_mont(L.fin[i]);
             // the kernels leave the left evaluation of pair b multiplied by gamma^b (k_bn_gp_round_jobs)
             const Fr ginv = fr_inv(g);
             Fr u = ginv;
-            for (size_t b = 1; b < nb; b++) { evals[2 * b] = fr_mul(evals[2 * b], u); u = fr_mul(u, ginv); }
+            for (size_t b = 1; b < held; b++) { evals[2 * b] = fr_mul(evals[2 * b], u); u = fr_mul(u, ginv); }
+            if (mirrored)   // folding is affine with coefficients summing to one: row + c stays row + c
+                for (size_t b = 0; b < held; b++) { evals[2 * (held + b)] = fr_add(evals[2 * b], *mirror_c); evals[2 * (held + b) + 1] = fr_add(evals[2 * b + 1], *mirror_c); }
         }
         for (size_t i = 0; i < 2 * nb; i++) write_be32(proof, fr_from_mont(evals[i]));  // prover.rs:257
         const Fr mu = fr_to_mont(chain[L.mu_at]);                                          // prover.rs:259
@@ -1004,7 +1064,9 @@ static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4,
                                                   H1 + (size_t)(G + i) * N);
             k_bn_hash_if<<<65536 / 256, 256, 0, st>>>((u32)lp.mems[m].cutoff, final_cts[c], HK, H2 + (size_t)i * M, H2 + (size_t)(G + i) * M);
         }
-        grand_product_core(ctx, 2 * G, N, nullptr, H1, gp1_at, gp1_bytes, tmp_claims, x);  // reads then writes (prover.rs:161-165)
+        static const bool use_mirror = [] { const char* e = getenv("HG_NO_MIRROR"); return !(e && e[0] == '1'); }();
+        // the write hashes are the read hashes + gamma^2 (k_bn_hash_rw): the top layer runs on the read rows only
+        grand_product_core(ctx, 2 * G, N, nullptr, H1, gp1_at, gp1_bytes, tmp_claims, x, (use_mirror && nu >= 2) ? &gamma2 : nullptr);  // reads then writes (prover.rs:161-165)
         grand_product_core(ctx, 2 * G, M, nullptr, H2, gp2_at, gp2_bytes, tmp_claims, y);  // inits then finals (prover.rs:167-171)
         // openings (prover.rs:173-178, mod.rs:80-93)
         Fr* eqy = dalloc(M);
