@@ -911,6 +911,40 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_dot_u64(const Fr* __restrict__ eq
     Fr s = block_sum_fr(fr_to_mont(wcol_reduce(acc)), sm);
     if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
+// the same for up to 4 integer tables sharing one eq table per thread (grid.y = group of 4): eq, 32 bytes per entry against 8 per
+// table, is read once per group instead of once per table; one column accumulator per table (more would cost the occupancy).
+// partials[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + t]
+constexpr int BN_DOT_GROUP = 4;
+struct DotU64Tabs { const u64* t[64]; };
+__global__ __launch_bounds__(BN_TPB) void k_bn_dot_u64_multi(const Fr* __restrict__ eq, DotU64Tabs tabs, int ntab_all, size_t n, Fr* __restrict__ partials) {
+    __shared__ Fr sm[BN_TPB];
+    const int t0 = blockIdx.y * BN_DOT_GROUP, ntab = min(BN_DOT_GROUP, ntab_all - t0);
+    WCol acc[BN_DOT_GROUP];
+#pragma unroll
+    for (int t = 0; t < BN_DOT_GROUP; t++) acc[t] = wcol_zero();
+    for (size_t k = (size_t)blockIdx.x * BN_TPB + threadIdx.x; k < n; k += (size_t)gridDim.x * BN_TPB) {
+        const Fr e = eq[k];
+#pragma unroll
+        for (int t = 0; t < BN_DOT_GROUP; t++)
+            if (t < ntab) wcol_mac_u64(acc[t], tabs.t[t0 + t][k], e);
+    }
+#pragma unroll
+    for (int t = 0; t < BN_DOT_GROUP; t++)
+        if (t < ntab) {
+            Fr s = block_sum_fr(fr_to_mont(wcol_reduce(acc[t])), sm);   // plain residue -> Montgomery form once per thread (as k_bn_dot_u64)
+            if (threadIdx.x == 0) partials[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * BN_DOT_GROUP + t] = s;
+        }
+}
+// out_slot[t] <- sum over the workgroups of table t (canonical, for the host)
+struct DotU64Out { Fr* out[64]; };
+__global__ __launch_bounds__(BN_TPB) void k_bn_dot_u64_reduce(const Fr* __restrict__ partials, int nblocks, DotU64Out outs) {
+    __shared__ Fr sm[BN_TPB];
+    const int t = blockIdx.x, grp = t / BN_DOT_GROUP, q = t % BN_DOT_GROUP;
+    Fr a = fr_zero();
+    for (int b = threadIdx.x; b < nblocks; b += BN_TPB) a = fr_add(a, partials[((size_t)grp * nblocks + b) * BN_DOT_GROUP + q]);
+    a = block_sum_fr(a, sm);
+    if (threadIdx.x == 0) *outs.out[t] = fr_from_mont(a);
+}
 // h(a,v,t) = a + v gamma + t gamma^2 - tau (prover.rs:44) for the reads (t) and writes (t + 1) of one memory
 struct HashK { Fr one2, gamma2x, gammasq2x, gammasq, tau; };  // R^2, gamma R^2, gamma^2 R^2 (raw), gamma^2 and tau (Montgomery)
 __global__ void k_bn_hash_rw(size_t n, const u64* __restrict__ dim, const u64* __restrict__ ep, const u64* __restrict__ ts, HashK K,
@@ -1072,20 +1106,36 @@ static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4,
         Fr* eqy = dalloc(M);
         build_eq(eq, x.data(), nu);
         build_eq(eqy, y.data(), 16);
+        // every opening at x in one launch, every opening at y in another (k_bn_dot_u64_multi); order on the wire per chunk: dim(x),
+        // read_ts(x), final_cts(y), then E_m(x)
         std::vector<const Fr*> open_at;
-        auto dot = [&](const Fr* e, const u64* t, size_t n) {   // results land in the mapped buffer; read after the final synchronisation
-            const int grid = (int)std::min<size_t>((n + BN_TPB - 1) / BN_TPB, 1024);
-            const ResRef o = res_slots(ctx, 1);
-            k_bn_dot_u64<<<grid, BN_TPB, 0, st>>>(e, t, n, d_part);
-            k_bn_reduce<<<1, BN_TPB, 0, st>>>(d_part, grid, 1, o.dev);
-            open_at.push_back(o.host);
-        };
-        for (auto& chk : lp.chunks) {
-            const int c = chk.first;
-            dot(eq, dims + (size_t)c * N, N);
-            dot(eq, read_ts[c], N);
-            dot(eqy, final_cts[c], M);
-            for (int m : chk.second) dot(eq, ep + (size_t)m * N, N);
+        {
+            DotU64Tabs tx, ty;
+            DotU64Out ox, oy;
+            memset(&tx, 0, sizeof(tx)); memset(&ty, 0, sizeof(ty)); memset(&ox, 0, sizeof(ox)); memset(&oy, 0, sizeof(oy));
+            int nx = 0, ny = 0;
+            auto add = [&](DotU64Tabs& T, DotU64Out& O, int& cnt, const u64* t) {
+                if (cnt >= 64) throw Error("hg_lasso_prove_bn254: too many openings");
+                const ResRef o = res_slots(ctx, 1);
+                T.t[cnt] = t; O.out[cnt] = o.dev; cnt++;
+                open_at.push_back(o.host);
+            };
+            for (auto& chk : lp.chunks) {
+                const int c = chk.first;
+                add(tx, ox, nx, dims + (size_t)c * N);
+                add(tx, ox, nx, read_ts[c]);
+                add(ty, oy, ny, final_cts[c]);
+                for (int m : chk.second) add(tx, ox, nx, ep + (size_t)m * N);
+            }
+            auto run = [&](const Fr* e, const DotU64Tabs& T, const DotU64Out& O, int cnt, size_t n) {
+                if (!cnt) return;
+                const int gx = (int)std::min<size_t>((n + BN_TPB - 1) / BN_TPB, 512), gy = (cnt + BN_DOT_GROUP - 1) / BN_DOT_GROUP;
+                Fr* part = dalloc((size_t)gx * gy * BN_DOT_GROUP);
+                k_bn_dot_u64_multi<<<dim3(gx, gy), BN_TPB, 0, st>>>(e, T, cnt, n, part);
+                k_bn_dot_u64_reduce<<<cnt, BN_TPB, 0, st>>>(part, gx, O);
+            };
+            run(eq, tx, ox, nx, N);
+            run(eqy, ty, oy, ny, M);
         }
         res_sync(ctx, st, "lasso_prove_bn254: sync");
         if (h_bad) throw Error("hg_lasso_prove_bn254: the node input holds a value that is not below 2^64 (not a range-shifted value)");
