@@ -1367,8 +1367,10 @@ __global__ __launch_bounds__(TPB) void k_lasso_split(LassoDev L, const u64* __re
             idx[2] = (u32)((v >> 32) & 0xFFFF); idx[3] = (u32)((v >> 48) & 0xFFFF);
             uses = L.lookup_uses[l];
         }
+        if (dims) {
 #pragma unroll
-        for (int c = 0; c < 4; c++) dims[(size_t)c * N + j] = idx[c];
+            for (int c = 0; c < 4; c++) dims[(size_t)c * N + j] = idx[c];
+        }
         u64 cv = 0;   // sum_m colpow[m] E_m[j]: at most four non-zero terms (the memories of the row's lookup)
         for (int m = 0; m < L.alpha; m++) {
             if (R.row[m] < 0) continue;
@@ -1379,6 +1381,20 @@ __global__ __launch_bounds__(TPB) void k_lasso_split(LassoDev L, const u64* __re
         }
         if (col) col[j] = cv;
     }
+}
+// the four 16-bit limbs only: the counter sorts need nothing else, so they can start while the E tables are still being written
+__global__ __launch_bounds__(TPB) void k_lasso_dims(LassoDev L, const u64* __restrict__ input, u64* __restrict__ dims) {
+    const size_t N = (size_t)1 << L.nu;
+    for (size_t j = (size_t)blockIdx.x * TPB + threadIdx.x; j < N; j += (size_t)gridDim.x * TPB) {
+        u64 v = 0;
+        if (j < L.rows) v = input[j] & L.lookup_mask[L.seg_lookup[j >> L.seg_shift]];
+#pragma unroll
+        for (int c = 0; c < 4; c++) dims[(size_t)c * N + j] = (v >> (16 * c)) & 0xFFFF;
+    }
+}
+void lasso_dims(hipStream_t st, const LassoDev& L, const u64* input, u64* dims) {
+    size_t N = (size_t)1 << L.nu;
+    k_lasso_dims<<<(unsigned)std::min<size_t>((N + TPB - 1) / TPB, 4096), TPB, 0, st>>>(L, input, dims);
 }
 void lasso_split(hipStream_t st, const LassoDev& L, const u64* input, u64* dims, u64* e_polys, const EpRows& rows, const ColPow* colpow, u64* col) {
     size_t N = (size_t)1 << L.nu;

@@ -176,6 +176,8 @@ struct EpRows { signed char row[32]; };
 EpRows ep_rows_all(int alpha);
 // col (optional, with colpow): col[j] = sum_m colpow.v[m] E_m[j] over the memories held - the ONE table the collation sum-check
 // needs besides E_0: its round polynomial is E_0(t) * sum_m M^m E_m(t), and the sum folds as a single table (folding is linear).
+// (dims may be null when lasso_dims has already written the limbs)
+void lasso_dims(hipStream_t st, const LassoDev& L, const u64* input, u64* dims);
 struct ColPow { u64 v[32]; };   // M^m for the memories to add up, 0 for the others
 void lasso_split(hipStream_t st, const LassoDev& L, const u64* input, u64* dims, u64* e_polys, const EpRows& rows, const ColPow* colpow = nullptr,
                  u64* col = nullptr);

@@ -1016,11 +1016,35 @@ struct Prover {
                 u64 mp = 1;
                 for (int m = 0; m < A; m++) { if (own_mem[m]) cp.v[m] = mp; mp = gl_mul(mp, M); }
             }
-            ctx->prof_begin(cls_aux, (double)N * 8 * (1 + 4 + ep_count + 1));
-            dev::lasso_split(st, L, d_input, dims, ep, ep_rows, &cp, ep + (size_t)ep_count * N);
+            // two streams: the limbs first, in their own small launch - the counter sorts (second stream) need nothing else and start
+            // while the E tables are still being written
+            if (fork_recorded) {
+                ctx->prof_begin(cls_aux, (double)N * 8 * (1 + 4));
+                dev::lasso_dims(st, L, d_input, dims);
+                ctx->prof_end();
+                hip_check(hipEventRecord(ctx->ev_aux[0], st), "lasso: limbs event");
+            }
+            ctx->prof_begin(cls_aux, (double)N * 8 * (1 + (fork_recorded ? 0 : 4) + ep_count + 1));
+            dev::lasso_split(st, L, d_input, fork_recorded ? nullptr : dims, ep, ep_rows, &cp, ep + (size_t)ep_count * N);
             ctx->prof_end();
-            if (fork_recorded) hip_check(hipEventRecord(ctx->ev_aux[0], st), "lasso: split event");
+            if (fork_recorded) hip_check(hipEventRecord(ctx->ev_aux[2], st), "lasso: E tables event");
         }
+        // MemoryCheckingProver::new (prover.rs:35-89)
+        const int nrows = split ? (int)local_pairs.size() : 2 * G;
+        // Grand product #1 without hash tables: the top layer's first round recomputes the hashes from dims / read_ts / E and
+        // writes tree level 1, the next layers' first rounds write levels 2 .. emit (HG_NO_HASH_FUSE=1: materialise them).
+        static const bool hash_fuse = [] { const char* e = getenv("HG_NO_HASH_FUSE"); return !(e && e[0] == '1'); }();
+        static const int emit_max = [] { const char* e = getenv("HG_GP_EMIT"); return e && *e ? atoi(e) : 4; }();
+        bool all_gp1 = any_gp1;
+        for (int n = 0; n < nu; n++) all_gp1 = all_gp1 && mine(gp1_owner[n]);
+        int emit = 0;
+        if (hash_fuse && all_gp1 && nu >= 12 && nrows > (p0_only ? 1 : 0))
+            for (int n = nu - 1; n >= 12 && emit < emit_max; n--) emit++;   // layers with 2^n >= 4096 entries per table
+        // Off the critical path, on the second stream: counter sorts (hidden under the collation sum-check), grand product #2's
+        // hashes and tree, the openings (hidden under grand product #1's rounds). Needs the hash-free grand product #1 (the
+        // classic path reads read_ts on the main stream right away).
+        const bool use_aux = fork_recorded && emit > 0;
+        auto aux = [&](const std::function<void()>& fn) { if (use_aux) on_aux(fn); else fn(); };
         // r, claimed sum (lasso.rs:85, 264-269)
         size_t r_off = epos();
         for (int i = 0; i < nu; i++) squeeze();
@@ -1034,11 +1058,17 @@ struct Prover {
         static const int lasso_sched = [] { const char* e = getenv("HG_LASSO_SCHED"); return e && *e ? atoi(e) : 0; }();
         const bool col_aux = fork_recorded && lasso_sched == 1;
         auto col_where = [&](const std::function<void()>& fn) { if (col_aux) on_aux(fn); else fn(); };
-        if (do_col) col_where([&] {
-            if (col_aux) hip_check(hipStreamWaitEvent(st, ctx->ev_aux[0], 0), "lasso: wait for the limb split");
+        // The claimed sum is only a result slot: with two streams it runs on the second one after grand product #2's tree (the main
+        // stream goes from the limb split straight into the collation rounds, the second stream is idle at that point anyway).
+        const bool claim_late = use_aux && !col_aux;
+        auto do_claim = [&] {
             eq_now(eq, nu, r_off);
             int grid = dev::lasso_claim(st, L, eq, ep, ep_rows_own, partials);  // sharded: this rank's memories only (partial sum)
             reduce(grid, 1, claim_slot);
+        };
+        if (do_col && !claim_late) col_where([&] {
+            if (col_aux) hip_check(hipStreamWaitEvent(st, ctx->ev_aux[2], 0), "lasso: wait for the E tables");
+            do_claim();
         });
         Cell claimed = cell();
         mark("lasso: claimed sum (lasso.rs:100-107)");
@@ -1062,22 +1092,6 @@ struct Prover {
         u64 gamma = gamma_e.c0, tau = tau_e.c0;     // prover.rs:38-39: base limb 0 only
         // counters: only the memories whose index equals a chunk (dimension) index reach the transcript
         // (lasso.rs:317-319 indexes read_ts/final_cts by chunk index)
-        // MemoryCheckingProver::new (prover.rs:35-89)
-        const int nrows = split ? (int)local_pairs.size() : 2 * G;
-        // Grand product #1 without hash tables: the top layer's first round recomputes the hashes from dims / read_ts / E and
-        // writes tree level 1, the next layers' first rounds write levels 2 .. emit (HG_NO_HASH_FUSE=1: materialise them).
-        static const bool hash_fuse = [] { const char* e = getenv("HG_NO_HASH_FUSE"); return !(e && e[0] == '1'); }();
-        static const int emit_max = [] { const char* e = getenv("HG_GP_EMIT"); return e && *e ? atoi(e) : 4; }();
-        bool all_gp1 = any_gp1;
-        for (int n = 0; n < nu; n++) all_gp1 = all_gp1 && mine(gp1_owner[n]);
-        int emit = 0;
-        if (hash_fuse && all_gp1 && nu >= 12 && nrows > (p0_only ? 1 : 0))
-            for (int n = nu - 1; n >= 12 && emit < emit_max; n--) emit++;   // layers with 2^n >= 4096 entries per table
-        // Off the critical path, on the second stream: counter sorts (hidden under the collation sum-check), grand product #2's
-        // hashes and tree, the openings (hidden under grand product #1's rounds). Needs the hash-free grand product #1 (the
-        // classic path reads read_ts on the main stream right away).
-        const bool use_aux = fork_recorded && emit > 0;
-        auto aux = [&](const std::function<void()>& fn) { if (use_aux) on_aux(fn); else fn(); };
         // a rank that only holds a few memories of grand product #1 needs the counters of their chunks only
         // (the chunk of pair 0, and the chunks whose dim / read_ts / final_cts openings it owns: those of its own memories)
         std::vector<char> need_chunk(4, split ? 0 : 1);
@@ -1237,6 +1251,8 @@ struct Prover {
             // grand product #1's first launch reads the counters, grand product #2's first rounds its tree: the main stream waits
             // for the second one only there, after the collation sum-check has been enqueued
             hip_check(hipEventRecord(ctx->ev_aux[1], ctx->stream2), "lasso: aux event");
+            on_aux([&] { hip_check(hipStreamWaitEvent(st, ctx->ev_aux[2], 0), "lasso: wait for the E tables"); });   // claimed sum, openings
+            if (do_col && claim_late) on_aux(do_claim);
             hg_ctx* c = ctx;
             st_before_gp = [c] { hip_check(hipStreamWaitEvent(c->stream, c->ev_aux[1], 0), "lasso: wait for counters / grand product #2 tree"); };
         }
