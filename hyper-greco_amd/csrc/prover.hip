@@ -687,15 +687,16 @@ struct Prover {
     }
     // the grand-product kernels leave the final LEFT evaluation of pair b multiplied by pw[b] (see kernels.hip)
     void defer_gp_unscale(size_t evals_slot, int nb, const dev::Powers& pw) {
-        ops.push_back([this, evals_slot, nb, pw] {
-            if (nb < 2) return;
-            if (pw.v[1].c0 == 0 && pw.v[1].c1 == 0) throw Error("grand product: zero batching weight");
-            const E2 ginv = e2_inv(pw.v[1]);  // pw[b] = gamma^b
-            E2 w = ginv;
-            for (int b = 1; b < nb; b++) {
-                ctx->h_res[evals_slot + 2 * b] = e2_mul(ctx->h_res[evals_slot + 2 * b], w);
-                w = e2_mul(w, ginv);
-            }
+        if (nb < 2) return;
+        if (pw.v[1].c0 == 0 && pw.v[1].c1 == 0) throw Error("grand product: zero batching weight");
+        // the inverse weights depend on the challenges only: computed here, during the walk (which a cached launch graph does not
+        // repeat), not in the replay that every prove runs after its synchronisation
+        auto winv = std::make_shared<std::vector<E2>>(nb);
+        const E2 ginv = e2_inv(pw.v[1]);  // pw[b] = gamma^b
+        E2 w = ginv;
+        for (int b = 1; b < nb; b++) { (*winv)[b] = w; w = e2_mul(w, ginv); }
+        ops.push_back([this, evals_slot, nb, winv] {
+            for (int b = 1; b < nb; b++) ctx->h_res[evals_slot + 2 * b] = e2_mul(ctx->h_res[evals_slot + 2 * b], (*winv)[b]);
         });
     }
     // proof map (HG_PROOF_MAP=<file>): byte offset of every protocol element, for diffing against a proof dumped by the
