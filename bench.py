@@ -244,6 +244,13 @@ def main():
 
     if shard:  # the sharded proof must equal the single-GPU proof bit for bit
         unsharded = hg.prove_resident(ctx, pk, vals, out).bytes()
+        # every rank must hand the collective a result buffer of the same length (they walk the same protocol): a mismatch would
+        # hang the all-reduce, so check it once, up front, through the caller-side entry points (no collective inside)
+        n_local = int(len(hg.prove_shard_begin(ctx, pk, vals, rank, world)))
+        hg.prove_shard_finish(ctx, out)   # (clears the pending shard; its partial-sum "proof" is discarded)
+        lens = [None] * world
+        dist.all_gather_object(lens, n_local)
+        assert len(set(lens)) == 1, f"ranks disagree on the result-buffer length: {lens}"
     for _ in range(max(args.warmup, 1)):
         step()
     first = out.bytes()

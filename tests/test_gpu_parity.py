@@ -224,7 +224,7 @@ def test_headline_config_properties(ctx):
     pk.free()
 
 
-@pytest.mark.parametrize("n,k,world", [(1024, 1, 2), (4096, 2, 3), (8192, 4, 8), (32768, 16, 8), (32768, 16, 2)])
+@pytest.mark.parametrize("n,k,world", [(1024, 1, 2), (4096, 2, 3), (8192, 4, 8), (32768, 16, 8), (32768, 16, 4), (32768, 16, 2)])
 def test_sharded_single_proof_reassembles_bit_exact(ctx, n, k, world):
     """Single-proof sharding (hg_prove_shard_*): run every virtual rank of a `world`-GPU job on this one GPU, sum the
     partial result buffers the way the all-gather + hg_prove_shard_combine does (lane-wise sum mod p: grand product
