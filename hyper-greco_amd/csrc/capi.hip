@@ -85,10 +85,14 @@ hg_ctx* hg_create(int device_id) {
     hip_check(hipSetDevice(device_id), "hipSetDevice");
     hg_ctx* c = new hg_ctx();
     c->device = device_id;
-    // the main stream carries the critical path (split -> collation -> grand product #1), the second stream work that hides under
-    // it: where the runtime offers stream priorities the main stream gets the highest, the second the lowest (HG_NO_PRIO=1: none)
+    // Two plain streams. Stream priorities (main high, second low; HG_PRIO=1 turns them on) measured no better on the streams
+    // themselves (3.00-3.02 ms either way) and much worse under the cached launch graph: the second and every later graph
+    // instantiated on a context replays its side branch on a stream of NORMAL priority, which competes with the high-priority main
+    // branch instead of hiding under it - 5.0 ms per prove instead of 3.05 (scripts/ub/repro_graph_slow.py; GPU_MAX_HW_QUEUES=2
+    // hides it, HG_PRIO unset removes it).
     int prio_lo = 0, prio_hi = 0;
-    if (getenv("HG_NO_PRIO") || hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) prio_lo = prio_hi = 0;
+    const char* want_prio = getenv("HG_PRIO");
+    if (!(want_prio && want_prio[0] == '1') || hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) prio_lo = prio_hi = 0;
     if (prio_lo != prio_hi) {
         hip_check(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi), "hipStreamCreate");
         hip_check(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_lo), "hipStreamCreate");

@@ -125,6 +125,8 @@ hg_ctx::~hg_ctx() {
     if (comm) { try { hg::comm_destroy(this); } catch (...) {} }
     if (d_xchg) (void)hipFree(d_xchg);
     if (stream2) { (void)hipStreamSynchronize(stream2); (void)hipStreamDestroy(stream2); }
+    if (bn_stream_hi) (void)hipStreamDestroy(bn_stream_hi);
+    if (bn_stream_lo) (void)hipStreamDestroy(bn_stream_lo);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
     for (auto e : ev_aux) if (e) (void)hipEventDestroy(e);

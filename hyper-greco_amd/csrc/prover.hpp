@@ -20,6 +20,7 @@ struct hg_ctx {
     typedef hg::u64 u64;
     int device = 0;
     hipStream_t stream = nullptr;   // Lasso node + everything sequential
+    hipStream_t bn_stream_hi = nullptr, bn_stream_lo = nullptr;   // BN254 prove only (bn254_gkr.inc: BnStreams), created on first use
     hipStream_t stream2 = nullptr;  // Vanilla / FFT node reductions (independent of the Lasso node on the device)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_aux[3] = {nullptr, nullptr, nullptr};  // Lasso node: limbs done (stream -> stream2), counters + grand product #2 levels done (stream2 -> stream), E tables done (stream -> stream2)
