@@ -1725,6 +1725,7 @@ struct ProveCache {
     const u64* d_ct0is = nullptr;
     bool one_stream = false;
     uint64_t epoch = 0;
+    int rank = 0, world = 1;   // a sharded proof's graph holds this rank's share; the all-reduce follows the replay on the stream
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     ~ProveCache() {
         if (exec) (void)hipGraphExecDestroy(exec);
@@ -1742,11 +1743,12 @@ static bool graph_allowed(const hg_ctx* ctx) {
     return !off && getenv("HG_PROOF_MAP") == nullptr && ctx->use_graph && ctx->prof_level == 0 && ctx->d_res == ctx->h_res;
 }
 // launches the cached graph, waits, replays the transcript
-static ProveResult prove_from_cache(hg_ctx* ctx, ProveCache* C) {
+static ProveResult prove_from_cache(hg_ctx* ctx, ProveCache* C, bool exchange = false, bool replay_now = true) {
     ProveResult res;
     const double t0 = wall_ms();
     hip_check(hipEventRecord(C->ev_a, ctx->stream), "event record");
     hip_check(hipGraphLaunch(C->exec, ctx->stream), "hipGraphLaunch");
+    if (exchange) comm_allreduce_results(ctx, C->P->res_used);   // the one collective of a sharded proof, behind the replayed graph
     hip_check(hipEventRecord(C->ev_b, ctx->stream), "event record");
     Prover* P = C->P.get();
     P->st = ctx->stream;
@@ -1755,9 +1757,10 @@ static ProveResult prove_from_cache(hg_ctx* ctx, ProveCache* C) {
     (void)hipEventElapsedTime(&gms, C->ev_a, C->ev_b);
     P->proof.bytes.clear();
     P->proof_map.clear();
+    res.gpu_ms = gms;
+    if (!replay_now) { res.prove_ms = wall_ms() - t0; res.enqueue_ms = P->t_enqueued - t0; return res; }   // caller-side exchange first (hg_prove_shard_*)
     P->replay();
     res.prove_ms = wall_ms() - t0;
-    res.gpu_ms = gms;
     res.enqueue_ms = P->t_enqueued - t0;
     res.sync_ms = P->t_synced - P->t_enqueued;
     res.replay_ms = P->t_replayed - P->t_synced;
@@ -1765,7 +1768,7 @@ static ProveResult prove_from_cache(hg_ctx* ctx, ProveCache* C) {
     return res;
 }
 // records the whole enqueue into a graph (no kernel runs during the capture), instantiates it, then proves through it
-static ProveResult prove_capture(hg_ctx* ctx, const hg_pk* pk, const hg_values* v) {
+static ProveResult prove_capture(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int rank = 0, int world = 1, bool exchange = false, bool replay_now = true) {
     hip_check(hipSetDevice(ctx->device), "hipSetDevice");
     prove_cache_drop(ctx);
     ctx->arena_reset();
@@ -1773,9 +1776,9 @@ static ProveResult prove_capture(hg_ctx* ctx, const hg_pk* pk, const hg_values* 
     std::unique_ptr<ProveCache> C(new ProveCache());
     hip_check(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
     try {
-        C->P.reset(new Prover(ctx, pk, 0, 1));
+        C->P.reset(new Prover(ctx, pk, rank, world));
         C->P->d_vals = v->d_vals;
-        enqueue_prove(ctx, pk, v, C->P.get(), 1, false);
+        enqueue_prove(ctx, pk, v, C->P.get(), world, false);   // (the exchange is not part of the graph: prove_from_cache)
     } catch (...) {
         hipGraph_t g = nullptr;
         (void)hipStreamEndCapture(ctx->stream, &g);
@@ -1789,24 +1792,39 @@ static ProveResult prove_capture(hg_ctx* ctx, const hg_pk* pk, const hg_values* 
     hip_check(hipGraphInstantiate(&C->exec, C->graph, nullptr, nullptr, 0), "hipGraphInstantiate");
     hip_check(hipEventCreate(&C->ev_a), "event"); hip_check(hipEventCreate(&C->ev_b), "event");
     C->pk = pk; C->pk_serial = pk->serial; C->d_vals = v->d_vals; C->d_ct0is = v->d_ct0is; C->one_stream = ctx->one_stream; C->epoch = ctx->arena_epoch;
+    C->rank = rank; C->world = world;
     ProveCache* raw = C.release();
     ctx->prove_cache = raw;
-    return prove_from_cache(ctx, raw);
+    return prove_from_cache(ctx, raw, exchange, replay_now);
+}
+
+// The cached-graph path of a (rank of a) prove: replays the cached graph when it was recorded for exactly this call, records one on
+// the third call in a row with the same key, values and share; otherwise returns false and the caller walks the protocol.
+static bool prove_through_graph(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int rank, int world, bool exchange, ProveResult* out, bool replay_now = true) {
+    if (!graph_allowed(ctx)) { ctx->same_key_proves = 0; return false; }
+    ProveCache* C = static_cast<ProveCache*>(ctx->prove_cache);
+    if (C && C->pk == pk && C->pk_serial == pk->serial && C->d_vals == v->d_vals && C->d_ct0is == v->d_ct0is && C->one_stream == ctx->one_stream &&
+        C->epoch == ctx->arena_epoch && C->rank == rank && C->world == world) {
+        *out = prove_from_cache(ctx, C, exchange, replay_now);
+        return true;
+    }
+    const void* vkey = v->d_vals.empty() ? nullptr : (const void*)v->d_vals[0];
+    const bool same = ctx->last_prove_key[0] == pk && ctx->last_prove_key[1] == vkey && ctx->last_prove_serial == pk->serial &&
+                      ctx->last_prove_share == rank * 65536 + world;
+    ctx->last_prove_serial = pk->serial;
+    ctx->last_prove_share = rank * 65536 + world;
+    ctx->same_key_proves = same ? ctx->same_key_proves + 1 : 0;
+    ctx->last_prove_key[0] = pk; ctx->last_prove_key[1] = vkey;
+    // third prove of the same (key, values): the arena has grown (1st) and been coalesced (2nd) - its addresses are now stable
+    if (ctx->same_key_proves >= 2 && ctx->chunks.size() <= 1) { *out = prove_capture(ctx, pk, v, rank, world, exchange, replay_now); return true; }
+    return false;
 }
 
 ProveResult prove_resident(hg_ctx* ctx, const hg_pk* pk, const hg_values* v) {
-    if (graph_allowed(ctx)) {
-        ProveCache* C = static_cast<ProveCache*>(ctx->prove_cache);
-        if (C && C->pk == pk && C->pk_serial == pk->serial && C->d_vals == v->d_vals && C->d_ct0is == v->d_ct0is && C->one_stream == ctx->one_stream && C->epoch == ctx->arena_epoch)
-            return prove_from_cache(ctx, C);
-        const void* vkey = v->d_vals.empty() ? nullptr : (const void*)v->d_vals[0];
-        const bool same = ctx->last_prove_key[0] == pk && ctx->last_prove_key[1] == vkey && ctx->last_prove_serial == pk->serial;
-        ctx->last_prove_serial = pk->serial;
-        ctx->same_key_proves = same ? ctx->same_key_proves + 1 : 0;
-        ctx->last_prove_key[0] = pk; ctx->last_prove_key[1] = vkey;
-        // third prove of the same (key, values): the arena has grown (1st) and been coalesced (2nd) - its addresses are now stable
-        if (ctx->same_key_proves >= 2 && ctx->chunks.size() <= 1) return prove_capture(ctx, pk, v);
-    } else ctx->same_key_proves = 0;
+    {
+        ProveResult cached;
+        if (prove_through_graph(ctx, pk, v, 0, 1, false, &cached)) return cached;
+    }
     if (ctx->prove_cache) prove_cache_drop(ctx);
     ProveResult res;
     double t3 = 0;
@@ -1826,6 +1844,11 @@ ProveResult prove_resident(hg_ctx* ctx, const hg_pk* pk, const hg_values* v) {
 ProveResult prove_sharded(hg_ctx* ctx, const hg_pk* pk, const hg_values* v) {
     if (!ctx->comm) throw Error("hg_prove_sharded: no communicator on this context (hg_comm_init)");
     if (ctx->d_res != ctx->h_res) throw Error("hg_prove_sharded: needs the host-mapped result buffer (unset HG_RES_DEVICE)");
+    {
+        ProveResult cached;   // this rank's share as a cached launch graph, the all-reduce enqueued behind it
+        if (prove_through_graph(ctx, pk, v, ctx->comm_rank, ctx->comm_world, true, &cached)) return cached;
+    }
+    if (ctx->prove_cache) prove_cache_drop(ctx);
     ProveResult res;
     double t3 = 0;
     float gms = 0;
@@ -1841,14 +1864,23 @@ ProveResult prove_sharded(hg_ctx* ctx, const hg_pk* pk, const hg_values* v) {
 }
 
 // sharded single proof: begin (this rank's jobs) -> caller sum-all-reduces ctx->h_res[0 .. n) -> finish
-struct PendingShard { std::unique_ptr<Prover> P; double t_start; float gpu_ms; };
+struct PendingShard { std::unique_ptr<Prover> own; Prover* P = nullptr; double t_start = 0; float gpu_ms = 0; };   // P: `own`, or the cached graph's prover
 static std::map<hg_ctx*, PendingShard> g_pending;  // one sharded prove in flight per context
 static std::mutex g_pending_mu;
 
 size_t prove_shard_begin(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int rank, int world) {
     if (world < 1 || rank < 0 || rank >= world) throw Error("prove_shard_begin: bad rank/world");
     PendingShard ps;
-    ps.P = prove_begin(ctx, pk, v, rank, world, &ps.t_start, &ps.gpu_ms);
+    ProveResult cached;
+    ps.t_start = wall_ms();
+    if (prove_through_graph(ctx, pk, v, rank, world, false, &cached, false)) {   // this rank's share replayed from its launch graph
+        ps.P = static_cast<ProveCache*>(ctx->prove_cache)->P.get();
+        ps.gpu_ms = (float)cached.gpu_ms;
+    } else {
+        if (ctx->prove_cache) prove_cache_drop(ctx);
+        ps.own = prove_begin(ctx, pk, v, rank, world, &ps.t_start, &ps.gpu_ms);
+        ps.P = ps.own.get();
+    }
     size_t n = ps.P->res_used;
     if (getenv("HG_SHARD_DEBUG")) fprintf(stderr, "[hg] shard rank %d/%d: gpu %.3f ms, enqueue %.3f ms\n", rank, world, ps.gpu_ms, ps.P->t_enqueued - ps.t_start);
     { std::lock_guard<std::mutex> lk(g_pending_mu); g_pending[ctx] = std::move(ps); }

@@ -39,6 +39,7 @@ struct hg_ctx {
     const void* last_prove_key[2] = {nullptr, nullptr};
     uint64_t last_prove_serial = 0;
     int same_key_proves = 0;
+    int last_prove_share = 1;       // rank * 65536 + world of the last resident / sharded prove (part of the "same call" test)
     bool use_graph = true;          // hg_set_option("graph", 0) / HG_NO_GRAPH=1 turn it off
     // options (hg_set_option)
     bool one_stream = false;  // keep every launch on `stream` (per-kernel timings without cross-stream interference)

@@ -246,6 +246,27 @@ def test_sharded_single_proof_reassembles_bit_exact(ctx, n, k, world):
     pk.free()
 
 
+def test_a_ranks_share_replays_from_its_launch_graph(ctx):
+    """The share of one rank of an 8-rank proof, five times in a row: two walks, the capture, two graph replays - the partial
+    result buffer must be the same every time, and the last one must still reassemble to the unsharded proof."""
+    n, k, world, r = 8192, 4, 8, 3
+    bfv = hg.BfvEncrypt.new(n, k)
+    pk = bfv.setup(ctx)
+    w = hg.Witness.synthetic(bfv.params, 0x4752454330 + n)
+    vals = hg.witness_gen(ctx, pk, w)
+    out = hg.ProofBuffer()
+    ref = hg.prove_resident(ctx, pk, vals, out).bytes()
+    others = {q: hg.prove_shard_begin(ctx, pk, vals, q, world).copy() for q in range(world) if q != r}
+    mine = [hg.prove_shard_begin(ctx, pk, vals, r, world).copy() for _ in range(5)]
+    for i in range(1, 5):
+        assert np.array_equal(mine[i], mine[0]), i
+    parts = [others[q] if q != r else mine[4] for q in range(world)]
+    hg.prove_shard_combine(ctx, np.stack(parts), world)
+    assert hg.prove_shard_finish(ctx, out).bytes() == ref
+    vals.free()
+    pk.free()
+
+
 @pytest.mark.parametrize("n,k,bits", FIX)
 @pytest.mark.parametrize("mode", [1, 2, 3])
 def test_protocol_modes_bit_exact_against_the_oracle(ctx, n, k, bits, mode):
@@ -387,8 +408,8 @@ def test_library_collective_single_rank_communicator(ctx):
     hg.comm_init(ctx, hg.comm_unique_id(), 0, 1)
     with pytest.raises(hg.HgError, match="already has a communicator"):
         hg.comm_init(ctx, hg.comm_unique_id(), 0, 1)
-    for _ in range(2):
-        assert hg.prove_sharded(ctx, pk, vals, out).bytes() == ref
+    for i in range(6):   # walk, walk, capture (the share's launch graph; the all-reduce follows it on the stream), replay x3
+        assert hg.prove_sharded(ctx, pk, vals, out).bytes() == ref, i
     hg.comm_destroy(ctx)
     assert hg.prove_resident(ctx, pk, vals, out).bytes() == ref
     vals.free()
