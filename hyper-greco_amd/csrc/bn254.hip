@@ -7,6 +7,7 @@
 //  lasso/src/lasso.rs:457-475 (collation g), lasso/src/memory_checking/prover.rs:268-279 (grand-product g);
 //  sk_encryption_circuit.rs:417-460, 614-626 (prove; Fr, Fr)]
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -38,16 +39,31 @@ static Fr fr_from_le32_mod(const uint8_t h[32]) {
     }
     return v;
 }
+// The chain does not depend on anything (transcript.rs:146-157: nothing is absorbed): computed once per process and extended on
+// demand - a prove squeezes ~9000 challenges, i.e. ~9000 Keccak permutations that used to run at the start of every prove
+// while the GPU waited.
+static std::mutex g_bn_chain_mu;
+static std::vector<Fr> g_bn_chain;
+static uint8_t g_bn_chain_h[32];
+// copies challenges [from, from + n) into out
+static void bn_chain_copy(size_t from, size_t n, Fr* out) {
+    std::lock_guard<std::mutex> lk(g_bn_chain_mu);
+    if (g_bn_chain.empty()) keccak256(nullptr, 0, g_bn_chain_h);
+    if (g_bn_chain.size() < from + n) {
+        const size_t want = std::max(from + n, g_bn_chain.size() + 4096);
+        g_bn_chain.reserve(want);
+        while (g_bn_chain.size() < want) {
+            g_bn_chain.push_back(fr_from_le32_mod(g_bn_chain_h));
+            uint8_t nx[32];
+            keccak256(g_bn_chain_h, 32, nx);
+            memcpy(g_bn_chain_h, nx, 32);
+        }
+    }
+    for (size_t i = 0; i < n; i++) out[i] = g_bn_chain[from + i];
+}
 std::vector<Fr> challenge_chain_bn254(size_t n) {
     std::vector<Fr> out(n);
-    uint8_t h[32];
-    keccak256(nullptr, 0, h);
-    for (size_t i = 0; i < n; i++) {
-        out[i] = fr_from_le32_mod(h);
-        uint8_t nx[32];
-        keccak256(h, 32, nx);
-        memcpy(h, nx, 32);
-    }
+    if (n) bn_chain_copy(0, n, out.data());
     return out;
 }
 
@@ -622,7 +638,8 @@ static size_t gp_challenges(int nv) { size_t need = 1; for (int n = 1; n < nv; n
 // mirror_c (Montgomery, optional): rows nb/2 .. nb-1 of level 0 are rows 0 .. nb/2-1 plus this constant (the Lasso write hashes are
 // the read hashes + gamma^2): the top layer then runs on the read rows only (GpJobDev::mirror).
 static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* const* tables, const Fr* d_lev0, size_t chain_skip,
-                               std::vector<uint8_t>& proof, std::vector<Fr>& claims_canon, std::vector<Fr>& point_canon, const Fr* mirror_c = nullptr) {
+                               std::vector<uint8_t>& proof, std::vector<Fr>& claims_canon, std::vector<Fr>& point_canon, const Fr* mirror_c = nullptr,
+                               std::function<void()>* defer = nullptr) {
     if (nb == 0 || len < 2 || (len & (len - 1))) throw Error("hg_grand_product_bn254: need nb >= 1 tables of a power-of-two length >= 2");
     hipc(hipSetDevice(ctx->device), "hipSetDevice");
     hipStream_t st = ctx->stream;
@@ -790,13 +807,23 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
                     k_bn_copy_from_mont<<<(unsigned)((cnt + 255) / 256), 256, 0, st>>>(((plan[n].nmain - 1) & 1) ? plan[n].buf1 : plan[n].buf0, layers[n].d_final, cnt);
                 }
         }
-        res_sync(ctx, st, "grand_product_bn254: sync");
+        // `defer`: the caller waits later (it has more to enqueue that does not depend on this grand product's results) and runs
+        // the transcript replay then; the buffers stay until the caller rewinds the arena
+        if (!defer) res_sync(ctx, st, "grand_product_bn254: sync");
     } catch (...) {
         ctx->arena_rewind(arena_mark);
         throw;
     }
-    ctx->arena_rewind(arena_mark);
-    // transcript replay
+    if (!defer) ctx->arena_rewind(arena_mark);
+    // the final point is challenges only: the last layer's round challenges, then its mu
+    point_canon.clear();
+    if (nv > 1) for (int rd = 0; rd < nv - 1; rd++) point_canon.push_back(chain[layers[nv - 1].r_at + rd]);
+    point_canon.push_back(chain[layers[nv - 1].mu_at]);
+    const bool has_mirror = mirror_c != nullptr;
+    const Fr mirror_val = mirror_c ? *mirror_c : fr_zero();
+    // transcript replay (reads the host-mapped result slots: valid after the synchronisation)
+    auto replay = [layers, chain, h_top, h_roots, nb, nv, has_mirror, mirror_val, &proof, &claims_canon] {
+    const Fr* mirror_c = has_mirror ? &mirror_val : nullptr;
     proof.clear();
     std::vector<Fr> claims(nb), x;
     for (size_t b = 0; b < nb; b++) { write_be32(proof, h_roots[b]); claims[b] = fr_to_mont(h_roots[b]); }
@@ -839,7 +866,9 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
     }
     claims_canon.resize(nb);
     for (size_t b = 0; b < nb; b++) claims_canon[b] = fr_from_mont(claims[b]);
-    point_canon = x;
+    };
+    if (defer) *defer = replay;
+    else replay();
 }
 void grand_product_bn254(hg_ctx* ctx, size_t nb, size_t len, const u64* const* tables, size_t chain_skip, std::vector<uint8_t>& proof,
                          u64* claims_out, u64* point_out) {
@@ -1007,7 +1036,8 @@ static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4,
     auto dalloc = [&](size_t n_fr) { return (Fr*)dalloc_b(n_fr * sizeof(Fr)); };
     auto grid1 = [](size_t n) { return (unsigned)((n + 255) / 256); };
     std::vector<uint8_t> gp1_bytes, gp2_bytes;
-    std::vector<Fr> x, y, tmp_claims, h_col((size_t)nu * 2), opens;
+    std::vector<Fr> x, y, tmp_claims, tmp_claims2, h_col((size_t)nu * 2), opens;
+    std::function<void()> replay_gp1, replay_gp2;
     Fr h_claimed;
     try {
         // polynomialize (lasso.rs:157-250): integer kernels of the Goldilocks path
@@ -1100,8 +1130,10 @@ static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4,
         }
         static const bool use_mirror = [] { const char* e = getenv("HG_NO_MIRROR"); return !(e && e[0] == '1'); }();
         // the write hashes are the read hashes + gamma^2 (k_bn_hash_rw): the top layer runs on the read rows only
-        grand_product_core(ctx, 2 * G, N, nullptr, H1, gp1_at, gp1_bytes, tmp_claims, x, (use_mirror && nu >= 2) ? &gamma2 : nullptr);  // reads then writes (prover.rs:161-165)
-        grand_product_core(ctx, 2 * G, M, nullptr, H2, gp2_at, gp2_bytes, tmp_claims, y);  // inits then finals (prover.rs:167-171)
+        // both grand products and the openings are enqueued back to back (nothing here depends on a result read by the host: the
+        // points are challenges); ONE wait at the end, then the two transcript replays
+        grand_product_core(ctx, 2 * G, N, nullptr, H1, gp1_at, gp1_bytes, tmp_claims, x, (use_mirror && nu >= 2) ? &gamma2 : nullptr, &replay_gp1);  // reads then writes (prover.rs:161-165)
+        grand_product_core(ctx, 2 * G, M, nullptr, H2, gp2_at, gp2_bytes, tmp_claims2, y, nullptr, &replay_gp2);  // inits then finals (prover.rs:167-171)
         // openings (prover.rs:173-178, mod.rs:80-93)
         Fr* eqy = dalloc(M);
         build_eq(eq, x.data(), nu);
@@ -1139,6 +1171,8 @@ static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4,
         }
         res_sync(ctx, st, "lasso_prove_bn254: sync");
         if (h_bad) throw Error("hg_lasso_prove_bn254: the node input holds a value that is not below 2^64 (not a range-shifted value)");
+        replay_gp1();
+        replay_gp2();
         h_claimed = *r_claimed.host;
         for (size_t i = 0; i < h_col.size(); i++) h_col[i] = r_col.host[i];
         for (const Fr* q : open_at) opens.push_back(*q);
