@@ -481,6 +481,22 @@ static void res_sync(hg_ctx* ctx, hipStream_t st, const char* what) {
     hipc(hipStreamSynchronize(st), what);
     hipc(hipGetLastError(), what);
 }
+// Small host->device descriptor uploads go through the context's pinned staging buffer (reset by arena_reset): a hipMemcpyAsync
+// from pageable memory is staged by the runtime IN STREAM ORDER, i.e. the host blocks until the stream has drained up to it -
+// which kept the host from running ahead of the node stream (the Lasso node started 3.5 ms into the prove). Falls back to the
+// pageable copy when the staging buffer is full (keep-alive is then the caller's business, as before).
+static void bn_upload(hg_ctx* ctx, hipStream_t st, void* dst, const void* src, size_t bytes, const char* what) {
+    const size_t need = (bytes + 63) & ~(size_t)63;
+    if (ctx->h_stage && ctx->stage_used + need <= ctx->stage_cap) {
+        void* p = ctx->h_stage + ctx->stage_used;
+        ctx->stage_used += need;
+        memcpy(p, src, bytes);
+        hipc(hipMemcpyAsync(dst, p, bytes, hipMemcpyHostToDevice, st), what);
+    } else {
+        hipc(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st), what);
+        hipc(hipStreamSynchronize(st), what);   // (the source may be a local)
+    }
+}
 __global__ void k_bn_copy_from_mont(const Fr* __restrict__ src, Fr* __restrict__ dst, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = fr_from_mont(src[i]);
@@ -792,10 +808,9 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
             GpJobDev* d_descs = static_cast<GpJobDev*>(ctx->alloc(descs.size() * sizeof(GpJobDev)));
             RedJobDev* d_reds = static_cast<RedJobDev*>(ctx->alloc(reds.size() * sizeof(RedJobDev)));
             TailJobDev* d_tails = static_cast<TailJobDev*>(ctx->alloc(std::max<size_t>(tails.size(), 1) * sizeof(TailJobDev)));
-            // (blocking copies: the staging vectors are locals)
-            hipc(hipMemcpy(d_descs, descs.data(), descs.size() * sizeof(GpJobDev), hipMemcpyHostToDevice), "upload round jobs");
-            hipc(hipMemcpy(d_reds, reds.data(), reds.size() * sizeof(RedJobDev), hipMemcpyHostToDevice), "upload reduce jobs");
-            if (!tails.empty()) hipc(hipMemcpy(d_tails, tails.data(), tails.size() * sizeof(TailJobDev), hipMemcpyHostToDevice), "upload tail jobs");
+            bn_upload(ctx, st, d_descs, descs.data(), descs.size() * sizeof(GpJobDev), "upload round jobs");
+            bn_upload(ctx, st, d_reds, reds.data(), reds.size() * sizeof(RedJobDev), "upload reduce jobs");
+            if (!tails.empty()) bn_upload(ctx, st, d_tails, tails.data(), tails.size() * sizeof(TailJobDev), "upload tail jobs");
             for (int rd = 0; rd < max_main; rd++) {
                 k_bn_gp_round_jobs<<<dim3(max_blocks[rd], nactive[rd], 1), BN_TPB, 0, st>>>(d_descs + off[rd]);
             }
