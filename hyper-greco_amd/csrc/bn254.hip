@@ -651,11 +651,51 @@ static Fr replay_round(const Fr* sums_canonical, int d, Fr claim, Fr r, Fr* c /*
 // big-endian elements. claims_out: nb final claims, point_out: nv coordinates.
 static size_t gp_challenges(int nv) { size_t need = 1; for (int n = 1; n < nv; n++) need += 2 + n; return need; }
 // core: level 0 already on the device in Montgomery form (nb rows of len), or uploaded from `tables` when d_lev0 is null
+// The round launches of one or several grand products: round rd of every layer of every product in ONE launch (the products are
+// as independent of each other as the layers of one product are). grand_product_core fills a set; gp_launch_set runs it.
+struct GpLaunchSet {
+    std::vector<std::vector<GpJobDev>> by_rd;
+    std::vector<RedJobDev> reds;
+    std::vector<TailJobDev> tails;
+    std::vector<std::function<void()>> posts;   // after the rounds: final values of layers without a tail
+    void merge(GpLaunchSet& o) {
+        if (by_rd.size() < o.by_rd.size()) by_rd.resize(o.by_rd.size());
+        for (size_t rd = 0; rd < o.by_rd.size(); rd++) by_rd[rd].insert(by_rd[rd].end(), o.by_rd[rd].begin(), o.by_rd[rd].end());
+        reds.insert(reds.end(), o.reds.begin(), o.reds.end());
+        tails.insert(tails.end(), o.tails.begin(), o.tails.end());
+        posts.insert(posts.end(), o.posts.begin(), o.posts.end());
+    }
+};
+static void gp_launch_set(hg_ctx* ctx, hipStream_t st, GpLaunchSet& S) {
+    std::vector<GpJobDev> descs;
+    std::vector<size_t> off;
+    std::vector<int> max_blocks;
+    for (auto& v : S.by_rd) {
+        off.push_back(descs.size());
+        int mb = 0;
+        for (auto& d : v) mb = std::max(mb, d.gx * d.gy);
+        max_blocks.push_back(mb);
+        descs.insert(descs.end(), v.begin(), v.end());
+    }
+    if (descs.empty()) return;
+    GpJobDev* d_descs = static_cast<GpJobDev*>(ctx->alloc(descs.size() * sizeof(GpJobDev)));
+    RedJobDev* d_reds = static_cast<RedJobDev*>(ctx->alloc(std::max<size_t>(S.reds.size(), 1) * sizeof(RedJobDev)));
+    TailJobDev* d_tails = static_cast<TailJobDev*>(ctx->alloc(std::max<size_t>(S.tails.size(), 1) * sizeof(TailJobDev)));
+    bn_upload(ctx, st, d_descs, descs.data(), descs.size() * sizeof(GpJobDev), "upload round jobs");
+    if (!S.reds.empty()) bn_upload(ctx, st, d_reds, S.reds.data(), S.reds.size() * sizeof(RedJobDev), "upload reduce jobs");
+    if (!S.tails.empty()) bn_upload(ctx, st, d_tails, S.tails.data(), S.tails.size() * sizeof(TailJobDev), "upload tail jobs");
+    for (size_t rd = 0; rd < S.by_rd.size(); rd++)
+        if (!S.by_rd[rd].empty()) k_bn_gp_round_jobs<<<dim3(max_blocks[rd], (unsigned)S.by_rd[rd].size(), 1), BN_TPB, 0, st>>>(d_descs + off[rd]);
+    if (!S.reds.empty()) k_bn_reduce_jobs<<<dim3(32, (unsigned)S.reds.size()), BN_TPB, 0, st>>>(d_reds, 3);
+    if (!S.tails.empty()) k_bn_tail_jobs<BN_GRANDPROD><<<(unsigned)S.tails.size(), 3 * BN_TPB, 0, st>>>(d_tails);
+    for (auto& f : S.posts) f();
+}
 // mirror_c (Montgomery, optional): rows nb/2 .. nb-1 of level 0 are rows 0 .. nb/2-1 plus this constant (the Lasso write hashes are
 // the read hashes + gamma^2): the top layer then runs on the read rows only (GpJobDev::mirror).
 static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* const* tables, const Fr* d_lev0, size_t chain_skip,
                                std::vector<uint8_t>& proof, std::vector<Fr>& claims_canon, std::vector<Fr>& point_canon, const Fr* mirror_c = nullptr,
-                               std::function<void()>* defer = nullptr) {
+                               std::function<void()>* defer = nullptr, GpLaunchSet* set = nullptr) {
+    if (set && !defer) throw Error("grand_product_core: a shared launch set needs the deferred form");
     if (nb == 0 || len < 2 || (len & (len - 1))) throw Error("hg_grand_product_bn254: need nb >= 1 tables of a power-of-two length >= 2");
     hipc(hipSetDevice(ctx->device), "hipSetDevice");
     hipStream_t st = ctx->stream;
@@ -738,15 +778,13 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
                 else k_bn_weight_rows<<<(unsigned)((nb * h + 255) / 256), 256, 0, st>>>(lev[nv - 1 - n], 2 * h, plan[n].d_pw, plan[n].lw, h, (int)nb);
             }
         }
-        std::vector<GpJobDev> descs;
-        std::vector<RedJobDev> reds;
-        std::vector<TailJobDev> tails;
-        std::vector<size_t> off(max_main + 1, 0);
-        std::vector<int> max_blocks(max_main, 0), nactive(max_main, 0);
+        GpLaunchSet own;
+        own.by_rd.resize(max_main);
+        std::vector<RedJobDev>& reds = own.reds;
+        std::vector<TailJobDev>& tails = own.tails;
         std::vector<int> red_index(nv, -1);
         for (int n = 1; n < nv; n++) { red_index[n] = (int)reds.size(); RedJobDev r; memset(&r, 0, sizeof(r)); reds.push_back(r); }
         for (int rd = 0; rd < max_main; rd++) {
-            off[rd] = descs.size();
             for (int n = 1; n < nv; n++) {
                 const LayerPlan& P = plan[n];
                 if (rd >= P.nmain) continue;
@@ -784,9 +822,7 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
                 const RoundGrid g = round_grid_gp(half, d.nb);
                 d.gx = g.gx; d.gy = g.gy;
                 reds[red_index[n]].n[rd] = g.blocks();
-                max_blocks[rd] = std::max(max_blocks[rd], g.blocks());
-                nactive[rd]++;
-                descs.push_back(d);
+                own.by_rd[rd].push_back(d);
             }
         }
         for (int n = 1; n < nv; n++) {
@@ -804,24 +840,15 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
                 tails.push_back(t);
             }
         }
-        if (!descs.empty()) {
-            GpJobDev* d_descs = static_cast<GpJobDev*>(ctx->alloc(descs.size() * sizeof(GpJobDev)));
-            RedJobDev* d_reds = static_cast<RedJobDev*>(ctx->alloc(reds.size() * sizeof(RedJobDev)));
-            TailJobDev* d_tails = static_cast<TailJobDev*>(ctx->alloc(std::max<size_t>(tails.size(), 1) * sizeof(TailJobDev)));
-            bn_upload(ctx, st, d_descs, descs.data(), descs.size() * sizeof(GpJobDev), "upload round jobs");
-            bn_upload(ctx, st, d_reds, reds.data(), reds.size() * sizeof(RedJobDev), "upload reduce jobs");
-            if (!tails.empty()) bn_upload(ctx, st, d_tails, tails.data(), tails.size() * sizeof(TailJobDev), "upload tail jobs");
-            for (int rd = 0; rd < max_main; rd++) {
-                k_bn_gp_round_jobs<<<dim3(max_blocks[rd], nactive[rd], 1), BN_TPB, 0, st>>>(d_descs + off[rd]);
+        for (int n = 1; n < nv; n++)   // layers without a tail (n = 1): the folded values are the last shared round's output
+            if (plan[n].nmain == n) {   // (a mirrored layer leaves the read rows' values only)
+                const size_t cnt = plan[n].mirror ? 2 * G2 : ntab;
+                const Fr* src = ((plan[n].nmain - 1) & 1) ? plan[n].buf1 : plan[n].buf0;
+                Fr* dst = layers[n].d_final;
+                own.posts.push_back([src, dst, cnt, st] { k_bn_copy_from_mont<<<(unsigned)((cnt + 255) / 256), 256, 0, st>>>(src, dst, cnt); });
             }
-            k_bn_reduce_jobs<<<dim3(32, (unsigned)reds.size()), BN_TPB, 0, st>>>(d_reds, 3);
-            if (!tails.empty()) k_bn_tail_jobs<BN_GRANDPROD><<<(unsigned)tails.size(), 3 * BN_TPB, 0, st>>>(d_tails);
-            for (int n = 1; n < nv; n++)   // layers without a tail (n = 1): the folded values are the last shared round's output
-                if (plan[n].nmain == n) {   // (a mirrored layer leaves the read rows' values only)
-                    const size_t cnt = plan[n].mirror ? 2 * G2 : ntab;
-                    k_bn_copy_from_mont<<<(unsigned)((cnt + 255) / 256), 256, 0, st>>>(((plan[n].nmain - 1) & 1) ? plan[n].buf1 : plan[n].buf0, layers[n].d_final, cnt);
-                }
-        }
+        if (set) set->merge(own);   // launched by the caller together with the other product's rounds (gp_launch_set)
+        else gp_launch_set(ctx, st, own);
         // `defer`: the caller waits later (it has more to enqueue that does not depend on this grand product's results) and runs
         // the transcript replay then; the buffers stay until the caller rewinds the arena
         if (!defer) res_sync(ctx, st, "grand_product_bn254: sync");
@@ -1147,8 +1174,10 @@ static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4,
         // the write hashes are the read hashes + gamma^2 (k_bn_hash_rw): the top layer runs on the read rows only
         // both grand products and the openings are enqueued back to back (nothing here depends on a result read by the host: the
         // points are challenges); ONE wait at the end, then the two transcript replays
-        grand_product_core(ctx, 2 * G, N, nullptr, H1, gp1_at, gp1_bytes, tmp_claims, x, (use_mirror && nu >= 2) ? &gamma2 : nullptr, &replay_gp1);  // reads then writes (prover.rs:161-165)
-        grand_product_core(ctx, 2 * G, M, nullptr, H2, gp2_at, gp2_bytes, tmp_claims2, y, nullptr, &replay_gp2);  // inits then finals (prover.rs:167-171)
+        GpLaunchSet gp_set;   // the rounds of BOTH grand products share their launches: the small one (2^16 rows) hides inside the big one's
+        grand_product_core(ctx, 2 * G, N, nullptr, H1, gp1_at, gp1_bytes, tmp_claims, x, (use_mirror && nu >= 2) ? &gamma2 : nullptr, &replay_gp1, &gp_set);  // reads then writes (prover.rs:161-165)
+        grand_product_core(ctx, 2 * G, M, nullptr, H2, gp2_at, gp2_bytes, tmp_claims2, y, nullptr, &replay_gp2, &gp_set);  // inits then finals (prover.rs:167-171)
+        gp_launch_set(ctx, st, gp_set);
         // openings (prover.rs:173-178, mod.rs:80-93)
         Fr* eqy = dalloc(M);
         build_eq(eq, x.data(), nu);
