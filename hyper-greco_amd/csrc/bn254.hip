@@ -615,6 +615,18 @@ __global__ void k_bn_prod_level(const Fr* __restrict__ in, size_t in_len, Fr* __
     const size_t b = i / h, j = i % h;
     out[b * h + j] = fr_mul_wide(in[b * in_len + j], in[b * in_len + j + h]);  // Layer::bottom / Layer::up: v_l * v_r on the MSB split
 }
+// level 1 of a mirrored product: `in` holds the nb/2 READ rows only; row b >= nb/2 of the output is the product of the read row
+// b - nb/2 shifted by c (the write rows are never materialised)
+__global__ void k_bn_prod_level_mirror(const Fr* __restrict__ in, size_t in_len, Fr* __restrict__ out, int nb, Fr c) {
+    const size_t h = in_len >> 1, total = h * nb;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const size_t b = i / h, j = i % h, half = (size_t)nb / 2;
+    const size_t src = b < half ? b : b - half;
+    Fr x = in[src * in_len + j], y = in[src * in_len + j + h];
+    if (b >= half) { x = fr_add(x, c); y = fr_add(y, c); }
+    out[b * h + j] = fr_mul_wide(x, y);
+}
 static void write_be32(std::vector<uint8_t>& out, const Fr& canonical) {  // transcript.rs:183-189: repr, byte-reversed
     for (int w = 3; w >= 0; w--)
         for (int b = 7; b >= 0; b--) out.push_back((uint8_t)(canonical.l[w] >> (8 * b)));
@@ -691,7 +703,8 @@ static void gp_launch_set(hg_ctx* ctx, hipStream_t st, GpLaunchSet& S) {
     for (auto& f : S.posts) f();
 }
 // mirror_c (Montgomery, optional): rows nb/2 .. nb-1 of level 0 are rows 0 .. nb/2-1 plus this constant (the Lasso write hashes are
-// the read hashes + gamma^2): the top layer then runs on the read rows only (GpJobDev::mirror).
+// the read hashes + gamma^2): the top layer then runs on the read rows only (GpJobDev::mirror) and d_lev0 HOLDS ONLY THOSE nb/2
+// ROWS - level 1 is computed from them (k_bn_prod_level_mirror). Needs len >= 4 (a level 1 and a sum-check layer on level 0).
 static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* const* tables, const Fr* d_lev0, size_t chain_skip,
                                std::vector<uint8_t>& proof, std::vector<Fr>& claims_canon, std::vector<Fr>& point_canon, const Fr* mirror_c = nullptr,
                                std::function<void()>* defer = nullptr, GpLaunchSet* set = nullptr) {
@@ -724,7 +737,8 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
         for (int k = 1; k < nv; k++) {
             Fr* lk = dalloc(nb * (len >> k));
             const size_t total = nb * (len >> k);
-            k_bn_prod_level<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(lev[k - 1], len >> (k - 1), lk, (int)nb);
+            if (k == 1 && mirror_c) k_bn_prod_level_mirror<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(lev[0], len, lk, (int)nb, *mirror_c);   // level 0: read rows only
+            else k_bn_prod_level<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(lev[k - 1], len >> (k - 1), lk, (int)nb);
             lev[k] = lk;
         }
         // roots and top evaluations: level nv-1 has rows of length 2
@@ -739,7 +753,7 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
         // plan every layer (buffers, result slots, launch shapes), then run the rounds of all layers round-synchronised
         struct LayerPlan { Fr *buf0, *buf1, *part, *tbuf, *d_pw, *lw, *S, *sbuf0, *sbuf1; int nmain; bool mirror; };
         const size_t G2 = nb / 2;
-        if (mirror_c && (nv < 2 || (nb & 1))) throw Error("hg_grand_product_bn254: mirrored rows need an even batch and two layers");
+        if (mirror_c && (nv < 2 || (nb & 1) || !d_lev0)) throw Error("hg_grand_product_bn254: mirrored rows need an even batch, two layers and device rows");
         std::vector<LayerPlan> plan(nv);
         int max_main = 0;
         if (nv > 32) throw Error("hg_grand_product_bn254: more than 32 layers");
@@ -1028,7 +1042,7 @@ __global__ void k_bn_hash_rw(size_t n, const u64* __restrict__ dim, const u64* _
     wcol_mac_u64(w, ts[j], K.gammasq2x);
     const Fr h = fr_sub(wcol_reduce(w), K.tau);
     rd[j] = h;
-    wr[j] = fr_add(h, K.gammasq);
+    if (wr) wr[j] = fr_add(h, K.gammasq);   // (null: the write rows are not materialised, see grand_product_core's mirror_c)
 }
 __global__ void k_bn_hash_if(u32 cutoff, const u64* __restrict__ fc, HashK K, Fr* __restrict__ init, Fr* __restrict__ fin) {
     u32 a = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1162,20 +1176,21 @@ static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4,
         HashK HK;
         HK.one2 = fr_r2(); HK.gamma2x = fr_to_mont(gamma); HK.gammasq2x = fr_to_mont(gamma2); HK.gammasq = gamma2; HK.tau = tau;
         const int G = (int)lp.gkr_order.size();
-        Fr* H1 = dalloc((size_t)2 * G * N);
+        static const bool use_mirror = [] { const char* e = getenv("HG_NO_MIRROR"); return !(e && e[0] == '1'); }();
+        const bool mirror = use_mirror && nu >= 2;   // write hash = read hash + gamma^2: only the read rows exist
+        Fr* H1 = dalloc((size_t)(mirror ? G : 2 * G) * N);
         Fr* H2 = dalloc((size_t)2 * G * M);
         for (int i = 0; i < G; i++) {
             const int m = lp.gkr_order[i], c = lp.gkr_chunk[i];
             k_bn_hash_rw<<<grid1(N), 256, 0, st>>>(N, dims + (size_t)c * N, ep + (size_t)m * N, read_ts[c], HK, H1 + (size_t)i * N,
-                                                  H1 + (size_t)(G + i) * N);
+                                                  mirror ? nullptr : H1 + (size_t)(G + i) * N);
             k_bn_hash_if<<<65536 / 256, 256, 0, st>>>((u32)lp.mems[m].cutoff, final_cts[c], HK, H2 + (size_t)i * M, H2 + (size_t)(G + i) * M);
         }
-        static const bool use_mirror = [] { const char* e = getenv("HG_NO_MIRROR"); return !(e && e[0] == '1'); }();
         // the write hashes are the read hashes + gamma^2 (k_bn_hash_rw): the top layer runs on the read rows only
         // both grand products and the openings are enqueued back to back (nothing here depends on a result read by the host: the
         // points are challenges); ONE wait at the end, then the two transcript replays
         GpLaunchSet gp_set;   // the rounds of BOTH grand products share their launches: the small one (2^16 rows) hides inside the big one's
-        grand_product_core(ctx, 2 * G, N, nullptr, H1, gp1_at, gp1_bytes, tmp_claims, x, (use_mirror && nu >= 2) ? &gamma2 : nullptr, &replay_gp1, &gp_set);  // reads then writes (prover.rs:161-165)
+        grand_product_core(ctx, 2 * G, N, nullptr, H1, gp1_at, gp1_bytes, tmp_claims, x, mirror ? &gamma2 : nullptr, &replay_gp1, &gp_set);  // reads then writes (prover.rs:161-165)
         grand_product_core(ctx, 2 * G, M, nullptr, H2, gp2_at, gp2_bytes, tmp_claims2, y, nullptr, &replay_gp2, &gp_set);  // inits then finals (prover.rs:167-171)
         gp_launch_set(ctx, st, gp_set);
         // openings (prover.rs:173-178, mod.rs:80-93)
