@@ -1109,18 +1109,25 @@ static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4,
         u64* ep = (u64*)dalloc_b((size_t)A * N * 8);
         dev::lasso_split(st, L, d_in, dims, ep, dev::ep_rows_all(L.alpha));
         std::map<int, u64*> read_ts, final_cts;
-        {
-            const size_t tb = dev::lasso_counter_temp_bytes(N);
-            void* temp = dalloc_b(tb);
-            u32* keys = (u32*)dalloc_b(N * 4); u32* keys2 = (u32*)dalloc_b(N * 4);
-            u32* rows = (u32*)dalloc_b(N * 4); u32* rows2 = (u32*)dalloc_b(N * 4);
-            u32* starts = (u32*)dalloc_b(65537 * 4);
+        {   // all counter chunks in one stable sort over (chunk, address) keys (as the Goldilocks prover: kernels.hip)
+            unsigned mask = 0;
+            dev::CounterOut co;
+            memset(&co, 0, sizeof(co));
             for (auto& chk : lp.chunks) {
                 const int c = chk.first;
+                if (c < 0 || c >= 4) throw Error("hg_lasso_prove_bn254: chunk index out of range");
+                mask |= 1u << c;
                 read_ts[c] = (u64*)dalloc_b(N * 8);
                 final_cts[c] = (u64*)dalloc_b(M * 8);
-                dev::lasso_counters(st, L, c, dims, read_ts[c], final_cts[c], temp, tb, keys, keys2, rows, rows2, starts);
+                co.read_ts[c] = read_ts[c]; co.final_cts[c] = final_cts[c];
             }
+            const size_t elems = std::max<size_t>(dev::lasso_counters_all_elems(L, mask), 1);
+            const size_t tb = dev::lasso_counters_all_temp_bytes(elems);
+            void* temp = dalloc_b(tb);
+            u32* keys = (u32*)dalloc_b(elems * 4); u32* keys2 = (u32*)dalloc_b(elems * 4);
+            u32* rows = (u32*)dalloc_b(elems * 4); u32* rows2 = (u32*)dalloc_b(elems * 4);
+            u32* starts = (u32*)dalloc_b((4 * 65536 + 1) * 4);
+            dev::lasso_counters_all(st, L, mask, dims, co, temp, tb, keys, keys2, rows, rows2, starts);
         }
         Fr* d_part = dalloc(1024 * 3);
         const ResRef r_claimed = res_slots(ctx, 1), r_col = res_slots(ctx, (size_t)nu * 2);
