@@ -1676,7 +1676,10 @@ void values_free(hg_values* v) {
 // everything a prove puts on the streams, in protocol order (also what a graph capture records)
 static void enqueue_prove(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, Prover* P, int world, bool exchange) {
     const Params& p = pk->params;
-    if (world > 1) hip_check(hipMemsetAsync(ctx->d_res, 0, ctx->res_cap * sizeof(E2), ctx->stream), "clear result buffer");
+    // un-owned result slots must read zero. The buffer is host memory across PCIe: clear only what a prove of this key uses (known
+    // from the previous walk of the same key; the first one clears everything)
+    const bool hinted = ctx->res_hint_serial == pk->serial && ctx->res_hint > 0 && ctx->res_hint <= ctx->res_cap;
+    if (world > 1) hip_check(hipMemsetAsync(ctx->d_res, 0, (hinted ? ctx->res_hint : ctx->res_cap) * sizeof(E2), ctx->stream), "clear result buffer");
     // "eval output" (sk_encryption_circuit.rs:444-448): point, ct0is MLE value
     const int ov = p.ct0is_log2();
     size_t point_off = P->epos();
@@ -1691,6 +1694,10 @@ static void enqueue_prove(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, Prov
     Cell out_value = cell();
     P->ops.push_back([P, out_value, vslot] { *out_value = P->h_res()[vslot]; });
     P->gkr(ClaimRef{point_off, ov, out_value});
+    if (world > 1) {
+        if (hinted && P->res_used > ctx->res_hint) throw Error("sharded prove: the result buffer grew between two proves of one key");
+        ctx->res_hint = P->res_used; ctx->res_hint_serial = pk->serial;
+    }
     if (exchange) comm_allreduce_results(ctx, P->res_used);  // the one collective of a sharded proof, on the stream
 }
 

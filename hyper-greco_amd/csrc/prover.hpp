@@ -67,6 +67,8 @@ struct hg_ctx {
     hg::E2* d_res = nullptr;
     hg::E2* h_res = nullptr;  // pinned
     size_t res_cap = 0;
+    size_t res_hint = 0;            // result slots a sharded prove of key `res_hint_serial` uses (enqueue_prove)
+    uint64_t res_hint_serial = 0;
     size_t bn_res_used = 0;  // bytes of the result buffer handed out to the BN254 path since the last arena_reset
     hg::E2* d_partials = nullptr;
     hg::E2* d_partials2 = nullptr;  // scratch of stream2
