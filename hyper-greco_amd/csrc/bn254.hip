@@ -301,7 +301,7 @@ __global__ void k_bn_gamma_powers(Fr* __restrict__ pw, GammaSet gs, int nb) {
 __global__ void k_bn_weight_rows(const Fr* __restrict__ rows, size_t row_len, const Fr* __restrict__ pw, Fr* __restrict__ out, size_t h, int nb) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= h * (size_t)nb) return;
-    const size_t b = idx / h, i = idx % h;
+    const size_t b = idx >> (__ffsll((long long)h) - 1), i = idx & (h - 1);   // (h is a power of two)
     const Fr x = rows[b * row_len + i];
     out[idx] = b == 0 ? x : fr_mul_wide(pw[b], x);
 }
@@ -611,10 +611,10 @@ void field_op_bn254(hg_ctx* ctx, int op, size_t n, const u64* a, const u64* b, u
 
 // ---- prove_grand_product over Fr [REF lasso/src/memory_checking/prover.rs:183-266, 268-294, 297-355] ----------------------
 __global__ void k_bn_prod_level(const Fr* __restrict__ in, size_t in_len, Fr* __restrict__ out, int nb) {
-    const size_t h = in_len >> 1, total = h * nb;
+    const size_t h = in_len >> 1, total = h * nb;   // (h is a power of two: shift and mask, not a 64-bit division per thread)
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    const size_t b = i / h, j = i % h;
+    const size_t b = i >> (__ffsll((long long)h) - 1), j = i & (h - 1);
     out[b * h + j] = fr_mul_wide(in[b * in_len + j], in[b * in_len + j + h]);  // Layer::bottom / Layer::up: v_l * v_r on the MSB split
 }
 // level 1 of a mirrored product: `in` holds the nb/2 READ rows only; row b >= nb/2 of the output is the product of the read row
@@ -623,7 +623,7 @@ __global__ void k_bn_prod_level_mirror(const Fr* __restrict__ in, size_t in_len,
     const size_t h = in_len >> 1, total = h * nb;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    const size_t b = i / h, j = i % h, half = (size_t)nb / 2;
+    const size_t b = i >> (__ffsll((long long)h) - 1), j = i & (h - 1), half = (size_t)nb / 2;
     const size_t src = b < half ? b : b - half;
     Fr x = in[src * in_len + j], y = in[src * in_len + j + h];
     if (b >= half) { x = fr_add(x, c); y = fr_add(y, c); }
