@@ -610,16 +610,22 @@ void field_op_bn254(hg_ctx* ctx, int op, size_t n, const u64* a, const u64* b, u
 }
 
 // ---- prove_grand_product over Fr [REF lasso/src/memory_checking/prover.rs:183-266, 268-294, 297-355] ----------------------
-__global__ void k_bn_prod_level(const Fr* __restrict__ in, size_t in_len, Fr* __restrict__ out, int nb) {
+// lw (optional, with pw): the left half of every output row times the row's weight pw[b] - what the sum-check layer that reads this
+// level wants as its left tables (k_bn_gp_round_jobs), written here instead of by a second pass over the level (k_bn_weight_rows)
+__global__ void k_bn_prod_level(const Fr* __restrict__ in, size_t in_len, Fr* __restrict__ out, int nb, const Fr* __restrict__ pw = nullptr,
+                                Fr* __restrict__ lw = nullptr) {
     const size_t h = in_len >> 1, total = h * nb;   // (h is a power of two: shift and mask, not a 64-bit division per thread)
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const size_t b = i >> (__ffsll((long long)h) - 1), j = i & (h - 1);
-    out[b * h + j] = fr_mul_wide(in[b * in_len + j], in[b * in_len + j + h]);  // Layer::bottom / Layer::up: v_l * v_r on the MSB split
+    const Fr v = fr_mul_wide(in[b * in_len + j], in[b * in_len + j + h]);  // Layer::bottom / Layer::up: v_l * v_r on the MSB split
+    out[b * h + j] = v;
+    if (lw && j < (h >> 1)) lw[b * (h >> 1) + j] = b == 0 ? v : fr_mul_wide(pw[b], v);
 }
 // level 1 of a mirrored product: `in` holds the nb/2 READ rows only; row b >= nb/2 of the output is the product of the read row
 // b - nb/2 shifted by c (the write rows are never materialised)
-__global__ void k_bn_prod_level_mirror(const Fr* __restrict__ in, size_t in_len, Fr* __restrict__ out, int nb, Fr c) {
+__global__ void k_bn_prod_level_mirror(const Fr* __restrict__ in, size_t in_len, Fr* __restrict__ out, int nb, Fr c, const Fr* __restrict__ pw = nullptr,
+                                       Fr* __restrict__ lw = nullptr) {
     const size_t h = in_len >> 1, total = h * nb;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
@@ -627,7 +633,9 @@ __global__ void k_bn_prod_level_mirror(const Fr* __restrict__ in, size_t in_len,
     const size_t src = b < half ? b : b - half;
     Fr x = in[src * in_len + j], y = in[src * in_len + j + h];
     if (b >= half) { x = fr_add(x, c); y = fr_add(y, c); }
-    out[b * h + j] = fr_mul_wide(x, y);
+    const Fr v = fr_mul_wide(x, y);
+    out[b * h + j] = v;
+    if (lw && j < (h >> 1)) lw[b * (h >> 1) + j] = b == 0 ? v : fr_mul_wide(pw[b], v);
 }
 static void write_be32(std::vector<uint8_t>& out, const Fr& canonical) {  // transcript.rs:183-189: repr, byte-reversed
     const size_t at = out.size();
@@ -740,20 +748,6 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
             k_bn_to_mont<<<(unsigned)((nb * len + 255) / 256), 256, 0, st>>>(l0, nb * len);
             lev[0] = l0;
         }
-        for (int k = 1; k < nv; k++) {
-            Fr* lk = dalloc(nb * (len >> k));
-            const size_t total = nb * (len >> k);
-            if (k == 1 && mirror_c) k_bn_prod_level_mirror<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(lev[0], len, lk, (int)nb, *mirror_c);   // level 0: read rows only
-            else k_bn_prod_level<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(lev[k - 1], len >> (k - 1), lk, (int)nb);
-            lev[k] = lk;
-        }
-        // roots and top evaluations: level nv-1 has rows of length 2
-        Fr* d_roots = dalloc(nb);
-        k_bn_prod_level<<<(unsigned)((nb + 255) / 256), 256, 0, st>>>(lev[nv - 1], 2, d_roots, (int)nb);
-        const ResRef top = res_slots(ctx, 2 * nb), roots = res_slots(ctx, nb);
-        k_bn_copy_from_mont<<<(unsigned)((2 * nb + 255) / 256), 256, 0, st>>>(lev[nv - 1], top.dev, 2 * nb);
-        k_bn_copy_from_mont<<<(unsigned)((nb + 255) / 256), 256, 0, st>>>(d_roots, roots.dev, nb);
-        h_top = top.host; h_roots = roots.host;
         size_t pos = chain_skip;
         layers[0].mu_at = pos++;
         // plan every layer (buffers, result slots, launch shapes), then run the rounds of all layers round-synchronised
@@ -790,13 +784,31 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
                 if ((h >> (rd + 1)) <= (size_t)BN_TAIL_HALF && n - rd <= BN_TAIL_ROUNDS) { P.nmain = rd; break; }
             max_main = std::max(max_main, P.nmain);
         }
-        if (nv > 1) {
-            k_bn_gamma_powers<<<dim3((unsigned)((nb + 255) / 256), nv), 256, 0, st>>>(pw_all, gammas, (int)nb);
-            for (int n = 1; n < nv; n++) {
-                const size_t h = (size_t)1 << n;
-                if (plan[n].mirror) k_bn_weight_rows_sum<<<(unsigned)((h + 255) / 256), 256, 0, st>>>(lev[nv - 1 - n], 2 * h, plan[n].d_pw, plan[n].lw, plan[n].S, h, (int)G2);
-                else k_bn_weight_rows<<<(unsigned)((nb * h + 255) / 256), 256, 0, st>>>(lev[nv - 1 - n], 2 * h, plan[n].d_pw, plan[n].lw, h, (int)nb);
-            }
+        if (nv > 1) k_bn_gamma_powers<<<dim3((unsigned)((nb + 255) / 256), nv), 256, 0, st>>>(pw_all, gammas, (int)nb);
+        // the product tree; level k (rows of length len >> k) is read by layer n = nv - 1 - k, whose weighted left halves are written
+        // in the same pass (level 0, the input, gets its own pass below)
+        for (int k = 1; k < nv; k++) {
+            Fr* lk = dalloc(nb * (len >> k));
+            const size_t total = nb * (len >> k);
+            const int n = nv - 1 - k;
+            const Fr* pw_n = n >= 1 ? plan[n].d_pw : nullptr;
+            Fr* lw_n = n >= 1 ? plan[n].lw : nullptr;
+            if (k == 1 && mirror_c) k_bn_prod_level_mirror<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(lev[0], len, lk, (int)nb, *mirror_c, pw_n, lw_n);   // level 0: read rows only
+            else k_bn_prod_level<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(lev[k - 1], len >> (k - 1), lk, (int)nb, pw_n, lw_n);
+            lev[k] = lk;
+        }
+        // roots and top evaluations: level nv-1 has rows of length 2
+        Fr* d_roots = dalloc(nb);
+        k_bn_prod_level<<<(unsigned)((nb + 255) / 256), 256, 0, st>>>(lev[nv - 1], 2, d_roots, (int)nb);
+        const ResRef top = res_slots(ctx, 2 * nb), roots = res_slots(ctx, nb);
+        k_bn_copy_from_mont<<<(unsigned)((2 * nb + 255) / 256), 256, 0, st>>>(lev[nv - 1], top.dev, 2 * nb);
+        k_bn_copy_from_mont<<<(unsigned)((nb + 255) / 256), 256, 0, st>>>(d_roots, roots.dev, nb);
+        h_top = top.host; h_roots = roots.host;
+        if (nv > 1) {   // the top layer reads level 0
+            const int n = nv - 1;
+            const size_t h = (size_t)1 << n;
+            if (plan[n].mirror) k_bn_weight_rows_sum<<<(unsigned)((h + 255) / 256), 256, 0, st>>>(lev[0], 2 * h, plan[n].d_pw, plan[n].lw, plan[n].S, h, (int)G2);
+            else k_bn_weight_rows<<<(unsigned)((nb * h + 255) / 256), 256, 0, st>>>(lev[0], 2 * h, plan[n].d_pw, plan[n].lw, h, (int)nb);
         }
         GpLaunchSet own;
         own.by_rd.resize(max_main);
