@@ -58,7 +58,7 @@ static size_t env_size(const char* name, size_t dflt) {
     return v && *v ? (size_t)strtoull(v, nullptr, 0) : dflt;
 }
 static size_t st_min_threads() { static size_t v = env_size("HG_ST_MIN_THREADS", 65536); return v; }
-static int st_max_blocks() { static int v = (int)std::min<size_t>(env_size("HG_ST_MAX_BLOCKS", SC_MAX_BLOCKS), SC_MAX_BLOCKS); return v; }
+static int st_max_blocks() { static int v = (int)std::min<size_t>(env_size("HG_ST_MAX_BLOCKS", 512), SC_MAX_BLOCKS); return v; }
 
 static inline int grid_for(size_t work_items) {
     size_t b = (work_items + TPB - 1) / TPB;
