@@ -486,6 +486,7 @@ struct Prover {
             if (L.after_seq) {
                 for (auto& f : st_after_seq) f();
                 st_after_seq.clear();
+                if (st_before_gp2) { st_before_gp2(); st_before_gp2 = nullptr; }   // the launches from here on contain grand product #2's jobs
                 continue;
             }
             for (size_t o = 0; o < L.items.size(); o += MAX_BATCH) {
@@ -532,6 +533,7 @@ struct Prover {
             }
         }
         if (st_before_gp) { st_before_gp(); st_before_gp = nullptr; }
+        if (st_before_gp2) { st_before_gp2(); st_before_gp2 = nullptr; }
         st_jobs.clear();
         st_seq.clear();
         st_credit_ntab.clear();
@@ -1110,6 +1112,7 @@ struct Prover {
         const bool counters_aux = counters_aux_env && !col_aux;   // schedule 1: the counters lead the main stream
         if (use_aux && counters_aux) flush_stride();  // collation rounds first: see below
         auto cnt_where = [&](const std::function<void()>& fn) { if (use_aux && counters_aux) on_aux(fn); else fn(); };
+        bool counters_event_recorded = false;
         if (need_counters) cnt_where([&] {
             if (use_aux && counters_aux) hip_check(hipStreamWaitEvent(st, ctx->ev_aux[0], 0), "lasso: wait for the limb split");
             // all requested chunks in ONE stable sort of (chunk, address) keys (HG_COUNTERS_PER_CHUNK=1: one sort per chunk)
@@ -1138,6 +1141,7 @@ struct Prover {
                 dev::lasso_counters_all(st, L, mask, dims, co, temp, tb, keys, keys2, rows, rows2, starts);
             }
             ctx->prof_end();
+            if (use_aux && counters_aux) { hip_check(hipEventRecord(ctx->ev_aux[3], st), "lasso: counters event"); counters_event_recorded = true; }
         });
         if (use_aux && !counters_aux && need_counters) {
             // grand product #2's hashes and the openings (second stream) read the counters (main stream)
@@ -1257,7 +1261,11 @@ struct Prover {
             on_aux([&] { hip_check(hipStreamWaitEvent(st, ctx->ev_aux[2], 0), "lasso: wait for the E tables"); });   // claimed sum, openings
             if (do_col && claim_late) on_aux(do_claim);
             hg_ctx* c = ctx;
-            st_before_gp = [c] { hip_check(hipStreamWaitEvent(c->stream, c->ev_aux[1], 0), "lasso: wait for counters / grand product #2 tree"); };
+            // the first launches (the hash-free first round of the top layer, the next layers' level-emitting first rounds) only
+            // need the counters; grand product #2's jobs join from the mixed first-round launch on and need its tree
+            const bool two_waits = counters_event_recorded;
+            st_before_gp = [c, two_waits] { hip_check(hipStreamWaitEvent(c->stream, c->ev_aux[two_waits ? 3 : 1], 0), "lasso: wait for the counters"); };
+            if (two_waits) st_before_gp2 = [c] { hip_check(hipStreamWaitEvent(c->stream, c->ev_aux[1], 0), "lasso: wait for grand product #2's tree"); };
         }
         // openings (prover.rs:173-178, mod.rs:80-93). With two streams eq(r, .) may still be in use by the claimed-sum kernel on
         // the main stream, so the openings get their own table.
@@ -1497,6 +1505,7 @@ struct Prover {
         st = s0; partials = p0; ctx->prof_stream = s0;
     }
     std::function<void()> st_before_gp;  // flush_stride runs it once before the first grand-product launch (cross-stream wait)
+    std::function<void()> st_before_gp2; // ... and this one once the sequenced first rounds of grand product #1's top layers are out
     void fork_nodes_stream() {
         if (!fork_recorded) return;
         hip_check(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0), "fork wait");

@@ -23,7 +23,7 @@ struct hg_ctx {
     hipStream_t bn_stream_hi = nullptr, bn_stream_lo = nullptr;   // BN254 prove only (bn254_gkr.inc: BnStreams), created on first use
     hipStream_t stream2 = nullptr;  // Vanilla / FFT node reductions (independent of the Lasso node on the device)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    hipEvent_t ev_aux[3] = {nullptr, nullptr, nullptr};  // Lasso node: limbs done (stream -> stream2), counters + grand product #2 levels done (stream2 -> stream), E tables done (stream -> stream2)
+    hipEvent_t ev_aux[4] = {nullptr, nullptr, nullptr, nullptr};  // Lasso node: limbs done (stream -> stream2), grand product #2 levels done (stream2 -> stream), E tables done (stream -> stream2), counters done (stream2 -> stream)
     hipStream_t prof_stream = nullptr;  // stream the profiling events are recorded on (the one being enqueued to)
     // multi-GPU (comm.hip): RCCL communicator of this rank (ncclComm_t, type-erased: RCCL is loaded at run time), exchange buffer
     void* comm = nullptr;
