@@ -809,156 +809,73 @@ __global__ __launch_bounds__(256) void k_col_step2(const StJob* __restrict__ job
     if (nblocks > 1) finish_partials(part, 4, tickets_of(partials) + y * 32, res + J.sums_slot + (size_t)rd * 2, sm, nblocks);
 }
 
-// ---- small rounds: one wave per pair index j, lanes along the tables ---------------------------------------------
-// For the rounds where the table index is the long axis (a few j, 25..50 table pairs) the per-j sums over the
-// tables are wave reductions (__shfl, no LDS, no barrier). `in` / `out` may be global or LDS (generic pointers).
-// Pair index jl of this call reads entry (in_j0 + jl) of a table laid out for in_half pairs and writes entry
-// (out_j0 + jl) of a table laid out for out_half = (number of pairs of this round) entries.
-template <int KIND, typename T, bool FIRST>
-__device__ __forceinline__ void sc_round_small(const T* in, size_t in_stride, size_t in_j0, size_t in_half, E2* out, size_t out_stride,
-                                               size_t out_j0, size_t out_half, size_t j_count, int ntab, E2 r,
-                                               const E2* __restrict__ pw, const E2* __restrict__ pwr, E2* acc, bool p0_only,
-                                               const StJob* __restrict__ mirror = nullptr) {
-    using V = Val<T>;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, W = blockDim.x >> 6;
-    for (size_t jl = wave; jl < j_count; jl += W) {
-        const size_t j = in_j0 + jl;
-        const size_t jo = dpos(out_j0 + jl, out_half);
-        if constexpr (KIND == SC_GRANDPROD) {
-            E2 s0 = e2_zero(), s2 = e2_zero(), s3 = e2_zero();
-            T p0 = V::zero(), p2 = V::zero(), p3 = V::zero();
-            const int nb = ntab >> 1;
-            for (int i = lane; i < nb; i += 64) {
-                T xl, yl, xr, yr;
-                load_xy<T, FIRST>(in + (size_t)(2 * i) * in_stride, j, in_half, xl, yl);
-                load_xy<T, FIRST>(in + (size_t)(2 * i + 1) * in_stride, j, in_half, xr, yr);
-                T dl = V::sub(yl, xl), dr = V::sub(yr, xr);
-                if (i == 0) { p0 = xl; p2 = V::add(yl, dl); p3 = V::add(p2, dl); }
-                const bool summed = !(p0_only && i == 0);
-                if constexpr (FIRST) {
-                    E2 gm = pw[i];
-                    if (summed) {
-                        s0 = e2_add(s0, V::scale(gm, V::mul(xl, xr)));
-                        s2 = e2_add(s2, V::scale(gm, V::mul(yl, yr)));
-                        s3 = e2_add(s3, V::scale(gm, V::mul(dl, dr)));
-                    }
-                    store_e2(out + (size_t)(2 * i) * out_stride + jo, e2_add(V::scale(gm, xl), V::scale(pwr[i], dl)));
-                } else {
-                    if (summed) {
-                        s0 = e2_add(s0, V::lift(V::mul(xl, xr)));
-                        s2 = e2_add(s2, V::lift(V::mul(yl, yr)));
-                        s3 = e2_add(s3, V::lift(V::mul(dl, dr)));
-                    }
-                    store_e2(out + (size_t)(2 * i) * out_stride + jo, V::fold(xl, dl, r));
-                }
-                store_e2(out + (size_t)(2 * i + 1) * out_stride + jo, V::fold(xr, dr, r));
-            }
-            if constexpr (!FIRST && std::is_same<T, E2>::value) {
-                if (mirror && lane == 63) {  // the linear table S of a mirrored job (StJob::mirror; nb <= 63): K1 S(t) + K2 joins P0 and P1
-                    E2 x, y;
-                    load_xy<E2, false>(in + (size_t)(2 * nb) * in_stride, j, in_half, x, y);
-                    s0 = e2_add(s0, e2_add(e2_mul(mirror->mk1, x), mirror->mk2));
-                    s2 = e2_add(s2, e2_add(e2_mul(mirror->mk1, y), mirror->mk2));
-                    store_e2(out + (size_t)(2 * nb) * out_stride + jo, V::fold(x, e2_sub(y, x), r));
-                }
-            }
-            s0 = wave_sum(s0); s2 = wave_sum(s2); s3 = wave_sum(s3);
-            if (lane == 0) gp_combine(s0, s2, s3, V::lift(p0), V::lift(p2), V::lift(p3), acc[0], acc[1], acc[2]);
-        } else {
-            T s0 = V::zero(), s2 = V::zero(), p0 = V::zero(), p2 = V::zero();
-            for (int i = lane; i < ntab; i += 64) {
-                T x, y;
-                load_xy<T, FIRST>(in + (size_t)i * in_stride, j, in_half, x, y);
-                T d = V::sub(y, x);
-                T v2 = V::add(y, d);
-                if (i == 0) { p0 = x; p2 = v2; }
-                const bool summed = !(p0_only && i == 0);
-                if constexpr (FIRST) {
-                    u64 m = pw[i].c0;
-                    if constexpr (std::is_same<T, u64>::value) {
-                        if (summed) { s0 = gl_add(s0, gl_mul(m, x)); s2 = gl_add(s2, gl_mul(m, v2)); }
-                        store_e2(out + (size_t)i * out_stride + jo, e2_add_f(e2_mul_f(pwr[i], d), gl_mul(m, x)));
-                    } else {
-                        if (summed) { s0 = e2_add(s0, e2_mul_f(x, m)); s2 = e2_add(s2, e2_mul_f(v2, m)); }
-                        store_e2(out + (size_t)i * out_stride + jo, e2_mul_f(V::fold(x, d, r), m));
-                    }
-                } else {
-                    if (summed) { s0 = V::add(s0, x); s2 = V::add(s2, v2); }
-                    store_e2(out + (size_t)i * out_stride + jo, V::fold(x, d, r));
-                }
-            }
-            E2 t0 = wave_sum(V::lift(s0)), t2 = wave_sum(V::lift(s2));
-            if (lane == 0) {
-                acc[0] = e2_add(acc[0], e2_mul(V::lift(p0), t0));
-                acc[1] = e2_add(acc[1], e2_mul(V::lift(p2), t2));
-            }
-        }
-    }
-}
+static inline size_t sc_lds_bytes(int nv, int bd) { return (SM_SLOTS + (size_t)nv * bd) * sizeof(E2); }
 
-// `nrounds` consecutive rounds of every item; workgroup (chunk k, item): see StItem / st_chunk in kernels.hpp.
-// Dynamic LDS: [16 block-sum slots][ntab * 2^c E2][ntab * 2^(c-1) E2] (intermediate folded tables, ping-pong).
+// ---- LDS-resident tail: ALL remaining rounds of a job in one workgroup ------------------------------------------------------
+// The item's first round (half = 2^h0 pair indices) reads the job's tables from HBM and folds them into LDS; every later round
+// runs LDS -> LDS with the thread mapping of the big rounds (sc_round_body: 2^jb threads along j, the rest along the tables), the
+// last one writes the ntab scalars. How many rounds fit depends on the job's table count (st_tail_h: 12 for the two collation
+// tables, 7 for the mirrored top layer, 6 for a full grand-product layer, 9-10 for the few tables of a sharded rank), so a small
+// job spends its whole launch-bound second half in ONE launch. Dynamic LDS: [SM_SLOTS][NV * 256 reduction slots][ntab 2^h0][ntab 2^(h0-1)].
+constexpr size_t ST_TAIL_LDS_BYTES = 120 * 1024;   // for the two table regions
+int st_tail_h(int ntab, int nvars) {
+    int h = 0;
+    while (h + 1 <= nvars - 1 && (size_t)ntab * (((size_t)1 << (h + 1)) + ((size_t)1 << h)) * sizeof(E2) <= ST_TAIL_LDS_BYTES) h++;
+    return h;
+}
 template <int KIND>
-__global__ __launch_bounds__(512) void k_st_chunk(const StJob* __restrict__ jobs, const StItem* __restrict__ items, int lds_ntab,
-                                                   const E2* __restrict__ chal, E2* __restrict__ partials, E2* __restrict__ res) {
+__global__ __launch_bounds__(256) void k_st_tail(const StJob* __restrict__ jobs, const StItem* __restrict__ items, const E2* __restrict__ chal,
+                                                 E2* __restrict__ res) {
     constexpr int NV = KIND == SC_GRANDPROD ? 3 : 2;
-    const StItem& I = items[blockIdx.y];
-    if ((int)blockIdx.x >= I.nchunks) return;
+    const StItem& I = items[blockIdx.x];
     const StJob& J = jobs[I.job];
     E2* sm = dyn_lds;
-    E2* scratch[2];
-    scratch[0] = dyn_lds + SM_SLOTS;
-    scratch[1] = scratch[0] + ((size_t)lds_ntab << ST_CHUNK_ROUNDS >> 1);
-    const int R = I.nrounds, c = I.c_log2;
+    E2* red = dyn_lds + SM_SLOTS;
+    E2* tab[2];
+    const int h0 = J.nvars - 1 - I.rd;
+    tab[0] = red + NV * 256;
+    tab[1] = tab[0] + ((size_t)J.ntab << h0);
     const bool p0_only = J.p0_only != 0;
-    const int per = R * NV;
-    E2* part = partials + (size_t)blockIdx.y * ((size_t)(1 << ST_CHUNK_ROUNDS) * ST_CHUNK_ROUNDS * NV);  // nchunks <= 2^ST_CHUNK_ROUNDS
+    const StJob* mirror = (KIND == SC_GRANDPROD && J.mirror) ? &J : nullptr;
     const void* in = I.in;
     size_t in_stride = I.in_stride;
-    size_t in_j0 = (size_t)blockIdx.x << c, in_half = (size_t)1 << (J.nvars - 1 - I.rd);
+    // The round sums go to the result buffer - host memory across PCIe - ONCE, at the end: a store per round followed by the
+    // round's barrier made every round wait for its PCIe write acknowledgement. The challenges are fetched once as well.
+    __shared__ E2 keep[3 * 32], rch[32];
+    if ((int)threadIdx.x < J.nvars - I.rd) rch[threadIdx.x] = chal[J.r_off + I.rd + threadIdx.x];
+    __syncthreads();
 #pragma unroll 1
-    for (int u = 0; u < R; u++) {
-        const int rd = I.rd + u;
-        const size_t jc = (size_t)1 << (c - u);          // pairs of this chunk in this round
-        const bool last = u == R - 1;
-        E2* out; size_t out_stride, out_j0, out_half;
-        if (last) { out = I.out; out_half = (size_t)1 << (J.nvars - 1 - rd); out_stride = out_half; out_j0 = (size_t)blockIdx.x << (c - u); }
-        else { out = scratch[u & 1]; out_half = jc; out_stride = jc; out_j0 = 0; }
-        const E2 r = chal[J.r_off + rd];
-        E2 a[NV];
+    for (int rd = I.rd; rd < J.nvars; rd++) {
+        const int h_log2 = J.nvars - 1 - rd;
+        const size_t half = (size_t)1 << h_log2;
+        const int jb_log2 = h_log2 < 8 ? h_log2 : 8;
+        const bool last = rd == J.nvars - 1;
+        E2* out = last ? J.final_out : tab[(rd - I.rd) & 1];
+        E2 acc[NV];
 #pragma unroll
-        for (int t = 0; t < NV; t++) a[t] = e2_zero();
-        if (rd == 0 && J.base) sc_round_small<KIND, u64, true>(reinterpret_cast<const u64*>(in), in_stride, in_j0, in_half, out, out_stride, out_j0, out_half, jc, J.ntab, r, J.pw, J.pwr, a, p0_only);
-        else if (rd == 0) sc_round_small<KIND, E2, true>(reinterpret_cast<const E2*>(in), in_stride, in_j0, in_half, out, out_stride, out_j0, out_half, jc, J.ntab, r, J.pw, J.pwr, a, p0_only);
-        else sc_round_small<KIND, E2, false>(reinterpret_cast<const E2*>(in), in_stride, in_j0, in_half, out, out_stride, out_j0, out_half, jc, J.ntab, r, J.pw, J.pwr, a, p0_only,
-                                             (KIND == SC_GRANDPROD && J.mirror) ? &J : nullptr);
-#pragma unroll
-        for (int t = 0; t < NV; t++) if ((threadIdx.x & 63) != 0) a[t] = e2_zero();
-        block_sum_multi<NV>(a, sm);   // also the barrier that completes the folded chunk in LDS
+        for (int t = 0; t < NV; t++) acc[t] = e2_zero();
+        const E2 r = rch[rd - I.rd];
+        if (rd == 0 && J.base) sc_round_body<KIND, u64, true>(reinterpret_cast<const u64*>(in), in_stride, out, half, J.ntab, half, r, J.pw, J.pwr, jb_log2, red, acc, 0, 1, p0_only);
+        else if (rd == 0) sc_round_body<KIND, E2, true>(reinterpret_cast<const E2*>(in), in_stride, out, half, J.ntab, half, r, J.pw, J.pwr, jb_log2, red, acc, 0, 1, p0_only);
+        else sc_round_body<KIND, E2, false>(reinterpret_cast<const E2*>(in), in_stride, out, half, J.ntab, half, r, J.pw, J.pwr, jb_log2, red, acc, 0, 1, p0_only, nullptr, mirror);
+        block_sum_multi<NV>(acc, sm);
         if (threadIdx.x == 0) {
 #pragma unroll
-            for (int t = 0; t < NV; t++) {
-                if (I.nchunks == 1) res[J.sums_slot + (size_t)rd * NV + t] = a[t];
-                else part_store(part + (size_t)blockIdx.x * per + u * NV + t, a[t]);
-            }
+            for (int t = 0; t < NV; t++) keep[(rd - I.rd) * NV + t] = acc[t];
         }
-        __syncthreads();
-        in = out; in_stride = out_stride; in_j0 = 0; in_half = jc >> 1;
+        __syncthreads();   // the folded tables of this round are complete in LDS
+        in = out; in_stride = half;
     }
-    if (I.nchunks > 1) finish_partials(part, per, tickets_of(partials) + blockIdx.y * 32, res + J.sums_slot + (size_t)I.rd * NV, sm, I.nchunks);
+    if ((int)threadIdx.x < (J.nvars - I.rd) * NV) res[J.sums_slot + (size_t)I.rd * NV + threadIdx.x] = keep[threadIdx.x];
 }
-void st_chunk(hipStream_t st, int kind, const StJob* jobs, const StItem* items, int nitems, int max_chunks, int max_ntab,
-              const E2* chal, E2* partials, E2* res) {
-    const size_t lds = (SM_SLOTS + ((size_t)max_ntab << ST_CHUNK_ROUNDS >> 1) + ((size_t)max_ntab << ST_CHUNK_ROUNDS >> 2)) * sizeof(E2);
-    dim3 grid(max_chunks, nitems);
-    if (kind == SC_GRANDPROD) {
-        k_st_chunk<SC_GRANDPROD><<<grid, 512, lds, st>>>(jobs, items, max_ntab, chal, partials, res);
-    } else {
-        k_st_chunk<SC_COLLATION><<<grid, 512, lds, st>>>(jobs, items, max_ntab, chal, partials, res);
-    }
+void st_tail(hipStream_t st, int kind, const StJob* jobs, const StItem* items, int nitems, size_t table_bytes, const E2* chal, E2* res) {
+    const size_t lds = (SM_SLOTS + 3 * 256) * sizeof(E2) + table_bytes;
+    static const hipError_t a1 = hipFuncSetAttribute((const void*)k_st_tail<SC_GRANDPROD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((SM_SLOTS + 3 * 256) * sizeof(E2) + ST_TAIL_LDS_BYTES));
+    static const hipError_t a2 = hipFuncSetAttribute((const void*)k_st_tail<SC_COLLATION>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((SM_SLOTS + 3 * 256) * sizeof(E2) + ST_TAIL_LDS_BYTES));
+    (void)a1; (void)a2;
+    if (kind == SC_GRANDPROD) k_st_tail<SC_GRANDPROD><<<nitems, 256, lds, st>>>(jobs, items, chal, res);
+    else k_st_tail<SC_COLLATION><<<nitems, 256, lds, st>>>(jobs, items, chal, res);
 }
-
-static inline size_t sc_lds_bytes(int nv, int bd) { return (SM_SLOTS + (size_t)nv * bd) * sizeof(E2); }
 
 int st_plan_blocks(StItem* items, int nitems, bool rounds2) {
     // total work of the launch decides how finely the small items are split along the tables (jb < 8)
@@ -1194,6 +1111,10 @@ __global__ __launch_bounds__(1024) void k_ps_tail(const PsJob* __restrict__ jobs
     int bd_log2 = 31 - __clz((int)blockDim.x);
     int in_buf = J.tail_buf;
     const E2* lin_a = nullptr; const E2* lin_b = nullptr;
+    // round sums to the (host-memory) result buffer once, at the end; challenges fetched once (as in k_st_tail)
+    __shared__ E2 keep[2 * 32], rch[32];
+    if ((int)threadIdx.x < J.nvars - J.tail_rd) rch[threadIdx.x] = chal[J.r_off + J.tail_rd + threadIdx.x];
+    __syncthreads();
     for (int rd = J.tail_rd; rd < J.nvars; rd++) {
         const int hl = J.nvars - 1 - rd;
         const size_t half = (size_t)1 << hl;
@@ -1204,17 +1125,18 @@ __global__ __launch_bounds__(1024) void k_ps_tail(const PsJob* __restrict__ jobs
         const bool fits = !last && 2 * (size_t)J.npairs * half <= ((rd - J.tail_rd) & 1 ? (size_t)2048 : (size_t)4096);
         E2* reg = dyn_lds + SM_SLOTS + (((rd - J.tail_rd) & 1) ? 4096 : 0);
         PsLds lds{lin_a, lin_b, fits ? reg : nullptr, fits ? reg + (size_t)J.npairs * half : nullptr};
-        E2 r = chal[J.r_off + rd];
+        E2 r = rch[rd - J.tail_rd];
         E2 a0 = e2_zero(), a2 = e2_zero();
         if (in_buf < 0 && !lin_a) ps_round_body<u64>(J, rd, in_buf, out_buf, half, r, jb_log2, a0, a2, 0, 1, lds);
         else ps_round_body<E2>(J, rd, lin_a ? 0 : in_buf, out_buf, half, r, jb_log2, a0, a2, 0, 1, lds);
         E2 sv[2] = {a0, a2};
         block_sum_multi<2>(sv, sm);
-        if (threadIdx.x == 0) { res[J.sums_slot + 2 * rd] = sv[0]; res[J.sums_slot + 2 * rd + 1] = sv[1]; }
+        if (threadIdx.x == 0) { keep[2 * (rd - J.tail_rd)] = sv[0]; keep[2 * (rd - J.tail_rd) + 1] = sv[1]; }
         __syncthreads();
         if (fits) { lin_a = lds.oa; lin_b = lds.ob; }
         else { lin_a = lin_b = nullptr; in_buf = out_buf; }
     }
+    if ((int)threadIdx.x < 2 * (J.nvars - J.tail_rd)) res[J.sums_slot + 2 * (size_t)J.tail_rd + threadIdx.x] = keep[threadIdx.x];
 }
 
 int ps_plan_blocks(PsItem* items, int nitems, const PsJob* host_jobs, bool rounds2) {
@@ -1252,6 +1174,21 @@ void ps_tail(hipStream_t st, const PsJob* jobs, int njobs, const E2* chal, E2* r
     static const hipError_t attr = hipFuncSetAttribute((const void*)k_ps_tail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)attr;
     k_ps_tail<<<njobs, 1024, lds, st>>>(jobs, chal, res);
+}
+
+// debugging aid (HG_STAMP=1): device wall clock (100 MHz) at a point of a stream, also inside a replayed launch graph
+__global__ void k_stamp(unsigned long long* t) { *t = wall_clock64(); }
+void stamp(hipStream_t st, unsigned long long* slot) { k_stamp<<<1, 1, 0, st>>>(slot); }
+
+// one launch instead of up to three memset nodes at the head of a prove (reduction tickets of both streams, the result-buffer prefix)
+__global__ void k_clear_words(ClearSet c) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, step = (size_t)gridDim.x * blockDim.x;
+    for (int r = 0; r < 3; r++)
+        for (size_t k = i; k < c.n[r]; k += step) c.p[r][k] = 0;
+}
+void clear_words(hipStream_t st, const ClearSet& c) {
+    size_t most = std::max(c.n[0], std::max(c.n[1], c.n[2]));
+    if (most) k_clear_words<<<(unsigned)std::min<size_t>((most + 255) / 256, 256), 256, 0, st>>>(c);
 }
 
 __global__ void k_scatter_e2(const ScatterEnt* __restrict__ ents, size_t n, E2* __restrict__ dst_base) {

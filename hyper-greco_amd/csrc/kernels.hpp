@@ -85,8 +85,8 @@ struct StItem {
     const void* in;
     size_t in_stride;
     E2* out;           // folded tables of the (last) round, stride = its half length
-    // chunk launches only (st_chunk): rounds [rd, rd + nrounds) run inside one workgroup per chunk of 2^c_log2 pair indices
-    int rd, nrounds, c_log2, nchunks;
+    // tail launches only (st_tail): rounds [rd, rd + nrounds) = all that remain run inside one workgroup
+    int rd, nrounds;
 };
 // Fills jb_log2 / blk0 / nblk of the items of one launch (host side, before upload); returns the grid size.
 // `rounds2`: fused two-round launch (one pair index per thread).
@@ -99,12 +99,11 @@ void st_step(hipStream_t st, int kind, bool base, const StJob* jobs, const StIte
 void st_first_hash(hipStream_t st, const StJob* job, const StItem* item, int grid, bool mirror, const E2* chal, E2* partials, E2* res);
 // fused step (folded Ext2 inputs; grand-product or collation shape): every item runs its job's rounds with half = 2^h_log2 and 2^(h_log2-1)
 void st_step2(hipStream_t st, int kind, const StJob* jobs, const StItem* items, int nitems, int grid, const E2* chal, E2* partials, E2* res);
-// chunk step: every item runs `nrounds` consecutive rounds; workgroup k owns pair indices [k 2^c, (k+1) 2^c) of the
-// first round (nrounds <= c + 1) and keeps the intermediate folded tables in LDS, so the small rounds of all jobs
-// take one launch per ST_CHUNK_ROUNDS rounds instead of one launch per round. With nchunks = 1 this is the tail.
-constexpr int ST_CHUNK_ROUNDS = 5;
-void st_chunk(hipStream_t st, int kind, const StJob* jobs, const StItem* items, int nitems, int max_chunks, int max_ntab,
-              const E2* chal, E2* partials, E2* res);
+// LDS-resident tail (st_tail): every item runs ALL rounds from its `rd` on in one workgroup; st_tail_h(ntab, nvars) = log2 of the
+// largest half length whose tables fit, i.e. the rounds with half <= 2^st_tail_h belong to the tail; table_bytes = max over the
+// items of ntab * (2^h0 + 2^(h0-1)) * sizeof(E2), h0 = nvars - 1 - rd
+int st_tail_h(int ntab, int nvars);
+void st_tail(hipStream_t st, int kind, const StJob* jobs, const StItem* items, int nitems, size_t table_bytes, const E2* chal, E2* res);
 constexpr int ST_STEP2_MIN_H = 9;  // fused steps need 2^h_log2 >= 2 * 256 (one pair index per thread, lane pairs share the second round)
 
 // PRODSUM sum-check instance (g = sum_i a_i b_i), device-visible descriptor; instances of equal nvars are
@@ -139,6 +138,9 @@ void ps_tail(hipStream_t st, const PsJob* jobs, int njobs, const E2* chal, E2* r
 // dst_base[ent[i].dst] = ent[i].src[0]: moves locally produced scalars to their global result slots
 struct ScatterEnt { const E2* src; size_t dst; };
 void scatter_e2(hipStream_t st, const ScatterEnt* ents, size_t n, E2* dst_base);
+void stamp(hipStream_t st, unsigned long long* slot);   // debugging aid: device wall clock at this point of the stream
+struct ClearSet { unsigned* p[3]; size_t n[3]; };   // up to three regions of 32-bit words
+void clear_words(hipStream_t st, const ClearSet& c);
 
 // out[v] = sum_b partials[b*nv + v], v < nv
 void reduce_partials(hipStream_t st, const E2* partials, int nblocks, int nv, E2* out);

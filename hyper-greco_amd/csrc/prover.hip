@@ -273,8 +273,22 @@ struct Prover {
         ctx->ensure_chain(16384);
         // arrival tickets of the last-workgroup reductions: a launch that died mid-way (fault, abort) would leave them non-zero
         // and every later prove on this context would silently lose round sums, so each prove starts from cleared tickets
-        for (E2* pbuf : {ctx->d_partials, ctx->d_partials2})
-            hip_check(hipMemsetAsync(reinterpret_cast<char*>(pbuf) + dev::PARTIALS_E2 * sizeof(E2), 0, dev::PARTIALS_TICKETS * sizeof(unsigned), ctx->stream), "clear reduction tickets");
+        // (one kernel, together with the result-buffer prefix a sharded prove clears: memset nodes cost a launch each)
+        dev::ClearSet cs;
+        memset(&cs, 0, sizeof(cs));
+        int nr = 0;
+        for (E2* pbuf : {ctx->d_partials, ctx->d_partials2}) {
+            cs.p[nr] = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(pbuf) + dev::PARTIALS_E2 * sizeof(E2));
+            cs.n[nr++] = dev::PARTIALS_TICKETS;
+        }
+        if (world > 1 && pk) {
+            // un-owned result slots must read zero. The buffer is host memory across PCIe: clear only what a prove of this key uses
+            // (known from the previous walk of the same key; the first one clears everything)
+            const bool hinted = ctx->res_hint_serial == pk->serial && ctx->res_hint > 0 && ctx->res_hint <= ctx->res_cap;
+            cs.p[2] = reinterpret_cast<unsigned*>(ctx->d_res);
+            cs.n[2] = (hinted ? ctx->res_hint : ctx->res_cap) * (sizeof(E2) / sizeof(unsigned));
+        }
+        dev::clear_words(ctx->stream, cs);
     }
     E2* d_res() { return ctx->d_res; }
     const E2* h_res() { return ctx->h_res; }
@@ -368,12 +382,15 @@ struct Prover {
         std::vector<int> next_h(nj);  // half-length (log2) of the job's next unscheduled round
         for (int q = 0; q < nj; q++) { cur_in[q] = st_jobs[q].in; cur_stride[q] = st_jobs[q].in_stride; next_h[q] = st_jobs[q].nvars - 1; }
         auto next_out = [&](int q) { return cur_in[q] == (const void*)st_jobs[q].buf[0] ? st_jobs[q].buf[1] : st_jobs[q].buf[0]; };
-        constexpr int CR = dev::ST_CHUNK_ROUNDS;
-        // rounds with half <= 2^H_SMALL run in chunk launches of CR rounds each: the last CR rounds always (one
-        // workgroup per job), the CR before them too when HG_CHUNK_A=1 (32 workgroups per job; measured slower than
-        // per-round launches on MI355X)
-        static const bool chunk_a = [] { const char* e = getenv("HG_CHUNK_A"); return e && e[0] == '1'; }();
-        const int H_SMALL = chunk_a ? 2 * CR - 1 : CR - 1;
+        // The rounds with half <= 2^h_small[q] of job q run in ONE single-workgroup launch with the folded tables in LDS (st_tail);
+        // how many fit depends on the job's table count (12 rounds for the two collation tables, 6 for a full grand-product layer).
+        // HG_TAIL_H caps it (4 = the five rounds of the round-1 chunk kernel).
+        static const int tail_cap = [] { const char* e = getenv("HG_TAIL_H"); return e && *e ? atoi(e) : 31; }();
+        std::vector<int> h_small(nj);
+        for (int q = 0; q < nj; q++) {
+            h_small[q] = std::min(dev::st_tail_h(st_jobs[q].ntab, st_jobs[q].nvars), tail_cap);
+            if (st_seq[q] > 0) h_small[q] = std::min(h_small[q], st_jobs[q].nvars - 2);   // a sequenced first round has its own kernel
+        }
         for (int kind : {dev::SC_COLLATION, dev::SC_GRANDPROD}) {
             int max_h = -1;
             for (auto& J : st_jobs) if (J.kind == kind) max_h = std::max(max_h, J.nvars - 1);
@@ -386,7 +403,7 @@ struct Prover {
                     for (int q = 0; q < nj; q++) {
                         const dev::StJob& J = st_jobs[q];
                         if (st_seq[q] != sq || J.kind != kind) continue;
-                        if (!J.base || next_h[q] <= H_SMALL) throw Error("sequenced first round on a job that has none");
+                        if (!J.base || next_h[q] <= h_small[q]) throw Error("sequenced first round on a job that has none");
                         Launch ls{kind, true, -1, false, 1, {}};
                         ls.hash = J.hash_src != nullptr;
                         dev::StItem it;
@@ -404,7 +421,7 @@ struct Prover {
                 Launch lall{kind, true, -1, false, 1, {}};
                 for (int q = 0; q < nj; q++) {
                     const dev::StJob& J = st_jobs[q];
-                    if (J.kind != kind || !J.base || next_h[q] <= H_SMALL || next_h[q] != J.nvars - 1) continue;  // (sequenced jobs are past their first round)
+                    if (J.kind != kind || !J.base || next_h[q] <= h_small[q] || next_h[q] != J.nvars - 1) continue;  // (sequenced jobs are past their first round)
                     dev::StItem it;
                     memset(&it, 0, sizeof(it));
                     it.job = q; it.h_log2 = next_h[q]; it.in = cur_in[q]; it.in_stride = cur_stride[q]; it.out = J.buf[0];
@@ -421,14 +438,14 @@ struct Prover {
                 for (int q = 0; q < nj; q++) {
                     const dev::StJob& J = st_jobs[q];
                     const int h = next_h[q];
-                    if (J.kind != kind || h <= H_SMALL) continue;
+                    if (J.kind != kind || h <= h_small[q]) continue;
                     const bool first = J.nvars - 1 == h;
                     if (first && J.hash_src) throw Error("hash-source job without a sequenced first round");
                     dev::StItem it;
                     memset(&it, 0, sizeof(it));
                     it.job = q; it.h_log2 = h; it.in = cur_in[q]; it.in_stride = cur_stride[q];
                     it.out = first ? J.buf[0] : next_out(q);
-                    const bool pair = fuse2 && !first && h - 1 > H_SMALL && h >= std::max(dev::ST_STEP2_MIN_H, fuse_min_h);
+                    const bool pair = fuse2 && !first && h - 1 > h_small[q] && h >= std::max(dev::ST_STEP2_MIN_H, fuse_min_h);
                     (pair ? l2 : le).items.push_back(it);
                     next_h[q] = h - (pair ? 2 : 1);
                     cur_in[q] = it.out; cur_stride[q] = (size_t)1 << (pair ? h - 1 : h);
@@ -437,22 +454,19 @@ struct Prover {
                 if (!l2.items.empty()) plan.push_back(l2);
                 if (!le.items.empty()) plan.push_back(le);
             }
-            // chunk launches: rounds with half 2^(H_SMALL) .. 2^CR (32 workgroups per job), then 2^(CR-1) .. 1 (one workgroup per job)
-            for (int lo : {CR, 0}) {
-                if (lo > H_SMALL) continue;
-                Launch lc{kind, false, lo, true, CR, {}};
+            // the tail launch: every job's remaining rounds
+            {
+                Launch lc{kind, false, 0, true, 0, {}};
                 for (int q = 0; q < nj; q++) {
                     const dev::StJob& J = st_jobs[q];
-                    if (J.kind != kind || next_h[q] < lo) continue;
+                    if (J.kind != kind || next_h[q] < 0) continue;
                     const int hs = next_h[q];
                     dev::StItem it;
                     memset(&it, 0, sizeof(it));
                     it.job = q; it.in = cur_in[q]; it.in_stride = cur_stride[q];
-                    it.rd = J.nvars - 1 - hs; it.nrounds = hs - lo + 1; it.c_log2 = it.nrounds - 1; it.nchunks = 1 << (hs - it.c_log2);
-                    it.out = lo == 0 ? J.final_out : (it.rd == 0 ? J.buf[0] : next_out(q));
+                    it.rd = J.nvars - 1 - hs; it.nrounds = hs + 1; it.out = J.final_out;
                     lc.items.push_back(it);
-                    next_h[q] = lo - 1;
-                    cur_in[q] = it.out; cur_stride[q] = (size_t)1 << lo;
+                    next_h[q] = -1;
                 }
                 if (!lc.items.empty()) plan.push_back(lc);
             }
@@ -482,7 +496,7 @@ struct Prover {
         };
         for (size_t li = 0; li < plan.size(); li++) {
             const Launch& L = plan[li];
-            if (L.kind == dev::SC_GRANDPROD && st_before_gp) { st_before_gp(); st_before_gp = nullptr; }
+            if (L.kind == dev::SC_GRANDPROD && st_before_gp) { stamp("collation done"); st_before_gp(); st_before_gp = nullptr; stamp("grand products may start"); }
             if (L.after_seq) {
                 for (auto& f : st_after_seq) f();
                 st_after_seq.clear();
@@ -501,18 +515,20 @@ struct Prover {
                     ctx->prof_begin(cls_gp_hash, bytes, model);
                     dev::st_first_hash(st, d_jobs + it.job, d_items + offs[li] + o, grids[li][0], st_jobs[it.job].mirror != 0, ctx->d_chal, partials, d_res());
                     ctx->prof_end();
+                    stamp("first hash round done");
                     continue;
                 }
                 if (L.tail) {
-                    int max_chunks = 1, max_ntab = 1;
+                    size_t table_bytes = 0;
                     for (int q = 0; q < cnt; q++) {
                         const dev::StItem& it = L.items[o + q];
                         const dev::StJob& J = st_jobs[it.job];
                         for (int k = 0; k < it.nrounds; k++) { bytes += round_bytes(it.job, it.rd + k, false); model += round_bytes(it.job, it.rd + k, true); }
-                        max_chunks = std::max(max_chunks, it.nchunks); max_ntab = std::max(max_ntab, J.ntab);
+                        const int h0 = J.nvars - 1 - it.rd;
+                        table_bytes = std::max(table_bytes, (size_t)J.ntab * (((size_t)1 << h0) + (((size_t)1 << h0) >> 1)) * sizeof(E2));
                     }
                     ctx->prof_begin(cls_tail, bytes, model);
-                    dev::st_chunk(st, L.kind, d_jobs, d_items + offs[li] + o, cnt, max_chunks, max_ntab, ctx->d_chal, partials, d_res());
+                    dev::st_tail(st, L.kind, d_jobs, d_items + offs[li] + o, cnt, table_bytes, ctx->d_chal, d_res());
                     ctx->prof_end();
                 } else {
                     for (int q = 0; q < cnt; q++) {
@@ -657,8 +673,17 @@ struct Prover {
     static constexpr size_t MAX_BATCH = 64;
     // pinned staging for small host->device descriptor copies (kept alive until the final synchronisation)
     // small host->device descriptor copy through the staging buffer, on the current stream
+    // Descriptor uploads (jobs, items, hash sources ...). Their contents depend on the key and the share only - the challenges are
+    // known up front - so a prove that is being recorded into a launch graph does not record them: they are copied ONCE before the
+    // first replay (prove_capture) and stay in the arena, which nothing else touches while the cached graph is valid (arena_epoch).
+    // As graph nodes they cost about 5 us each on the stream they sit on, ten to twenty per prove.
+    bool defer_uploads = false;
+    struct Upload { void* dst; const void* src; size_t bytes; };
+    std::vector<Upload> deferred_uploads;
     void upload(void* dst, const void* src, size_t bytes, const char* what) {
-        hip_check(hipMemcpyAsync(dst, stage(src, bytes), bytes, hipMemcpyHostToDevice, st), what);
+        const void* staged = stage(src, bytes);
+        if (defer_uploads) { deferred_uploads.push_back(Upload{dst, staged, bytes}); return; }
+        hip_check(hipMemcpyAsync(dst, staged, bytes, hipMemcpyHostToDevice, st), what);
     }
     void* stage(const void* src, size_t bytes) {
         size_t need = (bytes + 63) & ~(size_t)63;
@@ -1031,8 +1056,10 @@ struct Prover {
             }
             ctx->prof_begin(cls_aux, (double)N * 8 * (1 + (fork_recorded ? 0 : 4) + ep_count + 1));
             dev::lasso_split(st, L, d_input, fork_recorded ? nullptr : dims, ep, ep_rows, &cp, ep + (size_t)ep_count * N);
+            stamp("limb split done");
             ctx->prof_end();
             if (fork_recorded) hip_check(hipEventRecord(ctx->ev_aux[2], st), "lasso: E tables event");
+            if (fork_recorded && getenv("HG_DUMMY")) dev::stamp(st, ctx->alloc_n<unsigned long long>(1));
         }
         // MemoryCheckingProver::new (prover.rs:35-89)
         const int nrows = split ? (int)local_pairs.size() : 2 * G;
@@ -1110,7 +1137,10 @@ struct Prover {
         // (3.87 ms): HG_COUNTERS_MAIN=1 selects that.
         static const bool counters_aux_env = [] { const char* e = getenv("HG_COUNTERS_MAIN"); return !(e && e[0] == '1'); }();
         const bool counters_aux = counters_aux_env && !col_aux;   // schedule 1: the counters lead the main stream
-        if (use_aux && counters_aux) flush_stride();  // collation rounds first: see below
+        // Schedule 2 (HG_LASSO_SCHED=2): the collation rounds follow the counters on the SECOND stream. With the two-table collation
+        // (E_0 and C) they are a chain of short launches, about 0.2 ms that the main stream no longer spends ahead of grand product #1.
+        const bool col_after_counters = use_aux && counters_aux && lasso_sched == 2;
+        if (use_aux && counters_aux && !col_after_counters) flush_stride();  // collation rounds first: see below
         auto cnt_where = [&](const std::function<void()>& fn) { if (use_aux && counters_aux) on_aux(fn); else fn(); };
         bool counters_event_recorded = false;
         if (need_counters) cnt_where([&] {
@@ -1141,6 +1171,7 @@ struct Prover {
                 dev::lasso_counters_all(st, L, mask, dims, co, temp, tb, keys, keys2, rows, rows2, starts);
             }
             ctx->prof_end();
+            stamp("counters done");
             if (use_aux && counters_aux) { hip_check(hipEventRecord(ctx->ev_aux[3], st), "lasso: counters event"); counters_event_recorded = true; }
         });
         if (use_aux && !counters_aux && need_counters) {
@@ -1148,6 +1179,11 @@ struct Prover {
             hip_check(hipEventRecord(ctx->ev_aux[0], ctx->stream), "lasso: counters event");
             on_aux([&] { hip_check(hipStreamWaitEvent(st, ctx->ev_aux[0], 0), "lasso: wait for the counters"); });
         }
+        if (col_after_counters) on_aux([&] {
+            hip_check(hipStreamWaitEvent(st, ctx->ev_aux[2], 0), "lasso: wait for the E tables");
+            flush_stride();
+            stamp("collation done");
+        });
         // the collation rounds are launched now, not with the grand products at the end of the node: the host still has the whole
         // memory-checking bookkeeping to walk (about 0.5 ms) and the main stream would sit idle meanwhile; behind the counters, so
         // that the second stream (grand product #2's tree, openings) can start while they run
@@ -1257,9 +1293,10 @@ struct Prover {
         if (use_aux) {
             // grand product #1's first launch reads the counters, grand product #2's first rounds its tree: the main stream waits
             // for the second one only there, after the collation sum-check has been enqueued
+            on_aux([&] { stamp("grand product #2's tree done"); });
             hip_check(hipEventRecord(ctx->ev_aux[1], ctx->stream2), "lasso: aux event");
             on_aux([&] { hip_check(hipStreamWaitEvent(st, ctx->ev_aux[2], 0), "lasso: wait for the E tables"); });   // claimed sum, openings
-            if (do_col && claim_late) on_aux(do_claim);
+            // (the claimed sum's launches follow the grand products' below: see the openings)
             hg_ctx* c = ctx;
             // the first launches (the hash-free first round of the top layer, the next layers' level-emitting first rounds) only
             // need the counters; grand product #2's jobs join from the mixed first-round launch on and need its tree
@@ -1269,17 +1306,17 @@ struct Prover {
         }
         // openings (prover.rs:173-178, mod.rs:80-93). With two streams eq(r, .) may still be in use by the claimed-sum kernel on
         // the main stream, so the openings get their own table.
-        aux([&] {
+        // Their launches (and the claimed sum's) are enqueued AFTER the grand products': a replayed launch graph submits its nodes in
+        // the order they were recorded, a few microseconds each, so the main stream's first grand-product kernel could not start before
+        // everything recorded ahead of it was out - on a sharded rank, whose kernels are short, that left the main stream idle for
+        // 100-150 us (scripts/ub/graph_order.hip shows the effect in isolation).
         E2* eqx = (use_aux && do_open) ? ctx->alloc_n<E2>(N) : eq;  // (one stream: the eq(r,.) table is dead by now)
         E2* eqy = do_open ? ctx->alloc_n<E2>(M) : nullptr;
-        if (do_open) {
-            eq_now(eqx, nu, g1.point_off);
-            eq_now(eqy, 16, g2.point_off);
-        }
         // every opening at x in one launch, every opening at y in another (dev::dot_eq_many): results land in their wire slots
         dev::DotTabs tx, ty;
         memset(&tx, 0, sizeof(tx)); memset(&ty, 0, sizeof(ty));
         int nx = 0, ny = 0;
+        {
         auto add_x = [&](const u64* tab, size_t out_slot) {
             if (nx >= dev::DOT_MAX) throw Error("lasso: too many openings");
             tx.t[nx] = tab; tx.slot[nx] = (int)out_slot; nx++;
@@ -1301,18 +1338,27 @@ struct Prover {
                 if (do_open && own_mem[chk.second[i]]) add_x(epm(chk.second[i]), base_slot + 3 + i);
             chunk_slots.push_back({c, base_slot, 3 + chk.second.size()});
         }
-        if (nx) {
-            ctx->prof_begin(cls_aux, (double)N * (16.0 * ((nx + 7) / 8) + 8.0 * nx));
-            dev::dot_eq_many(st, eqx, tx, nx, N, partials, d_res());
-            ctx->prof_end();
-        }
-        if (ny) dev::dot_eq_many(st, eqy, ty, ny, M, partials, d_res());
         for (auto& cs : chunk_slots) {
             mark("lasso: openings of chunk " + std::to_string(cs.c) + ": dim(x), read_ts(x), final_cts(y), E_m(x) (prover.rs:173-178)");
             defer_write_slots(cs.base, cs.count);
         }
-        });
+        }
         flush_stride();  // collation + every grand-product layer, round-synchronised
+        aux([&] {
+            if (do_col && claim_late) do_claim();
+            if (do_open) {
+                eq_now(eqx, nu, g1.point_off);
+                eq_now(eqy, 16, g2.point_off);
+            }
+            if (nx) {
+                ctx->prof_begin(cls_aux, (double)N * (16.0 * ((nx + 7) / 8) + 8.0 * nx));
+                dev::dot_eq_many(st, eqx, tx, nx, N, partials, d_res());
+                ctx->prof_end();
+            }
+            if (ny) dev::dot_eq_many(st, eqy, ty, ny, M, partials, d_res());
+            stamp("claimed sum and openings done");
+        });
+        stamp("grand products done");
         return ClaimRef{r_off, nu, claimed};  // (r, claimed_sum) for the single predecessor (lasso.rs:97,113)
     }
 
@@ -1551,6 +1597,24 @@ struct Prover {
 
     // copies the result buffer back (the only synchronisation) and replays the transcript
     double t_enqueued = 0, t_synced = 0, t_replayed = 0;
+    // debugging aid (HG_STAMP=1): one-thread kernels that record the device clock at named points of both streams; printed after
+    // the synchronisation, relative to the first one. Works inside a replayed launch graph, where events and profilers do not.
+    std::vector<std::string> stamp_names;
+    unsigned long long* d_stamps = nullptr;
+    void stamp(const char* name) {
+        static const bool on = getenv("HG_STAMP") != nullptr;
+        if (!on) return;
+        if (!d_stamps) d_stamps = ctx->alloc_n<unsigned long long>(256);
+        if (stamp_names.size() >= 256) return;
+        dev::stamp(st, d_stamps + stamp_names.size());
+        stamp_names.push_back(std::string(st == ctx->stream ? "main " : "aux  ") + name);
+    }
+    void print_stamps() {
+        if (stamp_names.empty()) return;
+        std::vector<unsigned long long> h(stamp_names.size());
+        if (hipMemcpy(h.data(), d_stamps, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
+        for (size_t i = 0; i < h.size(); i++) fprintf(stderr, "stamp %8.1f us  %s\n", (double)(long long)(h[i] - h[0]) / 100.0, stamp_names[i].c_str());
+    }
     void sync_results() {
         if (res_used && ctx->d_res != ctx->h_res) hip_check(hipMemcpyAsync(ctx->h_res, ctx->d_res, res_used * sizeof(E2), hipMemcpyDeviceToHost, st), "copy results");
         t_enqueued = wall_ms();
@@ -1567,6 +1631,7 @@ struct Prover {
         }
         hip_check(hipGetLastError(), "prove: kernel launch");
         t_synced = wall_ms();
+        print_stamps();
     }
     void replay() {
         double t = wall_ms();
@@ -1685,10 +1750,9 @@ void values_free(hg_values* v) {
 // everything a prove puts on the streams, in protocol order (also what a graph capture records)
 static void enqueue_prove(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, Prover* P, int world, bool exchange) {
     const Params& p = pk->params;
-    // un-owned result slots must read zero. The buffer is host memory across PCIe: clear only what a prove of this key uses (known
-    // from the previous walk of the same key; the first one clears everything)
+    P->stamp("start");
+    // (a sharded prove's result-buffer prefix was cleared by the Prover's first launch)
     const bool hinted = ctx->res_hint_serial == pk->serial && ctx->res_hint > 0 && ctx->res_hint <= ctx->res_cap;
-    if (world > 1) hip_check(hipMemsetAsync(ctx->d_res, 0, (hinted ? ctx->res_hint : ctx->res_cap) * sizeof(E2), ctx->stream), "clear result buffer");
     // "eval output" (sk_encryption_circuit.rs:444-448): point, ct0is MLE value
     const int ov = p.ct0is_log2();
     size_t point_off = P->epos();
@@ -1707,6 +1771,7 @@ static void enqueue_prove(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, Prov
         if (hinted && P->res_used > ctx->res_hint) throw Error("sharded prove: the result buffer grew between two proves of one key");
         ctx->res_hint = P->res_used; ctx->res_hint_serial = pk->serial;
     }
+    P->stamp("end of the prove");
     if (exchange) comm_allreduce_results(ctx, P->res_used);  // the one collective of a sharded proof, on the stream
 }
 
@@ -1763,7 +1828,10 @@ static ProveResult prove_from_cache(hg_ctx* ctx, ProveCache* C, bool exchange = 
     ProveResult res;
     const double t0 = wall_ms();
     hip_check(hipEventRecord(C->ev_a, ctx->stream), "event record");
+    static const bool time_launch = getenv("HG_TIME_LAUNCH") != nullptr;   // (debugging aid: host time of the graph launch call)
+    const double tl0 = time_launch ? wall_ms() : 0;
     hip_check(hipGraphLaunch(C->exec, ctx->stream), "hipGraphLaunch");
+    if (time_launch) fprintf(stderr, "hipGraphLaunch: %.3f ms on the host\n", wall_ms() - tl0);
     if (exchange) comm_allreduce_results(ctx, C->P->res_used);   // the one collective of a sharded proof, behind the replayed graph
     hip_check(hipEventRecord(C->ev_b, ctx->stream), "event record");
     Prover* P = C->P.get();
@@ -1794,6 +1862,8 @@ static ProveResult prove_capture(hg_ctx* ctx, const hg_pk* pk, const hg_values* 
     try {
         C->P.reset(new Prover(ctx, pk, rank, world));
         C->P->d_vals = v->d_vals;
+        static const bool static_uploads = [] { const char* e = getenv("HG_GRAPH_UPLOADS"); return !(e && e[0] == '1'); }();
+        C->P->defer_uploads = static_uploads;
         enqueue_prove(ctx, pk, v, C->P.get(), world, false);   // (the exchange is not part of the graph: prove_from_cache)
     } catch (...) {
         hipGraph_t g = nullptr;
@@ -1802,6 +1872,10 @@ static ProveResult prove_capture(hg_ctx* ctx, const hg_pk* pk, const hg_values* 
         throw;
     }
     hip_check(hipStreamEndCapture(ctx->stream, &C->graph), "hipStreamEndCapture");
+    if (const char* dot = getenv("HG_GRAPH_DOT")) (void)hipGraphDebugDotPrint(C->graph, dot, hipGraphDebugDotFlagsKernelNodeParams);   // (debugging aid: the recorded dependencies)
+    for (auto& u : C->P->deferred_uploads)   // once, ahead of the first replay on the same stream
+        hip_check(hipMemcpyAsync(u.dst, u.src, u.bytes, hipMemcpyHostToDevice, ctx->stream), "descriptor upload");
+    C->P->deferred_uploads.clear();
     // (Re-issuing the captured nodes from the library on two real streams - kernel parameters and dependencies read back from the
     // graph - was measured against hipGraphLaunch: 3.50-3.59 ms vs 3.52-3.64 ms of GPU time and 0.53 vs 0.40 ms of host time per
     // prove. No gain, not kept: the serialised look of a replay in a rocprofv3 trace is a profiling artefact.)
