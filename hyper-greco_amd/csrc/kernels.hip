@@ -827,8 +827,22 @@ template <int KIND>
 __global__ __launch_bounds__(256) void k_st_tail(const StJob* __restrict__ jobs, const StItem* __restrict__ items, const E2* __restrict__ chal,
                                                  E2* __restrict__ res) {
     constexpr int NV = KIND == SC_GRANDPROD ? 3 : 2;
-    const StItem& I = items[blockIdx.x];
-    const StJob& J = jobs[I.job];
+    // The job and item descriptors are copied to LDS first: every round reads a dozen of their fields behind a barrier. (A round of
+    // this kernel takes 6.2-6.8 us whatever its size - in-kernel clock reads; that is the dependent chain of extension-field
+    // multiplications per round (fold factors, pair products, the p_0 scaling, the wave reductions), not memory: the same figure
+    // with the descriptors in global memory and with the round sums stored to the host-mapped result buffer every round.)
+    __shared__ StJob Jl;
+    __shared__ StItem Il;
+    {
+        const StItem* gi = items + blockIdx.x;
+        const unsigned* src = reinterpret_cast<const unsigned*>(jobs + gi->job);
+        unsigned* dst = reinterpret_cast<unsigned*>(&Jl);
+        for (unsigned k = threadIdx.x; k < sizeof(StJob) / 4; k += blockDim.x) dst[k] = src[k];
+        if (threadIdx.x < sizeof(StItem) / 4) reinterpret_cast<unsigned*>(&Il)[threadIdx.x] = reinterpret_cast<const unsigned*>(gi)[threadIdx.x];
+    }
+    __syncthreads();
+    const StItem& I = Il;
+    const StJob& J = Jl;
     E2* sm = dyn_lds;
     E2* red = dyn_lds + SM_SLOTS;
     E2* tab[2];
@@ -839,8 +853,8 @@ __global__ __launch_bounds__(256) void k_st_tail(const StJob* __restrict__ jobs,
     const StJob* mirror = (KIND == SC_GRANDPROD && J.mirror) ? &J : nullptr;
     const void* in = I.in;
     size_t in_stride = I.in_stride;
-    // The round sums go to the result buffer - host memory across PCIe - ONCE, at the end: a store per round followed by the
-    // round's barrier made every round wait for its PCIe write acknowledgement. The challenges are fetched once as well.
+    // The round sums go to the result buffer - host memory across PCIe - ONCE, at the end, not a store per round ahead of the
+    // round's barrier. The challenges are fetched once as well.
     __shared__ E2 keep[3 * 32], rch[32];
     if ((int)threadIdx.x < J.nvars - I.rd) rch[threadIdx.x] = chal[J.r_off + I.rd + threadIdx.x];
     __syncthreads();
@@ -1106,7 +1120,13 @@ __global__ __launch_bounds__(256) void k_ps_step2(const PsJob* __restrict__ jobs
 // (dynamic LDS: 16 block-sum slots, then PS_TAIL_LDS_E2 Ext2 entries: two ping-pong regions of 2/3 and 1/3)
 constexpr size_t PS_TAIL_LDS_E2 = 6144;  // first tail round: <= 2048 pair items -> 2 * 2048 folded entries, then half of that
 __global__ __launch_bounds__(1024) void k_ps_tail(const PsJob* __restrict__ jobs, const E2* __restrict__ chal, E2* __restrict__ res) {
-    const PsJob& J = jobs[blockIdx.x];
+    __shared__ PsJob Jl;   // (descriptor in LDS: see k_st_tail)
+    {
+        const unsigned* src = reinterpret_cast<const unsigned*>(jobs + blockIdx.x);
+        for (unsigned k = threadIdx.x; k < sizeof(PsJob) / 4; k += blockDim.x) reinterpret_cast<unsigned*>(&Jl)[k] = src[k];
+    }
+    __syncthreads();
+    const PsJob& J = Jl;
     E2* sm = dyn_lds;
     int bd_log2 = 31 - __clz((int)blockDim.x);
     int in_buf = J.tail_buf;
@@ -1554,6 +1574,31 @@ void prod_level(hipStream_t st, const u64* in, size_t in_len, u64* out, int nb) 
     size_t h = in_len >> 1;
     dim3 grid((unsigned)std::min<size_t>((h / 2 + TPB - 1) / TPB + 1, 256), (unsigned)nb);
     k_prod_level<<<grid, TPB, 0, st>>>(in, in_len, out);
+}
+// three levels per launch: thread j of a row holds the eight entries j + m * in_len/8 and writes 4 + 2 + 1 products (the mid-size
+// levels are launch-bound: six of them between the levels the sum-check first rounds emit and the single-workgroup tail)
+__global__ __launch_bounds__(TPB) void k_prod_level3(const u64* __restrict__ in, size_t in_len, u64* __restrict__ o1, u64* __restrict__ o2, u64* __restrict__ o3) {
+    const size_t e = in_len >> 3;
+    const u64* src = in + (size_t)blockIdx.y * in_len;
+    u64* d1 = o1 + (size_t)blockIdx.y * (4 * e);
+    u64* d2 = o2 + (size_t)blockIdx.y * (2 * e);
+    u64* d3 = o3 + (size_t)blockIdx.y * e;
+    for (size_t j = (size_t)blockIdx.x * TPB + threadIdx.x; j < e; j += (size_t)gridDim.x * TPB) {
+        u64 x[8];
+#pragma unroll
+        for (int m = 0; m < 8; m++) x[m] = src[j + m * e];
+        u64 y[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) { y[m] = gl_mul(x[m], x[m + 4]); d1[j + m * e] = y[m]; }
+        const u64 z0 = gl_mul(y[0], y[2]), z1 = gl_mul(y[1], y[3]);
+        d2[j] = z0; d2[j + e] = z1;
+        d3[j] = gl_mul(z0, z1);
+    }
+}
+void prod_level3(hipStream_t st, const u64* in, size_t in_len, u64* o1, u64* o2, u64* o3, int nb) {
+    const size_t e = in_len >> 3;
+    dim3 grid((unsigned)std::min<size_t>((e + TPB - 1) / TPB, 256), (unsigned)nb);
+    k_prod_level3<<<grid, TPB, 0, st>>>(in, in_len, o1, o2, o3);
 }
 // the small levels of the tree in one launch: workgroup b holds row b of a level of at most PROD_TAIL_LEN entries in LDS and
 // writes every level above it (levels[k] = row-major nb x (in_len >> (k+1)))

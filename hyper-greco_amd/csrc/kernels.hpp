@@ -208,6 +208,8 @@ struct HashIfArgs { u32 cutoff[32]; const u64* fc[32]; int row_init[32], row_fin
 void lasso_hash_if(hipStream_t st, const HashIfArgs& args, int G, u64 gamma, u64 tau, u64* H2);
 // product tree level: out[b][i] = in[b][i] * in[b][i + h], b < nb, i < h
 void prod_level(hipStream_t st, const u64* in, size_t in_len, u64* out, int nb);
+// three levels in one launch (in_len a multiple of 8): o1, o2, o3 = the levels of in_len/2, in_len/4, in_len/8 entries per row
+void prod_level3(hipStream_t st, const u64* in, size_t in_len, u64* o1, u64* o2, u64* o3, int nb);
 // all levels above a level of in_len <= PROD_TAIL_LEN entries in one launch (one workgroup per row)
 constexpr int PROD_TAIL_LEN = 2048;
 struct ProdTailOut { u64* p[12]; };

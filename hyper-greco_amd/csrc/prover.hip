@@ -856,6 +856,15 @@ struct Prover {
                     ctx->prof_end();
                     break;
                 }
+                // three levels per launch while the third one is still above the tail's size
+                static const bool level3 = [] { const char* e = getenv("HG_NO_LEVEL3"); return !(e && e[0] == '1'); }();
+                if (level3 && k + 2 <= deepest && (in_len >> 2) > (size_t)dev::PROD_TAIL_LEN && in_len <= ((size_t)1 << 18)) {
+                    ctx->prof_begin(cls_tree, (double)nl * in_len * 8.0 * 1.5 * 1.75);
+                    if (nl > 0) dev::prod_level3(st, lev[k - 1], in_len, lev_w[k], lev_w[k + 1], lev_w[k + 2], nl);
+                    ctx->prof_end();
+                    k += 2;
+                    continue;
+                }
                 ctx->prof_begin(cls_tree, (double)nl * in_len * 8.0 * 1.5);
                 if (nl > 0) dev::prod_level(st, lev[k - 1], in_len, lev_w[k], nl);
                 ctx->prof_end();
@@ -1758,6 +1767,8 @@ static void enqueue_prove(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, Prov
     size_t point_off = P->epos();
     for (int i = 0; i < ov; i++) P->squeeze();
     size_t vslot = P->slot(1);
+    // (on the main stream: moved behind the counter sorts on the second stream it starts the limb split 30 us earlier and changes
+    // nothing at the end of the prove - and the launch graph's stream assignment is touchy about what forks first)
     if (P->mine(P->own_out_claim)) {
         E2* eq = ctx->alloc_n<E2>((size_t)1 << ov);
         P->eq_now(eq, ov, point_off);
