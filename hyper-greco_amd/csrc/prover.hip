@@ -1803,6 +1803,7 @@ static std::unique_ptr<Prover> prove_begin(hg_ctx* ctx, const hg_pk* pk, const h
     *gpu_ms = 0;
     (void)hipEventElapsedTime(gpu_ms, ev_a, ev_b);
     (void)hipEventDestroy(ev_a); (void)hipEventDestroy(ev_b);
+    ctx->last_walk_gpu_ms = *gpu_ms;
     return P;
 }
 
@@ -1818,6 +1819,8 @@ struct ProveCache {
     bool one_stream = false;
     uint64_t epoch = 0;
     int rank = 0, world = 1;   // a sharded proof's graph holds this rank's share; the all-reduce follows the replay on the stream
+    float walk_gpu_ms = 0;     // GPU time of the walked prove that preceded the capture
+    int replays = 0, slow_replays = 0;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     ~ProveCache() {
         if (exec) (void)hipGraphExecDestroy(exec);
@@ -1850,6 +1853,14 @@ static ProveResult prove_from_cache(hg_ctx* ctx, ProveCache* C, bool exchange = 
     P->sync_results();
     float gms = 0;
     (void)hipEventElapsedTime(&gms, C->ev_a, C->ev_b);
+    // the first replays are checked against the plain launches this graph recorded: a graph that is clearly slower is given up
+    // for this key (prove_through_graph) - the proof it produced is still the proof
+    if (!exchange && C->replays < 4 && C->walk_gpu_ms > 0) {
+        C->replays++;
+        static const float factor = [] { const char* e = getenv("HG_GRAPH_GUARD_FACTOR"); return e && *e ? (float)atof(e) : 1.1f; }();   // (tests force it)
+        if (gms > factor * C->walk_gpu_ms + 0.1f) C->slow_replays++;
+        if (C->replays == 4 && C->slow_replays >= 3) { ctx->slow_graph_serial = C->pk_serial; ctx->slow_graph_share = C->rank * 65536 + C->world; }
+    }
     P->proof.bytes.clear();
     P->proof_map.clear();
     res.gpu_ms = gms;
@@ -1894,6 +1905,7 @@ static ProveResult prove_capture(hg_ctx* ctx, const hg_pk* pk, const hg_values* 
     hip_check(hipEventCreate(&C->ev_a), "event"); hip_check(hipEventCreate(&C->ev_b), "event");
     C->pk = pk; C->pk_serial = pk->serial; C->d_vals = v->d_vals; C->d_ct0is = v->d_ct0is; C->one_stream = ctx->one_stream; C->epoch = ctx->arena_epoch;
     C->rank = rank; C->world = world;
+    C->walk_gpu_ms = ctx->last_walk_gpu_ms;
     ProveCache* raw = C.release();
     ctx->prove_cache = raw;
     return prove_from_cache(ctx, raw, exchange, replay_now);
@@ -1903,6 +1915,10 @@ static ProveResult prove_capture(hg_ctx* ctx, const hg_pk* pk, const hg_values* 
 // the third call in a row with the same key, values and share; otherwise returns false and the caller walks the protocol.
 static bool prove_through_graph(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int rank, int world, bool exchange, ProveResult* out, bool replay_now = true) {
     if (!graph_allowed(ctx)) { ctx->same_key_proves = 0; return false; }
+    if (ctx->slow_graph_serial == pk->serial && ctx->slow_graph_share == rank * 65536 + world) {   // its graph replayed slower than plain launches
+        if (ctx->prove_cache) prove_cache_drop(ctx);
+        return false;
+    }
     ProveCache* C = static_cast<ProveCache*>(ctx->prove_cache);
     if (C && C->pk == pk && C->pk_serial == pk->serial && C->d_vals == v->d_vals && C->d_ct0is == v->d_ct0is && C->one_stream == ctx->one_stream &&
         C->epoch == ctx->arena_epoch && C->rank == rank && C->world == world) {

@@ -39,6 +39,11 @@ struct hg_ctx {
     const void* last_prove_key[2] = {nullptr, nullptr};
     uint64_t last_prove_serial = 0;
     int same_key_proves = 0;
+    // guard against a launch graph that replays slower than the plain launches it recorded (the runtime's stream assignment of a
+    // graph's branches is not under the library's control): GPU time of the last walked prove, and the key a slow graph was seen for
+    float last_walk_gpu_ms = 0;
+    uint64_t slow_graph_serial = 0;
+    int slow_graph_share = -1;
     int last_prove_share = 1;       // rank * 65536 + world of the last resident / sharded prove (part of the "same call" test)
     bool use_graph = true;          // hg_set_option("graph", 0) / HG_NO_GRAPH=1 turn it off
     // options (hg_set_option)

@@ -393,6 +393,32 @@ def test_cached_launch_graph_replays_and_invalidates(ctx):
     v1.free(); v2.free(); pk.free()
 
 
+def test_launch_graph_that_replays_slower_than_plain_launches_is_given_up():
+    """The library compares the first replays of a captured launch graph with the walked prove it recorded (the runtime decides which
+    stream a graph's branches run on) and falls back to plain launches for that key when the graph is clearly slower. Forced here with
+    HG_GRAPH_GUARD_FACTOR=0 in a child process: proofs stay identical and only the four checked replays go through the graph."""
+    import subprocess, sys
+    from hglib import ROOT
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import __graft_entry__ as entry\n"
+        "hg = entry.load_package()\n"
+        "ctx = hg.Context(0); bfv = hg.BfvEncrypt.new(4096, 2); pk = bfv.setup(ctx)\n"
+        "w = hg.Witness.synthetic(bfv.params, 5); v = hg.witness_gen(ctx, pk, w); out = hg.ProofBuffer()\n"
+        "first = None\n"
+        "for i in range(12):\n"
+        "    hg.prove_resident(ctx, pk, v, out); first = first or out.bytes(); assert out.bytes() == first, i\n"
+    ) % ROOT
+    env = dict(os.environ, HG_GRAPH_GUARD_FACTOR="0", HG_TIME_LAUNCH="1")   # (the second one logs every graph launch to stderr)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    # proves 0, 1: walks; 2: capture + first replay; 3 .. 5: replays - all four "slower" than the walk; 6 ..: walks again
+    assert r.stderr.count("hipGraphLaunch:") == 4, r.stderr[-2000:]
+    env = dict(os.environ, HG_TIME_LAUNCH="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0 and r.stderr.count("hipGraphLaunch:") == 10, r.stderr[-2000:]   # the guard leaves a healthy graph alone
+
+
 def test_library_collective_single_rank_communicator(ctx):
     """hg_comm_init / hg_prove_sharded with a one-rank RCCL communicator (the only size a one-GPU box offers): the limb-split
     kernel, ncclAllReduce on the prover stream and the fold-back kernel run for real and must leave the proof unchanged."""
