@@ -310,7 +310,7 @@ def test_protocol_modes_at_the_headline_size(ctx):
     pk.free()
 
 
-@pytest.mark.parametrize("nb,nv", [(2, 5), (6, 10), (50, 12), (3, 15)])
+@pytest.mark.parametrize("nb,nv", [(2, 5), (6, 10), (50, 12), (3, 15), (2, 17)])  # (the last two: three tree levels per launch, once and twice)
 def test_grand_product_entry_bit_exact(ctx, nb, nv):
     """hg_grand_product (the Goldilocks counterpart of hg_grand_product_bn254) against the oracle's
     prove_grand_product on random tables: proof bytes, final claims and the point."""
