@@ -1,5 +1,5 @@
 """Stability loop on one GPU: 1500 resident proves (the cached launch graph dropped and re-captured every 300), a BN254 prove every
-100, every proof compared with the first; prints the free GPU memory before and after."""
+100, a four-virtual-rank sharded proof every 250, EVERY proof compared with the first; prints the free GPU memory before and after."""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
@@ -12,11 +12,17 @@ w = hg.Witness.synthetic(bfv.params, 0x4752454330 + n); vals = hg.witness_gen(ct
 for _ in range(5): hg.prove_resident(ctx, pk, vals, out)
 ref = out.bytes(); ctx.prove_bn254(pk, w, cap=1 << 25); refb = ctx.prove_bn254(pk, w, cap=1 << 25)[0]
 f0 = free_mb(); t0 = time.time()
+import numpy as np
+def sharded(world):   # one proof as `world` virtual ranks on this GPU: partial result buffers combined, transcript replayed once
+    parts = [np.array(hg.prove_shard_begin(ctx, pk, vals, r, world), copy=True) for r in range(world)]
+    hg.prove_shard_combine(ctx, np.stack(parts), world)
+    return hg.prove_shard_finish(ctx, out).bytes()
 for i in range(1500):
-    hg.prove_resident(ctx, pk, vals, out)
+    assert hg.prove_resident(ctx, pk, vals, out).bytes() == ref, i   # (graph replays, except right after an invalidation)
     if i % 300 == 0:
-        assert out.bytes() == ref
         ctx.set_option("one_stream", i % 600 == 0)   # drops and re-captures the launch graph now and then
+    if i % 250 == 7:
+        assert sharded(4) == ref, i                  # other shares of the same key in between: the cached graph must not survive them
     if i % 100 == 0:
         assert ctx.prove_bn254(pk, w, cap=1 << 25)[0] == refb
 ctx.set_option("one_stream", 0)
