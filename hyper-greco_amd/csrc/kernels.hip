@@ -523,7 +523,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     E2* __restrict__ out = I.out;
     const E2 r = chal[J.r_off];
     const bool p0_only = J.p0_only != 0;
-    constexpr bool mirror = MIRROR;
+    [[maybe_unused]] constexpr bool mirror = MIRROR;
     const u64 gamma = H.gamma, gamma2 = H.gamma2, tau = H.tau;
     E2 acc[3] = {e2_zero(), e2_zero(), e2_zero()};
     for (size_t tile = bx; tile < ntiles; tile += nblocks) {
