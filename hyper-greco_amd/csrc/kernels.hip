@@ -509,7 +509,7 @@ __global__ __launch_bounds__(256) void k_st_step(const StJob* __restrict__ jobs,
 // two halves of a row), once per MEMORY for its read pair and its write pair (write hash = read hash + gamma^2), with the
 // dim / ts part shared by the memories of a chunk. E, dim, ts are small integers (< 2^16, < 2^16, < 2^32): gl_mul_small.
 // It also emits product-tree level 1 (J.next_level), so no separate hash or level-1 pass exists.
-template <bool MIRROR>   // write rows = read rows + gamma^2: not stored, not multiplied (StJob::mirror)
+template <bool MIRROR, bool RECOMP>   // MIRROR: write rows = read rows + gamma^2: not stored, not multiplied (StJob::mirror); RECOMP: E from the limbs
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_gp_first_hash(const StJob* __restrict__ job, const StItem* __restrict__ item,
                                                        const E2* __restrict__ chal, E2* __restrict__ partials, E2* __restrict__ res) {
     const StJob& J = *job;
@@ -534,6 +534,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         u64 p0 = 0, p2 = 0, p3 = 0;
         int cur_chunk = -1;
         u64 c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+        u32 a01 = 0, a23 = 0;          // RECOMP: the chunk's 16-bit limbs at 2j, 2j+1 | N/2+2j, N/2+2j+1
+        u32 uses_lo = 0, uses_hi = 0;  // RECOMP: memories the two rows' lookups use (alpha <= 32)
+        if constexpr (RECOMP) {
+            if (2 * j < H.rows) uses_lo = (u32)H.lookup_uses[H.seg_lookup[(2 * j) >> H.seg_shift]];
+            if (hN + 2 * j < H.rows) uses_hi = (u32)H.lookup_uses[H.seg_lookup[(hN + 2 * j) >> H.seg_shift]];
+        }
         for (int m = 0; m < H.nmem; m++) {
             const GpHashMem M = H.mems[m];
             if (M.chunk != cur_chunk) {  // uniform: memories are listed chunk by chunk
@@ -544,11 +550,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 const ulonglong2 tl = *reinterpret_cast<const ulonglong2*>(ts + 2 * j), th = *reinterpret_cast<const ulonglong2*>(ts + hN + 2 * j);
                 c0 = gl_sub(gl_add(dl.x, gl_mul_small(gamma2, (u32)tl.x)), tau); c1 = gl_sub(gl_add(dl.y, gl_mul_small(gamma2, (u32)tl.y)), tau);
                 c2 = gl_sub(gl_add(dh.x, gl_mul_small(gamma2, (u32)th.x)), tau); c3 = gl_sub(gl_add(dh.y, gl_mul_small(gamma2, (u32)th.y)), tau);
+                if constexpr (RECOMP) { a01 = (u32)dl.x | ((u32)dl.y << 16); a23 = (u32)dh.x | ((u32)dh.y << 16); }
             }
             // (prefetching the next memory's E loads was measured slower here: 594 vs 560 us)
-            const ulonglong2 el = *reinterpret_cast<const ulonglong2*>(M.ep + 2 * j), eh = *reinterpret_cast<const ulonglong2*>(M.ep + hN + 2 * j);
-            u64 xl = gl_add(c0, gl_mul_small(gamma, (u32)el.x)), yl = gl_add(c1, gl_mul_small(gamma, (u32)el.y));
-            u64 xr = gl_add(c2, gl_mul_small(gamma, (u32)eh.x)), yr = gl_add(c3, gl_mul_small(gamma, (u32)eh.y));
+            u32 e0, e1, e2v, e3;
+            if constexpr (RECOMP) {   // T_s[a] = a below the cutoff, 0 above; 0 for rows whose lookup does not use the memory
+                const u32 cut = M.cutoff;
+                const bool ul = (uses_lo >> M.mem) & 1, uh = (uses_hi >> M.mem) & 1;
+                e0 = a01 & 0xFFFF; e1 = a01 >> 16; e2v = a23 & 0xFFFF; e3 = a23 >> 16;
+                e0 = (ul && e0 < cut) ? e0 : 0; e1 = (ul && e1 < cut) ? e1 : 0;
+                e2v = (uh && e2v < cut) ? e2v : 0; e3 = (uh && e3 < cut) ? e3 : 0;
+            } else {
+                const ulonglong2 el = *reinterpret_cast<const ulonglong2*>(M.ep + 2 * j), eh = *reinterpret_cast<const ulonglong2*>(M.ep + hN + 2 * j);
+                e0 = (u32)el.x; e1 = (u32)el.y; e2v = (u32)eh.x; e3 = (u32)eh.y;
+            }
+            u64 xl = gl_add(c0, gl_mul_small(gamma, e0)), yl = gl_add(c1, gl_mul_small(gamma, e1));
+            u64 xr = gl_add(c2, gl_mul_small(gamma, e2v)), yr = gl_add(c3, gl_mul_small(gamma, e3));
             if (M.rd_row >= 0) {
                 const int i = M.rd_row;
                 if (i == 0) { const u64 d = gl_sub(yl, xl); p0 = xl; p2 = gl_add(yl, d); p3 = gl_add(p2, d); }
@@ -598,9 +615,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     if (nblocks > 1) finish_partials(partials, 3, tickets_of(partials), res + J.sums_slot, sm, nblocks);
 }
 static inline size_t sc_lds_bytes(int nv, int bd);
-void st_first_hash(hipStream_t st, const StJob* job, const StItem* item, int grid, bool mirror, const E2* chal, E2* partials, E2* res) {
-    if (mirror) k_gp_first_hash<true><<<grid, 256, sc_lds_bytes(0, 256), st>>>(job, item, chal, partials, res);
-    else k_gp_first_hash<false><<<grid, 256, sc_lds_bytes(0, 256), st>>>(job, item, chal, partials, res);
+void st_first_hash(hipStream_t st, const StJob* job, const StItem* item, int grid, bool mirror, bool recomp, const E2* chal, E2* partials, E2* res) {
+    const size_t lds = sc_lds_bytes(0, 256);
+    if (recomp) {
+        if (mirror) k_gp_first_hash<true, true><<<grid, 256, lds, st>>>(job, item, chal, partials, res);
+        else k_gp_first_hash<false, true><<<grid, 256, lds, st>>>(job, item, chal, partials, res);
+    } else {
+        if (mirror) k_gp_first_hash<true, false><<<grid, 256, lds, st>>>(job, item, chal, partials, res);
+        else k_gp_first_hash<false, false><<<grid, 256, lds, st>>>(job, item, chal, partials, res);
+    }
 }
 
 // ---- two grand-product rounds in one pass ------------------------------------------------------------------
@@ -1330,10 +1353,10 @@ __global__ __launch_bounds__(TPB) void k_lasso_split(LassoDev L, const u64* __re
         }
         u64 cv = 0;   // sum_m colpow[m] E_m[j]: at most four non-zero terms (the memories of the row's lookup)
         for (int m = 0; m < L.alpha; m++) {
-            if (R.row[m] < 0) continue;
+            if (R.row[m] < 0 && !(col && P.v[m])) continue;   // (a memory may enter C without its table being materialised)
             u32 a = idx[L.mem_dim[m]];
             u64 ev = ((uses >> m) & 1) && a < L.mem_cutoff[m] ? (u64)a : 0;  // T_s[a] (range.rs:15-17, 58-72)
-            e_polys[(size_t)R.row[m] * N + j] = ev;
+            if (R.row[m] >= 0) e_polys[(size_t)R.row[m] * N + j] = ev;
             if (col && ev && P.v[m]) cv = gl_add(cv, gl_mul_small(P.v[m], (u32)ev));
         }
         if (col) col[j] = cv;
@@ -1502,6 +1525,31 @@ __global__ __launch_bounds__(TPB) void k_lasso_claim(LassoDev L, const E2* __res
     E2 s = block_sum(acc, sm);
     if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
+// the same with the E values recomputed from the node input (no E tables): own = bit mask of the memories whose terms this rank sums
+__global__ __launch_bounds__(TPB) void k_lasso_claim_in(LassoDev L, const E2* __restrict__ eq, const u64* __restrict__ input, u32 own,
+                                                        E2* __restrict__ partials) {
+    __shared__ E2 sm[TPB / 64];
+    E2 acc = e2_zero();
+    for (size_t k = (size_t)blockIdx.x * TPB + threadIdx.x; k < L.rows; k += (size_t)gridDim.x * TPB) {
+        const int l = L.seg_lookup[k >> L.seg_shift];
+        const u64 v = input[k] & L.lookup_mask[l];
+        u64 comb = 0;  // combine_lookups (range.rs:184-195): sum_i M^i * operand_i
+        for (int i = 0; i < L.lookup_nmems[l]; i++) {
+            const int m = L.lookup_mems[l][i];
+            if (!((own >> m) & 1) || !((L.lookup_uses[l] >> m) & 1)) continue;
+            const u32 a = (u32)(v >> (16 * L.mem_dim[m])) & 0xFFFF;
+            if (a < L.mem_cutoff[m]) comb = gl_add(comb, gl_mul_small(L.mpow[i], a));
+        }
+        acc = e2_add(acc, e2_mul_f(eq[k], comb));
+    }
+    E2 s = block_sum(acc, sm);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+int lasso_claim_in(hipStream_t st, const LassoDev& L, const E2* eq, const u64* input, u32 own, E2* partials) {
+    int grid = grid_for(L.rows);
+    k_lasso_claim_in<<<grid, TPB, 0, st>>>(L, eq, input, own, partials);
+    return grid;
+}
 int lasso_claim(hipStream_t st, const LassoDev& L, const E2* eq, const u64* e_polys, const EpRows& rows, E2* partials) {
     int grid = grid_for(L.rows);
     k_lasso_claim<<<grid, TPB, 0, st>>>(L, eq, e_polys, rows, partials);
@@ -1638,13 +1686,36 @@ void gp_top(hipStream_t st, const u64* top, int nb, E2* roots, E2* evals) {
 // out[t] = sum_j eq[j] * tabs[t][j] for up to DOT_MAX base-field tables sharing one eq table, in ONE launch: grid.y = group of 8
 // tables (a thread keeps 8 accumulators; eq is re-read per group, from L2 / MALL after the first). The reduction launch has one
 // workgroup per table and writes result t to out[slot[t]].
-__global__ __launch_bounds__(TPB) void k_dot_eq(const E2* __restrict__ eq, DotTabs tabs, int ntab_all, size_t n, E2* __restrict__ partials) {
+// VIRT: tables with tabs.t[t] == nullptr are E tables that are not materialised - E_m[j] is recomputed from the node input (DotVirt:
+// memory tabs.emem[t]); a group's eight tables then cost one 8-byte load per entry instead of eight.
+template <bool VIRT>
+__global__ __launch_bounds__(TPB) void k_dot_eq(const E2* __restrict__ eq, DotTabs tabs, int ntab_all, size_t n, E2* __restrict__ partials, DotVirt V) {
     __shared__ E2 sm[TPB / 64];
     const int t0 = blockIdx.y * 8;
     const int ntab = min(8, ntab_all - t0);
     E2 acc[8];
 #pragma unroll
     for (int t = 0; t < 8; t++) acc[t] = e2_zero();
+    if constexpr (VIRT) {
+        for (size_t j = (size_t)blockIdx.x * TPB + threadIdx.x; j < n; j += (size_t)gridDim.x * TPB) {
+            const E2 e = eq[j];
+            u64 v = 0, uses = 0;
+            if (j < V.rows) { const int l = V.seg_lookup[j >> V.seg_shift]; v = V.input[j] & V.lookup_mask[l]; uses = V.lookup_uses[l]; }
+#pragma unroll
+            for (int t = 0; t < 8; t++)
+                if (t < ntab) {
+                    const u64* tab = tabs.t[t0 + t];
+                    u64 x;
+                    if (tab) x = tab[j];
+                    else {
+                        const int m = tabs.emem[t0 + t];
+                        const u32 a = (u32)(v >> (16 * V.mem_dim[m])) & 0xFFFF;
+                        x = ((uses >> m) & 1) && a < V.mem_cutoff[m] ? (u64)a : 0;
+                    }
+                    acc[t] = e2_add(acc[t], e2_mul_f(e, x));
+                }
+        }
+    } else
     if ((n & 1) == 0) {  // two entries per thread: 16-byte table loads
         for (size_t j = ((size_t)blockIdx.x * TPB + threadIdx.x) * 2; j < n; j += (size_t)gridDim.x * TPB * 2) {
             const E2 e0 = eq[j], e1 = eq[j + 1];
@@ -1678,13 +1749,16 @@ __global__ __launch_bounds__(TPB) void k_dot_reduce(const E2* __restrict__ parti
     a = block_sum(a, sm);
     if (threadIdx.x == 0) out[tabs.slot[v]] = a;
 }
-void dot_eq_many(hipStream_t st, const E2* eq, const DotTabs& tabs, int ntab, size_t n, E2* partials, E2* out) {
+void dot_eq_many(hipStream_t st, const E2* eq, const DotTabs& tabs, int ntab, size_t n, E2* partials, E2* out, const DotVirt* virt) {
     if (ntab <= 0) return;
     if (ntab > DOT_MAX) throw std::runtime_error("dot_eq_many: too many tables");
     // (measured slower here: column accumulators - 8 independent 8-byte streams per thread need the occupancy more -
     // and the last-arriving-workgroup reduction - 8 values x 1024 partials)
     const int gx = grid_for((n + 1) / 2);
-    k_dot_eq<<<dim3(gx, (ntab + 7) / 8), TPB, 0, st>>>(eq, tabs, ntab, n, partials);
+    DotVirt V;
+    memset(&V, 0, sizeof(V));
+    if (virt) { V = *virt; k_dot_eq<true><<<dim3(gx, (ntab + 7) / 8), TPB, 0, st>>>(eq, tabs, ntab, n, partials, V); }
+    else k_dot_eq<false><<<dim3(gx, (ntab + 7) / 8), TPB, 0, st>>>(eq, tabs, ntab, n, partials, V);
     k_dot_reduce<<<ntab, TPB, 0, st>>>(partials, gx, ntab, tabs, out);
 }
 void dot_eq(hipStream_t st, const E2* eq, const u64* const tabs[8], int ntab, size_t n, E2* partials, E2* out) {

@@ -44,6 +44,8 @@ struct GpHashMem {
     const u64* ep;       // E_m (2^nu integers)
     int chunk;           // dimension index: which dim / read_ts columns (the counters are indexed by chunk, lasso.rs:317-319)
     int rd_row, wr_row;  // this job's pair indices of the memory's read / write tables (weight pw[row], tables 2 row, 2 row + 1); -1: not held
+    u32 cutoff;          // E_m[j] = (row j's lookup uses memory `mem` and limb < cutoff) ? limb : 0 (k_lasso_split): ep == nullptr means
+    int mem;             // "recompute it from the chunk's limb" (GpHashSrc::seg_lookup ...), the E tables are then never written
 };
 struct GpHashSrc {
     const u64* dim[4];
@@ -51,6 +53,11 @@ struct GpHashSrc {
     const GpHashMem* mems;  // chunk-major (memory-GKR order)
     int nmem;
     u64 gamma, gamma2, tau;
+    // for recomputed E values (GpHashMem::ep == nullptr): LassoDev's row -> lookup map and the lookups' memory masks
+    int seg_shift;
+    size_t rows;
+    const uint8_t* seg_lookup;
+    u64 lookup_uses[32];
 };
 struct StJob {
     const void* in;
@@ -96,7 +103,8 @@ void st_step(hipStream_t st, int kind, bool base, const StJob* jobs, const StIte
              E2* partials, E2* res);
 // first round of ONE grand-product job whose level-0 rows are recomputed from the Lasso integer tables (StJob::hash_src)
 // (`mirror` = the host copy of job->mirror: selects the kernel variant)
-void st_first_hash(hipStream_t st, const StJob* job, const StItem* item, int grid, bool mirror, const E2* chal, E2* partials, E2* res);
+// (`recomp`: the memories' E values are recomputed from the limbs, GpHashMem::ep is not read)
+void st_first_hash(hipStream_t st, const StJob* job, const StItem* item, int grid, bool mirror, bool recomp, const E2* chal, E2* partials, E2* res);
 // fused step (folded Ext2 inputs; grand-product or collation shape): every item runs its job's rounds with half = 2^h_log2 and 2^(h_log2-1)
 void st_step2(hipStream_t st, int kind, const StJob* jobs, const StItem* items, int nitems, int grid, const E2* chal, E2* partials, E2* res);
 // LDS-resident tail (st_tail): every item runs ALL rounds from its `rd` on in one workgroup; st_tail_h(ntab, nvars) = log2 of the
@@ -197,6 +205,8 @@ void lasso_counters_all(hipStream_t st, const LassoDev& L, unsigned chunk_mask, 
 // sum_k eq[k] * sum_i M^i E_{mems(lookup(k))[i]}[k]  -> partials (nv = 1)
 // (memories not held - EpRows::row < 0 - contribute nothing: the ranks' partial claimed sums add up)
 int lasso_claim(hipStream_t st, const LassoDev& L, const E2* eq, const u64* e_polys, const EpRows& rows, E2* partials);
+// ... with the E values recomputed from the node input (no E tables); own = bit mask of the memories whose terms are summed
+int lasso_claim_in(hipStream_t st, const LassoDev& L, const E2* eq, const u64* input, u32 own, E2* partials);
 // multiset hashes h = a + v*gamma + t*gamma^2 - tau
 // for up to HASH_RW_MAX memories of one chunk (shared dim / read_ts columns); n >= 4, a multiple of 4
 // rd1/wr1 (may be null): first product-tree level rd[j]*rd[j+n/2], wr[j]*wr[j+n/2], n/2 entries each
@@ -220,8 +230,13 @@ void gp_top(hipStream_t st, const u64* top, int nb, E2* roots, E2* evals);
 void dot_eq(hipStream_t st, const E2* eq, const u64* const tabs[8], int ntab, size_t n, E2* partials, E2* out);
 // the same for up to DOT_MAX tables in one launch (+ one reduction launch): result t goes to out[tabs.slot[t]]
 constexpr int DOT_MAX = 64;
-struct DotTabs { const u64* t[DOT_MAX]; int slot[DOT_MAX]; };
-void dot_eq_many(hipStream_t st, const E2* eq, const DotTabs& tabs, int ntab, size_t n, E2* partials, E2* out);
+struct DotTabs { const u64* t[DOT_MAX]; int slot[DOT_MAX]; signed char emem[DOT_MAX]; };   // t == nullptr: the E table of memory emem (DotVirt)
+// what recomputing E_m[j] = (row j's lookup uses m and limb < cutoff_m) ? limb : 0 takes (k_lasso_split): the node input and LassoDev's maps
+struct DotVirt {
+    const u64* input; const uint8_t* seg_lookup; int seg_shift; size_t rows;
+    u64 lookup_mask[32]; u64 lookup_uses[32]; int mem_dim[32]; u32 mem_cutoff[32];
+};
+void dot_eq_many(hipStream_t st, const E2* eq, const DotTabs& tabs, int ntab, size_t n, E2* partials, E2* out, const DotVirt* virt = nullptr);
 
 // ---- Vanilla / FFT nodes ----------------------------------------------------------------------
 struct CsrLin { const u32* ptr; const u32* gate; const u64* coef; };           // per input position -> (gate, c)

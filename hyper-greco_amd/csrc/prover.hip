@@ -317,6 +317,7 @@ struct Prover {
 
     // Stride-layout sum-checks (collation, every grand-product layer) are queued as jobs and executed by
     // flush_stride() in a round-synchronised schedule (launch k = every job's next round(s)): they are independent on the device.
+    bool hash_recomp = false;   // the queued hash-source job recomputes its E values (lasso_node: lean form)
     std::vector<dev::StJob> st_jobs;
     // Grand-product jobs whose FIRST round also produces a product-tree level (or reads recomputed hashes) must run one after
     // the other, deepest layer first: job q with st_seq[q] = s > 0 gets its own first-round launch, in ascending s, before
@@ -513,7 +514,7 @@ struct Prover {
                     bytes = round_bytes(it.job, 0, false) + st_fused_bytes[it.job];
                     model = round_bytes(it.job, 0, true) + st_fused_bytes[it.job];
                     ctx->prof_begin(cls_gp_hash, bytes, model);
-                    dev::st_first_hash(st, d_jobs + it.job, d_items + offs[li] + o, grids[li][0], st_jobs[it.job].mirror != 0, ctx->d_chal, partials, d_res());
+                    dev::st_first_hash(st, d_jobs + it.job, d_items + offs[li] + o, grids[li][0], st_jobs[it.job].mirror != 0, hash_recomp, ctx->d_chal, partials, d_res());
                     ctx->prof_end();
                     stamp("first hash round done");
                     continue;
@@ -1038,6 +1039,26 @@ struct Prover {
             for (int m = 0; m < A; m++) if (own_mem[m]) ep_rows_own.row[m] = ep_rows.row[m];
         } else for (int m = 0; m < A; m++) col_mems.push_back(m);
         const bool col_p0_only = split && !own_mem[0];
+        // Lean form (default where the hash-free first round is used, HG_E_TABLES=1 turns it off): the E tables are NOT materialised.
+        // E_m[j] = (row j's lookup uses m and limb < cutoff_m) ? limb : 0 is a select on a limb, so the hash round, the claimed sum and
+        // the E_m(x) openings recompute it and the limb split writes E_0 (the collation sum-check's p_0 table) and C only.
+        bool lean_e = false;
+        {
+            static const bool e_tables = [] { const char* e = getenv("HG_E_TABLES"); return e && e[0] == '1'; }();
+            static const bool hash_fuse_env = [] { const char* e = getenv("HG_NO_HASH_FUSE"); return !(e && e[0] == '1'); }();
+            bool all1 = any_gp1;
+            for (int n = 0; n < nu; n++) all1 = all1 && mine(gp1_owner[n]);
+            const int nrows_ = split ? (int)local_pairs.size() : 2 * G;
+            static const bool emit_on = [] { const char* e = getenv("HG_GP_EMIT"); return !(e && *e) || atoi(e) > 0; }();
+            lean_e = !e_tables && hash_fuse_env && emit_on && all1 && nu >= 12 && nrows_ > (p0_only ? 1 : 0) && A <= 32;   // (= the condition of emit > 0 below)
+        }
+        if (lean_e) {
+            for (int m = 0; m < 32; m++) ep_rows.row[m] = ep_rows_own.row[m] = -1;
+            ep_rows.row[0] = 0;
+            ep_count = 1;
+        }
+        u32 own_mask = 0;
+        for (int m = 0; m < A && m < 32; m++) if (own_mem[m]) own_mask |= 1u << m;
         // polynomialize (lasso.rs:157-250)
         u64* dims = nullptr;
         u64* ep = nullptr;
@@ -1104,7 +1125,8 @@ struct Prover {
         const bool claim_late = use_aux && !col_aux;
         auto do_claim = [&] {
             eq_now(eq, nu, r_off);
-            int grid = dev::lasso_claim(st, L, eq, ep, ep_rows_own, partials);  // sharded: this rank's memories only (partial sum)
+            int grid = lean_e ? dev::lasso_claim_in(st, L, eq, d_input, own_mask, partials)
+                              : dev::lasso_claim(st, L, eq, ep, ep_rows_own, partials);  // sharded: this rank's memories only (partial sum)
             reduce(grid, 1, claim_slot);
         };
         if (do_col && !claim_late) col_where([&] {
@@ -1209,7 +1231,8 @@ struct Prover {
             for (int i = 0; i < G; i++) {  // memory-GKR order is chunk-major
                 dev::GpHashMem m;
                 m.chunk = lp.gkr_chunk[i]; m.rd_row = row_of(i); m.wr_row = row_of(G + i);
-                if (m.rd_row >= 0 || m.wr_row >= 0) { m.ep = epm(lp.gkr_order[i]); hm.push_back(m); }
+                m.mem = lp.gkr_order[i]; m.cutoff = L.mem_cutoff[m.mem];
+                if (m.rd_row >= 0 || m.wr_row >= 0) { m.ep = lean_e ? nullptr : epm(lp.gkr_order[i]); hm.push_back(m); }
             }
             dev::GpHashSrc hs;
             memset(&hs, 0, sizeof(hs));
@@ -1218,6 +1241,9 @@ struct Prover {
             dev::GpHashMem* d_hm = ctx->alloc_n<dev::GpHashMem>(hm.size());
             upload(d_hm, hm.data(), hm.size() * sizeof(dev::GpHashMem), "upload hash sources");
             hs.mems = d_hm; hs.nmem = (int)hm.size(); hs.gamma = gamma; hs.gamma2 = gl_mul(gamma, gamma); hs.tau = tau;
+            hs.seg_shift = L.seg_shift; hs.rows = L.rows; hs.seg_lookup = L.seg_lookup;
+            memcpy(hs.lookup_uses, L.lookup_uses, sizeof(hs.lookup_uses));
+            hash_recomp = lean_e;
             dev::GpHashSrc* d_hs = ctx->alloc_n<dev::GpHashSrc>(1);
             upload(d_hs, &hs, sizeof(hs), "upload hash sources");
             d_hash_src = d_hs;
@@ -1344,7 +1370,10 @@ struct Prover {
                 ty.t[ny] = final_cts[c]; ty.slot[ny] = (int)(base_slot + 2); ny++;
             }
             for (size_t i = 0; i < chk.second.size(); i++)
-                if (do_open && own_mem[chk.second[i]]) add_x(epm(chk.second[i]), base_slot + 3 + i);
+                if (do_open && own_mem[chk.second[i]]) {
+                    if (lean_e) { if (nx >= dev::DOT_MAX) throw Error("lasso: too many openings"); tx.t[nx] = nullptr; tx.emem[nx] = (signed char)chk.second[i]; tx.slot[nx] = (int)(base_slot + 3 + i); nx++; }
+                    else add_x(epm(chk.second[i]), base_slot + 3 + i);
+                }
             chunk_slots.push_back({c, base_slot, 3 + chk.second.size()});
         }
         for (auto& cs : chunk_slots) {
@@ -1361,7 +1390,14 @@ struct Prover {
             }
             if (nx) {
                 ctx->prof_begin(cls_aux, (double)N * (16.0 * ((nx + 7) / 8) + 8.0 * nx));
-                dev::dot_eq_many(st, eqx, tx, nx, N, partials, d_res());
+                dev::DotVirt dv;
+                memset(&dv, 0, sizeof(dv));
+                if (lean_e) {
+                    dv.input = d_input; dv.seg_lookup = L.seg_lookup; dv.seg_shift = L.seg_shift; dv.rows = L.rows;
+                    memcpy(dv.lookup_mask, L.lookup_mask, sizeof(dv.lookup_mask)); memcpy(dv.lookup_uses, L.lookup_uses, sizeof(dv.lookup_uses));
+                    memcpy(dv.mem_dim, L.mem_dim, sizeof(dv.mem_dim)); memcpy(dv.mem_cutoff, L.mem_cutoff, sizeof(dv.mem_cutoff));
+                }
+                dev::dot_eq_many(st, eqx, tx, nx, N, partials, d_res(), lean_e ? &dv : nullptr);
                 ctx->prof_end();
             }
             if (ny) dev::dot_eq_many(st, eqy, ty, ny, M, partials, d_res());
