@@ -1340,8 +1340,9 @@ __global__ __launch_bounds__(TPB) void k_lasso_split(LassoDev L, const u64* __re
     for (size_t j = (size_t)blockIdx.x * TPB + threadIdx.x; j < N; j += (size_t)gridDim.x * TPB) {
         u32 idx[4] = {0, 0, 0, 0};
         u64 uses = 0;
+        int l = -1;
         if (j < L.rows) {
-            int l = L.seg_lookup[j >> L.seg_shift];
+            l = L.seg_lookup[j >> L.seg_shift];
             u64 v = input[j] & L.lookup_mask[l];  // truncate to sum(chunk_bits) (lasso.rs:388-389)
             idx[0] = (u32)(v & 0xFFFF); idx[1] = (u32)((v >> 16) & 0xFFFF);
             idx[2] = (u32)((v >> 32) & 0xFFFF); idx[3] = (u32)((v >> 48) & 0xFFFF);
@@ -1351,15 +1352,24 @@ __global__ __launch_bounds__(TPB) void k_lasso_split(LassoDev L, const u64* __re
 #pragma unroll
             for (int c = 0; c < 4; c++) dims[(size_t)c * N + j] = idx[c];
         }
-        u64 cv = 0;   // sum_m colpow[m] E_m[j]: at most four non-zero terms (the memories of the row's lookup)
+        // C[j] = sum_m colpow[m] E_m[j]: at most four non-zero terms, those of the memories of the row's lookup (whether or not
+        // their tables are materialised)
+        if (col) {
+            u64 cv = 0;
+            if (l >= 0)
+                for (int i = 0; i < L.lookup_nmems[l]; i++) {
+                    const int m = L.lookup_mems[l][i];
+                    const u32 a = idx[L.mem_dim[m]];
+                    if (P.v[m] && ((uses >> m) & 1) && a && a < L.mem_cutoff[m]) cv = gl_add(cv, gl_mul_small(P.v[m], a));
+                }
+            col[j] = cv;
+        }
         for (int m = 0; m < L.alpha; m++) {
-            if (R.row[m] < 0 && !(col && P.v[m])) continue;   // (a memory may enter C without its table being materialised)
+            if (R.row[m] < 0) continue;
             u32 a = idx[L.mem_dim[m]];
             u64 ev = ((uses >> m) & 1) && a < L.mem_cutoff[m] ? (u64)a : 0;  // T_s[a] (range.rs:15-17, 58-72)
-            if (R.row[m] >= 0) e_polys[(size_t)R.row[m] * N + j] = ev;
-            if (col && ev && P.v[m]) cv = gl_add(cv, gl_mul_small(P.v[m], (u32)ev));
+            e_polys[(size_t)R.row[m] * N + j] = ev;
         }
-        if (col) col[j] = cv;
     }
 }
 // the four 16-bit limbs only: the counter sorts need nothing else, so they can start while the E tables are still being written
@@ -1705,14 +1715,12 @@ __global__ __launch_bounds__(TPB) void k_dot_eq(const E2* __restrict__ eq, DotTa
             for (int t = 0; t < 8; t++)
                 if (t < ntab) {
                     const u64* tab = tabs.t[t0 + t];
-                    u64 x;
-                    if (tab) x = tab[j];
+                    if (tab) acc[t] = e2_add(acc[t], e2_mul_f(e, tab[j]));
                     else {
                         const int m = tabs.emem[t0 + t];
                         const u32 a = (u32)(v >> (16 * V.mem_dim[m])) & 0xFFFF;
-                        x = ((uses >> m) & 1) && a < V.mem_cutoff[m] ? (u64)a : 0;
+                        if (((uses >> m) & 1) && a && a < V.mem_cutoff[m]) acc[t] = e2_add(acc[t], e2(gl_mul_small(e.c0, a), gl_mul_small(e.c1, a)));
                     }
-                    acc[t] = e2_add(acc[t], e2_mul_f(e, x));
                 }
         }
     } else

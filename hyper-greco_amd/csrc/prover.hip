@@ -327,6 +327,8 @@ struct Prover {
     std::vector<double> st_fused_bytes;  // algorithmic bytes of the passes a job's first round absorbs (hash build, tree level)
     std::vector<std::function<void()>> st_after_seq;
     double pending_fused_bytes = 0;      // set by the caller right before sc_stride (the hash build a hash-source job absorbs)
+    double pending_fused_model_extra = 0, hash_model_extra = 0;   // ... and what only the reference's traffic model counts of it (E reads)
+    std::vector<double> st_fused_model_extra;
     std::vector<dev::ScatterEnt> scatter;  // locally produced scalars -> global result slots (batch-subset grand products)
 
     ScHandle sc_stride(int kind, const void* in, bool base, size_t in_stride, int ntab, int nvars, const dev::Powers& pw, E2* final_out,
@@ -339,7 +341,7 @@ struct Prover {
         h.sums_slot = slot((size_t)nvars * h.nv);
         const size_t N = (size_t)1 << nvars;
         if (!enqueue) {  // another rank runs this job: transcript bookkeeping only
-            pending_fused_bytes = 0;
+            pending_fused_bytes = 0; pending_fused_model_extra = 0;
             for (int i = 0; i < nvars; i++) h.rs.push_back(squeeze());
             return h;
         }
@@ -364,7 +366,8 @@ struct Prover {
             // it replaces was (round-1 accounting: the totals stay comparable)
             double fused = next_level ? (double)((mirror ? mirror->credit_ntab : ntab) / 2) * (double)(2 * N) * 8.0 * (hash_src ? 0.5 : 1.5) : 0.0;
             st_fused_bytes.push_back(fused + pending_fused_bytes);
-            pending_fused_bytes = 0;
+            st_fused_model_extra.push_back(pending_fused_model_extra);
+            pending_fused_bytes = 0; pending_fused_model_extra = 0;
         }
         return h;
     }
@@ -512,7 +515,7 @@ struct Prover {
                     // algorithmic bytes: the sum-check round plus the passes this launch absorbs - the hash build
                     // (dims, read_ts per chunk; E read, read / write hashes written per memory) and product-tree level 1
                     bytes = round_bytes(it.job, 0, false) + st_fused_bytes[it.job];
-                    model = round_bytes(it.job, 0, true) + st_fused_bytes[it.job];
+                    model = round_bytes(it.job, 0, true) + st_fused_bytes[it.job] + st_fused_model_extra[it.job];
                     ctx->prof_begin(cls_gp_hash, bytes, model);
                     dev::st_first_hash(st, d_jobs + it.job, d_items + offs[li] + o, grids[li][0], st_jobs[it.job].mirror != 0, hash_recomp, ctx->d_chal, partials, d_res());
                     ctx->prof_end();
@@ -555,6 +558,7 @@ struct Prover {
         st_seq.clear();
         st_credit_ntab.clear();
         st_fused_bytes.clear();
+        st_fused_model_extra.clear();
         for (auto& f : st_after_seq) f();  // (no grand-product job was queued: nothing can depend on these, but keep the order)
         st_after_seq.clear();
         if (!scatter.empty()) {
@@ -921,7 +925,7 @@ struct Prover {
             const int seq = n >= nv - emit ? nv - n : 0;                    // first round launched alone, deepest layer first
             u64* nxt = seq ? lev_w[k + 1] : nullptr;                          // ... and writes tree level k + 1
             const dev::GpHashSrc* hs = (hash_src && k == 0) ? hash_src : nullptr;
-            if (hs) pending_fused_bytes = hash_fused_bytes;
+            if (hs) { pending_fused_bytes = hash_fused_bytes; pending_fused_model_extra = hash_model_extra; }
             const bool mirrored = hs && mirror_c;
             if (mirrored) {
                 // Top layer with row b + nb/2 = row b + c for every b < nb/2 (the Lasso write hashes, c = gamma^2): only the read rows
@@ -1052,6 +1056,7 @@ struct Prover {
             static const bool emit_on = [] { const char* e = getenv("HG_GP_EMIT"); return !(e && *e) || atoi(e) > 0; }();
             lean_e = !e_tables && hash_fuse_env && emit_on && all1 && nu >= 12 && nrows_ > (p0_only ? 1 : 0) && A <= 32;   // (= the condition of emit > 0 below)
         }
+        const int ep_count_full = ep_count;   // (what the reference's traffic model writes)
         if (lean_e) {
             for (int m = 0; m < 32; m++) ep_rows.row[m] = ep_rows_own.row[m] = -1;
             ep_rows.row[0] = 0;
@@ -1084,7 +1089,7 @@ struct Prover {
                 ctx->prof_end();
                 hip_check(hipEventRecord(ctx->ev_aux[0], st), "lasso: limbs event");
             }
-            ctx->prof_begin(cls_aux, (double)N * 8 * (1 + (fork_recorded ? 0 : 4) + ep_count + 1));
+            ctx->prof_begin(cls_aux, (double)N * 8 * (1 + (fork_recorded ? 0 : 4) + ep_count + 1), (double)N * 8 * (1 + (fork_recorded ? 0 : 4) + ep_count_full + 1));
             dev::lasso_split(st, L, d_input, fork_recorded ? nullptr : dims, ep, ep_rows, &cp, ep + (size_t)ep_count * N);
             stamp("limb split done");
             ctx->prof_end();
@@ -1253,7 +1258,8 @@ struct Prover {
             for (auto& m : hm) chunk_used[m.chunk] = 1;
             hash_build_bytes = 0;
             for (int c = 0; c < 4; c++) if (chunk_used[c]) hash_build_bytes += (double)N * 8 * 2;
-            for (auto& m : hm) hash_build_bytes += (double)N * 8 * ((m.rd_row >= 0) + (m.wr_row >= 0) + 1);
+            for (auto& m : hm) hash_build_bytes += (double)N * 8 * ((m.rd_row >= 0) + (m.wr_row >= 0) + (lean_e ? 0 : 1));
+            hash_model_extra = lean_e ? (double)N * 8 * (double)hm.size() : 0.0;   // the E reads of the reference's hash build: not streamed here
         }
         u64* H1 = (any_gp1 && !emit) ? ctx->alloc_n<u64>((size_t)nrows * N) : nullptr;
         u64* L1 = (any_gp1 && !emit && gp_deepest(nu, gp1_owner) >= 1) ? ctx->alloc_n<u64>((size_t)nrows * (N / 2)) : nullptr;
@@ -1389,7 +1395,10 @@ struct Prover {
                 eq_now(eqy, 16, g2.point_off);
             }
             if (nx) {
-                ctx->prof_begin(cls_aux, (double)N * (16.0 * ((nx + 7) / 8) + 8.0 * nx));
+                int nvirt = 0;
+                for (int t = 0; t < nx; t++) nvirt += tx.t[t] == nullptr;
+                // (a group of eight re-reads eq; recomputed E tables cost their group one 8-byte input read per entry)
+                ctx->prof_begin(cls_aux, (double)N * (16.0 * ((nx + 7) / 8) + 8.0 * (nx - nvirt) + (nvirt ? 8.0 * ((nx + 7) / 8) : 0.0)));
                 dev::DotVirt dv;
                 memset(&dv, 0, sizeof(dv));
                 if (lean_e) {
