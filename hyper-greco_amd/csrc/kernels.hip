@@ -1336,6 +1336,18 @@ EpRows ep_rows_all(int alpha) {
 }
 __global__ __launch_bounds__(TPB) void k_lasso_split(LassoDev L, const u64* __restrict__ input, u64* __restrict__ dims,
                                                      u64* __restrict__ e_polys, EpRows R, ColPow P, u64* __restrict__ col) {
+    // The per-lookup / per-memory maps go to LDS first: indexed by values that come out of the data, they would otherwise be a chain
+    // of dependent loads from the kernel-argument segment per row (45 us for 50 MB; the kernel sits at the head of the main stream).
+    __shared__ u64 s_mask[32], s_uses[32], s_pv[32];
+    __shared__ u32 s_cut[32];
+    __shared__ int s_nm[32], s_mems[32][4], s_dim[32], s_row[32];
+    if (threadIdx.x < 32) {
+        const int t = threadIdx.x;
+        s_mask[t] = L.lookup_mask[t]; s_uses[t] = L.lookup_uses[t]; s_pv[t] = P.v[t]; s_cut[t] = L.mem_cutoff[t];
+        s_nm[t] = L.lookup_nmems[t]; s_dim[t] = L.mem_dim[t]; s_row[t] = R.row[t];
+        for (int i = 0; i < 4; i++) s_mems[t][i] = L.lookup_mems[t][i];
+    }
+    __syncthreads();
     const size_t N = (size_t)1 << L.nu;
     for (size_t j = (size_t)blockIdx.x * TPB + threadIdx.x; j < N; j += (size_t)gridDim.x * TPB) {
         u32 idx[4] = {0, 0, 0, 0};
@@ -1343,10 +1355,10 @@ __global__ __launch_bounds__(TPB) void k_lasso_split(LassoDev L, const u64* __re
         int l = -1;
         if (j < L.rows) {
             l = L.seg_lookup[j >> L.seg_shift];
-            u64 v = input[j] & L.lookup_mask[l];  // truncate to sum(chunk_bits) (lasso.rs:388-389)
+            u64 v = input[j] & s_mask[l];  // truncate to sum(chunk_bits) (lasso.rs:388-389)
             idx[0] = (u32)(v & 0xFFFF); idx[1] = (u32)((v >> 16) & 0xFFFF);
             idx[2] = (u32)((v >> 32) & 0xFFFF); idx[3] = (u32)((v >> 48) & 0xFFFF);
-            uses = L.lookup_uses[l];
+            uses = s_uses[l];
         }
         if (dims) {
 #pragma unroll
@@ -1357,18 +1369,18 @@ __global__ __launch_bounds__(TPB) void k_lasso_split(LassoDev L, const u64* __re
         if (col) {
             u64 cv = 0;
             if (l >= 0)
-                for (int i = 0; i < L.lookup_nmems[l]; i++) {
-                    const int m = L.lookup_mems[l][i];
-                    const u32 a = idx[L.mem_dim[m]];
-                    if (P.v[m] && ((uses >> m) & 1) && a && a < L.mem_cutoff[m]) cv = gl_add(cv, gl_mul_small(P.v[m], a));
+                for (int i = 0; i < s_nm[l]; i++) {
+                    const int m = s_mems[l][i];
+                    const u32 a = idx[s_dim[m]];
+                    if (s_pv[m] && ((uses >> m) & 1) && a && a < s_cut[m]) cv = gl_add(cv, gl_mul_small(s_pv[m], a));
                 }
             col[j] = cv;
         }
         for (int m = 0; m < L.alpha; m++) {
-            if (R.row[m] < 0) continue;
-            u32 a = idx[L.mem_dim[m]];
-            u64 ev = ((uses >> m) & 1) && a < L.mem_cutoff[m] ? (u64)a : 0;  // T_s[a] (range.rs:15-17, 58-72)
-            e_polys[(size_t)R.row[m] * N + j] = ev;
+            if (s_row[m] < 0) continue;
+            u32 a = idx[s_dim[m]];
+            u64 ev = ((uses >> m) & 1) && a < s_cut[m] ? (u64)a : 0;  // T_s[a] (range.rs:15-17, 58-72)
+            e_polys[(size_t)s_row[m] * N + j] = ev;
         }
     }
 }
