@@ -1398,7 +1398,8 @@ struct Prover {
                 int nvirt = 0;
                 for (int t = 0; t < nx; t++) nvirt += tx.t[t] == nullptr;
                 // (a group of eight re-reads eq; recomputed E tables cost their group one 8-byte input read per entry)
-                ctx->prof_begin(cls_aux, (double)N * (16.0 * ((nx + 7) / 8) + 8.0 * (nx - nvirt) + (nvirt ? 8.0 * ((nx + 7) / 8) : 0.0)));
+                ctx->prof_begin(cls_aux, (double)N * (16.0 * ((nx + 7) / 8) + 8.0 * (nx - nvirt) + (nvirt ? 8.0 * ((nx + 7) / 8) : 0.0)),
+                                (double)N * (16.0 * ((nx + 7) / 8) + 8.0 * nx));   // (reference model: every opened table is read)
                 dev::DotVirt dv;
                 memset(&dv, 0, sizeof(dv));
                 if (lean_e) {
