@@ -419,6 +419,35 @@ def test_launch_graph_that_replays_slower_than_plain_launches_is_given_up():
     assert r.returncode == 0 and r.stderr.count("hipGraphLaunch:") == 10, r.stderr[-2000:]   # the guard leaves a healthy graph alone
 
 
+@pytest.mark.parametrize("switch", ["HG_E_TABLES=1", "HG_NO_MIRROR=1", "HG_NO_HASH_FUSE=1", "HG_ONE_STREAM=1", "HG_NO_GRAPH=1", "HG_TAIL_H=4",
+                                    "HG_NO_LEVEL3=1", "HG_GRAPH_UPLOADS=1", "HG_LASSO_SCHED=2", "HG_NO_FUSE2=1"])
+def test_alternative_paths_behind_the_environment_switches_stay_bit_exact(switch):
+    """Every switch that selects an older or alternative device path (E tables materialised, both rows of the top layer, hash tables,
+    one stream, plain launches, the five-round tail, one tree level per launch, upload nodes in the graph, collation on the second
+    stream, single-round launches) must produce the same bytes as the oracle. The library reads them once per process: child process,
+    five resident proves (walks, capture, replays) plus a four-rank sharded proof at n=4096 k=2."""
+    import subprocess, sys
+    from hglib import ROOT
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "import __graft_entry__ as entry\n"
+        "import orclib\n"
+        "hg = entry.load_package()\n"
+        "ctx = hg.Context(0); bfv = hg.BfvEncrypt.new(4096, 2); pk = bfv.setup(ctx)\n"
+        "w = hg.Witness.synthetic(bfv.params, 21); v = hg.witness_gen(ctx, pk, w); out = hg.ProofBuffer()\n"
+        "ref, _ = orclib.prove(orclib.params(4096, 2), orclib.Inputs(w.arrays()), threads=4)\n"
+        "for i in range(5): assert hg.prove_resident(ctx, pk, v, out).bytes() == ref, i\n"
+        "parts = [np.array(hg.prove_shard_begin(ctx, pk, v, r, 4), copy=True) for r in range(4)]\n"
+        "hg.prove_shard_combine(ctx, np.stack(parts), 4)\n"
+        "assert hg.prove_shard_finish(ctx, out).bytes() == ref\n"
+        "print('SWITCH OK')\n"
+    ) % (ROOT, os.path.join(ROOT, "tests"))
+    name, value = switch.split("=")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **{name: value}), cwd=ROOT)
+    assert r.returncode == 0 and "SWITCH OK" in r.stdout, (switch, r.stdout[-500:], r.stderr[-2000:])
+
+
 def test_library_collective_single_rank_communicator(ctx):
     """hg_comm_init / hg_prove_sharded with a one-rank RCCL communicator (the only size a one-GPU box offers): the limb-split
     kernel, ncclAllReduce on the prover stream and the fold-back kernel run for real and must leave the proof unchanged."""
