@@ -38,7 +38,7 @@ class HgKernelStat(C.Structure):
 EXPORTS = [
     "hg_last_error", "hg_device_count", "hg_create", "hg_destroy", "hg_set_option", "hg_params_builtin", "hg_params_derive", "hg_grand_product", "hg_fold", "hg_setup", "hg_pk_free",
     "hg_pk_lasso_layout", "hg_pk_info", "hg_witness_from_json", "hg_witness_synthetic", "hg_witness_from_arrays",
-    "hg_witness_get", "hg_witness_free", "hg_prove", "hg_verify", "hg_prove_mode", "hg_prove_resident_mode", "hg_verify_mode", "hg_witness_gen", "hg_values_free", "hg_values_get", "hg_comm_unique_id", "hg_comm_init", "hg_comm_destroy", "hg_prove_sharded", "hg_prove_shard_begin", "hg_prove_shard_combine", "hg_prove_shard_finish", "hg_prove_resident", "hg_circuit_eval", "hg_lasso_prove", "hg_lasso_prove_at", "hg_lasso_num_challenges", "hg_sumcheck", "hg_mle_eval",
+    "hg_witness_get", "hg_witness_free", "hg_prove", "hg_verify", "hg_prove_mode", "hg_prove_resident_mode", "hg_verify_mode", "hg_witness_gen", "hg_witness_gen_into", "hg_values_free", "hg_values_get", "hg_comm_unique_id", "hg_comm_init", "hg_comm_destroy", "hg_prove_sharded", "hg_prove_shard_begin", "hg_prove_shard_combine", "hg_prove_shard_finish", "hg_prove_resident", "hg_circuit_eval", "hg_lasso_prove", "hg_lasso_prove_at", "hg_lasso_num_challenges", "hg_sumcheck", "hg_mle_eval",
     "hg_ntt", "hg_challenges", "hg_challenges_bn254", "hg_bn254_field_op", "hg_sumcheck_bn254", "hg_grand_product_bn254", "hg_lasso_prove_bn254", "hg_witness_from_json_bn254", "hg_circuit_eval_bn254", "hg_prove_bn254", "hg_verify_bn254", "hg_mle_eval_bn254", "hg_ntt_bn254", "hg_profile", "hg_profile_select", "hg_profile_reset", "hg_profile_get",
 ]
 
@@ -77,6 +77,7 @@ def lib():
         L.hg_witness_free.argtypes = [C.c_void_p]
         L.hg_prove.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(HgTimings)]
         L.hg_witness_gen.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(HgTimings)]
+        L.hg_witness_gen_into.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(HgTimings)]
         L.hg_values_free.argtypes = [C.c_void_p]
         L.hg_values_get.restype = C.c_int64
         L.hg_values_get.argtypes = [C.c_void_p, C.c_void_p, C.c_int, u64p, C.c_size_t]
@@ -441,6 +442,15 @@ def witness_gen(ctx, pk, witness):
     tm = HgTimings()
     _check(lib().hg_witness_gen(ctx.h, pk.h, witness.h, C.byref(h), C.byref(tm)))
     return ResidentValues(h, {f: getattr(tm, f) for f, _ in HgTimings._fields_})
+
+
+def witness_gen_into(ctx, pk, witness, values):
+    """hg_witness_gen_into: circuit.evaluate() of another witness into the SAME resident tables (the launch graph recorded for
+    `values` stays valid)."""
+    tm = HgTimings()
+    _check(lib().hg_witness_gen_into(ctx.h, pk.h, witness.h, values.h, C.byref(tm)))
+    values.timings = {f: getattr(tm, f) for f, _ in HgTimings._fields_}
+    return values
 
 
 class ProofBuffer:

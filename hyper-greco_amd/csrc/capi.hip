@@ -117,6 +117,7 @@ hg_ctx* hg_create(int device_id) {
     c->stage_cap = (size_t)4 << 20;
     hip_check(hipHostMalloc((void**)&c->h_stage, c->stage_cap, hipHostMallocDefault), "hipHostMalloc(staging)");
     c->ensure_chain(16384);
+    ctx_register(c, true);
     return c;
     HG_CATCH(nullptr)
 }
@@ -127,7 +128,7 @@ int hg_set_option(hg_ctx* ctx, const char* name, int64_t value) {
     HG_TRY
     if (!ctx || !name) throw Error("hg_set_option: null argument");
     const std::string n(name);
-    if (n == "one_stream") ctx->one_stream = value != 0;
+    if (n == "one_stream") { if (ctx->one_stream != (value != 0)) ctx->walk_counts.clear(); ctx->one_stream = value != 0; }
     else if (n == "graph") { ctx->use_graph = value != 0; if (!ctx->use_graph) prove_cache_drop(ctx); }
     else throw Error("hg_set_option: unknown option " + n);
     return 0;
@@ -368,6 +369,17 @@ int hg_witness_gen(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, hg_values*
     HG_CATCH(-1)
 }
 
+int hg_witness_gen_into(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, hg_values* v, hg_timings* timings) {
+    HG_TRY
+    if (!ctx || !pk || !w || !v || !pk->ctx) throw Error("hg_witness_gen_into: needs a device context, a device prover key and an existing values object");
+    check_witness(pk, w, "hg_witness_gen_into");
+    double wm = 0, um = 0;
+    witness_gen_into(ctx, pk, w->w, v, &wm, &um);
+    if (timings) { memset(timings, 0, sizeof(*timings)); timings->witness_ms = wm; timings->upload_ms = um; }
+    return 0;
+    HG_CATCH(-1)
+}
+
 void hg_values_free(hg_values* v) { values_free(v); }
 
 int64_t hg_values_get(hg_ctx* ctx, const hg_values* v, int node, uint64_t* out, size_t cap) {
@@ -469,10 +481,12 @@ int hg_prove(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, uint8_t* proof, 
     check_witness(pk, w, "hg_prove");
     double t0 = now_ms_capi();
     double wm = 0, um = 0;
-    hg_values* v = witness_gen(ctx, pk, w->w, &wm, &um);
-    ProveResult r;
-    try { r = prove_resident(ctx, pk, v); } catch (...) { values_free(v); throw; }
-    values_free(v);
+    // the node tables live in a values object owned by the context and are refilled in place, so the launch graph recorded for
+    // them (third hg_prove with one key) proves every later witness without a protocol walk
+    if (ctx->scratch_values && ctx->scratch_serial != pk->serial) { values_free(ctx->scratch_values); ctx->scratch_values = nullptr; }
+    if (!ctx->scratch_values) { ctx->scratch_values = witness_gen(ctx, pk, w->w, &wm, &um); ctx->scratch_serial = pk->serial; }
+    else witness_gen_into(ctx, pk, w->w, ctx->scratch_values, &wm, &um);
+    ProveResult r = prove_resident(ctx, pk, ctx->scratch_values);
     if (timings) { timings->witness_ms = wm; timings->upload_ms = um; timings->prove_ms = r.prove_ms; timings->gpu_ms = r.gpu_ms; timings->total_ms = now_ms_capi() - t0; timings->enqueue_ms = r.enqueue_ms; timings->sync_ms = r.sync_ms; timings->replay_ms = r.replay_ms; }
     *len = r.proof.size();
     if (r.proof.size() > cap) throw Error("proof buffer too small");

@@ -408,6 +408,9 @@ __device__ __forceinline__ void finish_partials(E2* p, int per, unsigned* ticket
     __shared__ unsigned s_last;
     if (nblocks < 0) nblocks = (int)gridDim.x;
     if (threadIdx.x == 0) {
+#if !defined(HG_STRICT_TICKETS) && defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "the vmcnt-ordered ticket below is only valid on gfx942 / gfx950 (stores tracked by vmcnt, sc1 stores written through); build other architectures with -DHG_STRICT_TICKETS"
+#endif
 #ifdef HG_STRICT_TICKETS
         // C++-memory-model form: release on the ticket (pairs with the last arriver's acquire). On gfx950 an agent-scope
         // release is `buffer_wbl2 sc1` - a write-back of every dirty line of this XCD's L2, i.e. of the folded tables this very

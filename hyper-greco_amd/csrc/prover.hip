@@ -1,5 +1,6 @@
 #include "prover.hpp"
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -29,6 +30,7 @@ void* hg_ctx::alloc(size_t bytes) {
     auto note = [this] { size_t u = 0; for (auto& c : chunks) u += c.used; arena_high = std::max(arena_high, u); };
     for (auto& c : chunks)
         if (c.cap - c.used >= bytes) { void* p = c.p + c.used; c.used += bytes; c.high = std::max(c.high, c.used); note(); return p; }
+    if (arena_fixed) throw Error("arena: a recorded prove needs more workspace than the walked prove it follows");
     size_t cap = std::max<size_t>(bytes, (size_t)512 << 20);
     char* p = nullptr;
     hip_check(hipMalloc((void**)&p, cap), "hipMalloc(arena chunk)");
@@ -114,7 +116,10 @@ void hg_ctx::prof_collect() {
 }
 hg_ctx::~hg_ctx() {
     if (stream) (void)hipStreamSynchronize(stream);
+    hg::ctx_register(this, false);
+    hg::pending_shard_drop(this);
     hg::prove_cache_drop(this);
+    if (scratch_values) hg::values_free(scratch_values);
     for (auto& c : chunks) (void)hipFree(c.p);
     if (d_chal) (void)hipFree(d_chal);
     if (d_res && d_res != h_res) (void)hipFree(d_res);
@@ -1706,35 +1711,61 @@ struct Prover {
 };
 
 // ------------------------------------------------------------------------------------------------
-hg_values* witness_gen(hg_ctx* ctx, const hg_pk* pk, const Witness& w, double* witness_ms, double* upload_ms) {
-    // Circuit::evaluate on the device: inputs are uploaded, then the circuit is evaluated level by level
-    // (Vanilla nodes: gate-major kernel; FFT nodes: batched NTTs, same level + direction in one batch).
+// Lays out the node tables of `pk`'s circuit in ONE allocation (plus the NTT scratch): hg_values without contents.
+static hg_values* values_alloc(hg_ctx* ctx, const hg_pk* pk) {
     hip_check(hipSetDevice(ctx->device), "hipSetDevice");
     const HCircuit& c = pk->circuit;
     const Params& p = pk->params;
     const size_t nn = c.nodes.size();
-    double t0 = wall_ms();
-    std::vector<int> level(nn, 0);
-    int maxl = 0;
-    for (int id : c.topo) { for (int pr : c.nodes[id].preds) level[id] = std::max(level[id], level[pr] + 1); maxl = std::max(maxl, level[id]); }
     struct ValuesDeleter { void operator()(hg_values* p) const { values_free(p); } };
     std::unique_ptr<hg_values, ValuesDeleter> v(new hg_values());
+    static std::atomic<uint64_t> next_serial{1};
+    v->serial = next_serial++;
+    v->pk_serial = pk->serial;
+    v->device = ctx->device;
+    v->ctx = ctx;
+    v->level.assign(nn, 0);
+    for (int id : c.topo) { for (int pr : c.nodes[id].preds) v->level[id] = std::max(v->level[id], v->level[pr] + 1); v->max_level = std::max(v->max_level, v->level[id]); }
     v->d_vals.assign(nn, nullptr);
     v->sizes.assign(nn, 0);
     // layout: FFT nodes of one (level, direction) group are contiguous so that one batched NTT covers the group
-    std::vector<int> order(nn);
-    for (size_t i = 0; i < nn; i++) order[i] = (int)i;
+    v->order.resize(nn);
+    for (size_t i = 0; i < nn; i++) v->order[i] = (int)i;
+    const std::vector<int>& level = v->level;
     auto key = [&](int id) { const HNode& n = c.nodes[id]; return std::make_tuple(n.kind == NK_FFT ? 1 : 0, level[id], n.inverse ? 1 : 0, id); };
-    std::sort(order.begin(), order.end(), [&](int a, int b) { return key(a) < key(b); });
-    size_t total = w.ct0is.size();
+    std::sort(v->order.begin(), v->order.end(), [&](int a, int b) { return key(a) < key(b); });
+    v->ct0is_len = (size_t)p.k * p.SZ();
+    size_t total = v->ct0is_len;
     for (size_t id = 0; id < nn; id++) { v->sizes[id] = (size_t)1 << c.nodes[id].log2_out(); total += v->sizes[id]; }
     u64* base = nullptr;
     hip_check(hipMalloc((void**)&base, total * 8), "hipMalloc(node values)");
     v->owned.push_back(base);
     size_t off = 0;
-    std::vector<u64*> dv(nn);
-    for (int id : order) { dv[id] = base + off; v->d_vals[id] = dv[id]; off += v->sizes[id]; }
+    for (int id : v->order) { v->d_vals[id] = base + off; off += v->sizes[id]; }
     v->d_ct0is = base + off;
+    size_t max_fft = 0;
+    {
+        std::map<std::pair<int, int>, size_t> grp_sz;
+        for (size_t id = 0; id < nn; id++) if (c.nodes[id].kind == NK_FFT) grp_sz[{level[id], (int)c.nodes[id].inverse}] += v->sizes[id];
+        for (auto& kv : grp_sz) max_fft = std::max(max_fft, kv.second);
+    }
+    if (max_fft) { hip_check(hipMalloc((void**)&v->ntt_scratch, max_fft * 8), "hipMalloc(ntt scratch)"); v->owned.push_back(v->ntt_scratch); }
+    return v.release();
+}
+
+void witness_gen_into(hg_ctx* ctx, const hg_pk* pk, const Witness& w, hg_values* v, double* witness_ms, double* upload_ms) {
+    // Circuit::evaluate on the device: inputs are uploaded, then the circuit is evaluated level by level
+    // (Vanilla nodes: gate-major kernel; FFT nodes: batched NTTs, same level + direction in one batch).
+    // Every table keeps its address: a launch graph recorded for `v` proves the new witness as it is (the launch sequence of a
+    // prove depends on addresses only).
+    if (!v || v->pk_serial != pk->serial) throw Error("witness generation: the values object was laid out for another prover key");
+    if (v->device != ctx->device) throw Error("witness generation: the values object lives on another device");
+    hip_check(hipSetDevice(ctx->device), "hipSetDevice");
+    const HCircuit& c = pk->circuit;
+    const Params& p = pk->params;
+    if (w.ct0is.size() != v->ct0is_len) throw Error("circuit: ct0is size mismatch");
+    double t0 = wall_ms();
+    auto dv = [&](int id) { return const_cast<u64*>(v->d_vals[id]); };
     hipStream_t st = ctx->stream;
     {   // inputs in NodeId order: s, e, k1, ais.., r1is.., r2is (chain_par! sk_encryption_circuit.rs:408)
         const size_t SZ = p.SZ();
@@ -1742,62 +1773,72 @@ hg_values* witness_gen(hg_ctx* ctx, const hg_pk* pk, const Witness& w, double* w
         auto put = [&](const u64* src, size_t len) {
             int id = c.input_ids.at(idx++);
             if (len != v->sizes[id]) throw Error("circuit: input size mismatch");
-            hip_check(hipMemcpyAsync(dv[id], src, len * 8, hipMemcpyHostToDevice, st), "upload input");
+            hip_check(hipMemcpyAsync(dv(id), src, len * 8, hipMemcpyHostToDevice, st), "upload input");
         };
         put(w.s.data(), SZ); put(w.e.data(), SZ); put(w.k1.data(), SZ);
         for (int i = 0; i < p.k; i++) put(&w.ais[i * SZ], SZ);
         for (int i = 0; i < p.k; i++) put(&w.r1is[i * SZ], SZ);
         put(w.r2is.data(), w.r2is.size());
-        hip_check(hipMemcpyAsync(base + off, w.ct0is.data(), w.ct0is.size() * 8, hipMemcpyHostToDevice, st), "upload ct0is");
+        hip_check(hipMemcpyAsync(const_cast<u64*>(v->d_ct0is), w.ct0is.data(), w.ct0is.size() * 8, hipMemcpyHostToDevice, st), "upload ct0is");
     }
-    hip_check(hipStreamSynchronize(st), "upload sync");
+    if (upload_ms) hip_check(hipStreamSynchronize(st), "upload sync");   // (only to split the two timings)
     double t1 = wall_ms();
-    size_t max_fft = 0;
-    {
-        std::map<std::pair<int, int>, size_t> grp_sz;
-        for (size_t id = 0; id < nn; id++) if (c.nodes[id].kind == NK_FFT) grp_sz[{level[id], (int)c.nodes[id].inverse}] += v->sizes[id];
-        for (auto& kv : grp_sz) max_fft = std::max(max_fft, kv.second);
-    }
-    u64* ntt_scratch = nullptr;
-    if (max_fft) { hip_check(hipMalloc((void**)&ntt_scratch, max_fft * 8), "hipMalloc(ntt scratch)"); v->owned.push_back(ntt_scratch); }
-    for (int l = 1; l <= maxl; l++) {
+    for (int l = 1; l <= v->max_level; l++) {
         for (int inv = 0; inv < 2; inv++) {  // FFT groups
             std::vector<int> grp;
-            for (int id : order) if (c.nodes[id].kind == NK_FFT && level[id] == l && (int)c.nodes[id].inverse == inv) grp.push_back(id);
+            for (int id : v->order) if (c.nodes[id].kind == NK_FFT && v->level[id] == l && (int)c.nodes[id].inverse == inv) grp.push_back(id);
             if (grp.empty()) continue;
             const int L = c.nodes[grp[0]].log2_size;
             const size_t N = (size_t)1 << L;
             for (int id : grp) {
                 if (c.nodes[id].log2_size != L) throw Error("circuit: mixed FFT sizes in one level");
-                hip_check(hipMemcpyAsync(dv[id], dv[c.nodes[id].preds[0]], N * 8, hipMemcpyDeviceToDevice, st), "copy fft input");
+                hip_check(hipMemcpyAsync(dv(id), dv(c.nodes[id].preds[0]), N * 8, hipMemcpyDeviceToDevice, st), "copy fft input");
             }
             const u64* W = (inv ? pk->w_inv : pk->w_fwd).at(L);
-            dev::ntt_batch(st, dv[grp[0]], L, grp.size(), W, inv ? gl_inv(gl_from_u64(N)) : 1, ntt_scratch);
+            dev::ntt_batch(st, dv(grp[0]), L, grp.size(), W, inv ? gl_inv(gl_from_u64(N)) : 1, v->ntt_scratch);
         }
         for (int id : c.topo) {
             const HNode& n = c.nodes[id];
-            if (level[id] != l) continue;
+            if (v->level[id] != l) continue;
             if (n.kind == NK_VANILLA) {
                 dev::EvalNode e = pk->node_dev[id].fwd;
-                for (int i = 0; i < n.arity; i++) e.in[i] = dv[n.preds[i]];
-                e.out = dv[id];
+                for (int i = 0; i < n.arity; i++) e.in[i] = dv(n.preds[i]);
+                e.out = dv(id);
                 dev::gate_eval(st, e);
             } else if (n.kind == NK_LASSO) {
-                hip_check(hipMemsetAsync(dv[id], 0, 8, st), "lasso output");  // LassoNode::evaluate returns [0] (lasso.rs:53-55)
+                hip_check(hipMemsetAsync(dv(id), 0, 8, st), "lasso output");  // LassoNode::evaluate returns [0] (lasso.rs:53-55)
             }
         }
     }
     hip_check(hipStreamSynchronize(st), "witness generation sync");
-    if (ntt_scratch) { (void)hipFree(ntt_scratch); v->owned.pop_back(); }
     hip_check(hipGetLastError(), "witness generation");
     double t2 = wall_ms();
     if (upload_ms) *upload_ms = t1 - t0;
     if (witness_ms) *witness_ms = t2 - t1;
-    return v.release();
 }
+
+hg_values* witness_gen(hg_ctx* ctx, const hg_pk* pk, const Witness& w, double* witness_ms, double* upload_ms) {
+    hg_values* v = values_alloc(ctx, pk);
+    try { witness_gen_into(ctx, pk, w, v, witness_ms, upload_ms); } catch (...) { values_free(v); throw; }
+    return v;
+}
+
+// contexts alive in this process: a values object that is freed tells its context to drop the launch graphs recorded for it
+static std::mutex g_live_mu;
+static std::vector<hg_ctx*> g_live_ctx;
+void ctx_register(hg_ctx* ctx, bool alive) {
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    g_live_ctx.erase(std::remove(g_live_ctx.begin(), g_live_ctx.end(), ctx), g_live_ctx.end());
+    if (alive) g_live_ctx.push_back(ctx);
+}
+void prove_cache_forget_values(hg_ctx* ctx, uint64_t values_serial);
 
 void values_free(hg_values* v) {
     if (!v) return;
+    {
+        std::lock_guard<std::mutex> lk(g_live_mu);
+        for (hg_ctx* c : g_live_ctx) if (c == v->ctx) prove_cache_forget_values(c, v->serial);
+    }
     for (void* p : v->owned) (void)hipFree(p);
     delete v;
 }
@@ -1832,6 +1873,23 @@ static void enqueue_prove(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, Prov
     if (exchange) comm_allreduce_results(ctx, P->res_used);  // the one collective of a sharded proof, on the stream
 }
 
+// ---- walk bookkeeping: which (key, values object, share) has been proven by plain launches how often -----------------------------
+static hg_ctx::WalkCount* walk_find(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int share) {
+    for (auto& wc : ctx->walk_counts) if (wc.pk_serial == pk->serial && wc.values_serial == v->serial && wc.share == share) return &wc;
+    return nullptr;
+}
+static void walk_note(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int share, size_t arena_bytes, float gpu_ms) {
+    hg_ctx::WalkCount* wc = walk_find(ctx, pk, v, share);
+    if (!wc) {
+        if (ctx->walk_counts.size() >= 64) ctx->walk_counts.erase(ctx->walk_counts.begin());   // (values objects come and go)
+        ctx->walk_counts.push_back(hg_ctx::WalkCount{pk->serial, v->serial, share, 0, 0, 0.f});
+        wc = &ctx->walk_counts.back();
+    }
+    wc->walks++;
+    wc->arena_bytes = std::max(wc->arena_bytes, arena_bytes);
+    wc->gpu_ms = gpu_ms;
+}
+
 // enqueue + synchronise this rank's share of one proof; leaves the (partial) result buffer in ctx->h_res
 static std::unique_ptr<Prover> prove_begin(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int rank, int world, double* t_start, float* gpu_ms,
                                            bool exchange = false) {
@@ -1850,34 +1908,78 @@ static std::unique_ptr<Prover> prove_begin(hg_ctx* ctx, const hg_pk* pk, const h
     (void)hipEventElapsedTime(gpu_ms, ev_a, ev_b);
     (void)hipEventDestroy(ev_a); (void)hipEventDestroy(ev_b);
     ctx->last_walk_gpu_ms = *gpu_ms;
+    size_t used = 0;
+    for (auto& c : ctx->chunks) used += c.high;
+    walk_note(ctx, pk, v, rank * 65536 + world, used, *gpu_ms);
     return P;
 }
 
-// ---- cached launch graph (hg_ctx::prove_cache) ---------------------------------------------------------------------------
+// ---- cached launch graphs (hg_ctx::prove_cache) --------------------------------------------------------------------------------
+// One entry per (key, values object, share, stream option). An entry owns the hipGraph, the Prover whose transcript steps are
+// replayed on the host after each launch, and a PRIVATE arena the recorded kernels work in - so nothing else that happens on the
+// context (witness generation, other keys, kernel-level entry points) touches what a replay reads, and several entries coexist.
+// The tables of the values object are referenced by address: hg_witness_gen_into refills them in place and the same graph then
+// proves the new witness (no launch parameter, descriptor or grid size depends on table CONTENTS; tests/test_gpu_parity.py
+// test_graph_replay_across_witnesses checks it against the oracle).
 struct ProveCache {
     std::unique_ptr<Prover> P;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
-    const hg_pk* pk = nullptr;
-    uint64_t pk_serial = 0;
-    std::vector<const u64*> d_vals;
-    const u64* d_ct0is = nullptr;
+    uint64_t pk_serial = 0, values_serial = 0;
     bool one_stream = false;
-    uint64_t epoch = 0;
     int rank = 0, world = 1;   // a sharded proof's graph holds this rank's share; the all-reduce follows the replay on the stream
     float walk_gpu_ms = 0;     // GPU time of the walked prove that preceded the capture
     int replays = 0, slow_replays = 0;
+    uint64_t last_use = 0;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    char* arena = nullptr;     // private workspace of the recorded launches
+    size_t arena_cap = 0;
+    int device = 0;
     ~ProveCache() {
+        (void)hipSetDevice(device);
+        (void)hipDeviceSynchronize();   // (a replay may still be in flight when a context is torn down after an error)
         if (exec) (void)hipGraphExecDestroy(exec);
         if (graph) (void)hipGraphDestroy(graph);
         if (ev_a) (void)hipEventDestroy(ev_a);
         if (ev_b) (void)hipEventDestroy(ev_b);
+        if (arena) (void)hipFree(arena);
     }
 };
+struct ProveCacheSet {
+    std::vector<std::shared_ptr<ProveCache>> entries;
+    uint64_t clock = 0;
+};
+static size_t cache_max_entries() {
+    static const size_t n = [] { const char* e = getenv("HG_GRAPH_ENTRIES"); long v = e && *e ? atol(e) : 8; return (size_t)std::max(1L, std::min(64L, v)); }();
+    return n;
+}
 void prove_cache_drop(hg_ctx* ctx) {
-    delete static_cast<ProveCache*>(ctx->prove_cache);
+    delete static_cast<ProveCacheSet*>(ctx->prove_cache);
     ctx->prove_cache = nullptr;
+}
+static ProveCacheSet* cache_set(hg_ctx* ctx) {
+    if (!ctx->prove_cache) ctx->prove_cache = new ProveCacheSet();
+    return static_cast<ProveCacheSet*>(ctx->prove_cache);
+}
+static std::shared_ptr<ProveCache> cache_find(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int rank, int world) {
+    if (!ctx->prove_cache) return nullptr;
+    ProveCacheSet* S = static_cast<ProveCacheSet*>(ctx->prove_cache);
+    for (auto& e : S->entries)
+        if (e->pk_serial == pk->serial && e->values_serial == v->serial && e->one_stream == ctx->one_stream && e->rank == rank && e->world == world) {
+            e->last_use = ++S->clock;
+            return e;
+        }
+    return nullptr;
+}
+static void cache_erase(hg_ctx* ctx, const ProveCache* C) {
+    if (!ctx->prove_cache) return;
+    auto& es = static_cast<ProveCacheSet*>(ctx->prove_cache)->entries;
+    es.erase(std::remove_if(es.begin(), es.end(), [C](const std::shared_ptr<ProveCache>& e) { return e.get() == C; }), es.end());
+}
+void prove_cache_forget_values(hg_ctx* ctx, uint64_t values_serial) {
+    if (!ctx->prove_cache) return;
+    auto& es = static_cast<ProveCacheSet*>(ctx->prove_cache)->entries;
+    es.erase(std::remove_if(es.begin(), es.end(), [values_serial](const std::shared_ptr<ProveCache>& e) { return e->values_serial == values_serial; }), es.end());
 }
 static bool graph_allowed(const hg_ctx* ctx) {
     static const bool off = [] { const char* e = getenv("HG_NO_GRAPH"); return e && e[0] == '1'; }();
@@ -1887,6 +1989,7 @@ static bool graph_allowed(const hg_ctx* ctx) {
 static ProveResult prove_from_cache(hg_ctx* ctx, ProveCache* C, bool exchange = false, bool replay_now = true) {
     ProveResult res;
     const double t0 = wall_ms();
+    hip_check(hipSetDevice(ctx->device), "hipSetDevice");
     hip_check(hipEventRecord(C->ev_a, ctx->stream), "event record");
     static const bool time_launch = getenv("HG_TIME_LAUNCH") != nullptr;   // (debugging aid: host time of the graph launch call)
     const double tl0 = time_launch ? wall_ms() : 0;
@@ -1919,68 +2022,100 @@ static ProveResult prove_from_cache(hg_ctx* ctx, ProveCache* C, bool exchange = 
     res.proof = P->proof.bytes;
     return res;
 }
-// records the whole enqueue into a graph (no kernel runs during the capture), instantiates it, then proves through it
-static ProveResult prove_capture(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int rank = 0, int world = 1, bool exchange = false, bool replay_now = true) {
+// records the whole enqueue into a graph (no kernel runs during the capture) whose kernels work in a private arena, instantiates it
+static std::shared_ptr<ProveCache> prove_capture(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int rank, int world, const hg_ctx::WalkCount& wc) {
     hip_check(hipSetDevice(ctx->device), "hipSetDevice");
-    prove_cache_drop(ctx);
-    ctx->arena_reset();
     ctx->ensure_chain(16384);  // (may allocate and copy synchronously: not allowed once the capture has begun)
-    std::unique_ptr<ProveCache> C(new ProveCache());
-    hip_check(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
+    std::shared_ptr<ProveCache> C(new ProveCache());
+    C->device = ctx->device;
+    C->arena_cap = wc.arena_bytes + ((size_t)1 << 20);
+    hip_check(hipMalloc((void**)&C->arena, C->arena_cap), "hipMalloc(private arena of a launch graph)");
+    // the context's arena steps aside while the prove is recorded: every buffer the recorded kernels use comes from C->arena
+    std::vector<hg_ctx::Chunk> saved_chunks;
+    saved_chunks.swap(ctx->chunks);
+    const size_t saved_high = ctx->arena_high, saved_total = ctx->arena_total;
+    ctx->chunks.push_back(hg_ctx::Chunk{C->arena, C->arena_cap, 0, 0});
+    ctx->arena_fixed = true;
+    ctx->stage_used = 0;
+    auto restore = [&] {
+        ctx->arena_fixed = false;
+        ctx->chunks.swap(saved_chunks);
+        ctx->arena_high = saved_high; ctx->arena_total = saved_total;
+        ctx->arena_epoch++;
+    };
+    bool capturing = false;
     try {
+        hip_check(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
+        capturing = true;
         C->P.reset(new Prover(ctx, pk, rank, world));
         C->P->d_vals = v->d_vals;
         static const bool static_uploads = [] { const char* e = getenv("HG_GRAPH_UPLOADS"); return !(e && e[0] == '1'); }();
         C->P->defer_uploads = static_uploads;
+        if (getenv("HG_TEST_FAIL_CAPTURE")) throw Error("launch-graph capture failed (forced by HG_TEST_FAIL_CAPTURE)");
         enqueue_prove(ctx, pk, v, C->P.get(), world, false);   // (the exchange is not part of the graph: prove_from_cache)
+        capturing = false;
+        hip_check(hipStreamEndCapture(ctx->stream, &C->graph), "hipStreamEndCapture");
     } catch (...) {
-        hipGraph_t g = nullptr;
-        (void)hipStreamEndCapture(ctx->stream, &g);
-        if (g) (void)hipGraphDestroy(g);
+        if (capturing) {
+            hipGraph_t g = nullptr;
+            (void)hipStreamEndCapture(ctx->stream, &g);
+            if (g) (void)hipGraphDestroy(g);
+        }
+        (void)hipGetLastError();
+        restore();
         throw;
     }
-    hip_check(hipStreamEndCapture(ctx->stream, &C->graph), "hipStreamEndCapture");
+    restore();
     if (const char* dot = getenv("HG_GRAPH_DOT")) (void)hipGraphDebugDotPrint(C->graph, dot, hipGraphDebugDotFlagsKernelNodeParams);   // (debugging aid: the recorded dependencies)
-    for (auto& u : C->P->deferred_uploads)   // once, ahead of the first replay on the same stream
+    for (auto& u : C->P->deferred_uploads)   // once, ahead of the first replay on the same stream; their targets live in the private arena
         hip_check(hipMemcpyAsync(u.dst, u.src, u.bytes, hipMemcpyHostToDevice, ctx->stream), "descriptor upload");
+    hip_check(hipStreamSynchronize(ctx->stream), "descriptor uploads");   // (the pinned staging they came from is reused by the next prove)
     C->P->deferred_uploads.clear();
     // (Re-issuing the captured nodes from the library on two real streams - kernel parameters and dependencies read back from the
     // graph - was measured against hipGraphLaunch: 3.50-3.59 ms vs 3.52-3.64 ms of GPU time and 0.53 vs 0.40 ms of host time per
     // prove. No gain, not kept: the serialised look of a replay in a rocprofv3 trace is a profiling artefact.)
     hip_check(hipGraphInstantiate(&C->exec, C->graph, nullptr, nullptr, 0), "hipGraphInstantiate");
     hip_check(hipEventCreate(&C->ev_a), "event"); hip_check(hipEventCreate(&C->ev_b), "event");
-    C->pk = pk; C->pk_serial = pk->serial; C->d_vals = v->d_vals; C->d_ct0is = v->d_ct0is; C->one_stream = ctx->one_stream; C->epoch = ctx->arena_epoch;
+    C->pk_serial = pk->serial; C->values_serial = v->serial; C->one_stream = ctx->one_stream;
     C->rank = rank; C->world = world;
-    C->walk_gpu_ms = ctx->last_walk_gpu_ms;
-    ProveCache* raw = C.release();
-    ctx->prove_cache = raw;
-    return prove_from_cache(ctx, raw, exchange, replay_now);
+    C->walk_gpu_ms = wc.gpu_ms;
+    ProveCacheSet* S = cache_set(ctx);
+    while (S->entries.size() >= cache_max_entries()) {   // least recently used entry out
+        size_t lru = 0;
+        for (size_t i = 1; i < S->entries.size(); i++) if (S->entries[i]->last_use < S->entries[lru]->last_use) lru = i;
+        S->entries.erase(S->entries.begin() + lru);
+    }
+    C->last_use = ++S->clock;
+    S->entries.push_back(C);
+    return C;
 }
 
-// The cached-graph path of a (rank of a) prove: replays the cached graph when it was recorded for exactly this call, records one on
-// the third call in a row with the same key, values and share; otherwise returns false and the caller walks the protocol.
-static bool prove_through_graph(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int rank, int world, bool exchange, ProveResult* out, bool replay_now = true) {
-    if (!graph_allowed(ctx)) { ctx->same_key_proves = 0; return false; }
-    if (ctx->slow_graph_serial == pk->serial && ctx->slow_graph_share == rank * 65536 + world) {   // its graph replayed slower than plain launches
-        if (ctx->prove_cache) prove_cache_drop(ctx);
-        return false;
+// The cached-graph path of a (rank of a) prove: replays the graph recorded for exactly this key, values object and share; records one
+// on the third prove of that triple; otherwise returns null and the caller walks the protocol. *out is filled when non-null is returned.
+static std::shared_ptr<ProveCache> prove_through_graph(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int rank, int world, bool exchange, ProveResult* out, bool replay_now = true) {
+    if (v->pk_serial != pk->serial) throw Error("prove: the resident values were generated for another prover key");
+    if (!graph_allowed(ctx)) return nullptr;
+    const int share = rank * 65536 + world;
+    if (ctx->slow_graph_serial == pk->serial && ctx->slow_graph_share == share) {   // its graph replayed slower than plain launches
+        prove_cache_forget_values(ctx, v->serial);
+        return nullptr;
     }
-    ProveCache* C = static_cast<ProveCache*>(ctx->prove_cache);
-    if (C && C->pk == pk && C->pk_serial == pk->serial && C->d_vals == v->d_vals && C->d_ct0is == v->d_ct0is && C->one_stream == ctx->one_stream &&
-        C->epoch == ctx->arena_epoch && C->rank == rank && C->world == world) {
-        *out = prove_from_cache(ctx, C, exchange, replay_now);
-        return true;
+    if (ctx->no_graph_serial == pk->serial && ctx->no_graph_share == share) return nullptr;   // its capture failed: plain launches
+    std::shared_ptr<ProveCache> C = cache_find(ctx, pk, v, rank, world);
+    if (!C) {
+        const hg_ctx::WalkCount* wc = walk_find(ctx, pk, v, share);
+        if (!wc || wc->walks < 2) return nullptr;
+        try {
+            C = prove_capture(ctx, pk, v, rank, world, *wc);
+        } catch (const std::exception& e) {
+            // no graph for this key and share from now on; this prove and the later ones walk the protocol
+            ctx->no_graph_serial = pk->serial; ctx->no_graph_share = share;
+            if (getenv("HG_SHARD_DEBUG") || getenv("HG_GRAPH_DEBUG")) fprintf(stderr, "[hg] launch-graph capture failed, falling back to plain launches: %s\n", e.what());
+            return nullptr;
+        }
     }
-    const void* vkey = v->d_vals.empty() ? nullptr : (const void*)v->d_vals[0];
-    const bool same = ctx->last_prove_key[0] == pk && ctx->last_prove_key[1] == vkey && ctx->last_prove_serial == pk->serial &&
-                      ctx->last_prove_share == rank * 65536 + world;
-    ctx->last_prove_serial = pk->serial;
-    ctx->last_prove_share = rank * 65536 + world;
-    ctx->same_key_proves = same ? ctx->same_key_proves + 1 : 0;
-    ctx->last_prove_key[0] = pk; ctx->last_prove_key[1] = vkey;
-    // third prove of the same (key, values): the arena has grown (1st) and been coalesced (2nd) - its addresses are now stable
-    if (ctx->same_key_proves >= 2 && ctx->chunks.size() <= 1) { *out = prove_capture(ctx, pk, v, rank, world, exchange, replay_now); return true; }
-    return false;
+    *out = prove_from_cache(ctx, C.get(), exchange, replay_now);
+    return C;
 }
 
 ProveResult prove_resident(hg_ctx* ctx, const hg_pk* pk, const hg_values* v) {
@@ -1988,7 +2123,6 @@ ProveResult prove_resident(hg_ctx* ctx, const hg_pk* pk, const hg_values* v) {
         ProveResult cached;
         if (prove_through_graph(ctx, pk, v, 0, 1, false, &cached)) return cached;
     }
-    if (ctx->prove_cache) prove_cache_drop(ctx);
     ProveResult res;
     double t3 = 0;
     float gms = 0;
@@ -2011,7 +2145,6 @@ ProveResult prove_sharded(hg_ctx* ctx, const hg_pk* pk, const hg_values* v) {
         ProveResult cached;   // this rank's share as a cached launch graph, the all-reduce enqueued behind it
         if (prove_through_graph(ctx, pk, v, ctx->comm_rank, ctx->comm_world, true, &cached)) return cached;
     }
-    if (ctx->prove_cache) prove_cache_drop(ctx);
     ProveResult res;
     double t3 = 0;
     float gms = 0;
@@ -2027,31 +2160,36 @@ ProveResult prove_sharded(hg_ctx* ctx, const hg_pk* pk, const hg_values* v) {
 }
 
 // sharded single proof: begin (this rank's jobs) -> caller sum-all-reduces ctx->h_res[0 .. n) -> finish
-struct PendingShard { std::unique_ptr<Prover> own; Prover* P = nullptr; double t_start = 0; float gpu_ms = 0; };   // P: `own`, or the cached graph's prover
-static std::map<hg_ctx*, PendingShard> g_pending;  // one sharded prove in flight per context
-static std::mutex g_pending_mu;
+// One sharded prove in flight per context (hg_ctx::pending_shard). It OWNS what finish needs: its own Prover, or a reference to
+// the cache entry whose Prover recorded the replayed graph - dropping or evicting the entry in between cannot free it.
+struct PendingShard { std::unique_ptr<Prover> own; std::shared_ptr<ProveCache> cached; Prover* P = nullptr; double t_start = 0; float gpu_ms = 0; };
+void pending_shard_drop(hg_ctx* ctx) {
+    delete static_cast<PendingShard*>(ctx->pending_shard);
+    ctx->pending_shard = nullptr;
+}
 
 size_t prove_shard_begin(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int rank, int world) {
     if (world < 1 || rank < 0 || rank >= world) throw Error("prove_shard_begin: bad rank/world");
-    PendingShard ps;
+    pending_shard_drop(ctx);   // (a begin without its finish is superseded)
+    std::unique_ptr<PendingShard> ps(new PendingShard());
     ProveResult cached;
-    ps.t_start = wall_ms();
-    if (prove_through_graph(ctx, pk, v, rank, world, false, &cached, false)) {   // this rank's share replayed from its launch graph
-        ps.P = static_cast<ProveCache*>(ctx->prove_cache)->P.get();
-        ps.gpu_ms = (float)cached.gpu_ms;
+    ps->t_start = wall_ms();
+    if ((ps->cached = prove_through_graph(ctx, pk, v, rank, world, false, &cached, false))) {   // this rank's share replayed from its launch graph
+        ps->P = ps->cached->P.get();
+        ps->gpu_ms = (float)cached.gpu_ms;
     } else {
-        if (ctx->prove_cache) prove_cache_drop(ctx);
-        ps.own = prove_begin(ctx, pk, v, rank, world, &ps.t_start, &ps.gpu_ms);
-        ps.P = ps.own.get();
+        ps->own = prove_begin(ctx, pk, v, rank, world, &ps->t_start, &ps->gpu_ms);
+        ps->P = ps->own.get();
     }
-    size_t n = ps.P->res_used;
-    if (getenv("HG_SHARD_DEBUG")) fprintf(stderr, "[hg] shard rank %d/%d: gpu %.3f ms, enqueue %.3f ms\n", rank, world, ps.gpu_ms, ps.P->t_enqueued - ps.t_start);
-    { std::lock_guard<std::mutex> lk(g_pending_mu); g_pending[ctx] = std::move(ps); }
+    size_t n = ps->P->res_used;
+    if (getenv("HG_SHARD_DEBUG")) fprintf(stderr, "[hg] shard rank %d/%d: gpu %.3f ms, enqueue %.3f ms\n", rank, world, ps->gpu_ms, ps->P->t_enqueued - ps->t_start);
+    ctx->pending_shard = ps.release();
     return n;
 }
 // installs the modular sum of the ranks' partial result buffers (`world` buffers of n_u64 lanes each, rank-major)
 void prove_shard_combine(hg_ctx* ctx, const u64* gathered, int world, size_t n_u64) {
     if (2 * ctx->res_cap < n_u64) throw Error("prove_shard_combine: buffer larger than the result buffer");
+    if (!ctx->pending_shard) throw Error("prove_shard_combine: no sharded prove in flight on this context");
     u64* dst = reinterpret_cast<u64*>(ctx->h_res);
     for (size_t i = 0; i < n_u64; i++) {
         u64 acc = 0;
@@ -2065,24 +2203,19 @@ void prove_shard_combine(hg_ctx* ctx, const u64* gathered, int world, size_t n_u
 }
 
 ProveResult prove_shard_finish(hg_ctx* ctx) {
-    PendingShard ps;
-    {
-        std::lock_guard<std::mutex> lk(g_pending_mu);
-        auto it = g_pending.find(ctx);
-        if (it == g_pending.end()) throw Error("prove_shard_finish: no sharded prove in flight on this context");
-        ps = std::move(it->second);
-        g_pending.erase(it);
-    }
+    if (!ctx->pending_shard) throw Error("prove_shard_finish: no sharded prove in flight on this context (or it was superseded by another prove)");
+    std::unique_ptr<PendingShard> ps(static_cast<PendingShard*>(ctx->pending_shard));
+    ctx->pending_shard = nullptr;
     ProveResult res;
     const double tf0 = wall_ms();
-    ps.P->replay();
+    ps->P->replay();
     if (getenv("HG_SHARD_DEBUG")) fprintf(stderr, "[hg] shard finish: replay call %.3f ms\n", wall_ms() - tf0);
-    res.prove_ms = wall_ms() - ps.t_start;
-    res.gpu_ms = ps.gpu_ms;
-    res.enqueue_ms = ps.P->t_enqueued - ps.t_start;
-    res.sync_ms = ps.P->t_synced - ps.P->t_enqueued;
-    res.replay_ms = ps.P->t_replayed - ps.P->t_synced;
-    res.proof = std::move(ps.P->proof.bytes);
+    res.prove_ms = wall_ms() - ps->t_start;
+    res.gpu_ms = ps->gpu_ms;
+    res.enqueue_ms = ps->P->t_enqueued - ps->t_start;
+    res.sync_ms = ps->P->t_synced - ps->P->t_enqueued;
+    res.replay_ms = ps->P->t_replayed - ps->P->t_synced;
+    res.proof = std::move(ps->P->proof.bytes);
     return res;
 }
 

@@ -34,17 +34,25 @@ struct hg_ctx {
     // and on ADDRESSES only - every challenge is known up front, no kernel argument depends on the witness - so after two ordinary
     // proves of the same (key, values) pair the third is captured into a hipGraph and later ones replay it: the host's ~0.7 ms
     // protocol walk and ~200 launch calls collapse into one hipGraphLaunch. Any other use of the arena invalidates it.
-    void* prove_cache = nullptr;
+    // Round 3: the cache holds SEVERAL graphs (one per (key, values object, share), least recently used evicted), each with a
+    // PRIVATE arena, so a replay neither depends on nor is invalidated by anything else that uses the context's arena, and a
+    // values object that is refilled in place (hg_witness_gen_into) keeps its graph: a new witness every prove replays.
+    void* prove_cache = nullptr;    // prover.hip: ProveCacheSet
+    void* pending_shard = nullptr;  // prover.hip: PendingShard of hg_prove_shard_begin .. _finish (owned; dropped with the context)
     uint64_t arena_epoch = 0;       // bumped by arena_reset()
-    const void* last_prove_key[2] = {nullptr, nullptr};
-    uint64_t last_prove_serial = 0;
-    int same_key_proves = 0;
+    bool arena_fixed = false;       // alloc() must not grow the arena (a launch graph is being recorded into a private arena)
+    // walked proves seen per (key serial, values serial, share): the third one of a values object is recorded into a graph
+    struct WalkCount { uint64_t pk_serial, values_serial; int share; int walks; size_t arena_bytes; float gpu_ms; };
+    std::vector<WalkCount> walk_counts;
+    hg_values* scratch_values = nullptr;   // hg_prove's resident tables, refilled in place per call (so its launch graph survives)
+    uint64_t scratch_serial = 0;           // key serial they were laid out for
+    uint64_t no_graph_serial = 0;          // key whose graph capture failed: its proves walk (no retry)
+    int no_graph_share = -1;
     // guard against a launch graph that replays slower than the plain launches it recorded (the runtime's stream assignment of a
     // graph's branches is not under the library's control): GPU time of the last walked prove, and the key a slow graph was seen for
     float last_walk_gpu_ms = 0;
     uint64_t slow_graph_serial = 0;
     int slow_graph_share = -1;
-    int last_prove_share = 1;       // rank * 65536 + world of the last resident / sharded prove (part of the "same call" test)
     bool use_graph = true;          // hg_set_option("graph", 0) / HG_NO_GRAPH=1 turn it off
     // options (hg_set_option)
     bool one_stream = false;  // keep every launch on `stream` (per-kernel timings without cross-stream interference)
@@ -127,9 +135,19 @@ struct hg_pk {
 };
 
 struct hg_values {
+    uint64_t serial = 0;                 // unique per object, kept across in-place refills (hg_witness_gen_into): launch-graph cache key
+    uint64_t pk_serial = 0;              // the key whose circuit the tables are laid out for
+    int device = 0;
+    hg_ctx* ctx = nullptr;               // the context it was created on (told to drop its launch graphs when the object is freed)
     std::vector<const hg::u64*> d_vals;  // per node
     std::vector<size_t> sizes;
     const hg::u64* d_ct0is = nullptr;
+    hg::u64* ntt_scratch = nullptr;      // kept: a refill allocates nothing
+    size_t ct0is_len = 0;
+    // evaluation plan (witness_fill): levels, FFT groups
+    std::vector<int> level;
+    int max_level = 0;
+    std::vector<int> order;
     std::vector<void*> owned;
 };
 
@@ -141,7 +159,11 @@ struct ProveResult {
 };
 
 hg_values* witness_gen(hg_ctx* ctx, const hg_pk* pk, const Witness& w, double* witness_ms, double* upload_ms);
+// Circuit::evaluate into the tables of an existing values object (same addresses: its cached launch graph stays valid)
+void witness_gen_into(hg_ctx* ctx, const hg_pk* pk, const Witness& w, hg_values* v, double* witness_ms, double* upload_ms);
 void values_free(hg_values* v);
+void pending_shard_drop(hg_ctx* ctx);
+void ctx_register(hg_ctx* ctx, bool alive);
 ProveResult prove_resident(hg_ctx* ctx, const hg_pk* pk, const hg_values* v);
 // the same in a protocol mode of SURVEY.md 8(f) f-4 (bit 0 absorbing transcript, bit 1 extension-field memory checking):
 // round-by-round prover (prover_seq.hip); mode 0 = prove_resident

@@ -68,8 +68,9 @@ void hg_destroy(hg_ctx* ctx);
  *   "one_stream"  value != 0: every launch on one stream (the default overlaps the Vanilla / FFT node reductions, the counter
  *                 sorts and the openings with the Lasso node's critical path on a second stream); used to time kernels in isolation
  *   "graph"       value == 0: never replay a cached launch graph (default: after two ordinary resident proves of the same key and
- *                 values the third is captured into a hipGraph and later ones replay it - the launch sequence depends on
- *                 addresses only, because every challenge is known up front)
+ *                 values object the third is captured into a hipGraph and later ones replay it - the launch sequence depends on
+ *                 addresses only, because every challenge is known up front; a values object refilled by hg_witness_gen_into
+ *                 keeps its graph; up to HG_GRAPH_ENTRIES (8) graphs per context, each with a private workspace)
  * Returns 0, or -1 for an unknown name. */
 int hg_set_option(hg_ctx* ctx, const char* name, int64_t value);
 
@@ -139,6 +140,12 @@ int hg_verify_mode(const hg_pk* pk, const hg_witness* w, int mode, const uint8_t
  *   hg_prove_resident = "eval output" + "GKR prove" [REF sk_encryption_circuit.rs:444-457] on resident tables.
  * bench.py times hg_prove_resident (inputs already in HBM when the timed region starts). */
 int hg_witness_gen(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, hg_values** out, hg_timings* timings);
+/* The same into an EXISTING values object (of the same key and context): no allocation, every table keeps its address. This is the
+ * steady state of a prover that receives a new witness per proof, as the reference's caller does [REF bfv-gkr/src/test.rs:37-38]: the
+ * launch graph the library recorded for `v` (hg_set_option "graph") stays valid, because the launch sequence of a prove depends on
+ * addresses only - the next hg_prove_resident(v) replays it on the new witness. hg_prove does this internally with a values
+ * object owned by the context. */
+int hg_witness_gen_into(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, hg_values* v, hg_timings* timings);
 void hg_values_free(hg_values* v);
 /* copies node `node`'s table (NodeId order of configure) back to the host; returns its element count */
 int64_t hg_values_get(hg_ctx* ctx, const hg_values* v, int node, uint64_t* out, size_t cap);

@@ -364,8 +364,9 @@ def test_derived_parameter_set_proves_and_verifies(ctx):
 
 
 def test_cached_launch_graph_replays_and_invalidates(ctx):
-    """Resident proves of one (key, values) pair: the third is captured into a hipGraph, later ones replay it. The bytes must not
-    change, other arena users in between must invalidate the graph, another witness must not reuse it, and the oracle agrees."""
+    """Resident proves of one (key, values object) pair: the third is captured into a hipGraph, later ones replay it. The bytes must
+    not change; other users of the context's arena in between must NOT disturb it (the graph works in a private arena); another
+    values object gets its own graph and both replay in alternation; the oracle agrees throughout."""
     n, k = 4096, 2
     bfv = hg.BfvEncrypt.new(n, k)
     pk = bfv.setup(ctx)
@@ -375,22 +376,109 @@ def test_cached_launch_graph_replays_and_invalidates(ctx):
     p = orclib.params(n, k)
     ref1, _ = orclib.prove(p, orclib.Inputs(w1.arrays()), threads=4)
     ref2, _ = orclib.prove(p, orclib.Inputs(w2.arrays()), threads=4)
-    for i in range(6):                                                     # walk, walk (arena coalesced), capture, replay x3
+    for i in range(6):                                                     # walk, walk, capture, replay x3
         assert hg.prove_resident(ctx, pk, v1, out).bytes() == ref1, i
     rng = random.Random(3)
     tab = rand_f(rng, 1 << 10)
     ctx.mle_eval(tab, rand_f(rng, 20))                                     # another user of the context's arena
     for i in range(4):
-        assert hg.prove_resident(ctx, pk, v1, out).bytes() == ref1, i      # re-walked, re-captured, replayed
-    assert hg.prove_resident(ctx, pk, v2, out).bytes() == ref2             # other values: never the cached graph
-    for i in range(4):
-        assert hg.prove_resident(ctx, pk, v2, out).bytes() == ref2, i
-        assert hg.prove_resident(ctx, pk, v1, out).bytes() == ref1, i      # alternating keys: plain walks
+        assert hg.prove_resident(ctx, pk, v1, out).bytes() == ref1, i      # still the same graph
+    assert hg.prove_resident(ctx, pk, v2, out).bytes() == ref2             # other values: never v1's graph
+    for i in range(5):
+        assert hg.prove_resident(ctx, pk, v2, out).bytes() == ref2, i      # (its own graph from its third prove on)
+        assert hg.prove_resident(ctx, pk, v1, out).bytes() == ref1, i
+        ctx.mle_eval(tab, rand_f(rng, 20))
     ctx.set_option("graph", 0)
     for i in range(4):
         assert hg.prove_resident(ctx, pk, v1, out).bytes() == ref1, i
     ctx.set_option("graph", 1)
     v1.free(); v2.free(); pk.free()
+
+
+@pytest.mark.parametrize("n,k,seeds", [(4096, 2, 5), (32768, 16, 3)])
+def test_graph_replay_across_witnesses(ctx, n, k, seeds):
+    """The steady state of a prover that gets a NEW witness per proof (the reference proves each witness once, test.rs:37-38):
+    one values object refilled in place by hg_witness_gen_into, proven through the launch graph recorded for its addresses.
+    Every proof - walked, captured, replayed - must equal the oracle's proof of THAT witness (BASELINE configs[1] and [2])."""
+    bfv = hg.BfvEncrypt.new(n, k)
+    pk = bfv.setup(ctx)
+    p = orclib.params(n, k)
+    threads = min(64, os.cpu_count() or 8)
+    ws = [hg.Witness.synthetic(bfv.params, 0x77 + 13 * i) for i in range(seeds)]
+    refs = [orclib.prove(p, orclib.Inputs(w.arrays()), threads=threads)[0] for w in ws]
+    assert len(set(refs)) == seeds
+    out = hg.ProofBuffer()
+    vals = hg.witness_gen(ctx, pk, ws[0])
+    for i in range(3):                                                     # walk, walk, capture + first replay
+        assert hg.prove_resident(ctx, pk, vals, out).bytes() == refs[0], i
+    launches = []
+    for rnd in range(2):
+        for i in range(seeds):                                             # every later prove: another witness, the same graph
+            hg.witness_gen_into(ctx, pk, ws[i], vals)
+            assert hg.prove_resident(ctx, pk, vals, out).bytes() == refs[i], _first_diff(out.bytes(), refs[i], 16)
+            launches.append(out.timings()["enqueue_ms"])
+    # hg_prove (the drop-in for BfvEncrypt::prove) does the same with tables owned by the context
+    for rnd in range(2):
+        for i in range(seeds):
+            proof, tm = bfv.prove(ctx, pk, ws[i])
+            assert proof == refs[i], (rnd, i)
+    print("n=%d: enqueue ms per replayed prove %s; hg_prove end to end %s" % (n, ["%.2f" % x for x in launches[-3:]], {q: round(tm[q], 3) for q in ("upload_ms", "witness_ms", "prove_ms", "total_ms")}))
+    vals.free()
+    pk.free()
+
+
+def test_graph_capture_failure_falls_back_to_plain_launches(ctx, monkeypatch):
+    """A launch-graph capture that fails (forced) must not fail the prove nor be retried on every call: the key walks from then on."""
+    n, k = 4096, 2
+    bfv = hg.BfvEncrypt.new(n, k)
+    pk = bfv.setup(ctx)
+    w = hg.Witness.synthetic(bfv.params, 31)
+    vals = hg.witness_gen(ctx, pk, w)
+    out = hg.ProofBuffer()
+    ref = hg.prove_resident(ctx, pk, vals, out).bytes()
+    monkeypatch.setenv("HG_TEST_FAIL_CAPTURE", "1")
+    for i in range(4):                                                     # walk, failed capture -> walk, walk, walk
+        assert hg.prove_resident(ctx, pk, vals, out).bytes() == ref, i
+    monkeypatch.delenv("HG_TEST_FAIL_CAPTURE")
+    for i in range(3):                                                     # the key stays on plain launches (no retry), still correct
+        assert hg.prove_resident(ctx, pk, vals, out).bytes() == ref, i
+        assert out.timings()["enqueue_ms"] > 0.05
+    vals.free()
+    pk.free()
+
+
+def test_sharded_prove_in_flight_survives_other_proves(ctx):
+    """hg_prove_shard_begin .. _finish with other calls in between that drop or replace launch graphs (the pending
+    shard used to hold a raw pointer into the cache): the finish must still replay the right transcript; a finish without a begin
+    is an error, and a context destroyed with a shard in flight does not crash."""
+    n, k, world = 4096, 2, 2
+    bfv = hg.BfvEncrypt.new(n, k)
+    pk = bfv.setup(ctx)
+    w, w2 = hg.Witness.synthetic(bfv.params, 41), hg.Witness.synthetic(bfv.params, 42)
+    vals, vals2 = hg.witness_gen(ctx, pk, w), hg.witness_gen(ctx, pk, w2)
+    out, out2 = hg.ProofBuffer(), hg.ProofBuffer()
+    ref = hg.prove_resident(ctx, pk, vals, out).bytes()
+    for i in range(4):                                                     # rank 0's share: walk, walk, capture, replay
+        p0 = hg.prove_shard_begin(ctx, pk, vals, 0, world).copy()
+    p1 = hg.prove_shard_begin(ctx, pk, vals, 1, world).copy()
+    hg.prove_shard_begin(ctx, pk, vals, 0, world)                          # in flight, replayed from rank 0's graph
+    ctx.set_option("graph", 0)                                             # drops every cached graph
+    ctx.set_option("graph", 1)
+    hg.prove_shard_combine(ctx, np.stack([p0, p1]), world)
+    assert hg.prove_shard_finish(ctx, out).bytes() == ref
+    with pytest.raises(hg.HgError, match="no sharded prove in flight"):
+        hg.prove_shard_finish(ctx, out)
+    # a prove of other values between begin and finish overwrites the shared result buffer; combine reinstalls it, finish is right
+    hg.prove_shard_begin(ctx, pk, vals, 0, world)
+    hg.prove_resident(ctx, pk, vals2, out2)
+    hg.prove_shard_combine(ctx, np.stack([p0, p1]), world)
+    assert hg.prove_shard_finish(ctx, out).bytes() == ref
+    c2 = hg.Context(0)
+    pk2 = bfv.setup(c2)
+    v2 = hg.witness_gen(c2, pk2, w)
+    hg.prove_shard_begin(c2, pk2, v2, 0, world)
+    v2.free(); pk2.free(); c2.close()                                      # shard in flight: dropped with the context
+    vals.free(); vals2.free(); pk.free()
 
 
 def test_launch_graph_that_replays_slower_than_plain_launches_is_given_up():
