@@ -3,8 +3,10 @@
 configs[2]), on N MI355X GPUs of one node.
 
 A "step" = one GKR prove (the reference's "GKR prove" span [REF bfv-gkr/src/sk_encryption_circuit.rs:455-457],
-plus the output-claim evaluation :444-448) of one synthetic witness whose node tables are already resident in
-HBM. N > 1, default `--mode shard`: ONE proof is sharded over the N GPUs (strong scaling): every rank holds the
+plus the output-claim evaluation :444-448) of a synthetic witness whose node tables are already resident in
+HBM - a DIFFERENT witness every step (`--witnesses`, default 4 seeds in rotation: the reference proves each witness once,
+test.rs:37-38), every proof of the timed region checked afterwards against the walked proof of the same seed and one of
+them against the CPU oracle. N > 1, default `--mode shard`: ONE proof is sharded over the N GPUs (strong scaling): every rank holds the
 same witness, runs its share (the Lasso node split by memory, the node reductions dealt out whole) and
 ONE RCCL all-reduce of the scalar result buffer per proof, issued by the library on the prover stream, is the only exchange;
 `value` = max-over-ranks step time = ms per proof.
@@ -59,17 +61,42 @@ def pmc_traffic(cls, n, k):
     return None, None
 
 
-def cpu_baseline(n, k, seed, budget_s=60.0):
+def toolchain_probe():
+    """What a pin against the real Rust prover needs, looked for on THIS host (recorded in cpu_baseline.reference_attempt)."""
+    import shutil
+    import socket
+    import subprocess
+    cargo = shutil.which("cargo") is not None
+    nightly = False
+    if shutil.which("rustc"):
+        try:
+            nightly = "nightly" in subprocess.run(["rustc", "--version"], capture_output=True, text=True, timeout=10).stdout
+        except Exception:
+            pass
+    network = False
+    try:
+        socket.create_connection(("github.com", 443), timeout=2).close()
+        network = True
+    except Exception:
+        pass
+    return {"cargo": cargo, "rustc_nightly": nightly, "network": network, "reference_checkout": bool(os.environ.get("HYPER_GRECO")),
+            "pin": "not attempted: " + ("no cargo on this host" if not cargo else "no network for the reference's git dependencies" if not network else
+                                        "no reference checkout ($HYPER_GRECO)" if not os.environ.get("HYPER_GRECO") else "see rust/hg-shim/tests/proof_dump.rs")}
+
+
+def cpu_baseline(n, k, seed, budget_s=60.0, proofs_out=None):
     """CPU baseline on this host's cores, same witness as the GPU run, GKR-prove span only.
     kind "reference": the reference's own rayon prover (needs cargo + network + $HYPER_GRECO: scripts/reference_baseline.py);
     otherwise kind "port": the CPU oracle (this repo's restatement, OpenMP where the reference uses rayon). Method: the thread
     count is chosen among {16, 32, 64, 128} on the small configuration, then 1 warm + 3 timed runs, median. Bounded: a small config is timed first and the largest config whose predicted time fits the
     budget is run (scaled by the ratio of Lasso rows, stated in `sample`)."""
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    attempt = toolchain_probe()
     try:
         import reference_baseline
         ref = reference_baseline.measure(n, k, seed + n)
         if ref:
+            ref["reference_attempt"] = attempt
             return ref
     except Exception:
         pass
@@ -85,7 +112,9 @@ def cpu_baseline(n, k, seed, budget_s=60.0):
         w = hg.Witness.synthetic(p, seed + nn)
         inp = orclib.Inputs(w.arrays())
         op = orclib.params(nn, kk)
-        _, tm = orclib.prove(op, inp, threads=threads)
+        proof, tm = orclib.prove(op, inp, threads=threads)
+        if proofs_out is not None:
+            proofs_out[(nn, kk)] = proof   # (same seed as witness 0 of the GPU run: main() compares the bytes)
         return tm[1]  # GKR prove span only (witness generation excluded, like the GPU number)
 
     def rows(nn, kk):
@@ -110,7 +139,8 @@ def cpu_baseline(n, k, seed, budget_s=60.0):
                 sample += f"; scaled x{scale:.2f} (Lasso rows ratio) to n={n} k={k}"
             return {"value": round(ms * scale, 3), "unit": "ms", "cores": best, "kind": "port", "sample": sample,
                     "measured_ms": round(ms, 3), "runs_ms": [round(r, 1) for r in runs],
-                    "thread_sweep_ms_n4096": {str(t): round(v, 1) for t, v in sweep.items()}, "host_cores": cores}
+                    "thread_sweep_ms_n4096": {str(t): round(v, 1) for t, v in sweep.items()}, "host_cores": cores,
+                    "reference_attempt": attempt}
     return None
 
 
@@ -140,11 +170,98 @@ def selftest_dist(args, rank, world, dist, torch):
         dist.barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0, world, dist, torch, "cpu")
     seeds = [witness_seed(args.seed, args.n, r) for r in range(world)]
+    # the caller-side exchange of `--mode shard` without its device part: seeded partial buffers, all-gather, hg_shard_combine_host
+    import numpy as np
+    import __graft_entry__ as entry
+    hg = entry.load_package()
+    P = 0xFFFFFFFF00000001
+    part = np.random.default_rng(77 + rank).integers(0, P, size=1031, dtype=np.uint64)
+    part[:8] = P - 1
+    if world > 1:
+        t = torch.from_numpy(part.view(np.int64).copy())
+        bufs = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(bufs, t)
+        gathered = torch.stack(bufs).numpy().view(np.uint64)
+    else:
+        gathered = part[None, :]
+    want = np.array([sum(int(gathered[r][i]) for r in range(world)) % P for i in range(part.size)], dtype=np.uint64)
+    exchange = "identical" if np.array_equal(hg.shard_combine_host(gathered), want) else "DIFFERENT"
     if rank == 0:
         print(json.dumps({"selftest": "dist", "n_gpus": world, "steps": args.steps, "ms_per_step": elapsed / args.steps * 1e3,
-                          "value": elapsed / args.steps * 1e3 / world, "distinct_witness_seeds": len(set(seeds)) == world}), flush=True)
+                          "value": elapsed / args.steps * 1e3 / world, "distinct_witness_seeds": len(set(seeds)) == world,
+                          "exchange_selftest": exchange}), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+class deadline:
+    """Bounds a block that contains a collective: when it has not finished after `seconds`, the process reports on stderr and EXITS
+    with a non-zero code (os._exit from a watchdog thread: nothing is re-executed, no GPU call is made from the watchdog)."""
+
+    def __init__(self, seconds, what):
+        self.seconds, self.what, self.done = seconds, what, None
+
+    def __enter__(self):
+        if self.seconds and self.seconds > 0:
+            import threading
+            self.done = threading.Event()
+
+            def watch():
+                if not self.done.wait(self.seconds):
+                    sys.stderr.write(f"[bench] rank {os.environ.get('RANK', '0')}: {self.what} did not finish within {self.seconds:.0f} s - exiting\n")
+                    sys.stderr.flush()
+                    os._exit(3)
+            threading.Thread(target=watch, daemon=True).start()
+        return self
+
+    def __exit__(self, *exc):
+        if self.done is not None:
+            self.done.set()
+        return False
+
+
+def measure_end_to_end(hg, ctx, bfv, pk, witnesses, walked, args):
+    """BfvEncrypt::prove as the reference's caller sees it [REF sk_encryption_circuit.rs:417-460, poly.rs:12-44]: JSON args ->
+    get_inputs -> upload -> circuit.evaluate on the device -> GKR prove, every stage warmed, median of 5, a different witness
+    per call. Reported in config.end_to_end, never part of `value`."""
+    import statistics
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import witness_to_json
+    NW = len(witnesses)
+    res = {}
+    # arrays -> proof: hg_prove (upload, witness generation into the context's resident tables, launch-graph replay)
+    for i in range(3 * NW):   # walks, capture
+        proof, tm = bfv.prove(ctx, pk, witnesses[i % NW])
+        assert proof == walked[i % NW]
+    runs = []
+    for i in range(5):
+        t0 = time.perf_counter()
+        proof, tm = bfv.prove(ctx, pk, witnesses[i % NW])
+        runs.append(((time.perf_counter() - t0) * 1e3, tm))
+        assert proof == walked[i % NW], "hg_prove: proof differs from the resident prove of the same witness"
+    runs.sort(key=lambda r: r[0])
+    med = runs[len(runs) // 2]
+    res["arrays_to_proof_ms"] = round(med[0], 3)
+    res["stages_ms"] = {"upload": round(med[1]["upload_ms"], 3), "witness_gen_device": round(med[1]["witness_ms"], 3), "gkr_prove": round(med[1]["prove_ms"], 3)}
+    # JSON -> arrays: the reference's fixture format, written from witness 0 (the n=32768 fixture itself is a missing blob)
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "w.json")
+        with open(path, "w") as f:
+            json.dump(witness_to_json.arrays_to_args(args.n, args.k, witnesses[0].arrays()), f)
+        res["json_bytes"] = os.path.getsize(path)
+        ts = []
+        for i in range(6):
+            t0 = time.perf_counter()
+            wj = hg.Witness.from_json(bfv.params, path)
+            ts.append((time.perf_counter() - t0) * 1e3)
+        proof, _ = bfv.prove(ctx, pk, wj)
+        assert proof == walked[0], "the witness read back from JSON proves differently"
+        res["json_parse_ms"] = round(statistics.median(ts[1:]), 3)
+        res["json_parse_threads"] = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)
+    res["json_to_proof_ms"] = round(res["json_parse_ms"] + res["arrays_to_proof_ms"], 3)
+    res["note"] = "median of 5 after warm-up, a different witness per call; hg_witness_from_json + hg_prove (host arrays are pageable memory)"
+    return res
 
 
 def main():
@@ -155,6 +272,10 @@ def main():
     ap.add_argument("--ring-degree", "--n", dest="n", type=int, default=32768)
     ap.add_argument("--crt-moduli", "--k", dest="k", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--witnesses", type=int, default=4, help="number of different synthetic witnesses proven in rotation (one per step)")
+    ap.add_argument("--collective-timeout", type=float, default=300.0,
+                    help="N>1: seconds the communicator set-up and the first sharded prove may take before the rank exits non-zero")
     ap.add_argument("--seed", type=int, default=0x4752454330)
     ap.add_argument("--mode", choices=["shard", "dp"], default="shard",
                     help="N>1: shard ONE proof over the GPUs (strong scaling, default) or one independent proof per GPU (weak)")
@@ -198,12 +319,18 @@ def main():
     ctx = hg.Context(local_rank)
     bfv = hg.BfvEncrypt.new(args.n, args.k)
     pk = bfv.setup(ctx)
-    witness = hg.Witness.synthetic(bfv.params, witness_seed(args.seed, args.n, 0 if shard else rank))
-    vals = hg.witness_gen(ctx, pk, witness)  # node tables -> HBM (outside the timed region)
+    # NW different witnesses, each with its node tables resident in HBM before anything is timed. Sharded: every rank holds the same
+    # NW witnesses; dp: every rank has its own NW.
+    NW = max(1, args.witnesses)
+    wrank = 0 if shard else rank
+    seeds = [witness_seed(args.seed, args.n, wrank) + 104729 * j for j in range(NW)]
+    witnesses = [hg.Witness.synthetic(bfv.params, sd) for sd in seeds]
+    vals = [hg.witness_gen(ctx, pk, w) for w in witnesses]  # node tables -> HBM (outside the timed region)
     out = hg.ProofBuffer()
 
     lib_comm = shard and backend == "nccl"   # the library's own RCCL all-reduce (device buffers, no torch hop, no host staging)
     exchange_note = None
+    rccl_ranks_seen = None
     if lib_comm:
         # every rank must take the same path: a failure anywhere (no librccl, init error) sends ALL ranks to the torch exchange
         err = None
@@ -218,7 +345,9 @@ def main():
             err = err or "rank 0 could not create an RCCL id"
         else:
             try:
-                hg.comm_init(ctx, uid[0], rank, world)
+                with deadline(args.collective_timeout, "hg_comm_init (ncclCommInitRank over %d ranks)" % world):
+                    hg.comm_init(ctx, uid[0], rank, world)
+                rccl_ranks_seen = hg.comm_count(ctx)   # ncclCommCount of the library's communicator
             except Exception as e:  # noqa: BLE001
                 err = str(e)
         flag = torch.tensor([1 if err else 0], dtype=torch.int32, device=red_dev)
@@ -229,13 +358,14 @@ def main():
             lib_comm = False
             exchange_note = "library RCCL communicator unavailable (%s): exchange through torch.distributed all_gather" % (err or "another rank failed")
 
-    def step():
+    def step(j=0, out=out):
+        v = vals[j % NW]
         if not shard:
-            return hg.prove_resident(ctx, pk, vals, out)
+            return hg.prove_resident(ctx, pk, v, out)
         if lib_comm:
-            return hg.prove_sharded(ctx, pk, vals, out)   # this rank's jobs -> one ncclAllReduce on the prover stream -> replay
+            return hg.prove_sharded(ctx, pk, v, out)   # this rank's jobs -> one ncclAllReduce on the prover stream -> replay
         import numpy as np
-        part = hg.prove_shard_begin(ctx, pk, vals, rank, world)      # this rank's jobs, one stream sync
+        part = hg.prove_shard_begin(ctx, pk, v, rank, world)         # this rank's jobs, one stream sync
         t = torch.from_numpy(part.view(np.int64).copy()).to(red_dev)
         bufs = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(bufs, t)                                     # the only exchange of the proof (RCCL over xGMI)
@@ -243,28 +373,36 @@ def main():
         hg.prove_shard_combine(ctx, gathered, world)                 # lane-wise sum mod p (GP#1 round sums are partial sums)
         return hg.prove_shard_finish(ctx, out)                       # transcript replay -> identical bytes on every rank
 
-    if shard:  # the sharded proof must equal the single-GPU proof bit for bit
-        unsharded = hg.prove_resident(ctx, pk, vals, out).bytes()
+    unsharded = None
+    if shard:  # the sharded proofs must equal the single-GPU proofs bit for bit
+        unsharded = [hg.prove_resident(ctx, pk, v, out).bytes() for v in vals]
         # every rank must hand the collective a result buffer of the same length (they walk the same protocol): a mismatch would
         # hang the all-reduce, so check it once, up front, through the caller-side entry points (no collective inside)
-        n_local = int(len(hg.prove_shard_begin(ctx, pk, vals, rank, world)))
+        n_local = int(len(hg.prove_shard_begin(ctx, pk, vals[0], rank, world)))
         hg.prove_shard_finish(ctx, out)   # (clears the pending shard; its partial-sum "proof" is discarded)
         lens = [None] * world
         dist.all_gather_object(lens, n_local)
         assert len(set(lens)) == 1, f"ranks disagree on the result-buffer length: {lens}"
-    for _ in range(max(args.warmup, 1)):
-        step()
-    first = out.bytes()
+    # the first collective of the data path under a deadline: a hang (a rank that never arrives, a dead link) must end THIS process with
+    # a non-zero exit code instead of holding the node until the driver's limit
+    with deadline(args.collective_timeout if world > 1 else 0, "first sharded prove (the first RCCL all-reduce of the data path)"):
+        walked = [step(j).bytes() for j in range(NW)]   # plain launches: the reference every later proof of witness j is compared with
+    assert len(set(walked)) == NW or NW == 1, "different witnesses gave identical proofs"
     if shard:
-        assert first == unsharded, "sharded proof differs from the single-GPU proof"
+        assert walked == unsharded, "sharded proof differs from the single-GPU proof"
+    for _ in range(2):   # second walk, then the capture: from here on every step replays the launch graph of its values object
+        for j in range(NW):
+            assert step(j).bytes() == walked[j], "proof changed between runs"
+    for i in range(args.warmup):
+        step(i)
 
-    # which kernel class dominates? three untimed proves with events on every class, every launch on ONE stream (with the
+    # which kernel class dominates? untimed proves with events on every class, every launch on ONE stream (with the
     # second stream active a class's event time also contains whatever shared the GPU with it)
     ctx.set_option("one_stream", 1)
     ctx.profile(2)
     ctx.profile_reset()
-    for _ in range(3):
-        step()
+    for i in range(3):
+        step(i)
     ctx.profile(0)
     ctx.set_option("one_stream", 0)
     step()
@@ -273,39 +411,50 @@ def main():
     import gc
     gc.collect()
     gc.disable()  # a cyclic-GC pass over the interpreter's (PyTorch-sized) heap costs 80-100 ms: keep it out of the timed steps
+    outs = [hg.ProofBuffer(cap=max(1 << 16, 2 * len(walked[0]))) for _ in range(args.steps)]   # one per timed step: all of them checked afterwards
 
-    def timed(k):
+    def timed(k, keep=False):
         barrier()
         t0 = time.perf_counter()
-        for _ in range(k):
-            step()
+        for i in range(k):
+            step(i, outs[i] if keep else out)
         barrier()
         return time.perf_counter() - t0
 
-    # Two timed regions of K steps each, back to back, same schedule (two streams), same bytes:
-    #  A: HIP events around every launch of the dominant class. Events take the prover off its cached launch graph (recorded into
-    #     the graph as event nodes they serialise its branches: 4.9 ms per prove, scripts/ub/graph_events.hip), so these K steps walk
+    # Three timed regions of K steps each, back to back, same schedule (two streams), a different witness every step:
+    #  A: HIP events around every launch of the dominant class. Events take the prover off its cached launch graphs (recorded into
+    #     a graph as event nodes they serialise its branches: 4.9 ms per prove, scripts/ub/graph_events.hip), so these K steps walk
     #     the protocol and launch kernel by kernel. `roofline` comes from here.
-    #  B: nothing but the proves: the product's steady state (the cached launch graph replayed). `value` comes from here.
+    #  B: nothing but the proves: the product's steady state (the launch graph of each step's values object replayed). `value`.
+    #  C: the same with hg_set_option("graph", 0): every prove walks the protocol (`walked_ms_per_step`).
     ctx.profile(1)
     step()
     ctx.profile_reset()
     elapsed_a = timed(args.steps)
     ctx.profile(0)
-    assert out.bytes() == first, "proof changed between runs"
     gpu_ms_a = out.timings()["gpu_ms"]
-    for _ in range(3):   # back onto the launch graph (captured on the third plain prove of the same key and values)
-        step()
-    elapsed = timed(args.steps)
+    for i in range(NW):   # (back on the launch graphs)
+        assert step(i).bytes() == walked[i], "proof changed between runs"
+    elapsed = timed(args.steps, keep=True)
+    gpu_ms = outs[-1].timings()["gpu_ms"]
+    enqueue_ms = outs[-1].timings()["enqueue_ms"]
+    ctx.set_option("graph", 0)
+    step()
+    elapsed_c = timed(args.steps)
+    ctx.set_option("graph", 1)
     gc.enable()
-    assert out.bytes() == first, "proof changed between runs"
-    gpu_ms = out.timings()["gpu_ms"]
+    for i in range(args.steps):   # every proof of region B against the walked proof of the same witness
+        assert outs[i].bytes() == walked[i % NW], f"timed step {i}: the replayed proof differs from the walked proof of witness {i % NW}"
+    for i in range(NW):
+        assert step(i).bytes() == walked[i]
     elapsed = max_over_ranks(elapsed, world, dist, torch, red_dev)
     elapsed_a = max_over_ranks(elapsed_a, world, dist, torch, red_dev)
+    elapsed_c = max_over_ranks(elapsed_c, world, dist, torch, red_dev)
     ms_per_step = elapsed / args.steps * 1e3
     ms_per_step_a = elapsed_a / args.steps * 1e3
+    ms_per_step_c = elapsed_c / args.steps * 1e3
     dom = [s for s in ctx.profile_get() if s["name"] == DOMINANT][0]
-    timed_launches = dom["launches"]
+    first = walked[0]
 
     # one extra, untimed pass with events on every kernel class (one stream: isolated class times): the per-class breakdown
     ctx.set_option("one_stream", 1)
@@ -327,8 +476,8 @@ def main():
     step()
     ctx.profile(1)
     ctx.profile_reset()
-    for _ in range(3):
-        step()
+    for i in range(3):
+        step(i)
     ctx.profile(0)
     iso = [s for s in ctx.profile_get() if s["name"] == DOMINANT][0]
     iso_ms = iso["total_ms"] / max(iso["launches"], 1)
@@ -336,6 +485,10 @@ def main():
     iso_model = iso["model_bytes"] / max(iso["launches"], 1) / (iso_ms * 1e-3) / 1e9 if iso_ms > 0 else 0.0
     iso_gpu_ms = out.timings()["gpu_ms"]
     ctx.set_option("one_stream", 0)
+
+    end_to_end = None
+    if world == 1 and rank == 0 and not args.no_end_to_end:
+        end_to_end = measure_end_to_end(hg, ctx, bfv, pk, witnesses, walked, args)
 
     if rank == 0:
         per_launch_bytes = dom["algo_bytes"] / max(dom["launches"], 1)
@@ -357,7 +510,10 @@ def main():
             "dtype": "u64",
             "data": "synthetic",
             "config": {"workload": f"GKR prove (sk_encryption_circuit.rs:444-457) of the BFV sk-enc circuit, n={args.n} k={args.k} "
-                                   "Goldilocks/GoldilocksExt2, seeded synthetic witness, node tables resident in HBM",
+                                   f"Goldilocks/GoldilocksExt2, a new witness every step ({NW} seeded synthetic witnesses in rotation), node tables resident in HBM",
+                       "witnesses": NW, "witness_seeds": seeds,
+                       "proof_checks": {"timed_steps_equal_to_the_walked_proof_of_their_witness": args.steps,
+                                        "distinct_proofs": len(set(walked))},
                        "n": args.n, "k": args.k, "field": "goldilocks", "proofs_per_step": 1 if (shard or world == 1) else world,
                        "parallelism": ((f"shard{world}: one proof, Lasso node split by memory and node reductions dealt over {world} GPUs, "
                                         + ("one RCCL all-reduce of the result buffer per proof (inside the library)" if lib_comm
@@ -365,10 +521,15 @@ def main():
                                        if shard else f"dp{world}: one independent proof per GPU, no data-path collective"),
                        **({"exchange_note": exchange_note} if exchange_note else {}),
                        "proof_bytes": len(first), "gpu_ms_events": round(gpu_ms, 4),
-                       "timed_regions": {"value": f"{args.steps} proves, cached launch graph replayed, no profiling events",
+                       "host_enqueue_ms": round(enqueue_ms, 4),
+                       "walked_ms_per_step": round(ms_per_step_c, 4),
+                       "timed_regions": {"value": f"{args.steps} proves, a different witness each, the launch graph of each witness's tables replayed, no profiling events",
+                                         "walked_ms_per_step": f"{args.steps} proves right after, hg_set_option(graph, 0): the protocol walked and launched kernel by kernel",
                                          "roofline": f"{args.steps} proves immediately before, plain launches with HIP events around the dominant class: "
                                                      f"{ms_per_step_a:.4f} ms per prove, {gpu_ms_a:.4f} ms of GPU time"},
-                       "witness_gen_ms_device": round(vals.timings["witness_ms"], 2), "upload_ms": round(vals.timings["upload_ms"], 2)},
+                       **({"rccl_ranks_seen": rccl_ranks_seen} if rccl_ranks_seen is not None else {}),
+                       **({"end_to_end": end_to_end} if end_to_end else {}),
+                       "witness_gen_ms_device_first_call": round(vals[0].timings["witness_ms"], 2), "upload_ms_first_call": round(vals[0].timings["upload_ms"], 2)},
             # `achieved` / `avg_launch_us`: HIP events around the dominant kernel class over the K proves of timed region A, where its launches
             # share the GPU with the second stream (Vanilla / FFT reductions, counter sorts, openings); `isolated`: the same
             # launches timed in an extra untimed prove with every launch on one stream.
@@ -398,13 +559,15 @@ def main():
         }
         if world == 1:
             # the same proof over bn256::Fr (BASELINE config 5's field) on the same witness: reported next to the headline
-            # number, never part of `value`; 3 runs after one warm-up, best of 3
+            # number, never part of `value`; 5 runs after one warm-up, median of 5
             try:
+                witness = witnesses[0]
                 ctx.prove_bn254(pk, witness, cap=1 << 25)
-                runs = [ctx.prove_bn254(pk, witness, cap=1 << 25)[1:] for _ in range(3)]
-                best = min(runs, key=lambda t: t[1])
-                line["bn254"] = {"workload": f"BfvEncrypt::prove over bn256::Fr (hg_prove_bn254), n={args.n} k={args.k}, same witness",
-                                 "witness_gen_ms": round(best[0], 2), "prove_ms": round(best[1], 2), "dtype": "u256 (4x64 Montgomery)"}
+                runs = sorted((ctx.prove_bn254(pk, witness, cap=1 << 25)[1:] for _ in range(5)), key=lambda t: t[1])
+                best = runs[len(runs) // 2]
+                line["bn254"] = {"workload": f"BfvEncrypt::prove over bn256::Fr (hg_prove_bn254), n={args.n} k={args.k}, witness 0",
+                                 "witness_gen_ms": round(best[0], 2), "prove_ms": round(best[1], 2), "dtype": "u256 (4x64 Montgomery)",
+                                 "runs_ms": [round(r[1], 2) for r in runs], "statistic": "median of 5 after one warm-up"}
                 # this path is integer-ALU bound, not HBM bound: VALU wave-instructions of one prove (committed SQ_INSTS_VALU pass of
                 # this round, only valid for n=32768 k=16) over the measured time, against the VALU issue peak of the chip
                 try:
@@ -422,15 +585,24 @@ def main():
             except Exception as ex:
                 line["bn254"] = {"error": str(ex)}
         if world == 1 and not args.no_cpu_baseline:
+            oracle_proofs = {}
             try:
-                line["cpu_baseline"] = cpu_baseline(args.n, args.k, args.seed)
+                line["cpu_baseline"] = cpu_baseline(args.n, args.k, args.seed, proofs_out=oracle_proofs)
             except Exception as ex:  # the baseline must never take the GPU number down with it
                 line["cpu_baseline"] = {"error": str(ex)}
+            # the baseline leg proved witness 0 with the CPU oracle when the headline size fitted its budget: same bytes?
+            if (args.n, args.k) in oracle_proofs:
+                same = oracle_proofs[(args.n, args.k)] == walked[0]
+                line["config"]["proof_checks"]["witness_0_vs_cpu_oracle"] = "identical" if same else "DIFFERENT"
+                assert same, "the HIP proof of witness 0 differs from the CPU oracle's"
+            else:
+                line["config"]["proof_checks"]["witness_0_vs_cpu_oracle"] = "not run (the oracle was timed on a smaller configuration)"
         print(json.dumps(line), flush=True)
 
     if lib_comm:
         hg.comm_destroy(ctx)
-    vals.free()
+    for v in vals:
+        v.free()
     pk.free()
     ctx.close()
     if world > 1:

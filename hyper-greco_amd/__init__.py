@@ -38,7 +38,7 @@ class HgKernelStat(C.Structure):
 EXPORTS = [
     "hg_last_error", "hg_device_count", "hg_create", "hg_destroy", "hg_set_option", "hg_params_builtin", "hg_params_derive", "hg_grand_product", "hg_fold", "hg_setup", "hg_pk_free",
     "hg_pk_lasso_layout", "hg_pk_info", "hg_witness_from_json", "hg_witness_synthetic", "hg_witness_from_arrays",
-    "hg_witness_get", "hg_witness_free", "hg_prove", "hg_verify", "hg_prove_mode", "hg_prove_resident_mode", "hg_verify_mode", "hg_witness_gen", "hg_witness_gen_into", "hg_values_free", "hg_values_get", "hg_comm_unique_id", "hg_comm_init", "hg_comm_destroy", "hg_prove_sharded", "hg_prove_shard_begin", "hg_prove_shard_combine", "hg_prove_shard_finish", "hg_prove_resident", "hg_circuit_eval", "hg_lasso_prove", "hg_lasso_prove_at", "hg_lasso_num_challenges", "hg_sumcheck", "hg_mle_eval",
+    "hg_witness_get", "hg_witness_free", "hg_prove", "hg_verify", "hg_prove_mode", "hg_prove_resident_mode", "hg_verify_mode", "hg_witness_gen", "hg_witness_gen_into", "hg_values_free", "hg_values_get", "hg_comm_unique_id", "hg_comm_init", "hg_comm_destroy", "hg_comm_count", "hg_comm_selftest", "hg_prove_sharded", "hg_prove_shard_begin", "hg_prove_shard_combine", "hg_prove_shard_finish", "hg_shard_combine_host", "hg_prove_resident", "hg_circuit_eval", "hg_lasso_prove", "hg_lasso_prove_at", "hg_lasso_num_challenges", "hg_sumcheck", "hg_mle_eval",
     "hg_ntt", "hg_challenges", "hg_challenges_bn254", "hg_bn254_field_op", "hg_sumcheck_bn254", "hg_grand_product_bn254", "hg_lasso_prove_bn254", "hg_witness_from_json_bn254", "hg_circuit_eval_bn254", "hg_prove_bn254", "hg_verify_bn254", "hg_mle_eval_bn254", "hg_ntt_bn254", "hg_profile", "hg_profile_select", "hg_profile_reset", "hg_profile_get",
 ]
 
@@ -497,6 +497,17 @@ def prove_shard_combine(ctx, gathered, world):
     _check(lib().hg_prove_shard_combine(ctx.h, _ptr(gathered), world, gathered.size // world))
 
 
+def shard_combine_host(gathered):
+    """hg_shard_combine_host: [world, n] canonical u64 lanes -> lane-wise sum mod p (host only, no device needed)."""
+    a = np.ascontiguousarray(gathered, dtype=np.uint64)
+    world, n = a.shape
+    out = np.zeros(n, dtype=np.uint64)
+    L = lib()
+    L.hg_shard_combine_host.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
+    _check(L.hg_shard_combine_host(_ptr(a), world, n, _ptr(out)))
+    return out
+
+
 def prove_shard_finish(ctx, out):
     _check(lib().hg_prove_shard_finish(ctx.h, out.buf, out.cap, C.byref(out.len), C.byref(out.tm)))
     return out
@@ -554,6 +565,26 @@ def comm_init(ctx, uid, rank, world):
     L = lib()
     L.hg_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     _check(L.hg_comm_init(ctx.h, buf, rank, world))
+
+
+def comm_count(ctx):
+    """hg_comm_count: ranks of the context's RCCL communicator (ncclCommCount)."""
+    L = lib()
+    n = C.c_int(0)
+    L.hg_comm_count.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    _check(L.hg_comm_count(ctx.h, C.byref(n)))
+    return n.value
+
+
+def comm_selftest(ctx, rank_buffers):
+    """hg_comm_selftest: rank_buffers [world, n] u64 canonical lanes -> lane-wise sum mod p through the split / combine kernels."""
+    a = np.ascontiguousarray(rank_buffers, dtype=np.uint64)
+    world, n = a.shape
+    out = np.zeros(n, dtype=np.uint64)
+    L = lib()
+    L.hg_comm_selftest.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
+    _check(L.hg_comm_selftest(ctx.h, _ptr(a), world, n, _ptr(out)))
+    return out
 
 
 def comm_destroy(ctx):

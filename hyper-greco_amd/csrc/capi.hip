@@ -428,6 +428,14 @@ int hg_prove_shard_combine(hg_ctx* ctx, const uint64_t* gathered, int world, siz
     HG_CATCH(-1)
 }
 
+int hg_shard_combine_host(const uint64_t* gathered, int world, size_t n_u64, uint64_t* out) {
+    HG_TRY
+    if (!gathered || !out || world < 1) throw Error("hg_shard_combine_host: bad argument");
+    shard_combine_host(gathered, world, n_u64, out);
+    return 0;
+    HG_CATCH(-1)
+}
+
 int hg_prove_shard_finish(hg_ctx* ctx, uint8_t* proof, size_t cap, size_t* len, hg_timings* timings) {
     HG_TRY
     if (!ctx) throw Error("hg_prove_shard_finish: null context");
@@ -458,6 +466,20 @@ int hg_comm_destroy(hg_ctx* ctx) {
     HG_TRY
     if (!ctx) throw Error("hg_comm_destroy: null context");
     comm_destroy(ctx);
+    return 0;
+    HG_CATCH(-1)
+}
+int hg_comm_count(hg_ctx* ctx, int* ranks) {
+    HG_TRY
+    if (!ctx || !ranks) throw Error("hg_comm_count: null argument");
+    *ranks = comm_count(ctx);
+    return 0;
+    HG_CATCH(-1)
+}
+int hg_comm_selftest(hg_ctx* ctx, const uint64_t* rank_buffers, int world, size_t n_u64, uint64_t* out) {
+    HG_TRY
+    if (!ctx || !rank_buffers || !out) throw Error("hg_comm_selftest: null argument");
+    comm_selftest(ctx, rank_buffers, world, n_u64, out);
     return 0;
     HG_CATCH(-1)
 }

@@ -21,6 +21,7 @@ struct Rccl {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
 };
 Rccl& rccl() {
     static Rccl r;
@@ -36,6 +37,7 @@ Rccl& rccl() {
         r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.so, "ncclCommDestroy"));
         r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(r.so, "ncclAllReduce"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.so, "ncclGetErrorString"));
+        r.CommCount = reinterpret_cast<decltype(r.CommCount)>(dlsym(r.so, "ncclCommCount"));
     });
     if (!r.so || !r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce)
         throw Error("RCCL is not available (librccl.so could not be loaded): multi-GPU proving needs it");
@@ -62,7 +64,45 @@ __global__ void k_combine_limbs(const u64* __restrict__ x, size_t n, u64* __rest
     const u64 lo = gl_from_u64(x[2 * i]), hi = gl_from_u64(x[2 * i + 1]);
     res[i] = gl_add(lo, gl_mul(hi, 1ull << 32));
 }
+// what ncclSum does to the limb lanes of two ranks (selftest only)
+__global__ void k_add_lanes(u64* __restrict__ acc, const u64* __restrict__ x, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) acc[i] += x[i];
+}
 }  // namespace
+
+// The exchange arithmetic without a communicator: `world` rank buffers of n canonical lanes each (host, rank-major) go through
+// k_split_limbs, are added lane-wise as plain 64-bit integers (ncclSum on ncclUint64) and folded back by k_combine_limbs -> out[n].
+// A one-GPU box cannot run a communicator of more than one rank, so this is how the world > 1 branch of the fold-back (limb sums
+// up to world * (2^32 - 1)) is tested on hardware.
+void comm_selftest(hg_ctx* ctx, const u64* bufs, int world, size_t n, u64* out) {
+    if (world < 1 || n == 0) throw Error("hg_comm_selftest: bad argument");
+    hip_check(hipSetDevice(ctx->device), "hipSetDevice");
+    u64 *d_in = nullptr, *d_x = nullptr, *d_acc = nullptr;
+    hip_check(hipMalloc((void**)&d_in, n * 8), "hipMalloc");
+    hip_check(hipMalloc((void**)&d_x, 2 * n * 8), "hipMalloc");
+    hip_check(hipMalloc((void**)&d_acc, 2 * n * 8), "hipMalloc");
+    hip_check(hipMemsetAsync(d_acc, 0, 2 * n * 8, ctx->stream), "memset");
+    const unsigned grid = (unsigned)((n + 255) / 256), grid2 = (unsigned)((2 * n + 255) / 256);
+    for (int r = 0; r < world; r++) {
+        hip_check(hipMemcpyAsync(d_in, bufs + (size_t)r * n, n * 8, hipMemcpyHostToDevice, ctx->stream), "upload");
+        k_split_limbs<<<grid, 256, 0, ctx->stream>>>(d_in, n, d_x);
+        k_add_lanes<<<grid2, 256, 0, ctx->stream>>>(d_acc, d_x, 2 * n);
+    }
+    k_combine_limbs<<<grid, 256, 0, ctx->stream>>>(d_acc, n, d_in);
+    hip_check(hipMemcpyAsync(out, d_in, n * 8, hipMemcpyDeviceToHost, ctx->stream), "download");
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_in); (void)hipFree(d_x); (void)hipFree(d_acc);
+    hip_check(e, "hg_comm_selftest");
+}
+int comm_count(hg_ctx* ctx) {
+    if (!ctx->comm) return 0;
+    Rccl& r = rccl();
+    if (!r.CommCount) return ctx->comm_world;
+    int n = 0;
+    nccl_check(r.CommCount(static_cast<ncclComm_t>(ctx->comm), &n), "ncclCommCount");
+    return n;
+}
 
 void comm_unique_id(uint8_t out[128]) {
     ncclUniqueId id;

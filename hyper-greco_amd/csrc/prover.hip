@@ -2190,7 +2190,10 @@ size_t prove_shard_begin(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int r
 void prove_shard_combine(hg_ctx* ctx, const u64* gathered, int world, size_t n_u64) {
     if (2 * ctx->res_cap < n_u64) throw Error("prove_shard_combine: buffer larger than the result buffer");
     if (!ctx->pending_shard) throw Error("prove_shard_combine: no sharded prove in flight on this context");
-    u64* dst = reinterpret_cast<u64*>(ctx->h_res);
+    shard_combine_host(gathered, world, n_u64, reinterpret_cast<u64*>(ctx->h_res));
+}
+// lane-wise sum mod p of `world` buffers of canonical lanes (host only: what the caller-side exchange of a sharded proof computes)
+void shard_combine_host(const u64* gathered, int world, size_t n_u64, u64* dst) {
     for (size_t i = 0; i < n_u64; i++) {
         u64 acc = 0;
         for (int r = 0; r < world; r++) {

@@ -174,9 +174,12 @@ ProveResult prove_sharded(hg_ctx* ctx, const hg_pk* pk, const hg_values* v);
 void comm_unique_id(uint8_t out[128]);
 void comm_init(hg_ctx* ctx, const uint8_t id[128], int rank, int world);
 void comm_destroy(hg_ctx* ctx);
+int comm_count(hg_ctx* ctx);   // ncclCommCount of the context's communicator (0: none)
+void comm_selftest(hg_ctx* ctx, const u64* bufs, int world, size_t n, u64* out);
 void comm_allreduce_results(hg_ctx* ctx, size_t n_e2);
 void prove_shard_combine(hg_ctx* ctx, const u64* gathered, int world, size_t n_u64);
 ProveResult prove_shard_finish(hg_ctx* ctx);
+void shard_combine_host(const u64* gathered, int world, size_t n_u64, u64* dst);
 // Lasso node alone on a fresh transcript; claim_out = nu point coordinates then the value
 std::vector<uint8_t> prove_lasso_node(hg_ctx* ctx, const hg_pk* pk, const u64* lasso_in_host, size_t chain_skip, std::vector<E2>* claim_out);
 // one sum-check on caller tables (kernel-level parity entry point)

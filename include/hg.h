@@ -163,6 +163,9 @@ int hg_prove_shard_begin(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int r
                          size_t* n_u64);
 int hg_prove_shard_combine(hg_ctx* ctx, const uint64_t* gathered /* world x n_u64, rank-major */, int world, size_t n_u64);
 int hg_prove_shard_finish(hg_ctx* ctx, uint8_t* proof, size_t cap, size_t* len, hg_timings* timings);
+/* the arithmetic of hg_prove_shard_combine alone, host only (no context, no device): out[i] = sum over ranks of gathered[r][i] mod p;
+ * non-canonical lanes are an error. What a caller-side exchange (any byte transport) computes between _begin and _finish. */
+int hg_shard_combine_host(const uint64_t* gathered /* world x n_u64, rank-major */, int world, size_t n_u64, uint64_t* out);
 
 /* The same with the exchange INSIDE the library: one process per GPU, each with its own context and a copy of the resident
  * witness; one RCCL all-reduce per proof (each 64-bit lane as two 32-bit halves in 64-bit lanes, ncclSum, folded back mod p on
@@ -174,6 +177,12 @@ int hg_prove_shard_finish(hg_ctx* ctx, uint8_t* proof, size_t cap, size_t* len, 
 int hg_comm_unique_id(uint8_t out[128]);
 int hg_comm_init(hg_ctx* ctx, const uint8_t id[128], int rank, int world);
 int hg_comm_destroy(hg_ctx* ctx);
+/* number of ranks of the context's communicator as RCCL reports it (ncclCommCount); 0 without a communicator */
+int hg_comm_count(hg_ctx* ctx, int* ranks);
+/* The arithmetic of the exchange without a communicator (a one-GPU box cannot form one of more than one rank): `world` rank
+ * buffers of n_u64 canonical lanes (host, rank-major) are split into 32-bit halves on the device, added lane-wise as plain 64-bit
+ * integers - what ncclAllReduce(ncclUint64, ncclSum) does - and folded back mod p; out[n_u64] = lane-wise sum mod p. */
+int hg_comm_selftest(hg_ctx* ctx, const uint64_t* rank_buffers, int world, size_t n_u64, uint64_t* out);
 int hg_prove_sharded(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, uint8_t* proof, size_t cap, size_t* len, hg_timings* timings);
 
 /* = circuit.evaluate (host part of witness generation) [REF sk_encryption_circuit.rs:442]:

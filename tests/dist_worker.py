@@ -1,0 +1,87 @@
+"""Worker of tests/test_dist_gloo.py: one rank of a world_size-2 job (python -m torch.distributed.run ... dist_worker.py <mode>).
+
+mode "combine" (CPU only): the caller-side exchange of a sharded proof without the device part - every rank builds the partial
+    result buffer it would hold (seeded canonical lanes, zeros where it "owns nothing", lanes at p-1 on EVERY rank), the buffers
+    are all-gathered over gloo and summed by hg_shard_combine_host; every rank checks the result against Python integers.
+mode "prove" (needs a GPU; both ranks on device 0): the real two-process sharded prove - hg_prove_shard_begin on each rank's own
+    context, gloo all-gather of the partial buffers, hg_prove_shard_combine, hg_prove_shard_finish - at n=4096 k=2; every rank
+    must produce the CPU oracle's proof bytes. Three proofs in a row (walk, walk, launch-graph capture) with two witnesses."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import __graft_entry__ as entry  # noqa: E402
+
+P = 0xFFFFFFFF00000001
+
+
+def all_gather_u64(part, world):
+    t = torch.from_numpy(part.view(np.int64).copy())
+    bufs = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(bufs, t)
+    return torch.stack(bufs).numpy().view(np.uint64)
+
+
+def main():
+    mode = sys.argv[1]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend="gloo")
+    hg = entry.load_package()
+    if mode == "combine":
+        n = 4099
+        rng = np.random.default_rng(1234 + rank)
+        part = (rng.integers(0, P, size=n, dtype=np.uint64)).astype(np.uint64)
+        part[rank::3] = 0            # lanes this rank does not own
+        part[:16] = P - 1            # the largest canonical value on every rank
+        part[16:32] = 0xFFFFFFFF     # and the limb boundaries
+        part[32:48] = 0x100000000
+        gathered = all_gather_u64(part, world)
+        assert np.array_equal(gathered[rank], part)
+        got = hg.shard_combine_host(gathered)
+        want = np.array([sum(int(gathered[r][i]) for r in range(world)) % P for i in range(n)], dtype=np.uint64)
+        assert np.array_equal(got, want)
+        bad = gathered.copy()
+        bad[0][5] = P                # non-canonical lane: refused
+        try:
+            hg.shard_combine_host(bad)
+            raise SystemExit("non-canonical lane accepted")
+        except hg.HgError:
+            pass
+        dist.barrier()
+        print("rank %d COMBINE OK" % rank, flush=True)
+    elif mode == "prove":
+        import orclib
+        n, k = 4096, 2
+        ctx = hg.Context(0)
+        bfv = hg.BfvEncrypt.new(n, k)
+        pk = bfv.setup(ctx)
+        ws = [hg.Witness.synthetic(bfv.params, 0x51 + j) for j in range(2)]
+        refs = [orclib.prove(orclib.params(n, k), orclib.Inputs(w.arrays()), threads=4)[0] for w in ws]
+        vals = hg.witness_gen(ctx, pk, ws[0])
+        out = hg.ProofBuffer()
+        for it in range(5):          # walk, walk, capture, then a NEW witness through the same graph, twice
+            j = 0 if it < 3 else 1
+            if it == 3:
+                hg.witness_gen_into(ctx, pk, ws[1], vals)
+            part = hg.prove_shard_begin(ctx, pk, vals, rank, world)
+            gathered = all_gather_u64(np.array(part, copy=True), world)
+            hg.prove_shard_combine(ctx, gathered, world)
+            got = hg.prove_shard_finish(ctx, out).bytes()
+            assert got == refs[j], "rank %d, proof %d: sharded two-process proof differs from the CPU oracle" % (rank, it)
+        dist.barrier()
+        print("rank %d PROVE OK" % rank, flush=True)
+        vals.free(); pk.free(); ctx.close()
+    else:
+        raise SystemExit("unknown mode")
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

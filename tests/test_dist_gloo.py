@@ -1,19 +1,28 @@
-"""world_size-2 gloo test (CPU) of the N>1 path of bench.py: rendezvous on 127.0.0.1, barrier, max-over-ranks
-timing, one JSON line from rank 0, one independent witness seed per rank (weak scaling, no data-path collective)."""
+"""world_size-2 gloo tests of the N>1 path (one process per rank, rendezvous on 127.0.0.1).
+
+CPU (-m "not gpu"): bench.py's rendezvous / barrier / max-over-ranks / rank-0 reporting, and the caller-side exchange of a
+sharded proof - partial result buffers all-gathered over gloo and combined by hg_shard_combine_host - against Python integers.
+GPU (-m gpu): the real two-process sharded prove (tests/dist_worker.py "prove"), both ranks on device 0, compared with the oracle."""
 import json
 import os
 import subprocess
 import sys
 
+import pytest
+
 from hglib import ROOT
 
 
-def test_bench_two_ranks_gloo():
+def _launch(script_args, port, timeout=600):
     env = dict(os.environ)
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "0", "--selftest-dist"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+           "--master-port", str(port)] + script_args
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+
+
+def test_bench_two_ranks_gloo():
+    out = _launch([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "0", "--selftest-dist"], 29517, 300)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout  # only rank 0 reports
@@ -22,3 +31,29 @@ def test_bench_two_ranks_gloo():
     # max over ranks: rank 1 sleeps 20 ms per step
     assert d["ms_per_step"] >= 19.0
     assert abs(d["value"] - d["ms_per_step"] / 2) < 1e-9
+    assert d["exchange_selftest"] == "identical"   # partial buffers all-gathered over gloo, combined, compared with Python integers
+
+
+def test_sharded_exchange_two_ranks_gloo():
+    out = _launch([os.path.join(ROOT, "tests", "dist_worker.py"), "combine"], 29519, 300)
+    assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-2000:])
+    assert out.stdout.count("COMBINE OK") == 2, out.stdout
+
+
+def test_bench_collective_deadline_exits_nonzero():
+    """bench.py's guard around the first collective: a block that outlives its deadline ends the process with exit code 3."""
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "with bench.deadline(0.2, 'selftest'):\n    time.sleep(5)\nprint('NOT REACHED')\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 3 and "NOT REACHED" not in r.stdout and "did not finish within" in r.stderr
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "with bench.deadline(5, 'selftest'):\n    pass\ntime.sleep(0.3); print('FINE')\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "FINE" in r.stdout
+
+
+@pytest.mark.gpu
+def test_sharded_prove_two_processes_gloo_matches_the_oracle():
+    out = _launch([os.path.join(ROOT, "tests", "dist_worker.py"), "prove"], 29521, 900)
+    assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-3000:])
+    assert out.stdout.count("PROVE OK") == 2, out.stdout

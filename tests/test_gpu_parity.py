@@ -559,6 +559,25 @@ def test_library_collective_single_rank_communicator(ctx):
     pk.free()
 
 
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_exchange_limb_kernels_for_more_than_one_rank(ctx, world):
+    """k_split_limbs -> (what ncclSum does to the limb lanes of `world` ranks) -> k_combine_limbs against the lane-wise sum mod p
+    in Python integers. A one-GPU box only ever forms a one-rank communicator, where both limb sums stay below 2^32; here the
+    fold-back sees sums up to world (2^32 - 1), with lanes at p - 1 and at the limb boundaries on EVERY rank."""
+    rng = np.random.default_rng(world)
+    n = 20000 + world
+    bufs = rng.integers(0, P, size=(world, n), dtype=np.uint64)
+    edge = [P - 1, P - 2, 0xFFFFFFFF, 0x100000000, 0xFFFFFFFF00000000, 0xFFFFFFFEFFFFFFFF, 0, 1]
+    for i, e in enumerate(edge):
+        bufs[:, i] = e                       # the same extreme lane on every rank
+        bufs[:, 100 + i] = 0
+        bufs[i % world, 100 + i] = e         # ... and on one rank only
+    got = hg.comm_selftest(ctx, bufs)
+    want = np.array([sum(int(bufs[r][i]) for r in range(world)) % P for i in range(n)], dtype=np.uint64)
+    assert np.array_equal(got, want)
+    assert np.array_equal(hg.shard_combine_host(bufs), want)   # the caller-side combine agrees
+
+
 def test_bench_sharded_two_processes_on_one_gpu():
     """The N>1 bench path end to end with two real processes (gloo all-reduce through host tensors, both ranks on
     device 0): rendezvous, per-rank job ownership, the all-reduce, replay; bench.py itself asserts that the sharded
