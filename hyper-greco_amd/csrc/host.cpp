@@ -8,6 +8,10 @@
 #include <sstream>
 #include <functional>
 #include <omp.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 namespace hg {
 
@@ -177,19 +181,46 @@ void params_derive(uint32_t n, uint32_t k, const u64* qis, u64 t, hg_params* out
 // ------------------------------------------------------------------------------------------------
 // JSON witness: {"s":[".."],"e":[..],"k1":[..],"r2is":[[..]],"r1is":[[..]],"ais":[[..]],"ct0is":[[..]]}
 namespace {
+// One flat array of quoted decimals whose elements are parsed later, in parallel (parse_array_jobs)
+struct ArrayJob { size_t begin, end; int field, z; };   // bytes [begin, end) between the brackets; field: 0 s, 1 e, 2 k1, 3 r2is, 4 r1is, 5 ais, 6 ct0is
+
 struct JsonCursor {
-    const std::string& s;
+    const char* s;
+    size_t n;
     size_t i = 0;
-    explicit JsonCursor(const std::string& str) : s(str) {}
-    void ws() { while (i < s.size() && (s[i] == ' ' || s[i] == '\n' || s[i] == '\t' || s[i] == '\r')) i++; }
-    bool eat(char c) { ws(); if (i < s.size() && s[i] == c) { i++; return true; } return false; }
+    std::vector<ArrayJob> jobs;
+    std::vector<size_t> closers;   // positions of every ']' of the text, ascending (found in parallel by the constructor)
+    JsonCursor(const char* p, size_t len) : s(p), n(len) {
+        const int nt = std::max(1, std::min<int>(omp_get_max_threads(), (int)std::min<size_t>(32, len / ((size_t)1 << 20) + 1)));
+        std::vector<std::vector<size_t>> part(nt);
+#pragma omp parallel for schedule(static, 1) num_threads(nt)
+        for (int t = 0; t < nt; t++) {
+            size_t b = len * (size_t)t / nt;
+            const size_t e = len * (size_t)(t + 1) / nt;
+            while (b < e) {
+                const void* q = memchr(p + b, ']', e - b);
+                if (!q) break;
+                part[t].push_back((size_t)((const char*)q - p));
+                b = part[t].back() + 1;
+            }
+        }
+        for (auto& v : part) closers.insert(closers.end(), v.begin(), v.end());
+    }
+    size_t next_closer(size_t from) const {
+        auto it = std::lower_bound(closers.begin(), closers.end(), from);
+        if (it == closers.end()) throw Error("witness json: unterminated array");
+        return *it;
+    }
+    void ws() { while (i < n && (s[i] == ' ' || s[i] == '\n' || s[i] == '\t' || s[i] == '\r')) i++; }
+    bool eat(char c) { ws(); if (i < n && s[i] == c) { i++; return true; } return false; }
     void need(char c) { if (!eat(c)) throw Error(std::string("witness json: expected '") + c + "' at offset " + std::to_string(i)); }
     std::string str() {
         need('"');
         size_t b = i;
-        while (i < s.size() && s[i] != '"') i++;
-        if (i >= s.size()) throw Error("witness json: unterminated string");
-        return s.substr(b, i++ - b);
+        const void* q = memchr(s + i, '"', n - i);
+        if (!q) throw Error("witness json: unterminated string");
+        i = (size_t)((const char*)q - s);
+        return std::string(s + b, i++ - b);
     }
     bool bn254 = false;  // coefficients are bn256::Fr elements holding small signed integers (see witness_from_json_bn254)
     u64 felt_bn254(const std::string& d) {
@@ -221,12 +252,22 @@ struct JsonCursor {
             throw Error("witness json: bn254 coefficient is not a signed integer below 2^62 in magnitude (unsupported witness)");
         return GL_P - m[0];
     }
-    u64 felt() {  // F::from_str_vartime on a decimal string (poly.rs:13-16)
-        std::string d = str();
-        if (d.empty()) throw Error("witness json: empty coefficient");
-        if (bn254) return felt_bn254(d);
+    u64 felt_digits(const char* d, size_t len) {  // F::from_str_vartime on a decimal string (poly.rs:13-16)
+        if (len == 0) throw Error("witness json: empty coefficient");
+        if (bn254) return felt_bn254(std::string(d, len));
+        if (len <= 19) {   // below 10^19 < 2^64: plain 64-bit accumulation
+            u64 v = 0;
+            for (size_t q = 0; q < len; q++) {
+                const unsigned c = (unsigned char)d[q] - '0';
+                if (c > 9) throw Error("witness json: non-decimal coefficient");
+                v = v * 10 + c;
+            }
+            if (v >= GL_P) throw Error("witness json: coefficient out of field range");
+            return v;
+        }
         unsigned __int128 v = 0;
-        for (char c : d) {
+        for (size_t q = 0; q < len; q++) {
+            const char c = d[q];
             if (c < '0' || c > '9') throw Error("witness json: non-decimal coefficient");
             v = v * 10 + (unsigned)(c - '0');
             if (v >= ((unsigned __int128)1 << 64)) throw Error("witness json: coefficient out of field range");
@@ -234,21 +275,102 @@ struct JsonCursor {
         if ((u64)v >= GL_P) throw Error("witness json: coefficient out of field range");
         return (u64)v;
     }
-    std::vector<u64> felts() {
-        std::vector<u64> v;
+    // A flat array: only its extent is found here (a decimal string cannot contain ']', so the next ']' closes it; anything else
+    // between the brackets is rejected by the element parser); the elements are parsed by parse_array_jobs.
+    void felts(int field, int z = 0) {
         need('[');
-        if (eat(']')) return v;
-        do v.push_back(felt()); while (eat(','));
-        need(']');
-        return v;
+        const size_t end = next_closer(i);
+        jobs.push_back(ArrayJob{i, end, field, z});
+        i = end + 1;
     }
-    std::vector<std::vector<u64>> felts2() {
-        std::vector<std::vector<u64>> v;
+    int felts2(int field) {   // -> number of inner arrays
         need('[');
-        if (eat(']')) return v;
-        do v.push_back(felts()); while (eat(','));
+        if (eat(']')) return 0;
+        int z = 0;
+        do felts(field, z++); while (eat(','));
         need(']');
-        return v;
+        return z;
+    }
+    // Parses the elements of bytes [b, e): ws* ( '"' digits '"' ws* (',' | end) )*. Strict: anything else is an error.
+    void parse_piece(size_t b, size_t e, std::vector<u64>& out) {
+        size_t q = b;
+        auto skip = [&] { while (q < e && (s[q] == ' ' || s[q] == '\n' || s[q] == '\t' || s[q] == '\r')) q++; };
+        skip();
+        while (q < e) {
+            if (s[q] != '"') throw Error("witness json: expected '\"' at offset " + std::to_string(q));
+            const size_t d0 = ++q;
+            while (q < e && s[q] != '"') q++;
+            if (q >= e) throw Error("witness json: unterminated string");
+            out.push_back(felt_digits(s + d0, q - d0));
+            q++;
+            skip();
+            if (q < e) {
+                if (s[q] != ',') throw Error("witness json: expected ',' at offset " + std::to_string(q));
+                q++;
+                skip();
+                if (q >= e) throw Error("witness json: trailing ',' in an array");
+            }
+        }
+    }
+    // All deferred arrays, in parallel: every array is cut into pieces at element boundaries (the byte after a ','), every piece is
+    // parsed by one thread into its own vector, the pieces are concatenated per array. The 53 MB of decimal strings of an
+    // n=32768 k=16 witness (2.7 M coefficients) take a few ms on a many-core host instead of > 100 ms.
+    // place(job, count) -> where the job's `count` elements go (checks the count; the destination is already zero-filled)
+    void parse_array_jobs(const std::function<u64*(const ArrayJob&, size_t)>& place) {
+        struct Piece { size_t job, b, e; std::vector<u64> v; };
+        std::vector<Piece> pieces;
+        const size_t target = (size_t)256 << 10;   // bytes per piece
+        for (size_t j = 0; j < jobs.size(); j++) {
+            size_t b = jobs[j].begin;
+            const size_t e = jobs[j].end;
+            while (b < e) {
+                size_t cut = e;
+                if (e - b > target + target / 2) {
+                    const void* c = memchr(s + b + target, ',', e - (b + target));
+                    if (c) cut = (size_t)((const char*)c - s) + 1;   // the piece keeps its closing ','; the next starts at an element
+                }
+                pieces.push_back(Piece{j, b, cut, {}});
+                b = cut;
+            }
+        }
+        std::string err;
+        const int nt = std::max(1, std::min<int>(omp_get_max_threads(), std::min<int>(64, (int)pieces.size())));
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nt)
+        for (size_t q = 0; q < pieces.size(); q++) {
+            Piece& P = pieces[q];
+            try {
+                P.v.reserve((P.e - P.b) / 16 + 8);
+                size_t e = P.e;
+                const bool last = e == jobs[P.job].end;
+                if (!last) e--;   // drop the separator that ends this piece (parse_piece would call it a trailing ',')
+                parse_piece(P.b, e, P.v);
+            } catch (const std::exception& ex) {
+#pragma omp critical
+                if (err.empty()) err = ex.what();
+            }
+        }
+        if (!err.empty()) throw Error(err);
+        std::vector<size_t> first(jobs.size() + 1, pieces.size());
+        for (size_t q = pieces.size(); q-- > 0;) first[pieces[q].job] = q;
+        for (size_t j = jobs.size(); j-- > 0;) if (first[j] == pieces.size()) first[j] = first[j + 1];
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nt)
+        for (size_t j = 0; j < jobs.size(); j++) {
+            size_t total = 0;
+            for (size_t q = first[j]; q < pieces.size() && pieces[q].job == j; q++) total += pieces[q].v.size();
+            try {
+                u64* d = place(jobs[j], total);
+                size_t at = 0;
+                for (size_t q = first[j]; d && q < pieces.size() && pieces[q].job == j; q++) {
+                    memcpy(d + at, pieces[q].v.data(), pieces[q].v.size() * 8);
+                    at += pieces[q].v.size();
+                }
+            } catch (const std::exception& ex) {
+#pragma omp critical
+                if (err.empty()) err = ex.what();
+            }
+        }
+        if (!err.empty()) throw Error(err);
+        jobs.clear();
     }
 };
 
@@ -288,16 +410,24 @@ Witness layout_inputs(const Params& p, const RawArgs& a) {  // get_inputs (sk_en
     w.r1is.resize(k * SZ);
     w.r2is.assign(k * PZ, 0);
     w.ct0is.resize(k * SZ);
+    for (size_t z = 0; z < k; z++) if (a.r2is[z].size() + 1 != PZ) throw Error("witness: r2i must have n-1 coefficients");
+    std::string err;
+#pragma omp parallel for schedule(static, 1) num_threads((int)std::min<size_t>(k, (size_t)omp_get_max_threads()))
     for (size_t z = 0; z < k; z++) {
-        put_padded(a.ais[z], SZ, &w.ais[z * SZ]);
-        put_padded(a.r1is[z], SZ, &w.r1is[z * SZ]);
-        if (a.r2is[z].size() + 1 != PZ) throw Error("witness: r2i must have n-1 coefficients");
-        std::copy(a.r2is[z].begin(), a.r2is[z].end(), &w.r2is[z * PZ]);  // + one trailing zero (:402-405)
-        std::vector<u64> ct = shifted(a.ct0is[z], SZ);                    // :393
-        if (ct.size() != SZ) throw Error("witness: ct0i length");
-        std::copy(ct.begin() + 1, ct.end(), &w.ct0is[z * SZ]);            // [1..] then push 0 (:394-395)
-        w.ct0is[z * SZ + SZ - 1] = 0;
+        try {
+            put_padded(a.ais[z], SZ, &w.ais[z * SZ]);
+            put_padded(a.r1is[z], SZ, &w.r1is[z * SZ]);
+            std::copy(a.r2is[z].begin(), a.r2is[z].end(), &w.r2is[z * PZ]);  // + one trailing zero (:402-405)
+            std::vector<u64> ct = shifted(a.ct0is[z], SZ);                    // :393
+            if (ct.size() != SZ) throw Error("witness: ct0i length");
+            std::copy(ct.begin() + 1, ct.end(), &w.ct0is[z * SZ]);            // [1..] then push 0 (:394-395)
+            w.ct0is[z * SZ + SZ - 1] = 0;
+        } catch (const std::exception& ex) {   // (an exception must not leave the parallel region)
+#pragma omp critical
+            if (err.empty()) err = ex.what();
+        }
     }
+    if (!err.empty()) throw Error(err);
     return w;
 }
 }  // namespace
@@ -309,32 +439,69 @@ Witness witness_from_json(const Params& p, const std::string& path) { return wit
 // it in the Goldilocks form (p - |z|); the BN254 prover lifts z into Fr on the device (bn254_gkr.inc: k_bn_lift_signed).
 Witness witness_from_json_bn254(const Params& p, const std::string& path) { return witness_from_json_impl(p, path, true); }
 static Witness witness_from_json_impl(const Params& p, const std::string& path, bool bn254) {
-    std::ifstream f(path, std::ios::binary);
-    if (!f) throw Error("witness json: cannot open " + path);
-    std::stringstream ss;
-    ss << f.rdbuf();
-    std::string text = ss.str();
-    JsonCursor c(text);
+    // the file is mapped, not copied; the structure is walked once (only bracket searches), the coefficients are parsed in parallel
+    struct Mapped {
+        int fd = -1; void* p = MAP_FAILED; size_t n = 0;
+        ~Mapped() { if (p != MAP_FAILED) munmap(p, n); if (fd >= 0) close(fd); }
+    } m;
+    m.fd = open(path.c_str(), O_RDONLY);
+    if (m.fd < 0) throw Error("witness json: cannot open " + path);
+    struct stat stt;
+    if (fstat(m.fd, &stt) != 0 || stt.st_size <= 0) throw Error("witness json: cannot read " + path);
+    m.n = (size_t)stt.st_size;
+    m.p = mmap(nullptr, m.n, PROT_READ, MAP_PRIVATE | MAP_POPULATE, m.fd, 0);
+    if (m.p == MAP_FAILED) throw Error("witness json: cannot map " + path);
+    const bool tm = getenv("HG_JSON_TIMES") != nullptr;
+    const double t0 = omp_get_wtime();
+    JsonCursor c(static_cast<const char*>(m.p), m.n);
     c.bn254 = bn254;
-    RawArgs a;
     c.need('{');
-    int seen = 0;
+    int seen = 0, inner[7] = {1, 1, 1, 0, 0, 0, 0};
     do {
         std::string key = c.str();
         c.need(':');
-        if (key == "s") a.s = c.felts();
-        else if (key == "e") a.e = c.felts();
-        else if (key == "k1") a.k1 = c.felts();
-        else if (key == "r2is") a.r2is = c.felts2();
-        else if (key == "r1is") a.r1is = c.felts2();
-        else if (key == "ais") a.ais = c.felts2();
-        else if (key == "ct0is") a.ct0is = c.felts2();
+        if (key == "s") c.felts(0);
+        else if (key == "e") c.felts(1);
+        else if (key == "k1") c.felts(2);
+        else if (key == "r2is") inner[3] = c.felts2(3);
+        else if (key == "r1is") inner[4] = c.felts2(4);
+        else if (key == "ais") inner[5] = c.felts2(5);
+        else if (key == "ct0is") inner[6] = c.felts2(6);
         else throw Error("witness json: unknown key " + key);
         seen++;
     } while (c.eat(','));
     c.need('}');
     if (seen != 7) throw Error("witness json: expected 7 fields");
-    return layout_inputs(p, a);
+    const double t1 = omp_get_wtime();
+    // get_inputs (sk_encryption_circuit.rs:365-415) applied while the coefficients are placed: the layouts of layout_inputs()
+    // (Poly::new_padded / new_shifted, poly.rs:20-44) as destination offsets, so the 22 MB of tables are written once
+    const size_t SZ = p.SZ(), PZ = p.PZ(), k = (size_t)p.k;
+    for (int f = 3; f < 7; f++) if ((size_t)inner[f] < k) throw Error("witness: fewer CRT components than k");
+    Witness w;
+    w.s.resize(SZ); w.e.resize(SZ); w.k1.resize(SZ);
+    w.ais.resize(k * SZ); w.r1is.resize(k * SZ); w.r2is.resize(k * PZ); w.ct0is.resize(k * SZ);
+    // (a coefficient count that does not fit its table is an error here; Poly::new_shifted's resize would truncate it silently)
+    c.parse_array_jobs([&](const ArrayJob& J, size_t cnt) -> u64* {
+        const size_t z = (size_t)J.z;
+        if (J.field >= 3 && z >= k) return nullptr;   // components beyond k are parsed (validated) and ignored, as get_inputs ignores them
+        switch (J.field) {
+            case 0: if (cnt > SZ) throw Error("witness: polynomial longer than its table"); return w.s.data();                       // new_padded
+            case 1: case 2: {                                                                                                        // new_shifted(.., 2^L - 1)
+                if (cnt > SZ - 1) throw Error("witness: e/k1 length");
+                return (J.field == 1 ? w.e.data() : w.k1.data()) + (SZ - 1 - cnt);
+            }
+            case 3: if (cnt + 1 != PZ) throw Error("witness: r2i must have n-1 coefficients"); return &w.r2is[z * PZ];             // + one trailing zero (:402-405)
+            case 4: if (cnt > SZ) throw Error("witness: polynomial longer than its table"); return &w.r1is[z * SZ];
+            case 5: if (cnt > SZ) throw Error("witness: polynomial longer than its table"); return &w.ais[z * SZ];
+            default: {                                                                                                               // shifted to 2^L, first dropped, 0 pushed (:393-395)
+                if (cnt + 1 > SZ) throw Error("witness: ct0i length");
+                return &w.ct0is[z * SZ] + (SZ - cnt - 1);
+            }
+        }
+    });
+    const double t2 = omp_get_wtime();
+    if (tm) fprintf(stderr, "[hg] json: structure %.2f ms, coefficients + layout %.2f ms\n", (t1 - t0) * 1e3, (t2 - t1) * 1e3);
+    return w;
 }
 
 // ------------------------------------------------------------------------------------------------

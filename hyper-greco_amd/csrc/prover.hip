@@ -1646,12 +1646,16 @@ struct Prover {
         // The Vanilla / FFT node reductions go to the second stream: they are independent of the Lasso node on the
         // device and consist mostly of small launches that leave CUs idle, so the two streams overlap.
         fork_nodes_stream();
+        stamp("node reductions begin");
         flush_bookkeeping();                   // eq tables, constant sums, Libra gathers, DFT-row tables: batched
+        stamp("node bookkeeping done");
         flush_prodsum();                       // first wave: every FFT / Libra phase-1 reduction, batched
+        stamp("node phase 1 done");
         for (auto& f : second_wave) f();       // Libra phase-2 bookkeeping (needs the phase-1 scalars in HBM)
         second_wave.clear();
         flush_bookkeeping();
         flush_prodsum();
+        stamp("node reductions done");
         join_nodes_stream();
     }
 
