@@ -23,6 +23,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the CPU baseline shares this process with the product library's OpenMP runtime: idle teams must sleep, not spin (read when the
+# runtimes load; measured on 8 cores: the Vanilla-node share of the oracle prove 630 ms spinning vs 142 ms passive)
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 # profile class of the library -> kernel symbol in rocprofv3 output. The class with the largest share of the GPU time
@@ -88,7 +91,7 @@ def cpu_baseline(n, k, seed, budget_s=60.0, proofs_out=None):
     """CPU baseline on this host's cores, same witness as the GPU run, GKR-prove span only.
     kind "reference": the reference's own rayon prover (needs cargo + network + $HYPER_GRECO: scripts/reference_baseline.py);
     otherwise kind "port": the CPU oracle (this repo's restatement, OpenMP where the reference uses rayon). Method: the thread
-    count is chosen among {16, 32, 64, 128} on the small configuration, then 1 warm + 3 timed runs, median. Bounded: a small config is timed first and the largest config whose predicted time fits the
+    count is chosen among {16, 32, 64, 128, 256} on the small configuration, then 1 warm + 3 timed runs, median. Bounded: a small config is timed first and the largest config whose predicted time fits the
     budget is run (scaled by the ratio of Lasso rows, stated in `sample`)."""
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     attempt = toolchain_probe()
@@ -122,7 +125,7 @@ def cpu_baseline(n, k, seed, budget_s=60.0, proofs_out=None):
 
     # thread count: chosen on the small configuration (more threads than 128 thrash on this kind of host: a 256-thread run of
     # n=16384 was measured at 294 s against 2.2 s with 64)
-    cands = sorted({min(cores, t) for t in (16, 32, 64, 128)})
+    cands = sorted({min(cores, t) for t in (16, 32, 64, 128, 256)})
     run(4096, 2, cands[-1])  # warm the page cache / thread pool
     sweep = {th: run(4096, 2, th) for th in cands}
     best = min(sweep, key=sweep.get)

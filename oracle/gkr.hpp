@@ -68,12 +68,26 @@ static inline std::vector<E> fft_table(const std::vector<E>& r, size_t L, bool i
     if (inverse) w = f_inv(w);
     std::vector<F> W(N);
     W[0] = f_one();
-    for (size_t i = 1; i < N; i++) W[i] = f_mul(W[i - 1], w);
+    {   // powers of w: runs of 4096 in parallel, each started from w^(run start)
+        const size_t RUN = 4096, nrun = (N + RUN - 1) / RUN;
+        const F wrun = f_pow(w, RUN);
+        std::vector<F> start(nrun);
+        start[0] = f_one();
+        for (size_t q = 1; q < nrun; q++) start[q] = f_mul(start[q - 1], wrun);
+#pragma omp parallel for schedule(static) num_threads(orc_threads_for(N, 8192))
+        for (long long q = 0; q < (long long)nrun; q++) {
+            size_t i0 = (size_t)q * RUN, i1 = std::min(N, i0 + RUN);
+            W[i0] = start[q];
+            for (size_t i = i0 + 1; i < i1; i++) W[i] = f_mul(W[i - 1], w);
+        }
+    }
     std::vector<E> cur(1, inverse ? e_from_f(f_inv(f_from_u64(N))) : e_one());
     for (size_t bb = L; bb-- > 0;) {
         size_t sz = (size_t)1 << (L - bb);
         std::vector<E> nxt(sz);
-        for (size_t x = 0; x < sz; x++) {
+#pragma omp parallel for schedule(static) num_threads(orc_threads_for(sz, 4096))
+        for (long long xx = 0; xx < (long long)sz; xx++) {
+            const size_t x = (size_t)xx;
             F wx = W[(x << bb) & (N - 1)];
             E f = e_add_f(e_mul_f(r[bb], f_sub(wx, f_one())), f_one());
             nxt[x] = e_mul(cur[x & (sz / 2 - 1)], f);
@@ -205,10 +219,13 @@ static inline std::vector<Values> circuit_evaluate(const Circuit& c, const std::
 static inline std::vector<E> combined_eq(const std::vector<EvalClaim>& cl, const std::vector<E>& alpha) {
     std::vector<E> eqc = eq_table(cl[0].point);
     if (cl.size() == 1 && e_eq(alpha[0], e_one())) return eqc;
-    for (auto& x : eqc) x = e_mul(x, alpha[0]);
+    const long long n = (long long)eqc.size();
+#pragma omp parallel for schedule(static) num_threads(orc_threads_for((size_t)n, 4096))
+    for (long long i = 0; i < n; i++) eqc[i] = e_mul(eqc[i], alpha[0]);
     for (size_t a = 1; a < cl.size(); a++) {
         std::vector<E> t = eq_table(cl[a].point);
-        for (size_t i = 0; i < t.size(); i++) eqc[i] = e_add(eqc[i], e_mul(t[i], alpha[a]));
+#pragma omp parallel for schedule(static) num_threads(orc_threads_for((size_t)n, 4096))
+        for (long long i = 0; i < n; i++) eqc[i] = e_add(eqc[i], e_mul(t[i], alpha[a]));
     }
     return eqc;
 }
@@ -234,15 +251,38 @@ static inline std::vector<std::vector<EvalClaim>> vanilla_prove(const Node& n, c
     size_t nin = n.log2_sub_in + n.log2_reps;
     std::vector<E> eqc = combined_eq(cl, alpha);
     E claim = combined_value(cl, alpha);
-    for (size_t rep = 0; rep < R; rep++)
-        for (auto& t : n.w0) claim = e_sub(claim, e_mul_f(eqc[rep * G + t.gate], f_from_u64(t.c)));
+    // Bookkeeping loops in parallel (field sums are exact, so any order gives the same tables): a "slot" is one (repetition,
+    // band of input positions j); a slot's writes go to its own part of the tables, every slot scans the node's gate list. Nodes
+    // with many repetitions split by repetition, single-repetition nodes (up to 1.7 M gates) by bands of j.
+    const size_t bands = R >= 16 ? 1 : std::max<size_t>(1, std::min<size_t>(S / 1024, (size_t)omp_get_max_threads() / R));
+    const long long slots = (long long)(R * bands);
+    auto band_of = [&](size_t j) { return j * bands / S; };
+    {
+        E dsum = e_zero();
+#pragma omp parallel num_threads(orc_threads_for(R * n.w0.size(), 4096))
+        {
+            E a = e_zero();
+#pragma omp for nowait schedule(static)
+            for (long long rr = 0; rr < (long long)R; rr++)
+                for (auto& t : n.w0) a = e_add(a, e_mul_f(eqc[(size_t)rr * G + t.gate], f_from_u64(t.c)));
+#pragma omp critical
+            dsum = e_add(dsum, a);
+        }
+        claim = e_sub(claim, dsum);
+    }
     VanillaUse use = vanilla_use(n);
     // phase 1 bookkeeping tables
     std::vector<std::vector<E>> T(n.arity);
     for (size_t i = 0; i < n.arity; i++) if (use.left[i]) T[i].assign(S * R, e_zero());
-    for (size_t rep = 0; rep < R; rep++) {
-        for (auto& t : n.lin) { E& d = T[t.in][rep * S + t.j]; d = e_add(d, e_mul_f(eqc[rep * G + t.gate], f_from_u64(t.c))); }
+#pragma omp parallel for schedule(dynamic, 1) num_threads(orc_threads_for((size_t)slots * (n.lin.size() + n.mul.size()), 8192))
+    for (long long sl = 0; sl < slots; sl++) {
+        const size_t rep = (size_t)sl / bands, band = (size_t)sl % bands;
+        for (auto& t : n.lin) {
+            if (bands > 1 && band_of(t.j) != band) continue;
+            E& d = T[t.in][rep * S + t.j]; d = e_add(d, e_mul_f(eqc[rep * G + t.gate], f_from_u64(t.c)));
+        }
         for (auto& t : n.mul) {
+            if (bands > 1 && band_of(t.j0) != band) continue;
             E& d = T[t.i0][rep * S + t.j0];
             d = e_add(d, e_mul_f(eqc[rep * G + t.gate], f_mul(f_from_u64(t.c), (*in[t.i1])[rep * S + t.j1])));
         }
@@ -263,15 +303,32 @@ static inline std::vector<std::vector<EvalClaim>> vanilla_prove(const Node& n, c
     if (use.has_mul) {
         std::vector<E> eqx = eq_table(r1.point);
         E claim2 = r1.claim;
-        for (size_t rep = 0; rep < R; rep++)
-            for (auto& t : n.lin) claim2 = e_sub(claim2, e_mul(u[t.in], e_mul(e_mul_f(eqc[rep * G + t.gate], f_from_u64(t.c)), eqx[rep * S + t.j])));
+        {
+            E dsum = e_zero();
+#pragma omp parallel num_threads(orc_threads_for(R * n.lin.size(), 4096))
+            {
+                E a = e_zero();
+#pragma omp for nowait schedule(static)
+                for (long long rr = 0; rr < (long long)R; rr++) {
+                    const size_t rep = (size_t)rr;
+                    for (auto& t : n.lin) a = e_add(a, e_mul(u[t.in], e_mul(e_mul_f(eqc[rep * G + t.gate], f_from_u64(t.c)), eqx[rep * S + t.j])));
+                }
+#pragma omp critical
+                dsum = e_add(dsum, a);
+            }
+            claim2 = e_sub(claim2, dsum);
+        }
         std::vector<std::vector<E>> B(n.arity);
         for (size_t i = 0; i < n.arity; i++) if (use.right[i]) B[i].assign(S * R, e_zero());
-        for (size_t rep = 0; rep < R; rep++)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(orc_threads_for((size_t)slots * n.mul.size(), 8192))
+        for (long long sl = 0; sl < slots; sl++) {
+            const size_t rep = (size_t)sl / bands, band = (size_t)sl % bands;
             for (auto& t : n.mul) {
+                if (bands > 1 && band_of(t.j1) != band) continue;
                 E& d = B[t.i1][rep * S + t.j1];
                 d = e_add(d, e_mul(e_mul(e_mul_f(eqc[rep * G + t.gate], f_from_u64(t.c)), eqx[rep * S + t.j0]), u[t.i0]));
             }
+        }
         std::vector<ScTable> tabs2;
         std::vector<size_t> ri;
         for (size_t i = 0; i < n.arity; i++) if (use.right[i]) {
@@ -330,7 +387,8 @@ static inline std::vector<E> fft_combined_table(const Node& n, const std::vector
         std::vector<E> t = fft_table(cl[a].point, n.log2_size, n.inverse);
         if (a == 0 && cl.size() == 1) return t;
         if (a == 0) { Fc.assign(t.size(), e_zero()); }
-        for (size_t i = 0; i < t.size(); i++) Fc[i] = e_add(Fc[i], e_mul(t[i], alpha[a]));
+#pragma omp parallel for schedule(static) num_threads(orc_threads_for(t.size(), 4096))
+        for (long long i = 0; i < (long long)t.size(); i++) Fc[i] = e_add(Fc[i], e_mul(t[i], alpha[a]));
     }
     return Fc;
 }
@@ -377,12 +435,14 @@ static inline std::vector<std::vector<EvalClaim>> prove_gkr(const Circuit& c, co
         std::vector<const Values*> in;
         for (size_t p : c.preds[id]) in.push_back(&vals[p]);
         std::vector<std::vector<EvalClaim>> sub;
+        const double t0 = omp_get_wtime();
         switch (n.kind) {
-            case NK_VANILLA: sub = vanilla_prove(n, cl, alpha, in, tr); break;
-            case NK_FFT: sub = fft_prove(n, cl, alpha, *in[0], tr); break;
+            case NK_VANILLA: sub = vanilla_prove(n, cl, alpha, in, tr); orc_times().add("node vanilla (all)", t0); break;
+            case NK_FFT: sub = fft_prove(n, cl, alpha, *in[0], tr); orc_times().add("node fft (all)", t0); break;
             case NK_LASSO: {
                 LassoClaim lc = lasso_prove(*n.pre, n.lasso, in[0]->data(), tr);
                 sub = {{EvalClaim{lc.r, lc.value}}};
+                orc_times().add("node lasso (all)", t0);
                 break;
             }
             default: break;
@@ -390,6 +450,7 @@ static inline std::vector<std::vector<EvalClaim>> prove_gkr(const Circuit& c, co
         for (size_t i = 0; i < c.preds[id].size(); i++)
             for (auto& s : sub[i]) claims[c.preds[id][i]].push_back(s);
     }
+    orc_times().dump();
     return claims;
 }
 

@@ -295,19 +295,21 @@ static inline std::pair<std::vector<E>, std::vector<E>> prove_grand_product(
     size_t nv = ilog2_u64(len);  // table has nv variables; bottom layer has nv-1
     // level arrays: A_0 = v (view), A_k = A_{k-1}[lo] * A_{k-1}[hi]   (Layer::bottom :310-315, Layer::up :332-354)
     std::vector<std::vector<std::vector<T>>> lev(nb);
+    // one region for all tables and levels: (table, block of 4096 outputs) items per level, a barrier between levels
     for (size_t b = 0; b < nb; b++) {
         lev[b].resize(nv);  // lev[b][0] unused (view of vs[b])
-        const T* prev = vs[b];
-        size_t plen = len;
-        for (size_t k = 1; k < nv; k++) {
-            size_t h = plen >> 1;
-            lev[b][k].resize(h);
-            T* out = lev[b][k].data();
-#pragma omp parallel for schedule(static) if (h > 4096)
-            for (long long i = 0; i < (long long)h; i++) out[i] = G::mul(prev[i], prev[i + h]);
-            prev = out;
-            plen = h;
-        }
+        for (size_t k = 1; k < nv; k++) lev[b][k].resize(len >> k);
+    }
+    for (size_t k = 1; k < nv; k++) {
+        const size_t h = len >> k, BLK = 4096, nblk = (h + BLK - 1) / BLK;
+#pragma omp parallel for schedule(static) collapse(2) num_threads(orc_threads_for(nb * h, 8192))
+        for (long long bb = 0; bb < (long long)nb; bb++)
+            for (long long q = 0; q < (long long)nblk; q++) {
+                const T* prev = k == 1 ? vs[bb] : lev[bb][k - 1].data();
+                T* out = lev[bb][k].data();
+                const size_t i0 = (size_t)q * BLK, i1 = std::min(h, i0 + BLK);
+                for (size_t i = i0; i < i1; i++) out[i] = G::mul(prev[i], prev[i + h]);
+            }
     }
     auto level_ptr = [&](size_t b, size_t k) -> const T* { return k == 0 ? vs[b] : lev[b][k].data(); };
     // root products (prover.rs:197-221): written, since claimed_v_0s are all None
@@ -437,14 +439,29 @@ static inline std::pair<std::vector<E>, std::vector<E>> lasso_memory_checking(co
         const std::vector<uint64_t>& tab = pre.tables[pre.mem_subtable[m]];
         const std::vector<uint64_t>& ep = P.e_polys[m];
         init[i].resize(LASSO_M); fin[i].resize(LASSO_M); rd[i].resize(N); wr[i].resize(N);
+        (void)dim; (void)rts; (void)ep;
         for (size_t a = 0; a < LASSO_M; a++) {
             init[i][a] = hash(a, tab[a], 0);
             fin[i][a] = hash(a, tab[a], fct[a]);
         }
-        for (size_t j = 0; j < N; j++) {
-            rd[i][j] = hash(dim[j], ep[j], rts[j]);
-            wr[i][j] = hash(dim[j], ep[j], rts[j] + 1);
-        }
+    }
+    {   // read / write hashes: (memory, block of rows) items, so that more threads than memories have work
+        const size_t BLK = 16384, nblk = (N + BLK - 1) / BLK;
+#pragma omp parallel for schedule(static) collapse(2)
+        for (long long ii = 0; ii < (long long)A; ii++)
+            for (long long q = 0; q < (long long)nblk; q++) {
+                const size_t i = (size_t)ii, m = order[i], c = chunk_of[i];
+                const uint64_t* dim = P.dims[c].data();
+                const uint64_t* rts = P.read_cts[c].data();
+                const uint64_t* ep = P.e_polys[m].data();
+                T* rdp = rd[i].data();
+                T* wrp = wr[i].data();
+                const size_t j0 = (size_t)q * BLK, j1 = std::min(N, j0 + BLK);
+                for (size_t j = j0; j < j1; j++) {
+                    rdp[j] = hash(dim[j], ep[j], rts[j]);
+                    wrp[j] = hash(dim[j], ep[j], rts[j] + 1);
+                }
+            }
     }
     std::vector<const T*> v1, v2;
     for (size_t i = 0; i < A; i++) v1.push_back(rd[i].data());
@@ -460,12 +477,15 @@ static inline std::pair<std::vector<E>, std::vector<E>> lasso_memory_checking(co
 static inline LassoClaim lasso_prove(const LassoPre& pre, const LassoNodeDef& node, const F* inputs,
                                      TranscriptW& tr, LassoTrace* trace = nullptr) {
     const size_t nu = node.nu, N = (size_t)1 << nu;
+    double tq = omp_get_wtime();
     LassoPolys P = polynomialize(pre, nu, node.row_lookup, inputs);  // :64
+    orc_times().add("lasso polynomialize", tq); tq = omp_get_wtime();
     // :77 assert inputs == lookup_outputs: RangeLookup::output is the identity (range.rs:230-232) -> holds
     std::vector<E> r = tr.squeeze_n(nu);  // :85
     // prove_collation_sum_check :254-288
     E claimed_sum = lasso_sum_check_claim(pre, P, node.row_lookup, r);
     tr.write_e(claimed_sum);  // :269
+    orc_times().add("lasso claimed sum", tq); tq = omp_get_wtime();
     {
         std::vector<E> pw(pre.num_memories);  // distribute_powers(poly(0..alpha), M)  range.rs:197-204
         F c = f_one();
@@ -476,11 +496,13 @@ static inline LassoClaim lasso_prove(const LassoPre& pre, const LassoNodeDef& no
         for (size_t m = 0; m < pre.num_memories; m++) { ft[m] = ftab_from_u64(P.e_polys[m]); T.push_back(ScTable::from_f(ft[m].p(), N)); }
         prove_sum_check(g, claimed_sum, std::move(T), tr, trace ? &trace->collation_sums : nullptr);  // :278-279, result dropped :97
     }
+    orc_times().add("lasso collation sum-check", tq); tq = omp_get_wtime();
     E gamma_e = tr.squeeze(), tau_e = tr.squeeze();  // :99
     auto xy = tr.mode.ext_memcheck ? lasso_memory_checking<true>(pre, P, gamma_e, tau_e, tr, trace)
                                    : lasso_memory_checking<false>(pre, P, gamma_e, tau_e, tr, trace);
     const std::vector<E>& x = xy.first;
     const std::vector<E>& y = xy.second;
+    orc_times().add("lasso memory checking", tq); tq = omp_get_wtime();
     {
         std::vector<E> eqx = eq_table(x), eqy = eq_table(y);
         for (auto& ch : lasso_chunks(pre)) {  // prover.rs:173-178, mod.rs:80-93
@@ -491,6 +513,7 @@ static inline LassoClaim lasso_prove(const LassoPre& pre, const LassoNodeDef& no
             for (size_t m : ch.second) tr.write_e(dot_eq_u64(eqx, P.e_polys[m].data(), N));
         }
     }
+    orc_times().add("lasso openings", tq);
     if (trace && trace->polys_out) *trace->polys_out = std::move(P);
     return LassoClaim{r, claimed_sum};  // :97,113
 }

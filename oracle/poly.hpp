@@ -11,6 +11,30 @@
 #include <cstdint>
 #include <cstddef>
 #include "field.hpp"
+#include <algorithm>
+#include <omp.h>
+
+// threads for a parallel region over `work` items of which one thread should get at least `grain` (fork / join and per-thread set-up
+// dominate small regions on many-core hosts)
+#ifndef ORC_THREADS_FOR
+#define ORC_THREADS_FOR
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <string>
+// phase timers of a prove (ORC_TIMES=1 prints them when the prove ends): where a many-core baseline spends its time
+struct OrcTimes {
+    std::map<std::string, double> ms;
+    bool on = getenv("ORC_TIMES") != nullptr;
+    void add(const char* k, double t0) { if (on) ms[k] += (omp_get_wtime() - t0) * 1e3; }
+    void dump() { if (!on) return; for (auto& kv : ms) fprintf(stderr, "[oracle] %-28s %9.2f ms\n", kv.first.c_str(), kv.second); ms.clear(); }
+};
+static inline OrcTimes& orc_times() { static OrcTimes t; return t; }
+static inline int orc_threads_for(size_t work, size_t grain) {
+    const size_t mx = (size_t)omp_get_max_threads(), want = work / (grain ? grain : 1);
+    return (int)std::max<size_t>(1, std::min(mx, want));
+}
+#endif
 
 namespace ORC_NS {
 
@@ -19,7 +43,9 @@ static inline std::vector<E> eq_table(const E* r, size_t n) {
     t[0] = e_one();
     size_t s = 1;
     for (size_t i = 0; i < n; i++) {
-        for (size_t j = 0; j < s; j++) {
+#pragma omp parallel for schedule(static) num_threads(orc_threads_for(s, 4096))
+        for (long long jj = 0; jj < (long long)s; jj++) {
+            const size_t j = (size_t)jj;
             E hi = e_mul(t[j], r[i]);
             t[j + s] = hi;
             t[j] = e_sub(t[j], hi);
@@ -33,7 +59,7 @@ static inline std::vector<E> eq_table(const std::vector<E>& r) { return eq_table
 // sum_j eq[j] * tab[j]  (tab in the base field), parallel over j
 static inline E dot_eq_f(const std::vector<E>& eq, const F* tab, size_t n) {
     E total = e_zero();
-#pragma omp parallel
+#pragma omp parallel num_threads(orc_threads_for(n, 8192))
     {
         E a = e_zero();
 #pragma omp for nowait
@@ -49,7 +75,7 @@ static inline E dot_eq_f(const std::vector<E>& eq, const F* tab, size_t n) {
 // the same for a table of small non-negative integers (limb indices, counters, subtable values)
 static inline E dot_eq_u64(const std::vector<E>& eq, const uint64_t* tab, size_t n) {
     E total = e_zero();
-#pragma omp parallel
+#pragma omp parallel num_threads(orc_threads_for(n, 8192))
     {
         E a = e_zero();
 #pragma omp for nowait

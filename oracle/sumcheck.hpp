@@ -102,7 +102,10 @@ static inline void sc_round_evals(const ScFunc& g, const std::vector<ScTable>& T
     const size_t BLK = 256;
     const size_t nblk = (half + BLK - 1) / BLK;
     E acc[4] = {e_zero(), e_zero(), e_zero(), e_zero()};
-#pragma omp parallel
+    // (threads in proportion to the round's work: a late round of a few hundred pairs run by 128 threads costs a fork / join, eight
+    // allocations per thread and a critical section for nothing - that is what made the baseline SLOWER beyond 16 threads)
+    const int nthr = (int)std::min<size_t>(nblk, (size_t)orc_threads_for(P * half, 2048));
+#pragma omp parallel num_threads(nthr)
     {
         E a[4] = {e_zero(), e_zero(), e_zero(), e_zero()};
         std::vector<E> s0(BLK), s2(BLK), s3(BLK), q0(BLK), q2(BLK), q3(BLK);
@@ -208,7 +211,7 @@ static inline void sc_fold(std::vector<ScTable>& T, E r) {
         if (!t.own[dst]) t.own[dst].reset(new E[half ? half : 1]);
     }
     const size_t BLK = 1024, nblk = (half + BLK - 1) / BLK;
-#pragma omp parallel for schedule(static) collapse(2)
+#pragma omp parallel for schedule(static) collapse(2) num_threads(orc_threads_for(T.size() * half, 4096))
     for (long long ti = 0; ti < (long long)T.size(); ti++)
         for (long long bb = 0; bb < (long long)nblk; bb++) {
             ScTable& t = T[ti];

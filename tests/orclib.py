@@ -1,4 +1,8 @@
 """ctypes bindings to oracle/liboracle.so — the CPU oracle (test infrastructure only)."""
+import os as _os
+# Two OpenMP runtimes share a test process (libgomp behind the oracle, libomp behind the product library); with the default
+# active wait policy their idle teams spin against each other and the oracle gets SLOWER with more threads. Read at load time.
+_os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 import ctypes as C
 import json
 import os
