@@ -490,8 +490,18 @@ def main():
     ctx.set_option("one_stream", 0)
 
     end_to_end = None
+    verify_info = None
     if world == 1 and rank == 0 and not args.no_end_to_end:
         end_to_end = measure_end_to_end(hg, ctx, bfv, pk, witnesses, walked, args)
+        # BfvEncrypt::verify (host side, like the reference's; OpenMP over the table-sized loops) on the proof of witness 0
+        vt = []
+        for _ in range(4):
+            t0 = time.perf_counter()
+            ok, why = hg.verify(pk, witnesses[0], walked[0])
+            vt.append((time.perf_counter() - t0) * 1e3)
+            assert ok, why
+        verify_info = {"goldilocks_ms": round(sorted(vt[1:])[1], 2), "host_threads": min(64, os.cpu_count() or 1),
+                       "note": "hg_verify on the host (median of 3 after one warm-up); the reference reports 107.9 ms on an M1 Pro (README.md:44)"}
 
     if rank == 0:
         per_launch_bytes = dom["algo_bytes"] / max(dom["launches"], 1)
@@ -532,6 +542,7 @@ def main():
                                                      f"{ms_per_step_a:.4f} ms per prove, {gpu_ms_a:.4f} ms of GPU time"},
                        **({"rccl_ranks_seen": rccl_ranks_seen} if rccl_ranks_seen is not None else {}),
                        **({"end_to_end": end_to_end} if end_to_end else {}),
+                       **({"verify": verify_info} if verify_info else {}),
                        "witness_gen_ms_device_first_call": round(vals[0].timings["witness_ms"], 2), "upload_ms_first_call": round(vals[0].timings["upload_ms"], 2)},
             # `achieved` / `avg_launch_us`: HIP events around the dominant kernel class over the K proves of timed region A, where its launches
             # share the GPU with the second stream (Vanilla / FFT reductions, counter sorts, openings); `isolated`: the same
@@ -568,9 +579,13 @@ def main():
                 ctx.prove_bn254(pk, witness, cap=1 << 25)
                 runs = sorted((ctx.prove_bn254(pk, witness, cap=1 << 25)[1:] for _ in range(5)), key=lambda t: t[1])
                 best = runs[len(runs) // 2]
+                t0 = time.perf_counter()
+                okb, whyb = hg.verify_bn254(pk, witness, ctx.prove_bn254(pk, witness, cap=1 << 25)[0])
+                bn_verify_ms = (time.perf_counter() - t0) * 1e3
                 line["bn254"] = {"workload": f"BfvEncrypt::prove over bn256::Fr (hg_prove_bn254), n={args.n} k={args.k}, witness 0",
                                  "witness_gen_ms": round(best[0], 2), "prove_ms": round(best[1], 2), "dtype": "u256 (4x64 Montgomery)",
-                                 "runs_ms": [round(r[1], 2) for r in runs], "statistic": "median of 5 after one warm-up"}
+                                 "runs_ms": [round(r[1], 2) for r in runs], "statistic": "median of 5 after one warm-up",
+                                 "verify": {"accepted": bool(okb), "prove_plus_host_verify_ms": round(bn_verify_ms, 1)}}
                 # this path is integer-ALU bound, not HBM bound: VALU wave-instructions of one prove (committed SQ_INSTS_VALU pass of
                 # this round, only valid for n=32768 k=16) over the measured time, against the VALU issue peak of the chip
                 try:

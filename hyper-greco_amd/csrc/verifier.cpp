@@ -9,6 +9,8 @@
 // (F = E = bn256::Fr: the `bn254` test family, sk_encryption_circuit.rs:614-626).
 #include <cstring>
 #include <functional>
+#include <algorithm>
+#include <omp.h>
 #include "host.hpp"
 #include "bn254_field.hpp"
 
@@ -117,13 +119,35 @@ struct BnField {  // elements in Montgomery form
     };
 };
 
+// The verifier's table-sized loops (eq tables, MLE evaluations of the public inputs, the wiring-predicate sums of the Vanilla nodes,
+// DFT rows) run on the host's cores: the reference's verifier is rayon-parallel in the same places (README.md:44,56: 108 / 529 ms on
+// 10 cores); single-threaded this one took seconds at n=32768 k=16. Field sums are exact, so the order of a reduction is free.
+static inline int threads_for(size_t work, size_t grain) {
+    const size_t mx = (size_t)omp_get_max_threads(), want = work / grain;
+    return (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(mx, 64), want));
+}
+template <class F, class Fn> typename F::E par_sum(size_t n, size_t grain, Fn fn) {
+    typedef typename F::E E;
+    E total = F::zero();
+#pragma omp parallel num_threads(threads_for(n, grain))
+    {
+        E a = F::zero();
+#pragma omp for nowait schedule(static)
+        for (long long i = 0; i < (long long)n; i++) a = F::add(a, fn((size_t)i));
+#pragma omp critical
+        total = F::add(total, a);
+    }
+    return total;
+}
 template <class F> std::vector<typename F::E> eq_table(const std::vector<typename F::E>& r) {
     typedef typename F::E E;
     std::vector<E> t((size_t)1 << r.size());
     t[0] = F::one();
     size_t s = 1;
     for (size_t i = 0; i < r.size(); i++) {
-        for (size_t j = 0; j < s; j++) { E hi = F::mul(t[j], r[i]); t[j + s] = hi; t[j] = F::sub(t[j], hi); }
+        const E ri = r[i];
+#pragma omp parallel for schedule(static) num_threads(threads_for(s, 4096))
+        for (long long j = 0; j < (long long)s; j++) { E hi = F::mul(t[j], ri); t[j + s] = hi; t[j] = F::sub(t[j], hi); }
         s <<= 1;
     }
     return t;
@@ -131,10 +155,7 @@ template <class F> std::vector<typename F::E> eq_table(const std::vector<typenam
 template <class F> typename F::E mle_eval(const u64* tab, const std::vector<typename F::E>& pt) {
     typedef typename F::E E;
     std::vector<E> eq = eq_table<F>(pt);
-    E acc = F::zero();
-    for (size_t j = 0; j < eq.size(); j++)
-        if (tab[j]) acc = F::add(acc, F::mul_table(eq[j], tab[j]));
-    return acc;
+    return par_sum<F>(eq.size(), 4096, [&](size_t j) -> E { return tab[j] ? F::mul_table(eq[j], tab[j]) : F::zero(); });
 }
 template <class F> typename F::E horner(const std::vector<typename F::E>& c, typename F::E x) {
     typename F::E r = F::zero();
@@ -253,10 +274,15 @@ template <class F> struct Verifier {
     static std::vector<E> combined_eq(const std::vector<Claim>& cl, const std::vector<E>& alpha) {
         std::vector<E> eqc = eq_table<F>(cl[0].point);
         if (cl.size() == 1) return eqc;
-        for (auto& x : eqc) x = F::mul(x, alpha[0]);
+        const long long ne = (long long)eqc.size();
+        const E a0 = alpha[0];
+#pragma omp parallel for schedule(static) num_threads(threads_for((size_t)ne, 4096))
+        for (long long i = 0; i < ne; i++) eqc[i] = F::mul(eqc[i], a0);
         for (size_t a = 1; a < cl.size(); a++) {
             std::vector<E> t = eq_table<F>(cl[a].point);
-            for (size_t i = 0; i < t.size(); i++) eqc[i] = F::add(eqc[i], F::mul(t[i], alpha[a]));
+            const E aa = alpha[a];
+#pragma omp parallel for schedule(static) num_threads(threads_for((size_t)ne, 4096))
+            for (long long i = 0; i < ne; i++) eqc[i] = F::add(eqc[i], F::mul(t[i], aa));
         }
         return eqc;
     }
@@ -267,15 +293,24 @@ template <class F> struct Verifier {
         std::vector<E> eqc = combined_eq(cl, alpha);
         E claim = F::zero();
         for (size_t a = 0; a < cl.size(); a++) claim = F::add(claim, F::mul(cl[a].value, alpha[a]));
-        for (size_t rep = 0; rep < R; rep++) for (auto& t : n.w0) claim = F::sub(claim, F::mul_u(eqc[rep * G + t.gate], t.c));
+        if (!n.w0.empty()) {
+            const size_t nw = n.w0.size();
+            claim = F::sub(claim, par_sum<F>(R * nw, 4096, [&](size_t q) -> E { const auto& t = n.w0[q % nw]; return F::mul_u(eqc[(q / nw) * G + t.gate], t.c); }));
+        }
         auto r1 = sumcheck(2, nin, claim);
         std::vector<E> u(n.arity, F::zero());
         std::vector<std::vector<Claim>> sub(n.arity);
         for (int i = 0; i < n.arity; i++) if (n.left_use[i]) { u[i] = read_e(); sub[i].push_back(Claim{r1.second, u[i]}); }
         std::vector<E> eqx = eq_table<F>(r1.second);
         E lin = F::zero();
-        for (size_t rep = 0; rep < R; rep++)
-            for (auto& t : n.lin) lin = F::add(lin, F::mul(u[t.in], F::mul(F::mul_u(eqc[rep * G + t.gate], t.c), eqx[rep * S + t.j])));
+        if (!n.lin.empty()) {
+            const size_t nl = n.lin.size();
+            lin = par_sum<F>(R * nl, 2048, [&](size_t q) -> E {
+                const auto& t = n.lin[q % nl];
+                const size_t rep = q / nl;
+                return F::mul(u[t.in], F::mul(F::mul_u(eqc[rep * G + t.gate], t.c), eqx[rep * S + t.j]));
+            });
+        }
         if (n.mul.empty()) {
             if (!F::eq(r1.first, lin)) throw Reject("vanilla node: final evaluation mismatch");
             return sub;
@@ -284,10 +319,12 @@ template <class F> struct Verifier {
         std::vector<E> w(n.arity, F::zero());
         for (int i = 0; i < n.arity; i++) if (n.right_use[i]) { w[i] = read_e(); sub[i].push_back(Claim{r2.second, w[i]}); }
         std::vector<E> eqy = eq_table<F>(r2.second);
-        E fin = F::zero();
-        for (size_t rep = 0; rep < R; rep++)
-            for (auto& t : n.mul)
-                fin = F::add(fin, F::mul(F::mul(w[t.i1], u[t.i0]), F::mul(F::mul(F::mul_u(eqc[rep * G + t.gate], t.c), eqx[rep * S + t.j0]), eqy[rep * S + t.j1])));
+        const size_t nmul = n.mul.size();
+        E fin = par_sum<F>(R * nmul, 2048, [&](size_t q) -> E {
+            const auto& t = n.mul[q % nmul];
+            const size_t rep = q / nmul;
+            return F::mul(F::mul(w[t.i1], u[t.i0]), F::mul(F::mul(F::mul_u(eqc[rep * G + t.gate], t.c), eqx[rep * S + t.j0]), eqy[rep * S + t.j1]));
+        });
         if (!F::eq(r2.first, fin)) throw Reject("vanilla node: phase-2 final evaluation mismatch");
         return sub;
     }
@@ -297,14 +334,29 @@ template <class F> struct Verifier {
         const size_t N = (size_t)1 << L;
         const E w = F::root(L, inverse);
         std::vector<E> W(N);
-        W[0] = F::one();
-        for (size_t i = 1; i < N; i++) W[i] = F::mul(W[i - 1], w);
+        {   // powers of w in runs of 4096, each run started from a stride power
+            const size_t RUN = 4096, nrun = (N + RUN - 1) / RUN;
+            E wrun = F::one();
+            for (size_t i = 0; i < std::min(RUN, N); i++) wrun = F::mul(wrun, w);
+            std::vector<E> start(nrun);
+            start[0] = F::one();
+            for (size_t q = 1; q < nrun; q++) start[q] = F::mul(start[q - 1], wrun);
+#pragma omp parallel for schedule(static) num_threads(threads_for(N, 8192))
+            for (long long q = 0; q < (long long)nrun; q++) {
+                const size_t i0 = (size_t)q * RUN, i1 = std::min(N, i0 + RUN);
+                W[i0] = start[q];
+                for (size_t i = i0 + 1; i < i1; i++) W[i] = F::mul(W[i - 1], w);
+            }
+        }
         std::vector<E> cur(1, inverse ? F::inv_u((u64)N) : F::one());
         for (int b = L - 1; b >= 0; b--) {
             const size_t sz = (size_t)1 << (L - b);
             std::vector<E> nxt(sz);
-            for (size_t x = 0; x < sz; x++) {
-                E f = F::add(F::mul(r[b], F::sub(W[(x << b) & (N - 1)], F::one())), F::one());
+            const E rb = r[b];
+#pragma omp parallel for schedule(static) num_threads(threads_for(sz, 4096))
+            for (long long xx = 0; xx < (long long)sz; xx++) {
+                const size_t x = (size_t)xx;
+                E f = F::add(F::mul(rb, F::sub(W[(x << b) & (N - 1)], F::one())), F::one());
                 nxt[x] = F::mul(cur[x & (sz / 2 - 1)], f);
             }
             cur.swap(nxt);
@@ -321,8 +373,7 @@ template <class F> struct Verifier {
         E fr = F::zero();
         for (size_t a = 0; a < cl.size(); a++) {
             std::vector<E> row = fft_row(cl[a].point, n.log2_size, n.inverse);
-            E s = F::zero();
-            for (size_t x = 0; x < row.size(); x++) s = F::add(s, F::mul(row[x], eqx[x]));
+            E s = par_sum<F>(row.size(), 4096, [&](size_t x) -> E { return F::mul(row[x], eqx[x]); });
             fr = F::add(fr, F::mul(s, alpha[a]));
         }
         if (!F::eq(r.first, F::mul(u, fr))) throw Reject("fft node: final evaluation mismatch");
@@ -339,6 +390,8 @@ static std::string verify_impl(const Params& p, const LassoPlan& lp, const HCirc
         Verifier<F> V{ProofBytes{proof, len}, typename F::Chal{}};
         V.ch.set_mode(mode);
         V.ext_memcheck = (mode & 2) != 0;
+        double t_kind[3] = {0, 0, 0};
+        const double tv0 = omp_get_wtime();
         std::vector<E> point = V.squeeze_n(p.ct0is_log2());         // sk_encryption_circuit.rs:482
         E value = mle_eval<F>(w.ct0is.data(), point);               // :495
         std::vector<std::vector<Claim>> claims(c.nodes.size());
@@ -352,9 +405,11 @@ static std::string verify_impl(const Params& p, const LassoPlan& lp, const HCirc
             if (cl.empty()) throw Reject("node without claim");
             std::vector<E> alpha = cl.size() > 1 ? V.squeeze_n(cl.size()) : std::vector<E>{F::one()};
             std::vector<std::vector<Claim>> sub;
+            const double tn = omp_get_wtime();
             if (n.kind == NK_VANILLA) sub = V.vanilla(n, cl, alpha);
             else if (n.kind == NK_FFT) sub = V.fft(n, cl, alpha);
             else sub = {{V.lasso(lp)}};
+            t_kind[n.kind == NK_VANILLA ? 0 : n.kind == NK_FFT ? 1 : 2] += omp_get_wtime() - tn;
             for (size_t i = 0; i < n.preds.size(); i++) for (auto& s : sub[i]) claims[n.preds[i]].push_back(s);
         }
         // (the reference does not check that the proof stream is fully consumed either)
@@ -364,9 +419,24 @@ static std::string verify_impl(const Params& p, const LassoPlan& lp, const HCirc
         for (int i = 0; i < p.k; i++) tabs.push_back(&w.ais[i * SZ]);
         for (int i = 0; i < p.k; i++) tabs.push_back(&w.r1is[i * SZ]);
         tabs.push_back(w.r2is.data());
+        // (the 2k+4 inputs carry several claims each; every check is an eq table plus a dot product over 2^L entries: the checks are
+        // independent, so they are dealt to the cores and each runs its own loops single-threaded inside the region)
+        const double t_checks = omp_get_wtime();
+        std::vector<std::pair<size_t, const Claim*>> checks;
         for (size_t k = 0; k < c.input_ids.size(); k++)
-            for (auto& cl : claims[c.input_ids[k]])
-                if (!F::eq(mle_eval<F>(tabs[k], cl.point), cl.value)) throw Reject("input claim mismatch at input " + std::to_string(k));
+            for (auto& cl : claims[c.input_ids[k]]) checks.push_back({k, &cl});
+        long long bad = -1;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads_for(checks.size(), 1))
+        for (long long q = 0; q < (long long)checks.size(); q++) {
+            if (!F::eq(mle_eval<F>(tabs[checks[q].first], checks[q].second->point), checks[q].second->value)) {
+#pragma omp critical
+                if (bad < 0 || (long long)checks[q].first < bad) bad = (long long)checks[q].first;
+            }
+        }
+        if (bad >= 0) throw Reject("input claim mismatch at input " + std::to_string(bad));
+        if (getenv("HG_VERIFY_TIMES"))
+            fprintf(stderr, "[hg] verify: %.1f ms (vanilla nodes %.1f, fft nodes %.1f, lasso node %.1f, %zu input claims %.1f)\n", (omp_get_wtime() - tv0) * 1e3,
+                    t_kind[0] * 1e3, t_kind[1] * 1e3, t_kind[2] * 1e3, checks.size(), (omp_get_wtime() - t_checks) * 1e3);
         return "";
     } catch (const Reject& r) {
         return r.what();
