@@ -77,6 +77,452 @@ __global__ void k_gp_top_e2(const E2* __restrict__ top, int nb, E2* __restrict__
     evals[2 * b + 1] = r;
 }
 
+// ---- the transcript mailbox ------------------------------------------------------------------------------------------------
+// With an absorbing transcript a round's challenge is a hash of the round's message, so the device must hand the round sums to the
+// transcript and get the challenge back before it can fold. A stream synchronisation plus a challenge upload costs ~30 us per
+// round; here the host never synchronises inside a sum-check: the round kernels write their sums into the host-mapped result
+// buffer as always, a one-thread kernel (k_mail) then posts a sequence number into pinned host memory and SPINS on the host's
+// answer, the host thread (which has meanwhile enqueued the next launches) spins on the posted number, runs the transcript step
+// (interpolation, absorb, two Keccak permutations: ~2 us) and posts the challenge, which k_mail copies into the device
+// challenge table - and, after a first round, multiplies into the job's first-round weights. One PCIe round trip, no launch gap:
+// the kernels behind k_mail are already in the queue. The wait is bounded (a host that died cannot hang the device).
+struct Mail {
+    unsigned long long gpu_seq;   // written by the device: "results up to message gpu_seq are in the result buffer"
+    unsigned long long cpu_seq;   // written by the host: "the answer to message cpu_seq is in chal[]"
+    unsigned long long timeouts;  // device-side waits that gave up
+    unsigned long long pad;
+    E2 chal[4];
+};
+__global__ void k_mail(Mail* m, unsigned long long seq, E2* chain_dst, dev::StJob* patch, int npw) {   // one wave
+    __shared__ E2 s_r;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&m->gpu_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        const long long t0 = wall_clock64();   // 100 MHz
+        while (__hip_atomic_load(&m->cpu_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+            if (wall_clock64() - t0 > 500000000ll) { __hip_atomic_fetch_add(&m->timeouts, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }   // 5 s
+            __builtin_amdgcn_s_sleep(8);
+        }
+        E2 r;
+        r.c0 = __hip_atomic_load(&m->chal[0].c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        r.c1 = __hip_atomic_load(&m->chal[0].c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        chain_dst[0] = r;
+        s_r = r;
+    }
+    __syncthreads();
+    if (patch && (int)threadIdx.x < npw) patch->pwr[threadIdx.x] = e2_mul(patch->pw[threadIdx.x], s_r);   // first-round fold weights pw[i] * r_0
+}
+// posts a sequence number only (the host waits for results, the device for nothing)
+__global__ void k_post(Mail* m, unsigned long long seq) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(&m->gpu_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// ---- round kernels of the sequential prover ---------------------------------------------------------------------------------------
+// One launch per sum-check round, whatever the transcript: the kernel of round rd FOLDS the previous round's tables with r_(rd-1)
+// on the fly (that challenge is in the device table by now), writes the folded tables once, accumulates round rd's sums on them,
+// and its last-arriving workgroup hands the sums to the host transcript through the mailbox and waits for r_rd. Each table entry
+// is read once and written once per round, as in the fast path; what the fast path cannot do here is run rounds of different
+// sum-checks side by side or two rounds in one pass - every round's challenge depends on the round before.
+//   tables: T_0 = the input (u64 or E2), T_rd[j] = T_(rd-1)[2j] + r_(rd-1) (T_(rd-1)[2j+1] - T_(rd-1)[2j]) (convention C3), natural order;
+//   weights (gamma^b of a grand product's left tables, M^i of the collation tables) are multiplied in by the first fold, so that
+//   later rounds need none; round 0 applies them to the products instead. Final left evaluations therefore carry their weight
+//   (the host divides it out, as on the fast path).
+constexpr int SQ_MAX_BLOCKS = 1024;
+struct SqJob {
+    int kind;               // 0 collation, 1 grand product, 2 sum of pair products
+    int ntab, nvars, nv;    // nv = sums per round (t = 0, 2 [, 3])
+    const void* in;         // kinds 0 / 1: table t at in + t * in_stride elements
+    size_t in_stride;
+    const void* tab[2 * dev::PS_MAX_PAIRS];   // kind 2: a_i = tab[2i] (input element type), b_i = tab[2i+1] (E2)
+    E2* fin[2 * dev::PS_MAX_PAIRS];           // kind 2: where table t's final evaluation goes
+    E2* final_out;          // kinds 0 / 1: ntab final evaluations
+    E2* buf[2];             // T_rd (rd >= 1) = buf[rd & 1] + t * 2^(nvars - rd)
+    size_t r_off, sums_slot;
+    Mail* mail;
+    unsigned long long seq0;   // round rd's message is seq0 + rd
+    E2 pw[dev::PW_MAX];
+};
+template <typename T> __device__ __forceinline__ E2 sq_ld(const T* p, size_t i);
+template <> __device__ __forceinline__ E2 sq_ld<u64>(const u64* p, size_t i) { return e2(p[i], 0); }
+template <> __device__ __forceinline__ E2 sq_ld<E2>(const E2* p, size_t i) { return p[i]; }
+__device__ __forceinline__ E2 sq_fold(E2 x, E2 y, E2 r) { return e2_add(x, e2_mul(r, e2_sub(y, x))); }
+__device__ __forceinline__ E2 sq_fold_base(u64 x, u64 y, E2 r) { return e2_add_f(e2_mul_f(r, gl_sub(y, x)), x); }
+
+// (X, Y) = entries 2j, 2j+1 of table `t` in round rd; rd >= 1: folded on the fly from the four entries 4j .. 4j+3 of the round before
+// and stored. `wmul`: multiply by w (the first fold of a weighted table).
+template <typename TIN>
+__device__ __forceinline__ void sq_pair(const SqJob& J, int rd, int t, size_t j, E2 r_prev, bool wmul, E2 w, E2& X, E2& Y) {
+    const size_t len_prev = (size_t)1 << (J.nvars - rd + 1), len = len_prev >> 1;
+    if (rd == 0) {
+        const TIN* p = J.kind == 2 ? static_cast<const TIN*>(J.tab[t]) : static_cast<const TIN*>(J.in) + (size_t)t * J.in_stride;
+        X = sq_ld<TIN>(p, 2 * j); Y = sq_ld<TIN>(p, 2 * j + 1);
+        return;
+    }
+    if (rd == 1) {
+        const TIN* p = J.kind == 2 ? static_cast<const TIN*>(J.tab[t]) : static_cast<const TIN*>(J.in) + (size_t)t * J.in_stride;
+        if constexpr (sizeof(TIN) == 8) {
+            X = sq_fold_base(p[4 * j], p[4 * j + 1], r_prev); Y = sq_fold_base(p[4 * j + 2], p[4 * j + 3], r_prev);
+        } else {
+            X = sq_fold(p[4 * j], p[4 * j + 1], r_prev); Y = sq_fold(p[4 * j + 2], p[4 * j + 3], r_prev);
+        }
+        if (wmul) { X = e2_mul(X, w); Y = e2_mul(Y, w); }
+    } else {
+        const E2* p = J.buf[(rd - 1) & 1] + (size_t)t * len_prev;
+        X = sq_fold(p[4 * j], p[4 * j + 1], r_prev); Y = sq_fold(p[4 * j + 2], p[4 * j + 3], r_prev);
+    }
+    E2* o = J.buf[rd & 1] + (size_t)t * len;
+    o[2 * j] = X; o[2 * j + 1] = Y;
+}
+// kind 2's b tables are E2 whatever the a tables are
+__device__ __forceinline__ void sq_pair_b(const SqJob& J, int rd, int t, size_t j, E2 r_prev, E2& X, E2& Y) {
+    const size_t len_prev = (size_t)1 << (J.nvars - rd + 1), len = len_prev >> 1;
+    if (rd == 0) { const E2* p = static_cast<const E2*>(J.tab[t]); X = p[2 * j]; Y = p[2 * j + 1]; return; }
+    const E2* p = rd == 1 ? static_cast<const E2*>(J.tab[t]) : J.buf[(rd - 1) & 1] + (size_t)t * len_prev;
+    X = sq_fold(p[4 * j], p[4 * j + 1], r_prev); Y = sq_fold(p[4 * j + 2], p[4 * j + 3], r_prev);
+    E2* o = J.buf[rd & 1] + (size_t)t * len;
+    o[2 * j] = X; o[2 * j + 1] = Y;
+}
+
+template <int NV> __device__ __forceinline__ void sq_block_sum(E2* acc, E2 (*sm)[256]) {   // -> thread 0 holds the sums
+    for (int t = 0; t < NV; t++) sm[t][threadIdx.x] = acc[t];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) for (int t = 0; t < NV; t++) sm[t][threadIdx.x] = e2_add(sm[t][threadIdx.x], sm[t][threadIdx.x + s]);
+        __syncthreads();
+    }
+    for (int t = 0; t < NV; t++) acc[t] = sm[t][0];
+    __syncthreads();
+}
+// the last-arriving workgroup's thread 0: sums -> host memory, post, wait for the challenge, install it
+__device__ __forceinline__ void sq_mail_epilogue(const SqJob& J, int rd, const E2* total, E2* res, E2* chain_w) {
+    for (int t = 0; t < J.nv; t++) {
+        __hip_atomic_store(&res[J.sums_slot + (size_t)rd * J.nv + t].c0, total[t].c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&res[J.sums_slot + (size_t)rd * J.nv + t].c1, total[t].c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    Mail* m = J.mail;
+    const unsigned long long seq = J.seq0 + (unsigned long long)rd;
+    __hip_atomic_store(&m->gpu_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(&m->cpu_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+        if (wall_clock64() - t0 > 500000000ll) { __hip_atomic_fetch_add(&m->timeouts, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+        __builtin_amdgcn_s_sleep(4);
+    }
+    E2 r;
+    r.c0 = __hip_atomic_load(&m->chal[0].c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    r.c1 = __hip_atomic_load(&m->chal[0].c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    chain_w[J.r_off + rd] = r;
+}
+
+// the hypercube sums of round rd over this workgroup's share of the pair indices (tiles tile0, tile0 + step, ...), folding the round
+// before on the fly (see above); acc[t] += ... for t = 0, 2 [, 3]
+template <int KIND, typename TIN>
+__device__ __forceinline__ void sq_round_sums(const SqJob& J, int rd, int jb_log2, E2 r_prev, size_t tile0, size_t tile_step, E2* acc, E2 (*sm)[256]) {
+    constexpr int NV = KIND == 1 ? 3 : 2;
+    const int hl = J.nvars - 1 - rd;                 // log2 of this round's pair count
+    const size_t h = (size_t)1 << hl;
+    // 2^jb_log2 of the 256 threads run along the pair index j, the other 256 / 2^jb_log2 groups split the tables (host: sq_plan)
+    const int JB = 1 << jb_log2, G = 256 >> jb_log2;
+    const int jj = threadIdx.x & (JB - 1), g = threadIdx.x >> jb_log2;
+    const size_t ntiles = h >> jb_log2;
+    const int units = KIND == 0 ? J.ntab : J.ntab / 2;
+    for (size_t tile = tile0; tile < ntiles; tile += tile_step) {
+        const size_t j = (tile << jb_log2) + jj;
+        E2 s[NV], q[NV];
+#pragma unroll
+        for (int t = 0; t < NV; t++) { s[t] = e2_zero(); q[t] = e2_zero(); }
+        for (int u = g; u < units; u += G) {
+            const E2 w = KIND == 2 ? e2_one() : J.pw[u];
+            if (KIND == 0) {
+                E2 X, Y;
+                sq_pair<TIN>(J, rd, u, j, r_prev, rd == 1 && u > 0, w, X, Y);
+                const E2 v2 = e2_sub(e2_dbl(Y), X);
+                if (u == 0) { q[0] = X; q[1] = v2; }
+                if (rd == 0) { s[0] = e2_add(s[0], e2_mul_f(X, w.c0)); s[1] = e2_add(s[1], e2_mul_f(v2, w.c0)); }   // M^i is a base-field constant
+                else { s[0] = e2_add(s[0], X); s[1] = e2_add(s[1], v2); }
+            } else if (KIND == 1) {
+                E2 lx, ly, rx, ry;
+                sq_pair<TIN>(J, rd, 2 * u, j, r_prev, rd == 1 && u > 0, w, lx, ly);
+                sq_pair<TIN>(J, rd, 2 * u + 1, j, r_prev, false, w, rx, ry);
+                const E2 dl = e2_sub(ly, lx), dr = e2_sub(ry, rx);
+                const E2 l2 = e2_add(ly, dl), r2 = e2_add(ry, dr), l3 = e2_add(l2, dl), r3 = e2_add(r2, dr);
+                if (u == 0) { q[0] = lx; q[1] = l2; q[NV - 1] = l3; }
+                E2 p0 = e2_mul(lx, rx), p2 = e2_mul(l2, r2), p3 = e2_mul(l3, r3);
+                if (rd == 0 && u > 0) { p0 = e2_mul(p0, w); p2 = e2_mul(p2, w); p3 = e2_mul(p3, w); }
+                s[0] = e2_add(s[0], p0); s[1] = e2_add(s[1], p2); s[NV - 1] = e2_add(s[NV - 1], p3);
+            } else {
+                E2 ax, ay, bx, by;
+                sq_pair<TIN>(J, rd, 2 * u, j, r_prev, false, w, ax, ay);
+                sq_pair_b(J, rd, 2 * u + 1, j, r_prev, bx, by);
+                const E2 a2 = e2_sub(e2_dbl(ay), ax), b2 = e2_sub(e2_dbl(by), bx);
+                s[0] = e2_add(s[0], e2_mul(ax, bx)); s[1] = e2_add(s[1], e2_mul(a2, b2));
+            }
+        }
+        if (KIND == 2) {
+#pragma unroll
+            for (int t = 0; t < NV; t++) acc[t] = e2_add(acc[t], s[t]);
+        } else {
+            // the groups' shares of sum_i meet BEFORE the multiplication by p_0 (g = p_0 * sum_i ...); group 0 holds p_0's values
+            if (G > 1) {   // tree over the groups (thread index = g * JB + jj: halving the index range halves the groups)
+#pragma unroll
+                for (int t = 0; t < NV; t++) sm[t][threadIdx.x] = s[t];
+                __syncthreads();
+                for (int half = 128; half >= JB; half >>= 1) {
+                    if ((int)threadIdx.x < half) {
+#pragma unroll
+                        for (int t = 0; t < NV; t++) sm[t][threadIdx.x] = e2_add(sm[t][threadIdx.x], sm[t][threadIdx.x + half]);
+                    }
+                    __syncthreads();
+                }
+                if (g == 0) {
+#pragma unroll
+                    for (int t = 0; t < NV; t++) s[t] = sm[t][jj];
+                }
+                __syncthreads();
+            }
+            if (g == 0) {
+#pragma unroll
+                for (int t = 0; t < NV; t++) acc[t] = e2_add(acc[t], e2_mul(q[t], s[t]));
+            }
+        }
+    }
+}
+
+template <int KIND, typename TIN>
+__global__ __launch_bounds__(256) void k_sq_round(const SqJob* __restrict__ jp, int rd, int jb_log2, E2* chain, E2* __restrict__ partials, unsigned* ticket, E2* res) {
+    constexpr int NV = KIND == 1 ? 3 : 2;
+    __shared__ E2 sm[NV][256];
+    __shared__ unsigned s_last;
+    const SqJob& J = *jp;
+    const E2 r_prev = rd > 0 ? chain[J.r_off + rd - 1] : e2_zero();
+    E2 acc[NV];
+#pragma unroll
+    for (int t = 0; t < NV; t++) acc[t] = e2_zero();
+    sq_round_sums<KIND, TIN>(J, rd, jb_log2, r_prev, blockIdx.x, gridDim.x, acc, sm);
+    sq_block_sum<NV>(acc, sm);
+    const int nblocks = (int)gridDim.x;
+    if (nblocks == 1) {
+        if (threadIdx.x == 0) sq_mail_epilogue(J, rd, acc, res, chain);
+        return;
+    }
+    if (threadIdx.x == 0) {
+        for (int t = 0; t < NV; t++) {
+            __hip_atomic_store(&partials[(size_t)blockIdx.x * NV + t].c0, acc[t].c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&partials[(size_t)blockIdx.x * NV + t].c1, acc[t].c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // (the partials were written through with agent-scope atomic stores by THIS thread: their completion - vmcnt - is all the
+        // ticket must be ordered after; a formal release would write back every dirty line of the L2, i.e. the folded tables this
+        // kernel streams out. gfx942 / gfx950 only: kernels.hip, finish_partials)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+        const unsigned tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+#else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+        s_last = tk == (unsigned)nblocks - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    for (int t = 0; t < NV; t++) acc[t] = e2_zero();
+    for (int b = threadIdx.x; b < nblocks; b += 256)
+        for (int t = 0; t < NV; t++) {
+            E2 v;
+            v.c0 = __hip_atomic_load(&partials[(size_t)b * NV + t].c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v.c1 = __hip_atomic_load(&partials[(size_t)b * NV + t].c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            acc[t] = e2_add(acc[t], v);
+        }
+    sq_block_sum<NV>(acc, sm);
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sq_mail_epilogue(J, rd, acc, res, chain);
+    }
+}
+// rounds rd0 .. nvars-1 in ONE single-workgroup launch: a round here costs its arithmetic plus the mailbox round trip - no launch,
+// no job reload, no end-of-kernel flush - which is what the many short rounds of a proof are made of. The folded tables stay in
+// the ping-pong buffers (L2-resident at these sizes); the final evaluations are written at the end.
+template <int KIND, typename TIN>
+__global__ __launch_bounds__(256) void k_sq_tail(const SqJob* __restrict__ jp, int rd0, int units, E2* chain, E2* res) {
+    constexpr int NV = KIND == 1 ? 3 : 2;
+    __shared__ E2 sm[NV][256];
+    __shared__ E2 s_r;
+    const SqJob& J = *jp;
+    E2 r_prev = rd0 > 0 ? chain[J.r_off + rd0 - 1] : e2_zero();
+    for (int rd = rd0; rd < J.nvars; rd++) {
+        const int hl = J.nvars - 1 - rd;
+        int g_log2 = 0;
+        while ((1 << g_log2) < units && g_log2 < 8) g_log2++;
+        int jb_log2 = 8 - g_log2;
+        if (jb_log2 > hl) jb_log2 = hl;
+        E2 acc[NV];
+#pragma unroll
+        for (int t = 0; t < NV; t++) acc[t] = e2_zero();
+        sq_round_sums<KIND, TIN>(J, rd, jb_log2, r_prev, 0, 1, acc, sm);
+        sq_block_sum<NV>(acc, sm);
+        if (threadIdx.x == 0) { sq_mail_epilogue(J, rd, acc, res, chain); s_r = chain[J.r_off + rd]; }
+        __syncthreads();   // (also orders this round's table stores before the next round's loads: one workgroup)
+        r_prev = s_r;
+        __syncthreads();
+    }
+    const int n = J.nvars;
+    for (int t = threadIdx.x; t < J.ntab; t += 256) {
+        E2 v;
+        if (n == 1) {
+            if (J.kind == 2 && (t & 1)) { const E2* p = static_cast<const E2*>(J.tab[t]); v = sq_fold(p[0], p[1], r_prev); }
+            else {
+                const TIN* p = J.kind == 2 ? static_cast<const TIN*>(J.tab[t]) : static_cast<const TIN*>(J.in) + (size_t)t * J.in_stride;
+                v = sq_fold(sq_ld<TIN>(p, 0), sq_ld<TIN>(p, 1), r_prev);
+            }
+            if (J.kind == 0 && t > 0) v = e2_mul(v, J.pw[t]);
+            if (J.kind == 1 && !(t & 1) && t > 0) v = e2_mul(v, J.pw[t / 2]);
+        } else {
+            const E2* p = J.buf[(n - 1) & 1] + (size_t)t * 2;
+            v = sq_fold(p[0], p[1], r_prev);
+        }
+        if (J.kind == 2) *J.fin[t] = v; else J.final_out[t] = v;
+    }
+}
+// ALL rounds of one sum-check in ONE launch: a grid of co-resident workgroups walks the rounds together. Per round: every workgroup
+// that has pair indices in this round sums its share and bumps a ticket; the last one adds the partials, runs the mailbox round
+// trip and publishes the round's challenge by raising a flag the other workgroups spin on (a grid-wide barrier through the L2 /
+// memory: the folded tables cross XCDs, so both sides fence at agent scope). No launch happens while the device waits for the
+// host - a round costs its arithmetic, the barrier and the PCIe round trip.
+struct SqSync { unsigned ticket, round, timeouts, pad; };
+// thread mapping of a round with 2^hl pair indices and `units` table units (pairs / tables): as many groups along the units as
+// they can use (one unit per thread when the round is small: a workgroup that walks 50 pairs per thread is a 50 us latency
+// chain), fewer when the round has enough pair indices to fill the chip anyway (long coalesced runs along j); host and device
+__host__ __device__ __forceinline__ void sq_plan_dev(int hl, int units, int nblocks_max, int* jb_log2, int* nblk) {
+    int g_log2 = 0;
+    while ((1 << g_log2) < units && g_log2 < 8) g_log2++;
+    while (g_log2 > 0 && hl + g_log2 > 18) g_log2--;
+    int jb = 8 - g_log2;
+    if (jb > hl) jb = hl;
+    *jb_log2 = jb;
+    const size_t ntiles = ((size_t)1 << hl) >> jb;
+    *nblk = (int)(ntiles < (size_t)nblocks_max ? ntiles : (size_t)nblocks_max);
+}
+template <int KIND, typename TIN>
+__global__ __launch_bounds__(256) void k_sq_persist(const SqJob* __restrict__ jp, int units, E2* chain, E2* __restrict__ partials, SqSync* sy, E2* res,
+                                                    unsigned round0, unsigned ticket0) {   // the counters of *sy run on across sum-checks (never reset)
+    constexpr int NV = KIND == 1 ? 3 : 2;
+    __shared__ E2 sm[NV][256];
+    __shared__ unsigned s_last;
+    const SqJob& J = *jp;
+    const int nvars = J.nvars;
+    unsigned ticket_base = ticket0;
+    for (int rd = 0; rd < nvars; rd++) {
+        if (rd > 0) {   // the barrier: round rd-1's challenge is published (and every workgroup's folded tables are written back)
+            if (threadIdx.x == 0) {
+                const long long t0 = wall_clock64();
+                while ((int)(__hip_atomic_load(&sy->round, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - (round0 + (unsigned)rd)) < 0) {
+                    if (wall_clock64() - t0 > 600000000ll) { __hip_atomic_fetch_add(&sy->timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        int jb_log2, nblk;
+        sq_plan_dev(nvars - 1 - rd, units, (int)gridDim.x, &jb_log2, &nblk);
+        if ((int)blockIdx.x >= nblk) continue;   // nothing of this round here: on to the next barrier
+        E2 r_prev = e2_zero();
+        if (rd > 0) {
+            r_prev.c0 = __hip_atomic_load(&chain[J.r_off + rd - 1].c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            r_prev.c1 = __hip_atomic_load(&chain[J.r_off + rd - 1].c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        E2 acc[NV];
+#pragma unroll
+        for (int t = 0; t < NV; t++) acc[t] = e2_zero();
+        sq_round_sums<KIND, TIN>(J, rd, jb_log2, r_prev, blockIdx.x, (size_t)nblk, acc, sm);
+        sq_block_sum<NV>(acc, sm);
+        if (threadIdx.x == 0) {
+            if (nblk > 1) {
+#pragma unroll
+                for (int t = 0; t < NV; t++) {
+                    __hip_atomic_store(&partials[(size_t)blockIdx.x * NV + t].c0, acc[t].c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&partials[(size_t)blockIdx.x * NV + t].c1, acc[t].c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            // release: this workgroup's folded tables (plain stores of all its threads, ordered before this point by the
+            // barriers of the block sum) must be written back before another XCD reads them in the next round
+            const unsigned tk = __hip_atomic_fetch_add(&sy->ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = tk == ticket_base + (unsigned)nblk - 1 ? 1u : 0u;
+        }
+        ticket_base += (unsigned)nblk;
+        __syncthreads();
+        if (!s_last) continue;
+        if (nblk > 1) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#pragma unroll
+            for (int t = 0; t < NV; t++) acc[t] = e2_zero();
+            for (int b = threadIdx.x; b < nblk; b += 256)
+#pragma unroll
+                for (int t = 0; t < NV; t++) {
+                    E2 v;
+                    v.c0 = __hip_atomic_load(&partials[(size_t)b * NV + t].c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    v.c1 = __hip_atomic_load(&partials[(size_t)b * NV + t].c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    acc[t] = e2_add(acc[t], v);
+                }
+            sq_block_sum<NV>(acc, sm);
+        }
+        if (threadIdx.x == 0) {
+            sq_mail_epilogue(J, rd, acc, res, chain);   // sums -> host, wait, chain[r_off + rd] = r
+            __hip_atomic_store(&sy->round, round0 + (unsigned)(rd + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // (a workgroup that has left a round never comes back: the rounds only shrink) workgroup 0 is in every round: the final evaluations
+    if (blockIdx.x != 0) return;
+    if (threadIdx.x == 0) {
+        const long long t0 = wall_clock64();
+        while ((int)(__hip_atomic_load(&sy->round, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - (round0 + (unsigned)nvars)) < 0) {
+            if (wall_clock64() - t0 > 600000000ll) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    E2 r_last;
+    r_last.c0 = __hip_atomic_load(&chain[J.r_off + nvars - 1].c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    r_last.c1 = __hip_atomic_load(&chain[J.r_off + nvars - 1].c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int t = threadIdx.x; t < J.ntab; t += 256) {
+        E2 v;
+        if (nvars == 1) {
+            if (J.kind == 2 && (t & 1)) { const E2* p = static_cast<const E2*>(J.tab[t]); v = sq_fold(p[0], p[1], r_last); }
+            else {
+                const TIN* p = J.kind == 2 ? static_cast<const TIN*>(J.tab[t]) : static_cast<const TIN*>(J.in) + (size_t)t * J.in_stride;
+                v = sq_fold(sq_ld<TIN>(p, 0), sq_ld<TIN>(p, 1), r_last);
+            }
+            if (J.kind == 0 && t > 0) v = e2_mul(v, J.pw[t]);
+            if (J.kind == 1 && !(t & 1) && t > 0) v = e2_mul(v, J.pw[t / 2]);
+        } else {
+            const E2* p = J.buf[(nvars - 1) & 1] + (size_t)t * 2;
+            v = sq_fold(p[0], p[1], r_last);
+        }
+        if (J.kind == 2) *J.fin[t] = v; else J.final_out[t] = v;
+    }
+}
+// after the last round: table t's final evaluation = fold of its last two entries with the last challenge (weights: see above)
+template <typename TIN>
+__global__ void k_sq_final(const SqJob* __restrict__ jp, const E2* __restrict__ chain) {
+    const SqJob& J = *jp;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= J.ntab) return;
+    const int n = J.nvars;
+    const E2 r = chain[J.r_off + n - 1];
+    E2 v;
+    if (n == 1) {
+        if (J.kind == 2 && (t & 1)) { const E2* p = static_cast<const E2*>(J.tab[t]); v = sq_fold(p[0], p[1], r); }
+        else {
+            const TIN* p = J.kind == 2 ? static_cast<const TIN*>(J.tab[t]) : static_cast<const TIN*>(J.in) + (size_t)t * J.in_stride;
+            v = sq_fold(sq_ld<TIN>(p, 0), sq_ld<TIN>(p, 1), r);
+        }
+        if (J.kind == 0 && t > 0) v = e2_mul(v, J.pw[t]);
+        if (J.kind == 1 && !(t & 1) && t > 0) v = e2_mul(v, J.pw[t / 2]);
+    } else {
+        const E2* p = J.buf[(n - 1) & 1] + (size_t)t * 2;
+        v = sq_fold(p[0], p[1], r);
+    }
+    if (J.kind == 2) *J.fin[t] = v; else J.final_out[t] = v;
+}
+
 struct Claim {  // evaluation claim whose point is a run of this proof's challenge table
     size_t point_off;
     int len;
@@ -93,7 +539,12 @@ struct SeqProver {
     E2* d_chain = nullptr;  // the same in HBM: kernels take challenge positions, exactly like the fast path
     size_t chain_cap = 0;
     size_t res_used = 0;
-    size_t n_sync = 0;
+    size_t n_sync = 0;   // stream synchronisations
+    size_t n_drained = 0;
+    size_t n_mail = 0;   // mailbox round trips (no synchronisation: the device spins on the host's answer)
+    Mail* mail = nullptr;               // pinned host memory, mapped into the device
+    unsigned long long mail_seq = 0;
+    bool use_mail = true;
     std::vector<const u64*> d_vals;
     std::vector<std::vector<Claim>> claims;
 
@@ -104,8 +555,64 @@ struct SeqProver {
         hip_check(hipMemsetAsync(d_chain, 0, chain_cap * sizeof(E2), st), "clear challenge table");
         for (E2* pbuf : {ctx->d_partials, ctx->d_partials2})
             hip_check(hipMemsetAsync(reinterpret_cast<char*>(pbuf) + dev::PARTIALS_E2 * sizeof(E2), 0, dev::PARTIALS_TICKETS * sizeof(unsigned), st), "clear reduction tickets");
+        static const bool no_mail = [] { const char* e = getenv("HG_SEQ_NO_MAIL"); return e && e[0] == '1'; }();
+        use_mail = !no_mail && ctx->d_res == ctx->h_res;   // (the sums must land in host memory without a copy)
+        if (use_mail) {
+            hip_check(hipHostMalloc((void**)&mail, sizeof(Mail), hipHostMallocDefault), "hipHostMalloc(mailbox)");
+            memset(mail, 0, sizeof(Mail));
+        }
+    }
+    ~SeqProver() {
+        if (mail) {   // whatever still waits on the device is released before the mailbox goes away
+            __atomic_store_n(&mail->cpu_seq, ~0ull, __ATOMIC_RELEASE);
+            (void)hipStreamSynchronize(st);
+            (void)hipHostFree(mail);
+        }
+    }
+    // host side of the mailbox: wait until the device has posted `seq` (results of everything enqueued before are in h_res)
+    double t_wait_rounds = 0, t_wait_results = 0, t_enqueue_rounds = 0;   // HG_SEQ_TIMES=1: where the host's time goes
+    double t_kind[3][2] = {{0, 0}, {0, 0}, {0, 0}};   // ... waiting for round sums, by sum-check kind and single- / multi-workgroup round
+    size_t n_kind[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+    void mail_wait(unsigned long long seq) {
+        const double t0 = now_ms();
+        unsigned spins = 0;
+        while (__atomic_load_n(&mail->gpu_seq, __ATOMIC_ACQUIRE) < seq) {
+            __builtin_ia32_pause();
+            if ((++spins & 0xFFFF) == 0) {
+                hip_check(hipGetLastError(), "round (mailbox)");
+                if (hipStreamQuery(st) == hipSuccess && __atomic_load_n(&mail->gpu_seq, __ATOMIC_ACQUIRE) < seq) throw Error("mailbox: the stream drained without posting");
+                if (now_ms() - t0 > 10000.0) throw Error("mailbox: no answer from the device within 10 s");
+            }
+        }
+        n_mail++;
+        t_wait_rounds += now_ms() - t0;
+        if (slow_log && now_ms() - t0 > 3.0) fprintf(stderr, "[hg] slow: waited %.2f ms for message %llu (%s)\n", now_ms() - t0, seq, where);
+    }
+    const char* where = "";
+    bool slow_log = getenv("HG_SEQ_TIMES") != nullptr;
+    struct Slow {   // reports a host-side step that took more than 3 ms (HG_SEQ_TIMES=1)
+        SeqProver* P; const char* what; double t0;
+        Slow(SeqProver* p, const char* w) : P(p), what(w), t0(now_ms()) {}
+        ~Slow() { if (P->slow_log && now_ms() - t0 > 3.0) fprintf(stderr, "[hg] slow: %s took %.2f ms\n", what, now_ms() - t0); }
+    };
+    // "everything enqueued so far is done and its results are in h_res": a mailbox post when available, else a synchronisation
+    void wait_results() {
+        if (!use_mail) { sync(); return; }
+        const unsigned long long seq = ++mail_seq;
+        k_post<<<1, 64, 0, st>>>(mail, seq);
+        const double t0 = now_ms(), r0 = t_wait_rounds;
+        mail_wait(seq);
+        // the stream is drained here: let the runtime retire its completed commands now, a few at a time (this mode never
+        // synchronises; left alone the runtime reaped thousands of them at once, somewhere inside a launch: stalls of 30-40 ms)
+        static const int sync_every = [] { const char* e = getenv("HG_SEQ_SYNC_EVERY"); return e && *e ? atoi(e) : 4; }();
+        if (sync_every > 0 && (++n_drained % sync_every) == 0) { hip_check(hipStreamSynchronize(st), "drain"); n_sync++; }
+        else (void)hipStreamQuery(st);
+        t_wait_rounds = r0;
+        t_wait_results += now_ms() - t0;
     }
     bool ext_mc() const { return (mode & 2) != 0; }
+    // HG_SEQ_CLASSIC=1: the fast path's round kernels run twice per round (sums, then the fold once the challenge is known)
+    static bool classic() { static const bool c = [] { const char* e = getenv("HG_SEQ_CLASSIC"); return e && e[0] == '1'; }(); return c; }
     E2* d_res() { return ctx->d_res; }
     const E2* h_res() { return ctx->h_res; }
     size_t slot(size_t n) {
@@ -120,18 +627,20 @@ struct SeqProver {
         n_sync++;
     }
     // squeeze_challenge (transcript.rs:146-157): the value goes into the host chain and into the device table
-    E2 squeeze() {
+    E2 squeeze(bool upload_now = true) {
         if (chain.size() >= chain_cap) throw Error("challenge table exhausted");
         const E2 r = tr.squeeze();
         chain.push_back(r);
-        E2* h = static_cast<E2*>(stage(&r, sizeof(E2)));
-        hip_check(hipMemcpyAsync(d_chain + chain.size() - 1, h, sizeof(E2), hipMemcpyHostToDevice, st), "upload challenge");
+        if (upload_now) {   // (a round's challenge travels through the mailbox instead: mail_round)
+            E2* h = static_cast<E2*>(stage(&r, sizeof(E2)));
+            hip_check(hipMemcpyAsync(d_chain + chain.size() - 1, h, sizeof(E2), hipMemcpyHostToDevice, st), "upload challenge");
+        }
         return r;
     }
     void* stage(const void* src, size_t bytes) {
         size_t need = (bytes + 63) & ~(size_t)63;
         if (ctx->stage_used + need > ctx->stage_cap) {  // a proof in this mode uploads thousands of tiny descriptors: recycle
-            sync();
+            wait_results();
             ctx->stage_used = 0;
         }
         void* p = ctx->h_stage + ctx->stage_used;
@@ -147,7 +656,7 @@ struct SeqProver {
     void write_slots(size_t s, size_t n) { for (size_t i = 0; i < n; i++) tr.write_e(h_res()[s + i]); }
 
     // transcript side of one round: d+1 coefficients, eval(1) derived from the running claim (C1), then the challenge
-    E2 round_message(const E2* sums, int deg, E2& claim) {
+    E2 round_message(const E2* sums, int deg, E2& claim, bool upload_now = true) {
         E2 ev[4], c[4];
         ev[0] = sums[0];
         ev[1] = e2_sub(claim, sums[0]);
@@ -155,14 +664,167 @@ struct SeqProver {
         if (deg == 3) ev[3] = sums[2];
         interpolate(ev, deg, c);
         for (int k = 0; k <= deg; k++) tr.write_e(c[k]);
-        const E2 r = squeeze();
+        const E2 r = squeeze(upload_now);
         claim = horner(c, deg, r);
         return r;
+    }
+    // One round through the mailbox. Called right after the round's first pass has been enqueued: enqueues k_mail (post, wait, copy the
+    // challenge into the device table, patch the first-round weights of `patch`), lets the caller enqueue the second pass BEHIND it,
+    // then waits for the sums, runs the transcript step on the host and answers.
+    // The two halves of a round trip. A whole sum-check is ENQUEUED first (per round: first pass, k_mail, second pass - no launch
+    // parameter depends on a challenge, the kernels read it from the device table), then the host answers the rounds one by one:
+    // the device never waits for a launch, only for the answers.
+    unsigned long long mail_enqueue(size_t chain_pos, dev::StJob* patch, int npw) {
+        const unsigned long long seq = ++mail_seq;
+        k_mail<<<1, 64, 0, st>>>(mail, seq, d_chain + chain_pos, patch, npw);
+        return seq;
+    }
+    double t_answer = 0;
+    E2 mail_answer(unsigned long long seq, const E2* sums, int deg, E2& claim) {
+        mail_wait(seq);
+        const double t0 = slow_log ? now_ms() : 0;
+        const E2 r = round_message(sums, deg, claim, false);
+        mail->chal[0] = r;
+        __atomic_store_n(&mail->cpu_seq, seq, __ATOMIC_RELEASE);
+        if (slow_log) t_answer += now_ms() - t0;
+        return r;
+    }
+
+    // ---- one sum-check through the fused round kernels and the mailbox ---------------------------------------------------------
+    unsigned* d_ticket = nullptr;
+    SqSync* d_sqsync = nullptr;
+    unsigned sq_round0 = 0, sq_ticket0 = 0;
+    static constexpr int SQ_PERSIST_BLOCKS = 512;   // co-resident on 256 CUs at two workgroups per CU (96 VGPRs: five would fit)
+    template <int KIND> void launch_round(bool in_base, const SqJob* d_job, int rd, int jb_log2, int grid) {
+        if (in_base) k_sq_round<KIND, u64><<<grid, 256, 0, st>>>(d_job, rd, jb_log2, d_chain, ctx->d_partials, d_ticket, d_res());
+        else k_sq_round<KIND, E2><<<grid, 256, 0, st>>>(d_job, rd, jb_log2, d_chain, ctx->d_partials, d_ticket, d_res());
+    }
+    // thread mapping of a round with 2^hl pair indices and `units` table units (pairs / tables): as many groups along the units as
+    // they can use (one unit per thread when the round is small: a workgroup that walks 50 pairs per thread is a 50 us latency
+    // chain), fewer when the round has enough pair indices to fill the chip anyway (long coalesced runs along j)
+    static void sq_plan(int hl, int units, int* jb_log2, int* grid) {
+        int g_log2 = 0;
+        while ((1 << g_log2) < units && g_log2 < 8) g_log2++;
+        while (g_log2 > 0 && hl + g_log2 > 18) g_log2--;          // more than 2^18 threads' worth: trade groups for j
+        int jb = 8 - g_log2;
+        if (jb > hl) jb = hl;
+        *jb_log2 = jb;
+        const size_t ntiles = ((size_t)1 << hl) >> jb;
+        *grid = (int)std::min<size_t>(ntiles, SQ_MAX_BLOCKS);
+    }
+    // J: kind, ntab, nvars, tables, final destinations, pw filled in by the caller. Enqueues every round and the final fold, then
+    // answers the rounds in order. Returns the chain position of the point.
+    size_t run_sq(SqJob& J, bool in_base, E2& claim) {
+        if (!d_ticket) {
+            d_ticket = ctx->alloc_n<unsigned>(64);
+            hip_check(hipMemsetAsync(d_ticket, 0, 64 * sizeof(unsigned), st), "clear ticket");
+        }
+        const int nvars = J.nvars;
+        J.nv = J.kind == 1 ? 3 : 2;
+        const size_t point_off = epos();
+        J.r_off = point_off;
+        J.sums_slot = slot((size_t)nvars * J.nv);
+        const size_t N = (size_t)1 << nvars;
+        J.buf[1] = ctx->alloc_n<E2>((size_t)J.ntab * std::max<size_t>(N / 2, 1));
+        J.buf[0] = ctx->alloc_n<E2>((size_t)J.ntab * std::max<size_t>(N / 4, 1));
+        J.mail = mail;
+        J.seq0 = mail_seq + 1;
+        mail_seq += (unsigned long long)nvars;
+        const double te0 = now_ms();
+        where = J.kind == 0 ? "collation round" : J.kind == 1 ? "grand-product round" : "pair-product round";
+        const SqJob* d_job = nullptr;
+        { Slow sl(this, "run_sq set-up (allocations, job upload)"); d_job = upload(&J, 1); }
+        // the launches run a few rounds ahead of the answers: the device never waits for a launch, and the first round's answer does
+        // not wait for the host to have enqueued the whole sum-check
+        static const bool persist = [] { const char* e = getenv("HG_SEQ_NO_PERSIST"); return !(e && e[0] == '1'); }();
+        if (persist) {   // all rounds and the final evaluations in one launch (k_sq_persist); the host only answers
+            const int units_p = J.kind == 0 ? J.ntab : J.ntab / 2;
+            if (!d_sqsync) {
+                d_sqsync = ctx->alloc_n<SqSync>(1);
+                hip_check(hipMemsetAsync(d_sqsync, 0, sizeof(SqSync), st), "clear sync words");
+                sq_round0 = sq_ticket0 = 0;
+            }
+            int jb0 = 0, grid = 1;
+            sq_plan_dev(nvars - 1, units_p, SQ_PERSIST_BLOCKS, &jb0, &grid);
+            unsigned tickets = 0;
+            for (int rd = 0; rd < nvars; rd++) { int jb, nb; sq_plan_dev(nvars - 1 - rd, units_p, grid, &jb, &nb); tickets += (unsigned)nb; }
+            {
+                Slow sl(this, "enqueueing a sum-check");
+#define HG_SQ_LAUNCH(K, T) k_sq_persist<K, T><<<grid, 256, 0, st>>>(d_job, units_p, d_chain, ctx->d_partials, d_sqsync, d_res(), sq_round0, sq_ticket0)
+                if (J.kind == 0) { if (in_base) HG_SQ_LAUNCH(0, u64); else HG_SQ_LAUNCH(0, E2); }
+                else if (J.kind == 1) { if (in_base) HG_SQ_LAUNCH(1, u64); else HG_SQ_LAUNCH(1, E2); }
+                else { if (in_base) HG_SQ_LAUNCH(2, u64); else HG_SQ_LAUNCH(2, E2); }
+#undef HG_SQ_LAUNCH
+            }
+            sq_round0 += (unsigned)nvars; sq_ticket0 += tickets;
+            t_enqueue_rounds += now_ms() - te0;
+            for (int rd = 0; rd < nvars; rd++) {
+                const double w0 = t_wait_rounds;
+                mail_answer(J.seq0 + (unsigned long long)rd, h_res() + J.sums_slot + (size_t)rd * J.nv, J.kind == 1 ? 3 : 2, claim);
+                const int big = nvars - 1 - rd > 8 ? 1 : 0;
+                t_kind[J.kind][big] += t_wait_rounds - w0; n_kind[J.kind][big]++;
+            }
+            return point_off;
+        }
+        const int LOOKAHEAD = 6;
+        // the tail: all rounds from the first one with at most SQ_TAIL_ITEMS (pair index, table unit) items on, in one launch
+        const int units = J.kind == 0 ? J.ntab : J.ntab / 2;
+        static const size_t tail_items = [] { const char* e = getenv("HG_SEQ_TAIL_ITEMS"); return e && *e ? (size_t)atol(e) : (size_t)0; }();   // (measured: no gain at 512 / 2048 / 8192 - a tail round costs what a launched round costs, the host's turnaround; off by default)
+        int tail_rd = nvars;
+        while (tail_rd > 0 && ((size_t)units << (nvars - tail_rd)) <= tail_items) tail_rd--;   // round rd has 2^(nvars-1-rd) pair indices
+        if (tail_items == 0) tail_rd = nvars;
+        int enq = 0;
+        auto enqueue_round = [&] {
+            Slow sl(this, "enqueueing a round");
+            const int rd = enq;
+            if (rd >= tail_rd && rd < nvars) {   // the tail takes every remaining round and the final evaluations
+                enq = nvars + 1;
+                if (J.kind == 0) { if (in_base) k_sq_tail<0, u64><<<1, 256, 0, st>>>(d_job, rd, units, d_chain, d_res()); else k_sq_tail<0, E2><<<1, 256, 0, st>>>(d_job, rd, units, d_chain, d_res()); }
+                else if (J.kind == 1) { if (in_base) k_sq_tail<1, u64><<<1, 256, 0, st>>>(d_job, rd, units, d_chain, d_res()); else k_sq_tail<1, E2><<<1, 256, 0, st>>>(d_job, rd, units, d_chain, d_res()); }
+                else { if (in_base) k_sq_tail<2, u64><<<1, 256, 0, st>>>(d_job, rd, units, d_chain, d_res()); else k_sq_tail<2, E2><<<1, 256, 0, st>>>(d_job, rd, units, d_chain, d_res()); }
+                return;
+            }
+            enq++;
+            if (rd == nvars) {
+                if (in_base) k_sq_final<u64><<<(J.ntab + 63) / 64, 64, 0, st>>>(d_job, d_chain);
+                else k_sq_final<E2><<<(J.ntab + 63) / 64, 64, 0, st>>>(d_job, d_chain);
+                return;
+            }
+            int jb = 0, grid = 1;
+            sq_plan(nvars - 1 - rd, J.kind == 0 ? J.ntab : J.ntab / 2, &jb, &grid);
+            if (J.kind == 0) launch_round<0>(in_base, d_job, rd, jb, grid);
+            else if (J.kind == 1) launch_round<1>(in_base, d_job, rd, jb, grid);
+            else launch_round<2>(in_base, d_job, rd, jb, grid);
+        };
+        while (enq < std::min(nvars + 1, LOOKAHEAD)) enqueue_round();
+        t_enqueue_rounds += now_ms() - te0;
+        for (int rd = 0; rd < nvars; rd++) {
+            // answering is what the device waits for: a launch is squeezed in first only while the round's sums are not there yet
+            const unsigned long long seq = J.seq0 + (unsigned long long)rd;
+            while (enq <= nvars && enq < rd + 2 * LOOKAHEAD && (enq < rd + 2 || __atomic_load_n(&mail->gpu_seq, __ATOMIC_ACQUIRE) < seq)) {
+                const double t1 = now_ms(); enqueue_round(); t_enqueue_rounds += now_ms() - t1;
+            }
+            const double w0 = t_wait_rounds;
+            mail_answer(J.seq0 + (unsigned long long)rd, h_res() + J.sums_slot + (size_t)rd * J.nv, J.kind == 1 ? 3 : 2, claim);
+            const int big = nvars - 1 - rd > 8 ? 1 : 0;   // (statistics only)
+            t_kind[J.kind][big] += t_wait_rounds - w0; n_kind[J.kind][big]++;
+        }
+        while (enq <= nvars) enqueue_round();
+        return point_off;
     }
 
     // ---- prove_sum_check, stride layout (collation / grand-product shapes) ------------------------------------------------
     // tables: ntab rows at `in + t * in_stride` (u64 if base else E2). final evaluations land in d_res[evals_slot ..).
     size_t sumcheck_stride(int kind, const void* in, bool base, size_t in_stride, int ntab, int nvars, const dev::Powers& pw, E2& claim, size_t evals_slot) {
+        if (use_mail && !classic()) {
+            SqJob Q;
+            memset(&Q, 0, sizeof(Q));
+            Q.kind = kind == dev::SC_GRANDPROD ? 1 : 0; Q.ntab = ntab; Q.nvars = nvars;
+            Q.in = in; Q.in_stride = in_stride;
+            Q.final_out = d_res() + evals_slot;
+            memcpy(Q.pw, pw.v, sizeof(Q.pw));
+            return run_sq(Q, base, claim);
+        }
         const int nv = kind == dev::SC_GRANDPROD ? 3 : 2, deg = nv;
         const size_t point_off = epos();
         const size_t sums_slot = slot((size_t)nvars * nv);
@@ -177,29 +839,51 @@ struct SeqProver {
         J.r_off = point_off; J.sums_slot = sums_slot;
         memcpy(J.pw, pw.v, sizeof(J.pw));
         dev::StJob* d_job = upload(&J, 1);
-        const void* cur_in = in;
-        size_t cur_stride = in_stride;
-        for (int rd = 0; rd < nvars; rd++) {
-            const int h = nvars - 1 - rd;
-            dev::StItem it;
-            memset(&it, 0, sizeof(it));
-            it.job = 0; it.h_log2 = h; it.in = cur_in; it.in_stride = cur_stride;
-            it.out = rd == nvars - 1 ? J.final_out : (cur_in == (const void*)J.buf[0] ? J.buf[1] : J.buf[0]);
-            const int grid = dev::st_plan_blocks(&it, 1, false);
-            dev::StItem* d_it = upload(&it, 1);
-            if (rd == 0) {
-                // the first-round kernels store the weighted fold pw[i] * (x + r d) as pw[i] x + pwr[i] d with pwr = pw * r_0: r_0 is
-                // not known yet, so the first pass runs with pwr = 0 (sums unaffected) and the job is re-uploaded before pass 2
-                dev::st_step(st, kind, base, d_job, d_it, 1, grid, d_chain, ctx->d_partials, d_res());
-            } else dev::st_step(st, kind, false, d_job, d_it, 1, grid, d_chain, ctx->d_partials, d_res());
-            sync();
-            const E2 r = round_message(h_res() + sums_slot + (size_t)rd * nv, deg, claim);
-            if (rd == 0) {
-                for (int i = 0; i < dev::PW_MAX; i++) J.pwr[i] = e2_mul(pw.v[i], r);
-                hip_check(hipMemcpyAsync(d_job, stage(&J, sizeof(J)), sizeof(J), hipMemcpyHostToDevice, st), "upload job");
+        // every round's item and grid are known up front (sizes only): one upload for the whole sum-check
+        std::vector<dev::StItem> items(nvars);
+        std::vector<int> grids(nvars);
+        {
+            const void* cur_in = in;
+            size_t cur_stride = in_stride;
+            for (int rd = 0; rd < nvars; rd++) {
+                const int h = nvars - 1 - rd;
+                dev::StItem& it = items[rd];
+                memset(&it, 0, sizeof(it));
+                it.job = 0; it.h_log2 = h; it.in = cur_in; it.in_stride = cur_stride;
+                it.out = rd == nvars - 1 ? J.final_out : (cur_in == (const void*)J.buf[0] ? J.buf[1] : J.buf[0]);
+                grids[rd] = dev::st_plan_blocks(&it, 1, false);
+                cur_in = it.out; cur_stride = (size_t)1 << h;
             }
-            dev::st_step(st, kind, base && rd == 0, d_job, d_it, 1, grid, d_chain, ctx->d_partials, d_res());  // pass 2: the real fold
-            cur_in = it.out; cur_stride = (size_t)1 << h;
+        }
+        dev::StItem* d_items = upload(items.data(), items.size());
+        if (use_mail) {
+            int npw = 0;
+            for (int i = 0; i < dev::PW_MAX; i++) if (pw.v[i].c0 | pw.v[i].c1) npw = i + 1;
+            std::vector<unsigned long long> seqs(nvars);
+            for (int rd = 0; rd < nvars; rd++) {
+                // the first-round kernels store the weighted fold pw[i] * (x + r d) as pw[i] x + pwr[i] d with pwr = pw * r_0: r_0 is
+                // not known in the first pass (pwr = 0: sums unaffected); k_mail fills pwr in before the second pass
+                dev::st_step(st, kind, base && rd == 0, d_job, d_items + rd, 1, grids[rd], d_chain, ctx->d_partials, d_res());
+                seqs[rd] = mail_enqueue(point_off + rd, rd == 0 ? d_job : nullptr, rd == 0 ? npw : 0);
+                dev::st_step(st, kind, base && rd == 0, d_job, d_items + rd, 1, grids[rd], d_chain, ctx->d_partials, d_res());  // the real fold
+            }
+            for (int rd = 0; rd < nvars; rd++) mail_answer(seqs[rd], h_res() + sums_slot + (size_t)rd * nv, deg, claim);
+            return point_off;
+        }
+        for (int rd = 0; rd < nvars; rd++) {
+            dev::StItem* d_it = d_items + rd;
+            const int grid = grids[rd];
+            dev::st_step(st, kind, base && rd == 0, d_job, d_it, 1, grid, d_chain, ctx->d_partials, d_res());
+            auto pass2 = [&] { dev::st_step(st, kind, base && rd == 0, d_job, d_it, 1, grid, d_chain, ctx->d_partials, d_res()); };  // the real fold
+            {
+                sync();
+                const E2 r = round_message(h_res() + sums_slot + (size_t)rd * nv, deg, claim);
+                if (rd == 0) {
+                    for (int i = 0; i < dev::PW_MAX; i++) J.pwr[i] = e2_mul(pw.v[i], r);
+                    hip_check(hipMemcpyAsync(d_job, stage(&J, sizeof(J)), sizeof(J), hipMemcpyHostToDevice, st), "upload job");
+                }
+                pass2();
+            }
         }
         return point_off;
     }
@@ -207,6 +891,15 @@ struct SeqProver {
     // ---- prove_sum_check, sum of pair products (Libra / zkCNN reductions) --------------------------------------------------
     size_t sumcheck_prodsum(const std::vector<const u64*>& a, const std::vector<const E2*>& b, int nvars, const std::vector<E2*>& fin_a,
                             const std::vector<E2*>& fin_b, E2& claim) {
+        if (use_mail && !classic()) {
+            SqJob Q;
+            memset(&Q, 0, sizeof(Q));
+            const int np = (int)a.size();
+            if (np > dev::PS_MAX_PAIRS) throw Error("prodsum: too many table pairs");
+            Q.kind = 2; Q.ntab = 2 * np; Q.nvars = nvars;
+            for (int i = 0; i < np; i++) { Q.tab[2 * i] = a[i]; Q.tab[2 * i + 1] = b[i]; Q.fin[2 * i] = fin_a[i]; Q.fin[2 * i + 1] = fin_b[i]; }
+            return run_sq(Q, true, claim);
+        }
         const size_t point_off = epos();
         const size_t sums_slot = slot((size_t)nvars * 2);
         const int np = (int)a.size();
@@ -221,19 +914,37 @@ struct SeqProver {
         }
         for (int i = 0; i < np; i++) { J.a[i] = a[i]; J.b[i] = b[i]; J.fin_a[i] = fin_a[i]; J.fin_b[i] = fin_b[i]; }
         dev::PsJob* d_job = upload(&J, 1);
-        int cur = -1;
+        std::vector<dev::PsItem> items(nvars);
+        std::vector<int> grids(nvars);
+        {
+            int cur = -1;
+            for (int rd = 0; rd < nvars; rd++) {
+                dev::PsItem& it = items[rd];
+                memset(&it, 0, sizeof(it));
+                it.job = 0; it.rd = rd; it.in_buf = cur;
+                it.out_buf = rd == nvars - 1 ? -1 : (cur == 0 ? 1 : 0);
+                grids[rd] = dev::ps_plan_blocks(&it, 1, &J, false);
+                cur = it.out_buf;
+            }
+        }
+        dev::PsItem* d_items = upload(items.data(), items.size());
+        if (use_mail) {
+            std::vector<unsigned long long> seqs(nvars);
+            for (int rd = 0; rd < nvars; rd++) {
+                dev::ps_round(st, false, d_job, d_items + rd, 1, grids[rd], d_chain, ctx->d_partials, d_res());
+                seqs[rd] = mail_enqueue(point_off + rd, nullptr, 0);
+                dev::ps_round(st, false, d_job, d_items + rd, 1, grids[rd], d_chain, ctx->d_partials, d_res());
+            }
+            for (int rd = 0; rd < nvars; rd++) mail_answer(seqs[rd], h_res() + sums_slot + 2 * (size_t)rd, 2, claim);
+            return point_off;
+        }
         for (int rd = 0; rd < nvars; rd++) {
-            dev::PsItem it;
-            memset(&it, 0, sizeof(it));
-            it.job = 0; it.rd = rd; it.in_buf = cur;
-            it.out_buf = rd == nvars - 1 ? -1 : (cur == 0 ? 1 : 0);
-            const int grid = dev::ps_plan_blocks(&it, 1, &J, false);
-            dev::PsItem* d_it = upload(&it, 1);
+            dev::PsItem* d_it = d_items + rd;
+            const int grid = grids[rd];
             dev::ps_round(st, false, d_job, d_it, 1, grid, d_chain, ctx->d_partials, d_res());
             sync();
             round_message(h_res() + sums_slot + 2 * (size_t)rd, 2, claim);
             dev::ps_round(st, false, d_job, d_it, 1, grid, d_chain, ctx->d_partials, d_res());
-            cur = it.out_buf;
         }
         return point_off;
     }
@@ -286,7 +997,7 @@ struct SeqProver {
         const size_t roots = slot(nb), ev0 = slot(2 * (size_t)nb);
         if (ext) k_gp_top_e2<<<(nb + 63) / 64, 64, 0, st>>>(static_cast<const E2*>(lev[nv - 1]), nb, d_res() + roots, d_res() + ev0);
         else dev::gp_top(st, static_cast<const u64*>(lev[nv - 1]), nb, d_res() + roots, d_res() + ev0);
-        sync();
+        wait_results();
         std::vector<E2> cl(nb);
         for (int b = 0; b < nb; b++) { cl[b] = h_res()[roots + b]; tr.write_e(cl[b]); }  // root products (prover.rs:197-221)
         write_slots(ev0, 2 * (size_t)nb);                                                // layer 0: v_l, v_r (prover.rs:257)
@@ -308,7 +1019,7 @@ struct SeqProver {
             for (int b = 0; b < nb; b++) { pw.v[b] = g; claim = e2_add(claim, e2_mul(cl[b], g)); g = e2_mul(g, gamma); }  // prover.rs:281-286
             const size_t evals = slot(2 * (size_t)nb);
             point_off = sumcheck_stride(dev::SC_GRANDPROD, lev[k], !ext, h, 2 * nb, n, pw, claim, evals);
-            sync();
+            wait_results();
             // the kernels leave the final LEFT evaluation of pair b multiplied by pw[b] = gamma^b
             if (nb >= 2) {
                 if (pw.v[1].c0 == 0 && pw.v[1].c1 == 0) throw Error("grand product: zero batching weight");
@@ -324,6 +1035,7 @@ struct SeqProver {
 
     // ---- LassoNode::prove_claim_reduction (lasso.rs:57-114) ------------------------------------------------------------------
     Claim lasso_node(const u64* d_input) {
+        Slow sl_all(this, "lasso node (all of it)");
         const LassoPlan& lp = pk->lasso;
         const dev::LassoDev& L = pk->lasso_dev;
         const int nu = lp.nu, A = lp.alpha;
@@ -340,7 +1052,7 @@ struct SeqProver {
             int grid = dev::lasso_claim(st, L, eq, ep, dev::ep_rows_all(A), ctx->d_partials);
             dev::reduce_partials(st, ctx->d_partials, grid, 1, d_res() + claim_slot);
         }
-        sync();
+        wait_results();
         const E2 claimed = h_res()[claim_slot];
         tr.write_e(claimed);  // lasso.rs:100-107
         {   // collation sum-check (lasso.rs:271-279), result dropped (:97)
@@ -419,7 +1131,7 @@ struct SeqProver {
             dots(eqy, {final_cts[c]}, M, base + 2);
             wires.push_back({base, tmp});
         }
-        sync();
+        wait_results();
         size_t q = 0;
         for (auto& chk : lp.chunks) {  // dim(x), read_ts(x), final_cts(y), then E_m(x)
             const size_t base = wires[q].first, tmp = wires[q].second;
@@ -452,6 +1164,7 @@ struct SeqProver {
     }
 
     void vanilla_node(int id) {
+        Slow sl_all(this, "a vanilla node (all of it)");
         const HNode& n = pk->circuit.nodes[id];
         const hg_pk::NodeDev& nd = pk->node_dev[id];
         const int nin = n.log2_sub_in + n.log2_reps;
@@ -466,7 +1179,7 @@ struct SeqProver {
             const size_t s = slot(1);
             int grid = dev::vanilla_const_sum(st, nd.const_gate, nd.const_coef, nd.nconst, eqc, n.log2_sub_out, n.log2_reps, ctx->d_partials);
             dev::reduce_partials(st, ctx->d_partials, grid, 1, d_res() + s);
-            sync();
+            wait_results();
             claim = e2_sub(claim, h_res()[s]);
         }
         std::vector<int> li, ri;
@@ -493,7 +1206,7 @@ struct SeqProver {
         }
         if (!gj.empty()) dev::gather_jobs(st, upload(gj.data(), gj.size()), (int)gj.size(), SR);
         const size_t rx_off = sumcheck_prodsum(a, b, nin, fa, fb, claim);  // Libra phase 1
-        sync();
+        wait_results();
         for (int i : li) {
             const E2 v = h_res()[u_base + i];
             tr.write_e(v);
@@ -519,7 +1232,7 @@ struct SeqProver {
         }
         dev::gather_B_jobs(st, upload(bj.data(), bj.size()), (int)bj.size(), SR);
         const size_t ry_off = sumcheck_prodsum(a2, b2, nin, fa2, fb2, claim);
-        sync();
+        wait_results();
         for (int i : ri) {
             const E2 v = h_res()[w_base + i];
             tr.write_e(v);
@@ -528,6 +1241,7 @@ struct SeqProver {
     }
 
     void fft_node(int id) {
+        Slow sl_all(this, "an fft node (all of it)");
         const HNode& n = pk->circuit.nodes[id];
         const int L = n.log2_size;
         const size_t N = (size_t)1 << L;
@@ -542,7 +1256,7 @@ struct SeqProver {
         const size_t u = slot(1);
         E2* scratch = ctx->alloc_n<E2>(1);
         const size_t off = sumcheck_prodsum({d_vals[n.preds[0]]}, {F}, L, {d_res() + u}, {scratch}, claim);
-        sync();
+        wait_results();
         const E2 v = h_res()[u];
         tr.write_e(v);
         claims[n.preds[0]].push_back(Claim{off, L, v});
@@ -587,13 +1301,27 @@ ProveResult prove_resident_mode(hg_ctx* ctx, const hg_pk* pk, const hg_values* v
     E2* eq = ctx->alloc_n<E2>((size_t)1 << ov);
     P.eq_single(eq, ov, point_off);
     P.dots(eq, {v->d_ct0is}, (size_t)1 << ov, vslot);
-    P.sync();
+    P.wait_results();
     P.gkr(Claim{point_off, ov, ctx->h_res[vslot]});
     hip_check(hipGetLastError(), "prove (mode)");
     ProveResult res;
     res.prove_ms = now_ms() - t0;
     res.gpu_ms = res.prove_ms;
     res.sync_ms = (double)P.n_sync;  // number of synchronisations (reported through hg_timings::sync_ms in this mode)
+    res.enqueue_ms = (double)P.n_mail;  // ... and of mailbox round trips (hg_timings::enqueue_ms in this mode)
+    if (getenv("HG_SEQ_TIMES"))
+        fprintf(stderr, "[hg] mode %d: %.2f ms; host waited %.2f ms for round sums (%zu round trips), %.2f ms for other results, spent %.2f ms enqueueing rounds\n", mode,
+                res.prove_ms, P.t_wait_rounds, P.n_mail, P.t_wait_results, P.t_enqueue_rounds);
+    if (getenv("HG_SEQ_TIMES")) fprintf(stderr, "[hg]   host transcript steps between 'sums seen' and 'challenge posted': %.2f ms in total\n", P.t_answer);
+    if (getenv("HG_SEQ_TIMES"))
+        for (int kd = 0; kd < 3; kd++)
+            fprintf(stderr, "[hg]   kind %d: %zu one-workgroup rounds %.2f ms, %zu larger rounds %.2f ms\n", kd, P.n_kind[kd][0], P.t_kind[kd][0], P.n_kind[kd][1], P.t_kind[kd][1]);
+    if (P.mail && P.mail->timeouts) throw Error("mailbox: a device-side wait timed out");
+    if (P.d_sqsync) {
+        SqSync hs;
+        hip_check(hipMemcpy(&hs, P.d_sqsync, sizeof(hs), hipMemcpyDeviceToHost), "read sync words");
+        if (hs.timeouts) throw Error("sequential prover: a grid barrier timed out");
+    }
     res.proof = std::move(P.tr.bytes);
     return res;
 }

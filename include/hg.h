@@ -128,7 +128,9 @@ int hg_verify(const hg_pk* pk, const hg_witness* w, const uint8_t* proof, size_t
  *   2  extension-field memory checking: gamma, tau are used as E elements, not truncated to base limb 0
  *      [REF lasso/src/memory_checking/prover.rs:36-39; README.md:108 "Known issues"].
  * mode 0 = hg_prove / hg_verify (the reference as it is, bit-exact). Other modes are Goldilocks only and run the round-by-round
- * prover (one device synchronisation per sum-check round; timings->sync_ms then holds the NUMBER of synchronisations). */
+ * prover: the device hands every round's sums to the host transcript through a pinned mailbox and spins on the challenge (no
+ * stream synchronisation inside a sum-check); timings->sync_ms then holds the NUMBER of stream synchronisations and
+ * timings->enqueue_ms the number of mailbox round trips. HG_SEQ_NO_MAIL=1 restores one synchronisation per round. */
 int hg_prove_mode(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, int mode, uint8_t* proof, size_t cap, size_t* len, hg_timings* timings);
 int hg_prove_resident_mode(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int mode, uint8_t* proof, size_t cap, size_t* len, hg_timings* timings);
 int hg_verify_mode(const hg_pk* pk, const hg_witness* w, int mode, const uint8_t* proof, size_t len);
