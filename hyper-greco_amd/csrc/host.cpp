@@ -179,6 +179,45 @@ void params_derive(uint32_t n, uint32_t k, const u64* qis, u64 t, hg_params* out
 }
 
 // ------------------------------------------------------------------------------------------------
+// OpenMP inside a container: omp_get_max_threads() reports the machine's cores (256 on the MI355X boxes) while the cgroup may grant
+// far fewer CPUs (16 there: /sys/fs/cgroup/cpu.max = "1600000 100000"), and libomp's idle workers spin for 200 ms after every
+// parallel region. Together they exhaust the quota and the kernel THROTTLES the whole process for the rest of the 100 ms period -
+// measured as 30-40 ms stalls of the prover's host thread (the sequential prover's mailbox made them visible; cpu.stat
+// nr_throttled counted them). So, once per process: no more OpenMP threads than the quota grants, and idle workers sleep at once.
+extern "C" void kmp_set_blocktime(int) __attribute__((weak));
+int cgroup_cpu_quota() {   // CPUs granted by the cgroup (v2 cpu.max, v1 cfs quota), 0 = unlimited / unknown
+    auto read2 = [](const char* path, long long* a, long long* b) -> int {
+        FILE* f = fopen(path, "r");
+        if (!f) return 0;
+        char buf[64] = {0};
+        int n = 0;
+        if (fgets(buf, sizeof(buf), f)) {
+            if (strncmp(buf, "max", 3) == 0) n = -1;
+            else n = sscanf(buf, "%lld %lld", a, b);
+        }
+        fclose(f);
+        return n;
+    };
+    long long q = 0, per = 0;
+    int n = read2("/sys/fs/cgroup/cpu.max", &q, &per);
+    if (n == 2 && q > 0 && per > 0) return (int)((q + per - 1) / per);
+    if (n == 0) {
+        long long q1 = 0, p1 = 0, dummy = 0;
+        if (read2("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", &q1, &dummy) >= 1 && read2("/sys/fs/cgroup/cpu/cpu.cfs_period_us", &p1, &dummy) >= 1 && q1 > 0 && p1 > 0)
+            return (int)((q1 + p1 - 1) / p1);
+    }
+    return 0;
+}
+static const int g_openmp_guard = [] {
+    if (!getenv("OMP_NUM_THREADS")) {
+        const int q = cgroup_cpu_quota();
+        if (q > 0 && q < omp_get_max_threads()) omp_set_num_threads(q);
+    }
+    if (!getenv("KMP_BLOCKTIME") && !getenv("OMP_WAIT_POLICY") && kmp_set_blocktime) kmp_set_blocktime(0);
+    return 0;
+}();
+
+// ------------------------------------------------------------------------------------------------
 // JSON witness: {"s":[".."],"e":[..],"k1":[..],"r2is":[[..]],"r1is":[[..]],"ais":[[..]],"ct0is":[[..]]}
 namespace {
 // One flat array of quoted decimals whose elements are parsed later, in parallel (parse_array_jobs)

@@ -336,60 +336,10 @@ __global__ __launch_bounds__(256) void k_sq_round(const SqJob* __restrict__ jp, 
         sq_mail_epilogue(J, rd, acc, res, chain);
     }
 }
-// rounds rd0 .. nvars-1 in ONE single-workgroup launch: a round here costs its arithmetic plus the mailbox round trip - no launch,
-// no job reload, no end-of-kernel flush - which is what the many short rounds of a proof are made of. The folded tables stay in
-// the ping-pong buffers (L2-resident at these sizes); the final evaluations are written at the end.
-template <int KIND, typename TIN>
-__global__ __launch_bounds__(256) void k_sq_tail(const SqJob* __restrict__ jp, int rd0, int units, E2* chain, E2* res) {
-    constexpr int NV = KIND == 1 ? 3 : 2;
-    __shared__ E2 sm[NV][256];
-    __shared__ E2 s_r;
-    const SqJob& J = *jp;
-    E2 r_prev = rd0 > 0 ? chain[J.r_off + rd0 - 1] : e2_zero();
-    for (int rd = rd0; rd < J.nvars; rd++) {
-        const int hl = J.nvars - 1 - rd;
-        int g_log2 = 0;
-        while ((1 << g_log2) < units && g_log2 < 8) g_log2++;
-        int jb_log2 = 8 - g_log2;
-        if (jb_log2 > hl) jb_log2 = hl;
-        E2 acc[NV];
-#pragma unroll
-        for (int t = 0; t < NV; t++) acc[t] = e2_zero();
-        sq_round_sums<KIND, TIN>(J, rd, jb_log2, r_prev, 0, 1, acc, sm);
-        sq_block_sum<NV>(acc, sm);
-        if (threadIdx.x == 0) { sq_mail_epilogue(J, rd, acc, res, chain); s_r = chain[J.r_off + rd]; }
-        __syncthreads();   // (also orders this round's table stores before the next round's loads: one workgroup)
-        r_prev = s_r;
-        __syncthreads();
-    }
-    const int n = J.nvars;
-    for (int t = threadIdx.x; t < J.ntab; t += 256) {
-        E2 v;
-        if (n == 1) {
-            if (J.kind == 2 && (t & 1)) { const E2* p = static_cast<const E2*>(J.tab[t]); v = sq_fold(p[0], p[1], r_prev); }
-            else {
-                const TIN* p = J.kind == 2 ? static_cast<const TIN*>(J.tab[t]) : static_cast<const TIN*>(J.in) + (size_t)t * J.in_stride;
-                v = sq_fold(sq_ld<TIN>(p, 0), sq_ld<TIN>(p, 1), r_prev);
-            }
-            if (J.kind == 0 && t > 0) v = e2_mul(v, J.pw[t]);
-            if (J.kind == 1 && !(t & 1) && t > 0) v = e2_mul(v, J.pw[t / 2]);
-        } else {
-            const E2* p = J.buf[(n - 1) & 1] + (size_t)t * 2;
-            v = sq_fold(p[0], p[1], r_prev);
-        }
-        if (J.kind == 2) *J.fin[t] = v; else J.final_out[t] = v;
-    }
-}
-// ALL rounds of one sum-check in ONE launch: a grid of co-resident workgroups walks the rounds together. Per round: every workgroup
-// that has pair indices in this round sums its share and bumps a ticket; the last one adds the partials, runs the mailbox round
-// trip and publishes the round's challenge by raising a flag the other workgroups spin on (a grid-wide barrier through the L2 /
-// memory: the folded tables cross XCDs, so both sides fence at agent scope). No launch happens while the device waits for the
-// host - a round costs its arithmetic, the barrier and the PCIe round trip.
-struct SqSync { unsigned ticket, round, timeouts, pad; };
 // thread mapping of a round with 2^hl pair indices and `units` table units (pairs / tables): as many groups along the units as
 // they can use (one unit per thread when the round is small: a workgroup that walks 50 pairs per thread is a 50 us latency
 // chain), fewer when the round has enough pair indices to fill the chip anyway (long coalesced runs along j); host and device
-__host__ __device__ __forceinline__ void sq_plan_dev(int hl, int units, int nblocks_max, int* jb_log2, int* nblk) {
+static inline void sq_plan(int hl, int units, int nblocks_max, int* jb_log2, int* nblk) {
     int g_log2 = 0;
     while ((1 << g_log2) < units && g_log2 < 8) g_log2++;
     while (g_log2 > 0 && hl + g_log2 > 18) g_log2--;
@@ -398,106 +348,6 @@ __host__ __device__ __forceinline__ void sq_plan_dev(int hl, int units, int nblo
     *jb_log2 = jb;
     const size_t ntiles = ((size_t)1 << hl) >> jb;
     *nblk = (int)(ntiles < (size_t)nblocks_max ? ntiles : (size_t)nblocks_max);
-}
-template <int KIND, typename TIN>
-__global__ __launch_bounds__(256) void k_sq_persist(const SqJob* __restrict__ jp, int units, E2* chain, E2* __restrict__ partials, SqSync* sy, E2* res,
-                                                    unsigned round0, unsigned ticket0) {   // the counters of *sy run on across sum-checks (never reset)
-    constexpr int NV = KIND == 1 ? 3 : 2;
-    __shared__ E2 sm[NV][256];
-    __shared__ unsigned s_last;
-    const SqJob& J = *jp;
-    const int nvars = J.nvars;
-    unsigned ticket_base = ticket0;
-    for (int rd = 0; rd < nvars; rd++) {
-        if (rd > 0) {   // the barrier: round rd-1's challenge is published (and every workgroup's folded tables are written back)
-            if (threadIdx.x == 0) {
-                const long long t0 = wall_clock64();
-                while ((int)(__hip_atomic_load(&sy->round, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - (round0 + (unsigned)rd)) < 0) {
-                    if (wall_clock64() - t0 > 600000000ll) { __hip_atomic_fetch_add(&sy->timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-                    __builtin_amdgcn_s_sleep(2);
-                }
-            }
-            __syncthreads();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        int jb_log2, nblk;
-        sq_plan_dev(nvars - 1 - rd, units, (int)gridDim.x, &jb_log2, &nblk);
-        if ((int)blockIdx.x >= nblk) continue;   // nothing of this round here: on to the next barrier
-        E2 r_prev = e2_zero();
-        if (rd > 0) {
-            r_prev.c0 = __hip_atomic_load(&chain[J.r_off + rd - 1].c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            r_prev.c1 = __hip_atomic_load(&chain[J.r_off + rd - 1].c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        E2 acc[NV];
-#pragma unroll
-        for (int t = 0; t < NV; t++) acc[t] = e2_zero();
-        sq_round_sums<KIND, TIN>(J, rd, jb_log2, r_prev, blockIdx.x, (size_t)nblk, acc, sm);
-        sq_block_sum<NV>(acc, sm);
-        if (threadIdx.x == 0) {
-            if (nblk > 1) {
-#pragma unroll
-                for (int t = 0; t < NV; t++) {
-                    __hip_atomic_store(&partials[(size_t)blockIdx.x * NV + t].c0, acc[t].c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(&partials[(size_t)blockIdx.x * NV + t].c1, acc[t].c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-            // release: this workgroup's folded tables (plain stores of all its threads, ordered before this point by the
-            // barriers of the block sum) must be written back before another XCD reads them in the next round
-            const unsigned tk = __hip_atomic_fetch_add(&sy->ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-            s_last = tk == ticket_base + (unsigned)nblk - 1 ? 1u : 0u;
-        }
-        ticket_base += (unsigned)nblk;
-        __syncthreads();
-        if (!s_last) continue;
-        if (nblk > 1) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#pragma unroll
-            for (int t = 0; t < NV; t++) acc[t] = e2_zero();
-            for (int b = threadIdx.x; b < nblk; b += 256)
-#pragma unroll
-                for (int t = 0; t < NV; t++) {
-                    E2 v;
-                    v.c0 = __hip_atomic_load(&partials[(size_t)b * NV + t].c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    v.c1 = __hip_atomic_load(&partials[(size_t)b * NV + t].c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    acc[t] = e2_add(acc[t], v);
-                }
-            sq_block_sum<NV>(acc, sm);
-        }
-        if (threadIdx.x == 0) {
-            sq_mail_epilogue(J, rd, acc, res, chain);   // sums -> host, wait, chain[r_off + rd] = r
-            __hip_atomic_store(&sy->round, round0 + (unsigned)(rd + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    // (a workgroup that has left a round never comes back: the rounds only shrink) workgroup 0 is in every round: the final evaluations
-    if (blockIdx.x != 0) return;
-    if (threadIdx.x == 0) {
-        const long long t0 = wall_clock64();
-        while ((int)(__hip_atomic_load(&sy->round, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - (round0 + (unsigned)nvars)) < 0) {
-            if (wall_clock64() - t0 > 600000000ll) break;
-            __builtin_amdgcn_s_sleep(2);
-        }
-    }
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    E2 r_last;
-    r_last.c0 = __hip_atomic_load(&chain[J.r_off + nvars - 1].c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    r_last.c1 = __hip_atomic_load(&chain[J.r_off + nvars - 1].c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int t = threadIdx.x; t < J.ntab; t += 256) {
-        E2 v;
-        if (nvars == 1) {
-            if (J.kind == 2 && (t & 1)) { const E2* p = static_cast<const E2*>(J.tab[t]); v = sq_fold(p[0], p[1], r_last); }
-            else {
-                const TIN* p = J.kind == 2 ? static_cast<const TIN*>(J.tab[t]) : static_cast<const TIN*>(J.in) + (size_t)t * J.in_stride;
-                v = sq_fold(sq_ld<TIN>(p, 0), sq_ld<TIN>(p, 1), r_last);
-            }
-            if (J.kind == 0 && t > 0) v = e2_mul(v, J.pw[t]);
-            if (J.kind == 1 && !(t & 1) && t > 0) v = e2_mul(v, J.pw[t / 2]);
-        } else {
-            const E2* p = J.buf[(nvars - 1) & 1] + (size_t)t * 2;
-            v = sq_fold(p[0], p[1], r_last);
-        }
-        if (J.kind == 2) *J.fin[t] = v; else J.final_out[t] = v;
-    }
 }
 // after the last round: table t's final evaluation = fold of its last two entries with the last challenge (weights: see above)
 template <typename TIN>
@@ -692,25 +542,9 @@ struct SeqProver {
 
     // ---- one sum-check through the fused round kernels and the mailbox ---------------------------------------------------------
     unsigned* d_ticket = nullptr;
-    SqSync* d_sqsync = nullptr;
-    unsigned sq_round0 = 0, sq_ticket0 = 0;
-    static constexpr int SQ_PERSIST_BLOCKS = 512;   // co-resident on 256 CUs at two workgroups per CU (96 VGPRs: five would fit)
     template <int KIND> void launch_round(bool in_base, const SqJob* d_job, int rd, int jb_log2, int grid) {
         if (in_base) k_sq_round<KIND, u64><<<grid, 256, 0, st>>>(d_job, rd, jb_log2, d_chain, ctx->d_partials, d_ticket, d_res());
         else k_sq_round<KIND, E2><<<grid, 256, 0, st>>>(d_job, rd, jb_log2, d_chain, ctx->d_partials, d_ticket, d_res());
-    }
-    // thread mapping of a round with 2^hl pair indices and `units` table units (pairs / tables): as many groups along the units as
-    // they can use (one unit per thread when the round is small: a workgroup that walks 50 pairs per thread is a 50 us latency
-    // chain), fewer when the round has enough pair indices to fill the chip anyway (long coalesced runs along j)
-    static void sq_plan(int hl, int units, int* jb_log2, int* grid) {
-        int g_log2 = 0;
-        while ((1 << g_log2) < units && g_log2 < 8) g_log2++;
-        while (g_log2 > 0 && hl + g_log2 > 18) g_log2--;          // more than 2^18 threads' worth: trade groups for j
-        int jb = 8 - g_log2;
-        if (jb > hl) jb = hl;
-        *jb_log2 = jb;
-        const size_t ntiles = ((size_t)1 << hl) >> jb;
-        *grid = (int)std::min<size_t>(ntiles, SQ_MAX_BLOCKS);
     }
     // J: kind, ntab, nvars, tables, final destinations, pw filled in by the caller. Enqueues every round and the final fold, then
     // answers the rounds in order. Returns the chain position of the point.
@@ -736,54 +570,11 @@ struct SeqProver {
         { Slow sl(this, "run_sq set-up (allocations, job upload)"); d_job = upload(&J, 1); }
         // the launches run a few rounds ahead of the answers: the device never waits for a launch, and the first round's answer does
         // not wait for the host to have enqueued the whole sum-check
-        static const bool persist = [] { const char* e = getenv("HG_SEQ_NO_PERSIST"); return !(e && e[0] == '1'); }();
-        if (persist) {   // all rounds and the final evaluations in one launch (k_sq_persist); the host only answers
-            const int units_p = J.kind == 0 ? J.ntab : J.ntab / 2;
-            if (!d_sqsync) {
-                d_sqsync = ctx->alloc_n<SqSync>(1);
-                hip_check(hipMemsetAsync(d_sqsync, 0, sizeof(SqSync), st), "clear sync words");
-                sq_round0 = sq_ticket0 = 0;
-            }
-            int jb0 = 0, grid = 1;
-            sq_plan_dev(nvars - 1, units_p, SQ_PERSIST_BLOCKS, &jb0, &grid);
-            unsigned tickets = 0;
-            for (int rd = 0; rd < nvars; rd++) { int jb, nb; sq_plan_dev(nvars - 1 - rd, units_p, grid, &jb, &nb); tickets += (unsigned)nb; }
-            {
-                Slow sl(this, "enqueueing a sum-check");
-#define HG_SQ_LAUNCH(K, T) k_sq_persist<K, T><<<grid, 256, 0, st>>>(d_job, units_p, d_chain, ctx->d_partials, d_sqsync, d_res(), sq_round0, sq_ticket0)
-                if (J.kind == 0) { if (in_base) HG_SQ_LAUNCH(0, u64); else HG_SQ_LAUNCH(0, E2); }
-                else if (J.kind == 1) { if (in_base) HG_SQ_LAUNCH(1, u64); else HG_SQ_LAUNCH(1, E2); }
-                else { if (in_base) HG_SQ_LAUNCH(2, u64); else HG_SQ_LAUNCH(2, E2); }
-#undef HG_SQ_LAUNCH
-            }
-            sq_round0 += (unsigned)nvars; sq_ticket0 += tickets;
-            t_enqueue_rounds += now_ms() - te0;
-            for (int rd = 0; rd < nvars; rd++) {
-                const double w0 = t_wait_rounds;
-                mail_answer(J.seq0 + (unsigned long long)rd, h_res() + J.sums_slot + (size_t)rd * J.nv, J.kind == 1 ? 3 : 2, claim);
-                const int big = nvars - 1 - rd > 8 ? 1 : 0;
-                t_kind[J.kind][big] += t_wait_rounds - w0; n_kind[J.kind][big]++;
-            }
-            return point_off;
-        }
         const int LOOKAHEAD = 6;
-        // the tail: all rounds from the first one with at most SQ_TAIL_ITEMS (pair index, table unit) items on, in one launch
-        const int units = J.kind == 0 ? J.ntab : J.ntab / 2;
-        static const size_t tail_items = [] { const char* e = getenv("HG_SEQ_TAIL_ITEMS"); return e && *e ? (size_t)atol(e) : (size_t)0; }();   // (measured: no gain at 512 / 2048 / 8192 - a tail round costs what a launched round costs, the host's turnaround; off by default)
-        int tail_rd = nvars;
-        while (tail_rd > 0 && ((size_t)units << (nvars - tail_rd)) <= tail_items) tail_rd--;   // round rd has 2^(nvars-1-rd) pair indices
-        if (tail_items == 0) tail_rd = nvars;
         int enq = 0;
         auto enqueue_round = [&] {
             Slow sl(this, "enqueueing a round");
             const int rd = enq;
-            if (rd >= tail_rd && rd < nvars) {   // the tail takes every remaining round and the final evaluations
-                enq = nvars + 1;
-                if (J.kind == 0) { if (in_base) k_sq_tail<0, u64><<<1, 256, 0, st>>>(d_job, rd, units, d_chain, d_res()); else k_sq_tail<0, E2><<<1, 256, 0, st>>>(d_job, rd, units, d_chain, d_res()); }
-                else if (J.kind == 1) { if (in_base) k_sq_tail<1, u64><<<1, 256, 0, st>>>(d_job, rd, units, d_chain, d_res()); else k_sq_tail<1, E2><<<1, 256, 0, st>>>(d_job, rd, units, d_chain, d_res()); }
-                else { if (in_base) k_sq_tail<2, u64><<<1, 256, 0, st>>>(d_job, rd, units, d_chain, d_res()); else k_sq_tail<2, E2><<<1, 256, 0, st>>>(d_job, rd, units, d_chain, d_res()); }
-                return;
-            }
             enq++;
             if (rd == nvars) {
                 if (in_base) k_sq_final<u64><<<(J.ntab + 63) / 64, 64, 0, st>>>(d_job, d_chain);
@@ -791,7 +582,7 @@ struct SeqProver {
                 return;
             }
             int jb = 0, grid = 1;
-            sq_plan(nvars - 1 - rd, J.kind == 0 ? J.ntab : J.ntab / 2, &jb, &grid);
+            sq_plan(nvars - 1 - rd, J.kind == 0 ? J.ntab : J.ntab / 2, SQ_MAX_BLOCKS, &jb, &grid);
             if (J.kind == 0) launch_round<0>(in_base, d_job, rd, jb, grid);
             else if (J.kind == 1) launch_round<1>(in_base, d_job, rd, jb, grid);
             else launch_round<2>(in_base, d_job, rd, jb, grid);
@@ -1317,11 +1108,7 @@ ProveResult prove_resident_mode(hg_ctx* ctx, const hg_pk* pk, const hg_values* v
         for (int kd = 0; kd < 3; kd++)
             fprintf(stderr, "[hg]   kind %d: %zu one-workgroup rounds %.2f ms, %zu larger rounds %.2f ms\n", kd, P.n_kind[kd][0], P.t_kind[kd][0], P.n_kind[kd][1], P.t_kind[kd][1]);
     if (P.mail && P.mail->timeouts) throw Error("mailbox: a device-side wait timed out");
-    if (P.d_sqsync) {
-        SqSync hs;
-        hip_check(hipMemcpy(&hs, P.d_sqsync, sizeof(hs), hipMemcpyDeviceToHost), "read sync words");
-        if (hs.timeouts) throw Error("sequential prover: a grid barrier timed out");
-    }
+
     res.proof = std::move(P.tr.bytes);
     return res;
 }
