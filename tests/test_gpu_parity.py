@@ -539,6 +539,28 @@ def test_alternative_paths_behind_the_environment_switches_stay_bit_exact(switch
     assert r.returncode == 0 and "SWITCH OK" in r.stdout, (switch, r.stdout[-500:], r.stderr[-2000:])
 
 
+@pytest.mark.parametrize("switch", ["HG_NO_MIRROR=1", "HG_E_TABLES=1"])
+def test_environment_switches_at_the_headline_size(switch):
+    """Two of the switches above at n=32768 k=16 (BASELINE configs[2]), where every production shortcut is active: walks, the capture and
+    two graph replays must all give the oracle's bytes."""
+    import subprocess, sys
+    from hglib import ROOT
+    code = (
+        "import os, sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import __graft_entry__ as entry\n"
+        "import orclib\n"
+        "hg = entry.load_package()\n"
+        "ctx = hg.Context(0); bfv = hg.BfvEncrypt.new(32768, 16); pk = bfv.setup(ctx)\n"
+        "w = hg.Witness.synthetic(bfv.params, 77); v = hg.witness_gen(ctx, pk, w); out = hg.ProofBuffer()\n"
+        "ref, _ = orclib.prove(orclib.params(32768, 16), orclib.Inputs(w.arrays()), threads=min(16, os.cpu_count() or 8))\n"
+        "for i in range(5): assert hg.prove_resident(ctx, pk, v, out).bytes() == ref, i\n"
+        "print('SWITCH OK')\n"
+    ) % (ROOT, os.path.join(ROOT, "tests"))
+    name, value = switch.split("=")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, **{name: value}), cwd=ROOT)
+    assert r.returncode == 0 and "SWITCH OK" in r.stdout, (switch, r.stdout[-500:], r.stderr[-2000:])
+
+
 def test_library_collective_single_rank_communicator(ctx):
     """hg_comm_init / hg_prove_sharded with a one-rank RCCL communicator (the only size a one-GPU box offers): the limb-split
     kernel, ncclAllReduce on the prover stream and the fold-back kernel run for real and must leave the proof unchanged."""
