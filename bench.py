@@ -341,8 +341,19 @@ def main():
     wrank = 0 if shard else rank
     seeds = [witness_seed(args.seed, args.n, wrank) + 104729 * j for j in range(NW)]
     witnesses = [hg.Witness.synthetic(bfv.params, sd) for sd in seeds]
-    vals = [hg.witness_gen(ctx, pk, w) for w in witnesses]  # node tables -> HBM (outside the timed region)
+    # node tables -> HBM (outside the timed region). Sharded: a rank keeps only the tables its share reads (hg_witness_gen_shard:
+    # the witness is not replicated; HG_BENCH_REPLICATE=1 restores full copies)
+    per_rank = shard and os.environ.get("HG_BENCH_REPLICATE") != "1"
     out = hg.ProofBuffer()
+    unsharded = None
+    if shard:  # the sharded proofs must equal the single-GPU proofs bit for bit: proven once from a full copy, which is then released
+        unsharded = []
+        for w in witnesses:
+            fv = hg.witness_gen(ctx, pk, w)
+            unsharded.append(hg.prove_resident(ctx, pk, fv, out).bytes())
+            fv.free()
+    vals = [hg.witness_gen_shard(ctx, pk, w, rank, world) if per_rank else hg.witness_gen(ctx, pk, w) for w in witnesses]
+    resident = vals[0].info()
 
     lib_comm = shard and backend == "nccl"   # the library's own RCCL all-reduce (device buffers, no torch hop, no host staging)
     exchange_note = None
@@ -389,9 +400,7 @@ def main():
         hg.prove_shard_combine(ctx, gathered, world)                 # lane-wise sum mod p (GP#1 round sums are partial sums)
         return hg.prove_shard_finish(ctx, out)                       # transcript replay -> identical bytes on every rank
 
-    unsharded = None
-    if shard:  # the sharded proofs must equal the single-GPU proofs bit for bit
-        unsharded = [hg.prove_resident(ctx, pk, v, out).bytes() for v in vals]
+    if shard:
         # every rank must hand the collective a result buffer of the same length (they walk the same protocol): a mismatch would
         # hang the all-reduce, so check it once, up front, through the caller-side entry points (no collective inside)
         n_local = int(len(hg.prove_shard_begin(ctx, pk, vals[0], rank, world)))
@@ -463,6 +472,11 @@ def main():
         assert outs[i].bytes() == walked[i % NW], f"timed step {i}: the replayed proof differs from the walked proof of witness {i % NW}"
     for i in range(NW):
         assert step(i).bytes() == walked[i]
+    resident_all = None
+    if shard:
+        lst = [None] * world
+        dist.all_gather_object(lst, round(resident["resident_bytes"] / 1e6, 1))
+        resident_all = lst
     elapsed = max_over_ranks(elapsed, world, dist, torch, red_dev)
     elapsed_a = max_over_ranks(elapsed_a, world, dist, torch, red_dev)
     elapsed_c = max_over_ranks(elapsed_c, world, dist, torch, red_dev)
@@ -554,6 +568,9 @@ def main():
                                          "roofline": f"{args.steps} proves immediately before, plain launches with HIP events around the dominant class: "
                                                      f"{ms_per_step_a:.4f} ms per prove, {gpu_ms_a:.4f} ms of GPU time"},
                        **({"rccl_ranks_seen": rccl_ranks_seen} if rccl_ranks_seen is not None else {}),
+                       **({"resident_node_tables": {"rank0_MB": round(resident["resident_bytes"] / 1e6, 1), "per_rank_MB": resident_all,
+                                                    "full_set_MB": round(resident["full_bytes"] / 1e6, 1),
+                                                    "note": "hg_witness_gen_shard: a rank keeps the Lasso input and the inputs of the node reductions it owns"}} if shard else {}),
                        **({"end_to_end": end_to_end} if end_to_end else {}),
                        **({"verify": verify_info} if verify_info else {}),
                        "witness_gen_ms_device_first_call": round(vals[0].timings["witness_ms"], 2), "upload_ms_first_call": round(vals[0].timings["upload_ms"], 2)},

@@ -38,7 +38,7 @@ class HgKernelStat(C.Structure):
 EXPORTS = [
     "hg_last_error", "hg_device_count", "hg_create", "hg_destroy", "hg_set_option", "hg_params_builtin", "hg_params_derive", "hg_grand_product", "hg_fold", "hg_setup", "hg_pk_free",
     "hg_pk_lasso_layout", "hg_pk_info", "hg_witness_from_json", "hg_witness_synthetic", "hg_witness_from_arrays",
-    "hg_witness_get", "hg_witness_free", "hg_prove", "hg_verify", "hg_prove_mode", "hg_prove_resident_mode", "hg_verify_mode", "hg_witness_gen", "hg_witness_gen_into", "hg_values_free", "hg_values_get", "hg_comm_unique_id", "hg_comm_init", "hg_comm_destroy", "hg_comm_count", "hg_comm_selftest", "hg_prove_sharded", "hg_prove_shard_begin", "hg_prove_shard_combine", "hg_prove_shard_finish", "hg_shard_combine_host", "hg_prove_resident", "hg_circuit_eval", "hg_lasso_prove", "hg_lasso_prove_at", "hg_lasso_num_challenges", "hg_sumcheck", "hg_mle_eval",
+    "hg_witness_get", "hg_witness_free", "hg_prove", "hg_verify", "hg_prove_mode", "hg_prove_resident_mode", "hg_verify_mode", "hg_witness_gen", "hg_witness_gen_into", "hg_witness_gen_shard", "hg_values_info", "hg_values_free", "hg_values_get", "hg_comm_unique_id", "hg_comm_init", "hg_comm_destroy", "hg_comm_count", "hg_comm_selftest", "hg_prove_sharded", "hg_prove_shard_begin", "hg_prove_shard_combine", "hg_prove_shard_finish", "hg_shard_combine_host", "hg_prove_resident", "hg_circuit_eval", "hg_lasso_prove", "hg_lasso_prove_at", "hg_lasso_num_challenges", "hg_sumcheck", "hg_mle_eval",
     "hg_ntt", "hg_challenges", "hg_challenges_bn254", "hg_bn254_field_op", "hg_sumcheck_bn254", "hg_grand_product_bn254", "hg_lasso_prove_bn254", "hg_witness_from_json_bn254", "hg_circuit_eval_bn254", "hg_prove_bn254", "hg_verify_bn254", "hg_mle_eval_bn254", "hg_ntt_bn254", "hg_profile", "hg_profile_select", "hg_profile_reset", "hg_profile_get",
 ]
 
@@ -431,6 +431,14 @@ class ResidentValues:
         lib().hg_values_get(ctx.h, self.h, node_id, _ptr(a), n)
         return a
 
+    def info(self):
+        """hg_values_info: resident bytes, bytes of the full table set, resident tables, tables."""
+        out = (C.c_uint64 * 4)()
+        L = lib()
+        L.hg_values_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        _check(L.hg_values_info(self.h, out))
+        return {"resident_bytes": int(out[0]), "full_bytes": int(out[1]), "resident_tables": int(out[2]), "tables": int(out[3])}
+
     def free(self):
         if self.h:
             lib().hg_values_free(self.h)
@@ -441,6 +449,16 @@ def witness_gen(ctx, pk, witness):
     h = C.c_void_p()
     tm = HgTimings()
     _check(lib().hg_witness_gen(ctx.h, pk.h, witness.h, C.byref(h), C.byref(tm)))
+    return ResidentValues(h, {f: getattr(tm, f) for f, _ in HgTimings._fields_})
+
+
+def witness_gen_shard(ctx, pk, witness, rank, world):
+    """hg_witness_gen_shard: circuit.evaluate() keeping only the tables rank `rank` of a `world`-GPU proof reads."""
+    h = C.c_void_p()
+    tm = HgTimings()
+    L = lib()
+    L.hg_witness_gen_shard.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(HgTimings)]
+    _check(L.hg_witness_gen_shard(ctx.h, pk.h, witness.h, rank, world, C.byref(h), C.byref(tm)))
     return ResidentValues(h, {f: getattr(tm, f) for f, _ in HgTimings._fields_})
 
 

@@ -380,6 +380,28 @@ int hg_witness_gen_into(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, hg_va
     HG_CATCH(-1)
 }
 
+int hg_witness_gen_shard(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, int rank, int world, hg_values** out, hg_timings* timings) {
+    HG_TRY
+    if (!ctx || !pk || !w || !out || !pk->ctx) throw Error("hg_witness_gen_shard: needs a device context and a device prover key");
+    check_witness(pk, w, "hg_witness_gen_shard");
+    double wm = 0, um = 0;
+    *out = witness_gen_shard(ctx, pk, w->w, rank, world, &wm, &um);
+    if (timings) { memset(timings, 0, sizeof(*timings)); timings->witness_ms = wm; timings->upload_ms = um; }
+    return 0;
+    HG_CATCH(-1)
+}
+int hg_values_info(const hg_values* v, uint64_t out[4]) {
+    HG_TRY
+    if (!v || !out) throw Error("hg_values_info: null argument");
+    size_t n = 0;
+    for (auto p : v->d_vals) n += p != nullptr;
+    size_t full = v->full_bytes, res = v->resident_bytes;
+    if (v->shard_rank < 0) { full = v->ct0is_len * 8; for (size_t q : v->sizes) full += q * 8; res = full; }
+    out[0] = res; out[1] = full; out[2] = n; out[3] = v->d_vals.size();
+    return 0;
+    HG_CATCH(-1)
+}
+
 void hg_values_free(hg_values* v) { values_free(v); }
 
 int64_t hg_values_get(hg_ctx* ctx, const hg_values* v, int node, uint64_t* out, size_t cap) {

@@ -168,6 +168,51 @@ static E2 horner(const E2* c, int d, E2 x) {
     return r;
 }
 
+// ---- single-proof sharding over `world` GPUs: who owns what (shared by the prover and by the sharded witness generation) -------------
+ShardPlan shard_plan(const hg_pk* pk, int rank, int world) {
+    ShardPlan sp;
+    const HCircuit& c = pk->circuit;
+    const int nu = pk->lasso.nu;
+    sp.node_owner.assign(c.nodes.size(), 0);
+    sp.own_out_claim = 0;
+    if (world <= 1) return sp;
+    const int G = (int)pk->lasso.gkr_order.size();
+    const double N = (double)((size_t)1 << nu);
+    sp.gp1_mem_owner.assign(G, 0);
+    for (int i = 0; i < G; i++) sp.gp1_mem_owner[i] = (int)(((long long)i * world) / G);
+    // Load model in "table entries touched", calibrated on MI355X at n=32768 k=16. Per owned memory: two grand-product tables
+    // through every layer (~9 passes each), its E table in the split, the claim, the collation sum-check and the opening (~6).
+    // Per rank that owns any: the limb split of the input, the counters of the chunks it needs, and the p_0 tables.
+    std::vector<double> load(world, 0.0);
+    std::vector<int> nmem(world, 0);
+    for (int i = 0; i < G; i++) { load[sp.gp1_mem_owner[i]] += N * (2.0 * 9.0 + 6.0); nmem[sp.gp1_mem_owner[i]]++; }
+    for (int r = 0; r < world; r++) if (nmem[r]) load[r] += N * (5.0 + 3.5 * std::min(4, nmem[r]) + (r == sp.gp1_mem_owner[0] ? 0.0 : 11.0));
+    struct Item { double cost; int idx; };
+    std::vector<Item> items;
+    for (size_t id = 0; id < c.nodes.size(); id++) {
+        const HNode& n = c.nodes[id];
+        if (n.kind == NK_FFT) items.push_back({(double)((size_t)1 << n.log2_size) * 18.0, (int)id});
+        if (n.kind == NK_VANILLA) {
+            int np = 0;
+            for (int i = 0; i < n.arity; i++) np += n.left_use[i] + n.right_use[i];
+            items.push_back({(double)np * (double)((size_t)1 << (n.log2_sub_in + n.log2_reps)) * 12.0 + 3.0 * (double)((size_t)1 << n.log2_out()), (int)id});
+        }
+    }
+    std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.cost > b.cost; });
+    for (auto& it : items) {   // longest-processing-time-first
+        int r = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+        load[r] += it.cost;
+        sp.node_owner[it.idx] = r;
+    }
+    sp.own_out_claim = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+    if (getenv("HG_SHARD_DEBUG") && rank == 0) {
+        fprintf(stderr, "[hg] shard plan world %d: %d memories; out-claim -> %d; loads", world, G, sp.own_out_claim);
+        for (int r = 0; r < world; r++) fprintf(stderr, " %.1fM", load[r] / 1e6);
+        fprintf(stderr, "\n");
+    }
+    return sp;
+}
+
 typedef std::shared_ptr<E2> Cell;
 static Cell cell(E2 v = e2_zero()) { return std::make_shared<E2>(v); }
 
@@ -215,45 +260,11 @@ struct Prover {
     bool mine(int owner) const { return owner == rank; }
     void plan_shards() {
         if (!pk) return;
-        const HCircuit& c = pk->circuit;
-        const int nu = pk->lasso.nu;
-        node_owner.assign(c.nodes.size(), 0);
-        gp1_owner.assign(nu, rank);
-        if (world <= 1) return;
-        const int G = (int)pk->lasso.gkr_order.size();
-        const double N = (double)((size_t)1 << nu);
-        gp1_mem_owner.assign(G, 0);
-        for (int i = 0; i < G; i++) gp1_mem_owner[i] = (int)(((long long)i * world) / G);
-        // Load model in "table entries touched", calibrated on MI355X at n=32768 k=16. Per owned memory: two grand-product tables
-        // through every layer (~9 passes each), its E table in the split, the claim, the collation sum-check and the opening (~6).
-        // Per rank that owns any: the limb split of the input, the counters of the chunks it needs, and the p_0 tables.
-        std::vector<double> load(world, 0.0);
-        std::vector<int> nmem(world, 0);
-        for (int i = 0; i < G; i++) { load[gp1_mem_owner[i]] += N * (2.0 * 9.0 + 6.0); nmem[gp1_mem_owner[i]]++; }
-        for (int r = 0; r < world; r++) if (nmem[r]) load[r] += N * (5.0 + 3.5 * std::min(4, nmem[r]) + (r == gp1_mem_owner[0] ? 0.0 : 11.0));
-        struct Item { double cost; int idx; };
-        std::vector<Item> items;
-        for (size_t id = 0; id < c.nodes.size(); id++) {
-            const HNode& n = c.nodes[id];
-            if (n.kind == NK_FFT) items.push_back({(double)((size_t)1 << n.log2_size) * 18.0, (int)id});
-            if (n.kind == NK_VANILLA) {
-                int np = 0;
-                for (int i = 0; i < n.arity; i++) np += n.left_use[i] + n.right_use[i];
-                items.push_back({(double)np * (double)((size_t)1 << (n.log2_sub_in + n.log2_reps)) * 12.0 + 3.0 * (double)((size_t)1 << n.log2_out()), (int)id});
-            }
-        }
-        std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.cost > b.cost; });
-        for (auto& it : items) {   // longest-processing-time-first
-            int r = (int)(std::min_element(load.begin(), load.end()) - load.begin());
-            load[r] += it.cost;
-            node_owner[it.idx] = r;
-        }
-        own_out_claim = (int)(std::min_element(load.begin(), load.end()) - load.begin());
-        if (getenv("HG_SHARD_DEBUG") && rank == 0) {
-            fprintf(stderr, "[hg] shard plan world %d: %d memories; out-claim -> %d; loads", world, G, own_out_claim);
-            for (int r = 0; r < world; r++) fprintf(stderr, " %.1fM", load[r] / 1e6);
-            fprintf(stderr, "\n");
-        }
+        ShardPlan sp = shard_plan(pk, rank, world);
+        node_owner = std::move(sp.node_owner);
+        gp1_owner.assign(pk->lasso.nu, rank);
+        gp1_mem_owner = std::move(sp.gp1_mem_owner);
+        own_out_claim = sp.own_out_claim;
     }
 
     Prover(hg_ctx* c, const hg_pk* k, int rank_ = 0, int world_ = 1) : ctx(c), pk(k), st(c->stream), partials(c->d_partials), rank(rank_), world(world_) {
@@ -1757,6 +1768,7 @@ static hg_values* values_alloc(hg_ctx* ctx, const hg_pk* pk) {
     return v.release();
 }
 
+static void shard_fill(hg_ctx* ctx, hg_values* v, const hg_values* full);
 void witness_gen_into(hg_ctx* ctx, const hg_pk* pk, const Witness& w, hg_values* v, double* witness_ms, double* upload_ms) {
     // Circuit::evaluate on the device: inputs are uploaded, then the circuit is evaluated level by level
     // (Vanilla nodes: gate-major kernel; FFT nodes: batched NTTs, same level + direction in one batch).
@@ -1764,6 +1776,12 @@ void witness_gen_into(hg_ctx* ctx, const hg_pk* pk, const Witness& w, hg_values*
     // prove depends on addresses only).
     if (!v || v->pk_serial != pk->serial) throw Error("witness generation: the values object was laid out for another prover key");
     if (v->device != ctx->device) throw Error("witness generation: the values object lives on another device");
+    if (v->shard_rank >= 0) {   // a rank's share: evaluate in full into a temporary object, keep the rank's tables at their addresses
+        hg_values* full = witness_gen(ctx, pk, w, witness_ms, upload_ms);
+        try { shard_fill(ctx, v, full); } catch (...) { values_free(full); throw; }
+        values_free(full);
+        return;
+    }
     hip_check(hipSetDevice(ctx->device), "hipSetDevice");
     const HCircuit& c = pk->circuit;
     const Params& p = pk->params;
@@ -1825,6 +1843,60 @@ hg_values* witness_gen(hg_ctx* ctx, const hg_pk* pk, const Witness& w, double* w
     hg_values* v = values_alloc(ctx, pk);
     try { witness_gen_into(ctx, pk, w, v, witness_ms, upload_ms); } catch (...) { values_free(v); throw; }
     return v;
+}
+
+// ---- a rank's share of the node tables (BASELINE config 4: the witness is NOT replicated) ---------------------------------------------
+// Which tables rank `rank` of a `world`-GPU proof reads: the Lasso node's input (every rank holds memories of the Lasso node), the
+// inputs of the Vanilla / FFT node reductions it owns, ct0is if it evaluates the output claim.
+static void shard_needed(const hg_pk* pk, int rank, int world, std::vector<char>* need, bool* need_ct0is) {
+    const HCircuit& c = pk->circuit;
+    const ShardPlan sp = shard_plan(pk, rank, world);
+    need->assign(c.nodes.size(), 0);
+    bool any_mem = false;
+    for (int o : sp.gp1_mem_owner) any_mem |= o == rank;
+    for (size_t id = 0; id < c.nodes.size(); id++) {
+        const HNode& n = c.nodes[id];
+        if (n.kind == NK_LASSO && any_mem) (*need)[n.preds[0]] = 1;
+        if ((n.kind == NK_VANILLA || n.kind == NK_FFT) && sp.node_owner[id] == rank) for (int p : n.preds) (*need)[p] = 1;
+    }
+    *need_ct0is = sp.own_out_claim == rank;
+}
+// copies the needed tables out of a fully evaluated circuit into the compact allocation of `v` (same addresses every time)
+static void shard_fill(hg_ctx* ctx, hg_values* v, const hg_values* full) {
+    for (size_t id = 0; id < v->d_vals.size(); id++)
+        if (v->d_vals[id]) hip_check(hipMemcpyAsync(const_cast<u64*>(v->d_vals[id]), full->d_vals[id], v->sizes[id] * 8, hipMemcpyDeviceToDevice, ctx->stream), "keep node table");
+    if (v->d_ct0is) hip_check(hipMemcpyAsync(const_cast<u64*>(v->d_ct0is), full->d_ct0is, v->ct0is_len * 8, hipMemcpyDeviceToDevice, ctx->stream), "keep ct0is");
+    hip_check(hipStreamSynchronize(ctx->stream), "shard fill");
+}
+hg_values* witness_gen_shard(hg_ctx* ctx, const hg_pk* pk, const Witness& w, int rank, int world, double* witness_ms, double* upload_ms) {
+    if (world < 1 || rank < 0 || rank >= world) throw Error("witness_gen_shard: bad rank / world");
+    if (world == 1) return witness_gen(ctx, pk, w, witness_ms, upload_ms);
+    // The circuit is evaluated in full once (the per-modulus chains feed shared nodes: lasso_inputs_batched reads every r1_i, r2_i)
+    // into a temporary object; what this rank does not read is released before the function returns.
+    struct ValuesDeleter { void operator()(hg_values* p) const { values_free(p); } };
+    std::unique_ptr<hg_values, ValuesDeleter> full(witness_gen(ctx, pk, w, witness_ms, upload_ms));
+    std::vector<char> need;
+    bool need_ct0is = false;
+    shard_needed(pk, rank, world, &need, &need_ct0is);
+    std::unique_ptr<hg_values, ValuesDeleter> v(new hg_values());
+    static std::atomic<uint64_t> next_serial{(uint64_t)1 << 40};   // (disjoint from values_alloc's serials)
+    v->serial = next_serial++;
+    v->pk_serial = pk->serial; v->device = ctx->device; v->ctx = ctx;
+    v->sizes = full->sizes;
+    v->ct0is_len = full->ct0is_len;
+    v->d_vals.assign(full->d_vals.size(), nullptr);
+    v->shard_rank = rank; v->shard_world = world;
+    size_t total = need_ct0is ? v->ct0is_len : 0, all = v->ct0is_len;
+    for (size_t id = 0; id < need.size(); id++) { all += v->sizes[id]; if (need[id]) total += v->sizes[id]; }
+    u64* base = nullptr;
+    hip_check(hipMalloc((void**)&base, std::max<size_t>(total, 1) * 8), "hipMalloc(a rank's node tables)");
+    v->owned.push_back(base);
+    size_t off = 0;
+    for (size_t id = 0; id < need.size(); id++) if (need[id]) { v->d_vals[id] = base + off; off += v->sizes[id]; }
+    if (need_ct0is) v->d_ct0is = base + off;
+    v->resident_bytes = total * 8; v->full_bytes = all * 8;
+    shard_fill(ctx, v.get(), full.get());
+    return v.release();
 }
 
 // contexts alive in this process: a values object that is freed tells its context to drop the launch graphs recorded for it
@@ -2098,6 +2170,8 @@ static std::shared_ptr<ProveCache> prove_capture(hg_ctx* ctx, const hg_pk* pk, c
 // on the third prove of that triple; otherwise returns null and the caller walks the protocol. *out is filled when non-null is returned.
 static std::shared_ptr<ProveCache> prove_through_graph(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int rank, int world, bool exchange, ProveResult* out, bool replay_now = true) {
     if (v->pk_serial != pk->serial) throw Error("prove: the resident values were generated for another prover key");
+    if (v->shard_rank >= 0 && (v->shard_rank != rank || v->shard_world != world))
+        throw Error("prove: these values hold the tables of rank " + std::to_string(v->shard_rank) + " of " + std::to_string(v->shard_world) + " only (hg_witness_gen_shard)");
     if (!graph_allowed(ctx)) return nullptr;
     const int share = rank * 65536 + world;
     if (ctx->slow_graph_serial == pk->serial && ctx->slow_graph_share == share) {   // its graph replayed slower than plain launches

@@ -149,6 +149,9 @@ struct hg_values {
     int max_level = 0;
     std::vector<int> order;
     std::vector<void*> owned;
+    // a rank's share of a sharded proof (witness_gen_shard): the tables of nodes it does not read are not resident (d_vals[id] == nullptr)
+    int shard_rank = -1, shard_world = 0;   // -1: every table is resident
+    size_t resident_bytes = 0, full_bytes = 0;
 };
 
 namespace hg {
@@ -158,7 +161,14 @@ struct ProveResult {
     double witness_ms = 0, upload_ms = 0, prove_ms = 0, gpu_ms = 0, enqueue_ms = 0, sync_ms = 0, replay_ms = 0;
 };
 
+// who owns what when ONE proof is sharded over `world` GPUs (prover.hip): Vanilla / FFT node reductions dealt whole, the Lasso
+// node split by memory (memory-GKR index -> rank), the output claim's evaluation
+struct ShardPlan { std::vector<int> node_owner; std::vector<int> gp1_mem_owner; int own_out_claim = 0; };
+ShardPlan shard_plan(const hg_pk* pk, int rank, int world);
 hg_values* witness_gen(hg_ctx* ctx, const hg_pk* pk, const Witness& w, double* witness_ms, double* upload_ms);
+// Circuit::evaluate for ONE rank of a sharded proof: only the node tables the rank's share reads stay resident in HBM (the Lasso
+// node's input, the inputs of the node reductions it owns, ct0is for the owner of the output claim); the others are released
+hg_values* witness_gen_shard(hg_ctx* ctx, const hg_pk* pk, const Witness& w, int rank, int world, double* witness_ms, double* upload_ms);
 // Circuit::evaluate into the tables of an existing values object (same addresses: its cached launch graph stays valid)
 void witness_gen_into(hg_ctx* ctx, const hg_pk* pk, const Witness& w, hg_values* v, double* witness_ms, double* upload_ms);
 void values_free(hg_values* v);

@@ -148,6 +148,13 @@ int hg_witness_gen(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, hg_values*
  * addresses only - the next hg_prove_resident(v) replays it on the new witness. hg_prove does this internally with a values
  * object owned by the context. */
 int hg_witness_gen_into(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, hg_values* v, hg_timings* timings);
+/* The same for ONE rank of a proof sharded over `world` GPUs (BASELINE config 4): only the node tables the rank's share reads stay
+ * resident - the Lasso node's input, the inputs of the Vanilla / FFT node reductions the planner deals to it, ct0is on the rank that
+ * evaluates the output claim; the per-modulus objects a rank does not own [REF sk_encryption_circuit.rs:122-128, 245-260] are released.
+ * The result proves through hg_prove_sharded / hg_prove_shard_begin with the same (rank, world) only; hg_witness_gen_into refills it. */
+int hg_witness_gen_shard(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, int rank, int world, hg_values** out, hg_timings* timings);
+/* [resident bytes, bytes of the full set of node tables, resident tables, tables] */
+int hg_values_info(const hg_values* v, uint64_t out[4]);
 void hg_values_free(hg_values* v);
 /* copies node `node`'s table (NodeId order of configure) back to the host; returns its element count */
 int64_t hg_values_get(hg_ctx* ctx, const hg_values* v, int node, uint64_t* out, size_t cap);

@@ -246,6 +246,43 @@ def test_sharded_single_proof_reassembles_bit_exact(ctx, n, k, world):
     pk.free()
 
 
+@pytest.mark.parametrize("n,k,world", [(4096, 2, 2), (32768, 16, 8)])
+def test_sharded_proof_from_per_rank_resident_tables(ctx, n, k, world):
+    """BASELINE config 4 without replicating the witness: every virtual rank gets its own values object from hg_witness_gen_shard -
+    only the node tables its share reads (the others are not resident: a kernel touching them would fault) - runs its share, the
+    partial buffers are combined and replayed: the proof must equal the oracle's. A second witness goes through the same objects
+    (hg_witness_gen_into) and, from the third prove on, through each rank's launch graph."""
+    bfv = hg.BfvEncrypt.new(n, k)
+    pk = bfv.setup(ctx)
+    p = orclib.params(n, k)
+    threads = min(16, os.cpu_count() or 8)
+    ws = [hg.Witness.synthetic(bfv.params, 0x91 + i) for i in range(2)]
+    refs = [orclib.prove(p, orclib.Inputs(w.arrays()), threads=threads)[0] for w in ws]
+    vals = [hg.witness_gen_shard(ctx, pk, ws[0], r, world) for r in range(world)]
+    infos = [v.info() for v in vals]
+    full = infos[0]["full_bytes"]
+    assert all(i["resident_bytes"] < full for i in infos) and all(i["resident_tables"] < i["tables"] for i in infos)
+    if world == 8:
+        assert max(i["resident_bytes"] for i in infos) < full // 2, infos
+    print("n=%d world=%d: resident MB per rank %s of %.1f MB" % (n, world, ["%.1f" % (i["resident_bytes"] / 1e6) for i in infos], full / 1e6))
+    out = hg.ProofBuffer()
+    with pytest.raises(hg.HgError, match="of rank"):
+        hg.prove_shard_begin(ctx, pk, vals[0], 1, world)                   # another rank's share cannot run on these tables
+    with pytest.raises(hg.HgError, match="of rank"):
+        hg.prove_resident(ctx, pk, vals[0], out)
+    for it in range(5):                                                    # walk, walk, capture / replay; the second witness from it == 2 on
+        j = 0 if it < 2 else 1
+        if it == 2:
+            for r in range(world):
+                hg.witness_gen_into(ctx, pk, ws[1], vals[r])
+        parts = [hg.prove_shard_begin(ctx, pk, vals[r], r, world).copy() for r in range(world)]
+        hg.prove_shard_combine(ctx, np.stack(parts), world)
+        assert hg.prove_shard_finish(ctx, out).bytes() == refs[j], (it, _first_diff(out.bytes(), refs[j], 16))
+    for v in vals:
+        v.free()
+    pk.free()
+
+
 def test_a_ranks_share_replays_from_its_launch_graph(ctx):
     """The share of one rank of an 8-rank proof, five times in a row: two walks, the capture, two graph replays - the partial
     result buffer must be the same every time, and the last one must still reassemble to the unsharded proof."""
