@@ -467,6 +467,39 @@ def test_graph_replay_across_witnesses(ctx, n, k, seeds):
     pk.free()
 
 
+def test_graph_cache_eviction_and_refill_guards(ctx):
+    """One graph slot (HG_GRAPH_ENTRIES=1, child process): two values objects proven in alternation evict each other's graph over
+    and over - the bytes never change. In this process: a values object cannot be refilled for another key, and reports its size."""
+    import subprocess, sys
+    from hglib import ROOT
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import __graft_entry__ as entry\n"
+        "import orclib\n"
+        "hg = entry.load_package()\n"
+        "ctx = hg.Context(0); bfv = hg.BfvEncrypt.new(4096, 2); pk = bfv.setup(ctx); out = hg.ProofBuffer()\n"
+        "ws = [hg.Witness.synthetic(bfv.params, 61 + i) for i in range(2)]\n"
+        "vs = [hg.witness_gen(ctx, pk, w) for w in ws]\n"
+        "refs = [orclib.prove(orclib.params(4096, 2), orclib.Inputs(w.arrays()), threads=4)[0] for w in ws]\n"
+        "for i in range(10):\n"
+        "    for j in range(2): assert hg.prove_resident(ctx, pk, vs[j], out).bytes() == refs[j], (i, j)\n"
+        "print('EVICT OK')\n"
+    ) % (ROOT, os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, HG_GRAPH_ENTRIES="1"), cwd=ROOT)
+    assert r.returncode == 0 and "EVICT OK" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+    bfv = hg.BfvEncrypt.new(4096, 2)
+    pk, pk2 = bfv.setup(ctx), bfv.setup(ctx)
+    w = hg.Witness.synthetic(bfv.params, 63)
+    vals = hg.witness_gen(ctx, pk, w)
+    info = vals.info()
+    assert info["resident_bytes"] == info["full_bytes"] > 0 and info["resident_tables"] == info["tables"] == pk.num_nodes
+    with pytest.raises(hg.HgError, match="another prover key"):
+        hg.witness_gen_into(ctx, pk2, w, vals)
+    with pytest.raises(hg.HgError, match="another prover key"):
+        hg.prove_resident(ctx, pk2, vals, hg.ProofBuffer())
+    vals.free(); pk.free(); pk2.free()
+
+
 def test_graph_capture_failure_falls_back_to_plain_launches(ctx, monkeypatch):
     """A launch-graph capture that fails (forced) must not fail the prove nor be retried on every call: the key walks from then on."""
     n, k = 4096, 2
