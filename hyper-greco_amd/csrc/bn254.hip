@@ -200,7 +200,8 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_round(const Fr* __restrict__ in, 
 // mirror (top layer of the Lasso read / write product, see StJob::mirror in kernels.hpp): the job holds the read pairs only; s_in is
 // the linear table S = sum_i w_i (l_i + r_i) in natural order ([2j], [2j+1]), folded into s_out; K1 S(t) + K2 joins P0 and P1.
 struct GpJobDev { const Fr* l_base; const Fr* r_base; Fr* out; Fr* part; Fr r; unsigned long long half, l_stride, r_stride; int nb, gx, gy, mirror;
-                  const Fr* s_in; Fr* s_out; Fr k1, k2; };
+                  const Fr* s_in; Fr* s_out; Fr k1, k2;
+                  FoldK fk; };   // fold_consts(r): the round's folds x + r d run through fr_fold_const (bn254_wide.hpp)
 // Two lanes share one pair index j (quad_perm [1,0,3,2] swaps their registers): the even lane owns the LEFT tables, the odd lane the
 // RIGHT tables; each loads, folds and stores only its own tables, so every table entry is read from HBM once. With x, y = T[2j],
 // T[2j+1] and d = y - x the round polynomial needs P0 = sum xl xr, P1 = sum yl yr, Pinf = sum dl dr:
@@ -233,7 +234,6 @@ __global__ __launch_bounds__(BN_TPB) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const Fr* __restrict__ lb = J.l_base;
     Fr* __restrict__ out = J.out;
     const size_t half = J.half;
-    const Fr r = J.r;
     const int nb = J.nb, P = J.gy, bx = tile % J.gx, pi = tile / J.gx;
     Fr acc1 = fr_zero(), acc3 = fr_zero();   // even lane: g(0) and g(3); odd lane: g(2) (and an unused product)
     for (size_t j = (size_t)bx * BN_GP_J + jj; j < half; j += (size_t)J.gx * BN_GP_J) {   // both lanes of a pair share j
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(BN_TPB) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             {
                 const Fr x_a = mb[(size_t)ia * ms + 2 * j], y_a = mb[(size_t)ia * ms + 2 * j + 1];
                 d_a = fr_sub(y_a, x_a);
-                out[(size_t)(2 * ia + lane2) * half + j] = fr_add(x_a, fr_mul_wide(r, d_a));
+                out[(size_t)(2 * ia + lane2) * half + j] = fr_fold_const(x_a, d_a, J.fk.k);
                 // even lane: x (own) * x (other side) -> P0; odd lane: y (own) * y (other side) -> P1
                 wcol_mac(c1, fr_sel(isA, x_a, y_a), fr_swap_lane(fr_sel(isA, y_a, x_a)));
             }
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(BN_TPB) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             if (hb) {
                 const Fr x_b = mb[(size_t)ib * ms + 2 * j], y_b = mb[(size_t)ib * ms + 2 * j + 1];
                 d_b = fr_sub(y_b, x_b);
-                out[(size_t)(2 * ib + lane2) * half + j] = fr_add(x_b, fr_mul_wide(r, d_b));
+                out[(size_t)(2 * ib + lane2) * half + j] = fr_fold_const(x_b, d_b, J.fk.k);
                 wcol_mac(c1, fr_sel(isA, x_b, y_b), fr_swap_lane(fr_sel(isA, y_b, x_b)));
             }
             // Pinf: pair a on the even lane, pair b on the odd lane
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(BN_TPB) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         if (J.mirror && pi == 0) {   // (uniform over the workgroup) even lane: P0 += K1 S(0) + K2, odd lane: P1 += K1 S(1) + K2
             const Fr sx = J.s_in[2 * j], sy = J.s_in[2 * j + 1];
             R1 = fr_add(R1, fr_add(fr_mul_wide(J.k1, fr_sel(isA, sx, sy)), J.k2));
-            if (isA) J.s_out[j] = fr_add(sx, fr_mul_wide(r, fr_sub(sy, sx)));
+            if (isA) J.s_out[j] = fr_fold_const(sx, fr_sub(sy, sx), J.fk.k);
         }
         const Fr Ro = fr_swap_lane(R1), Pi = fr_add(Ri, fr_swap_lane(Ri));
         const Fr P0 = fr_sel(isA, R1, Ro), P1 = fr_sel(isA, Ro, R1);
@@ -833,6 +833,7 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
                 d.out = (rd & 1) ? P.buf1 : P.buf0;
                 d.part = P.part + (size_t)rd * BN_PART_STRIDE * 3;
                 d.r = fr_to_mont(chain[layers[n].r_at + rd]);
+                fold_consts(d.r, &d.fk);
                 d.half = half;
                 d.nb = (int)nb;
                 if (P.mirror) {

@@ -141,6 +141,101 @@ __device__ __forceinline__ Fr wcol_reduce(WCol& w) {
     return r;
 }
 
+// ---- x + r d for a multiplier r that is FIXED for a whole launch (the fold of a sum-check round) -----------------------------------
+// A general Montgomery product is 64 + 64 multiply-adds (product, reduction). With r fixed, the reduction moves into eight
+// precomputed constants K_i = r 2^(32 i) R^-1 mod p (plain integers below p, FoldK::k[8 i ..]): for residues in Montgomery form
+//   r d R^-1 = sum_i d_i K_i   (d_i = the 32-bit limbs of d),
+// 64 multiply-adds into EIGHT columns, and what is left to reduce is x + sum < 2^36 p: one quotient estimate (a double
+// multiplication by 2^224 / p, exact to well below one unit for quotients under 2^36, rounded down from slightly below), q p
+// subtracted with 16 multiply-adds, one conditional subtraction of p. The constants are read through a uniform address (scalar loads: they sit in
+// SGPRs, one per v_mad_u64_u32 as its single constant-bus operand). About half the instructions of fr_add(x, fr_mul_wide(r, d)).
+struct FoldK { u32 k[64]; };
+// K_i = REDC(r * 2^(32 i)), host or device (r in Montgomery form)
+BN_HD void fold_consts(const Fr& r, FoldK* out) {
+    for (int i = 0; i < 8; i++) {
+        Fr e = fr_make(0, 0, 0, 0);
+        e.l[i >> 1] = 1ULL << (32 * (i & 1));
+        const Fr ki = fr_mul(r, e);
+        for (int q = 0; q < 4; q++) { out->k[8 * i + 2 * q] = (u32)ki.l[q]; out->k[8 * i + 2 * q + 1] = (u32)(ki.l[q] >> 32); }
+    }
+}
+// C[k..k+3] += x * y[0..3] with the y in SGPRs, carries banked in T[k..k+3]
+#define BN_WIDE_ROW4S(c0, c1, c2, c3, t0, t1, t2, t3, x, y0, y1, y2, y3)                                                     \
+    do {                                                                                                                     \
+        u64 s0_, s1_, s2_, s3_;                                                                                              \
+        asm("v_mad_u64_u32 %0, %8, %12, %13, %0\n\t"                                                                         \
+            "v_mad_u64_u32 %1, %9, %12, %14, %1\n\t"                                                                         \
+            "v_mad_u64_u32 %2, %10, %12, %15, %2\n\t"                                                                        \
+            "v_mad_u64_u32 %3, %11, %12, %16, %3\n\t"                                                                        \
+            "v_addc_co_u32_e64 %4, %8, 0, %4, %8\n\t"                                                                        \
+            "v_addc_co_u32_e64 %5, %9, 0, %5, %9\n\t"                                                                        \
+            "v_addc_co_u32_e64 %6, %10, 0, %6, %10\n\t"                                                                      \
+            "v_addc_co_u32_e64 %7, %11, 0, %7, %11"                                                                          \
+            : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3), "=&s"(s0_), "=&s"(s1_), "=&s"(s2_), \
+              "=&s"(s3_)                                                                                                     \
+            : "v"(x), "s"(y0), "s"(y1), "s"(y2), "s"(y3));                                                                   \
+    } while (0)
+// x + r d mod p in [0, p), for x, d in [0, p) and K = fold_consts(r) behind a wave-uniform pointer
+__device__ __forceinline__ Fr fr_fold_const(const Fr& x, const Fr& d, const u32* __restrict__ K) {
+    u64 C[8];
+    u32 T[8];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { C[2 * i] = (u32)x.l[i]; C[2 * i + 1] = x.l[i] >> 32; T[2 * i] = 0; T[2 * i + 1] = 0; }
+    u32 dl[8];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { dl[2 * i] = (u32)d.l[i]; dl[2 * i + 1] = (u32)(d.l[i] >> 32); }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        BN_WIDE_ROW4S(C[0], C[1], C[2], C[3], T[0], T[1], T[2], T[3], dl[i], K[8 * i + 0], K[8 * i + 1], K[8 * i + 2], K[8 * i + 3]);
+        BN_WIDE_ROW4S(C[4], C[5], C[6], C[7], T[4], T[5], T[6], T[7], dl[i], K[8 * i + 4], K[8 * i + 5], K[8 * i + 6], K[8 * i + 7]);
+    }
+    // value = sum_k C[k] 2^(32 k) + sum_k T[k] 2^(32 k + 64) < 2^290: ten limbs
+    u32 L[10];
+    WRun run;
+    run.lo = 0; run.hi = 0;
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+        if (k < 8) wrun_add(run, C[k]);
+        if (k >= 2) wrun_add(run, (u64)T[k - 2]);
+        L[k] = (u32)run.lo;
+        wrun_shift(run);
+    }
+    // q = floor(value / p) estimated from the bits above 2^224, one unit low (so that the remainder is in [0, 3p))
+    const double top = (double)L[9] * 18446744073709551616.0 + (double)(((u64)L[8] << 32) | L[7]);
+    const double qd = top * 1.2317090423844144e-09;   // 2^224 / p (p = 0x30644e72e131a029... ~ 2^253.597)
+    // |qd - value / p| < 2^-15 (53-bit mantissa on a quotient below 2^36, 2^224 / p ~ 1e-9 for the dropped low bits): rounding
+    // down from qd - 2^-10 gives floor(value / p) or one less, never more
+    const u64 q = qd > 0.0009765625 ? (u64)(qd - 0.0009765625) : 0;
+    // value - q p: q = q_hi 2^32 + q_lo, q_hi < 16
+    const u32 pl[8] = {(u32)FR_P0, (u32)(FR_P0 >> 32), (u32)FR_P1, (u32)(FR_P1 >> 32), (u32)FR_P2, (u32)(FR_P2 >> 32), (u32)FR_P3, (u32)(FR_P3 >> 32)};
+    const u32 qlo = (u32)q, qhi = (u32)(q >> 32);
+    u32 Q[10];
+    {
+        u64 carry = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const u64 t = (u64)qlo * pl[k] + carry; Q[k] = (u32)t; carry = t >> 32; }
+        Q[8] = (u32)carry; Q[9] = 0;
+        carry = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const u64 t = (u64)qhi * pl[k] + Q[k + 1] + carry; Q[k + 1] = (u32)t; carry = t >> 32; }
+        Q[9] = (u32)carry;
+    }
+    u32 Rl[8];
+    {
+        long long borrow = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const long long t = (long long)L[k] - (long long)Q[k] + borrow; Rl[k] = (u32)t; borrow = t >> 32; }
+        // (limbs 8, 9 of the difference are zero: the remainder is below 3p < 2^256)
+    }
+    Fr r = fr_make((u64)Rl[0] | ((u64)Rl[1] << 32), (u64)Rl[2] | ((u64)Rl[3] << 32), (u64)Rl[4] | ((u64)Rl[5] << 32), (u64)Rl[6] | ((u64)Rl[7] << 32));
+    {   // remainder in [0, 2p): one branch-free subtraction of p
+        const Fr m = fr_sub_p(r);
+        const bool ge = fr_geq_p(r);
+        r = fr_make(ge ? m.l[0] : r.l[0], ge ? m.l[1] : r.l[1], ge ? m.l[2] : r.l[2], ge ? m.l[3] : r.l[3]);
+    }
+    return r;
+}
+
 __device__ __forceinline__ Fr fr_mul_wide(const Fr& a, const Fr& b) {
     WCol w = wcol_zero();
     wcol_mac(w, a, b);
