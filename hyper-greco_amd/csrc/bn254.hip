@@ -624,18 +624,23 @@ __global__ void k_bn_prod_level(const Fr* __restrict__ in, size_t in_len, Fr* __
 }
 // level 1 of a mirrored product: `in` holds the nb/2 READ rows only; row b >= nb/2 of the output is the product of the read row
 // b - nb/2 shifted by c (the write rows are never materialised)
-__global__ void k_bn_prod_level_mirror(const Fr* __restrict__ in, size_t in_len, Fr* __restrict__ out, int nb, Fr c, const Fr* __restrict__ pw = nullptr,
+__global__ void k_bn_prod_level_mirror(const Fr* __restrict__ in, size_t in_len, Fr* __restrict__ out, int nb, Fr c, Fr c2, FoldK kc, const Fr* __restrict__ pw = nullptr,
                                        Fr* __restrict__ lw = nullptr) {
-    const size_t h = in_len >> 1, total = h * nb;
+    // one thread per entry of a READ row: its product x y is the read row's level-1 entry, and the write row's entry is
+    // (x + c)(y + c) = x y + c (x + y) + c^2 - the multiplication by the launch-wide c goes through fr_fold_const (kc = fold_consts(c))
+    const size_t h = in_len >> 1, half = (size_t)nb / 2, total = h * half;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    const size_t b = i >> (__ffsll((long long)h) - 1), j = i & (h - 1), half = (size_t)nb / 2;
-    const size_t src = b < half ? b : b - half;
-    Fr x = in[src * in_len + j], y = in[src * in_len + j + h];
-    if (b >= half) { x = fr_add(x, c); y = fr_add(y, c); }
+    const size_t b = i >> (__ffsll((long long)h) - 1), j = i & (h - 1);
+    const Fr x = in[b * in_len + j], y = in[b * in_len + j + h];
     const Fr v = fr_mul_wide(x, y);
+    const Fr vw = fr_add(v, fr_fold_const(c2, fr_add(x, y), kc.k));
     out[b * h + j] = v;
-    if (lw && j < (h >> 1)) lw[b * (h >> 1) + j] = b == 0 ? v : fr_mul_wide(pw[b], v);
+    out[(b + half) * h + j] = vw;
+    if (lw && j < (h >> 1)) {
+        lw[b * (h >> 1) + j] = b == 0 ? v : fr_mul_wide(pw[b], v);
+        lw[(b + half) * (h >> 1) + j] = fr_mul_wide(pw[b + half], vw);
+    }
 }
 static void write_be32(std::vector<uint8_t>& out, const Fr& canonical) {  // transcript.rs:183-189: repr, byte-reversed
     const size_t at = out.size();
@@ -793,7 +798,11 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
             const int n = nv - 1 - k;
             const Fr* pw_n = n >= 1 ? plan[n].d_pw : nullptr;
             Fr* lw_n = n >= 1 ? plan[n].lw : nullptr;
-            if (k == 1 && mirror_c) k_bn_prod_level_mirror<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(lev[0], len, lk, (int)nb, *mirror_c, pw_n, lw_n);   // level 0: read rows only
+            if (k == 1 && mirror_c) {   // level 0: read rows only
+                FoldK kc;
+                fold_consts(*mirror_c, &kc);
+                k_bn_prod_level_mirror<<<(unsigned)((total / 2 + 255) / 256), 256, 0, st>>>(lev[0], len, lk, (int)nb, *mirror_c, fr_mul(*mirror_c, *mirror_c), kc, pw_n, lw_n);
+            }
             else k_bn_prod_level<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(lev[k - 1], len >> (k - 1), lk, (int)nb, pw_n, lw_n);
             lev[k] = lk;
         }
@@ -1053,29 +1062,43 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_dot_u64_reduce(const Fr* __restri
     if (threadIdx.x == 0) *outs.out[t] = fr_from_mont(a);
 }
 // h(a,v,t) = a + v gamma + t gamma^2 - tau (prover.rs:44) for the reads (t) and writes (t + 1) of one memory
-struct HashK { Fr one2, gamma2x, gammasq2x, gammasq, tau; };  // R^2, gamma R^2, gamma^2 R^2 (raw), gamma^2 and tau (Montgomery)
+struct HashK { Fr one2, gamma2x, gammasq2x, gammasq, tau;   // R^2, gamma R^2, gamma^2 R^2 (raw), gamma^2 and tau (Montgomery)
+               u32 kc[32]; };                              // limbs of R, gamma R, gamma^2 R, p - tau R: fr_lin3_const (bn254_wide.hpp)
+static void hashk_consts(HashK& K, const Fr& gamma_mont, const Fr& gamma2_mont, const Fr& tau_mont) {
+    const Fr c[4] = {fr_one_mont(), gamma_mont, gamma2_mont, fr_sub(fr_zero(), tau_mont)};
+    for (int q = 0; q < 4; q++) for (int i = 0; i < 4; i++) { K.kc[8 * q + 2 * i] = (u32)c[q].l[i]; K.kc[8 * q + 2 * i + 1] = (u32)(c[q].l[i] >> 32); }
+}
 __global__ void k_bn_hash_rw(size_t n, const u64* __restrict__ dim, const u64* __restrict__ ep, const u64* __restrict__ ts, HashK K,
                              Fr* __restrict__ rd, Fr* __restrict__ wr) {
     size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
-    WCol w = wcol_zero();
-    wcol_mac_u64(w, dim[j], K.one2);
-    wcol_mac_u64(w, ep[j], K.gamma2x);
-    wcol_mac_u64(w, ts[j], K.gammasq2x);
-    const Fr h = fr_sub(wcol_reduce(w), K.tau);
+    const u64 a = dim[j], v = ep[j], t = ts[j];
+    Fr h;
+    if (((a | v | t) >> 32) == 0) h = fr_lin3_const((u32)a, (u32)v, (u32)t, K.kc);   // addresses, limb values, counters: always
+    else {
+        WCol w = wcol_zero();
+        wcol_mac_u64(w, a, K.one2);
+        wcol_mac_u64(w, v, K.gamma2x);
+        wcol_mac_u64(w, t, K.gammasq2x);
+        h = fr_sub(wcol_reduce(w), K.tau);
+    }
     rd[j] = h;
     if (wr) wr[j] = fr_add(h, K.gammasq);   // (null: the write rows are not materialised, see grand_product_core's mirror_c)
 }
 __global__ void k_bn_hash_if(u32 cutoff, const u64* __restrict__ fc, HashK K, Fr* __restrict__ init, Fr* __restrict__ fin) {
     u32 a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= 65536) return;
-    WCol w = wcol_zero();
-    wcol_mac_u64(w, a, K.one2);
-    if (a < cutoff) wcol_mac_u64(w, a, K.gamma2x);
-    WCol w2 = w;
-    wcol_mac_u64(w2, fc[a], K.gammasq2x);
-    init[a] = fr_sub(wcol_reduce(w), K.tau);
-    fin[a] = fr_sub(wcol_reduce(w2), K.tau);
+    const u64 f = fc[a];
+    const u32 tv = a < cutoff ? a : 0u;
+    init[a] = fr_lin3_const(a, tv, 0u, K.kc);
+    if ((f >> 32) == 0) fin[a] = fr_lin3_const(a, tv, (u32)f, K.kc);
+    else {
+        WCol w2 = wcol_zero();
+        wcol_mac_u64(w2, a, K.one2);
+        if (a < cutoff) wcol_mac_u64(w2, a, K.gamma2x);
+        wcol_mac_u64(w2, f, K.gammasq2x);
+        fin[a] = fr_sub(wcol_reduce(w2), K.tau);
+    }
 }
 
 // low limbs of a Montgomery-form table; *bad is set when an element does not fit one limb
@@ -1204,6 +1227,7 @@ static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4,
         const Fr gamma = fr_to_mont(chain[gamma_at]), tau = fr_to_mont(chain[tau_at]), gamma2 = fr_mul(gamma, gamma);
         HashK HK;
         HK.one2 = fr_r2(); HK.gamma2x = fr_to_mont(gamma); HK.gammasq2x = fr_to_mont(gamma2); HK.gammasq = gamma2; HK.tau = tau;
+        hashk_consts(HK, gamma, gamma2, tau);
         const int G = (int)lp.gkr_order.size();
         static const bool use_mirror = [] { const char* e = getenv("HG_NO_MIRROR"); return !(e && e[0] == '1'); }();
         const bool mirror = use_mirror && nu >= 2;   // write hash = read hash + gamma^2: only the read rows exist

@@ -175,21 +175,9 @@ BN_HD void fold_consts(const Fr& r, FoldK* out) {
               "=&s"(s3_)                                                                                                     \
             : "v"(x), "s"(y0), "s"(y1), "s"(y2), "s"(y3));                                                                   \
     } while (0)
-// x + r d mod p in [0, p), for x, d in [0, p) and K = fold_consts(r) behind a wave-uniform pointer
-__device__ __forceinline__ Fr fr_fold_const(const Fr& x, const Fr& d, const u32* __restrict__ K) {
-    u64 C[8];
-    u32 T[8];
-#pragma unroll
-    for (int i = 0; i < 4; i++) { C[2 * i] = (u32)x.l[i]; C[2 * i + 1] = x.l[i] >> 32; T[2 * i] = 0; T[2 * i + 1] = 0; }
-    u32 dl[8];
-#pragma unroll
-    for (int i = 0; i < 4; i++) { dl[2 * i] = (u32)d.l[i]; dl[2 * i + 1] = (u32)(d.l[i] >> 32); }
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        BN_WIDE_ROW4S(C[0], C[1], C[2], C[3], T[0], T[1], T[2], T[3], dl[i], K[8 * i + 0], K[8 * i + 1], K[8 * i + 2], K[8 * i + 3]);
-        BN_WIDE_ROW4S(C[4], C[5], C[6], C[7], T[4], T[5], T[6], T[7], dl[i], K[8 * i + 4], K[8 * i + 5], K[8 * i + 6], K[8 * i + 7]);
-    }
-    // value = sum_k C[k] 2^(32 k) + sum_k T[k] 2^(32 k + 64) < 2^290: ten limbs
+// value = sum_k C[k] 2^(32 k) + sum_k T[k] 2^(32 k + 64) < 2^36 p  ->  value mod p in [0, p)
+__device__ __forceinline__ Fr wfold_finish(const u64* C, const u32* T) {
+    // ten limbs
     u32 L[10];
     WRun run;
     run.lo = 0; run.hi = 0;
@@ -234,6 +222,40 @@ __device__ __forceinline__ Fr fr_fold_const(const Fr& x, const Fr& d, const u32*
         r = fr_make(ge ? m.l[0] : r.l[0], ge ? m.l[1] : r.l[1], ge ? m.l[2] : r.l[2], ge ? m.l[3] : r.l[3]);
     }
     return r;
+}
+
+// a KA + v KV + t KT + add mod p for 32-bit integers a, v, t and residues KA, KV, KT, add in [0, p) given as eight 32-bit limbs each
+// behind wave-uniform pointers (K[0..7], K[8..15], K[16..23], K[24..31]): the multiset hash of the Lasso memory checking,
+// a + v gamma + t gamma^2 - tau, lands in Montgomery form directly when the constants are R, gamma R, gamma^2 R, p - tau R -
+// 24 multiply-adds and the short reduction instead of three short products and a Montgomery reduction.
+__device__ __forceinline__ Fr fr_lin3_const(u32 a, u32 v, u32 t, const u32* __restrict__ K) {
+    u64 C[8];
+    u32 T[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) { C[i] = K[24 + i]; T[i] = 0; }
+    BN_WIDE_ROW4S(C[0], C[1], C[2], C[3], T[0], T[1], T[2], T[3], a, K[0], K[1], K[2], K[3]);
+    BN_WIDE_ROW4S(C[4], C[5], C[6], C[7], T[4], T[5], T[6], T[7], a, K[4], K[5], K[6], K[7]);
+    BN_WIDE_ROW4S(C[0], C[1], C[2], C[3], T[0], T[1], T[2], T[3], v, K[8], K[9], K[10], K[11]);
+    BN_WIDE_ROW4S(C[4], C[5], C[6], C[7], T[4], T[5], T[6], T[7], v, K[12], K[13], K[14], K[15]);
+    BN_WIDE_ROW4S(C[0], C[1], C[2], C[3], T[0], T[1], T[2], T[3], t, K[16], K[17], K[18], K[19]);
+    BN_WIDE_ROW4S(C[4], C[5], C[6], C[7], T[4], T[5], T[6], T[7], t, K[20], K[21], K[22], K[23]);
+    return wfold_finish(C, T);
+}
+// x + r d mod p in [0, p), for x, d in [0, p) and K = fold_consts(r) behind a wave-uniform pointer
+__device__ __forceinline__ Fr fr_fold_const(const Fr& x, const Fr& d, const u32* __restrict__ K) {
+    u64 C[8];
+    u32 T[8];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { C[2 * i] = (u32)x.l[i]; C[2 * i + 1] = x.l[i] >> 32; T[2 * i] = 0; T[2 * i + 1] = 0; }
+    u32 dl[8];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { dl[2 * i] = (u32)d.l[i]; dl[2 * i + 1] = (u32)(d.l[i] >> 32); }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        BN_WIDE_ROW4S(C[0], C[1], C[2], C[3], T[0], T[1], T[2], T[3], dl[i], K[8 * i + 0], K[8 * i + 1], K[8 * i + 2], K[8 * i + 3]);
+        BN_WIDE_ROW4S(C[4], C[5], C[6], C[7], T[4], T[5], T[6], T[7], dl[i], K[8 * i + 4], K[8 * i + 5], K[8 * i + 6], K[8 * i + 7]);
+    }
+    return wfold_finish(C, T);
 }
 
 __device__ __forceinline__ Fr fr_mul_wide(const Fr& a, const Fr& b) {
