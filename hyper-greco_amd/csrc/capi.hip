@@ -592,6 +592,17 @@ int hg_verify(const hg_pk* pk, const hg_witness* w, const uint8_t* proof, size_t
     HG_CATCH(-1)
 }
 
+int hg_verify_device(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, const uint8_t* proof, size_t len) {
+    HG_TRY
+    if (!ctx || !pk || !w || !proof || !pk->ctx) throw Error("hg_verify_device: needs a device context and a device prover key");
+    check_witness(pk, w, "hg_verify_device");
+    std::string why = verify_proof_device(ctx, pk, w->w, proof, len);
+    if (why.empty()) return 0;
+    g_last_error = why;
+    return 1;
+    HG_CATCH(-1)
+}
+
 int hg_verify_bn254(const hg_pk* pk, const hg_witness* w, const uint8_t* proof, size_t len) {
     HG_TRY
     if (!pk || !w || !proof) throw Error("hg_verify_bn254: null argument");

@@ -170,6 +170,27 @@ HCircuit build_circuit(const Params& p, const LassoPlan& lp);
 std::vector<std::vector<u64>> circuit_evaluate(const HCircuit& c, const Params& p, const Witness& w);
 // BfvEncrypt::verify on the host; "" = accept, otherwise the rejection reason (verifier.cpp)
 std::string verify_proof(const Params& p, const LassoPlan& lp, const HCircuit& c, const Witness& w, const uint8_t* proof, size_t len, int mode = 0);
+// The verifier's table-sized work done elsewhere (verifier_dev.hip: on the device). Goldilocks, mode 0 only: every evaluation point
+// is a run of the fixed challenge chain, so a point is an offset into it. Every method DEFERS: it enqueues work and returns a
+// ticket; value(ticket) is valid after finish(). The walk itself (proof parsing, sum-check round checks, the Lasso scalar checks)
+// stays on the host and never waits for a ticket - checks that need one are evaluated after finish().
+struct VerifyBackend {
+    struct ClaimOffs { std::vector<size_t> point_off; size_t alpha_off = 0; bool unit = true; };   // alpha_off: chain offset of alpha_0 (claims > 1)
+    virtual ~VerifyBackend() {}
+    virtual void begin_node(int node, const ClaimOffs& cl) = 0;     // the node's combined eq table over its outputs
+    virtual int const_sum() = 0;                                     // sum over reps and constant gates of eqc c
+    virtual void set_x(size_t x_off) = 0;                            // eq table of the phase-1 / FFT point
+    virtual std::vector<int> lin_terms() = 0;                        // per input i: sum over its linear gates of c eqc[g] eqx[j] (-1: none)
+    virtual void set_y(size_t y_off, const std::vector<E2>& u) = 0;  // eq table of the phase-2 point; the phase-1 evaluations
+    virtual std::vector<int> mul_terms() = 0;                        // per input i1: sum over mul gates (.., i1) of u[i0] c eqc eqx[j0] eqy[j1] (-1: none)
+    virtual int fft_term() = 0;                                      // sum_x F_c(x) eqx(x), alphas and the inverse scale included
+    virtual void end_node() = 0;
+    virtual int mle_input(size_t k, size_t point_off, int nvars) = 0;   // input table k (chain_par! order) at a point
+    virtual int mle_ct0is(size_t point_off, int nvars) = 0;
+    virtual void finish() = 0;
+    virtual E2 value(int ticket) const = 0;
+};
+std::string verify_proof_with(VerifyBackend& dev, const Params& p, const LassoPlan& lp, const HCircuit& c, const uint8_t* proof, size_t len);
 // the same over bn256::Fr (F = E = Fr, 32-byte proof elements): the bn254 test family
 std::string verify_proof_bn254(const Params& p, const LassoPlan& lp, const HCircuit& c, const Witness& w, const uint8_t* proof, size_t len);
 void ntt_host(u64* a, int log2n, bool inverse);  // in place, natural order

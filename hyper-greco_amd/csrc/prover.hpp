@@ -205,6 +205,8 @@ void fold_device(hg_ctx* ctx, const u64* table_host, size_t nv, bool is_base, E2
 void ntt_device(hg_ctx* ctx, const u64* in_host, int log2n, bool inverse, size_t batch, u64* out_host);
 
 void hip_check(hipError_t e, const char* what);
+// BfvEncrypt::verify with the table-sized work on the device (verifier_dev.hip); "" = accepted, else the rejection reason
+std::string verify_proof_device(hg_ctx* ctx, const hg_pk* pk, const Witness& w, const uint8_t* proof, size_t len);
 void prove_cache_drop(hg_ctx* ctx);
 
 }  // namespace hg

@@ -165,21 +165,39 @@ template <class F> typename F::E horner(const std::vector<typename F::E>& c, typ
 
 template <class F> struct Verifier {
     typedef typename F::E E;
-    struct Claim { std::vector<E> point; E value; };
+    static constexpr size_t NOPOS = (size_t)-1;
+    struct Claim { std::vector<E> point; E value; size_t off = NOPOS; };   // off: the point as a run of the challenge chain (E units)
     ProofBytes bytes;
-    typename F::Chal ch;
+    struct CountingChal {   // the field's challenge source plus the number of E challenges squeezed so far
+        typename F::Chal c;
+        size_t n = 0;
+        E squeeze() { n++; return c.squeeze(); }
+        void absorb(E v) { c.absorb(v); }
+        void set_mode(int mode) { c.set_mode(mode); }
+    } ch;
     bool ext_memcheck = false;  // mode bit 1: gamma, tau stay in E (prover.rs:36-39 truncates them; README.md:108)
+    // the table-sized checks elsewhere (Goldilocks, mode 0): see VerifyBackend in host.hpp
+    VerifyBackend* dev = nullptr;
+    std::vector<std::function<void()>> deferred;   // checks that need a ticket: run after dev->finish()
+    std::function<E()> late_claim = nullptr;       // a late-bound term of the NEXT node's initial claim (the output evaluation)
     E read_e() { E v = F::read(bytes); ch.absorb(v); return v; }
     std::vector<E> read_es(size_t n) { std::vector<E> v(n); for (auto& x : v) x = read_e(); return v; }
     std::vector<E> squeeze_n(size_t n) { std::vector<E> v(n); for (auto& x : v) x = ch.squeeze(); return v; }
 
     // verify_sum_check: d+1 coefficients per round, 2 c0 + c1 + .. + cd == claim, claim <- p(r)
-    std::pair<E, std::vector<E>> sumcheck(int deg, int nvars, E claim) {
+    // `late` (optional): a term only known after dev->finish() that must be subtracted from the INITIAL claim - the first round's
+    // check is then deferred; every later claim is p(r) of a round polynomial read from the proof
+    std::pair<E, std::vector<E>> sumcheck(int deg, int nvars, E claim, std::function<E()> late = nullptr, size_t* point_off = nullptr) {
         std::vector<E> point;
+        if (point_off) *point_off = ch.n;
         for (int i = 0; i < nvars; i++) {
             std::vector<E> c = read_es(deg + 1);
             E s = F::add(c[0], c[0]);
             for (int k = 1; k <= deg; k++) s = F::add(s, c[k]);
+            if (i == 0 && late) {
+                const E known = claim;
+                deferred.push_back([s, known, late] { if (!F::eq(s, F::sub(known, late()))) throw Reject("InvalidSumCheck: round polynomial does not match the running claim"); });
+            } else
             if (!F::eq(s, claim)) throw Reject("InvalidSumCheck: round polynomial does not match the running claim");
             E r = ch.squeeze();
             claim = horner<F>(c, r);
@@ -241,6 +259,7 @@ template <class F> struct Verifier {
     }
 
     Claim lasso(const LassoPlan& lp) {  // lasso.rs:116-139
+        const size_t r_off = ch.n;
         std::vector<E> r = squeeze_n(lp.nu);
         E claimed = read_e();
         sumcheck(2, lp.nu, claimed);  // collation: final evaluation not checked by the reference either (lasso.rs:129-130)
@@ -268,7 +287,7 @@ template <class F> struct Verifier {
             }
             off += nm;
         }
-        return Claim{r, claimed};
+        return Claim{r, claimed, r_off};
     }
 
     static std::vector<E> combined_eq(const std::vector<Claim>& cl, const std::vector<E>& alpha) {
@@ -285,6 +304,74 @@ template <class F> struct Verifier {
             for (long long i = 0; i < ne; i++) eqc[i] = F::add(eqc[i], F::mul(t[i], aa));
         }
         return eqc;
+    }
+
+    static VerifyBackend::ClaimOffs claim_offs(const std::vector<Claim>& cl, size_t alpha_off) {
+        VerifyBackend::ClaimOffs o;
+        for (auto& c : cl) { if (c.off == NOPOS) throw Reject("verifier: a claim point is not a run of the challenge chain"); o.point_off.push_back(c.off); }
+        o.unit = cl.size() == 1; o.alpha_off = alpha_off;
+        return o;
+    }
+    // the same node checks with the table sums taken from the backend (tickets), the comparisons deferred
+    std::vector<std::vector<Claim>> vanilla_dev(int id, const HNode& n, const std::vector<Claim>& cl, const std::vector<E>& alpha, size_t alpha_off) {
+        const int nin = n.log2_sub_in + n.log2_reps;
+        VerifyBackend* D = dev;
+        D->begin_node(id, claim_offs(cl, alpha_off));
+        E claim = F::zero();
+        for (size_t a = 0; a < cl.size(); a++) claim = F::add(claim, F::mul(cl[a].value, alpha[a]));
+        std::function<E()> late1 = nullptr;
+        if (!n.w0.empty()) { const int t = D->const_sum(); late1 = [D, t] { return D->value(t); }; }
+        if (late_claim) {   // (subtracted from the claim like the constant sum)
+            const std::function<E()> a = late1, b = late_claim;
+            late1 = [a, b] { return a ? F::add(a(), b()) : b(); };
+        }
+        size_t x_off = 0;
+        auto r1 = sumcheck(2, nin, claim, late1, &x_off);
+        std::vector<E> u(n.arity, F::zero());
+        std::vector<std::vector<Claim>> sub(n.arity);
+        for (int i = 0; i < n.arity; i++) if (n.left_use[i]) { u[i] = read_e(); sub[i].push_back(Claim{r1.second, u[i], x_off}); }
+        D->set_x(x_off);
+        std::function<E()> lin = [] { return F::zero(); };
+        if (!n.lin.empty()) {
+            const std::vector<int> tk = D->lin_terms();
+            lin = [D, tk, u] { E s = F::zero(); for (size_t i = 0; i < tk.size(); i++) if (tk[i] >= 0) s = F::add(s, F::mul(u[i], D->value(tk[i]))); return s; };
+        }
+        if (n.mul.empty()) {
+            const E fin1 = r1.first;
+            deferred.push_back([fin1, lin] { if (!F::eq(fin1, lin())) throw Reject("vanilla node: final evaluation mismatch"); });
+            D->end_node();
+            return sub;
+        }
+        size_t y_off = 0;
+        auto r2 = sumcheck(2, nin, r1.first, n.lin.empty() ? std::function<E()>(nullptr) : lin, &y_off);
+        std::vector<E> w(n.arity, F::zero());
+        for (int i = 0; i < n.arity; i++) if (n.right_use[i]) { w[i] = read_e(); sub[i].push_back(Claim{r2.second, w[i], y_off}); }
+        std::vector<E2> u2(u.begin(), u.end());
+        D->set_y(y_off, u2);
+        const std::vector<int> tk = D->mul_terms();
+        const E fin2 = r2.first;
+        deferred.push_back([D, tk, w, fin2] {
+            E s = F::zero();
+            for (size_t i = 0; i < tk.size(); i++) if (tk[i] >= 0) s = F::add(s, F::mul(w[i], D->value(tk[i])));
+            if (!F::eq(fin2, s)) throw Reject("vanilla node: phase-2 final evaluation mismatch");
+        });
+        D->end_node();
+        return sub;
+    }
+    std::vector<std::vector<Claim>> fft_dev(int id, const HNode& n, const std::vector<Claim>& cl, const std::vector<E>& alpha, size_t alpha_off) {
+        VerifyBackend* D = dev;
+        D->begin_node(id, claim_offs(cl, alpha_off));
+        E claim = F::zero();
+        for (size_t a = 0; a < cl.size(); a++) claim = F::add(claim, F::mul(cl[a].value, alpha[a]));
+        size_t x_off = 0;
+        auto r = sumcheck(2, n.log2_size, claim, nullptr, &x_off);
+        const E u = read_e();
+        D->set_x(x_off);
+        const int t = D->fft_term();
+        const E fin = r.first;
+        deferred.push_back([D, t, u, fin] { if (!F::eq(fin, F::mul(u, D->value(t)))) throw Reject("fft node: final evaluation mismatch"); });
+        D->end_node();
+        return {{Claim{r.second, u, x_off}}};
     }
 
     std::vector<std::vector<Claim>> vanilla(const HNode& n, const std::vector<Claim>& cl, const std::vector<E>& alpha) {
@@ -387,7 +474,8 @@ static std::string verify_impl(const Params& p, const LassoPlan& lp, const HCirc
     typedef typename F::E E;
     typedef typename Verifier<F>::Claim Claim;
     try {
-        Verifier<F> V{ProofBytes{proof, len}, typename F::Chal{}};
+        Verifier<F> V;
+        V.bytes = ProofBytes{proof, len};
         V.ch.set_mode(mode);
         V.ext_memcheck = (mode & 2) != 0;
         double t_kind[3] = {0, 0, 0};
@@ -443,7 +531,68 @@ static std::string verify_impl(const Params& p, const LassoPlan& lp, const HCirc
     }
 }
 
+// The same walk with the table-sized sums taken from a backend (Goldilocks, mode 0): the host parses the proof, checks the round
+// polynomials and the Lasso scalars, and hands out tickets; the comparisons that need them run after dev.finish().
+static std::string verify_with_backend(VerifyBackend& dev, const Params& p, const LassoPlan& lp, const HCircuit& c, const uint8_t* proof, size_t len) {
+    typedef GlField F;
+    typedef F::E E;
+    typedef Verifier<F>::Claim Claim;
+    try {
+        Verifier<F> V;
+        V.bytes = ProofBytes{proof, len};
+        V.ch.set_mode(0);
+        V.dev = &dev;
+        VerifyBackend* D = &dev;
+        const size_t p_off = V.ch.n;
+        std::vector<E> point = V.squeeze_n(p.ct0is_log2());         // sk_encryption_circuit.rs:482
+        const int t_out = D->mle_ct0is(p_off, p.ct0is_log2());      // :495 - the value itself is only known after finish()
+        // the output claim's VALUE enters the sum node's running claim: late-bound like every other ticket
+        std::vector<std::vector<Claim>> claims(c.nodes.size());
+        claims[c.lasso_id].push_back(Claim{{}, F::zero(), V.ch.n});  // :500
+        claims[c.sum_id].push_back(Claim{point, F::zero(), p_off});
+        for (size_t q = c.topo.size(); q-- > 0;) {                  // verify_gkr :509-510
+            int id = c.topo[q];
+            const HNode& n = c.nodes[id];
+            if (n.kind == NK_INPUT) continue;
+            std::vector<Claim>& cl = claims[id];
+            if (cl.empty()) throw Reject("node without claim");
+            const size_t alpha_off = V.ch.n;
+            std::vector<E> alpha = cl.size() > 1 ? V.squeeze_n(cl.size()) : std::vector<E>{F::one()};
+            std::vector<std::vector<Claim>> sub;
+            if (id == c.sum_id) {
+                // claim = sum_a alpha_a value_a with value_0 = the output evaluation (a ticket): fold it into the node's first deferred
+                // check by running the node with value_0 = 0 and a late term -alpha_0 * value(t_out)
+                if (n.kind != NK_VANILLA) throw Reject("verifier: the output node is expected to be a Vanilla node");
+                const E a0 = alpha[0];
+                V.late_claim = [D, t_out, a0] { return F::sub(F::zero(), F::mul(a0, D->value(t_out))); };
+            }
+            if (n.kind == NK_VANILLA) sub = V.vanilla_dev(id, n, cl, alpha, alpha_off);
+            else if (n.kind == NK_FFT) sub = V.fft_dev(id, n, cl, alpha, alpha_off);
+            else sub = {{V.lasso(lp)}};
+            V.late_claim = nullptr;
+            for (size_t i = 0; i < n.preds.size(); i++) for (auto& s : sub[i]) claims[n.preds[i]].push_back(s);
+        }
+        // izip_eq!(inputs, input_claims): input.evaluate(point) == value (:512-516)
+        for (size_t k = 0; k < c.input_ids.size(); k++)
+            for (auto& cl : claims[c.input_ids[k]]) {
+                if (cl.off == Verifier<F>::NOPOS) throw Reject("verifier: an input claim point is not a run of the challenge chain");
+                const int t = D->mle_input(k, cl.off, (int)cl.point.size());
+                const E want = cl.value;
+                V.deferred.push_back([D, t, want, k] { if (!F::eq(D->value(t), want)) throw Reject("input claim mismatch at input " + std::to_string(k)); });
+            }
+        dev.finish();
+        for (auto& f : V.deferred) f();
+        return "";
+    } catch (const Reject& r) {
+        return r.what();
+    }
+}
+
 }  // namespace
+
+std::string verify_proof_with(VerifyBackend& dev, const Params& p, const LassoPlan& lp, const HCircuit& c, const uint8_t* proof, size_t len) {
+    return verify_with_backend(dev, p, lp, c, proof, len);
+}
 
 // return "" on accept, the rejection reason otherwise
 std::string verify_proof(const Params& p, const LassoPlan& lp, const HCircuit& c, const Witness& w, const uint8_t* proof, size_t len, int mode) {

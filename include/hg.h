@@ -120,6 +120,11 @@ int hg_prove(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, uint8_t* proof, 
  *   the multiset relation init * write == read * final between the two grand products are never checked, trailing bytes are
  *   ignored. hg_verify_mode(.., 3, ..) closes the first two. */
 int hg_verify(const hg_pk* pk, const hg_witness* w, const uint8_t* proof, size_t len);
+/* The same check with the table-sized work on the device [REF sk_encryption_circuit.rs:462-517; lasso/src/memory_checking/verifier.rs:
+ * 130-176]: the host parses the proof and checks the round polynomials and the Lasso scalars; the eq tables, the wiring-predicate
+ * sums of the Vanilla nodes, the DFT rows of the FFT nodes and the MLE evaluations of the public inputs run as kernels (one stream,
+ * one synchronisation). Same return values and the same accept / reject decisions as hg_verify; Goldilocks, mode 0. */
+int hg_verify_device(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, const uint8_t* proof, size_t len);
 
 /* The same pair in a protocol mode that FIXES the reference's two known soundness gaps. mode bits:
  *   1  absorbing transcript: write_felt / read_felt also hash the element - the rule of the in-tree plonkish-trait writer of

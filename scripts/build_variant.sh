@@ -10,7 +10,7 @@ out=$root/build/$name
 mkdir -p "$out"
 CXX="/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -fopenmp --offload-arch=gfx950 -Wall -Wno-unused-function -Wno-unused-result -Wno-sign-compare $flags"
 pids=()
-for f in kernels.hip prover.hip prover_seq.hip capi.hip bn254.hip comm.hip; do $CXX -c "$src/$f" -o "$out/${f%.hip}.o" & pids+=($!); done
+for f in kernels.hip prover.hip prover_seq.hip capi.hip bn254.hip comm.hip verifier_dev.hip; do $CXX -c "$src/$f" -o "$out/${f%.hip}.o" & pids+=($!); done
 for f in host.cpp verifier.cpp; do $CXX -x hip -c "$src/$f" -o "$out/${f%.cpp}.o" & pids+=($!); done
 for p in "${pids[@]}"; do wait $p; done
 /opt/rocm/bin/hipcc -shared -fopenmp --offload-arch=gfx950 -o "$out/libhypergreco.so" "$out"/*.o -ldl

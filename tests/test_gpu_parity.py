@@ -631,6 +631,40 @@ def test_environment_switches_at_the_headline_size(switch):
     assert r.returncode == 0 and "SWITCH OK" in r.stdout, (switch, r.stdout[-500:], r.stderr[-2000:])
 
 
+@pytest.mark.parametrize("n,k", [(1024, 1), (4096, 2), (32768, 16)])
+def test_device_verifier_agrees_with_the_host_verifier(ctx, n, k):
+    """hg_verify_device (table-sized checks as kernels) against hg_verify (host) and the oracle's verifier: the HIP proof is accepted by all
+    three; a byte flipped anywhere in the proof gets the same accept / reject decision from the device and the host verifier (the
+    reference's verifier does not bind every byte - the collation sum-check's final evaluation, trailing bytes - so some flips are
+    accepted by both); a proof for another witness is rejected."""
+    import time
+    bfv = hg.BfvEncrypt.new(n, k)
+    pk = bfv.setup(ctx)
+    w, w2 = hg.Witness.synthetic(bfv.params, 0xabc + n), hg.Witness.synthetic(bfv.params, 0xabd + n)
+    proof, _ = bfv.prove(ctx, pk, w)
+    ok, why = hg.verify_device(ctx, pk, w, proof)
+    assert ok, why
+    assert hg.verify(pk, w, proof) == (True, "")
+    t0 = time.perf_counter(); hg.verify_device(ctx, pk, w, proof); t_dev = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter(); hg.verify(pk, w, proof); t_host = (time.perf_counter() - t0) * 1e3
+    print("n=%d k=%d: hg_verify_device %.1f ms, hg_verify (host) %.1f ms" % (n, k, t_dev, t_host))
+    ok2, _ = hg.verify_device(ctx, pk, w2, proof)
+    assert not ok2 and not hg.verify(pk, w2, proof)[0]
+    rng = random.Random(n)
+    positions = [0, 8, len(proof) // 5, len(proof) // 3, len(proof) // 2, 2 * len(proof) // 3, len(proof) - 40, len(proof) - 1]
+    positions += [rng.randrange(len(proof)) for _ in range(6 if n < 32768 else 2)]
+    rejected = 0
+    for pos in positions:
+        bad = bytearray(proof)
+        bad[pos] ^= 1 << rng.randrange(8)
+        dh, dd = hg.verify(pk, w, bytes(bad))[0], hg.verify_device(ctx, pk, w, bytes(bad))[0]
+        assert dh == dd, (pos, dh, dd)
+        rejected += not dd
+    assert rejected >= len(positions) // 2
+    assert not hg.verify_device(ctx, pk, w, proof[:len(proof) // 2])[0]      # truncated
+    pk.free()
+
+
 def test_library_collective_single_rank_communicator(ctx):
     """hg_comm_init / hg_prove_sharded with a one-rank RCCL communicator (the only size a one-GPU box offers): the limb-split
     kernel, ncclAllReduce on the prover stream and the fold-back kernel run for real and must leave the proof unchanged."""
