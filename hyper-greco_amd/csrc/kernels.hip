@@ -6,7 +6,6 @@
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <algorithm>
-#include <rocprim/rocprim.hpp>
 #include <stdexcept>
 #include <string>
 #include <type_traits>
@@ -1409,17 +1408,6 @@ void lasso_split(hipStream_t st, const LassoDev& L, const u64* input, u64* dims,
     k_lasso_split<<<(unsigned)std::min<size_t>((N + TPB - 1) / TPB, 4096), TPB, 0, st>>>(L, input, dims, e_polys, rows, P, colpow ? col : nullptr);
 }
 
-// keys/rows of the rows that touch counter memory m, compacted: position q -> row (segment list in LassoDev)
-__global__ __launch_bounds__(TPB) void k_counter_keys(LassoDev L, int m, const u64* __restrict__ dim, u32* __restrict__ keys,
-                                                      u32* __restrict__ rows) {
-    const size_t cnt = (size_t)L.cnt_nsegs[m] << L.seg_shift;
-    const size_t smask = ((size_t)1 << L.seg_shift) - 1;
-    for (size_t q = (size_t)blockIdx.x * TPB + threadIdx.x; q < cnt; q += (size_t)gridDim.x * TPB) {
-        size_t row = ((size_t)L.cnt_segs[m][q >> L.seg_shift] << L.seg_shift) | (q & smask);
-        keys[q] = (u32)dim[row];
-        rows[q] = (u32)row;
-    }
-}
 __global__ __launch_bounds__(TPB) void k_counter_starts(const u32* __restrict__ ks, size_t n, u32* __restrict__ starts) {
     for (size_t p = (size_t)blockIdx.x * TPB + threadIdx.x; p < n; p += (size_t)gridDim.x * TPB) {
         u32 key = ks[p];
@@ -1436,16 +1424,148 @@ __global__ __launch_bounds__(TPB) void k_counter_ranks(const u32* __restrict__ k
         if (p + 1 == n || ks[p + 1] != key) final_cts[key] = (u64)rank + 1;
     }
 }
-constexpr unsigned COUNTER_KEY_BITS = 16;  // subtable addresses are 16-bit limbs: the one bit range of the size query and of the sort
+// ---- stable radix sort of (key, value) pairs on keys of at most 18 bits -------------------------------------------------------------
+// What the counters need (polynomialize, lasso.rs:170-204, is a sequential scan per memory: read_cts[j] = how many EARLIER rows hit
+// the same address): sort the (address, row) pairs by address, rows of one address staying in row order; a row's rank is then its
+// position in the address's run. Addresses are 16-bit limbs (18 bits with the chunk index), so two passes over 9-bit digits do it.
+// One pass = three launches:
+//   k_cs_hist     every WAVE owns a tile of 1024 consecutive pairs and counts its digits (LDS atomics) -> hist[digit][tile]
+//                 (the first pass also produces the pairs themselves from the limb tables: Gen)
+//   k_cs_scan     one workgroup per digit: exclusive scan of its row of hist (the tiles in order) in place, the digit's total
+//   k_cs_scatter  every wave re-reads its tile 64 pairs at a time, in order: a pair's destination is
+//                 base(digit) + scanned hist[digit][tile] + (pairs of the same digit seen earlier in this tile); the lanes of one step
+//                 rank themselves with nine ballots (the mask of lanes holding the same digit, its population count below the lane).
+// Stable by construction: tiles in order (the scan), steps in order, lanes in order. Replaces rocprim::radix_sort_pairs (14 launches
+// for the 18-bit keys of all four chunks, 160 us) with 6 launches.
+constexpr int CS_BITS = 9, CS_BINS = 1 << CS_BITS, CS_WTILE = 1024, CS_WAVES = 4;
+struct CsGenNone { __device__ __forceinline__ void operator()(size_t, u32&, u32&) const {} };
+// Gen(q, key, val): produces pair q (first pass) - or nothing (CsGenNone: the pairs are read from keys_in / vals_in)
+template <bool GEN, typename Gen>
+__global__ __launch_bounds__(64 * CS_WAVES) void k_cs_hist(const u32* __restrict__ keys_in, u32* __restrict__ keys_gen, u32* __restrict__ vals_gen, size_t n, int sh,
+                                                          u32* __restrict__ hist, size_t nwt, Gen gen) {
+    __shared__ u32 cnt[CS_WAVES][CS_BINS];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t wt = (size_t)blockIdx.x * CS_WAVES + wave;
+    for (int d = lane; d < CS_BINS; d += 64) cnt[wave][d] = 0;
+    __builtin_amdgcn_wave_barrier();
+    if (wt < nwt) {
+        const size_t i0 = wt * CS_WTILE;
+        for (int r = 0; r < CS_WTILE / 64; r++) {
+            const size_t i = i0 + (size_t)r * 64 + lane;
+            if (i < n) {
+                u32 key, val = 0;
+                if (GEN) { gen(i, key, val); keys_gen[i] = key; vals_gen[i] = val; }
+                else key = keys_in[i];
+                atomicAdd(&cnt[wave][(key >> sh) & (CS_BINS - 1)], 1u);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int d = lane; d < CS_BINS; d += 64) hist[(size_t)d * nwt + wt] = cnt[wave][d];
+    }
+}
+__global__ __launch_bounds__(256) void k_cs_scan(u32* __restrict__ hist, size_t nwt, u32* __restrict__ totals) {
+    __shared__ u32 part[256];
+    u32* row = hist + (size_t)blockIdx.x * nwt;
+    const size_t per = (nwt + 255) / 256, b = (size_t)threadIdx.x * per, e = b + per < nwt ? b + per : nwt;
+    u32 s = 0;
+    for (size_t i = b; i < e; i++) s += row[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {   // inclusive scan of the 256 chunk sums
+        const u32 v = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    u32 run = threadIdx.x ? part[threadIdx.x - 1] : 0;
+    for (size_t i = b; i < e; i++) { const u32 v = row[i]; row[i] = run; run += v; }
+    if (threadIdx.x == 255) totals[blockIdx.x] = part[255];
+}
+__global__ __launch_bounds__(64 * CS_WAVES) void k_cs_scatter(const u32* __restrict__ keys_in, const u32* __restrict__ vals_in, u32* __restrict__ keys_out,
+                                                             u32* __restrict__ vals_out, size_t n, int sh, const u32* __restrict__ hist,
+                                                             const u32* __restrict__ totals, size_t nwt) {
+    __shared__ u32 base[CS_BINS];
+    __shared__ u32 off[CS_WAVES][CS_BINS];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // base[d] = pairs with a smaller digit: exclusive scan of the 512 totals (two per thread)
+    {
+        const u32 a = totals[2 * threadIdx.x], b = totals[2 * threadIdx.x + 1];
+        base[threadIdx.x] = a + b;   // (slots 0..255 used as scan scratch first)
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            const u32 v = (int)threadIdx.x >= o ? base[threadIdx.x - o] : 0;
+            __syncthreads();
+            base[threadIdx.x] += v;
+            __syncthreads();
+        }
+        const u32 excl = threadIdx.x ? base[threadIdx.x - 1] : 0;
+        __syncthreads();
+        base[2 * threadIdx.x] = excl;
+        base[2 * threadIdx.x + 1] = excl + a;
+        __syncthreads();
+    }
+    const size_t wt = (size_t)blockIdx.x * CS_WAVES + wave;
+    if (wt >= nwt) return;
+    for (int d = lane; d < CS_BINS; d += 64) off[wave][d] = base[d] + hist[(size_t)d * nwt + wt];
+    __builtin_amdgcn_wave_barrier();
+    const size_t i0 = wt * CS_WTILE;
+    const unsigned long long lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
+    for (int r = 0; r < CS_WTILE / 64; r++) {
+        const size_t i = i0 + (size_t)r * 64 + lane;
+        const bool valid = i < n;
+        const u32 key = valid ? keys_in[i] : 0, val = valid ? vals_in[i] : 0;
+        const u32 d = (key >> sh) & (CS_BINS - 1);
+        unsigned long long m = __ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < CS_BITS; bit++) {
+            const bool on = (d >> bit) & 1;
+            const unsigned long long bal = __ballot(valid && on);
+            m &= on ? bal : ~bal;
+        }
+        if (valid) {
+            const u32 rank = (u32)__popcll(m & lt);
+            const u32 pos = off[wave][d] + rank;
+            keys_out[pos] = key;
+            vals_out[pos] = val;
+        }
+        __builtin_amdgcn_wave_barrier();   // every lane has read off[] before the leaders move it
+        if (valid && (m & lt) == 0) off[wave][d] += (u32)__popcll(m);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+static size_t cs_tiles(size_t n) { return (n + CS_WTILE - 1) / CS_WTILE; }
+static size_t cs_temp_bytes(size_t n) { return (cs_tiles(std::max<size_t>(n, 1)) * CS_BINS + CS_BINS) * sizeof(u32); }
+// sorts n pairs by the low `bits` (<= 18) bits of the key, stably. First pass: pairs generated by `gen` into (keys, vals); result in
+// (keys, vals) again - (keys2, vals2) is the ping-pong buffer.
+template <typename Gen>
+static void cs_sort_pairs(hipStream_t st, void* temp, size_t temp_bytes, u32* keys, u32* keys2, u32* vals, u32* vals2, size_t n, Gen gen) {
+    if (n == 0) return;
+    if (temp_bytes < cs_temp_bytes(n)) throw std::runtime_error("counter sort: scratch too small");
+    const size_t nwt = cs_tiles(n);
+    u32* hist = static_cast<u32*>(temp);
+    u32* totals = hist + nwt * CS_BINS;
+    const unsigned grid = (unsigned)((nwt + CS_WAVES - 1) / CS_WAVES);
+    k_cs_hist<true, Gen><<<grid, 64 * CS_WAVES, 0, st>>>(nullptr, keys, vals, n, 0, hist, nwt, gen);
+    k_cs_scan<<<CS_BINS, 256, 0, st>>>(hist, nwt, totals);
+    k_cs_scatter<<<grid, 64 * CS_WAVES, 0, st>>>(keys, vals, keys2, vals2, n, 0, hist, totals, nwt);
+    k_cs_hist<false, CsGenNone><<<grid, 64 * CS_WAVES, 0, st>>>(keys2, nullptr, nullptr, n, CS_BITS, hist, nwt, CsGenNone());
+    k_cs_scan<<<CS_BINS, 256, 0, st>>>(hist, nwt, totals);
+    k_cs_scatter<<<grid, 64 * CS_WAVES, 0, st>>>(keys2, vals2, keys, vals, n, CS_BITS, hist, totals, nwt);
+}
+
 static void check_hip(hipError_t e, const char* what) {
     if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
 }
-size_t lasso_counter_temp_bytes(size_t n) {
-    size_t bytes = 0;
-    check_hip(rocprim::radix_sort_pairs(nullptr, bytes, (u32*)nullptr, (u32*)nullptr, (u32*)nullptr, (u32*)nullptr, n, 0, COUNTER_KEY_BITS),
-              "radix_sort_pairs(size query)");
-    return bytes;
-}
+size_t lasso_counter_temp_bytes(size_t n) { return cs_temp_bytes(n); }
+struct CsGenChunk {   // pair q of one counter memory: (address, row) of the q-th row that touches it (segment list in LassoDev)
+    LassoDev L; int m; const u64* dim;
+    __device__ __forceinline__ void operator()(size_t q, u32& key, u32& val) const {
+        const size_t smask = ((size_t)1 << L.seg_shift) - 1;
+        const size_t row = ((size_t)L.cnt_segs[m][q >> L.seg_shift] << L.seg_shift) | (q & smask);
+        key = (u32)dim[row];
+        val = (u32)row;
+    }
+};
 void lasso_counters(hipStream_t st, const LassoDev& L, int m, const u64* dims, u64* read_ts, u64* final_cts, void* temp,
                     size_t temp_bytes, u32* keys, u32* keys_sorted, u32* rows_in, u32* rows_sorted, u32* starts) {
     const size_t N = (size_t)1 << L.nu;
@@ -1454,12 +1574,10 @@ void lasso_counters(hipStream_t st, const LassoDev& L, int m, const u64* dims, u
     const size_t cnt = (size_t)L.cnt_nsegs[m] << L.seg_shift;  // rows whose lookup type uses memory m (lasso.rs:181-183)
     if (cnt == 0) return;
     int grid = grid_for(cnt);
-    k_counter_keys<<<grid, TPB, 0, st>>>(L, m, dims + (size_t)L.mem_dim[m] * N, keys, rows_in);
-    // stable LSD radix sort on the 16-bit address keeps the rows of one address in row order
-    check_hip(rocprim::radix_sort_pairs(temp, temp_bytes, keys, keys_sorted, rows_in, rows_sorted, cnt, 0, COUNTER_KEY_BITS, st),
-              "radix_sort_pairs(counter keys)");
-    k_counter_starts<<<grid, TPB, 0, st>>>(keys_sorted, cnt, starts);
-    k_counter_ranks<<<grid, TPB, 0, st>>>(keys_sorted, rows_sorted, cnt, starts, read_ts, final_cts);
+    // stable sort on the 16-bit address keeps the rows of one address in row order (the pairs are produced by the first pass)
+    cs_sort_pairs(st, temp, temp_bytes, keys, keys_sorted, rows_in, rows_sorted, cnt, CsGenChunk{L, m, dims + (size_t)L.mem_dim[m] * N});
+    k_counter_starts<<<grid, TPB, 0, st>>>(keys, cnt, starts);
+    k_counter_ranks<<<grid, TPB, 0, st>>>(keys, rows_in, cnt, starts, read_ts, final_cts);
 }
 
 // ---- all counter memories in one sort -------------------------------------------------------------------------------------
@@ -1476,26 +1594,21 @@ static CounterPlan counter_plan(const LassoDev& L, unsigned chunk_mask) {
     return P;
 }
 size_t lasso_counters_all_elems(const LassoDev& L, unsigned chunk_mask) { CounterPlan P = counter_plan(L, chunk_mask); return P.off[P.nchunks]; }
-constexpr unsigned COUNTER_ALL_KEY_BITS = 18;  // chunk (2 bits) | 16-bit address
-size_t lasso_counters_all_temp_bytes(size_t n_elems) {
-    size_t bytes = 0;
-    check_hip(rocprim::radix_sort_pairs(nullptr, bytes, (u32*)nullptr, (u32*)nullptr, (u32*)nullptr, (u32*)nullptr, std::max<size_t>(n_elems, 1), 0,
-                                        COUNTER_ALL_KEY_BITS), "radix_sort_pairs(size query)");
-    return bytes;
-}
-__global__ __launch_bounds__(TPB) void k_counter_keys_all(LassoDev L, CounterPlan P, const u64* __restrict__ dims, u32* __restrict__ keys, u32* __restrict__ vals) {
-    const size_t N = (size_t)1 << L.nu, total = P.off[P.nchunks];
-    const size_t smask = ((size_t)1 << L.seg_shift) - 1;
-    for (size_t q = (size_t)blockIdx.x * TPB + threadIdx.x; q < total; q += (size_t)gridDim.x * TPB) {
+size_t lasso_counters_all_temp_bytes(size_t n_elems) { return cs_temp_bytes(n_elems); }
+struct CsGenAll {   // pair q of the concatenated chunks: ((chunk, address), row); rows ascend inside a chunk and the sort is stable
+    LassoDev L; CounterPlan P; const u64* dims;
+    __device__ __forceinline__ void operator()(size_t q, u32& key, u32& val) const {
+        const size_t N = (size_t)1 << L.nu;
+        const size_t smask = ((size_t)1 << L.seg_shift) - 1;
         int s = 0;
         while (s + 1 < P.nchunks && q >= P.off[s + 1]) s++;
         const int c = P.chunk[s];
         const size_t local = q - P.off[s];
         const size_t row = ((size_t)L.cnt_segs[c][local >> L.seg_shift] << L.seg_shift) | (local & smask);
-        keys[q] = ((u32)c << 16) | (u32)dims[(size_t)L.mem_dim[c] * N + row];
-        vals[q] = (u32)row;   // rows are listed in ascending order inside a chunk and the sort is stable: rank = position in the key's run
+        key = ((u32)c << 16) | (u32)dims[(size_t)L.mem_dim[c] * N + row];
+        val = (u32)row;
     }
-}
+};
 __global__ __launch_bounds__(TPB) void k_counter_ranks_all(const u32* __restrict__ ks, const u32* __restrict__ vs, size_t n, const u32* __restrict__ starts,
                                                            CounterOut out) {
     for (size_t p = (size_t)blockIdx.x * TPB + threadIdx.x; p < n; p += (size_t)gridDim.x * TPB) {
@@ -1525,11 +1638,10 @@ void lasso_counters_all(hipStream_t st, const LassoDev& L, unsigned chunk_mask, 
     const size_t total = P.off[P.nchunks];
     if (total == 0) return;
     const int grid = grid_for(total);
-    k_counter_keys_all<<<grid, TPB, 0, st>>>(L, P, dims, keys, vals);
-    // stable LSD radix sort on (chunk, address) keeps the rows of one address of one chunk in row order
-    check_hip(rocprim::radix_sort_pairs(temp, temp_bytes, keys, keys_sorted, vals, vals_sorted, total, 0, COUNTER_ALL_KEY_BITS, st), "radix_sort_pairs(counter keys)");
-    k_counter_starts<<<grid, TPB, 0, st>>>(keys_sorted, total, starts);
-    k_counter_ranks_all<<<grid, TPB, 0, st>>>(keys_sorted, vals_sorted, total, starts, out);
+    // stable sort on (chunk, address) keeps the rows of one address of one chunk in row order
+    cs_sort_pairs(st, temp, temp_bytes, keys, keys_sorted, vals, vals_sorted, total, CsGenAll{L, P, dims});
+    k_counter_starts<<<grid, TPB, 0, st>>>(keys, total, starts);
+    k_counter_ranks_all<<<grid, TPB, 0, st>>>(keys, vals, total, starts, out);
 }
 
 __global__ __launch_bounds__(TPB) void k_lasso_claim(LassoDev L, const E2* __restrict__ eq, const u64* __restrict__ e_polys, EpRows R,
