@@ -307,15 +307,15 @@ __global__ void k_bn_weight_rows(const Fr* __restrict__ rows, size_t row_len, co
 }
 // mirrored top layer: the weighted left halves of the READ rows (as k_bn_weight_rows) and, in the same pass, the linear table
 // S[i] = sum_b pw[b] (l_b[i] + r_b[i]) over the read rows b < nb (r_b = the right half of row b, in place at rows + h)
-__global__ __launch_bounds__(256) void k_bn_weight_rows_sum(const Fr* __restrict__ rows, size_t row_len, const Fr* __restrict__ pw, Fr* __restrict__ out,
-                                                          Fr* __restrict__ S, size_t h, int nb) {
+__global__ __launch_bounds__(256) void k_bn_weight_rows_sum(const Fr* __restrict__ rows, size_t row_len, const Fr* __restrict__ pw, const FoldK* __restrict__ fk,
+                                                          Fr* __restrict__ out, Fr* __restrict__ S, size_t h, int nb) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= h) return;
     Fr acc = fr_zero();
     WCol c = wcol_zero();
     for (int b = 0; b < nb; b++) {
         const Fr x = rows[(size_t)b * row_len + i];
-        const Fr lw = b == 0 ? x : fr_mul_wide(pw[b], x);
+        const Fr lw = b == 0 ? x : fr_fold_const(fr_zero(), x, fk[b].k);   // (b is the loop index: uniform over the wave)
         out[(size_t)b * h + i] = lw;
         acc = fr_add(acc, lw);
         wcol_mac(c, pw[b], rows[(size_t)b * row_len + h + i]);
@@ -622,24 +622,45 @@ __global__ void k_bn_prod_level(const Fr* __restrict__ in, size_t in_len, Fr* __
     out[b * h + j] = v;
     if (lw && j < (h >> 1)) lw[b * (h >> 1) + j] = b == 0 ? v : fr_mul_wide(pw[b], v);
 }
+// the same with the row index on grid.y (uniform per workgroup), so that the weight of row b is a LAUNCH-WIDE constant of the
+// workgroup: lw = pw[b] * v runs through fr_fold_const with the row's precomputed constants fk[b] (k_bn_fold_consts)
+__global__ void k_bn_prod_level_rows(const Fr* __restrict__ in, size_t in_len, Fr* __restrict__ out, const FoldK* __restrict__ fk, Fr* __restrict__ lw) {
+    const size_t h = in_len >> 1, b = blockIdx.y;
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= h) return;
+    const Fr v = fr_mul_wide(in[b * in_len + j], in[b * in_len + j + h]);
+    out[b * h + j] = v;
+    if (j < (h >> 1)) lw[b * (h >> 1) + j] = b == 0 ? v : fr_fold_const(fr_zero(), v, fk[b].k);
+}
+// fk[e] = fold_consts(pw[e]) for a run of weights (one thread per (weight, limb row))
+__global__ void k_bn_fold_consts(const Fr* __restrict__ pw, FoldK* __restrict__ fk, size_t count) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count * 8) return;
+    const size_t e = t >> 3;
+    const int i = (int)(t & 7);
+    Fr x = fr_make(0, 0, 0, 0);
+    x.l[i >> 1] = 1ULL << (32 * (i & 1));
+    const Fr ki = fr_mul_wide(pw[e], x);
+    for (int q = 0; q < 4; q++) { fk[e].k[8 * i + 2 * q] = (u32)ki.l[q]; fk[e].k[8 * i + 2 * q + 1] = (u32)(ki.l[q] >> 32); }
+}
 // level 1 of a mirrored product: `in` holds the nb/2 READ rows only; row b >= nb/2 of the output is the product of the read row
 // b - nb/2 shifted by c (the write rows are never materialised)
-__global__ void k_bn_prod_level_mirror(const Fr* __restrict__ in, size_t in_len, Fr* __restrict__ out, int nb, Fr c, Fr c2, FoldK kc, const Fr* __restrict__ pw = nullptr,
+__global__ void k_bn_prod_level_mirror(const Fr* __restrict__ in, size_t in_len, Fr* __restrict__ out, int nb, Fr c, Fr c2, FoldK kc, const FoldK* __restrict__ fk = nullptr,
                                        Fr* __restrict__ lw = nullptr) {
-    // one thread per entry of a READ row: its product x y is the read row's level-1 entry, and the write row's entry is
-    // (x + c)(y + c) = x y + c (x + y) + c^2 - the multiplication by the launch-wide c goes through fr_fold_const (kc = fold_consts(c))
-    const size_t h = in_len >> 1, half = (size_t)nb / 2, total = h * half;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const size_t b = i >> (__ffsll((long long)h) - 1), j = i & (h - 1);
+    // one thread per entry of a READ row (row index on grid.y): its product x y is the read row's level-1 entry, and the write row's
+    // entry is (x + c)(y + c) = x y + c (x + y) + c^2 - the multiplication by the launch-wide c goes through fr_fold_const (kc =
+    // fold_consts(c)), and so do the rows' weights (fk[b], fk[b + nb/2])
+    const size_t h = in_len >> 1, half = (size_t)nb / 2, b = blockIdx.y;
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= h) return;
     const Fr x = in[b * in_len + j], y = in[b * in_len + j + h];
     const Fr v = fr_mul_wide(x, y);
     const Fr vw = fr_add(v, fr_fold_const(c2, fr_add(x, y), kc.k));
     out[b * h + j] = v;
     out[(b + half) * h + j] = vw;
     if (lw && j < (h >> 1)) {
-        lw[b * (h >> 1) + j] = b == 0 ? v : fr_mul_wide(pw[b], v);
-        lw[(b + half) * (h >> 1) + j] = fr_mul_wide(pw[b + half], vw);
+        lw[b * (h >> 1) + j] = b == 0 ? v : fr_fold_const(fr_zero(), v, fk[b].k);
+        lw[(b + half) * (h >> 1) + j] = fr_fold_const(fr_zero(), vw, fk[b + half].k);
     }
 }
 static void write_be32(std::vector<uint8_t>& out, const Fr& canonical) {  // transcript.rs:183-189: repr, byte-reversed
@@ -789,7 +810,11 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
                 if ((h >> (rd + 1)) <= (size_t)BN_TAIL_HALF && n - rd <= BN_TAIL_ROUNDS) { P.nmain = rd; break; }
             max_main = std::max(max_main, P.nmain);
         }
-        if (nv > 1) k_bn_gamma_powers<<<dim3((unsigned)((nb + 255) / 256), nv), 256, 0, st>>>(pw_all, gammas, (int)nb);
+        FoldK* fk_all = static_cast<FoldK*>(ctx->alloc((size_t)nv * nb * sizeof(FoldK)));   // fold_consts of every weight gamma_n^b
+        if (nv > 1) {
+            k_bn_gamma_powers<<<dim3((unsigned)((nb + 255) / 256), nv), 256, 0, st>>>(pw_all, gammas, (int)nb);
+            k_bn_fold_consts<<<(unsigned)(((size_t)nv * nb * 8 + 255) / 256), 256, 0, st>>>(pw_all, fk_all, (size_t)nv * nb);
+        }
         // the product tree; level k (rows of length len >> k) is read by layer n = nv - 1 - k, whose weighted left halves are written
         // in the same pass (level 0, the input, gets its own pass below)
         for (int k = 1; k < nv; k++) {
@@ -801,7 +826,13 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
             if (k == 1 && mirror_c) {   // level 0: read rows only
                 FoldK kc;
                 fold_consts(*mirror_c, &kc);
-                k_bn_prod_level_mirror<<<(unsigned)((total / 2 + 255) / 256), 256, 0, st>>>(lev[0], len, lk, (int)nb, *mirror_c, fr_mul(*mirror_c, *mirror_c), kc, pw_n, lw_n);
+                const size_t hh = len >> 1;
+                k_bn_prod_level_mirror<<<dim3((unsigned)((hh + 255) / 256), (unsigned)(nb / 2)), 256, 0, st>>>(lev[0], len, lk, (int)nb, *mirror_c, fr_mul(*mirror_c, *mirror_c), kc,
+                                                                                                      n >= 1 ? fk_all + (size_t)n * nb : nullptr, lw_n);
+            }
+            else if (lw_n && (len >> k) >= 256) {   // long rows: the row index on grid.y, the row's weight as a launch-wide constant
+                const size_t hh = len >> k;
+                k_bn_prod_level_rows<<<dim3((unsigned)((hh + 255) / 256), (unsigned)nb), 256, 0, st>>>(lev[k - 1], len >> (k - 1), lk, fk_all + (size_t)n * nb, lw_n);
             }
             else k_bn_prod_level<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(lev[k - 1], len >> (k - 1), lk, (int)nb, pw_n, lw_n);
             lev[k] = lk;
@@ -816,7 +847,7 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
         if (nv > 1) {   // the top layer reads level 0
             const int n = nv - 1;
             const size_t h = (size_t)1 << n;
-            if (plan[n].mirror) k_bn_weight_rows_sum<<<(unsigned)((h + 255) / 256), 256, 0, st>>>(lev[0], 2 * h, plan[n].d_pw, plan[n].lw, plan[n].S, h, (int)G2);
+            if (plan[n].mirror) k_bn_weight_rows_sum<<<(unsigned)((h + 255) / 256), 256, 0, st>>>(lev[0], 2 * h, plan[n].d_pw, fk_all + (size_t)n * nb, plan[n].lw, plan[n].S, h, (int)G2);
             else k_bn_weight_rows<<<(unsigned)((nb * h + 255) / 256), 256, 0, st>>>(lev[0], 2 * h, plan[n].d_pw, plan[n].lw, h, (int)nb);
         }
         GpLaunchSet own;
