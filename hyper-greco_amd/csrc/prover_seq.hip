@@ -200,11 +200,20 @@ __device__ __forceinline__ void sq_mail_epilogue(const SqJob& J, int rd, const E
     }
     Mail* m = J.mail;
     const unsigned long long seq = J.seq0 + (unsigned long long)rd;
+    // The sums were written by THIS thread with system-scope atomic stores (written through, across PCIe in order): their completion
+    // (vmcnt) is all the post must be ordered after. A formal release would write back the whole L2 - the folded tables this kernel
+    // has just written for the NEXT kernel, which the kernel boundary orders anyway - and an acquire load in the poll loop would
+    // invalidate it on every iteration. gfx942 / gfx950 only (stores tracked by vmcnt), like the ticket above.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
     __hip_atomic_store(&m->gpu_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+#else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(&m->gpu_seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
     const long long t0 = wall_clock64();
-    while (__hip_atomic_load(&m->cpu_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+    while (__hip_atomic_load(&m->cpu_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {   // (the answer is read with system-scope atomic loads below)
         if (wall_clock64() - t0 > 500000000ll) { __hip_atomic_fetch_add(&m->timeouts, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
-        __builtin_amdgcn_s_sleep(4);
+        __builtin_amdgcn_s_sleep(2);
     }
     E2 r;
     r.c0 = __hip_atomic_load(&m->chal[0].c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

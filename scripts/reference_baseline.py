@@ -31,6 +31,12 @@ def measure(n, k, seed, runs=3, timeout_s=1800):
         return None
     bits = BITS[(n, k)]
     fixture = os.path.join(repo, "bfv-gkr", "src", "data", "goldilocks", f"sk_enc_{n}_{k}x{bits}_65537.json")
+    # The reference test reads its witness from this fixed path. A shipped fixture is never lost: it is moved aside first and put
+    # back whatever happens (a half-written file included); a fixture that did not exist (the n = 16384 / 32768 blobs) is removed again.
+    backup = fixture + ".hg-backup"
+    if os.path.exists(backup):
+        return None   # (an earlier run died between the two renames: do not touch anything, a human should look)
+    had_fixture = os.path.exists(fixture)
     try:
         sys.path.insert(0, os.path.join(ROOT, "scripts"))
         import witness_to_json
@@ -39,7 +45,10 @@ def measure(n, k, seed, runs=3, timeout_s=1800):
         hg = entry.load_package()
         import json
         w = hg.Witness.synthetic(hg.params_builtin(n, k), seed)
-        json.dump(witness_to_json.arrays_to_args(n, k, w.arrays()), open(fixture, "w"))
+        if had_fixture:
+            os.replace(fixture, backup)
+        with open(fixture, "w") as f:
+            json.dump(witness_to_json.arrays_to_args(n, k, w.arrays()), f)
         test = f"test_sk_enc_valid_goldilocks_{n}_{k}x{bits}_65537"
         cmd = ["cargo", "test", "-r", "-p", "bfv-gkr", test, "--", "--nocapture"]
         times = []
@@ -57,8 +66,18 @@ def measure(n, k, seed, runs=3, timeout_s=1800):
                 "sample": f"cargo test -r {test} (same synthetic witness as the GPU run, written by scripts/witness_to_json.py): 'GKR prove' span, "
                           f"1 warm + {runs} timed runs, median; rayon on all {cores} host cores",
                 "runs_ms": [round(t, 3) for t in times]}
-    except Exception:
+    except (OSError, subprocess.SubprocessError, ValueError, ImportError) as ex:
+        sys.stderr.write(f"[reference_baseline] not measured: {ex}\n")
         return None
+    finally:
+        try:
+            if had_fixture:
+                if os.path.exists(backup):
+                    os.replace(backup, fixture)
+            elif os.path.exists(fixture):
+                os.remove(fixture)
+        except OSError as ex:
+            sys.stderr.write(f"[reference_baseline] could not restore {fixture}: {ex}\n")
 
 
 if __name__ == "__main__":

@@ -358,3 +358,37 @@ def test_witness_for_other_parameters_is_refused():
     with pytest.raises(hg.HgError, match="witness was built for"):
         pk_big.circuit_eval(w_small)
     pk_big.free()
+
+
+def test_reference_baseline_leaves_the_reference_fixture_as_it_was(tmp_path, monkeypatch):
+    """scripts/reference_baseline.py writes the synthetic witness where the reference's test reads it - the shipped fixture at that
+    path must be back afterwards, byte for byte, whether cargo succeeds, fails or cannot be started."""
+    import stat
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import reference_baseline
+    repo = tmp_path / "hyper-greco"
+    data = repo / "bfv-gkr" / "src" / "data" / "goldilocks"
+    data.mkdir(parents=True)
+    fixture = data / "sk_enc_1024_1x27_65537.json"
+    original = b'{"shipped": "fixture"}\n'
+    fixture.write_bytes(original)
+    bindir = tmp_path / "bin"
+    bindir.mkdir()
+    cargo = bindir / "cargo"
+    seen = tmp_path / "seen.txt"
+    cargo.write_text("#!/bin/sh\nwc -c < %s >> %s\necho 'INFO GKR prove [ 1.50s | 37.12%% / 99.31%% ]'\nexit ${FAKE_CARGO_RC:-0}\n" % (fixture, seen))
+    cargo.chmod(cargo.stat().st_mode | stat.S_IEXEC)
+    monkeypatch.setenv("HYPER_GRECO", str(repo))
+    monkeypatch.setenv("PATH", str(bindir) + os.pathsep + os.environ["PATH"])
+    r = reference_baseline.measure(1024, 1, 5, runs=1)
+    assert r and r["kind"] == "reference" and abs(r["value"] - 1500.0) < 1e-6
+    assert fixture.read_bytes() == original and not (data / "sk_enc_1024_1x27_65537.json.hg-backup").exists()
+    assert int(seen.read_text().split()[0]) > 1000      # cargo saw the synthetic witness, not the shipped file
+    monkeypatch.setenv("FAKE_CARGO_RC", "1")
+    assert reference_baseline.measure(1024, 1, 5, runs=1) is None
+    assert fixture.read_bytes() == original
+    # a configuration whose fixture is a missing blob: nothing is left behind
+    assert reference_baseline.measure(2048, 1, 5, runs=1) is None
+    assert not (data / "sk_enc_2048_1x52_65537.json").exists()
