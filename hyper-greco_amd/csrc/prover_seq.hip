@@ -92,6 +92,7 @@ struct Mail {
     unsigned long long timeouts;  // device-side waits that gave up
     unsigned long long pad;
     E2 chal[4];
+    unsigned long long dbg[8];    // -DHG_SEQ_STAMPS: device clock (100 MHz) at kernel start, after the block sum, after the post, after the answer
 };
 __global__ void k_mail(Mail* m, unsigned long long seq, E2* chain_dst, dev::StJob* patch, int npw) {   // one wave
     __shared__ E2 s_r;
@@ -182,18 +183,39 @@ __device__ __forceinline__ void sq_pair_b(const SqJob& J, int rd, int t, size_t 
     o[2 * j] = X; o[2 * j + 1] = Y;
 }
 
-template <int NV> __device__ __forceinline__ void sq_block_sum(E2* acc, E2 (*sm)[256]) {   // -> thread 0 holds the sums
-    for (int t = 0; t < NV; t++) sm[t][threadIdx.x] = acc[t];
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) for (int t = 0; t < NV; t++) sm[t][threadIdx.x] = e2_add(sm[t][threadIdx.x], sm[t][threadIdx.x + s]);
-        __syncthreads();
+__device__ __forceinline__ E2 sq_shfl_xor(E2 v, int mask) {
+    E2 o;
+    o.c0 = (u64)__shfl_xor((unsigned long long)v.c0, mask, 64);
+    o.c1 = (u64)__shfl_xor((unsigned long long)v.c1, mask, 64);
+    return o;
+}
+// sum over the lanes of a wave whose index differs in the bits >= lo_bit (butterfly: every lane ends with the sum of its class)
+template <int NV> __device__ __forceinline__ void sq_wave_sum(E2* acc, int lo_bit) {
+    for (int m = 32; m >= (1 << lo_bit); m >>= 1) {
+#pragma unroll
+        for (int t = 0; t < NV; t++) acc[t] = e2_add(acc[t], sq_shfl_xor(acc[t], m));
     }
-    for (int t = 0; t < NV; t++) acc[t] = sm[t][0];
+}
+template <int NV> __device__ __forceinline__ void sq_block_sum(E2* acc, E2 (*sm)[256]) {   // -> thread 0 holds the sums
+    // wave butterflies, one LDS hop across the four waves (a tree of eight barrier steps cost 2-3 us of a 10 us round)
+    sq_wave_sum<NV>(acc, 0);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+#pragma unroll
+        for (int t = 0; t < NV; t++) sm[t][wave] = acc[t];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int t = 0; t < NV; t++) acc[t] = e2_add(e2_add(sm[t][0], sm[t][1]), e2_add(sm[t][2], sm[t][3]));
+    }
     __syncthreads();
 }
 // the last-arriving workgroup's thread 0: sums -> host memory, post, wait for the challenge, install it
-__device__ __forceinline__ void sq_mail_epilogue(const SqJob& J, int rd, const E2* total, E2* res, E2* chain_w) {
+__device__ __forceinline__ void sq_mail_epilogue(const SqJob& J, int rd, const E2* total, E2* res, E2* chain_w, long long t_start = 0) {
+#ifdef HG_SEQ_STAMPS
+    const long long t_sum = wall_clock64();
+#endif
     for (int t = 0; t < J.nv; t++) {
         __hip_atomic_store(&res[J.sums_slot + (size_t)rd * J.nv + t].c0, total[t].c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&res[J.sums_slot + (size_t)rd * J.nv + t].c1, total[t].c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -215,6 +237,10 @@ __device__ __forceinline__ void sq_mail_epilogue(const SqJob& J, int rd, const E
         if (wall_clock64() - t0 > 500000000ll) { __hip_atomic_fetch_add(&m->timeouts, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
         __builtin_amdgcn_s_sleep(2);
     }
+#ifdef HG_SEQ_STAMPS
+    const long long t_ans = wall_clock64();
+    m->dbg[0] += (unsigned long long)(t_sum - t_start); m->dbg[1] += (unsigned long long)(t0 - t_sum); m->dbg[2] += (unsigned long long)(t_ans - t0); m->dbg[3] += 1;
+#endif
     E2 r;
     r.c0 = __hip_atomic_load(&m->chal[0].c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     r.c1 = __hip_atomic_load(&m->chal[0].c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -270,20 +296,27 @@ __device__ __forceinline__ void sq_round_sums(const SqJob& J, int rd, int jb_log
             for (int t = 0; t < NV; t++) acc[t] = e2_add(acc[t], s[t]);
         } else {
             // the groups' shares of sum_i meet BEFORE the multiplication by p_0 (g = p_0 * sum_i ...); group 0 holds p_0's values
-            if (G > 1) {   // tree over the groups (thread index = g * JB + jj: halving the index range halves the groups)
+            if (G > 1) {
+                // thread index = g * JB + jj: inside a wave the groups sit in the lane bits above log2(JB) (butterfly), across the
+                // waves one LDS hop; group 0 (which holds p_0's values) ends up with the sum over all groups
+                if (jb_log2 < 6) sq_wave_sum<NV>(s, jb_log2);
+                const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+                const bool rep = jb_log2 < 6 ? lane < JB : true;   // one lane per (wave, jj) carries the wave's share
+                if (rep) {
 #pragma unroll
-                for (int t = 0; t < NV; t++) sm[t][threadIdx.x] = s[t];
-                __syncthreads();
-                for (int half = 128; half >= JB; half >>= 1) {
-                    if ((int)threadIdx.x < half) {
-#pragma unroll
-                        for (int t = 0; t < NV; t++) sm[t][threadIdx.x] = e2_add(sm[t][threadIdx.x], sm[t][threadIdx.x + half]);
-                    }
-                    __syncthreads();
+                    for (int t = 0; t < NV; t++) sm[t][jb_log2 < 6 ? wave * 64 + lane : threadIdx.x] = s[t];
                 }
+                __syncthreads();
                 if (g == 0) {
+                    if (jb_log2 < 6) {   // g == 0: wave 0, lanes jj < JB: add the other waves' lanes jj
 #pragma unroll
-                    for (int t = 0; t < NV; t++) s[t] = sm[t][jj];
+                        for (int t = 0; t < NV; t++) s[t] = e2_add(e2_add(sm[t][jj], sm[t][64 + jj]), e2_add(sm[t][128 + jj], sm[t][192 + jj]));
+                    } else {             // groups are whole waves (JB = 64, 128): add the other groups' threads jj
+                        for (int gg = 1; gg < G; gg++) {
+#pragma unroll
+                            for (int t = 0; t < NV; t++) s[t] = e2_add(s[t], sm[t][gg * JB + jj]);
+                        }
+                    }
                 }
                 __syncthreads();
             }
@@ -296,11 +329,19 @@ __device__ __forceinline__ void sq_round_sums(const SqJob& J, int rd, int jb_log
 }
 
 template <int KIND, typename TIN>
+// (A short round is a chain of dependent memory latencies - job descriptor, challenge, table entries, all cold in this XCD's L2:
+// kernel start -> sums 9-12 us, sums -> posted 1.4-2.4 us, posted -> answered 3.4 us, measured with -DHG_SEQ_STAMPS. Passing the
+// 2.2 KB job by value in the kernel arguments instead of behind a pointer was measured: 13.6 us against 12.2, not kept.)
 __global__ __launch_bounds__(256) void k_sq_round(const SqJob* __restrict__ jp, int rd, int jb_log2, E2* chain, E2* __restrict__ partials, unsigned* ticket, E2* res) {
     constexpr int NV = KIND == 1 ? 3 : 2;
     __shared__ E2 sm[NV][256];
     __shared__ unsigned s_last;
     const SqJob& J = *jp;
+#ifdef HG_SEQ_STAMPS
+    const long long t_start = wall_clock64();
+#else
+    const long long t_start = 0;
+#endif
     const E2 r_prev = rd > 0 ? chain[J.r_off + rd - 1] : e2_zero();
     E2 acc[NV];
 #pragma unroll
@@ -309,7 +350,7 @@ __global__ __launch_bounds__(256) void k_sq_round(const SqJob* __restrict__ jp, 
     sq_block_sum<NV>(acc, sm);
     const int nblocks = (int)gridDim.x;
     if (nblocks == 1) {
-        if (threadIdx.x == 0) sq_mail_epilogue(J, rd, acc, res, chain);
+        if (threadIdx.x == 0) sq_mail_epilogue(J, rd, acc, res, chain, t_start);
         return;
     }
     if (threadIdx.x == 0) {
@@ -342,7 +383,7 @@ __global__ __launch_bounds__(256) void k_sq_round(const SqJob* __restrict__ jp, 
     sq_block_sum<NV>(acc, sm);
     if (threadIdx.x == 0) {
         __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        sq_mail_epilogue(J, rd, acc, res, chain);
+        sq_mail_epilogue(J, rd, acc, res, chain, t_start);
     }
 }
 // thread mapping of a round with 2^hl pair indices and `units` table units (pairs / tables): as many groups along the units as
@@ -1113,6 +1154,11 @@ ProveResult prove_resident_mode(hg_ctx* ctx, const hg_pk* pk, const hg_values* v
         fprintf(stderr, "[hg] mode %d: %.2f ms; host waited %.2f ms for round sums (%zu round trips), %.2f ms for other results, spent %.2f ms enqueueing rounds\n", mode,
                 res.prove_ms, P.t_wait_rounds, P.n_mail, P.t_wait_results, P.t_enqueue_rounds);
     if (getenv("HG_SEQ_TIMES")) fprintf(stderr, "[hg]   host transcript steps between 'sums seen' and 'challenge posted': %.2f ms in total\n", P.t_answer);
+#ifdef HG_SEQ_STAMPS
+    if (P.mail && P.mail->dbg[3])
+        fprintf(stderr, "[hg]   device clocks per round (us): kernel start -> sums %.2f, sums -> posted %.2f, posted -> answered %.2f (%llu rounds)\n",
+                P.mail->dbg[0] / 100.0 / P.mail->dbg[3], P.mail->dbg[1] / 100.0 / P.mail->dbg[3], P.mail->dbg[2] / 100.0 / P.mail->dbg[3], P.mail->dbg[3]);
+#endif
     if (getenv("HG_SEQ_TIMES"))
         for (int kd = 0; kd < 3; kd++)
             fprintf(stderr, "[hg]   kind %d: %zu one-workgroup rounds %.2f ms, %zu larger rounds %.2f ms\n", kd, P.n_kind[kd][0], P.t_kind[kd][0], P.n_kind[kd][1], P.t_kind[kd][1]);
