@@ -330,6 +330,38 @@ def test_protocol_modes_bit_exact_against_the_oracle(ctx, n, k, bits, mode):
     pk.free()
 
 
+@pytest.mark.parametrize("switch", ["HG_SEQ_CLASSIC=1", "HG_SEQ_NO_MAIL=1", "HG_SEQ_SYNC_EVERY=1", "HG_SEQ_SYNC_EVERY=0"])
+def test_sequential_prover_switches_stay_bit_exact(switch):
+    """The sequential prover's alternatives - the fast path's round kernels run twice per round through the mailbox (CLASSIC), one
+    stream synchronisation per round instead of the mailbox (NO_MAIL), a real synchronisation at every / no drain point - give the
+    oracle's bytes in modes 1 and 3 (child process: the library reads the switches once)."""
+    import subprocess, sys
+    from hglib import ROOT
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import __graft_entry__ as entry\n"
+        "import orclib\n"
+        "hg = entry.load_package()\n"
+        "ctx = hg.Context(0); bfv = hg.BfvEncrypt.new(4096, 2); pk = bfv.setup(ctx)\n"
+        "w = hg.Witness.synthetic(bfv.params, 23)\n"
+        "inp = orclib.Inputs(w.arrays())\n"
+        "for mode in (1, 3):\n"
+        "    ref, _ = orclib.prove_f('goldilocks', orclib.params(4096, 2), inp, threads=4, mode=mode)\n"
+        "    for i in range(2):\n"
+        "        proof, tm = bfv.prove(ctx, pk, w, mode=mode)\n"
+        "        assert proof == ref, (mode, i)\n"
+        "print('SEQ OK', int(tm['sync_ms']), int(tm['enqueue_ms']))\n"
+    ) % (ROOT, os.path.join(ROOT, "tests"))
+    name, value = switch.split("=")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **{name: value}), cwd=ROOT)
+    assert r.returncode == 0 and "SEQ OK" in r.stdout, (switch, r.stdout[-500:], r.stderr[-2000:])
+    syncs, trips = (int(x) for x in r.stdout.split("SEQ OK")[1].split()[:2])
+    if switch == "HG_SEQ_NO_MAIL=1":
+        assert trips == 0 and syncs > 100
+    else:
+        assert trips > 100
+
+
 def test_protocol_modes_at_the_headline_size(ctx):
     """The same at n=32768 k=16 (mode 3 = both fixes): bit-exact against the oracle, accepted by both verifiers."""
     n, k = 32768, 16
