@@ -226,7 +226,7 @@ __device__ __forceinline__ void sq_mail_epilogue(const SqJob& J, int rd, const E
     // (vmcnt) is all the post must be ordered after. A formal release would write back the whole L2 - the folded tables this kernel
     // has just written for the NEXT kernel, which the kernel boundary orders anyway - and an acquire load in the poll loop would
     // invalidate it on every iteration. gfx942 / gfx950 only (stores tracked by vmcnt), like the ticket above.
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#if defined(HG_STRICT_TICKETS) || (defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__))
     __hip_atomic_store(&m->gpu_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 #else
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256) void k_sq_round(const SqJob* __restrict__ jp, 
         // (the partials were written through with agent-scope atomic stores by THIS thread: their completion - vmcnt - is all the
         // ticket must be ordered after; a formal release would write back every dirty line of the L2, i.e. the folded tables this
         // kernel streams out. gfx942 / gfx950 only: kernels.hip, finish_partials)
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#if defined(HG_STRICT_TICKETS) || (defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__))
         const unsigned tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
 #else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -330,6 +330,38 @@ def test_protocol_modes_bit_exact_against_the_oracle(ctx, n, k, bits, mode):
     pk.free()
 
 
+def test_strict_memory_model_build_is_bit_exact():
+    """build/strict/libhypergreco.so (-DHG_STRICT_TICKETS: acq_rel tickets, the form every architecture other than gfx942 / gfx950 must
+    use; built by __graft_entry__.build()) proves the same bytes as the oracle - plain launches, graph replays, a sharded proof and
+    the sequential prover."""
+    import subprocess, sys
+    from hglib import ROOT
+    lib = os.path.join(ROOT, "build", "strict", "libhypergreco.so")
+    if not os.path.exists(lib):
+        pytest.skip("build/strict/libhypergreco.so not built (run __graft_entry__.build())")
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "import __graft_entry__ as entry\n"
+        "import orclib\n"
+        "hg = entry.load_package()\n"
+        "assert 'strict' in hg.build.__globals__['_LIB_PATH']\n"
+        "ctx = hg.Context(0); bfv = hg.BfvEncrypt.new(4096, 2); pk = bfv.setup(ctx)\n"
+        "w = hg.Witness.synthetic(bfv.params, 29); v = hg.witness_gen(ctx, pk, w); out = hg.ProofBuffer()\n"
+        "inp = orclib.Inputs(w.arrays())\n"
+        "ref, _ = orclib.prove(orclib.params(4096, 2), inp, threads=4)\n"
+        "for i in range(5): assert hg.prove_resident(ctx, pk, v, out).bytes() == ref, i\n"
+        "parts = [np.array(hg.prove_shard_begin(ctx, pk, v, r, 3), copy=True) for r in range(3)]\n"
+        "hg.prove_shard_combine(ctx, np.stack(parts), 3)\n"
+        "assert hg.prove_shard_finish(ctx, out).bytes() == ref\n"
+        "ref3, _ = orclib.prove_f('goldilocks', orclib.params(4096, 2), inp, threads=4, mode=3)\n"
+        "assert bfv.prove(ctx, pk, w, mode=3)[0] == ref3\n"
+        "print('STRICT OK')\n"
+    ) % (ROOT, os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, HG_LIB=lib), cwd=ROOT)
+    assert r.returncode == 0 and "STRICT OK" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
 @pytest.mark.parametrize("switch", ["HG_SEQ_CLASSIC=1", "HG_SEQ_NO_MAIL=1", "HG_SEQ_SYNC_EVERY=1", "HG_SEQ_SYNC_EVERY=0"])
 def test_sequential_prover_switches_stay_bit_exact(switch):
     """The sequential prover's alternatives - the fast path's round kernels run twice per round through the mailbox (CLASSIC), one
