@@ -208,11 +208,18 @@ int cgroup_cpu_quota() {   // CPUs granted by the cgroup (v2 cpu.max, v1 cfs quo
     }
     return 0;
 }
+// threads an OpenMP region of this library may use: the runtime's default, capped by the cgroup quota (unless OMP_NUM_THREADS says
+// otherwise). A clause on the library's own regions - the process-wide default of a host application is not touched.
+int hg_omp_threads() {
+    static const int n = [] {
+        int t = omp_get_max_threads();
+        if (!getenv("OMP_NUM_THREADS")) { const int q = cgroup_cpu_quota(); if (q > 0 && q < t) t = q; }
+        return t < 1 ? 1 : t;
+    }();
+    return n;
+}
 static const int g_openmp_guard = [] {
-    if (!getenv("OMP_NUM_THREADS")) {
-        const int q = cgroup_cpu_quota();
-        if (q > 0 && q < omp_get_max_threads()) omp_set_num_threads(q);
-    }
+    // (idle workers that spin burn the quota for every thread of the process: the one process-wide setting this library makes)
     if (!getenv("KMP_BLOCKTIME") && !getenv("OMP_WAIT_POLICY") && kmp_set_blocktime) kmp_set_blocktime(0);
     return 0;
 }();
@@ -230,7 +237,7 @@ struct JsonCursor {
     std::vector<ArrayJob> jobs;
     std::vector<size_t> closers;   // positions of every ']' of the text, ascending (found in parallel by the constructor)
     JsonCursor(const char* p, size_t len) : s(p), n(len) {
-        const int nt = std::max(1, std::min<int>(omp_get_max_threads(), (int)std::min<size_t>(32, len / ((size_t)1 << 20) + 1)));
+        const int nt = std::max(1, std::min<int>(hg_omp_threads(), (int)std::min<size_t>(32, len / ((size_t)1 << 20) + 1)));
         std::vector<std::vector<size_t>> part(nt);
 #pragma omp parallel for schedule(static, 1) num_threads(nt)
         for (int t = 0; t < nt; t++) {
@@ -373,7 +380,7 @@ struct JsonCursor {
             }
         }
         std::string err;
-        const int nt = std::max(1, std::min<int>(omp_get_max_threads(), std::min<int>(64, (int)pieces.size())));
+        const int nt = std::max(1, std::min<int>(hg_omp_threads(), std::min<int>(64, (int)pieces.size())));
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nt)
         for (size_t q = 0; q < pieces.size(); q++) {
             Piece& P = pieces[q];
@@ -451,7 +458,7 @@ Witness layout_inputs(const Params& p, const RawArgs& a) {  // get_inputs (sk_en
     w.ct0is.resize(k * SZ);
     for (size_t z = 0; z < k; z++) if (a.r2is[z].size() + 1 != PZ) throw Error("witness: r2i must have n-1 coefficients");
     std::string err;
-#pragma omp parallel for schedule(static, 1) num_threads((int)std::min<size_t>(k, (size_t)omp_get_max_threads()))
+#pragma omp parallel for schedule(static, 1) num_threads((int)std::min<size_t>(k, (size_t)hg_omp_threads()))
     for (size_t z = 0; z < k; z++) {
         try {
             put_padded(a.ais[z], SZ, &w.ais[z * SZ]);
@@ -600,7 +607,7 @@ Witness witness_synthetic(const Params& p, u64 seed) {
         RawArgs out;
         out.r2is.resize(k); out.r1is.resize(k); out.ais.resize(k); out.ct0is.resize(k);
         bool ok = true;
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(hg_omp_threads())
         for (long long ii = 0; ii < (long long)k; ii++) {
             size_t i = (size_t)ii;
             const i128 q = (i128)p.raw.qis[i];
@@ -965,7 +972,7 @@ std::vector<std::vector<u64>> circuit_evaluate(const HCircuit& c, const Params& 
     for (int l = 1; l <= maxl; l++) {
         std::vector<int> ids;
         for (int id : c.topo) if (level[id] == l) ids.push_back(id);
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(hg_omp_threads())
         for (long long q = 0; q < (long long)ids.size(); q++) {
             int id = ids[q];
             const HNode& n = c.nodes[id];

@@ -28,7 +28,8 @@ struct Error : std::runtime_error {
 // chain c_j = LE(H_j) mod p, H_1 = Keccak256(""), H_{j+1} = Keccak256(H_j). The chain is cached
 // process-wide; `ChallengeSource` is the seam where an absorbing transcript would plug in.
 void keccak256(const uint8_t* data, size_t len, uint8_t out[32]);
-int cgroup_cpu_quota();  // CPUs the cgroup grants (0 = unlimited / unknown): the library sizes its OpenMP teams by it
+int cgroup_cpu_quota();  // CPUs the cgroup grants (0 = unlimited / unknown)
+int hg_omp_threads();    // threads one of the library's OpenMP regions may use (runtime default capped by the quota)
 const u64* challenge_chain(size_t n_base);  // pointer to >= n_base cached base-field challenges
 u64 felt_from_hash(const uint8_t h[32]);    // fe_mod_from_le_bytes (transcript.rs:202): 256-bit little-endian integer mod p
 

@@ -123,7 +123,7 @@ struct BnField {  // elements in Montgomery form
 // DFT rows) run on the host's cores: the reference's verifier is rayon-parallel in the same places (README.md:44,56: 108 / 529 ms on
 // 10 cores); single-threaded this one took seconds at n=32768 k=16. Field sums are exact, so the order of a reduction is free.
 static inline int threads_for(size_t work, size_t grain) {
-    const size_t mx = (size_t)omp_get_max_threads(), want = work / grain;
+    const size_t mx = (size_t)hg_omp_threads(), want = work / grain;
     return (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(mx, 64), want));
 }
 template <class F, class Fn> typename F::E par_sum(size_t n, size_t grain, Fn fn) {
