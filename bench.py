@@ -260,6 +260,18 @@ def measure_end_to_end(hg, ctx, bfv, pk, witnesses, walked, args):
     med = runs[len(runs) // 2]
     res["arrays_to_proof_ms"] = round(med[0], 3)
     res["stages_ms"] = {"upload": round(med[1]["upload_ms"], 3), "witness_gen_device": round(med[1]["witness_ms"], 3), "gkr_prove": round(med[1]["prove_ms"], 3)}
+    # a run of witnesses through hg_prove_stream: witness i+1's upload + evaluate under witness i's prove
+    run = [witnesses[i % NW] for i in range(4 * NW)]
+    for i in range(2):                                                       # both table sets walk twice and record their graphs
+        proofs, tm = bfv.prove_stream(ctx, pk, run)
+        assert proofs == [walked[i % NW] for i in range(len(run))], "hg_prove_stream: a proof differs from the resident prove of the same witness"
+    ts = []
+    for i in range(5):
+        proofs, tm = bfv.prove_stream(ctx, pk, run)
+        ts.append(tm["total_ms"] / len(run))
+    assert proofs == [walked[i % NW] for i in range(len(run))]
+    res["pipelined_arrays_to_proof_ms"] = round(statistics.median(ts), 3)
+    res["pipelined_run"] = len(run)
     # JSON -> arrays: the reference's fixture format, written from witness 0 (the n=32768 fixture itself is a missing blob)
     with tempfile.TemporaryDirectory() as td:
         path = os.path.join(td, "w.json")
@@ -276,7 +288,7 @@ def measure_end_to_end(hg, ctx, bfv, pk, witnesses, walked, args):
         res["json_parse_ms"] = round(statistics.median(ts[1:]), 3)
         res["json_parse_threads"] = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)
     res["json_to_proof_ms"] = round(res["json_parse_ms"] + res["arrays_to_proof_ms"], 3)
-    res["note"] = "median of 5 after warm-up, a different witness per call; hg_witness_from_json + hg_prove (host arrays are pageable memory)"
+    res["note"] = "median of 5 after warm-up, a different witness per call; hg_witness_from_json + hg_prove (host arrays are pageable memory); pipelined_*: hg_prove_stream over a run of witnesses, per proof"
     return res
 
 

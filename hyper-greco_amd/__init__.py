@@ -38,7 +38,7 @@ class HgKernelStat(C.Structure):
 EXPORTS = [
     "hg_last_error", "hg_device_count", "hg_create", "hg_destroy", "hg_set_option", "hg_params_builtin", "hg_params_derive", "hg_grand_product", "hg_fold", "hg_setup", "hg_pk_free",
     "hg_pk_lasso_layout", "hg_pk_info", "hg_witness_from_json", "hg_witness_synthetic", "hg_witness_from_arrays",
-    "hg_witness_get", "hg_witness_free", "hg_prove", "hg_verify", "hg_verify_device", "hg_prove_mode", "hg_prove_resident_mode", "hg_verify_mode", "hg_witness_gen", "hg_witness_gen_into", "hg_witness_gen_shard", "hg_values_info", "hg_values_free", "hg_values_get", "hg_comm_unique_id", "hg_comm_init", "hg_comm_destroy", "hg_comm_count", "hg_comm_selftest", "hg_prove_sharded", "hg_prove_shard_begin", "hg_prove_shard_combine", "hg_prove_shard_finish", "hg_shard_combine_host", "hg_prove_resident", "hg_circuit_eval", "hg_lasso_prove", "hg_lasso_prove_at", "hg_lasso_num_challenges", "hg_sumcheck", "hg_mle_eval",
+    "hg_witness_get", "hg_witness_free", "hg_prove", "hg_prove_stream", "hg_verify", "hg_verify_device", "hg_prove_mode", "hg_prove_resident_mode", "hg_verify_mode", "hg_witness_gen", "hg_witness_gen_into", "hg_witness_gen_shard", "hg_values_info", "hg_values_free", "hg_values_get", "hg_comm_unique_id", "hg_comm_init", "hg_comm_destroy", "hg_comm_count", "hg_comm_selftest", "hg_prove_sharded", "hg_prove_shard_begin", "hg_prove_shard_combine", "hg_prove_shard_finish", "hg_shard_combine_host", "hg_prove_resident", "hg_circuit_eval", "hg_lasso_prove", "hg_lasso_prove_at", "hg_lasso_num_challenges", "hg_sumcheck", "hg_mle_eval",
     "hg_ntt", "hg_challenges", "hg_challenges_bn254", "hg_bn254_field_op", "hg_sumcheck_bn254", "hg_grand_product_bn254", "hg_lasso_prove_bn254", "hg_witness_from_json_bn254", "hg_circuit_eval_bn254", "hg_prove_bn254", "hg_verify_bn254", "hg_mle_eval_bn254", "hg_ntt_bn254", "hg_profile", "hg_profile_select", "hg_profile_reset", "hg_profile_get",
 ]
 
@@ -414,6 +414,21 @@ class BfvEncrypt:
         else:
             _check(L.hg_prove(ctx.h, pk.h, witness.h, buf, cap, C.byref(ln), C.byref(tm)))
         return C.string_at(buf, ln.value), {f: getattr(tm, f) for f, _ in HgTimings._fields_}
+
+    def prove_stream(self, ctx, pk, witnesses, cap_each=1 << 20):
+        """hg_prove_stream: BfvEncrypt::prove for a run of witnesses, witness i+1's upload + evaluate under witness i's prove."""
+        n = len(witnesses)
+        L = lib()
+        L.hg_prove_stream.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(HgTimings)]
+        L.hg_prove_stream.restype = C.c_int
+        hs = (C.c_void_p * max(n, 1))(*[w.h for w in witnesses])
+        buf = (C.c_uint8 * (cap_each * max(n, 1)))()
+        lens = (C.c_size_t * max(n, 1))()
+        tm = HgTimings()
+        _check(L.hg_prove_stream(ctx.h, pk.h, hs, n, buf, cap_each, lens, C.byref(tm)))
+        raw = memoryview(buf)
+        proofs = [bytes(raw[i * cap_each:i * cap_each + lens[i]]) for i in range(n)]
+        return proofs, {f: getattr(tm, f) for f, _ in HgTimings._fields_}
 
 
 class ResidentValues:

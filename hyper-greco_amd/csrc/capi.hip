@@ -539,6 +539,29 @@ int hg_prove(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, uint8_t* proof, 
     HG_CATCH(-1)
 }
 
+int hg_prove_stream(hg_ctx* ctx, const hg_pk* pk, const hg_witness* const* ws, size_t n, uint8_t* proofs, size_t cap_each, size_t* lens, hg_timings* timings) {
+    HG_TRY
+    if (!ctx || !pk || (n && (!ws || !proofs || !lens))) throw Error("hg_prove_stream: null argument");
+    if (!pk->ctx) throw Error("hg_prove_stream: host-only prover key (created without a context)");
+    std::vector<const Witness*> W(n);
+    for (size_t i = 0; i < n; i++) {
+        if (!ws[i]) throw Error("hg_prove_stream: null witness");
+        check_witness(pk, ws[i], "hg_prove_stream");
+        W[i] = &ws[i]->w;
+    }
+    double total = 0;
+    std::vector<ProveResult> rs = prove_stream(ctx, pk, W, &total);
+    if (timings) { memset(timings, 0, sizeof(*timings)); timings->total_ms = total; }
+    for (size_t i = 0; i < n; i++) {
+        lens[i] = rs[i].proof.size();
+        if (rs[i].proof.size() > cap_each) throw Error("proof buffer too small");
+        memcpy(proofs + i * cap_each, rs[i].proof.data(), rs[i].proof.size());
+        if (timings) { timings->prove_ms += rs[i].prove_ms; timings->gpu_ms += rs[i].gpu_ms; timings->replay_ms += rs[i].replay_ms; }
+    }
+    return 0;
+    HG_CATCH(-1)
+}
+
 int hg_prove_resident_mode(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int mode, uint8_t* proof, size_t cap, size_t* len, hg_timings* timings) {
     HG_TRY
     if (!ctx || !pk || !v || !pk->ctx || !proof || !len) throw Error("hg_prove_resident_mode: needs a device context, a device prover key and resident values");

@@ -380,7 +380,7 @@ struct JsonCursor {
             }
         }
         std::string err;
-        const int nt = std::max(1, std::min<int>(hg_omp_threads(), std::min<int>(64, (int)pieces.size())));
+        [[maybe_unused]] const int nt = std::max(1, std::min<int>(hg_omp_threads(), std::min<int>(64, (int)pieces.size())));   // (the device pass of hipcc ignores the pragma)
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nt)
         for (size_t q = 0; q < pieces.size(); q++) {
             Piece& P = pieces[q];

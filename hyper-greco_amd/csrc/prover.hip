@@ -120,6 +120,9 @@ hg_ctx::~hg_ctx() {
     hg::pending_shard_drop(this);
     hg::prove_cache_drop(this);
     if (scratch_values) hg::values_free(scratch_values);
+    for (auto& v : stream_values) if (v) hg::values_free(v);
+    if (stream3) { (void)hipStreamSynchronize(stream3); (void)hipStreamDestroy(stream3); }
+    for (auto e : ev_ready) if (e) (void)hipEventDestroy(e);
     for (auto& c : chunks) (void)hipFree(c.p);
     if (d_chal) (void)hipFree(d_chal);
     if (d_res && d_res != h_res) (void)hipFree(d_res);
@@ -1769,7 +1772,12 @@ static hg_values* values_alloc(hg_ctx* ctx, const hg_pk* pk) {
 }
 
 static void shard_fill(hg_ctx* ctx, hg_values* v, const hg_values* full);
+static void witness_fill(hg_ctx* ctx, const hg_pk* pk, const Witness& w, hg_values* v, hipStream_t st, bool sync, double* witness_ms, double* upload_ms);
 void witness_gen_into(hg_ctx* ctx, const hg_pk* pk, const Witness& w, hg_values* v, double* witness_ms, double* upload_ms) {
+    witness_fill(ctx, pk, w, v, ctx->stream, true, witness_ms, upload_ms);
+}
+// `st`: the stream everything is enqueued on; sync == false: nothing waits (the caller orders later work behind an event on `st`)
+static void witness_fill(hg_ctx* ctx, const hg_pk* pk, const Witness& w, hg_values* v, hipStream_t st, bool sync, double* witness_ms, double* upload_ms) {
     // Circuit::evaluate on the device: inputs are uploaded, then the circuit is evaluated level by level
     // (Vanilla nodes: gate-major kernel; FFT nodes: batched NTTs, same level + direction in one batch).
     // Every table keeps its address: a launch graph recorded for `v` proves the new witness as it is (the launch sequence of a
@@ -1788,7 +1796,6 @@ void witness_gen_into(hg_ctx* ctx, const hg_pk* pk, const Witness& w, hg_values*
     if (w.ct0is.size() != v->ct0is_len) throw Error("circuit: ct0is size mismatch");
     double t0 = wall_ms();
     auto dv = [&](int id) { return const_cast<u64*>(v->d_vals[id]); };
-    hipStream_t st = ctx->stream;
     {   // inputs in NodeId order: s, e, k1, ais.., r1is.., r2is (chain_par! sk_encryption_circuit.rs:408)
         const size_t SZ = p.SZ();
         size_t idx = 0;
@@ -1803,7 +1810,7 @@ void witness_gen_into(hg_ctx* ctx, const hg_pk* pk, const Witness& w, hg_values*
         put(w.r2is.data(), w.r2is.size());
         hip_check(hipMemcpyAsync(const_cast<u64*>(v->d_ct0is), w.ct0is.data(), w.ct0is.size() * 8, hipMemcpyHostToDevice, st), "upload ct0is");
     }
-    if (upload_ms) hip_check(hipStreamSynchronize(st), "upload sync");   // (only to split the two timings)
+    if (upload_ms && sync) hip_check(hipStreamSynchronize(st), "upload sync");   // (only to split the two timings)
     double t1 = wall_ms();
     for (int l = 1; l <= v->max_level; l++) {
         for (int inv = 0; inv < 2; inv++) {  // FFT groups
@@ -1832,7 +1839,7 @@ void witness_gen_into(hg_ctx* ctx, const hg_pk* pk, const Witness& w, hg_values*
             }
         }
     }
-    hip_check(hipStreamSynchronize(st), "witness generation sync");
+    if (sync) hip_check(hipStreamSynchronize(st), "witness generation sync");
     hip_check(hipGetLastError(), "witness generation");
     double t2 = wall_ms();
     if (upload_ms) *upload_ms = t1 - t0;
@@ -2062,9 +2069,8 @@ static bool graph_allowed(const hg_ctx* ctx) {
     return !off && getenv("HG_PROOF_MAP") == nullptr && ctx->use_graph && ctx->prof_level == 0 && ctx->d_res == ctx->h_res;
 }
 // launches the cached graph, waits, replays the transcript
-static ProveResult prove_from_cache(hg_ctx* ctx, ProveCache* C, bool exchange = false, bool replay_now = true) {
-    ProveResult res;
-    const double t0 = wall_ms();
+// the launch alone (nothing waits): ev_a, the graph, [the collective], ev_b on the prover stream
+static void cache_launch(hg_ctx* ctx, ProveCache* C, bool exchange) {
     hip_check(hipSetDevice(ctx->device), "hipSetDevice");
     hip_check(hipEventRecord(C->ev_a, ctx->stream), "event record");
     static const bool time_launch = getenv("HG_TIME_LAUNCH") != nullptr;   // (debugging aid: host time of the graph launch call)
@@ -2073,6 +2079,11 @@ static ProveResult prove_from_cache(hg_ctx* ctx, ProveCache* C, bool exchange = 
     if (time_launch) fprintf(stderr, "hipGraphLaunch: %.3f ms on the host\n", wall_ms() - tl0);
     if (exchange) comm_allreduce_results(ctx, C->P->res_used);   // the one collective of a sharded proof, behind the replayed graph
     hip_check(hipEventRecord(C->ev_b, ctx->stream), "event record");
+}
+static ProveResult prove_from_cache(hg_ctx* ctx, ProveCache* C, bool exchange = false, bool replay_now = true, bool launched = false, double t_launch = 0) {
+    ProveResult res;
+    const double t0 = launched ? t_launch : wall_ms();
+    if (!launched) cache_launch(ctx, C, exchange);
     Prover* P = C->P.get();
     P->st = ctx->stream;
     P->sync_results();
@@ -2214,6 +2225,54 @@ ProveResult prove_resident(hg_ctx* ctx, const hg_pk* pk, const hg_values* v) {
     res.replay_ms = P->t_replayed - P->t_synced;
     res.proof = std::move(P->proof.bytes);
     return res;
+}
+
+// BfvEncrypt::prove for a run of witnesses, pipelined over two sets of node tables: while witness i is proven (graph replay on the
+// prover streams), witness i+1 is uploaded and evaluated on a third stream into the other set. The host launches the graph FIRST and
+// does the (host-side) staging of the next upload while the device proves. Walked proves (the first two per table set) are not
+// overlapped. Proofs are what hg_prove gives for each witness.
+std::vector<ProveResult> prove_stream(hg_ctx* ctx, const hg_pk* pk, const std::vector<const Witness*>& ws, double* total_ms) {
+    hip_check(hipSetDevice(ctx->device), "hipSetDevice");
+    const double t_all = wall_ms();
+    if (!ctx->stream3) {
+        hip_check(hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking), "hipStreamCreate");
+        for (auto& e : ctx->ev_ready) hip_check(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
+    }
+    if (ctx->stream_values[0] && ctx->stream_values_serial != pk->serial)
+        for (auto& v : ctx->stream_values) { values_free(v); v = nullptr; }
+    if (!ctx->stream_values[0]) {
+        for (auto& v : ctx->stream_values) v = values_alloc(ctx, pk);
+        ctx->stream_values_serial = pk->serial;
+    }
+    std::vector<ProveResult> out(ws.size());
+    if (ws.empty()) return out;
+    hg_values** V = ctx->stream_values;
+    double wm = 0, um = 0;
+    witness_fill(ctx, pk, *ws[0], V[0], ctx->stream3, false, &wm, &um);
+    hip_check(hipEventRecord(ctx->ev_ready[0], ctx->stream3), "event record");
+    for (size_t i = 0; i < ws.size(); i++) {
+        const int cur = (int)(i & 1), nxt = cur ^ 1;
+        hip_check(hipStreamWaitEvent(ctx->stream, ctx->ev_ready[cur], 0), "wait for the witness");
+        auto fill_next = [&] {
+            if (i + 1 >= ws.size()) return;
+            // (V[nxt] was last read by prove i-1, which has completed: its results were waited for)
+            witness_fill(ctx, pk, *ws[i + 1], V[nxt], ctx->stream3, false, &wm, &um);
+            hip_check(hipEventRecord(ctx->ev_ready[nxt], ctx->stream3), "event record");
+        };
+        std::shared_ptr<ProveCache> C = graph_allowed(ctx) ? cache_find(ctx, pk, V[cur], 0, 1) : nullptr;
+        if (C && !(ctx->slow_graph_serial == pk->serial && ctx->slow_graph_share == 1)) {
+            const double t0 = wall_ms();
+            cache_launch(ctx, C.get(), false);
+            fill_next();                                   // host staging + the third stream's work, under the replayed graph
+            out[i] = prove_from_cache(ctx, C.get(), false, true, true, t0);
+        } else {
+            fill_next();
+            out[i] = prove_resident(ctx, pk, V[cur]);      // walks (and records the graph on the third prove of this table set)
+        }
+    }
+    hip_check(hipStreamSynchronize(ctx->stream3), "stream3");
+    if (total_ms) *total_ms = wall_ms() - t_all;
+    return out;
 }
 
 ProveResult prove_sharded(hg_ctx* ctx, const hg_pk* pk, const hg_values* v) {

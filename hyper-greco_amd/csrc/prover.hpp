@@ -44,6 +44,12 @@ struct hg_ctx {
     // walked proves seen per (key serial, values serial, share): the third one of a values object is recorded into a graph
     struct WalkCount { uint64_t pk_serial, values_serial; int share; int walks; size_t arena_bytes; float gpu_ms; };
     std::vector<WalkCount> walk_counts;
+    // hg_prove_stream: the next witness is uploaded and evaluated on a third stream into the OTHER of two table sets while the
+    // current one is being proven
+    hipStream_t stream3 = nullptr;
+    hipEvent_t ev_ready[2] = {nullptr, nullptr};
+    hg_values* stream_values[2] = {nullptr, nullptr};
+    uint64_t stream_values_serial = 0;     // key serial they were laid out for
     hg_values* scratch_values = nullptr;   // hg_prove's resident tables, refilled in place per call (so its launch graph survives)
     uint64_t scratch_serial = 0;           // key serial they were laid out for
     uint64_t no_graph_serial = 0;          // key whose graph capture failed: its proves walk (no retry)
@@ -171,6 +177,8 @@ hg_values* witness_gen(hg_ctx* ctx, const hg_pk* pk, const Witness& w, double* w
 hg_values* witness_gen_shard(hg_ctx* ctx, const hg_pk* pk, const Witness& w, int rank, int world, double* witness_ms, double* upload_ms);
 // Circuit::evaluate into the tables of an existing values object (same addresses: its cached launch graph stays valid)
 void witness_gen_into(hg_ctx* ctx, const hg_pk* pk, const Witness& w, hg_values* v, double* witness_ms, double* upload_ms);
+// BfvEncrypt::prove for a run of witnesses, pipelined: upload + circuit.evaluate of witness i+1 overlap the GKR prove of witness i
+std::vector<ProveResult> prove_stream(hg_ctx* ctx, const hg_pk* pk, const std::vector<const Witness*>& ws, double* total_ms);
 void values_free(hg_values* v);
 void pending_shard_drop(hg_ctx* ctx);
 void ctx_register(hg_ctx* ctx, bool alive);

@@ -531,6 +531,41 @@ def test_graph_replay_across_witnesses(ctx, n, k, seeds):
     pk.free()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,k", [(1024, 1), (4096, 2)])
+def test_prove_stream_equals_one_by_one(ctx, n, k):
+    """hg_prove_stream (witness i+1 uploaded and evaluated on a third stream into a second table set while witness i is proven):
+    every proof of a run - walked ones at its start, replayed ones with the overlap later, runs of length 0 / 1 / odd / even, a
+    second run on warm graphs - equals the oracle's proof of that witness, in order."""
+    bfv = hg.BfvEncrypt.new(n, k)
+    pk = bfv.setup(ctx)
+    p = orclib.params(n, k)
+    ws = [hg.Witness.synthetic(bfv.params, 0x1234 + 7 * i) for i in range(5)]
+    refs = [orclib.prove(p, orclib.Inputs(w.arrays()), threads=min(16, os.cpu_count() or 8))[0] for w in ws]
+    assert len(set(refs)) == len(ws)
+    assert bfv.prove_stream(ctx, pk, [])[0] == []
+    assert bfv.prove_stream(ctx, pk, ws[:1])[0] == refs[:1]
+    order = [0, 1, 2, 3, 4, 4, 3, 0, 2, 1, 1]                               # 11 proofs: both table sets get past their capture
+    for rnd in range(3):
+        proofs, tm = bfv.prove_stream(ctx, pk, [ws[i] for i in order])
+        for j, i in enumerate(order):
+            assert proofs[j] == refs[i], (rnd, j, _first_diff(proofs[j], refs[i], 16))
+    print("n=%d: %d proofs in %.2f ms (%.3f ms each; sum of prove_ms %.2f, gpu_ms %.2f)" % (n, len(order), tm["total_ms"], tm["total_ms"] / len(order), tm["prove_ms"], tm["gpu_ms"]))
+    # hg_prove afterwards (tables of its own) is unaffected, and so is a stream under another key
+    assert bfv.prove(ctx, pk, ws[2])[0] == refs[2]
+    n2, k2 = (4096, 2) if n == 1024 else (1024, 1)
+    bfv2 = hg.BfvEncrypt.new(n2, k2)
+    pk2 = bfv2.setup(ctx)
+    w2 = hg.Witness.synthetic(bfv2.params, 5)
+    ref2 = orclib.prove(orclib.params(n2, k2), orclib.Inputs(w2.arrays()), threads=4)[0]
+    assert bfv2.prove_stream(ctx, pk2, [w2, w2, w2, w2])[0] == [ref2] * 4
+    assert bfv.prove_stream(ctx, pk, [ws[3], ws[0]])[0] == [refs[3], refs[0]]
+    with pytest.raises(hg.HgError):
+        bfv2.prove_stream(ctx, pk2, [ws[0]])                                 # a witness of another parameter set
+    pk2.free()
+    pk.free()
+
+
 def test_graph_cache_eviction_and_refill_guards(ctx):
     """One graph slot (HG_GRAPH_ENTRIES=1, child process): two values objects proven in alternation evict each other's graph over
     and over - the bytes never change. In this process: a values object cannot be refilled for another key, and reports its size."""
