@@ -140,6 +140,8 @@ struct SqJob {
     size_t r_off, sums_slot;
     Mail* mail;
     unsigned long long seq0;   // round rd's message is seq0 + rd
+    int dev_rounds;            // > 0: only rounds 0 .. dev_rounds-1 run on the device (the host finishes the sum-check, run_sq): the last
+    int pad_;                  //      of them posts its sums and does not wait for the challenge
     E2 pw[dev::PW_MAX];
 };
 template <typename T> __device__ __forceinline__ E2 sq_ld(const T* p, size_t i);
@@ -232,6 +234,7 @@ __device__ __forceinline__ void sq_mail_epilogue(const SqJob& J, int rd, const E
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_store(&m->gpu_seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #endif
+    if (J.dev_rounds && rd == J.dev_rounds - 1) return;   // the host takes over from here (its answer to this round never comes to the device)
     const long long t0 = wall_clock64();
     while (__hip_atomic_load(&m->cpu_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {   // (the answer is read with system-scope atomic loads below)
         if (wall_clock64() - t0 > 500000000ll) { __hip_atomic_fetch_add(&m->timeouts, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
@@ -423,6 +426,35 @@ __global__ void k_sq_final(const SqJob* __restrict__ jp, const E2* __restrict__ 
     if (J.kind == 2) *J.fin[t] = v; else J.final_out[t] = v;
 }
 
+// hands the tables of the last device round (T_(R-1): ntab runs of 2^(nvars-R+1) entries, contiguous) to the host: copies them into
+// pinned host memory and posts `seq`. One workgroup; runs behind round R-1's kernel, i.e. after every workgroup of it has stored its
+// share of the tables (kernel boundary).
+__global__ __launch_bounds__(256) void k_sq_export(const E2* __restrict__ src, unsigned n, E2* dst_host, Mail* m, unsigned long long seq) {
+    // 16-byte stores, consecutive lanes on consecutive entries: the host memory is uncached on the device side, the stores leave as
+    // full write bursts (8-byte system-scope atomic stores went out one by one: 250 us for 32 KB)
+    for (unsigned i = threadIdx.x; i < n; i += 256) dst_host[i] = src[i];
+    // plain stores may sit in this XCD's L2: every thread releases them to system scope (write-back + wait; the L2 holds little
+    // else right behind a kernel boundary), the barrier collects the threads, then the post
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&m->gpu_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// what the host computed for the device after a host tail, in one launch (kernel arguments carry the values: no copy engine in
+// the stream): the challenges the device has not seen, and final evaluations whose destination is device memory
+struct SqInstall {
+    E2* chain_dst;
+    int nchain, nres;
+    E2 chain[24];
+    E2* res_dst[2 * dev::PS_MAX_PAIRS];
+    E2 res[2 * dev::PS_MAX_PAIRS];
+};
+__global__ void k_sq_install(SqInstall a) {
+    const int i = threadIdx.x;
+    if (i < a.nchain) a.chain_dst[i] = a.chain[i];
+    if (i < a.nres) *a.res_dst[i] = a.res[i];
+}
+
 struct Claim {  // evaluation claim whose point is a run of this proof's challenge table
     size_t point_off;
     int len;
@@ -443,6 +475,10 @@ struct SeqProver {
     size_t n_drained = 0;
     size_t n_mail = 0;   // mailbox round trips (no synchronisation: the device spins on the host's answer)
     Mail* mail = nullptr;               // pinned host memory, mapped into the device
+    static constexpr size_t MAIL_BYTES = 4096, HOST_TAIL_CAP = 8192;
+    E2* h_tail = nullptr;               // (same allocation)
+    size_t host_tail_entries = 0;       // a sum-check's last rounds run on the host once all its tables together have at most this many entries (HG_SEQ_HOST_TAIL, 0 = never)
+    size_t n_host_rounds = 0;
     unsigned long long mail_seq = 0;
     bool use_mail = true;
     std::vector<const u64*> d_vals;
@@ -458,8 +494,13 @@ struct SeqProver {
         static const bool no_mail = [] { const char* e = getenv("HG_SEQ_NO_MAIL"); return e && e[0] == '1'; }();
         use_mail = !no_mail && ctx->d_res == ctx->h_res;   // (the sums must land in host memory without a copy)
         if (use_mail) {
-            hip_check(hipHostMalloc((void**)&mail, sizeof(Mail), hipHostMallocDefault), "hipHostMalloc(mailbox)");
+            // the mailbox and, behind it, the buffer through which the last tables of a sum-check travel to the host (host_tail)
+            hip_check(hipHostMalloc((void**)&mail, MAIL_BYTES + HOST_TAIL_CAP * sizeof(E2), hipHostMallocDefault), "hipHostMalloc(mailbox)");
             memset(mail, 0, sizeof(Mail));
+            h_tail = reinterpret_cast<E2*>(reinterpret_cast<char*>(mail) + MAIL_BYTES);
+            const char* e = getenv("HG_SEQ_HOST_TAIL");
+            host_tail_entries = e && *e ? (size_t)atol(e) : 1024;   // (c3, mode 3: 39.4 ms without, 38.8 at 512, 37.8 at 1024, 40.5 at 2048)
+            if (host_tail_entries > HOST_TAIL_CAP) host_tail_entries = HOST_TAIL_CAP;
         }
     }
     ~SeqProver() {
@@ -596,6 +637,123 @@ struct SeqProver {
         if (in_base) k_sq_round<KIND, u64><<<grid, 256, 0, st>>>(d_job, rd, jb_log2, d_chain, ctx->d_partials, d_ticket, d_res());
         else k_sq_round<KIND, E2><<<grid, 256, 0, st>>>(d_job, rd, jb_log2, d_chain, ctx->d_partials, d_ticket, d_res());
     }
+    // The last rounds of a sum-check on the host. Once the tables are small a round is nothing but latency on the device (kernel
+    // start, cold loads, the mailbox trip: 11-20 us); a host core does the same round in the time of its arithmetic alone. The
+    // device runs rounds 0 .. R-1, k_sq_export hands T_(R-1) over, and from there: fold with r_(R-1), sums, transcript, fold, ...
+    // exactly the kernels' definitions (T_rd[j] = fold of T_(rd-1)[2j], [2j+1]; weights were multiplied in by the first fold, R >= 2).
+    int host_tail_start(const SqJob& J) const {
+        if (!host_tail_entries || !h_tail) return 0;
+        for (int R = 2; R < J.nvars; R++)
+            if (((size_t)J.ntab << (J.nvars - R + 1)) <= host_tail_entries && J.nvars - R + 1 <= 24) return R;
+        return 0;
+    }
+    std::vector<E2> tail_a, tail_b;
+    // host arithmetic of the tail: products accumulated as 128-bit integers (+ carry), one reduction per extension-field coefficient
+    struct Acc { unsigned __int128 v = 0; u64 hi = 0; void add(u64 a, u64 b) { const unsigned __int128 p = (unsigned __int128)a * b; v += p; hi += v < p; } };
+    static u64 acc_reduce(const Acc& a) {   // v + hi 2^128 mod p; 2^128 = -2^32 (mod p)
+        u64 r = gl_reduce128((u64)a.v, (u64)(a.v >> 64));
+        if (a.hi) r = gl_sub(r, gl_mul(a.hi % GL_P, (u64)1 << 32));
+        return r;
+    }
+    struct MulBy {   // x -> r * x for a fixed r
+        u64 r0, r1, r1_7;
+        explicit MulBy(E2 r) : r0(r.c0), r1(r.c1), r1_7(gl_mul7_lazy(r.c1)) {}
+        E2 operator()(E2 d) const {
+            Acc c0, c1;
+            c0.add(r0, d.c0); c0.add(r1_7, d.c1);
+            c1.add(r0, d.c1); c1.add(r1, d.c0);
+            return e2(acc_reduce(c0), acc_reduce(c1));
+        }
+    };
+    struct DotAcc {  // sum of products of extension-field elements, reduced once
+        Acc c0, c1;
+        void add(E2 a, E2 b) { c0.add(a.c0, b.c0); c0.add(gl_mul7_lazy(a.c1), b.c1); c1.add(a.c0, b.c1); c1.add(a.c1, b.c0); }
+        E2 value() const { return e2(acc_reduce(c0), acc_reduce(c1)); }
+    };
+    SqInstall inst;
+    void put_result(E2* where, E2 v) {   // a final evaluation: the result buffer is host memory (use_mail), anything else is device memory
+        const E2* lo = ctx->h_res;
+        if (where >= lo && where < lo + ctx->res_cap) { *where = v; return; }
+        if (inst.nres >= 2 * dev::PS_MAX_PAIRS) throw Error("host tail: too many device-side results");
+        inst.res_dst[inst.nres] = where; inst.res[inst.nres] = v; inst.nres++;
+    }
+    void host_tail(const SqJob& J, int R, E2& claim) {
+        const int ntab = J.ntab, nvars = J.nvars, deg = J.kind == 1 ? 3 : 2;
+        size_t len = (size_t)1 << (nvars - R + 1);                 // entries per table of T_(R-1)
+        const E2* prev = h_tail;
+        std::vector<E2>* bufs[2] = {&tail_a, &tail_b};
+        E2 r = chain[J.r_off + R - 1];
+        auto fold = [](E2 x, E2 y, E2 rr) { return e2_add(x, e2_mul(rr, e2_sub(y, x))); };
+        for (int rd = R; rd < nvars; rd++) {
+            const size_t half = len >> 1;
+            std::vector<E2>& cur = *bufs[rd & 1];
+            cur.resize((size_t)ntab * half);
+            const MulBy times_r(r);
+            for (int t = 0; t < ntab; t++) {
+                const E2* pp = prev + (size_t)t * len;
+                E2* cc = cur.data() + (size_t)t * half;
+                for (size_t i = 0; i < half; i++) cc[i] = e2_add(pp[2 * i], times_r(e2_sub(pp[2 * i + 1], pp[2 * i])));
+            }
+            len = half;
+            prev = cur.data();
+            const size_t pairs = len >> 1;
+            E2 sums[3] = {e2_zero(), e2_zero(), e2_zero()};
+            if (J.kind == 2) {
+                DotAcc d0, d2;
+                for (int u = 0; u < ntab / 2; u++) {
+                    const E2 *A = prev + (size_t)(2 * u) * len, *B = prev + (size_t)(2 * u + 1) * len;
+                    for (size_t j = 0; j < pairs; j++) {
+                        const E2 ax = A[2 * j], ay = A[2 * j + 1], bx = B[2 * j], by = B[2 * j + 1];
+                        d0.add(ax, bx);
+                        d2.add(e2_sub(e2_dbl(ay), ax), e2_sub(e2_dbl(by), bx));
+                    }
+                }
+                sums[0] = d0.value(); sums[1] = d2.value();
+            } else if (J.kind == 0) {   // sum_j p_0(j) * sum_u p_u(j) at t = 0 and t = 2 (the tables carry their weights already)
+                for (size_t j = 0; j < pairs; j++) {
+                    E2 s0 = e2_zero(), s2 = e2_zero(), q0 = e2_zero(), q2 = e2_zero();
+                    for (int u = 0; u < ntab; u++) {
+                        const E2 X = prev[(size_t)u * len + 2 * j], Y = prev[(size_t)u * len + 2 * j + 1];
+                        const E2 v2 = e2_sub(e2_dbl(Y), X);
+                        if (u == 0) { q0 = X; q2 = v2; }
+                        s0 = e2_add(s0, X); s2 = e2_add(s2, v2);
+                    }
+                    sums[0] = e2_add(sums[0], e2_mul(q0, s0));
+                    sums[1] = e2_add(sums[1], e2_mul(q2, s2));
+                }
+            } else {                    // sum_j l_0(j) * sum_u l_u(j) r_u(j) at t = 0, 2, 3
+                for (size_t j = 0; j < pairs; j++) {
+                    E2 s0 = e2_zero(), s2 = e2_zero(), s3 = e2_zero(), q0 = e2_zero(), q2 = e2_zero(), q3 = e2_zero();
+                    for (int u = 0; u < ntab / 2; u++) {
+                        const E2 *Lp = prev + (size_t)(2 * u) * len + 2 * j, *Rp = prev + (size_t)(2 * u + 1) * len + 2 * j;
+                        const E2 lx = Lp[0], ly = Lp[1], rx = Rp[0], ry = Rp[1];
+                        const E2 dl = e2_sub(ly, lx), dr = e2_sub(ry, rx);
+                        const E2 l2 = e2_add(ly, dl), r2 = e2_add(ry, dr), l3 = e2_add(l2, dl), r3 = e2_add(r2, dr);
+                        if (u == 0) { q0 = lx; q2 = l2; q3 = l3; }
+                        s0 = e2_add(s0, e2_mul(lx, rx)); s2 = e2_add(s2, e2_mul(l2, r2)); s3 = e2_add(s3, e2_mul(l3, r3));
+                    }
+                    sums[0] = e2_add(sums[0], e2_mul(q0, s0));
+                    sums[1] = e2_add(sums[1], e2_mul(q2, s2));
+                    sums[2] = e2_add(sums[2], e2_mul(q3, s3));
+                }
+            }
+            r = round_message(sums, deg, claim, false);
+            n_host_rounds++;
+        }
+        inst.nres = 0;
+        for (int t = 0; t < ntab; t++) {   // k_sq_final: the last two entries folded with the last challenge
+            const E2 v = fold(prev[(size_t)t * 2], prev[(size_t)t * 2 + 1], r);
+            put_result(J.kind == 2 ? J.fin[t] : J.final_out + t, v);
+        }
+        // the challenges the device has not seen (r_(R-1) onwards) go into its table behind everything enqueued so far
+        const size_t first = J.r_off + R - 1, cnt = (size_t)(nvars - R + 1);
+        if (cnt > 24) throw Error("host tail: more rounds than the install launch carries");
+        inst.chain_dst = d_chain + first;
+        inst.nchain = (int)cnt;
+        for (size_t i = 0; i < cnt; i++) inst.chain[i] = chain[first + i];
+        k_sq_install<<<1, 64, 0, st>>>(inst);
+    }
+
     // J: kind, ntab, nvars, tables, final destinations, pw filled in by the caller. Enqueues every round and the final fold, then
     // answers the rounds in order. Returns the chain position of the point.
     size_t run_sq(SqJob& J, bool in_base, E2& claim) {
@@ -613,7 +771,10 @@ struct SeqProver {
         J.buf[0] = ctx->alloc_n<E2>((size_t)J.ntab * std::max<size_t>(N / 4, 1));
         J.mail = mail;
         J.seq0 = mail_seq + 1;
-        mail_seq += (unsigned long long)nvars;
+        const int R = host_tail_start(J);          // 0: every round on the device
+        J.dev_rounds = R;
+        const int ndev = R ? R : nvars;            // rounds on the device; one more launch behind them (export or final fold)
+        mail_seq += (unsigned long long)ndev + (R ? 1 : 0);
         const double te0 = now_ms();
         where = J.kind == 0 ? "collation round" : J.kind == 1 ? "grand-product round" : "pair-product round";
         const SqJob* d_job = nullptr;
@@ -626,8 +787,9 @@ struct SeqProver {
             Slow sl(this, "enqueueing a round");
             const int rd = enq;
             enq++;
-            if (rd == nvars) {
-                if (in_base) k_sq_final<u64><<<(J.ntab + 63) / 64, 64, 0, st>>>(d_job, d_chain);
+            if (rd == ndev) {
+                if (R) k_sq_export<<<1, 256, 0, st>>>(J.buf[(R - 1) & 1], (unsigned)((size_t)J.ntab << (nvars - R + 1)), h_tail, mail, J.seq0 + (unsigned long long)R);
+                else if (in_base) k_sq_final<u64><<<(J.ntab + 63) / 64, 64, 0, st>>>(d_job, d_chain);
                 else k_sq_final<E2><<<(J.ntab + 63) / 64, 64, 0, st>>>(d_job, d_chain);
                 return;
             }
@@ -637,12 +799,12 @@ struct SeqProver {
             else if (J.kind == 1) launch_round<1>(in_base, d_job, rd, jb, grid);
             else launch_round<2>(in_base, d_job, rd, jb, grid);
         };
-        while (enq < std::min(nvars + 1, LOOKAHEAD)) enqueue_round();
+        while (enq < std::min(ndev + 1, LOOKAHEAD)) enqueue_round();
         t_enqueue_rounds += now_ms() - te0;
-        for (int rd = 0; rd < nvars; rd++) {
+        for (int rd = 0; rd < ndev; rd++) {
             // answering is what the device waits for: a launch is squeezed in first only while the round's sums are not there yet
             const unsigned long long seq = J.seq0 + (unsigned long long)rd;
-            while (enq <= nvars && enq < rd + 2 * LOOKAHEAD && (enq < rd + 2 || __atomic_load_n(&mail->gpu_seq, __ATOMIC_ACQUIRE) < seq)) {
+            while (enq <= ndev && enq < rd + 2 * LOOKAHEAD && (enq < rd + 2 || __atomic_load_n(&mail->gpu_seq, __ATOMIC_ACQUIRE) < seq)) {
                 const double t1 = now_ms(); enqueue_round(); t_enqueue_rounds += now_ms() - t1;
             }
             const double w0 = t_wait_rounds;
@@ -650,9 +812,19 @@ struct SeqProver {
             const int big = nvars - 1 - rd > 8 ? 1 : 0;   // (statistics only)
             t_kind[J.kind][big] += t_wait_rounds - w0; n_kind[J.kind][big]++;
         }
-        while (enq <= nvars) enqueue_round();
+        while (enq <= ndev) enqueue_round();
+        if (R) {
+            const double w0 = now_ms(), r0 = t_wait_rounds;
+            mail_wait(J.seq0 + (unsigned long long)R);   // the tables are in h_tail
+            t_wait_rounds = r0;
+            t_wait_export += now_ms() - w0;
+            const double h0 = now_ms();
+            host_tail(J, R, claim);
+            t_host_tail += now_ms() - h0;
+        }
         return point_off;
     }
+    double t_wait_export = 0, t_host_tail = 0;
 
     // ---- prove_sum_check, stride layout (collation / grand-product shapes) ------------------------------------------------
     // tables: ntab rows at `in + t * in_stride` (u64 if base else E2). final evaluations land in d_res[evals_slot ..).
@@ -1154,6 +1326,7 @@ ProveResult prove_resident_mode(hg_ctx* ctx, const hg_pk* pk, const hg_values* v
         fprintf(stderr, "[hg] mode %d: %.2f ms; host waited %.2f ms for round sums (%zu round trips), %.2f ms for other results, spent %.2f ms enqueueing rounds\n", mode,
                 res.prove_ms, P.t_wait_rounds, P.n_mail, P.t_wait_results, P.t_enqueue_rounds);
     if (getenv("HG_SEQ_TIMES")) fprintf(stderr, "[hg]   host transcript steps between 'sums seen' and 'challenge posted': %.2f ms in total\n", P.t_answer);
+    if (getenv("HG_SEQ_TIMES")) fprintf(stderr, "[hg]   rounds finished on the host: %zu in %.2f ms, after waiting %.2f ms for their tables\n", P.n_host_rounds, P.t_host_tail, P.t_wait_export);
 #ifdef HG_SEQ_STAMPS
     if (P.mail && P.mail->dbg[3])
         fprintf(stderr, "[hg]   device clocks per round (us): kernel start -> sums %.2f, sums -> posted %.2f, posted -> answered %.2f (%llu rounds)\n",

@@ -362,10 +362,11 @@ def test_strict_memory_model_build_is_bit_exact():
     assert r.returncode == 0 and "STRICT OK" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
 
 
-@pytest.mark.parametrize("switch", ["HG_SEQ_CLASSIC=1", "HG_SEQ_NO_MAIL=1", "HG_SEQ_SYNC_EVERY=1", "HG_SEQ_SYNC_EVERY=0"])
+@pytest.mark.parametrize("switch", ["HG_SEQ_CLASSIC=1", "HG_SEQ_NO_MAIL=1", "HG_SEQ_SYNC_EVERY=1", "HG_SEQ_SYNC_EVERY=0", "HG_SEQ_HOST_TAIL=0", "HG_SEQ_HOST_TAIL=64", "HG_SEQ_HOST_TAIL=8192"])
 def test_sequential_prover_switches_stay_bit_exact(switch):
     """The sequential prover's alternatives - the fast path's round kernels run twice per round through the mailbox (CLASSIC), one
-    stream synchronisation per round instead of the mailbox (NO_MAIL), a real synchronisation at every / no drain point - give the
+    stream synchronisation per round instead of the mailbox (NO_MAIL), a real synchronisation at every / no drain point, the last
+    rounds of every sum-check on the device (HOST_TAIL=0) or on the host from 64 / 8192 table entries on - give the
     oracle's bytes in modes 1 and 3 (child process: the library reads the switches once)."""
     import subprocess, sys
     from hglib import ROOT
@@ -410,7 +411,9 @@ def test_protocol_modes_at_the_headline_size(ctx):
     proof2, tm = bfv.prove(ctx, pk, w, mode=3)   # (second call: warm arena)
     assert proof2 == ref
     print("mode 3 n=32768 k=16: prove %.1f ms, %d stream synchronisations, %d mailbox round trips" % (tm["prove_ms"], int(tm["sync_ms"]), int(tm["enqueue_ms"])))
-    assert int(tm["sync_ms"]) <= 128 and int(tm["enqueue_ms"]) >= 1800   # the rounds go through the mailbox; what is left: a real synchronisation at every fourth drain point
+    # the device's rounds go through the mailbox (the last rounds of a sum-check run on the host: of the 1800 rounds about 1000 are
+    # round trips); what is left of synchronisations: a real one at every fourth drain point
+    assert int(tm["sync_ms"]) <= 128 and 600 <= int(tm["enqueue_ms"]) <= 1800
     pk.free()
 
 
