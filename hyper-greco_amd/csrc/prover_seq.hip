@@ -92,7 +92,11 @@ struct Mail {
     unsigned long long timeouts;  // device-side waits that gave up
     unsigned long long pad;
     E2 chal[4];
-    unsigned long long dbg[8];    // -DHG_SEQ_STAMPS: device clock (100 MHz) at kernel start, after the block sum, after the post, after the answer
+    unsigned long long dbg[8];    // -DHG_SEQ_STAMPS: device clock (100 MHz) differences, see k_sq_round
+    // round sums of the fused round kernels: one 16-byte store per base-field word, the word and the message number side by side.
+    // A slot is written by ONE store instruction of one lane and arrives as one write: the host that reads `tag == seq` reads the
+    // value that came with it. No store has to be waited for before a separate "posted" word (1.4-2.4 us per round).
+    struct Slot { unsigned long long v, tag; } slot[32];
 };
 __global__ void k_mail(Mail* m, unsigned long long seq, E2* chain_dst, dev::StJob* patch, int npw) {   // one wave
     __shared__ E2 s_r;
@@ -144,6 +148,19 @@ struct SqJob {
     int pad_;                  //      of them posts its sums and does not wait for the challenge
     E2 pw[dev::PW_MAX];
 };
+// what a round launch is told besides the job (kernel arguments: nothing here waits for a load of the job descriptor)
+struct SqArgs {
+    int rd, jb_log2;
+    E2* chain_prev;                  // where r_(rd-1) goes in the device's challenge table (rd > 0)
+    unsigned long long* ready;       // device word: the number of the last message whose answer is in the table
+    Mail* mail;
+    unsigned long long seq;          // this round's message number; the round before has seq - 1
+    E2* partials;
+    unsigned* ticket;
+    const E2* src;                   // rd >= 2: T_(rd-1), table t at src + t * 2^(nvars-rd+1)
+    E2* dst;                         // rd >= 1: T_rd
+    int kind, ntab, nvars, last;     // (copies of the job's; last: the host takes over after this round, run_sq)
+};
 template <typename T> __device__ __forceinline__ E2 sq_ld(const T* p, size_t i);
 template <> __device__ __forceinline__ E2 sq_ld<u64>(const u64* p, size_t i) { return e2(p[i], 0); }
 template <> __device__ __forceinline__ E2 sq_ld<E2>(const E2* p, size_t i) { return p[i]; }
@@ -153,15 +170,16 @@ __device__ __forceinline__ E2 sq_fold_base(u64 x, u64 y, E2 r) { return e2_add_f
 // (X, Y) = entries 2j, 2j+1 of table `t` in round rd; rd >= 1: folded on the fly from the four entries 4j .. 4j+3 of the round before
 // and stored. `wmul`: multiply by w (the first fold of a weighted table).
 template <typename TIN>
-__device__ __forceinline__ void sq_pair(const SqJob& J, int rd, int t, size_t j, E2 r_prev, bool wmul, E2 w, E2& X, E2& Y) {
-    const size_t len_prev = (size_t)1 << (J.nvars - rd + 1), len = len_prev >> 1;
+__device__ __forceinline__ void sq_pair(const SqJob& J, const SqArgs& A, int t, size_t j, E2 r_prev, bool wmul, E2 w, E2& X, E2& Y) {
+    const int rd = A.rd;
+    const size_t len_prev = (size_t)1 << (A.nvars - rd + 1), len = len_prev >> 1;
     if (rd == 0) {
-        const TIN* p = J.kind == 2 ? static_cast<const TIN*>(J.tab[t]) : static_cast<const TIN*>(J.in) + (size_t)t * J.in_stride;
+        const TIN* p = A.kind == 2 ? static_cast<const TIN*>(J.tab[t]) : static_cast<const TIN*>(J.in) + (size_t)t * J.in_stride;
         X = sq_ld<TIN>(p, 2 * j); Y = sq_ld<TIN>(p, 2 * j + 1);
         return;
     }
     if (rd == 1) {
-        const TIN* p = J.kind == 2 ? static_cast<const TIN*>(J.tab[t]) : static_cast<const TIN*>(J.in) + (size_t)t * J.in_stride;
+        const TIN* p = A.kind == 2 ? static_cast<const TIN*>(J.tab[t]) : static_cast<const TIN*>(J.in) + (size_t)t * J.in_stride;
         if constexpr (sizeof(TIN) == 8) {
             X = sq_fold_base(p[4 * j], p[4 * j + 1], r_prev); Y = sq_fold_base(p[4 * j + 2], p[4 * j + 3], r_prev);
         } else {
@@ -169,19 +187,20 @@ __device__ __forceinline__ void sq_pair(const SqJob& J, int rd, int t, size_t j,
         }
         if (wmul) { X = e2_mul(X, w); Y = e2_mul(Y, w); }
     } else {
-        const E2* p = J.buf[(rd - 1) & 1] + (size_t)t * len_prev;
+        const E2* p = A.src + (size_t)t * len_prev;
         X = sq_fold(p[4 * j], p[4 * j + 1], r_prev); Y = sq_fold(p[4 * j + 2], p[4 * j + 3], r_prev);
     }
-    E2* o = J.buf[rd & 1] + (size_t)t * len;
+    E2* o = A.dst + (size_t)t * len;
     o[2 * j] = X; o[2 * j + 1] = Y;
 }
 // kind 2's b tables are E2 whatever the a tables are
-__device__ __forceinline__ void sq_pair_b(const SqJob& J, int rd, int t, size_t j, E2 r_prev, E2& X, E2& Y) {
-    const size_t len_prev = (size_t)1 << (J.nvars - rd + 1), len = len_prev >> 1;
+__device__ __forceinline__ void sq_pair_b(const SqJob& J, const SqArgs& A, int t, size_t j, E2 r_prev, E2& X, E2& Y) {
+    const int rd = A.rd;
+    const size_t len_prev = (size_t)1 << (A.nvars - rd + 1), len = len_prev >> 1;
     if (rd == 0) { const E2* p = static_cast<const E2*>(J.tab[t]); X = p[2 * j]; Y = p[2 * j + 1]; return; }
-    const E2* p = rd == 1 ? static_cast<const E2*>(J.tab[t]) : J.buf[(rd - 1) & 1] + (size_t)t * len_prev;
+    const E2* p = rd == 1 ? static_cast<const E2*>(J.tab[t]) : A.src + (size_t)t * len_prev;
     X = sq_fold(p[4 * j], p[4 * j + 1], r_prev); Y = sq_fold(p[4 * j + 2], p[4 * j + 3], r_prev);
-    E2* o = J.buf[rd & 1] + (size_t)t * len;
+    E2* o = A.dst + (size_t)t * len;
     o[2 * j] = X; o[2 * j + 1] = Y;
 }
 
@@ -213,73 +232,94 @@ template <int NV> __device__ __forceinline__ void sq_block_sum(E2* acc, E2 (*sm)
     }
     __syncthreads();
 }
-// the last-arriving workgroup's thread 0: sums -> host memory, post, wait for the challenge, install it
-__device__ __forceinline__ void sq_mail_epilogue(const SqJob& J, int rd, const E2* total, E2* res, E2* chain_w, long long t_start = 0) {
-#ifdef HG_SEQ_STAMPS
-    const long long t_sum = wall_clock64();
-#endif
-    for (int t = 0; t < J.nv; t++) {
-        __hip_atomic_store(&res[J.sums_slot + (size_t)rd * J.nv + t].c0, total[t].c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&res[J.sums_slot + (size_t)rd * J.nv + t].c1, total[t].c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    Mail* m = J.mail;
-    const unsigned long long seq = J.seq0 + (unsigned long long)rd;
-    // The sums were written by THIS thread with system-scope atomic stores (written through, across PCIe in order): their completion
-    // (vmcnt) is all the post must be ordered after. A formal release would write back the whole L2 - the folded tables this kernel
-    // has just written for the NEXT kernel, which the kernel boundary orders anyway - and an acquire load in the poll loop would
-    // invalidate it on every iteration. gfx942 / gfx950 only (stores tracked by vmcnt), like the ticket above.
+__device__ __forceinline__ void sq_store_slot(Mail::Slot* s, u64 v, unsigned long long tag) {
 #if defined(HG_STRICT_TICKETS) || (defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__))
-    __hip_atomic_store(&m->gpu_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&s->v, (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&s->tag, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 #else
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_store(&m->gpu_seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 w = {(unsigned)v, (unsigned)(v >> 32), (unsigned)tag, (unsigned)(tag >> 32)};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(s), "v"(w) : "memory");   // one write-through store to system scope
 #endif
-    if (J.dev_rounds && rd == J.dev_rounds - 1) return;   // the host takes over from here (its answer to this round never comes to the device)
-    const long long t0 = wall_clock64();
-    while (__hip_atomic_load(&m->cpu_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {   // (the answer is read with system-scope atomic loads below)
-        if (wall_clock64() - t0 > 500000000ll) { __hip_atomic_fetch_add(&m->timeouts, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
-        __builtin_amdgcn_s_sleep(2);
+}
+// the last-arriving workgroup's thread 0: the sums go to the host, tagged with the message number; nothing is waited for - the NEXT
+// launch's first workgroup picks the answer up (sq_wait_challenge), so that its launch and its first loads overlap the round trip
+__device__ __forceinline__ void sq_post_sums(const SqArgs& A, const E2* total, int nv) {
+    for (int t = 0; t < nv; t++) {
+        sq_store_slot(&A.mail->slot[2 * t], total[t].c0, A.seq);
+        sq_store_slot(&A.mail->slot[2 * t + 1], total[t].c1, A.seq);
     }
-#ifdef HG_SEQ_STAMPS
-    const long long t_ans = wall_clock64();
-    m->dbg[0] += (unsigned long long)(t_sum - t_start); m->dbg[1] += (unsigned long long)(t0 - t_sum); m->dbg[2] += (unsigned long long)(t_ans - t0); m->dbg[3] += 1;
+}
+// r of the message `seq_prev`: workgroup 0's thread 0 takes it from the mailbox (waiting for the host if need be), writes it into the
+// device's challenge table and raises `ready`; the other workgroups wait for `ready`. Returns r to every thread of the workgroup.
+__device__ __forceinline__ E2 sq_wait_challenge(Mail* m, unsigned long long seq_prev, E2* chain_slot, unsigned long long* ready, E2* s_r) {
+    if (threadIdx.x == 0) {
+        E2 r;
+        const long long t0 = wall_clock64();
+        if (blockIdx.x == 0) {
+            while (__hip_atomic_load(&m->cpu_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < seq_prev) {
+                if (wall_clock64() - t0 > 500000000ll) { __hip_atomic_fetch_add(&m->timeouts, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }   // 5 s
+                __builtin_amdgcn_s_sleep(2);
+            }
+            r.c0 = __hip_atomic_load(&m->chal[0].c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            r.c1 = __hip_atomic_load(&m->chal[0].c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&chain_slot->c0, r.c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&chain_slot->c1, r.c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if defined(HG_STRICT_TICKETS) || (defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__))
+            __hip_atomic_store(ready, seq_prev, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (this thread's two write-through stores are complete)
+            __hip_atomic_store(ready, seq_prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
-    E2 r;
-    r.c0 = __hip_atomic_load(&m->chal[0].c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    r.c1 = __hip_atomic_load(&m->chal[0].c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    chain_w[J.r_off + rd] = r;
+        } else {
+#if defined(HG_STRICT_TICKETS) || (defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__))
+            while (__hip_atomic_load(ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < seq_prev) {
+#else
+            while (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seq_prev) {
+#endif
+                if (wall_clock64() - t0 > 600000000ll) break;
+                __builtin_amdgcn_s_sleep(8);
+            }
+            r.c0 = __hip_atomic_load(&chain_slot->c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            r.c1 = __hip_atomic_load(&chain_slot->c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        *s_r = r;
+    }
+    __syncthreads();
+    return *s_r;
 }
 
 // the hypercube sums of round rd over this workgroup's share of the pair indices (tiles tile0, tile0 + step, ...), folding the round
 // before on the fly (see above); acc[t] += ... for t = 0, 2 [, 3]
 template <int KIND, typename TIN>
-__device__ __forceinline__ void sq_round_sums(const SqJob& J, int rd, int jb_log2, E2 r_prev, size_t tile0, size_t tile_step, E2* acc, E2 (*sm)[256]) {
+__device__ __forceinline__ void sq_round_sums(const SqJob& J, const SqArgs& A, E2 r_prev, size_t tile0, size_t tile_step, E2* acc, E2 (*sm)[256]) {
     constexpr int NV = KIND == 1 ? 3 : 2;
-    const int hl = J.nvars - 1 - rd;                 // log2 of this round's pair count
+    const int rd = A.rd, jb_log2 = A.jb_log2;
+    const int hl = A.nvars - 1 - rd;                 // log2 of this round's pair count
     const size_t h = (size_t)1 << hl;
     // 2^jb_log2 of the 256 threads run along the pair index j, the other 256 / 2^jb_log2 groups split the tables (host: sq_plan)
     const int JB = 1 << jb_log2, G = 256 >> jb_log2;
     const int jj = threadIdx.x & (JB - 1), g = threadIdx.x >> jb_log2;
     const size_t ntiles = h >> jb_log2;
-    const int units = KIND == 0 ? J.ntab : J.ntab / 2;
+    const int units = KIND == 0 ? A.ntab : A.ntab / 2;
     for (size_t tile = tile0; tile < ntiles; tile += tile_step) {
         const size_t j = (tile << jb_log2) + jj;
         E2 s[NV], q[NV];
 #pragma unroll
         for (int t = 0; t < NV; t++) { s[t] = e2_zero(); q[t] = e2_zero(); }
         for (int u = g; u < units; u += G) {
-            const E2 w = KIND == 2 ? e2_one() : J.pw[u];
+            const E2 w = (KIND == 2 || rd > 1) ? e2_one() : J.pw[u];   // (weights: round 0's products, round 1's first fold)
             if (KIND == 0) {
                 E2 X, Y;
-                sq_pair<TIN>(J, rd, u, j, r_prev, rd == 1 && u > 0, w, X, Y);
+                sq_pair<TIN>(J, A, u, j, r_prev, rd == 1 && u > 0, w, X, Y);
                 const E2 v2 = e2_sub(e2_dbl(Y), X);
                 if (u == 0) { q[0] = X; q[1] = v2; }
                 if (rd == 0) { s[0] = e2_add(s[0], e2_mul_f(X, w.c0)); s[1] = e2_add(s[1], e2_mul_f(v2, w.c0)); }   // M^i is a base-field constant
                 else { s[0] = e2_add(s[0], X); s[1] = e2_add(s[1], v2); }
             } else if (KIND == 1) {
                 E2 lx, ly, rx, ry;
-                sq_pair<TIN>(J, rd, 2 * u, j, r_prev, rd == 1 && u > 0, w, lx, ly);
-                sq_pair<TIN>(J, rd, 2 * u + 1, j, r_prev, false, w, rx, ry);
+                sq_pair<TIN>(J, A, 2 * u, j, r_prev, rd == 1 && u > 0, w, lx, ly);
+                sq_pair<TIN>(J, A, 2 * u + 1, j, r_prev, false, w, rx, ry);
                 const E2 dl = e2_sub(ly, lx), dr = e2_sub(ry, rx);
                 const E2 l2 = e2_add(ly, dl), r2 = e2_add(ry, dr), l3 = e2_add(l2, dl), r3 = e2_add(r2, dr);
                 if (u == 0) { q[0] = lx; q[1] = l2; q[NV - 1] = l3; }
@@ -288,8 +328,8 @@ __device__ __forceinline__ void sq_round_sums(const SqJob& J, int rd, int jb_log
                 s[0] = e2_add(s[0], p0); s[1] = e2_add(s[1], p2); s[NV - 1] = e2_add(s[NV - 1], p3);
             } else {
                 E2 ax, ay, bx, by;
-                sq_pair<TIN>(J, rd, 2 * u, j, r_prev, false, w, ax, ay);
-                sq_pair_b(J, rd, 2 * u + 1, j, r_prev, bx, by);
+                sq_pair<TIN>(J, A, 2 * u, j, r_prev, false, w, ax, ay);
+                sq_pair_b(J, A, 2 * u + 1, j, r_prev, bx, by);
                 const E2 a2 = e2_sub(e2_dbl(ay), ax), b2 = e2_sub(e2_dbl(by), bx);
                 s[0] = e2_add(s[0], e2_mul(ax, bx)); s[1] = e2_add(s[1], e2_mul(a2, b2));
             }
@@ -331,62 +371,90 @@ __device__ __forceinline__ void sq_round_sums(const SqJob& J, int rd, int jb_log
     }
 }
 
+// A short round is a chain of dependent latencies (measured with -DHG_SEQ_STAMPS when the kernel still waited for its own answer:
+// kernel start -> sums 9-12 us with the job descriptor, the challenge and the table entries loaded one behind the other, sums ->
+// posted 1.4-2.4 us, posted -> answered 3.4 us). Now: addresses come with the kernel arguments, the entries of the first tile are
+// touched BEFORE the wait for the challenge of the round before (which overlaps the launch as well), the sums leave in tagged
+// stores that nothing waits for. (Passing the whole 2.2 KB job by value was measured earlier: slower, 13.6 us against 12.2.)
 template <int KIND, typename TIN>
-// (A short round is a chain of dependent memory latencies - job descriptor, challenge, table entries, all cold in this XCD's L2:
-// kernel start -> sums 9-12 us, sums -> posted 1.4-2.4 us, posted -> answered 3.4 us, measured with -DHG_SEQ_STAMPS. Passing the
-// 2.2 KB job by value in the kernel arguments instead of behind a pointer was measured: 13.6 us against 12.2, not kept.)
-__global__ __launch_bounds__(256) void k_sq_round(const SqJob* __restrict__ jp, int rd, int jb_log2, E2* chain, E2* __restrict__ partials, unsigned* ticket, E2* res) {
+__global__ __launch_bounds__(256) void k_sq_round(const SqJob* __restrict__ jp, const SqArgs A) {
     constexpr int NV = KIND == 1 ? 3 : 2;
     __shared__ E2 sm[NV][256];
     __shared__ unsigned s_last;
+    __shared__ E2 s_r;
     const SqJob& J = *jp;
+    const int rd = A.rd;
 #ifdef HG_SEQ_STAMPS
     const long long t_start = wall_clock64();
-#else
-    const long long t_start = 0;
 #endif
-    const E2 r_prev = rd > 0 ? chain[J.r_off + rd - 1] : e2_zero();
+    E2 r_prev = e2_zero();
+    if (rd > 0) {
+        if (rd >= 2) {   // warm this workgroup's first tile while the answer is on its way (the loads are repeated below, from the caches)
+            const int hl = A.nvars - 1 - rd, JB = 1 << A.jb_log2, G = 256 >> A.jb_log2;
+            const int jj = threadIdx.x & (JB - 1), g = threadIdx.x >> A.jb_log2;
+            const size_t ntiles = ((size_t)1 << hl) >> A.jb_log2, len_prev = (size_t)1 << (A.nvars - rd + 1);
+            if (blockIdx.x < ntiles) {
+                const size_t j = ((size_t)blockIdx.x << A.jb_log2) + jj;
+                u64 touch = 0;
+                const int step = KIND == 0 ? 1 : 2;
+                for (int t = g * step; t < A.ntab; t += G * step) {
+                    touch ^= A.src[(size_t)t * len_prev + 4 * j].c0;
+                    if (step == 2) touch ^= A.src[(size_t)(t + 1) * len_prev + 4 * j].c0;
+                }
+                asm volatile("" ::"v"(touch));
+            }
+        }
+        r_prev = sq_wait_challenge(A.mail, A.seq - 1, A.chain_prev, A.ready, &s_r);
+    }
+#ifdef HG_SEQ_STAMPS
+    const long long t_r = wall_clock64();
+#endif
     E2 acc[NV];
 #pragma unroll
     for (int t = 0; t < NV; t++) acc[t] = e2_zero();
-    sq_round_sums<KIND, TIN>(J, rd, jb_log2, r_prev, blockIdx.x, gridDim.x, acc, sm);
+    sq_round_sums<KIND, TIN>(J, A, r_prev, blockIdx.x, gridDim.x, acc, sm);
     sq_block_sum<NV>(acc, sm);
     const int nblocks = (int)gridDim.x;
-    if (nblocks == 1) {
-        if (threadIdx.x == 0) sq_mail_epilogue(J, rd, acc, res, chain, t_start);
-        return;
-    }
-    if (threadIdx.x == 0) {
-        for (int t = 0; t < NV; t++) {
-            __hip_atomic_store(&partials[(size_t)blockIdx.x * NV + t].c0, acc[t].c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&partials[(size_t)blockIdx.x * NV + t].c1, acc[t].c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        // (the partials were written through with agent-scope atomic stores by THIS thread: their completion - vmcnt - is all the
-        // ticket must be ordered after; a formal release would write back every dirty line of the L2, i.e. the folded tables this
-        // kernel streams out. gfx942 / gfx950 only: kernels.hip, finish_partials)
+    if (nblocks > 1) {
+        if (threadIdx.x == 0) {
+            for (int t = 0; t < NV; t++) {
+                __hip_atomic_store(&A.partials[(size_t)blockIdx.x * NV + t].c0, acc[t].c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&A.partials[(size_t)blockIdx.x * NV + t].c1, acc[t].c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // (the partials were written through with agent-scope atomic stores by THIS thread: their completion - vmcnt - is all the
+            // ticket must be ordered after; a formal release would write back every dirty line of the L2, i.e. the folded tables this
+            // kernel streams out. gfx942 / gfx950 only: kernels.hip, finish_partials)
 #if defined(HG_STRICT_TICKETS) || (defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__))
-        const unsigned tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned tk = __hip_atomic_fetch_add(A.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
 #else
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned tk = __hip_atomic_fetch_add(A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
-        s_last = tk == (unsigned)nblocks - 1 ? 1u : 0u;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    for (int t = 0; t < NV; t++) acc[t] = e2_zero();
-    for (int b = threadIdx.x; b < nblocks; b += 256)
-        for (int t = 0; t < NV; t++) {
-            E2 v;
-            v.c0 = __hip_atomic_load(&partials[(size_t)b * NV + t].c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            v.c1 = __hip_atomic_load(&partials[(size_t)b * NV + t].c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            acc[t] = e2_add(acc[t], v);
+            s_last = tk == (unsigned)nblocks - 1 ? 1u : 0u;
         }
-    sq_block_sum<NV>(acc, sm);
+        __syncthreads();
+        if (!s_last) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        for (int t = 0; t < NV; t++) acc[t] = e2_zero();
+        for (int b = threadIdx.x; b < nblocks; b += 256)
+            for (int t = 0; t < NV; t++) {
+                E2 v;
+                v.c0 = __hip_atomic_load(&A.partials[(size_t)b * NV + t].c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v.c1 = __hip_atomic_load(&A.partials[(size_t)b * NV + t].c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                acc[t] = e2_add(acc[t], v);
+            }
+        sq_block_sum<NV>(acc, sm);
+        if (threadIdx.x == 0) __hip_atomic_store(A.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (threadIdx.x == 0) {
-        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        sq_mail_epilogue(J, rd, acc, res, chain, t_start);
+#ifdef HG_SEQ_STAMPS
+        const long long t_sum = wall_clock64();
+#endif
+        sq_post_sums(A, acc, NV);
+#ifdef HG_SEQ_STAMPS
+        Mail* m = A.mail;   // (statistics of the posting workgroup: start -> challenge in hand, -> sums, -> stores issued)
+        m->dbg[0] += (unsigned long long)(t_r - t_start); m->dbg[1] += (unsigned long long)(t_sum - t_r); m->dbg[2] += (unsigned long long)(wall_clock64() - t_sum); m->dbg[3] += 1;
+#endif
     }
 }
 // thread mapping of a round with 2^hl pair indices and `units` table units (pairs / tables): as many groups along the units as
@@ -404,12 +472,13 @@ static inline void sq_plan(int hl, int units, int nblocks_max, int* jb_log2, int
 }
 // after the last round: table t's final evaluation = fold of its last two entries with the last challenge (weights: see above)
 template <typename TIN>
-__global__ void k_sq_final(const SqJob* __restrict__ jp, const E2* __restrict__ chain) {
+__global__ void k_sq_final(const SqJob* __restrict__ jp, const SqArgs A) {   // A: seq = the last round's + 1, chain_prev = the last challenge's place
+    __shared__ E2 s_r;
     const SqJob& J = *jp;
+    const E2 r = sq_wait_challenge(A.mail, A.seq - 1, A.chain_prev, A.ready, &s_r);
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= J.ntab) return;
     const int n = J.nvars;
-    const E2 r = chain[J.r_off + n - 1];
     E2 v;
     if (n == 1) {
         if (J.kind == 2 && (t & 1)) { const E2* p = static_cast<const E2*>(J.tab[t]); v = sq_fold(p[0], p[1], r); }
@@ -551,6 +620,12 @@ struct SeqProver {
         t_wait_rounds = r0;
         t_wait_results += now_ms() - t0;
     }
+    // the final evaluations of the sum-check just run: already in the result buffer when the host finished it (host_tail)
+    bool sq_results_on_host = false;
+    void wait_sumcheck_results() {
+        if (sq_results_on_host) { sq_results_on_host = false; return; }
+        wait_results();
+    }
     bool ext_mc() const { return (mode & 2) != 0; }
     // HG_SEQ_CLASSIC=1: the fast path's round kernels run twice per round (sums, then the fold once the challenge is known)
     static bool classic() { static const bool c = [] { const char* e = getenv("HG_SEQ_CLASSIC"); return e && e[0] == '1'; }(); return c; }
@@ -633,9 +708,55 @@ struct SeqProver {
 
     // ---- one sum-check through the fused round kernels and the mailbox ---------------------------------------------------------
     unsigned* d_ticket = nullptr;
-    template <int KIND> void launch_round(bool in_base, const SqJob* d_job, int rd, int jb_log2, int grid) {
-        if (in_base) k_sq_round<KIND, u64><<<grid, 256, 0, st>>>(d_job, rd, jb_log2, d_chain, ctx->d_partials, d_ticket, d_res());
-        else k_sq_round<KIND, E2><<<grid, 256, 0, st>>>(d_job, rd, jb_log2, d_chain, ctx->d_partials, d_ticket, d_res());
+    SqArgs round_args(const SqJob& J, int rd, int jb_log2) {
+        SqArgs A;
+        memset(&A, 0, sizeof(A));
+        A.rd = rd; A.jb_log2 = jb_log2;
+        A.chain_prev = rd > 0 ? d_chain + J.r_off + rd - 1 : nullptr;
+        A.ready = reinterpret_cast<unsigned long long*>(d_ticket + 2);
+        A.mail = mail;
+        A.seq = J.seq0 + (unsigned long long)rd;
+        A.partials = ctx->d_partials;
+        A.ticket = d_ticket;
+        A.src = rd >= 2 ? J.buf[(rd - 1) & 1] : nullptr;
+        A.dst = rd >= 1 ? J.buf[rd & 1] : nullptr;
+        A.kind = J.kind; A.ntab = J.ntab; A.nvars = J.nvars;
+        A.last = J.dev_rounds && rd == J.dev_rounds - 1;
+        return A;
+    }
+    template <int KIND> void launch_round(bool in_base, const SqJob& J, const SqJob* d_job, int rd, int jb_log2, int grid) {
+        const SqArgs A = round_args(J, rd, jb_log2);
+        if (in_base) k_sq_round<KIND, u64><<<grid, 256, 0, st>>>(d_job, A);
+        else k_sq_round<KIND, E2><<<grid, 256, 0, st>>>(d_job, A);
+    }
+    // host side of a fused round: the sums arrive in the mailbox's tagged slots
+    bool slots_posted(unsigned long long seq, int nslots) const {
+        for (int k = nslots - 1; k >= 0; k--)
+            if (__atomic_load_n(&mail->slot[k].tag, __ATOMIC_ACQUIRE) != seq) return false;
+        return true;
+    }
+    E2 answer_round(unsigned long long seq, int nv, int deg, E2& claim) {
+        const double t0 = now_ms();
+        unsigned spins = 0;
+        while (!slots_posted(seq, 2 * nv)) {
+            __builtin_ia32_pause();
+            if ((++spins & 0xFFFF) == 0) {
+                hip_check(hipGetLastError(), "round (mailbox)");
+                if (hipStreamQuery(st) == hipSuccess && !slots_posted(seq, 2 * nv)) throw Error("mailbox: the stream drained without posting");
+                if (now_ms() - t0 > 10000.0) throw Error("mailbox: no answer from the device within 10 s");
+            }
+        }
+        n_mail++;
+        const double t1 = now_ms();
+        t_wait_rounds += t1 - t0;
+        if (slow_log && t1 - t0 > 3.0) fprintf(stderr, "[hg] slow: waited %.2f ms for message %llu (%s)\n", t1 - t0, seq, where);
+        E2 sums[3];
+        for (int t = 0; t < nv; t++) sums[t] = e2(mail->slot[2 * t].v, mail->slot[2 * t + 1].v);
+        const E2 r = round_message(sums, deg, claim, false);
+        mail->chal[0] = r;
+        __atomic_store_n(&mail->cpu_seq, seq, __ATOMIC_RELEASE);
+        if (slow_log) t_answer += now_ms() - t1;
+        return r;
     }
     // The last rounds of a sum-check on the host. Once the tables are small a round is nothing but latency on the device (kernel
     // start, cold loads, the mailbox trip: 11-20 us); a host core does the same round in the time of its arithmetic alone. The
@@ -781,7 +902,7 @@ struct SeqProver {
         { Slow sl(this, "run_sq set-up (allocations, job upload)"); d_job = upload(&J, 1); }
         // the launches run a few rounds ahead of the answers: the device never waits for a launch, and the first round's answer does
         // not wait for the host to have enqueued the whole sum-check
-        const int LOOKAHEAD = 6;
+        const int LOOKAHEAD = 6;   // (how far the launches may run ahead of the answers; the first answer waits for two launches only)
         int enq = 0;
         auto enqueue_round = [&] {
             Slow sl(this, "enqueueing a round");
@@ -789,26 +910,26 @@ struct SeqProver {
             enq++;
             if (rd == ndev) {
                 if (R) k_sq_export<<<1, 256, 0, st>>>(J.buf[(R - 1) & 1], (unsigned)((size_t)J.ntab << (nvars - R + 1)), h_tail, mail, J.seq0 + (unsigned long long)R);
-                else if (in_base) k_sq_final<u64><<<(J.ntab + 63) / 64, 64, 0, st>>>(d_job, d_chain);
-                else k_sq_final<E2><<<(J.ntab + 63) / 64, 64, 0, st>>>(d_job, d_chain);
+                else if (in_base) k_sq_final<u64><<<(J.ntab + 63) / 64, 64, 0, st>>>(d_job, round_args(J, nvars, 0));
+                else k_sq_final<E2><<<(J.ntab + 63) / 64, 64, 0, st>>>(d_job, round_args(J, nvars, 0));
                 return;
             }
             int jb = 0, grid = 1;
             sq_plan(nvars - 1 - rd, J.kind == 0 ? J.ntab : J.ntab / 2, SQ_MAX_BLOCKS, &jb, &grid);
-            if (J.kind == 0) launch_round<0>(in_base, d_job, rd, jb, grid);
-            else if (J.kind == 1) launch_round<1>(in_base, d_job, rd, jb, grid);
-            else launch_round<2>(in_base, d_job, rd, jb, grid);
+            if (J.kind == 0) launch_round<0>(in_base, J, d_job, rd, jb, grid);
+            else if (J.kind == 1) launch_round<1>(in_base, J, d_job, rd, jb, grid);
+            else launch_round<2>(in_base, J, d_job, rd, jb, grid);
         };
-        while (enq < std::min(ndev + 1, LOOKAHEAD)) enqueue_round();
+        while (enq < std::min(ndev + 1, 2)) enqueue_round();
         t_enqueue_rounds += now_ms() - te0;
         for (int rd = 0; rd < ndev; rd++) {
             // answering is what the device waits for: a launch is squeezed in first only while the round's sums are not there yet
             const unsigned long long seq = J.seq0 + (unsigned long long)rd;
-            while (enq <= ndev && enq < rd + 2 * LOOKAHEAD && (enq < rd + 2 || __atomic_load_n(&mail->gpu_seq, __ATOMIC_ACQUIRE) < seq)) {
+            while (enq <= ndev && enq < rd + 2 * LOOKAHEAD && (enq < rd + 2 || !slots_posted(seq, 2 * J.nv))) {
                 const double t1 = now_ms(); enqueue_round(); t_enqueue_rounds += now_ms() - t1;
             }
             const double w0 = t_wait_rounds;
-            mail_answer(J.seq0 + (unsigned long long)rd, h_res() + J.sums_slot + (size_t)rd * J.nv, J.kind == 1 ? 3 : 2, claim);
+            answer_round(seq, J.nv, J.kind == 1 ? 3 : 2, claim);
             const int big = nvars - 1 - rd > 8 ? 1 : 0;   // (statistics only)
             t_kind[J.kind][big] += t_wait_rounds - w0; n_kind[J.kind][big]++;
         }
@@ -822,6 +943,7 @@ struct SeqProver {
             host_tail(J, R, claim);
             t_host_tail += now_ms() - h0;
         }
+        sq_results_on_host = R != 0;
         return point_off;
     }
     double t_wait_export = 0, t_host_tail = 0;
@@ -1032,7 +1154,7 @@ struct SeqProver {
             for (int b = 0; b < nb; b++) { pw.v[b] = g; claim = e2_add(claim, e2_mul(cl[b], g)); g = e2_mul(g, gamma); }  // prover.rs:281-286
             const size_t evals = slot(2 * (size_t)nb);
             point_off = sumcheck_stride(dev::SC_GRANDPROD, lev[k], !ext, h, 2 * nb, n, pw, claim, evals);
-            wait_results();
+            wait_sumcheck_results();
             // the kernels leave the final LEFT evaluation of pair b multiplied by pw[b] = gamma^b
             if (nb >= 2) {
                 if (pw.v[1].c0 == 0 && pw.v[1].c1 == 0) throw Error("grand product: zero batching weight");
@@ -1219,7 +1341,7 @@ struct SeqProver {
         }
         if (!gj.empty()) dev::gather_jobs(st, upload(gj.data(), gj.size()), (int)gj.size(), SR);
         const size_t rx_off = sumcheck_prodsum(a, b, nin, fa, fb, claim);  // Libra phase 1
-        wait_results();
+        wait_sumcheck_results();
         for (int i : li) {
             const E2 v = h_res()[u_base + i];
             tr.write_e(v);
@@ -1245,7 +1367,7 @@ struct SeqProver {
         }
         dev::gather_B_jobs(st, upload(bj.data(), bj.size()), (int)bj.size(), SR);
         const size_t ry_off = sumcheck_prodsum(a2, b2, nin, fa2, fb2, claim);
-        wait_results();
+        wait_sumcheck_results();
         for (int i : ri) {
             const E2 v = h_res()[w_base + i];
             tr.write_e(v);
@@ -1269,7 +1391,7 @@ struct SeqProver {
         const size_t u = slot(1);
         E2* scratch = ctx->alloc_n<E2>(1);
         const size_t off = sumcheck_prodsum({d_vals[n.preds[0]]}, {F}, L, {d_res() + u}, {scratch}, claim);
-        wait_results();
+        wait_sumcheck_results();
         const E2 v = h_res()[u];
         tr.write_e(v);
         claims[n.preds[0]].push_back(Claim{off, L, v});
@@ -1329,7 +1451,7 @@ ProveResult prove_resident_mode(hg_ctx* ctx, const hg_pk* pk, const hg_values* v
     if (getenv("HG_SEQ_TIMES")) fprintf(stderr, "[hg]   rounds finished on the host: %zu in %.2f ms, after waiting %.2f ms for their tables\n", P.n_host_rounds, P.t_host_tail, P.t_wait_export);
 #ifdef HG_SEQ_STAMPS
     if (P.mail && P.mail->dbg[3])
-        fprintf(stderr, "[hg]   device clocks per round (us): kernel start -> sums %.2f, sums -> posted %.2f, posted -> answered %.2f (%llu rounds)\n",
+        fprintf(stderr, "[hg]   device clocks per round, posting workgroup (us): kernel start -> challenge in hand %.2f, -> sums %.2f, -> tagged stores issued %.2f (%llu rounds)\n",
                 P.mail->dbg[0] / 100.0 / P.mail->dbg[3], P.mail->dbg[1] / 100.0 / P.mail->dbg[3], P.mail->dbg[2] / 100.0 / P.mail->dbg[3], P.mail->dbg[3]);
 #endif
     if (getenv("HG_SEQ_TIMES"))
