@@ -244,11 +244,16 @@ __device__ __forceinline__ void sq_store_slot(Mail::Slot* s, u64 v, unsigned lon
 }
 // the last-arriving workgroup's thread 0: the sums go to the host, tagged with the message number; nothing is waited for - the NEXT
 // launch's first workgroup picks the answer up (sq_wait_challenge), so that its launch and its first loads overlap the round trip
+// (one more slot carries the XOR of the words: the host takes a message only when it adds up - a slot that were ever delivered in two
+// halves would read as "not there yet", not as a wrong sum)
 __device__ __forceinline__ void sq_post_sums(const SqArgs& A, const E2* total, int nv) {
+    u64 x = 0;
     for (int t = 0; t < nv; t++) {
         sq_store_slot(&A.mail->slot[2 * t], total[t].c0, A.seq);
         sq_store_slot(&A.mail->slot[2 * t + 1], total[t].c1, A.seq);
+        x ^= total[t].c0 ^ total[t].c1;
     }
+    sq_store_slot(&A.mail->slot[2 * nv], x, A.seq);
 }
 // r of the message `seq_prev`: workgroup 0's thread 0 takes it from the mailbox (waiting for the host if need be), writes it into the
 // device's challenge table and raises `ready`; the other workgroups wait for `ready`. Returns r to every thread of the workgroup.
@@ -730,10 +735,12 @@ struct SeqProver {
         else k_sq_round<KIND, E2><<<grid, 256, 0, st>>>(d_job, A);
     }
     // host side of a fused round: the sums arrive in the mailbox's tagged slots
-    bool slots_posted(unsigned long long seq, int nslots) const {
-        for (int k = nslots - 1; k >= 0; k--)
+    bool slots_posted(unsigned long long seq, int nslots) const {   // nslots words + their XOR
+        for (int k = nslots; k >= 0; k--)
             if (__atomic_load_n(&mail->slot[k].tag, __ATOMIC_ACQUIRE) != seq) return false;
-        return true;
+        unsigned long long x = 0;
+        for (int k = 0; k < nslots; k++) x ^= __atomic_load_n(&mail->slot[k].v, __ATOMIC_RELAXED);
+        return x == __atomic_load_n(&mail->slot[nslots].v, __ATOMIC_RELAXED);
     }
     E2 answer_round(unsigned long long seq, int nv, int deg, E2& claim) {
         const double t0 = now_ms();
