@@ -670,6 +670,39 @@ def main():
                                       "note": "hg_prove_resident_mode(.., 3): median of 3 after one warm-up; the host transcript answers every round through a pinned mailbox"}
             except Exception as ex:
                 line["sound_mode"] = {"error": str(ex)}
+        if world == 1 and not args.no_end_to_end:
+            # BASELINE config 4 as far as one GPU can show it: the shares of 2 / 4 / 8 ranks run one after the other on this GPU, each
+            # from its own resident tables (hg_witness_gen_shard), each through its own launch graph; the partial result buffers are
+            # summed as the all-reduce would (hg_shard_combine_host) and replayed: the proof must be the single-GPU proof. Reported:
+            # the slowest rank's share (what a node of that many GPUs would wait for before its one collective).
+            try:
+                import numpy as np
+                proj = {}
+                for wsz in (2, 4, 8):
+                    svals = [hg.witness_gen_shard(ctx, pk, witnesses[0], r, wsz) for r in range(wsz)]
+                    per_rank, parts = [], []
+                    for r in range(wsz):
+                        ts = []
+                        for i in range(6):   # walk, walk, capture, three replays (a new begin replaces the pending share of the one before)
+                            t0 = time.perf_counter()
+                            part = hg.prove_shard_begin(ctx, pk, svals[r], r, wsz)
+                            ts.append((time.perf_counter() - t0) * 1e3)
+                        per_rank.append(sorted(ts[3:])[1])
+                        parts.append(part.copy())
+                    t0 = time.perf_counter()
+                    hg.prove_shard_combine(ctx, hg.shard_combine_host(np.stack(parts))[None, :], 1)
+                    same = hg.prove_shard_finish(ctx, out).bytes() == walked[0]
+                    t_fin = (time.perf_counter() - t0) * 1e3
+                    proj[str(wsz)] = {"slowest_rank_ms": round(max(per_rank), 3), "fastest_rank_ms": round(min(per_rank), 3), "combine_and_replay_ms": round(t_fin, 3),
+                                      "resident_MB_per_rank_max": round(max(v.info()["resident_bytes"] for v in svals) / 1e6, 1),
+                                      "proof_equals_single_gpu": bool(same)}
+                    assert same, "virtual ranks: the combined proof differs from the single-GPU proof"
+                    for v in svals:
+                        v.free()
+                line["config"]["shard_projection"] = dict(proj, note="ONE GPU running every rank's share in turn (no collective, no xGMI): per-rank wall time of hg_prove_shard_begin "
+                                                                     "from the rank's launch graph, median of 3; not a multi-GPU measurement")
+            except Exception as ex:
+                line["config"]["shard_projection"] = {"error": str(ex)}
         if world == 1 and not args.no_cpu_baseline:
             oracle_proofs = {}
             try:
