@@ -128,6 +128,7 @@ hg_ctx::~hg_ctx() {
     if (d_res && d_res != h_res) (void)hipFree(d_res);
     if (h_res) (void)hipHostFree(h_res);
     if (h_stage) (void)hipHostFree(h_stage);
+    if (h_mailbox) (void)hipHostFree(h_mailbox);
     if (d_partials) (void)hipFree(d_partials);
     if (d_partials2) (void)hipFree(d_partials2);
     if (comm) { try { hg::comm_destroy(this); } catch (...) {} }

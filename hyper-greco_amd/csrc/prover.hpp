@@ -93,6 +93,8 @@ struct hg_ctx {
     hg::E2* d_partials2 = nullptr;  // scratch of stream2
     // pinned staging for small host->device descriptor copies; bump-allocated, reset per prove
     char* h_stage = nullptr;
+    void* h_mailbox = nullptr;   // pinned: the sequential prover's transcript mailbox + host-tail buffer (prover_seq.hip), allocated on first use
+    size_t mailbox_bytes = 0;
     size_t stage_cap = 0, stage_used = 0;
     // profiling
     int prof_level = 0;

@@ -569,7 +569,14 @@ struct SeqProver {
         use_mail = !no_mail && ctx->d_res == ctx->h_res;   // (the sums must land in host memory without a copy)
         if (use_mail) {
             // the mailbox and, behind it, the buffer through which the last tables of a sum-check travel to the host (host_tail)
-            hip_check(hipHostMalloc((void**)&mail, MAIL_BYTES + HOST_TAIL_CAP * sizeof(E2), hipHostMallocDefault), "hipHostMalloc(mailbox)");
+            // (kept by the context: pinning memory costs more than a dozen rounds)
+            const size_t need = MAIL_BYTES + HOST_TAIL_CAP * sizeof(E2);
+            if (!ctx->h_mailbox || ctx->mailbox_bytes < need) {
+                if (ctx->h_mailbox) { (void)hipHostFree(ctx->h_mailbox); ctx->h_mailbox = nullptr; }
+                hip_check(hipHostMalloc(&ctx->h_mailbox, need, hipHostMallocDefault), "hipHostMalloc(mailbox)");
+                ctx->mailbox_bytes = need;
+            }
+            mail = static_cast<Mail*>(ctx->h_mailbox);
             memset(mail, 0, sizeof(Mail));
             h_tail = reinterpret_cast<E2*>(reinterpret_cast<char*>(mail) + MAIL_BYTES);
             const char* e = getenv("HG_SEQ_HOST_TAIL");
@@ -581,7 +588,6 @@ struct SeqProver {
         if (mail) {   // whatever still waits on the device is released before the mailbox goes away
             __atomic_store_n(&mail->cpu_seq, ~0ull, __ATOMIC_RELEASE);
             (void)hipStreamSynchronize(st);
-            (void)hipHostFree(mail);
         }
     }
     // host side of the mailbox: wait until the device has posted `seq` (results of everything enqueued before are in h_res)
