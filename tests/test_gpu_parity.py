@@ -569,6 +569,22 @@ def test_prove_stream_equals_one_by_one(ctx, n, k):
     pk.free()
 
 
+def test_prove_stream_at_the_headline_size(ctx):
+    """hg_prove_stream at n=32768 k=16: a run that takes both table sets past their capture gives, proof by proof, what hg_prove
+    gives for the same witness (hg_prove's bytes are compared with the oracle in test_graph_replay_across_witnesses)."""
+    bfv = hg.BfvEncrypt.new(32768, 16)
+    pk = bfv.setup(ctx)
+    ws = [hg.Witness.synthetic(bfv.params, 0x77 + 13 * i) for i in range(3)]
+    one_by_one = [bfv.prove(ctx, pk, w)[0] for w in ws]
+    assert len(set(one_by_one)) == 3
+    order = [0, 1, 2, 2, 1, 0, 0, 2, 1]
+    for rnd in range(2):
+        proofs, tm = bfv.prove_stream(ctx, pk, [ws[i] for i in order])
+        assert proofs == [one_by_one[i] for i in order], rnd
+    print("n=32768: %d proofs in %.2f ms (%.3f ms each)" % (len(order), tm["total_ms"], tm["total_ms"] / len(order)))
+    pk.free()
+
+
 def test_graph_cache_eviction_and_refill_guards(ctx):
     """One graph slot (HG_GRAPH_ENTRIES=1, child process): two values objects proven in alternation evict each other's graph over
     and over - the bytes never change. In this process: a values object cannot be refilled for another key, and reports its size."""
