@@ -72,6 +72,26 @@ impl HipBfvEncrypt {
         proof
     }
 
+    /// `prove` for a run of stored witnesses under this key, the way a caller loops over ciphertexts [REF test.rs:31-44]: the
+    /// library uploads and evaluates witness i+1 while it proves witness i (`hg_prove_stream`); proof i is what `prove_json(paths[i])`
+    /// returns.
+    pub fn prove_json_stream(&mut self, paths: &[&str]) -> Vec<Vec<u8>> {
+        let ws: Vec<*mut HgWitness> = paths.iter().map(|p| self.load(p, Family::Goldilocks)).collect();
+        let cap = 1usize << 20;
+        let mut buf = vec![0u8; cap * ws.len().max(1)];
+        let mut lens = vec![0usize; ws.len().max(1)];
+        unsafe {
+            check(
+                hg_prove_stream(self.ctx, self.pk, ws.as_ptr() as *const *const HgWitness, ws.len(), buf.as_mut_ptr(), cap, lens.as_mut_ptr(), &mut self.timings),
+                "hg_prove_stream",
+            );
+            for w in &ws {
+                hg_witness_free(*w);
+            }
+        }
+        (0..ws.len()).map(|i| buf[i * cap..i * cap + lens[i]].to_vec()).collect()
+    }
+
     /// the same for the bn254 family: `bfv.prove::<Fr, Fr, Pcs>` [REF sk_encryption_circuit.rs:614-626]
     pub fn prove_json_bn254(&mut self, path: &str) -> Vec<u8> {
         let w = self.load(path, Family::Bn254);
