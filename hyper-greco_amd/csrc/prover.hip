@@ -1408,31 +1408,47 @@ struct Prover {
         }
         }
         flush_stride();  // collation + every grand-product layer, round-synchronised
-        aux([&] {
-            if (do_col && claim_late) do_claim();
-            if (do_open) {
-                eq_now(eqx, nu, g1.point_off);
-                eq_now(eqy, 16, g2.point_off);
-            }
-            if (nx) {
-                int nvirt = 0;
-                for (int t = 0; t < nx; t++) nvirt += tx.t[t] == nullptr;
-                // (a group of eight re-reads eq; recomputed E tables cost their group one 8-byte input read per entry)
-                ctx->prof_begin(cls_aux, (double)N * (16.0 * ((nx + 7) / 8) + 8.0 * (nx - nvirt) + (nvirt ? 8.0 * ((nx + 7) / 8) : 0.0)),
-                                (double)N * (16.0 * ((nx + 7) / 8) + 8.0 * nx));   // (reference model: every opened table is read)
-                dev::DotVirt dv;
-                memset(&dv, 0, sizeof(dv));
-                if (lean_e) {
-                    dv.input = d_input; dv.seg_lookup = L.seg_lookup; dv.seg_shift = L.seg_shift; dv.rows = L.rows;
-                    memcpy(dv.lookup_mask, L.lookup_mask, sizeof(dv.lookup_mask)); memcpy(dv.lookup_uses, L.lookup_uses, sizeof(dv.lookup_uses));
-                    memcpy(dv.mem_dim, L.mem_dim, sizeof(dv.mem_dim)); memcpy(dv.mem_cutoff, L.mem_cutoff, sizeof(dv.mem_cutoff));
+        aux([&] { if (do_col && claim_late) do_claim(); });
+        {
+            // the openings (two dot-product launches over every opened table: bandwidth) by value, so that they can also run later
+            const dev::DotTabs txv = tx, tyv = ty;
+            const int nxv = nx, nyv = ny;
+            const bool do_open_v = do_open, lean_v = lean_e;
+            E2 *eqx_v = eqx, *eqy_v = eqy;
+            const size_t p1 = g1.point_off, p2 = g2.point_off;
+            const dev::LassoDev* Lp = &L;
+            auto openings = [this, txv, tyv, nxv, nyv, do_open_v, lean_v, eqx_v, eqy_v, p1, p2, Lp, d_input, nu, N, M] {
+                if (do_open_v) {
+                    eq_now(eqx_v, nu, p1);
+                    eq_now(eqy_v, 16, p2);
                 }
-                dev::dot_eq_many(st, eqx, tx, nx, N, partials, d_res(), lean_e ? &dv : nullptr);
-                ctx->prof_end();
-            }
-            if (ny) dev::dot_eq_many(st, eqy, ty, ny, M, partials, d_res());
-            stamp("claimed sum and openings done");
-        });
+                if (nxv) {
+                    int nvirt = 0;
+                    for (int t = 0; t < nxv; t++) nvirt += txv.t[t] == nullptr;
+                    // (a group of eight re-reads eq; recomputed E tables cost their group one 8-byte input read per entry)
+                    ctx->prof_begin(cls_aux, (double)N * (16.0 * ((nxv + 7) / 8) + 8.0 * (nxv - nvirt) + (nvirt ? 8.0 * ((nxv + 7) / 8) : 0.0)),
+                                    (double)N * (16.0 * ((nxv + 7) / 8) + 8.0 * nxv));   // (reference model: every opened table is read)
+                    dev::DotVirt dv;
+                    memset(&dv, 0, sizeof(dv));
+                    if (lean_v) {
+                        const dev::LassoDev& L = *Lp;
+                        dv.input = d_input; dv.seg_lookup = L.seg_lookup; dv.seg_shift = L.seg_shift; dv.rows = L.rows;
+                        memcpy(dv.lookup_mask, L.lookup_mask, sizeof(dv.lookup_mask)); memcpy(dv.lookup_uses, L.lookup_uses, sizeof(dv.lookup_uses));
+                        memcpy(dv.mem_dim, L.mem_dim, sizeof(dv.mem_dim)); memcpy(dv.mem_cutoff, L.mem_cutoff, sizeof(dv.mem_cutoff));
+                    }
+                    dev::dot_eq_many(st, eqx_v, txv, nxv, N, partials, d_res(), lean_v ? &dv : nullptr);
+                    ctx->prof_end();
+                }
+                if (nyv) dev::dot_eq_many(st, eqy_v, tyv, nyv, M, partials, d_res());
+                stamp("claimed sum and openings done");
+            };
+            // Default: behind the node reductions on the second stream, not beside grand product #1's first (bandwidth-bound)
+            // rounds: the prove takes the same time either way (2.87 ms, +-0.02), the dominant round kernel runs at 0.63 of the
+            // HBM roofline inside a prove instead of 0.56. HG_LATE_OPENINGS=0: right away.
+            static const bool late = [] { const char* e = getenv("HG_LATE_OPENINGS"); return !(e && e[0] == '0'); }();
+            if (late && use_aux) late_aux.push_back(openings);
+            else aux(openings);
+        }
         stamp("grand products done");
         return ClaimRef{r_off, nu, claimed};  // (r, claimed_sum) for the single predecessor (lasso.rs:97,113)
     }
@@ -1615,6 +1631,7 @@ struct Prover {
     }
     // Runs `fn` with the second stream as the enqueue target (work of the Lasso node that is off its critical path: counter
     // sorts, grand product #2's hashes and tree, the openings). One stream only: runs it in place.
+    std::vector<std::function<void()>> late_aux;
     bool aux_started = false;
     template <typename Fn> void on_aux(Fn fn) {
         if (!fork_recorded) { fn(); return; }
@@ -1671,6 +1688,8 @@ struct Prover {
         flush_bookkeeping();
         flush_prodsum();
         stamp("node reductions done");
+        for (auto& f : late_aux) f();          // the Lasso node's openings (lasso_node)
+        late_aux.clear();
         join_nodes_stream();
     }
 
