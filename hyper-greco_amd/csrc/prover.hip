@@ -1417,7 +1417,7 @@ struct Prover {
             E2 *eqx_v = eqx, *eqy_v = eqy;
             const size_t p1 = g1.point_off, p2 = g2.point_off;
             const dev::LassoDev* Lp = &L;
-            auto openings = [this, txv, tyv, nxv, nyv, do_open_v, lean_v, eqx_v, eqy_v, p1, p2, Lp, d_input, nu, N, M] {
+            auto openings = [this, txv, tyv, nxv, nyv, do_open_v, lean_v, eqx_v, eqy_v, p1, p2, Lp, d_input, nu, N] {
                 if (do_open_v) {
                     eq_now(eqx_v, nu, p1);
                     eq_now(eqy_v, 16, p2);
