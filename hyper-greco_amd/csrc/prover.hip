@@ -1019,6 +1019,9 @@ struct Prover {
     }
 
     ClaimRef lasso_node(const u64* d_input) {
+        // where the node enters the transcript: `ch.pos / 2` extension-field challenges have been squeezed before it (the argument
+        // hg_lasso_prove_at takes to reproduce this section on its own)
+        mark("lasso node: enters after " + std::to_string(ch.pos / 2) + " squeezed challenges (lasso.rs:57-114)");
         const LassoPlan& lp = pk->lasso;
         const dev::LassoDev& L = pk->lasso_dev;
         const int nu = lp.nu, A = lp.alpha;

@@ -262,7 +262,13 @@ __device__ __forceinline__ E2 sq_wait_challenge(Mail* m, unsigned long long seq_
         E2 r;
         const long long t0 = wall_clock64();
         if (blockIdx.x == 0) {
+            // pairs with the host's release store of cpu_seq. On gfx942 / gfx950 the in-order loads plus the control dependency order
+            // the chal[] loads behind it; the memory-model form (any other target, HG_STRICT_TICKETS) acquires, as k_mail does
+#if defined(HG_STRICT_TICKETS) || (defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__))
+            while (__hip_atomic_load(&m->cpu_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq_prev) {
+#else
             while (__hip_atomic_load(&m->cpu_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < seq_prev) {
+#endif
                 if (wall_clock64() - t0 > 500000000ll) { __hip_atomic_fetch_add(&m->timeouts, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }   // 5 s
                 __builtin_amdgcn_s_sleep(2);
             }

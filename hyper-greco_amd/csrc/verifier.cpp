@@ -190,6 +190,9 @@ template <class F> struct Verifier {
     std::pair<E, std::vector<E>> sumcheck(int deg, int nvars, E claim, std::function<E()> late = nullptr, size_t* point_off = nullptr) {
         std::vector<E> point;
         if (point_off) *point_off = ch.n;
+        // a late term is folded into round 0's check: a sum-check without rounds has no place for it (no Vanilla node of the BFV
+        // circuit has such a shape; refuse it instead of silently comparing the raw claim)
+        if (late && nvars == 0) throw Error("verifier: a deferred claim term on a sum-check without rounds is not supported");
         for (int i = 0; i < nvars; i++) {
             std::vector<E> c = read_es(deg + 1);
             E s = F::add(c[0], c[0]);

@@ -207,6 +207,13 @@ std::string verify_proof_device(hg_ctx* ctx, const hg_pk* pk, const Witness& w, 
     for (int i = 0; i < p.k; i++) D.d_inputs.push_back(up(&w.r1is[(size_t)i * SZ], SZ));
     D.d_inputs.push_back(up(w.r2is.data(), w.r2is.size()));
     D.d_ct0is = up(w.ct0is.data(), w.ct0is.size());
+    // Rejection is a normal outcome and leaves kernels and staged descriptor copies queued (the walk returns from the middle of the
+    // proof): drain the stream on EVERY way out - accept, Reject, hg::Error - before the caller may reuse the staging buffer and the
+    // arena or free the witness whose uploads may still be pending.
+    struct Drain {
+        hipStream_t st;
+        ~Drain() { (void)hipStreamSynchronize(st); }
+    } drain{ctx->stream};
     return verify_proof_with(D, p, pk->lasso, pk->circuit, proof, len);
 }
 

@@ -112,8 +112,8 @@ void hg_witness_free(hg_witness* w);
 int hg_prove(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, uint8_t* proof, size_t cap, size_t* len,
              hg_timings* timings);
 
-/* hg_prove for a run of `n` witnesses under one key, pipelined [REF: the loop a caller of BfvEncrypt::prove writes, benches/
- *   sk_encryption.rs bench_function closure]: upload + circuit.evaluate of witness i+1 run on a third stream into a second set of node
+/* hg_prove for a run of `n` witnesses under one key, pipelined [REF: the loop a caller of BfvEncrypt::prove writes; the only
+ *   in-tree caller is the test macro bfv-gkr/src/test.rs:31-44, one witness per call - the reference has no batch entry]: upload + circuit.evaluate of witness i+1 run on a third stream into a second set of node
  *   tables while witness i is proven. Proof i is written at proofs + i*cap_each, its length to lens[i]; each proof is byte-identical
  *   to hg_prove's for that witness. timings (may be NULL): total_ms = wall clock of the whole run, prove_ms / gpu_ms = sums over
  *   the proofs. The first proofs of a context + key walk the protocol (the launch graph of a table set is recorded on its third

@@ -23,3 +23,4 @@ for r in range(R):
     if r % 5 == 0:
         assert bfv.prove(ctx, pk, ws[r % 5])[0] == refs[r % 5]
 print("n=%d: %d runs, %d proofs, %d mismatches, %.1f s" % (n, R, np_, bad, time.perf_counter() - t0))
+sys.exit(1 if bad else 0)

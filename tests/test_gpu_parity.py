@@ -114,7 +114,10 @@ def test_mle_eval_and_ntt(ctx):
                 assert (got[b << log2n:(b + 1) << log2n] == exp).all(), (log2n, inv, b)
 
 
-FIX = [(1024, 1, 27), (4096, 2, 55)]
+# every Goldilocks witness the reference holds (bfv-gkr/src/data/goldilocks/, copied as data into tests/golden/); 8192 is its only
+# witness with k = 4 (two r2is chunks, sk_encryption_circuit.rs:149-161)
+FIX = [(1024, 1, 27), (2048, 1, 52), (4096, 2, 55), (8192, 4, 55)]
+BN_FIX = [(1024, 1, 27), (2048, 1, 52), (4096, 2, 55)]   # bfv-gkr/src/data/bn254/
 
 
 @pytest.mark.parametrize("n,k", [(1024, 1), (4096, 2), (32768, 16)])
@@ -178,6 +181,11 @@ def test_full_prove_bit_exact_on_reference_fixtures(ctx, n, k, bits):
     assert ok, err
     ok, err = hg.verify(pk, w, proof)  # product-side verifier (BfvEncrypt::verify)
     assert ok, err
+    ok, err = hg.verify_device(ctx, pk, w, proof)  # the same decisions with the table-sized checks on the device
+    assert ok, err
+    bad = bytearray(proof)
+    bad[len(bad) // 3] ^= 4
+    assert not hg.verify(pk, w, bytes(bad))[0] and not hg.verify_device(ctx, pk, w, bytes(bad))[0]
     proof2, _ = bfv.prove(ctx, pk, w)  # determinism + arena reuse
     assert proof2 == proof
     pk.free()
@@ -570,17 +578,22 @@ def test_prove_stream_equals_one_by_one(ctx, n, k):
 
 
 def test_prove_stream_at_the_headline_size(ctx):
-    """hg_prove_stream at n=32768 k=16: a run that takes both table sets past their capture gives, proof by proof, what hg_prove
-    gives for the same witness (hg_prove's bytes are compared with the oracle in test_graph_replay_across_witnesses)."""
-    bfv = hg.BfvEncrypt.new(32768, 16)
+    """hg_prove_stream at n=32768 k=16: a run that takes both table sets past their capture gives, proof by proof, the ORACLE's
+    transcript of that witness (three oracle proves, about 3 s each on the GPU box), and hg_prove gives the same bytes."""
+    n, k = 32768, 16
+    bfv = hg.BfvEncrypt.new(n, k)
     pk = bfv.setup(ctx)
+    p = orclib.params(n, k)
+    threads = min(64, os.cpu_count() or 8)
     ws = [hg.Witness.synthetic(bfv.params, 0x77 + 13 * i) for i in range(3)]
-    one_by_one = [bfv.prove(ctx, pk, w)[0] for w in ws]
-    assert len(set(one_by_one)) == 3
+    refs = [orclib.prove(p, orclib.Inputs(w.arrays()), threads=threads)[0] for w in ws]
+    assert len(set(refs)) == 3
     order = [0, 1, 2, 2, 1, 0, 0, 2, 1]
     for rnd in range(2):
         proofs, tm = bfv.prove_stream(ctx, pk, [ws[i] for i in order])
-        assert proofs == [one_by_one[i] for i in order], rnd
+        for j, i in enumerate(order):
+            assert proofs[j] == refs[i], (rnd, j, _first_diff(proofs[j], refs[i], 16))
+    assert [bfv.prove(ctx, pk, w)[0] for w in ws] == refs
     print("n=32768: %d proofs in %.2f ms (%.3f ms each)" % (len(order), tm["total_ms"], tm["total_ms"] / len(order)))
     pk.free()
 
@@ -843,23 +856,35 @@ def test_bench_sharded_two_processes_on_one_gpu():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] == d["ms_per_step"]
 
 
-def test_lasso_node_inside_a_larger_transcript(ctx):
-    """hg_lasso_prove_at: the node entered after `skip` challenges equals the bytes the full prover writes for it."""
-    n, k = 1024, 1
+@pytest.mark.parametrize("n,k,bits", [(1024, 1, 27), (8192, 4, 55)])
+def test_lasso_node_inside_a_larger_transcript(ctx, n, k, bits, tmp_path, monkeypatch):
+    """hg_lasso_prove_at: the node entered after `skip` challenges writes exactly the bytes the full prover writes for it. The
+    position is COMPUTED, not searched for: the proof map of the full prove names the byte offset of the node's section and the
+    number of challenges squeezed before it; the section must equal hg_lasso_prove_at's output for that number, and the oracle's
+    Lasso prover entered at the same point must agree."""
+    import re
+    mp = tmp_path / "map.tsv"
+    monkeypatch.setenv("HG_PROOF_MAP", str(mp))
     bfv = hg.BfvEncrypt.new(n, k)
     pk = bfv.setup(ctx)
-    w = bfv.get_inputs(os.path.join(orclib.GOLDEN, "sk_enc_1024_1x27_65537.json"))
+    w = bfv.get_inputs(os.path.join(orclib.GOLDEN, f"sk_enc_{n}_{k}x{bits}_65537.json"))
     full, _ = bfv.prove(ctx, pk, w)
+    monkeypatch.delenv("HG_PROOF_MAP")
+    rows = [l.rstrip("\n").split("\t", 1) for l in open(mp)]
+    at = next(i for i, r in enumerate(rows) if r[1].startswith("lasso node: enters after"))
+    skip = int(re.search(r"enters after (\d+) squeezed", rows[at][1]).group(1))
+    start = int(rows[at][0])
+    end = next(int(r[0]) for r in rows[at + 1:] if not r[1].startswith(("lasso", "grand product")))
+    assert skip > 0 and 0 < start < end <= len(full)
     lasso_in, _ = pk.circuit_eval(w)
     base, _ = hg.LassoNode(pk).prove_claim_reduction(ctx, lasso_in)
-    # find where the node sits in the whole proof: try every 16-byte offset and challenge position until the bytes match
-    found = False
-    for skip in range(0, 400):
-        pr, _ = hg.LassoNode(pk).prove_claim_reduction(ctx, lasso_in, chain_skip=skip)
-        if pr != base and pr in full:
-            found = True
-            break
-    assert found, "no challenge offset reproduces the node's section of the full proof"
+    pr, _ = hg.LassoNode(pk).prove_claim_reduction(ctx, lasso_in, chain_skip=skip)
+    assert len(pr) == end - start == len(base) and pr != base
+    assert pr == full[start:end], _first_diff(pr, full[start:end], 16)
+    ref, _ = orclib.lasso_prove_f("goldilocks", orclib.params(n, k), lasso_in, threads=8, chain_skip=skip)
+    assert pr == ref, _first_diff(pr, ref, 16)
+    for other in (skip - 1, skip + 1):                                     # one challenge off: other bytes
+        assert hg.LassoNode(pk).prove_claim_reduction(ctx, lasso_in, chain_skip=other)[0] != pr
     pk.free()
 
 
@@ -1071,6 +1096,37 @@ def test_bn254_prove_bit_exact_on_the_reference_fixture(ctx):
     with pytest.raises(ValueError):
         G.verify(c, inputs, ct0is, bad, chal, verify_fn)
     assert not hg.verify_bn254(pk, w, b"".join(v.to_bytes(32, "big") for v in bad))[0]
+
+
+@pytest.mark.parametrize("n,k,bits", BN_FIX)
+def test_bn254_prove_bit_exact_on_every_reference_fixture(ctx, n, k, bits):
+    """hg_prove_bn254 on every bn254 witness the reference holds (bfv-gkr/src/data/bn254/): loader + device circuit evaluation
+    (sum == ct0is), every proof byte equal to the C++ Fr oracle's (orcbn_prove; its digest is pinned in tests/golden), the
+    oracle's verifier and the product's host verifier accept it, a flipped byte and another fixture's witness are rejected."""
+    import hashlib, json
+    bfv = hg.BfvEncrypt.new(n, k)
+    pk = bfv.setup(ctx)
+    w = hg.Witness.from_json_bn254(bfv.params, os.path.join(orclib.GOLDEN, f"bn254_sk_enc_{n}_{k}x{bits}_65537.json"))
+    inp = orclib.bn254_fixture_inputs(n, k, bits)
+    for f in ("s", "e", "k1", "ais", "r1is", "r2is", "ct0is"):
+        assert (w.arrays()[f] == inp.d[f]).all(), f
+    assert ctx.circuit_eval_bn254(pk, w, 0) == ctx.circuit_eval_bn254(pk, w, 2)          # sum node == ct0is, over Fr, on the device
+    proof, wms, pms = ctx.prove_bn254(pk, w)
+    p = orclib.params(n, k)
+    ref, _ = orclib.prove_f("bn254", p, inp, threads=8)
+    assert proof == ref, _first_diff(proof, ref)
+    gold = json.load(open(os.path.join(orclib.GOLDEN, "oracle_proof_digests.json")))[f"bn254_{n}_{k}"]
+    assert len(proof) == gold["bytes"] and hashlib.sha256(proof).hexdigest() == gold["sha256"]
+    ok, err = orclib.verify_f("bn254", p, inp, proof, threads=8)
+    assert ok, err
+    assert hg.verify_bn254(pk, w, proof) == (True, "")
+    bad = bytearray(proof)
+    bad[len(bad) // 2 + 31] ^= 1
+    assert not hg.verify_bn254(pk, w, bytes(bad))[0]
+    # the Goldilocks fixture of the same parameter set is another sample: its public inputs do not fit this proof
+    w_gl = hg.Witness.from_json(bfv.params, os.path.join(orclib.GOLDEN, f"sk_enc_{n}_{k}x{bits}_65537.json"))
+    assert not hg.verify_bn254(pk, w_gl, proof)[0]
+    pk.free()
 
 
 def test_bn254_prove_synthetic_k2_accepted_by_the_oracle_verifier(ctx):

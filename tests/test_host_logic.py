@@ -165,6 +165,43 @@ def test_product_verifier_accepts_oracle_proofs_and_rejects_tampering(n, k, bits
 BN_FIXTURE = os.path.join(orclib.GOLDEN, "bn254_sk_enc_1024_1x27_65537.json")
 
 
+@pytest.mark.parametrize("n,k,bits", [(2048, 1, 52), (4096, 2, 55)])
+def test_bn254_fixture_loader_on_the_larger_reference_fixtures(n, k, bits):
+    """hg_witness_from_json_bn254 on the other two bn254 witnesses the reference holds (k = 2: two CRT components, one r2is chunk):
+    the arrays equal the test-side layout of the same file and the integer witness satisfies sum == ct0is."""
+    bfv = hg.BfvEncrypt.new(n, k)
+    w = hg.Witness.from_json_bn254(bfv.params, os.path.join(orclib.GOLDEN, f"bn254_sk_enc_{n}_{k}x{bits}_65537.json"))
+    a = w.arrays()
+    exp = orclib.bn254_fixture_inputs(n, k, bits).d
+    for f in ("s", "e", "k1", "ais", "r1is", "r2is", "ct0is"):
+        assert (a[f] == exp[f]).all(), f
+    pk = bfv.setup(None)
+    _, sum_out = pk.circuit_eval(w)
+    assert (sum_out == a["ct0is"]).all()
+    pk.free()
+
+
+@pytest.mark.parametrize("n,k,bits", [(2048, 1, 52), (8192, 4, 55)])
+def test_goldilocks_fixture_loader_on_the_larger_reference_fixtures(n, k, bits):
+    """hg_witness_from_json on the Goldilocks witnesses beyond c1 / c2 (8192 is the reference's only k = 4 witness: two r2is
+    chunks, sk_encryption_circuit.rs:149-161): same arrays as the test-side layout, and the host verifier accepts the oracle's proof."""
+    bfv = hg.BfvEncrypt.new(n, k)
+    w = bfv.get_inputs(os.path.join(orclib.GOLDEN, f"sk_enc_{n}_{k}x{bits}_65537.json"))
+    a = w.arrays()
+    inp = orclib.fixture_inputs(n, k, bits)
+    for f in ("s", "e", "k1", "ais", "r1is", "r2is", "ct0is"):
+        assert (a[f] == inp.d[f]).all(), f
+    pk = bfv.setup(None)
+    _, sum_out = pk.circuit_eval(w)
+    assert (sum_out == a["ct0is"]).all()
+    proof, _ = orclib.prove(orclib.params(n, k), inp, threads=8)
+    assert hg.verify(pk, w, proof) == (True, "")
+    bad = bytearray(proof)
+    bad[len(bad) // 3] ^= 4
+    assert not hg.verify(pk, w, bytes(bad))[0]
+    pk.free()
+
+
 def test_bn254_fixture_loader_recovers_the_signed_integers(tmp_path):
     """The reference's bn254 witness holds small signed integers as Fr elements; the loader keeps them in the Goldilocks form.
     Lifted back into Fr they must equal the Python oracle's layout of the same file, and the integer witness satisfies the

@@ -157,7 +157,10 @@ def test_lasso_memory_maps():
                           "b82453@1", "b82463@1", "b89479@1", "b94161@1", "b94357@1"]
 
 
-FIX = [(1024, 1, 27), (4096, 2, 55)]
+# every Goldilocks witness the reference holds (bfv-gkr/src/data/goldilocks/); 8192 is its only one with k = 4, i.e. two r2is chunks
+# [REF sk_encryption_circuit.rs:149-161]
+FIX = [(1024, 1, 27), (2048, 1, 52), (4096, 2, 55), (8192, 4, 55)]
+BN_FIX = [(1024, 1, 27), (2048, 1, 52), (4096, 2, 55)]   # bfv-gkr/src/data/bn254/
 
 
 @pytest.mark.parametrize("n,k,bits", FIX)
@@ -430,6 +433,37 @@ def test_fr_wire_format_and_challenge_chain():
     assert ch == exp
     assert ch[0] == 7173236656320612194178997223602979818891828541827642103715116037219761443523
     assert orclib.challenge_chain("bn254", 8) == orclib.bn254().challenges(8, orclib.keccak256)
+
+
+@pytest.mark.parametrize("n,k,bits", BN_FIX)
+def test_fr_oracle_on_every_reference_bn254_fixture(n, k, bits):
+    """Every bn254 witness the reference holds: get_inputs layout, the circuit relation sum == ct0is and the range bounds on the
+    integer witness, orcbn_prove -> orcbn_verify round trip, tamper and wrong-public-input rejection, the regression digest, and
+    the element count of the Goldilocks proof of the same parameter set (same protocol with E = F)."""
+    p = orclib.params(n, k)
+    inp = orclib.bn254_fixture_inputs(n, k, bits)
+    lasso_in, sum_out, info = orclib.circuit_eval(p, inp)
+    assert (sum_out == inp.d["ct0is"]).all()
+    chunks = max(1, k // 2)
+    SZ = 1 << p.L
+    c = p.c
+    bounds = c["r1_bounds"][:k] + [c["r2_bounds"][0]] * chunks + [c["s_bound"], c["e_bound"], c["k1_bound"]]
+    for i, b in enumerate(bounds):
+        assert int(lasso_in[i * SZ:(i + 1) * SZ].max()) <= 2 * b
+    proof, _ = orclib.prove_f("bn254", p, inp, threads=8)
+    gold = json.load(open(os.path.join(orclib.GOLDEN, "oracle_proof_digests.json")))[f"bn254_{n}_{k}"]
+    assert len(proof) == gold["bytes"] and hashlib.sha256(proof).hexdigest() == gold["sha256"]
+    gl_proof, _ = orclib.prove(p, orclib.fixture_inputs(n, k, bits), threads=8)
+    assert len(proof) // 32 == len(gl_proof) // 16
+    ok, err = orclib.verify_f("bn254", p, inp, proof, threads=8)
+    assert ok, err
+    bad = bytearray(proof)
+    bad[len(bad) // 2 + 31] ^= 1
+    assert not orclib.verify_f("bn254", p, inp, bytes(bad), threads=8)[0]
+    d2 = dict(inp.d)
+    d2["ct0is"] = inp.d["ct0is"].copy()
+    d2["ct0is"][5] ^= np.uint64(1)
+    assert not orclib.verify_f("bn254", p, orclib.Inputs(d2), proof, threads=8)[0]
 
 
 def test_fr_oracle_reproduces_the_python_oracle_on_the_reference_bn254_fixture():
