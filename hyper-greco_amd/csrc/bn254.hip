@@ -22,6 +22,7 @@
 #include <map>
 #include "bn254_field.hpp"
 #include "bn254_wide.hpp"
+#include "bn254_lazy.hpp"
 #include "host.hpp"
 #include "prover.hpp"
 #include "kernels.hpp"
@@ -201,14 +202,8 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_round(const Fr* __restrict__ in, 
 // the linear table S = sum_i w_i (l_i + r_i) in natural order ([2j], [2j+1]), folded into s_out; K1 S(t) + K2 joins P0 and P1.
 struct GpJobDev { const Fr* l_base; const Fr* r_base; Fr* out; Fr* part; Fr r; unsigned long long half, l_stride, r_stride; int nb, gx, gy, mirror;
                   const Fr* s_in; Fr* s_out; Fr k1, k2;
-                  FoldK fk; };   // fold_consts(r): the round's folds x + r d run through fr_fold_const (bn254_wide.hpp)
-// Two lanes share one pair index j (quad_perm [1,0,3,2] swaps their registers): the even lane owns the LEFT tables, the odd lane the
-// RIGHT tables; each loads, folds and stores only its own tables, so every table entry is read from HBM once. With x, y = T[2j],
-// T[2j+1] and d = y - x the round polynomial needs P0 = sum xl xr, P1 = sum yl yr, Pinf = sum dl dr:
-//   g(0) = P0, g(2) = 2 P1 - P0 + 2 Pinf, g(3) = 3 P1 - 2 P0 + 6 Pinf.
-// Pairs are taken two at a time (a, b): the even lane accumulates P0 of both and Pinf of a, the odd lane P1 of both and Pinf of b -
-// the same instruction stream for both lanes (operands picked by v_cndmask), three multiply-accumulates and two folds per lane
-// per two pairs, i.e. exactly the 3 + 2 products a (pair, j) needs, two column accumulators per lane.
+                  FoldK fk;      // fold_consts(r): the round's folds x + r d run through lz_fold (bn254_lazy.hpp)
+                  int dbg, pad2; };   // HG_BN_DBG (timing experiments only; wrong results): 1 no stores, 2 no folds, 4 no multiply-accumulates
 __device__ __forceinline__ Fr fr_swap_lane(const Fr& v) {
     Fr o;
 #pragma unroll
@@ -221,71 +216,140 @@ __device__ __forceinline__ Fr fr_swap_lane(const Fr& v) {
     return o;
 }
 __device__ __forceinline__ Fr fr_sel(bool c, const Fr& a, const Fr& b) { return fr_make(c ? a.l[0] : b.l[0], c ? a.l[1] : b.l[1], c ? a.l[2] : b.l[2], c ? a.l[3] : b.l[3]); }
-constexpr int BN_GP_J = BN_TPB / 2;   // pair indices per workgroup
+// One lane per pair index j, three column accumulators (P0 = sum xl xr, P1 = sum yl yr, Pinf = sum dl dr over the job's pairs; x, y =
+// T[2j], T[2j+1], d = y - x), all arithmetic in the branch-free loose form of bn254_lazy.hpp:
+//   g(0) = p0 P0, g(2) = p2 (2 P1 - P0 + 2 Pinf), g(3) = p3 (3 P1 - 2 P0 + 6 Pinf)   (p_v = table 0 at v).
+// Per (pair, j): four 32-byte loads, three multiply-accumulates, two folds x + r d with the round's precomputed constants, two
+// 32-byte stores - one straight-line block of about 900 VALU instructions with three independent accumulation chains. (Round 3 dealt
+// a pair index to a lane PAIR with DPP operand swaps and used the canonical, branching field operations: 1700 instructions and 311
+// conditional branches per kernel, 0.59 of the issue rate.) The folded tables and the mirrored layer's S table are written LOOSE
+// (any representative below 2p): their readers are this kernel, the tail kernel (normalises on load) and fr_from_mont.
+constexpr int BN_GP_J = BN_TPB;   // pair indices per workgroup
 __global__ __launch_bounds__(BN_TPB) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_bn_gp_round_jobs(const GpJobDev* __restrict__ jobs) {
     const GpJobDev& J = jobs[blockIdx.y];
     const int tile = blockIdx.x;
     if (tile >= J.gx * J.gy) return;
-    __shared__ Fr sm[BN_TPB];
-    const bool isA = (threadIdx.x & 1) == 0;
-    const int jj = threadIdx.x >> 1, lane2 = threadIdx.x & 1;
-    const Fr* __restrict__ mb = isA ? J.l_base : J.r_base;   // my tables
-    const size_t ms = isA ? J.l_stride : J.r_stride;
+    // per wave: the eight 16-byte pieces (xl, yl, xr, yr) of every lane's NEXT TWO (pair, j) items, written by LDS-DMA while the
+    // current one is computed on. Two waves per SIMD at 256 VGPRs cannot hide a load -> wait -> compute chain otherwise (measured: the
+    // loads alone, one item in flight per wave, take 1.47 ms of a 2.3 ms launch - 64 KiB in flight per CU against a loaded memory
+    // latency of 3-5 us is 3.4 TB/s; fetching a wave's contiguous 4 KiB run as coalesced 1 KiB pieces instead was SLOWER, 1.93 ms: the
+    // 64-byte-strided reads back from LDS conflict 16 ways). Buffer t mod 2 holds item t; it is refilled with item t + 2 as soon as item
+    // t is in registers. The block sums at the end reuse the same bytes.
+    __shared__ lz_u32x4 stage[2][BN_TPB / 64][8][64];
+    static_assert(sizeof(stage) >= sizeof(Fr) * BN_TPB, "the block sums reuse the staging buffer");
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u32 lds0 = __builtin_amdgcn_readfirstlane((u32)(uintptr_t)(__attribute__((address_space(3))) void*)(&stage[0][wave][0][0]));
+    constexpr u32 BUF = (u32)sizeof(stage) / 2;
     const Fr* __restrict__ lb = J.l_base;
+    const Fr* __restrict__ rb = J.r_base;
+    const size_t ls = J.l_stride, rs = J.r_stride;
     Fr* __restrict__ out = J.out;
     const size_t half = J.half;
     const int nb = J.nb, P = J.gy, bx = tile % J.gx, pi = tile / J.gx;
-    Fr acc1 = fr_zero(), acc3 = fr_zero();   // even lane: g(0) and g(3); odd lane: g(2) (and an unused product)
-    for (size_t j = (size_t)bx * BN_GP_J + jj; j < half; j += (size_t)J.gx * BN_GP_J) {   // both lanes of a pair share j
-        WCol c1 = wcol_zero(), c2 = wcol_zero();
-        for (int ia = pi; ia < nb; ia += 2 * P) {
-            const int ib = ia + P;
-            const bool hb = ib < nb;   // uniform over the workgroup
-            Fr d_a;   // pair a first, then pair b: only d_a stays live in between
-            {
-                const Fr x_a = mb[(size_t)ia * ms + 2 * j], y_a = mb[(size_t)ia * ms + 2 * j + 1];
-                d_a = fr_sub(y_a, x_a);
-                out[(size_t)(2 * ia + lane2) * half + j] = fr_fold_const(x_a, d_a, J.fk.k);
-                // even lane: x (own) * x (other side) -> P0; odd lane: y (own) * y (other side) -> P1
-                wcol_mac(c1, fr_sel(isA, x_a, y_a), fr_swap_lane(fr_sel(isA, y_a, x_a)));
-            }
-            Fr d_b = fr_zero();
-            if (hb) {
-                const Fr x_b = mb[(size_t)ib * ms + 2 * j], y_b = mb[(size_t)ib * ms + 2 * j + 1];
-                d_b = fr_sub(y_b, x_b);
-                out[(size_t)(2 * ib + lane2) * half + j] = fr_fold_const(x_b, d_b, J.fk.k);
-                wcol_mac(c1, fr_sel(isA, x_b, y_b), fr_swap_lane(fr_sel(isA, y_b, x_b)));
-            }
-            // Pinf: pair a on the even lane, pair b on the odd lane
-            wcol_mac(c2, fr_sel(isA, d_a, d_b), fr_swap_lane(fr_sel(isA, d_b, d_a)));
+    const LzK KK = lz_load_k(J.fk.k);   // the round's fold constants: SGPR-resident for the whole kernel
+    const u32* K = KK.k;
+    const size_t jstep = (size_t)J.gx * BN_GP_J;
+    auto prefetch = [&](int i, size_t j, u32 buf) {   // lanes beyond the table issue nothing
+        if (j < half) {
+            const char* gl = reinterpret_cast<const char*>(&lb[(size_t)i * ls + 2 * j]);
+            const char* gr = reinterpret_cast<const char*>(&rb[(size_t)i * rs + 2 * j]);
+#pragma unroll
+            for (int k = 0; k < 4; k++) lz_glds16(gl + 16 * k, lds0 + buf * BUF + 1024u * k);
+#pragma unroll
+            for (int k = 0; k < 4; k++) lz_glds16(gr + 16 * k, lds0 + buf * BUF + 1024u * (4 + k));
         }
+    };
+    Fr acc0 = fr_zero(), acc2 = fr_zero(), acc3 = fr_zero();   // loose
+    // The wave's items, in order: t = 0 .. n_items - 1 <-> (jw, i) with i running fastest. All 64 lanes stay in the loops (the counts are
+    // uniform over the wave); a lane beyond the table (tables shorter than a wave) is masked where it loads, stores or sums.
+    const size_t jw0 = (size_t)bx * BN_GP_J + 64 * wave;
+    const u32 npi = (u32)((nb - pi + P - 1) / P);
+    const u32 n_items = jw0 < half ? (u32)((half - jw0 + jstep - 1) / jstep) * npi : 0u;
+    u32 issued = 0, t = 0;
+    int pf_i = pi;
+    size_t pf_jw = jw0;
+    auto issue_next = [&] {   // item `issued` into buffer issued & 1
+        prefetch(pf_i, pf_jw + lane, issued & 1);
+        issued++;
+        pf_i += P;
+        if (pf_i >= nb) { pf_i = pi; pf_jw += jstep; }
+    };
+    if (issued < n_items) issue_next();
+    if (issued < n_items) issue_next();
+    for (size_t jw = jw0; jw < half; jw += jstep) {
+        const size_t j = jw + lane;
+        const bool valid = j < half;
+        WCol c0 = wcol_zero(), c1 = wcol_zero(), ci = wcol_zero();
+        for (int i = pi; i < nb; i += P, t++) {
+            // Item t has landed when nothing older than the eight DMAs of item t + 1 is outstanding (the counter retires in order).
+            // NOTHING in this loop may make hipcc wait for memory on its own: a spilled register's reload is followed by a
+            // vmcnt(0) that also drains the DMAs in flight (the first form of this loop held the four operands in registers next to
+            // the three accumulators, spilled, and ran load -> wait -> compute in sequence: 2.3-2.5 ms for the first launch). So the
+            // staged item is the operand store: x and y are read from LDS when a step needs them and dropped again.
+            if (issued > t + 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else lz_wait_vm0();
+            const lz_u32x4* mine = &stage[t & 1][wave][0][lane];
+            Fr dl, dr;
+            {
+                const Fr xl = lz_from_x4(mine[0], mine[64]), yl = lz_from_x4(mine[128], mine[192]);
+                dl = lz_sub(yl, xl);
+                const Fr fl = lz_fold(xl, dl, K);
+                if (valid && !(J.dbg & 1)) lz_gstore(&out[(size_t)(2 * i) * half + j], fl);
+            }
+            asm volatile("" ::: "memory");
+            {
+                const Fr xr = lz_from_x4(mine[256], mine[320]), yr = lz_from_x4(mine[384], mine[448]);
+                dr = lz_sub(yr, xr);
+                const Fr fr_ = lz_fold(xr, dr, K);
+                if (valid && !(J.dbg & 1)) lz_gstore(&out[(size_t)(2 * i + 1) * half + j], fr_);
+            }
+            wcol_mac(ci, dl, dr);
+            asm volatile("" ::: "memory");
+            {
+                const Fr xl = lz_from_x4(mine[0], mine[64]), xr = lz_from_x4(mine[256], mine[320]);
+                wcol_mac(c0, xl, xr);
+            }
+            asm volatile("" ::: "memory");
+            {
+                const Fr yl = lz_from_x4(mine[128], mine[192]), yr = lz_from_x4(mine[384], mine[448]);
+                wcol_mac(c1, yl, yr);
+            }
+            lz_wait_lgkm0();  // the item is consumed: its buffer is free for item t + 2
+            if (issued < n_items) issue_next();
+        }
+        const size_t jc = valid ? j : 0;   // (masked lanes read entry 0 and contribute nothing)
         Fr p0, p2, p3;  // table 0 (= left table of pair 0, weight gamma^0 = 1) at 0, 2, 3 (loaded here: not live across the pair loop)
         {
-            const Fr x = lb[2 * j], y = lb[2 * j + 1];
-            const Fr d = fr_sub(y, x);
-            p0 = x; p2 = fr_add(y, d); p3 = fr_add(p2, d);
+            const Fr x = lz_gload(&lb[2 * jc]), y = lz_gload(&lb[2 * jc + 1]);
+            const Fr d = lz_subr(y, x);
+            p0 = x; p2 = lz_add(y, d); p3 = lz_add(p2, d);
         }
-        Fr R1 = wcol_reduce(c1);
-        const Fr Ri = wcol_reduce(c2);
-        if (J.mirror && pi == 0) {   // (uniform over the workgroup) even lane: P0 += K1 S(0) + K2, odd lane: P1 += K1 S(1) + K2
-            const Fr sx = J.s_in[2 * j], sy = J.s_in[2 * j + 1];
-            R1 = fr_add(R1, fr_add(fr_mul_wide(J.k1, fr_sel(isA, sx, sy)), J.k2));
-            if (isA) J.s_out[j] = fr_fold_const(sx, fr_sub(sy, sx), J.fk.k);
+        Fr P0 = lz_reduce(c0), P1 = lz_reduce(c1);
+        const Fr Pi = lz_reduce(ci);
+        if (J.mirror && pi == 0) {   // (uniform over the workgroup) P0 += K1 S(0) + K2, P1 += K1 S(1) + K2
+            const Fr sx = lz_gload(&J.s_in[2 * jc]), sy = lz_gload(&J.s_in[2 * jc + 1]);
+            P0 = lz_add(P0, lz_add(lz_mul(J.k1, sx), J.k2));
+            P1 = lz_add(P1, lz_add(lz_mul(J.k1, sy), J.k2));
+            const Fr sf = lz_fold(sx, lz_sub(sy, sx), K);
+            if (valid) lz_gstore(&J.s_out[j], sf);
         }
-        const Fr Ro = fr_swap_lane(R1), Pi = fr_add(Ri, fr_swap_lane(Ri));
-        const Fr P0 = fr_sel(isA, R1, Ro), P1 = fr_sel(isA, Ro, R1);
-        const Fr P1x2 = fr_add(P1, P1), Pix2 = fr_add(Pi, Pi);
-        const Fr q2 = fr_add(fr_sub(P1x2, P0), Pix2);
-        const Fr q3 = fr_add(fr_sub(fr_add(P1x2, P1), fr_add(P0, P0)), fr_add(fr_add(Pix2, Pix2), Pix2));
-        acc1 = fr_add(acc1, fr_mul_wide(fr_sel(isA, p0, p2), fr_sel(isA, P0, q2)));
-        acc3 = fr_add(acc3, fr_mul_wide(p3, q3));
+        const Fr P1x2 = lz_add(P1, P1), Pix2 = lz_add(Pi, Pi);
+        const Fr q2 = lz_add(lz_subr(P1x2, P0), Pix2);
+        const Fr q3 = lz_add(lz_subr(lz_add(P1x2, P1), lz_add(P0, P0)), lz_add(lz_add(Pix2, Pix2), Pix2));
+        const Fr t0 = lz_mul(p0, P0), t2 = lz_mul(p2, q2), t3 = lz_mul(p3, q3);
+        acc0 = lz_add(acc0, valid ? t0 : fr_zero());
+        acc2 = lz_add(acc2, valid ? t2 : fr_zero());
+        acc3 = lz_add(acc3, valid ? t3 : fr_zero());
     }
+    lz_wait_vm0();
+    __syncthreads();   // every wave is done with its staging bytes
+    Fr* sm = reinterpret_cast<Fr*>(&stage[0][0][0]);
     const size_t blk = (size_t)pi * J.gx + bx;
-    Fr s = block_sum_fr(isA ? acc1 : fr_zero(), sm);
+    Fr s = block_sum_fr(lz_canon(acc0), sm);
     if (threadIdx.x == 0) J.part[blk * 3 + 0] = s;
-    s = block_sum_fr(isA ? fr_zero() : acc1, sm);
+    s = block_sum_fr(lz_canon(acc2), sm);
     if (threadIdx.x == 0) J.part[blk * 3 + 1] = s;
-    s = block_sum_fr(isA ? acc3 : fr_zero(), sm);
+    s = block_sum_fr(lz_canon(acc3), sm);
     if (threadIdx.x == 0) J.part[blk * 3 + 2] = s;
 }
 // pw[n][b] = g_n^b for every layer n of a grand product in one launch (blockIdx.y = layer)
@@ -332,12 +396,12 @@ static RoundGrid round_grid(size_t half, int nitems) {
     g.gy = (int)std::max<size_t>(1, std::min<size_t>((size_t)nitems, (size_t)131072 / threads));
     return g;
 }
-// grand-product rounds: two lanes per pair index (k_bn_gp_round_jobs), pairs taken two at a time per group
+// grand-product rounds: one lane per pair index (k_bn_gp_round_jobs), the pairs dealt to gy groups in small rounds
 static RoundGrid round_grid_gp(size_t half, int nb) {
     RoundGrid g;
-    g.gx = (int)std::min<size_t>((half + BN_TPB / 2 - 1) / (BN_TPB / 2), (size_t)1024);
+    g.gx = (int)std::min<size_t>((half + BN_GP_J - 1) / BN_GP_J, (size_t)1024);
     const size_t threads = (size_t)g.gx * BN_TPB;
-    g.gy = (int)std::max<size_t>(1, std::min<size_t>((size_t)(nb + 1) / 2, (size_t)131072 / threads));
+    g.gy = (int)std::max<size_t>(1, std::min<size_t>((size_t)nb, (size_t)131072 / threads));
     return g;
 }
 constexpr int BN_PART_STRIDE = 2048;  // per-round slots (workgroups) in a partials buffer; round_grid never exceeds 1024 + 512
@@ -404,8 +468,9 @@ __device__ __forceinline__ void bn_tail_body(const Fr* __restrict__ in, Fr* __re
         Fr acc = fr_zero();
         for (int idx = t; idx < half * npairs; idx += BN_TPB) {
             const int j = idx % half, i = idx / half;
-            const Fr xa = cur[(size_t)(2 * i) * 2 * half + 2 * j], ya = cur[(size_t)(2 * i) * 2 * half + 2 * j + 1];
-            const Fr xb = cur[(size_t)(2 * i + 1) * 2 * half + 2 * j], yb = cur[(size_t)(2 * i + 1) * 2 * half + 2 * j + 1];
+            // (the round kernels leave loose values, bn254_lazy.hpp: the canonical operations below want them normalised)
+            const Fr xa = lz_canon(cur[(size_t)(2 * i) * 2 * half + 2 * j]), ya = lz_canon(cur[(size_t)(2 * i) * 2 * half + 2 * j + 1]);
+            const Fr xb = lz_canon(cur[(size_t)(2 * i + 1) * 2 * half + 2 * j]), yb = lz_canon(cur[(size_t)(2 * i + 1) * 2 * half + 2 * j + 1]);
             const Fr da = fr_sub(ya, xa), db = fr_sub(yb, xb);
             Fr av, bv;  // the pair at this group's evaluation point
             if (v == 0) { av = xa; bv = xb; }
@@ -413,7 +478,7 @@ __device__ __forceinline__ void bn_tail_body(const Fr* __restrict__ in, Fr* __re
             else { av = fr_add(fr_add(ya, da), da); bv = fr_add(fr_add(yb, db), db); }
             Fr term = fr_mul_wide(av, bv);
             if (KIND == BN_GRANDPROD) {
-                const Fr x0 = cur[2 * j], y0 = cur[2 * j + 1];
+                const Fr x0 = lz_canon(cur[2 * j]), y0 = lz_canon(cur[2 * j + 1]);
                 const Fr d0 = fr_sub(y0, x0);
                 const Fr pv = v == 0 ? x0 : (v == 1 ? fr_add(y0, d0) : fr_add(fr_add(y0, d0), d0));
                 term = fr_mul_wide(pv, term);
@@ -894,6 +959,8 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
                 }
                 const RoundGrid g = round_grid_gp(half, d.nb);
                 d.gx = g.gx; d.gy = g.gy;
+                static const int dbg = [] { const char* e = getenv("HG_BN_DBG"); return e && *e ? atoi(e) : 0; }();
+                d.dbg = dbg;
                 reds[red_index[n]].n[rd] = g.blocks();
                 own.by_rd[rd].push_back(d);
             }
@@ -1141,8 +1208,13 @@ __global__ void k_bn_low_limb(const Fr* __restrict__ in, u64* __restrict__ out, 
     if (v.l[1] | v.l[2] | v.l[3]) atomicOr(bad, 1);
 }
 // in4: host table (4 canonical limbs per element), or null with d_in_mont: the node input as it lies in HBM (Montgomery form)
+// the flag of k_bn_low_limb into a result slot (plain store into host-mapped memory; no blocking copy of a device word)
+__global__ void k_bn_flag_out(const int* __restrict__ flag, Fr* __restrict__ slot) { *slot = fr_make((u64)*flag, 0, 0, 0); }
+// mid (optional): called once while the node's launches are being enqueued, at stage `mid_at` (1: behind the limb split and the
+// counters, 2: behind the hashes and before the grand products, 3: behind everything) - the caller enqueues independent work on
+// another stream there, so that the device has both chains queued from the start of the prove (bn254_gkr.inc: BnProver::run)
 static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4, const Fr* d_in_mont, size_t chain_skip, std::vector<uint8_t>& proof,
-                                   u64* claim_out) {
+                                   u64* claim_out, const std::function<void()>* mid = nullptr, int mid_at = 0) {
     if (!pk->ctx) throw Error("hg_lasso_prove_bn254: host-only prover key");
     const LassoPlan& lp = pk->lasso;
     const dev::LassoDev& L = pk->lasso_dev;
@@ -1159,7 +1231,7 @@ static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4,
             low[j] = in4[4 * j];
         }
     }
-    int h_bad = 0;
+    const Fr* h_bad = nullptr;
     const size_t r_at = chain_skip, col_at = r_at + nu, gamma_at = col_at + nu, tau_at = gamma_at + 1, gp1_at = tau_at + 1,
                  gp2_at = gp1_at + gp_challenges(nu), total = gp2_at + gp_challenges(16);
     const std::vector<Fr> chain = challenge_chain_bn254(total);
@@ -1179,7 +1251,9 @@ static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4,
         else {
             hipc(hipMemsetAsync(d_bad, 0, sizeof(int), st), "clear flag");
             k_bn_low_limb<<<grid1(N), 256, 0, st>>>(d_in_mont, d_in, N, d_bad);
-            hipc(hipMemcpyAsync(&h_bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, st), "copy flag");  // (a blocking copy: pageable destination)
+            const ResRef fl = res_slots(ctx, 1);
+            k_bn_flag_out<<<1, 1, 0, st>>>(d_bad, fl.dev);
+            h_bad = fl.host;
         }
         u64* dims = (u64*)dalloc_b(4 * N * 8);
         u64* ep = (u64*)dalloc_b((size_t)A * N * 8);
@@ -1205,6 +1279,7 @@ static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4,
             u32* starts = (u32*)dalloc_b((4 * 65536 + 1) * 4);
             dev::lasso_counters_all(st, L, mask, dims, co, temp, tb, keys, keys2, rows, rows2, starts);
         }
+        if (mid && mid_at == 1) (*mid)();
         Fr* d_part = dalloc(1024 * 3);
         const ResRef r_claimed = res_slots(ctx, 1), r_col = res_slots(ctx, (size_t)nu * 2);
         Fr* eq_scratch = dalloc(eq_scratch_len(std::max(nu, 16)));
@@ -1273,6 +1348,7 @@ static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4,
         // the write hashes are the read hashes + gamma^2 (k_bn_hash_rw): the top layer runs on the read rows only
         // both grand products and the openings are enqueued back to back (nothing here depends on a result read by the host: the
         // points are challenges); ONE wait at the end, then the two transcript replays
+        if (mid && mid_at == 2) (*mid)();
         GpLaunchSet gp_set;   // the rounds of BOTH grand products share their launches: the small one (2^16 rows) hides inside the big one's
         grand_product_core(ctx, 2 * G, N, nullptr, H1, gp1_at, gp1_bytes, tmp_claims, x, mirror ? &gamma2 : nullptr, &replay_gp1, &gp_set);  // reads then writes (prover.rs:161-165)
         grand_product_core(ctx, 2 * G, M, nullptr, H2, gp2_at, gp2_bytes, tmp_claims2, y, nullptr, &replay_gp2, &gp_set);  // inits then finals (prover.rs:167-171)
@@ -1312,8 +1388,12 @@ static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4,
             run(eq, tx, ox, nx, N);
             run(eqy, ty, oy, ny, M);
         }
+        if (mid && mid_at >= 3) (*mid)();
+        static const bool times = getenv("HG_BN_TIMES") != nullptr;
+        const double t_enq = wall_ms();
         res_sync(ctx, st, "lasso_prove_bn254: sync");
-        if (h_bad) throw Error("hg_lasso_prove_bn254: the node input holds a value that is not below 2^64 (not a range-shifted value)");
+        if (times) fprintf(stderr, "[hg bn]   lasso node: enqueued, waited %.3f ms for its stream\n", wall_ms() - t_enq);
+        if (h_bad && h_bad->l[0]) throw Error("hg_lasso_prove_bn254: the node input holds a value that is not below 2^64 (not a range-shifted value)");
         {   // the two replays are independent (own byte buffers, own claim vectors): ~0.25 and ~0.2 ms of host field arithmetic
             std::exception_ptr err;
             std::thread other([&] { try { replay_gp2(); } catch (...) { err = std::current_exception(); } });
