@@ -367,7 +367,7 @@ __global__ void k_bn_weight_rows(const Fr* __restrict__ rows, size_t row_len, co
     if (idx >= h * (size_t)nb) return;
     const size_t b = idx >> (__ffsll((long long)h) - 1), i = idx & (h - 1);   // (h is a power of two)
     const Fr x = rows[b * row_len + i];
-    out[idx] = b == 0 ? x : fr_mul_wide(pw[b], x);
+    out[idx] = b == 0 ? x : lz_mul(pw[b], x);
 }
 // mirrored top layer: the weighted left halves of the READ rows (as k_bn_weight_rows) and, in the same pass, the linear table
 // S[i] = sum_b pw[b] (l_b[i] + r_b[i]) over the read rows b < nb (r_b = the right half of row b, in place at rows + h)
@@ -375,16 +375,16 @@ __global__ __launch_bounds__(256) void k_bn_weight_rows_sum(const Fr* __restrict
                                                           Fr* __restrict__ out, Fr* __restrict__ S, size_t h, int nb) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= h) return;
-    Fr acc = fr_zero();
+    Fr acc = fr_zero();   // loose throughout (bn254_lazy.hpp)
     WCol c = wcol_zero();
     for (int b = 0; b < nb; b++) {
-        const Fr x = rows[(size_t)b * row_len + i];
-        const Fr lw = b == 0 ? x : fr_fold_const(fr_zero(), x, fk[b].k);   // (b is the loop index: uniform over the wave)
-        out[(size_t)b * h + i] = lw;
-        acc = fr_add(acc, lw);
-        wcol_mac(c, pw[b], rows[(size_t)b * row_len + h + i]);
+        const Fr x = lz_gload(&rows[(size_t)b * row_len + i]);
+        const Fr lw = b == 0 ? x : lz_fold(fr_zero(), x, fk[b].k);   // (b is the loop index: uniform over the wave)
+        lz_gstore(&out[(size_t)b * h + i], lw);
+        acc = lz_add(acc, lw);
+        wcol_mac(c, pw[b], lz_gload(&rows[(size_t)b * row_len + h + i]));
     }
-    S[i] = fr_add(acc, wcol_reduce(c));
+    lz_gstore(&S[i], lz_add(acc, lz_reduce(c)));
 }
 // launch shape of a round over `half` pair indices and `nitems` independent items (pairs / tables): grid.x workgroups along j,
 // grid.y groups of items; large rounds keep one thread per j, small ones spread the items
@@ -509,6 +509,51 @@ __global__ __launch_bounds__(BN_TPB * (KIND == BN_GRANDPROD ? 3 : 2)) void k_bn_
     bn_tail_body<KIND>(J.in, J.buf, J.npairs, J.half0, J.nrounds, J.rs, J.sums_out, J.fin_out);
 }
 
+// ---- PRODSUM rounds (Libra / zkCNN node reductions, bn254_gkr.inc; the collation sum-check of the Lasso node) ----------------
+// The second sum is g(2) ITSELF, not a coefficient from which the host could rebuild it with the running claim: the reference's prover
+// takes eval(1) from the claim and computes eval(2) (convention C1), and the claim is not the sum of g for the collation sum-check of
+// the Lasso node (Expression::poly(0) stands where an eq table would, lasso.rs:457-475) nor for any node of an INVALID witness - the
+// transcript must be the reference's there too (test_bn254_invalid_witness_rejected_by_both_verifiers).
+struct PsJobDev { const Fr* t[2 * dev::PS_MAX_PAIRS]; Fr* out; Fr* part; Fr r; unsigned long long half; int npairs, gx, gy, pad; FoldK fk; };   // fk = fold_consts(r)
+// One round of g = sum_i a_i b_i for many independent sum-checks (blockIdx.y = job). Two workgroup sets per tile (v = 0: g(0) = sum xa xb
+// and the folds of the a tables, v = 1: g(2) = sum (2 ya - xa)(2 yb - xb) and the folds of the b tables; ids 8 (2 q + v) + xcd keep a
+// tile's two workgroups on one XCD, adjacent in dispatch order, so the second reads the tables from L2): one column accumulator, one
+// multiply-accumulate and one fold per lane and (pair, j) keeps the kernel at ~120 VGPRs = four waves per SIMD, which is what hides the
+// load latency of these mostly small, single-pair jobs (one lane doing both halves needs 259 registers, one wave per SIMD: 1.3x
+// slower). Loose arithmetic throughout (bn254_lazy.hpp); the folded tables are loose.
+__global__ __launch_bounds__(BN_TPB) void k_bn_ps_round_jobs(const PsJobDev* __restrict__ jobs) {
+    const PsJobDev& J = jobs[blockIdx.y];
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, v = slot & 1, tile = (slot >> 1) * 8 + xcd;
+    if (tile >= J.gx * J.gy) return;
+    __shared__ Fr sm[BN_TPB];
+    Fr acc = fr_zero();   // loose
+    const int bx = tile % J.gx, pi = tile / J.gx, P = J.gy, npairs = J.npairs;
+    const size_t half = J.half;
+    Fr* __restrict__ out = J.out;
+    const u32* __restrict__ K = J.fk.k;
+    for (size_t j = (size_t)bx * BN_TPB + threadIdx.x; j < half; j += (size_t)J.gx * BN_TPB) {
+        WCol s = wcol_zero();
+        for (int i = pi; i < npairs; i += P) {
+            const Fr* ta = J.t[2 * i];
+            const Fr* tb = J.t[2 * i + 1];
+            const Fr xa = lz_gload(&ta[2 * j]), ya = lz_gload(&ta[2 * j + 1]);
+            const Fr xb = lz_gload(&tb[2 * j]), yb = lz_gload(&tb[2 * j + 1]);
+            if (v == 0) {   // (uniform over the workgroup)
+                wcol_mac(s, xa, xb);
+                lz_gstore(&out[(size_t)(2 * i) * half + j], lz_fold(xa, lz_sub(ya, xa), K));
+            } else {
+                const Fr db = lz_sub(yb, xb);
+                wcol_mac(s, lz_add(ya, lz_subr(ya, xa)), lz_add(yb, lz_cond_sub_2p(db)));   // (2 ya - xa)(2 yb - xb)
+                lz_gstore(&out[(size_t)(2 * i + 1) * half + j], lz_fold(xb, db, K));
+            }
+        }
+        acc = lz_add(acc, lz_reduce(s));
+    }
+    const size_t blk = (size_t)pi * J.gx + bx;
+    const Fr r = block_sum_fr(lz_canon(acc), sm);
+    if (threadIdx.x == 0) J.part[blk * 2 + v] = r;
+}
+
 // ---- host arithmetic for the transcript replay (Montgomery form) ---------------------------------------------
 static Fr fr_pow(Fr b, const u64 e[4]) {
     Fr r = fr_one_mont();
@@ -548,21 +593,26 @@ static void res_sync(hg_ctx* ctx, hipStream_t st, const char* what) {
     hipc(hipStreamSynchronize(st), what);
     hipc(hipGetLastError(), what);
 }
-// Small host->device descriptor uploads go through the context's pinned staging buffer (reset by arena_reset): a hipMemcpyAsync
-// from pageable memory is staged by the runtime IN STREAM ORDER, i.e. the host blocks until the stream has drained up to it -
-// which kept the host from running ahead of the node stream (the Lasso node started 3.5 ms into the prove). Falls back to the
-// pageable copy when the staging buffer is full (keep-alive is then the caller's business, as before).
-static void bn_upload(hg_ctx* ctx, hipStream_t st, void* dst, const void* src, size_t bytes, const char* what) {
-    const size_t need = (bytes + 63) & ~(size_t)63;
-    if (ctx->h_stage && ctx->stage_used + need <= ctx->stage_cap) {
-        void* p = ctx->h_stage + ctx->stage_used;
-        ctx->stage_used += need;
-        memcpy(p, src, bytes);
-        hipc(hipMemcpyAsync(dst, p, bytes, hipMemcpyHostToDevice, st), what);
-    } else {
-        hipc(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st), what);
-        hipc(hipStreamSynchronize(st), what);   // (the source may be a local)
-    }
+// Host -> device descriptor arrays: staged in the context's pinned buffer and in its device mirror AT THE SAME OFFSET; bn_flush copies
+// everything staged since the last flush in one transfer on the stream whose launches read it (call it after staging, before the
+// first launch of a phase). Round 3 issued one hipMemcpyAsync per array: ~100 copy kernels per prove, and a copy from pageable
+// memory would make the host wait for the stream.
+static void* bn_stage_bytes(hg_ctx* ctx, const void* src, size_t bytes) {
+    const size_t need = (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255;
+    if (!ctx->h_stage || ctx->stage_used + need > ctx->stage_cap) throw Error("bn254: descriptor staging buffer exhausted");
+    if (!ctx->bn_dstage) hipc(hipMalloc((void**)&ctx->bn_dstage, ctx->stage_cap), "hipMalloc(descriptor mirror)");
+    if (ctx->bn_flushed > ctx->stage_used) ctx->bn_flushed = ctx->stage_used;   // (the staging buffer was reset by another user)
+    memcpy(ctx->h_stage + ctx->stage_used, src, bytes);
+    void* d = ctx->bn_dstage + ctx->stage_used;
+    ctx->stage_used += need;
+    return d;
+}
+template <typename T> static T* bn_stage(hg_ctx* ctx, const T* src, size_t n) { return static_cast<T*>(bn_stage_bytes(ctx, src, n * sizeof(T))); }
+static void bn_flush(hg_ctx* ctx, hipStream_t st) {
+    if (ctx->bn_flushed > ctx->stage_used) ctx->bn_flushed = ctx->stage_used;
+    if (ctx->stage_used == ctx->bn_flushed) return;
+    hipc(hipMemcpyAsync(ctx->bn_dstage + ctx->bn_flushed, ctx->h_stage + ctx->bn_flushed, ctx->stage_used - ctx->bn_flushed, hipMemcpyHostToDevice, st), "upload descriptors");
+    ctx->bn_flushed = ctx->stage_used;
 }
 __global__ void k_bn_copy_from_mont(const Fr* __restrict__ src, Fr* __restrict__ dst, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -683,9 +733,9 @@ __global__ void k_bn_prod_level(const Fr* __restrict__ in, size_t in_len, Fr* __
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const size_t b = i >> (__ffsll((long long)h) - 1), j = i & (h - 1);
-    const Fr v = fr_mul_wide(in[b * in_len + j], in[b * in_len + j + h]);  // Layer::bottom / Layer::up: v_l * v_r on the MSB split
+    const Fr v = lz_mul(in[b * in_len + j], in[b * in_len + j + h]);  // Layer::bottom / Layer::up: v_l * v_r on the MSB split (loose in, loose out)
     out[b * h + j] = v;
-    if (lw && j < (h >> 1)) lw[b * (h >> 1) + j] = b == 0 ? v : fr_mul_wide(pw[b], v);
+    if (lw && j < (h >> 1)) lw[b * (h >> 1) + j] = b == 0 ? v : lz_mul(pw[b], v);
 }
 // the same with the row index on grid.y (uniform per workgroup), so that the weight of row b is a LAUNCH-WIDE constant of the
 // workgroup: lw = pw[b] * v runs through fr_fold_const with the row's precomputed constants fk[b] (k_bn_fold_consts)
@@ -693,9 +743,9 @@ __global__ void k_bn_prod_level_rows(const Fr* __restrict__ in, size_t in_len, F
     const size_t h = in_len >> 1, b = blockIdx.y;
     const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= h) return;
-    const Fr v = fr_mul_wide(in[b * in_len + j], in[b * in_len + j + h]);
-    out[b * h + j] = v;
-    if (j < (h >> 1)) lw[b * (h >> 1) + j] = b == 0 ? v : fr_fold_const(fr_zero(), v, fk[b].k);
+    const Fr v = lz_mul(lz_gload(&in[b * in_len + j]), lz_gload(&in[b * in_len + j + h]));
+    lz_gstore(&out[b * h + j], v);
+    if (j < (h >> 1)) lz_gstore(&lw[b * (h >> 1) + j], b == 0 ? v : lz_fold(fr_zero(), v, fk[b].k));
 }
 // fk[e] = fold_consts(pw[e]) for a run of weights (one thread per (weight, limb row))
 __global__ void k_bn_fold_consts(const Fr* __restrict__ pw, FoldK* __restrict__ fk, size_t count) {
@@ -718,14 +768,14 @@ __global__ void k_bn_prod_level_mirror(const Fr* __restrict__ in, size_t in_len,
     const size_t h = in_len >> 1, half = (size_t)nb / 2, b = blockIdx.y;
     const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= h) return;
-    const Fr x = in[b * in_len + j], y = in[b * in_len + j + h];
-    const Fr v = fr_mul_wide(x, y);
-    const Fr vw = fr_add(v, fr_fold_const(c2, fr_add(x, y), kc.k));
-    out[b * h + j] = v;
-    out[(b + half) * h + j] = vw;
+    const Fr x = lz_gload(&in[b * in_len + j]), y = lz_gload(&in[b * in_len + j + h]);   // loose (k_bn_hash_rw)
+    const Fr v = lz_mul(x, y);
+    const Fr vw = lz_add(v, lz_fold(c2, lz_add(x, y), kc.k));
+    lz_gstore(&out[b * h + j], v);
+    lz_gstore(&out[(b + half) * h + j], vw);
     if (lw && j < (h >> 1)) {
-        lw[b * (h >> 1) + j] = b == 0 ? v : fr_fold_const(fr_zero(), v, fk[b].k);
-        lw[(b + half) * (h >> 1) + j] = fr_fold_const(fr_zero(), vw, fk[b + half].k);
+        lz_gstore(&lw[b * (h >> 1) + j], b == 0 ? v : lz_fold(fr_zero(), v, fk[b].k));
+        lz_gstore(&lw[(b + half) * (h >> 1) + j], lz_fold(fr_zero(), vw, fk[b + half].k));
     }
 }
 static void write_be32(std::vector<uint8_t>& out, const Fr& canonical) {  // transcript.rs:183-189: repr, byte-reversed
@@ -763,6 +813,12 @@ static Fr replay_round(const Fr* sums_canonical, int d, Fr claim, Fr r, Fr* c /*
     return h;
 }
 
+static int ps_nmain(int nv) {   // rounds done by the shared launches; the rest (short tables) by the job's tail workgroup
+    const size_t N = (size_t)1 << nv;
+    for (int rd = 1; rd < nv; rd++)
+        if ((N >> (rd + 1)) <= (size_t)BN_TAIL_HALF && nv - rd <= BN_TAIL_ROUNDS) return rd;
+    throw Error("bn254 prodsum: table too short for the tail split");
+}
 // nb tables of `len` = 2^nv elements each (host, canonical). The transcript is entered after `chain_skip` challenges.
 // proof: root products, then per layer the sum-check rounds (4 coefficients each) and the 2 nb evaluations, as 32-byte
 // big-endian elements. claims_out: nb final claims, point_out: nv coordinates.
@@ -795,12 +851,10 @@ static void gp_launch_set(hg_ctx* ctx, hipStream_t st, GpLaunchSet& S) {
         descs.insert(descs.end(), v.begin(), v.end());
     }
     if (descs.empty()) return;
-    GpJobDev* d_descs = static_cast<GpJobDev*>(ctx->alloc(descs.size() * sizeof(GpJobDev)));
-    RedJobDev* d_reds = static_cast<RedJobDev*>(ctx->alloc(std::max<size_t>(S.reds.size(), 1) * sizeof(RedJobDev)));
-    TailJobDev* d_tails = static_cast<TailJobDev*>(ctx->alloc(std::max<size_t>(S.tails.size(), 1) * sizeof(TailJobDev)));
-    bn_upload(ctx, st, d_descs, descs.data(), descs.size() * sizeof(GpJobDev), "upload round jobs");
-    if (!S.reds.empty()) bn_upload(ctx, st, d_reds, S.reds.data(), S.reds.size() * sizeof(RedJobDev), "upload reduce jobs");
-    if (!S.tails.empty()) bn_upload(ctx, st, d_tails, S.tails.data(), S.tails.size() * sizeof(TailJobDev), "upload tail jobs");
+    const GpJobDev* d_descs = bn_stage(ctx, descs.data(), descs.size());
+    const RedJobDev* d_reds = S.reds.empty() ? nullptr : bn_stage(ctx, S.reds.data(), S.reds.size());
+    const TailJobDev* d_tails = S.tails.empty() ? nullptr : bn_stage(ctx, S.tails.data(), S.tails.size());
+    bn_flush(ctx, st);
     for (size_t rd = 0; rd < S.by_rd.size(); rd++)
         if (!S.by_rd[rd].empty()) k_bn_gp_round_jobs<<<dim3(max_blocks[rd], (unsigned)S.by_rd[rd].size(), 1), BN_TPB, 0, st>>>(d_descs + off[rd]);
     if (!S.reds.empty()) k_bn_reduce_jobs<<<dim3(32, (unsigned)S.reds.size()), BN_TPB, 0, st>>>(d_reds, 3);
@@ -1099,8 +1153,9 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_lasso_claim(dev::LassoDev L, cons
     if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
 // The two tables of the collation sum-check (lasso.rs:271-279): g = E_0 * sum_m M^m E_m only needs E_0 and the weighted SUM of
-// the E tables (folding is linear, the final evaluations are dropped, lasso.rs:97). out[0][k] = E_0[k], out[1][k] = sum_{m >= 1}
-// M^m E_m[k] (so that the two rows add up to the full sum), both in Montgomery form; at most four memories are non-zero in a row.
+// the E tables (folding is linear, the final evaluations are dropped, lasso.rs:97). out[0][k] = E_0[k], out[1][k] = sum_{m >= 0}
+// M^m E_m[k] (the full weighted sum: g = out[0] * out[1] is then ONE product pair of the PRODSUM round kernel), both in Montgomery
+// form; at most four memories are non-zero in a row.
 struct BnColPow { Fr v[32]; };  // (M^m) R^2 (raw limbs of fr_to_mont(M^m)), see k_bn_lasso_claim
 __global__ __launch_bounds__(BN_TPB) void k_bn_collation_tabs(dev::LassoDev L, const u64* __restrict__ e_polys, BnColPow P, Fr* __restrict__ out) {
     const size_t N = (size_t)1 << L.nu;
@@ -1108,7 +1163,7 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_collation_tabs(dev::LassoDev L, c
         WCol c0 = wcol_zero(), c1 = wcol_zero();
         if (k < L.rows) {
             const u64 uses = L.lookup_uses[L.seg_lookup[k >> L.seg_shift]];
-            if (uses & 1) wcol_mac_u64(c0, e_polys[k], P.v[0]);
+            if (uses & 1) { wcol_mac_u64(c0, e_polys[k], P.v[0]); wcol_mac_u64(c1, e_polys[k], P.v[0]); }
             for (int m = 1; m < L.alpha; m++)
                 if ((uses >> m) & 1) wcol_mac_u64(c1, e_polys[(size_t)m * N + k], P.v[m]);
         }
@@ -1166,13 +1221,40 @@ static void hashk_consts(HashK& K, const Fr& gamma_mont, const Fr& gamma2_mont, 
     const Fr c[4] = {fr_one_mont(), gamma_mont, gamma2_mont, fr_sub(fr_zero(), tau_mont)};
     for (int q = 0; q < 4; q++) for (int i = 0; i < 4; i++) { K.kc[8 * q + 2 * i] = (u32)c[q].l[i]; K.kc[8 * q + 2 * i + 1] = (u32)(c[q].l[i] >> 32); }
 }
+// all memories of the node in one launch (blockIdx.y = position in the memory-GKR order): the read (and write) hash rows, and for
+// blockIdx.x beyond the rows' blocks the init / final rows of the same memory (k_bn_hash_if's work)
+struct HashMem { const u64* dim; const u64* ep; const u64* ts; const u64* fc; Fr* rd; Fr* wr; Fr* init; Fr* fin; u32 cutoff, pad; };
+struct HashMems { HashMem m[32]; };
+__device__ __forceinline__ void bn_hash_if_entry(u32 a, u32 cutoff, const u64* __restrict__ fc, const HashK& K, Fr* __restrict__ init, Fr* __restrict__ fin);
+__global__ __launch_bounds__(256) void k_bn_hash_all(size_t n, HashMems M, HashK K) {
+    const HashMem& m = M.m[blockIdx.y];
+    const size_t nblk = (n + 255) / 256;
+    if (blockIdx.x >= nblk) {   // (uniform) the 2^16-entry init / final rows
+        bn_hash_if_entry((u32)((blockIdx.x - nblk) * 256 + threadIdx.x), m.cutoff, m.fc, K, m.init, m.fin);
+        return;
+    }
+    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const u64 a = m.dim[j], v = m.ep[j], t = m.ts[j];
+    Fr h;   // loose (bn254_lazy.hpp): read by the product-tree and round kernels
+    if (((a | v | t) >> 32) == 0) h = lz_lin3((u32)a, (u32)v, (u32)t, K.kc);   // addresses, limb values, counters: always
+    else {
+        WCol w = wcol_zero();
+        wcol_mac_u64(w, a, K.one2);
+        wcol_mac_u64(w, v, K.gamma2x);
+        wcol_mac_u64(w, t, K.gammasq2x);
+        h = fr_sub(wcol_reduce(w), K.tau);
+    }
+    lz_gstore(&m.rd[j], h);
+    if (m.wr) lz_gstore(&m.wr[j], lz_add(h, K.gammasq));   // (null: the write rows are not materialised, see grand_product_core's mirror_c)
+}
 __global__ void k_bn_hash_rw(size_t n, const u64* __restrict__ dim, const u64* __restrict__ ep, const u64* __restrict__ ts, HashK K,
                              Fr* __restrict__ rd, Fr* __restrict__ wr) {
     size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     const u64 a = dim[j], v = ep[j], t = ts[j];
-    Fr h;
-    if (((a | v | t) >> 32) == 0) h = fr_lin3_const((u32)a, (u32)v, (u32)t, K.kc);   // addresses, limb values, counters: always
+    Fr h;   // loose (bn254_lazy.hpp): read by the product-tree and round kernels
+    if (((a | v | t) >> 32) == 0) h = lz_lin3((u32)a, (u32)v, (u32)t, K.kc);   // addresses, limb values, counters: always
     else {
         WCol w = wcol_zero();
         wcol_mac_u64(w, a, K.one2);
@@ -1181,10 +1263,9 @@ __global__ void k_bn_hash_rw(size_t n, const u64* __restrict__ dim, const u64* _
         h = fr_sub(wcol_reduce(w), K.tau);
     }
     rd[j] = h;
-    if (wr) wr[j] = fr_add(h, K.gammasq);   // (null: the write rows are not materialised, see grand_product_core's mirror_c)
+    if (wr) wr[j] = lz_add(h, K.gammasq);   // (null: the write rows are not materialised, see grand_product_core's mirror_c)
 }
-__global__ void k_bn_hash_if(u32 cutoff, const u64* __restrict__ fc, HashK K, Fr* __restrict__ init, Fr* __restrict__ fin) {
-    u32 a = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void bn_hash_if_entry(u32 a, u32 cutoff, const u64* __restrict__ fc, const HashK& K, Fr* __restrict__ init, Fr* __restrict__ fin) {
     if (a >= 65536) return;
     const u64 f = fc[a];
     const u32 tv = a < cutoff ? a : 0u;
@@ -1197,6 +1278,9 @@ __global__ void k_bn_hash_if(u32 cutoff, const u64* __restrict__ fc, HashK K, Fr
         wcol_mac_u64(w2, f, K.gammasq2x);
         fin[a] = fr_sub(wcol_reduce(w2), K.tau);
     }
+}
+__global__ void k_bn_hash_if(u32 cutoff, const u64* __restrict__ fc, HashK K, Fr* __restrict__ init, Fr* __restrict__ fin) {
+    bn_hash_if_entry(blockIdx.x * blockDim.x + threadIdx.x, cutoff, fc, K, init, fin);
 }
 
 // low limbs of a Montgomery-form table; *bad is set when an element does not fit one limb
@@ -1243,6 +1327,7 @@ static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4,
     std::vector<Fr> x, y, tmp_claims, tmp_claims2, h_col((size_t)nu * 2), opens;
     std::function<void()> replay_gp1, replay_gp2;
     Fr h_claimed;
+    int col_nmain = 0;
     try {
         // polynomialize (lasso.rs:157-250): integer kernels of the Goldilocks path
         u64* d_in = (u64*)dalloc_b(N * 8);
@@ -1308,26 +1393,49 @@ static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4,
                 for (int i = 0; i < 32; i++) { cp.v[i] = i < A ? fr_to_mont(pwr) : fr_zero(); pwr = fr_mul(pwr, m); }
             }
             k_bn_collation_tabs<<<(unsigned)std::min<size_t>((N + BN_TPB - 1) / BN_TPB, 4096), BN_TPB, 0, st>>>(L, ep, cp, tabs);
-            Fr* d_pw = dalloc(2);
-            k_bn_powers<<<1, 256, 0, st>>>(d_pw, fr_one_mont(), (size_t)2);   // weights 1, 1: the powers of M are inside the second table
+            // g = tabs[0] * tabs[1]: a PRODSUM sum-check with one pair (k_bn_ps_round_jobs for the long rounds, one tail workgroup for
+            // the rest); the round slots hold (g(0), g(2))
+            if (nu > 32) throw Error("hg_lasso_prove_bn254: more than 32 rounds");
+            col_nmain = ps_nmain(nu);
             Fr* buf0 = dalloc(N);
             Fr* buf1 = dalloc(std::max<size_t>(N / 2, 1));
-            Fr* d_sums = r_col.dev;
-            const Fr* cur = tabs;
-            Fr* nxt = buf0;
-            if (nu > 32) throw Error("hg_lasso_prove_bn254: more than 32 rounds");
             Fr* part = dalloc((size_t)nu * BN_PART_STRIDE * 2);
-            RoundCounts rc;
-            for (int rd = 0; rd < nu; rd++) {
+            Fr* tbuf = dalloc(2 * 2 * (size_t)BN_TAIL_HALF);
+            Fr* fin_dummy = dalloc(2);
+            std::vector<PsJobDev> descs(col_nmain);
+            RedJobDev red;
+            memset(&red, 0, sizeof(red));
+            std::vector<int> blocks(col_nmain);
+            for (int rd = 0; rd < col_nmain; rd++) {
                 const size_t half = N >> (rd + 1);
-                const RoundGrid g = round_grid(half, 2);
-                k_bn_round<BN_COLLATION><<<dim3(g.gx, g.gy), BN_TPB, 0, st>>>(cur, nxt, 2, half, fr_to_mont(chain[col_at + rd]), d_pw,
-                                                                               part + (size_t)rd * BN_PART_STRIDE * 2);
-                rc.n[rd] = g.blocks();
-                cur = nxt;
-                nxt = nxt == buf0 ? buf1 : buf0;
+                PsJobDev& d = descs[rd];
+                memset(&d, 0, sizeof(d));
+                const Fr* inb = (rd & 1) ? buf0 : buf1;
+                d.t[0] = rd == 0 ? tabs : inb;
+                d.t[1] = rd == 0 ? tabs + N : inb + 2 * half;
+                d.out = (rd & 1) ? buf1 : buf0;
+                d.part = part + (size_t)rd * BN_PART_STRIDE * 2;
+                d.r = fr_to_mont(chain[col_at + rd]);
+                fold_consts(d.r, &d.fk);
+                d.half = half; d.npairs = 1;
+                const RoundGrid g = round_grid(half, 1);
+                d.gx = g.gx; d.gy = g.gy;
+                red.n[rd] = blocks[rd] = g.blocks();
             }
-            k_bn_reduce_rounds<<<nu, BN_TPB, 0, st>>>(part, rc, 2, d_sums);
+            red.part = part; red.out = r_col.dev; red.nrounds = col_nmain;
+            TailJobDev tl;
+            memset(&tl, 0, sizeof(tl));
+            tl.in = ((col_nmain - 1) & 1) ? buf1 : buf0;
+            tl.buf = tbuf; tl.sums_out = r_col.dev + (size_t)col_nmain * 2; tl.fin_out = fin_dummy;
+            for (int q = 0; q < BN_TAIL_ROUNDS; q++) tl.rs.r[q] = q < nu - col_nmain ? fr_to_mont(chain[col_at + col_nmain + q]) : fr_zero();
+            tl.npairs = 1; tl.half0 = (int)(N >> (col_nmain + 1)); tl.nrounds = nu - col_nmain;
+            const PsJobDev* d_descs = bn_stage(ctx, descs.data(), descs.size());
+            const RedJobDev* d_red = bn_stage(ctx, &red, 1);
+            const TailJobDev* d_tl = bn_stage(ctx, &tl, 1);
+            bn_flush(ctx, st);
+            for (int rd = 0; rd < col_nmain; rd++) k_bn_ps_round_jobs<<<dim3(2 * ((blocks[rd] + 7) / 8 * 8), 1, 1), BN_TPB, 0, st>>>(d_descs + rd);
+            k_bn_reduce_jobs<<<dim3(32, 1), BN_TPB, 0, st>>>(d_red, 2);
+            k_bn_tail_jobs<BN_PRODSUM><<<1, 2 * BN_TPB, 0, st>>>(d_tl);
         }
         // MemoryCheckingProver::new (prover.rs:35-89): gamma, tau are the challenges themselves (E = F)
         const Fr gamma = fr_to_mont(chain[gamma_at]), tau = fr_to_mont(chain[tau_at]), gamma2 = fr_mul(gamma, gamma);
@@ -1339,11 +1447,18 @@ static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4,
         const bool mirror = use_mirror && nu >= 2;   // write hash = read hash + gamma^2: only the read rows exist
         Fr* H1 = dalloc((size_t)(mirror ? G : 2 * G) * N);
         Fr* H2 = dalloc((size_t)2 * G * M);
-        for (int i = 0; i < G; i++) {
-            const int m = lp.gkr_order[i], c = lp.gkr_chunk[i];
-            k_bn_hash_rw<<<grid1(N), 256, 0, st>>>(N, dims + (size_t)c * N, ep + (size_t)m * N, read_ts[c], HK, H1 + (size_t)i * N,
-                                                  mirror ? nullptr : H1 + (size_t)(G + i) * N);
-            k_bn_hash_if<<<65536 / 256, 256, 0, st>>>((u32)lp.mems[m].cutoff, final_cts[c], HK, H2 + (size_t)i * M, H2 + (size_t)(G + i) * M);
+        {   // every memory's read (write) hash rows and init / final rows in one launch
+            if (G > 32) throw Error("hg_lasso_prove_bn254: more than 32 memories");
+            HashMems HM;
+            memset(&HM, 0, sizeof(HM));
+            for (int i = 0; i < G; i++) {
+                const int m = lp.gkr_order[i], c = lp.gkr_chunk[i];
+                HashMem& h = HM.m[i];
+                h.dim = dims + (size_t)c * N; h.ep = ep + (size_t)m * N; h.ts = read_ts[c]; h.fc = final_cts[c];
+                h.rd = H1 + (size_t)i * N; h.wr = mirror ? nullptr : H1 + (size_t)(G + i) * N;
+                h.init = H2 + (size_t)i * M; h.fin = H2 + (size_t)(G + i) * M; h.cutoff = (u32)lp.mems[m].cutoff;
+            }
+            k_bn_hash_all<<<dim3(grid1(N) + 65536 / 256, (unsigned)G), 256, 0, st>>>(N, HM, HK);
         }
         // the write hashes are the read hashes + gamma^2 (k_bn_hash_rw): the top layer runs on the read rows only
         // both grand products and the openings are enqueued back to back (nothing here depends on a result read by the host: the
@@ -1467,6 +1582,86 @@ __global__ void k_bn_ntt_stage(Fr* __restrict__ a, const Fr* __restrict__ W, int
     a[i0] = fr_add(u, v);
     a[i1] = fr_sub(u, v);
 }
+// ---- four-step NTT with LDS-resident sub-transforms (2^8 <= N <= 2^16): N = N1 N2, the counterpart of k_ntt4_cols / k_ntt4_rows ----
+//   X[k1 + N1 k2] = sum_{n2} w_N^(n2 k1) [ sum_{n1} x[N2 n1 + n2] w_N1^(n1 k1) ] w_N2^(n2 k2)
+// columns kernel: BN_NTT_TILE consecutive n2 per workgroup, the N1-point transforms in LDS (decimation in frequency, result bit-
+// reversed in the slow index), the twiddle w_N^(n2 k1) on the way out; rows kernel: BN_NTT_TILE consecutive k1, N2-point transforms,
+// the 1/N of the inverse transform and the canonical form on the way out. Two launches and two passes over HBM per batch instead of
+// a bit-reversal, log2 N radix-2 stage launches, a scaling pass and a copy. Loose arithmetic inside (bn254_lazy.hpp).
+constexpr int BN_NTT_TILE = 4;
+template <int STRIDE>
+__device__ __forceinline__ void bn_lds_ntt_dif(Fr* tile, int m, const Fr* __restrict__ W, int wstep_log2) {
+    // 2^m-point transform along the slow index of tile[pos * STRIDE + c]; twiddle w_M^j = W[j << wstep_log2]
+    const int M = 1 << m;
+    for (int s = m - 1; s >= 0; s--) {
+        const int h = 1 << s;
+        for (int q = threadIdx.x; q < (M / 2) * BN_NTT_TILE; q += blockDim.x) {
+            const int c = q & (BN_NTT_TILE - 1), p = q / BN_NTT_TILE;
+            const int j = p & (h - 1), a = ((p >> s) << (s + 1)) + j;
+            const Fr x = tile[a * STRIDE + c], y = tile[(a + h) * STRIDE + c];
+            tile[a * STRIDE + c] = lz_add(x, y);
+            tile[(a + h) * STRIDE + c] = j ? lz_mul(lz_sub(x, y), W[((size_t)j << (m - 1 - s)) << wstep_log2]) : lz_subr(x, y);
+        }
+        __syncthreads();
+    }
+}
+__device__ __forceinline__ u32 bn_brev_bits(u32 x, int bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
+struct NttSrc { const Fr* p[64]; };   // per transform of the batch: where its input lies (null: in place, at in + b N)
+__global__ __launch_bounds__(256) void k_bn_ntt4_cols(const Fr* __restrict__ in, Fr* __restrict__ out, int n, int n1, const Fr* __restrict__ W, NttSrc srcs) {
+    extern __shared__ Fr bn_ntile[];
+    const int n2 = n - n1;
+    const size_t N = (size_t)1 << n, N2 = (size_t)1 << n2;
+    const int N1 = 1 << n1;
+    const size_t i2_0 = (size_t)blockIdx.x * BN_NTT_TILE;
+    const Fr* x = blockIdx.y < 64 && srcs.p[blockIdx.y] ? srcs.p[blockIdx.y] : in + (size_t)blockIdx.y * N;
+    Fr* y = out + (size_t)blockIdx.y * N;
+    for (int idx = threadIdx.x; idx < N1 * BN_NTT_TILE; idx += blockDim.x) {
+        const int i1 = idx / BN_NTT_TILE, c = idx & (BN_NTT_TILE - 1);
+        bn_ntile[idx] = x[(size_t)i1 * N2 + i2_0 + c];
+    }
+    __syncthreads();
+    bn_lds_ntt_dif<BN_NTT_TILE>(bn_ntile, n1, W, n2);   // w_N1 = w^(N2)
+    for (int idx = threadIdx.x; idx < N1 * BN_NTT_TILE; idx += blockDim.x) {
+        const int pos = idx / BN_NTT_TILE, c = idx & (BN_NTT_TILE - 1);
+        const u32 k1 = bn_brev_bits((u32)pos, n1);
+        const size_t i2 = i2_0 + c, e = (size_t)k1 * i2;   // e < N
+        const Fr v = bn_ntile[idx];
+        y[(size_t)k1 * N2 + i2] = e ? lz_mul(v, W[e]) : v;
+    }
+}
+__global__ __launch_bounds__(256) void k_bn_ntt4_rows(const Fr* __restrict__ in, Fr* __restrict__ out, int n, int n1, const Fr* __restrict__ W, Fr scale, int scaled) {
+    extern __shared__ Fr bn_ntile[];
+    constexpr int ST = BN_NTT_TILE + 1;
+    const int n2 = n - n1;
+    const size_t N = (size_t)1 << n, N1 = (size_t)1 << n1;
+    const int N2 = 1 << n2;
+    const size_t k1_0 = (size_t)blockIdx.x * BN_NTT_TILE;
+    const Fr* y = in + (size_t)blockIdx.y * N;
+    Fr* X = out + (size_t)blockIdx.y * N;
+    for (int idx = threadIdx.x; idx < N2 * BN_NTT_TILE; idx += blockDim.x) {
+        const int r = idx >> n2, i2 = idx & (N2 - 1);
+        bn_ntile[i2 * ST + r] = y[(k1_0 + r) * (size_t)N2 + i2];
+    }
+    __syncthreads();
+    bn_lds_ntt_dif<ST>(bn_ntile, n2, W, n1);   // w_N2 = w^(N1)
+    for (int idx = threadIdx.x; idx < N2 * BN_NTT_TILE; idx += blockDim.x) {
+        const int pos = idx / BN_NTT_TILE, r = idx & (BN_NTT_TILE - 1);
+        const u32 k2 = bn_brev_bits((u32)pos, n2);
+        const Fr v = bn_ntile[pos * ST + r];
+        X[k1_0 + r + N1 * (size_t)k2] = lz_canon(scaled ? lz_mul(v, scale) : v);   // the node tables are canonical (k_bn_gate_eval adds them)
+    }
+}
+// in place on `a` through `tmp` (same size); W[i] = w^i for i < 2^log2n; returns false when the size is outside the four-step range
+static bool ntt4_dev(hipStream_t st, Fr* a, Fr* tmp, const Fr* W, int log2n, bool scaled, Fr scale, size_t batch, const NttSrc* srcs = nullptr) {
+    if (log2n < 8 || log2n > 16 || (srcs && batch > 64)) return false;
+    NttSrc none;
+    memset(&none, 0, sizeof(none));
+    const int n1 = log2n / 2, n2 = log2n - n1;
+    const size_t lds = (size_t)(1 << (n1 > n2 ? n1 : n2)) * (BN_NTT_TILE + 1) * sizeof(Fr);
+    k_bn_ntt4_cols<<<dim3(1u << n2 >> 2, (unsigned)batch), 256, lds, st>>>(a, tmp, log2n, n1, W, srcs ? *srcs : none);
+    k_bn_ntt4_rows<<<dim3(1u << n1 >> 2, (unsigned)batch), 256, lds, st>>>(tmp, a, log2n, n1, W, scale, scaled ? 1 : 0);
+    return true;
+}
 __global__ void k_bn_scale(Fr* __restrict__ a, Fr c, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) a[i] = fr_mul(a[i], c);
@@ -1517,17 +1712,18 @@ void ntt_bn254(hg_ctx* ctx, const u64* in4, int log2n, bool inverse, size_t batc
     Fr *a = nullptr, *b = nullptr, *W = nullptr;
     hipc(hipMalloc((void**)&a, total * sizeof(Fr)), "hipMalloc");
     hipc(hipMalloc((void**)&b, total * sizeof(Fr)), "hipMalloc");
-    hipc(hipMalloc((void**)&W, std::max<size_t>(n / 2, 1) * sizeof(Fr)), "hipMalloc");
+    hipc(hipMalloc((void**)&W, n * sizeof(Fr)), "hipMalloc");
     hipError_t e = hipMemcpyAsync(a, in4, total * sizeof(Fr), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
         k_bn_to_mont<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(a, total);
-        k_bn_powers<<<(unsigned)((std::max<size_t>(n / 2, 1) + 255) / 256), 256, 0, st>>>(W, w, std::max<size_t>(n / 2, 1));
+        k_bn_powers<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(W, w, n);
+        const Fr ninv = inverse ? fr_inv(fr_to_mont(fr_make((u64)n, 0, 0, 0))) : fr_one_mont();
+        if (ntt4_dev(st, a, b, W, log2n, inverse, ninv, batch)) std::swap(a, b);   // (result in `a`: the code below reads `b`)
+        else {
         k_bn_bitrev<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(a, b, log2n, total);
         const size_t th = total / 2;
         for (int s = 0; s < log2n; s++) k_bn_ntt_stage<<<(unsigned)((th + 255) / 256), 256, 0, st>>>(b, W, log2n, s, th);
-        if (inverse) {
-            const Fr ninv = fr_inv(fr_to_mont(fr_make((u64)n, 0, 0, 0)));
-            k_bn_scale<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(b, ninv, total);
+        if (inverse) k_bn_scale<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(b, ninv, total);
         }
         k_bn_from_mont<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(b, total);
         e = hipMemcpyAsync(out4, b, total * sizeof(Fr), hipMemcpyDeviceToHost, st);

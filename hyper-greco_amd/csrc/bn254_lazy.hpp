@@ -206,6 +206,20 @@ __device__ __forceinline__ Fr lz_reduce(WCol& w) {
     // what is left, divided by 2^256: columns 8 .. 15 with their carry counters, plus the tail of columns 6, 7 and the running carry
     return lz_finish(&w.C[8], &w.T[8], carry + (w.C[7] >> 32) + (u64)w.T[6], w.T[7]);
 }
+// a KA + v KV + t KT + add for 32-bit integers a, v, t (constants as fr_lin3_const, bn254_wide.hpp), loose result
+__device__ __forceinline__ Fr lz_lin3(u32 a, u32 v, u32 t, const u32* __restrict__ K) {
+    u64 C[8];
+    u32 T[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) { C[i] = K[24 + i]; T[i] = 0; }
+    BN_WIDE_ROW4S(C[0], C[1], C[2], C[3], T[0], T[1], T[2], T[3], a, K[0], K[1], K[2], K[3]);
+    BN_WIDE_ROW4S(C[4], C[5], C[6], C[7], T[4], T[5], T[6], T[7], a, K[4], K[5], K[6], K[7]);
+    BN_WIDE_ROW4S(C[0], C[1], C[2], C[3], T[0], T[1], T[2], T[3], v, K[8], K[9], K[10], K[11]);
+    BN_WIDE_ROW4S(C[4], C[5], C[6], C[7], T[4], T[5], T[6], T[7], v, K[12], K[13], K[14], K[15]);
+    BN_WIDE_ROW4S(C[0], C[1], C[2], C[3], T[0], T[1], T[2], T[3], t, K[16], K[17], K[18], K[19]);
+    BN_WIDE_ROW4S(C[4], C[5], C[6], C[7], T[4], T[5], T[6], T[7], t, K[20], K[21], K[22], K[23]);
+    return lz_finish(C, T, 0, 0);
+}
 __device__ __forceinline__ Fr lz_mul(const Fr& a, const Fr& b) {
     WCol w = wcol_zero();
     wcol_mac(w, a, b);

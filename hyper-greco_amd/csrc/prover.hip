@@ -69,6 +69,7 @@ void hg_ctx::arena_reset() {
     }
     for (auto& c : chunks) { c.used = 0; c.high = 0; }
     stage_used = 0;
+    bn_flushed = 0;
     bn_res_used = 0;
 }
 void hg_ctx::ensure_chain(size_t n_e) {
@@ -128,6 +129,7 @@ hg_ctx::~hg_ctx() {
     if (d_res && d_res != h_res) (void)hipFree(d_res);
     if (h_res) (void)hipHostFree(h_res);
     if (h_stage) (void)hipHostFree(h_stage);
+    if (bn_dstage) (void)hipFree(bn_dstage);
     if (h_mailbox) (void)hipHostFree(h_mailbox);
     if (d_partials) (void)hipFree(d_partials);
     if (d_partials2) (void)hipFree(d_partials2);

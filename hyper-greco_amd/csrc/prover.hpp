@@ -96,6 +96,10 @@ struct hg_ctx {
     void* h_mailbox = nullptr;   // pinned: the sequential prover's transcript mailbox + host-tail buffer (prover_seq.hip), allocated on first use
     size_t mailbox_bytes = 0;
     size_t stage_cap = 0, stage_used = 0;
+    // BN254 path: device mirror of the staging buffer - descriptors are staged at the same offset on both sides and copied over in
+    // ONE transfer per launch phase (bn254.hip: bn_stage / bn_flush) instead of one small copy per descriptor array
+    char* bn_dstage = nullptr;
+    size_t bn_flushed = 0;
     // profiling
     int prof_level = 0;
     struct ProfEvent { int cls; hipEvent_t a, b; };
