@@ -397,11 +397,17 @@ static RoundGrid round_grid(size_t half, int nitems) {
     return g;
 }
 // grand-product rounds: one lane per pair index (k_bn_gp_round_jobs), the pairs dealt to gy groups in small rounds
-static RoundGrid round_grid_gp(size_t half, int nb) {
+// `launch_wgs`: workgroups the whole launch (round rd of every layer of the products sharing it) has when no job deals its pairs out
+// (gy = 1). Dealing a job's pairs to gy groups shortens its serial chain but every group pays the per-j epilogue (three reductions,
+// three products: ~5300 instructions against ~1050 per (pair, j)) - worth it only when the launch would otherwise leave the device
+// empty. Round 3 decided per job (any job below 2^17 pair indices was dealt out, also inside launches that fill the device many
+// times over): 22 % of the kernel's instructions went into those epilogues.
+static RoundGrid round_grid_gp(size_t half, int nb, size_t launch_wgs) {
     RoundGrid g;
     g.gx = (int)std::min<size_t>((half + BN_GP_J - 1) / BN_GP_J, (size_t)1024);
-    const size_t threads = (size_t)g.gx * BN_TPB;
-    g.gy = (int)std::max<size_t>(1, std::min<size_t>((size_t)nb, (size_t)131072 / threads));
+    static const size_t target = [] { const char* e = getenv("HG_BN_GP_WGS"); return e && *e ? (size_t)atol(e) : (size_t)2048; }();
+    const size_t want = launch_wgs ? (target + launch_wgs - 1) / launch_wgs : (size_t)nb;
+    g.gy = (int)std::max<size_t>(1, std::min<size_t>((size_t)nb, want));
     return g;
 }
 constexpr int BN_PART_STRIDE = 2048;  // per-round slots (workgroups) in a partials buffer; round_grid never exceeds 1024 + 512
@@ -831,7 +837,10 @@ struct GpLaunchSet {
     std::vector<RedJobDev> reds;
     std::vector<TailJobDev> tails;
     std::vector<std::function<void()>> posts;   // after the rounds: final values of layers without a tail
+    std::vector<size_t> wgs;                    // per round: workgroups of the jobs queued so far at gy = 1 (round_grid_gp)
     void merge(GpLaunchSet& o) {
+        if (wgs.size() < o.wgs.size()) wgs.resize(o.wgs.size(), 0);
+        for (size_t rd = 0; rd < o.wgs.size(); rd++) wgs[rd] += o.wgs[rd];
         if (by_rd.size() < o.by_rd.size()) by_rd.resize(o.by_rd.size());
         for (size_t rd = 0; rd < o.by_rd.size(); rd++) by_rd[rd].insert(by_rd[rd].end(), o.by_rd[rd].begin(), o.by_rd[rd].end());
         reds.insert(reds.end(), o.reds.begin(), o.reds.end());
@@ -975,7 +984,12 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
         std::vector<TailJobDev>& tails = own.tails;
         std::vector<int> red_index(nv, -1);
         for (int n = 1; n < nv; n++) { red_index[n] = (int)reds.size(); RedJobDev r; memset(&r, 0, sizeof(r)); reds.push_back(r); }
+        own.wgs.assign(max_main, 0);
+        for (int rd = 0; rd < max_main; rd++)
+            for (int n = 1; n < nv; n++)
+                if (rd < plan[n].nmain) own.wgs[rd] += std::min<size_t>(((((size_t)1 << n) >> (rd + 1)) + BN_GP_J - 1) / BN_GP_J, (size_t)1024);
         for (int rd = 0; rd < max_main; rd++) {
+            const size_t launch_wgs = own.wgs[rd] + (set && (size_t)rd < set->wgs.size() ? set->wgs[rd] : 0);
             for (int n = 1; n < nv; n++) {
                 const LayerPlan& P = plan[n];
                 if (rd >= P.nmain) continue;
@@ -1011,7 +1025,7 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
                     d.s_in = rd == 0 ? P.S : ((rd & 1) ? P.sbuf0 : P.sbuf1);
                     d.s_out = (rd & 1) ? P.sbuf1 : P.sbuf0;
                 }
-                const RoundGrid g = round_grid_gp(half, d.nb);
+                const RoundGrid g = round_grid_gp(half, d.nb, launch_wgs);
                 d.gx = g.gx; d.gy = g.gy;
                 static const int dbg = [] { const char* e = getenv("HG_BN_DBG"); return e && *e ? atoi(e) : 0; }();
                 d.dbg = dbg;
