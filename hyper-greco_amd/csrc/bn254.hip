@@ -784,6 +784,34 @@ __global__ void k_bn_prod_level_mirror(const Fr* __restrict__ in, size_t in_len,
         lz_gstore(&lw[(b + half) * (h >> 1) + j], lz_fold(fr_zero(), vw, fk[b + half].k));
     }
 }
+// The short end of the product tree in ONE single-workgroup launch: every level whose rows are shorter than 256 entries (a level
+// reads the one before it: the workgroup barrier orders them), then the root products and the canonical copies of the roots and of
+// the two-entry top level for the host - what took a launch per level plus three more per grand product.
+struct ProdTailLevels { const Fr* in; size_t in_len; int nb, nlev; Fr* lev[12]; Fr* lw[12]; const Fr* pw[12]; Fr* top_out; Fr* roots_out; };
+__global__ __launch_bounds__(1024) void k_bn_prod_tail_levels(ProdTailLevels A) {
+    const Fr* in = A.in;
+    size_t in_len = A.in_len;
+    const int nb = A.nb;
+    for (int q = 0; q < A.nlev; q++) {
+        const size_t h = in_len >> 1, total = h * nb;
+        const int sh = __ffsll((long long)h) - 1;
+        for (size_t idx = threadIdx.x; idx < total; idx += 1024) {
+            const size_t b = idx >> sh, j = idx & (h - 1);
+            const Fr v = lz_mul(in[b * in_len + j], in[b * in_len + j + h]);
+            A.lev[q][b * h + j] = v;
+            if (A.lw[q] && j < (h >> 1)) A.lw[q][b * (h >> 1) + j] = b == 0 ? v : lz_mul(A.pw[q][b], v);
+        }
+        __syncthreads();
+        in = A.lev[q];
+        in_len = h;
+    }
+    for (int b = threadIdx.x; b < nb; b += 1024) {   // in: rows of length 2
+        const Fr l = in[2 * b], r = in[2 * b + 1];
+        A.top_out[2 * b] = fr_from_mont(l);
+        A.top_out[2 * b + 1] = fr_from_mont(r);
+        A.roots_out[b] = fr_from_mont(lz_mul(l, r));
+    }
+}
 static void write_be32(std::vector<uint8_t>& out, const Fr& canonical) {  // transcript.rs:183-189: repr, byte-reversed
     const size_t at = out.size();
     out.resize(at + 32);
@@ -945,9 +973,11 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
         }
         // the product tree; level k (rows of length len >> k) is read by layer n = nv - 1 - k, whose weighted left halves are written
         // in the same pass (level 0, the input, gets its own pass below)
+        ProdTailLevels tl;
+        memset(&tl, 0, sizeof(tl));
+        tl.nb = (int)nb;
         for (int k = 1; k < nv; k++) {
             Fr* lk = dalloc(nb * (len >> k));
-            const size_t total = nb * (len >> k);
             const int n = nv - 1 - k;
             const Fr* pw_n = n >= 1 ? plan[n].d_pw : nullptr;
             Fr* lw_n = n >= 1 ? plan[n].lw : nullptr;
@@ -962,15 +992,18 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
                 const size_t hh = len >> k;
                 k_bn_prod_level_rows<<<dim3((unsigned)((hh + 255) / 256), (unsigned)nb), 256, 0, st>>>(lev[k - 1], len >> (k - 1), lk, fk_all + (size_t)n * nb, lw_n);
             }
-            else k_bn_prod_level<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(lev[k - 1], len >> (k - 1), lk, (int)nb, pw_n, lw_n);
+            else {   // short rows: queued for the single-workgroup launch below
+                if (tl.nlev == 0) { tl.in = lev[k - 1]; tl.in_len = len >> (k - 1); }
+                if (tl.nlev >= 12) throw Error("hg_grand_product_bn254: more than 12 short tree levels");
+                tl.lev[tl.nlev] = lk; tl.lw[tl.nlev] = lw_n; tl.pw[tl.nlev] = pw_n; tl.nlev++;
+            }
             lev[k] = lk;
         }
-        // roots and top evaluations: level nv-1 has rows of length 2
-        Fr* d_roots = dalloc(nb);
-        k_bn_prod_level<<<(unsigned)((nb + 255) / 256), 256, 0, st>>>(lev[nv - 1], 2, d_roots, (int)nb);
+        // short levels, roots and top evaluations (level nv-1 has rows of length 2)
+        if (tl.nlev == 0) { tl.in = lev[nv - 1]; tl.in_len = 2; }
         const ResRef top = res_slots(ctx, 2 * nb), roots = res_slots(ctx, nb);
-        k_bn_copy_from_mont<<<(unsigned)((2 * nb + 255) / 256), 256, 0, st>>>(lev[nv - 1], top.dev, 2 * nb);
-        k_bn_copy_from_mont<<<(unsigned)((nb + 255) / 256), 256, 0, st>>>(d_roots, roots.dev, nb);
+        tl.top_out = top.dev; tl.roots_out = roots.dev;
+        k_bn_prod_tail_levels<<<1, 1024, 0, st>>>(tl);
         h_top = top.host; h_roots = roots.host;
         if (nv > 1) {   // the top layer reads level 0
             const int n = nv - 1;
@@ -1130,6 +1163,226 @@ void grand_product_bn254(hg_ctx* ctx, size_t nb, size_t len, const u64* const* t
     for (size_t b = 0; b < nb; b++) memcpy(claims_out + 4 * b, claims[b].l, 32);
     for (size_t i = 0; i < x.size(); i++) memcpy(point_out + 4 * i, x[i].l, 32);
 }
+
+// ---- MLE evaluation and NTT over Fr (the other primitives of the path, A13/A14) -------------------------------------
+// t'[j] = t[2j] + r (t[2j+1] - t[2j]): binds the lowest variable (fix_var order of the path)
+__global__ void k_bn_fold(const Fr* __restrict__ in, Fr* __restrict__ out, size_t half, Fr r) {
+    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= half) return;
+    const Fr x = in[2 * j], y = in[2 * j + 1];
+    out[j] = fr_add(x, fr_mul(r, fr_sub(y, x)));
+}
+// m variables bound per launch (2 <= m <= 10): workgroup g folds the 2^m consecutive entries in[g 2^m ..] into out[g] - an MLE
+// evaluation over 20 variables in two launches instead of twenty. to_slot: the single result is written canonical (result slot).
+struct FoldPoint { Fr r[10]; };
+__global__ __launch_bounds__(256) void k_bn_fold_multi(const Fr* __restrict__ in, Fr* __restrict__ out, int m, FoldPoint P, int to_slot) {
+    __shared__ Fr sm[256];
+    const int t = threadIdx.x;
+    const int le = m > 8 ? m - 8 : 0, E = 1 << le;   // entries per thread, folded in registers first
+    const int cnt0 = 1 << (m - le);                  // values entering the LDS tree
+    const Fr* base = in + ((size_t)blockIdx.x << m);
+    if (t < cnt0) {
+        Fr v[4];
+        for (int e = 0; e < E; e++) v[e] = base[(size_t)t * E + e];
+        for (int l = 0; l < le; l++)
+            for (int e = 0; e < (E >> (l + 1)); e++) v[e] = lz_add(v[2 * e], lz_mul(P.r[l], lz_sub(v[2 * e + 1], v[2 * e])));
+        sm[t] = v[0];
+    }
+    int cnt = cnt0;
+    for (int l = le; l < m; l++) {
+        __syncthreads();
+        Fr x = fr_zero(), y = fr_zero();
+        if (t < cnt / 2) { x = sm[2 * t]; y = sm[2 * t + 1]; }
+        __syncthreads();
+        if (t < cnt / 2) sm[t] = lz_add(x, lz_mul(P.r[l], lz_sub(y, x)));
+        cnt >>= 1;
+    }
+    if (t == 0) out[blockIdx.x] = to_slot ? fr_from_mont(sm[0]) : lz_canon(sm[0]);
+}
+// W[i] = w^i (Montgomery), i < n
+__global__ void k_bn_powers(Fr* __restrict__ W, Fr w, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr r = fr_one_mont(), b = w;
+    for (size_t e = i; e; e >>= 1) { if (e & 1) r = fr_mul(r, b); b = fr_mul(b, b); }
+    W[i] = r;
+}
+__global__ void k_bn_bitrev(const Fr* __restrict__ in, Fr* __restrict__ out, int log2n, size_t total) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const size_t n = (size_t)1 << log2n, b = i >> log2n, k = i & (n - 1);
+    size_t rv = 0;
+    for (int q = 0; q < log2n; q++) rv |= ((k >> q) & 1) << (log2n - 1 - q);
+    out[(b << log2n) + rv] = in[i];
+}
+// one radix-2 decimation-in-time stage (input bit-reversed): butterflies of span 2^s
+__global__ void k_bn_ntt_stage(Fr* __restrict__ a, const Fr* __restrict__ W, int log2n, int s, size_t total_half) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total_half) return;
+    const size_t half_n = (size_t)1 << (log2n - 1);
+    const size_t b = i / half_n, t = i % half_n;
+    const size_t span = (size_t)1 << s, grp = t >> s, pos = t & (span - 1);
+    const size_t i0 = (b << log2n) + (grp << (s + 1)) + pos, i1 = i0 + span;
+    const Fr w = W[pos << (log2n - 1 - s)];
+    const Fr u = a[i0], v = fr_mul(a[i1], w);
+    a[i0] = fr_add(u, v);
+    a[i1] = fr_sub(u, v);
+}
+// ---- four-step NTT with LDS-resident sub-transforms (2^8 <= N <= 2^16): N = N1 N2, the counterpart of k_ntt4_cols / k_ntt4_rows ----
+//   X[k1 + N1 k2] = sum_{n2} w_N^(n2 k1) [ sum_{n1} x[N2 n1 + n2] w_N1^(n1 k1) ] w_N2^(n2 k2)
+// columns kernel: BN_NTT_TILE consecutive n2 per workgroup, the N1-point transforms in LDS (decimation in frequency, result bit-
+// reversed in the slow index), the twiddle w_N^(n2 k1) on the way out; rows kernel: BN_NTT_TILE consecutive k1, N2-point transforms,
+// the 1/N of the inverse transform and the canonical form on the way out. Two launches and two passes over HBM per batch instead of
+// a bit-reversal, log2 N radix-2 stage launches, a scaling pass and a copy. Loose arithmetic inside (bn254_lazy.hpp).
+constexpr int BN_NTT_TILE = 4;
+template <int STRIDE>
+__device__ __forceinline__ void bn_lds_ntt_dif(Fr* tile, int m, const Fr* __restrict__ W, int wstep_log2) {
+    // 2^m-point transform along the slow index of tile[pos * STRIDE + c]; twiddle w_M^j = W[j << wstep_log2]
+    const int M = 1 << m;
+    for (int s = m - 1; s >= 0; s--) {
+        const int h = 1 << s;
+        for (int q = threadIdx.x; q < (M / 2) * BN_NTT_TILE; q += blockDim.x) {
+            const int c = q & (BN_NTT_TILE - 1), p = q / BN_NTT_TILE;
+            const int j = p & (h - 1), a = ((p >> s) << (s + 1)) + j;
+            const Fr x = tile[a * STRIDE + c], y = tile[(a + h) * STRIDE + c];
+            tile[a * STRIDE + c] = lz_add(x, y);
+            tile[(a + h) * STRIDE + c] = j ? lz_mul(lz_sub(x, y), W[((size_t)j << (m - 1 - s)) << wstep_log2]) : lz_subr(x, y);
+        }
+        __syncthreads();
+    }
+}
+__device__ __forceinline__ u32 bn_brev_bits(u32 x, int bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
+struct NttSrc { const Fr* p[64]; };   // per transform of the batch: where its input lies (null: in place, at in + b N)
+__global__ __launch_bounds__(256) void k_bn_ntt4_cols(const Fr* __restrict__ in, Fr* __restrict__ out, int n, int n1, const Fr* __restrict__ W, NttSrc srcs) {
+    extern __shared__ Fr bn_ntile[];
+    const int n2 = n - n1;
+    const size_t N = (size_t)1 << n, N2 = (size_t)1 << n2;
+    const int N1 = 1 << n1;
+    const size_t i2_0 = (size_t)blockIdx.x * BN_NTT_TILE;
+    const Fr* x = blockIdx.y < 64 && srcs.p[blockIdx.y] ? srcs.p[blockIdx.y] : in + (size_t)blockIdx.y * N;
+    Fr* y = out + (size_t)blockIdx.y * N;
+    for (int idx = threadIdx.x; idx < N1 * BN_NTT_TILE; idx += blockDim.x) {
+        const int i1 = idx / BN_NTT_TILE, c = idx & (BN_NTT_TILE - 1);
+        bn_ntile[idx] = x[(size_t)i1 * N2 + i2_0 + c];
+    }
+    __syncthreads();
+    bn_lds_ntt_dif<BN_NTT_TILE>(bn_ntile, n1, W, n2);   // w_N1 = w^(N2)
+    for (int idx = threadIdx.x; idx < N1 * BN_NTT_TILE; idx += blockDim.x) {
+        const int pos = idx / BN_NTT_TILE, c = idx & (BN_NTT_TILE - 1);
+        const u32 k1 = bn_brev_bits((u32)pos, n1);
+        const size_t i2 = i2_0 + c, e = (size_t)k1 * i2;   // e < N
+        const Fr v = bn_ntile[idx];
+        y[(size_t)k1 * N2 + i2] = e ? lz_mul(v, W[e]) : v;
+    }
+}
+__global__ __launch_bounds__(256) void k_bn_ntt4_rows(const Fr* __restrict__ in, Fr* __restrict__ out, int n, int n1, const Fr* __restrict__ W, Fr scale, int scaled) {
+    extern __shared__ Fr bn_ntile[];
+    constexpr int ST = BN_NTT_TILE + 1;
+    const int n2 = n - n1;
+    const size_t N = (size_t)1 << n, N1 = (size_t)1 << n1;
+    const int N2 = 1 << n2;
+    const size_t k1_0 = (size_t)blockIdx.x * BN_NTT_TILE;
+    const Fr* y = in + (size_t)blockIdx.y * N;
+    Fr* X = out + (size_t)blockIdx.y * N;
+    for (int idx = threadIdx.x; idx < N2 * BN_NTT_TILE; idx += blockDim.x) {
+        const int r = idx >> n2, i2 = idx & (N2 - 1);
+        bn_ntile[i2 * ST + r] = y[(k1_0 + r) * (size_t)N2 + i2];
+    }
+    __syncthreads();
+    bn_lds_ntt_dif<ST>(bn_ntile, n2, W, n1);   // w_N2 = w^(N1)
+    for (int idx = threadIdx.x; idx < N2 * BN_NTT_TILE; idx += blockDim.x) {
+        const int pos = idx / BN_NTT_TILE, r = idx & (BN_NTT_TILE - 1);
+        const u32 k2 = bn_brev_bits((u32)pos, n2);
+        const Fr v = bn_ntile[pos * ST + r];
+        X[k1_0 + r + N1 * (size_t)k2] = lz_canon(scaled ? lz_mul(v, scale) : v);   // the node tables are canonical (k_bn_gate_eval adds them)
+    }
+}
+// in place on `a` through `tmp` (same size); W[i] = w^i for i < 2^log2n; returns false when the size is outside the four-step range
+static bool ntt4_dev(hipStream_t st, Fr* a, Fr* tmp, const Fr* W, int log2n, bool scaled, Fr scale, size_t batch, const NttSrc* srcs = nullptr) {
+    if (log2n < 8 || log2n > 16 || (srcs && batch > 64)) return false;
+    NttSrc none;
+    memset(&none, 0, sizeof(none));
+    const int n1 = log2n / 2, n2 = log2n - n1;
+    const size_t lds = (size_t)(1 << (n1 > n2 ? n1 : n2)) * (BN_NTT_TILE + 1) * sizeof(Fr);
+    k_bn_ntt4_cols<<<dim3(1u << n2 >> 2, (unsigned)batch), 256, lds, st>>>(a, tmp, log2n, n1, W, srcs ? *srcs : none);
+    k_bn_ntt4_rows<<<dim3(1u << n1 >> 2, (unsigned)batch), 256, lds, st>>>(tmp, a, log2n, n1, W, scale, scaled ? 1 : 0);
+    return true;
+}
+__global__ void k_bn_scale(Fr* __restrict__ a, Fr c, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = fr_mul(a[i], c);
+}
+
+// 2^28-th root of unity of bn256::Fr = 7^((r-1)/2^28) (halo2curves ROOT_OF_UNITY, S = 28; checked: order exactly 2^28)
+static Fr fr_root_of_unity(int log2n) {
+    if (log2n > 28) throw Error("bn254: two-adicity is 28");
+    Fr w = fr_to_mont(fr_make(0xd34f1ed960c37c9cULL, 0x3215cf6dd39329c8ULL, 0x98865ea93dd31f74ULL, 0x03ddb9f5166d18b7ULL));
+    for (int i = log2n; i < 28; i++) w = fr_mul(w, w);
+    return w;
+}
+
+// = BoxMultilinearPoly::evaluate over Fr [REF memory_checking/mod.rs:80-93, sk_encryption_circuit.rs:446]
+void mle_eval_bn254(hg_ctx* ctx, const u64* table4, size_t nv, const u64* point4, u64* out4) {
+    hipc(hipSetDevice(ctx->device), "hipSetDevice");
+    hipStream_t st = ctx->stream;
+    const size_t N = (size_t)1 << nv;
+    Fr *a = nullptr, *b = nullptr;
+    hipc(hipMalloc((void**)&a, N * sizeof(Fr)), "hipMalloc");
+    hipc(hipMalloc((void**)&b, std::max<size_t>(N / 2, 1) * sizeof(Fr)), "hipMalloc");
+    hipError_t e = hipMemcpyAsync(a, table4, N * sizeof(Fr), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        k_bn_to_mont<<<(unsigned)((N + 255) / 256), 256, 0, st>>>(a, N);
+        Fr *cur = a, *nxt = b;
+        for (size_t v = 0; v < nv; v++) {
+            const size_t half = N >> (v + 1);
+            const Fr r = fr_to_mont(fr_make(point4[4 * v], point4[4 * v + 1], point4[4 * v + 2], point4[4 * v + 3]));
+            k_bn_fold<<<(unsigned)((half + 255) / 256), 256, 0, st>>>(cur, nxt, half, r);
+            std::swap(cur, nxt);
+        }
+        k_bn_from_mont<<<1, 64, 0, st>>>(cur, 1);
+        e = hipMemcpyAsync(out4, cur, sizeof(Fr), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    (void)hipFree(a); (void)hipFree(b);
+    hipc(e, "hg_mle_eval_bn254");
+}
+
+// = FftNode evaluate over Fr: out[k] = sum_j in[j] w^(jk), w the 2^log2n-th root of unity (inverse: w^-1 and 1/n);
+// natural order in and out [REF sk_encryption_circuit.rs:224,249,251]
+void ntt_bn254(hg_ctx* ctx, const u64* in4, int log2n, bool inverse, size_t batch, u64* out4) {
+    hipc(hipSetDevice(ctx->device), "hipSetDevice");
+    hipStream_t st = ctx->stream;
+    const size_t n = (size_t)1 << log2n, total = n * batch;
+    Fr w = fr_root_of_unity(log2n);
+    if (inverse) w = fr_inv(w);
+    Fr *a = nullptr, *b = nullptr, *W = nullptr;
+    hipc(hipMalloc((void**)&a, total * sizeof(Fr)), "hipMalloc");
+    hipc(hipMalloc((void**)&b, total * sizeof(Fr)), "hipMalloc");
+    hipc(hipMalloc((void**)&W, n * sizeof(Fr)), "hipMalloc");
+    hipError_t e = hipMemcpyAsync(a, in4, total * sizeof(Fr), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        k_bn_to_mont<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(a, total);
+        k_bn_powers<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(W, w, n);
+        const Fr ninv = inverse ? fr_inv(fr_to_mont(fr_make((u64)n, 0, 0, 0))) : fr_one_mont();
+        if (ntt4_dev(st, a, b, W, log2n, inverse, ninv, batch)) std::swap(a, b);   // (result in `a`: the code below reads `b`)
+        else {
+        k_bn_bitrev<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(a, b, log2n, total);
+        const size_t th = total / 2;
+        for (int s = 0; s < log2n; s++) k_bn_ntt_stage<<<(unsigned)((th + 255) / 256), 256, 0, st>>>(b, W, log2n, s, th);
+        if (inverse) k_bn_scale<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(b, ninv, total);
+        }
+        k_bn_from_mont<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(b, total);
+        e = hipMemcpyAsync(out4, b, total * sizeof(Fr), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    (void)hipFree(a); (void)hipFree(b); (void)hipFree(W);
+    hipc(e, "hg_ntt_bn254");
+}
+
+// (defined below, behind bn254_gkr.inc: it uses that file's eq-table job arrays)
+static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4, const Fr* d_in_mont, size_t chain_skip, std::vector<uint8_t>& proof,
+                                   u64* claim_out, const std::function<void()>* mid = nullptr, int mid_at = 0);
+#include "bn254_gkr.inc"
 
 // ---- LassoNode::prove_claim_reduction over Fr [REF lasso/src/lasso.rs:57-114] -------------------------------------------
 // The limb split and the counters are integer work on the low limb (fe_to_bits_le truncates to at most 63 bits,
@@ -1312,7 +1565,7 @@ __global__ void k_bn_flag_out(const int* __restrict__ flag, Fr* __restrict__ slo
 // counters, 2: behind the hashes and before the grand products, 3: behind everything) - the caller enqueues independent work on
 // another stream there, so that the device has both chains queued from the start of the prove (bn254_gkr.inc: BnProver::run)
 static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4, const Fr* d_in_mont, size_t chain_skip, std::vector<uint8_t>& proof,
-                                   u64* claim_out, const std::function<void()>* mid = nullptr, int mid_at = 0) {
+                                   u64* claim_out, const std::function<void()>* mid, int mid_at) {
     if (!pk->ctx) throw Error("hg_lasso_prove_bn254: host-only prover key");
     const LassoPlan& lp = pk->lasso;
     const dev::LassoDev& L = pk->lasso_dev;
@@ -1381,11 +1634,24 @@ static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4,
         if (mid && mid_at == 1) (*mid)();
         Fr* d_part = dalloc(1024 * 3);
         const ResRef r_claimed = res_slots(ctx, 1), r_col = res_slots(ctx, (size_t)nu * 2);
-        Fr* eq_scratch = dalloc(eq_scratch_len(std::max(nu, 16)));
-        auto build_eq = [&](Fr* eq, const Fr* pt_canon, int n) { build_eq_dev(st, eq, pt_canon, n, eq_scratch); };
-        // r, claimed sum (lasso.rs:85, 264-269)
+        // The three eq tables of the node - at r (claimed sum), at the grand products' final points x and y (openings) - are challenges
+        // only (a grand product's point is the run of its last layer's round challenges and mu): built now, in three launches for all
+        // of them (heads, then two levels of outer products) instead of thirteen spread over the node.
         Fr* eq = dalloc(N);
-        build_eq(eq, &chain[r_at], nu);
+        Fr* eqx = dalloc(N);
+        Fr* eqy = dalloc(M);
+        auto final_point_at = [](size_t gp_at, int nv) { size_t pos = gp_at + 1; for (int n = 1; n < nv - 1; n++) pos += 2 + n; return nv > 1 ? pos + 1 : gp_at; };
+        {
+            DevPool eq_pool(ctx);
+            std::vector<std::shared_ptr<void>> keep;
+            EqPlan plan;
+            plan.add(eq, &chain[r_at], nu, dalloc(eq_scratch_len(nu)));
+            plan.add(eqx, &chain[final_point_at(gp1_at, nu)], nu, dalloc(eq_scratch_len(nu)));
+            plan.add(eqy, &chain[final_point_at(gp2_at, 16)], 16, dalloc(eq_scratch_len(16)));
+            eq_plan_flush(st, eq_pool, plan, keep);
+            eq_pool.marks.clear();   // (the arena is rewound by this function, not by the pool)
+        }
+        // r, claimed sum (lasso.rs:85, 264-269)
         MPow mp;
         {
             const Fr m = fr_small(M);
@@ -1483,9 +1749,10 @@ static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4,
         grand_product_core(ctx, 2 * G, M, nullptr, H2, gp2_at, gp2_bytes, tmp_claims2, y, nullptr, &replay_gp2, &gp_set);  // inits then finals (prover.rs:167-171)
         gp_launch_set(ctx, st, gp_set);
         // openings (prover.rs:173-178, mod.rs:80-93)
-        Fr* eqy = dalloc(M);
-        build_eq(eq, x.data(), nu);
-        build_eq(eqy, y.data(), 16);
+        // (the points the grand products report are the runs the eq tables were built from)
+        if (x.size() != (size_t)nu || y.size() != 16) throw Error("hg_lasso_prove_bn254: unexpected grand-product point length");
+        for (int i = 0; i < nu; i++) if (!fr_eq(x[i], chain[final_point_at(gp1_at, nu) + i])) throw Error("hg_lasso_prove_bn254: grand product #1's point is not the expected challenge run");
+        for (int i = 0; i < 16; i++) if (!fr_eq(y[i], chain[final_point_at(gp2_at, 16) + i])) throw Error("hg_lasso_prove_bn254: grand product #2's point is not the expected challenge run");
         // every opening at x in one launch, every opening at y in another (k_bn_dot_u64_multi); order on the wire per chunk: dim(x),
         // read_ts(x), final_cts(y), then E_m(x)
         std::vector<const Fr*> open_at;
@@ -1514,7 +1781,7 @@ static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4,
                 k_bn_dot_u64_multi<<<dim3(gx, gy), BN_TPB, 0, st>>>(e, T, cnt, n, part);
                 k_bn_dot_u64_reduce<<<cnt, BN_TPB, 0, st>>>(part, gx, O);
             };
-            run(eq, tx, ox, nx, N);
+            run(eqx, tx, ox, nx, N);
             run(eqy, ty, oy, ny, M);
         }
         if (mid && mid_at >= 3) (*mid)();
@@ -1559,195 +1826,6 @@ void lasso_prove_bn254(hg_ctx* ctx, const hg_pk* pk, const u64* in4, size_t chai
     lasso_prove_bn254_impl(ctx, pk, in4, nullptr, chain_skip, proof, claim_out);
 }
 
-// ---- MLE evaluation and NTT over Fr (the other primitives of the path, A13/A14) -------------------------------------
-// t'[j] = t[2j] + r (t[2j+1] - t[2j]): binds the lowest variable (fix_var order of the path)
-__global__ void k_bn_fold(const Fr* __restrict__ in, Fr* __restrict__ out, size_t half, Fr r) {
-    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= half) return;
-    const Fr x = in[2 * j], y = in[2 * j + 1];
-    out[j] = fr_add(x, fr_mul(r, fr_sub(y, x)));
-}
-// W[i] = w^i (Montgomery), i < n
-__global__ void k_bn_powers(Fr* __restrict__ W, Fr w, size_t n) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Fr r = fr_one_mont(), b = w;
-    for (size_t e = i; e; e >>= 1) { if (e & 1) r = fr_mul(r, b); b = fr_mul(b, b); }
-    W[i] = r;
-}
-__global__ void k_bn_bitrev(const Fr* __restrict__ in, Fr* __restrict__ out, int log2n, size_t total) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const size_t n = (size_t)1 << log2n, b = i >> log2n, k = i & (n - 1);
-    size_t rv = 0;
-    for (int q = 0; q < log2n; q++) rv |= ((k >> q) & 1) << (log2n - 1 - q);
-    out[(b << log2n) + rv] = in[i];
-}
-// one radix-2 decimation-in-time stage (input bit-reversed): butterflies of span 2^s
-__global__ void k_bn_ntt_stage(Fr* __restrict__ a, const Fr* __restrict__ W, int log2n, int s, size_t total_half) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total_half) return;
-    const size_t half_n = (size_t)1 << (log2n - 1);
-    const size_t b = i / half_n, t = i % half_n;
-    const size_t span = (size_t)1 << s, grp = t >> s, pos = t & (span - 1);
-    const size_t i0 = (b << log2n) + (grp << (s + 1)) + pos, i1 = i0 + span;
-    const Fr w = W[pos << (log2n - 1 - s)];
-    const Fr u = a[i0], v = fr_mul(a[i1], w);
-    a[i0] = fr_add(u, v);
-    a[i1] = fr_sub(u, v);
-}
-// ---- four-step NTT with LDS-resident sub-transforms (2^8 <= N <= 2^16): N = N1 N2, the counterpart of k_ntt4_cols / k_ntt4_rows ----
-//   X[k1 + N1 k2] = sum_{n2} w_N^(n2 k1) [ sum_{n1} x[N2 n1 + n2] w_N1^(n1 k1) ] w_N2^(n2 k2)
-// columns kernel: BN_NTT_TILE consecutive n2 per workgroup, the N1-point transforms in LDS (decimation in frequency, result bit-
-// reversed in the slow index), the twiddle w_N^(n2 k1) on the way out; rows kernel: BN_NTT_TILE consecutive k1, N2-point transforms,
-// the 1/N of the inverse transform and the canonical form on the way out. Two launches and two passes over HBM per batch instead of
-// a bit-reversal, log2 N radix-2 stage launches, a scaling pass and a copy. Loose arithmetic inside (bn254_lazy.hpp).
-constexpr int BN_NTT_TILE = 4;
-template <int STRIDE>
-__device__ __forceinline__ void bn_lds_ntt_dif(Fr* tile, int m, const Fr* __restrict__ W, int wstep_log2) {
-    // 2^m-point transform along the slow index of tile[pos * STRIDE + c]; twiddle w_M^j = W[j << wstep_log2]
-    const int M = 1 << m;
-    for (int s = m - 1; s >= 0; s--) {
-        const int h = 1 << s;
-        for (int q = threadIdx.x; q < (M / 2) * BN_NTT_TILE; q += blockDim.x) {
-            const int c = q & (BN_NTT_TILE - 1), p = q / BN_NTT_TILE;
-            const int j = p & (h - 1), a = ((p >> s) << (s + 1)) + j;
-            const Fr x = tile[a * STRIDE + c], y = tile[(a + h) * STRIDE + c];
-            tile[a * STRIDE + c] = lz_add(x, y);
-            tile[(a + h) * STRIDE + c] = j ? lz_mul(lz_sub(x, y), W[((size_t)j << (m - 1 - s)) << wstep_log2]) : lz_subr(x, y);
-        }
-        __syncthreads();
-    }
-}
-__device__ __forceinline__ u32 bn_brev_bits(u32 x, int bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
-struct NttSrc { const Fr* p[64]; };   // per transform of the batch: where its input lies (null: in place, at in + b N)
-__global__ __launch_bounds__(256) void k_bn_ntt4_cols(const Fr* __restrict__ in, Fr* __restrict__ out, int n, int n1, const Fr* __restrict__ W, NttSrc srcs) {
-    extern __shared__ Fr bn_ntile[];
-    const int n2 = n - n1;
-    const size_t N = (size_t)1 << n, N2 = (size_t)1 << n2;
-    const int N1 = 1 << n1;
-    const size_t i2_0 = (size_t)blockIdx.x * BN_NTT_TILE;
-    const Fr* x = blockIdx.y < 64 && srcs.p[blockIdx.y] ? srcs.p[blockIdx.y] : in + (size_t)blockIdx.y * N;
-    Fr* y = out + (size_t)blockIdx.y * N;
-    for (int idx = threadIdx.x; idx < N1 * BN_NTT_TILE; idx += blockDim.x) {
-        const int i1 = idx / BN_NTT_TILE, c = idx & (BN_NTT_TILE - 1);
-        bn_ntile[idx] = x[(size_t)i1 * N2 + i2_0 + c];
-    }
-    __syncthreads();
-    bn_lds_ntt_dif<BN_NTT_TILE>(bn_ntile, n1, W, n2);   // w_N1 = w^(N2)
-    for (int idx = threadIdx.x; idx < N1 * BN_NTT_TILE; idx += blockDim.x) {
-        const int pos = idx / BN_NTT_TILE, c = idx & (BN_NTT_TILE - 1);
-        const u32 k1 = bn_brev_bits((u32)pos, n1);
-        const size_t i2 = i2_0 + c, e = (size_t)k1 * i2;   // e < N
-        const Fr v = bn_ntile[idx];
-        y[(size_t)k1 * N2 + i2] = e ? lz_mul(v, W[e]) : v;
-    }
-}
-__global__ __launch_bounds__(256) void k_bn_ntt4_rows(const Fr* __restrict__ in, Fr* __restrict__ out, int n, int n1, const Fr* __restrict__ W, Fr scale, int scaled) {
-    extern __shared__ Fr bn_ntile[];
-    constexpr int ST = BN_NTT_TILE + 1;
-    const int n2 = n - n1;
-    const size_t N = (size_t)1 << n, N1 = (size_t)1 << n1;
-    const int N2 = 1 << n2;
-    const size_t k1_0 = (size_t)blockIdx.x * BN_NTT_TILE;
-    const Fr* y = in + (size_t)blockIdx.y * N;
-    Fr* X = out + (size_t)blockIdx.y * N;
-    for (int idx = threadIdx.x; idx < N2 * BN_NTT_TILE; idx += blockDim.x) {
-        const int r = idx >> n2, i2 = idx & (N2 - 1);
-        bn_ntile[i2 * ST + r] = y[(k1_0 + r) * (size_t)N2 + i2];
-    }
-    __syncthreads();
-    bn_lds_ntt_dif<ST>(bn_ntile, n2, W, n1);   // w_N2 = w^(N1)
-    for (int idx = threadIdx.x; idx < N2 * BN_NTT_TILE; idx += blockDim.x) {
-        const int pos = idx / BN_NTT_TILE, r = idx & (BN_NTT_TILE - 1);
-        const u32 k2 = bn_brev_bits((u32)pos, n2);
-        const Fr v = bn_ntile[pos * ST + r];
-        X[k1_0 + r + N1 * (size_t)k2] = lz_canon(scaled ? lz_mul(v, scale) : v);   // the node tables are canonical (k_bn_gate_eval adds them)
-    }
-}
-// in place on `a` through `tmp` (same size); W[i] = w^i for i < 2^log2n; returns false when the size is outside the four-step range
-static bool ntt4_dev(hipStream_t st, Fr* a, Fr* tmp, const Fr* W, int log2n, bool scaled, Fr scale, size_t batch, const NttSrc* srcs = nullptr) {
-    if (log2n < 8 || log2n > 16 || (srcs && batch > 64)) return false;
-    NttSrc none;
-    memset(&none, 0, sizeof(none));
-    const int n1 = log2n / 2, n2 = log2n - n1;
-    const size_t lds = (size_t)(1 << (n1 > n2 ? n1 : n2)) * (BN_NTT_TILE + 1) * sizeof(Fr);
-    k_bn_ntt4_cols<<<dim3(1u << n2 >> 2, (unsigned)batch), 256, lds, st>>>(a, tmp, log2n, n1, W, srcs ? *srcs : none);
-    k_bn_ntt4_rows<<<dim3(1u << n1 >> 2, (unsigned)batch), 256, lds, st>>>(tmp, a, log2n, n1, W, scale, scaled ? 1 : 0);
-    return true;
-}
-__global__ void k_bn_scale(Fr* __restrict__ a, Fr c, size_t n) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) a[i] = fr_mul(a[i], c);
-}
-
-// 2^28-th root of unity of bn256::Fr = 7^((r-1)/2^28) (halo2curves ROOT_OF_UNITY, S = 28; checked: order exactly 2^28)
-static Fr fr_root_of_unity(int log2n) {
-    if (log2n > 28) throw Error("bn254: two-adicity is 28");
-    Fr w = fr_to_mont(fr_make(0xd34f1ed960c37c9cULL, 0x3215cf6dd39329c8ULL, 0x98865ea93dd31f74ULL, 0x03ddb9f5166d18b7ULL));
-    for (int i = log2n; i < 28; i++) w = fr_mul(w, w);
-    return w;
-}
-
-// = BoxMultilinearPoly::evaluate over Fr [REF memory_checking/mod.rs:80-93, sk_encryption_circuit.rs:446]
-void mle_eval_bn254(hg_ctx* ctx, const u64* table4, size_t nv, const u64* point4, u64* out4) {
-    hipc(hipSetDevice(ctx->device), "hipSetDevice");
-    hipStream_t st = ctx->stream;
-    const size_t N = (size_t)1 << nv;
-    Fr *a = nullptr, *b = nullptr;
-    hipc(hipMalloc((void**)&a, N * sizeof(Fr)), "hipMalloc");
-    hipc(hipMalloc((void**)&b, std::max<size_t>(N / 2, 1) * sizeof(Fr)), "hipMalloc");
-    hipError_t e = hipMemcpyAsync(a, table4, N * sizeof(Fr), hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) {
-        k_bn_to_mont<<<(unsigned)((N + 255) / 256), 256, 0, st>>>(a, N);
-        Fr *cur = a, *nxt = b;
-        for (size_t v = 0; v < nv; v++) {
-            const size_t half = N >> (v + 1);
-            const Fr r = fr_to_mont(fr_make(point4[4 * v], point4[4 * v + 1], point4[4 * v + 2], point4[4 * v + 3]));
-            k_bn_fold<<<(unsigned)((half + 255) / 256), 256, 0, st>>>(cur, nxt, half, r);
-            std::swap(cur, nxt);
-        }
-        k_bn_from_mont<<<1, 64, 0, st>>>(cur, 1);
-        e = hipMemcpyAsync(out4, cur, sizeof(Fr), hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-    }
-    (void)hipFree(a); (void)hipFree(b);
-    hipc(e, "hg_mle_eval_bn254");
-}
-
-// = FftNode evaluate over Fr: out[k] = sum_j in[j] w^(jk), w the 2^log2n-th root of unity (inverse: w^-1 and 1/n);
-// natural order in and out [REF sk_encryption_circuit.rs:224,249,251]
-void ntt_bn254(hg_ctx* ctx, const u64* in4, int log2n, bool inverse, size_t batch, u64* out4) {
-    hipc(hipSetDevice(ctx->device), "hipSetDevice");
-    hipStream_t st = ctx->stream;
-    const size_t n = (size_t)1 << log2n, total = n * batch;
-    Fr w = fr_root_of_unity(log2n);
-    if (inverse) w = fr_inv(w);
-    Fr *a = nullptr, *b = nullptr, *W = nullptr;
-    hipc(hipMalloc((void**)&a, total * sizeof(Fr)), "hipMalloc");
-    hipc(hipMalloc((void**)&b, total * sizeof(Fr)), "hipMalloc");
-    hipc(hipMalloc((void**)&W, n * sizeof(Fr)), "hipMalloc");
-    hipError_t e = hipMemcpyAsync(a, in4, total * sizeof(Fr), hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) {
-        k_bn_to_mont<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(a, total);
-        k_bn_powers<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(W, w, n);
-        const Fr ninv = inverse ? fr_inv(fr_to_mont(fr_make((u64)n, 0, 0, 0))) : fr_one_mont();
-        if (ntt4_dev(st, a, b, W, log2n, inverse, ninv, batch)) std::swap(a, b);   // (result in `a`: the code below reads `b`)
-        else {
-        k_bn_bitrev<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(a, b, log2n, total);
-        const size_t th = total / 2;
-        for (int s = 0; s < log2n; s++) k_bn_ntt_stage<<<(unsigned)((th + 255) / 256), 256, 0, st>>>(b, W, log2n, s, th);
-        if (inverse) k_bn_scale<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(b, ninv, total);
-        }
-        k_bn_from_mont<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(b, total);
-        e = hipMemcpyAsync(out4, b, total * sizeof(Fr), hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-    }
-    (void)hipFree(a); (void)hipFree(b); (void)hipFree(W);
-    hipc(e, "hg_ntt_bn254");
-}
-
-#include "bn254_gkr.inc"
 
 }  // namespace bn
 }  // namespace hg
