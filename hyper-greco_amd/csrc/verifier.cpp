@@ -9,6 +9,7 @@
 // (F = E = bn256::Fr: the `bn254` test family, sk_encryption_circuit.rs:614-626).
 #include <cstring>
 #include <functional>
+#include <map>
 #include <algorithm>
 #include <omp.h>
 #include "host.hpp"
@@ -139,6 +140,29 @@ template <class F, class Fn> typename F::E par_sum(size_t n, size_t grain, Fn fn
     }
     return total;
 }
+// sum over (rep, t), rep < R, t < nt, of fn(rep, t) into `nacc` buckets chosen by the term (fn adds into acc[]): the wiring-predicate
+// sums of the Vanilla nodes. Every thread takes a contiguous run of the R * nt terms and steps (rep, t) along it - no division per
+// term - and the per-input (per input pair) factors u_i (w_i1 u_i0) are applied once per bucket at the end, not once per term.
+template <class F, class Fn> std::vector<typename F::E> par_buckets(size_t R, size_t nt, size_t nacc, size_t grain, Fn fn) {
+    typedef typename F::E E;
+    std::vector<E> total(nacc, F::zero());
+    const size_t n = R * nt;
+    if (!n) return total;
+#pragma omp parallel num_threads(threads_for(n, grain))
+    {
+        std::vector<E> acc(nacc, F::zero());
+        const size_t T = (size_t)omp_get_num_threads(), me = (size_t)omp_get_thread_num();
+        const size_t q0 = n * me / T, q1 = n * (me + 1) / T;
+        size_t rep = q0 / nt, t = q0 % nt;
+        for (size_t q = q0; q < q1; q++) {
+            fn(rep, t, acc.data());
+            if (++t == nt) { t = 0; rep++; }
+        }
+#pragma omp critical
+        for (size_t i = 0; i < nacc; i++) total[i] = F::add(total[i], acc[i]);
+    }
+    return total;
+}
 template <class F> std::vector<typename F::E> eq_table(const std::vector<typename F::E>& r) {
     typedef typename F::E E;
     std::vector<E> t((size_t)1 << r.size());
@@ -250,12 +274,28 @@ template <class F> struct Verifier {
         for (size_t i = 0; i < b; i++) {
             if ((int)i < cl2) { result = F::add(result, F::mul_u(y[i], 1ULL << i)); continue; }
             E g_value = F::zero();
-            if ((int)i == cl2)
-                for (u64 k = 0; k < extra; k++) {
-                    E term = F::from_u(g_base + k);
-                    for (int j = 0; j < cl2; j++) term = F::mul(term, (k >> j) & 1 ? y[j] : F::sub(F::one(), y[j]));
-                    g_value = F::add(g_value, term);
+            if ((int)i == cl2 && extra) {
+                // sum_{k < extra} (g_base + k) eq(y[0..cl2), k) (range.rs:93-105 walks the extra terms one by one: up to 2^16 of them,
+                // cl2 products each - 10 ms of the verification at n=32768) in closed form: [0, extra) is a union of dyadic blocks, one per
+                // set bit i of `extra` (the bits above i as in `extra`, bit i clear, the bits below free), and over a block
+                //   sum eq = P (1 - y_i),   sum k eq = P (1 - y_i) (V + sum_{j < i} 2^j y_j)
+                // with P the eq factor and V the value of the fixed high bits. The same field element: every step is an exact identity.
+                std::vector<E> low(cl2 + 1, F::zero());   // low[i] = sum_{j < i} 2^j y_j
+                for (int j = 0; j < cl2; j++) low[j + 1] = F::add(low[j], F::mul_u(y[j], 1ULL << j));
+                E P = F::one(), S0 = F::zero(), S1 = F::zero();
+                u64 V = 0;
+                for (int q = cl2 - 1; q >= 0; q--) {
+                    const E one_minus = F::sub(F::one(), y[q]);
+                    if ((extra >> q) & 1) {
+                        const E wgt = F::mul(P, one_minus);
+                        S0 = F::add(S0, wgt);
+                        S1 = F::add(S1, F::mul(wgt, F::add(F::from_u(V), low[q])));
+                        P = F::mul(P, y[q]);
+                        V += 1ULL << q;
+                    } else P = F::mul(P, one_minus);
                 }
+                g_value = F::add(F::mul(F::from_u(g_base), S0), S1);
+            }
             result = F::add(F::mul(F::sub(F::one(), y[i]), result), F::mul(y[i], g_value));
         }
         return result;
@@ -385,7 +425,7 @@ template <class F> struct Verifier {
         for (size_t a = 0; a < cl.size(); a++) claim = F::add(claim, F::mul(cl[a].value, alpha[a]));
         if (!n.w0.empty()) {
             const size_t nw = n.w0.size();
-            claim = F::sub(claim, par_sum<F>(R * nw, 4096, [&](size_t q) -> E { const auto& t = n.w0[q % nw]; return F::mul_u(eqc[(q / nw) * G + t.gate], t.c); }));
+            claim = F::sub(claim, par_buckets<F>(R, nw, 1, 4096, [&](size_t rep, size_t ti, E* acc) { const auto& t = n.w0[ti]; acc[0] = F::add(acc[0], F::mul_u(eqc[rep * G + t.gate], t.c)); })[0]);
         }
         auto r1 = sumcheck(2, nin, claim);
         std::vector<E> u(n.arity, F::zero());
@@ -394,12 +434,11 @@ template <class F> struct Verifier {
         std::vector<E> eqx = eq_table<F>(r1.second);
         E lin = F::zero();
         if (!n.lin.empty()) {
-            const size_t nl = n.lin.size();
-            lin = par_sum<F>(R * nl, 2048, [&](size_t q) -> E {
-                const auto& t = n.lin[q % nl];
-                const size_t rep = q / nl;
-                return F::mul(u[t.in], F::mul(F::mul_u(eqc[rep * G + t.gate], t.c), eqx[rep * S + t.j]));
+            const std::vector<E> per_in = par_buckets<F>(R, n.lin.size(), (size_t)n.arity, 2048, [&](size_t rep, size_t ti, E* acc) {
+                const auto& t = n.lin[ti];
+                acc[t.in] = F::add(acc[t.in], F::mul(F::mul_u(eqc[rep * G + t.gate], t.c), eqx[rep * S + t.j]));
             });
+            for (int i = 0; i < n.arity; i++) lin = F::add(lin, F::mul(u[i], per_in[i]));
         }
         if (n.mul.empty()) {
             if (!F::eq(r1.first, lin)) throw Reject("vanilla node: final evaluation mismatch");
@@ -409,22 +448,27 @@ template <class F> struct Verifier {
         std::vector<E> w(n.arity, F::zero());
         for (int i = 0; i < n.arity; i++) if (n.right_use[i]) { w[i] = read_e(); sub[i].push_back(Claim{r2.second, w[i]}); }
         std::vector<E> eqy = eq_table<F>(r2.second);
-        const size_t nmul = n.mul.size();
-        E fin = par_sum<F>(R * nmul, 2048, [&](size_t q) -> E {
-            const auto& t = n.mul[q % nmul];
-            const size_t rep = q / nmul;
-            return F::mul(F::mul(w[t.i1], u[t.i0]), F::mul(F::mul(F::mul_u(eqc[rep * G + t.gate], t.c), eqx[rep * S + t.j0]), eqy[rep * S + t.j1]));
+        const size_t ar = (size_t)n.arity;
+        const std::vector<E> per_pair = par_buckets<F>(R, n.mul.size(), ar * ar, 2048, [&](size_t rep, size_t ti, E* acc) {
+            const auto& t = n.mul[ti];
+            E& a = acc[(size_t)t.i1 * ar + t.i0];
+            a = F::add(a, F::mul(F::mul(F::mul_u(eqc[rep * G + t.gate], t.c), eqx[rep * S + t.j0]), eqy[rep * S + t.j1]));
         });
+        E fin = F::zero();
+        for (size_t i1 = 0; i1 < ar; i1++)
+            for (size_t i0 = 0; i0 < ar; i0++) fin = F::add(fin, F::mul(F::mul(w[i1], u[i0]), per_pair[i1 * ar + i0]));
         if (!F::eq(r2.first, fin)) throw Reject("vanilla node: phase-2 final evaluation mismatch");
         return sub;
     }
 
     // F(r, x) = scale * prod_b (1 + r_b (w^(2^b x) - 1)), built in O(N): factor b depends on x mod 2^(L-b)
-    static std::vector<E> fft_row(const std::vector<E>& r, int L, bool inverse) {
+    std::map<std::pair<int, bool>, std::vector<E>> w_tables;   // powers of the root per (size, direction): shared by every FFT node of a proof
+    const std::vector<E>& fft_powers(int L, bool inverse) {
         const size_t N = (size_t)1 << L;
         const E w = F::root(L, inverse);
-        std::vector<E> W(N);
-        {   // powers of w in runs of 4096, each run started from a stride power
+        std::vector<E>& W = w_tables[{L, inverse}];
+        if (W.empty()) {   // powers of w in runs of 4096, each run started from a stride power
+            W.resize(N);
             const size_t RUN = 4096, nrun = (N + RUN - 1) / RUN;
             E wrun = F::one();
             for (size_t i = 0; i < std::min(RUN, N); i++) wrun = F::mul(wrun, w);
@@ -438,6 +482,11 @@ template <class F> struct Verifier {
                 for (size_t i = i0 + 1; i < i1; i++) W[i] = F::mul(W[i - 1], w);
             }
         }
+        return W;
+    }
+    std::vector<E> fft_row(const std::vector<E>& r, int L, bool inverse) {   // (reads the table of powers: fill it before going parallel)
+        const size_t N = (size_t)1 << L;
+        const std::vector<E>& W = w_tables.at({L, inverse});
         std::vector<E> cur(1, inverse ? F::inv_u((u64)N) : F::one());
         for (int b = L - 1; b >= 0; b--) {
             const size_t sz = (size_t)1 << (L - b);
@@ -459,15 +508,37 @@ template <class F> struct Verifier {
         for (size_t a = 0; a < cl.size(); a++) claim = F::add(claim, F::mul(cl[a].value, alpha[a]));
         auto r = sumcheck(2, n.log2_size, claim);
         E u = read_e();
-        std::vector<E> eqx = eq_table<F>(r.second);
-        E fr = F::zero();
-        for (size_t a = 0; a < cl.size(); a++) {
-            std::vector<E> row = fft_row(cl[a].point, n.log2_size, n.inverse);
-            E s = par_sum<F>(row.size(), 4096, [&](size_t x) -> E { return F::mul(row[x], eqx[x]); });
-            fr = F::add(fr, F::mul(s, alpha[a]));
-        }
-        if (!F::eq(r.first, F::mul(u, fr))) throw Reject("fft node: final evaluation mismatch");
+        // The final check (an eq table, one DFT row per claim and their dot products: ~4 N products) does not feed the walk: it is
+        // queued and the 2k+1 FFT nodes' checks run side by side at the end (run_node_checks), each single-threaded - inside one node
+        // the loops are too short for the cores (16 threads on 2^16 entries reached a fifth of their sum).
+        const int L = n.log2_size;
+        const bool inverse = n.inverse;
+        (void)fft_powers(L, inverse);   // (the shared table of powers is filled here, on the walk's thread)
+        const std::vector<E> pt = r.second;
+        const E fin = r.first;
+        node_checks.push_back([this, cl, alpha, pt, fin, u, L, inverse]() -> std::string {
+            std::vector<E> eqx = eq_table<F>(pt);
+            E fr = F::zero();
+            for (size_t a = 0; a < cl.size(); a++) {
+                std::vector<E> row = fft_row(cl[a].point, L, inverse);
+                E s = F::zero();
+                for (size_t x = 0; x < row.size(); x++) s = F::add(s, F::mul(row[x], eqx[x]));
+                fr = F::add(fr, F::mul(s, alpha[a]));
+            }
+            return F::eq(fin, F::mul(u, fr)) ? std::string() : std::string("fft node: final evaluation mismatch");
+        });
         return {{Claim{r.second, u}}};
+    }
+    // queued node checks, dealt to the cores; "" or the first failure in walk order
+    std::vector<std::function<std::string()>> node_checks;
+    std::string run_node_checks() {
+        std::vector<std::string> why(node_checks.size());
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads_for(node_checks.size() * 65536, 65536))
+        for (long long q = 0; q < (long long)node_checks.size(); q++) {
+            try { why[q] = node_checks[q](); } catch (const std::exception& e) { why[q] = e.what(); }
+        }
+        for (auto& s : why) if (!s.empty()) return s;
+        return std::string();
     }
 };
 
@@ -502,6 +573,12 @@ static std::string verify_impl(const Params& p, const LassoPlan& lp, const HCirc
             else sub = {{V.lasso(lp)}};
             t_kind[n.kind == NK_VANILLA ? 0 : n.kind == NK_FFT ? 1 : 2] += omp_get_wtime() - tn;
             for (size_t i = 0; i < n.preds.size(); i++) for (auto& s : sub[i]) claims[n.preds[i]].push_back(s);
+        }
+        {
+            const double tq = omp_get_wtime();
+            const std::string why = V.run_node_checks();
+            t_kind[1] += omp_get_wtime() - tq;
+            if (!why.empty()) throw Reject(why);
         }
         // (the reference does not check that the proof stream is fully consumed either)
         // izip_eq!(inputs, input_claims): input.evaluate(point) == value (:512-516)

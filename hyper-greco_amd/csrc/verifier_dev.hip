@@ -7,24 +7,50 @@
 // Everything is enqueued on one stream while the host keeps parsing; one synchronisation; then the deferred comparisons.
 // Goldilocks, protocol mode 0 (the evaluation points are offsets into the fixed chain).
 #include <cstring>
+#include <omp.h>
 #include "prover.hpp"
 
 namespace hg {
 namespace {
 
-__global__ __launch_bounds__(256) void k_dot_e2(const E2* __restrict__ a, const E2* __restrict__ b, size_t n, E2* __restrict__ partials) {
+// every dot product of the verification in two launches: job q = sum_i a_q[i] * b_q[i] (a: E2 table or a table of base-field
+// integers, b: an eq table), VD_BLOCKS workgroups per job, then one workgroup per job adds their partial sums into the job's slot
+constexpr int VD_BLOCKS = 32;
+struct DotJob { const void* a; const E2* b; size_t n; int slot; int a_is_u64; };
+__global__ __launch_bounds__(256) void k_vdot_jobs(const DotJob* __restrict__ jobs, E2* __restrict__ partials) {
     __shared__ E2 sm[256];
+    const DotJob& J = jobs[blockIdx.y];
     E2 acc = e2_zero();
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc = e2_add(acc, e2_mul(a[i], b[i]));
+    if (J.a_is_u64) {
+        const u64* a = static_cast<const u64*>(J.a);
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < J.n; i += (size_t)VD_BLOCKS * 256) { const u64 v = a[i]; if (v) acc = e2_add(acc, e2_mul_f(J.b[i], v)); }
+    } else {
+        const E2* a = static_cast<const E2*>(J.a);
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < J.n; i += (size_t)VD_BLOCKS * 256) acc = e2_add(acc, e2_mul(a[i], J.b[i]));
+    }
     sm[threadIdx.x] = acc;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s) sm[threadIdx.x] = e2_add(sm[threadIdx.x], sm[threadIdx.x + s]);
         __syncthreads();
     }
-    if (threadIdx.x == 0) partials[blockIdx.x] = sm[0];
+    if (threadIdx.x == 0) partials[(size_t)blockIdx.y * VD_BLOCKS + blockIdx.x] = sm[0];
+}
+__global__ __launch_bounds__(64) void k_vdot_reduce(const DotJob* __restrict__ jobs, const E2* __restrict__ partials, E2* __restrict__ res) {
+    __shared__ E2 sm[64];
+    sm[threadIdx.x] = threadIdx.x < VD_BLOCKS ? partials[(size_t)blockIdx.x * VD_BLOCKS + threadIdx.x] : e2_zero();
+    __syncthreads();
+    for (int s = 32; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sm[threadIdx.x] = e2_add(sm[threadIdx.x], sm[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) res[jobs[blockIdx.x].slot] = sm[0];
 }
 
+// The walk (verifier.cpp) only RECORDS what it needs - every evaluation point is a run of the challenge chain, so no table depends
+// on a value the host would have to read back - and finish() launches it by kind over job arrays, as the prover's bookkeeping does:
+// all eq tables (a node's claims combined inside the kernel), the constant-gate sums, all Libra gathers, all DFT-row tables, all
+// phase-2 gathers, all dot products. Round 3 launched per node and per input as the walk went: ~700 launches, 17.6 ms at n=32768 k=16.
 struct DevBackend : VerifyBackend {
     hg_ctx* ctx;
     const hg_pk* pk;
@@ -34,11 +60,28 @@ struct DevBackend : VerifyBackend {
     size_t res_used = 0;
     // the node being checked
     int node = -1;
-    std::vector<size_t> mark;
-    E2 *eqc = nullptr, *eqx = nullptr, *eqy = nullptr, *d_u = nullptr;
+    E2 *eqc = nullptr, *eqx = nullptr, *eqy = nullptr;
+    const E2* d_u = nullptr;
     dev::ClaimSet cs;
+    // recorded work
+    std::vector<dev::EqJob> eqs;
+    int eq_max_n = 0;
+    struct ConstSum { const hg_pk::NodeDev* nd; const E2* eqc; int log2_G, log2_R, slot; };
+    std::vector<ConstSum> consts;
+    std::vector<dev::GatherJob> gts;
+    std::vector<dev::GatherBJob> gbs;
+    size_t gt_max = 0, gb_max = 0;
+    std::vector<dev::FftJob> ffts;
+    int fft_max_L = 0, fft_max_claims = 0;
+    std::vector<DotJob> dots;
+    std::vector<E2> h_u;          // the phase-1 evaluations of every Vanilla node with a phase 2, back to back
+    E2* d_u_all = nullptr;
+    static constexpr size_t U_CAP = 8192;
 
-    DevBackend(hg_ctx* c, const hg_pk* k) : ctx(c), pk(k), st(c->stream) { memset(&cs, 0, sizeof(cs)); }
+    DevBackend(hg_ctx* c, const hg_pk* k) : ctx(c), pk(k), st(c->stream) {
+        memset(&cs, 0, sizeof(cs));
+        d_u_all = ctx->alloc_n<E2>(U_CAP);
+    }
     int slot() {
         if (res_used + 1 > ctx->res_cap) throw Error("verifier: result buffer exhausted");
         return (int)res_used++;
@@ -57,19 +100,12 @@ struct DevBackend : VerifyBackend {
         return d;
     }
     E2* eq_of(int nvars, const dev::ClaimSet& c) {
-        const size_t N = (size_t)1 << nvars;
-        E2* out = ctx->alloc_n<E2>(N);
-        std::vector<dev::EqJob> jobs;
-        E2* tmp = c.n > 1 ? ctx->alloc_n<E2>((size_t)c.n * N) : nullptr;
-        for (int a = 0; a < c.n; a++) {
-            dev::EqJob J;
-            memset(&J, 0, sizeof(J));
-            J.n = nvars; J.out = c.n > 1 ? tmp + (size_t)a * N : out;
-            J.cs.n = 1; J.cs.unit_alpha = c.unit_alpha; J.cs.alpha_off = c.alpha_off + a; J.cs.point_off[0] = c.point_off[a];
-            jobs.push_back(J);
-        }
-        dev::eq_jobs(st, upload(jobs.data(), jobs.size()), (int)jobs.size(), nvars, ctx->d_chal);
-        if (c.n > 1) dev::sum_tables(st, out, tmp, c.n, N);
+        E2* out = ctx->alloc_n<E2>((size_t)1 << nvars);
+        dev::EqJob J;
+        memset(&J, 0, sizeof(J));
+        J.n = nvars; J.out = out; J.cs = c;
+        eqs.push_back(J);
+        eq_max_n = std::max(eq_max_n, nvars);
         return out;
     }
     E2* eq_single(int nvars, size_t off) {
@@ -78,17 +114,14 @@ struct DevBackend : VerifyBackend {
         c.n = 1; c.unit_alpha = 1; c.point_off[0] = off;
         return eq_of(nvars, c);
     }
-    int dot_e2(const E2* a, const E2* b, size_t n) {
-        const int grid = (int)std::min<size_t>((n + 255) / 256, 256);
-        k_dot_e2<<<grid, 256, 0, st>>>(a, b, n, ctx->d_partials);
+    int dot(const void* a, bool a_is_u64, const E2* b, size_t n) {
         const int t = slot();
-        dev::reduce_partials(st, ctx->d_partials, grid, 1, ctx->d_res + t);
+        dots.push_back(DotJob{a, b, n, t, a_is_u64 ? 1 : 0});
         return t;
     }
 
     void begin_node(int id, const ClaimOffs& cl) override {
         node = id;
-        mark = ctx->arena_mark();
         const HNode& n = pk->circuit.nodes[id];
         if (cl.point_off.size() > (size_t)dev::MAX_CLAIMS) throw Error("verifier: too many claims on one node");
         memset(&cs, 0, sizeof(cs));
@@ -97,14 +130,13 @@ struct DevBackend : VerifyBackend {
         cs.alpha_off = cl.alpha_off;
         for (int a = 0; a < cs.n; a++) cs.point_off[a] = cl.point_off[a];
         eqc = n.kind == NK_VANILLA ? eq_of(n.log2_out(), cs) : nullptr;
-        eqx = eqy = d_u = nullptr;
+        eqx = eqy = nullptr;
+        d_u = nullptr;
     }
     int const_sum() override {
         const HNode& n = pk->circuit.nodes[node];
-        const hg_pk::NodeDev& nd = pk->node_dev[node];
-        const int grid = dev::vanilla_const_sum(st, nd.const_gate, nd.const_coef, nd.nconst, eqc, n.log2_sub_out, n.log2_reps, ctx->d_partials);
         const int t = slot();
-        dev::reduce_partials(st, ctx->d_partials, grid, 1, ctx->d_res + t);
+        consts.push_back(ConstSum{&pk->node_dev[node], eqc, n.log2_sub_out, n.log2_reps, t});
         return t;
     }
     void set_x(size_t x_off) override {
@@ -123,15 +155,18 @@ struct DevBackend : VerifyBackend {
             memset(&gj, 0, sizeof(gj));
             gj.g.lin = nd.lin[i];   // (no mul part: the verifier's linear term has no input tables)
             gj.eqc = eqc; gj.log2_S = n.log2_sub_in; gj.log2_G = n.log2_sub_out; gj.log2_R = n.log2_reps; gj.T = T;
-            dev::gather_jobs(st, upload(&gj, 1), 1, SR);
-            tk[i] = dot_e2(T, eqx, SR);
+            gts.push_back(gj);
+            gt_max = std::max(gt_max, SR);
+            tk[i] = dot(T, false, eqx, SR);
         }
         return tk;
     }
     void set_y(size_t y_off, const std::vector<E2>& u) override {
         const HNode& n = pk->circuit.nodes[node];
         eqy = eq_single(n.log2_sub_in + n.log2_reps, y_off);
-        d_u = upload(u.data(), u.size());
+        if (h_u.size() + u.size() > U_CAP) throw Error("verifier: too many phase-1 evaluations");
+        d_u = d_u_all + h_u.size();
+        h_u.insert(h_u.end(), u.begin(), u.end());
     }
     std::vector<int> mul_terms() override {
         const HNode& n = pk->circuit.nodes[node];
@@ -141,9 +176,9 @@ struct DevBackend : VerifyBackend {
         for (int i = 0; i < n.arity; i++) {
             if (!n.right_use[i] || !nd.mulR[i].ptr) continue;
             E2* B = ctx->alloc_n<E2>(SR);
-            dev::GatherBJob bj{nd.mulR[i], eqc, eqx, d_u, n.log2_sub_in, n.log2_sub_out, n.log2_reps, B};
-            dev::gather_B_jobs(st, upload(&bj, 1), 1, SR);
-            tk[i] = dot_e2(B, eqy, SR);
+            gbs.push_back(dev::GatherBJob{nd.mulR[i], eqc, eqx, d_u, n.log2_sub_in, n.log2_sub_out, n.log2_reps, B});
+            gb_max = std::max(gb_max, SR);
+            tk[i] = dot(B, false, eqy, SR);
         }
         return tk;
     }
@@ -153,30 +188,56 @@ struct DevBackend : VerifyBackend {
         const size_t N = (size_t)1 << L;
         E2* F = ctx->alloc_n<E2>(N);
         const u64* W = (n.inverse ? pk->w_inv : pk->w_fwd).at(L);
-        dev::FftJob fj{F, W, n.inverse ? gl_inv(gl_from_u64(N)) : 1, L, cs};
-        E2* tab = ctx->alloc_n<E2>((size_t)cs.n * (N >> 4) + 1);
-        dev::fft_jobs(st, upload(&fj, 1), 1, L, cs.n, ctx->d_chal, tab);
-        return dot_e2(F, eqx, N);
+        ffts.push_back(dev::FftJob{F, W, n.inverse ? gl_inv(gl_from_u64(N)) : 1, L, cs});
+        fft_max_L = std::max(fft_max_L, L);
+        fft_max_claims = std::max(fft_max_claims, cs.n);
+        return dot(F, false, eqx, N);
     }
-    void end_node() override {
-        ctx->arena_rewind(mark);   // (one stream: the next node's kernels are ordered behind this node's)
-        node = -1;
-    }
-    int mle_u64(const u64* tab, size_t point_off, int nvars) {
-        const std::vector<size_t> m = ctx->arena_mark();
-        E2* eq = eq_single(nvars, point_off);
-        const int t = slot();
-        const u64* tabs[8] = {tab};
-        dev::dot_eq(st, eq, tabs, 1, (size_t)1 << nvars, ctx->d_partials, ctx->d_res + t);
-        ctx->arena_rewind(m);
-        return t;
-    }
+    void end_node() override { node = -1; }
+    int mle_u64(const u64* tab, size_t point_off, int nvars) { return dot(tab, true, eq_single(nvars, point_off), (size_t)1 << nvars); }
     int mle_input(size_t k, size_t point_off, int nvars) override {
         if (k >= d_inputs.size()) throw Error("verifier: no such input table");
         return mle_u64(d_inputs[k], point_off, nvars);
     }
     int mle_ct0is(size_t point_off, int nvars) override { return mle_u64(d_ct0is, point_off, nvars); }
     void finish() override {
+        static const bool times = getenv("HG_VERIFY_TIMES") != nullptr;
+        const double t0 = times ? omp_get_wtime() : 0;
+        if (times) { hip_check(hipStreamSynchronize(st), "sync"); fprintf(stderr, "[hg] verify_device: uploads drained %.2f ms after the walk ended; %zu eq tables, %zu gathers, %zu + %zu, %zu dots\n", (omp_get_wtime() - t0) * 1e3, eqs.size(), gts.size(), gbs.size(), ffts.size(), dots.size()); }
+        auto lap = [&](const char* what) { if (times) { hip_check(hipStreamSynchronize(st), "sync"); fprintf(stderr, "[hg] verify_device: %8.2f ms  %s\n", (omp_get_wtime() - t0) * 1e3, what); } };
+        // descriptors first (one staging area; the copies are stream-ordered ahead of the launches), then one launch per kind
+        const dev::EqJob* d_eqs = eqs.empty() ? nullptr : upload(eqs.data(), eqs.size());
+        const dev::GatherJob* d_gts = gts.empty() ? nullptr : upload(gts.data(), gts.size());
+        const dev::GatherBJob* d_gbs = gbs.empty() ? nullptr : upload(gbs.data(), gbs.size());
+        const dev::FftJob* d_ffts = ffts.empty() ? nullptr : upload(ffts.data(), ffts.size());
+        const DotJob* d_dots = dots.empty() ? nullptr : upload(dots.data(), dots.size());
+        if (!h_u.empty()) {
+            const E2* staged = upload(h_u.data(), h_u.size());
+            hip_check(hipMemcpyAsync(d_u_all, staged, h_u.size() * sizeof(E2), hipMemcpyDeviceToDevice, st), "verifier: phase-1 evaluations");
+        }
+        lap("descriptors uploaded");
+        if (d_eqs) dev::eq_jobs(st, d_eqs, (int)eqs.size(), eq_max_n, ctx->d_chal);
+        lap("eq tables");
+        for (const ConstSum& c : consts) {
+            const int grid = dev::vanilla_const_sum(st, c.nd->const_gate, c.nd->const_coef, c.nd->nconst, c.eqc, c.log2_G, c.log2_R, ctx->d_partials);
+            dev::reduce_partials(st, ctx->d_partials, grid, 1, ctx->d_res + c.slot);
+        }
+        lap("constant sums");
+        if (d_gts) dev::gather_jobs(st, d_gts, (int)gts.size(), gt_max);
+        lap("phase-1 gathers");
+        if (d_ffts) {
+            E2* tab = ctx->alloc_n<E2>(ffts.size() * (size_t)fft_max_claims * ((size_t)1 << (fft_max_L > 4 ? fft_max_L - 4 : 0)) + 1);
+            dev::fft_jobs(st, d_ffts, (int)ffts.size(), fft_max_L, fft_max_claims, ctx->d_chal, tab);
+        }
+        lap("DFT-row tables");
+        if (d_gbs) dev::gather_B_jobs(st, d_gbs, (int)gbs.size(), gb_max);
+        lap("phase-2 gathers");
+        if (d_dots) {
+            E2* part = ctx->alloc_n<E2>(dots.size() * (size_t)VD_BLOCKS);
+            k_vdot_jobs<<<dim3(VD_BLOCKS, (unsigned)dots.size()), 256, 0, st>>>(d_dots, part);
+            k_vdot_reduce<<<(unsigned)dots.size(), 64, 0, st>>>(d_dots, part, ctx->d_res);
+        }
+        lap("dot products");
         if (ctx->d_res != ctx->h_res && res_used)
             hip_check(hipMemcpyAsync(ctx->h_res, ctx->d_res, res_used * sizeof(E2), hipMemcpyDeviceToHost, st), "verifier: copy results");
         hip_check(hipStreamSynchronize(st), "verifier: synchronise");
@@ -189,6 +250,8 @@ struct DevBackend : VerifyBackend {
 
 // public inputs and ct0is are uploaded (22 MB at n=32768 k=16), the proof is parsed on the host; "" = accepted
 std::string verify_proof_device(hg_ctx* ctx, const hg_pk* pk, const Witness& w, const uint8_t* proof, size_t len) {
+    const double tv0 = omp_get_wtime();
+    struct Total { double t0; ~Total() { if (getenv("HG_VERIFY_TIMES")) fprintf(stderr, "[hg] verify_device: %.2f ms in all\n", (omp_get_wtime() - t0) * 1e3); } } total{tv0};
     hip_check(hipSetDevice(ctx->device), "hipSetDevice");
     ctx->arena_reset();
     ctx->ensure_chain(16384);
@@ -207,6 +270,7 @@ std::string verify_proof_device(hg_ctx* ctx, const hg_pk* pk, const Witness& w, 
     for (int i = 0; i < p.k; i++) D.d_inputs.push_back(up(&w.r1is[(size_t)i * SZ], SZ));
     D.d_inputs.push_back(up(w.r2is.data(), w.r2is.size()));
     D.d_ct0is = up(w.ct0is.data(), w.ct0is.size());
+    if (getenv("HG_VERIFY_TIMES")) fprintf(stderr, "[hg] verify_device: inputs enqueued at %.2f ms\n", (omp_get_wtime() - tv0) * 1e3);
     // Rejection is a normal outcome and leaves kernels and staged descriptor copies queued (the walk returns from the middle of the
     // proof): drain the stream on EVERY way out - accept, Reject, hg::Error - before the caller may reuse the staging buffer and the
     // arena or free the witness whose uploads may still be pending.
