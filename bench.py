@@ -485,10 +485,42 @@ def main():
     for i in range(NW):
         assert step(i).bytes() == walked[i]
     resident_all = None
+    peak_all = None
+    witness_ms_all = None
+    dp_leg = None
     if shard:
         lst = [None] * world
         dist.all_gather_object(lst, round(resident["resident_bytes"] / 1e6, 1))
         resident_all = lst
+        lst = [None] * world
+        dist.all_gather_object(lst, round(resident.get("peak_bytes", resident["resident_bytes"]) / 1e6, 1))
+        peak_all = lst
+        lst = [None] * world
+        dist.all_gather_object(lst, round(vals[0].timings["witness_ms"] + vals[0].timings["upload_ms"], 3))
+        witness_ms_all = lst
+        # The same N GPUs used the other way round, in the same run: one INDEPENDENT proof per GPU (no data-path collective, weak
+        # scaling) - the aggregate proofs/s the node delivers when latency of one proof does not matter. A different witness per rank
+        # (own full table set), the launch graph replayed, every proof compared with the walked proof of its witness.
+        dp_w = hg.Witness.synthetic(bfv.params, witness_seed(args.seed, args.n, rank) + 7)
+        dp_vals = hg.witness_gen(ctx, pk, dp_w)
+        dp_out = hg.ProofBuffer()
+        dp_ref = hg.prove_resident(ctx, pk, dp_vals, dp_out).bytes()
+        for _ in range(3):
+            assert hg.prove_resident(ctx, pk, dp_vals, dp_out).bytes() == dp_ref
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            hg.prove_resident(ctx, pk, dp_vals, dp_out)
+        barrier()
+        dp_elapsed = max_over_ranks(time.perf_counter() - t0, world, dist, torch, red_dev)
+        assert dp_out.bytes() == dp_ref
+        refs = [None] * world
+        dist.all_gather_object(refs, hash(dp_ref))
+        dp_leg = {"mode": f"dp{world}: one independent proof per GPU, no data-path collective (weak scaling)",
+                  "ms_per_step": round(dp_elapsed / args.steps * 1e3, 4), "proofs_per_step": world,
+                  "proofs_per_s": round(world * args.steps / dp_elapsed, 2), "distinct_proofs": len(set(refs)),
+                  "note": "timed like `value` (barrier, K steps, barrier, max over ranks) right after the sharded regions; `value` stays the sharded proof's ms"}
+        dp_vals.free()
     elapsed = max_over_ranks(elapsed, world, dist, torch, red_dev)
     elapsed_a = max_over_ranks(elapsed_a, world, dist, torch, red_dev)
     elapsed_c = max_over_ranks(elapsed_c, world, dist, torch, red_dev)
@@ -589,8 +621,11 @@ def main():
                                                      f"{ms_per_step_a:.4f} ms per prove, {gpu_ms_a:.4f} ms of GPU time"},
                        **({"rccl_ranks_seen": rccl_ranks_seen} if rccl_ranks_seen is not None else {}),
                        **({"resident_node_tables": {"rank0_MB": round(resident["resident_bytes"] / 1e6, 1), "per_rank_MB": resident_all,
+                                                    "per_rank_peak_MB": peak_all, "per_rank_witness_ms": witness_ms_all,
                                                     "full_set_MB": round(resident["full_bytes"] / 1e6, 1),
-                                                    "note": "hg_witness_gen_shard: a rank keeps the Lasso input and the inputs of the node reductions it owns"}} if shard else {}),
+                                                    "note": "hg_witness_gen_shard: a rank keeps the Lasso input and the inputs of the node reductions it owns, and evaluates only "
+                                                            "the cone of those tables (peak = its tables + the cone's subset tables; witness ms = upload + evaluation of the cone)"}} if shard else {}),
+                       **({"dp_aggregate": dp_leg} if dp_leg else {}),
                        **({"end_to_end": end_to_end} if end_to_end else {}),
                        **({"verify": verify_info} if verify_info else {}),
                        "witness_gen_ms_device_first_call": round(vals[0].timings["witness_ms"], 2), "upload_ms_first_call": round(vals[0].timings["upload_ms"], 2)},
@@ -694,7 +729,10 @@ def main():
                     same = hg.prove_shard_finish(ctx, out).bytes() == walked[0]
                     t_fin = (time.perf_counter() - t0) * 1e3
                     proj[str(wsz)] = {"slowest_rank_ms": round(max(per_rank), 3), "fastest_rank_ms": round(min(per_rank), 3), "combine_and_replay_ms": round(t_fin, 3),
+                                      "per_rank_ms": [round(t, 3) for t in per_rank],
                                       "resident_MB_per_rank_max": round(max(v.info()["resident_bytes"] for v in svals) / 1e6, 1),
+                                      "peak_MB_per_rank_max": round(max(v.info()["peak_bytes"] for v in svals) / 1e6, 1),
+                                      "witness_ms_per_rank_max": round(max(v.timings["witness_ms"] + v.timings["upload_ms"] for v in svals), 3),
                                       "proof_equals_single_gpu": bool(same)}
                     assert same, "virtual ranks: the combined proof differs from the single-GPU proof"
                     for v in svals:

@@ -402,6 +402,13 @@ int hg_values_info(const hg_values* v, uint64_t out[4]) {
     HG_CATCH(-1)
 }
 
+int64_t hg_values_peak_bytes(const hg_values* v) {
+    if (!v) return -1;
+    uint64_t info[4];
+    if (hg_values_info(v, info) != 0) return -1;
+    return (int64_t)(info[0] + v->cone_bytes);
+}
+
 void hg_values_free(hg_values* v) { values_free(v); }
 
 int64_t hg_values_get(hg_ctx* ctx, const hg_values* v, int node, uint64_t* out, size_t cap) {

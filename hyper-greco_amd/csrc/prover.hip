@@ -1755,7 +1755,7 @@ struct Prover {
 
 // ------------------------------------------------------------------------------------------------
 // Lays out the node tables of `pk`'s circuit in ONE allocation (plus the NTT scratch): hg_values without contents.
-static hg_values* values_alloc(hg_ctx* ctx, const hg_pk* pk) {
+static hg_values* values_alloc(hg_ctx* ctx, const hg_pk* pk, const std::vector<char>* mask = nullptr, bool with_ct0is = true) {
     hip_check(hipSetDevice(ctx->device), "hipSetDevice");
     const HCircuit& c = pk->circuit;
     const Params& p = pk->params;
@@ -1778,25 +1778,28 @@ static hg_values* values_alloc(hg_ctx* ctx, const hg_pk* pk) {
     auto key = [&](int id) { const HNode& n = c.nodes[id]; return std::make_tuple(n.kind == NK_FFT ? 1 : 0, level[id], n.inverse ? 1 : 0, id); };
     std::sort(v->order.begin(), v->order.end(), [&](int a, int b) { return key(a) < key(b); });
     v->ct0is_len = (size_t)p.k * p.SZ();
-    size_t total = v->ct0is_len;
-    for (size_t id = 0; id < nn; id++) { v->sizes[id] = (size_t)1 << c.nodes[id].log2_out(); total += v->sizes[id]; }
+    if (mask) { v->mask = *mask; v->with_ct0is = with_ct0is; }
+    auto in = [&](size_t id) { return v->mask.empty() || v->mask[id]; };
+    size_t total = v->with_ct0is ? v->ct0is_len : 0;
+    for (size_t id = 0; id < nn; id++) { v->sizes[id] = (size_t)1 << c.nodes[id].log2_out(); if (in(id)) total += v->sizes[id]; }
     u64* base = nullptr;
-    hip_check(hipMalloc((void**)&base, total * 8), "hipMalloc(node values)");
+    hip_check(hipMalloc((void**)&base, std::max<size_t>(total, 1) * 8), "hipMalloc(node values)");
     v->owned.push_back(base);
     size_t off = 0;
-    for (int id : v->order) { v->d_vals[id] = base + off; off += v->sizes[id]; }
-    v->d_ct0is = base + off;
+    for (int id : v->order) if (in((size_t)id)) { v->d_vals[id] = base + off; off += v->sizes[id]; }   // (a masked FFT group stays contiguous)
+    if (v->with_ct0is) v->d_ct0is = base + off;
     size_t max_fft = 0;
     {
         std::map<std::pair<int, int>, size_t> grp_sz;
-        for (size_t id = 0; id < nn; id++) if (c.nodes[id].kind == NK_FFT) grp_sz[{level[id], (int)c.nodes[id].inverse}] += v->sizes[id];
+        for (size_t id = 0; id < nn; id++) if (c.nodes[id].kind == NK_FFT && in(id)) grp_sz[{level[id], (int)c.nodes[id].inverse}] += v->sizes[id];
         for (auto& kv : grp_sz) max_fft = std::max(max_fft, kv.second);
     }
     if (max_fft) { hip_check(hipMalloc((void**)&v->ntt_scratch, max_fft * 8), "hipMalloc(ntt scratch)"); v->owned.push_back(v->ntt_scratch); }
+    v->resident_bytes = (total + max_fft) * 8;
     return v.release();
 }
 
-static void shard_fill(hg_ctx* ctx, hg_values* v, const hg_values* full);
+static void shard_fill(hg_ctx* ctx, hg_values* v, const hg_values* full, hipStream_t st, bool sync);
 static void witness_fill(hg_ctx* ctx, const hg_pk* pk, const Witness& w, hg_values* v, hipStream_t st, bool sync, double* witness_ms, double* upload_ms);
 void witness_gen_into(hg_ctx* ctx, const hg_pk* pk, const Witness& w, hg_values* v, double* witness_ms, double* upload_ms) {
     witness_fill(ctx, pk, w, v, ctx->stream, true, witness_ms, upload_ms);
@@ -1809,10 +1812,11 @@ static void witness_fill(hg_ctx* ctx, const hg_pk* pk, const Witness& w, hg_valu
     // prove depends on addresses only).
     if (!v || v->pk_serial != pk->serial) throw Error("witness generation: the values object was laid out for another prover key");
     if (v->device != ctx->device) throw Error("witness generation: the values object lives on another device");
-    if (v->shard_rank >= 0) {   // a rank's share: evaluate in full into a temporary object, keep the rank's tables at their addresses
-        hg_values* full = witness_gen(ctx, pk, w, witness_ms, upload_ms);
-        try { shard_fill(ctx, v, full); } catch (...) { values_free(full); throw; }
-        values_free(full);
+    if (v->ctx != ctx) throw Error("witness generation: the values object was created on another context");
+    if (v->shard_rank >= 0) {   // a rank's share: evaluate the cone its tables depend on into the object's own subset tables, copy them over
+        if (!v->eval_cone) throw Error("witness generation: a rank's values object without its evaluation cone");
+        witness_fill(ctx, pk, w, v->eval_cone, st, false, witness_ms, upload_ms);
+        shard_fill(ctx, v, v->eval_cone, st, sync);
         return;
     }
     hip_check(hipSetDevice(ctx->device), "hipSetDevice");
@@ -1821,26 +1825,27 @@ static void witness_fill(hg_ctx* ctx, const hg_pk* pk, const Witness& w, hg_valu
     if (w.ct0is.size() != v->ct0is_len) throw Error("circuit: ct0is size mismatch");
     double t0 = wall_ms();
     auto dv = [&](int id) { return const_cast<u64*>(v->d_vals[id]); };
+    auto in = [&](int id) { return v->mask.empty() || v->mask[id]; };   // (a subset object evaluates its nodes only: their inputs are in it)
     {   // inputs in NodeId order: s, e, k1, ais.., r1is.., r2is (chain_par! sk_encryption_circuit.rs:408)
         const size_t SZ = p.SZ();
         size_t idx = 0;
         auto put = [&](const u64* src, size_t len) {
             int id = c.input_ids.at(idx++);
             if (len != v->sizes[id]) throw Error("circuit: input size mismatch");
-            hip_check(hipMemcpyAsync(dv(id), src, len * 8, hipMemcpyHostToDevice, st), "upload input");
+            if (in(id)) hip_check(hipMemcpyAsync(dv(id), src, len * 8, hipMemcpyHostToDevice, st), "upload input");
         };
         put(w.s.data(), SZ); put(w.e.data(), SZ); put(w.k1.data(), SZ);
         for (int i = 0; i < p.k; i++) put(&w.ais[i * SZ], SZ);
         for (int i = 0; i < p.k; i++) put(&w.r1is[i * SZ], SZ);
         put(w.r2is.data(), w.r2is.size());
-        hip_check(hipMemcpyAsync(const_cast<u64*>(v->d_ct0is), w.ct0is.data(), w.ct0is.size() * 8, hipMemcpyHostToDevice, st), "upload ct0is");
+        if (v->d_ct0is) hip_check(hipMemcpyAsync(const_cast<u64*>(v->d_ct0is), w.ct0is.data(), w.ct0is.size() * 8, hipMemcpyHostToDevice, st), "upload ct0is");
     }
     if (upload_ms && sync) hip_check(hipStreamSynchronize(st), "upload sync");   // (only to split the two timings)
     double t1 = wall_ms();
     for (int l = 1; l <= v->max_level; l++) {
         for (int inv = 0; inv < 2; inv++) {  // FFT groups
             std::vector<int> grp;
-            for (int id : v->order) if (c.nodes[id].kind == NK_FFT && v->level[id] == l && (int)c.nodes[id].inverse == inv) grp.push_back(id);
+            for (int id : v->order) if (c.nodes[id].kind == NK_FFT && v->level[id] == l && (int)c.nodes[id].inverse == inv && in(id)) grp.push_back(id);
             if (grp.empty()) continue;
             const int L = c.nodes[grp[0]].log2_size;
             const size_t N = (size_t)1 << L;
@@ -1853,7 +1858,7 @@ static void witness_fill(hg_ctx* ctx, const hg_pk* pk, const Witness& w, hg_valu
         }
         for (int id : c.topo) {
             const HNode& n = c.nodes[id];
-            if (v->level[id] != l) continue;
+            if (v->level[id] != l || !in(id)) continue;
             if (n.kind == NK_VANILLA) {
                 dev::EvalNode e = pk->node_dev[id].fwd;
                 for (int i = 0; i < n.arity; i++) e.in[i] = dv(n.preds[i]);
@@ -1894,29 +1899,43 @@ static void shard_needed(const hg_pk* pk, int rank, int world, std::vector<char>
     *need_ct0is = sp.own_out_claim == rank;
 }
 // copies the needed tables out of a fully evaluated circuit into the compact allocation of `v` (same addresses every time)
-static void shard_fill(hg_ctx* ctx, hg_values* v, const hg_values* full) {
+static void shard_fill(hg_ctx* ctx, hg_values* v, const hg_values* full, hipStream_t st, bool sync) {
     for (size_t id = 0; id < v->d_vals.size(); id++)
-        if (v->d_vals[id]) hip_check(hipMemcpyAsync(const_cast<u64*>(v->d_vals[id]), full->d_vals[id], v->sizes[id] * 8, hipMemcpyDeviceToDevice, ctx->stream), "keep node table");
-    if (v->d_ct0is) hip_check(hipMemcpyAsync(const_cast<u64*>(v->d_ct0is), full->d_ct0is, v->ct0is_len * 8, hipMemcpyDeviceToDevice, ctx->stream), "keep ct0is");
-    hip_check(hipStreamSynchronize(ctx->stream), "shard fill");
+        if (v->d_vals[id]) {
+            if (!full->d_vals[id]) throw Error("shard fill: a resident table is not in the evaluated cone");
+            hip_check(hipMemcpyAsync(const_cast<u64*>(v->d_vals[id]), full->d_vals[id], v->sizes[id] * 8, hipMemcpyDeviceToDevice, st), "keep node table");
+        }
+    if (v->d_ct0is) {
+        if (!full->d_ct0is) throw Error("shard fill: ct0is is not in the evaluated cone");
+        hip_check(hipMemcpyAsync(const_cast<u64*>(v->d_ct0is), full->d_ct0is, v->ct0is_len * 8, hipMemcpyDeviceToDevice, st), "keep ct0is");
+    }
+    if (sync) hip_check(hipStreamSynchronize(st), "shard fill");
 }
 hg_values* witness_gen_shard(hg_ctx* ctx, const hg_pk* pk, const Witness& w, int rank, int world, double* witness_ms, double* upload_ms) {
     if (world < 1 || rank < 0 || rank >= world) throw Error("witness_gen_shard: bad rank / world");
     if (world == 1) return witness_gen(ctx, pk, w, witness_ms, upload_ms);
-    // The circuit is evaluated in full once (the per-modulus chains feed shared nodes: lasso_inputs_batched reads every r1_i, r2_i)
-    // into a temporary object; what this rank does not read is released before the function returns.
+    // Only the CONE of the rank's tables is evaluated: a table the rank reads, and recursively everything it is computed from - the
+    // per-modulus chains (a_i -> FFT -> mul -> IFFT -> ... [REF sk_encryption_circuit.rs:122-128, 245-260]) of the moduli whose node
+    // reductions it owns, the inputs behind the Lasso node's table - into a subset object the values object keeps (eval_cone), so that
+    // a refill (hg_witness_gen_into) allocates nothing. Peak residency of the rank = its tables + the cone (hg_values_info).
     struct ValuesDeleter { void operator()(hg_values* p) const { values_free(p); } };
-    std::unique_ptr<hg_values, ValuesDeleter> full(witness_gen(ctx, pk, w, witness_ms, upload_ms));
     std::vector<char> need;
     bool need_ct0is = false;
     shard_needed(pk, rank, world, &need, &need_ct0is);
+    const HCircuit& c = pk->circuit;
+    std::vector<char> cone = need;
+    for (size_t q = c.topo.size(); q-- > 0;) {   // reverse topological order: a node's predecessors come later in this walk
+        const int id = c.topo[q];
+        if (cone[id]) for (int pr : c.nodes[id].preds) cone[pr] = 1;
+    }
+    std::unique_ptr<hg_values, ValuesDeleter> sub(values_alloc(ctx, pk, &cone, need_ct0is));
     std::unique_ptr<hg_values, ValuesDeleter> v(new hg_values());
     static std::atomic<uint64_t> next_serial{(uint64_t)1 << 40};   // (disjoint from values_alloc's serials)
     v->serial = next_serial++;
     v->pk_serial = pk->serial; v->device = ctx->device; v->ctx = ctx;
-    v->sizes = full->sizes;
-    v->ct0is_len = full->ct0is_len;
-    v->d_vals.assign(full->d_vals.size(), nullptr);
+    v->sizes = sub->sizes;
+    v->ct0is_len = sub->ct0is_len;
+    v->d_vals.assign(sub->d_vals.size(), nullptr);
     v->shard_rank = rank; v->shard_world = world;
     size_t total = need_ct0is ? v->ct0is_len : 0, all = v->ct0is_len;
     for (size_t id = 0; id < need.size(); id++) { all += v->sizes[id]; if (need[id]) total += v->sizes[id]; }
@@ -1927,7 +1946,9 @@ hg_values* witness_gen_shard(hg_ctx* ctx, const hg_pk* pk, const Witness& w, int
     for (size_t id = 0; id < need.size(); id++) if (need[id]) { v->d_vals[id] = base + off; off += v->sizes[id]; }
     if (need_ct0is) v->d_ct0is = base + off;
     v->resident_bytes = total * 8; v->full_bytes = all * 8;
-    shard_fill(ctx, v.get(), full.get());
+    v->cone_bytes = sub->resident_bytes;
+    v->eval_cone = sub.release();
+    witness_fill(ctx, pk, w, v.get(), ctx->stream, true, witness_ms, upload_ms);
     return v.release();
 }
 
@@ -1948,6 +1969,7 @@ void values_free(hg_values* v) {
         for (hg_ctx* c : g_live_ctx) if (c == v->ctx) prove_cache_forget_values(c, v->serial);
     }
     for (void* p : v->owned) (void)hipFree(p);
+    if (v->eval_cone) values_free(v->eval_cone);
     delete v;
 }
 

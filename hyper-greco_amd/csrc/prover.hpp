@@ -164,6 +164,13 @@ struct hg_values {
     // a rank's share of a sharded proof (witness_gen_shard): the tables of nodes it does not read are not resident (d_vals[id] == nullptr)
     int shard_rank = -1, shard_world = 0;   // -1: every table is resident
     size_t resident_bytes = 0, full_bytes = 0;
+    // evaluation of a SUBSET of the circuit (witness_fill): mask[id] != 0 for the nodes that are laid out and evaluated (empty: all).
+    // A rank's values object owns such a subset object for the cone of nodes its resident tables depend on (eval_cone): a refill
+    // evaluates the cone into it and copies the resident tables over - nothing is allocated, the rest of the circuit is never touched.
+    std::vector<char> mask;
+    bool with_ct0is = true;
+    hg_values* eval_cone = nullptr;
+    size_t cone_bytes = 0;                 // bytes of eval_cone (tables + NTT scratch): resident_bytes + cone_bytes = the rank's peak
 };
 
 namespace hg {

@@ -165,10 +165,15 @@ int hg_witness_gen_into(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, hg_va
 /* The same for ONE rank of a proof sharded over `world` GPUs (BASELINE config 4): only the node tables the rank's share reads stay
  * resident - the Lasso node's input, the inputs of the Vanilla / FFT node reductions the planner deals to it, ct0is on the rank that
  * evaluates the output claim; the per-modulus objects a rank does not own [REF sk_encryption_circuit.rs:122-128, 245-260] are released.
- * The result proves through hg_prove_sharded / hg_prove_shard_begin with the same (rank, world) only; hg_witness_gen_into refills it. */
+ * Only the cone of those tables is ever evaluated (the per-modulus chains of the moduli the rank owns, not the whole circuit), into
+ * subset tables the object keeps, so hg_witness_gen_into refills it without allocating (hg_values_peak_bytes: tables + cone).
+ * The result proves through hg_prove_sharded / hg_prove_shard_begin with the same (rank, world) only. */
 int hg_witness_gen_shard(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, int rank, int world, hg_values** out, hg_timings* timings);
 /* [resident bytes, bytes of the full set of node tables, resident tables, tables] */
 int hg_values_info(const hg_values* v, uint64_t out[4]);
+/* Device bytes the object holds in all: its resident tables plus, for a rank's share (hg_witness_gen_shard), the subset tables its
+ * refills evaluate into - the cone of nodes the resident tables are computed from, never the whole circuit. -1 for a null handle. */
+int64_t hg_values_peak_bytes(const hg_values* v);
 void hg_values_free(hg_values* v);
 /* copies node `node`'s table (NodeId order of configure) back to the host; returns its element count */
 int64_t hg_values_get(hg_ctx* ctx, const hg_values* v, int node, uint64_t* out, size_t cap);

@@ -5,7 +5,11 @@ mode "combine" (CPU only): the caller-side exchange of a sharded proof without t
     are all-gathered over gloo and summed by hg_shard_combine_host; every rank checks the result against Python integers.
 mode "prove" (needs a GPU; both ranks on device 0): the real two-process sharded prove - hg_prove_shard_begin on each rank's own
     context, gloo all-gather of the partial buffers, hg_prove_shard_combine, hg_prove_shard_finish - at n=4096 k=2; every rank
-    must produce the CPU oracle's proof bytes. Three proofs in a row (walk, walk, launch-graph capture) with two witnesses."""
+    must produce the CPU oracle's proof bytes. Five proofs in a row (walk, walk, launch-graph capture, replays) with two witnesses.
+mode "prove_c3" (needs a GPU; both ranks on device 0): the same at BASELINE config 4's size, n=32768 k=16, with PER-RANK tables: every
+    process evaluates only the cone of its own share (hg_witness_gen_shard: the other rank's per-modulus chains are never computed or
+    resident), proves its share, exchanges the partial buffers over gloo; the second witness goes in through hg_witness_gen_into.
+    Every rank's proof must be the CPU oracle's."""
 import os
 import sys
 
@@ -77,6 +81,32 @@ def main():
             assert got == refs[j], "rank %d, proof %d: sharded two-process proof differs from the CPU oracle" % (rank, it)
         dist.barrier()
         print("rank %d PROVE OK" % rank, flush=True)
+        vals.free(); pk.free(); ctx.close()
+    elif mode == "prove_c3":
+        import orclib
+        n, k = 32768, 16
+        ctx = hg.Context(0)
+        bfv = hg.BfvEncrypt.new(n, k)
+        pk = bfv.setup(ctx)
+        ws = [hg.Witness.synthetic(bfv.params, 0x61 + j) for j in range(2)]
+        threads = max(2, min(16, (os.cpu_count() or 4) // 2))
+        refs = [orclib.prove(orclib.params(n, k), orclib.Inputs(w.arrays()), threads=threads)[0] for w in ws]
+        vals = hg.witness_gen_shard(ctx, pk, ws[0], rank, world)
+        info = vals.info()
+        assert info["resident_bytes"] < info["full_bytes"] and info["resident_tables"] < info["tables"], info
+        assert info["resident_bytes"] < info["peak_bytes"] < info["full_bytes"] + info["resident_bytes"], info   # its tables + the cone, not the circuit
+        out = hg.ProofBuffer()
+        for it in range(4):          # walk, walk, then the second witness (refill in place): capture, replay
+            j = 0 if it < 2 else 1
+            if it == 2:
+                hg.witness_gen_into(ctx, pk, ws[1], vals)
+            part = hg.prove_shard_begin(ctx, pk, vals, rank, world)
+            gathered = all_gather_u64(np.array(part, copy=True), world)
+            hg.prove_shard_combine(ctx, gathered, world)
+            got = hg.prove_shard_finish(ctx, out).bytes()
+            assert got == refs[j], "rank %d, proof %d: sharded two-process proof (per-rank tables, n=32768) differs from the CPU oracle" % (rank, it)
+        dist.barrier()
+        print("rank %d PROVE_C3 OK resident %.1f MB peak %.1f MB of %.1f MB" % (rank, info["resident_bytes"] / 1e6, info["peak_bytes"] / 1e6, info["full_bytes"] / 1e6), flush=True)
         vals.free(); pk.free(); ctx.close()
     else:
         raise SystemExit("unknown mode")

@@ -57,3 +57,12 @@ def test_sharded_prove_two_processes_gloo_matches_the_oracle():
     out = _launch([os.path.join(ROOT, "tests", "dist_worker.py"), "prove"], 29521, 900)
     assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-3000:])
     assert out.stdout.count("PROVE OK") == 2, out.stdout
+
+
+@pytest.mark.gpu
+def test_sharded_prove_two_processes_per_rank_tables_at_the_headline_size():
+    """BASELINE config 4's size with per-rank tables in two real processes (tests/dist_worker.py "prove_c3"): every process evaluates
+    the cone of its own share only, the exchange goes over gloo, both ranks reproduce the oracle's transcript for two witnesses."""
+    out = _launch([os.path.join(ROOT, "tests", "dist_worker.py"), "prove_c3"], 29523, 1500)
+    assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-3000:])
+    assert out.stdout.count("PROVE_C3 OK") == 2, out.stdout
