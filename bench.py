@@ -42,7 +42,7 @@ CLASS_SYMBOL = {
     "sc_round<prodsum>": "k_ps_one(",
     "sc_round2<prodsum>": "k_ps_step2(",
 }
-PMC_TAG = "r03"  # profiles/<tag>_pmc_hbm_traffic.json, profiles/<tag>_bn254_pmc_sq.json: this round's committed counter passes
+PMC_TAG = "r04"  # profiles/<tag>_pmc_hbm_traffic.json, profiles/<tag>_bn254_pmc_sq.json: this round's committed counter passes
 PMC_CMD = ("rocprofv3 --pmc FETCH_SIZE -- python3 scripts/prove_once.py 32768 16 2 ; rocprofv3 --pmc WRITE_SIZE -- (same): separate passes, "
            "HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 per launch (gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md), "
            "scripts/pmc_summary.py")
