@@ -202,8 +202,7 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_round(const Fr* __restrict__ in, 
 // the linear table S = sum_i w_i (l_i + r_i) in natural order ([2j], [2j+1]), folded into s_out; K1 S(t) + K2 joins P0 and P1.
 struct GpJobDev { const Fr* l_base; const Fr* r_base; Fr* out; Fr* part; Fr r; unsigned long long half, l_stride, r_stride; int nb, gx, gy, mirror;
                   const Fr* s_in; Fr* s_out; Fr k1, k2;
-                  FoldK fk;      // fold_consts(r): the round's folds x + r d run through lz_fold (bn254_lazy.hpp)
-                  int dbg, pad2; };   // HG_BN_DBG (timing experiments only; wrong results): 1 no stores, 2 no folds, 4 no multiply-accumulates
+                  FoldK fk; };   // fold_consts(r): the round's folds x + r d run through lz_fold (bn254_lazy.hpp)
 __device__ __forceinline__ Fr fr_swap_lane(const Fr& v) {
     Fr o;
 #pragma unroll
@@ -294,14 +293,14 @@ __global__ __launch_bounds__(BN_TPB) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 const Fr xl = lz_from_x4(mine[0], mine[64]), yl = lz_from_x4(mine[128], mine[192]);
                 dl = lz_sub(yl, xl);
                 const Fr fl = lz_fold(xl, dl, K);
-                if (valid && !(J.dbg & 1)) lz_gstore(&out[(size_t)(2 * i) * half + j], fl);
+                if (valid) lz_gstore(&out[(size_t)(2 * i) * half + j], fl);
             }
             asm volatile("" ::: "memory");
             {
                 const Fr xr = lz_from_x4(mine[256], mine[320]), yr = lz_from_x4(mine[384], mine[448]);
                 dr = lz_sub(yr, xr);
                 const Fr fr_ = lz_fold(xr, dr, K);
-                if (valid && !(J.dbg & 1)) lz_gstore(&out[(size_t)(2 * i + 1) * half + j], fr_);
+                if (valid) lz_gstore(&out[(size_t)(2 * i + 1) * half + j], fr_);
             }
             wcol_mac(ci, dl, dr);
             asm volatile("" ::: "memory");
@@ -1060,8 +1059,6 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
                 }
                 const RoundGrid g = round_grid_gp(half, d.nb, launch_wgs);
                 d.gx = g.gx; d.gy = g.gy;
-                static const int dbg = [] { const char* e = getenv("HG_BN_DBG"); return e && *e ? atoi(e) : 0; }();
-                d.dbg = dbg;
                 reds[red_index[n]].n[rd] = g.blocks();
                 own.by_rd[rd].push_back(d);
             }
