@@ -87,6 +87,31 @@ __global__ void k_bn_from_mont(Fr* __restrict__ t, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) t[i] = fr_from_mont(t[i]);
 }
+// ops 5 .. 9: the loose arithmetic of bn254_lazy.hpp on RAW 256-bit operands (no conversion: the test feeds the edge values 0, p - 1, p,
+// 2p - 1, 2^256 - 1 as they are); results normalised with lz_canon so that the test can compare residues:
+//   5  lz_mul(a, b) = a b R^-1 mod p                      (any operands)
+//   6  lz_fold(a, b, fold_consts(r)) = a + r b R^-1 mod p, r = 2^200 + 12345 (raw); a < 2p, b any
+//   7  lz_add(a, b), 8  lz_subr(a, b)                     (a, b < 2p)
+//   9  three products through one lz_reduce: (a b + a a + b b) R^-1 mod p with the subtraction operand lz_sub(a, b) as a factor of a
+//      fourth: + lz_sub(a, b) * b                          (a, b < 2p)
+__global__ void k_bn_lazy_op(int op, size_t n, const Fr* __restrict__ a, const Fr* __restrict__ b, Fr* __restrict__ out, FoldK fk) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Fr x = a[i], y = b[i];
+    Fr r;
+    if (op == 5) r = lz_mul(x, y);
+    else if (op == 6) {
+        const LzK KK = lz_load_k(fk.k);
+        r = lz_fold(x, y, KK.k);
+    } else if (op == 7) r = lz_add(x, y);
+    else if (op == 8) r = lz_subr(x, y);
+    else {
+        WCol w = wcol_zero();
+        wcol_mac(w, x, y); wcol_mac(w, x, x); wcol_mac(w, y, y); wcol_mac(w, lz_sub(x, y), y);
+        r = lz_reduce(w);
+    }
+    out[i] = lz_canon(r);
+}
 // op 0 add, 1 sub, 2 mul, 3 / 4 the column-accumulator forms (canonical in / out): the field KAT entry point
 __global__ void k_bn_binop(int op, size_t n, const Fr* __restrict__ a, const Fr* __restrict__ b, Fr* __restrict__ out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -712,7 +737,7 @@ void sumcheck_bn254(hg_ctx* ctx, int kind, size_t nv, size_t ntab, const u64* co
 }
 
 void field_op_bn254(hg_ctx* ctx, int op, size_t n, const u64* a, const u64* b, u64* out) {
-    if (op < 0 || op > 4) throw Error("hg_bn254_field_op: op must be 0 (add), 1 (sub), 2 (mul), 3 (wide mul) or 4 (wide a b + a a + b b)");
+    if (op < 0 || op > 9) throw Error("hg_bn254_field_op: op must be 0 (add), 1 (sub), 2 (mul), 3 (wide mul), 4 (wide a b + a a + b b) or 5 .. 9 (loose forms, raw operands)");
     hipc(hipSetDevice(ctx->device), "hipSetDevice");
     Fr *da = nullptr, *db = nullptr, *dc = nullptr;
     hipc(hipMalloc((void**)&da, n * sizeof(Fr)), "hipMalloc");
@@ -720,6 +745,12 @@ void field_op_bn254(hg_ctx* ctx, int op, size_t n, const u64* a, const u64* b, u
     hipc(hipMalloc((void**)&dc, n * sizeof(Fr)), "hipMalloc");
     hipError_t e1 = hipMemcpy(da, a, n * sizeof(Fr), hipMemcpyHostToDevice), e2 = hipMemcpy(db, b, n * sizeof(Fr), hipMemcpyHostToDevice);
     if (e1 == hipSuccess && e2 == hipSuccess) {
+        if (op >= 5) {
+            FoldK fk;
+            Fr rr = fr_make(12345, 0, 0, 1ULL << 8);   // r = 2^200 + 12345 as a raw residue (fold_consts: K_i = r 2^(32 i) R^-1 mod p)
+            fold_consts(rr, &fk);
+            k_bn_lazy_op<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(op, n, da, db, dc, fk);
+        } else
         k_bn_binop<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(op, n, da, db, dc);
         e1 = hipStreamSynchronize(ctx->stream);
         if (e1 == hipSuccess) e1 = hipMemcpy(out, dc, n * sizeof(Fr), hipMemcpyDeviceToHost);

@@ -267,7 +267,10 @@ int hg_challenges(size_t n, uint64_t* out);
 /* = Keccak256Transcript::squeeze_challenge over Fr: c_j = LE(Keccak^j("")) mod r [REF transcript.rs:146-157,198-203]; n x 4 limbs */
 int hg_challenges_bn254(size_t n, uint64_t* out4);
 /* device field arithmetic on n element pairs: op 0 add, 1 sub, 2 mul, 3 mul through the column accumulators, 4 a b + a a + b b
- * through one deferred reduction (known-answer tests of the Montgomery kernels) */
+ * through one deferred reduction (known-answer tests of the Montgomery kernels; operands and results canonical, converted inside).
+ * ops 5 .. 9: the branch-free loose forms the hot kernels use (bn254_lazy.hpp) on RAW 256-bit operands, results as canonical
+ * residues: 5 a b R^-1 (any operands), 6 a + r b R^-1 with r = 2^200 + 12345 (a < 2p), 7 a + b, 8 a - b (a, b < 2p),
+ * 9 (a b + a a + b b + (a - b + 2p) b) R^-1 through one reduction (a, b < 2p); R = 2^256. */
 int hg_bn254_field_op(hg_ctx* ctx, int op, size_t n, const uint64_t* a4, const uint64_t* b4, uint64_t* out4);
 /* = gkr::sum_check::prove_sum_check over Fr on caller tables, same shapes and conventions as hg_sumcheck
  *   [REF call sites lasso.rs:278-279, prover.rs:242-252]. tables[i]: host pointer, 2^nv elements (4 limbs each).

@@ -929,6 +929,32 @@ def test_bn254_field_kernels_against_python_integers(ctx):
     assert ctx.bn254_field_op(4, a, b) == [(x * y + x * x + y * y) % bn.R for x, y in zip(a, b)]    # three products, one reduction
 
 
+def test_bn254_loose_arithmetic_against_python_integers(ctx):
+    """bn254_lazy.hpp - the branch-free arithmetic of the hot bn254 kernels, where a residue is any representative below 2p, a
+    difference is y - x + 2p and a reduction ends in a floating-point quotient estimate - on RAW operands including every edge of
+    its contracts: 0, 1, p - 1, p, p + 1, 2p - 1 (sums / differences), and for products anything up to 2^256 - 1."""
+    bn = orclib.bn254()
+    p = bn.R
+    Rinv = pow(1 << 256, -1, p)
+    rng = random.Random(2540)
+    lt2p = [0, 1, 2, p - 1, p, p + 1, 2 * p - 2, 2 * p - 1, (1 << 254) - 1, 1 << 253, (1 << 64) - 1, 1 << 64, (1 << 128) + 5]
+    a = lt2p + [rng.randrange(2 * p) for _ in range(4000)]
+    b = list(reversed(lt2p)) + [rng.randrange(2 * p) for _ in range(4000)]
+    assert ctx.bn254_field_op(7, a, b) == [(x + y) % p for x, y in zip(a, b)]
+    assert ctx.bn254_field_op(8, a, b) == [(x - y) % p for x, y in zip(a, b)]
+    assert ctx.bn254_field_op(9, a, b) == [((x * y + x * x + y * y + (x - y + 2 * p) * y) * Rinv) % p for x, y in zip(a, b)]
+    r = (1 << 200) + 12345
+    anyv = [0, 1, p, 2 * p, 4 * p - 1, (1 << 256) - 1, (1 << 256) - 2, 1 << 255, (1 << 224) - 1, 0xFFFFFFFF, 1 << 32] + [rng.randrange(1 << 256) for _ in range(4000)]
+    a6 = [a[i % len(a)] for i in range(len(anyv))]
+    assert ctx.bn254_field_op(6, a6, anyv) == [(x + r * d * Rinv) % p for x, d in zip(a6, anyv)]
+    a5 = anyv
+    b5 = list(reversed(anyv))
+    assert ctx.bn254_field_op(5, a5, b5) == [(x * y * Rinv) % p for x, y in zip(a5, b5)]
+    # the largest sum a reduction sees in the kernels: 50 products of operands below 4p (the column accumulators carry it exactly)
+    big = [4 * p - 1] * 64
+    assert ctx.bn254_field_op(5, big, big) == [((4 * p - 1) ** 2 * Rinv) % p] * 64
+
+
 def test_bn254_challenges_match_the_oracle():
     bn = orclib.bn254()
     assert hg.challenges_bn254(40) == bn.challenges(40, orclib.keccak256)
