@@ -6,6 +6,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <tuple>
 #include "prover.hpp"
 
 // BN254 slice (bn254.hip)
@@ -202,6 +203,7 @@ int hg_setup(hg_ctx* ctx, const hg_params* params, hg_pk** out) {
         nd.lin.assign(n.arity, dev::CsrLin{nullptr, nullptr, nullptr});
         nd.mulL.assign(n.arity, dev::CsrMul{nullptr, nullptr, nullptr, nullptr, nullptr});
         nd.mulR.assign(n.arity, dev::CsrMul{nullptr, nullptr, nullptr, nullptr, nullptr});
+        nd.seg.assign(n.arity, hg_pk::NodeDev::Seg{});
         std::vector<std::vector<const LinTerm*>> lin_by(n.arity);
         std::vector<std::vector<const MulTerm*>> ml_by(n.arity), mr_by(n.arity);
         for (auto& t : n.lin) lin_by[t.in].push_back(&t);
@@ -228,6 +230,38 @@ int hg_setup(hg_ctx* ctx, const hg_params* params, hg_pk** out) {
             };
             if (!ml_by[i].empty()) nd.mulL[i] = mk(ml_by[i], true);
             if (!mr_by[i].empty()) nd.mulR[i] = mk(mr_by[i], false);
+            {   // run-length segments of the phase-1 table of input i
+                struct Ent { int other_in; long long goff, joff; u64 c; u32 x; };
+                std::vector<Ent> ents;
+                ents.reserve(lin_by[i].size() + ml_by[i].size());
+                for (const LinTerm* t : lin_by[i]) ents.push_back(Ent{-1, (long long)t->gate - (long long)t->j, 0, t->c, t->j});
+                for (const MulTerm* t : ml_by[i]) ents.push_back(Ent{(int)t->i1, (long long)t->gate - (long long)t->j0, (long long)t->j1 - (long long)t->j0, t->c, t->j0});
+                std::sort(ents.begin(), ents.end(), [](const Ent& a, const Ent& b) {
+                    return std::tie(a.other_in, a.goff, a.joff, a.c, a.x) < std::tie(b.other_in, b.goff, b.joff, b.c, b.x);
+                });
+                std::vector<dev::GatherSeg> segs;
+                bool ok = !ents.empty();
+                for (size_t e = 0; e < ents.size() && ok; e++) {
+                    const Ent& t = ents[e];
+                    if (!segs.empty()) {
+                        dev::GatherSeg& g = segs.back();
+                        const bool same = g.other_in == t.other_in && g.goff == (int)t.goff && g.joff == (int)t.joff && g.coef == t.c;
+                        if (same && t.x == g.hi) { g.hi++; continue; }
+                        if (same && t.x < g.hi) { ok = false; break; }  // the same term twice: leave it to the general form
+                    }
+                    if (segs.size() >= 64 || t.goff < INT32_MIN || t.goff > INT32_MAX) { ok = false; break; }
+                    segs.push_back(dev::GatherSeg{t.x, t.x + 1, (int)t.goff, t.other_in, (int)t.joff, 0, t.c});
+                }
+                if (ok) {
+                    hg_pk::NodeDev::Seg& sg = nd.seg[i];
+                    sg.nseg = (int)segs.size();
+                    sg.d = upload_vec(pk.get(), segs);
+                    const dev::GatherSeg& g = segs[0];
+                    sg.alias = segs.size() == 1 && g.other_in < 0 && g.coef == 1 && g.lo == 0 && g.hi == S && g.goff >= 0 &&
+                               (n.log2_reps == 0 || (n.log2_sub_out == n.log2_sub_in && g.goff == 0));
+                    sg.alias_off = (size_t)g.goff;
+                }
+            }
         }
         {   // gate-major (forward) wiring for witness generation on the device
             dev::EvalNode& f = nd.fwd;

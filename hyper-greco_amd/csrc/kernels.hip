@@ -124,6 +124,21 @@ __device__ __forceinline__ void store_e2_nt(E2* p, E2 v) {
     __builtin_nontemporal_store(v.c1, &p->c1);
 }
 
+// loads / stores through the GLOBAL address space: a pointer read from a job descriptor is generic to hipcc (flat_load, which also
+// counts as an LDS access: its waits cover scalar and LDS traffic too)
+typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ E2 gload_e2(const E2* p) {
+    const u64x2_t v = *reinterpret_cast<const __attribute__((address_space(1))) u64x2_t*>((unsigned long long)p);
+    return e2(v.x, v.y);
+}
+__device__ __forceinline__ u64 gload_u64(const u64* p) {
+    return *reinterpret_cast<const __attribute__((address_space(1))) u64*>((unsigned long long)p);
+}
+__device__ __forceinline__ void gstore_e2(E2* p, E2 v) {
+    u64x2_t w; w.x = v.c0; w.y = v.c1;
+    *reinterpret_cast<__attribute__((address_space(1))) u64x2_t*>((unsigned long long)p) = w;
+}
+
 // ---- first grand-product round of one table pair on base-field values ---------------------------------------------
 // Accumulates gamma^i * (P0, P1, Pinf) with P0 = xl xr, P1 = yl yr, Pinf = (yl - xl)(yr - xr) (each base product reduced once,
 // its two weighted copies unreduced), stores the folded left table multiplied by gamma^i and the folded right table, and -
@@ -1218,7 +1233,8 @@ void ps_tail(hipStream_t st, const PsJob* jobs, int njobs, const E2* chal, E2* r
     const size_t lds = (SM_SLOTS + PS_TAIL_LDS_E2) * sizeof(E2);
     static const hipError_t attr = hipFuncSetAttribute((const void*)k_ps_tail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)attr;
-    k_ps_tail<<<njobs, 1024, lds, st>>>(jobs, chal, res);
+    static const int threads = (int)env_size("HG_PS_TAIL_THREADS", 1024);
+    k_ps_tail<<<njobs, threads, lds, st>>>(jobs, chal, res);
 }
 
 // debugging aid (HG_STAMP=1): device wall clock (100 MHz) at a point of a stream, also inside a replayed launch graph
@@ -1322,6 +1338,100 @@ __global__ __launch_bounds__(TPB) void k_sum_tables(E2* __restrict__ out, const 
 }
 void sum_tables(hipStream_t st, E2* out, const E2* tabs, int ntabs, size_t n) {
     k_sum_tables<<<(unsigned)std::min<size_t>((n + TPB - 1) / TPB, 2048), TPB, 0, st>>>(out, tabs, ntabs, n);
+}
+// ---- two-launch form -----
+__device__ __forceinline__ E2 eq_bits_tree(const E2* __restrict__ pt, int nbits, size_t idx) {  // the same product, balanced (independent factors: ILP)
+    E2 f[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) f[i] = i < nbits ? ((idx >> i) & 1 ? pt[i] : e2_sub(e2_one(), pt[i])) : e2_one();
+    if (nbits <= 4) return e2_mul(e2_mul(f[0], f[1]), e2_mul(f[2], f[3]));
+    if (nbits <= 8) return e2_mul(e2_mul(e2_mul(f[0], f[1]), e2_mul(f[2], f[3])), e2_mul(e2_mul(f[4], f[5]), e2_mul(f[6], f[7])));
+    E2 p = e2_mul(e2_mul(e2_mul(f[0], f[1]), e2_mul(f[2], f[3])), e2_mul(e2_mul(f[4], f[5]), e2_mul(f[6], f[7])));
+    E2 q = e2_mul(e2_mul(e2_mul(f[8], f[9]), e2_mul(f[10], f[11])), e2_mul(e2_mul(f[12], f[13]), e2_mul(f[14], f[15])));
+    return e2_mul(p, q);
+}
+// one workgroup per (job, claim, part): part p writes B[256 p .. 256 p + 255] (and A when p == 0)
+__global__ __launch_bounds__(256) void k_eq_prep(const EqJob* __restrict__ jobs, int njobs, const E2* __restrict__ chal) {
+    int jl = 0, jh = njobs - 1;
+    while (jl < jh) {
+        int mid = (jl + jh + 1) >> 1;
+        if (jobs[mid].pblk0 <= (int)blockIdx.x) jl = mid; else jh = mid - 1;
+    }
+    const EqJob& J = jobs[jl];
+    const int n = J.n, lo = n < 8 ? n : 8, hi = n - lo;
+    const size_t nB = (size_t)1 << hi;
+    const int nparts = (int)((nB + 255) / 256);
+    const int local = (int)blockIdx.x - J.pblk0;
+    const int a = local / nparts, part = local % nparts;
+    const E2* pt = (J.point_dev ? J.point_dev : chal) + J.cs.point_off[a];
+    E2* A = J.ab + (size_t)a * eq_ab_entries(n);
+    E2* B = A + 256;
+    const int t = threadIdx.x;
+    if (part == 0 && t < (1 << lo)) store_e2(A + t, eq_bits_tree(pt, lo, (size_t)t));
+    const size_t h = (size_t)part * 256 + t;
+    if (h < nB) {
+        E2 bv = eq_bits_tree(pt + lo, hi, h);
+        if (!J.cs.unit_alpha) bv = e2_mul(bv, chal[J.cs.alpha_off + a]);
+        store_e2(B + h, bv);
+    }
+}
+constexpr int EQ_ROWS = 8;   // table rows (of 256 outputs) per workgroup of the fill launch, at most
+__global__ __launch_bounds__(256) void k_eq_fill(const EqJob* __restrict__ jobs, int njobs) {
+    int jl = 0, jh = njobs - 1;
+    while (jl < jh) {
+        int mid = (jl + jh + 1) >> 1;
+        if (jobs[mid].blk0 <= (int)blockIdx.x) jl = mid; else jh = mid - 1;
+    }
+    const EqJob& J = jobs[jl];
+    const int n = J.n, lo = n < 8 ? n : 8, hi = n - lo;
+    const int t = threadIdx.x;
+    if (t >= (1 << lo)) return;
+    const size_t nrows = (size_t)1 << hi;
+    const size_t r0 = (size_t)((int)blockIdx.x - J.blk0) * J.rows;
+    const int cnt = (int)(r0 + J.rows < nrows ? J.rows : nrows - r0);
+    const size_t stride = eq_ab_entries(n);
+    const E2* ab = J.ab;
+    E2* out = J.out + (r0 << lo) + t;
+    // all row factors of a claim are fetched before the first product (independent loads, one wait); the products of all claims
+    // of an output accumulate unreduced (gl_wide.hpp): two column accumulators, two reductions per output
+    WAcc w0[EQ_ROWS], w1[EQ_ROWS];
+#pragma unroll
+    for (int k = 0; k < EQ_ROWS; k++) { w0[k] = wacc_zero(); w1[k] = wacc_zero(); }
+    for (int a = 0; a < J.cs.n; a++) {
+        const FoldR fa = fold_r(gload_e2(ab + a * stride + t));
+        E2 bv[EQ_ROWS];
+#pragma unroll
+        for (int k = 0; k < EQ_ROWS; k++) bv[k] = gload_e2(ab + a * stride + 256 + r0 + (k < cnt ? k : 0));
+#pragma unroll
+        for (int k = 0; k < EQ_ROWS; k++) {
+            wmac_pair(w0[k], fa.r0, bv[k].c0, fa.r17, bv[k].c1);
+            wmac_pair(w1[k], fa.r0, bv[k].c1, fa.r1, bv[k].c0);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < EQ_ROWS; k++)
+        if (k < cnt) gstore_e2(out + ((size_t)k << lo), e2(wreduce(w0[k]), wreduce(w1[k])));
+}
+EqAbGrid eq_ab_plan(EqJob* host_jobs, int njobs) {
+    // rows per workgroup: 8 (2048 outputs) when that still gives the launch a few thousand workgroups, fewer for small batches
+    size_t rows_total = 0;
+    for (int q = 0; q < njobs; q++) rows_total += (size_t)1 << (host_jobs[q].n > 8 ? host_jobs[q].n - 8 : 0);
+    int rows = EQ_ROWS;
+    while (rows > 1 && rows_total / rows < 2048) rows >>= 1;
+    int blk = 0, pblk = 0;
+    for (int q = 0; q < njobs; q++) {
+        const size_t nrows = (size_t)1 << (host_jobs[q].n > 8 ? host_jobs[q].n - 8 : 0);
+        host_jobs[q].blk0 = blk;
+        host_jobs[q].rows = rows;
+        host_jobs[q].pblk0 = pblk;
+        blk += (int)((nrows + rows - 1) / rows);
+        pblk += host_jobs[q].cs.n * (int)((nrows + 255) / 256);
+    }
+    return EqAbGrid{pblk, blk};
+}
+void eq_jobs_ab(hipStream_t st, const EqJob* jobs, int njobs, EqAbGrid grid, const E2* chal) {
+    k_eq_prep<<<grid.prep, 256, 0, st>>>(jobs, njobs, chal);
+    k_eq_fill<<<grid.fill, 256, 0, st>>>(jobs, njobs);
 }
 void eq_jobs(hipStream_t st, const EqJob* jobs, int njobs, int max_n, const E2* chal) {
     int hi = max_n > 8 ? max_n - 8 : 0;
@@ -2050,6 +2160,80 @@ __global__ __launch_bounds__(TPB) void k_gather_jobs(const GatherJob* __restrict
         }
         store_e2(J.T + idx, acc);
     }
+}
+// run-length form (see kernels.hpp): 1-D grid, job q owns workgroups [blk0_q, blk0_(q+1)), 4 outputs per thread
+constexpr int GSEG_PER_THREAD = 4;
+constexpr int GSEG_MAX = 64;
+__global__ __launch_bounds__(TPB) void k_gather_seg_jobs(const GatherSegJob* __restrict__ jobs, int njobs) {
+    int jl = 0, jh = njobs - 1;
+    while (jl < jh) {
+        int mid = (jl + jh + 1) >> 1;
+        if (jobs[mid].blk0 <= (int)blockIdx.x) jl = mid; else jh = mid - 1;
+    }
+    const GatherSegJob& J = jobs[jl];
+    __shared__ GatherSeg sg[GSEG_MAX];   // the segment list, read once per workgroup
+    const int nseg = J.nseg;
+    {
+        const unsigned* src = reinterpret_cast<const unsigned*>(J.segs);
+        for (unsigned k = threadIdx.x; k < nseg * (sizeof(GatherSeg) / 4); k += TPB) reinterpret_cast<unsigned*>(sg)[k] = src[k];
+    }
+    __syncthreads();
+    const int log2_S = J.log2_S, log2_G = J.log2_G;
+    const size_t total = (size_t)1 << (log2_S + J.log2_R);
+    const size_t smask = ((size_t)1 << log2_S) - 1;
+    const E2* eqc = J.eqc;
+    const size_t base = (size_t)((int)blockIdx.x - J.blk0) * (TPB * GSEG_PER_THREAD) + threadIdx.x;
+    size_t x[GSEG_PER_THREAD], rep[GSEG_PER_THREAD];
+    E2 acc[GSEG_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < GSEG_PER_THREAD; k++) {
+        const size_t idx = base + (size_t)k * TPB;
+        x[k] = idx & smask; rep[k] = idx >> log2_S;
+        if (idx >= total) x[k] = ~(size_t)0;   // in no segment
+        acc[k] = e2_zero();
+    }
+    for (int s = 0; s < nseg; s++) {
+        const GatherSeg g = sg[s];
+        bool in[GSEG_PER_THREAD];
+        E2 q[GSEG_PER_THREAD];
+        u64 other[GSEG_PER_THREAD];
+        // every load of the step first (positions outside the segment read entry 0 of their table and are dropped)
+#pragma unroll
+        for (int k = 0; k < GSEG_PER_THREAD; k++) {
+            in[k] = x[k] >= g.lo && x[k] < g.hi;
+            q[k] = gload_e2(eqc + (in[k] ? (rep[k] << log2_G) + (size_t)((long long)x[k] + g.goff) : 0));
+        }
+        if (g.other_in >= 0) {
+            const u64* ov = J.in_vals[g.other_in];
+#pragma unroll
+            for (int k = 0; k < GSEG_PER_THREAD; k++) other[k] = gload_u64(ov + (in[k] ? (rep[k] << log2_S) + (size_t)((long long)x[k] + g.joff) : 0));
+        }
+#pragma unroll
+        for (int k = 0; k < GSEG_PER_THREAD; k++) {
+            u64 c = g.coef;
+            E2 v = q[k];
+            if (g.other_in >= 0) v = e2_mul_f(v, c == 1 ? other[k] : gl_mul(c, other[k]));
+            else if (c != 1) v = e2_mul_f(v, c);
+            if (in[k]) acc[k] = e2_add(acc[k], v);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < GSEG_PER_THREAD; k++) {
+        const size_t idx = base + (size_t)k * TPB;
+        if (idx < total) gstore_e2(J.T + idx, acc[k]);
+    }
+}
+int gather_seg_plan(GatherSegJob* host_jobs, int njobs) {
+    int blk = 0;
+    for (int q = 0; q < njobs; q++) {
+        const size_t total = (size_t)1 << (host_jobs[q].log2_S + host_jobs[q].log2_R);
+        host_jobs[q].blk0 = blk;
+        blk += (int)((total + TPB * GSEG_PER_THREAD - 1) / (TPB * GSEG_PER_THREAD));
+    }
+    return blk;
+}
+void gather_seg_jobs(hipStream_t st, const GatherSegJob* jobs, int njobs, int grid) {
+    k_gather_seg_jobs<<<grid, TPB, 0, st>>>(jobs, njobs);
 }
 void gather_jobs(hipStream_t st, const GatherJob* jobs, int njobs, size_t max_total) {
     k_gather_jobs<<<dim3((unsigned)std::min<size_t>((max_total + TPB - 1) / TPB, 1024), njobs), TPB, 0, st>>>(jobs);

@@ -160,8 +160,20 @@ struct EqJob {
     int n;
     const E2* point_dev;  // nullptr: points index the chain
     ClaimSet cs;
+    // two-launch form (eq_jobs_ab): per claim a low table A (256 entries) and a high table B (2^(n - 8) entries, alpha folded in)
+    E2* ab;               // cs.n * eq_ab_entries(n) entries of scratch
+    int blk0, rows;       // first workgroup of the fill launch, table rows (of 2^min(n, 8) outputs) per workgroup
+    int pblk0;            // first workgroup of the prep launch (one per claim and 256 entries of B)
 };
 void eq_jobs(hipStream_t st, const EqJob* jobs, int njobs, int max_n, const E2* chal);
+// The same tables in two launches: k_eq_prep builds A and B of every (job, claim) - a few hundred workgroups, ~14 dependent
+// products - and k_eq_fill streams out[idx] = sum_a A_a[idx & 255] * B_a[idx >> 8]: ONE product per claim and output and no
+// per-workgroup setup (k_eq_jobs rebuilds A and a slice of B in every workgroup: 21 dependent products ahead of 16-32 outputs
+// per thread). eq_ab_plan fills ab-independent launch fields of the HOST copies (blk0, rows) and returns the fill grid.
+__host__ __device__ inline size_t eq_ab_entries(int n) { return 256 + ((size_t)1 << (n > 8 ? n - 8 : 0)); }
+struct EqAbGrid { int prep, fill; };
+EqAbGrid eq_ab_plan(EqJob* host_jobs, int njobs);
+void eq_jobs_ab(hipStream_t st, const EqJob* jobs, int njobs, EqAbGrid grid, const E2* chal);
 void sum_tables(hipStream_t st, E2* out, const E2* tabs, int ntabs, size_t n);  // out[i] = sum_t tabs[t*n + i]
 
 // ---- Lasso ------------------------------------------------------------------------------------
@@ -248,6 +260,14 @@ struct GatherT {
 };
 struct GatherJob { GatherT g; const E2* eqc; int log2_S, log2_G, log2_R; E2* T; };
 void gather_jobs(hipStream_t st, const GatherJob* jobs, int njobs, size_t max_total);
+// Run-length form of the same table for wiring that is affine in the input position (every node of the BFV circuit:
+// relays, scaled relays, sums and element-wise products connect position x to gate x + const): a short list of segments
+//   T[rep*S + x] += c * eqc[rep*G + x + goff] (* in_other[rep*S + x + joff])   for lo <= x < hi
+// read through scalar loads; every table access is coalesced and no per-term metadata is streamed.
+struct GatherSeg { u32 lo, hi; int goff; int other_in; int joff; int pad; u64 coef; };  // other_in < 0: linear term
+struct GatherSegJob { const GatherSeg* segs; int nseg; const E2* eqc; int log2_S, log2_G, log2_R; E2* T; const u64* in_vals[PS_MAX_PAIRS]; int blk0; };
+void gather_seg_jobs(hipStream_t st, const GatherSegJob* jobs, int njobs, int grid);
+int gather_seg_plan(GatherSegJob* host_jobs, int njobs);   // fills blk0, returns the grid
 // B[rep*S + y] = sum_mulR eqc[rep*G+gate]*c*eqx[rep*S + j0]*u[i0]
 void vanilla_gather_B(hipStream_t st, const CsrMul& mulR, const E2* eqc, const E2* eqx, const E2* u, int log2_S, int log2_G, int log2_R, E2* B);
 struct GatherBJob { CsrMul m; const E2* eqc; const E2* eqx; const E2* u; int log2_S, log2_G, log2_R; E2* B; };

@@ -769,6 +769,7 @@ struct Prover {
     std::vector<dev::EqJob> eq_queue;
     std::vector<std::function<void()>> after_eq;  // device work that reads the queued eq tables
     std::vector<dev::GatherJob> gather_queue;
+    std::vector<dev::GatherSegJob> gather_seg_queue;
     std::vector<dev::GatherBJob> gatherB_queue;
     std::vector<dev::FftJob> fft_queue;
 
@@ -777,17 +778,29 @@ struct Prover {
         memset(&J, 0, sizeof(J));
         J.out = out; J.n = n; J.point_dev = point_dev;
         J.cs.n = 1; J.cs.unit_alpha = 1; J.cs.point_off[0] = point_off;
+        const bool two = eq_two_launch() && n <= 24;
+        dev::EqAbGrid grid{0, 0};
+        if (two) { J.ab = ctx->alloc_n<E2>(dev::eq_ab_entries(n)); grid = dev::eq_ab_plan(&J, 1); }
         dev::EqJob* d = ctx->alloc_n<dev::EqJob>(1);
         upload(d, &J, sizeof(J), "upload eq job");
         ctx->prof_begin(cls_aux, 16.0 * ((size_t)1 << n));
-        dev::eq_jobs(st, d, 1, n, ctx->d_chal);
+        if (two) dev::eq_jobs_ab(st, d, 1, grid, ctx->d_chal);
+        else dev::eq_jobs(st, d, 1, n, ctx->d_chal);
         ctx->prof_end();
     }
     std::vector<std::function<void()>> eq_post;  // sums of per-claim eq tables, run right after the eq batch
+    // HG_EQ_ONE_LAUNCH=1: the round-3 kernel (every workgroup rebuilds its low / high factor tables)
+    static bool eq_two_launch() { static const bool v = [] { const char* e = getenv("HG_EQ_ONE_LAUNCH"); return !(e && e[0] == '1'); }(); return v; }
     void queue_eq(E2* out, int n, const dev::ClaimSet& cs) {
         dev::EqJob J;
         memset(&J, 0, sizeof(J));
         J.n = n;
+        if (eq_two_launch() && n <= 24) {  // all claims in one job: the fill kernel sums them
+            J.out = out; J.cs = cs;
+            J.ab = ctx->alloc_n<E2>((size_t)cs.n * dev::eq_ab_entries(n));
+            eq_queue.push_back(J);
+            return;
+        }
         if (cs.n == 1) { J.out = out; J.cs = cs; eq_queue.push_back(J); return; }
         // several claims: one job per claim (all of them run in parallel in the batch), then one summing pass
         const size_t N = (size_t)1 << n;
@@ -814,6 +827,16 @@ struct Prover {
     void flush_bookkeeping() {
         int max_n = 0; double eb = 0;
         for (auto& J : eq_queue) { max_n = std::max(max_n, J.n); eb += 16.0 * ((size_t)1 << J.n); }
+        {   // jobs of the two-launch form first (queue_eq gives every job of a prove the same form)
+            std::vector<dev::EqJob> ab, old;
+            for (auto& J : eq_queue) (J.ab ? ab : old).push_back(J);
+            if (!ab.empty() && !old.empty()) throw Error("eq tables: mixed job forms in one batch");
+            if (!ab.empty()) {
+                const dev::EqAbGrid grid = dev::eq_ab_plan(ab.data(), (int)ab.size());
+                flush_jobs(ab, cls_aux, eb, [&](dev::EqJob* d, int nj) { dev::eq_jobs_ab(st, d, nj, grid, ctx->d_chal); });
+                eq_queue.clear();
+            }
+        }
         flush_jobs(eq_queue, cls_aux, eb, [&](dev::EqJob* d, int nj) { dev::eq_jobs(st, d, nj, max_n, ctx->d_chal); });
         for (auto& f : eq_post) f();
         eq_post.clear();
@@ -822,6 +845,12 @@ struct Prover {
         size_t max_total = 0; double gb = 0;
         for (auto& J : gather_queue) { size_t t = (size_t)1 << (J.log2_S + J.log2_R); max_total = std::max(max_total, t); gb += 24.0 * t; }
         flush_jobs(gather_queue, cls_gather, gb, [&](dev::GatherJob* d, int nj) { dev::gather_jobs(st, d, nj, max_total); });
+        if (!gather_seg_queue.empty()) {
+            double sb = 0;
+            for (auto& J : gather_seg_queue) sb += 16.0 * (J.nseg + 1) * ((size_t)1 << (J.log2_S + J.log2_R));
+            const int grid = dev::gather_seg_plan(gather_seg_queue.data(), (int)gather_seg_queue.size());
+            flush_jobs(gather_seg_queue, cls_gather, sb, [&](dev::GatherSegJob* d, int nj) { dev::gather_seg_jobs(st, d, nj, grid); });
+        }
         size_t maxB = 0; double bb = 0;
         for (auto& J : gatherB_queue) { size_t t = (size_t)1 << (J.log2_S + J.log2_R); maxB = std::max(maxB, t); bb += 40.0 * t; }
         flush_jobs(gatherB_queue, cls_gather, bb, [&](dev::GatherBJob* d, int nj) { dev::gather_B_jobs(st, d, nj, maxB); });
@@ -1447,10 +1476,12 @@ struct Prover {
                 if (nyv) dev::dot_eq_many(st, eqy_v, tyv, nyv, M, partials, d_res());
                 stamp("claimed sum and openings done");
             };
-            // Default: behind the node reductions on the second stream, not beside grand product #1's first (bandwidth-bound)
-            // rounds: the prove takes the same time either way (2.87 ms, +-0.02), the dominant round kernel runs at 0.63 of the
-            // HBM roofline inside a prove instead of 0.56. HG_LATE_OPENINGS=0: right away.
-            static const bool late = [] { const char* e = getenv("HG_LATE_OPENINGS"); return !(e && e[0] == '0'); }();
+            // Default (round 4): right away on the second stream, beside the first hash round. Round 3 ran them behind the node
+            // reductions (HG_LATE_OPENINGS=1; 2: between the two waves of node reductions): the same prove time then, and the dominant
+            // round kernel at 0.63 instead of 0.56 of the HBM roofline inside a prove. With the shorter node bookkeeping of round 4 the
+            // second stream ends with the main one, and 0.15 ms of openings behind it ran alone: 2.566 (0) / 2.598 (2) / 2.610 ms (1),
+            // medians of 120 interleaved replays.
+            static const bool late = [] { const char* e = getenv("HG_LATE_OPENINGS"); return e && (e[0] == '1' || e[0] == '2'); }();
             if (late && use_aux) late_aux.push_back(openings);
             else aux(openings);
         }
@@ -1522,11 +1553,23 @@ struct Prover {
         std::vector<E2*> fa, fb;
         size_t u_base = slot(n.arity);
         E2* scratch = own ? ctx->alloc_n<E2>(n.arity) : nullptr;
+        // HG_GATHER_CSR=1: the general (per-term) form for every table
+        static const bool use_seg = [] { const char* e = getenv("HG_GATHER_CSR"); return !(e && e[0] == '1'); }();
         for (int i : li) {
-            E2* T = own ? ctx->alloc_n<E2>(SR) : nullptr;
+            const hg_pk::NodeDev::Seg& sg = nd.seg[i];
+            E2* T = nullptr;
+            if (own && use_seg && sg.alias) T = eqc + sg.alias_off;   // one unit relay per position: the table is a slice of eqc
+            else if (own) T = ctx->alloc_n<E2>(SR);
             gt.lin = nd.lin[i];
             gt.mul = nd.mulL[i];
-            if (own) gather_queue.push_back(dev::GatherJob{gt, eqc, n.log2_sub_in, n.log2_sub_out, n.log2_reps, T});
+            if (own && use_seg && sg.alias) {
+            } else if (own && use_seg && sg.d) {
+                dev::GatherSegJob sj;
+                memset(&sj, 0, sizeof(sj));
+                sj.segs = sg.d; sj.nseg = sg.nseg; sj.eqc = eqc; sj.log2_S = n.log2_sub_in; sj.log2_G = n.log2_sub_out; sj.log2_R = n.log2_reps; sj.T = T;
+                for (int q = 0; q < n.arity; q++) sj.in_vals[q] = gt.in_vals[q];
+                gather_seg_queue.push_back(sj);
+            } else if (own) gather_queue.push_back(dev::GatherJob{gt, eqc, n.log2_sub_in, n.log2_sub_out, n.log2_reps, T});
             a.push_back(d_vals[n.preds[i]]);
             b.push_back(T);
             fa.push_back(d_res() + u_base + i);
@@ -1688,6 +1731,9 @@ struct Prover {
         stamp("node bookkeeping done");
         flush_prodsum();                       // first wave: every FFT / Libra phase-1 reduction, batched
         stamp("node phase 1 done");
+        static const bool mid_openings = [] { const char* e = getenv("HG_LATE_OPENINGS"); return e && e[0] == '2'; }();
+        if (mid_openings) { for (auto& f : late_aux) f(); late_aux.clear(); }   // HG_LATE_OPENINGS=2: between the two waves
+
         for (auto& f : second_wave) f();       // Libra phase-2 bookkeeping (needs the phase-1 scalars in HBM)
         second_wave.clear();
         flush_bookkeeping();

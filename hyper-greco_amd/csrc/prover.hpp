@@ -135,6 +135,10 @@ struct hg_pk {
         std::vector<hg::dev::CsrLin> lin;    // [arity]
         std::vector<hg::dev::CsrMul> mulL;   // [arity] keyed by left operand
         std::vector<hg::dev::CsrMul> mulR;   // [arity] keyed by right operand
+        // run-length form of lin + mulL per input (kernels.hpp GatherSeg), when the wiring is affine in the input position;
+        // `alias`: the table IS a slice of the node's eq table (one unit-coefficient relay per position): nothing to build
+        struct Seg { const hg::dev::GatherSeg* d = nullptr; int nseg = 0; bool alias = false; size_t alias_off = 0; };
+        std::vector<Seg> seg;                // [arity]
         const hg::u32* const_gate = nullptr;
         const hg::u64* const_coef = nullptr;
         size_t nconst = 0;
