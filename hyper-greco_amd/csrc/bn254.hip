@@ -544,7 +544,7 @@ __global__ __launch_bounds__(BN_TPB * (KIND == BN_GRANDPROD ? 3 : 2)) void k_bn_
 // takes eval(1) from the claim and computes eval(2) (convention C1), and the claim is not the sum of g for the collation sum-check of
 // the Lasso node (Expression::poly(0) stands where an eq table would, lasso.rs:457-475) nor for any node of an INVALID witness - the
 // transcript must be the reference's there too (test_bn254_invalid_witness_rejected_by_both_verifiers).
-struct PsJobDev { const Fr* t[2 * dev::PS_MAX_PAIRS]; Fr* out; Fr* part; Fr r; unsigned long long half; int npairs, gx, gy, pad; FoldK fk; };   // fk = fold_consts(r)
+struct PsJobDev { const Fr* t[2 * dev::PS_MAX_PAIRS]; Fr* out; Fr* part; Fr r; unsigned long long half; int npairs, gx, gy, pad; FoldK fk; };   // fk = fold_consts(r); pad bit 0: every pair has the same b table, bit 1: write its fold once per pair
 // One round of g = sum_i a_i b_i for many independent sum-checks (blockIdx.y = job). Two workgroup sets per tile (v = 0: g(0) = sum xa xb
 // and the folds of the a tables, v = 1: g(2) = sum (2 ya - xa)(2 yb - xb) and the folds of the b tables; ids 8 (2 q + v) + xcd keep a
 // tile's two workgroups on one XCD, adjacent in dispatch order, so the second reads the tables from L2): one column accumulator, one
@@ -561,8 +561,37 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_ps_round_jobs(const PsJobDev* __r
     const size_t half = J.half;
     Fr* __restrict__ out = J.out;
     const u32* __restrict__ K = J.fk.k;
+    const bool shared = J.pad & 1, replicate = J.pad & 2;
     for (size_t j = (size_t)bx * BN_TPB + threadIdx.x; j < half; j += (size_t)J.gx * BN_TPB) {
         WCol s = wcol_zero();
+        if (shared) {
+            // every pair has the SAME b table (the node's eq table: one unit relay per position and input): sum_i a_i b = (sum_i a_i) b,
+            // one product per evaluation point and ONE fold of b instead of npairs (exact arithmetic: the same field elements)
+            const Fr* tb = J.t[1];
+            const Fr xb = lz_gload(&tb[2 * j]), yb = lz_gload(&tb[2 * j + 1]);
+            Fr sa = fr_zero();
+            for (int i = pi; i < npairs; i += P) {
+                const Fr* ta = J.t[2 * i];
+                const Fr xa = lz_gload(&ta[2 * j]), ya = lz_gload(&ta[2 * j + 1]);
+                if (v == 0) {
+                    sa = lz_add(sa, xa);
+                    lz_gstore(&out[(size_t)(2 * i) * half + j], lz_fold(xa, lz_sub(ya, xa), K));
+                } else sa = lz_add(sa, lz_add(ya, lz_subr(ya, xa)));
+            }
+            if (v == 0) wcol_mac(s, sa, xb);
+            else {
+                const Fr db = lz_sub(yb, xb);
+                wcol_mac(s, sa, lz_add(yb, lz_cond_sub_2p(db)));
+                if (pi == 0) {
+                    const Fr fb = lz_fold(xb, db, K);
+                    lz_gstore(&out[half + j], fb);
+                    if (replicate)   // the last shared-launch round: the tail workgroup reads one b table per pair
+                        for (int i = 1; i < npairs; i++) lz_gstore(&out[(size_t)(2 * i + 1) * half + j], fb);
+                }
+            }
+            acc = lz_add(acc, lz_reduce(s));
+            continue;
+        }
         for (int i = pi; i < npairs; i += P) {
             const Fr* ta = J.t[2 * i];
             const Fr* tb = J.t[2 * i + 1];

@@ -1451,11 +1451,15 @@ struct Prover {
             E2 *eqx_v = eqx, *eqy_v = eqy;
             const size_t p1 = g1.point_off, p2 = g2.point_off;
             const dev::LassoDev* Lp = &L;
-            auto openings = [this, txv, tyv, nxv, nyv, do_open_v, lean_v, eqx_v, eqy_v, p1, p2, Lp, d_input, nu, N] {
+            // the two eq tables of the opening points are challenges only: built right away on the second stream (beside the first hash
+            // round), whatever the place of the dot products - at the end of the second stream they ran alone, 0.05 ms of its length
+            auto open_tables = [this, do_open_v, eqx_v, eqy_v, p1, p2, nu] {
                 if (do_open_v) {
                     eq_now(eqx_v, nu, p1);
                     eq_now(eqy_v, 16, p2);
                 }
+            };
+            auto openings = [this, txv, tyv, nxv, nyv, do_open_v, lean_v, eqx_v, eqy_v, p1, p2, Lp, d_input, nu, N] {
                 if (nxv) {
                     int nvirt = 0;
                     for (int t = 0; t < nxv; t++) nvirt += txv.t[t] == nullptr;
@@ -1476,12 +1480,13 @@ struct Prover {
                 if (nyv) dev::dot_eq_many(st, eqy_v, tyv, nyv, M, partials, d_res());
                 stamp("claimed sum and openings done");
             };
-            // Default (round 4): right away on the second stream, beside the first hash round. Round 3 ran them behind the node
-            // reductions (HG_LATE_OPENINGS=1; 2: between the two waves of node reductions): the same prove time then, and the dominant
-            // round kernel at 0.63 instead of 0.56 of the HBM roofline inside a prove. With the shorter node bookkeeping of round 4 the
-            // second stream ends with the main one, and 0.15 ms of openings behind it ran alone: 2.566 (0) / 2.598 (2) / 2.610 ms (1),
-            // medians of 120 interleaved replays.
-            static const bool late = [] { const char* e = getenv("HG_LATE_OPENINGS"); return e && (e[0] == '1' || e[0] == '2'); }();
+            // Default: the dot products behind the node reductions on the second stream, not beside grand product #1's first
+            // (bandwidth-bound) rounds - HG_LATE_OPENINGS=0: right away; 2: between the two waves of node reductions. Round 4, medians of
+            // 120 interleaved graph replays: 2.566 (0) / 2.598 (2) / 2.610 ms (1) with the eq tables still inside the late part; but
+            // placed early they push the node reductions' VALU-heavy rounds under the dominant round kernel's launches (272 instead
+            // of 240 us per launch, 0.56 instead of 0.63 of the HBM roofline inside a prove) for a difference bench.py cannot resolve.
+            static const bool late = [] { const char* e = getenv("HG_LATE_OPENINGS"); return !(e && e[0] == '0'); }();
+            aux(open_tables);
             if (late && use_aux) late_aux.push_back(openings);
             else aux(openings);
         }

@@ -712,11 +712,13 @@ def test_launch_graph_that_replays_slower_than_plain_launches_is_given_up():
 
 
 @pytest.mark.parametrize("switch", ["HG_E_TABLES=1", "HG_NO_MIRROR=1", "HG_NO_HASH_FUSE=1", "HG_ONE_STREAM=1", "HG_NO_GRAPH=1", "HG_TAIL_H=4", "HG_LATE_OPENINGS=0",
-                                    "HG_NO_LEVEL3=1", "HG_GRAPH_UPLOADS=1", "HG_LASSO_SCHED=2", "HG_NO_FUSE2=1"])
+                                    "HG_LATE_OPENINGS=2", "HG_NO_LEVEL3=1", "HG_GRAPH_UPLOADS=1", "HG_LASSO_SCHED=2", "HG_NO_FUSE2=1",
+                                    "HG_GATHER_CSR=1", "HG_EQ_ONE_LAUNCH=1", "HG_PS_TAIL_THREADS=256"])
 def test_alternative_paths_behind_the_environment_switches_stay_bit_exact(switch):
     """Every switch that selects an older or alternative device path (E tables materialised, both rows of the top layer, hash tables,
-    one stream, plain launches, the five-round tail, one tree level per launch, upload nodes in the graph, collation on the second
-    stream, single-round launches) must produce the same bytes as the oracle. The library reads them once per process: child process,
+    one stream, plain launches, the five-round tail, the openings behind / between the node reductions, one tree level per launch, upload
+    nodes in the graph, collation on the second stream, single-round launches, per-term Libra gathers instead of run-length segments
+    and aliased eq slices, one-launch eq tables, a 256-thread PRODSUM tail) must produce the same bytes as the oracle. The library reads them once per process: child process,
     five resident proves (walks, capture, replays) plus a four-rank sharded proof at n=4096 k=2."""
     import subprocess, sys
     from hglib import ROOT
@@ -740,7 +742,7 @@ def test_alternative_paths_behind_the_environment_switches_stay_bit_exact(switch
     assert r.returncode == 0 and "SWITCH OK" in r.stdout, (switch, r.stdout[-500:], r.stderr[-2000:])
 
 
-@pytest.mark.parametrize("switch", ["HG_NO_MIRROR=1", "HG_E_TABLES=1"])
+@pytest.mark.parametrize("switch", ["HG_NO_MIRROR=1", "HG_E_TABLES=1", "HG_GATHER_CSR=1"])
 def test_environment_switches_at_the_headline_size(switch):
     """Two of the switches above at n=32768 k=16 (BASELINE configs[2]), where every production shortcut is active: walks, the capture and
     two graph replays must all give the oracle's bytes."""
@@ -755,6 +757,29 @@ def test_environment_switches_at_the_headline_size(switch):
         "w = hg.Witness.synthetic(bfv.params, 77); v = hg.witness_gen(ctx, pk, w); out = hg.ProofBuffer()\n"
         "ref, _ = orclib.prove(orclib.params(32768, 16), orclib.Inputs(w.arrays()), threads=min(16, os.cpu_count() or 8))\n"
         "for i in range(5): assert hg.prove_resident(ctx, pk, v, out).bytes() == ref, i\n"
+        "print('SWITCH OK')\n"
+    ) % (ROOT, os.path.join(ROOT, "tests"))
+    name, value = switch.split("=")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, **{name: value}), cwd=ROOT)
+    assert r.returncode == 0 and "SWITCH OK" in r.stdout, (switch, r.stdout[-500:], r.stderr[-2000:])
+
+
+@pytest.mark.parametrize("switch", ["HG_BN_NO_SHARED_B=1", "HG_GATHER_CSR=1", "HG_BN_SCHED=0"])
+def test_bn254_environment_switches_stay_bit_exact(switch):
+    """The BN254 prove with its alternative paths (every pair of a PRODSUM job multiplied separately although the pairs share one b
+    table; per-term Libra gathers instead of aliased eq slices; the node launches ahead of the Lasso node) gives the C++ Fr oracle's
+    bytes at n=4096 k=2. Child process: the switches are read once."""
+    import subprocess, sys
+    from hglib import ROOT
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import __graft_entry__ as entry\n"
+        "import orclib\n"
+        "hg = entry.load_package()\n"
+        "ctx = hg.Context(0); bfv = hg.BfvEncrypt.new(4096, 2); pk = bfv.setup(ctx)\n"
+        "w = hg.Witness.synthetic(bfv.params, 31)\n"
+        "ref = orclib.prove_f('bn254', orclib.params(4096, 2), orclib.Inputs(w.arrays()), threads=4)[0]\n"
+        "for i in range(2): assert ctx.prove_bn254(pk, w, cap=1 << 24)[0] == ref, i\n"
         "print('SWITCH OK')\n"
     ) % (ROOT, os.path.join(ROOT, "tests"))
     name, value = switch.split("=")
