@@ -38,7 +38,7 @@ class HgKernelStat(C.Structure):
 EXPORTS = [
     "hg_last_error", "hg_device_count", "hg_create", "hg_destroy", "hg_set_option", "hg_params_builtin", "hg_params_derive", "hg_grand_product", "hg_fold", "hg_setup", "hg_pk_free",
     "hg_pk_lasso_layout", "hg_pk_info", "hg_witness_from_json", "hg_witness_synthetic", "hg_witness_from_arrays",
-    "hg_witness_get", "hg_witness_free", "hg_prove", "hg_prove_stream", "hg_verify", "hg_verify_device", "hg_prove_mode", "hg_prove_resident_mode", "hg_verify_mode", "hg_witness_gen", "hg_witness_gen_into", "hg_witness_gen_shard", "hg_values_info", "hg_values_peak_bytes", "hg_values_free", "hg_values_get", "hg_comm_unique_id", "hg_comm_init", "hg_comm_destroy", "hg_comm_count", "hg_comm_selftest", "hg_prove_sharded", "hg_prove_shard_begin", "hg_prove_shard_combine", "hg_prove_shard_finish", "hg_shard_combine_host", "hg_prove_resident", "hg_circuit_eval", "hg_lasso_prove", "hg_lasso_prove_at", "hg_lasso_num_challenges", "hg_sumcheck", "hg_mle_eval",
+    "hg_witness_get", "hg_witness_free", "hg_prove", "hg_prove_stream", "hg_verify", "hg_verify_device", "hg_prove_mode", "hg_prove_resident_mode", "hg_verify_mode", "hg_group_local", "hg_group_external", "hg_group_free", "hg_prove_resident_mode_sharded", "hg_witness_gen", "hg_witness_gen_into", "hg_witness_gen_shard", "hg_values_info", "hg_values_peak_bytes", "hg_values_free", "hg_values_get", "hg_comm_unique_id", "hg_comm_init", "hg_comm_destroy", "hg_comm_count", "hg_comm_selftest", "hg_prove_sharded", "hg_prove_shard_begin", "hg_prove_shard_combine", "hg_prove_shard_finish", "hg_shard_combine_host", "hg_prove_resident", "hg_circuit_eval", "hg_lasso_prove", "hg_lasso_prove_at", "hg_lasso_num_challenges", "hg_sumcheck", "hg_mle_eval",
     "hg_ntt", "hg_challenges", "hg_challenges_bn254", "hg_bn254_field_op", "hg_sumcheck_bn254", "hg_grand_product_bn254", "hg_lasso_prove_bn254", "hg_witness_from_json_bn254", "hg_circuit_eval_bn254", "hg_prove_bn254", "hg_verify_bn254", "hg_mle_eval_bn254", "hg_ntt_bn254", "hg_profile", "hg_profile_select", "hg_profile_reset", "hg_profile_get",
 ]
 
@@ -515,6 +515,65 @@ def prove_resident_mode(ctx, pk, values, out, mode):
     L = lib()
     L.hg_prove_resident_mode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(HgTimings)]
     _check(L.hg_prove_resident_mode(ctx.h, pk.h, values.h, mode, out.buf, out.cap, C.byref(out.len), C.byref(out.tm)))
+    return out
+
+
+REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t)
+
+
+class Group:
+    """hg_group: the ranks of a sharded round-by-round prove. Group.local(world): ranks are threads of this process. Group.external(fn,
+    world): fn(words: numpy u64 view) adds the ranks' words lane-wise mod p IN PLACE (an all-gather + modular sum, say)."""
+
+    def __init__(self, h, world, keep=None):
+        self.h, self.world, self._keep = h, world, keep
+
+    @classmethod
+    def local(cls, world):
+        L = lib()
+        L.hg_group_local.restype = C.c_void_p
+        L.hg_group_local.argtypes = [C.c_int]
+        h = L.hg_group_local(world)
+        if not h:
+            raise HgError(lib().hg_last_error().decode())
+        return cls(h, world)
+
+    @classmethod
+    def external(cls, fn, world):
+        L = lib()
+
+        def tramp(_user, words, n):
+            try:
+                fn(np.ctypeslib.as_array(words, shape=(n,)))
+                return 0
+            except Exception:   # the library turns a non-zero return into an error of the prove
+                import traceback
+                traceback.print_exc()
+                return -1
+
+        cb = REDUCE_FN(tramp)
+        L.hg_group_external.restype = C.c_void_p
+        L.hg_group_external.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        h = L.hg_group_external(C.cast(cb, C.c_void_p), None, world)
+        if not h:
+            raise HgError(lib().hg_last_error().decode())
+        return cls(h, world, keep=cb)
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().hg_group_free.argtypes = [C.c_void_p]
+                lib().hg_group_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+def prove_resident_mode_sharded(ctx, pk, values, out, mode, rank, group):
+    """hg_prove_resident_mode_sharded: this rank's run of the round-by-round prover, one all-reduce per sum-check round through `group`."""
+    L = lib()
+    L.hg_prove_resident_mode_sharded.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(HgTimings)]
+    _check(L.hg_prove_resident_mode_sharded(ctx.h, pk.h, values.h, mode, rank, group.h, out.buf, out.cap, C.byref(out.len), C.byref(out.tm)))
     return out
 
 

@@ -3,6 +3,8 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -131,6 +133,7 @@ int hg_set_option(hg_ctx* ctx, const char* name, int64_t value) {
     const std::string n(name);
     if (n == "one_stream") { if (ctx->one_stream != (value != 0)) ctx->walk_counts.clear(); ctx->one_stream = value != 0; }
     else if (n == "graph") { ctx->use_graph = value != 0; if (!ctx->use_graph) prove_cache_drop(ctx); }
+    else if (n == "seq_max_blocks") { if (value < 1 || value > 1024) throw Error("hg_set_option: seq_max_blocks must be 1..1024"); ctx->seq_max_blocks = (int)value; }
     else throw Error("hg_set_option: unknown option " + n);
     return 0;
     HG_CATCH(-1)
@@ -608,6 +611,74 @@ int hg_prove_resident_mode(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int
     if (!ctx || !pk || !v || !pk->ctx || !proof || !len) throw Error("hg_prove_resident_mode: needs a device context, a device prover key and resident values");
     double t0 = now_ms_capi();
     ProveResult r = prove_resident_mode(ctx, pk, v, mode);
+    if (timings) { memset(timings, 0, sizeof(*timings)); timings->prove_ms = r.prove_ms; timings->gpu_ms = r.gpu_ms; timings->total_ms = now_ms_capi() - t0; timings->enqueue_ms = r.enqueue_ms; timings->sync_ms = r.sync_ms; timings->replay_ms = r.replay_ms; }
+    *len = r.proof.size();
+    if (r.proof.size() > cap) throw Error("proof buffer too small");
+    memcpy(proof, r.proof.data(), r.proof.size());
+    return 0;
+    HG_CATCH(-1)
+}
+// ---- ranks of a sharded round-by-round prove ------------------------------------------------------------------------------------
+struct hg_group {
+    int world = 1;
+    // external: the caller's all-reduce
+    int (*fn)(void*, uint64_t*, size_t) = nullptr;
+    void* user = nullptr;
+    // local: ranks are threads of this process
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<uint64_t> acc, res;
+    int arrived = 0;
+    unsigned long long gen = 0;
+    bool broken = false;
+};
+static int group_reduce(void* gp, uint64_t* words, size_t n) {
+    hg_group* g = static_cast<hg_group*>(gp);
+    if (g->fn) return g->fn(g->user, words, n);
+    std::unique_lock<std::mutex> lk(g->mu);
+    if (g->broken) return -1;
+    if (g->arrived == 0) g->acc.assign(words, words + n);
+    else {
+        if (g->acc.size() != n) { g->broken = true; g->cv.notify_all(); return -1; }   // the ranks are not in the same round
+        for (size_t i = 0; i < n; i++) g->acc[i] = gl_add(g->acc[i], words[i]);
+    }
+    if (++g->arrived == g->world) {
+        g->res = g->acc;
+        g->arrived = 0;
+        g->gen++;
+        g->cv.notify_all();
+    } else {
+        const unsigned long long mine = g->gen;
+        // a rank that never arrives (it failed) must not hold the others for ever
+        if (!g->cv.wait_for(lk, std::chrono::seconds(20), [&] { return g->gen != mine || g->broken; }) || g->broken) { g->broken = true; g->cv.notify_all(); return -1; }
+    }
+    std::copy(g->res.begin(), g->res.end(), words);
+    return 0;
+}
+hg_group* hg_group_local(int world) {
+    HG_TRY
+    if (world < 1 || world > 64) throw Error("hg_group_local: world out of range");
+    hg_group* g = new hg_group();
+    g->world = world;
+    return g;
+    HG_CATCH(nullptr)
+}
+hg_group* hg_group_external(void* reduce_fn, void* user, int world) {
+    HG_TRY
+    if (world < 1 || !reduce_fn) throw Error("hg_group_external: needs a reduce function and a world size");
+    hg_group* g = new hg_group();
+    g->world = world;
+    g->fn = reinterpret_cast<int (*)(void*, uint64_t*, size_t)>(reduce_fn);
+    g->user = user;
+    return g;
+    HG_CATCH(nullptr)
+}
+void hg_group_free(hg_group* g) { delete g; }
+int hg_prove_resident_mode_sharded(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int mode, int rank, hg_group* group, uint8_t* proof, size_t cap, size_t* len, hg_timings* timings) {
+    HG_TRY
+    if (!ctx || !pk || !v || !pk->ctx || !proof || !len || !group) throw Error("hg_prove_resident_mode_sharded: needs a device context, a device prover key, resident values and a group");
+    double t0 = now_ms_capi();
+    ProveResult r = prove_resident_mode_sharded(ctx, pk, v, mode, rank, group->world, group_reduce, group);
     if (timings) { memset(timings, 0, sizeof(*timings)); timings->prove_ms = r.prove_ms; timings->gpu_ms = r.gpu_ms; timings->total_ms = now_ms_capi() - t0; timings->enqueue_ms = r.enqueue_ms; timings->sync_ms = r.sync_ms; timings->replay_ms = r.replay_ms; }
     *len = r.proof.size();
     if (r.proof.size() > cap) throw Error("proof buffer too small");

@@ -21,6 +21,7 @@ struct hg_ctx {
     int device = 0;
     hipStream_t stream = nullptr;   // Lasso node + everything sequential
     hipStream_t bn_stream_hi = nullptr, bn_stream_lo = nullptr;   // BN254 prove only (bn254_gkr.inc: BnStreams), created on first use
+    int seq_max_blocks = 1024;      // hg_set_option "seq_max_blocks": workgroups per round kernel of the round-by-round prover
     hipStream_t stream2 = nullptr;  // Vanilla / FFT node reductions (independent of the Lasso node on the device)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_aux[4] = {nullptr, nullptr, nullptr, nullptr};  // Lasso node: limbs done (stream -> stream2), grand product #2 levels done (stream2 -> stream), E tables done (stream -> stream2), counters done (stream2 -> stream)
@@ -203,6 +204,8 @@ ProveResult prove_resident(hg_ctx* ctx, const hg_pk* pk, const hg_values* v);
 // the same in a protocol mode of SURVEY.md 8(f) f-4 (bit 0 absorbing transcript, bit 1 extension-field memory checking):
 // round-by-round prover (prover_seq.hip); mode 0 = prove_resident
 ProveResult prove_resident_mode(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int mode);
+ProveResult prove_resident_mode_sharded(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int mode, int rank, int world,
+                                        int (*reduce)(void*, uint64_t*, size_t), void* user);
 size_t prove_shard_begin(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int rank, int world);  // -> #E2 slots in ctx->h_res
 // the whole sharded proof with the exchange inside the library (comm.hip): begin -> RCCL all-reduce on the stream -> replay
 ProveResult prove_sharded(hg_ctx* ctx, const hg_pk* pk, const hg_values* v);

@@ -160,6 +160,7 @@ struct SqArgs {
     const E2* src;                   // rd >= 2: T_(rd-1), table t at src + t * 2^(nvars-rd+1)
     E2* dst;                         // rd >= 1: T_rd
     int kind, ntab, nvars, last;     // (copies of the job's; last: the host takes over after this round, run_sq)
+    int rank, world;                 // sharded form (prove_resident_mode_sharded): this rank evaluates the sums of the tiles t = rank (mod world)
 };
 template <typename T> __device__ __forceinline__ E2 sq_ld(const T* p, size_t i);
 template <> __device__ __forceinline__ E2 sq_ld<u64>(const u64* p, size_t i) { return e2(p[i], 0); }
@@ -315,6 +316,20 @@ __device__ __forceinline__ void sq_round_sums(const SqJob& J, const SqArgs& A, E
     const int units = KIND == 0 ? A.ntab : A.ntab / 2;
     for (size_t tile = tile0; tile < ntiles; tile += tile_step) {
         const size_t j = (tile << jb_log2) + jj;
+        // sharded form: every rank folds every tile (it needs the whole table of the next round), the hypercube sums of a tile are
+        // evaluated by ONE rank; the ranks' partial sums meet in the round's all-reduce on the host side (answer_round)
+        const bool own = A.world <= 1 || (int)(tile % (size_t)A.world) == A.rank;
+        if (!own) {
+            if (rd == 0) continue;   // nothing to fold yet
+            for (int u = g; u < units; u += G) {
+                const E2 w = (KIND == 2 || rd > 1) ? e2_one() : J.pw[u];
+                E2 X, Y;
+                if (KIND == 0) sq_pair<TIN>(J, A, u, j, r_prev, rd == 1 && u > 0, w, X, Y);
+                else if (KIND == 1) { sq_pair<TIN>(J, A, 2 * u, j, r_prev, rd == 1 && u > 0, w, X, Y); sq_pair<TIN>(J, A, 2 * u + 1, j, r_prev, false, w, X, Y); }
+                else { sq_pair<TIN>(J, A, 2 * u, j, r_prev, false, w, X, Y); sq_pair_b(J, A, 2 * u + 1, j, r_prev, X, Y); }
+            }
+            continue;
+        }
         E2 s[NV], q[NV];
 #pragma unroll
         for (int t = 0; t < NV; t++) { s[t] = e2_zero(); q[t] = e2_zero(); }
@@ -563,6 +578,23 @@ struct SeqProver {
     bool use_mail = true;
     std::vector<const u64*> d_vals;
     std::vector<std::vector<Claim>> claims;
+    // sharded form: one all-reduce per sum-check round (the form that stays available for an absorbing transcript).
+    // `reduce` adds n canonical Goldilocks words lane-wise mod p over the ranks, in place, and returns 0.
+    int shard_rank = 0, shard_world = 1;
+    int (*reduce)(void*, uint64_t*, size_t) = nullptr;
+    void* reduce_user = nullptr;
+    size_t n_reduce = 0;
+    void reduce_sums(E2* sums, int nv) {
+        if (shard_world <= 1) return;
+        uint64_t w[6];
+        for (int t = 0; t < nv; t++) { w[2 * t] = sums[t].c0; w[2 * t + 1] = sums[t].c1; }
+        if (reduce(reduce_user, w, (size_t)2 * nv) != 0) throw Error("sharded prove: the round's all-reduce failed");
+        for (int t = 0; t < nv; t++) {
+            if (w[2 * t] >= GL_P || w[2 * t + 1] >= GL_P) throw Error("sharded prove: the all-reduce returned a non-canonical word");
+            sums[t] = e2(w[2 * t], w[2 * t + 1]);
+        }
+        n_reduce++;
+    }
 
     SeqProver(hg_ctx* c, const hg_pk* k, int m) : ctx(c), pk(k), mode(m), st(c->stream) {
         tr.absorb = (m & 1) != 0;
@@ -739,6 +771,7 @@ struct SeqProver {
         A.dst = rd >= 1 ? J.buf[rd & 1] : nullptr;
         A.kind = J.kind; A.ntab = J.ntab; A.nvars = J.nvars;
         A.last = J.dev_rounds && rd == J.dev_rounds - 1;
+        A.rank = shard_rank; A.world = shard_world;
         return A;
     }
     template <int KIND> void launch_round(bool in_base, const SqJob& J, const SqJob* d_job, int rd, int jb_log2, int grid) {
@@ -771,6 +804,7 @@ struct SeqProver {
         if (slow_log && t1 - t0 > 3.0) fprintf(stderr, "[hg] slow: waited %.2f ms for message %llu (%s)\n", t1 - t0, seq, where);
         E2 sums[3];
         for (int t = 0; t < nv; t++) sums[t] = e2(mail->slot[2 * t].v, mail->slot[2 * t + 1].v);
+        reduce_sums(sums, nv);   // (sharded form: this rank's tiles only so far)
         const E2 r = round_message(sums, deg, claim, false);
         mail->chal[0] = r;
         __atomic_store_n(&mail->cpu_seq, seq, __ATOMIC_RELEASE);
@@ -934,7 +968,7 @@ struct SeqProver {
                 return;
             }
             int jb = 0, grid = 1;
-            sq_plan(nvars - 1 - rd, J.kind == 0 ? J.ntab : J.ntab / 2, SQ_MAX_BLOCKS, &jb, &grid);
+            sq_plan(nvars - 1 - rd, J.kind == 0 ? J.ntab : J.ntab / 2, std::min(SQ_MAX_BLOCKS, ctx->seq_max_blocks), &jb, &grid);
             if (J.kind == 0) launch_round<0>(in_base, J, d_job, rd, jb, grid);
             else if (J.kind == 1) launch_round<1>(in_base, J, d_job, rd, jb, grid);
             else launch_round<2>(in_base, J, d_job, rd, jb, grid);
@@ -970,6 +1004,7 @@ struct SeqProver {
     // ---- prove_sum_check, stride layout (collation / grand-product shapes) ------------------------------------------------
     // tables: ntab rows at `in + t * in_stride` (u64 if base else E2). final evaluations land in d_res[evals_slot ..).
     size_t sumcheck_stride(int kind, const void* in, bool base, size_t in_stride, int ntab, int nvars, const dev::Powers& pw, E2& claim, size_t evals_slot) {
+        if (shard_world > 1 && !(use_mail && !classic())) throw Error("sharded prove: needs the mailbox round kernels (HG_SEQ_NO_MAIL / HG_SEQ_CLASSIC / HG_RES_DEVICE unset)");
         if (use_mail && !classic()) {
             SqJob Q;
             memset(&Q, 0, sizeof(Q));
@@ -1045,6 +1080,7 @@ struct SeqProver {
     // ---- prove_sum_check, sum of pair products (Libra / zkCNN reductions) --------------------------------------------------
     size_t sumcheck_prodsum(const std::vector<const u64*>& a, const std::vector<const E2*>& b, int nvars, const std::vector<E2*>& fin_a,
                             const std::vector<E2*>& fin_b, E2& claim) {
+        if (shard_world > 1 && !(use_mail && !classic())) throw Error("sharded prove: needs the mailbox round kernels (HG_SEQ_NO_MAIL / HG_SEQ_CLASSIC / HG_RES_DEVICE unset)");
         if (use_mail && !classic()) {
             SqJob Q;
             memset(&Q, 0, sizeof(Q));
@@ -1439,12 +1475,26 @@ struct SeqProver {
 // BfvEncrypt::prove on resident node values in a non-default protocol mode; gpu_ms = wall time of the whole walk (the device
 // is synchronised every round, so there is no separate device span)
 ProveResult prove_resident_mode(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int mode) {
-    if (mode == 0) return prove_resident(ctx, pk, v);
+    return prove_resident_mode_sharded(ctx, pk, v, mode, 0, 1, nullptr, nullptr);
+}
+// The round-by-round prover on `world` ranks, each holding the whole witness: rank r evaluates the hypercube sums of the tiles
+// t = r (mod world) of every round kernel and folds everything; one all-reduce (`reduce`) per round completes the sums, after which
+// every rank's transcript absorbs the same message and squeezes the same challenge. Rounds finished on the host (host_tail) and the
+// scalar steps between the sum-checks are replicated. Every rank returns the same proof, byte for byte the single-rank one.
+ProveResult prove_resident_mode_sharded(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int mode, int rank, int world,
+                                        int (*reduce)(void*, uint64_t*, size_t), void* user) {
+    if (world < 1 || rank < 0 || rank >= world) throw Error("sharded prove: rank out of range");
+    if (world > 1 && !reduce) throw Error("sharded prove: no all-reduce given");
+    if (mode == 0) {
+        if (world > 1) throw Error("sharded prove: mode 0 shards through hg_prove_sharded / hg_prove_shard_begin (one all-reduce per proof)");
+        return prove_resident(ctx, pk, v);
+    }
     if (mode < 0 || mode > 3) throw Error("hg_prove_mode: unknown mode bits");
     hip_check(hipSetDevice(ctx->device), "hipSetDevice");
     ctx->arena_reset();
     const double t0 = now_ms();
     SeqProver P(ctx, pk, mode);
+    P.shard_rank = rank; P.shard_world = world; P.reduce = reduce; P.reduce_user = user;
     P.d_vals = v->d_vals;
     const Params& p = pk->params;
     // "eval output" (sk_encryption_circuit.rs:444-448)
@@ -1463,6 +1513,7 @@ ProveResult prove_resident_mode(hg_ctx* ctx, const hg_pk* pk, const hg_values* v
     res.gpu_ms = res.prove_ms;
     res.sync_ms = (double)P.n_sync;  // number of synchronisations (reported through hg_timings::sync_ms in this mode)
     res.enqueue_ms = (double)P.n_mail;  // ... and of mailbox round trips (hg_timings::enqueue_ms in this mode)
+    res.replay_ms = (double)P.n_reduce; // ... and of all-reduces (sharded form; hg_timings::replay_ms in this mode)
     if (getenv("HG_SEQ_TIMES"))
         fprintf(stderr, "[hg] mode %d: %.2f ms; host waited %.2f ms for round sums (%zu round trips), %.2f ms for other results, spent %.2f ms enqueueing rounds\n", mode,
                 res.prove_ms, P.t_wait_rounds, P.n_mail, P.t_wait_results, P.t_enqueue_rounds);

@@ -24,6 +24,7 @@ typedef struct hg_ctx hg_ctx;         /* one per GPU: stream, workspace arena, c
 typedef struct hg_pk hg_pk;           /* prover key = LassoPreprocessing + circuit wiring, device resident */
 typedef struct hg_witness hg_witness; /* BfvSkEncryptArgs after get_inputs(): laid-out field tables (host) */
 typedef struct hg_values hg_values;   /* circuit.evaluate() result: every node's table, resident in HBM */
+typedef struct hg_group hg_group;     /* the ranks of a sharded round-by-round prove: who adds the partial round sums */
 
 /* Per-parameter-set constants [REF bfv-gkr/src/constants/mod.rs:16-35, constants/sk_enc_constants_*.rs] */
 typedef struct hg_params {
@@ -71,6 +72,10 @@ void hg_destroy(hg_ctx* ctx);
  *                 values object the third is captured into a hipGraph and later ones replay it - the launch sequence depends on
  *                 addresses only, because every challenge is known up front; a values object refilled by hg_witness_gen_into
  *                 keeps its graph; up to HG_GRAPH_ENTRIES (8) graphs per context, each with a private workspace)
+ *   "seq_max_blocks"  workgroups per round kernel of the round-by-round prover (modes 1-3; 1..1024, default 1024). A round kernel waits
+ *                 ON THE DEVICE for the challenge of the round before; ranks of a sharded prove that SHARE a device (tests with several
+ *                 ranks on one GPU) must leave each other room - a device filled with one rank's waiting workgroups never runs the
+ *                 round of the rank it is waiting for. One rank per device needs no cap.
  * Returns 0, or -1 for an unknown name. */
 int hg_set_option(hg_ctx* ctx, const char* name, int64_t value);
 
@@ -148,6 +153,23 @@ int hg_verify_device(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, const ui
 int hg_prove_mode(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, int mode, uint8_t* proof, size_t cap, size_t* len, hg_timings* timings);
 int hg_prove_resident_mode(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int mode, uint8_t* proof, size_t cap, size_t* len, hg_timings* timings);
 int hg_verify_mode(const hg_pk* pk, const hg_witness* w, int mode, const uint8_t* proof, size_t len);
+
+/* The round-by-round prover (modes 1-3) on several ranks, with ONE all-reduce per sum-check round: the exchange pattern an absorbing
+ * transcript leaves [REF bfv-gkr/src/transcript.rs:205-208, 224-233: every round's message is hashed before the next challenge is
+ * squeezed], SURVEY 8(e)'s conservative form of the north_star partition. Every rank holds the whole witness (hg_witness_gen) and runs
+ * the whole protocol; inside every round kernel rank r evaluates the hypercube sums of the tiles t = r (mod world) only - the
+ * prove_sum_check work of [REF lasso/src/lasso.rs:278-279; memory_checking/prover.rs:242-252] split along the hypercube - and folds
+ * everything; the group adds the ranks' partial sums (at most six canonical Goldilocks words, lane-wise mod p), after which every
+ * rank's transcript absorbs the same message and squeezes the same challenge. Rounds finished on the host and the scalar steps between
+ * sum-checks are replicated. Every rank returns the same proof, byte for byte the one hg_prove_resident_mode gives.
+ *   hg_group_local(world)    ranks are threads of this process, one context each (any devices): barrier + modular sum in memory;
+ *   hg_group_external(fn, user, world)   fn = int (*)(void* user, uint64_t* words, size_t n): adds `words` over the ranks in place
+ *                            (e.g. an all-gather over torch.distributed / MPI followed by the modular sum) and returns 0.
+ * timings->replay_ms holds the number of all-reduces of the proof. Mode 0 shards through hg_prove_sharded (one all-reduce per proof). */
+hg_group* hg_group_local(int world);
+hg_group* hg_group_external(void* reduce_fn, void* user, int world);
+void hg_group_free(hg_group* g);
+int hg_prove_resident_mode_sharded(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int mode, int rank, hg_group* group, uint8_t* proof, size_t cap, size_t* len, hg_timings* timings);
 
 /* The two halves of hg_prove, split where the reference splits its spans:
  *   hg_witness_gen   = "wintess gen": circuit.evaluate(inputs) [REF sk_encryption_circuit.rs:439-442] ON THE DEVICE: the

@@ -9,7 +9,11 @@ mode "prove" (needs a GPU; both ranks on device 0): the real two-process sharded
 mode "prove_c3" (needs a GPU; both ranks on device 0): the same at BASELINE config 4's size, n=32768 k=16, with PER-RANK tables: every
     process evaluates only the cone of its own share (hg_witness_gen_shard: the other rank's per-modulus chains are never computed or
     resident), proves its share, exchanges the partial buffers over gloo; the second witness goes in through hg_witness_gen_into.
-    Every rank's proof must be the CPU oracle's."""
+    Every rank's proof must be the CPU oracle's.
+mode "prove_seq" (needs a GPU; both ranks on device 0): the round-by-round prover of protocol mode 3 (absorbing transcript +
+    extension-field memory checking) on two processes, ONE all-reduce per sum-check round (hg_prove_resident_mode_sharded with an
+    external group: the six words of a round's partial sums are all-gathered over gloo and added mod p); n=1024 k=1 and n=4096 k=2,
+    every rank's proof must be the CPU oracle's proof of that mode."""
 import os
 import sys
 
@@ -108,6 +112,37 @@ def main():
         dist.barrier()
         print("rank %d PROVE_C3 OK resident %.1f MB peak %.1f MB of %.1f MB" % (rank, info["resident_bytes"] / 1e6, info["peak_bytes"] / 1e6, info["full_bytes"] / 1e6), flush=True)
         vals.free(); pk.free(); ctx.close()
+    elif mode == "prove_seq":
+        import orclib
+        ctx = hg.Context(0)
+        ctx.set_option("seq_max_blocks", 128)   # both processes share device 0: a round kernel waits on the device for its challenge (hg.h)
+        for n, k in ((1024, 1), (4096, 2)):
+            bfv = hg.BfvEncrypt.new(n, k)
+            pk = bfv.setup(ctx)
+            w = hg.Witness.synthetic(bfv.params, 0x71 + n)
+            ref = orclib.prove_f("goldilocks", orclib.params(n, k), orclib.Inputs(w.arrays()), threads=4, mode=3)[0]
+            vals = hg.witness_gen(ctx, pk, w)
+            calls = [0]
+
+            def reduce(words):   # the round's all-reduce: gather every rank's partial sums, add them as field elements, in place
+                g = all_gather_u64(np.array(words, copy=True), world)
+                acc = [0] * len(words)
+                for r in range(world):
+                    for i in range(len(words)):
+                        acc[i] = (acc[i] + int(g[r][i])) % P
+                for i in range(len(words)):
+                    words[i] = acc[i]
+                calls[0] += 1
+
+            group = hg.Group.external(reduce, world)
+            out = hg.ProofBuffer()
+            got = hg.prove_resident_mode_sharded(ctx, pk, vals, out, 3, rank, group).bytes()
+            assert got == ref, "rank %d: the two-process round-by-round proof (n=%d) differs from the CPU oracle's mode-3 proof" % (rank, n)
+            assert calls[0] == int(out.timings()["replay_ms"]) > 100, (calls[0], out.timings())
+            vals.free(); pk.free()
+        dist.barrier()
+        print("rank %d PROVE_SEQ OK (%d all-reduces for the last proof)" % (rank, calls[0]), flush=True)
+        ctx.close()
     else:
         raise SystemExit("unknown mode")
     dist.destroy_process_group()

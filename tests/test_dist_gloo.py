@@ -66,3 +66,12 @@ def test_sharded_prove_two_processes_per_rank_tables_at_the_headline_size():
     out = _launch([os.path.join(ROOT, "tests", "dist_worker.py"), "prove_c3"], 29523, 1500)
     assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-3000:])
     assert out.stdout.count("PROVE_C3 OK") == 2, out.stdout
+
+
+@pytest.mark.gpu
+def test_round_by_round_prover_two_processes_one_allreduce_per_round():
+    """SURVEY 8(e)'s per-round exchange across two real processes (tests/dist_worker.py "prove_seq"): mode 3, the round sums
+    all-reduced over gloo once per sum-check round, both ranks reproduce the oracle's mode-3 transcript."""
+    out = _launch([os.path.join(ROOT, "tests", "dist_worker.py"), "prove_seq"], 29525, 900)
+    assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-3000:])
+    assert out.stdout.count("PROVE_SEQ OK") == 2, out.stdout

@@ -338,6 +338,102 @@ def test_protocol_modes_bit_exact_against_the_oracle(ctx, n, k, bits, mode):
     pk.free()
 
 
+_SHARDED_SEQ_CODE = r"""
+import sys, threading
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+import __graft_entry__ as entry
+import orclib
+hg = entry.load_package()
+n, k, world, mode = %(n)d, %(k)d, %(world)d, %(mode)d
+bfv = hg.BfvEncrypt.new(n, k)
+w = hg.Witness.synthetic(bfv.params, 400 + n + mode)
+ref, _ = orclib.prove_f("goldilocks", orclib.params(n, k), orclib.Inputs(w.arrays()), threads=8, mode=mode)
+group = hg.Group.local(world)
+results, errs = [None] * world, []
+def run(r):
+    try:
+        c = hg.Context(0)
+        c.set_option("seq_max_blocks", 128)   # the ranks share one device: a round kernel waits ON the device for its challenge (hg.h)
+        pk = bfv.setup(c)
+        v = hg.witness_gen(c, pk, w)
+        out = hg.ProofBuffer()
+        hg.prove_resident_mode_sharded(c, pk, v, out, mode, r, group)
+        results[r] = (out.bytes(), out.timings())
+        v.free(); pk.free()
+    except Exception as e:   # (a failed rank breaks the group: the others return an error instead of waiting for ever)
+        errs.append((r, repr(e)))
+ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+for t in ts: t.start()
+for t in ts: t.join(300)
+assert not errs, errs
+for r in range(world):
+    assert results[r] is not None and results[r][0] == ref, r
+n_red = [int(results[r][1]["replay_ms"]) for r in range(world)]
+trips = [int(results[r][1]["enqueue_ms"]) for r in range(world)]
+assert len(set(n_red)) == 1 and n_red[0] > 100, n_red   # the same rounds on every rank
+assert all(nr <= t for nr, t in zip(n_red, trips)), (n_red, trips)   # every all-reduce rides on a mailbox round trip
+# world = 1 through the same entry point is the plain prover; mode 0 shards per proof, not per round
+c = hg.Context(0); pk = bfv.setup(c); v = hg.witness_gen(c, pk, w); out = hg.ProofBuffer()
+assert hg.prove_resident_mode_sharded(c, pk, v, out, mode, 0, hg.Group.local(1)).bytes() == ref
+assert int(out.timings()["replay_ms"]) == 0
+try:
+    hg.prove_resident_mode_sharded(c, pk, v, out, 0, 0, hg.Group.local(2))
+    raise SystemExit("mode 0 accepted")
+except hg.HgError:
+    pass
+print("SHARDED SEQ OK mode %%d n=%%d world=%%d: %%d all-reduces, %%d mailbox round trips per rank" %% (mode, n, world, n_red[0], trips[0]))
+"""
+
+
+@pytest.mark.parametrize("n,k,world,mode", [(1024, 1, 2, 3), (4096, 2, 3, 3), (4096, 2, 4, 1), (4096, 2, 2, 2)])
+def test_sharded_round_by_round_prover_one_allreduce_per_round(n, k, world, mode):
+    """SURVEY 8(e), the form that stays available for an absorbing transcript: `world` ranks (threads of one process, one context
+    each, all on device 0: hg_group_local) run hg_prove_resident_mode_sharded; inside every round kernel a rank evaluates the sums of
+    its tiles only, the group adds the partial sums once per round, every transcript absorbs the same message. Every rank's proof must
+    be the oracle's proof of that mode byte for byte - one wrong partial sum changes every later challenge - and the number of
+    all-reduces is the number of rounds the device ran. Child process: ranks that share a device must not share a hardware queue
+    either (a round kernel waiting for its challenge would hold back the round of the rank it waits for), so the HIP runtime is
+    given one queue per stream (GPU_MAX_HW_QUEUES, read when the runtime starts)."""
+    import subprocess, sys
+    from hglib import ROOT
+    code = _SHARDED_SEQ_CODE % dict(root=ROOT, tests=os.path.join(ROOT, "tests"), n=n, k=k, world=world, mode=mode)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, GPU_MAX_HW_QUEUES="24"), cwd=ROOT)
+    assert r.returncode == 0 and "SHARDED SEQ OK" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
+    print(r.stdout.strip().splitlines()[-1])
+
+
+def test_sharded_round_by_round_prover_at_the_headline_size():
+    """The same at n=32768 k=16, mode 3, two ranks: bit-exact against the single-rank prove."""
+    import threading
+    n, k, world, mode = 32768, 16, 2, 3
+    bfv = hg.BfvEncrypt.new(n, k)
+    w = hg.Witness.synthetic(bfv.params, 0x4752454330 + n)
+    c0 = hg.Context(0); pk0 = bfv.setup(c0); v0 = hg.witness_gen(c0, pk0, w); out0 = hg.ProofBuffer()
+    ref = hg.prove_resident_mode(c0, pk0, v0, out0, mode).bytes()
+    group = hg.Group.local(world)
+    results, errs = [None] * world, []
+
+    def run(r):
+        try:
+            c = c0 if r == 0 else hg.Context(0)
+            c.set_option("seq_max_blocks", 256)   # (two ranks on one device: hg.h)
+            pk = pk0 if r == 0 else bfv.setup(c)
+            v = v0 if r == 0 else hg.witness_gen(c, pk, w)
+            out = hg.ProofBuffer()
+            hg.prove_resident_mode_sharded(c, pk, v, out, mode, r, group)
+            results[r] = (out.bytes(), out.timings())
+        except Exception as e:
+            errs.append((r, repr(e)))
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ts: t.start()
+    for t in ts: t.join(600)
+    assert not errs, errs
+    assert results[0][0] == ref and results[1][0] == ref
+    print("mode 3 n=32768 k=16, 2 ranks on one GPU: %.1f / %.1f ms, %d all-reduces" % (results[0][1]["prove_ms"], results[1][1]["prove_ms"], int(results[0][1]["replay_ms"])))
+    pk0.free()
+
+
 def test_strict_memory_model_build_is_bit_exact():
     """build/strict/libhypergreco.so (-DHG_STRICT_TICKETS: acq_rel tickets, the form every architecture other than gfx942 / gfx950 must
     use; built by __graft_entry__.build()) proves the same bytes as the oracle - plain launches, graph replays, a sharded proof and

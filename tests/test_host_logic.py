@@ -265,7 +265,7 @@ def test_bn254_host_verifier_agrees_with_the_oracle():
 
 # ---- Rust shim crate (rust/hg-shim): the FFI block must mirror include/hg.h signature by signature -------------------------
 _C2RUST = {"int": "c_int", "uint32_t": "u32", "uint64_t": "u64", "int64_t": "i64", "size_t": "usize", "double": "f64", "uint8_t": "u8",
-           "char": "c_char", "void": "c_void", "hg_ctx": "HgCtx", "hg_pk": "HgPk", "hg_witness": "HgWitness", "hg_values": "HgValues",
+           "char": "c_char", "void": "c_void", "hg_ctx": "HgCtx", "hg_pk": "HgPk", "hg_witness": "HgWitness", "hg_values": "HgValues", "hg_group": "HgGroup",
            "hg_params": "HgParams", "hg_timings": "HgTimings", "hg_kernel_stat": "HgKernelStat"}
 
 
