@@ -133,7 +133,6 @@ int hg_set_option(hg_ctx* ctx, const char* name, int64_t value) {
     const std::string n(name);
     if (n == "one_stream") { if (ctx->one_stream != (value != 0)) ctx->walk_counts.clear(); ctx->one_stream = value != 0; }
     else if (n == "graph") { ctx->use_graph = value != 0; if (!ctx->use_graph) prove_cache_drop(ctx); }
-    else if (n == "seq_max_blocks") { if (value < 1 || value > 1024) throw Error("hg_set_option: seq_max_blocks must be 1..1024"); ctx->seq_max_blocks = (int)value; }
     else throw Error("hg_set_option: unknown option " + n);
     return 0;
     HG_CATCH(-1)

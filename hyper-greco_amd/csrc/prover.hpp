@@ -21,7 +21,6 @@ struct hg_ctx {
     int device = 0;
     hipStream_t stream = nullptr;   // Lasso node + everything sequential
     hipStream_t bn_stream_hi = nullptr, bn_stream_lo = nullptr;   // BN254 prove only (bn254_gkr.inc: BnStreams), created on first use
-    int seq_max_blocks = 1024;      // hg_set_option "seq_max_blocks": workgroups per round kernel of the round-by-round prover
     hipStream_t stream2 = nullptr;  // Vanilla / FFT node reductions (independent of the Lasso node on the device)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_aux[4] = {nullptr, nullptr, nullptr, nullptr};  // Lasso node: limbs done (stream -> stream2), grand product #2 levels done (stream2 -> stream), E tables done (stream -> stream2), counters done (stream2 -> stream)

@@ -968,17 +968,22 @@ struct SeqProver {
                 return;
             }
             int jb = 0, grid = 1;
-            sq_plan(nvars - 1 - rd, J.kind == 0 ? J.ntab : J.ntab / 2, std::min(SQ_MAX_BLOCKS, ctx->seq_max_blocks), &jb, &grid);
+            sq_plan(nvars - 1 - rd, J.kind == 0 ? J.ntab : J.ntab / 2, SQ_MAX_BLOCKS, &jb, &grid);
             if (J.kind == 0) launch_round<0>(in_base, J, d_job, rd, jb, grid);
             else if (J.kind == 1) launch_round<1>(in_base, J, d_job, rd, jb, grid);
             else launch_round<2>(in_base, J, d_job, rd, jb, grid);
         };
-        while (enq < std::min(ndev + 1, 2)) enqueue_round();
+        // Sharded form: a round is launched only once the challenge of the round before has been posted, so that NO kernel ever waits
+        // on the device. A rank's host answers a round only after the all-reduce, i.e. after every other rank's round kernel has run;
+        // ranks that share a device (or a hardware queue of it: ranks as threads of one process) would otherwise wait for a kernel
+        // that cannot start behind their own waiting one. One launch latency per round: this form is bound by the all-reduce anyway.
+        const bool lockstep = shard_world > 1;
+        while (enq < std::min(ndev + 1, lockstep ? 1 : 2)) enqueue_round();
         t_enqueue_rounds += now_ms() - te0;
         for (int rd = 0; rd < ndev; rd++) {
             // answering is what the device waits for: a launch is squeezed in first only while the round's sums are not there yet
             const unsigned long long seq = J.seq0 + (unsigned long long)rd;
-            while (enq <= ndev && enq < rd + 2 * LOOKAHEAD && (enq < rd + 2 || !slots_posted(seq, 2 * J.nv))) {
+            while (enq <= ndev && (lockstep ? enq <= rd : (enq < rd + 2 * LOOKAHEAD && (enq < rd + 2 || !slots_posted(seq, 2 * J.nv))))) {
                 const double t1 = now_ms(); enqueue_round(); t_enqueue_rounds += now_ms() - t1;
             }
             const double w0 = t_wait_rounds;

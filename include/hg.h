@@ -72,10 +72,6 @@ void hg_destroy(hg_ctx* ctx);
  *                 values object the third is captured into a hipGraph and later ones replay it - the launch sequence depends on
  *                 addresses only, because every challenge is known up front; a values object refilled by hg_witness_gen_into
  *                 keeps its graph; up to HG_GRAPH_ENTRIES (8) graphs per context, each with a private workspace)
- *   "seq_max_blocks"  workgroups per round kernel of the round-by-round prover (modes 1-3; 1..1024, default 1024). A round kernel waits
- *                 ON THE DEVICE for the challenge of the round before; ranks of a sharded prove that SHARE a device (tests with several
- *                 ranks on one GPU) must leave each other room - a device filled with one rank's waiting workgroups never runs the
- *                 round of the rank it is waiting for. One rank per device needs no cap.
  * Returns 0, or -1 for an unknown name. */
 int hg_set_option(hg_ctx* ctx, const char* name, int64_t value);
 
@@ -165,6 +161,9 @@ int hg_verify_mode(const hg_pk* pk, const hg_witness* w, int mode, const uint8_t
  *   hg_group_local(world)    ranks are threads of this process, one context each (any devices): barrier + modular sum in memory;
  *   hg_group_external(fn, user, world)   fn = int (*)(void* user, uint64_t* words, size_t n): adds `words` over the ranks in place
  *                            (e.g. an all-gather over torch.distributed / MPI followed by the modular sum) and returns 0.
+ * In this form a round kernel is launched only after the challenge of the round before has been posted (the single-rank prover
+ * launches ahead and lets the kernel wait on the device): no kernel ever waits for the host, so ranks may share a device or a
+ * hardware queue (ranks as threads of one process in the tests) without waiting for each other's waiting kernels.
  * timings->replay_ms holds the number of all-reduces of the proof. Mode 0 shards through hg_prove_sharded (one all-reduce per proof). */
 hg_group* hg_group_local(int world);
 hg_group* hg_group_external(void* reduce_fn, void* user, int world);

@@ -115,7 +115,6 @@ def main():
     elif mode == "prove_seq":
         import orclib
         ctx = hg.Context(0)
-        ctx.set_option("seq_max_blocks", 128)   # both processes share device 0: a round kernel waits on the device for its challenge (hg.h)
         for n, k in ((1024, 1), (4096, 2)):
             bfv = hg.BfvEncrypt.new(n, k)
             pk = bfv.setup(ctx)

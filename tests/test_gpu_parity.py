@@ -353,7 +353,6 @@ results, errs = [None] * world, []
 def run(r):
     try:
         c = hg.Context(0)
-        c.set_option("seq_max_blocks", 128)   # the ranks share one device: a round kernel waits ON the device for its challenge (hg.h)
         pk = bfv.setup(c)
         v = hg.witness_gen(c, pk, w)
         out = hg.ProofBuffer()
@@ -391,13 +390,12 @@ def test_sharded_round_by_round_prover_one_allreduce_per_round(n, k, world, mode
     each, all on device 0: hg_group_local) run hg_prove_resident_mode_sharded; inside every round kernel a rank evaluates the sums of
     its tiles only, the group adds the partial sums once per round, every transcript absorbs the same message. Every rank's proof must
     be the oracle's proof of that mode byte for byte - one wrong partial sum changes every later challenge - and the number of
-    all-reduces is the number of rounds the device ran. Child process: ranks that share a device must not share a hardware queue
-    either (a round kernel waiting for its challenge would hold back the round of the rank it waits for), so the HIP runtime is
-    given one queue per stream (GPU_MAX_HW_QUEUES, read when the runtime starts)."""
+    all-reduces is the number of rounds the device ran. (The ranks share the device and, as threads of one process, its hardware
+    queues: the sharded form launches a round only when its challenge is known, so no kernel waits on the device.)"""
     import subprocess, sys
     from hglib import ROOT
     code = _SHARDED_SEQ_CODE % dict(root=ROOT, tests=os.path.join(ROOT, "tests"), n=n, k=k, world=world, mode=mode)
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, GPU_MAX_HW_QUEUES="24"), cwd=ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ), cwd=ROOT)
     assert r.returncode == 0 and "SHARDED SEQ OK" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
     print(r.stdout.strip().splitlines()[-1])
 
@@ -416,7 +414,6 @@ def test_sharded_round_by_round_prover_at_the_headline_size():
     def run(r):
         try:
             c = c0 if r == 0 else hg.Context(0)
-            c.set_option("seq_max_blocks", 256)   # (two ranks on one device: hg.h)
             pk = pk0 if r == 0 else bfv.setup(c)
             v = v0 if r == 0 else hg.witness_gen(c, pk, w)
             out = hg.ProofBuffer()
