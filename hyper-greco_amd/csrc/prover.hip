@@ -1480,11 +1480,14 @@ struct Prover {
                 if (nyv) dev::dot_eq_many(st, eqy_v, tyv, nyv, M, partials, d_res());
                 stamp("claimed sum and openings done");
             };
-            // Default: the dot products behind the node reductions on the second stream, not beside grand product #1's first
-            // (bandwidth-bound) rounds - HG_LATE_OPENINGS=0: right away; 2: between the two waves of node reductions. Round 4, medians of
-            // 120 interleaved graph replays: 2.566 (0) / 2.598 (2) / 2.610 ms (1) with the eq tables still inside the late part; but
-            // placed early they push the node reductions' VALU-heavy rounds under the dominant round kernel's launches (272 instead
-            // of 240 us per launch, 0.56 instead of 0.63 of the HBM roofline inside a prove) for a difference bench.py cannot resolve.
+            // Where the openings' dot products run (HG_LATE_OPENINGS; the two eq tables above are built right away in every case).
+            // 1 (default): behind the node reductions on the second stream. 0: right away, beside the first hash round. 2: between the
+            // two waves of node reductions. Round 4, medians of 120 interleaved graph replays: 2.566 (0) / 2.598 (2) / 2.610 ms (1);
+            // bench.py with 40 steps: 2.82-2.84 (0) against 2.87-2.90 ms (1) per proof - with the shorter node bookkeeping both chains
+            // end together and 0.15 ms of openings behind them run alone. 0 is not the default because the node reductions then start
+            // 0.5 ms later and their VALU-heavy first rounds share the GPU with all of the dominant round kernel's launches: 265-277
+            // instead of 246-261 us per launch, 0.55-0.57 instead of 0.58-0.61 of the HBM roofline inside a prove (0.74 isolated either
+            // way) for a gain of 1.5-2 % that one bench.py run of 10 steps does not resolve.
             static const bool late = [] { const char* e = getenv("HG_LATE_OPENINGS"); return !(e && e[0] == '0'); }();
             aux(open_tables);
             if (late && use_aux) late_aux.push_back(openings);

@@ -18,7 +18,7 @@ for r in csv.DictReader(open(f)):
     if r["Counter_Name"] == "SQ_INSTS_VALU" and "hg::bn::" in r["Kernel_Name"]:
         per[r["Kernel_Name"].split("(")[0]] += float(r["Counter_Value"])
 proves = 3  # scripts/bn254_prove_bench.py runs three proves
-WITNESS_GEN = ("k_bn_ntt_stage", "k_bn_gate_eval", "k_bn_lift_signed", "k_bn_bitrev", "k_bn_scale", "k_bn_powers")  # bn_witness_gen: outside the timed prove
+WITNESS_GEN = ("k_bn_ntt_stage", "k_bn_ntt4_", "k_bn_gate_eval", "k_bn_lift_signed", "k_bn_lift_jobs", "k_bn_bitrev", "k_bn_scale", "k_bn_powers")  # bn_witness_gen: outside the timed prove
 wit = sum(v for k, v in per.items() if any(w in k for w in WITNESS_GEN))
 out = {"command": "rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES -- python3 scripts/bn254_prove_bench.py (3 proves of n=32768 k=16)",
        "valu_wave_insts_per_prove": sum(per.values()) / proves,
