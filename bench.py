@@ -703,6 +703,38 @@ def main():
                 line["sound_mode"] = {"mode": 3, "prove_ms": round(med[0], 2), "stream_synchronisations": med[1], "mailbox_round_trips": med[2],
                                       "runs_ms": [round(r[0], 2) for r in runs[1:]], "accepted_by_hg_verify_mode_3": bool(okm),
                                       "note": "hg_prove_resident_mode(.., 3): median of 3 after one warm-up; the host transcript answers every round through a pinned mailbox"}
+                # the same mode on two ranks with ONE all-reduce per sum-check round (the exchange an absorbing transcript
+                # leaves; hg_prove_resident_mode_sharded). The ranks are two threads of this process, each with its own context, BOTH on
+                # this GPU: what is shown is that the path runs here and gives the single-rank proof, not a multi-GPU time.
+                try:
+                    import threading
+                    ref3 = outm.bytes()
+                    ctx_b = hg.Context(local_rank)
+                    pk_b = bfv.setup(ctx_b)
+                    vals_b = hg.witness_gen(ctx_b, pk_b, witnesses[0])
+                    group = hg.Group.local(2)
+                    got, errs = [None, None], []
+
+                    def seq_rank(r):
+                        try:
+                            o = hg.ProofBuffer()
+                            hg.prove_resident_mode_sharded(ctx if r == 0 else ctx_b, pk if r == 0 else pk_b, vals[0] if r == 0 else vals_b, o, 3, r, group)
+                            got[r] = (o.bytes(), o.timings())
+                        except Exception as ex:
+                            errs.append(str(ex))
+
+                    for _ in range(2):
+                        ths = [threading.Thread(target=seq_rank, args=(r,)) for r in range(2)]
+                        for t in ths: t.start()
+                        for t in ths: t.join(120)
+                    line["sound_mode"]["sharded_two_ranks_one_gpu"] = (
+                        {"error": "; ".join(errs)} if errs or None in got else
+                        {"identical_to_single_rank": got[0][0] == ref3 and got[1][0] == ref3, "allreduces_per_proof": int(got[0][1]["replay_ms"]),
+                         "prove_ms_per_rank": [round(g[1]["prove_ms"], 2) for g in got],
+                         "note": "two ranks as threads on ONE GPU, in-process group (hg_group_local): every rank folds everything and evaluates half of each round's sums; one all-reduce of <= 6 words per round"})
+                    vals_b.free(); pk_b.free(); ctx_b.close()
+                except Exception as ex:
+                    line["sound_mode"]["sharded_two_ranks_one_gpu"] = {"error": str(ex)}
             except Exception as ex:
                 line["sound_mode"] = {"error": str(ex)}
         if world == 1 and not args.no_end_to_end:
