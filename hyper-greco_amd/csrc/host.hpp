@@ -74,8 +74,10 @@ struct ChallengeSource {
 
 struct ProofStream {
     std::vector<uint8_t> bytes;
+    size_t pos = (size_t)-1;   // != -1: write at this offset of the (pre-sized) buffer instead of appending (out-of-order transcript replay)
     void write_f(u64 a) {  // canonical repr, byte-reversed to big-endian (transcript.rs:183-189)
         u64 be = __builtin_bswap64(a);
+        if (pos != (size_t)-1) { memcpy(bytes.data() + pos, &be, 8); pos += 8; return; }
         size_t at = bytes.size();
         bytes.resize(at + 8);
         memcpy(bytes.data() + at, &be, 8);

@@ -1260,6 +1260,12 @@ void scatter_e2(hipStream_t st, const ScatterEnt* ents, size_t n, E2* dst_base) 
     if (n) k_scatter_e2<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(ents, n, dst_base);
 }
 
+__global__ void k_set_e2(E2* dst, E2 v) {
+    __hip_atomic_store(&dst->c1, (unsigned long long)v.c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&dst->c0, (unsigned long long)v.c0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+void set_e2(hipStream_t st, E2* dst, E2 v) { k_set_e2<<<1, 1, 0, st>>>(dst, v); }
+
 __global__ __launch_bounds__(TPB) void k_reduce_partials(const E2* __restrict__ partials, int nblocks, int nv, E2* __restrict__ out) {
     __shared__ E2 sm[TPB / 64];
     for (int v = 0; v < nv; v++) {

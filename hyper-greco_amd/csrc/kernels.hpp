@@ -146,6 +146,7 @@ void ps_tail(hipStream_t st, const PsJob* jobs, int njobs, const E2* chal, E2* r
 // dst_base[ent[i].dst] = ent[i].src[0]: moves locally produced scalars to their global result slots
 struct ScatterEnt { const E2* src; size_t dst; };
 void scatter_e2(hipStream_t st, const ScatterEnt* ents, size_t n, E2* dst_base);
+void set_e2(hipStream_t st, E2* dst, E2 v);   // *dst = v (one thread): a progress mark in the host-mapped result buffer
 void stamp(hipStream_t st, unsigned long long* slot);   // debugging aid: device wall clock at this point of the stream
 struct ClearSet { unsigned* p[3]; size_t n[3]; };   // up to three regions of 32-bit words
 void clear_words(hipStream_t st, const ClearSet& c);

@@ -248,6 +248,28 @@ struct Prover {
     ChallengeSource ch;
     ProofStream proof;
     std::vector<std::function<void()>> ops;  // transcript steps, replayed after the single synchronisation
+    // Out-of-order replay (cached launch graphs, one rank): the steps of the node reductions that do not descend from the Lasso node
+    // (55 of the 65 nodes at n=32768 k=16, two thirds of the replay's arithmetic) read only results the second stream has written by
+    // the time it raises `early_slot`, 0.15 ms before the prove ends (the Lasso node's openings follow): the host runs them while it
+    // waits, each at the byte offset the first in-order replay of this object recorded for it, and only the rest after the
+    // synchronisation. The transcript is the same sequence of bytes; only the order in which the host fills it in changes.
+    std::vector<char> op_early;      // parallel to ops
+    std::vector<size_t> op_off;      // byte offset of step i's output; op_off[ops.size()] = proof length (valid once offsets_known)
+    bool offsets_known = false, cur_early = false, early_done = false;
+    size_t early_slot = (size_t)-1;
+    void push_op(std::function<void()> f) { ops.push_back(std::move(f)); op_early.push_back(cur_early ? 1 : 0); }
+    static bool early_replay_on() { static const bool v = [] { const char* e = getenv("HG_NO_EARLY_REPLAY"); return !(e && e[0] == '1'); }(); return v; }
+    bool early_ready() const {
+        if (early_done || !offsets_known || early_slot == (size_t)-1) return false;
+        return __atomic_load_n(&ctx->h_res[early_slot].c0, __ATOMIC_ACQUIRE) == 1;
+    }
+    void run_early() {
+        proof.bytes.resize(op_off[ops.size()]);
+        for (size_t i = 0; i < ops.size(); i++)
+            if (op_early[i]) { proof.pos = op_off[i]; ops[i](); }
+        proof.pos = (size_t)-1;
+        early_done = true;
+    }
     size_t res_used = 0;
     int cls_gp_hash, cls_gp_base, cls_gp_ext, cls_gp_ext2, cls_col_ext2, cls_col_base, cls_col_ext, cls_ps, cls_ps2, cls_reduce, cls_aux, cls_tree, cls_hash, cls_gather, cls_tail, cls_ps_tail;
 
@@ -723,7 +745,7 @@ struct Prover {
 
     // transcript side of prove_sum_check: d+1 coefficients per round, eval(1) derived from the running claim
     void defer_sumcheck(const ScHandle& h, int deg, Cell claim_in, Cell claim_out) {
-        ops.push_back([this, h, deg, claim_in, claim_out] {
+        push_op([this, h, deg, claim_in, claim_out] {
             E2 claim = *claim_in;
             if (h.scaled)   // mirrored grand product: the kernels summed everything but the common factor 1 + kappa
                 for (size_t q = 0; q < (size_t)h.nvars * h.nv; q++) ctx->h_res[h.sums_slot + q] = e2_mul(ctx->h_res[h.sums_slot + q], h.scale);
@@ -751,7 +773,7 @@ struct Prover {
         const E2 ginv = e2_inv(pw.v[1]);  // pw[b] = gamma^b
         E2 w = ginv;
         for (int b = 1; b < nb; b++) { (*winv)[b] = w; w = e2_mul(w, ginv); }
-        ops.push_back([this, evals_slot, nb, winv] {
+        push_op([this, evals_slot, nb, winv] {
             for (int b = 1; b < nb; b++) ctx->h_res[evals_slot + 2 * b] = e2_mul(ctx->h_res[evals_slot + 2 * b], (*winv)[b]);
         });
     }
@@ -759,10 +781,10 @@ struct Prover {
     // Rust reference (scripts/proof_diff.py) - each label names the convention that decides those bytes
     std::vector<std::pair<size_t, std::string>> proof_map;
     void mark(const std::string& label) {
-        if (getenv("HG_PROOF_MAP")) ops.push_back([this, label] { proof_map.push_back({proof.bytes.size(), label}); });
+        if (getenv("HG_PROOF_MAP")) push_op([this, label] { proof_map.push_back({proof.bytes.size(), label}); });
     }
     void defer_write_slots(size_t s, size_t n) {
-        ops.push_back([this, s, n] { for (size_t i = 0; i < n; i++) proof.write_e(h_res()[s + i]); });
+        push_op([this, s, n] { for (size_t i = 0; i < n; i++) proof.write_e(h_res()[s + i]); });
     }
 
     // ---- batched bookkeeping kernels (eq tables, zkCNN DFT rows, Libra gathers) ------------------------
@@ -941,11 +963,11 @@ struct Prover {
             }
         auto claims = std::make_shared<std::vector<E2>>(nb);
         mark("grand product: " + std::to_string(nb) + " root products (prover.rs:197-221)");
-        ops.push_back([this, roots, nb, claims] {  // root products (prover.rs:197-221)
+        push_op([this, roots, nb, claims] {  // root products (prover.rs:197-221)
             for (int b = 0; b < nb; b++) { (*claims)[b] = h_res()[roots + b]; proof.write_e((*claims)[b]); }
         });
         auto layer_down = [this, claims, nb](size_t evals_slot, E2 mu) {  // prover.rs:288-294
-            ops.push_back([this, claims, nb, evals_slot, mu] {
+            push_op([this, claims, nb, evals_slot, mu] {
                 const E2* ev = h_res() + evals_slot;
                 for (int b = 0; b < nb; b++) (*claims)[b] = e2_add(ev[2 * b], e2_mul(mu, e2_sub(ev[2 * b + 1], ev[2 * b])));
             });
@@ -966,7 +988,7 @@ struct Prover {
             E2 g = e2_one();
             for (int b = 0; b < nb; b++) { pw.v[b] = g; g = e2_mul(g, gamma); }
             Cell claim = cell();
-            ops.push_back([claims, nb, pw, claim] {  // sum_check_claim (prover.rs:281-286)
+            push_op([claims, nb, pw, claim] {  // sum_check_claim (prover.rs:281-286)
                 E2 c = e2_zero();
                 for (int b = 0; b < nb; b++) c = e2_add(c, e2_mul((*claims)[b], pw.v[b]));
                 *claim = c;
@@ -1036,7 +1058,7 @@ struct Prover {
             if (mirrored) {   // the write rows' evaluations: folding is affine with coefficients summing to one, so row + c stays row + c
                 const u64 c = *mirror_c;
                 const int G2 = nb / 2;
-                ops.push_back([this, evals, G2, c] {
+                push_op([this, evals, G2, c] {
                     for (int b = 0; b < G2; b++)
                         for (int t = 0; t < 2; t++) ctx->h_res[evals + 2 * (size_t)(G2 + b) + t] = e2_add_f(ctx->h_res[evals + 2 * (size_t)b + t], c);
                 });
@@ -1194,7 +1216,7 @@ struct Prover {
         });
         Cell claimed = cell();
         mark("lasso: claimed sum (lasso.rs:100-107)");
-        ops.push_back([this, claim_slot, claimed] { *claimed = h_res()[claim_slot]; proof.write_e(*claimed); });
+        push_op([this, claim_slot, claimed] { *claimed = h_res()[claim_slot]; proof.write_e(*claimed); });
         {   // collation sum-check (lasso.rs:271-279): g = poly(0) * sum_i M^i poly(i). Only the SUM enters the round polynomials and the
             // final evaluations are dropped (lasso.rs:97), so the sum-check runs on two tables: E_0 (supplies p_0, not summed) and
             // C = sum_i M^i E_i, written by the limb split (folding is linear: fold(C) = sum_i M^i fold(E_i)). Sharded: every rank's C
@@ -1519,7 +1541,7 @@ struct Prover {
         Cell v = cell();
         std::vector<Cell> vals;
         for (auto& c : cl) vals.push_back(c.value);
-        ops.push_back([v, vals, alphas] {
+        push_op([v, vals, alphas] {
             E2 s = e2_zero();
             for (size_t a = 0; a < vals.size(); a++) s = e2_add(s, e2_mul(*vals[a], alphas[a]));
             *v = s;
@@ -1547,7 +1569,7 @@ struct Prover {
                 int grid = dev::vanilla_const_sum(st, ndp0->const_gate, ndp0->const_coef, ndp0->nconst, eqc, np0->log2_sub_out, np0->log2_reps, partials);
                 reduce(grid, 1, s);
             });
-            ops.push_back([this, s, claim] { *claim = e2_sub(*claim, h_res()[s]); });
+            push_op([this, s, claim] { *claim = e2_sub(*claim, h_res()[s]); });
         }
         // phase 1: sum_x sum_i in_i(x) T_i(x)
         std::vector<int> li, ri;
@@ -1592,7 +1614,7 @@ struct Prover {
             defer_write_slots(u_base + i, 1);
             Cell v = cell();
             size_t sl = u_base + i;
-            ops.push_back([this, v, sl] { *v = h_res()[sl]; });
+            push_op([this, v, sl] { *v = h_res()[sl]; });
             claims[n.preds[i]].push_back(ClaimRef{s1.point_off, nin, v});
         }
         if (!n.mul.empty()) {
@@ -1644,7 +1666,7 @@ struct Prover {
                 defer_write_slots(w_base + i, 1);
                 Cell v = cell();
                 size_t sl = w_base + i;
-                ops.push_back([this, v, sl] { *v = h_res()[sl]; });
+                push_op([this, v, sl] { *v = h_res()[sl]; });
                 claims[n.preds[i]].push_back(ClaimRef{s2.point_off, nin, v});
             }
         }
@@ -1670,7 +1692,7 @@ struct Prover {
         mark("fft node " + std::to_string(id) + ": input evaluation");
         defer_write_slots(u, 1);
         Cell v = cell();
-        ops.push_back([this, v, u] { *v = h_res()[u]; });
+        push_op([this, v, u] { *v = h_res()[u]; });
         claims[n.preds[0]].push_back(ClaimRef{s.point_off, L, v});
     }
 
@@ -1717,9 +1739,22 @@ struct Prover {
         claims[c.lasso_id].push_back(ClaimRef{epos(), 0, cell()});  // EvalClaim::new(vec![], E::ZERO) (:450)
         claims[c.sum_id].push_back(sum_claim);
         record_fork();
+        // nodes whose claims descend from the Lasso node (the node itself and, transitively, its predecessors): their transcript steps
+        // wait for the Lasso node's results; every other node's steps can be replayed as soon as the node reductions are done
+        std::vector<char> lasso_cone(c.nodes.size(), 0);
+        {
+            std::vector<int> stack{c.lasso_id};
+            lasso_cone[c.lasso_id] = 1;
+            while (!stack.empty()) {
+                const int u = stack.back(); stack.pop_back();
+                for (int pr : c.nodes[u].preds) if (!lasso_cone[pr]) { lasso_cone[pr] = 1; stack.push_back(pr); }
+            }
+        }
+        const bool early_ok = world == 1 && fork_recorded && early_replay_on();
         for (size_t q = c.topo.size(); q-- > 0;) {
             int id = c.topo[q];
             const HNode& n = c.nodes[id];
+            cur_early = early_ok && !lasso_cone[id];
             switch (n.kind) {
                 case NK_INPUT: break;
                 case NK_VANILLA: vanilla_node(id); break;
@@ -1731,6 +1766,7 @@ struct Prover {
                 }
             }
         }
+        cur_early = false;
         // The Vanilla / FFT node reductions go to the second stream: they are independent of the Lasso node on the
         // device and consist mostly of small launches that leave CUs idle, so the two streams overlap.
         fork_nodes_stream();
@@ -1747,6 +1783,10 @@ struct Prover {
         flush_bookkeeping();
         flush_prodsum();
         stamp("node reductions done");
+        if (early_ok) {   // every result an early transcript step reads is in the buffer: tell the host (out-of-order replay, see `ops`)
+            early_slot = slot(1);
+            dev::set_e2(st, d_res() + early_slot, e2(1, 0));
+        }
         for (auto& f : late_aux) f();          // the Lasso node's openings (lasso_node)
         late_aux.clear();
         join_nodes_stream();
@@ -1784,6 +1824,7 @@ struct Prover {
             hipError_t q = hipEventQuery(ctx->ev_join);
             if (q == hipSuccess) break;
             if (q != hipErrorNotReady) hip_check(q, "prove: event query");
+            if (early_ready()) run_early();   // (the node reductions are done, the Lasso node's last launches are not)
             if (wall_ms() - t_spin > 2000.0) { hip_check(hipStreamSynchronize(st), "prove: stream sync"); break; }
         }
         hip_check(hipGetLastError(), "prove: kernel launch");
@@ -1793,7 +1834,22 @@ struct Prover {
     void replay() {
         double t = wall_ms();
         proof.bytes.reserve((size_t)1 << 18);
-        for (auto& op : ops) op();
+        const size_t nops = ops.size();
+        if (early_done) {   // the early steps are in place: the rest, each at its recorded offset
+            for (size_t i = 0; i < nops; i++)
+                if (!op_early[i]) { proof.pos = op_off[i]; ops[i](); }
+            proof.pos = (size_t)-1;
+            early_done = false;
+        } else {
+            const bool rec = !offsets_known;
+            if (rec) op_off.assign(nops + 1, 0);
+            for (size_t i = 0; i < nops; i++) {
+                if (rec) op_off[i] = proof.bytes.size();
+                else if (op_off[i] != proof.bytes.size()) throw Error("transcript replay: a step's output moved (its length depends on the witness?)");
+                ops[i]();
+            }
+            if (rec) { op_off[nops] = proof.bytes.size(); offsets_known = true; }
+        }
         if (const char* path = getenv("HG_PROOF_MAP")) {
             if (FILE* f = fopen(path, "w")) {
                 for (auto& m : proof_map) fprintf(f, "%zu\t%s\n", m.first, m.second.c_str());
@@ -2047,7 +2103,9 @@ static void enqueue_prove(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, Prov
         dev::dot_eq(ctx->stream, eq, tabs, 1, (size_t)1 << ov, ctx->d_partials, P->d_res() + vslot);
     }
     Cell out_value = cell();
-    P->ops.push_back([P, out_value, vslot] { *out_value = P->h_res()[vslot]; });
+    P->cur_early = world == 1 && Prover::early_replay_on();   // (its slot is written ahead of the fork of the second stream)
+    P->push_op([P, out_value, vslot] { *out_value = P->h_res()[vslot]; });
+    P->cur_early = false;
     P->gkr(ClaimRef{point_off, ov, out_value});
     if (world > 1) {
         if (hinted && P->res_used > ctx->res_hint) throw Error("sharded prove: the result buffer grew between two proves of one key");
@@ -2173,6 +2231,13 @@ static bool graph_allowed(const hg_ctx* ctx) {
 // the launch alone (nothing waits): ev_a, the graph, [the collective], ev_b on the prover stream
 static void cache_launch(hg_ctx* ctx, ProveCache* C, bool exchange) {
     hip_check(hipSetDevice(ctx->device), "hipSetDevice");
+    {   // a fresh transcript; the early-replay flag of this graph's prove back to "not yet"
+        Prover* P = C->P.get();
+        P->proof.bytes.clear();
+        P->proof_map.clear();
+        P->early_done = false;
+        if (P->early_slot != (size_t)-1) __atomic_store_n(&ctx->h_res[P->early_slot].c0, (u64)0, __ATOMIC_RELEASE);
+    }
     hip_check(hipEventRecord(C->ev_a, ctx->stream), "event record");
     static const bool time_launch = getenv("HG_TIME_LAUNCH") != nullptr;   // (debugging aid: host time of the graph launch call)
     const double tl0 = time_launch ? wall_ms() : 0;
@@ -2198,8 +2263,6 @@ static ProveResult prove_from_cache(hg_ctx* ctx, ProveCache* C, bool exchange = 
         if (gms > factor * C->walk_gpu_ms + 0.1f) C->slow_replays++;
         if (C->replays == 4 && C->slow_replays >= 3) { ctx->slow_graph_serial = C->pk_serial; ctx->slow_graph_share = C->rank * 65536 + C->world; }
     }
-    P->proof.bytes.clear();
-    P->proof_map.clear();
     res.gpu_ms = gms;
     if (!replay_now) { res.prove_ms = wall_ms() - t0; res.enqueue_ms = P->t_enqueued - t0; return res; }   // caller-side exchange first (hg_prove_shard_*)
     P->replay();
@@ -2521,7 +2584,7 @@ void sumcheck_on_tables(hg_ctx* ctx, SumcheckIO& io) {
     P.defer_sumcheck(h, deg, claim, out);
     if (io.kind == 0) {  // collation kernels leave the final evaluation of table i multiplied by M^i (pw[i])
         std::vector<E2> w = io.pw;
-        P.ops.push_back([ctx, evals, ntab, w] {
+        P.push_op([ctx, evals, ntab, w] {
             for (int i = 0; i < ntab && i < (int)w.size(); i++) ctx->h_res[evals + i] = e2_mul(ctx->h_res[evals + i], e2_inv(w[i]));
         });
     }
