@@ -1520,6 +1520,9 @@ struct Prover {
     }
 
     // ---- GKR driver ----------------------------------------------------------------------------
+    std::map<std::pair<size_t, int>, E2*> eq_shared;             // (point, variables) -> eq table of a single unit-weight claim
+    std::map<std::tuple<size_t, int, int>, E2*> fft_shared;      // (point, log2 size, inverse) -> DFT-row table of a single claim
+    static bool share_tables() { static const bool v = [] { const char* e = getenv("HG_NO_TABLE_SHARE"); return !(e && e[0] == '1'); }(); return v; }
     std::vector<const u64*> d_vals;               // node values in HBM
     std::vector<std::vector<ClaimRef>> claims;    // per node
 
@@ -1559,8 +1562,20 @@ struct Prover {
         for (auto& c : claims[id]) if (c.len != n.log2_out()) throw Error("gkr: claim arity mismatch");
         Cell claim = combined_value(claims[id], alphas);
         const bool own = mine(node_owner[id]);
-        E2* eqc = own ? ctx->alloc_n<E2>((size_t)1 << n.log2_out()) : nullptr;
-        if (own) queue_eq(eqc, n.log2_out(), cs);
+        // Nodes that received their only claim from the same sum-check share the point (every input of a Vanilla node is opened at the
+        // node's r_x: the five inputs of the final sum, the eight chunk nodes behind the Lasso input ...): one eq table serves them all
+        // (read-only everywhere). HG_NO_TABLE_SHARE=1: one table per node.
+        E2* eqc = nullptr;
+        if (own) {
+            const std::pair<size_t, int> key{cs.point_off[0], n.log2_out()};
+            auto hit = cs.n == 1 && share_tables() ? eq_shared.find(key) : eq_shared.end();
+            if (hit != eq_shared.end()) eqc = hit->second;
+            else {
+                eqc = ctx->alloc_n<E2>((size_t)1 << n.log2_out());
+                queue_eq(eqc, n.log2_out(), cs);
+                if (cs.n == 1) eq_shared[key] = eqc;
+            }
+        }
         const hg_pk::NodeDev* ndp0 = &nd;
         const HNode* np0 = &n;
         if (nd.nconst) {  // claim -= sum_g eqc[g] * w0_g
@@ -1680,10 +1695,21 @@ struct Prover {
         dev::ClaimSet cs = claim_set(claims[id], &alphas);
         Cell claim = combined_value(claims[id], alphas);
         const bool own = mine(node_owner[id]);
-        E2* F = own ? ctx->alloc_n<E2>(N) : nullptr;
+        // (the sixteen inverse-FFT nodes behind sai_par are all opened at sai_par's r_x: one DFT-row table)
+        E2* F = nullptr;
+        bool F_shared = false;
+        if (own) {
+            const std::tuple<size_t, int, int> key{claims[id].size() == 1 ? claims[id][0].point_off : (size_t)-1, L, n.inverse ? 1 : 0};
+            auto hit = claims[id].size() == 1 && share_tables() ? fft_shared.find(key) : fft_shared.end();
+            if (hit != fft_shared.end()) { F = hit->second; F_shared = true; }
+            else {
+                F = ctx->alloc_n<E2>(N);
+                if (claims[id].size() == 1) fft_shared[key] = F;
+            }
+        }
         const u64* W = (n.inverse ? pk->w_inv : pk->w_fwd).at(L);
         u64 scale = n.inverse ? gl_inv(gl_from_u64(N)) : 1;
-        if (own) fft_queue.push_back(dev::FftJob{F, W, scale, L, cs});
+        if (own && !F_shared) fft_queue.push_back(dev::FftJob{F, W, scale, L, cs});
         size_t u = slot(1);
         E2* scratch = own ? ctx->alloc_n<E2>(1) : nullptr;
         ScHandle s = sc_prodsum({d_vals[n.preds[0]]}, {F}, L, {d_res() + u}, {scratch}, own);
