@@ -2012,6 +2012,93 @@ void dot_eq_many(hipStream_t st, const E2* eq, const DotTabs& tabs, int ntab, si
     else k_dot_eq<false><<<dim3(gx, (ntab + 7) / 8), TPB, 0, st>>>(eq, tabs, ntab, n, partials, V);
     k_dot_reduce<<<ntab, TPB, 0, st>>>(partials, gx, ntab, tabs, out);
 }
+struct OpenPlan { int nmat, nvirt; short mat[DOT_MAX], virt[DOT_MAX]; };
+constexpr int OPEN_ACT = 8;
+__global__ __launch_bounds__(TPB) void k_open_x(const E2* __restrict__ eq, DotTabs tabs, OpenPlan P, int ntab_all, size_t n, size_t chunk,
+                                                E2* __restrict__ partials, DotVirt V) {
+    __shared__ E2 sm[TPB / 64];
+    __shared__ int s_act[OPEN_ACT];
+    __shared__ int s_nact, s_l;
+    const size_t row0 = (size_t)blockIdx.x * chunk, row1 = row0 + chunk < n ? row0 + chunk : n;
+    const int ngm = (P.nmat + 7) / 8;
+    E2 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) acc[t] = e2_zero();
+    if ((int)blockIdx.y < ngm) {   // a group of materialised tables
+        const int t0 = blockIdx.y * 8;
+        const int nt = P.nmat - t0 < 8 ? P.nmat - t0 : 8;
+        for (size_t j = row0 + threadIdx.x; j < row1; j += TPB) {
+            const E2 e = eq[j];
+#pragma unroll
+            for (int t = 0; t < 8; t++)
+                if (t < nt) acc[t] = e2_add(acc[t], e2_mul_f(e, tabs.t[P.mat[t0 + t]][j]));
+        }
+#pragma unroll
+        for (int t = 0; t < 8; t++)
+            if (t < nt) {
+                const E2 s = block_sum(acc[t], sm);
+                if (threadIdx.x == 0) partials[(size_t)blockIdx.x * ntab_all + P.mat[t0 + t]] = s;
+            }
+        return;
+    }
+    // the recomputed E tables: the rows of this workgroup belong to one lookup
+    if (threadIdx.x == 0) {
+        int nact = 0, l = 0;
+        if (row0 < V.rows) {
+            l = V.seg_lookup[row0 >> V.seg_shift];
+            const u64 uses = V.lookup_uses[l];
+            for (int m = 0; m < 32; m++)
+                if (((uses >> m) & 1) && nact < OPEN_ACT) s_act[nact++] = m;
+        }
+        s_nact = nact; s_l = l;
+    }
+    __syncthreads();
+    const int nact = s_nact;
+    const u64 mask = V.lookup_mask[s_l];
+    int sh[OPEN_ACT];
+    u32 cut[OPEN_ACT];
+#pragma unroll
+    for (int k = 0; k < OPEN_ACT; k++) { const int m = k < nact ? s_act[k] : 0; sh[k] = 16 * V.mem_dim[m]; cut[k] = k < nact ? V.mem_cutoff[m] : 0u; }
+    const size_t rend = row1 < V.rows ? row1 : V.rows;
+    for (size_t j = row0 + threadIdx.x; j < rend; j += TPB) {
+        const E2 e = eq[j];
+        const u64 v = V.input[j] & mask;
+#pragma unroll
+        for (int k = 0; k < OPEN_ACT; k++) {
+            const u32 a = (u32)(v >> sh[k]) & 0xFFFF;
+            if (a && a < cut[k]) acc[k] = e2_add(acc[k], e2(gl_mul_small(e.c0, a), gl_mul_small(e.c1, a)));
+        }
+    }
+    E2 sum[OPEN_ACT];
+#pragma unroll
+    for (int k = 0; k < OPEN_ACT; k++) sum[k] = k < nact ? block_sum(acc[k], sm) : e2_zero();   // (nact is uniform: the barriers inside match)
+    if (threadIdx.x == 0)
+        for (int i = 0; i < P.nvirt; i++) {
+            const int vi = P.virt[i], m = tabs.emem[vi];
+            E2 val = e2_zero();
+#pragma unroll
+            for (int k = 0; k < OPEN_ACT; k++) if (k < nact && s_act[k] == m) val = sum[k];
+            partials[(size_t)blockIdx.x * ntab_all + vi] = val;
+        }
+}
+bool open_x(hipStream_t st, const E2* eq, const DotTabs& tabs, int ntab, size_t n, E2* partials, E2* out, const DotVirt& virt) {
+    static const bool off = [] { const char* e = getenv("HG_OPEN_GROUPS"); return e && e[0] == '1'; }();   // HG_OPEN_GROUPS=1: dot_eq_many's groups of eight
+    if (off || ntab <= 0 || ntab > DOT_MAX) return false;
+    const int gx = grid_for((n + 1) / 2);
+    if (n % (size_t)gx) return false;
+    const size_t chunk = n / (size_t)gx;
+    if ((chunk & (chunk - 1)) || chunk > ((size_t)1 << virt.seg_shift)) return false;
+    for (int l = 0; l < 32; l++) if (__builtin_popcountll(virt.lookup_uses[l]) > OPEN_ACT) return false;
+    OpenPlan P;
+    memset(&P, 0, sizeof(P));
+    for (int t = 0; t < ntab; t++) {
+        if (tabs.t[t]) P.mat[P.nmat++] = (short)t; else P.virt[P.nvirt++] = (short)t;
+    }
+    const int ngm = (P.nmat + 7) / 8;
+    k_open_x<<<dim3(gx, ngm + (P.nvirt ? 1 : 0)), TPB, 0, st>>>(eq, tabs, P, ntab, n, chunk, partials, virt);
+    k_dot_reduce<<<ntab, TPB, 0, st>>>(partials, gx, ntab, tabs, out);
+    return true;
+}
 void dot_eq(hipStream_t st, const E2* eq, const u64* const tabs[8], int ntab, size_t n, E2* partials, E2* out) {
     DotTabs d;
     memset(&d, 0, sizeof(d));

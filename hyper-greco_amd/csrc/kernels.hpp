@@ -250,6 +250,12 @@ struct DotVirt {
     u64 lookup_mask[32]; u64 lookup_uses[32]; int mem_dim[32]; u32 mem_cutoff[32];
 };
 void dot_eq_many(hipStream_t st, const E2* eq, const DotTabs& tabs, int ntab, size_t n, E2* partials, E2* out, const DotVirt* virt = nullptr);
+// The Lasso node's openings at x in their own launch shape: a workgroup walks a contiguous run of rows inside ONE lookup segment, so
+// of the alpha recomputed E tables only the few memories that lookup uses (one per chunk position) can be non-zero there - one
+// multiply-add per row and USED memory instead of one per row and memory, eq and the node input read once for all of them; the
+// materialised tables (chunk values, read counters) in groups of eight beside it. Returns false (nothing launched) when the shape
+// does not fit (rows per workgroup not a power of two inside a segment, a lookup with more than eight memories): use dot_eq_many.
+bool open_x(hipStream_t st, const E2* eq, const DotTabs& tabs, int ntab, size_t n, E2* partials, E2* out, const DotVirt& virt);
 
 // ---- Vanilla / FFT nodes ----------------------------------------------------------------------
 struct CsrLin { const u32* ptr; const u32* gate; const u64* coef; };           // per input position -> (gate, c)

@@ -1496,7 +1496,8 @@ struct Prover {
                         memcpy(dv.lookup_mask, L.lookup_mask, sizeof(dv.lookup_mask)); memcpy(dv.lookup_uses, L.lookup_uses, sizeof(dv.lookup_uses));
                         memcpy(dv.mem_dim, L.mem_dim, sizeof(dv.mem_dim)); memcpy(dv.mem_cutoff, L.mem_cutoff, sizeof(dv.mem_cutoff));
                     }
-                    dev::dot_eq_many(st, eqx_v, txv, nxv, N, partials, d_res(), lean_v ? &dv : nullptr);
+                    if (!(lean_v && dev::open_x(st, eqx_v, txv, nxv, N, partials, d_res(), dv)))
+                        dev::dot_eq_many(st, eqx_v, txv, nxv, N, partials, d_res(), lean_v ? &dv : nullptr);
                     ctx->prof_end();
                 }
                 if (nyv) dev::dot_eq_many(st, eqy_v, tyv, nyv, M, partials, d_res());
