@@ -1538,6 +1538,52 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_dot_u64_reduce(const Fr* __restri
     a = block_sum_fr(a, sm);
     if (threadIdx.x == 0) *outs.out[t] = fr_from_mont(a);
 }
+// The openings of the E tables at x: a workgroup walks `chunk` consecutive rows, all of one lookup segment, where only the (at most
+// four) memories that lookup uses have non-zero entries - one multiply-accumulate per row and USED memory, eq (32 bytes per entry)
+// read once for all of them, instead of one per row and memory in groups of four tables (k_bn_dot_u64_multi: 25 tables = 7 passes
+// over eq). partials[bx * 32 + m]; memories the segment does not use get zero.
+struct BnOpenE { const u64* ep; size_t N, rows; const uint8_t* seg_lookup; int seg_shift, nE; int nmems[32]; int mems[32][4]; int mem[32]; Fr* out[32]; };
+__global__ __launch_bounds__(BN_TPB) void k_bn_open_e(const Fr* __restrict__ eq, BnOpenE O, size_t chunk, Fr* __restrict__ partials) {
+    __shared__ Fr sm[BN_TPB];
+    const size_t row0 = (size_t)blockIdx.x * chunk;
+    const size_t row1 = row0 + chunk < O.N ? row0 + chunk : O.N;
+    int nact = 0, act[4] = {0, 0, 0, 0};
+    if (row0 < O.rows) {
+        const int l = O.seg_lookup[row0 >> O.seg_shift];
+        nact = O.nmems[l];
+        for (int k = 0; k < 4; k++) act[k] = O.mems[l][k];
+    }
+    if (threadIdx.x < 32) {   // memories this segment does not touch
+        bool used = false;
+        for (int k = 0; k < 4; k++) used = used || (k < nact && act[k] == (int)threadIdx.x);
+        if (!used) partials[(size_t)blockIdx.x * 32 + threadIdx.x] = fr_zero();
+    }
+    if (!nact) return;
+    WCol acc[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) acc[k] = wcol_zero();
+    const size_t rend = row1 < O.rows ? row1 : O.rows;
+    for (size_t j = row0 + threadIdx.x; j < rend; j += BN_TPB) {
+        const Fr e = eq[j];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (k < nact) wcol_mac_u64(acc[k], O.ep[(size_t)act[k] * O.N + j], e);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (k < nact) {   // (nact is uniform over the workgroup)
+            const Fr s = block_sum_fr(fr_to_mont(wcol_reduce(acc[k])), sm);
+            if (threadIdx.x == 0) partials[(size_t)blockIdx.x * 32 + act[k]] = s;
+        }
+}
+__global__ __launch_bounds__(BN_TPB) void k_bn_open_e_reduce(const Fr* __restrict__ partials, int nblocks, BnOpenE O) {
+    __shared__ Fr sm[BN_TPB];
+    const int m = O.mem[blockIdx.x];
+    Fr a = fr_zero();
+    for (int b = threadIdx.x; b < nblocks; b += BN_TPB) a = fr_add(a, partials[(size_t)b * 32 + m]);
+    a = block_sum_fr(a, sm);
+    if (threadIdx.x == 0) *O.out[blockIdx.x] = fr_from_mont(a);
+}
 // h(a,v,t) = a + v gamma + t gamma^2 - tau (prover.rs:44) for the reads (t) and writes (t + 1) of one memory
 struct HashK { Fr one2, gamma2x, gammasq2x, gammasq, tau;   // R^2, gamma R^2, gamma^2 R^2 (raw), gamma^2 and tau (Montgomery)
                u32 kc[32]; };                              // limbs of R, gamma R, gamma^2 R, p - tau R: fr_lin3_const (bn254_wide.hpp)
@@ -1824,12 +1870,25 @@ static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4,
                 T.t[cnt] = t; O.out[cnt] = o.dev; cnt++;
                 open_at.push_back(o.host);
             };
+            // the E tables at x go through k_bn_open_e when the launch shape fits (a workgroup's rows inside one lookup segment)
+            static const bool e_groups = [] { const char* e = getenv("HG_OPEN_GROUPS"); return e && e[0] == '1'; }();
+            const int egx = (int)std::min<size_t>((N + BN_TPB - 1) / BN_TPB, 1024);
+            const size_t echunk = N / (size_t)egx;
+            bool e_fast = !e_groups && N % (size_t)egx == 0 && (echunk & (echunk - 1)) == 0 && echunk <= ((size_t)1 << L.seg_shift) && L.alpha <= 32;
+            for (int l = 0; l < L.num_lookups && e_fast; l++) if (L.lookup_nmems[l] > 4) e_fast = false;
+            BnOpenE OE;
+            memset(&OE, 0, sizeof(OE));
             for (auto& chk : lp.chunks) {
                 const int c = chk.first;
                 add(tx, ox, nx, dims + (size_t)c * N);
                 add(tx, ox, nx, read_ts[c]);
                 add(ty, oy, ny, final_cts[c]);
-                for (int m : chk.second) add(tx, ox, nx, ep + (size_t)m * N);
+                for (int m : chk.second) {
+                    if (!e_fast) { add(tx, ox, nx, ep + (size_t)m * N); continue; }
+                    const ResRef o = res_slots(ctx, 1);
+                    OE.mem[OE.nE] = m; OE.out[OE.nE] = o.dev; OE.nE++;
+                    open_at.push_back(o.host);
+                }
             }
             auto run = [&](const Fr* e, const DotU64Tabs& T, const DotU64Out& O, int cnt, size_t n) {
                 if (!cnt) return;
@@ -1839,6 +1898,13 @@ static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4,
                 k_bn_dot_u64_reduce<<<cnt, BN_TPB, 0, st>>>(part, gx, O);
             };
             run(eqx, tx, ox, nx, N);
+            if (e_fast && OE.nE) {
+                OE.ep = ep; OE.N = N; OE.rows = L.rows; OE.seg_lookup = L.seg_lookup; OE.seg_shift = L.seg_shift;
+                for (int l = 0; l < 32; l++) { OE.nmems[l] = l < L.num_lookups ? L.lookup_nmems[l] : 0; for (int k = 0; k < 4; k++) OE.mems[l][k] = L.lookup_mems[l][k]; }
+                Fr* part = dalloc((size_t)egx * 32);
+                k_bn_open_e<<<egx, BN_TPB, 0, st>>>(eqx, OE, echunk, part);
+                k_bn_open_e_reduce<<<OE.nE, BN_TPB, 0, st>>>(part, egx, OE);
+            }
             run(eqy, ty, oy, ny, M);
         }
         if (mid && mid_at >= 3) (*mid)();
