@@ -544,7 +544,7 @@ __global__ __launch_bounds__(BN_TPB * (KIND == BN_GRANDPROD ? 3 : 2)) void k_bn_
 // takes eval(1) from the claim and computes eval(2) (convention C1), and the claim is not the sum of g for the collation sum-check of
 // the Lasso node (Expression::poly(0) stands where an eq table would, lasso.rs:457-475) nor for any node of an INVALID witness - the
 // transcript must be the reference's there too (test_bn254_invalid_witness_rejected_by_both_verifiers).
-struct PsJobDev { const Fr* t[2 * dev::PS_MAX_PAIRS]; Fr* out; Fr* part; Fr r; unsigned long long half; int npairs, gx, gy, pad; FoldK fk; };   // fk = fold_consts(r); pad bit 0: every pair has the same b table, bit 1: write its fold once per pair
+struct PsJobDev { const Fr* t[2 * dev::PS_MAX_PAIRS]; Fr* out; Fr* part; Fr r; unsigned long long half; int npairs, gx, gy, pad; unsigned long long wlo, whi; FoldK fk; };   // fk = fold_consts(r); pad bit 0: every pair has the same b table, bit 1: write its fold once per pair; bit 2: the (single) b table is zero outside the pair indices [wlo, whi), bit 3: write zeros there
 // One round of g = sum_i a_i b_i for many independent sum-checks (blockIdx.y = job). Two workgroup sets per tile (v = 0: g(0) = sum xa xb
 // and the folds of the a tables, v = 1: g(2) = sum (2 ya - xa)(2 yb - xb) and the folds of the b tables; ids 8 (2 q + v) + xcd keep a
 // tile's two workgroups on one XCD, adjacent in dispatch order, so the second reads the tables from L2): one column accumulator, one
@@ -590,6 +590,17 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_ps_round_jobs(const PsJobDev* __r
                 }
             }
             acc = lz_add(acc, lz_reduce(s));
+            continue;
+        }
+        if ((J.pad & 4) && (j < J.wlo || j >= J.whi)) {
+            // the b table is zero here (a chunk node's table covers one 2^L slice of the 2^(L+3) positions): no product, the fold of b
+            // is zero and is not even written - the next round does not look outside its (halved) window either, except behind the
+            // last shared-launch round, whose successor (the tail workgroup) reads whole tables
+            if (v == 0) {
+                const Fr* ta = J.t[0];
+                const Fr xa = lz_gload(&ta[2 * j]), ya = lz_gload(&ta[2 * j + 1]);
+                lz_gstore(&out[j], lz_fold(xa, lz_sub(ya, xa), K));
+            } else if (J.pad & 8) lz_gstore(&out[half + j], fr_zero());
             continue;
         }
         for (int i = pi; i < npairs; i += P) {

@@ -262,6 +262,8 @@ int hg_setup(hg_ctx* ctx, const hg_params* params, hg_pk** out) {
                     sg.alias = segs.size() == 1 && g.other_in < 0 && g.coef == 1 && g.lo == 0 && g.hi == S && g.goff >= 0 &&
                                (n.log2_reps == 0 || (n.log2_sub_out == n.log2_sub_in && g.goff == 0));
                     sg.alias_off = (size_t)g.goff;
+                    sg.win_lo = segs[0].lo; sg.win_hi = segs[0].hi;
+                    for (auto& q : segs) { sg.win_lo = std::min<size_t>(sg.win_lo, q.lo); sg.win_hi = std::max<size_t>(sg.win_hi, q.hi); }
                 }
             }
         }

@@ -137,7 +137,8 @@ struct hg_pk {
         std::vector<hg::dev::CsrMul> mulR;   // [arity] keyed by right operand
         // run-length form of lin + mulL per input (kernels.hpp GatherSeg), when the wiring is affine in the input position;
         // `alias`: the table IS a slice of the node's eq table (one unit-coefficient relay per position): nothing to build
-        struct Seg { const hg::dev::GatherSeg* d = nullptr; int nseg = 0; bool alias = false; size_t alias_off = 0; };
+        struct Seg { const hg::dev::GatherSeg* d = nullptr; int nseg = 0; bool alias = false; size_t alias_off = 0;
+                     size_t win_lo = 0, win_hi = 0; };   // positions outside [win_lo, win_hi) have no term: the table is zero there
         std::vector<Seg> seg;                // [arity]
         const hg::u32* const_gate = nullptr;
         const hg::u64* const_coef = nullptr;
