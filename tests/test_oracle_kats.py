@@ -518,3 +518,31 @@ def test_absorbing_transcript_depends_on_every_message():
     assert not orclib.lasso_verify_f("goldilocks", p, a, mode=0)[0]
     b, _ = orclib.lasso_prove_f("goldilocks", p, lasso_in, threads=4, mode=0)
     assert a != b and b == orclib.lasso_prove(p, lasso_in, threads=4)[0]
+
+
+def test_unused_memories_of_a_chunk_have_identical_hash_rows_inside_a_lookup_segment():
+    """The structural fact behind the next optimisation of the read / write grand product: the hash of memory m
+    at row j is h(dim_c[j], E_m[j], read_ts_c[j]) with chunk value and read counter taken per CHUNK position c = mem_dim[m]
+    (lasso.rs:317-319) and E_m[j] = 0 on every row whose lookup does not use m - so inside a lookup segment all unused memories of a
+    chunk have the same (address, value, timestamp) triples, and a lookup uses at most one memory per chunk position. Checked on the
+    reference's own witnesses (k = 1, 2, 4)."""
+    for n, k, bits in ((1024, 1, 27), (4096, 2, 55), (8192, 4, 55)):
+        p = orclib.params(n, k)
+        w = json.load(open(os.path.join(orclib.GOLDEN, f"sk_enc_{n}_{k}x{bits}_65537.json")))
+        lasso_in, _, _ = orclib.circuit_eval(p, orclib.Inputs(orclib.layout_inputs(n, k, w)))
+        P = orclib.lasso_polys(p, lasso_in)
+        A, rows, md, lm = P["A"], P["rows"], P["mem_dim"], P["lookup_mems"]
+        rl = np.array(P["row_lookup"])[:rows]
+        ep = np.array(P["e_polys"], dtype=np.uint64)[:, :rows]
+        for l, mems in enumerate(lm):
+            assert len(set(md[m] for m in mems)) == len(mems) <= 4, (l, mems)   # one memory per chunk position
+        for m in range(A):
+            unused = ~np.isin(rl, [l for l in range(len(lm)) if m in lm[l]])
+            assert not ep[m][unused].any(), (n, m)                               # E_m vanishes where m is not looked up
+        # rows come in whole segments per lookup
+        change = np.flatnonzero(np.diff(rl)) + 1
+        assert all(int(c) % n == 0 for c in change), change[:8]   # segments of 2^n_log2 = n rows
+        # distinct (chunk, used-memory-or-class) tables per segment: at most 2 per chunk position
+        per_chunk = [sum(1 for m in range(A) if md[m] == c) for c in range(4)]
+        print(f"n={n} k={k}: alpha={A}, memories per chunk position {per_chunk}, {len(change) + 1} segments: "
+              f"<= {sum(min(2, c) for c in per_chunk)} distinct read tables per segment instead of {A}")
