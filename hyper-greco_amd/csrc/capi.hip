@@ -103,6 +103,8 @@ hg_ctx* hg_create(int device_id) {
         hip_check(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate");
         hip_check(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking), "hipStreamCreate");
     }
+    hip_check(hipStreamCreateWithFlags(&c->stream_col, hipStreamNonBlocking), "hipStreamCreate");
+    hip_check(hipEventCreateWithFlags(&c->ev_col, hipEventDisableTiming), "hipEventCreate");
     hip_check(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming), "hipEventCreate");
     hip_check(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming), "hipEventCreate");
     for (auto& e : c->ev_aux) hip_check(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
@@ -117,6 +119,8 @@ hg_ctx* hg_create(int device_id) {
     hip_check(hipMalloc((void**)&c->d_partials2, dev::PARTIALS_BYTES), "hipMalloc(partials2)");
     hip_check(hipMemset(c->d_partials, 0, dev::PARTIALS_BYTES), "hipMemset(partials)");
     hip_check(hipMemset(c->d_partials2, 0, dev::PARTIALS_BYTES), "hipMemset(partials2)");
+    hip_check(hipMalloc((void**)&c->d_partials3, dev::PARTIALS_BYTES), "hipMalloc(partials3)");
+    hip_check(hipMemset(c->d_partials3, 0, dev::PARTIALS_BYTES), "hipMemset(partials3)");
     c->stage_cap = (size_t)4 << 20;
     hip_check(hipHostMalloc((void**)&c->h_stage, c->stage_cap, hipHostMallocDefault), "hipHostMalloc(staging)");
     c->ensure_chain(16384);

@@ -133,6 +133,9 @@ hg_ctx::~hg_ctx() {
     if (h_mailbox) (void)hipHostFree(h_mailbox);
     if (d_partials) (void)hipFree(d_partials);
     if (d_partials2) (void)hipFree(d_partials2);
+    if (d_partials3) (void)hipFree(d_partials3);
+    if (stream_col) { (void)hipStreamSynchronize(stream_col); (void)hipStreamDestroy(stream_col); }
+    if (ev_col) (void)hipEventDestroy(ev_col);
     if (comm) { try { hg::comm_destroy(this); } catch (...) {} }
     if (d_xchg) (void)hipFree(d_xchg);
     if (stream2) { (void)hipStreamSynchronize(stream2); (void)hipStreamDestroy(stream2); }
@@ -324,6 +327,10 @@ struct Prover {
         for (E2* pbuf : {ctx->d_partials, ctx->d_partials2}) {
             cs.p[nr] = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(pbuf) + dev::PARTIALS_E2 * sizeof(E2));
             cs.n[nr++] = dev::PARTIALS_TICKETS;
+        }
+        if (world <= 1) {   // (one rank: the third region is free for the collation stream's tickets, HG_LASSO_SCHED=3)
+            cs.p[2] = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ctx->d_partials3) + dev::PARTIALS_E2 * sizeof(E2));
+            cs.n[2] = dev::PARTIALS_TICKETS;
         }
         if (world > 1 && pk) {
             // un-owned result slots must read zero. The buffer is host memory across PCIe: clear only what a prove of this key uses
@@ -1193,12 +1200,13 @@ struct Prover {
         for (int i = 0; i < nu; i++) squeeze();
         E2* eq = (do_col || do_open) ? ctx->alloc_n<E2>(N) : nullptr;
         size_t claim_slot = slot(1);
-        // Stream assignment inside the node (two streams). Schedule 0 (default): collation on the main stream ahead of the grand
+        // Stream assignment inside the node. Schedule 3 (default since round 4, one rank): as schedule 0 with the collation rounds on
+        // a third stream (see col_third below). Schedule 0: collation on the main stream ahead of the grand
         // products, counters / grand product #2's tree / openings on the second stream. Schedule 1 (HG_LASSO_SCHED=1): the main
         // stream carries split -> counters -> grand product #1 (the longest dependent chain starts as early as possible), the claimed
         // sum and the collation sum-check run on the second stream - measured SLOWER (3.8-3.9 ms vs 3.55 ms: the second stream
         // becomes the long pole and its bandwidth-bound collation rounds slow the grand-product kernels down).
-        static const int lasso_sched = [] { const char* e = getenv("HG_LASSO_SCHED"); return e && *e ? atoi(e) : 0; }();
+        static const int lasso_sched = [] { const char* e = getenv("HG_LASSO_SCHED"); return e && *e ? atoi(e) : 3; }();
         const bool col_aux = fork_recorded && lasso_sched == 1;
         auto col_where = [&](const std::function<void()>& fn) { if (col_aux) on_aux(fn); else fn(); };
         // The claimed sum is only a result slot: with two streams it runs on the second one after grand product #2's tree (the main
@@ -1252,7 +1260,14 @@ struct Prover {
         // Schedule 2 (HG_LASSO_SCHED=2): the collation rounds follow the counters on the SECOND stream. With the two-table collation
         // (E_0 and C) they are a chain of short launches, about 0.2 ms that the main stream no longer spends ahead of grand product #1.
         const bool col_after_counters = use_aux && counters_aux && lasso_sched == 2;
-        if (use_aux && counters_aux && !col_after_counters) flush_stride();  // collation rounds first: see below
+        // Schedule 3 (default; one rank): the collation rounds - 0.2 ms of short launches whose results only the host reads - on a THIRD
+        // stream forked from the main one behind the E tables and joined to it at the end of the prove: the main stream goes from the
+        // limb split straight to the first hash round (which waits for the counters only). 2.574 -> 2.524 ms (96 replays each).
+        // (Forked from and joined to the ORIGIN stream of the capture, like the second stream: a stream forked from the second one
+        // and joined back into it sent hipStreamEndCapture into an endless recursion on a sharded rank's graph, NOTEBOOK.md.)
+        const bool col_third = use_aux && counters_aux && lasso_sched == 3 && world == 1 && fork_recorded;
+        if (col_third) on_col([&] { flush_stride(); });
+        else if (use_aux && counters_aux && !col_after_counters) flush_stride();  // collation rounds first: see below
         auto cnt_where = [&](const std::function<void()>& fn) { if (use_aux && counters_aux) on_aux(fn); else fn(); };
         bool counters_event_recorded = false;
         if (need_counters) cnt_where([&] {
@@ -1747,6 +1762,17 @@ struct Prover {
         fn();
         st = s0; partials = p0; ctx->prof_stream = s0;
     }
+    bool col_pending = false;
+    template <typename Fn> void on_col(Fn fn) {   // the collation rounds on their own stream: behind the E tables, joined at the end of the prove
+        hipStream_t s0 = st;
+        E2* p0 = partials;
+        hip_check(hipStreamWaitEvent(ctx->stream_col, ctx->ev_aux[2], 0), "collation: wait for the E tables");
+        st = ctx->stream_col; partials = ctx->d_partials3; ctx->prof_stream = st;
+        fn();
+        hip_check(hipEventRecord(ctx->ev_col, ctx->stream_col), "collation: done event");
+        st = s0; partials = p0; ctx->prof_stream = s0;
+        col_pending = true;
+    }
     std::function<void()> st_before_gp;  // flush_stride runs it once before the first grand-product launch (cross-stream wait)
     std::function<void()> st_before_gp2; // ... and this one once the sequenced first rounds of grand product #1's top layers are out
     void fork_nodes_stream() {
@@ -1755,6 +1781,7 @@ struct Prover {
         st = ctx->stream2; partials = ctx->d_partials2; ctx->prof_stream = st; forked = true;
     }
     void join_nodes_stream() {
+        if (col_pending) { hip_check(hipStreamWaitEvent(ctx->stream, ctx->ev_col, 0), "collation: join wait"); col_pending = false; }
         if (!forked) return;
         hip_check(hipEventRecord(ctx->ev_join, ctx->stream2), "join event");
         st = ctx->stream; partials = ctx->d_partials; ctx->prof_stream = st;

@@ -22,6 +22,9 @@ struct hg_ctx {
     hipStream_t stream = nullptr;   // Lasso node + everything sequential
     hipStream_t bn_stream_hi = nullptr, bn_stream_lo = nullptr;   // BN254 prove only (bn254_gkr.inc: BnStreams), created on first use
     hipStream_t stream2 = nullptr;  // Vanilla / FFT node reductions (independent of the Lasso node on the device)
+    hipStream_t stream_col = nullptr;   // HG_LASSO_SCHED=3: the collation sum-check's short launches, off the main stream (forked from and joined to it)
+    hipEvent_t ev_col = nullptr;
+    hg::E2* d_partials3 = nullptr;      // scratch of stream_col
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_aux[4] = {nullptr, nullptr, nullptr, nullptr};  // Lasso node: limbs done (stream -> stream2), grand product #2 levels done (stream2 -> stream), E tables done (stream -> stream2), counters done (stream2 -> stream)
     hipStream_t prof_stream = nullptr;  // stream the profiling events are recorded on (the one being enqueued to)
