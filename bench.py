@@ -295,8 +295,8 @@ def measure_end_to_end(hg, ctx, bfv, pk, witnesses, walked, args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--ring-degree", "--n", dest="n", type=int, default=32768)
     ap.add_argument("--crt-moduli", "--k", dest="k", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
