@@ -410,6 +410,37 @@ __global__ __launch_bounds__(256) void k_bn_weight_rows_sum(const Fr* __restrict
     }
     lz_gstore(&S[i], lz_add(acc, lz_reduce(c)));
 }
+// Slot form of the mirrored top layer (grand_product_core): row v of `rows` holds, in every segment pair, the values of one CLASS of
+// memories with identical rows there; W[v * npairs + sp] = the sum of the class members' weights, fk = fold_consts of it. Slot 0
+// is memory 0 alone (weight one: the p_0 factor of the round polynomial is its plain left table).
+__global__ __launch_bounds__(256) void k_bn_weight_slots_sum(const Fr* __restrict__ rows, size_t row_len, const Fr* __restrict__ W, const FoldK* __restrict__ fk,
+                                                            Fr* __restrict__ out, Fr* __restrict__ S, size_t h, int V, int npairs, int seg_shift) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= h) return;
+    const int sp = __builtin_amdgcn_readfirstlane((int)(i >> seg_shift));   // (a wave's 64 consecutive positions lie in one segment)
+    Fr acc = fr_zero();   // loose throughout (bn254_lazy.hpp)
+    WCol c = wcol_zero();
+    for (int v = 0; v < V; v++) {
+        const Fr x = lz_gload(&rows[(size_t)v * row_len + i]);
+        const Fr lw = v == 0 ? x : lz_fold(fr_zero(), x, fk[(size_t)v * npairs + sp].k);
+        lz_gstore(&out[(size_t)v * h + i], lw);
+        acc = lz_add(acc, lw);
+        wcol_mac(c, W[(size_t)v * npairs + sp], lz_gload(&rows[(size_t)v * row_len + h + i]));
+    }
+    lz_gstore(&S[i], lz_add(acc, lz_reduce(c)));
+}
+// After seg_shift rounds a slot table is one entry per segment pair: the per-memory tables of the remaining rounds are gathered from
+// them (left tables: weight of the memory over the weight of its class, `ratio`; right tables as they are). in: table t at in + t * npairs
+// (left of slot v: t = 2v, right: 2v + 1), out: the same layout over the G2 memories.
+__global__ void k_bn_gp_regroup(const Fr* __restrict__ in, Fr* __restrict__ out, const unsigned char* __restrict__ slot_of, const Fr* __restrict__ ratio, int G2, int npairs) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= G2 * npairs) return;
+    const int b = idx / npairs, sp = idx % npairs;
+    const int v = slot_of[idx];
+    const Fr l = in[(size_t)(2 * v) * npairs + sp], r = in[(size_t)(2 * v + 1) * npairs + sp];
+    out[(size_t)(2 * b) * npairs + sp] = b == 0 ? l : lz_mul(ratio[idx], l);
+    out[(size_t)(2 * b + 1) * npairs + sp] = r;
+}
 // launch shape of a round over `half` pair indices and `nitems` independent items (pairs / tables): grid.x workgroups along j,
 // grid.y groups of items; large rounds keep one thread per j, small ones spread the items
 struct RoundGrid { int gx, gy; int blocks() const { return gx * gy; } };
@@ -837,14 +868,15 @@ __global__ void k_bn_fold_consts(const Fr* __restrict__ pw, FoldK* __restrict__ 
 // level 1 of a mirrored product: `in` holds the nb/2 READ rows only; row b >= nb/2 of the output is the product of the read row
 // b - nb/2 shifted by c (the write rows are never materialised)
 __global__ void k_bn_prod_level_mirror(const Fr* __restrict__ in, size_t in_len, Fr* __restrict__ out, int nb, Fr c, Fr c2, FoldK kc, const FoldK* __restrict__ fk = nullptr,
-                                       Fr* __restrict__ lw = nullptr) {
+                                       Fr* __restrict__ lw = nullptr, const unsigned char* __restrict__ slot_of = nullptr, int npairs = 0, int seg_shift = 0) {
     // one thread per entry of a READ row (row index on grid.y): its product x y is the read row's level-1 entry, and the write row's
     // entry is (x + c)(y + c) = x y + c (x + y) + c^2 - the multiplication by the launch-wide c goes through fr_fold_const (kc =
     // fold_consts(c)), and so do the rows' weights (fk[b], fk[b + nb/2])
     const size_t h = in_len >> 1, half = (size_t)nb / 2, b = blockIdx.y;
     const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= h) return;
-    const Fr x = lz_gload(&in[b * in_len + j]), y = lz_gload(&in[b * in_len + j + h]);   // loose (k_bn_hash_rw)
+    const size_t rb = slot_of ? slot_of[b * (size_t)npairs + (j >> seg_shift)] : b;   // slot form: the row that holds memory b's values in this segment pair
+    const Fr x = lz_gload(&in[rb * in_len + j]), y = lz_gload(&in[rb * in_len + j + h]);   // loose (k_bn_hash_rw)
     const Fr v = lz_mul(x, y);
     const Fr vw = lz_add(v, lz_fold(c2, lz_add(x, y), kc.k));
     lz_gstore(&out[b * h + j], v);
@@ -935,6 +967,7 @@ struct GpLaunchSet {
     std::vector<RedJobDev> reds;
     std::vector<TailJobDev> tails;
     std::vector<std::function<void()>> posts;   // after the rounds: final values of layers without a tail
+    std::vector<std::pair<size_t, std::function<void()>>> pre;   // (round, launch) ahead of that round's launch (the slot form's regroup)
     std::vector<size_t> wgs;                    // per round: workgroups of the jobs queued so far at gy = 1 (round_grid_gp)
     void merge(GpLaunchSet& o) {
         if (wgs.size() < o.wgs.size()) wgs.resize(o.wgs.size(), 0);
@@ -944,6 +977,7 @@ struct GpLaunchSet {
         reds.insert(reds.end(), o.reds.begin(), o.reds.end());
         tails.insert(tails.end(), o.tails.begin(), o.tails.end());
         posts.insert(posts.end(), o.posts.begin(), o.posts.end());
+        pre.insert(pre.end(), o.pre.begin(), o.pre.end());
     }
 };
 static void gp_launch_set(hg_ctx* ctx, hipStream_t st, GpLaunchSet& S) {
@@ -962,19 +996,38 @@ static void gp_launch_set(hg_ctx* ctx, hipStream_t st, GpLaunchSet& S) {
     const RedJobDev* d_reds = S.reds.empty() ? nullptr : bn_stage(ctx, S.reds.data(), S.reds.size());
     const TailJobDev* d_tails = S.tails.empty() ? nullptr : bn_stage(ctx, S.tails.data(), S.tails.size());
     bn_flush(ctx, st);
-    for (size_t rd = 0; rd < S.by_rd.size(); rd++)
+    for (size_t rd = 0; rd < S.by_rd.size(); rd++) {
+        for (auto& pf : S.pre) if (pf.first == rd) pf.second();
         if (!S.by_rd[rd].empty()) k_bn_gp_round_jobs<<<dim3(max_blocks[rd], (unsigned)S.by_rd[rd].size(), 1), BN_TPB, 0, st>>>(d_descs + off[rd]);
+    }
     if (!S.reds.empty()) k_bn_reduce_jobs<<<dim3(32, (unsigned)S.reds.size()), BN_TPB, 0, st>>>(d_reds, 3);
     if (!S.tails.empty()) k_bn_tail_jobs<BN_GRANDPROD><<<(unsigned)S.tails.size(), 3 * BN_TPB, 0, st>>>(d_tails);
     for (auto& f : S.posts) f();
 }
+// Slot form of the mirrored top layer (the Lasso read / write product). The hash of memory m at row j is h(dim_c[j], E_m[j], ts_c[j]):
+// chunk value and counter belong to the memory's CHUNK position, E_m[j] is zero on every row whose lookup does not use m, and rows come
+// in segments of 2^seg_shift per lookup - inside a segment all unused memories of a chunk position have the same row. The top layer
+// multiplies the two HALVES of a row (prover.rs:308-313), i.e. segment s with segment s + npairs: memories that are in the same class
+// in BOTH segments ("joint class") contribute w_b l r with the same l r. `slot_of[b][sp]` numbers the joint classes of segment pair
+// sp (slot 0 = memory 0 alone: its plain left table is the p_0 factor), `rep[v][sp]` names a member. Level 0 is then V slot rows
+// instead of nb / 2 memory rows, the layer's first seg_shift rounds run on V pairs whose left tables carry the class weights
+// sum_{b in class} gamma^b; after them a table is one entry per segment pair and the per-memory tables are gathered back
+// (k_bn_gp_regroup) for the remaining rounds. Same field elements as the memory form (exact arithmetic).
+struct GpSlots {
+    int V = 0, npairs = 0, seg_shift = 0, G2 = 0;
+    std::vector<unsigned char> slot_of;   // [G2][npairs]
+    std::vector<unsigned char> rep;       // [V][npairs]
+    const unsigned char* d_slot_of = nullptr;
+    const unsigned char* d_rep = nullptr;
+};
 // mirror_c (Montgomery, optional): rows nb/2 .. nb-1 of level 0 are rows 0 .. nb/2-1 plus this constant (the Lasso write hashes are
 // the read hashes + gamma^2): the top layer then runs on the read rows only (GpJobDev::mirror) and d_lev0 HOLDS ONLY THOSE nb/2
 // ROWS - level 1 is computed from them (k_bn_prod_level_mirror). Needs len >= 4 (a level 1 and a sum-check layer on level 0).
 static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* const* tables, const Fr* d_lev0, size_t chain_skip,
                                std::vector<uint8_t>& proof, std::vector<Fr>& claims_canon, std::vector<Fr>& point_canon, const Fr* mirror_c = nullptr,
-                               std::function<void()>* defer = nullptr, GpLaunchSet* set = nullptr) {
+                               std::function<void()>* defer = nullptr, GpLaunchSet* set = nullptr, const GpSlots* slots = nullptr) {
     if (set && !defer) throw Error("grand_product_core: a shared launch set needs the deferred form");
+    if (slots && (!mirror_c || !d_lev0 || slots->G2 != (int)(nb / 2) || ((len / 2) >> slots->seg_shift) != (size_t)slots->npairs)) throw Error("grand_product_core: slot plan does not fit");
     if (nb == 0 || len < 2 || (len & (len - 1))) throw Error("hg_grand_product_bn254: need nb >= 1 tables of a power-of-two length >= 2");
     hipc(hipSetDevice(ctx->device), "hipSetDevice");
     hipStream_t st = ctx->stream;
@@ -1007,6 +1060,8 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
         const size_t G2 = nb / 2;
         if (mirror_c && (nv < 2 || (nb & 1) || !d_lev0)) throw Error("hg_grand_product_bn254: mirrored rows need an even batch, two layers and device rows");
         std::vector<LayerPlan> plan(nv);
+        const Fr* slot_ratio = nullptr;   // slot form of the top layer: gamma^b / class weight per (memory, segment pair)
+        Fr* slot_regroup = nullptr;       // ... and the per-memory tables gathered after its first seg_shift rounds
         int max_main = 0;
         if (nv > 32) throw Error("hg_grand_product_bn254: more than 32 layers");
         Fr* pw_all = dalloc((size_t)nv * nb);
@@ -1056,7 +1111,8 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
                 fold_consts(*mirror_c, &kc);
                 const size_t hh = len >> 1;
                 k_bn_prod_level_mirror<<<dim3((unsigned)((hh + 255) / 256), (unsigned)(nb / 2)), 256, 0, st>>>(lev[0], len, lk, (int)nb, *mirror_c, fr_mul(*mirror_c, *mirror_c), kc,
-                                                                                                      n >= 1 ? fk_all + (size_t)n * nb : nullptr, lw_n);
+                                                                                                      n >= 1 ? fk_all + (size_t)n * nb : nullptr, lw_n,
+                                                                                                      slots ? slots->d_slot_of : nullptr, slots ? slots->npairs : 0, slots ? slots->seg_shift : 0);
             }
             else if (lw_n && (len >> k) >= 256) {   // long rows: the row index on grid.y, the row's weight as a launch-wide constant
                 const size_t hh = len >> k;
@@ -1078,7 +1134,38 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
         if (nv > 1) {   // the top layer reads level 0
             const int n = nv - 1;
             const size_t h = (size_t)1 << n;
-            if (plan[n].mirror) k_bn_weight_rows_sum<<<(unsigned)((h + 255) / 256), 256, 0, st>>>(lev[0], 2 * h, plan[n].d_pw, fk_all + (size_t)n * nb, plan[n].lw, plan[n].S, h, (int)G2);
+            if (plan[n].mirror && slots) {
+                // class weights W[v][sp] = sum of gamma^b over the members, their fold constants, and gamma^b / W for the regroup
+                const int V = slots->V, NP = slots->npairs;
+                const Fr g = fr_to_mont(chain[layers[n].gamma_at]);
+                std::vector<Fr> pwh(G2), W((size_t)V * NP, fr_zero()), ratio((size_t)G2 * NP, fr_zero());
+                { Fr w = fr_one_mont(); for (size_t b = 0; b < G2; b++) { pwh[b] = w; w = fr_mul(w, g); } }
+                for (size_t b = 0; b < G2; b++)
+                    for (int sp = 0; sp < NP; sp++) { Fr& x = W[(size_t)slots->slot_of[b * NP + sp] * NP + sp]; x = fr_add(x, pwh[b]); }
+                {   // one inversion for all class weights (prefix products), empty slots (weight zero) left out
+                    std::vector<size_t> idx;
+                    for (size_t q = 0; q < W.size(); q++) if (W[q].l[0] | W[q].l[1] | W[q].l[2] | W[q].l[3]) idx.push_back(q);
+                    std::vector<Fr> pre(idx.size() + 1, fr_one_mont());
+                    for (size_t q = 0; q < idx.size(); q++) pre[q + 1] = fr_mul(pre[q], W[idx[q]]);
+                    Fr inv = fr_inv(pre[idx.size()]);
+                    std::vector<Fr> Winv(W.size(), fr_zero());
+                    for (size_t q = idx.size(); q-- > 0;) { Winv[idx[q]] = fr_mul(inv, pre[q]); inv = fr_mul(inv, W[idx[q]]); }
+                    for (size_t b = 0; b < G2; b++)
+                        for (int sp = 0; sp < NP; sp++) {
+                            const size_t w = (size_t)slots->slot_of[b * NP + sp] * NP + sp;
+                            if (!(W[w].l[0] | W[w].l[1] | W[w].l[2] | W[w].l[3])) throw Error("hg_grand_product_bn254: degenerate batching challenge (a class weight is zero)");
+                            ratio[b * NP + sp] = fr_mul(pwh[b], Winv[w]);
+                        }
+                }
+                const Fr* dW = bn_stage(ctx, W.data(), W.size());
+                slot_ratio = bn_stage(ctx, ratio.data(), ratio.size());
+                bn_flush(ctx, st);
+                FoldK* fkW = static_cast<FoldK*>(ctx->alloc(W.size() * sizeof(FoldK)));
+                k_bn_fold_consts<<<(unsigned)((W.size() * 8 + 255) / 256), 256, 0, st>>>(dW, fkW, W.size());
+                k_bn_weight_slots_sum<<<(unsigned)((h + 255) / 256), 256, 0, st>>>(lev[0], 2 * h, dW, fkW, plan[n].lw, plan[n].S, h, V, NP, slots->seg_shift);
+                slot_regroup = dalloc(2 * G2 * (size_t)NP);
+            }
+            else if (plan[n].mirror) k_bn_weight_rows_sum<<<(unsigned)((h + 255) / 256), 256, 0, st>>>(lev[0], 2 * h, plan[n].d_pw, fk_all + (size_t)n * nb, plan[n].lw, plan[n].S, h, (int)G2);
             else k_bn_weight_rows<<<(unsigned)((nb * h + 255) / 256), 256, 0, st>>>(lev[0], 2 * h, plan[n].d_pw, plan[n].lw, h, (int)nb);
         }
         GpLaunchSet own;
@@ -1099,11 +1186,21 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
                 const size_t h = (size_t)1 << n, half = h >> (rd + 1);
                 GpJobDev d;
                 memset(&d, 0, sizeof(d));
+                const bool slot_layer = slots && P.mirror;
                 if (rd == 0) {   // rows [v_l | v_r] of length 2h: weighted left halves (compact), right halves in place
                     d.l_base = P.lw; d.l_stride = h;
                     d.r_base = lev[nv - 1 - n] + h; d.r_stride = 2 * h;
                 } else {         // folded tables: table t at inb + t * 2 * half
                     const Fr* inb = (rd & 1) ? P.buf0 : P.buf1;
+                    if (slot_layer && rd == slots->seg_shift) {   // the slot tables are one entry per segment pair now: back to one pair per memory
+                        const Fr* prev = inb;
+                        Fr* rg = slot_regroup;
+                        const unsigned char* so = slots->d_slot_of;
+                        const Fr* ra = slot_ratio;
+                        const int g2 = (int)G2, np = slots->npairs;
+                        own.pre.push_back({(size_t)rd, [prev, rg, so, ra, g2, np, st] { k_bn_gp_regroup<<<(unsigned)((g2 * np + 255) / 256), 256, 0, st>>>(prev, rg, so, ra, g2, np); }});
+                        inb = slot_regroup;
+                    }
                     d.l_base = inb; d.r_base = inb + 2 * half; d.l_stride = d.r_stride = 4 * half;
                 }
                 d.out = (rd & 1) ? P.buf1 : P.buf0;
@@ -1121,7 +1218,7 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
                     const Fr onek = fr_add(fr_one_mont(), kappa);
                     if (!(onek.l[0] | onek.l[1] | onek.l[2] | onek.l[3])) throw Error("hg_grand_product_bn254: degenerate batching challenge");
                     const Fr kp = fr_mul(kappa, fr_inv(onek));
-                    d.nb = (int)G2;
+                    d.nb = slot_layer && rd < slots->seg_shift ? slots->V : (int)G2;
                     d.mirror = 1;
                     d.k1 = fr_mul(kp, *mirror_c);
                     d.k2 = fr_mul(fr_mul(kp, fr_mul(*mirror_c, *mirror_c)), lam);
@@ -1607,15 +1704,28 @@ static void hashk_consts(HashK& K, const Fr& gamma_mont, const Fr& gamma2_mont, 
 struct HashMem { const u64* dim; const u64* ep; const u64* ts; const u64* fc; Fr* rd; Fr* wr; Fr* init; Fr* fin; u32 cutoff, pad; };
 struct HashMems { HashMem m[32]; };
 __device__ __forceinline__ void bn_hash_if_entry(u32 a, u32 cutoff, const u64* __restrict__ fc, const HashK& K, Fr* __restrict__ init, Fr* __restrict__ fin);
-__global__ __launch_bounds__(256) void k_bn_hash_all(size_t n, HashMems M, HashK K) {
-    const HashMem& m = M.m[blockIdx.y];
-    const size_t nblk = (n + 255) / 256;
+// Slot form (GpSlotsDev, see grand_product_core): blockIdx.y = slot, the row written is slot_rows + slot * n and its entries in row
+// segment s come from the memory that represents the slot there (rep); the init / final rows are then a launch of their own
+// (row_blocks = 0: every workgroup is an init / final one).
+struct HashSlots { const unsigned char* rep; Fr* slot_rows; int npairs, seg_shift; };
+__global__ __launch_bounds__(256) void k_bn_hash_all(size_t n, HashMems M, HashK K, size_t row_blocks, HashSlots SL) {
+    const size_t nblk = row_blocks;
     if (blockIdx.x >= nblk) {   // (uniform) the 2^16-entry init / final rows
-        bn_hash_if_entry((u32)((blockIdx.x - nblk) * 256 + threadIdx.x), m.cutoff, m.fc, K, m.init, m.fin);
+        const HashMem& mi = M.m[blockIdx.y];
+        bn_hash_if_entry((u32)((blockIdx.x - nblk) * 256 + threadIdx.x), mi.cutoff, mi.fc, K, mi.init, mi.fin);
         return;
     }
     const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
+    int pos = blockIdx.y;
+    Fr* rd_row = nullptr;
+    if (SL.rep) {   // (uniform over the workgroup: 256 consecutive rows lie in one segment)
+        const size_t sp = (j >> SL.seg_shift) % (size_t)SL.npairs;
+        pos = SL.rep[(size_t)blockIdx.y * SL.npairs + sp];
+        rd_row = SL.slot_rows + (size_t)blockIdx.y * n;
+    }
+    const HashMem& m = M.m[pos];
+    if (!rd_row) rd_row = m.rd;
     const u64 a = m.dim[j], v = m.ep[j], t = m.ts[j];
     Fr h;   // loose (bn254_lazy.hpp): read by the product-tree and round kernels
     if (((a | v | t) >> 32) == 0) h = lz_lin3((u32)a, (u32)v, (u32)t, K.kc);   // addresses, limb values, counters: always
@@ -1626,8 +1736,8 @@ __global__ __launch_bounds__(256) void k_bn_hash_all(size_t n, HashMems M, HashK
         wcol_mac_u64(w, t, K.gammasq2x);
         h = fr_sub(wcol_reduce(w), K.tau);
     }
-    lz_gstore(&m.rd[j], h);
-    if (m.wr) lz_gstore(&m.wr[j], lz_add(h, K.gammasq));   // (null: the write rows are not materialised, see grand_product_core's mirror_c)
+    lz_gstore(&rd_row[j], h);
+    if (m.wr && !SL.rep) lz_gstore(&m.wr[j], lz_add(h, K.gammasq));   // (null: the write rows are not materialised, see grand_product_core's mirror_c)
 }
 __global__ void k_bn_hash_rw(size_t n, const u64* __restrict__ dim, const u64* __restrict__ ep, const u64* __restrict__ ts, HashK K,
                              Fr* __restrict__ rd, Fr* __restrict__ wr) {
@@ -1839,7 +1949,45 @@ static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4,
         const int G = (int)lp.gkr_order.size();
         static const bool use_mirror = [] { const char* e = getenv("HG_NO_MIRROR"); return !(e && e[0] == '1'); }();
         const bool mirror = use_mirror && nu >= 2;   // write hash = read hash + gamma^2: only the read rows exist
-        Fr* H1 = dalloc((size_t)(mirror ? G : 2 * G) * N);
+        // Slot form of the read rows (GpSlots above): joint classes of the memories per segment pair (s, s + npairs)
+        GpSlots slots;
+        static const bool no_slots = [] { const char* e = getenv("HG_BN_NO_SLOTS"); return e && e[0] == '1'; }();
+        if (mirror && !no_slots && G <= 32 && L.seg_shift >= 1 && nu - 1 > L.seg_shift && ((N / 2) >> L.seg_shift) >= 1 && ((N / 2) >> L.seg_shift) <= 64) {
+            const int NP = (int)((N / 2) >> L.seg_shift);
+            auto cls = [&](int i, int s) -> int {   // class of GKR position i in row segment s: itself when its memory is looked up there, else its chunk position
+                const size_t row0 = (size_t)s << L.seg_shift;
+                if (row0 < L.rows) {
+                    const int l = lp.seg_lookup[s];
+                    if ((L.lookup_uses[l] >> lp.gkr_order[i]) & 1) return 1000 + i;
+                }
+                return lp.gkr_chunk[i];
+            };
+            slots.npairs = NP; slots.seg_shift = L.seg_shift; slots.G2 = G;
+            slots.slot_of.assign((size_t)G * NP, 0);
+            std::vector<std::vector<int>> reps(NP);
+            int V = 0;
+            for (int sp = 0; sp < NP; sp++) {
+                std::vector<std::pair<int, int>> keys;   // slot -> key
+                for (int i = 0; i < G; i++) {
+                    const std::pair<int, int> key = i == 0 ? std::make_pair(-1, -1) : std::make_pair(cls(i, sp), cls(i, sp + NP));
+                    int v = -1;
+                    for (size_t q = 0; q < keys.size(); q++) if (keys[q] == key) v = (int)q;
+                    if (v < 0) { v = (int)keys.size(); keys.push_back(key); reps[sp].push_back(i); }
+                    slots.slot_of[(size_t)i * NP + sp] = (unsigned char)v;
+                }
+                V = std::max(V, (int)keys.size());
+            }
+            slots.V = V;
+            slots.rep.assign((size_t)V * NP, 0);
+            for (int sp = 0; sp < NP; sp++) for (size_t v = 0; v < reps[sp].size(); v++) slots.rep[v * NP + sp] = (unsigned char)reps[sp][v];
+            if (V < G) {   // (nothing to gain otherwise)
+                slots.d_slot_of = bn_stage(ctx, slots.slot_of.data(), slots.slot_of.size());
+                slots.d_rep = bn_stage(ctx, slots.rep.data(), slots.rep.size());
+                bn_flush(ctx, st);
+            } else slots.V = 0;
+        }
+        const bool use_slots = slots.V > 0;
+        Fr* H1 = dalloc((size_t)(use_slots ? slots.V : (mirror ? G : 2 * G)) * N);
         Fr* H2 = dalloc((size_t)2 * G * M);
         {   // every memory's read (write) hash rows and init / final rows in one launch
             if (G > 32) throw Error("hg_lasso_prove_bn254: more than 32 memories");
@@ -1849,17 +1997,25 @@ static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4,
                 const int m = lp.gkr_order[i], c = lp.gkr_chunk[i];
                 HashMem& h = HM.m[i];
                 h.dim = dims + (size_t)c * N; h.ep = ep + (size_t)m * N; h.ts = read_ts[c]; h.fc = final_cts[c];
-                h.rd = H1 + (size_t)i * N; h.wr = mirror ? nullptr : H1 + (size_t)(G + i) * N;
+                h.rd = use_slots ? nullptr : H1 + (size_t)i * N; h.wr = mirror ? nullptr : H1 + (size_t)(G + i) * N;
                 h.init = H2 + (size_t)i * M; h.fin = H2 + (size_t)(G + i) * M; h.cutoff = (u32)lp.mems[m].cutoff;
             }
-            k_bn_hash_all<<<dim3(grid1(N) + 65536 / 256, (unsigned)G), 256, 0, st>>>(N, HM, HK);
+            HashSlots HS;
+            memset(&HS, 0, sizeof(HS));
+            if (use_slots) {
+                HS.rep = slots.d_rep; HS.slot_rows = H1; HS.npairs = slots.npairs; HS.seg_shift = slots.seg_shift;
+                k_bn_hash_all<<<dim3(grid1(N), (unsigned)slots.V), 256, 0, st>>>(N, HM, HK, (size_t)grid1(N), HS);   // the slot rows
+                HashSlots none;
+                memset(&none, 0, sizeof(none));
+                k_bn_hash_all<<<dim3(65536 / 256, (unsigned)G), 256, 0, st>>>(N, HM, HK, 0, none);                  // init / final rows per memory
+            } else k_bn_hash_all<<<dim3(grid1(N) + 65536 / 256, (unsigned)G), 256, 0, st>>>(N, HM, HK, (size_t)grid1(N), HS);
         }
         // the write hashes are the read hashes + gamma^2 (k_bn_hash_rw): the top layer runs on the read rows only
         // both grand products and the openings are enqueued back to back (nothing here depends on a result read by the host: the
         // points are challenges); ONE wait at the end, then the two transcript replays
         if (mid && mid_at == 2) (*mid)();
         GpLaunchSet gp_set;   // the rounds of BOTH grand products share their launches: the small one (2^16 rows) hides inside the big one's
-        grand_product_core(ctx, 2 * G, N, nullptr, H1, gp1_at, gp1_bytes, tmp_claims, x, mirror ? &gamma2 : nullptr, &replay_gp1, &gp_set);  // reads then writes (prover.rs:161-165)
+        grand_product_core(ctx, 2 * G, N, nullptr, H1, gp1_at, gp1_bytes, tmp_claims, x, mirror ? &gamma2 : nullptr, &replay_gp1, &gp_set, use_slots ? &slots : nullptr);  // reads then writes (prover.rs:161-165)
         grand_product_core(ctx, 2 * G, M, nullptr, H2, gp2_at, gp2_bytes, tmp_claims2, y, nullptr, &replay_gp2, &gp_set);  // inits then finals (prover.rs:167-171)
         gp_launch_set(ctx, st, gp_set);
         // openings (prover.rs:173-178, mod.rs:80-93)
