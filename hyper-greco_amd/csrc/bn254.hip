@@ -1987,6 +1987,7 @@ static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4,
             } else slots.V = 0;
         }
         const bool use_slots = slots.V > 0;
+        if (getenv("HG_BN_TIMES")) fprintf(stderr, "[hg bn]   read rows: %d slot rows for %d memories, %d segment pairs of 2^%d rows\n", use_slots ? slots.V : G, G, slots.npairs, slots.seg_shift);
         Fr* H1 = dalloc((size_t)(use_slots ? slots.V : (mirror ? G : 2 * G)) * N);
         Fr* H2 = dalloc((size_t)2 * G * M);
         {   // every memory's read (write) hash rows and init / final rows in one launch
