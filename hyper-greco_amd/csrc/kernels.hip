@@ -557,6 +557,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             if (2 * j < H.rows) uses_lo = (u32)H.lookup_uses[H.seg_lookup[(2 * j) >> H.seg_shift]];
             if (hN + 2 * j < H.rows) uses_hi = (u32)H.lookup_uses[H.seg_lookup[(hN + 2 * j) >> H.seg_shift]];
         }
+        const int sp = H.slot_of ? (int)((2 * j) >> H.seg_shift) : 0;   // slot form: this tile's segment pair (uniform: 512 positions of one segment)
         for (int m = 0; m < H.nmem; m++) {
             const GpHashMem M = H.mems[m];
             if (M.chunk != cur_chunk) {  // uniform: memories are listed chunk by chunk
@@ -586,14 +587,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             if (M.rd_row >= 0) {
                 const int i = M.rd_row;
                 if (i == 0) { const u64 d = gl_sub(yl, xl); p0 = xl; p2 = gl_add(yl, d); p3 = gl_add(p2, d); }
-                gp_first_pair(A, xl, yl, xr, yr, J.pw[i], J.pwr[i], r, !(p0_only && i == 0), out + (size_t)(2 * i) * half + jo,
-                              out + (size_t)(2 * i + 1) * half + jo, J.next_level ? J.next_level + (size_t)i * hN + 2 * j : nullptr);
-                if constexpr (MIRROR) if (!(p0_only && i == 0)) {
-                    const E2 gm = J.pw[i];
-                    const u64 hx = gl_add(xl, xr), hy = gl_add(yl, yr);
-                    Sx = e2_add(Sx, e2_mul_f(gm, hx));
-                    Sy = e2_add(Sy, e2_mul_f(gm, hy));
-                }
+                // memory form: row i is table pair i with weight pw[i]. Slot form: only the row that represents its joint class in
+                // this segment pair enters the sums and is folded, as table pair `v` with the class weight; every row still gets its
+                // level-1 entries (identical inside a class).
+                int v = i;
+                bool folded = true, summed = !(p0_only && i == 0);
+                E2 gm, gr;
+                if (H.slot_of) {
+                    v = H.slot_of[(size_t)i * H.npairs + sp];
+                    folded = H.rep[(size_t)v * H.npairs + sp] == i;
+                    const E2* w = H.slotw + ((size_t)v * H.npairs + sp) * 2;
+                    gm = w[0]; gr = w[1];
+                } else { gm = J.pw[i]; gr = J.pwr[i]; }
+                u64* nxt = J.next_level ? J.next_level + (size_t)i * hN + 2 * j : nullptr;
+                if (folded) {
+                    gp_first_pair(A, xl, yl, xr, yr, gm, gr, r, summed, out + (size_t)(2 * v) * half + jo, out + (size_t)(2 * v + 1) * half + jo, nxt);
+                    if constexpr (MIRROR) if (summed) {
+                        const u64 hx = gl_add(xl, xr), hy = gl_add(yl, yr);
+                        Sx = e2_add(Sx, e2_mul_f(gm, hx));
+                        Sy = e2_add(Sy, e2_mul_f(gm, hy));
+                    }
+                } else if (nxt) *reinterpret_cast<ulonglong2*>(nxt) = make_ulonglong2(gl_mul(xl, xr), gl_mul(yl, yr));
             }
             if (M.wr_row >= 0) {
                 const int i = M.wr_row;
@@ -605,6 +619,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     *reinterpret_cast<ulonglong2*>(J.next_level + (size_t)i * hN + 2 * j) = make_ulonglong2(gl_mul(xl, xr), gl_mul(yl, yr));
             }
         }
+        if (H.slot_of)   // a segment pair with fewer classes than the job has table pairs: the rest is zero there
+            for (int v = 1; v < H.nslots; v++)
+                if (H.rep[(size_t)v * H.npairs + sp] == 255) {
+                    store_e2_nt(out + (size_t)(2 * v) * half + jo, e2_zero());
+                    store_e2_nt(out + (size_t)(2 * v + 1) * half + jo, e2_zero());
+                }
         E2 s0, s2, s3;
         gp_first_acc_reduce(A, s0, s2, s3);
         if constexpr (MIRROR) {
@@ -882,6 +902,8 @@ __global__ __launch_bounds__(256) void k_st_tail(const StJob* __restrict__ jobs,
     }
     __syncthreads();
     const StItem& I = Il;
+    if (threadIdx.x == 0 && Il.ntab > 0) Jl.ntab = Il.ntab;   // (a slot-form job regrouped into its per-memory tables ahead of this launch)
+    __syncthreads();
     const StJob& J = Jl;
     E2* sm = dyn_lds;
     E2* red = dyn_lds + SM_SLOTS;
@@ -921,6 +943,27 @@ __global__ __launch_bounds__(256) void k_st_tail(const StJob* __restrict__ jobs,
         in = out; in_stride = half;
     }
     if ((int)threadIdx.x < (J.nvars - I.rd) * NV) res[J.sums_slot + (size_t)I.rd * NV + threadIdx.x] = keep[threadIdx.x];
+}
+__global__ void k_gp_slot_regroup(const E2* __restrict__ in, E2* __restrict__ out, const uint8_t* __restrict__ slot_of, const E2* __restrict__ ratio,
+                                  int nrows, int nslots, int npairs, int len_log2, int sh) {
+    const size_t len = (size_t)1 << len_log2;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= ((size_t)nrows + 1) << len_log2) return;
+    const int b = (int)(idx >> len_log2);
+    const size_t p = idx & (len - 1);   // storage position inside a table; the tables are de-interleaved
+    if (b == nrows) { out[((size_t)(2 * nrows) << len_log2) + p] = in[((size_t)(2 * nslots) << len_log2) + p]; return; }   // S
+    const size_t t = p < len / 2 ? 2 * p : 2 * (p - len / 2) + 1;   // the logical entry at that position
+    const int sp = (int)(t >> sh);
+    const int v = slot_of[(size_t)b * npairs + sp];
+    const E2 l = in[((size_t)(2 * v) << len_log2) + p], r = in[((size_t)(2 * v + 1) << len_log2) + p];
+    out[((size_t)(2 * b) << len_log2) + p] = b == 0 ? l : e2_mul(ratio[(size_t)b * npairs + sp], l);
+    out[((size_t)(2 * b + 1) << len_log2) + p] = r;
+}
+void gp_slot_regroup(hipStream_t st, const E2* in, E2* out, const uint8_t* slot_of, const E2* ratio, int nrows, int nslots, int npairs, int len_log2) {
+    int np_log2 = 0;
+    while ((1 << np_log2) < npairs) np_log2++;
+    const size_t n = ((size_t)nrows + 1) << len_log2;
+    k_gp_slot_regroup<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(in, out, slot_of, ratio, nrows, nslots, npairs, len_log2, len_log2 - np_log2);
 }
 void st_tail(hipStream_t st, int kind, const StJob* jobs, const StItem* items, int nitems, size_t table_bytes, const E2* chal, E2* res) {
     const size_t lds = (SM_SLOTS + 3 * 256) * sizeof(E2) + table_bytes;

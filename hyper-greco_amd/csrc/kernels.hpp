@@ -58,7 +58,21 @@ struct GpHashSrc {
     size_t rows;
     const uint8_t* seg_lookup;
     u64 lookup_uses[32];
+    // Slot form of the mirrored top layer (prover.hip: grand_product): inside a lookup segment the memories the lookup does not use
+    // have, per chunk position, identical hash rows, and the layer pairs segment s with s + npairs - memories in the same class in
+    // both segments ("joint class") contribute w_b l r with the same l r. slot_of[row * npairs + sp] numbers the joint classes of
+    // segment pair sp (slot 0 = row 0 alone), rep[slot * npairs + sp] names the read row that represents a slot there, slotw[(slot *
+    // npairs + sp) * 2] = the class weight sum_b gamma^b and [.. + 1] = that times r_0. The job then holds 2 V + 1 tables (the
+    // slots' weighted left / right halves and S); product-tree level 1 is still emitted per memory row. null: memory form.
+    const uint8_t* slot_of;
+    const uint8_t* rep;
+    const E2* slotw;
+    int npairs, nslots;
 };
+// the per-memory tables of a slot-form job, gathered once its tables are down to 2^len_log2 >= npairs entries (every entry still
+// inside one segment pair): in / out hold tables of that length (DE-INTERLEAVED like every folded table); left table of read row b
+// = ratio[b * npairs + sp] * left table of its slot, right table as it is, S (the last table of both) copied
+void gp_slot_regroup(hipStream_t st, const E2* in, E2* out, const uint8_t* slot_of, const E2* ratio, int nrows, int nslots, int npairs, int len_log2);
 struct StJob {
     const void* in;
     size_t in_stride;
@@ -94,6 +108,7 @@ struct StItem {
     E2* out;           // folded tables of the (last) round, stride = its half length
     // tail launches only (st_tail): rounds [rd, rd + nrounds) = all that remain run inside one workgroup
     int rd, nrounds;
+    int ntab;          // tail launches: > 0 = the job's table count from here on (a slot-form job regrouped into its per-memory tables)
 };
 // Fills jb_log2 / blk0 / nblk of the items of one launch (host side, before upload); returns the grid size.
 // `rounds2`: fused two-round launch (one pair index per thread).

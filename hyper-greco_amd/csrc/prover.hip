@@ -240,6 +240,9 @@ struct ScHandle {
     bool scaled = false;   // the device sums are the round sums divided by `scale` (mirrored grand product, StJob::mirror)
     E2 scale = {0, 0};
 };
+// Slot form of a mirrored top layer (GpHashSrc::slot_of in kernels.hpp): the job runs on `2 nslots + 1` tables until its tables are short
+// enough for the single-workgroup tail, which runs on the `tail_ntab` = 2 nrows + 1 per-memory tables gathered from them.
+struct SlotPlan { int tail_ntab = 0; const uint8_t* d_slot_of = nullptr; const E2* d_ratio = nullptr; int nrows = 0, nslots = 0, npairs = 0, max_rd = 0; };
 struct MirrorSpec { E2 k1, k2; int credit_ntab; };  // StJob::mk1 / mk2; the table count the launch is credited with (the unmirrored batch)
 
 struct Prover {
@@ -374,6 +377,7 @@ struct Prover {
     // the other, deepest layer first: job q with st_seq[q] = s > 0 gets its own first-round launch, in ascending s, before
     // the shared first-round launch of everything else; `st_after_seq` then builds the remaining (small) tree levels.
     std::vector<int> st_seq;
+    std::vector<SlotPlan> st_slot;     // per queued job
     std::vector<int> st_credit_ntab;   // per queued job: table count of the reference's batch (traffic model of SURVEY.md 8(d)); = ntab without a shortcut
     std::vector<double> st_fused_bytes;  // algorithmic bytes of the passes a job's first round absorbs (hash build, tree level)
     std::vector<std::function<void()>> st_after_seq;
@@ -384,7 +388,7 @@ struct Prover {
 
     ScHandle sc_stride(int kind, const void* in, bool base, size_t in_stride, int ntab, int nvars, const dev::Powers& pw, E2* final_out,
                        bool enqueue = true, bool p0_only = false, int seq = 0, u64* next_level = nullptr, const dev::GpHashSrc* hash_src = nullptr,
-                       const MirrorSpec* mirror = nullptr, int model_ntab = 0) {
+                       const MirrorSpec* mirror = nullptr, int model_ntab = 0, const SlotPlan* slots = nullptr) {
         ScHandle h;
         h.nv = kind == dev::SC_GRANDPROD ? 3 : 2;
         h.nvars = nvars;
@@ -411,6 +415,7 @@ struct Prover {
         if (nvars > 0)  // weight * r_0: the first round stores the weighted fold (kernels.hip)
             for (int i = 0; i < dev::PW_MAX; i++) J.pwr[i] = e2_mul(pw.v[i], h.rs[0]);
         if (nvars > 0) {
+            st_slot.push_back(slots ? *slots : SlotPlan());
             st_jobs.push_back(J); st_seq.push_back(seq); st_credit_ntab.push_back(mirror ? mirror->credit_ntab : (model_ntab ? model_ntab : ntab));
             // a level-writing first round replaces prod_level on its input level: (nb rows of 2N entries) x 8 B x 1.5 (read +
             // write), as prod_level is credited; the hash-source job's level 1 is credited with its write only, as the hash kernel
@@ -423,6 +428,8 @@ struct Prover {
         return h;
     }
 
+    // half-length (log2) at which a slot-form job's tail starts: what its PER-MEMORY tables allow (HG_TAIL_H does not apply)
+    static int slot_tail_h(int tail_ntab, int nvars) { return std::min(dev::st_tail_h(tail_ntab, nvars), nvars - 2); }
     void flush_stride() {
         if (st_jobs.empty()) return;
         const int nj = (int)st_jobs.size();
@@ -432,6 +439,8 @@ struct Prover {
         static const int fuse_min_h = [] { const char* e = getenv("HG_FUSE_MIN_H"); return e && *e ? atoi(e) : 13; }();
         struct Launch { int kind; bool base; int h_log2; bool tail; int nrounds; std::vector<dev::StItem> items; bool hash = false; bool after_seq = false; };
         std::vector<Launch> plan;
+        struct Regroup { int job; const E2* in; E2* out; int len_log2; };
+        std::vector<Regroup> regroups;
         std::vector<const void*> cur_in(nj);
         std::vector<size_t> cur_stride(nj);
         std::vector<int> next_h(nj);  // half-length (log2) of the job's next unscheduled round
@@ -443,8 +452,10 @@ struct Prover {
         static const int tail_cap = [] { const char* e = getenv("HG_TAIL_H"); return e && *e ? atoi(e) : 31; }();
         std::vector<int> h_small(nj);
         for (int q = 0; q < nj; q++) {
-            h_small[q] = std::min(dev::st_tail_h(st_jobs[q].ntab, st_jobs[q].nvars), tail_cap);
+            const SlotPlan& sp = st_slot[q];
+            h_small[q] = sp.tail_ntab ? slot_tail_h(sp.tail_ntab, st_jobs[q].nvars) : std::min(dev::st_tail_h(st_jobs[q].ntab, st_jobs[q].nvars), tail_cap);
             if (st_seq[q] > 0) h_small[q] = std::min(h_small[q], st_jobs[q].nvars - 2);   // a sequenced first round has its own kernel
+            if (sp.tail_ntab && st_jobs[q].nvars - 1 - h_small[q] > sp.max_rd) throw Error("slot-form job: the tail starts below the segment pairs");
         }
         for (int kind : {dev::SC_COLLATION, dev::SC_GRANDPROD}) {
             int max_h = -1;
@@ -520,6 +531,13 @@ struct Prover {
                     memset(&it, 0, sizeof(it));
                     it.job = q; it.in = cur_in[q]; it.in_stride = cur_stride[q];
                     it.rd = J.nvars - 1 - hs; it.nrounds = hs + 1; it.out = J.final_out;
+                    if (st_slot[q].tail_ntab) {   // the tail reads the per-memory tables (gathered right before it is launched)
+                        const SlotPlan& sp = st_slot[q];
+                        if (cur_stride[q] != (size_t)2 << hs) throw Error("slot-form job: unexpected table length at the tail");
+                        E2* rg = ctx->alloc_n<E2>((size_t)sp.tail_ntab << (hs + 1));
+                        regroups.push_back(Regroup{q, (const E2*)cur_in[q], rg, hs + 1});
+                        it.in = rg; it.ntab = sp.tail_ntab;
+                    }
                     lc.items.push_back(it);
                     next_h[q] = -1;
                 }
@@ -580,7 +598,11 @@ struct Prover {
                         const dev::StJob& J = st_jobs[it.job];
                         for (int k = 0; k < it.nrounds; k++) { bytes += round_bytes(it.job, it.rd + k, false); model += round_bytes(it.job, it.rd + k, true); }
                         const int h0 = J.nvars - 1 - it.rd;
-                        table_bytes = std::max(table_bytes, (size_t)J.ntab * (((size_t)1 << h0) + (((size_t)1 << h0) >> 1)) * sizeof(E2));
+                        table_bytes = std::max(table_bytes, (size_t)(it.ntab > 0 ? it.ntab : J.ntab) * (((size_t)1 << h0) + (((size_t)1 << h0) >> 1)) * sizeof(E2));
+                        for (const Regroup& g : regroups) if (g.job == it.job) {
+                            const SlotPlan& sp = st_slot[it.job];
+                            dev::gp_slot_regroup(st, g.in, g.out, sp.d_slot_of, sp.d_ratio, sp.nrows, sp.nslots, sp.npairs, g.len_log2);
+                        }
                     }
                     ctx->prof_begin(cls_tail, bytes, model);
                     dev::st_tail(st, L.kind, d_jobs, d_items + offs[li] + o, cnt, table_bytes, ctx->d_chal, d_res());
@@ -608,6 +630,7 @@ struct Prover {
         st_jobs.clear();
         st_seq.clear();
         st_credit_ntab.clear();
+        st_slot.clear();
         st_fused_bytes.clear();
         st_fused_model_extra.clear();
         for (auto& f : st_after_seq) f();  // (no grand-product job was queued: nothing can depend on these, but keep the order)
@@ -904,6 +927,8 @@ struct Prover {
     // `hash_src` (device pointer): level 0 is not materialised, the top layer's first round recomputes it (k_gp_first_hash).
     // `emit` > 0: tree levels 1 .. emit are written by the first rounds of the top `emit` layers (their products ARE the next
     // level), which therefore run one after the other before everything else; the remaining small levels follow them.
+    // Joint classes of the read rows of the Lasso top layer (GpHashSrc::slot_of), built with the hash sources in lasso_node
+    struct GpSlots { int V = 0, NP = 0, G = 0, seg_shift = 0; std::vector<uint8_t> slot_of, rep; uint8_t* d_slot_of = nullptr; uint8_t* d_rep = nullptr; E2* d_slotw = nullptr; E2* d_ratio = nullptr; } gp_slots;
     GpOut grand_product(const u64* H, size_t len, int nb, const std::vector<int>& owner, const u64* lev1 = nullptr,
                         const std::vector<int>* local = nullptr, bool p0_only = false, const dev::GpHashSrc* hash_src = nullptr, int emit = 0,
                         double hash_fused_bytes = 0, const u64* mirror_c = nullptr) {
@@ -1037,8 +1062,40 @@ struct Prover {
                 ms.credit_ntab = 2 * nl;
                 E2* fin = ctx->alloc_n<E2>(2 * (size_t)R + 1);
                 const bool run = mine(owner[n]) && R > (p0_only ? 1 : 0);
-                sc = sc_stride(dev::SC_GRANDPROD, lev[k], true, h, 2 * R + 1, n, pwl, fin, run, p0_only, seq, nxt, hs, &ms);
+                const bool slotted = gp_slots.V > 0;   // (decided with the hash sources, lasso_node)
+                if (slotted && (local || p0_only || !run || R != gp_slots.G)) throw Error("grand product: slot form on a partial batch");
+                SlotPlan spl;
+                if (slotted) {
+                    spl.tail_ntab = 2 * R + 1; spl.d_slot_of = gp_slots.d_slot_of; spl.d_ratio = gp_slots.d_ratio;
+                    spl.nrows = R; spl.nslots = gp_slots.V; spl.npairs = gp_slots.NP; spl.max_rd = gp_slots.seg_shift;
+                }
+                sc = sc_stride(dev::SC_GRANDPROD, lev[k], true, h, slotted ? 2 * gp_slots.V + 1 : 2 * R + 1, n, pwl, fin, run, p0_only, seq, nxt, hs, &ms, 0,
+                               slotted ? &spl : nullptr);
                 sc.scaled = true; sc.scale = onek;
+                if (slotted) {
+                    // class weights W[v][sp] = sum of the members' gamma^b (and W r_0 for the first round's weighted fold), and per row
+                    // gamma^b / W of its class: what turns a slot's folded left table back into the row's
+                    const int V = gp_slots.V, NP = gp_slots.NP;
+                    std::vector<E2> W((size_t)V * NP, e2_zero());
+                    for (int i = 0; i < R; i++)
+                        for (int sp = 0; sp < NP; sp++) { E2& w = W[(size_t)gp_slots.slot_of[(size_t)i * NP + sp] * NP + sp]; w = e2_add(w, pwl.v[i]); }
+                    // one inversion for all of them (empty classes - fewer than V in a segment pair - keep weight zero)
+                    std::vector<E2> pre(W.size()), inv(W.size(), e2_zero());
+                    E2 run_p = e2_one();
+                    for (size_t q = 0; q < W.size(); q++) { pre[q] = run_p; if (W[q].c0 | W[q].c1) run_p = e2_mul(run_p, W[q]); }
+                    E2 run_i = e2_inv(run_p);
+                    for (size_t q = W.size(); q-- > 0;) if (W[q].c0 | W[q].c1) { inv[q] = e2_mul(run_i, pre[q]); run_i = e2_mul(run_i, W[q]); }
+                    std::vector<E2> slotw(2 * W.size()), ratio((size_t)R * NP);
+                    for (size_t q = 0; q < W.size(); q++) { slotw[2 * q] = W[q]; slotw[2 * q + 1] = e2_mul(W[q], sc.rs[0]); }
+                    for (int i = 0; i < R; i++)
+                        for (int sp = 0; sp < NP; sp++) {
+                            const size_t q = (size_t)gp_slots.slot_of[(size_t)i * NP + sp] * NP + sp;
+                            if (!(W[q].c0 | W[q].c1)) throw Error("grand product: degenerate batching challenge");
+                            ratio[(size_t)i * NP + sp] = e2_mul(pwl.v[i], inv[q]);
+                        }
+                    upload(gp_slots.d_slotw, slotw.data(), slotw.size() * sizeof(E2), "upload slot weights");
+                    upload(gp_slots.d_ratio, ratio.data(), ratio.size() * sizeof(E2), "upload slot ratios");
+                }
                 if (run)
                     for (int li = p0_only ? 1 : 0; li < R; li++) {
                         scatter.push_back({fin + 2 * li, evals + 2 * (size_t)rows[li]});
@@ -1340,6 +1397,49 @@ struct Prover {
             hs.seg_shift = L.seg_shift; hs.rows = L.rows; hs.seg_lookup = L.seg_lookup;
             memcpy(hs.lookup_uses, L.lookup_uses, sizeof(hs.lookup_uses));
             hash_recomp = lean_e;
+            // Slot form (kernels.hpp, GpHashSrc::slot_of): inside a lookup's row segment the memories it does not use have, per chunk,
+            // identical hash rows, and the top layer multiplies segment s with segment s + npairs (Layer::bottom splits a row into
+            // halves): memories in the same class in both segments share one table pair until the tables are down to the segment pairs.
+            static const bool no_slots = [] { const char* e = getenv("HG_NO_SLOTS"); return e && e[0] == '1'; }();
+            static const bool use_mirror_top = [] { const char* e = getenv("HG_NO_MIRROR"); return !(e && e[0] == '1'); }();
+            gp_slots = GpSlots();
+            const int nvars_top = nu - 1;
+            if (!split && !no_slots && use_mirror_top && G <= 32 && (int)hm.size() == G && L.seg_shift >= 1 && nvars_top - 1 > L.seg_shift &&
+                ((N / 2) >> L.seg_shift) <= 64 && nvars_top - 1 - slot_tail_h(2 * G + 1, nvars_top) <= L.seg_shift) {
+                const int NP = (int)((N / 2) >> L.seg_shift);
+                auto cls = [&](int i, int s) -> int {   // class of GKR position i in row segment s: itself where its memory is looked up, else its chunk
+                    if (((size_t)s << L.seg_shift) < L.rows && ((L.lookup_uses[lp.seg_lookup[s]] >> lp.gkr_order[i]) & 1)) return 1000 + i;
+                    return lp.gkr_chunk[i];
+                };
+                GpSlots& gs = gp_slots;
+                gs.NP = NP; gs.G = G; gs.seg_shift = L.seg_shift;
+                gs.slot_of.assign((size_t)G * NP, 0);
+                std::vector<std::vector<int>> reps(NP);
+                int V = 0;
+                for (int sp = 0; sp < NP; sp++) {
+                    std::vector<std::pair<int, int>> keys;
+                    for (int i = 0; i < G; i++) {
+                        const std::pair<int, int> key = i == 0 ? std::make_pair(-1, -1) : std::make_pair(cls(i, sp), cls(i, sp + NP));   // row 0 alone: p_0
+                        int v = -1;
+                        for (size_t q = 0; q < keys.size(); q++) if (keys[q] == key) v = (int)q;
+                        if (v < 0) { v = (int)keys.size(); keys.push_back(key); reps[sp].push_back(i); }
+                        gs.slot_of[(size_t)i * NP + sp] = (uint8_t)v;
+                    }
+                    V = std::max(V, (int)keys.size());
+                }
+                if (V < G) {
+                    gs.V = V;
+                    gs.rep.assign((size_t)V * NP, 255);
+                    for (int sp = 0; sp < NP; sp++) for (size_t v = 0; v < reps[sp].size(); v++) gs.rep[v * NP + sp] = (uint8_t)reps[sp][v];
+                    gs.d_slot_of = ctx->alloc_n<uint8_t>(gs.slot_of.size());
+                    gs.d_rep = ctx->alloc_n<uint8_t>(gs.rep.size());
+                    gs.d_slotw = ctx->alloc_n<E2>(2 * (size_t)V * NP);
+                    gs.d_ratio = ctx->alloc_n<E2>((size_t)G * NP);
+                    upload(gs.d_slot_of, gs.slot_of.data(), gs.slot_of.size(), "upload slot map");
+                    upload(gs.d_rep, gs.rep.data(), gs.rep.size(), "upload slot representatives");
+                    hs.slot_of = gs.d_slot_of; hs.rep = gs.d_rep; hs.slotw = gs.d_slotw; hs.npairs = NP; hs.nslots = V;
+                }
+            }
             dev::GpHashSrc* d_hs = ctx->alloc_n<dev::GpHashSrc>(1);
             upload(d_hs, &hs, sizeof(hs), "upload hash sources");
             d_hash_src = d_hs;
