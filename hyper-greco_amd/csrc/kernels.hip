@@ -173,6 +173,14 @@ __device__ __forceinline__ void gp_first_pair(GpFirstAcc& A, u64 xl, u64 yl, u64
     wmac2(h0, r.c0, dr, h1, r.c1, dr);
     store_e2_nt(out_r, e2(wreduce(h0), wreduce(h1)));
 }
+// product-tree entries (q0, q1) of positions 2j, 2j + 1 to every row named by `mask` (GpHashSrc::emit_rd, StJob::emit_mask)
+__device__ __forceinline__ void emit_rows(u64* __restrict__ next_level, size_t row_stride, size_t at, u64 mask, ulonglong2 q) {
+    while (mask) {
+        const int t = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        *reinterpret_cast<ulonglong2*>(next_level + (size_t)t * row_stride + at) = q;
+    }
+}
 __device__ __forceinline__ void gp_first_acc_reduce(const GpFirstAcc& A, E2& s0, E2& s2, E2& s3) {
     s0 = e2(wreduce(A.a0), wreduce(A.b0)); s2 = e2(wreduce(A.a1), wreduce(A.b1)); s3 = e2(wreduce(A.ai), wreduce(A.bi));
 }
@@ -246,11 +254,20 @@ __device__ __forceinline__ void sc_round_body(const T* __restrict__ in, size_t i
                 // first round on base-field rows: sum_i gamma^i (xl xr) etc. with the Ext2 weight gamma^i = pw[i];
                 // each base product is reduced once, its two weighted copies accumulate unreduced.
                 GpFirstAcc A = gp_first_acc_zero();
+                const bool slotted = mirror && mirror->slotw;   // (FIRST: `mirror` carries the job for its slot form)
+                const size_t grp = slotted ? (2 * j) >> mirror->slot_shift : 0;
                 for (int i = g; i < nb; i += G) {
                     u64 xl, yl, xr, yr;
                     load_xy<u64, true>(in + (size_t)(2 * i) * in_stride, j, half, xl, yl);
                     load_xy<u64, true>(in + (size_t)(2 * i + 1) * in_stride, j, half, xr, yr);
                     if (i == 0) { const u64 dl = gl_sub(yl, xl); p0 = xl; p2 = gl_add(yl, dl); p3 = gl_add(p2, dl); }
+                    if (slotted) {
+                        const size_t at = (size_t)i * mirror->slot_ng + grp;
+                        ulonglong2 q;
+                        gp_first_pair(A, xl, yl, xr, yr, mirror->slotw[2 * at], mirror->slotw[2 * at + 1], r, true, out + (size_t)(2 * i) * out_stride + jo,
+                                      out + (size_t)(2 * i + 1) * out_stride + jo, next_level ? reinterpret_cast<u64*>(&q) : nullptr);
+                        if (next_level) emit_rows(next_level, in_stride, 2 * j, mirror->emit_mask[at], q);
+                    } else
                     gp_first_pair(A, xl, yl, xr, yr, pw[i], pwr[i], r, !(p0_only && i == 0), out + (size_t)(2 * i) * out_stride + jo,
                                   out + (size_t)(2 * i + 1) * out_stride + jo, next_level ? next_level + (size_t)i * in_stride + 2 * j : nullptr);
                 }
@@ -506,7 +523,8 @@ __global__ __launch_bounds__(256) void k_st_step(const StJob* __restrict__ jobs,
     E2 acc[NV];
 #pragma unroll
     for (int t = 0; t < NV; t++) acc[t] = e2_zero();
-    if (rd == 0) sc_round_body<KIND, T, true>(reinterpret_cast<const T*>(in), in_stride, out, half, J.ntab, half, chal[J.r_off + rd], J.pw, J.pwr, jb_log2, red, acc, bx, nblocks, J.p0_only != 0, J.next_level);
+    if (rd == 0) sc_round_body<KIND, T, true>(reinterpret_cast<const T*>(in), in_stride, out, half, J.ntab, half, chal[J.r_off + rd], J.pw, J.pwr, jb_log2, red, acc, bx, nblocks, J.p0_only != 0, J.next_level,
+                                              J.slotw ? &J : nullptr);
     else sc_round_body<KIND, T, false>(reinterpret_cast<const T*>(in), in_stride, out, half, J.ntab, half, chal[J.r_off + rd], J.pw, J.pwr, jb_log2, red, acc, bx, nblocks, J.p0_only != 0, nullptr,
                                        J.mirror ? &J : nullptr);
     E2* part = partials + (size_t)y * SC_MAX_BLOCKS * NV;
@@ -570,6 +588,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 c2 = gl_sub(gl_add(dh.x, gl_mul_small(gamma2, (u32)th.x)), tau); c3 = gl_sub(gl_add(dh.y, gl_mul_small(gamma2, (u32)th.y)), tau);
                 if constexpr (RECOMP) { a01 = (u32)dl.x | ((u32)dl.y << 16); a23 = (u32)dh.x | ((u32)dh.y << 16); }
             }
+            // slot form: a memory that represents no joint class in this segment pair has nothing to do (its rows equal its class's)
+            int slot_v = 0;
+            if (H.slot_of) {
+                slot_v = H.slot_of[(size_t)M.rd_row * H.npairs + sp];
+                if (H.rep[(size_t)slot_v * H.npairs + sp] != M.rd_row) continue;
+            }
             // (prefetching the next memory's E loads was measured slower here: 594 vs 560 us)
             u32 e0, e1, e2v, e3;
             if constexpr (RECOMP) {   // T_s[a] = a below the cutoff, 0 above; 0 for rows whose lookup does not use the memory
@@ -584,30 +608,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             }
             u64 xl = gl_add(c0, gl_mul_small(gamma, e0)), yl = gl_add(c1, gl_mul_small(gamma, e1));
             u64 xr = gl_add(c2, gl_mul_small(gamma, e2v)), yr = gl_add(c3, gl_mul_small(gamma, e3));
+            if (H.slot_of) {
+                // the class's table pair, weighted with the class weight; tree level 1 of the read and of the write row (+ gamma^2:
+                // t + 1) go to every row that equals this class's here
+                const int i = M.rd_row;
+                if (i == 0) { const u64 d = gl_sub(yl, xl); p0 = xl; p2 = gl_add(yl, d); p3 = gl_add(p2, d); }
+                const size_t at = (size_t)slot_v * H.npairs + sp;
+                const E2 gm = H.slotw[2 * at], gr = H.slotw[2 * at + 1];
+                ulonglong2 q;
+                gp_first_pair(A, xl, yl, xr, yr, gm, gr, r, true, out + (size_t)(2 * slot_v) * half + jo, out + (size_t)(2 * slot_v + 1) * half + jo,
+                              J.next_level ? reinterpret_cast<u64*>(&q) : nullptr);
+                const u64 hx = gl_add(xl, xr), hy = gl_add(yl, yr);
+                Sx = e2_add(Sx, e2_mul_f(gm, hx));
+                Sy = e2_add(Sy, e2_mul_f(gm, hy));
+                if (J.next_level) {
+                    emit_rows(J.next_level, hN, 2 * j, H.emit_rd[at], q);
+                    xl = gl_add(xl, gamma2); yl = gl_add(yl, gamma2); xr = gl_add(xr, gamma2); yr = gl_add(yr, gamma2);
+                    emit_rows(J.next_level, hN, 2 * j, H.emit_wr[at], make_ulonglong2(gl_mul(xl, xr), gl_mul(yl, yr)));
+                }
+                continue;
+            }
             if (M.rd_row >= 0) {
                 const int i = M.rd_row;
                 if (i == 0) { const u64 d = gl_sub(yl, xl); p0 = xl; p2 = gl_add(yl, d); p3 = gl_add(p2, d); }
-                // memory form: row i is table pair i with weight pw[i]. Slot form: only the row that represents its joint class in
-                // this segment pair enters the sums and is folded, as table pair `v` with the class weight; every row still gets its
-                // level-1 entries (identical inside a class).
-                int v = i;
-                bool folded = true, summed = !(p0_only && i == 0);
-                E2 gm, gr;
-                if (H.slot_of) {
-                    v = H.slot_of[(size_t)i * H.npairs + sp];
-                    folded = H.rep[(size_t)v * H.npairs + sp] == i;
-                    const E2* w = H.slotw + ((size_t)v * H.npairs + sp) * 2;
-                    gm = w[0]; gr = w[1];
-                } else { gm = J.pw[i]; gr = J.pwr[i]; }
-                u64* nxt = J.next_level ? J.next_level + (size_t)i * hN + 2 * j : nullptr;
-                if (folded) {
-                    gp_first_pair(A, xl, yl, xr, yr, gm, gr, r, summed, out + (size_t)(2 * v) * half + jo, out + (size_t)(2 * v + 1) * half + jo, nxt);
-                    if constexpr (MIRROR) if (summed) {
-                        const u64 hx = gl_add(xl, xr), hy = gl_add(yl, yr);
-                        Sx = e2_add(Sx, e2_mul_f(gm, hx));
-                        Sy = e2_add(Sy, e2_mul_f(gm, hy));
-                    }
-                } else if (nxt) *reinterpret_cast<ulonglong2*>(nxt) = make_ulonglong2(gl_mul(xl, xr), gl_mul(yl, yr));
+                gp_first_pair(A, xl, yl, xr, yr, J.pw[i], J.pwr[i], r, !(p0_only && i == 0), out + (size_t)(2 * i) * half + jo,
+                              out + (size_t)(2 * i + 1) * half + jo, J.next_level ? J.next_level + (size_t)i * hN + 2 * j : nullptr);
+                if constexpr (MIRROR) if (!(p0_only && i == 0)) {
+                    const E2 gm = J.pw[i];
+                    const u64 hx = gl_add(xl, xr), hy = gl_add(yl, yr);
+                    Sx = e2_add(Sx, e2_mul_f(gm, hx));
+                    Sy = e2_add(Sy, e2_mul_f(gm, hy));
+                }
             }
             if (M.wr_row >= 0) {
                 const int i = M.wr_row;
@@ -945,10 +976,10 @@ __global__ __launch_bounds__(256) void k_st_tail(const StJob* __restrict__ jobs,
     if ((int)threadIdx.x < (J.nvars - I.rd) * NV) res[J.sums_slot + (size_t)I.rd * NV + threadIdx.x] = keep[threadIdx.x];
 }
 __global__ void k_gp_slot_regroup(const E2* __restrict__ in, E2* __restrict__ out, const uint8_t* __restrict__ slot_of, const E2* __restrict__ ratio,
-                                  int nrows, int nslots, int npairs, int len_log2, int sh) {
+                                  int nrows, int nslots, int npairs, int len_log2, int sh, int has_s) {
     const size_t len = (size_t)1 << len_log2;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= ((size_t)nrows + 1) << len_log2) return;
+    if (idx >= ((size_t)nrows + has_s) << len_log2) return;
     const int b = (int)(idx >> len_log2);
     const size_t p = idx & (len - 1);   // storage position inside a table; the tables are de-interleaved
     if (b == nrows) { out[((size_t)(2 * nrows) << len_log2) + p] = in[((size_t)(2 * nslots) << len_log2) + p]; return; }   // S
@@ -959,11 +990,11 @@ __global__ void k_gp_slot_regroup(const E2* __restrict__ in, E2* __restrict__ ou
     out[((size_t)(2 * b) << len_log2) + p] = b == 0 ? l : e2_mul(ratio[(size_t)b * npairs + sp], l);
     out[((size_t)(2 * b + 1) << len_log2) + p] = r;
 }
-void gp_slot_regroup(hipStream_t st, const E2* in, E2* out, const uint8_t* slot_of, const E2* ratio, int nrows, int nslots, int npairs, int len_log2) {
+void gp_slot_regroup(hipStream_t st, const E2* in, E2* out, const uint8_t* slot_of, const E2* ratio, int nrows, int nslots, int npairs, int len_log2, bool has_s) {
     int np_log2 = 0;
     while ((1 << np_log2) < npairs) np_log2++;
-    const size_t n = ((size_t)nrows + 1) << len_log2;
-    k_gp_slot_regroup<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(in, out, slot_of, ratio, nrows, nslots, npairs, len_log2, len_log2 - np_log2);
+    const size_t n = ((size_t)nrows + (has_s ? 1 : 0)) << len_log2;
+    k_gp_slot_regroup<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(in, out, slot_of, ratio, nrows, nslots, npairs, len_log2, len_log2 - np_log2, has_s ? 1 : 0);
 }
 void st_tail(hipStream_t st, int kind, const StJob* jobs, const StItem* items, int nitems, size_t table_bytes, const E2* chal, E2* res) {
     const size_t lds = (SM_SLOTS + 3 * 256) * sizeof(E2) + table_bytes;

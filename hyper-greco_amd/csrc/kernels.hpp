@@ -68,11 +68,18 @@ struct GpHashSrc {
     const uint8_t* rep;
     const E2* slotw;
     int npairs, nslots;
+    // slot form: product-tree level 1 goes to the rows named by these bit masks instead of one row per memory - bit t of
+    // emit_rd[slot * npairs + sp] (emit_wr: for the write row, read + gamma^2) = "row t of J.next_level equals this class's product
+    // in segment pair sp". The rows are the next layer's own slot rows (StJob::slotw) or, below the last slot-form layer, the
+    // per-memory rows. Memories that represent no class are skipped altogether.
+    const u64* emit_rd;
+    const u64* emit_wr;
 };
 // the per-memory tables of a slot-form job, gathered once its tables are down to 2^len_log2 >= npairs entries (every entry still
 // inside one segment pair): in / out hold tables of that length (DE-INTERLEAVED like every folded table); left table of read row b
 // = ratio[b * npairs + sp] * left table of its slot, right table as it is, S (the last table of both) copied
-void gp_slot_regroup(hipStream_t st, const E2* in, E2* out, const uint8_t* slot_of, const E2* ratio, int nrows, int nslots, int npairs, int len_log2);
+// has_s = false: a layer below the top one (2 nrows / 2 nslots tables, no S).
+void gp_slot_regroup(hipStream_t st, const E2* in, E2* out, const uint8_t* slot_of, const E2* ratio, int nrows, int nslots, int npairs, int len_log2, bool has_s = true);
 struct StJob {
     const void* in;
     size_t in_stride;
@@ -80,6 +87,13 @@ struct StJob {
     E2* final_out;     // ntab folded scalars
     int kind, ntab, nvars, base;
     int p0_only;       // grand product on a subset of the batch (multi-GPU): pair 0 only supplies p_0, its product is not summed
+    // Slot form of a layer below the top one (see GpHashSrc::slot_of; prover.hip: grand_product): the job's table pairs are joint
+    // classes of rows, its input rows are slot rows written by the layer above. The first round takes the weight of pair v at table
+    // position 2j from slotw[(v * slot_ng + (2j >> slot_shift)) * 2] (and times r_0 from [.. + 1]) instead of pw / pwr, and writes the
+    // next tree level through emit_mask[v * slot_ng + group] as the top layer does (GpHashSrc::emit_rd).
+    const E2* slotw;
+    const u64* emit_mask;
+    int slot_ng, slot_shift;
     // Mirrored grand product (top layer of the Lasso read / write product): every WRITE row is its READ row plus the constant
     // c = gamma^2 and carries kappa times its weight, so the write pairs are never stored or multiplied. With l, r the halves of a
     // read row and S = sum_i w_i (l_i + r_i):  sum_i w_i [l_i r_i + kappa (l_i + c)(r_i + c)] = (1 + kappa) [ sum_i w_i l_i r_i +

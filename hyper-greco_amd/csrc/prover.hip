@@ -242,7 +242,10 @@ struct ScHandle {
 };
 // Slot form of a mirrored top layer (GpHashSrc::slot_of in kernels.hpp): the job runs on `2 nslots + 1` tables until its tables are short
 // enough for the single-workgroup tail, which runs on the `tail_ntab` = 2 nrows + 1 per-memory tables gathered from them.
-struct SlotPlan { int tail_ntab = 0; const uint8_t* d_slot_of = nullptr; const E2* d_ratio = nullptr; int nrows = 0, nslots = 0, npairs = 0, max_rd = 0; };
+struct SlotPlan {
+    int tail_ntab = 0; const uint8_t* d_slot_of = nullptr; const E2* d_ratio = nullptr; int nrows = 0, nslots = 0, npairs = 0, max_rd = 0;
+    const E2* job_slotw = nullptr; const u64* job_emit = nullptr;   // layers below the top one: StJob::slotw / emit_mask (the top layer's are in its GpHashSrc)
+};
 struct MirrorSpec { E2 k1, k2; int credit_ntab; };  // StJob::mk1 / mk2; the table count the launch is credited with (the unmirrored batch)
 
 struct Prover {
@@ -410,6 +413,7 @@ struct Prover {
         J.r_off = h.point_off; J.sums_slot = h.sums_slot;
         J.next_level = next_level; J.hash_src = hash_src;
         if (mirror) { J.mirror = 1; J.mk1 = mirror->k1; J.mk2 = mirror->k2; }
+        if (slots && slots->job_slotw) { J.slotw = slots->job_slotw; J.emit_mask = slots->job_emit; J.slot_ng = slots->npairs; J.slot_shift = slots->max_rd; }
         memcpy(J.pw, pw.v, sizeof(J.pw));
         for (int i = 0; i < nvars; i++) h.rs.push_back(squeeze());
         if (nvars > 0)  // weight * r_0: the first round stores the weighted fold (kernels.hip)
@@ -420,7 +424,7 @@ struct Prover {
             // a level-writing first round replaces prod_level on its input level: (nb rows of 2N entries) x 8 B x 1.5 (read +
             // write), as prod_level is credited; the hash-source job's level 1 is credited with its write only, as the hash kernel
             // it replaces was (round-1 accounting: the totals stay comparable)
-            double fused = next_level ? (double)((mirror ? mirror->credit_ntab : ntab) / 2) * (double)(2 * N) * 8.0 * (hash_src ? 0.5 : 1.5) : 0.0;
+            double fused = next_level ? (double)(st_credit_ntab.back() / 2) * (double)(2 * N) * 8.0 * (hash_src ? 0.5 : 1.5) : 0.0;
             st_fused_bytes.push_back(fused + pending_fused_bytes);
             st_fused_model_extra.push_back(pending_fused_model_extra);
             pending_fused_bytes = 0; pending_fused_model_extra = 0;
@@ -601,7 +605,7 @@ struct Prover {
                         table_bytes = std::max(table_bytes, (size_t)(it.ntab > 0 ? it.ntab : J.ntab) * (((size_t)1 << h0) + (((size_t)1 << h0) >> 1)) * sizeof(E2));
                         for (const Regroup& g : regroups) if (g.job == it.job) {
                             const SlotPlan& sp = st_slot[it.job];
-                            dev::gp_slot_regroup(st, g.in, g.out, sp.d_slot_of, sp.d_ratio, sp.nrows, sp.nslots, sp.npairs, g.len_log2);
+                            dev::gp_slot_regroup(st, g.in, g.out, sp.d_slot_of, sp.d_ratio, sp.nrows, sp.nslots, sp.npairs, g.len_log2, (sp.tail_ntab & 1) != 0);
                         }
                     }
                     ctx->prof_begin(cls_tail, bytes, model);
@@ -928,7 +932,38 @@ struct Prover {
     // `emit` > 0: tree levels 1 .. emit are written by the first rounds of the top `emit` layers (their products ARE the next
     // level), which therefore run one after the other before everything else; the remaining small levels follow them.
     // Joint classes of the read rows of the Lasso top layer (GpHashSrc::slot_of), built with the hash sources in lasso_node
-    struct GpSlots { int V = 0, NP = 0, G = 0, seg_shift = 0; std::vector<uint8_t> slot_of, rep; uint8_t* d_slot_of = nullptr; uint8_t* d_rep = nullptr; E2* d_slotw = nullptr; E2* d_ratio = nullptr; } gp_slots;
+    // (layer 0 = the top layer, rows = the G read rows; layer d >= 1: rows = the 2 G read and write rows, groups of 2^(d+1) segments)
+    struct SlotLayer {
+        int V = 0, ng = 0, nrows = 0;
+        std::vector<uint8_t> slot_of, rep;   // [row * ng + group], [slot * ng + group] (255: no such class there)
+        uint8_t* d_slot_of = nullptr; uint8_t* d_rep = nullptr; E2* d_slotw = nullptr; E2* d_ratio = nullptr;
+        u64* d_emit = nullptr;               // layer 0: V * ng read masks then V * ng write masks
+    };
+    struct GpSlots { int V = 0, NP = 0, G = 0, seg_shift = 0; std::vector<SlotLayer> layer; } gp_slots;
+    // class weights W[v][g] = sum of the members' gamma^b (and W r_0 for the first round's weighted fold), and per row gamma^b / W of
+    // its class: what turns a class's folded left table back into the row's (gp_slot_regroup)
+    void slot_weights(const SlotLayer& sl, const dev::Powers& pw, E2 r0) {
+        const int V = sl.V, ng = sl.ng, R = sl.nrows;
+        std::vector<E2> W((size_t)V * ng, e2_zero());
+        for (int b = 0; b < R; b++)
+            for (int g = 0; g < ng; g++) { E2& w = W[(size_t)sl.slot_of[(size_t)b * ng + g] * ng + g]; w = e2_add(w, pw.v[b]); }
+        // one inversion for all of them (a group with fewer classes than V keeps weight zero on the rest)
+        std::vector<E2> pre(W.size()), inv(W.size(), e2_zero());
+        E2 run_p = e2_one();
+        for (size_t q = 0; q < W.size(); q++) { pre[q] = run_p; if (W[q].c0 | W[q].c1) run_p = e2_mul(run_p, W[q]); }
+        E2 run_i = e2_inv(run_p);
+        for (size_t q = W.size(); q-- > 0;) if (W[q].c0 | W[q].c1) { inv[q] = e2_mul(run_i, pre[q]); run_i = e2_mul(run_i, W[q]); }
+        std::vector<E2> slotw(2 * W.size()), ratio((size_t)R * ng);
+        for (size_t q = 0; q < W.size(); q++) { slotw[2 * q] = W[q]; slotw[2 * q + 1] = e2_mul(W[q], r0); }
+        for (int b = 0; b < R; b++)
+            for (int g = 0; g < ng; g++) {
+                const size_t q = (size_t)sl.slot_of[(size_t)b * ng + g] * ng + g;
+                if (!(W[q].c0 | W[q].c1)) throw Error("grand product: degenerate batching challenge");
+                ratio[(size_t)b * ng + g] = e2_mul(pw.v[b], inv[q]);
+            }
+        upload(sl.d_slotw, slotw.data(), slotw.size() * sizeof(E2), "upload slot weights");
+        upload(sl.d_ratio, ratio.data(), ratio.size() * sizeof(E2), "upload slot ratios");
+    }
     GpOut grand_product(const u64* H, size_t len, int nb, const std::vector<int>& owner, const u64* lev1 = nullptr,
                         const std::vector<int>* local = nullptr, bool p0_only = false, const dev::GpHashSrc* hash_src = nullptr, int emit = 0,
                         double hash_fused_bytes = 0, const u64* mirror_c = nullptr) {
@@ -1062,45 +1097,34 @@ struct Prover {
                 ms.credit_ntab = 2 * nl;
                 E2* fin = ctx->alloc_n<E2>(2 * (size_t)R + 1);
                 const bool run = mine(owner[n]) && R > (p0_only ? 1 : 0);
-                const bool slotted = gp_slots.V > 0;   // (decided with the hash sources, lasso_node)
+                const bool slotted = !gp_slots.layer.empty();   // (decided with the hash sources, lasso_node)
                 if (slotted && (local || p0_only || !run || R != gp_slots.G)) throw Error("grand product: slot form on a partial batch");
                 SlotPlan spl;
                 if (slotted) {
-                    spl.tail_ntab = 2 * R + 1; spl.d_slot_of = gp_slots.d_slot_of; spl.d_ratio = gp_slots.d_ratio;
-                    spl.nrows = R; spl.nslots = gp_slots.V; spl.npairs = gp_slots.NP; spl.max_rd = gp_slots.seg_shift;
+                    const SlotLayer& sl = gp_slots.layer[0];
+                    spl.tail_ntab = 2 * R + 1; spl.d_slot_of = sl.d_slot_of; spl.d_ratio = sl.d_ratio;
+                    spl.nrows = R; spl.nslots = sl.V; spl.npairs = sl.ng; spl.max_rd = gp_slots.seg_shift;
                 }
-                sc = sc_stride(dev::SC_GRANDPROD, lev[k], true, h, slotted ? 2 * gp_slots.V + 1 : 2 * R + 1, n, pwl, fin, run, p0_only, seq, nxt, hs, &ms, 0,
+                sc = sc_stride(dev::SC_GRANDPROD, lev[k], true, h, slotted ? 2 * gp_slots.layer[0].V + 1 : 2 * R + 1, n, pwl, fin, run, p0_only, seq, nxt, hs, &ms, 0,
                                slotted ? &spl : nullptr);
                 sc.scaled = true; sc.scale = onek;
-                if (slotted) {
-                    // class weights W[v][sp] = sum of the members' gamma^b (and W r_0 for the first round's weighted fold), and per row
-                    // gamma^b / W of its class: what turns a slot's folded left table back into the row's
-                    const int V = gp_slots.V, NP = gp_slots.NP;
-                    std::vector<E2> W((size_t)V * NP, e2_zero());
-                    for (int i = 0; i < R; i++)
-                        for (int sp = 0; sp < NP; sp++) { E2& w = W[(size_t)gp_slots.slot_of[(size_t)i * NP + sp] * NP + sp]; w = e2_add(w, pwl.v[i]); }
-                    // one inversion for all of them (empty classes - fewer than V in a segment pair - keep weight zero)
-                    std::vector<E2> pre(W.size()), inv(W.size(), e2_zero());
-                    E2 run_p = e2_one();
-                    for (size_t q = 0; q < W.size(); q++) { pre[q] = run_p; if (W[q].c0 | W[q].c1) run_p = e2_mul(run_p, W[q]); }
-                    E2 run_i = e2_inv(run_p);
-                    for (size_t q = W.size(); q-- > 0;) if (W[q].c0 | W[q].c1) { inv[q] = e2_mul(run_i, pre[q]); run_i = e2_mul(run_i, W[q]); }
-                    std::vector<E2> slotw(2 * W.size()), ratio((size_t)R * NP);
-                    for (size_t q = 0; q < W.size(); q++) { slotw[2 * q] = W[q]; slotw[2 * q + 1] = e2_mul(W[q], sc.rs[0]); }
-                    for (int i = 0; i < R; i++)
-                        for (int sp = 0; sp < NP; sp++) {
-                            const size_t q = (size_t)gp_slots.slot_of[(size_t)i * NP + sp] * NP + sp;
-                            if (!(W[q].c0 | W[q].c1)) throw Error("grand product: degenerate batching challenge");
-                            ratio[(size_t)i * NP + sp] = e2_mul(pwl.v[i], inv[q]);
-                        }
-                    upload(gp_slots.d_slotw, slotw.data(), slotw.size() * sizeof(E2), "upload slot weights");
-                    upload(gp_slots.d_ratio, ratio.data(), ratio.size() * sizeof(E2), "upload slot ratios");
-                }
+                if (slotted) slot_weights(gp_slots.layer[0], pwl, sc.rs[0]);
                 if (run)
                     for (int li = p0_only ? 1 : 0; li < R; li++) {
                         scatter.push_back({fin + 2 * li, evals + 2 * (size_t)rows[li]});
                         scatter.push_back({fin + 2 * li + 1, evals + 2 * (size_t)rows[li] + 1});
                     }
+            } else if (!local && hash_src && k >= 1 && k < (int)gp_slots.layer.size()) {
+                // slot form below the top layer: the input rows are this layer's slot rows (written by the layer above), the tail runs
+                // on the 2 nb per-row tables again
+                const SlotLayer& sl = gp_slots.layer[k];
+                if (sl.nrows != nb || !mine(owner[n]) || !seq) throw Error("grand product: slot form on a partial batch");
+                SlotPlan spl;
+                spl.tail_ntab = 2 * nb; spl.d_slot_of = sl.d_slot_of; spl.d_ratio = sl.d_ratio;
+                spl.nrows = nb; spl.nslots = sl.V; spl.npairs = sl.ng; spl.max_rd = gp_slots.seg_shift;
+                spl.job_slotw = sl.d_slotw; spl.job_emit = sl.d_emit;
+                sc = sc_stride(dev::SC_GRANDPROD, lev[k], true, h, 2 * sl.V, n, pw, d_res() + evals, true, false, seq, nxt, nullptr, nullptr, 2 * nb, &spl);
+                slot_weights(sl, pw, sc.rs[0]);
             } else if (!local) sc = sc_stride(dev::SC_GRANDPROD, lev[k], true, h, 2 * nb, n, pw, d_res() + evals, mine(owner[n]), false, seq, nxt, hs);
             else {
                 // this rank's share of the batch: local pair li is global pair b = local[li], weight gamma^b
@@ -1411,33 +1435,82 @@ struct Prover {
                     if (((size_t)s << L.seg_shift) < L.rows && ((L.lookup_uses[lp.seg_lookup[s]] >> lp.gkr_order[i]) & 1)) return 1000 + i;
                     return lp.gkr_chunk[i];
                 };
+                if (getenv("HG_SLOT_DEBUG"))   // joint classes of deeper layers: layer d multiplies 2^(d+1) segments NP >> d apart
+                    for (int d = 0; d < 4 && (NP >> d) >= 1; d++) {
+                        const int np = NP >> d, cnt = 2 << d;
+                        int vmax = 0;
+                        for (int sp = 0; sp < np; sp++) {
+                            std::vector<std::vector<int>> keys;
+                            for (int i = 0; i < G; i++) {
+                                std::vector<int> key;
+                                for (int q = 0; q < cnt; q++) key.push_back(cls(i, sp + q * np));
+                                if (std::find(keys.begin(), keys.end(), key) == keys.end()) keys.push_back(key);
+                            }
+                            vmax = std::max(vmax, (int)keys.size());
+                        }
+                        fprintf(stderr, "[hg slots] layer %d: %d segment groups of %d, at most %d classes of %d memories\n", d, np, cnt, vmax, G);
+                    }
+                static const int depth_max = [] { const char* e = getenv("HG_SLOT_DEPTH"); return e && *e ? atoi(e) : 4; }();
                 GpSlots& gs = gp_slots;
                 gs.NP = NP; gs.G = G; gs.seg_shift = L.seg_shift;
-                gs.slot_of.assign((size_t)G * NP, 0);
-                std::vector<std::vector<int>> reps(NP);
-                int V = 0;
-                for (int sp = 0; sp < NP; sp++) {
-                    std::vector<std::pair<int, int>> keys;
-                    for (int i = 0; i < G; i++) {
-                        const std::pair<int, int> key = i == 0 ? std::make_pair(-1, -1) : std::make_pair(cls(i, sp), cls(i, sp + NP));   // row 0 alone: p_0
-                        int v = -1;
-                        for (size_t q = 0; q < keys.size(); q++) if (keys[q] == key) v = (int)q;
-                        if (v < 0) { v = (int)keys.size(); keys.push_back(key); reps[sp].push_back(i); }
-                        gs.slot_of[(size_t)i * NP + sp] = (uint8_t)v;
+                // layer d multiplies 2^(d+1) segments NP >> d apart: its classes are over those; rows: reads (layer 0), reads then writes
+                for (int d = 0; d < std::min(depth_max, emit); d++) {
+                    SlotLayer sl;
+                    sl.ng = NP >> d; sl.nrows = d == 0 ? G : 2 * G;
+                    const int nvars_d = nu - 1 - d;
+                    if (sl.ng < 2 || nvars_d - 1 <= L.seg_shift || nvars_d - 1 - slot_tail_h(d == 0 ? 2 * G + 1 : 4 * G, nvars_d) > L.seg_shift) break;
+                    sl.slot_of.assign((size_t)sl.nrows * sl.ng, 0);
+                    std::vector<std::vector<int>> reps(sl.ng);
+                    for (int g = 0; g < sl.ng; g++) {
+                        std::vector<std::vector<int>> keys;
+                        for (int b = 0; b < sl.nrows; b++) {
+                            std::vector<int> key;
+                            if (b == 0) key.push_back(-1);   // row 0 alone: p_0
+                            else {
+                                key.push_back(b >= G ? 1 : 0);
+                                for (int q = 0; q < (2 << d); q++) key.push_back(cls(b % G, g + q * sl.ng));
+                            }
+                            int v = -1;
+                            for (size_t q = 0; q < keys.size(); q++) if (keys[q] == key) v = (int)q;
+                            if (v < 0) { v = (int)keys.size(); keys.push_back(key); reps[g].push_back(b); }
+                            sl.slot_of[(size_t)b * sl.ng + g] = (uint8_t)v;
+                        }
+                        sl.V = std::max(sl.V, (int)keys.size());
                     }
-                    V = std::max(V, (int)keys.size());
+                    if (sl.V >= sl.nrows || sl.V > 64) break;   // (nothing to gain)
+                    sl.rep.assign((size_t)sl.V * sl.ng, 255);
+                    for (int g = 0; g < sl.ng; g++) for (size_t v = 0; v < reps[g].size(); v++) sl.rep[v * sl.ng + g] = (uint8_t)reps[g][v];
+                    gs.layer.push_back(sl);
                 }
-                if (V < G) {
-                    gs.V = V;
-                    gs.rep.assign((size_t)V * NP, 255);
-                    for (int sp = 0; sp < NP; sp++) for (size_t v = 0; v < reps[sp].size(); v++) gs.rep[v * NP + sp] = (uint8_t)reps[sp][v];
-                    gs.d_slot_of = ctx->alloc_n<uint8_t>(gs.slot_of.size());
-                    gs.d_rep = ctx->alloc_n<uint8_t>(gs.rep.size());
-                    gs.d_slotw = ctx->alloc_n<E2>(2 * (size_t)V * NP);
-                    gs.d_ratio = ctx->alloc_n<E2>((size_t)G * NP);
-                    upload(gs.d_slot_of, gs.slot_of.data(), gs.slot_of.size(), "upload slot map");
-                    upload(gs.d_rep, gs.rep.data(), gs.rep.size(), "upload slot representatives");
-                    hs.slot_of = gs.d_slot_of; hs.rep = gs.d_rep; hs.slotw = gs.d_slotw; hs.npairs = NP; hs.nslots = V;
+                // where each layer's first round writes the next tree level: the next layer's slot rows, or the per-memory rows
+                for (size_t d = 0; d < gs.layer.size(); d++) {
+                    SlotLayer& sl = gs.layer[d];
+                    const SlotLayer* nx = d + 1 < gs.layer.size() ? &gs.layer[d + 1] : nullptr;
+                    const int T = nx ? nx->V : 2 * G, ngn = sl.ng / 2;
+                    std::vector<u64> em((size_t)sl.V * sl.ng * (d == 0 ? 2 : 1), 0);
+                    for (int g = 0; g < sl.ng; g++)
+                        for (int t = 0; t < T; t++) {
+                            const int b = nx ? nx->rep[(size_t)t * ngn + (g % ngn)] : t;   // the row whose values target row t holds there
+                            if (b == 255) continue;
+                            if (d == 0) {
+                                const int u = sl.slot_of[(size_t)(b % G) * sl.ng + g];
+                                em[(b >= G ? (size_t)sl.V * sl.ng : 0) + (size_t)u * sl.ng + g] |= (u64)1 << t;
+                            } else em[(size_t)sl.slot_of[(size_t)b * sl.ng + g] * sl.ng + g] |= (u64)1 << t;
+                        }
+                    sl.d_slot_of = ctx->alloc_n<uint8_t>(sl.slot_of.size());
+                    sl.d_rep = ctx->alloc_n<uint8_t>(sl.rep.size());
+                    sl.d_slotw = ctx->alloc_n<E2>(2 * (size_t)sl.V * sl.ng);
+                    sl.d_ratio = ctx->alloc_n<E2>((size_t)sl.nrows * sl.ng);
+                    sl.d_emit = ctx->alloc_n<u64>(em.size());
+                    upload(sl.d_slot_of, sl.slot_of.data(), sl.slot_of.size(), "upload slot map");
+                    upload(sl.d_rep, sl.rep.data(), sl.rep.size(), "upload slot representatives");
+                    upload(sl.d_emit, em.data(), em.size() * sizeof(u64), "upload slot emission masks");
+                }
+                if (!gs.layer.empty()) {
+                    const SlotLayer& s0 = gs.layer[0];
+                    gs.V = s0.V;
+                    hs.slot_of = s0.d_slot_of; hs.rep = s0.d_rep; hs.slotw = s0.d_slotw; hs.npairs = NP; hs.nslots = s0.V;
+                    hs.emit_rd = s0.d_emit; hs.emit_wr = s0.d_emit + (size_t)s0.V * s0.ng;
                 }
             }
             dev::GpHashSrc* d_hs = ctx->alloc_n<dev::GpHashSrc>(1);
