@@ -149,13 +149,14 @@ __device__ __forceinline__ GpFirstAcc gp_first_acc_zero() {
     A.a0 = wacc_zero(); A.b0 = wacc_zero(); A.a1 = wacc_zero(); A.b1 = wacc_zero(); A.ai = wacc_zero(); A.bi = wacc_zero();
     return A;
 }
+template <bool WANT_Q>   // WANT_Q: the products of the two positions are always computed and handed back (slot form: the caller stores them)
 __device__ __forceinline__ void gp_first_pair(GpFirstAcc& A, u64 xl, u64 yl, u64 xr, u64 yr, E2 gm, E2 gr, E2 r, bool summed,
-                                              E2* __restrict__ out_l, E2* __restrict__ out_r, u64* __restrict__ nxt) {
+                                              E2* __restrict__ out_l, E2* __restrict__ out_r, u64* __restrict__ nxt, u64& q0, u64& q1) {
     const u64 dl = gl_sub(yl, xl), dr = gl_sub(yr, xr);
-    if (summed || nxt) {
+    if (WANT_Q || summed || nxt) {
         // (reading v_l v_r from the tree level above instead of multiplying was measured slower: the
         // first round is bound by its 8-byte-element traffic, not by these products)
-        const u64 q0 = gl_mul(xl, xr), q1 = gl_mul(yl, yr);
+        q0 = gl_mul(xl, xr); q1 = gl_mul(yl, yr);
         if (nxt) *reinterpret_cast<ulonglong2*>(nxt) = make_ulonglong2(q0, q1);
         if (summed) {
             const u64 qi = gl_mul(dl, dr);
@@ -196,7 +197,7 @@ __device__ __forceinline__ void gp_first_acc_reduce(const GpFirstAcc& A, E2& s0,
 // gamma^i (pw[i]); later rounds then need no per-pair scaling at all (the weight rides along in the table),
 // which removes 3 of the 8 extension multiplications per (pair, j). The host divides the final left
 // evaluations by gamma^i again before they reach the transcript.
-template <int KIND, typename T, bool FIRST>
+template <int KIND, typename T, bool FIRST, bool SLOT = false>   // SLOT: first round of a slot-form job (StJob::slotw), passed as `mirror`
 __device__ __forceinline__ void sc_round_body(const T* __restrict__ in, size_t in_stride, E2* __restrict__ out,
                                               size_t out_stride, int ntab, size_t half, E2 r, const E2* __restrict__ pw, const E2* __restrict__ pwr,
                                               int jb_log2, E2* __restrict__ red, E2* acc, size_t first_tile, size_t tile_step,
@@ -254,22 +255,26 @@ __device__ __forceinline__ void sc_round_body(const T* __restrict__ in, size_t i
                 // first round on base-field rows: sum_i gamma^i (xl xr) etc. with the Ext2 weight gamma^i = pw[i];
                 // each base product is reduced once, its two weighted copies accumulate unreduced.
                 GpFirstAcc A = gp_first_acc_zero();
-                const bool slotted = mirror && mirror->slotw;   // (FIRST: `mirror` carries the job for its slot form)
-                const size_t grp = slotted ? (2 * j) >> mirror->slot_shift : 0;
+                // (slot form: the group is uniform over the tile - a segment holds at least 512 positions; with 64 or more threads along j
+                // the pair index is uniform over a wave as well, so the weights and the mask are scalar loads)
+                [[maybe_unused]] const size_t grp = SLOT ? ((tile << jb_log2) * 2) >> mirror->slot_shift : 0;
                 for (int i = g; i < nb; i += G) {
                     u64 xl, yl, xr, yr;
                     load_xy<u64, true>(in + (size_t)(2 * i) * in_stride, j, half, xl, yl);
                     load_xy<u64, true>(in + (size_t)(2 * i + 1) * in_stride, j, half, xr, yr);
                     if (i == 0) { const u64 dl = gl_sub(yl, xl); p0 = xl; p2 = gl_add(yl, dl); p3 = gl_add(p2, dl); }
-                    if (slotted) {
-                        const size_t at = (size_t)i * mirror->slot_ng + grp;
-                        ulonglong2 q;
-                        gp_first_pair(A, xl, yl, xr, yr, mirror->slotw[2 * at], mirror->slotw[2 * at + 1], r, true, out + (size_t)(2 * i) * out_stride + jo,
-                                      out + (size_t)(2 * i + 1) * out_stride + jo, next_level ? reinterpret_cast<u64*>(&q) : nullptr);
-                        if (next_level) emit_rows(next_level, in_stride, 2 * j, mirror->emit_mask[at], q);
-                    } else
-                    gp_first_pair(A, xl, yl, xr, yr, pw[i], pwr[i], r, !(p0_only && i == 0), out + (size_t)(2 * i) * out_stride + jo,
-                                  out + (size_t)(2 * i + 1) * out_stride + jo, next_level ? next_level + (size_t)i * in_stride + 2 * j : nullptr);
+                    if constexpr (SLOT) {
+                        size_t at = (size_t)i * mirror->slot_ng + grp;
+                        if (jb_log2 >= 6) at = (size_t)__builtin_amdgcn_readfirstlane((int)at);
+                        u64 q0, q1;
+                        gp_first_pair<true>(A, xl, yl, xr, yr, mirror->slotw[2 * at], mirror->slotw[2 * at + 1], r, true, out + (size_t)(2 * i) * out_stride + jo,
+                                            out + (size_t)(2 * i + 1) * out_stride + jo, nullptr, q0, q1);
+                        if (next_level) emit_rows(next_level, in_stride, 2 * j, mirror->emit_mask[at], make_ulonglong2(q0, q1));
+                    } else {
+                        u64 q0, q1;
+                        gp_first_pair<false>(A, xl, yl, xr, yr, pw[i], pwr[i], r, !(p0_only && i == 0), out + (size_t)(2 * i) * out_stride + jo,
+                                             out + (size_t)(2 * i + 1) * out_stride + jo, next_level ? next_level + (size_t)i * in_stride + 2 * j : nullptr, q0, q1);
+                    }
                 }
                 gp_first_acc_reduce(A, s0, s2, s3);
             } else {
@@ -506,7 +511,7 @@ __device__ __forceinline__ int find_item(const StItem* __restrict__ items, int n
     return lo;
 }
 // one step: every item runs its job's round with half = 2^item.h_log2
-template <int KIND, typename T>
+template <int KIND, typename T, bool SLOT = false>   // SLOT: the first round of ONE slot-form job (StJob::slotw)
 __global__ __launch_bounds__(256) void k_st_step(const StJob* __restrict__ jobs, const StItem* __restrict__ items, int nitems,
                                                  const E2* __restrict__ chal, E2* __restrict__ partials, E2* __restrict__ res) {
     constexpr int NV = KIND == SC_GRANDPROD ? 3 : 2;
@@ -523,8 +528,8 @@ __global__ __launch_bounds__(256) void k_st_step(const StJob* __restrict__ jobs,
     E2 acc[NV];
 #pragma unroll
     for (int t = 0; t < NV; t++) acc[t] = e2_zero();
-    if (rd == 0) sc_round_body<KIND, T, true>(reinterpret_cast<const T*>(in), in_stride, out, half, J.ntab, half, chal[J.r_off + rd], J.pw, J.pwr, jb_log2, red, acc, bx, nblocks, J.p0_only != 0, J.next_level,
-                                              J.slotw ? &J : nullptr);
+    if (rd == 0) sc_round_body<KIND, T, true, SLOT>(reinterpret_cast<const T*>(in), in_stride, out, half, J.ntab, half, chal[J.r_off + rd], J.pw, J.pwr, jb_log2, red, acc, bx, nblocks, J.p0_only != 0, J.next_level,
+                                                    SLOT ? &J : nullptr);
     else sc_round_body<KIND, T, false>(reinterpret_cast<const T*>(in), in_stride, out, half, J.ntab, half, chal[J.r_off + rd], J.pw, J.pwr, jb_log2, red, acc, bx, nblocks, J.p0_only != 0, nullptr,
                                        J.mirror ? &J : nullptr);
     E2* part = partials + (size_t)y * SC_MAX_BLOCKS * NV;
@@ -544,8 +549,12 @@ __global__ __launch_bounds__(256) void k_st_step(const StJob* __restrict__ jobs,
 // two halves of a row), once per MEMORY for its read pair and its write pair (write hash = read hash + gamma^2), with the
 // dim / ts part shared by the memories of a chunk. E, dim, ts are small integers (< 2^16, < 2^16, < 2^32): gl_mul_small.
 // It also emits product-tree level 1 (J.next_level), so no separate hash or level-1 pass exists.
-template <bool MIRROR, bool RECOMP>   // MIRROR: write rows = read rows + gamma^2: not stored, not multiplied (StJob::mirror); RECOMP: E from the limbs
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_gp_first_hash(const StJob* __restrict__ job, const StItem* __restrict__ item,
+// SLOT: slot form (GpHashSrc::slot_of; always mirrored)
+template <bool MIRROR, bool RECOMP, bool SLOT = false>   // MIRROR: write rows = read rows + gamma^2: not stored, not multiplied (StJob::mirror); RECOMP: E from the limbs
+#ifndef HG_HASH_SLOT_WAVES
+#define HG_HASH_SLOT_WAVES 3
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SLOT ? HG_HASH_SLOT_WAVES : 3, SLOT ? HG_HASH_SLOT_WAVES : 3))) void k_gp_first_hash(const StJob* __restrict__ job, const StItem* __restrict__ item,
                                                        const E2* __restrict__ chal, E2* __restrict__ partials, E2* __restrict__ res) {
     const StJob& J = *job;
     const StItem& I = *item;
@@ -575,9 +584,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             if (2 * j < H.rows) uses_lo = (u32)H.lookup_uses[H.seg_lookup[(2 * j) >> H.seg_shift]];
             if (hN + 2 * j < H.rows) uses_hi = (u32)H.lookup_uses[H.seg_lookup[(hN + 2 * j) >> H.seg_shift]];
         }
-        const int sp = H.slot_of ? (int)((2 * j) >> H.seg_shift) : 0;   // slot form: this tile's segment pair (uniform: 512 positions of one segment)
-        for (int m = 0; m < H.nmem; m++) {
-            const GpHashMem M = H.mems[m];
+        [[maybe_unused]] const int sp = SLOT ? (int)((tile << 9) >> H.seg_shift) : 0;   // slot form: this tile's segment pair (uniform: 512 positions of one segment)
+        // slot form: only the memories that represent a joint class in this segment pair (in ascending order, so still chunk by chunk)
+        for (int m = 0; m < (SLOT ? H.nslots : H.nmem); m++) {
+            [[maybe_unused]] int slot_v = m;
+            int mi = m;
+            if constexpr (SLOT) {
+                mi = H.rep[(size_t)m * H.npairs + sp];
+                if (mi == 255) {   // fewer classes here than the job has table pairs: the rest is zero
+                    store_e2_nt(out + (size_t)(2 * m) * half + jo, e2_zero());
+                    store_e2_nt(out + (size_t)(2 * m + 1) * half + jo, e2_zero());
+                    continue;
+                }
+            }
+            const GpHashMem M = H.mems[mi];
             if (M.chunk != cur_chunk) {  // uniform: memories are listed chunk by chunk
                 cur_chunk = M.chunk;
                 const u64* __restrict__ dim = H.dim[cur_chunk];
@@ -587,12 +607,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 c0 = gl_sub(gl_add(dl.x, gl_mul_small(gamma2, (u32)tl.x)), tau); c1 = gl_sub(gl_add(dl.y, gl_mul_small(gamma2, (u32)tl.y)), tau);
                 c2 = gl_sub(gl_add(dh.x, gl_mul_small(gamma2, (u32)th.x)), tau); c3 = gl_sub(gl_add(dh.y, gl_mul_small(gamma2, (u32)th.y)), tau);
                 if constexpr (RECOMP) { a01 = (u32)dl.x | ((u32)dl.y << 16); a23 = (u32)dh.x | ((u32)dh.y << 16); }
-            }
-            // slot form: a memory that represents no joint class in this segment pair has nothing to do (its rows equal its class's)
-            int slot_v = 0;
-            if (H.slot_of) {
-                slot_v = H.slot_of[(size_t)M.rd_row * H.npairs + sp];
-                if (H.rep[(size_t)slot_v * H.npairs + sp] != M.rd_row) continue;
             }
             // (prefetching the next memory's E loads was measured slower here: 594 vs 560 us)
             u32 e0, e1, e2v, e3;
@@ -608,31 +622,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             }
             u64 xl = gl_add(c0, gl_mul_small(gamma, e0)), yl = gl_add(c1, gl_mul_small(gamma, e1));
             u64 xr = gl_add(c2, gl_mul_small(gamma, e2v)), yr = gl_add(c3, gl_mul_small(gamma, e3));
-            if (H.slot_of) {
+            if constexpr (SLOT) {
                 // the class's table pair, weighted with the class weight; tree level 1 of the read and of the write row (+ gamma^2:
                 // t + 1) go to every row that equals this class's here
                 const int i = M.rd_row;
                 if (i == 0) { const u64 d = gl_sub(yl, xl); p0 = xl; p2 = gl_add(yl, d); p3 = gl_add(p2, d); }
                 const size_t at = (size_t)slot_v * H.npairs + sp;
                 const E2 gm = H.slotw[2 * at], gr = H.slotw[2 * at + 1];
-                ulonglong2 q;
-                gp_first_pair(A, xl, yl, xr, yr, gm, gr, r, true, out + (size_t)(2 * slot_v) * half + jo, out + (size_t)(2 * slot_v + 1) * half + jo,
-                              J.next_level ? reinterpret_cast<u64*>(&q) : nullptr);
+                u64 q0, q1;
+                gp_first_pair<true>(A, xl, yl, xr, yr, gm, gr, r, true, out + (size_t)(2 * slot_v) * half + jo, out + (size_t)(2 * slot_v + 1) * half + jo, nullptr, q0, q1);
                 const u64 hx = gl_add(xl, xr), hy = gl_add(yl, yr);
                 Sx = e2_add(Sx, e2_mul_f(gm, hx));
                 Sy = e2_add(Sy, e2_mul_f(gm, hy));
                 if (J.next_level) {
-                    emit_rows(J.next_level, hN, 2 * j, H.emit_rd[at], q);
+                    emit_rows(J.next_level, hN, 2 * j, H.emit_rd[at], make_ulonglong2(q0, q1));
                     xl = gl_add(xl, gamma2); yl = gl_add(yl, gamma2); xr = gl_add(xr, gamma2); yr = gl_add(yr, gamma2);
                     emit_rows(J.next_level, hN, 2 * j, H.emit_wr[at], make_ulonglong2(gl_mul(xl, xr), gl_mul(yl, yr)));
                 }
-                continue;
-            }
+            } else {
             if (M.rd_row >= 0) {
                 const int i = M.rd_row;
                 if (i == 0) { const u64 d = gl_sub(yl, xl); p0 = xl; p2 = gl_add(yl, d); p3 = gl_add(p2, d); }
-                gp_first_pair(A, xl, yl, xr, yr, J.pw[i], J.pwr[i], r, !(p0_only && i == 0), out + (size_t)(2 * i) * half + jo,
-                              out + (size_t)(2 * i + 1) * half + jo, J.next_level ? J.next_level + (size_t)i * hN + 2 * j : nullptr);
+                u64 q0, q1;
+                gp_first_pair<false>(A, xl, yl, xr, yr, J.pw[i], J.pwr[i], r, !(p0_only && i == 0), out + (size_t)(2 * i) * half + jo,
+                                     out + (size_t)(2 * i + 1) * half + jo, J.next_level ? J.next_level + (size_t)i * hN + 2 * j : nullptr, q0, q1);
                 if constexpr (MIRROR) if (!(p0_only && i == 0)) {
                     const E2 gm = J.pw[i];
                     const u64 hx = gl_add(xl, xr), hy = gl_add(yl, yr);
@@ -643,19 +656,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             if (M.wr_row >= 0) {
                 const int i = M.wr_row;
                 xl = gl_add(xl, gamma2); yl = gl_add(yl, gamma2); xr = gl_add(xr, gamma2); yr = gl_add(yr, gamma2);  // t + 1
-                if constexpr (!MIRROR)
-                    gp_first_pair(A, xl, yl, xr, yr, J.pw[i], J.pwr[i], r, true, out + (size_t)(2 * i) * half + jo,
-                                  out + (size_t)(2 * i + 1) * half + jo, J.next_level ? J.next_level + (size_t)i * hN + 2 * j : nullptr);
-                else if (J.next_level)   // only the tree needs the write row: its level-1 entries
+                if constexpr (!MIRROR) {
+                    u64 q0, q1;
+                    gp_first_pair<false>(A, xl, yl, xr, yr, J.pw[i], J.pwr[i], r, true, out + (size_t)(2 * i) * half + jo,
+                                         out + (size_t)(2 * i + 1) * half + jo, J.next_level ? J.next_level + (size_t)i * hN + 2 * j : nullptr, q0, q1);
+                } else if (J.next_level)   // only the tree needs the write row: its level-1 entries
                     *reinterpret_cast<ulonglong2*>(J.next_level + (size_t)i * hN + 2 * j) = make_ulonglong2(gl_mul(xl, xr), gl_mul(yl, yr));
             }
+            }
         }
-        if (H.slot_of)   // a segment pair with fewer classes than the job has table pairs: the rest is zero there
-            for (int v = 1; v < H.nslots; v++)
-                if (H.rep[(size_t)v * H.npairs + sp] == 255) {
-                    store_e2_nt(out + (size_t)(2 * v) * half + jo, e2_zero());
-                    store_e2_nt(out + (size_t)(2 * v + 1) * half + jo, e2_zero());
-                }
         E2 s0, s2, s3;
         gp_first_acc_reduce(A, s0, s2, s3);
         if constexpr (MIRROR) {
@@ -683,9 +692,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     if (nblocks > 1) finish_partials(partials, 3, tickets_of(partials), res + J.sums_slot, sm, nblocks);
 }
 static inline size_t sc_lds_bytes(int nv, int bd);
-void st_first_hash(hipStream_t st, const StJob* job, const StItem* item, int grid, bool mirror, bool recomp, const E2* chal, E2* partials, E2* res) {
+void st_first_hash(hipStream_t st, const StJob* job, const StItem* item, int grid, bool mirror, bool recomp, const E2* chal, E2* partials, E2* res, bool slot) {
     const size_t lds = sc_lds_bytes(0, 256);
-    if (recomp) {
+    if (slot) {
+        if (!mirror) throw std::runtime_error("st_first_hash: the slot form is a mirrored job");
+        if (recomp) k_gp_first_hash<true, true, true><<<grid, 256, lds, st>>>(job, item, chal, partials, res);
+        else k_gp_first_hash<true, false, true><<<grid, 256, lds, st>>>(job, item, chal, partials, res);
+    } else if (recomp) {
         if (mirror) k_gp_first_hash<true, true><<<grid, 256, lds, st>>>(job, item, chal, partials, res);
         else k_gp_first_hash<false, true><<<grid, 256, lds, st>>>(job, item, chal, partials, res);
     } else {
@@ -1024,10 +1037,13 @@ int st_plan_blocks(StItem* items, int nitems, bool rounds2) {
     return blk;
 }
 void st_step(hipStream_t st, int kind, bool base, const StJob* jobs, const StItem* items, int nitems, int grid, const E2* chal,
-             E2* partials, E2* res) {
+             E2* partials, E2* res, bool slot) {
     const int nv = kind == SC_GRANDPROD ? 3 : 2;
     const size_t lds = sc_lds_bytes(nv, 256);
-    if (kind == SC_GRANDPROD) {
+    if (slot) {
+        if (kind != SC_GRANDPROD || !base || nitems != 1) throw std::runtime_error("st_step: a slot-form first round is launched alone");
+        k_st_step<SC_GRANDPROD, u64, true><<<grid, 256, lds, st>>>(jobs, items, nitems, chal, partials, res);
+    } else if (kind == SC_GRANDPROD) {
         if (base) k_st_step<SC_GRANDPROD, u64><<<grid, 256, lds, st>>>(jobs, items, nitems, chal, partials, res);
         else k_st_step<SC_GRANDPROD, E2><<<grid, 256, lds, st>>>(jobs, items, nitems, chal, partials, res);
     } else {

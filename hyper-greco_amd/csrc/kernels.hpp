@@ -129,11 +129,11 @@ struct StItem {
 int st_plan_blocks(StItem* items, int nitems, bool rounds2);
 // step: every item runs its job's round with half = 2^item.h_log2; `grid` from st_plan_blocks
 void st_step(hipStream_t st, int kind, bool base, const StJob* jobs, const StItem* items, int nitems, int grid, const E2* chal,
-             E2* partials, E2* res);
+             E2* partials, E2* res, bool slot = false);
 // first round of ONE grand-product job whose level-0 rows are recomputed from the Lasso integer tables (StJob::hash_src)
 // (`mirror` = the host copy of job->mirror: selects the kernel variant)
 // (`recomp`: the memories' E values are recomputed from the limbs, GpHashMem::ep is not read)
-void st_first_hash(hipStream_t st, const StJob* job, const StItem* item, int grid, bool mirror, bool recomp, const E2* chal, E2* partials, E2* res);
+void st_first_hash(hipStream_t st, const StJob* job, const StItem* item, int grid, bool mirror, bool recomp, const E2* chal, E2* partials, E2* res, bool slot = false);
 // fused step (folded Ext2 inputs; grand-product or collation shape): every item runs its job's rounds with half = 2^h_log2 and 2^(h_log2-1)
 void st_step2(hipStream_t st, int kind, const StJob* jobs, const StItem* items, int nitems, int grid, const E2* chal, E2* partials, E2* res);
 // LDS-resident tail (st_tail): every item runs ALL rounds from its `rd` on in one workgroup; st_tail_h(ntab, nvars) = log2 of the

@@ -590,7 +590,7 @@ struct Prover {
                     bytes = round_bytes(it.job, 0, false) + st_fused_bytes[it.job];
                     model = round_bytes(it.job, 0, true) + st_fused_bytes[it.job] + st_fused_model_extra[it.job];
                     ctx->prof_begin(cls_gp_hash, bytes, model);
-                    dev::st_first_hash(st, d_jobs + it.job, d_items + offs[li] + o, grids[li][0], st_jobs[it.job].mirror != 0, hash_recomp, ctx->d_chal, partials, d_res());
+                    dev::st_first_hash(st, d_jobs + it.job, d_items + offs[li] + o, grids[li][0], st_jobs[it.job].mirror != 0, hash_recomp, ctx->d_chal, partials, d_res(), st_slot[it.job].tail_ntab != 0);
                     ctx->prof_end();
                     stamp("first hash round done");
                     continue;
@@ -624,7 +624,8 @@ struct Prover {
                     int cls = L.kind == dev::SC_GRANDPROD ? (L.base ? cls_gp_base : (L.nrounds == 2 ? cls_gp_ext2 : cls_gp_ext)) : (L.base ? cls_col_base : (L.nrounds == 2 ? cls_col_ext2 : cls_col_ext));
                     ctx->prof_begin(cls, bytes, model);
                     if (L.nrounds == 2) dev::st_step2(st, L.kind, d_jobs, d_items + offs[li] + o, cnt, grid, ctx->d_chal, partials, d_res());
-                    else dev::st_step(st, L.kind, L.base, d_jobs, d_items + offs[li] + o, cnt, grid, ctx->d_chal, partials, d_res());
+                    else dev::st_step(st, L.kind, L.base, d_jobs, d_items + offs[li] + o, cnt, grid, ctx->d_chal, partials, d_res(),
+                                      L.base && st_jobs[L.items[o].job].slotw != nullptr);
                     ctx->prof_end();
                 }
             }
@@ -1428,7 +1429,7 @@ struct Prover {
             static const bool use_mirror_top = [] { const char* e = getenv("HG_NO_MIRROR"); return !(e && e[0] == '1'); }();
             gp_slots = GpSlots();
             const int nvars_top = nu - 1;
-            if (!split && !no_slots && use_mirror_top && G <= 32 && (int)hm.size() == G && L.seg_shift >= 1 && nvars_top - 1 > L.seg_shift &&
+            if (!split && !no_slots && use_mirror_top && G <= 32 && (int)hm.size() == G && L.seg_shift >= 9 && nvars_top - 1 > L.seg_shift &&
                 ((N / 2) >> L.seg_shift) <= 64 && nvars_top - 1 - slot_tail_h(2 * G + 1, nvars_top) <= L.seg_shift) {
                 const int NP = (int)((N / 2) >> L.seg_shift);
                 auto cls = [&](int i, int s) -> int {   // class of GKR position i in row segment s: itself where its memory is looked up, else its chunk
