@@ -1693,16 +1693,23 @@ struct Prover {
                 stamp("claimed sum and openings done");
             };
             // Where the openings' dot products run (HG_LATE_OPENINGS; the two eq tables above are built right away in every case).
-            // 1 (default): behind the node reductions on the second stream. 0: right away, beside the first hash round. 2: between the
+            // 3 (default since the slot form): see below. 1: behind the node reductions on the second stream. 0: right away, beside the first hash round. 2: between the
             // two waves of node reductions. Round 4, medians of 120 interleaved graph replays: 2.566 (0) / 2.598 (2) / 2.610 ms (1);
             // bench.py with 40 steps: 2.82-2.84 (0) against 2.87-2.90 ms (1) per proof - with the shorter node bookkeeping both chains
             // end together and 0.15 ms of openings behind them run alone. 0 is not the default because the node reductions then start
             // 0.5 ms later and their VALU-heavy first rounds share the GPU with all of the dominant round kernel's launches: 265-277
             // instead of 246-261 us per launch, 0.55-0.57 instead of 0.58-0.61 of the HBM roofline inside a prove (0.74 isolated either
             // way) for a gain of 1.5-2 % that one bench.py run of 10 steps does not resolve.
-            static const bool late = [] { const char* e = getenv("HG_LATE_OPENINGS"); return !(e && e[0] == '0'); }();
+            // 3: at the end of the MAIN stream, behind the grand products (which, in their slot form, end before the node reductions do:
+            // stamps 1.92 against 1.99 ms, and the openings ran alone behind the latter until 2.08 ms). Medians of 72 interleaved graph
+            // replays: 1.982 (3) / 2.023 (1) / 2.023 (2) / 2.057 ms (0).
+            static const int late = [] { const char* e = getenv("HG_LATE_OPENINGS"); return e && *e ? atoi(e) : 3; }();
             aux(open_tables);
-            if (late && use_aux) late_aux.push_back(openings);
+            if (late == 3 && use_aux && world == 1) {
+                hip_check(hipEventRecord(ctx->ev_aux[4], ctx->stream2), "lasso: opening tables event");
+                hip_check(hipStreamWaitEvent(ctx->stream, ctx->ev_aux[4], 0), "lasso: wait for the opening tables");
+                openings();
+            } else if (late && use_aux) late_aux.push_back(openings);
             else aux(openings);
         }
         stamp("grand products done");
@@ -1949,12 +1956,23 @@ struct Prover {
     }
     std::function<void()> st_before_gp;  // flush_stride runs it once before the first grand-product launch (cross-stream wait)
     std::function<void()> st_before_gp2; // ... and this one once the sequenced first rounds of grand product #1's top layers are out
+    // The node reductions on the THIRD stream (the collation rounds' - a few launches at the start of the prove): they then start with
+    // the prove instead of behind the Lasso node's second-stream work (counters, grand product #2's tree, opening tables: 0.6 ms),
+    // into the idle capacity those latency-bound launches leave. HG_NODES_STREAM=2: on the second stream, as before the slot form.
+    bool nodes_on_col = false;
     void fork_nodes_stream() {
         if (!fork_recorded) return;
         hip_check(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0), "fork wait");
+        static const bool third = [] { const char* e = getenv("HG_NODES_STREAM"); return !(e && e[0] == '2'); }();
+        if (third && world == 1 && late_aux.empty()) {   // (openings queued behind the node reductions read the second stream's counters)
+            hip_check(hipStreamWaitEvent(ctx->stream_col, ctx->ev_fork, 0), "fork wait");
+            st = ctx->stream_col; partials = ctx->d_partials3; ctx->prof_stream = st; forked = true; nodes_on_col = true;
+            return;
+        }
         st = ctx->stream2; partials = ctx->d_partials2; ctx->prof_stream = st; forked = true;
     }
     void join_nodes_stream() {
+        if (nodes_on_col) { hip_check(hipEventRecord(ctx->ev_col, ctx->stream_col), "node reductions: done event"); col_pending = true; nodes_on_col = false; }
         if (col_pending) { hip_check(hipStreamWaitEvent(ctx->stream, ctx->ev_col, 0), "collation: join wait"); col_pending = false; }
         if (!forked) return;
         hip_check(hipEventRecord(ctx->ev_join, ctx->stream2), "join event");
@@ -2032,7 +2050,7 @@ struct Prover {
         if (!d_stamps) d_stamps = ctx->alloc_n<unsigned long long>(256);
         if (stamp_names.size() >= 256) return;
         dev::stamp(st, d_stamps + stamp_names.size());
-        stamp_names.push_back(std::string(st == ctx->stream ? "main " : "aux  ") + name);
+        stamp_names.push_back(std::string(st == ctx->stream ? "main " : (st == ctx->stream_col ? "col  " : "aux  ")) + name);
     }
     void print_stamps() {
         if (stamp_names.empty()) return;

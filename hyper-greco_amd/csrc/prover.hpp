@@ -26,7 +26,7 @@ struct hg_ctx {
     hipEvent_t ev_col = nullptr;
     hg::E2* d_partials3 = nullptr;      // scratch of stream_col
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    hipEvent_t ev_aux[4] = {nullptr, nullptr, nullptr, nullptr};  // Lasso node: limbs done (stream -> stream2), grand product #2 levels done (stream2 -> stream), E tables done (stream -> stream2), counters done (stream2 -> stream)
+    hipEvent_t ev_aux[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // Lasso node: limbs done (stream -> stream2), grand product #2 levels done (stream2 -> stream), E tables done (stream -> stream2), counters done (stream2 -> stream), opening tables done (stream2 -> stream)
     hipStream_t prof_stream = nullptr;  // stream the profiling events are recorded on (the one being enqueued to)
     // multi-GPU (comm.hip): RCCL communicator of this rank (ncclComm_t, type-erased: RCCL is loaded at run time), exchange buffer
     void* comm = nullptr;
