@@ -33,12 +33,12 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICRO
 # inside the timed region.
 CLASS_SYMBOL = {
     "sc_round2<grand_product,ext>": "k_st_step2(",
-    "sc_round<grand_product,ext>": "k_st_step<1, hg::E2>",
-    "sc_round<grand_product,base>": "k_st_step<1, unsigned long>",
-    "sc_round<grand_product,hash>": "k_gp_first_hash(",
+    "sc_round<grand_product,ext>": "k_st_step<1, hg::E2",
+    "sc_round<grand_product,base>": "k_st_step<1, unsigned long",      # (two instantiations: slot form and memory form)
+    "sc_round<grand_product,hash>": "k_gp_first_hash<",
     "sc_round2<collation,ext>": "k_col_step2(",
-    "sc_round<collation,ext>": "k_st_step<0, hg::E2>",
-    "sc_round<collation,base>": "k_st_step<0, unsigned long>",
+    "sc_round<collation,ext>": "k_st_step<0, hg::E2",
+    "sc_round<collation,base>": "k_st_step<0, unsigned long",
     "sc_round<prodsum>": "k_ps_one(",
     "sc_round2<prodsum>": "k_ps_step2(",
 }
@@ -646,6 +646,14 @@ def main():
                                       "frac": round(iso_achieved / HBM_PEAK_GBS, 4), "gpu_ms_one_stream": round(iso_gpu_ms, 4),
                                       "note": "hg_set_option(one_stream): no cross-stream overlap; traffic_frac uses this duration"}},
             "kernel_classes": classes,
+            # the largest classes of the per-class pass (one stream: isolated durations) against the same HBM peak, per launch; frac = bytes
+            # this implementation streams, model_frac = the reference algorithm's bytes for the same launches (above 1 where the slot
+            # form / the mirrored top layer avoid most of them)
+            "roofline_by_class": [{"kernel": name, "symbol": CLASS_SYMBOL.get(name, ""), "launches_per_step": c["launches"],
+                                   "isolated_avg_launch_us": round(c["ms"] / max(c["launches"], 1) * 1e3, 2),
+                                   "frac": round(c["algo_GB"] / (c["ms"] * 1e-3) / HBM_PEAK_GBS, 4) if c["ms"] > 0 else None,
+                                   "model_frac": round(c["model_GB"] / (c["ms"] * 1e-3) / HBM_PEAK_GBS, 4) if c["ms"] > 0 else None}
+                                  for name, c in sorted(classes.items(), key=lambda kv: -kv[1]["ms"])[:4] if name != "aux"],
             # whole prove against the same roofline: algorithmic bytes of every kernel class (SURVEY 8(d) accounting) over the
             # GPU time of one prove (HIP events around the whole enqueue)
             # algo_GB / achieved / frac: SURVEY 8(d)'s "(ii) whole-prove algorithmic bytes / time" with the bytes of the REFERENCE's
