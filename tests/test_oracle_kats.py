@@ -546,3 +546,43 @@ def test_unused_memories_of_a_chunk_have_identical_hash_rows_inside_a_lookup_seg
         per_chunk = [sum(1 for m in range(A) if md[m] == c) for c in range(4)]
         print(f"n={n} k={k}: alpha={A}, memories per chunk position {per_chunk}, {len(change) + 1} segments: "
               f"<= {sum(min(2, c) for c in per_chunk)} distinct read tables per segment instead of {A}")
+
+
+def test_joint_classes_of_the_product_tree_layers_share_their_rows():
+    """What the slot form of grand product #1 rests on (prover.hip: lasso_node / GpSlots), checked on the reference's
+    own witnesses with the class rule restated here: layer d of the product tree multiplies 2^(d+1) row segments that lie
+    (segments >> (d+1)) apart; two memories whose classes agree on all of them (class of a memory in a segment = itself where the
+    segment's lookup uses it, else its chunk position) have identical level-d product rows inside that segment group - for the read
+    hashes and for the write hashes (read + gamma^2). gamma, tau: arbitrary field elements."""
+    P = (1 << 64) - (1 << 32) + 1
+    gamma, tau = 0x1234567887654321 % P, 0x0FEDCBA998765432 % P
+    for n, k, bits in ((1024, 1, 27), (4096, 2, 55)):
+        p = orclib.params(n, k)
+        w = json.load(open(os.path.join(orclib.GOLDEN, f"sk_enc_{n}_{k}x{bits}_65537.json")))
+        lasso_in, _, _ = orclib.circuit_eval(p, orclib.Inputs(orclib.layout_inputs(n, k, w)))
+        L = orclib.lasso_polys(p, lasso_in)
+        A, nu, rows, md, lm = L["A"], L["nu"], L["rows"], L["mem_dim"], L["lookup_mems"]
+        N = 1 << nu
+        nseg = N // n
+        seg_lookup = [L["row_lookup"][s * n] if s * n < rows else None for s in range(nseg)]
+        def cls(m, s):
+            return 1000 + m if seg_lookup[s] is not None and m in lm[seg_lookup[s]] else md[m]
+        dims = [np.array(d, dtype=object) for d in L["dims"]]
+        ts = [np.array(t, dtype=object) for t in L["read_cts"]]   # (per memory; equal for the memories of a chunk position)
+        for add in (0, gamma * gamma % P):   # read rows, write rows
+            lev = [(dims[md[m]] + np.array(L["e_polys"][m], dtype=object) * gamma + ts[m] * (gamma * gamma % P) - tau + add) % P for m in range(A)]
+            for d in range(3):
+                half = len(lev[0]) // 2
+                lev = [(r[:half] * r[half:]) % P for r in lev]          # level d + 1: v_l * v_r on the MSB split (prover.rs:308-313)
+                ng = nseg >> (d + 1)
+                if ng < 1: break
+                found = 0
+                for g in range(ng):
+                    groups = {}
+                    for m in range(A):
+                        groups.setdefault(tuple(cls(m, g + q * ng) for q in range(2 << d)), []).append(m)
+                    for members in groups.values():
+                        for m in members[1:]:
+                            assert (lev[m][g * n:(g + 1) * n] == lev[members[0]][g * n:(g + 1) * n]).all(), (n, d, g, members)
+                    found = max(found, len(groups))
+                assert found < A or d > 0, (n, d, found)   # (the top layer always has something to share)
