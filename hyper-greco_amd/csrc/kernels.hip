@@ -267,7 +267,7 @@ __device__ __forceinline__ void sc_round_body(const T* __restrict__ in, size_t i
                         size_t at = (size_t)i * mirror->slot_ng + grp;
                         if (jb_log2 >= 6) at = (size_t)__builtin_amdgcn_readfirstlane((int)at);
                         u64 q0, q1;
-                        gp_first_pair<true>(A, xl, yl, xr, yr, mirror->slotw[2 * at], mirror->slotw[2 * at + 1], r, true, out + (size_t)(2 * i) * out_stride + jo,
+                        gp_first_pair<true>(A, xl, yl, xr, yr, mirror->slotw[2 * at], mirror->slotw[2 * at + 1], r, !(p0_only && i == 0), out + (size_t)(2 * i) * out_stride + jo,
                                             out + (size_t)(2 * i + 1) * out_stride + jo, nullptr, q0, q1);
                         if (next_level) emit_rows(next_level, in_stride, 2 * j, mirror->emit_mask[at], make_ulonglong2(q0, q1));
                     } else {
@@ -630,10 +630,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SLOT ? HG_H
                 const size_t at = (size_t)slot_v * H.npairs + sp;
                 const E2 gm = H.slotw[2 * at], gr = H.slotw[2 * at + 1];
                 u64 q0, q1;
-                gp_first_pair<true>(A, xl, yl, xr, yr, gm, gr, r, true, out + (size_t)(2 * slot_v) * half + jo, out + (size_t)(2 * slot_v + 1) * half + jo, nullptr, q0, q1);
-                const u64 hx = gl_add(xl, xr), hy = gl_add(yl, yr);
-                Sx = e2_add(Sx, e2_mul_f(gm, hx));
-                Sy = e2_add(Sy, e2_mul_f(gm, hy));
+                const bool summed = !(p0_only && slot_v == 0);   // (sharded: class 0 = pair 0, held for p_0 only)
+                gp_first_pair<true>(A, xl, yl, xr, yr, gm, gr, r, summed, out + (size_t)(2 * slot_v) * half + jo, out + (size_t)(2 * slot_v + 1) * half + jo, nullptr, q0, q1);
+                if (summed) {
+                    const u64 hx = gl_add(xl, xr), hy = gl_add(yl, yr);
+                    Sx = e2_add(Sx, e2_mul_f(gm, hx));
+                    Sy = e2_add(Sy, e2_mul_f(gm, hy));
+                }
                 if (J.next_level) {
                     emit_rows(J.next_level, hN, 2 * j, H.emit_rd[at], make_ulonglong2(q0, q1));
                     xl = gl_add(xl, gamma2); yl = gl_add(yl, gamma2); xr = gl_add(xr, gamma2); yr = gl_add(yr, gamma2);

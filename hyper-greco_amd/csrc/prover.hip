@@ -1099,7 +1099,7 @@ struct Prover {
                 E2* fin = ctx->alloc_n<E2>(2 * (size_t)R + 1);
                 const bool run = mine(owner[n]) && R > (p0_only ? 1 : 0);
                 const bool slotted = !gp_slots.layer.empty();   // (decided with the hash sources, lasso_node)
-                if (slotted && (local || p0_only || !run || R != gp_slots.G)) throw Error("grand product: slot form on a partial batch");
+                if (slotted && (!run || R != gp_slots.G)) throw Error("grand product: the slot plan does not fit the rows held");
                 SlotPlan spl;
                 if (slotted) {
                     const SlotLayer& sl = gp_slots.layer[0];
@@ -1133,6 +1133,16 @@ struct Prover {
                 memset(&pwl, 0, sizeof(pwl));
                 for (int li = 0; li < nl; li++) pwl.v[li] = pw.v[(*local)[li]];
                 E2* fin = nl ? ctx->alloc_n<E2>(2 * (size_t)nl) : nullptr;
+                if (hash_src && k >= 1 && k < (int)gp_slots.layer.size()) {   // slot form below the top layer, on the rows this rank holds
+                    const SlotLayer& sl = gp_slots.layer[k];
+                    if (sl.nrows != nl || !mine(owner[n]) || !seq || nl <= (p0_only ? 1 : 0)) throw Error("grand product: the slot plan does not fit the rows held");
+                    SlotPlan spl;
+                    spl.tail_ntab = 2 * nl; spl.d_slot_of = sl.d_slot_of; spl.d_ratio = sl.d_ratio;
+                    spl.nrows = nl; spl.nslots = sl.V; spl.npairs = sl.ng; spl.max_rd = gp_slots.seg_shift;
+                    spl.job_slotw = sl.d_slotw; spl.job_emit = sl.d_emit;
+                    sc = sc_stride(dev::SC_GRANDPROD, lev[k], true, h, 2 * sl.V, n, pwl, fin, true, p0_only, seq, nxt, nullptr, nullptr, 2 * nl, &spl);
+                    slot_weights(sl, pwl, sc.rs[0]);
+                } else
                 sc = sc_stride(dev::SC_GRANDPROD, lev[k], true, h, 2 * nl, n, pwl, fin, mine(owner[n]) && nl > (p0_only ? 1 : 0), p0_only, seq, nxt, hs);
                 if (mine(owner[n]))
                     for (int li = p0_only ? 1 : 0; li < nl; li++) {
@@ -1429,8 +1439,21 @@ struct Prover {
             static const bool use_mirror_top = [] { const char* e = getenv("HG_NO_MIRROR"); return !(e && e[0] == '1'); }();
             gp_slots = GpSlots();
             const int nvars_top = nu - 1;
-            if (!split && !no_slots && use_mirror_top && G <= 32 && (int)hm.size() == G && L.seg_shift >= 9 && nvars_top - 1 > L.seg_shift &&
-                ((N / 2) >> L.seg_shift) <= 64 && nvars_top - 1 - slot_tail_h(2 * G + 1, nvars_top) <= L.seg_shift) {
+            // rows of the grand product as this rank holds them (all of them on one GPU; its own memories' on a sharded rank): reads first
+            std::vector<int> rowmem;    // memory-GKR index of row t
+            std::vector<char> roww;     // write row?
+            if (!split) { for (int t = 0; t < 2 * G; t++) { rowmem.push_back(t % G); roww.push_back(t >= G); } }
+            else for (int b : local_pairs) { rowmem.push_back(b % G); roww.push_back(b >= G); }
+            const int NL = (int)rowmem.size();
+            int R = 0;
+            while (R < NL && !roww[R]) R++;
+            std::vector<int> read_row_of(G, -1);
+            for (int t = 0; t < R; t++) read_row_of[rowmem[t]] = t;
+            bool rows_fit = (int)hm.size() == R && R >= 2 && NL <= 64;
+            for (int t = 0; t < R && rows_fit; t++) rows_fit = hm[t].rd_row == t;           // (the hash kernel walks hm by read row)
+            for (int t = R; t < NL && rows_fit; t++) rows_fit = roww[t] && read_row_of[rowmem[t]] >= 0;
+            if (rows_fit && !no_slots && use_mirror_top && G <= 32 && L.seg_shift >= 9 && nvars_top - 1 > L.seg_shift &&
+                ((N / 2) >> L.seg_shift) <= 64 && nvars_top - 1 - slot_tail_h(2 * R + 1, nvars_top) <= L.seg_shift) {
                 const int NP = (int)((N / 2) >> L.seg_shift);
                 auto cls = [&](int i, int s) -> int {   // class of GKR position i in row segment s: itself where its memory is looked up, else its chunk
                     if (((size_t)s << L.seg_shift) < L.rows && ((L.lookup_uses[lp.seg_lookup[s]] >> lp.gkr_order[i]) & 1)) return 1000 + i;
@@ -1453,13 +1476,13 @@ struct Prover {
                     }
                 static const int depth_max = [] { const char* e = getenv("HG_SLOT_DEPTH"); return e && *e ? atoi(e) : 4; }();
                 GpSlots& gs = gp_slots;
-                gs.NP = NP; gs.G = G; gs.seg_shift = L.seg_shift;
+                gs.NP = NP; gs.G = R; gs.seg_shift = L.seg_shift;
                 // layer d multiplies 2^(d+1) segments NP >> d apart: its classes are over those; rows: reads (layer 0), reads then writes
                 for (int d = 0; d < std::min(depth_max, emit); d++) {
                     SlotLayer sl;
-                    sl.ng = NP >> d; sl.nrows = d == 0 ? G : 2 * G;
+                    sl.ng = NP >> d; sl.nrows = d == 0 ? R : NL;
                     const int nvars_d = nu - 1 - d;
-                    if (sl.ng < 2 || nvars_d - 1 <= L.seg_shift || nvars_d - 1 - slot_tail_h(d == 0 ? 2 * G + 1 : 4 * G, nvars_d) > L.seg_shift) break;
+                    if (sl.ng < 2 || nvars_d - 1 <= L.seg_shift || nvars_d - 1 - slot_tail_h(d == 0 ? 2 * R + 1 : 2 * NL, nvars_d) > L.seg_shift) break;
                     sl.slot_of.assign((size_t)sl.nrows * sl.ng, 0);
                     std::vector<std::vector<int>> reps(sl.ng);
                     for (int g = 0; g < sl.ng; g++) {
@@ -1468,8 +1491,8 @@ struct Prover {
                             std::vector<int> key;
                             if (b == 0) key.push_back(-1);   // row 0 alone: p_0
                             else {
-                                key.push_back(b >= G ? 1 : 0);
-                                for (int q = 0; q < (2 << d); q++) key.push_back(cls(b % G, g + q * sl.ng));
+                                key.push_back(roww[b] ? 1 : 0);
+                                for (int q = 0; q < (2 << d); q++) key.push_back(cls(rowmem[b], g + q * sl.ng));
                             }
                             int v = -1;
                             for (size_t q = 0; q < keys.size(); q++) if (keys[q] == key) v = (int)q;
@@ -1487,15 +1510,15 @@ struct Prover {
                 for (size_t d = 0; d < gs.layer.size(); d++) {
                     SlotLayer& sl = gs.layer[d];
                     const SlotLayer* nx = d + 1 < gs.layer.size() ? &gs.layer[d + 1] : nullptr;
-                    const int T = nx ? nx->V : 2 * G, ngn = sl.ng / 2;
+                    const int T = nx ? nx->V : NL, ngn = sl.ng / 2;
                     std::vector<u64> em((size_t)sl.V * sl.ng * (d == 0 ? 2 : 1), 0);
                     for (int g = 0; g < sl.ng; g++)
                         for (int t = 0; t < T; t++) {
                             const int b = nx ? nx->rep[(size_t)t * ngn + (g % ngn)] : t;   // the row whose values target row t holds there
                             if (b == 255) continue;
-                            if (d == 0) {
-                                const int u = sl.slot_of[(size_t)(b % G) * sl.ng + g];
-                                em[(b >= G ? (size_t)sl.V * sl.ng : 0) + (size_t)u * sl.ng + g] |= (u64)1 << t;
+                            if (d == 0) {   // (the top layer holds the read rows only: a write row's values come from its read row's class)
+                                const int u = sl.slot_of[(size_t)(roww[b] ? read_row_of[rowmem[b]] : b) * sl.ng + g];
+                                em[(roww[b] ? (size_t)sl.V * sl.ng : 0) + (size_t)u * sl.ng + g] |= (u64)1 << t;
                             } else em[(size_t)sl.slot_of[(size_t)b * sl.ng + g] * sl.ng + g] |= (u64)1 << t;
                         }
                     sl.d_slot_of = ctx->alloc_n<uint8_t>(sl.slot_of.size());
