@@ -440,7 +440,7 @@ struct Prover {
         // launch plan: (kind, base? | fused pair?, h_log2 | tail) -> items (job, where the round reads and writes).
         // Folded tables ping-pong between the job's two buffers; the host tracks where each job's live tables are.
         static const bool fuse2 = [] { const char* e = getenv("HG_NO_FUSE2"); return !(e && e[0] == '1'); }();
-        static const int fuse_min_h = [] { const char* e = getenv("HG_FUSE_MIN_H"); return e && *e ? atoi(e) : 13; }();
+        static const int fuse_min_h = [] { const char* e = getenv("HG_FUSE_MIN_H"); return e && *e ? atoi(e) : 15; }();   // (13 until the slot form; 1.96-1.99 against 1.99-2.01 ms at 15, three interleaved A/Bs)
         struct Launch { int kind; bool base; int h_log2; bool tail; int nrounds; std::vector<dev::StItem> items; bool hash = false; bool after_seq = false; };
         std::vector<Launch> plan;
         struct Regroup { int job; const E2* in; E2* out; int len_log2; };
@@ -702,7 +702,7 @@ struct Prover {
         // plan every step first (step s = every job's next round, or its next two rounds when its table is long
         // enough), upload all items in one copy, then launch; the host tracks each job's ping-pong buffer
         static const bool ps_fuse2 = [] { const char* e = getenv("HG_NO_PS_FUSE2"); return !(e && e[0] == '1'); }();
-        static const int ps_fuse_min_h = [] { const char* e = getenv("HG_PS_FUSE_MIN_H"); return e && *e ? atoi(e) : 11; }();
+        static const int ps_fuse_min_h = [] { const char* e = getenv("HG_PS_FUSE_MIN_H"); return e && *e ? atoi(e) : 9; }();   // (11 until the node reductions moved to the third stream: 1.92-1.94 against 1.96 ms)
         struct PsLaunch { bool two; int cnt, grid; size_t off; double bytes; };
         std::vector<PsLaunch> launches;
         std::vector<dev::PsItem> all_items;

@@ -807,7 +807,7 @@ def test_launch_graph_that_replays_slower_than_plain_launches_is_given_up():
 @pytest.mark.parametrize("switch", ["HG_E_TABLES=1", "HG_NO_MIRROR=1", "HG_NO_HASH_FUSE=1", "HG_ONE_STREAM=1", "HG_NO_GRAPH=1", "HG_TAIL_H=4", "HG_LATE_OPENINGS=0", "HG_LATE_OPENINGS=1",
                                     "HG_LATE_OPENINGS=2", "HG_NO_LEVEL3=1", "HG_GRAPH_UPLOADS=1", "HG_LASSO_SCHED=2", "HG_LASSO_SCHED=0", "HG_NO_FUSE2=1",
                                     "HG_GATHER_CSR=1", "HG_EQ_ONE_LAUNCH=1", "HG_PS_TAIL_THREADS=256", "HG_NO_EARLY_REPLAY=1", "HG_NO_TABLE_SHARE=1", "HG_OPEN_GROUPS=1", "HG_NO_SLOTS=1", "HG_SLOT_DEPTH=1",
-                                    "HG_SLOT_DEPTH=2"])
+                                    "HG_SLOT_DEPTH=2", "HG_FUSE_MIN_H=13", "HG_NODES_STREAM=2", "HG_PS_FUSE_MIN_H=11"])
 def test_alternative_paths_behind_the_environment_switches_stay_bit_exact(switch):
     """Every switch that selects an older or alternative device path (E tables materialised, both rows of the top layer, hash tables,
     one stream, plain launches, the five-round tail, the openings behind / between the node reductions, one tree level per launch, upload
