@@ -846,11 +846,14 @@ __global__ void k_bn_prod_level(const Fr* __restrict__ in, size_t in_len, Fr* __
 }
 // the same with the row index on grid.y (uniform per workgroup), so that the weight of row b is a LAUNCH-WIDE constant of the
 // workgroup: lw = pw[b] * v runs through fr_fold_const with the row's precomputed constants fk[b] (k_bn_fold_consts)
-__global__ void k_bn_prod_level_rows(const Fr* __restrict__ in, size_t in_len, Fr* __restrict__ out, const FoldK* __restrict__ fk, Fr* __restrict__ lw) {
+// slot_of (optional): `in` holds slot rows - row b's values at entry j are those of slot row slot_of[b * ng + (j >> seg_shift)]
+__global__ void k_bn_prod_level_rows(const Fr* __restrict__ in, size_t in_len, Fr* __restrict__ out, const FoldK* __restrict__ fk, Fr* __restrict__ lw,
+                                     const unsigned char* __restrict__ slot_of = nullptr, int ng = 0, int seg_shift = 0) {
     const size_t h = in_len >> 1, b = blockIdx.y;
     const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= h) return;
-    const Fr v = lz_mul(lz_gload(&in[b * in_len + j]), lz_gload(&in[b * in_len + j + h]));
+    const size_t rb = slot_of ? slot_of[b * (size_t)ng + (j >> seg_shift)] : b;
+    const Fr v = lz_mul(lz_gload(&in[rb * in_len + j]), lz_gload(&in[rb * in_len + j + h]));
     lz_gstore(&out[b * h + j], v);
     if (j < (h >> 1)) lz_gstore(&lw[b * (h >> 1) + j], b == 0 ? v : lz_fold(fr_zero(), v, fk[b].k));
 }
@@ -885,6 +888,60 @@ __global__ void k_bn_prod_level_mirror(const Fr* __restrict__ in, size_t in_len,
         lz_gstore(&lw[b * (h >> 1) + j], b == 0 ? v : lz_fold(fr_zero(), v, fk[b].k));
         lz_gstore(&lw[(b + half) * (h >> 1) + j], lz_fold(fr_zero(), vw, fk[b + half].k));
     }
+}
+// Level 1 of a mirrored product whose NEXT layer runs in slot form (GpSlots::deep[0]): one thread per entry of a level-1 SLOT row (slot on
+// grid.y). rep1 names the row (b < nb/2: read row of memory b, else the write row of memory b - nb/2) whose product the slot row holds
+// in the entry's segment group; the level-0 values come from the slot rows of the top layer through slot_of0 as in
+// k_bn_prod_level_mirror. lw: the next layer's left halves with the class weights (fkW[slot * ng1 + group]) folded in.
+__global__ void k_bn_prod_level_mirror_slots(const Fr* __restrict__ in, size_t in_len, Fr* __restrict__ out, int nb, Fr c2, FoldK kc, const FoldK* __restrict__ fkW,
+                                             Fr* __restrict__ lw, const unsigned char* __restrict__ slot_of0, int npairs, const unsigned char* __restrict__ rep1, int ng1,
+                                             int seg_shift) {
+    const size_t h = in_len >> 1, half = (size_t)nb / 2, v1 = blockIdx.y;
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= h) return;
+    const int seg = __builtin_amdgcn_readfirstlane((int)(j >> seg_shift));   // (a wave's 64 consecutive entries lie in one segment)
+    const int grp = seg % ng1;
+    const int b = rep1[v1 * (size_t)ng1 + grp];
+    Fr v = fr_zero();
+    if (b != 255) {
+        const size_t mem = (size_t)b % half;
+        const size_t rb = slot_of0[mem * (size_t)npairs + seg];
+        const Fr x = lz_gload(&in[rb * in_len + j]), y = lz_gload(&in[rb * in_len + j + h]);
+        v = lz_mul(x, y);
+        if ((size_t)b >= half) v = lz_add(v, lz_fold(c2, lz_add(x, y), kc.k));   // (x + c)(y + c)
+    }
+    lz_gstore(&out[v1 * h + j], v);
+    if (j < (h >> 1)) lz_gstore(&lw[v1 * (h >> 1) + j], (v1 == 0 || b == 255) ? v : lz_fold(fr_zero(), v, fkW[v1 * (size_t)ng1 + grp].k));
+}
+// A deeper level in slot form from the slot rows of the level above: entry j of slot row v = the product entry of row b = rep_out[v][group
+// of j], whose values in the level above are those of slot row slot_of_in[b][group of j there]; lw as in k_bn_prod_level_mirror_slots.
+__global__ void k_bn_prod_level_slots(const Fr* __restrict__ in, size_t in_len, Fr* __restrict__ out, const FoldK* __restrict__ fkW, Fr* __restrict__ lw,
+                                      const unsigned char* __restrict__ slot_of_in, int ng_in, const unsigned char* __restrict__ rep_out, int ng_out, int seg_shift) {
+    const size_t h = in_len >> 1, v = blockIdx.y;
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= h) return;
+    const int gin = __builtin_amdgcn_readfirstlane((int)(j >> seg_shift));   // group in the level above (0 .. ng_in - 1: j < h = half a row)
+    const int grp = gin % ng_out;
+    const int b = rep_out[v * (size_t)ng_out + grp];
+    Fr x = fr_zero();
+    if (b != 255) {
+        const size_t rb = slot_of_in[(size_t)b * ng_in + gin];
+        x = lz_mul(lz_gload(&in[rb * in_len + j]), lz_gload(&in[rb * in_len + j + h]));
+    }
+    lz_gstore(&out[v * h + j], x);
+    if (j < (h >> 1)) lz_gstore(&lw[v * (h >> 1) + j], (v == 0 || b == 255) ? x : lz_fold(fr_zero(), x, fkW[v * (size_t)ng_out + grp].k));
+}
+// The per-row tables of a slot-form layer ahead of its tail: tables of `len` >= ng entries each (entry j belongs to group j >> sh), table
+// 2v / 2v + 1 = left / right of slot v at in + t * len; out: the same layout over the nrows rows (left: times ratio[row][group]).
+__global__ void k_bn_gp_regroup_tab(const Fr* __restrict__ in, Fr* __restrict__ out, const unsigned char* __restrict__ slot_of, const Fr* __restrict__ ratio, int nrows, int ng,
+                                    int len, int sh) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nrows * len) return;
+    const int b = idx / len, j = idx % len, g = j >> sh;
+    const int v = slot_of[b * ng + g];
+    const Fr l = in[(size_t)(2 * v) * len + j], r = in[(size_t)(2 * v + 1) * len + j];
+    out[(size_t)(2 * b) * len + j] = b == 0 ? l : lz_mul(ratio[b * ng + g], l);
+    out[(size_t)(2 * b + 1) * len + j] = r;
 }
 // The short end of the product tree in ONE single-workgroup launch: every level whose rows are shorter than 256 entries (a level
 // reads the one before it: the workgroup barrier orders them), then the root products and the canonical copies of the roots and of
@@ -968,6 +1025,7 @@ struct GpLaunchSet {
     std::vector<TailJobDev> tails;
     std::vector<std::function<void()>> posts;   // after the rounds: final values of layers without a tail
     std::vector<std::pair<size_t, std::function<void()>>> pre;   // (round, launch) ahead of that round's launch (the slot form's regroup)
+    std::vector<std::function<void()>> pre_tail;                 // ahead of the tail launch (the regroup of a slot-form layer with a tail)
     std::vector<size_t> wgs;                    // per round: workgroups of the jobs queued so far at gy = 1 (round_grid_gp)
     void merge(GpLaunchSet& o) {
         if (wgs.size() < o.wgs.size()) wgs.resize(o.wgs.size(), 0);
@@ -978,6 +1036,7 @@ struct GpLaunchSet {
         tails.insert(tails.end(), o.tails.begin(), o.tails.end());
         posts.insert(posts.end(), o.posts.begin(), o.posts.end());
         pre.insert(pre.end(), o.pre.begin(), o.pre.end());
+        pre_tail.insert(pre_tail.end(), o.pre_tail.begin(), o.pre_tail.end());
     }
 };
 static void gp_launch_set(hg_ctx* ctx, hipStream_t st, GpLaunchSet& S) {
@@ -1001,6 +1060,7 @@ static void gp_launch_set(hg_ctx* ctx, hipStream_t st, GpLaunchSet& S) {
         if (!S.by_rd[rd].empty()) k_bn_gp_round_jobs<<<dim3(max_blocks[rd], (unsigned)S.by_rd[rd].size(), 1), BN_TPB, 0, st>>>(d_descs + off[rd]);
     }
     if (!S.reds.empty()) k_bn_reduce_jobs<<<dim3(32, (unsigned)S.reds.size()), BN_TPB, 0, st>>>(d_reds, 3);
+    for (auto& f : S.pre_tail) f();
     if (!S.tails.empty()) k_bn_tail_jobs<BN_GRANDPROD><<<(unsigned)S.tails.size(), 3 * BN_TPB, 0, st>>>(d_tails);
     for (auto& f : S.posts) f();
 }
@@ -1019,6 +1079,20 @@ struct GpSlots {
     std::vector<unsigned char> rep;       // [V][npairs]
     const unsigned char* d_slot_of = nullptr;
     const unsigned char* d_rep = nullptr;
+    // The layers below the top one in slot form as well (HG_BN_SLOT_DEPTH = number of slot-form layers, 1 = the top one only): the first multiplies FOUR segments npairs / 2 apart,
+    // its rows are the nb read and write rows; V classes per group of four (slot 0 = row 0 alone). Level 1 of the tree is then V
+    // slot rows (k_bn_prod_level_mirror_slots: entry j of slot row v = the product entry of row rep[v][group of j]), whose left
+    // halves carry the class weights; the layer's shared rounds run on V pairs and k_bn_gp_regroup_tab gathers the per-row tables for its tail.
+    // deep[q]: layer nv - 2 - q (2^(q+2) segments npairs >> (q+1) apart); level q + 1 of the tree is its V slot rows
+    // (k_bn_prod_level_slots from the slot rows of the level above), the first level below the last slot-form layer is read back per row.
+    struct Deep {
+        int V = 0, ng = 0;
+        std::vector<unsigned char> slot_of;  // [nb][ng]
+        std::vector<unsigned char> rep;      // [V][ng] (255: no such class in that group)
+        const unsigned char* d_slot_of = nullptr;
+        const unsigned char* d_rep = nullptr;
+    };
+    std::vector<Deep> deep;
 };
 // mirror_c (Montgomery, optional): rows nb/2 .. nb-1 of level 0 are rows 0 .. nb/2-1 plus this constant (the Lasso write hashes are
 // the read hashes + gamma^2): the top layer then runs on the read rows only (GpJobDev::mirror) and d_lev0 HOLDS ONLY THOSE nb/2
@@ -1096,6 +1170,40 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
             k_bn_gamma_powers<<<dim3((unsigned)((nb + 255) / 256), nv), 256, 0, st>>>(pw_all, gammas, (int)nb);
             k_bn_fold_consts<<<(unsigned)(((size_t)nv * nb * 8 + 255) / 256), 256, 0, st>>>(pw_all, fk_all, (size_t)nv * nb);
         }
+        // slot form of the layers below the top one (GpSlots::deep): class weights, their fold constants, gamma^b / W per (row, group)
+        int D1 = 0;   // deep layers in slot form: layer nv - 2 - q for q < D1 (each needs a tail that starts while a table still has an entry per group)
+        while (slots && D1 < (int)slots->deep.size() && nv - 2 - D1 >= 1 && plan[nv - 2 - D1].nmain < nv - 2 - D1 && plan[nv - 2 - D1].nmain <= slots->seg_shift &&
+               (len >> (D1 + 2)) >= 256) D1++;   // (levels 1 .. D1 + 1 go through the long-row kernels)
+        std::vector<const FoldK*> fkW(D1, nullptr);
+        std::vector<const Fr*> deep_ratio(D1, nullptr);
+        for (int q = 0; q < D1; q++) {
+            const GpSlots::Deep& dp = slots->deep[q];
+            const int n = nv - 2 - q, V1 = dp.V, NG = dp.ng;
+            const Fr g = fr_to_mont(chain[layers[n].gamma_at]);
+            std::vector<Fr> pwh(nb), W((size_t)V1 * NG, fr_zero()), ratio((size_t)nb * NG, fr_zero());
+            { Fr w = fr_one_mont(); for (size_t b = 0; b < nb; b++) { pwh[b] = w; w = fr_mul(w, g); } }
+            for (size_t b = 0; b < nb; b++)
+                for (int u = 0; u < NG; u++) { Fr& x = W[(size_t)dp.slot_of[b * NG + u] * NG + u]; x = fr_add(x, pwh[b]); }
+            std::vector<size_t> idx;
+            for (size_t u = 0; u < W.size(); u++) if (W[u].l[0] | W[u].l[1] | W[u].l[2] | W[u].l[3]) idx.push_back(u);
+            std::vector<Fr> pre(idx.size() + 1, fr_one_mont());
+            for (size_t u = 0; u < idx.size(); u++) pre[u + 1] = fr_mul(pre[u], W[idx[u]]);
+            Fr inv = fr_inv(pre[idx.size()]);
+            std::vector<Fr> Winv(W.size(), fr_zero());
+            for (size_t u = idx.size(); u-- > 0;) { Winv[idx[u]] = fr_mul(inv, pre[u]); inv = fr_mul(inv, W[idx[u]]); }
+            for (size_t b = 0; b < nb; b++)
+                for (int u = 0; u < NG; u++) {
+                    const size_t w = (size_t)dp.slot_of[b * NG + u] * NG + u;
+                    if (!(W[w].l[0] | W[w].l[1] | W[w].l[2] | W[w].l[3])) throw Error("hg_grand_product_bn254: degenerate batching challenge (a class weight is zero)");
+                    ratio[b * NG + u] = fr_mul(pwh[b], Winv[w]);
+                }
+            const Fr* dW = bn_stage(ctx, W.data(), W.size());
+            deep_ratio[q] = bn_stage(ctx, ratio.data(), ratio.size());
+            bn_flush(ctx, st);
+            FoldK* fk = static_cast<FoldK*>(ctx->alloc(W.size() * sizeof(FoldK)));
+            k_bn_fold_consts<<<(unsigned)((W.size() * 8 + 255) / 256), 256, 0, st>>>(dW, fk, W.size());
+            fkW[q] = fk;
+        }
         // the product tree; level k (rows of length len >> k) is read by layer n = nv - 1 - k, whose weighted left halves are written
         // in the same pass (level 0, the input, gets its own pass below)
         ProdTailLevels tl;
@@ -1110,12 +1218,22 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
                 FoldK kc;
                 fold_consts(*mirror_c, &kc);
                 const size_t hh = len >> 1;
+                if (D1 >= 1) k_bn_prod_level_mirror_slots<<<dim3((unsigned)((hh + 255) / 256), (unsigned)slots->deep[0].V), 256, 0, st>>>(lev[0], len, lk, (int)nb, fr_mul(*mirror_c, *mirror_c), kc, fkW[0], lw_n,
+                                                                                                                      slots->d_slot_of, slots->npairs, slots->deep[0].d_rep, slots->deep[0].ng, slots->seg_shift);
+                else
                 k_bn_prod_level_mirror<<<dim3((unsigned)((hh + 255) / 256), (unsigned)(nb / 2)), 256, 0, st>>>(lev[0], len, lk, (int)nb, *mirror_c, fr_mul(*mirror_c, *mirror_c), kc,
                                                                                                       n >= 1 ? fk_all + (size_t)n * nb : nullptr, lw_n,
                                                                                                       slots ? slots->d_slot_of : nullptr, slots ? slots->npairs : 0, slots ? slots->seg_shift : 0);
             }
             else if (lw_n && (len >> k) >= 256) {   // long rows: the row index on grid.y, the row's weight as a launch-wide constant
                 const size_t hh = len >> k;
+                if (k >= 2 && k - 1 < D1)          // slot rows of the level above -> this level's slot rows (layer nv - 1 - k = deep[k - 1])
+                    k_bn_prod_level_slots<<<dim3((unsigned)((hh + 255) / 256), (unsigned)slots->deep[k - 1].V), 256, 0, st>>>(lev[k - 1], len >> (k - 1), lk, fkW[k - 1], lw_n, slots->deep[k - 2].d_slot_of,
+                                                                                                                      slots->deep[k - 2].ng, slots->deep[k - 1].d_rep, slots->deep[k - 1].ng, slots->seg_shift);
+                else if (k >= 2 && k - 2 < D1)     // the first level below the slot-form layers: per row, read through the map of the layer above
+                    k_bn_prod_level_rows<<<dim3((unsigned)((hh + 255) / 256), (unsigned)nb), 256, 0, st>>>(lev[k - 1], len >> (k - 1), lk, fk_all + (size_t)n * nb, lw_n,
+                                                                                                   slots->deep[k - 2].d_slot_of, slots->deep[k - 2].ng, slots->seg_shift);
+                else
                 k_bn_prod_level_rows<<<dim3((unsigned)((hh + 255) / 256), (unsigned)nb), 256, 0, st>>>(lev[k - 1], len >> (k - 1), lk, fk_all + (size_t)n * nb, lw_n);
             }
             else {   // short rows: queued for the single-workgroup launch below
@@ -1208,7 +1326,7 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
                 d.r = fr_to_mont(chain[layers[n].r_at + rd]);
                 fold_consts(d.r, &d.fk);
                 d.half = half;
-                d.nb = (int)nb;
+                d.nb = (nv - 2 - n >= 0 && nv - 2 - n < D1) ? slots->deep[nv - 2 - n].V : (int)nb;
                 if (P.mirror) {
                     // sum_b w_b l_b r_b over reads and writes = (1 + kappa) [sum_reads w l r + K1 S + K2], kappa = gamma^(nb/2), c = *mirror_c:
                     // K1 = kappa c / (1 + kappa), K2 = kappa c^2 sum_{b < nb/2} gamma^b / (1 + kappa); the host applies 1 + kappa
@@ -1236,10 +1354,24 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
             const LayerRec& L = layers[n];
             RedJobDev& r = reds[red_index[n]];
             r.part = P.part; r.out = L.d_sums; r.nrounds = P.nmain;
-            const Fr* last = ((P.nmain - 1) & 1) ? P.buf1 : P.buf0;   // output of the last shared round
+            const Fr* last = ((P.nmain - 1) & 1) ? P.buf1 : P.buf0;   // output of the last shared round (not const: a slot-form layer regroups it)
             if (P.nmain < n) {
                 TailJobDev t;
                 memset(&t, 0, sizeof(t));
+                if (nv - 2 - n >= 0 && nv - 2 - n < D1) {   // back to one pair per row ahead of the tail
+                    const GpSlots::Deep& dp = slots->deep[nv - 2 - n];
+                    const int tlen = (int)(((size_t)1 << n) >> P.nmain);   // table length after the shared rounds (>= ng entries)
+                    int sh = 0;
+                    while ((dp.ng << sh) < tlen) sh++;
+                    if ((dp.ng << sh) != tlen) throw Error("grand_product_core: slot tables shorter than the segment groups");
+                    Fr* rg = dalloc(ntab * (size_t)tlen);
+                    const Fr* prev = last;
+                    const unsigned char* so = dp.d_slot_of;
+                    const Fr* ra = deep_ratio[nv - 2 - n];
+                    const int nr = (int)nb, ng = dp.ng;
+                    own.pre_tail.push_back([prev, rg, so, ra, nr, ng, tlen, sh, st] { k_bn_gp_regroup_tab<<<(unsigned)((nr * tlen + 255) / 256), 256, 0, st>>>(prev, rg, so, ra, nr, ng, tlen, sh); });
+                    last = rg;
+                }
                 t.in = last; t.buf = P.tbuf; t.sums_out = L.d_sums + (size_t)P.nmain * 3; t.fin_out = L.d_final;
                 for (int q = 0; q < BN_TAIL_ROUNDS; q++) t.rs.r[q] = q < n - P.nmain ? fr_to_mont(chain[L.r_at + P.nmain + q]) : fr_zero();
                 t.npairs = (int)nb; t.half0 = (int)(((size_t)1 << n) >> (P.nmain + 1)); t.nrounds = n - P.nmain;
@@ -1983,11 +2115,39 @@ static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4,
             if (V < G) {   // (nothing to gain otherwise)
                 slots.d_slot_of = bn_stage(ctx, slots.slot_of.data(), slots.slot_of.size());
                 slots.d_rep = bn_stage(ctx, slots.rep.data(), slots.rep.size());
+                // the layers below: layer q + 1 multiplies 2^(q+2) segments NP >> (q+1) apart; read and write rows apart, row 0 alone
+                static const int depth = [] { const char* e = getenv("HG_BN_SLOT_DEPTH"); return e && *e ? atoi(e) : 4; }();
+                for (int q = 0; q + 2 <= depth && (NP >> (q + 1)) >= 2 && 2 * G <= 254; q++) {
+                    GpSlots::Deep dp;
+                    const int NG = NP >> (q + 1), cnt = 4 << q;
+                    dp.ng = NG;
+                    dp.slot_of.assign((size_t)2 * G * NG, 0);
+                    std::vector<std::vector<int>> reps1(NG);
+                    for (int u = 0; u < NG; u++) {
+                        std::vector<std::vector<int>> keys;
+                        for (int b = 0; b < 2 * G; b++) {
+                            std::vector<int> key;
+                            if (b == 0) key.push_back(-1);
+                            else { key.push_back(b >= G ? 1 : 0); for (int t = 0; t < cnt; t++) key.push_back(cls(b % G, u + t * NG)); }
+                            int v = -1;
+                            for (size_t w = 0; w < keys.size(); w++) if (keys[w] == key) v = (int)w;
+                            if (v < 0) { v = (int)keys.size(); keys.push_back(key); reps1[u].push_back(b); }
+                            dp.slot_of[(size_t)b * NG + u] = (unsigned char)v;
+                        }
+                        dp.V = std::max(dp.V, (int)keys.size());
+                    }
+                    if (dp.V >= 2 * G) break;
+                    dp.rep.assign((size_t)dp.V * NG, 255);
+                    for (int u = 0; u < NG; u++) for (size_t v = 0; v < reps1[u].size(); v++) dp.rep[v * NG + u] = (unsigned char)reps1[u][v];
+                    dp.d_slot_of = bn_stage(ctx, dp.slot_of.data(), dp.slot_of.size());
+                    dp.d_rep = bn_stage(ctx, dp.rep.data(), dp.rep.size());
+                    slots.deep.push_back(std::move(dp));
+                }
                 bn_flush(ctx, st);
             } else slots.V = 0;
         }
         const bool use_slots = slots.V > 0;
-        if (getenv("HG_BN_TIMES")) fprintf(stderr, "[hg bn]   read rows: %d slot rows for %d memories, %d segment pairs of 2^%d rows\n", use_slots ? slots.V : G, G, slots.npairs, slots.seg_shift);
+        if (getenv("HG_BN_TIMES")) fprintf(stderr, "[hg bn]   read rows: %d slot rows for %d memories, %d segment pairs of 2^%d rows; %d slot-form layers below\n", use_slots ? slots.V : G, G, slots.npairs, slots.seg_shift, (int)slots.deep.size());
         Fr* H1 = dalloc((size_t)(use_slots ? slots.V : (mirror ? G : 2 * G)) * N);
         Fr* H2 = dalloc((size_t)2 * G * M);
         {   // every memory's read (write) hash rows and init / final rows in one launch
