@@ -63,7 +63,8 @@ struct GpHashSrc {
     // both segments ("joint class") contribute w_b l r with the same l r. slot_of[row * npairs + sp] numbers the joint classes of
     // segment pair sp (slot 0 = row 0 alone), rep[slot * npairs + sp] names the read row that represents a slot there, slotw[(slot *
     // npairs + sp) * 2] = the class weight sum_b gamma^b and [.. + 1] = that times r_0. The job then holds 2 V + 1 tables (the
-    // slots' weighted left / right halves and S); product-tree level 1 is still emitted per memory row. null: memory form.
+    // slots' weighted left / right halves and S); rep = 255: no such class in that segment pair (its tables are zero there).
+    // null: memory form (k_gp_first_hash<.., SLOT = false>).
     const uint8_t* slot_of;
     const uint8_t* rep;
     const E2* slotw;

@@ -926,21 +926,15 @@ struct Prover {
         for (int n = 0; n < nv; n++) if (mine(owner[n])) deepest = std::max(deepest, nv - 1 - n);
         return deepest;
     }
-    // lev1 (optional): the first tree level, already produced by the hash kernel.
-    // `local` (multi-GPU split by batch item): H holds only the rows of the global pairs listed in `local` (ascending);
-    // with p0_only the first of them is pair 0, held only to supply p_0.
-    // `hash_src` (device pointer): level 0 is not materialised, the top layer's first round recomputes it (k_gp_first_hash).
-    // `emit` > 0: tree levels 1 .. emit are written by the first rounds of the top `emit` layers (their products ARE the next
-    // level), which therefore run one after the other before everything else; the remaining small levels follow them.
     // Joint classes of the read rows of the Lasso top layer (GpHashSrc::slot_of), built with the hash sources in lasso_node
-    // (layer 0 = the top layer, rows = the G read rows; layer d >= 1: rows = the 2 G read and write rows, groups of 2^(d+1) segments)
+    // (layer 0 = the top layer, rows = the read rows held; layer d >= 1: rows = the read and write rows held, groups of 2^(d+1) segments)
     struct SlotLayer {
         int V = 0, ng = 0, nrows = 0;
         std::vector<uint8_t> slot_of, rep;   // [row * ng + group], [slot * ng + group] (255: no such class there)
         uint8_t* d_slot_of = nullptr; uint8_t* d_rep = nullptr; E2* d_slotw = nullptr; E2* d_ratio = nullptr;
         u64* d_emit = nullptr;               // layer 0: V * ng read masks then V * ng write masks
     };
-    struct GpSlots { int V = 0, NP = 0, G = 0, seg_shift = 0; std::vector<SlotLayer> layer; } gp_slots;
+    struct GpSlots { int V = 0, NP = 0, G = 0 /* read rows held */, seg_shift = 0; std::vector<SlotLayer> layer; } gp_slots;
     // class weights W[v][g] = sum of the members' gamma^b (and W r_0 for the first round's weighted fold), and per row gamma^b / W of
     // its class: what turns a class's folded left table back into the row's (gp_slot_regroup)
     void slot_weights(const SlotLayer& sl, const dev::Powers& pw, E2 r0) {
@@ -965,6 +959,12 @@ struct Prover {
         upload(sl.d_slotw, slotw.data(), slotw.size() * sizeof(E2), "upload slot weights");
         upload(sl.d_ratio, ratio.data(), ratio.size() * sizeof(E2), "upload slot ratios");
     }
+    // lev1 (optional): the first tree level, already produced by the hash kernel.
+    // `local` (multi-GPU split by batch item): H holds only the rows of the global pairs listed in `local` (ascending);
+    // with p0_only the first of them is pair 0, held only to supply p_0.
+    // `hash_src` (device pointer): level 0 is not materialised, the top layer's first round recomputes it (k_gp_first_hash).
+    // `emit` > 0: tree levels 1 .. emit are written by the first rounds of the top `emit` layers (their products ARE the next
+    // level), which therefore run one after the other before everything else; the remaining small levels follow them.
     GpOut grand_product(const u64* H, size_t len, int nb, const std::vector<int>& owner, const u64* lev1 = nullptr,
                         const std::vector<int>* local = nullptr, bool p0_only = false, const dev::GpHashSrc* hash_src = nullptr, int emit = 0,
                         double hash_fused_bytes = 0, const u64* mirror_c = nullptr) {
