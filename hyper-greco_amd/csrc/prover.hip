@@ -1530,6 +1530,11 @@ struct Prover {
                     upload(sl.d_rep, sl.rep.data(), sl.rep.size(), "upload slot representatives");
                     upload(sl.d_emit, em.data(), em.size() * sizeof(u64), "upload slot emission masks");
                 }
+                if (getenv("HG_SLOT_DEBUG")) {
+                    std::string vs;
+                    for (auto& sl : gs.layer) vs += " " + std::to_string(sl.V) + "/" + std::to_string(sl.nrows);
+                    fprintf(stderr, "[hg slots] adopted: %d layers, classes / rows per layer:%s\n", (int)gs.layer.size(), vs.c_str());
+                }
                 if (!gs.layer.empty()) {
                     const SlotLayer& s0 = gs.layer[0];
                     gs.V = s0.V;

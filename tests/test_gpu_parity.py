@@ -1416,3 +1416,28 @@ def test_bn254_prove_other_parameter_sets_accepted_by_the_host_verifier(ctx, n, 
     proof2, _, _ = ctx.prove_bn254(pk, w, cap=1 << 25)   # determinism + arena reuse
     assert proof2 == proof
     pk.free()
+
+
+@pytest.mark.gpu
+def test_slot_form_is_the_path_that_runs():
+    """The slot form of grand product #1 must actually be taken where it applies - otherwise the switch tests above would
+    compare the memory form with itself. HG_SLOT_DEBUG=1 makes the library report the layers it adopted; HG_BN_TIMES=1 the bn254 prove's."""
+    import subprocess, sys
+    from hglib import ROOT
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import __graft_entry__ as entry\n"
+        "hg = entry.load_package()\n"
+        "ctx = hg.Context(0); bfv = hg.BfvEncrypt.new(4096, 2); pk = bfv.setup(ctx)\n"
+        "w = hg.Witness.synthetic(bfv.params, 5); v = hg.witness_gen(ctx, pk, w); out = hg.ProofBuffer()\n"
+        "hg.prove_resident(ctx, pk, v, out)\n"
+        "ctx.prove_bn254(pk, w, cap=1 << 24)\n"
+        "print('RAN')\n"
+    ) % (ROOT,)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, HG_SLOT_DEBUG="1", HG_BN_TIMES="1"), cwd=ROOT)
+    assert r.returncode == 0 and "RAN" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+    adopted = [l for l in r.stderr.splitlines() if l.startswith("[hg slots] adopted:")]
+    assert adopted and int(adopted[0].split()[3]) >= 2, r.stderr[-2000:]          # the top layer and at least one below it
+    bn = [l for l in r.stderr.splitlines() if "slot rows for" in l]
+    assert bn and int(bn[0].split("read rows:")[1].split()[0]) < int(bn[0].split("slot rows for")[1].split()[0]), r.stderr[-2000:]
+    assert int(bn[0].split("rows;")[1].split()[0]) >= 1, r.stderr[-2000:]       # ... and in the bn254 prove
