@@ -214,6 +214,7 @@ int hg_setup(hg_ctx* ctx, const hg_params* params, hg_pk** out) {
         std::vector<std::vector<const MulTerm*>> ml_by(n.arity), mr_by(n.arity);
         for (auto& t : n.lin) lin_by[t.in].push_back(&t);
         for (auto& t : n.mul) { ml_by[t.i0].push_back(&t); mr_by[t.i1].push_back(&t); }
+        std::vector<std::vector<dev::GatherSeg>> segs_of(n.arity);   // run-length form per input (empty: not affine), for eq_form below
         for (int i = 0; i < n.arity; i++) {
             if (!lin_by[i].empty()) {
                 std::vector<u32> ptr, gate(lin_by[i].size());
@@ -259,6 +260,7 @@ int hg_setup(hg_ctx* ctx, const hg_params* params, hg_pk** out) {
                     segs.push_back(dev::GatherSeg{t.x, t.x + 1, (int)t.goff, t.other_in, (int)t.joff, 0, t.c});
                 }
                 if (ok) {
+                    segs_of[i] = segs;
                     hg_pk::NodeDev::Seg& sg = nd.seg[i];
                     sg.nseg = (int)segs.size();
                     sg.d = upload_vec(pk.get(), segs);
@@ -270,6 +272,53 @@ int hg_setup(hg_ctx* ctx, const hg_params* params, hg_pk** out) {
                     for (auto& q : segs) { sg.win_lo = std::min<size_t>(sg.win_lo, q.lo); sg.win_hi = std::max<size_t>(sg.win_hi, q.hi); }
                 }
             }
+        }
+        {   // eq-factored form of the node's Libra phase 1 (kernels.hpp PsJob::eq_n): no mul gates, every used input relays the same
+            // aligned window [lo, lo + 2^w) of its positions onto aligned 2^w blocks of gates (any constant coefficient per block),
+            // constants constant over such blocks. Table i is then kappa_i eq(z', .), kappa_i = sum_t coef_t eq(z_(w..); block_t).
+            hg_pk::NodeDev::EqForm& ef = nd.eq_form;
+            const int nin = n.log2_sub_in + n.log2_reps;
+            bool ok = n.mul.empty() && nin <= dev::PS_EQ_MAX_VARS;
+            long long lo0 = -1; int w0 = -1;
+            ef.terms.assign(n.arity, {});
+            int used = 0;
+            for (int i = 0; i < n.arity && ok; i++) {
+                if (!n.left_use[i]) continue;
+                used++;
+                if (segs_of[i].empty()) { ok = false; break; }
+                for (const dev::GatherSeg& g : segs_of[i]) {
+                    if (g.other_in >= 0) { ok = false; break; }
+                    if (n.log2_reps > 0) {   // replicated sub-circuit: only the identity relay (gate = position in every repetition)
+                        if (!(n.log2_sub_out == n.log2_sub_in && g.lo == 0 && g.hi == S && g.goff == 0)) { ok = false; break; }
+                        if (w0 >= 0 && (lo0 != 0 || w0 != nin)) { ok = false; break; }
+                        lo0 = 0; w0 = nin;
+                        ef.terms[i].push_back({g.coef, 0u});
+                        continue;
+                    }
+                    const u64 len = (u64)g.hi - g.lo;
+                    const long long g0 = (long long)g.goff + (long long)g.lo;
+                    if (len == 0 || (len & (len - 1)) || (g.lo & (len - 1)) || g0 < 0 || ((u64)g0 & (len - 1))) { ok = false; break; }
+                    const int w = 63 - __builtin_clzll(len);
+                    if (w0 >= 0 && (lo0 != (long long)g.lo || w0 != w)) { ok = false; break; }
+                    lo0 = g.lo; w0 = w;
+                    ef.terms[i].push_back({g.coef, (u32)((u64)g0 >> w)});
+                }
+            }
+            if (ok && used > 0 && !n.w0.empty()) {
+                if (n.log2_reps > 0) ok = false;
+                std::map<u32, std::pair<u64, size_t>> blocks;   // block -> (value, count)
+                for (auto& t : n.w0) {
+                    if (!ok) break;
+                    auto it = blocks.find(t.gate >> w0);
+                    if (it == blocks.end()) blocks[t.gate >> w0] = {t.c, 1};
+                    else if (it->second.first != t.c) ok = false;
+                    else it->second.second++;
+                }
+                for (auto& kv : blocks) { if (kv.second.second != ((size_t)1 << w0)) ok = false; ef.consts.push_back({kv.second.first, kv.first}); }
+            }
+            ef.ok = ok && used > 0 && w0 >= 0;
+            ef.w = w0; ef.hib = ef.ok ? (unsigned)((u64)lo0 >> w0) : 0;
+            if (!ef.ok) { ef.terms.clear(); ef.consts.clear(); }
         }
         {   // gate-major (forward) wiring for witness generation on the device
             dev::EvalNode& f = nd.fwd;

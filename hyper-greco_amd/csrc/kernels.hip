@@ -439,8 +439,12 @@ __device__ __forceinline__ E2 part_load(const E2* p) {
 __device__ __forceinline__ unsigned* tickets_of(E2* partials) { return reinterpret_cast<unsigned*>(partials + PARTIALS_E2); }
 // Called by the whole workgroup after thread 0 part_store()d its `per` values at p[blockIdx.x * per ..]. In the
 // workgroup that arrives last (block-uniform), sums the nblocks partials of each value and stores them to out[0..per).
+struct NoPost { __device__ __forceinline__ void operator()(E2*) const {} };
+// `post` (thread 0 of the last workgroup) may turn the `per` <= 6 summed values into what is stored (k_ps_step2<true>: the sums are
+// inner products the round's four values are combinations of - formed once per job here instead of once per workgroup)
+template <typename Post = NoPost>
 __device__ __forceinline__ void finish_partials(E2* p, int per, unsigned* ticket, E2* __restrict__ out, E2* sm /* >= 16 */,
-                                                int nblocks = -1) {
+                                                int nblocks = -1, Post post = Post()) {
     __shared__ unsigned s_last;
     if (nblocks < 0) nblocks = (int)gridDim.x;
     if (threadIdx.x == 0) {
@@ -481,11 +485,11 @@ __device__ __forceinline__ void finish_partials(E2* p, int per, unsigned* ticket
             for (int v = 0; v < PER_MAX; v++) if (v0 + v < per) a[v] = e2_add(a[v], t[v]);
         }
 #pragma unroll
-        for (int v = 0; v < PER_MAX; v++) {
-            if (v0 + v < per) {
-                E2 r = block_sum_n(a[v], sm);
-                if (threadIdx.x == 0) out[v0 + v] = r;
-            }
+        for (int v = 0; v < PER_MAX; v++) if (v0 + v < per) a[v] = block_sum_n(a[v], sm);
+        if (threadIdx.x == 0) {
+            if constexpr (!std::is_same<Post, NoPost>::value) post(a);
+#pragma unroll
+            for (int v = 0; v < PER_MAX; v++) if (v0 + v < per) out[v0 + v] = a[v];
         }
     }
     if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
@@ -1228,6 +1232,168 @@ __device__ __forceinline__ void ps_step2_body(const PsJob& J, const PsItem& I, s
     acc[2] = v[2];
     acc[3] = e2_add(e2_sub(e2_dbl(v[3]), v[2]), e2_dbl(v[4]));
 }
+// The same two rounds of an eq-factored job (PsJob::eq_n): no b table, and everything a round needs is LINEAR in the tables.
+// Thread j'' owns the four entries 4j'' .. 4j''+3 of every table (p = b0 + 2 b1: b0 is folded with r_t, b1 with r_(t+1)):
+//  * a_i is only folded: a''_i[j''] = sum_p c_p a_i[4j''+p], c = (1-r_t, r_t) x (1-r_(t+1), r_(t+1)) - one four-term dot product
+//    and one reduction per output entry instead of three folds;
+//  * with A = sum_i kappa_i a_i (built once by k_ps_eq_A ahead of round 0; a_0 itself when eq_single) and U_p = sum_j'' eq(z'_(t+2..);
+//    j'') A[4j''+p], both rounds' sums are combinations of the four U_p:  S_0 = (1-z) U_0 + z U_2, S_1 = (1-z) U_1 + z U_3 with
+//    z = z'_(t+1) (round t), S'_0 = (1-r_t) U_0 + r_t U_1, S'_1 = (1-r_t) U_2 + r_t U_3 (round t+1). The eq factor of j'' is
+//    lo[tid] * SUF_(t+10)[tile] (PsEqPoint): the second is uniform over the tile (zero outside a windowed table's block: nothing
+//    is added there), the first multiplies the thread's four sums once, after the loop.
+// Folded tables are written 4-WAY de-interleaved (entry e of a table of length len at (e & 3) len/4 + (e >> 2)) so that the next
+// pass's four loads are 16 B per lane and contiguous across the wave; the pass ahead of the tail writes the tail's layout.
+__device__ __forceinline__ void w2_mac_pre(W2& w, u64 a0, u64 a1, u64 a17, E2 b) {   // w += (a0, a1) * b, a17 = 7 a1 (any residue)
+    wmac_pair(w.c0, a0, b.c0, a17, b.c1);
+    wmac_pair(w.c1, a0, b.c1, a1, b.c0);
+}
+struct Fold4 { E2 c[4]; u64 c17[4]; };   // the four-term double fold's constants (c17 = 7 c.c1 as any residue)
+__device__ __forceinline__ Fold4 fold4(const E2* __restrict__ c) {   // c = the pass's (1-ra)(1-rb), ra (1-rb), (1-ra) rb, ra rb (PsJob::eq_scal)
+    Fold4 f;
+#pragma unroll
+    for (int p = 0; p < 4; p++) { f.c[p] = c[p]; f.c17[p] = gl_mul7_lazy(f.c[p].c1); }
+    return f;
+}
+__device__ __forceinline__ E2 fold4_apply(const Fold4& f, const u64 (&v)[4]) {
+    WAcc a = wacc_zero(), b = wacc_zero();
+#pragma unroll
+    for (int p = 0; p < 4; p++) wmac2(a, f.c[p].c0, v[p], b, f.c[p].c1, v[p]);
+    return e2(wreduce(a), wreduce(b));
+}
+__device__ __forceinline__ E2 fold4_apply(const Fold4& f, const E2 (&v)[4]) {
+    WAcc a = wacc_zero(), b = wacc_zero();
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        wmac_pair(a, f.c[p].c0, v[p].c0, f.c17[p], v[p].c1);
+        wmac_pair(b, f.c[p].c0, v[p].c1, f.c[p].c1, v[p].c0);
+    }
+    return e2(wreduce(a), wreduce(b));
+}
+// the four entries of thread jq: natural order (round-0 inputs) or 4-way de-interleaved (tables this kernel wrote), q = len / 4
+template <typename T>
+__device__ __forceinline__ void load4(const T* tab, bool natural, size_t jq, size_t q, T (&v)[4]) {
+    if (natural) { load_pair<T>(tab + 4 * jq, v[0], v[1]); load_pair<T>(tab + 4 * jq + 2, v[2], v[3]); }
+    else {
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            if constexpr (std::is_same<T, u64>::value) v[p] = gload_u64(tab + (size_t)p * q + jq);
+            else v[p] = gload_e2(tab + (size_t)p * q + jq);
+        }
+    }
+}
+constexpr int PS_EQ_OUT_TAIL = 1;   // PsItem::pad of an eq-factored item: the pass writes the tail's (2-way) layout
+// The workgroups of an item form I.jb_log2 groups of I.nblk / groups: group g folds the tables [g gs, (g+1) gs) (a job of 27 tables
+// would otherwise be a serial chain of 27 dependent load -> fold -> store steps per tile), group 0 also owns A and the sums.
+template <typename TA>
+__device__ __forceinline__ bool ps_eq_step2_body(const PsJob& J, const PsItem& I, size_t half, E2* acc /*[4]*/, E2* sm) {
+    constexpr bool BASE = std::is_same<TA, u64>::value;
+    const int tid = threadIdx.x;
+    const size_t q = half >> 1, ntiles = q >> 8;   // q output entries per table; the host plans such a pass at half >= 2^9 only
+    const int ngroups = I.jb_log2, nblocks = I.nblk / ngroups;
+    const int grp = ((int)blockIdx.x - I.blk0) / nblocks, bx = ((int)blockIdx.x - I.blk0) % nblocks;
+    const int rd = I.rd, nm = J.eq_n;
+    const int gs = (nm + ngroups - 1) / ngroups, m0 = grp * gs, m1 = m0 + gs < nm ? m0 + gs : nm;
+    const bool single = J.eq_single != 0, natural = I.in_buf < 0, out_tail = (I.pad & PS_EQ_OUT_TAIL) != 0;
+    const bool sums = grp == 0;
+    const Fold4 f4 = fold4(J.eq_scal + 2 * J.nvars + 1 + nm + J.nvars + 4 * (rd >> 1));
+    const E2* __restrict__ hi = J.eq_suf + (((size_t)1 << (J.nvars - (rd + 10))) - 1);   // SUF_(rd+10): one entry per tile
+    const E2* __restrict__ Ain = single ? nullptr : (natural ? J.eqA0 : J.bufA[I.in_buf]);
+    W2 U[4];
+#pragma unroll
+    for (int p = 0; p < 4; p++) U[p] = w2_zero();
+    auto member_tab = [&](int i) { return natural ? reinterpret_cast<const TA*>(J.a[i]) : reinterpret_cast<const TA*>(J.bufa[I.in_buf]) + (size_t)i * 4 * q; };
+    // the loads of the next (tile, table) are in flight while the current one is computed on
+    TA nv[4];
+    E2 nhv = e2_zero();
+    if ((size_t)bx < ntiles && m0 < m1) { load4<TA>(member_tab(m0), natural, ((size_t)bx << 8) + tid, q, nv); nhv = gload_e2(hi + bx); }
+    for (size_t tile = bx; tile < ntiles; tile += nblocks) {
+        const size_t jq = (tile << 8) + tid;
+        const size_t jo = out_tail ? dpos(jq, q) : (jq & 3) * (q >> 2) + (jq >> 2);
+        const E2 hv = nhv;
+        const bool more = tile + nblocks < ntiles;
+        if (more) nhv = gload_e2(hi + tile + nblocks);
+        const bool live = (hv.c0 | hv.c1) != 0;   // (uniform)
+        const u64 h17 = gl_mul7_lazy(hv.c1);
+        E2 Av[4];
+        if (!single && sums) load4<E2>(Ain, false, jq, q, Av);
+        for (int i = m0; i < m1; i++) {
+            TA v[4];
+#pragma unroll
+            for (int p = 0; p < 4; p++) v[p] = nv[p];
+            if (i + 1 < m1) load4<TA>(member_tab(i + 1), natural, jq, q, nv);
+            else if (more) load4<TA>(member_tab(m0), natural, ((tile + nblocks) << 8) + tid, q, nv);
+            if (single && live) {
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    if constexpr (BASE) wmac2(U[p].c0, hv.c0, v[p], U[p].c1, hv.c1, v[p]);
+                    else w2_mac_pre(U[p], hv.c0, hv.c1, h17, v[p]);
+                }
+            }
+            gstore_e2(J.bufa[I.out_buf] + (size_t)i * q + jo, fold4_apply(f4, v));
+        }
+        if (!single && sums) {
+            if (live) {
+#pragma unroll
+                for (int p = 0; p < 4; p++) w2_mac_pre(U[p], hv.c0, hv.c1, h17, Av[p]);
+            }
+            gstore_e2(J.bufA[I.out_buf] + jo, fold4_apply(f4, Av));
+        }
+    }
+    if (!sums) return false;
+    const E2 l8 = gload_e2(J.eq_lo + (size_t)(rd + 1) * 384 + tid);   // eq(z'_(rd+2..rd+9); tid)
+    E2 v[4];
+#pragma unroll
+    for (int p = 0; p < 4; p++) v[p] = e2_mul(l8, w2_reduce(U[p]));
+    block_sum_multi<4>(v, sm);   // this workgroup's share of U_0 .. U_3, valid in thread 0
+#pragma unroll
+    for (int p = 0; p < 4; p++) acc[p] = v[p];
+    return true;
+}
+// U_0 .. U_3 -> the four values of the two rounds (see ps_eq_step2_body), once per job
+struct PsEqPost {
+    const PsJob* J; int rd; E2 ra;
+    __device__ __forceinline__ void operator()(E2* v) const {
+        const E2* __restrict__ pre = J->eq_scal + 2 * rd;
+        const E2 z = J->eq_scal[2 * J->nvars + 1 + J->eq_n + rd + 1];   // z'_(rd+1)
+        const E2 S0 = e2_add(v[0], e2_mul(z, e2_sub(v[2], v[0]))), S1 = e2_add(v[1], e2_mul(z, e2_sub(v[3], v[1])));
+        const E2 T0 = e2_add(v[0], e2_mul(ra, e2_sub(v[1], v[0]))), T1 = e2_add(v[2], e2_mul(ra, e2_sub(v[3], v[2])));
+        v[0] = e2_mul(pre[0], S0);
+        v[1] = e2_mul(pre[1], e2_sub(e2_dbl(S1), S0));
+        v[2] = e2_mul(pre[2], T0);
+        v[3] = e2_mul(pre[3], e2_sub(e2_dbl(T1), T0));
+    }
+};
+// A = sum_i kappa_i a_i of the eq-factored jobs with several tables (base-field inputs in natural order), written 4-way
+// de-interleaved for the first pass; one thread per four entries, job = jobs[ids[blockIdx.y]]
+__global__ __launch_bounds__(256) void k_ps_eq_A(const PsJob* __restrict__ jobs, const int* __restrict__ ids) {
+    const PsJob& J = jobs[ids[blockIdx.y]];
+    const size_t q = ((size_t)1 << J.nvars) >> 2;
+    const E2* __restrict__ kap = J.eq_scal + 2 * J.nvars + 1;
+    for (size_t jq = (size_t)blockIdx.x * blockDim.x + threadIdx.x; jq < q; jq += (size_t)gridDim.x * blockDim.x) {
+        WAcc w[4][2];
+#pragma unroll
+        for (int p = 0; p < 4; p++) { w[p][0] = wacc_zero(); w[p][1] = wacc_zero(); }
+        u64 nv[4];
+        load4<u64>(reinterpret_cast<const u64*>(J.a[0]), true, jq, q, nv);
+        for (int i = 0; i < J.eq_n; i++) {
+            u64 v[4];
+#pragma unroll
+            for (int p = 0; p < 4; p++) v[p] = nv[p];
+            if (i + 1 < J.eq_n) load4<u64>(reinterpret_cast<const u64*>(J.a[i + 1]), true, jq, q, nv);
+            const E2 k = kap[i];
+#pragma unroll
+            for (int p = 0; p < 4; p++) wmac2(w[p][0], k.c0, v[p], w[p][1], k.c1, v[p]);
+        }
+#pragma unroll
+        for (int p = 0; p < 4; p++) gstore_e2(J.eqA0 + (size_t)p * q + jq, e2(wreduce(w[p][0]), wreduce(w[p][1])));
+    }
+}
+void ps_eq_A(hipStream_t st, const PsJob* jobs, const int* ids, int nids, size_t max_quads) {
+    if (nids <= 0) return;
+    const size_t bx = std::min<size_t>((max_quads + 255) / 256, 1024);
+    k_ps_eq_A<<<dim3((unsigned)std::max<size_t>(bx, 1), (unsigned)nids), 256, 0, st>>>(jobs, ids);
+}
+template <bool EQ>   // EQ: the items are eq-factored jobs (PsJob::eq_n)
 __global__ __launch_bounds__(256) void k_ps_step2(const PsJob* __restrict__ jobs, const PsItem* __restrict__ items, int nitems,
                                                   const E2* __restrict__ chal, E2* __restrict__ partials, E2* __restrict__ res) {
     const int y = find_ps_item(items, nitems, blockIdx.x);
@@ -1238,7 +1404,20 @@ __global__ __launch_bounds__(256) void k_ps_step2(const PsJob* __restrict__ jobs
     E2* sm = dyn_lds;
     const size_t half = (size_t)1 << (J.nvars - 1 - rd);
     E2 acc[4];
-    if (I.in_buf < 0) ps_step2_body<u64>(J, I, half, chal[J.r_off + rd], chal[J.r_off + rd + 1], acc, sm);
+    if constexpr (EQ) {   // (a kernel of its own: both bodies in one took the other jobs' rounds from 166 to 206 registers, three waves to two)
+        const bool sums = I.in_buf < 0 ? ps_eq_step2_body<u64>(J, I, half, acc, sm) : ps_eq_step2_body<E2>(J, I, half, acc, sm);
+        if (!sums) return;   // (uniform: a workgroup that only folds tables)
+        const int nb = I.nblk / I.jb_log2;   // the workgroups of group 0
+        const PsEqPost post{&J, rd, chal[J.r_off + rd]};
+        E2* part = partials + (size_t)y * SC_MAX_BLOCKS * 4;
+        if (nb == 1) {
+            if (threadIdx.x == 0) { post(acc); for (int t = 0; t < 4; t++) res[J.sums_slot + 2 * rd + t] = acc[t]; }
+            return;
+        }
+        if (threadIdx.x == 0) for (int t = 0; t < 4; t++) part_store(part + (size_t)bx * 4 + t, acc[t]);
+        finish_partials(part, 4, tickets_of(partials) + y * 32, res + J.sums_slot + 2 * rd, sm, nb, post);
+        return;
+    } else if (I.in_buf < 0) ps_step2_body<u64>(J, I, half, chal[J.r_off + rd], chal[J.r_off + rd + 1], acc, sm);
     else ps_step2_body<E2>(J, I, half, chal[J.r_off + rd], chal[J.r_off + rd + 1], acc, sm);
     const E2 s0 = acc[0], s2 = acc[1];  // summed over the workgroup by ps_step2_body (thread 0)
     E2* part = partials + (size_t)y * SC_MAX_BLOCKS * 4;
@@ -1267,6 +1446,21 @@ __global__ __launch_bounds__(1024) void k_ps_tail(const PsJob* __restrict__ jobs
     // round sums to the (host-memory) result buffer once, at the end; challenges fetched once (as in k_st_tail)
     __shared__ E2 keep[2 * 32], rch[32];
     if ((int)threadIdx.x < J.nvars - J.tail_rd) rch[threadIdx.x] = chal[J.r_off + J.tail_rd + threadIdx.x];
+    if (J.eq_n) {
+        // an eq-factored job hands over without b tables: b_i = kappa_i P_tail_rd eq(z'_(tail_rd..); .), written de-interleaved like
+        // every folded table (position p holds logical entry 2p, or 2(p - len/2) + 1 in the upper half)
+        const size_t len = (size_t)1 << (J.nvars - J.tail_rd);
+        const E2* __restrict__ suf = J.eq_suf + (len - 1);
+        const E2 P = J.eq_scal[2 * J.nvars];
+        const E2* __restrict__ kap = J.eq_scal + 2 * J.nvars + 1;
+        E2* bt = J.bufb[J.tail_buf];
+        for (size_t p = threadIdx.x; p < len; p += blockDim.x) {
+            const size_t e = p < len / 2 ? 2 * p : 2 * (p - len / 2) + 1;
+            const E2 s = e2_mul(P, gload_e2(suf + e));
+            for (int i = 0; i < J.eq_n; i++) gstore_e2(bt + (size_t)i * len + p, e2_mul(kap[i], s));
+        }
+        __threadfence_block();
+    }
     __syncthreads();
     for (int rd = J.tail_rd; rd < J.nvars; rd++) {
         const int hl = J.nvars - 1 - rd;
@@ -1292,7 +1486,84 @@ __global__ __launch_bounds__(1024) void k_ps_tail(const PsJob* __restrict__ jobs
     if ((int)threadIdx.x < 2 * (J.nvars - J.tail_rd)) res[J.sums_slot + 2 * (size_t)J.tail_rd + threadIdx.x] = keep[threadIdx.x];
 }
 
+// Factor tables of the eq-factored jobs' points (PsEqPoint). Every table is a product of at most two small factor tables kept in
+// LDS: TOP = eq over the top 7 coordinates, MID_k = eq over coordinates k .. nvars-8 (the stored suffix tables reach at most 6 + 7
+// bits at the sizes of this circuit; PS_EQ_MAX_VARS bounds the general case), so no entry costs more than ~10 dependent products
+// and nothing waits on a table written by the same launch. grid = points x PS_EQ_PARTS, each part writes a slice of the outputs.
+constexpr int PS_EQ_PARTS = 8, PS_EQ_TOPB = 7, PS_EQ_MID_MAX = 1024;
+__device__ __forceinline__ E2 eq_bits(const E2* z, int first, int bits, unsigned v) {   // eq(z_(first .. first+bits-1); v)
+    E2 acc = e2_one();
+    for (int b = 0; b < bits; b++) {
+        const E2 zz = z[first + b];
+        acc = e2_mul(acc, (v >> b) & 1 ? zz : e2_sub(e2_one(), zz));
+    }
+    return acc;
+}
+__global__ __launch_bounds__(256) void k_ps_eq_prep(const PsEqPoint* __restrict__ pts, const E2* __restrict__ chal) {
+    const PsEqPoint P = pts[blockIdx.x / PS_EQ_PARTS];
+    const int part = blockIdx.x % PS_EQ_PARTS, tid = threadIdx.x, n = P.nvars;
+    __shared__ E2 z[32], top[1 << PS_EQ_TOPB], mid[2 * PS_EQ_MID_MAX];
+    if (tid < n) z[tid] = tid < P.w ? chal[P.point_off + tid] : e2((P.hib >> (tid - P.w)) & 1u, 0);
+    __syncthreads();
+    // TOP over coordinates n-tb .. n-1; MID_k over k .. n-tb-1 for k >= kmin, 2^(n-tb-k) entries at mid + 2^(n-tb-k) - 1
+    const int tb = n < PS_EQ_TOPB ? n : PS_EQ_TOPB, nt = n - tb;
+    for (int t = tid; t < (1 << tb); t += blockDim.x) top[t] = eq_bits(z, nt, tb, (unsigned)t);
+    const int kmid = P.kmin < nt ? P.kmin : nt;
+    const size_t mid_total = ((size_t)2 << (nt - kmid)) - 1;
+    for (size_t q = tid; q < mid_total; q += blockDim.x) {
+        const int lg = 63 - __clzll((long long)(q + 1));   // table of 2^lg entries, entry q + 1 - 2^lg
+        mid[q] = eq_bits(z, nt - lg, lg, (unsigned)(q + 1 - ((size_t)1 << lg)));
+    }
+    __syncthreads();
+    // suffix tables: SUF_k[x] = MID_k[x & (2^(nt-k) - 1)] * TOP[x >> (nt - k)] for k <= nt, a sub-cube of TOP above
+    const size_t suf_total = ((size_t)2 << (n - P.kmin)) - 1;
+    for (size_t q = (size_t)part * blockDim.x + tid; q < suf_total; q += (size_t)PS_EQ_PARTS * blockDim.x) {
+        const int lg = 63 - __clzll((long long)(q + 1));   // = n - k
+        const size_t x = q + 1 - ((size_t)1 << lg);
+        const int k = n - lg;
+        E2 v;
+        if (k >= nt) v = eq_bits(z, k, lg, (unsigned)x);
+        else {
+            const int mb = nt - k;
+            v = e2_mul(mid[((size_t)1 << mb) - 1 + (x & (((size_t)1 << mb) - 1))], top[x >> mb]);
+        }
+        gstore_e2(P.suf + q, v);
+    }
+    // per-round thread factors
+    const size_t lo_total = n > 8 ? (size_t)(n - 8) * 384 : 0;
+    for (size_t q = (size_t)part * blockDim.x + tid; q < lo_total; q += (size_t)PS_EQ_PARTS * blockDim.x) {
+        const int rd = (int)(q / 384), t = (int)(q % 384);
+        gstore_e2(P.lo + q, t < 256 ? eq_bits(z, rd + 1, 8, (unsigned)t) : eq_bits(z, rd + 2, 7, (unsigned)(t - 256)));
+    }
+}
+void ps_eq_prep(hipStream_t st, const PsEqPoint* pts, int npts, const E2* chal) {
+    if (npts > 0) k_ps_eq_prep<<<npts * PS_EQ_PARTS, 256, 0, st>>>(pts, chal);
+}
+
 int ps_plan_blocks(PsItem* items, int nitems, const PsJob* host_jobs, bool rounds2) {
+    if (nitems > 0 && host_jobs[items[0].job].eq_n) {   // eq-factored items (a launch holds one kind): a tile = 256 threads x 4 entries
+        size_t all_tiles = 0;
+        for (int q = 0; q < nitems; q++) all_tiles += ((size_t)1 << (host_jobs[items[q].job].nvars - 1 - items[q].rd)) >> 9;
+        // a workgroup pays ~1000 instructions per thread once (four reductions, four products, the block sums) against 100-150 per
+        // table and tile: several tiles each when the launch has them, the tables of a many-table job dealt to groups of workgroups
+        static const size_t target_blocks = env_size("HG_PS_EQ_TARGET_BLOCKS", 1024);
+        static const size_t serial_big = env_size("HG_PS_EQ_SERIAL", 16), serial_small = env_size("HG_PS_EQ_SERIAL_SMALL", 6);
+        const size_t per = std::min<size_t>(std::max<size_t>(all_tiles / target_blocks, 1), 16);
+        const size_t budget = all_tiles >= 1024 ? serial_big : serial_small;   // (table, tile) steps per thread
+        int blk = 0;
+        for (int q = 0; q < nitems; q++) {
+            PsItem& I = items[q];
+            const PsJob& J = host_jobs[I.job];
+            const size_t ntiles = ((size_t)1 << (J.nvars - 1 - I.rd)) >> 9;
+            const size_t nb = std::min<size_t>(std::max<size_t>((ntiles + per - 1) / per, 1), (size_t)st_max_blocks());
+            const size_t tiles_each = (ntiles + nb - 1) / nb;
+            size_t groups = std::min<size_t>(std::max<size_t>((tiles_each * J.eq_n + budget - 1) / budget, 1), (size_t)J.eq_n);
+            I.jb_log2 = (int)groups; I.blk0 = blk;   // (jb_log2 of an eq-factored item = its number of table groups)
+            I.nblk = (int)(nb * groups);
+            blk += I.nblk;
+        }
+        return blk;
+    }
     size_t total = 0;
     for (int q = 0; q < nitems; q++) total += ((size_t)1 << (host_jobs[items[q].job].nvars - 1 - items[q].rd)) * host_jobs[items[q].job].npairs;
     int jb0 = 8;
@@ -1318,8 +1589,11 @@ int ps_plan_blocks(PsItem* items, int nitems, const PsJob* host_jobs, bool round
     }
     return blk;
 }
-void ps_round(hipStream_t st, bool rounds2, const PsJob* jobs, const PsItem* items, int nitems, int grid, const E2* chal, E2* partials, E2* res) {
-    if (rounds2) k_ps_step2<<<grid, 256, SM_SLOTS * sizeof(E2), st>>>(jobs, items, nitems, chal, partials, res);
+void ps_round(hipStream_t st, bool rounds2, const PsJob* jobs, const PsItem* items, int nitems, int grid, const E2* chal, E2* partials, E2* res, bool eq) {
+    if (eq) {
+        if (!rounds2) throw std::runtime_error("ps_round: eq-factored jobs run in fused pairs of rounds");
+        k_ps_step2<true><<<grid, 256, SM_SLOTS * sizeof(E2), st>>>(jobs, items, nitems, chal, partials, res);
+    } else if (rounds2) k_ps_step2<false><<<grid, 256, SM_SLOTS * sizeof(E2), st>>>(jobs, items, nitems, chal, partials, res);
     else k_ps_one<<<grid, 256, SM_SLOTS * sizeof(E2), st>>>(jobs, items, nitems, chal, partials, res);
 }
 void ps_tail(hipStream_t st, const PsJob* jobs, int njobs, const E2* chal, E2* res) {

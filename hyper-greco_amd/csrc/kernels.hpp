@@ -158,7 +158,41 @@ struct PsJob {
     int tail_buf;                 // where that round reads: -1 = a[] / b[], else bufa/bufb[tail_buf]
     size_t r_off;                 // chain index of round 0's challenge
     size_t sums_slot;             // result slots: 2 per round
+    // Eq-factored job (eq_n = npairs > 0): EVERY bookkeeping table is b_i(x) = kappa_i eq(z', x) for one point z'
+    // (a Libra phase-1 table whose wiring relays aligned blocks: a slice of the node's eq table times a constant). No b table exists
+    // before the tail: with rho the challenges so far, A = sum_i kappa_i a_i and P_rd = prod_(j<rd) eq(z'_j, rho_j), round rd's
+    // polynomial is P_rd eq(z'_rd; X) [(1 - X) S_0 + X S_1], S_t = sum_x' eq(z'_(rd+1..); x') A(rho, t, x'): inner products of
+    // the folded A with a suffix eq table, whatever npairs is; the a_i are only folded (kernels.hip: ps_eq_step2_body). The suffix
+    // table is never stored at full length either: it is a per-thread factor lo[tid] times SUF_k[tile] (PsEqPoint), the second
+    // uniform over a workgroup's tile. eq_single (npairs == 1): A is a_0 itself, kappa_0 is folded into the prefactors.
+    // eq_scal: [2 rd], [2 rd + 1] = P_rd (1 - z'_rd), P_rd (3 z'_rd - 1) (times kappa_0 if eq_single); [2 nvars] = P_tail_rd;
+    // [2 nvars + 1 + i] = kappa_i; [2 nvars + 1 + npairs + k] = z'_k; then four constants per pass (rounds 2s, 2s+1): (1-ra)(1-rb),
+    // ra (1-rb), (1-ra) rb, ra rb. The tail materialises b_i = kappa_i P_tail_rd SUF_tail_rd in bufb[tail_buf] and runs as ever.
+    int eq_n, eq_single;
+    const E2* eq_scal;
+    const E2* eq_lo;              // PsEqPoint::lo of the job's point
+    const E2* eq_suf;             // PsEqPoint::suf
+    E2* bufA[2];                  // folded A, ping-pong like bufa (one table); unused if eq_single
+    E2* eqA0;                     // A itself (2^nvars entries, 4-way de-interleaved), built by ps_eq_A ahead of round 0; unused if eq_single
 };
+// One point z' of eq-factored jobs and the tables ps_eq_prep builds for it (shared by the jobs opened at the same point).
+// z'_k = chain[point_off + k] for k < w, bit (k - w) of hib above (a wiring that relays ONE aligned block of the input: the table
+// is zero outside it, i.e. an eq table whose top coordinates are Boolean).
+struct PsEqPoint {
+    size_t point_off;
+    int w, nvars;
+    unsigned hib;
+    int kmin;                     // SUF_k is stored for k in [kmin, nvars]
+    E2* lo;                       // [nvars - 8][384]: round rd -> eq(z'_(rd+1..rd+8); t), t < 256, then eq(z'_(rd+2..rd+8); t), t < 128
+    E2* suf;                      // SUF_k = eq(z'_(k..nvars-1); .), 2^(nvars-k) entries at suf + 2^(nvars-k) - 1
+};
+inline int ps_eq_kmin(int nvars) { int k = nvars - 13 < 9 ? nvars - 13 : 9; return k < 0 ? 0 : k; }
+inline size_t ps_eq_lo_entries(int nvars) { return nvars > 8 ? (size_t)(nvars - 8) * 384 : 0; }
+inline size_t ps_eq_suf_entries(int nvars) { return ((size_t)2 << (nvars - ps_eq_kmin(nvars))) - 1; }
+constexpr int PS_EQ_MAX_VARS = 26;   // (the prep kernel's LDS factor tables)
+void ps_eq_prep(hipStream_t st, const PsEqPoint* pts, int npts, const E2* chal);
+// A = sum_i kappa_i a_i of jobs[ids[.]] (eq-factored, several tables); max_quads = the largest job's 2^nvars / 4
+void ps_eq_A(hipStream_t st, const PsJob* jobs, const int* ids, int nids, size_t max_quads);
 // one (job, round) of a PRODSUM launch; the items of a launch share a 1-D grid like StItem
 struct PsItem {
     int job, jb_log2, blk0, nblk;
@@ -169,7 +203,8 @@ struct PsItem {
 // fills jb_log2 / blk0 / nblk of the items of one launch (host side); returns the grid size. rounds2: fused launch.
 int ps_plan_blocks(PsItem* items, int nitems, const PsJob* host_jobs, bool rounds2);
 // one round (rounds2: two consecutive rounds, lane pairs share the second) of every item's job; jobs of different sizes share the launch
-void ps_round(hipStream_t st, bool rounds2, const PsJob* jobs, const PsItem* items, int nitems, int grid, const E2* chal, E2* partials, E2* res);
+// eq: every item is an eq-factored job (a launch holds one kind)
+void ps_round(hipStream_t st, bool rounds2, const PsJob* jobs, const PsItem* items, int nitems, int grid, const E2* chal, E2* partials, E2* res, bool eq = false);
 // rounds [tail_rd, nvars) of every job, one workgroup per job
 void ps_tail(hipStream_t st, const PsJob* jobs, int njobs, const E2* chal, E2* res);
 

@@ -679,6 +679,88 @@ struct Prover {
         ps_queue[nvars].push_back(J);
         return h;
     }
+    // ---- eq-factored PRODSUM jobs (kernels.hpp PsJob::eq_n) ---------------------------------------------------------------
+    // HG_NO_PS_EQ=1: every Libra table materialised (the form every node had until round 5; needs the fused rounds)
+    static bool ps_eq_on() {
+        static const bool v = [] { const char* e = getenv("HG_NO_PS_EQ"); const char* f = getenv("HG_NO_PS_FUSE2"); return !(e && e[0] == '1') && !(f && f[0] == '1'); }();
+        return v;
+    }
+    static size_t ps_tail_items() { static const size_t v = [] { const char* e = getenv("HG_PS_TAIL_ITEMS"); return e && *e ? (size_t)atol(e) : TAIL_ITEMS; }(); return v; }
+    // First tail round of an eq-factored job, -1: the job is too small for the form. Every round ahead of the tail runs in a fused
+    // pair (the tail may start one round later than TAIL_ITEMS says), the last pair at half >= 2^9, and the table handed to the
+    // tail must be one of the point's stored suffix tables.
+    static int eq_tail_rd(int npairs, int nvars) {
+        if (npairs < 1 || npairs > dev::PS_MAX_PAIRS || nvars > dev::PS_EQ_MAX_VARS) return -1;
+        const size_t N = (size_t)1 << nvars;
+        int rd = 0;
+        while (rd < nvars && ((N >> rd) / 2) * (size_t)npairs > ps_tail_items()) rd++;
+        if (rd & 1) rd++;
+        if (rd < 2 || rd > nvars - 8 || rd < dev::ps_eq_kmin(nvars)) return -1;
+        return rd;
+    }
+    std::vector<E2> eq_scal_host;   // prefactors / kappa of the queued eq-factored jobs (PsJob::eq_scal), one upload per flush
+    std::vector<dev::PsEqPoint> eqpt_queue;
+    std::map<std::tuple<size_t, int, int, unsigned>, std::pair<E2*, E2*>> eqpt_shared;   // (point, w, nvars, hib) -> the point's (lo, suf) tables
+    // g = sum_i a_i(x) kappa_i eq(z', x): zp = z' (host copy of the coordinates), the first w of them the chain run at z_off
+    ScHandle sc_prodsum_eq(const std::vector<const u64*>& a, const std::vector<E2>& kappa, const std::vector<E2>& zp, size_t z_off, int w, unsigned hib,
+                           int nvars, int tail_rd, const std::vector<E2*>& fin_a, const std::vector<E2*>& fin_b, bool enqueue) {
+        ScHandle h;
+        h.nv = 2;
+        h.nvars = nvars;
+        h.point_off = epos();
+        h.sums_slot = slot((size_t)nvars * 2);
+        for (int i = 0; i < nvars; i++) h.rs.push_back(squeeze());
+        if (!enqueue) return h;
+        const int np = (int)a.size();
+        const size_t N = (size_t)1 << nvars;
+        dev::PsJob J;
+        memset(&J, 0, sizeof(J));
+        J.npairs = np; J.nvars = nvars; J.r_off = h.point_off; J.sums_slot = h.sums_slot;
+        J.tail_rd = tail_rd; J.eq_n = np; J.eq_single = np == 1 ? 1 : 0;
+        for (int q = 0; q < 2; q++) {
+            J.bufa[q] = ctx->alloc_n<E2>((size_t)np * (N >> (q + 1)));
+            if (np > 1) J.bufA[q] = ctx->alloc_n<E2>(N >> (q + 1));
+        }
+        if (np > 1) J.eqA0 = ctx->alloc_n<E2>(N);
+        for (int q = 0; q < 2; q++) J.bufb[q] = ctx->alloc_n<E2>((size_t)np * (N >> tail_rd));   // the tail's prologue writes one of them; its rounds ping-pong
+        for (int i = 0; i < np; i++) { J.a[i] = a[i]; J.fin_a[i] = fin_a[i]; J.fin_b[i] = fin_b[i]; }
+        // prefactors of the rounds ahead of the tail, P at the hand-off, kappa
+        std::vector<E2> scal((size_t)2 * nvars + 1 + np + nvars + 4 * (size_t)(tail_rd / 2), e2_zero());
+        E2 P = e2_one();
+        for (int rd = 0; rd <= tail_rd && rd < nvars; rd++) {
+            if (rd == tail_rd) { scal[(size_t)2 * nvars] = P; break; }
+            const E2 z = zp[rd], omz = e2_sub(e2_one(), z);
+            E2 p0 = e2_mul(P, omz), p2 = e2_mul(P, e2_sub(e2_add(e2_dbl(z), z), e2_one()));
+            if (np == 1) { p0 = e2_mul(p0, kappa[0]); p2 = e2_mul(p2, kappa[0]); }
+            scal[(size_t)2 * rd] = p0; scal[(size_t)2 * rd + 1] = p2;
+            P = e2_mul(P, e2_add(e2_mul(z, h.rs[rd]), e2_mul(omz, e2_sub(e2_one(), h.rs[rd]))));
+        }
+        for (int i = 0; i < np; i++) scal[(size_t)2 * nvars + 1 + i] = kappa[i];
+        for (int k = 0; k < nvars; k++) scal[(size_t)2 * nvars + 1 + np + k] = zp[k];
+        for (int rd = 0; rd + 1 < tail_rd; rd += 2) {   // the four-term double fold of the pass at (rd, rd + 1): entry 4j + p, p = b0 + 2 b1
+            const E2 ra = h.rs[rd], rb = h.rs[rd + 1], na = e2_sub(e2_one(), ra), nb = e2_sub(e2_one(), rb);
+            E2* c = &scal[(size_t)2 * nvars + 1 + np + nvars + 4 * (size_t)(rd / 2)];
+            c[0] = e2_mul(na, nb); c[1] = e2_mul(ra, nb); c[2] = e2_mul(na, rb); c[3] = e2_mul(ra, rb);
+        }
+        // (uploaded by flush_prodsum on the stream the rounds run on - this walk is still enqueueing to the main one; until then
+        // eq_scal holds the job's offset into eq_scal_host)
+        J.eq_scal = reinterpret_cast<const E2*>(eq_scal_host.size() * sizeof(E2));
+        eq_scal_host.insert(eq_scal_host.end(), scal.begin(), scal.end());
+        const auto key = std::make_tuple(z_off, w, nvars, hib);
+        auto hit = eqpt_shared.find(key);
+        if (hit == eqpt_shared.end()) {
+            dev::PsEqPoint pt;
+            memset(&pt, 0, sizeof(pt));
+            pt.point_off = z_off; pt.w = w; pt.nvars = nvars; pt.hib = hib; pt.kmin = dev::ps_eq_kmin(nvars);
+            pt.lo = ctx->alloc_n<E2>(dev::ps_eq_lo_entries(nvars));
+            pt.suf = ctx->alloc_n<E2>(dev::ps_eq_suf_entries(nvars));
+            eqpt_queue.push_back(pt);
+            hit = eqpt_shared.emplace(key, std::make_pair(pt.lo, pt.suf)).first;
+        }
+        J.eq_lo = hit->second.first; J.eq_suf = hit->second.second;
+        ps_queue[nvars].push_back(J);
+        return h;
+    }
     void flush_prodsum() {
         // round-synchronised: launch rd runs round rd of every queued job whatever its size; the last rounds of each
         // job (TAIL_ITEMS work items or fewer) run in one single-workgroup-per-job launch
@@ -686,52 +768,62 @@ struct Prover {
         for (auto& kv : ps_queue) { jobs.insert(jobs.end(), kv.second.begin(), kv.second.end()); kv.second.clear(); }
         if (jobs.empty()) return;
         const int nj = (int)jobs.size();
+        if (!eq_scal_host.empty()) {
+            E2* d_scal = ctx->alloc_n<E2>(eq_scal_host.size());
+            upload(d_scal, eq_scal_host.data(), eq_scal_host.size() * sizeof(E2), "upload eq-form scalars");
+            for (auto& J : jobs) if (J.eq_n) J.eq_scal = d_scal + reinterpret_cast<size_t>(J.eq_scal) / sizeof(E2);
+            eq_scal_host.clear();
+        }
         int max_rd = 0;
         for (auto& J : jobs) {
             const size_t N = (size_t)1 << J.nvars;
             int rd = 0;
-            static const size_t ps_tail_items = [] { const char* e = getenv("HG_PS_TAIL_ITEMS"); return e && *e ? (size_t)atol(e) : TAIL_ITEMS; }();
-            while (rd < J.nvars && ((N >> rd) / 2) * (size_t)J.npairs > ps_tail_items) rd++;
+            if (J.eq_n) rd = J.tail_rd;   // (planned when the job was queued: eq_tail_rd)
+            else while (rd < J.nvars && ((N >> rd) / 2) * (size_t)J.npairs > ps_tail_items()) rd++;
             J.tail_rd = rd;
             max_rd = std::max(max_rd, rd);
         }
         auto round_bytes = [&](const dev::PsJob& J, int rd) {
             size_t half = ((size_t)1 << J.nvars) >> (rd + 1);
+            if (J.eq_n && rd < J.tail_rd)   // no b tables; the folded A beside the a_i (formed in round 0, not read)
+                return (double)J.npairs * (2.0 * half * (rd == 0 ? 8 : 16) + half * 16.0) + (J.eq_single ? 0.0 : (rd == 0 ? 0.0 : 2.0 * half * 16) + half * 16.0);
             return (double)J.npairs * (2.0 * half * ((rd == 0 ? 8 : 16) + 16) + half * 32.0);
         };
         // plan every step first (step s = every job's next round, or its next two rounds when its table is long
         // enough), upload all items in one copy, then launch; the host tracks each job's ping-pong buffer
         static const bool ps_fuse2 = [] { const char* e = getenv("HG_NO_PS_FUSE2"); return !(e && e[0] == '1'); }();
         static const int ps_fuse_min_h = [] { const char* e = getenv("HG_PS_FUSE_MIN_H"); return e && *e ? atoi(e) : 9; }();   // (11 until the node reductions moved to the third stream: 1.92-1.94 against 1.96 ms)
-        struct PsLaunch { bool two; int cnt, grid; size_t off; double bytes; };
+        struct PsLaunch { bool two, eq; int cnt, grid; size_t off; double bytes; };
         std::vector<PsLaunch> launches;
         std::vector<dev::PsItem> all_items;
         std::vector<int> next_rd(nj, 0), cur_buf(nj, -1);
         for (;;) {
-            std::vector<dev::PsItem> one, two;
+            std::vector<dev::PsItem> one, two, two_eq;   // (eq-factored jobs have a kernel of their own)
             for (int q = 0; q < nj; q++) {
                 const dev::PsJob& J = jobs[q];
                 const int rd = next_rd[q];
                 if (rd >= J.tail_rd) continue;
                 const int h = J.nvars - 1 - rd;
-                const bool pair = ps_fuse2 && rd + 1 < J.tail_rd && h >= std::max(9, ps_fuse_min_h);
+                const bool pair = J.eq_n ? true : ps_fuse2 && rd + 1 < J.tail_rd && h >= std::max(9, ps_fuse_min_h);
                 dev::PsItem it;
                 memset(&it, 0, sizeof(it));
                 it.job = q; it.rd = rd; it.in_buf = cur_buf[q]; it.out_buf = cur_buf[q] == 1 ? 0 : 1;
                 if (cur_buf[q] < 0) it.out_buf = pair ? 1 : 0;  // sizes: bufa[0] holds N/2 entries per table, bufa[1] N/4
-                (pair ? two : one).push_back(it);
+                if (J.eq_n && rd + 2 >= J.tail_rd) it.pad = 1;   // (PS_EQ_OUT_TAIL: this pass writes the layout the tail reads)
+                (J.eq_n ? two_eq : pair ? two : one).push_back(it);
                 next_rd[q] = rd + (pair ? 2 : 1);
                 cur_buf[q] = it.out_buf;
             }
-            if (one.empty() && two.empty()) break;
-            for (int kind = 0; kind < 2; kind++) {
-                std::vector<dev::PsItem>& items = kind ? two : one;
+            if (one.empty() && two.empty() && two_eq.empty()) break;
+            for (int kind = 0; kind < 3; kind++) {   // the eq-factored jobs first: the largest tables of the first wave
+                std::vector<dev::PsItem>& items = kind == 0 ? two_eq : kind == 1 ? one : two;
+                const bool fused = kind != 1;
                 for (size_t o = 0; o < items.size(); o += MAX_BATCH) {
                     const int cnt = (int)std::min<size_t>(MAX_BATCH, items.size() - o);
-                    const int grid = dev::ps_plan_blocks(items.data() + o, cnt, jobs.data(), kind == 1);
+                    const int grid = dev::ps_plan_blocks(items.data() + o, cnt, jobs.data(), fused);
                     double bytes = 0;
-                    for (int q = 0; q < cnt; q++) for (int k = 0; k <= kind; k++) bytes += round_bytes(jobs[items[o + q].job], items[o + q].rd + k);
-                    launches.push_back({kind == 1, cnt, grid, all_items.size(), bytes});
+                    for (int q = 0; q < cnt; q++) for (int k = 0; k <= (fused ? 1 : 0); k++) bytes += round_bytes(jobs[items[o + q].job], items[o + q].rd + k);
+                    launches.push_back({fused, kind == 0, cnt, grid, all_items.size(), bytes});
                     all_items.insert(all_items.end(), items.begin() + o, items.begin() + o + cnt);
                 }
             }
@@ -739,12 +831,29 @@ struct Prover {
         for (int q = 0; q < nj; q++) jobs[q].tail_buf = cur_buf[q];
         dev::PsJob* d_jobs = ctx->alloc_n<dev::PsJob>(nj);
         upload(d_jobs, jobs.data(), (size_t)nj * sizeof(dev::PsJob), "upload jobs");
+        {   // A = sum_i kappa_i a_i of the eq-factored jobs with several tables
+            std::vector<int> ids;
+            size_t max_quads = 0; double ab = 0;
+            for (int q = 0; q < nj; q++) if (jobs[q].eq_n > 1) {
+                ids.push_back(q);
+                const size_t N = (size_t)1 << jobs[q].nvars;
+                max_quads = std::max(max_quads, N >> 2);
+                ab += (double)N * (8.0 * jobs[q].eq_n + 16.0);
+            }
+            if (!ids.empty()) {
+                int* d_ids = ctx->alloc_n<int>(ids.size());
+                upload(d_ids, ids.data(), ids.size() * sizeof(int), "upload eq-form job list");
+                ctx->prof_begin(cls_aux, ab);
+                dev::ps_eq_A(st, d_jobs, d_ids, (int)ids.size(), max_quads);
+                ctx->prof_end();
+            }
+        }
         if (!all_items.empty()) {
             dev::PsItem* d_items = ctx->alloc_n<dev::PsItem>(all_items.size());
             upload(d_items, all_items.data(), all_items.size() * sizeof(dev::PsItem), "upload items");
             for (auto& L : launches) {
                 ctx->prof_begin(L.two ? cls_ps2 : cls_ps, L.bytes);
-                dev::ps_round(st, L.two, d_jobs, d_items + L.off, L.cnt, L.grid, ctx->d_chal, partials, d_res());
+                dev::ps_round(st, L.two, d_jobs, d_items + L.off, L.cnt, L.grid, ctx->d_chal, partials, d_res(), L.eq);
                 ctx->prof_end();
             }
         }
@@ -882,6 +991,11 @@ struct Prover {
         q.clear();
     }
     void flush_bookkeeping() {
+        if (!eqpt_queue.empty()) {   // factor tables of the eq-factored jobs' points
+            double pb = 0;
+            for (auto& p : eqpt_queue) pb += 16.0 * (dev::ps_eq_lo_entries(p.nvars) + dev::ps_eq_suf_entries(p.nvars));
+            flush_jobs(eqpt_queue, cls_aux, pb, [&](dev::PsEqPoint* d, int np) { dev::ps_eq_prep(st, d, np, ctx->d_chal); });
+        }
         int max_n = 0; double eb = 0;
         for (auto& J : eq_queue) { max_n = std::max(max_n, J.n); eb += 16.0 * ((size_t)1 << J.n); }
         {   // jobs of the two-launch form first (queue_eq gives every job of a prove the same form)
@@ -1787,6 +1901,61 @@ struct Prover {
         for (auto& c : claims[id]) if (c.len != n.log2_out()) throw Error("gkr: claim arity mismatch");
         Cell claim = combined_value(claims[id], alphas);
         const bool own = mine(node_owner[id]);
+        std::vector<int> li, ri;
+        for (int i = 0; i < n.arity; i++) { if (n.left_use[i]) li.push_back(i); if (n.right_use[i]) ri.push_back(i); }
+        if (n.arity > dev::PS_MAX_PAIRS) throw Error("vanilla: arity too large");
+        // phase 1's transcript side, common to both forms below
+        auto phase1_steps = [&](const ScHandle& s1, size_t u_base, Cell after1) {
+            mark("vanilla node " + std::to_string(id) + ": Libra phase 1 sum-check, " + std::to_string(nin) + " rounds x 3 coefficients [G1 node order, G2 alpha per claim, G3 Libra form]");
+            defer_sumcheck(s1, 2, claim, after1);
+            for (int i : li) {
+                mark("vanilla node " + std::to_string(id) + ": input " + std::to_string(i) + " evaluation at r_x");
+                defer_write_slots(u_base + i, 1);
+                Cell v = cell();
+                size_t sl = u_base + i;
+                push_op([this, v, sl] { *v = h_res()[sl]; });
+                claims[n.preds[i]].push_back(ClaimRef{s1.point_off, nin, v});
+            }
+        };
+        // Eq-factored form (kernels.hpp PsJob::eq_n; found at setup, hg_pk::NodeDev::EqForm): the node relays aligned blocks, so with
+        // ONE claim at z every phase-1 table is kappa_i eq(z', .), z' = (z_0 .. z_(w-1), bits of hib), kappa_i = sum_t coef_t
+        // eq(z_(w..); block_t). Neither the node's eq table nor any bookkeeping table is built; additive constants, which are constant
+        // over those blocks, leave the claim as a scalar of the challenges.
+        const hg_pk::NodeDev::EqForm& ef = nd.eq_form;
+        const int eq_tail = ef.ok && cs.n == 1 && ps_eq_on() ? eq_tail_rd((int)li.size(), nin) : -1;
+        if (eq_tail >= 0) {
+            const u64* chain = challenge_chain(2 * (cs.point_off[0] + n.log2_out()));
+            auto zc = [&](int k) { return e2(chain[2 * (cs.point_off[0] + k)], chain[2 * (cs.point_off[0] + k) + 1]); };
+            const int hb = n.log2_out() - ef.w;
+            auto eq_hi = [&](u32 block) {
+                E2 acc = e2_one();
+                for (int b = 0; b < hb; b++) acc = e2_mul(acc, (block >> b) & 1 ? zc(ef.w + b) : e2_sub(e2_one(), zc(ef.w + b)));
+                return acc;
+            };
+            if (!ef.consts.empty()) {
+                E2 c = e2_zero();
+                for (auto& t : ef.consts) c = e2_add(c, e2_mul_f(eq_hi(t.second), t.first));
+                push_op([claim, c] { *claim = e2_sub(*claim, c); });
+            }
+            std::vector<const u64*> a;
+            std::vector<E2> kappa;
+            std::vector<E2*> fa, fb;
+            const size_t u_base = slot(n.arity);
+            E2* scratch = own ? ctx->alloc_n<E2>(n.arity) : nullptr;
+            for (int i : li) {
+                E2 k = e2_zero();
+                for (auto& t : ef.terms[i]) k = e2_add(k, e2_mul_f(eq_hi(t.second), t.first));
+                a.push_back(d_vals[n.preds[i]]);
+                kappa.push_back(k);
+                fa.push_back(d_res() + u_base + i);
+                fb.push_back(scratch + i);
+            }
+            std::vector<E2> zp(nin);
+            for (int k = 0; k < nin; k++) zp[k] = k < ef.w ? zc(k) : e2((ef.hib >> (k - ef.w)) & 1u, 0);
+            ScHandle s1 = sc_prodsum_eq(a, kappa, zp, cs.point_off[0], ef.w, ef.hib, nin, eq_tail, fa, fb, own);
+            phase1_steps(s1, u_base, cell());
+            return;
+        }
         // Nodes that received their only claim from the same sum-check share the point (every input of a Vanilla node is opened at the
         // node's r_x: the five inputs of the final sum, the eight chunk nodes behind the Lasso input ...): one eq table serves them all
         // (read-only everywhere). HG_NO_TABLE_SHARE=1: one table per node.
@@ -1812,11 +1981,8 @@ struct Prover {
             push_op([this, s, claim] { *claim = e2_sub(*claim, h_res()[s]); });
         }
         // phase 1: sum_x sum_i in_i(x) T_i(x)
-        std::vector<int> li, ri;
-        for (int i = 0; i < n.arity; i++) { if (n.left_use[i]) li.push_back(i); if (n.right_use[i]) ri.push_back(i); }
         dev::GatherT gt;
         memset(&gt, 0, sizeof(gt));
-        if (n.arity > dev::PS_MAX_PAIRS) throw Error("vanilla: arity too large");
         for (int i = 0; i < n.arity; i++) gt.in_vals[i] = d_vals[n.preds[i]];
         std::vector<const u64*> a;
         std::vector<const E2*> b;
@@ -1847,16 +2013,7 @@ struct Prover {
         }
         ScHandle s1 = sc_prodsum(a, b, nin, fa, fb, own);
         Cell after1 = cell();
-        mark("vanilla node " + std::to_string(id) + ": Libra phase 1 sum-check, " + std::to_string(nin) + " rounds x 3 coefficients [G1 node order, G2 alpha per claim, G3 Libra form]");
-        defer_sumcheck(s1, 2, claim, after1);
-        for (int i : li) {
-            mark("vanilla node " + std::to_string(id) + ": input " + std::to_string(i) + " evaluation at r_x");
-            defer_write_slots(u_base + i, 1);
-            Cell v = cell();
-            size_t sl = u_base + i;
-            push_op([this, v, sl] { *v = h_res()[sl]; });
-            claims[n.preds[i]].push_back(ClaimRef{s1.point_off, nin, v});
-        }
+        phase1_steps(s1, u_base, after1);
         if (!n.mul.empty()) {
             if (!n.lin.empty()) throw Error("vanilla: nodes mixing linear and mul gates are not on this path");
             // phase 2: sum_y sum_i in_i(y) B_i(y), claim carried over from phase 1 (no linear part).

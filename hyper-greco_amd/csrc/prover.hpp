@@ -143,6 +143,12 @@ struct hg_pk {
         struct Seg { const hg::dev::GatherSeg* d = nullptr; int nseg = 0; bool alias = false; size_t alias_off = 0;
                      size_t win_lo = 0, win_hi = 0; };   // positions outside [win_lo, win_hi) have no term: the table is zero there
         std::vector<Seg> seg;                // [arity]
+        // eq-factored form of Libra phase 1 (kernels.hpp PsJob::eq_n), found at setup (capi.hip): the table of every used input is a
+        // constant times eq(z', .), z' = the first w coordinates of the claim point and the bits of hib above them
+        struct EqForm { bool ok = false; int w = 0; unsigned hib = 0;
+                        std::vector<std::vector<std::pair<hg::u64, hg::u32>>> terms;   // per input: (coefficient, gate block)
+                        std::vector<std::pair<hg::u64, hg::u32>> consts; };            // additive constants per gate block: (value, block)
+        EqForm eq_form;
         const hg::u32* const_gate = nullptr;
         const hg::u64* const_coef = nullptr;
         size_t nconst = 0;
