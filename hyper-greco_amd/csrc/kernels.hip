@@ -1073,12 +1073,9 @@ __device__ __forceinline__ void ps_io(const PsJob& J, int rd, int rounds, int in
     else { size_t len = N >> (rd + rounds); oa = J.bufa[out_buf] + (size_t)i * len; ob = J.bufb[out_buf] + (size_t)i * len; }
 }
 
-// optional LDS-resident tables (the single-workgroup tail keeps its intermediate folds on chip): table i of a region at
-// base + i * (its length); null = the global buffers of ps_io
-struct PsLds { const E2* ia; const E2* ib; E2* oa; E2* ob; };
 template <typename TA>
 __device__ __forceinline__ void ps_round_body(const PsJob& J, int rd, int in_buf, int out_buf, size_t half, E2 r, int jb_log2, E2& a0, E2& a2,
-                                              size_t first_tile, size_t tile_step, PsLds lds = PsLds{nullptr, nullptr, nullptr, nullptr}) {
+                                              size_t first_tile, size_t tile_step) {
     using V = Val<TA>;
     const int BD = blockDim.x, tid = threadIdx.x;
     const int G = BD >> jb_log2;
@@ -1096,8 +1093,6 @@ __device__ __forceinline__ void ps_round_body(const PsJob& J, int rd, int in_buf
             touched = true;
             const void* pa; const E2* pb; E2* oa; E2* ob;
             ps_io(J, rd, 1, in_buf, out_buf, i, pa, pb, oa, ob);
-            if (lds.ia) { pa = lds.ia + (size_t)i * 2 * half; pb = lds.ib + (size_t)i * 2 * half; }
-            if (lds.oa) { oa = lds.oa + (size_t)i * half; ob = lds.ob + (size_t)i * half; }
             TA xa, ya;
             E2 xb, yb;
             if (in_buf < 0) {
@@ -1428,10 +1423,84 @@ __global__ __launch_bounds__(256) void k_ps_step2(const PsJob* __restrict__ jobs
     }
     if (nblocks > 1) finish_partials(part, 4, tickets_of(partials) + y * 32, res + J.sums_slot + 2 * rd, sm, nblocks);
 }
-// rounds [tail_rd, nvars) of every job, one workgroup per job; the folds between the rounds live in LDS
-// (dynamic LDS: 16 block-sum slots, then PS_TAIL_LDS_E2 Ext2 entries: two ping-pong regions of 2/3 and 1/3)
-constexpr size_t PS_TAIL_LDS_E2 = 6144;  // first tail round: <= 2048 pair items -> 2 * 2048 folded entries, then half of that
-__global__ __launch_bounds__(1024) void k_ps_tail(const PsJob* __restrict__ jobs, const E2* __restrict__ chal, E2* __restrict__ res) {
+// rounds [tail_rd, nvars) of every job, one workgroup per job. A round here is a chain of dependent instructions and barriers,
+// not work (measured: 7 us per round with 1024 threads, block sums through thread 0 and spilled registers; 147 us per launch), so:
+//  * the first round reads its (pair, j) items from HBM four at a time (all loads of a batch in flight before the first product)
+//    and writes the folds to LDS; every later round reads and writes the SAME LDS region (all reads, barrier, all writes,
+//    barrier: the folds of a round fit its thread's registers), tables de-interleaved as in HBM so both reads are conflict-free;
+//  * per-wave sums by DPP, then ONE wave adds the per-wave values (no serial loop in thread 0), overlapping the other waves' writes;
+//  * once a round has at most 64 items, wave 0 finishes the job alone: no barrier, no LDS hop for the sums;
+//  * an eq-factored job (PsJob::eq_n) never stores its b tables: the first round forms b = (kappa_i P) SUF_tail_rd on the fly.
+constexpr int PS_TAIL_THREADS = 512;
+constexpr size_t PS_TAIL_ITEMS_MAX = 4096;                 // (pair, j) items of a job's first tail round (host: flush_prodsum)
+constexpr size_t PS_TAIL_LDS_E2 = 2 * PS_TAIL_ITEMS_MAX;   // their folds: the a tables, then the b tables
+template <typename TA>
+__device__ __forceinline__ void ps_tail_item(TA xa, TA ya, E2 xb, E2 yb, const FoldR& fr, WE2& w0, WE2& w2, E2& fa, E2& fb) {
+    using V = Val<TA>;
+    const TA da = V::sub(ya, xa);
+    const E2 db = e2_sub(yb, xb);
+    const E2 vb = e2_add(yb, db);
+    const TA va = V::add(ya, da);
+    if constexpr (std::is_same<TA, u64>::value) {
+        wmac2(w0.A, xb.c0, xa, w0.C, xb.c1, xa);
+        wmac2(w2.A, vb.c0, va, w2.C, vb.c1, va);
+        WAcc f0 = wacc_zero(), f1 = wacc_zero();
+        f0.L = xa;
+        wmac2(f0, fr.r0, da, f1, fr.r1, da);
+        fa = e2(wreduce(f0), wreduce(f1));
+    } else {
+        we2_mac(w0, xb, xa);
+        we2_mac(w2, vb, va);
+        fa = e2_fold_wide(xa, da, fr);
+    }
+    fb = e2_fold_wide(xb, db, fr);
+}
+// first tail round: items from HBM (or, the b side of an eq-factored job, from the point's suffix table), folds to T (fin_a / fin_b
+// when it is also the last round)
+template <typename TA>
+__device__ __forceinline__ void ps_tail_first(const PsJob& J, const E2* __restrict__ kq, E2 r, E2* __restrict__ T, WE2& w0, WE2& w2, bool& touched) {
+    const int BD = blockDim.x, tid = threadIdx.x;
+    const int rd = J.tail_rd, hl = J.nvars - 1 - rd;
+    const size_t half = (size_t)1 << hl, len = half << 1, items = (size_t)J.npairs * half;
+    const bool natural = J.tail_buf < 0, last = hl == 0;
+    const FoldR fr = fold_r(r);
+    const E2* __restrict__ suf = J.eq_n ? J.eq_suf + (len - 1) : nullptr;   // SUF_tail_rd
+    for (size_t t0 = tid; t0 < items; t0 += (size_t)4 * BD) {
+        TA xa[4], ya[4];
+        E2 xb[4], yb[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const size_t t = t0 + (size_t)k * BD;
+            if (t < items) {
+                const int i = (int)(t >> hl);
+                const size_t j = t & (half - 1);
+                if (natural) {
+                    load_pair<TA>(reinterpret_cast<const TA*>(J.a[i]) + 2 * j, xa[k], ya[k]);
+                    load_pair<E2>(J.b[i] + 2 * j, xb[k], yb[k]);
+                } else {
+                    load_xy<TA, false>(reinterpret_cast<const TA*>(J.bufa[J.tail_buf]) + (size_t)i * len, j, half, xa[k], ya[k]);
+                    if (suf) load_pair<E2>(suf + 2 * j, xb[k], yb[k]);
+                    else load_xy<E2, false>(J.bufb[J.tail_buf] + (size_t)i * len, j, half, xb[k], yb[k]);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const size_t t = t0 + (size_t)k * BD;
+            if (t < items) {
+                const int i = (int)(t >> hl);
+                const size_t j = t & (half - 1);
+                if (suf) { xb[k] = e2_mul(kq[i], xb[k]); yb[k] = e2_mul(kq[i], yb[k]); }
+                E2 fa, fb;
+                ps_tail_item<TA>(xa[k], ya[k], xb[k], yb[k], fr, w0, w2, fa, fb);
+                touched = true;
+                if (last) { J.fin_a[i][0] = fa; J.fin_b[i][0] = fb; }
+                else { const size_t o = (size_t)i * half + dpos(j, half); T[o] = fa; T[items + o] = fb; }
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(PS_TAIL_THREADS) void k_ps_tail(const PsJob* __restrict__ jobs, const E2* __restrict__ chal, E2* __restrict__ res) {
     __shared__ PsJob Jl;   // (descriptor in LDS: see k_st_tail)
     {
         const unsigned* src = reinterpret_cast<const unsigned*>(jobs + blockIdx.x);
@@ -1439,51 +1508,99 @@ __global__ __launch_bounds__(1024) void k_ps_tail(const PsJob* __restrict__ jobs
     }
     __syncthreads();
     const PsJob& J = Jl;
-    E2* sm = dyn_lds;
-    int bd_log2 = 31 - __clz((int)blockDim.x);
-    int in_buf = J.tail_buf;
-    const E2* lin_a = nullptr; const E2* lin_b = nullptr;
-    // round sums to the (host-memory) result buffer once, at the end; challenges fetched once (as in k_st_tail)
-    __shared__ E2 keep[2 * 32], rch[32];
-    if ((int)threadIdx.x < J.nvars - J.tail_rd) rch[threadIdx.x] = chal[J.r_off + J.tail_rd + threadIdx.x];
-    if (J.eq_n) {
-        // an eq-factored job hands over without b tables: b_i = kappa_i P_tail_rd eq(z'_(tail_rd..); .), written de-interleaved like
-        // every folded table (position p holds logical entry 2p, or 2(p - len/2) + 1 in the upper half)
-        const size_t len = (size_t)1 << (J.nvars - J.tail_rd);
-        const E2* __restrict__ suf = J.eq_suf + (len - 1);
-        const E2 P = J.eq_scal[2 * J.nvars];
-        const E2* __restrict__ kap = J.eq_scal + 2 * J.nvars + 1;
-        E2* bt = J.bufb[J.tail_buf];
-        for (size_t p = threadIdx.x; p < len; p += blockDim.x) {
-            const size_t e = p < len / 2 ? 2 * p : 2 * (p - len / 2) + 1;
-            const E2 s = e2_mul(P, gload_e2(suf + e));
-            for (int i = 0; i < J.eq_n; i++) gstore_e2(bt + (size_t)i * len + p, e2_mul(kap[i], s));
-        }
-        __threadfence_block();
-    }
+    E2* T = dyn_lds;
+    const int BD = blockDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = BD >> 6;
+    const int R = J.nvars - J.tail_rd;   // rounds of this tail
+    // round sums to the (host-memory) result buffer once, at the end; challenges fetched once
+    __shared__ E2 keep[2 * 32], rch[32], red[2][2 * 16], kq[PS_MAX_PAIRS];
+    if (tid < R) rch[tid] = chal[J.r_off + J.tail_rd + tid];
+    if (tid < J.eq_n) kq[tid] = e2_mul(J.eq_scal[2 * J.nvars + 1 + tid], J.eq_scal[2 * J.nvars]);   // kappa_i P_tail_rd
     __syncthreads();
-    for (int rd = J.tail_rd; rd < J.nvars; rd++) {
-        const int hl = J.nvars - 1 - rd;
-        const size_t half = (size_t)1 << hl;
-        const int jb_log2 = hl < bd_log2 ? hl : bd_log2;
-        const bool last = rd == J.nvars - 1;
-        const int out_buf = last ? -1 : (in_buf == 0 ? 1 : 0);
-        // this round's folds: npairs tables of `half` entries for a and for b
-        const bool fits = !last && 2 * (size_t)J.npairs * half <= ((rd - J.tail_rd) & 1 ? (size_t)2048 : (size_t)4096);
-        E2* reg = dyn_lds + SM_SLOTS + (((rd - J.tail_rd) & 1) ? 4096 : 0);
-        PsLds lds{lin_a, lin_b, fits ? reg : nullptr, fits ? reg + (size_t)J.npairs * half : nullptr};
-        E2 r = rch[rd - J.tail_rd];
-        E2 a0 = e2_zero(), a2 = e2_zero();
-        if (in_buf < 0 && !lin_a) ps_round_body<u64>(J, rd, in_buf, out_buf, half, r, jb_log2, a0, a2, 0, 1, lds);
-        else ps_round_body<E2>(J, rd, lin_a ? 0 : in_buf, out_buf, half, r, jb_log2, a0, a2, 0, 1, lds);
-        E2 sv[2] = {a0, a2};
-        block_sum_multi<2>(sv, sm);
-        if (threadIdx.x == 0) { keep[2 * (rd - J.tail_rd)] = sv[0]; keep[2 * (rd - J.tail_rd) + 1] = sv[1]; }
+    int hl = J.nvars - 1 - J.tail_rd;
+    size_t half = (size_t)1 << hl, items = (size_t)J.npairs * half;
+    // a round's per-wave sums -> red[round parity][wave]; wave 0 adds them (after the barrier that follows) into keep[]
+    auto wave_part = [&](int r, WE2& w0, WE2& w2, bool touched) {
+        E2 s0 = e2_zero(), s2 = e2_zero();
+        if (touched) { s0 = we2_reduce(w0); s2 = we2_reduce(w2); }
+        s0 = wave_sum(s0); s2 = wave_sum(s2);
+        if (lane == 0) { red[r & 1][2 * wave] = s0; red[r & 1][2 * wave + 1] = s2; }
+    };
+    auto wave0_total = [&](int r) {
+        E2 s0 = lane < nw ? red[r & 1][2 * lane] : e2_zero(), s2 = lane < nw ? red[r & 1][2 * lane + 1] : e2_zero();
+        s0 = wave_sum(s0); s2 = wave_sum(s2);
+        if (lane == 0) { keep[2 * r] = s0; keep[2 * r + 1] = s2; }
+    };
+    {
+        WE2 w0 = we2_zero(), w2 = we2_zero();
+        bool touched = false;
+        if (J.tail_buf < 0) ps_tail_first<u64>(J, kq, rch[0], T, w0, w2, touched);
+        else ps_tail_first<E2>(J, kq, rch[0], T, w0, w2, touched);
+        wave_part(0, w0, w2, touched);
         __syncthreads();
-        if (fits) { lin_a = lds.oa; lin_b = lds.ob; }
-        else { lin_a = lin_b = nullptr; in_buf = out_buf; }
+        if (wave == 0) wave0_total(0);
     }
-    if ((int)threadIdx.x < 2 * (J.nvars - J.tail_rd)) res[J.sums_slot + 2 * (size_t)J.tail_rd + threadIdx.x] = keep[threadIdx.x];
+    int r = 1;
+    // rounds on the LDS tables, whole workgroup: at most PS_TAIL_ITEMS_MAX / 2 / PS_TAIL_THREADS = 4 items per thread
+    for (; r < R && (items >> 1) > 64; r++) {
+        const size_t in_items = items, in_half = half;
+        hl--; half >>= 1; items >>= 1;
+        const FoldR fr = fold_r(rch[r]);
+        WE2 w0 = we2_zero(), w2 = we2_zero();
+        bool touched = false;
+        E2 fa[4], fb[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const size_t t = (size_t)tid + (size_t)k * BD;
+            if (t < items) {
+                const size_t i = t >> hl, j = t & (half - 1);
+                const E2* pa = T + i * in_half;
+                const E2* pb = T + in_items + i * in_half;
+                ps_tail_item<E2>(pa[j], pa[half + j], pb[j], pb[half + j], fr, w0, w2, fa[k], fb[k]);
+                touched = true;
+            }
+        }
+        wave_part(r, w0, w2, touched);
+        __syncthreads();   // every read of this round's tables is done; the per-wave sums are in red[]
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const size_t t = (size_t)tid + (size_t)k * BD;
+            if (t < items) {
+                const size_t i = t >> hl, j = t & (half - 1);
+                const size_t o = i * half + dpos(j, half);
+                T[o] = fa[k]; T[items + o] = fb[k];
+            }
+        }
+        if (wave == 0) wave0_total(r);
+        __syncthreads();
+    }
+    if (wave != 0) return;
+    // at most 64 items per round from here on (128 in the table pair read first): wave 0 alone, in program order
+    for (; r < R; r++) {
+        const size_t in_items = items, in_half = half;
+        hl--; half >>= 1; items >>= 1;
+        const bool last = hl == 0 && r == R - 1;
+        const FoldR fr = fold_r(rch[r]);
+        WE2 w0 = we2_zero(), w2 = we2_zero();
+        E2 fa = e2_zero(), fb = e2_zero();
+        const size_t t = lane;
+        const size_t i = t >> hl, j = t & (half - 1);
+        const bool mine = t < items;
+        if (mine) {
+            const E2* pa = T + i * in_half;
+            const E2* pb = T + in_items + i * in_half;
+            ps_tail_item<E2>(pa[j], pa[half + j], pb[j], pb[half + j], fr, w0, w2, fa, fb);
+        }
+        E2 s0 = mine ? we2_reduce(w0) : e2_zero(), s2 = mine ? we2_reduce(w2) : e2_zero();
+        s0 = wave_sum(s0); s2 = wave_sum(s2);
+        if (lane == 0) { keep[2 * r] = s0; keep[2 * r + 1] = s2; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (the wave's LDS reads above stay ahead of the writes below)
+        if (mine) {
+            if (last) { J.fin_a[i][0] = fa; J.fin_b[i][0] = fb; }
+            else { const size_t o = i * half + dpos(j, half); T[o] = fa; T[items + o] = fb; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    if (lane < 2 * R) res[J.sums_slot + 2 * (size_t)J.tail_rd + lane] = keep[lane];
 }
 
 // Factor tables of the eq-factored jobs' points (PsEqPoint). Every table is a product of at most two small factor tables kept in
@@ -1596,12 +1713,12 @@ void ps_round(hipStream_t st, bool rounds2, const PsJob* jobs, const PsItem* ite
     } else if (rounds2) k_ps_step2<false><<<grid, 256, SM_SLOTS * sizeof(E2), st>>>(jobs, items, nitems, chal, partials, res);
     else k_ps_one<<<grid, 256, SM_SLOTS * sizeof(E2), st>>>(jobs, items, nitems, chal, partials, res);
 }
+size_t ps_tail_items_max() { return PS_TAIL_ITEMS_MAX; }
 void ps_tail(hipStream_t st, const PsJob* jobs, int njobs, const E2* chal, E2* res) {
-    const size_t lds = (SM_SLOTS + PS_TAIL_LDS_E2) * sizeof(E2);
+    const size_t lds = PS_TAIL_LDS_E2 * sizeof(E2);
     static const hipError_t attr = hipFuncSetAttribute((const void*)k_ps_tail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)attr;
-    static const int threads = (int)env_size("HG_PS_TAIL_THREADS", 1024);
-    k_ps_tail<<<njobs, threads, lds, st>>>(jobs, chal, res);
+    k_ps_tail<<<njobs, PS_TAIL_THREADS, lds, st>>>(jobs, chal, res);
 }
 
 // debugging aid (HG_STAMP=1): device wall clock (100 MHz) at a point of a stream, also inside a replayed launch graph

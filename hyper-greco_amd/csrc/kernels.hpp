@@ -207,6 +207,7 @@ int ps_plan_blocks(PsItem* items, int nitems, const PsJob* host_jobs, bool round
 void ps_round(hipStream_t st, bool rounds2, const PsJob* jobs, const PsItem* items, int nitems, int grid, const E2* chal, E2* partials, E2* res, bool eq = false);
 // rounds [tail_rd, nvars) of every job, one workgroup per job
 void ps_tail(hipStream_t st, const PsJob* jobs, int njobs, const E2* chal, E2* res);
+size_t ps_tail_items_max();   // (pair, j) items a job may bring to its first tail round (the folds live in LDS from there on)
 
 // dst_base[ent[i].dst] = ent[i].src[0]: moves locally produced scalars to their global result slots
 struct ScatterEnt { const E2* src; size_t dst; };

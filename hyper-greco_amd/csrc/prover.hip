@@ -685,7 +685,10 @@ struct Prover {
         static const bool v = [] { const char* e = getenv("HG_NO_PS_EQ"); const char* f = getenv("HG_NO_PS_FUSE2"); return !(e && e[0] == '1') && !(f && f[0] == '1'); }();
         return v;
     }
-    static size_t ps_tail_items() { static const size_t v = [] { const char* e = getenv("HG_PS_TAIL_ITEMS"); return e && *e ? (size_t)atol(e) : TAIL_ITEMS; }(); return v; }
+    static size_t ps_tail_items() {   // (HG_PS_TAIL_ITEMS can only lower it: the tail keeps a job's folds in LDS)
+        static const size_t v = [] { const char* e = getenv("HG_PS_TAIL_ITEMS"); return std::min<size_t>(e && *e ? (size_t)atol(e) : TAIL_ITEMS, dev::ps_tail_items_max()); }();
+        return v;
+    }
     // First tail round of an eq-factored job, -1: the job is too small for the form. Every round ahead of the tail runs in a fused
     // pair (the tail may start one round later than TAIL_ITEMS says), the last pair at half >= 2^9, and the table handed to the
     // tail must be one of the point's stored suffix tables.
@@ -722,7 +725,6 @@ struct Prover {
             if (np > 1) J.bufA[q] = ctx->alloc_n<E2>(N >> (q + 1));
         }
         if (np > 1) J.eqA0 = ctx->alloc_n<E2>(N);
-        for (int q = 0; q < 2; q++) J.bufb[q] = ctx->alloc_n<E2>((size_t)np * (N >> tail_rd));   // the tail's prologue writes one of them; its rounds ping-pong
         for (int i = 0; i < np; i++) { J.a[i] = a[i]; J.fin_a[i] = fin_a[i]; J.fin_b[i] = fin_b[i]; }
         // prefactors of the rounds ahead of the tail, P at the hand-off, kappa
         std::vector<E2> scal((size_t)2 * nvars + 1 + np + nvars + 4 * (size_t)(tail_rd / 2), e2_zero());
@@ -1845,9 +1847,17 @@ struct Prover {
             // 3: at the end of the MAIN stream, behind the grand products (which, in their slot form, end before the node reductions do:
             // stamps 1.92 against 1.99 ms, and the openings ran alone behind the latter until 2.08 ms). Medians of 72 interleaved graph
             // replays: 1.982 (3) / 2.023 (1) / 2.023 (2) / 2.057 ms (0).
-            static const int late = [] { const char* e = getenv("HG_LATE_OPENINGS"); return e && *e ? atoi(e) : 3; }();
+            // 4 (default since the eq-factored node reductions, which end 0.25 ms before the grand products): behind the node reductions
+            // on THEIR stream (the third one), which waits for the opening tables of the second. Medians of 72 interleaved graph
+            // replays: 1.85-1.86 (4) / 1.83-1.85 (1: the same behind node reductions on the second stream) / 1.87-1.91 (3) / 1.846 (0) /
+            // 1.864 ms (2). A fourth stream for the node reductions alone: 1.85 - a replayed launch graph does not run a fourth branch
+            // beside the other three (its first kernel starts 0.6 ms into the prove, with or without GPU_MAX_HW_QUEUES=8).
+            static const int late = [] { const char* e = getenv("HG_LATE_OPENINGS"); return e && *e ? atoi(e) : 4; }();
             aux(open_tables);
-            if (late == 3 && use_aux && world == 1) {
+            if (late == 4 && use_aux && world == 1) {
+                hip_check(hipEventRecord(ctx->ev_aux[4], ctx->stream2), "lasso: opening tables event");
+                late_col.push_back(openings);
+            } else if (late == 3 && use_aux && world == 1) {
                 hip_check(hipEventRecord(ctx->ev_aux[4], ctx->stream2), "lasso: opening tables event");
                 hip_check(hipStreamWaitEvent(ctx->stream, ctx->ev_aux[4], 0), "lasso: wait for the opening tables");
                 openings();
@@ -2118,6 +2128,7 @@ struct Prover {
     // Runs `fn` with the second stream as the enqueue target (work of the Lasso node that is off its critical path: counter
     // sorts, grand product #2's hashes and tree, the openings). One stream only: runs it in place.
     std::vector<std::function<void()>> late_aux;
+    std::vector<std::function<void()>> late_col;   // the same, for whichever stream the node reductions run on; needs ev_aux[4] (HG_LATE_OPENINGS=4)
     bool aux_started = false;
     template <typename Fn> void on_aux(Fn fn) {
         if (!fork_recorded) { fn(); return; }
@@ -2220,6 +2231,11 @@ struct Prover {
         }
         for (auto& f : late_aux) f();          // the Lasso node's openings (lasso_node)
         late_aux.clear();
+        if (!late_col.empty()) {
+            if (st != ctx->stream2) hip_check(hipStreamWaitEvent(st, ctx->ev_aux[4], 0), "openings: wait for the opening tables");
+            for (auto& f : late_col) f();
+            late_col.clear();
+        }
         join_nodes_stream();
     }
 
