@@ -505,14 +505,14 @@ __device__ __forceinline__ void st_io(const StJob& J, int rd, const void*& in, s
     out = rd == J.nvars - 1 ? J.final_out : J.buf[rd & 1];
 }
 
-// The items of a launch share a 1-D grid: item y owns workgroups [blk0, blk0 + nblk). Binary search (uniform).
+// The items of a launch share a 1-D grid: item y owns workgroups [blk0, blk0 + nblk).
+// (a launch holds at most 64 items: ONE 64-lane load of the items' first workgroups and a ballot, instead of a binary search whose six
+// dependent loads stood at the head of every workgroup of every round launch)
 __device__ __forceinline__ int find_item(const StItem* __restrict__ items, int nitems, int blk) {
-    int lo = 0, hi = nitems - 1;
-    while (lo < hi) {
-        int mid = (lo + hi + 1) >> 1;
-        if (items[mid].blk0 <= blk) lo = mid; else hi = mid - 1;
-    }
-    return lo;
+    const int l = threadIdx.x & 63;
+    const int b0 = l < nitems ? items[l].blk0 : 0x7fffffff;
+    const unsigned long long m = __ballot(b0 <= blk);
+    return __builtin_amdgcn_readfirstlane(__popcll(m) - 1);
 }
 // one step: every item runs its job's round with half = 2^item.h_log2
 template <int KIND, typename T, bool SLOT = false>   // SLOT: the first round of ONE slot-form job (StJob::slotw)
@@ -927,15 +927,16 @@ static inline size_t sc_lds_bytes(int nv, int bd) { return (SM_SLOTS + (size_t)n
 // runs LDS -> LDS with the thread mapping of the big rounds (sc_round_body: 2^jb threads along j, the rest along the tables), the
 // last one writes the ntab scalars. How many rounds fit depends on the job's table count (st_tail_h: 12 for the two collation
 // tables, 7 for the mirrored top layer, 6 for a full grand-product layer, 9-10 for the few tables of a sharded rank), so a small
-// job spends its whole launch-bound second half in ONE launch. Dynamic LDS: [SM_SLOTS][NV * 256 reduction slots][ntab 2^h0][ntab 2^(h0-1)].
+// job spends its whole launch-bound second half in ONE launch. Dynamic LDS: [SM_SLOTS][NV * ST_TAIL_THREADS reduction slots][ntab 2^h0][ntab 2^(h0-1)].
 constexpr size_t ST_TAIL_LDS_BYTES = 120 * 1024;   // for the two table regions
+constexpr int ST_TAIL_THREADS = 256;               // (512: 92.8 against 84 us for the grand-product tail - the per-round chain is the same and the sums cross more waves)
 int st_tail_h(int ntab, int nvars) {
     int h = 0;
     while (h + 1 <= nvars - 1 && (size_t)ntab * (((size_t)1 << (h + 1)) + ((size_t)1 << h)) * sizeof(E2) <= ST_TAIL_LDS_BYTES) h++;
     return h;
 }
 template <int KIND>
-__global__ __launch_bounds__(256) void k_st_tail(const StJob* __restrict__ jobs, const StItem* __restrict__ items, const E2* __restrict__ chal,
+__global__ __launch_bounds__(ST_TAIL_THREADS) void k_st_tail(const StJob* __restrict__ jobs, const StItem* __restrict__ items, const E2* __restrict__ chal,
                                                  E2* __restrict__ res) {
     constexpr int NV = KIND == SC_GRANDPROD ? 3 : 2;
     // The job and item descriptors are copied to LDS first: every round reads a dozen of their fields behind a barrier. (A round of
@@ -960,7 +961,7 @@ __global__ __launch_bounds__(256) void k_st_tail(const StJob* __restrict__ jobs,
     E2* red = dyn_lds + SM_SLOTS;
     E2* tab[2];
     const int h0 = J.nvars - 1 - I.rd;
-    tab[0] = red + NV * 256;
+    tab[0] = red + NV * ST_TAIL_THREADS;
     tab[1] = tab[0] + ((size_t)J.ntab << h0);
     const bool p0_only = J.p0_only != 0;
     const StJob* mirror = (KIND == SC_GRANDPROD && J.mirror) ? &J : nullptr;
@@ -1017,12 +1018,12 @@ void gp_slot_regroup(hipStream_t st, const E2* in, E2* out, const uint8_t* slot_
     k_gp_slot_regroup<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(in, out, slot_of, ratio, nrows, nslots, npairs, len_log2, len_log2 - np_log2, has_s ? 1 : 0);
 }
 void st_tail(hipStream_t st, int kind, const StJob* jobs, const StItem* items, int nitems, size_t table_bytes, const E2* chal, E2* res) {
-    const size_t lds = (SM_SLOTS + 3 * 256) * sizeof(E2) + table_bytes;
-    static const hipError_t a1 = hipFuncSetAttribute((const void*)k_st_tail<SC_GRANDPROD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((SM_SLOTS + 3 * 256) * sizeof(E2) + ST_TAIL_LDS_BYTES));
-    static const hipError_t a2 = hipFuncSetAttribute((const void*)k_st_tail<SC_COLLATION>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((SM_SLOTS + 3 * 256) * sizeof(E2) + ST_TAIL_LDS_BYTES));
+    const size_t lds = (SM_SLOTS + 3 * ST_TAIL_THREADS) * sizeof(E2) + table_bytes;
+    static const hipError_t a1 = hipFuncSetAttribute((const void*)k_st_tail<SC_GRANDPROD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((SM_SLOTS + 3 * ST_TAIL_THREADS) * sizeof(E2) + ST_TAIL_LDS_BYTES));
+    static const hipError_t a2 = hipFuncSetAttribute((const void*)k_st_tail<SC_COLLATION>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((SM_SLOTS + 3 * ST_TAIL_THREADS) * sizeof(E2) + ST_TAIL_LDS_BYTES));
     (void)a1; (void)a2;
-    if (kind == SC_GRANDPROD) k_st_tail<SC_GRANDPROD><<<nitems, 256, lds, st>>>(jobs, items, chal, res);
-    else k_st_tail<SC_COLLATION><<<nitems, 256, lds, st>>>(jobs, items, chal, res);
+    if (kind == SC_GRANDPROD) k_st_tail<SC_GRANDPROD><<<nitems, ST_TAIL_THREADS, lds, st>>>(jobs, items, chal, res);
+    else k_st_tail<SC_COLLATION><<<nitems, ST_TAIL_THREADS, lds, st>>>(jobs, items, chal, res);
 }
 
 int st_plan_blocks(StItem* items, int nitems, bool rounds2) {
@@ -1128,13 +1129,11 @@ __device__ __forceinline__ void ps_round_body(const PsJob& J, int rd, int in_buf
 }
 
 // one round of every item's job; items share a 1-D grid (item y owns workgroups [blk0, blk0 + nblk))
-__device__ __forceinline__ int find_ps_item(const PsItem* __restrict__ items, int nitems, int blk) {
-    int lo = 0, hi = nitems - 1;
-    while (lo < hi) {
-        int mid = (lo + hi + 1) >> 1;
-        if (items[mid].blk0 <= blk) lo = mid; else hi = mid - 1;
-    }
-    return lo;
+__device__ __forceinline__ int find_ps_item(const PsItem* __restrict__ items, int nitems, int blk) {   // (see find_item)
+    const int l = threadIdx.x & 63;
+    const int b0 = l < nitems ? items[l].blk0 : 0x7fffffff;
+    const unsigned long long m = __ballot(b0 <= blk);
+    return __builtin_amdgcn_readfirstlane(__popcll(m) - 1);
 }
 __global__ __launch_bounds__(256) void k_ps_one(const PsJob* __restrict__ jobs, const PsItem* __restrict__ items, int nitems,
                                                 const E2* __restrict__ chal, E2* __restrict__ partials, E2* __restrict__ res) {
@@ -1293,6 +1292,7 @@ __device__ __forceinline__ bool ps_eq_step2_body(const PsJob& J, const PsItem& I
     const Fold4 f4 = fold4(J.eq_scal + 2 * J.nvars + 1 + nm + J.nvars + 4 * (rd >> 1));
     const E2* __restrict__ hi = J.eq_suf + (((size_t)1 << (J.nvars - (rd + 10))) - 1);   // SUF_(rd+10): one entry per tile
     const E2* __restrict__ Ain = single ? nullptr : (natural ? J.eqA0 : J.bufA[I.in_buf]);
+    const E2 l8 = gload_e2(J.eq_lo + (size_t)(rd + 1) * 384 + tid);   // eq(z'_(rd+2..rd+9); tid): the thread's factor, applied after the loop
     W2 U[4];
 #pragma unroll
     for (int p = 0; p < 4; p++) U[p] = w2_zero();
@@ -1335,7 +1335,6 @@ __device__ __forceinline__ bool ps_eq_step2_body(const PsJob& J, const PsItem& I
         }
     }
     if (!sums) return false;
-    const E2 l8 = gload_e2(J.eq_lo + (size_t)(rd + 1) * 384 + tid);   // eq(z'_(rd+2..rd+9); tid)
     E2 v[4];
 #pragma unroll
     for (int p = 0; p < 4; p++) v[p] = e2_mul(l8, w2_reduce(U[p]));
@@ -1607,7 +1606,7 @@ __global__ __launch_bounds__(PS_TAIL_THREADS) void k_ps_tail(const PsJob* __rest
 // LDS: TOP = eq over the top 7 coordinates, MID_k = eq over coordinates k .. nvars-8 (the stored suffix tables reach at most 6 + 7
 // bits at the sizes of this circuit; PS_EQ_MAX_VARS bounds the general case), so no entry costs more than ~10 dependent products
 // and nothing waits on a table written by the same launch. grid = points x PS_EQ_PARTS, each part writes a slice of the outputs.
-constexpr int PS_EQ_PARTS = 8, PS_EQ_TOPB = 7, PS_EQ_MID_MAX = 1024;
+constexpr int PS_EQ_PARTS = 32, PS_EQ_TOPB = 7, PS_EQ_MID_MAX = 1024;
 __device__ __forceinline__ E2 eq_bits(const E2* z, int first, int bits, unsigned v) {   // eq(z_(first .. first+bits-1); v)
     E2 acc = e2_one();
     for (int b = 0; b < bits; b++) {
@@ -1689,7 +1688,7 @@ int ps_plan_blocks(PsItem* items, int nitems, const PsJob* host_jobs, bool round
     // launch has enough of them (the items have only 1-3 table pairs each, unlike the grand-product jobs)
     size_t all_tiles = 0;
     for (int q = 0; q < nitems; q++) all_tiles += ((size_t)1 << (host_jobs[items[q].job].nvars - 1 - items[q].rd)) >> jb0;
-    static const size_t target_blocks = env_size("HG_PS_TARGET_BLOCKS", 4096);
+    static const size_t target_blocks = env_size("HG_PS_TARGET_BLOCKS", 1024);   // (4096 until round 5: 102 -> 55 us for the first launch of a prove in isolation, GPU time 1.875 -> 1.820 ms)
     size_t per = all_tiles / target_blocks;
     if (per < 1) per = 1;
     if (per > 32) per = 32;
