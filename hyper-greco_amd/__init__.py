@@ -32,7 +32,7 @@ class HgTimings(C.Structure):
 
 
 class HgKernelStat(C.Structure):
-    _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double), ("algo_bytes", C.c_double), ("model_bytes", C.c_double)]
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double), ("algo_bytes", C.c_double), ("model_bytes", C.c_double), ("hbm_bytes", C.c_double)]
 
 
 EXPORTS = [
@@ -174,7 +174,7 @@ class Context:
     def profile_get(self):
         arr = (HgKernelStat * 32)()
         n = lib().hg_profile_get(self.h, arr, 32)
-        return [dict(name=arr[i].name.decode(), launches=int(arr[i].launches), total_ms=arr[i].total_ms, algo_bytes=arr[i].algo_bytes, model_bytes=arr[i].model_bytes)
+        return [dict(name=arr[i].name.decode(), launches=int(arr[i].launches), total_ms=arr[i].total_ms, algo_bytes=arr[i].algo_bytes, model_bytes=arr[i].model_bytes, hbm_bytes=arr[i].hbm_bytes)
                 for i in range(n)]
 
     # ---- BN254 slice: elements are Python ints at this level, 4 little-endian u64 limbs at the C ABI

@@ -1035,7 +1035,7 @@ int hg_profile_select(hg_ctx* ctx, const char* name) {
 }
 int hg_profile_reset(hg_ctx* ctx) {
     if (!ctx) { g_last_error = "hg_profile_reset: null context"; return -1; }
-    for (auto& s : ctx->prof_stats) { s.launches = 0; s.ms = 0; s.bytes = 0; s.model = 0; }
+    for (auto& s : ctx->prof_stats) { s.launches = 0; s.ms = 0; s.bytes = 0; s.model = 0; s.design = 0; }
     return 0;
 }
 int hg_profile_get(hg_ctx* ctx, hg_kernel_stat* out, int cap) {
@@ -1045,7 +1045,7 @@ int hg_profile_get(hg_ctx* ctx, hg_kernel_stat* out, int cap) {
         if (n >= cap) break;
         memset(&out[n], 0, sizeof(out[n]));
         strncpy(out[n].name, s.name.c_str(), sizeof(out[n].name) - 1);
-        out[n].launches = s.launches; out[n].total_ms = s.ms; out[n].algo_bytes = s.bytes; out[n].model_bytes = s.model;
+        out[n].launches = s.launches; out[n].total_ms = s.ms; out[n].algo_bytes = s.bytes; out[n].model_bytes = s.model; out[n].hbm_bytes = s.design;
         n++;
     }
     return n;

@@ -88,7 +88,7 @@ int hg_ctx::prof_class(const char* name, bool dominant) {
     prof_stats.push_back(s);
     return (int)prof_stats.size() - 1;
 }
-void hg_ctx::prof_begin(int cls, double bytes, double model_bytes) {
+void hg_ctx::prof_begin(int cls, double bytes, double model_bytes, double design_bytes) {
     cur_cls = -1;
     if (prof_level == 0) return;
     if (prof_level == 1 && !prof_stats[cls].dominant) return;
@@ -101,6 +101,7 @@ void hg_ctx::prof_begin(int cls, double bytes, double model_bytes) {
     prof_stats[cls].launches++;
     prof_stats[cls].bytes += bytes;
     prof_stats[cls].model += model_bytes < 0 ? bytes : model_bytes;
+    prof_stats[cls].design += design_bytes < 0 ? bytes : design_bytes;
 }
 void hg_ctx::prof_end() {
     if (cur_cls < 0) return;
@@ -384,6 +385,10 @@ struct Prover {
     std::vector<int> st_credit_ntab;   // per queued job: table count of the reference's batch (traffic model of SURVEY.md 8(d)); = ntab without a shortcut
     std::vector<double> st_fused_bytes;  // algorithmic bytes of the passes a job's first round absorbs (hash build, tree level)
     std::vector<std::function<void()>> st_after_seq;
+    // what a job's first round moves to or from HBM beside its own tables (hg_kernel_stat::hbm_bytes): the tree level it writes
+    // (rows actually written x their length) and, for the hash-source job, the integer tables it reads INSTEAD of its input rows
+    double pending_level_design = 0, pending_hash_reads = -1, hash_design_reads = 0;
+    std::vector<double> st_level_design, st_hash_reads;
     double pending_fused_bytes = 0;      // set by the caller right before sc_stride (the hash build a hash-source job absorbs)
     double pending_fused_model_extra = 0, hash_model_extra = 0;   // ... and what only the reference's traffic model counts of it (E reads)
     std::vector<double> st_fused_model_extra;
@@ -399,7 +404,7 @@ struct Prover {
         h.sums_slot = slot((size_t)nvars * h.nv);
         const size_t N = (size_t)1 << nvars;
         if (!enqueue) {  // another rank runs this job: transcript bookkeeping only
-            pending_fused_bytes = 0; pending_fused_model_extra = 0;
+            pending_fused_bytes = 0; pending_fused_model_extra = 0; pending_level_design = 0; pending_hash_reads = -1;
             for (int i = 0; i < nvars; i++) h.rs.push_back(squeeze());
             return h;
         }
@@ -427,7 +432,9 @@ struct Prover {
             double fused = next_level ? (double)(st_credit_ntab.back() / 2) * (double)(2 * N) * 8.0 * (hash_src ? 0.5 : 1.5) : 0.0;
             st_fused_bytes.push_back(fused + pending_fused_bytes);
             st_fused_model_extra.push_back(pending_fused_model_extra);
-            pending_fused_bytes = 0; pending_fused_model_extra = 0;
+            st_level_design.push_back(next_level ? pending_level_design : 0.0);
+            st_hash_reads.push_back(hash_src ? pending_hash_reads : -1.0);
+            pending_fused_bytes = 0; pending_fused_model_extra = 0; pending_level_design = 0; pending_hash_reads = -1;
         }
         return h;
     }
@@ -571,6 +578,17 @@ struct Prover {
             size_t half = (size_t)1 << (J.nvars - 1 - rd);
             return (double)(model ? st_credit_ntab[q] : J.ntab) * (2.0 * half * ((J.base && rd == 0) ? 8 : 16) + half * 16.0);
         };
+        // the same launch in bytes moved to or from HBM by design (hg_kernel_stat::hbm_bytes): the tables of round rd read once, the
+        // folds of round rd + nrounds - 1 written once (the tail: nothing written), plus the tree level a first round emits
+        auto design_bytes = [&](int q, int rd, int nrounds, bool tail) {
+            const dev::StJob& J = st_jobs[q];
+            const size_t half = (size_t)1 << (J.nvars - 1 - rd);
+            double b = (double)J.ntab * 2.0 * half * ((J.base && rd == 0) ? 8 : 16);
+            if (rd == 0 && st_hash_reads[q] >= 0) b = st_hash_reads[q];
+            if (!tail) b += (double)J.ntab * (double)(half >> (nrounds - 1)) * 16.0;
+            if (rd == 0) b += st_level_design[q];
+            return b;
+        };
         for (size_t li = 0; li < plan.size(); li++) {
             const Launch& L = plan[li];
             if (L.kind == dev::SC_GRANDPROD && st_before_gp) { stamp("collation done"); st_before_gp(); st_before_gp = nullptr; stamp("grand products may start"); }
@@ -589,7 +607,7 @@ struct Prover {
                     // (dims, read_ts per chunk; E read, read / write hashes written per memory) and product-tree level 1
                     bytes = round_bytes(it.job, 0, false) + st_fused_bytes[it.job];
                     model = round_bytes(it.job, 0, true) + st_fused_bytes[it.job] + st_fused_model_extra[it.job];
-                    ctx->prof_begin(cls_gp_hash, bytes, model);
+                    ctx->prof_begin(cls_gp_hash, bytes, model, design_bytes(it.job, 0, 1, false));
                     dev::st_first_hash(st, d_jobs + it.job, d_items + offs[li] + o, grids[li][0], st_jobs[it.job].mirror != 0, hash_recomp, ctx->d_chal, partials, d_res(), st_slot[it.job].tail_ntab != 0);
                     ctx->prof_end();
                     stamp("first hash round done");
@@ -597,10 +615,12 @@ struct Prover {
                 }
                 if (L.tail) {
                     size_t table_bytes = 0;
+                    double design = 0;
                     for (int q = 0; q < cnt; q++) {
                         const dev::StItem& it = L.items[o + q];
                         const dev::StJob& J = st_jobs[it.job];
                         for (int k = 0; k < it.nrounds; k++) { bytes += round_bytes(it.job, it.rd + k, false); model += round_bytes(it.job, it.rd + k, true); }
+                        design += (double)(it.ntab > 0 ? it.ntab : J.ntab) * 2.0 * (double)((size_t)1 << (J.nvars - 1 - it.rd)) * ((J.base && it.rd == 0) ? 8 : 16);
                         const int h0 = J.nvars - 1 - it.rd;
                         table_bytes = std::max(table_bytes, (size_t)(it.ntab > 0 ? it.ntab : J.ntab) * (((size_t)1 << h0) + (((size_t)1 << h0) >> 1)) * sizeof(E2));
                         for (const Regroup& g : regroups) if (g.job == it.job) {
@@ -608,13 +628,15 @@ struct Prover {
                             dev::gp_slot_regroup(st, g.in, g.out, sp.d_slot_of, sp.d_ratio, sp.nrows, sp.nslots, sp.npairs, g.len_log2, (sp.tail_ntab & 1) != 0);
                         }
                     }
-                    ctx->prof_begin(cls_tail, bytes, model);
+                    ctx->prof_begin(cls_tail, bytes, model, design);
                     dev::st_tail(st, L.kind, d_jobs, d_items + offs[li] + o, cnt, table_bytes, ctx->d_chal, d_res());
                     ctx->prof_end();
                 } else {
+                    double design = 0;
                     for (int q = 0; q < cnt; q++) {
                         const dev::StItem& it = L.items[o + q];
                         const dev::StJob& J = st_jobs[it.job];
+                        design += design_bytes(it.job, J.nvars - 1 - it.h_log2, L.nrounds, false);
                         // algorithmic bytes in the per-round accounting of SURVEY.md 8(d): a fused launch is credited with both of
                         // its rounds although the intermediate folded tables never reach HBM
                         for (int k = 0; k < L.nrounds; k++) { bytes += round_bytes(it.job, J.nvars - 1 - it.h_log2 + k, false); model += round_bytes(it.job, J.nvars - 1 - it.h_log2 + k, true); }
@@ -622,7 +644,7 @@ struct Prover {
                     }
                     const int grid = grids[li][o / MAX_BATCH];
                     int cls = L.kind == dev::SC_GRANDPROD ? (L.base ? cls_gp_base : (L.nrounds == 2 ? cls_gp_ext2 : cls_gp_ext)) : (L.base ? cls_col_base : (L.nrounds == 2 ? cls_col_ext2 : cls_col_ext));
-                    ctx->prof_begin(cls, bytes, model);
+                    ctx->prof_begin(cls, bytes, model, design);
                     if (L.nrounds == 2) dev::st_step2(st, L.kind, d_jobs, d_items + offs[li] + o, cnt, grid, ctx->d_chal, partials, d_res());
                     else dev::st_step(st, L.kind, L.base, d_jobs, d_items + offs[li] + o, cnt, grid, ctx->d_chal, partials, d_res(),
                                       L.base && st_jobs[L.items[o].job].slotw != nullptr);
@@ -638,6 +660,8 @@ struct Prover {
         st_slot.clear();
         st_fused_bytes.clear();
         st_fused_model_extra.clear();
+        st_level_design.clear();
+        st_hash_reads.clear();
         for (auto& f : st_after_seq) f();  // (no grand-product job was queued: nothing can depend on these, but keep the order)
         st_after_seq.clear();
         if (!scatter.empty()) {
@@ -795,7 +819,14 @@ struct Prover {
         // enough), upload all items in one copy, then launch; the host tracks each job's ping-pong buffer
         static const bool ps_fuse2 = [] { const char* e = getenv("HG_NO_PS_FUSE2"); return !(e && e[0] == '1'); }();
         static const int ps_fuse_min_h = [] { const char* e = getenv("HG_PS_FUSE_MIN_H"); return e && *e ? atoi(e) : 9; }();   // (11 until the node reductions moved to the third stream: 1.92-1.94 against 1.96 ms)
-        struct PsLaunch { bool two, eq; int cnt, grid; size_t off; double bytes; };
+        // ... and in bytes moved to or from HBM by design: a pass reads its tables once and writes the folds of its LAST round
+        auto design_bytes = [&](const dev::PsJob& J, int rd, int nrounds) {
+            const size_t half = ((size_t)1 << J.nvars) >> (rd + 1), out = half >> (nrounds - 1);
+            const double ea = rd == 0 ? 8 : 16;
+            if (J.eq_n) return (double)J.npairs * (2.0 * half * ea + out * 16.0) + (J.eq_single ? 0.0 : 2.0 * half * 16.0 + out * 16.0);
+            return (double)J.npairs * (2.0 * half * (ea + 16) + out * 32.0);
+        };
+        struct PsLaunch { bool two, eq; int cnt, grid; size_t off; double bytes, design; };
         std::vector<PsLaunch> launches;
         std::vector<dev::PsItem> all_items;
         std::vector<int> next_rd(nj, 0), cur_buf(nj, -1);
@@ -823,9 +854,12 @@ struct Prover {
                 for (size_t o = 0; o < items.size(); o += MAX_BATCH) {
                     const int cnt = (int)std::min<size_t>(MAX_BATCH, items.size() - o);
                     const int grid = dev::ps_plan_blocks(items.data() + o, cnt, jobs.data(), fused);
-                    double bytes = 0;
-                    for (int q = 0; q < cnt; q++) for (int k = 0; k <= (fused ? 1 : 0); k++) bytes += round_bytes(jobs[items[o + q].job], items[o + q].rd + k);
-                    launches.push_back({fused, kind == 0, cnt, grid, all_items.size(), bytes});
+                    double bytes = 0, design = 0;
+                    for (int q = 0; q < cnt; q++) {
+                        for (int k = 0; k <= (fused ? 1 : 0); k++) bytes += round_bytes(jobs[items[o + q].job], items[o + q].rd + k);
+                        design += design_bytes(jobs[items[o + q].job], items[o + q].rd, fused ? 2 : 1);
+                    }
+                    launches.push_back({fused, kind == 0, cnt, grid, all_items.size(), bytes, design});
                     all_items.insert(all_items.end(), items.begin() + o, items.begin() + o + cnt);
                 }
             }
@@ -854,14 +888,20 @@ struct Prover {
             dev::PsItem* d_items = ctx->alloc_n<dev::PsItem>(all_items.size());
             upload(d_items, all_items.data(), all_items.size() * sizeof(dev::PsItem), "upload items");
             for (auto& L : launches) {
-                ctx->prof_begin(L.two ? cls_ps2 : cls_ps, L.bytes);
+                ctx->prof_begin(L.two ? cls_ps2 : cls_ps, L.bytes, -1.0, L.design);
                 dev::ps_round(st, L.two, d_jobs, d_items + L.off, L.cnt, L.grid, ctx->d_chal, partials, d_res(), L.eq);
                 ctx->prof_end();
             }
         }
-        double tb = 0;
-        for (auto& J : jobs) for (int rd = J.tail_rd; rd < J.nvars; rd++) tb += round_bytes(J, rd);
-        ctx->prof_begin(cls_ps_tail, tb);
+        double tb = 0, td = 0;
+        for (auto& J : jobs) {
+            for (int rd = J.tail_rd; rd < J.nvars; rd++) tb += round_bytes(J, rd);
+            if (J.tail_rd < J.nvars) {   // the tail reads its first round's tables (an eq-factored job: the a tables and a suffix table), the rest runs in LDS
+                const size_t half = ((size_t)1 << J.nvars) >> (J.tail_rd + 1);
+                td += (double)J.npairs * 2.0 * half * (J.tail_rd == 0 ? 8 : 16) + (J.eq_n ? 2.0 * half * 16 : (double)J.npairs * 2.0 * half * 16);
+            }
+        }
+        ctx->prof_begin(cls_ps_tail, tb, -1.0, td);
         dev::ps_tail(st, d_jobs, nj, ctx->d_chal, d_res());
         ctx->prof_end();
     }
@@ -1182,7 +1222,11 @@ struct Prover {
             const int seq = n >= nv - emit ? nv - n : 0;                    // first round launched alone, deepest layer first
             u64* nxt = seq ? lev_w[k + 1] : nullptr;                          // ... and writes tree level k + 1
             const dev::GpHashSrc* hs = (hash_src && k == 0) ? hash_src : nullptr;
-            if (hs) { pending_fused_bytes = hash_fused_bytes; pending_fused_model_extra = hash_model_extra; }
+            if (hs) { pending_fused_bytes = hash_fused_bytes; pending_fused_model_extra = hash_model_extra; pending_hash_reads = hash_design_reads; }
+            if (nxt) {   // rows of level k + 1 this first round writes: the next layer's slot rows in slot form, one per row held otherwise
+                const bool next_slots = hash_src && !local && k + 1 < (int)gp_slots.layer.size();
+                pending_level_design = (double)(next_slots ? gp_slots.layer[k + 1].V : nl) * (double)(len >> (k + 1)) * 8.0;
+            }
             const bool mirrored = hs && mirror_c;
             if (mirrored) {
                 // Top layer with row b + nb/2 = row b + c for every b < nb/2 (the Lasso write hashes, c = gamma^2): only the read rows
@@ -1669,6 +1713,9 @@ struct Prover {
             for (int c = 0; c < 4; c++) if (chunk_used[c]) hash_build_bytes += (double)N * 8 * 2;
             for (auto& m : hm) hash_build_bytes += (double)N * 8 * ((m.rd_row >= 0) + (m.wr_row >= 0) + (lean_e ? 0 : 1));
             hash_model_extra = lean_e ? (double)N * 8 * (double)hm.size() : 0.0;   // the E reads of the reference's hash build: not streamed here
+            // what the kernel really reads: dim + read_ts of every chunk in use, the E tables unless they are recomputed, the row -> lookup map
+            hash_design_reads = (lean_e ? 0.0 : (double)N * 8 * (double)hm.size()) + (double)N;
+            for (int c = 0; c < 4; c++) if (chunk_used[c]) hash_design_reads += (double)N * 8 * 2;
         }
         u64* H1 = (any_gp1 && !emit) ? ctx->alloc_n<u64>((size_t)nrows * N) : nullptr;
         u64* L1 = (any_gp1 && !emit && gp_deepest(nu, gp1_owner) >= 1) ? ctx->alloc_n<u64>((size_t)nrows * (N / 2)) : nullptr;

@@ -108,12 +108,13 @@ struct hg_ctx {
     struct ProfEvent { int cls; hipEvent_t a, b; };
     std::vector<ProfEvent> prof_events;
     std::vector<hipEvent_t> event_pool;
-    struct ProfStat { std::string name; uint64_t launches = 0; double ms = 0, bytes = 0, model = 0; bool dominant = false; };
+    struct ProfStat { std::string name; uint64_t launches = 0; double ms = 0, bytes = 0, model = 0, design = 0; bool dominant = false; };
     std::vector<ProfStat> prof_stats;
     int prof_class(const char* name, bool dominant);
     // bytes: what the launch streams by this implementation's algorithm; model_bytes (< 0: the same): the same work in the traffic
     // model of the reference's algorithm - they differ where an algebraic shortcut avoids tables
-    void prof_begin(int cls, double bytes, double model_bytes = -1.0);
+    // design_bytes (< 0: the same as bytes): what the launch moves to or from HBM by design (hg_kernel_stat::hbm_bytes)
+    void prof_begin(int cls, double bytes, double model_bytes = -1.0, double design_bytes = -1.0);
     void prof_end();
     void prof_collect();
     int cur_cls = -1;

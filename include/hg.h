@@ -56,6 +56,9 @@ typedef struct hg_kernel_stat {
     double algo_bytes; /* algorithmic bytes over all launches: tables read once + folded tables written once */
     double model_bytes; /* the same launches in the traffic model of the REFERENCE's algorithm: larger than algo_bytes
                            where an algebraic shortcut avoids tables (mirrored grand product, two-table collation sum-check) */
+    double hbm_bytes;   /* what the launches move to or from HBM BY DESIGN: every table a launch reads and every table it writes, once -
+                           nothing for tables that are recomputed and never stored (the hash rows of the first grand-product round), for
+                           the intermediate folds of a two-round launch, or for rounds that run inside LDS */
 } hg_kernel_stat;
 
 const char* hg_last_error(void);

@@ -11,7 +11,9 @@ cd $GRAFT_REPO_ROOT
 python scripts/summarize_trace.py $(ls $O/bnprof_$tag/*kernel_trace.csv | head -1) 40 > $O/${tag}_bn254_prove_kernel_trace_summary.txt
 python scripts/pmc_sq.py $(ls $O/bnpmc_$tag/*counter_collection.csv | head -1) 40 > $O/${tag}_bn254_pmc_sq.txt
 python - <<PY
-import csv, json, collections, glob
+import csv, json, collections, glob, sys
+sys.path.insert(0, "$GRAFT_REPO_ROOT/scripts")
+from code_hash import code_hash
 f = glob.glob("$O/bnpmc_$tag/*counter_collection.csv")[0]
 tot = collections.Counter(); per = collections.defaultdict(float)
 for r in csv.DictReader(open(f)):
@@ -20,7 +22,7 @@ for r in csv.DictReader(open(f)):
 proves = 3  # scripts/bn254_prove_bench.py runs three proves
 WITNESS_GEN = ("k_bn_ntt_stage", "k_bn_ntt4_", "k_bn_gate_eval", "k_bn_lift_signed", "k_bn_lift_jobs", "k_bn_bitrev", "k_bn_scale", "k_bn_powers")  # bn_witness_gen: outside the timed prove
 wit = sum(v for k, v in per.items() if any(w in k for w in WITNESS_GEN))
-out = {"command": "rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES -- python3 scripts/bn254_prove_bench.py (3 proves of n=32768 k=16)",
+out = {"code_hash": code_hash(), "command": "rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES -- python3 scripts/bn254_prove_bench.py (3 proves of n=32768 k=16)",
        "valu_wave_insts_per_prove": sum(per.values()) / proves,
        "witness_gen_valu_wave_insts_per_prove": wit / proves,
        "prove_valu_wave_insts_per_prove": (sum(per.values()) - wit) / proves,

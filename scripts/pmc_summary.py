@@ -3,7 +3,9 @@
 kernel: HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 — FETCH_SIZE counts 64 B per 128-B request on gfx950
 (wide coalesced streams), hence the factor 2; WRITE_SIZE is exact for 16-B-per-lane stores.
 Usage: pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> [out.json]"""
-import csv, json, sys, collections
+import csv, json, os, sys, collections
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from code_hash import code_hash
 
 def load(path, name):
     agg = collections.defaultdict(lambda: [0, 0.0])
@@ -26,4 +28,5 @@ for k in sorted(fetch, key=lambda k: -(2 * fetch[k][1] + write.get(k, [0, 0])[1]
     out[k] = {"launches": n, "fetch_kb_raw": f, "write_kb": w, "hbm_bytes_per_launch": per}
     print(f"{n:8d} {f:16.1f} {w:14.1f} {per/1e6:14.2f}  {k[:100]}")
 if len(sys.argv) > 3:
+    out["_meta"] = {"code_hash": code_hash(), "workload": "scripts/prove_once.py 32768 16 2 (3 resident proves incl. warm-up; per-launch averages)"}
     json.dump(out, open(sys.argv[3], "w"), indent=1)
