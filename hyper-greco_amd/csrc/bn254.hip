@@ -460,7 +460,7 @@ static RoundGrid round_grid(size_t half, int nitems) {
 static RoundGrid round_grid_gp(size_t half, int nb, size_t launch_wgs) {
     RoundGrid g;
     g.gx = (int)std::min<size_t>((half + BN_GP_J - 1) / BN_GP_J, (size_t)1024);
-    static const size_t target = [] { const char* e = getenv("HG_BN_GP_WGS"); return e && *e ? (size_t)atol(e) : (size_t)2048; }();
+    constexpr size_t target = 2048;   // (256 .. 4096 swept in round 4: 13.4 / 13.4 / 13.2 / 13.1 / 13.5 ms)
     const size_t want = launch_wgs ? (target + launch_wgs - 1) / launch_wgs : (size_t)nb;
     g.gy = (int)std::max<size_t>(1, std::min<size_t>((size_t)nb, want));
     return g;
@@ -677,7 +677,7 @@ static void hipc(hipError_t e, const char* what) {
 }
 
 // Scalar results (round sums, folded values, openings) are written by the kernels straight into the context's result buffer,
-// which is host-mapped pinned memory unless HG_RES_DEVICE is set: no copy-back calls, the host reads them after a synchronisation.
+// which is host-mapped pinned memory: no copy-back calls, the host reads them after a synchronisation.
 struct ResRef { Fr* dev; const Fr* host; };
 static ResRef res_slots(hg_ctx* ctx, size_t n) {
     const size_t bytes = std::max<size_t>(n, 1) * sizeof(Fr);
@@ -2079,11 +2079,13 @@ static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4,
         HK.one2 = fr_r2(); HK.gamma2x = fr_to_mont(gamma); HK.gammasq2x = fr_to_mont(gamma2); HK.gammasq = gamma2; HK.tau = tau;
         hashk_consts(HK, gamma, gamma2, tau);
         const int G = (int)lp.gkr_order.size();
-        static const bool use_mirror = [] { const char* e = getenv("HG_NO_MIRROR"); return !(e && e[0] == '1'); }();
+        constexpr bool use_mirror = true;
         const bool mirror = use_mirror && nu >= 2;   // write hash = read hash + gamma^2: only the read rows exist
         // Slot form of the read rows (GpSlots above): joint classes of the memories per segment pair (s, s + npairs)
         GpSlots slots;
-        static const bool no_slots = [] { const char* e = getenv("HG_BN_NO_SLOTS"); return e && e[0] == '1'; }();
+        // HG_BN_SLOT_DEPTH = number of slot-form layers (default 4; 0 = every memory's own rows)
+        static const int depth = [] { const char* e = getenv("HG_BN_SLOT_DEPTH"); return e && *e ? atoi(e) : 4; }();
+        const bool no_slots = depth <= 0;
         if (mirror && !no_slots && G <= 32 && L.seg_shift >= 1 && nu - 1 > L.seg_shift && ((N / 2) >> L.seg_shift) >= 1 && ((N / 2) >> L.seg_shift) <= 64) {
             const int NP = (int)((N / 2) >> L.seg_shift);
             auto cls = [&](int i, int s) -> int {   // class of GKR position i in row segment s: itself when its memory is looked up there, else its chunk position
@@ -2116,7 +2118,6 @@ static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4,
                 slots.d_slot_of = bn_stage(ctx, slots.slot_of.data(), slots.slot_of.size());
                 slots.d_rep = bn_stage(ctx, slots.rep.data(), slots.rep.size());
                 // the layers below: layer q + 1 multiplies 2^(q+2) segments NP >> (q+1) apart; read and write rows apart, row 0 alone
-                static const int depth = [] { const char* e = getenv("HG_BN_SLOT_DEPTH"); return e && *e ? atoi(e) : 4; }();
                 for (int q = 0; q + 2 <= depth && (NP >> (q + 1)) >= 2 && 2 * G <= 254; q++) {
                     GpSlots::Deep dp;
                     const int NG = NP >> (q + 1), cnt = 4 << q;
@@ -2199,10 +2200,9 @@ static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4,
                 open_at.push_back(o.host);
             };
             // the E tables at x go through k_bn_open_e when the launch shape fits (a workgroup's rows inside one lookup segment)
-            static const bool e_groups = [] { const char* e = getenv("HG_OPEN_GROUPS"); return e && e[0] == '1'; }();
             const int egx = (int)std::min<size_t>((N + BN_TPB - 1) / BN_TPB, 1024);
             const size_t echunk = N / (size_t)egx;
-            bool e_fast = !e_groups && N % (size_t)egx == 0 && (echunk & (echunk - 1)) == 0 && echunk <= ((size_t)1 << L.seg_shift) && L.alpha <= 32;
+            bool e_fast = N % (size_t)egx == 0 && (echunk & (echunk - 1)) == 0 && echunk <= ((size_t)1 << L.seg_shift) && L.alpha <= 32;
             for (int l = 0; l < L.num_lookups && e_fast; l++) if (L.lookup_nmems[l] > 4) e_fast = false;
             BnOpenE OE;
             memset(&OE, 0, sizeof(OE));

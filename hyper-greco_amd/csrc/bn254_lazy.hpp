@@ -98,9 +98,12 @@ __device__ __forceinline__ Fr lz_canon(const Fr& a) {   // a in [0, 2p) -> [0, p
 constexpr u32 LZ_NP0 = 0x0fffffffu, LZ_NP1 = 0xbc1e0a6cu, LZ_NP2 = 0x86468f6eu, LZ_NP3 = 0xd7cc17b7u, LZ_NP4 = 0x7e7ea7a2u, LZ_NP5 = 0x47afba49u,
               LZ_NP6 = 0x1ece5fd6u, LZ_NP7 = 0xcf9bb18du;   // 2^256 - p
 
-// V = e0 + e1 2^32 + sum_k C[k] 2^(32 k) + sum_k T[k] 2^(32 k + 64) (k < 8), V < 2^40 p  ->  V mod p as a loose residue in [0, 2p).
+// V = e0 + e1 2^32 + sum_k C[k] 2^(32 k) + sum_k T[k] 2^(32 k + 64) (k < 8), V < 2^36 p  ->  V mod p as a loose residue in [0, 2p).
+// (The callers stay below ~2^36 p: lz_fold 2p + 8 2^32 p, lz_reduce ~2^10 p, lz_lin3 ~2^34 p. At q ~ 2^40 the five conversions, the
+// product with 2^224 / p and that constant's own rounding add up to ~0.85 2^-10 - too close to the 2^-10 margin to promise; at
+// 2^36 they are below 2^-13.)
 // q = floor(V / p) or one less from a double-precision estimate of V / 2^224 (the neglected low parts are below 2^-27 of a unit of q,
-// the conversions below 2^-14; 2^-10 is subtracted before rounding down), then V + q (2^256 - p) is formed modulo 2^256 with 15
+// the conversions below 2^-14 at that bound; 2^-10 is subtracted before rounding down), then V + q (2^256 - p) is formed modulo 2^256 with 15
 // multiply-adds into the same columns and normalised into eight 32-bit limbs: what is left is exactly V - q p, which is below 2p.
 __device__ __forceinline__ Fr lz_finish(u64* C, u32* T, u64 e0, u32 e1) {
     const double top = (double)C[7] + (double)(u32)(C[6] >> 32) + (double)T[5] + 4294967296.0 * (double)T[6] + 18446744073709551616.0 * (double)T[7];

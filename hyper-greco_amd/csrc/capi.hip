@@ -88,21 +88,12 @@ hg_ctx* hg_create(int device_id) {
     hip_check(hipSetDevice(device_id), "hipSetDevice");
     hg_ctx* c = new hg_ctx();
     c->device = device_id;
-    // Two plain streams. Stream priorities (main high, second low; HG_PRIO=1 turns them on) measured no better on the streams
-    // themselves (3.00-3.02 ms either way) and much worse under the cached launch graph: the second and every later graph
-    // instantiated on a context replays its side branch on a stream of NORMAL priority, which competes with the high-priority main
-    // branch instead of hiding under it - 5.0 ms per prove instead of 3.05 (scripts/ub/repro_graph_slow.py; GPU_MAX_HW_QUEUES=2
-    // hides it, HG_PRIO unset removes it).
-    int prio_lo = 0, prio_hi = 0;
-    const char* want_prio = getenv("HG_PRIO");
-    if (!(want_prio && want_prio[0] == '1') || hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) prio_lo = prio_hi = 0;
-    if (prio_lo != prio_hi) {
-        hip_check(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi), "hipStreamCreate");
-        hip_check(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_lo), "hipStreamCreate");
-    } else {
-        hip_check(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate");
-        hip_check(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking), "hipStreamCreate");
-    }
+    // Plain streams. Stream priorities (main high, second low) measured no better on the streams themselves (3.00-3.02 ms either
+    // way) and much worse under the cached launch graph: the second and every later graph instantiated on a context replays its side
+    // branch on a stream of NORMAL priority, which competes with the high-priority main branch instead of hiding under it - 5.0 ms
+    // per prove instead of 3.05 (scripts/ub/repro_graph_slow.py). Removed in round 5.
+    hip_check(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate");
+    hip_check(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking), "hipStreamCreate");
     hip_check(hipStreamCreateWithFlags(&c->stream_col, hipStreamNonBlocking), "hipStreamCreate");
     hip_check(hipEventCreateWithFlags(&c->ev_col, hipEventDisableTiming), "hipEventCreate");
     hip_check(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming), "hipEventCreate");
@@ -112,9 +103,8 @@ hg_ctx* hg_create(int device_id) {
     c->res_cap = (size_t)1 << 17;
     hip_check(hipHostMalloc((void**)&c->h_res, c->res_cap * sizeof(E2), hipHostMallocDefault), "hipHostMalloc(results)");
     // The kernels write the (≈160 KB of) result slots straight into the pinned host buffer: no device-to-host copy at the end of
-    // a prove (measured -0.05 ms at n=32768 k=16). HG_RES_DEVICE=1 restores a device buffer plus one hipMemcpyAsync.
-    if (getenv("HG_RES_DEVICE")) hip_check(hipMalloc((void**)&c->d_res, c->res_cap * sizeof(E2)), "hipMalloc(results)");
-    else c->d_res = c->h_res;
+    // a prove (measured -0.05 ms at n=32768 k=16).
+    c->d_res = c->h_res;
     hip_check(hipMalloc((void**)&c->d_partials, dev::PARTIALS_BYTES), "hipMalloc(partials)");
     hip_check(hipMalloc((void**)&c->d_partials2, dev::PARTIALS_BYTES), "hipMalloc(partials2)");
     hip_check(hipMemset(c->d_partials, 0, dev::PARTIALS_BYTES), "hipMemset(partials)");

@@ -178,6 +178,15 @@ void params_derive(uint32_t n, uint32_t k, const u64* qis, u64 t, hg_params* out
     }
 }
 
+bool hg_debug(const char* token) {
+    const char* e = getenv("HG_DEBUG");
+    if (!e || !*e) return false;
+    const size_t n = strlen(token);
+    for (const char* p = e; (p = strstr(p, token)) != nullptr; p += n)
+        if ((p == e || p[-1] == ',') && (p[n] == 0 || p[n] == ',')) return true;
+    return false;
+}
+
 // ------------------------------------------------------------------------------------------------
 // OpenMP inside a container: omp_get_max_threads() reports the machine's cores (256 on the MI355X boxes) while the cgroup may grant
 // far fewer CPUs (16 there: /sys/fs/cgroup/cpu.max = "1600000 100000"), and libomp's idle workers spin for 200 ms after every

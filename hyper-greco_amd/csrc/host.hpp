@@ -31,6 +31,10 @@ void keccak256(const uint8_t* data, size_t len, uint8_t out[32]);
 int cgroup_cpu_quota();  // CPUs the cgroup grants (0 = unlimited / unknown)
 int hg_omp_threads();    // threads one of the library's OpenMP regions may use (runtime default capped by the quota)
 const u64* challenge_chain(size_t n_base);  // pointer to >= n_base cached base-field challenges
+// Diagnostics on stderr: HG_DEBUG = comma-separated tokens, read at every call (tests set and unset it inside one process).
+//   shard: per-rank times of a sharded prove, the shard plan, failed graph captures    slots: the slot-form layers a prove adopted
+//   eq: how many queued node reductions run eq-factored    launch: host time of every launch-graph replay    fail_capture: makes the next launch-graph capture fail (fallback test)
+bool hg_debug(const char* token);
 u64 felt_from_hash(const uint8_t h[32]);    // fe_mod_from_le_bytes (transcript.rs:202): 256-bit little-endian integer mod p
 
 // The transcript with its hash state kept explicitly: the bytes absorbed since the last squeeze (H::update appends;

@@ -51,13 +51,10 @@ __device__ __forceinline__ E2 block_sum(E2 v, E2* sm) {
     return v;
 }
 
-// launch-shape knobs (tuning hooks; the defaults are the measured best on MI355X)
-static size_t env_size(const char* name, size_t dflt) {
-    const char* v = getenv(name);
-    return v && *v ? (size_t)strtoull(v, nullptr, 0) : dflt;
-}
-static size_t st_min_threads() { static size_t v = env_size("HG_ST_MIN_THREADS", 65536); return v; }
-static int st_max_blocks() { static int v = (int)std::min<size_t>(env_size("HG_ST_MAX_BLOCKS", 512), SC_MAX_BLOCKS); return v; }
+// launch shapes (the measured best on MI355X)
+// (measured at n=32768 k=16: 32768 / 131072 / 262144 threads 2.05 / 2.04 / 2.14 against 1.97 ms; 1024 / 256 workgroups 1.99 / 2.11 against 1.97)
+static size_t st_min_threads() { return 65536; }
+static int st_max_blocks() { return 512; }
 
 static inline int grid_for(size_t work_items) {
     size_t b = (work_items + TPB - 1) / TPB;
@@ -1664,8 +1661,7 @@ int ps_plan_blocks(PsItem* items, int nitems, const PsJob* host_jobs, bool round
         for (int q = 0; q < nitems; q++) all_tiles += ((size_t)1 << (host_jobs[items[q].job].nvars - 1 - items[q].rd)) >> 9;
         // a workgroup pays ~1000 instructions per thread once (four reductions, four products, the block sums) against 100-150 per
         // table and tile: several tiles each when the launch has them, the tables of a many-table job dealt to groups of workgroups
-        static const size_t target_blocks = env_size("HG_PS_EQ_TARGET_BLOCKS", 1024);
-        static const size_t serial_big = env_size("HG_PS_EQ_SERIAL", 16), serial_small = env_size("HG_PS_EQ_SERIAL_SMALL", 6);
+        constexpr size_t target_blocks = 1024, serial_big = 16, serial_small = 6;   // (2048 / 512 workgroups: 91 / 65 us for the first launch against 68)
         const size_t per = std::min<size_t>(std::max<size_t>(all_tiles / target_blocks, 1), 16);
         const size_t budget = all_tiles >= 1024 ? serial_big : serial_small;   // (table, tile) steps per thread
         int blk = 0;
@@ -1690,7 +1686,7 @@ int ps_plan_blocks(PsItem* items, int nitems, const PsJob* host_jobs, bool round
     // launch has enough of them (the items have only 1-3 table pairs each, unlike the grand-product jobs)
     size_t all_tiles = 0;
     for (int q = 0; q < nitems; q++) all_tiles += ((size_t)1 << (host_jobs[items[q].job].nvars - 1 - items[q].rd)) >> jb0;
-    static const size_t target_blocks = env_size("HG_PS_TARGET_BLOCKS", 1024);   // (4096 until round 5: 102 -> 55 us for the first launch of a prove in isolation, GPU time 1.875 -> 1.820 ms)
+    constexpr size_t target_blocks = 1024;   // (4096 until round 5: 102 -> 55 us for the first launch of a prove in isolation, GPU time 1.875 -> 1.820 ms; 2048 / 512: 1.842 / 1.862)
     size_t per = all_tiles / target_blocks;
     if (per < 1) per = 1;
     if (per > 32) per = 32;
@@ -2567,8 +2563,7 @@ __global__ __launch_bounds__(TPB) void k_open_x(const E2* __restrict__ eq, DotTa
         }
 }
 bool open_x(hipStream_t st, const E2* eq, const DotTabs& tabs, int ntab, size_t n, E2* partials, E2* out, const DotVirt& virt) {
-    static const bool off = [] { const char* e = getenv("HG_OPEN_GROUPS"); return e && e[0] == '1'; }();   // HG_OPEN_GROUPS=1: dot_eq_many's groups of eight
-    if (off || ntab <= 0 || ntab > DOT_MAX) return false;
+    if (ntab <= 0 || ntab > DOT_MAX) return false;   // (false: the caller takes dot_eq_many's groups of eight)
     const int gx = grid_for((n + 1) / 2);
     if (n % (size_t)gx) return false;
     const size_t chunk = n / (size_t)gx;

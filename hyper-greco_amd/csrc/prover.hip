@@ -215,7 +215,7 @@ ShardPlan shard_plan(const hg_pk* pk, int rank, int world) {
         sp.node_owner[it.idx] = r;
     }
     sp.own_out_claim = (int)(std::min_element(load.begin(), load.end()) - load.begin());
-    if (getenv("HG_SHARD_DEBUG") && rank == 0) {
+    if (hg_debug("shard") && rank == 0) {
         fprintf(stderr, "[hg] shard plan world %d: %d memories; out-claim -> %d; loads", world, G, sp.own_out_claim);
         for (int r = 0; r < world; r++) fprintf(stderr, " %.1fM", load[r] / 1e6);
         fprintf(stderr, "\n");
@@ -268,7 +268,7 @@ struct Prover {
     bool offsets_known = false, cur_early = false, early_done = false;
     size_t early_slot = (size_t)-1;
     void push_op(std::function<void()> f) { ops.push_back(std::move(f)); op_early.push_back(cur_early ? 1 : 0); }
-    static bool early_replay_on() { static const bool v = [] { const char* e = getenv("HG_NO_EARLY_REPLAY"); return !(e && e[0] == '1'); }(); return v; }
+    static bool early_replay_on() { return true; }
     bool early_ready() const {
         if (early_done || !offsets_known || early_slot == (size_t)-1) return false;
         return __atomic_load_n(&ctx->h_res[early_slot].c0, __ATOMIC_ACQUIRE) == 1;
@@ -335,7 +335,7 @@ struct Prover {
             cs.p[nr] = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(pbuf) + dev::PARTIALS_E2 * sizeof(E2));
             cs.n[nr++] = dev::PARTIALS_TICKETS;
         }
-        if (world <= 1) {   // (one rank: the third region is free for the collation stream's tickets, HG_LASSO_SCHED=3)
+        if (world <= 1) {   // (one rank: the third region is free for the third stream's tickets)
             cs.p[2] = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ctx->d_partials3) + dev::PARTIALS_E2 * sizeof(E2));
             cs.n[2] = dev::PARTIALS_TICKETS;
         }
@@ -446,8 +446,7 @@ struct Prover {
         const int nj = (int)st_jobs.size();
         // launch plan: (kind, base? | fused pair?, h_log2 | tail) -> items (job, where the round reads and writes).
         // Folded tables ping-pong between the job's two buffers; the host tracks where each job's live tables are.
-        static const bool fuse2 = [] { const char* e = getenv("HG_NO_FUSE2"); return !(e && e[0] == '1'); }();
-        static const int fuse_min_h = [] { const char* e = getenv("HG_FUSE_MIN_H"); return e && *e ? atoi(e) : 15; }();   // (13 until the slot form; 1.96-1.99 against 1.99-2.01 ms at 15, three interleaved A/Bs)
+        constexpr int fuse_min_h = 15;   // fused pairs of rounds from half = 2^15 up (13 until the slot form: 1.96-1.99 against 1.99-2.01 ms; round 5: 13 / 11 / 9 = 1.864 / 1.905 / 1.980 against 1.831)
         struct Launch { int kind; bool base; int h_log2; bool tail; int nrounds; std::vector<dev::StItem> items; bool hash = false; bool after_seq = false; };
         std::vector<Launch> plan;
         struct Regroup { int job; const E2* in; E2* out; int len_log2; };
@@ -459,12 +458,10 @@ struct Prover {
         auto next_out = [&](int q) { return cur_in[q] == (const void*)st_jobs[q].buf[0] ? st_jobs[q].buf[1] : st_jobs[q].buf[0]; };
         // The rounds with half <= 2^h_small[q] of job q run in ONE single-workgroup launch with the folded tables in LDS (st_tail);
         // how many fit depends on the job's table count (12 rounds for the two collation tables, 6 for a full grand-product layer).
-        // HG_TAIL_H caps it (4 = the five rounds of the round-1 chunk kernel).
-        static const int tail_cap = [] { const char* e = getenv("HG_TAIL_H"); return e && *e ? atoi(e) : 31; }();
         std::vector<int> h_small(nj);
         for (int q = 0; q < nj; q++) {
             const SlotPlan& sp = st_slot[q];
-            h_small[q] = sp.tail_ntab ? slot_tail_h(sp.tail_ntab, st_jobs[q].nvars) : std::min(dev::st_tail_h(st_jobs[q].ntab, st_jobs[q].nvars), tail_cap);
+            h_small[q] = sp.tail_ntab ? slot_tail_h(sp.tail_ntab, st_jobs[q].nvars) : dev::st_tail_h(st_jobs[q].ntab, st_jobs[q].nvars);
             if (st_seq[q] > 0) h_small[q] = std::min(h_small[q], st_jobs[q].nvars - 2);   // a sequenced first round has its own kernel
             if (sp.tail_ntab && st_jobs[q].nvars - 1 - h_small[q] > sp.max_rd) throw Error("slot-form job: the tail starts below the segment pairs");
         }
@@ -522,7 +519,7 @@ struct Prover {
                     memset(&it, 0, sizeof(it));
                     it.job = q; it.h_log2 = h; it.in = cur_in[q]; it.in_stride = cur_stride[q];
                     it.out = first ? J.buf[0] : next_out(q);
-                    const bool pair = fuse2 && !first && h - 1 > h_small[q] && h >= std::max(dev::ST_STEP2_MIN_H, fuse_min_h);
+                    const bool pair = !first && h - 1 > h_small[q] && h >= std::max(dev::ST_STEP2_MIN_H, fuse_min_h);
                     (pair ? l2 : le).items.push_back(it);
                     next_h[q] = h - (pair ? 2 : 1);
                     cur_in[q] = it.out; cur_stride[q] = (size_t)1 << (pair ? h - 1 : h);
@@ -704,15 +701,9 @@ struct Prover {
         return h;
     }
     // ---- eq-factored PRODSUM jobs (kernels.hpp PsJob::eq_n) ---------------------------------------------------------------
-    // HG_NO_PS_EQ=1: every Libra table materialised (the form every node had until round 5; needs the fused rounds)
-    static bool ps_eq_on() {
-        static const bool v = [] { const char* e = getenv("HG_NO_PS_EQ"); const char* f = getenv("HG_NO_PS_FUSE2"); return !(e && e[0] == '1') && !(f && f[0] == '1'); }();
-        return v;
-    }
-    static size_t ps_tail_items() {   // (HG_PS_TAIL_ITEMS can only lower it: the tail keeps a job's folds in LDS)
-        static const size_t v = [] { const char* e = getenv("HG_PS_TAIL_ITEMS"); return std::min<size_t>(e && *e ? (size_t)atol(e) : TAIL_ITEMS, dev::ps_tail_items_max()); }();
-        return v;
-    }
+    // HG_NO_PS_EQ=1: every Libra table materialised (the general form, which small or non-affine nodes take anyway)
+    static bool ps_eq_on() { static const bool v = [] { const char* e = getenv("HG_NO_PS_EQ"); return !(e && e[0] == '1'); }(); return v; }
+    static size_t ps_tail_items() { return std::min<size_t>(TAIL_ITEMS, dev::ps_tail_items_max()); }   // (the tail keeps a job's folds in LDS)
     // First tail round of an eq-factored job, -1: the job is too small for the form. Every round ahead of the tail runs in a fused
     // pair (the tail may start one round later than TAIL_ITEMS says), the last pair at half >= 2^9, and the table handed to the
     // tail must be one of the point's stored suffix tables.
@@ -794,6 +785,11 @@ struct Prover {
         for (auto& kv : ps_queue) { jobs.insert(jobs.end(), kv.second.begin(), kv.second.end()); kv.second.clear(); }
         if (jobs.empty()) return;
         const int nj = (int)jobs.size();
+        if (hg_debug("eq")) {
+            int ne = 0; size_t ee = 0, et = 0;
+            for (auto& J : jobs) { const size_t e = (size_t)J.npairs << J.nvars; et += e; if (J.eq_n) { ne++; ee += e; } }
+            fprintf(stderr, "[hg eq] %d of %d queued node reductions eq-factored, %zu of %zu table entries\n", ne, nj, ee, et);
+        }
         if (!eq_scal_host.empty()) {
             E2* d_scal = ctx->alloc_n<E2>(eq_scal_host.size());
             upload(d_scal, eq_scal_host.data(), eq_scal_host.size() * sizeof(E2), "upload eq-form scalars");
@@ -817,8 +813,7 @@ struct Prover {
         };
         // plan every step first (step s = every job's next round, or its next two rounds when its table is long
         // enough), upload all items in one copy, then launch; the host tracks each job's ping-pong buffer
-        static const bool ps_fuse2 = [] { const char* e = getenv("HG_NO_PS_FUSE2"); return !(e && e[0] == '1'); }();
-        static const int ps_fuse_min_h = [] { const char* e = getenv("HG_PS_FUSE_MIN_H"); return e && *e ? atoi(e) : 9; }();   // (11 until the node reductions moved to the third stream: 1.92-1.94 against 1.96 ms)
+        constexpr int ps_fuse_min_h = 9;   // fused pairs from half = 2^9 (11 until the node reductions moved to the third stream: 1.92-1.94 against 1.96 ms)
         // ... and in bytes moved to or from HBM by design: a pass reads its tables once and writes the folds of its LAST round
         auto design_bytes = [&](const dev::PsJob& J, int rd, int nrounds) {
             const size_t half = ((size_t)1 << J.nvars) >> (rd + 1), out = half >> (nrounds - 1);
@@ -837,7 +832,7 @@ struct Prover {
                 const int rd = next_rd[q];
                 if (rd >= J.tail_rd) continue;
                 const int h = J.nvars - 1 - rd;
-                const bool pair = J.eq_n ? true : ps_fuse2 && rd + 1 < J.tail_rd && h >= std::max(9, ps_fuse_min_h);
+                const bool pair = J.eq_n ? true : rd + 1 < J.tail_rd && h >= std::max(9, ps_fuse_min_h);
                 dev::PsItem it;
                 memset(&it, 0, sizeof(it));
                 it.job = q; it.rd = rd; it.in_buf = cur_buf[q]; it.out_buf = cur_buf[q] == 1 ? 0 : 1;
@@ -997,8 +992,8 @@ struct Prover {
         ctx->prof_end();
     }
     std::vector<std::function<void()>> eq_post;  // sums of per-claim eq tables, run right after the eq batch
-    // HG_EQ_ONE_LAUNCH=1: the round-3 kernel (every workgroup rebuilds its low / high factor tables)
-    static bool eq_two_launch() { static const bool v = [] { const char* e = getenv("HG_EQ_ONE_LAUNCH"); return !(e && e[0] == '1'); }(); return v; }
+    // (tables of more than 2^24 entries take the one-launch kernel, whose workgroups rebuild their own low / high factor tables)
+    static bool eq_two_launch() { return true; }
     void queue_eq(E2* out, int n, const dev::ClaimSet& cs) {
         dev::EqJob J;
         memset(&J, 0, sizeof(J));
@@ -1159,8 +1154,7 @@ struct Prover {
                     break;
                 }
                 // three levels per launch while the third one is still above the tail's size
-                static const bool level3 = [] { const char* e = getenv("HG_NO_LEVEL3"); return !(e && e[0] == '1'); }();
-                if (level3 && k + 2 <= deepest && (in_len >> 2) > (size_t)dev::PROD_TAIL_LEN && in_len <= ((size_t)1 << 18)) {
+                if (k + 2 <= deepest && (in_len >> 2) > (size_t)dev::PROD_TAIL_LEN && in_len <= ((size_t)1 << 18)) {
                     ctx->prof_begin(cls_tree, (double)nl * in_len * 8.0 * 1.5 * 1.75);
                     if (nl > 0) dev::prod_level3(st, lev[k - 1], in_len, lev_w[k], lev_w[k + 1], lev_w[k + 2], nl);
                     ctx->prof_end();
@@ -1378,18 +1372,15 @@ struct Prover {
             for (int m = 0; m < A; m++) if (own_mem[m]) ep_rows_own.row[m] = ep_rows.row[m];
         } else for (int m = 0; m < A; m++) col_mems.push_back(m);
         const bool col_p0_only = split && !own_mem[0];
-        // Lean form (default where the hash-free first round is used, HG_E_TABLES=1 turns it off): the E tables are NOT materialised.
+        // Lean form (wherever the hash-free first round is used): the E tables are NOT materialised.
         // E_m[j] = (row j's lookup uses m and limb < cutoff_m) ? limb : 0 is a select on a limb, so the hash round, the claimed sum and
         // the E_m(x) openings recompute it and the limb split writes E_0 (the collation sum-check's p_0 table) and C only.
         bool lean_e = false;
         {
-            static const bool e_tables = [] { const char* e = getenv("HG_E_TABLES"); return e && e[0] == '1'; }();
-            static const bool hash_fuse_env = [] { const char* e = getenv("HG_NO_HASH_FUSE"); return !(e && e[0] == '1'); }();
             bool all1 = any_gp1;
             for (int n = 0; n < nu; n++) all1 = all1 && mine(gp1_owner[n]);
             const int nrows_ = split ? (int)local_pairs.size() : 2 * G;
-            static const bool emit_on = [] { const char* e = getenv("HG_GP_EMIT"); return !(e && *e) || atoi(e) > 0; }();
-            lean_e = !e_tables && hash_fuse_env && emit_on && all1 && nu >= 12 && nrows_ > (p0_only ? 1 : 0) && A <= 32;   // (= the condition of emit > 0 below)
+            lean_e = all1 && nu >= 12 && nrows_ > (p0_only ? 1 : 0) && A <= 32;   // (= the condition of emit > 0 below)
         }
         const int ep_count_full = ep_count;   // (what the reference's traffic model writes)
         if (lean_e) {
@@ -1429,18 +1420,17 @@ struct Prover {
             stamp("limb split done");
             ctx->prof_end();
             if (fork_recorded) hip_check(hipEventRecord(ctx->ev_aux[2], st), "lasso: E tables event");
-            if (fork_recorded && getenv("HG_DUMMY")) dev::stamp(st, ctx->alloc_n<unsigned long long>(1));
         }
         // MemoryCheckingProver::new (prover.rs:35-89)
         const int nrows = split ? (int)local_pairs.size() : 2 * G;
         // Grand product #1 without hash tables: the top layer's first round recomputes the hashes from dims / read_ts / E and
-        // writes tree level 1, the next layers' first rounds write levels 2 .. emit (HG_NO_HASH_FUSE=1: materialise them).
-        static const bool hash_fuse = [] { const char* e = getenv("HG_NO_HASH_FUSE"); return !(e && e[0] == '1'); }();
-        static const int emit_max = [] { const char* e = getenv("HG_GP_EMIT"); return e && *e ? atoi(e) : 4; }();
+        // writes tree level 1, the next layers' first rounds write levels 2 .. emit (a fifth level-emitting layer: no gain). Small
+        // tables and sharded ranks that do not run every layer take the classic path: hash rows and tree levels materialised.
+        constexpr int emit_max = 4;
         bool all_gp1 = any_gp1;
         for (int n = 0; n < nu; n++) all_gp1 = all_gp1 && mine(gp1_owner[n]);
         int emit = 0;
-        if (hash_fuse && all_gp1 && nu >= 12 && nrows > (p0_only ? 1 : 0))
+        if (all_gp1 && nu >= 12 && nrows > (p0_only ? 1 : 0))
             for (int n = nu - 1; n >= 12 && emit < emit_max; n--) emit++;   // layers with 2^n >= 4096 entries per table
         // Off the critical path, on the second stream: counter sorts (hidden under the collation sum-check), grand product #2's
         // hashes and tree, the openings (hidden under grand product #1's rounds). Needs the hash-free grand product #1 (the
@@ -1452,28 +1442,22 @@ struct Prover {
         for (int i = 0; i < nu; i++) squeeze();
         E2* eq = (do_col || do_open) ? ctx->alloc_n<E2>(N) : nullptr;
         size_t claim_slot = slot(1);
-        // Stream assignment inside the node. Schedule 3 (default since round 4, one rank): as schedule 0 with the collation rounds on
-        // a third stream (see col_third below). Schedule 0: collation on the main stream ahead of the grand
-        // products, counters / grand product #2's tree / openings on the second stream. Schedule 1 (HG_LASSO_SCHED=1): the main
-        // stream carries split -> counters -> grand product #1 (the longest dependent chain starts as early as possible), the claimed
-        // sum and the collation sum-check run on the second stream - measured SLOWER (3.8-3.9 ms vs 3.55 ms: the second stream
-        // becomes the long pole and its bandwidth-bound collation rounds slow the grand-product kernels down).
-        static const int lasso_sched = [] { const char* e = getenv("HG_LASSO_SCHED"); return e && *e ? atoi(e) : 3; }();
-        const bool col_aux = fork_recorded && lasso_sched == 1;
-        auto col_where = [&](const std::function<void()>& fn) { if (col_aux) on_aux(fn); else fn(); };
+        // Stream assignment inside the node (one rank): the main stream goes from the limb split to the first hash round; counters,
+        // grand product #2's tree and the opening tables on the second stream; the collation rounds on the third (col_third below).
+        // A sharded rank keeps the collation rounds on the main stream ahead of its grand products. (Measured and removed in round 5:
+        // the collation sum-check and the claimed sum on the second stream with the counters leading the main one, 3.8-3.9 against
+        // 3.55 ms; the collation rounds behind the counters on the second stream, 2.74-2.82 against 2.64 ms; the counters on the
+        // main stream, 3.87 against 3.63 ms.)
         // The claimed sum is only a result slot: with two streams it runs on the second one after grand product #2's tree (the main
         // stream goes from the limb split straight into the collation rounds, the second stream is idle at that point anyway).
-        const bool claim_late = use_aux && !col_aux;
+        const bool claim_late = use_aux;
         auto do_claim = [&] {
             eq_now(eq, nu, r_off);
             int grid = lean_e ? dev::lasso_claim_in(st, L, eq, d_input, own_mask, partials)
                               : dev::lasso_claim(st, L, eq, ep, ep_rows_own, partials);  // sharded: this rank's memories only (partial sum)
             reduce(grid, 1, claim_slot);
         };
-        if (do_col && !claim_late) col_where([&] {
-            if (col_aux) hip_check(hipStreamWaitEvent(st, ctx->ev_aux[2], 0), "lasso: wait for the E tables");
-            do_claim();
-        });
+        if (do_col && !claim_late) do_claim();
         Cell claimed = cell();
         mark("lasso: claimed sum (lasso.rs:100-107)");
         push_op([this, claim_slot, claimed] { *claimed = h_res()[claim_slot]; proof.write_e(*claimed); });
@@ -1490,7 +1474,6 @@ struct Prover {
                                     (int)col_mems.size());
             mark("lasso: collation sum-check, " + std::to_string(nu) + " rounds x 3 coefficients (lasso.rs:271-279) [C1, C3; poly(0) quirk]");
             defer_sumcheck(sc, 2, claimed, nullptr);
-            if (col_aux) on_aux([&] { flush_stride(); });  // all collation rounds, now, on the second stream
         }
         E2 gamma_e = squeeze(), tau_e = squeeze();  // lasso.rs:99
         u64 gamma = gamma_e.c0, tau = tau_e.c0;     // prover.rs:38-39: base limb 0 only
@@ -1504,28 +1487,19 @@ struct Prover {
             for (int i : local_mems) need_chunk[lp.gkr_chunk[i]] = 1;
         }
         std::map<int, u64*> read_ts, final_cts;
-        // The counters feed grand product #1's first launch. On the second stream they hide under the collation rounds (measured
-        // 3.63 ms per prove); on the main stream, ahead of the collation rounds, they cost their ~250 us of small launches in full
-        // (3.87 ms): HG_COUNTERS_MAIN=1 selects that.
-        static const bool counters_aux_env = [] { const char* e = getenv("HG_COUNTERS_MAIN"); return !(e && e[0] == '1'); }();
-        const bool counters_aux = counters_aux_env && !col_aux;   // schedule 1: the counters lead the main stream
-        // Schedule 2 (HG_LASSO_SCHED=2): the collation rounds follow the counters on the SECOND stream. With the two-table collation
-        // (E_0 and C) they are a chain of short launches, about 0.2 ms that the main stream no longer spends ahead of grand product #1.
-        const bool col_after_counters = use_aux && counters_aux && lasso_sched == 2;
-        // Schedule 3 (default; one rank): the collation rounds - 0.2 ms of short launches whose results only the host reads - on a THIRD
-        // stream forked from the main one behind the E tables and joined to it at the end of the prove: the main stream goes from the
-        // limb split straight to the first hash round (which waits for the counters only). 2.574 -> 2.524 ms (96 replays each).
+        // The counters feed grand product #1's first launch; on the second stream they hide under the collation rounds.
+        // The collation rounds - 0.2 ms of short launches whose results only the host reads - run on a THIRD stream forked from the main
+        // one behind the E tables and joined to it at the end of the prove (one rank): the main stream goes from the limb split
+        // straight to the first hash round (which waits for the counters only). 2.574 -> 2.524 ms (96 replays each).
         // (Forked from and joined to the ORIGIN stream of the capture, like the second stream: a stream forked from the second one
         // and joined back into it sent hipStreamEndCapture into an endless recursion on a sharded rank's graph, NOTEBOOK.md.)
-        const bool col_third = use_aux && counters_aux && lasso_sched == 3 && world == 1 && fork_recorded;
+        const bool col_third = use_aux && world == 1 && fork_recorded;
         if (col_third) on_col([&] { flush_stride(); });
-        else if (use_aux && counters_aux && !col_after_counters) flush_stride();  // collation rounds first: see below
-        auto cnt_where = [&](const std::function<void()>& fn) { if (use_aux && counters_aux) on_aux(fn); else fn(); };
+        else if (use_aux) flush_stride();  // collation rounds first: see below
         bool counters_event_recorded = false;
-        if (need_counters) cnt_where([&] {
-            if (use_aux && counters_aux) hip_check(hipStreamWaitEvent(st, ctx->ev_aux[0], 0), "lasso: wait for the limb split");
-            // all requested chunks in ONE stable sort of (chunk, address) keys (HG_COUNTERS_PER_CHUNK=1: one sort per chunk)
-            static const bool per_chunk = [] { const char* e = getenv("HG_COUNTERS_PER_CHUNK"); return e && e[0] == '1'; }();
+        if (need_counters) aux([&] {
+            if (use_aux) hip_check(hipStreamWaitEvent(st, ctx->ev_aux[0], 0), "lasso: wait for the limb split");
+            // all requested chunks in ONE stable sort of (chunk, address) keys
             unsigned mask = 0;
             for (auto& chk : lp.chunks) {
                 int c = chk.first;
@@ -1534,34 +1508,20 @@ struct Prover {
                 read_ts[c] = ctx->alloc_n<u64>(N);
                 final_cts[c] = ctx->alloc_n<u64>(M);
             }
-            const size_t elems = per_chunk ? N : std::max<size_t>(dev::lasso_counters_all_elems(L, mask), 1);
-            size_t tb = per_chunk ? dev::lasso_counter_temp_bytes(N) : dev::lasso_counters_all_temp_bytes(elems);
+            const size_t elems = std::max<size_t>(dev::lasso_counters_all_elems(L, mask), 1);
+            size_t tb = dev::lasso_counters_all_temp_bytes(elems);
             void* temp = ctx->alloc(tb);
             u32* keys = ctx->alloc_n<u32>(elems); u32* keys2 = ctx->alloc_n<u32>(elems);
             u32* rows = ctx->alloc_n<u32>(elems); u32* rows2 = ctx->alloc_n<u32>(elems);
             u32* starts = ctx->alloc_n<u32>(4 * 65536 + 1);
             ctx->prof_begin(cls_aux, (double)elems * 40);
-            if (per_chunk) {
-                for (int c = 0; c < 4; c++) if ((mask >> c) & 1) dev::lasso_counters(st, L, c, dims, read_ts[c], final_cts[c], temp, tb, keys, keys2, rows, rows2, starts);
-            } else {
-                dev::CounterOut co;
-                memset(&co, 0, sizeof(co));
-                for (int c = 0; c < 4; c++) if ((mask >> c) & 1) { co.read_ts[c] = read_ts[c]; co.final_cts[c] = final_cts[c]; }
-                dev::lasso_counters_all(st, L, mask, dims, co, temp, tb, keys, keys2, rows, rows2, starts);
-            }
+            dev::CounterOut co;
+            memset(&co, 0, sizeof(co));
+            for (int c = 0; c < 4; c++) if ((mask >> c) & 1) { co.read_ts[c] = read_ts[c]; co.final_cts[c] = final_cts[c]; }
+            dev::lasso_counters_all(st, L, mask, dims, co, temp, tb, keys, keys2, rows, rows2, starts);
             ctx->prof_end();
             stamp("counters done");
-            if (use_aux && counters_aux) { hip_check(hipEventRecord(ctx->ev_aux[3], st), "lasso: counters event"); counters_event_recorded = true; }
-        });
-        if (use_aux && !counters_aux && need_counters) {
-            // grand product #2's hashes and the openings (second stream) read the counters (main stream)
-            hip_check(hipEventRecord(ctx->ev_aux[0], ctx->stream), "lasso: counters event");
-            on_aux([&] { hip_check(hipStreamWaitEvent(st, ctx->ev_aux[0], 0), "lasso: wait for the counters"); });
-        }
-        if (col_after_counters) on_aux([&] {
-            hip_check(hipStreamWaitEvent(st, ctx->ev_aux[2], 0), "lasso: wait for the E tables");
-            flush_stride();
-            stamp("collation done");
+            if (use_aux) { hip_check(hipEventRecord(ctx->ev_aux[3], st), "lasso: counters event"); counters_event_recorded = true; }
         });
         // the collation rounds are launched now, not with the grand products at the end of the node: the host still has the whole
         // memory-checking bookkeeping to walk (about 0.5 ms) and the main stream would sit idle meanwhile; behind the counters, so
@@ -1595,8 +1555,8 @@ struct Prover {
             // Slot form (kernels.hpp, GpHashSrc::slot_of): inside a lookup's row segment the memories it does not use have, per chunk,
             // identical hash rows, and the top layer multiplies segment s with segment s + npairs (Layer::bottom splits a row into
             // halves): memories in the same class in both segments share one table pair until the tables are down to the segment pairs.
-            static const bool no_slots = [] { const char* e = getenv("HG_NO_SLOTS"); return e && e[0] == '1'; }();
-            static const bool use_mirror_top = [] { const char* e = getenv("HG_NO_MIRROR"); return !(e && e[0] == '1'); }();
+            // HG_SLOT_DEPTH = number of slot-form layers (default 4; 0 = the memory form throughout, the path small tables take anyway)
+            static const int depth_max = [] { const char* e = getenv("HG_SLOT_DEPTH"); return e && *e ? atoi(e) : 4; }();
             gp_slots = GpSlots();
             const int nvars_top = nu - 1;
             // rows of the grand product as this rank holds them (all of them on one GPU; its own memories' on a sharded rank): reads first
@@ -1612,14 +1572,14 @@ struct Prover {
             bool rows_fit = (int)hm.size() == R && R >= 2 && NL <= 64;
             for (int t = 0; t < R && rows_fit; t++) rows_fit = hm[t].rd_row == t;           // (the hash kernel walks hm by read row)
             for (int t = R; t < NL && rows_fit; t++) rows_fit = roww[t] && read_row_of[rowmem[t]] >= 0;
-            if (rows_fit && !no_slots && use_mirror_top && G <= 32 && L.seg_shift >= 9 && nvars_top - 1 > L.seg_shift &&
+            if (rows_fit && depth_max > 0 && G <= 32 && L.seg_shift >= 9 && nvars_top - 1 > L.seg_shift &&
                 ((N / 2) >> L.seg_shift) <= 64 && nvars_top - 1 - slot_tail_h(2 * R + 1, nvars_top) <= L.seg_shift) {
                 const int NP = (int)((N / 2) >> L.seg_shift);
                 auto cls = [&](int i, int s) -> int {   // class of GKR position i in row segment s: itself where its memory is looked up, else its chunk
                     if (((size_t)s << L.seg_shift) < L.rows && ((L.lookup_uses[lp.seg_lookup[s]] >> lp.gkr_order[i]) & 1)) return 1000 + i;
                     return lp.gkr_chunk[i];
                 };
-                if (getenv("HG_SLOT_DEBUG"))   // joint classes of deeper layers: layer d multiplies 2^(d+1) segments NP >> d apart
+                if (hg_debug("slots"))   // joint classes of deeper layers: layer d multiplies 2^(d+1) segments NP >> d apart
                     for (int d = 0; d < 4 && (NP >> d) >= 1; d++) {
                         const int np = NP >> d, cnt = 2 << d;
                         int vmax = 0;
@@ -1634,7 +1594,6 @@ struct Prover {
                         }
                         fprintf(stderr, "[hg slots] layer %d: %d segment groups of %d, at most %d classes of %d memories\n", d, np, cnt, vmax, G);
                     }
-                static const int depth_max = [] { const char* e = getenv("HG_SLOT_DEPTH"); return e && *e ? atoi(e) : 4; }();
                 GpSlots& gs = gp_slots;
                 gs.NP = NP; gs.G = R; gs.seg_shift = L.seg_shift;
                 // layer d multiplies 2^(d+1) segments NP >> d apart: its classes are over those; rows: reads (layer 0), reads then writes
@@ -1690,7 +1649,7 @@ struct Prover {
                     upload(sl.d_rep, sl.rep.data(), sl.rep.size(), "upload slot representatives");
                     upload(sl.d_emit, em.data(), em.size() * sizeof(u64), "upload slot emission masks");
                 }
-                if (getenv("HG_SLOT_DEBUG")) {
+                if (hg_debug("slots")) {
                     std::string vs;
                     for (auto& sl : gs.layer) vs += " " + std::to_string(sl.V) + "/" + std::to_string(sl.nrows);
                     fprintf(stderr, "[hg slots] adopted: %d layers, classes / rows per layer:%s\n", (int)gs.layer.size(), vs.c_str());
@@ -1776,7 +1735,7 @@ struct Prover {
         });
         mark("lasso: memory checking, grand product #1 over reads then writes (prover.rs:161-165)");
         // the write hash of a row is its read hash + gamma^2 (prover.rs:44: t + 1): the top layer runs on the read rows only
-        static const bool use_mirror = [] { const char* e = getenv("HG_NO_MIRROR"); return !(e && e[0] == '1'); }();
+        constexpr bool use_mirror = true;
         const u64 gamma_sq = gl_mul(gamma, gamma);
         const u64* mirror_c = (emit > 0 && use_mirror) ? &gamma_sq : nullptr;
         GpOut g1 = split ? grand_product(H1, N, 2 * G, gp1_owner, L1, &local_pairs, p0_only, d_hash_src, emit, hash_build_bytes, mirror_c)
@@ -1861,7 +1820,7 @@ struct Prover {
                     eq_now(eqy_v, 16, p2);
                 }
             };
-            auto openings = [this, txv, tyv, nxv, nyv, do_open_v, lean_v, eqx_v, eqy_v, p1, p2, Lp, d_input, nu, N] {
+            auto openings = [this, txv, tyv, nxv, nyv, lean_v, eqx_v, eqy_v, Lp, d_input, N] {
                 if (nxv) {
                     int nvirt = 0;
                     for (int t = 0; t < nxv; t++) nvirt += txv.t[t] == nullptr;
@@ -1883,32 +1842,18 @@ struct Prover {
                 if (nyv) dev::dot_eq_many(st, eqy_v, tyv, nyv, M, partials, d_res());
                 stamp("claimed sum and openings done");
             };
-            // Where the openings' dot products run (HG_LATE_OPENINGS; the two eq tables above are built right away in every case).
-            // 3 (default since the slot form): see below. 1: behind the node reductions on the second stream. 0: right away, beside the first hash round. 2: between the
-            // two waves of node reductions. Round 4, medians of 120 interleaved graph replays: 2.566 (0) / 2.598 (2) / 2.610 ms (1);
-            // bench.py with 40 steps: 2.82-2.84 (0) against 2.87-2.90 ms (1) per proof - with the shorter node bookkeeping both chains
-            // end together and 0.15 ms of openings behind them run alone. 0 is not the default because the node reductions then start
-            // 0.5 ms later and their VALU-heavy first rounds share the GPU with all of the dominant round kernel's launches: 265-277
-            // instead of 246-261 us per launch, 0.55-0.57 instead of 0.58-0.61 of the HBM roofline inside a prove (0.74 isolated either
-            // way) for a gain of 1.5-2 % that one bench.py run of 10 steps does not resolve.
-            // 3: at the end of the MAIN stream, behind the grand products (which, in their slot form, end before the node reductions do:
-            // stamps 1.92 against 1.99 ms, and the openings ran alone behind the latter until 2.08 ms). Medians of 72 interleaved graph
-            // replays: 1.982 (3) / 2.023 (1) / 2.023 (2) / 2.057 ms (0).
-            // 4 (default since the eq-factored node reductions, which end 0.25 ms before the grand products): behind the node reductions
-            // on THEIR stream (the third one), which waits for the opening tables of the second. Medians of 72 interleaved graph
-            // replays: 1.85-1.86 (4) / 1.83-1.85 (1: the same behind node reductions on the second stream) / 1.87-1.91 (3) / 1.846 (0) /
-            // 1.864 ms (2). A fourth stream for the node reductions alone: 1.85 - a replayed launch graph does not run a fourth branch
-            // beside the other three (its first kernel starts 0.6 ms into the prove, with or without GPU_MAX_HW_QUEUES=8).
-            static const int late = [] { const char* e = getenv("HG_LATE_OPENINGS"); return e && *e ? atoi(e) : 4; }();
+            // Where the openings' dot products run (the two eq tables above are built right away in every case): behind the node
+            // reductions, on THEIR stream (one rank: the third one, which waits for the opening tables of the second; a sharded rank:
+            // the second). Since the eq-factored node reductions (round 5) those end 0.25 ms before the grand products do. Measured and
+            // removed: right away beside the first hash round (1.846 ms), between the two waves of node reductions (1.864), at the end of
+            // the main stream behind the grand products (1.87-1.91; the round-4 default) against 1.83-1.86 ms; a fourth stream for the
+            // node reductions alone: 1.85 - a replayed launch graph does not run a fourth branch beside the other three (its first
+            // kernel starts 0.6 ms into the prove, with or without GPU_MAX_HW_QUEUES=8).
             aux(open_tables);
-            if (late == 4 && use_aux && world == 1) {
+            if (use_aux && world == 1) {
                 hip_check(hipEventRecord(ctx->ev_aux[4], ctx->stream2), "lasso: opening tables event");
                 late_col.push_back(openings);
-            } else if (late == 3 && use_aux && world == 1) {
-                hip_check(hipEventRecord(ctx->ev_aux[4], ctx->stream2), "lasso: opening tables event");
-                hip_check(hipStreamWaitEvent(ctx->stream, ctx->ev_aux[4], 0), "lasso: wait for the opening tables");
-                openings();
-            } else if (late && use_aux) late_aux.push_back(openings);
+            } else if (use_aux) late_aux.push_back(openings);
             else aux(openings);
         }
         stamp("grand products done");
@@ -1918,7 +1863,7 @@ struct Prover {
     // ---- GKR driver ----------------------------------------------------------------------------
     std::map<std::pair<size_t, int>, E2*> eq_shared;             // (point, variables) -> eq table of a single unit-weight claim
     std::map<std::tuple<size_t, int, int>, E2*> fft_shared;      // (point, log2 size, inverse) -> DFT-row table of a single claim
-    static bool share_tables() { static const bool v = [] { const char* e = getenv("HG_NO_TABLE_SHARE"); return !(e && e[0] == '1'); }(); return v; }
+    static bool share_tables() { return true; }
     std::vector<const u64*> d_vals;               // node values in HBM
     std::vector<std::vector<ClaimRef>> claims;    // per node
 
@@ -2015,7 +1960,7 @@ struct Prover {
         }
         // Nodes that received their only claim from the same sum-check share the point (every input of a Vanilla node is opened at the
         // node's r_x: the five inputs of the final sum, the eight chunk nodes behind the Lasso input ...): one eq table serves them all
-        // (read-only everywhere). HG_NO_TABLE_SHARE=1: one table per node.
+        // (read-only everywhere).
         E2* eqc = nullptr;
         if (own) {
             const std::pair<size_t, int> key{cs.point_off[0], n.log2_out()};
@@ -2175,7 +2120,7 @@ struct Prover {
     // Runs `fn` with the second stream as the enqueue target (work of the Lasso node that is off its critical path: counter
     // sorts, grand product #2's hashes and tree, the openings). One stream only: runs it in place.
     std::vector<std::function<void()>> late_aux;
-    std::vector<std::function<void()>> late_col;   // the same, for whichever stream the node reductions run on; needs ev_aux[4] (HG_LATE_OPENINGS=4)
+    std::vector<std::function<void()>> late_col;   // the same, for whichever stream the node reductions run on; needs ev_aux[4]
     bool aux_started = false;
     template <typename Fn> void on_aux(Fn fn) {
         if (!fork_recorded) { fn(); return; }
@@ -2201,13 +2146,12 @@ struct Prover {
     std::function<void()> st_before_gp2; // ... and this one once the sequenced first rounds of grand product #1's top layers are out
     // The node reductions on the THIRD stream (the collation rounds' - a few launches at the start of the prove): they then start with
     // the prove instead of behind the Lasso node's second-stream work (counters, grand product #2's tree, opening tables: 0.6 ms),
-    // into the idle capacity those latency-bound launches leave. HG_NODES_STREAM=2: on the second stream, as before the slot form.
+    // into the idle capacity those latency-bound launches leave.
     bool nodes_on_col = false;
     void fork_nodes_stream() {
         if (!fork_recorded) return;
         hip_check(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0), "fork wait");
-        static const bool third = [] { const char* e = getenv("HG_NODES_STREAM"); return !(e && e[0] == '2'); }();
-        if (third && world == 1 && late_aux.empty()) {   // (openings queued behind the node reductions read the second stream's counters)
+        if (world == 1 && late_aux.empty()) {
             hip_check(hipStreamWaitEvent(ctx->stream_col, ctx->ev_fork, 0), "fork wait");
             st = ctx->stream_col; partials = ctx->d_partials3; ctx->prof_stream = st; forked = true; nodes_on_col = true;
             return;
@@ -2264,8 +2208,6 @@ struct Prover {
         stamp("node bookkeeping done");
         flush_prodsum();                       // first wave: every FFT / Libra phase-1 reduction, batched
         stamp("node phase 1 done");
-        static const bool mid_openings = [] { const char* e = getenv("HG_LATE_OPENINGS"); return e && e[0] == '2'; }();
-        if (mid_openings) { for (auto& f : late_aux) f(); late_aux.clear(); }   // HG_LATE_OPENINGS=2: between the two waves
 
         for (auto& f : second_wave) f();       // Libra phase-2 bookkeeping (needs the phase-1 scalars in HBM)
         second_wave.clear();
@@ -2419,8 +2361,14 @@ static void witness_fill(hg_ctx* ctx, const hg_pk* pk, const Witness& w, hg_valu
     if (v->ctx != ctx) throw Error("witness generation: the values object was created on another context");
     if (v->shard_rank >= 0) {   // a rank's share: evaluate the cone its tables depend on into the object's own subset tables, copy them over
         if (!v->eval_cone) throw Error("witness generation: a rank's values object without its evaluation cone");
-        witness_fill(ctx, pk, w, v->eval_cone, st, false, witness_ms, upload_ms);
+        // (timed around the real completion: the inner call only enqueues - upload, the cone's NTT / gate kernels - and the single
+        // synchronisation is shard_fill's. The span is not split: witness_ms = all of it, upload_ms = 0. Without `sync` nothing waits
+        // and both are the host's enqueue time.)
+        const double t0 = wall_ms();
+        witness_fill(ctx, pk, w, v->eval_cone, st, false, nullptr, nullptr);
         shard_fill(ctx, v, v->eval_cone, st, sync);
+        if (witness_ms) *witness_ms = wall_ms() - t0;
+        if (upload_ms) *upload_ms = 0;
         return;
     }
     hip_check(hipSetDevice(ctx->device), "hipSetDevice");
@@ -2733,7 +2681,7 @@ static void cache_launch(hg_ctx* ctx, ProveCache* C, bool exchange) {
         if (P->early_slot != (size_t)-1) __atomic_store_n(&ctx->h_res[P->early_slot].c0, (u64)0, __ATOMIC_RELEASE);
     }
     hip_check(hipEventRecord(C->ev_a, ctx->stream), "event record");
-    static const bool time_launch = getenv("HG_TIME_LAUNCH") != nullptr;   // (debugging aid: host time of the graph launch call)
+    const bool time_launch = hg_debug("launch");   // (debugging aid: host time of the graph launch call)
     const double tl0 = time_launch ? wall_ms() : 0;
     hip_check(hipGraphLaunch(C->exec, ctx->stream), "hipGraphLaunch");
     if (time_launch) fprintf(stderr, "hipGraphLaunch: %.3f ms on the host\n", wall_ms() - tl0);
@@ -2794,9 +2742,8 @@ static std::shared_ptr<ProveCache> prove_capture(hg_ctx* ctx, const hg_pk* pk, c
         capturing = true;
         C->P.reset(new Prover(ctx, pk, rank, world));
         C->P->d_vals = v->d_vals;
-        static const bool static_uploads = [] { const char* e = getenv("HG_GRAPH_UPLOADS"); return !(e && e[0] == '1'); }();
-        C->P->defer_uploads = static_uploads;
-        if (getenv("HG_TEST_FAIL_CAPTURE")) throw Error("launch-graph capture failed (forced by HG_TEST_FAIL_CAPTURE)");
+        C->P->defer_uploads = true;   // (descriptor uploads are not graph nodes: Prover::upload)
+        if (hg_debug("fail_capture")) throw Error("launch-graph capture failed (forced by HG_DEBUG=fail_capture)");
         enqueue_prove(ctx, pk, v, C->P.get(), world, false);   // (the exchange is not part of the graph: prove_from_cache)
         capturing = false;
         hip_check(hipStreamEndCapture(ctx->stream, &C->graph), "hipStreamEndCapture");
@@ -2811,7 +2758,6 @@ static std::shared_ptr<ProveCache> prove_capture(hg_ctx* ctx, const hg_pk* pk, c
         throw;
     }
     restore();
-    if (const char* dot = getenv("HG_GRAPH_DOT")) (void)hipGraphDebugDotPrint(C->graph, dot, hipGraphDebugDotFlagsKernelNodeParams);   // (debugging aid: the recorded dependencies)
     for (auto& u : C->P->deferred_uploads)   // once, ahead of the first replay on the same stream; their targets live in the private arena
         hip_check(hipMemcpyAsync(u.dst, u.src, u.bytes, hipMemcpyHostToDevice, ctx->stream), "descriptor upload");
     hip_check(hipStreamSynchronize(ctx->stream), "descriptor uploads");   // (the pinned staging they came from is reused by the next prove)
@@ -2857,7 +2803,7 @@ static std::shared_ptr<ProveCache> prove_through_graph(hg_ctx* ctx, const hg_pk*
         } catch (const std::exception& e) {
             // no graph for this key and share from now on; this prove and the later ones walk the protocol
             ctx->no_graph_serial = pk->serial; ctx->no_graph_share = share;
-            if (getenv("HG_SHARD_DEBUG") || getenv("HG_GRAPH_DEBUG")) fprintf(stderr, "[hg] launch-graph capture failed, falling back to plain launches: %s\n", e.what());
+            if (hg_debug("shard")) fprintf(stderr, "[hg] launch-graph capture failed, falling back to plain launches: %s\n", e.what());
             return nullptr;
         }
     }
@@ -2935,7 +2881,7 @@ std::vector<ProveResult> prove_stream(hg_ctx* ctx, const hg_pk* pk, const std::v
 
 ProveResult prove_sharded(hg_ctx* ctx, const hg_pk* pk, const hg_values* v) {
     if (!ctx->comm) throw Error("hg_prove_sharded: no communicator on this context (hg_comm_init)");
-    if (ctx->d_res != ctx->h_res) throw Error("hg_prove_sharded: needs the host-mapped result buffer (unset HG_RES_DEVICE)");
+    if (ctx->d_res != ctx->h_res) throw Error("hg_prove_sharded: needs the host-mapped result buffer");
     {
         ProveResult cached;   // this rank's share as a cached launch graph, the all-reduce enqueued behind it
         if (prove_through_graph(ctx, pk, v, ctx->comm_rank, ctx->comm_world, true, &cached)) return cached;
@@ -2977,7 +2923,7 @@ size_t prove_shard_begin(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int r
         ps->P = ps->own.get();
     }
     size_t n = ps->P->res_used;
-    if (getenv("HG_SHARD_DEBUG")) fprintf(stderr, "[hg] shard rank %d/%d: gpu %.3f ms, enqueue %.3f ms\n", rank, world, ps->gpu_ms, ps->P->t_enqueued - ps->t_start);
+    if (hg_debug("shard")) fprintf(stderr, "[hg] shard rank %d/%d: gpu %.3f ms, enqueue %.3f ms\n", rank, world, ps->gpu_ms, ps->P->t_enqueued - ps->t_start);
     ctx->pending_shard = ps.release();
     return n;
 }
@@ -3007,7 +2953,7 @@ ProveResult prove_shard_finish(hg_ctx* ctx) {
     ProveResult res;
     const double tf0 = wall_ms();
     ps->P->replay();
-    if (getenv("HG_SHARD_DEBUG")) fprintf(stderr, "[hg] shard finish: replay call %.3f ms\n", wall_ms() - tf0);
+    if (hg_debug("shard")) fprintf(stderr, "[hg] shard finish: replay call %.3f ms\n", wall_ms() - tf0);
     res.prove_ms = wall_ms() - ps->t_start;
     res.gpu_ms = ps->gpu_ms;
     res.enqueue_ms = ps->P->t_enqueued - ps->t_start;

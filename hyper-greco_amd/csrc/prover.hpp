@@ -22,7 +22,7 @@ struct hg_ctx {
     hipStream_t stream = nullptr;   // Lasso node + everything sequential
     hipStream_t bn_stream_hi = nullptr, bn_stream_lo = nullptr;   // BN254 prove only (bn254_gkr.inc: BnStreams), created on first use
     hipStream_t stream2 = nullptr;  // Vanilla / FFT node reductions (independent of the Lasso node on the device)
-    hipStream_t stream_col = nullptr;   // HG_LASSO_SCHED=3: the collation sum-check's short launches, off the main stream (forked from and joined to it)
+    hipStream_t stream_col = nullptr;   // one rank: the collation sum-check's short launches, then the node reductions, off the main stream (forked from and joined to it)
     hipEvent_t ev_col = nullptr;
     hg::E2* d_partials3 = nullptr;      // scratch of stream_col
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;

@@ -1009,7 +1009,7 @@ struct SeqProver {
     // ---- prove_sum_check, stride layout (collation / grand-product shapes) ------------------------------------------------
     // tables: ntab rows at `in + t * in_stride` (u64 if base else E2). final evaluations land in d_res[evals_slot ..).
     size_t sumcheck_stride(int kind, const void* in, bool base, size_t in_stride, int ntab, int nvars, const dev::Powers& pw, E2& claim, size_t evals_slot) {
-        if (shard_world > 1 && !(use_mail && !classic())) throw Error("sharded prove: needs the mailbox round kernels (HG_SEQ_NO_MAIL / HG_SEQ_CLASSIC / HG_RES_DEVICE unset)");
+        if (shard_world > 1 && !(use_mail && !classic())) throw Error("sharded prove: needs the mailbox round kernels (HG_SEQ_NO_MAIL / HG_SEQ_CLASSIC unset)");
         if (use_mail && !classic()) {
             SqJob Q;
             memset(&Q, 0, sizeof(Q));
@@ -1085,7 +1085,7 @@ struct SeqProver {
     // ---- prove_sum_check, sum of pair products (Libra / zkCNN reductions) --------------------------------------------------
     size_t sumcheck_prodsum(const std::vector<const u64*>& a, const std::vector<const E2*>& b, int nvars, const std::vector<E2*>& fin_a,
                             const std::vector<E2*>& fin_b, E2& claim) {
-        if (shard_world > 1 && !(use_mail && !classic())) throw Error("sharded prove: needs the mailbox round kernels (HG_SEQ_NO_MAIL / HG_SEQ_CLASSIC / HG_RES_DEVICE unset)");
+        if (shard_world > 1 && !(use_mail && !classic())) throw Error("sharded prove: needs the mailbox round kernels (HG_SEQ_NO_MAIL / HG_SEQ_CLASSIC unset)");
         if (use_mail && !classic()) {
             SqJob Q;
             memset(&Q, 0, sizeof(Q));

@@ -254,6 +254,15 @@ std::string verify_proof_device(hg_ctx* ctx, const hg_pk* pk, const Witness& w, 
     struct Total { double t0; ~Total() { if (getenv("HG_VERIFY_TIMES")) fprintf(stderr, "[hg] verify_device: %.2f ms in all\n", (omp_get_wtime() - t0) * 1e3); } } total{tv0};
     hip_check(hipSetDevice(ctx->device), "hipSetDevice");
     ctx->arena_reset();
+    // Rejection is a normal outcome and leaves kernels and staged descriptor copies queued (the walk returns from the middle of the
+    // proof), and an hg::Error may leave from any of the uploads below: drain the stream on EVERY way out - accept, Reject, hg::Error -
+    // before the caller may reuse the staging buffer and the arena or free the witness whose uploads may still be pending. (The guard
+    // stands ahead of the first enqueue. Peak arena use: every node's tables stay until the batched finish - the per-node rewind
+    // went with the per-kind launches - about the size of the node tables, 0.13 GB at n=32768 k=16.)
+    struct Drain {
+        hipStream_t st;
+        ~Drain() { (void)hipStreamSynchronize(st); }
+    } drain{ctx->stream};
     ctx->ensure_chain(16384);
     const Params& p = pk->params;
     DevBackend D(ctx, pk);
@@ -271,13 +280,6 @@ std::string verify_proof_device(hg_ctx* ctx, const hg_pk* pk, const Witness& w, 
     D.d_inputs.push_back(up(w.r2is.data(), w.r2is.size()));
     D.d_ct0is = up(w.ct0is.data(), w.ct0is.size());
     if (getenv("HG_VERIFY_TIMES")) fprintf(stderr, "[hg] verify_device: inputs enqueued at %.2f ms\n", (omp_get_wtime() - tv0) * 1e3);
-    // Rejection is a normal outcome and leaves kernels and staged descriptor copies queued (the walk returns from the middle of the
-    // proof): drain the stream on EVERY way out - accept, Reject, hg::Error - before the caller may reuse the staging buffer and the
-    // arena or free the witness whose uploads may still be pending.
-    struct Drain {
-        hipStream_t st;
-        ~Drain() { (void)hipStreamSynchronize(st); }
-    } drain{ctx->stream};
     return verify_proof_with(D, p, pk->lasso, pk->circuit, proof, len);
 }
 

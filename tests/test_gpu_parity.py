@@ -733,10 +733,10 @@ def test_graph_capture_failure_falls_back_to_plain_launches(ctx, monkeypatch):
     vals = hg.witness_gen(ctx, pk, w)
     out = hg.ProofBuffer()
     ref = hg.prove_resident(ctx, pk, vals, out).bytes()
-    monkeypatch.setenv("HG_TEST_FAIL_CAPTURE", "1")
+    monkeypatch.setenv("HG_DEBUG", "fail_capture")
     for i in range(4):                                                     # walk, failed capture -> walk, walk, walk
         assert hg.prove_resident(ctx, pk, vals, out).bytes() == ref, i
-    monkeypatch.delenv("HG_TEST_FAIL_CAPTURE")
+    monkeypatch.delenv("HG_DEBUG")
     for i in range(3):                                                     # the key stays on plain launches (no retry), still correct
         assert hg.prove_resident(ctx, pk, vals, out).bytes() == ref, i
         assert out.timings()["enqueue_ms"] > 0.05
@@ -794,26 +794,21 @@ def test_launch_graph_that_replays_slower_than_plain_launches_is_given_up():
         "for i in range(12):\n"
         "    hg.prove_resident(ctx, pk, v, out); first = first or out.bytes(); assert out.bytes() == first, i\n"
     ) % ROOT
-    env = dict(os.environ, HG_GRAPH_GUARD_FACTOR="0", HG_TIME_LAUNCH="1")   # (the second one logs every graph launch to stderr)
+    env = dict(os.environ, HG_GRAPH_GUARD_FACTOR="0", HG_DEBUG="launch")   # (the second one logs every graph launch to stderr)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     # proves 0, 1: walks; 2: capture + first replay; 3 .. 5: replays - all four "slower" than the walk; 6 ..: walks again
     assert r.stderr.count("hipGraphLaunch:") == 4, r.stderr[-2000:]
-    env = dict(os.environ, HG_TIME_LAUNCH="1")
+    env = dict(os.environ, HG_DEBUG="launch")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0 and r.stderr.count("hipGraphLaunch:") == 10, r.stderr[-2000:]   # the guard leaves a healthy graph alone
 
 
-@pytest.mark.parametrize("switch", ["HG_E_TABLES=1", "HG_NO_MIRROR=1", "HG_NO_HASH_FUSE=1", "HG_ONE_STREAM=1", "HG_NO_GRAPH=1", "HG_TAIL_H=4", "HG_LATE_OPENINGS=0", "HG_LATE_OPENINGS=1",
-                                    "HG_LATE_OPENINGS=2", "HG_NO_LEVEL3=1", "HG_GRAPH_UPLOADS=1", "HG_LASSO_SCHED=2", "HG_LASSO_SCHED=0", "HG_NO_FUSE2=1",
-                                    "HG_GATHER_CSR=1", "HG_EQ_ONE_LAUNCH=1", "HG_PS_TAIL_THREADS=256", "HG_NO_EARLY_REPLAY=1", "HG_NO_TABLE_SHARE=1", "HG_OPEN_GROUPS=1", "HG_NO_SLOTS=1", "HG_SLOT_DEPTH=1",
-                                    "HG_SLOT_DEPTH=2", "HG_FUSE_MIN_H=13", "HG_NODES_STREAM=2", "HG_PS_FUSE_MIN_H=11"])
+@pytest.mark.parametrize("switch", ["HG_ONE_STREAM=1", "HG_NO_GRAPH=1", "HG_GATHER_CSR=1", "HG_NO_PS_EQ=1", "HG_SLOT_DEPTH=0", "HG_SLOT_DEPTH=1", "HG_SLOT_DEPTH=2"])
 def test_alternative_paths_behind_the_environment_switches_stay_bit_exact(switch):
-    """Every switch that selects an older or alternative device path (E tables materialised, both rows of the top layer, hash tables,
-    one stream, plain launches, the five-round tail, the openings behind / between the node reductions, one tree level per launch, upload
-    nodes in the graph, collation on the second stream, single-round launches, per-term Libra gathers instead of run-length segments
-    and aliased eq slices, one-launch eq tables, a 256-thread PRODSUM tail, the transcript replayed strictly in order, one table pair per
-    memory instead of per joint class in the read / write product's top layer) must produce the
+    """The switches that are left select a supported configuration (one stream, plain launches) or force the GENERAL form of a
+    path at a size where the specialised one would run (per-term Libra gathers instead of run-length segments, every Libra table
+    materialised instead of the eq-factored rounds, fewer or no slot-form layers in the read / write product): each must produce the
     same bytes as the oracle. The library reads them once per process: child process,
     five resident proves (walks, capture, replays) plus a four-rank sharded proof at n=4096 k=2."""
     import subprocess, sys
@@ -838,7 +833,7 @@ def test_alternative_paths_behind_the_environment_switches_stay_bit_exact(switch
     assert r.returncode == 0 and "SWITCH OK" in r.stdout, (switch, r.stdout[-500:], r.stderr[-2000:])
 
 
-@pytest.mark.parametrize("switch", ["HG_NO_MIRROR=1", "HG_E_TABLES=1", "HG_GATHER_CSR=1", "HG_NO_SLOTS=1", "HG_SLOT_DEPTH=1", "HG_SLOT_DEPTH=3"])
+@pytest.mark.parametrize("switch", ["HG_GATHER_CSR=1", "HG_NO_PS_EQ=1", "HG_SLOT_DEPTH=0", "HG_SLOT_DEPTH=1", "HG_SLOT_DEPTH=3"])
 def test_environment_switches_at_the_headline_size(switch):
     """Two of the switches above at n=32768 k=16 (BASELINE configs[2]), where every production shortcut is active: walks, the capture and
     two graph replays must all give the oracle's bytes."""
@@ -860,7 +855,7 @@ def test_environment_switches_at_the_headline_size(switch):
     assert r.returncode == 0 and "SWITCH OK" in r.stdout, (switch, r.stdout[-500:], r.stderr[-2000:])
 
 
-@pytest.mark.parametrize("switch", ["HG_BN_NO_SHARED_B=1", "HG_GATHER_CSR=1", "HG_BN_SCHED=0", "HG_NO_TABLE_SHARE=1", "HG_OPEN_GROUPS=1", "HG_BN_NO_WINDOW=1", "HG_BN_NO_SLOTS=1", "HG_BN_SLOT_DEPTH=1", "HG_BN_SLOT_DEPTH=2"])
+@pytest.mark.parametrize("switch", ["HG_GATHER_CSR=1", "HG_BN_SLOT_DEPTH=0", "HG_BN_SLOT_DEPTH=1", "HG_BN_SLOT_DEPTH=2"])
 def test_bn254_environment_switches_stay_bit_exact(switch):
     """The BN254 prove with its alternative paths (every pair of a PRODSUM job multiplied separately although the pairs share one b
     table; per-term Libra gathers instead of aliased eq slices; the node launches ahead of the Lasso node) gives the C++ Fr oracle's
@@ -1419,9 +1414,31 @@ def test_bn254_prove_other_parameter_sets_accepted_by_the_host_verifier(ctx, n, 
 
 
 @pytest.mark.gpu
+def test_eq_factored_rounds_are_the_path_that_runs():
+    """The eq-factored PRODSUM rounds must actually be taken at the headline size - otherwise HG_NO_PS_EQ=1 would compare
+    the materialised form with itself: 14 of the 65 first-wave node reductions, most of the table entries."""
+    import subprocess, sys
+    from hglib import ROOT
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import __graft_entry__ as entry\n"
+        "hg = entry.load_package()\n"
+        "ctx = hg.Context(0); bfv = hg.BfvEncrypt.new(32768, 16); pk = bfv.setup(ctx)\n"
+        "w = hg.Witness.synthetic(bfv.params, 5); v = hg.witness_gen(ctx, pk, w); out = hg.ProofBuffer()\n"
+        "hg.prove_resident(ctx, pk, v, out)\n"
+        "print('RAN')\n"
+    ) % (ROOT,)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, HG_DEBUG="eq"), cwd=ROOT)
+    assert r.returncode == 0 and "RAN" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+    lines = [l.split() for l in r.stderr.splitlines() if l.startswith("[hg eq]")]
+    assert lines and int(lines[0][2]) == 14 and int(lines[0][4]) == 65, r.stderr[-2000:]
+    assert int(lines[0][9]) * 4 > int(lines[0][11]) * 3, r.stderr[-2000:]      # more than three quarters of the entries
+
+
+@pytest.mark.gpu
 def test_slot_form_is_the_path_that_runs():
     """The slot form of grand product #1 must actually be taken where it applies - otherwise the switch tests above would
-    compare the memory form with itself. HG_SLOT_DEBUG=1 makes the library report the layers it adopted; HG_BN_TIMES=1 the bn254 prove's."""
+    compare the memory form with itself. HG_DEBUG=slots makes the library report the layers it adopted; HG_BN_TIMES=1 the bn254 prove's."""
     import subprocess, sys
     from hglib import ROOT
     code = (
@@ -1434,7 +1451,7 @@ def test_slot_form_is_the_path_that_runs():
         "ctx.prove_bn254(pk, w, cap=1 << 24)\n"
         "print('RAN')\n"
     ) % (ROOT,)
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, HG_SLOT_DEBUG="1", HG_BN_TIMES="1"), cwd=ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, HG_DEBUG="slots", HG_BN_TIMES="1"), cwd=ROOT)
     assert r.returncode == 0 and "RAN" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
     adopted = [l for l in r.stderr.splitlines() if l.startswith("[hg slots] adopted:")]
     assert adopted and int(adopted[0].split()[3]) >= 2, r.stderr[-2000:]          # the top layer and at least one below it
