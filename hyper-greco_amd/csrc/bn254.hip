@@ -2148,7 +2148,7 @@ static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4,
             } else slots.V = 0;
         }
         const bool use_slots = slots.V > 0;
-        if (getenv("HG_BN_TIMES")) fprintf(stderr, "[hg bn]   read rows: %d slot rows for %d memories, %d segment pairs of 2^%d rows; %d slot-form layers below\n", use_slots ? slots.V : G, G, slots.npairs, slots.seg_shift, (int)slots.deep.size());
+        if (hg_times("bn")) fprintf(stderr, "[hg bn]   read rows: %d slot rows for %d memories, %d segment pairs of 2^%d rows; %d slot-form layers below\n", use_slots ? slots.V : G, G, slots.npairs, slots.seg_shift, (int)slots.deep.size());
         Fr* H1 = dalloc((size_t)(use_slots ? slots.V : (mirror ? G : 2 * G)) * N);
         Fr* H2 = dalloc((size_t)2 * G * M);
         {   // every memory's read (write) hash rows and init / final rows in one launch
@@ -2236,7 +2236,7 @@ static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4,
             run(eqy, ty, oy, ny, M);
         }
         if (mid && mid_at >= 3) (*mid)();
-        static const bool times = getenv("HG_BN_TIMES") != nullptr;
+        static const bool times = hg_times("bn");
         const double t_enq = wall_ms();
         res_sync(ctx, st, "lasso_prove_bn254: sync");
         if (times) fprintf(stderr, "[hg bn]   lasso node: enqueued, waited %.3f ms for its stream\n", wall_ms() - t_enq);

@@ -178,14 +178,18 @@ void params_derive(uint32_t n, uint32_t k, const u64* qis, u64 t, hg_params* out
     }
 }
 
-bool hg_debug(const char* token) {
-    const char* e = getenv("HG_DEBUG");
+static bool env_token(const char* var, const char* token) {
+    const char* e = getenv(var);
     if (!e || !*e) return false;
     const size_t n = strlen(token);
     for (const char* p = e; (p = strstr(p, token)) != nullptr; p += n)
         if ((p == e || p[-1] == ',') && (p[n] == 0 || p[n] == ',')) return true;
     return false;
 }
+bool hg_debug(const char* token) { return env_token("HG_DEBUG", token); }
+bool hg_times(const char* token) { return env_token("HG_TIMES", token); }
+const char* hg_proof_map_path() { const char* e = getenv("HG_PROOF_MAP"); return e && *e ? e : nullptr; }
+bool hg_env_on(const char* name) { const char* e = getenv(name); return e && e[0] == '1'; }
 
 // ------------------------------------------------------------------------------------------------
 // OpenMP inside a container: omp_get_max_threads() reports the machine's cores (256 on the MI355X boxes) while the cgroup may grant
@@ -506,7 +510,7 @@ static Witness witness_from_json_impl(const Params& p, const std::string& path, 
     m.n = (size_t)stt.st_size;
     m.p = mmap(nullptr, m.n, PROT_READ, MAP_PRIVATE | MAP_POPULATE, m.fd, 0);
     if (m.p == MAP_FAILED) throw Error("witness json: cannot map " + path);
-    const bool tm = getenv("HG_JSON_TIMES") != nullptr;
+    const bool tm = hg_times("json");
     const double t0 = omp_get_wtime();
     JsonCursor c(static_cast<const char*>(m.p), m.n);
     c.bn254 = bn254;

@@ -35,6 +35,12 @@ const u64* challenge_chain(size_t n_base);  // pointer to >= n_base cached base-
 //   shard: per-rank times of a sharded prove, the shard plan, failed graph captures    slots: the slot-form layers a prove adopted
 //   eq: how many queued node reductions run eq-factored    launch: host time of every launch-graph replay    fail_capture: makes the next launch-graph capture fail (fallback test)
 bool hg_debug(const char* token);
+// Timing breakdowns on stderr: HG_TIMES = comma-separated tokens, read at every call.
+//   seq: the round-by-round prover (waits, host steps, drains)    bn: the bn254 prove and its witness generation
+//   verify: hg_verify / hg_verify_device    json: the JSON witness loader
+bool hg_times(const char* token);
+const char* hg_proof_map_path();   // HG_PROOF_MAP=<file>: byte offset of every protocol element of a proof (scripts/proof_diff.py); null: off
+bool hg_env_on(const char* name);  // "<name>=1" in the environment (read once per call site through a static)
 u64 felt_from_hash(const uint8_t h[32]);    // fe_mod_from_le_bytes (transcript.rs:202): 256-bit little-endian integer mod p
 
 // The transcript with its hash state kept explicitly: the bytes absorbed since the last squeeze (H::update appends;

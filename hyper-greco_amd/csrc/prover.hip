@@ -123,6 +123,7 @@ hg_ctx::~hg_ctx() {
     hg::prove_cache_drop(this);
     if (scratch_values) hg::values_free(scratch_values);
     for (auto& v : stream_values) if (v) hg::values_free(v);
+    for (auto& p : stream_pinned) if (p) (void)hipHostFree(p);
     if (stream3) { (void)hipStreamSynchronize(stream3); (void)hipStreamDestroy(stream3); }
     for (auto e : ev_ready) if (e) (void)hipEventDestroy(e);
     for (auto& c : chunks) (void)hipFree(c.p);
@@ -702,7 +703,7 @@ struct Prover {
     }
     // ---- eq-factored PRODSUM jobs (kernels.hpp PsJob::eq_n) ---------------------------------------------------------------
     // HG_NO_PS_EQ=1: every Libra table materialised (the general form, which small or non-affine nodes take anyway)
-    static bool ps_eq_on() { static const bool v = [] { const char* e = getenv("HG_NO_PS_EQ"); return !(e && e[0] == '1'); }(); return v; }
+    static bool ps_eq_on() { static const bool v = !hg_env_on("HG_NO_PS_EQ"); return v; }
     static size_t ps_tail_items() { return std::min<size_t>(TAIL_ITEMS, dev::ps_tail_items_max()); }   // (the tail keeps a job's folds in LDS)
     // First tail round of an eq-factored job, -1: the job is too small for the form. Every round ahead of the tail runs in a fused
     // pair (the tail may start one round later than TAIL_ITEMS says), the last pair at half >= 2^9, and the table handed to the
@@ -962,7 +963,7 @@ struct Prover {
     // Rust reference (scripts/proof_diff.py) - each label names the convention that decides those bytes
     std::vector<std::pair<size_t, std::string>> proof_map;
     void mark(const std::string& label) {
-        if (getenv("HG_PROOF_MAP")) push_op([this, label] { proof_map.push_back({proof.bytes.size(), label}); });
+        if (hg_proof_map_path()) push_op([this, label] { proof_map.push_back({proof.bytes.size(), label}); });
     }
     void defer_write_slots(size_t s, size_t n) {
         push_op([this, s, n] { for (size_t i = 0; i < n; i++) proof.write_e(h_res()[s + i]); });
@@ -1992,7 +1993,7 @@ struct Prover {
         size_t u_base = slot(n.arity);
         E2* scratch = own ? ctx->alloc_n<E2>(n.arity) : nullptr;
         // HG_GATHER_CSR=1: the general (per-term) form for every table
-        static const bool use_seg = [] { const char* e = getenv("HG_GATHER_CSR"); return !(e && e[0] == '1'); }();
+        static const bool use_seg = !hg_env_on("HG_GATHER_CSR");
         for (int i : li) {
             const hg_pk::NodeDev::Seg& sg = nd.seg[i];
             E2* T = nullptr;
@@ -2112,7 +2113,7 @@ struct Prover {
     // Lasso node is enqueued (record_fork, at the start of the walk); HG_ONE_STREAM=1 keeps everything on one stream.
     bool fork_recorded = false;
     void record_fork() {
-        static const bool one_stream = [] { const char* e = getenv("HG_ONE_STREAM"); return e && e[0] == '1'; }();
+        static const bool one_stream = hg_env_on("HG_ONE_STREAM");
         if (one_stream || ctx->one_stream) return;
         hip_check(hipEventRecord(ctx->ev_fork, ctx->stream), "fork event");   // after the result-buffer clear / ticket reset
         fork_recorded = true;
@@ -2235,7 +2236,7 @@ struct Prover {
     std::vector<std::string> stamp_names;
     unsigned long long* d_stamps = nullptr;
     void stamp(const char* name) {
-        static const bool on = getenv("HG_STAMP") != nullptr;
+        static const bool on = hg_env_on("HG_STAMP");
         if (!on) return;
         if (!d_stamps) d_stamps = ctx->alloc_n<unsigned long long>(256);
         if (stamp_names.size() >= 256) return;
@@ -2248,20 +2249,21 @@ struct Prover {
         if (hipMemcpy(h.data(), d_stamps, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
         for (size_t i = 0; i < h.size(); i++) fprintf(stderr, "stamp %8.1f us  %s\n", (double)(long long)(h[i] - h[0]) / 100.0, stamp_names[i].c_str());
     }
-    void sync_results() {
+    // `done` (hg_prove_stream): an event already recorded behind this prove - the stream may hold the NEXT prove by now
+    void sync_results(hipEvent_t done = nullptr) {
         if (res_used && ctx->d_res != ctx->h_res) hip_check(hipMemcpyAsync(ctx->h_res, ctx->d_res, res_used * sizeof(E2), hipMemcpyDeviceToHost, st), "copy results");
         t_enqueued = wall_ms();
         // The only synchronisation of a prove. Spin on an event instead of hipStreamSynchronize: a blocking wait can cost
         // up to milliseconds of wake-up latency when another runtime in the process (PyTorch in bench.py) has switched the
         // device to blocking-sync scheduling; the wait is a few milliseconds at most, so a busy core is the cheaper price.
-        hip_check(hipEventRecord(ctx->ev_join, st), "prove: done event");
+        if (!done) { hip_check(hipEventRecord(ctx->ev_join, st), "prove: done event"); done = ctx->ev_join; }
         const double t_spin = wall_ms();
         for (;;) {
-            hipError_t q = hipEventQuery(ctx->ev_join);
+            hipError_t q = hipEventQuery(done);
             if (q == hipSuccess) break;
             if (q != hipErrorNotReady) hip_check(q, "prove: event query");
             if (early_ready()) run_early();   // (the node reductions are done, the Lasso node's last launches are not)
-            if (wall_ms() - t_spin > 2000.0) { hip_check(hipStreamSynchronize(st), "prove: stream sync"); break; }
+            if (wall_ms() - t_spin > 2000.0) { hip_check(hipEventSynchronize(done), "prove: event sync"); break; }
         }
         hip_check(hipGetLastError(), "prove: kernel launch");
         t_synced = wall_ms();
@@ -2286,7 +2288,7 @@ struct Prover {
             }
             if (rec) { op_off[nops] = proof.bytes.size(); offsets_known = true; }
         }
-        if (const char* path = getenv("HG_PROOF_MAP")) {
+        if (const char* path = hg_proof_map_path()) {
             if (FILE* f = fopen(path, "w")) {
                 for (auto& m : proof_map) fprintf(f, "%zu\t%s\n", m.first, m.second.c_str());
                 fprintf(f, "%zu\tend of proof\n", proof.bytes.size());
@@ -2346,12 +2348,15 @@ static hg_values* values_alloc(hg_ctx* ctx, const hg_pk* pk, const std::vector<c
 }
 
 static void shard_fill(hg_ctx* ctx, hg_values* v, const hg_values* full, hipStream_t st, bool sync);
-static void witness_fill(hg_ctx* ctx, const hg_pk* pk, const Witness& w, hg_values* v, hipStream_t st, bool sync, double* witness_ms, double* upload_ms);
+static void witness_fill(hg_ctx* ctx, const hg_pk* pk, const Witness& w, hg_values* v, hipStream_t st, bool sync, double* witness_ms, double* upload_ms, u64* pinned = nullptr);
 void witness_gen_into(hg_ctx* ctx, const hg_pk* pk, const Witness& w, hg_values* v, double* witness_ms, double* upload_ms) {
     witness_fill(ctx, pk, w, v, ctx->stream, true, witness_ms, upload_ms);
 }
 // `st`: the stream everything is enqueued on; sync == false: nothing waits (the caller orders later work behind an event on `st`)
-static void witness_fill(hg_ctx* ctx, const hg_pk* pk, const Witness& w, hg_values* v, hipStream_t st, bool sync, double* witness_ms, double* upload_ms) {
+// `pinned` (hg_prove_stream): page-locked staging for the whole witness. The caller's arrays are pageable, and an "asynchronous" copy
+// from pageable memory is staged by the runtime inside the call, 37 times per witness (0.9 ms of host time at n=32768 k=16, during
+// which nothing else is enqueued): the arrays are gathered into `pinned` by all host threads first, then copied by real DMAs.
+static void witness_fill(hg_ctx* ctx, const hg_pk* pk, const Witness& w, hg_values* v, hipStream_t st, bool sync, double* witness_ms, double* upload_ms, u64* pinned) {
     // Circuit::evaluate on the device: inputs are uploaded, then the circuit is evaluated level by level
     // (Vanilla nodes: gate-major kernel; FFT nodes: batched NTTs, same level + direction in one batch).
     // Every table keeps its address: a launch graph recorded for `v` proves the new witness as it is (the launch sequence of a
@@ -2365,7 +2370,7 @@ static void witness_fill(hg_ctx* ctx, const hg_pk* pk, const Witness& w, hg_valu
         // synchronisation is shard_fill's. The span is not split: witness_ms = all of it, upload_ms = 0. Without `sync` nothing waits
         // and both are the host's enqueue time.)
         const double t0 = wall_ms();
-        witness_fill(ctx, pk, w, v->eval_cone, st, false, nullptr, nullptr);
+        witness_fill(ctx, pk, w, v->eval_cone, st, false, nullptr, nullptr, pinned);
         shard_fill(ctx, v, v->eval_cone, st, sync);
         if (witness_ms) *witness_ms = wall_ms() - t0;
         if (upload_ms) *upload_ms = 0;
@@ -2381,16 +2386,36 @@ static void witness_fill(hg_ctx* ctx, const hg_pk* pk, const Witness& w, hg_valu
     {   // inputs in NodeId order: s, e, k1, ais.., r1is.., r2is (chain_par! sk_encryption_circuit.rs:408)
         const size_t SZ = p.SZ();
         size_t idx = 0;
+        struct Copy { u64* dst; const u64* src; size_t len; };
+        std::vector<Copy> copies;
         auto put = [&](const u64* src, size_t len) {
             int id = c.input_ids.at(idx++);
             if (len != v->sizes[id]) throw Error("circuit: input size mismatch");
-            if (in(id)) hip_check(hipMemcpyAsync(dv(id), src, len * 8, hipMemcpyHostToDevice, st), "upload input");
+            if (in(id)) copies.push_back({dv(id), src, len});
         };
         put(w.s.data(), SZ); put(w.e.data(), SZ); put(w.k1.data(), SZ);
         for (int i = 0; i < p.k; i++) put(&w.ais[i * SZ], SZ);
         for (int i = 0; i < p.k; i++) put(&w.r1is[i * SZ], SZ);
         put(w.r2is.data(), w.r2is.size());
-        if (v->d_ct0is) hip_check(hipMemcpyAsync(const_cast<u64*>(v->d_ct0is), w.ct0is.data(), w.ct0is.size() * 8, hipMemcpyHostToDevice, st), "upload ct0is");
+        if (v->d_ct0is) copies.push_back({const_cast<u64*>(v->d_ct0is), w.ct0is.data(), w.ct0is.size()});
+        if (pinned) {   // gather, all threads: pieces of 64 KiB
+            std::vector<size_t> off(copies.size() + 1, 0);
+            for (size_t q = 0; q < copies.size(); q++) off[q + 1] = off[q] + copies[q].len;
+            const size_t piece = 8192, npieces = (off.back() + piece - 1) / piece;
+            [[maybe_unused]] const int nt = std::max(1, std::min(hg_omp_threads(), 32));
+#pragma omp parallel for schedule(static) num_threads(nt)
+            for (long long pc = 0; pc < (long long)npieces; pc++) {
+                size_t a = (size_t)pc * piece, b = std::min(off.back(), a + piece);
+                size_t q = (size_t)(std::upper_bound(off.begin(), off.end(), a) - off.begin()) - 1;
+                while (a < b) {
+                    const size_t take = std::min(b, off[q + 1]) - a;
+                    memcpy(pinned + a, copies[q].src + (a - off[q]), take * 8);
+                    a += take; q++;
+                }
+            }
+            for (size_t q = 0; q < copies.size(); q++) copies[q].src = pinned + off[q];
+        }
+        for (auto& cp : copies) hip_check(hipMemcpyAsync(cp.dst, cp.src, cp.len * 8, hipMemcpyHostToDevice, st), "upload input");
     }
     if (upload_ms && sync) hip_check(hipStreamSynchronize(st), "upload sync");   // (only to split the two timings)
     double t1 = wall_ms();
@@ -2529,6 +2554,7 @@ void values_free(hg_values* v) {
 static void enqueue_prove(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, Prover* P, int world, bool exchange) {
     const Params& p = pk->params;
     P->stamp("start");
+    if (world == 1) P->res_used = v->res_base;
     // (a sharded prove's result-buffer prefix was cleared by the Prover's first launch)
     const bool hinted = ctx->res_hint_serial == pk->serial && ctx->res_hint > 0 && ctx->res_hint <= ctx->res_cap;
     // "eval output" (sk_encryption_circuit.rs:444-448): point, ct0is MLE value
@@ -2666,8 +2692,8 @@ void prove_cache_forget_values(hg_ctx* ctx, uint64_t values_serial) {
     es.erase(std::remove_if(es.begin(), es.end(), [values_serial](const std::shared_ptr<ProveCache>& e) { return e->values_serial == values_serial; }), es.end());
 }
 static bool graph_allowed(const hg_ctx* ctx) {
-    static const bool off = [] { const char* e = getenv("HG_NO_GRAPH"); return e && e[0] == '1'; }();
-    return !off && getenv("HG_PROOF_MAP") == nullptr && ctx->use_graph && ctx->prof_level == 0 && ctx->d_res == ctx->h_res;
+    static const bool off = hg_env_on("HG_NO_GRAPH");
+    return !off && hg_proof_map_path() == nullptr && ctx->use_graph && ctx->prof_level == 0 && ctx->d_res == ctx->h_res;
 }
 // launches the cached graph, waits, replays the transcript
 // the launch alone (nothing waits): ev_a, the graph, [the collective], ev_b on the prover stream
@@ -2688,13 +2714,14 @@ static void cache_launch(hg_ctx* ctx, ProveCache* C, bool exchange) {
     if (exchange) comm_allreduce_results(ctx, C->P->res_used);   // the one collective of a sharded proof, behind the replayed graph
     hip_check(hipEventRecord(C->ev_b, ctx->stream), "event record");
 }
-static ProveResult prove_from_cache(hg_ctx* ctx, ProveCache* C, bool exchange = false, bool replay_now = true, bool launched = false, double t_launch = 0) {
+// (`launched`: cache_launch has been called; `behind`: and other work may have been enqueued behind it - wait for THIS graph's event)
+static ProveResult prove_from_cache(hg_ctx* ctx, ProveCache* C, bool exchange = false, bool replay_now = true, bool launched = false, double t_launch = 0, bool behind = false) {
     ProveResult res;
     const double t0 = launched ? t_launch : wall_ms();
     if (!launched) cache_launch(ctx, C, exchange);
     Prover* P = C->P.get();
     P->st = ctx->stream;
-    P->sync_results();
+    P->sync_results(behind ? C->ev_b : nullptr);
     float gms = 0;
     (void)hipEventElapsedTime(&gms, C->ev_a, C->ev_b);
     // the first replays are checked against the plain launches this graph recorded: a graph that is clearly slower is given up
@@ -2846,34 +2873,58 @@ std::vector<ProveResult> prove_stream(hg_ctx* ctx, const hg_pk* pk, const std::v
         for (auto& v : ctx->stream_values) { values_free(v); v = nullptr; }
     if (!ctx->stream_values[0]) {
         for (auto& v : ctx->stream_values) v = values_alloc(ctx, pk);
+        ctx->stream_values[1]->res_base = ctx->res_cap / 2;
         ctx->stream_values_serial = pk->serial;
     }
     std::vector<ProveResult> out(ws.size());
     if (ws.empty()) return out;
     hg_values** V = ctx->stream_values;
+    {   // pinned staging, one buffer per table set (kept with the context)
+        size_t words = V[0]->ct0is_len;
+        for (int id : pk->circuit.input_ids) words += V[0]->sizes[id];
+        if (ctx->stream_pinned_words < words) {
+            for (auto& p : ctx->stream_pinned) { if (p) (void)hipHostFree(p); p = nullptr; }
+            for (auto& p : ctx->stream_pinned) hip_check(hipHostMalloc((void**)&p, words * 8, hipHostMallocDefault), "hipHostMalloc(witness staging)");
+            ctx->stream_pinned_words = words;
+        }
+    }
     double wm = 0, um = 0;
-    witness_fill(ctx, pk, *ws[0], V[0], ctx->stream3, false, &wm, &um);
+    witness_fill(ctx, pk, *ws[0], V[0], ctx->stream3, false, &wm, &um, ctx->stream_pinned[0]);
     hip_check(hipEventRecord(ctx->ev_ready[0], ctx->stream3), "event record");
+    // Steady state (both table sets have their launch graph): prove i is launched BEHIND prove i-1 before the host waits for i-1 and
+    // replays its transcript - the two write different halves of the result buffer (hg_values::res_base) - so the GPU goes from one
+    // prove straight into the next and the replay (0.1 ms) and the launch overlap a running prove; witness i+1 is staged and uploaded
+    // into the table set prove i-1 has just released.
+    struct Pending { std::shared_ptr<ProveCache> C; size_t idx = 0; double t0 = 0; } pend;
+    auto finish = [&] {
+        if (!pend.C) return;
+        out[pend.idx] = prove_from_cache(ctx, pend.C.get(), false, true, true, pend.t0, true);
+        pend.C = nullptr;
+    };
     for (size_t i = 0; i < ws.size(); i++) {
         const int cur = (int)(i & 1), nxt = cur ^ 1;
         hip_check(hipStreamWaitEvent(ctx->stream, ctx->ev_ready[cur], 0), "wait for the witness");
         auto fill_next = [&] {
             if (i + 1 >= ws.size()) return;
             // (V[nxt] was last read by prove i-1, which has completed: its results were waited for)
-            witness_fill(ctx, pk, *ws[i + 1], V[nxt], ctx->stream3, false, &wm, &um);
+            // (... and so has the DMA out of stream_pinned[nxt], which preceded that table set's evaluation)
+            witness_fill(ctx, pk, *ws[i + 1], V[nxt], ctx->stream3, false, &wm, &um, ctx->stream_pinned[nxt]);
             hip_check(hipEventRecord(ctx->ev_ready[nxt], ctx->stream3), "event record");
         };
         std::shared_ptr<ProveCache> C = graph_allowed(ctx) ? cache_find(ctx, pk, V[cur], 0, 1) : nullptr;
         if (C && !(ctx->slow_graph_serial == pk->serial && ctx->slow_graph_share == 1)) {
             const double t0 = wall_ms();
-            cache_launch(ctx, C.get(), false);
-            fill_next();                                   // host staging + the third stream's work, under the replayed graph
-            out[i] = prove_from_cache(ctx, C.get(), false, true, true, t0);
+            cache_launch(ctx, C.get(), false);             // (behind prove i-1 on the prover stream, if that one is still pending)
+            finish();                                      // prove i-1: wait for its own event, replay - under prove i
+            fill_next();                                   // host staging + the third stream's work, under prove i as well
+            pend.C = C; pend.idx = i; pend.t0 = t0;
         } else {
+            finish();
             fill_next();
             out[i] = prove_resident(ctx, pk, V[cur]);      // walks (and records the graph on the third prove of this table set)
         }
     }
+    finish();
     hip_check(hipStreamSynchronize(ctx->stream3), "stream3");
     if (total_ms) *total_ms = wall_ms() - t_all;
     return out;

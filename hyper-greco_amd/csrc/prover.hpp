@@ -53,6 +53,8 @@ struct hg_ctx {
     hipEvent_t ev_ready[2] = {nullptr, nullptr};
     hg_values* stream_values[2] = {nullptr, nullptr};
     uint64_t stream_values_serial = 0;     // key serial they were laid out for
+    hg::u64* stream_pinned[2] = {nullptr, nullptr};   // pinned staging of one witness each (hg_prove_stream): host arrays are pageable
+    size_t stream_pinned_words = 0;
     hg_values* scratch_values = nullptr;   // hg_prove's resident tables, refilled in place per call (so its launch graph survives)
     uint64_t scratch_serial = 0;           // key serial they were laid out for
     uint64_t no_graph_serial = 0;          // key whose graph capture failed: its proves walk (no retry)
@@ -186,6 +188,9 @@ struct hg_values {
     bool with_ct0is = true;
     hg_values* eval_cone = nullptr;
     size_t cone_bytes = 0;                 // bytes of eval_cone (tables + NTT scratch): resident_bytes + cone_bytes = the rank's peak
+    // first result slot of this object's one-rank proves (hg_prove_stream: its second table set writes the upper half of the
+    // result buffer, so that a proof can be replayed on the host while the next prove - of the other set - already runs)
+    size_t res_base = 0;
 };
 
 namespace hg {

@@ -603,7 +603,7 @@ struct SeqProver {
         hip_check(hipMemsetAsync(d_chain, 0, chain_cap * sizeof(E2), st), "clear challenge table");
         for (E2* pbuf : {ctx->d_partials, ctx->d_partials2})
             hip_check(hipMemsetAsync(reinterpret_cast<char*>(pbuf) + dev::PARTIALS_E2 * sizeof(E2), 0, dev::PARTIALS_TICKETS * sizeof(unsigned), st), "clear reduction tickets");
-        static const bool no_mail = [] { const char* e = getenv("HG_SEQ_NO_MAIL"); return e && e[0] == '1'; }();
+        static const bool no_mail = hg_env_on("HG_SEQ_NO_MAIL");
         use_mail = !no_mail && ctx->d_res == ctx->h_res;   // (the sums must land in host memory without a copy)
         if (use_mail) {
             // the mailbox and, behind it, the buffer through which the last tables of a sum-check travel to the host (host_tail)
@@ -648,7 +648,7 @@ struct SeqProver {
         if (slow_log && now_ms() - t0 > 3.0) fprintf(stderr, "[hg] slow: waited %.2f ms for message %llu (%s)\n", now_ms() - t0, seq, where);
     }
     const char* where = "";
-    bool slow_log = getenv("HG_SEQ_TIMES") != nullptr;
+    bool slow_log = hg_times("seq");
     struct Slow {   // reports a host-side step that took more than 3 ms (HG_SEQ_TIMES=1)
         SeqProver* P; const char* what; double t0;
         Slow(SeqProver* p, const char* w) : P(p), what(w), t0(now_ms()) {}
@@ -677,7 +677,7 @@ struct SeqProver {
     }
     bool ext_mc() const { return (mode & 2) != 0; }
     // HG_SEQ_CLASSIC=1: the fast path's round kernels run twice per round (sums, then the fold once the challenge is known)
-    static bool classic() { static const bool c = [] { const char* e = getenv("HG_SEQ_CLASSIC"); return e && e[0] == '1'; }(); return c; }
+    static bool classic() { static const bool c = hg_env_on("HG_SEQ_CLASSIC"); return c; }
     E2* d_res() { return ctx->d_res; }
     const E2* h_res() { return ctx->h_res; }
     size_t slot(size_t n) {
@@ -1519,17 +1519,17 @@ ProveResult prove_resident_mode_sharded(hg_ctx* ctx, const hg_pk* pk, const hg_v
     res.sync_ms = (double)P.n_sync;  // number of synchronisations (reported through hg_timings::sync_ms in this mode)
     res.enqueue_ms = (double)P.n_mail;  // ... and of mailbox round trips (hg_timings::enqueue_ms in this mode)
     res.replay_ms = (double)P.n_reduce; // ... and of all-reduces (sharded form; hg_timings::replay_ms in this mode)
-    if (getenv("HG_SEQ_TIMES"))
+    if (hg_times("seq"))
         fprintf(stderr, "[hg] mode %d: %.2f ms; host waited %.2f ms for round sums (%zu round trips), %.2f ms for other results, spent %.2f ms enqueueing rounds\n", mode,
                 res.prove_ms, P.t_wait_rounds, P.n_mail, P.t_wait_results, P.t_enqueue_rounds);
-    if (getenv("HG_SEQ_TIMES")) fprintf(stderr, "[hg]   host transcript steps between 'sums seen' and 'challenge posted': %.2f ms in total\n", P.t_answer);
-    if (getenv("HG_SEQ_TIMES")) fprintf(stderr, "[hg]   rounds finished on the host: %zu in %.2f ms, after waiting %.2f ms for their tables\n", P.n_host_rounds, P.t_host_tail, P.t_wait_export);
+    if (hg_times("seq")) fprintf(stderr, "[hg]   host transcript steps between 'sums seen' and 'challenge posted': %.2f ms in total\n", P.t_answer);
+    if (hg_times("seq")) fprintf(stderr, "[hg]   rounds finished on the host: %zu in %.2f ms, after waiting %.2f ms for their tables\n", P.n_host_rounds, P.t_host_tail, P.t_wait_export);
 #ifdef HG_SEQ_STAMPS
     if (P.mail && P.mail->dbg[3])
         fprintf(stderr, "[hg]   device clocks per round, posting workgroup (us): kernel start -> challenge in hand %.2f, -> sums %.2f, -> tagged stores issued %.2f (%llu rounds)\n",
                 P.mail->dbg[0] / 100.0 / P.mail->dbg[3], P.mail->dbg[1] / 100.0 / P.mail->dbg[3], P.mail->dbg[2] / 100.0 / P.mail->dbg[3], P.mail->dbg[3]);
 #endif
-    if (getenv("HG_SEQ_TIMES"))
+    if (hg_times("seq"))
         for (int kd = 0; kd < 3; kd++)
             fprintf(stderr, "[hg]   kind %d: %zu one-workgroup rounds %.2f ms, %zu larger rounds %.2f ms\n", kd, P.n_kind[kd][0], P.t_kind[kd][0], P.n_kind[kd][1], P.t_kind[kd][1]);
     if (P.mail && P.mail->timeouts) throw Error("mailbox: a device-side wait timed out");

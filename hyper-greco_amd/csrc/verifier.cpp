@@ -602,7 +602,7 @@ static std::string verify_impl(const Params& p, const LassoPlan& lp, const HCirc
             }
         }
         if (bad >= 0) throw Reject("input claim mismatch at input " + std::to_string(bad));
-        if (getenv("HG_VERIFY_TIMES"))
+        if (hg_times("verify"))
             fprintf(stderr, "[hg] verify: %.1f ms (vanilla nodes %.1f, fft nodes %.1f, lasso node %.1f, %zu input claims %.1f)\n", (omp_get_wtime() - tv0) * 1e3,
                     t_kind[0] * 1e3, t_kind[1] * 1e3, t_kind[2] * 1e3, checks.size(), (omp_get_wtime() - t_checks) * 1e3);
         return "";

@@ -201,7 +201,7 @@ struct DevBackend : VerifyBackend {
     }
     int mle_ct0is(size_t point_off, int nvars) override { return mle_u64(d_ct0is, point_off, nvars); }
     void finish() override {
-        static const bool times = getenv("HG_VERIFY_TIMES") != nullptr;
+        static const bool times = hg_times("verify");
         const double t0 = times ? omp_get_wtime() : 0;
         if (times) { hip_check(hipStreamSynchronize(st), "sync"); fprintf(stderr, "[hg] verify_device: uploads drained %.2f ms after the walk ended; %zu eq tables, %zu gathers, %zu + %zu, %zu dots\n", (omp_get_wtime() - t0) * 1e3, eqs.size(), gts.size(), gbs.size(), ffts.size(), dots.size()); }
         auto lap = [&](const char* what) { if (times) { hip_check(hipStreamSynchronize(st), "sync"); fprintf(stderr, "[hg] verify_device: %8.2f ms  %s\n", (omp_get_wtime() - t0) * 1e3, what); } };
@@ -251,7 +251,7 @@ struct DevBackend : VerifyBackend {
 // public inputs and ct0is are uploaded (22 MB at n=32768 k=16), the proof is parsed on the host; "" = accepted
 std::string verify_proof_device(hg_ctx* ctx, const hg_pk* pk, const Witness& w, const uint8_t* proof, size_t len) {
     const double tv0 = omp_get_wtime();
-    struct Total { double t0; ~Total() { if (getenv("HG_VERIFY_TIMES")) fprintf(stderr, "[hg] verify_device: %.2f ms in all\n", (omp_get_wtime() - t0) * 1e3); } } total{tv0};
+    struct Total { double t0; ~Total() { if (hg_times("verify")) fprintf(stderr, "[hg] verify_device: %.2f ms in all\n", (omp_get_wtime() - t0) * 1e3); } } total{tv0};
     hip_check(hipSetDevice(ctx->device), "hipSetDevice");
     ctx->arena_reset();
     // Rejection is a normal outcome and leaves kernels and staged descriptor copies queued (the walk returns from the middle of the
@@ -279,7 +279,7 @@ std::string verify_proof_device(hg_ctx* ctx, const hg_pk* pk, const Witness& w, 
     for (int i = 0; i < p.k; i++) D.d_inputs.push_back(up(&w.r1is[(size_t)i * SZ], SZ));
     D.d_inputs.push_back(up(w.r2is.data(), w.r2is.size()));
     D.d_ct0is = up(w.ct0is.data(), w.ct0is.size());
-    if (getenv("HG_VERIFY_TIMES")) fprintf(stderr, "[hg] verify_device: inputs enqueued at %.2f ms\n", (omp_get_wtime() - tv0) * 1e3);
+    if (hg_times("verify")) fprintf(stderr, "[hg] verify_device: inputs enqueued at %.2f ms\n", (omp_get_wtime() - tv0) * 1e3);
     return verify_proof_with(D, p, pk->lasso, pk->circuit, proof, len);
 }
 

@@ -1438,7 +1438,7 @@ def test_eq_factored_rounds_are_the_path_that_runs():
 @pytest.mark.gpu
 def test_slot_form_is_the_path_that_runs():
     """The slot form of grand product #1 must actually be taken where it applies - otherwise the switch tests above would
-    compare the memory form with itself. HG_DEBUG=slots makes the library report the layers it adopted; HG_BN_TIMES=1 the bn254 prove's."""
+    compare the memory form with itself. HG_DEBUG=slots makes the library report the layers it adopted; HG_TIMES=bn the bn254 prove's."""
     import subprocess, sys
     from hglib import ROOT
     code = (
@@ -1451,7 +1451,7 @@ def test_slot_form_is_the_path_that_runs():
         "ctx.prove_bn254(pk, w, cap=1 << 24)\n"
         "print('RAN')\n"
     ) % (ROOT,)
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, HG_DEBUG="slots", HG_BN_TIMES="1"), cwd=ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, HG_DEBUG="slots", HG_TIMES="bn"), cwd=ROOT)
     assert r.returncode == 0 and "RAN" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
     adopted = [l for l in r.stderr.splitlines() if l.startswith("[hg slots] adopted:")]
     assert adopted and int(adopted[0].split()[3]) >= 2, r.stderr[-2000:]          # the top layer and at least one below it
