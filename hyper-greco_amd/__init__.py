@@ -647,6 +647,11 @@ def fold(ctx, table, is_base, r):
     return out.reshape(-1, 2)
 
 
+def device_count():
+    """hg_device_count: HIP devices visible to this process (0 without a GPU)."""
+    return int(lib().hg_device_count())
+
+
 def comm_unique_id():
     """hg_comm_unique_id: the 128-byte RCCL id rank 0 shares with the other ranks."""
     buf = (C.c_uint8 * 128)()

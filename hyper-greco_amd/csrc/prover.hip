@@ -206,7 +206,10 @@ ShardPlan shard_plan(const hg_pk* pk, int rank, int world) {
         if (n.kind == NK_VANILLA) {
             int np = 0;
             for (int i = 0; i < n.arity; i++) np += n.left_use[i] + n.right_use[i];
-            items.push_back({(double)np * (double)((size_t)1 << (n.log2_sub_in + n.log2_reps)) * 12.0 + 3.0 * (double)((size_t)1 << n.log2_out()), (int)id});
+            // (a node whose Libra tables are eq slices - hg_pk::NodeDev::EqForm - builds no table and folds only its inputs)
+            const bool eqf = id < pk->node_dev.size() && pk->node_dev[id].eq_form.ok;
+            const double in_sz = (double)((size_t)1 << (n.log2_sub_in + n.log2_reps));
+            items.push_back({eqf ? (double)np * in_sz * 4.0 : (double)np * in_sz * 12.0 + 3.0 * (double)((size_t)1 << n.log2_out()), (int)id});
         }
     }
     std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.cost > b.cost; });

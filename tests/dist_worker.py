@@ -13,7 +13,10 @@ mode "prove_c3" (needs a GPU; both ranks on device 0): the same at BASELINE conf
 mode "prove_seq" (needs a GPU; both ranks on device 0): the round-by-round prover of protocol mode 3 (absorbing transcript +
     extension-field memory checking) on two processes, ONE all-reduce per sum-check round (hg_prove_resident_mode_sharded with an
     external group: the six words of a round's partial sums are all-gathered over gloo and added mod p); n=1024 k=1 and n=4096 k=2,
-    every rank's proof must be the CPU oracle's proof of that mode."""
+    every rank's proof must be the CPU oracle's proof of that mode.
+mode "prove_rccl" (needs TWO GPUs: rank r on device r): hg_prove_sharded - the library's own ncclAllReduce of the result buffer over
+    xGMI behind each rank's share, per-rank tables (hg_witness_gen_shard) - at n=4096 k=2 and n=32768 k=16; gloo only carries the
+    128-byte RCCL id. Every rank's proof must be the CPU oracle's. (RCCL refuses two ranks on one device, so this cannot be faked.)"""
 import os
 import sys
 
@@ -141,6 +144,33 @@ def main():
             vals.free(); pk.free()
         dist.barrier()
         print("rank %d PROVE_SEQ OK (%d all-reduces for the last proof)" % (rank, calls[0]), flush=True)
+        ctx.close()
+    elif mode == "prove_rccl":
+        import orclib
+        assert hg.device_count() >= world, "prove_rccl needs one GPU per rank"
+        ctx = hg.Context(rank)
+        uid = [hg.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        hg.comm_init(ctx, uid[0], rank, world)
+        assert hg.comm_count(ctx) == world
+        for n, k in ((4096, 2), (32768, 16)):
+            bfv = hg.BfvEncrypt.new(n, k)
+            pk = bfv.setup(ctx)
+            ws = [hg.Witness.synthetic(bfv.params, 0x81 + j + n) for j in range(2)]
+            threads = max(2, min(16, (os.cpu_count() or 4) // world))
+            refs = [orclib.prove(orclib.params(n, k), orclib.Inputs(w.arrays()), threads=threads)[0] for w in ws]
+            vals = hg.witness_gen_shard(ctx, pk, ws[0], rank, world)
+            out = hg.ProofBuffer()
+            for it in range(5):      # walk, walk, capture, then the second witness through the same graph, twice
+                j = 0 if it < 3 else 1
+                if it == 3:
+                    hg.witness_gen_into(ctx, pk, ws[1], vals)
+                got = hg.prove_sharded(ctx, pk, vals, out).bytes()
+                assert got == refs[j], "rank %d, n=%d, proof %d: the proof sharded over RCCL differs from the CPU oracle" % (rank, n, it)
+            vals.free(); pk.free()
+        dist.barrier()
+        hg.comm_destroy(ctx)
+        print("rank %d PROVE_RCCL OK" % rank, flush=True)
         ctx.close()
     else:
         raise SystemExit("unknown mode")

@@ -75,3 +75,19 @@ def test_round_by_round_prover_two_processes_one_allreduce_per_round():
     out = _launch([os.path.join(ROOT, "tests", "dist_worker.py"), "prove_seq"], 29525, 900)
     assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-3000:])
     assert out.stdout.count("PROVE_SEQ OK") == 2, out.stdout
+
+
+@pytest.mark.gpu
+def test_sharded_prove_over_real_rccl_two_gpus():
+    """hg_prove_sharded over the library's own RCCL communicator with TWO ranks on TWO GPUs (tests/dist_worker.py "prove_rccl"; the
+    all-reduce of the result buffer crosses xGMI), n=4096 k=2 and n=32768 k=16 with per-rank tables, both ranks' proofs equal to the
+    oracle's. Skipped on a one-GPU box: RCCL refuses two ranks on one device ("Duplicate GPU detected"), so there is nothing to fake.
+    The device count is read in a child process - the test process itself never initialises a GPU ahead of the torchrun launch."""
+    r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); import __graft_entry__ as e; print(e.load_package().device_count())" % ROOT],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    if int(r.stdout.strip().splitlines()[-1]) < 2:
+        pytest.skip("needs two GPUs (this box has %s)" % r.stdout.strip().splitlines()[-1])
+    out = _launch([os.path.join(ROOT, "tests", "dist_worker.py"), "prove_rccl"], 29527, 1800)
+    assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-3000:])
+    assert out.stdout.count("PROVE_RCCL OK") == 2, out.stdout
