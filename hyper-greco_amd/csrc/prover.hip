@@ -206,10 +206,10 @@ ShardPlan shard_plan(const hg_pk* pk, int rank, int world) {
         if (n.kind == NK_VANILLA) {
             int np = 0;
             for (int i = 0; i < n.arity; i++) np += n.left_use[i] + n.right_use[i];
-            // (a node whose Libra tables are eq slices - hg_pk::NodeDev::EqForm - builds no table and folds only its inputs)
-            const bool eqf = id < pk->node_dev.size() && pk->node_dev[id].eq_form.ok;
-            const double in_sz = (double)((size_t)1 << (n.log2_sub_in + n.log2_reps));
-            items.push_back({eqf ? (double)np * in_sz * 4.0 : (double)np * in_sz * 12.0 + 3.0 * (double)((size_t)1 << n.log2_out()), (int)id});
+            // (the eq-factored nodes - hg_pk::NodeDev::EqForm - are cheaper than this says, but pricing them so dealt a rank nodes of
+            // every modulus chain: no faster in the one-GPU projection, 1.31 / 1.42 against 1.38 / 1.34 ms on two ranks, and the rank's
+            // evaluation cone became the whole circuit)
+            items.push_back({(double)np * (double)((size_t)1 << (n.log2_sub_in + n.log2_reps)) * 12.0 + 3.0 * (double)((size_t)1 << n.log2_out()), (int)id});
         }
     }
     std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.cost > b.cost; });
@@ -1525,7 +1525,7 @@ struct Prover {
             dev::lasso_counters_all(st, L, mask, dims, co, temp, tb, keys, keys2, rows, rows2, starts);
             ctx->prof_end();
             stamp("counters done");
-            if (use_aux) { hip_check(hipEventRecord(ctx->ev_aux[3], st), "lasso: counters event"); counters_event_recorded = true; }
+            if (use_aux) { hip_check(hipEventRecord(ctx->ev_aux[3], st), "lasso: counters event"); counters_event_recorded = true; counters_event_live = true; }
         });
         // the collation rounds are launched now, not with the grand products at the end of the node: the host still has the whole
         // memory-checking bookkeeping to walk (about 0.5 ms) and the main stream would sit idle meanwhile; behind the counters, so
@@ -2151,12 +2151,15 @@ struct Prover {
     // The node reductions on the THIRD stream (the collation rounds' - a few launches at the start of the prove): they then start with
     // the prove instead of behind the Lasso node's second-stream work (counters, grand product #2's tree, opening tables: 0.6 ms),
     // into the idle capacity those latency-bound launches leave.
-    bool nodes_on_col = false;
+    bool nodes_on_col = false, counters_event_live = false;   // (the second: ev_aux[3] was recorded by this prove's Lasso node)
     void fork_nodes_stream() {
         if (!fork_recorded) return;
         hip_check(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0), "fork wait");
         if (world == 1 && late_aux.empty()) {
             hip_check(hipStreamWaitEvent(ctx->stream_col, ctx->ev_fork, 0), "fork wait");
+            // (behind the counters of the second stream: the first hash round waits for those, and the node reductions' first launches
+            // beside them only stretch that wait - 1.79 against 1.81 ms)
+            if (counters_event_live) hip_check(hipStreamWaitEvent(ctx->stream_col, ctx->ev_aux[3], 0), "node reductions: wait for the counters");
             st = ctx->stream_col; partials = ctx->d_partials3; ctx->prof_stream = st; forked = true; nodes_on_col = true;
             return;
         }
