@@ -54,7 +54,7 @@ __device__ __forceinline__ E2 block_sum(E2 v, E2* sm) {
 // launch shapes (the measured best on MI355X)
 // (measured at n=32768 k=16: 32768 / 131072 / 262144 threads 2.05 / 2.04 / 2.14 against 1.97 ms; 1024 / 256 workgroups 1.99 / 2.11 against 1.97)
 static size_t st_min_threads() { return 65536; }
-static int st_max_blocks() { return 512; }
+static int st_max_blocks() { return 512; }   // (384 / 768 / 1024 in round 5: 1.894 / 1.785 / 1.812 against 1.797 ms)
 
 static inline int grid_for(size_t work_items) {
     size_t b = (work_items + TPB - 1) / TPB;
