@@ -37,7 +37,7 @@ class HgKernelStat(C.Structure):
 
 EXPORTS = [
     "hg_last_error", "hg_device_count", "hg_create", "hg_destroy", "hg_set_option", "hg_params_builtin", "hg_params_derive", "hg_grand_product", "hg_fold", "hg_setup", "hg_pk_free",
-    "hg_pk_lasso_layout", "hg_pk_info", "hg_witness_from_json", "hg_witness_synthetic", "hg_witness_from_arrays",
+    "hg_pk_lasso_layout", "hg_pk_info", "hg_pk_node_eq_form", "hg_witness_from_json", "hg_witness_synthetic", "hg_witness_from_arrays",
     "hg_witness_get", "hg_witness_free", "hg_prove", "hg_prove_stream", "hg_verify", "hg_verify_device", "hg_prove_mode", "hg_prove_resident_mode", "hg_verify_mode", "hg_group_local", "hg_group_external", "hg_group_free", "hg_prove_resident_mode_sharded", "hg_witness_gen", "hg_witness_gen_into", "hg_witness_gen_shard", "hg_values_info", "hg_values_peak_bytes", "hg_values_free", "hg_values_get", "hg_comm_unique_id", "hg_comm_init", "hg_comm_destroy", "hg_comm_count", "hg_comm_selftest", "hg_prove_sharded", "hg_prove_shard_begin", "hg_prove_shard_combine", "hg_prove_shard_finish", "hg_shard_combine_host", "hg_prove_resident", "hg_circuit_eval", "hg_lasso_prove", "hg_lasso_prove_at", "hg_lasso_num_challenges", "hg_sumcheck", "hg_mle_eval",
     "hg_ntt", "hg_challenges", "hg_challenges_bn254", "hg_bn254_field_op", "hg_sumcheck_bn254", "hg_grand_product_bn254", "hg_lasso_prove_bn254", "hg_witness_from_json_bn254", "hg_circuit_eval_bn254", "hg_prove_bn254", "hg_verify_bn254", "hg_mle_eval_bn254", "hg_ntt_bn254", "hg_profile", "hg_profile_select", "hg_profile_reset", "hg_profile_get",
 ]
@@ -371,6 +371,15 @@ class ProverKey:
         _check(lib().hg_pk_lasso_layout(self.h, buf, 1 << 16))
         mems, lk = buf.value.decode().split("|")
         return mems.split(","), lk.split(";")
+
+    def node_eq_form(self, node):
+        """hg_pk_node_eq_form: how setup classified a node - dict(kind, eq_form, block_log2, window, terms, in_log2)."""
+        out = (C.c_int64 * 6)()
+        L = lib()
+        L.hg_pk_node_eq_form.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]
+        _check(L.hg_pk_node_eq_form(self.h, int(node), out))
+        return {"kind": ("input", "vanilla", "fft", "lasso")[int(out[0])], "eq_form": bool(out[1]), "block_log2": int(out[2]), "window": int(out[3]),
+                "terms": int(out[4]), "in_log2": int(out[5])}
 
     def circuit_eval(self, w):
         lasso_in = np.zeros(1 << self.nu, dtype=np.uint64)

@@ -381,6 +381,21 @@ int hg_pk_info(const hg_pk* pk, uint64_t out[6]) {
     return 0;
 }
 
+int hg_pk_node_eq_form(const hg_pk* pk, int node, int64_t out[6]) {
+    if (!pk || !out) { g_last_error = "hg_pk_node_eq_form: null argument"; return -1; }
+    if (node < 0 || (size_t)node >= pk->circuit.nodes.size()) { g_last_error = "hg_pk_node_eq_form: no such node"; return -1; }
+    const HNode& n = pk->circuit.nodes[node];
+    out[0] = n.kind == NK_VANILLA ? 1 : (n.kind == NK_FFT ? 2 : (n.kind == NK_LASSO ? 3 : 0));
+    out[1] = out[2] = out[3] = out[4] = out[5] = 0;
+    if (n.kind != NK_VANILLA) return 0;
+    const hg_pk::NodeDev::EqForm& ef = pk->node_dev[node].eq_form;
+    out[1] = ef.ok ? 1 : 0;
+    out[2] = ef.w; out[3] = ef.hib;
+    for (auto& t : ef.terms) out[4] += (int64_t)t.size();
+    out[5] = n.log2_sub_in + n.log2_reps;
+    return 0;
+}
+
 int hg_witness_from_json(const hg_params* params, const char* path, hg_witness** w) {
     HG_TRY
     if (!params || !path || !w) throw Error("hg_witness_from_json: null argument");

@@ -96,6 +96,11 @@ void hg_pk_free(hg_pk* pk);
 int hg_pk_lasso_layout(const hg_pk* pk, char* out, size_t cap);
 /* [nu, num_nodes, rows, alpha, NodeId of lasso_inputs_batched, NodeId of sum] */
 int hg_pk_info(const hg_pk* pk, uint64_t out[6]);
+/* How hg_setup classified one node of the circuit (for tests; host-only keys too): [kind (0 input, 1 Vanilla, 2 FFT, 3 Lasso),
+ * eq-factored form found (every Libra phase-1 table of the node is a constant times an eq table: VanillaNode wirings that relay aligned
+ * blocks, sk_encryption_circuit.rs:97-285), log2 of the relayed block, index of the input window, number of (coefficient, gate block)
+ * terms, log2 of the input size]. Whether a prove uses the form also depends on the node having ONE claim and on its size. */
+int hg_pk_node_eq_form(const hg_pk* pk, int node, int64_t out[6]);
 
 /* = serde_json::from_str::<BfvSkEncryptArgs> + BfvEncrypt::get_inputs / Poly::{new,new_padded,new_shifted}
  *   [REF bfv-gkr/src/test.rs:21-33, sk_encryption_circuit.rs:365-415, poly.rs:12-44] */

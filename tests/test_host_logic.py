@@ -429,3 +429,28 @@ def test_reference_baseline_leaves_the_reference_fixture_as_it_was(tmp_path, mon
     # a configuration whose fixture is a missing blob: nothing is left behind
     assert reference_baseline.measure(2048, 1, 5, runs=1) is None
     assert not (data / "sk_enc_2048_1x52_65537.json").exists()
+
+
+def test_setup_finds_the_eq_factored_nodes():
+    """hg_setup's classification of the Vanilla nodes (hg_pk::NodeDev::EqForm, host-only key): the wirings of BfvEncryptBlock::configure
+    [REF sk_encryption_circuit.rs:97-285] that relay aligned blocks - es, k1kis (k blocks of one input each), r1iqis (times q_i), the
+    chunk nodes (ONE block, a window of r2is), lasso_inputs_batched (with its additive bounds), s_eval_copy, sai_par and the final sum -
+    are eq-factored; the k sai_eval nodes (mul gates) and r2i_cyclo (two relays per position plus a zero gate) are not."""
+    for n, k in ((1024, 1), (4096, 2), (32768, 16)):
+        bfv = hg.BfvEncrypt.new(n, k)
+        pk = bfv.setup(None)
+        rows = [pk.node_eq_form(i) for i in range(pk.num_nodes)]
+        van = [r for r in rows if r["kind"] == "vanilla"]
+        L = n.bit_length()             # log2_size = N_LOG2 + 1
+        chunks = max(1, (n * k) // (2 * n))   # r2is has n k entries, a chunk node relays 2n of them
+        assert len(van) == 7 + chunks + k + 1, (n, k, len(van))   # es k1kis r1iqis lasso_in s_eval_copy sai_par sum + chunks + sai_eval + cyclo
+        eq = [r for r in van if r["eq_form"]]
+        assert len(eq) == 7 + chunks, (n, k, [(r["in_log2"], r["terms"]) for r in eq])
+        assert len([r for r in van if not r["eq_form"]]) == k + 1
+        lasso_in = rows[pk.lasso_in_id]
+        assert lasso_in["eq_form"] and lasso_in["block_log2"] == L and lasso_in["terms"] == k + chunks + 3 and lasso_in["window"] == 0
+        total = rows[pk.sum_id]
+        assert total["eq_form"] and total["terms"] == 5 and total["block_log2"] == total["in_log2"] == L + (k.bit_length() - 1)
+        wins = sorted(r["window"] for r in eq if r["in_log2"] > r["block_log2"])   # the chunk nodes: window c of the r2is table
+        assert wins == list(range(chunks)) or chunks == 1, (n, k, wins)
+        pk.free()
