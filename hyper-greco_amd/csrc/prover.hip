@@ -726,6 +726,7 @@ static void enqueue_prove(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, Prov
         if (hinted && P->res_used > ctx->res_hint) throw Error("sharded prove: the result buffer grew between two proves of one key");
         ctx->res_hint = P->res_used; ctx->res_hint_serial = pk->serial;
     }
+    if (world == 1 && v->res_limit && P->res_used > v->res_limit) throw Error("hg_prove_stream: a prove's result slots do not fit half of the result buffer");
     P->stamp("end of the prove");
     if (exchange) comm_allreduce_results(ctx, P->res_used);  // the one collective of a sharded proof, on the stream
 }
@@ -1020,6 +1021,7 @@ std::vector<ProveResult> prove_stream(hg_ctx* ctx, const hg_pk* pk, const std::v
         for (auto& v : ctx->stream_values) { values_free(v); v = nullptr; }
     if (!ctx->stream_values[0]) {
         for (auto& v : ctx->stream_values) v = values_alloc(ctx, pk);
+        ctx->stream_values[0]->res_limit = ctx->res_cap / 2;
         ctx->stream_values[1]->res_base = ctx->res_cap / 2;
         ctx->stream_values_serial = pk->serial;
     }

@@ -190,7 +190,7 @@ struct hg_values {
     size_t cone_bytes = 0;                 // bytes of eval_cone (tables + NTT scratch): resident_bytes + cone_bytes = the rank's peak
     // first result slot of this object's one-rank proves (hg_prove_stream: its second table set writes the upper half of the
     // result buffer, so that a proof can be replayed on the host while the next prove - of the other set - already runs)
-    size_t res_base = 0;
+    size_t res_base = 0, res_limit = 0;   // (res_limit != 0: the slots of a prove must end below it - the other table set's half)
 };
 
 namespace hg {
