@@ -84,57 +84,63 @@ template <> struct Val<E2> {
     static __device__ __forceinline__ E2 zero() { return e2_zero(); }
 };
 
-template <typename T>
-__device__ __forceinline__ void load_pair(const T* p, T& x, T& y);
-template <>
-__device__ __forceinline__ void load_pair<u64>(const u64* p, u64& x, u64& y) {
-    ulonglong2 v = *reinterpret_cast<const ulonglong2*>(p);
-    x = v.x; y = v.y;
+// Loads / stores of table entries go through the GLOBAL address space: a pointer read from a job descriptor is generic to hipcc, and a
+// generic access is a flat_load / flat_store - counted by vmcnt AND lgkmcnt and returned out of order, so every wait behind one is
+// `vmcnt(0) lgkmcnt(0)`, and every wait for a scalar load or an LDS read drains the table loads in flight as well. (No table these
+// helpers touch lives in LDS except in k_st_tail, whose rounds run LDS -> LDS through sc_round_body: GIO = false keeps the generic form.)
+typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
+#define HG_GLOBAL(T, p) (reinterpret_cast<__attribute__((address_space(1))) T*>((unsigned long long)(p)))
+template <bool GIO = true>
+__device__ __forceinline__ u64x2_t load16(const void* p) {
+    if constexpr (GIO) return *HG_GLOBAL(const u64x2_t, p);
+    else return *reinterpret_cast<const u64x2_t*>(p);
 }
-template <>
-__device__ __forceinline__ void load_pair<E2>(const E2* p, E2& x, E2& y) {
-    ulonglong2 a = *reinterpret_cast<const ulonglong2*>(p);
-    ulonglong2 b = *reinterpret_cast<const ulonglong2*>(p + 1);
-    x = e2(a.x, a.y); y = e2(b.x, b.y);
+template <bool GIO = true>
+__device__ __forceinline__ void store16(void* p, u64 a, u64 b) {
+    u64x2_t w; w.x = a; w.y = b;
+    if constexpr (GIO) *HG_GLOBAL(u64x2_t, p) = w;
+    else *reinterpret_cast<u64x2_t*>(p) = w;
+}
+template <typename T, bool GIO = true>
+__device__ __forceinline__ void load_pair(const T* p, T& x, T& y) {
+    if constexpr (std::is_same<T, u64>::value) {
+        const u64x2_t v = load16<GIO>(p);
+        x = v.x; y = v.y;
+    } else {
+        const u64x2_t a = load16<GIO>(p), b = load16<GIO>(p + 1);
+        x = e2(a.x, a.y); y = e2(b.x, b.y);
+    }
 }
 // Folded (E2) tables are stored DE-INTERLEAVED: logical entry i of a table of length 2h lives at (i & 1) * h + (i >> 1),
 // so the pair (T[2j], T[2j+1]) the next round needs is (buf[j], buf[h + j]): both loads are 16 B per lane and
 // contiguous across the wave (a 32-B lane stride would halve the useful bytes per load instruction).
 // Round-0 inputs (level rows, node tables, bookkeeping tables) are in natural order.
-template <typename T, bool NATURAL>
+template <typename T, bool NATURAL, bool GIO = true>
 __device__ __forceinline__ void load_xy(const T* tab, size_t j, size_t half, T& x, T& y) {
-    if constexpr (NATURAL || std::is_same<T, u64>::value) load_pair<T>(tab + 2 * j, x, y);
+    if constexpr (NATURAL || std::is_same<T, u64>::value) load_pair<T, GIO>(tab + 2 * j, x, y);
     else {
-        ulonglong2 a = *reinterpret_cast<const ulonglong2*>(tab + j);
-        ulonglong2 b = *reinterpret_cast<const ulonglong2*>(tab + half + j);
+        const u64x2_t a = load16<GIO>(tab + j), b = load16<GIO>(tab + half + j);
         x = e2(a.x, a.y); y = e2(b.x, b.y);
     }
 }
 // position of logical entry j in a de-interleaved table of length `len`
 __device__ __forceinline__ size_t dpos(size_t j, size_t len) { return (j & 1) * (len >> 1) + (j >> 1); }
-__device__ __forceinline__ void store_e2(E2* p, E2 v) {
-    *reinterpret_cast<ulonglong2*>(p) = make_ulonglong2(v.c0, v.c1);
-}
+template <bool GIO = true>
+__device__ __forceinline__ void store_e2(E2* p, E2 v) { store16<GIO>(p, v.c0, v.c1); }
 // streaming store for tables far larger than the caches (the first-round folds of the big layers): measured +5 % on that kernel
+template <bool GIO = true>
 __device__ __forceinline__ void store_e2_nt(E2* p, E2 v) {
-    __builtin_nontemporal_store(v.c0, &p->c0);
-    __builtin_nontemporal_store(v.c1, &p->c1);
+    u64x2_t w; w.x = v.c0; w.y = v.c1;
+    if constexpr (GIO) __builtin_nontemporal_store(w, HG_GLOBAL(u64x2_t, p));
+    else *reinterpret_cast<u64x2_t*>(p) = w;
 }
-
-// loads / stores through the GLOBAL address space: a pointer read from a job descriptor is generic to hipcc (flat_load, which also
-// counts as an LDS access: its waits cover scalar and LDS traffic too)
-typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store_u64x2(u64* p, u64 a, u64 b) { store16<true>(p, a, b); }
 __device__ __forceinline__ E2 gload_e2(const E2* p) {
-    const u64x2_t v = *reinterpret_cast<const __attribute__((address_space(1))) u64x2_t*>((unsigned long long)p);
+    const u64x2_t v = *HG_GLOBAL(const u64x2_t, p);
     return e2(v.x, v.y);
 }
-__device__ __forceinline__ u64 gload_u64(const u64* p) {
-    return *reinterpret_cast<const __attribute__((address_space(1))) u64*>((unsigned long long)p);
-}
-__device__ __forceinline__ void gstore_e2(E2* p, E2 v) {
-    u64x2_t w; w.x = v.c0; w.y = v.c1;
-    *reinterpret_cast<__attribute__((address_space(1))) u64x2_t*>((unsigned long long)p) = w;
-}
+__device__ __forceinline__ u64 gload_u64(const u64* p) { return *HG_GLOBAL(const u64, p); }
+__device__ __forceinline__ void gstore_e2(E2* p, E2 v) { store_e2(p, v); }
 
 // ---- first grand-product round of one table pair on base-field values ---------------------------------------------
 // Accumulates gamma^i * (P0, P1, Pinf) with P0 = xl xr, P1 = yl yr, Pinf = (yl - xl)(yr - xr) (each base product reduced once,
@@ -146,7 +152,7 @@ __device__ __forceinline__ GpFirstAcc gp_first_acc_zero() {
     A.a0 = wacc_zero(); A.b0 = wacc_zero(); A.a1 = wacc_zero(); A.b1 = wacc_zero(); A.ai = wacc_zero(); A.bi = wacc_zero();
     return A;
 }
-template <bool WANT_Q>   // WANT_Q: the products of the two positions are always computed and handed back (slot form: the caller stores them)
+template <bool WANT_Q, bool GIO = true>   // WANT_Q: the products of the two positions are always computed and handed back (slot form: the caller stores them)
 __device__ __forceinline__ void gp_first_pair(GpFirstAcc& A, u64 xl, u64 yl, u64 xr, u64 yr, E2 gm, E2 gr, E2 r, bool summed,
                                               E2* __restrict__ out_l, E2* __restrict__ out_r, u64* __restrict__ nxt, u64& q0, u64& q1) {
     const u64 dl = gl_sub(yl, xl), dr = gl_sub(yr, xr);
@@ -154,7 +160,7 @@ __device__ __forceinline__ void gp_first_pair(GpFirstAcc& A, u64 xl, u64 yl, u64
         // (reading v_l v_r from the tree level above instead of multiplying was measured slower: the
         // first round is bound by its 8-byte-element traffic, not by these products)
         q0 = gl_mul(xl, xr); q1 = gl_mul(yl, yr);
-        if (nxt) *reinterpret_cast<ulonglong2*>(nxt) = make_ulonglong2(q0, q1);
+        if (nxt) store_u64x2(nxt, q0, q1);
         if (summed) {
             const u64 qi = gl_mul(dl, dr);
             wmac2(A.a0, gm.c0, q0, A.b0, gm.c1, q0);
@@ -166,21 +172,114 @@ __device__ __forceinline__ void gp_first_pair(GpFirstAcc& A, u64 xl, u64 yl, u64
     WAcc f0 = wacc_zero(), f1 = wacc_zero(), h0 = wacc_zero(), h1 = wacc_zero();
     wmac_pair(f0, gm.c0, xl, gr.c0, dl);
     wmac_pair(f1, gm.c1, xl, gr.c1, dl);
-    store_e2_nt(out_l, e2(wreduce(f0), wreduce(f1)));
+    store_e2_nt<GIO>(out_l, e2(wreduce(f0), wreduce(f1)));
     h0.L = xr;
     wmac2(h0, r.c0, dr, h1, r.c1, dr);
-    store_e2_nt(out_r, e2(wreduce(h0), wreduce(h1)));
+    store_e2_nt<GIO>(out_r, e2(wreduce(h0), wreduce(h1)));
 }
 // product-tree entries (q0, q1) of positions 2j, 2j + 1 to every row named by `mask` (GpHashSrc::emit_rd, StJob::emit_mask)
 __device__ __forceinline__ void emit_rows(u64* __restrict__ next_level, size_t row_stride, size_t at, u64 mask, ulonglong2 q) {
     while (mask) {
         const int t = __ffsll((long long)mask) - 1;
         mask &= mask - 1;
-        *reinterpret_cast<ulonglong2*>(next_level + (size_t)t * row_stride + at) = q;
+        store_u64x2(next_level + (size_t)t * row_stride + at, q.x, q.y);
     }
 }
 __device__ __forceinline__ void gp_first_acc_reduce(const GpFirstAcc& A, E2& s0, E2& s2, E2& s3) {
     s0 = e2(wreduce(A.a0), wreduce(A.b0)); s2 = e2(wreduce(A.a1), wreduce(A.b1)); s3 = e2(wreduce(A.ai), wreduce(A.bi));
+}
+
+// ---- first grand-product round on base-field rows: the whole round of one workgroup ---------------------------------------------
+// (sc_round_body's FIRST / u64 / grand-product case.) The workgroup's (tile, pair) items form ONE stream: the four values, the two
+// weights and the emit mask of item t+1 are requested before item t is computed on, all through the global address space, so that
+// the waits are counted (`vmcnt(n)`) and nothing of item t waits for a store of item t-1. The first form of this loop asked for the
+// values, waited, asked for the weights (generic loads), waited, computed, stored, asked for the emit mask and waited again, draining
+// its own stores: three memory round trips in series per item, T = T_mem + T_valu (0.38 / 0.40 of the two roofs in round 5).
+// (The weights as scalar loads - the pair index is uniform over a wave when 64 or more threads run along j - were tried: hipcc
+// waits for a scalar load where it is issued, and that latency is then exposed once per item.)
+template <bool SLOT, bool GIO>
+__device__ __forceinline__ void gp_first_round_body(const u64* __restrict__ in, size_t in_stride, E2* __restrict__ out, size_t out_stride, int ntab, size_t half, E2 r,
+                                                    const E2* __restrict__ pw, const E2* __restrict__ pwr, int jb_log2, E2* __restrict__ red, E2* acc,
+                                                    size_t first_tile, size_t tile_step, bool p0_only, u64* __restrict__ next_level, const StJob* __restrict__ mirror) {
+    const int BD = blockDim.x, tid = threadIdx.x;
+    const int G = BD >> jb_log2;
+    const int jj = tid & ((1 << jb_log2) - 1), g = tid >> jb_log2;
+    const size_t ntiles = half >> jb_log2;
+    const int nb = ntab >> 1;
+    // (descriptor fields read once: behind the loop's stores hipcc reloads them every iteration)
+    const E2* __restrict__ slotw = SLOT ? mirror->slotw : nullptr;
+    // (no next level: the mask is loaded all the same - from the weights, any readable words - and ignored; see the loop)
+    const u64* __restrict__ emask = !SLOT ? nullptr : next_level ? mirror->emit_mask : reinterpret_cast<const u64*>(mirror->slotw);
+    const int slot_ng = SLOT ? mirror->slot_ng : 0, slot_shift = SLOT ? mirror->slot_shift : 0;
+    struct Item { u64 xl, yl, xr, yr; E2 gm, gr; u64 em; };
+    auto any_item = [] {   // "no value yet" without an instruction (and without a dependence on the loads of the item in flight)
+        const u64 z = 0, u = __builtin_nondeterministic_value(z);
+        return Item{u, u, u, u, e2(u, u), e2(u, u), u};
+    };
+    auto fetch = [&](size_t tile, int i, Item& it) {
+        const size_t j = (tile << jb_log2) + jj;
+        load_xy<u64, true, GIO>(in + (size_t)(2 * i) * in_stride, j, half, it.xl, it.yl);
+        load_xy<u64, true, GIO>(in + (size_t)(2 * i + 1) * in_stride, j, half, it.xr, it.yr);
+        it.em = 0;
+        if constexpr (SLOT) {
+            // (slot form: the group is uniform over the tile - a segment holds at least 512 positions)
+            const size_t at = (size_t)i * slot_ng + (((tile << jb_log2) * 2) >> slot_shift);
+            it.gm = gload_e2(slotw + 2 * at); it.gr = gload_e2(slotw + 2 * at + 1);
+            it.em = gload_u64(emask + at);   // (always: see below)
+        } else if constexpr (GIO) { it.gm = gload_e2(pw + i); it.gr = gload_e2(pwr + i); }
+        else { it.gm = pw[i]; it.gr = pwr[i]; }   // (k_st_tail: the job descriptor is in LDS)
+    };
+    // Every iteration issues the SAME loads whatever the item (the last one asks for the thread's first item again): the waits
+    // hipcc inserts are the minimum over all paths to them, and one path without the next item's loads makes every wait for the
+    // current item's values a wait for the next item's as well.
+    const bool active = g < nb && first_tile < ntiles;
+    Item cur = any_item();
+    if (active) fetch(first_tile, g, cur);
+    for (size_t tile = first_tile; tile < ntiles; tile += tile_step) {
+        const size_t j = (tile << jb_log2) + jj;
+        const size_t jo = dpos(j, half);
+        GpFirstAcc A = gp_first_acc_zero();
+        u64 p0 = 0, p2 = 0, p3 = 0;
+        if (active) for (int i = g; i < nb; i += G) {
+            const bool more_i = i + G < nb, more_t = tile + tile_step < ntiles;
+            Item nxt;
+            fetch(more_i || !more_t ? tile : tile + tile_step, more_i ? i + G : g, nxt);
+            if (i == 0) { const u64 dl = gl_sub(cur.yl, cur.xl); p0 = cur.xl; p2 = gl_add(cur.yl, dl); p3 = gl_add(p2, dl); }
+            u64 q0, q1;
+            if constexpr (SLOT) {
+                gp_first_pair<true, GIO>(A, cur.xl, cur.yl, cur.xr, cur.yr, cur.gm, cur.gr, r, !(p0_only && i == 0), out + (size_t)(2 * i) * out_stride + jo,
+                                         out + (size_t)(2 * i + 1) * out_stride + jo, nullptr, q0, q1);
+                if (next_level) emit_rows(next_level, in_stride, 2 * j, cur.em, make_ulonglong2(q0, q1));
+            } else {
+                gp_first_pair<false, GIO>(A, cur.xl, cur.yl, cur.xr, cur.yr, cur.gm, cur.gr, r, !(p0_only && i == 0), out + (size_t)(2 * i) * out_stride + jo,
+                                          out + (size_t)(2 * i + 1) * out_stride + jo, next_level ? next_level + (size_t)i * in_stride + 2 * j : nullptr, q0, q1);
+            }
+            cur = nxt;
+        }
+        E2 s0, s2, s3;
+        gp_first_acc_reduce(A, s0, s2, s3);
+        if (G > 1) {
+            red[tid] = s0; red[BD + tid] = s2; red[2 * BD + tid] = s3;
+            __syncthreads();
+            if (g == 0) {
+                const int gmax = G < nb ? G : nb;
+                for (int gg = 1; gg < gmax; gg++) {
+                    int o = (gg << jb_log2) + jj;
+                    s0 = e2_add(s0, red[o]); s2 = e2_add(s2, red[BD + o]); s3 = e2_add(s3, red[2 * BD + o]);
+                }
+            }
+            __syncthreads();
+        }
+        if (g == 0) {
+            // (s0, s2, s3) hold (sum P0, sum P1, sum Pinf): q(2) = 2 P1 - P0 + 2 Pinf, q(3) = 3 P1 - 2 P0 + 6 Pinf
+            const E2 P1x2 = e2_dbl(s2), Pix2 = e2_dbl(s3);
+            const E2 q2 = e2_add(e2_sub(P1x2, s0), Pix2);
+            const E2 q3 = e2_add(e2_sub(e2_add(P1x2, s2), e2_dbl(s0)), e2_add(e2_dbl(Pix2), Pix2));
+            acc[0] = e2_add(acc[0], e2_mul_f(s0, p0));
+            acc[1] = e2_add(acc[1], e2_mul_f(q2, p2));
+            acc[2] = e2_add(acc[2], e2_mul_f(q3, p3));
+        }
+    }
 }
 
 // ---- one sum-check round as a device function ---------------------------------------------------
@@ -194,12 +293,16 @@ __device__ __forceinline__ void gp_first_acc_reduce(const GpFirstAcc& A, E2& s0,
 // gamma^i (pw[i]); later rounds then need no per-pair scaling at all (the weight rides along in the table),
 // which removes 3 of the 8 extension multiplications per (pair, j). The host divides the final left
 // evaluations by gamma^i again before they reach the transcript.
-template <int KIND, typename T, bool FIRST, bool SLOT = false>   // SLOT: first round of a slot-form job (StJob::slotw), passed as `mirror`
+template <int KIND, typename T, bool FIRST, bool SLOT = false, bool GIO = true>   // SLOT: first round of a slot-form job (StJob::slotw), passed as `mirror`; GIO = false: tables behind generic pointers (k_st_tail: LDS)
 __device__ __forceinline__ void sc_round_body(const T* __restrict__ in, size_t in_stride, E2* __restrict__ out,
                                               size_t out_stride, int ntab, size_t half, E2 r, const E2* __restrict__ pw, const E2* __restrict__ pwr,
                                               int jb_log2, E2* __restrict__ red, E2* acc, size_t first_tile, size_t tile_step,
                                               bool p0_only = false, u64* __restrict__ next_level = nullptr, const StJob* __restrict__ mirror = nullptr) {
     using V = Val<T>;
+    if constexpr (KIND == SC_GRANDPROD && FIRST && std::is_same<T, u64>::value) {
+        gp_first_round_body<SLOT, GIO>(in, in_stride, out, out_stride, ntab, half, r, pw, pwr, jb_log2, red, acc, first_tile, tile_step, p0_only, next_level, mirror);
+        return;
+    }
     const int BD = blockDim.x, tid = threadIdx.x;
     const int G = BD >> jb_log2;
     const int jj = tid & ((1 << jb_log2) - 1), g = tid >> jb_log2;
@@ -220,14 +323,14 @@ __device__ __forceinline__ void sc_round_body(const T* __restrict__ in, size_t i
                 // software pipeline: the four loads of the next pair are in flight while this pair is processed
                 E2 xl, yl, xr, yr;
                 if (g < nb) {
-                    load_xy<E2, false>(in + (size_t)(2 * g) * in_stride, j, half, xl, yl);
-                    load_xy<E2, false>(in + (size_t)(2 * g + 1) * in_stride, j, half, xr, yr);
+                    load_xy<E2, false, GIO>(in + (size_t)(2 * g) * in_stride, j, half, xl, yl);
+                    load_xy<E2, false, GIO>(in + (size_t)(2 * g + 1) * in_stride, j, half, xr, yr);
                 }
                 for (int i = g; i < nb; i += G) {
                     E2 nxl = xl, nyl = yl, nxr = xr, nyr = yr;
                     if (i + G < nb) {
-                        load_xy<E2, false>(in + (size_t)(2 * (i + G)) * in_stride, j, half, nxl, nyl);
-                        load_xy<E2, false>(in + (size_t)(2 * (i + G) + 1) * in_stride, j, half, nxr, nyr);
+                        load_xy<E2, false, GIO>(in + (size_t)(2 * (i + G)) * in_stride, j, half, nxl, nyl);
+                        load_xy<E2, false, GIO>(in + (size_t)(2 * (i + G) + 1) * in_stride, j, half, nxr, nyr);
                     }
                     E2 dl = e2_sub(yl, xl), dr = e2_sub(yr, xr);
                     if (i == 0) { p0 = xl; p2 = e2_add(yl, dl); p3 = e2_add(p2, dl); }
@@ -236,51 +339,23 @@ __device__ __forceinline__ void sc_round_body(const T* __restrict__ in, size_t i
                         we2_mac(w1, yl, yr);
                         we2_mac(wi, dl, dr);
                     }
-                    store_e2(out + (size_t)(2 * i) * out_stride + jo, e2_fold_wide(xl, dl, fr));
-                    store_e2(out + (size_t)(2 * i + 1) * out_stride + jo, e2_fold_wide(xr, dr, fr));
+                    store_e2<GIO>(out + (size_t)(2 * i) * out_stride + jo, e2_fold_wide(xl, dl, fr));
+                    store_e2<GIO>(out + (size_t)(2 * i + 1) * out_stride + jo, e2_fold_wide(xr, dr, fr));
                     xl = nxl; yl = nyl; xr = nxr; yr = nyr;
                 }
                 s0 = we2_reduce(w0); s2 = we2_reduce(w1); s3 = we2_reduce(wi);
                 if (mirror && g == 0) {  // the linear table S of a mirrored job (StJob::mirror): K1 S(t) + K2 joins P0 and P1
                     E2 x, y;
-                    load_xy<E2, false>(in + (size_t)(2 * nb) * in_stride, j, half, x, y);
+                    load_xy<E2, false, GIO>(in + (size_t)(2 * nb) * in_stride, j, half, x, y);
                     s0 = e2_add(s0, e2_add(e2_mul(mirror->mk1, x), mirror->mk2));
                     s2 = e2_add(s2, e2_add(e2_mul(mirror->mk1, y), mirror->mk2));
-                    store_e2(out + (size_t)(2 * nb) * out_stride + jo, e2_fold_wide(x, e2_sub(y, x), fr));
+                    store_e2<GIO>(out + (size_t)(2 * nb) * out_stride + jo, e2_fold_wide(x, e2_sub(y, x), fr));
                 }
-            } else if constexpr (FIRST && std::is_same<T, u64>::value) {
-                // first round on base-field rows: sum_i gamma^i (xl xr) etc. with the Ext2 weight gamma^i = pw[i];
-                // each base product is reduced once, its two weighted copies accumulate unreduced.
-                GpFirstAcc A = gp_first_acc_zero();
-                // (slot form: the group is uniform over the tile - a segment holds at least 512 positions; with 64 or more threads along j
-                // the pair index is uniform over a wave as well, so the weights and the mask are scalar loads)
-                [[maybe_unused]] const size_t grp = SLOT ? ((tile << jb_log2) * 2) >> mirror->slot_shift : 0;
-                // (prefetching the next pair's four values, as the extension-field rounds do, measured slower here: 151 / 97 / 76 / 121 us
-                // against 136 / 91 / 79 / 113 for the four base-field first rounds of a prove)
-                for (int i = g; i < nb; i += G) {
-                    u64 xl, yl, xr, yr;
-                    load_xy<u64, true>(in + (size_t)(2 * i) * in_stride, j, half, xl, yl);
-                    load_xy<u64, true>(in + (size_t)(2 * i + 1) * in_stride, j, half, xr, yr);
-                    if (i == 0) { const u64 dl = gl_sub(yl, xl); p0 = xl; p2 = gl_add(yl, dl); p3 = gl_add(p2, dl); }
-                    if constexpr (SLOT) {
-                        size_t at = (size_t)i * mirror->slot_ng + grp;
-                        if (jb_log2 >= 6) at = (size_t)__builtin_amdgcn_readfirstlane((int)at);
-                        u64 q0, q1;
-                        gp_first_pair<true>(A, xl, yl, xr, yr, mirror->slotw[2 * at], mirror->slotw[2 * at + 1], r, !(p0_only && i == 0), out + (size_t)(2 * i) * out_stride + jo,
-                                            out + (size_t)(2 * i + 1) * out_stride + jo, nullptr, q0, q1);
-                        if (next_level) emit_rows(next_level, in_stride, 2 * j, mirror->emit_mask[at], make_ulonglong2(q0, q1));
-                    } else {
-                        u64 q0, q1;
-                        gp_first_pair<false>(A, xl, yl, xr, yr, pw[i], pwr[i], r, !(p0_only && i == 0), out + (size_t)(2 * i) * out_stride + jo,
-                                             out + (size_t)(2 * i + 1) * out_stride + jo, next_level ? next_level + (size_t)i * in_stride + 2 * j : nullptr, q0, q1);
-                    }
-                }
-                gp_first_acc_reduce(A, s0, s2, s3);
             } else {
             for (int i = g; i < nb; i += G) {
                 T xl, yl, xr, yr;
-                load_xy<T, FIRST>(in + (size_t)(2 * i) * in_stride, j, half, xl, yl);
-                load_xy<T, FIRST>(in + (size_t)(2 * i + 1) * in_stride, j, half, xr, yr);
+                load_xy<T, FIRST, GIO>(in + (size_t)(2 * i) * in_stride, j, half, xl, yl);
+                load_xy<T, FIRST, GIO>(in + (size_t)(2 * i + 1) * in_stride, j, half, xr, yr);
                 T dl = V::sub(yl, xl), dr = V::sub(yr, xr);
                 if (i == 0) { p0 = xl; p2 = V::add(yl, dl); p3 = V::add(p2, dl); }
                 const bool summed = !(p0_only && i == 0);
@@ -291,8 +366,8 @@ __device__ __forceinline__ void sc_round_body(const T* __restrict__ in, size_t i
                     s3 = e2_add(s3, V::scale(gm, V::mul(dl, dr)));
                 }
                 // gamma^i * (xl + r dl) = gamma^i xl + (gamma^i r) dl
-                store_e2(out + (size_t)(2 * i) * out_stride + jo, e2_add(V::scale(gm, xl), V::scale(pwr[i], dl)));
-                store_e2(out + (size_t)(2 * i + 1) * out_stride + jo, V::fold(xr, dr, r));
+                store_e2<GIO>(out + (size_t)(2 * i) * out_stride + jo, e2_add(V::scale(gm, xl), V::scale(pwr[i], dl)));
+                store_e2<GIO>(out + (size_t)(2 * i + 1) * out_stride + jo, V::fold(xr, dr, r));
             }
             }
             if (G > 1) {
@@ -325,7 +400,7 @@ __device__ __forceinline__ void sc_round_body(const T* __restrict__ in, size_t i
                 WAcc w0 = wacc_zero(), w2 = wacc_zero();
                 for (int i = g; i < ntab; i += G) {
                     u64 x, y;
-                    load_xy<u64, true>(in + (size_t)i * in_stride, j, half, x, y);
+                    load_xy<u64, true, GIO>(in + (size_t)i * in_stride, j, half, x, y);
                     u64 d = gl_sub(y, x);
                     u64 v2 = gl_add(y, d);
                     if (i == 0) { p0 = x; p2 = v2; }
@@ -335,24 +410,24 @@ __device__ __forceinline__ void sc_round_body(const T* __restrict__ in, size_t i
                     WAcc f0 = wacc_zero(), f1 = wacc_zero();
                     wmac_pair(f0, m, x, mr.c0, d);
                     wmac(f1, mr.c1, d);
-                    store_e2(out + (size_t)i * out_stride + jo, e2(wreduce(f0), wreduce(f1)));
+                    store_e2<GIO>(out + (size_t)i * out_stride + jo, e2(wreduce(f0), wreduce(f1)));
                 }
                 s0 = wreduce(w0); s2 = wreduce(w2);
             } else if constexpr (!FIRST && std::is_same<T, E2>::value) {
                 const FoldR fr = fold_r(r);
                 for (int i = g; i < ntab; i += G) {
                     E2 x, y;
-                    load_xy<E2, false>(in + (size_t)i * in_stride, j, half, x, y);
+                    load_xy<E2, false, GIO>(in + (size_t)i * in_stride, j, half, x, y);
                     E2 d = e2_sub(y, x);
                     E2 v2 = e2_add(y, d);
                     if (i == 0) { p0 = x; p2 = v2; }
                     if (!(p0_only && i == 0)) { s0 = e2_add(s0, x); s2 = e2_add(s2, v2); }
-                    store_e2(out + (size_t)i * out_stride + jo, e2_fold_wide(x, d, fr));
+                    store_e2<GIO>(out + (size_t)i * out_stride + jo, e2_fold_wide(x, d, fr));
                 }
             } else {
             for (int i = g; i < ntab; i += G) {
                 T x, y;
-                load_xy<T, FIRST>(in + (size_t)i * in_stride, j, half, x, y);
+                load_xy<T, FIRST, GIO>(in + (size_t)i * in_stride, j, half, x, y);
                 T d = V::sub(y, x);
                 T v2 = V::add(y, d);
                 if (i == 0) { p0 = x; p2 = v2; }
@@ -361,14 +436,14 @@ __device__ __forceinline__ void sc_round_body(const T* __restrict__ in, size_t i
                     u64 m = pw[i].c0;
                     if constexpr (std::is_same<T, u64>::value) {
                         if (summed) { s0 = gl_add(s0, gl_mul(m, x)); s2 = gl_add(s2, gl_mul(m, v2)); }
-                        store_e2(out + (size_t)i * out_stride + jo, e2_add_f(e2_mul_f(pwr[i], d), gl_mul(m, x)));
+                        store_e2<GIO>(out + (size_t)i * out_stride + jo, e2_add_f(e2_mul_f(pwr[i], d), gl_mul(m, x)));
                     } else {
                         if (summed) { s0 = e2_add(s0, e2_mul_f(x, m)); s2 = e2_add(s2, e2_mul_f(v2, m)); }
-                        store_e2(out + (size_t)i * out_stride + jo, e2_mul_f(V::fold(x, d, r), m));
+                        store_e2<GIO>(out + (size_t)i * out_stride + jo, e2_mul_f(V::fold(x, d, r), m));
                     }
                 } else {
                     if (summed) { s0 = V::add(s0, x); s2 = V::add(s2, v2); }
-                    store_e2(out + (size_t)i * out_stride + jo, V::fold(x, d, r));
+                    store_e2<GIO>(out + (size_t)i * out_stride + jo, V::fold(x, d, r));
                 }
             }
             }
@@ -982,9 +1057,9 @@ __global__ __launch_bounds__(ST_TAIL_THREADS) void k_st_tail(const StJob* __rest
 #pragma unroll
         for (int t = 0; t < NV; t++) acc[t] = e2_zero();
         const E2 r = rch[rd - I.rd];
-        if (rd == 0 && J.base) sc_round_body<KIND, u64, true>(reinterpret_cast<const u64*>(in), in_stride, out, half, J.ntab, half, r, J.pw, J.pwr, jb_log2, red, acc, 0, 1, p0_only);
-        else if (rd == 0) sc_round_body<KIND, E2, true>(reinterpret_cast<const E2*>(in), in_stride, out, half, J.ntab, half, r, J.pw, J.pwr, jb_log2, red, acc, 0, 1, p0_only);
-        else sc_round_body<KIND, E2, false>(reinterpret_cast<const E2*>(in), in_stride, out, half, J.ntab, half, r, J.pw, J.pwr, jb_log2, red, acc, 0, 1, p0_only, nullptr, mirror);
+        if (rd == 0 && J.base) sc_round_body<KIND, u64, true, false, false>(reinterpret_cast<const u64*>(in), in_stride, out, half, J.ntab, half, r, J.pw, J.pwr, jb_log2, red, acc, 0, 1, p0_only);
+        else if (rd == 0) sc_round_body<KIND, E2, true, false, false>(reinterpret_cast<const E2*>(in), in_stride, out, half, J.ntab, half, r, J.pw, J.pwr, jb_log2, red, acc, 0, 1, p0_only);
+        else sc_round_body<KIND, E2, false, false, false>(reinterpret_cast<const E2*>(in), in_stride, out, half, J.ntab, half, r, J.pw, J.pwr, jb_log2, red, acc, 0, 1, p0_only, nullptr, mirror);
         block_sum_multi<NV>(acc, sm);
         if (threadIdx.x == 0) {
 #pragma unroll
