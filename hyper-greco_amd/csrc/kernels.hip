@@ -772,12 +772,183 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SLOT ? HG_H
     }
     if (nblocks > 1) finish_partials(partials, 3, tickets_of(partials), res + J.sums_slot, sm, nblocks);
 }
+// ---- the same first round, slot form with recomputed E (the form the large parameter sets run), restructured -----------------------
+// k_gp_first_hash<true, true, true> asks memory six times in series per (tile, slot) - the slot's representative, that memory's
+// descriptor, the chunk's dim / ts values, the class weights, the two emit masks (each wait behind a store draining the stores too) -
+// and its 512 workgroups take tiles 512 apart. Here a workgroup takes CONSECUTIVE tiles: they lie in one segment pair (a segment
+// holds 2^(seg_shift - 9) >= 1 tiles, 32 at n = 32768), so everything that depends on (slot, segment pair) only - representative,
+// memory descriptor, weights, masks, the lookups' memory sets - is staged in LDS once per workgroup (again when the segment pair
+// changes), and the dim / ts values of the NEXT chunk (of this tile or the next) are requested when the current chunk's are taken.
+struct HashSlotD {
+    E2 gm, gr;            // class weight, times r_0
+    u64 erd, ewr;         // emit masks (read row, write row)
+    int chunk, next_chunk;  // next_chunk: the chunk of the next slot of this list with another chunk, -1: none
+    int rd_row, mem;
+    u32 cutoff;
+    int valid;            // 0: no such class in this segment pair (zero tables)
+    int pad[2];
+};
+static_assert(sizeof(HashSlotD) == 80, "HashSlotD layout");
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gp_first_hash_slot(const StJob* __restrict__ job, const StItem* __restrict__ item, const E2* __restrict__ chal,
+                                                           E2* __restrict__ partials, E2* __restrict__ res) {
+    const StJob& J = *job;
+    const StItem& I = *item;
+    const GpHashSrc& H = *J.hash_src;
+    const size_t half = (size_t)1 << I.h_log2;
+    const size_t hN = half << 1;
+    const size_t ntiles = half >> 8;
+    const int nblocks = I.nblk, bx = (int)blockIdx.x, tid = threadIdx.x;
+    E2* __restrict__ out = I.out;
+    const E2 r = chal[J.r_off];
+    const bool p0_only = J.p0_only != 0;
+    const u64 gamma = H.gamma, gamma2 = H.gamma2, tau = H.tau;
+    const int nslots = H.nslots, npairs = H.npairs, seg_shift = H.seg_shift;
+    u64* __restrict__ next_level = J.next_level;
+    const int ntab = J.ntab;
+    const E2 mk1 = J.mk1, mk2 = J.mk2;
+    const size_t per = (ntiles + nblocks - 1) / nblocks;
+    const size_t t_lo = (size_t)bx * per, t_hi = t_lo + per < ntiles ? t_lo + per : ntiles;
+    __shared__ HashSlotD D[64];
+    __shared__ const u64* s_dim[4];
+    __shared__ const u64* s_ts[4];
+    __shared__ int s_first_chunk;
+    __shared__ u32 s_uses[2];
+    int staged_sp = -1;
+    auto stage = [&](int sp, size_t tile) {   // (all threads; uniform arguments)
+        __syncthreads();
+        if (tid < nslots) {
+            HashSlotD d;
+            const size_t at = (size_t)tid * npairs + sp;
+            const int mi = H.rep[at];
+            d.gm = gload_e2(H.slotw + 2 * at); d.gr = gload_e2(H.slotw + 2 * at + 1);
+            d.erd = next_level ? gload_u64(H.emit_rd + at) : 0; d.ewr = next_level ? gload_u64(H.emit_wr + at) : 0;
+            d.valid = mi != 255;
+            d.chunk = -1; d.next_chunk = -1; d.rd_row = 0; d.mem = 0; d.cutoff = 0; d.pad[0] = d.pad[1] = 0;
+            if (d.valid) { const GpHashMem M = H.mems[mi]; d.chunk = M.chunk; d.rd_row = M.rd_row; d.mem = M.mem; d.cutoff = M.cutoff; }
+            D[tid] = d;
+        }
+        if (tid < 4) { s_dim[tid] = H.dim[tid]; s_ts[tid] = H.ts[tid]; }
+        if (tid == 64) {   // the memories the lookups of this tile's two row segments use (alpha <= 32)
+            const size_t p = tile << 9;
+            s_uses[0] = p < H.rows ? (u32)H.lookup_uses[H.seg_lookup[p >> seg_shift]] : 0u;
+            s_uses[1] = hN + p < H.rows ? (u32)H.lookup_uses[H.seg_lookup[(hN + p) >> seg_shift]] : 0u;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int nc = -1, last = -1;
+            for (int m = nslots - 1; m >= 0; m--) {
+                if (!D[m].valid) continue;
+                if (last >= 0 && D[m].chunk != last) nc = last;
+                D[m].next_chunk = nc;
+                last = D[m].chunk;
+            }
+            s_first_chunk = last;
+        }
+        __syncthreads();
+        staged_sp = sp;
+    };
+    struct Raw { u64x2_t dl, dh, tl, th; };
+    auto request = [&](size_t tile, int chunk, Raw& w) {
+        const size_t j = (tile << 8) + tid;
+        const u64* __restrict__ dim = s_dim[chunk];
+        const u64* __restrict__ ts = s_ts[chunk];
+        w.dl = load16<true>(dim + 2 * j); w.dh = load16<true>(dim + hN + 2 * j);
+        w.tl = load16<true>(ts + 2 * j); w.th = load16<true>(ts + hN + 2 * j);
+    };
+    E2 acc[3] = {e2_zero(), e2_zero(), e2_zero()};
+    Raw nxt;
+    if (t_lo < t_hi) {
+        stage((int)((t_lo << 9) >> seg_shift), t_lo);
+        request(t_lo, s_first_chunk < 0 ? 0 : s_first_chunk, nxt);
+    }
+    for (size_t tile = t_lo; tile < t_hi; tile++) {
+        const int sp = (int)((tile << 9) >> seg_shift);
+        if (sp != staged_sp) {   // (rare: a workgroup's tiles straddle two segment pairs) - the values asked for may be another chunk's
+            stage(sp, tile);
+            request(tile, s_first_chunk < 0 ? 0 : s_first_chunk, nxt);
+        }
+        const size_t j = (tile << 8) + tid;
+        const size_t jo = dpos(j, half);
+        const u32 uses_lo = 2 * j < H.rows ? s_uses[0] : 0u, uses_hi = hN + 2 * j < H.rows ? s_uses[1] : 0u;   // (row segment sp and sp + npairs)
+        GpFirstAcc A = gp_first_acc_zero();
+        E2 Sx = e2_zero(), Sy = e2_zero();
+        u64 p0 = 0, p2 = 0, p3 = 0;
+        int cur_chunk = -1;
+        u64 c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+        u32 a01 = 0, a23 = 0;
+        for (int m = 0; m < nslots; m++) {
+            const int valid = __builtin_amdgcn_readfirstlane(D[m].valid);
+            if (!valid) {
+                store_e2_nt(out + (size_t)(2 * m) * half + jo, e2_zero());
+                store_e2_nt(out + (size_t)(2 * m + 1) * half + jo, e2_zero());
+                continue;
+            }
+            const int chunk = __builtin_amdgcn_readfirstlane(D[m].chunk);
+            if (chunk != cur_chunk) {   // (uniform) take the values asked for, ask for the next chunk's: this tile's, else the next tile's first
+                cur_chunk = chunk;
+                const Raw w = nxt;
+                const int nc = __builtin_amdgcn_readfirstlane(D[m].next_chunk);
+                const bool more_t = tile + 1 < t_hi;
+                request(nc >= 0 || !more_t ? tile : tile + 1, nc >= 0 ? nc : (more_t ? s_first_chunk : chunk), nxt);
+                c0 = gl_sub(gl_add(w.dl.x, gl_mul_small(gamma2, (u32)w.tl.x)), tau); c1 = gl_sub(gl_add(w.dl.y, gl_mul_small(gamma2, (u32)w.tl.y)), tau);
+                c2 = gl_sub(gl_add(w.dh.x, gl_mul_small(gamma2, (u32)w.th.x)), tau); c3 = gl_sub(gl_add(w.dh.y, gl_mul_small(gamma2, (u32)w.th.y)), tau);
+                a01 = (u32)w.dl.x | ((u32)w.dl.y << 16); a23 = (u32)w.dh.x | ((u32)w.dh.y << 16);
+            }
+            const u32 cut = (u32)__builtin_amdgcn_readfirstlane((int)D[m].cutoff);
+            const int mem = __builtin_amdgcn_readfirstlane(D[m].mem), rd_row = __builtin_amdgcn_readfirstlane(D[m].rd_row);
+            const bool ul = (uses_lo >> mem) & 1, uh = (uses_hi >> mem) & 1;
+            u32 e0 = a01 & 0xFFFF, e1 = a01 >> 16, e2v = a23 & 0xFFFF, e3 = a23 >> 16;
+            e0 = (ul && e0 < cut) ? e0 : 0; e1 = (ul && e1 < cut) ? e1 : 0;
+            e2v = (uh && e2v < cut) ? e2v : 0; e3 = (uh && e3 < cut) ? e3 : 0;
+            u64 xl = gl_add(c0, gl_mul_small(gamma, e0)), yl = gl_add(c1, gl_mul_small(gamma, e1));
+            u64 xr = gl_add(c2, gl_mul_small(gamma, e2v)), yr = gl_add(c3, gl_mul_small(gamma, e3));
+            if (rd_row == 0) { const u64 d = gl_sub(yl, xl); p0 = xl; p2 = gl_add(yl, d); p3 = gl_add(p2, d); }
+            const E2 gm = D[m].gm, gr = D[m].gr;
+            u64 q0, q1;
+            const bool summed = !(p0_only && m == 0);   // (sharded: class 0 = pair 0, held for p_0 only)
+            gp_first_pair<true>(A, xl, yl, xr, yr, gm, gr, r, summed, out + (size_t)(2 * m) * half + jo, out + (size_t)(2 * m + 1) * half + jo, nullptr, q0, q1);
+            if (summed) {
+                const u64 hx = gl_add(xl, xr), hy = gl_add(yl, yr);
+                Sx = e2_add(Sx, e2_mul_f(gm, hx));
+                Sy = e2_add(Sy, e2_mul_f(gm, hy));
+            }
+            if (next_level) {
+                const u64 erd = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(D[m].erd >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)D[m].erd);
+                const u64 ewr = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(D[m].ewr >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)D[m].ewr);
+                emit_rows(next_level, hN, 2 * j, erd, make_ulonglong2(q0, q1));
+                xl = gl_add(xl, gamma2); yl = gl_add(yl, gamma2); xr = gl_add(xr, gamma2); yr = gl_add(yr, gamma2);
+                emit_rows(next_level, hN, 2 * j, ewr, make_ulonglong2(gl_mul(xl, xr), gl_mul(yl, yr)));
+            }
+        }
+        E2 s0, s2, s3;
+        gp_first_acc_reduce(A, s0, s2, s3);
+        s0 = e2_add(s0, e2_add(e2_mul(mk1, Sx), mk2));
+        s2 = e2_add(s2, e2_add(e2_mul(mk1, Sy), mk2));
+        store_e2_nt(out + (size_t)(ntab - 1) * half + jo, e2_add(Sx, e2_mul(r, e2_sub(Sy, Sx))));
+        const E2 P1x2 = e2_dbl(s2), Pix2 = e2_dbl(s3);
+        const E2 q2 = e2_add(e2_sub(P1x2, s0), Pix2);
+        const E2 q3 = e2_add(e2_sub(e2_add(P1x2, s2), e2_dbl(s0)), e2_add(e2_dbl(Pix2), Pix2));
+        acc[0] = e2_add(acc[0], e2_mul_f(s0, p0));
+        acc[1] = e2_add(acc[1], e2_mul_f(q2, p2));
+        acc[2] = e2_add(acc[2], e2_mul_f(q3, p3));
+    }
+    E2* sm = dyn_lds;
+    block_sum_multi<3>(acc, sm);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            if (nblocks == 1) res[J.sums_slot + t] = acc[t];
+            else part_store(partials + (size_t)bx * 3 + t, acc[t]);
+        }
+    }
+    if (nblocks > 1) finish_partials(partials, 3, tickets_of(partials), res + J.sums_slot, sm, nblocks);
+}
 static inline size_t sc_lds_bytes(int nv, int bd);
 void st_first_hash(hipStream_t st, const StJob* job, const StItem* item, int grid, bool mirror, bool recomp, const E2* chal, E2* partials, E2* res, bool slot) {
     const size_t lds = sc_lds_bytes(0, 256);
     if (slot) {
         if (!mirror) throw std::runtime_error("st_first_hash: the slot form is a mirrored job");
-        if (recomp) k_gp_first_hash<true, true, true><<<grid, 256, lds, st>>>(job, item, chal, partials, res);
+        if (recomp) k_gp_first_hash_slot<<<grid, 256, lds, st>>>(job, item, chal, partials, res);
         else k_gp_first_hash<true, false, true><<<grid, 256, lds, st>>>(job, item, chal, partials, res);
     } else if (recomp) {
         if (mirror) k_gp_first_hash<true, true><<<grid, 256, lds, st>>>(job, item, chal, partials, res);
