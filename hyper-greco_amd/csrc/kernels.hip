@@ -53,8 +53,8 @@ __device__ __forceinline__ E2 block_sum(E2 v, E2* sm) {
 
 // launch shapes (the measured best on MI355X)
 // (measured at n=32768 k=16: 32768 / 131072 / 262144 threads 2.05 / 2.04 / 2.14 against 1.97 ms; 1024 / 256 workgroups 1.99 / 2.11 against 1.97)
-static size_t st_min_threads() { return 65536; }
-static int st_max_blocks() { return 512; }   // (384 / 768 / 1024 in round 5: 1.894 / 1.785 / 1.812 against 1.797 ms)
+static size_t st_min_threads() { return 65536; }   // (with the pipelined round bodies of round 5: 32768 / 131072 / 262144 = 1.764 / 1.721 / 1.829 against 1.695 ms)
+static int st_max_blocks() { return 512; }   // (384 / 768 / 1024 in round 5: 1.894 / 1.785 / 1.812 against 1.797 ms; with the pipelined round bodies 1.729 / 1.704 / 1.678 against 1.695)
 
 static inline int grid_for(size_t work_items) {
     size_t b = (work_items + TPB - 1) / TPB;
@@ -282,6 +282,11 @@ __device__ __forceinline__ void gp_first_round_body(const u64* __restrict__ in, 
     }
 }
 
+struct GpItemE2 { E2 xl, yl, xr, yr; };
+__device__ __forceinline__ GpItemE2 gp_item_any() {   // "no value yet" without an instruction
+    const u64 z = 0, u = __builtin_nondeterministic_value(z);
+    return GpItemE2{e2(u, u), e2(u, u), e2(u, u), e2(u, u)};
+}
 // ---- one sum-check round as a device function ---------------------------------------------------
 // Thread mapping inside a workgroup of BD threads: JB = 2^jb_log2 threads along the pair index j
 // (coalesced) times G = BD/JB groups along the table index i. Large rounds use JB = BD (one thread per
@@ -307,6 +312,7 @@ __device__ __forceinline__ void sc_round_body(const T* __restrict__ in, size_t i
     const int G = BD >> jb_log2;
     const int jj = tid & ((1 << jb_log2) - 1), g = tid >> jb_log2;
     const size_t ntiles = half >> jb_log2;  // host guarantees 2^jb_log2 <= half
+    [[maybe_unused]] GpItemE2 gp_cur = gp_item_any();   // (grand product, later rounds: the item in flight across the tile loop)
     for (size_t tile = first_tile; tile < ntiles; tile += tile_step) {
         const size_t j = (tile << jb_log2) + jj;
         const size_t jo = dpos(j, half);  // this round's output (length `half`) is written de-interleaved
@@ -320,18 +326,21 @@ __device__ __forceinline__ void sc_round_body(const T* __restrict__ in, size_t i
             if constexpr (!FIRST && std::is_same<T, E2>::value) {
                 WE2 w0 = we2_zero(), w1 = we2_zero(), wi = we2_zero();
                 const FoldR fr = fold_r(r);
-                // software pipeline: the four loads of the next pair are in flight while this pair is processed
-                E2 xl, yl, xr, yr;
-                if (g < nb) {
-                    load_xy<E2, false, GIO>(in + (size_t)(2 * g) * in_stride, j, half, xl, yl);
-                    load_xy<E2, false, GIO>(in + (size_t)(2 * g + 1) * in_stride, j, half, xr, yr);
-                }
-                for (int i = g; i < nb; i += G) {
-                    E2 nxl = xl, nyl = yl, nxr = xr, nyr = yr;
-                    if (i + G < nb) {
-                        load_xy<E2, false, GIO>(in + (size_t)(2 * (i + G)) * in_stride, j, half, nxl, nyl);
-                        load_xy<E2, false, GIO>(in + (size_t)(2 * (i + G) + 1) * in_stride, j, half, nxr, nyr);
-                    }
+                // software pipeline over the workgroup's whole (tile, pair) stream: the four loads of the NEXT item are requested before
+                // this one is computed on, into registers of their own (a copy of the current item's would wait for them and for the
+                // stores behind them first), and every iteration requests the same loads (the last item asks for the thread's first
+                // again): hipcc's waits are the minimum over all paths to them (gp_first_round_body).
+                auto fetch = [&](size_t tl, int i, GpItemE2& it) {
+                    const size_t jn = (tl << jb_log2) + jj;
+                    load_xy<E2, false, GIO>(in + (size_t)(2 * i) * in_stride, jn, half, it.xl, it.yl);
+                    load_xy<E2, false, GIO>(in + (size_t)(2 * i + 1) * in_stride, jn, half, it.xr, it.yr);
+                };
+                if (g < nb && tile == first_tile) fetch(tile, g, gp_cur);
+                if (g < nb) for (int i = g; i < nb; i += G) {
+                    const bool more_i = i + G < nb, more_t = tile + tile_step < ntiles;
+                    GpItemE2 nxt;
+                    fetch(more_i || !more_t ? tile : tile + tile_step, more_i ? i + G : g, nxt);
+                    const E2 xl = gp_cur.xl, yl = gp_cur.yl, xr = gp_cur.xr, yr = gp_cur.yr;
                     E2 dl = e2_sub(yl, xl), dr = e2_sub(yr, xr);
                     if (i == 0) { p0 = xl; p2 = e2_add(yl, dl); p3 = e2_add(p2, dl); }
                     if (!(p0_only && i == 0)) {  // a p0-only pair 0 belongs to another rank's share of the batch
@@ -341,7 +350,7 @@ __device__ __forceinline__ void sc_round_body(const T* __restrict__ in, size_t i
                     }
                     store_e2<GIO>(out + (size_t)(2 * i) * out_stride + jo, e2_fold_wide(xl, dl, fr));
                     store_e2<GIO>(out + (size_t)(2 * i + 1) * out_stride + jo, e2_fold_wide(xr, dr, fr));
-                    xl = nxl; yl = nyl; xr = nxr; yr = nyr;
+                    gp_cur = nxt;
                 }
                 s0 = we2_reduce(w0); s2 = we2_reduce(w1); s3 = we2_reduce(wi);
                 if (mirror && g == 0) {  // the linear table S of a mirrored job (StJob::mirror): K1 S(t) + K2 joins P0 and P1
@@ -782,7 +791,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SLOT ? HG_H
 struct HashSlotD {
     E2 gm, gr;            // class weight, times r_0
     u64 erd, ewr;         // emit masks (read row, write row)
-    int chunk, next_chunk;  // next_chunk: the chunk of the next slot of this list with another chunk, -1: none
+    int chunk, pad0;
     int rd_row, mem;
     u32 cutoff;
     int valid;            // 0: no such class in this segment pair (zero tables)
@@ -811,7 +820,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __shared__ HashSlotD D[64];
     __shared__ const u64* s_dim[4];
     __shared__ const u64* s_ts[4];
-    __shared__ int s_first_chunk;
+    __shared__ int s_ng, s_glo[65], s_gchunk[64];   // runs of slots whose classes share a chunk (the memories are listed chunk by chunk): [s_glo[k], s_glo[k+1])
     __shared__ u32 s_uses[2];
     int staged_sp = -1;
     auto stage = [&](int sp, size_t tile) {   // (all threads; uniform arguments)
@@ -823,7 +832,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             d.gm = gload_e2(H.slotw + 2 * at); d.gr = gload_e2(H.slotw + 2 * at + 1);
             d.erd = next_level ? gload_u64(H.emit_rd + at) : 0; d.ewr = next_level ? gload_u64(H.emit_wr + at) : 0;
             d.valid = mi != 255;
-            d.chunk = -1; d.next_chunk = -1; d.rd_row = 0; d.mem = 0; d.cutoff = 0; d.pad[0] = d.pad[1] = 0;
+            d.chunk = -1; d.pad0 = 0; d.rd_row = 0; d.mem = 0; d.cutoff = 0; d.pad[0] = d.pad[1] = 0;
             if (d.valid) { const GpHashMem M = H.mems[mi]; d.chunk = M.chunk; d.rd_row = M.rd_row; d.mem = M.mem; d.cutoff = M.cutoff; }
             D[tid] = d;
         }
@@ -835,14 +844,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         __syncthreads();
         if (tid == 0) {
-            int nc = -1, last = -1;
-            for (int m = nslots - 1; m >= 0; m--) {
-                if (!D[m].valid) continue;
-                if (last >= 0 && D[m].chunk != last) nc = last;
-                D[m].next_chunk = nc;
-                last = D[m].chunk;
+            int ng = 0, cur = -1;
+            for (int m = 0; m < nslots; m++) {
+                if (!D[m].valid || D[m].chunk == cur) continue;
+                cur = D[m].chunk;
+                s_glo[ng] = ng == 0 ? 0 : m; s_gchunk[ng] = cur; ng++;
             }
-            s_first_chunk = last;
+            if (ng == 0) { s_glo[0] = 0; s_gchunk[0] = 0; ng = 1; }   // (no class at all here: zero tables; the values asked for are ignored)
+            s_glo[ng] = nslots;
+            s_ng = ng;
         }
         __syncthreads();
         staged_sp = sp;
@@ -859,13 +869,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     Raw nxt;
     if (t_lo < t_hi) {
         stage((int)((t_lo << 9) >> seg_shift), t_lo);
-        request(t_lo, s_first_chunk < 0 ? 0 : s_first_chunk, nxt);
+        request(t_lo, s_gchunk[0], nxt);
     }
     for (size_t tile = t_lo; tile < t_hi; tile++) {
         const int sp = (int)((tile << 9) >> seg_shift);
         if (sp != staged_sp) {   // (rare: a workgroup's tiles straddle two segment pairs) - the values asked for may be another chunk's
             stage(sp, tile);
-            request(tile, s_first_chunk < 0 ? 0 : s_first_chunk, nxt);
+            request(tile, s_gchunk[0], nxt);
         }
         const size_t j = (tile << 8) + tid;
         const size_t jo = dpos(j, half);
@@ -873,26 +883,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         GpFirstAcc A = gp_first_acc_zero();
         E2 Sx = e2_zero(), Sy = e2_zero();
         u64 p0 = 0, p2 = 0, p3 = 0;
-        int cur_chunk = -1;
-        u64 c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-        u32 a01 = 0, a23 = 0;
-        for (int m = 0; m < nslots; m++) {
+        const int ng = s_ng;
+        for (int k = 0; k < ng; k++) {
+        // take the values asked for, ask for the next run's: this tile's, else the next tile's first (the last run of the workgroup asks
+        // for its own again: every run issues the same loads). The values are consumed BEFORE the request and the slots of the run
+        // do not touch them: the loop over the slots carries no copy of values in flight.
+        const u64 c0 = gl_sub(gl_add(nxt.dl.x, gl_mul_small(gamma2, (u32)nxt.tl.x)), tau), c1 = gl_sub(gl_add(nxt.dl.y, gl_mul_small(gamma2, (u32)nxt.tl.y)), tau);
+        const u64 c2 = gl_sub(gl_add(nxt.dh.x, gl_mul_small(gamma2, (u32)nxt.th.x)), tau), c3 = gl_sub(gl_add(nxt.dh.y, gl_mul_small(gamma2, (u32)nxt.th.y)), tau);
+        const u32 a01 = (u32)nxt.dl.x | ((u32)nxt.dl.y << 16), a23 = (u32)nxt.dh.x | ((u32)nxt.dh.y << 16);   // the chunk's 16-bit limbs at 2j, 2j+1 | N/2+2j, N/2+2j+1
+        {
+            const bool more_k = k + 1 < ng, more_t = tile + 1 < t_hi;
+            request(more_k || !more_t ? tile : tile + 1, s_gchunk[more_k ? k + 1 : (more_t ? 0 : k)], nxt);
+        }
+        const int m_hi = s_glo[k + 1];
+        for (int m = s_glo[k]; m < m_hi; m++) {
             const int valid = __builtin_amdgcn_readfirstlane(D[m].valid);
             if (!valid) {
                 store_e2_nt(out + (size_t)(2 * m) * half + jo, e2_zero());
                 store_e2_nt(out + (size_t)(2 * m + 1) * half + jo, e2_zero());
                 continue;
-            }
-            const int chunk = __builtin_amdgcn_readfirstlane(D[m].chunk);
-            if (chunk != cur_chunk) {   // (uniform) take the values asked for, ask for the next chunk's: this tile's, else the next tile's first
-                cur_chunk = chunk;
-                const Raw w = nxt;
-                const int nc = __builtin_amdgcn_readfirstlane(D[m].next_chunk);
-                const bool more_t = tile + 1 < t_hi;
-                request(nc >= 0 || !more_t ? tile : tile + 1, nc >= 0 ? nc : (more_t ? s_first_chunk : chunk), nxt);
-                c0 = gl_sub(gl_add(w.dl.x, gl_mul_small(gamma2, (u32)w.tl.x)), tau); c1 = gl_sub(gl_add(w.dl.y, gl_mul_small(gamma2, (u32)w.tl.y)), tau);
-                c2 = gl_sub(gl_add(w.dh.x, gl_mul_small(gamma2, (u32)w.th.x)), tau); c3 = gl_sub(gl_add(w.dh.y, gl_mul_small(gamma2, (u32)w.th.y)), tau);
-                a01 = (u32)w.dl.x | ((u32)w.dl.y << 16); a23 = (u32)w.dh.x | ((u32)w.dh.y << 16);
             }
             const u32 cut = (u32)__builtin_amdgcn_readfirstlane((int)D[m].cutoff);
             const int mem = __builtin_amdgcn_readfirstlane(D[m].mem), rd_row = __builtin_amdgcn_readfirstlane(D[m].rd_row);
@@ -919,6 +928,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 xl = gl_add(xl, gamma2); yl = gl_add(yl, gamma2); xr = gl_add(xr, gamma2); yr = gl_add(yr, gamma2);
                 emit_rows(next_level, hN, 2 * j, ewr, make_ulonglong2(gl_mul(xl, xr), gl_mul(yl, yr)));
             }
+        }
         }
         E2 s0, s2, s3;
         gp_first_acc_reduce(A, s0, s2, s3);
@@ -1016,6 +1026,11 @@ __global__ __launch_bounds__(256) void k_st_step2(const StJob* __restrict__ jobs
     E2 acc[6];
 #pragma unroll
     for (int t = 0; t < 6; t++) acc[t] = e2_zero();
+    GpItemE2 cur = gp_item_any();
+    if ((size_t)bx < ntiles) {
+        load_xy<E2, false>(in, ((size_t)bx << 8) + tid, half, cur.xl, cur.yl);
+        load_xy<E2, false>(in + in_stride, ((size_t)bx << 8) + tid, half, cur.xr, cur.yr);
+    }
     for (size_t tile = bx; tile < ntiles; tile += nblocks) {
         const size_t j = (tile << 8) + tid;
         const size_t j2 = j >> 1;
@@ -1041,17 +1056,19 @@ __global__ __launch_bounds__(256) void k_st_step2(const StJob* __restrict__ jobs
             const E2 fs = e2_fold_wide(ms, es, fb);
             if (!odd) store_e2(out + (size_t)(2 * nb) * half2 + jo2, fs);
         }
-        // software pipeline: the four loads of the next pair are in flight while this pair is processed (two waves per SIMD
-        // cannot hide an HBM round trip behind ~800 instructions otherwise)
-        E2 xl, yl, xr, yr;
-        load_xy<E2, false>(in, j, half, xl, yl);
-        load_xy<E2, false>(in + in_stride, j, half, xr, yr);
+        // software pipeline over the workgroup's whole (tile, pair) stream (two waves per SIMD cannot hide an HBM round trip behind
+        // ~800 instructions otherwise): the next item's four loads go out before this one is computed on, into registers of their
+        // own, and every iteration issues them (the last item asks for the thread's first again) - see gp_first_round_body
         for (int i = 0; i < nb; i++) {
-            E2 nxl = xl, nyl = yl, nxr = xr, nyr = yr;
-            if (i + 1 < nb) {
-                load_xy<E2, false>(in + (size_t)(2 * i + 2) * in_stride, j, half, nxl, nyl);
-                load_xy<E2, false>(in + (size_t)(2 * i + 3) * in_stride, j, half, nxr, nyr);
+            const bool more_i = i + 1 < nb, more_t = tile + nblocks < ntiles;
+            GpItemE2 nxt;
+            {
+                const size_t jn = ((more_i || !more_t ? tile : tile + nblocks) << 8) + tid;
+                const int in_ = more_i ? i + 1 : 0;
+                load_xy<E2, false>(in + (size_t)(2 * in_) * in_stride, jn, half, nxt.xl, nxt.yl);
+                load_xy<E2, false>(in + (size_t)(2 * in_ + 1) * in_stride, jn, half, nxt.xr, nxt.yr);
             }
+            const E2 xl = cur.xl, yl = cur.yl, xr = cur.xr, yr = cur.yr;
             const E2 dl = e2_sub(yl, xl), dr = e2_sub(yr, xr);
             const bool summed = !(p0_only && i == 0);
             if (i == 0) { p0 = xl; p2 = e2_add(yl, dl); p3 = e2_add(p2, dl); }
@@ -1073,7 +1090,7 @@ __global__ __launch_bounds__(256) void k_st_step2(const StJob* __restrict__ jobs
             }
             const E2 fx = odd ? mr : ml, fd = odd ? er : el;
             store_e2(out + (size_t)(2 * i + (odd ? 1 : 0)) * half2 + jo2, e2_fold_wide(fx, fd, fb));
-            xl = nxl; yl = nyl; xr = nxr; yr = nyr;
+            cur = nxt;
         }
         gp_combine(we2_reduce(w0), we2_reduce(w1), we2_reduce(wi), p0, p2, p3, acc[0], acc[1], acc[2]);
         const E2 mine = w2_reduce(vm), other = swap_lane(mine);
