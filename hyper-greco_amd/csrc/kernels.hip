@@ -1435,21 +1435,35 @@ __device__ __forceinline__ void ps_step2_body(const PsJob& J, const PsItem& I, s
     WE2 w0 = we2_zero(), w2 = we2_zero();
     W2 vm = w2_zero();
     WAcc vi = wacc_zero();
+    // the (tile, pair) items of the workgroup as one stream, the next item's four loads requested before the current one is computed
+    // on, by every iteration alike (the last asks for the first again): gp_first_round_body
+    struct Item { TA xa, ya; E2 xb, yb; };
+    const int np = J.npairs;
+    auto fetch = [&](size_t tl, int i, Item& it) {
+        const size_t jn = (tl << 8) + tid;
+        const void* pa; const E2* pb; E2* oa; E2* ob;
+        ps_io(J, I.rd, 2, I.in_buf, I.out_buf, i, pa, pb, oa, ob);
+        if (I.in_buf < 0) {
+            load_pair<TA>(reinterpret_cast<const TA*>(pa) + 2 * jn, it.xa, it.ya);
+            load_pair<E2>(pb + 2 * jn, it.xb, it.yb);
+        } else {
+            load_xy<TA, false>(reinterpret_cast<const TA*>(pa), jn, half, it.xa, it.ya);
+            load_xy<E2, false>(pb, jn, half, it.xb, it.yb);
+        }
+    };
+    Item cur;
+    if ((size_t)bx < ntiles) fetch(bx, 0, cur);
     for (size_t tile = bx; tile < ntiles; tile += nblocks) {
         const size_t j = (tile << 8) + tid;
         const size_t jo2 = dpos(j >> 1, half2);
-        for (int i = 0; i < J.npairs; i++) {
+        for (int i = 0; i < np; i++) {
+            const bool more_i = i + 1 < np, more_t = tile + nblocks < ntiles;
+            Item nxt;
+            fetch(more_i || !more_t ? tile : tile + nblocks, more_i ? i + 1 : 0, nxt);
             const void* pa; const E2* pb; E2* oa; E2* ob;
             ps_io(J, I.rd, 2, I.in_buf, I.out_buf, i, pa, pb, oa, ob);
-            TA xa, ya;
-            E2 xb, yb;
-            if (I.in_buf < 0) {
-                load_pair<TA>(reinterpret_cast<const TA*>(pa) + 2 * j, xa, ya);
-                load_pair<E2>(pb + 2 * j, xb, yb);
-            } else {
-                load_xy<TA, false>(reinterpret_cast<const TA*>(pa), j, half, xa, ya);
-                load_xy<E2, false>(pb, j, half, xb, yb);
-            }
+            const TA xa = cur.xa, ya = cur.ya;
+            const E2 xb = cur.xb, yb = cur.yb;
             TA da = V::sub(ya, xa);
             E2 db = e2_sub(yb, xb);
             E2 vb = e2_add(yb, db);
@@ -1476,6 +1490,7 @@ __device__ __forceinline__ void ps_step2_body(const PsJob& J, const PsItem& I, s
             wmac_pair(vi, ea.c0, b, c, d);
             const E2 fx = odd ? mb : ma, fd = odd ? eb : ea;
             store_e2((odd ? ob : oa) + jo2, e2_fold_wide(fx, fd, fb));
+            cur = nxt;
         }
     }
     acc[0] = we2_reduce(w0);
@@ -1559,10 +1574,11 @@ __device__ __forceinline__ bool ps_eq_step2_body(const PsJob& J, const PsItem& I
 #pragma unroll
     for (int p = 0; p < 4; p++) U[p] = w2_zero();
     auto member_tab = [&](int i) { return natural ? reinterpret_cast<const TA*>(J.a[i]) : reinterpret_cast<const TA*>(J.bufa[I.in_buf]) + (size_t)i * 4 * q; };
-    // the loads of the next (tile, table) are in flight while the current one is computed on
-    TA nv[4];
+    // the loads of the next (tile, table) are in flight while the current one is computed on: requested into registers of their own
+    // before the current values are touched, by every iteration alike (the last asks for the first again) - gp_first_round_body
+    TA cv[4];
     E2 nhv = e2_zero();
-    if ((size_t)bx < ntiles && m0 < m1) { load4<TA>(member_tab(m0), natural, ((size_t)bx << 8) + tid, q, nv); nhv = gload_e2(hi + bx); }
+    if ((size_t)bx < ntiles && m0 < m1) { load4<TA>(member_tab(m0), natural, ((size_t)bx << 8) + tid, q, cv); nhv = gload_e2(hi + bx); }
     for (size_t tile = bx; tile < ntiles; tile += nblocks) {
         const size_t jq = (tile << 8) + tid;
         const size_t jo = out_tail ? dpos(jq, q) : (jq & 3) * (q >> 2) + (jq >> 2);
@@ -1574,11 +1590,12 @@ __device__ __forceinline__ bool ps_eq_step2_body(const PsJob& J, const PsItem& I
         E2 Av[4];
         if (!single && sums) load4<E2>(Ain, false, jq, q, Av);
         for (int i = m0; i < m1; i++) {
-            TA v[4];
-#pragma unroll
-            for (int p = 0; p < 4; p++) v[p] = nv[p];
-            if (i + 1 < m1) load4<TA>(member_tab(i + 1), natural, jq, q, nv);
-            else if (more) load4<TA>(member_tab(m0), natural, ((tile + nblocks) << 8) + tid, q, nv);
+            TA nv[4];
+            {
+                const bool more_i = i + 1 < m1;
+                load4<TA>(member_tab(more_i ? i + 1 : m0), natural, more_i || !more ? jq : ((tile + nblocks) << 8) + tid, q, nv);
+            }
+            const TA (&v)[4] = cv;
             if (single && live) {
 #pragma unroll
                 for (int p = 0; p < 4; p++) {
@@ -1587,6 +1604,8 @@ __device__ __forceinline__ bool ps_eq_step2_body(const PsJob& J, const PsItem& I
                 }
             }
             gstore_e2(J.bufa[I.out_buf] + (size_t)i * q + jo, fold4_apply(f4, v));
+#pragma unroll
+            for (int p = 0; p < 4; p++) cv[p] = nv[p];
         }
         if (!single && sums) {
             if (live) {
