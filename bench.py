@@ -35,7 +35,7 @@ CLASS_SYMBOL = {
     "sc_round2<grand_product,ext>": "k_st_step2(",
     "sc_round<grand_product,ext>": "k_st_step<1, hg::E2",
     "sc_round<grand_product,base>": "k_st_step<1, unsigned long",      # (two instantiations: slot form and memory form)
-    "sc_round<grand_product,hash>": "k_gp_first_hash<",
+    "sc_round<grand_product,hash>": "k_gp_first_hash",                 # (k_gp_first_hash_slot at the headline size, k_gp_first_hash<..> otherwise)
     "sc_round2<collation,ext>": "k_col_step2(",
     "sc_round<collation,ext>": "k_st_step<0, hg::E2",
     "sc_round<collation,base>": "k_st_step<0, unsigned long",
