@@ -54,7 +54,10 @@ __device__ __forceinline__ E2 block_sum(E2 v, E2* sm) {
 // launch shapes (the measured best on MI355X)
 // (measured at n=32768 k=16: 32768 / 131072 / 262144 threads 2.05 / 2.04 / 2.14 against 1.97 ms; 1024 / 256 workgroups 1.99 / 2.11 against 1.97)
 static size_t st_min_threads() { return 65536; }   // (with the pipelined round bodies of round 5: 32768 / 131072 / 262144 = 1.764 / 1.721 / 1.829 against 1.695 ms)
-static int st_max_blocks() { return 512; }   // (384 / 768 / 1024 in round 5: 1.894 / 1.785 / 1.812 against 1.797 ms; with the pipelined round bodies 1.729 / 1.704 / 1.678 against 1.695)
+#ifndef HG_TEST_ST_MAX_BLOCKS
+#define HG_TEST_ST_MAX_BLOCKS 512   // (a test build with 48: workgroups whose tiles straddle segment pairs - k_gp_first_hash_slot restages - and long tile loops)
+#endif
+static int st_max_blocks() { return HG_TEST_ST_MAX_BLOCKS; }   // (384 / 768 / 1024 in round 5: 1.894 / 1.785 / 1.812 against 1.797 ms; with the pipelined round bodies 1.729 / 1.704 / 1.678 against 1.695)
 
 static inline int grid_for(size_t work_items) {
     size_t b = (work_items + TPB - 1) / TPB;

@@ -434,7 +434,9 @@ def test_sharded_round_by_round_prover_at_the_headline_size():
 def test_strict_memory_model_build_is_bit_exact():
     """build/strict/libhypergreco.so (-DHG_STRICT_TICKETS: acq_rel tickets, the form every architecture other than gfx942 / gfx950 must
     use; built by __graft_entry__.build()) proves the same bytes as the oracle - plain launches, graph replays, a sharded proof and
-    the sequential prover."""
+    the sequential prover. The same build caps the stride-layout launches at 48 workgroups: at n=32768 k=16 every round
+    kernel then walks long tile loops (the pipelined item streams cross many tile boundaries) and the slot-form hash kernel's
+    workgroups straddle segment pairs (its restaging path)."""
     import subprocess, sys
     from hglib import ROOT
     lib = os.path.join(ROOT, "build", "strict", "libhypergreco.so")
@@ -457,6 +459,10 @@ def test_strict_memory_model_build_is_bit_exact():
         "assert hg.prove_shard_finish(ctx, out).bytes() == ref\n"
         "ref3, _ = orclib.prove_f('goldilocks', orclib.params(4096, 2), inp, threads=4, mode=3)\n"
         "assert bfv.prove(ctx, pk, w, mode=3)[0] == ref3\n"
+        "pk.free(); bfv = hg.BfvEncrypt.new(32768, 16); pk = bfv.setup(ctx)\n"   # (48 workgroups per launch: the slot-form hash kernel restages)
+        "w = hg.Witness.synthetic(bfv.params, 31); v = hg.witness_gen(ctx, pk, w)\n"
+        "ref, _ = orclib.prove(orclib.params(32768, 16), orclib.Inputs(w.arrays()), threads=16)\n"
+        "for i in range(4): assert hg.prove_resident(ctx, pk, v, out).bytes() == ref, ('c3', i)\n"
         "print('STRICT OK')\n"
     ) % (ROOT, os.path.join(ROOT, "tests"))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, HG_LIB=lib), cwd=ROOT)
