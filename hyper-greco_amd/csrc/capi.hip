@@ -526,11 +526,12 @@ int hg_prove_resident(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, uint8_t*
     HG_TRY
     if (!ctx || !pk || !v || !pk->ctx) throw Error("hg_prove_resident: needs a device context, a device prover key and resident values");
     double t0 = now_ms_capi();
-    ProveResult r = prove_resident(ctx, pk, v);
+    ProveResult r = prove_resident(ctx, pk, v, true);
     if (timings) { memset(timings, 0, sizeof(*timings)); timings->prove_ms = r.prove_ms; timings->gpu_ms = r.gpu_ms; timings->total_ms = now_ms_capi() - t0; timings->enqueue_ms = r.enqueue_ms; timings->sync_ms = r.sync_ms; timings->replay_ms = r.replay_ms; }
-    *len = r.proof.size();
-    if (r.proof.size() > cap) throw Error("proof buffer too small");
-    memcpy(proof, r.proof.data(), r.proof.size());
+    const std::vector<uint8_t>& pb = r.bytes();
+    *len = pb.size();
+    if (pb.size() > cap) throw Error("proof buffer too small");
+    memcpy(proof, pb.data(), pb.size());
     return 0;
     HG_CATCH(-1)
 }
@@ -633,11 +634,12 @@ int hg_prove(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, uint8_t* proof, 
     if (ctx->scratch_values && ctx->scratch_serial != pk->serial) { values_free(ctx->scratch_values); ctx->scratch_values = nullptr; }
     if (!ctx->scratch_values) { ctx->scratch_values = witness_gen(ctx, pk, w->w, &wm, &um); ctx->scratch_serial = pk->serial; }
     else witness_gen_into(ctx, pk, w->w, ctx->scratch_values, &wm, &um);
-    ProveResult r = prove_resident(ctx, pk, ctx->scratch_values);
+    ProveResult r = prove_resident(ctx, pk, ctx->scratch_values, true);
     if (timings) { timings->witness_ms = wm; timings->upload_ms = um; timings->prove_ms = r.prove_ms; timings->gpu_ms = r.gpu_ms; timings->total_ms = now_ms_capi() - t0; timings->enqueue_ms = r.enqueue_ms; timings->sync_ms = r.sync_ms; timings->replay_ms = r.replay_ms; }
-    *len = r.proof.size();
-    if (r.proof.size() > cap) throw Error("proof buffer too small");
-    memcpy(proof, r.proof.data(), r.proof.size());
+    const std::vector<uint8_t>& pb = r.bytes();
+    *len = pb.size();
+    if (pb.size() > cap) throw Error("proof buffer too small");
+    memcpy(proof, pb.data(), pb.size());
     return 0;
     HG_CATCH(-1)
 }

@@ -405,10 +405,17 @@ struct Prover {
         // device to blocking-sync scheduling; the wait is a few milliseconds at most, so a busy core is the cheaper price.
         if (!done) { hip_check(hipEventRecord(ctx->ev_join, st), "prove: done event"); done = ctx->ev_join; }
         const double t_spin = wall_ms();
+        // (while it waits the host keeps asking for the result buffer's lines, a few per query, round and round: what the device has
+        // written for good by then - the sums of the launched rounds - is in the cache when the replay reads it; a line the device
+        // writes later is simply invalidated again)
+        const char* warm_p = reinterpret_cast<const char*>(ctx->h_res);
+        const size_t warm_n = res_used * sizeof(E2) / 64;
+        size_t warm = 0;
         for (;;) {
             hipError_t q = hipEventQuery(done);
             if (q == hipSuccess) break;
             if (q != hipErrorNotReady) hip_check(q, "prove: event query");
+            if (warm_n) for (int k = 0; k < 8; k++) { __builtin_prefetch(warm_p + (warm % warm_n) * 64, 0, 3); warm++; }
             if (early_ready()) run_early();   // (the node reductions are done, the Lasso node's last launches are not)
             if (wall_ms() - t_spin > 2000.0) { hip_check(hipEventSynchronize(done), "prove: event sync"); break; }
         }
@@ -416,8 +423,17 @@ struct Prover {
         t_synced = wall_ms();
         print_stamps();
     }
+    // The transcript steps read ~9000 result values the device has just written: lines the host has never seen, one dependent miss
+    // to DRAM each when the steps touch them one by one (130-150 us for the 277 steps behind the synchronisation). Asked for all
+    // at once they arrive while the first steps run.
+    void prefetch_results() const {
+        const char* p = reinterpret_cast<const char*>(ctx->h_res);
+        const size_t bytes = res_used * sizeof(E2);
+        for (size_t o = 0; o < bytes; o += 64) __builtin_prefetch(p + o, 0, 3);
+    }
     void replay() {
         double t = wall_ms();
+        prefetch_results();
         proof.bytes.reserve((size_t)1 << 18);
         const size_t nops = ops.size();
         if (early_done) {   // the early steps are in place: the rest, each at its recorded offset
@@ -863,7 +879,7 @@ static void cache_launch(hg_ctx* ctx, ProveCache* C, bool exchange) {
     hip_check(hipEventRecord(C->ev_b, ctx->stream), "event record");
 }
 // (`launched`: cache_launch has been called; `behind`: and other work may have been enqueued behind it - wait for THIS graph's event)
-static ProveResult prove_from_cache(hg_ctx* ctx, ProveCache* C, bool exchange = false, bool replay_now = true, bool launched = false, double t_launch = 0, bool behind = false) {
+static ProveResult prove_from_cache(hg_ctx* ctx, ProveCache* C, bool exchange = false, bool replay_now = true, bool launched = false, double t_launch = 0, bool behind = false, bool borrow = false) {
     ProveResult res;
     const double t0 = launched ? t_launch : wall_ms();
     if (!launched) cache_launch(ctx, C, exchange);
@@ -887,7 +903,8 @@ static ProveResult prove_from_cache(hg_ctx* ctx, ProveCache* C, bool exchange = 
     res.enqueue_ms = P->t_enqueued - t0;
     res.sync_ms = P->t_synced - P->t_enqueued;
     res.replay_ms = P->t_replayed - P->t_synced;
-    res.proof = P->proof.bytes;
+    if (borrow) res.proof_ref = &P->proof.bytes;
+    else res.proof = P->proof.bytes;
     return res;
 }
 // records the whole enqueue into a graph (no kernel runs during the capture) whose kernels work in a private arena, instantiates it
@@ -958,7 +975,7 @@ static std::shared_ptr<ProveCache> prove_capture(hg_ctx* ctx, const hg_pk* pk, c
 
 // The cached-graph path of a (rank of a) prove: replays the graph recorded for exactly this key, values object and share; records one
 // on the third prove of that triple; otherwise returns null and the caller walks the protocol. *out is filled when non-null is returned.
-static std::shared_ptr<ProveCache> prove_through_graph(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int rank, int world, bool exchange, ProveResult* out, bool replay_now = true) {
+static std::shared_ptr<ProveCache> prove_through_graph(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int rank, int world, bool exchange, ProveResult* out, bool replay_now = true, bool borrow = false) {
     if (v->pk_serial != pk->serial) throw Error("prove: the resident values were generated for another prover key");
     if (v->shard_rank >= 0 && (v->shard_rank != rank || v->shard_world != world))
         throw Error("prove: these values hold the tables of rank " + std::to_string(v->shard_rank) + " of " + std::to_string(v->shard_world) + " only (hg_witness_gen_shard)");
@@ -982,14 +999,14 @@ static std::shared_ptr<ProveCache> prove_through_graph(hg_ctx* ctx, const hg_pk*
             return nullptr;
         }
     }
-    *out = prove_from_cache(ctx, C.get(), exchange, replay_now);
+    *out = prove_from_cache(ctx, C.get(), exchange, replay_now, false, 0, false, borrow);
     return C;
 }
 
-ProveResult prove_resident(hg_ctx* ctx, const hg_pk* pk, const hg_values* v) {
+ProveResult prove_resident(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, bool borrow) {
     {
         ProveResult cached;
-        if (prove_through_graph(ctx, pk, v, 0, 1, false, &cached)) return cached;
+        if (prove_through_graph(ctx, pk, v, 0, 1, false, &cached, true, borrow)) return cached;
     }
     ProveResult res;
     double t3 = 0;

@@ -197,6 +197,10 @@ namespace hg {
 
 struct ProveResult {
     std::vector<uint8_t> proof;
+    // prove_resident(.., borrow = true) from a cached launch graph: the bytes stay in the cached prover's buffer (valid until the next
+    // prove of the context) and `proof` is empty - no 150 KB allocation (an mmap, its page faults and an munmap) and copy per proof
+    const std::vector<uint8_t>* proof_ref = nullptr;
+    const std::vector<uint8_t>& bytes() const { return proof_ref ? *proof_ref : proof; }
     double witness_ms = 0, upload_ms = 0, prove_ms = 0, gpu_ms = 0, enqueue_ms = 0, sync_ms = 0, replay_ms = 0;
 };
 
@@ -215,7 +219,7 @@ std::vector<ProveResult> prove_stream(hg_ctx* ctx, const hg_pk* pk, const std::v
 void values_free(hg_values* v);
 void pending_shard_drop(hg_ctx* ctx);
 void ctx_register(hg_ctx* ctx, bool alive);
-ProveResult prove_resident(hg_ctx* ctx, const hg_pk* pk, const hg_values* v);
+ProveResult prove_resident(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, bool borrow = false);
 // the same in a protocol mode of SURVEY.md 8(f) f-4 (bit 0 absorbing transcript, bit 1 extension-field memory checking):
 // round-by-round prover (prover_seq.hip); mode 0 = prove_resident
 ProveResult prove_resident_mode(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int mode);
