@@ -99,6 +99,53 @@ __device__ __forceinline__ void wmac_pair(WAcc& w, u64 a, u64 b, u64 c, u64 d) {
         : "v"(a0), "v"(a1), "v"(b0), "v"(b1), "v"(e0), "v"(e1), "v"(f0), "v"(f1));
 }
 
+// The same accumulations STARTING an accumulator (the per-item folds x + r d: one or two products on top of x, reduced at once): the
+// first product of a column has nothing to add to and cannot carry, so the nine zeroing moves of wacc_zero() and two carry banks go.
+// w = x + a * b + c * d
+__device__ __forceinline__ WAcc wacc_pair_init(u64 x, u64 a, u64 b, u64 c, u64 d) {
+    WAcc w;
+    w.L = x;
+    u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    u32 e0 = (u32)c, e1 = (u32)(c >> 32), f0 = (u32)d, f1 = (u32)(d >> 32);
+    u64 c0, c1, c2, c3;
+    asm("v_mad_u64_u32 %0, %6, %10, %12, %0\n\t"    // L += a0 b0
+        "v_mad_u64_u32 %1, %7, %10, %13, 0\n\t"     // M  = a0 b1
+        "v_mad_u64_u32 %2, %8, %11, %13, 0\n\t"     // H  = a1 b1
+        "v_addc_co_u32_e64 %3, %6, 0, 0, %6\n\t"    // tL = carry
+        "v_mad_u64_u32 %0, %6, %14, %16, %0\n\t"    // L += e0 f0
+        "v_mad_u64_u32 %1, %7, %11, %12, %1\n\t"    // M += a1 b0
+        "v_mad_u64_u32 %2, %8, %15, %17, %2\n\t"    // H += e1 f1
+        "v_addc_co_u32_e64 %3, %6, 0, %3, %6\n\t"
+        "v_addc_co_u32_e64 %4, %7, 0, 0, %7\n\t"    // tM = carry
+        "v_mad_u64_u32 %1, %7, %14, %17, %1\n\t"    // M += e0 f1
+        "v_addc_co_u32_e64 %5, %8, 0, 0, %8\n\t"    // tH = carry
+        "v_mad_u64_u32 %1, %9, %15, %16, %1\n\t"    // M += e1 f0
+        "v_addc_co_u32_e64 %4, %7, 0, %4, %7\n\t"
+        "s_nop 0\n\t"
+        "v_addc_co_u32_e64 %4, %9, 0, %4, %9"
+        : "+v"(w.L), "=&v"(w.M), "=&v"(w.H), "=&v"(w.tL), "=&v"(w.tM), "=&v"(w.tH), "=&s"(c0), "=&s"(c1), "=&s"(c2), "=&s"(c3)
+        : "v"(a0), "v"(a1), "v"(b0), "v"(b1), "v"(e0), "v"(e1), "v"(f0), "v"(f1));
+    return w;
+}
+// w = x + a * b
+__device__ __forceinline__ WAcc wacc_mul_init(u64 x, u64 a, u64 b) {
+    WAcc w;
+    w.L = x;
+    w.tH = 0;
+    u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    u64 c0, c1, c2;
+    asm("v_mad_u64_u32 %0, %5, %8, %10, %0\n\t"     // L += a0 b0
+        "v_mad_u64_u32 %1, %6, %8, %11, 0\n\t"      // M  = a0 b1
+        "v_mad_u64_u32 %2, %7, %9, %11, 0\n\t"      // H  = a1 b1
+        "v_addc_co_u32_e64 %3, %5, 0, 0, %5\n\t"    // tL = carry
+        "v_mad_u64_u32 %1, %6, %9, %10, %1\n\t"     // M += a1 b0
+        "s_nop 1\n\t"
+        "v_addc_co_u32_e64 %4, %6, 0, 0, %6"          // tM = carry
+        : "+v"(w.L), "=&v"(w.M), "=&v"(w.H), "=&v"(w.tL), "=&v"(w.tM), "=&s"(c0), "=&s"(c1), "=&s"(c2)
+        : "v"(a0), "v"(a1), "v"(b0), "v"(b1));
+    return w;
+}
+
 // lo + hi * 2^64 with hi < 2^32  ->  canonical
 __device__ __forceinline__ u64 gl_reduce96(u64 lo, u32 hi) {
     u64 t1 = ((u64)hi << 32) - hi;  // hi * (2^32 - 1) < 2^64
@@ -147,10 +194,8 @@ struct FoldR {
 };
 __device__ __forceinline__ FoldR fold_r(E2 r) { FoldR f; f.r0 = r.c0; f.r1 = r.c1; f.r17 = gl_mul_small(r.c1, 7); return f; }
 __device__ __forceinline__ E2 e2_fold_wide(E2 x, E2 d, const FoldR& f) {
-    WAcc a = wacc_zero(), b = wacc_zero();
-    a.L = x.c0; b.L = x.c1;
-    wmac_pair(a, f.r0, d.c0, f.r17, d.c1);
-    wmac_pair(b, f.r0, d.c1, f.r1, d.c0);
+    const WAcc a = wacc_pair_init(x.c0, f.r0, d.c0, f.r17, d.c1);
+    const WAcc b = wacc_pair_init(x.c1, f.r0, d.c1, f.r1, d.c0);
     return e2(wreduce(a), wreduce(b));
 }
 

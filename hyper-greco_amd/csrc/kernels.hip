@@ -172,12 +172,9 @@ __device__ __forceinline__ void gp_first_pair(GpFirstAcc& A, u64 xl, u64 yl, u64
         }
     }
     // gamma^i * (xl + r dl) = gamma^i xl + (gamma^i r) dl
-    WAcc f0 = wacc_zero(), f1 = wacc_zero(), h0 = wacc_zero(), h1 = wacc_zero();
-    wmac_pair(f0, gm.c0, xl, gr.c0, dl);
-    wmac_pair(f1, gm.c1, xl, gr.c1, dl);
+    const WAcc f0 = wacc_pair_init(0, gm.c0, xl, gr.c0, dl), f1 = wacc_pair_init(0, gm.c1, xl, gr.c1, dl);
     store_e2_nt<GIO>(out_l, e2(wreduce(f0), wreduce(f1)));
-    h0.L = xr;
-    wmac2(h0, r.c0, dr, h1, r.c1, dr);
+    const WAcc h0 = wacc_mul_init(xr, r.c0, dr), h1 = wacc_mul_init(0, r.c1, dr);
     store_e2_nt<GIO>(out_r, e2(wreduce(h0), wreduce(h1)));
 }
 // product-tree entries (q0, q1) of positions 2j, 2j + 1 to every row named by `mask` (GpHashSrc::emit_rd, StJob::emit_mask)
@@ -419,9 +416,7 @@ __device__ __forceinline__ void sc_round_body(const T* __restrict__ in, size_t i
                     const u64 m = pw[i].c0;
                     const E2 mr = pwr[i];
                     if (!(p0_only && i == 0)) wmac2(w0, m, x, w2, m, v2);  // (a p0-only table 0 belongs to another rank's share)
-                    WAcc f0 = wacc_zero(), f1 = wacc_zero();
-                    wmac_pair(f0, m, x, mr.c0, d);
-                    wmac(f1, mr.c1, d);
+                    const WAcc f0 = wacc_pair_init(0, m, x, mr.c0, d), f1 = wacc_mul_init(0, mr.c1, d);
                     store_e2<GIO>(out + (size_t)i * out_stride + jo, e2(wreduce(f0), wreduce(f1)));
                 }
                 s0 = wreduce(w0); s2 = wreduce(w2);
@@ -1375,9 +1370,7 @@ __device__ __forceinline__ void ps_round_body(const PsJob& J, int rd, int in_buf
             if constexpr (std::is_same<TA, u64>::value) {
                 wmac2(w0.A, xb.c0, xa, w0.C, xb.c1, xa);
                 wmac2(w2.A, vb.c0, va, w2.C, vb.c1, va);
-                WAcc f0 = wacc_zero(), f1 = wacc_zero();
-                f0.L = xa;
-                wmac2(f0, fr.r0, da, f1, fr.r1, da);
+                const WAcc f0 = wacc_mul_init(xa, fr.r0, da), f1 = wacc_mul_init(0, fr.r1, da);
                 store_e2(oa + jo, e2(wreduce(f0), wreduce(f1)));
             } else {
                 we2_mac(w0, xb, xa);
@@ -1475,9 +1468,7 @@ __device__ __forceinline__ void ps_step2_body(const PsJob& J, const PsItem& I, s
             if constexpr (std::is_same<TA, u64>::value) {
                 wmac2(w0.A, xb.c0, xa, w0.C, xb.c1, xa);
                 wmac2(w2.A, vb.c0, va, w2.C, vb.c1, va);
-                WAcc f0 = wacc_zero(), f1 = wacc_zero();
-                f0.L = xa;
-                wmac2(f0, fa.r0, da, f1, fa.r1, da);
+                const WAcc f0 = wacc_mul_init(xa, fa.r0, da), f1 = wacc_mul_init(0, fa.r1, da);
                 ma = e2(wreduce(f0), wreduce(f1));
             } else {
                 we2_mac(w0, xb, xa);
@@ -1529,15 +1520,15 @@ __device__ __forceinline__ Fold4 fold4(const E2* __restrict__ c) {   // c = the 
     return f;
 }
 __device__ __forceinline__ E2 fold4_apply(const Fold4& f, const u64 (&v)[4]) {
-    WAcc a = wacc_zero(), b = wacc_zero();
+    WAcc a = wacc_mul_init(0, f.c[0].c0, v[0]), b = wacc_mul_init(0, f.c[0].c1, v[0]);
 #pragma unroll
-    for (int p = 0; p < 4; p++) wmac2(a, f.c[p].c0, v[p], b, f.c[p].c1, v[p]);
+    for (int p = 1; p < 4; p++) wmac2(a, f.c[p].c0, v[p], b, f.c[p].c1, v[p]);
     return e2(wreduce(a), wreduce(b));
 }
 __device__ __forceinline__ E2 fold4_apply(const Fold4& f, const E2 (&v)[4]) {
-    WAcc a = wacc_zero(), b = wacc_zero();
+    WAcc a = wacc_pair_init(0, f.c[0].c0, v[0].c0, f.c17[0], v[0].c1), b = wacc_pair_init(0, f.c[0].c0, v[0].c1, f.c[0].c1, v[0].c0);
 #pragma unroll
-    for (int p = 0; p < 4; p++) {
+    for (int p = 1; p < 4; p++) {
         wmac_pair(a, f.c[p].c0, v[p].c0, f.c17[p], v[p].c1);
         wmac_pair(b, f.c[p].c0, v[p].c1, f.c[p].c1, v[p].c0);
     }
@@ -1727,9 +1718,7 @@ __device__ __forceinline__ void ps_tail_item(TA xa, TA ya, E2 xb, E2 yb, const F
     if constexpr (std::is_same<TA, u64>::value) {
         wmac2(w0.A, xb.c0, xa, w0.C, xb.c1, xa);
         wmac2(w2.A, vb.c0, va, w2.C, vb.c1, va);
-        WAcc f0 = wacc_zero(), f1 = wacc_zero();
-        f0.L = xa;
-        wmac2(f0, fr.r0, da, f1, fr.r1, da);
+        const WAcc f0 = wacc_mul_init(xa, fr.r0, da), f1 = wacc_mul_init(0, fr.r1, da);
         fa = e2(wreduce(f0), wreduce(f1));
     } else {
         we2_mac(w0, xb, xa);
