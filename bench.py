@@ -77,6 +77,7 @@ class Counters:
             if got != want:
                 self.note = (self.note or "") + f"profiles/{name}: taken on code {got}, this is {want} - refused; "
                 continue
+            self.proves = d["_meta"].get("proves") or self.proves   # counted by the pass itself (k_clear_words launches); 2 in files older than round 6
             d.pop("_meta", None)
             setattr(self, attr, d)
             self.files[attr] = f"profiles/{name}"

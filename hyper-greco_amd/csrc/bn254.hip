@@ -23,6 +23,7 @@
 #include "bn254_field.hpp"
 #include "bn254_wide.hpp"
 #include "bn254_lazy.hpp"
+#include "bn254_mfma.hpp"
 #include "host.hpp"
 #include "prover.hpp"
 #include "kernels.hpp"
@@ -94,8 +95,22 @@ __global__ void k_bn_from_mont(Fr* __restrict__ t, size_t n) {
 //   7  lz_add(a, b), 8  lz_subr(a, b)                     (a, b < 2p)
 //   9  three products through one lz_reduce: (a b + a a + b b) R^-1 mod p with the subtraction operand lz_sub(a, b) as a factor of a
 //      fourth: + lz_sub(a, b) * b                          (a, b < 2p)
-__global__ void k_bn_lazy_op(int op, size_t n, const Fr* __restrict__ a, const Fr* __restrict__ b, Fr* __restrict__ out, FoldK fk) {
+//  10  mf_fold (bn254_mfma.hpp): a + r (b - a) R^-1 mod p on the matrix cores, r as in 6 (a, b < 2^256: any bytes)
+__global__ void k_bn_lazy_op(int op, size_t n, const Fr* __restrict__ a, const Fr* __restrict__ b, Fr* __restrict__ out, FoldK fk, const MfA* __restrict__ mfa) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (op >= 10) {   // whole waves: a lane beyond n works on entry n - 1 and stores nothing
+        const int lane = threadIdx.x & 63;
+        Fr r;
+        {
+            const MfLane K = mf_load(mfa, lane);
+            const size_t i0 = i - lane, e0 = i0 + (lane & 31) < n ? i0 + (lane & 31) : n - 1, e1 = i0 + 32 + (lane & 31) < n ? i0 + 32 + (lane & 31) : n - 1;
+            const int h16 = 16 * (lane >> 5);
+            r = mf_fold(K, mf_gload16(reinterpret_cast<const char*>(&a[e0]) + h16), mf_gload16(reinterpret_cast<const char*>(&b[e0]) + h16),
+                        mf_gload16(reinterpret_cast<const char*>(&a[e1]) + h16), mf_gload16(reinterpret_cast<const char*>(&b[e1]) + h16));
+        }
+        if (i < n) out[i] = lz_canon(r);
+        return;
+    }
     if (i >= n) return;
     const Fr x = a[i], y = b[i];
     Fr r;
@@ -227,7 +242,14 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_round(const Fr* __restrict__ in, 
 // the linear table S = sum_i w_i (l_i + r_i) in natural order ([2j], [2j+1]), folded into s_out; K1 S(t) + K2 joins P0 and P1.
 struct GpJobDev { const Fr* l_base; const Fr* r_base; Fr* out; Fr* part; Fr r; unsigned long long half, l_stride, r_stride; int nb, gx, gy, mirror;
                   const Fr* s_in; Fr* s_out; Fr k1, k2;
-                  FoldK fk; };   // fold_consts(r): the round's folds x + r d run through lz_fold (bn254_lazy.hpp)
+                  FoldK fk;      // fold_consts(r): the mirrored layer's S table folds through lz_fold (bn254_lazy.hpp)
+                  int wg0, pad0; // first workgroup of the job in its round's launch
+                  Fr* acc;       // per-thread running sums [gx gy BN_TPB][3] of a job whose threads take more than one pair index (half > gx BN_GP_J), else null
+                  MfA* mf; };    // the round's folds x + r (y - x) as an int8 matrix product (bn254_mfma.hpp); filled by k_bn_mf_consts ahead of the rounds
+__global__ __launch_bounds__(64) void k_bn_mf_consts_one(const Fr* __restrict__ r, MfA* __restrict__ out) { mf_consts_column(*r, threadIdx.x, out); }
+// the MfA of every job of a descriptor array: one workgroup of 64 threads per job
+template <typename JOB>
+__global__ __launch_bounds__(64) void k_bn_mf_consts(const JOB* __restrict__ jobs) { mf_consts_column(jobs[blockIdx.x].r, threadIdx.x, jobs[blockIdx.x].mf); }
 __device__ __forceinline__ Fr fr_swap_lane(const Fr& v) {
     Fr o;
 #pragma unroll
@@ -249,10 +271,13 @@ __device__ __forceinline__ Fr fr_sel(bool c, const Fr& a, const Fr& b) { return 
 // conditional branches per kernel, 0.59 of the issue rate.) The folded tables and the mirrored layer's S table are written LOOSE
 // (any representative below 2p): their readers are this kernel, the tail kernel (normalises on load) and fr_from_mont.
 constexpr int BN_GP_J = BN_TPB;   // pair indices per workgroup
-__global__ __launch_bounds__(BN_TPB) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_bn_gp_round_jobs(const GpJobDev* __restrict__ jobs) {
-    const GpJobDev& J = jobs[blockIdx.y];
-    const int tile = blockIdx.x;
-    if (tile >= J.gx * J.gy) return;
+// Launch: ONE grid dimension over the workgroups of every job of the round (jobmap[blockIdx.x] = job, GpJobDev::wg0 = the job's first
+// workgroup). Until round 6 the grid was (largest job's workgroups) x (jobs) and a workgroup beyond its job's count returned at once:
+// 134 000 workgroups per prove of which ~15 000 had work - every empty one still claimed 64 KiB of LDS and 256 registers per lane
+// for the microsecond its descriptor load took.
+__global__ __launch_bounds__(BN_TPB) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_bn_gp_round_jobs(const GpJobDev* __restrict__ jobs, const unsigned short* __restrict__ jobmap) {
+    const GpJobDev& J = jobs[jobmap[blockIdx.x]];
+    const int tile = (int)blockIdx.x - J.wg0;
     // per wave: the eight 16-byte pieces (xl, yl, xr, yr) of every lane's NEXT TWO (pair, j) items, written by LDS-DMA while the
     // current one is computed on. Two waves per SIMD at 256 VGPRs cannot hide a load -> wait -> compute chain otherwise (measured: the
     // loads alone, one item in flight per wave, take 1.47 ms of a 2.3 ms launch - 64 KiB in flight per CU against a loaded memory
@@ -270,8 +295,7 @@ __global__ __launch_bounds__(BN_TPB) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     Fr* __restrict__ out = J.out;
     const size_t half = J.half;
     const int nb = J.nb, P = J.gy, bx = tile % J.gx, pi = tile / J.gx;
-    const LzK KK = lz_load_k(J.fk.k);   // the round's fold constants: SGPR-resident for the whole kernel
-    const u32* K = KK.k;
+    const MfLane MK = mf_load(J.mf, lane);   // the round's fold as a matrix product: this lane's rows of A and its C operand
     const size_t jstep = (size_t)J.gx * BN_GP_J;
     auto prefetch = [&](int i, size_t j, u32 buf) {   // lanes beyond the table issue nothing
         if (j < half) {
@@ -283,6 +307,9 @@ __global__ __launch_bounds__(BN_TPB) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             for (int k = 0; k < 4; k++) lz_glds16(gr + 16 * k, lds0 + buf * BUF + 1024u * (4 + k));
         }
     };
+    // the thread's running sums of g(0), g(2), g(3) over its pair indices live in HBM between two of them (J.acc; loose): 24 registers
+    // that the matrix-core folds' accumulators need. A thread with one pair index (most jobs) never touches the buffer.
+    Fr* __restrict__ accp = J.acc ? J.acc + ((size_t)(pi * J.gx + bx) * BN_TPB + threadIdx.x) * 3 : nullptr;
     Fr acc0 = fr_zero(), acc2 = fr_zero(), acc3 = fr_zero();   // loose
     // The wave's items, in order: t = 0 .. n_items - 1 <-> (jw, i) with i running fastest. All 64 lanes stay in the loops (the counts are
     // uniform over the wave); a lane beyond the table (tables shorter than a wave) is masked where it loads, stores or sums.
@@ -313,21 +340,26 @@ __global__ __launch_bounds__(BN_TPB) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             if (issued > t + 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else lz_wait_vm0();
             const lz_u32x4* mine = &stage[t & 1][wave][0][lane];
-            Fr dl, dr;
+            // the folds on the matrix cores (bn254_mfma.hpp): the operand of lane (n, h) is piece h of the staged x / y of elements n and
+            // 32 + n - the same bytes, read once more in another order
+            const mf_v4i* mfp = reinterpret_cast<const mf_v4i*>(&stage[t & 1][wave][lane >> 5][lane & 31]);
             {
-                const Fr xl = lz_from_x4(mine[0], mine[64]), yl = lz_from_x4(mine[128], mine[192]);
-                dl = lz_sub(yl, xl);
-                const Fr fl = lz_fold(xl, dl, K);
+                const Fr fl = mf_fold(MK, mfp[0], mfp[128], mfp[32], mfp[160]);
                 if (valid) lz_gstore(&out[(size_t)(2 * i) * half + j], fl);
             }
             asm volatile("" ::: "memory");
             {
-                const Fr xr = lz_from_x4(mine[256], mine[320]), yr = lz_from_x4(mine[384], mine[448]);
-                dr = lz_sub(yr, xr);
-                const Fr fr_ = lz_fold(xr, dr, K);
+                const Fr fr_ = mf_fold(MK, mfp[256], mfp[384], mfp[288], mfp[416]);
                 if (valid) lz_gstore(&out[(size_t)(2 * i + 1) * half + j], fr_);
             }
-            wcol_mac(ci, dl, dr);
+            asm volatile("" ::: "memory");
+            {
+                const Fr xl = lz_from_x4(mine[0], mine[64]), yl = lz_from_x4(mine[128], mine[192]);
+                const Fr dl = lz_sub(yl, xl);
+                const Fr xr = lz_from_x4(mine[256], mine[320]), yr = lz_from_x4(mine[384], mine[448]);
+                const Fr dr = lz_sub(yr, xr);
+                wcol_mac(ci, dl, dr);
+            }
             asm volatile("" ::: "memory");
             {
                 const Fr xl = lz_from_x4(mine[0], mine[64]), xr = lz_from_x4(mine[256], mine[320]);
@@ -354,16 +386,26 @@ __global__ __launch_bounds__(BN_TPB) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             const Fr sx = lz_gload(&J.s_in[2 * jc]), sy = lz_gload(&J.s_in[2 * jc + 1]);
             P0 = lz_add(P0, lz_add(lz_mul(J.k1, sx), J.k2));
             P1 = lz_add(P1, lz_add(lz_mul(J.k1, sy), J.k2));
-            const Fr sf = lz_fold(sx, lz_sub(sy, sx), K);
+            const Fr sf = lz_fold(sx, lz_sub(sy, sx), J.fk.k);
             if (valid) lz_gstore(&J.s_out[j], sf);
         }
         const Fr P1x2 = lz_add(P1, P1), Pix2 = lz_add(Pi, Pi);
         const Fr q2 = lz_add(lz_subr(P1x2, P0), Pix2);
         const Fr q3 = lz_add(lz_subr(lz_add(P1x2, P1), lz_add(P0, P0)), lz_add(lz_add(Pix2, Pix2), Pix2));
         const Fr t0 = lz_mul(p0, P0), t2 = lz_mul(p2, q2), t3 = lz_mul(p3, q3);
-        acc0 = lz_add(acc0, valid ? t0 : fr_zero());
-        acc2 = lz_add(acc2, valid ? t2 : fr_zero());
-        acc3 = lz_add(acc3, valid ? t3 : fr_zero());
+        acc0 = valid ? t0 : fr_zero();
+        acc2 = valid ? t2 : fr_zero();
+        acc3 = valid ? t3 : fr_zero();
+        if (jw != jw0) {   // (uniform over the wave; implies accp)
+            acc0 = lz_add(acc0, lz_gload(&accp[0]));
+            acc2 = lz_add(acc2, lz_gload(&accp[1]));
+            acc3 = lz_add(acc3, lz_gload(&accp[2]));
+        }
+        if (jw + jstep < half) {
+            lz_gstore(&accp[0], acc0);
+            lz_gstore(&accp[1], acc2);
+            lz_gstore(&accp[2], acc3);
+        }
     }
     lz_wait_vm0();
     __syncthreads();   // every wave is done with its staging bytes
@@ -575,25 +617,29 @@ __global__ __launch_bounds__(BN_TPB * (KIND == BN_GRANDPROD ? 3 : 2)) void k_bn_
 // takes eval(1) from the claim and computes eval(2) (convention C1), and the claim is not the sum of g for the collation sum-check of
 // the Lasso node (Expression::poly(0) stands where an eq table would, lasso.rs:457-475) nor for any node of an INVALID witness - the
 // transcript must be the reference's there too (test_bn254_invalid_witness_rejected_by_both_verifiers).
-struct PsJobDev { const Fr* t[2 * dev::PS_MAX_PAIRS]; Fr* out; Fr* part; Fr r; unsigned long long half; int npairs, gx, gy, pad; unsigned long long wlo, whi; FoldK fk; };   // fk = fold_consts(r); pad bit 0: every pair has the same b table, bit 1: write its fold once per pair; bit 2: the (single) b table is zero outside the pair indices [wlo, whi), bit 3: write zeros there
+struct PsJobDev { const Fr* t[2 * dev::PS_MAX_PAIRS]; Fr* out; Fr* part; Fr r; unsigned long long half; int npairs, gx, gy, pad; unsigned long long wlo, whi; FoldK fk; MfA* mf; int wg0, pad0; };   // fk = fold_consts(r); pad bit 0: every pair has the same b table, bit 1: write its fold once per pair; bit 2: the (single) b table is zero outside the pair indices [wlo, whi), bit 3: write zeros there
 // One round of g = sum_i a_i b_i for many independent sum-checks (blockIdx.y = job). Two workgroup sets per tile (v = 0: g(0) = sum xa xb
 // and the folds of the a tables, v = 1: g(2) = sum (2 ya - xa)(2 yb - xb) and the folds of the b tables; ids 8 (2 q + v) + xcd keep a
 // tile's two workgroups on one XCD, adjacent in dispatch order, so the second reads the tables from L2): one column accumulator, one
 // multiply-accumulate and one fold per lane and (pair, j) keeps the kernel at ~120 VGPRs = four waves per SIMD, which is what hides the
 // load latency of these mostly small, single-pair jobs (one lane doing both halves needs 259 registers, one wave per SIMD: 1.3x
 // slower). Loose arithmetic throughout (bn254_lazy.hpp); the folded tables are loose.
-__global__ __launch_bounds__(BN_TPB) void k_bn_ps_round_jobs(const PsJobDev* __restrict__ jobs) {
-    const PsJobDev& J = jobs[blockIdx.y];
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, v = slot & 1, tile = (slot >> 1) * 8 + xcd;
-    if (tile >= J.gx * J.gy) return;
-    __shared__ Fr sm[BN_TPB];
+// MF: the folds run on the matrix cores (bn254_mfma.hpp: a wave folds its 64 entries together; needs whole waves inside the table and
+// inside / outside a windowed table's window, i.e. half and the window bounds multiples of 64 - every launched round of the large
+// parameter sets); otherwise lane by lane through lz_fold.
+template <bool MF>
+__device__ __forceinline__ void ps_round_body(const PsJobDev& J, int tile, int v, Fr* sm) {
     Fr acc = fr_zero();   // loose
     const int bx = tile % J.gx, pi = tile / J.gx, P = J.gy, npairs = J.npairs;
     const size_t half = J.half;
     Fr* __restrict__ out = J.out;
     const u32* __restrict__ K = J.fk.k;
     const bool shared = J.pad & 1, replicate = J.pad & 2;
+    const int lane = threadIdx.x & 63;
+    MfLane MK;
+    if (MF) MK = mf_load(J.mf, lane);
     for (size_t j = (size_t)bx * BN_TPB + threadIdx.x; j < half; j += (size_t)J.gx * BN_TPB) {
+        const size_t jw = j - lane;   // the wave's first entry
         WCol s = wcol_zero();
         if (shared) {
             // every pair has the SAME b table (the node's eq table: one unit relay per position and input): sum_i a_i b = (sum_i a_i) b,
@@ -603,18 +649,24 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_ps_round_jobs(const PsJobDev* __r
             Fr sa = fr_zero();
             for (int i = pi; i < npairs; i += P) {
                 const Fr* ta = J.t[2 * i];
-                const Fr xa = lz_gload(&ta[2 * j]), ya = lz_gload(&ta[2 * j + 1]);
                 if (v == 0) {
+                    const Fr xa = lz_gload(&ta[2 * j]);
                     sa = lz_add(sa, xa);
-                    lz_gstore(&out[(size_t)(2 * i) * half + j], lz_fold(xa, lz_sub(ya, xa), K));
-                } else sa = lz_add(sa, lz_add(ya, lz_subr(ya, xa)));
+                    Fr f;
+                    if (MF) f = mf_fold_global(MK, ta, jw, half, lane);
+                    else { const Fr ya = lz_gload(&ta[2 * j + 1]); f = lz_fold(xa, lz_sub(ya, xa), K); }
+                    lz_gstore(&out[(size_t)(2 * i) * half + j], f);
+                } else {
+                    const Fr xa = lz_gload(&ta[2 * j]), ya = lz_gload(&ta[2 * j + 1]);
+                    sa = lz_add(sa, lz_add(ya, lz_subr(ya, xa)));
+                }
             }
             if (v == 0) wcol_mac(s, sa, xb);
             else {
                 const Fr db = lz_sub(yb, xb);
                 wcol_mac(s, sa, lz_add(yb, lz_cond_sub_2p(db)));
                 if (pi == 0) {
-                    const Fr fb = lz_fold(xb, db, K);
+                    const Fr fb = MF ? mf_fold_global(MK, tb, jw, half, lane) : lz_fold(xb, db, K);
                     lz_gstore(&out[half + j], fb);
                     if (replicate)   // the last shared-launch round: the tail workgroup reads one b table per pair
                         for (int i = 1; i < npairs; i++) lz_gstore(&out[(size_t)(2 * i + 1) * half + j], fb);
@@ -623,29 +675,36 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_ps_round_jobs(const PsJobDev* __r
             acc = lz_add(acc, lz_reduce(s));
             continue;
         }
-        if ((J.pad & 4) && (j < J.wlo || j >= J.whi)) {
+        if ((J.pad & 4) && (j < J.wlo || j >= J.whi)) {   // (MF: uniform over the wave)
             // the b table is zero here (a chunk node's table covers one 2^L slice of the 2^(L+3) positions): no product, the fold of b
             // is zero and is not even written - the next round does not look outside its (halved) window either, except behind the
             // last shared-launch round, whose successor (the tail workgroup) reads whole tables
             if (v == 0) {
                 const Fr* ta = J.t[0];
-                const Fr xa = lz_gload(&ta[2 * j]), ya = lz_gload(&ta[2 * j + 1]);
-                lz_gstore(&out[j], lz_fold(xa, lz_sub(ya, xa), K));
+                Fr f;
+                if (MF) f = mf_fold_global(MK, ta, jw, half, lane);
+                else { const Fr xa = lz_gload(&ta[2 * j]), ya = lz_gload(&ta[2 * j + 1]); f = lz_fold(xa, lz_sub(ya, xa), K); }
+                lz_gstore(&out[j], f);
             } else if (J.pad & 8) lz_gstore(&out[half + j], fr_zero());
             continue;
         }
         for (int i = pi; i < npairs; i += P) {
             const Fr* ta = J.t[2 * i];
             const Fr* tb = J.t[2 * i + 1];
-            const Fr xa = lz_gload(&ta[2 * j]), ya = lz_gload(&ta[2 * j + 1]);
-            const Fr xb = lz_gload(&tb[2 * j]), yb = lz_gload(&tb[2 * j + 1]);
             if (v == 0) {   // (uniform over the workgroup)
+                const Fr xa = lz_gload(&ta[2 * j]), xb = lz_gload(&tb[2 * j]);
                 wcol_mac(s, xa, xb);
-                lz_gstore(&out[(size_t)(2 * i) * half + j], lz_fold(xa, lz_sub(ya, xa), K));
+                Fr f;
+                if (MF) f = mf_fold_global(MK, ta, jw, half, lane);
+                else { const Fr ya = lz_gload(&ta[2 * j + 1]); f = lz_fold(xa, lz_sub(ya, xa), K); }
+                lz_gstore(&out[(size_t)(2 * i) * half + j], f);
             } else {
+                const Fr xa = lz_gload(&ta[2 * j]), ya = lz_gload(&ta[2 * j + 1]);
+                const Fr xb = lz_gload(&tb[2 * j]), yb = lz_gload(&tb[2 * j + 1]);
                 const Fr db = lz_sub(yb, xb);
                 wcol_mac(s, lz_add(ya, lz_subr(ya, xa)), lz_add(yb, lz_cond_sub_2p(db)));   // (2 ya - xa)(2 yb - xb)
-                lz_gstore(&out[(size_t)(2 * i + 1) * half + j], lz_fold(xb, db, K));
+                const Fr f = MF ? mf_fold_global(MK, tb, jw, half, lane) : lz_fold(xb, db, K);
+                lz_gstore(&out[(size_t)(2 * i + 1) * half + j], f);
             }
         }
         acc = lz_add(acc, lz_reduce(s));
@@ -653,6 +712,19 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_ps_round_jobs(const PsJobDev* __r
     const size_t blk = (size_t)pi * J.gx + bx;
     const Fr r = block_sum_fr(lz_canon(acc), sm);
     if (threadIdx.x == 0) J.part[blk * 2 + v] = r;
+}
+// Launch: one grid dimension over every job's workgroups (jobmap[blockIdx.x >> 4] = job; a job owns a multiple of 16 consecutive
+// workgroups from PsJobDev::wg0 on, so that the pairing by XCD below survives); jobmap null: one job, the grid is its own. Until
+// round 6 the grid was (largest job) x (jobs): 570 000 workgroups per prove, three quarters of them without work.
+__global__ __launch_bounds__(BN_TPB) void k_bn_ps_round_jobs(const PsJobDev* __restrict__ jobs, const unsigned short* __restrict__ jobmap) {
+    const PsJobDev& J = jobs[jobmap ? jobmap[blockIdx.x >> 4] : 0];
+    const int local = (int)blockIdx.x - J.wg0;
+    const int xcd = local & 7, slot = local >> 3, v = slot & 1, tile = (slot >> 1) * 8 + xcd;
+    if (tile >= J.gx * J.gy) return;
+    __shared__ Fr sm[BN_TPB];
+    const bool mf = J.mf && (J.half & 63) == 0 && (!(J.pad & 4) || ((J.wlo | J.whi) & 63) == 0);
+    if (mf) ps_round_body<true>(J, tile, v, sm);
+    else ps_round_body<false>(J, tile, v, sm);
 }
 
 // ---- host arithmetic for the transcript replay (Montgomery form) ---------------------------------------------
@@ -808,7 +880,7 @@ void sumcheck_bn254(hg_ctx* ctx, int kind, size_t nv, size_t ntab, const u64* co
 }
 
 void field_op_bn254(hg_ctx* ctx, int op, size_t n, const u64* a, const u64* b, u64* out) {
-    if (op < 0 || op > 9) throw Error("hg_bn254_field_op: op must be 0 (add), 1 (sub), 2 (mul), 3 (wide mul), 4 (wide a b + a a + b b) or 5 .. 9 (loose forms, raw operands)");
+    if (op < 0 || op > 10) throw Error("hg_bn254_field_op: op must be 0 (add), 1 (sub), 2 (mul), 3 (wide mul), 4 (wide a b + a a + b b), 5 .. 9 (loose forms, raw operands) or 10 (the matrix-core fold)");
     hipc(hipSetDevice(ctx->device), "hipSetDevice");
     Fr *da = nullptr, *db = nullptr, *dc = nullptr;
     hipc(hipMalloc((void**)&da, n * sizeof(Fr)), "hipMalloc");
@@ -820,7 +892,14 @@ void field_op_bn254(hg_ctx* ctx, int op, size_t n, const u64* a, const u64* b, u
             FoldK fk;
             Fr rr = fr_make(12345, 0, 0, 1ULL << 8);   // r = 2^200 + 12345 as a raw residue (fold_consts: K_i = r 2^(32 i) R^-1 mod p)
             fold_consts(rr, &fk);
-            k_bn_lazy_op<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(op, n, da, db, dc, fk);
+            MfA* mfa = nullptr;
+            hipc(hipMalloc((void**)&mfa, sizeof(MfA) + sizeof(Fr)), "hipMalloc");
+            Fr* d_r = reinterpret_cast<Fr*>(mfa + 1);
+            hipc(hipMemcpyAsync(d_r, &rr, sizeof(Fr), hipMemcpyHostToDevice, ctx->stream), "upload");
+            k_bn_mf_consts_one<<<1, 64, 0, ctx->stream>>>(d_r, mfa);
+            k_bn_lazy_op<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(op, n, da, db, dc, fk, mfa);
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipFree(mfa);
         } else
         k_bn_binop<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(op, n, da, db, dc);
         e1 = hipStreamSynchronize(ctx->stream);
@@ -1041,23 +1120,35 @@ struct GpLaunchSet {
 };
 static void gp_launch_set(hg_ctx* ctx, hipStream_t st, GpLaunchSet& S) {
     std::vector<GpJobDev> descs;
-    std::vector<size_t> off;
-    std::vector<int> max_blocks;
+    std::vector<size_t> off, map_off;
+    std::vector<int> total_blocks;
+    std::vector<unsigned short> jobmap;   // per round: workgroup -> job of the round
     for (auto& v : S.by_rd) {
         off.push_back(descs.size());
-        int mb = 0;
-        for (auto& d : v) mb = std::max(mb, d.gx * d.gy);
-        max_blocks.push_back(mb);
+        map_off.push_back(jobmap.size());
+        int wg = 0;
+        for (size_t q = 0; q < v.size(); q++) {
+            v[q].wg0 = wg;
+            wg += v[q].gx * v[q].gy;
+            jobmap.insert(jobmap.end(), (size_t)v[q].gx * v[q].gy, (unsigned short)q);
+        }
+        total_blocks.push_back(wg);
         descs.insert(descs.end(), v.begin(), v.end());
     }
     if (descs.empty()) return;
+    {   // the folds' matrices, one per (layer, round): built on the device from the descriptors' challenges, one launch for the whole set
+        MfA* mfa = static_cast<MfA*>(ctx->alloc(descs.size() * sizeof(MfA)));
+        for (size_t i = 0; i < descs.size(); i++) descs[i].mf = mfa + i;
+    }
     const GpJobDev* d_descs = bn_stage(ctx, descs.data(), descs.size());
+    const unsigned short* d_map = bn_stage(ctx, jobmap.data(), jobmap.size());
     const RedJobDev* d_reds = S.reds.empty() ? nullptr : bn_stage(ctx, S.reds.data(), S.reds.size());
     const TailJobDev* d_tails = S.tails.empty() ? nullptr : bn_stage(ctx, S.tails.data(), S.tails.size());
     bn_flush(ctx, st);
+    k_bn_mf_consts<GpJobDev><<<(unsigned)descs.size(), 64, 0, st>>>(d_descs);
     for (size_t rd = 0; rd < S.by_rd.size(); rd++) {
         for (auto& pf : S.pre) if (pf.first == rd) pf.second();
-        if (!S.by_rd[rd].empty()) k_bn_gp_round_jobs<<<dim3(max_blocks[rd], (unsigned)S.by_rd[rd].size(), 1), BN_TPB, 0, st>>>(d_descs + off[rd]);
+        if (!S.by_rd[rd].empty()) k_bn_gp_round_jobs<<<(unsigned)total_blocks[rd], BN_TPB, 0, st>>>(d_descs + off[rd], d_map + map_off[rd]);
     }
     if (!S.reds.empty()) k_bn_reduce_jobs<<<dim3(32, (unsigned)S.reds.size()), BN_TPB, 0, st>>>(d_reds, 3);
     for (auto& f : S.pre_tail) f();
@@ -1345,6 +1436,7 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
                 }
                 const RoundGrid g = round_grid_gp(half, d.nb, launch_wgs);
                 d.gx = g.gx; d.gy = g.gy;
+                if (half > (size_t)g.gx * BN_GP_J) d.acc = dalloc((size_t)g.blocks() * BN_TPB * 3);   // (the largest layers' first rounds only)
                 reds[red_index[n]].n[rd] = g.blocks();
                 own.by_rd[rd].push_back(d);
             }
@@ -2065,11 +2157,16 @@ static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4,
             tl.buf = tbuf; tl.sums_out = r_col.dev + (size_t)col_nmain * 2; tl.fin_out = fin_dummy;
             for (int q = 0; q < BN_TAIL_ROUNDS; q++) tl.rs.r[q] = q < nu - col_nmain ? fr_to_mont(chain[col_at + col_nmain + q]) : fr_zero();
             tl.npairs = 1; tl.half0 = (int)(N >> (col_nmain + 1)); tl.nrounds = nu - col_nmain;
+            {   // the folds' matrices (bn254_mfma.hpp), one per round
+                MfA* mfa = static_cast<MfA*>(dalloc_b(descs.size() * sizeof(MfA)));
+                for (size_t i = 0; i < descs.size(); i++) descs[i].mf = mfa + i;
+            }
             const PsJobDev* d_descs = bn_stage(ctx, descs.data(), descs.size());
             const RedJobDev* d_red = bn_stage(ctx, &red, 1);
             const TailJobDev* d_tl = bn_stage(ctx, &tl, 1);
             bn_flush(ctx, st);
-            for (int rd = 0; rd < col_nmain; rd++) k_bn_ps_round_jobs<<<dim3(2 * ((blocks[rd] + 7) / 8 * 8), 1, 1), BN_TPB, 0, st>>>(d_descs + rd);
+            if (!descs.empty()) k_bn_mf_consts<PsJobDev><<<(unsigned)descs.size(), 64, 0, st>>>(d_descs);
+            for (int rd = 0; rd < col_nmain; rd++) k_bn_ps_round_jobs<<<dim3(2 * ((blocks[rd] + 7) / 8 * 8), 1, 1), BN_TPB, 0, st>>>(d_descs + rd, nullptr);
             k_bn_reduce_jobs<<<dim3(32, 1), BN_TPB, 0, st>>>(d_red, 2);
             k_bn_tail_jobs<BN_PRODSUM><<<1, 2 * BN_TPB, 0, st>>>(d_tl);
         }
@@ -2236,7 +2333,7 @@ static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4,
             run(eqy, ty, oy, ny, M);
         }
         if (mid && mid_at >= 3) (*mid)();
-        static const bool times = hg_times("bn");
+        const bool times = hg_times("bn");   // read at every call (host.hpp)
         const double t_enq = wall_ms();
         res_sync(ctx, st, "lasso_prove_bn254: sync");
         if (times) fprintf(stderr, "[hg bn]   lasso node: enqueued, waited %.3f ms for its stream\n", wall_ms() - t_enq);

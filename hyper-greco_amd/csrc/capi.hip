@@ -296,7 +296,14 @@ int hg_setup(hg_ctx* ctx, const hg_params* params, hg_pk** out) {
             }
             if (ok && used > 0 && !n.w0.empty()) {
                 if (n.log2_reps > 0) ok = false;
-                std::map<u32, std::pair<u64, size_t>> blocks;   // block -> (value, count)
+                // block-uniform means: EVERY gate of the block carries the constant exactly once, with one value. Counted per DISTINCT gate
+                // (a wiring with two constant terms on some gates of a block and none on others has 2^w entries too)
+                std::map<u32, std::pair<u64, size_t>> blocks;   // block -> (value, distinct gates seen)
+                std::vector<u32> gates;
+                gates.reserve(n.w0.size());
+                for (auto& t : n.w0) gates.push_back(t.gate);
+                std::sort(gates.begin(), gates.end());
+                if (std::adjacent_find(gates.begin(), gates.end()) != gates.end()) ok = false;   // a gate with two constant terms: not the form
                 for (auto& t : n.w0) {
                     if (!ok) break;
                     auto it = blocks.find(t.gate >> w0);

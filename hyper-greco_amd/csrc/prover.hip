@@ -285,6 +285,7 @@ struct Prover {
         early_done = true;
     }
     size_t res_used = 0;
+    size_t res_end = 0;   // slots are handed out below this index (0: the whole result buffer); hg_prove_stream's first table set owns the lower half only
     int cls_gp_hash, cls_gp_base, cls_gp_ext, cls_gp_ext2, cls_col_ext2, cls_col_base, cls_col_ext, cls_ps, cls_ps2, cls_reduce, cls_aux, cls_tree, cls_hash, cls_gather, cls_tail, cls_ps_tail;
 
     // ---- single-proof sharding over `world` GPUs ---------------------------------------------------
@@ -355,7 +356,8 @@ struct Prover {
     E2* d_res() { return ctx->d_res; }
     const E2* h_res() { return ctx->h_res; }
     size_t slot(size_t n) {
-        if (res_used + n > ctx->res_cap) throw Error("result buffer exhausted");
+        // checked where the slot is handed out: nothing is enqueued that would write into the other table set's half
+        if (res_used + n > (res_end ? res_end : ctx->res_cap)) throw Error(res_end ? "hg_prove_stream: a prove's result slots do not fit half of the result buffer" : "result buffer exhausted");
         size_t s = res_used;
         res_used += n;
         return s;
@@ -718,6 +720,7 @@ static void enqueue_prove(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, Prov
     const Params& p = pk->params;
     P->stamp("start");
     if (world == 1) P->res_used = v->res_base;
+    P->res_end = world == 1 ? v->res_limit : 0;
     // (a sharded prove's result-buffer prefix was cleared by the Prover's first launch)
     const bool hinted = ctx->res_hint_serial == pk->serial && ctx->res_hint > 0 && ctx->res_hint <= ctx->res_cap;
     // "eval output" (sk_encryption_circuit.rs:444-448): point, ct0is MLE value
@@ -742,7 +745,6 @@ static void enqueue_prove(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, Prov
         if (hinted && P->res_used > ctx->res_hint) throw Error("sharded prove: the result buffer grew between two proves of one key");
         ctx->res_hint = P->res_used; ctx->res_hint_serial = pk->serial;
     }
-    if (world == 1 && v->res_limit && P->res_used > v->res_limit) throw Error("hg_prove_stream: a prove's result slots do not fit half of the result buffer");
     P->stamp("end of the prove");
     if (exchange) comm_allreduce_results(ctx, P->res_used);  // the one collective of a sharded proof, on the stream
 }

@@ -201,7 +201,7 @@ struct DevBackend : VerifyBackend {
     }
     int mle_ct0is(size_t point_off, int nvars) override { return mle_u64(d_ct0is, point_off, nvars); }
     void finish() override {
-        static const bool times = hg_times("verify");
+        const bool times = hg_times("verify");   // read at every call (host.hpp)
         const double t0 = times ? omp_get_wtime() : 0;
         if (times) { hip_check(hipStreamSynchronize(st), "sync"); fprintf(stderr, "[hg] verify_device: uploads drained %.2f ms after the walk ended; %zu eq tables, %zu gathers, %zu + %zu, %zu dots\n", (omp_get_wtime() - t0) * 1e3, eqs.size(), gts.size(), gbs.size(), ffts.size(), dots.size()); }
         auto lap = [&](const char* what) { if (times) { hip_check(hipStreamSynchronize(st), "sync"); fprintf(stderr, "[hg] verify_device: %8.2f ms  %s\n", (omp_get_wtime() - t0) * 1e3, what); } };

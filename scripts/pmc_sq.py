@@ -21,5 +21,6 @@ for k in sorted(agg, key=lambda k: -agg[k][key])[:top]:
 
 if len(sys.argv) > 3:
     out = {k: dict(launches=cnt[k], **{n: agg[k][n] for n in names}) for k in agg}
-    out["_meta"] = {"code_hash": code_hash(), "workload": "scripts/prove_once.py 32768 16 2 (3 resident proves incl. warm-up; sums over all launches)"}
+    proves = max([v for k, v in cnt.items() if "k_clear_words" in k] or [0])   # one k_clear_words launch per prove
+    out["_meta"] = {"code_hash": code_hash(), "proves": proves, "workload": f"scripts/prove_once.py 32768 16 {proves} ({proves} resident proves, no warm-up; sums over all launches)"}
     json.dump(out, open(sys.argv[3], "w"), indent=1)

@@ -28,5 +28,6 @@ for k in sorted(fetch, key=lambda k: -(2 * fetch[k][1] + write.get(k, [0, 0])[1]
     out[k] = {"launches": n, "fetch_kb_raw": f, "write_kb": w, "hbm_bytes_per_launch": per}
     print(f"{n:8d} {f:16.1f} {w:14.1f} {per/1e6:14.2f}  {k[:100]}")
 if len(sys.argv) > 3:
-    out["_meta"] = {"code_hash": code_hash(), "workload": "scripts/prove_once.py 32768 16 2 (3 resident proves incl. warm-up; per-launch averages)"}
+    proves = max([v["launches"] for k, v in out.items() if "k_clear_words" in k] or [0])   # one k_clear_words launch per prove
+    out["_meta"] = {"code_hash": code_hash(), "proves": proves, "workload": f"scripts/prove_once.py 32768 16 {proves} ({proves} resident proves, no warm-up; per-launch averages)"}
     json.dump(out, open(sys.argv[3], "w"), indent=1)

@@ -1072,6 +1072,10 @@ def test_bn254_loose_arithmetic_against_python_integers(ctx):
     a5 = anyv
     b5 = list(reversed(anyv))
     assert ctx.bn254_field_op(5, a5, b5) == [(x * y * Rinv) % p for x, y in zip(a5, b5)]
+    # bn254_mfma.hpp: the fold x + r (y - x) as an int8 matrix product (any 256-bit operands; lengths that are not a multiple of 64
+    # leave a partial wave). Same residues as the multiply-add form above.
+    for cut in (len(anyv), 4001, 65, 3):
+        assert ctx.bn254_field_op(10, a5[:cut], b5[:cut]) == [(x + r * (y - x) * Rinv) % p for x, y in zip(a5[:cut], b5[:cut])]
     # the largest sum a reduction sees in the kernels: 50 products of operands below 4p (the column accumulators carry it exactly)
     big = [4 * p - 1] * 64
     assert ctx.bn254_field_op(5, big, big) == [((4 * p - 1) ** 2 * Rinv) % p] * 64
