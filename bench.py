@@ -339,6 +339,51 @@ def measure_end_to_end(hg, ctx, bfv, pk, witnesses, walked, args):
     return res
 
 
+def measure_cold_start(hg, device, args, witness, expect):
+    """The drop-in caller's sequence, COLD, as test_sk_enc_valid runs it [REF bfv-gkr/src/test.rs:31-44]: BfvEncrypt::new + setup, read the
+    args file, prove ONCE, verify - in fresh contexts of this process (the HIP runtime itself is already up: hg_create of a second
+    context). Two variants: with hg_warmup behind hg_setup (what a drop-in BfvEncrypt::setup calls: tables, staging and the launch graph
+    recorded on a zero witness, so the first prove replays) and without (the first prove walks the protocol)."""
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import witness_to_json
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "w.json")
+        with open(path, "w") as f:
+            json.dump(witness_to_json.arrays_to_args(args.n, args.k, witness.arrays()), f)
+        for warm in (True, False):
+            t0 = time.perf_counter()
+            c = hg.Context(device)
+            t1 = time.perf_counter()
+            b = hg.BfvEncrypt.new(args.n, args.k)
+            k = b.setup(c)
+            t2 = time.perf_counter()
+            wu = b.warmup(c, k) if warm else 0.0
+            t3 = time.perf_counter()
+            w = b.get_inputs(path)
+            t4 = time.perf_counter()
+            proof, tm = b.prove(c, k, w, cap=1 << 20)
+            t5 = time.perf_counter()
+            ok, err = hg.verify_device(c, k, w, proof)
+            t6 = time.perf_counter()
+            assert proof == expect, "cold start: the first proof of a fresh context differs from the resident prove of the same witness"
+            assert ok, err
+            r = {"hg_create_ms": round((t1 - t0) * 1e3, 2), "setup_ms": round((t2 - t1) * 1e3, 2), "witness_from_json_ms": round((t4 - t3) * 1e3, 2),
+                 "first_prove_ms": round((t5 - t4) * 1e3, 3),
+                 "first_prove_stages_ms": {"upload": round(tm["upload_ms"], 3), "witness_gen_device": round(tm["witness_ms"], 3), "gkr_prove": round(tm["prove_ms"], 3)},
+                 "verify_device_ms": round((t6 - t5) * 1e3, 2)}
+            if warm: r["warmup_ms"] = round((t3 - t2) * 1e3, 2)
+            res["with_hg_warmup" if warm else "without_warmup"] = r
+            k.free()
+            c.close()
+    res["first_prove_ms"] = res["with_hg_warmup"]["first_prove_ms"]
+    res["setup_ms"] = round(res["with_hg_warmup"]["setup_ms"] + res["with_hg_warmup"]["warmup_ms"], 2)
+    res["note"] = ("fresh hg_create + hg_setup (+ hg_warmup) + hg_witness_from_json + the FIRST hg_prove + hg_verify_device, one pass each (no warm-up, no median); "
+                   "first_prove_ms = hg_prove from the parsed (pageable) arrays: staging, upload, circuit evaluation on the device, GKR prove; setup_ms = hg_setup + hg_warmup")
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -613,9 +658,11 @@ def main():
     ctx.set_option("one_stream", 0)
 
     end_to_end = None
+    cold_start = None
     verify_info = None
     if world == 1 and rank == 0 and not args.no_end_to_end:
         end_to_end = measure_end_to_end(hg, ctx, bfv, pk, witnesses, walked, args)
+        cold_start = measure_cold_start(hg, local_rank, args, witnesses[0], walked[0])
         # BfvEncrypt::verify (host side, like the reference's; OpenMP over the table-sized loops) on the proof of witness 0
         vt = []
         for _ in range(4):
@@ -702,6 +749,7 @@ def main():
                                                             "the cone of those tables (peak = its tables + the cone's subset tables; witness ms = upload + evaluation of the cone)"}} if shard else {}),
                        **({"dp_aggregate": dp_leg} if dp_leg else {}),
                        **({"end_to_end": end_to_end} if end_to_end else {}),
+                       **({"cold_start": cold_start} if cold_start else {}),
                        **({"verify": verify_info} if verify_info else {}),
                        "witness_gen_ms_device_first_call": round(vals[0].timings["witness_ms"], 2), "upload_ms_first_call": round(vals[0].timings["upload_ms"], 2)},
             # `achieved` / `avg_launch_us`: HIP events around the dominant kernel class over the K proves of timed region A, where its launches

@@ -38,7 +38,7 @@ class HgKernelStat(C.Structure):
 EXPORTS = [
     "hg_last_error", "hg_device_count", "hg_create", "hg_destroy", "hg_set_option", "hg_params_builtin", "hg_params_derive", "hg_grand_product", "hg_fold", "hg_setup", "hg_pk_free",
     "hg_pk_lasso_layout", "hg_pk_info", "hg_pk_node_eq_form", "hg_witness_from_json", "hg_witness_synthetic", "hg_witness_from_arrays",
-    "hg_witness_get", "hg_witness_free", "hg_prove", "hg_prove_stream", "hg_verify", "hg_verify_device", "hg_prove_mode", "hg_prove_resident_mode", "hg_verify_mode", "hg_group_local", "hg_group_external", "hg_group_free", "hg_prove_resident_mode_sharded", "hg_witness_gen", "hg_witness_gen_into", "hg_witness_gen_shard", "hg_values_info", "hg_values_peak_bytes", "hg_values_free", "hg_values_get", "hg_comm_unique_id", "hg_comm_init", "hg_comm_destroy", "hg_comm_count", "hg_comm_selftest", "hg_prove_sharded", "hg_prove_shard_begin", "hg_prove_shard_combine", "hg_prove_shard_finish", "hg_shard_combine_host", "hg_prove_resident", "hg_circuit_eval", "hg_lasso_prove", "hg_lasso_prove_at", "hg_lasso_num_challenges", "hg_sumcheck", "hg_mle_eval",
+    "hg_witness_get", "hg_witness_free", "hg_prove", "hg_warmup", "hg_prove_stream", "hg_verify", "hg_verify_device", "hg_prove_mode", "hg_prove_resident_mode", "hg_verify_mode", "hg_group_local", "hg_group_external", "hg_group_free", "hg_prove_resident_mode_sharded", "hg_witness_gen", "hg_witness_gen_into", "hg_witness_gen_shard", "hg_values_info", "hg_values_peak_bytes", "hg_values_free", "hg_values_get", "hg_comm_unique_id", "hg_comm_init", "hg_comm_destroy", "hg_comm_count", "hg_comm_selftest", "hg_prove_sharded", "hg_prove_shard_begin", "hg_prove_shard_combine", "hg_prove_shard_finish", "hg_shard_combine_host", "hg_prove_resident", "hg_circuit_eval", "hg_lasso_prove", "hg_lasso_prove_at", "hg_lasso_num_challenges", "hg_sumcheck", "hg_mle_eval",
     "hg_ntt", "hg_challenges", "hg_challenges_bn254", "hg_bn254_field_op", "hg_sumcheck_bn254", "hg_grand_product_bn254", "hg_lasso_prove_bn254", "hg_witness_from_json_bn254", "hg_circuit_eval_bn254", "hg_prove_bn254", "hg_verify_bn254", "hg_mle_eval_bn254", "hg_ntt_bn254", "hg_profile", "hg_profile_select", "hg_profile_reset", "hg_profile_get",
 ]
 
@@ -407,6 +407,15 @@ class BfvEncrypt:
         h = C.c_void_p()
         _check(lib().hg_setup(ctx.h if ctx is not None else None, C.byref(self.params), C.byref(h)))
         return ProverKey(h, self.params)
+
+    def warmup(self, ctx, pk):
+        """hg_warmup: context-owned tables, witness staging and the recorded launch graph ahead of the first prove; returns the ms it took."""
+        L = lib()
+        L.hg_warmup.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+        L.hg_warmup.restype = C.c_int
+        ms = C.c_double(0)
+        _check(L.hg_warmup(ctx.h, pk.h, C.byref(ms)))
+        return ms.value
 
     def get_inputs(self, path):
         return Witness.from_json(self.params, path)

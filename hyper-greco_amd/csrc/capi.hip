@@ -35,9 +35,13 @@ static thread_local std::string g_last_error;
     catch (const std::exception& ex) { g_last_error = ex.what(); return ret; } \
     catch (...) { g_last_error = "unknown error"; return ret; }
 
+// (called from the worker threads of hg_setup's node loop: the current device is per thread, the key's list of allocations is shared)
 template <typename T>
 static const T* upload_vec(hg_pk* pk, const std::vector<T>& v) {
     if (!pk->ctx) return nullptr;  // host-only key (hg_setup(NULL, ..)): wiring without a device copy
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    hip_check(hipSetDevice(pk->ctx->device), "hipSetDevice");
     T* d = nullptr;
     size_t bytes = std::max<size_t>(v.size() * sizeof(T), 16);
     hip_check(hipMalloc((void**)&d, bytes), "hipMalloc(prover key)");
@@ -139,6 +143,7 @@ int hg_params_builtin(uint32_t n, uint32_t k, hg_params* out) {
     HG_CATCH(-1)
 }
 
+static double now_ms_capi() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 int hg_setup(hg_ctx* ctx, const hg_params* params, hg_pk** out) {
     HG_TRY
     if (!params || !out) throw Error("hg_setup: null argument");
@@ -147,8 +152,13 @@ int hg_setup(hg_ctx* ctx, const hg_params* params, hg_pk** out) {
     static std::atomic<uint64_t> next_serial{1};
     pk->serial = next_serial++;
     pk->ctx = ctx;
+    const bool times = hg_times("setup");
+    const double ts0 = now_ms_capi();
+    auto lap = [&](const char* what) { if (times) fprintf(stderr, "[hg setup] %8.2f ms  %s\n", now_ms_capi() - ts0, what); };
     pk->lasso = lasso_preprocess(pk->params);
+    lap("lasso_preprocess");
     pk->circuit = build_circuit(pk->params, pk->lasso);
+    lap("build_circuit");
     const LassoPlan& lp = pk->lasso;
     if (lp.alpha > 32 || lp.lookups.size() > 32) throw Error("lasso: more than 32 memories / lookup types");
     dev::LassoDev& L = pk->lasso_dev;
@@ -178,7 +188,7 @@ int hg_setup(hg_ctx* ctx, const hg_params* params, hg_pk** out) {
     // circuit wiring as CSR per (node, input)
     const HCircuit& c = pk->circuit;
     pk->node_dev.resize(c.nodes.size());
-    for (size_t id = 0; id < c.nodes.size(); id++) {
+    for (size_t id = 0; id < c.nodes.size(); id++) {   // twiddle tables, one per transform size and direction
         const HNode& n = c.nodes[id];
         if (n.kind == NK_FFT) {
             for (int inv = 0; inv < 2; inv++) {
@@ -193,7 +203,20 @@ int hg_setup(hg_ctx* ctx, const hg_params* params, hg_pk** out) {
                 tab[n.log2_size] = upload_vec(pk.get(), W);
             }
         }
-        if (n.kind != NK_VANILLA) continue;
+    }
+    lap("twiddle tables");
+    // the Vanilla nodes' wiring in the forms the kernels read, node by node on all host threads (round 6: this loop was 0.8 of the
+    // 1.1 s a set-up took on eight cores): a node touches its own NodeDev only, uploads go through upload_vec's lock
+    std::exception_ptr node_error;
+    std::vector<size_t> by_size;
+    for (size_t id = 0; id < c.nodes.size(); id++) if (c.nodes[id].kind == NK_VANILLA) by_size.push_back(id);
+    std::sort(by_size.begin(), by_size.end(), [&](size_t a, size_t b) { return c.nodes[a].lin.size() + 2 * c.nodes[a].mul.size() > c.nodes[b].lin.size() + 2 * c.nodes[b].mul.size(); });
+    [[maybe_unused]] const int setup_threads = std::max(1, std::min(hg_omp_threads(), 64));
+#pragma omp parallel for schedule(dynamic, 1) num_threads(setup_threads)
+    for (long long qi = 0; qi < (long long)by_size.size(); qi++) {
+      try {
+        const size_t id = by_size[(size_t)qi];
+        const HNode& n = c.nodes[id];
         hg_pk::NodeDev& nd = pk->node_dev[id];
         const size_t S = (size_t)1 << n.log2_sub_in;
         nd.lin.assign(n.arity, dev::CsrLin{nullptr, nullptr, nullptr});
@@ -355,7 +378,13 @@ int hg_setup(hg_ctx* ctx, const hg_params* params, hg_pk** out) {
             nd.const_coef = upload_vec(pk.get(), cf);
             nd.nconst = g.size();
         }
+      } catch (...) {
+#pragma omp critical(hg_setup_error)
+        if (!node_error) node_error = std::current_exception();
+      }
     }
+    if (node_error) std::rethrow_exception(node_error);
+    lap("node wiring (CSR, segments, eq forms, gate-major form) built and uploaded");
     *out = pk.release();
     return 0;
     HG_CATCH(-1)
@@ -527,7 +556,6 @@ int64_t hg_values_get(hg_ctx* ctx, const hg_values* v, int node, uint64_t* out, 
     HG_CATCH(-1)
 }
 
-static double now_ms_capi() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int hg_prove_resident(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, uint8_t* proof, size_t cap, size_t* len, hg_timings* timings) {
     HG_TRY
@@ -640,13 +668,23 @@ int hg_prove(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, uint8_t* proof, 
     // them (third hg_prove with one key) proves every later witness without a protocol walk
     if (ctx->scratch_values && ctx->scratch_serial != pk->serial) { values_free(ctx->scratch_values); ctx->scratch_values = nullptr; }
     if (!ctx->scratch_values) { ctx->scratch_values = witness_gen(ctx, pk, w->w, &wm, &um); ctx->scratch_serial = pk->serial; }
-    else witness_gen_into(ctx, pk, w->w, ctx->scratch_values, &wm, &um);
+    else witness_gen_into_staged(ctx, pk, w->w, ctx->scratch_values, &wm, &um);
     ProveResult r = prove_resident(ctx, pk, ctx->scratch_values, true);
     if (timings) { timings->witness_ms = wm; timings->upload_ms = um; timings->prove_ms = r.prove_ms; timings->gpu_ms = r.gpu_ms; timings->total_ms = now_ms_capi() - t0; timings->enqueue_ms = r.enqueue_ms; timings->sync_ms = r.sync_ms; timings->replay_ms = r.replay_ms; }
     const std::vector<uint8_t>& pb = r.bytes();
     *len = pb.size();
     if (pb.size() > cap) throw Error("proof buffer too small");
     memcpy(proof, pb.data(), pb.size());
+    return 0;
+    HG_CATCH(-1)
+}
+
+int hg_warmup(hg_ctx* ctx, const hg_pk* pk, double* ms) {
+    HG_TRY
+    if (!ctx || !pk) throw Error("hg_warmup: null argument");
+    if (!pk->ctx) throw Error("hg_warmup: host-only prover key (created without a context)");
+    const double t = prove_warmup(ctx, pk);
+    if (ms) *ms = t;
     return 0;
     HG_CATCH(-1)
 }

@@ -636,7 +636,7 @@ Witness witness_synthetic(const Params& p, u64 seed) {
                 else for (size_t m = 0; m < n; m++) { dl[m] -= alo[m]; dh[m] -= ahi[m]; }
             }
             std::vector<i128> h(2 * n, 0);  // ct0i_hat, ascending, degree <= 2n-2
-            for (size_t j = 0; j < 2 * n - 1; j++) h[j] = ((i128)acc_hi[j] << 32) + (i128)acc_lo[j];
+            for (size_t j = 0; j < 2 * n - 1; j++) h[j] = (i128)acc_hi[j] * ((i128)1 << 32) + (i128)acc_lo[j];   // (a product, not a shift: acc_hi may be negative)
             for (size_t j = 0; j < n; j++) h[j] += (i128)e[j] + k0 * (i128)k1[j];
             std::vector<i128> ct0(n), r2(n - 1), r1(2 * n - 1);
             for (size_t j = 0; j < n; j++) ct0[j] = centre_mod(h[j] - h[j + n], q);

@@ -37,7 +37,7 @@ const u64* challenge_chain(size_t n_base);  // pointer to >= n_base cached base-
 bool hg_debug(const char* token);
 // Timing breakdowns on stderr: HG_TIMES = comma-separated tokens, read at every call.
 //   seq: the round-by-round prover (waits, host steps, drains)    bn: the bn254 prove and its witness generation
-//   verify: hg_verify / hg_verify_device    json: the JSON witness loader
+//   verify: hg_verify / hg_verify_device    json: the JSON witness loader    setup: the phases of hg_setup
 bool hg_times(const char* token);
 const char* hg_proof_map_path();   // HG_PROOF_MAP=<file>: byte offset of every protocol element of a proof (scripts/proof_diff.py); null: off
 bool hg_env_on(const char* name);  // "<name>=1" in the environment (read once per call site through a static)

@@ -214,6 +214,8 @@ hg_values* witness_gen(hg_ctx* ctx, const hg_pk* pk, const Witness& w, double* w
 hg_values* witness_gen_shard(hg_ctx* ctx, const hg_pk* pk, const Witness& w, int rank, int world, double* witness_ms, double* upload_ms);
 // Circuit::evaluate into the tables of an existing values object (same addresses: its cached launch graph stays valid)
 void witness_gen_into(hg_ctx* ctx, const hg_pk* pk, const Witness& w, hg_values* v, double* witness_ms, double* upload_ms);
+void witness_gen_into_staged(hg_ctx* ctx, const hg_pk* pk, const Witness& w, hg_values* v, double* witness_ms, double* upload_ms);   // through the context's page-locked staging
+double prove_warmup(hg_ctx* ctx, const hg_pk* pk);   // hg_warmup
 // BfvEncrypt::prove for a run of witnesses, pipelined: upload + circuit.evaluate of witness i+1 overlap the GKR prove of witness i
 std::vector<ProveResult> prove_stream(hg_ctx* ctx, const hg_pk* pk, const std::vector<const Witness*>& ws, double* total_ms);
 void values_free(hg_values* v);

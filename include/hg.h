@@ -121,6 +121,13 @@ void hg_witness_free(hg_witness* w);
 int hg_prove(hg_ctx* ctx, const hg_pk* pk, const hg_witness* w, uint8_t* proof, size_t cap, size_t* len,
              hg_timings* timings);
 
+/* Makes the FIRST hg_prove of a key a warm one - what a drop-in BfvEncrypt::setup calls right after hg_setup [REF the caller's sequence
+ *   bfv-gkr/src/test.rs:31-44: setup, then ONE prove per witness]: allocates the context-owned node tables and the page-locked witness
+ *   staging, proves an all-zero witness until the launch graph of those tables is recorded (two protocol walks and the capture; nothing
+ *   of it depends on table contents), so that the first real hg_prove refills the tables in place and replays the graph. *ms (may be
+ *   NULL): the time it took. Optional: without it the first two hg_prove calls of a key walk the protocol and the third records. */
+int hg_warmup(hg_ctx* ctx, const hg_pk* pk, double* ms);
+
 /* hg_prove for a run of `n` witnesses under one key, pipelined [REF: the loop a caller of BfvEncrypt::prove writes; the only
  *   in-tree caller is the test macro bfv-gkr/src/test.rs:31-44, one witness per call - the reference has no batch entry]: upload + circuit.evaluate of witness i+1 run on a third stream into a second set of node
  *   tables while witness i is proven. Proof i is written at proofs + i*cap_each, its length to lens[i]; each proof is byte-identical

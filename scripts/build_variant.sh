@@ -13,5 +13,7 @@ pids=()
 for f in kernels.hip prover.hip prover_seq.hip capi.hip bn254.hip comm.hip verifier_dev.hip; do $CXX -c "$src/$f" -o "$out/${f%.hip}.o" & pids+=($!); done
 for f in host.cpp verifier.cpp; do $CXX -x hip -c "$src/$f" -o "$out/${f%.cpp}.o" & pids+=($!); done
 for p in "${pids[@]}"; do wait $p; done
-/opt/rocm/bin/hipcc -shared -fopenmp --offload-arch=gfx950 -o "$out/libhypergreco.so" "$out"/*.o -ldl
+# sanitizer flags (make asan) must reach the link too
+lflags=$(echo "$flags" | tr ' ' '\n' | grep -E '^-fsanitize|^-shared-libsan|^-fno-gpu-sanitize' | tr '\n' ' ' || true)
+/opt/rocm/bin/hipcc -shared -fopenmp --offload-arch=gfx950 $lflags -o "$out/libhypergreco.so" "$out"/*.o -ldl
 echo "$out/libhypergreco.so"

@@ -609,6 +609,36 @@ def test_cached_launch_graph_replays_and_invalidates(ctx):
     v1.free(); v2.free(); pk.free()
 
 
+def test_warmup_makes_the_first_prove_a_graph_replay(capfd, monkeypatch):
+    """hg_warmup (what a drop-in BfvEncrypt::setup calls behind hg_setup; the reference's caller proves ONCE per witness, test.rs:37-38):
+    the context-owned tables, the witness staging and the launch graph exist before the first witness arrives - the first hg_prove of
+    a fresh context replays (HG_DEBUG=launch reports every hipGraphLaunch) and its bytes are the oracle's, for every later witness too."""
+    n, k = 4096, 2
+    c = hg.Context(0)
+    bfv = hg.BfvEncrypt.new(n, k)
+    pk = bfv.setup(c)
+    assert bfv.warmup(c, pk) > 0
+    p = orclib.params(n, k)
+    monkeypatch.setenv("HG_DEBUG", "launch")
+    for seed in (31, 32, 33):
+        w = hg.Witness.synthetic(bfv.params, seed)
+        ref, _ = orclib.prove(p, orclib.Inputs(w.arrays()), threads=4)
+        capfd.readouterr()
+        proof, _ = bfv.prove(c, pk, w)
+        assert "hipGraphLaunch" in capfd.readouterr().err, f"witness {seed}: hg_prove after hg_warmup walked the protocol"
+        assert proof == ref
+    monkeypatch.delenv("HG_DEBUG")
+    # without the warm-up the first prove of a fresh context walks (and is the same proof)
+    c2 = hg.Context(0)
+    pk2 = bfv.setup(c2)
+    monkeypatch.setenv("HG_DEBUG", "launch")
+    capfd.readouterr()
+    proof2, _ = bfv.prove(c2, pk2, w)
+    assert "hipGraphLaunch" not in capfd.readouterr().err
+    assert proof2 == ref
+    pk.free(); pk2.free(); c.close(); c2.close()
+
+
 @pytest.mark.parametrize("n,k,seeds", [(4096, 2, 5), (32768, 16, 3)])
 def test_graph_replay_across_witnesses(ctx, n, k, seeds):
     """The steady state of a prover that gets a NEW witness per proof (the reference proves each witness once, test.rs:37-38):
