@@ -42,12 +42,116 @@ CLASS_SYMBOL = {
     "sc_round<prodsum>": "k_ps_one(",
     "sc_round2<prodsum>": "k_ps_step2<",      # (two instantiations: eq-factored jobs and the others)
 }
-PMC_TAG = "r05"  # profiles/<tag>_pmc_hbm_traffic.json, <tag>_pmc_sq.json, <tag>_bn254_pmc_sq.json: this round's committed counter passes
+# The class `roofline` reports, FIXED per round so that `frac` is comparable between runs of one round: the class with the largest isolated
+# time in this round's committed one-stream trace (profiles/r06_one_stream_kernel_trace_summary.txt: the four base-field first rounds of
+# the grand-product layers, 0.32 ms per prove). Until round 5 the line named whichever of two tied classes was ahead in the run.
+ROOFLINE_CLASS = "sc_round<grand_product,base>"
+PMC_TAG = "r06"  # profiles/<tag>_pmc_hbm_traffic.json, <tag>_pmc_sq.json, <tag>_bn254_pmc_sq.json, <tag>_isa_mix.json: this round's committed passes
 PMC_CMD = ("rocprofv3 --pmc FETCH_SIZE -- python3 scripts/prove_once.py 32768 16 2 ; rocprofv3 --pmc WRITE_SIZE -- (same): separate passes, "
            "HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 per launch (gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md), "
-           "scripts/pmc_summary.py; rocprofv3 --pmc SQ_INSTS_VALU ... -- (same), scripts/pmc_sq.py (scripts/measure_r05.sh)")
+           "scripts/pmc_summary.py; rocprofv3 --pmc SQ_INSTS_VALU ... -- (same), scripts/pmc_sq.py (scripts/measure_r06.sh; taken inside this run when rocprofv3 is on the box, see roofline.counters.measured)")
 VALU_PEAK_G = 256 * 4 * 2.4e9 / 4 / 1e9   # CUs x SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction = 614 G wave-instr/s
 VALU_MEASURED_G = 532.0                   # what v_mad_u64_u32 / VOP3 issues at on this chip (scripts/ub/ratebench.hip: 0.52 G/s per SIMD)
+NSIMD = 256 * 4
+
+
+class IssueModel:
+    """The VALU issue roof of a kernel, priced per instruction class instead of one nominal rate (round 6). scripts/ub/ratebench.hip
+    measures what every opcode the kernels are made of issues at on this chip (profiles/r06_ratebench.txt, wave-instructions per second
+    and SIMD, 8 waves per SIMD, independent chains): the plain VOP1 / VOP2 integer forms (class A: v_mov_b32, v_add_u32, v_and_b32,
+    v_lshrrev_b32 ...) at ~1.0 G/s, everything else (class B: v_mad_u64_u32, carries, 64-bit shifts and adds, compares, selects,
+    v_fma_f64) at ~0.54 G/s - two and about four cycles of the clock the chip holds under that load. scripts/isa_census.py --json gives
+    each kernel's static class mix (profiles/r06_isa_mix.json, hash-checked like the counter files). The issue time of N VALU
+    wave-instructions of a kernel is N (f_A / R_A + f_B / R_B) / 1024 SIMDs; issue_frac = that over the measured duration. Static mix of the
+    whole kernel body, dynamic count from SQ_INSTS_VALU: loops dominate both, prologues make it approximate."""
+    CLASS_A_ROWS = ("v_mov_b32 ", "v_add_u32", "v_and_b32", "v_lshrrev_b32", "v_sub_u32", "v_xor_b32", "v_mov_b32 imm")
+    SKIP_ROWS = ("(2 instr)", "(4 instr)", "v_cndmask_b32 ")   # multi-instruction rows; the VOP2 select row is a vcc-dependent chain, not an issue rate
+
+    def __init__(self):
+        self.rate_a = self.rate_b = None
+        self.mix, self.note = None, None
+        try:
+            a, b = [], []
+            for ln in open(os.path.join(ROOT, "profiles", f"{PMC_TAG}_ratebench.txt")):
+                if "G wave-instr/s/SIMD" not in ln or any(x in ln for x in self.SKIP_ROWS):
+                    continue
+                rate = float(ln.split(" ms")[1].split("G wave-instr")[0])
+                (a if any(ln.startswith(x) for x in self.CLASS_A_ROWS) else b).append(rate)
+            self.rate_a, self.rate_b = sum(a) / len(a) * 1e9, sum(b) / len(b) * 1e9
+        except Exception as e:  # noqa: BLE001
+            self.note = f"profiles/{PMC_TAG}_ratebench.txt: {e}; "
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", f"{PMC_TAG}_isa_mix.json")))
+            if d.get("_meta", {}).get("code_hash") != code_hash():
+                self.note = (self.note or "") + f"profiles/{PMC_TAG}_isa_mix.json: taken on code {d.get('_meta', {}).get('code_hash')}, this is {code_hash()} - refused; "
+            else:
+                d.pop("_meta", None)
+                self.mix = d
+        except Exception as e:  # noqa: BLE001
+            self.note = (self.note or "") + f"profiles/{PMC_TAG}_isa_mix.json: {e}; "
+
+    def ok(self):
+        return bool(self.rate_a and self.rate_b and self.mix)
+
+    def share_a(self, sym):
+        """class-A share of the VALU instructions of every kernel whose demangled name contains `sym` (None: unknown)"""
+        if not self.mix or not sym:
+            return None
+        key = sym.replace("hg::", "").rstrip("(")
+        m = [v for k, v in self.mix.items() if key in k]
+        tot = sum(v["valu"] for v in m)
+        return sum(v["class_a"] for v in m) / tot if tot else None
+
+    def seconds(self, n_valu, sym):
+        """issue time of n_valu wave-instructions of kernel `sym` on the whole chip"""
+        fa = self.share_a(sym)
+        if not self.ok() or n_valu is None or fa is None:
+            return None
+        return n_valu * (fa / self.rate_a + (1.0 - fa) / self.rate_b) / NSIMD
+
+    def describe(self):
+        return {"class_a_G_per_simd": round(self.rate_a / 1e9, 3) if self.rate_a else None, "class_b_G_per_simd": round(self.rate_b / 1e9, 3) if self.rate_b else None,
+                "files": [f"profiles/{PMC_TAG}_ratebench.txt", f"profiles/{PMC_TAG}_isa_mix.json"], **({"note": self.note} if self.note else {})}
+
+
+def live_counter_passes(n, k, budget_s=150.0):
+    """The three PMC passes behind roofline.traffic / wave_insts_per_launch, taken INSIDE this run when rocprofv3 is on the box (child
+    processes, the profiled program directly after `--`; FETCH_SIZE and WRITE_SIZE in separate passes as the MI355X guide prescribes, no
+    trace domain beside --pmc). Returns (dir with <tag>_pmc_hbm_traffic.json / <tag>_pmc_sq.json, note) or (None, reason): the caller then reads
+    the committed files of profiles/."""
+    import shutil
+    import subprocess
+    import tempfile
+    if (n, k) != (32768, 16):
+        return None, "counter passes exist for n=32768 k=16 only"
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not on this box"
+    td = tempfile.mkdtemp(prefix="hg_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    env.pop("HG_LIB", None) if False else None
+    t_end = time.time() + budget_s
+    prog = [sys.executable, os.path.join(ROOT, "scripts", "prove_once.py"), "32768", "16", "2"]
+    sets = (("FETCH", ["FETCH_SIZE"]), ("WRITE", ["WRITE_SIZE"]),
+            ("SQ", ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAVES"]))
+    try:
+        for name, ctrs in sets:
+            left = t_end - time.time()
+            if left < 10:
+                return None, "counter passes: time budget spent"
+            subprocess.run([exe, "--pmc", *ctrs, "-d", os.path.join(td, name), "-o", "run", "--output-format", "csv", "--", *prog],
+                           cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=left, check=True)
+        import glob
+        f = lambda nm: glob.glob(os.path.join(td, nm, "**", "*counter_collection.csv"), recursive=True)[0]
+        subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "pmc_summary.py"), f("FETCH"), f("WRITE"), os.path.join(td, f"{PMC_TAG}_pmc_hbm_traffic.json")],
+                       stdout=subprocess.DEVNULL, check=True, timeout=60)
+        subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "pmc_sq.py"), f("SQ"), "40", os.path.join(td, f"{PMC_TAG}_pmc_sq.json")],
+                       stdout=subprocess.DEVNULL, check=True, timeout=60)
+        return td, None
+    except Exception as e:  # noqa: BLE001
+        return None, f"counter passes failed ({type(e).__name__}: {e})"
+
+
 # kernels of a prove_once run that are not part of a prove (witness generation, memsets)
 NOT_PROVE = ("k_ntt4", "k_gate_eval", "k_lift", "__amd_rocclr", "k_output_mle")
 sys.path.insert(0, os.path.join(ROOT, "scripts"))
@@ -59,15 +163,17 @@ class Counters:
     and ONLY for the code state they were taken on: a file whose `code_hash` is not the hash of the sources this process runs
     (scripts/code_hash.py) is refused, and every figure that would come from it is null with the reason in `note`."""
 
-    def __init__(self, n, k, tag=PMC_TAG):
+    def __init__(self, n, k, tag=PMC_TAG, live_dir=None, live_note=None):
         self.traffic, self.sq, self.note, self.proves = None, None, None, 2
         self.files = {}
+        self.measured = "in this run (rocprofv3 child processes of bench.py)" if live_dir else f"read from profiles/ ({live_note or 'no live pass'})"
+        self.dir = live_dir or os.path.join(ROOT, "profiles")
         if (n, k) != (32768, 16):
             self.note = "counter passes exist for n=32768 k=16 only"
             return
         want = code_hash()
         for attr, name in (("traffic", f"{tag}_pmc_hbm_traffic.json"), ("sq", f"{tag}_pmc_sq.json")):
-            path = os.path.join(ROOT, "profiles", name)
+            path = os.path.join(self.dir, name)
             try:
                 d = json.load(open(path))
             except Exception:
@@ -80,7 +186,7 @@ class Counters:
             self.proves = d["_meta"].get("proves") or self.proves   # counted by the pass itself (k_clear_words launches); 2 in files older than round 6
             d.pop("_meta", None)
             setattr(self, attr, d)
-            self.files[attr] = f"profiles/{name}"
+            self.files[attr] = f"profiles/{name}" if not live_dir else f"{name} (this run)"
 
     @staticmethod
     def _match(d, sym):
@@ -103,6 +209,21 @@ class Counters:
         m = self._match(self.sq, sym)
         ln = sum(v["launches"] for _, v in m)
         return sum(v.get("SQ_INSTS_VALU", 0.0) for _, v in m) / ln if ln else None
+
+    def issue_seconds_of_a_prove(self, im):
+        """sum over the prove's kernels of their VALU instructions priced with each kernel's own class mix (IssueModel); None if unknown"""
+        if not self.sq or not im.ok():
+            return None
+        tot = 0.0
+        for k, v in self.sq.items():
+            if any(x in k for x in NOT_PROVE):
+                continue
+            name = k.split("(")[0].replace("hg::dev::", "").replace("hg::bn::", "bn::").replace("hg::", "").replace("void ", "")
+            t = im.seconds(v.get("SQ_INSTS_VALU", 0.0), name)
+            if t is None:   # a kernel the census does not know: all class B
+                t = v.get("SQ_INSTS_VALU", 0.0) / im.rate_b / NSIMD
+            tot += t
+        return tot / self.proves
 
     def prove_totals(self):
         """(HBM bytes, VALU wave-instructions) of one prove: every kernel of the run but witness generation"""
@@ -393,6 +514,7 @@ def main():
     ap.add_argument("--crt-moduli", "--k", dest="k", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-live-counters", action="store_true", help="do not run the rocprofv3 --pmc passes inside this run (read profiles/ instead)")
     ap.add_argument("--witnesses", type=int, default=4, help="number of different synthetic witnesses proven in rotation (one per step)")
     ap.add_argument("--collective-timeout", type=float, default=300.0,
                     help="N>1: seconds the communicator set-up and the first sharded prove may take before the rank exits non-zero")
@@ -535,7 +657,9 @@ def main():
     ctx.profile(0)
     ctx.set_option("one_stream", 0)
     step()
-    DOMINANT = max((s for s in ctx.profile_get() if s["name"] in CLASS_SYMBOL and s["launches"]), key=lambda s: s["total_ms"])["name"]
+    seen = [s for s in ctx.profile_get() if s["name"] in CLASS_SYMBOL and s["launches"]]
+    # the round's fixed class (ROOFLINE_CLASS) where the parameter set launches it, else the class with the largest isolated time
+    DOMINANT = ROOFLINE_CLASS if any(s["name"] == ROOFLINE_CLASS for s in seen) else max(seen, key=lambda s: s["total_ms"])["name"]
     ctx.profile_select(DOMINANT)
     import gc
     gc.collect()
@@ -685,14 +809,21 @@ def main():
         per_launch_bytes = dom["hbm_bytes"] / max(dom["launches"], 1)
         avg_ms = dom["total_ms"] / max(dom["launches"], 1)
         achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        pmc = Counters(args.n, args.k)
+        live_dir, live_note = (None, "not requested (--no-live-counters)") if args.no_live_counters or world > 1 else live_counter_passes(args.n, args.k)
+        pmc = Counters(args.n, args.k, live_dir=live_dir, live_note=live_note)
+        im = IssueModel()
         sym = CLASS_SYMBOL.get(DOMINANT, "")
         traffic, _ = pmc.hbm_bytes(sym)
         valu_pl = pmc.valu(sym)
         valu_ach = valu_pl / (avg_ms * 1e-3) / 1e9 if valu_pl and avg_ms > 0 else None
         valu_frac = valu_ach / VALU_PEAK_G if valu_ach else None
         hbm_frac = achieved / HBM_PEAK_GBS
-        valu_bound = valu_frac is not None and valu_frac > hbm_frac
+        # the issue roof of THIS kernel: its VALU instructions priced by class (IssueModel) over the same launch duration
+        issue_s = im.seconds(valu_pl, sym)
+        issue_frac = issue_s / (avg_ms * 1e-3) if issue_s is not None and avg_ms > 0 else None
+        issue_frac_iso = issue_s / (iso_ms * 1e-3) if issue_s is not None and iso_ms > 0 else None
+        vbest = issue_frac if issue_frac is not None else valu_frac
+        valu_bound = vbest is not None and vbest > hbm_frac
 
         def class_row(name, c):
             """one class against both roofs, isolated duration (one stream): frac = the larger of the two"""
@@ -704,11 +835,15 @@ def main():
             hf = c["hbm_GB"] / (ms * 1e-3) / HBM_PEAK_GBS if ms > 0 else None
             pf = pb * ln / 1e9 / (ms * 1e-3) / HBM_PEAK_GBS if pb and ms > 0 else None
             vf = vi * ln / 1e9 / (ms * 1e-3) / VALU_PEAK_G if vi and ms > 0 else None
-            fr = max(x for x in (hf, vf) if x is not None) if (hf is not None or vf is not None) else None
+            it = im.seconds(vi * ln if vi else None, symc)
+            isf = it / (ms * 1e-3) if it is not None and ms > 0 else None
+            vbest = isf if isf is not None else vf
+            fr = max(x for x in (hf, vbest) if x is not None) if (hf is not None or vbest is not None) else None
             return {"kernel": name, "symbol": symc, "launches_per_step": c["launches"], "isolated_avg_launch_us": round(ms / ln * 1e3, 2),
                     "hbm_frac": round(hf, 4) if hf is not None else None, "pmc_hbm_frac": round(pf, 4) if pf is not None else None,
-                    "valu_frac": round(vf, 4) if vf is not None else None, "frac": round(fr, 4) if fr is not None else None,
-                    "bound": "valu" if (vf is not None and hf is not None and vf > hf) else "hbm"}
+                    "issue_frac": round(isf, 4) if isf is not None else None, "class_a_share": round(im.share_a(symc), 3) if im.share_a(symc) is not None else None,
+                    "valu_frac_nominal_614G": round(vf, 4) if vf is not None else None, "frac": round(fr, 4) if fr is not None else None,
+                    "bound": "issue" if (vbest is not None and hf is not None and vbest > hf) else "hbm"}
         pmc_bytes_prove, valu_prove = pmc.prove_totals()
         line = {
             "metric": f"GKR prove ms, n={args.n} k={args.k} Goldilocks; achieved HBM GB/s vs roofline",
@@ -759,10 +894,20 @@ def main():
             # HBM: bytes the class moves to or from HBM by design (`hbm_bytes_per_launch`) over the average launch duration measured with
             # HIP events inside timed region A (its launches share the GPU with the other streams there); `traffic` = the same launches'
             # HBM bytes by the PMC counters. VALU: SQ_INSTS_VALU per launch over the same duration against 614 G wave-instr/s.
-            "roofline": {"bound": "valu" if valu_bound else "hbm", "kernel": DOMINANT, "symbol": sym,
-                         "achieved": round(valu_ach if valu_bound else achieved, 2), "peak": round(VALU_PEAK_G, 1) if valu_bound else HBM_PEAK_GBS,
+            # `bound` / `frac`: the larger of the HBM fraction and the ISSUE fraction (`issue_frac`: the kernel's VALU instructions priced by
+            # instruction class - IssueModel - over the launch duration; `peak` then is the rate at which THIS kernel's mix issues).
+            "roofline": {"bound": "issue" if valu_bound else "hbm", "kernel": DOMINANT, "symbol": sym,
+                         "achieved": round(valu_ach if valu_bound else achieved, 2),
+                         "peak": (round(valu_ach / issue_frac, 1) if issue_frac else round(VALU_PEAK_G, 1)) if valu_bound else HBM_PEAK_GBS,
                          "unit": "G wave-instr/s" if valu_bound else "GB/s",
-                         "frac": round(valu_frac if valu_bound else hbm_frac, 4), "traffic": round(traffic) if traffic else None,
+                         "frac": round(vbest if valu_bound else hbm_frac, 4), "traffic": round(traffic) if traffic else None,
+                         "issue_frac": round(issue_frac, 4) if issue_frac is not None else None,
+                         "issue": {"frac": round(issue_frac, 4) if issue_frac is not None else None,
+                                   "frac_isolated": round(issue_frac_iso, 4) if issue_frac_iso is not None else None,
+                                   "class_a_share": round(im.share_a(sym), 3) if im.share_a(sym) is not None else None,
+                                   "issue_us_per_launch": round(issue_s * 1e6, 2) if issue_s is not None else None,
+                                   "rates": im.describe(),
+                                   "note": "sum over the kernel's VALU instructions of 1 / (issue rate of their class on this chip); class mix from the assembly, count from SQ_INSTS_VALU"},
                          "hbm": {"achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 4),
                                  "hbm_bytes_per_launch": round(per_launch_bytes),
                                  "pmc_frac": round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and avg_ms > 0 else None},
@@ -770,7 +915,7 @@ def main():
                                   "frac": round(valu_frac, 4) if valu_frac else None,
                                   "frac_of_measured_issue_rate": round(valu_ach / VALU_MEASURED_G, 4) if valu_ach else None,
                                   "wave_insts_per_launch": round(valu_pl) if valu_pl else None},
-                         "counters": {"files": pmc.files, "code_hash": code_hash(), "command": PMC_CMD, **({"note": pmc.note} if pmc.note else {})},
+                         "counters": {"measured": pmc.measured, "files": pmc.files, "code_hash": code_hash(), "command": PMC_CMD, **({"note": pmc.note} if pmc.note else {})},
                          "launches_per_step": dom["launches"] // max(args.steps, 1),
                          "avg_launch_us": round(avg_ms * 1e3, 3),
                          "isolated": {"avg_launch_us": round(iso_ms * 1e3, 3), "hbm_achieved": round(iso_achieved, 2),
@@ -797,6 +942,7 @@ def main():
                             "valu_wave_insts": round(valu_prove) if valu_prove else None,
                             "valu_frac": round(valu_prove / 1e9 / (gpu_ms * 1e-3) / VALU_PEAK_G, 4) if valu_prove and gpu_ms > 0 else None,
                             "valu_frac_of_measured_issue_rate": round(valu_prove / 1e9 / (gpu_ms * 1e-3) / VALU_MEASURED_G, 4) if valu_prove and gpu_ms > 0 else None,
+                            "issue_frac": round(pmc.issue_seconds_of_a_prove(im) / (gpu_ms * 1e-3), 4) if pmc.issue_seconds_of_a_prove(im) and gpu_ms > 0 else None,
                             "reference_model_GB": round(sum(c["model_GB"] for c in classes.values()), 3),
                             "reference_model_x_hbm_peak": round(sum(c["model_GB"] for c in classes.values()) / (gpu_ms * 1e-3) / HBM_PEAK_GBS, 4) if gpu_ms > 0 else None},
         }
@@ -824,8 +970,21 @@ def main():
                     if (args.n, args.k) == (32768, 16) and sq.get("code_hash") == code_hash():
                         insts = sq["prove_valu_wave_insts_per_prove"]   # WITHOUT witness generation: the timed span is the prove
                         ach = insts / (best[1] * 1e-3) / 1e9
+                        # issue roof: the listed kernels priced with their own class mix, the remainder as class B
+                        bn_issue = None
+                        if im.ok():
+                            WG = ("k_bn_ntt", "k_bn_gate_eval", "k_bn_lift", "k_bn_bitrev", "k_bn_scale", "k_bn_powers")
+                            listed, bn_issue = 0.0, 0.0
+                            for kn, nv in sq.get("by_kernel_per_prove", {}).items():
+                                if any(w in kn for w in WG):
+                                    continue
+                                listed += nv
+                                t = im.seconds(nv, kn.replace("hg::bn::", "bn::").replace("hg::dev::", "").replace("void ", ""))
+                                bn_issue += t if t is not None else nv / im.rate_b / NSIMD
+                            bn_issue += max(insts - listed, 0.0) / im.rate_b / NSIMD
                         line["bn254"]["roofline"] = {"bound": "valu", "achieved": round(ach, 1), "peak": round(VALU_PEAK_G, 1), "unit": "G wave-instr/s",
                                                      "frac": round(ach / VALU_PEAK_G, 4), "frac_of_measured_issue_rate": round(ach / VALU_MEASURED_G, 4),
+                                                     "issue_frac": round(bn_issue / (best[1] * 1e-3), 4) if bn_issue else None,
                                                      "valu_wave_insts_per_prove": round(insts),
                                                      "source": {"file": f"profiles/{PMC_TAG}_bn254_pmc_sq.json", "command": sq["command"], "code_hash": sq["code_hash"]}}
                     elif (args.n, args.k) == (32768, 16):

@@ -26,7 +26,7 @@ out = {"code_hash": code_hash(), "command": "rocprofv3 --pmc SQ_INSTS_VALU SQ_AC
        "valu_wave_insts_per_prove": sum(per.values()) / proves,
        "witness_gen_valu_wave_insts_per_prove": wit / proves,
        "prove_valu_wave_insts_per_prove": (sum(per.values()) - wit) / proves,
-       "by_kernel_per_prove": {k: v / proves for k, v in sorted(per.items(), key=lambda kv: -kv[1])[:12]}}
+       "by_kernel_per_prove": {k: v / proves for k, v in sorted(per.items(), key=lambda kv: -kv[1])}}
 json.dump(out, open("$O/${tag}_bn254_pmc_sq.json", "w"), indent=1)
 print(out["valu_wave_insts_per_prove"])
 PY
