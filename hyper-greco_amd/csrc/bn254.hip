@@ -345,12 +345,12 @@ __global__ __launch_bounds__(BN_TPB) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             const mf_v4i* mfp = reinterpret_cast<const mf_v4i*>(&stage[t & 1][wave][lane >> 5][lane & 31]);
             {
                 const Fr fl = mf_fold(MK, mfp[0], mfp[128], mfp[32], mfp[160]);
-                if (valid) lz_gstore(&out[(size_t)(2 * i) * half + j], fl);
+                if (valid) lz_gstore_nt(&out[(size_t)(2 * i) * half + j], fl);
             }
             asm volatile("" ::: "memory");
             {
                 const Fr fr_ = mf_fold(MK, mfp[256], mfp[384], mfp[288], mfp[416]);
-                if (valid) lz_gstore(&out[(size_t)(2 * i + 1) * half + j], fr_);
+                if (valid) lz_gstore_nt(&out[(size_t)(2 * i + 1) * half + j], fr_);
             }
             asm volatile("" ::: "memory");
             {
@@ -933,7 +933,7 @@ __global__ void k_bn_prod_level_rows(const Fr* __restrict__ in, size_t in_len, F
     if (j >= h) return;
     const size_t rb = slot_of ? slot_of[b * (size_t)ng + (j >> seg_shift)] : b;
     const Fr v = lz_mul(lz_gload(&in[rb * in_len + j]), lz_gload(&in[rb * in_len + j + h]));
-    lz_gstore(&out[b * h + j], v);
+    lz_gstore_nt(&out[b * h + j], v);
     if (j < (h >> 1)) lz_gstore(&lw[b * (h >> 1) + j], b == 0 ? v : lz_fold(fr_zero(), v, fk[b].k));
 }
 // fk[e] = fold_consts(pw[e]) for a run of weights (one thread per (weight, limb row))
@@ -989,7 +989,7 @@ __global__ void k_bn_prod_level_mirror_slots(const Fr* __restrict__ in, size_t i
         v = lz_mul(x, y);
         if ((size_t)b >= half) v = lz_add(v, lz_fold(c2, lz_add(x, y), kc.k));   // (x + c)(y + c)
     }
-    lz_gstore(&out[v1 * h + j], v);
+    lz_gstore_nt(&out[v1 * h + j], v);
     if (j < (h >> 1)) lz_gstore(&lw[v1 * (h >> 1) + j], (v1 == 0 || b == 255) ? v : lz_fold(fr_zero(), v, fkW[v1 * (size_t)ng1 + grp].k));
 }
 // A deeper level in slot form from the slot rows of the level above: entry j of slot row v = the product entry of row b = rep_out[v][group
@@ -1007,7 +1007,7 @@ __global__ void k_bn_prod_level_slots(const Fr* __restrict__ in, size_t in_len, 
         const size_t rb = slot_of_in[(size_t)b * ng_in + gin];
         x = lz_mul(lz_gload(&in[rb * in_len + j]), lz_gload(&in[rb * in_len + j + h]));
     }
-    lz_gstore(&out[v * h + j], x);
+    lz_gstore_nt(&out[v * h + j], x);
     if (j < (h >> 1)) lz_gstore(&lw[v * (h >> 1) + j], (v == 0 || b == 255) ? x : lz_fold(fr_zero(), x, fkW[v * (size_t)ng_out + grp].k));
 }
 // The per-row tables of a slot-form layer ahead of its tail: tables of `len` >= ng entries each (entry j belongs to group j >> sh), table

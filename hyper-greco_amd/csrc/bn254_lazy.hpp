@@ -146,6 +146,16 @@ __device__ __forceinline__ void lz_gstore(Fr* p, const Fr& v) {
     b.x = (u32)v.l[2]; b.y = (u32)(v.l[2] >> 32); b.z = (u32)v.l[3]; b.w = (u32)(v.l[3] >> 32);
     g[0] = a; g[1] = b;
 }
+// the same as a streaming store: tables far larger than the caches that nothing re-reads before the next launch (the folded tables of the
+// big rounds, the tree levels, the hash rows)
+__device__ __forceinline__ void lz_gstore_nt(Fr* p, const Fr& v) {
+    __attribute__((address_space(1))) lz_u32x4* g = (__attribute__((address_space(1))) lz_u32x4*)p;
+    lz_u32x4 a, b;
+    a.x = (u32)v.l[0]; a.y = (u32)(v.l[0] >> 32); a.z = (u32)v.l[1]; a.w = (u32)(v.l[1] >> 32);
+    b.x = (u32)v.l[2]; b.y = (u32)(v.l[2] >> 32); b.z = (u32)v.l[3]; b.w = (u32)(v.l[3] >> 32);
+    __builtin_nontemporal_store(a, g);
+    __builtin_nontemporal_store(b, g + 1);
+}
 // LDS-DMA prefetch (gfx950 global_load_lds_dwordx4): 16 bytes per lane from a per-lane global address straight into LDS at
 // (wave-uniform byte address) + lane * 16, no VGPR destination - the way to have the NEXT work item's table entries in flight
 // while a kernel that already fills its 256 VGPRs with column accumulators computes on the current one. The instruction is inline
