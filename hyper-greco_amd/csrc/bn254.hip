@@ -488,7 +488,10 @@ __global__ void k_bn_gp_regroup(const Fr* __restrict__ in, Fr* __restrict__ out,
 struct RoundGrid { int gx, gy; int blocks() const { return gx * gy; } };
 static RoundGrid round_grid(size_t half, int nitems) {
     RoundGrid g;
-    g.gx = (int)std::min<size_t>((half + BN_TPB - 1) / BN_TPB, (size_t)1024);
+    // pair indices per thread in the long rounds: a workgroup's fixed cost (first loads, block sums, partial store) is paid once per four
+    // (round 6, config-5 prove with 1 / 2 / 4 / 8: 8.6-9.0 / 8.7 / 8.5-8.6 / 8.8-8.9 ms)
+    const size_t want = half >= ((size_t)BN_TPB << 4) ? 4 : 1;
+    g.gx = (int)std::min<size_t>((half + BN_TPB * want - 1) / (BN_TPB * want), (size_t)1024);
     const size_t threads = (size_t)g.gx * BN_TPB;
     g.gy = (int)std::max<size_t>(1, std::min<size_t>((size_t)nitems, (size_t)131072 / threads));
     return g;
@@ -2099,6 +2102,19 @@ static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4,
             eq_plan_flush(st, eq_pool, plan, keep);
             eq_pool.marks.clear();   // (the arena is rewound by this function, not by the pool)
         }
+        // The claimed sum and the collation sum-check (0.9 ms of mostly launch-bound rounds nothing but the host reads) go to the SECOND
+        // stream, behind the node reductions already enqueued there (round 6; HG_BN_COL_MAIN=1: on the main stream as before): the hashes,
+        // the product trees and the grand products - 4.7 ms of HBM-bound launches - then start right behind the counters instead of
+        // behind those rounds, and the launch-bound work of the other stream runs under them. The main stream waits for the second one
+        // before the synchronisation at the end of the node.
+        static const bool col_main = hg_env_on("HG_BN_COL_MAIN");
+        hipStream_t st_col = (col_main || !ctx->stream2 || ctx->stream2 == st) ? st : ctx->stream2;
+        if (st_col != st) {
+            if (!ctx->bn_ev[0]) for (auto& e : ctx->bn_ev) hipc(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
+            bn_flush(ctx, st);   // (descriptors staged so far belong to launches of the main stream)
+            hipc(hipEventRecord(ctx->bn_ev[0], st), "event record");   // limb split, E tables, eq tables: what the claim and the collation tables read
+            hipc(hipStreamWaitEvent(st_col, ctx->bn_ev[0], 0), "stream wait");
+        }
         // r, claimed sum (lasso.rs:85, 264-269)
         MPow mp;
         {
@@ -2108,8 +2124,8 @@ static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4,
         }
         {
             const int grid = (int)std::min<size_t>((L.rows + BN_TPB - 1) / BN_TPB, 1024);
-            k_bn_lasso_claim<<<grid, BN_TPB, 0, st>>>(L, eq, ep, mp, d_part);
-            k_bn_reduce<<<1, BN_TPB, 0, st>>>(d_part, grid, 1, r_claimed.dev);
+            k_bn_lasso_claim<<<grid, BN_TPB, 0, st_col>>>(L, eq, ep, mp, d_part);
+            k_bn_reduce<<<1, BN_TPB, 0, st_col>>>(d_part, grid, 1, r_claimed.dev);
         }
         // collation sum-check (lasso.rs:271-279): g = poly(0) * sum_i M^i poly(i) - on two tables, E_0 and the weighted sum of the others
         {
@@ -2120,7 +2136,7 @@ static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4,
                 Fr pwr = fr_one_mont();
                 for (int i = 0; i < 32; i++) { cp.v[i] = i < A ? fr_to_mont(pwr) : fr_zero(); pwr = fr_mul(pwr, m); }
             }
-            k_bn_collation_tabs<<<(unsigned)std::min<size_t>((N + BN_TPB - 1) / BN_TPB, 4096), BN_TPB, 0, st>>>(L, ep, cp, tabs);
+            k_bn_collation_tabs<<<(unsigned)std::min<size_t>((N + BN_TPB - 1) / BN_TPB, 4096), BN_TPB, 0, st_col>>>(L, ep, cp, tabs);
             // g = tabs[0] * tabs[1]: a PRODSUM sum-check with one pair (k_bn_ps_round_jobs for the long rounds, one tail workgroup for
             // the rest); the round slots hold (g(0), g(2))
             if (nu > 32) throw Error("hg_lasso_prove_bn254: more than 32 rounds");
@@ -2164,11 +2180,12 @@ static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4,
             const PsJobDev* d_descs = bn_stage(ctx, descs.data(), descs.size());
             const RedJobDev* d_red = bn_stage(ctx, &red, 1);
             const TailJobDev* d_tl = bn_stage(ctx, &tl, 1);
-            bn_flush(ctx, st);
-            if (!descs.empty()) k_bn_mf_consts<PsJobDev><<<(unsigned)descs.size(), 64, 0, st>>>(d_descs);
-            for (int rd = 0; rd < col_nmain; rd++) k_bn_ps_round_jobs<<<dim3(2 * ((blocks[rd] + 7) / 8 * 8), 1, 1), BN_TPB, 0, st>>>(d_descs + rd, nullptr);
-            k_bn_reduce_jobs<<<dim3(32, 1), BN_TPB, 0, st>>>(d_red, 2);
-            k_bn_tail_jobs<BN_PRODSUM><<<1, 2 * BN_TPB, 0, st>>>(d_tl);
+            bn_flush(ctx, st_col);
+            if (!descs.empty()) k_bn_mf_consts<PsJobDev><<<(unsigned)descs.size(), 64, 0, st_col>>>(d_descs);
+            for (int rd = 0; rd < col_nmain; rd++) k_bn_ps_round_jobs<<<dim3(2 * ((blocks[rd] + 7) / 8 * 8), 1, 1), BN_TPB, 0, st_col>>>(d_descs + rd, nullptr);
+            k_bn_reduce_jobs<<<dim3(32, 1), BN_TPB, 0, st_col>>>(d_red, 2);
+            k_bn_tail_jobs<BN_PRODSUM><<<1, 2 * BN_TPB, 0, st_col>>>(d_tl);
+            if (st_col != st) hipc(hipEventRecord(ctx->bn_ev[1], st_col), "event record");
         }
         // MemoryCheckingProver::new (prover.rs:35-89): gamma, tau are the challenges themselves (E = F)
         const Fr gamma = fr_to_mont(chain[gamma_at]), tau = fr_to_mont(chain[tau_at]), gamma2 = fr_mul(gamma, gamma);
@@ -2333,6 +2350,7 @@ static void lasso_prove_bn254_impl(hg_ctx* ctx, const hg_pk* pk, const u64* in4,
             run(eqy, ty, oy, ny, M);
         }
         if (mid && mid_at >= 3) (*mid)();
+        if (st_col != st) hipc(hipStreamWaitEvent(st, ctx->bn_ev[1], 0), "stream wait");   // the claimed sum and the collation rounds' sums
         const bool times = hg_times("bn");   // read at every call (host.hpp)
         const double t_enq = wall_ms();
         res_sync(ctx, st, "lasso_prove_bn254: sync");

@@ -141,6 +141,7 @@ hg_ctx::~hg_ctx() {
     if (comm) { try { hg::comm_destroy(this); } catch (...) {} }
     if (d_xchg) (void)hipFree(d_xchg);
     if (stream2) { (void)hipStreamSynchronize(stream2); (void)hipStreamDestroy(stream2); }
+    for (auto& e : bn_ev) if (e) (void)hipEventDestroy(e);
     if (bn_stream_hi) (void)hipStreamDestroy(bn_stream_hi);
     if (bn_stream_lo) (void)hipStreamDestroy(bn_stream_lo);
     if (ev_fork) (void)hipEventDestroy(ev_fork);

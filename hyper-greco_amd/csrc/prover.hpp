@@ -21,6 +21,7 @@ struct hg_ctx {
     int device = 0;
     hipStream_t stream = nullptr;   // Lasso node + everything sequential
     hipStream_t bn_stream_hi = nullptr, bn_stream_lo = nullptr;   // BN254 prove only (bn254_gkr.inc: BnStreams), created on first use
+    hipEvent_t bn_ev[2] = {nullptr, nullptr};                     // BN254 Lasso node: its claim / collation rounds on the second stream (bn254.hip)
     hipStream_t stream2 = nullptr;  // Vanilla / FFT node reductions (independent of the Lasso node on the device)
     hipStream_t stream_col = nullptr;   // one rank: the collation sum-check's short launches, then the node reductions, off the main stream (forked from and joined to it)
     hipEvent_t ev_col = nullptr;
