@@ -596,6 +596,55 @@ struct SeqProver {
         n_reduce++;
     }
 
+    // ---- node ownership (round 6; SURVEY 8(e): "one CRT modulus per GPU, allreduce per round") -------------------------------------------
+    // own_mode: the values object is a rank's share (hg_witness_gen_shard): it holds the Lasso node's input and the inputs of the node
+    // reductions this rank owns (shard_plan: node chains dealt by modulus, as in mode 0). A Vanilla / FFT node's reduction then runs on
+    // its owner alone - every tile of every round kernel, the rounds it finishes on the host - and the other ranks ("ghosts") launch
+    // nothing for it: they take part in the same all-reduces with zeros, absorb the same messages and squeeze the same challenges. The
+    // Lasso node keeps the tile-split form (every rank holds its input).
+    bool own_mode = false;
+    ShardPlan plan;
+    int cur_owner = -1;   // the owner of the node reduction being walked; -1: every rank works (tile split)
+    bool ghost() const { return cur_owner >= 0 && cur_owner != shard_rank; }
+    bool solo() const { return cur_owner >= 0 && cur_owner == shard_rank; }
+    struct Owned {        // scope of one node reduction
+        SeqProver* P;
+        Owned(SeqProver* p, int owner) : P(p) { P->cur_owner = P->own_mode ? owner : -1; }
+        ~Owned() { P->cur_owner = -1; }
+    };
+    // values that exist on one rank only (`have`) -> every rank: one all-reduce in which the others add zeros
+    void share(E2* v, size_t n, bool have) {
+        if (shard_world <= 1 || n == 0) return;
+        std::vector<uint64_t> w(2 * n, 0);
+        if (have) for (size_t i = 0; i < n; i++) { w[2 * i] = v[i].c0; w[2 * i + 1] = v[i].c1; }
+        if (reduce(reduce_user, w.data(), w.size()) != 0) throw Error("sharded prove: an all-reduce failed");
+        for (size_t i = 0; i < n; i++) {
+            if (w[2 * i] >= GL_P || w[2 * i + 1] >= GL_P) throw Error("sharded prove: the all-reduce returned a non-canonical word");
+            v[i] = e2(w[2 * i], w[2 * i + 1]);
+        }
+        n_reduce++;
+    }
+    void share_slot_list(const std::vector<size_t>& slots) {   // result slots of the current node: the owner's values to every rank
+        if (cur_owner < 0) return;
+        std::vector<E2> t(slots.size());
+        for (size_t i = 0; i < slots.size(); i++) t[i] = ctx->h_res[slots[i]];
+        share(t.data(), t.size(), solo());
+        for (size_t i = 0; i < slots.size(); i++) ctx->h_res[slots[i]] = t[i];
+    }
+    // challenges a ghost squeezed for a sum-check it did not run, into its own device table (later nodes it owns are opened at them)
+    void install_chain(size_t first, size_t cnt) {
+        while (cnt) {
+            const size_t take = std::min<size_t>(cnt, 24);
+            SqInstall in;
+            memset(&in, 0, sizeof(in));
+            in.chain_dst = d_chain + first;
+            in.nchain = (int)take;
+            for (size_t i = 0; i < take; i++) in.chain[i] = chain[first + i];
+            k_sq_install<<<1, 64, 0, st>>>(in);
+            first += take; cnt -= take;
+        }
+    }
+
     SeqProver(hg_ctx* c, const hg_pk* k, int m) : ctx(c), pk(k), mode(m), st(c->stream) {
         tr.absorb = (m & 1) != 0;
         chain_cap = 1 << 15;
@@ -771,7 +820,7 @@ struct SeqProver {
         A.dst = rd >= 1 ? J.buf[rd & 1] : nullptr;
         A.kind = J.kind; A.ntab = J.ntab; A.nvars = J.nvars;
         A.last = J.dev_rounds && rd == J.dev_rounds - 1;
-        A.rank = shard_rank; A.world = shard_world;
+        A.rank = cur_owner >= 0 ? 0 : shard_rank; A.world = cur_owner >= 0 ? 1 : shard_world;   // (a node's owner evaluates every tile itself)
         return A;
     }
     template <int KIND> void launch_round(bool in_base, const SqJob& J, const SqJob* d_job, int rd, int jb_log2, int grid) {
@@ -821,7 +870,7 @@ struct SeqProver {
             if (((size_t)J.ntab << (J.nvars - R + 1)) <= host_tail_entries && J.nvars - R + 1 <= 24) return R;
         return 0;
     }
-    std::vector<E2> tail_a, tail_b;
+    std::vector<E2> tail_a, tail_b, tail_sums;   // (tail_sums: the host rounds' sums of a node this rank owns, for the ghosts)
     // host arithmetic of the tail: products accumulated as 128-bit integers (+ carry), one reduction per extension-field coefficient
     struct Acc { unsigned __int128 v = 0; u64 hi = 0; void add(u64 a, u64 b) { const unsigned __int128 p = (unsigned __int128)a * b; v += p; hi += v < p; } };
     static u64 acc_reduce(const Acc& a) {   // v + hi 2^128 mod p; 2^128 = -2^32 (mod p)
@@ -911,6 +960,7 @@ struct SeqProver {
                     sums[2] = e2_add(sums[2], e2_mul(q3, s3));
                 }
             }
+            if (solo()) tail_sums.insert(tail_sums.end(), sums, sums + J.nv);
             r = round_message(sums, deg, claim, false);
             n_host_rounds++;
         }
@@ -939,6 +989,24 @@ struct SeqProver {
         J.nv = J.kind == 1 ? 3 : 2;
         const size_t point_off = epos();
         J.r_off = point_off;
+        if (ghost()) {
+            // another rank runs this sum-check: the same all-reduces with zeros (one per device round, one for the rounds its host
+            // finishes), the same transcript steps; the challenges go into this rank's device table afterwards
+            const int R = host_tail_start(J), ndev = R ? R : nvars, deg = J.kind == 1 ? 3 : 2;
+            for (int rd = 0; rd < ndev; rd++) {
+                E2 sums[3] = {e2_zero(), e2_zero(), e2_zero()};
+                reduce_sums(sums, J.nv);
+                round_message(sums, deg, claim, false);
+            }
+            if (R) {
+                std::vector<E2> ts((size_t)(nvars - R) * J.nv, e2_zero());
+                share(ts.data(), ts.size(), false);
+                for (int rd = R; rd < nvars; rd++) round_message(ts.data() + (size_t)(rd - R) * J.nv, deg, claim, false);
+            }
+            install_chain(point_off, (size_t)nvars);
+            sq_results_on_host = true;   // (nothing of it is on this rank's device: the final evaluations arrive through share_slot_list)
+            return point_off;
+        }
         J.sums_slot = slot((size_t)nvars * J.nv);
         const size_t N = (size_t)1 << nvars;
         J.buf[1] = ctx->alloc_n<E2>((size_t)J.ntab * std::max<size_t>(N / 2, 1));
@@ -998,8 +1066,10 @@ struct SeqProver {
             t_wait_rounds = r0;
             t_wait_export += now_ms() - w0;
             const double h0 = now_ms();
+            tail_sums.clear();
             host_tail(J, R, claim);
             t_host_tail += now_ms() - h0;
+            if (solo()) share(tail_sums.data(), tail_sums.size(), true);   // the ghosts absorb the same messages
         }
         sq_results_on_host = R != 0;
         return point_off;
@@ -1364,17 +1434,23 @@ struct SeqProver {
         const hg_pk::NodeDev& nd = pk->node_dev[id];
         const int nin = n.log2_sub_in + n.log2_reps;
         const size_t SR = (size_t)1 << nin;
+        Owned scope(this, own_mode ? plan.node_owner[id] : -1);
+        const bool gh = ghost();   // another rank's node: no device work here, its results arrive through the group
+        if (own_mode && hg_debug("shard")) fprintf(stderr, "[hg] rank %d: vanilla node %d, owner %d\n", shard_rank, id, cur_owner);
         std::vector<E2> alphas;
         dev::ClaimSet cs = claim_set(claims[id], &alphas);
         for (auto& c : claims[id]) if (c.len != n.log2_out()) throw Error("gkr: claim arity mismatch");
         E2 claim = combined(claims[id], alphas);
-        E2* eqc = ctx->alloc_n<E2>((size_t)1 << n.log2_out());
-        eq_table(eqc, n.log2_out(), cs);
+        E2* eqc = gh ? nullptr : ctx->alloc_n<E2>((size_t)1 << n.log2_out());
+        if (!gh) eq_table(eqc, n.log2_out(), cs);
         if (nd.nconst) {  // claim -= sum_g eqc[g] w0_g
             const size_t s = slot(1);
-            int grid = dev::vanilla_const_sum(st, nd.const_gate, nd.const_coef, nd.nconst, eqc, n.log2_sub_out, n.log2_reps, ctx->d_partials);
-            dev::reduce_partials(st, ctx->d_partials, grid, 1, d_res() + s);
-            wait_results();
+            if (!gh) {
+                int grid = dev::vanilla_const_sum(st, nd.const_gate, nd.const_coef, nd.nconst, eqc, n.log2_sub_out, n.log2_reps, ctx->d_partials);
+                dev::reduce_partials(st, ctx->d_partials, grid, 1, d_res() + s);
+                wait_results();
+            }
+            share_slot_list({s});
             claim = e2_sub(claim, h_res()[s]);
         }
         std::vector<int> li, ri;
@@ -1387,10 +1463,10 @@ struct SeqProver {
         std::vector<const E2*> b;
         std::vector<E2*> fa, fb;
         const size_t u_base = slot(n.arity);
-        E2* scratch = ctx->alloc_n<E2>(n.arity);
+        E2* scratch = gh ? nullptr : ctx->alloc_n<E2>(n.arity);
         std::vector<dev::GatherJob> gj;
         for (int i : li) {
-            E2* T = ctx->alloc_n<E2>(SR);
+            E2* T = gh ? nullptr : ctx->alloc_n<E2>(SR);
             gt.lin = nd.lin[i];
             gt.mul = nd.mulL[i];
             gj.push_back(dev::GatherJob{gt, eqc, n.log2_sub_in, n.log2_sub_out, n.log2_reps, T});
@@ -1399,9 +1475,14 @@ struct SeqProver {
             fa.push_back(d_res() + u_base + i);
             fb.push_back(scratch + i);
         }
-        if (!gj.empty()) dev::gather_jobs(st, upload(gj.data(), gj.size()), (int)gj.size(), SR);
+        if (!gj.empty() && !gh) dev::gather_jobs(st, upload(gj.data(), gj.size()), (int)gj.size(), SR);
         const size_t rx_off = sumcheck_prodsum(a, b, nin, fa, fb, claim);  // Libra phase 1
         wait_sumcheck_results();
+        {
+            std::vector<size_t> sl;
+            for (int i : li) sl.push_back(u_base + i);
+            share_slot_list(sl);
+        }
         for (int i : li) {
             const E2 v = h_res()[u_base + i];
             tr.write_e(v);
@@ -1410,24 +1491,29 @@ struct SeqProver {
         if (n.mul.empty()) return;
         if (!n.lin.empty()) throw Error("vanilla: nodes mixing linear and mul gates are not on this path");
         // phase 2: sum_y sum_i in_i(y) B_i(y); the claim carries over (no linear part)
-        E2* eqx = ctx->alloc_n<E2>(SR);
-        eq_single(eqx, nin, rx_off);
+        E2* eqx = gh ? nullptr : ctx->alloc_n<E2>(SR);
+        if (!gh) eq_single(eqx, nin, rx_off);
         std::vector<const u64*> a2;
         std::vector<const E2*> b2;
         std::vector<E2*> fa2, fb2;
         const size_t w_base = slot(n.arity);
         std::vector<dev::GatherBJob> bj;
         for (int i : ri) {
-            E2* B = ctx->alloc_n<E2>(SR);
+            E2* B = gh ? nullptr : ctx->alloc_n<E2>(SR);
             bj.push_back(dev::GatherBJob{nd.mulR[i], eqc, eqx, d_res() + u_base, n.log2_sub_in, n.log2_sub_out, n.log2_reps, B});
             a2.push_back(d_vals[n.preds[i]]);
             b2.push_back(B);
             fa2.push_back(d_res() + w_base + i);
             fb2.push_back(scratch + i);
         }
-        dev::gather_B_jobs(st, upload(bj.data(), bj.size()), (int)bj.size(), SR);
+        if (!gh) dev::gather_B_jobs(st, upload(bj.data(), bj.size()), (int)bj.size(), SR);
         const size_t ry_off = sumcheck_prodsum(a2, b2, nin, fa2, fb2, claim);
         wait_sumcheck_results();
+        {
+            std::vector<size_t> sl;
+            for (int i : ri) sl.push_back(w_base + i);
+            share_slot_list(sl);
+        }
         for (int i : ri) {
             const E2 v = h_res()[w_base + i];
             tr.write_e(v);
@@ -1440,18 +1526,24 @@ struct SeqProver {
         const HNode& n = pk->circuit.nodes[id];
         const int L = n.log2_size;
         const size_t N = (size_t)1 << L;
+        Owned scope(this, own_mode ? plan.node_owner[id] : -1);
+        const bool gh = ghost();
+        if (own_mode && hg_debug("shard")) fprintf(stderr, "[hg] rank %d: fft node %d, owner %d\n", shard_rank, id, cur_owner);
         std::vector<E2> alphas;
         dev::ClaimSet cs = claim_set(claims[id], &alphas);
         E2 claim = combined(claims[id], alphas);
-        E2* F = ctx->alloc_n<E2>(N);
-        const u64* W = (n.inverse ? pk->w_inv : pk->w_fwd).at(L);
-        dev::FftJob fj{F, W, n.inverse ? gl_inv(gl_from_u64(N)) : 1, L, cs};
-        E2* tab = ctx->alloc_n<E2>((size_t)cs.n * (N >> 4) + 1);
-        dev::fft_jobs(st, upload(&fj, 1), 1, L, cs.n, d_chain, tab);
+        E2* F = gh ? nullptr : ctx->alloc_n<E2>(N);
+        if (!gh) {
+            const u64* W = (n.inverse ? pk->w_inv : pk->w_fwd).at(L);
+            dev::FftJob fj{F, W, n.inverse ? gl_inv(gl_from_u64(N)) : 1, L, cs};
+            E2* tab = ctx->alloc_n<E2>((size_t)cs.n * (N >> 4) + 1);
+            dev::fft_jobs(st, upload(&fj, 1), 1, L, cs.n, d_chain, tab);
+        }
         const size_t u = slot(1);
-        E2* scratch = ctx->alloc_n<E2>(1);
+        E2* scratch = gh ? nullptr : ctx->alloc_n<E2>(1);
         const size_t off = sumcheck_prodsum({d_vals[n.preds[0]]}, {F}, L, {d_res() + u}, {scratch}, claim);
         wait_sumcheck_results();
+        share_slot_list({u});
         const E2 v = h_res()[u];
         tr.write_e(v);
         claims[n.preds[0]].push_back(Claim{off, L, v});
@@ -1482,10 +1574,11 @@ struct SeqProver {
 ProveResult prove_resident_mode(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int mode) {
     return prove_resident_mode_sharded(ctx, pk, v, mode, 0, 1, nullptr, nullptr);
 }
-// The round-by-round prover on `world` ranks, each holding the whole witness: rank r evaluates the hypercube sums of the tiles
+// The round-by-round prover on `world` ranks. With the whole witness on every rank: rank r evaluates the hypercube sums of the tiles
 // t = r (mod world) of every round kernel and folds everything; one all-reduce (`reduce`) per round completes the sums, after which
 // every rank's transcript absorbs the same message and squeezes the same challenge. Rounds finished on the host (host_tail) and the
-// scalar steps between the sum-checks are replicated. Every rank returns the same proof, byte for byte the single-rank one.
+// scalar steps between the sum-checks are replicated. With a rank's share of the witness (hg_witness_gen_shard): node ownership, see
+// SeqProver::own_mode. Every rank returns the same proof, byte for byte the single-rank one.
 ProveResult prove_resident_mode_sharded(hg_ctx* ctx, const hg_pk* pk, const hg_values* v, int mode, int rank, int world,
                                         int (*reduce)(void*, uint64_t*, size_t), void* user) {
     if (world < 1 || rank < 0 || rank >= world) throw Error("sharded prove: rank out of range");
@@ -1501,16 +1594,25 @@ ProveResult prove_resident_mode_sharded(hg_ctx* ctx, const hg_pk* pk, const hg_v
     SeqProver P(ctx, pk, mode);
     P.shard_rank = rank; P.shard_world = world; P.reduce = reduce; P.reduce_user = user;
     P.d_vals = v->d_vals;
+    if (v->shard_rank >= 0) {   // a rank's share of the witness (hg_witness_gen_shard): node reductions run on their owners only
+        if (v->shard_rank != rank || v->shard_world != world) throw Error("sharded prove: these values hold the tables of rank " + std::to_string(v->shard_rank) + " of " + std::to_string(v->shard_world));
+        P.own_mode = world > 1;
+        P.plan = shard_plan(pk, rank, world);
+    }
     const Params& p = pk->params;
     // "eval output" (sk_encryption_circuit.rs:444-448)
     const int ov = p.ct0is_log2();
     const size_t point_off = P.epos();
     for (int i = 0; i < ov; i++) P.squeeze();
     const size_t vslot = P.slot(1);
-    E2* eq = ctx->alloc_n<E2>((size_t)1 << ov);
-    P.eq_single(eq, ov, point_off);
-    P.dots(eq, {v->d_ct0is}, (size_t)1 << ov, vslot);
-    P.wait_results();
+    const bool out_mine = !P.own_mode || P.plan.own_out_claim == rank;   // (own_mode: ct0is is resident on the owner of the output claim only)
+    if (out_mine) {
+        E2* eq = ctx->alloc_n<E2>((size_t)1 << ov);
+        P.eq_single(eq, ov, point_off);
+        P.dots(eq, {v->d_ct0is}, (size_t)1 << ov, vslot);
+        P.wait_results();
+    }
+    if (P.own_mode) P.share(ctx->h_res + vslot, 1, out_mine);
     P.gkr(Claim{point_off, ov, ctx->h_res[vslot]});
     hip_check(hipGetLastError(), "prove (mode)");
     ProveResult res;

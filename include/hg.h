@@ -179,7 +179,12 @@ int hg_verify_mode(const hg_pk* pk, const hg_witness* w, int mode, const uint8_t
  * In this form a round kernel is launched only after the challenge of the round before has been posted (the single-rank prover
  * launches ahead and lets the kernel wait on the device): no kernel ever waits for the host, so ranks may share a device or a
  * hardware queue (ranks as threads of one process in the tests) without waiting for each other's waiting kernels.
- * timings->replay_ms holds the number of all-reduces of the proof. Mode 0 shards through hg_prove_sharded (one all-reduce per proof). */
+ * timings->replay_ms holds the number of all-reduces of the proof. Mode 0 shards through hg_prove_sharded (one all-reduce per proof).
+ * WITHOUT replicating the witness (round 6): when `v` is a rank's share (hg_witness_gen_shard: the Lasso node's input and the inputs of
+ * the node reductions the rank owns, chains dealt by CRT modulus as in mode 0), a Vanilla / FFT node's reduction runs on its owner
+ * alone - every tile of its round kernels, the rounds finished on the host - and the other ranks launch nothing for it: they join the
+ * same all-reduces with zeros (one per device round; one of up to 144 words for the rounds the owner's host finished; one for the final
+ * evaluations), absorb the same messages and squeeze the same challenges. The Lasso node keeps the tile-split form. Same proof bytes. */
 hg_group* hg_group_local(int world);
 hg_group* hg_group_external(void* reduce_fn, void* user, int world);
 void hg_group_free(hg_group* g);

@@ -14,6 +14,9 @@ mode "prove_seq" (needs a GPU; both ranks on device 0): the round-by-round prove
     extension-field memory checking) on two processes, ONE all-reduce per sum-check round (hg_prove_resident_mode_sharded with an
     external group: the six words of a round's partial sums are all-gathered over gloo and added mod p); n=1024 k=1 and n=4096 k=2,
     every rank's proof must be the CPU oracle's proof of that mode.
+mode "prove_seq_own" (needs a GPU; both ranks on device 0): the same prover at n=32768 k=16 WITHOUT replicating the witness: per-rank tables
+    (hg_witness_gen_shard) and node ownership - a Vanilla / FFT node's reduction runs on its owner alone, the other process joins the same
+    all-reduces with zeros; every rank's proof must be the CPU oracle's mode-3 proof, with less than the full set of tables resident.
 mode "prove_rccl" (needs TWO GPUs: rank r on device r): hg_prove_sharded - the library's own ncclAllReduce of the result buffer over
     xGMI behind each rank's share, per-rank tables (hg_witness_gen_shard) - at n=4096 k=2 and n=32768 k=16; gloo only carries the
     128-byte RCCL id. Every rank's proof must be the CPU oracle's. (RCCL refuses two ranks on one device, so this cannot be faked.)"""
@@ -145,6 +148,37 @@ def main():
         dist.barrier()
         print("rank %d PROVE_SEQ OK (%d all-reduces for the last proof)" % (rank, calls[0]), flush=True)
         ctx.close()
+    elif mode == "prove_seq_own":
+        import orclib
+        ctx = hg.Context(0)
+        n, k = 32768, 16
+        bfv = hg.BfvEncrypt.new(n, k)
+        pk = bfv.setup(ctx)
+        w = hg.Witness.synthetic(bfv.params, 0x91 + n)
+        threads = max(2, min(16, (os.cpu_count() or 4) // world))
+        ref = orclib.prove_f("goldilocks", orclib.params(n, k), orclib.Inputs(w.arrays()), threads=threads, mode=3)[0]
+        vals = hg.witness_gen_shard(ctx, pk, w, rank, world)      # this rank's share of the node tables only
+        info = vals.info()
+        assert info["resident_bytes"] < info["full_bytes"] and info["resident_tables"] < info["tables"], info
+        calls = [0]
+
+        def reduce(words):   # a round's (or a shared result's) all-reduce: gather, add as field elements, in place - vectorised, the messages reach 144 words
+            g = all_gather_u64(np.array(words, copy=True), world)
+            acc = np.zeros(len(words), dtype=object)
+            for r in range(world):
+                acc = (acc + g[r].astype(object)) % P
+            for i in range(len(words)):
+                words[i] = int(acc[i])
+            calls[0] += 1
+
+        group = hg.Group.external(reduce, world)
+        out = hg.ProofBuffer()
+        got = hg.prove_resident_mode_sharded(ctx, pk, vals, out, 3, rank, group).bytes()
+        assert got == ref, "rank %d: the two-process round-by-round proof with node ownership (n=%d k=%d) differs from the CPU oracle's mode-3 proof" % (rank, n, k)
+        assert calls[0] == int(out.timings()["replay_ms"]) > 1000, (calls[0], out.timings())
+        dist.barrier()
+        print("rank %d PROVE_SEQ_OWN OK resident %.1f MB of %.1f MB, %d all-reduces, %.0f ms" % (rank, info["resident_bytes"] / 1e6, info["full_bytes"] / 1e6, calls[0], out.timings()["prove_ms"]), flush=True)
+        vals.free(); pk.free(); ctx.close()
     elif mode == "prove_rccl":
         import orclib
         assert hg.device_count() >= world, "prove_rccl needs one GPU per rank"

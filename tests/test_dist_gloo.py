@@ -78,6 +78,15 @@ def test_round_by_round_prover_two_processes_one_allreduce_per_round():
 
 
 @pytest.mark.gpu
+def test_round_by_round_prover_two_processes_node_ownership_at_the_headline_size():
+    """The memory-sharded form of the per-round exchange (round 6; tests/dist_worker.py "prove_seq_own"): n=32768 k=16, mode 3, two real
+    processes over gloo, per-rank tables and node ownership; both proofs are the CPU oracle's, resident_bytes < full on every rank."""
+    out = _launch([os.path.join(ROOT, "tests", "dist_worker.py"), "prove_seq_own"], 29527, 1500)
+    assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-3000:])
+    assert out.stdout.count("PROVE_SEQ_OWN OK") == 2, out.stdout
+
+
+@pytest.mark.gpu
 def test_sharded_prove_over_real_rccl_two_gpus():
     """hg_prove_sharded over the library's own RCCL communicator with TWO ranks on TWO GPUs (tests/dist_worker.py "prove_rccl"; the
     all-reduce of the result buffer crosses xGMI), n=4096 k=2 and n=32768 k=16 with per-rank tables, both ranks' proofs equal to the
