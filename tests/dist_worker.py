@@ -150,7 +150,7 @@ def main():
         ctx.close()
     elif mode == "prove_seq_own":
         import orclib
-        ctx = hg.Context(0)
+        ctx = hg.Context(rank if hg.device_count() >= world else 0)   # one GPU per rank where the box has them (the exchange stays on gloo)
         n, k = 32768, 16
         bfv = hg.BfvEncrypt.new(n, k)
         pk = bfv.setup(ctx)
