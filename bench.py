@@ -1064,6 +1064,38 @@ def main():
                         {"identical_to_single_rank": got[0][0] == ref3 and got[1][0] == ref3, "allreduces_per_proof": int(got[0][1]["replay_ms"]),
                          "prove_ms_per_rank": [round(g[1]["prove_ms"], 2) for g in got],
                          "note": "two ranks as threads on ONE GPU, in-process group (hg_group_local): every rank folds everything and evaluates half of each round's sums; one all-reduce of <= 6 words per round"})
+                    # ... and WITHOUT replicating the witness (round 6): per-rank tables (hg_witness_gen_shard), a node reduction runs on its owner alone
+                    if not hung and not errs:
+                        sv = [hg.witness_gen_shard(ctx if r == 0 else ctx_b, pk if r == 0 else pk_b, witnesses[0], r, 2) for r in range(2)]
+                        infos = [v.info() for v in sv]
+                        group2 = hg.Group.local(2)
+                        got2, errs2 = [None, None], []
+
+                        def own_rank(r):
+                            try:
+                                o = hg.ProofBuffer()
+                                hg.prove_resident_mode_sharded(ctx if r == 0 else ctx_b, pk if r == 0 else pk_b, sv[r], o, 3, r, group2)
+                                got2[r] = (o.bytes(), o.timings())
+                            except Exception as ex:
+                                errs2.append(str(ex))
+
+                        for _ in range(2):
+                            ths = [threading.Thread(target=own_rank, args=(r,), daemon=True) for r in range(2)]
+                            for t in ths: t.start()
+                            for t in ths: t.join(120)
+                            if any(t.is_alive() for t in ths):
+                                hung = True
+                                errs2.append("a rank thread did not finish within 120 s")
+                                break
+                        line["sound_mode"]["node_ownership_two_ranks_one_gpu"] = (
+                            {"error": "; ".join(errs2)} if errs2 or None in got2 else
+                            {"identical_to_single_rank": got2[0][0] == ref3 and got2[1][0] == ref3, "allreduces_per_proof": int(got2[0][1]["replay_ms"]),
+                             "prove_ms_per_rank": [round(g[1]["prove_ms"], 2) for g in got2],
+                             "resident_MB_per_rank": [round(i["resident_bytes"] / 1e6, 1) for i in infos], "full_set_MB": round(infos[0]["full_bytes"] / 1e6, 1),
+                             "note": "two ranks as threads on ONE GPU: each holds its share of the node tables only; a Vanilla / FFT node's reduction runs on its owner, the "
+                                     "other rank joins the same all-reduces with zeros; the Lasso node keeps the tile-split form"})
+                        if not hung:
+                            for v in sv: v.free()
                     if not hung:
                         vals_b.free(); pk_b.free(); ctx_b.close()
                 except Exception as ex:
