@@ -454,3 +454,23 @@ def test_setup_finds_the_eq_factored_nodes():
         wins = sorted(r["window"] for r in eq if r["in_log2"] > r["block_log2"])   # the chunk nodes: window c of the r2is table
         assert wins == list(range(chunks)) or chunks == 1, (n, k, wins)
         pk.free()
+
+
+def test_bench_issue_model_reads_the_committed_rate_table():
+    """bench.py prices a kernel's VALU instructions per instruction class (roofline.issue_frac): the two rates come from the committed output
+    of scripts/ub/ratebench.hip (profiles/r06_ratebench.txt). The plain VOP1 / VOP2 integer forms must come out at about twice the rate of
+    everything else, and a kernel's issue time must lie between the all-class-A and the all-class-B price of its instruction count."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("hg_bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    im = bench.IssueModel()
+    assert im.rate_a and im.rate_b, im.note
+    assert 0.9e9 < im.rate_a < 1.2e9 and 0.45e9 < im.rate_b < 0.65e9 and 1.6 < im.rate_a / im.rate_b < 2.2, (im.rate_a, im.rate_b)
+    if im.ok():   # (the class mix is refused when it was taken on other sources: then only the rates are checked)
+        sym = bench.CLASS_SYMBOL[bench.ROOFLINE_CLASS]
+        fa = im.share_a(sym)
+        assert fa is not None and 0.05 < fa < 0.5, fa
+        n = 25.5e6
+        t = im.seconds(n, sym)
+        assert n / im.rate_a / bench.NSIMD < t < n / im.rate_b / bench.NSIMD
