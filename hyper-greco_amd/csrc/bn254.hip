@@ -574,29 +574,32 @@ __device__ __forceinline__ void bn_tail_body(const Fr* __restrict__ in, Fr* __re
         Fr acc = fr_zero();
         for (int idx = t; idx < half * npairs; idx += BN_TPB) {
             const int j = idx % half, i = idx / half;
-            // (the round kernels leave loose values, bn254_lazy.hpp: the canonical operations below want them normalised)
-            const Fr xa = lz_canon(cur[(size_t)(2 * i) * 2 * half + 2 * j]), ya = lz_canon(cur[(size_t)(2 * i) * 2 * half + 2 * j + 1]);
-            const Fr xb = lz_canon(cur[(size_t)(2 * i + 1) * 2 * half + 2 * j]), yb = lz_canon(cur[(size_t)(2 * i + 1) * 2 * half + 2 * j + 1]);
-            const Fr da = fr_sub(ya, xa), db = fr_sub(yb, xb);
+            // loose arithmetic throughout (bn254_lazy.hpp: the round kernels leave loose values, every product below takes them as they
+            // are; until round 6 this body normalised on load and multiplied canonically - compare-and-branch code on a dependent chain)
+            const Fr xa = cur[(size_t)(2 * i) * 2 * half + 2 * j], ya = cur[(size_t)(2 * i) * 2 * half + 2 * j + 1];
+            const Fr xb = cur[(size_t)(2 * i + 1) * 2 * half + 2 * j], yb = cur[(size_t)(2 * i + 1) * 2 * half + 2 * j + 1];
+            const Fr da = lz_subr(ya, xa), db = lz_subr(yb, xb);
             Fr av, bv;  // the pair at this group's evaluation point
             if (v == 0) { av = xa; bv = xb; }
-            else if (v == 1) { av = fr_add(ya, da); bv = fr_add(yb, db); }
-            else { av = fr_add(fr_add(ya, da), da); bv = fr_add(fr_add(yb, db), db); }
-            Fr term = fr_mul_wide(av, bv);
+            else if (v == 1) { av = lz_add(ya, da); bv = lz_add(yb, db); }
+            else { av = lz_add(lz_add(ya, da), da); bv = lz_add(lz_add(yb, db), db); }
+            Fr term = lz_mul(av, bv);
             if (KIND == BN_GRANDPROD) {
-                const Fr x0 = lz_canon(cur[2 * j]), y0 = lz_canon(cur[2 * j + 1]);
-                const Fr d0 = fr_sub(y0, x0);
-                const Fr pv = v == 0 ? x0 : (v == 1 ? fr_add(y0, d0) : fr_add(fr_add(y0, d0), d0));
-                term = fr_mul_wide(pv, term);
+                const Fr x0 = cur[2 * j], y0 = cur[2 * j + 1];
+                const Fr d0 = lz_subr(y0, x0);
+                const Fr pv = v == 0 ? x0 : (v == 1 ? lz_add(y0, d0) : lz_add(lz_add(y0, d0), d0));
+                term = lz_mul(pv, term);
             }
-            acc = fr_add(acc, term);
-            if (v == 0) nxt[(size_t)(2 * i) * half + j] = fr_add(xa, fr_mul_wide(r, da));
-            else if (v == 1) nxt[(size_t)(2 * i + 1) * half + j] = fr_add(xb, fr_mul_wide(r, db));
+            acc = lz_add(acc, term);
+            if (v == 0) nxt[(size_t)(2 * i) * half + j] = lz_add(xa, lz_mul(r, da));
+            else if (v == 1) nxt[(size_t)(2 * i + 1) * half + j] = lz_add(xb, lz_mul(r, db));
         }
         sm[v][t] = acc;
         __syncthreads();
-        for (int s = BN_TPB / 2; s > 0; s >>= 1) {
-            if (t < s) sm[v][t] = fr_add(sm[v][t], sm[v][t + s]);
+        int s0 = BN_TPB / 2;   // threads at or above half * npairs hold zero: the tree starts at the first level that has a non-zero partner
+        while (s0 > 1 && s0 >= half * npairs) s0 >>= 1;
+        for (int s = s0; s > 0; s >>= 1) {
+            if (t < s) sm[v][t] = lz_add(sm[v][t], sm[v][t + s]);
             __syncthreads();
         }
         if (t == 0) sums_out[rd * NV + v] = fr_from_mont(sm[v][0]);
@@ -995,6 +998,71 @@ __global__ void k_bn_prod_level_mirror_slots(const Fr* __restrict__ in, size_t i
     lz_gstore_nt(&out[v1 * h + j], v);
     if (j < (h >> 1)) lz_gstore(&lw[v1 * (h >> 1) + j], (v1 == 0 || b == 255) ? v : lz_fold(fr_zero(), v, fkW[v1 * (size_t)ng1 + grp].k));
 }
+// Level 0 of the mirrored top layer in slot form, ONE pass (round 6): what k_bn_weight_slots_sum (the layer's weighted left halves and
+// its S table) and k_bn_prod_level_mirror_slots (level 1 in the next layer's slot rows) each read for themselves - the first all V0
+// slot rows once (605 MB at c3), the second a level-0 row once per level-1 row that is made from it (1.3 GB for 22 rows out of 9). One
+// thread per position j walks the V0 rows: x = row[j], y = row[j + h] are loaded once, the products x y and (x + c)(y + c) go to every
+// level-1 slot row whose representative in j's segment group is a read / write row held by this level-0 row (a uniform scan of rep1),
+// the left half and W y join the layer's own tables. Same values as the two kernels (exact arithmetic).
+__global__ __launch_bounds__(256) void k_bn_level0_slots_fused(const Fr* __restrict__ in, size_t in_len, Fr* __restrict__ out1, int nb, Fr c2, FoldK kc, const FoldK* __restrict__ fkW1,
+                                                              Fr* __restrict__ lw1, const unsigned char* __restrict__ slot_of0, int npairs, const unsigned char* __restrict__ rep1,
+                                                              int ng1, int V1, int seg_shift, const Fr* __restrict__ W0, const FoldK* __restrict__ fk0, Fr* __restrict__ lw0,
+                                                              Fr* __restrict__ S, int V0) {
+    const size_t h = in_len >> 1, half = (size_t)nb / 2;
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // (launched with h / 256 workgroups exactly: h >= 2^seg_shift >= 256)
+    // (h is a multiple of the workgroup's 256 positions and they lie in one segment: nobody returned above, the maps below are the workgroup's)
+    const int seg = __builtin_amdgcn_readfirstlane((int)(j >> seg_shift));
+    const int grp = seg % ng1;
+    const bool low = j < (h >> 1);   // (uniform over the wave: h / 2 is a multiple of 64)
+    // which level-1 rows take their entry from level-0 row v in this segment: lists per v, built once per workgroup (scanning rep1 /
+    // slot_of0 from every (v, v1) was ~200 dependent scalar loads per thread)
+    __shared__ unsigned char s_cnt[64], s_list[64][64], s_wr[64][64], s_empty[64];
+    if (threadIdx.x < 64) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int ne = 0;
+        for (int v1 = 0; v1 < V1; v1++) {
+            const int b = rep1[v1 * (size_t)ng1 + grp];
+            if (b == 255) { s_empty[ne++] = (unsigned char)v1; continue; }
+            const int v = slot_of0[((size_t)b % half) * (size_t)npairs + seg];
+            const int k = s_cnt[v]++;
+            s_list[v][k] = (unsigned char)v1;
+            s_wr[v][k] = (size_t)b >= half ? 1 : 0;
+        }
+        s_cnt[63] = (unsigned char)ne;   // (V0 <= 32: slot 63 is free)
+    }
+    __syncthreads();
+    Fr acc = fr_zero();   // loose throughout (bn254_lazy.hpp)
+    WCol c = wcol_zero();
+    for (int v = 0; v < V0; v++) {
+        const Fr x = lz_gload(&in[(size_t)v * in_len + j]), y = lz_gload(&in[(size_t)v * in_len + j + h]);
+        const Fr l0 = v == 0 ? x : lz_fold(fr_zero(), x, fk0[(size_t)v * npairs + seg].k);
+        lz_gstore(&lw0[(size_t)v * h + j], l0);
+        acc = lz_add(acc, l0);
+        wcol_mac(c, W0[(size_t)v * npairs + seg], y);
+        const Fr pr = lz_mul(x, y);
+        const Fr pw = lz_add(pr, lz_fold(c2, lz_add(x, y), kc.k));   // (x + c)(y + c)
+        const int cnt = __builtin_amdgcn_readfirstlane((int)s_cnt[v]);
+        for (int k = 0; k < cnt; k++) {
+            const int v1 = __builtin_amdgcn_readfirstlane((int)s_list[v][k]);
+            const bool wr = __builtin_amdgcn_readfirstlane((int)s_wr[v][k]) != 0;
+            const Fr val = wr ? pw : pr;
+            lz_gstore_nt(&out1[v1 * h + j], val);
+            if (low) lz_gstore(&lw1[v1 * (h >> 1) + j], v1 == 0 ? val : lz_fold(fr_zero(), val, fkW1[v1 * (size_t)ng1 + grp].k));
+        }
+    }
+    {   // slot rows without a member in this segment group
+        const int ne = __builtin_amdgcn_readfirstlane((int)s_cnt[63]);
+        for (int k = 0; k < ne; k++) {
+            const int v1 = __builtin_amdgcn_readfirstlane((int)s_empty[k]);
+            lz_gstore_nt(&out1[v1 * h + j], fr_zero());
+            if (low) lz_gstore(&lw1[v1 * (h >> 1) + j], fr_zero());
+        }
+    }
+    lz_gstore(&S[j], lz_add(acc, lz_reduce(c)));
+}
+
 // A deeper level in slot form from the slot rows of the level above: entry j of slot row v = the product entry of row b = rep_out[v][group
 // of j], whose values in the level above are those of slot row slot_of_in[b][group of j there]; lw as in k_bn_prod_level_mirror_slots.
 __global__ void k_bn_prod_level_slots(const Fr* __restrict__ in, size_t in_len, Fr* __restrict__ out, const FoldK* __restrict__ fkW, Fr* __restrict__ lw,
@@ -1025,19 +1093,19 @@ __global__ void k_bn_gp_regroup_tab(const Fr* __restrict__ in, Fr* __restrict__ 
     out[(size_t)(2 * b) * len + j] = b == 0 ? l : lz_mul(ratio[b * ng + g], l);
     out[(size_t)(2 * b + 1) * len + j] = r;
 }
-// The short end of the product tree in ONE single-workgroup launch: every level whose rows are shorter than 256 entries (a level
-// reads the one before it: the workgroup barrier orders them), then the root products and the canonical copies of the roots and of
-// the two-entry top level for the host - what took a launch per level plus three more per grand product.
+// The short end of the product tree in ONE launch, a workgroup per row: every level whose rows are shorter than 256 entries (a level
+// reads the one before it, of the same row: the workgroup barrier orders them), then the row's root product and the canonical copies
+// of the root and of the two-entry top level for the host - what took a launch per level plus three more per grand product. (Until
+// round 6 one workgroup of 1024 threads walked all rows: ~19 000 dependent-chain products on one CU, 93-110 us per grand product;
+// 28-33 us now.)
 struct ProdTailLevels { const Fr* in; size_t in_len; int nb, nlev; Fr* lev[12]; Fr* lw[12]; const Fr* pw[12]; Fr* top_out; Fr* roots_out; };
-__global__ __launch_bounds__(1024) void k_bn_prod_tail_levels(ProdTailLevels A) {
+__global__ __launch_bounds__(128) void k_bn_prod_tail_levels(ProdTailLevels A) {
     const Fr* in = A.in;
     size_t in_len = A.in_len;
-    const int nb = A.nb;
+    const size_t b = blockIdx.x;
     for (int q = 0; q < A.nlev; q++) {
-        const size_t h = in_len >> 1, total = h * nb;
-        const int sh = __ffsll((long long)h) - 1;
-        for (size_t idx = threadIdx.x; idx < total; idx += 1024) {
-            const size_t b = idx >> sh, j = idx & (h - 1);
+        const size_t h = in_len >> 1;
+        for (size_t j = threadIdx.x; j < h; j += blockDim.x) {
             const Fr v = lz_mul(in[b * in_len + j], in[b * in_len + j + h]);
             A.lev[q][b * h + j] = v;
             if (A.lw[q] && j < (h >> 1)) A.lw[q][b * (h >> 1) + j] = b == 0 ? v : lz_mul(A.pw[q][b], v);
@@ -1046,7 +1114,7 @@ __global__ __launch_bounds__(1024) void k_bn_prod_tail_levels(ProdTailLevels A) 
         in = A.lev[q];
         in_len = h;
     }
-    for (int b = threadIdx.x; b < nb; b += 1024) {   // in: rows of length 2
+    if (threadIdx.x == 0) {   // in: rows of length 2
         const Fr l = in[2 * b], r = in[2 * b + 1];
         A.top_out[2 * b] = fr_from_mont(l);
         A.top_out[2 * b + 1] = fr_from_mont(r);
@@ -1298,6 +1366,42 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
             k_bn_fold_consts<<<(unsigned)((W.size() * 8 + 255) / 256), 256, 0, st>>>(dW, fk, W.size());
             fkW[q] = fk;
         }
+        // the mirrored top layer's class weights (slot form): W[v][sp] = sum of gamma^b over the members, their fold constants, and
+        // gamma^b / W for the regroup - ahead of the product tree, whose first pass shares the layer's level-0 reads (k_bn_level0_slots_fused)
+        const Fr* top_dW = nullptr;
+        FoldK* top_fkW = nullptr;
+        if (nv > 1 && plan[nv - 1].mirror && slots) {
+            const int n = nv - 1;
+            const int V = slots->V, NP = slots->npairs;
+            const Fr g = fr_to_mont(chain[layers[n].gamma_at]);
+            std::vector<Fr> pwh(G2), W((size_t)V * NP, fr_zero()), ratio((size_t)G2 * NP, fr_zero());
+            { Fr w = fr_one_mont(); for (size_t b = 0; b < G2; b++) { pwh[b] = w; w = fr_mul(w, g); } }
+            for (size_t b = 0; b < G2; b++)
+                for (int sp = 0; sp < NP; sp++) { Fr& x = W[(size_t)slots->slot_of[b * NP + sp] * NP + sp]; x = fr_add(x, pwh[b]); }
+            {   // one inversion for all class weights (prefix products), empty slots (weight zero) left out
+                std::vector<size_t> idx;
+                for (size_t q = 0; q < W.size(); q++) if (W[q].l[0] | W[q].l[1] | W[q].l[2] | W[q].l[3]) idx.push_back(q);
+                std::vector<Fr> pre(idx.size() + 1, fr_one_mont());
+                for (size_t q = 0; q < idx.size(); q++) pre[q + 1] = fr_mul(pre[q], W[idx[q]]);
+                Fr inv = fr_inv(pre[idx.size()]);
+                std::vector<Fr> Winv(W.size(), fr_zero());
+                for (size_t q = idx.size(); q-- > 0;) { Winv[idx[q]] = fr_mul(inv, pre[q]); inv = fr_mul(inv, W[idx[q]]); }
+                for (size_t b = 0; b < G2; b++)
+                    for (int sp = 0; sp < NP; sp++) {
+                        const size_t w = (size_t)slots->slot_of[b * NP + sp] * NP + sp;
+                        if (!(W[w].l[0] | W[w].l[1] | W[w].l[2] | W[w].l[3])) throw Error("hg_grand_product_bn254: degenerate batching challenge (a class weight is zero)");
+                        ratio[b * NP + sp] = fr_mul(pwh[b], Winv[w]);
+                    }
+            }
+            top_dW = bn_stage(ctx, W.data(), W.size());
+            slot_ratio = bn_stage(ctx, ratio.data(), ratio.size());
+            bn_flush(ctx, st);
+            top_fkW = static_cast<FoldK*>(ctx->alloc(W.size() * sizeof(FoldK)));
+            k_bn_fold_consts<<<(unsigned)((W.size() * 8 + 255) / 256), 256, 0, st>>>(top_dW, top_fkW, W.size());
+            slot_regroup = dalloc(2 * G2 * (size_t)slots->npairs);
+        }
+        static const bool no_fused0 = hg_env_on("HG_BN_NO_FUSED0");
+        const bool fused0 = top_dW && mirror_c && D1 >= 1 && !no_fused0 && slots->seg_shift >= 8 && ((len >> 1) & 255) == 0 && slots->V <= 32 && slots->deep[0].V <= 64;   // level 0 read once for the layer's own tables and for level 1
         // the product tree; level k (rows of length len >> k) is read by layer n = nv - 1 - k, whose weighted left halves are written
         // in the same pass (level 0, the input, gets its own pass below)
         ProdTailLevels tl;
@@ -1312,7 +1416,11 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
                 FoldK kc;
                 fold_consts(*mirror_c, &kc);
                 const size_t hh = len >> 1;
-                if (D1 >= 1) k_bn_prod_level_mirror_slots<<<dim3((unsigned)((hh + 255) / 256), (unsigned)slots->deep[0].V), 256, 0, st>>>(lev[0], len, lk, (int)nb, fr_mul(*mirror_c, *mirror_c), kc, fkW[0], lw_n,
+                if (fused0)
+                    k_bn_level0_slots_fused<<<(unsigned)((hh + 255) / 256), 256, 0, st>>>(lev[0], len, lk, (int)nb, fr_mul(*mirror_c, *mirror_c), kc, fkW[0], lw_n, slots->d_slot_of, slots->npairs,
+                                                                                      slots->deep[0].d_rep, slots->deep[0].ng, slots->deep[0].V, slots->seg_shift, top_dW, top_fkW,
+                                                                                      plan[nv - 1].lw, plan[nv - 1].S, slots->V);
+                else if (D1 >= 1) k_bn_prod_level_mirror_slots<<<dim3((unsigned)((hh + 255) / 256), (unsigned)slots->deep[0].V), 256, 0, st>>>(lev[0], len, lk, (int)nb, fr_mul(*mirror_c, *mirror_c), kc, fkW[0], lw_n,
                                                                                                                       slots->d_slot_of, slots->npairs, slots->deep[0].d_rep, slots->deep[0].ng, slots->seg_shift);
                 else
                 k_bn_prod_level_mirror<<<dim3((unsigned)((hh + 255) / 256), (unsigned)(nb / 2)), 256, 0, st>>>(lev[0], len, lk, (int)nb, *mirror_c, fr_mul(*mirror_c, *mirror_c), kc,
@@ -1341,41 +1449,13 @@ static void grand_product_core(hg_ctx* ctx, size_t nb, size_t len, const u64* co
         if (tl.nlev == 0) { tl.in = lev[nv - 1]; tl.in_len = 2; }
         const ResRef top = res_slots(ctx, 2 * nb), roots = res_slots(ctx, nb);
         tl.top_out = top.dev; tl.roots_out = roots.dev;
-        k_bn_prod_tail_levels<<<1, 1024, 0, st>>>(tl);
+        k_bn_prod_tail_levels<<<(unsigned)nb, 128, 0, st>>>(tl);
         h_top = top.host; h_roots = roots.host;
         if (nv > 1) {   // the top layer reads level 0
             const int n = nv - 1;
             const size_t h = (size_t)1 << n;
             if (plan[n].mirror && slots) {
-                // class weights W[v][sp] = sum of gamma^b over the members, their fold constants, and gamma^b / W for the regroup
-                const int V = slots->V, NP = slots->npairs;
-                const Fr g = fr_to_mont(chain[layers[n].gamma_at]);
-                std::vector<Fr> pwh(G2), W((size_t)V * NP, fr_zero()), ratio((size_t)G2 * NP, fr_zero());
-                { Fr w = fr_one_mont(); for (size_t b = 0; b < G2; b++) { pwh[b] = w; w = fr_mul(w, g); } }
-                for (size_t b = 0; b < G2; b++)
-                    for (int sp = 0; sp < NP; sp++) { Fr& x = W[(size_t)slots->slot_of[b * NP + sp] * NP + sp]; x = fr_add(x, pwh[b]); }
-                {   // one inversion for all class weights (prefix products), empty slots (weight zero) left out
-                    std::vector<size_t> idx;
-                    for (size_t q = 0; q < W.size(); q++) if (W[q].l[0] | W[q].l[1] | W[q].l[2] | W[q].l[3]) idx.push_back(q);
-                    std::vector<Fr> pre(idx.size() + 1, fr_one_mont());
-                    for (size_t q = 0; q < idx.size(); q++) pre[q + 1] = fr_mul(pre[q], W[idx[q]]);
-                    Fr inv = fr_inv(pre[idx.size()]);
-                    std::vector<Fr> Winv(W.size(), fr_zero());
-                    for (size_t q = idx.size(); q-- > 0;) { Winv[idx[q]] = fr_mul(inv, pre[q]); inv = fr_mul(inv, W[idx[q]]); }
-                    for (size_t b = 0; b < G2; b++)
-                        for (int sp = 0; sp < NP; sp++) {
-                            const size_t w = (size_t)slots->slot_of[b * NP + sp] * NP + sp;
-                            if (!(W[w].l[0] | W[w].l[1] | W[w].l[2] | W[w].l[3])) throw Error("hg_grand_product_bn254: degenerate batching challenge (a class weight is zero)");
-                            ratio[b * NP + sp] = fr_mul(pwh[b], Winv[w]);
-                        }
-                }
-                const Fr* dW = bn_stage(ctx, W.data(), W.size());
-                slot_ratio = bn_stage(ctx, ratio.data(), ratio.size());
-                bn_flush(ctx, st);
-                FoldK* fkW = static_cast<FoldK*>(ctx->alloc(W.size() * sizeof(FoldK)));
-                k_bn_fold_consts<<<(unsigned)((W.size() * 8 + 255) / 256), 256, 0, st>>>(dW, fkW, W.size());
-                k_bn_weight_slots_sum<<<(unsigned)((h + 255) / 256), 256, 0, st>>>(lev[0], 2 * h, dW, fkW, plan[n].lw, plan[n].S, h, V, NP, slots->seg_shift);
-                slot_regroup = dalloc(2 * G2 * (size_t)NP);
+                if (!fused0) k_bn_weight_slots_sum<<<(unsigned)((h + 255) / 256), 256, 0, st>>>(lev[0], 2 * h, top_dW, top_fkW, plan[n].lw, plan[n].S, h, slots->V, slots->npairs, slots->seg_shift);
             }
             else if (plan[n].mirror) k_bn_weight_rows_sum<<<(unsigned)((h + 255) / 256), 256, 0, st>>>(lev[0], 2 * h, plan[n].d_pw, fk_all + (size_t)n * nb, plan[n].lw, plan[n].S, h, (int)G2);
             else k_bn_weight_rows<<<(unsigned)((nb * h + 255) / 256), 256, 0, st>>>(lev[0], 2 * h, plan[n].d_pw, plan[n].lw, h, (int)nb);

@@ -944,7 +944,7 @@ def test_environment_switches_at_the_headline_size(switch):
     assert r.returncode == 0 and "SWITCH OK" in r.stdout, (switch, r.stdout[-500:], r.stderr[-2000:])
 
 
-@pytest.mark.parametrize("switch", ["HG_GATHER_CSR=1", "HG_BN_SLOT_DEPTH=0", "HG_BN_SLOT_DEPTH=1", "HG_BN_SLOT_DEPTH=2"])
+@pytest.mark.parametrize("switch", ["HG_GATHER_CSR=1", "HG_BN_SLOT_DEPTH=0", "HG_BN_SLOT_DEPTH=1", "HG_BN_SLOT_DEPTH=2", "HG_BN_NO_FUSED0=1"])
 def test_bn254_environment_switches_stay_bit_exact(switch):
     """The BN254 prove with its alternative paths (every pair of a PRODSUM job multiplied separately although the pairs share one b
     table; per-term Libra gathers instead of aliased eq slices; the node launches ahead of the Lasso node) gives the C++ Fr oracle's
