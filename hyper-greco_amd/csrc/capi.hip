@@ -115,6 +115,10 @@ hg_ctx* hg_create(int device_id) {
     hip_check(hipMemset(c->d_partials2, 0, dev::PARTIALS_BYTES), "hipMemset(partials2)");
     hip_check(hipMalloc((void**)&c->d_partials3, dev::PARTIALS_BYTES), "hipMalloc(partials3)");
     hip_check(hipMemset(c->d_partials3, 0, dev::PARTIALS_BYTES), "hipMemset(partials3)");
+    hip_check(hipStreamCreateWithFlags(&c->stream_sum, hipStreamNonBlocking), "hipStreamCreate");
+    for (auto& e : c->ev_sum) hip_check(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
+    hip_check(hipMalloc((void**)&c->d_partials4, dev::PARTIALS_BYTES), "hipMalloc(partials4)");
+    hip_check(hipMemset(c->d_partials4, 0, dev::PARTIALS_BYTES), "hipMemset(partials4)");
     c->stage_cap = (size_t)4 << 20;
     hip_check(hipHostMalloc((void**)&c->h_stage, c->stage_cap, hipHostMallocDefault), "hipHostMalloc(staging)");
     c->ensure_chain(16384);

@@ -298,7 +298,10 @@ __device__ __forceinline__ GpItemE2 gp_item_any() {   // "no value yet" without 
 // gamma^i (pw[i]); later rounds then need no per-pair scaling at all (the weight rides along in the table),
 // which removes 3 of the 8 extension multiplications per (pair, j). The host divides the final left
 // evaluations by gamma^i again before they reach the transcript.
-template <int KIND, typename T, bool FIRST, bool SLOT = false, bool GIO = true>   // SLOT: first round of a slot-form job (StJob::slotw), passed as `mirror`; GIO = false: tables behind generic pointers (k_st_tail: LDS)
+// MODE (grand product, later rounds on Ext2 tables only; round 6): 0 = the round; 1 = its folds only (the next round needs nothing else: the
+// challenges are known before the proof), 2 = its sums only - a small round is one workgroup's dependent chain, and the chain of a
+// fold-only launch is a third of the whole round's; the sums of every split round then run in one launch beside the rounds that follow
+template <int KIND, typename T, bool FIRST, bool SLOT = false, bool GIO = true, int MODE = 0>   // SLOT: first round of a slot-form job (StJob::slotw), passed as `mirror`; GIO = false: tables behind generic pointers (k_st_tail: LDS)
 __device__ __forceinline__ void sc_round_body(const T* __restrict__ in, size_t in_stride, E2* __restrict__ out,
                                               size_t out_stride, int ntab, size_t half, E2 r, const E2* __restrict__ pw, const E2* __restrict__ pwr,
                                               int jb_log2, E2* __restrict__ red, E2* acc, size_t first_tile, size_t tile_step,
@@ -308,6 +311,7 @@ __device__ __forceinline__ void sc_round_body(const T* __restrict__ in, size_t i
         gp_first_round_body<SLOT, GIO>(in, in_stride, out, out_stride, ntab, half, r, pw, pwr, jb_log2, red, acc, first_tile, tile_step, p0_only, next_level, mirror);
         return;
     }
+    static_assert(MODE == 0 || (KIND == SC_GRANDPROD && !FIRST && std::is_same<T, E2>::value), "split rounds: grand product, Ext2 tables");
     const int BD = blockDim.x, tid = threadIdx.x;
     const int G = BD >> jb_log2;
     const int jj = tid & ((1 << jb_log2) - 1), g = tid >> jb_log2;
@@ -343,22 +347,26 @@ __device__ __forceinline__ void sc_round_body(const T* __restrict__ in, size_t i
                     const E2 xl = gp_cur.xl, yl = gp_cur.yl, xr = gp_cur.xr, yr = gp_cur.yr;
                     E2 dl = e2_sub(yl, xl), dr = e2_sub(yr, xr);
                     if (i == 0) { p0 = xl; p2 = e2_add(yl, dl); p3 = e2_add(p2, dl); }
-                    if (!(p0_only && i == 0)) {  // a p0-only pair 0 belongs to another rank's share of the batch
+                    if (MODE != 1 && !(p0_only && i == 0)) {  // a p0-only pair 0 belongs to another rank's share of the batch
                         we2_mac(w0, xl, xr);
                         we2_mac(w1, yl, yr);
                         we2_mac(wi, dl, dr);
                     }
-                    store_e2<GIO>(out + (size_t)(2 * i) * out_stride + jo, e2_fold_wide(xl, dl, fr));
-                    store_e2<GIO>(out + (size_t)(2 * i + 1) * out_stride + jo, e2_fold_wide(xr, dr, fr));
+                    if (MODE != 2) {
+                        store_e2<GIO>(out + (size_t)(2 * i) * out_stride + jo, e2_fold_wide(xl, dl, fr));
+                        store_e2<GIO>(out + (size_t)(2 * i + 1) * out_stride + jo, e2_fold_wide(xr, dr, fr));
+                    }
                     gp_cur = nxt;
                 }
-                s0 = we2_reduce(w0); s2 = we2_reduce(w1); s3 = we2_reduce(wi);
+                if (MODE != 1) { s0 = we2_reduce(w0); s2 = we2_reduce(w1); s3 = we2_reduce(wi); }
                 if (mirror && g == 0) {  // the linear table S of a mirrored job (StJob::mirror): K1 S(t) + K2 joins P0 and P1
                     E2 x, y;
                     load_xy<E2, false, GIO>(in + (size_t)(2 * nb) * in_stride, j, half, x, y);
-                    s0 = e2_add(s0, e2_add(e2_mul(mirror->mk1, x), mirror->mk2));
-                    s2 = e2_add(s2, e2_add(e2_mul(mirror->mk1, y), mirror->mk2));
-                    store_e2<GIO>(out + (size_t)(2 * nb) * out_stride + jo, e2_fold_wide(x, e2_sub(y, x), fr));
+                    if (MODE != 1) {
+                        s0 = e2_add(s0, e2_add(e2_mul(mirror->mk1, x), mirror->mk2));
+                        s2 = e2_add(s2, e2_add(e2_mul(mirror->mk1, y), mirror->mk2));
+                    }
+                    if (MODE != 2) store_e2<GIO>(out + (size_t)(2 * nb) * out_stride + jo, e2_fold_wide(x, e2_sub(y, x), fr));
                 }
             } else {
             for (int i = g; i < nb; i += G) {
@@ -379,6 +387,7 @@ __device__ __forceinline__ void sc_round_body(const T* __restrict__ in, size_t i
                 store_e2<GIO>(out + (size_t)(2 * i + 1) * out_stride + jo, V::fold(xr, dr, r));
             }
             }
+            if constexpr (MODE == 1) continue;   // (folds only: no sums)
             if (G > 1) {
                 red[tid] = s0; red[BD + tid] = s2; red[2 * BD + tid] = s3;
                 __syncthreads();
@@ -596,7 +605,7 @@ __device__ __forceinline__ int find_item(const StItem* __restrict__ items, int n
     return __builtin_amdgcn_readfirstlane(__popcll(m) - 1);
 }
 // one step: every item runs its job's round with half = 2^item.h_log2
-template <int KIND, typename T, bool SLOT = false>   // SLOT: the first round of ONE slot-form job (StJob::slotw)
+template <int KIND, typename T, bool SLOT = false, int MODE = 0>   // SLOT: the first round of ONE slot-form job (StJob::slotw); MODE: sc_round_body
 __global__ __launch_bounds__(256) void k_st_step(const StJob* __restrict__ jobs, const StItem* __restrict__ items, int nitems,
                                                  const E2* __restrict__ chal, E2* __restrict__ partials, E2* __restrict__ res) {
     constexpr int NV = KIND == SC_GRANDPROD ? 3 : 2;
@@ -615,8 +624,9 @@ __global__ __launch_bounds__(256) void k_st_step(const StJob* __restrict__ jobs,
     for (int t = 0; t < NV; t++) acc[t] = e2_zero();
     if (rd == 0) sc_round_body<KIND, T, true, SLOT>(reinterpret_cast<const T*>(in), in_stride, out, half, J.ntab, half, chal[J.r_off + rd], J.pw, J.pwr, jb_log2, red, acc, bx, nblocks, J.p0_only != 0, J.next_level,
                                                     SLOT ? &J : nullptr);
-    else sc_round_body<KIND, T, false>(reinterpret_cast<const T*>(in), in_stride, out, half, J.ntab, half, chal[J.r_off + rd], J.pw, J.pwr, jb_log2, red, acc, bx, nblocks, J.p0_only != 0, nullptr,
-                                       J.mirror ? &J : nullptr);
+    else sc_round_body<KIND, T, false, false, true, MODE>(reinterpret_cast<const T*>(in), in_stride, out, half, J.ntab, half, chal[J.r_off + rd], J.pw, J.pwr, jb_log2, red, acc, bx, nblocks, J.p0_only != 0, nullptr,
+                                                          J.mirror ? &J : nullptr);
+    if constexpr (MODE == 1) return;
     E2* part = partials + (size_t)y * SC_MAX_BLOCKS * NV;
     block_sum_multi<NV>(acc, sm);
     if (threadIdx.x == 0) {
@@ -1305,9 +1315,15 @@ int st_plan_blocks(StItem* items, int nitems, bool rounds2) {
     return blk;
 }
 void st_step(hipStream_t st, int kind, bool base, const StJob* jobs, const StItem* items, int nitems, int grid, const E2* chal,
-             E2* partials, E2* res, bool slot) {
+             E2* partials, E2* res, bool slot, int mode) {
     const int nv = kind == SC_GRANDPROD ? 3 : 2;
     const size_t lds = sc_lds_bytes(nv, 256);
+    if (mode) {   // a split round (sc_round_body): later rounds of grand-product jobs only
+        if (kind != SC_GRANDPROD || base || slot) throw std::runtime_error("st_step: split rounds are grand-product rounds on Ext2 tables");
+        if (mode == 1) k_st_step<SC_GRANDPROD, E2, false, 1><<<grid, 256, lds, st>>>(jobs, items, nitems, chal, partials, res);
+        else k_st_step<SC_GRANDPROD, E2, false, 2><<<grid, 256, lds, st>>>(jobs, items, nitems, chal, partials, res);
+        return;
+    }
     if (slot) {
         if (kind != SC_GRANDPROD || !base || nitems != 1) throw std::runtime_error("st_step: a slot-form first round is launched alone");
         k_st_step<SC_GRANDPROD, u64, true><<<grid, 256, lds, st>>>(jobs, items, nitems, chal, partials, res);
@@ -1999,11 +2015,11 @@ void stamp(hipStream_t st, unsigned long long* slot) { k_stamp<<<1, 1, 0, st>>>(
 // one launch instead of up to three memset nodes at the head of a prove (reduction tickets of both streams, the result-buffer prefix)
 __global__ void k_clear_words(ClearSet c) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, step = (size_t)gridDim.x * blockDim.x;
-    for (int r = 0; r < 3; r++)
+    for (int r = 0; r < 4; r++)
         for (size_t k = i; k < c.n[r]; k += step) c.p[r][k] = 0;
 }
 void clear_words(hipStream_t st, const ClearSet& c) {
-    size_t most = std::max(c.n[0], std::max(c.n[1], c.n[2]));
+    size_t most = std::max(std::max(c.n[0], c.n[1]), std::max(c.n[2], c.n[3]));
     if (most) k_clear_words<<<(unsigned)std::min<size_t>((most + 255) / 256, 256), 256, 0, st>>>(c);
 }
 

@@ -129,8 +129,9 @@ struct StItem {
 // `rounds2`: fused two-round launch (one pair index per thread).
 int st_plan_blocks(StItem* items, int nitems, bool rounds2);
 // step: every item runs its job's round with half = 2^item.h_log2; `grid` from st_plan_blocks
+// `mode`: 0 the round, 1 its folds only, 2 its sums only (later rounds of grand-product jobs; kernels.hip: sc_round_body)
 void st_step(hipStream_t st, int kind, bool base, const StJob* jobs, const StItem* items, int nitems, int grid, const E2* chal,
-             E2* partials, E2* res, bool slot = false);
+             E2* partials, E2* res, bool slot = false, int mode = 0);
 // first round of ONE grand-product job whose level-0 rows are recomputed from the Lasso integer tables (StJob::hash_src)
 // (`mirror` = the host copy of job->mirror: selects the kernel variant)
 // (`recomp`: the memories' E values are recomputed from the limbs, GpHashMem::ep is not read)
@@ -214,7 +215,7 @@ struct ScatterEnt { const E2* src; size_t dst; };
 void scatter_e2(hipStream_t st, const ScatterEnt* ents, size_t n, E2* dst_base);
 void set_e2(hipStream_t st, E2* dst, E2 v);   // *dst = v (one thread): a progress mark in the host-mapped result buffer
 void stamp(hipStream_t st, unsigned long long* slot);   // debugging aid: device wall clock at this point of the stream
-struct ClearSet { unsigned* p[3]; size_t n[3]; };   // up to three regions of 32-bit words
+struct ClearSet { unsigned* p[4]; size_t n[4]; };   // up to four regions of 32-bit words
 void clear_words(hipStream_t st, const ClearSet& c);
 
 // out[v] = sum_b partials[b*nv + v], v < nv

@@ -136,6 +136,9 @@ hg_ctx::~hg_ctx() {
     if (d_partials) (void)hipFree(d_partials);
     if (d_partials2) (void)hipFree(d_partials2);
     if (d_partials3) (void)hipFree(d_partials3);
+    if (d_partials4) (void)hipFree(d_partials4);
+    if (stream_sum) { (void)hipStreamSynchronize(stream_sum); (void)hipStreamDestroy(stream_sum); }
+    for (auto& e : ev_sum) if (e) (void)hipEventDestroy(e);
     if (stream_col) { (void)hipStreamSynchronize(stream_col); (void)hipStreamDestroy(stream_col); }
     if (ev_col) (void)hipEventDestroy(ev_col);
     if (comm) { try { hg::comm_destroy(this); } catch (...) {} }
@@ -287,7 +290,7 @@ struct Prover {
     }
     size_t res_used = 0;
     size_t res_end = 0;   // slots are handed out below this index (0: the whole result buffer); hg_prove_stream's first table set owns the lower half only
-    int cls_gp_hash, cls_gp_base, cls_gp_ext, cls_gp_ext2, cls_col_ext2, cls_col_base, cls_col_ext, cls_ps, cls_ps2, cls_reduce, cls_aux, cls_tree, cls_hash, cls_gather, cls_tail, cls_ps_tail;
+    int cls_gp_sums, cls_gp_hash, cls_gp_base, cls_gp_ext, cls_gp_ext2, cls_col_ext2, cls_col_base, cls_col_ext, cls_ps, cls_ps2, cls_reduce, cls_aux, cls_tree, cls_hash, cls_gather, cls_tail, cls_ps_tail;
 
     // ---- single-proof sharding over `world` GPUs ---------------------------------------------------
     // Every rank walks the whole protocol (same challenges, same result slots) but only enqueues the work it owns; unowned
@@ -316,6 +319,7 @@ struct Prover {
         plan_shards();
         cls_gp_ext2 = ctx->prof_class("sc_round2<grand_product,ext>", true);
         cls_gp_ext = ctx->prof_class("sc_round<grand_product,ext>", false);
+        cls_gp_sums = ctx->prof_class("sc_round_sums<grand_product,ext>", false);
         cls_gp_base = ctx->prof_class("sc_round<grand_product,base>", false);
         cls_gp_hash = ctx->prof_class("sc_round<grand_product,hash>", false);
         cls_col_base = ctx->prof_class("sc_round<collation,base>", false);
@@ -341,6 +345,8 @@ struct Prover {
             cs.p[nr] = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(pbuf) + dev::PARTIALS_E2 * sizeof(E2));
             cs.n[nr++] = dev::PARTIALS_TICKETS;
         }
+        cs.p[3] = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ctx->d_partials4) + dev::PARTIALS_E2 * sizeof(E2));   // (the split rounds' sums stream)
+        cs.n[3] = dev::PARTIALS_TICKETS;
         if (world <= 1) {   // (one rank: the third region is free for the third stream's tickets)
             cs.p[2] = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ctx->d_partials3) + dev::PARTIALS_E2 * sizeof(E2));
             cs.n[2] = dev::PARTIALS_TICKETS;

@@ -26,6 +26,12 @@ struct hg_ctx {
     hipStream_t stream_col = nullptr;   // one rank: the collation sum-check's short launches, then the node reductions, off the main stream (forked from and joined to it)
     hipEvent_t ev_col = nullptr;
     hg::E2* d_partials3 = nullptr;      // scratch of stream_col
+    // the sums of the grand products' split rounds (prover_sumcheck.inc: flush_stride) run beside the rounds that follow them: forked from
+    // the main stream behind the last fold-only launch (ev_sum[0]), joined to it at the end of the prove (ev_sum[1], sum_pending)
+    hipStream_t stream_sum = nullptr;
+    hipEvent_t ev_sum[2] = {nullptr, nullptr};
+    hg::E2* d_partials4 = nullptr;      // scratch of stream_sum
+    bool sum_pending = false;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_aux[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // Lasso node: limbs done (stream -> stream2), grand product #2 levels done (stream2 -> stream), E tables done (stream -> stream2), counters done (stream2 -> stream), opening tables done (stream2 -> stream)
     hipStream_t prof_stream = nullptr;  // stream the profiling events are recorded on (the one being enqueued to)

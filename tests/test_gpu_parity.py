@@ -893,7 +893,7 @@ def test_launch_graph_that_replays_slower_than_plain_launches_is_given_up():
     assert r.returncode == 0 and r.stderr.count("hipGraphLaunch:") == 10, r.stderr[-2000:]   # the guard leaves a healthy graph alone
 
 
-@pytest.mark.parametrize("switch", ["HG_ONE_STREAM=1", "HG_NO_GRAPH=1", "HG_GATHER_CSR=1", "HG_NO_PS_EQ=1", "HG_SLOT_DEPTH=0", "HG_SLOT_DEPTH=1", "HG_SLOT_DEPTH=2"])
+@pytest.mark.parametrize("switch", ["HG_ONE_STREAM=1", "HG_NO_GRAPH=1", "HG_GATHER_CSR=1", "HG_NO_PS_EQ=1", "HG_SLOT_DEPTH=0", "HG_SLOT_DEPTH=1", "HG_SLOT_DEPTH=2", "HG_NO_SPLIT=1"])
 def test_alternative_paths_behind_the_environment_switches_stay_bit_exact(switch):
     """The switches that are left select a supported configuration (one stream, plain launches) or force the GENERAL form of a
     path at a size where the specialised one would run (per-term Libra gathers instead of run-length segments, every Libra table
@@ -922,7 +922,7 @@ def test_alternative_paths_behind_the_environment_switches_stay_bit_exact(switch
     assert r.returncode == 0 and "SWITCH OK" in r.stdout, (switch, r.stdout[-500:], r.stderr[-2000:])
 
 
-@pytest.mark.parametrize("switch", ["HG_GATHER_CSR=1", "HG_NO_PS_EQ=1", "HG_SLOT_DEPTH=0", "HG_SLOT_DEPTH=1", "HG_SLOT_DEPTH=3"])
+@pytest.mark.parametrize("switch", ["HG_GATHER_CSR=1", "HG_NO_PS_EQ=1", "HG_SLOT_DEPTH=0", "HG_SLOT_DEPTH=1", "HG_SLOT_DEPTH=3", "HG_NO_SPLIT=1"])
 def test_environment_switches_at_the_headline_size(switch):
     """Two of the switches above at n=32768 k=16 (BASELINE configs[2]), where every production shortcut is active: walks, the capture and
     two graph replays must all give the oracle's bytes."""
