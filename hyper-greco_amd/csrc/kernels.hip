@@ -2890,7 +2890,7 @@ __global__ __launch_bounds__(TPB) void k_gather_B(CsrMul m, const E2* __restrict
             u64 c = m.coef[e];
             if (c != 1) q = e2_mul_f(q, c);
             q = e2_mul(q, eqx[(rep << log2_S) + m.other_j[e]]);
-            acc = e2_add(acc, e2_mul(q, u[m.other_in[e]]));
+            acc = e2_add(acc, u ? e2_mul(q, u[m.other_in[e]]) : q);   // (u null: the factor is applied by the caller)
         }
         store_e2(B + idx, acc);
     }
@@ -2913,7 +2913,7 @@ __global__ __launch_bounds__(TPB) void k_gather_B_jobs(const GatherBJob* __restr
             u64 c = m.coef[e];
             if (c != 1) q = e2_mul_f(q, c);
             q = e2_mul(q, J.eqx[(rep << J.log2_S) + m.other_j[e]]);
-            acc = e2_add(acc, e2_mul(q, J.u[m.other_in[e]]));
+            acc = e2_add(acc, J.u ? e2_mul(q, J.u[m.other_in[e]]) : q);   // (u null: the factor is applied by the host's transcript replay)
         }
         store_e2(J.B + idx, acc);
     }

@@ -344,7 +344,7 @@ void gather_seg_jobs(hipStream_t st, const GatherSegJob* jobs, int njobs, int gr
 int gather_seg_plan(GatherSegJob* host_jobs, int njobs);   // fills blk0, returns the grid
 // B[rep*S + y] = sum_mulR eqc[rep*G+gate]*c*eqx[rep*S + j0]*u[i0]
 void vanilla_gather_B(hipStream_t st, const CsrMul& mulR, const E2* eqc, const E2* eqx, const E2* u, int log2_S, int log2_G, int log2_R, E2* B);
-struct GatherBJob { CsrMul m; const E2* eqc; const E2* eqx; const E2* u; int log2_S, log2_G, log2_R; E2* B; };
+struct GatherBJob { CsrMul m; const E2* eqc; const E2* eqx; const E2* u; int log2_S, log2_G, log2_R; E2* B; };   // u: the left inputs' values at r_x (result slots), or null = ones
 void gather_B_jobs(hipStream_t st, const GatherBJob* jobs, int njobs, size_t max_total);
 // sum over reps and constant gates of eqc[rep*G+gate]*c -> partials (nv = 1)
 int vanilla_const_sum(hipStream_t st, const u32* gate, const u64* coef, size_t nterms, const E2* eqc, int log2_G, int log2_R, E2* partials);

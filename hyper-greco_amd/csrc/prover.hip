@@ -248,6 +248,7 @@ struct ScHandle {
     std::vector<E2> rs;
     bool scaled = false;   // the device sums are the round sums divided by `scale` (mirrored grand product, StJob::mirror)
     E2 scale = {0, 0};
+    std::shared_ptr<E2> scale_cell;   // ... or by a value the replay knows when it gets there (Libra phase 2 run beside phase 1: u = in(r_x))
 };
 // Slot form of a mirrored top layer (GpHashSrc::slot_of in kernels.hpp): the job runs on `2 nslots + 1` tables until its tables are short
 // enough for the single-workgroup tail, which runs on the `tail_ntab` = 2 nrows + 1 per-memory tables gathered from them.

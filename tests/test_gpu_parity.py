@@ -893,7 +893,7 @@ def test_launch_graph_that_replays_slower_than_plain_launches_is_given_up():
     assert r.returncode == 0 and r.stderr.count("hipGraphLaunch:") == 10, r.stderr[-2000:]   # the guard leaves a healthy graph alone
 
 
-@pytest.mark.parametrize("switch", ["HG_ONE_STREAM=1", "HG_NO_GRAPH=1", "HG_GATHER_CSR=1", "HG_NO_PS_EQ=1", "HG_SLOT_DEPTH=0", "HG_SLOT_DEPTH=1", "HG_SLOT_DEPTH=2", "HG_NO_SPLIT=1"])
+@pytest.mark.parametrize("switch", ["HG_ONE_STREAM=1", "HG_NO_GRAPH=1", "HG_GATHER_CSR=1", "HG_NO_PS_EQ=1", "HG_SLOT_DEPTH=0", "HG_SLOT_DEPTH=1", "HG_SLOT_DEPTH=2", "HG_NO_SPLIT=1", "HG_PHASE2_LATE=1"])
 def test_alternative_paths_behind_the_environment_switches_stay_bit_exact(switch):
     """The switches that are left select a supported configuration (one stream, plain launches) or force the GENERAL form of a
     path at a size where the specialised one would run (per-term Libra gathers instead of run-length segments, every Libra table
@@ -922,7 +922,7 @@ def test_alternative_paths_behind_the_environment_switches_stay_bit_exact(switch
     assert r.returncode == 0 and "SWITCH OK" in r.stdout, (switch, r.stdout[-500:], r.stderr[-2000:])
 
 
-@pytest.mark.parametrize("switch", ["HG_GATHER_CSR=1", "HG_NO_PS_EQ=1", "HG_SLOT_DEPTH=0", "HG_SLOT_DEPTH=1", "HG_SLOT_DEPTH=3", "HG_NO_SPLIT=1"])
+@pytest.mark.parametrize("switch", ["HG_GATHER_CSR=1", "HG_NO_PS_EQ=1", "HG_SLOT_DEPTH=0", "HG_SLOT_DEPTH=1", "HG_SLOT_DEPTH=3", "HG_NO_SPLIT=1", "HG_PHASE2_LATE=1"])
 def test_environment_switches_at_the_headline_size(switch):
     """Two of the switches above at n=32768 k=16 (BASELINE configs[2]), where every production shortcut is active: walks, the capture and
     two graph replays must all give the oracle's bytes."""
@@ -1509,7 +1509,8 @@ def test_bn254_prove_other_parameter_sets_accepted_by_the_host_verifier(ctx, n, 
 @pytest.mark.gpu
 def test_eq_factored_rounds_are_the_path_that_runs():
     """The eq-factored PRODSUM rounds must actually be taken at the headline size - otherwise HG_NO_PS_EQ=1 would compare
-    the materialised form with itself: 14 of the 65 first-wave node reductions, most of the table entries."""
+    the materialised form with itself: 14 of the 81 first-wave node reductions (65 Libra phase-1 / FFT reductions and, since round 6,
+    the 16 mul nodes' phase 2 beside them), most of the table entries."""
     import subprocess, sys
     from hglib import ROOT
     code = (
@@ -1524,8 +1525,8 @@ def test_eq_factored_rounds_are_the_path_that_runs():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, HG_DEBUG="eq"), cwd=ROOT)
     assert r.returncode == 0 and "RAN" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
     lines = [l.split() for l in r.stderr.splitlines() if l.startswith("[hg eq]")]
-    assert lines and int(lines[0][2]) == 14 and int(lines[0][4]) == 65, r.stderr[-2000:]
-    assert int(lines[0][9]) * 4 > int(lines[0][11]) * 3, r.stderr[-2000:]      # more than three quarters of the entries
+    assert lines and int(lines[0][2]) == 14 and int(lines[0][4]) == 81, r.stderr[-2000:]
+    assert int(lines[0][9]) * 10 > int(lines[0][11]) * 7, r.stderr[-2000:]     # most of the entries (13.4 M of 18.3 M)
 
 
 @pytest.mark.gpu
