@@ -1281,6 +1281,33 @@ __global__ void k_gp_slot_regroup(const E2* __restrict__ in, E2* __restrict__ ou
     out[((size_t)(2 * b) << len_log2) + p] = b == 0 ? l : e2_mul(ratio[(size_t)b * npairs + sp], l);
     out[((size_t)(2 * b + 1) << len_log2) + p] = r;
 }
+// the same for several jobs in one launch (grid.y = job): the four slot-form layers' regroups ahead of the tail were four launches on the
+// critical chain of the prove
+__global__ void k_gp_slot_regroup_jobs(const SlotRegroupJob* __restrict__ jobs) {
+    const SlotRegroupJob& J = jobs[blockIdx.y];
+    const size_t len = (size_t)1 << J.len_log2;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= ((size_t)J.nrows + J.has_s) << J.len_log2) return;
+    const int b = (int)(idx >> J.len_log2);
+    const size_t p = idx & (len - 1);   // storage position inside a table; the tables are de-interleaved
+    if (b == J.nrows) { J.out[((size_t)(2 * J.nrows) << J.len_log2) + p] = J.in[((size_t)(2 * J.nslots) << J.len_log2) + p]; return; }   // S
+    const size_t t = p < len / 2 ? 2 * p : 2 * (p - len / 2) + 1;   // the logical entry at that position
+    const int sp = (int)(t >> J.sh);
+    const int v = J.slot_of[(size_t)b * J.npairs + sp];
+    const E2 l = J.in[((size_t)(2 * v) << J.len_log2) + p], r = J.in[((size_t)(2 * v + 1) << J.len_log2) + p];
+    J.out[((size_t)(2 * b) << J.len_log2) + p] = b == 0 ? l : e2_mul(J.ratio[(size_t)b * J.npairs + sp], l);
+    J.out[((size_t)(2 * b + 1) << J.len_log2) + p] = r;
+}
+void gp_slot_regroup_jobs(hipStream_t st, const SlotRegroupJob* jobs, int njobs, size_t max_entries) {
+    if (njobs) k_gp_slot_regroup_jobs<<<dim3((unsigned)((max_entries + 255) / 256), (unsigned)njobs), 256, 0, st>>>(jobs);
+}
+SlotRegroupJob gp_slot_regroup_job(const E2* in, E2* out, const uint8_t* slot_of, const E2* ratio, int nrows, int nslots, int npairs, int len_log2, bool has_s) {
+    int np_log2 = 0;
+    while ((1 << np_log2) < npairs) np_log2++;
+    SlotRegroupJob J;
+    J.in = in; J.out = out; J.slot_of = slot_of; J.ratio = ratio; J.nrows = nrows; J.nslots = nslots; J.npairs = npairs; J.len_log2 = len_log2; J.sh = len_log2 - np_log2; J.has_s = has_s ? 1 : 0;
+    return J;
+}
 void gp_slot_regroup(hipStream_t st, const E2* in, E2* out, const uint8_t* slot_of, const E2* ratio, int nrows, int nslots, int npairs, int len_log2, bool has_s) {
     int np_log2 = 0;
     while ((1 << np_log2) < npairs) np_log2++;

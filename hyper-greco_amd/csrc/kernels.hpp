@@ -81,6 +81,9 @@ struct GpHashSrc {
 // = ratio[b * npairs + sp] * left table of its slot, right table as it is, S (the last table of both) copied
 // has_s = false: a layer below the top one (2 nrows / 2 nslots tables, no S).
 void gp_slot_regroup(hipStream_t st, const E2* in, E2* out, const uint8_t* slot_of, const E2* ratio, int nrows, int nslots, int npairs, int len_log2, bool has_s = true);
+struct SlotRegroupJob { const E2* in; E2* out; const uint8_t* slot_of; const E2* ratio; int nrows, nslots, npairs, len_log2, sh, has_s; };
+SlotRegroupJob gp_slot_regroup_job(const E2* in, E2* out, const uint8_t* slot_of, const E2* ratio, int nrows, int nslots, int npairs, int len_log2, bool has_s);
+void gp_slot_regroup_jobs(hipStream_t st, const SlotRegroupJob* jobs, int njobs, size_t max_entries);   // every job in one launch
 struct StJob {
     const void* in;
     size_t in_stride;
